@@ -1,0 +1,534 @@
+"""Oracle (CPU restatement) of the FEM relaxation path.  TEST INFRASTRUCTURE --
+see ``oracle/__init__.py``; never imported by the product package.
+
+Restates, with scipy.sparse like the reference, the element maths of
+material.py, the assembly of mesh.py:2893-3083, the cross-link terms and the
+linear system of optimizer.py:802-901,1257-1437,1573-1590, and the solver
+contract of optimizer.py:1945-2080.  Mixed precision follows the reference:
+vertices/shape matrix float64, D float32, cross-link matrix float32, stress
+cast to float32, final system float64.
+"""
+import numpy as np
+from scipy import sparse
+from scipy.sparse import linalg as spla
+
+GEAR_INITIAL, GEAR_FIXED, GEAR_MOVING, GEAR_STAGING = -1, 0, 1, 2   # constant.py:6-10
+MODEL_ENG, MODEL_SVK, MODEL_NHK = 0, 1, 2                            # constant.py:34-36
+
+
+def cross2d(a, b):
+    """common.py:895-896."""
+    return a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+
+
+# ------------------------------------------------------------------ element maths
+def eng_shape_matrix(tripts, T, num_dof):
+    """material.py:134-159: N (3T x num_dof) CSR float64; rows exx, eyy, gxy."""
+    tripts = np.asarray(tripts, dtype=np.float64).reshape(-1, 3, 2)
+    T = np.asarray(T).reshape(-1, 3)
+    e = np.roll(tripts, -1, axis=-2) - np.roll(tripts, 1, axis=-2)     # e_i = p_{i+1} - p_{i-1}
+    nt = tripts.shape[0]
+    a = np.abs(cross2d(e[:, 0, :], e[:, 1, :])).reshape(-1, 1, 1)       # 2*area
+    e = e / (a ** 0.5)
+    ty = e[:, :, 1]
+    tx = -e[:, :, 0]
+    cols = np.concatenate((2 * T, 2 * T + 1, 2 * T, 2 * T + 1), axis=-1)
+    vals = np.concatenate((ty, tx, tx, ty), axis=-1)
+    indptr = np.cumsum(np.insert(np.tile([3, 3, 6], nt), 0, 0))
+    return sparse.csr_matrix((vals.ravel(), cols.ravel(), indptr), shape=(3 * nt, num_dof))
+
+
+def eng_stiffness_from_shape(N, multiplier=None, nu=0.0, mat_multiplier=1.0, stretch_factor=None):
+    """material.py:162-182: K = N^T D N, D float32 per triangle."""
+    nt = N.shape[0] // 3
+    if mat_multiplier == 0 or nt == 0:
+        return None
+    m = np.full(nt, mat_multiplier, dtype=np.float32)
+    if multiplier is not None:
+        m = multiplier * m
+    if stretch_factor is not None:
+        m = m * np.asarray(stretch_factor).ravel()
+    d0 = (m.reshape(-1, 1) * np.array([1, 1, (1 - nu) / 2])).ravel()
+    if nu == 0:
+        D = sparse.diags(d0, dtype=np.float32)
+    else:
+        d1 = (m.reshape(-1, 1) * np.array([nu, 0, 0])).ravel()[:-1]
+        D = sparse.diags([d1, d0, d1], [-1, 0, 1], dtype=np.float32)
+    return N.T @ D @ N
+
+
+def mesh_stiffness(v_shape, v_cur, triangles, tri_mult=None, nu=0.0, mat_multiplier=1.0):
+    """mesh.py:3058-3083 for a mesh whose triangles all use one linear ENG
+    material (the default table, default_material_table.yaml):
+    K from the shape gear, stress = K (v_cur - v_shape) cast float32."""
+    v_shape = np.asarray(v_shape, dtype=np.float64)
+    T = np.asarray(triangles)
+    ndof = 2 * v_shape.shape[0]
+    N = eng_shape_matrix(v_shape[T], T, ndof)
+    K = eng_stiffness_from_shape(N, multiplier=tri_mult, nu=nu, mat_multiplier=mat_multiplier)
+    if v_cur is None or v_cur is v_shape:
+        stress = np.zeros(ndof, dtype=np.float32)
+    else:
+        stress = K.dot((np.asarray(v_cur, dtype=np.float64) - v_shape).ravel()).astype(np.float32)
+    return K, stress
+
+
+def element_shape_B(tripts):
+    """material.py:185-209: B (T x 4 x 6, float32) and a = 2*area (T x 1 x 1)."""
+    tripts = np.asarray(tripts, dtype=np.float64).reshape(-1, 3, 2)
+    e = np.roll(tripts, -1, axis=-2) - np.roll(tripts, 1, axis=-2)
+    a = np.abs(cross2d(e[:, 0, :], e[:, 1, :])).reshape(-1, 1, 1)
+    e = e / a
+    B = np.zeros((tripts.shape[0], 4, 6), dtype=np.float32)
+    t0 = e[:, :, 1]
+    t1 = -e[:, :, 0]
+    B[:, 0, 0::2] = t0
+    B[:, 1, 0::2] = t1
+    B[:, 2, 1::2] = t0
+    B[:, 3, 1::2] = t1
+    return B, a
+
+
+def element_stiffness(B, areas, uv, model, nu=0.0):
+    """material.py:212-309 (without stiffness_func): tangent K_e (T x 6 x 6)
+    and internal force P_e (T x 6 x 1), float32 pipeline like the reference."""
+    f32 = np.float32
+    nt = B.shape[0]
+    uv = np.asarray(uv).astype(f32).reshape(-1, 6, 1)
+    D = np.eye(3, dtype=f32)
+    D[[0, 1], [1, 0]] = nu
+    D[-1, -1] = (1 - nu) / 2
+    sel = np.array([[1, 0, 0, 0], [0, 0, 0, 1], [0, 1, 1, 0]], dtype=f32)
+    if model == MODEL_ENG:
+        Bn = sel @ B
+        K = areas * (np.swapaxes(Bn, 1, 2) @ D @ Bn)
+        P = K @ uv
+    elif model == MODEL_SVK:
+        Ft = (B @ uv).reshape(-1, 2, 2) + np.eye(2, dtype=f32)
+        FtT = np.swapaxes(Ft, 1, 2)
+        Et = 0.5 * (FtT @ Ft - np.eye(2, dtype=f32))
+        E = sel @ Et.reshape(-1, 4, 1)
+        Bc = np.array([[1, 0, 1, 0], [0, 1, 0, 1]], dtype=f32) @ B
+        Fc = np.tile(FtT, (1, 1, 3))
+        Bn = np.concatenate((Bc * Fc, np.sum(Bc * Fc[:, ::-1, :], axis=1, keepdims=True)), axis=1)
+        S = D @ E
+        Sg = np.zeros((nt, 4, 4), dtype=f32)
+        Sg[:, 0, 0] = S[:, 0, 0]; Sg[:, 2, 2] = S[:, 0, 0]
+        Sg[:, 1, 1] = S[:, 1, 0]; Sg[:, 3, 3] = S[:, 1, 0]
+        Sg[:, 0, 1] = S[:, 2, 0]; Sg[:, 1, 0] = S[:, 2, 0]
+        Sg[:, 2, 3] = S[:, 2, 0]; Sg[:, 3, 2] = S[:, 2, 0]
+        P = areas * (np.swapaxes(Bn, 1, 2) @ S)
+        K = areas * (np.swapaxes(Bn, 1, 2) @ D @ Bn + np.swapaxes(B, 1, 2) @ Sg @ B)
+    elif model == MODEL_NHK:
+        Ft = (B @ uv).reshape(-1, 2, 2) + np.eye(2, dtype=f32)
+        J = np.linalg.det(Ft).reshape(-1, 1, 1)
+        U = np.array([[0, 0, 0, 1], [0, 0, -1, 0], [0, -1, 0, 0], [1, 0, 0, 0]], dtype=f32)
+        F = Ft.reshape(-1, 4, 1)
+        Fu = U @ F
+        I4 = np.eye(4, dtype=f32)
+        P = 0.5 * areas * (np.swapaxes(B, 1, 2) @ (I4 - U / J) @ F)
+        K = 0.5 * areas * (np.swapaxes(B, 1, 2) @ (I4 - U / J + (Fu @ np.swapaxes(Fu, 1, 2)) / (J ** 2)) @ B)
+    else:
+        raise NotImplementedError
+    return K, P
+
+
+# ------------------------------------------------------------------ mesh state
+class RefMesh:
+    """Minimal state of mesh.py:212-293,1221-1325 needed on the FEM path:
+    four gears of vertices + offsets with the reference's aliasing rules."""
+
+    def __init__(self, vertices, triangles, uid=0, locked=False, soft_factor=1.0,
+                 stiffness_multiplier=None, nu=0.0):
+        v = np.asarray(vertices, dtype=np.float64).reshape(-1, 2)
+        self.triangles = np.asarray(triangles).reshape(-1, 3)
+        self._v = {GEAR_INITIAL: v, GEAR_FIXED: v, GEAR_MOVING: None, GEAR_STAGING: None}
+        z = np.zeros((1, 2))
+        self._off = {GEAR_INITIAL: z, GEAR_FIXED: z, GEAR_MOVING: z, GEAR_STAGING: z}
+        self.uid = float(uid)
+        self.locked = locked
+        self.soft_factor = soft_factor
+        self.nu = nu
+        if stiffness_multiplier is None:
+            stiffness_multiplier = np.ones(self.triangles.shape[0], dtype=np.float32)
+        self.stiffness_multiplier = stiffness_multiplier
+
+    @property
+    def num_vertices(self):
+        return self._v[GEAR_INITIAL].shape[0]
+
+    def vertices(self, gear):                               # mesh.py:1221-1234,1286-1320
+        if gear == GEAR_MOVING and self._v[gear] is None:
+            return self._v[GEAR_FIXED]
+        if gear == GEAR_STAGING and self._v[gear] is None:
+            return self.vertices(GEAR_MOVING)
+        return self._v[gear]
+
+    def offset(self, gear):                                 # mesh.py:1256-1265
+        if self._v[gear] is None:
+            if gear == GEAR_MOVING:
+                return self._off[GEAR_FIXED]
+            return self.offset(GEAR_MOVING)
+        return self._off[gear]
+
+    def vertices_w_offset(self, gear):
+        return self.vertices(gear) + self.offset(gear)
+
+    def apply_translation(self, dxy, gear):                 # mesh.py:2272-2286 (unmasked)
+        dxy = np.asarray(dxy, dtype=np.float64).reshape(1, 2)
+        if self.locked or not np.any(dxy):
+            return
+        v = self.vertices(gear)
+        off = self.offset(gear)
+        self._v[gear] = v
+        self._off[gear] = off + dxy
+
+    def set_field(self, dxy, gear=(GEAR_FIXED, GEAR_MOVING)):   # mesh.py:2400-2413 (unmasked)
+        if self.locked:
+            return
+        v0 = self.vertices(gear[0])
+        off0 = self.offset(gear[0])
+        m = np.mean(dxy.reshape(-1, 2), axis=0, keepdims=True)
+        self._v[gear[-1]] = v0 + (dxy - m)
+        self._off[gear[-1]] = off0 + m
+
+    def anneal_copy(self, gear=(GEAR_MOVING, GEAR_FIXED)):   # mesh.py:2452-2456
+        if self.locked:
+            return
+        off0 = self.offset(gear[0])
+        v0 = self.vertices(gear[0])
+        self._v[gear[1]] = v0
+        self._off[gear[1]] = off0
+
+    def triangle_areas(self, gear=GEAR_INITIAL):            # mesh.py:1753-1758, common.py:672-676
+        p = self.vertices(gear)[self.triangles]
+        return cross2d(p[:, 1] - p[:, 0], p[:, 2] - p[:, 1])
+
+    def cart2bary(self, xy, gear, tid):                     # mesh.py:2191-2217 (tid given)
+        xy = np.atleast_2d(xy) - self.offset(gear)
+        p = self.vertices(gear)[self.triangles[tid]]
+        v0 = xy - p[:, 0]; v1 = xy - p[:, 1]; v2 = xy - p[:, 2]
+        a0 = cross2d(v1, v2); a1 = cross2d(v2, v0); a2 = cross2d(v0, v1)
+        ac = a0 + a1 + a2
+        return np.stack((a0 / ac, a1 / ac, a2 / ac), axis=-1)
+
+    def bary2cart(self, tid, B, gear, offsetting=True):     # mesh.py:2220-2228
+        v = self.vertices_w_offset(gear) if offsetting else self.vertices(gear)
+        return np.sum(v[self.triangles[tid]] * B.reshape(-1, 3, 1), axis=-2)
+
+    def stiffness_matrix(self, gear=(GEAR_FIXED, GEAR_MOVING)):
+        v0 = self.vertices(gear[0])
+        v1 = self.vertices(gear[-1])
+        return mesh_stiffness(v0, None if v1 is v0 else v1, self.triangles,
+                              tri_mult=self.stiffness_multiplier, nu=self.nu)
+
+
+class RefLink:
+    """optimizer.py:17-50: matches as (tid, barycentric) pairs on two meshes."""
+
+    def __init__(self, mesh0, mesh1, tid0, tid1, B0, B1, weight=None, strain=0.05):
+        self.meshes = [mesh0, mesh1]
+        self.tid0 = np.asarray(tid0); self.tid1 = np.asarray(tid1)
+        self.B0 = np.asarray(B0, dtype=np.float64); self.B1 = np.asarray(B1, dtype=np.float64)
+        a0 = mesh0.triangle_areas(GEAR_INITIAL)[self.tid0]
+        a1 = mesh1.triangle_areas(GEAR_INITIAL)[self.tid1]
+        self.sample_err = 0.4387 * (np.minimum(a0, a1)) ** 0.5 * strain     # :26-30
+        self.weight = ((self.tid0 >= 0) & (self.tid1 >= 0)).astype(np.float32)
+        if weight is not None:
+            self.weight = self.weight * weight
+        self.residue_weight = np.ones_like(self.weight)
+
+    def total_weight(self):                                 # :313-317
+        return self.weight * self.residue_weight
+
+    def dxy(self, gears):                                   # :226-255
+        m0, m1 = self.meshes
+        x0 = m0.bary2cart(self.tid0, self.B0, gears[0], offsetting=False)
+        x1 = m1.bary2cart(self.tid1, self.B1, gears[1], offsetting=False)
+        return (x1 - x0) + (m1.offset(gears[1]) - m0.offset(gears[0]))
+
+    def residue_weights(self, gears, mode, length):         # :174-205
+        d = self.dxy(gears)
+        dis = np.sum(d ** 2, axis=-1) ** 0.5
+        dis = ((dis ** 2 - self.sample_err ** 2).clip(0, None)) ** 0.5
+        if mode == 'huber':
+            w = length / np.maximum(dis, length)
+        else:
+            w = dis <= length
+        return np.asarray(w).astype(np.float32)
+
+
+# ------------------------------------------------------------------ system assembly
+def index_offsets(meshes):
+    """optimizer.py:960-970: DoF offset per mesh, -1 for locked."""
+    off = []
+    cur = 0
+    for m in meshes:
+        if m.locked:
+            off.append(-1)
+        else:
+            off.append(cur)
+            cur += 2 * m.num_vertices
+    return off, cur
+
+
+def system_stiffness(meshes, gear=(GEAR_FIXED, GEAR_MOVING)):
+    """optimizer.py:802-829: block-diagonal K*soft_factor and stress."""
+    Ks, Ss = [], []
+    for m in meshes:
+        if m.locked:
+            continue
+        K, s = m.stiffness_matrix(gear)
+        Ks.append(K * m.soft_factor)
+        Ss.append(s * m.soft_factor)
+    return sparse.block_diag(Ks, format='csr'), np.concatenate(Ss, axis=None)
+
+
+def crosslink_shape_matrix(meshes, links):
+    """optimizer.py:873-901 + Link.shape_matrix_contrib (114-131): S float32."""
+    offs, ndof = index_offsets(meshes)
+    lut = {id(m): o for m, o in zip(meshes, offs)}
+    data, idx, ptr = [], [], [np.array([0])]
+    cur = 0
+    for lk in links:
+        m0, m1 = lk.meshes
+        Bs, Is = [], []
+        if not m0.locked:
+            Bs.append(lk.B0)
+            Is.append(2 * m0.triangles[lk.tid0] + lut[id(m0)])
+        if not m1.locked:
+            Bs.append(-lk.B1)
+            Is.append(2 * m1.triangles[lk.tid1] + lut[id(m1)])
+        if not Bs:
+            continue
+        B = np.concatenate(Bs, axis=-1)
+        I = np.concatenate(Is, axis=-1)
+        data.append(B.ravel()); idx.append(I.ravel())
+        ptr.append((np.arange(B.shape[0]) + 1) * B.shape[1] + cur)
+        cur += B.size
+    data = np.concatenate(data); idx = np.concatenate(idx); ptr = np.concatenate(ptr)
+    return sparse.csr_matrix((data, idx, ptr), shape=(ptr.size - 1, ndof), dtype=np.float32)
+
+
+def crosslink_terms(meshes, links, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING):
+    """optimizer.py:832-870: C = Cx + Cy (float32), rhs float64."""
+    S = crosslink_shape_matrix(meshes, links)
+    rows = []
+    wts = []
+    for lk in links:
+        if all(m.locked for m in lk.meshes):
+            continue
+        gears = [target_gear if m.locked else start_gear for m in lk.meshes]
+        rows.append(lk.dxy(gears))
+        wts.append(lk.total_weight())
+    r = np.concatenate(rows, axis=0).astype(np.float64)
+    w = np.concatenate(wts).astype(np.float32)
+    D = sparse.diags(w, shape=(w.size, w.size))
+    Cx = (S.T @ D @ S).T
+    Cy = sparse.csr_matrix((Cx.data, Cx.indices + 1, np.insert(Cx.indptr[:-1], 0, 0)), shape=Cx.shape)
+    C = Cx + Cy
+    rhs = S.T.dot(w * r[:, 0])
+    ry = S.T.dot(w * r[:, 1])
+    rhs[1:] = rhs[1:] + ry[0:-1]
+    return C, rhs
+
+
+def relative_lambda_trace(K, C, stiffness_lambda, crosslink_lambda):
+    """optimizer.py:1573-1590."""
+    if stiffness_lambda < 0 or crosslink_lambda < 0:
+        ratio = abs(stiffness_lambda / crosslink_lambda)
+        tr = C.trace()
+        if tr == 0:
+            stiffness_lambda = 0
+        else:
+            dk = K.diagonal()
+            dc = C.diagonal()
+            stiffness_lambda = abs(ratio * tr / np.sum(dk[dc != 0]))
+        crosslink_lambda = 1.0
+    return stiffness_lambda, crosslink_lambda
+
+
+def linear_system(meshes, links, stiffness_lambda=1.0, crosslink_lambda=-1.0,
+                  shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING):
+    """optimizer.py:1307-1310,1416-1418: A = ls*K + lc*C, b = lc*rhs - ls*stress."""
+    K, stress = system_stiffness(meshes, gear=(shape_gear, start_gear))
+    C, rhs = crosslink_terms(meshes, links, start_gear=start_gear, target_gear=target_gear)
+    ls, lc = relative_lambda_trace(K, C, stiffness_lambda, crosslink_lambda)
+    A = ls * K + lc * C
+    b = lc * rhs - ls * stress
+    return A, b, (K, stress, C, rhs, ls, lc)
+
+
+# ------------------------------------------------------------------ solvers
+def jacobi_diag(A):
+    """optimizer.py:1962-1966: 1/clip(diag(A), min(1, max/1000))."""
+    d = A.diagonal()
+    if d.max() <= 0:
+        return None
+    return 1.0 / d.clip(min(1.0, d.max() / 1000), None)
+
+
+def pcg(A, b, x0=None, rtol=1e-7, maxiter=10000, minv=None):
+    """Jacobi-preconditioned CG to ||Ax-b|| <= rtol*||b|| (true residual
+    re-evaluated at exit).  This is the algorithm the HIP solver implements;
+    it reaches the same fixed point as the reference's restarted MINRES
+    (SURVEY.md sec.7 'Hard parts')."""
+    A = sparse.csr_matrix(A)
+    n = b.size
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
+    if minv is None:
+        minv = jacobi_diag(A)
+        if minv is None:
+            minv = np.ones(n)
+    bn = np.linalg.norm(b)
+    if bn == 0 or maxiter == 0:
+        return np.zeros(n), 0, 0.0
+    r = b - A.dot(x)
+    z = minv * r
+    p = z.copy()
+    rz = r.dot(z)
+    it = 0
+    while it < maxiter:
+        if np.linalg.norm(r) <= rtol * bn:
+            break
+        Ap = A.dot(p)
+        alpha = rz / p.dot(Ap)
+        x += alpha * p
+        r -= alpha * Ap
+        z = minv * r
+        rz_new = r.dot(z)
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+        it += 1
+    rel = np.linalg.norm(A.dot(x) - b) / bn
+    return x, it, rel
+
+
+def solve_direct(A, b):
+    """Ground truth for parity: sparse LU of the symmetrised system."""
+    A = sparse.csc_matrix(0.5 * (A + A.T))
+    return spla.spsolve(A, b)
+
+
+def solve_reference_style(A, b, tol=1e-7, atol=None, maxiter=None, eval_step=10, chances=None,
+                          early_stop_thresh=None, x0=None):
+    """optimizer.py:1945-2080 with solver='minres', M='jacobi',
+    tolerated_perturbation=None (the unseeded-random early exit is disabled so
+    that the result is deterministic), no edc, check_converge=True.
+    Returns (x, number of minres iterations, number of outer restarts)."""
+    A = sparse.csr_matrix(0.5 * (A + A.T))
+    d = A.diagonal()
+    M = sparse.diags(1 / d.clip(min(1.0, d.max() / 1000), None)) if d.max() > 0 else None
+    bn = np.linalg.norm(b)
+    if maxiter == 0 or bn == 0:
+        return np.zeros_like(b), 0, 0
+    if atol is not None:
+        tol = max(tol, atol / bn)
+    atol = tol * bn
+    x = np.zeros_like(b) if x0 is None else x0
+    tol0 = tol
+    total_it = 0
+    rounds = 0
+    maxiter_t = maxiter
+
+    class _Stop(Exception):
+        pass
+
+    while True:
+        st = dict(count=0, min_cost=np.inf, sol=None, last_cost=np.inf, last_x=0, exit_count=0, code=0)
+
+        def cb(xk):                                         # optimizer.py:1913-1942
+            st['count'] += 1
+            c = st['count']
+            if (c % eval_step == 0) or (c < min(eval_step, 5)):
+                cost = np.linalg.norm(A.dot(xk) - b)
+                if cost < st['min_cost']:
+                    st['min_cost'] = cost
+                    st['sol'] = xk.copy()
+                if cost < atol:
+                    raise _Stop
+                if (chances is not None) and (c >= eval_step):
+                    if cost > st['last_cost']:
+                        st['exit_count'] += 1
+                    elif early_stop_thresh is not None:
+                        if np.max(np.abs(xk - st['last_x'])) <= early_stop_thresh:
+                            st['exit_count'] += 1
+                        else:
+                            st['exit_count'] = 0
+                    else:
+                        st['exit_count'] = 0
+                    if st['exit_count'] > chances:
+                        st['code'] = 2
+                        raise _Stop
+                    st['last_x'] = xk.copy()
+                    st['last_cost'] = cost
+        mi = 100 if maxiter_t is None else min(maxiter_t, 100)
+        try:
+            x, _ = spla.minres(A, b, x0=x, M=M, maxiter=mi, callback=cb, rtol=tol)
+            cost0 = np.linalg.norm(A.dot(x) - b)
+            if cost0 > st['min_cost']:
+                x = st['sol']
+            cost = min(cost0, st['min_cost'])
+        except _Stop:
+            x = st['sol']
+            cost = st['min_cost']
+        total_it += st['count']
+        rounds += 1
+        if cost <= atol:
+            break
+        if st['code'] != 0:
+            break
+        if maxiter_t is not None:
+            maxiter_t -= st['count']
+            if maxiter_t <= 0:
+                break
+        tol = max(tol0, 0.1 * atol / cost)
+    return x, total_it, rounds
+
+
+def apply_solution(meshes, dd, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING):
+    """optimizer.py:1421-1434 + mesh.py:2400-2413."""
+    offs, _ = index_offsets(meshes)
+    for m, o in zip(meshes, offs):
+        if o < 0:
+            continue
+        d = dd[o:o + 2 * m.num_vertices].reshape(-1, 2)
+        m.set_field(d, gear=(start_gear, target_gear))
+
+
+def optimize_linear(meshes, links, tol=1e-7, stiffness_lambda=1.0, crosslink_lambda=-1.0,
+                    shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING, exact=True):
+    """optimizer.py:1257-1437 (no groupings / edc).  exact=True solves the
+    system to its fixed point (the parity anchor); otherwise PCG to tol."""
+    A, b, _ = linear_system(meshes, links, stiffness_lambda, crosslink_lambda,
+                            shape_gear, start_gear, target_gear)
+    A = 0.5 * (A + A.T)
+    if exact:
+        dd = solve_direct(A, b)
+    else:
+        dd, _, _ = pcg(A, b, rtol=tol)
+    cost = (float(np.linalg.norm(b)), float(np.linalg.norm(A.dot(dd) - b)))
+    if cost[1] < cost[0]:
+        apply_solution(meshes, dd, start_gear, target_gear)
+    return cost
+
+
+# ------------------------------------------------------------------ synthetic meshes
+def grid_mesh(nx, ny, h=10.0, origin=(0.0, 0.0), diag='alt'):
+    """Structured triangulation of an nx x ny node grid (not a reference
+    function: `triangle` is absent; meshes are inputs)."""
+    xs = origin[0] + h * np.arange(nx)
+    ys = origin[1] + h * np.arange(ny)
+    vx, vy = np.meshgrid(xs, ys)
+    v = np.stack((vx.ravel(), vy.ravel()), axis=-1)
+    idx = np.arange(nx * ny).reshape(ny, nx)
+    a = idx[:-1, :-1].ravel(); b = idx[:-1, 1:].ravel()
+    c = idx[1:, :-1].ravel(); d = idx[1:, 1:].ravel()
+    if diag == 'alt':
+        par = ((np.arange(nx - 1)[None, :] + np.arange(ny - 1)[:, None]) % 2).ravel().astype(bool)
+    else:
+        par = np.zeros(a.size, dtype=bool)
+    t0 = np.where(par[:, None], np.stack((a, b, c), -1), np.stack((a, b, d), -1))
+    t1 = np.where(par[:, None], np.stack((b, d, c), -1), np.stack((a, d, c), -1))
+    tri = np.concatenate((t0, t1), axis=0)
+    return v, tri

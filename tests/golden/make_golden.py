@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures tests/golden/*.npz from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference; the GPU box never
+sees it).  The reference is 100 % Python but imports C-backed packages that
+are absent here (cv2, shapely, triangle, ...); they are replaced by MagicMock
+modules -- every function captured below executes on
+numpy/scipy alone.  Output = inputs + the reference's outputs, nothing else.
+
+    cd /tmp && python /root/repo/tests/golden/make_golden.py
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+os.environ.setdefault('OMP_NUM_THREADS', '1')
+for _name in ['cv2', 'h5py', 'shapely', 'shapely.geometry', 'shapely.ops', 'triangle', 'rtree',
+              'rtree.index', 'pyamg', 'tensorstore', 'skimage', 'skimage.morphology', 'google',
+              'google.cloud', 'google.cloud.storage', 'dask', 'dask.distributed', 'dask_jobqueue']:
+    _m = MagicMock()
+    _m.__path__ = []
+    sys.modules[_name] = _m
+sys.path.insert(0, '/root/reference')
+os.chdir('/tmp')
+
+import numpy as np                                   # noqa: E402
+from scipy import sparse                             # noqa: E402
+from scipy.ndimage import gaussian_filter            # noqa: E402
+from scipy.spatial import Delaunay                   # noqa: E402
+
+from feabas import matcher, common, optimizer, material   # noqa: E402
+from feabas.mesh import Mesh                               # noqa: E402
+import feabas.constant as const                            # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def texture(rng, h, w, sigma=1.5):
+    """band-limited noise: smoothed white noise + a slow component."""
+    a = gaussian_filter(rng.standard_normal((h, w)), sigma)
+    b = gaussian_filter(rng.standard_normal((h, w)), 8 * sigma)
+    t = a / a.std() + 0.7 * b / b.std()
+    return t
+
+
+def to_u8(t):
+    return np.clip(128 + 40 * t / t.std(), 0, 255).astype(np.uint8)
+
+
+def coo(M):
+    M = sparse.coo_matrix(M)
+    M.sum_duplicates()
+    o = np.lexsort((M.col, M.row))
+    return M.row[o].astype(np.int64), M.col[o].astype(np.int64), M.data[o]
+
+
+# ----------------------------------------------------------------------- G1
+def g1_xcorr():
+    rng = np.random.default_rng(101)
+    out = {}
+    cases = {
+        'A': ((75, 73), (75, 73), 6),
+        'B': ((74, 72), (67, 75), 6),
+        'C': ((128, 128), (128, 128), 4),
+    }
+    for name, (s0, s1, n) in cases.items():
+        H = max(s0[0], s1[0]); W = max(s0[1], s1[1])
+        big = common.masked_dog_filter(to_u8(texture(rng, 4 * H, 4 * W)), 2.5).astype(np.float32)
+        # shifts: small, ~half block, and one exactly at the padded F/2 wrap
+        shifts = [(0, 0), (3, -2), (-7, 5), (H // 2 - 1, -(W // 2 - 2)), (-(H // 2), W // 2), (11, 17)][:n]
+        i0 = np.zeros((n,) + s0, np.float32)
+        i1 = np.zeros((n,) + s1, np.float32)
+        for k, (sy, sx) in enumerate(shifts):
+            y0 = H + 5 * k; x0 = W + 3 * k
+            i0[k] = big[y0:y0 + s0[0], x0:x0 + s0[1]]
+            i1[k] = big[y0 + sy:y0 + sy + s1[0], x0 + sx:x0 + sx + s1[1]]
+        i1 += 0.05 * i1.std() * rng.standard_normal(i1.shape).astype(np.float32)
+        out[f'{name}_img0'] = i0
+        out[f'{name}_img1'] = i1
+        for pad in (True, False):
+            for sub in (True, False):
+                for cm in (0, 1, 2):
+                    dx, dy, cf = matcher.xcorr_fft(i0, i1, conf_mode=cm, pad=pad, subpixel=sub)
+                    key = f'{name}_p{int(pad)}_s{int(sub)}_c{cm}'
+                    out[key + '_dx'] = np.asarray(dx, dtype=np.float64)
+                    out[key + '_dy'] = np.asarray(dy, dtype=np.float64)
+                    out[key + '_conf'] = np.asarray(cf)
+    # 4-D (N,H,W,C) input
+    i0 = np.stack([out['A_img0'][:3, :40, :36], out['A_img0'][:3, 20:60, 30:66]], axis=-1)
+    i1 = np.stack([out['A_img1'][:3, :40, :36], out['A_img1'][:3, 20:60, 30:66]], axis=-1)
+    out['D_img0'] = np.ascontiguousarray(i0)
+    out['D_img1'] = np.ascontiguousarray(i1)
+    for pad in (True, False):
+        dx, dy, cf = matcher.xcorr_fft(i0, i1, conf_mode=2, pad=pad, subpixel=True)
+        out[f'D_p{int(pad)}_s1_c2_dx'] = dx
+        out[f'D_p{int(pad)}_s1_c2_dy'] = dy
+        out[f'D_p{int(pad)}_s1_c2_conf'] = cf
+    np.savez_compressed(os.path.join(OUT, 'g1_xcorr.npz'), **out)
+
+
+# ----------------------------------------------------------------------- G2
+def g2_dog():
+    rng = np.random.default_rng(202)
+    img = to_u8(texture(rng, 160, 128))
+    blob = gaussian_filter(rng.standard_normal((160, 128)), 12) > 0.0
+    blob[:, :6] = True
+    out = {'img': img, 'mask': blob}
+    for s in (1.25, 2.5, 3.5):
+        out[f'dog_s{s}'] = common.masked_dog_filter(img, s)
+    out['dog_masked_signed'] = common.masked_dog_filter(img, 2.5, mask=blob)
+    out['dog_masked_unsigned'] = common.masked_dog_filter(img, 2.5, mask=blob, signed=False)
+    stack = np.stack([to_u8(texture(rng, 64, 48)) for _ in range(3)])
+    out['stack'] = stack
+    out['dog_stack_s2.5'] = common.masked_dog_filter(stack, 2.5)
+    fimg = texture(rng, 50, 70).astype(np.float32)
+    out['fimg'] = fimg
+    out['dog_fimg_s1.25'] = common.masked_dog_filter(fimg, 1.25)
+    np.savez_compressed(os.path.join(OUT, 'g2_dog.npz'), **out)
+
+
+# ----------------------------------------------------------------------- G3
+def g3_global():
+    rng = np.random.default_rng(303)
+    big = to_u8(texture(rng, 520, 360))
+    s0 = big[40:440, 30:290]
+    s1 = big[40 - 7:440 - 7, 30 + 5:290 + 5]
+    d0 = common.masked_dog_filter(s0, 1.25).astype(np.float32)
+    d1 = common.masked_dog_filter(s1, 1.25).astype(np.float32)
+    out = {'d0': d0, 'd1': d1}
+    out['plain'] = np.array(matcher.global_translation_matcher(d0, d1, conf_thresh=0.3), dtype=np.float64)
+    # force the 6-block fallback; a zero-variance block in img1 must be skipped
+    e1 = d1.copy()
+    e1[:134, :130] = 0
+    out['e1'] = e1
+    out['fallback'] = np.array(matcher.global_translation_matcher(d0, e1, conf_thresh=2.0), dtype=np.float64)
+    # unequal strip sizes
+    f1 = d1[:380, :250].copy()
+    out['f1'] = f1
+    out['unequal'] = np.array(matcher.global_translation_matcher(d0, f1, conf_thresh=2.0), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'g3_global.npz'), **out)
+
+
+# ----------------------------------------------------------------------- FEM helpers
+def grid(nx, ny, h, origin=(0.0, 0.0)):
+    xs = origin[0] + h * np.arange(nx)
+    ys = origin[1] + h * np.arange(ny)
+    vx, vy = np.meshgrid(xs, ys)
+    v = np.stack((vx.ravel(), vy.ravel()), axis=-1)
+    idx = np.arange(nx * ny).reshape(ny, nx)
+    a = idx[:-1, :-1].ravel(); b = idx[:-1, 1:].ravel(); c = idx[1:, :-1].ravel(); d = idx[1:, 1:].ravel()
+    par = ((np.arange(nx - 1)[None, :] + np.arange(ny - 1)[:, None]) % 2).ravel().astype(bool)
+    t0 = np.where(par[:, None], np.stack((a, b, c), -1), np.stack((a, b, d), -1))
+    t1 = np.where(par[:, None], np.stack((b, d, c), -1), np.stack((a, d, c), -1))
+    return v, np.concatenate((t0, t1), axis=0)
+
+
+def mat_table(nu):
+    d = dict(material.MATERIAL_DEFAULT)
+    d['poisson_ratio'] = nu
+    return material.MaterialTable(table={'default': d})
+
+
+# ----------------------------------------------------------------------- G4 / G5
+def g45_stiffness():
+    rng = np.random.default_rng(404)
+    out = {}
+    vg, tg = grid(20, 15, 10.0)
+    pts = rng.uniform(0, 200, size=(180, 2))
+    td = Delaunay(pts).simplices.astype(np.int64)
+    for name, (v, t) in {'grid': (vg, tg), 'rand': (pts, td)}.items():
+        out[f'{name}_v'] = v
+        out[f'{name}_t'] = t
+        mult = rng.uniform(0.2, 2.0, size=t.shape[0]).astype(np.float32)
+        out[f'{name}_mult'] = mult
+        disp = np.stack((3 * np.sin(v[:, 1] / 40), 2 * np.cos(v[:, 0] / 55)), axis=-1) + 0.3 * rng.standard_normal(v.shape)
+        out[f'{name}_vmov'] = v + disp
+        for nu in (0.0, 0.3):
+            mat = material.Material(**dict(material.MATERIAL_DEFAULT, poisson_ratio=nu))
+            N = mat.sparse_engineering_shape_matrix(v[t], t, 2 * v.shape[0])
+            r, c, d = coo(N)
+            out[f'{name}_nu{nu}_N_r'] = r; out[f'{name}_nu{nu}_N_c'] = c; out[f'{name}_nu{nu}_N_d'] = d
+            K = mat.engineering_stiffness_matrix_from_shape(N, multiplier=mult)
+            r, c, d = coo(K)
+            out[f'{name}_nu{nu}_K_r'] = r; out[f'{name}_nu{nu}_K_c'] = c; out[f'{name}_nu{nu}_K_d'] = d
+            # G5: through Mesh.stiffness_matrix with a displaced MOVING gear
+            m = Mesh(v.copy(), t.copy(), material_table=mat_table(nu), stiffness_multiplier=mult.copy(),
+                     moving_vertices=v + disp, uid=7)
+            Km, stress = m.stiffness_matrix(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING))
+            r, c, d = coo(Km)
+            out[f'{name}_nu{nu}_Km_r'] = r; out[f'{name}_nu{nu}_Km_c'] = c; out[f'{name}_nu{nu}_Km_d'] = d
+            out[f'{name}_nu{nu}_stress'] = stress
+    np.savez_compressed(os.path.join(OUT, 'g45_stiffness.npz'), **out)
+
+
+# ----------------------------------------------------------------------- G6-G9
+def build_slm(rng, out=None):
+    """3-mesh system: mesh0 locked, meshes 1 and 2 free, links 0-1, 1-2, 0-2."""
+    v0, t0 = grid(12, 9, 10.0)
+    v1, t1 = grid(10, 10, 11.0, origin=(3.0, -2.0))
+    v2, t2 = grid(9, 12, 9.0, origin=(-4.0, 5.0))
+    ms = [Mesh(v0, t0, uid=0, locked=True), Mesh(v1, t1, uid=1), Mesh(v2, t2, uid=2, soft_factor=0.5)]
+    ms[1].apply_translation((1.5, -0.75), const.MESH_GEAR_FIXED)
+    ms[2].apply_translation((-2.25, 1.0), const.MESH_GEAR_FIXED)
+    links = []
+    spec = []
+    for (a, b, n) in ((0, 1, 60), (1, 2, 50), (0, 2, 40)):
+        tid0 = rng.integers(0, ms[a].triangles.shape[0], size=n)
+        tid1 = rng.integers(0, ms[b].triangles.shape[0], size=n)
+        B0 = rng.dirichlet((1, 1, 1), size=n)
+        B1 = rng.dirichlet((1, 1, 1), size=n)
+        w = rng.uniform(0.3, 1.0, size=n).astype(np.float32)
+        links.append(optimizer.Link(ms[a], ms[b], tid0, tid1, B0, B1, weight=w))
+        spec.append((a, b, tid0, tid1, B0, B1, w))
+    if out is not None:
+        for k, m in enumerate(ms):
+            out[f'm{k}_v'] = m.vertices(gear=const.MESH_GEAR_INITIAL)
+            out[f'm{k}_t'] = m.triangles
+            out[f'm{k}_off'] = m.offset(gear=const.MESH_GEAR_FIXED)
+        for k, (a, b, tid0, tid1, B0, B1, w) in enumerate(spec):
+            out[f'l{k}_ab'] = np.array([a, b])
+            out[f'l{k}_tid0'] = tid0; out[f'l{k}_tid1'] = tid1
+            out[f'l{k}_B0'] = B0; out[f'l{k}_B1'] = B1; out[f'l{k}_w'] = w
+    return ms, links
+
+
+def g6789_system():
+    rng = np.random.default_rng(606)
+    out = {}
+    ms, links = build_slm(rng, out)
+    slm = optimizer.SLM(ms, links=list(links), stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    S, _ = slm.crosslink_shape_matrix()
+    r, c, d = coo(S); out['S_r'] = r; out['S_c'] = c; out['S_d'] = d
+    K, stress = slm.stiffness_matrix(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING))
+    C, rhs = slm.crosslink_terms(start_gear=const.MESH_GEAR_MOVING, target_gear=const.MESH_GEAR_MOVING)
+    r, c, d = coo(K); out['K_r'] = r; out['K_c'] = c; out['K_d'] = d
+    r, c, d = coo(C); out['C_r'] = r; out['C_c'] = c; out['C_d'] = d
+    out['stress'] = stress
+    out['rhs'] = rhs
+    ls, lc = slm.relative_lambda_trace(1.0, -1.0)
+    out['lambdas'] = np.array([ls, lc], dtype=np.float64)
+    A = ls * K + lc * C
+    b = lc * rhs - ls * stress
+    r, c, d = coo(A); out['A_r'] = r; out['A_c'] = c; out['A_d'] = d
+    out['b'] = b
+    # G7: solve() tight, deterministic
+    x = optimizer.solve(A, b, 'minres', tol=1e-11, M='jacobi', tolerated_perturbation=None,
+                        check_converge=True, chances=None, eval_step=10)
+    out['x_solve'] = x
+    from scipy.sparse.linalg import spsolve
+    out['x_direct'] = spsolve(sparse.csc_matrix(0.5 * (A + A.T)), b)
+    edc = np.ones(b.size, dtype=bool)
+    edc[:3] = False
+    edc[100:140:7] = False
+    out['edc'] = edc
+    out['x_edc'] = optimizer.solve(A, b, 'minres', tol=1e-11, M='jacobi', tolerated_perturbation=None,
+                                   check_converge=True, chances=None, eval_step=10, extra_dof_constraint=edc)
+    # G8: optimize_linear end-to-end
+    cost = slm.optimize_linear(tol=1e-11, tolerated_perturbation=None,
+                               callback_settings={'chances': None, 'eval_step': 10}, check_converge=True)
+    out['cost'] = np.array(cost, dtype=np.float64)
+    for k, m in enumerate(ms):
+        out[f'm{k}_v_after'] = m.vertices(gear=const.MESH_GEAR_MOVING)
+        out[f'm{k}_off_after'] = m.offset(gear=const.MESH_GEAR_MOVING)
+    # G9: residue weights (after the solve)
+    for k, lk in enumerate(links):
+        out[f'l{k}_sample_err'] = np.asarray(lk.sample_err, dtype=np.float64)
+        lk.set_huber_residue_filter(0.5)
+        lk.adjust_weight_from_residue(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING))
+        out[f'l{k}_huber'] = lk._residue_weight.copy()
+        lk.set_hard_residue_filter(0.8)
+        lk.adjust_weight_from_residue(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING))
+        out[f'l{k}_thresh'] = np.asarray(lk._residue_weight).astype(np.float32)
+        out[f'l{k}_dxy_after'] = lk.dxy(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), use_mask=False)
+    np.savez_compressed(os.path.join(OUT, 'g6789_system.npz'), **out)
+
+
+# ----------------------------------------------------------------------- G10
+def g10_elements():
+    rng = np.random.default_rng(1010)
+    out = {}
+    p = rng.uniform(0, 30, size=(50, 3, 2))
+    e = p[:, 1] - p[:, 0]; f = p[:, 2] - p[:, 1]
+    flip = (e[:, 0] * f[:, 1] - e[:, 1] * f[:, 0]) < 0
+    p[flip] = p[flip][:, ::-1]
+    uv = 0.1 * rng.standard_normal((50, 6)) * np.sqrt(np.abs(e[:, :1] * f[:, 1:] - e[:, 1:] * f[:, :1]))
+    out['tripts'] = p
+    out['uv'] = uv
+    for model, tag in ((const.MATERIAL_MODEL_ENG, 'eng'), (const.MATERIAL_MODEL_SVK, 'svk'), (const.MATERIAL_MODEL_NHK, 'nhk')):
+        for nu in ((0.0, 0.3) if model != const.MATERIAL_MODEL_NHK else (0.0,)):
+            mat = material.Material(type=model, poisson_ratio=nu, name=f'g10_{tag}_{nu}', uid=50 + model)
+            Ms = list(mat.shape_matrix_from_vertices(p))
+            if model == const.MATERIAL_MODEL_ENG and nu == 0.0:
+                out['B'] = Ms[0]; out['areas'] = Ms[1]
+            K, P, mm = mat.element_stiffness_matrices_from_shape_matrices(Ms, uv=uv)
+            out[f'{tag}_nu{nu}_K'] = K
+            out[f'{tag}_nu{nu}_P'] = P
+    np.savez_compressed(os.path.join(OUT, 'g10_elements.npz'), **out)
+
+
+# ----------------------------------------------------------------------- G11
+def g11_bbox():
+    out = {}
+    cases = [((0, 0, 510, 4096), 1024, 1, 1), ((0, 0, 510, 4096), 75, 2, 1), ((-3.5, 10.5, 500.5, 3010.5), 75, 2, 1),
+             ((0, 0, 4000, 400), 74.3, 1, 0.7), ((0, 0, 260, 400), None, (3, 2), 1), ((5, 7, 133, 80), 25, 2, 1)]
+    for k, (bb, bs, mnb, sf) in enumerate(cases):
+        kw = dict(min_num_blocks=mnb, shrink_factor=sf)
+        if bs is not None:
+            kw['block_size'] = bs
+        res = common.divide_bbox(bb, **kw)
+        out[f'div{k}_in'] = np.array(list(bb) + [bs if bs is not None else -1, sf] + list(np.atleast_1d(mnb)), dtype=np.float64)
+        out[f'div{k}_out'] = np.stack(res, axis=-1).astype(np.float64)
+    rng = np.random.default_rng(1111)
+    ij = rng.integers(0, 37, size=(200, 2)).astype(np.float64)
+    out['z_in'] = ij
+    out['z_out'] = common.z_order(ij)
+    bbs = np.array([[0, 0, 75, 73], [10, -4, 85, 70], [3, 3, 4, 9]], dtype=np.float64)
+    out['bb_in'] = bbs
+    out['bb_centers'] = common.bbox_centers(bbs)
+    out['bb_sizes'] = common.bbox_sizes(bbs)
+    # distributor_cartesian_bbox arithmetic on plain bboxes (mesh.bbox is just min/max of vertices)
+    class _M:
+        def __init__(self, bb): self._bb = bb
+        def bbox(self, gear=None): return self._bb
+    for k, (b0, b1, sp, mnb) in enumerate([((-0.5 + 6, -0.5 - 4, 509.5 + 6, 4095.5 - 4), (-0.5, -0.5, 509.5, 4095.5), 1024, 1),
+                                           ((-0.5 + 6, -0.5 - 4, 509.5 + 6, 4095.5 - 4), (-0.5, -0.5, 509.5, 4095.5), 75.0, 2)]):
+        r0, r1 = matcher.distributor_cartesian_bbox(_M(b0), _M(b1), sp, min_num_blocks=mnb, zorder=True)
+        out[f'dist{k}_in'] = np.array(list(b0) + list(b1) + [sp, mnb], dtype=np.float64)
+        out[f'dist{k}_bb0'] = r0.astype(np.float64)
+        out[f'dist{k}_bb1'] = r1.astype(np.float64)
+    from scipy.fftpack import next_fast_len
+    out['nfl'] = np.array([next_fast_len(n) for n in range(1, 4200)], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, 'g11_bbox.npz'), **out)
+
+
+if __name__ == '__main__':
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox):
+        fn()
+        print('wrote', fn.__name__)

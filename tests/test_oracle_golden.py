@@ -1,0 +1,198 @@
+"""The oracle (oracle/*.py) against golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only.  Tolerances: integer peaks exact,
+sub-pixel / conf 1e-4 (north_star), float32 images 1e-5 rel, FEM float64 1e-10
+rel, solver solutions 1e-8 rel."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from conftest import load_golden
+from oracle import ncc_ref, fem_ref
+
+
+def _sp(g, key, shape):
+    return sparse.csr_matrix((g[key + '_d'], (g[key + '_r'], g[key + '_c'])), shape=shape)
+
+
+def _relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize('case', ['A', 'B', 'C'])
+@pytest.mark.parametrize('pad', [1, 0])
+@pytest.mark.parametrize('sub', [1, 0])
+@pytest.mark.parametrize('cm', [0, 1, 2])
+def test_g1_xcorr(case, pad, sub, cm):
+    g = load_golden('g1_xcorr.npz')
+    dx, dy, cf = ncc_ref.xcorr_fft(g[f'{case}_img0'], g[f'{case}_img1'], conf_mode=cm, pad=bool(pad), subpixel=bool(sub))
+    key = f'{case}_p{pad}_s{sub}_c{cm}'
+    np.testing.assert_array_equal(np.round(dx), np.round(g[key + '_dx']))
+    np.testing.assert_array_equal(np.round(dy), np.round(g[key + '_dy']))
+    np.testing.assert_allclose(dx, g[key + '_dx'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(dy, g[key + '_dy'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(cf, g[key + '_conf'], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize('pad', [1, 0])
+def test_g1_xcorr_channels(pad):
+    g = load_golden('g1_xcorr.npz')
+    dx, dy, cf = ncc_ref.xcorr_fft(g['D_img0'], g['D_img1'], conf_mode=2, pad=bool(pad), subpixel=True)
+    np.testing.assert_allclose(dx, g[f'D_p{pad}_s1_c2_dx'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(dy, g[f'D_p{pad}_s1_c2_dy'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(cf, g[f'D_p{pad}_s1_c2_conf'], atol=1e-4, rtol=0)
+
+
+def test_g2_dog():
+    g = load_golden('g2_dog.npz')
+    for s in (1.25, 2.5, 3.5):
+        assert _relerr(ncc_ref.masked_dog_filter(g['img'], s), g[f'dog_s{s}']) < 1e-5
+    assert _relerr(ncc_ref.masked_dog_filter(g['img'], 2.5, mask=g['mask']), g['dog_masked_signed']) < 1e-5
+    assert _relerr(ncc_ref.masked_dog_filter(g['img'], 2.5, mask=g['mask'], signed=False), g['dog_masked_unsigned']) < 1e-5
+    assert _relerr(ncc_ref.masked_dog_filter(g['stack'], 2.5), g['dog_stack_s2.5']) < 1e-5
+    out = ncc_ref.masked_dog_filter(g['fimg'], 1.25)
+    assert out.dtype == np.float32
+    assert _relerr(out, g['dog_fimg_s1.25']) < 1e-5
+
+
+def test_g3_global_translation():
+    g = load_golden('g3_global.npz')
+    r = ncc_ref.global_translation_matcher(g['d0'], g['d1'], conf_thresh=0.3)
+    np.testing.assert_allclose(r, g['plain'], atol=1e-4)
+    r = ncc_ref.global_translation_matcher(g['d0'], g['e1'], conf_thresh=2.0)
+    np.testing.assert_allclose(r, g['fallback'], atol=1e-4)
+    r = ncc_ref.global_translation_matcher(g['d0'], g['f1'], conf_thresh=2.0)
+    np.testing.assert_allclose(r, g['unequal'], atol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['grid', 'rand'])
+@pytest.mark.parametrize('nu', [0.0, 0.3])
+def test_g45_stiffness(name, nu):
+    g = load_golden('g45_stiffness.npz')
+    v, t, mult = g[f'{name}_v'], g[f'{name}_t'], g[f'{name}_mult']
+    nd = 2 * v.shape[0]
+    N = fem_ref.eng_shape_matrix(v[t], t, nd)
+    Ng = _sp(g, f'{name}_nu{nu}_N', N.shape)
+    assert abs(N - Ng).max() <= 1e-12 * abs(Ng).max()
+    K = fem_ref.eng_stiffness_from_shape(N, multiplier=mult, nu=nu)
+    Kg = _sp(g, f'{name}_nu{nu}_K', (nd, nd))
+    assert abs(K - Kg).max() <= 1e-10 * abs(Kg).max()
+    Km, stress = fem_ref.mesh_stiffness(v, g[f'{name}_vmov'], t, tri_mult=mult, nu=nu)
+    Kmg = _sp(g, f'{name}_nu{nu}_Km', (nd, nd))
+    assert abs(Km - Kmg).max() <= 1e-10 * abs(Kmg).max()
+    assert stress.dtype == np.float32
+    np.testing.assert_allclose(stress, g[f'{name}_nu{nu}_stress'], rtol=1e-6, atol=1e-6 * np.abs(stress).max())
+
+
+def build_ref_system(g):
+    ms = []
+    for k in range(3):
+        m = fem_ref.RefMesh(g[f'm{k}_v'], g[f'm{k}_t'], uid=k, locked=(k == 0), soft_factor=(0.5 if k == 2 else 1.0))
+        m._off[fem_ref.GEAR_FIXED] = g[f'm{k}_off']
+        ms.append(m)
+    links = []
+    for k in range(3):
+        a, b = g[f'l{k}_ab']
+        links.append(fem_ref.RefLink(ms[a], ms[b], g[f'l{k}_tid0'], g[f'l{k}_tid1'], g[f'l{k}_B0'], g[f'l{k}_B1'], weight=g[f'l{k}_w']))
+    return ms, links
+
+
+def test_g6_system_terms():
+    g = load_golden('g6789_system.npz')
+    ms, links = build_ref_system(g)
+    S = fem_ref.crosslink_shape_matrix(ms, links)
+    Sg = _sp(g, 'S', S.shape)
+    assert abs(S - Sg).max() <= 1e-6
+    A, b, (K, stress, C, rhs, ls, lc) = fem_ref.linear_system(ms, links, 1.0, -1.0)
+    nd = b.size
+    assert abs(K - _sp(g, 'K', (nd, nd))).max() <= 1e-10 * abs(K).max()
+    assert abs(C - _sp(g, 'C', (nd, nd))).max() <= 1e-6 * abs(C).max()
+    np.testing.assert_allclose(rhs, g['rhs'], rtol=1e-6, atol=1e-6 * np.abs(g['rhs']).max())
+    np.testing.assert_allclose([ls, lc], g['lambdas'], rtol=1e-6)
+    assert abs(A - _sp(g, 'A', (nd, nd))).max() <= 1e-6 * abs(A).max()
+    np.testing.assert_allclose(b, g['b'], rtol=1e-6, atol=1e-6 * np.abs(g['b']).max())
+
+
+def test_g7_solve():
+    g = load_golden('g6789_system.npz')
+    nd = g['b'].size
+    A = _sp(g, 'A', (nd, nd))
+    b = g['b']
+    xd = fem_ref.solve_direct(A, b)
+    assert _relerr(xd, g['x_direct']) < 1e-8
+    # the reference's own (tight, deterministic) solve reaches the same fixed point
+    assert _relerr(g['x_solve'], g['x_direct']) < 1e-6
+    x, it, rel = fem_ref.pcg(0.5 * (A + A.T), b, rtol=1e-12, maxiter=20000)
+    assert rel < 1e-10
+    assert _relerr(x, g['x_direct']) < 1e-8
+    xr, nit, rounds = fem_ref.solve_reference_style(A, b, tol=1e-11)
+    assert _relerr(xr, g['x_solve']) < 1e-6
+    # DoF elimination (extra_dof_constraint)
+    edc = g['edc']
+    As = sparse.csr_matrix(0.5 * (A + A.T))[edc][:, edc]
+    xe = np.zeros(nd)
+    xe[edc] = fem_ref.solve_direct(As, b[edc])
+    assert _relerr(xe, g['x_edc']) < 1e-6
+
+
+def test_g8_optimize_linear():
+    g = load_golden('g6789_system.npz')
+    ms, links = build_ref_system(g)
+    cost = fem_ref.optimize_linear(ms, links, exact=True)
+    assert abs(cost[0] - g['cost'][0]) < 1e-8 * g['cost'][0]
+    for k, m in enumerate(ms):
+        v = m.vertices(fem_ref.GEAR_MOVING)
+        off = m.offset(fem_ref.GEAR_MOVING)
+        full = v + off
+        full_g = g[f'm{k}_v_after'] + g[f'm{k}_off_after']
+        assert np.abs(full - full_g).max() < 1e-6
+        assert np.abs(off - g[f'm{k}_off_after']).max() < 1e-6
+    # G9
+    for k, lk in enumerate(links):
+        np.testing.assert_allclose(lk.sample_err, g[f'l{k}_sample_err'], rtol=1e-12)
+        d = lk.dxy((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING))
+        assert np.abs(d - g[f'l{k}_dxy_after']).max() < 1e-6
+        np.testing.assert_allclose(lk.residue_weights((1, 1), 'huber', 0.5), g[f'l{k}_huber'], atol=1e-5)
+        thr = lk.residue_weights((1, 1), 'threshold', 0.8)
+        dis = np.sum(d ** 2, axis=-1) ** 0.5
+        sure = np.abs(((dis ** 2 - lk.sample_err ** 2).clip(0, None)) ** 0.5 - 0.8) > 1e-5
+        np.testing.assert_array_equal(thr[sure], g[f'l{k}_thresh'][sure])
+
+
+def test_g10_elements():
+    g = load_golden('g10_elements.npz')
+    B, a = fem_ref.element_shape_B(g['tripts'])
+    np.testing.assert_allclose(B, g['B'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(a, g['areas'], rtol=1e-12)
+    for tag, model in (('eng', 0), ('svk', 1), ('nhk', 2)):
+        for nu in ((0.0, 0.3) if model != 2 else (0.0,)):
+            K, P = fem_ref.element_stiffness(B, a, g['uv'], model, nu=nu)
+            Kg, Pg = g[f'{tag}_nu{nu}_K'], g[f'{tag}_nu{nu}_P']
+            assert np.abs(K - Kg).max() <= 1e-5 * np.abs(Kg).max()
+            assert np.abs(P - Pg).max() <= 1e-5 * np.abs(Pg).max()
+
+
+def test_g11_bbox():
+    g = load_golden('g11_bbox.npz')
+    nfl = np.array([ncc_ref.next_fast_len(n) for n in range(1, 4200)])
+    np.testing.assert_array_equal(nfl, g['nfl'])
+    k = 0
+    while f'div{k}_in' in g:
+        p = g[f'div{k}_in']
+        bb = tuple(p[:4]); bs = p[4]; sf = p[5]; mnb = tuple(int(v) for v in p[6:])
+        if len(mnb) == 1:
+            mnb = mnb[0]
+        kw = dict(min_num_blocks=mnb, shrink_factor=sf)
+        if bs > 0:
+            kw['block_size'] = bs
+        res = np.stack(ncc_ref.divide_bbox(bb, **kw), axis=-1)
+        np.testing.assert_array_equal(res, g[f'div{k}_out'])
+        k += 1
+    assert k >= 6
+    np.testing.assert_array_equal(ncc_ref.z_order(g['z_in']), g['z_out'])
+    np.testing.assert_allclose(ncc_ref.bbox_centers(g['bb_in']), g['bb_centers'])
+    np.testing.assert_allclose(ncc_ref.bbox_sizes(g['bb_in']), g['bb_sizes'])
+    for k in range(2):
+        p = g[f'dist{k}_in']
+        r0, r1 = ncc_ref.distributor_cartesian_bbox(p[:4], p[4:8], p[8], min_num_blocks=int(p[9]))
+        np.testing.assert_array_equal(r0, g[f'dist{k}_bb0'])
+        np.testing.assert_array_equal(r1, g[f'dist{k}_bb1'])
