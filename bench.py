@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Benchmark of the FEABAS hot paths on MI355X (contract: see the task brief).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Headline metric (BASELINE.json): tile-pair NCC matches/s on config[1] -- 1024 synthetic
+4096x4096 tile pairs (512 left-right + 512 up-down, 10 % overlap + margin 100 => strips of
+4096x510 / 510x4096 uint8), inputs resident in HBM.  One "step" = one pass of the device pair
+matcher (feabas_amd/stitch_pipeline.py) over one batch of --pairs-per-step pairs.  The same
+JSON line carries the FEM half of the metric ("fem": PCG iterations/s on the 1e6-DoF system of
+config[2]), the roofline of the dominant kernel and a CPU baseline timed with the oracle.
+With N > 1 every rank matches its own shard of pairs (no data-path collective) and the match
+tables are gathered with one RCCL all_gather per step; value = all pairs / max-over-ranks time.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--pairs-per-step', type=int, default=64)
+    ap.add_argument('--resident-pairs', type=int, default=1024)
+    ap.add_argument('--tile', type=int, default=4096)
+    ap.add_argument('--no-fem', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fem-grid', type=int, default=708)
+    ap.add_argument('--fem-iters', type=int, default=200)
+    return ap.parse_args()
+
+
+def ncc_bytes_model(H, W, spacings_blocks):
+    """Algorithmic HBM bytes of one tile pair: strips read once, DoG outputs
+    written once, every NCC = inputs + 48 S (streaming class) or inputs + 20 (on-chip class)."""
+    from feabas_amd.matcher import next_fast_len as nfl
+    total = 2 * H * W                                  # uint8 strips
+    total += 2 * (H // 2) * (W // 2) * 4 + 2 * H * W * 4   # coarse + fine DoG writes
+    hc, wc = H // 2, W // 2
+    fh, fw = nfl(2 * hc - 1), nfl(2 * wc - 1)
+    total += 2 * hc * wc * 4 + 48 * fh * (fw // 2 + 1)
+    for (nblk, h, w, pad) in spacings_blocks:
+        fh, fw = (nfl(2 * h - 1), nfl(2 * w - 1)) if pad else (nfl(h), nfl(w))
+        if fh * fw <= 256 * 256:
+            total += nblk * (2 * h * w * 4 + 20)
+        else:
+            total += nblk * (2 * h * w * 4 + 48 * fh * (fw // 2 + 1))
+    return total
+
+
+def build_fem_system(grid, nlinks, seed=0):
+    """config[2]: grid x grid node mesh (h = 10), one locked twin, random links, smooth imposed displacement."""
+    from feabas_amd import mesh, optimizer
+    n = grid
+    xs = 10.0 * np.arange(n)
+    vx, vy = np.meshgrid(xs, xs)
+    v = np.stack((vx.ravel(), vy.ravel()), axis=-1)
+    idx = np.arange(n * n).reshape(n, n)
+    a = idx[:-1, :-1].ravel(); b = idx[:-1, 1:].ravel(); c = idx[1:, :-1].ravel(); d = idx[1:, 1:].ravel()
+    par = ((np.arange(n - 1)[None, :] + np.arange(n - 1)[:, None]) % 2).ravel().astype(bool)
+    t0 = np.where(par[:, None], np.stack((a, b, c), -1), np.stack((a, b, d), -1))
+    t1 = np.where(par[:, None], np.stack((b, d, c), -1), np.stack((a, d, c), -1))
+    tri = np.concatenate((t0, t1), axis=0).astype(np.int32)
+    rng = np.random.default_rng(seed)
+    L = 10.0 * (n - 1)
+    disp = np.stack((5 * np.sin(2 * np.pi * v[:, 1] / L), 4 * np.cos(2 * np.pi * v[:, 0] / L)), axis=-1)
+    m0 = mesh.Mesh(v + disp, tri, uid=0, locked=True)
+    m1 = mesh.Mesh(v.copy(), tri, uid=1)
+    tid = rng.integers(0, tri.shape[0], nlinks)
+    B = rng.dirichlet((1, 1, 1), nlinks)
+    w = rng.uniform(0.3, 1.0, nlinks).astype(np.float32)
+    link = optimizer.Link(m0, m1, tid, tid, B, B, weight=w)
+    return optimizer.SLM([m0, m1], [link], stiffness_lambda=1.0, crosslink_lambda=-1.0)
+
+
+def bench_fem(args, lib, ctx, _lib):
+    """PCG iterations/s and time to 1e-4 on the ~1e6-DoF relaxation (config[2])."""
+    t0 = time.time()
+    slm = build_fem_system(args.fem_grid, 200000)
+    slm._assemble(0, 1, 1)                                 # symbolic + numeric assembly
+    t_asm_first = time.time() - t0
+    t0 = time.time()
+    slm._assemble(0, 1, 1)                                 # numeric only (pattern cached)
+    _lib.check(lib.fb_sync(ctx))
+    t_asm = time.time() - t0
+    sl, cl = slm.relative_lambda_trace(1.0, -1.0)
+    _lib.check(lib.fb_sys_form(ctx, slm._sys, sl, cl))
+    nv = C.c_int64(); nnzb = C.c_int64(); nl = C.c_int64()
+    _lib.check(lib.fb_sys_info(ctx, slm._sys, C.byref(nv), C.byref(nnzb), C.byref(nl)))
+    rr = C.c_double()
+    _lib.check(lib.fb_sys_solve_fixed(ctx, slm._sys, 20, C.byref(rr)))          # warm-up
+    _lib.check(lib.fb_sync(ctx))
+    _lib.check(lib.fb_prof_reset(ctx)); _lib.check(lib.fb_prof_enable(ctx, 1))
+    t0 = time.time()
+    _lib.check(lib.fb_sys_solve_fixed(ctx, slm._sys, args.fem_iters, C.byref(rr)))
+    _lib.check(lib.fb_sync(ctx))
+    dt = time.time() - t0
+    _lib.check(lib.fb_prof_enable(ctx, 0))
+    prof = _lib.prof_snapshot()
+    # time to 1e-4 relative residual (the reference's final_elastic tolerance, stitching_configs.yaml:63-72)
+    x = np.zeros(2 * nv.value)
+    it = C.c_int()
+    t0 = time.time()
+    _lib.check(lib.fb_sys_solve(ctx, slm._sys, _lib.ptr(x), 0, 1e-4, 0.0, -1, 1, C.byref(it), C.byref(rr)))
+    t_solve = time.time() - t0
+    n = 2 * nv.value
+    # bytes per PCG iteration with this storage: 2x2 blocks of float64 + int32 block column + int32 row pointer,
+    # SpMV vector traffic (x gather counted once, y write) + 12 vector passes (SURVEY.md sec.8d formula, BSR sizes)
+    it_bytes = nnzb.value * (32 + 4) + nv.value * 4 + n * 8 * 2 + 12 * n * 8
+    k1 = prof.get('pcg_spmv_fused', (0, 0.0)); k2 = prof.get('pcg_update_fused', (0, 0.0))
+    spmv_bytes = nnzb.value * 36 + nv.value * 4 + n * 8 * 5          # A + z,p_old own rows + p_new, Ap writes (+gather once)
+    out = dict(dof=n, nnz_blocks=nnzb.value, links=nl.value, iters_per_s=args.fem_iters / dt,
+               ms_per_iter=1e3 * dt / args.fem_iters, bytes_per_iter=it_bytes,
+               hbm_gbs=it_bytes * args.fem_iters / dt / 1e9, hbm_frac=it_bytes * args.fem_iters / dt / 1e9 / HBM_PEAK_GBS,
+               solve_to_1e4_s=t_solve, solve_iters=it.value, solve_relres=rr.value,
+               assemble_numeric_s=t_asm, assemble_first_s=t_asm_first,
+               spmv_kernel_us=1e3 * k1[1] / max(k1[0], 1), update_kernel_us=1e3 * k2[1] / max(k2[0], 1),
+               spmv_kernel_gbs=spmv_bytes / max(1e-9, (k1[1] / max(k1[0], 1)) * 1e-3) / 1e9)
+    return out
+
+
+def cpu_baseline_ncc(h0, h1, seconds=20.0):
+    """the oracle pair pipeline on the host, one process / one thread, on a bounded sample"""
+    from oracle import pipeline_ref
+    done = 0
+    t0 = time.time()
+    while done < h0.shape[0]:
+        pipeline_ref.match_pair(h0[done], h1[done])
+        done += 1
+        if time.time() - t0 > seconds:
+            break
+    dt = time.time() - t0
+    return done / dt, done, dt
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    os.environ['FEABAS_HIP_DEVICE'] = str(local_rank)
+
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    lib, ctx = _lib.load(), _lib.ctx(local_rank)
+
+    T = args.tile
+    ov = int(round(0.1 * T)) + 100                        # 10 % overlap + margin 100 (stitching_configs.yaml:21)
+    ov += ov % 2
+    P = args.pairs_per_step
+    n_res = max(P, args.resident_pairs // 2 // P * P)     # resident pairs per orientation
+    shapes = {'LR': (T, ov), 'UD': (ov, T)}
+    strips = {}
+    matchers = {}
+    for k, (H, W) in shapes.items():
+        s0 = _lib.DeviceBuffer(n_res * H * W); s1 = _lib.DeviceBuffer(n_res * H * W); sh = _lib.DeviceBuffer(n_res * 8)
+        _lib.check(lib.fb_synth_strips_dev(ctx, n_res, rank * 100000 + (0 if k == 'LR' else 50000), H, W, 2026, 20,
+                                           s0.ptr, s1.ptr, sh.ptr))
+        strips[k] = (s0, s1, sh.to_array((n_res, 2), np.int32))
+        matchers[k] = StripBatchMatcher(P, H, W)
+    _lib.check(lib.fb_sync(ctx))
+
+    def step(i):
+        k = 'LR' if i % 2 == 0 else 'UD'
+        H, W = shapes[k]
+        s0, s1, _ = strips[k]
+        b = (i // 2) % (n_res // P)
+        res = matchers[k].match(s0.offset(b * P * H * W), s1.offset(b * P * H * W))
+        if dist is not None:
+            # match table of this step: [P][400][5] (xy0, xy1, weight), zero padded; one all_gather over RCCL
+            tab = np.zeros((P, 400, 5), dtype=np.float32)
+            for p, r in enumerate(res):
+                if r['xy0'] is not None:
+                    m = min(400, r['xy0'].shape[0])
+                    tab[p, :m, 0:2] = r['xy0'][:m]; tab[p, :m, 2:4] = r['xy1'][:m]; tab[p, :m, 4] = r['weight'][:m]
+            t = torch.from_numpy(tab).cuda(non_blocking=True)
+            out = torch.empty((world,) + tab.shape, dtype=torch.float32, device='cuda')
+            dist.all_gather_into_tensor(out, t)
+        return k, b, res
+
+    def barrier():
+        _lib.check(lib.fb_sync(ctx))
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    _lib.check(lib.fb_prof_reset(ctx)); _lib.check(lib.fb_prof_enable(ctx, 1))
+    t0 = time.time()
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    barrier()
+    dt = time.time() - t0
+    _lib.check(lib.fb_prof_enable(ctx, 0))
+    prof = _lib.prof_snapshot()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    pairs = args.steps * P * world
+
+    # correctness of the timed work: recovered translations = injected shifts, matches found
+    k, b, res = last
+    sh = strips[k][2][b * P:(b + 1) * P]
+    ok_shift = sum(1 for p, r in enumerate(res) if (r['tx'], r['ty']) == (-sh[p, 0], -sh[p, 1]))
+    n_matches = float(np.mean([0 if r['xy0'] is None else r['xy0'].shape[0] for r in res]))
+
+    # roofline of the dominant kernel (by accumulated event time inside the timed region)
+    dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else (None, (0, 0.0))
+    Hl, Wl = shapes['LR']
+    fine_w = -(-Wl // 7)
+    pair_bytes = ncc_bytes_model(Hl, Wl, [(4, Hl // 4, Wl, True), (385, 75, fine_w, False)])
+    total_ms = sum(v[1] for v in prof.values())
+    roof = dict(bound='hbm', kernel=dom[0], launches=dom[1][0],
+                avg_launch_ms=(dom[1][1] / max(dom[1][0], 1)), share_of_gpu_time=(dom[1][1] / max(total_ms, 1e-9)),
+                achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None, traffic=None,
+                pipeline_algorithmic_bytes_per_pair=pair_bytes,
+                pipeline_achieved_gbs=pair_bytes * pairs / world / dt / 1e9,
+                pipeline_frac=pair_bytes * pairs / world / dt / 1e9 / HBM_PEAK_GBS,
+                kernel_ms={k_: round(v[1], 3) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
+    dom_bytes = kernel_bytes_per_launch(dom[0], prof, args, shapes, P)
+    if dom_bytes is not None and dom[1][0] > 0:
+        roof['achieved'] = dom_bytes / (dom[1][1] / dom[1][0] * 1e-3) / 1e9
+        roof['frac'] = roof['achieved'] / HBM_PEAK_GBS
+
+    line = dict(metric='tile_pair_ncc_matches_per_s', value=pairs / dt, unit='pairs/s', n_gpus=world, steps=args.steps,
+                warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='weak',
+                vs_baseline=None, dtype='f32', data='synthetic',
+                config=dict(workload=f'config[1]: {2 * n_res} resident synthetic {T}x{T} tile pairs ({n_res} LR + {n_res} UD strips '
+                                     f'{Hl}x{Wl}), {P} pairs per step; stages: x0.5 downsample, DoG, global NCC, DoG, '
+                                     f'4 coarse + 385 fine block NCCs (translation-only crops, no mesh relaxation yet)',
+                            pairs_per_step=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33),
+                check=dict(shift_recovered=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches),
+                roofline=roof)
+
+    if rank == 0 and not args.no_fem:
+        for m in matchers.values():
+            m.free()
+        line['fem'] = bench_fem(args, lib, ctx, _lib)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        H, W = shapes['LR']
+        s0, s1, _ = strips['LR']
+        ns = min(32, n_res)
+        h0 = s0.to_array((ns, H, W), np.uint8); h1 = s1.to_array((ns, H, W), np.uint8)
+        rate, done, secs = cpu_baseline_ncc(h0, h1)
+        line['cpu_baseline'] = dict(value=rate, unit='pairs/s', cores=1, kind='port',
+                                    sample=f'{done} LR pairs of the same synthetic strips through oracle/pipeline_ref.match_pair '
+                                           f'(scipy.fft/ndimage, 1 process, {secs:.1f} s)')
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def kernel_bytes_per_launch(name, prof, args, shapes, P):
+    """algorithmic bytes one launch of the library's own kernels moves (averaged over the LR/UD steps)"""
+    from feabas_amd.matcher import next_fast_len as nfl
+    Hl, Wl = shapes['LR']
+    if name == 'dog_tile':
+        # launches per step: coarse (2P images, uint8 in) + 2 x fine (P images, uint8 in); average them
+        coarse = 2 * P * (Hl // 2) * (Wl // 2) * (1 + 4)
+        fine = P * Hl * Wl * (1 + 4)
+        return (coarse + 2 * fine) / 3
+    return None
+
+
+if __name__ == '__main__':
+    main()

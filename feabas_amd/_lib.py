@@ -1,0 +1,196 @@
+"""ctypes binding of libfeabas_hip.so (include/feabas_hip.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible,
+every compute entry point raises.  Build with ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C feabas_amd/csrc``.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfeabas_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'feabas_hip.h')
+
+
+class FeabasHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'libfeabas_hip error {code}: {msg}')
+        self.code = code
+
+
+FB_ERR_NOCONV = -5
+FB_ERR_BREAKDOWN = -6
+
+_lib = None
+_ctx = None
+_ctx_device = None
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_i64 = C.c_int64
+c_d = C.c_double
+c_sz = C.c_size_t
+
+_PROTOS = {
+    'fb_create': (c_p, [c_i]),
+    'fb_destroy': (None, [c_p]),
+    'fb_last_error': (C.c_char_p, [c_p]),
+    'fb_sync': (c_i, [c_p]),
+    'fb_stream': (c_p, [c_p]),
+    'fb_device_info': (c_i, [c_p, C.c_char_p, c_i, C.POINTER(c_i), C.POINTER(c_sz)]),
+    'fb_version': (C.c_char_p, []),
+    'fb_malloc': (c_i, [c_p, c_sz, C.POINTER(c_p)]),
+    'fb_free': (c_i, [c_p, c_p]),
+    'fb_memcpy_h2d': (c_i, [c_p, c_p, c_p, c_sz]),
+    'fb_memcpy_d2h': (c_i, [c_p, c_p, c_p, c_sz]),
+    'fb_memset': (c_i, [c_p, c_p, c_i, c_sz]),
+    'fb_timer_start': (c_i, [c_p]),
+    'fb_timer_stop': (c_i, [c_p, C.POINTER(C.c_float)]),
+    'fb_prof_enable': (c_i, [c_p, c_i]),
+    'fb_prof_reset': (c_i, [c_p]),
+    'fb_prof_count': (c_i, [c_p]),
+    'fb_prof_get': (c_i, [c_p, c_i, C.c_char_p, c_i, C.POINTER(c_i), C.POINTER(c_d)]),
+    'fb_next_fast_len': (c_i, [c_i]),
+    'fb_ncc_batch': (c_i, [c_p, c_p, c_p] + [c_i] * 9 + [c_p, c_p, c_p]),
+    'fb_ncc_batch_dev': (c_i, [c_p, c_p, c_p] + [c_i] * 9 + [c_p, c_p, c_p]),
+    'fb_ncc_blocks_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'fb_ncc_last_surfaces': (c_i, [c_p, c_p, c_p, C.POINTER(c_i), C.POINTER(c_i)]),
+    'fb_dog': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
+    'fb_dog_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
+    'fb_area_downsample2': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    'fb_area_downsample2_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    'fb_synth_strips_dev': (c_i, [c_p, c_i, c_i, c_i, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
+    'fb_sys_create': (c_i, [c_p, c_i64, C.POINTER(c_p)]),
+    'fb_sys_destroy': (None, [c_p, c_p]),
+    'fb_sys_add_mesh': (c_i, [c_p, c_p, c_i64, c_p, c_i, c_i, C.POINTER(c_i)]),
+    'fb_sys_set_links': (c_i, [c_p, c_p, c_i64, c_p]),
+    'fb_sys_finalize': (c_i, [c_p, c_p, C.POINTER(c_i64)]),
+    'fb_sys_pattern': (c_i, [c_p, c_p, c_p, c_p]),
+    'fb_sys_info': (c_i, [c_p, c_p, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)]),
+    'fb_sys_assemble_mesh': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_d, c_d]),
+    'fb_sys_assemble_links': (c_i, [c_p, c_p, c_p, c_p, c_p]),
+    'fb_sys_lambda': (c_i, [c_p, c_p, c_d, c_d, C.POINTER(c_d), C.POINTER(c_d)]),
+    'fb_sys_form': (c_i, [c_p, c_p, c_d, c_d]),
+    'fb_sys_solve': (c_i, [c_p, c_p, c_p, c_i, c_d, c_d, c_i, c_i, C.POINTER(c_i), C.POINTER(c_d)]),
+    'fb_sys_solve_fixed': (c_i, [c_p, c_p, c_i, C.POINTER(c_d)]),
+    'fb_sys_get': (c_i, [c_p, c_p, c_i, c_p]),
+    'fb_pcg': (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i, c_d, c_d, c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_d)]),
+    'fb_csr_upload': (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i, C.POINTER(c_p)]),
+    'fb_csr_destroy': (None, [c_p, c_p]),
+    'fb_csr_info': (c_i, [c_p, c_p] + [C.POINTER(c_i64)] * 4),
+    'fb_spmv': (c_i, [c_p, c_p, c_p, c_p]),
+    'fb_pcg_csr': (c_i, [c_p, c_p, c_p, c_p, c_i, c_d, c_d, c_i, c_i, C.POINTER(c_i), C.POINTER(c_d)]),
+    'fb_pcg_fixed_iters': (c_i, [c_p, c_p, c_p, c_i, C.POINTER(c_d)]),
+}
+
+
+def declared_symbols():
+    """Every function name include/feabas_hip.h declares."""
+    with open(HEADER_PATH) as f:
+        txt = f.read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(fb_[a-z0-9_]+)\s*\(', txt)))
+
+
+def load():
+    """Load the shared library (no GPU needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f'{LIB_PATH} not found: build it with __graft_entry__.build() '
+                          '(feabas_amd has no CPU fallback)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ctx(device=None):
+    """The per-process context (one GPU per process; LOCAL_RANK picks the device)."""
+    global _ctx, _ctx_device
+    lib = load()
+    if device is None:
+        device = int(os.environ.get('FEABAS_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    if _ctx is not None and _ctx_device == device:
+        return _ctx
+    if _ctx is not None:
+        lib.fb_destroy(_ctx)
+        _ctx = None
+    h = lib.fb_create(device)
+    if not h:
+        raise RuntimeError(f'fb_create({device}) failed: no usable MI355X/HIP device '
+                           '(feabas_amd has no CPU fallback)')
+    _ctx = h
+    _ctx_device = device
+    return _ctx
+
+
+def check(rc, allow=()):
+    if rc != 0 and rc not in allow:
+        msg = load().fb_last_error(_ctx)
+        raise FeabasHipError(rc, msg.decode() if msg else '?')
+    return rc
+
+
+def ptr(a):
+    """Raw pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(c_p)
+
+
+def as_c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class DeviceBuffer:
+    """A context-owned device allocation (plumbing for resident pipelines)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = c_p()
+        check(load().fb_malloc(ctx(), self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_array(cls, a):
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes)
+        check(load().fb_memcpy_h2d(ctx(), buf.ptr, ptr(a), a.nbytes))
+        return buf
+
+    def to_array(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(load().fb_memcpy_d2h(ctx(), ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def offset(self, nbytes):
+        return c_p(self.ptr.value + int(nbytes))
+
+    def free(self):
+        if self.ptr is not None and _ctx is not None:
+            load().fb_free(_ctx, self.ptr)
+        self.ptr = None
+
+
+def prof_snapshot():
+    """{kernel name: (launches, total ms)} from the library's event profile."""
+    lib = load()
+    out = {}
+    n = lib.fb_prof_count(ctx())
+    name = C.create_string_buffer(128)
+    launches = c_i()
+    ms = c_d()
+    for i in range(n):
+        check(lib.fb_prof_get(ctx(), i, name, 128, C.byref(launches), C.byref(ms)))
+        out[name.value.decode()] = (launches.value, ms.value)
+    return out

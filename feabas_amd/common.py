@@ -1,0 +1,129 @@
+"""Host mirror of the feabas.common helpers that sit on the NCC path.
+
+``masked_dog_filter`` runs on the GPU (fb_dog); the bounding-box helpers are
+integer bookkeeping that stays on the host exactly as in the reference.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+
+Match = namedtuple('Match', ('xy0', 'xy1', 'weight'))       # feabas/common.py:18
+
+
+def masked_dog_filter(img, sigma, mask=None, signed=True):
+    """feabas/common.py:353-377 on the GPU.  img: (N x) H x W uint8/float;
+    returns float32 of the same shape."""
+    img = np.asarray(img)
+    if img.ndim < 2:
+        raise ValueError('masked_dog_filter expects at least a 2-D image')
+    shp = img.shape
+    h, w = shp[-2:]
+    n = int(np.prod(shp[:-2])) if img.ndim > 2 else 1
+    if img.dtype == np.uint8:
+        src, dt = np.ascontiguousarray(img), 0
+    else:
+        # the reference filters floating input in its own precision; the matcher only feeds float32
+        src, dt = np.ascontiguousarray(img, dtype=np.float32), 1
+    m = None
+    if mask is not None:
+        m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        if m.shape != (h, w):
+            raise ValueError('mask must be H x W')
+    out = np.empty((n, h, w), dtype=np.float32)
+    _lib.check(_lib.load().fb_dog(_lib.ctx(), _lib.ptr(src), dt, n, h, w, float(sigma), _lib.ptr(m),
+                                  1 if signed else 0, _lib.ptr(out)))
+    return out.reshape(shp)
+
+
+def area_downsample2(img):
+    """cv2.resize(img, None, fx=0.5, fy=0.5, INTER_AREA) for even-sized uint8
+    images (feabas/matcher.py:255-256) on the GPU."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    shp = img.shape
+    h, w = shp[-2:]
+    n = int(np.prod(shp[:-2])) if img.ndim > 2 else 1
+    out = np.empty(shp[:-2] + (h // 2, w // 2), dtype=np.uint8)
+    _lib.check(_lib.load().fb_area_downsample2(_lib.ctx(), _lib.ptr(img), n, h, w, _lib.ptr(out)))
+    return out
+
+
+def numpy_array(obj, copy=False):
+    return np.array(obj, copy=True) if copy else np.asarray(obj)
+
+
+def divide_bbox(bbox, **kwargs):
+    """feabas/common.py:380-409."""
+    xmin, ymin, xmax, ymax = bbox
+    ht = ymax - ymin
+    wd = xmax - xmin
+    block_size = kwargs.get('block_size', max(ht, wd))
+    min_num_blocks = kwargs.get('min_num_blocks', 1)
+    round_output = kwargs.get('round_output', True)
+    shrink_factor = kwargs.get('shrink_factor', 1)
+    if not hasattr(block_size, '__len__'):
+        block_size = (block_size, block_size)
+    if not hasattr(min_num_blocks, '__len__'):
+        min_num_blocks = (min_num_blocks, min_num_blocks)
+    n_x = max(np.ceil(wd / block_size[1]), min_num_blocks[1])
+    n_y = max(np.ceil(ht / block_size[0]), min_num_blocks[0])
+    step_x = int(np.ceil(wd / n_x))
+    step_y = int(np.ceil(ht / n_y))
+    x_start = np.linspace(xmin, xmax - step_x, num=int(n_x), endpoint=True)
+    y_start = np.linspace(ymin, ymax - step_y, num=int(n_y), endpoint=True)
+    if shrink_factor != 1:
+        sx, sy = step_x * shrink_factor, step_y * shrink_factor
+        x_start = x_start + (step_x - sx) / 2
+        y_start = y_start + (step_y - sy) / 2
+        step_x, step_y = int(np.ceil(sx)), int(np.ceil(sy))
+    if round_output:
+        x_start = np.round(x_start).astype(np.int32)
+        y_start = np.round(y_start).astype(np.int32)
+    gx, gy = np.meshgrid(x_start, y_start)
+    gx, gy = gx.ravel(), gy.ravel()
+    return gx, gy, gx + step_x, gy + step_y
+
+
+def intersect_bbox(bbox0, bbox1):
+    """feabas/common.py:412-417."""
+    lo_x, lo_y = max(bbox0[0], bbox1[0]), max(bbox0[1], bbox1[1])
+    hi_x, hi_y = min(bbox0[2], bbox1[2]), min(bbox0[3], bbox1[3])
+    return (lo_x, lo_y, hi_x, hi_y), (lo_x < hi_x) and (lo_y < hi_y)
+
+
+def z_order(indices, base=2):
+    """feabas/common.py:196-215."""
+    indices = np.asarray(indices)
+    ndim = indices.shape[-1]
+    rem = indices - indices.min(axis=0)
+    digits = np.zeros_like(rem)
+    level = 0
+    while np.any(rem > 0):
+        digits = digits + (rem % base) * (base ** (ndim * level))
+        rem = np.floor(rem / base)
+        level += 1
+    score = np.sum(digits * (base ** np.arange(ndim)), axis=-1)
+    return np.argsort(score, kind='stable')
+
+
+def bbox_centers(bboxes):
+    """feabas/common.py:687-690 (pixel-centre convention: -0.5)."""
+    b = np.asarray(bboxes, dtype=np.float64).reshape(-1, 4)
+    return 0.5 * np.stack((b[:, 0] + b[:, 2], b[:, 1] + b[:, 3]), axis=-1) - 0.5
+
+
+def bbox_sizes(bboxes):
+    """feabas/common.py:693-696: (height, width)."""
+    b = np.asarray(bboxes).reshape(-1, 4)
+    return np.stack((b[:, 3] - b[:, 1], b[:, 2] - b[:, 0]), axis=-1).clip(0, None)
+
+
+def cross2d(v0, v1):
+    return v0[..., 0] * v1[..., 1] - v0[..., 1] * v1[..., 0]
+
+
+def signed_area(vertices, triangles):
+    """feabas/common.py:672-676."""
+    p = vertices[triangles]
+    return cross2d(p[:, 1, :] - p[:, 0, :], p[:, 2, :] - p[:, 1, :])

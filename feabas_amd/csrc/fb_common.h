@@ -1,0 +1,99 @@
+// Internal definitions shared by the HIP translation units of libfeabas_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "feabas_hip.h"
+
+struct fb_prof_entry {
+    std::string name;
+    int launches = 0;
+    double total_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct fb_fft_plan {
+    rocfft_plan fwd = nullptr;
+    rocfft_plan inv = nullptr;
+    size_t work_bytes = 0;
+};
+
+struct fb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+    // scratch arena (grow-only) for the NCC streaming class
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    // rocFFT plans keyed by (Fh, Fw, batch)
+    std::map<std::tuple<int, int, int>, fb_fft_plan> plans;
+    rocfft_execution_info fft_info = nullptr;
+    void* fft_work = nullptr;
+    size_t fft_work_bytes = 0;
+    bool rocfft_ready = false;
+    // surfaces of the last streaming-class call (debug aid)
+    int last_Fh = 0, last_Fw = 0, last_N = 0;
+    const float* last_C = nullptr;
+    const float* last_Cm = nullptr;
+    // stopwatch + per-kernel profile
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool prof_on = false;
+    std::vector<fb_prof_entry> prof;
+    std::vector<void*> owned;   // fb_malloc'ed pointers
+    size_t ncc_arena_limit = (size_t)8 << 30;
+};
+
+int fb_fail(fb_ctx* ctx, int code, const char* fmt, ...);
+
+#define FB_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fb_fail((ctx), FB_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,         \
+                           hipGetErrorString(e__));                                                \
+    } while (0)
+
+#define FB_FFT(ctx, call)                                                                          \
+    do {                                                                                           \
+        rocfft_status s__ = (call);                                                                \
+        if (s__ != rocfft_status_success)                                                          \
+            return fb_fail((ctx), FB_ERR_FFT, "%s:%d %s -> rocfft status %d", __FILE__, __LINE__,  \
+                           #call, (int)s__);                                                       \
+    } while (0)
+
+#define FB_CHECK_ARG(ctx, cond)                                                                    \
+    do {                                                                                           \
+        if (!(cond)) return fb_fail((ctx), FB_ERR_ARG, "%s:%d invalid argument: %s", __FILE__,     \
+                                    __LINE__, #cond);                                              \
+    } while (0)
+
+// grow-only scratch arena
+int fb_arena_reserve(fb_ctx* ctx, size_t bytes);
+
+// per-kernel profiling scope: records an event pair around a launch when enabled
+struct fb_prof_scope {
+    fb_ctx* ctx;
+    int idx = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    fb_prof_scope(fb_ctx* c, const char* name);
+    ~fb_prof_scope();
+};
+#define FB_PROF(ctx, name) fb_prof_scope prof_scope__((ctx), (name))
+
+static inline int fb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// cross-TU entry points
+int fb_ncc_small_supported(int Fh, int Fw, int H0, int W0, int H1, int W1, int C);
+int fb_ncc_small_launch(fb_ctx* ctx, const float* img0, const float* img1, int N, int H0, int W0,
+                        int H1, int W1, int Fh, int Fw, int subpixel, int conf_mode, double* dx,
+                        double* dy, float* conf);

@@ -1,0 +1,207 @@
+// Context, device memory, stopwatch and per-kernel profile of libfeabas_hip.so.
+#include "fb_common.h"
+
+int fb_fail(fb_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int fb_arena_reserve(fb_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->arena_bytes) return FB_OK;
+    if (ctx->arena) {
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FB_HIP(ctx, hipFree(ctx->arena));
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 3);
+    hipError_t e = hipMalloc(&ctx->arena, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        e = hipMalloc(&ctx->arena, want);
+    }
+    if (e != hipSuccess) return fb_fail(ctx, FB_ERR_NOMEM, "arena hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    ctx->arena_bytes = want;
+    return FB_OK;
+}
+
+fb_prof_scope::fb_prof_scope(fb_ctx* c, const char* name) : ctx(c) {
+    if (!ctx->prof_on) return;
+    for (size_t i = 0; i < ctx->prof.size(); ++i)
+        if (ctx->prof[i].name == name) idx = (int)i;
+    if (idx < 0) {
+        ctx->prof.emplace_back();
+        ctx->prof.back().name = name;
+        idx = (int)ctx->prof.size() - 1;
+    }
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, ctx->stream);
+}
+
+fb_prof_scope::~fb_prof_scope() {
+    if (idx < 0) return;
+    hipEventRecord(e1, ctx->stream);
+    ctx->prof[idx].pending.emplace_back(e0, e1);
+}
+
+static void prof_drain(fb_ctx* ctx) {
+    for (auto& p : ctx->prof) {
+        for (auto& ev : p.pending) {
+            float ms = 0.f;
+            hipEventSynchronize(ev.second);
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                p.total_ms += ms;
+                p.launches += 1;
+            }
+            hipEventDestroy(ev.first);
+            hipEventDestroy(ev.second);
+        }
+        p.pending.clear();
+    }
+}
+
+extern "C" {
+
+const char* fb_version(void) { return "feabas_hip 0.1 (gfx950)"; }
+
+fb_ctx* fb_create(int device_id) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nullptr;
+    if (device_id < 0 || device_id >= ndev) return nullptr;
+    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    fb_ctx* ctx = new fb_ctx();
+    ctx->device = device_id;
+    if (hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void fb_destroy(fb_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    for (auto& kv : ctx->plans) {
+        if (kv.second.fwd) rocfft_plan_destroy(kv.second.fwd);
+        if (kv.second.inv) rocfft_plan_destroy(kv.second.inv);
+    }
+    if (ctx->fft_info) rocfft_execution_info_destroy(ctx->fft_info);
+    if (ctx->fft_work) hipFree(ctx->fft_work);
+    if (ctx->arena) hipFree(ctx->arena);
+    for (void* p : ctx->owned) hipFree(p);
+    if (ctx->rocfft_ready) rocfft_cleanup();
+    hipEventDestroy(ctx->t0);
+    hipEventDestroy(ctx->t1);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* fb_last_error(fb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int fb_sync(fb_ctx* ctx) {
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FB_OK;
+}
+
+void* fb_stream(fb_ctx* ctx) { return (void*)ctx->stream; }
+
+int fb_device_info(fb_ctx* ctx, char* name, int name_len, int* num_cu, size_t* hbm_bytes) {
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    }
+    if (num_cu) *num_cu = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
+    return FB_OK;
+}
+
+int fb_malloc(fb_ctx* ctx, size_t bytes, void** dptr) {
+    FB_CHECK_ARG(ctx, dptr != nullptr);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) return fb_fail(ctx, FB_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    ctx->owned.push_back(p);
+    *dptr = p;
+    return FB_OK;
+}
+
+int fb_free(fb_ctx* ctx, void* dptr) {
+    if (!dptr) return FB_OK;
+    for (size_t i = 0; i < ctx->owned.size(); ++i) {
+        if (ctx->owned[i] == dptr) {
+            ctx->owned.erase(ctx->owned.begin() + i);
+            FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            FB_HIP(ctx, hipFree(dptr));
+            return FB_OK;
+        }
+    }
+    return fb_fail(ctx, FB_ERR_ARG, "fb_free: pointer not owned by this context");
+}
+
+int fb_memcpy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FB_OK;
+}
+
+int fb_memcpy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FB_OK;
+}
+
+int fb_memset(fb_ctx* ctx, void* dst, int value, size_t bytes) {
+    FB_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return FB_OK;
+}
+
+int fb_timer_start(fb_ctx* ctx) {
+    FB_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+    return FB_OK;
+}
+
+int fb_timer_stop(fb_ctx* ctx, float* ms) {
+    FB_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+    FB_HIP(ctx, hipEventSynchronize(ctx->t1));
+    FB_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+    return FB_OK;
+}
+
+int fb_prof_enable(fb_ctx* ctx, int on) {
+    if (!on) prof_drain(ctx);
+    ctx->prof_on = on != 0;
+    return FB_OK;
+}
+
+int fb_prof_reset(fb_ctx* ctx) {
+    prof_drain(ctx);
+    ctx->prof.clear();
+    return FB_OK;
+}
+
+int fb_prof_count(fb_ctx* ctx) {
+    prof_drain(ctx);
+    return (int)ctx->prof.size();
+}
+
+int fb_prof_get(fb_ctx* ctx, int index, char* name, int name_len, int* launches, double* total_ms) {
+    prof_drain(ctx);
+    FB_CHECK_ARG(ctx, index >= 0 && index < (int)ctx->prof.size());
+    const fb_prof_entry& p = ctx->prof[index];
+    if (name && name_len > 0) snprintf(name, name_len, "%s", p.name.c_str());
+    if (launches) *launches = p.launches;
+    if (total_ms) *total_ms = p.total_ms;
+    return FB_OK;
+}
+
+}  // extern "C"

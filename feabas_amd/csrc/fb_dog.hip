@@ -1,0 +1,297 @@
+// Band-pass pre-filter of the matcher: common.masked_dog_filter (feabas/common.py:353-377)
+// and the 2x area downsample in front of the coarse match (matcher.py:255-256).
+//
+// DoG = G(img) - G(G(img)), each G = scipy.ndimage.gaussian_filter1d along W then H with
+// mode='nearest', truncate 4 sigma.  scipy keeps float32 between passes and accumulates
+// each output sample in double, centre tap first, then tap pairs from the outermost in;
+// the kernels below reproduce that order.  One workgroup filters a 64x64 output tile
+// through all four passes inside LDS (two ping-pong buffers): HBM traffic is one read of
+// the (haloed) input and one float32 write per pixel.
+#include "fb_common.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int kMaxRadius = 40;
+struct Taps { double w[kMaxRadius + 1]; };      // w[0] = centre, w[k] = tap at +-k (kernel argument)
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <typename T>
+__device__ __forceinline__ float load_px(const T* p, size_t i);
+template <>
+__device__ __forceinline__ float load_px<uint8_t>(const uint8_t* p, size_t i) { return (float)p[i]; }
+template <>
+__device__ __forceinline__ float load_px<float>(const float* p, size_t i) { return p[i]; }
+
+// 1-D correlation at LDS position `base` with element stride `st` (symmetric taps)
+__device__ __forceinline__ float fir_sym(const float* s, int base, int st, int r, const Taps& t) {
+    double acc = (double)s[base] * t.w[0];
+    for (int k = r; k >= 1; --k)
+        acc += ((double)s[base - k * st] + (double)s[base + k * st]) * t.w[k];
+    return (float)acc;
+}
+
+// NPASS = 2: out = G(in).  NPASS = 4: out = G(in) - G(G(in)), optional masked-halo epilogue.
+// A value stored at tile-local (ty,tx) always is the value of the stage's image at the
+// CLAMPED global coordinate, which is exactly scipy's 'nearest' extension of that stage.
+template <typename T, int NPASS>
+__global__ void dog_tile(const T* __restrict__ img, float* __restrict__ out, const float* __restrict__ halo,
+                         int H, int W, int r, int TY, int TX, int signed_out, float in_scale, const uint8_t* __restrict__ mask, const Taps taps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = blockIdx.z;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int hal = (NPASS == 4) ? 2 * r : r;          // input halo
+    const int AW = TX + 2 * hal, AH = TY + 2 * hal;     // stage-0 tile
+    float* bufA = smem;                                 // AH x AW, later G0: (TY+2r) x (TX+2r)
+    float* bufB = smem + AH * AW;                       // AH x (AW-2r), later (TY+2r|TY) x TX
+    const T* src = img + (size_t)n * H * W;
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    // stage 0: load (clamped) input tile.  With a mask, the input is ptp*(mask==0) (common.py:369)
+    for (int i = tid; i < AH * AW; i += nt) {
+        const int ty = i / AW, tx = i - ty * AW;
+        const int gy = clampi(y0 - hal + ty, 0, H - 1), gx = clampi(x0 - hal + tx, 0, W - 1);
+        float v;
+        if (mask) v = mask[(size_t)gy * W + gx] ? 0.f : in_scale;
+        else v = load_px<T>(src, (size_t)gy * W + gx);
+        bufA[i] = v;
+    }
+    __syncthreads();
+    // stage 1: rows.  B (AH x BW), BW = AW - 2r; B(ty,tx) <- global x = x0-(hal-r)+tx
+    const int BW = AW - 2 * r;
+    for (int i = tid; i < AH * BW; i += nt) {
+        const int ty = i / BW, tx = i - ty * BW;
+        const int gx = clampi(x0 - (hal - r) + tx, 0, W - 1);
+        bufB[i] = fir_sym(bufA, ty * AW + (gx - (x0 - hal)), 1, r, taps);
+    }
+    __syncthreads();
+    // stage 2: columns.  G0 (GH x BW), GH = AH - 2r, into bufA
+    const int GH = AH - 2 * r;
+    for (int i = tid; i < GH * BW; i += nt) {
+        const int ty = i / BW, tx = i - ty * BW;
+        const int gy = clampi(y0 - (hal - r) + ty, 0, H - 1);
+        bufA[i] = fir_sym(bufB, (gy - (y0 - hal)) * BW + tx, BW, r, taps);
+    }
+    __syncthreads();
+    if (NPASS == 2) {
+        for (int i = tid; i < TY * TX; i += nt) {
+            const int ty = i / TX, tx = i - ty * TX;
+            const int gy = y0 + ty, gx = x0 + tx;
+            if (gy < H && gx < W) out[((size_t)n * H + gy) * W + gx] = bufA[ty * BW + tx] * 2.0f;   // (sc^2/s0^2) = 2, common.py:371
+        }
+        return;
+    }
+    // stage 3: rows of G0 -> D (GH x TX) in bufB
+    for (int i = tid; i < GH * TX; i += nt) {
+        const int ty = i / TX, tx = i - ty * TX;
+        const int gx = clampi(x0 + tx, 0, W - 1);
+        bufB[i] = fir_sym(bufA, ty * BW + (gx - (x0 - r)), 1, r, taps);
+    }
+    __syncthreads();
+    // stage 4: columns of D -> G1; out = G0 - G1
+    for (int i = tid; i < TY * TX; i += nt) {
+        const int ty = i / TX, tx = i - ty * TX;
+        const int gy = y0 + ty, gx = x0 + tx;
+        if (gy >= H || gx >= W) continue;
+        const float g1 = fir_sym(bufB, (gy - (y0 - r)) * TX + tx, TX, r, taps);
+        const float g0 = bufA[(ty + r) * BW + (tx + r)];
+        float v = g0 - g1;
+        if (halo) {                                     // common.py:372-374
+            const float a = fmaxf(fabsf(v) - halo[(size_t)gy * W + gx], 0.f);
+            v = v > 0.f ? a : (v < 0.f ? -a : 0.f * a);
+        }
+        if (!signed_out) v = fabsf(v);
+        out[((size_t)n * H + gy) * W + gx] = v;
+    }
+}
+
+// global min / max of the whole input (np.ptp, common.py:369)
+template <typename T>
+__global__ void minmax_kernel(const T* __restrict__ img, size_t total, float* __restrict__ mm) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = load_px<T>(img, i);
+        lo = fminf(lo, v); hi = fmaxf(hi, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_down(lo, off));
+        hi = fmaxf(hi, __shfl_down(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // float atomics through the integer ordering trick are avoided: one slot per wave
+        const size_t slot = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        mm[2 * slot] = lo; mm[2 * slot + 1] = hi;
+    }
+}
+
+__global__ void any_zero_kernel(const uint8_t* __restrict__ m, size_t total, int* flag) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        if (m[i] == 0) { *flag = 1; return; }
+}
+
+__global__ void area_down2_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int N, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / ((size_t)Ho * Wo);
+        const int rem = (int)(i - n * (size_t)Ho * Wo);
+        const int y = rem / Wo, x = rem - y * Wo;
+        const uint8_t* p = in + (n * H + 2 * y) * (size_t)W + 2 * x;
+        const int s = (int)p[0] + (int)p[1] + (int)p[W] + (int)p[W + 1];
+        out[i] = (uint8_t)((s + 2) >> 2);
+    }
+}
+
+int set_taps(fb_ctx* ctx, double sigma, int* radius, Taps* out) {
+    const int r = (int)(4.0 * sigma + 0.5);
+    if (r < 1 || r > kMaxRadius) return fb_fail(ctx, FB_ERR_ARG, "fb_dog: sigma %.3f gives radius %d outside [1,%d]", sigma, r, kMaxRadius);
+    double w[2 * kMaxRadius + 1];
+    double sum = 0.0;
+    for (int k = -r; k <= r; ++k) {            // scipy.ndimage._gaussian_kernel1d
+        w[k + r] = std::exp(-0.5 / (sigma * sigma) * (double)k * (double)k);
+        sum += w[k + r];
+    }
+    for (int k = 0; k <= kMaxRadius; ++k) out->w[k] = k <= r ? w[r + k] / sum : 0.0;
+    *radius = r;
+    return FB_OK;
+}
+
+template <typename T, int NPASS>
+int launch_tile(fb_ctx* ctx, const T* img, float* out, const float* halo, int N, int H, int W, int r, int signed_out,
+                float in_scale, const uint8_t* mask, const Taps& taps) {
+    // largest square tile whose two LDS buffers fit in 64 KiB (2 workgroups per CU) or, failing that, 150 KiB
+    const int hal = (NPASS == 4) ? 2 * r : r;
+    int T_ = 64;
+    auto lds_bytes = [&](int t) { const int A = t + 2 * hal; return (size_t)(A * A + A * (A - 2 * r)) * sizeof(float); };
+    while (T_ > 16 && lds_bytes(T_) > 150 * 1024) T_ -= 16;
+    if (lds_bytes(T_) > 150 * 1024) return fb_fail(ctx, FB_ERR_ARG, "fb_dog: radius %d too large for the LDS tile", r);
+    const size_t lds = lds_bytes(T_);
+    auto kern = dog_tile<T, NPASS>;
+    FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(fb_cdiv(W, T_), fb_cdiv(H, T_), N);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img, out, halo, H, W, r, T_, T_, signed_out, in_scale, mask, taps);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+template <typename T>
+int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, const uint8_t* mask, int signed_out, float* out) {
+    int rc, r = 0;
+    Taps taps;
+    float* halo = nullptr;
+    if (mask) {
+        // common.py:368: only when the mask has a zero somewhere
+        int* flag = nullptr;
+        FB_HIP(ctx, hipMalloc(&flag, sizeof(int)));
+        FB_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(any_zero_kernel, dim3(256), dim3(256), 0, ctx->stream, mask, (size_t)H * W, flag);
+        int hflag = 0;
+        FB_HIP(ctx, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FB_HIP(ctx, hipFree(flag));
+        if (hflag) {
+            const int nblk = 256, nslots = nblk * 4;
+            float* mm = nullptr;
+            FB_HIP(ctx, hipMalloc(&mm, sizeof(float) * 2 * nslots));
+            hipLaunchKernelGGL(minmax_kernel<T>, dim3(nblk), dim3(256), 0, ctx->stream, img, (size_t)N * H * W, mm);
+            std::vector<float> hmm(2 * nslots);
+            FB_HIP(ctx, hipMemcpyAsync(hmm.data(), mm, sizeof(float) * 2 * nslots, hipMemcpyDeviceToHost, ctx->stream));
+            FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            FB_HIP(ctx, hipFree(mm));
+            float lo = INFINITY, hi = -INFINITY;
+            for (int i = 0; i < nslots; ++i) { lo = std::min(lo, hmm[2 * i]); hi = std::max(hi, hmm[2 * i + 1]); }
+            const float ptp = hi - lo;
+            // halo = G_{sigma*sqrt2}(ptp*(mask==0)) * 2   (common.py:369-371)
+            const double sc = std::sqrt(2.0 * sigma * sigma);
+            rc = set_taps(ctx, sc, &r, &taps);
+            if (rc) return rc;
+            FB_HIP(ctx, hipMalloc(&halo, sizeof(float) * (size_t)H * W));
+            rc = launch_tile<T, 2>(ctx, (const T*)nullptr, halo, nullptr, 1, H, W, r, 1, ptp, mask, taps);
+            if (rc) { hipFree(halo); return rc; }
+        }
+    }
+    rc = set_taps(ctx, sigma, &r, &taps);
+    if (!rc) {
+        FB_PROF(ctx, "dog_tile");
+        rc = launch_tile<T, 4>(ctx, img, out, halo, N, H, W, r, signed_out, 0.f, nullptr, taps);
+    }
+    if (halo) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(halo);
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fb_dog_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* mask,
+               int signed_out, float* out) {
+    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && sigma > 0);
+    FB_CHECK_ARG(ctx, dtype == FB_U8 || dtype == FB_F32);
+    if (N == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, img && out);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    if (dtype == FB_U8) return dog_dev_t<uint8_t>(ctx, (const uint8_t*)img, N, H, W, sigma, mask, signed_out, out);
+    return dog_dev_t<float>(ctx, (const float*)img, N, H, W, sigma, mask, signed_out, out);
+}
+
+int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* mask, int signed_out,
+           float* out) {
+    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && sigma > 0);
+    FB_CHECK_ARG(ctx, dtype == FB_U8 || dtype == FB_F32);
+    if (N == 0) return FB_OK;
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)N * H * W, esz = dtype == FB_U8 ? 1 : 4;
+    void* din = nullptr; float* dout = nullptr; uint8_t* dmask = nullptr;
+    FB_HIP(ctx, hipMalloc(&din, px * esz));
+    FB_HIP(ctx, hipMalloc(&dout, px * sizeof(float)));
+    hipMemcpyAsync(din, img, px * esz, hipMemcpyHostToDevice, ctx->stream);
+    if (mask) {
+        FB_HIP(ctx, hipMalloc(&dmask, (size_t)H * W));
+        hipMemcpyAsync(dmask, mask, (size_t)H * W, hipMemcpyHostToDevice, ctx->stream);
+    }
+    int rc = fb_dog_dev(ctx, din, dtype, N, H, W, sigma, dmask, signed_out, dout);
+    if (!rc) {
+        hipMemcpyAsync(out, dout, px * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fb_fail(ctx, FB_ERR_HIP, "fb_dog: %s", hipGetErrorString(e));
+    }
+    hipFree(din); hipFree(dout); if (dmask) hipFree(dmask);
+    return rc;
+}
+
+int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {
+    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0));
+    if (N == 0) return FB_OK;
+    FB_PROF(ctx, "area_down2");
+    const size_t total = (size_t)N * (H / 2) * (W / 2);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(area_down2_kernel, dim3(blocks), dim3(256), 0, ctx->stream, img, out, N, H, W);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {
+    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0));
+    if (N == 0) return FB_OK;
+    const size_t bi = (size_t)N * H * W, bo = bi / 4;
+    uint8_t *din = nullptr, *dout = nullptr;
+    FB_HIP(ctx, hipMalloc(&din, bi));
+    FB_HIP(ctx, hipMalloc(&dout, bo));
+    hipMemcpyAsync(din, img, bi, hipMemcpyHostToDevice, ctx->stream);
+    int rc = fb_area_downsample2_dev(ctx, din, N, H, W, dout);
+    if (!rc) {
+        hipMemcpyAsync(out, dout, bo, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fb_fail(ctx, FB_ERR_HIP, "fb_area_downsample2: %s", hipGetErrorString(e));
+    }
+    hipFree(din); hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"

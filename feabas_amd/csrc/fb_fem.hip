@@ -1,0 +1,479 @@
+// FEM path, assembly: a spring-linked-mesh system resident on the GPU.
+//   stiffness   K = sum_e N_e^T D_e N_e * soft   (material.py:134-182, mesh.py:3058-3083, optimizer.py:802-829)
+//   cross links C = S^T diag(w) S (x and y copies), rhs = S^T (w r)   (optimizer.py:832-901)
+//   lambdas     relative_lambda_trace            (optimizer.py:1573-1590)
+//   system      A = ls K + lc C,  b = lc rhs - ls stress            (optimizer.py:1416-1418)
+// One 2x2 block per coupled vertex pair; every vertex row is owned by one thread which walks the
+// triangles / matches incident to that vertex, so the assembly has no atomics and a fixed
+// summation order (bitwise reproducible).  The symbolic pattern is built once per topology on the
+// host (C++), the numeric phases run on the device.
+#include "fb_solver.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+struct fb_mesh_blk {
+    int voff = 0, V = 0, T = 0;
+    std::vector<int> tri;            // host copy (local vertex ids)
+    int* d_tri = nullptr;
+    int* d_vtptr = nullptr;          // [V+1] incident triangle slots per vertex
+    int* d_vtidx = nullptr;          // [3T] encoded 3*t + local
+    float* d_mult = nullptr;         // [T]
+    double2* d_vshape = nullptr;     // [V]
+    double2* d_vcur = nullptr;       // [V]
+};
+
+struct fb_system {
+    int nv = 0;
+    bool finalized = false;
+    std::vector<fb_mesh_blk> meshes;
+    // links
+    int64_t nlink = 0;
+    std::vector<int> nodes;          // [K][6] global free vertex ids, -1 = locked side
+    int* d_nodes = nullptr;
+    int* d_vmptr = nullptr;          // [nv+1]
+    int* d_vmidx = nullptr;          // encoded 6*i + slot
+    double* d_bary = nullptr;        // [K][6] signed (+B0 | -B1)
+    float* d_w = nullptr;            // [K]
+    double2* d_rxy = nullptr;        // [K]
+    // pattern (host copy) + values
+    std::vector<int> browptr, bcol;
+    double* d_K = nullptr;           // [nnzb][4]
+    double* d_Cacc = nullptr;        // [nnzb]
+    float* d_C = nullptr;            // [nnzb]
+    double2* d_rhs = nullptr;        // [nv]
+    float2* d_stress = nullptr;      // [nv]
+    double* d_parts = nullptr;       // reduction scratch
+    fb_bsr* M = nullptr;             // A + PCG workspace, shares the pattern
+};
+
+namespace {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ int find_col(const int* __restrict__ col, int lo, int hi, int c) {
+    for (int j = lo; j < hi; ++j)
+        if (col[j] == c) return j;
+    return -1;
+}
+
+// thread per vertex row of one mesh: element stiffness blocks of the incident triangles
+__global__ void asm_stiffness_kernel(int voff, int V, const int* __restrict__ tri, const int* __restrict__ vtptr,
+                                     const int* __restrict__ vtidx, const double2* __restrict__ vs, const double2* __restrict__ vc,
+                                     const float* __restrict__ mult, double c2, double cnu, double soft, float softf,
+                                     const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ Kval,
+                                     float2* __restrict__ stress) {
+#pragma clang fp contract(off)
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int grow = voff + v;
+    const int lo = rowptr[grow], hi = rowptr[grow + 1];
+    for (int j = lo; j < hi; ++j) reinterpret_cast<double4*>(Kval)[j] = make_double4(0.0, 0.0, 0.0, 0.0);
+    for (int s = vtptr[v]; s < vtptr[v + 1]; ++s) {
+        const int enc = vtidx[s];
+        const int t = enc / 3, a = enc - 3 * t;
+        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        const double2 p0 = vs[i0], p1 = vs[i1], p2 = vs[i2];
+        // e_i = p_{i+1} - p_{i-1}   (material.py:146-148)
+        double ex[3], ey[3];
+        ex[0] = p1.x - p2.x; ey[0] = p1.y - p2.y;
+        ex[1] = p2.x - p0.x; ey[1] = p2.y - p0.y;
+        ex[2] = p0.x - p1.x; ey[2] = p0.y - p1.y;
+        const double area2 = fabs(ex[0] * ey[1] - ey[0] * ex[1]);
+        const double sq = sqrt(area2);
+        for (int k = 0; k < 3; ++k) { ex[k] = ex[k] / sq; ey[k] = ey[k] / sq; }
+        const float m = mult ? mult[t] : 1.0f;
+        // D = diag(m, m, m(1-nu)/2) + nu*m coupling, stored float32 (material.py:174-180)
+        const double d0 = (double)m;
+        const double d2 = (double)(float)((double)m * c2);
+        const double dn = (double)(float)((double)m * cnu);
+        const int idx[3] = {i0, i1, i2};
+        const double exa = ex[a], eya = ey[a];
+        for (int b = 0; b < 3; ++b) {
+            const int j = find_col(col, lo, hi, voff + idx[b]);
+            if (j < 0) continue;
+            const double exb = ex[b], eyb = ey[b];
+            double4 k = reinterpret_cast<double4*>(Kval)[j];
+            k.x += d0 * (eya * eyb) + d2 * (exa * exb);            // (a,x),(b,x)
+            k.y += -(dn * (eya * exb)) - d2 * (exa * eyb);         // (a,x),(b,y)
+            k.z += -(dn * (exa * eyb)) - d2 * (eya * exb);         // (a,y),(b,x)
+            k.w += d0 * (exa * exb) + d2 * (eya * eyb);            // (a,y),(b,y)
+            reinterpret_cast<double4*>(Kval)[j] = k;
+        }
+    }
+    // stress = K (v_cur - v_shape) -> float32 -> * soft   (mesh.py:3068-3072, optimizer.py:822)
+    double sx = 0.0, sy = 0.0;
+    if (vc) {
+        for (int j = lo; j < hi; ++j) {
+            const int c = col[j] - voff;
+            if (c < 0 || c >= V) continue;
+            const double4 k = reinterpret_cast<const double4*>(Kval)[j];
+            const double dxv = vc[c].x - vs[c].x, dyv = vc[c].y - vs[c].y;
+            sx += k.x * dxv + k.y * dyv;
+            sy += k.z * dxv + k.w * dyv;
+        }
+    }
+    stress[grow] = make_float2((float)sx * softf, (float)sy * softf);
+    if (soft != 1.0) {
+        for (int j = lo; j < hi; ++j) {
+            double4 k = reinterpret_cast<double4*>(Kval)[j];
+            k.x *= soft; k.y *= soft; k.z *= soft; k.w *= soft;
+            reinterpret_cast<double4*>(Kval)[j] = k;
+        }
+    }
+}
+
+// thread per free vertex: cross-link contributions of the matches incident to it
+__global__ void asm_links_kernel(int nv, const int* __restrict__ vmptr, const int* __restrict__ vmidx, const int* __restrict__ nodes,
+                                 const double* __restrict__ bary, const float* __restrict__ w, const double2* __restrict__ rxy,
+                                 const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ Cacc,
+                                 float* __restrict__ Cval, double2* __restrict__ rhs) {
+#pragma clang fp contract(off)
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const int lo = rowptr[v], hi = rowptr[v + 1];
+    for (int j = lo; j < hi; ++j) Cacc[j] = 0.0;
+    double rx = 0.0, ry = 0.0;
+    for (int s = vmptr[v]; s < vmptr[v + 1]; ++s) {
+        const int enc = vmidx[s];
+        const int i = enc / 6, a = enc - 6 * i;
+        const float wi = w[i];
+        if (wi == 0.0f) continue;                       // masked-out match: contributes exact zeros
+        const float sa = (float)bary[6 * (size_t)i + a];   // S is float32 (optimizer.py:896)
+        for (int b = 0; b < 6; ++b) {
+            const int nbv = nodes[6 * (size_t)i + b];
+            if (nbv < 0) continue;
+            const float sb = (float)bary[6 * (size_t)i + b];
+            // w * s_a * s_b from the float32 factors, kept in double: the reference rounds the products
+            // and their sum to float32, which leaves its C (and A) indefinite at the 1e-8 level; the
+            // exact rank-one sum is positive semi-definite, which CG needs on systems with a null space.
+            const double prod = ((double)sa * (double)sb) * (double)wi;
+            const int j = find_col(col, lo, hi, nbv);
+            if (j >= 0) Cacc[j] += prod;
+        }
+        const double2 r = rxy[i];
+        rx += (double)sa * ((double)wi * r.x);          // optimizer.py:863-865
+        ry += (double)sa * ((double)wi * r.y);
+    }
+    for (int j = lo; j < hi; ++j) Cval[j] = (float)Cacc[j];
+    rhs[v] = make_double2(rx, ry);
+}
+
+// partial sums for relative_lambda_trace: [0] sum diag C, [1] sum of K diagonal where C diag != 0
+__global__ void lambda_trace_kernel(int nv, const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ Kval,
+                                    const float* __restrict__ Cval, double* __restrict__ parts) {
+    __shared__ double sh0[kT / 64], sh1[kT / 64];
+    double tc = 0.0, tk = 0.0;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x) {
+        const int j = find_col(col, rowptr[v], rowptr[v + 1], v);
+        if (j < 0) continue;
+        const float c = Cval[j];
+        if (c != 0.0f) {
+            const double4 k = reinterpret_cast<const double4*>(Kval)[j];
+            tc += 2.0 * (double)c;
+            tk += k.x + k.w;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { tc += __shfl_down(tc, off); tk += __shfl_down(tk, off); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh0[wave] = tc; sh1[wave] = tk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) { tc += sh0[wv]; tk += sh1[wv]; }
+        parts[2 * blockIdx.x] = tc; parts[2 * blockIdx.x + 1] = tk;
+    }
+}
+
+// A = ls K + lc C (x) I2 ; b = lc rhs - ls stress
+__global__ void form_system_kernel(int nv, int64_t nnzb, const double* __restrict__ Kval, const double* __restrict__ Cval,
+                                   const double2* __restrict__ rhs, const float2* __restrict__ stress, double ls, double lc,
+                                   double* __restrict__ Aval, double2* __restrict__ b) {
+#pragma clang fp contract(off)
+    const float lsf = (float)ls;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnzb; j += (int64_t)gridDim.x * blockDim.x) {
+        const double4 k = reinterpret_cast<const double4*>(Kval)[j];
+        const double c = lc * Cval[j];
+        reinterpret_cast<double4*>(Aval)[j] = make_double4(ls * k.x + c, ls * k.y, ls * k.z, ls * k.w + c);
+    }
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x) {
+        const double2 r = rhs[v];
+        const float2 s = stress[v];
+        b[v] = make_double2(lc * r.x - (double)(lsf * s.x), lc * r.y - (double)(lsf * s.y));
+    }
+}
+
+template <typename T>
+int upload(fb_ctx* ctx, T** dptr, const T* host, size_t count) {
+    if (!*dptr) FB_HIP(ctx, hipMalloc((void**)dptr, std::max<size_t>(16, sizeof(T) * count)));
+    if (host && count) FB_HIP(ctx, hipMemcpyAsync(*dptr, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+    return FB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fb_sys_create(fb_ctx* ctx, int64_t nvert_free, fb_system** out) {
+    FB_CHECK_ARG(ctx, nvert_free > 0 && nvert_free < (1LL << 30) && out);
+    fb_system* s = new fb_system();
+    s->nv = (int)nvert_free;
+    *out = s;
+    return FB_OK;
+}
+
+void fb_sys_destroy(fb_ctx* ctx, fb_system* s) {
+    if (!s) return;
+    hipStreamSynchronize(ctx->stream);
+    for (auto& m : s->meshes) {
+        hipFree(m.d_tri); hipFree(m.d_vtptr); hipFree(m.d_vtidx); hipFree(m.d_mult); hipFree(m.d_vshape); hipFree(m.d_vcur);
+    }
+    hipFree(s->d_nodes); hipFree(s->d_vmptr); hipFree(s->d_vmidx); hipFree(s->d_bary); hipFree(s->d_w); hipFree(s->d_rxy);
+    hipFree(s->d_K); hipFree(s->d_Cacc); hipFree(s->d_C); hipFree(s->d_rhs); hipFree(s->d_stress); hipFree(s->d_parts);
+    if (s->M) fb_bsr_free(ctx, s->M);
+    delete s;
+}
+
+int fb_sys_add_mesh(fb_ctx* ctx, fb_system* s, int64_t voff, const int32_t* tri, int V, int T, int* mesh_id) {
+    FB_CHECK_ARG(ctx, s && !s->finalized && tri && V > 0 && T >= 0 && voff >= 0 && voff + V <= s->nv);
+    for (int i = 0; i < 3 * T; ++i) FB_CHECK_ARG(ctx, tri[i] >= 0 && tri[i] < V);
+    fb_mesh_blk m;
+    m.voff = (int)voff; m.V = V; m.T = T;
+    m.tri.assign(tri, tri + 3 * (size_t)T);
+    s->meshes.push_back(std::move(m));
+    if (mesh_id) *mesh_id = (int)s->meshes.size() - 1;
+    return FB_OK;
+}
+
+int fb_sys_set_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6) {
+    FB_CHECK_ARG(ctx, s && !s->finalized && K >= 0 && (K == 0 || nodes6) && K < (1LL << 31) / 6);
+    for (int64_t i = 0; i < 6 * K; ++i) FB_CHECK_ARG(ctx, nodes6[i] >= -1 && nodes6[i] < s->nv);
+    s->nlink = K;
+    s->nodes.assign(nodes6, nodes6 + 6 * K);
+    return FB_OK;
+}
+
+int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
+    FB_CHECK_ARG(ctx, s && !s->finalized);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    const int nv = s->nv;
+    // ---- symbolic pattern: bucket the (row, col) pairs by row, then sort + unique each short row
+    std::vector<int64_t> cnt((size_t)nv + 1, 0);
+    for (auto& m : s->meshes)
+        for (int t = 0; t < m.T; ++t)
+            for (int a = 0; a < 3; ++a) cnt[(size_t)m.voff + m.tri[3 * (size_t)t + a] + 1] += 3;
+    for (int64_t i = 0; i < s->nlink; ++i) {
+        int live = 0;
+        for (int b = 0; b < 6; ++b) live += s->nodes[6 * i + b] >= 0;
+        for (int a = 0; a < 6; ++a)
+            if (s->nodes[6 * i + a] >= 0) cnt[(size_t)s->nodes[6 * i + a] + 1] += live;
+    }
+    for (int v = 0; v < nv; ++v) cnt[v + 1] += 1;                       // keep the diagonal in every row
+    for (int v = 0; v < nv; ++v) cnt[v + 1] += cnt[v];
+    std::vector<int> raw((size_t)cnt[nv]);
+    std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+    for (int v = 0; v < nv; ++v) raw[fill[v]++] = v;
+    for (auto& m : s->meshes)
+        for (int t = 0; t < m.T; ++t)
+            for (int a = 0; a < 3; ++a) {
+                const int r = m.voff + m.tri[3 * (size_t)t + a];
+                for (int b = 0; b < 3; ++b) raw[fill[r]++] = m.voff + m.tri[3 * (size_t)t + b];
+            }
+    for (int64_t i = 0; i < s->nlink; ++i)
+        for (int a = 0; a < 6; ++a) {
+            const int r = s->nodes[6 * i + a];
+            if (r < 0) continue;
+            for (int b = 0; b < 6; ++b)
+                if (s->nodes[6 * i + b] >= 0) raw[fill[r]++] = s->nodes[6 * i + b];
+        }
+    s->browptr.assign((size_t)nv + 1, 0);
+    s->bcol.clear();
+    s->bcol.reserve(raw.size() / 2);
+    for (int v = 0; v < nv; ++v) {
+        auto b = raw.begin() + cnt[v], e = raw.begin() + cnt[v + 1];
+        std::sort(b, e);
+        e = std::unique(b, e);
+        s->bcol.insert(s->bcol.end(), b, e);
+        if (s->bcol.size() >= (size_t)(1u << 31)) return fb_fail(ctx, FB_ERR_ARG, "pattern exceeds int32 block indexing");
+        s->browptr[v + 1] = (int)s->bcol.size();
+    }
+    const int64_t nnzb = (int64_t)s->bcol.size();
+    // ---- device pattern lives in the solver matrix
+    int rc = fb_bsr_alloc(ctx, nv, nnzb, &s->M);
+    if (rc) return rc;
+    FB_HIP(ctx, hipMemcpyAsync(s->M->d.rowptr, s->browptr.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice, ctx->stream));
+    FB_HIP(ctx, hipMemcpyAsync(s->M->d.col, s->bcol.data(), sizeof(int) * (size_t)nnzb, hipMemcpyHostToDevice, ctx->stream));
+    FB_HIP(ctx, hipMalloc((void**)&s->d_K, sizeof(double) * 4 * (size_t)nnzb));
+    FB_HIP(ctx, hipMalloc((void**)&s->d_Cacc, sizeof(double) * (size_t)nnzb));
+    FB_HIP(ctx, hipMalloc((void**)&s->d_C, sizeof(float) * (size_t)nnzb));
+    FB_HIP(ctx, hipMalloc((void**)&s->d_rhs, sizeof(double2) * (size_t)nv));
+    FB_HIP(ctx, hipMalloc((void**)&s->d_stress, sizeof(float2) * (size_t)nv));
+    FB_HIP(ctx, hipMalloc((void**)&s->d_parts, sizeof(double) * 2 * 1024));
+    FB_HIP(ctx, hipMemsetAsync(s->d_K, 0, sizeof(double) * 4 * (size_t)nnzb, ctx->stream));
+    FB_HIP(ctx, hipMemsetAsync(s->d_C, 0, sizeof(float) * (size_t)nnzb, ctx->stream));
+    FB_HIP(ctx, hipMemsetAsync(s->d_rhs, 0, sizeof(double2) * (size_t)nv, ctx->stream));
+    FB_HIP(ctx, hipMemsetAsync(s->d_stress, 0, sizeof(float2) * (size_t)nv, ctx->stream));
+    // ---- vertex -> incident triangle slots, per mesh
+    for (auto& m : s->meshes) {
+        std::vector<int> ptr((size_t)m.V + 1, 0), idx(3 * (size_t)m.T);
+        for (size_t k = 0; k < 3 * (size_t)m.T; ++k) ptr[(size_t)m.tri[k] + 1]++;
+        for (int v = 0; v < m.V; ++v) ptr[v + 1] += ptr[v];
+        std::vector<int> f(ptr.begin(), ptr.end() - 1);
+        for (int t = 0; t < m.T; ++t)
+            for (int a = 0; a < 3; ++a) idx[f[m.tri[3 * (size_t)t + a]]++] = 3 * t + a;
+        if ((rc = upload(ctx, &m.d_tri, m.tri.data(), m.tri.size()))) return rc;
+        if ((rc = upload(ctx, &m.d_vtptr, ptr.data(), ptr.size()))) return rc;
+        if ((rc = upload(ctx, &m.d_vtidx, idx.data(), idx.size()))) return rc;
+        FB_HIP(ctx, hipMalloc((void**)&m.d_mult, std::max<size_t>(16, sizeof(float) * (size_t)m.T)));
+        FB_HIP(ctx, hipMalloc((void**)&m.d_vshape, sizeof(double2) * (size_t)m.V));
+        FB_HIP(ctx, hipMalloc((void**)&m.d_vcur, sizeof(double2) * (size_t)m.V));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // ptr/idx are locals
+    }
+    // ---- vertex -> incident match slots
+    {
+        std::vector<int> ptr((size_t)nv + 1, 0), idx;
+        for (int64_t k = 0; k < 6 * s->nlink; ++k)
+            if (s->nodes[k] >= 0) ptr[(size_t)s->nodes[k] + 1]++;
+        for (int v = 0; v < nv; ++v) ptr[v + 1] += ptr[v];
+        idx.resize((size_t)ptr[nv]);
+        std::vector<int> f(ptr.begin(), ptr.end() - 1);
+        for (int64_t k = 0; k < 6 * s->nlink; ++k)
+            if (s->nodes[k] >= 0) idx[f[s->nodes[k]]++] = (int)k;
+        if ((rc = upload(ctx, &s->d_vmptr, ptr.data(), ptr.size()))) return rc;
+        if ((rc = upload(ctx, &s->d_vmidx, idx.data(), idx.size()))) return rc;
+        if ((rc = upload(ctx, &s->d_nodes, s->nodes.data(), s->nodes.size()))) return rc;
+        FB_HIP(ctx, hipMalloc((void**)&s->d_bary, std::max<size_t>(16, sizeof(double) * 6 * (size_t)s->nlink)));
+        FB_HIP(ctx, hipMalloc((void**)&s->d_w, std::max<size_t>(16, sizeof(float) * (size_t)s->nlink)));
+        FB_HIP(ctx, hipMalloc((void**)&s->d_rxy, std::max<size_t>(16, sizeof(double2) * (size_t)s->nlink)));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    s->finalized = true;
+    if (nnzb_out) *nnzb_out = nnzb;
+    return FB_OK;
+}
+
+int fb_sys_pattern(fb_ctx* ctx, fb_system* s, int64_t* browptr, int32_t* bcol) {
+    FB_CHECK_ARG(ctx, s && s->finalized);
+    if (browptr) for (size_t i = 0; i < s->browptr.size(); ++i) browptr[i] = s->browptr[i];
+    if (bcol) std::copy(s->bcol.begin(), s->bcol.end(), bcol);
+    return FB_OK;
+}
+
+int fb_sys_assemble_mesh(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur, const float* tri_mult,
+                         double nu, double soft) {
+    FB_CHECK_ARG(ctx, s && s->finalized && mesh_id >= 0 && mesh_id < (int)s->meshes.size() && v_shape);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    fb_mesh_blk& m = s->meshes[mesh_id];
+    FB_HIP(ctx, hipMemcpyAsync(m.d_vshape, v_shape, sizeof(double2) * (size_t)m.V, hipMemcpyHostToDevice, ctx->stream));
+    if (v_cur) FB_HIP(ctx, hipMemcpyAsync(m.d_vcur, v_cur, sizeof(double2) * (size_t)m.V, hipMemcpyHostToDevice, ctx->stream));
+    if (tri_mult) FB_HIP(ctx, hipMemcpyAsync(m.d_mult, tri_mult, sizeof(float) * (size_t)m.T, hipMemcpyHostToDevice, ctx->stream));
+    {
+        FB_PROF(ctx, "fem_asm_stiffness");
+        hipLaunchKernelGGL(asm_stiffness_kernel, dim3(fb_cdiv(m.V, kT)), dim3(kT), 0, ctx->stream, m.voff, m.V, m.d_tri, m.d_vtptr,
+                           m.d_vtidx, m.d_vshape, v_cur ? m.d_vcur : (const double2*)nullptr, tri_mult ? m.d_mult : (const float*)nullptr,
+                           (1.0 - nu) / 2.0, nu, soft, (float)soft, s->M->d.rowptr, s->M->d.col, s->d_K, s->d_stress);
+    }
+    FB_HIP(ctx, hipGetLastError());
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FB_OK;
+}
+
+int fb_sys_assemble_links(fb_ctx* ctx, fb_system* s, const double* bary6, const float* w, const double* rxy) {
+    FB_CHECK_ARG(ctx, s && s->finalized && (s->nlink == 0 || (bary6 && w && rxy)));
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    if (s->nlink) {
+        FB_HIP(ctx, hipMemcpyAsync(s->d_bary, bary6, sizeof(double) * 6 * (size_t)s->nlink, hipMemcpyHostToDevice, ctx->stream));
+        FB_HIP(ctx, hipMemcpyAsync(s->d_w, w, sizeof(float) * (size_t)s->nlink, hipMemcpyHostToDevice, ctx->stream));
+        FB_HIP(ctx, hipMemcpyAsync(s->d_rxy, rxy, sizeof(double2) * (size_t)s->nlink, hipMemcpyHostToDevice, ctx->stream));
+    }
+    {
+        FB_PROF(ctx, "fem_asm_links");
+        hipLaunchKernelGGL(asm_links_kernel, dim3(fb_cdiv(s->nv, kT)), dim3(kT), 0, ctx->stream, s->nv, s->d_vmptr, s->d_vmidx, s->d_nodes,
+                           s->d_bary, s->d_w, s->d_rxy, s->M->d.rowptr, s->M->d.col, s->d_Cacc, s->d_C, s->d_rhs);
+    }
+    FB_HIP(ctx, hipGetLastError());
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FB_OK;
+}
+
+int fb_sys_lambda(fb_ctx* ctx, fb_system* s, double stiffness_lambda, double crosslink_lambda, double* sl_out, double* cl_out) {
+    FB_CHECK_ARG(ctx, s && s->finalized && sl_out && cl_out);
+    double sl = stiffness_lambda, cl = crosslink_lambda;
+    if (sl < 0 || cl < 0) {                                          // optimizer.py:1575-1589
+        const int g = std::min(1024, std::max(1, fb_cdiv(s->nv, kT)));
+        hipLaunchKernelGGL(lambda_trace_kernel, dim3(g), dim3(kT), 0, ctx->stream, s->nv, s->M->d.rowptr, s->M->d.col, s->d_K, s->d_C, s->d_parts);
+        std::vector<double> hp(2 * (size_t)g);
+        FB_HIP(ctx, hipMemcpyAsync(hp.data(), s->d_parts, sizeof(double) * 2 * g, hipMemcpyDeviceToHost, ctx->stream));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double tc = 0.0, tk = 0.0;
+        for (int i = 0; i < g; ++i) { tc += hp[2 * i]; tk += hp[2 * i + 1]; }
+        const double ratio = std::fabs(sl / cl);
+        sl = (tc == 0.0) ? 0.0 : std::fabs(ratio * tc / tk);
+        cl = 1.0;
+    }
+    *sl_out = sl; *cl_out = cl;
+    return FB_OK;
+}
+
+int fb_sys_form(fb_ctx* ctx, fb_system* s, double sl, double cl) {
+    FB_CHECK_ARG(ctx, s && s->finalized);
+    FB_PROF(ctx, "fem_form_system");
+    const int g = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (s->M->nnzb + kT - 1) / kT));
+    hipLaunchKernelGGL(form_system_kernel, dim3(g), dim3(kT), 0, ctx->stream, s->nv, s->M->nnzb, s->d_K, s->d_Cacc, s->d_rhs, s->d_stress, sl, cl,
+                       s->M->d.val, s->M->b);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, double atol, int maxiter, int precond, int* iters,
+                 double* relres) {
+    FB_CHECK_ARG(ctx, s && s->finalized && x);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    if (use_x0) FB_HIP(ctx, hipMemcpyAsync(s->M->x, x, sizeof(double2) * (size_t)s->nv, hipMemcpyHostToDevice, ctx->stream));
+    else FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
+    int rc = fb_bsr_setup_jacobi(ctx, s->M, precond);
+    if (rc) return rc;
+    rc = fb_bsr_pcg_dev(ctx, s->M, rtol, atol, maxiter, 0, iters, relres);
+    if (rc && rc != FB_ERR_NOCONV) return rc;
+    FB_HIP(ctx, hipMemcpyAsync(x, s->M->x, sizeof(double2) * (size_t)s->nv, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+int fb_sys_solve_fixed(fb_ctx* ctx, fb_system* s, int iters, double* relres) {
+    FB_CHECK_ARG(ctx, s && s->finalized && iters > 0);
+    FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
+    int rc = fb_bsr_setup_jacobi(ctx, s->M, 1);
+    if (rc) return rc;
+    int done = 0;
+    return fb_bsr_pcg_dev(ctx, s->M, 0.0, 0.0, 0, iters, &done, relres);
+}
+
+// which: 0 K [nnzb][4] f64, 1 C [nnzb] f32, 2 rhs [2nv] f64, 3 stress [2nv] f32, 4 A [nnzb][4] f64, 5 b [2nv] f64
+int fb_sys_get(fb_ctx* ctx, fb_system* s, int which, void* out) {
+    FB_CHECK_ARG(ctx, s && s->finalized && out && which >= 0 && which <= 5);
+    const size_t nnzb = (size_t)s->M->nnzb, nv = (size_t)s->nv;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+        case 0: src = s->d_K; bytes = sizeof(double) * 4 * nnzb; break;
+        case 1: src = s->d_C; bytes = sizeof(float) * nnzb; break;
+        case 2: src = s->d_rhs; bytes = sizeof(double2) * nv; break;
+        case 3: src = s->d_stress; bytes = sizeof(float2) * nv; break;
+        case 4: src = s->M->d.val; bytes = sizeof(double) * 4 * nnzb; break;
+        default: src = s->M->b; bytes = sizeof(double2) * nv; break;
+    }
+    FB_HIP(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FB_OK;
+}
+
+int fb_sys_info(fb_ctx* ctx, fb_system* s, int64_t* nv, int64_t* nnzb, int64_t* nlink) {
+    FB_CHECK_ARG(ctx, s != nullptr);
+    if (nv) *nv = s->nv;
+    if (nnzb) *nnzb = s->M ? s->M->nnzb : 0;
+    if (nlink) *nlink = s->nlink;
+    return FB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// Device-resident 2x2-block CSR matrix + PCG workspace (internal).
+#pragma once
+#include "fb_common.h"
+
+struct fb_bsr_dev {
+    int nb = 0;          // block rows (= vertices)
+    int* rowptr = nullptr;
+    int* col = nullptr;
+    double* val = nullptr;   // [nnzb][4] row-major 2x2
+};
+
+struct fb_pcg_state {
+    double tol2bb;   // (tol*||b||)^2
+    double rr;
+    int flag;        // 0 running, 1 converged, 2 breakdown
+    int iter;
+};
+
+struct fb_bsr {
+    fb_bsr_dev d;
+    int64_t nnzb = 0;
+    double2 *x = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *Ap = nullptr, *minv = nullptr, *b = nullptr,
+            *diag = nullptr;
+    double* parts = nullptr;
+    fb_pcg_state* state = nullptr;
+    double diag_max = 0.0;
+};
+
+struct fb_csr {
+    int64_t n = 0, nnz = 0;
+    fb_bsr* M = nullptr;
+};
+
+int fb_bsr_alloc(fb_ctx* ctx, int nb, int64_t nnzb, fb_bsr** out);
+int fb_bsr_free(fb_ctx* ctx, fb_bsr* M);
+int fb_bsr_upload(fb_ctx* ctx, int nb, const std::vector<int>& rowptr, const std::vector<int>& col, const std::vector<double>& val,
+                  fb_bsr** out);
+int fb_bsr_spmv_dev(fb_ctx* ctx, fb_bsr* M, const double2* v, double2* y);
+int fb_bsr_setup_jacobi(fb_ctx* ctx, fb_bsr* M, int precond);
+int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter, int fixed_iters, int* iters_out, double* relres_out);
+int fb_csr_to_bsr_host(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* idx, const double* val, int symmetrize,
+                       int* nb_out, std::vector<int>& browptr, std::vector<int>& bcol, std::vector<double>& bval);

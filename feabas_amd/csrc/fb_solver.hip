@@ -1,0 +1,533 @@
+// FEM path, solver: 2x2-block CSR (one block row per mesh vertex, DoF order [x,y]) SpMV with
+// coalesced value/index streams and an LDS row reduction, and a Jacobi-preconditioned CG
+// whose iteration is two kernels with the dot products fused in.
+// Replaces optimizer.solve (feabas/optimizer.py:1945-2080): same fixed point
+// (||Ax-b|| <= max(rtol, atol/||b||) ||b|| on the symmetrised system, reference Jacobi
+// M0 = 1/clip(diag, min(1, max/1000)), optimizer.py:1962-1966), not the reference's
+// restarted-MINRES iteration path (SURVEY.md sec.7 "Hard parts").
+#include "fb_solver.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int kT = 256;          // threads per workgroup == block rows per row-chunk
+constexpr int kCap = 3072;       // LDS capacity in blocks (16 B each = 48 KiB)
+constexpr int kMaxWG1 = 1024;    // SpMV workgroups (each loops over row chunks)
+constexpr int kWG2 = 512;        // vector-update workgroups
+constexpr int kNP = 1024;        // partial-sum slots per array
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    return t;
+}
+
+// every workgroup sums the same partial array in the same order -> identical scalar everywhere
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n, double* sh) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += part[i];
+    return block_sum(v, sh);
+}
+
+// MODE 0: y = A v.   MODE 1 (PCG step A): p_new = z + beta p_old, Ap = A p_new, partial p.Ap
+// MODE 2: r = b - A v  (y := residual), partial r.r into part_out
+template <int MODE>
+__global__ __launch_bounds__(kT) void bsr_spmv_kernel(
+    fb_bsr_dev A, const double2* __restrict__ v, const double2* __restrict__ p_old, double2* __restrict__ p_new,
+    double2* __restrict__ y, const double2* __restrict__ bvec, double* __restrict__ part_out, double* __restrict__ part_pp,
+    const double* __restrict__ part_rz_new, const double* __restrict__ part_rz_old, const double* __restrict__ part_rr,
+    int nparts_in, fb_pcg_state* st, int iter) {
+    __shared__ double2 contrib[kCap];
+    __shared__ double sh[kT / 64];
+    __shared__ int sflag;
+    double beta = 0.0;
+    if (MODE == 1) {
+        if (threadIdx.x == 0) sflag = st->flag;
+        __syncthreads();
+        if (sflag) return;
+        const double rr = sum_partials(part_rr, nparts_in, sh);
+        if (rr <= st->tol2bb) {
+            if (threadIdx.x == 0 && blockIdx.x == 0) { st->flag = 1; st->iter = iter; st->rr = rr; }
+            return;
+        }
+        if (iter > 0) {
+            const double rzn = sum_partials(part_rz_new, nparts_in, sh);
+            const double rzo = sum_partials(part_rz_old, nparts_in, sh);
+            beta = rzn / rzo;
+        }
+    }
+    double acc_dot = 0.0, acc_pp = 0.0;
+    const int nchunks = (A.nb + kT - 1) / kT;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int r0 = chunk * kT;
+        const int r1 = min(A.nb, r0 + kT);
+        const int b0 = A.rowptr[r0], b1 = A.rowptr[r1];
+        const int row = r0 + threadIdx.x;
+        int lo = 0, hi = 0;
+        if (row < r1) { lo = A.rowptr[row]; hi = A.rowptr[row + 1]; }
+        double2 acc = make_double2(0.0, 0.0);
+        for (int c0 = b0; c0 < b1; c0 += kCap) {
+            const int c1 = min(b1, c0 + kCap);
+            for (int j = c0 + threadIdx.x; j < c1; j += kT) {
+                const int col = A.col[j];
+                const double4 a = reinterpret_cast<const double4*>(A.val)[j];   // [a00 a01 a10 a11]
+                double2 pv;
+                if (MODE == 1) {
+                    pv = v[col];                                   // z
+                    if (iter > 0) { const double2 po = p_old[col]; pv.x += beta * po.x; pv.y += beta * po.y; }
+                } else {
+                    pv = v[col];
+                }
+                contrib[j - c0] = make_double2(a.x * pv.x + a.y * pv.y, a.z * pv.x + a.w * pv.y);
+            }
+            __syncthreads();
+            const int jl = max(lo, c0), jh = min(hi, c1);
+            for (int j = jl; j < jh; ++j) { const double2 c = contrib[j - c0]; acc.x += c.x; acc.y += c.y; }
+            __syncthreads();
+        }
+        if (row < r1) {
+            if (MODE == 0) {
+                y[row] = acc;
+            } else if (MODE == 1) {
+                double2 pr = v[row];
+                if (iter > 0) { const double2 po = p_old[row]; pr.x += beta * po.x; pr.y += beta * po.y; }
+                p_new[row] = pr;
+                y[row] = acc;
+                acc_dot += pr.x * acc.x + pr.y * acc.y;
+                acc_pp += pr.x * pr.x + pr.y * pr.y;
+            } else {
+                const double2 bb = bvec[row];
+                const double2 r = make_double2(bb.x - acc.x, bb.y - acc.y);
+                y[row] = r;
+                acc_dot += r.x * r.x + r.y * r.y;
+            }
+        }
+    }
+    if (MODE != 0) {
+        const double t = block_sum(acc_dot, sh);
+        if (threadIdx.x == 0) part_out[blockIdx.x] = t;
+        if (MODE == 1) {
+            const double t2 = block_sum(acc_pp, sh);
+            if (threadIdx.x == 0) part_pp[blockIdx.x] = t2;
+        }
+    }
+}
+
+// PCG step B: alpha = rz/pAp; x += alpha p; r -= alpha Ap; z = minv r; partial r.z, r.r
+__global__ __launch_bounds__(kT) void pcg_update_kernel(
+    int nb, double2* __restrict__ x, double2* __restrict__ r, double2* __restrict__ z, const double2* __restrict__ p,
+    const double2* __restrict__ Ap, const double2* __restrict__ minv, const double* __restrict__ part_pAp,
+    const double* __restrict__ part_pp, double curv_eps, int np_pAp,
+    const double* __restrict__ part_rz_cur, int np_rz, double* __restrict__ part_rz_out, double* __restrict__ part_rr_out,
+    fb_pcg_state* st, int iter) {
+    __shared__ double sh[kT / 64];
+    __shared__ int sflag;
+    if (threadIdx.x == 0) sflag = st->flag;
+    __syncthreads();
+    if (sflag) return;
+    const double pAp = sum_partials(part_pAp, np_pAp, sh);
+    const double rz = sum_partials(part_rz_cur, np_rz, sh);
+    if (!(pAp > 0.0)) {
+        // p^T A p <= 0: rounding noise of a direction inside the null space of a consistent semi-definite
+        // system (flag 3: end the leg, the host re-evaluates the true residual) or genuine negative
+        // curvature (flag 2: the matrix is not positive semi-definite).
+        const double pp = sum_partials(part_pp, np_pAp, sh);
+        if (threadIdx.x == 0 && blockIdx.x == 0) { st->flag = (pAp < -curv_eps * pp) ? 2 : 3; st->iter = iter; }
+        return;
+    }
+    const double alpha = rz / pAp;
+    double s_rz = 0.0, s_rr = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const double2 pi = p[i], api = Ap[i], mi = minv[i];
+        double2 xi = x[i], ri = r[i];
+        xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+        ri.x -= alpha * api.x; ri.y -= alpha * api.y;
+        const double2 zi = make_double2(mi.x * ri.x, mi.y * ri.y);
+        x[i] = xi; r[i] = ri; z[i] = zi;
+        s_rz += ri.x * zi.x + ri.y * zi.y;
+        s_rr += ri.x * ri.x + ri.y * ri.y;
+    }
+    const double t1 = block_sum(s_rz, sh);
+    const double t2 = block_sum(s_rr, sh);
+    if (threadIdx.x == 0) { part_rz_out[blockIdx.x] = t1; part_rr_out[blockIdx.x] = t2; }
+}
+
+// z = minv r, partial r.z and r.r (start of a PCG leg)
+__global__ __launch_bounds__(kT) void pcg_init_kernel(int nb, const double2* __restrict__ r, double2* __restrict__ z,
+                                                       const double2* __restrict__ minv, double* __restrict__ part_rz,
+                                                       double* __restrict__ part_rr) {
+    __shared__ double sh[kT / 64];
+    double s_rz = 0.0, s_rr = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const double2 ri = r[i], mi = minv[i];
+        const double2 zi = make_double2(mi.x * ri.x, mi.y * ri.y);
+        z[i] = zi;
+        s_rz += ri.x * zi.x + ri.y * zi.y;
+        s_rr += ri.x * ri.x + ri.y * ri.y;
+    }
+    const double t1 = block_sum(s_rz, sh);
+    const double t2 = block_sum(s_rr, sh);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = t1; part_rr[blockIdx.x] = t2; }
+}
+
+// diagonal of the block matrix (for Jacobi) + partial max
+__global__ void bsr_diag_kernel(fb_bsr_dev A, double2* __restrict__ diag, double* __restrict__ part_max) {
+    __shared__ double sh[kT / 64];
+    double mx = -INFINITY;
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < A.nb; row += gridDim.x * blockDim.x) {
+        double2 d = make_double2(0.0, 0.0);
+        for (int j = A.rowptr[row]; j < A.rowptr[row + 1]; ++j)
+            if (A.col[j] == row) { const double4 a = reinterpret_cast<const double4*>(A.val)[j]; d.x += a.x; d.y += a.w; }
+        diag[row] = d;
+        mx = fmax(mx, fmax(d.x, d.y));
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmax(mx, sh[w]);
+        part_max[blockIdx.x] = mx;
+    }
+}
+
+__global__ void jacobi_kernel(int nb, const double2* __restrict__ diag, double2* __restrict__ minv, double floor_, int identity) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        if (identity) { minv[i] = make_double2(1.0, 1.0); continue; }
+        const double2 d = diag[i];
+        minv[i] = make_double2(1.0 / fmax(d.x, floor_), 1.0 / fmax(d.y, floor_));
+    }
+}
+
+int grid1(const fb_bsr_dev& A) { return std::max(1, std::min(kMaxWG1, (A.nb + kT - 1) / kT)); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- fb_bsr
+int fb_bsr_free(fb_ctx* ctx, fb_bsr* M) {
+    if (!M) return FB_OK;
+    hipStreamSynchronize(ctx->stream);
+    hipFree(M->d.rowptr); hipFree(M->d.col); hipFree(M->d.val);
+    for (double2* v : {M->x, M->r, M->z, M->p0, M->p1, M->Ap, M->minv, M->b, M->diag}) hipFree(v);
+    hipFree(M->parts); hipFree(M->state);
+    delete M;
+    return FB_OK;
+}
+
+int fb_bsr_alloc(fb_ctx* ctx, int nb, int64_t nnzb, fb_bsr** out) {
+    if (nnzb >= (1LL << 31)) return fb_fail(ctx, FB_ERR_ARG, "block count %lld exceeds int32 indexing", (long long)nnzb);
+    fb_bsr* M = new fb_bsr();
+    M->d.nb = nb;
+    M->nnzb = nnzb;
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
+    A((void**)&M->d.rowptr, sizeof(int) * ((size_t)nb + 1));
+    A((void**)&M->d.col, sizeof(int) * (size_t)nnzb);
+    A((void**)&M->d.val, sizeof(double) * 4 * (size_t)nnzb);
+    for (double2** v : {&M->x, &M->r, &M->z, &M->p0, &M->p1, &M->Ap, &M->minv, &M->b, &M->diag}) A((void**)v, sizeof(double2) * (size_t)nb);
+    A((void**)&M->parts, sizeof(double) * kNP * 8);
+    A((void**)&M->state, sizeof(fb_pcg_state));
+    if (e != hipSuccess) {
+        fb_bsr_free(ctx, M);
+        return fb_fail(ctx, FB_ERR_NOMEM, "fb_bsr_alloc: %s", hipGetErrorString(e));
+    }
+    *out = M;
+    return FB_OK;
+}
+
+int fb_bsr_upload(fb_ctx* ctx, int nb, const std::vector<int>& rowptr, const std::vector<int>& col, const std::vector<double>& val,
+                  fb_bsr** out) {
+    fb_bsr* M = nullptr;
+    int rc = fb_bsr_alloc(ctx, nb, (int64_t)col.size(), &M);
+    if (rc) return rc;
+    FB_HIP(ctx, hipMemcpyAsync(M->d.rowptr, rowptr.data(), sizeof(int) * rowptr.size(), hipMemcpyHostToDevice, ctx->stream));
+    FB_HIP(ctx, hipMemcpyAsync(M->d.col, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice, ctx->stream));
+    FB_HIP(ctx, hipMemcpyAsync(M->d.val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = M;
+    return FB_OK;
+}
+
+// y = A v on device vectors
+int fb_bsr_spmv_dev(fb_ctx* ctx, fb_bsr* M, const double2* v, double2* y) {
+    FB_PROF(ctx, "bsr_spmv");
+    hipLaunchKernelGGL(bsr_spmv_kernel<0>, dim3(grid1(M->d)), dim3(kT), 0, ctx->stream, M->d, v, nullptr, nullptr, y, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+int fb_bsr_setup_jacobi(fb_ctx* ctx, fb_bsr* M, int precond) {
+    const int g = std::min(kNP, std::max(1, (M->d.nb + kT - 1) / kT));
+    hipLaunchKernelGGL(bsr_diag_kernel, dim3(g), dim3(kT), 0, ctx->stream, M->d, M->diag, M->parts);
+    std::vector<double> pm(g);
+    FB_HIP(ctx, hipMemcpyAsync(pm.data(), M->parts, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double mx = -INFINITY;
+    for (double v : pm) mx = std::max(mx, v);
+    M->diag_max = mx;
+    const int identity = (precond == 0) || !(mx > 0.0);       // optimizer.py:1963-1966: M0 = None when max <= 0
+    const double floor_ = std::min(1.0, mx / 1000.0);
+    hipLaunchKernelGGL(jacobi_kernel, dim3(g), dim3(kT), 0, ctx->stream, M->d.nb, M->diag, M->minv, floor_, identity);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+// Solve A x = b for the vectors resident in M (M->b set, M->x = x0).  fixed_iters > 0: run exactly
+// that many iterations with no convergence exit.
+int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter, int fixed_iters, int* iters_out, double* relres_out) {
+    const int nb = M->d.nb;
+    const int g1 = grid1(M->d);
+    const int g2 = std::min(kWG2, std::max(1, (nb + kT - 1) / kT));
+    double* P = M->parts;
+    double* part_pAp = P;                 // [kNP]
+    double* part_rz[2] = {P + kNP, P + 2 * kNP};
+    double* part_rr[2] = {P + 3 * kNP, P + 4 * kNP};
+    double* part_tmp = P + 5 * kNP;
+    double* part_pp = P + 6 * kNP;
+    const double curv_eps = 1e-9 * std::max(M->diag_max, 0.0);
+    // ||b||^2
+    std::vector<double> hp(kNP);
+    auto host_sum = [&](double* dev, int n, double* out) -> int {
+        FB_HIP(ctx, hipMemcpyAsync(hp.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += hp[i];
+        *out = s;
+        return FB_OK;
+    };
+    int rc;
+    // bb via MODE 2 with v = 0?  cheaper: r = b - A x0 gives rr; bb needs its own pass: use init kernel with minv as weights
+    hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->b, M->z, M->minv, part_tmp, part_rr[0]);
+    double bb = 0.0;
+    if ((rc = host_sum(part_rr[0], g2, &bb))) return rc;
+    if (iters_out) *iters_out = 0;
+    if (relres_out) *relres_out = 0.0;
+    if (bb == 0.0 || (maxiter == 0 && fixed_iters <= 0)) {          // maxiter: <0 unlimited, 0 -> zeros, >0 cap          // optimizer.py:1974-1975
+        FB_HIP(ctx, hipMemsetAsync(M->x, 0, sizeof(double2) * nb, ctx->stream));
+        return FB_OK;
+    }
+    const double bnorm = std::sqrt(bb);
+    double tol = rtol;
+    if (atol > 0.0) tol = std::max(tol, atol / bnorm);               // optimizer.py:1993-1996
+    if (fixed_iters > 0) tol = 0.0;
+    const int limit = fixed_iters > 0 ? fixed_iters : (maxiter > 0 ? maxiter : 100 * 1000);
+    int total_iters = 0;
+    double relres = 0.0;
+    const int check_every = 32;
+    for (int leg = 0; leg < 8; ++leg) {
+        // r = b - A x, rr
+        {
+            FB_PROF(ctx, "bsr_spmv_residual");
+            hipLaunchKernelGGL(bsr_spmv_kernel<2>, dim3(g1), dim3(kT), 0, ctx->stream, M->d, M->x, nullptr, nullptr, M->r, M->b,
+                               part_tmp, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0);
+        }
+        double rr = 0.0;
+        if ((rc = host_sum(part_tmp, g1, &rr))) return rc;
+        relres = std::sqrt(rr) / bnorm;
+        if (fixed_iters <= 0 && relres <= tol) break;
+        if (total_iters >= limit) break;
+        // start a leg
+        fb_pcg_state hs;
+        hs.tol2bb = tol * tol * bb;
+        // inside a leg the recurrence residual is compared against a slightly tighter target so that the
+        // true residual re-evaluated at the end of the leg meets `tol`
+        hs.tol2bb *= 0.81;
+        hs.flag = 0; hs.iter = 0; hs.rr = rr;
+        FB_HIP(ctx, hipMemcpyAsync(M->state, &hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->r, M->z, M->minv, part_rz[1], part_rr[1]);
+        int it = 0;
+        bool stop = false;
+        while (!stop) {
+            const int batch = std::min(check_every, limit - total_iters - it);
+            if (batch <= 0) break;
+            for (int k = 0; k < batch; ++k, ++it) {
+                const int cur = it & 1, prev = cur ^ 1;      // K2 of iteration `it` writes slot cur; slot prev holds r_it.z_it
+                double2* p_new = cur ? M->p1 : M->p0;
+                double2* p_old = cur ? M->p0 : M->p1;
+                {
+                    FB_PROF(ctx, "pcg_spmv_fused");
+                    hipLaunchKernelGGL(bsr_spmv_kernel<1>, dim3(g1), dim3(kT), 0, ctx->stream, M->d, M->z, p_old, p_new, M->Ap, nullptr,
+                                       part_pAp, part_pp, part_rz[prev], part_rz[cur], part_rr[prev], g2, M->state, it);
+                }
+                {
+                    FB_PROF(ctx, "pcg_update_fused");
+                    hipLaunchKernelGGL(pcg_update_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->r, M->z, p_new, M->Ap, M->minv,
+                                       part_pAp, part_pp, curv_eps, g1, part_rz[prev], g2, part_rz[cur], part_rr[cur], M->state, it);
+                }
+            }
+            FB_HIP(ctx, hipGetLastError());
+            FB_HIP(ctx, hipMemcpyAsync(&hs, M->state, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+            FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (hs.flag == 1 || hs.flag == 3) { it = hs.iter; stop = true; }
+            else if (hs.flag == 2) {
+                total_iters += hs.iter;
+                if (iters_out) *iters_out = total_iters;
+                return fb_fail(ctx, FB_ERR_BREAKDOWN, "PCG breakdown at iteration %d: p^T A p <= 0 (matrix not positive semi-definite)", total_iters);
+            }
+        }
+        total_iters += it;
+        if (fixed_iters > 0) {
+            // report the true residual after the fixed number of iterations
+            hipLaunchKernelGGL(bsr_spmv_kernel<2>, dim3(g1), dim3(kT), 0, ctx->stream, M->d, M->x, nullptr, nullptr, M->r, M->b,
+                               part_tmp, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0);
+            if ((rc = host_sum(part_tmp, g1, &rr))) return rc;
+            relres = std::sqrt(rr) / bnorm;
+            break;
+        }
+    }
+    if (iters_out) *iters_out = total_iters;
+    if (relres_out) *relres_out = relres;
+    if (fixed_iters <= 0 && relres > tol && maxiter < 0)
+        return fb_fail(ctx, FB_ERR_NOCONV, "PCG stopped at relative residual %.3e > %.3e after %d iterations", relres, tol, total_iters);
+    return FB_OK;
+}
+
+// ---------------------------------------------------------------------------------- scalar CSR -> BSR (host)
+int fb_csr_to_bsr_host(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* idx, const double* val, int symmetrize,
+                       int* nb_out, std::vector<int>& browptr, std::vector<int>& bcol, std::vector<double>& bval) {
+    const int64_t nb = (n + 1) / 2;
+    if (nb >= (1LL << 31)) return fb_fail(ctx, FB_ERR_ARG, "matrix too large");
+    // entries (block row, block col, sub index, value); with symmetrize each entry also contributes its transpose / 2
+    struct Ent { int64_t key; int sub; double v; };
+    const int64_t nnz = indptr[n];
+    std::vector<Ent> ents;
+    ents.reserve((size_t)nnz * (symmetrize ? 2 : 1));
+    for (int64_t r = 0; r < n; ++r) {
+        for (int64_t j = indptr[r]; j < indptr[r + 1]; ++j) {
+            const int64_t c = idx[j];
+            if (c < 0 || c >= n) return fb_fail(ctx, FB_ERR_ARG, "column index %lld out of range", (long long)c);
+            const double v = symmetrize ? 0.5 * val[j] : val[j];
+            ents.push_back({(r / 2) * nb + (c / 2), (int)((r & 1) * 2 + (c & 1)), v});
+            if (symmetrize) ents.push_back({(c / 2) * nb + (r / 2), (int)((c & 1) * 2 + (r & 1)), v});
+        }
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
+    browptr.assign((size_t)nb + 1, 0);
+    bcol.clear(); bval.clear();
+    int64_t last = -1;
+    for (const Ent& e : ents) {
+        if (e.key != last) {
+            last = e.key;
+            bcol.push_back((int)(e.key % nb));
+            bval.insert(bval.end(), 4, 0.0);
+            browptr[(size_t)(e.key / nb) + 1] += 1;
+        }
+        bval[bval.size() - 4 + e.sub] += e.v;
+    }
+    for (int64_t i = 0; i < nb; ++i) browptr[i + 1] += browptr[i];
+    // an odd n leaves a dangling DoF: give it a unit diagonal so that the padded system stays regular
+    if (n & 1) {
+        const int br = (int)(nb - 1);
+        bool found = false;
+        for (int j = browptr[br]; j < browptr[br + 1]; ++j)
+            if (bcol[j] == br) { bval[(size_t)j * 4 + 3] += 1.0; found = true; }
+        if (!found) return fb_fail(ctx, FB_ERR_ARG, "odd-sized matrix without a diagonal block in its last row is not supported");
+    }
+    *nb_out = (int)nb;
+    return FB_OK;
+}
+
+extern "C" {
+
+int fb_csr_upload(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* idx, const double* val, int symmetrize, fb_csr** out) {
+    FB_CHECK_ARG(ctx, n > 0 && indptr && idx && val && out);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int> browptr, bcol;
+    std::vector<double> bval;
+    int nb = 0;
+    int rc = fb_csr_to_bsr_host(ctx, n, indptr, idx, val, symmetrize, &nb, browptr, bcol, bval);
+    if (rc) return rc;
+    fb_bsr* M = nullptr;
+    rc = fb_bsr_upload(ctx, nb, browptr, bcol, bval, &M);
+    if (rc) return rc;
+    fb_csr* A = new fb_csr();
+    A->n = n;
+    A->nnz = indptr[n];
+    A->M = M;
+    *out = A;
+    return FB_OK;
+}
+
+void fb_csr_destroy(fb_ctx* ctx, fb_csr* A) {
+    if (!A) return;
+    fb_bsr_free(ctx, A->M);
+    delete A;
+}
+
+int fb_csr_info(fb_ctx* ctx, fb_csr* A, int64_t* n, int64_t* nnz, int64_t* nb, int64_t* nnzb) {
+    FB_CHECK_ARG(ctx, A != nullptr);
+    if (n) *n = A->n;
+    if (nnz) *nnz = A->nnz;
+    if (nb) *nb = A->M->d.nb;
+    if (nnzb) *nnzb = A->M->nnzb;
+    return FB_OK;
+}
+
+static int upload_vec(fb_ctx* ctx, fb_csr* A, double2* dst, const double* src) {
+    const size_t nbytes = sizeof(double) * (size_t)A->n;
+    FB_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(double2) * (size_t)A->M->d.nb, ctx->stream));
+    if (src) FB_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    return FB_OK;
+}
+
+int fb_spmv(fb_ctx* ctx, fb_csr* A, const double* x_host, double* y_host) {
+    FB_CHECK_ARG(ctx, A && x_host && y_host);
+    int rc = upload_vec(ctx, A, A->M->x, x_host);
+    if (rc) return rc;
+    rc = fb_bsr_spmv_dev(ctx, A->M, A->M->x, A->M->Ap);
+    if (rc) return rc;
+    FB_HIP(ctx, hipMemcpyAsync(y_host, A->M->Ap, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FB_OK;
+}
+
+int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, double rtol, double atol, int maxiter, int precond,
+               int* iters, double* relres) {
+    FB_CHECK_ARG(ctx, A && b && x);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = upload_vec(ctx, A, A->M->b, b);
+    if (rc) return rc;
+    rc = upload_vec(ctx, A, A->M->x, use_x0 ? x : nullptr);
+    if (rc) return rc;
+    rc = fb_bsr_setup_jacobi(ctx, A->M, precond);
+    if (rc) return rc;
+    rc = fb_bsr_pcg_dev(ctx, A->M, rtol, atol, maxiter, 0, iters, relres);
+    if (rc && rc != FB_ERR_NOCONV) return rc;
+    FB_HIP(ctx, hipMemcpyAsync(x, A->M->x, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+int fb_pcg_fixed_iters(fb_ctx* ctx, fb_csr* A, const double* b_host, int iters, double* relres) {
+    FB_CHECK_ARG(ctx, A && iters > 0);
+    int rc;
+    if (b_host) {
+        rc = upload_vec(ctx, A, A->M->b, b_host);
+        if (rc) return rc;
+        rc = fb_bsr_setup_jacobi(ctx, A->M, 1);
+        if (rc) return rc;
+    }
+    FB_HIP(ctx, hipMemsetAsync(A->M->x, 0, sizeof(double2) * (size_t)A->M->d.nb, ctx->stream));
+    int done = 0;
+    return fb_bsr_pcg_dev(ctx, A->M, 0.0, 0.0, 0, iters, &done, relres);
+}
+
+int fb_pcg(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* idx, const double* val, const double* b, double* x,
+           int use_x0, double rtol, double atol, int maxiter, int precond, int symmetrize, int* iters, double* relres) {
+    fb_csr* A = nullptr;
+    int rc = fb_csr_upload(ctx, n, indptr, idx, val, symmetrize, &A);
+    if (rc) return rc;
+    rc = fb_pcg_csr(ctx, A, b, x, use_x0, rtol, atol, maxiter, precond, iters, relres);
+    fb_csr_destroy(ctx, A);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""Host mirror of feabas.matcher for the NCC path.
+
+``xcorr_fft`` runs on the GPU (fb_ncc_batch); ``global_translation_matcher``
+and the block distributor keep the reference's host-side control flow and call
+the GPU kernels for the arithmetic.
+"""
+import numpy as np
+
+from . import _lib, common
+from . import constant as const
+
+
+def next_fast_len(n):
+    """scipy.fftpack.next_fast_len (feabas/matcher.py:6,59-62)."""
+    return int(_lib.load().fb_next_fast_len(int(n)))
+
+
+def xcorr_fft(img0, img1, conf_mode=const.FFT_CONF_MIRROR, **kwargs):
+    """feabas/matcher.py:22-135.
+
+    img0: N x H0 x W0 (x C), img1: N x H1 x W1 (x C).  Returns dx, dy (float64)
+    and conf so that centre(img1) + (dx, dy) corresponds to centre(img0).
+    kwargs: sigma, mask0, mask1 (DoG pre-filter, matcher.py:54-56), subpixel,
+    pad.  ``normalize=True`` is not used by any reference call site and is
+    rejected.
+    """
+    sigma = kwargs.get('sigma', 0)
+    mask0 = kwargs.get('mask0', None)
+    mask1 = kwargs.get('mask1', None)
+    if kwargs.get('normalize', False):
+        raise NotImplementedError('xcorr_fft(normalize=True) is outside the hot path (no reference call site uses it)')
+    subpixel = kwargs.get('subpixel', False)
+    pad = kwargs.get('pad', True)
+    img0 = np.asarray(img0)
+    img1 = np.asarray(img1)
+    if img0.ndim > 3:
+        img0 = np.moveaxis(img0, -1, 1)
+    if img1.ndim > 3:
+        img1 = np.moveaxis(img1, -1, 1)
+    if sigma > 0:
+        img0 = common.masked_dog_filter(img0, sigma, mask=mask0)
+        img1 = common.masked_dog_filter(img1, sigma, mask=mask1)
+    a = np.ascontiguousarray(img0, dtype=np.float32)
+    b = np.ascontiguousarray(img1, dtype=np.float32)
+    n = a.shape[0]
+    ch = a.shape[1] if a.ndim > 3 else 1
+    if b.shape[0] != n or (b.shape[1] if b.ndim > 3 else 1) != ch:
+        raise ValueError('img0 and img1 must agree in batch and channel counts')
+    h0, w0 = a.shape[-2:]
+    h1, w1 = b.shape[-2:]
+    dx = np.empty(n, dtype=np.float64)
+    dy = np.empty(n, dtype=np.float64)
+    conf = np.empty(n, dtype=np.float32)
+    if n > 0:
+        _lib.check(_lib.load().fb_ncc_batch(_lib.ctx(), _lib.ptr(a), _lib.ptr(b), n, ch, h0, w0, h1, w1,
+                                            1 if pad else 0, 1 if subpixel else 0, int(conf_mode),
+                                            _lib.ptr(dx), _lib.ptr(dy), _lib.ptr(conf)))
+    return dx, dy, conf
+
+
+def _best_divide(shape, divide_factor):
+    """grid (rows, cols) of ~divide_factor blocks with the most moderate aspect
+    ratio (feabas/matcher.py:162-177)."""
+    if hasattr(divide_factor, '__len__'):
+        return tuple(divide_factor[:2])
+    aspect = shape[0] / shape[1]
+    best = np.inf
+    grid = None
+    for f in range(1, int(divide_factor ** 0.5) + 1):
+        if divide_factor % f != 0:
+            continue
+        q = f ** 2 / divide_factor
+        for cand, val in (((int(divide_factor / f), int(f)), abs(np.log(aspect * q))),
+                          ((int(f), int(divide_factor / f)), abs(np.log(aspect / q)))):
+            if val < best:
+                best, grid = val, cand
+    return grid
+
+
+def _fit_span(lo, hi, full, limit):
+    """grow [lo, hi) to `full` pixels and slide it inside [0, limit) (matcher.py:189-194)."""
+    grow = int(np.ceil((full - (hi - lo)) / 2))
+    span = np.array((lo - grow, hi + grow))
+    return (span - min(span[0], 0) - max(span[1] - limit, 0)).clip(0, limit)
+
+
+def global_translation_matcher(img0, img1, **kwargs):
+    """feabas/matcher.py:138-221: whole-image translation, with a second shot on
+    ~divide_factor sub-blocks when the confidence is low."""
+    sigma = kwargs.get('sigma', 0.0)
+    conf_mode = kwargs.get('conf_mode', const.FFT_CONF_MIRROR)
+    conf_thresh = kwargs.get('conf_thresh', 0.3)
+    divide_factor = kwargs.get('divide_factor', 6)
+    if sigma > 0:
+        img0 = common.masked_dog_filter(img0, sigma, mask=kwargs.get('mask0', None))
+        img1 = common.masked_dog_filter(img1, sigma, mask=kwargs.get('mask1', None))
+    ht0, wd0 = img0.shape[-2:]
+    ht1, wd1 = img1.shape[-2:]
+    tx, ty, conf = xcorr_fft(img0[None], img1[None], conf_mode=conf_mode, pad=True)
+    tx, ty, conf = tx.item(), ty.item(), conf.item()
+    tx += (wd1 - wd0) / 2
+    ty += (ht1 - ht0) / 2
+    if conf > conf_thresh:
+        return tx, ty, conf
+    grid = _best_divide(np.minimum((ht0, wd0), (ht1, wd1)), divide_factor)
+    xa0, ya0, xb0, yb0 = common.divide_bbox((0, 0, wd0, ht0), min_num_blocks=grid)
+    xa1, ya1, xb1, yb1 = common.divide_bbox((0, 0, wd1, ht1), min_num_blocks=grid)
+    blocks0, blocks1, off_x, off_y = [], [], [], []
+    for k in range(xa0.size):
+        bw = max(xb0[k] - xa0[k], xb1[k] - xa1[k])
+        bh = max(yb0[k] - ya0[k], yb1[k] - ya1[k])
+        ys0 = _fit_span(ya0[k], yb0[k], bh, ht0)
+        xs0 = _fit_span(xa0[k], xb0[k], bw, wd0)
+        blk0 = img0[ys0[0]:ys0[1], xs0[0]:xs0[1]]
+        if np.ptp(blk0) == 0:
+            continue
+        ys1 = _fit_span(ya1[k], yb1[k], bh, ht1)
+        xs1 = _fit_span(xa1[k], xb1[k], bw, wd1)
+        blk1 = img1[ys1[0]:ys1[1], xs1[0]:xs1[1]]
+        if np.ptp(blk1) == 0:
+            continue
+        blocks0.append(blk0)
+        blocks1.append(blk1)
+        off_x.append((np.ptp(xs1) - np.ptp(xs0)) / 2 + xs1[0] - xs0[0])
+        off_y.append((np.ptp(ys1) - np.ptp(ys0)) / 2 + ys1[0] - ys0[0])
+    if not blocks0:
+        return tx, ty, conf
+    btx, bty, bconf = xcorr_fft(np.stack(blocks0, axis=0), np.stack(blocks1, axis=0), conf_mode=conf_mode, pad=True)
+    btx = btx + np.array(off_x)
+    bty = bty + np.array(off_y)
+    k_best = int(np.argmax(bconf))
+    if bconf[k_best] >= conf:
+        tx, ty, conf = btx[k_best], bty[k_best], bconf[k_best]
+    return tx, ty, conf
+
+
+def distributor_cartesian_bbox(mesh0, mesh1, spacing, **kwargs):
+    """feabas/matcher.py:865-891: z-ordered block grid over the intersection of
+    the two mesh bounding boxes.  mesh0/mesh1 need a ``bbox(gear=)`` method."""
+    gear = kwargs.get('gear', const.MESH_GEAR_MOVING)
+    min_num_blocks = kwargs.get('min_num_blocks', 1)
+    shrink_factor = kwargs.get('shrink_factor', 1)
+    zorder = kwargs.get('zorder', False)
+    if not hasattr(shrink_factor, '__len__'):
+        shrink_factor = (shrink_factor, shrink_factor)
+    bbox, valid = common.intersect_bbox(mesh0.bbox(gear=gear), mesh1.bbox(gear=gear))
+    if not valid:
+        return None, None
+    bb0 = np.stack(common.divide_bbox(bbox, block_size=spacing, min_num_blocks=min_num_blocks,
+                                      shrink_factor=shrink_factor[0]), axis=-1)
+    bb1 = np.stack(common.divide_bbox(bbox, block_size=spacing, min_num_blocks=min_num_blocks,
+                                      shrink_factor=shrink_factor[1]), axis=-1)
+    if zorder:
+        col = np.round((bb0[:, 0] - bb0[:, 0].min()) / spacing)
+        row = np.round((bb0[:, 1] - bb0[:, 1].min()) / spacing)
+        order = common.z_order(np.stack((col, row), axis=-1))
+        bb0, bb1 = bb0[order], bb1[order]
+    return bb0, bb1
+
+
+def block_displacements_to_points(bboxes0, bboxes1, dx, dy):
+    """feabas/matcher.py:840-849: block displacement -> a pair of matched points."""
+    ctr0 = common.bbox_centers(bboxes0)
+    ctr1 = common.bbox_centers(bboxes1)
+    sz0 = common.bbox_sizes(bboxes0).astype(np.float64)
+    sz1 = common.bbox_sizes(bboxes1).astype(np.float64)
+    ratio = (sz0 / (sz0 + sz1))[:, ::-1]
+    dxy = np.stack((dx, dy), axis=-1)
+    return ctr0 - dxy * ratio, ctr1 + dxy * (1 - ratio)
+
+
+def auto_spacings(shape0, shape1):
+    """feabas/matcher.py:243-251."""
+    shp = np.minimum(shape0, shape1)
+    s_max = max(shp) * 0.25
+    s_min = max(min(75, min(shp) / 3), 25)
+    if s_min > s_max:
+        return np.array([s_min])
+    count = max(1, round(np.log(s_max / s_min) / np.log(4)))
+    return np.exp(np.linspace(np.log(s_min), np.log(s_max), num=count, endpoint=True))

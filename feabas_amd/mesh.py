@@ -1,0 +1,269 @@
+"""Host mirror of the part of feabas.mesh.Mesh that sits on the FEM path.
+
+Vertex state (four "gears" + offsets, feabas/mesh.py:233-293, 1221-1325),
+point location helpers (2191-2228), field application (2381-2458) are small
+host bookkeeping; ``stiffness_matrix`` (2893-3083) is assembled on the GPU.
+Meshing itself (``triangle``, shapely) is out of scope: (vertices, triangles)
+are inputs.
+"""
+import ctypes as C
+
+import numpy as np
+from scipy import sparse
+
+from . import _lib, common
+from . import constant as const
+
+
+class Mesh:
+    uid_counter = 0.0
+
+    def __init__(self, vertices, triangles, **kwargs):
+        vertices = np.asarray(vertices, dtype=np.float64).reshape(-1, 2)
+        self.triangles = np.ascontiguousarray(np.asarray(triangles).reshape(-1, 3), dtype=np.int32)
+        self._vertices = {const.MESH_GEAR_INITIAL: vertices,
+                          const.MESH_GEAR_FIXED: kwargs.get('fixed_vertices', vertices),
+                          const.MESH_GEAR_MOVING: kwargs.get('moving_vertices', None),
+                          const.MESH_GEAR_STAGING: kwargs.get('staging_vertices', None)}
+        zero = np.zeros((1, 2), dtype=np.float64)
+        self._offsets = {const.MESH_GEAR_INITIAL: kwargs.get('initial_offset', zero)}
+        if ('fixed_vertices' not in kwargs) and ('fixed_offset' not in kwargs):       # mesh.py:241-244
+            self._offsets[const.MESH_GEAR_FIXED] = kwargs.get('initial_offset', zero)
+        else:
+            self._offsets[const.MESH_GEAR_FIXED] = kwargs.get('fixed_offset', zero)
+        self._offsets[const.MESH_GEAR_MOVING] = kwargs.get('moving_offset', zero)
+        self._offsets[const.MESH_GEAR_STAGING] = kwargs.get('staging_offset', zero)
+        self._current_gear = const.MESH_GEAR_FIXED
+        mult = kwargs.get('stiffness_multiplier', None)
+        self._stiffness_multiplier = None if mult is None else np.ascontiguousarray(mult, dtype=np.float32)
+        # one linear engineering material per mesh (the default material table)
+        self.poisson_ratio = float(kwargs.get('poisson_ratio', 0.0))
+        self.material_multiplier = float(kwargs.get('material_multiplier', 1.0))
+        self.resolution = kwargs.get('resolution', 4.0)
+        self.locked = kwargs.get('locked', False)
+        self.soft_factor = kwargs.get('soft_factor', 1.0)
+        uid = kwargs.get('uid', None)
+        if uid is None:
+            self.uid = float(Mesh.uid_counter)
+            Mesh.uid_counter += 1
+        else:
+            self.uid = float(uid)
+            Mesh.uid_counter = float(max(Mesh.uid_counter, uid) + 1)
+        self._trifinders = {}
+
+    # ------------------------------------------------------------------ state
+    @property
+    def num_vertices(self):
+        return self._vertices[const.MESH_GEAR_INITIAL].shape[0]
+
+    @property
+    def num_triangles(self):
+        return self.triangles.shape[0]
+
+    @property
+    def is_linear(self):
+        return True
+
+    @property
+    def stiffness_multiplier(self):
+        if self._stiffness_multiplier is None:
+            return np.ones(self.num_triangles, dtype=np.float32)
+        return self._stiffness_multiplier
+
+    def vertices(self, gear=None):
+        gear = self._current_gear if gear is None else gear
+        v = self._vertices[gear]
+        if v is None:
+            if gear == const.MESH_GEAR_MOVING:
+                return self._vertices[const.MESH_GEAR_FIXED]
+            if gear == const.MESH_GEAR_STAGING:
+                return self.vertices(const.MESH_GEAR_MOVING)
+        return v
+
+    def offset(self, gear=None):
+        gear = self._current_gear if gear is None else gear
+        if self._vertices[gear] is None:
+            if gear == const.MESH_GEAR_MOVING:
+                return self._offsets[const.MESH_GEAR_FIXED]
+            return self.offset(const.MESH_GEAR_MOVING)
+        return self._offsets[gear]
+
+    def vertices_w_offset(self, gear=None):
+        return self.vertices(gear) + self.offset(gear)
+
+    def bbox(self, gear=const.MESH_GEAR_MOVING, offsetting=True):
+        v = self.vertices_w_offset(gear) if offsetting else self.vertices(gear)
+        lo, hi = v.min(axis=0), v.max(axis=0)
+        return np.array((lo[0], lo[1], hi[0], hi[1]))
+
+    def lock(self):
+        self.locked = True
+
+    def unlock(self):
+        self.locked = False
+
+    def copy(self, **override):
+        kw = dict(fixed_vertices=self._vertices[const.MESH_GEAR_FIXED],
+                  moving_vertices=self._vertices[const.MESH_GEAR_MOVING],
+                  staging_vertices=self._vertices[const.MESH_GEAR_STAGING],
+                  initial_offset=self._offsets[const.MESH_GEAR_INITIAL],
+                  fixed_offset=self._offsets[const.MESH_GEAR_FIXED],
+                  moving_offset=self._offsets[const.MESH_GEAR_MOVING],
+                  staging_offset=self._offsets[const.MESH_GEAR_STAGING],
+                  stiffness_multiplier=self._stiffness_multiplier, poisson_ratio=self.poisson_ratio,
+                  material_multiplier=self.material_multiplier, resolution=self.resolution,
+                  locked=self.locked, soft_factor=self.soft_factor, uid=self.uid)
+        kw.update(override)
+        return Mesh(self._vertices[const.MESH_GEAR_INITIAL], self.triangles, **kw)
+
+    # ------------------------------------------------------------------ transformations
+    def _changed(self, gear):
+        self._trifinders.pop(gear, None)
+
+    def set_vertices(self, v, gear):                       # mesh.py:2232-2242 (unmasked)
+        if self.locked:
+            return
+        if self._vertices[gear] is None:
+            self.set_offset(self.offset(gear), gear)
+        self._vertices[gear] = v
+        self._changed(gear)
+
+    def set_offset(self, offset, gear):
+        if self.locked:
+            return
+        self._offsets[gear] = offset
+
+    def apply_translation(self, dxy, gear):                # mesh.py:2272-2286 (unmasked)
+        dxy = np.asarray(dxy, dtype=np.float64).reshape(1, 2)
+        if self.locked or not np.any(dxy):
+            return
+        v = self.vertices(gear)
+        off = self.offset(gear)
+        self._vertices[gear] = v
+        self.set_offset(off + dxy, gear)
+
+    def apply_field(self, dxy, gear):                      # mesh.py:2381-2397 (unmasked)
+        if self.locked or not np.any(dxy):
+            return
+        v0 = self.vertices(gear)
+        off0 = self.offset(gear)
+        m = np.mean(dxy.reshape(-1, 2), axis=0, keepdims=True)
+        self.set_vertices(v0 + (dxy - m), gear)
+        self.set_offset(off0 + m, gear)
+
+    def set_field(self, dxy, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)):   # mesh.py:2400-2413 (unmasked)
+        if self.locked:
+            return
+        if gear[0] == gear[-1]:
+            self.apply_field(dxy, gear[0])
+            return
+        v0 = self.vertices(gear[0])
+        off0 = self.offset(gear[0])
+        m = np.mean(dxy.reshape(-1, 2), axis=0, keepdims=True)
+        self.set_vertices(v0 + (dxy - m), gear[-1])
+        self.set_offset(off0 + m, gear[-1])
+
+    def anneal(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT):
+        if self.locked:
+            return
+        if mode != const.ANNEAL_COPY_EXACT:                # mesh.py:2452-2456; rigid/affine annealing is host geometry (out of scope)
+            raise NotImplementedError('only ANNEAL_COPY_EXACT is on the hot path')
+        off0 = self.offset(gear[0])
+        v0 = self.vertices(gear[0])
+        self.set_vertices(v0, gear[1])
+        self.set_offset(off0, gear[1])
+
+    # ------------------------------------------------------------------ geometry
+    def triangle_areas(self, gear=const.MESH_GEAR_INITIAL):   # mesh.py:1753-1758
+        return common.signed_area(self.vertices(gear), self.triangles)
+
+    def tri_finder(self, pts, gear=None):
+        """point -> triangle id (-1 outside).  The reference goes through
+        matplotlib's trapezoid-map finder per connected region (mesh.py:2080-2188);
+        a single finder over the whole mesh covers the non-overlapping meshes used here."""
+        from matplotlib.tri import Triangulation
+        gear = self._current_gear if gear is None else gear
+        if gear not in self._trifinders:
+            v = self.vertices(gear)
+            self._trifinders[gear] = Triangulation(v[:, 0], v[:, 1], self.triangles).get_trifinder()
+        p = (np.asarray(pts, dtype=np.float64) - self.offset(gear)).reshape(-1, 2)
+        return np.asarray(self._trifinders[gear](p[:, 0], p[:, 1]), dtype=np.int32)
+
+    def cart2bary(self, xy, gear, tid=None, **kwargs):     # mesh.py:2191-2217
+        xy = np.atleast_2d(xy)
+        if tid is None:
+            tid = self.tri_finder(xy, gear=gear)
+        inside = tid >= 0
+        if not np.any(inside):
+            return tid, np.full((tid.size, 3), np.nan, dtype=np.float32)
+        q = xy[inside, :] - self.offset(gear)
+        p = self.vertices(gear)[np.atleast_2d(self.triangles[tid[inside], :])]
+        d0, d1, d2 = q - p[:, 0, :], q - p[:, 1, :], q - p[:, 2, :]
+        a0, a1, a2 = common.cross2d(d1, d2), common.cross2d(d2, d0), common.cross2d(d0, d1)
+        tot = a0 + a1 + a2
+        bary = np.stack((a0 / tot, a1 / tot, a2 / tot), axis=-1)
+        if np.all(inside):
+            return tid, bary
+        full = np.full((tid.size, 3), np.nan, dtype=bary.dtype)
+        full[inside, :] = bary
+        return tid, full
+
+    def bary2cart(self, tid, B, gear, offsetting=True):    # mesh.py:2220-2228
+        idx = np.atleast_2d(self.triangles[tid, :])
+        v = self.vertices_w_offset(gear) if offsetting else self.vertices(gear)
+        return np.sum(v[idx] * np.asarray(B).reshape(-1, 3, 1), axis=-2)
+
+    # ------------------------------------------------------------------ stiffness (GPU)
+    def element_multiplier(self):
+        """per-triangle float32 multiplier: mesh multiplier x material multiplier (material.py:168-171)."""
+        m = np.full(self.num_triangles, self.material_multiplier, dtype=np.float32)
+        if self._stiffness_multiplier is not None:
+            m = self._stiffness_multiplier * m
+        return np.ascontiguousarray(m, dtype=np.float32)
+
+    def stiffness_matrix(self, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), **kwargs):
+        """feabas/mesh.py:3058-3083 -> (scipy CSR 2V x 2V float64, stress float32),
+        assembled by the HIP kernel on a one-mesh system."""
+        lib = _lib.load()
+        ctx = _lib.ctx()
+        sysh = C.c_void_p()
+        _lib.check(lib.fb_sys_create(ctx, self.num_vertices, C.byref(sysh)))
+        try:
+            mid = C.c_int()
+            _lib.check(lib.fb_sys_add_mesh(ctx, sysh, 0, _lib.ptr(self.triangles), self.num_vertices,
+                                           self.num_triangles, C.byref(mid)))
+            _lib.check(lib.fb_sys_set_links(ctx, sysh, 0, None))
+            nnzb = C.c_int64()
+            _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
+            v0 = np.ascontiguousarray(self.vertices(gear[0]), dtype=np.float64)
+            v1 = self.vertices(gear[-1])
+            v1c = None if v1 is v0 or v1 is self.vertices(gear[0]) else np.ascontiguousarray(v1, dtype=np.float64)
+            _lib.check(lib.fb_sys_assemble_mesh(ctx, sysh, mid.value, _lib.ptr(v0), _lib.ptr(v1c),
+                                                _lib.ptr(self.element_multiplier()), self.poisson_ratio, 1.0))
+            K = bsr_download(sysh, 0, self.num_vertices, nnzb.value)
+            stress = np.empty(2 * self.num_vertices, dtype=np.float32)
+            _lib.check(lib.fb_sys_get(ctx, sysh, 3, _lib.ptr(stress)))
+        finally:
+            lib.fb_sys_destroy(ctx, sysh)
+        return K, stress
+
+
+def bsr_download(sysh, which, nv, nnzb):
+    """pattern + 2x2 block values of a system matrix -> scipy CSR (2nv x 2nv)."""
+    lib = _lib.load()
+    ctx = _lib.ctx()
+    rowptr = np.empty(nv + 1, dtype=np.int64)
+    col = np.empty(nnzb, dtype=np.int32)
+    _lib.check(lib.fb_sys_pattern(ctx, sysh, _lib.ptr(rowptr), _lib.ptr(col)))
+    if which == 1:
+        c = np.empty(nnzb, dtype=np.float32)
+        _lib.check(lib.fb_sys_get(ctx, sysh, 1, _lib.ptr(c)))
+        val = np.zeros((nnzb, 2, 2), dtype=np.float32)
+        val[:, 0, 0] = c
+        val[:, 1, 1] = c
+    else:
+        val = np.empty((nnzb, 2, 2), dtype=np.float64)
+        _lib.check(lib.fb_sys_get(ctx, sysh, which, _lib.ptr(val)))
+    M = sparse.bsr_matrix((val, col, rowptr), shape=(2 * nv, 2 * nv)).tocsr()
+    M.eliminate_zeros()
+    return M

@@ -1,0 +1,433 @@
+"""Host mirror of feabas.optimizer for the FEM path: ``Link``, ``SLM`` and
+``solve`` keep the reference's call surface; assembly and the iterative solve
+run on the GPU through the fb_sys_* / fb_pcg entry points.
+
+What is deliberately different from the reference: the solver iterates
+Jacobi-PCG to the reference's stopping rule (true residual <= tol*||b||)
+instead of restarted MINRES, and none of the reference's wall-clock /
+random-perturbation early exits (optimizer.py:1955-1961, 2056-2063) exist, so
+results are deterministic.
+"""
+import ctypes as C
+
+import numpy as np
+from scipy import sparse
+
+from . import _lib
+from . import constant as const
+from .mesh import Mesh, bsr_download
+
+
+class Link:
+    """feabas/optimizer.py:17-435 (the part used on the hot path): matched
+    points stored as (triangle id, barycentric) on two meshes."""
+
+    def __init__(self, mesh0, mesh1, tid0, tid1, B0, B1, weight=None, **kwargs):
+        self.strain = kwargs.get('strain', const.DEFAULT_AVG_DEFORM)
+        self.meshes = [mesh0, mesh1]
+        self.uids = [mesh0.uid, mesh1.uid]
+        self.name = kwargs.get('name', '_'.join(str(s) for s in self.uids))
+        self._tid0 = np.asarray(tid0)
+        self._tid1 = np.asarray(tid1)
+        self._B0 = np.asarray(B0, dtype=np.float64)
+        self._B1 = np.asarray(B1, dtype=np.float64)
+        se = kwargs.get('sample_err', None)
+        if se is None:                                      # optimizer.py:26-30
+            a0 = mesh0.triangle_areas(gear=const.MESH_GEAR_INITIAL)[self._tid0]
+            a1 = mesh1.triangle_areas(gear=const.MESH_GEAR_INITIAL)[self._tid1]
+            se = 0.4387 * (np.minimum(a0, a1)) ** 0.5 * self.strain
+        self._sample_err = se
+        self._weight = ((self._tid0 >= 0) & (self._tid1 >= 0)).astype(np.float32)
+        if weight is not None:
+            self._weight = self._weight * weight
+        self._residue_weight = np.ones_like(self._weight)
+        self._weight_func = None
+        self._mask = None
+        self._disabled = False
+
+    @classmethod
+    def from_coordinates(cls, mesh0, mesh1, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL),
+                         weight=None, **kwargs):
+        """optimizer.py:53-82."""
+        xy0 = np.asarray(xy0)
+        xy1 = np.asarray(xy1)
+        if xy0.size == 0:
+            return None, None
+        tid0, B0 = mesh0.cart2bary(xy0, gear[0], tid=None)
+        in0 = tid0 >= 0
+        if not np.any(in0):
+            return None, None
+        if not np.all(in0):
+            tid0, B0, xy1 = tid0[in0], B0[in0], xy1[in0]
+            if isinstance(weight, np.ndarray):
+                weight = weight[in0]
+        tid1, B1 = mesh1.cart2bary(xy1, gear[1], tid=None)
+        in1 = tid1 >= 0
+        if not np.any(in1):
+            return None, None
+        if not np.all(in1):
+            tid0, tid1, B0, B1 = tid0[in1], tid1[in1], B0[in1], B1[in1]
+            if isinstance(weight, np.ndarray):
+                weight = weight[in1]
+            in0[in0] = in1
+        kwargs.pop('render_weight_threshold', None)
+        kwargs.pop('check_duplicates', None)
+        return cls(mesh0, mesh1, tid0, tid1, B0, B1, weight=weight, **kwargs), in0
+
+    # --- views
+    @property
+    def mask(self):
+        if self._mask is None:
+            self._mask = (self._weight * self._residue_weight) > 0
+        return self._mask
+
+    def _sel(self, arr, use_mask):
+        return arr[self.mask] if use_mask else arr
+
+    def tid0(self, use_mask=False):
+        return self._sel(self._tid0, use_mask)
+
+    def tid1(self, use_mask=False):
+        return self._sel(self._tid1, use_mask)
+
+    def B0(self, use_mask=False):
+        return self._sel(self._B0, use_mask)
+
+    def B1(self, use_mask=False):
+        return self._sel(self._B1, use_mask)
+
+    def weight(self, use_mask=False):
+        return self._sel(self._weight * self._residue_weight, use_mask)
+
+    @property
+    def sample_err(self):
+        se = np.array(self._sample_err)
+        if se.size == 1:
+            se = np.full(self._tid0.size, se)
+        return se
+
+    @property
+    def locked(self):
+        return [self.meshes[0].locked, self.meshes[1].locked]
+
+    @property
+    def relevant(self):
+        return not (self._disabled or np.all(self.locked))
+
+    @property
+    def num_matches(self):
+        return 0 if self._disabled else int(np.sum(self.mask))
+
+    def xy0(self, gear=const.MESH_GEAR_MOVING, use_mask=True, combine=True):
+        xy = self.meshes[0].bary2cart(self.tid0(use_mask), self.B0(use_mask), gear, offsetting=False)
+        off = self.meshes[0].offset(gear)
+        return xy + off if combine else (xy, off)
+
+    def xy1(self, gear=const.MESH_GEAR_MOVING, use_mask=True, combine=True):
+        xy = self.meshes[1].bary2cart(self.tid1(use_mask), self.B1(use_mask), gear, offsetting=False)
+        off = self.meshes[1].offset(gear)
+        return xy + off if combine else (xy, off)
+
+    def dxy(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), use_mask=False):
+        """optimizer.py:248-255."""
+        if not hasattr(gear, '__len__'):
+            gear = (gear, gear)
+        p0, o0 = self.xy0(gear=gear[0], use_mask=use_mask, combine=False)
+        p1, o1 = self.xy1(gear=gear[1], use_mask=use_mask, combine=False)
+        return (p1 - p0) + (o1 - o0)
+
+    # --- residue weighting (optimizer.py:174-205)
+    def set_hard_residue_filter(self, residue_len):
+        self._weight_func = lambda x: x <= residue_len
+
+    def set_huber_residue_filter(self, residue_len):
+        self._weight_func = lambda x: residue_len / np.maximum(x, residue_len)
+
+    def adjust_weight_from_residue(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING)):
+        if self._weight_func is None:
+            return False, False
+        prev_w = self._residue_weight
+        prev_conn = self.num_matches > 0
+        d = self.dxy(gear=gear, use_mask=False)
+        dis = np.sum(d ** 2, axis=-1) ** 0.5
+        dis = ((dis ** 2 - self.sample_err ** 2).clip(0, None)) ** 0.5
+        new_w = np.asarray(self._weight_func(dis)).astype(np.float32)
+        if np.any(new_w != prev_w):
+            self._residue_weight = new_w
+            self._mask = None
+            return True, (self.num_matches > 0) != prev_conn
+        return False, False
+
+    def reset_mask(self):
+        self._residue_weight = np.ones_like(self._weight)
+        self._mask = None
+
+
+class SLM:
+    """feabas/optimizer.py:487-1873, linear-elastic relaxation subset:
+    ``optimize_linear`` / ``optimize_elastic`` on linear engineering meshes."""
+
+    def __init__(self, meshes, links=None, **kwargs):
+        self.meshes = list(meshes)
+        self.links = [] if links is None else links
+        self._stiffness_lambda = kwargs.get('stiffness_lambda', 1.0)
+        self._crosslink_lambda = kwargs.get('crosslink_lambda', -1.0)
+        self._sys = None
+        self._sys_key = None
+        self.last_solve = None
+
+    def __del__(self):
+        self._drop_system()
+
+    def _drop_system(self):
+        if getattr(self, '_sys', None) is not None:
+            try:
+                _lib.load().fb_sys_destroy(_lib.ctx(), self._sys)
+            except Exception:
+                pass
+            self._sys = None
+            self._sys_key = None
+
+    # ------------------------------------------------------------------ system manipulation
+    def add_link(self, link, **kwargs):
+        if link is None:
+            return False
+        self.links.append(link)
+        return True
+
+    def add_link_from_coordinates(self, uid0, uid1, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL),
+                                  weight=None, **kwargs):
+        """optimizer.py:637-701 for two whole meshes addressed by uid."""
+        lut = {m.uid: m for m in self.meshes}
+        link, mask = Link.from_coordinates(lut[float(uid0)], lut[float(uid1)], xy0, xy1, gear=gear, weight=weight, **kwargs)
+        if link is None:
+            return False
+        self.links.append(link)
+        return True
+
+    def clear_links(self):
+        self.links = []
+
+    def set_link_residue_huber(self, residue_len):
+        for lk in self.links:
+            lk.set_huber_residue_filter(residue_len)
+
+    def set_link_residue_threshold(self, residue_len):
+        for lk in self.links:
+            lk.set_hard_residue_filter(residue_len)
+
+    def adjust_link_weight_by_residue(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), **kwargs):
+        wm = cm = False
+        for lk in self.links:
+            a, b = lk.adjust_weight_from_residue(gear=gear)
+            wm |= a
+            cm |= b
+        return wm, cm
+
+    @property
+    def lock_flags(self):
+        return np.array([m.locked for m in self.meshes], dtype=bool)
+
+    @property
+    def index_offsets(self):
+        """optimizer.py:960-970: uid -> first DoF (or -1)."""
+        out = {}
+        cur = 0
+        for m in self.meshes:
+            if m.locked:
+                out[m.uid] = -1
+            else:
+                out[m.uid] = cur
+                cur += 2 * m.num_vertices
+        return out
+
+    @property
+    def degree_of_freedom(self):
+        return int(sum(2 * m.num_vertices for m in self.meshes if not m.locked))
+
+    # ------------------------------------------------------------------ GPU system
+    def _active_links(self):
+        return [lk for lk in self.links if lk.relevant and lk._tid0.size > 0]
+
+    def _ensure_system(self):
+        """(Re)build the symbolic GPU system when the topology (free meshes, link
+        connectivity) changed; numeric re-assembly reuses it."""
+        lib = _lib.load()
+        ctx = _lib.ctx()
+        offs = self.index_offsets
+        links = self._active_links()
+        node_rows = []
+        for lk in links:
+            cols = []
+            for side, (m, tid) in enumerate(zip(lk.meshes, (lk._tid0, lk._tid1))):
+                if m.locked:
+                    cols.append(np.full((tid.size, 3), -1, dtype=np.int32))
+                else:
+                    cols.append((m.triangles[tid] + offs[m.uid] // 2).astype(np.int32))
+            node_rows.append(np.concatenate(cols, axis=-1))
+        nodes6 = np.ascontiguousarray(np.concatenate(node_rows, axis=0), dtype=np.int32) if node_rows else np.zeros((0, 6), np.int32)
+        key = (tuple((m.uid, m.locked, m.num_vertices, m.triangles.ctypes.data) for m in self.meshes), nodes6.tobytes())
+        if self._sys is not None and key == self._sys_key:
+            return links
+        self._drop_system()
+        nv = self.degree_of_freedom // 2
+        sysh = C.c_void_p()
+        _lib.check(lib.fb_sys_create(ctx, nv, C.byref(sysh)))
+        self._sys = sysh
+        self._mesh_ids = {}
+        for m in self.meshes:
+            if m.locked:
+                continue
+            mid = C.c_int()
+            _lib.check(lib.fb_sys_add_mesh(ctx, sysh, offs[m.uid] // 2, _lib.ptr(m.triangles), m.num_vertices,
+                                           m.num_triangles, C.byref(mid)))
+            self._mesh_ids[m.uid] = mid.value
+        _lib.check(lib.fb_sys_set_links(ctx, sysh, nodes6.shape[0], _lib.ptr(nodes6)))
+        nnzb = C.c_int64()
+        _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
+        self._nnzb = nnzb.value
+        self._nv = nv
+        self._sys_key = key
+        return links
+
+    def _assemble(self, shape_gear, start_gear, target_gear):
+        """numeric assembly of K, stress, C, rhs on the GPU (optimizer.py:1307-1310)."""
+        lib = _lib.load()
+        ctx = _lib.ctx()
+        links = self._ensure_system()
+        for m in self.meshes:
+            if m.locked:
+                continue
+            v0 = np.ascontiguousarray(m.vertices(shape_gear), dtype=np.float64)
+            v1 = m.vertices(start_gear)
+            v1c = None if v1 is m.vertices(shape_gear) else np.ascontiguousarray(v1, dtype=np.float64)
+            _lib.check(lib.fb_sys_assemble_mesh(ctx, self._sys, self._mesh_ids[m.uid], _lib.ptr(v0), _lib.ptr(v1c),
+                                                _lib.ptr(m.element_multiplier()), m.poisson_ratio, float(m.soft_factor)))
+        bary, wts, res = [], [], []
+        for lk in links:
+            gears = [target_gear if m.locked else start_gear for m in lk.meshes]
+            bary.append(np.concatenate((lk._B0, -lk._B1), axis=-1))
+            wts.append(lk.weight(use_mask=False))
+            res.append(lk.dxy(gear=gears, use_mask=False))
+        if links:
+            bary = np.ascontiguousarray(np.concatenate(bary, axis=0), dtype=np.float64)
+            wts = np.ascontiguousarray(np.concatenate(wts), dtype=np.float32)
+            res = np.ascontiguousarray(np.concatenate(res, axis=0), dtype=np.float64)
+            _lib.check(lib.fb_sys_assemble_links(ctx, self._sys, _lib.ptr(bary), _lib.ptr(wts), _lib.ptr(res)))
+        else:
+            _lib.check(lib.fb_sys_assemble_links(ctx, self._sys, None, None, None))
+
+    # --- exported equation terms (parity / inspection; optimizer.py:802-901)
+    def stiffness_matrix(self, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), **kwargs):
+        self._assemble(gear[0], gear[-1], gear[-1])
+        K = bsr_download(self._sys, 0, self._nv, self._nnzb)
+        stress = np.empty(2 * self._nv, dtype=np.float32)
+        _lib.check(_lib.load().fb_sys_get(_lib.ctx(), self._sys, 3, _lib.ptr(stress)))
+        return K, stress
+
+    def crosslink_terms(self, start_gear=const.MESH_GEAR_MOVING, target_gear=const.MESH_GEAR_MOVING, **kwargs):
+        self._assemble(const.MESH_GEAR_FIXED, start_gear, target_gear)
+        Cm = bsr_download(self._sys, 1, self._nv, self._nnzb)
+        rhs = np.empty(2 * self._nv, dtype=np.float64)
+        _lib.check(_lib.load().fb_sys_get(_lib.ctx(), self._sys, 2, _lib.ptr(rhs)))
+        return Cm, rhs
+
+    def relative_lambda_trace(self, stiffness_lambda, crosslink_lambda):
+        sl, cl = C.c_double(), C.c_double()
+        _lib.check(_lib.load().fb_sys_lambda(_lib.ctx(), self._sys, float(stiffness_lambda), float(crosslink_lambda),
+                                             C.byref(sl), C.byref(cl)))
+        return sl.value, cl.value
+
+    # ------------------------------------------------------------------ optimize
+    def optimize_linear(self, **kwargs):
+        """feabas/optimizer.py:1257-1437 without groupings / DoF elimination.
+        Returns (||b||, ||A d - b||) and writes the field into the meshes."""
+        maxiter = kwargs.get('maxiter', None)
+        tol = kwargs.get('tol', 1e-7)
+        atol = kwargs.get('atol', 0.0)
+        shape_gear = kwargs.get('shape_gear', const.MESH_GEAR_FIXED)
+        target_gear = kwargs.get('target_gear', const.MESH_GEAR_MOVING)
+        start_gear = kwargs.get('start_gear', target_gear)
+        stiffness_lambda = kwargs.get('stiffness_lambda', self._stiffness_lambda)
+        crosslink_lambda = kwargs.get('crosslink_lambda', self._crosslink_lambda)
+        precondition = kwargs.get('precondition', 'jacobi')
+        for unsupported in ('groupings', 'remove_material_dof'):
+            if kwargs.get(unsupported, None) is not None:
+                raise NotImplementedError(f'optimize_linear({unsupported}=...) is outside the round-1 hot path')
+        if kwargs.get('remove_extra_dof', False):
+            raise NotImplementedError('optimize_linear(remove_extra_dof=True) is outside the round-1 hot path')
+        if np.all(self.lock_flags):
+            return 0, 0
+        lib = _lib.load()
+        ctx = _lib.ctx()
+        self._assemble(shape_gear, start_gear, target_gear)
+        sl, cl = self.relative_lambda_trace(stiffness_lambda, crosslink_lambda)
+        _lib.check(lib.fb_sys_form(ctx, self._sys, sl, cl))
+        b = np.empty(2 * self._nv, dtype=np.float64)
+        _lib.check(lib.fb_sys_get(ctx, self._sys, 5, _lib.ptr(b)))
+        dd = np.zeros(2 * self._nv, dtype=np.float64)
+        iters, relres = C.c_int(), C.c_double()
+        mi = -1 if maxiter is None else int(maxiter)
+        pre = 0 if precondition is None else 1
+        _lib.check(lib.fb_sys_solve(ctx, self._sys, _lib.ptr(dd), 0, float(tol), float(atol or 0.0), mi, pre,
+                                    C.byref(iters), C.byref(relres)), allow=(_lib.FB_ERR_NOCONV,))
+        bn = float(np.linalg.norm(b))
+        cost = (bn, float(relres.value * bn))
+        self.last_solve = dict(iters=iters.value, relres=relres.value, stiffness_lambda=sl, crosslink_lambda=cl)
+        if cost[1] < cost[0]:                               # optimizer.py:1421
+            offs = self.index_offsets
+            for m in self.meshes:
+                if m.locked:
+                    continue
+                o = offs[m.uid]
+                m.set_field(dd[o:o + 2 * m.num_vertices].reshape(-1, 2), gear=(start_gear, target_gear))
+        return cost
+
+    def optimize_elastic(self, **kwargs):
+        """optimizer.py:1547-1555 for linear systems."""
+        if kwargs.get('online_anneal', False):
+            raise NotImplementedError('Newton-Raphson / online annealing is a "next" row (SURVEY.md sec.8f)')
+        return self.optimize_linear(**kwargs)
+
+
+def solve(A, b, solver='minres', x0=None, tol=1e-7, atol=None, maxiter=None, M=None, **kwargs):
+    """feabas/optimizer.py:1945-2080: solve A x = b to ||Ax-b|| <= max(tol, atol/||b||) ||b||
+    on the GPU (Jacobi-PCG on 0.5 (A + A^T)).  ``solver`` is accepted for signature
+    compatibility; ``M`` other than None / 'jacobi' is not available (no pyamg on device)."""
+    edc = kwargs.get('extra_dof_constraint', None)
+    A = sparse.csr_matrix(A)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    if (maxiter == 0) or (np.linalg.norm(b) == 0):
+        return np.zeros_like(b)
+    if isinstance(M, str) and M.lower().startswith(('smooth', 'sa')):
+        raise NotImplementedError("smoothed-aggregation preconditioning is not on the GPU path; use M='jacobi'")
+    full_n = b.size
+    if edc is not None:                                     # optimizer.py:1976-1991
+        if (not isinstance(edc, np.ndarray)) or (edc.dtype != bool):
+            sel = edc
+            edc = np.zeros(full_n, dtype=bool)
+            edc[sel] = True
+        if np.all(edc):
+            edc = None
+        elif not np.any(edc):
+            return np.zeros_like(b)
+        else:
+            A = A[edc][:, edc]
+            b = np.ascontiguousarray(b[edc])
+            if x0 is not None:
+                x0 = x0[edc]
+    A.sort_indices()
+    n = b.size
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    idx = np.ascontiguousarray(A.indices, dtype=np.int32)
+    val = np.ascontiguousarray(A.data, dtype=np.float64)
+    x = np.zeros(n, dtype=np.float64) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+    iters, relres = C.c_int(), C.c_double()
+    _lib.check(_lib.load().fb_pcg(_lib.ctx(), n, _lib.ptr(indptr), _lib.ptr(idx), _lib.ptr(val), _lib.ptr(b), _lib.ptr(x),
+                                  0 if x0 is None else 1, float(tol), float(atol or 0.0), -1 if maxiter is None else int(maxiter),
+                                  1, 1, C.byref(iters), C.byref(relres)), allow=(_lib.FB_ERR_NOCONV,))
+    if edc is not None:
+        full = np.zeros(full_n, dtype=np.float64)
+        full[edc] = x
+        x = full
+    return x

@@ -1,0 +1,231 @@
+"""Device-resident tile-pair matcher: the NCC side of ``matcher.stitching_matcher``
+(feabas/matcher.py:224-367) for a BATCH of overlap-strip pairs that already sit in HBM.
+
+Per pair, in the reference's order:
+  1. x0.5 area downsample (matcher.py:255-256)            fb_area_downsample2_dev
+  2. DoG at sigma*0.5 (273-274)                             fb_dog_dev
+  3. global translation, padded FFT (275 -> 138-158)        fb_ncc_batch_dev
+  4. DoG at full resolution (336-337)                       fb_dog_dev
+  5. coarse-to-fine block matching over the auto spacings (243-251, 578-745): blocks from
+     distributor_cartesian_bbox (865-891), crops by integer translation
+     (MeshRenderer.crop_multiple for a translated, undeformed mesh), xcorr_fft with the
+     reference's pad / subpixel schedule (579-603, 690-716), block -> point pairs (840-849)
+                                                            fb_ncc_blocks_dev
+What is NOT here yet (DESIGN.md "scope of the pair pipeline"): the low-confidence fallback
+of global_translation_matcher (159-221, host path exists in matcher.py), the mesh relaxation
+between spacings when a coarse round moves blocks by > 0.1 px (725-742) together with the
+bilinear patch gather it then needs, and the final strain estimate.
+Pairs that would take those branches are flagged in the result (``needs_host``).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import constant as const
+from .matcher import auto_spacings, next_fast_len
+
+
+def _divide_bbox_batch(xmin, ymin, xmax, ymax, block_size, min_num_blocks):
+    """feabas/common.py:380-409 for arrays of bounding boxes that share (Nx, Ny).
+    Returns x0, y0 [P, Ny*Nx] int32 and the block width/height per pair."""
+    wd = xmax - xmin
+    ht = ymax - ymin
+    nx = np.maximum(np.ceil(wd / block_size), min_num_blocks)
+    ny = np.maximum(np.ceil(ht / block_size), min_num_blocks)
+    dx = np.ceil(wd / nx).astype(np.int64)
+    dy = np.ceil(ht / ny).astype(np.int64)
+    return nx.astype(np.int64), ny.astype(np.int64), dx, dy
+
+
+def _z_order_batch(ix, iy):
+    """feabas/common.py:196-215 along the last axis (base 2, two dimensions)."""
+    ix = ix - ix.min(axis=-1, keepdims=True)
+    iy = iy - iy.min(axis=-1, keepdims=True)
+    sx = np.zeros_like(ix)
+    sy = np.zeros_like(iy)
+    level = 0
+    while np.any(ix > 0) or np.any(iy > 0):
+        sx = sx + (ix % 2) * (2 ** (2 * level))
+        sy = sy + (iy % 2) * (2 ** (2 * level))
+        ix = np.floor(ix / 2)
+        iy = np.floor(iy / 2)
+        level += 1
+    return np.argsort(sx + 2 * sy, axis=-1, kind='stable')
+
+
+class StripBatchMatcher:
+    def __init__(self, P, H, W, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
+                 conf_mode=const.FFT_CONF_MIRROR):
+        assert coarse_downsample in (0.5, 1)
+        assert H % 2 == 0 and W % 2 == 0 or coarse_downsample == 1
+        self.P, self.H, self.W = int(P), int(H), int(W)
+        self.sigma = float(sigma)
+        self.cds = coarse_downsample
+        self.conf_thresh = float(conf_thresh)
+        self.mnb = int(min_num_blocks)
+        self.conf_mode = int(conf_mode)
+        self.spacings = np.sort(auto_spacings((H, W), (H, W)))[::-1]     # matcher.py:243-251, 567
+        hc, wc = (H // 2, W // 2) if coarse_downsample == 0.5 else (H, W)
+        self.hc, self.wc = hc, wc
+        n = self.P
+        self.d_small = _lib.DeviceBuffer(2 * n * hc * wc) if coarse_downsample == 0.5 else None
+        self.d_dogc = _lib.DeviceBuffer(2 * n * hc * wc * 4)
+        self.d_dogf = _lib.DeviceBuffer(2 * n * H * W * 4)
+        self.max_blocks = n * 1024
+        self.d_blk = _lib.DeviceBuffer(self.max_blocks * 9 * 4)
+        self.d_dx = _lib.DeviceBuffer(self.max_blocks * 8)
+        self.d_dy = _lib.DeviceBuffer(self.max_blocks * 8)
+        self.d_cf = _lib.DeviceBuffer(self.max_blocks * 4)
+
+    def free(self):
+        for b in (self.d_small, self.d_dogc, self.d_dogf, self.d_blk, self.d_dx, self.d_dy, self.d_cf):
+            if b is not None:
+                b.free()
+
+    # ------------------------------------------------------------------ stages
+    def _global(self, strips0, strips1):
+        lib, ctx = _lib.load(), _lib.ctx()
+        n, H, W, hc, wc = self.P, self.H, self.W, self.hc, self.wc
+        if self.cds == 0.5:
+            _lib.check(lib.fb_area_downsample2_dev(ctx, strips0, n, H, W, self.d_small.ptr))
+            _lib.check(lib.fb_area_downsample2_dev(ctx, strips1, n, H, W, self.d_small.offset(n * hc * wc)))
+            _lib.check(lib.fb_dog_dev(ctx, self.d_small.ptr, 0, 2 * n, hc, wc, self.sigma * self.cds, None, 1, self.d_dogc.ptr))
+        else:
+            _lib.check(lib.fb_dog_dev(ctx, strips0, 0, n, hc, wc, self.sigma, None, 1, self.d_dogc.ptr))
+            _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, hc, wc, self.sigma, None, 1, self.d_dogc.offset(n * hc * wc * 4)))
+        _lib.check(lib.fb_ncc_batch_dev(ctx, self.d_dogc.ptr, self.d_dogc.offset(n * hc * wc * 4), n, 1, hc, wc, hc, wc,
+                                        1, 0, self.conf_mode, self.d_dx.ptr, self.d_dy.ptr, self.d_cf.ptr))
+        tx = self.d_dx.to_array((n,), np.float64)
+        ty = self.d_dy.to_array((n,), np.float64)
+        cf = self.d_cf.to_array((n,), np.float32)
+        return tx, ty, cf            # equal strip sizes: (W1-W0)/2 = 0 (matcher.py:155-156)
+
+    def _fine_dog(self, strips0, strips1):
+        lib, ctx = _lib.load(), _lib.ctx()
+        n, H, W = self.P, self.H, self.W
+        if self.cds == 1:
+            self.d_dogf_view = self.d_dogc        # matcher.py:315-317: same image when fine == coarse
+            return
+        _lib.check(lib.fb_dog_dev(ctx, strips0, 0, n, H, W, self.sigma, None, 1, self.d_dogf.ptr))
+        _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, H, W, self.sigma, None, 1, self.d_dogf.offset(n * H * W * 4)))
+        self.d_dogf_view = self.d_dogf
+
+    def _blocks(self, tx, ty, sel, spacing, mnb):
+        """block descriptors for the pairs `sel` (all share Nx, Ny): returns (blk [Q, nblk, 9], bboxes [Q, nblk, 4])"""
+        H, W = self.H, self.W
+        # mesh bounding boxes in the MOVING gear (Mesh.from_bbox: vertices at pixel centres - 0.5)
+        xmin = np.maximum(-0.5 + tx[sel], -0.5); ymin = np.maximum(-0.5 + ty[sel], -0.5)
+        xmax = np.minimum(W - 0.5 + tx[sel], W - 0.5); ymax = np.minimum(H - 0.5 + ty[sel], H - 0.5)
+        nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
+        assert np.all(nx == nx[0]) and np.all(ny == ny[0])
+        nxi, nyi = int(nx[0]), int(ny[0])
+        xt = np.round(np.linspace(xmin, xmax - dx, num=nxi, endpoint=True, axis=-1)).astype(np.int32)    # [Q, nx]
+        yt = np.round(np.linspace(ymin, ymax - dy, num=nyi, endpoint=True, axis=-1)).astype(np.int32)    # [Q, ny]
+        x0 = np.broadcast_to(xt[:, None, :], (sel.size, nyi, nxi)).reshape(sel.size, -1)
+        y0 = np.broadcast_to(yt[:, :, None], (sel.size, nyi, nxi)).reshape(sel.size, -1)
+        order = _z_order_batch(np.round((x0 - x0.min(axis=-1, keepdims=True)) / spacing),
+                               np.round((y0 - y0.min(axis=-1, keepdims=True)) / spacing))
+        x0 = np.take_along_axis(x0, order, axis=-1)
+        y0 = np.take_along_axis(y0, order, axis=-1)
+        nblk = x0.shape[1]
+        bb = np.stack((x0, y0, x0 + dx[:, None].astype(np.int32), y0 + dy[:, None].astype(np.int32)), axis=-1)
+        blk = np.empty((sel.size, nblk, 9), dtype=np.int32)
+        blk[:, :, 0] = sel[:, None]
+        # image-0 window: output coordinate - mesh offset (renderer.crop_field: bbox - offset)
+        blk[:, :, 1] = x0 - np.round(tx[sel]).astype(np.int32)[:, None]
+        blk[:, :, 2] = y0 - np.round(ty[sel]).astype(np.int32)[:, None]
+        blk[:, :, 3] = dy[:, None]; blk[:, :, 4] = dx[:, None]
+        blk[:, :, 5] = x0; blk[:, :, 6] = y0
+        blk[:, :, 7] = dy[:, None]; blk[:, :, 8] = dx[:, None]
+        return blk, bb
+
+    def _match_round(self, tx, ty, active, spacing, mnb, pad_flags, subpixel):
+        """one spacing round for the `active` pairs; returns per-pair lists of (bboxes, dx, dy, conf)"""
+        lib, ctx = _lib.load(), _lib.ctx()
+        n, H, W = self.P, self.H, self.W
+        out = {}
+        # group by block grid, then by FFT shape (matcher.py:59-62 on the block size)
+        xmin = np.maximum(-0.5 + tx, -0.5); xmax = np.minimum(W - 0.5 + tx, W - 0.5)
+        ymin = np.maximum(-0.5 + ty, -0.5); ymax = np.minimum(H - 0.5 + ty, H - 0.5)
+        nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
+        fh = np.array([next_fast_len(2 * v - 1 if p else v) for v, p in zip(dy, pad_flags)])
+        fw = np.array([next_fast_len(2 * v - 1 if p else v) for v, p in zip(dx, pad_flags)])
+        key = np.stack((nx, ny, fh, fw), axis=-1)
+        key[~active] = -1
+        groups = {}
+        for p in np.flatnonzero(active):
+            groups.setdefault(tuple(key[p]), []).append(p)
+        dogf = self.d_dogf_view
+        img1 = dogf.offset(n * H * W * 4)
+        for (gnx, gny, gfh, gfw), members in groups.items():
+            sel = np.array(members)
+            blk, bb = self._blocks(tx, ty, sel, spacing, mnb)
+            nb = blk.shape[0] * blk.shape[1]
+            assert nb <= self.max_blocks
+            flat = np.ascontiguousarray(blk.reshape(-1, 9))
+            _lib.check(lib.fb_memcpy_h2d(ctx, self.d_blk.ptr, _lib.ptr(flat), flat.nbytes))
+            _lib.check(lib.fb_ncc_blocks_dev(ctx, dogf.ptr, img1, H, W, H, W, nb, self.d_blk.ptr, int(gfh), int(gfw),
+                                             1 if subpixel else 0, self.conf_mode, self.d_dx.ptr, self.d_dy.ptr, self.d_cf.ptr))
+            ddx = self.d_dx.to_array((nb,), np.float64).reshape(sel.size, -1)
+            ddy = self.d_dy.to_array((nb,), np.float64).reshape(sel.size, -1)
+            dcf = self.d_cf.to_array((nb,), np.float32).reshape(sel.size, -1)
+            for k, p in enumerate(sel):
+                out[int(p)] = (bb[k], ddx[k], ddy[k], dcf[k])
+        return out
+
+    # ------------------------------------------------------------------ driver
+    def match(self, strips0, strips1):
+        """strips0/strips1: device pointers to uint8 [P][H][W].  Returns a list of per-pair dicts."""
+        n = self.P
+        tx, ty, cf0 = self._global(strips0, strips1)
+        scale = 1.0 / self.cds
+        tx = tx * scale; ty = ty * scale                     # matcher.py:338-339
+        ok = cf0 >= self.conf_thresh                         # matcher.py:277-278
+        self._fine_dog(strips0, strips1)
+        results = [dict(tx=tx[p], ty=ty[p], conf0=float(cf0[p]), xy0=None, xy1=None, weight=None, needs_host=False)
+                   for p in range(n)]
+        spacings = self.spacings
+        sp_indx = np.zeros(n, dtype=np.int64)
+        pad = np.ones(n, dtype=bool)
+        active = ok.copy()
+        last = {}
+        for rnd in range(spacings.size):
+            # every active pair sits at spacing index `rnd` (pairs that would skip ahead are handled below)
+            sp = spacings[rnd]
+            is_last = rnd == spacings.size - 1
+            mnb = self.mnb if is_last else 1
+            res = self._match_round(tx, ty, active, sp, mnb, pad, subpixel=is_last)
+            for p, (bb, ddx, ddy, dcf) in res.items():
+                keep = dcf > self.conf_thresh                # matcher.py:671-683
+                if not np.any(keep):
+                    if rnd == 0:
+                        active[p] = False                    # invalid_output (matcher.py:672-673)
+                    continue
+                ctr = 0.5 * np.stack((bb[:, 0] + bb[:, 2], bb[:, 1] + bb[:, 3]), axis=-1) - 0.5      # bbox_centers
+                dxy = np.stack((ddx, ddy), axis=-1)
+                xy0 = (ctr - dxy * 0.5)[keep]                # equal block sizes: ratio 0.5 (matcher.py:844-849)
+                xy1 = (ctr + dxy * 0.5)[keep]
+                max_dis = np.max(np.sum((xy0 - xy1) ** 2, axis=-1)) ** 0.5
+                last[p] = (xy0, xy1, dcf[keep], max_dis)
+                if not is_last:
+                    # spacing schedule (matcher.py:689-716)
+                    next_pos = np.searchsorted(-spacings, -4 * max_dis) - 1
+                    if next_pos > rnd:
+                        pad[p] = min(next_pos, rnd + 1) > rnd + 1          # always False with max_spacing_skip = 0
+                    else:
+                        pad[p] = True
+                    if max_dis > 0.1:
+                        # the reference relaxes the mesh here and crops the next round through the deformed
+                        # mesh (matcher.py:725-742): not on the device path yet
+                        results[p]['needs_host'] = True
+        for p, (xy0, xy1, wt, max_dis) in last.items():
+            if not active[p]:
+                continue
+            r = results[p]
+            # output in the INITIAL gear: mesh0 points lose the translation (matcher.py:748-751)
+            r['xy0'] = xy0 - np.array([tx[p], ty[p]])
+            r['xy1'] = xy1
+            r['weight'] = wt
+            r['max_dis'] = max_dis
+        return results

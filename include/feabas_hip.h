@@ -1,0 +1,194 @@
+/* feabas_hip.h -- C ABI of libfeabas_hip.so, the MI355X (gfx950) implementation of
+ * FEABAS's two hot paths: the FFT cross-correlation matcher (feabas/matcher.py) and
+ * the finite-element mesh relaxation (feabas/optimizer.py + mesh.py + material.py).
+ *
+ * The reference has no FFI of its own (it is pure Python over numpy/scipy); the
+ * boundary it offers is the Python function surface of feabas.matcher /
+ * feabas.optimizer / feabas.mesh.  Each entry point below names the reference
+ * function (file:line under feabas/) whose arithmetic it replaces; the Python
+ * package feabas_amd binds them with ctypes and keeps the reference signatures
+ * (INTEGRATION.md shows the stub a FEABAS maintainer would add).
+ *
+ * Conventions
+ *  - handle based: one fb_ctx per process per GPU, no global state;
+ *  - every call returns 0 on success or a negative fb_status; the message is
+ *    retrievable with fb_last_error(ctx); nothing throws across the boundary;
+ *  - "host" entry points take caller-owned host buffers and are synchronous;
+ *    "_dev" entry points take device pointers, enqueue on the context stream and
+ *    return without synchronising (call fb_sync);
+ *  - images are C-contiguous, row-major; DoF order is [x0,y0,x1,y1,...]
+ *    (material.py:155, optimizer.py:124).
+ */
+#ifndef FEABAS_HIP_H
+#define FEABAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fb_ctx fb_ctx;
+
+typedef enum fb_status_e {
+    FB_OK = 0,
+    FB_ERR_ARG = -1,        /* invalid argument / shape */
+    FB_ERR_HIP = -2,        /* HIP runtime error */
+    FB_ERR_FFT = -3,        /* rocFFT error */
+    FB_ERR_NOMEM = -4,
+    FB_ERR_NOCONV = -5,     /* solver did not reach the requested residual */
+    FB_ERR_BREAKDOWN = -6,  /* PCG breakdown: p^T A p <= 0 (matrix not PSD) */
+    FB_ERR_COMM = -7
+} fb_status;
+
+/* constant.py:39-41 */
+#define FB_CONF_NONE 0
+#define FB_CONF_STD 1
+#define FB_CONF_MIRROR 2
+
+/* image element types accepted by fb_dog */
+#define FB_U8 0
+#define FB_F32 1
+
+/* ------------------------------------------------------------------ context */
+fb_ctx* fb_create(int device_id);
+void fb_destroy(fb_ctx* ctx);
+const char* fb_last_error(fb_ctx* ctx);
+int fb_sync(fb_ctx* ctx);
+void* fb_stream(fb_ctx* ctx);                 /* hipStream_t of the context */
+int fb_device_info(fb_ctx* ctx, char* name, int name_len, int* num_cu, size_t* hbm_bytes);
+const char* fb_version(void);
+
+/* device memory owned by the context (freed by fb_free or fb_destroy) */
+int fb_malloc(fb_ctx* ctx, size_t bytes, void** dptr);
+int fb_free(fb_ctx* ctx, void* dptr);
+int fb_memcpy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
+int fb_memcpy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
+int fb_memset(fb_ctx* ctx, void* dst, int value, size_t bytes);
+
+/* HIP-event stopwatch on the context stream (bench.py's timed region) and
+ * per-kernel accumulators.  fb_prof_enable(1) brackets every launch of the
+ * library's own kernels with events; fb_prof_get returns the number of launches
+ * and their summed duration for a kernel name. */
+int fb_timer_start(fb_ctx* ctx);
+int fb_timer_stop(fb_ctx* ctx, float* ms);
+int fb_prof_enable(fb_ctx* ctx, int on);
+int fb_prof_reset(fb_ctx* ctx);
+int fb_prof_count(fb_ctx* ctx);
+int fb_prof_get(fb_ctx* ctx, int index, char* name, int name_len, int* launches, double* total_ms);
+
+/* ------------------------------------------------------------------ NCC path */
+/* next 5-smooth length, scipy.fftpack.next_fast_len as used at matcher.py:59-62 */
+int fb_next_fast_len(int n);
+
+/* matcher.xcorr_fft (matcher.py:22-135) with sigma=0, normalize=False:
+ * img0 [N][C][H0][W0], img1 [N][C][H1][W1] float32 (C = 1 for 3-D stacks; the
+ * reference's (N,H,W,C) input must be moved to channel-major by the caller, as
+ * matcher.py:50-53 does).  Outputs dx, dy (float64[N]) and conf (float32[N]):
+ * centre(img1) + (dx,dy) <-> centre(img0).  Integer peaks follow numpy's
+ * first-maximum rule (matcher.py:82). */
+int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C,
+                 int H0, int W0, int H1, int W1, int pad, int subpixel, int conf_mode,
+                 double* dx, double* dy, float* conf);
+int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, int C,
+                     int H0, int W0, int H1, int W1, int pad, int subpixel, int conf_mode,
+                     double* dx, double* dy, float* conf);
+/* Block matching straight from resident image stacks: the translation-only form of
+ * MeshRenderer.crop_multiple + xcorr_fft (matcher.py:834-846).  imgs0 [P][IH0][IW0], imgs1
+ * [P][IH1][IW1] float32 (DoG output); blk [N][9] int32 = {image, x0, y0, h0, w0, x1, y1, h1, w1}:
+ * block n correlates the h0 x w0 window at (x0,y0) of imgs0[image] with the h1 x w1 window at
+ * (x1,y1) of imgs1[image]; pixels outside an image read 0 (dal.StreamLoader fillval).  All blocks
+ * of a call share the FFT shape (Fh, Fw) the caller derives with the rule of matcher.py:59-62. */
+int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1,
+                      int N, const int* blk, int Fh, int Fw, int subpixel, int conf_mode,
+                      double* dx, double* dy, float* conf);
+/* debugging / parity aid: the two correlation surfaces (un-normalised) of the
+ * last fb_ncc_batch* call that went through the streaming (rocFFT) class. */
+int fb_ncc_last_surfaces(fb_ctx* ctx, float* C_out, float* Cm_out, int* Fh, int* Fw);
+
+/* common.masked_dog_filter (common.py:353-377).  img: [N][H][W] uint8 or float32;
+ * mask: [H][W] uint8 (0 = outside) or NULL; out: [N][H][W] float32. */
+int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma,
+           const uint8_t* mask, int signed_out, float* out);
+int fb_dog_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma,
+               const uint8_t* mask, int signed_out, float* out);
+
+/* cv2.resize(fx=fy=0.5, INTER_AREA) of even-sized uint8 images (matcher.py:255-256) */
+int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out);
+int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out);
+
+/* Synthetic overlap strips for benchmarks (not a reference function): pair p gets an integer
+ * offset (sx, sy) in [-max_shift, max_shift]^2 derived from (seed, pair0 + p); strips0/strips1 are
+ * uint8 [P][H][W] with strips1(x, y) = texture(x + sx, y + sy); shifts_dev receives [P][2] = {sx, sy}. */
+int fb_synth_strips_dev(fb_ctx* ctx, int P, int pair0, int H, int W, uint32_t seed, int max_shift,
+                        uint8_t* strips0, uint8_t* strips1, int* shifts_dev);
+
+/* ------------------------------------------------------------------ FEM path */
+/* A spring-linked-mesh system (optimizer.SLM, optimizer.py:487-1873) resident on the
+ * GPU.  Free (unlocked) meshes occupy consecutive ranges of a global free-vertex
+ * numbering, DoF = 2*vertex + {0,1} exactly like SLM.index_offsets
+ * (optimizer.py:960-970); locked meshes only appear through the links' residuals.
+ *
+ *   fb_sys_create -> fb_sys_add_mesh (per free mesh) -> fb_sys_set_links -> fb_sys_finalize
+ *   (symbolic: one 2x2 block per coupled vertex pair)
+ *   fb_sys_assemble_mesh  : Mesh.stiffness_matrix (mesh.py:3058-3083) with the linear
+ *                           engineering element of material.py:134-182, times soft_factor
+ *                           (optimizer.py:821-822); stress = K (v_cur - v_shape) as float32
+ *   fb_sys_assemble_links : SLM.crosslink_terms (optimizer.py:832-901)
+ *   fb_sys_lambda         : SLM.relative_lambda_trace (optimizer.py:1573-1590)
+ *   fb_sys_form           : A = ls K + lc C, b = lc rhs - ls stress (optimizer.py:1417-1418)
+ *   fb_sys_solve          : optimizer.solve (optimizer.py:1945-2080)
+ */
+typedef struct fb_system fb_system;
+int fb_sys_create(fb_ctx* ctx, int64_t nvert_free, fb_system** out);
+void fb_sys_destroy(fb_ctx* ctx, fb_system* sys);
+/* tri: [T][3] vertex ids local to the mesh; the mesh owns global vertices [voff, voff+V) */
+int fb_sys_add_mesh(fb_ctx* ctx, fb_system* sys, int64_t voff, const int32_t* tri, int V, int T, int* mesh_id);
+/* nodes6: [K][6] global free-vertex ids of the two triangles a match sits in
+ * (slots 0-2 side 0, slots 3-5 side 1); -1 marks a vertex of a locked mesh */
+int fb_sys_set_links(fb_ctx* ctx, fb_system* sys, int64_t K, const int32_t* nodes6);
+int fb_sys_finalize(fb_ctx* ctx, fb_system* sys, int64_t* nnzb);
+int fb_sys_pattern(fb_ctx* ctx, fb_system* sys, int64_t* browptr /*[nv+1]*/, int32_t* bcol /*[nnzb]*/);
+int fb_sys_info(fb_ctx* ctx, fb_system* sys, int64_t* nv, int64_t* nnzb, int64_t* nlink);
+/* v_shape, v_cur: [V][2] float64 (v_cur NULL = zero stress); tri_mult: [T] float32 or NULL
+ * (mesh.stiffness_multiplier * material.stiffness_multiplier) */
+int fb_sys_assemble_mesh(fb_ctx* ctx, fb_system* sys, int mesh_id, const double* v_shape, const double* v_cur,
+                         const float* tri_mult, double nu, double soft);
+/* bary6: [K][6] = [+B0 | -B1] (Link.shape_matrix_contrib, optimizer.py:114-131); w: [K] float32
+ * (weight * residue_weight); rxy: [K][2] residual x1 - x0 (Link.dxy, optimizer.py:248-255) */
+int fb_sys_assemble_links(fb_ctx* ctx, fb_system* sys, const double* bary6, const float* w, const double* rxy);
+int fb_sys_lambda(fb_ctx* ctx, fb_system* sys, double stiffness_lambda, double crosslink_lambda, double* sl_out, double* cl_out);
+int fb_sys_form(fb_ctx* ctx, fb_system* sys, double sl, double cl);
+/* x: [2 nv] float64, x0 on entry when use_x0.  maxiter < 0: until converged, 0: zeros, > 0: cap */
+int fb_sys_solve(fb_ctx* ctx, fb_system* sys, double* x, int use_x0, double rtol, double atol, int maxiter, int precond,
+                 int* iters, double* relres);
+int fb_sys_solve_fixed(fb_ctx* ctx, fb_system* sys, int iters, double* relres);
+/* download: 0 K [nnzb][2][2] f64, 1 C [nnzb] f32 (nodal: C_xx = C_yy), 2 rhs [2nv] f64,
+ * 3 stress [2nv] f32, 4 A [nnzb][2][2] f64, 5 b [2nv] f64 */
+int fb_sys_get(fb_ctx* ctx, fb_system* sys, int which, void* out);
+
+/* optimizer.solve (optimizer.py:1945-2080) fixed point: Jacobi-preconditioned CG
+ * on the symmetrised CSR system until ||Ax-b|| <= max(rtol, atol/||b||) ||b||.
+ * x holds x0 on entry when use_x0 != 0.  precond: 0 none, 1 reference Jacobi
+ * (optimizer.py:1962-1966). */
+int fb_pcg(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* idx, const double* val,
+           const double* b, double* x, int use_x0, double rtol, double atol, int maxiter,
+           int precond, int symmetrize, int* iters, double* relres);
+
+/* resident form: upload once, iterate many times (bench / Newton steps) */
+typedef struct fb_csr fb_csr;
+int fb_csr_upload(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* idx, const double* val,
+                  int symmetrize, fb_csr** out);
+void fb_csr_destroy(fb_ctx* ctx, fb_csr* A);
+int fb_csr_info(fb_ctx* ctx, fb_csr* A, int64_t* n, int64_t* nnz, int64_t* nb, int64_t* nnzb);
+int fb_spmv(fb_ctx* ctx, fb_csr* A, const double* x_host, double* y_host);
+int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, double rtol, double atol,
+               int maxiter, int precond, int* iters, double* relres);
+/* exactly `iters` PCG iterations with no convergence exit (throughput bench) */
+int fb_pcg_fixed_iters(fb_ctx* ctx, fb_csr* A, const double* b_host, int iters, double* relres);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEABAS_HIP_H */

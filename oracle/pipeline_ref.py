@@ -1,0 +1,82 @@
+"""Oracle of the per-tile-pair matcher (NCC side of matcher.stitching_matcher,
+feabas/matcher.py:224-367 + 430-751) for pairs whose block rounds never move a
+block by more than 0.1 px before the last round -- the branch in which the
+reference performs no mesh relaxation (matcher.py:725) and every crop of
+MeshRenderer.crop_multiple is an integer translation of the DoG'd strip.
+TEST INFRASTRUCTURE (see oracle/__init__.py).  cv2 / triangle / shapely are not
+needed on this branch; the x0.5 INTER_AREA downsample is the unpinned
+restatement ncc_ref.area_downsample2.
+"""
+import numpy as np
+
+from . import ncc_ref
+
+
+def _crop(img, x0, y0, h, w):
+    """h x w window at (x0, y0), zero outside the image (StreamLoader fillval=0 +
+    cv2.remap BORDER_CONSTANT, common.py:329-330)."""
+    out = np.zeros((h, w), dtype=img.dtype)
+    H, W = img.shape
+    ya, yb = max(y0, 0), min(y0 + h, H)
+    xa, xb = max(x0, 0), min(x0 + w, W)
+    if ya < yb and xa < xb:
+        out[ya - y0:yb - y0, xa - x0:xb - x0] = img[ya:yb, xa:xb]
+    return out
+
+
+def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
+               conf_mode=ncc_ref.FFT_CONF_MIRROR):
+    """strip0/strip1: uint8 H x W overlap strips.  Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host)."""
+    H, W = strip0.shape
+    if coarse_downsample == 0.5:
+        g0 = ncc_ref.area_downsample2(strip0)
+        g1 = ncc_ref.area_downsample2(strip1)
+    else:
+        g0, g1 = strip0, strip1
+    g0 = ncc_ref.masked_dog_filter(g0, sigma * coarse_downsample)          # matcher.py:273-274
+    g1 = ncc_ref.masked_dog_filter(g1, sigma * coarse_downsample)
+    tx, ty, conf0 = ncc_ref.global_translation_matcher(g0, g1, conf_mode=conf_mode, conf_thresh=conf_thresh)
+    res = dict(tx=tx / coarse_downsample, ty=ty / coarse_downsample, conf0=conf0, xy0=None, xy1=None, weight=None,
+               needs_host=False)
+    if conf0 < conf_thresh:                                                  # matcher.py:277-278
+        return res
+    if coarse_downsample == 1:
+        f0, f1 = g0, g1
+    else:
+        f0 = ncc_ref.masked_dog_filter(strip0, sigma)                        # matcher.py:336-337
+        f1 = ncc_ref.masked_dog_filter(strip1, sigma)
+    tx, ty = res['tx'], res['ty']
+    spacings = np.sort(ncc_ref.auto_spacings((H, W), (H, W)))[::-1]
+    bbox0 = (-0.5 + tx, -0.5 + ty, W - 0.5 + tx, H - 0.5 + ty)              # Mesh.from_bbox + apply_translation
+    bbox1 = (-0.5, -0.5, W - 0.5, H - 0.5)
+    pad = True
+    itx, ity = int(round(tx)), int(round(ty))
+    last = None
+    for rnd, sp in enumerate(spacings):
+        is_last = rnd == spacings.size - 1
+        mnb = min_num_blocks if is_last else 1
+        bb0, bb1 = ncc_ref.distributor_cartesian_bbox(bbox0, bbox1, sp, min_num_blocks=mnb, zorder=True)
+        h = int(bb0[0, 3] - bb0[0, 1]); w = int(bb0[0, 2] - bb0[0, 0])
+        s0 = np.stack([_crop(f0, int(b[0]) - itx, int(b[1]) - ity, h, w) for b in bb0])
+        s1 = np.stack([_crop(f1, int(b[0]), int(b[1]), h, w) for b in bb1])
+        dx, dy, cf = ncc_ref.xcorr_fft(s0, s1, conf_mode=conf_mode, pad=pad, subpixel=is_last)
+        xy0, xy1 = ncc_ref.block_points(bb0, bb1, dx, dy)
+        keep = cf > conf_thresh
+        if not np.any(keep):
+            if rnd == 0:
+                return res
+            continue
+        xy0, xy1, wt = xy0[keep], xy1[keep], cf[keep]
+        max_dis = np.max(np.sum((xy0 - xy1) ** 2, axis=-1)) ** 0.5
+        last = (xy0, xy1, wt, max_dis)
+        if not is_last:
+            next_pos = np.searchsorted(-spacings, -4 * max_dis) - 1           # matcher.py:689-716
+            pad = (min(next_pos, rnd + 1) > rnd + 1) if next_pos > rnd else True
+            if max_dis > 0.1:
+                res['needs_host'] = True
+    if last is not None:
+        res['xy0'] = last[0] - np.array([tx, ty])
+        res['xy1'] = last[1]
+        res['weight'] = last[2]
+        res['max_dis'] = last[3]
+    return res

@@ -1,0 +1,95 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports
+every symbol include/feabas_hip.h declares (no compute calls), and the host
+logic (bbox helpers, next_fast_len) matches the golden vectors."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+import feabas_amd
+from feabas_amd import _lib, common, matcher
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _lib.declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), n
+    # and every prototype we bind is declared in the header
+    assert set(_lib._PROTOS) <= set(names)
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = _lib.load()
+    if lib.fb_create(0):
+        pytest.skip('a GPU is visible')
+    with pytest.raises(RuntimeError):
+        matcher.xcorr_fft(np.zeros((1, 8, 8), np.float32), np.zeros((1, 8, 8), np.float32))
+
+
+def test_product_does_not_import_oracle():
+    import os, re
+    root = os.path.dirname(os.path.abspath(feabas_amd.__file__))
+    for fn in os.listdir(root):
+        if fn.endswith('.py'):
+            src = open(os.path.join(root, fn)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), fn
+
+
+def test_next_fast_len():
+    g = load_golden('g11_bbox.npz')
+    got = np.array([matcher.next_fast_len(n) for n in range(1, 4200)])
+    np.testing.assert_array_equal(got, g['nfl'])
+
+
+def test_bbox_helpers_golden():
+    g = load_golden('g11_bbox.npz')
+    k = 0
+    while f'div{k}_in' in g:
+        p = g[f'div{k}_in']
+        mnb = tuple(int(v) for v in p[6:])
+        kw = dict(min_num_blocks=mnb[0] if len(mnb) == 1 else mnb, shrink_factor=p[5])
+        if p[4] > 0:
+            kw['block_size'] = p[4]
+        res = np.stack(common.divide_bbox(tuple(p[:4]), **kw), axis=-1)
+        np.testing.assert_array_equal(res, g[f'div{k}_out'])
+        k += 1
+    np.testing.assert_array_equal(common.z_order(g['z_in']), g['z_out'])
+    np.testing.assert_allclose(common.bbox_centers(g['bb_in']), g['bb_centers'])
+    np.testing.assert_allclose(common.bbox_sizes(g['bb_in']), g['bb_sizes'])
+
+    class M:
+        def __init__(self, bb): self.bb = bb
+        def bbox(self, gear=None): return self.bb
+    for k in range(2):
+        p = g[f'dist{k}_in']
+        r0, r1 = matcher.distributor_cartesian_bbox(M(p[:4]), M(p[4:8]), p[8], min_num_blocks=int(p[9]), zorder=True)
+        np.testing.assert_array_equal(r0, g[f'dist{k}_bb0'])
+        np.testing.assert_array_equal(r1, g[f'dist{k}_bb1'])
+
+
+def test_mesh_gears_and_field_semantics():
+    from feabas_amd.mesh import Mesh
+    from feabas_amd import constant as const
+    from oracle import fem_ref
+    v, t = fem_ref.grid_mesh(5, 4, 10.0)
+    m = Mesh(v, t, uid=3)
+    r = fem_ref.RefMesh(v, t, uid=3)
+    m.apply_translation((1.5, -2.0), const.MESH_GEAR_FIXED)
+    r.apply_translation((1.5, -2.0), fem_ref.GEAR_FIXED)
+    d = np.random.default_rng(0).standard_normal(v.shape)
+    m.set_field(d, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING))
+    r.set_field(d, gear=(fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING))
+    for gear in (-1, 0, 1, 2):
+        np.testing.assert_allclose(m.vertices(gear), r.vertices(gear))
+        np.testing.assert_allclose(m.offset(gear), r.offset(gear))
+    m.anneal(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT)
+    r.anneal_copy((fem_ref.GEAR_MOVING, fem_ref.GEAR_FIXED))
+    np.testing.assert_allclose(m.vertices_w_offset(0), r.vertices_w_offset(0))
+    tid = np.array([0, 5, 11])
+    xy = r.bary2cart(tid, np.array([[0.2, 0.3, 0.5]] * 3), 1)
+    tid2, B = m.cart2bary(xy, 1, tid=None)
+    np.testing.assert_array_equal(tid2, tid)
+    np.testing.assert_allclose(B, [[0.2, 0.3, 0.5]] * 3, atol=1e-12)

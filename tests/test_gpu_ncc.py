@@ -1,0 +1,155 @@
+"""GPU parity of the NCC path through the C-ABI: golden vectors from the
+reference, seeded comparisons with the oracle, edge cases.  Bar: integer peaks
+bit-exact, sub-pixel offsets and confidence within 1e-4 (north_star)."""
+import numpy as np
+import pytest
+from scipy.ndimage import gaussian_filter
+
+from conftest import load_golden
+from oracle import ncc_ref
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4
+
+
+def _check(got, exp, atol=ATOL, conf_atol=None):
+    dx, dy, cf = got
+    ex, ey, ec = exp
+    np.testing.assert_array_equal(np.round(dx), np.round(ex))
+    np.testing.assert_array_equal(np.round(dy), np.round(ey))
+    np.testing.assert_allclose(dx, ex, atol=atol, rtol=0)
+    np.testing.assert_allclose(dy, ey, atol=atol, rtol=0)
+    np.testing.assert_allclose(cf, ec, atol=atol if conf_atol is None else conf_atol, rtol=0)
+
+
+@pytest.mark.parametrize('case', ['A', 'B', 'C'])
+@pytest.mark.parametrize('pad', [1, 0])
+@pytest.mark.parametrize('sub', [1, 0])
+@pytest.mark.parametrize('cm', [0, 1, 2])
+def test_xcorr_golden(fb, case, pad, sub, cm):
+    g = load_golden('g1_xcorr.npz')
+    got = fb.matcher.xcorr_fft(g[f'{case}_img0'], g[f'{case}_img1'], conf_mode=cm, pad=bool(pad), subpixel=bool(sub))
+    key = f'{case}_p{pad}_s{sub}_c{cm}'
+    catol = None
+    if cm == 1:
+        # FFT_CONF_STD = (1 - exp(-Cmax/Cstd)) ** (Fh*Fw) with the base rounded to float32 by numpy
+        # (matcher.py:133): one float32 ulp of the base moves the result by Fh*Fw*6e-8, which is the
+        # reference's own resolution.  No reference call site uses this mode.
+        f = {'A': 150 * 150, 'B': 144 * 150, 'C': 256 * 256}[case] if pad else {'A': 75 * 75, 'B': 75 * 75, 'C': 128 * 128}[case]
+        catol = 2.5 * f * 6e-8
+    _check(got, (g[key + '_dx'], g[key + '_dy'], g[key + '_conf']), conf_atol=catol)
+
+
+@pytest.mark.parametrize('pad', [1, 0])
+def test_xcorr_golden_channels(fb, pad):
+    g = load_golden('g1_xcorr.npz')
+    got = fb.matcher.xcorr_fft(g['D_img0'], g['D_img1'], conf_mode=2, pad=bool(pad), subpixel=True)
+    _check(got, (g[f'D_p{pad}_s1_c2_dx'], g[f'D_p{pad}_s1_c2_dy'], g[f'D_p{pad}_s1_c2_conf']))
+
+
+def _pairs(rng, n, s0, s1, maxshift):
+    H = max(s0[0], s1[0]); W = max(s0[1], s1[1])
+    big = gaussian_filter(rng.standard_normal((3 * H + 64, 3 * W + 64)), 1.5).astype(np.float32)
+    big -= gaussian_filter(big, 4.0)
+    i0 = np.empty((n,) + s0, np.float32); i1 = np.empty((n,) + s1, np.float32)
+    for k in range(n):
+        y = rng.integers(H, 2 * H); x = rng.integers(W, 2 * W)
+        sy, sx = rng.integers(-maxshift, maxshift + 1, 2)
+        i0[k] = big[y:y + s0[0], x:x + s0[1]]
+        i1[k] = big[y + sy:y + sy + s1[0], x + sx:x + sx + s1[1]]
+    i1 += 0.05 * i1.std() * rng.standard_normal(i1.shape).astype(np.float32)
+    return i0, i1
+
+
+@pytest.mark.parametrize('shape,n,pad', [
+    (((75, 73), (75, 73)), 385, False),     # the 4k-pair fine class, unpadded round
+    (((75, 73), (75, 73)), 64, True),       # padded 150 x 150
+    (((74, 72), (67, 75)), 33, True),       # README config, unequal blocks
+    (((280, 280), (280, 280)), 16, True),   # alignment spacing 400
+    (((70, 70), (70, 70)), 100, True),      # alignment spacing 100
+    (((1, 40), (1, 40)), 3, True),          # degenerate one-row images
+])
+def test_xcorr_vs_oracle(fb, shape, n, pad):
+    rng = np.random.default_rng(hash((shape, n, pad)) % (2 ** 32))
+    i0, i1 = _pairs(rng, n, shape[0], shape[1], maxshift=max(1, min(shape[0]) // 4)) if shape[0][0] > 1 else (
+        rng.standard_normal((n,) + shape[0]).astype(np.float32), rng.standard_normal((n,) + shape[1]).astype(np.float32))
+    for sub in (True, False):
+        got = fb.matcher.xcorr_fft(i0, i1, pad=pad, subpixel=sub)
+        exp = ncc_ref.xcorr_fft(i0, i1, pad=pad, subpixel=sub)
+        _check(got, exp)
+
+
+def test_xcorr_streaming_class(fb):
+    """coarse classes of the 4k tile pair at reduced count: 1024x510 blocks (FFT 2048x1024)
+    and the 2048x255 global strip (FFT 4096x512)."""
+    rng = np.random.default_rng(5)
+    i0, i1 = _pairs(rng, 2, (1024, 510), (1024, 510), maxshift=20)
+    _check(fb.matcher.xcorr_fft(i0, i1, pad=True), ncc_ref.xcorr_fft(i0, i1, pad=True))
+    j0, j1 = _pairs(rng, 1, (2048, 255), (2048, 255), maxshift=12)
+    _check(fb.matcher.xcorr_fft(j0, j1, pad=True, subpixel=True), ncc_ref.xcorr_fft(j0, j1, pad=True, subpixel=True))
+
+
+def test_xcorr_edge_cases(fb):
+    z = np.zeros((2, 20, 24), np.float32)
+    dx, dy, cf = fb.matcher.xcorr_fft(z, z, pad=True, subpixel=True)
+    ex, ey, ec = ncc_ref.xcorr_fft(z, z, pad=True, subpixel=True)
+    np.testing.assert_array_equal(dx, ex); np.testing.assert_array_equal(dy, ey); np.testing.assert_array_equal(cf, ec)
+    e = fb.matcher.xcorr_fft(np.zeros((0, 8, 8), np.float32), np.zeros((0, 8, 8), np.float32))
+    assert all(a.shape == (0,) for a in e)
+    # exact tie: two identical maxima -> first index wins (numpy argmax rule)
+    a = np.zeros((1, 16, 16), np.float32); a[0, 4, 4] = 1
+    b = np.zeros((1, 16, 16), np.float32); b[0, 6, 9] = 1; b[0, 2, 3] = 1
+    _check(fb.matcher.xcorr_fft(a, b, pad=False), ncc_ref.xcorr_fft(a, b, pad=False))
+
+
+def test_xcorr_shift_property(fb):
+    """size-independent property at the full 4k fine-class batch: a circular shift of img1
+    moves the unpadded peak by exactly that shift."""
+    rng = np.random.default_rng(11)
+    t = gaussian_filter(rng.standard_normal((385, 75, 75)), (0, 1.2, 1.2)).astype(np.float32)
+    sh = rng.integers(-30, 31, size=(385, 2))
+    u = np.stack([np.roll(t[k], tuple(sh[k]), axis=(0, 1)) for k in range(385)])
+    dx, dy, cf = fb.matcher.xcorr_fft(t, u, pad=False)
+    np.testing.assert_array_equal(dx, sh[:, 1]); np.testing.assert_array_equal(dy, sh[:, 0])
+    assert np.all(cf > 0.5)
+
+
+def test_global_translation_golden(fb):
+    g = load_golden('g3_global.npz')
+    np.testing.assert_allclose(fb.matcher.global_translation_matcher(g['d0'], g['d1'], conf_thresh=0.3), g['plain'], atol=ATOL)
+    np.testing.assert_allclose(fb.matcher.global_translation_matcher(g['d0'], g['e1'], conf_thresh=2.0), g['fallback'], atol=ATOL)
+    np.testing.assert_allclose(fb.matcher.global_translation_matcher(g['d0'], g['f1'], conf_thresh=2.0), g['unequal'], atol=ATOL)
+
+
+def test_dog_golden(fb):
+    g = load_golden('g2_dog.npz')
+
+    def rel(a, b):
+        return np.abs(a - b).max() / np.abs(b).max()
+    for s in (1.25, 2.5, 3.5):
+        assert rel(fb.common.masked_dog_filter(g['img'], s), g[f'dog_s{s}']) < 1e-5
+    assert rel(fb.common.masked_dog_filter(g['img'], 2.5, mask=g['mask']), g['dog_masked_signed']) < 1e-5
+    assert rel(fb.common.masked_dog_filter(g['img'], 2.5, mask=g['mask'], signed=False), g['dog_masked_unsigned']) < 1e-5
+    assert rel(fb.common.masked_dog_filter(g['stack'], 2.5), g['dog_stack_s2.5']) < 1e-5
+    assert rel(fb.common.masked_dog_filter(g['fimg'], 1.25), g['dog_fimg_s1.25']) < 1e-5
+
+
+def test_dog_vs_oracle_strip(fb):
+    """the 4k strip shapes: fine 4096x510 sigma 2.5 and coarse 2048x255 sigma 1.25; ragged tile edges"""
+    rng = np.random.default_rng(3)
+    for (h, w, s) in ((4096, 510, 2.5), (2048, 255, 1.25), (97, 131, 2.5), (7, 300, 1.25)):
+        img = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        got = fb.common.masked_dog_filter(img, s)
+        exp = ncc_ref.masked_dog_filter(img, s)
+        assert np.abs(got - exp).max() <= 1e-5 * np.abs(exp).max()
+    # all-ones mask: identical to the unmasked filter (common.py:368)
+    img = rng.integers(0, 256, size=(64, 64), dtype=np.uint8)
+    np.testing.assert_array_equal(fb.common.masked_dog_filter(img, 2.5, mask=np.ones((64, 64), bool)),
+                                  fb.common.masked_dog_filter(img, 2.5))
+
+
+def test_area_downsample(fb):
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, size=(3, 510, 4096), dtype=np.uint8)
+    np.testing.assert_array_equal(fb.common.area_downsample2(img), ncc_ref.area_downsample2(img))
