@@ -188,11 +188,9 @@ def main():
         res = matchers[k].match(s0.offset(b * P * H * W), s1.offset(b * P * H * W))
         if dist is not None:
             # match table of this step: [P][400][5] (xy0, xy1, weight), zero padded; one all_gather over RCCL
-            tab = np.zeros((P, 400, 5), dtype=np.float32)
-            for p, r in enumerate(res):
-                if r['xy0'] is not None:
-                    m = min(400, r['xy0'].shape[0])
-                    tab[p, :m, 0:2] = r['xy0'][:m]; tab[p, :m, 2:4] = r['xy1'][:m]; tab[p, :m, 4] = r['weight'][:m]
+            tab = np.zeros((P * 400, 6), dtype=np.float32)
+            m = min(tab.shape[0], res['pair'].size)
+            tab[:m, 0] = res['pair'][:m]; tab[:m, 1:3] = res['xy0'][:m]; tab[:m, 3:5] = res['xy1'][:m]; tab[:m, 5] = res['weight'][:m]
             t = torch.from_numpy(tab).cuda(non_blocking=True)
             out = torch.empty((world,) + tab.shape, dtype=torch.float32, device='cuda')
             dist.all_gather_into_tensor(out, t)
@@ -226,8 +224,10 @@ def main():
     # correctness of the timed work: recovered translations = injected shifts, matches found
     k, b, res = last
     sh = strips[k][2][b * P:(b + 1) * P]
-    ok_shift = sum(1 for p, r in enumerate(res) if (r['tx'], r['ty']) == (-sh[p, 0], -sh[p, 1]))
-    n_matches = float(np.mean([0 if r['xy0'] is None else r['xy0'].shape[0] for r in res]))
+    ok_shift = int(np.sum((np.abs(res['tx'] + sh[:, 0]) <= 1) & (np.abs(res['ty'] + sh[:, 1]) <= 1)))
+    d = res['xy1'] - res['xy0'] + sh[res['pair']]
+    ok_match = float(np.mean(np.abs(d).max(axis=1) < 0.5)) if d.size else 0.0
+    n_matches = res['pair'].size / P
 
     # roofline of the dominant kernel (by accumulated event time inside the timed region)
     dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else (None, (0, 0.0))
@@ -254,7 +254,8 @@ def main():
                                      f'{Hl}x{Wl}), {P} pairs per step; stages: x0.5 downsample, DoG, global NCC, DoG, '
                                      f'4 coarse + 385 fine block NCCs (translation-only crops, no mesh relaxation yet)',
                             pairs_per_step=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33),
-                check=dict(shift_recovered=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches),
+                check=dict(global_shift_within_1px=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches, matches_within_half_px_of_truth=ok_match,
+                           pairs_needing_mesh_relaxation=int(res['needs_host'].sum())),
                 roofline=roof)
 
     if rank == 0 and not args.no_fem:

@@ -51,6 +51,7 @@ struct fb_ctx {
     std::vector<fb_prof_entry> prof;
     std::vector<void*> owned;   // fb_malloc'ed pointers
     size_t ncc_arena_limit = (size_t)8 << 30;
+    bool dog_exact = false;      // double-precision tap accumulation (scipy's arithmetic) instead of the float fast path
 };
 
 int fb_fail(fb_ctx* ctx, int code, const char* fmt, ...);
@@ -97,3 +98,6 @@ int fb_ncc_small_supported(int Fh, int Fw, int H0, int W0, int H1, int W1, int C
 int fb_ncc_small_launch(fb_ctx* ctx, const float* img0, const float* img1, int N, int H0, int W0,
                         int H1, int W1, int Fh, int Fw, int subpixel, int conf_mode, double* dx,
                         double* dy, float* conf);
+int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, int N, int H0, int W0, int H1, int W1,
+                           const int* blk, int IH0, int IW0, int IH1, int IW1, int Fh, int Fw, int subpixel,
+                           int conf_mode, double* dx, double* dy, float* conf);

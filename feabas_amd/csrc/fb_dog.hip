@@ -159,6 +159,192 @@ int set_taps(fb_ctx* ctx, double sigma, int* radius, Taps* out) {
     return FB_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fast path (unmasked DoG, radius known at compile time): same four passes, but every thread
+// produces RUN consecutive outputs along the filter axis from RUN + 2R values held in registers
+// (one LDS read per ~0.3 outputs instead of 21), and the taps are applied in float32.  Row passes
+// map lanes to rows (pitch/4 odd -> conflict-free ds_read_b128), column passes map lanes to columns.
+// The 'nearest' extension is restored after each pass by replicating the image-border column/row.
+struct TapsF { float w[kMaxRadius + 1]; };
+constexpr int RUN = 8;
+constexpr int FT = 64;     // output tile
+
+__host__ __device__ constexpr int pitch_for(int cols) { int p = (cols + 3) / 4 * 4; return (p / 4) % 2 ? p : p + 4; }
+__host__ __device__ constexpr int up8(int v) { return (v + RUN - 1) / RUN * RUN; }
+
+template <int R>
+struct FastGeom {
+    static constexpr int HAL = 2 * R;
+    static constexpr int AH = FT + 2 * HAL, AW = FT + 2 * HAL;      // stage-0 tile
+    static constexpr int BW = AW - 2 * R, GH = AH - 2 * R;           // after row pass / after column pass
+    static constexpr int PA = pitch_for(up8(BW) + 2 * R);            // row-pass overread stays inside the row
+    static constexpr int PB = pitch_for(BW);
+    static constexpr int PD = pitch_for(FT);
+    static constexpr int SZ_A = (AH * PA > GH * PB ? AH * PA : GH * PB);
+    static constexpr int SZ_B = (AH * PB > GH * PD ? AH * PB : GH * PD);
+};
+
+template <int R>
+__device__ __forceinline__ void fir_run(const float (&in)[RUN + 2 * R], const TapsF& t, float (&out)[RUN]) {
+#pragma unroll
+    for (int j = 0; j < RUN; ++j) {
+        float acc = in[j + R] * t.w[0];
+#pragma unroll
+        for (int k = R; k >= 1; --k) acc = fmaf(in[j + R - k] + in[j + R + k], t.w[k], acc);
+        out[j] = acc;
+    }
+}
+
+// rows x ncols_out outputs; src/dst are LDS arrays with pitches ps/pd; output col c reads src cols [c, c+2R]
+template <int R>
+__device__ __forceinline__ void row_pass(const float* __restrict__ src, int ps, float* __restrict__ dst, int pd, int rows,
+                                         int ncols_out, const TapsF& t) {
+    const int nruns = (ncols_out + RUN - 1) / RUN;
+    for (int item = threadIdx.x; item < rows * nruns; item += blockDim.x) {
+        const int run = item / rows, row = item - run * rows;       // lanes walk rows
+        float in[RUN + 2 * R], o[RUN];
+        const float* p = src + row * ps + run * RUN;
+#pragma unroll
+        for (int q = 0; q < (RUN + 2 * R) / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+            in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int q = (RUN + 2 * R) / 4 * 4; q < RUN + 2 * R; ++q) in[q] = p[q];
+        fir_run<R>(in, t, o);
+        float* d = dst + row * pd + run * RUN;
+        if (run * RUN + RUN <= ncols_out) {
+            *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < RUN; ++j)
+                if (run * RUN + j < ncols_out) d[j] = o[j];
+        }
+    }
+}
+
+// nrows_out x cols outputs; output row y reads src rows [y, y+2R]
+template <int R>
+__device__ __forceinline__ void col_pass(const float* __restrict__ src, int ps, int src_rows, float* __restrict__ dst, int pd,
+                                         int nrows_out, int cols, const TapsF& t) {
+    const int nruns = (nrows_out + RUN - 1) / RUN;
+    for (int item = threadIdx.x; item < cols * nruns; item += blockDim.x) {
+        const int run = item / cols, c = item - run * cols;         // lanes walk columns
+        float in[RUN + 2 * R], o[RUN];
+        const float* p = src + c;
+#pragma unroll
+        for (int q = 0; q < RUN + 2 * R; ++q) in[q] = p[min(run * RUN + q, src_rows - 1) * ps];
+        fir_run<R>(in, t, o);
+        float* d = dst + (run * RUN) * pd + c;
+#pragma unroll
+        for (int j = 0; j < RUN; ++j)
+            if (run * RUN + j < nrows_out) d[j * pd] = o[j];
+    }
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void dog_fast(const T* __restrict__ img, float* __restrict__ out, int H, int W, int signed_out,
+                                                const TapsF taps) {
+    using G = FastGeom<R>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* bufA = smem;
+    float* bufB = smem + G::SZ_A;
+    const int n = blockIdx.z;
+    const int x0 = blockIdx.x * FT, y0 = blockIdx.y * FT;
+    const T* src = img + (size_t)n * H * W;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // stage 0: clamped input tile ('nearest' extension of the image)
+    for (int i = tid; i < G::AH * G::AW; i += nt) {
+        const int ty = i / G::AW, tx = i - ty * G::AW;
+        const int gy = clampi(y0 - G::HAL + ty, 0, H - 1), gx = clampi(x0 - G::HAL + tx, 0, W - 1);
+        bufA[ty * G::PA + tx] = load_px<T>(src, (size_t)gy * W + gx);
+    }
+    __syncthreads();
+    // stage 1: rows A -> B (AH x BW); B col tx <-> global x = x0 - R + tx
+    row_pass<R>(bufA, G::PA, bufB, G::PB, G::AH, G::BW, taps);
+    __syncthreads();
+    {   // replicate the image-border columns
+        const int cl = -(x0 - R), cr = (W - 1) - (x0 - R);          // B columns of global x = 0 and x = W-1
+        if (cl > 0 || cr < G::BW - 1) {
+            for (int i = tid; i < G::AH * G::BW; i += nt) {
+                const int ty = i / G::BW, tx = i - ty * G::BW;
+                if (tx < cl) bufB[ty * G::PB + tx] = bufB[ty * G::PB + cl];
+                else if (tx > cr) bufB[ty * G::PB + tx] = bufB[ty * G::PB + cr];
+            }
+            __syncthreads();
+        }
+    }
+    // stage 2: columns B -> G0 (GH x BW) in bufA (pitch PB); G0 row ty <-> global y = y0 - R + ty
+    col_pass<R>(bufB, G::PB, G::AH, bufA, G::PB, G::GH, G::BW, taps);
+    __syncthreads();
+    {   // replicate the image-border rows
+        const int rt = -(y0 - R), rb = (H - 1) - (y0 - R);
+        if (rt > 0 || rb < G::GH - 1) {
+            for (int i = tid; i < G::GH * G::BW; i += nt) {
+                const int ty = i / G::BW, tx = i - ty * G::BW;
+                if (ty < rt) bufA[ty * G::PB + tx] = bufA[rt * G::PB + tx];
+                else if (ty > rb) bufA[ty * G::PB + tx] = bufA[rb * G::PB + tx];
+            }
+            __syncthreads();
+        }
+    }
+    // stage 3: rows G0 -> D (GH x FT) in bufB (pitch PD); D col tx <-> global x = x0 + tx
+    row_pass<R>(bufA, G::PB, bufB, G::PD, G::GH, FT, taps);
+    __syncthreads();
+    // stage 4: columns D -> G1 (FT x FT); out = G0 - G1
+    {
+        const int nruns = FT / RUN;
+        for (int item = tid; item < FT * nruns; item += nt) {
+            const int run = item / FT, c = item - run * FT;
+            float in[RUN + 2 * R], o[RUN];
+            const float* p = bufB + (run * RUN) * G::PD + c;
+#pragma unroll
+            for (int q = 0; q < RUN + 2 * R; ++q) in[q] = p[q * G::PD];
+            fir_run<R>(in, taps, o);
+            const int gx = x0 + c;
+            if (gx >= W) continue;
+#pragma unroll
+            for (int j = 0; j < RUN; ++j) {
+                const int ty = run * RUN + j, gy = y0 + ty;
+                if (gy >= H) break;
+                float v = bufA[(ty + R) * G::PB + (c + R)] - o[j];
+                if (!signed_out) v = fabsf(v);
+                out[((size_t)n * H + gy) * W + gx] = v;
+            }
+        }
+    }
+}
+
+template <typename T, int R>
+int launch_fast(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const Taps& taps) {
+    using G = FastGeom<R>;
+    TapsF tf;
+    for (int k = 0; k <= kMaxRadius; ++k) tf.w[k] = (float)taps.w[k];
+    const size_t lds = (size_t)(G::SZ_A + G::SZ_B) * sizeof(float);
+    auto kern = dog_fast<T, R>;
+    FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(fb_cdiv(W, FT), fb_cdiv(H, FT), N);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img, out, H, W, signed_out, tf);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+template <typename T>
+int launch_fast_any(fb_ctx* ctx, int r, const T* img, float* out, int N, int H, int W, int signed_out, const Taps& taps, bool* done) {
+    *done = true;
+    switch (r) {
+        case 5: return launch_fast<T, 5>(ctx, img, out, N, H, W, signed_out, taps);
+        case 6: return launch_fast<T, 6>(ctx, img, out, N, H, W, signed_out, taps);
+        case 8: return launch_fast<T, 8>(ctx, img, out, N, H, W, signed_out, taps);
+        case 10: return launch_fast<T, 10>(ctx, img, out, N, H, W, signed_out, taps);
+        case 12: return launch_fast<T, 12>(ctx, img, out, N, H, W, signed_out, taps);
+        case 14: return launch_fast<T, 14>(ctx, img, out, N, H, W, signed_out, taps);
+        default: *done = false; return FB_OK;
+    }
+}
+
 template <typename T, int NPASS>
 int launch_tile(fb_ctx* ctx, const T* img, float* out, const float* halo, int N, int H, int W, int r, int signed_out,
                 float in_scale, const uint8_t* mask, const Taps& taps) {
@@ -215,8 +401,15 @@ int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, cons
     }
     rc = set_taps(ctx, sigma, &r, &taps);
     if (!rc) {
-        FB_PROF(ctx, "dog_tile");
-        rc = launch_tile<T, 4>(ctx, img, out, halo, N, H, W, r, signed_out, 0.f, nullptr, taps);
+        bool done = false;
+        if (!halo && !ctx->dog_exact) {
+            FB_PROF(ctx, "dog_fast");
+            rc = launch_fast_any<T>(ctx, r, img, out, N, H, W, signed_out, taps, &done);
+        }
+        if (!rc && !done) {
+            FB_PROF(ctx, "dog_tile");
+            rc = launch_tile<T, 4>(ctx, img, out, halo, N, H, W, r, signed_out, 0.f, nullptr, taps);
+        }
     }
     if (halo) {
         hipStreamSynchronize(ctx->stream);

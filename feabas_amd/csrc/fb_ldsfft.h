@@ -1,0 +1,202 @@
+// Workgroup-cooperative batched 1-D FFTs on LDS-resident complex data, lengths 2^a 3^b 5^c.
+//
+// Forward = decimation in frequency, in place, natural order in -> digit-reversed order out.
+// Inverse = decimation in time, in place, digit-reversed order in -> natural order out (unnormalised).
+// Pointwise products commute with the permutation, so a forward / multiply / inverse chain never
+// un-scrambles; code that needs a particular frequency uses fft_pos().
+//
+// Element i of transform m lives at  base[m * ms + i * is]  (float2 units).  `lanes_on_m` picks
+// which index consecutive lanes walk, so that the unit-stride index is the fast one (rows: is == 1,
+// lanes walk i; columns: ms == 1, lanes walk m): ds_read/write_b64 then sweeps consecutive banks.
+#pragma once
+#include <hip/hip_runtime.h>
+
+constexpr int kFftMaxFactors = 10;
+
+struct FftPlan {
+    int n;                          // length
+    int nf;                         // number of radix passes
+    int radix[kFftMaxFactors];      // in forward (DIF) order
+};
+
+// host: factor n (5-smooth) preferring radix 4
+static inline bool fft_make_plan(int n, FftPlan* p) {
+    p->n = n;
+    p->nf = 0;
+    int m = n;
+    while (m % 4 == 0) { p->radix[p->nf++] = 4; m /= 4; if (p->nf >= kFftMaxFactors) return false; }
+    while (m % 2 == 0) { p->radix[p->nf++] = 2; m /= 2; if (p->nf >= kFftMaxFactors) return false; }
+    while (m % 5 == 0) { p->radix[p->nf++] = 5; m /= 5; if (p->nf >= kFftMaxFactors) return false; }
+    while (m % 3 == 0) { p->radix[p->nf++] = 3; m /= 3; if (p->nf >= kFftMaxFactors) return false; }
+    return m == 1;
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmulcf(float2 a, float2 b) {   // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward) / +i (inverse)
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }
+
+// position of frequency k in the digit-reversed output of the forward transform
+__device__ __forceinline__ int fft_pos(const FftPlan& p, int k) {
+    int pos = 0, stride = p.n;
+    for (int s = 0; s < p.nf; ++s) {
+        const int r = p.radix[s];
+        stride /= r;
+        pos += (k % r) * stride;
+        k /= r;
+    }
+    return pos;
+}
+
+// r-point DFT kernels; INV selects the conjugate transform
+template <bool INV>
+__device__ __forceinline__ void dft2(float2* v) {
+    const float2 a = v[0], b = v[1];
+    v[0] = caddf(a, b); v[1] = csubf(a, b);
+}
+template <bool INV>
+__device__ __forceinline__ void dft3(float2* v) {
+    const float c = -0.5f, s = 0.86602540378443864676f;
+    const float2 t1 = caddf(v[1], v[2]);
+    const float2 t2 = make_float2(v[0].x + c * t1.x, v[0].y + c * t1.y);
+    const float2 d = csubf(v[1], v[2]);
+    // forward: -i * s * d ; inverse: +i * s * d
+    const float2 t3 = INV ? make_float2(-s * d.y, s * d.x) : make_float2(s * d.y, -s * d.x);
+    v[0] = caddf(v[0], t1);
+    v[1] = caddf(t2, t3);
+    v[2] = csubf(t2, t3);
+}
+template <bool INV>
+__device__ __forceinline__ void dft4(float2* v) {
+    const float2 a = caddf(v[0], v[2]), b = csubf(v[0], v[2]);
+    const float2 c = caddf(v[1], v[3]), d0 = csubf(v[1], v[3]);
+    const float2 d = INV ? mul_pi(d0) : mul_mi(d0);
+    v[0] = caddf(a, c); v[2] = csubf(a, c);
+    v[1] = caddf(b, d); v[3] = csubf(b, d);
+}
+template <bool INV>
+__device__ __forceinline__ void dft5(float2* v) {
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;    // cos(2pi/5), cos(4pi/5)
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;     // sin(2pi/5), sin(4pi/5)
+    const float2 a1 = caddf(v[1], v[4]), b1 = csubf(v[1], v[4]);
+    const float2 a2 = caddf(v[2], v[3]), b2 = csubf(v[2], v[3]);
+    const float2 m1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+    const float2 m2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+    // n1 = s1 b1 + s2 b2 ; n2 = s2 b1 - s1 b2 ; forward multiplies them by -i, inverse by +i
+    const float2 n1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    const float2 n2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    const float2 r1 = INV ? mul_pi(n1) : mul_mi(n1);
+    const float2 r2 = INV ? mul_pi(n2) : mul_mi(n2);
+    v[0] = caddf(v[0], caddf(a1, a2));
+    v[1] = caddf(m1, r1); v[4] = csubf(m1, r1);
+    v[2] = caddf(m2, r2); v[3] = csubf(m2, r2);
+}
+
+template <int R, bool INV>
+__device__ __forceinline__ void dft_r(float2* v) {
+    if (R == 2) dft2<INV>(v);
+    else if (R == 3) dft3<INV>(v);
+    else if (R == 4) dft4<INV>(v);
+    else dft5<INV>(v);
+}
+
+// exact t / d for 0 <= t < 2^22 through a float reciprocal (the integer divide costs ~40 VALU instructions)
+__device__ __forceinline__ int fdiv_i(int t, int d, float inv) {
+    int q = (int)((float)t * inv);
+    int r = t - q * d;
+    if (r >= d) { ++q; r -= d; }
+    if (r < 0) { --q; }
+    return q;
+}
+
+// one radix-R pass over M transforms.  L = current block length (multiple of R), Lp = L / R.
+// tw[n] = exp(-2 pi i n / N), n < N (LDS).  All offsets are 32-bit (LDS).
+template <int R, bool INV>
+__device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int ms, int L, const float2* __restrict__ tw,
+                                         bool lanes_on_m, int tid, int nthreads) {
+    const int Lp = L / R;
+    const int per = N / R;                // butterflies per transform
+    const int total = per * M;
+    const int tstep = N / L;              // twiddle index step: w_L^(j p) = tw[j * p * N / L]
+    const float inv_M = 1.0f / (float)M, inv_per = 1.0f / (float)per, inv_Lp = 1.0f / (float)Lp;
+    const int leg = Lp * is;
+    // two butterflies per trip: both operand sets are read before either result is written, so the LDS
+    // latencies of the pair overlap (the compiler cannot prove the two in-place updates independent)
+    for (int t = tid; t < total; t += 2 * nthreads) {
+        const int t2 = t + nthreads;
+        const bool has2 = t2 < total;
+        int off[2], jj[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tt = u ? (has2 ? t2 : t) : t;
+            int m, bj;
+            if (lanes_on_m) { bj = fdiv_i(tt, M, inv_M); m = tt - bj * M; }
+            else { m = fdiv_i(tt, per, inv_per); bj = tt - m * per; }
+            const int b = (Lp == per) ? 0 : fdiv_i(bj, Lp, inv_Lp);
+            jj[u] = bj - b * Lp;
+            off[u] = m * ms + (b * L + jj[u]) * is;
+        }
+        float2 v[2][R];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[u][q] = base[off[u] + q * leg];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (INV) {
+                if (L > R) {
+#pragma unroll
+                    for (int q = 1; q < R; ++q) v[u][q] = cmulcf(v[u][q], tw[jj[u] * q * tstep]);  // conj twiddle first (DIT)
+                }
+                dft_r<R, true>(v[u]);
+            } else {
+                dft_r<R, false>(v[u]);
+                if (L > R) {
+#pragma unroll
+                    for (int q = 1; q < R; ++q) v[u][q] = cmulf(v[u][q], tw[jj[u] * q * tstep]);   // twiddle after (DIF)
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) base[off[0] + q * leg] = v[0][q];
+        if (has2) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) base[off[1] + q * leg] = v[1][q];
+        }
+    }
+}
+
+// full batched transform; every pass ends with a workgroup barrier
+template <bool INV>
+__device__ __forceinline__ void fft_batch(float2* base, const FftPlan& plan, int M, int is, int ms, const float2* tw, bool lanes_on_m) {
+    const int N = plan.n;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (!INV) {
+        int L = N;
+        for (int s = 0; s < plan.nf; ++s) {
+            const int r = plan.radix[s];
+            if (r == 4) fft_pass<4, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 2) fft_pass<2, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 5) fft_pass<5, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else fft_pass<3, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            L /= r;
+            __syncthreads();
+        }
+    } else {
+        int L = 1;
+        for (int s = plan.nf - 1; s >= 0; --s) {
+            const int r = plan.radix[s];
+            L *= r;
+            if (r == 4) fft_pass<4, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 2) fft_pass<2, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 5) fft_pass<5, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else fft_pass<3, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            __syncthreads();
+        }
+    }
+}

@@ -23,6 +23,7 @@ struct PeakPartial {
 // img [n][H][W] -> R [n][Fh][Fw], zero padded bottom/right (rfft2(s=...), matcher.py:63-64)
 __global__ void ncc_pad_load(const float* __restrict__ img0, const float* __restrict__ img1,
                              float* __restrict__ R, int NC, int H0, int W0, int H1, int W1, int Fh, int Fw) {
+    // NC = slots per side in R (the plan batch), gridDim.y = images actually present
     const int sel = blockIdx.z;
     const int n = blockIdx.y;
     const float* src = sel ? img1 : img0;
@@ -257,14 +258,31 @@ int get_plan(fb_ctx* ctx, int Fh, int Fw, int batch, fb_fft_plan** out) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// plan batch for a call of N items: the next power of two, capped by what fits the arena budget
+int quantised_chunk(fb_ctx* ctx, int N, size_t per_pair) {
+    size_t cap = std::max<size_t>(1, ctx->ncc_arena_limit / per_pair);
+    size_t capq = 1;
+    while (capq * 2 <= cap) capq *= 2;
+    size_t q = 1;
+    while (q < (size_t)N) q *= 2;
+    // large transforms: one fixed plan batch per shape (rocFFT plan creation costs ~1 s each)
+    if (per_pair >= ((size_t)4 << 20)) q = std::max<size_t>(q, 64);
+    return (int)std::min(q, capq);
+}
+
 // one sub-batch of nb pairs through the rocFFT pipeline; all pointers are device pointers
 struct CropSrc { const int* blk; int IH0, IW0, IH1, IW1; };
 
 int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int nb, int C, int H0, int W0, int H1,
                         int W1, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf,
-                        const CropSrc* crop = nullptr) {
+                        const CropSrc* crop = nullptr, int nbq = 0) {
+    // nbq >= nb: number of slots the buffers and the rocFFT plans are built for (quantised so that
+    // plans are reused across calls); slots [nb, nbq) hold stale data whose transforms are ignored.
+    if (nbq < nb) nbq = nb;
+    const int nreal = nb;
     const int Sw = Fw / 2 + 1;
     const size_t F = (size_t)Fh * Fw, S = (size_t)Fh * Sw;
+    nb = nbq;
     const int NC = nb * C;
     const int want_q = conf_mode == FB_CONF_MIRROR;
     // arena layout
@@ -284,12 +302,12 @@ int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
 
     if (crop) {
         FB_PROF(ctx, "ncc_crop_load");
-        dim3 grid((unsigned)std::min<size_t>((F + kThreads - 1) / kThreads, 4096), (unsigned)NC, 2);
+        dim3 grid((unsigned)std::min<size_t>((F + kThreads - 1) / kThreads, 4096), (unsigned)(nreal * C), 2);
         hipLaunchKernelGGL(ncc_crop_load, grid, dim3(kThreads), 0, ctx->stream, img0, img1, crop->blk, R, NC, crop->IH0, crop->IW0,
                            crop->IH1, crop->IW1, Fh, Fw);
     } else {
         FB_PROF(ctx, "ncc_pad_load");
-        dim3 grid((unsigned)std::min<size_t>((F + kThreads - 1) / kThreads, 4096), (unsigned)NC, 2);
+        dim3 grid((unsigned)std::min<size_t>((F + kThreads - 1) / kThreads, 4096), (unsigned)(nreal * C), 2);
         hipLaunchKernelGGL(ncc_pad_load, grid, dim3(kThreads), 0, ctx->stream, img0, img1, R, NC, H0, W0, H1, W1, Fh, Fw);
     }
     fb_fft_plan* pl = nullptr;
@@ -307,9 +325,9 @@ int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     float2* Q = C > 1 ? S2 + (size_t)nb * S : F1;
     {
         FB_PROF(ctx, "ncc_spectral_mul");
-        const long long total = (long long)nb * S;
+        const long long total = (long long)nreal * S;
         const int blocks = (int)std::min<long long>((total + kThreads - 1) / kThreads, 8192);
-        hipLaunchKernelGGL(ncc_spectral_mul, dim3(blocks), dim3(kThreads), 0, ctx->stream, F0, F1, P, Q, (long long)S, nb, C, want_q);
+        hipLaunchKernelGGL(ncc_spectral_mul, dim3(blocks), dim3(kThreads), 0, ctx->stream, F0, F1, P, Q, (long long)S, nreal, C, want_q);
     }
     // inverse: P -> R[0..nb), Q -> R[nb..2nb)
     float* Csurf = R;
@@ -333,16 +351,16 @@ int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     }
     {
         FB_PROF(ctx, "ncc_peak_partial");
-        hipLaunchKernelGGL(ncc_peak_partial, dim3(kPeakChunks, nb), dim3(kThreads), 0, ctx->stream, Csurf, Msurf, part,
+        hipLaunchKernelGGL(ncc_peak_partial, dim3(kPeakChunks, nreal), dim3(kThreads), 0, ctx->stream, Csurf, Msurf, part,
                            (int)F, want_q, conf_mode == FB_CONF_STD);
     }
     {
         FB_PROF(ctx, "ncc_peak_final");
-        hipLaunchKernelGGL(ncc_peak_final, dim3(fb_cdiv(nb, 64)), dim3(64), 0, ctx->stream, Csurf, part, kPeakChunks, Fh, Fw,
-                           H0, W0, H1, W1, crop ? crop->blk : (const int*)nullptr, subpixel, conf_mode, dx, dy, conf, nb);
+        hipLaunchKernelGGL(ncc_peak_final, dim3(fb_cdiv(nreal, 64)), dim3(64), 0, ctx->stream, Csurf, part, kPeakChunks, Fh, Fw,
+                           H0, W0, H1, W1, crop ? crop->blk : (const int*)nullptr, subpixel, conf_mode, dx, dy, conf, nreal);
     }
     FB_HIP(ctx, hipGetLastError());
-    ctx->last_Fh = Fh; ctx->last_Fw = Fw; ctx->last_N = nb;
+    ctx->last_Fh = Fh; ctx->last_Fw = Fw; ctx->last_N = nreal;
     ctx->last_C = Csurf; ctx->last_Cm = want_q ? Msurf : nullptr;
     return FB_OK;
 }
@@ -381,11 +399,11 @@ int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, i
     if (rc) return rc;
     // sub-batch so that the arena stays under the limit
     const size_t per_pair = (size_t)C * ((size_t)Fh * Fw * 4 + (size_t)Fh * (Fw / 2 + 1) * 8) * 2 + (C > 1 ? (size_t)Fh * (Fw / 2 + 1) * 16 : 0);
-    int nb_max = (int)std::max<size_t>(1, ctx->ncc_arena_limit / per_pair);
+    const int nb_max = quantised_chunk(ctx, N, per_pair);
     for (int n0 = 0; n0 < N; n0 += nb_max) {
         const int nb = std::min(nb_max, N - n0);
         rc = ncc_stream_subbatch(ctx, img0 + (size_t)n0 * C * H0 * W0, img1 + (size_t)n0 * C * H1 * W1, nb, C, H0, W0, H1, W1,
-                                 Fh, Fw, subpixel, conf_mode, dx + n0, dy + n0, conf + n0);
+                                 Fh, Fw, subpixel, conf_mode, dx + n0, dy + n0, conf + n0, nullptr, nb_max);
         if (rc) return rc;
     }
     return FB_OK;
@@ -429,15 +447,17 @@ int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int I
     if (N == 0) return FB_OK;
     FB_CHECK_ARG(ctx, imgs0 && imgs1 && blk && dx && dy && conf);
     FB_HIP(ctx, hipSetDevice(ctx->device));
+    if (fb_ncc_small_supported(Fh, Fw, 0, 0, 0, 0, 1))
+        return fb_ncc_small_launch_ex(ctx, imgs0, imgs1, N, 0, 0, 0, 0, blk, IH0, IW0, IH1, IW1, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
     int rc = ensure_rocfft(ctx);
     if (rc) return rc;
     const size_t per_pair = ((size_t)Fh * Fw * 4 + (size_t)Fh * (Fw / 2 + 1) * 8) * 2;
-    const int nb_max = (int)std::max<size_t>(1, ctx->ncc_arena_limit / per_pair);
+    const int nb_max = quantised_chunk(ctx, N, per_pair);
     CropSrc crop{blk, IH0, IW0, IH1, IW1};
     for (int n0 = 0; n0 < N; n0 += nb_max) {
         const int nb = std::min(nb_max, N - n0);
         crop.blk = blk + (size_t)n0 * kBlkStride;
-        rc = ncc_stream_subbatch(ctx, imgs0, imgs1, nb, 1, 0, 0, 0, 0, Fh, Fw, subpixel, conf_mode, dx + n0, dy + n0, conf + n0, &crop);
+        rc = ncc_stream_subbatch(ctx, imgs0, imgs1, nb, 1, 0, 0, 0, 0, Fh, Fw, subpixel, conf_mode, dx + n0, dy + n0, conf + n0, &crop, nb_max);
         if (rc) return rc;
     }
     return FB_OK;

@@ -141,91 +141,106 @@ class StripBatchMatcher:
         return blk, bb
 
     def _match_round(self, tx, ty, active, spacing, mnb, pad_flags, subpixel):
-        """one spacing round for the `active` pairs; returns per-pair lists of (bboxes, dx, dy, conf)"""
+        """one spacing round for the `active` pairs.  Returns a list of groups
+        (pair ids [Q], bboxes [Q, nblk, 4], dx, dy, conf [Q, nblk])."""
         lib, ctx = _lib.load(), _lib.ctx()
         n, H, W = self.P, self.H, self.W
-        out = {}
         # group by block grid, then by FFT shape (matcher.py:59-62 on the block size)
         xmin = np.maximum(-0.5 + tx, -0.5); xmax = np.minimum(W - 0.5 + tx, W - 0.5)
         ymin = np.maximum(-0.5 + ty, -0.5); ymax = np.minimum(H - 0.5 + ty, H - 0.5)
         nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
-        fh = np.array([next_fast_len(2 * v - 1 if p else v) for v, p in zip(dy, pad_flags)])
-        fw = np.array([next_fast_len(2 * v - 1 if p else v) for v, p in zip(dx, pad_flags)])
-        key = np.stack((nx, ny, fh, fw), axis=-1)
-        key[~active] = -1
-        groups = {}
-        for p in np.flatnonzero(active):
-            groups.setdefault(tuple(key[p]), []).append(p)
+        nfl_h = np.array([next_fast_len(v) for v in range(0, 2 * H + 2)])
+        nfl_w = nfl_h if W == H else np.array([next_fast_len(v) for v in range(0, 2 * W + 2)])
+        fh = np.where(pad_flags, nfl_h[np.clip(2 * dy - 1, 0, None)], nfl_h[dy])
+        fw = np.where(pad_flags, nfl_w[np.clip(2 * dx - 1, 0, None)], nfl_w[dx])
+        key = ((nx * 4096 + ny) * 8192 + fh) * 8192 + fw
+        key = np.where(active, key, -1)
+        groups = []
         dogf = self.d_dogf_view
         img1 = dogf.offset(n * H * W * 4)
-        for (gnx, gny, gfh, gfw), members in groups.items():
-            sel = np.array(members)
+        for kv in np.unique(key):
+            if kv < 0:
+                continue
+            sel = np.flatnonzero(key == kv)
+            gfh, gfw = int(fh[sel[0]]), int(fw[sel[0]])
             blk, bb = self._blocks(tx, ty, sel, spacing, mnb)
             nb = blk.shape[0] * blk.shape[1]
             assert nb <= self.max_blocks
             flat = np.ascontiguousarray(blk.reshape(-1, 9))
             _lib.check(lib.fb_memcpy_h2d(ctx, self.d_blk.ptr, _lib.ptr(flat), flat.nbytes))
-            _lib.check(lib.fb_ncc_blocks_dev(ctx, dogf.ptr, img1, H, W, H, W, nb, self.d_blk.ptr, int(gfh), int(gfw),
+            _lib.check(lib.fb_ncc_blocks_dev(ctx, dogf.ptr, img1, H, W, H, W, nb, self.d_blk.ptr, gfh, gfw,
                                              1 if subpixel else 0, self.conf_mode, self.d_dx.ptr, self.d_dy.ptr, self.d_cf.ptr))
             ddx = self.d_dx.to_array((nb,), np.float64).reshape(sel.size, -1)
             ddy = self.d_dy.to_array((nb,), np.float64).reshape(sel.size, -1)
             dcf = self.d_cf.to_array((nb,), np.float32).reshape(sel.size, -1)
-            for k, p in enumerate(sel):
-                out[int(p)] = (bb[k], ddx[k], ddy[k], dcf[k])
-        return out
+            groups.append((sel, bb, ddx, ddy, dcf))
+        return groups
 
     # ------------------------------------------------------------------ driver
     def match(self, strips0, strips1):
-        """strips0/strips1: device pointers to uint8 [P][H][W].  Returns a list of per-pair dicts."""
+        """strips0/strips1: device pointers to uint8 [P][H][W].  Returns a dict of arrays:
+        tx, ty, conf0, valid, needs_host [P]; the match table as flat arrays pair, xy0, xy1, weight
+        (rows of one pair are contiguous, pairs in ascending order within a block-grid group)."""
         n = self.P
         tx, ty, cf0 = self._global(strips0, strips1)
         scale = 1.0 / self.cds
         tx = tx * scale; ty = ty * scale                     # matcher.py:338-339
-        ok = cf0 >= self.conf_thresh                         # matcher.py:277-278
+        active = cf0 >= self.conf_thresh                     # matcher.py:277-278
         self._fine_dog(strips0, strips1)
-        results = [dict(tx=tx[p], ty=ty[p], conf0=float(cf0[p]), xy0=None, xy1=None, weight=None, needs_host=False)
-                   for p in range(n)]
         spacings = self.spacings
-        sp_indx = np.zeros(n, dtype=np.int64)
         pad = np.ones(n, dtype=bool)
-        active = ok.copy()
-        last = {}
+        needs_host = np.zeros(n, dtype=bool)
+        has_last = np.zeros(n, dtype=bool)
+        table = None
+        txy = np.stack((tx, ty), axis=-1)
         for rnd in range(spacings.size):
-            # every active pair sits at spacing index `rnd` (pairs that would skip ahead are handled below)
             sp = spacings[rnd]
             is_last = rnd == spacings.size - 1
             mnb = self.mnb if is_last else 1
-            res = self._match_round(tx, ty, active, sp, mnb, pad, subpixel=is_last)
-            for p, (bb, ddx, ddy, dcf) in res.items():
+            rows = []
+            for sel, bb, ddx, ddy, dcf in self._match_round(tx, ty, active, sp, mnb, pad, subpixel=is_last):
                 keep = dcf > self.conf_thresh                # matcher.py:671-683
-                if not np.any(keep):
-                    if rnd == 0:
-                        active[p] = False                    # invalid_output (matcher.py:672-673)
-                    continue
-                ctr = 0.5 * np.stack((bb[:, 0] + bb[:, 2], bb[:, 1] + bb[:, 3]), axis=-1) - 0.5      # bbox_centers
+                anyk = keep.any(axis=1)
+                if rnd == 0:
+                    active[sel[~anyk]] = False               # invalid_output (matcher.py:672-673)
+                ctr = 0.5 * np.stack((bb[..., 0] + bb[..., 2], bb[..., 1] + bb[..., 3]), axis=-1) - 0.5      # bbox_centers
                 dxy = np.stack((ddx, ddy), axis=-1)
-                xy0 = (ctr - dxy * 0.5)[keep]                # equal block sizes: ratio 0.5 (matcher.py:844-849)
-                xy1 = (ctr + dxy * 0.5)[keep]
-                max_dis = np.max(np.sum((xy0 - xy1) ** 2, axis=-1)) ** 0.5
-                last[p] = (xy0, xy1, dcf[keep], max_dis)
+                xy0 = ctr - dxy * 0.5                        # equal block sizes: ratio 0.5 (matcher.py:844-849)
+                xy1 = ctr + dxy * 0.5
+                dis2 = np.where(keep, np.sum((xy0 - xy1) ** 2, axis=-1), -1.0)
+                max_dis = np.sqrt(np.maximum(dis2.max(axis=1), 0.0))
                 if not is_last:
-                    # spacing schedule (matcher.py:689-716)
+                    # spacing schedule (matcher.py:689-716), max_spacing_skip = 0
                     next_pos = np.searchsorted(-spacings, -4 * max_dis) - 1
-                    if next_pos > rnd:
-                        pad[p] = min(next_pos, rnd + 1) > rnd + 1          # always False with max_spacing_skip = 0
-                    else:
-                        pad[p] = True
-                    if max_dis > 0.1:
-                        # the reference relaxes the mesh here and crops the next round through the deformed
-                        # mesh (matcher.py:725-742): not on the device path yet
-                        results[p]['needs_host'] = True
-        for p, (xy0, xy1, wt, max_dis) in last.items():
-            if not active[p]:
-                continue
-            r = results[p]
-            # output in the INITIAL gear: mesh0 points lose the translation (matcher.py:748-751)
-            r['xy0'] = xy0 - np.array([tx[p], ty[p]])
-            r['xy1'] = xy1
-            r['weight'] = wt
-            r['max_dis'] = max_dis
-        return results
+                    pad[sel] = np.where(next_pos > rnd, np.minimum(next_pos, rnd + 1) > rnd + 1, True)
+                    # max_dis > 0.1: the reference relaxes the mesh and crops the next round through the
+                    # deformed mesh (matcher.py:725-742) -- not on the device path yet
+                    needs_host[sel[anyk & (max_dis > 0.1)]] = True
+                pid = np.broadcast_to(sel[:, None], keep.shape)
+                rows.append((pid[keep], xy0[keep], xy1[keep], dcf[keep]))
+                has_last[sel[anyk]] = True
+            if rows:
+                table = tuple(np.concatenate([r[k] for r in rows], axis=0) for k in range(4))
+        valid = active & has_last
+        if table is None:
+            table = (np.zeros(0, np.int64), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0, np.float32))
+        pid, xy0, xy1, wt = table
+        ok = valid[pid]
+        pid, xy0, xy1, wt = pid[ok], xy0[ok], xy1[ok], wt[ok]
+        # output in the INITIAL gear: mesh0 points lose the translation (matcher.py:748-751)
+        xy0 = xy0 - txy[pid]
+        return dict(tx=tx, ty=ty, conf0=cf0, valid=valid, needs_host=needs_host, pair=pid, xy0=xy0, xy1=xy1, weight=wt)
+
+    @staticmethod
+    def per_pair(res):
+        """split the flat match table into the per-pair tuples stitching_matcher returns"""
+        out = []
+        for p in range(res['tx'].size):
+            m = res['pair'] == p
+            if res['valid'][p]:
+                out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=bool(res['needs_host'][p]),
+                                xy0=res['xy0'][m], xy1=res['xy1'][m], weight=res['weight'][m]))
+            else:
+                out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=False,
+                                xy0=None, xy1=None, weight=None))
+        return out

@@ -24,7 +24,7 @@ def test_pipeline_vs_oracle(fb, H, W, P):
     from feabas_amd.stitch_pipeline import StripBatchMatcher
     s0, s1, shifts = _synth(fb, P, H, W, seed=7, max_shift=12)
     m = StripBatchMatcher(P, H, W)
-    got = m.match(s0.ptr, s1.ptr)
+    got = StripBatchMatcher.per_pair(m.match(s0.ptr, s1.ptr))
     h0 = s0.to_array((P, H, W), np.uint8); h1 = s1.to_array((P, H, W), np.uint8)
     assert h0.std() > 20                                     # real texture
     for p in range(P):
