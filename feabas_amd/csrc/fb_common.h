@@ -51,6 +51,7 @@ struct fb_ctx {
     std::vector<fb_prof_entry> prof;
     std::vector<void*> owned;   // fb_malloc'ed pointers
     size_t ncc_arena_limit = (size_t)8 << 30;
+    bool use_rocfft = false;     // FEABAS_HIP_ROCFFT=1: streaming-class FFTs through rocFFT instead of the hand-written kernels
     bool dog_exact = false;      // double-precision tap accumulation (scipy's arithmetic) instead of the float fast path
 };
 

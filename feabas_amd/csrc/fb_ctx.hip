@@ -1,6 +1,8 @@
 // Context, device memory, stopwatch and per-kernel profile of libfeabas_hip.so.
 #include "fb_common.h"
 
+#include <cstdlib>
+
 int fb_fail(fb_ctx* ctx, int code, const char* fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -77,6 +79,8 @@ fb_ctx* fb_create(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) return nullptr;
     fb_ctx* ctx = new fb_ctx();
     ctx->device = device_id;
+    if (const char* e = getenv("FEABAS_HIP_ROCFFT")) ctx->use_rocfft = atoi(e) != 0;
+    if (const char* e = getenv("FEABAS_HIP_DOG_EXACT")) ctx->dog_exact = atoi(e) != 0;
     if (hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {

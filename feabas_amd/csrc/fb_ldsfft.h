@@ -24,6 +24,8 @@ static inline bool fft_make_plan(int n, FftPlan* p) {
     p->n = n;
     p->nf = 0;
     int m = n;
+    while (m % 16 == 0) { p->radix[p->nf++] = 16; m /= 16; if (p->nf >= kFftMaxFactors) return false; }
+    while (m % 8 == 0) { p->radix[p->nf++] = 8; m /= 8; if (p->nf >= kFftMaxFactors) return false; }
     while (m % 4 == 0) { p->radix[p->nf++] = 4; m /= 4; if (p->nf >= kFftMaxFactors) return false; }
     while (m % 2 == 0) { p->radix[p->nf++] = 2; m /= 2; if (p->nf >= kFftMaxFactors) return false; }
     while (m % 5 == 0) { p->radix[p->nf++] = 5; m /= 5; if (p->nf >= kFftMaxFactors) return false; }
@@ -97,13 +99,92 @@ __device__ __forceinline__ void dft5(float2* v) {
     v[2] = caddf(m2, r2); v[3] = csubf(m2, r2);
 }
 
+// w_16^k = exp(-2 pi i k / 16), k = 0..9 (the products j2 * p1 that occur in the 4 x 4 and 4 x 2 splits)
+__device__ __forceinline__ float2 w16c(int k) {
+    const float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f, h = 0.70710678118654752440f;
+    switch (k) {
+        case 0: return make_float2(1.f, 0.f);
+        case 1: return make_float2(c1, -s1);
+        case 2: return make_float2(h, -h);
+        case 3: return make_float2(s1, -c1);
+        case 4: return make_float2(0.f, -1.f);
+        case 6: return make_float2(-h, -h);
+        case 9: return make_float2(-c1, s1);
+        default: return make_float2(0.f, 0.f);
+    }
+}
+
+// 8-point DFT as 4 x 2 Cooley-Tukey in registers (natural order in and out)
+template <bool INV>
+__device__ __forceinline__ void dft8(float2* v) {
+    float2 a[2][4];
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[j2][q] = v[j2 + 2 * q];
+        dft4<INV>(a[j2]);
+    }
+#pragma unroll
+    for (int p1 = 1; p1 < 4; ++p1) {
+        const float2 w = w16c(2 * p1);                 // w_8^p1
+        a[1][p1] = INV ? cmulcf(a[1][p1], w) : cmulf(a[1][p1], w);
+    }
+#pragma unroll
+    for (int p1 = 0; p1 < 4; ++p1) {
+        v[p1] = caddf(a[0][p1], a[1][p1]);
+        v[p1 + 4] = csubf(a[0][p1], a[1][p1]);
+    }
+}
+
+// 16-point DFT as 4 x 4 Cooley-Tukey in registers
+template <bool INV>
+__device__ __forceinline__ void dft16(float2* v) {
+    float2 a[4][4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[j2][q] = v[j2 + 4 * q];
+        dft4<INV>(a[j2]);
+    }
+#pragma unroll
+    for (int j2 = 1; j2 < 4; ++j2)
+#pragma unroll
+        for (int p1 = 1; p1 < 4; ++p1) {
+            const float2 w = w16c(j2 * p1);
+            a[j2][p1] = INV ? cmulcf(a[j2][p1], w) : cmulf(a[j2][p1], w);
+        }
+#pragma unroll
+    for (int p1 = 0; p1 < 4; ++p1) {
+        float2 b[4];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) b[j2] = a[j2][p1];
+        dft4<INV>(b);
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) v[p1 + 4 * p2] = b[p2];
+    }
+}
+
 template <int R, bool INV>
 __device__ __forceinline__ void dft_r(float2* v) {
     if (R == 2) dft2<INV>(v);
     else if (R == 3) dft3<INV>(v);
     else if (R == 4) dft4<INV>(v);
-    else dft5<INV>(v);
+    else if (R == 5) dft5<INV>(v);
+    else if (R == 8) dft8<INV>(v);
+    else dft16<INV>(v);
 }
+
+// twiddle sources: a full table (small lengths) or a two-level table w^n = hi[n >> 6] * lo[n & 63]
+// (long lengths: 2 x 64 entries instead of N)
+struct TwTable {
+    const float2* t;
+    __device__ __forceinline__ float2 operator()(int n) const { return t[n]; }
+};
+struct TwSplit {
+    const float2* hi;
+    const float2* lo;
+    __device__ __forceinline__ float2 operator()(int n) const { return cmulf(hi[n >> 6], lo[n & 63]); }
+};
 
 // exact t / d for 0 <= t < 2^22 through a float reciprocal (the integer divide costs ~40 VALU instructions)
 __device__ __forceinline__ int fdiv_i(int t, int d, float inv) {
@@ -116,8 +197,8 @@ __device__ __forceinline__ int fdiv_i(int t, int d, float inv) {
 
 // one radix-R pass over M transforms.  L = current block length (multiple of R), Lp = L / R.
 // tw[n] = exp(-2 pi i n / N), n < N (LDS).  All offsets are 32-bit (LDS).
-template <int R, bool INV>
-__device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int ms, int L, const float2* __restrict__ tw,
+template <int R, bool INV, typename TW>
+__device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int ms, int L, const TW& tw,
                                          bool lanes_on_m, int tid, int nthreads) {
     const int Lp = L / R;
     const int per = N / R;                // butterflies per transform
@@ -127,12 +208,13 @@ __device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int
     const int leg = Lp * is;
     // two butterflies per trip: both operand sets are read before either result is written, so the LDS
     // latencies of the pair overlap (the compiler cannot prove the two in-place updates independent)
-    for (int t = tid; t < total; t += 2 * nthreads) {
+    constexpr int U = (R >= 8) ? 1 : 2;
+    for (int t = tid; t < total; t += U * nthreads) {
         const int t2 = t + nthreads;
-        const bool has2 = t2 < total;
-        int off[2], jj[2];
+        const bool has2 = (U == 2) && t2 < total;
+        int off[U], jj[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int tt = u ? (has2 ? t2 : t) : t;
             int m, bj;
             if (lanes_on_m) { bj = fdiv_i(tt, M, inv_M); m = tt - bj * M; }
@@ -141,24 +223,24 @@ __device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int
             jj[u] = bj - b * Lp;
             off[u] = m * ms + (b * L + jj[u]) * is;
         }
-        float2 v[2][R];
+        float2 v[U][R];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int q = 0; q < R; ++q) v[u][q] = base[off[u] + q * leg];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (INV) {
                 if (L > R) {
 #pragma unroll
-                    for (int q = 1; q < R; ++q) v[u][q] = cmulcf(v[u][q], tw[jj[u] * q * tstep]);  // conj twiddle first (DIT)
+                    for (int q = 1; q < R; ++q) v[u][q] = cmulcf(v[u][q], tw(jj[u] * q * tstep));  // conj twiddle first (DIT)
                 }
                 dft_r<R, true>(v[u]);
             } else {
                 dft_r<R, false>(v[u]);
                 if (L > R) {
 #pragma unroll
-                    for (int q = 1; q < R; ++q) v[u][q] = cmulf(v[u][q], tw[jj[u] * q * tstep]);   // twiddle after (DIF)
+                    for (int q = 1; q < R; ++q) v[u][q] = cmulf(v[u][q], tw(jj[u] * q * tstep));   // twiddle after (DIF)
                 }
             }
         }
@@ -166,21 +248,23 @@ __device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int
         for (int q = 0; q < R; ++q) base[off[0] + q * leg] = v[0][q];
         if (has2) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) base[off[1] + q * leg] = v[1][q];
+            for (int q = 0; q < R; ++q) base[off[U - 1] + q * leg] = v[U - 1][q];
         }
     }
 }
 
 // full batched transform; every pass ends with a workgroup barrier
-template <bool INV>
-__device__ __forceinline__ void fft_batch(float2* base, const FftPlan& plan, int M, int is, int ms, const float2* tw, bool lanes_on_m) {
+template <bool INV, typename TW>
+__device__ __forceinline__ void fft_batch_tw(float2* base, const FftPlan& plan, int M, int is, int ms, const TW& tw, bool lanes_on_m) {
     const int N = plan.n;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (!INV) {
         int L = N;
         for (int s = 0; s < plan.nf; ++s) {
             const int r = plan.radix[s];
-            if (r == 4) fft_pass<4, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            if (r == 16) fft_pass<16, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 8) fft_pass<8, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 4) fft_pass<4, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 2) fft_pass<2, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 5) fft_pass<5, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else fft_pass<3, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
@@ -192,11 +276,18 @@ __device__ __forceinline__ void fft_batch(float2* base, const FftPlan& plan, int
         for (int s = plan.nf - 1; s >= 0; --s) {
             const int r = plan.radix[s];
             L *= r;
-            if (r == 4) fft_pass<4, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            if (r == 16) fft_pass<16, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 8) fft_pass<8, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 4) fft_pass<4, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 2) fft_pass<2, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 5) fft_pass<5, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else fft_pass<3, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             __syncthreads();
         }
     }
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft_batch(float2* base, const FftPlan& plan, int M, int is, int ms, const float2* tw, bool lanes_on_m) {
+    fft_batch_tw<INV>(base, plan, M, is, ms, TwTable{tw}, lanes_on_m);
 }

@@ -2,9 +2,13 @@
 // pad-load, spectral-multiply and peak-reduction kernels around it.
 // Replaces matcher.xcorr_fft (feabas/matcher.py:22-135); numerics per SURVEY.md A.1.
 #include "fb_common.h"
+#include "fb_ldsfft.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <map>
+#include <vector>
 
 namespace {
 
@@ -146,7 +150,8 @@ __device__ __forceinline__ double round_half_even(double x) { return rint(x); }
 // stage 2: combine partials; sub-pixel fit; confidence (matcher.py:82-134)
 __global__ void ncc_peak_final(const float* __restrict__ Csurf, const PeakPartial* __restrict__ part, int nchunks,
                                int Fh, int Fw, int H0, int W0, int H1, int W1, const int* __restrict__ blk, int subpixel, int conf_mode,
-                               double* __restrict__ dx, double* __restrict__ dy, float* __restrict__ conf, int N) {
+                               double* __restrict__ dx, double* __restrict__ dy, float* __restrict__ conf, int N,
+                               const float* __restrict__ ct9 = nullptr) {
 #pragma clang fp contract(off)
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
@@ -165,12 +170,16 @@ __global__ void ncc_peak_final(const float* __restrict__ Csurf, const PeakPartia
     const int py = iv / Fw, px = iv - py * Fw;
     double ddx = (double)px, ddy = (double)py;
     if (subpixel) {
-        const float* c = Csurf + (size_t)n * Fh * Fw;
         float ct[9];
-        for (int j = 0; j < 9; ++j) {
-            int yy = py + (j / 3 - 1), xx = px + (j % 3 - 1);
-            yy = (yy + Fh) % Fh; xx = (xx + Fw) % Fw;
-            ct[j] = c[(size_t)yy * Fw + xx];
+        if (Csurf) {
+            const float* c = Csurf + (size_t)n * Fh * Fw;
+            for (int j = 0; j < 9; ++j) {
+                int yy = py + (j / 3 - 1), xx = px + (j % 3 - 1);
+                yy = (yy + Fh) % Fh; xx = (xx + Fw) % Fw;
+                ct[j] = c[(size_t)yy * Fw + xx];
+            }
+        } else {
+            for (int j = 0; j < 9; ++j) ct[j] = ct9[(size_t)n * 9 + j];
         }
         const float tx = (ct[5] - ct[3]) / 2.f;
         const float ty = (ct[7] - ct[1]) / 2.f;
@@ -365,6 +374,312 @@ int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     return FB_OK;
 }
 
+
+// =============================================================================================
+// Streaming class without rocFFT: three hand-written kernels per batch.
+//   rows : packed R2C along x of the NON-ZERO rows only (both images ride one complex FFT),
+//          spectra stored transposed  T[n][kx][y], y < Hs
+//   cols : per (n, kx): zero-pad to Fh, forward FFT of both columns, conj/plain products,
+//          inverse FFT, stored  V[n][kx][y], y < Fh
+//   inv  : per tile of rows: Hermitian-extend + pack W = P + iQ, inverse FFT along x, reduce
+//          max/arg-max of C, max |Cm| (the correlation surfaces are never written)
+// HBM traffic per block pair = inputs + 16 S_h (T write) + 16 S_h (T read) + 16 S (V write)
+// + 16 S (V read), S = Fh (Fw/2+1), S_h = Hs (Fw/2+1): the algorithmic minimum of SURVEY.md 8(d).
+struct StreamGeom {
+    int N, Fh, Fw, Sw, Hs, TR, TRI;
+    int H0, W0, H1, W1;
+    FftPlan pw, ph;
+    const float2 *twW_hi, *twW_lo, *twH_hi, *twH_lo;
+    const float* img0;
+    const float* img1;
+    const int* blk;
+    int IH0, IW0, IH1, IW1;
+    int want_q, want_std;
+};
+
+constexpr int kStreamThreads = 512;
+
+__device__ __forceinline__ void load_tw(float2* hi, float2* lo, const float2* ghi, const float2* glo) {
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) { hi[i] = ghi[i]; lo[i] = glo[i]; }
+}
+
+__global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGeom g, float2* __restrict__ T0, float2* __restrict__ T1) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int Fw = g.Fw, Sw = g.Sw, TR = g.TR, pitch = Fw + 1;
+    float2* G = lds;
+    float2* thi = G + (size_t)TR * pitch;
+    float2* tlo = thi + 64;
+    short* posW = reinterpret_cast<short*>(tlo + 64);
+    const int n = blockIdx.y, y0 = blockIdx.x * TR;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int h0 = g.H0, w0 = g.W0, h1 = g.H1, w1 = g.W1, ox0 = 0, oy0 = 0, ox1 = 0, oy1 = 0;
+    int p0 = w0, p1 = w1, my0 = h0 - 1, mx0 = w0 - 1, my1 = h1 - 1, mx1 = w1 - 1;
+    const float* s0; const float* s1;
+    if (g.blk) {
+        const int* d = g.blk + (size_t)n * kBlkStride;
+        s0 = g.img0 + (size_t)d[0] * g.IH0 * g.IW0;
+        s1 = g.img1 + (size_t)d[0] * g.IH1 * g.IW1;
+        ox0 = d[1]; oy0 = d[2]; h0 = d[3]; w0 = d[4]; ox1 = d[5]; oy1 = d[6]; h1 = d[7]; w1 = d[8];
+        p0 = g.IW0; p1 = g.IW1; my0 = g.IH0 - 1; mx0 = g.IW0 - 1; my1 = g.IH1 - 1; mx1 = g.IW1 - 1;
+    } else {
+        s0 = g.img0 + (size_t)n * h0 * w0;
+        s1 = g.img1 + (size_t)n * h1 * w1;
+    }
+    load_tw(thi, tlo, g.twW_hi, g.twW_lo);
+    for (int i = tid; i < Fw; i += nt) posW[i] = (short)fft_pos(g.pw, i);
+    // packed load z = img0 + i img1 (zero padded), branch-free
+    for (int r = 0; r < TR; ++r) {
+        const int y = y0 + r;
+        const int gy0 = oy0 + y, gy1 = oy1 + y;
+        const bool vy0 = y < h0 && gy0 >= 0 && gy0 <= my0, vy1 = y < h1 && gy1 >= 0 && gy1 <= my1;
+        const float* r0 = s0 + (size_t)min(max(gy0, 0), my0) * p0;
+        const float* r1 = s1 + (size_t)min(max(gy1, 0), my1) * p1;
+        for (int x = tid; x < Fw; x += nt) {
+            const int gx0 = ox0 + x, gx1 = ox1 + x;
+            const float a = r0[min(max(gx0, 0), mx0)], b = r1[min(max(gx1, 0), mx1)];
+            const bool v0 = vy0 && x < w0 && gx0 >= 0 && gx0 <= mx0;
+            const bool v1 = vy1 && x < w1 && gx1 >= 0 && gx1 <= mx1;
+            G[r * pitch + x] = make_float2(v0 ? a : 0.f, v1 ? b : 0.f);
+        }
+    }
+    __syncthreads();
+    fft_batch_tw<false>(G, g.pw, TR, 1, pitch, TwSplit{thi, tlo}, false);
+    // split the packed spectra and store transposed: lanes walk the TR rows (contiguous in T)
+    const size_t tbase = (size_t)n * Sw * g.Hs;
+    for (int t = tid; t < Sw * TR; t += nt) {
+        const int r = t & (TR - 1), kx = t / TR;
+        const float2 zk = G[r * pitch + posW[kx]];
+        const float2 zn = G[r * pitch + posW[kx == 0 ? 0 : Fw - kx]];
+        const size_t o = tbase + (size_t)kx * g.Hs + y0 + r;
+        T0[o] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        T1[o] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    }
+}
+
+__global__ __launch_bounds__(256) void ncc_stream_cols(const StreamGeom g, const float2* __restrict__ T0, const float2* __restrict__ T1,
+                                                       float2* __restrict__ V0, float2* __restrict__ V1) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int Fh = g.Fh, pitch = Fh + 1;
+    float2* U = lds;                      // [2][pitch]
+    float2* thi = U + 2 * (size_t)pitch;
+    float2* tlo = thi + 64;
+    const int kx = blockIdx.x, n = blockIdx.y;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    load_tw(thi, tlo, g.twH_hi, g.twH_lo);
+    const size_t tb = ((size_t)n * g.Sw + kx) * g.Hs;
+    for (int y = tid; y < Fh; y += nt) {
+        const bool in = y < g.Hs;
+        U[y] = in ? T0[tb + y] : make_float2(0.f, 0.f);
+        U[pitch + y] = in ? T1[tb + y] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    fft_batch_tw<false>(U, g.ph, 2, 1, pitch, TwSplit{thi, tlo}, false);
+    for (int y = tid; y < Fh; y += nt) {
+        const float2 a = U[y], b = U[pitch + y];
+        U[y] = make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+        U[pitch + y] = g.want_q ? make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    fft_batch_tw<true>(U, g.ph, g.want_q ? 2 : 1, 1, pitch, TwSplit{thi, tlo}, false);
+    const size_t vb = ((size_t)n * g.Sw + kx) * Fh;
+    for (int y = tid; y < Fh; y += nt) {
+        V0[vb + y] = U[y];
+        if (g.want_q) V1[vb + y] = U[pitch + y];
+    }
+}
+
+// rows_sel == nullptr: tile of TRI consecutive rows, reduce into part[n][tile].
+// rows_sel != nullptr (sub-pixel neighbours): 3 rows around the peak of block n, outputs ct9.
+__global__ __launch_bounds__(kStreamThreads) void ncc_stream_inv(const StreamGeom g, const float2* __restrict__ V0, const float2* __restrict__ V1,
+                                                                 PeakPartial* __restrict__ part, const PeakPartial* __restrict__ part_in,
+                                                                 int nparts, float* __restrict__ ct9) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int Fh = g.Fh, Fw = g.Fw, Sw = g.Sw, pitch = Fw + 1;
+    const bool neigh = ct9 != nullptr;
+    const int TRI = neigh ? 4 : g.TRI;
+    float2* G = lds;
+    float2* thi = G + (size_t)TRI * pitch;
+    float2* tlo = thi + 64;
+    short* posW = reinterpret_cast<short*>(tlo + 64);
+    __shared__ float sv[kStreamThreads / 64]; __shared__ int si[kStreamThreads / 64]; __shared__ float sm[kStreamThreads / 64];
+    __shared__ double ssum[kStreamThreads / 64]; __shared__ double ssq[kStreamThreads / 64];
+    __shared__ int s_peak;
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    load_tw(thi, tlo, g.twW_hi, g.twW_lo);
+    for (int i = tid; i < Fw; i += nt) posW[i] = (short)fft_pos(g.pw, i);
+    int y0 = blockIdx.x * TRI;
+    int py = 0, px = 0;
+    if (neigh) {
+        if (tid == 0) {
+            const PeakPartial* p = part_in + (size_t)n * nparts;
+            float v = p[0].vmax; int iv = p[0].imax;
+            for (int c = 1; c < nparts; ++c) peak_merge(v, iv, p[c].vmax, p[c].imax);
+            if (iv == 0x7fffffff) iv = 0;
+            s_peak = iv;
+        }
+        __syncthreads();
+        py = s_peak / Fw; px = s_peak - py * Fw;
+    }
+    __syncthreads();
+    const int nmir = Fw - Sw;
+    const size_t vb = (size_t)n * Sw * Fh;
+    for (int t = tid; t < Sw * TRI; t += nt) {
+        const int r = t & (TRI - 1), kx = t / TRI;
+        int y = y0 + r;
+        bool ok = y < Fh;
+        if (neigh) { y = (py + r - 1 + Fh) % Fh; ok = r < 3; }
+        float2 pk = make_float2(0.f, 0.f), qk = make_float2(0.f, 0.f);
+        if (ok) {
+            pk = V0[vb + (size_t)kx * Fh + y];
+            if (g.want_q) qk = V1[vb + (size_t)kx * Fh + y];
+        }
+        const bool self = (kx == 0) || (2 * kx == Fw);
+        G[r * pitch + posW[kx]] = self ? make_float2(pk.x, qk.x) : make_float2(pk.x - qk.y, pk.y + qk.x);
+        if (kx >= 1 && kx <= nmir) G[r * pitch + posW[Fw - kx]] = make_float2(pk.x + qk.y, qk.x - pk.y);
+    }
+    __syncthreads();
+    fft_batch_tw<true>(G, g.pw, TRI, 1, pitch, TwSplit{thi, tlo}, false);
+    if (neigh) {
+        if (tid < 9) ct9[(size_t)n * 9 + tid] = G[(tid / 3) * pitch + (px + (tid % 3 - 1) + Fw) % Fw].x;
+        return;
+    }
+    float v = -INFINITY; int iv = 0x7fffffff; float mm = 0.f;
+    double s = 0.0, ss = 0.0;
+    for (int r = 0; r < TRI; ++r) {
+        const int y = y0 + r;
+        if (y >= Fh) break;
+        for (int x = tid; x < Fw; x += nt) {
+            const float2 c = G[r * pitch + x];
+            if (c.x > v) { v = c.x; iv = y * Fw + x; }
+            mm = fmaxf(mm, fabsf(c.y));
+            if (g.want_std) { s += (double)c.x; ss += (double)c.x * (double)c.x; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float v2 = __shfl_down(v, off);
+        const int i2 = __shfl_down(iv, off);
+        peak_merge(v, iv, v2, i2);
+        mm = fmaxf(mm, __shfl_down(mm, off));
+        if (g.want_std) { s += __shfl_down(s, off); ss += __shfl_down(ss, off); }
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) { sv[wave] = v; si[wave] = iv; sm[wave] = mm; ssum[wave] = s; ssq[wave] = ss; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (int)(nt >> 6); ++w) {
+            peak_merge(v, iv, sv[w], si[w]);
+            mm = fmaxf(mm, sm[w]);
+            s += ssum[w]; ss += ssq[w];
+        }
+        PeakPartial p; p.vmax = v; p.imax = iv; p.mmax = mm; p.pad_ = 0; p.sum = s; p.sumsq = ss;
+        part[(size_t)n * gridDim.x + blockIdx.x] = p;
+    }
+}
+
+std::map<std::pair<int, int>, std::pair<float2*, float2*>> g_split_tables;
+
+int get_split_table(fb_ctx* ctx, int n, const float2** hi, const float2** lo) {
+    auto key = std::make_pair(ctx->device, n);
+    auto it = g_split_tables.find(key);
+    if (it == g_split_tables.end()) {
+        std::vector<float2> h(128);
+        for (int k = 0; k < 64; ++k) {
+            const double a = -2.0 * M_PI * (double)(64 * k) / (double)n, b = -2.0 * M_PI * (double)k / (double)n;
+            h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+            h[64 + k] = make_float2((float)std::cos(b), (float)std::sin(b));
+        }
+        float2* d = nullptr;
+        FB_HIP(ctx, hipMalloc((void**)&d, sizeof(float2) * 128));
+        FB_HIP(ctx, hipMemcpy(d, h.data(), sizeof(float2) * 128, hipMemcpyHostToDevice));
+        it = g_split_tables.emplace(key, std::make_pair(d, d + 64)).first;
+    }
+    *hi = it->second.first; *lo = it->second.second;
+    return FB_OK;
+}
+
+int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+
+bool stream_custom_supported(int Fh, int Fw, int C) {
+    if (C != 1 || Fw > 4096 || Fh > 4096 || Fw < 4 || Fh < 2) return false;   // 2-level twiddles cover N <= 4096; posW is int16
+    FftPlan p;
+    return fft_make_plan(Fh, &p) && fft_make_plan(Fw, &p);
+}
+
+// sub-batch of nb block pairs through the three custom kernels
+int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int nb, int H0, int W0, int H1, int W1, int hmax, int Fh,
+                        int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf, const CropSrc* crop) {
+    StreamGeom g;
+    g.N = nb; g.Fh = Fh; g.Fw = Fw; g.Sw = Fw / 2 + 1;
+    const size_t lds_budget = (getenv("FB_TRB") ? (size_t)atoi(getenv("FB_TRB")) : 70) * 1024;
+    g.TR = std::min(16, pow2_floor((int)std::max<size_t>(1, lds_budget / ((size_t)(Fw + 1) * sizeof(float2)))));
+    g.TRI = g.TR;
+    const int rows = std::min(Fh, std::max(1, hmax));
+    g.Hs = (rows + g.TR - 1) / g.TR * g.TR;
+    g.H0 = H0; g.W0 = W0; g.H1 = H1; g.W1 = W1;
+    if (!fft_make_plan(Fw, &g.pw) || !fft_make_plan(Fh, &g.ph)) return fb_fail(ctx, FB_ERR_ARG, "ncc: FFT shape %dx%d is not 5-smooth", Fh, Fw);
+    int rc = get_split_table(ctx, Fw, &g.twW_hi, &g.twW_lo);
+    if (rc) return rc;
+    rc = get_split_table(ctx, Fh, &g.twH_hi, &g.twH_lo);
+    if (rc) return rc;
+    g.img0 = img0; g.img1 = img1;
+    g.blk = crop ? crop->blk : nullptr;
+    g.IH0 = crop ? crop->IH0 : 0; g.IW0 = crop ? crop->IW0 : 0; g.IH1 = crop ? crop->IH1 : 0; g.IW1 = crop ? crop->IW1 : 0;
+    g.want_q = conf_mode == FB_CONF_MIRROR;
+    g.want_std = conf_mode == FB_CONF_STD;
+    const size_t nT = (size_t)nb * g.Sw * g.Hs, nV = (size_t)nb * g.Sw * Fh;
+    const int ntiles = (Fh + g.TRI - 1) / g.TRI;
+    size_t off = 0;
+    const size_t oT0 = off; off += align_up(nT * sizeof(float2), 256);
+    const size_t oT1 = off; off += align_up(nT * sizeof(float2), 256);
+    const size_t oV0 = off; off += align_up(nV * sizeof(float2), 256);
+    const size_t oV1 = off; off += align_up(nV * sizeof(float2), 256);
+    const size_t oP = off; off += align_up((size_t)nb * ntiles * sizeof(PeakPartial), 256);
+    const size_t oC = off; off += align_up((size_t)nb * 9 * sizeof(float), 256);
+    rc = fb_arena_reserve(ctx, off);
+    if (rc) return rc;
+    char* base = (char*)ctx->arena;
+    float2 *T0 = (float2*)(base + oT0), *T1 = (float2*)(base + oT1), *V0 = (float2*)(base + oV0), *V1 = (float2*)(base + oV1);
+    PeakPartial* part = (PeakPartial*)(base + oP);
+    float* ct9 = (float*)(base + oC);
+    const size_t lds_rows = ((size_t)g.TR * (Fw + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
+    const size_t lds_cols = (2 * (size_t)(Fh + 1) + 128) * sizeof(float2);
+    const size_t lds_inv = ((size_t)g.TRI * (Fw + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
+    FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+    FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
+    FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_inv, ((size_t)4 * (Fw + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) * sizeof(short))));
+    {
+        FB_PROF(ctx, "ncc_stream_rows");
+        hipLaunchKernelGGL(ncc_stream_rows, dim3(g.Hs / g.TR, nb), dim3(kStreamThreads), lds_rows, ctx->stream, g, T0, T1);
+    }
+    {
+        FB_PROF(ctx, "ncc_stream_cols");
+        hipLaunchKernelGGL(ncc_stream_cols, dim3(g.Sw, nb), dim3(256), lds_cols, ctx->stream, g, T0, T1, V0, V1);
+    }
+    {
+        FB_PROF(ctx, "ncc_stream_inv");
+        hipLaunchKernelGGL(ncc_stream_inv, dim3(ntiles, nb), dim3(kStreamThreads), lds_inv, ctx->stream, g, V0, V1, part, nullptr, 0, nullptr);
+    }
+    if (subpixel) {
+        FB_PROF(ctx, "ncc_stream_neighbors");
+        const size_t lds_n = ((size_t)4 * (Fw + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
+        hipLaunchKernelGGL(ncc_stream_inv, dim3(1, nb), dim3(kStreamThreads), lds_n, ctx->stream, g, V0, V1, nullptr, part, ntiles, ct9);
+    }
+    {
+        FB_PROF(ctx, "ncc_peak_final");
+        hipLaunchKernelGGL(ncc_peak_final, dim3(fb_cdiv(nb, 64)), dim3(64), 0, ctx->stream, (const float*)nullptr, part, ntiles, Fh, Fw, H0, W0, H1,
+                           W1, crop ? crop->blk : (const int*)nullptr, subpixel, conf_mode, dx, dy, conf, nb, subpixel ? ct9 : (const float*)nullptr);
+    }
+    FB_HIP(ctx, hipGetLastError());
+    ctx->last_C = nullptr; ctx->last_Cm = nullptr;
+    return FB_OK;
+}
+
+size_t custom_bytes_per_pair(int Fh, int Fw, int hmax) {
+    const size_t Sw = Fw / 2 + 1;
+    return 2 * Sw * (size_t)(std::min(Fh, hmax) + 16) * 8 + 2 * Sw * (size_t)Fh * 8 + 4096;
+}
+
 }  // namespace
 
 extern "C" {
@@ -395,6 +710,17 @@ int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, i
     FB_CHECK_ARG(ctx, (long long)Fh * Fw < (1LL << 31));
     if (C == 1 && fb_ncc_small_supported(Fh, Fw, H0, W0, H1, W1, C))
         return fb_ncc_small_launch(ctx, img0, img1, N, H0, W0, H1, W1, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
+    if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, C)) {
+        const int hmax = std::max(H0, H1);
+        const int nb_max = (int)std::max<size_t>(1, ctx->ncc_arena_limit / custom_bytes_per_pair(Fh, Fw, hmax));
+        for (int n0 = 0; n0 < N; n0 += nb_max) {
+            const int nb = std::min(nb_max, N - n0);
+            int rc2 = ncc_custom_subbatch(ctx, img0 + (size_t)n0 * H0 * W0, img1 + (size_t)n0 * H1 * W1, nb, H0, W0, H1, W1, hmax, Fh, Fw,
+                                          subpixel, conf_mode, dx + n0, dy + n0, conf + n0, nullptr);
+            if (rc2) return rc2;
+        }
+        return FB_OK;
+    }
     int rc = ensure_rocfft(ctx);
     if (rc) return rc;
     // sub-batch so that the arena stays under the limit
@@ -441,7 +767,7 @@ int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C
 }
 
 int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1, int N,
-                      const int* blk, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
+                      const int* blk, int hmax, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
     FB_CHECK_ARG(ctx, N >= 0 && IH0 > 0 && IW0 > 0 && IH1 > 0 && IW1 > 0 && Fh > 0 && Fw > 0);
     FB_CHECK_ARG(ctx, conf_mode >= 0 && conf_mode <= 2 && (long long)Fh * Fw < (1LL << 31));
     if (N == 0) return FB_OK;
@@ -449,6 +775,18 @@ int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int I
     FB_HIP(ctx, hipSetDevice(ctx->device));
     if (fb_ncc_small_supported(Fh, Fw, 0, 0, 0, 0, 1))
         return fb_ncc_small_launch_ex(ctx, imgs0, imgs1, N, 0, 0, 0, 0, blk, IH0, IW0, IH1, IW1, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
+    if (hmax <= 0 || hmax > Fh) hmax = Fh;
+    if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, 1)) {
+        const int nbm = (int)std::max<size_t>(1, ctx->ncc_arena_limit / custom_bytes_per_pair(Fh, Fw, hmax));
+        CropSrc cs{blk, IH0, IW0, IH1, IW1};
+        for (int n0 = 0; n0 < N; n0 += nbm) {
+            const int nb = std::min(nbm, N - n0);
+            cs.blk = blk + (size_t)n0 * kBlkStride;
+            int rc2 = ncc_custom_subbatch(ctx, imgs0, imgs1, nb, 0, 0, 0, 0, hmax, Fh, Fw, subpixel, conf_mode, dx + n0, dy + n0, conf + n0, &cs);
+            if (rc2) return rc2;
+        }
+        return FB_OK;
+    }
     int rc = ensure_rocfft(ctx);
     if (rc) return rc;
     const size_t per_pair = ((size_t)Fh * Fw * 4 + (size_t)Fh * (Fw / 2 + 1) * 8) * 2;

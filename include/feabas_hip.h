@@ -99,9 +99,10 @@ int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, i
  * [P][IH1][IW1] float32 (DoG output); blk [N][9] int32 = {image, x0, y0, h0, w0, x1, y1, h1, w1}:
  * block n correlates the h0 x w0 window at (x0,y0) of imgs0[image] with the h1 x w1 window at
  * (x1,y1) of imgs1[image]; pixels outside an image read 0 (dal.StreamLoader fillval).  All blocks
- * of a call share the FFT shape (Fh, Fw) the caller derives with the rule of matcher.py:59-62. */
+ * of a call share the FFT shape (Fh, Fw) the caller derives with the rule of matcher.py:59-62;
+ * hmax = upper bound of the block heights (0 = unknown). */
 int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1,
-                      int N, const int* blk, int Fh, int Fw, int subpixel, int conf_mode,
+                      int N, const int* blk, int hmax, int Fh, int Fw, int subpixel, int conf_mode,
                       double* dx, double* dy, float* conf);
 /* debugging / parity aid: the two correlation surfaces (un-normalised) of the
  * last fb_ncc_batch* call that went through the streaming (rocFFT) class. */

@@ -23,3 +23,10 @@ for (h, w, pad) in ((75, 73, 0), (72, 72, 0), (64, 64, 0), (75, 73, 1)):
     for N in (1, 256, 768, 1536, 7680, 24640):
         t = run(N, h, w, pad)
         print(f'{h}x{w} pad={pad} N={N:6d}: {t:8.3f} ms  {1e3*t/N:8.2f} us/block  {N/t/1e3*1e3:10.0f} blocks/s')
+print('--- streaming class')
+for (h, w, N) in ((1024, 510, 128), (1024, 490, 64), (2048, 255, 32), (510, 1024, 128), (255, 2048, 32), (280, 280, 400)):
+    t = run(N, h, w, 1, sub=0, reps=3)
+    from feabas_amd.matcher import next_fast_len as nfl
+    fh, fw = nfl(2 * h - 1), nfl(2 * w - 1)
+    alg = N * (2 * h * w * 4 + 48 * fh * (fw // 2 + 1))
+    print(f'{h}x{w} -> FFT {fh}x{fw} N={N:4d}: {t:8.3f} ms  {1e3*t/N:8.2f} us/pair  algorithmic {alg/t/1e6:8.1f} GB/s')
