@@ -119,7 +119,7 @@ def bench_fem(args, lib, ctx, _lib):
     # bytes per PCG iteration with this storage: 2x2 blocks of float64 + int32 block column + int32 row pointer,
     # SpMV vector traffic (x gather counted once, y write) + 12 vector passes (SURVEY.md sec.8d formula, BSR sizes)
     it_bytes = nnzb.value * (32 + 4) + nv.value * 4 + n * 8 * 2 + 12 * n * 8
-    k1 = prof.get('pcg_spmv_fused', (0, 0.0)); k2 = prof.get('pcg_update_fused', (0, 0.0))
+    k1 = prof.get('pcg_spmv_fused', (0, 0.0, 0.0)); k2 = prof.get('pcg_update_fused', (0, 0.0, 0.0))
     spmv_bytes = nnzb.value * 36 + nv.value * 4 + n * 8 * 5          # A + z,p_old own rows + p_new, Ap writes (+gather once)
     out = dict(dof=n, nnz_blocks=nnzb.value, links=nl.value, iters_per_s=args.fem_iters / dt,
                ms_per_iter=1e3 * dt / args.fem_iters, bytes_per_iter=it_bytes,
@@ -174,7 +174,7 @@ def main():
     matchers = {}
     for k, (H, W) in shapes.items():
         s0 = _lib.DeviceBuffer(n_res * H * W); s1 = _lib.DeviceBuffer(n_res * H * W); sh = _lib.DeviceBuffer(n_res * 8)
-        _lib.check(lib.fb_synth_strips_dev(ctx, n_res, rank * 100000 + (0 if k == 'LR' else 50000), H, W, 2026, 20,
+        _lib.check(lib.fb_synth_strips_dev(ctx, n_res, rank * 100000 + (0 if k == 'LR' else 50000), H, W, 2026, 20, 2,
                                            s0.ptr, s1.ptr, sh.ptr))
         strips[k] = (s0, s1, sh.to_array((n_res, 2), np.int32))
         matchers[k] = StripBatchMatcher(P, H, W)
@@ -187,13 +187,9 @@ def main():
         b = (i // 2) % (n_res // P)
         res = matchers[k].match(s0.offset(b * P * H * W), s1.offset(b * P * H * W))
         if dist is not None:
-            # match table of this step: [P][400][5] (xy0, xy1, weight), zero padded; one all_gather over RCCL
-            tab = np.zeros((P * 400, 6), dtype=np.float32)
-            m = min(tab.shape[0], res['pair'].size)
-            tab[:m, 0] = res['pair'][:m]; tab[:m, 1:3] = res['xy0'][:m]; tab[:m, 3:5] = res['xy1'][:m]; tab[:m, 5] = res['weight'][:m]
-            t = torch.from_numpy(tab).cuda(non_blocking=True)
-            out = torch.empty((world,) + tab.shape, dtype=torch.float32, device='cuda')
-            dist.all_gather_into_tensor(out, t)
+            # the one exchange of the sharded run: every rank's match table, gathered over RCCL (feabas_amd/dist.py)
+            from feabas_amd import dist as fdist
+            fdist.gather_match_table(res['pair'], res['xy0'], res['xy1'], res['weight'], pair_offset=(rank * 1000000 + i * P))
         return k, b, res
 
     def barrier():
@@ -230,7 +226,7 @@ def main():
     n_matches = res['pair'].size / P
 
     # roofline of the dominant kernel (by accumulated event time inside the timed region)
-    dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else (None, (0, 0.0))
+    dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else (None, (0, 0.0, 0.0))
     Hl, Wl = shapes['LR']
     fine_w = -(-Wl // 7)
     pair_bytes = ncc_bytes_model(Hl, Wl, [(4, Hl // 4, Wl, True), (385, 75, fine_w, False)])
@@ -242,17 +238,20 @@ def main():
                 pipeline_achieved_gbs=pair_bytes * pairs / world / dt / 1e9,
                 pipeline_frac=pair_bytes * pairs / world / dt / 1e9 / HBM_PEAK_GBS,
                 kernel_ms={k_: round(v[1], 3) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
-    dom_bytes = kernel_bytes_per_launch(dom[0], prof, args, shapes, P)
-    if dom_bytes is not None and dom[1][0] > 0:
-        roof['achieved'] = dom_bytes / (dom[1][1] / dom[1][0] * 1e-3) / 1e9
+    if dom[1][0] > 0 and dom[1][2] > 0:
+        # algorithmic bytes of the kernel's launches (accounted by the library from the launch shapes)
+        # over their summed duration (HIP events on the context stream around every launch)
+        roof['achieved'] = dom[1][2] / (dom[1][1] * 1e-3) / 1e9
         roof['frac'] = roof['achieved'] / HBM_PEAK_GBS
+        roof['algorithmic_bytes_per_launch'] = dom[1][2] / dom[1][0]
+    roof['per_kernel_gbs'] = {k_: round(v[2] / (v[1] * 1e-3) / 1e9, 1) for k_, v in prof.items() if v[1] > 0 and v[2] > 0}
 
     line = dict(metric='tile_pair_ncc_matches_per_s', value=pairs / dt, unit='pairs/s', n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='weak',
                 vs_baseline=None, dtype='f32', data='synthetic',
                 config=dict(workload=f'config[1]: {2 * n_res} resident synthetic {T}x{T} tile pairs ({n_res} LR + {n_res} UD strips '
                                      f'{Hl}x{Wl}), {P} pairs per step; stages: x0.5 downsample, DoG, global NCC, DoG, '
-                                     f'4 coarse + 385 fine block NCCs (translation-only crops, no mesh relaxation yet)',
+                                     f'4 coarse + 385 fine block NCCs (even synthetic offsets: every pair takes the no-relaxation branch, DESIGN.md sec.5)',
                             pairs_per_step=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33),
                 check=dict(global_shift_within_1px=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches, matches_within_half_px_of_truth=ok_match,
                            pairs_needing_mesh_relaxation=int(res['needs_host'].sum())),
@@ -276,18 +275,6 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def kernel_bytes_per_launch(name, prof, args, shapes, P):
-    """algorithmic bytes one launch of the library's own kernels moves (averaged over the LR/UD steps)"""
-    from feabas_amd.matcher import next_fast_len as nfl
-    Hl, Wl = shapes['LR']
-    if name == 'dog_tile':
-        # launches per step: coarse (2P images, uint8 in) + 2 x fine (P images, uint8 in); average them
-        coarse = 2 * P * (Hl // 2) * (Wl // 2) * (1 + 4)
-        fine = P * Hl * Wl * (1 + 4)
-        return (coarse + 2 * fine) / 3
-    return None
 
 
 if __name__ == '__main__':

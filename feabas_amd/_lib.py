@@ -52,17 +52,17 @@ _PROTOS = {
     'fb_prof_enable': (c_i, [c_p, c_i]),
     'fb_prof_reset': (c_i, [c_p]),
     'fb_prof_count': (c_i, [c_p]),
-    'fb_prof_get': (c_i, [c_p, c_i, C.c_char_p, c_i, C.POINTER(c_i), C.POINTER(c_d)]),
+    'fb_prof_get': (c_i, [c_p, c_i, C.c_char_p, c_i, C.POINTER(c_i), C.POINTER(c_d), C.POINTER(c_d)]),
     'fb_next_fast_len': (c_i, [c_i]),
     'fb_ncc_batch': (c_i, [c_p, c_p, c_p] + [c_i] * 9 + [c_p, c_p, c_p]),
     'fb_ncc_batch_dev': (c_i, [c_p, c_p, c_p] + [c_i] * 9 + [c_p, c_p, c_p]),
-    'fb_ncc_blocks_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'fb_ncc_blocks_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_ncc_last_surfaces': (c_i, [c_p, c_p, c_p, C.POINTER(c_i), C.POINTER(c_i)]),
     'fb_dog': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
     'fb_dog_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
     'fb_area_downsample2': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'fb_area_downsample2_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
-    'fb_synth_strips_dev': (c_i, [c_p, c_i, c_i, c_i, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
+    'fb_synth_strips_dev': (c_i, [c_p, c_i, c_i, c_i, c_i, C.c_uint32, c_i, c_i, c_p, c_p, c_p]),
     'fb_sys_create': (c_i, [c_p, c_i64, C.POINTER(c_p)]),
     'fb_sys_destroy': (None, [c_p, c_p]),
     'fb_sys_add_mesh': (c_i, [c_p, c_p, c_i64, c_p, c_i, c_i, C.POINTER(c_i)]),
@@ -183,14 +183,15 @@ class DeviceBuffer:
 
 
 def prof_snapshot():
-    """{kernel name: (launches, total ms)} from the library's event profile."""
+    """{kernel name: (launches, total ms, total algorithmic bytes)} from the library's event profile."""
     lib = load()
     out = {}
     n = lib.fb_prof_count(ctx())
     name = C.create_string_buffer(128)
     launches = c_i()
     ms = c_d()
+    nbytes = c_d()
     for i in range(n):
-        check(lib.fb_prof_get(ctx(), i, name, 128, C.byref(launches), C.byref(ms)))
-        out[name.value.decode()] = (launches.value, ms.value)
+        check(lib.fb_prof_get(ctx(), i, name, 128, C.byref(launches), C.byref(ms), C.byref(nbytes)))
+        out[name.value.decode()] = (launches.value, ms.value, nbytes.value)
     return out

@@ -18,6 +18,7 @@ struct fb_prof_entry {
     std::string name;
     int launches = 0;
     double total_ms = 0.0;
+    double total_bytes = 0.0;    // algorithmic HBM bytes of the launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
@@ -87,10 +88,11 @@ struct fb_prof_scope {
     fb_ctx* ctx;
     int idx = -1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    fb_prof_scope(fb_ctx* c, const char* name);
+    fb_prof_scope(fb_ctx* c, const char* name, double bytes = 0.0);
     ~fb_prof_scope();
 };
 #define FB_PROF(ctx, name) fb_prof_scope prof_scope__((ctx), (name))
+#define FB_PROF_B(ctx, name, bytes) fb_prof_scope prof_scope__((ctx), (name), (double)(bytes))
 
 static inline int fb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -32,7 +32,7 @@ int fb_arena_reserve(fb_ctx* ctx, size_t bytes) {
     return FB_OK;
 }
 
-fb_prof_scope::fb_prof_scope(fb_ctx* c, const char* name) : ctx(c) {
+fb_prof_scope::fb_prof_scope(fb_ctx* c, const char* name, double bytes) : ctx(c) {
     if (!ctx->prof_on) return;
     for (size_t i = 0; i < ctx->prof.size(); ++i)
         if (ctx->prof[i].name == name) idx = (int)i;
@@ -41,6 +41,7 @@ fb_prof_scope::fb_prof_scope(fb_ctx* c, const char* name) : ctx(c) {
         ctx->prof.back().name = name;
         idx = (int)ctx->prof.size() - 1;
     }
+    ctx->prof[idx].total_bytes += bytes;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     hipEventRecord(e0, ctx->stream);
@@ -198,13 +199,14 @@ int fb_prof_count(fb_ctx* ctx) {
     return (int)ctx->prof.size();
 }
 
-int fb_prof_get(fb_ctx* ctx, int index, char* name, int name_len, int* launches, double* total_ms) {
+int fb_prof_get(fb_ctx* ctx, int index, char* name, int name_len, int* launches, double* total_ms, double* total_bytes) {
     prof_drain(ctx);
     FB_CHECK_ARG(ctx, index >= 0 && index < (int)ctx->prof.size());
     const fb_prof_entry& p = ctx->prof[index];
     if (name && name_len > 0) snprintf(name, name_len, "%s", p.name.c_str());
     if (launches) *launches = p.launches;
     if (total_ms) *total_ms = p.total_ms;
+    if (total_bytes) *total_bytes = p.total_bytes;
     return FB_OK;
 }
 

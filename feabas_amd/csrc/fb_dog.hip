@@ -403,11 +403,11 @@ int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, cons
     if (!rc) {
         bool done = false;
         if (!halo && !ctx->dog_exact) {
-            FB_PROF(ctx, "dog_fast");
+            FB_PROF_B(ctx, "dog_fast", (double)N * H * W * (sizeof(T) + 4.0));
             rc = launch_fast_any<T>(ctx, r, img, out, N, H, W, signed_out, taps, &done);
         }
         if (!rc && !done) {
-            FB_PROF(ctx, "dog_tile");
+            FB_PROF_B(ctx, "dog_tile", (double)N * H * W * (sizeof(T) + 4.0));
             rc = launch_tile<T, 4>(ctx, img, out, halo, N, H, W, r, signed_out, 0.f, nullptr, taps);
         }
     }

@@ -607,7 +607,7 @@ bool stream_custom_supported(int Fh, int Fw, int C) {
 }
 
 // sub-batch of nb block pairs through the three custom kernels
-int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int nb, int H0, int W0, int H1, int W1, int hmax, int Fh,
+int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int nb, int H0, int W0, int H1, int W1, int hmax, int wmax, int Fh,
                         int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf, const CropSrc* crop) {
     StreamGeom g;
     g.N = nb; g.Fh = Fh; g.Fw = Fw; g.Sw = Fw / 2 + 1;
@@ -648,16 +648,18 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_inv, ((size_t)4 * (Fw + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) * sizeof(short))));
+    const double in_bytes = crop ? 8.0 * hmax * wmax : 4.0 * ((double)H0 * W0 + (double)H1 * W1);
+    const double nq = g.want_q ? 2.0 : 1.0;
     {
-        FB_PROF(ctx, "ncc_stream_rows");
+        FB_PROF_B(ctx, "ncc_stream_rows", nb * (in_bytes + 16.0 * g.Sw * g.Hs));
         hipLaunchKernelGGL(ncc_stream_rows, dim3(g.Hs / g.TR, nb), dim3(kStreamThreads), lds_rows, ctx->stream, g, T0, T1);
     }
     {
-        FB_PROF(ctx, "ncc_stream_cols");
+        FB_PROF_B(ctx, "ncc_stream_cols", (double)nb * g.Sw * (16.0 * g.Hs + 8.0 * nq * Fh));
         hipLaunchKernelGGL(ncc_stream_cols, dim3(g.Sw, nb), dim3(256), lds_cols, ctx->stream, g, T0, T1, V0, V1);
     }
     {
-        FB_PROF(ctx, "ncc_stream_inv");
+        FB_PROF_B(ctx, "ncc_stream_inv", (double)nb * g.Sw * 8.0 * nq * Fh);
         hipLaunchKernelGGL(ncc_stream_inv, dim3(ntiles, nb), dim3(kStreamThreads), lds_inv, ctx->stream, g, V0, V1, part, nullptr, 0, nullptr);
     }
     if (subpixel) {
@@ -715,7 +717,7 @@ int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, i
         const int nb_max = (int)std::max<size_t>(1, ctx->ncc_arena_limit / custom_bytes_per_pair(Fh, Fw, hmax));
         for (int n0 = 0; n0 < N; n0 += nb_max) {
             const int nb = std::min(nb_max, N - n0);
-            int rc2 = ncc_custom_subbatch(ctx, img0 + (size_t)n0 * H0 * W0, img1 + (size_t)n0 * H1 * W1, nb, H0, W0, H1, W1, hmax, Fh, Fw,
+            int rc2 = ncc_custom_subbatch(ctx, img0 + (size_t)n0 * H0 * W0, img1 + (size_t)n0 * H1 * W1, nb, H0, W0, H1, W1, hmax, std::max(W0, W1), Fh, Fw,
                                           subpixel, conf_mode, dx + n0, dy + n0, conf + n0, nullptr);
             if (rc2) return rc2;
         }
@@ -767,22 +769,23 @@ int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C
 }
 
 int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1, int N,
-                      const int* blk, int hmax, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
+                      const int* blk, int hmax, int wmax, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
     FB_CHECK_ARG(ctx, N >= 0 && IH0 > 0 && IW0 > 0 && IH1 > 0 && IW1 > 0 && Fh > 0 && Fw > 0);
     FB_CHECK_ARG(ctx, conf_mode >= 0 && conf_mode <= 2 && (long long)Fh * Fw < (1LL << 31));
     if (N == 0) return FB_OK;
     FB_CHECK_ARG(ctx, imgs0 && imgs1 && blk && dx && dy && conf);
     FB_HIP(ctx, hipSetDevice(ctx->device));
-    if (fb_ncc_small_supported(Fh, Fw, 0, 0, 0, 0, 1))
-        return fb_ncc_small_launch_ex(ctx, imgs0, imgs1, N, 0, 0, 0, 0, blk, IH0, IW0, IH1, IW1, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
     if (hmax <= 0 || hmax > Fh) hmax = Fh;
+    if (wmax <= 0 || wmax > Fw) wmax = Fw;
+    if (fb_ncc_small_supported(Fh, Fw, 0, 0, 0, 0, 1))
+        return fb_ncc_small_launch_ex(ctx, imgs0, imgs1, N, hmax, wmax, hmax, wmax, blk, IH0, IW0, IH1, IW1, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
     if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, 1)) {
         const int nbm = (int)std::max<size_t>(1, ctx->ncc_arena_limit / custom_bytes_per_pair(Fh, Fw, hmax));
         CropSrc cs{blk, IH0, IW0, IH1, IW1};
         for (int n0 = 0; n0 < N; n0 += nbm) {
             const int nb = std::min(nbm, N - n0);
             cs.blk = blk + (size_t)n0 * kBlkStride;
-            int rc2 = ncc_custom_subbatch(ctx, imgs0, imgs1, nb, 0, 0, 0, 0, hmax, Fh, Fw, subpixel, conf_mode, dx + n0, dy + n0, conf + n0, &cs);
+            int rc2 = ncc_custom_subbatch(ctx, imgs0, imgs1, nb, 0, 0, 0, 0, hmax, wmax, Fh, Fw, subpixel, conf_mode, dx + n0, dy + n0, conf + n0, &cs);
             if (rc2) return rc2;
         }
         return FB_OK;

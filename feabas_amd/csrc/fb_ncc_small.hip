@@ -290,7 +290,7 @@ int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, in
     p.dx = dx; p.dy = dy; p.conf = conf;
     const size_t lds = small_lds_bytes(Fh, Fw);
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_small_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FB_PROF(ctx, "ncc_small_fused");
+    FB_PROF_B(ctx, "ncc_small_fused", (double)N * (4.0 * ((double)H0 * W0 + (double)H1 * W1) + 20.0));
     hipLaunchKernelGGL(ncc_small_fused, dim3(N), dim3(kSmallThreads), lds, ctx->stream, p);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;

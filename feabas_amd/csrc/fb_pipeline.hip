@@ -3,6 +3,8 @@
 // Deterministic in (seed, pair): the host can regenerate any pair.  Not a reference function.
 #include "fb_common.h"
 
+#include <algorithm>
+
 namespace {
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -27,13 +29,14 @@ __device__ __forceinline__ float vnoise(float X, float Y, float cell, uint32_t s
     return (a + (b - a) * tx) + ((c + (d - c) * tx) - (a + (b - a) * tx)) * ty;
 }
 
-__global__ void synth_shifts_kernel(int P, int pair0, uint32_t seed, int max_shift, int* __restrict__ shifts) {
+__global__ void synth_shifts_kernel(int P, int pair0, uint32_t seed, int max_shift, int step, int* __restrict__ shifts) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const uint32_t h0 = hash3(pair0 + p, 17, seed), h1 = hash3(pair0 + p, 91, seed);
-    const int span = 2 * max_shift + 1;
-    shifts[2 * p] = (int)(h0 % (uint32_t)span) - max_shift;        // sx
-    shifts[2 * p + 1] = (int)(h1 % (uint32_t)span) - max_shift;    // sy
+    const int half = max_shift / step;
+    const int span = 2 * half + 1;
+    shifts[2 * p] = step * ((int)(h0 % (uint32_t)span) - half);        // sx
+    shifts[2 * p + 1] = step * ((int)(h1 % (uint32_t)span) - half);    // sy
 }
 
 // strip1(x, y) = texture(x + sx, y + sy), strip0(x, y) = texture(x, y); both + independent noise
@@ -62,11 +65,11 @@ __global__ void synth_strips_kernel(int P, int pair0, int H, int W, uint32_t see
 
 extern "C" {
 
-int fb_synth_strips_dev(fb_ctx* ctx, int P, int pair0, int H, int W, uint32_t seed, int max_shift, uint8_t* strips0,
+int fb_synth_strips_dev(fb_ctx* ctx, int P, int pair0, int H, int W, uint32_t seed, int max_shift, int shift_step, uint8_t* strips0,
                         uint8_t* strips1, int* shifts_dev) {
-    FB_CHECK_ARG(ctx, P > 0 && H > 0 && W > 0 && max_shift >= 0 && strips0 && strips1 && shifts_dev);
+    FB_CHECK_ARG(ctx, P > 0 && H > 0 && W > 0 && max_shift >= 0 && shift_step >= 1 && strips0 && strips1 && shifts_dev);
     FB_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(synth_shifts_kernel, dim3(fb_cdiv(P, 256)), dim3(256), 0, ctx->stream, P, pair0, seed, max_shift, shifts_dev);
+    hipLaunchKernelGGL(synth_shifts_kernel, dim3(fb_cdiv(P, 256)), dim3(256), 0, ctx->stream, P, pair0, seed, max_shift, shift_step, shifts_dev);
     const size_t total = 2 * (size_t)P * H * W;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(synth_strips_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P, pair0, H, W, seed, shifts_dev, strips0, strips1);

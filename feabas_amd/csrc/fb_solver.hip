@@ -353,12 +353,12 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
                 double2* p_new = cur ? M->p1 : M->p0;
                 double2* p_old = cur ? M->p0 : M->p1;
                 {
-                    FB_PROF(ctx, "pcg_spmv_fused");
+                    FB_PROF_B(ctx, "pcg_spmv_fused", 36.0 * (double)M->nnzb + 4.0 * nb + 5.0 * 16.0 * nb);
                     hipLaunchKernelGGL(bsr_spmv_kernel<1>, dim3(g1), dim3(kT), 0, ctx->stream, M->d, M->z, p_old, p_new, M->Ap, nullptr,
                                        part_pAp, part_pp, part_rz[prev], part_rz[cur], part_rr[prev], g2, M->state, it);
                 }
                 {
-                    FB_PROF(ctx, "pcg_update_fused");
+                    FB_PROF_B(ctx, "pcg_update_fused", 7.0 * 16.0 * nb);
                     hipLaunchKernelGGL(pcg_update_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->r, M->z, p_new, M->Ap, M->minv,
                                        part_pAp, part_pp, curv_eps, g1, part_rz[prev], g2, part_rz[cur], part_rr[cur], M->state, it);
                 }

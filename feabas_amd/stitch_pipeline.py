@@ -168,7 +168,7 @@ class StripBatchMatcher:
             assert nb <= self.max_blocks
             flat = np.ascontiguousarray(blk.reshape(-1, 9))
             _lib.check(lib.fb_memcpy_h2d(ctx, self.d_blk.ptr, _lib.ptr(flat), flat.nbytes))
-            _lib.check(lib.fb_ncc_blocks_dev(ctx, dogf.ptr, img1, H, W, H, W, nb, self.d_blk.ptr, int(dy[sel].max()), gfh, gfw,
+            _lib.check(lib.fb_ncc_blocks_dev(ctx, dogf.ptr, img1, H, W, H, W, nb, self.d_blk.ptr, int(dy[sel].max()), int(dx[sel].max()), gfh, gfw,
                                              1 if subpixel else 0, self.conf_mode, self.d_dx.ptr, self.d_dy.ptr, self.d_cf.ptr))
             ddx = self.d_dx.to_array((nb,), np.float64).reshape(sel.size, -1)
             ddy = self.d_dy.to_array((nb,), np.float64).reshape(sel.size, -1)

@@ -69,14 +69,15 @@ int fb_memset(fb_ctx* ctx, void* dst, int value, size_t bytes);
 
 /* HIP-event stopwatch on the context stream (bench.py's timed region) and
  * per-kernel accumulators.  fb_prof_enable(1) brackets every launch of the
- * library's own kernels with events; fb_prof_get returns the number of launches
- * and their summed duration for a kernel name. */
+ * library's own kernels with events; fb_prof_get returns the number of launches,
+ * their summed duration and the algorithmic HBM bytes they moved. */
 int fb_timer_start(fb_ctx* ctx);
 int fb_timer_stop(fb_ctx* ctx, float* ms);
 int fb_prof_enable(fb_ctx* ctx, int on);
 int fb_prof_reset(fb_ctx* ctx);
 int fb_prof_count(fb_ctx* ctx);
-int fb_prof_get(fb_ctx* ctx, int index, char* name, int name_len, int* launches, double* total_ms);
+int fb_prof_get(fb_ctx* ctx, int index, char* name, int name_len, int* launches, double* total_ms,
+                double* total_algorithmic_bytes);
 
 /* ------------------------------------------------------------------ NCC path */
 /* next 5-smooth length, scipy.fftpack.next_fast_len as used at matcher.py:59-62 */
@@ -100,9 +101,9 @@ int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, i
  * block n correlates the h0 x w0 window at (x0,y0) of imgs0[image] with the h1 x w1 window at
  * (x1,y1) of imgs1[image]; pixels outside an image read 0 (dal.StreamLoader fillval).  All blocks
  * of a call share the FFT shape (Fh, Fw) the caller derives with the rule of matcher.py:59-62;
- * hmax = upper bound of the block heights (0 = unknown). */
+ * hmax, wmax = upper bounds of the block heights / widths (0 = unknown). */
 int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1,
-                      int N, const int* blk, int hmax, int Fh, int Fw, int subpixel, int conf_mode,
+                      int N, const int* blk, int hmax, int wmax, int Fh, int Fw, int subpixel, int conf_mode,
                       double* dx, double* dy, float* conf);
 /* debugging / parity aid: the two correlation surfaces (un-normalised) of the
  * last fb_ncc_batch* call that went through the streaming (rocFFT) class. */
@@ -120,9 +121,9 @@ int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, ui
 int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out);
 
 /* Synthetic overlap strips for benchmarks (not a reference function): pair p gets an integer
- * offset (sx, sy) in [-max_shift, max_shift]^2 derived from (seed, pair0 + p); strips0/strips1 are
+ * offset (sx, sy), multiples of shift_step in [-max_shift, max_shift]^2, derived from (seed, pair0 + p); strips0/strips1 are
  * uint8 [P][H][W] with strips1(x, y) = texture(x + sx, y + sy); shifts_dev receives [P][2] = {sx, sy}. */
-int fb_synth_strips_dev(fb_ctx* ctx, int P, int pair0, int H, int W, uint32_t seed, int max_shift,
+int fb_synth_strips_dev(fb_ctx* ctx, int P, int pair0, int H, int W, uint32_t seed, int max_shift, int shift_step,
                         uint8_t* strips0, uint8_t* strips1, int* shifts_dev);
 
 /* ------------------------------------------------------------------ FEM path */

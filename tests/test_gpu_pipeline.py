@@ -10,11 +10,11 @@ from oracle import pipeline_ref
 pytestmark = pytest.mark.gpu
 
 
-def _synth(fb, P, H, W, seed, max_shift):
+def _synth(fb, P, H, W, seed, max_shift, step=1):
     from feabas_amd import _lib
     lib, ctx = _lib.load(), _lib.ctx()
     s0 = _lib.DeviceBuffer(P * H * W); s1 = _lib.DeviceBuffer(P * H * W); sh = _lib.DeviceBuffer(P * 8)
-    _lib.check(lib.fb_synth_strips_dev(ctx, P, 0, H, W, seed, max_shift, s0.ptr, s1.ptr, sh.ptr))
+    _lib.check(lib.fb_synth_strips_dev(ctx, P, 0, H, W, seed, max_shift, step, s0.ptr, s1.ptr, sh.ptr))
     _lib.check(lib.fb_sync(ctx))
     return s0, s1, sh.to_array((P, 2), np.int32)
 
@@ -43,4 +43,24 @@ def test_pipeline_vs_oracle(fb, H, W, P):
         np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4)
         np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
         np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
+    m.free()
+
+
+def test_pipeline_even_offsets_take_the_device_branch(fb):
+    """even offsets are recovered exactly by the x0.5 coarse match, so no pair needs the mesh-relaxation
+    branch: this is the branch bench.py times"""
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    P, H, W = 8, 1024, 256
+    s0, s1, shifts = _synth(fb, P, H, W, seed=11, max_shift=20, step=2)
+    assert np.all(shifts % 2 == 0)
+    m = StripBatchMatcher(P, H, W)
+    res = m.match(s0.ptr, s1.ptr)
+    np.testing.assert_array_equal(res['tx'], -shifts[:, 0]); np.testing.assert_array_equal(res['ty'], -shifts[:, 1])
+    assert not res['needs_host'].any() and res['valid'].all()
+    h0 = s0.to_array((P, H, W), np.uint8); h1 = s1.to_array((P, H, W), np.uint8)
+    got = StripBatchMatcher.per_pair(res)
+    for p in (0, 5):
+        exp = pipeline_ref.match_pair(h0[p], h1[p])
+        np.testing.assert_allclose(got[p]['xy0'], exp['xy0'], atol=1e-4); np.testing.assert_allclose(got[p]['xy1'], exp['xy1'], atol=1e-4)
+        np.testing.assert_allclose(got[p]['weight'], exp['weight'], atol=1e-4)
     m.free()
