@@ -20,12 +20,12 @@ struct FftPlan {
 };
 
 // host: factor n (5-smooth) preferring radix 4
-static inline bool fft_make_plan(int n, FftPlan* p) {
+static inline bool fft_make_plan(int n, FftPlan* p, int max_radix = 16) {
     p->n = n;
     p->nf = 0;
     int m = n;
-    while (m % 16 == 0) { p->radix[p->nf++] = 16; m /= 16; if (p->nf >= kFftMaxFactors) return false; }
-    while (m % 8 == 0) { p->radix[p->nf++] = 8; m /= 8; if (p->nf >= kFftMaxFactors) return false; }
+    while (max_radix >= 16 && m % 16 == 0) { p->radix[p->nf++] = 16; m /= 16; if (p->nf >= kFftMaxFactors) return false; }
+    while (max_radix >= 8 && m % 8 == 0) { p->radix[p->nf++] = 8; m /= 8; if (p->nf >= kFftMaxFactors) return false; }
     while (m % 4 == 0) { p->radix[p->nf++] = 4; m /= 4; if (p->nf >= kFftMaxFactors) return false; }
     while (m % 2 == 0) { p->radix[p->nf++] = 2; m /= 2; if (p->nf >= kFftMaxFactors) return false; }
     while (m % 5 == 0) { p->radix[p->nf++] = 5; m /= 5; if (p->nf >= kFftMaxFactors) return false; }
@@ -186,6 +186,15 @@ struct TwSplit {
     __device__ __forceinline__ float2 operator()(int n) const { return cmulf(hi[n >> 6], lo[n & 63]); }
 };
 
+// w[q] = w1^q for q = 1..R-1 through squarings/products of depth <= log2(R) (error ~ depth * 6e-8):
+// one table lookup per butterfly instead of R-1
+template <int R>
+__device__ __forceinline__ void twiddle_powers(float2 w1, float2* w) {
+    w[1] = w1;
+#pragma unroll
+    for (int q = 2; q < R; ++q) w[q] = (q & 1) ? cmulf(w[q - 1], w1) : cmulf(w[q / 2], w[q / 2]);
+}
+
 // exact t / d for 0 <= t < 2^22 through a float reciprocal (the integer divide costs ~40 VALU instructions)
 __device__ __forceinline__ int fdiv_i(int t, int d, float inv) {
     int q = (int)((float)t * inv);
@@ -232,15 +241,27 @@ __device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int
         for (int u = 0; u < U; ++u) {
             if (INV) {
                 if (L > R) {
+                    float2 w[R];
+                    if (R >= 8) twiddle_powers<R>(tw(jj[u] * tstep), w);
+                    else {
 #pragma unroll
-                    for (int q = 1; q < R; ++q) v[u][q] = cmulcf(v[u][q], tw(jj[u] * q * tstep));  // conj twiddle first (DIT)
+                        for (int q = 1; q < R; ++q) w[q] = tw(jj[u] * q * tstep);
+                    }
+#pragma unroll
+                    for (int q = 1; q < R; ++q) v[u][q] = cmulcf(v[u][q], w[q]);  // conj twiddle first (DIT)
                 }
                 dft_r<R, true>(v[u]);
             } else {
                 dft_r<R, false>(v[u]);
                 if (L > R) {
+                    float2 w[R];
+                    if (R >= 8) twiddle_powers<R>(tw(jj[u] * tstep), w);
+                    else {
 #pragma unroll
-                    for (int q = 1; q < R; ++q) v[u][q] = cmulf(v[u][q], tw(jj[u] * q * tstep));   // twiddle after (DIF)
+                        for (int q = 1; q < R; ++q) w[q] = tw(jj[u] * q * tstep);
+                    }
+#pragma unroll
+                    for (int q = 1; q < R; ++q) v[u][q] = cmulf(v[u][q], w[q]);   // twiddle after (DIF)
                 }
             }
         }
@@ -254,7 +275,7 @@ __device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int
 }
 
 // full batched transform; every pass ends with a workgroup barrier
-template <bool INV, typename TW>
+template <bool INV, typename TW, int MAXR = 16>
 __device__ __forceinline__ void fft_batch_tw(float2* base, const FftPlan& plan, int M, int is, int ms, const TW& tw, bool lanes_on_m) {
     const int N = plan.n;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -262,8 +283,8 @@ __device__ __forceinline__ void fft_batch_tw(float2* base, const FftPlan& plan, 
         int L = N;
         for (int s = 0; s < plan.nf; ++s) {
             const int r = plan.radix[s];
-            if (r == 16) fft_pass<16, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (r == 8) fft_pass<8, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            if (MAXR >= 16 && r == 16) fft_pass<16, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (MAXR >= 8 && r == 8) fft_pass<8, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 4) fft_pass<4, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 2) fft_pass<2, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 5) fft_pass<5, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
@@ -276,8 +297,8 @@ __device__ __forceinline__ void fft_batch_tw(float2* base, const FftPlan& plan, 
         for (int s = plan.nf - 1; s >= 0; --s) {
             const int r = plan.radix[s];
             L *= r;
-            if (r == 16) fft_pass<16, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (r == 8) fft_pass<8, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            if (MAXR >= 16 && r == 16) fft_pass<16, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (MAXR >= 8 && r == 8) fft_pass<8, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 4) fft_pass<4, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 2) fft_pass<2, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             else if (r == 5) fft_pass<5, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
@@ -289,5 +310,5 @@ __device__ __forceinline__ void fft_batch_tw(float2* base, const FftPlan& plan, 
 
 template <bool INV>
 __device__ __forceinline__ void fft_batch(float2* base, const FftPlan& plan, int M, int is, int ms, const float2* tw, bool lanes_on_m) {
-    fft_batch_tw<INV>(base, plan, M, is, ms, TwTable{tw}, lanes_on_m);
+    fft_batch_tw<INV, TwTable, 5>(base, plan, M, is, ms, TwTable{tw}, lanes_on_m);      // small lengths: radix <= 5 keeps VGPRs low
 }

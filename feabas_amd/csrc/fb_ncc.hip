@@ -456,7 +456,7 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
     }
 }
 
-__global__ __launch_bounds__(256) void ncc_stream_cols(const StreamGeom g, const float2* __restrict__ T0, const float2* __restrict__ T1,
+__global__ __launch_bounds__(256, 4) void ncc_stream_cols(const StreamGeom g, const float2* __restrict__ T0, const float2* __restrict__ T1,
                                                        float2* __restrict__ V0, float2* __restrict__ V1) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int Fh = g.Fh, pitch = Fh + 1;

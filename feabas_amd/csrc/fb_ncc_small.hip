@@ -269,7 +269,7 @@ int get_table(fb_ctx* ctx, int n, const float2** out) {
 int fb_ncc_small_supported(int Fh, int Fw, int, int, int, int, int C) {
     if (C != 1 || Fw > 192 || Fh < 1 || Fw < 2) return 0;        // split/pack loops cover Sw <= 192
     FftPlan p;
-    if (!fft_make_plan(Fh, &p) || !fft_make_plan(Fw, &p)) return 0;
+    if (!fft_make_plan(Fh, &p, 5) || !fft_make_plan(Fw, &p, 5)) return 0;
     return small_lds_bytes(Fh, Fw) <= kSmallLdsBudget;
 }
 
@@ -280,7 +280,7 @@ int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, in
     p.N = N; p.Fh = Fh; p.Fw = Fw; p.Sw = Fw / 2 + 1; p.RS = 2 * p.Sw;
     p.H0 = H0; p.W0 = W0; p.H1 = H1; p.W1 = W1;
     p.subpixel = subpixel; p.conf_mode = conf_mode;
-    if (!fft_make_plan(Fw, &p.pw) || !fft_make_plan(Fh, &p.ph)) return fb_fail(ctx, FB_ERR_ARG, "ncc_small: %dx%d is not 5-smooth", Fh, Fw);
+    if (!fft_make_plan(Fw, &p.pw, 5) || !fft_make_plan(Fh, &p.ph, 5)) return fb_fail(ctx, FB_ERR_ARG, "ncc_small: %dx%d is not 5-smooth", Fh, Fw);
     int rc = get_table(ctx, Fw, &p.tw_w);
     if (rc) return rc;
     rc = get_table(ctx, Fh, &p.tw_h);
