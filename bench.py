@@ -174,7 +174,7 @@ def main():
     matchers = {}
     for k, (H, W) in shapes.items():
         s0 = _lib.DeviceBuffer(n_res * H * W); s1 = _lib.DeviceBuffer(n_res * H * W); sh = _lib.DeviceBuffer(n_res * 8)
-        _lib.check(lib.fb_synth_strips_dev(ctx, n_res, rank * 100000 + (0 if k == 'LR' else 50000), H, W, 2026, 20, 2,
+        _lib.check(lib.fb_synth_strips_dev(ctx, n_res, rank * 100000 + (0 if k == 'LR' else 50000), H, W, 2026, 20, 1,
                                            s0.ptr, s1.ptr, sh.ptr))
         strips[k] = (s0, s1, sh.to_array((n_res, 2), np.int32))
         matchers[k] = StripBatchMatcher(P, H, W)
@@ -251,7 +251,7 @@ def main():
                 vs_baseline=None, dtype='f32', data='synthetic',
                 config=dict(workload=f'config[1]: {2 * n_res} resident synthetic {T}x{T} tile pairs ({n_res} LR + {n_res} UD strips '
                                      f'{Hl}x{Wl}), {P} pairs per step; stages: x0.5 downsample, DoG, global NCC, DoG, '
-                                     f'4 coarse + 385 fine block NCCs (even synthetic offsets: every pair takes the no-relaxation branch, DESIGN.md sec.5)',
+                                     f'4 coarse + 385 fine block NCCs (integer synthetic offsets; odd ones take the rigid mesh-relaxation branch, DESIGN.md sec.5)',
                             pairs_per_step=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33),
                 check=dict(global_shift_within_1px=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches, matches_within_half_px_of_truth=ok_match,
                            pairs_needing_mesh_relaxation=int(res['needs_host'].sum())),

@@ -12,10 +12,11 @@ Per pair, in the reference's order:
      reference's pad / subpixel schedule (579-603, 690-716), block -> point pairs (840-849)
                                                             fb_ncc_blocks_dev
 What is NOT here yet (DESIGN.md "scope of the pair pipeline"): the low-confidence fallback
-of global_translation_matcher (159-221, host path exists in matcher.py), the mesh relaxation
-between spacings when a coarse round moves blocks by > 0.1 px (725-742) together with the
-bilinear patch gather it then needs, and the final strain estimate.
-Pairs that would take those branches are flagged in the result (``needs_host``).
+of global_translation_matcher (159-221, host path exists in matcher.py); NON-RIGID mesh relaxation
+between spacings (725-742; a uniform block displacement is applied as the rigid translation it
+relaxes to) together with the bilinear patch gather it needs; the
+final residue re-weighting and strain estimate.  Pairs that would take the non-rigid branch are
+flagged in the result (``needs_host``).
 """
 import ctypes as C
 
@@ -111,12 +112,12 @@ class StripBatchMatcher:
         _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, H, W, self.sigma, None, 1, self.d_dogf.offset(n * H * W * 4)))
         self.d_dogf_view = self.d_dogf
 
-    def _blocks(self, tx, ty, sel, spacing, mnb):
+    def _blocks(self, tx, ty, t1, sel, spacing, mnb):
         """block descriptors for the pairs `sel` (all share Nx, Ny): returns (blk [Q, nblk, 9], bboxes [Q, nblk, 4])"""
         H, W = self.H, self.W
         # mesh bounding boxes in the MOVING gear (Mesh.from_bbox: vertices at pixel centres - 0.5)
-        xmin = np.maximum(-0.5 + tx[sel], -0.5); ymin = np.maximum(-0.5 + ty[sel], -0.5)
-        xmax = np.minimum(W - 0.5 + tx[sel], W - 0.5); ymax = np.minimum(H - 0.5 + ty[sel], H - 0.5)
+        xmin = np.maximum(-0.5 + tx[sel], -0.5 + t1[sel, 0]); ymin = np.maximum(-0.5 + ty[sel], -0.5 + t1[sel, 1])
+        xmax = np.minimum(W - 0.5 + tx[sel], W - 0.5 + t1[sel, 0]); ymax = np.minimum(H - 0.5 + ty[sel], H - 0.5 + t1[sel, 1])
         nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
         assert np.all(nx == nx[0]) and np.all(ny == ny[0])
         nxi, nyi = int(nx[0]), int(ny[0])
@@ -136,18 +137,19 @@ class StripBatchMatcher:
         blk[:, :, 1] = x0 - np.round(tx[sel]).astype(np.int32)[:, None]
         blk[:, :, 2] = y0 - np.round(ty[sel]).astype(np.int32)[:, None]
         blk[:, :, 3] = dy[:, None]; blk[:, :, 4] = dx[:, None]
-        blk[:, :, 5] = x0; blk[:, :, 6] = y0
+        blk[:, :, 5] = x0 - np.round(t1[sel, 0]).astype(np.int32)[:, None]
+        blk[:, :, 6] = y0 - np.round(t1[sel, 1]).astype(np.int32)[:, None]
         blk[:, :, 7] = dy[:, None]; blk[:, :, 8] = dx[:, None]
         return blk, bb
 
-    def _match_round(self, tx, ty, active, spacing, mnb, pad_flags, subpixel):
+    def _match_round(self, tx, ty, t1, active, spacing, mnb, pad_flags, subpixel):
         """one spacing round for the `active` pairs.  Returns a list of groups
         (pair ids [Q], bboxes [Q, nblk, 4], dx, dy, conf [Q, nblk])."""
         lib, ctx = _lib.load(), _lib.ctx()
         n, H, W = self.P, self.H, self.W
         # group by block grid, then by FFT shape (matcher.py:59-62 on the block size)
-        xmin = np.maximum(-0.5 + tx, -0.5); xmax = np.minimum(W - 0.5 + tx, W - 0.5)
-        ymin = np.maximum(-0.5 + ty, -0.5); ymax = np.minimum(H - 0.5 + ty, H - 0.5)
+        xmin = np.maximum(-0.5 + tx, -0.5 + t1[:, 0]); xmax = np.minimum(W - 0.5 + tx, W - 0.5 + t1[:, 0])
+        ymin = np.maximum(-0.5 + ty, -0.5 + t1[:, 1]); ymax = np.minimum(H - 0.5 + ty, H - 0.5 + t1[:, 1])
         nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
         nfl_h = np.array([next_fast_len(v) for v in range(0, 2 * H + 2)])
         nfl_w = nfl_h if W == H else np.array([next_fast_len(v) for v in range(0, 2 * W + 2)])
@@ -163,7 +165,7 @@ class StripBatchMatcher:
                 continue
             sel = np.flatnonzero(key == kv)
             gfh, gfw = int(fh[sel[0]]), int(fw[sel[0]])
-            blk, bb = self._blocks(tx, ty, sel, spacing, mnb)
+            blk, bb = self._blocks(tx, ty, t1, sel, spacing, mnb)
             nb = blk.shape[0] * blk.shape[1]
             assert nb <= self.max_blocks
             flat = np.ascontiguousarray(blk.reshape(-1, 9))
@@ -193,12 +195,13 @@ class StripBatchMatcher:
         has_last = np.zeros(n, dtype=bool)
         table = None
         txy = np.stack((tx, ty), axis=-1)
+        t1 = np.zeros((n, 2))                                # translation of mesh1 acquired by rigid relaxations
         for rnd in range(spacings.size):
             sp = spacings[rnd]
             is_last = rnd == spacings.size - 1
             mnb = self.mnb if is_last else 1
             rows = []
-            for sel, bb, ddx, ddy, dcf in self._match_round(tx, ty, active, sp, mnb, pad, subpixel=is_last):
+            for sel, bb, ddx, ddy, dcf in self._match_round(tx, ty, t1, active, sp, mnb, pad, subpixel=is_last):
                 keep = dcf > self.conf_thresh                # matcher.py:671-683
                 anyk = keep.any(axis=1)
                 if rnd == 0:
@@ -207,17 +210,29 @@ class StripBatchMatcher:
                 dxy = np.stack((ddx, ddy), axis=-1)
                 xy0 = ctr - dxy * 0.5                        # equal block sizes: ratio 0.5 (matcher.py:844-849)
                 xy1 = ctr + dxy * 0.5
+                xy1_init = xy1 - t1[sel][:, None, :]         # INITIAL gear of mesh1 at link creation (matcher.py:748-751)
                 dis2 = np.where(keep, np.sum((xy0 - xy1) ** 2, axis=-1), -1.0)
                 max_dis = np.sqrt(np.maximum(dis2.max(axis=1), 0.0))
                 if not is_last:
                     # spacing schedule (matcher.py:689-716), max_spacing_skip = 0
                     next_pos = np.searchsorted(-spacings, -4 * max_dis) - 1
                     pad[sel] = np.where(next_pos > rnd, np.minimum(next_pos, rnd + 1) > rnd + 1, True)
-                    # max_dis > 0.1: the reference relaxes the mesh and crops the next round through the
-                    # deformed mesh (matcher.py:725-742) -- not on the device path yet
-                    needs_host[sel[anyk & (max_dis > 0.1)]] = True
+                    # max_dis > 0.1: the reference relaxes mesh1 against the links (matcher.py:725-742).  When every
+                    # kept block reports the same displacement the exact minimiser is the rigid translation
+                    # u = xy0 - xy1 of mesh1 (zero elastic and zero link energy; checked against the FEM oracle in
+                    # tests/test_gpu_pipeline.py); residues vanish, so the huber re-weighting changes nothing.
+                    # Any other field needs the deformed-mesh crop: flagged.
+                    move = anyk & (max_dis > 0.1)
+                    if move.any():
+                        u = xy0 - xy1                                          # [Q, nblk, 2]
+                        first = np.argmax(keep, axis=1)
+                        u0 = u[np.arange(sel.size), first]                     # displacement of the first kept block
+                        uniform = np.all(~keep[..., None] | (u == u0[:, None, :]), axis=(1, 2))
+                        rigid = move & uniform
+                        t1[sel[rigid]] += u0[rigid]
+                        needs_host[sel[move & ~uniform]] = True
                 pid = np.broadcast_to(sel[:, None], keep.shape)
-                rows.append((pid[keep], xy0[keep], xy1[keep], dcf[keep]))
+                rows.append((pid[keep], xy0[keep], xy1_init[keep], dcf[keep]))
                 has_last[sel[anyk]] = True
             if rows:
                 table = tuple(np.concatenate([r[k] for r in rows], axis=0) for k in range(4))

@@ -9,7 +9,59 @@ restatement ncc_ref.area_downsample2.
 """
 import numpy as np
 
-from . import ncc_ref
+from . import ncc_ref, fem_ref
+
+
+def cartesian_mesh(W, H, mesh_size, min_num_blocks=2, max_aspect_ratio=2):
+    """Mesh.from_bbox((0,0,W,H), cartesian=True) (mesh.py:403-435): node grid at pixel centres - 0.5.
+    The reference lets `triangle` pick one diagonal per rectangle (implementation defined, SURVEY.md A.4);
+    here every cell (a b / c d) is split along a-d into (a,b,d), (a,d,c)."""
+    nx = max(np.round(W / mesh_size), min_num_blocks)
+    ny = max(np.round(H / mesh_size), min_num_blocks)
+    dx, dy = W / nx, H / ny
+    if dx > max_aspect_ratio * dy:
+        dx = max_aspect_ratio * dy
+    elif dy > max_aspect_ratio * dx:
+        dy = max_aspect_ratio * dx
+    nx = int(np.ceil(W / dx)) + 1
+    ny = int(np.ceil(H / dy)) + 1
+    xs = np.linspace(0, W, num=nx, endpoint=True) - 0.5
+    ys = np.linspace(0, H, num=ny, endpoint=True) - 0.5
+    vx, vy = np.meshgrid(xs, ys)
+    v = np.stack((vx.ravel(), vy.ravel()), axis=-1)
+    idx = np.arange(nx * ny).reshape(ny, nx)
+    a = idx[:-1, :-1].ravel(); b = idx[:-1, 1:].ravel(); c = idx[1:, :-1].ravel(); d = idx[1:, 1:].ravel()
+    tri = np.stack((np.stack((a, b, d), -1), np.stack((a, d, c), -1)), axis=1).reshape(-1, 3)
+    return v, tri, xs, ys
+
+
+def locate_cartesian(xs, ys, pts):
+    """triangle id of points in the mesh of cartesian_mesh (vertex coordinates without offset)"""
+    nx, ny = xs.size, ys.size
+    i = np.clip(np.searchsorted(xs, pts[:, 0], side='right') - 1, 0, nx - 2)
+    j = np.clip(np.searchsorted(ys, pts[:, 1], side='right') - 1, 0, ny - 2)
+    u = (pts[:, 0] - xs[i]) / (xs[i + 1] - xs[i])
+    w = (pts[:, 1] - ys[j]) / (ys[j + 1] - ys[j])
+    return 2 * (j * (nx - 1) + i) + (w > u)
+
+
+def relax_mesh1(W, H, mesh_size, t0, t1, xy0, xy1, weight):
+    """matcher.py:717-729 with an exact solve: mesh0 (locked, translated by t0), mesh1 (free, translated by t1),
+    one link from the matched points (MOVING gear).  Returns the displacement of every mesh1 vertex."""
+    v, tri, xs, ys = cartesian_mesh(W, H, mesh_size)
+    m0 = fem_ref.RefMesh(v, tri, uid=0)
+    m0.apply_translation(t0, fem_ref.GEAR_FIXED)
+    m0.locked = True
+    m1 = fem_ref.RefMesh(v, tri, uid=1)
+    m1.apply_translation(t1, fem_ref.GEAR_FIXED)
+    tid0 = locate_cartesian(xs, ys, xy0 - m0.offset(fem_ref.GEAR_MOVING))
+    tid1 = locate_cartesian(xs, ys, xy1 - m1.offset(fem_ref.GEAR_MOVING))
+    B0 = m0.cart2bary(xy0, fem_ref.GEAR_MOVING, tid0)
+    B1 = m1.cart2bary(xy1, fem_ref.GEAR_MOVING, tid1)
+    link = fem_ref.RefLink(m0, m1, tid0, tid1, B0, B1, weight=weight)
+    before = m1.vertices_w_offset(fem_ref.GEAR_MOVING).copy()
+    fem_ref.optimize_linear([m0, m1], [link], exact=True)
+    return m1.vertices_w_offset(fem_ref.GEAR_MOVING) - before
 
 
 def _crop(img, x0, y0, h, w):
@@ -48,17 +100,19 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
     tx, ty = res['tx'], res['ty']
     spacings = np.sort(ncc_ref.auto_spacings((H, W), (H, W)))[::-1]
     bbox0 = (-0.5 + tx, -0.5 + ty, W - 0.5 + tx, H - 0.5 + ty)              # Mesh.from_bbox + apply_translation
-    bbox1 = (-0.5, -0.5, W - 0.5, H - 0.5)
     pad = True
     itx, ity = int(round(tx)), int(round(ty))
+    t1 = np.zeros(2)                                                         # rigid motion mesh1 acquired so far
     last = None
     for rnd, sp in enumerate(spacings):
+        bbox1 = (-0.5 + t1[0], -0.5 + t1[1], W - 0.5 + t1[0], H - 0.5 + t1[1])
+        i1x, i1y = int(round(t1[0])), int(round(t1[1]))
         is_last = rnd == spacings.size - 1
         mnb = min_num_blocks if is_last else 1
         bb0, bb1 = ncc_ref.distributor_cartesian_bbox(bbox0, bbox1, sp, min_num_blocks=mnb, zorder=True)
         h = int(bb0[0, 3] - bb0[0, 1]); w = int(bb0[0, 2] - bb0[0, 0])
         s0 = np.stack([_crop(f0, int(b[0]) - itx, int(b[1]) - ity, h, w) for b in bb0])
-        s1 = np.stack([_crop(f1, int(b[0]), int(b[1]), h, w) for b in bb1])
+        s1 = np.stack([_crop(f1, int(b[0]) - i1x, int(b[1]) - i1y, h, w) for b in bb1])
         dx, dy, cf = ncc_ref.xcorr_fft(s0, s1, conf_mode=conf_mode, pad=pad, subpixel=is_last)
         xy0, xy1 = ncc_ref.block_points(bb0, bb1, dx, dy)
         keep = cf > conf_thresh
@@ -68,12 +122,18 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
             continue
         xy0, xy1, wt = xy0[keep], xy1[keep], cf[keep]
         max_dis = np.max(np.sum((xy0 - xy1) ** 2, axis=-1)) ** 0.5
-        last = (xy0, xy1, wt, max_dis)
+        last = (xy0, xy1 - t1, wt, max_dis)                   # INITIAL gear: barycentric coordinates are fixed at link creation
         if not is_last:
             next_pos = np.searchsorted(-spacings, -4 * max_dis) - 1           # matcher.py:689-716
             pad = (min(next_pos, rnd + 1) > rnd + 1) if next_pos > rnd else True
             if max_dis > 0.1:
-                res['needs_host'] = True
+                # mesh relaxation (matcher.py:725-729), exact solve on the cartesian mesh pair
+                u = relax_mesh1(W, H, float(np.min(spacings)), (tx, ty), t1, xy0, xy1, wt)
+                um = u.mean(axis=0)
+                if np.abs(u - um).max() < 1e-6 and np.abs(um - np.round(um)).max() < 1e-6:
+                    t1 = t1 + np.round(um)                   # a rigid integer translation: crops stay exact
+                else:
+                    res['needs_host'] = True                 # deformed-mesh crop (cv2.remap), SURVEY.md sec.8f row 1
     if last is not None:
         res['xy0'] = last[0] - np.array([tx, ty])
         res['xy1'] = last[1]

@@ -37,7 +37,7 @@ def test_pipeline_vs_oracle(fb, H, W, P):
         d = np.median(g['xy1'] - g['xy0'], axis=0)
         assert np.abs(d + shifts[p]).max() < 0.3
         assert abs(g['conf0'] - exp['conf0']) < 1e-4
-        assert g['needs_host'] == exp['needs_host']
+        assert g['needs_host'] == exp['needs_host'] == False      # odd offsets relax rigidly (FEM oracle inside pipeline_ref)
         assert g['xy0'].shape == exp['xy0'].shape and g['xy0'].shape[0] > 10
         np.testing.assert_array_equal(np.round(g['xy1'] - g['xy0']), np.round(exp['xy1'] - exp['xy0']))
         np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4)
