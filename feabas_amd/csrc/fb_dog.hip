@@ -204,10 +204,12 @@ __device__ __forceinline__ void row_pass(const float* __restrict__ src, int ps, 
     for (int item = threadIdx.x; item < rows * nruns; item += blockDim.x) {
         const int run = item / rows, row = item - run * rows;       // lanes walk rows
         float in[RUN + 2 * R], o[RUN];
+        // 16-byte aligned by construction (pitches and run offsets are multiples of 4 floats): ds_read_b128
+        const float4* p4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(src, 16)) + ((row * ps + run * RUN) >> 2);
         const float* p = src + row * ps + run * RUN;
 #pragma unroll
         for (int q = 0; q < (RUN + 2 * R) / 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+            const float4 v = p4[q];
             in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
         }
 #pragma unroll
@@ -255,11 +257,29 @@ __global__ __launch_bounds__(256) void dog_fast(const T* __restrict__ img, float
     const int x0 = blockIdx.x * FT, y0 = blockIdx.y * FT;
     const T* src = img + (size_t)n * H * W;
     const int tid = threadIdx.x, nt = blockDim.x;
-    // stage 0: clamped input tile ('nearest' extension of the image)
-    for (int i = tid; i < G::AH * G::AW; i += nt) {
-        const int ty = i / G::AW, tx = i - ty * G::AW;
-        const int gy = clampi(y0 - G::HAL + ty, 0, H - 1), gx = clampi(x0 - G::HAL + tx, 0, W - 1);
-        bufA[ty * G::PA + tx] = load_px<T>(src, (size_t)gy * W + gx);
+    // stage 0: clamped input tile ('nearest' extension of the image).  Threads = 2 row groups x 128 columns;
+    // 8 rows are fetched per trip so that the loads are in flight together (a load -> LDS store per trip
+    // exposes the full memory latency every iteration).
+    {
+        static_assert(G::AW <= 128, "tile wider than the load mapping");
+        const int tx = tid & 127, tyo = tid >> 7, nrg = nt >> 7;
+        const int gx = clampi(x0 - G::HAL + tx, 0, W - 1);
+        constexpr int UB = 8;
+        for (int tb = tyo; tb < G::AH; tb += UB * nrg) {
+            float val[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int ty = min(tb + u * nrg, G::AH - 1);
+                val[u] = load_px<T>(src, (size_t)clampi(y0 - G::HAL + ty, 0, H - 1) * W + gx);
+            }
+            if (tx < G::AW) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int ty = tb + u * nrg;
+                    if (ty < G::AH) bufA[ty * G::PA + tx] = val[u];
+                }
+            }
+        }
     }
     __syncthreads();
     // stage 1: rows A -> B (AH x BW); B col tx <-> global x = x0 - R + tx
@@ -268,10 +288,12 @@ __global__ __launch_bounds__(256) void dog_fast(const T* __restrict__ img, float
     {   // replicate the image-border columns
         const int cl = -(x0 - R), cr = (W - 1) - (x0 - R);          // B columns of global x = 0 and x = W-1
         if (cl > 0 || cr < G::BW - 1) {
-            for (int i = tid; i < G::AH * G::BW; i += nt) {
-                const int ty = i / G::BW, tx = i - ty * G::BW;
-                if (tx < cl) bufB[ty * G::PB + tx] = bufB[ty * G::PB + cl];
-                else if (tx > cr) bufB[ty * G::PB + tx] = bufB[ty * G::PB + cr];
+            // only the columns outside the image are touched: lanes walk rows
+            const int nleft = max(cl, 0), nright = max(G::BW - 1 - cr, 0);
+            for (int i = tid; i < G::AH * (nleft + nright); i += nt) {
+                const int k = i / G::AH, ty = i - k * G::AH;
+                const int tx = k < nleft ? k : cr + 1 + (k - nleft);
+                bufB[ty * G::PB + tx] = bufB[ty * G::PB + (k < nleft ? cl : cr)];
             }
             __syncthreads();
         }
@@ -282,10 +304,11 @@ __global__ __launch_bounds__(256) void dog_fast(const T* __restrict__ img, float
     {   // replicate the image-border rows
         const int rt = -(y0 - R), rb = (H - 1) - (y0 - R);
         if (rt > 0 || rb < G::GH - 1) {
-            for (int i = tid; i < G::GH * G::BW; i += nt) {
-                const int ty = i / G::BW, tx = i - ty * G::BW;
-                if (ty < rt) bufA[ty * G::PB + tx] = bufA[rt * G::PB + tx];
-                else if (ty > rb) bufA[ty * G::PB + tx] = bufA[rb * G::PB + tx];
+            const int ntop = max(rt, 0), nbot = max(G::GH - 1 - rb, 0);
+            for (int i = tid; i < G::BW * (ntop + nbot); i += nt) {
+                const int k = i / G::BW, tx = i - k * G::BW;
+                const int ty = k < ntop ? k : rb + 1 + (k - ntop);
+                bufA[ty * G::PB + tx] = bufA[(k < ntop ? rt : rb) * G::PB + tx];
             }
             __syncthreads();
         }

@@ -195,6 +195,10 @@ __device__ __forceinline__ void twiddle_powers(float2 w1, float2* w) {
     for (int q = 2; q < R; ++q) w[q] = (q & 1) ? cmulf(w[q - 1], w1) : cmulf(w[q / 2], w[q / 2]);
 }
 
+// LDS skew for unit-stride transforms: one spare slot every 16 elements.  Late passes walk the data with
+// strides of 8..128 elements; without the skew 4 to 8 lanes of a half-wave land on the same banks.
+__device__ __forceinline__ int fft_padx(int e) { return e + (e >> 4); }
+
 // exact t / d for 0 <= t < 2^22 through a float reciprocal (the integer divide costs ~40 VALU instructions)
 __device__ __forceinline__ int fdiv_i(int t, int d, float inv) {
     int q = (int)((float)t * inv);
@@ -206,7 +210,7 @@ __device__ __forceinline__ int fdiv_i(int t, int d, float inv) {
 
 // one radix-R pass over M transforms.  L = current block length (multiple of R), Lp = L / R.
 // tw[n] = exp(-2 pi i n / N), n < N (LDS).  All offsets are 32-bit (LDS).
-template <int R, bool INV, typename TW>
+template <int R, bool INV, typename TW, bool PAD = false>
 __device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int ms, int L, const TW& tw,
                                          bool lanes_on_m, int tid, int nthreads) {
     const int Lp = L / R;
@@ -221,7 +225,7 @@ __device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int
     for (int t = tid; t < total; t += U * nthreads) {
         const int t2 = t + nthreads;
         const bool has2 = (U == 2) && t2 < total;
-        int off[U], jj[U];
+        int off[U], jj[U], eoff[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int tt = u ? (has2 ? t2 : t) : t;
@@ -230,13 +234,14 @@ __device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int
             else { m = fdiv_i(tt, per, inv_per); bj = tt - m * per; }
             const int b = (Lp == per) ? 0 : fdiv_i(bj, Lp, inv_Lp);
             jj[u] = bj - b * Lp;
-            off[u] = m * ms + (b * L + jj[u]) * is;
+            off[u] = PAD ? (m * ms) : (m * ms + (b * L + jj[u]) * is);
+            if (PAD) eoff[u] = b * L + jj[u];
         }
         float2 v[U][R];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[u][q] = base[off[u] + q * leg];
+            for (int q = 0; q < R; ++q) v[u][q] = base[PAD ? off[u] + fft_padx(eoff[u] + q * Lp) : off[u] + q * leg];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (INV) {
@@ -266,16 +271,16 @@ __device__ __forceinline__ void fft_pass(float2* base, int N, int M, int is, int
             }
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) base[off[0] + q * leg] = v[0][q];
+        for (int q = 0; q < R; ++q) base[PAD ? off[0] + fft_padx(eoff[0] + q * Lp) : off[0] + q * leg] = v[0][q];
         if (has2) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) base[off[U - 1] + q * leg] = v[U - 1][q];
+            for (int q = 0; q < R; ++q) base[PAD ? off[U - 1] + fft_padx(eoff[U - 1] + q * Lp) : off[U - 1] + q * leg] = v[U - 1][q];
         }
     }
 }
 
 // full batched transform; every pass ends with a workgroup barrier
-template <bool INV, typename TW, int MAXR = 16>
+template <bool INV, typename TW, int MAXR = 16, bool PAD = false>
 __device__ __forceinline__ void fft_batch_tw(float2* base, const FftPlan& plan, int M, int is, int ms, const TW& tw, bool lanes_on_m) {
     const int N = plan.n;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -283,12 +288,12 @@ __device__ __forceinline__ void fft_batch_tw(float2* base, const FftPlan& plan, 
         int L = N;
         for (int s = 0; s < plan.nf; ++s) {
             const int r = plan.radix[s];
-            if (MAXR >= 16 && r == 16) fft_pass<16, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (MAXR >= 8 && r == 8) fft_pass<8, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (r == 4) fft_pass<4, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (r == 2) fft_pass<2, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (r == 5) fft_pass<5, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else fft_pass<3, false>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            if (MAXR >= 16 && r == 16) fft_pass<16, false, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (MAXR >= 8 && r == 8) fft_pass<8, false, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 4) fft_pass<4, false, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 2) fft_pass<2, false, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 5) fft_pass<5, false, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else fft_pass<3, false, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             L /= r;
             __syncthreads();
         }
@@ -297,12 +302,12 @@ __device__ __forceinline__ void fft_batch_tw(float2* base, const FftPlan& plan, 
         for (int s = plan.nf - 1; s >= 0; --s) {
             const int r = plan.radix[s];
             L *= r;
-            if (MAXR >= 16 && r == 16) fft_pass<16, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (MAXR >= 8 && r == 8) fft_pass<8, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (r == 4) fft_pass<4, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (r == 2) fft_pass<2, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else if (r == 5) fft_pass<5, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
-            else fft_pass<3, true>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            if (MAXR >= 16 && r == 16) fft_pass<16, true, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (MAXR >= 8 && r == 8) fft_pass<8, true, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 4) fft_pass<4, true, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 2) fft_pass<2, true, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else if (r == 5) fft_pass<5, true, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
+            else fft_pass<3, true, TW, PAD>(base, N, M, is, ms, L, tw, lanes_on_m, tid, nt);
             __syncthreads();
         }
     }

@@ -405,7 +405,7 @@ __device__ __forceinline__ void load_tw(float2* hi, float2* lo, const float2* gh
 
 __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGeom g, float2* __restrict__ T0, float2* __restrict__ T1) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int Fw = g.Fw, Sw = g.Sw, TR = g.TR, pitch = Fw + 1;
+    const int Fw = g.Fw, Sw = g.Sw, TR = g.TR, pitch = fft_padx(Fw) + 1;
     float2* G = lds;
     float2* thi = G + (size_t)TR * pitch;
     float2* tlo = thi + 64;
@@ -426,24 +426,37 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
         s1 = g.img1 + (size_t)n * h1 * w1;
     }
     load_tw(thi, tlo, g.twW_hi, g.twW_lo);
-    for (int i = tid; i < Fw; i += nt) posW[i] = (short)fft_pos(g.pw, i);
-    // packed load z = img0 + i img1 (zero padded), branch-free
-    for (int r = 0; r < TR; ++r) {
-        const int y = y0 + r;
-        const int gy0 = oy0 + y, gy1 = oy1 + y;
-        const bool vy0 = y < h0 && gy0 >= 0 && gy0 <= my0, vy1 = y < h1 && gy1 >= 0 && gy1 <= my1;
-        const float* r0 = s0 + (size_t)min(max(gy0, 0), my0) * p0;
-        const float* r1 = s1 + (size_t)min(max(gy1, 0), my1) * p1;
-        for (int x = tid; x < Fw; x += nt) {
-            const int gx0 = ox0 + x, gx1 = ox1 + x;
-            const float a = r0[min(max(gx0, 0), mx0)], b = r1[min(max(gx1, 0), mx1)];
-            const bool v0 = vy0 && x < w0 && gx0 >= 0 && gx0 <= mx0;
-            const bool v1 = vy1 && x < w1 && gx1 >= 0 && gx1 <= mx1;
-            G[r * pitch + x] = make_float2(v0 ? a : 0.f, v1 ? b : 0.f);
+    for (int i = tid; i < Fw; i += nt) posW[i] = (short)fft_padx(fft_pos(g.pw, i));
+    // packed load z = img0 + i img1 (zero padded), branch-free; all rows of a column chunk are fetched before
+    // any LDS store so that the loads overlap
+    for (int xb = 0; xb < Fw; xb += nt) {
+        const int x = xb + tid;
+        const int gx0 = ox0 + x, gx1 = ox1 + x;
+        const bool vx0 = x < w0 && gx0 >= 0 && gx0 <= mx0, vx1 = x < w1 && gx1 >= 0 && gx1 <= mx1;
+        const int cx0 = min(max(gx0, 0), mx0), cx1 = min(max(gx1, 0), mx1);
+        float a[16], b[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r < TR) {
+                const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
+                a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
+                b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
+            }
+        }
+        if (x < Fw) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r < TR) {
+                    const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
+                    const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
+                    const bool v1 = vx1 && y < h1 && gy1 >= 0 && gy1 <= my1;
+                    G[r * pitch + fft_padx(x)] = make_float2(v0 ? a[r] : 0.f, v1 ? b[r] : 0.f);
+                }
+            }
         }
     }
     __syncthreads();
-    fft_batch_tw<false>(G, g.pw, TR, 1, pitch, TwSplit{thi, tlo}, false);
+    fft_batch_tw<false, TwSplit, 16, true>(G, g.pw, TR, 1, pitch, TwSplit{thi, tlo}, false);
     // split the packed spectra and store transposed: lanes walk the TR rows (contiguous in T)
     const size_t tbase = (size_t)n * Sw * g.Hs;
     for (int t = tid; t < Sw * TR; t += nt) {
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
 __global__ __launch_bounds__(256, 4) void ncc_stream_cols(const StreamGeom g, const float2* __restrict__ T0, const float2* __restrict__ T1,
                                                        float2* __restrict__ V0, float2* __restrict__ V1) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int Fh = g.Fh, pitch = Fh + 1;
+    const int Fh = g.Fh, pitch = fft_padx(Fh) + 1;
     float2* U = lds;                      // [2][pitch]
     float2* thi = U + 2 * (size_t)pitch;
     float2* tlo = thi + 64;
@@ -467,24 +480,35 @@ __global__ __launch_bounds__(256, 4) void ncc_stream_cols(const StreamGeom g, co
     const int tid = threadIdx.x, nt = blockDim.x;
     load_tw(thi, tlo, g.twH_hi, g.twH_lo);
     const size_t tb = ((size_t)n * g.Sw + kx) * g.Hs;
-    for (int y = tid; y < Fh; y += nt) {
-        const bool in = y < g.Hs;
-        U[y] = in ? T0[tb + y] : make_float2(0.f, 0.f);
-        U[pitch + y] = in ? T1[tb + y] : make_float2(0.f, 0.f);
+    for (int yb = 0; yb < Fh; yb += 8 * nt) {
+        float2 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int y = yb + u * nt + tid;
+            const bool in = y < g.Hs;
+            a[u] = in ? T0[tb + y] : make_float2(0.f, 0.f);
+            b[u] = in ? T1[tb + y] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int y = yb + u * nt + tid;
+            if (y < Fh) { U[fft_padx(y)] = a[u]; U[pitch + fft_padx(y)] = b[u]; }
+        }
     }
     __syncthreads();
-    fft_batch_tw<false>(U, g.ph, 2, 1, pitch, TwSplit{thi, tlo}, false);
+    fft_batch_tw<false, TwSplit, 16, true>(U, g.ph, 2, 1, pitch, TwSplit{thi, tlo}, false);
     for (int y = tid; y < Fh; y += nt) {
-        const float2 a = U[y], b = U[pitch + y];
-        U[y] = make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
-        U[pitch + y] = g.want_q ? make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x) : make_float2(0.f, 0.f);
+        const int yp = fft_padx(y);
+        const float2 a = U[yp], b = U[pitch + yp];
+        U[yp] = make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+        U[pitch + yp] = g.want_q ? make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x) : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    fft_batch_tw<true>(U, g.ph, g.want_q ? 2 : 1, 1, pitch, TwSplit{thi, tlo}, false);
+    fft_batch_tw<true, TwSplit, 16, true>(U, g.ph, g.want_q ? 2 : 1, 1, pitch, TwSplit{thi, tlo}, false);
     const size_t vb = ((size_t)n * g.Sw + kx) * Fh;
     for (int y = tid; y < Fh; y += nt) {
-        V0[vb + y] = U[y];
-        if (g.want_q) V1[vb + y] = U[pitch + y];
+        V0[vb + y] = U[fft_padx(y)];
+        if (g.want_q) V1[vb + y] = U[pitch + fft_padx(y)];
     }
 }
 
@@ -494,7 +518,7 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_inv(const StreamGeo
                                                                  PeakPartial* __restrict__ part, const PeakPartial* __restrict__ part_in,
                                                                  int nparts, float* __restrict__ ct9) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int Fh = g.Fh, Fw = g.Fw, Sw = g.Sw, pitch = Fw + 1;
+    const int Fh = g.Fh, Fw = g.Fw, Sw = g.Sw, pitch = fft_padx(Fw) + 1;
     const bool neigh = ct9 != nullptr;
     const int TRI = neigh ? 4 : g.TRI;
     float2* G = lds;
@@ -507,7 +531,7 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_inv(const StreamGeo
     const int n = blockIdx.y;
     const int tid = threadIdx.x, nt = blockDim.x;
     load_tw(thi, tlo, g.twW_hi, g.twW_lo);
-    for (int i = tid; i < Fw; i += nt) posW[i] = (short)fft_pos(g.pw, i);
+    for (int i = tid; i < Fw; i += nt) posW[i] = (short)fft_padx(fft_pos(g.pw, i));
     int y0 = blockIdx.x * TRI;
     int py = 0, px = 0;
     if (neigh) {
@@ -524,24 +548,35 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_inv(const StreamGeo
     __syncthreads();
     const int nmir = Fw - Sw;
     const size_t vb = (size_t)n * Sw * Fh;
-    for (int t = tid; t < Sw * TRI; t += nt) {
-        const int r = t & (TRI - 1), kx = t / TRI;
-        int y = y0 + r;
-        bool ok = y < Fh;
-        if (neigh) { y = (py + r - 1 + Fh) % Fh; ok = r < 3; }
-        float2 pk = make_float2(0.f, 0.f), qk = make_float2(0.f, 0.f);
-        if (ok) {
-            pk = V0[vb + (size_t)kx * Fh + y];
-            if (g.want_q) qk = V1[vb + (size_t)kx * Fh + y];
+    for (int tb = 0; tb < Sw * TRI; tb += 8 * nt) {
+        float2 pk[8], qk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = tb + u * nt + tid;
+            const int r = t & (TRI - 1), kx = min(t / TRI, Sw - 1);
+            int y = y0 + r;
+            bool ok = y < Fh && t < Sw * TRI;
+            if (neigh) { y = (py + r - 1 + Fh) % Fh; ok = r < 3 && t < Sw * TRI; }
+            y = min(y, Fh - 1);
+            pk[u] = V0[vb + (size_t)kx * Fh + y];
+            qk[u] = g.want_q ? V1[vb + (size_t)kx * Fh + y] : make_float2(0.f, 0.f);
+            if (!ok) { pk[u] = make_float2(0.f, 0.f); qk[u] = make_float2(0.f, 0.f); }
         }
-        const bool self = (kx == 0) || (2 * kx == Fw);
-        G[r * pitch + posW[kx]] = self ? make_float2(pk.x, qk.x) : make_float2(pk.x - qk.y, pk.y + qk.x);
-        if (kx >= 1 && kx <= nmir) G[r * pitch + posW[Fw - kx]] = make_float2(pk.x + qk.y, qk.x - pk.y);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = tb + u * nt + tid;
+            if (t < Sw * TRI) {
+                const int r = t & (TRI - 1), kx = t / TRI;
+                const bool self = (kx == 0) || (2 * kx == Fw);
+                G[r * pitch + posW[kx]] = self ? make_float2(pk[u].x, qk[u].x) : make_float2(pk[u].x - qk[u].y, pk[u].y + qk[u].x);
+                if (kx >= 1 && kx <= nmir) G[r * pitch + posW[Fw - kx]] = make_float2(pk[u].x + qk[u].y, qk[u].x - pk[u].y);
+            }
+        }
     }
     __syncthreads();
-    fft_batch_tw<true>(G, g.pw, TRI, 1, pitch, TwSplit{thi, tlo}, false);
+    fft_batch_tw<true, TwSplit, 16, true>(G, g.pw, TRI, 1, pitch, TwSplit{thi, tlo}, false);
     if (neigh) {
-        if (tid < 9) ct9[(size_t)n * 9 + tid] = G[(tid / 3) * pitch + (px + (tid % 3 - 1) + Fw) % Fw].x;
+        if (tid < 9) ct9[(size_t)n * 9 + tid] = G[(tid / 3) * pitch + fft_padx((px + (tid % 3 - 1) + Fw) % Fw)].x;
         return;
     }
     float v = -INFINITY; int iv = 0x7fffffff; float mm = 0.f;
@@ -550,7 +585,7 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_inv(const StreamGeo
         const int y = y0 + r;
         if (y >= Fh) break;
         for (int x = tid; x < Fw; x += nt) {
-            const float2 c = G[r * pitch + x];
+            const float2 c = G[r * pitch + fft_padx(x)];
             if (c.x > v) { v = c.x; iv = y * Fw + x; }
             mm = fmaxf(mm, fabsf(c.y));
             if (g.want_std) { s += (double)c.x; ss += (double)c.x * (double)c.x; }
@@ -612,7 +647,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     StreamGeom g;
     g.N = nb; g.Fh = Fh; g.Fw = Fw; g.Sw = Fw / 2 + 1;
     const size_t lds_budget = (getenv("FB_TRB") ? (size_t)atoi(getenv("FB_TRB")) : 70) * 1024;
-    g.TR = std::min(16, pow2_floor((int)std::max<size_t>(1, lds_budget / ((size_t)(Fw + 1) * sizeof(float2)))));
+    g.TR = std::min(16, pow2_floor((int)std::max<size_t>(1, lds_budget / ((size_t)(Fw + Fw / 16 + 1) * sizeof(float2)))));
     g.TRI = g.TR;
     const int rows = std::min(Fh, std::max(1, hmax));
     g.Hs = (rows + g.TR - 1) / g.TR * g.TR;
@@ -642,12 +677,12 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     float2 *T0 = (float2*)(base + oT0), *T1 = (float2*)(base + oT1), *V0 = (float2*)(base + oV0), *V1 = (float2*)(base + oV1);
     PeakPartial* part = (PeakPartial*)(base + oP);
     float* ct9 = (float*)(base + oC);
-    const size_t lds_rows = ((size_t)g.TR * (Fw + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
-    const size_t lds_cols = (2 * (size_t)(Fh + 1) + 128) * sizeof(float2);
-    const size_t lds_inv = ((size_t)g.TRI * (Fw + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
+    const size_t lds_rows = ((size_t)g.TR * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
+    const size_t lds_cols = (2 * (size_t)(Fh + Fh / 16 + 1) + 128) * sizeof(float2);
+    const size_t lds_inv = ((size_t)g.TRI * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
-    FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_inv, ((size_t)4 * (Fw + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) * sizeof(short))));
+    FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_inv, ((size_t)4 * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) * sizeof(short))));
     const double in_bytes = crop ? 8.0 * hmax * wmax : 4.0 * ((double)H0 * W0 + (double)H1 * W1);
     const double nq = g.want_q ? 2.0 : 1.0;
     {
@@ -664,7 +699,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     }
     if (subpixel) {
         FB_PROF(ctx, "ncc_stream_neighbors");
-        const size_t lds_n = ((size_t)4 * (Fw + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
+        const size_t lds_n = ((size_t)4 * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
         hipLaunchKernelGGL(ncc_stream_inv, dim3(1, nb), dim3(kStreamThreads), lds_n, ctx->stream, g, V0, V1, nullptr, part, ntiles, ct9);
     }
     {
@@ -815,3 +850,59 @@ int fb_ncc_last_surfaces(fb_ctx* ctx, float* C_out, float* Cm_out, int* Fh, int*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// test hook: batched 1-D complex FFT through the LDS mixed-radix core (forward: natural order out)
+namespace {
+template <bool PAD>
+__global__ __launch_bounds__(256) void debug_fft_kernel(const float2* __restrict__ in, float2* __restrict__ out, int M, FftPlan plan,
+                                                        const float2* ghi, const float2* glo, int inverse) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int N = plan.n, pitch = (PAD ? fft_padx(N) : N) + 1;
+    float2* G = lds;
+    float2* thi = G + (size_t)M * pitch;
+    float2* tlo = thi + 64;
+    load_tw(thi, tlo, ghi, glo);
+    for (int i = threadIdx.x; i < M * N; i += blockDim.x) {
+        const int m = i / N, e = i - m * N;
+        // the inverse consumes digit-reversed input
+        const int src = inverse ? fft_pos(plan, e) : e;
+        G[m * pitch + (PAD ? fft_padx(src) : src)] = in[i];
+    }
+    __syncthreads();
+    if (inverse) fft_batch_tw<true, TwSplit, 16, PAD>(G, plan, M, 1, pitch, TwSplit{thi, tlo}, false);
+    else fft_batch_tw<false, TwSplit, 16, PAD>(G, plan, M, 1, pitch, TwSplit{thi, tlo}, false);
+    for (int i = threadIdx.x; i < M * N; i += blockDim.x) {
+        const int m = i / N, k = i - m * N;
+        const int pos = inverse ? k : fft_pos(plan, k);
+        out[i] = G[m * pitch + (PAD ? fft_padx(pos) : pos)];
+    }
+}
+}  // namespace
+
+extern "C" int fb_debug_fft1d(fb_ctx* ctx, const float* in_host, float* out_host, int M, int N, int inverse, int pad) {
+    FB_CHECK_ARG(ctx, M > 0 && N >= 2 && N <= 4096 && in_host && out_host);
+    FftPlan plan;
+    if (!fft_make_plan(N, &plan)) return fb_fail(ctx, FB_ERR_ARG, "fb_debug_fft1d: %d is not 5-smooth", N);
+    const float2 *hi, *lo;
+    int rc = get_split_table(ctx, N, &hi, &lo);
+    if (rc) return rc;
+    const size_t bytes = sizeof(float2) * (size_t)M * N;
+    const size_t lds = ((size_t)M * (N + N / 16 + 2) + 128) * sizeof(float2);
+    if (lds > 150 * 1024) return fb_fail(ctx, FB_ERR_ARG, "fb_debug_fft1d: M*N too large for LDS");
+    float2 *din = nullptr, *dout = nullptr;
+    FB_HIP(ctx, hipMalloc((void**)&din, bytes));
+    FB_HIP(ctx, hipMalloc((void**)&dout, bytes));
+    FB_HIP(ctx, hipMemcpyAsync(din, in_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (pad) {
+        FB_HIP(ctx, hipFuncSetAttribute((const void*)debug_fft_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(debug_fft_kernel<true>, dim3(1), dim3(256), lds, ctx->stream, din, dout, M, plan, hi, lo, inverse);
+    } else {
+        FB_HIP(ctx, hipFuncSetAttribute((const void*)debug_fft_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(debug_fft_kernel<false>, dim3(1), dim3(256), lds, ctx->stream, din, dout, M, plan, hi, lo, inverse);
+    }
+    FB_HIP(ctx, hipMemcpyAsync(out_host, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(din); hipFree(dout);
+    return FB_OK;
+}

@@ -109,6 +109,10 @@ int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int I
  * last fb_ncc_batch* call that went through the streaming (rocFFT) class. */
 int fb_ncc_last_surfaces(fb_ctx* ctx, float* C_out, float* Cm_out, int* Fh, int* Fw);
 
+/* test hook: M complex transforms of length N (5-smooth, <= 4096) through the LDS FFT core the NCC
+ * kernels are built on; in/out are host arrays [M][N][2] float32; inverse is un-normalised. */
+int fb_debug_fft1d(fb_ctx* ctx, const float* in_host, float* out_host, int M, int N, int inverse, int pad);
+
 /* common.masked_dog_filter (common.py:353-377).  img: [N][H][W] uint8 or float32;
  * mask: [H][W] uint8 (0 = outside) or NULL; out: [N][H][W] float32. */
 int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma,

@@ -1,0 +1,22 @@
+"""The LDS mixed-radix FFT core (feabas_amd/csrc/fb_ldsfft.h) against numpy, every radix mix the NCC path uses."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('n', [2, 8, 16, 64, 75, 72, 150, 144, 135, 500, 512, 576, 1000, 1024, 2048, 3000, 4096])
+@pytest.mark.parametrize('pad', [0, 1])
+def test_fft1d_vs_numpy(fb, n, pad):
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(n)
+    m = max(1, min(4, 8192 // n))
+    x = (rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))).astype(np.complex64)
+    out = np.empty_like(x)
+    _lib.check(lib.fb_debug_fft1d(ctx, _lib.ptr(x), _lib.ptr(out), m, n, 0, pad))
+    ref = np.fft.fft(x.astype(np.complex128), axis=-1)
+    assert np.abs(out - ref).max() <= 3e-6 * np.abs(ref).max()
+    _lib.check(lib.fb_debug_fft1d(ctx, _lib.ptr(x), _lib.ptr(out), m, n, 1, pad))
+    ref = np.fft.ifft(x.astype(np.complex128), axis=-1) * n
+    assert np.abs(out - ref).max() <= 3e-6 * np.abs(ref).max()
