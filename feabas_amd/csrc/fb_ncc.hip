@@ -386,7 +386,7 @@ int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
 // HBM traffic per block pair = inputs + 16 S_h (T write) + 16 S_h (T read) + 16 S (V write)
 // + 16 S (V read), S = Fh (Fw/2+1), S_h = Hs (Fw/2+1): the algorithmic minimum of SURVEY.md 8(d).
 struct StreamGeom {
-    int N, Fh, Fw, Sw, Hs, TR, TRI;
+    int N, Fh, Fw, Sw, Kp, Hs, TR, TRI;   // Kp = ceil(Sw / 2): spectra are stored as interleaved column pairs
     int H0, W0, H1, W1;
     FftPlan pw, ph;
     const float2 *twW_hi, *twW_lo, *twH_hi, *twH_lo;
@@ -457,58 +457,72 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
     }
     __syncthreads();
     fft_batch_tw<false, TwSplit, 16, true>(G, g.pw, TR, 1, pitch, TwSplit{thi, tlo}, false);
-    // split the packed spectra and store transposed: lanes walk the TR rows (contiguous in T)
-    const size_t tbase = (size_t)n * Sw * g.Hs;
-    for (int t = tid; t < Sw * TR; t += nt) {
-        const int r = t & (TR - 1), kx = t / TR;
-        const float2 zk = G[r * pitch + posW[kx]];
-        const float2 zn = G[r * pitch + posW[kx == 0 ? 0 : Fw - kx]];
-        const size_t o = tbase + (size_t)kx * g.Hs + y0 + r;
-        T0[o] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-        T1[o] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    // split the packed spectra and store transposed as interleaved column pairs T[n][kx/2][y][kx&1]:
+    // a (pair, tile) is 2*TR consecutive float2 = 128 B at TR = 8, lanes walk it contiguously
+    const size_t tbase = (size_t)n * g.Kp * g.Hs * 2;
+    for (int t = tid; t < 2 * g.Kp * TR; t += nt) {
+        const int c = t & 1, r = (t >> 1) & (TR - 1), kp = t / (2 * TR);
+        const int kx = 2 * kp + c;
+        float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+        if (kx < Sw) {
+            const float2 zk = G[r * pitch + posW[kx]];
+            const float2 zn = G[r * pitch + posW[kx == 0 ? 0 : Fw - kx]];
+            a = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            b = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        }
+        const size_t o = tbase + ((size_t)kp * g.Hs + y0 + r) * 2 + c;
+        T0[o] = a;
+        T1[o] = b;
     }
 }
 
-__global__ __launch_bounds__(256, 4) void ncc_stream_cols(const StreamGeom g, const float2* __restrict__ T0, const float2* __restrict__ T1,
-                                                       float2* __restrict__ V0, float2* __restrict__ V1) {
+// one workgroup = one PAIR of adjacent kx columns of one block pair: four length-Fh transforms
+// (image 0/1 x column 0/1) forward, products, inverse.  Loads and stores are fully contiguous.
+__global__ __launch_bounds__(kStreamThreads) void ncc_stream_cols(const StreamGeom g, const float2* __restrict__ T0, const float2* __restrict__ T1,
+                                                                  float2* __restrict__ V0, float2* __restrict__ V1) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int Fh = g.Fh, pitch = fft_padx(Fh) + 1;
-    float2* U = lds;                      // [2][pitch]
-    float2* thi = U + 2 * (size_t)pitch;
+    float2* U = lds;                      // [4][pitch]: (img0,c0) (img0,c1) (img1,c0) (img1,c1)
+    float2* thi = U + 4 * (size_t)pitch;
     float2* tlo = thi + 64;
-    const int kx = blockIdx.x, n = blockIdx.y;
+    const int kp = blockIdx.x, n = blockIdx.y;
     const int tid = threadIdx.x, nt = blockDim.x;
     load_tw(thi, tlo, g.twH_hi, g.twH_lo);
-    const size_t tb = ((size_t)n * g.Sw + kx) * g.Hs;
-    for (int yb = 0; yb < Fh; yb += 8 * nt) {
+    const size_t tb = ((size_t)n * g.Kp + kp) * g.Hs * 2;
+    for (int eb = 0; eb < 2 * Fh; eb += 8 * nt) {
         float2 a[8], b[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int y = yb + u * nt + tid;
-            const bool in = y < g.Hs;
-            a[u] = in ? T0[tb + y] : make_float2(0.f, 0.f);
-            b[u] = in ? T1[tb + y] : make_float2(0.f, 0.f);
+            const int e = eb + u * nt + tid;            // e = 2 y + c
+            const bool in = e < 2 * g.Hs;
+            a[u] = in ? T0[tb + e] : make_float2(0.f, 0.f);
+            b[u] = in ? T1[tb + e] : make_float2(0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int y = yb + u * nt + tid;
-            if (y < Fh) { U[fft_padx(y)] = a[u]; U[pitch + fft_padx(y)] = b[u]; }
+            const int e = eb + u * nt + tid;
+            if (e < 2 * Fh) {
+                const int c = e & 1, yp = fft_padx(e >> 1);
+                U[c * pitch + yp] = a[u];
+                U[(2 + c) * pitch + yp] = b[u];
+            }
         }
     }
     __syncthreads();
-    fft_batch_tw<false, TwSplit, 16, true>(U, g.ph, 2, 1, pitch, TwSplit{thi, tlo}, false);
-    for (int y = tid; y < Fh; y += nt) {
-        const int yp = fft_padx(y);
-        const float2 a = U[yp], b = U[pitch + yp];
-        U[yp] = make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
-        U[pitch + yp] = g.want_q ? make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x) : make_float2(0.f, 0.f);
+    fft_batch_tw<false, TwSplit, 16, true>(U, g.ph, 4, 1, pitch, TwSplit{thi, tlo}, false);
+    for (int e = tid; e < 2 * Fh; e += nt) {
+        const int c = e & 1, yp = fft_padx(e >> 1);
+        const float2 a = U[c * pitch + yp], b = U[(2 + c) * pitch + yp];
+        U[c * pitch + yp] = make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+        U[(2 + c) * pitch + yp] = g.want_q ? make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x) : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    fft_batch_tw<true, TwSplit, 16, true>(U, g.ph, g.want_q ? 2 : 1, 1, pitch, TwSplit{thi, tlo}, false);
-    const size_t vb = ((size_t)n * g.Sw + kx) * Fh;
-    for (int y = tid; y < Fh; y += nt) {
-        V0[vb + y] = U[fft_padx(y)];
-        if (g.want_q) V1[vb + y] = U[pitch + fft_padx(y)];
+    fft_batch_tw<true, TwSplit, 16, true>(U, g.ph, g.want_q ? 4 : 2, 1, pitch, TwSplit{thi, tlo}, false);
+    const size_t vb = ((size_t)n * g.Kp + kp) * Fh * 2;
+    for (int e = tid; e < 2 * Fh; e += nt) {
+        const int c = e & 1, yp = fft_padx(e >> 1);
+        V0[vb + e] = U[c * pitch + yp];
+        if (g.want_q) V1[vb + e] = U[(2 + c) * pitch + yp];
     }
 }
 
@@ -547,26 +561,29 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_inv(const StreamGeo
     }
     __syncthreads();
     const int nmir = Fw - Sw;
-    const size_t vb = (size_t)n * Sw * Fh;
-    for (int tb = 0; tb < Sw * TRI; tb += 8 * nt) {
+    const size_t vb = (size_t)n * g.Kp * Fh * 2;
+    const int nitems = 2 * g.Kp * TRI;
+    for (int tb = 0; tb < nitems; tb += 8 * nt) {
         float2 pk[8], qk[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int t = tb + u * nt + tid;
-            const int r = t & (TRI - 1), kx = min(t / TRI, Sw - 1);
+            const int t = min(tb + u * nt + tid, nitems - 1);
+            const int c = t & 1, r = (t >> 1) & (TRI - 1), kp = t / (2 * TRI);
             int y = y0 + r;
-            bool ok = y < Fh && t < Sw * TRI;
-            if (neigh) { y = (py + r - 1 + Fh) % Fh; ok = r < 3 && t < Sw * TRI; }
+            bool ok = y < Fh;
+            if (neigh) { y = (py + r - 1 + Fh) % Fh; ok = r < 3; }
             y = min(y, Fh - 1);
-            pk[u] = V0[vb + (size_t)kx * Fh + y];
-            qk[u] = g.want_q ? V1[vb + (size_t)kx * Fh + y] : make_float2(0.f, 0.f);
+            const size_t o = vb + ((size_t)kp * Fh + y) * 2 + c;
+            pk[u] = V0[o];
+            qk[u] = g.want_q ? V1[o] : make_float2(0.f, 0.f);
             if (!ok) { pk[u] = make_float2(0.f, 0.f); qk[u] = make_float2(0.f, 0.f); }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int t = tb + u * nt + tid;
-            if (t < Sw * TRI) {
-                const int r = t & (TRI - 1), kx = t / TRI;
+            const int c = t & 1, r = (t >> 1) & (TRI - 1), kp = t / (2 * TRI);
+            const int kx = 2 * kp + c;
+            if (t < nitems && kx < Sw) {
                 const bool self = (kx == 0) || (2 * kx == Fw);
                 G[r * pitch + posW[kx]] = self ? make_float2(pk[u].x, qk[u].x) : make_float2(pk[u].x - qk[u].y, pk[u].y + qk[u].x);
                 if (kx >= 1 && kx <= nmir) G[r * pitch + posW[Fw - kx]] = make_float2(pk[u].x + qk[u].y, qk[u].x - pk[u].y);
@@ -636,7 +653,8 @@ int get_split_table(fb_ctx* ctx, int n, const float2** hi, const float2** lo) {
 int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
 bool stream_custom_supported(int Fh, int Fw, int C) {
-    if (C != 1 || Fw > 4096 || Fh > 4096 || Fw < 4 || Fh < 2) return false;   // 2-level twiddles cover N <= 4096; posW is int16
+    if (C != 1 || Fw > 4096 || Fh > 4096 || Fw < 4 || Fh < 2) return false;
+    if ((4 * (size_t)(Fh + Fh / 16 + 1) + 128) * sizeof(float2) > 150 * 1024) return false;   // four columns must fit the LDS   // 2-level twiddles cover N <= 4096; posW is int16
     FftPlan p;
     return fft_make_plan(Fh, &p) && fft_make_plan(Fw, &p);
 }
@@ -645,7 +663,7 @@ bool stream_custom_supported(int Fh, int Fw, int C) {
 int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int nb, int H0, int W0, int H1, int W1, int hmax, int wmax, int Fh,
                         int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf, const CropSrc* crop) {
     StreamGeom g;
-    g.N = nb; g.Fh = Fh; g.Fw = Fw; g.Sw = Fw / 2 + 1;
+    g.N = nb; g.Fh = Fh; g.Fw = Fw; g.Sw = Fw / 2 + 1; g.Kp = (g.Sw + 1) / 2;
     const size_t lds_budget = (getenv("FB_TRB") ? (size_t)atoi(getenv("FB_TRB")) : 70) * 1024;
     g.TR = std::min(16, pow2_floor((int)std::max<size_t>(1, lds_budget / ((size_t)(Fw + Fw / 16 + 1) * sizeof(float2)))));
     g.TRI = g.TR;
@@ -662,7 +680,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     g.IH0 = crop ? crop->IH0 : 0; g.IW0 = crop ? crop->IW0 : 0; g.IH1 = crop ? crop->IH1 : 0; g.IW1 = crop ? crop->IW1 : 0;
     g.want_q = conf_mode == FB_CONF_MIRROR;
     g.want_std = conf_mode == FB_CONF_STD;
-    const size_t nT = (size_t)nb * g.Sw * g.Hs, nV = (size_t)nb * g.Sw * Fh;
+    const size_t nT = (size_t)nb * g.Kp * 2 * g.Hs, nV = (size_t)nb * g.Kp * 2 * Fh;
     const int ntiles = (Fh + g.TRI - 1) / g.TRI;
     size_t off = 0;
     const size_t oT0 = off; off += align_up(nT * sizeof(float2), 256);
@@ -678,7 +696,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     PeakPartial* part = (PeakPartial*)(base + oP);
     float* ct9 = (float*)(base + oC);
     const size_t lds_rows = ((size_t)g.TR * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
-    const size_t lds_cols = (2 * (size_t)(Fh + Fh / 16 + 1) + 128) * sizeof(float2);
+    const size_t lds_cols = (4 * (size_t)(Fh + Fh / 16 + 1) + 128) * sizeof(float2);
     const size_t lds_inv = ((size_t)g.TRI * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
@@ -691,7 +709,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     }
     {
         FB_PROF_B(ctx, "ncc_stream_cols", (double)nb * g.Sw * (16.0 * g.Hs + 8.0 * nq * Fh));
-        hipLaunchKernelGGL(ncc_stream_cols, dim3(g.Sw, nb), dim3(256), lds_cols, ctx->stream, g, T0, T1, V0, V1);
+        hipLaunchKernelGGL(ncc_stream_cols, dim3(g.Kp, nb), dim3(kStreamThreads), lds_cols, ctx->stream, g, T0, T1, V0, V1);
     }
     {
         FB_PROF_B(ctx, "ncc_stream_inv", (double)nb * g.Sw * 8.0 * nq * Fh);
@@ -713,7 +731,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
 }
 
 size_t custom_bytes_per_pair(int Fh, int Fw, int hmax) {
-    const size_t Sw = Fw / 2 + 1;
+    const size_t Sw = (size_t)(Fw / 2 + 2) / 2 * 2;      // column pairs
     return 2 * Sw * (size_t)(std::min(Fh, hmax) + 16) * 8 + 2 * Sw * (size_t)Fh * 8 + 4096;
 }
 

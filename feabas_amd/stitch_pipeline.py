@@ -67,6 +67,7 @@ class StripBatchMatcher:
         self.mnb = int(min_num_blocks)
         self.conf_mode = int(conf_mode)
         self.spacings = np.sort(auto_spacings((H, W), (H, W)))[::-1]     # matcher.py:243-251, 567
+        self._nfl = np.array([next_fast_len(v) for v in range(0, 2 * max(H, W) + 2)])
         hc, wc = (H // 2, W // 2) if coarse_downsample == 0.5 else (H, W)
         self.hc, self.wc = hc, wc
         n = self.P
@@ -151,8 +152,7 @@ class StripBatchMatcher:
         xmin = np.maximum(-0.5 + tx, -0.5 + t1[:, 0]); xmax = np.minimum(W - 0.5 + tx, W - 0.5 + t1[:, 0])
         ymin = np.maximum(-0.5 + ty, -0.5 + t1[:, 1]); ymax = np.minimum(H - 0.5 + ty, H - 0.5 + t1[:, 1])
         nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
-        nfl_h = np.array([next_fast_len(v) for v in range(0, 2 * H + 2)])
-        nfl_w = nfl_h if W == H else np.array([next_fast_len(v) for v in range(0, 2 * W + 2)])
+        nfl_h = nfl_w = self._nfl
         fh = np.where(pad_flags, nfl_h[np.clip(2 * dy - 1, 0, None)], nfl_h[dy])
         fw = np.where(pad_flags, nfl_w[np.clip(2 * dx - 1, 0, None)], nfl_w[dx])
         key = ((nx * 4096 + ny) * 8192 + fh) * 8192 + fw
