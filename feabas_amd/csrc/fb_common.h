@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -29,6 +30,9 @@ struct fb_fft_plan {
 };
 
 struct fb_ctx {
+    // every compute entry point holds this while it enqueues: calls from several host threads interleave at
+    // call granularity only (the scratch arena and the profile are shared)
+    std::recursive_mutex mtx;
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -91,6 +95,7 @@ struct fb_prof_scope {
     fb_prof_scope(fb_ctx* c, const char* name, double bytes = 0.0);
     ~fb_prof_scope();
 };
+#define FB_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock_guard__((ctx)->mtx)
 #define FB_PROF(ctx, name) fb_prof_scope prof_scope__((ctx), (name))
 #define FB_PROF_B(ctx, name, bytes) fb_prof_scope prof_scope__((ctx), (name), (double)(bytes))
 

@@ -130,6 +130,7 @@ int fb_device_info(fb_ctx* ctx, char* name, int name_len, int* num_cu, size_t* h
 }
 
 int fb_malloc(fb_ctx* ctx, size_t bytes, void** dptr) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, dptr != nullptr);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     void* p = nullptr;
@@ -141,6 +142,7 @@ int fb_malloc(fb_ctx* ctx, size_t bytes, void** dptr) {
 }
 
 int fb_free(fb_ctx* ctx, void* dptr) {
+    FB_LOCK(ctx);
     if (!dptr) return FB_OK;
     for (size_t i = 0; i < ctx->owned.size(); ++i) {
         if (ctx->owned[i] == dptr) {
@@ -183,23 +185,27 @@ int fb_timer_stop(fb_ctx* ctx, float* ms) {
 }
 
 int fb_prof_enable(fb_ctx* ctx, int on) {
+    FB_LOCK(ctx);
     if (!on) prof_drain(ctx);
     ctx->prof_on = on != 0;
     return FB_OK;
 }
 
 int fb_prof_reset(fb_ctx* ctx) {
+    FB_LOCK(ctx);
     prof_drain(ctx);
     ctx->prof.clear();
     return FB_OK;
 }
 
 int fb_prof_count(fb_ctx* ctx) {
+    FB_LOCK(ctx);
     prof_drain(ctx);
     return (int)ctx->prof.size();
 }
 
 int fb_prof_get(fb_ctx* ctx, int index, char* name, int name_len, int* launches, double* total_ms, double* total_bytes) {
+    FB_LOCK(ctx);
     prof_drain(ctx);
     FB_CHECK_ARG(ctx, index >= 0 && index < (int)ctx->prof.size());
     const fb_prof_entry& p = ctx->prof[index];

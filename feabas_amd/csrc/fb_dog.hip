@@ -247,7 +247,7 @@ __device__ __forceinline__ void col_pass(const float* __restrict__ src, int ps, 
 }
 
 template <typename T, int R>
-__global__ __launch_bounds__(256) void dog_fast(const T* __restrict__ img, float* __restrict__ out, int H, int W, int signed_out,
+__global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, float* __restrict__ out, int H, int W, int signed_out,
                                                 const TapsF taps) {
     using G = FastGeom<R>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -349,7 +349,7 @@ int launch_fast(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int 
     auto kern = dog_fast<T, R>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(fb_cdiv(W, FT), fb_cdiv(H, FT), N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img, out, H, W, signed_out, tf);
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, ctx->stream, img, out, H, W, signed_out, tf);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
@@ -447,6 +447,7 @@ extern "C" {
 
 int fb_dog_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* mask,
                int signed_out, float* out) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && sigma > 0);
     FB_CHECK_ARG(ctx, dtype == FB_U8 || dtype == FB_F32);
     if (N == 0) return FB_OK;
@@ -458,6 +459,7 @@ int fb_dog_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, dou
 
 int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* mask, int signed_out,
            float* out) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && sigma > 0);
     FB_CHECK_ARG(ctx, dtype == FB_U8 || dtype == FB_F32);
     if (N == 0) return FB_OK;
@@ -482,6 +484,7 @@ int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double 
 }
 
 int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0));
     if (N == 0) return FB_OK;
     FB_PROF(ctx, "area_down2");
@@ -493,6 +496,7 @@ int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W
 }
 
 int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0));
     if (N == 0) return FB_OK;
     const size_t bi = (size_t)N * H * W, bo = bi / 4;

@@ -254,6 +254,7 @@ int fb_sys_set_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6
 }
 
 int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && !s->finalized);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     const int nv = s->nv;
@@ -361,6 +362,7 @@ int fb_sys_pattern(fb_ctx* ctx, fb_system* s, int64_t* browptr, int32_t* bcol) {
 
 int fb_sys_assemble_mesh(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur, const float* tri_mult,
                          double nu, double soft) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && mesh_id >= 0 && mesh_id < (int)s->meshes.size() && v_shape);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     fb_mesh_blk& m = s->meshes[mesh_id];
@@ -379,6 +381,7 @@ int fb_sys_assemble_mesh(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v
 }
 
 int fb_sys_assemble_links(fb_ctx* ctx, fb_system* s, const double* bary6, const float* w, const double* rxy) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && (s->nlink == 0 || (bary6 && w && rxy)));
     FB_HIP(ctx, hipSetDevice(ctx->device));
     if (s->nlink) {
@@ -397,6 +400,7 @@ int fb_sys_assemble_links(fb_ctx* ctx, fb_system* s, const double* bary6, const 
 }
 
 int fb_sys_lambda(fb_ctx* ctx, fb_system* s, double stiffness_lambda, double crosslink_lambda, double* sl_out, double* cl_out) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && sl_out && cl_out);
     double sl = stiffness_lambda, cl = crosslink_lambda;
     if (sl < 0 || cl < 0) {                                          // optimizer.py:1575-1589
@@ -416,6 +420,7 @@ int fb_sys_lambda(fb_ctx* ctx, fb_system* s, double stiffness_lambda, double cro
 }
 
 int fb_sys_form(fb_ctx* ctx, fb_system* s, double sl, double cl) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized);
     FB_PROF(ctx, "fem_form_system");
     const int g = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (s->M->nnzb + kT - 1) / kT));
@@ -427,6 +432,7 @@ int fb_sys_form(fb_ctx* ctx, fb_system* s, double sl, double cl) {
 
 int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, double atol, int maxiter, int precond, int* iters,
                  double* relres) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && x);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     if (use_x0) FB_HIP(ctx, hipMemcpyAsync(s->M->x, x, sizeof(double2) * (size_t)s->nv, hipMemcpyHostToDevice, ctx->stream));
@@ -441,6 +447,7 @@ int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, 
 }
 
 int fb_sys_solve_fixed(fb_ctx* ctx, fb_system* s, int iters, double* relres) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && iters > 0);
     FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
     int rc = fb_bsr_setup_jacobi(ctx, s->M, 1);
@@ -451,6 +458,7 @@ int fb_sys_solve_fixed(fb_ctx* ctx, fb_system* s, int iters, double* relres) {
 
 // which: 0 K [nnzb][4] f64, 1 C [nnzb] f32, 2 rhs [2nv] f64, 3 stress [2nv] f32, 4 A [nnzb][4] f64, 5 b [2nv] f64
 int fb_sys_get(fb_ctx* ctx, fb_system* s, int which, void* out) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && out && which >= 0 && which <= 5);
     const size_t nnzb = (size_t)s->M->nnzb, nv = (size_t)s->nv;
     const void* src = nullptr;

@@ -755,6 +755,7 @@ int fb_next_fast_len(int n) {
 
 int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, int C, int H0, int W0, int H1, int W1,
                      int pad, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, N >= 0 && C >= 1 && H0 > 0 && W0 > 0 && H1 > 0 && W1 > 0);
     FB_CHECK_ARG(ctx, conf_mode >= 0 && conf_mode <= 2);
     if (N == 0) return FB_OK;
@@ -792,6 +793,7 @@ int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, i
 
 int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C, int H0, int W0, int H1, int W1, int pad,
                  int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, N >= 0 && C >= 1 && H0 > 0 && W0 > 0 && H1 > 0 && W1 > 0);
     if (N == 0) return FB_OK;
     FB_HIP(ctx, hipSetDevice(ctx->device));
@@ -823,6 +825,7 @@ int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C
 
 int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1, int N,
                       const int* blk, int hmax, int wmax, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, N >= 0 && IH0 > 0 && IW0 > 0 && IH1 > 0 && IW1 > 0 && Fh > 0 && Fw > 0);
     FB_CHECK_ARG(ctx, conf_mode >= 0 && conf_mode <= 2 && (long long)Fh * Fw < (1LL << 31));
     if (N == 0) return FB_OK;
@@ -858,6 +861,7 @@ int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int I
 }
 
 int fb_ncc_last_surfaces(fb_ctx* ctx, float* C_out, float* Cm_out, int* Fh, int* Fw) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, ctx->last_C != nullptr);
     if (Fh) *Fh = ctx->last_Fh;
     if (Fw) *Fw = ctx->last_Fw;
@@ -899,6 +903,7 @@ __global__ __launch_bounds__(256) void debug_fft_kernel(const float2* __restrict
 }  // namespace
 
 extern "C" int fb_debug_fft1d(fb_ctx* ctx, const float* in_host, float* out_host, int M, int N, int inverse, int pad) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, M > 0 && N >= 2 && N <= 4096 && in_host && out_host);
     FftPlan plan;
     if (!fft_make_plan(N, &plan)) return fb_fail(ctx, FB_ERR_ARG, "fb_debug_fft1d: %d is not 5-smooth", N);

@@ -67,6 +67,7 @@ extern "C" {
 
 int fb_synth_strips_dev(fb_ctx* ctx, int P, int pair0, int H, int W, uint32_t seed, int max_shift, int shift_step, uint8_t* strips0,
                         uint8_t* strips1, int* shifts_dev) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, P > 0 && H > 0 && W > 0 && max_shift >= 0 && shift_step >= 1 && strips0 && strips1 && shifts_dev);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(synth_shifts_kernel, dim3(fb_cdiv(P, 256)), dim3(256), 0, ctx->stream, P, pair0, seed, max_shift, shift_step, shifts_dev);

@@ -438,6 +438,7 @@ int fb_csr_to_bsr_host(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int3
 extern "C" {
 
 int fb_csr_upload(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* idx, const double* val, int symmetrize, fb_csr** out) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, n > 0 && indptr && idx && val && out);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<int> browptr, bcol;
@@ -479,6 +480,7 @@ static int upload_vec(fb_ctx* ctx, fb_csr* A, double2* dst, const double* src) {
 }
 
 int fb_spmv(fb_ctx* ctx, fb_csr* A, const double* x_host, double* y_host) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, A && x_host && y_host);
     int rc = upload_vec(ctx, A, A->M->x, x_host);
     if (rc) return rc;
@@ -491,6 +493,7 @@ int fb_spmv(fb_ctx* ctx, fb_csr* A, const double* x_host, double* y_host) {
 
 int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, double rtol, double atol, int maxiter, int precond,
                int* iters, double* relres) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, A && b && x);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     int rc = upload_vec(ctx, A, A->M->b, b);
@@ -507,6 +510,7 @@ int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, d
 }
 
 int fb_pcg_fixed_iters(fb_ctx* ctx, fb_csr* A, const double* b_host, int iters, double* relres) {
+    FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, A && iters > 0);
     int rc;
     if (b_host) {
@@ -522,6 +526,7 @@ int fb_pcg_fixed_iters(fb_ctx* ctx, fb_csr* A, const double* b_host, int iters, 
 
 int fb_pcg(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* idx, const double* val, const double* b, double* x,
            int use_x0, double rtol, double atol, int maxiter, int precond, int symmetrize, int* iters, double* relres) {
+    FB_LOCK(ctx);
     fb_csr* A = nullptr;
     int rc = fb_csr_upload(ctx, n, indptr, idx, val, symmetrize, &A);
     if (rc) return rc;
