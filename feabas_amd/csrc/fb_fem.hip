@@ -20,6 +20,9 @@ struct fb_mesh_blk {
     int* d_vtptr = nullptr;          // [V+1] incident triangle slots per vertex
     int* d_vtidx = nullptr;          // [3T] encoded 3*t + local
     float* d_mult = nullptr;         // [T]
+    int* d_model = nullptr;          // [T] material model per triangle (optional)
+    double* d_nu = nullptr;          // [T]
+    float* d_matmult = nullptr;      // [T]
     double2* d_vshape = nullptr;     // [V]
     double2* d_vcur = nullptr;       // [V]
 };
@@ -58,10 +61,114 @@ __device__ __forceinline__ int find_col(const int* __restrict__ col, int lo, int
     return -1;
 }
 
-// thread per vertex row of one mesh: element stiffness blocks of the incident triangles
+// tangent stiffness rows (2 x 6) and internal force (2) of local vertex `a` of one St-Venant-Kirchhoff (model 1)
+// or Neo-Hookean (model 2) element, float32 like the reference (material.py:185-309, DTYPE = float32)
+__device__ __forceinline__ void nonlinear_element_rows(const double2* pts, const float* uv, int model, float nu, int a,
+                                                      float (&Krow)[2][6], float (&Prow)[2]) {
+#pragma clang fp contract(off)
+    double ex[3], ey[3];
+    ex[0] = pts[1].x - pts[2].x; ey[0] = pts[1].y - pts[2].y;
+    ex[1] = pts[2].x - pts[0].x; ey[1] = pts[2].y - pts[0].y;
+    ex[2] = pts[0].x - pts[1].x; ey[2] = pts[0].y - pts[1].y;
+    const double area2 = fabs(ex[0] * ey[1] - ey[0] * ex[1]);
+    const float af = (float)area2;
+    float B[4][6];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) B[r][c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float t0 = (float)(ey[i] / area2), t1 = (float)(-ex[i] / area2);
+        B[0][2 * i] = t0; B[1][2 * i] = t1; B[2][2 * i + 1] = t0; B[3][2 * i + 1] = t1;
+    }
+    float g[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc += B[r][c] * uv[c];
+        g[r] = acc;
+    }
+    const float F00 = 1.f + g[0], F01 = g[1], F10 = g[2], F11 = 1.f + g[3];      // Ft = (B uv).reshape(2,2) + I
+    float M4[4][4];      // K = scale * B^T M4 B (+ Bn^T D Bn for SVK)
+    float Pv[4];         // P = scale * B^T Pv     (SVK: handled through Bn)
+    float scale;
+    float Bn[3][6]; float Dm[3][3]; float S3[3];
+    const bool svk = model == 1;
+    if (svk) {
+        // E = 1/2 (Ft^T Ft - I) in Voigt form, S = D E, geometric term Sg (material.py:261-291)
+        const float e00 = 0.5f * (F00 * F00 + F10 * F10 - 1.f), e11 = 0.5f * (F01 * F01 + F11 * F11 - 1.f);
+        const float e01 = 0.5f * (F00 * F01 + F10 * F11);
+        const float E3[3] = {e00, e11, e01 + e01};
+        Dm[0][0] = 1.f; Dm[0][1] = nu; Dm[0][2] = 0.f; Dm[1][0] = nu; Dm[1][1] = 1.f; Dm[1][2] = 0.f;
+        Dm[2][0] = 0.f; Dm[2][1] = 0.f; Dm[2][2] = (1.f - nu) / 2.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) S3[r] = Dm[r][0] * E3[0] + Dm[r][1] * E3[1] + Dm[r][2] * E3[2];
+        // Bc = [[1,0,1,0],[0,1,0,1]] B ; Fc column 2i+c = FtT[:, c] ; Bn = [Bc*Fc ; sum(Bc*Fc[::-1])]
+        const float FtT[2][2] = {{F00, F10}, {F01, F11}};
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const float bc0 = B[0][c] + B[2][c], bc1 = B[1][c] + B[3][c];
+            const float fc0 = FtT[0][c & 1], fc1 = FtT[1][c & 1];
+            Bn[0][c] = bc0 * fc0; Bn[1][c] = bc1 * fc1; Bn[2][c] = bc0 * fc1 + bc1 * fc0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) M4[r][c] = 0.f;
+        M4[0][0] = S3[0]; M4[2][2] = S3[0]; M4[1][1] = S3[1]; M4[3][3] = S3[1];
+        M4[0][1] = S3[2]; M4[1][0] = S3[2]; M4[2][3] = S3[2]; M4[3][2] = S3[2];
+        scale = af;
+    } else {
+        // Neo-Hookean (material.py:293-302): K = a/2 B^T (I - U/J + Fu Fu^T / J^2) B, P = a/2 B^T (I - U/J) F
+        const float J = F00 * F11 - F01 * F10;
+        const float Fv[4] = {F00, F01, F10, F11};
+        const float Fu[4] = {F11, -F10, -F01, F00};
+        const float U[4][4] = {{0, 0, 0, 1}, {0, 0, -1, 0}, {0, -1, 0, 0}, {1, 0, 0, 0}};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float base = (r == c ? 1.f : 0.f) - U[r][c] / J;
+                M4[r][c] = base + (Fu[r] * Fu[c]) / (J * J);
+                acc += base * Fv[c];
+            }
+            Pv[r] = acc;
+        }
+        scale = 0.5f * af;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int p = 2 * a + k;
+        // row p of B^T M4 B
+        float bm[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bm[c] = B[0][p] * M4[0][c] + B[1][p] * M4[1][c] + B[2][p] * M4[2][c] + B[3][p] * M4[3][c];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            float v = bm[0] * B[0][q] + bm[1] * B[1][q] + bm[2] * B[2][q] + bm[3] * B[3][q];
+            if (svk) {
+                float bd[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) bd[c] = Bn[0][p] * Dm[0][c] + Bn[1][p] * Dm[1][c] + Bn[2][p] * Dm[2][c];
+                v = (bd[0] * Bn[0][q] + bd[1] * Bn[1][q] + bd[2] * Bn[2][q]) + v;
+            }
+            Krow[k][q] = scale * v;
+        }
+        if (svk) Prow[k] = scale * (Bn[0][p] * S3[0] + Bn[1][p] * S3[1] + Bn[2][p] * S3[2]);
+        else Prow[k] = scale * (B[0][p] * Pv[0] + B[1][p] * Pv[1] + B[2][p] * Pv[2] + B[3][p] * Pv[3]);
+    }
+}
+
+// thread per vertex row of one mesh: element stiffness blocks of the incident triangles.
+// model == nullptr: every triangle is a linear engineering element with Poisson ratio cnu_u / multiplier mult.
+// Otherwise per-triangle model (0 ENG, 1 SVK, 2 NHK), nu and material multiplier (mesh.py:2914-2933, 2992-3054).
 __global__ void asm_stiffness_kernel(int voff, int V, const int* __restrict__ tri, const int* __restrict__ vtptr,
                                      const int* __restrict__ vtidx, const double2* __restrict__ vs, const double2* __restrict__ vc,
-                                     const float* __restrict__ mult, double c2, double cnu, double soft, float softf,
+                                     const float* __restrict__ mult, double c2_u, double cnu_u, double soft, float softf,
+                                     const int* __restrict__ model, const double* __restrict__ tri_nu, const float* __restrict__ matmult,
                                      const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ Kval,
                                      float2* __restrict__ stress) {
 #pragma clang fp contract(off)
@@ -70,51 +177,70 @@ __global__ void asm_stiffness_kernel(int voff, int V, const int* __restrict__ tr
     const int grow = voff + v;
     const int lo = rowptr[grow], hi = rowptr[grow + 1];
     for (int j = lo; j < hi; ++j) reinterpret_cast<double4*>(Kval)[j] = make_double4(0.0, 0.0, 0.0, 0.0);
+    double sx = 0.0, sy = 0.0;        // linear part: K_lin (v_cur - v_shape)
+    double px = 0.0, py = 0.0;        // internal force of the non-linear elements
     for (int s = vtptr[v]; s < vtptr[v + 1]; ++s) {
         const int enc = vtidx[s];
         const int t = enc / 3, a = enc - 3 * t;
-        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-        const double2 p0 = vs[i0], p1 = vs[i1], p2 = vs[i2];
-        // e_i = p_{i+1} - p_{i-1}   (material.py:146-148)
-        double ex[3], ey[3];
-        ex[0] = p1.x - p2.x; ey[0] = p1.y - p2.y;
-        ex[1] = p2.x - p0.x; ey[1] = p2.y - p0.y;
-        ex[2] = p0.x - p1.x; ey[2] = p0.y - p1.y;
-        const double area2 = fabs(ex[0] * ey[1] - ey[0] * ex[1]);
-        const double sq = sqrt(area2);
-        for (int k = 0; k < 3; ++k) { ex[k] = ex[k] / sq; ey[k] = ey[k] / sq; }
-        const float m = mult ? mult[t] : 1.0f;
-        // D = diag(m, m, m(1-nu)/2) + nu*m coupling, stored float32 (material.py:174-180)
-        const double d0 = (double)m;
-        const double d2 = (double)(float)((double)m * c2);
-        const double dn = (double)(float)((double)m * cnu);
-        const int idx[3] = {i0, i1, i2};
-        const double exa = ex[a], eya = ey[a];
-        for (int b = 0; b < 3; ++b) {
-            const int j = find_col(col, lo, hi, voff + idx[b]);
-            if (j < 0) continue;
-            const double exb = ex[b], eyb = ey[b];
-            double4 k = reinterpret_cast<double4*>(Kval)[j];
-            k.x += d0 * (eya * eyb) + d2 * (exa * exb);            // (a,x),(b,x)
-            k.y += -(dn * (eya * exb)) - d2 * (exa * eyb);         // (a,x),(b,y)
-            k.z += -(dn * (exa * eyb)) - d2 * (eya * exb);         // (a,y),(b,x)
-            k.w += d0 * (exa * exb) + d2 * (eya * eyb);            // (a,y),(b,y)
-            reinterpret_cast<double4*>(Kval)[j] = k;
+        const int idx[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+        const double2 pts[3] = {vs[idx[0]], vs[idx[1]], vs[idx[2]]};
+        const int md = model ? model[t] : 0;
+        float m = mult ? mult[t] : 1.0f;
+        if (matmult) m = m * matmult[t];
+        if (md == 0) {
+            // e_i = p_{i+1} - p_{i-1}   (material.py:146-148)
+            double ex[3], ey[3];
+            ex[0] = pts[1].x - pts[2].x; ey[0] = pts[1].y - pts[2].y;
+            ex[1] = pts[2].x - pts[0].x; ey[1] = pts[2].y - pts[0].y;
+            ex[2] = pts[0].x - pts[1].x; ey[2] = pts[0].y - pts[1].y;
+            const double area2 = fabs(ex[0] * ey[1] - ey[0] * ex[1]);
+            const double sq = sqrt(area2);
+            for (int k = 0; k < 3; ++k) { ex[k] = ex[k] / sq; ey[k] = ey[k] / sq; }
+            const double nu = tri_nu ? tri_nu[t] : cnu_u;
+            const double c2 = tri_nu ? (1.0 - nu) / 2.0 : c2_u;
+            // D = diag(m, m, m(1-nu)/2) + nu*m coupling, stored float32 (material.py:174-180)
+            const double d0 = (double)m;
+            const double d2 = (double)(float)((double)m * c2);
+            const double dn = (double)(float)((double)m * nu);
+            const double exa = ex[a], eya = ey[a];
+            for (int b = 0; b < 3; ++b) {
+                const int j = find_col(col, lo, hi, voff + idx[b]);
+                if (j < 0) continue;
+                const double exb = ex[b], eyb = ey[b];
+                const double kxx = d0 * (eya * eyb) + d2 * (exa * exb);            // (a,x),(b,x)
+                const double kxy = -(dn * (eya * exb)) - d2 * (exa * eyb);         // (a,x),(b,y)
+                const double kyx = -(dn * (exa * eyb)) - d2 * (eya * exb);         // (a,y),(b,x)
+                const double kyy = d0 * (exa * exb) + d2 * (eya * eyb);            // (a,y),(b,y)
+                double4 k = reinterpret_cast<double4*>(Kval)[j];
+                k.x += kxx; k.y += kxy; k.z += kyx; k.w += kyy;
+                reinterpret_cast<double4*>(Kval)[j] = k;
+                if (vc) {
+                    const double dxv = vc[idx[b]].x - vs[idx[b]].x, dyv = vc[idx[b]].y - vs[idx[b]].y;
+                    sx += kxx * dxv + kxy * dyv;
+                    sy += kyx * dxv + kyy * dyv;
+                }
+            }
+        } else {
+            float uv[6];
+            for (int b = 0; b < 3; ++b) {
+                uv[2 * b] = vc ? (float)(vc[idx[b]].x - vs[idx[b]].x) : 0.f;
+                uv[2 * b + 1] = vc ? (float)(vc[idx[b]].y - vs[idx[b]].y) : 0.f;
+            }
+            float Krow[2][6], Prow[2];
+            nonlinear_element_rows(pts, uv, md, tri_nu ? (float)tri_nu[t] : (float)cnu_u, a, Krow, Prow);
+            for (int b = 0; b < 3; ++b) {
+                const int j = find_col(col, lo, hi, voff + idx[b]);
+                if (j < 0) continue;
+                double4 k = reinterpret_cast<double4*>(Kval)[j];
+                k.x += (double)(Krow[0][2 * b] * m); k.y += (double)(Krow[0][2 * b + 1] * m);
+                k.z += (double)(Krow[1][2 * b] * m); k.w += (double)(Krow[1][2 * b + 1] * m);
+                reinterpret_cast<double4*>(Kval)[j] = k;
+            }
+            px += (double)(Prow[0] * m); py += (double)(Prow[1] * m);
         }
     }
-    // stress = K (v_cur - v_shape) -> float32 -> * soft   (mesh.py:3068-3072, optimizer.py:822)
-    double sx = 0.0, sy = 0.0;
-    if (vc) {
-        for (int j = lo; j < hi; ++j) {
-            const int c = col[j] - voff;
-            if (c < 0 || c >= V) continue;
-            const double4 k = reinterpret_cast<const double4*>(Kval)[j];
-            const double dxv = vc[c].x - vs[c].x, dyv = vc[c].y - vs[c].y;
-            sx += k.x * dxv + k.y * dyv;
-            sy += k.z * dxv + k.w * dyv;
-        }
-    }
-    stress[grow] = make_float2((float)sx * softf, (float)sy * softf);
+    // stress = K_lin (v_cur - v_shape) -> float32, + internal force, * soft   (mesh.py:3068-3082, optimizer.py:822)
+    stress[grow] = make_float2(((float)sx + (float)px) * softf, ((float)sy + (float)py) * softf);
     if (soft != 1.0) {
         for (int j = lo; j < hi; ++j) {
             double4 k = reinterpret_cast<double4*>(Kval)[j];
@@ -227,6 +353,7 @@ void fb_sys_destroy(fb_ctx* ctx, fb_system* s) {
     hipStreamSynchronize(ctx->stream);
     for (auto& m : s->meshes) {
         hipFree(m.d_tri); hipFree(m.d_vtptr); hipFree(m.d_vtidx); hipFree(m.d_mult); hipFree(m.d_vshape); hipFree(m.d_vcur);
+        hipFree(m.d_model); hipFree(m.d_nu); hipFree(m.d_matmult);
     }
     hipFree(s->d_nodes); hipFree(s->d_vmptr); hipFree(s->d_vmidx); hipFree(s->d_bary); hipFree(s->d_w); hipFree(s->d_rxy);
     hipFree(s->d_K); hipFree(s->d_Cacc); hipFree(s->d_C); hipFree(s->d_rhs); hipFree(s->d_stress); hipFree(s->d_parts);
@@ -360,24 +487,47 @@ int fb_sys_pattern(fb_ctx* ctx, fb_system* s, int64_t* browptr, int32_t* bcol) {
     return FB_OK;
 }
 
-int fb_sys_assemble_mesh(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur, const float* tri_mult,
-                         double nu, double soft) {
-    FB_LOCK(ctx);
+static int assemble_mesh_impl(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur, const float* tri_mult,
+                              double nu, double soft, const int32_t* tri_model, const double* tri_nu, const float* tri_matmult) {
     FB_CHECK_ARG(ctx, s && s->finalized && mesh_id >= 0 && mesh_id < (int)s->meshes.size() && v_shape);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     fb_mesh_blk& m = s->meshes[mesh_id];
     FB_HIP(ctx, hipMemcpyAsync(m.d_vshape, v_shape, sizeof(double2) * (size_t)m.V, hipMemcpyHostToDevice, ctx->stream));
     if (v_cur) FB_HIP(ctx, hipMemcpyAsync(m.d_vcur, v_cur, sizeof(double2) * (size_t)m.V, hipMemcpyHostToDevice, ctx->stream));
     if (tri_mult) FB_HIP(ctx, hipMemcpyAsync(m.d_mult, tri_mult, sizeof(float) * (size_t)m.T, hipMemcpyHostToDevice, ctx->stream));
+    if (tri_model) {
+        FB_CHECK_ARG(ctx, tri_nu && tri_matmult);
+        for (int t = 0; t < m.T; ++t) FB_CHECK_ARG(ctx, tri_model[t] >= 0 && tri_model[t] <= 2);
+        int rc;
+        if ((rc = upload(ctx, &m.d_model, tri_model, (size_t)m.T))) return rc;
+        if ((rc = upload(ctx, &m.d_nu, tri_nu, (size_t)m.T))) return rc;
+        if ((rc = upload(ctx, &m.d_matmult, tri_matmult, (size_t)m.T))) return rc;
+    }
     {
         FB_PROF(ctx, "fem_asm_stiffness");
         hipLaunchKernelGGL(asm_stiffness_kernel, dim3(fb_cdiv(m.V, kT)), dim3(kT), 0, ctx->stream, m.voff, m.V, m.d_tri, m.d_vtptr,
                            m.d_vtidx, m.d_vshape, v_cur ? m.d_vcur : (const double2*)nullptr, tri_mult ? m.d_mult : (const float*)nullptr,
-                           (1.0 - nu) / 2.0, nu, soft, (float)soft, s->M->d.rowptr, s->M->d.col, s->d_K, s->d_stress);
+                           (1.0 - nu) / 2.0, nu, soft, (float)soft, tri_model ? m.d_model : (const int*)nullptr,
+                           tri_model ? m.d_nu : (const double*)nullptr, tri_model ? m.d_matmult : (const float*)nullptr,
+                           s->M->d.rowptr, s->M->d.col, s->d_K, s->d_stress);
     }
     FB_HIP(ctx, hipGetLastError());
     FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FB_OK;
+}
+
+int fb_sys_assemble_mesh(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur, const float* tri_mult,
+                         double nu, double soft) {
+    FB_LOCK(ctx);
+    return assemble_mesh_impl(ctx, s, mesh_id, v_shape, v_cur, tri_mult, nu, soft, nullptr, nullptr, nullptr);
+}
+
+int fb_sys_assemble_mesh_materials(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur,
+                                   const float* tri_mult, const int32_t* tri_model, const double* tri_nu, const float* tri_matmult,
+                                   double soft) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, tri_model && tri_nu && tri_matmult);
+    return assemble_mesh_impl(ctx, s, mesh_id, v_shape, v_cur, tri_mult, 0.0, soft, tri_model, tri_nu, tri_matmult);
 }
 
 int fb_sys_assemble_links(fb_ctx* ctx, fb_system* s, const double* bary6, const float* w, const double* rxy) {

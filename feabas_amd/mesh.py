@@ -39,6 +39,13 @@ class Mesh:
         # one linear engineering material per mesh (the default material table)
         self.poisson_ratio = float(kwargs.get('poisson_ratio', 0.0))
         self.material_multiplier = float(kwargs.get('material_multiplier', 1.0))
+        # optional per-triangle materials (material.py: model 0 ENG, 1 SVK, 2 NHK; Poisson ratio; multiplier)
+        tm = kwargs.get('tri_model', None)
+        self.tri_model = None if tm is None else np.ascontiguousarray(tm, dtype=np.int32)
+        if self.tri_model is not None:
+            nt = self.triangles.shape[0]
+            self.tri_nu = np.ascontiguousarray(np.broadcast_to(kwargs.get('tri_nu', self.poisson_ratio), (nt,)), dtype=np.float64)
+            self.tri_matmult = np.ascontiguousarray(np.broadcast_to(kwargs.get('tri_matmult', self.material_multiplier), (nt,)), dtype=np.float32)
         self.resolution = kwargs.get('resolution', 4.0)
         self.locked = kwargs.get('locked', False)
         self.soft_factor = kwargs.get('soft_factor', 1.0)
@@ -62,7 +69,7 @@ class Mesh:
 
     @property
     def is_linear(self):
-        return True
+        return self.tri_model is None or not np.any(self.tri_model != const.MATERIAL_MODEL_ENG)
 
     @property
     def stiffness_multiplier(self):
@@ -111,6 +118,8 @@ class Mesh:
                   moving_offset=self._offsets[const.MESH_GEAR_MOVING],
                   staging_offset=self._offsets[const.MESH_GEAR_STAGING],
                   stiffness_multiplier=self._stiffness_multiplier, poisson_ratio=self.poisson_ratio,
+                  tri_model=self.tri_model, tri_nu=getattr(self, 'tri_nu', None) if self.tri_model is not None else self.poisson_ratio,
+                  tri_matmult=getattr(self, 'tri_matmult', None) if self.tri_model is not None else self.material_multiplier,
                   material_multiplier=self.material_multiplier, resolution=self.resolution,
                   locked=self.locked, soft_factor=self.soft_factor, uid=self.uid)
         kw.update(override)
@@ -221,6 +230,18 @@ class Mesh:
             m = self._stiffness_multiplier * m
         return np.ascontiguousarray(m, dtype=np.float32)
 
+    def assemble_into(self, sysh, mesh_id, v_shape, v_cur, soft):
+        """numeric assembly of this mesh's stiffness rows into a GPU system"""
+        lib, ctx = _lib.load(), _lib.ctx()
+        if self.tri_model is None:
+            _lib.check(lib.fb_sys_assemble_mesh(ctx, sysh, mesh_id, _lib.ptr(v_shape), _lib.ptr(v_cur),
+                                                _lib.ptr(self.element_multiplier()), self.poisson_ratio, float(soft)))
+        else:
+            _lib.check(lib.fb_sys_assemble_mesh_materials(ctx, sysh, mesh_id, _lib.ptr(v_shape), _lib.ptr(v_cur),
+                                                          _lib.ptr(np.ascontiguousarray(self.stiffness_multiplier, dtype=np.float32)),
+                                                          _lib.ptr(self.tri_model), _lib.ptr(self.tri_nu), _lib.ptr(self.tri_matmult),
+                                                          float(soft)))
+
     def stiffness_matrix(self, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), **kwargs):
         """feabas/mesh.py:3058-3083 -> (scipy CSR 2V x 2V float64, stress float32),
         assembled by the HIP kernel on a one-mesh system."""
@@ -238,8 +259,7 @@ class Mesh:
             v0 = np.ascontiguousarray(self.vertices(gear[0]), dtype=np.float64)
             v1 = self.vertices(gear[-1])
             v1c = None if v1 is v0 or v1 is self.vertices(gear[0]) else np.ascontiguousarray(v1, dtype=np.float64)
-            _lib.check(lib.fb_sys_assemble_mesh(ctx, sysh, mid.value, _lib.ptr(v0), _lib.ptr(v1c),
-                                                _lib.ptr(self.element_multiplier()), self.poisson_ratio, 1.0))
+            self.assemble_into(sysh, mid.value, v0, v1c, 1.0)
             K = bsr_download(sysh, 0, self.num_vertices, nnzb.value)
             stress = np.empty(2 * self.num_vertices, dtype=np.float32)
             _lib.check(lib.fb_sys_get(ctx, sysh, 3, _lib.ptr(stress)))

@@ -301,8 +301,7 @@ class SLM:
             v0 = np.ascontiguousarray(m.vertices(shape_gear), dtype=np.float64)
             v1 = m.vertices(start_gear)
             v1c = None if v1 is m.vertices(shape_gear) else np.ascontiguousarray(v1, dtype=np.float64)
-            _lib.check(lib.fb_sys_assemble_mesh(ctx, self._sys, self._mesh_ids[m.uid], _lib.ptr(v0), _lib.ptr(v1c),
-                                                _lib.ptr(m.element_multiplier()), m.poisson_ratio, float(m.soft_factor)))
+            m.assemble_into(self._sys, self._mesh_ids[m.uid], v0, v1c, float(m.soft_factor))
         bary, wts, res = [], [], []
         for lk in links:
             gears = [target_gear if m.locked else start_gear for m in lk.meshes]
@@ -383,11 +382,48 @@ class SLM:
                 m.set_field(dd[o:o + 2 * m.num_vertices].reshape(-1, 2), gear=(start_gear, target_gear))
         return cost
 
+    @property
+    def is_linear(self):
+        return all(m.is_linear for m in self.meshes)
+
+    def cost(self, stiffness_lambda, crosslink_lambda):
+        """optimizer.py:1593-1601: ||lc rhs - ls stress|| of the assembled terms"""
+        lib, ctx = _lib.load(), _lib.ctx()
+        sl, cl = self.relative_lambda_trace(stiffness_lambda, crosslink_lambda)
+        rhs = np.empty(2 * self._nv); stress = np.empty(2 * self._nv, dtype=np.float32)
+        _lib.check(lib.fb_sys_get(ctx, self._sys, 2, _lib.ptr(rhs)))
+        _lib.check(lib.fb_sys_get(ctx, self._sys, 3, _lib.ptr(stress)))
+        return float(np.linalg.norm(cl * rhs - sl * stress))
+
+    def optimize_Newton_Raphson(self, **kwargs):
+        """Newton iteration for meshes with non-linear elements (structure of optimizer.py:1440-1544): every step
+        re-assembles the tangent stiffness / internal force at the current MOVING gear on the GPU and solves the
+        tangent problem with optimize_linear.  Annealing and residue re-weighting between steps are not included."""
+        max_newtonstep = kwargs.pop('max_newtonstep', 5)
+        tol = kwargs.pop('tol', 1e-7)
+        step_tol = max(tol, 1e-5) if max_newtonstep > 1 else tol
+        cost0 = None
+        cost = np.inf
+        for ke in range(max_newtonstep):
+            step_cost = self.optimize_linear(tol=step_tol, shape_gear=const.MESH_GEAR_FIXED, start_gear=const.MESH_GEAR_MOVING,
+                                             target_gear=const.MESH_GEAR_MOVING, **kwargs)
+            if cost0 is None:
+                cost0 = step_cost[0]
+            if step_cost[0] < step_cost[1]:
+                break
+            cost = min(cost, step_cost[0])
+            if step_cost[0] <= tol * cost0:
+                break
+            step_tol = max(tol, step_tol * 0.1)
+        return cost0, cost
+
     def optimize_elastic(self, **kwargs):
-        """optimizer.py:1547-1555 for linear systems."""
+        """optimizer.py:1547-1555."""
         if kwargs.get('online_anneal', False):
-            raise NotImplementedError('Newton-Raphson / online annealing is a "next" row (SURVEY.md sec.8f)')
-        return self.optimize_linear(**kwargs)
+            raise NotImplementedError('online annealing is outside the hot path (rigid fits on the host)')
+        if self.is_linear:
+            return self.optimize_linear(**kwargs)
+        return self.optimize_Newton_Raphson(**kwargs)
 
 
 def solve(A, b, solver='minres', x0=None, tol=1e-7, atol=None, maxiter=None, M=None, **kwargs):

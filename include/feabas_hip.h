@@ -161,6 +161,13 @@ int fb_sys_info(fb_ctx* ctx, fb_system* sys, int64_t* nv, int64_t* nnzb, int64_t
  * (mesh.stiffness_multiplier * material.stiffness_multiplier) */
 int fb_sys_assemble_mesh(fb_ctx* ctx, fb_system* sys, int mesh_id, const double* v_shape, const double* v_cur,
                          const float* tri_mult, double nu, double soft);
+/* Mixed materials (Mesh.stiffness_matrix with non-engineering elements, mesh.py:2992-3083;
+ * element maths material.py:185-309): per-triangle model (0 engineering-linear, 1 St-Venant-Kirchhoff,
+ * 2 Neo-Hookean), Poisson ratio and material stiffness multiplier.  K is the tangent stiffness at v_cur,
+ * stress = K_lin (v_cur - v_shape) + internal force of the non-linear elements, float32. */
+int fb_sys_assemble_mesh_materials(fb_ctx* ctx, fb_system* sys, int mesh_id, const double* v_shape, const double* v_cur,
+                                   const float* tri_mult, const int32_t* tri_model, const double* tri_nu,
+                                   const float* tri_matmult, double soft);
 /* bary6: [K][6] = [+B0 | -B1] (Link.shape_matrix_contrib, optimizer.py:114-131); w: [K] float32
  * (weight * residue_weight); rxy: [K][2] residual x1 - x0 (Link.dxy, optimizer.py:248-255) */
 int fb_sys_assemble_links(fb_ctx* ctx, fb_system* sys, const double* bary6, const float* w, const double* rxy);

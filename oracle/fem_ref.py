@@ -532,3 +532,39 @@ def grid_mesh(nx, ny, h=10.0, origin=(0.0, 0.0), diag='alt'):
     t1 = np.where(par[:, None], np.stack((b, d, c), -1), np.stack((a, d, c), -1))
     tri = np.concatenate((t0, t1), axis=0)
     return v, tri
+
+
+def mesh_stiffness_mixed(v_shape, v_cur, triangles, tri_mult, model, nu, matmult):
+    """mesh.py:3058-3083 for a mesh that mixes linear engineering triangles (model 0, N^T D N path,
+    mesh.py:2914-2933) with St-Venant-Kirchhoff / Neo-Hookean triangles (models 1 / 2, element loop of
+    mesh.py:2992-3054).  Per-triangle arrays: tri_mult (mesh multiplier, float32), model, nu, matmult
+    (material multiplier).  Returns (K float64 CSR, stress float32)."""
+    v_shape = np.asarray(v_shape, dtype=np.float64)
+    v_cur = np.asarray(v_cur, dtype=np.float64)
+    T = np.asarray(triangles)
+    ndof = 2 * v_shape.shape[0]
+    dxy = v_cur - v_shape
+    K = sparse.csr_matrix((ndof, ndof), dtype=np.float64)
+    lin = model == MODEL_ENG
+    for nu_v in np.unique(nu[lin]):
+        for mm_v in np.unique(matmult[lin & (nu == nu_v)]):
+            sel = np.flatnonzero(lin & (nu == nu_v) & (matmult == mm_v))
+            N = eng_shape_matrix(v_shape[T[sel]], T[sel], ndof)
+            K = K + eng_stiffness_from_shape(N, multiplier=tri_mult[sel], nu=float(nu_v), mat_multiplier=float(mm_v))
+    stress = K.dot(dxy.ravel()).astype(np.float32)                        # mesh.py:3068-3072
+    Td = np.repeat(T * 2, 2, axis=-1)
+    Td[:, 1::2] += 1
+    V = np.zeros(ndof, dtype=np.float32)
+    for md in (MODEL_SVK, MODEL_NHK):
+        for nu_v in np.unique(nu[model == md]):
+            for mm_v in np.unique(matmult[(model == md) & (nu == nu_v)]):
+                sel = np.flatnonzero((model == md) & (nu == nu_v) & (matmult == mm_v))
+                B, areas = element_shape_B(v_shape[T[sel]])
+                uv = dxy[T[sel]].reshape(-1, 6)
+                Ke, Pe = element_stiffness(B, areas, uv, md, nu=float(nu_v))
+                mm = tri_mult[sel].reshape(-1, 1, 1) * float(mm_v)       # mesh.py:3041
+                i1 = np.tile(Td[sel].reshape(-1, 1, 6), (1, 6, 1))
+                i2 = np.swapaxes(i1, 1, 2)
+                K = K + sparse.csr_matrix(((Ke * mm).ravel(), (i1.ravel(), i2.ravel())), shape=(ndof, ndof))
+                np.add.at(V, Td[sel].ravel(), (Pe * mm).ravel())
+    return sparse.csr_matrix(K), stress + V

@@ -332,7 +332,39 @@ def g11_bbox():
     np.savez_compressed(os.path.join(OUT, 'g11_bbox.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G12
+def g12_mixed_materials():
+    """Mesh.stiffness_matrix on a mesh with linear ENG, Neo-Hookean and St-Venant-Kirchhoff regions
+    (mesh.py:2992-3083): tangent stiffness + internal force at a displaced MOVING gear."""
+    rng = np.random.default_rng(1212)
+    v, t = grid(14, 10, 10.0)
+    mids = np.zeros(t.shape[0], dtype=np.int16)
+    ctr = v[t].mean(axis=1)
+    mids[ctr[:, 0] > 90] = 5
+    mids[(ctr[:, 0] <= 90) & (ctr[:, 1] > 60)] = 6
+    tab = {'default': dict(material.MATERIAL_DEFAULT),
+           'nhk': {'type': const.MATERIAL_MODEL_NHK, 'uid': 5, 'stiffness_multiplier': 0.7},
+           'svk': {'type': const.MATERIAL_MODEL_SVK, 'uid': 6, 'poisson_ratio': 0.25, 'stiffness_multiplier': 1.3}}
+    mt = material.MaterialTable(table=tab)
+    disp = np.stack((2 * np.sin(v[:, 1] / 30), 1.5 * np.cos(v[:, 0] / 40)), -1)
+    mult = rng.uniform(0.5, 1.5, t.shape[0]).astype(np.float32)
+    m = Mesh(v.copy(), t.copy(), material_table=mt, material_ids=mids.copy(), stiffness_multiplier=mult.copy(),
+             moving_vertices=v + disp, uid=3)
+    K, stress = m.stiffness_matrix(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING))
+    out = {'v': v, 'vmov': v + disp, 't': m.triangles, 'mult': m._stiffness_multiplier, 'mids': m._material_ids.astype(np.int32)}
+    # per-triangle material description in the (material-sorted) triangle order of the Mesh
+    model = np.zeros(m.triangles.shape[0], dtype=np.int32); nu = np.zeros(m.triangles.shape[0]); mm = np.ones(m.triangles.shape[0])
+    for name, uid in (('nhk', 5), ('svk', 6)):
+        sel = m._material_ids == uid
+        model[sel] = mt[name]._type; nu[sel] = mt[name]._poisson_ratio; mm[sel] = mt[name]._stiffness_multiplier
+    out['model'] = model; out['nu'] = nu; out['matmult'] = mm
+    r, c, d = coo(K)
+    out['K_r'] = r; out['K_c'] = c; out['K_d'] = d
+    out['stress'] = stress
+    np.savez_compressed(os.path.join(OUT, 'g12_mixed_materials.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials):
         fn()
         print('wrote', fn.__name__)

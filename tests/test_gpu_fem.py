@@ -181,3 +181,40 @@ def test_pcg_breakdown_reported(fb):
     with pytest.raises(Exception) as e:
         fb.optimizer.solve(A, np.array([1.0, 1.0, 0, 0]), 'minres', tol=1e-10)
     assert 'breakdown' in str(e.value)
+
+
+def test_mixed_materials_golden(fb):
+    """linear ENG + Neo-Hookean + St-Venant-Kirchhoff regions: tangent stiffness and internal force (mesh.py:2992-3083)"""
+    g = load_golden('g12_mixed_materials.npz')
+    m = fb.mesh.Mesh(g['v'], g['t'], stiffness_multiplier=g['mult'], moving_vertices=g['vmov'], tri_model=g['model'],
+                     tri_nu=g['nu'], tri_matmult=g['matmult'].astype(np.float32), uid=3)
+    assert not m.is_linear
+    K, stress = m.stiffness_matrix(gear=(0, 1))
+    nd = 2 * g['v'].shape[0]
+    Kg = _sp(g, 'K', (nd, nd))
+    assert abs(K - Kg).max() <= 5e-6 * abs(Kg).max()
+    np.testing.assert_allclose(stress, g['stress'], atol=5e-6 * np.abs(g['stress']).max())
+    Ko, so = fem_ref.mesh_stiffness_mixed(g['v'], g['vmov'], g['t'], g['mult'], g['model'], g['nu'], g['matmult'])
+    assert abs(K - Ko).max() <= 5e-6 * abs(Ko).max()
+
+
+def test_newton_raphson_reduces_the_nonlinear_residual(fb):
+    """tangent solves on a Neo-Hookean / SVK mesh pulled by links: the out-of-balance force drops step by step"""
+    g = load_golden('g12_mixed_materials.npz')
+    v, t = g['v'], g['t']
+    rng = np.random.default_rng(3)
+    disp = 0.3 * (g['vmov'] - v)
+    m0 = fb.mesh.Mesh(v + disp, t, uid=0, locked=True)
+    m1 = fb.mesh.Mesh(v.copy(), t, stiffness_multiplier=g['mult'], tri_model=g['model'], tri_nu=g['nu'],
+                      tri_matmult=g['matmult'].astype(np.float32), uid=1)
+    n = 200
+    tid = rng.integers(0, t.shape[0], n); B = rng.dirichlet((1, 1, 1), n)
+    slm = fb.optimizer.SLM([m0, m1], [fb.optimizer.Link(m0, m1, tid, tid, B, B, weight=np.ones(n, np.float32))],
+                           stiffness_lambda=1.0, crosslink_lambda=1.0)
+    costs = []
+    for _ in range(4):
+        c = slm.optimize_linear(tol=1e-9, start_gear=1, target_gear=1)
+        costs.append(c[0])
+    assert costs[1] < 0.2 * costs[0] and costs[3] < 1e-3 * costs[0]       # quadratic-ish decay of ||b||
+    got = m1.vertices_w_offset(1) - v
+    assert np.abs(got - disp).max() < np.abs(disp).max()                   # the mesh follows the links

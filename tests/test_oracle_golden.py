@@ -196,3 +196,12 @@ def test_g11_bbox():
         r0, r1 = ncc_ref.distributor_cartesian_bbox(p[:4], p[4:8], p[8], min_num_blocks=int(p[9]))
         np.testing.assert_array_equal(r0, g[f'dist{k}_bb0'])
         np.testing.assert_array_equal(r1, g[f'dist{k}_bb1'])
+
+
+def test_g12_mixed_materials():
+    g = load_golden('g12_mixed_materials.npz')
+    K, stress = fem_ref.mesh_stiffness_mixed(g['v'], g['vmov'], g['t'], g['mult'], g['model'], g['nu'], g['matmult'])
+    nd = 2 * g['v'].shape[0]
+    Kg = _sp(g, 'K', (nd, nd))
+    assert abs(K - Kg).max() <= 2e-6 * abs(Kg).max()
+    np.testing.assert_allclose(stress, g['stress'], atol=2e-6 * np.abs(g['stress']).max())
