@@ -103,11 +103,14 @@ def bench_fem(args, lib, ctx, _lib):
     rr = C.c_double()
     _lib.check(lib.fb_sys_solve_fixed(ctx, slm._sys, 20, C.byref(rr)))          # warm-up
     _lib.check(lib.fb_sync(ctx))
-    _lib.check(lib.fb_prof_reset(ctx)); _lib.check(lib.fb_prof_enable(ctx, 1))
     t0 = time.time()
     _lib.check(lib.fb_sys_solve_fixed(ctx, slm._sys, args.fem_iters, C.byref(rr)))
     _lib.check(lib.fb_sync(ctx))
     dt = time.time() - t0
+    # per-kernel durations from a second, event-bracketed run (the events cost a few us per launch)
+    _lib.check(lib.fb_prof_reset(ctx)); _lib.check(lib.fb_prof_enable(ctx, 1))
+    _lib.check(lib.fb_sys_solve_fixed(ctx, slm._sys, 64, C.byref(rr)))
+    _lib.check(lib.fb_sync(ctx))
     _lib.check(lib.fb_prof_enable(ctx, 0))
     prof = _lib.prof_snapshot()
     # time to 1e-4 relative residual (the reference's final_elastic tolerance, stitching_configs.yaml:63-72)

@@ -75,17 +75,31 @@ __global__ __launch_bounds__(kT) void bsr_spmv_kernel(
         double2 acc = make_double2(0.0, 0.0);
         for (int c0 = b0; c0 < b1; c0 += kCap) {
             const int c1 = min(b1, c0 + kCap);
-            for (int j = c0 + threadIdx.x; j < c1; j += kT) {
-                const int col = A.col[j];
-                const double4 a = reinterpret_cast<const double4*>(A.val)[j];   // [a00 a01 a10 a11]
-                double2 pv;
-                if (MODE == 1) {
-                    pv = v[col];                                   // z
-                    if (iter > 0) { const double2 po = p_old[col]; pv.x += beta * po.x; pv.y += beta * po.y; }
-                } else {
-                    pv = v[col];
+            // four blocks per trip: column indices, values and gathered vector entries of all four are requested
+            // before the first product is formed (the col -> gather dependency otherwise serialises the loop)
+            for (int jb = c0 + threadIdx.x; jb < c1; jb += 4 * kT) {
+                int colv[4]; double4 av[4]; double2 zv[4], pv_old[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(jb + u * kT, c1 - 1);
+                    colv[u] = A.col[j];
+                    av[u] = reinterpret_cast<const double4*>(A.val)[j];
                 }
-                contrib[j - c0] = make_double2(a.x * pv.x + a.y * pv.y, a.z * pv.x + a.w * pv.y);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    zv[u] = v[colv[u]];
+                    if (MODE == 1 && iter > 0) pv_old[u] = p_old[colv[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = jb + u * kT;
+                    if (j < c1) {
+                        double2 pv = zv[u];
+                        if (MODE == 1 && iter > 0) { pv.x += beta * pv_old[u].x; pv.y += beta * pv_old[u].y; }
+                        const double4 a = av[u];
+                        contrib[j - c0] = make_double2(a.x * pv.x + a.y * pv.y, a.z * pv.x + a.w * pv.y);
+                    }
+                }
             }
             __syncthreads();
             const int jl = max(lo, c0), jh = min(hi, c1);
@@ -144,15 +158,27 @@ __global__ __launch_bounds__(kT) void pcg_update_kernel(
     }
     const double alpha = rz / pAp;
     double s_rz = 0.0, s_rr = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
-        const double2 pi = p[i], api = Ap[i], mi = minv[i];
-        double2 xi = x[i], ri = r[i];
-        xi.x += alpha * pi.x; xi.y += alpha * pi.y;
-        ri.x -= alpha * api.x; ri.y -= alpha * api.y;
-        const double2 zi = make_double2(mi.x * ri.x, mi.y * ri.y);
-        x[i] = xi; r[i] = ri; z[i] = zi;
-        s_rz += ri.x * zi.x + ri.y * zi.y;
-        s_rr += ri.x * ri.x + ri.y * ri.y;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nb; i0 += 2 * stride) {
+        const int i1 = i0 + stride;
+        const bool two = i1 < nb;
+        const int ib = two ? i1 : i0;
+        const double2 pa = p[i0], apa = Ap[i0], ma = minv[i0], pb = p[ib], apb = Ap[ib], mb = minv[ib];
+        double2 xa = x[i0], ra = r[i0], xb = x[ib], rb = r[ib];
+        xa.x += alpha * pa.x; xa.y += alpha * pa.y;
+        ra.x -= alpha * apa.x; ra.y -= alpha * apa.y;
+        const double2 za = make_double2(ma.x * ra.x, ma.y * ra.y);
+        x[i0] = xa; r[i0] = ra; z[i0] = za;
+        s_rz += ra.x * za.x + ra.y * za.y;
+        s_rr += ra.x * ra.x + ra.y * ra.y;
+        if (two) {
+            xb.x += alpha * pb.x; xb.y += alpha * pb.y;
+            rb.x -= alpha * apb.x; rb.y -= alpha * apb.y;
+            const double2 zb = make_double2(mb.x * rb.x, mb.y * rb.y);
+            x[i1] = xb; r[i1] = rb; z[i1] = zb;
+            s_rz += rb.x * zb.x + rb.y * zb.y;
+            s_rr += rb.x * rb.x + rb.y * rb.y;
+        }
     }
     const double t1 = block_sum(s_rz, sh);
     const double t2 = block_sum(s_rr, sh);
