@@ -33,6 +33,7 @@ struct fb_system {
     std::vector<fb_mesh_blk> meshes;
     // links
     int64_t nlink = 0;
+    int64_t link_cap = 0;            // capacity of the device link buffers
     std::vector<int> nodes;          // [K][6] global free vertex ids, -1 = locked side
     int* d_nodes = nullptr;
     int* d_vmptr = nullptr;          // [nv+1]
@@ -48,6 +49,8 @@ struct fb_system {
     double2* d_rhs = nullptr;        // [nv]
     float2* d_stress = nullptr;      // [nv]
     double* d_parts = nullptr;       // reduction scratch
+    double* d_glambda = nullptr;     // per-group stiffness lambda
+    int glambda_cap = 0;
     fb_bsr* M = nullptr;             // A + PCG workspace, shares the pattern
 };
 
@@ -329,6 +332,55 @@ __global__ void form_system_kernel(int nv, int64_t nnzb, const double* __restric
     }
 }
 
+// one workgroup per group of `gs` consecutive vertices: lambda_s of relative_lambda_trace for that group
+__global__ void group_lambda_kernel(int gs, const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ Kval,
+                                    const float* __restrict__ Cval, double sl, double cl, double* __restrict__ lam) {
+    __shared__ double sh0[kT / 64], sh1[kT / 64];
+    const int g = blockIdx.x;
+    double tc = 0.0, tk = 0.0;
+    for (int i = threadIdx.x; i < gs; i += blockDim.x) {
+        const int v = g * gs + i;
+        const int j = find_col(col, rowptr[v], rowptr[v + 1], v);
+        if (j < 0) continue;
+        const float c = Cval[j];
+        if (c != 0.0f) {
+            const double4 k = reinterpret_cast<const double4*>(Kval)[j];
+            tc += 2.0 * (double)c;
+            tk += k.x + k.w;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { tc += __shfl_down(tc, off); tk += __shfl_down(tk, off); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh0[wave] = tc; sh1[wave] = tk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) { tc += sh0[wv]; tk += sh1[wv]; }
+        double l = sl;
+        // a range without links keeps its bare stiffness (b = 0 there, so x stays 0) instead of a zero block
+        if (sl < 0 || cl < 0) l = (tc == 0.0) ? 1.0 : fabs(fabs(sl / cl) * tc / tk);
+        lam[g] = l;
+    }
+}
+
+// thread per vertex row: A = ls[g] K + lc C (x) I2, b = lc rhs - ls[g] stress
+__global__ void form_groups_kernel(int nv, int gs, const int* __restrict__ rowptr, const double* __restrict__ Kval,
+                                   const double* __restrict__ Cval, const double2* __restrict__ rhs, const float2* __restrict__ stress,
+                                   const double* __restrict__ lam, double lc, double* __restrict__ Aval, double2* __restrict__ b) {
+#pragma clang fp contract(off)
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const double ls = lam[v / gs];
+    const float lsf = (float)ls;
+    for (int j = rowptr[v]; j < rowptr[v + 1]; ++j) {
+        const double4 k = reinterpret_cast<const double4*>(Kval)[j];
+        const double c = lc * Cval[j];
+        reinterpret_cast<double4*>(Aval)[j] = make_double4(ls * k.x + c, ls * k.y, ls * k.z, ls * k.w + c);
+    }
+    const double2 r = rhs[v];
+    const float2 s = stress[v];
+    b[v] = make_double2(lc * r.x - (double)(lsf * s.x), lc * r.y - (double)(lsf * s.y));
+}
+
 template <typename T>
 int upload(fb_ctx* ctx, T** dptr, const T* host, size_t count) {
     if (!*dptr) FB_HIP(ctx, hipMalloc((void**)dptr, std::max<size_t>(16, sizeof(T) * count)));
@@ -337,6 +389,37 @@ int upload(fb_ctx* ctx, T** dptr, const T* host, size_t count) {
 }
 
 }  // namespace
+
+// vertex -> incident match slots (CSR over free vertices) + device link buffers sized for the current links
+static int build_link_index(fb_ctx* ctx, fb_system* s) {
+    const int nv = s->nv;
+    std::vector<int> ptr((size_t)nv + 1, 0), idx;
+    for (int64_t k = 0; k < 6 * s->nlink; ++k)
+        if (s->nodes[k] >= 0) ptr[(size_t)s->nodes[k] + 1]++;
+    for (int v = 0; v < nv; ++v) ptr[v + 1] += ptr[v];
+    idx.resize((size_t)ptr[nv]);
+    std::vector<int> f(ptr.begin(), ptr.end() - 1);
+    for (int64_t k = 0; k < 6 * s->nlink; ++k)
+        if (s->nodes[k] >= 0) idx[f[s->nodes[k]]++] = (int)k;
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (s->nlink > s->link_cap || !s->d_vmidx) {
+        hipFree(s->d_vmidx); hipFree(s->d_nodes); hipFree(s->d_bary); hipFree(s->d_w); hipFree(s->d_rxy);
+        s->d_vmidx = nullptr; s->d_nodes = nullptr; s->d_bary = nullptr; s->d_w = nullptr; s->d_rxy = nullptr;
+        const size_t cap = (size_t)std::max<int64_t>(16, s->nlink + s->nlink / 4);
+        FB_HIP(ctx, hipMalloc((void**)&s->d_vmidx, sizeof(int) * 6 * cap));
+        FB_HIP(ctx, hipMalloc((void**)&s->d_nodes, sizeof(int) * 6 * cap));
+        FB_HIP(ctx, hipMalloc((void**)&s->d_bary, sizeof(double) * 6 * cap));
+        FB_HIP(ctx, hipMalloc((void**)&s->d_w, sizeof(float) * cap));
+        FB_HIP(ctx, hipMalloc((void**)&s->d_rxy, sizeof(double2) * cap));
+        s->link_cap = (int64_t)cap;
+    }
+    if (!s->d_vmptr) FB_HIP(ctx, hipMalloc((void**)&s->d_vmptr, sizeof(int) * ((size_t)nv + 1)));
+    FB_HIP(ctx, hipMemcpyAsync(s->d_vmptr, ptr.data(), sizeof(int) * ptr.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!idx.empty()) FB_HIP(ctx, hipMemcpyAsync(s->d_vmidx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (s->nlink) FB_HIP(ctx, hipMemcpyAsync(s->d_nodes, s->nodes.data(), sizeof(int) * s->nodes.size(), hipMemcpyHostToDevice, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // ptr/idx are locals
+    return FB_OK;
+}
 
 extern "C" {
 
@@ -356,7 +439,7 @@ void fb_sys_destroy(fb_ctx* ctx, fb_system* s) {
         hipFree(m.d_model); hipFree(m.d_nu); hipFree(m.d_matmult);
     }
     hipFree(s->d_nodes); hipFree(s->d_vmptr); hipFree(s->d_vmidx); hipFree(s->d_bary); hipFree(s->d_w); hipFree(s->d_rxy);
-    hipFree(s->d_K); hipFree(s->d_Cacc); hipFree(s->d_C); hipFree(s->d_rhs); hipFree(s->d_stress); hipFree(s->d_parts);
+    hipFree(s->d_glambda); hipFree(s->d_K); hipFree(s->d_Cacc); hipFree(s->d_C); hipFree(s->d_rhs); hipFree(s->d_stress); hipFree(s->d_parts);
     if (s->M) fb_bsr_free(ctx, s->M);
     delete s;
 }
@@ -458,26 +541,37 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
         FB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // ptr/idx are locals
     }
     // ---- vertex -> incident match slots
-    {
-        std::vector<int> ptr((size_t)nv + 1, 0), idx;
-        for (int64_t k = 0; k < 6 * s->nlink; ++k)
-            if (s->nodes[k] >= 0) ptr[(size_t)s->nodes[k] + 1]++;
-        for (int v = 0; v < nv; ++v) ptr[v + 1] += ptr[v];
-        idx.resize((size_t)ptr[nv]);
-        std::vector<int> f(ptr.begin(), ptr.end() - 1);
-        for (int64_t k = 0; k < 6 * s->nlink; ++k)
-            if (s->nodes[k] >= 0) idx[f[s->nodes[k]]++] = (int)k;
-        if ((rc = upload(ctx, &s->d_vmptr, ptr.data(), ptr.size()))) return rc;
-        if ((rc = upload(ctx, &s->d_vmidx, idx.data(), idx.size()))) return rc;
-        if ((rc = upload(ctx, &s->d_nodes, s->nodes.data(), s->nodes.size()))) return rc;
-        FB_HIP(ctx, hipMalloc((void**)&s->d_bary, std::max<size_t>(16, sizeof(double) * 6 * (size_t)s->nlink)));
-        FB_HIP(ctx, hipMalloc((void**)&s->d_w, std::max<size_t>(16, sizeof(float) * (size_t)s->nlink)));
-        FB_HIP(ctx, hipMalloc((void**)&s->d_rxy, std::max<size_t>(16, sizeof(double2) * (size_t)s->nlink)));
-        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    s->link_cap = 0;
+    if ((rc = build_link_index(ctx, s))) return rc;
     s->finalized = true;
     if (nnzb_out) *nnzb_out = nnzb;
     return FB_OK;
+}
+
+// Replace the links of a finalized system by links that add no new vertex coupling (every pair of free
+// vertices of a match is already in the pattern -- e.g. matches against locked meshes, whose three free
+// vertices share a triangle).  Only the vertex -> match index is rebuilt; the symbolic pattern is reused.
+int fb_sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && K >= 0 && (K == 0 || nodes6) && K < (1LL << 31) / 6);
+    for (int64_t i = 0; i < K; ++i) {
+        for (int a = 0; a < 6; ++a) {
+            const int u = nodes6[6 * i + a];
+            FB_CHECK_ARG(ctx, u >= -1 && u < s->nv);
+            if (u < 0) continue;
+            for (int b = 0; b < 6; ++b) {
+                const int w = nodes6[6 * i + b];
+                if (w < 0) continue;
+                const int* lo = s->bcol.data() + s->browptr[u];
+                const int* hi = s->bcol.data() + s->browptr[u + 1];
+                if (!std::binary_search(lo, hi, w))
+                    return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld couples vertices %d and %d outside the pattern", (long long)i, u, w);
+            }
+        }
+    }
+    s->nlink = K;
+    s->nodes.assign(nodes6, nodes6 + 6 * K);
+    return build_link_index(ctx, s);
 }
 
 int fb_sys_pattern(fb_ctx* ctx, fb_system* s, int64_t* browptr, int32_t* bcol) {
@@ -566,6 +660,31 @@ int fb_sys_lambda(fb_ctx* ctx, fb_system* s, double stiffness_lambda, double cro
         cl = 1.0;
     }
     *sl_out = sl; *cl_out = cl;
+    return FB_OK;
+}
+
+// Block-diagonal systems made of `ngroups` equal vertex ranges (one independent SLM per range, e.g. one tile pair
+// each): relative_lambda_trace (optimizer.py:1573-1590) is evaluated per range and A = ls[g] K + lc C,
+// b = lc rhs - ls[g] stress is formed with the range's own lambda.
+int fb_sys_form_groups(fb_ctx* ctx, fb_system* s, int ngroups, double stiffness_lambda, double crosslink_lambda, double* ls_out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && ngroups > 0 && s->nv % ngroups == 0);
+    const int gs = s->nv / ngroups;
+    if (!s->d_glambda || s->glambda_cap < ngroups) {
+        hipFree(s->d_glambda);
+        FB_HIP(ctx, hipMalloc((void**)&s->d_glambda, sizeof(double) * (size_t)ngroups));
+        s->glambda_cap = ngroups;
+    }
+    hipLaunchKernelGGL(group_lambda_kernel, dim3(ngroups), dim3(kT), 0, ctx->stream, gs, s->M->d.rowptr, s->M->d.col, s->d_K, s->d_C,
+                       stiffness_lambda, crosslink_lambda, s->d_glambda);
+    const double cl = (stiffness_lambda < 0 || crosslink_lambda < 0) ? 1.0 : crosslink_lambda;
+    hipLaunchKernelGGL(form_groups_kernel, dim3(fb_cdiv(s->nv, kT)), dim3(kT), 0, ctx->stream, s->nv, gs, s->M->d.rowptr, s->d_K, s->d_Cacc,
+                       s->d_rhs, s->d_stress, s->d_glambda, cl, s->M->d.val, s->M->b);
+    FB_HIP(ctx, hipGetLastError());
+    if (ls_out) {
+        FB_HIP(ctx, hipMemcpyAsync(ls_out, s->d_glambda, sizeof(double) * (size_t)ngroups, hipMemcpyDeviceToHost, ctx->stream));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return FB_OK;
 }
 

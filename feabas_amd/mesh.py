@@ -58,6 +58,48 @@ class Mesh:
             Mesh.uid_counter = float(max(Mesh.uid_counter, uid) + 1)
         self._trifinders = {}
 
+    @classmethod
+    def from_bbox(cls, bbox, cartesian=True, **kwargs):
+        """feabas/mesh.py:403-435, cartesian branch: a regular node grid over the bounding box (vertices at
+        pixel centres - 0.5).  The reference hands the rectangles to `triangle`, whose choice of diagonal is
+        implementation defined; here every cell (a b / c d) becomes (a, b, d), (a, d, c).  The node
+        coordinates of the grid are kept in ``grid_xs`` / ``grid_ys`` for O(1) point location."""
+        if not cartesian:
+            raise NotImplementedError('Mesh.from_bbox(cartesian=False) needs the `triangle` mesher (SURVEY.md sec.7)')
+        mesh_size = kwargs.pop('mesh_size')
+        min_num_blocks = kwargs.pop('min_num_blocks', 2)
+        max_aspect_ratio = kwargs.pop('max_aspect_ratio', 2)
+        x0, y0 = float(bbox[0]), float(bbox[1])
+        wd, ht = float(bbox[2]) - x0, float(bbox[3]) - y0
+        nx = max(np.round(wd / mesh_size), min_num_blocks)
+        ny = max(np.round(ht / mesh_size), min_num_blocks)
+        dx, dy = wd / nx, ht / ny
+        if dx > max_aspect_ratio * dy:
+            dx = max_aspect_ratio * dy
+        elif dy > max_aspect_ratio * dx:
+            dy = max_aspect_ratio * dx
+        nx = int(np.ceil(wd / dx)) + 1
+        ny = int(np.ceil(ht / dy)) + 1
+        xs = np.linspace(x0, x0 + wd, num=nx, endpoint=True) - 0.5
+        ys = np.linspace(y0, y0 + ht, num=ny, endpoint=True) - 0.5
+        vx, vy = np.meshgrid(xs, ys)
+        v = np.stack((vx.ravel(), vy.ravel()), axis=-1)
+        idx = np.arange(nx * ny).reshape(ny, nx)
+        a, b, c, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+        tri = np.stack((np.stack((a, b, d), -1), np.stack((a, d, c), -1)), axis=1).reshape(-1, 3)
+        m = cls(v, tri, **kwargs)
+        m.grid_xs, m.grid_ys = xs, ys
+        return m
+
+    def locate_cartesian(self, pts):
+        """triangle id of points given in the INITIAL gear of a from_bbox(cartesian=True) mesh"""
+        xs, ys = self.grid_xs, self.grid_ys
+        i = np.clip(np.searchsorted(xs, pts[..., 0], side='right') - 1, 0, xs.size - 2)
+        j = np.clip(np.searchsorted(ys, pts[..., 1], side='right') - 1, 0, ys.size - 2)
+        u = (pts[..., 0] - xs[i]) / (xs[i + 1] - xs[i])
+        w = (pts[..., 1] - ys[j]) / (ys[j + 1] - ys[j])
+        return (2 * (j * (xs.size - 1) + i) + (w > u)).astype(np.int32)
+
     # ------------------------------------------------------------------ state
     @property
     def num_vertices(self):

@@ -25,6 +25,9 @@ import numpy as np
 from . import _lib
 from . import constant as const
 from .matcher import auto_spacings, next_fast_len
+from .mesh import Mesh
+
+DEFAULT_AVG_DEFORM = 0.05            # feabas/config.py:32
 
 
 def _divide_bbox_batch(xmin, ymin, xmax, ymax, block_size, min_num_blocks):
@@ -57,7 +60,7 @@ def _z_order_batch(ix, iy):
 
 class StripBatchMatcher:
     def __init__(self, P, H, W, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
-                 conf_mode=const.FFT_CONF_MIRROR):
+                 conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9):
         assert coarse_downsample in (0.5, 1)
         assert H % 2 == 0 and W % 2 == 0 or coarse_downsample == 1
         self.P, self.H, self.W = int(P), int(H), int(W)
@@ -79,8 +82,16 @@ class StripBatchMatcher:
         self.d_dx = _lib.DeviceBuffer(self.max_blocks * 8)
         self.d_dy = _lib.DeviceBuffer(self.max_blocks * 8)
         self.d_cf = _lib.DeviceBuffer(self.max_blocks * 4)
+        self.residue_len = float(residue_len)                 # matcher.py:236 (fine_downsample = 1)
+        self.stiffness_lambda = float(stiffness_lambda)       # matcher.py:507
+        self.relax_tol = float(relax_tol)
+        self._relax_sys = None
+        self.last_relax = None
 
     def free(self):
+        if self._relax_sys is not None:
+            _lib.load().fb_sys_destroy(_lib.ctx(), self._relax_sys)
+            self._relax_sys = None
         for b in (self.d_small, self.d_dogc, self.d_dogf, self.d_blk, self.d_dx, self.d_dy, self.d_cf):
             if b is not None:
                 b.free()
@@ -178,6 +189,78 @@ class StripBatchMatcher:
             groups.append((sel, bb, ddx, ddy, dcf))
         return groups
 
+    # ------------------------------------------------------------------ last-round relaxation
+    def _relax_system(self):
+        """P copies of the cartesian mesh of matcher.py:354-356 as ONE block-diagonal GPU system.  mesh0 is
+        locked (matcher.py:361), so a match couples only the three vertices of its mesh1 triangle: the symbolic
+        pattern and the stiffness K never change between batches; only the links do."""
+        if self._relax_sys is not None:
+            return self._relax_sys
+        lib, ctx = _lib.load(), _lib.ctx()
+        m = Mesh.from_bbox((0, 0, self.W, self.H), cartesian=True, mesh_size=float(np.min(self.spacings)),
+                           min_num_blocks=self.mnb, uid=1)
+        self._mesh = m
+        V = m.num_vertices
+        sysh = C.c_void_p()
+        _lib.check(lib.fb_sys_create(ctx, self.P * V, C.byref(sysh)))
+        v0 = np.ascontiguousarray(m.vertices(const.MESH_GEAR_INITIAL), dtype=np.float64)
+        for p in range(self.P):
+            mid = C.c_int()
+            _lib.check(lib.fb_sys_add_mesh(ctx, sysh, p * V, _lib.ptr(m.triangles), V, m.num_triangles, C.byref(mid)))
+        _lib.check(lib.fb_sys_set_links(ctx, sysh, 0, None))
+        nnzb = C.c_int64()
+        _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
+        for p in range(self.P):
+            m.assemble_into(sysh, p, v0, None, 1.0)           # translation invariant: shape = INITIAL vertices, no stress
+        self._relax_sys = sysh
+        return sysh
+
+    def _final_relax(self, pid, xy0, xy1, wt, t1):
+        """matcher.py:725-737 for every pair of the batch at once: relax mesh1 against the last-round links
+        (optimize_linear, to the fixed point), then huber residue weights (optimizer.py:174-191, 203-205).
+        pid [K] sorted or not; xy0/xy1 [K, 2] in the MOVING gear; wt [K] confidences; t1 [P, 2] mesh1 offsets.
+        Returns the residue weight [K] float32, the displacement of the mesh1 end of each match and of every
+        mesh1 vertex [P, V, 2]."""
+        lib, ctx = _lib.load(), _lib.ctx()
+        sysh = self._relax_system()
+        m = self._mesh
+        V = m.num_vertices
+        K = pid.size
+        q1 = xy1 - t1[pid]                                    # mesh1 coordinates without its offset
+        tid1 = m.locate_cartesian(q1)
+        tv = m.triangles[tid1]                                # [K, 3]
+        pv = m.vertices(const.MESH_GEAR_INITIAL)[tv]          # [K, 3, 2]
+        d0, d1, d2 = q1 - pv[:, 0], q1 - pv[:, 1], q1 - pv[:, 2]
+        a0 = d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0]        # mesh.py:2191-2217
+        a1 = d2[:, 0] * d0[:, 1] - d2[:, 1] * d0[:, 0]
+        a2 = d0[:, 0] * d1[:, 1] - d0[:, 1] * d1[:, 0]
+        tot = a0 + a1 + a2
+        B1 = np.stack((a0 / tot, a1 / tot, a2 / tot), axis=-1)
+        nodes6 = np.full((K, 6), -1, dtype=np.int32)
+        nodes6[:, 3:] = tv + (pid * V)[:, None]
+        bary6 = np.zeros((K, 6))
+        bary6[:, 0] = 1.0                                     # locked side: not used by the assembly
+        bary6[:, 3:] = -B1
+        w32 = np.ascontiguousarray(wt, dtype=np.float32)
+        dxy = np.ascontiguousarray(xy1 - xy0, dtype=np.float64)          # Link.dxy (optimizer.py:248-255)
+        _lib.check(lib.fb_sys_update_links(ctx, sysh, K, _lib.ptr(nodes6)))
+        _lib.check(lib.fb_sys_assemble_links(ctx, sysh, _lib.ptr(bary6), _lib.ptr(w32), _lib.ptr(dxy)))
+        _lib.check(lib.fb_sys_form_groups(ctx, sysh, self.P, self.stiffness_lambda, -1.0, None))
+        x = np.zeros(2 * self.P * V, dtype=np.float64)
+        iters, relres = C.c_int(), C.c_double()
+        _lib.check(lib.fb_sys_solve(ctx, sysh, _lib.ptr(x), 0, self.relax_tol, 0.0, 20 * V, 1, C.byref(iters), C.byref(relres)),
+                   allow=(_lib.FB_ERR_NOCONV,))
+        self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K))
+        x = x.reshape(-1, 2)
+        u = np.sum(x[nodes6[:, 3:]] * B1[:, :, None], axis=1)            # displacement of the mesh1 end of each match
+        res = dxy + u
+        dis2 = np.sum(res ** 2, axis=-1)
+        area = float(np.abs(m.triangle_areas(const.MESH_GEAR_INITIAL)[0]))
+        sample_err = 0.4387 * area ** 0.5 * DEFAULT_AVG_DEFORM          # optimizer.py:26-30, equal triangles on both sides
+        dis = np.sqrt(np.clip(dis2 - sample_err ** 2, 0, None))
+        L = self.residue_len
+        return (L / np.maximum(dis, L)).astype(np.float32), u, x.reshape(self.P, V, 2)
+
     # ------------------------------------------------------------------ driver
     def match(self, strips0, strips1):
         """strips0/strips1: device pointers to uint8 [P][H][W].  Returns a dict of arrays:
@@ -196,16 +279,18 @@ class StripBatchMatcher:
         table = None
         txy = np.stack((tx, ty), axis=-1)
         t1 = np.zeros((n, 2))                                # translation of mesh1 acquired by rigid relaxations
+        live = active.copy()                                 # pairs still iterating over the spacings
         for rnd in range(spacings.size):
             sp = spacings[rnd]
             is_last = rnd == spacings.size - 1
             mnb = self.mnb if is_last else 1
             rows = []
-            for sel, bb, ddx, ddy, dcf in self._match_round(tx, ty, t1, active, sp, mnb, pad, subpixel=is_last):
+            for sel, bb, ddx, ddy, dcf in self._match_round(tx, ty, t1, live, sp, mnb, pad, subpixel=is_last):
                 keep = dcf > self.conf_thresh                # matcher.py:671-683
                 anyk = keep.any(axis=1)
                 if rnd == 0:
                     active[sel[~anyk]] = False               # invalid_output (matcher.py:672-673)
+                live[sel[~anyk]] = False                     # ... or break with the links so far (674-675)
                 ctr = 0.5 * np.stack((bb[..., 0] + bb[..., 2], bb[..., 1] + bb[..., 3]), axis=-1) - 0.5      # bbox_centers
                 dxy = np.stack((ddx, ddy), axis=-1)
                 xy0 = ctr - dxy * 0.5                        # equal block sizes: ratio 0.5 (matcher.py:844-849)
@@ -232,10 +317,27 @@ class StripBatchMatcher:
                         t1[sel[rigid]] += u0[rigid]
                         needs_host[sel[move & ~uniform]] = True
                 pid = np.broadcast_to(sel[:, None], keep.shape)
-                rows.append((pid[keep], xy0[keep], xy1_init[keep], dcf[keep]))
+                relax = np.broadcast_to((max_dis > 0.1)[:, None], keep.shape)
+                rows.append((pid[keep], xy0[keep], xy1_init[keep], dcf[keep], xy1[keep], relax[keep]))
                 has_last[sel[anyk]] = True
             if rows:
-                table = tuple(np.concatenate([r[k] for r in rows], axis=0) for k in range(4))
+                prev = table
+                table = tuple(np.concatenate([r[k] for r in rows], axis=0) for k in range(6))
+                if is_last and self.residue_len > 0:
+                    # last round (matcher.py:725-737): relaxation + huber residue weights, pairs with max_dis > 0.1
+                    pid_l, xy0_l, _, wt_l, xy1_l, rl = table
+                    if rl.any():
+                        rw, _, _ = self._final_relax(pid_l[rl], xy0_l[rl], xy1_l[rl], wt_l[rl], t1)
+                        wt_new = wt_l.copy()
+                        wt_new[rl] = wt_l[rl] * rw                                 # Link.weight (optimizer.py:313-317)
+                        table = table[:3] + (wt_new,) + table[4:]
+                table = table[:4]
+                if prev is not None and prev[0].size:
+                    # a pair without a confident block in this round keeps the links of its last good round
+                    # (the reference breaks out of the loop before clear_links, matcher.py:671-679)
+                    carry = ~np.isin(prev[0], table[0])
+                    if carry.any():
+                        table = tuple(np.concatenate((a, b[carry]), axis=0) for a, b in zip(table, prev))
         valid = active & has_last
         if table is None:
             table = (np.zeros(0, np.int64), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0, np.float32))

@@ -171,6 +171,13 @@ int fb_sys_assemble_mesh_materials(fb_ctx* ctx, fb_system* sys, int mesh_id, con
 /* bary6: [K][6] = [+B0 | -B1] (Link.shape_matrix_contrib, optimizer.py:114-131); w: [K] float32
  * (weight * residue_weight); rxy: [K][2] residual x1 - x0 (Link.dxy, optimizer.py:248-255) */
 int fb_sys_assemble_links(fb_ctx* ctx, fb_system* sys, const double* bary6, const float* w, const double* rxy);
+/* Replace the links of a finalized system without touching the symbolic pattern (the new matches must
+ * couple only vertices that are already coupled, e.g. matches against locked meshes). */
+int fb_sys_update_links(fb_ctx* ctx, fb_system* sys, int64_t K, const int32_t* nodes6);
+/* Block-diagonal batch of `ngroups` independent systems stored as equal consecutive vertex ranges (one
+ * tile pair each, matcher.py:551): relative_lambda_trace per range, then A and b as in fb_sys_form. */
+int fb_sys_form_groups(fb_ctx* ctx, fb_system* sys, int ngroups, double stiffness_lambda, double crosslink_lambda,
+                       double* ls_out);
 int fb_sys_lambda(fb_ctx* ctx, fb_system* sys, double stiffness_lambda, double crosslink_lambda, double* sl_out, double* cl_out);
 int fb_sys_form(fb_ctx* ctx, fb_system* sys, double sl, double cl);
 /* x: [2 nv] float64, x0 on entry when use_x0.  maxiter < 0: until converged, 0: zeros, > 0: cap */

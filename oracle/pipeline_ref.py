@@ -1,8 +1,9 @@
 """Oracle of the per-tile-pair matcher (NCC side of matcher.stitching_matcher,
 feabas/matcher.py:224-367 + 430-751) for pairs whose block rounds never move a
-block by more than 0.1 px before the last round -- the branch in which the
-reference performs no mesh relaxation (matcher.py:725) and every crop of
-MeshRenderer.crop_multiple is an integer translation of the DoG'd strip.
+block by a non-uniform amount before the last round -- the branch in which every
+mesh relaxation between rounds (matcher.py:725) is a rigid integer translation and every crop of
+MeshRenderer.crop_multiple is an integer translation of the DoG'd strip.  The last round's relaxation and
+huber residue weights (matcher.py:725-737) are solved exactly on the cartesian mesh pair.
 TEST INFRASTRUCTURE (see oracle/__init__.py).  cv2 / triangle / shapely are not
 needed on this branch; the x0.5 INTER_AREA downsample is the unpinned
 restatement ncc_ref.area_downsample2.
@@ -45,10 +46,11 @@ def locate_cartesian(xs, ys, pts):
     return 2 * (j * (nx - 1) + i) + (w > u)
 
 
-def relax_mesh1(W, H, mesh_size, t0, t1, xy0, xy1, weight):
-    """matcher.py:717-729 with an exact solve: mesh0 (locked, translated by t0), mesh1 (free, translated by t1),
-    one link from the matched points (MOVING gear).  Returns the displacement of every mesh1 vertex."""
-    v, tri, xs, ys = cartesian_mesh(W, H, mesh_size)
+def relax_mesh1(W, H, mesh_size, t0, t1, xy0, xy1, weight, residue_len=0.0, min_num_blocks=2, return_mesh=False):
+    """matcher.py:717-737 with an exact solve: mesh0 (locked, translated by t0), mesh1 (free, translated by t1),
+    one link from the matched points (MOVING gear).  Returns the displacement of every mesh1 vertex and, with
+    residue_len > 0, the huber residue weight of every match after the relaxation (optimizer.py:174-191)."""
+    v, tri, xs, ys = cartesian_mesh(W, H, mesh_size, min_num_blocks=min_num_blocks)
     m0 = fem_ref.RefMesh(v, tri, uid=0)
     m0.apply_translation(t0, fem_ref.GEAR_FIXED)
     m0.locked = True
@@ -61,7 +63,12 @@ def relax_mesh1(W, H, mesh_size, t0, t1, xy0, xy1, weight):
     link = fem_ref.RefLink(m0, m1, tid0, tid1, B0, B1, weight=weight)
     before = m1.vertices_w_offset(fem_ref.GEAR_MOVING).copy()
     fem_ref.optimize_linear([m0, m1], [link], exact=True)
-    return m1.vertices_w_offset(fem_ref.GEAR_MOVING) - before
+    u = m1.vertices_w_offset(fem_ref.GEAR_MOVING) - before
+    if return_mesh:
+        return u, m0, m1, link
+    if residue_len > 0:
+        return u, link.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), 'huber', residue_len)
+    return u
 
 
 def _crop(img, x0, y0, h, w):
@@ -77,7 +84,7 @@ def _crop(img, x0, y0, h, w):
 
 
 def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
-               conf_mode=ncc_ref.FFT_CONF_MIRROR):
+               conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0):
     """strip0/strip1: uint8 H x W overlap strips.  Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host)."""
     H, W = strip0.shape
     if coarse_downsample == 0.5:
@@ -119,16 +126,21 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
         if not np.any(keep):
             if rnd == 0:
                 return res
-            continue
+            break                                            # matcher.py:671-679: keep the links of the last good round
         xy0, xy1, wt = xy0[keep], xy1[keep], cf[keep]
         max_dis = np.max(np.sum((xy0 - xy1) ** 2, axis=-1)) ** 0.5
         last = (xy0, xy1 - t1, wt, max_dis)                   # INITIAL gear: barycentric coordinates are fixed at link creation
+        if is_last and max_dis > 0.1 and residue_len > 0:
+            # matcher.py:725-737: relax, then Link.weight = conf * huber residue weight (no second solve: sp_indx ran out)
+            _, rw = relax_mesh1(W, H, float(np.min(spacings)), (tx, ty), t1, xy0, xy1, wt, residue_len=residue_len,
+                                min_num_blocks=min_num_blocks)
+            last = (xy0, xy1 - t1, wt * rw, max_dis)
         if not is_last:
             next_pos = np.searchsorted(-spacings, -4 * max_dis) - 1           # matcher.py:689-716
             pad = (min(next_pos, rnd + 1) > rnd + 1) if next_pos > rnd else True
             if max_dis > 0.1:
                 # mesh relaxation (matcher.py:725-729), exact solve on the cartesian mesh pair
-                u = relax_mesh1(W, H, float(np.min(spacings)), (tx, ty), t1, xy0, xy1, wt)
+                u = relax_mesh1(W, H, float(np.min(spacings)), (tx, ty), t1, xy0, xy1, wt, min_num_blocks=min_num_blocks)
                 um = u.mean(axis=0)
                 if np.abs(u - um).max() < 1e-6 and np.abs(um - np.round(um)).max() < 1e-6:
                     t1 = t1 + np.round(um)                   # a rigid integer translation: crops stay exact

@@ -64,3 +64,36 @@ def test_pipeline_even_offsets_take_the_device_branch(fb):
         np.testing.assert_allclose(got[p]['xy0'], exp['xy0'], atol=1e-4); np.testing.assert_allclose(got[p]['xy1'], exp['xy1'], atol=1e-4)
         np.testing.assert_allclose(got[p]['weight'], exp['weight'], atol=1e-4)
     m.free()
+
+
+def test_final_relax_huber_weights_vs_fem_oracle(fb):
+    """last-round relaxation + huber residue weights (matcher.py:725-737) for a batch of pairs whose matches
+    carry a smooth deformation plus gross outliers, against the exact FEM solve of the oracle, pair by pair"""
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    P, H, W = 3, 256, 1024
+    m = StripBatchMatcher(P, H, W)
+    rng = np.random.default_rng(5)
+    t0 = np.array([[3.0, -2.0], [-7.0, 4.0], [0.0, 0.0]])
+    t1 = np.array([[1.0, 0.0], [0.0, -3.0], [0.0, 0.0]])
+    pid, xy0, xy1, wt = [], [], [], []
+    for p in range(P):
+        gx, gy = np.meshgrid(np.arange(40, W - 40, 61.0), np.arange(30, H - 30, 47.0))
+        c = np.stack((gx.ravel(), gy.ravel()), -1) + t1[p]
+        if p == 2:
+            c = c[:5]                                                   # a sparse pair: most of the mesh is unconstrained
+        f = 1.5 * np.stack((np.sin(c[:, 0] / 300.0), np.cos(c[:, 1] / 90.0)), -1) + rng.normal(0, 0.2, c.shape)
+        bad = rng.random(c.shape[0]) < 0.15
+        f[bad] += rng.uniform(6, 25, (bad.sum(), 1)) * np.array([[0.8, -0.6]])
+        pid.append(np.full(c.shape[0], p)); xy0.append(c - 0.5 * f); xy1.append(c + 0.5 * f)
+        wt.append(rng.uniform(0.35, 1.0, c.shape[0]).astype(np.float32))
+    order = rng.permutation(sum(a.size for a in pid))                   # rows of a pair need not be contiguous
+    pid = np.concatenate(pid)[order]; xy0 = np.concatenate(xy0)[order]; xy1 = np.concatenate(xy1)[order]; wt = np.concatenate(wt)[order]
+    rw, u, x = m._final_relax(pid, xy0, xy1, wt, t1)
+    assert m.last_relax['relres'] < 1e-8
+    assert rw.min() < 0.6 and (rw == 1).sum() > rw.size // 2            # outliers damped, inliers untouched
+    for p in range(P):
+        s = pid == p
+        uo, rwo = pipeline_ref.relax_mesh1(W, H, float(np.min(m.spacings)), t0[p], t1[p], xy0[s], xy1[s], wt[s], residue_len=5.0)
+        np.testing.assert_allclose(x[p], uo, atol=1e-4)
+        np.testing.assert_allclose(rw[s], rwo, atol=1e-5)
+    m.free()
