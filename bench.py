@@ -14,6 +14,7 @@ tables are gathered with one RCCL all_gather per step; value = all pairs / max-o
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -266,6 +267,15 @@ def main():
         roof['achieved'] = dom[1][2] / (dom[1][1] * 1e-3) / 1e9
         roof['frac'] = roof['achieved'] / HBM_PEAK_GBS
         roof['algorithmic_bytes_per_launch'] = dom[1][2] / dom[1][0]
+    # HBM bytes per launch of that kernel from the PMC passes of this same command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    # separate rocprofv3 --pmc runs, tools/pmc_traffic.py); counters cannot be read from inside the timed run
+    tfile = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*pmc_traffic.json')))
+    if tfile and dom[0] is not None:
+        tk = json.load(open(tfile[-1]))['kernels']
+        hit = [v for k_, v in tk.items() if k_.startswith(dom[0])]
+        if hit:
+            roof['traffic'] = hit[0]['hbm_bytes_per_launch']
+            roof['traffic_source'] = 'profiles/' + os.path.basename(tfile[-1])
     roof['per_kernel_gbs'] = {k_: round(v[2] / (v[1] * 1e-3) / 1e9, 1) for k_, v in prof.items() if v[1] > 0 and v[2] > 0}
 
     line = dict(metric='tile_pair_ncc_matches_per_s', value=pairs / dt, unit='pairs/s', n_gpus=world, steps=args.steps,
