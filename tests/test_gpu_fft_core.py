@@ -20,3 +20,20 @@ def test_fft1d_vs_numpy(fb, n, pad):
     _lib.check(lib.fb_debug_fft1d(ctx, _lib.ptr(x), _lib.ptr(out), m, n, 1, pad))
     ref = np.fft.ifft(x.astype(np.complex128), axis=-1) * n
     assert np.abs(out - ref).max() <= 3e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('n', [64, 128, 256, 512, 1024, 2048, 4096])
+def test_fft1d_pow2_packed_core_vs_numpy(fb, n):
+    """fb_fft2.h: compile-time plans + packed-FP32 butterflies (the streaming-class kernels at power-of-two shapes)"""
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(n + 1)
+    m = max(1, min(4, 8192 // n))
+    x = (rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))).astype(np.complex64)
+    out = np.empty_like(x)
+    _lib.check(lib.fb_debug_fft1d(ctx, _lib.ptr(x), _lib.ptr(out), m, n, 0, 2))
+    ref = np.fft.fft(x.astype(np.complex128), axis=-1)
+    assert np.abs(out - ref).max() <= 3e-6 * np.abs(ref).max()
+    _lib.check(lib.fb_debug_fft1d(ctx, _lib.ptr(x), _lib.ptr(out), m, n, 1, 2))
+    ref = np.fft.ifft(x.astype(np.complex128), axis=-1) * n
+    assert np.abs(out - ref).max() <= 3e-6 * np.abs(ref).max()
