@@ -123,8 +123,26 @@ constexpr int p2_tw_entries(int N) { return N / 16; }            // tw[i] = exp(
 
 // one radix-R pass (block length L) over M transforms of length N; transform m starts at base + m * pitch
 // (pitch >= fft_padx(N)); element e of a transform sits at fft_padx(e).
-template <int N, int R, int L, bool INV>
-__device__ __forceinline__ void p2_pass(f2* base, int M, int pitch, const f2* tw, int tid, int nt) {
+// position of frequency k in the digit-reversed output of the forward transform (== fft_pos of the generic plan)
+template <int N>
+__device__ __forceinline__ int p2_pos(int k) {
+    int pos = 0, stride = N;
+#pragma unroll
+    for (int s = 0; s < p2_n16(N); ++s) {
+        stride >>= 4;
+        pos += (k & 15) * stride;
+        k >>= 4;
+    }
+    return pos + k;          // trailing radix (stride 1)
+}
+
+struct P2Store {             // default sink of a pass: write the butterfly back in place
+    static constexpr bool kStore = true;
+    __device__ __forceinline__ void operator()(int, int, f2) const {}
+};
+
+template <int N, int R, int L, bool INV, typename SINK = P2Store>
+__device__ __forceinline__ void p2_pass(f2* base, int M, int pitch, const f2* tw, int tid, int nt, const SINK& sink = SINK()) {
     constexpr int Lp = L / R, per = N / R, lper = p2_log2(per), lLp = p2_log2(Lp);
     const int total = per * M;
     for (int t = tid; t < total; t += nt) {
@@ -136,24 +154,37 @@ __device__ __forceinline__ void p2_pass(f2* base, int M, int pitch, const f2* tw
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = p[q * Lp + ((q * Lp) >> 4)];
         if (L > R) {
+            // w[q] = w1^q by squarings / products of depth <= log2(R); each power is applied as soon as it exists so
+            // that at most R / 2 of them are live
             f2 w[R];
             w[1] = tw[jj * (N / L)];
-#pragma unroll
-            for (int q = 2; q < R; ++q) w[q] = (q & 1) ? pk_cmul(w[q - 1], w[1]) : pk_cmul(w[q / 2], w[q / 2]);
             if (INV) {
+                v[1] = pk_cmulc(v[1], w[1]);                                  // DIT: conjugate twiddle first
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = pk_cmulc(v[q], w[q]);      // DIT: conjugate twiddle first
+                for (int q = 2; q < R; ++q) {
+                    w[q] = (q & 1) ? pk_cmul(w[q - 1], w[1]) : pk_cmul(w[q / 2], w[q / 2]);
+                    v[q] = pk_cmulc(v[q], w[q]);
+                }
                 pk_dft<R, true>(v);
             } else {
                 pk_dft<R, false>(v);
+                v[1] = pk_cmul(v[1], w[1]);                                   // DIF: twiddle after
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = pk_cmul(v[q], w[q]);       // DIF: twiddle after
+                for (int q = 2; q < R; ++q) {
+                    w[q] = (q & 1) ? pk_cmul(w[q - 1], w[1]) : pk_cmul(w[q / 2], w[q / 2]);
+                    v[q] = pk_cmul(v[q], w[q]);
+                }
             }
         } else {
             pk_dft<R, INV>(v);
         }
+        if (SINK::kStore) {
 #pragma unroll
-        for (int q = 0; q < R; ++q) p[q * Lp + ((q * Lp) >> 4)] = v[q];
+            for (int q = 0; q < R; ++q) p[q * Lp + ((q * Lp) >> 4)] = v[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) sink(m, e0 + q * Lp, v[q]);      // (transform, element index, value)
+        }
     }
 }
 
@@ -164,7 +195,44 @@ struct P2Stage {       // S-th radix-16 pass counted in DIF order
     }
 };
 
+// geometry of the pass that ends the forward / starts the inverse transform (block length == radix, no twiddles)
+constexpr int p2_last_radix(int N) { return p2_rem(N) > 1 ? p2_rem(N) : 16; }
+
+// forward transform without its last pass / inverse transform without its first pass: the caller fuses
+// those two with the pointwise work in between (each touches R consecutive elements of a transform)
+template <int N>
+__device__ __forceinline__ void p2_fft_fwd_head(f2* base, int M, int pitch, const f2* tw) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    constexpr int n16 = p2_n16(N), rem = p2_rem(N), nh = rem > 1 ? n16 : n16 - 1;
+    if (nh >= 1) { P2Stage<N, 0, false>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
+    if (nh >= 2) { P2Stage<N, (nh >= 2 ? 1 : 0), false>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
+    if (nh >= 3) { P2Stage<N, (nh >= 3 ? 2 : 0), false>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
+}
+template <int N, typename SINK = P2Store>
+__device__ __forceinline__ void p2_fft_inv_tail(f2* base, int M, int pitch, const f2* tw, const SINK& sink = SINK()) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    constexpr int n16 = p2_n16(N), rem = p2_rem(N), nh = rem > 1 ? n16 : n16 - 1;
+    if (nh >= 3) { P2Stage<N, (nh >= 3 ? 2 : 0), true>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
+    if (nh >= 2) { P2Stage<N, (nh >= 2 ? 1 : 0), true>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
+    if (nh >= 1) {
+        p2_pass<N, 16, N, true, SINK>(base, M, pitch, tw, tid, nt, sink);
+        if (SINK::kStore) __syncthreads();
+    }
+}
+
 // full transform of M rows; every pass ends with a workgroup barrier
+// inverse transform whose last pass (radix 16, L = N: outputs in natural order) hands its results to `sink`
+// instead of writing them back (N >= 256 so that the last pass is not also the first)
+template <int N, typename SINK>
+__device__ __forceinline__ void p2_fft_inv_sink(f2* base, int M, int pitch, const f2* tw, const SINK& sink) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    constexpr int n16 = p2_n16(N), rem = p2_rem(N);
+    if (rem > 1) { p2_pass<N, (rem > 1 ? rem : 2), (rem > 1 ? rem : 2), true>(base, M, pitch, tw, tid, nt); __syncthreads(); }
+    if (n16 >= 3) { P2Stage<N, (n16 >= 3 ? 2 : 0), true>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
+    if (n16 >= 2) { P2Stage<N, (n16 >= 2 ? 1 : 0), true>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
+    p2_pass<N, 16, N, true, SINK>(base, M, pitch, tw, tid, nt, sink);
+}
+
 template <int N, bool INV>
 __device__ __forceinline__ void p2_fft(f2* base, int M, int pitch, const f2* tw) {
     const int tid = threadIdx.x, nt = blockDim.x;

@@ -631,308 +631,7 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_inv(const StreamGeo
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Power-of-two shapes (every FFT of the 4k configuration: 4096x512, 2048x1024, 1024x2048): the same
-// three kernels on the packed-math compile-time core of fb_fft2.h.  Layouts of T and V are unchanged.
-struct P2Geom {
-    const float2 *twW, *twH;     // tw[i] = exp(-2 pi i / F), i < F / 16
-    int lTR;                     // log2(TR)
-};
-
-constexpr int p2_padx(int e) { return e + (e >> 4); }
-// rows per tile of the row kernels: the largest power of two <= 16 whose tile fits a 70 KiB LDS budget (2 workgroups per CU)
-constexpr int p2_tr(int F) {
-    int t = 16;
-    while (t > 1 && (size_t)t * (p2_padx(F) + 1) * 8 > 70 * 1024) t >>= 1;
-    return t;
-}
-
-template <int FW>
-__global__ __launch_bounds__(kStreamThreads) void ncc_rows_p2(const StreamGeom g, const P2Geom q, float4* __restrict__ T0, float4* __restrict__ T1) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    constexpr int pitch = p2_padx(FW) + 1, Sw = FW / 2 + 1;
-    constexpr int TR = p2_tr(FW), lTR = p2_log2(TR);
-    f2* G = reinterpret_cast<f2*>(lds);
-    f2* tw = G + (size_t)TR * pitch;
-    short* posW = reinterpret_cast<short*>(tw + p2_tw_entries(FW));
-    const int n = blockIdx.y, y0 = blockIdx.x * TR;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    int h0 = g.H0, w0 = g.W0, h1 = g.H1, w1 = g.W1, ox0 = 0, oy0 = 0, ox1 = 0, oy1 = 0;
-    int p0 = w0, p1 = w1, my0 = h0 - 1, mx0 = w0 - 1, my1 = h1 - 1, mx1 = w1 - 1;
-    const float* s0; const float* s1;
-    if (g.blk) {
-        const int* d = g.blk + (size_t)n * kBlkStride;
-        s0 = g.img0 + (size_t)d[0] * g.IH0 * g.IW0;
-        s1 = g.img1 + (size_t)d[0] * g.IH1 * g.IW1;
-        ox0 = d[1]; oy0 = d[2]; h0 = d[3]; w0 = d[4]; ox1 = d[5]; oy1 = d[6]; h1 = d[7]; w1 = d[8];
-        p0 = g.IW0; p1 = g.IW1; my0 = g.IH0 - 1; mx0 = g.IW0 - 1; my1 = g.IH1 - 1; mx1 = g.IW1 - 1;
-    } else {
-        s0 = g.img0 + (size_t)n * h0 * w0;
-        s1 = g.img1 + (size_t)n * h1 * w1;
-    }
-    for (int i = tid; i < p2_tw_entries(FW); i += nt) tw[i] = (f2){q.twW[i].x, q.twW[i].y};
-    for (int i = tid; i < FW; i += nt) posW[i] = (short)fft_padx(fft_pos(g.pw, i));
-    // packed load z = img0 + i img1 (zero padded); columns beyond both crops are only cleared
-    const int wmax = max(w0, w1);
-    for (int xb = 0; xb < FW; xb += nt) {
-        const int x = xb + tid;
-        if (xb >= wmax) {
-            if (x < FW)
-                for (int r = 0; r < TR; ++r) G[r * pitch + fft_padx(x)] = (f2){0.f, 0.f};
-            continue;
-        }
-        const int gx0 = ox0 + x, gx1 = ox1 + x;
-        const bool vx0 = x < w0 && gx0 >= 0 && gx0 <= mx0, vx1 = x < w1 && gx1 >= 0 && gx1 <= mx1;
-        const int cx0 = min(max(gx0, 0), mx0), cx1 = min(max(gx1, 0), mx1);
-        constexpr int CH = TR < 4 ? TR : 4;          // rows in flight per thread (bounds the scalar row-address state)
-#pragma unroll 1
-        for (int rb = 0; rb < TR; rb += CH) {
-            float a[CH], b[CH];
-#pragma unroll
-            for (int r = 0; r < CH; ++r) {
-                const int y = y0 + rb + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
-                b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
-            }
-            if (x < FW) {
-#pragma unroll
-                for (int r = 0; r < CH; ++r) {
-                    const int y = y0 + rb + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                    const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
-                    const bool v1 = vx1 && y < h1 && gy1 >= 0 && gy1 <= my1;
-                    G[(rb + r) * pitch + fft_padx(x)] = (f2){v0 ? a[r] : 0.f, v1 ? b[r] : 0.f};
-                }
-            }
-        }
-    }
-    __syncthreads();
-    p2_fft<FW, false>(G, TR, pitch, tw);
-    // split the packed spectra; one item = both columns of a pair for one row = one float4 per image,
-    // lanes walk the rows of a tile: TR * 16 B contiguous per (pair, tile)
-    const size_t tbase = (size_t)n * g.Kp * g.Hs;
-    const int items = g.Kp << lTR;
-    for (int t = tid; t < items; t += nt) {
-        const int r = t & (TR - 1), kp = t >> lTR;
-        float4 oa, ob;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int kx = 2 * kp + c;
-            f2 a = {0.f, 0.f}, b = {0.f, 0.f};
-            if (kx < Sw) {
-                const f2 zk = G[r * pitch + posW[kx]];
-                const f2 zn = G[r * pitch + posW[(FW - kx) & (FW - 1)]];
-                const f2 sm = zk + zn, df = zk - zn;
-                a = (f2){0.5f * sm.x, 0.5f * df.y};
-                b = (f2){0.5f * sm.y, -0.5f * df.x};
-            }
-            if (c == 0) { oa.x = a.x; oa.y = a.y; ob.x = b.x; ob.y = b.y; }
-            else { oa.z = a.x; oa.w = a.y; ob.z = b.x; ob.w = b.y; }
-        }
-        const size_t o = tbase + (size_t)kp * g.Hs + y0 + r;
-        T0[o] = oa;
-        T1[o] = ob;
-    }
-}
-
-template <int FH>
-__global__ __launch_bounds__(kStreamThreads) void ncc_cols_p2(const StreamGeom g, const P2Geom q, const float4* __restrict__ T0, const float4* __restrict__ T1,
-                                                              float4* __restrict__ V0, float4* __restrict__ V1) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    constexpr int pitch = p2_padx(FH) + 1;
-    f2* U = reinterpret_cast<f2*>(lds);       // [4][pitch]: (img0,c0) (img0,c1) (img1,c0) (img1,c1)
-    f2* tw = U + 4 * (size_t)pitch;
-    const int kp = blockIdx.x, n = blockIdx.y;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < p2_tw_entries(FH); i += nt) tw[i] = (f2){q.twH[i].x, q.twH[i].y};
-    const size_t tb = ((size_t)n * g.Kp + kp) * g.Hs;
-    const int Hs = g.Hs;
-    for (int yb = 0; yb < FH; yb += 4 * nt) {
-        float4 a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int y = yb + u * nt + tid;
-            const bool in = y < Hs;
-            a[u] = in ? T0[tb + y] : make_float4(0.f, 0.f, 0.f, 0.f);
-            b[u] = in ? T1[tb + y] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int y = yb + u * nt + tid;
-            if (y < FH) {
-                const int yp = fft_padx(y);
-                U[yp] = (f2){a[u].x, a[u].y};
-                U[pitch + yp] = (f2){a[u].z, a[u].w};
-                U[2 * pitch + yp] = (f2){b[u].x, b[u].y};
-                U[3 * pitch + yp] = (f2){b[u].z, b[u].w};
-            }
-        }
-    }
-    __syncthreads();
-    p2_fft<FH, false>(U, 4, pitch, tw);
-    const bool wq = g.want_q != 0;
-    for (int e = tid; e < 2 * FH; e += nt) {
-        const int c = e & 1, yp = fft_padx(e >> 1);
-        const f2 a = U[c * pitch + yp], b = U[(2 + c) * pitch + yp];
-        U[c * pitch + yp] = pk_cmulc(b, a);                          // conj(F0) F1
-        U[(2 + c) * pitch + yp] = wq ? pk_cmul(a, b) : (f2){0.f, 0.f};   // F0 F1 (mirror confidence)
-    }
-    __syncthreads();
-    p2_fft<FH, true>(U, wq ? 4 : 2, pitch, tw);
-    const size_t vb = ((size_t)n * g.Kp + kp) * FH;
-    for (int y = tid; y < FH; y += nt) {
-        const int yp = fft_padx(y);
-        const f2 p0 = U[yp], p1 = U[pitch + yp];
-        V0[vb + y] = make_float4(p0.x, p0.y, p1.x, p1.y);
-        if (wq) {
-            const f2 q0 = U[2 * pitch + yp], q1 = U[3 * pitch + yp];
-            V1[vb + y] = make_float4(q0.x, q0.y, q1.x, q1.y);
-        }
-    }
-}
-
-template <int FW>
-__global__ __launch_bounds__(kStreamThreads) void ncc_inv_p2(const StreamGeom g, const P2Geom q, const float4* __restrict__ V0, const float4* __restrict__ V1,
-                                                             PeakPartial* __restrict__ part, const PeakPartial* __restrict__ part_in,
-                                                             int nparts, float* __restrict__ ct9) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    constexpr int pitch = p2_padx(FW) + 1, Sw = FW / 2 + 1;
-    const int Fh = g.Fh;
-    const bool neigh = ct9 != nullptr;
-    constexpr int TRc = p2_tr(FW);
-    const int TRI = neigh ? 4 : TRc, lTRI = neigh ? 2 : p2_log2(TRc);
-    f2* G = reinterpret_cast<f2*>(lds);
-    f2* tw = G + (size_t)TRI * pitch;
-    short* posW = reinterpret_cast<short*>(tw + p2_tw_entries(FW));
-    __shared__ float sv[kStreamThreads / 64]; __shared__ int si[kStreamThreads / 64]; __shared__ float sm[kStreamThreads / 64];
-    __shared__ double ssum[kStreamThreads / 64]; __shared__ double ssq[kStreamThreads / 64];
-    __shared__ int s_peak;
-    const int n = blockIdx.y;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < p2_tw_entries(FW); i += nt) tw[i] = (f2){q.twW[i].x, q.twW[i].y};
-    for (int i = tid; i < FW; i += nt) posW[i] = (short)fft_padx(fft_pos(g.pw, i));
-    const int y0 = blockIdx.x * TRI;
-    int py = 0, px = 0;
-    if (neigh) {
-        if (tid == 0) {
-            const PeakPartial* p = part_in + (size_t)n * nparts;
-            float v = p[0].vmax; int iv = p[0].imax;
-            for (int c = 1; c < nparts; ++c) peak_merge(v, iv, p[c].vmax, p[c].imax);
-            if (iv == 0x7fffffff) iv = 0;
-            s_peak = iv;
-        }
-        __syncthreads();
-        py = s_peak / FW; px = s_peak - py * FW;
-    }
-    __syncthreads();
-    const bool wq = g.want_q != 0;
-    const size_t vb = (size_t)n * g.Kp * Fh;
-    const int nitems = g.Kp << lTRI;
-    for (int tb = 0; tb < nitems; tb += 4 * nt) {
-        float4 pk[4], qk[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = min(tb + u * nt + tid, nitems - 1);
-            const int r = t & (TRI - 1), kp = t >> lTRI;
-            int y = y0 + r;
-            bool ok = y < Fh;
-            if (neigh) { y = py + r - 1; y += (y < 0) ? Fh : 0; y -= (y >= Fh) ? Fh : 0; ok = r < 3; }
-            y = min(y, Fh - 1);
-            const size_t o = vb + (size_t)kp * Fh + y;
-            pk[u] = V0[o];
-            qk[u] = wq ? V1[o] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!ok) { pk[u] = make_float4(0.f, 0.f, 0.f, 0.f); qk[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = tb + u * nt + tid;
-            if (t < nitems) {
-                const int r = t & (TRI - 1), kp = t >> lTRI;
-                f2* row = G + r * pitch;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int kx = 2 * kp + c;
-                    const f2 P = c ? (f2){pk[u].z, pk[u].w} : (f2){pk[u].x, pk[u].y};
-                    const f2 Q = c ? (f2){qk[u].z, qk[u].w} : (f2){qk[u].x, qk[u].y};
-                    if (kx < Sw) {
-                        // W = P + i Q on the half spectrum, Hermitian extension conj(P) + i conj(Q) on the mirror half
-                        const bool self = (kx == 0) || (2 * kx == FW);
-                        row[posW[kx]] = self ? (f2){P.x, Q.x} : pk_add_pi(P, Q);
-                        if (kx >= 1 && kx < FW - kx) row[posW[FW - kx]] = (f2){P.x + Q.y, Q.x - P.y};
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    p2_fft<FW, true>(G, TRI, pitch, tw);
-    if (neigh) {
-        if (tid < 9) {
-            int x = px + (tid % 3 - 1); x += (x < 0) ? FW : 0; x -= (x >= FW) ? FW : 0;
-            ct9[(size_t)n * 9 + tid] = G[(tid / 3) * pitch + fft_padx(x)].x;
-        }
-        return;
-    }
-    float v = -INFINITY; int iv = 0x7fffffff; float mm = 0.f;
-    double s = 0.0, ss = 0.0;
-    for (int r = 0; r < TRI; ++r) {
-        const int y = y0 + r;
-        if (y >= Fh) break;
-        for (int x = tid; x < FW; x += nt) {
-            const f2 c = G[r * pitch + fft_padx(x)];
-            if (c.x > v) { v = c.x; iv = y * FW + x; }
-            mm = fmaxf(mm, fabsf(c.y));
-            if (g.want_std) { s += (double)c.x; ss += (double)c.x * (double)c.x; }
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const float v2 = __shfl_down(v, off);
-        const int i2 = __shfl_down(iv, off);
-        peak_merge(v, iv, v2, i2);
-        mm = fmaxf(mm, __shfl_down(mm, off));
-        if (g.want_std) { s += __shfl_down(s, off); ss += __shfl_down(ss, off); }
-    }
-    const int wave = tid >> 6, lane = tid & 63;
-    if (lane == 0) { sv[wave] = v; si[wave] = iv; sm[wave] = mm; ssum[wave] = s; ssq[wave] = ss; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < (int)(nt >> 6); ++w) {
-            peak_merge(v, iv, sv[w], si[w]);
-            mm = fmaxf(mm, sm[w]);
-            s += ssum[w]; ss += ssq[w];
-        }
-        PeakPartial p; p.vmax = v; p.imax = iv; p.mmax = mm; p.pad_ = 0; p.sum = s; p.sumsq = ss;
-        part[(size_t)n * gridDim.x + blockIdx.x] = p;
-    }
-}
-
-template <int F> struct P2Launch {
-    static void rows(hipStream_t st, dim3 grid, size_t lds, const StreamGeom& g, const P2Geom& q, float2* T0, float2* T1) {
-        hipFuncSetAttribute((const void*)ncc_rows_p2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ncc_rows_p2<F>, grid, dim3(kStreamThreads), lds, st, g, q, (float4*)T0, (float4*)T1);
-    }
-    static void cols(hipStream_t st, dim3 grid, size_t lds, const StreamGeom& g, const P2Geom& q, const float2* T0, const float2* T1, float2* V0, float2* V1) {
-        hipFuncSetAttribute((const void*)ncc_cols_p2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ncc_cols_p2<F>, grid, dim3(kStreamThreads), lds, st, g, q, (const float4*)T0, (const float4*)T1, (float4*)V0, (float4*)V1);
-    }
-    static void inv(hipStream_t st, dim3 grid, size_t lds, const StreamGeom& g, const P2Geom& q, const float2* V0, const float2* V1, PeakPartial* part,
-                    const PeakPartial* part_in, int nparts, float* ct9) {
-        hipFuncSetAttribute((const void*)ncc_inv_p2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ncc_inv_p2<F>, grid, dim3(kStreamThreads), lds, st, g, q, (const float4*)V0, (const float4*)V1, part, part_in, nparts, ct9);
-    }
-};
-
-#define FB_P2_SWITCH(F, CALL)                                                                                   \
-    switch (F) {                                                                                                \
-        case 64: P2Launch<64>::CALL; break;                                                                     \
-        case 128: P2Launch<128>::CALL; break;                                                                   \
-        case 256: P2Launch<256>::CALL; break;                                                                   \
-        case 512: P2Launch<512>::CALL; break;                                                                   \
-        case 1024: P2Launch<1024>::CALL; break;                                                                 \
-        case 2048: P2Launch<2048>::CALL; break;                                                                 \
-        default: P2Launch<4096>::CALL; break;                                                                   \
-    }
-
-bool p2_shape(int F) { return F >= 64 && F <= 4096 && (F & (F - 1)) == 0; }
+#include "fb_ncc_p2.inc"
 
 std::map<std::pair<int, int>, std::pair<float2*, float2*>> g_split_tables;
 
@@ -1033,38 +732,49 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     const double nq = g.want_q ? 2.0 : 1.0;
     P2Geom q;
     size_t lds_rows2 = 0, lds_cols2 = 0, lds_inv2 = 0, lds_n2 = 0;
+    // grid: one workgroup per item by default (measured fastest: the hardware dispatcher overlaps one workgroup's loads
+    // with its CU neighbour's FFT); FB_P2_SLOTS=k runs k persistent workgroups per CU with register prefetch instead
+    const int slots_per_cu = getenv("FB_P2_SLOTS") ? atoi(getenv("FB_P2_SLOTS")) : 0;
+    const int wg_slots = slots_per_cu > 0 ? slots_per_cu * ctx->prop.multiProcessorCount : (1 << 30);
     if (p2) {
         rc = get_tw16_table(ctx, Fw, &q.twW);
         if (rc) return rc;
         rc = get_tw16_table(ctx, Fh, &q.twH);
         if (rc) return rc;
-        q.lTR = 0;
-        while ((1 << q.lTR) < g.TR) ++q.lTR;
         const size_t pw = (size_t)(Fw + Fw / 16 + 1), ph = (size_t)(Fh + Fh / 16 + 1);
-        lds_rows2 = ((size_t)g.TR * pw + Fw / 16) * sizeof(float2) + (size_t)Fw * sizeof(short);
+        lds_rows2 = ((size_t)g.TR * pw + Fw / 16) * sizeof(float2);
         lds_cols2 = (4 * ph + Fh / 16) * sizeof(float2);
-        lds_inv2 = ((size_t)g.TRI * pw + Fw / 16) * sizeof(float2) + (size_t)Fw * sizeof(short);
-        lds_n2 = ((size_t)4 * pw + Fw / 16) * sizeof(float2) + (size_t)Fw * sizeof(short);
+        lds_inv2 = ((size_t)g.TRI * pw + Fw / 16) * sizeof(float2);
+        lds_n2 = ((size_t)4 * pw + Fw / 16) * sizeof(float2);
+        q.lTRI = 0;
+        while ((1 << q.lTRI) < g.TRI) ++q.lTRI;
+        q.ntiles_inv = ntiles;
     }
     {
         FB_PROF_B(ctx, "ncc_stream_rows", nb * (in_bytes + 16.0 * g.Sw * g.Hs));
-        if (p2) { FB_P2_SWITCH(Fw, rows(ctx->stream, dim3(g.Hs / g.TR, nb), lds_rows2, g, q, T0, T1)); }
-        else hipLaunchKernelGGL(ncc_stream_rows, dim3(g.Hs / g.TR, nb), dim3(kStreamThreads), lds_rows, ctx->stream, g, T0, T1);
+        if (p2) {
+            q.tiles = g.Hs / g.TR; q.total = q.tiles * nb;
+            FB_P2_SWITCH(Fw, rows(ctx->stream, std::min(q.total, wg_slots), lds_rows2, g, q, T0, T1));
+        } else hipLaunchKernelGGL(ncc_stream_rows, dim3(g.Hs / g.TR, nb), dim3(kStreamThreads), lds_rows, ctx->stream, g, T0, T1);
     }
     {
         FB_PROF_B(ctx, "ncc_stream_cols", (double)nb * g.Sw * (16.0 * g.Hs + 8.0 * nq * Fh));
-        if (p2) { FB_P2_SWITCH(Fh, cols(ctx->stream, dim3(g.Kp, nb), lds_cols2, g, q, T0, T1, V0, V1)); }
-        else hipLaunchKernelGGL(ncc_stream_cols, dim3(g.Kp, nb), dim3(kStreamThreads), lds_cols, ctx->stream, g, T0, T1, V0, V1);
+        if (p2) {
+            q.tiles = g.Kp; q.total = g.Kp * nb;
+            FB_P2_SWITCH(Fh, cols(ctx->stream, std::min(q.total, wg_slots), lds_cols2, g, q, T0, T1, V0, V1));
+        } else hipLaunchKernelGGL(ncc_stream_cols, dim3(g.Kp, nb), dim3(kStreamThreads), lds_cols, ctx->stream, g, T0, T1, V0, V1);
     }
     {
         FB_PROF_B(ctx, "ncc_stream_inv", (double)nb * g.Sw * 8.0 * nq * Fh);
-        if (p2) { FB_P2_SWITCH(Fw, inv(ctx->stream, dim3(ntiles, nb), lds_inv2, g, q, V0, V1, part, nullptr, 0, nullptr)); }
-        else hipLaunchKernelGGL(ncc_stream_inv, dim3(ntiles, nb), dim3(kStreamThreads), lds_inv, ctx->stream, g, V0, V1, part, nullptr, 0, nullptr);
+        if (p2) {
+            q.tiles = ntiles; q.total = ntiles * nb;
+            FB_P2_SWITCH(Fw, inv(ctx->stream, std::min(q.total, wg_slots), lds_inv2, g, q, V0, V1, part));
+        } else hipLaunchKernelGGL(ncc_stream_inv, dim3(ntiles, nb), dim3(kStreamThreads), lds_inv, ctx->stream, g, V0, V1, part, nullptr, 0, nullptr);
     }
     if (subpixel) {
         FB_PROF(ctx, "ncc_stream_neighbors");
         const size_t lds_n = ((size_t)4 * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
-        if (p2) { FB_P2_SWITCH(Fw, inv(ctx->stream, dim3(1, nb), std::max(lds_n2, lds_inv2), g, q, V0, V1, nullptr, part, ntiles, ct9)); }
+        if (p2) { FB_P2_SWITCH(Fw, neigh(ctx->stream, nb, lds_n2, g, q, V0, V1, part, ntiles, ct9)); }
         else hipLaunchKernelGGL(ncc_stream_inv, dim3(1, nb), dim3(kStreamThreads), lds_n, ctx->stream, g, V0, V1, nullptr, part, ntiles, ct9);
     }
     {

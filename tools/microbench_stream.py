@@ -12,7 +12,7 @@ dx = _lib.DeviceBuffer(N * 8); dy = _lib.DeviceBuffer(N * 8); cf = _lib.DeviceBu
 for r in range(2):
     _lib.check(lib.fb_ncc_batch_dev(ctx, d0.ptr, d1.ptr, N, 1, h, w, h, w, 1, 0, 2, dx.ptr, dy.ptr, cf.ptr))
 _lib.check(lib.fb_sync(ctx)); _lib.check(lib.fb_prof_reset(ctx)); _lib.check(lib.fb_prof_enable(ctx, 1))
-for r in range(5):
+for r in range(int(os.environ.get('REPS', 5))):
     _lib.check(lib.fb_ncc_batch_dev(ctx, d0.ptr, d1.ptr, N, 1, h, w, h, w, 1, 0, 2, dx.ptr, dy.ptr, cf.ptr))
 _lib.check(lib.fb_sync(ctx)); _lib.check(lib.fb_prof_enable(ctx, 0))
 for k, (n, ms, b) in _lib.prof_snapshot().items():
