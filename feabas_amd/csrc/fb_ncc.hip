@@ -787,6 +787,23 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     return FB_OK;
 }
 
+// A zero-padded (linear) correlation does not depend on the padded length: every lag keeps its value, and the
+// peak / sub-pixel / MIRROR-confidence arithmetic only ever looks at lags.  When the reference's 5-smooth
+// next_fast_len(s0 + s1 - 1) sits just below a power of two (1000, 972, 960 -> 1024), the power of two runs on
+// the packed compile-time FFT core instead of the generic mixed-radix one.  Never applied to circular
+// (pad=False) axes or to FFT_CONF_STD, whose result depends on the surface size.
+void promote_linear_shape(int& Fh, int& Fw, int need_h, int need_w, int conf_mode) {
+    if (conf_mode == FB_CONF_STD || getenv("FEABAS_HIP_FFT_EXACT")) return;
+    auto up = [](int F, int need) {
+        if (F < need) return F;
+        int P = 64;
+        while (P < F) P <<= 1;
+        return (P <= 4096 && 5 * P <= 6 * F) ? P : F;
+    };
+    const int ph = up(Fh, need_h), pw = up(Fw, need_w);
+    if (p2_shape(ph) && p2_shape(pw)) { Fh = ph; Fw = pw; }
+}
+
 size_t custom_bytes_per_pair(int Fh, int Fw, int hmax) {
     const size_t Sw = (size_t)(Fw / 2 + 2) / 2 * 2;      // column pairs
     return 2 * Sw * (size_t)(std::min(Fh, hmax) + 16) * 8 + 2 * Sw * (size_t)Fh * 8 + 4096;
@@ -818,13 +835,16 @@ int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, i
     if (N == 0) return FB_OK;
     FB_CHECK_ARG(ctx, img0 && img1 && dx && dy && conf);
     FB_HIP(ctx, hipSetDevice(ctx->device));
-    const int Fh = pad ? fb_next_fast_len(H0 + H1 - 1) : fb_next_fast_len(std::max(H0, H1));
-    const int Fw = pad ? fb_next_fast_len(W0 + W1 - 1) : fb_next_fast_len(std::max(W0, W1));
+    const int Fh_ref = pad ? fb_next_fast_len(H0 + H1 - 1) : fb_next_fast_len(std::max(H0, H1));
+    const int Fw_ref = pad ? fb_next_fast_len(W0 + W1 - 1) : fb_next_fast_len(std::max(W0, W1));
+    const int Fh = Fh_ref, Fw = Fw_ref;
     FB_CHECK_ARG(ctx, (long long)Fh * Fw < (1LL << 31));
     if (C == 1 && fb_ncc_small_supported(Fh, Fw, H0, W0, H1, W1, C))
         return fb_ncc_small_launch(ctx, img0, img1, N, H0, W0, H1, W1, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
     if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, C)) {
         const int hmax = std::max(H0, H1);
+        int Fh = Fh_ref, Fw = Fw_ref;
+        promote_linear_shape(Fh, Fw, H0 + H1 - 1, W0 + W1 - 1, conf_mode);
         const int nb_max = (int)std::max<size_t>(1, ctx->ncc_arena_limit / custom_bytes_per_pair(Fh, Fw, hmax));
         for (int n0 = 0; n0 < N; n0 += nb_max) {
             const int nb = std::min(nb_max, N - n0);
@@ -893,6 +913,7 @@ int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int I
     if (fb_ncc_small_supported(Fh, Fw, 0, 0, 0, 0, 1))
         return fb_ncc_small_launch_ex(ctx, imgs0, imgs1, N, hmax, wmax, hmax, wmax, blk, IH0, IW0, IH1, IW1, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
     if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, 1)) {
+        promote_linear_shape(Fh, Fw, 2 * hmax - 1, 2 * wmax - 1, conf_mode);
         const int nbm = (int)std::max<size_t>(1, ctx->ncc_arena_limit / custom_bytes_per_pair(Fh, Fw, hmax));
         CropSrc cs{blk, IH0, IW0, IH1, IW1};
         for (int n0 = 0; n0 < N; n0 += nbm) {

@@ -90,6 +90,27 @@ def test_xcorr_streaming_class(fb):
     _check(fb.matcher.xcorr_fft(j0, j1, pad=True, subpixel=True), ncc_ref.xcorr_fft(j0, j1, pad=True, subpixel=True))
 
 
+@pytest.mark.parametrize('shape', [(250, 247), (500, 245), (486, 120)])
+def test_xcorr_linear_shapes_promoted_to_pow2(fb, shape):
+    """padded (linear) correlations whose 5-smooth FFT size sits just below a power of two run at the power of two on
+    the device (500 -> 512, 1000 -> 1024, 972 -> 1024): same lags, same peak, same confidences as the reference size"""
+    import os
+    rng = np.random.default_rng(shape[0])
+    i0, i1 = _pairs(rng, 3, shape, shape, maxshift=15)
+    for sub in (True, False):
+        exp = ncc_ref.xcorr_fft(i0, i1, pad=True, subpixel=sub)
+        got = fb.matcher.xcorr_fft(i0, i1, pad=True, subpixel=sub)
+        _check(got, exp)
+        os.environ['FEABAS_HIP_FFT_EXACT'] = '1'          # the reference's own FFT size on the generic mixed-radix core
+        try:
+            ref_size = fb.matcher.xcorr_fft(i0, i1, pad=True, subpixel=sub)
+        finally:
+            del os.environ['FEABAS_HIP_FFT_EXACT']
+        _check(ref_size, exp)
+        np.testing.assert_array_equal(np.round(got[0]), np.round(ref_size[0]))
+        np.testing.assert_allclose(got[2], ref_size[2], atol=2e-5)
+
+
 def test_xcorr_edge_cases(fb):
     z = np.zeros((2, 20, 24), np.float32)
     dx, dy, cf = fb.matcher.xcorr_fft(z, z, pad=True, subpixel=True)

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from feabas_amd import _lib
 lib, ctx = _lib.load(), _lib.ctx()
-N, h, w = 128, 1024, 510
+N, h, w = int(os.environ.get('NB', 128)), int(os.environ.get('BH', 1024)), int(os.environ.get('BW', 510))
 rng = np.random.default_rng(0)
 a = rng.standard_normal((N, h, w)).astype(np.float32)
 d0 = _lib.DeviceBuffer.from_array(a); d1 = _lib.DeviceBuffer.from_array(np.roll(a, (2, -3), (1, 2)))
