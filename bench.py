@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--pairs-per-step', type=int, default=64)
     ap.add_argument('--resident-pairs', type=int, default=1024)
     ap.add_argument('--tile', type=int, default=4096)
-    ap.add_argument('--host-threads', type=int, default=2, help='host threads driving the device (LR and UD batches alternate between them)')
+    ap.add_argument('--host-threads', type=int, default=4, help='host threads driving the device (even; steps are dealt round-robin, LR and UD batches alternate)')
     ap.add_argument('--no-fem', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fem-grid', type=int, default=708)
@@ -177,12 +177,14 @@ def main():
     shapes = {'LR': (T, ov), 'UD': (ov, T)}
     strips = {}
     matchers = {}
+    mper = max(1, args.host_threads // 2)          # matcher instances per orientation: one per host thread
     for k, (H, W) in shapes.items():
         s0 = _lib.DeviceBuffer(n_res * H * W); s1 = _lib.DeviceBuffer(n_res * H * W); sh = _lib.DeviceBuffer(n_res * 8)
         _lib.check(lib.fb_synth_strips_dev(ctx, n_res, rank * 100000 + (0 if k == 'LR' else 50000), H, W, 2026, 20, 1,
                                            s0.ptr, s1.ptr, sh.ptr))
         strips[k] = (s0, s1, sh.to_array((n_res, 2), np.int32))
-        matchers[k] = StripBatchMatcher(P, H, W)
+        for j in range(mper):
+            matchers[(k, j)] = StripBatchMatcher(P, H, W)
     _lib.check(lib.fb_sync(ctx))
 
     def step(i):
@@ -190,7 +192,7 @@ def main():
         H, W = shapes[k]
         s0, s1, _ = strips[k]
         b = (i // 2) % (n_res // P)
-        res = matchers[k].match(s0.offset(b * P * H * W), s1.offset(b * P * H * W))
+        res = matchers[(k, (i // 2) % mper)].match(s0.offset(b * P * H * W), s1.offset(b * P * H * W))
         if dist is not None:
             # the one exchange of the sharded run: every rank's match table, gathered over RCCL (feabas_amd/dist.py)
             from feabas_amd import dist as fdist
@@ -218,7 +220,8 @@ def main():
         def worker(mine):
             for i in mine:
                 results[i] = step(i)
-        ths = [threading.Thread(target=worker, args=([i for i in idx if i % 2 == k],)) for k in range(2)]
+        T = max(2, args.host_threads // 2 * 2)
+        ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k],)) for k in range(T)]
         for t in ths:
             t.start()
         for t in ths:

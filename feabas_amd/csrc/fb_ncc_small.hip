@@ -6,6 +6,7 @@
 // shapes whose working set fits the 160 KiB LDS (e.g. the 75 x 75 fine blocks of the 4k tile pair).
 #include "fb_common.h"
 #include "fb_ldsfft.h"
+#include "fb_fft3.h"
 
 #include <cmath>
 #include <map>
@@ -33,19 +34,44 @@ struct SmallParams {
     float* conf;
 };
 
-size_t small_lds_bytes(int Fh, int Fw) {
+bool small_ct_len(int n) { return n == 64 || n == 72 || n == 75 || n == 80 || n == 81 || n == 90 || n == 96 || n == 100; }
+
+// row pitch (float2 units) of the [Fh][pitch] work array: at least the 2 Sw packed columns; FB_SMALL_PITCH adds
+// padding columns (bank-conflict experiments)
+int small_pitch(int Fw) {
     const int Sw = Fw / 2 + 1;
-    return ((size_t)Fh * (2 * Sw) + Fw + Fh) * sizeof(float2) + 256 + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
+    const int extra = getenv("FB_SMALL_PITCH") ? atoi(getenv("FB_SMALL_PITCH")) : 0;
+    return 2 * Sw + std::max(0, extra);
+}
+
+size_t small_lds_bytes(int Fh, int Fw) {
+    return ((size_t)Fh * small_pitch(Fw) + Fw + Fh) * sizeof(float2) + 256 + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
 }
 
 __device__ __forceinline__ void merge_peak(float& v, int& i, float v2, int i2) {
     if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
 }
 
+// The fine-block lengths that occur around the default spacings (blocks of 64..100 px, matcher.py:243-251) run on
+// the compile-time packed core (fb_fft3.h, plans of fft_make_plan(n, ., 8)); anything else on the generic core.
+#define FB_SMALL_FFT(LEN, INV, COLS, M, TW, ELSE)                                                            \
+    switch (LEN) {                                                                                           \
+        case 64: p3_fft<64, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 72: p3_fft<72, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 75: p3_fft<75, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 80: p3_fft<80, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 81: p3_fft<81, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 90: p3_fft<90, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 96: p3_fft<96, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 100: p3_fft<100, 8, INV, COLS>(Gp, M, RS, TW); break;                                           \
+        default: ELSE; break;                                                                                \
+    }
+
 __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallParams prm) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int Fh = prm.Fh, Fw = prm.Fw, Sw = prm.Sw, RS = prm.RS;
     float2* G = lds;                                   // [Fh][RS]
+    f2* Gp = reinterpret_cast<f2*>(lds);
     float2* twW = lds + (size_t)Fh * RS;               // [Fw]
     float2* twH = twW + Fw;                            // [Fh]
     float* red = reinterpret_cast<float*>(twH + Fh);   // reduction scratch (<= 256 B)
@@ -96,7 +122,7 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
     __syncthreads();
     const int rows_nz = max(h0, h1);
     // ---- forward along x on the non-zero rows
-    fft_batch<false>(G, prm.pw, rows_nz, 1, RS, twW, false);
+    FB_SMALL_FFT(Fw, false, false, rows_nz, reinterpret_cast<const f2*>(twW), fft_batch<false>(G, prm.pw, rows_nz, 1, RS, twW, false));
     // ---- split the packed row spectra: row y -> [A(kx) | B(kx)], kx < Sw (one wave per row; the wave's
     //      LDS queue is in order, so all reads of a row precede its writes)
     for (int y = wave; y < rows_nz; y += nwaves) {
@@ -123,7 +149,7 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
     }
     __syncthreads();
     // ---- forward along y on the 2 Sw columns
-    fft_batch<false>(G, prm.ph, 2 * Sw, RS, 1, twH, true);
+    FB_SMALL_FFT(Fh, false, true, 2 * Sw, reinterpret_cast<const f2*>(twH), fft_batch<false>(G, prm.ph, 2 * Sw, RS, 1, twH, true));
     // ---- spectral products (matcher.py:65, 114): P = conj(F0) F1 over A's slots, Q = F0 F1 over B's
     const bool want_q = prm.conf_mode == FB_CONF_MIRROR;
     for (int y = wave; y < Fh; y += nwaves)
@@ -135,7 +161,7 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
     }
     __syncthreads();
     // ---- inverse along y
-    fft_batch<true>(G, prm.ph, 2 * Sw, RS, 1, twH, true);
+    FB_SMALL_FFT(Fh, true, true, 2 * Sw, reinterpret_cast<const f2*>(twH), fft_batch<true>(G, prm.ph, 2 * Sw, RS, 1, twH, true));
     // ---- Hermitian-extend and pack: W = P + iQ in the digit-reversed order the inverse row pass consumes
     const int nmir = Fw - Sw;                          // kx in [1, nmir] have a mirror Fw - kx >= Sw
     for (int y = wave; y < Fh; y += nwaves) {
@@ -162,7 +188,7 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
     }
     __syncthreads();
     // ---- inverse along x: row y now holds (C[y][x], Cm[y][x]) x < Fw, un-normalised
-    fft_batch<true>(G, prm.pw, Fh, 1, RS, twW, false);
+    FB_SMALL_FFT(Fw, true, false, Fh, reinterpret_cast<const f2*>(twW), fft_batch<true>(G, prm.pw, Fh, 1, RS, twW, false));
     // ---- reductions (matcher.py:82, 124-125, 130-131)
     float v = -INFINITY; int iv = 0x7fffffff; float mm = 0.f;
     double s = 0.0, ss = 0.0;
@@ -277,10 +303,13 @@ int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, in
                            int IH0, int IW0, int IH1, int IW1, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy,
                            float* conf) {
     SmallParams p;
-    p.N = N; p.Fh = Fh; p.Fw = Fw; p.Sw = Fw / 2 + 1; p.RS = 2 * p.Sw;
+    p.N = N; p.Fh = Fh; p.Fw = Fw; p.Sw = Fw / 2 + 1; p.RS = small_pitch(Fw);
     p.H0 = H0; p.W0 = W0; p.H1 = H1; p.W1 = W1;
     p.subpixel = subpixel; p.conf_mode = conf_mode;
-    if (!fft_make_plan(Fw, &p.pw, 5) || !fft_make_plan(Fh, &p.ph, 5)) return fb_fail(ctx, FB_ERR_ARG, "ncc_small: %dx%d is not 5-smooth", Fh, Fw);
+    // positions (posW) must follow the plan the FFT of that length actually runs: radix <= 8 on the compile-time
+    // core, radix <= 5 on the generic one
+    if (!fft_make_plan(Fw, &p.pw, small_ct_len(Fw) ? 8 : 5) || !fft_make_plan(Fh, &p.ph, small_ct_len(Fh) ? 8 : 5))
+        return fb_fail(ctx, FB_ERR_ARG, "ncc_small: %dx%d is not 5-smooth", Fh, Fw);
     int rc = get_table(ctx, Fw, &p.tw_w);
     if (rc) return rc;
     rc = get_table(ctx, Fh, &p.tw_h);
