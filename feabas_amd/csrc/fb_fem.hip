@@ -51,6 +51,8 @@ struct fb_system {
     double* d_parts = nullptr;       // reduction scratch
     double* d_glambda = nullptr;     // per-group stiffness lambda
     int glambda_cap = 0;
+    void* d_gstat = nullptr;         // per-group solve statistics (relres f64, iters i32, flag i32)
+    int gstat_cap = 0;
     fb_bsr* M = nullptr;             // A + PCG workspace, shares the pattern
 };
 
@@ -439,7 +441,7 @@ void fb_sys_destroy(fb_ctx* ctx, fb_system* s) {
         hipFree(m.d_model); hipFree(m.d_nu); hipFree(m.d_matmult);
     }
     hipFree(s->d_nodes); hipFree(s->d_vmptr); hipFree(s->d_vmidx); hipFree(s->d_bary); hipFree(s->d_w); hipFree(s->d_rxy);
-    hipFree(s->d_glambda); hipFree(s->d_K); hipFree(s->d_Cacc); hipFree(s->d_C); hipFree(s->d_rhs); hipFree(s->d_stress); hipFree(s->d_parts);
+    hipFree(s->d_glambda); hipFree(s->d_gstat); hipFree(s->d_K); hipFree(s->d_Cacc); hipFree(s->d_C); hipFree(s->d_rhs); hipFree(s->d_stress); hipFree(s->d_parts);
     if (s->M) fb_bsr_free(ctx, s->M);
     delete s;
 }
@@ -713,6 +715,42 @@ int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, 
     FB_HIP(ctx, hipMemcpyAsync(x, s->M->x, sizeof(double2) * (size_t)s->nv, hipMemcpyDeviceToHost, ctx->stream));
     FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return rc;
+}
+
+// Batched in-matcher relaxations: the system is block diagonal with `ngroups` equal vertex ranges (fb_sys_form_groups);
+// every range is solved to its own tolerance by one workgroup (fb_bsr_pcg_groups).  x: host [2 nv].
+// iters_max / relres_max: worst range.  Returns FB_ERR_NOCONV when a range stopped above its tolerance.
+int fb_sys_solve_groups(fb_ctx* ctx, fb_system* s, int ngroups, double* x, double rtol, double atol, int maxiter, int precond, int* iters_max,
+                        double* relres_max) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && x && ngroups > 0 && s->nv % ngroups == 0);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    if (s->gstat_cap < ngroups) {
+        hipFree(s->d_gstat);
+        FB_HIP(ctx, hipMalloc((void**)&s->d_gstat, 16 * (size_t)ngroups));
+        s->gstat_cap = ngroups;
+    }
+    double* d_rel = reinterpret_cast<double*>(s->d_gstat);
+    int* d_it = reinterpret_cast<int*>(d_rel + ngroups);
+    int* d_fl = d_it + ngroups;
+    int rc = fb_bsr_pcg_groups(ctx, s->M, ngroups, rtol, atol, maxiter, precond, d_it, d_rel, d_fl);
+    if (rc) return rc;
+    std::vector<char> hs(16 * (size_t)ngroups);
+    FB_HIP(ctx, hipMemcpyAsync(x, s->M->x, sizeof(double2) * (size_t)s->nv, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipMemcpyAsync(hs.data(), s->d_gstat, hs.size(), hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double* hr = reinterpret_cast<const double*>(hs.data());
+    const int* hi = reinterpret_cast<const int*>(hr + ngroups);
+    const int* hf = hi + ngroups;
+    int mi = 0, bad = 0; double mr = 0.0;
+    for (int g = 0; g < ngroups; ++g) {
+        mi = std::max(mi, hi[g]); mr = std::max(mr, hr[g]);
+        if (hf[g] == 2) return fb_fail(ctx, FB_ERR_BREAKDOWN, "fb_sys_solve_groups: negative curvature in range %d", g);
+        if (hf[g] == 0 && hi[g] > 0) bad = 1;          // iteration cap reached
+    }
+    if (iters_max) *iters_max = mi;
+    if (relres_max) *relres_max = mr;
+    return bad ? FB_ERR_NOCONV : FB_OK;
 }
 
 int fb_sys_solve_fixed(fb_ctx* ctx, fb_system* s, int iters, double* relres) {

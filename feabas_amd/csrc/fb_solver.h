@@ -40,3 +40,7 @@ int fb_bsr_setup_jacobi(fb_ctx* ctx, fb_bsr* M, int precond);
 int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter, int fixed_iters, int* iters_out, double* relres_out);
 int fb_csr_to_bsr_host(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* idx, const double* val, int symmetrize,
                        int* nb_out, std::vector<int>& browptr, std::vector<int>& bcol, std::vector<double>& bval);
+
+// one workgroup per equal vertex range of a block-diagonal system: whole Jacobi-PCG in LDS (results in M->x)
+int fb_bsr_pcg_groups(fb_ctx* ctx, fb_bsr* M, int ngroups, double rtol, double atol, int maxiter, int precond, int* iters_dev, double* relres_dev,
+                      int* flags_dev);

@@ -232,6 +232,167 @@ __global__ void jacobi_kernel(int nb, const double2* __restrict__ diag, double2*
     }
 }
 
+// ---------------------------------------------------------------------------------- batched small solves
+// Block-diagonal systems (one independent spring-linked mesh pair per equal vertex range, e.g. the in-matcher
+// relaxations of matcher.py:717-742): ONE workgroup runs the whole Jacobi-PCG of one range with its vectors in
+// LDS -- no launch per iteration, no host polling, and every range stops on its own residual like the
+// reference's per-pair SLM does.  Reductions follow a fixed tree, so results are reproducible.
+constexpr int kGT = 512;
+
+__device__ __forceinline__ double group_sum(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();                       // sh may still be read from the previous reduction
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double s = sh[0];
+    for (int w = 1; w < kGT / 64; ++w) s += sh[w];
+    return s;
+}
+__device__ __forceinline__ double group_max(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double s = sh[0];
+    for (int w = 1; w < kGT / 64; ++w) s = fmax(s, sh[w]);
+    return s;
+}
+
+// y_i = sum_j A_ij v_j for the rows of this group; columns are group-local (block-diagonal system)
+__device__ __forceinline__ double2 group_row_spmv(const fb_bsr_dev& A, int row, int base, const double2* v) {
+    double2 acc = make_double2(0.0, 0.0);
+    for (int j = A.rowptr[row]; j < A.rowptr[row + 1]; ++j) {
+        const double4 a = reinterpret_cast<const double4*>(A.val)[j];
+        const double2 u = v[A.col[j] - base];
+        acc.x += a.x * u.x + a.y * u.y;
+        acc.y += a.z * u.x + a.w * u.y;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(kGT) void pcg_groups_kernel(fb_bsr_dev A, const double2* __restrict__ b, double2* __restrict__ x, int gs, double rtol,
+                                                         double atol, int maxiter, int precond, int* __restrict__ iters,
+                                                         double* __restrict__ relres, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) double2 gl[];
+    double2* xs = gl; double2* r = gl + gs; double2* z = gl + 2 * gs; double2* pv = gl + 3 * gs; double2* mi = gl + 4 * gs;
+    __shared__ double sh[kGT / 64];
+    const int g = blockIdx.x, base = g * gs, tid = threadIdx.x;
+    // Jacobi preconditioner of this range (optimizer.py:1958-1966): 1 / clip(diag, min(1, max / 1000))
+    double dmax = -INFINITY;
+    for (int i = tid; i < gs; i += kGT) {
+        const int row = base + i;
+        double2 d = make_double2(0.0, 0.0);
+        for (int j = A.rowptr[row]; j < A.rowptr[row + 1]; ++j)
+            if (A.col[j] == row) { const double4 a = reinterpret_cast<const double4*>(A.val)[j]; d.x += a.x; d.y += a.w; }
+        mi[i] = d;
+        dmax = fmax(dmax, fmax(d.x, d.y));
+    }
+    dmax = group_max(dmax, sh);
+    const bool identity = precond == 0 || !(dmax > 0.0);
+    const double floor_ = fmin(1.0, dmax / 1000.0);
+    const double curv_eps = 1e-9 * fmax(dmax, 0.0);
+    double bb = 0.0;
+    for (int i = tid; i < gs; i += kGT) {
+        const double2 d = mi[i];
+        mi[i] = identity ? make_double2(1.0, 1.0) : make_double2(1.0 / fmax(d.x, floor_), 1.0 / fmax(d.y, floor_));
+        const double2 bi = b[base + i];
+        xs[i] = make_double2(0.0, 0.0);
+        r[i] = bi;
+        bb += bi.x * bi.x + bi.y * bi.y;
+    }
+    bb = group_sum(bb, sh);
+    int it = 0, flag = 0;
+    double rr = bb;
+    if (bb > 0.0 && maxiter != 0) {
+        const double bnorm = sqrt(bb);
+        double tol = rtol;
+        if (atol > 0.0) tol = fmax(tol, atol / bnorm);
+        const double tol2 = tol * tol * bb;
+        const int limit = maxiter > 0 ? maxiter : 100000;
+        double rz = 0.0;
+        for (int i = tid; i < gs; i += kGT) {
+            const double2 ri = r[i], m = mi[i];
+            const double2 zi = make_double2(m.x * ri.x, m.y * ri.y);
+            z[i] = zi; pv[i] = zi;
+            rz += ri.x * zi.x + ri.y * zi.y;
+        }
+        rz = group_sum(rz, sh);                        // (barriers inside: pv is complete)
+        while (it < limit) {
+            double pAp = 0.0, pp = 0.0;
+            // rows of a thread stay with it through the iteration: Ap is kept in z (z is dead until it is recomputed)
+            for (int i = tid; i < gs; i += kGT) {
+                const double2 ap = group_row_spmv(A, base + i, base, pv);
+                const double2 pi = pv[i];
+                z[i] = ap;
+                pAp += pi.x * ap.x + pi.y * ap.y;
+                pp += pi.x * pi.x + pi.y * pi.y;
+            }
+            pAp = group_sum(pAp, sh);
+            pp = group_sum(pp, sh);
+            if (!(pAp > curv_eps * pp)) { flag = (pAp < -curv_eps * pp) ? 2 : 3; break; }     // breakdown / semi-definite stagnation
+            const double alpha = rz / pAp;
+            double rr_new = 0.0, rz_new = 0.0;
+            for (int i = tid; i < gs; i += kGT) {
+                const double2 pi = pv[i], ap = z[i], m = mi[i];
+                double2 xi = xs[i], ri = r[i];
+                xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+                ri.x -= alpha * ap.x; ri.y -= alpha * ap.y;
+                xs[i] = xi; r[i] = ri;
+                const double2 zi = make_double2(m.x * ri.x, m.y * ri.y);
+                z[i] = zi;
+                rr_new += ri.x * ri.x + ri.y * ri.y;
+                rz_new += ri.x * zi.x + ri.y * zi.y;
+            }
+            rr = group_sum(rr_new, sh);
+            rz_new = group_sum(rz_new, sh);
+            ++it;
+            if (rr <= tol2) { flag = 1; break; }
+            const double beta = rz_new / rz;
+            rz = rz_new;
+            for (int i = tid; i < gs; i += kGT) {
+                const double2 zi = z[i], pi = pv[i];
+                pv[i] = make_double2(zi.x + beta * pi.x, zi.y + beta * pi.y);
+            }
+            __syncthreads();
+        }
+        // true residual of the returned iterate
+        __syncthreads();
+        double rt = 0.0;
+        for (int i = tid; i < gs; i += kGT) {
+            const double2 ax = group_row_spmv(A, base + i, base, xs);
+            const double2 bi = b[base + i];
+            const double dx = bi.x - ax.x, dy = bi.y - ax.y;
+            rt += dx * dx + dy * dy;
+        }
+        rr = group_sum(rt, sh);
+    }
+    for (int i = tid; i < gs; i += kGT) x[base + i] = xs[i];
+    if (tid == 0) {
+        iters[g] = it;
+        relres[g] = bb > 0.0 ? sqrt(rr / bb) : 0.0;
+        flags[g] = flag;
+    }
+}
+
+}  // namespace
+
+int fb_bsr_pcg_groups(fb_ctx* ctx, fb_bsr* M, int ngroups, double rtol, double atol, int maxiter, int precond, int* iters_dev, double* relres_dev,
+                      int* flags_dev) {
+    const int gs = M->d.nb / ngroups;
+    const size_t lds = sizeof(double2) * 5 * (size_t)gs;
+    if (M->d.nb % ngroups != 0 || lds > 150 * 1024) return fb_fail(ctx, FB_ERR_ARG, "fb_bsr_pcg_groups: %d vertices per group do not fit the LDS", gs);
+    FB_HIP(ctx, hipFuncSetAttribute((const void*)pcg_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FB_PROF(ctx, "pcg_groups");
+    hipLaunchKernelGGL(pcg_groups_kernel, dim3(ngroups), dim3(kGT), lds, ctx->stream, M->d, M->b, M->x, gs, rtol, atol, maxiter, precond, iters_dev,
+                       relres_dev, flags_dev);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+namespace {
+
 int grid1(const fb_bsr_dev& A) { return std::max(1, std::min(kMaxWG1, (A.nb + kT - 1) / kT)); }
 
 }  // namespace

@@ -79,9 +79,7 @@ class StripBatchMatcher:
         self.d_dogf = _lib.DeviceBuffer(2 * n * H * W * 4)
         self.max_blocks = n * 1024
         self.d_blk = _lib.DeviceBuffer(self.max_blocks * 9 * 4)
-        self.d_dx = _lib.DeviceBuffer(self.max_blocks * 8)
-        self.d_dy = _lib.DeviceBuffer(self.max_blocks * 8)
-        self.d_cf = _lib.DeviceBuffer(self.max_blocks * 4)
+        self.d_out = _lib.DeviceBuffer(self.max_blocks * 20)       # per launch: [dx f64 N][dy f64 N][conf f32 N], one D2H copy
         self.residue_len = float(residue_len)                 # matcher.py:236 (fine_downsample = 1)
         self.stiffness_lambda = float(stiffness_lambda)       # matcher.py:507
         self.relax_tol = float(relax_tol)
@@ -92,7 +90,7 @@ class StripBatchMatcher:
         if self._relax_sys is not None:
             _lib.load().fb_sys_destroy(_lib.ctx(), self._relax_sys)
             self._relax_sys = None
-        for b in (self.d_small, self.d_dogc, self.d_dogf, self.d_blk, self.d_dx, self.d_dy, self.d_cf):
+        for b in (self.d_small, self.d_dogc, self.d_dogf, self.d_blk, self.d_out):
             if b is not None:
                 b.free()
 
@@ -108,11 +106,13 @@ class StripBatchMatcher:
             _lib.check(lib.fb_dog_dev(ctx, strips0, 0, n, hc, wc, self.sigma, None, 1, self.d_dogc.ptr))
             _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, hc, wc, self.sigma, None, 1, self.d_dogc.offset(n * hc * wc * 4)))
         _lib.check(lib.fb_ncc_batch_dev(ctx, self.d_dogc.ptr, self.d_dogc.offset(n * hc * wc * 4), n, 1, hc, wc, hc, wc,
-                                        1, 0, self.conf_mode, self.d_dx.ptr, self.d_dy.ptr, self.d_cf.ptr))
-        tx = self.d_dx.to_array((n,), np.float64)
-        ty = self.d_dy.to_array((n,), np.float64)
-        cf = self.d_cf.to_array((n,), np.float32)
-        return tx, ty, cf            # equal strip sizes: (W1-W0)/2 = 0 (matcher.py:155-156)
+                                        1, 0, self.conf_mode, self.d_out.ptr, self.d_out.offset(8 * n), self.d_out.offset(16 * n)))
+        return self._fetch_out(n)    # equal strip sizes: (W1-W0)/2 = 0 (matcher.py:155-156)
+
+    def _fetch_out(self, nb):
+        """(dx, dy, conf) of the last launch that wrote nb results into d_out"""
+        raw = self.d_out.to_array((20 * nb,), np.uint8)
+        return raw[:8 * nb].view(np.float64), raw[8 * nb:16 * nb].view(np.float64), raw[16 * nb:].view(np.float32)
 
     def _fine_dog(self, strips0, strips1):
         lib, ctx = _lib.load(), _lib.ctx()
@@ -182,10 +182,8 @@ class StripBatchMatcher:
             flat = np.ascontiguousarray(blk.reshape(-1, 9))
             _lib.check(lib.fb_memcpy_h2d(ctx, self.d_blk.ptr, _lib.ptr(flat), flat.nbytes))
             _lib.check(lib.fb_ncc_blocks_dev(ctx, dogf.ptr, img1, H, W, H, W, nb, self.d_blk.ptr, int(dy[sel].max()), int(dx[sel].max()), gfh, gfw,
-                                             1 if subpixel else 0, self.conf_mode, self.d_dx.ptr, self.d_dy.ptr, self.d_cf.ptr))
-            ddx = self.d_dx.to_array((nb,), np.float64).reshape(sel.size, -1)
-            ddy = self.d_dy.to_array((nb,), np.float64).reshape(sel.size, -1)
-            dcf = self.d_cf.to_array((nb,), np.float32).reshape(sel.size, -1)
+                                             1 if subpixel else 0, self.conf_mode, self.d_out.ptr, self.d_out.offset(8 * nb), self.d_out.offset(16 * nb)))
+            ddx, ddy, dcf = (a.reshape(sel.size, -1) for a in self._fetch_out(nb))
             groups.append((sel, bb, ddx, ddy, dcf))
         return groups
 
@@ -248,7 +246,7 @@ class StripBatchMatcher:
         _lib.check(lib.fb_sys_form_groups(ctx, sysh, self.P, self.stiffness_lambda, -1.0, None))
         x = np.zeros(2 * self.P * V, dtype=np.float64)
         iters, relres = C.c_int(), C.c_double()
-        _lib.check(lib.fb_sys_solve(ctx, sysh, _lib.ptr(x), 0, self.relax_tol, 0.0, 20 * V, 1, C.byref(iters), C.byref(relres)),
+        _lib.check(lib.fb_sys_solve_groups(ctx, sysh, self.P, _lib.ptr(x), self.relax_tol, 0.0, 20 * V, 1, C.byref(iters), C.byref(relres)),
                    allow=(_lib.FB_ERR_NOCONV,))
         self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K))
         x = x.reshape(-1, 2)

@@ -178,6 +178,11 @@ int fb_sys_update_links(fb_ctx* ctx, fb_system* sys, int64_t K, const int32_t* n
  * tile pair each, matcher.py:551): relative_lambda_trace per range, then A and b as in fb_sys_form. */
 int fb_sys_form_groups(fb_ctx* ctx, fb_system* sys, int ngroups, double stiffness_lambda, double crosslink_lambda,
                        double* ls_out);
+/* Solve every range of a block-diagonal batch (after fb_sys_form_groups) with its own Jacobi-PCG, one workgroup
+ * per range, to ||A x - b|| <= max(rtol, atol/||b||) ||b|| of THAT range -- the in-matcher relaxations of
+ * matcher.py:717-742 for a whole batch of tile pairs in one launch.  x: host [2 nv]; iters_max / relres_max: worst range. */
+int fb_sys_solve_groups(fb_ctx* ctx, fb_system* sys, int ngroups, double* x, double rtol, double atol, int maxiter, int precond,
+                        int* iters_max, double* relres_max);
 int fb_sys_lambda(fb_ctx* ctx, fb_system* sys, double stiffness_lambda, double crosslink_lambda, double* sl_out, double* cl_out);
 int fb_sys_form(fb_ctx* ctx, fb_system* sys, double sl, double cl);
 /* x: [2 nv] float64, x0 on entry when use_x0.  maxiter < 0: until converged, 0: zeros, > 0: cap */
