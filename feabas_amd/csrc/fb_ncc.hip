@@ -154,18 +154,27 @@ __global__ void ncc_peak_final(const float* __restrict__ Csurf, const PeakPartia
                                double* __restrict__ dx, double* __restrict__ dy, float* __restrict__ conf, int N,
                                const float* __restrict__ ct9 = nullptr) {
 #pragma clang fp contract(off)
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per block pair: lanes stride over the partials, shuffle tree, lane 0 finishes
+    const int n = blockIdx.x, lane = threadIdx.x;
     if (n >= N) return;
-    if (blk) {      // per-block sizes (crop mode)
-        const int* d = blk + (size_t)n * kBlkStride;
-        H0 = d[3]; W0 = d[4]; H1 = d[7]; W1 = d[8];
-    }
     const PeakPartial* p = part + (size_t)n * nchunks;
-    float v = p[0].vmax; int iv = p[0].imax; float mm = p[0].mmax; double s = p[0].sum, ss = p[0].sumsq;
-    for (int c = 1; c < nchunks; ++c) {
+    float v = -INFINITY; int iv = 0x7fffffff; float mm = 0.f; double s = 0.0, ss = 0.0;
+    for (int c = lane; c < nchunks; c += 64) {
         peak_merge(v, iv, p[c].vmax, p[c].imax);
         mm = fmaxf(mm, p[c].mmax);
         s += p[c].sum; ss += p[c].sumsq;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float v2 = __shfl_down(v, off);
+        const int i2 = __shfl_down(iv, off);
+        peak_merge(v, iv, v2, i2);
+        mm = fmaxf(mm, __shfl_down(mm, off));
+        s += __shfl_down(s, off); ss += __shfl_down(ss, off);
+    }
+    if (lane != 0) return;
+    if (blk) {      // per-block sizes (crop mode)
+        const int* d = blk + (size_t)n * kBlkStride;
+        H0 = d[3]; W0 = d[4]; H1 = d[7]; W1 = d[8];
     }
     if (iv == 0x7fffffff) iv = 0;      // all -inf / NaN surface: numpy argmax -> 0
     const int py = iv / Fw, px = iv - py * Fw;
@@ -366,7 +375,7 @@ int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     }
     {
         FB_PROF(ctx, "ncc_peak_final");
-        hipLaunchKernelGGL(ncc_peak_final, dim3(fb_cdiv(nreal, 64)), dim3(64), 0, ctx->stream, Csurf, part, kPeakChunks, Fh, Fw,
+        hipLaunchKernelGGL(ncc_peak_final, dim3(nreal), dim3(64), 0, ctx->stream, Csurf, part, kPeakChunks, Fh, Fw,
                            H0, W0, H1, W1, crop ? crop->blk : (const int*)nullptr, subpixel, conf_mode, dx, dy, conf, nreal);
     }
     FB_HIP(ctx, hipGetLastError());
@@ -779,7 +788,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     }
     {
         FB_PROF(ctx, "ncc_peak_final");
-        hipLaunchKernelGGL(ncc_peak_final, dim3(fb_cdiv(nb, 64)), dim3(64), 0, ctx->stream, (const float*)nullptr, part, ntiles, Fh, Fw, H0, W0, H1,
+        hipLaunchKernelGGL(ncc_peak_final, dim3(nb), dim3(64), 0, ctx->stream, (const float*)nullptr, part, ntiles, Fh, Fw, H0, W0, H1,
                            W1, crop ? crop->blk : (const int*)nullptr, subpixel, conf_mode, dx, dy, conf, nb, subpixel ? ct9 : (const float*)nullptr);
     }
     FB_HIP(ctx, hipGetLastError());
