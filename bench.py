@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=32)
+    ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--pairs-per-step', type=int, default=64)
     ap.add_argument('--resident-pairs', type=int, default=1024)
     ap.add_argument('--tile', type=int, default=4096)
@@ -228,6 +228,11 @@ def main():
             t.join()
         return results[idx[-1]]
 
+    # one-time set-up outside the step count: every matcher instance builds its resident relaxation system, twiddle
+    # tables and scratch arena on its first batch (lazy), so each is run once before the W warm-up steps
+    for (k, j), m in matchers.items():
+        H, W = shapes[k]
+        m.match(strips[k][0].ptr, strips[k][1].ptr)
     run_steps(0, args.warmup)
     barrier()
     _lib.check(lib.fb_prof_reset(ctx)); _lib.check(lib.fb_prof_enable(ctx, 1))
@@ -275,7 +280,8 @@ def main():
     tfile = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*pmc_traffic.json')))
     if tfile and dom[0] is not None:
         tk = json.load(open(tfile[-1]))['kernels']
-        hit = [v for k_, v in tk.items() if k_.startswith(dom[0])]
+        alias = {'ncc_stream_cols': 'ncc_cols_p2', 'ncc_stream_rows': 'ncc_rows_p2', 'ncc_stream_inv': 'ncc_inv_p2'}     # profile label -> device symbol
+        hit = [v for k_, v in tk.items() if k_.startswith(dom[0]) or k_ == alias.get(dom[0])]
         if hit:
             roof['traffic'] = hit[0]['hbm_bytes_per_launch']
             roof['traffic_source'] = 'profiles/' + os.path.basename(tfile[-1])
