@@ -364,6 +364,34 @@ __global__ void group_lambda_kernel(int gs, const int* __restrict__ rowptr, cons
     }
 }
 
+// one workgroup per group: e[g] = x^T K x over the group's vertex range (K block-diagonal per group)
+__global__ void group_energy_kernel(int gs, const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ Kval,
+                                    const double2* __restrict__ x, double* __restrict__ e) {
+    __shared__ double sh[kT / 64];
+    const int g = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < gs; i += blockDim.x) {
+        const int v = g * gs + i;
+        double2 y = make_double2(0.0, 0.0);
+        for (int j = rowptr[v]; j < rowptr[v + 1]; ++j) {
+            const double4 k = reinterpret_cast<const double4*>(Kval)[j];
+            const double2 u = x[col[j]];
+            y.x += k.x * u.x + k.y * u.y;
+            y.y += k.z * u.x + k.w * u.y;
+        }
+        const double2 xi = x[v];
+        acc += xi.x * y.x + xi.y * y.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) acc += sh[w];
+        e[g] = acc;
+    }
+}
+
 // thread per vertex row: A = ls[g] K + lc C (x) I2, b = lc rhs - ls[g] stress
 __global__ void form_groups_kernel(int nv, int gs, const int* __restrict__ rowptr, const double* __restrict__ Kval,
                                    const double* __restrict__ Cval, const double2* __restrict__ rhs, const float2* __restrict__ stress,
@@ -751,6 +779,27 @@ int fb_sys_solve_groups(fb_ctx* ctx, fb_system* s, int ngroups, double* x, doubl
     if (iters_max) *iters_max = mi;
     if (relres_max) *relres_max = mr;
     return bad ? FB_ERR_NOCONV : FB_OK;
+}
+
+// Elastic energy x^T K x of every equal vertex range of a block-diagonal batch (K = the stiffness of the last
+// fb_sys_assemble_mesh): the Es / Es0 terms of the matcher's strain estimate (matcher.py:764-777).  x: host [2 nv].
+int fb_sys_group_energy(fb_ctx* ctx, fb_system* s, int ngroups, const double* x, double* energy) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && x && energy && ngroups > 0 && s->nv % ngroups == 0);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    if (s->gstat_cap < ngroups) {
+        hipFree(s->d_gstat);
+        FB_HIP(ctx, hipMalloc((void**)&s->d_gstat, 16 * (size_t)ngroups));
+        s->gstat_cap = ngroups;
+    }
+    // M->z is free outside a solve: staging area for x
+    FB_HIP(ctx, hipMemcpyAsync(s->M->z, x, sizeof(double2) * (size_t)s->nv, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(group_energy_kernel, dim3(ngroups), dim3(kT), 0, ctx->stream, s->nv / ngroups, s->M->d.rowptr, s->M->d.col, s->d_K, s->M->z,
+                       reinterpret_cast<double*>(s->d_gstat));
+    FB_HIP(ctx, hipGetLastError());
+    FB_HIP(ctx, hipMemcpyAsync(energy, s->d_gstat, sizeof(double) * (size_t)ngroups, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FB_OK;
 }
 
 int fb_sys_solve_fixed(fb_ctx* ctx, fb_system* s, int iters, double* relres) {

@@ -11,12 +11,13 @@ Per pair, in the reference's order:
      (MeshRenderer.crop_multiple for a translated, undeformed mesh), xcorr_fft with the
      reference's pad / subpixel schedule (579-603, 690-716), block -> point pairs (840-849)
                                                             fb_ncc_blocks_dev
+  6. last-round mesh relaxation + huber residue weights (725-737) and the strain estimate (752-777)
+     for the whole batch as one block-diagonal system             fb_sys_update_links / _form_groups / _solve_groups
 What is NOT here yet (DESIGN.md "scope of the pair pipeline"): the low-confidence fallback
 of global_translation_matcher (159-221, host path exists in matcher.py); NON-RIGID mesh relaxation
 between spacings (725-742; a uniform block displacement is applied as the rigid translation it
-relaxes to) together with the bilinear patch gather it needs; the
-final residue re-weighting and strain estimate.  Pairs that would take the non-rigid branch are
-flagged in the result (``needs_host``).
+relaxes to) together with the bilinear patch gather it needs.
+Pairs that would take the non-rigid branch are flagged in the result (``needs_host``).
 """
 import ctypes as C
 
@@ -60,7 +61,7 @@ def _z_order_batch(ix, iy):
 
 class StripBatchMatcher:
     def __init__(self, P, H, W, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
-                 conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9):
+                 conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9, compute_strain=True):
         assert coarse_downsample in (0.5, 1)
         assert H % 2 == 0 and W % 2 == 0 or coarse_downsample == 1
         self.P, self.H, self.W = int(P), int(H), int(W)
@@ -83,6 +84,8 @@ class StripBatchMatcher:
         self.residue_len = float(residue_len)                 # matcher.py:236 (fine_downsample = 1)
         self.stiffness_lambda = float(stiffness_lambda)       # matcher.py:507
         self.relax_tol = float(relax_tol)
+        self.compute_strain = bool(compute_strain)          # matcher.py:497
+        self.last_strain_solve = None
         self._relax_sys = None
         self.last_relax = None
 
@@ -198,59 +201,99 @@ class StripBatchMatcher:
         m = Mesh.from_bbox((0, 0, self.W, self.H), cartesian=True, mesh_size=float(np.min(self.spacings)),
                            min_num_blocks=self.mnb, uid=1)
         self._mesh = m
-        V = m.num_vertices
+        V, T, P = m.num_vertices, m.num_triangles, self.P
         sysh = C.c_void_p()
-        _lib.check(lib.fb_sys_create(ctx, self.P * V, C.byref(sysh)))
-        v0 = np.ascontiguousarray(m.vertices(const.MESH_GEAR_INITIAL), dtype=np.float64)
-        for p in range(self.P):
-            mid = C.c_int()
-            _lib.check(lib.fb_sys_add_mesh(ctx, sysh, p * V, _lib.ptr(m.triangles), V, m.num_triangles, C.byref(mid)))
+        _lib.check(lib.fb_sys_create(ctx, P * V, C.byref(sysh)))
+        # the P copies enter as ONE mesh (one assembly launch per stiffness state)
+        tri_u = np.ascontiguousarray((m.triangles[None, :, :] + (np.arange(P) * V)[:, None, None]).reshape(-1, 3), dtype=np.int32)
+        mid = C.c_int()
+        _lib.check(lib.fb_sys_add_mesh(ctx, sysh, 0, _lib.ptr(tri_u), P * V, P * T, C.byref(mid)))
         _lib.check(lib.fb_sys_set_links(ctx, sysh, 0, None))
         nnzb = C.c_int64()
         _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
-        for p in range(self.P):
-            m.assemble_into(sysh, p, v0, None, 1.0)           # translation invariant: shape = INITIAL vertices, no stress
+        self._mult_u = np.ascontiguousarray(np.tile(m.element_multiplier(), P), dtype=np.float32)
+        self._v_init_u = np.ascontiguousarray(np.tile(m.vertices(const.MESH_GEAR_INITIAL), (P, 1)), dtype=np.float64)
         self._relax_sys = sysh
+        self._k_state = None
+        self._assemble_union(self._v_init_u, 'initial')       # translation invariant: shape = INITIAL vertices, no stress
+        v0 = self._v_init_u.reshape(P, V, 2)
+        v0 = np.ascontiguousarray((v0 - v0.mean(axis=1, keepdims=True)).reshape(-1, 2))
+        es0 = np.empty(P)
+        _lib.check(lib.fb_sys_group_energy(ctx, sysh, P, _lib.ptr(v0), _lib.ptr(es0)))
+        self._es0 = float(es0[0])                             # v0^T K v0 of the centred mesh: the same for every copy and rotation
         return sysh
 
-    def _final_relax(self, pid, xy0, xy1, wt, t1):
+    def _assemble_union(self, v_shape, state):
+        """stiffness K of the P mesh copies at the given shapes ([P V, 2]); skipped when K already holds `state`"""
+        if state is not None and state == self._k_state:
+            return
+        m = self._mesh
+        _lib.check(_lib.load().fb_sys_assemble_mesh(_lib.ctx(), self._relax_sys, 0, _lib.ptr(v_shape), None, _lib.ptr(self._mult_u),
+                                                    m.poisson_ratio, 1.0))
+        self._k_state = state
+
+    def _links(self, pid, q1):
+        """matches at mesh1 coordinates q1 (INITIAL gear) of pairs pid -> dict(nodes6 [K, 6], B1 [K, 3], bary6 [K, 6]).
+        On the cartesian grid (cells (a b / c d) split into (a, b, d), (a, d, c), Mesh.from_bbox) point location and
+        Mesh.cart2bary (mesh.py:2191-2217) reduce to the cell coordinates (u, w) of the point: (1 - u, u - w, w) in the
+        lower triangle, (1 - w, u, w - u) in the upper one."""
+        m = self._mesh
+        V = m.num_vertices
+        xs, ys = m.grid_xs, m.grid_ys
+        nx = xs.size
+        i = np.clip(np.searchsorted(xs, q1[:, 0], side='right') - 1, 0, nx - 2)
+        j = np.clip(np.searchsorted(ys, q1[:, 1], side='right') - 1, 0, ys.size - 2)
+        u = (q1[:, 0] - xs[i]) / (xs[i + 1] - xs[i])
+        w = (q1[:, 1] - ys[j]) / (ys[j + 1] - ys[j])
+        up = w > u
+        na = j * nx + i + pid * V                              # a; b = a + 1, c = a + nx, d = a + nx + 1
+        K = pid.size
+        nodes6 = np.full((K, 6), -1, dtype=np.int32)
+        nodes6[:, 3] = na
+        nodes6[:, 4] = np.where(up, na + nx + 1, na + 1)
+        nodes6[:, 5] = np.where(up, na + nx, na + nx + 1)
+        B1 = np.empty((K, 3))
+        B1[:, 0] = np.where(up, 1.0 - w, 1.0 - u)
+        B1[:, 1] = np.where(up, u, u - w)
+        B1[:, 2] = np.where(up, w - u, w)
+        bary6 = np.zeros((K, 6))
+        bary6[:, 0] = 1.0                                     # locked side: not used by the assembly
+        bary6[:, 3:] = -B1
+        return dict(nodes6=nodes6, B1=B1, bary6=bary6, loaded=False)
+
+    def _solve_links(self, links, wt, dxy, tol):
+        """assemble the links, form every pair's system with its own lambda, solve all pairs -> vertex field [P V, 2]"""
+        lib, ctx = _lib.load(), _lib.ctx()
+        sysh = self._relax_sys
+        V = self._mesh.num_vertices
+        w32 = np.ascontiguousarray(wt, dtype=np.float32)
+        dxy = np.ascontiguousarray(dxy, dtype=np.float64)
+        nodes6, bary6 = links['nodes6'], links['bary6']
+        if not links['loaded']:                                # the vertex -> match index of the resident system follows the links
+            _lib.check(lib.fb_sys_update_links(ctx, sysh, nodes6.shape[0], _lib.ptr(nodes6)))
+            links['loaded'] = True
+        _lib.check(lib.fb_sys_assemble_links(ctx, sysh, _lib.ptr(bary6), _lib.ptr(w32), _lib.ptr(dxy)))
+        _lib.check(lib.fb_sys_form_groups(ctx, sysh, self.P, self.stiffness_lambda, -1.0, None))
+        x = np.zeros(2 * self.P * V, dtype=np.float64)
+        iters, relres = C.c_int(), C.c_double()
+        _lib.check(lib.fb_sys_solve_groups(ctx, sysh, self.P, _lib.ptr(x), tol, 0.0, 20 * V, 1, C.byref(iters), C.byref(relres)),
+                   allow=(_lib.FB_ERR_NOCONV,))
+        return x.reshape(-1, 2), dict(iters=iters.value, relres=relres.value, matches=int(nodes6.shape[0]))
+
+    def _final_relax(self, pid, xy0, xy1, wt, t1, links=None):
         """matcher.py:725-737 for every pair of the batch at once: relax mesh1 against the last-round links
         (optimize_linear, to the fixed point), then huber residue weights (optimizer.py:174-191, 203-205).
         pid [K] sorted or not; xy0/xy1 [K, 2] in the MOVING gear; wt [K] confidences; t1 [P, 2] mesh1 offsets.
         Returns the residue weight [K] float32, the displacement of the mesh1 end of each match and of every
         mesh1 vertex [P, V, 2]."""
-        lib, ctx = _lib.load(), _lib.ctx()
-        sysh = self._relax_system()
+        self._relax_system()
         m = self._mesh
         V = m.num_vertices
-        K = pid.size
-        q1 = xy1 - t1[pid]                                    # mesh1 coordinates without its offset
-        tid1 = m.locate_cartesian(q1)
-        tv = m.triangles[tid1]                                # [K, 3]
-        pv = m.vertices(const.MESH_GEAR_INITIAL)[tv]          # [K, 3, 2]
-        d0, d1, d2 = q1 - pv[:, 0], q1 - pv[:, 1], q1 - pv[:, 2]
-        a0 = d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0]        # mesh.py:2191-2217
-        a1 = d2[:, 0] * d0[:, 1] - d2[:, 1] * d0[:, 0]
-        a2 = d0[:, 0] * d1[:, 1] - d0[:, 1] * d1[:, 0]
-        tot = a0 + a1 + a2
-        B1 = np.stack((a0 / tot, a1 / tot, a2 / tot), axis=-1)
-        nodes6 = np.full((K, 6), -1, dtype=np.int32)
-        nodes6[:, 3:] = tv + (pid * V)[:, None]
-        bary6 = np.zeros((K, 6))
-        bary6[:, 0] = 1.0                                     # locked side: not used by the assembly
-        bary6[:, 3:] = -B1
-        w32 = np.ascontiguousarray(wt, dtype=np.float32)
-        dxy = np.ascontiguousarray(xy1 - xy0, dtype=np.float64)          # Link.dxy (optimizer.py:248-255)
-        _lib.check(lib.fb_sys_update_links(ctx, sysh, K, _lib.ptr(nodes6)))
-        _lib.check(lib.fb_sys_assemble_links(ctx, sysh, _lib.ptr(bary6), _lib.ptr(w32), _lib.ptr(dxy)))
-        _lib.check(lib.fb_sys_form_groups(ctx, sysh, self.P, self.stiffness_lambda, -1.0, None))
-        x = np.zeros(2 * self.P * V, dtype=np.float64)
-        iters, relres = C.c_int(), C.c_double()
-        _lib.check(lib.fb_sys_solve_groups(ctx, sysh, self.P, _lib.ptr(x), self.relax_tol, 0.0, 20 * V, 1, C.byref(iters), C.byref(relres)),
-                   allow=(_lib.FB_ERR_NOCONV,))
-        self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K))
-        x = x.reshape(-1, 2)
-        u = np.sum(x[nodes6[:, 3:]] * B1[:, :, None], axis=1)            # displacement of the mesh1 end of each match
+        if links is None:
+            links = self._links(pid, xy1 - t1[pid])           # mesh1 coordinates without its offset
+        dxy = xy1 - xy0                                       # Link.dxy (optimizer.py:248-255)
+        x, self.last_relax = self._solve_links(links, wt, dxy, self.relax_tol)
+        u = np.sum(x[links['nodes6'][:, 3:]] * links['B1'][:, :, None], axis=1)            # displacement of the mesh1 end of each match
         res = dxy + u
         dis2 = np.sum(res ** 2, axis=-1)
         area = float(np.abs(m.triangle_areas(const.MESH_GEAR_INITIAL)[0]))
@@ -258,6 +301,106 @@ class StripBatchMatcher:
         dis = np.sqrt(np.clip(dis2 - sample_err ** 2, 0, None))
         L = self.residue_len
         return (L / np.maximum(dis, L)).astype(np.float32), u, x.reshape(self.P, V, 2)
+
+    def _rigid_fits(self, pid, p0, p1, wt):
+        """spatial.fit_affine(p0, p1, return_rigid=True, weight, svd_clip=(1, 1)) for every pair at once.  One pass
+        accumulates the raw (weighted and unweighted) moments of every pair; centring by the unweighted means and the
+        common scale max(std0, std1) (spatial.py:24-33) are applied to the P small moment matrices, then the weighted
+        least squares is the 3x3 normal-equation solve of each pair and the rigid part the polar rotation of its 2x2
+        block.  Pairs that are rank deficient, reflected or have fewer than 3 matches go through the
+        statement-by-statement host function.  The rows of a pair must be contiguous."""
+        from .common import fit_affine
+        P, K = self.P, pid.size
+        starts = np.concatenate(([0], np.flatnonzero(np.diff(pid) != 0) + 1))
+        present = pid[starts]
+        w = np.asarray(wt, dtype=np.float64)
+        x0, y0, x1, y1 = p0[:, 0], p0[:, 1], p1[:, 0], p1[:, 1]
+        F = np.empty((K, 21))
+        F[:, 0] = 1.0; F[:, 1] = x0; F[:, 2] = y0; F[:, 3] = x1; F[:, 4] = y1
+        F[:, 5] = x0 * x0; F[:, 6] = y0 * y0; F[:, 7] = x1 * x1; F[:, 8] = y1 * y1
+        F[:, 9] = w; F[:, 10] = w * x1; F[:, 11] = w * y1; F[:, 12] = w * x0; F[:, 13] = w * y0
+        F[:, 14] = F[:, 10] * x1; F[:, 15] = F[:, 10] * y1; F[:, 16] = F[:, 11] * y1
+        F[:, 17] = F[:, 10] * x0; F[:, 18] = F[:, 10] * y0; F[:, 19] = F[:, 11] * x0; F[:, 20] = F[:, 11] * y0
+        S = np.zeros((P, 21))
+        S[present] = np.add.reduceat(F, starts, axis=0)
+        cnt = S[:, 0]
+        n = np.maximum(cnt, 1.0)
+        m0x, m0y, m1x, m1y = S[:, 1] / n, S[:, 2] / n, S[:, 3] / n, S[:, 4] / n
+        var0 = (S[:, 5] / n - m0x ** 2) + (S[:, 6] / n - m0y ** 2)
+        var1 = (S[:, 7] / n - m1x ** 2) + (S[:, 8] / n - m1y ** 2)
+        scl = np.sqrt(np.maximum(np.maximum(var0, var1), 0.0))
+        scl = np.where(scl < 1e-6, 1.0, scl)
+        sw, sx1, sy1, sx0, sy0 = S[:, 9], S[:, 10], S[:, 11], S[:, 12], S[:, 13]
+        cx1, cy1, cx0, cy0 = sx1 - m1x * sw, sy1 - m1y * sw, sx0 - m0x * sw, sy0 - m0y * sw     # sums of w (p - mean)
+        G = np.empty((P, 3, 3)); Hm = np.empty((P, 3, 3))
+        s2 = scl * scl
+        G[:, 0, 0] = (S[:, 14] - 2 * m1x * sx1 + m1x ** 2 * sw) / s2
+        G[:, 0, 1] = G[:, 1, 0] = (S[:, 15] - m1x * sy1 - m1y * sx1 + m1x * m1y * sw) / s2
+        G[:, 1, 1] = (S[:, 16] - 2 * m1y * sy1 + m1y ** 2 * sw) / s2
+        G[:, 0, 2] = G[:, 2, 0] = cx1 / scl
+        G[:, 1, 2] = G[:, 2, 1] = cy1 / scl
+        G[:, 2, 2] = sw
+        Hm[:, 0, 0] = (S[:, 17] - m1x * sx0 - m0x * sx1 + m1x * m0x * sw) / s2
+        Hm[:, 0, 1] = (S[:, 18] - m1x * sy0 - m0y * sx1 + m1x * m0y * sw) / s2
+        Hm[:, 1, 0] = (S[:, 19] - m1y * sx0 - m0x * sy1 + m1y * m0x * sw) / s2
+        Hm[:, 1, 1] = (S[:, 20] - m1y * sy0 - m0y * sy1 + m1y * m0y * sw) / s2
+        Hm[:, 0, 2] = cx1 / scl; Hm[:, 1, 2] = cy1 / scl
+        Hm[:, 2, 0] = cx0 / scl; Hm[:, 2, 1] = cy0 / scl; Hm[:, 2, 2] = sw
+        ok = cnt >= 3
+        ev = np.linalg.eigvalsh(np.where(ok[:, None, None], G, np.eye(3)))
+        ok &= ev[:, 0] > 1e-9 * ev[:, 2]
+        A = np.tile(np.eye(3), (P, 1, 1))
+        A[ok] = np.linalg.solve(G[ok], Hm[ok])
+        ok &= np.linalg.det(A) > 0
+        u, sv, vh = np.linalg.svd(A[:, :2, :2])
+        R = A.copy()
+        R[:, :2, :2] = u @ vh                                  # singular values clipped to (1, 1)
+        mm0 = np.stack((m0x, m0y), axis=-1); mm1 = np.stack((m1x, m1y), axis=-1)
+        R[:, 2, :2] = A[:, 2, :2] + mm0 - np.einsum('pi,pij->pj', mm1, R[:, :2, :2])
+        R[:, :, 2] = np.array([0.0, 0.0, 1.0])
+        for p in np.flatnonzero(~ok & (cnt > 0)):
+            s = pid == p
+            R[p] = fit_affine(p0[s], p1[s], return_rigid=True, weight=wt[s], svd_clip=(1, 1), avoid_flip=True)[1]
+        return R
+
+    def _strain(self, pid, xy0, xy1, wt, txy, links=None):
+        """matcher.py:752-777 for every pair of the batch: fresh mesh pair, rigid initialisation of mesh1 from the
+        final matches (optimize_affine_cascade, svd_clip (1, 1)), anneal, optimize_linear(tol=1e-6), strain =
+        sqrt(Es / Es0) with the stiffness of mesh1 at its rigidly placed shape.  pid/xy0/xy1/wt: the final match table
+        (INITIAL gears), rows of a pair contiguous; txy [P, 2] translation of the locked mesh0.  Returns strain [P]
+        (DEFAULT_AVG_DEFORM where a pair has no match).
+
+        The stiffness of the rotated mesh is Q K Q^T (Q = the rotation on every vertex) and the link terms are
+        multiples of I2, so the relaxed field of the rotated pair is the rotation of the field that
+        (ls K + C) x' = Q^T b gives with the stiffness K of the INITIAL shape: the batch reuses the resident K and
+        rotates only right-hand sides; Es = x'^T K x' and Es0 = v_initial^T K v_initial (centred) are rotation free."""
+        lib, ctx = _lib.load(), _lib.ctx()
+        self._relax_system()
+        m = self._mesh
+        V, P = m.num_vertices, self.P
+        strain = np.full(P, DEFAULT_AVG_DEFORM)
+        if pid.size == 0:
+            return strain
+        nseg = 1 + int(np.count_nonzero(np.diff(pid) != 0))
+        if nseg != int(np.count_nonzero(np.bincount(pid, minlength=P))):          # rows of a pair not contiguous
+            o = np.argsort(pid, kind='stable')
+            pid, xy0, xy1, wt = pid[o], xy0[o], xy1[o], wt[o]
+            links = None
+        p0 = xy0 + txy[pid]                                    # mesh0 points, FIXED gear
+        R = self._rigid_fits(pid, p0, xy1, wt)
+        R2 = R[:, :2, :2]
+        if links is None:
+            links = self._links(pid, xy1)
+        xy1_f = np.einsum('ki,kij->kj', xy1, R2[pid]) + R[pid, 2, :2]             # Mesh.set_affine (mesh.py:2342-2354) on the match points
+        dxy_back = np.einsum('kj,kij->ki', xy1_f - p0, R2[pid])                    # Q^T applied to the link residuals
+        x, self.last_strain_solve = self._solve_links(links, wt, dxy_back, 1e-6)
+        dd = x.reshape(P, V, 2)
+        dv = dd - dd.mean(axis=1, keepdims=True)               # Mesh.set_field keeps the mean in the offset (mesh.py:2409-2413)
+        Es = np.empty(P)
+        _lib.check(lib.fb_sys_group_energy(ctx, self._relax_sys, P, _lib.ptr(np.ascontiguousarray(dv.reshape(-1, 2))), _lib.ptr(Es)))
+        has = np.bincount(pid, minlength=P) > 0
+        strain[has] = np.sqrt(np.maximum(Es[has], 0.0) / self._es0)
+        return strain
 
     # ------------------------------------------------------------------ driver
     def match(self, strips0, strips1):
@@ -275,6 +418,7 @@ class StripBatchMatcher:
         needs_host = np.zeros(n, dtype=bool)
         has_last = np.zeros(n, dtype=bool)
         table = None
+        last_links = None
         txy = np.stack((tx, ty), axis=-1)
         t1 = np.zeros((n, 2))                                # translation of mesh1 acquired by rigid relaxations
         live = active.copy()                                 # pairs still iterating over the spacings
@@ -321,13 +465,18 @@ class StripBatchMatcher:
             if rows:
                 prev = table
                 table = tuple(np.concatenate([r[k] for r in rows], axis=0) for k in range(6))
+                last_links = None
                 if is_last and self.residue_len > 0:
-                    # last round (matcher.py:725-737): relaxation + huber residue weights, pairs with max_dis > 0.1
-                    pid_l, xy0_l, _, wt_l, xy1_l, rl = table
+                    # last round (matcher.py:725-737): relaxation + huber residue weights, pairs with max_dis > 0.1.  All rows
+                    # of the round enter the block-diagonal system (a pair that needs no relaxation is solved and ignored), so
+                    # that the strain estimate below can reuse the same links
+                    pid_l, xy0_l, xy1i_l, wt_l, xy1_l, rl = table
                     if rl.any():
-                        rw, _, _ = self._final_relax(pid_l[rl], xy0_l[rl], xy1_l[rl], wt_l[rl], t1)
+                        self._relax_system()
+                        last_links = self._links(pid_l, xy1i_l)
+                        rw, _, _ = self._final_relax(pid_l, xy0_l, xy1_l, wt_l, t1, links=last_links)
                         wt_new = wt_l.copy()
-                        wt_new[rl] = wt_l[rl] * rw                                 # Link.weight (optimizer.py:313-317)
+                        wt_new[rl] = wt_l[rl] * rw[rl]                             # Link.weight (optimizer.py:313-317)
                         table = table[:3] + (wt_new,) + table[4:]
                 table = table[:4]
                 if prev is not None and prev[0].size:
@@ -336,15 +485,19 @@ class StripBatchMatcher:
                     carry = ~np.isin(prev[0], table[0])
                     if carry.any():
                         table = tuple(np.concatenate((a, b[carry]), axis=0) for a, b in zip(table, prev))
+                        last_links = None
         valid = active & has_last
         if table is None:
             table = (np.zeros(0, np.int64), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0, np.float32))
         pid, xy0, xy1, wt = table
         ok = valid[pid]
-        pid, xy0, xy1, wt = pid[ok], xy0[ok], xy1[ok], wt[ok]
+        if not ok.all():
+            pid, xy0, xy1, wt = pid[ok], xy0[ok], xy1[ok], wt[ok]
+            last_links = None
         # output in the INITIAL gear: mesh0 points lose the translation (matcher.py:748-751)
         xy0 = xy0 - txy[pid]
-        return dict(tx=tx, ty=ty, conf0=cf0, valid=valid, needs_host=needs_host, pair=pid, xy0=xy0, xy1=xy1, weight=wt)
+        strain = self._strain(pid, xy0, xy1, wt, txy, links=last_links) if self.compute_strain else np.full(n, DEFAULT_AVG_DEFORM)
+        return dict(tx=tx, ty=ty, conf0=cf0, valid=valid, needs_host=needs_host, pair=pid, xy0=xy0, xy1=xy1, weight=wt, strain=strain)
 
     @staticmethod
     def per_pair(res):
@@ -354,8 +507,8 @@ class StripBatchMatcher:
             m = res['pair'] == p
             if res['valid'][p]:
                 out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=bool(res['needs_host'][p]),
-                                xy0=res['xy0'][m], xy1=res['xy1'][m], weight=res['weight'][m]))
+                                xy0=res['xy0'][m], xy1=res['xy1'][m], weight=res['weight'][m], strain=float(res['strain'][p])))
             else:
                 out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=False,
-                                xy0=None, xy1=None, weight=None))
+                                xy0=None, xy1=None, weight=None, strain=DEFAULT_AVG_DEFORM))
         return out

@@ -183,6 +183,9 @@ int fb_sys_form_groups(fb_ctx* ctx, fb_system* sys, int ngroups, double stiffnes
  * matcher.py:717-742 for a whole batch of tile pairs in one launch.  x: host [2 nv]; iters_max / relres_max: worst range. */
 int fb_sys_solve_groups(fb_ctx* ctx, fb_system* sys, int ngroups, double* x, double rtol, double atol, int maxiter, int precond,
                         int* iters_max, double* relres_max);
+/* x^T K x per equal vertex range (K of the last fb_sys_assemble_mesh*): Es and Es0 of the strain estimate,
+ * matcher.py:764-777.  x: host [2 nv], energy: host [ngroups]. */
+int fb_sys_group_energy(fb_ctx* ctx, fb_system* sys, int ngroups, const double* x, double* energy);
 int fb_sys_lambda(fb_ctx* ctx, fb_system* sys, double stiffness_lambda, double crosslink_lambda, double* sl_out, double* cl_out);
 int fb_sys_form(fb_ctx* ctx, fb_system* sys, double sl, double cl);
 /* x: [2 nv] float64, x0 on entry when use_x0.  maxiter < 0: until converged, 0: zeros, > 0: cap */

@@ -192,6 +192,14 @@ class RefMesh:
         self._v[gear[-1]] = v0 + (dxy - m)
         self._off[gear[-1]] = off0 + m
 
+    def set_affine(self, A, gear=(GEAR_FIXED, GEAR_MOVING)):     # mesh.py:2342-2354 (unmasked, gear[0] != gear[-1])
+        if self.locked:
+            return
+        v0 = self.vertices(gear[0])
+        off0 = self.offset(gear[0])
+        self._v[gear[-1]] = v0 @ A[:-1, :-1]
+        self._off[gear[-1]] = off0 @ A[:-1, :-1] + A[-1, :-1]
+
     def anneal_copy(self, gear=(GEAR_MOVING, GEAR_FIXED)):   # mesh.py:2452-2456
         if self.locked:
             return
@@ -511,6 +519,52 @@ def optimize_linear(meshes, links, tol=1e-7, stiffness_lambda=1.0, crosslink_lam
     if cost[1] < cost[0]:
         apply_solution(meshes, dd, start_gear, target_gear)
     return cost
+
+
+def fit_affine(pts0, pts1, return_rigid=False, weight=None, svd_clip=(1, 1), avoid_flip=True):
+    """spatial.py:21-73: pts0 ~ pts1 @ A (3x3, row-vector convention); with return_rigid also the transform whose
+    2x2 part has its singular values clipped to svd_clip.  Restated statement by statement (including the scaled
+    translation row of the least-squares solution that the reference carries into the result)."""
+    pts0 = np.asarray(pts0, dtype=np.float64).reshape(-1, 2)
+    pts1 = np.asarray(pts1, dtype=np.float64).reshape(-1, 2)
+    mm0 = pts0.mean(axis=0)
+    mm1 = pts1.mean(axis=0)
+    pts0 = pts0 - mm0
+    pts1 = pts1 - mm1
+    std0 = np.sum(np.std(pts0, axis=0) ** 2) ** 0.5
+    std1 = np.sum(np.std(pts1, axis=0) ** 2) ** 0.5
+    std_scl = max(std0, std1)
+    if std_scl < 1e-6:
+        std_scl = 1
+    p0 = np.insert(pts0 / std_scl, 2, 1, axis=-1)
+    p1 = np.insert(pts1 / std_scl, 2, 1, axis=-1)
+    if weight is not None:
+        w = np.asarray(weight) ** 0.5
+        p0 = p0 * w.reshape(-1, 1)
+        p1 = p1 * w.reshape(-1, 1)
+    res = np.linalg.lstsq(p1, p0, rcond=None)
+    r1 = np.linalg.matrix_rank(p0)
+    A = res[0]
+    r = min(res[2], r1)
+    if avoid_flip and np.linalg.det(A) < 0:
+        r = 2
+    if r == 1:
+        A = np.eye(3)
+    elif r == 2:
+        q0 = np.concatenate((pts0, pts0[:, ::-1] * np.array([1, -1])), axis=0)
+        q1 = np.concatenate((pts1, pts1[:, ::-1] * np.array([1, -1])), axis=0)
+        A = np.linalg.lstsq(np.insert(q1 / std_scl, 2, 1, axis=-1), np.insert(q0 / std_scl, 2, 1, axis=-1), rcond=None)[0]
+    R = A
+    if return_rigid and svd_clip is not None:
+        u, sv, vh = np.linalg.svd(A[:2, :2], compute_uv=True)
+        sv = sv.clip(svd_clip[0], svd_clip[-1])
+        R = A.copy()
+        R[:2, :2] = u @ np.diag(sv) @ vh
+        R[-1, :2] = R[-1, :2] + mm0 - mm1 @ R[:2, :2]
+        R[:, -1] = np.array([0, 0, 1])
+    A[-1, :2] = A[-1, :2] + mm0 - mm1 @ A[:2, :2]
+    A[:, -1] = np.array([0, 0, 1])
+    return (A, R) if return_rigid else A
 
 
 # ------------------------------------------------------------------ synthetic meshes

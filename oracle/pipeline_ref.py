@@ -71,6 +71,44 @@ def relax_mesh1(W, H, mesh_size, t0, t1, xy0, xy1, weight, residue_len=0.0, min_
     return u
 
 
+def strain_estimate(W, H, mesh_size, t0, xy0, xy1, weight, min_num_blocks=2, stiffness_lambda=1.0):
+    """matcher.py:752-777 with exact solves: fresh mesh pair (mesh0 locked at its translation t0), one link from the
+    final matches (INITIAL gear), rigid initialisation of mesh1 (optimize_affine_cascade, optimizer.py:1128-1189,
+    svd_clip (1, 1)), anneal, optimize_linear, strain = sqrt(Es / Es0) on the free mesh."""
+    v, tri, xs, ys = cartesian_mesh(W, H, mesh_size, min_num_blocks=min_num_blocks)
+    m0 = fem_ref.RefMesh(v, tri, uid=0)
+    m0.apply_translation(t0, fem_ref.GEAR_FIXED)
+    m0.locked = True
+    m1 = fem_ref.RefMesh(v, tri, uid=1)
+    tid0 = locate_cartesian(xs, ys, xy0)
+    tid1 = locate_cartesian(xs, ys, xy1)
+    B0 = m0.cart2bary(xy0, fem_ref.GEAR_INITIAL, tid0)
+    B1 = m1.cart2bary(xy1, fem_ref.GEAR_INITIAL, tid1)
+    link = fem_ref.RefLink(m0, m1, tid0, tid1, B0, B1, weight=weight)
+    return strain_from_link(m0, m1, link, stiffness_lambda=stiffness_lambda)[0]
+
+
+def strain_from_link(m0, m1, link, stiffness_lambda=1.0):
+    """core of strain_estimate for a locked m0 (FIXED gear placed), an untouched m1 and their link.
+    Returns (strain, Es, Es0, R)."""
+    tid0, tid1, B0, B1 = link.tid0, link.tid1, link.B0, link.B1
+    # cascade: mesh1 points at INITIAL onto mesh0 points at FIXED
+    p1 = m1.bary2cart(tid1, B1, fem_ref.GEAR_INITIAL)
+    p0 = m0.bary2cart(tid0, B0, fem_ref.GEAR_FIXED)
+    _, R = fem_ref.fit_affine(p0, p1, return_rigid=True, weight=link.total_weight(), svd_clip=(1, 1), avoid_flip=True)
+    m1.set_affine(R, gear=(fem_ref.GEAR_INITIAL, fem_ref.GEAR_FIXED))
+    m1.anneal_copy(gear=(fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING))
+    fem_ref.optimize_linear([m0, m1], [link], stiffness_lambda=stiffness_lambda, exact=True)
+    v0 = m1.vertices(fem_ref.GEAR_FIXED)
+    dv = m1.vertices(fem_ref.GEAR_MOVING) - v0
+    v0 = v0 - np.mean(v0, axis=0, keepdims=True)
+    dv = dv - np.mean(dv, axis=0, keepdims=True)
+    St, _ = m1.stiffness_matrix()
+    Es = max(0, St.dot(dv.ravel()).dot(dv.ravel()))
+    Es0 = max(0, St.dot(v0.ravel()).dot(v0.ravel()))
+    return (Es / Es0) ** 0.5, Es, Es0, R
+
+
 def _crop(img, x0, y0, h, w):
     """h x w window at (x0, y0), zero outside the image (StreamLoader fillval=0 +
     cv2.remap BORDER_CONSTANT, common.py:329-330)."""
@@ -96,7 +134,7 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
     g1 = ncc_ref.masked_dog_filter(g1, sigma * coarse_downsample)
     tx, ty, conf0 = ncc_ref.global_translation_matcher(g0, g1, conf_mode=conf_mode, conf_thresh=conf_thresh)
     res = dict(tx=tx / coarse_downsample, ty=ty / coarse_downsample, conf0=conf0, xy0=None, xy1=None, weight=None,
-               needs_host=False)
+               needs_host=False, strain=0.05)
     if conf0 < conf_thresh:                                                  # matcher.py:277-278
         return res
     if coarse_downsample == 1:
@@ -151,4 +189,7 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
         res['xy1'] = last[1]
         res['weight'] = last[2]
         res['max_dis'] = last[3]
+        # matcher.py:752-777 (compute_strain defaults to True)
+        res['strain'] = strain_estimate(W, H, float(np.min(spacings)), (tx, ty), res['xy0'], res['xy1'], res['weight'],
+                                        min_num_blocks=min_num_blocks)
     return res

@@ -364,7 +364,76 @@ def g12_mixed_materials():
     np.savez_compressed(os.path.join(OUT, 'g12_mixed_materials.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G13
+def g13_strain():
+    """spatial.fit_affine (spatial.py:21-73) and the matcher's strain estimate (matcher.py:752-777): rigid
+    initialisation by optimize_affine_cascade, anneal, optimize_linear, sqrt(Es / Es0)."""
+    from feabas import spatial
+    rng = np.random.default_rng(1313)
+    out = {}
+    # fit_affine: generic weighted, collinear (rank 2), reflected (avoid_flip) point sets
+    for k in range(4):
+        n = 40
+        p1 = rng.uniform(-200, 200, size=(n, 2))
+        th = rng.uniform(-0.2, 0.2)
+        M = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]]) @ np.diag(rng.uniform(0.9, 1.1, 2))
+        if k == 2:
+            p1[:, 1] = 0.5 * p1[:, 0] + 3.0                       # collinear
+        if k == 3:
+            M = M @ np.diag([1.0, -1.0])                          # reflection
+        p0 = p1 @ M + rng.uniform(-30, 30, size=(1, 2)) + rng.normal(0, 0.5, size=(n, 2))
+        w = rng.uniform(0.3, 1.0, size=n).astype(np.float32)
+        A, R = spatial.fit_affine(p0, p1, return_rigid=True, weight=w, svd_clip=(1, 1), avoid_flip=True)
+        out[f'fa{k}_p0'] = p0; out[f'fa{k}_p1'] = p1; out[f'fa{k}_w'] = w; out[f'fa{k}_A'] = A; out[f'fa{k}_R'] = R
+    # strain chain on a cartesian pair
+    nx, ny, h = 15, 5, 20.0
+    xs = h * np.arange(nx) - 0.5; ys = h * np.arange(ny) - 0.5
+    vx, vy = np.meshgrid(xs, ys)
+    v = np.stack((vx.ravel(), vy.ravel()), axis=-1)
+    idx = np.arange(nx * ny).reshape(ny, nx)
+    a = idx[:-1, :-1].ravel(); b = idx[:-1, 1:].ravel(); c = idx[1:, :-1].ravel(); d = idx[1:, 1:].ravel()
+    tri = np.stack((np.stack((a, b, d), -1), np.stack((a, d, c), -1)), axis=1).reshape(-1, 3)
+    m0 = Mesh(v, tri, uid=0)
+    m0.apply_translation((3.0, -2.0), const.MESH_GEAR_FIXED)
+    m0.lock()
+    m1 = Mesh(v, tri, uid=1)
+    n = 60
+    tid1 = rng.integers(0, tri.shape[0], size=n)
+    B1 = rng.dirichlet((2, 2, 2), size=n)
+    xy1 = m1.bary2cart(tid1, B1, const.MESH_GEAR_INITIAL, offsetting=True)
+    th = 0.01
+    xy0_fixed = (xy1 - xy1.mean(0)) @ np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]]) + xy1.mean(0) + np.array([3.4, -1.7]) \
+        + 0.8 * np.stack((np.sin(xy1[:, 0] / 60.0), np.cos(xy1[:, 1] / 25.0)), -1)
+    # mesh0 points: barycentrics in mesh0 of (xy0_fixed - translation), clipped into the mesh by construction of the field
+    q0 = xy0_fixed - np.array([3.0, -2.0])
+    i = np.clip(np.searchsorted(xs, q0[:, 0], side='right') - 1, 0, nx - 2)
+    j = np.clip(np.searchsorted(ys, q0[:, 1], side='right') - 1, 0, ny - 2)
+    uu = (q0[:, 0] - xs[i]) / h; ww = (q0[:, 1] - ys[j]) / h
+    tid0 = 2 * (j * (nx - 1) + i) + (ww > uu)
+    _, B0 = m0.cart2bary(xy0_fixed, const.MESH_GEAR_FIXED, tid=tid0)
+    w = rng.uniform(0.35, 1.0, size=n).astype(np.float32)
+    link = optimizer.Link(m0, m1, tid0, tid1, B0, B1, weight=w)
+    opt = optimizer.SLM([m0, m1], stiffness_lambda=1.0, assert_dominance=False)
+    opt.add_link(link)
+    opt.optimize_affine_cascade(start_gear=const.MESH_GEAR_INITIAL, target_gear=const.MESH_GEAR_FIXED, svd_clip=(1, 1))
+    out['st_v_fixed'] = m1.vertices(gear=const.MESH_GEAR_FIXED).copy()
+    out['st_off_fixed'] = m1.offset(gear=const.MESH_GEAR_FIXED).copy()
+    opt.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_COPY_EXACT)
+    opt.optimize_linear(tol=1e-11, tolerated_perturbation=None, callback_settings={'chances': None, 'eval_step': 10}, check_converge=True)
+    v0 = m1.vertices(gear=const.MESH_GEAR_FIXED)
+    v1 = m1.vertices(gear=const.MESH_GEAR_MOVING)
+    dv = v1 - v0
+    v0 = v0 - np.mean(v0, axis=0, keepdims=True)
+    dv = dv - np.mean(dv, axis=0, keepdims=True)
+    St, _ = m1.stiffness_matrix()
+    Es = max(0, St.dot(dv.ravel()).dot(dv.ravel()))
+    Es0 = max(0, St.dot(v0.ravel()).dot(v0.ravel()))
+    out.update(st_v=v, st_tri=tri, st_t0=np.array([3.0, -2.0]), st_tid0=tid0, st_B0=B0, st_tid1=tid1, st_B1=B1, st_w=w,
+               st_Es=np.float64(Es), st_Es0=np.float64(Es0), st_strain=np.float64((Es / Es0) ** 0.5), st_v_moving=v1.copy())
+    np.savez_compressed(os.path.join(OUT, 'g13_strain.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain):
         fn()
         print('wrote', fn.__name__)

@@ -43,6 +43,7 @@ def test_pipeline_vs_oracle(fb, H, W, P):
         np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4)
         np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
         np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
+        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=2e-3, atol=1e-7)
     m.free()
 
 
@@ -96,4 +97,38 @@ def test_final_relax_huber_weights_vs_fem_oracle(fb):
         uo, rwo = pipeline_ref.relax_mesh1(W, H, float(np.min(m.spacings)), t0[p], t1[p], xy0[s], xy1[s], wt[s], residue_len=5.0)
         np.testing.assert_allclose(x[p], uo, atol=1e-4)
         np.testing.assert_allclose(rw[s], rwo, atol=1e-5)
+    m.free()
+
+
+def test_strain_estimate_vs_fem_oracle(fb):
+    """matcher.py:752-777 for a batch: rigid initialisation (fit_affine, pinned by golden G13), relaxation, sqrt(Es / Es0),
+    against the oracle's exact chain pair by pair -- matches carry a small rotation and a smooth deformation"""
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    P, H, W = 3, 256, 1024
+    m = StripBatchMatcher(P, H, W)
+    rng = np.random.default_rng(9)
+    txy = np.array([[3.0, -2.0], [-7.0, 4.0], [0.0, 0.0]])
+    pid, xy0, xy1, wt = [], [], [], []
+    for p in range(P):
+        gx, gy = np.meshgrid(np.arange(40, W - 40, 61.0), np.arange(30, H - 30, 47.0))
+        c = np.stack((gx.ravel(), gy.ravel()), -1)
+        if p == 2:
+            c = c[::7]
+        th = 0.004 * (p + 1)
+        Rm = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+        f = (c - c.mean(0)) @ Rm + c.mean(0) - c + 0.6 * np.stack((np.sin(c[:, 0] / 200.0), np.cos(c[:, 1] / 70.0)), -1)
+        pid.append(np.full(c.shape[0], p)); xy0.append(c + 0.5 * f - txy[p]); xy1.append(c - 0.5 * f)
+        wt.append(rng.uniform(0.35, 1.0, c.shape[0]).astype(np.float32))
+    pid = np.concatenate(pid); xy0 = np.concatenate(xy0); xy1 = np.concatenate(xy1); wt = np.concatenate(wt)
+    got = m._strain(pid, xy0, xy1, wt, txy)
+    assert m.last_strain_solve['relres'] < 1e-5
+    for p in range(P):
+        s = pid == p
+        exp = pipeline_ref.strain_estimate(W, H, float(np.min(m.spacings)), txy[p], xy0[s], xy1[s], wt[s])
+        assert exp > 1e-4
+        np.testing.assert_allclose(got[p], exp, rtol=1e-3)
+    # the relaxation of the next batch needs the stiffness at the INITIAL shape again
+    rw, u, x = m._final_relax(pid, xy0 + txy[pid], xy1, wt, np.zeros((P, 2)))
+    uo, rwo = pipeline_ref.relax_mesh1(W, H, float(np.min(m.spacings)), txy[0], np.zeros(2), (xy0 + txy[pid])[pid == 0], xy1[pid == 0], wt[pid == 0], residue_len=5.0)
+    np.testing.assert_allclose(x[0], uo, atol=1e-4)
     m.free()

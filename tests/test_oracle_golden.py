@@ -205,3 +205,30 @@ def test_g12_mixed_materials():
     Kg = _sp(g, 'K', (nd, nd))
     assert abs(K - Kg).max() <= 2e-6 * abs(Kg).max()
     np.testing.assert_allclose(stress, g['stress'], atol=2e-6 * np.abs(g['stress']).max())
+
+
+# ----------------------------------------------------------------------- G13: fit_affine + strain estimate
+@pytest.mark.parametrize('k', [0, 1, 2, 3])
+def test_g13_fit_affine(k):
+    g = load_golden('g13_strain.npz')
+    A, R = fem_ref.fit_affine(g[f'fa{k}_p0'], g[f'fa{k}_p1'], return_rigid=True, weight=g[f'fa{k}_w'], svd_clip=(1, 1), avoid_flip=True)
+    np.testing.assert_allclose(A, g[f'fa{k}_A'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(R, g[f'fa{k}_R'], rtol=0, atol=1e-9)
+
+
+def test_g13_strain_chain():
+    """matcher.py:752-777 on a cartesian pair: cascade -> anneal -> optimize_linear -> sqrt(Es / Es0)"""
+    from oracle import pipeline_ref
+    g = load_golden('g13_strain.npz')
+    m0 = fem_ref.RefMesh(g['st_v'], g['st_tri'], uid=0)
+    m0.apply_translation(g['st_t0'], fem_ref.GEAR_FIXED)
+    m0.locked = True
+    m1 = fem_ref.RefMesh(g['st_v'], g['st_tri'], uid=1)
+    link = fem_ref.RefLink(m0, m1, g['st_tid0'], g['st_tid1'], g['st_B0'], g['st_B1'], weight=g['st_w'])
+    strain, Es, Es0, R = pipeline_ref.strain_from_link(m0, m1, link)
+    np.testing.assert_allclose(m1.vertices(fem_ref.GEAR_FIXED), g['st_v_fixed'], atol=1e-9)
+    np.testing.assert_allclose(m1.offset(fem_ref.GEAR_FIXED), g['st_off_fixed'], atol=1e-9)
+    np.testing.assert_allclose(m1.vertices(fem_ref.GEAR_MOVING), g['st_v_moving'], atol=1e-6)
+    np.testing.assert_allclose(Es0, float(g['st_Es0']), rtol=1e-10)
+    np.testing.assert_allclose(Es, float(g['st_Es']), rtol=1e-6)
+    np.testing.assert_allclose(strain, float(g['st_strain']), rtol=1e-6)
