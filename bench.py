@@ -158,7 +158,7 @@ def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):      # launched by torch.distributed.run
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -193,11 +193,13 @@ def main():
         s0, s1, _ = strips[k]
         b = (i // 2) % (n_res // P)
         res = matchers[(k, (i // 2) % mper)].match(s0.offset(b * P * H * W), s1.offset(b * P * H * W))
+        return k, b, res
+
+    def exchange(i, res):
+        # the one exchange of the sharded run: every rank's match table, gathered over RCCL (feabas_amd/dist.py)
         if dist is not None:
-            # the one exchange of the sharded run: every rank's match table, gathered over RCCL (feabas_amd/dist.py)
             from feabas_amd import dist as fdist
             fdist.gather_match_table(res['pair'], res['xy0'], res['xy1'], res['weight'], pair_offset=(rank * 1000000 + i * P))
-        return k, b, res
 
     def barrier():
         _lib.check(lib.fb_sync(ctx))
@@ -207,21 +209,39 @@ def main():
             torch.cuda.synchronize()
 
     def run_steps(first, count):
-        """`count` steps starting at index `first`; with 2 host threads the LR steps run on one thread and the UD
-        steps on the other, so that one thread's block-list bookkeeping overlaps the other's kernels (the library
-        serialises calls per context; every step still runs completely inside the timed region)"""
+        """`count` steps starting at index `first`, dealt round-robin to the host threads so that one thread's block-list
+        bookkeeping overlaps the others' kernels (the library serialises calls per context; every step runs completely
+        inside the timed region).  Collectives are issued by ONE thread in step order -- the same order on every rank --
+        while the workers go on with later steps."""
         idx = list(range(first, first + count))
+        if not idx:
+            return None
         if args.host_threads <= 1:
-            out = [step(i) for i in idx]
-            return out[-1]
+            out = None
+            for i in idx:
+                out = step(i)
+                exchange(i, out[2])
+            return out
         import threading
         results = {}
+        cv = threading.Condition()
 
         def worker(mine):
             for i in mine:
-                results[i] = step(i)
+                r = step(i)
+                with cv:
+                    results[i] = r
+                    cv.notify_all()
+
+        def comm():
+            for i in idx:
+                with cv:
+                    cv.wait_for(lambda: i in results)
+                    r = results[i]
+                exchange(i, r[2])
         T = max(2, args.host_threads // 2 * 2)
         ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k],)) for k in range(T)]
+        ths.append(threading.Thread(target=comm))
         for t in ths:
             t.start()
         for t in ths:

@@ -16,4 +16,4 @@ print('ms per match() of %d pairs: %.2f' % (P, (time.time() - t0) / 5 * 1e3))
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): m.match(s0.ptr, s1.ptr)
 pr.disable()
-pstats.Stats(pr).sort_stats('tottime').print_stats(22)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(30)
