@@ -78,6 +78,8 @@ _PROTOS = {
     'fb_sys_form_groups': (c_i, [c_p, c_p, c_i, c_d, c_d, c_p]),
     'fb_sys_solve_groups': (c_i, [c_p, c_p, c_i, c_p, c_d, c_d, c_i, c_i, c_p, c_p]),
     'fb_sys_group_energy': (c_i, [c_p, c_p, c_i, c_p, c_p]),
+    'fb_pairs_relax': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_d, c_d, c_d, c_p, c_p, c_p, c_p]),
+    'fb_pairs_strain': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_d, c_i, c_d, c_p, c_p, c_p]),
     'fb_sys_lambda': (c_i, [c_p, c_p, c_d, c_d, C.POINTER(c_d), C.POINTER(c_d)]),
     'fb_sys_form': (c_i, [c_p, c_p, c_d, c_d]),
     'fb_sys_solve': (c_i, [c_p, c_p, c_p, c_i, c_d, c_d, c_i, c_i, C.POINTER(c_i), C.POINTER(c_d)]),

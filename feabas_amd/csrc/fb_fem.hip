@@ -54,6 +54,9 @@ struct fb_system {
     void* d_gstat = nullptr;         // per-group solve statistics (relres f64, iters i32, flag i32)
     int gstat_cap = 0;
     fb_bsr* M = nullptr;             // A + PCG workspace, shares the pattern
+    // host scratch of the batched tile-pair stages (fb_pairs_*)
+    std::vector<int32_t> h_nodes6;
+    std::vector<double> h_bary6, h_B1, h_dxy, h_x;
 };
 
 namespace {
@@ -837,6 +840,125 @@ int fb_sys_info(fb_ctx* ctx, fb_system* s, int64_t* nv, int64_t* nnzb, int64_t* 
     if (nv) *nv = s->nv;
     if (nnzb) *nnzb = s->M ? s->M->nnzb : 0;
     if (nlink) *nlink = s->nlink;
+    return FB_OK;
+}
+
+// ---------------------------------------------------------------------------------- batched tile-pair stages
+// The in-matcher FEM work of a batch of P tile pairs on ONE resident block-diagonal system: P copies of the
+// cartesian mesh of matcher.py:354-359 (nx x ny nodes, cells (a b / c d) split into (a, b, d), (a, d, c)), mesh0
+// locked, so a match touches only the three mesh1 vertices of its triangle.  Host glue in C++ (the per-match
+// bookkeeping is O(K) and would otherwise serialise on the Python interpreter lock of the calling threads).
+namespace {
+// matches -> (nodes6, B1, bary6): Mesh.cart2bary (mesh.py:2191-2217) on the grid reduces to the cell coordinates
+int pairs_build_links(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
+                      const double* xy1_init) {
+    const int V = s->nv / P;
+    if (nx < 2 || ny < 2 || nx * ny != V) return fb_fail(ctx, FB_ERR_ARG, "fb_pairs: grid %d x %d does not match %d vertices per pair", nx, ny, V);
+    s->h_nodes6.resize(6 * (size_t)K);
+    s->h_bary6.resize(6 * (size_t)K);
+    s->h_B1.resize(3 * (size_t)K);
+    for (int64_t k = 0; k < K; ++k) {
+        const int p = pid[k];
+        if (p < 0 || p >= P) return fb_fail(ctx, FB_ERR_ARG, "fb_pairs: pair id %d outside [0, %d)", p, P);
+        const double qx = xy1_init[2 * k], qy = xy1_init[2 * k + 1];
+        int i = (int)(std::upper_bound(xs, xs + nx, qx) - xs) - 1;       // np.searchsorted(side='right') - 1
+        int j = (int)(std::upper_bound(ys, ys + ny, qy) - ys) - 1;
+        i = std::min(std::max(i, 0), nx - 2);
+        j = std::min(std::max(j, 0), ny - 2);
+        const double u = (qx - xs[i]) / (xs[i + 1] - xs[i]), w = (qy - ys[j]) / (ys[j + 1] - ys[j]);
+        const bool up = w > u;
+        const int na = j * nx + i + p * V;
+        int32_t* n6 = &s->h_nodes6[6 * (size_t)k];
+        n6[0] = n6[1] = n6[2] = -1;
+        n6[3] = na; n6[4] = up ? na + nx + 1 : na + 1; n6[5] = up ? na + nx : na + nx + 1;
+        double* b1 = &s->h_B1[3 * (size_t)k];
+        b1[0] = up ? 1.0 - w : 1.0 - u; b1[1] = up ? u : u - w; b1[2] = up ? w - u : w;
+        double* b6 = &s->h_bary6[6 * (size_t)k];
+        b6[0] = 1.0; b6[1] = 0.0; b6[2] = 0.0; b6[3] = -b1[0]; b6[4] = -b1[1]; b6[5] = -b1[2];
+    }
+    return fb_sys_update_links(ctx, s, K, s->h_nodes6.data());
+}
+}  // namespace
+
+// matcher.py:725-737 for a batch: relax every pair's mesh1 against its matches (optimize_linear to rtol), then the
+// huber residue weight L / max(sqrt(max(|r|^2 - sample_err^2, 0)), L) of every match (optimizer.py:174-205).
+// xy0_mov: mesh0 points in the MOVING gear, xy1_init: mesh1 points in its INITIAL gear, t1 [P][2]: mesh1 offsets.
+int fb_pairs_relax(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
+                   const double* xy0_mov, const double* xy1_init, const double* t1, const float* conf, double residue_len, double sample_err,
+                   double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && P > 0 && s->nv % P == 0 && K > 0 && pid && xy0_mov && xy1_init && t1 && conf && rw);
+    int rc = pairs_build_links(ctx, s, P, nx, ny, xs, ys, K, pid, xy1_init);
+    if (rc) return rc;
+    s->h_dxy.resize(2 * (size_t)K);
+    for (int64_t k = 0; k < K; ++k) {                       // Link.dxy (optimizer.py:248-255) in the MOVING gears
+        const int p = pid[k];
+        s->h_dxy[2 * k] = (xy1_init[2 * k] + t1[2 * p]) - xy0_mov[2 * k];
+        s->h_dxy[2 * k + 1] = (xy1_init[2 * k + 1] + t1[2 * p + 1]) - xy0_mov[2 * k + 1];
+    }
+    if ((rc = fb_sys_assemble_links(ctx, s, s->h_bary6.data(), conf, s->h_dxy.data()))) return rc;
+    if ((rc = fb_sys_form_groups(ctx, s, P, stiffness_lambda, -1.0, nullptr))) return rc;
+    s->h_x.resize(2 * (size_t)s->nv);
+    const int V = s->nv / P;
+    rc = fb_sys_solve_groups(ctx, s, P, s->h_x.data(), rtol, 0.0, 20 * V, 1, iters, relres);
+    if (rc && rc != FB_ERR_NOCONV) return rc;
+    for (int64_t k = 0; k < K; ++k) {
+        const int32_t* n6 = &s->h_nodes6[6 * (size_t)k];
+        const double* b1 = &s->h_B1[3 * (size_t)k];
+        double ux = 0.0, uy = 0.0;
+        for (int a = 0; a < 3; ++a) { ux += s->h_x[2 * (size_t)n6[3 + a]] * b1[a]; uy += s->h_x[2 * (size_t)n6[3 + a] + 1] * b1[a]; }
+        const double rx = s->h_dxy[2 * k] + ux, ry = s->h_dxy[2 * k + 1] + uy;
+        const double d2 = rx * rx + ry * ry - sample_err * sample_err;
+        const double dis = std::sqrt(d2 > 0.0 ? d2 : 0.0);
+        rw[k] = (float)(residue_len / std::max(dis, residue_len));
+    }
+    if (x_out) std::copy(s->h_x.begin(), s->h_x.end(), x_out);
+    return FB_OK;
+}
+
+// matcher.py:752-777 for a batch, after the rigid initialisation R [P][3][3] (row vectors: v_fixed = v_initial R[:2,:2],
+// offset R[2,:2]) of every pair's mesh1: relaxation to 1e-6 and strain = sqrt(Es / Es0).  The stiffness of a rotated
+// mesh is Q K Q^T and the link terms are multiples of I2, so the system is solved with the resident K of the INITIAL
+// shape and right-hand sides rotated back by Q^T; es0 = v^T K v of the centred INITIAL mesh (rotation free).
+// links_loaded != 0: the links of the preceding fb_pairs_relax call (same K rows) are reused.
+int fb_pairs_strain(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
+                    const double* xy0_fixed, const double* xy1_init, const float* weight, const double* R, double stiffness_lambda, double es0,
+                    int links_loaded, double default_strain, double* strain, int* iters, double* relres) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && P > 0 && s->nv % P == 0 && K > 0 && pid && xy0_fixed && xy1_init && weight && R && strain && es0 > 0.0);
+    int rc;
+    if (!links_loaded || s->nlink != K || (int64_t)s->h_B1.size() != 3 * K) {
+        if ((rc = pairs_build_links(ctx, s, P, nx, ny, xs, ys, K, pid, xy1_init))) return rc;
+    }
+    s->h_dxy.resize(2 * (size_t)K);
+    std::vector<char> has((size_t)P, 0);
+    for (int64_t k = 0; k < K; ++k) {
+        const int p = pid[k];
+        FB_CHECK_ARG(ctx, p >= 0 && p < P);
+        has[p] = 1;
+        const double* r = R + 9 * (size_t)p;                 // r[0] r[1] / r[3] r[4] = 2x2, r[6] r[7] = offset
+        const double x1 = xy1_init[2 * k], y1 = xy1_init[2 * k + 1];
+        const double fx = x1 * r[0] + y1 * r[3] + r[6] - xy0_fixed[2 * k];        // Mesh.set_affine on the match point, minus mesh0's
+        const double fy = x1 * r[1] + y1 * r[4] + r[7] - xy0_fixed[2 * k + 1];
+        s->h_dxy[2 * k] = fx * r[0] + fy * r[1];                                   // Q^T f
+        s->h_dxy[2 * k + 1] = fx * r[3] + fy * r[4];
+    }
+    if ((rc = fb_sys_assemble_links(ctx, s, s->h_bary6.data(), weight, s->h_dxy.data()))) return rc;
+    if ((rc = fb_sys_form_groups(ctx, s, P, stiffness_lambda, -1.0, nullptr))) return rc;
+    s->h_x.resize(2 * (size_t)s->nv);
+    const int V = s->nv / P;
+    rc = fb_sys_solve_groups(ctx, s, P, s->h_x.data(), 1e-6, 0.0, 20 * V, 1, iters, relres);
+    if (rc && rc != FB_ERR_NOCONV) return rc;
+    for (int p = 0; p < P; ++p) {                           // Mesh.set_field keeps the mean in the offset (mesh.py:2409-2413)
+        double mx = 0.0, my = 0.0;
+        double* x = &s->h_x[2 * (size_t)p * V];
+        for (int v = 0; v < V; ++v) { mx += x[2 * v]; my += x[2 * v + 1]; }
+        mx /= V; my /= V;
+        for (int v = 0; v < V; ++v) { x[2 * v] -= mx; x[2 * v + 1] -= my; }
+    }
+    std::vector<double> es((size_t)P);
+    if ((rc = fb_sys_group_energy(ctx, s, P, s->h_x.data(), es.data()))) return rc;
+    for (int p = 0; p < P; ++p) strain[p] = has[p] ? std::sqrt(std::max(es[p], 0.0) / es0) : default_strain;
     return FB_OK;
 }
 

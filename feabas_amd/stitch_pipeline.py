@@ -232,75 +232,32 @@ class StripBatchMatcher:
                                                     m.poisson_ratio, 1.0))
         self._k_state = state
 
-    def _links(self, pid, q1):
-        """matches at mesh1 coordinates q1 (INITIAL gear) of pairs pid -> dict(nodes6 [K, 6], B1 [K, 3], bary6 [K, 6]).
-        On the cartesian grid (cells (a b / c d) split into (a, b, d), (a, d, c), Mesh.from_bbox) point location and
-        Mesh.cart2bary (mesh.py:2191-2217) reduce to the cell coordinates (u, w) of the point: (1 - u, u - w, w) in the
-        lower triangle, (1 - w, u, w - u) in the upper one."""
-        m = self._mesh
-        V = m.num_vertices
-        xs, ys = m.grid_xs, m.grid_ys
-        nx = xs.size
-        i = np.clip(np.searchsorted(xs, q1[:, 0], side='right') - 1, 0, nx - 2)
-        j = np.clip(np.searchsorted(ys, q1[:, 1], side='right') - 1, 0, ys.size - 2)
-        u = (q1[:, 0] - xs[i]) / (xs[i + 1] - xs[i])
-        w = (q1[:, 1] - ys[j]) / (ys[j + 1] - ys[j])
-        up = w > u
-        na = j * nx + i + pid * V                              # a; b = a + 1, c = a + nx, d = a + nx + 1
-        K = pid.size
-        nodes6 = np.full((K, 6), -1, dtype=np.int32)
-        nodes6[:, 3] = na
-        nodes6[:, 4] = np.where(up, na + nx + 1, na + 1)
-        nodes6[:, 5] = np.where(up, na + nx, na + nx + 1)
-        B1 = np.empty((K, 3))
-        B1[:, 0] = np.where(up, 1.0 - w, 1.0 - u)
-        B1[:, 1] = np.where(up, u, u - w)
-        B1[:, 2] = np.where(up, w - u, w)
-        bary6 = np.zeros((K, 6))
-        bary6[:, 0] = 1.0                                     # locked side: not used by the assembly
-        bary6[:, 3:] = -B1
-        return dict(nodes6=nodes6, B1=B1, bary6=bary6, loaded=False)
-
-    def _solve_links(self, links, wt, dxy, tol):
-        """assemble the links, form every pair's system with its own lambda, solve all pairs -> vertex field [P V, 2]"""
+    def _final_relax(self, pid, xy0, xy1, wt, t1):
+        """matcher.py:725-737 for every pair of the batch at once (fb_pairs_relax): relax mesh1 against the last-round
+        links (optimize_linear, to the fixed point), then huber residue weights (optimizer.py:174-191, 203-205).
+        pid [K]; xy0/xy1 [K, 2] in the MOVING gear; wt [K] confidences; t1 [P, 2] mesh1 offsets.
+        Returns the residue weight [K] float32 and the displacement of every mesh1 vertex [P, V, 2]."""
         lib, ctx = _lib.load(), _lib.ctx()
-        sysh = self._relax_sys
-        V = self._mesh.num_vertices
-        w32 = np.ascontiguousarray(wt, dtype=np.float32)
-        dxy = np.ascontiguousarray(dxy, dtype=np.float64)
-        nodes6, bary6 = links['nodes6'], links['bary6']
-        if not links['loaded']:                                # the vertex -> match index of the resident system follows the links
-            _lib.check(lib.fb_sys_update_links(ctx, sysh, nodes6.shape[0], _lib.ptr(nodes6)))
-            links['loaded'] = True
-        _lib.check(lib.fb_sys_assemble_links(ctx, sysh, _lib.ptr(bary6), _lib.ptr(w32), _lib.ptr(dxy)))
-        _lib.check(lib.fb_sys_form_groups(ctx, sysh, self.P, self.stiffness_lambda, -1.0, None))
-        x = np.zeros(2 * self.P * V, dtype=np.float64)
-        iters, relres = C.c_int(), C.c_double()
-        _lib.check(lib.fb_sys_solve_groups(ctx, sysh, self.P, _lib.ptr(x), tol, 0.0, 20 * V, 1, C.byref(iters), C.byref(relres)),
-                   allow=(_lib.FB_ERR_NOCONV,))
-        return x.reshape(-1, 2), dict(iters=iters.value, relres=relres.value, matches=int(nodes6.shape[0]))
-
-    def _final_relax(self, pid, xy0, xy1, wt, t1, links=None):
-        """matcher.py:725-737 for every pair of the batch at once: relax mesh1 against the last-round links
-        (optimize_linear, to the fixed point), then huber residue weights (optimizer.py:174-191, 203-205).
-        pid [K] sorted or not; xy0/xy1 [K, 2] in the MOVING gear; wt [K] confidences; t1 [P, 2] mesh1 offsets.
-        Returns the residue weight [K] float32, the displacement of the mesh1 end of each match and of every
-        mesh1 vertex [P, V, 2]."""
-        self._relax_system()
+        sysh = self._relax_system()
         m = self._mesh
-        V = m.num_vertices
-        if links is None:
-            links = self._links(pid, xy1 - t1[pid])           # mesh1 coordinates without its offset
-        dxy = xy1 - xy0                                       # Link.dxy (optimizer.py:248-255)
-        x, self.last_relax = self._solve_links(links, wt, dxy, self.relax_tol)
-        u = np.sum(x[links['nodes6'][:, 3:]] * links['B1'][:, :, None], axis=1)            # displacement of the mesh1 end of each match
-        res = dxy + u
-        dis2 = np.sum(res ** 2, axis=-1)
+        V, K = m.num_vertices, pid.size
+        pid32 = np.ascontiguousarray(pid, dtype=np.int32)
+        xy0c = np.ascontiguousarray(xy0, dtype=np.float64)
+        xy1i = np.ascontiguousarray(xy1 - t1[pid], dtype=np.float64)             # mesh1 coordinates without its offset
+        t1c = np.ascontiguousarray(t1, dtype=np.float64)
+        w32 = np.ascontiguousarray(wt, dtype=np.float32)
+        rw = np.empty(K, dtype=np.float32)
+        x = np.empty(2 * self.P * V, dtype=np.float64)
+        iters, relres = C.c_int(), C.c_double()
         area = float(np.abs(m.triangle_areas(const.MESH_GEAR_INITIAL)[0]))
         sample_err = 0.4387 * area ** 0.5 * DEFAULT_AVG_DEFORM          # optimizer.py:26-30, equal triangles on both sides
-        dis = np.sqrt(np.clip(dis2 - sample_err ** 2, 0, None))
-        L = self.residue_len
-        return (L / np.maximum(dis, L)).astype(np.float32), u, x.reshape(self.P, V, 2)
+        _lib.check(lib.fb_pairs_relax(ctx, sysh, self.P, m.grid_xs.size, m.grid_ys.size, _lib.ptr(m.grid_xs), _lib.ptr(m.grid_ys), K,
+                                      _lib.ptr(pid32), _lib.ptr(xy0c), _lib.ptr(xy1i), _lib.ptr(t1c), _lib.ptr(w32), self.residue_len,
+                                      sample_err, self.stiffness_lambda, self.relax_tol, _lib.ptr(rw), _lib.ptr(x),
+                                      C.byref(iters), C.byref(relres)))
+        self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K))
+        self._links_rows = (K, pid32, xy1i)                   # what the links resident in the system were built from
+        return rw, x.reshape(self.P, V, 2)
 
     def _rigid_fits(self, pid, p0, p1, wt):
         """spatial.fit_affine(p0, p1, return_rigid=True, weight, svd_clip=(1, 1)) for every pair at once.  One pass
@@ -363,43 +320,35 @@ class StripBatchMatcher:
             R[p] = fit_affine(p0[s], p1[s], return_rigid=True, weight=wt[s], svd_clip=(1, 1), avoid_flip=True)[1]
         return R
 
-    def _strain(self, pid, xy0, xy1, wt, txy, links=None):
+    def _strain(self, pid, xy0, xy1, wt, txy, reuse_links=False):
         """matcher.py:752-777 for every pair of the batch: fresh mesh pair, rigid initialisation of mesh1 from the
-        final matches (optimize_affine_cascade, svd_clip (1, 1)), anneal, optimize_linear(tol=1e-6), strain =
-        sqrt(Es / Es0) with the stiffness of mesh1 at its rigidly placed shape.  pid/xy0/xy1/wt: the final match table
-        (INITIAL gears), rows of a pair contiguous; txy [P, 2] translation of the locked mesh0.  Returns strain [P]
-        (DEFAULT_AVG_DEFORM where a pair has no match).
-
-        The stiffness of the rotated mesh is Q K Q^T (Q = the rotation on every vertex) and the link terms are
-        multiples of I2, so the relaxed field of the rotated pair is the rotation of the field that
-        (ls K + C) x' = Q^T b gives with the stiffness K of the INITIAL shape: the batch reuses the resident K and
-        rotates only right-hand sides; Es = x'^T K x' and Es0 = v_initial^T K v_initial (centred) are rotation free."""
+        final matches (optimize_affine_cascade, svd_clip (1, 1); host, `_rigid_fits`), anneal, optimize_linear(tol=1e-6),
+        strain = sqrt(Es / Es0) with the stiffness of mesh1 at its rigidly placed shape (fb_pairs_strain).
+        pid/xy0/xy1/wt: the final match table (INITIAL gears), rows of a pair contiguous; txy [P, 2] translation of the
+        locked mesh0.  Returns strain [P] (DEFAULT_AVG_DEFORM where a pair has no match).  reuse_links: the table is
+        row for row the one the preceding `_final_relax` call was given."""
         lib, ctx = _lib.load(), _lib.ctx()
-        self._relax_system()
+        sysh = self._relax_system()
         m = self._mesh
-        V, P = m.num_vertices, self.P
-        strain = np.full(P, DEFAULT_AVG_DEFORM)
+        P = self.P
         if pid.size == 0:
-            return strain
+            return np.full(P, DEFAULT_AVG_DEFORM)
         nseg = 1 + int(np.count_nonzero(np.diff(pid) != 0))
         if nseg != int(np.count_nonzero(np.bincount(pid, minlength=P))):          # rows of a pair not contiguous
             o = np.argsort(pid, kind='stable')
             pid, xy0, xy1, wt = pid[o], xy0[o], xy1[o], wt[o]
-            links = None
-        p0 = xy0 + txy[pid]                                    # mesh0 points, FIXED gear
-        R = self._rigid_fits(pid, p0, xy1, wt)
-        R2 = R[:, :2, :2]
-        if links is None:
-            links = self._links(pid, xy1)
-        xy1_f = np.einsum('ki,kij->kj', xy1, R2[pid]) + R[pid, 2, :2]             # Mesh.set_affine (mesh.py:2342-2354) on the match points
-        dxy_back = np.einsum('kj,kij->ki', xy1_f - p0, R2[pid])                    # Q^T applied to the link residuals
-        x, self.last_strain_solve = self._solve_links(links, wt, dxy_back, 1e-6)
-        dd = x.reshape(P, V, 2)
-        dv = dd - dd.mean(axis=1, keepdims=True)               # Mesh.set_field keeps the mean in the offset (mesh.py:2409-2413)
-        Es = np.empty(P)
-        _lib.check(lib.fb_sys_group_energy(ctx, self._relax_sys, P, _lib.ptr(np.ascontiguousarray(dv.reshape(-1, 2))), _lib.ptr(Es)))
-        has = np.bincount(pid, minlength=P) > 0
-        strain[has] = np.sqrt(np.maximum(Es[has], 0.0) / self._es0)
+            reuse_links = False
+        p0 = np.ascontiguousarray(xy0 + txy[pid], dtype=np.float64)              # mesh0 points, FIXED gear
+        xy1c = np.ascontiguousarray(xy1, dtype=np.float64)
+        w32 = np.ascontiguousarray(wt, dtype=np.float32)
+        R = np.ascontiguousarray(self._rigid_fits(pid, p0, xy1c, w32))
+        pid32 = np.ascontiguousarray(pid, dtype=np.int32)
+        strain = np.empty(P)
+        iters, relres = C.c_int(), C.c_double()
+        _lib.check(lib.fb_pairs_strain(ctx, sysh, P, m.grid_xs.size, m.grid_ys.size, _lib.ptr(m.grid_xs), _lib.ptr(m.grid_ys), pid.size,
+                                       _lib.ptr(pid32), _lib.ptr(p0), _lib.ptr(xy1c), _lib.ptr(w32), _lib.ptr(R), self.stiffness_lambda,
+                                       self._es0, 1 if reuse_links else 0, DEFAULT_AVG_DEFORM, _lib.ptr(strain), C.byref(iters), C.byref(relres)))
+        self.last_strain_solve = dict(iters=iters.value, relres=relres.value, matches=int(pid.size))
         return strain
 
     # ------------------------------------------------------------------ driver
@@ -472,9 +421,8 @@ class StripBatchMatcher:
                     # that the strain estimate below can reuse the same links
                     pid_l, xy0_l, xy1i_l, wt_l, xy1_l, rl = table
                     if rl.any():
-                        self._relax_system()
-                        last_links = self._links(pid_l, xy1i_l)
-                        rw, _, _ = self._final_relax(pid_l, xy0_l, xy1_l, wt_l, t1, links=last_links)
+                        rw, _ = self._final_relax(pid_l, xy0_l, xy1_l, wt_l, t1)
+                        last_links = True
                         wt_new = wt_l.copy()
                         wt_new[rl] = wt_l[rl] * rw[rl]                             # Link.weight (optimizer.py:313-317)
                         table = table[:3] + (wt_new,) + table[4:]
@@ -496,7 +444,7 @@ class StripBatchMatcher:
             last_links = None
         # output in the INITIAL gear: mesh0 points lose the translation (matcher.py:748-751)
         xy0 = xy0 - txy[pid]
-        strain = self._strain(pid, xy0, xy1, wt, txy, links=last_links) if self.compute_strain else np.full(n, DEFAULT_AVG_DEFORM)
+        strain = self._strain(pid, xy0, xy1, wt, txy, reuse_links=bool(last_links)) if self.compute_strain else np.full(n, DEFAULT_AVG_DEFORM)
         return dict(tx=tx, ty=ty, conf0=cf0, valid=valid, needs_host=needs_host, pair=pid, xy0=xy0, xy1=xy1, weight=wt, strain=strain)
 
     @staticmethod

@@ -186,6 +186,18 @@ int fb_sys_solve_groups(fb_ctx* ctx, fb_system* sys, int ngroups, double* x, dou
 /* x^T K x per equal vertex range (K of the last fb_sys_assemble_mesh*): Es and Es0 of the strain estimate,
  * matcher.py:764-777.  x: host [2 nv], energy: host [ngroups]. */
 int fb_sys_group_energy(fb_ctx* ctx, fb_system* sys, int ngroups, const double* x, double* energy);
+/* ---- batched tile-pair stages (the FEM work inside matcher.iterative_xcorr_matcher_w_mesh for P pairs at once).
+ * sys: P copies of the cartesian mesh of matcher.py:354-359 (nx x ny nodes at xs, ys; cells (a b / c d) split into
+ * (a, b, d), (a, d, c)) entered as one mesh, no links at finalize; mesh0 of every pair is locked.
+ * fb_pairs_relax  : matcher.py:725-737 -- optimize_linear of every pair against its K matches, then the huber residue
+ *                   weight rw[K] of every match (optimizer.py:174-205).  x_out (nullable): vertex field [2 nv].
+ * fb_pairs_strain : matcher.py:752-777 after the rigid fit R [P][3][3] of every pair (spatial.fit_affine, host). */
+int fb_pairs_relax(fb_ctx* ctx, fb_system* sys, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
+                   const double* xy0_moving, const double* xy1_initial, const double* t1, const float* conf, double residue_len,
+                   double sample_err, double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres);
+int fb_pairs_strain(fb_ctx* ctx, fb_system* sys, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
+                    const double* xy0_fixed, const double* xy1_initial, const float* weight, const double* R, double stiffness_lambda,
+                    double es0, int links_loaded, double default_strain, double* strain, int* iters, double* relres);
 int fb_sys_lambda(fb_ctx* ctx, fb_system* sys, double stiffness_lambda, double crosslink_lambda, double* sl_out, double* cl_out);
 int fb_sys_form(fb_ctx* ctx, fb_system* sys, double sl, double cl);
 /* x: [2 nv] float64, x0 on entry when use_x0.  maxiter < 0: until converged, 0: zeros, > 0: cap */

@@ -89,7 +89,7 @@ def test_final_relax_huber_weights_vs_fem_oracle(fb):
         wt.append(rng.uniform(0.35, 1.0, c.shape[0]).astype(np.float32))
     order = rng.permutation(sum(a.size for a in pid))                   # rows of a pair need not be contiguous
     pid = np.concatenate(pid)[order]; xy0 = np.concatenate(xy0)[order]; xy1 = np.concatenate(xy1)[order]; wt = np.concatenate(wt)[order]
-    rw, u, x = m._final_relax(pid, xy0, xy1, wt, t1)
+    rw, x = m._final_relax(pid, xy0, xy1, wt, t1)
     assert m.last_relax['relres'] < 1e-8
     assert rw.min() < 0.6 and (rw == 1).sum() > rw.size // 2            # outliers damped, inliers untouched
     for p in range(P):
@@ -128,7 +128,7 @@ def test_strain_estimate_vs_fem_oracle(fb):
         assert exp > 1e-4
         np.testing.assert_allclose(got[p], exp, rtol=1e-3)
     # the relaxation of the next batch needs the stiffness at the INITIAL shape again
-    rw, u, x = m._final_relax(pid, xy0 + txy[pid], xy1, wt, np.zeros((P, 2)))
+    rw, x = m._final_relax(pid, xy0 + txy[pid], xy1, wt, np.zeros((P, 2)))
     uo, rwo = pipeline_ref.relax_mesh1(W, H, float(np.min(m.spacings)), txy[0], np.zeros(2), (xy0 + txy[pid])[pid == 0], xy1[pid == 0], wt[pid == 0], residue_len=5.0)
     np.testing.assert_allclose(x[0], uo, atol=1e-4)
     m.free()
