@@ -36,7 +36,8 @@ def parse():
     ap.add_argument('--pairs-per-step', type=int, default=64)
     ap.add_argument('--resident-pairs', type=int, default=1024)
     ap.add_argument('--tile', type=int, default=4096)
-    ap.add_argument('--host-threads', type=int, default=4, help='host threads driving the device (even; steps are dealt round-robin, LR and UD batches alternate)')
+    ap.add_argument('--host-threads', type=int, default=8, help='host threads driving the device (even; steps are dealt round-robin, LR and UD batches alternate)')
+    ap.add_argument('--multi-stream', type=int, default=1, help='1: one context (HIP stream) per host thread; 0: all threads share one stream')
     ap.add_argument('--no-fem', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fem-grid', type=int, default=708)
@@ -201,8 +202,14 @@ def main():
             from feabas_amd import dist as fdist
             fdist.gather_match_table(res['pair'], res['xy0'], res['xy1'], res['weight'], pair_offset=(rank * 1000000 + i * P))
 
+    # every host thread drives the device through its own context (stream): a thread's synchronisation then waits for
+    # its own kernels only, and kernels of different batches may overlap on the device
+    nthr = max(2, args.host_threads // 2 * 2) if args.host_threads > 1 else 1
+    ctxs = [ctx] + [_lib.new_context(local_rank) for _ in range(nthr - 1)] if args.multi_stream and nthr > 1 else [ctx]
+
     def barrier():
-        _lib.check(lib.fb_sync(ctx))
+        for h in ctxs:
+            _lib.check(lib.fb_sync(h))
         if dist is not None:
             torch.cuda.synchronize()
             dist.barrier()
@@ -226,7 +233,8 @@ def main():
         results = {}
         cv = threading.Condition()
 
-        def worker(mine):
+        def worker(mine, h):
+            _lib.use_context(h)
             for i in mine:
                 r = step(i)
                 with cv:
@@ -239,8 +247,8 @@ def main():
                     cv.wait_for(lambda: i in results)
                     r = results[i]
                 exchange(i, r[2])
-        T = max(2, args.host_threads // 2 * 2)
-        ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k],)) for k in range(T)]
+        T = nthr
+        ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k], ctxs[k % len(ctxs)])) for k in range(T)]
         ths.append(threading.Thread(target=comm))
         for t in ths:
             t.start()
@@ -255,13 +263,30 @@ def main():
         m.match(strips[k][0].ptr, strips[k][1].ptr)
     run_steps(0, args.warmup)
     barrier()
-    _lib.check(lib.fb_prof_reset(ctx)); _lib.check(lib.fb_prof_enable(ctx, 1))
+    for h in ctxs:
+        _lib.check(lib.fb_prof_reset(h)); _lib.check(lib.fb_prof_enable(h, 1))
     t0 = time.time()
     last = run_steps(args.warmup, args.steps)
     barrier()
     dt = time.time() - t0
-    _lib.check(lib.fb_prof_enable(ctx, 0))
-    prof = _lib.prof_snapshot()
+    prof_timed = {}
+    for h in ctxs:
+        _lib.check(lib.fb_prof_enable(h, 0))
+        for k_, v in _lib.prof_snapshot(h).items():
+            o = prof_timed.get(k_, (0, 0.0, 0.0))
+            prof_timed[k_] = (o[0] + v[0], o[1] + v[1], o[2] + v[2])
+    prof = prof_timed
+    iso_steps = 0
+    if len(ctxs) > 1:
+        # With one stream per host thread the kernels of different batches overlap on the device, so the event durations
+        # taken inside the timed region are not per-kernel costs.  The roofline numbers come from a few more steps of the
+        # same workload issued on ONE stream (nothing else on the device), after the timed region.
+        iso_steps = 4
+        _lib.check(lib.fb_prof_reset(ctx)); _lib.check(lib.fb_prof_enable(ctx, 1))
+        for i in range(iso_steps):
+            step(args.warmup + args.steps + i)
+        _lib.check(lib.fb_sync(ctx)); _lib.check(lib.fb_prof_enable(ctx, 0))
+        prof = _lib.prof_snapshot(ctx)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -288,7 +313,12 @@ def main():
                 pipeline_algorithmic_bytes_per_pair=pair_bytes,
                 pipeline_achieved_gbs=pair_bytes * pairs / world / dt / 1e9,
                 pipeline_frac=pair_bytes * pairs / world / dt / 1e9 / HBM_PEAK_GBS,
-                kernel_ms={k_: round(v[1], 3) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
+                kernel_ms={k_: round(v[1], 3) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+                kernel_ms_steps=(iso_steps if iso_steps else args.steps),
+                measured_on=(f'{iso_steps} extra steps of the same workload on one stream after the timed region (the timed region runs one '
+                             f'stream per host thread: its kernels overlap, event sum {sum(v[1] for v in prof_timed.values()) / max(args.steps, 1):.2f} '
+                             f'ms per step against {1e3 * dt / max(args.steps, 1):.2f} ms wall); --multi-stream 0 times the kernels inside the timed region'
+                             if iso_steps else 'the timed region (one stream)'))
     if dom[1][0] > 0 and dom[1][2] > 0:
         # algorithmic bytes of the kernel's launches (accounted by the library from the launch shapes)
         # over their summed duration (HIP events on the context stream around every launch)

@@ -6,6 +6,7 @@ __graft_entry__ as g; g.build()"`` or ``make -C feabas_amd/csrc``.
 """
 import ctypes as C
 import os
+import threading
 import re
 
 import numpy as np
@@ -120,9 +121,34 @@ def load():
     return lib
 
 
+_tls = threading.local()
+
+
+def new_context(device=None):
+    """An additional context on the process's device: its own HIP stream, scratch arena and event profile.  Host
+    threads that drive the device concurrently use one each (``use_context``) so that a thread's synchronisation waits
+    only for its own work."""
+    lib = load()
+    if device is None:
+        device = _ctx_device if _ctx_device is not None else int(os.environ.get('FEABAS_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    h = lib.fb_create(device)
+    if not h:
+        raise RuntimeError(f'fb_create({device}) failed')
+    return h
+
+
+def use_context(h):
+    """Make `h` the calling thread's current context (None: back to the process context)."""
+    _tls.ctx = h
+
+
 def ctx(device=None):
-    """The per-process context (one GPU per process; LOCAL_RANK picks the device)."""
+    """The current context: the calling thread's (``use_context``) or the per-process one (one GPU per process;
+    LOCAL_RANK picks the device)."""
     global _ctx, _ctx_device
+    h = getattr(_tls, 'ctx', None)
+    if h is not None and device is None:
+        return h
     lib = load()
     if device is None:
         device = int(os.environ.get('FEABAS_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
@@ -142,7 +168,7 @@ def ctx(device=None):
 
 def check(rc, allow=()):
     if rc != 0 and rc not in allow:
-        msg = load().fb_last_error(_ctx)
+        msg = load().fb_last_error(ctx())
         raise FeabasHipError(rc, msg.decode() if msg else '?')
     return rc
 
@@ -190,16 +216,17 @@ class DeviceBuffer:
         self.ptr = None
 
 
-def prof_snapshot():
-    """{kernel name: (launches, total ms, total algorithmic bytes)} from the library's event profile."""
+def prof_snapshot(h=None):
+    """{kernel name: (launches, total ms, total algorithmic bytes)} from the event profile of context h (default: current)."""
     lib = load()
     out = {}
-    n = lib.fb_prof_count(ctx())
+    h = ctx() if h is None else h
+    n = lib.fb_prof_count(h)
     name = C.create_string_buffer(128)
     launches = c_i()
     ms = c_d()
     nbytes = c_d()
     for i in range(n):
-        check(lib.fb_prof_get(ctx(), i, name, 128, C.byref(launches), C.byref(ms), C.byref(nbytes)))
+        check(lib.fb_prof_get(h, i, name, 128, C.byref(launches), C.byref(ms), C.byref(nbytes)))
         out[name.value.decode()] = (launches.value, ms.value, nbytes.value)
     return out

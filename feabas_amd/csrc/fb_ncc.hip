@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -645,6 +646,8 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_inv(const StreamGeo
 std::map<std::pair<int, int>, std::pair<float2*, float2*>> g_split_tables;
 
 int get_split_table(fb_ctx* ctx, int n, const float2** hi, const float2** lo) {
+    static std::mutex mtx;                      // process-wide table shared by every context of the device
+    std::lock_guard<std::mutex> lk(mtx);
     auto key = std::make_pair(ctx->device, n);
     auto it = g_split_tables.find(key);
     if (it == g_split_tables.end()) {
@@ -666,6 +669,8 @@ int get_split_table(fb_ctx* ctx, int n, const float2** hi, const float2** lo) {
 // tw[i] = exp(-2 pi i / n), i < n / 16 (the twiddle bases of the power-of-two core, fb_fft2.h)
 std::map<std::pair<int, int>, float2*> g_tw16_tables;
 int get_tw16_table(fb_ctx* ctx, int n, const float2** tw) {
+    static std::mutex mtx;                      // process-wide table shared by every context of the device
+    std::lock_guard<std::mutex> lk(mtx);
     auto key = std::make_pair(ctx->device, n);
     auto it = g_tw16_tables.find(key);
     if (it == g_tw16_tables.end()) {

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -273,6 +274,8 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
 std::map<std::pair<int, int>, float2*> g_tables;
 
 int get_table(fb_ctx* ctx, int n, const float2** out) {
+    static std::mutex mtx;                      // process-wide table shared by every context of the device
+    std::lock_guard<std::mutex> lk(mtx);
     auto key = std::make_pair(ctx->device, n);
     auto it = g_tables.find(key);
     if (it == g_tables.end()) {
