@@ -757,7 +757,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
         if (rc) return rc;
         const size_t pw = (size_t)(Fw + Fw / 16 + 1), ph = (size_t)(Fh + Fh / 16 + 1);
         lds_rows2 = ((size_t)g.TR * pw + Fw / 16) * sizeof(float2);
-        lds_cols2 = (4 * ph + Fh / 16) * sizeof(float2);
+        lds_cols2 = (4 * (size_t)p2_np(Fh) * ph + Fh / 16) * sizeof(float2);
         lds_inv2 = ((size_t)g.TRI * pw + Fw / 16) * sizeof(float2);
         lds_n2 = ((size_t)4 * pw + Fw / 16) * sizeof(float2);
         q.lTRI = 0;
@@ -774,7 +774,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     {
         FB_PROF_B(ctx, "ncc_stream_cols", (double)nb * g.Sw * (16.0 * g.Hs + 8.0 * nq * Fh));
         if (p2) {
-            q.tiles = g.Kp; q.total = g.Kp * nb;
+            q.tiles = (g.Kp + p2_np(Fh) - 1) / p2_np(Fh); q.total = q.tiles * nb;       // groups of column pairs
             FB_P2_SWITCH(Fh, cols(ctx->stream, std::min(q.total, wg_slots), lds_cols2, g, q, T0, T1, V0, V1));
         } else hipLaunchKernelGGL(ncc_stream_cols, dim3(g.Kp, nb), dim3(kStreamThreads), lds_cols, ctx->stream, g, T0, T1, V0, V1);
     }
