@@ -132,3 +132,32 @@ def test_strain_estimate_vs_fem_oracle(fb):
     uo, rwo = pipeline_ref.relax_mesh1(W, H, float(np.min(m.spacings)), txy[0], np.zeros(2), (xy0 + txy[pid])[pid == 0], xy1[pid == 0], wt[pid == 0], residue_len=5.0)
     np.testing.assert_allclose(x[0], uo, atol=1e-4)
     m.free()
+
+
+def test_contexts_per_thread_give_identical_results(fb):
+    """two host threads, each with its own context (HIP stream, arena), run the same batch concurrently: bitwise the same
+    match table as the process context (shared twiddle tables are built under a lock, kernels are deterministic)"""
+    import threading
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    P, H, W = 4, 1024, 256
+    s0, s1, shifts = _synth(fb, P, H, W, seed=21, max_shift=9)
+    ref = StripBatchMatcher(P, H, W)
+    want = ref.match(s0.ptr, s1.ptr)
+    out = {}
+
+    def work(k):
+        _lib.use_context(_lib.new_context())
+        m = StripBatchMatcher(P, H, W)
+        for _ in range(3):
+            out[k] = m.match(s0.ptr, s1.ptr)
+        m.free()
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for k in range(2):
+        for key in ('tx', 'ty', 'conf0', 'pair', 'xy0', 'xy1', 'weight', 'strain'):
+            np.testing.assert_array_equal(out[k][key], want[key])
+    ref.free()
