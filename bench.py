@@ -257,10 +257,22 @@ def main():
         return results[idx[-1]]
 
     # one-time set-up outside the step count: every matcher instance builds its resident relaxation system, twiddle
-    # tables and scratch arena on its first batch (lazy), so each is run once before the W warm-up steps
-    for (k, j), m in matchers.items():
-        H, W = shapes[k]
-        m.match(strips[k][0].ptr, strips[k][1].ptr)
+    # tables and scratch arena on its first batch (lazy), and every context allocates its arena on first use -- so each
+    # host thread runs its own matcher once on its own context before the W warm-up steps
+    def setup_thread(k):
+        if len(ctxs) > 1:
+            _lib.use_context(ctxs[k % len(ctxs)])
+        step(k)
+    if nthr > 1:
+        import threading
+        sts = [threading.Thread(target=setup_thread, args=(k,)) for k in range(nthr)]
+        for t in sts:
+            t.start()
+        for t in sts:
+            t.join()
+    else:
+        step(0); step(1)
+    barrier()
     run_steps(0, args.warmup)
     barrier()
     for h in ctxs:
@@ -315,9 +327,12 @@ def main():
                 pipeline_frac=pair_bytes * pairs / world / dt / 1e9 / HBM_PEAK_GBS,
                 kernel_ms={k_: round(v[1], 3) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
                 kernel_ms_steps=(iso_steps if iso_steps else args.steps),
+                avg_launch_ms_timed_region=(prof_timed[dom[0]][1] / max(prof_timed[dom[0]][0], 1) if dom[0] in prof_timed else None),
                 measured_on=(f'{iso_steps} extra steps of the same workload on one stream after the timed region (the timed region runs one '
                              f'stream per host thread: its kernels overlap, event sum {sum(v[1] for v in prof_timed.values()) / max(args.steps, 1):.2f} '
-                             f'ms per step against {1e3 * dt / max(args.steps, 1):.2f} ms wall); --multi-stream 0 times the kernels inside the timed region'
+                             f'ms per step against {1e3 * dt / max(args.steps, 1):.2f} ms wall -- avg_launch_ms_timed_region is that overlapped duration and is what '
+                             f'rocprofv3 --stats of this command reports, profiles/*_bench_kernel_stats.csv); --multi-stream 0 times the kernels inside '
+                             f'the timed region (profiles/*_bench_one_stream_kernel_stats.csv)'
                              if iso_steps else 'the timed region (one stream)'))
     if dom[1][0] > 0 and dom[1][2] > 0:
         # algorithmic bytes of the kernel's launches (accounted by the library from the launch shapes)
