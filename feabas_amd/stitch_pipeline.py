@@ -13,8 +13,9 @@ Per pair, in the reference's order:
                                                             fb_ncc_blocks_dev
   6. last-round mesh relaxation + huber residue weights (725-737) and the strain estimate (752-777)
      for the whole batch as one block-diagonal system             fb_sys_update_links / _form_groups / _solve_groups
-What is NOT here yet (DESIGN.md "scope of the pair pipeline"): the low-confidence fallback
-of global_translation_matcher (159-221, host path exists in matcher.py); NON-RIGID mesh relaxation
+The low-confidence second shot of global_translation_matcher (159-221) runs per affected pair through the host
+mirror in matcher.py (block NCCs on the device).
+What is NOT here yet (DESIGN.md "scope of the pair pipeline"): NON-RIGID mesh relaxation
 between spacings (725-742; a uniform block displacement is applied as the rigid translation it
 relaxes to) together with the bilinear patch gather it needs.
 Pairs that would take the non-rigid branch are flagged in the result (``needs_host``).
@@ -110,7 +111,20 @@ class StripBatchMatcher:
             _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, hc, wc, self.sigma, None, 1, self.d_dogc.offset(n * hc * wc * 4)))
         _lib.check(lib.fb_ncc_batch_dev(ctx, self.d_dogc.ptr, self.d_dogc.offset(n * hc * wc * 4), n, 1, hc, wc, hc, wc,
                                         1, 0, self.conf_mode, self.d_out.ptr, self.d_out.offset(8 * n), self.d_out.offset(16 * n)))
-        return self._fetch_out(n)    # equal strip sizes: (W1-W0)/2 = 0 (matcher.py:155-156)
+        tx, ty, cf = (np.array(a) for a in self._fetch_out(n))    # equal strip sizes: (W1-W0)/2 = 0 (matcher.py:155-156)
+        # low-confidence pairs get the second shot on ~6 sub-blocks (matcher.py:159-221).  Rare: the two coarse DoG
+        # strips of such a pair are handed to the host mirror of global_translation_matcher, whose block NCCs run on
+        # the device again.
+        low = np.flatnonzero(~(cf > self.conf_thresh))
+        if low.size:
+            from .matcher import global_translation_matcher
+            img_bytes = hc * wc * 4
+            for p in low:
+                g0 = np.empty((hc, wc), dtype=np.float32); g1 = np.empty((hc, wc), dtype=np.float32)
+                _lib.check(lib.fb_memcpy_d2h(ctx, _lib.ptr(g0), self.d_dogc.offset(p * img_bytes), img_bytes))
+                _lib.check(lib.fb_memcpy_d2h(ctx, _lib.ptr(g1), self.d_dogc.offset((n + p) * img_bytes), img_bytes))
+                tx[p], ty[p], cf[p] = global_translation_matcher(g0, g1, conf_mode=self.conf_mode, conf_thresh=self.conf_thresh)
+        return tx, ty, cf
 
     def _fetch_out(self, nb):
         """(dx, dy, conf) of the last launch that wrote nb results into d_out"""

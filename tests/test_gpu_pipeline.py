@@ -161,3 +161,35 @@ def test_contexts_per_thread_give_identical_results(fb):
         for key in ('tx', 'ty', 'conf0', 'pair', 'xy0', 'xy1', 'weight', 'strain'):
             np.testing.assert_array_equal(out[k][key], want[key])
     ref.free()
+
+
+def test_pipeline_global_translation_second_shot(fb):
+    """a pair whose strips agree only inside one sixth of their area: the whole-strip NCC is not confident, the
+    block-wise second shot of global_translation_matcher (matcher.py:159-221) is; same decision and numbers as the oracle"""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    from scipy.ndimage import gaussian_filter
+    P, H, W = 2, 1536, 256
+    rng = np.random.default_rng(77)
+
+    def tex(h, w):
+        t = gaussian_filter(rng.standard_normal((h, w)), 1.5) + 0.5 * gaussian_filter(rng.standard_normal((h, w)), 6.0)
+        return np.clip(128 + 40 * t / t.std(), 0, 255).astype(np.uint8)
+    s0 = np.stack([tex(H, W) for _ in range(P)])
+    s1 = np.stack([tex(H, W) for _ in range(P)])                        # unrelated everywhere ...
+    s1[0, 1320:1380, :] = np.roll(s0[0], (4, -6), (0, 1))[1320:1380, :]  # ... except 60 rows of pair 0
+    s1[1] = np.roll(s0[1], (2, 8), (0, 1))                               # pair 1: an ordinary pair
+    d0 = _lib.DeviceBuffer.from_array(s0); d1 = _lib.DeviceBuffer.from_array(s1)
+    m = StripBatchMatcher(P, H, W)
+    got = StripBatchMatcher.per_pair(m.match(d0.ptr, d1.ptr))
+    exp = [pipeline_ref.match_pair(s0[p], s1[p]) for p in range(P)]
+    from oracle import ncc_ref
+    c0 = ncc_ref.masked_dog_filter(ncc_ref.area_downsample2(s0[0]), 1.25); c1 = ncc_ref.masked_dog_filter(ncc_ref.area_downsample2(s1[0]), 1.25)
+    assert ncc_ref.xcorr_fft(c0[None], c1[None], pad=True)[2][0] < 0.1          # the whole-strip shot fails on pair 0
+    for p in range(P):
+        assert (got[p]['tx'], got[p]['ty']) == (exp[p]['tx'], exp[p]['ty'])
+        assert abs(got[p]['conf0'] - exp[p]['conf0']) < 1e-4
+    # pair 0 went through the second shot: its offset is the one of the matching rows
+    assert (got[0]['tx'], got[0]['ty']) == (-6.0, 4.0) and got[0]['conf0'] > 0.33
+    assert (got[1]['tx'], got[1]['ty']) == (8.0, 2.0)
+    m.free(); d0.free(); d1.free()
