@@ -133,7 +133,7 @@ def bench_fem(args, lib, ctx, _lib):
                solve_to_1e4_s=t_solve, solve_iters=it.value, solve_relres=rr.value,
                assemble_numeric_s=t_asm, assemble_first_s=t_asm_first,
                spmv_kernel_us=1e3 * k1[1] / max(k1[0], 1), update_kernel_us=1e3 * k2[1] / max(k2[0], 1),
-               spmv_kernel_gbs=spmv_bytes / max(1e-9, (k1[1] / max(k1[0], 1)) * 1e-3) / 1e9)
+               spmv_kernel_gbs=spmv_bytes / max(1e-9, (k1[1] / max(k1[0], 1)) * 1e-3) / 1e9, x=x)
     return out
 
 
@@ -363,10 +363,24 @@ def main():
                            pairs_needing_mesh_relaxation=int(res['needs_host'].sum())),
                 roofline=roof)
 
-    if rank == 0 and not args.no_fem:
+    if not args.no_fem:
+        # FEM path (config[2]): every rank relaxes its own ~1e6-DoF section system -- sections are independent SLMs
+        # (SURVEY.md sec.8e), no collective on the data path; the node displacements are all-gathered afterwards
         for m in matchers.values():
             m.free()
-        line['fem'] = bench_fem(args, lib, ctx, _lib)
+        fem = bench_fem(args, lib, ctx, _lib)
+        if dist is not None:
+            from feabas_amd import dist as fdist
+            t0 = time.time()
+            parts = fdist.allgather_ragged(fem.pop('x').reshape(-1, 2))
+            fem['allgather_displacements_s'] = time.time() - t0
+            fem['allgather_bytes'] = int(sum(p.nbytes for p in parts))
+            tt = torch.tensor([fem['iters_per_s']], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            fem['iters_per_s_all_ranks'] = float(tt.item())
+        fem.pop('x', None)
+        if rank == 0:
+            line['fem'] = fem
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         H, W = shapes['LR']
         s0, s1, _ = strips['LR']
