@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--tile', type=int, default=4096)
     ap.add_argument('--host-threads', type=int, default=8, help='host threads driving the device (even; steps are dealt round-robin, LR and UD batches alternate)')
     ap.add_argument('--multi-stream', type=int, default=1, help='1: one context (HIP stream) per host thread; 0: all threads share one stream')
+    ap.add_argument('--warp', type=float, default=0.4, help='amplitude (px) of the smooth sub-pixel warp between the strips of a pair (SURVEY config 2)')
     ap.add_argument('--no-fem', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fem-grid', type=int, default=708)
@@ -181,7 +182,7 @@ def main():
     mper = max(1, args.host_threads // 2)          # matcher instances per orientation: one per host thread
     for k, (H, W) in shapes.items():
         s0 = _lib.DeviceBuffer(n_res * H * W); s1 = _lib.DeviceBuffer(n_res * H * W); sh = _lib.DeviceBuffer(n_res * 8)
-        _lib.check(lib.fb_synth_strips_dev(ctx, n_res, rank * 100000 + (0 if k == 'LR' else 50000), H, W, 2026, 20, 1,
+        _lib.check(lib.fb_synth_strips_dev(ctx, n_res, rank * 100000 + (0 if k == 'LR' else 50000), H, W, 2026, 20, 1, args.warp,
                                            s0.ptr, s1.ptr, sh.ptr))
         strips[k] = (s0, s1, sh.to_array((n_res, 2), np.int32))
         for j in range(mper):
@@ -357,7 +358,8 @@ def main():
                 vs_baseline=None, dtype='f32', data='synthetic',
                 config=dict(workload=f'config[1]: {2 * n_res} resident synthetic {T}x{T} tile pairs ({n_res} LR + {n_res} UD strips '
                                      f'{Hl}x{Wl}), {P} pairs per step; stages: x0.5 downsample, DoG, global NCC, DoG, '
-                                     f'4 coarse + 385 fine block NCCs (integer synthetic offsets; odd ones take the rigid mesh-relaxation branch, DESIGN.md sec.5)',
+                                     f'4 coarse + 385 fine block NCCs, last-round relaxation + residue weights + strain (integer synthetic offsets in +-20 px plus a smooth '
+                                     f'{args.warp} px warp; odd offsets take the rigid mesh-relaxation branch, DESIGN.md sec.5)',
                             pairs_per_step=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33),
                 check=dict(global_shift_within_1px=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches, matches_within_half_px_of_truth=ok_match,
                            pairs_needing_mesh_relaxation=int(res['needs_host'].sum())),

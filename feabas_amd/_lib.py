@@ -64,7 +64,7 @@ _PROTOS = {
     'fb_dog_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
     'fb_area_downsample2': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'fb_area_downsample2_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
-    'fb_synth_strips_dev': (c_i, [c_p, c_i, c_i, c_i, c_i, C.c_uint32, c_i, c_i, c_p, c_p, c_p]),
+    'fb_synth_strips_dev': (c_i, [c_p, c_i, c_i, c_i, c_i, C.c_uint32, c_i, c_i, C.c_float, c_p, c_p, c_p]),
     'fb_sys_create': (c_i, [c_p, c_i64, C.POINTER(c_p)]),
     'fb_sys_destroy': (None, [c_p, c_p]),
     'fb_sys_add_mesh': (c_i, [c_p, c_p, c_i64, c_p, c_i, c_i, C.POINTER(c_i)]),

@@ -126,8 +126,9 @@ int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W
 
 /* Synthetic overlap strips for benchmarks (not a reference function): pair p gets an integer
  * offset (sx, sy), multiples of shift_step in [-max_shift, max_shift]^2, derived from (seed, pair0 + p); strips0/strips1 are
- * uint8 [P][H][W] with strips1(x, y) = texture(x + sx, y + sy); shifts_dev receives [P][2] = {sx, sy}. */
-int fb_synth_strips_dev(fb_ctx* ctx, int P, int pair0, int H, int W, uint32_t seed, int max_shift, int shift_step,
+ * uint8 [P][H][W] with strips1(x, y) = texture(x + sx + wx, y + sy + wy), (wx, wy) a smooth warp of amplitude `warp` px
+ * (<= 0.4); shifts_dev receives [P][2] = {sx, sy}. */
+int fb_synth_strips_dev(fb_ctx* ctx, int P, int pair0, int H, int W, uint32_t seed, int max_shift, int shift_step, float warp,
                         uint8_t* strips0, uint8_t* strips1, int* shifts_dev);
 
 /* ------------------------------------------------------------------ FEM path */

@@ -10,11 +10,11 @@ from oracle import pipeline_ref
 pytestmark = pytest.mark.gpu
 
 
-def _synth(fb, P, H, W, seed, max_shift, step=1):
+def _synth(fb, P, H, W, seed, max_shift, step=1, warp=0.0):
     from feabas_amd import _lib
     lib, ctx = _lib.load(), _lib.ctx()
     s0 = _lib.DeviceBuffer(P * H * W); s1 = _lib.DeviceBuffer(P * H * W); sh = _lib.DeviceBuffer(P * 8)
-    _lib.check(lib.fb_synth_strips_dev(ctx, P, 0, H, W, seed, max_shift, step, s0.ptr, s1.ptr, sh.ptr))
+    _lib.check(lib.fb_synth_strips_dev(ctx, P, 0, H, W, seed, max_shift, step, warp, s0.ptr, s1.ptr, sh.ptr))
     _lib.check(lib.fb_sync(ctx))
     return s0, s1, sh.to_array((P, 2), np.int32)
 
@@ -193,3 +193,32 @@ def test_pipeline_global_translation_second_shot(fb):
     assert (got[0]['tx'], got[0]['ty']) == (-6.0, 4.0) and got[0]['conf0'] > 0.33
     assert (got[1]['tx'], got[1]['ty']) == (8.0, 2.0)
     m.free(); d0.free(); d1.free()
+
+
+def test_pipeline_with_subpixel_warp_vs_oracle(fb):
+    """SURVEY config-2 style pairs: integer offset + smooth <= 0.4 px warp.  The last-round matches then carry sub-pixel
+    structure: relaxation, residue weights and a non-zero strain, all equal to the oracle's"""
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    P, H, W = 4, 1024, 256
+    s0, s1, shifts = _synth(fb, P, H, W, seed=5, max_shift=10, warp=0.4)
+    m = StripBatchMatcher(P, H, W)
+    got = StripBatchMatcher.per_pair(m.match(s0.ptr, s1.ptr))
+    h0 = s0.to_array((P, H, W), np.uint8); h1 = s1.to_array((P, H, W), np.uint8)
+    nz = 0
+    for p in range(P):
+        exp = pipeline_ref.match_pair(h0[p], h1[p])
+        g = got[p]
+        assert (g['tx'], g['ty']) == (exp['tx'], exp['ty'])
+        assert g['needs_host'] == exp['needs_host']
+        if exp['needs_host']:
+            continue
+        nz += 1
+        assert g['xy0'].shape == exp['xy0'].shape
+        np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4)
+        np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
+        np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
+        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=2e-3, atol=1e-7)
+        assert exp['strain'] > 1e-5                      # the warp is seen
+        assert np.abs(g['xy1'] - g['xy0'] + shifts[p]).max() < 0.75
+    assert nz >= 2
+    m.free()

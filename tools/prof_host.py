@@ -7,7 +7,7 @@ from feabas_amd.stitch_pipeline import StripBatchMatcher
 lib, ctx = _lib.load(), _lib.ctx()
 P, H, W = 64, 4096, 510
 s0 = _lib.DeviceBuffer(P * H * W); s1 = _lib.DeviceBuffer(P * H * W); sh = _lib.DeviceBuffer(P * 8)
-_lib.check(lib.fb_synth_strips_dev(ctx, P, 0, H, W, 2026, 20, 1, s0.ptr, s1.ptr, sh.ptr))
+_lib.check(lib.fb_synth_strips_dev(ctx, P, 0, H, W, 2026, 20, 1, 0.4, s0.ptr, s1.ptr, sh.ptr))
 m = StripBatchMatcher(P, H, W)
 m.match(s0.ptr, s1.ptr); m.match(s0.ptr, s1.ptr)
 t0 = time.time()
