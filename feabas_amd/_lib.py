@@ -58,6 +58,7 @@ _PROTOS = {
     'fb_ncc_batch': (c_i, [c_p, c_p, c_p] + [c_i] * 9 + [c_p, c_p, c_p]),
     'fb_ncc_batch_dev': (c_i, [c_p, c_p, c_p] + [c_i] * 9 + [c_p, c_p, c_p]),
     'fb_ncc_blocks_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'fb_ncc_blocks_affine_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_debug_fft1d': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i]),
     'fb_ncc_last_surfaces': (c_i, [c_p, c_p, c_p, C.POINTER(c_i), C.POINTER(c_i)]),
     'fb_dog': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),

@@ -106,6 +106,31 @@ int fb_ncc_small_supported(int Fh, int Fw, int H0, int W0, int H1, int W1, int C
 int fb_ncc_small_launch(fb_ctx* ctx, const float* img0, const float* img1, int N, int H0, int W0,
                         int H1, int W1, int Fh, int Fw, int subpixel, int conf_mode, double* dx,
                         double* dy, float* conf);
+// ---- affine patch gather (the affine-approximated branch of MeshRenderer.crop_field, renderer.py:419-451, 499-511,
+// followed by common.render_by_subregions -> cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0), common.py:218-350).
+// prm[10] per block: x0, y0 (block origin in the renderer's output space, offset removed), A00, A10, t0, A01, A11, t1
+// (source x = X A00 + Y A10 + t0, source y = X A01 + Y A11 + t1), xmin, ymin (integer origin of the sub-image the
+// reference hands to cv2.remap: the float32 map is taken relative to it).  cv2.remap quantises the float32 map to
+// 1/32 px (INTER_BITS = 5, round half to even) and blends the 4 taps with float32 table weights; taps outside the
+// image are the border value 0.
+#define FB_AFFINE_STRIDE 10
+__device__ __forceinline__ float fb_sample_affine(const float* __restrict__ img, int IH, int IW, const double* __restrict__ prm, int i, int j) {
+#pragma clang fp contract(off)
+    const double xx = prm[0] + (double)i, yy = prm[1] + (double)j;
+    const double mx = (xx * prm[2] + yy * prm[3]) + prm[4];
+    const double my = (xx * prm[5] + yy * prm[6]) + prm[7];
+    const float fx = (float)(mx - prm[8]), fy = (float)(my - prm[9]);
+    const int sx = (int)rintf(fx * 32.0f), sy = (int)rintf(fy * 32.0f);
+    const int ix = (sx >> 5) + (int)prm[8], iy = (sy >> 5) + (int)prm[9];
+    const float ax = (float)(sx & 31) * (1.0f / 32.0f), ay = (float)(sy & 31) * (1.0f / 32.0f);
+    const float w00 = (1.0f - ay) * (1.0f - ax), w01 = (1.0f - ay) * ax, w10 = ay * (1.0f - ax), w11 = ay * ax;
+    const bool x0ok = ix >= 0 && ix < IW, x1ok = ix + 1 >= 0 && ix + 1 < IW, y0ok = iy >= 0 && iy < IH, y1ok = iy + 1 >= 0 && iy + 1 < IH;
+    const int cx0 = min(max(ix, 0), IW - 1), cx1 = min(max(ix + 1, 0), IW - 1), cy0 = min(max(iy, 0), IH - 1), cy1 = min(max(iy + 1, 0), IH - 1);
+    const float v00 = img[(size_t)cy0 * IW + cx0], v01 = img[(size_t)cy0 * IW + cx1];
+    const float v10 = img[(size_t)cy1 * IW + cx0], v11 = img[(size_t)cy1 * IW + cx1];
+    return ((((y0ok && x0ok) ? v00 : 0.f) * w00 + ((y0ok && x1ok) ? v01 : 0.f) * w01) + ((y1ok && x0ok) ? v10 : 0.f) * w10) + ((y1ok && x1ok) ? v11 : 0.f) * w11;
+}
+
 int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, int N, int H0, int W0, int H1, int W1,
                            const int* blk, int IH0, int IW0, int IH1, int IW1, int Fh, int Fw, int subpixel,
-                           int conf_mode, double* dx, double* dy, float* conf);
+                           int conf_mode, double* dx, double* dy, float* conf, const double* aff1 = nullptr);

@@ -291,7 +291,7 @@ int quantised_chunk(fb_ctx* ctx, int N, size_t per_pair) {
 }
 
 // one sub-batch of nb pairs through the rocFFT pipeline; all pointers are device pointers
-struct CropSrc { const int* blk; int IH0, IW0, IH1, IW1; };
+struct CropSrc { const int* blk; int IH0, IW0, IH1, IW1; const double* aff = nullptr; };
 
 int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int nb, int C, int H0, int W0, int H1,
                         int W1, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf,
@@ -406,6 +406,7 @@ struct StreamGeom {
     const int* blk;
     int IH0, IW0, IH1, IW1;
     int want_q, want_std;
+    const double* aff;            // per block affine gather of image 1 (crop mode only) or nullptr
 };
 
 constexpr int kStreamThreads = 512;
@@ -451,7 +452,8 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
             if (r < TR) {
                 const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
                 a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
-                b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
+                if (g.aff) b[r] = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
+                else b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
             }
         }
         if (x < Fw) {
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
                 if (r < TR) {
                     const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
                     const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
-                    const bool v1 = vx1 && y < h1 && gy1 >= 0 && gy1 <= my1;
+                    const bool v1 = g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1);
                     G[r * pitch + fft_padx(x)] = make_float2(v0 ? a[r] : 0.f, v1 ? b[r] : 0.f);
                 }
             }
@@ -718,6 +720,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     if (rc) return rc;
     g.img0 = img0; g.img1 = img1;
     g.blk = crop ? crop->blk : nullptr;
+    g.aff = crop ? crop->aff : nullptr;
     g.IH0 = crop ? crop->IH0 : 0; g.IW0 = crop ? crop->IW0 : 0; g.IH1 = crop ? crop->IH1 : 0; g.IW1 = crop ? crop->IW1 : 0;
     g.want_q = conf_mode == FB_CONF_MIRROR;
     g.want_std = conf_mode == FB_CONF_STD;
@@ -914,8 +917,9 @@ int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C
     return rc;
 }
 
-int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1, int N,
-                      const int* blk, int hmax, int wmax, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
+int fb_ncc_blocks_affine_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1, int N,
+                             const int* blk, const double* aff1, int hmax, int wmax, int Fh, int Fw, int subpixel, int conf_mode, double* dx,
+                             double* dy, float* conf) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, N >= 0 && IH0 > 0 && IW0 > 0 && IH1 > 0 && IW1 > 0 && Fh > 0 && Fw > 0);
     FB_CHECK_ARG(ctx, conf_mode >= 0 && conf_mode <= 2 && (long long)Fh * Fw < (1LL << 31));
@@ -925,7 +929,7 @@ int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int I
     if (hmax <= 0 || hmax > Fh) hmax = Fh;
     if (wmax <= 0 || wmax > Fw) wmax = Fw;
     if (fb_ncc_small_supported(Fh, Fw, 0, 0, 0, 0, 1))
-        return fb_ncc_small_launch_ex(ctx, imgs0, imgs1, N, hmax, wmax, hmax, wmax, blk, IH0, IW0, IH1, IW1, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
+        return fb_ncc_small_launch_ex(ctx, imgs0, imgs1, N, hmax, wmax, hmax, wmax, blk, IH0, IW0, IH1, IW1, Fh, Fw, subpixel, conf_mode, dx, dy, conf, aff1);
     if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, 1)) {
         promote_linear_shape(Fh, Fw, 2 * hmax - 1, 2 * wmax - 1, conf_mode);
         const int nbm = (int)std::max<size_t>(1, ctx->ncc_arena_limit / custom_bytes_per_pair(Fh, Fw, hmax));
@@ -933,11 +937,13 @@ int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int I
         for (int n0 = 0; n0 < N; n0 += nbm) {
             const int nb = std::min(nbm, N - n0);
             cs.blk = blk + (size_t)n0 * kBlkStride;
+            cs.aff = aff1 ? aff1 + (size_t)n0 * FB_AFFINE_STRIDE : nullptr;
             int rc2 = ncc_custom_subbatch(ctx, imgs0, imgs1, nb, 0, 0, 0, 0, hmax, wmax, Fh, Fw, subpixel, conf_mode, dx + n0, dy + n0, conf + n0, &cs);
             if (rc2) return rc2;
         }
         return FB_OK;
     }
+    if (aff1) return fb_fail(ctx, FB_ERR_ARG, "fb_ncc_blocks_affine_dev: FFT shape %dx%d has no custom kernel (rocFFT path crops by translation only)", Fh, Fw);
     int rc = ensure_rocfft(ctx);
     if (rc) return rc;
     const size_t per_pair = ((size_t)Fh * Fw * 4 + (size_t)Fh * (Fw / 2 + 1) * 8) * 2;
@@ -950,6 +956,11 @@ int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int I
         if (rc) return rc;
     }
     return FB_OK;
+}
+
+int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1, int N,
+                      const int* blk, int hmax, int wmax, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
+    return fb_ncc_blocks_affine_dev(ctx, imgs0, imgs1, IH0, IW0, IH1, IW1, N, blk, nullptr, hmax, wmax, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
 }
 
 int fb_ncc_last_surfaces(fb_ctx* ctx, float* C_out, float* Cm_out, int* Fh, int* Fw) {

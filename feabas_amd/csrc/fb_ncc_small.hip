@@ -29,6 +29,7 @@ struct SmallParams {
     const float* img0;
     const float* img1;
     const int* blk;                     // crop mode when non-null: {img, x0, y0, h0, w0, x1, y1, h1, w1}
+    const double* aff;                  // per block affine gather of image 1 (fb_sample_affine) or nullptr
     int IH0, IW0, IH1, IW1;
     double* dx;
     double* dy;
@@ -115,8 +116,13 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
                 const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= maxy0;
                 const bool v1 = vx1 && y < h1 && gy1 >= 0 && gy1 <= maxy1;
                 const float a = s0[(size_t)min(max(gy0, 0), maxy0) * pitch0 + cx0];
-                const float b = s1[(size_t)min(max(gy1, 0), maxy1) * pitch1 + cx1];
-                if (x < RS) G[y * RS + x] = make_float2(v0 ? a : 0.f, v1 ? b : 0.f);
+                float b;
+                bool v1e = v1;
+                if (prm.aff) {          // image 1 through the (deformed, affine-approximated) mesh: bilinear gather, zero outside the image
+                    v1e = x < w1 && y < h1;
+                    b = fb_sample_affine(s1, IH1, IW1, prm.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
+                } else b = s1[(size_t)min(max(gy1, 0), maxy1) * pitch1 + cx1];
+                if (x < RS) G[y * RS + x] = make_float2(v0 ? a : 0.f, v1e ? b : 0.f);
             }
         }
     }
@@ -304,7 +310,7 @@ int fb_ncc_small_supported(int Fh, int Fw, int, int, int, int, int C) {
 
 int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, int N, int H0, int W0, int H1, int W1, const int* blk,
                            int IH0, int IW0, int IH1, int IW1, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy,
-                           float* conf) {
+                           float* conf, const double* aff1) {
     SmallParams p;
     p.N = N; p.Fh = Fh; p.Fw = Fw; p.Sw = Fw / 2 + 1; p.RS = small_pitch(Fw);
     p.H0 = H0; p.W0 = W0; p.H1 = H1; p.W1 = W1;
@@ -317,7 +323,7 @@ int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, in
     if (rc) return rc;
     rc = get_table(ctx, Fh, &p.tw_h);
     if (rc) return rc;
-    p.img0 = img0; p.img1 = img1; p.blk = blk;
+    p.img0 = img0; p.img1 = img1; p.blk = blk; p.aff = blk ? aff1 : nullptr;
     p.IH0 = IH0; p.IW0 = IW0; p.IH1 = IH1; p.IW1 = IW1;
     p.dx = dx; p.dy = dy; p.conf = conf;
     const size_t lds = small_lds_bytes(Fh, Fw);

@@ -105,6 +105,17 @@ int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, i
 int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1,
                       int N, const int* blk, int hmax, int wmax, int Fh, int Fw, int subpixel, int conf_mode,
                       double* dx, double* dy, float* conf);
+/* As fb_ncc_blocks_dev, but the window of image 1 is gathered through a per-block affine map with the bilinear rule of
+ * cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0): the affine-approximated branch of MeshRenderer.crop_multiple
+ * (renderer.py:419-451, 499-511 -> common.render_by_subregions, common.py:218-350) that
+ * matcher.bboxes_mesh_renderer_matcher (matcher.py:833-846) takes for a deformed mesh1.
+ * aff1: device double [N][10] = {x0, y0, A00, A10, t0, A01, A11, t1, xmin, ymin}: output pixel (i, j) of block n reads
+ * image 1 at (X A00 + Y A10 + t0, X A01 + Y A11 + t1), X = x0 + i, Y = y0 + j; (xmin, ymin) = integer origin of the
+ * sub-image the reference passes to cv2.remap (the float32 map is relative to it).  blk[n] = {image, x0, y0, h0, w0,
+ * (unused) x1, y1, h1, w1}.  NULL aff1 = fb_ncc_blocks_dev. */
+int fb_ncc_blocks_affine_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1, int N,
+                             const int* blk, const double* aff1, int hmax, int wmax, int Fh, int Fw, int subpixel, int conf_mode,
+                             double* dx, double* dy, float* conf);
 /* debugging / parity aid: the two correlation surfaces (un-normalised) of the
  * last fb_ncc_batch* call that went through the streaming (rocFFT) class. */
 int fb_ncc_last_surfaces(fb_ctx* ctx, float* C_out, float* Cm_out, int* Fh, int* Fw);

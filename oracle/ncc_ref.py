@@ -339,3 +339,53 @@ def auto_spacings(shape0, shape1):
         return np.array([smn])
     nsp = max(1, round(np.log(smx / smn) / np.log(4)))
     return np.exp(np.linspace(np.log(smn), np.log(smx), num=nsp, endpoint=True))
+
+
+# ------------------------------------------------------------------ affine patch gather (UNPINNED: cv2 is absent)
+def remap_bilinear_cv(img, map_x, map_y):
+    """cv2.remap(img, map_x, map_y, INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0) for a float32
+    single-channel image, as common.remap calls it (common.py:218-255).  UNPINNED restatement of OpenCV's
+    remapBilinear: the float32 maps are quantised to 1/32 px (INTER_BITS = 5, cvRound = round half to even), the four
+    taps are blended with float32 table weights, taps outside the image are the border value."""
+    img = np.asarray(img, dtype=np.float32)
+    H, W = img.shape
+    mx = np.asarray(map_x, dtype=np.float32)
+    my = np.asarray(map_y, dtype=np.float32)
+    sx = np.rint(mx * np.float32(32)).astype(np.int64)
+    sy = np.rint(my * np.float32(32)).astype(np.int64)
+    ix, iy = sx >> 5, sy >> 5
+    ax = (sx & 31).astype(np.float32) * np.float32(1 / 32)
+    ay = (sy & 31).astype(np.float32) * np.float32(1 / 32)
+    one = np.float32(1)
+    w00 = (one - ay) * (one - ax); w01 = (one - ay) * ax; w10 = ay * (one - ax); w11 = ay * ax
+
+    def tap(yy, xx):
+        inside = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        return np.where(inside, img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], np.float32(0))
+    return ((tap(iy, ix) * w00 + tap(iy, ix + 1) * w01) + tap(iy + 1, ix) * w10) + tap(iy + 1, ix + 1) * w11
+
+
+def crop_affine(img, x0, y0, h, w, A, t, origin):
+    """MeshRenderer.crop_field_affine (renderer.py:419-435) + render_by_subregions (common.py:311-330) for one block:
+    output pixel (i, j) samples `img` at (X A[0,0] + Y A[1,0] + t[0], X A[0,1] + Y A[1,1] + t[1]), X = x0 + i, Y = y0 + j;
+    `origin` = (xmin, ymin), the integer origin of the sub-image handed to cv2.remap (maps are float32 relative to it)."""
+    xs = np.linspace(x0, x0 + w, num=w, endpoint=False, dtype=float)
+    ys = np.linspace(y0, y0 + h, num=h, endpoint=False, dtype=float)
+    xx, yy = np.meshgrid(xs, ys)
+    x_field = xx * A[0, 0] + yy * A[1, 0] + t[0]
+    y_field = xx * A[0, 1] + yy * A[1, 1] + t[1]
+    mxt = (x_field - origin[0]).astype(np.float32)
+    myt = (y_field - origin[1]).astype(np.float32)
+    H, W = img.shape
+    # the sub-image starts at `origin`: evaluate on the full image with maps shifted back by the integer origin
+    sx = np.rint(mxt * np.float32(32)).astype(np.int64); sy = np.rint(myt * np.float32(32)).astype(np.int64)
+    ix = (sx >> 5) + int(origin[0]); iy = (sy >> 5) + int(origin[1])
+    ax = (sx & 31).astype(np.float32) * np.float32(1 / 32); ay = (sy & 31).astype(np.float32) * np.float32(1 / 32)
+    one = np.float32(1)
+    w00 = (one - ay) * (one - ax); w01 = (one - ay) * ax; w10 = ay * (one - ax); w11 = ay * ax
+    img = np.asarray(img, dtype=np.float32)
+
+    def tap(yy_, xx_):
+        inside = (yy_ >= 0) & (yy_ < H) & (xx_ >= 0) & (xx_ < W)
+        return np.where(inside, img[np.clip(yy_, 0, H - 1), np.clip(xx_, 0, W - 1)], np.float32(0))
+    return ((tap(iy, ix) * w00 + tap(iy, ix + 1) * w01) + tap(iy + 1, ix) * w10) + tap(iy + 1, ix + 1) * w11

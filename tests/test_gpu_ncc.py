@@ -174,3 +174,53 @@ def test_area_downsample(fb):
     rng = np.random.default_rng(4)
     img = rng.integers(0, 256, size=(3, 510, 4096), dtype=np.uint8)
     np.testing.assert_array_equal(fb.common.area_downsample2(img), ncc_ref.area_downsample2(img))
+
+
+@pytest.mark.parametrize('bh,bw,pad', [(75, 73, False), (75, 73, True), (250, 247, True)])
+def test_blocks_affine_gather_vs_oracle(fb, bh, bw, pad):
+    """fb_ncc_blocks_affine_dev: image 1 sampled through a per-block affine map with cv2.remap's bilinear rule (oracle
+    restatement, unpinned) -- on-chip kernel, generic streaming kernels (150 x 150) and power-of-two kernels (512 x 512)"""
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(bh + bw + int(pad))
+    n_img, IH, IW = 2, 600, 640
+    from scipy.ndimage import gaussian_filter
+    base = np.stack([gaussian_filter(rng.standard_normal((IH + 40, IW + 40)), 1.2) for _ in range(n_img)]).astype(np.float32)
+    img0 = np.ascontiguousarray(base[:, 20:20 + IH, 20:20 + IW])
+    # image 1 = image 0 seen through a slight magnification + rotation (resampled here with scipy, independent of the sampler under test)
+    from scipy.ndimage import affine_transform
+    th, sc = 0.002, 1.0015
+    M = sc * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    img1 = np.stack([affine_transform(base[k], M, offset=(20 - 1.3, 20 + 2.2), output_shape=(IH, IW), order=3) for k in range(n_img)]).astype(np.float32)
+    N = 12
+    blk = np.zeros((N, 9), dtype=np.int32)
+    aff = np.zeros((N, 10))
+    A = np.array([[1.0012, 0.0017], [-0.0019, 0.9991]])
+    exp0, exp1 = [], []
+    for k in range(N):
+        im = k % n_img
+        x0 = int(rng.integers(-10, IW - bw + 10)); y0 = int(rng.integers(-10, IH - bh + 10))
+        t = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3)])
+        blk[k] = (im, x0, y0, bh, bw, x0, y0, bh, bw)
+        xmin = int(np.floor(min(x0 * A[0, 0] + y0 * A[1, 0] + t[0], x0 * A[0, 0] + (y0 + bh) * A[1, 0] + t[0]))) - 4
+        ymin = int(np.floor(min(x0 * A[0, 1] + y0 * A[1, 1] + t[1], (x0 + bw) * A[0, 1] + y0 * A[1, 1] + t[1]))) - 4
+        aff[k] = (x0, y0, A[0, 0], A[1, 0], t[0], A[0, 1], A[1, 1], t[1], xmin, ymin)
+        c0 = np.zeros((bh, bw), np.float32)
+        ya, yb, xa, xb = max(y0, 0), min(y0 + bh, IH), max(x0, 0), min(x0 + bw, IW)
+        c0[ya - y0:yb - y0, xa - x0:xb - x0] = img0[im, ya:yb, xa:xb]
+        exp0.append(c0)
+        exp1.append(ncc_ref.crop_affine(img1[im], x0, y0, bh, bw, A, t, (xmin, ymin)))
+    exp = ncc_ref.xcorr_fft(np.stack(exp0), np.stack(exp1), pad=pad, subpixel=True)
+    nfl = ncc_ref.next_fast_len
+    Fh, Fw = (nfl(2 * bh - 1), nfl(2 * bw - 1)) if pad else (nfl(bh), nfl(bw))
+    d0 = _lib.DeviceBuffer.from_array(img0); d1 = _lib.DeviceBuffer.from_array(img1)
+    dblk = _lib.DeviceBuffer.from_array(blk); daff = _lib.DeviceBuffer.from_array(aff)
+    out = _lib.DeviceBuffer(N * 20)
+    _lib.check(lib.fb_ncc_blocks_affine_dev(ctx, d0.ptr, d1.ptr, IH, IW, IH, IW, N, dblk.ptr, daff.ptr, bh, bw, Fh, Fw, 1, 2,
+                                            out.ptr, out.offset(8 * N), out.offset(16 * N)))
+    raw = out.to_array((20 * N,), np.uint8)
+    got = (raw[:8 * N].view(np.float64), raw[8 * N:16 * N].view(np.float64), raw[16 * N:].view(np.float32))
+    _check(got, exp)
+    assert np.median(exp[2]) > 0.5                       # the blocks do match
+    for b in (d0, d1, dblk, daff, out):
+        b.free()
