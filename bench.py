@@ -138,6 +138,30 @@ def bench_fem(args, lib, ctx, _lib):
     return out
 
 
+def bench_xcorr_classes(lib, ctx, _lib):
+    """kernel-only rate of matcher.xcorr_fft at the three shape classes of the 4k configuration:
+    block pairs per second with the stacks resident in HBM"""
+    out = {}
+    rng = np.random.default_rng(1)
+    for name, (N, h, w, pad, sub) in {'fine_75x73_fft75x75': (24640, 75, 73, 0, 1), 'coarse_1024x510_fft2048x1024': (128, 1024, 510, 1, 0),
+                                      'global_2048x255_fft4096x512': (32, 2048, 255, 1, 0)}.items():
+        a = rng.standard_normal((min(N, 256), h, w)).astype(np.float32)
+        a = np.tile(a, (-(-N // a.shape[0]), 1, 1))[:N]
+        d0 = _lib.DeviceBuffer.from_array(a); d1 = _lib.DeviceBuffer.from_array(np.roll(a, (2, -3), (1, 2)))
+        o = _lib.DeviceBuffer(N * 20)
+        ms = C.c_float(); best = 1e9
+        for r in range(4):
+            _lib.check(lib.fb_timer_start(ctx))
+            _lib.check(lib.fb_ncc_batch_dev(ctx, d0.ptr, d1.ptr, N, 1, h, w, h, w, pad, sub, 2, o.ptr, o.offset(8 * N), o.offset(16 * N)))
+            _lib.check(lib.fb_timer_stop(ctx, C.byref(ms)))
+            if r:
+                best = min(best, ms.value)
+        out[name] = dict(block_pairs_per_s=N / (best * 1e-3), us_per_block_pair=1e3 * best / N)
+        for b in (d0, d1, o):
+            b.free()
+    return out
+
+
 def cpu_baseline_ncc(h0, h1, seconds=20.0):
     """the oracle pair pipeline on the host, one process / one thread, on a bounded sample"""
     from oracle import pipeline_ref
@@ -383,6 +407,8 @@ def main():
         fem.pop('x', None)
         if rank == 0:
             line['fem'] = fem
+    if rank == 0:
+        line['xcorr_fft_classes'] = bench_xcorr_classes(lib, ctx, _lib)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         H, W = shapes['LR']
         s0, s1, _ = strips['LR']
