@@ -178,3 +178,64 @@ def auto_spacings(shape0, shape1):
         return np.array([s_min])
     count = max(1, round(np.log(s_max / s_min) / np.log(4)))
     return np.exp(np.linspace(np.log(s_min), np.log(s_max), num=count, endpoint=True))
+
+
+_pair_matchers = {}
+
+
+def stitching_matcher(img0, img1, **kwargs):
+    """feabas/matcher.py:224-367 for one pair of overlap strips: returns ``(xy0, xy1, weight, strain, phtm)`` in
+    strip-local pixel coordinates, or ``(None, None, conf_thresh, None, None)`` when the strips do not match
+    (matcher.py:278) -- no exception for "no match".
+
+    The whole sequence runs on the device through the batch pipeline (``stitch_pipeline.StripBatchMatcher`` with a batch
+    of one; callers with many pairs should use the batch class directly).  Supported: equal-shape 2-D uint8 strips,
+    ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, unmasked images.  Anything the device
+    path does not cover (masks, photometric statistics, explicit spacings, a mesh relaxation that is not a rigid
+    translation between rounds) raises NotImplementedError instead of silently taking another route."""
+    from .stitch_pipeline import StripBatchMatcher
+    kw = dict(kwargs)
+    sigma = kw.pop('sigma', 2.5)
+    coarse_downsample = kw.pop('coarse_downsample', 1)
+    fine_downsample = kw.pop('fine_downsample', 1)
+    conf_mode = kw.pop('conf_mode', const.FFT_CONF_MIRROR)
+    conf_thresh = kw.pop('conf_thresh', 0.3)
+    min_num_blocks = kw.pop('min_num_blocks', 2)
+    residue_len = kw.pop('residue_len', 5)
+    residue_mode = kw.pop('residue_mode', 'huber')
+    stiffness_lambda = kw.pop('stiffness_lambda', 1)
+    compute_strain = kw.pop('compute_strain', True)
+    for name in ('mask0', 'mask1', 'spacings'):
+        if kw.pop(name, None) is not None:
+            raise NotImplementedError(f'stitching_matcher({name}=...) is not on the device path')
+    if kw.pop('compute_photometric', False):
+        raise NotImplementedError('stitching_matcher(compute_photometric=True) is not on the device path')
+    kw.pop('opt_tol', None); kw.pop('pad', None)
+    if kw:
+        raise NotImplementedError(f'stitching_matcher: unsupported options {sorted(kw)}')
+    if fine_downsample != 1 or coarse_downsample not in (1, 0.5) or residue_mode != 'huber':
+        raise NotImplementedError('stitching_matcher: fine_downsample != 1, coarse_downsample outside (1, 0.5) or a non-huber '
+                                  'residue mode is not on the device path')
+    img0 = np.ascontiguousarray(img0); img1 = np.ascontiguousarray(img1)
+    if img0.ndim != 2 or img0.shape != img1.shape or img0.dtype != np.uint8 or img1.dtype != np.uint8:
+        raise NotImplementedError('stitching_matcher: the device path takes two uint8 strips of equal shape')
+    H, W = img0.shape
+    key = (H, W, float(sigma), coarse_downsample, float(conf_thresh), int(min_num_blocks), int(conf_mode), float(residue_len),
+           float(stiffness_lambda), bool(compute_strain), id(_lib.ctx()))
+    m = _pair_matchers.get(key)
+    if m is None:
+        m = StripBatchMatcher(1, H, W, sigma=sigma, coarse_downsample=coarse_downsample, conf_thresh=conf_thresh,
+                              min_num_blocks=min_num_blocks, conf_mode=conf_mode, residue_len=residue_len,
+                              stiffness_lambda=stiffness_lambda, compute_strain=compute_strain)
+        _pair_matchers[key] = m
+    d0 = _lib.DeviceBuffer.from_array(img0); d1 = _lib.DeviceBuffer.from_array(img1)
+    try:
+        res = StripBatchMatcher.per_pair(m.match(d0.ptr, d1.ptr))[0]
+    finally:
+        d0.free(); d1.free()
+    if res['xy0'] is None:
+        return None, None, conf_thresh, None, None
+    if res['needs_host']:
+        raise NotImplementedError('stitching_matcher: this pair needs the deformed-mesh crop between spacings '
+                                  '(MeshRenderer.crop_multiple on a non-rigidly relaxed mesh), which is not on the device path')
+    return res['xy0'], res['xy1'], res['weight'], res['strain'], None

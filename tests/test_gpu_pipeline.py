@@ -222,3 +222,20 @@ def test_pipeline_with_subpixel_warp_vs_oracle(fb):
         assert np.abs(g['xy1'] - g['xy0'] + shifts[p]).max() < 0.75
     assert nz >= 2
     m.free()
+
+
+def test_stitching_matcher_drop_in(fb):
+    """the per-pair surface stitcher.py:593 calls: (xy0, xy1, weight, strain, phtm), and the no-match convention"""
+    P, H, W = 2, 1024, 256
+    s0, s1, shifts = _synth(fb, P, H, W, seed=31, max_shift=8, warp=0.3)
+    h0 = s0.to_array((P, H, W), np.uint8); h1 = s1.to_array((P, H, W), np.uint8)
+    xy0, xy1, wt, strain, phtm = fb.matcher.stitching_matcher(h0[0], h1[0], sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33)
+    exp = pipeline_ref.match_pair(h0[0], h1[0])
+    assert phtm is None and not exp['needs_host']
+    np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4)
+    np.testing.assert_allclose(wt, exp['weight'], atol=1e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=2e-3, atol=1e-7)
+    # unrelated strips: no match is a value, not an exception (matcher.py:278)
+    out = fb.matcher.stitching_matcher(h0[0], h1[1][::-1].copy(), sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33)
+    assert out[0] is None and out[1] is None and out[2] == 0.33 and out[3] is None and out[4] is None
+    with pytest.raises(NotImplementedError):
+        fb.matcher.stitching_matcher(h0[0], h1[0], mask0=np.ones((H, W), bool))
