@@ -214,6 +214,17 @@ class Mesh:
         self.set_vertices(v0 + (dxy - m), gear[-1])
         self.set_offset(off0 + m, gear[-1])
 
+    def set_affine(self, A, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)):      # mesh.py:2342-2354 (unmasked)
+        if self.locked:
+            return
+        A = np.asarray(A, dtype=np.float64)
+        if gear[0] == gear[-1]:
+            raise NotImplementedError('Mesh.set_affine within one gear (apply_affine) is not mirrored')
+        v0 = self.vertices(gear[0])
+        off0 = self.offset(gear[0])
+        self.set_vertices(v0 @ A[:-1, :-1], gear[-1])
+        self.set_offset(off0 @ A[:-1, :-1] + A[-1, :-1], gear[-1])
+
     def anneal(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT):
         if self.locked:
             return

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 from scipy import sparse
 
-from . import _lib
+from . import _lib, common
 from . import constant as const
 from .mesh import Mesh, bsr_download
 
@@ -223,6 +223,100 @@ class SLM:
             wm |= a
             cm |= b
         return wm, cm
+
+    def anneal(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT):
+        """optimizer.py:757-760 (ANNEAL_COPY_EXACT; the rigid / affine annealing modes are host geometry that is not mirrored)."""
+        for m in self.meshes:
+            m.anneal(gear=gear, mode=mode)
+
+    def linkage_adjacency(self, directional=False):
+        """optimizer.py:1678-1695: mesh x mesh matrix of summed link weights."""
+        from scipy import sparse
+        uid2idx = {m.uid: k for k, m in enumerate(self.meshes)}
+        rows, cols, vals = [], [], []
+        for lk in self.links:
+            a, b = uid2idx.get(lk.uids[0], -1), uid2idx.get(lk.uids[1], -1)
+            if a < 0 or b < 0:
+                continue
+            rows.append(a); cols.append(b); vals.append(float(np.sum(lk.weight(use_mask=True))))
+        n = len(self.meshes)
+        A = sparse.csr_matrix((vals, (rows, cols)), shape=(n, n))
+        if not directional:
+            A = A + A.transpose()
+        A.eliminate_zeros()
+        return A
+
+    @property
+    def connected_subsystems(self):
+        """optimizer.py:1698-1703: (labels, count) of the link-connected components."""
+        from scipy.sparse import csgraph
+        n, labels = csgraph.connected_components(self.linkage_adjacency(), directed=False, return_labels=True)
+        return labels, n
+
+    def match_residues(self, gear=const.MESH_GEAR_MOVING, use_mask=False, quantile=0.75):
+        """optimizer.py:1758-1774."""
+        dis = []
+        for lk in self.links:
+            if use_mask and not lk.relevant:
+                dis.append(np.nan)
+                continue
+            d = np.sum(lk.dxy(gear=gear, use_mask=use_mask) ** 2, axis=-1) ** 0.5
+            if d.size == 0:
+                dis.append(np.nan)
+            elif quantile == 1:
+                dis.append(np.max(d))
+            elif quantile == 0:
+                dis.append(np.min(d))
+            else:
+                dis.append(np.quantile(d, quantile))
+        return np.array(dis)
+
+    def optimize_affine_cascade(self, **kwargs):
+        """optimizer.py:1128-1189: starting from the meshes linked to locked (or already placed) ones, fit one affine /
+        rigid transform per free mesh onto its placed neighbours (spatial.fit_affine, host) and write it to target_gear."""
+        target_gear = kwargs.get('target_gear', const.MESH_GEAR_MOVING)
+        start_gear = kwargs.get('start_gear', target_gear)
+        svd_clip = kwargs.get('svd_clip', (1, 1))
+        Adj = self.linkage_adjacency()
+        to_optimize = ~self.lock_flags
+        uid2idx = {m.uid: k for k, m in enumerate(self.meshes)}
+        pairs = np.array([[uid2idx.get(lk.uids[0], -1), uid2idx.get(lk.uids[1], -1)] for lk in self.links], dtype=np.int64).reshape(-1, 2)
+        pairs[np.any(pairs < 0, axis=-1)] = -1
+        modified = False
+        while np.any(to_optimize):
+            wsum = Adj.dot((~to_optimize).astype(np.float64)) * to_optimize
+            if not np.any(wsum > 0):
+                wsum = Adj.dot(np.ones(to_optimize.size)) * to_optimize
+                if not np.any(wsum > 0):
+                    break
+            idx0 = int(np.argmax(wsum))
+            placed = ~to_optimize[pairs]
+            placed[pairs < 0] = False
+            sel = np.nonzero(np.any(pairs == idx0, axis=-1) & np.any(placed, axis=-1))[0]
+            if sel.size == 0:
+                to_optimize[idx0] = False
+                continue
+            p_from, p_to, wts = [], [], []
+            for li in sel:
+                lk = self.links[li]
+                if lk.uids[0] == self.meshes[idx0].uid:
+                    p_from.append(lk.xy0(gear=start_gear, use_mask=True, combine=True))
+                    p_to.append(lk.xy1(gear=target_gear, use_mask=True, combine=True))
+                else:
+                    p_from.append(lk.xy1(gear=start_gear, use_mask=True, combine=True))
+                    p_to.append(lk.xy0(gear=target_gear, use_mask=True, combine=True))
+                wts.append(lk.weight(use_mask=True))
+            xy_from = np.concatenate(p_from, axis=0)
+            if xy_from.size == 0:
+                to_optimize[idx0] = False
+                continue
+            xy_to = np.concatenate(p_to, axis=0)
+            _, A = common.fit_affine(xy_to, xy_from, return_rigid=True, weight=np.concatenate(wts, axis=None), svd_clip=svd_clip, avoid_flip=True)
+            if (not modified) and np.any(xy_from != xy_to):
+                modified = True
+            self.meshes[idx0].set_affine(A, gear=(start_gear, target_gear))
+            to_optimize[idx0] = False
+        return modified
 
     @property
     def lock_flags(self):

@@ -218,3 +218,34 @@ def test_newton_raphson_reduces_the_nonlinear_residual(fb):
     assert costs[1] < 0.2 * costs[0] and costs[3] < 1e-3 * costs[0]       # quadratic-ish decay of ||b||
     got = m1.vertices_w_offset(1) - v
     assert np.abs(got - disp).max() < np.abs(disp).max()                   # the mesh follows the links
+
+
+def test_g13_strain_chain_through_the_class_api(fb):
+    """matcher.py:752-777 written with the mirrored classes: SLM.optimize_affine_cascade -> anneal -> optimize_linear ->
+    Mesh.stiffness_matrix energies, against the reference's own numbers (golden G13).  Here the stiffness is assembled
+    at the rigidly rotated shape; the batch pipeline instead rotates right-hand sides -- same strain."""
+    from conftest import load_golden
+    g = load_golden('g13_strain.npz')
+    const = fb.constant
+    m0 = fb.mesh.Mesh(g['st_v'], g['st_tri'], uid=0)
+    m0.apply_translation(g['st_t0'], const.MESH_GEAR_FIXED)
+    m0.lock()
+    m1 = fb.mesh.Mesh(g['st_v'], g['st_tri'], uid=1)
+    link = fb.optimizer.Link(m0, m1, g['st_tid0'], g['st_tid1'], g['st_B0'], g['st_B1'], weight=g['st_w'])
+    opt = fb.optimizer.SLM([m0, m1], stiffness_lambda=1.0)
+    opt.add_link(link)
+    assert opt.optimize_affine_cascade(start_gear=const.MESH_GEAR_INITIAL, target_gear=const.MESH_GEAR_FIXED, svd_clip=(1, 1))
+    np.testing.assert_allclose(m1.vertices(const.MESH_GEAR_FIXED), g['st_v_fixed'], atol=1e-9)
+    np.testing.assert_allclose(m1.offset(const.MESH_GEAR_FIXED), g['st_off_fixed'], atol=1e-9)
+    opt.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_COPY_EXACT)
+    opt.optimize_linear(tol=1e-11)
+    v0 = m1.vertices(const.MESH_GEAR_FIXED)
+    dv = m1.vertices(const.MESH_GEAR_MOVING) - v0
+    np.testing.assert_allclose(m1.vertices(const.MESH_GEAR_MOVING), g['st_v_moving'], atol=1e-6)
+    v0 = v0 - v0.mean(axis=0, keepdims=True); dv = dv - dv.mean(axis=0, keepdims=True)
+    St, _ = m1.stiffness_matrix()
+    Es = max(0, St.dot(dv.ravel()).dot(dv.ravel())); Es0 = max(0, St.dot(v0.ravel()).dot(v0.ravel()))
+    np.testing.assert_allclose(Es0, float(g['st_Es0']), rtol=1e-6)
+    np.testing.assert_allclose((Es / Es0) ** 0.5, float(g['st_strain']), rtol=1e-5)
+    labels, n = opt.connected_subsystems
+    assert n == 1 and opt.match_residues(quantile=1).shape == (1,)
