@@ -54,6 +54,8 @@ struct fb_system {
     void* d_gstat = nullptr;         // per-group solve statistics (relres f64, iters i32, flag i32)
     int gstat_cap = 0;
     fb_bsr* M = nullptr;             // A + PCG workspace, shares the pattern
+    double* d_Kscr = nullptr;        // scratch rows for meshes that ADD into shared rows (grouped meshes)
+    float2* d_sscr = nullptr;
     // host scratch of the batched tile-pair stages (fb_pairs_*)
     std::vector<int32_t> h_nodes6;
     std::vector<double> h_bary6, h_B1, h_dxy, h_x;
@@ -256,6 +258,24 @@ __global__ void asm_stiffness_kernel(int voff, int V, const int* __restrict__ tr
             reinterpret_cast<double4*>(Kval)[j] = k;
         }
     }
+}
+
+// rows [voff, voff + V): K += Kscr, stress += sscr (a mesh that shares its vertex rows with another mesh of its group)
+__global__ void add_rows_kernel(int voff, int V, const int* __restrict__ rowptr, const double* __restrict__ Kscr, const float2* __restrict__ sscr,
+                                double* __restrict__ Kval, float2* __restrict__ stress) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int grow = voff + v;
+    for (int j = rowptr[grow]; j < rowptr[grow + 1]; ++j) {
+        double4 k = reinterpret_cast<double4*>(Kval)[j];
+        const double4 a = reinterpret_cast<const double4*>(Kscr)[j];
+        k.x += a.x; k.y += a.y; k.z += a.z; k.w += a.w;
+        reinterpret_cast<double4*>(Kval)[j] = k;
+    }
+    const float2 a = sscr[grow];
+    float2 t = stress[grow];
+    t.x += a.x; t.y += a.y;
+    stress[grow] = t;
 }
 
 // thread per free vertex: cross-link contributions of the matches incident to it
@@ -472,7 +492,7 @@ void fb_sys_destroy(fb_ctx* ctx, fb_system* s) {
         hipFree(m.d_model); hipFree(m.d_nu); hipFree(m.d_matmult);
     }
     hipFree(s->d_nodes); hipFree(s->d_vmptr); hipFree(s->d_vmidx); hipFree(s->d_bary); hipFree(s->d_w); hipFree(s->d_rxy);
-    hipFree(s->d_glambda); hipFree(s->d_gstat); hipFree(s->d_K); hipFree(s->d_Cacc); hipFree(s->d_C); hipFree(s->d_rhs); hipFree(s->d_stress); hipFree(s->d_parts);
+    hipFree(s->d_glambda); hipFree(s->d_gstat); hipFree(s->d_Kscr); hipFree(s->d_sscr); hipFree(s->d_K); hipFree(s->d_Cacc); hipFree(s->d_C); hipFree(s->d_rhs); hipFree(s->d_stress); hipFree(s->d_parts);
     if (s->M) fb_bsr_free(ctx, s->M);
     delete s;
 }
@@ -615,7 +635,8 @@ int fb_sys_pattern(fb_ctx* ctx, fb_system* s, int64_t* browptr, int32_t* bcol) {
 }
 
 static int assemble_mesh_impl(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur, const float* tri_mult,
-                              double nu, double soft, const int32_t* tri_model, const double* tri_nu, const float* tri_matmult) {
+                              double nu, double soft, const int32_t* tri_model, const double* tri_nu, const float* tri_matmult,
+                              bool accumulate = false) {
     FB_CHECK_ARG(ctx, s && s->finalized && mesh_id >= 0 && mesh_id < (int)s->meshes.size() && v_shape);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     fb_mesh_blk& m = s->meshes[mesh_id];
@@ -636,7 +657,10 @@ static int assemble_mesh_impl(fb_ctx* ctx, fb_system* s, int mesh_id, const doub
                            m.d_vtidx, m.d_vshape, v_cur ? m.d_vcur : (const double2*)nullptr, tri_mult ? m.d_mult : (const float*)nullptr,
                            (1.0 - nu) / 2.0, nu, soft, (float)soft, tri_model ? m.d_model : (const int*)nullptr,
                            tri_model ? m.d_nu : (const double*)nullptr, tri_model ? m.d_matmult : (const float*)nullptr,
-                           s->M->d.rowptr, s->M->d.col, s->d_K, s->d_stress);
+                           s->M->d.rowptr, s->M->d.col, accumulate ? s->d_Kscr : s->d_K, accumulate ? s->d_sscr : s->d_stress);
+        if (accumulate)
+            hipLaunchKernelGGL(add_rows_kernel, dim3(fb_cdiv(m.V, kT)), dim3(kT), 0, ctx->stream, m.voff, m.V, s->M->d.rowptr, s->d_Kscr, s->d_sscr,
+                               s->d_K, s->d_stress);
     }
     FB_HIP(ctx, hipGetLastError());
     FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -647,6 +671,20 @@ int fb_sys_assemble_mesh(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v
                          double nu, double soft) {
     FB_LOCK(ctx);
     return assemble_mesh_impl(ctx, s, mesh_id, v_shape, v_cur, tri_mult, nu, soft, nullptr, nullptr, nullptr);
+}
+
+// As fb_sys_assemble_mesh, but the mesh ADDS its stiffness rows and stress to what the rows already hold: meshes that were
+// entered at the same vertex offset share their degrees of freedom (`groupings` of SLM.optimize_linear, optimizer.py:1378-1415:
+// T K T^T sums the members of a group).  Assemble the first member with fb_sys_assemble_mesh, the others with this.
+int fb_sys_assemble_mesh_add(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur, const float* tri_mult,
+                             double nu, double soft) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized);
+    if (!s->d_Kscr) {
+        FB_HIP(ctx, hipMalloc((void**)&s->d_Kscr, sizeof(double) * 4 * (size_t)s->M->nnzb));
+        FB_HIP(ctx, hipMalloc((void**)&s->d_sscr, sizeof(float2) * (size_t)s->nv));
+    }
+    return assemble_mesh_impl(ctx, s, mesh_id, v_shape, v_cur, tri_mult, nu, soft, nullptr, nullptr, nullptr, true);
 }
 
 int fb_sys_assemble_mesh_materials(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur,

@@ -283,12 +283,16 @@ class Mesh:
             m = self._stiffness_multiplier * m
         return np.ascontiguousarray(m, dtype=np.float32)
 
-    def assemble_into(self, sysh, mesh_id, v_shape, v_cur, soft):
-        """numeric assembly of this mesh's stiffness rows into a GPU system"""
+    def assemble_into(self, sysh, mesh_id, v_shape, v_cur, soft, add=False):
+        """numeric assembly of this mesh's stiffness rows into a GPU system (add: on top of the rows' current content,
+        for a mesh that shares its degrees of freedom with an earlier member of its group)"""
         lib, ctx = _lib.load(), _lib.ctx()
         if self.tri_model is None:
-            _lib.check(lib.fb_sys_assemble_mesh(ctx, sysh, mesh_id, _lib.ptr(v_shape), _lib.ptr(v_cur),
-                                                _lib.ptr(self.element_multiplier()), self.poisson_ratio, float(soft)))
+            fn = lib.fb_sys_assemble_mesh_add if add else lib.fb_sys_assemble_mesh
+            _lib.check(fn(ctx, sysh, mesh_id, _lib.ptr(v_shape), _lib.ptr(v_cur),
+                          _lib.ptr(self.element_multiplier()), self.poisson_ratio, float(soft)))
+        elif add:
+            raise NotImplementedError('grouped meshes with non-linear materials')
         else:
             _lib.check(lib.fb_sys_assemble_mesh_materials(ctx, sysh, mesh_id, _lib.ptr(v_shape), _lib.ptr(v_cur),
                                                           _lib.ptr(np.ascontiguousarray(self.stiffness_multiplier, dtype=np.float32)),

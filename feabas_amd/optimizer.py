@@ -339,38 +339,69 @@ class SLM:
     def degree_of_freedom(self):
         return int(sum(2 * m.num_vertices for m in self.meshes if not m.locked))
 
+    def _layout(self, groupings=None):
+        """degree-of-freedom layout: {uid: first DoF or -1}, total DoF, and (with groupings, optimizer.py:1378-1415) the set
+        of meshes that ADD into rows another member of their group owns, plus mean group size.  Members of a group share
+        their DoFs; a group with a locked member is locked as a whole."""
+        if groupings is None:
+            return self.index_offsets, self.degree_of_freedom, set(), 1.0
+        groupings = np.asarray(groupings)
+        assert groupings.size == len(self.meshes)
+        group_u, indx, group_nm, g_cnt = np.unique(groupings, return_index=True, return_inverse=True, return_counts=True)
+        if group_u.size == groupings.size:
+            return self.index_offsets, self.degree_of_freedom, set(), 1.0
+        glock = np.zeros(group_u.size, dtype=bool)
+        np.logical_or.at(glock, group_nm, self.lock_flags)
+        vnum = np.array([self.meshes[k].num_vertices * 2 for k in indx]) * (~glock)
+        acc = np.cumsum(vnum)
+        goff = np.concatenate(([0], acc[:-1]))
+        goff[glock] = -1
+        offs, adders, seen = {}, set(), set()
+        for k, m in enumerate(self.meshes):
+            g = group_nm[k]
+            if m.locked or goff[g] < 0:
+                offs[m.uid] = -1
+                continue
+            assert m.num_vertices * 2 == vnum[g], 'meshes of a group must have the same number of vertices'
+            offs[m.uid] = int(goff[g])
+            if g in seen:
+                adders.add(m.uid)
+            seen.add(g)
+        return offs, int(acc[-1]), adders, float(np.mean(g_cnt))
+
     # ------------------------------------------------------------------ GPU system
     def _active_links(self):
         return [lk for lk in self.links if lk.relevant and lk._tid0.size > 0]
 
-    def _ensure_system(self):
+    def _ensure_system(self, groupings=None):
         """(Re)build the symbolic GPU system when the topology (free meshes, link
-        connectivity) changed; numeric re-assembly reuses it."""
+        connectivity, groupings) changed; numeric re-assembly reuses it."""
         lib = _lib.load()
         ctx = _lib.ctx()
-        offs = self.index_offsets
-        links = self._active_links()
+        offs, dof, adders, gmean = self._layout(groupings)
+        self._offs, self._adders, self._gmean = offs, adders, gmean
+        links = [lk for lk in self._active_links() if offs[lk.meshes[0].uid] >= 0 or offs[lk.meshes[1].uid] >= 0]
         node_rows = []
         for lk in links:
             cols = []
             for side, (m, tid) in enumerate(zip(lk.meshes, (lk._tid0, lk._tid1))):
-                if m.locked:
+                if offs[m.uid] < 0:
                     cols.append(np.full((tid.size, 3), -1, dtype=np.int32))
                 else:
                     cols.append((m.triangles[tid] + offs[m.uid] // 2).astype(np.int32))
             node_rows.append(np.concatenate(cols, axis=-1))
         nodes6 = np.ascontiguousarray(np.concatenate(node_rows, axis=0), dtype=np.int32) if node_rows else np.zeros((0, 6), np.int32)
-        key = (tuple((m.uid, m.locked, m.num_vertices, m.triangles.ctypes.data) for m in self.meshes), nodes6.tobytes())
+        key = (tuple((m.uid, offs[m.uid], m.num_vertices, m.triangles.ctypes.data) for m in self.meshes), nodes6.tobytes())
         if self._sys is not None and key == self._sys_key:
             return links
         self._drop_system()
-        nv = self.degree_of_freedom // 2
+        nv = dof // 2
         sysh = C.c_void_p()
         _lib.check(lib.fb_sys_create(ctx, nv, C.byref(sysh)))
         self._sys = sysh
         self._mesh_ids = {}
         for m in self.meshes:
-            if m.locked:
+            if offs[m.uid] < 0:
                 continue
             mid = C.c_int()
             _lib.check(lib.fb_sys_add_mesh(ctx, sysh, offs[m.uid] // 2, _lib.ptr(m.triangles), m.num_vertices,
@@ -384,21 +415,22 @@ class SLM:
         self._sys_key = key
         return links
 
-    def _assemble(self, shape_gear, start_gear, target_gear):
+    def _assemble(self, shape_gear, start_gear, target_gear, groupings=None):
         """numeric assembly of K, stress, C, rhs on the GPU (optimizer.py:1307-1310)."""
         lib = _lib.load()
         ctx = _lib.ctx()
-        links = self._ensure_system()
+        links = self._ensure_system(groupings)
+        offs = self._offs
         for m in self.meshes:
-            if m.locked:
+            if offs[m.uid] < 0:
                 continue
             v0 = np.ascontiguousarray(m.vertices(shape_gear), dtype=np.float64)
             v1 = m.vertices(start_gear)
             v1c = None if v1 is m.vertices(shape_gear) else np.ascontiguousarray(v1, dtype=np.float64)
-            m.assemble_into(self._sys, self._mesh_ids[m.uid], v0, v1c, float(m.soft_factor))
+            m.assemble_into(self._sys, self._mesh_ids[m.uid], v0, v1c, float(m.soft_factor), add=m.uid in self._adders)
         bary, wts, res = [], [], []
         for lk in links:
-            gears = [target_gear if m.locked else start_gear for m in lk.meshes]
+            gears = [target_gear if offs[m.uid] < 0 else start_gear for m in lk.meshes]
             bary.append(np.concatenate((lk._B0, -lk._B1), axis=-1))
             wts.append(lk.weight(use_mask=False))
             res.append(lk.dxy(gear=gears, use_mask=False))
@@ -433,8 +465,8 @@ class SLM:
 
     # ------------------------------------------------------------------ optimize
     def optimize_linear(self, **kwargs):
-        """feabas/optimizer.py:1257-1437 without groupings / DoF elimination.
-        Returns (||b||, ||A d - b||) and writes the field into the meshes."""
+        """feabas/optimizer.py:1257-1437 including `groupings` (members of a group share their degrees of freedom),
+        without the DoF-elimination options.  Returns (||b||, ||A d - b||) and writes the field into the meshes."""
         maxiter = kwargs.get('maxiter', None)
         tol = kwargs.get('tol', 1e-7)
         atol = kwargs.get('atol', 0.0)
@@ -444,17 +476,27 @@ class SLM:
         stiffness_lambda = kwargs.get('stiffness_lambda', self._stiffness_lambda)
         crosslink_lambda = kwargs.get('crosslink_lambda', self._crosslink_lambda)
         precondition = kwargs.get('precondition', 'jacobi')
-        for unsupported in ('groupings', 'remove_material_dof'):
-            if kwargs.get(unsupported, None) is not None:
-                raise NotImplementedError(f'optimize_linear({unsupported}=...) is outside the round-1 hot path')
+        groupings = kwargs.get('groupings', None)
+        if kwargs.get('remove_material_dof', None) is not None:
+            raise NotImplementedError('optimize_linear(remove_material_dof=...) is outside the hot path')
         if kwargs.get('remove_extra_dof', False):
             raise NotImplementedError('optimize_linear(remove_extra_dof=True) is outside the round-1 hot path')
         if np.all(self.lock_flags):
             return 0, 0
         lib = _lib.load()
         ctx = _lib.ctx()
-        self._assemble(shape_gear, start_gear, target_gear)
-        sl, cl = self.relative_lambda_trace(stiffness_lambda, crosslink_lambda)
+        if groupings is not None and all(o < 0 for o in self._layout(groupings)[0].values()):
+            return 0, 0                                          # optimizer.py:1383-1384: every group holds a locked mesh
+        grouped = groupings is not None and np.unique(np.asarray(groupings)).size < len(self.meshes)
+        if grouped:
+            # relative_lambda_trace reads the cached MESH-level K and C (optimizer.py:1573-1590), the grouped matrices only
+            # enter A and b: the lambdas come from the ungrouped system, assembled first
+            self._assemble(shape_gear, start_gear, target_gear, None)
+            sl, cl = self.relative_lambda_trace(stiffness_lambda, crosslink_lambda)
+            self._assemble(shape_gear, start_gear, target_gear, groupings)
+        else:
+            self._assemble(shape_gear, start_gear, target_gear, None)
+            sl, cl = self.relative_lambda_trace(stiffness_lambda, crosslink_lambda)
         _lib.check(lib.fb_sys_form(ctx, self._sys, sl, cl))
         b = np.empty(2 * self._nv, dtype=np.float64)
         _lib.check(lib.fb_sys_get(ctx, self._sys, 5, _lib.ptr(b)))
@@ -464,15 +506,15 @@ class SLM:
         pre = 0 if precondition is None else 1
         _lib.check(lib.fb_sys_solve(ctx, self._sys, _lib.ptr(dd), 0, float(tol), float(atol or 0.0), mi, pre,
                                     C.byref(iters), C.byref(relres)), allow=(_lib.FB_ERR_NOCONV,))
-        bn = float(np.linalg.norm(b))
+        bn = float(np.linalg.norm(b)) / self._gmean           # grouped terms are divided by mean(count) (optimizer.py:1408-1411)
         cost = (bn, float(relres.value * bn))
         self.last_solve = dict(iters=iters.value, relres=relres.value, stiffness_lambda=sl, crosslink_lambda=cl)
         if cost[1] < cost[0]:                               # optimizer.py:1421
-            offs = self.index_offsets
+            offs = self._offs
             for m in self.meshes:
-                if m.locked:
-                    continue
                 o = offs[m.uid]
+                if m.locked or o < 0:
+                    continue
                 m.set_field(dd[o:o + 2 * m.num_vertices].reshape(-1, 2), gear=(start_gear, target_gear))
         return cost
 

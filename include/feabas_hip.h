@@ -173,6 +173,10 @@ int fb_sys_info(fb_ctx* ctx, fb_system* sys, int64_t* nv, int64_t* nnzb, int64_t
  * (mesh.stiffness_multiplier * material.stiffness_multiplier) */
 int fb_sys_assemble_mesh(fb_ctx* ctx, fb_system* sys, int mesh_id, const double* v_shape, const double* v_cur,
                          const float* tri_mult, double nu, double soft);
+/* Same, but ADDS to the rows: for meshes entered at the same vertex offset as an earlier mesh (the `groupings` of
+ * SLM.optimize_linear, optimizer.py:1378-1415, make the members of a group share their degrees of freedom). */
+int fb_sys_assemble_mesh_add(fb_ctx* ctx, fb_system* sys, int mesh_id, const double* v_shape, const double* v_cur,
+                             const float* tri_mult, double nu, double soft);
 /* Mixed materials (Mesh.stiffness_matrix with non-engineering elements, mesh.py:2992-3083;
  * element maths material.py:185-309): per-triangle model (0 engineering-linear, 1 St-Venant-Kirchhoff,
  * 2 Neo-Hookean), Poisson ratio and material stiffness multiplier.  K is the tangent stiffness at v_cur,

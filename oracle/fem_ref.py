@@ -504,6 +504,57 @@ def apply_solution(meshes, dd, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING):
         m.set_field(d, gear=(start_gear, target_gear))
 
 
+def optimize_linear_grouped(meshes, links, groupings, stiffness_lambda=1.0, crosslink_lambda=-1.0,
+                            shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING, return_system=False):
+    """optimizer.py:1378-1437 with `groupings`: the members of a group share their degrees of freedom
+    (T K T^T / mean(count) ...), a group with a locked member is locked; exact solve.  Returns (||b||, ||A d - b||)."""
+    K, stress = system_stiffness(meshes, gear=(shape_gear, start_gear))
+    C, rhs = crosslink_terms(meshes, links, start_gear=start_gear, target_gear=target_gear)
+    # the lambdas come from the cached MESH-level terms (relative_lambda_trace reads self.stiffness_matrix() /
+    # self.crosslink_terms(), optimizer.py:1573-1590), not from the grouped matrices
+    ls, lc = relative_lambda_trace(K, C, stiffness_lambda, crosslink_lambda)
+    lock = np.array([m.locked for m in meshes])
+    groupings = np.asarray(groupings)
+    group_u, indx, group_nm, g_cnt = np.unique(groupings, return_index=True, return_inverse=True, return_counts=True)
+    glock = np.zeros(group_u.size, dtype=bool)
+    np.logical_or.at(glock, group_nm, lock)
+    vnum = np.array([meshes[k].num_vertices * 2 for k in indx]) * (~glock)
+    acc = np.cumsum(vnum)
+    gdof = int(acc[-1])
+    goff = np.concatenate(([0], acc[:-1]))
+    goff[glock] = -1
+    expanded = goff[group_nm]
+    cur = 0
+    i0, i1 = [], []
+    for m, gio in zip(meshes, expanded):
+        if m.locked:
+            continue
+        sz = 2 * m.num_vertices
+        if gio >= 0:
+            i0.append(np.arange(cur, cur + sz)); i1.append(np.arange(gio, gio + sz))
+        cur += sz
+    i0 = np.concatenate(i0); i1 = np.concatenate(i1)
+    T = sparse.csr_matrix((np.ones(i0.size, dtype=np.float32), (i1, i0)), shape=(gdof, K.shape[0]))
+    mc = np.mean(g_cnt)
+    K = T @ K @ T.transpose() / mc
+    C = T @ C @ T.transpose() / mc
+    stress = T @ stress / mc
+    rhs = T @ rhs / mc
+    A = ls * K + lc * C
+    b = lc * rhs - ls * stress
+    A = 0.5 * (A + A.T)
+    dd = solve_direct(A, b)
+    cost = (float(np.linalg.norm(b)), float(np.linalg.norm(A.dot(dd) - b)))
+    if cost[1] < cost[0]:
+        for m, gio in zip(meshes, expanded):
+            if m.locked or gio < 0:
+                continue
+            m.set_field(dd[gio:gio + 2 * m.num_vertices].reshape(-1, 2), gear=(start_gear, target_gear))
+    if return_system:
+        return cost, A, b, expanded
+    return cost
+
+
 def optimize_linear(meshes, links, tol=1e-7, stiffness_lambda=1.0, crosslink_lambda=-1.0,
                     shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING, exact=True):
     """optimizer.py:1257-1437 (no groupings / edc).  exact=True solves the

@@ -433,7 +433,42 @@ def g13_strain():
     np.savez_compressed(os.path.join(OUT, 'g13_strain.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G14
+def g14_groupings():
+    """SLM.optimize_linear(groupings=...) (optimizer.py:1378-1415): meshes 1 and 2 form one group (shared DoFs),
+    mesh 0 is locked, mesh 3 is on its own."""
+    rng = np.random.default_rng(1414)
+    out = {}
+    v0, t0 = grid(10, 8, 10.0)
+    va, ta = grid(9, 9, 11.0, origin=(2.0, -3.0))
+    v3, t3 = grid(8, 10, 9.0, origin=(-5.0, 4.0))
+    ms = [Mesh(v0, t0, uid=0, locked=True), Mesh(va, ta, uid=1), Mesh(va + np.array([0.4, -0.2]), ta, uid=2, soft_factor=0.7), Mesh(v3, t3, uid=3)]
+    ms[1].apply_translation((1.0, 0.5), const.MESH_GEAR_FIXED)
+    ms[3].apply_translation((-1.5, 2.0), const.MESH_GEAR_FIXED)
+    links = []
+    for k, (a, b, n) in enumerate(((0, 1, 40), (1, 3, 35), (2, 3, 30), (0, 2, 25))):
+        tid0 = rng.integers(0, ms[a].triangles.shape[0], size=n)
+        tid1 = rng.integers(0, ms[b].triangles.shape[0], size=n)
+        B0 = rng.dirichlet((1, 1, 1), size=n); B1 = rng.dirichlet((1, 1, 1), size=n)
+        w = rng.uniform(0.3, 1.0, size=n).astype(np.float32)
+        links.append(optimizer.Link(ms[a], ms[b], tid0, tid1, B0, B1, weight=w))
+        out[f'l{k}_ab'] = np.array([a, b]); out[f'l{k}_tid0'] = tid0; out[f'l{k}_tid1'] = tid1
+        out[f'l{k}_B0'] = B0; out[f'l{k}_B1'] = B1; out[f'l{k}_w'] = w
+    for k, m in enumerate(ms):
+        out[f'm{k}_v'] = m.vertices(gear=const.MESH_GEAR_INITIAL); out[f'm{k}_t'] = m.triangles
+        out[f'm{k}_off'] = m.offset(gear=const.MESH_GEAR_FIXED)
+    groupings = np.array([0, 1, 1, 2])
+    slm = optimizer.SLM(ms, links=links, stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    cost = slm.optimize_linear(tol=1e-11, groupings=groupings, tolerated_perturbation=None,
+                               callback_settings={'chances': None, 'eval_step': 10}, check_converge=True)
+    out['groupings'] = groupings
+    out['cost'] = np.array(cost, dtype=np.float64)
+    for k, m in enumerate(ms):
+        out[f'm{k}_v_after'] = m.vertices(gear=const.MESH_GEAR_MOVING); out[f'm{k}_off_after'] = m.offset(gear=const.MESH_GEAR_MOVING)
+    np.savez_compressed(os.path.join(OUT, 'g14_groupings.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings):
         fn()
         print('wrote', fn.__name__)

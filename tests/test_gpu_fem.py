@@ -249,3 +249,31 @@ def test_g13_strain_chain_through_the_class_api(fb):
     np.testing.assert_allclose((Es / Es0) ** 0.5, float(g['st_strain']), rtol=1e-5)
     labels, n = opt.connected_subsystems
     assert n == 1 and opt.match_residues(quantile=1).shape == (1,)
+
+
+def test_g14_optimize_linear_groupings(fb):
+    """SLM.optimize_linear(groupings=...) (optimizer.py:1378-1415): the members of a group are entered at the same vertex
+    offset and their stiffness / stress rows add up on the device (fb_sys_assemble_mesh_add).  ||b|| against the reference
+    (G14), the field against the oracle's exact solve of the same grouped system (itself pinned by G14)"""
+    from conftest import load_golden
+    from test_oracle_golden import g14_oracle_system
+    from oracle import fem_ref
+    g = load_golden('g14_groupings.npz')
+    const = fb.constant
+    ms = [fb.mesh.Mesh(g[f'm{k}_v'], g[f'm{k}_t'], uid=k, soft_factor=(0.7 if k == 2 else 1.0), fixed_offset=g[f'm{k}_off']) for k in range(4)]
+    ms[0].lock()
+    links = []
+    for k in range(4):
+        a, b = g[f'l{k}_ab']
+        links.append(fb.optimizer.Link(ms[a], ms[b], g[f'l{k}_tid0'], g[f'l{k}_tid1'], g[f'l{k}_B0'], g[f'l{k}_B1'], weight=g[f'l{k}_w']))
+    slm = fb.optimizer.SLM(ms, links=links, stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    cost = slm.optimize_linear(tol=1e-12, groupings=g['groupings'])
+    np.testing.assert_allclose(cost[0], g['cost'][0], rtol=1e-6)
+    oms, olinks = g14_oracle_system(g)
+    fem_ref.optimize_linear_grouped(oms, olinks, g['groupings'])
+    scale = np.abs(g['m1_v_after'] - g['m1_v']).max()
+    for k in range(1, 4):
+        np.testing.assert_allclose(ms[k].vertices(const.MESH_GEAR_MOVING) + ms[k].offset(const.MESH_GEAR_MOVING),
+                                   oms[k].vertices_w_offset(fem_ref.GEAR_MOVING), atol=1e-4 * scale)
+    # meshes 1 and 2 moved as one
+    np.testing.assert_allclose(ms[1].vertices(const.MESH_GEAR_MOVING) - g['m1_v'], ms[2].vertices(const.MESH_GEAR_MOVING) - g['m2_v'], atol=1e-9 * scale)

@@ -232,3 +232,34 @@ def test_g13_strain_chain():
     np.testing.assert_allclose(Es0, float(g['st_Es0']), rtol=1e-10)
     np.testing.assert_allclose(Es, float(g['st_Es']), rtol=1e-6)
     np.testing.assert_allclose(strain, float(g['st_strain']), rtol=1e-6)
+
+
+# ----------------------------------------------------------------------- G14: optimize_linear(groupings=...)
+def g14_oracle_system(g):
+    ms = [fem_ref.RefMesh(g[f'm{k}_v'], g[f'm{k}_t'], uid=k, soft_factor=(0.7 if k == 2 else 1.0)) for k in range(4)]
+    ms[0].locked = True
+    for k in range(4):
+        ms[k]._off[fem_ref.GEAR_FIXED] = g[f'm{k}_off']
+    links = []
+    for k in range(4):
+        a, b = g[f'l{k}_ab']
+        links.append(fem_ref.RefLink(ms[a], ms[b], g[f'l{k}_tid0'], g[f'l{k}_tid1'], g[f'l{k}_B0'], g[f'l{k}_B1'], weight=g[f'l{k}_w']))
+    return ms, links
+
+
+def test_g14_groupings():
+    """the grouped system A, b of the restatement is the reference's: ||b|| equal, and the reference's own (iteratively
+    solved, relres 1e-8) displacement field leaves a residual of that size in it.  (The system is ill conditioned: the
+    reference's iterate is ~1 % away from the fixed point, so the fields themselves are compared loosely.)"""
+    g = load_golden('g14_groupings.npz')
+    ms, links = g14_oracle_system(g)
+    cost, A, b, expanded = fem_ref.optimize_linear_grouped(ms, links, g['groupings'], return_system=True)
+    np.testing.assert_allclose(cost[0], g['cost'][0], rtol=1e-9)
+    dd_ref = np.zeros(b.size)
+    for k in (1, 3):                                        # one member per free group
+        d = (g[f'm{k}_v_after'] + g[f'm{k}_off_after']) - (g[f'm{k}_v'] + g[f'm{k}_off'])
+        dd_ref[expanded[k]:expanded[k] + d.size] = d.ravel()
+    assert np.linalg.norm(A.dot(dd_ref) - b) <= 3e-8 * np.linalg.norm(b)
+    scale = np.abs(g['m1_v_after'] - g['m1_v']).max()
+    for k in range(1, 4):
+        np.testing.assert_allclose(ms[k].vertices_w_offset(fem_ref.GEAR_MOVING), g[f'm{k}_v_after'] + g[f'm{k}_off_after'], atol=0.05 * scale)
