@@ -108,6 +108,33 @@ __device__ __forceinline__ void pk_dft16(f2* v) {
         for (int p2 = 0; p2 < 4; ++p2) v[p1 + 4 * p2] = b[p2];
     }
 }
+// 16-point DFT whose inputs v[8..15] are zero (the first pass of a transform whose upper half is zero padding):
+// the first-stage 4-point transforms see (x0, x1, 0, 0)
+template <bool INV>
+__device__ __forceinline__ void pk_dft16_lo8(f2* v) {
+    f2 a[4][4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+        const f2 x0 = v[j2], x1 = v[j2 + 4];
+        a[j2][0] = x0 + x1; a[j2][2] = x0 - x1;
+        a[j2][1] = INV ? pk_add_pi(x0, x1) : pk_add_mi(x0, x1);
+        a[j2][3] = INV ? pk_add_mi(x0, x1) : pk_add_pi(x0, x1);
+    }
+#pragma unroll
+    for (int j2 = 1; j2 < 4; ++j2)
+#pragma unroll
+        for (int p1 = 1; p1 < 4; ++p1) a[j2][p1] = pk_twc<INV>(a[j2][p1], j2 * p1);
+#pragma unroll
+    for (int p1 = 0; p1 < 4; ++p1) {
+        f2 b[4];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) b[j2] = a[j2][p1];
+        pk_dft4<INV>(b);
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) v[p1 + 4 * p2] = b[p2];
+    }
+}
+
 template <int R, bool INV>
 __device__ __forceinline__ void pk_dft(f2* v) {
     if (R == 2) pk_dft2<INV>(v);
@@ -141,7 +168,8 @@ struct P2Store {             // default sink of a pass: write the butterfly back
     __device__ __forceinline__ void operator()(int, int, f2) const {}
 };
 
-template <int N, int R, int L, bool INV, typename SINK = P2Store>
+// ZH: the elements N/2 .. N-1 of every transform are zero and are NOT stored in LDS (forward radix-16 pass with L == N only)
+template <int N, int R, int L, bool INV, typename SINK = P2Store, bool ZH = false>
 __device__ __forceinline__ void p2_pass(f2* base, int M, int pitch, const f2* tw, int tid, int nt, const SINK& sink = SINK()) {
     constexpr int Lp = L / R, per = N / R, lper = p2_log2(per), lLp = p2_log2(Lp);
     const int total = per * M;
@@ -152,7 +180,7 @@ __device__ __forceinline__ void p2_pass(f2* base, int M, int pitch, const f2* tw
         f2* p = base + m * pitch + e0 + (e0 >> 4);
         f2 v[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = p[q * Lp + ((q * Lp) >> 4)];
+        for (int q = 0; q < R; ++q) v[q] = (ZH && q >= R / 2) ? (f2){0.f, 0.f} : p[q * Lp + ((q * Lp) >> 4)];
         if (L > R) {
             // w[q] = w1^q by squarings / products of depth <= log2(R); each power is applied as soon as it exists so
             // that at most R / 2 of them are live
@@ -167,7 +195,8 @@ __device__ __forceinline__ void p2_pass(f2* base, int M, int pitch, const f2* tw
                 }
                 pk_dft<R, true>(v);
             } else {
-                pk_dft<R, false>(v);
+                if (ZH && R == 16) pk_dft16_lo8<false>(v);
+                else pk_dft<R, false>(v);
                 v[1] = pk_cmul(v[1], w[1]);                                   // DIF: twiddle after
 #pragma unroll
                 for (int q = 2; q < R; ++q) {
@@ -201,10 +230,14 @@ constexpr int p2_last_radix(int N) { return p2_rem(N) > 1 ? p2_rem(N) : 16; }
 // forward transform without its last pass / inverse transform without its first pass: the caller fuses
 // those two with the pointwise work in between (each touches R consecutive elements of a transform)
 template <int N>
-__device__ __forceinline__ void p2_fft_fwd_head(f2* base, int M, int pitch, const f2* tw) {
+__device__ __forceinline__ void p2_fft_fwd_head(f2* base, int M, int pitch, const f2* tw, bool upper_half_zero = false) {
     const int tid = threadIdx.x, nt = blockDim.x;
     constexpr int n16 = p2_n16(N), rem = p2_rem(N), nh = rem > 1 ? n16 : n16 - 1;
-    if (nh >= 1) { P2Stage<N, 0, false>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
+    if (nh >= 1) {
+        if (upper_half_zero) p2_pass<N, 16, N, false, P2Store, true>(base, M, pitch, tw, tid, nt);
+        else P2Stage<N, 0, false>::run(base, M, pitch, tw, tid, nt);
+        __syncthreads();
+    }
     if (nh >= 2) { P2Stage<N, (nh >= 2 ? 1 : 0), false>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
     if (nh >= 3) { P2Stage<N, (nh >= 3 ? 2 : 0), false>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
 }
