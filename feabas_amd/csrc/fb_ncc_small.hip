@@ -38,12 +38,11 @@ struct SmallParams {
 
 bool small_ct_len(int n) { return n == 64 || n == 72 || n == 75 || n == 80 || n == 81 || n == 90 || n == 96 || n == 100; }
 
-// row pitch (float2 units) of the [Fh][pitch] work array: at least the 2 Sw packed columns; FB_SMALL_PITCH adds
-// padding columns (bank-conflict experiments)
+// row pitch (float2 units) of the [Fh][pitch] work array: the 2 Sw packed columns (extra padding columns were measured
+// to change nothing: the row passes are not limited by bank conflicts between rows)
 int small_pitch(int Fw) {
     const int Sw = Fw / 2 + 1;
-    const int extra = getenv("FB_SMALL_PITCH") ? atoi(getenv("FB_SMALL_PITCH")) : 0;
-    return 2 * Sw + std::max(0, extra);
+    return 2 * Sw;
 }
 
 size_t small_lds_bytes(int Fh, int Fw) {
