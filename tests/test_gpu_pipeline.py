@@ -239,3 +239,24 @@ def test_stitching_matcher_drop_in(fb):
     assert out[0] is None and out[1] is None and out[2] == 0.33 and out[3] is None and out[4] is None
     with pytest.raises(NotImplementedError):
         fb.matcher.stitching_matcher(h0[0], h1[0], mask0=np.ones((H, W), bool))
+
+
+@pytest.mark.parametrize('H,W', [(3000, 500), (400, 4000)])
+def test_pipeline_readme_tile_shapes(fb, H, W):
+    """the README 3000 x 4000 tiles: strips 3000 x 500 / 400 x 4000 -> non-power-of-two FFT shapes (3000 x 500 global,
+    1200 x 1000 / 800 x 1600 coarse blocks, 150 x 144 / 135 x 150 padded fine blocks) on the generic mixed-radix kernels"""
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    P = 2
+    s0, s1, shifts = _synth(fb, P, H, W, seed=3, max_shift=14, step=2, warp=0.3)
+    m = StripBatchMatcher(P, H, W)
+    got = StripBatchMatcher.per_pair(m.match(s0.ptr, s1.ptr))
+    h0 = s0.to_array((P, H, W), np.uint8); h1 = s1.to_array((P, H, W), np.uint8)
+    exp = pipeline_ref.match_pair(h0[0], h1[0])
+    g = got[0]
+    assert (g['tx'], g['ty']) == (exp['tx'], exp['ty']) == (-shifts[0, 0], -shifts[0, 1])
+    assert g['needs_host'] == exp['needs_host'] == False
+    assert g['xy0'].shape == exp['xy0'].shape and g['xy0'].shape[0] > 100
+    np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4); np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
+    np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
+    np.testing.assert_allclose(g['strain'], exp['strain'], rtol=2e-3, atol=1e-7)
+    m.free()
