@@ -31,9 +31,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=32)
-    ap.add_argument('--warmup', type=int, default=4)
-    ap.add_argument('--pairs-per-step', type=int, default=64)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--pairs-per-step', type=int, default=512, help='tile pairs per step = one batch of the hot path; processed as sub-batches of --sub-batch pairs dealt to the host threads')
+    ap.add_argument('--sub-batch', type=int, default=64, help='pairs per StripBatchMatcher call')
     ap.add_argument('--resident-pairs', type=int, default=1024)
     ap.add_argument('--tile', type=int, default=4096)
     ap.add_argument('--host-threads', type=int, default=8, help='host threads driving the device (even; steps are dealt round-robin, LR and UD batches alternate)')
@@ -198,7 +199,8 @@ def main():
     T = args.tile
     ov = int(round(0.1 * T)) + 100                        # 10 % overlap + margin 100 (stitching_configs.yaml:21)
     ov += ov % 2
-    P = args.pairs_per_step
+    P = args.sub_batch                                     # pairs per matcher call
+    S = max(1, args.pairs_per_step // P)                   # matcher calls per step
     n_res = max(P, args.resident_pairs // 2 // P * P)     # resident pairs per orientation
     shapes = {'LR': (T, ov), 'UD': (ov, T)}
     strips = {}
@@ -298,12 +300,12 @@ def main():
     else:
         step(0); step(1)
     barrier()
-    run_steps(0, args.warmup)
+    run_steps(0, args.warmup * S)
     barrier()
     for h in ctxs:
         _lib.check(lib.fb_prof_reset(h)); _lib.check(lib.fb_prof_enable(h, 1))
     t0 = time.time()
-    last = run_steps(args.warmup, args.steps)
+    last = run_steps(args.warmup * S, args.steps * S)
     barrier()
     dt = time.time() - t0
     prof_timed = {}
@@ -321,14 +323,14 @@ def main():
         iso_steps = 4
         _lib.check(lib.fb_prof_reset(ctx)); _lib.check(lib.fb_prof_enable(ctx, 1))
         for i in range(iso_steps):
-            step(args.warmup + args.steps + i)
+            step((args.warmup + args.steps) * S + i)
         _lib.check(lib.fb_sync(ctx)); _lib.check(lib.fb_prof_enable(ctx, 0))
         prof = _lib.prof_snapshot(ctx)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    pairs = args.steps * P * world
+    pairs = args.steps * S * P * world
 
     # correctness of the timed work: recovered translations = injected shifts, matches found
     k, b, res = last
@@ -351,11 +353,11 @@ def main():
                 pipeline_achieved_gbs=pair_bytes * pairs / world / dt / 1e9,
                 pipeline_frac=pair_bytes * pairs / world / dt / 1e9 / HBM_PEAK_GBS,
                 kernel_ms={k_: round(v[1], 3) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
-                kernel_ms_steps=(iso_steps if iso_steps else args.steps),
+                kernel_ms_steps=(iso_steps if iso_steps else args.steps * S),       # matcher calls the kernel_ms totals cover
                 avg_launch_ms_timed_region=(prof_timed[dom[0]][1] / max(prof_timed[dom[0]][0], 1) if dom[0] in prof_timed else None),
-                measured_on=(f'{iso_steps} extra steps of the same workload on one stream after the timed region (the timed region runs one '
-                             f'stream per host thread: its kernels overlap, event sum {sum(v[1] for v in prof_timed.values()) / max(args.steps, 1):.2f} '
-                             f'ms per step against {1e3 * dt / max(args.steps, 1):.2f} ms wall -- avg_launch_ms_timed_region is that overlapped duration and is what '
+                measured_on=(f'{iso_steps} extra matcher calls ({P} pairs each) of the same workload on one stream after the timed region (the timed region runs one '
+                             f'stream per host thread: its kernels overlap, event sum {sum(v[1] for v in prof_timed.values()) / max(args.steps * S, 1):.2f} '
+                             f'ms per sub-batch against {1e3 * dt / max(args.steps * S, 1):.2f} ms wall -- avg_launch_ms_timed_region is that overlapped duration and is what '
                              f'rocprofv3 --stats of this command reports, profiles/*_bench_kernel_stats.csv); --multi-stream 0 times the kernels inside '
                              f'the timed region (profiles/*_bench_one_stream_kernel_stats.csv)'
                              if iso_steps else 'the timed region (one stream)'))
@@ -381,10 +383,10 @@ def main():
                 warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='weak',
                 vs_baseline=None, dtype='f32', data='synthetic',
                 config=dict(workload=f'config[1]: {2 * n_res} resident synthetic {T}x{T} tile pairs ({n_res} LR + {n_res} UD strips '
-                                     f'{Hl}x{Wl}), {P} pairs per step; stages: x0.5 downsample, DoG, global NCC, DoG, '
+                                     f'{Hl}x{Wl}), {P * S} pairs per step ({S} matcher calls of {P} pairs dealt to {nthr} host threads); stages: x0.5 downsample, DoG, global NCC, DoG, '
                                      f'4 coarse + 385 fine block NCCs, last-round relaxation + residue weights + strain (integer synthetic offsets in +-20 px plus a smooth '
                                      f'{args.warp} px warp; odd offsets take the rigid mesh-relaxation branch, DESIGN.md sec.5)',
-                            pairs_per_step=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33),
+                            pairs_per_step=P * S, pairs_per_matcher_call=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33),
                 check=dict(global_shift_within_1px=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches, matches_within_half_px_of_truth=ok_match,
                            pairs_needing_mesh_relaxation=int(res['needs_host'].sum())),
                 roofline=roof)
