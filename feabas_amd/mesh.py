@@ -214,6 +214,22 @@ class Mesh:
         self.set_vertices(v0 + (dxy - m), gear[-1])
         self.set_offset(off0 + m, gear[-1])
 
+    def set_translation(self, dxy, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)):   # mesh.py:2289-2300 (unmasked)
+        if self.locked:
+            return
+        if gear[0] == gear[-1]:
+            self.apply_translation(dxy, gear[0])
+            return
+        dxy = np.asarray(dxy, dtype=np.float64).reshape(1, 2)
+        self.set_vertices(self.vertices(gear[0]), gear[-1])
+        self.set_offset(self.offset(gear[0]) + dxy, gear[-1])
+
+    def estimate_translation(self, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)):   # mesh.py:2309-2321 (unmasked)
+        if gear[0] == gear[-1]:
+            return np.zeros(2)
+        d = self.vertices(gear[-1]).mean(axis=0) - self.vertices(gear[0]).mean(axis=0)
+        return d.ravel() + (self.offset(gear[-1]) - self.offset(gear[0])).ravel()
+
     def set_affine(self, A, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)):      # mesh.py:2342-2354 (unmasked)
         if self.locked:
             return

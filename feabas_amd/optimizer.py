@@ -158,6 +158,16 @@ class Link:
             return True, (self.num_matches > 0) != prev_conn
         return False, False
 
+    def disable(self):                                     # optimizer.py:208-213
+        self._disabled = True
+
+    def enable(self):
+        self._disabled = False
+
+    @property
+    def weight_sum(self):                                  # optimizer.py:391-395
+        return 0 if self._disabled else np.sum(self.weight(use_mask=True))
+
     def reset_mask(self):
         self._residue_weight = np.ones_like(self._weight)
         self._mask = None
@@ -270,6 +280,109 @@ class SLM:
             else:
                 dis.append(np.quantile(d, quantile))
         return np.array(dis)
+
+    def optimize_translation_lsqr(self, **kwargs):
+        """optimizer.py:974-1078: one translation per free mesh from the weighted medians of the link residuals, least
+        squares (scipy lsqr, host -- SURVEY.md b13: #tiles unknowns, stays on the host like in the reference).  Returns
+        (cost, per-link residue) and writes the translations to target_gear."""
+        from scipy.sparse.linalg import lsqr
+        maxiter = kwargs.get('maxiter', None)
+        tol = kwargs.get('tol', 1e-07)
+        start_gear = kwargs.get('start_gear', const.MESH_GEAR_FIXED)
+        target_gear = kwargs.get('target_gear', const.MESH_GEAR_FIXED)
+        return_residue = kwargs.get('return_residue', True)
+        locked = self.lock_flags
+        free_idx = np.nonzero(~locked)[0]
+        nl = len(self.links)
+        if nl == 0 or free_idx.size == 0:
+            return None, None
+        col_of = {self.meshes[k].uid: c for c, k in enumerate(free_idx)}
+        known = {m.uid for m in self.meshes}
+        labels, _ = self.connected_subsystems
+        floating = sorted(set(labels[~locked]).difference(set(labels[locked])))       # components without a locked mesh
+        A = sparse.lil_matrix((nl + len(floating), free_idx.size))
+        bx = np.zeros(nl + len(floating)); by = np.zeros(nl + len(floating))
+        rel = np.zeros(nl, dtype=np.float32)
+        row = 0
+        for k, lk in enumerate(self.links):
+            if (not lk.relevant) or (lk.uids[0] not in known) or (lk.uids[1] not in known):
+                continue
+            wt = lk.weight_sum ** 0.5
+            if wt == 0:
+                continue
+            gears = []
+            for side, sign in ((0, 1.0), (1, -1.0)):
+                if lk.uids[side] in col_of:
+                    A[row, col_of[lk.uids[side]]] = sign * wt
+                    gears.append(start_gear)
+                else:
+                    gears.append(target_gear)
+            d = np.median(lk.dxy(gear=gears, use_mask=True), axis=0)
+            bx[row] = d[0] * wt; by[row] = d[1] * wt
+            rel[k] = wt
+            row += 1
+        if row == 0:
+            return None, None
+        wt = (A.power(2).sum(axis=None) / A.getnnz(axis=None)) ** 0.5
+        lab_free = labels[~locked]
+        for lbl in floating:                                   # pin one mesh of every floating component to its current estimate
+            pos = int(np.nonzero(lab_free == lbl)[0][0])
+            A[row, pos] = wt
+            t = self.meshes[free_idx[pos]].estimate_translation(gear=(start_gear, target_gear))
+            bx[row] = t[0] * wt; by[row] = t[1] * wt
+            row += 1
+        A = A.tocsr()
+        Tx = lsqr(A, bx, atol=tol, btol=tol, iter_lim=maxiter)[0]
+        Ty = lsqr(A, by, atol=tol, btol=tol, iter_lim=maxiter)[0]
+        rx = A.dot(Tx) - bx; ry = A.dot(Ty) - by
+        c0 = c1 = 0.0
+        if np.linalg.norm(bx) <= np.linalg.norm(rx):
+            Tx = np.zeros_like(Tx)
+        else:
+            c0 += np.linalg.norm(bx); c1 += np.linalg.norm(rx)
+        if np.linalg.norm(by) <= np.linalg.norm(ry):
+            Ty = np.zeros_like(Ty)
+        else:
+            c0 += np.linalg.norm(by); c1 += np.linalg.norm(ry)
+        cost = None
+        if np.any(Tx != 0) or np.any(Ty != 0):
+            for k, tx, ty in zip(free_idx, Tx, Ty):
+                self.meshes[k].set_translation((tx, ty), gear=(start_gear, target_gear))
+            cost = (float(c0), float(c1))
+        residue = None
+        if return_residue and cost is not None:
+            sel = rel > 0
+            nrel = int(np.sum(sel))
+            residue = np.zeros(nl, dtype=np.float32)
+            residue[sel] = (rx[:nrel] ** 2 + ry[:nrel] ** 2) ** 0.5 / rel[sel]
+        return cost, residue
+
+    def optimize_translation_w_filtering(self, **kwargs):
+        """optimizer.py:1081-1125: translation least squares, then links whose residue exceeds residue_threshold are
+        disabled (the worst first, at most one per mesh and sweep) and the fit is repeated."""
+        maxiter = kwargs.get('maxiter', None)
+        tol = kwargs.get('tol', 1e-07)
+        target_gear = kwargs.get('target_gear', const.MESH_GEAR_FIXED)
+        start_gear = kwargs.get('start_gear', target_gear)
+        thresh = kwargs.get('residue_threshold', None)
+        cost0, residue = self.optimize_translation_lsqr(maxiter=maxiter, tol=tol, start_gear=start_gear, target_gear=target_gear)
+        disabled = 0
+        if thresh is not None and thresh > 0 and cost0 is not None:
+            while True:
+                bad = sorted(((residue[k], self.links[k].uids, k) for k in np.flatnonzero(residue > thresh)), reverse=True)
+                if not bad:
+                    break
+                touched = set()
+                for _, uids, k in bad:
+                    if touched.isdisjoint(uids):
+                        self.links[k].disable()
+                        disabled += 1
+                    touched.update(uids)
+                cost1, residue = self.optimize_translation_lsqr(maxiter=maxiter, tol=tol, start_gear=start_gear, target_gear=target_gear)
+                if cost1 is None or cost1[1] >= cost1[0]:
+                    break
+                cost0 = (cost0[0], min(cost1[1], cost0[1]))
+        return disabled, cost0
 
     def optimize_affine_cascade(self, **kwargs):
         """optimizer.py:1128-1189: starting from the meshes linked to locked (or already placed) ones, fit one affine /

@@ -468,7 +468,52 @@ def g14_groupings():
     np.savez_compressed(os.path.join(OUT, 'g14_groupings.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G15
+def g15_translation():
+    """SLM.optimize_translation_lsqr / optimize_translation_w_filtering (optimizer.py:974-1125): a 2 x 3 arrangement of
+    tiles with known offsets, one locked, one link carrying a gross error."""
+    rng = np.random.default_rng(1515)
+    out = {}
+    v, t = grid(6, 5, 20.0)
+    true_t = np.array([[0, 0], [3.0, -2.0], [-4.0, 1.5], [2.5, 2.5], [-1.0, -3.0], [5.0, 0.5]])
+    ms = [Mesh(v, t, uid=k) for k in range(6)]
+    ms[0].lock()
+    pairs = [(0, 1), (1, 2), (0, 3), (3, 4), (4, 5), (1, 4), (2, 5)]
+    links = []
+    for k, (a, b) in enumerate(pairs):
+        n = 12
+        tid0 = rng.integers(0, t.shape[0], size=n); tid1 = rng.integers(0, t.shape[0], size=n)
+        B0 = rng.dirichlet((2, 2, 2), size=n); B1 = rng.dirichlet((2, 2, 2), size=n)
+        # consistent with the true offsets: p0 + t_a == p1 + t_b  (+ noise); build xy1 from xy0
+        xy0 = ms[a].bary2cart(tid0, B0, const.MESH_GEAR_FIXED, offsetting=True)
+        xy1 = xy0 + true_t[a] - true_t[b] + rng.normal(0, 0.05, size=(n, 2))
+        if k == 5:
+            xy1 = xy1 + np.array([9.0, -7.0])                       # a bad link
+        # barycentrics of xy1 in mesh b (may fall outside the triangle: barycentric extrapolation is fine for this test)
+        _, B1 = ms[b].cart2bary(xy1, const.MESH_GEAR_FIXED, tid=tid1)
+        w = rng.uniform(0.4, 1.0, size=n).astype(np.float32)
+        links.append(optimizer.Link(ms[a], ms[b], tid0, tid1, B0, B1, weight=w))
+        out[f'l{k}_ab'] = np.array([a, b]); out[f'l{k}_tid0'] = tid0; out[f'l{k}_tid1'] = tid1
+        out[f'l{k}_B0'] = B0; out[f'l{k}_B1'] = B1; out[f'l{k}_w'] = w
+    out['v'] = v; out['t'] = t
+    slm = optimizer.SLM(ms, links=links)
+    cost, residue = slm.optimize_translation_lsqr(tol=1e-12)
+    out['lsqr_cost'] = np.array(cost); out['lsqr_residue'] = residue
+    out['lsqr_offsets'] = np.stack([m.offset(gear=const.MESH_GEAR_FIXED).ravel() for m in ms])
+    # fresh system for the filtered variant
+    ms2 = [Mesh(v, t, uid=k) for k in range(6)]
+    ms2[0].lock()
+    links2 = [optimizer.Link(ms2[a], ms2[b], out[f'l{k}_tid0'], out[f'l{k}_tid1'], out[f'l{k}_B0'], out[f'l{k}_B1'], weight=out[f'l{k}_w'])
+              for k, (a, b) in enumerate(pairs)]
+    slm2 = optimizer.SLM(ms2, links=links2)
+    nd, cost2 = slm2.optimize_translation_w_filtering(tol=1e-12, residue_threshold=1.0)
+    out['filt_disabled'] = np.array(nd); out['filt_cost'] = np.array(cost2)
+    out['filt_offsets'] = np.stack([m.offset(gear=const.MESH_GEAR_FIXED).ravel() for m in ms2])
+    out['filt_link_disabled'] = np.array([lk._disabled for lk in links2])
+    np.savez_compressed(os.path.join(OUT, 'g15_translation.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation):
         fn()
         print('wrote', fn.__name__)

@@ -93,3 +93,35 @@ def test_mesh_gears_and_field_semantics():
     tid2, B = m.cart2bary(xy, 1, tid=None)
     np.testing.assert_array_equal(tid2, tid)
     np.testing.assert_allclose(B, [[0.2, 0.3, 0.5]] * 3, atol=1e-12)
+
+
+def test_translation_optimisers_vs_reference_golden():
+    """SLM.optimize_translation_lsqr / optimize_translation_w_filtering (optimizer.py:974-1125) are host code in the reference and
+    here (scipy lsqr on #tiles unknowns): golden G15 from the reference, no GPU involved"""
+    from conftest import load_golden
+    import feabas_amd
+    from feabas_amd import constant as const
+    from feabas_amd.mesh import Mesh
+    from feabas_amd.optimizer import Link, SLM
+    g = load_golden('g15_translation.npz')
+
+    def system():
+        ms = [Mesh(g['v'], g['t'], uid=k) for k in range(6)]
+        ms[0].lock()
+        links = []
+        for k in range(7):
+            a, b = g[f'l{k}_ab']
+            links.append(Link(ms[a], ms[b], g[f'l{k}_tid0'], g[f'l{k}_tid1'], g[f'l{k}_B0'], g[f'l{k}_B1'], weight=g[f'l{k}_w']))
+        return ms, links, SLM(ms, links=links)
+    ms, links, slm = system()
+    cost, residue = slm.optimize_translation_lsqr(tol=1e-12)
+    np.testing.assert_allclose(cost, g['lsqr_cost'], rtol=1e-9)
+    np.testing.assert_allclose(residue, g['lsqr_residue'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.stack([m.offset(const.MESH_GEAR_FIXED).ravel() for m in ms]), g['lsqr_offsets'], atol=1e-8)
+    ms, links, slm = system()
+    nd, cost2 = slm.optimize_translation_w_filtering(tol=1e-12, residue_threshold=1.0)
+    assert nd == int(g['filt_disabled'])
+    np.testing.assert_array_equal(np.array([lk._disabled for lk in links]), g['filt_link_disabled'])
+    np.testing.assert_allclose(cost2[0], g['filt_cost'][0], rtol=1e-9)
+    assert cost2[1] < 1e-9
+    np.testing.assert_allclose(np.stack([m.offset(const.MESH_GEAR_FIXED).ravel() for m in ms]), g['filt_offsets'], atol=1e-8)
