@@ -36,6 +36,35 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ part, 
     return block_sum(v, sh);
 }
 
+// K partial arrays reduced together: all loads are issued before the one pair of barriers (a prologue of K separate
+// reductions costs K dependent round trips at the head of every PCG kernel).  Per array the summation order is that of
+// sum_partials, so the scalars are bitwise the same.
+template <int K>
+__device__ __forceinline__ void sum_partials_k(const double* const* part, const int* n, double* out, double (*sh)[kT / 64]) {
+    double v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = 0.0;
+        for (int i = threadIdx.x; i < n[k]; i += blockDim.x) v[k] += part[k][i];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sh[k][wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[k][w];
+        out[k] = t;
+    }
+}
+
 // MODE 0: y = A v.   MODE 1 (PCG step A): p_new = z + beta p_old, Ap = A p_new, partial p.Ap
 // MODE 2: r = b - A v  (y := residual), partial r.r into part_out
 template <int MODE>
@@ -46,22 +75,31 @@ __global__ __launch_bounds__(kT) void bsr_spmv_kernel(
     int nparts_in, fb_pcg_state* st, int iter) {
     __shared__ double2 contrib[kCap];
     __shared__ double sh[kT / 64];
+    __shared__ double sh3[3][kT / 64];
     __shared__ int sflag;
     double beta = 0.0;
     if (MODE == 1) {
         if (threadIdx.x == 0) sflag = st->flag;
-        __syncthreads();
+        double rr, rzn = 0.0, rzo = 1.0;
+        if (iter > 0) {
+            const double* ptrs[3] = {part_rr, part_rz_new, part_rz_old};
+            const int ns[3] = {nparts_in, nparts_in, nparts_in};
+            double o[3];
+            sum_partials_k<3>(ptrs, ns, o, sh3);             // (its barriers also publish sflag)
+            rr = o[0]; rzn = o[1]; rzo = o[2];
+        } else {
+            const double* ptrs[1] = {part_rr};
+            const int ns[1] = {nparts_in};
+            double o[1];
+            sum_partials_k<1>(ptrs, ns, o, sh3);
+            rr = o[0];
+        }
         if (sflag) return;
-        const double rr = sum_partials(part_rr, nparts_in, sh);
         if (rr <= st->tol2bb) {
             if (threadIdx.x == 0 && blockIdx.x == 0) { st->flag = 1; st->iter = iter; st->rr = rr; }
             return;
         }
-        if (iter > 0) {
-            const double rzn = sum_partials(part_rz_new, nparts_in, sh);
-            const double rzo = sum_partials(part_rz_old, nparts_in, sh);
-            beta = rzn / rzo;
-        }
+        if (iter > 0) beta = rzn / rzo;
     }
     double acc_dot = 0.0, acc_pp = 0.0;
     const int nchunks = (A.nb + kT - 1) / kT;
@@ -142,12 +180,18 @@ __global__ __launch_bounds__(kT) void pcg_update_kernel(
     const double* __restrict__ part_rz_cur, int np_rz, double* __restrict__ part_rz_out, double* __restrict__ part_rr_out,
     fb_pcg_state* st, int iter) {
     __shared__ double sh[kT / 64];
+    __shared__ double sh2[2][kT / 64];
     __shared__ int sflag;
     if (threadIdx.x == 0) sflag = st->flag;
-    __syncthreads();
+    double pAp, rz;
+    {
+        const double* ptrs[2] = {part_pAp, part_rz_cur};
+        const int ns[2] = {np_pAp, np_rz};
+        double o[2];
+        sum_partials_k<2>(ptrs, ns, o, sh2);                 // (its barriers also publish sflag)
+        pAp = o[0]; rz = o[1];
+    }
     if (sflag) return;
-    const double pAp = sum_partials(part_pAp, np_pAp, sh);
-    const double rz = sum_partials(part_rz_cur, np_rz, sh);
     if (!(pAp > 0.0)) {
         // p^T A p <= 0: rounding noise of a direction inside the null space of a consistent semi-definite
         // system (flag 3: end the leg, the host re-evaluates the true residual) or genuine negative
