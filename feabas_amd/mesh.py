@@ -10,6 +10,7 @@ import ctypes as C
 
 import numpy as np
 from scipy import sparse
+from scipy.sparse import csgraph
 
 from . import _lib, common
 from . import constant as const
@@ -171,12 +172,17 @@ class Mesh:
     def _changed(self, gear):
         self._trifinders.pop(gear, None)
 
-    def set_vertices(self, v, gear):                       # mesh.py:2232-2242 (unmasked)
+    def set_vertices(self, v, gear, vtx_mask=None):        # mesh.py:2232-2243
         if self.locked:
             return
         if self._vertices[gear] is None:
             self.set_offset(self.offset(gear), gear)
-        self._vertices[gear] = v
+        if vtx_mask is None:
+            self._vertices[gear] = v
+        else:
+            cur = self.vertices(gear).copy()
+            cur[vtx_mask] = v
+            self._vertices[gear] = cur
         self._changed(gear)
 
     def set_offset(self, offset, gear):
@@ -193,14 +199,32 @@ class Mesh:
         self._vertices[gear] = v
         self.set_offset(off + dxy, gear)
 
-    def apply_field(self, dxy, gear):                      # mesh.py:2381-2397 (unmasked)
+    def apply_field(self, dxy, gear, vtx_mask=None):       # mesh.py:2381-2397
         if self.locked or not np.any(dxy):
             return
         v0 = self.vertices(gear)
         off0 = self.offset(gear)
+        if vtx_mask is not None:                           # a masked field moves only those vertices, the offset stays
+            self.set_vertices(v0[vtx_mask] + dxy, gear, vtx_mask=vtx_mask)
+            self.set_offset(off0, gear)
+            return
         m = np.mean(dxy.reshape(-1, 2), axis=0, keepdims=True)
         self.set_vertices(v0 + (dxy - m), gear)
         self.set_offset(off0 + m, gear)
+
+    def apply_affine(self, A, gear, vtx_mask=None):        # mesh.py:2324-2339
+        A = np.asarray(A, dtype=np.float64)
+        if self.locked or np.all(A == np.eye(3)):
+            return
+        v0 = self.vertices(gear)
+        off0 = self.offset(gear)
+        if vtx_mask is None:
+            self.set_vertices(v0 @ A[:-1, :-1], gear)
+            self.set_offset(off0 @ A[:-1, :-1] + A[-1, :-1], gear)
+        else:
+            v1 = v0[vtx_mask] @ A[:-1, :-1] + off0 @ A[:-1, :-1] + A[-1, :-1] - off0
+            self.set_vertices(v1, gear, vtx_mask=vtx_mask)
+            self.set_offset(off0, gear)
 
     def set_field(self, dxy, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)):   # mesh.py:2400-2413 (unmasked)
         if self.locked:
@@ -235,25 +259,82 @@ class Mesh:
             return
         A = np.asarray(A, dtype=np.float64)
         if gear[0] == gear[-1]:
-            raise NotImplementedError('Mesh.set_affine within one gear (apply_affine) is not mirrored')
+            self.apply_affine(A, gear[0])
+            return
         v0 = self.vertices(gear[0])
         off0 = self.offset(gear[0])
         self.set_vertices(v0 @ A[:-1, :-1], gear[-1])
         self.set_offset(off0 @ A[:-1, :-1] + A[-1, :-1], gear[-1])
 
-    def anneal(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT):
+    def connected_vertices(self):                          # mesh.py:1762-1780 (whole mesh)
+        """(number of connected components, component label of every vertex)"""
+        t = self.triangles
+        e = np.concatenate((t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]), axis=0)
+        n = self.num_vertices
+        adj = sparse.csr_matrix((np.ones(e.shape[0], dtype=bool), (e[:, 0], e[:, 1])), shape=(n, n))
+        return csgraph.connected_components(adj, directed=False, return_labels=True)
+
+    def anneal(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_CONNECTED_RIGID):
+        """feabas/mesh.py:2421-2458: move the resting state gear[1] towards gear[0] -- one rigid / affine fit for the
+        whole mesh, one per connected component (after the global rigid one), or an exact copy."""
         if self.locked:
             return
-        if mode != const.ANNEAL_COPY_EXACT:                # mesh.py:2452-2456; rigid/affine annealing is host geometry (out of scope)
-            raise NotImplementedError('only ANNEAL_COPY_EXACT is on the hot path')
-        off0 = self.offset(gear[0])
-        v0 = self.vertices(gear[0])
-        self.set_vertices(v0, gear[1])
-        self.set_offset(off0, gear[1])
+        if mode in (const.ANNEAL_GLOBAL_RIGID, const.ANNEAL_GLOBAL_AFFINE):
+            v0 = self.vertices_w_offset(gear[0])
+            v1 = self.vertices_w_offset(gear[1])
+            if mode == const.ANNEAL_GLOBAL_RIGID:
+                _, R = common.fit_affine(v0, v1, return_rigid=True)
+                self.apply_affine(R, gear[1])
+            else:
+                self.apply_affine(common.fit_affine(v0, v1, return_rigid=False), gear[1])
+        elif mode in (const.ANNEAL_CONNECTED_RIGID, const.ANNEAL_CONNECTED_AFFINE):
+            n_conn, v_conn = self.connected_vertices()
+            self.anneal(gear=gear, mode=const.ANNEAL_GLOBAL_RIGID)
+            if n_conn == 1 and mode == const.ANNEAL_CONNECTED_RIGID:
+                return
+            v0 = self.vertices_w_offset(gear[0])
+            v1 = self.vertices_w_offset(gear[1])
+            for cid in range(n_conn):
+                idx = v_conn == cid
+                if mode == const.ANNEAL_CONNECTED_RIGID:
+                    _, R = common.fit_affine(v0[idx], v1[idx], return_rigid=True)
+                    self.apply_affine(R, gear[1], vtx_mask=idx)
+                else:
+                    self.apply_affine(common.fit_affine(v0[idx], v1[idx], return_rigid=False), gear[1], vtx_mask=idx)
+        elif mode == const.ANNEAL_COPY_EXACT:
+            off0 = self.offset(gear[0])
+            v0 = self.vertices(gear[0])
+            self.set_vertices(v0, gear[1])
+            self.set_offset(off0, gear[1])
+        else:
+            raise ValueError(mode)
 
     # ------------------------------------------------------------------ geometry
     def triangle_areas(self, gear=const.MESH_GEAR_INITIAL):   # mesh.py:1753-1758
         return common.signed_area(self.vertices(gear), self.triangles)
+
+    def triangle_area_deform(self, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING)):   # mesh.py:1979-1986
+        return common.signed_area(self.vertices(gear[-1]), self.triangles) / common.signed_area(self.vertices(gear[0]), self.triangles)
+
+    def triangle_edge_deform(self, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING)):   # mesh.py:1966-1976
+        v0, v1 = self.vertices(gear[0]), self.vertices(gear[-1])
+        t = self.triangles
+        tr = np.roll(t, 1, axis=-1)
+        d0 = np.sum((v0[t] - v0[tr]) ** 2, axis=-1)
+        d1 = np.sum((v1[t] - v1[tr]) ** 2, axis=-1)
+        return np.exp(np.max(np.abs(0.5 * np.log(d1 / d0)), axis=-1))
+
+    @staticmethod
+    def svds_to_deform(s):                                 # mesh.py:3358-3365
+        """(N, k) singular values -> deformation: 0..1 while not flipped, >= 1 when flipped"""
+        s = np.asarray(s, dtype=np.float64)
+        d = np.where(s < 1, 1 - s, 1 - 1 / np.where(s == 0, 1, s))
+        return np.max(d, axis=-1)
+
+    def effective_stiffness_multiplier(self, gear=None):   # mesh.py:1600-1621 (materials without a stiffness_func)
+        if self.tri_model is None:
+            return self.stiffness_multiplier * np.float32(self.material_multiplier)
+        return self.stiffness_multiplier * self.tri_matmult
 
     def tri_finder(self, pts, gear=None):
         """point -> triangle id (-1 outside).  The reference goes through
@@ -333,6 +414,44 @@ class Mesh:
             v1 = self.vertices(gear[-1])
             v1c = None if v1 is v0 or v1 is self.vertices(gear[0]) else np.ascontiguousarray(v1, dtype=np.float64)
             self.assemble_into(sysh, mid.value, v0, v1c, 1.0)
+            K = bsr_download(sysh, 0, self.num_vertices, nnzb.value)
+            stress = np.empty(2 * self.num_vertices, dtype=np.float32)
+            _lib.check(lib.fb_sys_get(ctx, sysh, 3, _lib.ptr(stress)))
+        finally:
+            lib.fb_sys_destroy(ctx, sysh)
+        return K, stress
+
+    def stiffness_matrix_local_normalized(self, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), tri_mask=None, **kwargs):
+        """feabas/mesh.py:3086-3129 -> (scipy CSR, stress float32) of the sub-mesh ``tri_mask``: every triangle as the
+        default linear material (Poisson ratio 0, D = m diag(1, 1, 1/2)) with its effective multiplier clipped at
+        max / max_stiffness_ratio; shape matrix at gear[0], stress = K (v[gear1] - v[gear0]).  Assembled by the same HIP
+        kernel as ``stiffness_matrix`` -- the triangles outside the mask enter with multiplier 0."""
+        max_stiffness_ratio = kwargs.get('max_stiffness_ratio', 1000)
+        tidx = np.arange(self.num_triangles)
+        if tri_mask is not None:
+            tidx = tidx[tri_mask]
+        if tidx.size == 0:
+            return None, None
+        mm = np.asarray(self.effective_stiffness_multiplier(), dtype=np.float32)[tidx]
+        if max_stiffness_ratio is not None:
+            mn = np.max(mm) / max_stiffness_ratio
+            if mn == 0:
+                mn = 1
+            mm = mm.clip(mn, None)
+        mult = np.zeros(self.num_triangles, dtype=np.float32)
+        mult[tidx] = mm
+        lib, ctx = _lib.load(), _lib.ctx()
+        sysh = C.c_void_p()
+        _lib.check(lib.fb_sys_create(ctx, self.num_vertices, C.byref(sysh)))
+        try:
+            mid = C.c_int()
+            _lib.check(lib.fb_sys_add_mesh(ctx, sysh, 0, _lib.ptr(self.triangles), self.num_vertices, self.num_triangles, C.byref(mid)))
+            _lib.check(lib.fb_sys_set_links(ctx, sysh, 0, None))
+            nnzb = C.c_int64()
+            _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
+            v0 = np.ascontiguousarray(self.vertices(gear[0]), dtype=np.float64)
+            v1 = np.ascontiguousarray(self.vertices(gear[-1]), dtype=np.float64)
+            _lib.check(lib.fb_sys_assemble_mesh(ctx, sysh, mid.value, _lib.ptr(v0), _lib.ptr(v1), _lib.ptr(mult), 0.0, 1.0))
             K = bsr_download(sysh, 0, self.num_vertices, nnzb.value)
             stress = np.empty(2 * self.num_vertices, dtype=np.float32)
             _lib.check(lib.fb_sys_get(ctx, sysh, 3, _lib.ptr(stress)))

@@ -716,3 +716,82 @@ def solve(A, b, solver='minres', x0=None, tol=1e-7, atol=None, maxiter=None, M=N
         full[edc] = x
         x = full
     return x
+
+
+def relax_mesh(M, free_vertices=None, free_triangles=None, **kwargs):
+    """feabas/optimizer.py:2110-2154: relax a region of one mesh with the rest of it held.  The free vertices are the
+    given ones, or those that belong to free triangles only.  The resting shape is the INITIAL one, rigidly aligned to
+    the current state per connected component; the sub-mesh of triangles touching a free vertex is assembled with
+    clipped multipliers (``Mesh.stiffness_matrix_local_normalized``, HIP) and the free block solved by the device PCG.
+    Returns whether the mesh was modified.  ``tolerated_perturbation`` / ``callback_settings`` are accepted and unused:
+    the PCG runs to ``tol``."""
+    gear = kwargs.get('gear', (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING))
+    maxiter = kwargs.get('maxiter', None)
+    tol = kwargs.get('tol', 1e-7)
+    atol = kwargs.get('atol', 0.0)
+    cond = kwargs.get('precondition', 'jacobi')
+    modified = False
+    locked = M.locked
+    M.locked = False
+    try:
+        if free_vertices is not None:
+            vindx = free_vertices
+        elif free_triangles is not None:
+            T = M.triangles[~np.asarray(free_triangles, dtype=bool)]
+            vindx = ~np.isin(np.arange(M.num_vertices), np.unique(T))
+        else:
+            return modified
+        vmask = np.zeros(M.num_vertices, dtype=bool)
+        vmask[vindx] = True
+        if not np.any(vmask):
+            return modified
+        tmask = np.any(vmask[M.triangles], axis=-1)
+        vmask_pad = np.repeat(vmask, 2)
+        fixed_vertices = M.vertices(gear=gear[0])
+        fixed_offset = M.offset(gear=gear[0])
+        M.anneal(gear=(const.MESH_GEAR_INITIAL, gear[0]), mode=const.ANNEAL_COPY_EXACT)
+        M.anneal(gear=gear[::-1], mode=const.ANNEAL_CONNECTED_RIGID)
+        stiff_M, stress_v = M.stiffness_matrix_local_normalized(gear=gear, tri_mask=tmask)
+        if stiff_M is not None:
+            A = stiff_M[vmask_pad][:, vmask_pad]
+            b = -stress_v[vmask_pad].astype(np.float64)
+            dd = solve(A, b, kwargs.get('solver', 'minres'), tol=tol, maxiter=maxiter, atol=atol, M=cond)
+            cost = (np.linalg.norm(b), np.linalg.norm(A.dot(dd) - b))
+            if (cost[1] < cost[0]) and np.any(dd != 0):
+                modified = True
+                M.apply_field(dd.reshape(-1, 2), gear[-1], vtx_mask=vmask)
+        if gear[0] != gear[1]:
+            M.set_vertices(fixed_vertices, gear=gear[0])
+            M.set_offset(fixed_offset, gear=gear[0])
+    finally:
+        M.locked = locked
+    return modified
+
+
+def relax_mesh_most_deformed(M, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), deform_cutoff=const.MAXIMUM_DEFORM_ALLOWED, iqr=0):
+    """feabas/optimizer.py:2157-2190: free the flipped triangles' vertices (``deform_cutoff`` < 0) or the triangles
+    around those deformed beyond the cutoff (area or edge stretch, relative to the median of the normally stiff
+    triangles; optionally an inter-quartile outlier rule), and relax them."""
+    modified = False
+    sa = M.triangle_area_deform(gear=gear).reshape(-1, 1)
+    if deform_cutoff < 0:
+        tmask = Mesh.svds_to_deform(sa) >= 1
+        if not np.any(tmask):
+            return modified
+        return relax_mesh(M, free_vertices=np.unique(M.triangles[tmask]), gear=gear)
+    deform_thresh = 1 - 1 / (abs(deform_cutoff) + 1)
+    sd = M.triangle_edge_deform(gear=gear).reshape(-1, 1)
+    defm = np.maximum(Mesh.svds_to_deform(sa), Mesh.svds_to_deform(sd))
+    m0 = M.effective_stiffness_multiplier()
+    idx_m = m0 >= 0.5 * np.median(m0)
+    defm = defm - np.median(defm[idx_m])
+    thresh_t = max(deform_thresh, 0)
+    if iqr > 0:
+        qq = np.quantile(defm[idx_m], (0.25, 0.75))
+        thresh_t = min(thresh_t, np.max(qq) + iqr * np.ptp(qq))
+    tmask = defm > max(thresh_t, 1.0e-3)
+    if not np.any(tmask):
+        return modified
+    vid = np.unique(M.triangles[tmask])
+    tmask = np.all(np.isin(M.triangles, vid), axis=-1)
+    return relax_mesh(M, free_triangles=tmask, gear=gear)

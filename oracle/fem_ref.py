@@ -10,7 +10,7 @@ cast to float32, final system float64.
 """
 import numpy as np
 from scipy import sparse
-from scipy.sparse import linalg as spla
+from scipy.sparse import csgraph, linalg as spla
 
 GEAR_INITIAL, GEAR_FIXED, GEAR_MOVING, GEAR_STAGING = -1, 0, 1, 2   # constant.py:6-10
 MODEL_ENG, MODEL_SVK, MODEL_NHK = 0, 1, 2                            # constant.py:34-36
@@ -207,6 +207,127 @@ class RefMesh:
         v0 = self.vertices(gear[0])
         self._v[gear[1]] = v0
         self._off[gear[1]] = off0
+
+    # ---- masked state changes, rigid / affine annealing, deformation measures (the relax_mesh path)
+    def set_vertices(self, v, gear, vtx_mask=None):         # mesh.py:2232-2243
+        if self.locked:
+            return
+        if self._v[gear] is None:
+            self._off[gear] = self.offset(gear)
+        if vtx_mask is None:
+            self._v[gear] = v
+        else:
+            cur = self.vertices(gear).copy()
+            cur[vtx_mask] = v
+            self._v[gear] = cur
+
+    def set_offset(self, offset, gear):                     # mesh.py:2246-2249
+        if not self.locked:
+            self._off[gear] = offset
+
+    def apply_field(self, dxy, gear, vtx_mask=None):        # mesh.py:2381-2397
+        if self.locked or not np.any(dxy):
+            return
+        v0 = self.vertices(gear)
+        off0 = self.offset(gear)
+        if vtx_mask is None:
+            m = np.mean(dxy.reshape(-1, 2), axis=0, keepdims=True)
+            self.set_vertices(v0 + (dxy - m), gear)
+            self.set_offset(off0 + m, gear)
+        else:
+            self.set_vertices(v0[vtx_mask] + dxy, gear, vtx_mask=vtx_mask)
+            self.set_offset(off0, gear)
+
+    def apply_affine(self, A, gear, vtx_mask=None):         # mesh.py:2324-2339
+        if self.locked or np.all(A == np.eye(3)):
+            return
+        v0 = self.vertices(gear)
+        off0 = self.offset(gear)
+        if vtx_mask is None:
+            self.set_vertices(v0 @ A[:-1, :-1], gear)
+            self.set_offset(off0 @ A[:-1, :-1] + A[-1, :-1], gear)
+        else:
+            v1 = v0[vtx_mask] @ A[:-1, :-1] + off0 @ A[:-1, :-1] + A[-1, :-1] - off0
+            self.set_vertices(v1, gear, vtx_mask=vtx_mask)
+            self.set_offset(off0, gear)
+
+    def connected_vertices(self):                           # mesh.py:1762-1780, 1644-1656
+        t = self.triangles
+        e = np.concatenate((t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]), axis=0)
+        n = self.num_vertices
+        A = sparse.csr_matrix((np.ones(e.shape[0], dtype=bool), (e[:, 0], e[:, 1])), shape=(n, n))
+        return csgraph.connected_components(A, directed=False, return_labels=True)
+
+    def anneal(self, gear=(GEAR_MOVING, GEAR_FIXED), mode=2):   # mesh.py:2421-2458; modes constant.py:27-31
+        if self.locked:
+            return
+        if mode in (0, 1):
+            v0 = self.vertices_w_offset(gear[0])
+            v1 = self.vertices_w_offset(gear[1])
+            if mode == 0:
+                _, R = fit_affine(v0, v1, return_rigid=True)
+                self.apply_affine(R, gear[1])
+            else:
+                self.apply_affine(fit_affine(v0, v1, return_rigid=False), gear[1])
+        elif mode in (2, 3):
+            n_conn, v_conn = self.connected_vertices()
+            self.anneal(gear=gear, mode=0)
+            if n_conn == 1 and mode == 2:
+                return
+            v0 = self.vertices_w_offset(gear[0])
+            v1 = self.vertices_w_offset(gear[1])
+            for cid in range(n_conn):
+                idx = v_conn == cid
+                if mode == 2:
+                    _, R = fit_affine(v0[idx], v1[idx], return_rigid=True)
+                    self.apply_affine(R, gear[1], vtx_mask=idx)
+                else:
+                    self.apply_affine(fit_affine(v0[idx], v1[idx], return_rigid=False), gear[1], vtx_mask=idx)
+        elif mode == 4:
+            self.set_vertices(self.vertices(gear[0]), gear[1])
+            self.set_offset(self.offset(gear[0]), gear[1])
+        else:
+            raise ValueError
+
+    def triangle_area_deform(self, gear=(GEAR_INITIAL, GEAR_MOVING)):   # mesh.py:1979-1986
+        def area(v):
+            p = v[self.triangles]
+            return cross2d(p[:, 1] - p[:, 0], p[:, 2] - p[:, 1])
+        return area(self.vertices(gear[-1])) / area(self.vertices(gear[0]))
+
+    def triangle_edge_deform(self, gear=(GEAR_INITIAL, GEAR_MOVING)):   # mesh.py:1966-1976
+        v0 = self.vertices(gear[0])
+        v1 = self.vertices(gear[-1])
+        T = self.triangles
+        Tr = np.roll(T, 1, axis=-1)
+        d0 = np.sum((v0[T] - v0[Tr]) ** 2, axis=-1)
+        d1 = np.sum((v1[T] - v1[Tr]) ** 2, axis=-1)
+        return np.exp(np.max(np.abs(0.5 * np.log(d1 / d0)), axis=-1))
+
+    def effective_stiffness_multiplier(self):               # mesh.py:1600-1621, one material without stiffness_func
+        return self.stiffness_multiplier * np.ones_like(self.stiffness_multiplier)
+
+    def stiffness_matrix_local_normalized(self, gear=(GEAR_FIXED, GEAR_MOVING), tri_mask=None, max_stiffness_ratio=1000):
+        """mesh.py:3086-3129: K = N^T diag(m, m, m/2) N over the masked triangles (shape at gear[0], Poisson ratio 0,
+        multipliers clipped at max/max_stiffness_ratio), stress = float32(K (v[gear1] - v[gear0]))."""
+        tidx = np.arange(self.triangles.shape[0])
+        if tri_mask is not None:
+            tidx = tidx[tri_mask]
+        if tidx.size == 0:
+            return None, None
+        v0 = self.vertices(gear[0])
+        T = self.triangles[tidx]
+        N = eng_shape_matrix(v0[T], T, 2 * self.num_vertices)
+        mm = self.effective_stiffness_multiplier()[tidx]
+        if max_stiffness_ratio is not None:
+            mn = np.max(mm) / max_stiffness_ratio
+            if mn == 0:
+                mn = 1
+            mm = mm.clip(mn, None)
+        D = sparse.diags((mm.reshape(-1, 1) * np.array([1, 1, 0.5])).ravel(), dtype=np.float32)
+        K = N.T @ D @ N
+        dxy = self.vertices(gear[-1]) - v0
+        return K, K.dot(dxy.ravel()).astype(np.float32)
 
     def triangle_areas(self, gear=GEAR_INITIAL):            # mesh.py:1753-1758, common.py:672-676
         p = self.vertices(gear)[self.triangles]
@@ -616,6 +737,87 @@ def fit_affine(pts0, pts1, return_rigid=False, weight=None, svd_clip=(1, 1), avo
     A[-1, :2] = A[-1, :2] + mm0 - mm1 @ A[:2, :2]
     A[:, -1] = np.array([0, 0, 1])
     return (A, R) if return_rigid else A
+
+
+def svds_to_deform(s):
+    """mesh.py:3358-3365: (N, k) singular values -> deformation in [0, 1) (not flipped) or >= 1 (flipped)."""
+    s = np.asarray(s, dtype=np.float64)
+    d = np.where(s < 1, 1 - s, 1 - 1 / np.where(s == 0, 1, s))
+    return np.max(d, axis=-1)
+
+
+def relax_mesh(M, free_vertices=None, free_triangles=None, gear=(GEAR_FIXED, GEAR_MOVING)):
+    """optimizer.py:2110-2154 with the inner ``solve`` replaced by the exact solution of the same system: free the
+    given vertices (or those belonging only to free triangles), re-rest the mesh on its INITIAL shape rigidly aligned
+    to the current one, relax the free vertices with the rest held."""
+    locked = M.locked
+    M.locked = False
+    nv = M.num_vertices
+    if free_vertices is not None:
+        vindx = free_vertices
+    elif free_triangles is not None:
+        T = M.triangles[~free_triangles]
+        vindx = ~np.isin(np.arange(nv), np.unique(T))
+    else:
+        return False
+    vmask = np.zeros(nv, dtype=bool)
+    vmask[vindx] = True
+    if not np.any(vmask):
+        return False
+    tmask = np.any(vmask[M.triangles], axis=-1)
+    vmask_pad = np.repeat(vmask, 2)
+    fixed_vertices = M.vertices(gear[0])
+    fixed_offset = M.offset(gear[0])
+    M.anneal(gear=(GEAR_INITIAL, gear[0]), mode=4)
+    M.anneal(gear=gear[::-1], mode=2)
+    K, stress = M.stiffness_matrix_local_normalized(gear=gear, tri_mask=tmask)
+    if K is None:
+        return False
+    A = sparse.csr_matrix(K)[vmask_pad][:, vmask_pad]
+    b = -stress[vmask_pad].astype(np.float64)
+    dd = solve_direct(A, b) if np.any(b) else np.zeros_like(b)
+    modified = False
+    if np.linalg.norm(A.dot(dd) - b) < np.linalg.norm(b) and np.any(dd != 0):
+        modified = True
+        M.apply_field(dd.reshape(-1, 2), gear[-1], vtx_mask=vmask)
+    if gear[0] != gear[1]:
+        M.set_vertices(fixed_vertices, gear[0])
+        M.set_offset(fixed_offset, gear[0])
+    M.locked = locked
+    return modified
+
+
+def most_deformed_region(M, gear=(GEAR_FIXED, GEAR_MOVING), deform_cutoff=0.35, iqr=0):
+    """the selection of optimizer.py:2157-2188: (free_vertices, None) for the flip-only mode (deform_cutoff < 0),
+    (None, free_triangles) otherwise, (None, None) if nothing exceeds the threshold."""
+    sa = M.triangle_area_deform(gear=gear).reshape(-1, 1)
+    if deform_cutoff < 0:
+        tmask = svds_to_deform(sa) >= 1
+        if not np.any(tmask):
+            return None, None
+        return np.unique(M.triangles[tmask]), None
+    deform_thresh = 1 - 1 / (abs(deform_cutoff) + 1)
+    sd = M.triangle_edge_deform(gear=gear).reshape(-1, 1)
+    defm = np.maximum(svds_to_deform(sa), svds_to_deform(sd))
+    m0 = M.effective_stiffness_multiplier()
+    idx_m = m0 >= 0.5 * np.median(m0)
+    defm = defm - np.median(defm[idx_m])
+    thresh_t = max(deform_thresh, 0)
+    if iqr > 0:
+        qq = np.quantile(defm[idx_m], (0.25, 0.75))
+        thresh_t = min(thresh_t, np.max(qq) + iqr * np.ptp(qq))
+    tmask = defm > max(thresh_t, 1.0e-3)
+    if not np.any(tmask):
+        return None, None
+    vid = np.unique(M.triangles[tmask])
+    return None, np.all(np.isin(M.triangles, vid), axis=-1)
+
+
+def relax_mesh_most_deformed(M, gear=(GEAR_FIXED, GEAR_MOVING), deform_cutoff=0.35, iqr=0):
+    fv, ft = most_deformed_region(M, gear=gear, deform_cutoff=deform_cutoff, iqr=iqr)
+    if fv is None and ft is None:
+        return False
+    return relax_mesh(M, free_vertices=fv, free_triangles=ft, gear=gear)
 
 
 # ------------------------------------------------------------------ synthetic meshes

@@ -513,7 +513,104 @@ def g15_translation():
     np.savez_compressed(os.path.join(OUT, 'g15_translation.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G16
+def g16_relax():
+    """optimizer.relax_mesh / relax_mesh_most_deformed (optimizer.py:2110-2190), Mesh.stiffness_matrix_local_normalized
+    (mesh.py:3086-3129), the rigid/affine anneal modes (mesh.py:2421-2456) and the per-triangle deformation measures
+    (mesh.py:1966-1986, 3358-3365)."""
+    from feabas import config
+    rng = np.random.default_rng(1616)
+    out = {}
+    gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
+    tight = dict(tol=1e-11, tolerated_perturbation=None, callback_settings={'chances': None, 'eval_step': 10})
+    v, t = grid(16, 12, 10.0)
+    mult = rng.uniform(0.5, 2.0, size=t.shape[0]).astype(np.float32)
+    mult[5] = 1e-5                                      # below max/1000: exercises the multiplier clip
+    disp = np.stack((2 * np.sin(v[:, 1] / 40), 1.5 * np.cos(v[:, 0] / 55)), axis=-1)
+    hot = np.array([16 * 5 + 7, 16 * 5 + 8, 16 * 6 + 7])
+    disp[hot] += np.array([[14.0, 3.0], [-6.0, 9.0], [4.0, -8.0]])      # three flipped triangles
+    out['v'] = v; out['t'] = t; out['mult'] = mult; out['vmov'] = v + disp
+    out['moff'] = np.array([[3.0, -1.5]])
+
+    def fresh():
+        return Mesh(v.copy(), t.copy(), stiffness_multiplier=mult.copy(), moving_vertices=v + disp,
+                    moving_offset=out['moff'].copy(), uid=3)
+
+    m = fresh()
+    out['area_deform'] = m.triangle_area_deform(gear=gear)
+    out['edge_deform'] = m.triangle_edge_deform(gear=gear)
+    out['eff_mult'] = m.effective_stiffness_multiplier(gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING))
+    out['svd_deform_area'] = Mesh.svds_to_deform(out['area_deform'].reshape(-1, 1))
+    tm = np.zeros(t.shape[0], dtype=bool)
+    tm[rng.choice(t.shape[0], 60, replace=False)] = True
+    tm[5] = True
+    out['tmask'] = tm
+    K, stress = m.stiffness_matrix_local_normalized(gear=gear, tri_mask=tm)
+    r, c, d = coo(K)
+    out['Kn_r'] = r; out['Kn_c'] = c; out['Kn_d'] = d; out['Kn_stress'] = stress
+    # relax_mesh with a block of free triangles, converged
+    ft = np.zeros(t.shape[0], dtype=bool)
+    ctr = v[t].mean(axis=1)
+    ft[(np.abs(ctr[:, 0] - 75) < 38) & (np.abs(ctr[:, 1] - 55) < 32)] = True
+    out['free_tri'] = ft
+    m = fresh()
+    out['ft_modified'] = np.array(optimizer.relax_mesh(m, free_triangles=ft, gear=gear, **tight))
+    out['ft_vmov'] = m.vertices(gear=gear[1]); out['ft_moff'] = m.offset(gear=gear[1])
+    out['ft_vfix'] = m.vertices(gear=gear[0]); out['ft_foff'] = m.offset(gear=gear[0])
+    # ... and with a list of free vertices
+    fv = np.unique(t[np.isin(t, hot).any(axis=1)])
+    out['free_vtx'] = fv
+    m = fresh()
+    out['fv_modified'] = np.array(optimizer.relax_mesh(m, free_vertices=fv, gear=gear, **tight))
+    out['fv_vmov'] = m.vertices(gear=gear[1]); out['fv_moff'] = m.offset(gear=gear[1])
+    # relax_mesh_most_deformed: which region it frees (the arguments it hands to relax_mesh) and its result with the
+    # reference's default solver settings
+    captured = {}
+    orig = optimizer.relax_mesh
+
+    def spy(M, free_vertices=None, free_triangles=None, **kw):
+        captured['fv'] = None if free_vertices is None else np.array(free_vertices)
+        captured['ft'] = None if free_triangles is None else np.array(free_triangles)
+        return orig(M, free_vertices=free_vertices, free_triangles=free_triangles, **kw)
+
+    optimizer.relax_mesh = spy
+    try:
+        m = fresh()
+        out['md_flip_modified'] = np.array(optimizer.relax_mesh_most_deformed(m, gear=gear, deform_cutoff=-1))
+        out['md_flip_free_vtx'] = captured['fv']
+        out['md_flip_vmov'] = m.vertices(gear=gear[1]); out['md_flip_moff'] = m.offset(gear=gear[1])
+        out['md_flip_area_deform'] = m.triangle_area_deform(gear=gear)
+        for name, iqr in (('md_cut', 0), ('md_iqr', 1.5)):
+            m = fresh()
+            captured.clear()
+            out[f'{name}_modified'] = np.array(optimizer.relax_mesh_most_deformed(m, gear=gear, deform_cutoff=config.MAXIMUM_DEFORM_ALLOWED, iqr=iqr))
+            out[f'{name}_free_tri'] = captured['ft']
+            out[f'{name}_vmov'] = m.vertices(gear=gear[1]); out[f'{name}_moff'] = m.offset(gear=gear[1])
+        out['deform_cutoff'] = np.array(config.MAXIMUM_DEFORM_ALLOWED)
+    finally:
+        optimizer.relax_mesh = orig
+    # anneal modes on a mesh with two connected components
+    v2, t2 = grid(6, 5, 10.0, origin=(100.0, 20.0))
+    vv = np.concatenate((v[:16 * 4], v2), axis=0)
+    t_a = t[np.all(t < 16 * 4, axis=1)]
+    tt = np.concatenate((t_a, t2 + 16 * 4), axis=0)
+    th0, th1 = 0.05, -0.08
+    R0 = np.array([[np.cos(th0), np.sin(th0)], [-np.sin(th0), np.cos(th0)]])
+    R1 = np.array([[np.cos(th1), np.sin(th1)], [-np.sin(th1), np.cos(th1)]])
+    vm = vv.copy()
+    vm[:16 * 4] = vv[:16 * 4] @ R0 * 1.03 + np.array([4.0, -2.0])
+    vm[16 * 4:] = vv[16 * 4:] @ R1 * 0.97 + np.array([-3.0, 5.0])
+    vm += 0.2 * rng.standard_normal(vm.shape)
+    out['an_v'] = vv; out['an_t'] = tt; out['an_vmov'] = vm
+    for name, mode in (('grigid', const.ANNEAL_GLOBAL_RIGID), ('gaffine', const.ANNEAL_GLOBAL_AFFINE),
+                       ('crigid', const.ANNEAL_CONNECTED_RIGID), ('caffine', const.ANNEAL_CONNECTED_AFFINE)):
+        m = Mesh(vv.copy(), tt.copy(), moving_vertices=vm.copy(), moving_offset=np.array([[1.0, 2.0]]), uid=4)
+        m.anneal(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=mode)
+        out[f'an_{name}_vfix'] = m.vertices(gear=const.MESH_GEAR_FIXED); out[f'an_{name}_foff'] = m.offset(gear=const.MESH_GEAR_FIXED)
+    np.savez_compressed(os.path.join(OUT, 'g16_relax.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax):
         fn()
         print('wrote', fn.__name__)

@@ -125,3 +125,37 @@ def test_translation_optimisers_vs_reference_golden():
     np.testing.assert_allclose(cost2[0], g['filt_cost'][0], rtol=1e-9)
     assert cost2[1] < 1e-9
     np.testing.assert_allclose(np.stack([m.offset(const.MESH_GEAR_FIXED).ravel() for m in ms]), g['filt_offsets'], atol=1e-8)
+
+
+@pytest.mark.parametrize('name,mode', [('grigid', 0), ('gaffine', 1), ('crigid', 2), ('caffine', 3)])
+def test_g16_anneal_modes(name, mode):
+    """Mesh.anneal rigid / affine, whole mesh and per connected component (mesh.py:2421-2451), and the region
+    relax_mesh_most_deformed frees (optimizer.py:2157-2188) -- host logic of the product against the reference"""
+    from conftest import load_golden
+    from feabas_amd import constant as const
+    from feabas_amd.mesh import Mesh
+    g = load_golden('g16_relax.npz')
+    m = Mesh(g['an_v'], g['an_t'], moving_vertices=g['an_vmov'].copy(), moving_offset=np.array([[1.0, 2.0]]), uid=4)
+    m.anneal(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=mode)
+    np.testing.assert_allclose(m.vertices(const.MESH_GEAR_FIXED), g[f'an_{name}_vfix'], atol=1e-9)
+    np.testing.assert_allclose(m.offset(const.MESH_GEAR_FIXED), g[f'an_{name}_foff'], atol=1e-9)
+
+
+def test_g16_masked_field_and_measures():
+    from conftest import load_golden
+    from feabas_amd import constant as const
+    from feabas_amd.mesh import Mesh
+    g = load_golden('g16_relax.npz')
+    gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
+    m = Mesh(g['v'], g['t'], stiffness_multiplier=g['mult'], moving_vertices=g['vmov'].copy(), moving_offset=g['moff'].copy(), uid=3)
+    np.testing.assert_allclose(m.triangle_area_deform(gear), g['area_deform'], rtol=1e-12)
+    np.testing.assert_allclose(m.triangle_edge_deform(gear), g['edge_deform'], rtol=1e-12)
+    np.testing.assert_allclose(Mesh.svds_to_deform(g['area_deform'].reshape(-1, 1)), g['svd_deform_area'], rtol=1e-12)
+    np.testing.assert_allclose(m.effective_stiffness_multiplier(), g['eff_mult'], rtol=1e-7)
+    vm = np.zeros(g['v'].shape[0], dtype=bool)
+    vm[g['free_vtx']] = True
+    d = np.arange(2 * vm.sum(), dtype=np.float64).reshape(-1, 2)
+    m.apply_field(d, gear[1], vtx_mask=vm)                  # mesh.py:2393-2396: only the masked vertices move, the offset stays
+    np.testing.assert_array_equal(m.vertices(gear[1])[vm], g['vmov'][vm] + d)
+    np.testing.assert_array_equal(m.vertices(gear[1])[~vm], g['vmov'][~vm])
+    np.testing.assert_array_equal(m.offset(gear[1]), g['moff'])

@@ -277,3 +277,77 @@ def test_g14_optimize_linear_groupings(fb):
                                    oms[k].vertices_w_offset(fem_ref.GEAR_MOVING), atol=1e-4 * scale)
     # meshes 1 and 2 moved as one
     np.testing.assert_allclose(ms[1].vertices(const.MESH_GEAR_MOVING) - g['m1_v'], ms[2].vertices(const.MESH_GEAR_MOVING) - g['m2_v'], atol=1e-9 * scale)
+
+
+# ----------------------------------------------------------------------- G16: relax_mesh (optimizer.py:2110-2190)
+def _g16_mesh(fb, g):
+    return fb.mesh.Mesh(g['v'], g['t'], stiffness_multiplier=g['mult'], moving_vertices=g['vmov'].copy(),
+                        moving_offset=g['moff'].copy(), uid=3)
+
+
+def test_g16_local_normalized_stiffness(fb):
+    """Mesh.stiffness_matrix_local_normalized (mesh.py:3086-3129) assembled on the device against the reference"""
+    from conftest import load_golden
+    from scipy import sparse
+    g = load_golden('g16_relax.npz')
+    const = fb.constant
+    m = _g16_mesh(fb, g)
+    K, stress = m.stiffness_matrix_local_normalized(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), tri_mask=g['tmask'])
+    n = 2 * g['v'].shape[0]
+    Kr = sparse.csr_matrix((g['Kn_d'], (g['Kn_r'], g['Kn_c'])), shape=(n, n))
+    assert abs(K - Kr).max() <= 1e-6 * abs(Kr).max()        # D is float32 on both sides
+    assert stress.dtype == np.float32
+    np.testing.assert_allclose(stress, g['Kn_stress'], atol=2e-6 * np.abs(g['Kn_stress']).max())
+    np.testing.assert_allclose(m.triangle_area_deform((const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)), g['area_deform'], rtol=1e-12)
+    np.testing.assert_allclose(m.triangle_edge_deform((const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)), g['edge_deform'], rtol=1e-12)
+    np.testing.assert_allclose(m.effective_stiffness_multiplier(), g['eff_mult'], rtol=1e-7)
+
+
+@pytest.mark.parametrize('which', ['ft', 'fv'])
+def test_g16_relax_mesh(fb, which):
+    """relax_mesh: device assembly + device PCG of the free block against the reference's converged result"""
+    from conftest import load_golden
+    g = load_golden('g16_relax.npz')
+    const = fb.constant
+    gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
+    m = _g16_mesh(fb, g)
+    if which == 'ft':
+        mod = fb.optimizer.relax_mesh(m, free_triangles=g['free_tri'], gear=gear, tol=1e-11)
+    else:
+        mod = fb.optimizer.relax_mesh(m, free_vertices=g['free_vtx'], gear=gear, tol=1e-11)
+    assert mod == bool(g[f'{which}_modified'])
+    moved = np.abs(g[f'{which}_vmov'] - g['vmov']).max()
+    np.testing.assert_allclose(m.vertices(gear[1]), g[f'{which}_vmov'], atol=1e-6 * moved)
+    np.testing.assert_array_equal(m.offset(gear[1]), g[f'{which}_moff'])
+    np.testing.assert_array_equal(m.vertices(gear[0]), g['v'])
+    # a locked mesh is relaxed all the same and stays locked (optimizer.py:2119-2120, 2153)
+    m2 = _g16_mesh(fb, g)
+    m2.lock()
+    assert fb.optimizer.relax_mesh(m2, free_vertices=g['free_vtx'], gear=gear, tol=1e-11) and m2.locked
+    np.testing.assert_allclose(m2.vertices(gear[1]), g['fv_vmov'], atol=1e-6 * moved)
+    # nothing to free
+    assert not fb.optimizer.relax_mesh(m, gear=gear)
+    assert not fb.optimizer.relax_mesh(m, free_triangles=np.zeros(g['t'].shape[0], dtype=bool), gear=gear)
+
+
+@pytest.mark.parametrize('name,kw', [('md_flip', dict(deform_cutoff=-1)), ('md_cut', dict(deform_cutoff=0.35)),
+                                     ('md_iqr', dict(deform_cutoff=0.35, iqr=1.5))])
+def test_g16_relax_most_deformed(fb, name, kw):
+    """relax_mesh_most_deformed: same region as the reference (via the oracle's pinned selection), the field at the
+    reference's own stopping size (its default exits stop within 0.25 px of the fixed point), flips removed"""
+    from conftest import load_golden
+    from test_oracle_golden import g16_oracle_mesh, GEARS_FM
+    from oracle import fem_ref
+    g = load_golden('g16_relax.npz')
+    const = fb.constant
+    gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
+    m = _g16_mesh(fb, g)
+    assert fb.optimizer.relax_mesh_most_deformed(m, gear=gear, **kw) == bool(g[f'{name}_modified'])
+    np.testing.assert_allclose(m.vertices(gear[1]), g[f'{name}_vmov'], atol=0.25)
+    om = g16_oracle_mesh(g)
+    fem_ref.relax_mesh_most_deformed(om, GEARS_FM, **kw)
+    scale = np.abs(om.vertices(fem_ref.GEAR_MOVING) - g['vmov']).max()
+    np.testing.assert_allclose(m.vertices(gear[1]), om.vertices(fem_ref.GEAR_MOVING), atol=1e-4 * scale)
+    if name == 'md_flip':
+        assert (m.triangle_area_deform(gear) > 0).all()
+        assert not fb.optimizer.relax_mesh_most_deformed(m, gear=gear, deform_cutoff=-1)      # nothing flipped any more

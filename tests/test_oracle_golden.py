@@ -263,3 +263,90 @@ def test_g14_groupings():
     scale = np.abs(g['m1_v_after'] - g['m1_v']).max()
     for k in range(1, 4):
         np.testing.assert_allclose(ms[k].vertices_w_offset(fem_ref.GEAR_MOVING), g[f'm{k}_v_after'] + g[f'm{k}_off_after'], atol=0.05 * scale)
+
+
+# ----------------------------------------------------------------------- G16: relax_mesh
+def g16_oracle_mesh(g, cls=None):
+    cls = fem_ref.RefMesh if cls is None else cls
+    m = cls(g['v'], g['t'], uid=3, stiffness_multiplier=g['mult'])
+    m.set_vertices(g['vmov'].copy(), fem_ref.GEAR_MOVING)
+    m.set_offset(g['moff'].copy(), fem_ref.GEAR_MOVING)
+    return m
+
+
+GEARS_FM = (fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING)
+
+
+def test_g16_deformation_measures():
+    g = load_golden('g16_relax.npz')
+    m = g16_oracle_mesh(g)
+    np.testing.assert_allclose(m.triangle_area_deform(GEARS_FM), g['area_deform'], rtol=1e-12)
+    np.testing.assert_allclose(m.triangle_edge_deform(GEARS_FM), g['edge_deform'], rtol=1e-12)
+    np.testing.assert_allclose(m.effective_stiffness_multiplier(), g['eff_mult'], rtol=1e-7)
+    np.testing.assert_allclose(fem_ref.svds_to_deform(g['area_deform'].reshape(-1, 1)), g['svd_deform_area'], rtol=1e-12)
+
+
+def test_g16_local_normalized_stiffness():
+    g = load_golden('g16_relax.npz')
+    m = g16_oracle_mesh(g)
+    K, stress = m.stiffness_matrix_local_normalized(GEARS_FM, tri_mask=g['tmask'])
+    n = 2 * g['v'].shape[0]
+    Kr = _sp(g, 'Kn', (n, n))
+    assert abs(K - Kr).max() <= 1e-12 * abs(Kr).max()
+    np.testing.assert_allclose(stress, g['Kn_stress'], atol=2e-6 * np.abs(g['Kn_stress']).max())
+
+
+@pytest.mark.parametrize('which', ['ft', 'fv'])
+def test_g16_relax_mesh(which):
+    """the reference's converged (relres 1e-11) relaxation against the exact solve of the restated system"""
+    g = load_golden('g16_relax.npz')
+    m = g16_oracle_mesh(g)
+    if which == 'ft':
+        mod = fem_ref.relax_mesh(m, free_triangles=g['free_tri'], gear=GEARS_FM)
+    else:
+        mod = fem_ref.relax_mesh(m, free_vertices=g['free_vtx'], gear=GEARS_FM)
+    assert mod == bool(g[f'{which}_modified'])
+    moved = np.abs(g[f'{which}_vmov'] - g['vmov']).max()
+    assert moved > 1.0
+    np.testing.assert_allclose(m.vertices(fem_ref.GEAR_MOVING), g[f'{which}_vmov'], atol=1e-7 * moved)
+    np.testing.assert_array_equal(m.offset(fem_ref.GEAR_MOVING), g[f'{which}_moff'])
+    if which == 'ft':                                       # the FIXED gear is restored
+        np.testing.assert_array_equal(m.vertices(fem_ref.GEAR_FIXED), g['ft_vfix'])
+        np.testing.assert_array_equal(m.offset(fem_ref.GEAR_FIXED), g['ft_foff'])
+
+
+def test_g16_most_deformed_region():
+    g = load_golden('g16_relax.npz')
+    m = g16_oracle_mesh(g)
+    fv, ft = fem_ref.most_deformed_region(m, GEARS_FM, deform_cutoff=-1)
+    np.testing.assert_array_equal(fv, g['md_flip_free_vtx'])
+    assert ft is None
+    for name, iqr in (('md_cut', 0), ('md_iqr', 1.5)):
+        fv, ft = fem_ref.most_deformed_region(m, GEARS_FM, deform_cutoff=float(g['deform_cutoff']), iqr=iqr)
+        assert fv is None
+        np.testing.assert_array_equal(ft, g[f'{name}_free_tri'])
+
+
+@pytest.mark.parametrize('name,kw', [('md_flip', dict(deform_cutoff=-1)), ('md_cut', dict(deform_cutoff=0.35)),
+                                     ('md_iqr', dict(deform_cutoff=0.35, iqr=1.5))])
+def test_g16_relax_most_deformed(name, kw):
+    """the reference ran these with its default solver exits (tol 1e-7 + the tolerated-perturbation stop), so the field
+    is compared at the size of that stop (0.25 px), the flips it removes exactly"""
+    g = load_golden('g16_relax.npz')
+    m = g16_oracle_mesh(g)
+    assert fem_ref.relax_mesh_most_deformed(m, GEARS_FM, **kw) == bool(g[f'{name}_modified'])
+    np.testing.assert_allclose(m.vertices(fem_ref.GEAR_MOVING), g[f'{name}_vmov'], atol=0.25)
+    if name == 'md_flip':
+        assert (g['area_deform'] < 0).sum() == 3 and (g['md_flip_area_deform'] > 0).all()
+        assert (m.triangle_area_deform(GEARS_FM) > 0).all()
+
+
+@pytest.mark.parametrize('name,mode', [('grigid', 0), ('gaffine', 1), ('crigid', 2), ('caffine', 3)])
+def test_g16_anneal_modes(name, mode):
+    g = load_golden('g16_relax.npz')
+    m = fem_ref.RefMesh(g['an_v'], g['an_t'], uid=4)
+    m.set_vertices(g['an_vmov'].copy(), fem_ref.GEAR_MOVING)
+    m.set_offset(np.array([[1.0, 2.0]]), fem_ref.GEAR_MOVING)
+    m.anneal(gear=(fem_ref.GEAR_MOVING, fem_ref.GEAR_FIXED), mode=mode)
+    np.testing.assert_allclose(m.vertices(fem_ref.GEAR_FIXED), g[f'an_{name}_vfix'], atol=1e-9)
+    np.testing.assert_allclose(m.offset(fem_ref.GEAR_FIXED), g[f'an_{name}_foff'], atol=1e-9)
