@@ -226,16 +226,29 @@ class SLM:
         for lk in self.links:
             lk.set_hard_residue_filter(residue_len)
 
-    def adjust_link_weight_by_residue(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), **kwargs):
+    def relax_higly_deformed(self, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), deform_cutoff=const.MAXIMUM_DEFORM_ALLOWED, iqr=0):
+        """optimizer.py:763-772 (name as in the reference): relax the most deformed region of every free mesh; the
+        cutoff handed down is the already converted threshold, as the reference does"""
+        modified = 0
+        deform_thresh = 1 - 1 / (abs(deform_cutoff) + 1)
+        for m in self.meshes:
+            if m.locked:
+                continue
+            modified = modified + relax_mesh_most_deformed(m, gear=gear, deform_cutoff=deform_thresh, iqr=iqr)
+        return modified
+
+    def adjust_link_weight_by_residue(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), relax_first=False, **kwargs):
         wm = cm = False
+        if relax_first:
+            self.relax_higly_deformed()
         for lk in self.links:
             a, b = lk.adjust_weight_from_residue(gear=gear)
             wm |= a
             cm |= b
         return wm, cm
 
-    def anneal(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT):
-        """optimizer.py:757-760 (ANNEAL_COPY_EXACT; the rigid / affine annealing modes are host geometry that is not mirrored)."""
+    def anneal(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_CONNECTED_RIGID):
+        """optimizer.py:757-760"""
         for m in self.meshes:
             m.anneal(gear=gear, mode=mode)
 

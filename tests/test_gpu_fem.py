@@ -351,3 +351,21 @@ def test_g16_relax_most_deformed(fb, name, kw):
     if name == 'md_flip':
         assert (m.triangle_area_deform(gear) > 0).all()
         assert not fb.optimizer.relax_mesh_most_deformed(m, gear=gear, deform_cutoff=-1)      # nothing flipped any more
+
+
+def test_slm_relax_higly_deformed(fb):
+    """SLM.relax_higly_deformed (optimizer.py:763-772) = relax_mesh_most_deformed of every free mesh with the converted
+    cutoff; locked meshes are skipped"""
+    from conftest import load_golden
+    g = load_golden('g16_relax.npz')
+    const = fb.constant
+    gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
+    a, b, c = _g16_mesh(fb, g), _g16_mesh(fb, g), _g16_mesh(fb, g)
+    b.uid, c.uid = 4.0, 5.0
+    b.lock()
+    slm = fb.optimizer.SLM([a, b])
+    assert slm.relax_higly_deformed(gear=gear) == 1
+    np.testing.assert_array_equal(b.vertices(gear[1]), g['vmov'])
+    assert fb.optimizer.relax_mesh_most_deformed(c, gear=gear, deform_cutoff=1 - 1 / 1.35)
+    np.testing.assert_allclose(a.vertices(gear[1]), c.vertices(gear[1]), atol=1e-9)
+    assert np.abs(a.vertices(gear[1]) - g['vmov']).max() > 1.0
