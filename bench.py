@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+RESIDUE_LEN = 2.0              # configs/default_stitching_configs.yaml:15 (matcher_config.residue_len of the default stitching run)
 
 
 def parse():
@@ -169,7 +170,7 @@ def cpu_baseline_ncc(h0, h1, seconds=20.0):
     done = 0
     t0 = time.time()
     while done < h0.shape[0]:
-        pipeline_ref.match_pair(h0[done], h1[done])
+        pipeline_ref.match_pair(h0[done], h1[done], residue_len=RESIDUE_LEN)
         done += 1
         if time.time() - t0 > seconds:
             break
@@ -212,7 +213,7 @@ def main():
                                            s0.ptr, s1.ptr, sh.ptr))
         strips[k] = (s0, s1, sh.to_array((n_res, 2), np.int32))
         for j in range(mper):
-            matchers[(k, j)] = StripBatchMatcher(P, H, W)
+            matchers[(k, j)] = StripBatchMatcher(P, H, W, residue_len=RESIDUE_LEN)
     _lib.check(lib.fb_sync(ctx))
 
     def step(i):
@@ -386,7 +387,7 @@ def main():
                                      f'{Hl}x{Wl}), {P * S} pairs per step ({S} matcher calls of {P} pairs dealt to {nthr} host threads); stages: x0.5 downsample, DoG, global NCC, DoG, '
                                      f'4 coarse + 385 fine block NCCs, last-round relaxation + residue weights + strain (integer synthetic offsets in +-20 px plus a smooth '
                                      f'{args.warp} px warp; odd offsets take the rigid mesh-relaxation branch, DESIGN.md sec.5)',
-                            pairs_per_step=P * S, pairs_per_matcher_call=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33),
+                            pairs_per_step=P * S, pairs_per_matcher_call=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33, residue_mode='huber', residue_len=RESIDUE_LEN),
                 check=dict(global_shift_within_1px=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches, matches_within_half_px_of_truth=ok_match,
                            pairs_needing_mesh_relaxation=int(res['needs_host'].sum())),
                 roofline=roof)

@@ -269,9 +269,51 @@ class StripBatchMatcher:
                                       _lib.ptr(pid32), _lib.ptr(xy0c), _lib.ptr(xy1i), _lib.ptr(t1c), _lib.ptr(w32), self.residue_len,
                                       sample_err, self.stiffness_lambda, self.relax_tol, _lib.ptr(rw), _lib.ptr(x),
                                       C.byref(iters), C.byref(relres)))
-        self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K))
+        self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K), relaxed_first=0)
         self._links_rows = (K, pid32, xy1i)                   # what the links resident in the system were built from
-        return rw, x.reshape(self.P, V, 2)
+        x = x.reshape(self.P, V, 2)
+        self._relax_first(x, pid32, xy0c, xy1i, t1c, rw, sample_err)
+        return rw, x
+
+    def _relax_first(self, x, pid, xy0, xy1i, t1, rw, sample_err):
+        """adjust_link_weight_by_residue(relax_first=True) (matcher.py:736 -> optimizer.py:763-779): before the residues
+        are taken, a region of mesh1 that the relaxation deformed beyond the cutoff is relaxed on its own
+        (relax_mesh_most_deformed).  Screen: with d = the largest displacement difference along a grid edge relative to
+        that edge, every triangle's area and edge deformation is below 2 d, and nothing is freed below
+        1 - 1 / (1 + (1 - 1 / 1.35)) = 0.206 -- pairs with d <= 0.1 are done.  The others (gross mismatches only) take the
+        reference's statements one pair at a time: optimizer.relax_mesh_most_deformed (device assembly + PCG), then the
+        residue weights of that pair from the relaxed mesh."""
+        m = self._mesh
+        nx, ny = m.grid_xs.size, m.grid_ys.size
+        g = x.reshape(self.P, ny, nx, 2)
+        ex = np.sqrt(np.sum(np.diff(g, axis=2) ** 2, axis=-1)) / np.diff(m.grid_xs)[None, None, :]
+        ey = np.sqrt(np.sum(np.diff(g, axis=1) ** 2, axis=-1)) / np.diff(m.grid_ys)[None, :, None]
+        d = np.maximum(ex.max(axis=(1, 2)), ey.max(axis=(1, 2)))
+        suspects = np.flatnonzero(d > 0.1)
+        if suspects.size == 0:
+            return
+        from .optimizer import relax_mesh_most_deformed
+        gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
+        cutoff = 1 - 1 / (const.MAXIMUM_DEFORM_ALLOWED + 1)      # SLM.relax_higly_deformed hands the converted value down
+        v_init = m.vertices(const.MESH_GEAR_INITIAL)
+        for p in suspects:
+            rows = np.flatnonzero(pid == p)
+            if rows.size == 0:
+                continue
+            m1 = m.copy(uid=1)
+            m1.grid_xs, m1.grid_ys = m.grid_xs, m.grid_ys
+            m1.set_field(t1[p] + x[p], gear=gear)
+            if not relax_mesh_most_deformed(m1, gear=gear, deform_cutoff=cutoff):
+                continue
+            self.last_relax['relaxed_first'] += 1
+            pts = xy1i[rows]
+            tid = m1.locate_cartesian(pts)
+            _, B = m1.cart2bary(pts, const.MESH_GEAR_INITIAL, tid=tid)
+            dxy = m1.bary2cart(tid, B, const.MESH_GEAR_MOVING, offsetting=True) - xy0[rows]
+            dis = np.sum(dxy ** 2, axis=-1) ** 0.5
+            dis = ((dis ** 2 - sample_err ** 2).clip(0, None)) ** 0.5                # optimizer.py:183-185
+            rw[rows] = (self.residue_len / np.maximum(dis, self.residue_len)).astype(np.float32)
+            x[p] = m1.vertices_w_offset(const.MESH_GEAR_MOVING) - (v_init + t1[p])
 
     def _rigid_fits(self, pid, p0, p1, wt):
         """spatial.fit_affine(p0, p1, return_rigid=True, weight, svd_clip=(1, 1)) for every pair at once.  One pass

@@ -12,6 +12,8 @@ import numpy as np
 
 from . import ncc_ref, fem_ref
 
+MAXIMUM_DEFORM_ALLOWED = 0.35     # feabas/config.py:33
+
 
 def cartesian_mesh(W, H, mesh_size, min_num_blocks=2, max_aspect_ratio=2):
     """Mesh.from_bbox((0,0,W,H), cartesian=True) (mesh.py:403-435): node grid at pixel centres - 0.5.
@@ -63,6 +65,11 @@ def relax_mesh1(W, H, mesh_size, t0, t1, xy0, xy1, weight, residue_len=0.0, min_
     link = fem_ref.RefLink(m0, m1, tid0, tid1, B0, B1, weight=weight)
     before = m1.vertices_w_offset(fem_ref.GEAR_MOVING).copy()
     fem_ref.optimize_linear([m0, m1], [link], exact=True)
+    if residue_len > 0:
+        # adjust_link_weight_by_residue(relax_first=True) (matcher.py:736, optimizer.py:763-779): a region of the free mesh
+        # deformed beyond the (twice converted) cutoff is relaxed before the residues are taken
+        cutoff = 1 - 1 / (MAXIMUM_DEFORM_ALLOWED + 1)
+        fem_ref.relax_mesh_most_deformed(m1, gear=(fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING), deform_cutoff=cutoff)
     u = m1.vertices_w_offset(fem_ref.GEAR_MOVING) - before
     if return_mesh:
         return u, m0, m1, link

@@ -100,6 +100,37 @@ def test_final_relax_huber_weights_vs_fem_oracle(fb):
     m.free()
 
 
+def test_final_relax_relaxes_grossly_deformed_region_first(fb):
+    """adjust_link_weight_by_residue(relax_first=True) (matcher.py:736, optimizer.py:763-779): a cluster of confident
+    but wrong matches bends mesh1 beyond the deformation cutoff; that region is relaxed on its own before the residue
+    weights are taken.  Pair 1 stays below the screen and takes the plain path.  Against the oracle's exact chain."""
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    P, H, W = 3, 256, 1024
+    m = StripBatchMatcher(P, H, W)
+    rng = np.random.default_rng(15)
+    t1 = np.array([[0.0, 0.0], [2.0, -1.0], [-3.0, 1.0]])
+    pid, xy0, xy1, wt = [], [], [], []
+    for p, mag in enumerate((60.0, 0.0, 40.0)):
+        gx, gy = np.meshgrid(np.arange(40, W - 40, 61.0), np.arange(30, H - 30, 47.0))
+        c = np.stack((gx.ravel(), gy.ravel()), -1) + t1[p]
+        f = rng.normal(0, 0.1, c.shape)
+        bad = (np.abs(c[:, 0] - 500) < 70) & (np.abs(c[:, 1] - 120) < 50)
+        f[bad] += np.array([[mag * 0.8, -mag * 0.6]])
+        w = rng.uniform(0.35, 1.0, c.shape[0]).astype(np.float32)
+        w[bad] = 1.0
+        pid.append(np.full(c.shape[0], p)); xy0.append(c - 0.5 * f); xy1.append(c + 0.5 * f); wt.append(w)
+    pid = np.concatenate(pid); xy0 = np.concatenate(xy0); xy1 = np.concatenate(xy1); wt = np.concatenate(wt)
+    rw, x = m._final_relax(pid, xy0, xy1, wt, t1)
+    assert m.last_relax['relaxed_first'] == 2
+    for p in range(P):
+        s = pid == p
+        uo, rwo = pipeline_ref.relax_mesh1(W, H, float(np.min(m.spacings)), np.zeros(2), t1[p], xy0[s], xy1[s], wt[s], residue_len=5.0)
+        scale = max(np.abs(uo).max(), 1.0)
+        np.testing.assert_allclose(x[p], uo, atol=1e-4 * scale)
+        np.testing.assert_allclose(rw[s], rwo, atol=1e-4)
+    m.free()
+
+
 def test_strain_estimate_vs_fem_oracle(fb):
     """matcher.py:752-777 for a batch: rigid initialisation (fit_affine, pinned by golden G13), relaxation, sqrt(Es / Es0),
     against the oracle's exact chain pair by pair -- matches carry a small rotation and a smooth deformation"""
