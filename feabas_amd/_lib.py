@@ -65,6 +65,7 @@ _PROTOS = {
     'fb_dog_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
     'fb_area_downsample2': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'fb_area_downsample2_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    'fb_remap_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'fb_synth_strips_dev': (c_i, [c_p, c_i, c_i, c_i, c_i, C.c_uint32, c_i, c_i, C.c_float, c_p, c_p, c_p]),
     'fb_sys_create': (c_i, [c_p, c_i64, C.POINTER(c_p)]),
     'fb_sys_destroy': (None, [c_p, c_p]),
@@ -82,6 +83,7 @@ _PROTOS = {
     'fb_sys_solve_groups': (c_i, [c_p, c_p, c_i, c_p, c_d, c_d, c_i, c_i, c_p, c_p]),
     'fb_sys_group_energy': (c_i, [c_p, c_p, c_i, c_p, c_p]),
     'fb_pairs_relax': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_d, c_d, c_d, c_p, c_p, c_p, c_p]),
+    'fb_pairs_relax_bary': (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_d, c_d, c_d, c_d, c_p, c_p, c_p, c_p]),
     'fb_pairs_strain': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_d, c_i, c_d, c_p, c_p, c_p]),
     'fb_sys_lambda': (c_i, [c_p, c_p, c_d, c_d, C.POINTER(c_d), C.POINTER(c_d)]),
     'fb_sys_form': (c_i, [c_p, c_p, c_d, c_d]),

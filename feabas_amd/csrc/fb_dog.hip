@@ -132,6 +132,29 @@ __global__ void any_zero_kernel(const uint8_t* __restrict__ m, size_t total, int
         if (m[i] == 0) { *flag = 1; return; }
 }
 
+// one thread = one output pixel; maps are float32 relative to the integer origin of the sub-image the reference
+// hands to cv2.remap; 1/32-px quantisation and float32 table weights as in fb_sample_affine (fb_common.h)
+__global__ void remap_kernel(const float* __restrict__ imgs, int IH, int IW, int N, const int* __restrict__ img_id, int h, int w,
+                             const float* __restrict__ map_x, const float* __restrict__ map_y, const uint8_t* __restrict__ mask,
+                             const int* __restrict__ origin, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const size_t per = (size_t)h * w, total = (size_t)N * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / per);
+        if (mask && !mask[i]) { out[i] = 0.f; continue; }
+        const float* img = imgs + (size_t)img_id[n] * IH * IW;
+        const int sx = (int)rintf(map_x[i] * 32.0f), sy = (int)rintf(map_y[i] * 32.0f);
+        const int ix = (sx >> 5) + origin[2 * n], iy = (sy >> 5) + origin[2 * n + 1];
+        const float ax = (float)(sx & 31) * (1.0f / 32.0f), ay = (float)(sy & 31) * (1.0f / 32.0f);
+        const float w00 = (1.0f - ay) * (1.0f - ax), w01 = (1.0f - ay) * ax, w10 = ay * (1.0f - ax), w11 = ay * ax;
+        const bool x0ok = ix >= 0 && ix < IW, x1ok = ix + 1 >= 0 && ix + 1 < IW, y0ok = iy >= 0 && iy < IH, y1ok = iy + 1 >= 0 && iy + 1 < IH;
+        const int cx0 = min(max(ix, 0), IW - 1), cx1 = min(max(ix + 1, 0), IW - 1), cy0 = min(max(iy, 0), IH - 1), cy1 = min(max(iy + 1, 0), IH - 1);
+        const float v00 = img[(size_t)cy0 * IW + cx0], v01 = img[(size_t)cy0 * IW + cx1];
+        const float v10 = img[(size_t)cy1 * IW + cx0], v11 = img[(size_t)cy1 * IW + cx1];
+        out[i] = ((((y0ok && x0ok) ? v00 : 0.f) * w00 + ((y0ok && x1ok) ? v01 : 0.f) * w01) + ((y1ok && x0ok) ? v10 : 0.f) * w10) + ((y1ok && x1ok) ? v11 : 0.f) * w11;
+    }
+}
+
 __global__ void area_down2_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int N, int H, int W) {
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)N * Ho * Wo;
@@ -481,6 +504,22 @@ int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double 
     }
     hipFree(din); hipFree(dout); if (dmask) hipFree(dmask);
     return rc;
+}
+
+// common.remap (cv2.remap INTER_LINEAR, BORDER_CONSTANT 0; common.py:218-255, 329-330) of resident float32 images
+// through explicit per-pixel maps: the exact piecewise-linear tier of MeshRenderer.crop_multiple (renderer.py:511-563),
+// whose field the host evaluates for the few blocks that no affine map approximates within tolerance.
+int fb_remap_dev(fb_ctx* ctx, const float* imgs, int IH, int IW, int N, const int* img_id, int h, int w, const float* map_x,
+                 const float* map_y, const uint8_t* mask, const int* origin, float* out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, imgs && IH > 0 && IW > 0 && N >= 0 && h > 0 && w > 0 && img_id && map_x && map_y && origin && out);
+    if (N == 0) return FB_OK;
+    FB_PROF(ctx, "remap");
+    const size_t total = (size_t)N * h * w;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(remap_kernel, dim3(blocks), dim3(256), 0, ctx->stream, imgs, IH, IW, N, img_id, h, w, map_x, map_y, mask, origin, out);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
 }
 
 int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {

@@ -918,22 +918,12 @@ int pairs_build_links(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const do
 }
 }  // namespace
 
-// matcher.py:725-737 for a batch: relax every pair's mesh1 against its matches (optimize_linear to rtol), then the
-// huber residue weight L / max(sqrt(max(|r|^2 - sample_err^2, 0)), L) of every match (optimizer.py:174-205).
-// xy0_mov: mesh0 points in the MOVING gear, xy1_init: mesh1 points in its INITIAL gear, t1 [P][2]: mesh1 offsets.
-int fb_pairs_relax(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
-                   const double* xy0_mov, const double* xy1_init, const double* t1, const float* conf, double residue_len, double sample_err,
-                   double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres) {
-    FB_LOCK(ctx);
-    FB_CHECK_ARG(ctx, s && s->finalized && P > 0 && s->nv % P == 0 && K > 0 && pid && xy0_mov && xy1_init && t1 && conf && rw);
-    int rc = pairs_build_links(ctx, s, P, nx, ny, xs, ys, K, pid, xy1_init);
-    if (rc) return rc;
-    s->h_dxy.resize(2 * (size_t)K);
-    for (int64_t k = 0; k < K; ++k) {                       // Link.dxy (optimizer.py:248-255) in the MOVING gears
-        const int p = pid[k];
-        s->h_dxy[2 * k] = (xy1_init[2 * k] + t1[2 * p]) - xy0_mov[2 * k];
-        s->h_dxy[2 * k + 1] = (xy1_init[2 * k + 1] + t1[2 * p + 1]) - xy0_mov[2 * k + 1];
-    }
+namespace {
+// shared tail of fb_pairs_relax / fb_pairs_relax_bary: the links (h_nodes6, h_B1, h_bary6) are resident, h_dxy holds the
+// residual of every match before the solve.  Solve every pair, then the huber residue weights.
+int pairs_relax_core(fb_ctx* ctx, fb_system* s, int P, int64_t K, const float* conf, double residue_len, double sample_err,
+                     double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres) {
+    int rc;
     if ((rc = fb_sys_assemble_links(ctx, s, s->h_bary6.data(), conf, s->h_dxy.data()))) return rc;
     if ((rc = fb_sys_form_groups(ctx, s, P, stiffness_lambda, -1.0, nullptr))) return rc;
     s->h_x.resize(2 * (size_t)s->nv);
@@ -952,6 +942,58 @@ int fb_pairs_relax(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const doubl
     }
     if (x_out) std::copy(s->h_x.begin(), s->h_x.end(), x_out);
     return FB_OK;
+}
+}  // namespace
+
+// matcher.py:725-737 for a batch: relax every pair's mesh1 against its matches (optimize_linear to rtol), then the
+// huber residue weight L / max(sqrt(max(|r|^2 - sample_err^2, 0)), L) of every match (optimizer.py:174-205).
+// xy0_mov: mesh0 points in the MOVING gear, xy1_init: mesh1 points in its INITIAL gear, t1 [P][2]: mesh1 offsets.
+int fb_pairs_relax(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
+                   const double* xy0_mov, const double* xy1_init, const double* t1, const float* conf, double residue_len, double sample_err,
+                   double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && P > 0 && s->nv % P == 0 && K > 0 && pid && xy0_mov && xy1_init && t1 && conf && rw);
+    int rc = pairs_build_links(ctx, s, P, nx, ny, xs, ys, K, pid, xy1_init);
+    if (rc) return rc;
+    s->h_dxy.resize(2 * (size_t)K);
+    for (int64_t k = 0; k < K; ++k) {                       // Link.dxy (optimizer.py:248-255) in the MOVING gears
+        const int p = pid[k];
+        s->h_dxy[2 * k] = (xy1_init[2 * k] + t1[2 * p]) - xy0_mov[2 * k];
+        s->h_dxy[2 * k + 1] = (xy1_init[2 * k + 1] + t1[2 * p + 1]) - xy0_mov[2 * k + 1];
+    }
+    return pairs_relax_core(ctx, s, P, K, conf, residue_len, sample_err, stiffness_lambda, rtol, rw, x_out, iters, relres);
+}
+
+// The same relaxation for matches that were located in a DEFORMED mesh1 (Link.from_coordinates on the MOVING gear of a
+// mesh that an earlier round relaxed, matcher.py:717; mesh.py:2191-2217): the caller hands over the three mesh1 vertices
+// (ids inside the union mesh) and barycentric coordinates of every match and dxy0 = the link residual with mesh1 at its
+// FIXED gear (B1 . v_fixed - xy0).  The unknown is the TOTAL displacement from the FIXED gear, so that the elastic
+// energy of the earlier deformation (the `stress` term of optimizer.py:1417-1418) is inside the system: the minimiser
+// is the reference's MOVING gear after optimize_linear, whatever the starting field.
+int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int32_t* nodes3, const double* B1, const double* dxy0,
+                        const float* conf, double residue_len, double sample_err, double stiffness_lambda, double rtol, float* rw,
+                        double* x_out, int* iters, double* relres) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && P > 0 && s->nv % P == 0 && K > 0 && nodes3 && B1 && dxy0 && conf && rw);
+    s->h_nodes6.resize(6 * (size_t)K);
+    s->h_bary6.resize(6 * (size_t)K);
+    s->h_B1.assign(B1, B1 + 3 * (size_t)K);
+    s->h_dxy.assign(dxy0, dxy0 + 2 * (size_t)K);
+    for (int64_t k = 0; k < K; ++k) {
+        int32_t* n6 = &s->h_nodes6[6 * (size_t)k];
+        double* b6 = &s->h_bary6[6 * (size_t)k];
+        n6[0] = n6[1] = n6[2] = -1;
+        b6[0] = 1.0; b6[1] = 0.0; b6[2] = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const int32_t v = nodes3[3 * k + a];
+            if (v < 0 || v >= s->nv) return fb_fail(ctx, FB_ERR_ARG, "fb_pairs_relax_bary: vertex %d outside [0, %d)", v, s->nv);
+            n6[3 + a] = v;
+            b6[3 + a] = -B1[3 * k + a];
+        }
+    }
+    int rc = fb_sys_update_links(ctx, s, K, s->h_nodes6.data());
+    if (rc) return rc;
+    return pairs_relax_core(ctx, s, P, K, conf, residue_len, sample_err, stiffness_lambda, rtol, rw, x_out, iters, relres);
 }
 
 // matcher.py:752-777 for a batch, after the rigid initialisation R [P][3][3] (row vectors: v_fixed = v_initial R[:2,:2],

@@ -190,9 +190,9 @@ def stitching_matcher(img0, img1, **kwargs):
 
     The whole sequence runs on the device through the batch pipeline (``stitch_pipeline.StripBatchMatcher`` with a batch
     of one; callers with many pairs should use the batch class directly).  Supported: equal-shape 2-D uint8 strips,
-    ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, unmasked images.  Anything the device
-    path does not cover (masks, photometric statistics, explicit spacings, a mesh relaxation that is not a rigid
-    translation between rounds) raises NotImplementedError instead of silently taking another route."""
+    ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, unmasked images; mesh relaxations
+    between spacings of any shape (rigid or deformed mesh1).  Anything the device path does not cover (masks, photometric
+    statistics, explicit spacings) raises NotImplementedError instead of silently taking another route."""
     from .stitch_pipeline import StripBatchMatcher
     kw = dict(kwargs)
     sigma = kw.pop('sigma', 2.5)
@@ -235,7 +235,4 @@ def stitching_matcher(img0, img1, **kwargs):
         d0.free(); d1.free()
     if res['xy0'] is None:
         return None, None, conf_thresh, None, None
-    if res['needs_host']:
-        raise NotImplementedError('stitching_matcher: this pair needs the deformed-mesh crop between spacings '
-                                  '(MeshRenderer.crop_multiple on a non-rigidly relaxed mesh), which is not on the device path')
     return res['xy0'], res['xy1'], res['weight'], res['strain'], None

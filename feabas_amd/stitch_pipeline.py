@@ -15,10 +15,13 @@ Per pair, in the reference's order:
      for the whole batch as one block-diagonal system             fb_sys_update_links / _form_groups / _solve_groups
 The low-confidence second shot of global_translation_matcher (159-221) runs per affected pair through the host
 mirror in matcher.py (block NCCs on the device).
-What is NOT here yet (DESIGN.md "scope of the pair pipeline"): NON-RIGID mesh relaxation
-between spacings (725-742; a uniform block displacement is applied as the rigid translation it
-relaxes to) together with the bilinear patch gather it needs.
-Pairs that would take the non-rigid branch are flagged in the result (``needs_host``).
+Mesh relaxation between spacings (725-742): a uniform block displacement is applied as the rigid translation it relaxes
+to (crops stay integer translations); any other field makes the pair DEFORMED: mesh1 keeps the relaxed displacement of
+its nodes (fb_pairs_relax_bary: total displacement from the FIXED gear, huber re-weighting and second solve included),
+the next round's blocks come from the deformed bounding box, image-1 windows are gathered through the renderer's tiers
+(deformed.block_affines -> fb_ncc_blocks_affine_dev inside the NCC loaders; the exact piecewise-linear tier through
+fb_remap_dev + fb_ncc_batch_dev), matches are located in the deformed triangles (deformed.locate) and reported in the
+INITIAL gear through their barycentric coordinates (matcher.py:748-751).  SURVEY.md sec.8f rows 1-2.
 """
 import ctypes as C
 
@@ -28,6 +31,7 @@ from . import _lib
 from . import constant as const
 from .matcher import auto_spacings, next_fast_len
 from .mesh import Mesh
+from . import deformed as dfm
 
 DEFAULT_AVG_DEFORM = 0.05            # feabas/config.py:32
 
@@ -89,6 +93,7 @@ class StripBatchMatcher:
         self.last_strain_solve = None
         self._relax_sys = None
         self.last_relax = None
+        self.last_tiers = {}
 
     def free(self):
         if self._relax_sys is not None:
@@ -141,12 +146,16 @@ class StripBatchMatcher:
         _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, H, W, self.sigma, None, 1, self.d_dogf.offset(n * H * W * 4)))
         self.d_dogf_view = self.d_dogf
 
-    def _blocks(self, tx, ty, t1, sel, spacing, mnb):
-        """block descriptors for the pairs `sel` (all share Nx, Ny): returns (blk [Q, nblk, 9], bboxes [Q, nblk, 4])"""
+    def _blocks(self, tx, ty, t1, sel, spacing, mnb, bounds=None):
+        """block descriptors for the pairs `sel` (all share Nx, Ny): returns (blk [Q, nblk, 9], bboxes [Q, nblk, 4]).
+        bounds: (xmin, ymin, xmax, ymax) of the intersected mesh bounding boxes of `sel` when mesh1 is deformed."""
         H, W = self.H, self.W
         # mesh bounding boxes in the MOVING gear (Mesh.from_bbox: vertices at pixel centres - 0.5)
-        xmin = np.maximum(-0.5 + tx[sel], -0.5 + t1[sel, 0]); ymin = np.maximum(-0.5 + ty[sel], -0.5 + t1[sel, 1])
-        xmax = np.minimum(W - 0.5 + tx[sel], W - 0.5 + t1[sel, 0]); ymax = np.minimum(H - 0.5 + ty[sel], H - 0.5 + t1[sel, 1])
+        if bounds is None:
+            xmin = np.maximum(-0.5 + tx[sel], -0.5 + t1[sel, 0]); ymin = np.maximum(-0.5 + ty[sel], -0.5 + t1[sel, 1])
+            xmax = np.minimum(W - 0.5 + tx[sel], W - 0.5 + t1[sel, 0]); ymax = np.minimum(H - 0.5 + ty[sel], H - 0.5 + t1[sel, 1])
+        else:
+            xmin, ymin, xmax, ymax = bounds
         nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
         assert np.all(nx == nx[0]) and np.all(ny == ny[0])
         nxi, nyi = int(nx[0]), int(ny[0])
@@ -166,8 +175,11 @@ class StripBatchMatcher:
         blk[:, :, 1] = x0 - np.round(tx[sel]).astype(np.int32)[:, None]
         blk[:, :, 2] = y0 - np.round(ty[sel]).astype(np.int32)[:, None]
         blk[:, :, 3] = dy[:, None]; blk[:, :, 4] = dx[:, None]
-        blk[:, :, 5] = x0 - np.round(t1[sel, 0]).astype(np.int32)[:, None]
-        blk[:, :, 6] = y0 - np.round(t1[sel, 1]).astype(np.int32)[:, None]
+        if t1 is None:                                       # deformed mesh1: the window comes from the affine / exact gather
+            blk[:, :, 5] = 0; blk[:, :, 6] = 0
+        else:
+            blk[:, :, 5] = x0 - np.round(t1[sel, 0]).astype(np.int32)[:, None]
+            blk[:, :, 6] = y0 - np.round(t1[sel, 1]).astype(np.int32)[:, None]
         blk[:, :, 7] = dy[:, None]; blk[:, :, 8] = dx[:, None]
         return blk, bb
 
@@ -203,6 +215,182 @@ class StripBatchMatcher:
             ddx, ddy, dcf = (a.reshape(sel.size, -1) for a in self._fetch_out(nb))
             groups.append((sel, bb, ddx, ddy, dcf))
         return groups
+
+    # ------------------------------------------------------------------ deformed pairs
+    def _scratch(self, name, nbytes):
+        """grow-only device scratch of the rarely taken exact-field tier"""
+        buf = getattr(self, '_scr_' + name, None)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                buf.free()
+            buf = _lib.DeviceBuffer(int(nbytes))
+            setattr(self, '_scr_' + name, buf)
+        return buf
+
+    def _match_round_deformed(self, tx, ty, U, pairs, spacing, mnb, pad_flags, subpixel, is_last):
+        """one spacing round for pairs whose mesh1 is deformed (U [P, V, 2] = MOVING - INITIAL of its nodes): the block grid
+        covers the intersection with the deformed bounding box (matcher.py:877), image-0 windows are integer crops
+        (mesh0 is a translated grid), image-1 windows go through MeshRenderer.crop_multiple's tiers with
+        affine_approx_tol = 0.1 in the last round, max(1, 0.02 spacing) before (matcher.py:578-603).  Same return as
+        `_match_round`; `self.last_tiers[pair]` keeps the tier of every block."""
+        lib, ctx = _lib.load(), _lib.ctx()
+        n, H, W = self.P, self.H, self.W
+        self._relax_system()
+        m = self._mesh
+        v_init = m.vertices(const.MESH_GEAR_INITIAL)
+        tris = m.triangles
+        tol = 0.1 if is_last else max(1.0, 0.02 * float(spacing))
+        vm = v_init[None, :, :] + U[pairs]                                   # [Q, V, 2]
+        xmin = np.maximum(-0.5 + tx[pairs], vm[:, :, 0].min(axis=1)); ymin = np.maximum(-0.5 + ty[pairs], vm[:, :, 1].min(axis=1))
+        xmax = np.minimum(W - 0.5 + tx[pairs], vm[:, :, 0].max(axis=1)); ymax = np.minimum(H - 0.5 + ty[pairs], vm[:, :, 1].max(axis=1))
+        ok = (xmax > xmin) & (ymax > ymin)                                    # common.intersect_bbox validity
+        nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
+        pf = pad_flags[pairs]
+        nfl = self._nfl
+        fh = np.where(pf, nfl[np.clip(2 * dy - 1, 0, nfl.size - 1)], nfl[np.clip(dy, 0, nfl.size - 1)])
+        fw = np.where(pf, nfl[np.clip(2 * dx - 1, 0, nfl.size - 1)], nfl[np.clip(dx, 0, nfl.size - 1)])
+        key = (((nx * 4096 + ny) * 8192 + fh) * 8192 + fw) * 2 + pf
+        key = np.where(ok, key, -1)
+        dogf = self.d_dogf_view
+        img1 = dogf.offset(n * H * W * 4)
+        groups = []
+        for kv in np.unique(key):
+            if kv < 0:
+                continue
+            gi = np.flatnonzero(key == kv)
+            sel = pairs[gi]
+            gfh, gfw, gpad = int(fh[gi[0]]), int(fw[gi[0]]), bool(pf[gi[0]])
+            blk, bb = self._blocks(tx, ty, None, sel, spacing, mnb, bounds=(xmin[gi], ymin[gi], xmax[gi], ymax[gi]))
+            Q, nblk = blk.shape[:2]
+            h, w = int(dy[gi[0]]), int(dx[gi[0]])
+            aff = np.zeros((Q, nblk, 10))
+            exact = []                                                        # (q, block ids, map_x, map_y, mask)
+            for q in range(Q):
+                tier, A, hits = dfm.block_affines(vm[gi[q]], v_init, tris, bb[q], tol)
+                self.last_tiers[int(sel[q])] = tier
+                aff[q, :, 0] = bb[q, :, 0]; aff[q, :, 1] = bb[q, :, 1]
+                aff[q, :, 2] = A[:, 0, 0]; aff[q, :, 3] = A[:, 1, 0]; aff[q, :, 4] = A[:, 2, 0]
+                aff[q, :, 5] = A[:, 0, 1]; aff[q, :, 6] = A[:, 1, 1]; aff[q, :, 7] = A[:, 2, 1]
+                # one remap origin for the whole stack of a pair (render_by_subregions, common.py:316-321):
+                # floor(min of the rendered maps) - 4; an affine map takes its extremes at the corner pixels
+                cx = np.stack((bb[q, :, 0], bb[q, :, 2] - 1, bb[q, :, 2] - 1, bb[q, :, 0]), axis=-1).astype(np.float64)
+                cy = np.stack((bb[q, :, 1], bb[q, :, 1], bb[q, :, 3] - 1, bb[q, :, 3] - 1), axis=-1).astype(np.float64)
+                mx = cx * A[:, None, 0, 0] + cy * A[:, None, 1, 0] + A[:, None, 2, 0]
+                my = cx * A[:, None, 0, 1] + cy * A[:, None, 1, 1] + A[:, None, 2, 1]
+                aff_rows = tier < 3
+                lo_x = mx[aff_rows].min() if aff_rows.any() else np.inf
+                lo_y = my[aff_rows].min() if aff_rows.any() else np.inf
+                ex = np.flatnonzero(~aff_rows)
+                if ex.size:
+                    maps = [dfm.exact_field(vm[gi[q]], v_init, tris, np.flatnonzero(hits[b]), int(bb[q, b, 0]), int(bb[q, b, 1]), h, w) for b in ex]
+                    emx = np.stack([a[0] for a in maps]); emy = np.stack([a[1] for a in maps]); emk = np.stack([a[2] for a in maps])
+                    if emk.any():
+                        lo_x = min(lo_x, emx[emk].min()); lo_y = min(lo_y, emy[emk].min())
+                    exact.append((q, ex, emx, emy, emk))
+                if np.isfinite(lo_x):
+                    aff[q, :, 8] = np.floor(lo_x) - 4; aff[q, :, 9] = np.floor(lo_y) - 4
+            nb = Q * nblk
+            assert nb <= self.max_blocks
+            flat = np.ascontiguousarray(blk.reshape(-1, 9))
+            affc = np.ascontiguousarray(aff.reshape(-1, 10))
+            d_aff = self._scratch('aff', affc.nbytes)
+            _lib.check(lib.fb_memcpy_h2d(ctx, self.d_blk.ptr, _lib.ptr(flat), flat.nbytes))
+            _lib.check(lib.fb_memcpy_h2d(ctx, d_aff.ptr, _lib.ptr(affc), affc.nbytes))
+            _lib.check(lib.fb_ncc_blocks_affine_dev(ctx, dogf.ptr, img1, H, W, H, W, nb, self.d_blk.ptr, d_aff.ptr, h, w, gfh, gfw,
+                                                    1 if subpixel else 0, self.conf_mode, self.d_out.ptr, self.d_out.offset(8 * nb),
+                                                    self.d_out.offset(16 * nb)))
+            ddx, ddy, dcf = (np.array(a).reshape(Q, nblk) for a in self._fetch_out(nb))
+            if exact:
+                self._exact_blocks(exact, blk, aff, sel, h, w, gpad, subpixel, ddx, ddy, dcf)
+            groups.append((sel, bb, ddx, ddy, dcf))
+        return groups
+
+    def _exact_blocks(self, exact, blk, aff, sel, h, w, pad, subpixel, ddx, ddy, dcf):
+        """the exact-field tier (renderer.py:511-563) of a few blocks: both windows are materialised (fb_remap_dev; the
+        image-0 window through an integer map) and correlated as a stack (fb_ncc_batch_dev)."""
+        lib, ctx = _lib.load(), _lib.ctx()
+        n, H, W = self.P, self.H, self.W
+        dogf = self.d_dogf_view                                              # [2 n][H][W]: image 1 of pair p is image n + p
+        where = [(q, b, k, rec) for rec in exact for q in (rec[0],) for k, b in enumerate(rec[1])]
+        nb = len(where)
+        N2 = 2 * nb
+        jj, ii = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing='ij')
+        ids = np.empty(N2, dtype=np.int32); org = np.empty((N2, 2), dtype=np.int32)
+        mxa = np.empty((N2, h, w), dtype=np.float32); mya = np.empty((N2, h, w), dtype=np.float32); mka = np.ones((N2, h, w), dtype=np.uint8)
+        for e, (q, b, k, rec) in enumerate(where):
+            # first half of the stack: image-0 windows, integer crop at blk's (x0, y0); second half: image-1 windows
+            # through the exact map, relative to the pair's remap origin
+            ids[e] = int(sel[q]); org[e] = (int(blk[q, b, 1]), int(blk[q, b, 2])); mxa[e] = ii; mya[e] = jj
+            ids[nb + e] = n + int(sel[q]); org[nb + e] = (int(aff[q, b, 8]), int(aff[q, b, 9]))
+            mxa[nb + e] = rec[2][k] - aff[q, b, 8]; mya[nb + e] = rec[3][k] - aff[q, b, 9]; mka[nb + e] = rec[4][k]
+        px = h * w
+        bufs = {k: self._scratch(k, sz) for k, sz in (('ids', 4 * N2), ('org', 8 * N2), ('mx', 4 * N2 * px), ('my', 4 * N2 * px),
+                                                      ('mk', N2 * px), ('st', 4 * N2 * px), ('res', 20 * nb))}
+        for k, a_ in (('ids', ids), ('org', org), ('mx', mxa), ('my', mya), ('mk', mka)):
+            _lib.check(lib.fb_memcpy_h2d(ctx, bufs[k].ptr, _lib.ptr(a_), a_.nbytes))
+        _lib.check(lib.fb_remap_dev(ctx, dogf.ptr, H, W, N2, bufs['ids'].ptr, h, w, bufs['mx'].ptr, bufs['my'].ptr, bufs['mk'].ptr,
+                                    bufs['org'].ptr, bufs['st'].ptr))
+        r = bufs['res']
+        _lib.check(lib.fb_ncc_batch_dev(ctx, bufs['st'].ptr, bufs['st'].offset(4 * nb * px), nb, 1, h, w, h, w, 1 if pad else 0,
+                                        1 if subpixel else 0, self.conf_mode, r.ptr, r.offset(8 * nb), r.offset(16 * nb)))
+        raw = r.to_array((20 * nb,), np.uint8)
+        ex_dx, ex_dy, ex_cf = raw[:8 * nb].view(np.float64), raw[8 * nb:16 * nb].view(np.float64), raw[16 * nb:].view(np.float32)
+        for e, (q, b, _, _) in enumerate(where):
+            ddx[q, b], ddy[q, b], dcf[q, b] = ex_dx[e], ex_dy[e], ex_cf[e]
+
+    def _relax_general(self, pid, xy0_mov, nodes3, B1, conf, resolve):
+        """matcher.py:725-741 for matches given by their mesh1 triangle (nodes3: vertex ids inside the union mesh) and
+        barycentric coordinates: optimize_linear as the TOTAL displacement of mesh1 from its FIXED gear
+        (fb_pairs_relax_bary), relax_higly_deformed + huber residue weights, and -- `resolve`, the rounds before the last --
+        a second solve for the pairs whose weights changed (matcher.py:737-741).
+        Returns rw [K] and the node displacement x [P, V, 2] (rows of pairs without matches are zero)."""
+        lib, ctx = _lib.load(), _lib.ctx()
+        sysh = self._relax_system()
+        m = self._mesh
+        V, K = m.num_vertices, pid.size
+        nodes3 = np.ascontiguousarray(nodes3, dtype=np.int32)
+        B1 = np.ascontiguousarray(B1, dtype=np.float64)
+        xy0c = np.ascontiguousarray(xy0_mov, dtype=np.float64)
+        xy1_fixed = np.sum(self._v_init_u[nodes3] * B1[:, :, None], axis=1)      # mesh1 at its FIXED gear (= INITIAL, no offset)
+        dxy0 = np.ascontiguousarray(xy1_fixed - xy0c)
+        area = float(np.abs(m.triangle_areas(const.MESH_GEAR_INITIAL)[0]))
+        sample_err = 0.4387 * area ** 0.5 * DEFAULT_AVG_DEFORM
+        tid_local = (self._tri_of_nodes(nodes3 - (np.asarray(pid)[:, None] * V))).astype(np.int32)
+        pid32 = np.ascontiguousarray(pid, dtype=np.int32)
+        zero_t = np.zeros((self.P, 2))
+
+        def solve(w32):
+            rw = np.empty(K, dtype=np.float32)
+            x = np.empty(2 * self.P * V, dtype=np.float64)
+            iters, relres = C.c_int(), C.c_double()
+            _lib.check(lib.fb_pairs_relax_bary(ctx, sysh, self.P, K, _lib.ptr(nodes3), _lib.ptr(B1), _lib.ptr(dxy0), _lib.ptr(w32),
+                                               self.residue_len if self.residue_len > 0 else 1.0, sample_err, self.stiffness_lambda,
+                                               self.relax_tol, _lib.ptr(rw), _lib.ptr(x), C.byref(iters), C.byref(relres)))
+            self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K), relaxed_first=0)
+            return rw, x.reshape(self.P, V, 2)
+
+        w32 = np.ascontiguousarray(conf, dtype=np.float32)
+        rw, x = solve(w32)
+        self._links_rows = None
+        if self.residue_len <= 0:
+            return np.ones(K, dtype=np.float32), x
+        self._relax_first(x, pid32, xy0c, None, zero_t, rw, sample_err, tid_B=(tid_local, B1))
+        if resolve and np.any(rw != 1):
+            changed = np.unique(pid32[rw != 1])
+            _, x2 = solve(np.ascontiguousarray(w32 * rw))
+            x[changed] = x2[changed]
+        return rw, x
+
+    def _tri_of_nodes(self, local3):
+        """triangle id of a vertex triple given in the order of Mesh.triangles"""
+        if not hasattr(self, '_tri_lut'):
+            t = self._mesh.triangles.astype(np.int64)
+            V = self._mesh.num_vertices
+            self._tri_lut = {int(k): i for i, k in enumerate((t[:, 0] * V + t[:, 1]) * V + t[:, 2])}
+        V = self._mesh.num_vertices
+        l3 = np.asarray(local3, dtype=np.int64)
+        keys = (l3[:, 0] * V + l3[:, 1]) * V + l3[:, 2]
+        return np.array([self._tri_lut[int(k)] for k in keys], dtype=np.int64)
 
     # ------------------------------------------------------------------ last-round relaxation
     def _relax_system(self):
@@ -275,7 +463,7 @@ class StripBatchMatcher:
         self._relax_first(x, pid32, xy0c, xy1i, t1c, rw, sample_err)
         return rw, x
 
-    def _relax_first(self, x, pid, xy0, xy1i, t1, rw, sample_err):
+    def _relax_first(self, x, pid, xy0, xy1i, t1, rw, sample_err, tid_B=None):
         """adjust_link_weight_by_residue(relax_first=True) (matcher.py:736 -> optimizer.py:763-779): before the residues
         are taken, a region of mesh1 that the relaxation deformed beyond the cutoff is relaxed on its own
         (relax_mesh_most_deformed).  Screen: with d = the largest displacement difference along a grid edge relative to
@@ -306,9 +494,12 @@ class StripBatchMatcher:
             if not relax_mesh_most_deformed(m1, gear=gear, deform_cutoff=cutoff):
                 continue
             self.last_relax['relaxed_first'] += 1
-            pts = xy1i[rows]
-            tid = m1.locate_cartesian(pts)
-            _, B = m1.cart2bary(pts, const.MESH_GEAR_INITIAL, tid=tid)
+            if tid_B is None:
+                pts = xy1i[rows]
+                tid = m1.locate_cartesian(pts)
+                _, B = m1.cart2bary(pts, const.MESH_GEAR_INITIAL, tid=tid)
+            else:
+                tid, B = tid_B[0][rows], tid_B[1][rows]
             dxy = m1.bary2cart(tid, B, const.MESH_GEAR_MOVING, offsetting=True) - xy0[rows]
             dis = np.sum(dxy ** 2, axis=-1) ** 0.5
             dis = ((dis ** 2 - sample_err ** 2).clip(0, None)) ** 0.5                # optimizer.py:183-185
@@ -408,10 +599,27 @@ class StripBatchMatcher:
         return strain
 
     # ------------------------------------------------------------------ driver
+    def _rows_bary(self, pid, xy1_init, nodes3, B1):
+        """mesh1 triangle (vertex ids inside the union mesh) and barycentric coordinates of every row; rows of pairs whose
+        mesh1 is still a translated grid (nodes3 < 0) are located on the grid (cart2bary, mesh.py:2191-2217)."""
+        self._relax_system()
+        m = self._mesh
+        V = m.num_vertices
+        nodes3 = np.array(nodes3, dtype=np.int64); B1 = np.array(B1, dtype=np.float64)
+        g = np.flatnonzero(nodes3[:, 0] < 0)
+        if g.size:
+            tid = m.locate_cartesian(xy1_init[g])
+            _, Bg = m.cart2bary(xy1_init[g], const.MESH_GEAR_INITIAL, tid=tid)
+            nodes3[g] = m.triangles[tid] + (np.asarray(pid)[g] * V)[:, None]
+            B1[g] = Bg
+        return nodes3, B1
+
     def match(self, strips0, strips1):
         """strips0/strips1: device pointers to uint8 [P][H][W].  Returns a dict of arrays:
-        tx, ty, conf0, valid, needs_host [P]; the match table as flat arrays pair, xy0, xy1, weight
-        (rows of one pair are contiguous, pairs in ascending order within a block-grid group)."""
+        tx, ty, conf0, valid, needs_host, deformed [P]; the match table as flat arrays pair, xy0, xy1, weight
+        (rows of one pair are contiguous, pairs in ascending order within a block-grid group).  `needs_host` is kept
+        for callers of earlier versions and is always False: pairs whose mesh relaxation between spacings is not a rigid
+        translation are `deformed` and stay on the device path."""
         n = self.P
         tx, ty, cf0 = self._global(strips0, strips1)
         scale = 1.0 / self.cds
@@ -420,31 +628,60 @@ class StripBatchMatcher:
         self._fine_dog(strips0, strips1)
         spacings = self.spacings
         pad = np.ones(n, dtype=bool)
-        needs_host = np.zeros(n, dtype=bool)
         has_last = np.zeros(n, dtype=bool)
         table = None
         last_links = None
         txy = np.stack((tx, ty), axis=-1)
         t1 = np.zeros((n, 2))                                # translation of mesh1 acquired by rigid relaxations
+        U = None                                             # [n, V, 2] node displacement of a deformed mesh1 (MOVING - INITIAL)
+        is_deformed = np.zeros(n, dtype=bool)
+        self.last_tiers = {}
         live = active.copy()                                 # pairs still iterating over the spacings
         for rnd in range(spacings.size):
             sp = spacings[rnd]
             is_last = rnd == spacings.size - 1
             mnb = self.mnb if is_last else 1
             rows = []
-            for sel, bb, ddx, ddy, dcf in self._match_round(tx, ty, t1, live, sp, mnb, pad, subpixel=is_last):
+            to_relax = np.zeros(n, dtype=bool)               # pairs whose relaxation of this round is not a rigid translation
+            groups = [(g, False) for g in self._match_round(tx, ty, t1, live & ~is_deformed, sp, mnb, pad, subpixel=is_last)]
+            dp = np.flatnonzero(live & is_deformed)
+            if dp.size:
+                groups += [(g, True) for g in self._match_round_deformed(tx, ty, U, dp, sp, mnb, pad, is_last, is_last)]
+                m = self._mesh
+                v_init = m.vertices(const.MESH_GEAR_INITIAL); V = m.num_vertices
+            for (sel, bb, ddx, ddy, dcf), is_def in groups:
                 keep = dcf > self.conf_thresh                # matcher.py:671-683
                 anyk = keep.any(axis=1)
-                if rnd == 0:
-                    active[sel[~anyk]] = False               # invalid_output (matcher.py:672-673)
-                live[sel[~anyk]] = False                     # ... or break with the links so far (674-675)
                 ctr = 0.5 * np.stack((bb[..., 0] + bb[..., 2], bb[..., 1] + bb[..., 3]), axis=-1) - 0.5      # bbox_centers
                 dxy = np.stack((ddx, ddy), axis=-1)
                 xy0 = ctr - dxy * 0.5                        # equal block sizes: ratio 0.5 (matcher.py:844-849)
                 xy1 = ctr + dxy * 0.5
-                xy1_init = xy1 - t1[sel][:, None, :]         # INITIAL gear of mesh1 at link creation (matcher.py:748-751)
                 dis2 = np.where(keep, np.sum((xy0 - xy1) ** 2, axis=-1), -1.0)
                 max_dis = np.sqrt(np.maximum(dis2.max(axis=1), 0.0))
+                nodes3 = np.full(keep.shape + (3,), -1, dtype=np.int64)
+                B1 = np.full(keep.shape + (3,), np.nan)
+                if is_def:
+                    # Link.from_coordinates on the MOVING gear of the deformed mesh1 (matcher.py:717, optimizer.py:51-82):
+                    # points outside the mesh are dropped; the INITIAL coordinates follow from the barycentric ones
+                    xy1_init = np.zeros_like(xy1)
+                    for q, p in enumerate(sel):
+                        k = np.flatnonzero(keep[q])
+                        if k.size == 0:
+                            continue
+                        tid, Bq = dfm.locate(v_init + U[p], m.triangles, m.grid_xs, m.grid_ys, xy1[q, k])
+                        inside = tid >= 0
+                        keep[q, k[~inside]] = False
+                        k, tid, Bq = k[inside], tid[inside], Bq[inside]
+                        nodes3[q, k] = m.triangles[tid] + p * V
+                        B1[q, k] = Bq
+                        xy1_init[q, k] = np.sum(v_init[m.triangles[tid]] * Bq[:, :, None], axis=1)
+                    has_link = keep.any(axis=1)
+                else:
+                    xy1_init = xy1 - t1[sel][:, None, :]     # INITIAL gear of mesh1 at link creation (matcher.py:748-751)
+                    has_link = anyk
+                if rnd == 0:
+                    active[sel[~has_link]] = False           # invalid_output (matcher.py:672-673, 719-721)
+                live[sel[~has_link]] = False                 # ... or break with the links so far (674-675, 722-723)
                 if not is_last:
                     # spacing schedule (matcher.py:689-716), max_spacing_skip = 0
                     next_pos = np.searchsorted(-spacings, -4 * max_dis) - 1
@@ -453,35 +690,53 @@ class StripBatchMatcher:
                     # kept block reports the same displacement the exact minimiser is the rigid translation
                     # u = xy0 - xy1 of mesh1 (zero elastic and zero link energy; checked against the FEM oracle in
                     # tests/test_gpu_pipeline.py); residues vanish, so the huber re-weighting changes nothing.
-                    # Any other field needs the deformed-mesh crop: flagged.
-                    move = anyk & (max_dis > 0.1)
-                    if move.any():
+                    # Any other field is solved on the device below and makes the pair `deformed`.
+                    move = has_link & (max_dis > 0.1)
+                    if is_def:
+                        to_relax[sel[move]] = True
+                    elif move.any():
                         u = xy0 - xy1                                          # [Q, nblk, 2]
                         first = np.argmax(keep, axis=1)
                         u0 = u[np.arange(sel.size), first]                     # displacement of the first kept block
                         uniform = np.all(~keep[..., None] | (u == u0[:, None, :]), axis=(1, 2))
                         rigid = move & uniform
                         t1[sel[rigid]] += u0[rigid]
-                        needs_host[sel[move & ~uniform]] = True
+                        to_relax[sel[move & ~uniform]] = True
                 pid = np.broadcast_to(sel[:, None], keep.shape)
                 relax = np.broadcast_to((max_dis > 0.1)[:, None], keep.shape)
-                rows.append((pid[keep], xy0[keep], xy1_init[keep], dcf[keep], xy1[keep], relax[keep]))
-                has_last[sel[anyk]] = True
+                rows.append((pid[keep], xy0[keep], xy1_init[keep], dcf[keep], xy1[keep], relax[keep], nodes3[keep], B1[keep]))
+                has_last[sel[has_link]] = True
             if rows:
                 prev = table
-                table = tuple(np.concatenate([r[k] for r in rows], axis=0) for k in range(6))
+                table = tuple(np.concatenate([r[k] for r in rows], axis=0) for k in range(8))
                 last_links = None
-                if is_last and self.residue_len > 0:
+                pid_l, xy0_l, xy1i_l, wt_l, xy1_l, rl, nd_l, B1_l = table
+                if to_relax.any():
+                    # non-rigid relaxation between spacings (matcher.py:725-741): mesh1 of these pairs keeps the field
+                    r = to_relax[pid_l]
+                    nd_r, B1_r = self._rows_bary(pid_l[r], xy1i_l[r], nd_l[r], B1_l[r])
+                    rw, x = self._relax_general(pid_l[r], xy0_l[r], nd_r, B1_r, wt_l[r], resolve=True)
+                    if U is None:
+                        U = np.zeros((n,) + x.shape[1:])
+                    pr = np.flatnonzero(to_relax)
+                    U[pr] = x[pr]
+                    is_deformed[pr] = True
+                    wt_new = wt_l.copy()
+                    wt_new[r] = wt_l[r] * rw                                      # Link.weight (optimizer.py:313-317)
+                    table = table[:3] + (wt_new,) + table[4:]
+                if is_last and self.residue_len > 0 and rl.any():
                     # last round (matcher.py:725-737): relaxation + huber residue weights, pairs with max_dis > 0.1.  All rows
                     # of the round enter the block-diagonal system (a pair that needs no relaxation is solved and ignored), so
                     # that the strain estimate below can reuse the same links
-                    pid_l, xy0_l, xy1i_l, wt_l, xy1_l, rl = table
-                    if rl.any():
+                    if is_deformed.any():
+                        nd_a, B1_a = self._rows_bary(pid_l, xy1i_l, nd_l, B1_l)
+                        rw, _ = self._relax_general(pid_l, xy0_l, nd_a, B1_a, wt_l, resolve=False)
+                    else:
                         rw, _ = self._final_relax(pid_l, xy0_l, xy1_l, wt_l, t1)
                         last_links = True
-                        wt_new = wt_l.copy()
-                        wt_new[rl] = wt_l[rl] * rw[rl]                             # Link.weight (optimizer.py:313-317)
-                        table = table[:3] + (wt_new,) + table[4:]
+                    wt_new = wt_l.copy()
+                    wt_new[rl] = wt_l[rl] * rw[rl]                             # Link.weight (optimizer.py:313-317)
+                    table = table[:3] + (wt_new,) + table[4:]
                 table = table[:4]
                 if prev is not None and prev[0].size:
                     # a pair without a confident block in this round keeps the links of its last good round
@@ -501,7 +756,9 @@ class StripBatchMatcher:
         # output in the INITIAL gear: mesh0 points lose the translation (matcher.py:748-751)
         xy0 = xy0 - txy[pid]
         strain = self._strain(pid, xy0, xy1, wt, txy, reuse_links=bool(last_links)) if self.compute_strain else np.full(n, DEFAULT_AVG_DEFORM)
-        return dict(tx=tx, ty=ty, conf0=cf0, valid=valid, needs_host=needs_host, pair=pid, xy0=xy0, xy1=xy1, weight=wt, strain=strain)
+        self.last_field = U
+        return dict(tx=tx, ty=ty, conf0=cf0, valid=valid, needs_host=np.zeros(n, dtype=bool), deformed=is_deformed, pair=pid, xy0=xy0, xy1=xy1,
+                    weight=wt, strain=strain)
 
     @staticmethod
     def per_pair(res):
@@ -510,9 +767,9 @@ class StripBatchMatcher:
         for p in range(res['tx'].size):
             m = res['pair'] == p
             if res['valid'][p]:
-                out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=bool(res['needs_host'][p]),
+                out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=False, deformed=bool(res['deformed'][p]),
                                 xy0=res['xy0'][m], xy1=res['xy1'][m], weight=res['weight'][m], strain=float(res['strain'][p])))
             else:
-                out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=False,
+                out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=False, deformed=False,
                                 xy0=None, xy1=None, weight=None, strain=DEFAULT_AVG_DEFORM))
         return out

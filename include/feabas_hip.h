@@ -134,6 +134,13 @@ int fb_dog_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, dou
 /* cv2.resize(fx=fy=0.5, INTER_AREA) of even-sized uint8 images (matcher.py:255-256) */
 int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out);
 int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out);
+/* common.remap = cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) (common.py:218-255, called at 329-330) of resident float32
+ * images through explicit per-pixel maps: the exact piecewise-linear tier of MeshRenderer.crop_multiple
+ * (renderer.py:511-563).  All pointers are device pointers.  imgs [P][IH][IW]; img_id [N]; map_x, map_y float32
+ * [N][h][w] relative to origin [N][2] = the integer (xmin, ymin) of the sub-image of render_by_subregions
+ * (common.py:316-321); mask uint8 [N][h][w] (nullable; 0 = fill value 0); out float32 [N][h][w]. */
+int fb_remap_dev(fb_ctx* ctx, const float* imgs, int IH, int IW, int N, const int* img_id, int h, int w, const float* map_x,
+                 const float* map_y, const uint8_t* mask, const int* origin, float* out);
 
 /* Synthetic overlap strips for benchmarks (not a reference function): pair p gets an integer
  * offset (sx, sy), multiples of shift_step in [-max_shift, max_shift]^2, derived from (seed, pair0 + p); strips0/strips1 are
@@ -211,6 +218,14 @@ int fb_sys_group_energy(fb_ctx* ctx, fb_system* sys, int ngroups, const double* 
 int fb_pairs_relax(fb_ctx* ctx, fb_system* sys, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
                    const double* xy0_moving, const double* xy1_initial, const double* t1, const float* conf, double residue_len,
                    double sample_err, double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres);
+/* fb_pairs_relax for matches located in a DEFORMED mesh1 (a pair whose earlier relaxation was not a rigid translation;
+ * Link.from_coordinates on the MOVING gear, optimizer.py:51-82 -> mesh.py:2191-2217): nodes3 [K][3] = the mesh1 vertices
+ * of every match (ids inside the union mesh), B1 [K][3] its barycentric coordinates, dxy0 [K][2] = the link residual
+ * with mesh1 at its FIXED gear.  x_out = TOTAL displacement from the FIXED gear (the stress term of
+ * optimizer.py:1417-1418 is inside the system). */
+int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* sys, int P, int64_t K, const int32_t* nodes3, const double* B1, const double* dxy0,
+                        const float* conf, double residue_len, double sample_err, double stiffness_lambda, double rtol, float* rw,
+                        double* x_out, int* iters, double* relres);
 int fb_pairs_strain(fb_ctx* ctx, fb_system* sys, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
                     const double* xy0_fixed, const double* xy1_initial, const float* weight, const double* R, double stiffness_lambda,
                     double es0, int links_loaded, double default_strain, double* strain, int* iters, double* relres);

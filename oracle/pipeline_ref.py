@@ -1,12 +1,15 @@
 """Oracle of the per-tile-pair matcher (NCC side of matcher.stitching_matcher,
-feabas/matcher.py:224-367 + 430-751) for pairs whose block rounds never move a
-block by a non-uniform amount before the last round -- the branch in which every
-mesh relaxation between rounds (matcher.py:725) is a rigid integer translation and every crop of
-MeshRenderer.crop_multiple is an integer translation of the DoG'd strip.  The last round's relaxation and
-huber residue weights (matcher.py:725-737) are solved exactly on the cartesian mesh pair.
-TEST INFRASTRUCTURE (see oracle/__init__.py).  cv2 / triangle / shapely are not
-needed on this branch; the x0.5 INTER_AREA downsample is the unpinned
-restatement ncc_ref.area_downsample2.
+feabas/matcher.py:224-367 + 430-751).  Two branches:
+ * rigid: every mesh relaxation between rounds (matcher.py:725) is a rigid integer translation and every crop of
+   MeshRenderer.crop_multiple is an integer translation of the DoG'd strip;
+ * deformed: any other relaxation.  mesh1 keeps its relaxed MOVING gear, the next round's blocks come from the deformed
+   bounding box, image-1 patches are rendered through the mesh with the renderer's three tiers (global affine,
+   per-block affine, exact piecewise-linear field; renderer.py:47-166, 397-563, 601-648) and cv2.remap's bilinear rule
+   (UNPINNED restatement, ncc_ref.remap_bilinear_cv), links are located in the deformed mesh (mesh.py:2080-2217).
+Every relaxation is solved exactly on the cartesian mesh pair (the reference iterates to tol 0.01 / max(1, max_dis)).
+TEST INFRASTRUCTURE (see oracle/__init__.py).  cv2 / triangle / shapely are absent: the x0.5 INTER_AREA downsample is
+the unpinned restatement ncc_ref.area_downsample2, shapely's triangle / box `intersects` is a separating-axis test,
+matplotlib.tri (present) provides the trifinder and the linear interpolator like the reference.
 """
 import numpy as np
 
@@ -128,6 +131,143 @@ def _crop(img, x0, y0, h, w):
     return out
 
 
+# ------------------------------------------------------------------ deformed mesh1: renderer tiers + link location
+def tri_box_intersects(tp, box):
+    """shapely `intersects` of closed triangles tp [T, 3, 2] with the closed box (xmin, ymin, xmax, ymax) -- what
+    STRtree.query(box, predicate='intersects') answers at renderer.py:405.  Separating axes: the two box axes and the
+    three edge normals; touching counts as intersecting."""
+    tp = np.asarray(tp, dtype=np.float64)
+    x0, y0, x1, y1 = (float(b) for b in box)
+    sep = (tp[:, :, 0].max(axis=1) < x0) | (tp[:, :, 0].min(axis=1) > x1) | (tp[:, :, 1].max(axis=1) < y0) | (tp[:, :, 1].min(axis=1) > y1)
+    corners = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]])
+    for k in range(3):
+        e = tp[:, (k + 1) % 3] - tp[:, k]
+        nrm = np.stack((-e[:, 1], e[:, 0]), axis=-1)
+        pt = np.einsum('tvj,tj->tv', tp, nrm)
+        pb = corners @ nrm.T                                    # [4, T]
+        sep |= (pt.max(axis=1) < pb.min(axis=0)) | (pt.min(axis=1) > pb.max(axis=0))
+    return ~sep
+
+
+def _mpl_triangulation(m1):
+    import matplotlib.tri
+    v0 = m1.vertices(fem_ref.GEAR_MOVING)
+    return matplotlib.tri.Triangulation(v0[:, 0], v0[:, 1], triangles=m1.triangles)
+
+
+def locate_deformed(m1, xy):
+    """Mesh.tri_finder (mesh.py:2080-2143) for one contiguous region without collisions: matplotlib's trifinder on the
+    MOVING vertices (offset removed from the points); -1 outside the mesh."""
+    pts = np.atleast_2d(xy) - m1.offset(fem_ref.GEAR_MOVING)
+    return np.asarray(_mpl_triangulation(m1).get_trifinder()(pts[:, 0], pts[:, 1]))
+
+
+def affine_residue(v1, v0, A):
+    return np.max(np.sum((v1 - v0 @ A[:2, :2] - A[-1, :2]) ** 2, axis=-1)) ** 0.5
+
+
+def render_blocks_mesh1(m1, img, bboxes, tol, return_tiers=False):
+    """MeshRenderer.from_mesh(mesh1, affine_approx_tol=tol) (renderer.py:47-166) + crop_multiple(bboxes, mode=RENDER_FULL,
+    log_sigma=0, remap_interp=INTER_LINEAR) (renderer.py:601-648) for a mesh of one region without collisions over a
+    StreamLoader of `img` (fillval 0).  Per block (crop_field, renderer.py:453-563): the global affine when its residue
+    is below tol, else the affine fitted to the vertices of the triangles that touch the block when that is below tol,
+    else the exact piecewise-linear field (masked outside the mesh).  All fields are rendered as ONE map
+    (render_by_subregions, common.py:257-350: one remap origin for the whole stack)."""
+    import matplotlib.tri
+    off = m1.offset(fem_ref.GEAR_MOVING).ravel()
+    v0 = m1.vertices(fem_ref.GEAR_MOVING)
+    v1 = m1.vertices_w_offset(fem_ref.GEAR_INITIAL)
+    A_g = fem_ref.fit_affine(v1, v0)
+    res_g = affine_residue(v1, v0, A_g)
+    tri = None
+    fx, fy, msk, tiers = [], [], [], []
+    for bbox in np.asarray(bboxes):
+        bbox0 = np.asarray(bbox, dtype=np.float64) - np.tile(off, 2)
+        outwd = round(bbox0[2] - bbox0[0]); outht = round(bbox0[3] - bbox0[1])
+        xs = np.linspace(bbox0[0], bbox0[2], num=outwd, endpoint=False, dtype=float)
+        ys = np.linspace(bbox0[1], bbox0[3], num=outht, endpoint=False, dtype=float)
+        xx, yy = np.meshgrid(xs, ys)
+        A = None
+        if tol > 0:
+            if res_g < tol:
+                A, tier = A_g, 1
+            else:
+                hit = tri_box_intersects(v0[m1.triangles], bbox0 - 0.5)
+                if hit.any():
+                    idx = np.unique(m1.triangles[hit])
+                    _, A_b = fem_ref.fit_affine(v1[idx], v0[idx], return_rigid=True, svd_clip=None)
+                    if affine_residue(v1[idx], v0[idx], A_b) < tol:
+                        A, tier = A_b, 2
+        if A is not None:
+            x_f = xx * A[0, 0] + yy * A[1, 0] + A[2, 0]
+            y_f = xx * A[0, 1] + yy * A[1, 1] + A[2, 1]
+            mk = np.ones_like(x_f, dtype=bool)
+        else:
+            tier = 3
+            if tri is None:
+                tri = _mpl_triangulation(m1)
+                ix = matplotlib.tri.LinearTriInterpolator(tri, v1[:, 0])
+                iy = matplotlib.tri.LinearTriInterpolator(tri, v1[:, 1])
+            mx, my = ix(xx, yy), iy(xx, yy)
+            bad = np.ma.getmaskarray(mx) | np.ma.getmaskarray(my)
+            x_f = np.nan_to_num(np.ma.getdata(mx)); y_f = np.nan_to_num(np.ma.getdata(my))
+            mk = ~bad
+        fx.append(x_f); fy.append(y_f); msk.append(mk); tiers.append(tier)
+    map_x = np.concatenate(fx, axis=0); map_y = np.concatenate(fy, axis=0); mask = np.concatenate(msk, axis=0)
+    out = np.zeros(map_x.shape, dtype=np.float32)
+    if mask.any():
+        xmin = np.floor(map_x[mask].min()) - 4; ymin = np.floor(map_y[mask].min()) - 4
+        val = remap_origin(img, map_x, map_y, (int(xmin), int(ymin)))
+        out[mask] = val[mask]
+    out = out.reshape(len(fx), -1, map_x.shape[1])
+    return (out, np.array(tiers)) if return_tiers else out
+
+
+def remap_origin(img, map_x, map_y, origin):
+    """common.remap on the sub-image img_loader.crop((xmin, ymin, xmax, ymax)) (zero outside the strip) with maps made
+    relative to its integer origin in float32 (common.py:329-330): ncc_ref.remap_bilinear_cv on the zero-extended image."""
+    mxt = (map_x - origin[0]).astype(np.float32); myt = (map_y - origin[1]).astype(np.float32)
+    H, W = img.shape
+    sx = np.rint(mxt * np.float32(32)).astype(np.int64); sy = np.rint(myt * np.float32(32)).astype(np.int64)
+    ix = (sx >> 5) + int(origin[0]); iy = (sy >> 5) + int(origin[1])
+    ax = (sx & 31).astype(np.float32) * np.float32(1 / 32); ay = (sy & 31).astype(np.float32) * np.float32(1 / 32)
+    one = np.float32(1)
+    w00 = (one - ay) * (one - ax); w01 = (one - ay) * ax; w10 = ay * (one - ax); w11 = ay * ax
+    img = np.asarray(img, dtype=np.float32)
+
+    def tap(yy_, xx_):
+        inside = (yy_ >= 0) & (yy_ < H) & (xx_ >= 0) & (xx_ < W)
+        return np.where(inside, img[np.clip(yy_, 0, H - 1), np.clip(xx_, 0, W - 1)], np.float32(0))
+    return ((tap(iy, ix) * w00 + tap(iy, ix + 1) * w01) + tap(iy + 1, ix) * w10) + tap(iy + 1, ix + 1) * w11
+
+
+def relax_deformed(m0, m1, xs, ys, xy0, xy1, weight, residue_len, resolve):
+    """matcher.py:717-742 on a mesh pair that keeps its state: link from the matched points in the MOVING gears (mesh0 is
+    the translated grid, mesh1 is located through its deformed triangles; points outside are dropped, optimizer.py:
+    51-82), optimize_linear (exact), then -- residue_len > 0 -- relax_higly_deformed + huber residue weights
+    (optimizer.py:763-790) and, when a weight changed and `resolve`, a second solve (matcher.py:737-741).
+    Returns (link, kept rows)."""
+    tid1 = locate_deformed(m1, xy1)
+    ok = tid1 >= 0
+    xy0, xy1, weight, tid1 = xy0[ok], xy1[ok], weight[ok], tid1[ok]
+    if not ok.any():
+        return None, ok
+    tid0 = locate_cartesian(xs, ys, xy0 - m0.offset(fem_ref.GEAR_MOVING))
+    B0 = m0.cart2bary(xy0, fem_ref.GEAR_MOVING, tid0)
+    B1 = m1.cart2bary(xy1, fem_ref.GEAR_MOVING, tid1)
+    link = fem_ref.RefLink(m0, m1, tid0, tid1, B0, B1, weight=weight)
+    fem_ref.optimize_linear([m0, m1], [link], exact=True)
+    if residue_len > 0:
+        cutoff = 1 - 1 / (MAXIMUM_DEFORM_ALLOWED + 1)
+        fem_ref.relax_mesh_most_deformed(m1, gear=(fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING), deform_cutoff=cutoff)
+        rw = link.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), 'huber', residue_len)
+        if np.any(rw != link.residue_weight):
+            link.residue_weight = rw
+            if resolve:
+                fem_ref.optimize_linear([m0, m1], [link], exact=True)
+    return link, ok
+
+
 def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
                conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0):
     """strip0/strip1: uint8 H x W overlap strips.  Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host)."""
@@ -156,15 +296,30 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
     itx, ity = int(round(tx)), int(round(ty))
     t1 = np.zeros(2)                                                         # rigid motion mesh1 acquired so far
     last = None
+    deformed = None                                                          # (m0, m1, xs, ys) once mesh1 is not a translated grid
+    mesh_size = float(np.min(spacings))
     for rnd, sp in enumerate(spacings):
-        bbox1 = (-0.5 + t1[0], -0.5 + t1[1], W - 0.5 + t1[0], H - 0.5 + t1[1])
-        i1x, i1y = int(round(t1[0])), int(round(t1[1]))
         is_last = rnd == spacings.size - 1
         mnb = min_num_blocks if is_last else 1
+        if deformed is None:
+            bbox1 = (-0.5 + t1[0], -0.5 + t1[1], W - 0.5 + t1[0], H - 0.5 + t1[1])
+        else:
+            vm = deformed[1].vertices_w_offset(fem_ref.GEAR_MOVING)          # Mesh.bbox(gear=MOVING), matcher.py:877
+            bbox1 = (vm[:, 0].min(), vm[:, 1].min(), vm[:, 0].max(), vm[:, 1].max())
+        i1x, i1y = int(round(t1[0])), int(round(t1[1]))
         bb0, bb1 = ncc_ref.distributor_cartesian_bbox(bbox0, bbox1, sp, min_num_blocks=mnb, zorder=True)
+        if bb0 is None:
+            if rnd == 0:
+                return res
+            break
         h = int(bb0[0, 3] - bb0[0, 1]); w = int(bb0[0, 2] - bb0[0, 0])
         s0 = np.stack([_crop(f0, int(b[0]) - itx, int(b[1]) - ity, h, w) for b in bb0])
-        s1 = np.stack([_crop(f1, int(b[0]) - i1x, int(b[1]) - i1y, h, w) for b in bb1])
+        if deformed is None:
+            s1 = np.stack([_crop(f1, int(b[0]) - i1x, int(b[1]) - i1y, h, w) for b in bb1])
+        else:
+            tol = 0.1 if is_last else max(1, 0.02 * sp)                      # matcher.py:578-603 (affine_approximated_render)
+            s1, tiers = render_blocks_mesh1(deformed[1], f1, bb1, tol, return_tiers=True)
+            res.setdefault('tiers', []).append(tiers)
         dx, dy, cf = ncc_ref.xcorr_fft(s0, s1, conf_mode=conf_mode, pad=pad, subpixel=is_last)
         xy0, xy1 = ncc_ref.block_points(bb0, bb1, dx, dy)
         keep = cf > conf_thresh
@@ -174,23 +329,56 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
             break                                            # matcher.py:671-679: keep the links of the last good round
         xy0, xy1, wt = xy0[keep], xy1[keep], cf[keep]
         max_dis = np.max(np.sum((xy0 - xy1) ** 2, axis=-1)) ** 0.5
-        last = (xy0, xy1 - t1, wt, max_dis)                   # INITIAL gear: barycentric coordinates are fixed at link creation
-        if is_last and max_dis > 0.1 and residue_len > 0:
-            # matcher.py:725-737: relax, then Link.weight = conf * huber residue weight (no second solve: sp_indx ran out)
-            _, rw = relax_mesh1(W, H, float(np.min(spacings)), (tx, ty), t1, xy0, xy1, wt, residue_len=residue_len,
-                                min_num_blocks=min_num_blocks)
-            last = (xy0, xy1 - t1, wt * rw, max_dis)
         if not is_last:
             next_pos = np.searchsorted(-spacings, -4 * max_dis) - 1           # matcher.py:689-716
             pad = (min(next_pos, rnd + 1) > rnd + 1) if next_pos > rnd else True
+        if deformed is not None:
+            m0, m1, xs, ys = deformed
             if max_dis > 0.1:
-                # mesh relaxation (matcher.py:725-729), exact solve on the cartesian mesh pair
-                u = relax_mesh1(W, H, float(np.min(spacings)), (tx, ty), t1, xy0, xy1, wt, min_num_blocks=min_num_blocks)
-                um = u.mean(axis=0)
-                if np.abs(u - um).max() < 1e-6 and np.abs(um - np.round(um)).max() < 1e-6:
-                    t1 = t1 + np.round(um)                   # a rigid integer translation: crops stay exact
-                else:
-                    res['needs_host'] = True                 # deformed-mesh crop (cv2.remap), SURVEY.md sec.8f row 1
+                link, ok = relax_deformed(m0, m1, xs, ys, xy0, xy1, wt, residue_len, resolve=not is_last)
+            else:                                            # link only (matcher.py:717), no relaxation
+                tid1 = locate_deformed(m1, xy1)
+                ok = tid1 >= 0
+                link = None
+                if ok.any():
+                    tid0 = locate_cartesian(xs, ys, xy0[ok] - m0.offset(fem_ref.GEAR_MOVING))
+                    link = fem_ref.RefLink(m0, m1, tid0, tid1[ok], m0.cart2bary(xy0[ok], fem_ref.GEAR_MOVING, tid0),
+                                           m1.cart2bary(xy1[ok], fem_ref.GEAR_MOVING, tid1[ok]), weight=wt[ok])
+            if not is_last:                                  # the field the next round renders through
+                res['mesh1_field'] = m1.vertices_w_offset(fem_ref.GEAR_MOVING) - m1.vertices_w_offset(fem_ref.GEAR_INITIAL)
+            if link is None:                                 # matcher.py:719-723: no link could be made
+                if rnd == 0:
+                    return res
+                break
+            last = (m0.bary2cart(link.tid0, link.B0, fem_ref.GEAR_INITIAL) + np.array([tx, ty]),
+                    m1.bary2cart(link.tid1, link.B1, fem_ref.GEAR_INITIAL), link.total_weight(), max_dis)
+            continue
+        last = (xy0, xy1 - t1, wt, max_dis)                   # INITIAL gear: barycentric coordinates are fixed at link creation
+        if is_last and max_dis > 0.1 and residue_len > 0:
+            # matcher.py:725-737: relax, then Link.weight = conf * huber residue weight (no second solve: sp_indx ran out)
+            _, rw = relax_mesh1(W, H, mesh_size, (tx, ty), t1, xy0, xy1, wt, residue_len=residue_len,
+                                min_num_blocks=min_num_blocks)
+            last = (xy0, xy1 - t1, wt * rw, max_dis)
+        if not is_last and max_dis > 0.1:
+            # mesh relaxation (matcher.py:725-729), exact solve on the cartesian mesh pair
+            u, m0, m1, link = relax_mesh1(W, H, mesh_size, (tx, ty), t1, xy0, xy1, wt, min_num_blocks=min_num_blocks, return_mesh=True)
+            um = u.mean(axis=0)
+            if np.abs(u - um).max() < 1e-6 and np.abs(um - np.round(um)).max() < 1e-6:
+                t1 = t1 + np.round(um)                   # a rigid integer translation: crops stay exact
+            else:
+                # any other field: mesh1 keeps its MOVING gear.  Residue step of matcher.py:730-741 on that state
+                if residue_len > 0:
+                    cutoff = 1 - 1 / (MAXIMUM_DEFORM_ALLOWED + 1)
+                    fem_ref.relax_mesh_most_deformed(m1, gear=(fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING), deform_cutoff=cutoff)
+                    rw = link.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), 'huber', residue_len)
+                    if np.any(rw != link.residue_weight):
+                        link.residue_weight = rw
+                        fem_ref.optimize_linear([m0, m1], [link], exact=True)
+                        last = (xy0, xy1 - t1, link.total_weight(), max_dis)
+                _, _, xs, ys = cartesian_mesh(W, H, mesh_size, min_num_blocks=min_num_blocks)
+                deformed = (m0, m1, xs, ys)
+                res['deformed'] = True
+                res['mesh1_field'] = m1.vertices_w_offset(fem_ref.GEAR_MOVING) - m1.vertices_w_offset(fem_ref.GEAR_INITIAL)
     if last is not None:
         res['xy0'] = last[0] - np.array([tx, ty])
         res['xy1'] = last[1]

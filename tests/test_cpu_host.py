@@ -159,3 +159,95 @@ def test_g16_masked_field_and_measures():
     np.testing.assert_array_equal(m.vertices(gear[1])[vm], g['vmov'][vm] + d)
     np.testing.assert_array_equal(m.vertices(gear[1])[~vm], g['vmov'][~vm])
     np.testing.assert_array_equal(m.offset(gear[1]), g['moff'])
+
+
+def _kinked_mesh():
+    from oracle import pipeline_ref, fem_ref
+    W, H = 120, 1536
+    v, tri, xs, ys = pipeline_ref.cartesian_mesh(W, H, 40.0)
+    rng = np.random.default_rng(0)
+    U = np.stack((2.5 * np.sin(v[:, 1] / 300) + 0.8 * np.cos(v[:, 0] / 40), 1.5 * np.cos(v[:, 1] / 200)), -1)
+    k = rng.integers(0, v.shape[0], 6)
+    U[k] += rng.normal(0, 0.6, (6, 2))
+    m1 = fem_ref.RefMesh(v, tri, uid=1)
+    m1.set_field(U, gear=(fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING))
+    return W, H, v, tri, xs, ys, m1, rng
+
+
+def test_deformed_block_tiers_match_the_renderer_restatement():
+    """feabas_amd/deformed.py (batched numpy over the blocks of a pair) against the statement-by-statement oracle of
+    MeshRenderer.from_mesh / crop_field (renderer.py:90-109, 397-416, 499-511): tier of every block, the triangles that
+    touch it, and the affine maps"""
+    from feabas_amd import deformed
+    from oracle import pipeline_ref, fem_ref, ncc_ref
+    W, H, v, tri, xs, ys, m1, rng = _kinked_mesh()
+    vm = m1.vertices_w_offset(fem_ref.GEAR_MOVING)
+    bb0, bb1 = ncc_ref.distributor_cartesian_bbox((2.5, -2.5, W + 2.5, H - 2.5), (vm[:, 0].min(), vm[:, 1].min(), vm[:, 0].max(), vm[:, 1].max()),
+                                                  40.0, min_num_blocks=2)
+    img = rng.standard_normal((H, W)).astype(np.float32)
+    seen = set()
+    for tol in (0.1, 0.3, 1.0, 5.0):
+        _, tiers = pipeline_ref.render_blocks_mesh1(m1, img, bb1, tol, return_tiers=True)
+        tier, A, hits = deformed.block_affines(vm, v, tri, bb1, tol)
+        np.testing.assert_array_equal(tier, tiers)
+        seen |= set(tier.tolist())
+        off = m1.offset(fem_ref.GEAR_MOVING).ravel()
+        v0 = m1.vertices(fem_ref.GEAR_MOVING)
+        for b in np.flatnonzero(tier == 2)[:25]:
+            hit = pipeline_ref.tri_box_intersects(v0[tri], bb1[b] - np.tile(off, 2) - 0.5)
+            np.testing.assert_array_equal(hit, hits[b])
+            idx = np.unique(tri[hit])
+            _, Ab = fem_ref.fit_affine(v[idx], v0[idx], return_rigid=True, svd_clip=None)
+            pt = np.array([[bb1[b, 0], bb1[b, 1]], [bb1[b, 2], bb1[b, 3]]], dtype=float)
+            np.testing.assert_allclose(pt @ A[b, :2, :2] + A[b, 2, :2], (pt - off) @ Ab[:2, :2] + Ab[2, :2], atol=1e-9)
+    assert seen == {1, 2, 3}
+
+
+def test_deformed_exact_field_and_point_location_match_matplotlib():
+    """deformed.exact_field / deformed.locate against matplotlib.tri (what the reference uses: LinearTriInterpolator,
+    renderer.py:116-117; trifinder, mesh.py:2113)"""
+    import matplotlib.tri as mt
+    from feabas_amd import deformed
+    from oracle import fem_ref
+    W, H, v, tri, xs, ys, m1, rng = _kinked_mesh()
+    vm = m1.vertices_w_offset(fem_ref.GEAR_MOVING)
+    T = mt.Triangulation(vm[:, 0], vm[:, 1], tri)
+    ix, iy = mt.LinearTriInterpolator(T, v[:, 0]), mt.LinearTriInterpolator(T, v[:, 1])
+    for x0, y0, h, w in ((40, 200, 38, 40), (-6, -5, 50, 45), (90, 1500, 44, 40)):       # inside, corner, far corner
+        hit = deformed.tri_box_hits(vm[tri], np.array([[x0, y0, x0 + w, y0 + h]]) - 0.5)[0]
+        mx, my, mk = deformed.exact_field(vm, v, tri, np.flatnonzero(hit), x0, y0, h, w)
+        xx, yy = np.meshgrid(np.arange(x0, x0 + w, dtype=float), np.arange(y0, y0 + h, dtype=float))
+        ex, ey = ix(xx, yy), iy(xx, yy)
+        np.testing.assert_array_equal(mk, ~np.ma.getmaskarray(ex))
+        np.testing.assert_allclose(mx[mk], ex.filled(0)[mk], atol=1e-9); np.testing.assert_allclose(my[mk], ey.filled(0)[mk], atol=1e-9)
+    pts = np.stack((rng.uniform(vm[:, 0].min() - 2, vm[:, 0].max() + 2, 4000), rng.uniform(vm[:, 1].min() - 2, vm[:, 1].max() + 2, 4000)), -1)
+    tid, B = deformed.locate(vm, tri, xs, ys, pts)
+    np.testing.assert_array_equal(tid, T.get_trifinder()(pts[:, 0], pts[:, 1]))
+    ok = tid >= 0
+    assert 0 < (~ok).sum() < ok.sum()
+    np.testing.assert_allclose(np.sum(vm[tri[tid[ok]]] * B[ok][:, :, None], axis=1), pts[ok], atol=1e-9)
+
+
+def test_oracle_deformed_branch_recovers_a_smooth_warp():
+    """the oracle's deformed branch on a pair warped by a few pixels: matches in the INITIAL gear follow the injected
+    displacement (size-independent property: xy1 - xy0 = -(shift + warp) at the match)"""
+    from scipy.ndimage import gaussian_filter, map_coordinates
+    from oracle import pipeline_ref
+    H, W = 1536, 120
+    rng = np.random.default_rng(1)
+    pad = 64
+    tex = gaussian_filter(rng.standard_normal((H + 2 * pad, W + 2 * pad)), 1.6) + 1.8 * gaussian_filter(rng.standard_normal((H + 2 * pad, W + 2 * pad)), 5.0)
+    tex = 128 + 45 * tex / tex.std()
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    wx = 3.0 * np.sin(2 * np.pi * yy / H * 1.5 + 0.3) * np.cos(np.pi * xx / H)
+    wy = 3.0 * np.cos(2 * np.pi * xx / H * 1.2 + 0.7) * (0.5 + 0.5 * np.sin(2 * np.pi * yy / H))
+    s0 = np.clip(np.round(map_coordinates(tex, [yy + pad, xx + pad], order=1)), 0, 255).astype(np.uint8)
+    s1 = np.clip(np.round(map_coordinates(tex, [yy + pad - 3 + wy, xx + pad + 4 + wx], order=3)), 0, 255).astype(np.uint8)
+    r = pipeline_ref.match_pair(s0, s1, residue_len=2.0)
+    assert r['deformed'] and r['xy0'].shape[0] > 100
+    # strip1(q) = tex(q + s + w(q)) and strip0(p) = tex(p): a match has p = q + s + w(q)
+    q = r['xy1']
+    wq = np.stack((map_coordinates(wx, [q[:, 1], q[:, 0]], order=1), map_coordinates(wy, [q[:, 1], q[:, 0]], order=1)), -1)
+    err = (r['xy0'] - q) - (np.array([4.0, -3.0]) + wq)
+    assert np.abs(err).max() < 1.0 and np.percentile(np.abs(err), 90) < 0.4 and np.abs(np.median(err, axis=0)).max() < 0.15
+    assert np.ptp(r['mesh1_field'][:, 0]) > 2.0

@@ -291,3 +291,133 @@ def test_pipeline_readme_tile_shapes(fb, H, W):
     np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
     np.testing.assert_allclose(g['strain'], exp['strain'], rtol=2e-3, atol=1e-7)
     m.free()
+
+
+def _warped_pair(H, W, seed, shift=(4, -3), warp=3.0, noise=4.0):
+    """strip1(x, y) = texture(x + sx + wx, y + sy + wy) with a smooth warp of several pixels: the coarse blocks then
+    disagree and the relaxation between the spacings is not a rigid translation"""
+    from scipy.ndimage import gaussian_filter, map_coordinates
+    rng = np.random.default_rng(seed)
+    pad = 64
+    tex = gaussian_filter(rng.standard_normal((H + 2 * pad, W + 2 * pad)), 1.6)
+    tex += 1.8 * gaussian_filter(rng.standard_normal(tex.shape), 5.0)
+    tex = 128 + 45 * tex / tex.std()
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    L = max(H, W)
+    u, v = (yy, xx) if H >= W else (xx, yy)                   # u runs along the strip
+    wa = warp * np.sin(2 * np.pi * u / L * 1.5 + 0.3) * np.cos(np.pi * v / L)
+    wb = warp * np.cos(2 * np.pi * v / L * 1.2 + 0.7) * (0.5 + 0.5 * np.sin(2 * np.pi * u / L))
+    wx, wy = (wa, wb) if H >= W else (wb, wa)
+    s0 = map_coordinates(tex, [yy + pad, xx + pad], order=1)
+    s1 = map_coordinates(tex, [yy + pad + shift[1] + wy, xx + pad + shift[0] + wx], order=3)
+    s0 = s0 + rng.normal(0, noise, s0.shape); s1 = s1 + rng.normal(0, noise, s1.shape)
+    return np.clip(np.round(s0), 0, 255).astype(np.uint8), np.clip(np.round(s1), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize('H,W', [(1536, 120), (120, 1536)])
+def test_pipeline_deformed_mesh_between_spacings_vs_oracle(fb, H, W):
+    """a warp of a few pixels makes the coarse blocks disagree, so mesh1 is relaxed into a
+    non-rigid field (matcher.py:725-741); the fine round crops image 1 through the deformed mesh
+    (MeshRenderer.crop_multiple tiers), locates its matches in the deformed triangles and reports them in the INITIAL
+    gear.  One batch mixes deformed pairs with a rigid one.  Against the oracle's deformed branch."""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    pairs = [_warped_pair(H, W, 1, (4, -3), 3.0), _warped_pair(H, W, 2, (-6, 2), 0.0), _warped_pair(H, W, 3, (1, 5), 2.0)]
+    s0 = np.stack([p[0] for p in pairs]); s1 = np.stack([p[1] for p in pairs])
+    P = len(pairs)
+    d0 = _lib.DeviceBuffer.from_array(s0); d1 = _lib.DeviceBuffer.from_array(s1)
+    m = StripBatchMatcher(P, H, W, residue_len=2.0)
+    assert m.spacings.size == 2
+    res = m.match(d0.ptr, d1.ptr)
+    got = StripBatchMatcher.per_pair(res)
+    ndef = 0
+    for p in range(P):
+        exp = pipeline_ref.match_pair(s0[p], s1[p], residue_len=2.0)
+        g = got[p]
+        assert (g['tx'], g['ty']) == (exp['tx'], exp['ty'])
+        assert g['deformed'] == bool(exp.get('deformed', False))
+        assert g['xy0'].shape == exp['xy0'].shape and g['xy0'].shape[0] > 60
+        if g['deformed']:
+            ndef += 1
+            np.testing.assert_array_equal(m.last_tiers[p], exp['tiers'][-1])
+            field = m.last_field[p]
+            assert np.abs(field - exp['mesh1_field']).max() < 1e-5 * max(1.0, np.abs(exp['mesh1_field']).max())
+            assert np.ptp(field[:, 0]) > 0.5 or np.ptp(field[:, 1]) > 0.5        # really not a translation
+        # the exact solve of the oracle and the device PCG (1e-9) give affine maps that differ at the 1e-8 level; a
+        # sample position that sits on a 1/32-px rounding boundary may then flip, which moves a sub-pixel peak by ~1e-3
+        np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=3e-3)
+        np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=3e-3)
+        np.testing.assert_allclose(g['weight'], exp['weight'], atol=2e-3)
+        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=5e-3, atol=1e-6)
+    assert ndef == 2
+    m.free(); d0.free(); d1.free()
+
+
+def test_deformed_round_exact_field_tier_vs_oracle(fb):
+    """a mesh1 with kinks that no block affine follows within 0.1 px: those blocks take the exact piecewise-linear tier
+    (host field -> fb_remap_dev -> fb_ncc_batch_dev), the others the affine gather inside the NCC loaders; tiers,
+    displacements and confidences against the oracle's render_blocks_mesh1 + xcorr_fft"""
+    from feabas_amd import _lib, constant as const
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    from oracle import ncc_ref, fem_ref
+    H, W, P = 1536, 120, 2
+    pairs = [_warped_pair(H, W, 11, (3, -2), 1.0), _warped_pair(H, W, 12, (0, 0), 0.5)]
+    s0 = np.stack([p[0] for p in pairs]); s1 = np.stack([p[1] for p in pairs])
+    d0 = _lib.DeviceBuffer.from_array(s0); d1 = _lib.DeviceBuffer.from_array(s1)
+    m = StripBatchMatcher(P, H, W)
+    m._fine_dog(d0.ptr, d1.ptr)
+    m._relax_system()
+    v = m._mesh.vertices(const.MESH_GEAR_INITIAL)
+    rng = np.random.default_rng(4)
+    U = np.zeros((P,) + v.shape)
+    for p in range(P):
+        U[p] = np.stack((2.0 * np.sin(v[:, 1] / 300) + 0.8 * np.cos(v[:, 0] / 40), 1.5 * np.cos(v[:, 1] / 200)), -1)
+        k = rng.integers(0, v.shape[0], 8)
+        U[p, k] += rng.normal(0, 0.7, (8, 2))
+    tx = np.array([-3.0, 0.0]); ty = np.array([2.0, 0.0])
+    pad = np.zeros(P, dtype=bool)
+    groups = m._match_round_deformed(tx, ty, U, np.arange(P), m.spacings[-1], m.mnb, pad, True, True)
+    f0 = m.d_dogf_view.to_array((2 * P, H, W), np.float32)
+    seen = 0
+    for sel, bb, ddx, ddy, dcf in groups:
+        for q, p in enumerate(sel):
+            m1 = fem_ref.RefMesh(v, m._mesh.triangles, uid=1)
+            m1.set_field(U[p], gear=(fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING))
+            st1, tiers = pipeline_ref.render_blocks_mesh1(m1, f0[P + p], bb[q], 0.1, return_tiers=True)
+            np.testing.assert_array_equal(m.last_tiers[int(p)], tiers)
+            assert (tiers == 3).sum() >= 3 and (tiers == 2).sum() >= 3
+            h, w = st1.shape[1:]
+            st0 = np.stack([pipeline_ref._crop(f0[p], int(b[0] - tx[p]), int(b[1] - ty[p]), h, w) for b in bb[q]])
+            ex, ey, ec = ncc_ref.xcorr_fft(st0, st1, pad=False, subpixel=True)
+            good = ec > 0.5
+            assert good.sum() > 0.4 * good.size and good[tiers == 3].sum() >= 2
+            np.testing.assert_array_equal(np.round(ddx[q][good]), np.round(ex[good]))
+            np.testing.assert_allclose(ddx[q][good], ex[good], atol=1e-3); np.testing.assert_allclose(ddy[q][good], ey[good], atol=1e-3)
+            np.testing.assert_allclose(dcf[q], ec, atol=1e-3)
+            seen += 1
+    assert seen == P
+    m.free(); d0.free(); d1.free()
+
+
+def test_remap_kernel_vs_oracle(fb):
+    """fb_remap_dev = common.remap (cv2.remap bilinear, constant border 0) relative to an integer origin, masked"""
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(8)
+    IH, IW, N, h, w = 90, 70, 3, 33, 41
+    imgs = rng.standard_normal((2, IH, IW)).astype(np.float32)
+    ids = np.array([1, 0, 1], dtype=np.int32)
+    org = np.array([[-5, -7], [10, 3], [30, 40]], dtype=np.int32)
+    mx = rng.uniform(-8, IW + 8, (N, h, w)); my = rng.uniform(-8, IH + 8, (N, h, w))
+    mk = (rng.random((N, h, w)) > 0.2)
+    mxr = (mx - org[:, None, None, 0]).astype(np.float32); myr = (my - org[:, None, None, 1]).astype(np.float32)
+    bufs = [_lib.DeviceBuffer.from_array(np.ascontiguousarray(a)) for a in (imgs, ids, mxr, myr, mk.astype(np.uint8), org)]
+    out = _lib.DeviceBuffer(4 * N * h * w)
+    _lib.check(lib.fb_remap_dev(ctx, bufs[0].ptr, IH, IW, N, bufs[1].ptr, h, w, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr, bufs[5].ptr, out.ptr))
+    got = out.to_array((N, h, w), np.float32)
+    for n in range(N):
+        exp = pipeline_ref.remap_origin(imgs[ids[n]], mx[n], my[n], (int(org[n, 0]), int(org[n, 1])))
+        exp = np.where(mk[n], exp, 0)
+        np.testing.assert_array_equal(got[n], exp.astype(np.float32))
+    for b in bufs + [out]:
+        b.free()
