@@ -386,10 +386,10 @@ def main():
                 config=dict(workload=f'config[1]: {2 * n_res} resident synthetic {T}x{T} tile pairs ({n_res} LR + {n_res} UD strips '
                                      f'{Hl}x{Wl}), {P * S} pairs per step ({S} matcher calls of {P} pairs dealt to {nthr} host threads); stages: x0.5 downsample, DoG, global NCC, DoG, '
                                      f'4 coarse + 385 fine block NCCs, last-round relaxation + residue weights + strain (integer synthetic offsets in +-20 px plus a smooth '
-                                     f'{args.warp} px warp; odd offsets take the rigid mesh-relaxation branch, DESIGN.md sec.5)',
+                                     f'{args.warp} px warp; odd offsets take the rigid mesh-relaxation branch, pairs whose coarse blocks disagree the deformed-mesh branch, DESIGN.md sec.5)',
                             pairs_per_step=P * S, pairs_per_matcher_call=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33, residue_mode='huber', residue_len=RESIDUE_LEN),
                 check=dict(global_shift_within_1px=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches, matches_within_half_px_of_truth=ok_match,
-                           pairs_needing_mesh_relaxation=int(res['needs_host'].sum())),
+                           pairs_with_deformed_mesh=int(res['deformed'].sum())),
                 roofline=roof)
 
     if not args.no_fem:

@@ -1,0 +1,221 @@
+// Host-side geometry of tile pairs whose mesh1 is deformed (feabas_amd/deformed.py states the same functions in numpy
+// and is their test oracle on the CPU): the tier decision of MeshRenderer.crop_field with the affine approximator of
+// MeshRenderer.from_mesh (feabas/renderer.py:90-109, 397-416, 453-511) for every block of a batch of pairs, and
+// Mesh.tri_finder + cart2bary (feabas/mesh.py:2080-2217) on the deformed cartesian mesh.  The reference keeps this on
+// the host too (shapely STRtree + numpy lstsq + matplotlib trifinder); here it is plain C++ so that the host threads
+// that drive the device do it without the Python interpreter lock.  No device work, ctx may be NULL.
+#include "fb_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace {
+
+struct Fit {
+    double a00, a01, a10, a11, t0, t1, res;   // image = moving @ [[a00 a01] [a10 a11]] + (t0, t1)
+    bool ok;
+};
+
+// spatial.fit_affine(pts0 = v_init[idx], pts1 = vm[idx]) (spatial.py:21-73, unweighted): on centred points the least
+// squares is block diagonal -- the 2x2 part solves the normal equations, the translation is mm0 - mm1 @ A
+Fit fit_rows(const double* vm, const double* vi, const int* idx, int cnt) {
+    Fit f{1, 0, 0, 1, 0, 0, std::numeric_limits<double>::infinity(), false};
+    if (cnt < 3) return f;
+    double m0x = 0, m0y = 0, m1x = 0, m1y = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const int v = idx[k];
+        m0x += vi[2 * v]; m0y += vi[2 * v + 1]; m1x += vm[2 * v]; m1y += vm[2 * v + 1];
+    }
+    m0x /= cnt; m0y /= cnt; m1x /= cnt; m1y /= cnt;
+    double g00 = 0, g01 = 0, g11 = 0, h00 = 0, h01 = 0, h10 = 0, h11 = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const int v = idx[k];
+        const double c1x = vm[2 * v] - m1x, c1y = vm[2 * v + 1] - m1y, c0x = vi[2 * v] - m0x, c0y = vi[2 * v + 1] - m0y;
+        g00 += c1x * c1x; g01 += c1x * c1y; g11 += c1y * c1y;
+        h00 += c1x * c0x; h01 += c1x * c0y; h10 += c1y * c0x; h11 += c1y * c0y;
+    }
+    const double det = g00 * g11 - g01 * g01, scale = std::max(g00, g11);
+    if (!(det > 1e-9 * scale * scale)) return f;
+    f.a00 = (g11 * h00 - g01 * h10) / det; f.a01 = (g11 * h01 - g01 * h11) / det;
+    f.a10 = (g00 * h10 - g01 * h00) / det; f.a11 = (g00 * h11 - g01 * h01) / det;
+    if (!(f.a00 * f.a11 - f.a01 * f.a10 > 0)) return f;      // flipped: spatial.py:48-60 takes another route
+    f.t0 = m0x - (m1x * f.a00 + m1y * f.a10);
+    f.t1 = m0y - (m1x * f.a01 + m1y * f.a11);
+    double worst = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const int v = idx[k];
+        const double dx = vi[2 * v] - (vm[2 * v] * f.a00 + vm[2 * v + 1] * f.a10 + f.t0);
+        const double dy = vi[2 * v + 1] - (vm[2 * v] * f.a01 + vm[2 * v + 1] * f.a11 + f.t1);
+        worst = std::max(worst, dx * dx + dy * dy);
+    }
+    f.res = std::sqrt(worst);
+    f.ok = true;
+    return f;
+}
+
+// closed triangle against closed box: separating axes = the two box axes and the three edge normals
+bool tri_hits_box(const double* p0, const double* p1, const double* p2, double bx0, double by0, double bx1, double by1) {
+    const double tx0 = std::min(p0[0], std::min(p1[0], p2[0])), tx1 = std::max(p0[0], std::max(p1[0], p2[0]));
+    const double ty0 = std::min(p0[1], std::min(p1[1], p2[1])), ty1 = std::max(p0[1], std::max(p1[1], p2[1]));
+    if (tx1 < bx0 || tx0 > bx1 || ty1 < by0 || ty0 > by1) return false;
+    const double* tp[3] = {p0, p1, p2};
+    const double cx[4] = {bx0, bx1, bx1, bx0}, cy[4] = {by0, by0, by1, by1};
+    for (int k = 0; k < 3; ++k) {
+        const double ex = tp[(k + 1) % 3][0] - tp[k][0], ey = tp[(k + 1) % 3][1] - tp[k][1];
+        const double nx = -ey, ny = ex;
+        double tmin = std::numeric_limits<double>::infinity(), tmax = -tmin, bmin = tmin, bmax = -tmin;
+        for (int a = 0; a < 3; ++a) { const double d = tp[a][0] * nx + tp[a][1] * ny; tmin = std::min(tmin, d); tmax = std::max(tmax, d); }
+        for (int a = 0; a < 4; ++a) { const double d = cx[a] * nx + cy[a] * ny; bmin = std::min(bmin, d); bmax = std::max(bmax, d); }
+        if (tmax < bmin || tmin > bmax) return false;
+    }
+    return true;
+}
+
+inline void tri_nodes(int t, int nx, int* n3) {
+    const int cell = t >> 1, j = cell / (nx - 1), i = cell - j * (nx - 1), a = j * nx + i;
+    n3[0] = a;
+    if (t & 1) { n3[1] = a + nx + 1; n3[2] = a + nx; } else { n3[1] = a + 1; n3[2] = a + nx + 1; }
+}
+
+}  // namespace
+
+extern "C" {
+
+// vm [Q][V][2]: MOVING vertices (with offset) of mesh1 of every pair, V = nx ny nodes of the grid xs x ys (the INITIAL
+// vertices); bboxes [Q][nblk][4] int32 in the MOVING frame.  tier [Q][nblk]: 1 global affine, 2 block affine, 3 exact
+// field, -1 = the block's vertex set is degenerate or its fit flipped (caller takes the statement-by-statement route);
+// A6 [Q][nblk][6] = {A00, A10, t0, A01, A11, t1} (image x = X A00 + Y A10 + t0, image y = X A01 + Y A11 + t1);
+// lo [Q][2] = smallest image x / y any affine block of the pair samples (+inf without one): the remap origin of
+// render_by_subregions (common.py:316-321) is floor(lo) - 4 once the exact-field blocks are included.
+int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int nblk,
+                              const int32_t* bboxes, double tol, int32_t* tier, double* A6, double* lo) {
+    FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs && ys && vm && nblk >= 0 && bboxes && tier && A6 && lo);
+    const int V = nx * ny;
+    std::vector<double> vi(2 * (size_t)V);
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) { vi[2 * (j * nx + i)] = xs[i]; vi[2 * (j * nx + i) + 1] = ys[j]; }
+    std::vector<int> all(V), stamp(V), members;
+    for (int v = 0; v < V; ++v) all[v] = v;
+    members.reserve(64);
+    const double inf = std::numeric_limits<double>::infinity();
+    for (int q = 0; q < Q; ++q) {
+        const double* v = vm + 2 * (size_t)q * V;
+        int32_t* tq = tier + (size_t)q * nblk;
+        double* aq = A6 + 6 * (size_t)q * nblk;
+        const int32_t* bq = bboxes + 4 * (size_t)q * nblk;
+        double lox = inf, loy = inf;
+        auto put = [&](int b, const Fit& f) {
+            double* a = aq + 6 * (size_t)b;
+            a[0] = f.a00; a[1] = f.a10; a[2] = f.t0; a[3] = f.a01; a[4] = f.a11; a[5] = f.t1;
+            const double X[2] = {(double)bq[4 * b], (double)bq[4 * b + 2] - 1.0}, Y[2] = {(double)bq[4 * b + 1], (double)bq[4 * b + 3] - 1.0};
+            for (int cxi = 0; cxi < 2; ++cxi)
+                for (int cyi = 0; cyi < 2; ++cyi) {
+                    lox = std::min(lox, X[cxi] * f.a00 + Y[cyi] * f.a10 + f.t0);
+                    loy = std::min(loy, X[cxi] * f.a01 + Y[cyi] * f.a11 + f.t1);
+                }
+        };
+        Fit g{1, 0, 0, 1, 0, 0, inf, false};
+        if (tol > 0) g = fit_rows(v, vi.data(), all.data(), V);
+        if (tol > 0 && g.ok && g.res < tol) {
+            for (int b = 0; b < nblk; ++b) { tq[b] = 1; put(b, g); }
+        } else {
+            double uminx = inf, umaxx = -inf, uminy = inf, umaxy = -inf;
+            for (int k = 0; k < V; ++k) {
+                const double ux = v[2 * k] - vi[2 * k], uy = v[2 * k + 1] - vi[2 * k + 1];
+                uminx = std::min(uminx, ux); umaxx = std::max(umaxx, ux); uminy = std::min(uminy, uy); umaxy = std::max(umaxy, uy);
+            }
+            std::fill(stamp.begin(), stamp.end(), -1);
+            for (int b = 0; b < nblk; ++b) {
+                const double bx0 = bq[4 * b] - 0.5, by0 = bq[4 * b + 1] - 0.5, bx1 = bq[4 * b + 2] - 0.5, by1 = bq[4 * b + 3] - 0.5;
+                // cells whose deformed extent can reach the box
+                int ilo = 0, ihi = nx - 2, jlo = 0, jhi = ny - 2;
+                while (ilo < nx - 2 && xs[ilo + 1] + umaxx < bx0) ++ilo;
+                while (ihi > 0 && xs[ihi] + uminx > bx1) --ihi;
+                while (jlo < ny - 2 && ys[jlo + 1] + umaxy < by0) ++jlo;
+                while (jhi > 0 && ys[jhi] + uminy > by1) --jhi;
+                members.clear();
+                for (int j = jlo; j <= jhi; ++j)
+                    for (int i = ilo; i <= ihi; ++i)
+                        for (int half = 0; half < 2; ++half) {
+                            int n3[3];
+                            tri_nodes(2 * (j * (nx - 1) + i) + half, nx, n3);
+                            if (!tri_hits_box(v + 2 * n3[0], v + 2 * n3[1], v + 2 * n3[2], bx0, by0, bx1, by1)) continue;
+                            for (int a = 0; a < 3; ++a)
+                                if (stamp[n3[a]] != b) { stamp[n3[a]] = b; members.push_back(n3[a]); }
+                        }
+                tq[b] = 3;
+                double* a = aq + 6 * (size_t)b;
+                a[0] = 1; a[1] = 0; a[2] = 0; a[3] = 0; a[4] = 1; a[5] = 0;
+                if (!(tol > 0) || members.empty()) continue;
+                std::sort(members.begin(), members.end());
+                const Fit f = fit_rows(v, vi.data(), members.data(), (int)members.size());
+                if (!f.ok) { tq[b] = -1; continue; }
+                if (f.res < tol) { tq[b] = 2; put(b, f); }
+            }
+        }
+        lo[2 * q] = lox; lo[2 * q + 1] = loy;
+    }
+    return FB_OK;
+}
+
+// Mesh.tri_finder + cart2bary on the deformed grid mesh: point k belongs to pair pair_of[k] (index into vm [Q][V][2]).
+// The cell is guessed by pulling the point back with the displacement of its nearest node (two passes), then the
+// triangles of the 3 x 3 cells around it are tested in a fixed order; the first that contains the point wins.
+// tid [K] = triangle (cells (a b / c d) -> 2 cell: (a, b, d), 2 cell + 1: (a, d, c)) or -1 outside; B [K][3] (nan outside).
+int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int64_t K,
+                       const int32_t* pair_of, const double* pts, int32_t* tid, double* B) {
+    FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs && ys && vm && K >= 0 && (K == 0 || (pair_of && pts && tid && B)));
+    const int V = nx * ny;
+    const double eps = 1e-9, nan = std::numeric_limits<double>::quiet_NaN(), inf = std::numeric_limits<double>::infinity();
+    std::vector<double> mean(2 * (size_t)std::max(Q, 1), 0.0);
+    for (int q = 0; q < Q; ++q) {
+        const double* v = vm + 2 * (size_t)q * V;
+        double mx = 0, my = 0;
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) { mx += v[2 * (j * nx + i)] - xs[i]; my += v[2 * (j * nx + i) + 1] - ys[j]; }
+        mean[2 * q] = mx / V; mean[2 * q + 1] = my / V;
+    }
+    static const int order[3] = {0, -1, 1};
+    for (int64_t k = 0; k < K; ++k) {
+        const int q = pair_of[k];
+        if (q < 0 || q >= Q) return fb_fail(ctx, FB_ERR_ARG, "fb_deformed_locate: pair %d outside [0, %d)", q, Q);
+        const double* v = vm + 2 * (size_t)q * V;
+        const double px = pts[2 * k], py = pts[2 * k + 1];
+        double qx = px - mean[2 * q], qy = py - mean[2 * q + 1];
+        for (int pass = 0; pass < 2; ++pass) {
+            int i = (int)std::nearbyint((qx - xs[0]) / (xs[nx - 1] - xs[0]) * (nx - 1));
+            int j = (int)std::nearbyint((qy - ys[0]) / (ys[ny - 1] - ys[0]) * (ny - 1));
+            i = std::min(std::max(i, 0), nx - 1); j = std::min(std::max(j, 0), ny - 1);
+            qx = px - (v[2 * (j * nx + i)] - xs[i]); qy = py - (v[2 * (j * nx + i) + 1] - ys[j]);
+        }
+        int ci = (int)(std::upper_bound(xs, xs + nx, qx) - xs) - 1, cj = (int)(std::upper_bound(ys, ys + ny, qy) - ys) - 1;
+        ci = std::min(std::max(ci, 0), nx - 2); cj = std::min(std::max(cj, 0), ny - 2);
+        double best = -inf, bb[3] = {nan, nan, nan};
+        int bt = -1;
+        for (int dj = 0; dj < 3 && best < 0; ++dj)
+            for (int di = 0; di < 3 && best < 0; ++di) {
+                const int ii = ci + order[di], jj = cj + order[dj];
+                if (ii < 0 || ii >= nx - 1 || jj < 0 || jj >= ny - 1) continue;
+                for (int half = 0; half < 2 && best < 0; ++half) {
+                    const int t = 2 * (jj * (nx - 1) + ii) + half;
+                    int n3[3];
+                    tri_nodes(t, nx, n3);
+                    const double d0x = px - v[2 * n3[0]], d0y = py - v[2 * n3[0] + 1];
+                    const double d1x = px - v[2 * n3[1]], d1y = py - v[2 * n3[1] + 1];
+                    const double d2x = px - v[2 * n3[2]], d2y = py - v[2 * n3[2] + 1];
+                    const double a0 = d1x * d2y - d1y * d2x, a1 = d2x * d0y - d2y * d0x, a2 = d0x * d1y - d0y * d1x;
+                    const double tot = a0 + a1 + a2;
+                    const double b0 = a0 / tot, b1 = a1 / tot, b2 = a2 / tot;
+                    double score = std::min(b0, std::min(b1, b2));
+                    if (std::isnan(score)) score = -inf;
+                    if (score > best) { best = score; bt = t; bb[0] = b0; bb[1] = b1; bb[2] = b2; }
+                }
+            }
+        if (best < -eps) { bt = -1; bb[0] = bb[1] = bb[2] = nan; }
+        tid[k] = bt; B[3 * k] = bb[0]; B[3 * k + 1] = bb[1]; B[3 * k + 2] = bb[2];
+    }
+    return FB_OK;
+}
+
+}  // extern "C"

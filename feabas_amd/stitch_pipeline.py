@@ -265,25 +265,40 @@ class StripBatchMatcher:
             h, w = int(dy[gi[0]]), int(dx[gi[0]])
             aff = np.zeros((Q, nblk, 10))
             exact = []                                                        # (q, block ids, map_x, map_y, mask)
+            # tiers + affine maps of all blocks of the group (C++, no interpreter lock; deformed.block_affines is the
+            # same computation in numpy)
+            vmg = np.ascontiguousarray(vm[gi])
+            bbi = np.ascontiguousarray(bb, dtype=np.int32)
+            tiers = np.empty((Q, nblk), dtype=np.int32); A6 = np.empty((Q, nblk, 6)); lo = np.empty((Q, 2))
+            _lib.check(lib.fb_deformed_block_affines(ctx, Q, m.grid_xs.size, m.grid_ys.size, _lib.ptr(m.grid_xs), _lib.ptr(m.grid_ys),
+                                                     _lib.ptr(vmg), nblk, _lib.ptr(bbi), tol, _lib.ptr(tiers), _lib.ptr(A6), _lib.ptr(lo)))
+            aff[:, :, 0] = bb[:, :, 0]; aff[:, :, 1] = bb[:, :, 1]
+            aff[:, :, 2:8] = A6
             for q in range(Q):
-                tier, A, hits = dfm.block_affines(vm[gi[q]], v_init, tris, bb[q], tol)
-                self.last_tiers[int(sel[q])] = tier
-                aff[q, :, 0] = bb[q, :, 0]; aff[q, :, 1] = bb[q, :, 1]
-                aff[q, :, 2] = A[:, 0, 0]; aff[q, :, 3] = A[:, 1, 0]; aff[q, :, 4] = A[:, 2, 0]
-                aff[q, :, 5] = A[:, 0, 1]; aff[q, :, 6] = A[:, 1, 1]; aff[q, :, 7] = A[:, 2, 1]
+                tier = tiers[q]
+                if (tier < 0).any():                                          # degenerate / flipped fit: statement-by-statement route
+                    tier, A, _ = dfm.block_affines(vmg[q], v_init, tris, bb[q], tol)
+                    tiers[q] = tier
+                    aff[q, :, 2] = A[:, 0, 0]; aff[q, :, 3] = A[:, 1, 0]; aff[q, :, 4] = A[:, 2, 0]
+                    aff[q, :, 5] = A[:, 0, 1]; aff[q, :, 6] = A[:, 1, 1]; aff[q, :, 7] = A[:, 2, 1]
+                    rows = np.flatnonzero(tier < 3)
+                    if rows.size:
+                        cx = np.stack((bb[q, rows, 0], bb[q, rows, 2] - 1), axis=-1).astype(np.float64)
+                        cy = np.stack((bb[q, rows, 1], bb[q, rows, 3] - 1), axis=-1).astype(np.float64)
+                        lo[q, 0] = (cx[:, :, None] * A[rows, None, None, 0, 0] + cy[:, None, :] * A[rows, None, None, 1, 0] + A[rows, None, None, 2, 0]).min()
+                        lo[q, 1] = (cx[:, :, None] * A[rows, None, None, 0, 1] + cy[:, None, :] * A[rows, None, None, 1, 1] + A[rows, None, None, 2, 1]).min()
+                    else:
+                        lo[q] = np.inf
+                self.last_tiers[int(sel[q])] = tier.copy()
                 # one remap origin for the whole stack of a pair (render_by_subregions, common.py:316-321):
-                # floor(min of the rendered maps) - 4; an affine map takes its extremes at the corner pixels
-                cx = np.stack((bb[q, :, 0], bb[q, :, 2] - 1, bb[q, :, 2] - 1, bb[q, :, 0]), axis=-1).astype(np.float64)
-                cy = np.stack((bb[q, :, 1], bb[q, :, 1], bb[q, :, 3] - 1, bb[q, :, 3] - 1), axis=-1).astype(np.float64)
-                mx = cx * A[:, None, 0, 0] + cy * A[:, None, 1, 0] + A[:, None, 2, 0]
-                my = cx * A[:, None, 0, 1] + cy * A[:, None, 1, 1] + A[:, None, 2, 1]
-                aff_rows = tier < 3
-                lo_x = mx[aff_rows].min() if aff_rows.any() else np.inf
-                lo_y = my[aff_rows].min() if aff_rows.any() else np.inf
-                ex = np.flatnonzero(~aff_rows)
+                # floor(min of the rendered maps) - 4; an affine map takes its extremes at the corner pixels (lo)
+                lo_x, lo_y = lo[q]
+                ex = np.flatnonzero(tier == 3)
                 if ex.size:
-                    maps = [dfm.exact_field(vm[gi[q]], v_init, tris, np.flatnonzero(hits[b]), int(bb[q, b, 0]), int(bb[q, b, 1]), h, w) for b in ex]
-                    emx = np.stack([a[0] for a in maps]); emy = np.stack([a[1] for a in maps]); emk = np.stack([a[2] for a in maps])
+                    hits = dfm.tri_box_hits(vmg[q][tris], bb[q, ex] - 0.5)
+                    maps = [dfm.exact_field(vmg[q], v_init, tris, np.flatnonzero(hits[k]), int(bb[q, b, 0]), int(bb[q, b, 1]), h, w)
+                            for k, b in enumerate(ex)]
+                    emx = np.stack([a_[0] for a_ in maps]); emy = np.stack([a_[1] for a_ in maps]); emk = np.stack([a_[2] for a_ in maps])
                     if emk.any():
                         lo_x = min(lo_x, emx[emk].min()); lo_y = min(lo_y, emy[emk].min())
                     exact.append((q, ex, emx, emy, emk))
@@ -382,15 +397,12 @@ class StripBatchMatcher:
         return rw, x
 
     def _tri_of_nodes(self, local3):
-        """triangle id of a vertex triple given in the order of Mesh.triangles"""
-        if not hasattr(self, '_tri_lut'):
-            t = self._mesh.triangles.astype(np.int64)
-            V = self._mesh.num_vertices
-            self._tri_lut = {int(k): i for i, k in enumerate((t[:, 0] * V + t[:, 1]) * V + t[:, 2])}
-        V = self._mesh.num_vertices
+        """triangle id of a vertex triple given in the order of Mesh.triangles: cell (a b / c d) -> (a, b, d), (a, d, c)"""
+        nx = self._mesh.grid_xs.size
         l3 = np.asarray(local3, dtype=np.int64)
-        keys = (l3[:, 0] * V + l3[:, 1]) * V + l3[:, 2]
-        return np.array([self._tri_lut[int(k)] for k in keys], dtype=np.int64)
+        a = l3[:, 0]
+        j, i = a // nx, a % nx
+        return 2 * (j * (nx - 1) + i) + (l3[:, 1] != a + 1)
 
     # ------------------------------------------------------------------ last-round relaxation
     def _relax_system(self):
@@ -664,17 +676,20 @@ class StripBatchMatcher:
                     # Link.from_coordinates on the MOVING gear of the deformed mesh1 (matcher.py:717, optimizer.py:51-82):
                     # points outside the mesh are dropped; the INITIAL coordinates follow from the barycentric ones
                     xy1_init = np.zeros_like(xy1)
-                    for q, p in enumerate(sel):
-                        k = np.flatnonzero(keep[q])
-                        if k.size == 0:
-                            continue
-                        tid, Bq = dfm.locate(v_init + U[p], m.triangles, m.grid_xs, m.grid_ys, xy1[q, k])
+                    qq, kk = np.nonzero(keep)
+                    if qq.size:
+                        vmg = np.ascontiguousarray(v_init[None, :, :] + U[sel])
+                        pts = np.ascontiguousarray(xy1[qq, kk]); q32 = np.ascontiguousarray(qq, dtype=np.int32)
+                        tid = np.empty(qq.size, dtype=np.int32); Bq = np.empty((qq.size, 3))
+                        _lib.check(_lib.load().fb_deformed_locate(_lib.ctx(), sel.size, m.grid_xs.size, m.grid_ys.size, _lib.ptr(m.grid_xs),
+                                                                  _lib.ptr(m.grid_ys), _lib.ptr(vmg), qq.size, _lib.ptr(q32), _lib.ptr(pts),
+                                                                  _lib.ptr(tid), _lib.ptr(Bq)))
                         inside = tid >= 0
-                        keep[q, k[~inside]] = False
-                        k, tid, Bq = k[inside], tid[inside], Bq[inside]
-                        nodes3[q, k] = m.triangles[tid] + p * V
-                        B1[q, k] = Bq
-                        xy1_init[q, k] = np.sum(v_init[m.triangles[tid]] * Bq[:, :, None], axis=1)
+                        keep[qq[~inside], kk[~inside]] = False
+                        qq, kk, tid, Bq = qq[inside], kk[inside], tid[inside], Bq[inside]
+                        nodes3[qq, kk] = m.triangles[tid] + (sel[qq] * V)[:, None]
+                        B1[qq, kk] = Bq
+                        xy1_init[qq, kk] = np.sum(v_init[m.triangles[tid]] * Bq[:, :, None], axis=1)
                     has_link = keep.any(axis=1)
                 else:
                     xy1_init = xy1 - t1[sel][:, None, :]     # INITIAL gear of mesh1 at link creation (matcher.py:748-751)

@@ -226,6 +226,19 @@ int fb_pairs_relax(fb_ctx* ctx, fb_system* sys, int P, int nx, int ny, const dou
 int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* sys, int P, int64_t K, const int32_t* nodes3, const double* B1, const double* dxy0,
                         const float* conf, double residue_len, double sample_err, double stiffness_lambda, double rtol, float* rw,
                         double* x_out, int* iters, double* relres);
+/* ---- host geometry of pairs whose mesh1 is deformed (no device work; ctx may be NULL).
+ * fb_deformed_block_affines: the tier decision of MeshRenderer.crop_field with the affine approximator of
+ *   MeshRenderer.from_mesh (renderer.py:90-109, 397-416, 453-511) for the nblk blocks of Q pairs.  vm [Q][nx ny][2] =
+ *   MOVING vertices (with offset) of the cartesian mesh1 whose INITIAL nodes are xs x ys; bboxes [Q][nblk][4] int32;
+ *   tol = affine_approx_tol.  tier [Q][nblk]: 1 global affine, 2 block affine, 3 exact field, -1 degenerate / flipped
+ *   fit (caller's statement-by-statement route); A6 [Q][nblk][6] = {A00, A10, t0, A01, A11, t1}; lo [Q][2] = smallest
+ *   image x / y an affine block samples (the remap origin of common.py:316-321 is floor(lo) - 4).
+ * fb_deformed_locate: Mesh.tri_finder + cart2bary (mesh.py:2080-2217) on those meshes: point k of pair pair_of[k] ->
+ *   tid [K] (cell (a b / c d): 2 cell = (a, b, d), 2 cell + 1 = (a, d, c); -1 outside) and B [K][3]. */
+int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int nblk,
+                              const int32_t* bboxes, double tol, int32_t* tier, double* A6, double* lo);
+int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int64_t K,
+                       const int32_t* pair_of, const double* pts, int32_t* tid, double* B);
 int fb_pairs_strain(fb_ctx* ctx, fb_system* sys, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
                     const double* xy0_fixed, const double* xy1_initial, const float* weight, const double* R, double stiffness_lambda,
                     double es0, int links_loaded, double default_strain, double* strain, int* iters, double* relres);

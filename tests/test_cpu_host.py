@@ -251,3 +251,55 @@ def test_oracle_deformed_branch_recovers_a_smooth_warp():
     err = (r['xy0'] - q) - (np.array([4.0, -3.0]) + wq)
     assert np.abs(err).max() < 1.0 and np.percentile(np.abs(err), 90) < 0.4 and np.abs(np.median(err, axis=0)).max() < 0.15
     assert np.ptp(r['mesh1_field'][:, 0]) > 2.0
+
+
+def test_cxx_deformed_geometry_matches_numpy():
+    """fb_deformed_block_affines / fb_deformed_locate (host C++ behind the C ABI, no device work, ctx = NULL) against the
+    numpy statements of feabas_amd/deformed.py, which the tests above pin to the renderer restatement"""
+    from feabas_amd import _lib, deformed
+    from oracle import pipeline_ref, ncc_ref
+    lib = _lib.load()
+    W, H = 120, 1536
+    v, tri, xs, ys = pipeline_ref.cartesian_mesh(W, H, 40.0)
+    rng = np.random.default_rng(0)
+    Q = 3
+    vm = np.empty((Q,) + v.shape)
+    for q in range(Q):
+        U = np.stack((2.5 * np.sin(v[:, 1] / 300) + 0.8 * np.cos(v[:, 0] / 40), 1.5 * np.cos(v[:, 1] / 200)), -1) * (0.02 if q == 2 else 1)
+        k = rng.integers(0, v.shape[0], 6)
+        U[k] += rng.normal(0, 0.6 if q < 2 else 0.0, (6, 2))
+        vm[q] = v + U + rng.normal(0, 1, 2)
+    bbs = [ncc_ref.distributor_cartesian_bbox((2.5, -2.5, W + 2.5, H - 2.5), (vm[q, :, 0].min(), vm[q, :, 1].min(), vm[q, :, 0].max(), vm[q, :, 1].max()),
+                                              40.0, min_num_blocks=2)[1] for q in range(Q)]
+    nblk = min(b.shape[0] for b in bbs)
+    bb = np.ascontiguousarray(np.stack([b[:nblk] for b in bbs]), dtype=np.int32)
+    seen = set()
+    for tol in (0.1, 0.3, 1.0, 5.0):
+        tier = np.empty((Q, nblk), np.int32); A6 = np.empty((Q, nblk, 6)); lo = np.empty((Q, 2))
+        assert lib.fb_deformed_block_affines(None, Q, xs.size, ys.size, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(vm), nblk, _lib.ptr(bb), tol,
+                                             _lib.ptr(tier), _lib.ptr(A6), _lib.ptr(lo)) == 0
+        for q in range(Q):
+            t2, A, _ = deformed.block_affines(vm[q], v, tri, bb[q], tol)
+            np.testing.assert_array_equal(t2, tier[q])
+            seen |= set(t2.tolist())
+            a = t2 < 3
+            if a.any():
+                ref = np.stack((A[:, 0, 0], A[:, 1, 0], A[:, 2, 0], A[:, 0, 1], A[:, 1, 1], A[:, 2, 1]), -1)
+                np.testing.assert_allclose(A6[q][a], ref[a], atol=1e-9)
+                cx = np.stack((bb[q, a, 0], bb[q, a, 2] - 1), -1).astype(float); cy = np.stack((bb[q, a, 1], bb[q, a, 3] - 1), -1).astype(float)
+                mx = cx[:, :, None] * ref[a, 0, None, None] + cy[:, None, :] * ref[a, 1, None, None] + ref[a, 2, None, None]
+                assert abs(mx.min() - lo[q, 0]) < 1e-9
+    assert seen == {1, 2, 3}
+    K = 5000
+    po = rng.integers(0, Q, K).astype(np.int32)
+    pts = np.stack((rng.uniform(-5, W + 5, K), rng.uniform(-5, H + 5, K)), -1)
+    tid = np.empty(K, np.int32); B = np.empty((K, 3))
+    assert lib.fb_deformed_locate(None, Q, xs.size, ys.size, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(vm), K, _lib.ptr(po), _lib.ptr(pts),
+                                  _lib.ptr(tid), _lib.ptr(B)) == 0
+    for q in range(Q):
+        s_ = po == q
+        t2, B2 = deformed.locate(vm[q], tri, xs, ys, pts[s_])
+        np.testing.assert_array_equal(t2, tid[s_])
+        ok = t2 >= 0
+        np.testing.assert_allclose(B[s_][ok], B2[ok], atol=1e-12)
+    assert 0 < (tid < 0).sum() < K // 2
