@@ -181,6 +181,7 @@ def auto_spacings(shape0, shape1):
 
 
 _pair_matchers = {}
+_PAIR_MATCHER_CACHE = 4
 
 
 def stitching_matcher(img0, img1, **kwargs):
@@ -220,6 +221,9 @@ def stitching_matcher(img0, img1, **kwargs):
     if img0.ndim != 2 or img0.shape != img1.shape or img0.dtype != np.uint8 or img1.dtype != np.uint8:
         raise NotImplementedError('stitching_matcher: the device path takes two uint8 strips of equal shape')
     H, W = img0.shape
+    if coarse_downsample == 0.5 and (H % 2 or W % 2):
+        raise NotImplementedError('stitching_matcher: coarse_downsample = 0.5 needs even strip sizes (cv2.resize(INTER_AREA) at a '
+                                  'non-integer ratio is not restated)')
     key = (H, W, float(sigma), coarse_downsample, float(conf_thresh), int(min_num_blocks), int(conf_mode), float(residue_len),
            float(stiffness_lambda), bool(compute_strain), id(_lib.ctx()))
     m = _pair_matchers.get(key)
@@ -227,7 +231,12 @@ def stitching_matcher(img0, img1, **kwargs):
         m = StripBatchMatcher(1, H, W, sigma=sigma, coarse_downsample=coarse_downsample, conf_thresh=conf_thresh,
                               min_num_blocks=min_num_blocks, conf_mode=conf_mode, residue_len=residue_len,
                               stiffness_lambda=stiffness_lambda, compute_strain=compute_strain)
+        # strip shapes vary from pair to pair (stitcher.py:561-571): keep the device buffers of a few recent shapes only
+        while len(_pair_matchers) >= _PAIR_MATCHER_CACHE:
+            _pair_matchers.pop(next(iter(_pair_matchers))).free()
         _pair_matchers[key] = m
+    else:
+        _pair_matchers[key] = _pair_matchers.pop(key)              # most recently used last
     d0 = _lib.DeviceBuffer.from_array(img0); d1 = _lib.DeviceBuffer.from_array(img1)
     try:
         res = StripBatchMatcher.per_pair(m.match(d0.ptr, d1.ptr))[0]

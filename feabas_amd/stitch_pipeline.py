@@ -102,6 +102,9 @@ class StripBatchMatcher:
         for b in (self.d_small, self.d_dogc, self.d_dogf, self.d_blk, self.d_out):
             if b is not None:
                 b.free()
+        for name in [k for k in vars(self) if k.startswith('_scr_')]:
+            getattr(self, name).free()
+            delattr(self, name)
 
     # ------------------------------------------------------------------ stages
     def _global(self, strips0, strips1):

@@ -421,3 +421,22 @@ def test_remap_kernel_vs_oracle(fb):
         np.testing.assert_array_equal(got[n], exp.astype(np.float32))
     for b in bufs + [out]:
         b.free()
+
+
+def test_stitching_matcher_varied_strip_shapes_and_corner_pairs(fb):
+    """strips of real sections differ in shape from pair to pair (stitcher.py:561-571), corner overlaps are square
+    (SURVEY config 4: 510 x 510): the per-pair surface follows the oracle on each, and the cache of per-shape device
+    buffers stays bounded"""
+    from feabas_amd import matcher as mt
+    shapes = [(510, 510), (1010, 262), (260, 998), (1024, 256), (512, 300), (300, 512)]
+    for k, (H, W) in enumerate(shapes):
+        s0, s1 = _warped_pair(H, W, 40 + k, shift=(3 - k, 2 * k - 4), warp=0.3)
+        xy0, xy1, wt, strain, _ = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+        exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0)
+        assert xy0.shape == exp['xy0'].shape and xy0.shape[0] >= 9
+        np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
+        np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
+        assert np.abs(np.median(xy1 - xy0, axis=0) + np.array([3 - k, 2 * k - 4])).max() < 0.5
+    assert len(mt._pair_matchers) <= mt._PAIR_MATCHER_CACHE
+    with pytest.raises(NotImplementedError):
+        fb.matcher.stitching_matcher(np.zeros((301, 512), np.uint8), np.zeros((301, 512), np.uint8), coarse_downsample=0.5)
