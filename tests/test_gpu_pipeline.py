@@ -440,3 +440,32 @@ def test_stitching_matcher_varied_strip_shapes_and_corner_pairs(fb):
     assert len(mt._pair_matchers) <= mt._PAIR_MATCHER_CACHE
     with pytest.raises(NotImplementedError):
         fb.matcher.stitching_matcher(np.zeros((301, 512), np.uint8), np.zeros((301, 512), np.uint8), coarse_downsample=0.5)
+
+
+def test_pipeline_three_spacings_deformed_twice_vs_oracle(fb):
+    """a 3600 x 72 strip has three spacings (900, 150, 25): the relaxation after the first round deforms mesh1, the
+    second round crops through it and relaxes AGAIN from the deformed state (the stress term of optimizer.py:1417-1418;
+    the device solves for the total displacement from the FIXED gear instead), the third round crops through that
+    field.  Node field after the second relaxation, tiers of the last round and the final matches against the oracle."""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    H, W = 3600, 72
+    pairs = [_warped_pair(H, W, 21, (2, -3), 2.5), _warped_pair(H, W, 22, (-3, 4), 1.5)]
+    s0 = np.stack([p[0] for p in pairs]); s1 = np.stack([p[1] for p in pairs])
+    P = len(pairs)
+    d0 = _lib.DeviceBuffer.from_array(s0); d1 = _lib.DeviceBuffer.from_array(s1)
+    m = StripBatchMatcher(P, H, W, residue_len=2.0)
+    assert m.spacings.size == 3
+    got = StripBatchMatcher.per_pair(m.match(d0.ptr, d1.ptr))
+    for p in range(P):
+        exp = pipeline_ref.match_pair(s0[p], s1[p], residue_len=2.0)
+        g = got[p]
+        assert (g['tx'], g['ty']) == (exp['tx'], exp['ty'])
+        assert g['deformed'] and exp['deformed'] and len(exp['tiers']) == 2
+        np.testing.assert_array_equal(m.last_tiers[p], exp['tiers'][-1])
+        assert np.abs(m.last_field[p] - exp['mesh1_field']).max() < 1e-5 * max(1.0, np.abs(exp['mesh1_field']).max())
+        assert g['xy0'].shape == exp['xy0'].shape and g['xy0'].shape[0] > 200
+        np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=3e-3); np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=3e-3)
+        np.testing.assert_allclose(g['weight'], exp['weight'], atol=2e-3)
+        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=5e-3, atol=1e-6)
+    m.free(); d0.free(); d1.free()
