@@ -159,6 +159,71 @@ int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* 
     return FB_OK;
 }
 
+// field_w_weight (renderer.py:259-300) for NB blocks: block e belongs to pair pair_of[e] (index into vm) and covers the
+// h x w output pixels at (x0, y0) = org[e]; every pixel is located in the MOVING triangles that can reach the block and
+// mapped to the image by linear interpolation of the INITIAL vertices (matplotlib.tri.LinearTriInterpolator in the
+// reference).  map_x, map_y [NB][h][w] float64, mask [NB][h][w] uint8 (0 = outside every triangle).
+// deformed.exact_field is the numpy statement of the same computation.
+int fb_deformed_exact_field(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int NB,
+                            const int32_t* pair_of, const int32_t* org, int h, int w, double* map_x, double* map_y, uint8_t* mask) {
+    FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs && ys && vm && NB >= 0 && h > 0 && w > 0 && (NB == 0 || (pair_of && org && map_x && map_y && mask)));
+    const int V = nx * ny;
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<int> cand;
+    for (int e = 0; e < NB; ++e) {
+        const int q = pair_of[e];
+        if (q < 0 || q >= Q) return fb_fail(ctx, FB_ERR_ARG, "fb_deformed_exact_field: pair %d outside [0, %d)", q, Q);
+        const double* v = vm + 2 * (size_t)q * V;
+        double uminx = inf, umaxx = -inf, uminy = inf, umaxy = -inf;
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const double ux = v[2 * (j * nx + i)] - xs[i], uy = v[2 * (j * nx + i) + 1] - ys[j];
+                uminx = std::min(uminx, ux); umaxx = std::max(umaxx, ux); uminy = std::min(uminy, uy); umaxy = std::max(umaxy, uy);
+            }
+        const int x0 = org[2 * e], y0 = org[2 * e + 1];
+        const double bx0 = x0 - 0.5, by0 = y0 - 0.5, bx1 = x0 + w - 0.5, by1 = y0 + h - 0.5;
+        int ilo = 0, ihi = nx - 2, jlo = 0, jhi = ny - 2;
+        while (ilo < nx - 2 && xs[ilo + 1] + umaxx < bx0) ++ilo;
+        while (ihi > 0 && xs[ihi] + uminx > bx1) --ihi;
+        while (jlo < ny - 2 && ys[jlo + 1] + umaxy < by0) ++jlo;
+        while (jhi > 0 && ys[jhi] + uminy > by1) --jhi;
+        cand.clear();
+        for (int j = jlo; j <= jhi; ++j)                      // ascending triangle id, like np.flatnonzero(hits)
+            for (int i = ilo; i <= ihi; ++i)
+                for (int half = 0; half < 2; ++half) {
+                    const int t = 2 * (j * (nx - 1) + i) + half;
+                    int n3[3];
+                    tri_nodes(t, nx, n3);
+                    if (tri_hits_box(v + 2 * n3[0], v + 2 * n3[1], v + 2 * n3[2], bx0, by0, bx1, by1)) cand.push_back(t);
+                }
+        const size_t base = (size_t)e * h * w;
+        for (int r = 0; r < h; ++r)
+            for (int c = 0; c < w; ++c) {
+                const double px = (double)x0 + c, py = (double)y0 + r;
+                double mx = 0.0, my = 0.0;
+                uint8_t inside = 0;
+                for (size_t ci = 0; ci < cand.size() && !inside; ++ci) {
+                    int n3[3];
+                    tri_nodes(cand[ci], nx, n3);
+                    const double d0x = px - v[2 * n3[0]], d0y = py - v[2 * n3[0] + 1];
+                    const double d1x = px - v[2 * n3[1]], d1y = py - v[2 * n3[1] + 1];
+                    const double d2x = px - v[2 * n3[2]], d2y = py - v[2 * n3[2] + 1];
+                    const double a0 = d1x * d2y - d1y * d2x, a1 = d2x * d0y - d2y * d0x, a2 = d0x * d1y - d0y * d1x;
+                    const double tot = a0 + a1 + a2;
+                    const double b0 = a0 / tot, b1 = a1 / tot, b2 = a2 / tot;
+                    if (b0 >= 0 && b1 >= 0 && b2 >= 0) {
+                        const int i0 = n3[0] % nx, j0 = n3[0] / nx, i1 = n3[1] % nx, j1 = n3[1] / nx, i2 = n3[2] % nx, j2 = n3[2] / nx;
+                        mx = b0 * xs[i0] + b1 * xs[i1] + b2 * xs[i2];
+                        my = b0 * ys[j0] + b1 * ys[j1] + b2 * ys[j2];
+                        inside = 1;
+                    }
+                }
+                map_x[base + (size_t)r * w + c] = mx; map_y[base + (size_t)r * w + c] = my; mask[base + (size_t)r * w + c] = inside;
+            }
+    }
+    return FB_OK;
+}
+
 // Mesh.tri_finder + cart2bary on the deformed grid mesh: point k belongs to pair pair_of[k] (index into vm [Q][V][2]).
 // The cell is guessed by pulling the point back with the displacement of its nearest node (two passes), then the
 // triangles of the 3 x 3 cells around it are tested in a fixed order; the first that contains the point wins.

@@ -298,10 +298,15 @@ class StripBatchMatcher:
                 lo_x, lo_y = lo[q]
                 ex = np.flatnonzero(tier == 3)
                 if ex.size:
-                    hits = dfm.tri_box_hits(vmg[q][tris], bb[q, ex] - 0.5)
-                    maps = [dfm.exact_field(vmg[q], v_init, tris, np.flatnonzero(hits[k]), int(bb[q, b, 0]), int(bb[q, b, 1]), h, w)
-                            for k, b in enumerate(ex)]
-                    emx = np.stack([a_[0] for a_ in maps]); emy = np.stack([a_[1] for a_ in maps]); emk = np.stack([a_[2] for a_ in maps])
+                    # exact piecewise-linear field of these blocks (C++; deformed.exact_field states it in numpy)
+                    po = np.zeros(ex.size, dtype=np.int32)
+                    org = np.ascontiguousarray(bb[q, ex, :2], dtype=np.int32)
+                    emx = np.empty((ex.size, h, w)); emy = np.empty((ex.size, h, w)); emk8 = np.empty((ex.size, h, w), dtype=np.uint8)
+                    vq = np.ascontiguousarray(vmg[q][None])
+                    _lib.check(lib.fb_deformed_exact_field(ctx, 1, m.grid_xs.size, m.grid_ys.size, _lib.ptr(m.grid_xs), _lib.ptr(m.grid_ys),
+                                                           _lib.ptr(vq), ex.size, _lib.ptr(po), _lib.ptr(org), h, w, _lib.ptr(emx), _lib.ptr(emy),
+                                                           _lib.ptr(emk8)))
+                    emk = emk8.astype(bool)
                     if emk.any():
                         lo_x = min(lo_x, emx[emk].min()); lo_y = min(lo_y, emy[emk].min())
                     exact.append((q, ex, emx, emy, emk))

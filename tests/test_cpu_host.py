@@ -303,3 +303,16 @@ def test_cxx_deformed_geometry_matches_numpy():
         ok = t2 >= 0
         np.testing.assert_allclose(B[s_][ok], B2[ok], atol=1e-12)
     assert 0 < (tid < 0).sum() < K // 2
+    # exact field of a few blocks (inside, corners) of pair 1
+    h, w = 38, 40
+    org = np.array([[40, 200], [-6, -5], [90, 1500], [60, 700]], dtype=np.int32)
+    po = np.ones(4, np.int32)
+    mx = np.empty((4, h, w)); my = np.empty((4, h, w)); mk = np.empty((4, h, w), np.uint8)
+    assert lib.fb_deformed_exact_field(None, Q, xs.size, ys.size, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(vm), 4, _lib.ptr(po), _lib.ptr(org), h, w,
+                                       _lib.ptr(mx), _lib.ptr(my), _lib.ptr(mk)) == 0
+    for e in range(4):
+        hit = deformed.tri_box_hits(vm[1][tri], np.array([[org[e, 0], org[e, 1], org[e, 0] + w, org[e, 1] + h]]) - 0.5)[0]
+        a, b, c = deformed.exact_field(vm[1], v, tri, np.flatnonzero(hit), int(org[e, 0]), int(org[e, 1]), h, w)
+        np.testing.assert_array_equal(c, mk[e].astype(bool))
+        np.testing.assert_array_equal(a[c], mx[e][c]); np.testing.assert_array_equal(b[c], my[e][c])
+    assert 0 < mk.mean() < 1
