@@ -191,9 +191,10 @@ def stitching_matcher(img0, img1, **kwargs):
 
     The whole sequence runs on the device through the batch pipeline (``stitch_pipeline.StripBatchMatcher`` with a batch
     of one; callers with many pairs should use the batch class directly).  Supported: equal-shape 2-D uint8 strips,
-    ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, unmasked images; mesh relaxations
-    between spacings of any shape (rigid or deformed mesh1).  Anything the device path does not cover (masks, photometric
-    statistics, explicit spacings) raises NotImplementedError instead of silently taking another route."""
+    ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, optional masks (mask0 / mask1, True =
+    valid pixel) and photometric statistics; mesh relaxations between spacings of any shape (rigid or deformed mesh1).
+    Anything the device path does not cover (explicit spacings, fine_downsample != 1, a threshold residue mode) raises
+    NotImplementedError instead of silently taking another route."""
     from .stitch_pipeline import StripBatchMatcher
     kw = dict(kwargs)
     sigma = kw.pop('sigma', 2.5)
@@ -206,11 +207,13 @@ def stitching_matcher(img0, img1, **kwargs):
     residue_mode = kw.pop('residue_mode', 'huber')
     stiffness_lambda = kw.pop('stiffness_lambda', 1)
     compute_strain = kw.pop('compute_strain', True)
-    for name in ('mask0', 'mask1', 'spacings'):
-        if kw.pop(name, None) is not None:
-            raise NotImplementedError(f'stitching_matcher({name}=...) is not on the device path')
-    if kw.pop('compute_photometric', False):
-        raise NotImplementedError('stitching_matcher(compute_photometric=True) is not on the device path')
+    mask0 = kw.pop('mask0', None)
+    mask1 = kw.pop('mask1', None)
+    if kw.pop('spacings', None) is not None:
+        raise NotImplementedError('stitching_matcher(spacings=...) is not on the device path')
+    compute_photometric = bool(kw.pop('compute_photometric', False))
+    if compute_photometric and not sigma > 0:
+        raise NotImplementedError('stitching_matcher(compute_photometric=True) needs sigma > 0 on the device path')
     kw.pop('opt_tol', None); kw.pop('pad', None)
     if kw:
         raise NotImplementedError(f'stitching_matcher: unsupported options {sorted(kw)}')
@@ -239,9 +242,14 @@ def stitching_matcher(img0, img1, **kwargs):
         _pair_matchers[key] = _pair_matchers.pop(key)              # most recently used last
     d0 = _lib.DeviceBuffer.from_array(img0); d1 = _lib.DeviceBuffer.from_array(img1)
     try:
-        res = StripBatchMatcher.per_pair(m.match(d0.ptr, d1.ptr))[0]
+        for name, mk in (('mask0', mask0), ('mask1', mask1)):
+            if mk is not None and np.asarray(mk).shape != (H, W):
+                raise ValueError(f'stitching_matcher: {name} must have the shape of its strip')
+        out = m.match(d0.ptr, d1.ptr, masks0=None if mask0 is None else [mask0], masks1=None if mask1 is None else [mask1],
+                      compute_photometric=compute_photometric)
+        res = StripBatchMatcher.per_pair(out)[0]
     finally:
         d0.free(); d1.free()
     if res['xy0'] is None:
         return None, None, conf_thresh, None, None
-    return res['xy0'], res['xy1'], res['weight'], res['strain'], None
+    return res['xy0'], res['xy1'], res['weight'], res['strain'], (out['phtm'][0] if compute_photometric else None)

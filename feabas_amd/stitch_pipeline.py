@@ -107,7 +107,19 @@ class StripBatchMatcher:
             delattr(self, name)
 
     # ------------------------------------------------------------------ stages
-    def _global(self, strips0, strips1):
+    def _masked_dog(self, src_ptr, dtype, h, w, sigma, mask, dst_ptr):
+        """common.masked_dog_filter(img, sigma, mask=mask) (common.py:353-377) of ONE resident image into its slot"""
+        lib, ctx = _lib.load(), _lib.ctx()
+        mk = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        assert mk.shape == (h, w)
+        d_m = _lib.DeviceBuffer.from_array(mk)
+        try:
+            _lib.check(lib.fb_dog_dev(ctx, src_ptr, dtype, 1, h, w, sigma, d_m.ptr, 1, dst_ptr))
+            _lib.check(lib.fb_sync(ctx))
+        finally:
+            d_m.free()
+
+    def _global(self, strips0, strips1, masks=None):
         lib, ctx = _lib.load(), _lib.ctx()
         n, H, W, hc, wc = self.P, self.H, self.W, self.hc, self.wc
         if self.cds == 0.5:
@@ -117,6 +129,16 @@ class StripBatchMatcher:
         else:
             _lib.check(lib.fb_dog_dev(ctx, strips0, 0, n, hc, wc, self.sigma, None, 1, self.d_dogc.ptr))
             _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, hc, wc, self.sigma, None, 1, self.d_dogc.offset(n * hc * wc * 4)))
+        if masks is not None:
+            # masked pairs: the coarse DoG of their images again, with the halo suppression of common.py:368-374; the
+            # coarse mask is cv2.resize(mask, fx=0.5, INTER_NEAREST) = every second pixel (matcher.py:257-264)
+            for side, (strips, mlist) in enumerate(((strips0, masks[0]), (strips1, masks[1]))):
+                for p, mk in enumerate(mlist):
+                    if mk is None:
+                        continue
+                    mg = np.asarray(mk)[::2, ::2] if self.cds == 0.5 else np.asarray(mk)
+                    src = self.d_small.offset((side * n + p) * hc * wc) if self.cds == 0.5 else C.c_void_p(strips + p * H * W)
+                    self._masked_dog(src, 0, hc, wc, self.sigma * self.cds, mg, self.d_dogc.offset((side * n + p) * hc * wc * 4))
         _lib.check(lib.fb_ncc_batch_dev(ctx, self.d_dogc.ptr, self.d_dogc.offset(n * hc * wc * 4), n, 1, hc, wc, hc, wc,
                                         1, 0, self.conf_mode, self.d_out.ptr, self.d_out.offset(8 * n), self.d_out.offset(16 * n)))
         tx, ty, cf = (np.array(a) for a in self._fetch_out(n))    # equal strip sizes: (W1-W0)/2 = 0 (matcher.py:155-156)
@@ -139,7 +161,7 @@ class StripBatchMatcher:
         raw = self.d_out.to_array((20 * nb,), np.uint8)
         return raw[:8 * nb].view(np.float64), raw[8 * nb:16 * nb].view(np.float64), raw[16 * nb:].view(np.float32)
 
-    def _fine_dog(self, strips0, strips1):
+    def _fine_dog(self, strips0, strips1, masks=None):
         lib, ctx = _lib.load(), _lib.ctx()
         n, H, W = self.P, self.H, self.W
         if self.cds == 1:
@@ -147,7 +169,47 @@ class StripBatchMatcher:
             return
         _lib.check(lib.fb_dog_dev(ctx, strips0, 0, n, H, W, self.sigma, None, 1, self.d_dogf.ptr))
         _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, H, W, self.sigma, None, 1, self.d_dogf.offset(n * H * W * 4)))
+        if masks is not None:
+            for side, (strips, mlist) in enumerate(((strips0, masks[0]), (strips1, masks[1]))):
+                for p, mk in enumerate(mlist):
+                    if mk is not None:
+                        self._masked_dog(C.c_void_p(strips + p * H * W), 0, H, W, self.sigma, mk, self.d_dogf.offset((side * n + p) * H * W * 4))
         self.d_dogf_view = self.d_dogf
+
+    def _photometric(self, strips0, strips1, tx_c, ty_c, masks):
+        """matcher.py:279-314 (sigma > 0) for every pair: mean grey level of the raw coarse images and mean |DoG| of the
+        filtered ones over the overlap of the translated bounding boxes.  Host numpy on downloaded coarse images, like
+        the reference; tx_c, ty_c: the global translation at the coarse scale."""
+        n, H, W, hc, wc = self.P, self.H, self.W, self.hc, self.wc
+        if self.cds == 0.5:
+            raw = self.d_small.to_array((2 * n, hc, wc), np.uint8)
+        else:
+            raw = np.empty((2 * n, hc, wc), dtype=np.uint8)
+            for side, strips in enumerate((strips0, strips1)):
+                _lib.check(_lib.load().fb_memcpy_d2h(_lib.ctx(), _lib.ptr(raw[side * n:(side + 1) * n]), C.c_void_p(strips), n * hc * wc))
+        dog = self.d_dogc.to_array((2 * n, hc, wc), np.float32)
+        out = []
+        for p in range(n):
+            txx, tyy = int(tx_c[p]), int(ty_c[p])
+            xa, ya = max(txx, 0), max(tyy, 0)
+            xb, yb = min(wc + txx, wc), min(hc + tyy, hc)
+            i0 = (slice(ya - tyy, yb - tyy), slice(xa - txx, xb - txx)); i1 = (slice(ya, yb), slice(xa, xb))
+            shape = (max(yb - ya, 0), max(xb - xa, 0))
+
+            def coarse(mk):
+                if mk is None:
+                    return None
+                return np.asarray(mk, dtype=bool)[::2, ::2] if self.cds == 0.5 else np.asarray(mk, dtype=bool)
+            mg0 = coarse(masks[0][p]) if masks is not None else None
+            mg1 = coarse(masks[1][p]) if masks is not None else None
+            m0 = np.ones(shape, dtype=bool) if mg0 is None else mg0[i0]
+            m1 = np.ones(shape, dtype=bool) if mg1 is None else mg1[i1]
+            mp = m0 & m1
+            if np.sum(m0) <= 3:
+                out.append(None)
+                continue
+            out.append((np.mean(raw[p][i0][mp]), np.mean(raw[n + p][i1][mp]), np.mean(np.abs(dog[p][i0][mp])), np.mean(np.abs(dog[n + p][i1][mp]))))
+        return out
 
     def _blocks(self, tx, ty, t1, sel, spacing, mnb, bounds=None):
         """block descriptors for the pairs `sel` (all share Nx, Ny): returns (blk [Q, nblk, 9], bboxes [Q, nblk, 4]).
@@ -634,18 +696,30 @@ class StripBatchMatcher:
             B1[g] = Bg
         return nodes3, B1
 
-    def match(self, strips0, strips1):
-        """strips0/strips1: device pointers to uint8 [P][H][W].  Returns a dict of arrays:
+    def match(self, strips0, strips1, masks0=None, masks1=None, compute_photometric=False):
+        """strips0/strips1: device pointers to uint8 [P][H][W].  masks0/masks1: optional lists of P host arrays (H x W,
+        non-zero = valid pixel) or None entries -- the masked DoG of matcher.py:257-274, 336-337.  compute_photometric:
+        result['phtm'] = per pair (av0, av1, std0, std1) of matcher.py:279-314.  Returns a dict of arrays:
         tx, ty, conf0, valid, needs_host, deformed [P]; the match table as flat arrays pair, xy0, xy1, weight
         (rows of one pair are contiguous, pairs in ascending order within a block-grid group).  `needs_host` is kept
         for callers of earlier versions and is always False: pairs whose mesh relaxation between spacings is not a rigid
         translation are `deformed` and stay on the device path."""
         n = self.P
-        tx, ty, cf0 = self._global(strips0, strips1)
+        strips0 = strips0.value if hasattr(strips0, 'value') else strips0
+        strips1 = strips1.value if hasattr(strips1, 'value') else strips1
+        masks = None
+        if masks0 is not None or masks1 is not None:
+            masks = (list(masks0) if masks0 is not None else [None] * n, list(masks1) if masks1 is not None else [None] * n)
+            # a mask without a zero changes nothing (common.py:368)
+            masks = tuple([None if (mk is None or np.all(mk)) else mk for mk in ml] for ml in masks)
+            if all(mk is None for ml in masks for mk in ml):
+                masks = None
+        tx, ty, cf0 = self._global(strips0, strips1, masks)
+        phtm = self._photometric(strips0, strips1, tx, ty, masks) if compute_photometric else None
         scale = 1.0 / self.cds
         tx = tx * scale; ty = ty * scale                     # matcher.py:338-339
         active = cf0 >= self.conf_thresh                     # matcher.py:277-278
-        self._fine_dog(strips0, strips1)
+        self._fine_dog(strips0, strips1, masks)
         spacings = self.spacings
         pad = np.ones(n, dtype=bool)
         has_last = np.zeros(n, dtype=bool)
@@ -781,7 +855,7 @@ class StripBatchMatcher:
         strain = self._strain(pid, xy0, xy1, wt, txy, reuse_links=bool(last_links)) if self.compute_strain else np.full(n, DEFAULT_AVG_DEFORM)
         self.last_field = U
         return dict(tx=tx, ty=ty, conf0=cf0, valid=valid, needs_host=np.zeros(n, dtype=bool), deformed=is_deformed, pair=pid, xy0=xy0, xy1=xy1,
-                    weight=wt, strain=strain)
+                    weight=wt, strain=strain, phtm=phtm)
 
     @staticmethod
     def per_pair(res):

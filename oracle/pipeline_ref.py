@@ -268,27 +268,53 @@ def relax_deformed(m0, m1, xs, ys, xy0, xy1, weight, residue_len, resolve):
     return link, ok
 
 
+def photometric(raw0, raw1, g0, g1, tx0, ty0, mask0_g=None, mask1_g=None):
+    """matcher.py:279-314 with sigma > 0: mean grey level of the two raw coarse images and mean |DoG| of the filtered ones
+    over the overlap of the translated bounding boxes (both masks applied)."""
+    txx, tyy = int(tx0), int(ty0)
+    bb0 = (txx, tyy, g0.shape[1] + txx, g0.shape[0] + tyy)
+    bb1 = (0, 0, g1.shape[1], g1.shape[0])
+    (xa, ya, xb, yb), _ = ncc_ref.intersect_bbox(bb0, bb1)
+    xa, ya, xb, yb = int(xa), int(ya), int(xb), int(yb)
+    i0 = (slice(ya - tyy, yb - tyy), slice(xa - txx, xb - txx))
+    i1 = (slice(ya, yb), slice(xa, xb))
+    m0 = np.ones((yb - ya, xb - xa), dtype=bool) if mask0_g is None else mask0_g[i0]
+    m1 = np.ones((yb - ya, xb - xa), dtype=bool) if mask1_g is None else mask1_g[i1]
+    mp = m0 & m1
+    if np.sum(m0) <= 3:
+        return None
+    return (np.mean(raw0[i0][mp]), np.mean(raw1[i1][mp]), np.mean(np.abs(g0[i0][mp])), np.mean(np.abs(g1[i1][mp])))
+
+
 def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
-               conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0):
-    """strip0/strip1: uint8 H x W overlap strips.  Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host)."""
+               conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0, mask0=None, mask1=None, compute_photometric=False):
+    """strip0/strip1: uint8 H x W overlap strips (mask0/mask1: bool, True = valid pixel).
+    Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host, strain, phtm, ...)."""
     H, W = strip0.shape
     if coarse_downsample == 0.5:
         g0 = ncc_ref.area_downsample2(strip0)
         g1 = ncc_ref.area_downsample2(strip1)
+        # cv2.resize(mask, fx=0.5, INTER_NEAREST) (matcher.py:257-264): source pixel floor(dst / 0.5) (UNPINNED)
+        mask0_g = None if mask0 is None else np.asarray(mask0, dtype=bool)[::2, ::2]
+        mask1_g = None if mask1 is None else np.asarray(mask1, dtype=bool)[::2, ::2]
     else:
         g0, g1 = strip0, strip1
-    g0 = ncc_ref.masked_dog_filter(g0, sigma * coarse_downsample)          # matcher.py:273-274
-    g1 = ncc_ref.masked_dog_filter(g1, sigma * coarse_downsample)
+        mask0_g, mask1_g = mask0, mask1
+    raw0, raw1 = g0, g1
+    g0 = ncc_ref.masked_dog_filter(g0, sigma * coarse_downsample, mask=mask0_g)          # matcher.py:273-274
+    g1 = ncc_ref.masked_dog_filter(g1, sigma * coarse_downsample, mask=mask1_g)
     tx, ty, conf0 = ncc_ref.global_translation_matcher(g0, g1, conf_mode=conf_mode, conf_thresh=conf_thresh)
     res = dict(tx=tx / coarse_downsample, ty=ty / coarse_downsample, conf0=conf0, xy0=None, xy1=None, weight=None,
-               needs_host=False, strain=0.05)
+               needs_host=False, strain=0.05, phtm=None)
     if conf0 < conf_thresh:                                                  # matcher.py:277-278
         return res
+    if compute_photometric:
+        res['phtm'] = photometric(raw0, raw1, g0, g1, tx, ty, mask0_g, mask1_g)
     if coarse_downsample == 1:
         f0, f1 = g0, g1
     else:
-        f0 = ncc_ref.masked_dog_filter(strip0, sigma)                        # matcher.py:336-337
-        f1 = ncc_ref.masked_dog_filter(strip1, sigma)
+        f0 = ncc_ref.masked_dog_filter(strip0, sigma, mask=mask0)            # matcher.py:336-337
+        f1 = ncc_ref.masked_dog_filter(strip1, sigma, mask=mask1)
     tx, ty = res['tx'], res['ty']
     spacings = np.sort(ncc_ref.auto_spacings((H, W), (H, W)))[::-1]
     bbox0 = (-0.5 + tx, -0.5 + ty, W - 0.5 + tx, H - 0.5 + ty)              # Mesh.from_bbox + apply_translation

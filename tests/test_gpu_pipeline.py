@@ -269,7 +269,7 @@ def test_stitching_matcher_drop_in(fb):
     out = fb.matcher.stitching_matcher(h0[0], h1[1][::-1].copy(), sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33)
     assert out[0] is None and out[1] is None and out[2] == 0.33 and out[3] is None and out[4] is None
     with pytest.raises(NotImplementedError):
-        fb.matcher.stitching_matcher(h0[0], h1[0], mask0=np.ones((H, W), bool))
+        fb.matcher.stitching_matcher(h0[0], h1[0], spacings=[100.0])
 
 
 @pytest.mark.parametrize('H,W', [(3000, 500), (400, 4000)])
@@ -469,3 +469,26 @@ def test_pipeline_three_spacings_deformed_twice_vs_oracle(fb):
         np.testing.assert_allclose(g['weight'], exp['weight'], atol=2e-3)
         np.testing.assert_allclose(g['strain'], exp['strain'], rtol=5e-3, atol=1e-6)
     m.free(); d0.free(); d1.free()
+
+
+def test_stitching_matcher_masks_and_photometric(fb):
+    """mask0 / mask1 (masked DoG with halo suppression at both scales, matcher.py:257-274, 336-337; the coarse mask is
+    every second pixel) and compute_photometric (279-314) through the per-pair surface, against the oracle"""
+    H, W = 1024, 256
+    s0, s1 = _warped_pair(H, W, 77, shift=(-5, 3), warp=0.3)
+    mask0 = np.ones((H, W), dtype=bool); mask0[100:180, 30:120] = False; mask0[700:, :40] = False
+    mask1 = np.ones((H, W), dtype=bool); mask1[400:520, 150:] = False
+    s0 = s0.copy(); s0[~mask0] = 0
+    s1 = s1.copy(); s1[~mask1] = 0
+    for m0, m1 in ((mask0, mask1), (None, mask1), (np.ones((H, W), bool), None)):
+        xy0, xy1, wt, strain, phtm = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2,
+                                                                   mask0=m0, mask1=m1, compute_photometric=True)
+        exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0, mask0=m0, mask1=m1, compute_photometric=True)
+        assert xy0.shape == exp['xy0'].shape and xy0.shape[0] > 20
+        np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
+        np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
+        np.testing.assert_allclose(phtm, exp['phtm'], rtol=1e-5)
+    # the masks matter: without them the blanked regions change the filtered images
+    plain = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+    masked = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2, mask0=mask0, mask1=mask1)
+    assert plain[4] is None and (plain[0].shape != masked[0].shape or np.abs(plain[2] - masked[2]).max() > 1e-3)
