@@ -193,7 +193,7 @@ def stitching_matcher(img0, img1, **kwargs):
     of one; callers with many pairs should use the batch class directly).  Supported: equal-shape 2-D uint8 strips,
     ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, optional masks (mask0 / mask1, True =
     valid pixel) and photometric statistics; mesh relaxations between spacings of any shape (rigid or deformed mesh1).
-    Anything the device path does not cover (explicit spacings, fine_downsample != 1, a threshold residue mode) raises
+    Explicit ``spacings`` are taken in pixels.  Anything the device path does not cover (spacings < 1, fine_downsample != 1, a threshold residue mode) raises
     NotImplementedError instead of silently taking another route."""
     from .stitch_pipeline import StripBatchMatcher
     kw = dict(kwargs)
@@ -209,8 +209,11 @@ def stitching_matcher(img0, img1, **kwargs):
     compute_strain = kw.pop('compute_strain', True)
     mask0 = kw.pop('mask0', None)
     mask1 = kw.pop('mask1', None)
-    if kw.pop('spacings', None) is not None:
-        raise NotImplementedError('stitching_matcher(spacings=...) is not on the device path')
+    spacings = kw.pop('spacings', None)
+    if spacings is not None:
+        spacings = np.asarray(spacings, dtype=np.float64).ravel()
+        if spacings.size == 0 or np.any(spacings < 1):
+            raise NotImplementedError('stitching_matcher: spacings relative to the overlap (< 1) are not on the device path')
     compute_photometric = bool(kw.pop('compute_photometric', False))
     if compute_photometric and not sigma > 0:
         raise NotImplementedError('stitching_matcher(compute_photometric=True) needs sigma > 0 on the device path')
@@ -228,12 +231,12 @@ def stitching_matcher(img0, img1, **kwargs):
         raise NotImplementedError('stitching_matcher: coarse_downsample = 0.5 needs even strip sizes (cv2.resize(INTER_AREA) at a '
                                   'non-integer ratio is not restated)')
     key = (H, W, float(sigma), coarse_downsample, float(conf_thresh), int(min_num_blocks), int(conf_mode), float(residue_len),
-           float(stiffness_lambda), bool(compute_strain), id(_lib.ctx()))
+           float(stiffness_lambda), bool(compute_strain), None if spacings is None else tuple(spacings.tolist()), id(_lib.ctx()))
     m = _pair_matchers.get(key)
     if m is None:
         m = StripBatchMatcher(1, H, W, sigma=sigma, coarse_downsample=coarse_downsample, conf_thresh=conf_thresh,
                               min_num_blocks=min_num_blocks, conf_mode=conf_mode, residue_len=residue_len,
-                              stiffness_lambda=stiffness_lambda, compute_strain=compute_strain)
+                              stiffness_lambda=stiffness_lambda, compute_strain=compute_strain, spacings=spacings)
         # strip shapes vary from pair to pair (stitcher.py:561-571): keep the device buffers of a few recent shapes only
         while len(_pair_matchers) >= _PAIR_MATCHER_CACHE:
             _pair_matchers.pop(next(iter(_pair_matchers))).free()

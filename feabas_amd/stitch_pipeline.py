@@ -66,7 +66,7 @@ def _z_order_batch(ix, iy):
 
 class StripBatchMatcher:
     def __init__(self, P, H, W, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
-                 conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9, compute_strain=True):
+                 conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9, compute_strain=True, spacings=None):
         assert coarse_downsample in (0.5, 1)
         assert H % 2 == 0 and W % 2 == 0 or coarse_downsample == 1
         self.P, self.H, self.W = int(P), int(H), int(W)
@@ -75,7 +75,12 @@ class StripBatchMatcher:
         self.conf_thresh = float(conf_thresh)
         self.mnb = int(min_num_blocks)
         self.conf_mode = int(conf_mode)
-        self.spacings = np.sort(auto_spacings((H, W), (H, W)))[::-1]     # matcher.py:243-251, 567
+        if spacings is None:
+            self.spacings = np.sort(auto_spacings((H, W), (H, W)))[::-1]     # matcher.py:243-251, 567
+        else:
+            self.spacings = np.sort(np.asarray(spacings, dtype=np.float64).ravel())[::-1]
+            if self.spacings.size == 0 or np.any(self.spacings < 1):
+                raise NotImplementedError('spacings relative to the overlap (< 1, matcher.py:343-350) are not on the device path')
         self._nfl = np.array([next_fast_len(v) for v in range(0, 2 * max(H, W) + 2)])
         hc, wc = (H // 2, W // 2) if coarse_downsample == 0.5 else (H, W)
         self.hc, self.wc = hc, wc

@@ -287,7 +287,7 @@ def photometric(raw0, raw1, g0, g1, tx0, ty0, mask0_g=None, mask1_g=None):
 
 
 def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
-               conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0, mask0=None, mask1=None, compute_photometric=False):
+               conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0, mask0=None, mask1=None, compute_photometric=False, spacings=None):
     """strip0/strip1: uint8 H x W overlap strips (mask0/mask1: bool, True = valid pixel).
     Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host, strain, phtm, ...)."""
     H, W = strip0.shape
@@ -316,7 +316,7 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
         f0 = ncc_ref.masked_dog_filter(strip0, sigma, mask=mask0)            # matcher.py:336-337
         f1 = ncc_ref.masked_dog_filter(strip1, sigma, mask=mask1)
     tx, ty = res['tx'], res['ty']
-    spacings = np.sort(ncc_ref.auto_spacings((H, W), (H, W)))[::-1]
+    spacings = np.sort(ncc_ref.auto_spacings((H, W), (H, W)) if spacings is None else np.asarray(spacings, dtype=np.float64))[::-1]
     bbox0 = (-0.5 + tx, -0.5 + ty, W - 0.5 + tx, H - 0.5 + ty)              # Mesh.from_bbox + apply_translation
     pad = True
     itx, ity = int(round(tx)), int(round(ty))

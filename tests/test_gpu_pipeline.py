@@ -269,7 +269,13 @@ def test_stitching_matcher_drop_in(fb):
     out = fb.matcher.stitching_matcher(h0[0], h1[1][::-1].copy(), sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33)
     assert out[0] is None and out[1] is None and out[2] == 0.33 and out[3] is None and out[4] is None
     with pytest.raises(NotImplementedError):
-        fb.matcher.stitching_matcher(h0[0], h1[0], spacings=[100.0])
+        fb.matcher.stitching_matcher(h0[0], h1[0], spacings=[0.5])
+    # explicit spacings in pixels (matcher.py:252-253)
+    xy0, xy1, wt, strain, _ = fb.matcher.stitching_matcher(h0[0], h1[0], sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, spacings=[60.0, 200.0])
+    exp = pipeline_ref.match_pair(h0[0], h1[0], spacings=[60.0, 200.0])
+    assert xy0.shape == exp['xy0'].shape
+    np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
+    np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
 
 
 @pytest.mark.parametrize('H,W', [(3000, 500), (400, 4000)])
