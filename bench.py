@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fem-grid', type=int, default=708)
     ap.add_argument('--fem-iters', type=int, default=200)
+    ap.add_argument('--fem-cpu-iters', type=int, default=40, help='iterations of the CPU baseline PCG (about 0.1 s each at 1e6 DoF)')
     return ap.parse_args()
 
 
@@ -137,6 +138,30 @@ def bench_fem(args, lib, ctx, _lib):
                assemble_numeric_s=t_asm, assemble_first_s=t_asm_first,
                spmv_kernel_us=1e3 * k1[1] / max(k1[0], 1), update_kernel_us=1e3 * k2[1] / max(k2[0], 1),
                spmv_kernel_gbs=spmv_bytes / max(1e-9, (k1[1] / max(k1[0], 1)) * 1e-3) / 1e9, x=x)
+    if not args.no_cpu_baseline:
+        # reported baseline: the same A, b through the oracle's Jacobi-PCG on scipy CSR, one host thread
+        # (scipy's SpMV is single threaded), a bounded number of iterations
+        from feabas_amd.mesh import bsr_download
+        from oracle import fem_ref
+        A = bsr_download(slm._sys, 4, nv.value, nnzb.value)
+        b = np.empty(n)
+        _lib.check(lib.fb_sys_get(ctx, slm._sys, 5, _lib.ptr(b)))
+        t0 = time.time()
+        _, cit, _ = fem_ref.pcg(A, b, rtol=1e-30, maxiter=args.fem_cpu_iters)
+        cdt = time.time() - t0
+        out['cpu_baseline'] = dict(value=cit / cdt, unit='PCG iterations/s', cores=1, kind='port',
+                                   sample=f'{cit} iterations of oracle/fem_ref.pcg (scipy CSR, {A.nnz} non-zeros) on the same system, {cdt:.1f} s')
+    # hard variant: 5 k links, about one per 100 nodes -- the elastic term carries the solution
+    # across the mesh, >= 1e3 iterations
+    del slm
+    hard = build_fem_system(args.fem_grid, 5000, seed=1)
+    hard._assemble(0, 1, 1)
+    sl, cl = hard.relative_lambda_trace(1.0, -1.0)
+    _lib.check(lib.fb_sys_form(ctx, hard._sys, sl, cl))
+    xh = np.zeros(n)
+    t0 = time.time()
+    rc = lib.fb_sys_solve(ctx, hard._sys, _lib.ptr(xh), 0, 1e-4, 0.0, 20000, 1, C.byref(it), C.byref(rr))
+    out['hard_5k_links'] = dict(solve_to_1e4_s=time.time() - t0, solve_iters=it.value, solve_relres=rr.value, converged=bool(rc == 0))
     return out
 
 
