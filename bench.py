@@ -171,7 +171,9 @@ def bench_xcorr_classes(lib, ctx, _lib):
     out = {}
     rng = np.random.default_rng(1)
     for name, (N, h, w, pad, sub) in {'fine_75x73_fft75x75': (24640, 75, 73, 0, 1), 'coarse_1024x510_fft2048x1024': (128, 1024, 510, 1, 0),
-                                      'global_2048x255_fft4096x512': (32, 2048, 255, 1, 0)}.items():
+                                      'global_2048x255_fft4096x512': (32, 2048, 255, 1, 0),
+                                      # literal stress variant of SURVEY.md sec.8d: whole 4096 x 4096 tiles
+                                      'full_4096x4096_fft4096x4096': (4, 4096, 4096, 0, 1), 'full_4096x4096_fft8192x8192_padded': (4, 4096, 4096, 1, 1)}.items():
         a = rng.standard_normal((min(N, 256), h, w)).astype(np.float32)
         a = np.tile(a, (-(-N // a.shape[0]), 1, 1))[:N]
         d0 = _lib.DeviceBuffer.from_array(a); d1 = _lib.DeviceBuffer.from_array(np.roll(a, (2, -3), (1, 2)))
