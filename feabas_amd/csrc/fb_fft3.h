@@ -37,15 +37,46 @@ __device__ __forceinline__ void pk_dft5(f2* v) {
     v[2] = INV ? pk_add_pi(m2, n2) : pk_add_mi(m2, n2);
     v[3] = INV ? pk_add_mi(m2, n2) : pk_add_pi(m2, n2);
 }
+// exp(-2 pi i m / n) as a compile-time constant pair
+template <int M_, int N_>
+__device__ __forceinline__ f2 pk_wconst() {
+    constexpr double a = -6.283185307179586476925286766559 * (double)M_ / (double)N_;
+    return (f2){(float)__builtin_cos(a), (float)__builtin_sin(a)};
+}
+// 9-point DFT as 3 x 3 Cooley-Tukey in registers (natural order in and out): n = 3 n1 + n2, k = k1 + 3 k2
+template <bool INV>
+__device__ __forceinline__ void pk_dft9(f2* v) {
+    f2 y[3][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 3; ++n2) {
+#pragma unroll
+        for (int n1 = 0; n1 < 3; ++n1) y[n2][n1] = v[3 * n1 + n2];
+        pk_dft3<INV>(y[n2]);
+    }
+    y[1][1] = INV ? pk_cmulc(y[1][1], pk_wconst<1, 9>()) : pk_cmul(y[1][1], pk_wconst<1, 9>());
+    y[1][2] = INV ? pk_cmulc(y[1][2], pk_wconst<2, 9>()) : pk_cmul(y[1][2], pk_wconst<2, 9>());
+    y[2][1] = INV ? pk_cmulc(y[2][1], pk_wconst<2, 9>()) : pk_cmul(y[2][1], pk_wconst<2, 9>());
+    y[2][2] = INV ? pk_cmulc(y[2][2], pk_wconst<4, 9>()) : pk_cmul(y[2][2], pk_wconst<4, 9>());
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+        f2 z[3] = {y[0][k1], y[1][k1], y[2][k1]};
+        pk_dft3<INV>(z);
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) v[k1 + 3 * k2] = z[k2];
+    }
+}
 template <int R, bool INV>
 __device__ __forceinline__ void pk_dft_any(f2* v) {
     if (R == 3) pk_dft3<INV>(v);
     else if (R == 5) pk_dft5<INV>(v);
+    else if (R == 9) pk_dft9<INV>(v);
     else pk_dft<R, INV>(v);
 }
 
 // radix of pass s (DIF order) of fft_make_plan(N, ., MAXR), and the block length that pass works on
 constexpr int p3_pick(int m, int maxr) {
+    if (maxr == 9)           // the plans of fft_make_plan(., ., 9): 8, 9, then 4 / 2 / 5 / 3
+        return (m % 8 == 0) ? 8 : (m % 9 == 0) ? 9 : (m % 4 == 0) ? 4 : (m % 2 == 0) ? 2 : (m % 5 == 0) ? 5 : 3;
     return (maxr >= 16 && m % 16 == 0) ? 16 : (maxr >= 8 && m % 8 == 0) ? 8 : (m % 4 == 0) ? 4 : (m % 2 == 0) ? 2 : (m % 5 == 0) ? 5 : 3;
 }
 constexpr int p3_nf(int N, int maxr) { int m = N, c = 0; while (m > 1) { m /= p3_pick(m, maxr); ++c; } return c; }

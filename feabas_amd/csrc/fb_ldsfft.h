@@ -19,11 +19,18 @@ struct FftPlan {
     int radix[kFftMaxFactors];      // in forward (DIF) order
 };
 
-// host: factor n (5-smooth) preferring radix 4
+// host: factor n (5-smooth) preferring radix 4.  max_radix = 9 selects the plans of the compile-time small core
+// (fb_fft3.h): the composite odd radix 9 next to 8 / 4 / 2 / 5 / 3 -- 72 = 8 x 9, 81 = 9 x 9 (a radix 15 for 75 was
+// measured too: its registers cost the occupancy it saves in LDS passes).
 static inline bool fft_make_plan(int n, FftPlan* p, int max_radix = 16) {
     p->n = n;
     p->nf = 0;
     int m = n;
+    if (max_radix == 9) {
+        while (m % 8 == 0) { p->radix[p->nf++] = 8; m /= 8; if (p->nf >= kFftMaxFactors) return false; }
+        while (m % 9 == 0) { p->radix[p->nf++] = 9; m /= 9; if (p->nf >= kFftMaxFactors) return false; }
+        max_radix = 4;
+    }
     while (max_radix >= 16 && m % 16 == 0) { p->radix[p->nf++] = 16; m /= 16; if (p->nf >= kFftMaxFactors) return false; }
     while (max_radix >= 8 && m % 8 == 0) { p->radix[p->nf++] = 8; m /= 8; if (p->nf >= kFftMaxFactors) return false; }
     while (m % 4 == 0) { p->radix[p->nf++] = 4; m /= 4; if (p->nf >= kFftMaxFactors) return false; }

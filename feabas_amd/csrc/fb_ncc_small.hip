@@ -54,17 +54,17 @@ __device__ __forceinline__ void merge_peak(float& v, int& i, float v2, int i2) {
 }
 
 // The fine-block lengths that occur around the default spacings (blocks of 64..100 px, matcher.py:243-251) run on
-// the compile-time packed core (fb_fft3.h, plans of fft_make_plan(n, ., 8)); anything else on the generic core.
+// the compile-time packed core (fb_fft3.h, plans of fft_make_plan(n, ., 9)); anything else on the generic core.
 #define FB_SMALL_FFT(LEN, INV, COLS, M, TW, ELSE)                                                            \
     switch (LEN) {                                                                                           \
-        case 64: p3_fft<64, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
-        case 72: p3_fft<72, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
-        case 75: p3_fft<75, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
-        case 80: p3_fft<80, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
-        case 81: p3_fft<81, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
-        case 90: p3_fft<90, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
-        case 96: p3_fft<96, 8, INV, COLS>(Gp, M, RS, TW); break;                                             \
-        case 100: p3_fft<100, 8, INV, COLS>(Gp, M, RS, TW); break;                                           \
+        case 64: p3_fft<64, 9, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 72: p3_fft<72, 9, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 75: p3_fft<75, 9, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 80: p3_fft<80, 9, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 81: p3_fft<81, 9, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 90: p3_fft<90, 9, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 96: p3_fft<96, 9, INV, COLS>(Gp, M, RS, TW); break;                                             \
+        case 100: p3_fft<100, 9, INV, COLS>(Gp, M, RS, TW); break;                                           \
         default: ELSE; break;                                                                                \
     }
 
@@ -314,9 +314,9 @@ int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, in
     p.N = N; p.Fh = Fh; p.Fw = Fw; p.Sw = Fw / 2 + 1; p.RS = small_pitch(Fw);
     p.H0 = H0; p.W0 = W0; p.H1 = H1; p.W1 = W1;
     p.subpixel = subpixel; p.conf_mode = conf_mode;
-    // positions (posW) must follow the plan the FFT of that length actually runs: radix <= 8 on the compile-time
+    // positions (posW) must follow the plan the FFT of that length actually runs: radices 9 / 8 / ... on the compile-time
     // core, radix <= 5 on the generic one
-    if (!fft_make_plan(Fw, &p.pw, small_ct_len(Fw) ? 8 : 5) || !fft_make_plan(Fh, &p.ph, small_ct_len(Fh) ? 8 : 5))
+    if (!fft_make_plan(Fw, &p.pw, small_ct_len(Fw) ? 9 : 5) || !fft_make_plan(Fh, &p.ph, small_ct_len(Fh) ? 9 : 5))
         return fb_fail(ctx, FB_ERR_ARG, "ncc_small: %dx%d is not 5-smooth", Fh, Fw);
     int rc = get_table(ctx, Fw, &p.tw_w);
     if (rc) return rc;
