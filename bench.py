@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--host-threads', type=int, default=8, help='host threads driving the device (even; steps are dealt round-robin, LR and UD batches alternate)')
     ap.add_argument('--multi-stream', type=int, default=1, help='1: one context (HIP stream) per host thread; 0: all threads share one stream')
     ap.add_argument('--warp', type=float, default=0.4, help='amplitude (px) of the smooth sub-pixel warp between the strips of a pair (SURVEY config 2)')
+    ap.add_argument('--host-ingest-pairs', type=int, default=512, help='pairs of the PCIe-inclusive measurement (0: skip)')
     ap.add_argument('--no-fem', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fem-grid', type=int, default=708)
@@ -439,6 +440,25 @@ def main():
             line['fem'] = fem
     if rank == 0:
         line['xcorr_fft_classes'] = bench_xcorr_classes(lib, ctx, _lib)
+    if rank == 0 and world == 1 and args.host_ingest_pairs > 0:
+        # the boundary as stitcher.py uses it: strips in host memory.  PCIe-inclusive rate through stitching_matcher_batch
+        # (page-locked staging, copy and kernels of different chunks overlapped); never `value`
+        from feabas_amd import matcher as fmatcher
+        H, W = shapes['LR']
+        s0, s1, _ = strips['LR']
+        nh = min(args.host_ingest_pairs, n_res)
+        h0 = s0.to_array((nh, H, W), np.uint8); h1 = s1.to_array((nh, H, W), np.uint8)
+        host_pairs = [(h0[k], h1[k]) for k in range(nh)]
+        cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=RESIDUE_LEN)
+        fmatcher.stitching_matcher_batch(host_pairs[:P * 4], batch=P, threads=4, **cfg)        # set-up pass
+        t0 = time.time()
+        outp = fmatcher.stitching_matcher_batch(host_pairs, batch=P, threads=4, **cfg)
+        dth = time.time() - t0
+        line['host_ingest'] = dict(value=nh / dth, unit='pairs/s', pairs=nh, matched=int(sum(o[0] is not None for o in outp)),
+                                   note='strips handed over in host memory (4.2 MB per pair over PCIe), results returned per pair; '
+                                        '4 host threads, 64-pair chunks')
+        fmatcher.stitching_matcher_batch_release()
+        del h0, h1, host_pairs, outp
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         H, W = shapes['LR']
         s0, s1, _ = strips['LR']

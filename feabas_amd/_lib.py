@@ -46,6 +46,8 @@ _PROTOS = {
     'fb_malloc': (c_i, [c_p, c_sz, C.POINTER(c_p)]),
     'fb_free': (c_i, [c_p, c_p]),
     'fb_memcpy_h2d': (c_i, [c_p, c_p, c_p, c_sz]),
+    'fb_host_alloc': (c_i, [c_p, C.c_size_t, C.POINTER(c_p)]),
+    'fb_host_free': (c_i, [c_p, c_p]),
     'fb_memcpy_d2h': (c_i, [c_p, c_p, c_p, c_sz]),
     'fb_memset': (c_i, [c_p, c_p, c_i, c_sz]),
     'fb_timer_start': (c_i, [c_p]),
@@ -149,6 +151,12 @@ def use_context(h):
     _tls.ctx = h
 
 
+def destroy_context(h):
+    """Destroy a context made by ``new_context`` (its stream, arena and every buffer it still owns)."""
+    if h is not None and h != _ctx:
+        load().fb_destroy(h)
+
+
 def ctx(device=None):
     """The current context: the calling thread's (``use_context``) or the per-process one (one GPU per process;
     LOCAL_RANK picks the device)."""
@@ -198,7 +206,8 @@ class DeviceBuffer:
     def __init__(self, nbytes):
         self.nbytes = int(nbytes)
         p = c_p()
-        check(load().fb_malloc(ctx(), self.nbytes, C.byref(p)))
+        self.ctx = ctx()                                  # the owning context (a host thread may have its own)
+        check(load().fb_malloc(self.ctx, self.nbytes, C.byref(p)))
         self.ptr = p
 
     @classmethod
@@ -219,7 +228,30 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr is not None and _ctx is not None:
-            load().fb_free(_ctx, self.ptr)
+            load().fb_free(self.ctx, self.ptr)
+        self.ptr = None
+
+
+class PinnedBuffer:
+    """page-locked host staging memory (fb_host_alloc) viewed as a numpy array"""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = c_p()
+        self.ctx = ctx()
+        check(load().fb_host_alloc(self.ctx, self.nbytes, C.byref(p)))
+        self.ptr = p
+        self._raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(self.nbytes,))
+
+    def array(self, shape, dtype, offset=0):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        assert offset + n <= self.nbytes
+        return self._raw[offset:offset + n].view(dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr is not None and _ctx is not None:
+            self._raw = None
+            load().fb_host_free(self.ctx, self.ptr)
         self.ptr = None
 
 

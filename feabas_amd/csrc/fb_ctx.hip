@@ -141,6 +141,27 @@ int fb_malloc(fb_ctx* ctx, size_t bytes, void** dptr) {
     return FB_OK;
 }
 
+// page-locked host staging memory: fb_memcpy_h2d / _d2h from it run at the link rate instead of through the driver's
+// bounce buffers (the strips of a tile pair are 4 MB; pageable copies cap the ingest well below the kernels' rate)
+int fb_host_alloc(fb_ctx* ctx, size_t bytes, void** hptr) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, hptr != nullptr);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) return fb_fail(ctx, FB_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    *hptr = p;
+    return FB_OK;
+}
+
+int fb_host_free(fb_ctx* ctx, void* hptr) {
+    FB_LOCK(ctx);
+    if (!hptr) return FB_OK;
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FB_HIP(ctx, hipHostFree(hptr));
+    return FB_OK;
+}
+
 int fb_free(fb_ctx* ctx, void* dptr) {
     FB_LOCK(ctx);
     if (!dptr) return FB_OK;

@@ -182,31 +182,33 @@ def auto_spacings(shape0, shape1):
 
 _pair_matchers = {}
 _PAIR_MATCHER_CACHE = 4
+_batch_workers = {}          # (process context, worker index) -> {ctx, state}: resources stitching_matcher_batch keeps
 
 
-def stitching_matcher(img0, img1, **kwargs):
-    """feabas/matcher.py:224-367 for one pair of overlap strips: returns ``(xy0, xy1, weight, strain, phtm)`` in
-    strip-local pixel coordinates, or ``(None, None, conf_thresh, None, None)`` when the strips do not match
-    (matcher.py:278) -- no exception for "no match".
+def stitching_matcher_batch_release():
+    """free the contexts, staging buffers and matchers that stitching_matcher_batch keeps between calls"""
+    for (_, t), slot in list(_batch_workers.items()):
+        _lib.use_context(slot.get('ctx'))
+        for r in slot.get('state', {}).get('res', ()):
+            r.free()
+        _lib.use_context(None)
+        if t > 0:
+            _lib.destroy_context(slot.get('ctx'))
+    _batch_workers.clear()
 
-    The whole sequence runs on the device through the batch pipeline (``stitch_pipeline.StripBatchMatcher`` with a batch
-    of one; callers with many pairs should use the batch class directly).  Supported: equal-shape 2-D uint8 strips,
-    ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, optional masks (mask0 / mask1, True =
-    valid pixel) and photometric statistics; mesh relaxations between spacings of any shape (rigid or deformed mesh1).
-    Explicit ``spacings`` are taken in pixels.  Anything the device path does not cover (spacings < 1, fine_downsample != 1, a threshold residue mode) raises
-    NotImplementedError instead of silently taking another route."""
-    from .stitch_pipeline import StripBatchMatcher
+
+def _stitching_options(kwargs):
+    """matcher_config of stitching_matcher (matcher.py:229-241) -> (StripBatchMatcher options, mask0, mask1,
+    compute_photometric); options the device path does not cover raise NotImplementedError"""
     kw = dict(kwargs)
     sigma = kw.pop('sigma', 2.5)
     coarse_downsample = kw.pop('coarse_downsample', 1)
     fine_downsample = kw.pop('fine_downsample', 1)
-    conf_mode = kw.pop('conf_mode', const.FFT_CONF_MIRROR)
-    conf_thresh = kw.pop('conf_thresh', 0.3)
-    min_num_blocks = kw.pop('min_num_blocks', 2)
-    residue_len = kw.pop('residue_len', 5)
     residue_mode = kw.pop('residue_mode', 'huber')
-    stiffness_lambda = kw.pop('stiffness_lambda', 1)
-    compute_strain = kw.pop('compute_strain', True)
+    opts = dict(sigma=sigma, coarse_downsample=coarse_downsample, conf_thresh=kw.pop('conf_thresh', 0.3),
+                min_num_blocks=kw.pop('min_num_blocks', 2), conf_mode=kw.pop('conf_mode', const.FFT_CONF_MIRROR),
+                residue_len=kw.pop('residue_len', 5), stiffness_lambda=kw.pop('stiffness_lambda', 1),
+                compute_strain=kw.pop('compute_strain', True))
     mask0 = kw.pop('mask0', None)
     mask1 = kw.pop('mask1', None)
     spacings = kw.pop('spacings', None)
@@ -214,6 +216,7 @@ def stitching_matcher(img0, img1, **kwargs):
         spacings = np.asarray(spacings, dtype=np.float64).ravel()
         if spacings.size == 0 or np.any(spacings < 1):
             raise NotImplementedError('stitching_matcher: spacings relative to the overlap (< 1) are not on the device path')
+    opts['spacings'] = spacings
     compute_photometric = bool(kw.pop('compute_photometric', False))
     if compute_photometric and not sigma > 0:
         raise NotImplementedError('stitching_matcher(compute_photometric=True) needs sigma > 0 on the device path')
@@ -223,6 +226,10 @@ def stitching_matcher(img0, img1, **kwargs):
     if fine_downsample != 1 or coarse_downsample not in (1, 0.5) or residue_mode != 'huber':
         raise NotImplementedError('stitching_matcher: fine_downsample != 1, coarse_downsample outside (1, 0.5) or a non-huber '
                                   'residue mode is not on the device path')
+    return opts, mask0, mask1, compute_photometric
+
+
+def _check_strips(img0, img1, coarse_downsample):
     img0 = np.ascontiguousarray(img0); img1 = np.ascontiguousarray(img1)
     if img0.ndim != 2 or img0.shape != img1.shape or img0.dtype != np.uint8 or img1.dtype != np.uint8:
         raise NotImplementedError('stitching_matcher: the device path takes two uint8 strips of equal shape')
@@ -230,13 +237,29 @@ def stitching_matcher(img0, img1, **kwargs):
     if coarse_downsample == 0.5 and (H % 2 or W % 2):
         raise NotImplementedError('stitching_matcher: coarse_downsample = 0.5 needs even strip sizes (cv2.resize(INTER_AREA) at a '
                                   'non-integer ratio is not restated)')
-    key = (H, W, float(sigma), coarse_downsample, float(conf_thresh), int(min_num_blocks), int(conf_mode), float(residue_len),
-           float(stiffness_lambda), bool(compute_strain), None if spacings is None else tuple(spacings.tolist()), id(_lib.ctx()))
+    return img0, img1
+
+
+def stitching_matcher(img0, img1, **kwargs):
+    """feabas/matcher.py:224-367 for one pair of overlap strips: returns ``(xy0, xy1, weight, strain, phtm)`` in
+    strip-local pixel coordinates, or ``(None, None, conf_thresh, None, None)`` when the strips do not match
+    (matcher.py:278) -- no exception for "no match".
+
+    The whole sequence runs on the device through the batch pipeline (``stitch_pipeline.StripBatchMatcher`` with a batch
+    of one; callers with many pairs use ``stitching_matcher_batch``).  Supported: equal-shape 2-D uint8 strips,
+    ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, optional masks (mask0 / mask1, True =
+    valid pixel) and photometric statistics; mesh relaxations between spacings of any shape (rigid or deformed mesh1).
+    Explicit ``spacings`` are taken in pixels.  Anything the device path does not cover (spacings < 1, fine_downsample != 1,
+    a threshold residue mode) raises NotImplementedError instead of silently taking another route."""
+    from .stitch_pipeline import StripBatchMatcher
+    opts, mask0, mask1, compute_photometric = _stitching_options(kwargs)
+    img0, img1 = _check_strips(img0, img1, opts['coarse_downsample'])
+    H, W = img0.shape
+    spacings = opts['spacings']
+    key = (H, W) + tuple(None if v is None else (tuple(v.tolist()) if isinstance(v, np.ndarray) else v) for v in opts.values()) + (id(_lib.ctx()),)
     m = _pair_matchers.get(key)
     if m is None:
-        m = StripBatchMatcher(1, H, W, sigma=sigma, coarse_downsample=coarse_downsample, conf_thresh=conf_thresh,
-                              min_num_blocks=min_num_blocks, conf_mode=conf_mode, residue_len=residue_len,
-                              stiffness_lambda=stiffness_lambda, compute_strain=compute_strain, spacings=spacings)
+        m = StripBatchMatcher(1, H, W, **opts)
         # strip shapes vary from pair to pair (stitcher.py:561-571): keep the device buffers of a few recent shapes only
         while len(_pair_matchers) >= _PAIR_MATCHER_CACHE:
             _pair_matchers.pop(next(iter(_pair_matchers))).free()
@@ -254,5 +277,90 @@ def stitching_matcher(img0, img1, **kwargs):
     finally:
         d0.free(); d1.free()
     if res['xy0'] is None:
-        return None, None, conf_thresh, None, None
+        return None, None, opts['conf_thresh'], None, None
     return res['xy0'], res['xy1'], res['weight'], res['strain'], (out['phtm'][0] if compute_photometric else None)
+
+
+def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
+    """``stitching_matcher`` for a list of host-resident strip pairs -- what ``Stitcher.subprocess_match_list_of_overlaps``
+    (stitcher.py:552-613) does one pair at a time.  pairs: sequence of ``(img0, img1)`` or ``(img0, img1, mask0, mask1)``;
+    kwargs: the matcher_config of ``stitching_matcher`` (masks per pair, not as options).  Pairs are bucketed by strip
+    shape, every bucket is cut into chunks of ``batch`` pairs and the chunks are dealt to ``threads`` host threads, each
+    with its own context (HIP stream), page-locked staging buffer and ``StripBatchMatcher``, so that packing and the
+    host-to-device copy of one chunk overlap the kernels of another.  Returns the 5-tuples in input order (the
+    reference's no-match tuple where the strips do not match); a pair the device path cannot take raises like
+    ``stitching_matcher``."""
+    import threading
+    from .stitch_pipeline import StripBatchMatcher
+    for name in ('mask0', 'mask1'):
+        if kwargs.get(name, None) is not None:
+            raise ValueError('stitching_matcher_batch: masks are given per pair, as (img0, img1, mask0, mask1)')
+    opts, _, _, compute_photometric = _stitching_options(kwargs)
+    items = []
+    for k, pr in enumerate(pairs):
+        img0, img1 = _check_strips(pr[0], pr[1], opts['coarse_downsample'])
+        mk0, mk1 = (pr[2], pr[3]) if len(pr) > 2 else (None, None)
+        for mk in (mk0, mk1):
+            if mk is not None and np.asarray(mk).shape != img0.shape:
+                raise ValueError('stitching_matcher_batch: a mask must have the shape of its strip')
+        items.append((img0, img1, mk0, mk1))
+    buckets = {}
+    for k, it in enumerate(items):
+        buckets.setdefault(it[0].shape, []).append(k)
+    chunks = [(shape, idx[c:c + batch]) for shape, idx in buckets.items() for c in range(0, len(idx), batch)]
+    results = [None] * len(items)
+    errors = []
+    nthr = max(1, min(int(threads), len(chunks)))
+    main_ctx = _lib.ctx()
+    okey = (batch,) + tuple(None if v is None else (tuple(v.tolist()) if isinstance(v, np.ndarray) else v) for v in opts.values())
+
+    def worker(t):
+        # worker t keeps its context and the resources of the last shape it worked on between calls
+        # (stitching_matcher_batch_release frees them)
+        slot = _batch_workers.setdefault((id(main_ctx), t), {})
+        if 'ctx' not in slot:
+            slot['ctx'] = main_ctx if t == 0 else _lib.new_context()
+        _lib.use_context(slot['ctx'])
+        state = slot.setdefault('state', {})
+        try:
+            for shape, idx in chunks[t::nthr]:
+                H, W = shape
+                if state.get('key') != (shape, okey):
+                    for r in state.get('res', ()):
+                        r.free()
+                    state.clear()
+                    m = StripBatchMatcher(batch, H, W, **opts)
+                    pin = _lib.PinnedBuffer(2 * batch * H * W)
+                    dev = _lib.DeviceBuffer(2 * batch * H * W)
+                    state.update(key=(shape, okey), res=(m, pin, dev))
+                m, pin, dev = state['res']
+                stage = pin.array((2, batch, H, W), np.uint8)
+                n = len(idx)
+                for j in range(batch):                        # a short chunk is padded with its first pair
+                    src = items[idx[j if j < n else 0]]
+                    stage[0, j] = src[0]; stage[1, j] = src[1]
+                _lib.check(_lib.load().fb_memcpy_h2d(_lib.ctx(), dev.ptr, pin.ptr, 2 * batch * H * W))
+                mk0 = [items[idx[j if j < n else 0]][2] for j in range(batch)]
+                mk1 = [items[idx[j if j < n else 0]][3] for j in range(batch)]
+                has_mask = any(v is not None for v in mk0 + mk1)
+                out = m.match(dev.ptr, dev.offset(batch * H * W), masks0=mk0 if has_mask else None, masks1=mk1 if has_mask else None,
+                              compute_photometric=compute_photometric)
+                per = StripBatchMatcher.per_pair(out)
+                for j in range(n):
+                    r = per[j]
+                    if r['xy0'] is None:
+                        results[idx[j]] = (None, None, opts['conf_thresh'], None, None)
+                    else:
+                        results[idx[j]] = (r['xy0'], r['xy1'], r['weight'], r['strain'], out['phtm'][j] if compute_photometric else None)
+        except Exception as e:                                # noqa: BLE001 -- re-raised in the calling thread
+            errors.append(e)
+        finally:
+            _lib.use_context(None)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    if errors:
+        raise errors[0]
+    return results

@@ -63,6 +63,9 @@ const char* fb_version(void);
 /* device memory owned by the context (freed by fb_free or fb_destroy) */
 int fb_malloc(fb_ctx* ctx, size_t bytes, void** dptr);
 int fb_free(fb_ctx* ctx, void* dptr);
+/* page-locked host staging memory for fb_memcpy_h2d / fb_memcpy_d2h at the link rate */
+int fb_host_alloc(fb_ctx* ctx, size_t bytes, void** hptr);
+int fb_host_free(fb_ctx* ctx, void* hptr);
 int fb_memcpy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
 int fb_memcpy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
 int fb_memset(fb_ctx* ctx, void* dst, int value, size_t bytes);

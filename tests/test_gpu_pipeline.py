@@ -498,3 +498,36 @@ def test_stitching_matcher_masks_and_photometric(fb):
     plain = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
     masked = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2, mask0=mask0, mask1=mask1)
     assert plain[4] is None and (plain[0].shape != masked[0].shape or np.abs(plain[2] - masked[2]).max() > 1e-3)
+
+
+def test_stitching_matcher_batch_matches_the_per_pair_surface(fb):
+    """host-resident pairs of mixed shapes (one masked) through stitching_matcher_batch (shape buckets, chunks dealt to
+    host threads with their own contexts, page-locked staging): the same tuples as stitching_matcher, in input order"""
+    cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2, compute_photometric=True)
+    shapes = [(1024, 256), (256, 1024), (1024, 256), (510, 510), (1024, 256), (256, 1024), (1024, 256)]
+    pairs = []
+    for k, (H, W) in enumerate(shapes):
+        s0, s1 = _warped_pair(H, W, 60 + k, shift=(k - 3, 2 - k), warp=0.3)
+        if k == 2:
+            mk = np.ones((H, W), dtype=bool); mk[300:420, 60:200] = False
+            pairs.append((s0, s1, mk, None))
+        elif k == 4:
+            pairs.append((s0, s1[::-1].copy()))                      # unrelated strips: the no-match tuple
+        else:
+            pairs.append((s0, s1))
+    got = fb.matcher.stitching_matcher_batch(pairs, batch=2, threads=2, **cfg)
+    assert len(got) == len(pairs)
+    for k, pr in enumerate(pairs):
+        kw = dict(cfg)
+        if len(pr) > 2:
+            kw.update(mask0=pr[2], mask1=pr[3])
+        exp = fb.matcher.stitching_matcher(pr[0], pr[1], **kw)
+        if exp[0] is None:
+            assert got[k][0] is None and got[k][2] == exp[2]
+            continue
+        for a, b in zip(got[k][:4], exp[:4]):
+            np.testing.assert_allclose(a, b, atol=1e-6)
+        np.testing.assert_allclose(got[k][4], exp[4], rtol=1e-6)
+    assert got[4][0] is None
+    fb.matcher.stitching_matcher_batch_release()
+    assert not fb.matcher._batch_workers
