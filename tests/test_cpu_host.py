@@ -316,3 +316,19 @@ def test_cxx_deformed_geometry_matches_numpy():
         np.testing.assert_array_equal(c, mk[e].astype(bool))
         np.testing.assert_array_equal(a[c], mx[e][c]); np.testing.assert_array_equal(b[c], my[e][c])
     assert 0 < mk.mean() < 1
+
+
+def test_find_overlaps_readme_grid():
+    """stitcher.find_overlaps (stitcher.py:418-437) on the README's 3 x 2 grid: 4 left-right + 3 up-down + 4 diagonal
+    corner overlaps, each as (later tile, earlier tile), z-ordered by overlap centre"""
+    from feabas_amd import stitcher
+    nom = np.array([[x, y] for y in (0, 2700) for x in (0, 3600, 7200)])
+    bboxes = np.concatenate((nom, nom + np.array([4000, 3000])), axis=1)
+    ov = stitcher.find_overlaps(bboxes, tile_size=(3000, 4000))
+    assert ov.shape == (11, 2) and np.all(ov[:, 0] > ov[:, 1])
+    assert {tuple(p) for p in ov.tolist()} == {(1, 0), (2, 1), (3, 0), (4, 0), (4, 1), (4, 3), (3, 1), (5, 1), (5, 2), (5, 4), (4, 2)}
+    _, wd = stitcher.bbox_intersections(bboxes[ov[:, 0]], bboxes[ov[:, 1]])
+    assert sorted(wd.tolist()) == [300] * 7 + [400] * 4
+    assert stitcher.find_overlaps(bboxes[:1]).shape == (0, 2)
+    m, s, p, err = stitcher.match_list_of_overlaps(np.empty((0, 2), int), [], bboxes)
+    assert (m, s, p, err) == ({}, {}, {}, False)

@@ -531,3 +531,51 @@ def test_stitching_matcher_batch_matches_the_per_pair_surface(fb):
     assert got[4][0] is None
     fb.matcher.stitching_matcher_batch_release()
     assert not fb.matcher._batch_workers
+
+
+def test_config0_readme_grid_matching_stage(fb):
+    """BASELINE config[0] (plumbing): the README's 3 x 2 grid of 3000 x 4000 tiles at 10 % overlap, stage jitter of up to
+    15 px, through the host mirror of the matching stage (stitcher.find_overlaps -> match_list_of_overlaps): 11 overlaps
+    (4 left-right, 3 up-down, 4 diagonal corners), every one matched, and the matches carry the injected jitter"""
+    from scipy.ndimage import gaussian_filter
+    from feabas_amd import stitcher
+    rng = np.random.default_rng(0)
+    TH, TW = 3000, 4000
+    nom = np.array([[x, y] for y in (0, 2700) for x in (0, 3600, 7200)])
+    jit = rng.integers(-15, 16, nom.shape)
+    pad = 32
+    canvas = gaussian_filter(rng.standard_normal((2700 + TH + 2 * pad, 7200 + TW + 2 * pad)).astype(np.float32), 1.5)
+    canvas += 1.5 * gaussian_filter(rng.standard_normal(canvas.shape).astype(np.float32), 6.0)
+    canvas = 128 + 40 * canvas / canvas.std()
+    tiles = []
+    for (x, y), (jx, jy) in zip(nom, jit):
+        t = canvas[pad + y + jy:pad + y + jy + TH, pad + x + jx:pad + x + jx + TW] + rng.normal(0, 5, (TH, TW))
+        tiles.append(np.clip(np.round(t), 0, 255).astype(np.uint8))
+    bboxes = np.concatenate((nom, nom + np.array([TW, TH])), axis=1)
+    overlaps = stitcher.find_overlaps(bboxes, tile_size=(TH, TW))
+    assert overlaps.shape == (11, 2)
+    cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2, residue_mode='huber', pad=True, spacings=None,
+               fine_downsample=1.0, compute_photometric=False)                  # default_stitching_configs.yaml:13-23
+    matches, strains, phtm, err = stitcher.match_list_of_overlaps(overlaps, tiles, bboxes, min_overlap_width=25, margin=100,
+                                                                  matcher_config=cfg, batch=4, threads=2)
+    assert not err and len(matches) == 11 and not phtm
+    for (i, j), (xy0, xy1, wt) in matches.items():
+        exp = (nom[i] + jit[i]) - (nom[j] + jit[j])          # same canvas point: p_j - p_i
+        d = np.median(xy1 - xy0, axis=0)
+        assert np.abs(d - exp).max() < 0.5, ((i, j), d, exp)
+        assert xy0.shape[0] >= 9 and strains[(i, j)] < 0.01
+        assert xy0.min() >= -1 and (xy0.max(axis=0) <= np.array([TW, TH])).all()
+    # one left-right pair against the oracle, strip for strip
+    i, j = (int(v) for v in overlaps[np.argmax([abs(nom[a][0] - nom[b][0]) == 3600 and nom[a][1] == nom[b][1] for a, b in overlaps])])
+    bb_ov, wd = stitcher.bbox_intersections(bboxes[i], bboxes[j])
+    bb_ov = bb_ov + np.array([-100, -100, 100, 100])
+    b0 = stitcher.bbox_intersections(bb_ov, bboxes[i])[0]; b1 = stitcher.bbox_intersections(bb_ov, bboxes[j])[0]
+    s0 = tiles[i][b0[1] - bboxes[i][1]:b0[3] - bboxes[i][1], b0[0] - bboxes[i][0]:b0[2] - bboxes[i][0]]
+    s1 = tiles[j][b1[1] - bboxes[j][1]:b1[3] - bboxes[j][1], b1[0] - bboxes[j][0]:b1[2] - bboxes[j][0]]
+    assert s0.shape == s1.shape == (3000, 500)
+    exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0)
+    xy0, xy1, wt = matches[(i, j)]
+    np.testing.assert_allclose(xy0 - (b0[:2] - bboxes[i][:2]), exp['xy0'], atol=2e-4)
+    np.testing.assert_allclose(xy1 - (b1[:2] - bboxes[j][:2]), exp['xy1'], atol=2e-4)
+    np.testing.assert_allclose(wt, exp['weight'], atol=2e-4)
+    fb.matcher.stitching_matcher_batch_release()
