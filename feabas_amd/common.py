@@ -37,14 +37,19 @@ def masked_dog_filter(img, sigma, mask=None, signed=True):
     return out.reshape(shp)
 
 
+def half_size(n):
+    """output length of cv2.resize(fx=0.5): cvRound(n * 0.5), round half to even"""
+    return int(round(n * 0.5))
+
+
 def area_downsample2(img):
-    """cv2.resize(img, None, fx=0.5, fy=0.5, INTER_AREA) for even-sized uint8
-    images (feabas/matcher.py:255-256) on the GPU."""
+    """cv2.resize(img, None, fx=0.5, fy=0.5, INTER_AREA) of uint8 images (feabas/matcher.py:255-256) on the GPU; odd
+    sizes follow the integer-scale area path's edge rule (see fb_dog.hip)."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     shp = img.shape
     h, w = shp[-2:]
     n = int(np.prod(shp[:-2])) if img.ndim > 2 else 1
-    out = np.empty(shp[:-2] + (h // 2, w // 2), dtype=np.uint8)
+    out = np.empty(shp[:-2] + (half_size(h), half_size(w)), dtype=np.uint8)
     _lib.check(_lib.load().fb_area_downsample2(_lib.ctx(), _lib.ptr(img), n, h, w, _lib.ptr(out)))
     return out
 

@@ -155,16 +155,29 @@ __global__ void remap_kernel(const float* __restrict__ imgs, int IH, int IW, int
     }
 }
 
+// cv2.resize(fx = fy = 0.5, INTER_AREA) on its integer-scale path (resizeAreaFast): output size cvRound(n / 2) per axis
+// (round half to even); a full 2x2 cell is (sum + 2) >> 2; a cell cut by the image edge averages the pixels that exist,
+// float(sum) / count rounded half to even
+__host__ __device__ inline int half_size(int n) { return (n & 1) ? (((n >> 1) & 1) ? (n >> 1) + 1 : (n >> 1)) : (n >> 1); }
+
 __global__ void area_down2_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int N, int H, int W) {
-    const int Ho = H / 2, Wo = W / 2;
+    const int Ho = half_size(H), Wo = half_size(W);
     const size_t total = (size_t)N * Ho * Wo;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t n = i / ((size_t)Ho * Wo);
         const int rem = (int)(i - n * (size_t)Ho * Wo);
         const int y = rem / Wo, x = rem - y * Wo;
         const uint8_t* p = in + (n * H + 2 * y) * (size_t)W + 2 * x;
-        const int s = (int)p[0] + (int)p[1] + (int)p[W] + (int)p[W + 1];
-        out[i] = (uint8_t)((s + 2) >> 2);
+        const bool x1 = 2 * x + 1 < W, y1 = 2 * y + 1 < H;
+        if (x1 && y1) {
+            const int s = (int)p[0] + (int)p[1] + (int)p[W] + (int)p[W + 1];
+            out[i] = (uint8_t)((s + 2) >> 2);
+        } else {
+            int s = (int)p[0], c = 1;
+            if (x1) { s += (int)p[1]; ++c; }
+            if (y1) { s += (int)p[W]; ++c; }
+            out[i] = (uint8_t)rintf((float)s / (float)c);
+        }
     }
 }
 
@@ -524,10 +537,10 @@ int fb_remap_dev(fb_ctx* ctx, const float* imgs, int IH, int IW, int N, const in
 
 int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {
     FB_LOCK(ctx);
-    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0));
+    FB_CHECK_ARG(ctx, N >= 0 && H > 1 && W > 1);
     if (N == 0) return FB_OK;
     FB_PROF(ctx, "area_down2");
-    const size_t total = (size_t)N * (H / 2) * (W / 2);
+    const size_t total = (size_t)N * half_size(H) * half_size(W);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
     hipLaunchKernelGGL(area_down2_kernel, dim3(blocks), dim3(256), 0, ctx->stream, img, out, N, H, W);
     FB_HIP(ctx, hipGetLastError());
@@ -536,9 +549,9 @@ int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W
 
 int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {
     FB_LOCK(ctx);
-    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0));
+    FB_CHECK_ARG(ctx, N >= 0 && H > 1 && W > 1);
     if (N == 0) return FB_OK;
-    const size_t bi = (size_t)N * H * W, bo = bi / 4;
+    const size_t bi = (size_t)N * H * W, bo = (size_t)N * half_size(H) * half_size(W);
     uint8_t *din = nullptr, *dout = nullptr;
     FB_HIP(ctx, hipMalloc(&din, bi));
     FB_HIP(ctx, hipMalloc(&dout, bo));

@@ -233,10 +233,8 @@ def _check_strips(img0, img1, coarse_downsample):
     img0 = np.ascontiguousarray(img0); img1 = np.ascontiguousarray(img1)
     if img0.ndim != 2 or img0.shape != img1.shape or img0.dtype != np.uint8 or img1.dtype != np.uint8:
         raise NotImplementedError('stitching_matcher: the device path takes two uint8 strips of equal shape')
-    H, W = img0.shape
-    if coarse_downsample == 0.5 and (H % 2 or W % 2):
-        raise NotImplementedError('stitching_matcher: coarse_downsample = 0.5 needs even strip sizes (cv2.resize(INTER_AREA) at a '
-                                  'non-integer ratio is not restated)')
+    if min(img0.shape) < 4:
+        raise NotImplementedError('stitching_matcher: strips thinner than 4 pixels are not on the device path')
     return img0, img1
 
 

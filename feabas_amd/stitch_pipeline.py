@@ -68,7 +68,6 @@ class StripBatchMatcher:
     def __init__(self, P, H, W, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
                  conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9, compute_strain=True, spacings=None):
         assert coarse_downsample in (0.5, 1)
-        assert H % 2 == 0 and W % 2 == 0 or coarse_downsample == 1
         self.P, self.H, self.W = int(P), int(H), int(W)
         self.sigma = float(sigma)
         self.cds = coarse_downsample
@@ -82,7 +81,8 @@ class StripBatchMatcher:
             if self.spacings.size == 0 or np.any(self.spacings < 1):
                 raise NotImplementedError('spacings relative to the overlap (< 1, matcher.py:343-350) are not on the device path')
         self._nfl = np.array([next_fast_len(v) for v in range(0, 2 * max(H, W) + 2)])
-        hc, wc = (H // 2, W // 2) if coarse_downsample == 0.5 else (H, W)
+        from .common import half_size
+        hc, wc = (half_size(H), half_size(W)) if coarse_downsample == 0.5 else (H, W)      # cv2.resize(fx=0.5): cvRound(n / 2)
         self.hc, self.wc = hc, wc
         n = self.P
         self.d_small = _lib.DeviceBuffer(2 * n * hc * wc) if coarse_downsample == 0.5 else None
@@ -141,7 +141,7 @@ class StripBatchMatcher:
                 for p, mk in enumerate(mlist):
                     if mk is None:
                         continue
-                    mg = np.asarray(mk)[::2, ::2] if self.cds == 0.5 else np.asarray(mk)
+                    mg = np.asarray(mk)[::2, ::2][:hc, :wc] if self.cds == 0.5 else np.asarray(mk)
                     src = self.d_small.offset((side * n + p) * hc * wc) if self.cds == 0.5 else C.c_void_p(strips + p * H * W)
                     self._masked_dog(src, 0, hc, wc, self.sigma * self.cds, mg, self.d_dogc.offset((side * n + p) * hc * wc * 4))
         _lib.check(lib.fb_ncc_batch_dev(ctx, self.d_dogc.ptr, self.d_dogc.offset(n * hc * wc * 4), n, 1, hc, wc, hc, wc,
@@ -204,7 +204,7 @@ class StripBatchMatcher:
             def coarse(mk):
                 if mk is None:
                     return None
-                return np.asarray(mk, dtype=bool)[::2, ::2] if self.cds == 0.5 else np.asarray(mk, dtype=bool)
+                return np.asarray(mk, dtype=bool)[::2, ::2][:hc, :wc] if self.cds == 0.5 else np.asarray(mk, dtype=bool)
             mg0 = coarse(masks[0][p]) if masks is not None else None
             mg1 = coarse(masks[1][p]) if masks is not None else None
             m0 = np.ones(shape, dtype=bool) if mg0 is None else mg0[i0]

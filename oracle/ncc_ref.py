@@ -156,17 +156,31 @@ def gaussian_taps(sigma, truncate=4.0):
     return w / w.sum()
 
 
+def half_size(n):
+    """output length of cv2.resize(fx=0.5) for an input length n: cvRound(n * 0.5), round half to even"""
+    return int(round(n * 0.5))
+
+
 def area_downsample2(img):
-    """2x2 box mean of an even-sized uint8 image, rounded half-up to uint8:
-    what cv2.resize(fx=fy=0.5, INTER_AREA) computes on its integer fast path
-    (matcher.py:255-256).  cv2 is absent from the build container, so this
-    step is "parity unpinned" (SURVEY.md A.4); benchmarks feed even sizes."""
+    """cv2.resize(img, None, fx=0.5, fy=0.5, INTER_AREA) of a uint8 image (matcher.py:255-256): the integer-scale
+    area path (resizeAreaFast).  Output size cvRound(n / 2) per axis (round half to even); a full 2x2 cell is
+    (sum + 2) >> 2 (the vector kernel's rounding, used everywhere here); a cell cut by the image edge -- odd sizes whose
+    half rounds up -- averages the pixels that exist, float(sum) / count rounded half to even; an odd size whose half
+    rounds down drops the last row / column.  cv2 is absent from the build container, so this step is "parity
+    unpinned" (SURVEY.md A.4)."""
     img = np.asarray(img)
     h, w = img.shape[-2:]
-    assert h % 2 == 0 and w % 2 == 0
-    v = img.astype(np.uint16)
+    ho, wo = half_size(h), half_size(w)
+    v = np.zeros(img.shape[:-2] + (2 * ho, 2 * wo), dtype=np.uint16)
+    cnt = np.zeros((2 * ho, 2 * wo), dtype=np.uint16)
+    hh, ww = min(h, 2 * ho), min(w, 2 * wo)
+    v[..., :hh, :ww] = img[..., :hh, :ww]
+    cnt[:hh, :ww] = 1
     s = v[..., 0::2, 0::2] + v[..., 0::2, 1::2] + v[..., 1::2, 0::2] + v[..., 1::2, 1::2]
-    return ((s + 2) >> 2).astype(np.uint8)
+    c = cnt[0::2, 0::2] + cnt[0::2, 1::2] + cnt[1::2, 0::2] + cnt[1::2, 1::2]
+    full = (s + 2) >> 2
+    part = np.rint(s.astype(np.float32) / np.maximum(c, 1).astype(np.float32))
+    return np.where(c == 4, full, part).astype(np.uint8)
 
 
 # ------------------------------------------------------------------ bbox helpers

@@ -295,8 +295,8 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
         g0 = ncc_ref.area_downsample2(strip0)
         g1 = ncc_ref.area_downsample2(strip1)
         # cv2.resize(mask, fx=0.5, INTER_NEAREST) (matcher.py:257-264): source pixel floor(dst / 0.5) (UNPINNED)
-        mask0_g = None if mask0 is None else np.asarray(mask0, dtype=bool)[::2, ::2]
-        mask1_g = None if mask1 is None else np.asarray(mask1, dtype=bool)[::2, ::2]
+        mask0_g = None if mask0 is None else np.asarray(mask0, dtype=bool)[::2, ::2][:g0.shape[0], :g0.shape[1]]
+        mask1_g = None if mask1 is None else np.asarray(mask1, dtype=bool)[::2, ::2][:g1.shape[0], :g1.shape[1]]
     else:
         g0, g1 = strip0, strip1
         mask0_g, mask1_g = mask0, mask1

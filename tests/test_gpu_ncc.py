@@ -174,6 +174,12 @@ def test_area_downsample(fb):
     rng = np.random.default_rng(4)
     img = rng.integers(0, 256, size=(3, 510, 4096), dtype=np.uint8)
     np.testing.assert_array_equal(fb.common.area_downsample2(img), ncc_ref.area_downsample2(img))
+    # odd sizes: cvRound(n / 2) outputs (half to even), edge cells average the pixels that exist
+    for shape, out_shape in (((2, 511, 4095), (256, 2048)), ((2, 509, 4097), (254, 2048)), ((1, 7, 5), (4, 2)), ((1, 5, 7), (2, 4))):
+        img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        got = fb.common.area_downsample2(img)
+        assert got.shape[-2:] == out_shape
+        np.testing.assert_array_equal(got, ncc_ref.area_downsample2(img))
 
 
 @pytest.mark.parametrize('bh,bw,pad', [(75, 73, False), (75, 73, True), (250, 247, True)])

@@ -444,8 +444,20 @@ def test_stitching_matcher_varied_strip_shapes_and_corner_pairs(fb):
         np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
         assert np.abs(np.median(xy1 - xy0, axis=0) + np.array([3 - k, 2 * k - 4])).max() < 0.5
     assert len(mt._pair_matchers) <= mt._PAIR_MATCHER_CACHE
-    with pytest.raises(NotImplementedError):
-        fb.matcher.stitching_matcher(np.zeros((301, 512), np.uint8), np.zeros((301, 512), np.uint8), coarse_downsample=0.5)
+
+
+@pytest.mark.parametrize('H,W', [(1023, 255), (1021, 258), (257, 1019), (511, 509)])
+def test_stitching_matcher_odd_strip_sizes(fb, H, W):
+    """odd strip sizes (stage jitter makes most real overlaps odd in some dimension): the x0.5 coarse image has
+    cvRound(n / 2) pixels per axis and its edge cells average the pixels that exist (cv2's integer-scale area path,
+    unpinned like the even case); against the oracle"""
+    s0, s1 = _warped_pair(H, W, H + W, shift=(4, -5), warp=0.3)
+    xy0, xy1, wt, strain, _ = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+    exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0)
+    assert xy0.shape == exp['xy0'].shape and xy0.shape[0] >= 9
+    np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
+    np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
+    assert np.abs(np.median(xy1 - xy0, axis=0) + np.array([4, -5])).max() < 0.5
 
 
 def test_pipeline_three_spacings_deformed_twice_vs_oracle(fb):
