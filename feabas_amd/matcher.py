@@ -308,9 +308,10 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
     chunks = [(shape, idx[c:c + batch]) for shape, idx in buckets.items() for c in range(0, len(idx), batch)]
     results = [None] * len(items)
     errors = []
+    need = max(2 * len(idx) * shape[0] * shape[1] for shape, idx in chunks) if chunks else 0
     nthr = max(1, min(int(threads), len(chunks)))
     main_ctx = _lib.ctx()
-    okey = (batch,) + tuple(None if v is None else (tuple(v.tolist()) if isinstance(v, np.ndarray) else v) for v in opts.values())
+    okey = tuple(None if v is None else (tuple(v.tolist()) if isinstance(v, np.ndarray) else v) for v in opts.values())
 
     def worker(t):
         # worker t keeps its context and the resources of the last shape it worked on between calls
@@ -323,25 +324,26 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         try:
             for shape, idx in chunks[t::nthr]:
                 H, W = shape
-                if state.get('key') != (shape, okey):
-                    for r in state.get('res', ()):
-                        r.free()
-                    state.clear()
-                    m = StripBatchMatcher(batch, H, W, **opts)
-                    pin = _lib.PinnedBuffer(2 * batch * H * W)
-                    dev = _lib.DeviceBuffer(2 * batch * H * W)
-                    state.update(key=(shape, okey), res=(m, pin, dev))
+                n = len(idx)                                  # a short chunk (ragged shapes) gets a matcher of its own size
+                if state.get('key') != (shape, n, okey):
+                    if 'res' in state:
+                        state['res'][0].free()
+                    if state.get('bytes', 0) < need:          # staging buffers: one pair of allocations for the largest chunk
+                        for r in state.get('res', (None,))[1:]:
+                            r.free()
+                        state['io'] = (_lib.PinnedBuffer(need), _lib.DeviceBuffer(need))
+                        state['bytes'] = need
+                    state.update(key=(shape, n, okey), res=(StripBatchMatcher(n, H, W, **opts),) + state['io'])
                 m, pin, dev = state['res']
-                stage = pin.array((2, batch, H, W), np.uint8)
-                n = len(idx)
-                for j in range(batch):                        # a short chunk is padded with its first pair
-                    src = items[idx[j if j < n else 0]]
+                stage = pin.array((2, n, H, W), np.uint8)
+                for j in range(n):
+                    src = items[idx[j]]
                     stage[0, j] = src[0]; stage[1, j] = src[1]
-                _lib.check(_lib.load().fb_memcpy_h2d(_lib.ctx(), dev.ptr, pin.ptr, 2 * batch * H * W))
-                mk0 = [items[idx[j if j < n else 0]][2] for j in range(batch)]
-                mk1 = [items[idx[j if j < n else 0]][3] for j in range(batch)]
+                _lib.check(_lib.load().fb_memcpy_h2d(_lib.ctx(), dev.ptr, pin.ptr, 2 * n * H * W))
+                mk0 = [items[idx[j]][2] for j in range(n)]
+                mk1 = [items[idx[j]][3] for j in range(n)]
                 has_mask = any(v is not None for v in mk0 + mk1)
-                out = m.match(dev.ptr, dev.offset(batch * H * W), masks0=mk0 if has_mask else None, masks1=mk1 if has_mask else None,
+                out = m.match(dev.ptr, dev.offset(n * H * W), masks0=mk0 if has_mask else None, masks1=mk1 if has_mask else None,
                               compute_photometric=compute_photometric)
                 per = StripBatchMatcher.per_pair(out)
                 for j in range(n):

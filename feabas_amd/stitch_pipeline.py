@@ -64,6 +64,18 @@ def _z_order_batch(ix, iy):
     return np.argsort(sx + 2 * sy, axis=-1, kind='stable')
 
 
+_NFL = np.zeros(0, dtype=np.int64)
+
+
+def _nfl_table(n):
+    """next_fast_len(v) for v < n, shared by every matcher of the process (strip shapes vary from pair to pair)"""
+    global _NFL
+    if _NFL.size < n:
+        grown = np.array([next_fast_len(v) for v in range(_NFL.size, max(n, 2 * _NFL.size, 8194))], dtype=np.int64)
+        _NFL = np.concatenate((_NFL, grown))
+    return _NFL
+
+
 class StripBatchMatcher:
     def __init__(self, P, H, W, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
                  conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9, compute_strain=True, spacings=None):
@@ -80,7 +92,7 @@ class StripBatchMatcher:
             self.spacings = np.sort(np.asarray(spacings, dtype=np.float64).ravel())[::-1]
             if self.spacings.size == 0 or np.any(self.spacings < 1):
                 raise NotImplementedError('spacings relative to the overlap (< 1, matcher.py:343-350) are not on the device path')
-        self._nfl = np.array([next_fast_len(v) for v in range(0, 2 * max(H, W) + 2)])
+        self._nfl = _nfl_table(2 * max(H, W) + 2)
         from .common import half_size
         hc, wc = (half_size(H), half_size(W)) if coarse_downsample == 0.5 else (H, W)      # cv2.resize(fx=0.5): cvRound(n / 2)
         self.hc, self.wc = hc, wc
