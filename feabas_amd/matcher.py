@@ -183,6 +183,7 @@ def auto_spacings(shape0, shape1):
 _pair_matchers = {}
 _PAIR_MATCHER_CACHE = 4
 _batch_workers = {}          # (process context, worker index) -> {ctx, state}: resources stitching_matcher_batch keeps
+_pools = {}                  # context -> MatcherPool of the per-pair surface
 
 
 def stitching_matcher_batch_release():
@@ -191,6 +192,8 @@ def stitching_matcher_batch_release():
         _lib.use_context(slot.get('ctx'))
         for r in slot.get('state', {}).get('res', ()):
             r.free()
+        if 'pool' in slot.get('state', {}):
+            slot['state']['pool'].free()
         _lib.use_context(None)
         if t > 0:
             _lib.destroy_context(slot.get('ctx'))
@@ -257,7 +260,9 @@ def stitching_matcher(img0, img1, **kwargs):
     key = (H, W) + tuple(None if v is None else (tuple(v.tolist()) if isinstance(v, np.ndarray) else v) for v in opts.values()) + (id(_lib.ctx()),)
     m = _pair_matchers.get(key)
     if m is None:
-        m = StripBatchMatcher(1, H, W, **opts)
+        from .stitch_pipeline import MatcherPool
+        pool = _pools.setdefault(id(_lib.ctx()), MatcherPool())
+        m = StripBatchMatcher(1, H, W, pool=pool, **opts)
         # strip shapes vary from pair to pair (stitcher.py:561-571): keep the device buffers of a few recent shapes only
         while len(_pair_matchers) >= _PAIR_MATCHER_CACHE:
             _pair_matchers.pop(next(iter(_pair_matchers))).free()
@@ -333,7 +338,10 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
                             r.free()
                         state['io'] = (_lib.PinnedBuffer(need), _lib.DeviceBuffer(need))
                         state['bytes'] = need
-                    state.update(key=(shape, n, okey), res=(StripBatchMatcher(n, H, W, **opts),) + state['io'])
+                    if 'pool' not in state:
+                        from .stitch_pipeline import MatcherPool
+                        state['pool'] = MatcherPool()
+                    state.update(key=(shape, n, okey), res=(StripBatchMatcher(n, H, W, pool=state['pool'], **opts),) + state['io'])
                 m, pin, dev = state['res']
                 stage = pin.array((2, n, H, W), np.uint8)
                 for j in range(n):

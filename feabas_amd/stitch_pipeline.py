@@ -76,10 +76,49 @@ def _nfl_table(n):
     return _NFL
 
 
+class MatcherPool:
+    """Device buffers and relaxation systems that outlive a StripBatchMatcher.  Strip shapes vary from pair to pair in a
+    real section (stitcher.py:561-571), so matchers come and go; their buffers are handed back here instead of to
+    hipFree, and a relaxation system is kept per (pairs, grid) topology -- only its stiffness values are re-assembled
+    for a new geometry.  One pool per context (host thread)."""
+
+    def __init__(self):
+        self.buffers = []
+        self.systems = {}
+
+    def take(self, nbytes):
+        nbytes = int(nbytes)
+        best = None
+        for k, b in enumerate(self.buffers):
+            if b.nbytes >= nbytes and b.nbytes <= 4 * max(nbytes, 4096) and (best is None or b.nbytes < self.buffers[best].nbytes):
+                best = k
+        if best is not None:
+            return self.buffers.pop(best)
+        return _lib.DeviceBuffer(nbytes)
+
+    def give(self, buf):
+        if buf is not None and buf.ptr is not None:
+            self.buffers.append(buf)
+            if len(self.buffers) > 24:                          # bound the pool: drop the smallest
+                self.buffers.sort(key=lambda b: b.nbytes)
+                self.buffers.pop(0).free()
+
+    def free(self):
+        for b in self.buffers:
+            b.free()
+        self.buffers = []
+        for sysh in self.systems.values():
+            _lib.load().fb_sys_destroy(_lib.ctx(), sysh)
+        self.systems = {}
+
+
 class StripBatchMatcher:
     def __init__(self, P, H, W, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
-                 conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9, compute_strain=True, spacings=None):
+                 conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9, compute_strain=True, spacings=None,
+                 pool=None):
         assert coarse_downsample in (0.5, 1)
+        self._pool = pool
+        alloc = pool.take if pool is not None else _lib.DeviceBuffer
         self.P, self.H, self.W = int(P), int(H), int(W)
         self.sigma = float(sigma)
         self.cds = coarse_downsample
@@ -97,12 +136,12 @@ class StripBatchMatcher:
         hc, wc = (half_size(H), half_size(W)) if coarse_downsample == 0.5 else (H, W)      # cv2.resize(fx=0.5): cvRound(n / 2)
         self.hc, self.wc = hc, wc
         n = self.P
-        self.d_small = _lib.DeviceBuffer(2 * n * hc * wc) if coarse_downsample == 0.5 else None
-        self.d_dogc = _lib.DeviceBuffer(2 * n * hc * wc * 4)
-        self.d_dogf = _lib.DeviceBuffer(2 * n * H * W * 4)
+        self.d_small = alloc(2 * n * hc * wc) if coarse_downsample == 0.5 else None
+        self.d_dogc = alloc(2 * n * hc * wc * 4)
+        self.d_dogf = alloc(2 * n * H * W * 4)
         self.max_blocks = n * 1024
-        self.d_blk = _lib.DeviceBuffer(self.max_blocks * 9 * 4)
-        self.d_out = _lib.DeviceBuffer(self.max_blocks * 20)       # per launch: [dx f64 N][dy f64 N][conf f32 N], one D2H copy
+        self.d_blk = alloc(self.max_blocks * 9 * 4)
+        self.d_out = alloc(self.max_blocks * 20)       # per launch: [dx f64 N][dy f64 N][conf f32 N], one D2H copy
         self.residue_len = float(residue_len)                 # matcher.py:236 (fine_downsample = 1)
         self.stiffness_lambda = float(stiffness_lambda)       # matcher.py:507
         self.relax_tol = float(relax_tol)
@@ -113,14 +152,21 @@ class StripBatchMatcher:
         self.last_tiers = {}
 
     def free(self):
+        pool = self._pool
         if self._relax_sys is not None:
-            _lib.load().fb_sys_destroy(_lib.ctx(), self._relax_sys)
+            if pool is not None:
+                pool.systems[self._sys_key] = self._relax_sys          # kept for the next matcher of this topology
+            else:
+                _lib.load().fb_sys_destroy(_lib.ctx(), self._relax_sys)
             self._relax_sys = None
-        for b in (self.d_small, self.d_dogc, self.d_dogf, self.d_blk, self.d_out):
+        for name in ('d_small', 'd_dogc', 'd_dogf', 'd_blk', 'd_out'):
+            b = getattr(self, name, None)
             if b is not None:
-                b.free()
+                pool.give(b) if pool is not None else b.free()
+                setattr(self, name, None)
         for name in [k for k in vars(self) if k.startswith('_scr_')]:
-            getattr(self, name).free()
+            b = getattr(self, name)
+            pool.give(b) if pool is not None else b.free()
             delattr(self, name)
 
     # ------------------------------------------------------------------ stages
@@ -304,8 +350,8 @@ class StripBatchMatcher:
         buf = getattr(self, '_scr_' + name, None)
         if buf is None or buf.nbytes < nbytes:
             if buf is not None:
-                buf.free()
-            buf = _lib.DeviceBuffer(int(nbytes))
+                self._pool.give(buf) if self._pool is not None else buf.free()
+            buf = self._pool.take(nbytes) if self._pool is not None else _lib.DeviceBuffer(int(nbytes))
             setattr(self, '_scr_' + name, buf)
         return buf
 
@@ -503,15 +549,19 @@ class StripBatchMatcher:
                            min_num_blocks=self.mnb, uid=1)
         self._mesh = m
         V, T, P = m.num_vertices, m.num_triangles, self.P
-        sysh = C.c_void_p()
-        _lib.check(lib.fb_sys_create(ctx, P * V, C.byref(sysh)))
-        # the P copies enter as ONE mesh (one assembly launch per stiffness state)
-        tri_u = np.ascontiguousarray((m.triangles[None, :, :] + (np.arange(P) * V)[:, None, None]).reshape(-1, 3), dtype=np.int32)
-        mid = C.c_int()
-        _lib.check(lib.fb_sys_add_mesh(ctx, sysh, 0, _lib.ptr(tri_u), P * V, P * T, C.byref(mid)))
-        _lib.check(lib.fb_sys_set_links(ctx, sysh, 0, None))
-        nnzb = C.c_int64()
-        _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
+        self._sys_key = (P, m.grid_xs.size, m.grid_ys.size)
+        sysh = self._pool.systems.pop(self._sys_key, None) if self._pool is not None else None
+        if sysh is None:
+            sysh = C.c_void_p()
+            _lib.check(lib.fb_sys_create(ctx, P * V, C.byref(sysh)))
+            # the P copies enter as ONE mesh (one assembly launch per stiffness state)
+            tri_u = np.ascontiguousarray((m.triangles[None, :, :] + (np.arange(P) * V)[:, None, None]).reshape(-1, 3), dtype=np.int32)
+            mid = C.c_int()
+            _lib.check(lib.fb_sys_add_mesh(ctx, sysh, 0, _lib.ptr(tri_u), P * V, P * T, C.byref(mid)))
+            _lib.check(lib.fb_sys_set_links(ctx, sysh, 0, None))
+            nnzb = C.c_int64()
+            _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
+        # (a system of the same topology from the pool keeps its symbolic pattern; the stiffness is re-assembled below)
         self._mult_u = np.ascontiguousarray(np.tile(m.element_multiplier(), P), dtype=np.float32)
         self._v_init_u = np.ascontiguousarray(np.tile(m.vertices(const.MESH_GEAR_INITIAL), (P, 1)), dtype=np.float64)
         self._relax_sys = sysh
