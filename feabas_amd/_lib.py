@@ -67,6 +67,8 @@ _PROTOS = {
     'fb_dog_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
     'fb_area_downsample2': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'fb_area_downsample2_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    'fb_area_downsample2_sizes_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    'fb_dog_sizes_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_d, c_i, c_p]),
     'fb_remap_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'fb_synth_strips_dev': (c_i, [c_p, c_i, c_i, c_i, c_i, C.c_uint32, c_i, c_i, C.c_float, c_p, c_p, c_p]),
     'fb_sys_create': (c_i, [c_p, c_i64, C.POINTER(c_p)]),
@@ -85,7 +87,8 @@ _PROTOS = {
     'fb_sys_solve_groups': (c_i, [c_p, c_p, c_i, c_p, c_d, c_d, c_i, c_i, c_p, c_p]),
     'fb_sys_group_energy': (c_i, [c_p, c_p, c_i, c_p, c_p]),
     'fb_pairs_relax': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_d, c_d, c_d, c_p, c_p, c_p, c_p]),
-    'fb_pairs_relax_bary': (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_d, c_d, c_d, c_d, c_p, c_p, c_p, c_p]),
+    'fb_pairs_relax_bary': (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_d, c_d, c_p, c_d, c_d, c_p, c_p, c_p, c_p]),
+    'fb_pairs_strain_bary': (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_d, c_p, c_p, c_p]),
     'fb_deformed_block_affines': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_d, c_p, c_p, c_p]),
     'fb_deformed_exact_field': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     'fb_deformed_locate': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),

@@ -160,15 +160,19 @@ __global__ void remap_kernel(const float* __restrict__ imgs, int IH, int IW, int
 // float(sum) / count rounded half to even
 __host__ __device__ inline int half_size(int n) { return (n & 1) ? (((n >> 1) & 1) ? (n >> 1) + 1 : (n >> 1)) : (n >> 1); }
 
-__global__ void area_down2_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int N, int H, int W) {
+// sizes (nullable) [N][2] = {h, w} of image n inside its H x W slot (strips of unequal size share a padded stack): the
+// output slot is half_size(H) x half_size(W), image n fills its half_size(h) x half_size(w) corner, the rest is zero
+__global__ void area_down2_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int N, int H, int W, const int* __restrict__ sizes) {
     const int Ho = half_size(H), Wo = half_size(W);
     const size_t total = (size_t)N * Ho * Wo;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t n = i / ((size_t)Ho * Wo);
         const int rem = (int)(i - n * (size_t)Ho * Wo);
         const int y = rem / Wo, x = rem - y * Wo;
+        const int Hn = sizes ? sizes[2 * n] : H, Wn = sizes ? sizes[2 * n + 1] : W;
+        if (y >= half_size(Hn) || x >= half_size(Wn)) { out[i] = 0; continue; }
         const uint8_t* p = in + (n * H + 2 * y) * (size_t)W + 2 * x;
-        const bool x1 = 2 * x + 1 < W, y1 = 2 * y + 1 < H;
+        const bool x1 = 2 * x + 1 < Wn, y1 = 2 * y + 1 < Hn;
         if (x1 && y1) {
             const int s = (int)p[0] + (int)p[1] + (int)p[W] + (int)p[W + 1];
             out[i] = (uint8_t)((s + 2) >> 2);
@@ -283,15 +287,26 @@ __device__ __forceinline__ void col_pass(const float* __restrict__ src, int ps, 
 }
 
 template <typename T, int R>
-__global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, float* __restrict__ out, int H, int W, int signed_out,
-                                                const TapsF taps) {
+__global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, float* __restrict__ out, int SH, int SW, int signed_out,
+                                                const int* __restrict__ sizes, const TapsF taps) {
     using G = FastGeom<R>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bufA = smem;
     float* bufB = smem + G::SZ_A;
     const int n = blockIdx.z;
     const int x0 = blockIdx.x * FT, y0 = blockIdx.y * FT;
-    const T* src = img + (size_t)n * H * W;
+    // image n occupies the H x W corner of its SH x SW slot (sizes == nullptr: the whole slot); the 'nearest' extension
+    // and the output are those of the H x W image
+    const int H = sizes ? sizes[2 * n] : SH, W = sizes ? sizes[2 * n + 1] : SW;
+    if (x0 >= W || y0 >= H) {
+        // a tile of the slot outside the image: zero, so that windows cropped past the image border read the fill value
+        for (int i = threadIdx.x; i < FT * FT; i += blockDim.x) {
+            const int gy = y0 + i / FT, gx = x0 + i % FT;
+            if (gy < SH && gx < SW) out[((size_t)n * SH + gy) * SW + gx] = 0.f;
+        }
+        return;
+    }
+    const T* src = img + (size_t)n * SH * SW;
     const int tid = threadIdx.x, nt = blockDim.x;
     // stage 0: clamped input tile ('nearest' extension of the image).  Threads = 2 row groups x 128 columns;
     // 8 rows are fetched per trip so that the loads are in flight together (a load -> LDS store per trip
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, floa
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 const int ty = min(tb + u * nrg, G::AH - 1);
-                val[u] = load_px<T>(src, (size_t)clampi(y0 - G::HAL + ty, 0, H - 1) * W + gx);
+                val[u] = load_px<T>(src, (size_t)clampi(y0 - G::HAL + ty, 0, H - 1) * SW + gx);
             }
             if (tx < G::AW) {
 #pragma unroll
@@ -363,21 +378,21 @@ __global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, floa
             for (int q = 0; q < RUN + 2 * R; ++q) in[q] = p[q * G::PD];
             fir_run<R>(in, taps, o);
             const int gx = x0 + c;
-            if (gx >= W) continue;
+            if (gx >= SW) continue;
 #pragma unroll
             for (int j = 0; j < RUN; ++j) {
                 const int ty = run * RUN + j, gy = y0 + ty;
-                if (gy >= H) break;
+                if (gy >= SH) break;
                 float v = bufA[(ty + R) * G::PB + (c + R)] - o[j];
                 if (!signed_out) v = fabsf(v);
-                out[((size_t)n * H + gy) * W + gx] = v;
+                out[((size_t)n * SH + gy) * SW + gx] = (gx < W && gy < H) ? v : 0.f;      // slot pixels outside the image: 0
             }
         }
     }
 }
 
 template <typename T, int R>
-int launch_fast(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const Taps& taps) {
+int launch_fast(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const Taps& taps, const int* sizes) {
     using G = FastGeom<R>;
     TapsF tf;
     for (int k = 0; k <= kMaxRadius; ++k) tf.w[k] = (float)taps.w[k];
@@ -385,21 +400,22 @@ int launch_fast(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int 
     auto kern = dog_fast<T, R>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(fb_cdiv(W, FT), fb_cdiv(H, FT), N);
-    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, ctx->stream, img, out, H, W, signed_out, tf);
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, ctx->stream, img, out, H, W, signed_out, sizes, tf);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
 
 template <typename T>
-int launch_fast_any(fb_ctx* ctx, int r, const T* img, float* out, int N, int H, int W, int signed_out, const Taps& taps, bool* done) {
+int launch_fast_any(fb_ctx* ctx, int r, const T* img, float* out, int N, int H, int W, int signed_out, const Taps& taps, bool* done,
+                    const int* sizes = nullptr) {
     *done = true;
     switch (r) {
-        case 5: return launch_fast<T, 5>(ctx, img, out, N, H, W, signed_out, taps);
-        case 6: return launch_fast<T, 6>(ctx, img, out, N, H, W, signed_out, taps);
-        case 8: return launch_fast<T, 8>(ctx, img, out, N, H, W, signed_out, taps);
-        case 10: return launch_fast<T, 10>(ctx, img, out, N, H, W, signed_out, taps);
-        case 12: return launch_fast<T, 12>(ctx, img, out, N, H, W, signed_out, taps);
-        case 14: return launch_fast<T, 14>(ctx, img, out, N, H, W, signed_out, taps);
+        case 5: return launch_fast<T, 5>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+        case 6: return launch_fast<T, 6>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+        case 8: return launch_fast<T, 8>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+        case 10: return launch_fast<T, 10>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+        case 12: return launch_fast<T, 12>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+        case 14: return launch_fast<T, 14>(ctx, img, out, N, H, W, signed_out, taps, sizes);
         default: *done = false; return FB_OK;
     }
 }
@@ -493,6 +509,29 @@ int fb_dog_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, dou
     return dog_dev_t<float>(ctx, (const float*)img, N, H, W, sigma, mask, signed_out, out);
 }
 
+// DoG of N images of unequal size that share a padded stack: image n is the sizes[n] = {h, w} corner of its H x W slot
+// (device int32 [N][2]); each is filtered as an h x w image ('nearest' extension at ITS border), pixels outside are
+// left untouched.  Fast path only (the radii of the matcher's sigmas).
+int fb_dog_sizes_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, const int* sizes, double sigma, int signed_out,
+                     float* out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && sigma > 0 && sizes);
+    FB_CHECK_ARG(ctx, dtype == FB_U8 || dtype == FB_F32);
+    if (N == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, img && out);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    int r = 0;
+    Taps taps;
+    int rc = set_taps(ctx, sigma, &r, &taps);
+    if (rc) return rc;
+    bool done = false;
+    FB_PROF_B(ctx, "dog_fast", (double)N * H * W * ((dtype == FB_U8 ? 1.0 : 4.0) + 4.0));
+    if (dtype == FB_U8) rc = launch_fast_any<uint8_t>(ctx, r, (const uint8_t*)img, out, N, H, W, signed_out, taps, &done, sizes);
+    else rc = launch_fast_any<float>(ctx, r, (const float*)img, out, N, H, W, signed_out, taps, &done, sizes);
+    if (!rc && !done) return fb_fail(ctx, FB_ERR_ARG, "fb_dog_sizes_dev: sigma %.3f (radius %d) has no fast kernel", sigma, r);
+    return rc;
+}
+
 int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* mask, int signed_out,
            float* out) {
     FB_LOCK(ctx);
@@ -535,16 +574,20 @@ int fb_remap_dev(fb_ctx* ctx, const float* imgs, int IH, int IW, int N, const in
     return FB_OK;
 }
 
-int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {
+int fb_area_downsample2_sizes_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, const int* sizes, uint8_t* out) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, N >= 0 && H > 1 && W > 1);
     if (N == 0) return FB_OK;
     FB_PROF(ctx, "area_down2");
     const size_t total = (size_t)N * half_size(H) * half_size(W);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(area_down2_kernel, dim3(blocks), dim3(256), 0, ctx->stream, img, out, N, H, W);
+    hipLaunchKernelGGL(area_down2_kernel, dim3(blocks), dim3(256), 0, ctx->stream, img, out, N, H, W, sizes);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
+}
+
+int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {
+    return fb_area_downsample2_sizes_dev(ctx, img, N, H, W, nullptr, out);
 }
 
 int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out) {

@@ -922,7 +922,8 @@ namespace {
 // shared tail of fb_pairs_relax / fb_pairs_relax_bary: the links (h_nodes6, h_B1, h_bary6) are resident, h_dxy holds the
 // residual of every match before the solve.  Solve every pair, then the huber residue weights.
 int pairs_relax_core(fb_ctx* ctx, fb_system* s, int P, int64_t K, const float* conf, double residue_len, double sample_err,
-                     double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres) {
+                     double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres,
+                     const double* sample_err_each = nullptr) {
     int rc;
     if ((rc = fb_sys_assemble_links(ctx, s, s->h_bary6.data(), conf, s->h_dxy.data()))) return rc;
     if ((rc = fb_sys_form_groups(ctx, s, P, stiffness_lambda, -1.0, nullptr))) return rc;
@@ -936,7 +937,8 @@ int pairs_relax_core(fb_ctx* ctx, fb_system* s, int P, int64_t K, const float* c
         double ux = 0.0, uy = 0.0;
         for (int a = 0; a < 3; ++a) { ux += s->h_x[2 * (size_t)n6[3 + a]] * b1[a]; uy += s->h_x[2 * (size_t)n6[3 + a] + 1] * b1[a]; }
         const double rx = s->h_dxy[2 * k] + ux, ry = s->h_dxy[2 * k + 1] + uy;
-        const double d2 = rx * rx + ry * ry - sample_err * sample_err;
+        const double se = sample_err_each ? sample_err_each[k] : sample_err;
+        const double d2 = rx * rx + ry * ry - se * se;
         const double dis = std::sqrt(d2 > 0.0 ? d2 : 0.0);
         rw[k] = (float)(residue_len / std::max(dis, residue_len));
     }
@@ -971,8 +973,8 @@ int fb_pairs_relax(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const doubl
 // energy of the earlier deformation (the `stress` term of optimizer.py:1417-1418) is inside the system: the minimiser
 // is the reference's MOVING gear after optimize_linear, whatever the starting field.
 int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int32_t* nodes3, const double* B1, const double* dxy0,
-                        const float* conf, double residue_len, double sample_err, double stiffness_lambda, double rtol, float* rw,
-                        double* x_out, int* iters, double* relres) {
+                        const float* conf, double residue_len, double sample_err, const double* sample_err_each, double stiffness_lambda,
+                        double rtol, float* rw, double* x_out, int* iters, double* relres) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && P > 0 && s->nv % P == 0 && K > 0 && nodes3 && B1 && dxy0 && conf && rw);
     s->h_nodes6.resize(6 * (size_t)K);
@@ -993,7 +995,7 @@ int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int32
     }
     int rc = fb_sys_update_links(ctx, s, K, s->h_nodes6.data());
     if (rc) return rc;
-    return pairs_relax_core(ctx, s, P, K, conf, residue_len, sample_err, stiffness_lambda, rtol, rw, x_out, iters, relres);
+    return pairs_relax_core(ctx, s, P, K, conf, residue_len, sample_err, stiffness_lambda, rtol, rw, x_out, iters, relres, sample_err_each);
 }
 
 // matcher.py:752-777 for a batch, after the rigid initialisation R [P][3][3] (row vectors: v_fixed = v_initial R[:2,:2],
@@ -1001,6 +1003,31 @@ int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int32
 // mesh is Q K Q^T and the link terms are multiples of I2, so the system is solved with the resident K of the INITIAL
 // shape and right-hand sides rotated back by Q^T; es0 = v^T K v of the centred INITIAL mesh (rotation free).
 // links_loaded != 0: the links of the preceding fb_pairs_relax call (same K rows) are reused.
+namespace {
+// tail of fb_pairs_strain / fb_pairs_strain_bary: links resident, h_dxy = Q^T f of every match; es0 [P] or one value
+int pairs_strain_core(fb_ctx* ctx, fb_system* s, int P, const std::vector<char>& has, const float* weight, double stiffness_lambda,
+                      const double* es0, int es0_stride, double default_strain, double* strain, int* iters, double* relres) {
+    int rc;
+    if ((rc = fb_sys_assemble_links(ctx, s, s->h_bary6.data(), weight, s->h_dxy.data()))) return rc;
+    if ((rc = fb_sys_form_groups(ctx, s, P, stiffness_lambda, -1.0, nullptr))) return rc;
+    s->h_x.resize(2 * (size_t)s->nv);
+    const int V = s->nv / P;
+    rc = fb_sys_solve_groups(ctx, s, P, s->h_x.data(), 1e-6, 0.0, 20 * V, 1, iters, relres);
+    if (rc && rc != FB_ERR_NOCONV) return rc;
+    for (int p = 0; p < P; ++p) {                           // Mesh.set_field keeps the mean in the offset (mesh.py:2409-2413)
+        double mx = 0.0, my = 0.0;
+        double* x = &s->h_x[2 * (size_t)p * V];
+        for (int v = 0; v < V; ++v) { mx += x[2 * v]; my += x[2 * v + 1]; }
+        mx /= V; my /= V;
+        for (int v = 0; v < V; ++v) { x[2 * v] -= mx; x[2 * v + 1] -= my; }
+    }
+    std::vector<double> es((size_t)P);
+    if ((rc = fb_sys_group_energy(ctx, s, P, s->h_x.data(), es.data()))) return rc;
+    for (int p = 0; p < P; ++p) strain[p] = has[p] ? std::sqrt(std::max(es[p], 0.0) / es0[(size_t)p * es0_stride]) : default_strain;
+    return FB_OK;
+}
+}  // namespace
+
 int fb_pairs_strain(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
                     const double* xy0_fixed, const double* xy1_init, const float* weight, const double* R, double stiffness_lambda, double es0,
                     int links_loaded, double default_strain, double* strain, int* iters, double* relres) {
@@ -1023,23 +1050,46 @@ int fb_pairs_strain(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const doub
         s->h_dxy[2 * k] = fx * r[0] + fy * r[1];                                   // Q^T f
         s->h_dxy[2 * k + 1] = fx * r[3] + fy * r[4];
     }
-    if ((rc = fb_sys_assemble_links(ctx, s, s->h_bary6.data(), weight, s->h_dxy.data()))) return rc;
-    if ((rc = fb_sys_form_groups(ctx, s, P, stiffness_lambda, -1.0, nullptr))) return rc;
-    s->h_x.resize(2 * (size_t)s->nv);
-    const int V = s->nv / P;
-    rc = fb_sys_solve_groups(ctx, s, P, s->h_x.data(), 1e-6, 0.0, 20 * V, 1, iters, relres);
-    if (rc && rc != FB_ERR_NOCONV) return rc;
-    for (int p = 0; p < P; ++p) {                           // Mesh.set_field keeps the mean in the offset (mesh.py:2409-2413)
-        double mx = 0.0, my = 0.0;
-        double* x = &s->h_x[2 * (size_t)p * V];
-        for (int v = 0; v < V; ++v) { mx += x[2 * v]; my += x[2 * v + 1]; }
-        mx /= V; my /= V;
-        for (int v = 0; v < V; ++v) { x[2 * v] -= mx; x[2 * v + 1] -= my; }
+    return pairs_strain_core(ctx, s, P, has, weight, stiffness_lambda, &es0, 0, default_strain, strain, iters, relres);
+}
+
+// fb_pairs_strain for pairs whose meshes share a topology but not a geometry (strips of unequal size): the caller locates
+// the matches (nodes3, B1 in the INITIAL mesh of its pair) and gives Es0 per pair
+int fb_pairs_strain_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int32_t* pid, const int32_t* nodes3, const double* B1,
+                         const double* xy0_fixed, const double* xy1_init, const float* weight, const double* R, double stiffness_lambda,
+                         const double* es0, double default_strain, double* strain, int* iters, double* relres) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && P > 0 && s->nv % P == 0 && K > 0 && pid && nodes3 && B1 && xy0_fixed && xy1_init && weight && R && strain && es0);
+    s->h_nodes6.resize(6 * (size_t)K);
+    s->h_bary6.resize(6 * (size_t)K);
+    s->h_B1.assign(B1, B1 + 3 * (size_t)K);
+    s->h_dxy.resize(2 * (size_t)K);
+    std::vector<char> has((size_t)P, 0);
+    for (int64_t k = 0; k < K; ++k) {
+        const int p = pid[k];
+        FB_CHECK_ARG(ctx, p >= 0 && p < P);
+        has[p] = 1;
+        int32_t* n6 = &s->h_nodes6[6 * (size_t)k];
+        double* b6 = &s->h_bary6[6 * (size_t)k];
+        n6[0] = n6[1] = n6[2] = -1;
+        b6[0] = 1.0; b6[1] = 0.0; b6[2] = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const int32_t v = nodes3[3 * k + a];
+            if (v < 0 || v >= s->nv) return fb_fail(ctx, FB_ERR_ARG, "fb_pairs_strain_bary: vertex %d outside [0, %d)", v, s->nv);
+            n6[3 + a] = v;
+            b6[3 + a] = -B1[3 * k + a];
+        }
+        const double* r = R + 9 * (size_t)p;
+        const double x1 = xy1_init[2 * k], y1 = xy1_init[2 * k + 1];
+        const double fx = x1 * r[0] + y1 * r[3] + r[6] - xy0_fixed[2 * k];
+        const double fy = x1 * r[1] + y1 * r[4] + r[7] - xy0_fixed[2 * k + 1];
+        s->h_dxy[2 * k] = fx * r[0] + fy * r[1];
+        s->h_dxy[2 * k + 1] = fx * r[3] + fy * r[4];
     }
-    std::vector<double> es((size_t)P);
-    if ((rc = fb_sys_group_energy(ctx, s, P, s->h_x.data(), es.data()))) return rc;
-    for (int p = 0; p < P; ++p) strain[p] = has[p] ? std::sqrt(std::max(es[p], 0.0) / es0) : default_strain;
-    return FB_OK;
+    int rc = fb_sys_update_links(ctx, s, K, s->h_nodes6.data());
+    if (rc) return rc;
+    for (int p = 0; p < P; ++p) FB_CHECK_ARG(ctx, !has[p] || es0[p] > 0.0);
+    return pairs_strain_core(ctx, s, P, has, weight, stiffness_lambda, es0, 1, default_strain, strain, iters, relres);
 }
 
 }  // extern "C"

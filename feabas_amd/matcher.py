@@ -190,10 +190,11 @@ def stitching_matcher_batch_release():
     """free the contexts, staging buffers and matchers that stitching_matcher_batch keeps between calls"""
     for (_, t), slot in list(_batch_workers.items()):
         _lib.use_context(slot.get('ctx'))
-        for r in slot.get('state', {}).get('res', ()):
+        st = slot.get('state', {})
+        for r in tuple(st.get('res', ())) + tuple(st.get('io', ())):
             r.free()
-        if 'pool' in slot.get('state', {}):
-            slot['state']['pool'].free()
+        if 'pool' in st:
+            st['pool'].free()
         _lib.use_context(None)
         if t > 0:
             _lib.destroy_context(slot.get('ctx'))
@@ -307,19 +308,49 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
             if mk is not None and np.asarray(mk).shape != img0.shape:
                 raise ValueError('stitching_matcher_batch: a mask must have the shape of its strip')
         items.append((img0, img1, mk0, mk1))
-    buckets = {}
+    # chunks: ('uniform', (H, W), indices) -- pairs of one strip shape, through StripBatchMatcher (masks, photometric
+    # statistics and the deformed-mesh branch included); ('ragged', key, indices) -- pairs of unequal shape that share the
+    # mesh topology and the number of spacings, through RaggedStripBatchMatcher (strips differ in shape from pair to pair
+    # in a real section, stitcher.py:561-571; a batch per shape would be a batch of one)
+    from .stitch_pipeline import RaggedStripBatchMatcher, MatcherPool
+    by_shape = {}
     for k, it in enumerate(items):
-        buckets.setdefault(it[0].shape, []).append(k)
-    chunks = [(shape, idx[c:c + batch]) for shape, idx in buckets.items() for c in range(0, len(idx), batch)]
+        by_shape.setdefault(it[0].shape, []).append(k)
+    chunks, loose = [], []
+    for shape, idx in by_shape.items():
+        special = [k for k in idx if items[k][2] is not None or items[k][3] is not None or compute_photometric]
+        plain = [k for k in idx if k not in set(special)]
+        for c in range(0, len(special), batch):
+            chunks.append(('uniform', shape, special[c:c + batch]))
+        full = len(plain) // batch * batch if len(plain) >= batch else 0
+        for c in range(0, full, batch):
+            chunks.append(('uniform', shape, plain[c:c + batch]))
+        loose.extend(plain[full:])
+    by_key = {}
+    for k in loose:
+        H, W = items[k][0].shape
+        by_key.setdefault(RaggedStripBatchMatcher.bucket_key(H, W, opts['min_num_blocks'], opts['spacings']), []).append(k)
+    for key, idx in by_key.items():
+        for c in range(0, len(idx), batch):
+            part = idx[c:c + batch]
+            if len({items[k][0].shape for k in part}) == 1:
+                chunks.append(('uniform', items[part[0]][0].shape, part))
+            else:
+                chunks.append(('ragged', key, part))
     results = [None] * len(items)
     errors = []
-    need = max(2 * len(idx) * shape[0] * shape[1] for shape, idx in chunks) if chunks else 0
+    deferred = []
+
+    def slot_bytes(kind, idx):
+        hm = max(items[k][0].shape[0] for k in idx); wm = max(items[k][0].shape[1] for k in idx)
+        return 2 * len(idx) * hm * wm
+    need = max((slot_bytes(kind, idx) for kind, _, idx in chunks), default=0)
     nthr = max(1, min(int(threads), len(chunks)))
     main_ctx = _lib.ctx()
     okey = tuple(None if v is None else (tuple(v.tolist()) if isinstance(v, np.ndarray) else v) for v in opts.values())
 
     def worker(t):
-        # worker t keeps its context and the resources of the last shape it worked on between calls
+        # worker t keeps its context, staging buffers, buffer pool and the matcher of the last uniform shape between calls
         # (stitching_matcher_batch_release frees them)
         slot = _batch_workers.setdefault((id(main_ctx), t), {})
         if 'ctx' not in slot:
@@ -327,39 +358,48 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         _lib.use_context(slot['ctx'])
         state = slot.setdefault('state', {})
         try:
-            for shape, idx in chunks[t::nthr]:
-                H, W = shape
-                n = len(idx)                                  # a short chunk (ragged shapes) gets a matcher of its own size
-                if state.get('key') != (shape, n, okey):
-                    if 'res' in state:
-                        state['res'][0].free()
-                    if state.get('bytes', 0) < need:          # staging buffers: one pair of allocations for the largest chunk
-                        for r in state.get('res', (None,))[1:]:
-                            r.free()
-                        state['io'] = (_lib.PinnedBuffer(need), _lib.DeviceBuffer(need))
-                        state['bytes'] = need
-                    if 'pool' not in state:
-                        from .stitch_pipeline import MatcherPool
-                        state['pool'] = MatcherPool()
-                    state.update(key=(shape, n, okey), res=(StripBatchMatcher(n, H, W, pool=state['pool'], **opts),) + state['io'])
-                m, pin, dev = state['res']
-                stage = pin.array((2, n, H, W), np.uint8)
-                for j in range(n):
-                    src = items[idx[j]]
-                    stage[0, j] = src[0]; stage[1, j] = src[1]
-                _lib.check(_lib.load().fb_memcpy_h2d(_lib.ctx(), dev.ptr, pin.ptr, 2 * n * H * W))
-                mk0 = [items[idx[j]][2] for j in range(n)]
-                mk1 = [items[idx[j]][3] for j in range(n)]
+            if 'pool' not in state:
+                state['pool'] = MatcherPool()
+            if state.get('bytes', 0) < need:                  # staging buffers: one pair of allocations for the largest chunk
+                for r in state.get('io', ()):
+                    r.free()
+                state['io'] = (_lib.PinnedBuffer(need), _lib.DeviceBuffer(need))
+                state['bytes'] = need
+            pin, dev = state['io']
+            for kind, what, idx in chunks[t::nthr]:
+                n = len(idx)
+                Hm = max(items[k][0].shape[0] for k in idx); Wm = max(items[k][0].shape[1] for k in idx)
+                if kind == 'uniform':
+                    if state.get('key') != (what, n, okey):
+                        if 'res' in state:
+                            state.pop('res')[0].free()
+                        state.update(key=(what, n, okey), res=(StripBatchMatcher(n, Hm, Wm, pool=state['pool'], **opts),))
+                    m = state['res'][0]
+                else:
+                    m = RaggedStripBatchMatcher([items[k][0].shape for k in idx], pool=state['pool'], **opts)
+                stage = pin.array((2, n, Hm, Wm), np.uint8)
+                for j, k in enumerate(idx):
+                    h, w = items[k][0].shape
+                    stage[0, j, :h, :w] = items[k][0]; stage[1, j, :h, :w] = items[k][1]
+                _lib.check(_lib.load().fb_memcpy_h2d(_lib.ctx(), dev.ptr, pin.ptr, 2 * n * Hm * Wm))
+                mk0 = [items[k][2] for k in idx]
+                mk1 = [items[k][3] for k in idx]
                 has_mask = any(v is not None for v in mk0 + mk1)
-                out = m.match(dev.ptr, dev.offset(n * H * W), masks0=mk0 if has_mask else None, masks1=mk1 if has_mask else None,
-                              compute_photometric=compute_photometric)
+                try:
+                    out = m.match(dev.ptr, dev.offset(n * Hm * Wm), masks0=mk0 if has_mask else None, masks1=mk1 if has_mask else None,
+                                  compute_photometric=compute_photometric)
+                finally:
+                    if kind == 'ragged':
+                        m.free()
                 per = StripBatchMatcher.per_pair(out)
-                for j in range(n):
+                for j, k in enumerate(idx):
                     r = per[j]
-                    if r['xy0'] is None:
-                        results[idx[j]] = (None, None, opts['conf_thresh'], None, None)
+                    if r.get('deferred'):
+                        deferred.append(k)
+                    elif r['xy0'] is None:
+                        results[k] = (None, None, opts['conf_thresh'], None, None)
                     else:
-                        results[idx[j]] = (r['xy0'], r['xy1'], r['weight'], r['strain'], out['phtm'][j] if compute_photometric else None)
+                        results[k] = (r['xy0'], r['xy1'], r['weight'], r['strain'], out['phtm'][j] if compute_photometric else None)
         except Exception as e:                                # noqa: BLE001 -- re-raised in the calling thread
             errors.append(e)
         finally:
@@ -371,4 +411,6 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         th.join()
     if errors:
         raise errors[0]
+    for k in deferred:                                        # pairs of a ragged batch that take the deformed-mesh branch
+        results[k] = stitching_matcher(items[k][0], items[k][1], **kwargs)
     return results

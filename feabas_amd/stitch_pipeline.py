@@ -132,6 +132,10 @@ class StripBatchMatcher:
             if self.spacings.size == 0 or np.any(self.spacings < 1):
                 raise NotImplementedError('spacings relative to the overlap (< 1, matcher.py:343-350) are not on the device path')
         self._nfl = _nfl_table(2 * max(H, W) + 2)
+        # per-pair strip extents and spacing values ([P], [P, nsp]): constant here, set by RaggedStripBatchMatcher
+        self._Hs = np.full(self.P, self.H, dtype=np.int64)
+        self._Ws = np.full(self.P, self.W, dtype=np.int64)
+        self._sp = np.tile(self.spacings, (self.P, 1))
         from .common import half_size
         hc, wc = (half_size(H), half_size(W)) if coarse_downsample == 0.5 else (H, W)      # cv2.resize(fx=0.5): cvRound(n / 2)
         self.hc, self.wc = hc, wc
@@ -150,6 +154,7 @@ class StripBatchMatcher:
         self._relax_sys = None
         self.last_relax = None
         self.last_tiers = {}
+        self._ragged = False
 
     def free(self):
         pool = self._pool
@@ -277,7 +282,8 @@ class StripBatchMatcher:
     def _blocks(self, tx, ty, t1, sel, spacing, mnb, bounds=None):
         """block descriptors for the pairs `sel` (all share Nx, Ny): returns (blk [Q, nblk, 9], bboxes [Q, nblk, 4]).
         bounds: (xmin, ymin, xmax, ymax) of the intersected mesh bounding boxes of `sel` when mesh1 is deformed."""
-        H, W = self.H, self.W
+        H, W = self._Hs[sel], self._Ws[sel]
+        spacing = np.broadcast_to(np.asarray(spacing, dtype=np.float64), (sel.size,))
         # mesh bounding boxes in the MOVING gear (Mesh.from_bbox: vertices at pixel centres - 0.5)
         if bounds is None:
             xmin = np.maximum(-0.5 + tx[sel], -0.5 + t1[sel, 0]); ymin = np.maximum(-0.5 + ty[sel], -0.5 + t1[sel, 1])
@@ -291,8 +297,8 @@ class StripBatchMatcher:
         yt = np.round(np.linspace(ymin, ymax - dy, num=nyi, endpoint=True, axis=-1)).astype(np.int32)    # [Q, ny]
         x0 = np.broadcast_to(xt[:, None, :], (sel.size, nyi, nxi)).reshape(sel.size, -1)
         y0 = np.broadcast_to(yt[:, :, None], (sel.size, nyi, nxi)).reshape(sel.size, -1)
-        order = _z_order_batch(np.round((x0 - x0.min(axis=-1, keepdims=True)) / spacing),
-                               np.round((y0 - y0.min(axis=-1, keepdims=True)) / spacing))
+        order = _z_order_batch(np.round((x0 - x0.min(axis=-1, keepdims=True)) / spacing[:, None]),
+                               np.round((y0 - y0.min(axis=-1, keepdims=True)) / spacing[:, None]))
         x0 = np.take_along_axis(x0, order, axis=-1)
         y0 = np.take_along_axis(y0, order, axis=-1)
         nblk = x0.shape[1]
@@ -315,16 +321,20 @@ class StripBatchMatcher:
         """one spacing round for the `active` pairs.  Returns a list of groups
         (pair ids [Q], bboxes [Q, nblk, 4], dx, dy, conf [Q, nblk])."""
         lib, ctx = _lib.load(), _lib.ctx()
-        n, H, W = self.P, self.H, self.W
+        n, H, W = self.P, self.H, self.W                     # H, W: the slot size of the strip stacks
+        Hs, Ws = self._Hs, self._Ws                          # per-pair strip extents
+        spacing = np.broadcast_to(np.asarray(spacing, dtype=np.float64), (n,))
         # group by block grid, then by FFT shape (matcher.py:59-62 on the block size)
-        xmin = np.maximum(-0.5 + tx, -0.5 + t1[:, 0]); xmax = np.minimum(W - 0.5 + tx, W - 0.5 + t1[:, 0])
-        ymin = np.maximum(-0.5 + ty, -0.5 + t1[:, 1]); ymax = np.minimum(H - 0.5 + ty, H - 0.5 + t1[:, 1])
+        xmin = np.maximum(-0.5 + tx, -0.5 + t1[:, 0]); xmax = np.minimum(Ws - 0.5 + tx, Ws - 0.5 + t1[:, 0])
+        ymin = np.maximum(-0.5 + ty, -0.5 + t1[:, 1]); ymax = np.minimum(Hs - 0.5 + ty, Hs - 0.5 + t1[:, 1])
         nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
+        ok = (xmax > xmin) & (ymax > ymin)
+        dx = np.where(ok, dx, 1); dy = np.where(ok, dy, 1)
         nfl_h = nfl_w = self._nfl
         fh = np.where(pad_flags, nfl_h[np.clip(2 * dy - 1, 0, None)], nfl_h[dy])
         fw = np.where(pad_flags, nfl_w[np.clip(2 * dx - 1, 0, None)], nfl_w[dx])
         key = ((nx * 4096 + ny) * 8192 + fh) * 8192 + fw
-        key = np.where(active, key, -1)
+        key = np.where(active & ok, key, -1)
         groups = []
         dogf = self.d_dogf_view
         img1 = dogf.offset(n * H * W * 4)
@@ -333,7 +343,7 @@ class StripBatchMatcher:
                 continue
             sel = np.flatnonzero(key == kv)
             gfh, gfw = int(fh[sel[0]]), int(fw[sel[0]])
-            blk, bb = self._blocks(tx, ty, t1, sel, spacing, mnb)
+            blk, bb = self._blocks(tx, ty, t1, sel, spacing[sel], mnb)
             nb = blk.shape[0] * blk.shape[1]
             assert nb <= self.max_blocks
             flat = np.ascontiguousarray(blk.reshape(-1, 9))
@@ -503,6 +513,9 @@ class StripBatchMatcher:
         dxy0 = np.ascontiguousarray(xy1_fixed - xy0c)
         area = float(np.abs(m.triangle_areas(const.MESH_GEAR_INITIAL)[0]))
         sample_err = 0.4387 * area ** 0.5 * DEFAULT_AVG_DEFORM
+        se_each = None
+        if self._ragged:                                      # triangle areas differ from pair to pair
+            se_each = np.ascontiguousarray(self._sample_err_each[np.asarray(pid)])
         tid_local = (self._tri_of_nodes(nodes3 - (np.asarray(pid)[:, None] * V))).astype(np.int32)
         pid32 = np.ascontiguousarray(pid, dtype=np.int32)
         zero_t = np.zeros((self.P, 2))
@@ -512,7 +525,7 @@ class StripBatchMatcher:
             x = np.empty(2 * self.P * V, dtype=np.float64)
             iters, relres = C.c_int(), C.c_double()
             _lib.check(lib.fb_pairs_relax_bary(ctx, sysh, self.P, K, _lib.ptr(nodes3), _lib.ptr(B1), _lib.ptr(dxy0), _lib.ptr(w32),
-                                               self.residue_len if self.residue_len > 0 else 1.0, sample_err, self.stiffness_lambda,
+                                               self.residue_len if self.residue_len > 0 else 1.0, sample_err, _lib.ptr(se_each), self.stiffness_lambda,
                                                self.relax_tol, _lib.ptr(rw), _lib.ptr(x), C.byref(iters), C.byref(relres)))
             self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K), relaxed_first=0)
             return rw, x.reshape(self.P, V, 2)
@@ -522,7 +535,7 @@ class StripBatchMatcher:
         self._links_rows = None
         if self.residue_len <= 0:
             return np.ones(K, dtype=np.float32), x
-        self._relax_first(x, pid32, xy0c, None, zero_t, rw, sample_err, tid_B=(tid_local, B1))
+        self._relax_first(x, pid32, xy0c, None, zero_t, rw, sample_err if se_each is None else se_each, tid_B=(tid_local, B1))
         if resolve and np.any(rw != 1):
             changed = np.unique(pid32[rw != 1])
             _, x2 = solve(np.ascontiguousarray(w32 * rw))
@@ -572,7 +585,14 @@ class StripBatchMatcher:
         es0 = np.empty(P)
         _lib.check(lib.fb_sys_group_energy(ctx, sysh, P, _lib.ptr(v0), _lib.ptr(es0)))
         self._es0 = float(es0[0])                             # v0^T K v0 of the centred mesh: the same for every copy and rotation
+        self._gx = np.tile(m.grid_xs, (P, 1)); self._gy = np.tile(m.grid_ys, (P, 1))      # node coordinates of every pair's grid
         return sysh
+
+    def _pair_mesh(self, p):
+        """a fresh Mesh object of pair p's mesh1 (host statements that work pair by pair)"""
+        m = self._mesh.copy(uid=1)
+        m.grid_xs, m.grid_ys = self._mesh.grid_xs, self._mesh.grid_ys
+        return m
 
     def _assemble_union(self, v_shape, state):
         """stiffness K of the P mesh copies at the given shapes ([P V, 2]); skipped when K already holds `state`"""
@@ -623,8 +643,8 @@ class StripBatchMatcher:
         m = self._mesh
         nx, ny = m.grid_xs.size, m.grid_ys.size
         g = x.reshape(self.P, ny, nx, 2)
-        ex = np.sqrt(np.sum(np.diff(g, axis=2) ** 2, axis=-1)) / np.diff(m.grid_xs)[None, None, :]
-        ey = np.sqrt(np.sum(np.diff(g, axis=1) ** 2, axis=-1)) / np.diff(m.grid_ys)[None, :, None]
+        ex = np.sqrt(np.sum(np.diff(g, axis=2) ** 2, axis=-1)) / np.diff(self._gx, axis=1)[:, None, :]
+        ey = np.sqrt(np.sum(np.diff(g, axis=1) ** 2, axis=-1)) / np.diff(self._gy, axis=1)[:, :, None]
         d = np.maximum(ex.max(axis=(1, 2)), ey.max(axis=(1, 2)))
         suspects = np.flatnonzero(d > 0.1)
         if suspects.size == 0:
@@ -632,13 +652,13 @@ class StripBatchMatcher:
         from .optimizer import relax_mesh_most_deformed
         gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
         cutoff = 1 - 1 / (const.MAXIMUM_DEFORM_ALLOWED + 1)      # SLM.relax_higly_deformed hands the converted value down
-        v_init = m.vertices(const.MESH_GEAR_INITIAL)
+        se_each = np.broadcast_to(np.asarray(sample_err, dtype=np.float64), (pid.size,))
         for p in suspects:
             rows = np.flatnonzero(pid == p)
             if rows.size == 0:
                 continue
-            m1 = m.copy(uid=1)
-            m1.grid_xs, m1.grid_ys = m.grid_xs, m.grid_ys
+            m1 = self._pair_mesh(p)
+            v_init = m1.vertices(const.MESH_GEAR_INITIAL)
             m1.set_field(t1[p] + x[p], gear=gear)
             if not relax_mesh_most_deformed(m1, gear=gear, deform_cutoff=cutoff):
                 continue
@@ -651,7 +671,7 @@ class StripBatchMatcher:
                 tid, B = tid_B[0][rows], tid_B[1][rows]
             dxy = m1.bary2cart(tid, B, const.MESH_GEAR_MOVING, offsetting=True) - xy0[rows]
             dis = np.sum(dxy ** 2, axis=-1) ** 0.5
-            dis = ((dis ** 2 - sample_err ** 2).clip(0, None)) ** 0.5                # optimizer.py:183-185
+            dis = ((dis ** 2 - se_each[rows] ** 2).clip(0, None)) ** 0.5              # optimizer.py:183-185
             rw[rows] = (self.residue_len / np.maximum(dis, self.residue_len)).astype(np.float32)
             x[p] = m1.vertices_w_offset(const.MESH_GEAR_MOVING) - (v_init + t1[p])
 
@@ -796,6 +816,7 @@ class StripBatchMatcher:
         t1 = np.zeros((n, 2))                                # translation of mesh1 acquired by rigid relaxations
         U = None                                             # [n, V, 2] node displacement of a deformed mesh1 (MOVING - INITIAL)
         is_deformed = np.zeros(n, dtype=bool)
+        deferred = np.zeros(n, dtype=bool)
         self.last_tiers = {}
         live = active.copy()                                 # pairs still iterating over the spacings
         for rnd in range(spacings.size):
@@ -804,7 +825,7 @@ class StripBatchMatcher:
             mnb = self.mnb if is_last else 1
             rows = []
             to_relax = np.zeros(n, dtype=bool)               # pairs whose relaxation of this round is not a rigid translation
-            groups = [(g, False) for g in self._match_round(tx, ty, t1, live & ~is_deformed, sp, mnb, pad, subpixel=is_last)]
+            groups = [(g, False) for g in self._match_round(tx, ty, t1, live & ~is_deformed, self._sp[:, rnd], mnb, pad, subpixel=is_last)]
             dp = np.flatnonzero(live & is_deformed)
             if dp.size:
                 groups += [(g, True) for g in self._match_round_deformed(tx, ty, U, dp, sp, mnb, pad, is_last, is_last)]
@@ -848,7 +869,7 @@ class StripBatchMatcher:
                 live[sel[~has_link]] = False                 # ... or break with the links so far (674-675, 722-723)
                 if not is_last:
                     # spacing schedule (matcher.py:689-716), max_spacing_skip = 0
-                    next_pos = np.searchsorted(-spacings, -4 * max_dis) - 1
+                    next_pos = np.sum(self._sp[sel] > (4 * max_dis)[:, None], axis=1) - 1     # = searchsorted(-spacings, -4 max_dis) - 1
                     pad[sel] = np.where(next_pos > rnd, np.minimum(next_pos, rnd + 1) > rnd + 1, True)
                     # max_dis > 0.1: the reference relaxes mesh1 against the links (matcher.py:725-742).  When every
                     # kept block reports the same displacement the exact minimiser is the rigid translation
@@ -874,6 +895,14 @@ class StripBatchMatcher:
                 prev = table
                 table = tuple(np.concatenate([r[k] for r in rows], axis=0) for k in range(8))
                 last_links = None
+                if to_relax.any() and self._ragged:
+                    # pairs of unequal strip size take the deformed-mesh branch one by one (the caller re-runs them through a
+                    # matcher of their own): out of this batch
+                    deferred |= to_relax
+                    live[to_relax] = False
+                    keep_rows = ~to_relax[table[0]]
+                    table = tuple(a[keep_rows] for a in table)
+                    to_relax[:] = False
                 pid_l, xy0_l, xy1i_l, wt_l, xy1_l, rl, nd_l, B1_l = table
                 if to_relax.any():
                     # non-rigid relaxation between spacings (matcher.py:725-741): mesh1 of these pairs keeps the field
@@ -892,7 +921,7 @@ class StripBatchMatcher:
                     # last round (matcher.py:725-737): relaxation + huber residue weights, pairs with max_dis > 0.1.  All rows
                     # of the round enter the block-diagonal system (a pair that needs no relaxation is solved and ignored), so
                     # that the strain estimate below can reuse the same links
-                    if is_deformed.any():
+                    if is_deformed.any() or self._ragged:
                         nd_a, B1_a = self._rows_bary(pid_l, xy1i_l, nd_l, B1_l)
                         rw, _ = self._relax_general(pid_l, xy0_l, nd_a, B1_a, wt_l, resolve=False)
                     else:
@@ -909,7 +938,7 @@ class StripBatchMatcher:
                     if carry.any():
                         table = tuple(np.concatenate((a, b[carry]), axis=0) for a, b in zip(table, prev))
                         last_links = None
-        valid = active & has_last
+        valid = active & has_last & ~deferred
         if table is None:
             table = (np.zeros(0, np.int64), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0, np.float32))
         pid, xy0, xy1, wt = table
@@ -921,8 +950,8 @@ class StripBatchMatcher:
         xy0 = xy0 - txy[pid]
         strain = self._strain(pid, xy0, xy1, wt, txy, reuse_links=bool(last_links)) if self.compute_strain else np.full(n, DEFAULT_AVG_DEFORM)
         self.last_field = U
-        return dict(tx=tx, ty=ty, conf0=cf0, valid=valid, needs_host=np.zeros(n, dtype=bool), deformed=is_deformed, pair=pid, xy0=xy0, xy1=xy1,
-                    weight=wt, strain=strain, phtm=phtm)
+        return dict(tx=tx, ty=ty, conf0=cf0, valid=valid, needs_host=np.zeros(n, dtype=bool), deformed=is_deformed, deferred=deferred, pair=pid,
+                    xy0=xy0, xy1=xy1, weight=wt, strain=strain, phtm=phtm)
 
     @staticmethod
     def per_pair(res):
@@ -932,8 +961,211 @@ class StripBatchMatcher:
             m = res['pair'] == p
             if res['valid'][p]:
                 out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=False, deformed=bool(res['deformed'][p]),
-                                xy0=res['xy0'][m], xy1=res['xy1'][m], weight=res['weight'][m], strain=float(res['strain'][p])))
+                                deferred=False, xy0=res['xy0'][m], xy1=res['xy1'][m], weight=res['weight'][m], strain=float(res['strain'][p])))
             else:
                 out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=False, deformed=False,
+                                deferred=bool(res['deferred'][p]) if 'deferred' in res else False,
                                 xy0=None, xy1=None, weight=None, strain=DEFAULT_AVG_DEFORM))
         return out
+
+
+class RaggedStripBatchMatcher(StripBatchMatcher):
+    """A batch of tile pairs whose strips differ in SIZE (the usual case in a real section: the overlap follows the stage
+    jitter, stitcher.py:561-571) but share the mesh topology and the number of spacings -- `ragged_bucket_key`.  Strips sit
+    in zero-padded slots of the largest size; every stage works on each pair's own extent: x0.5 downsample and DoG with
+    per-image sizes (fb_area_downsample2_sizes_dev, fb_dog_sizes_dev), the whole-strip NCC through block descriptors
+    grouped by FFT shape, per-pair block grids and spacing values, one mesh GEOMETRY per pair inside the shared
+    block-diagonal system (per-pair node coordinates, Es0 and sample errors; fb_pairs_relax_bary / fb_pairs_strain_bary).
+    A pair whose relaxation between spacings is not a rigid translation is reported `deferred`: the caller runs it
+    through a matcher of its own (`StripBatchMatcher` handles the deformed-mesh branch for equal shapes).
+    Masks and photometric statistics are not taken here."""
+
+    @staticmethod
+    def bucket_key(H, W, min_num_blocks=2, spacings=None):
+        """pairs with equal keys can share a batch: number of spacings, node grid of Mesh.from_bbox (mesh.py:403-435)"""
+        sp = np.sort(auto_spacings((H, W), (H, W)))[::-1] if spacings is None else np.sort(np.asarray(spacings, dtype=np.float64))[::-1]
+        m = Mesh.from_bbox((0, 0, W, H), cartesian=True, mesh_size=float(np.min(sp)), min_num_blocks=min_num_blocks, uid=1)
+        return (sp.size, m.grid_xs.size, m.grid_ys.size)
+
+    def __init__(self, shapes, **opts):
+        shapes = np.asarray(shapes, dtype=np.int64).reshape(-1, 2)
+        Hmax, Wmax = int(shapes[:, 0].max()), int(shapes[:, 1].max())
+        spacings = opts.get('spacings', None)
+        super().__init__(shapes.shape[0], Hmax, Wmax, **opts)
+        self._ragged = True
+        self._Hs, self._Ws = shapes[:, 0].copy(), shapes[:, 1].copy()
+        if spacings is None:
+            sp = [np.sort(auto_spacings((h, w), (h, w)))[::-1] for h, w in shapes]
+            if len({a.size for a in sp}) != 1:
+                raise ValueError('RaggedStripBatchMatcher: the pairs of a batch must have the same number of spacings')
+            self._sp = np.stack(sp)
+        self._nfl = _nfl_table(2 * max(Hmax, Wmax) + 2)
+        from .common import half_size
+        if self.cds == 0.5:
+            self._hcs = np.array([half_size(int(h)) for h in self._Hs]); self._wcs = np.array([half_size(int(w)) for w in self._Ws])
+        else:
+            self._hcs, self._wcs = self._Hs, self._Ws
+        n = self.P
+        self.d_sizes = _lib.DeviceBuffer.from_array(np.ascontiguousarray(np.tile(shapes, (2, 1)), dtype=np.int32))
+        self.d_sizes_c = _lib.DeviceBuffer.from_array(np.ascontiguousarray(np.tile(np.stack((self._hcs, self._wcs), -1), (2, 1)), dtype=np.int32))
+
+    def free(self):
+        for name in ('d_sizes', 'd_sizes_c'):
+            b = getattr(self, name, None)
+            if b is not None:
+                b.free()
+                setattr(self, name, None)
+        super().free()
+
+    # ---- image stages on per-image extents
+    def _global(self, strips0, strips1, masks=None):
+        if masks is not None:
+            raise NotImplementedError('RaggedStripBatchMatcher: masks are not taken (use StripBatchMatcher per shape)')
+        lib, ctx = _lib.load(), _lib.ctx()
+        n, H, W, hc, wc = self.P, self.H, self.W, self.hc, self.wc
+        if self.cds == 0.5:
+            _lib.check(lib.fb_area_downsample2_sizes_dev(ctx, strips0, n, H, W, self.d_sizes.ptr, self.d_small.ptr))
+            _lib.check(lib.fb_area_downsample2_sizes_dev(ctx, strips1, n, H, W, self.d_sizes.ptr, self.d_small.offset(n * hc * wc)))
+            _lib.check(lib.fb_dog_sizes_dev(ctx, self.d_small.ptr, 0, 2 * n, hc, wc, self.d_sizes_c.ptr, self.sigma * self.cds, 1, self.d_dogc.ptr))
+        else:
+            _lib.check(lib.fb_dog_sizes_dev(ctx, strips0, 0, n, hc, wc, self.d_sizes_c.ptr, self.sigma, 1, self.d_dogc.ptr))
+            _lib.check(lib.fb_dog_sizes_dev(ctx, strips1, 0, n, hc, wc, self.d_sizes_c.ptr, self.sigma, 1, self.d_dogc.offset(n * hc * wc * 4)))
+        # whole-strip NCC (matcher.py:153) of every pair's own extent: block descriptors, one launch per FFT shape
+        fh = self._nfl[2 * self._hcs - 1]; fw = self._nfl[2 * self._wcs - 1]
+        tx = np.zeros(n); ty = np.zeros(n); cf = np.zeros(n, dtype=np.float32)
+        key = fh * 65536 + fw
+        img1 = self.d_dogc.offset(n * hc * wc * 4)
+        for kv in np.unique(key):
+            sel = np.flatnonzero(key == kv)
+            blk = np.zeros((sel.size, 9), dtype=np.int32)
+            blk[:, 0] = sel
+            blk[:, 3] = self._hcs[sel]; blk[:, 4] = self._wcs[sel]; blk[:, 7] = self._hcs[sel]; blk[:, 8] = self._wcs[sel]
+            _lib.check(lib.fb_memcpy_h2d(ctx, self.d_blk.ptr, _lib.ptr(blk), blk.nbytes))
+            nb = sel.size
+            _lib.check(lib.fb_ncc_blocks_dev(ctx, self.d_dogc.ptr, img1, hc, wc, hc, wc, nb, self.d_blk.ptr, int(self._hcs[sel].max()), int(self._wcs[sel].max()),
+                                             int(fh[sel[0]]), int(fw[sel[0]]), 0, self.conf_mode, self.d_out.ptr, self.d_out.offset(8 * nb),
+                                             self.d_out.offset(16 * nb)))
+            gx, gy, gc = self._fetch_out(nb)
+            tx[sel] = gx; ty[sel] = gy; cf[sel] = gc
+        low = np.flatnonzero(~(cf > self.conf_thresh))
+        if low.size:                                          # second shot of global_translation_matcher (matcher.py:159-221), per pair
+            from .matcher import global_translation_matcher
+            full = self.d_dogc.to_array((2 * n, hc, wc), np.float32) if low.size > 2 else None
+            for p in low:
+                h_, w_ = int(self._hcs[p]), int(self._wcs[p])
+                if full is not None:
+                    g0, g1 = full[p, :h_, :w_], full[n + p, :h_, :w_]
+                else:
+                    g0 = self.d_dogc.to_array((2 * n, hc, wc), np.float32)[p, :h_, :w_]
+                    g1 = self.d_dogc.to_array((2 * n, hc, wc), np.float32)[n + p, :h_, :w_]
+                tx[p], ty[p], cf[p] = global_translation_matcher(np.ascontiguousarray(g0), np.ascontiguousarray(g1), conf_mode=self.conf_mode,
+                                                                  conf_thresh=self.conf_thresh)
+        return tx, ty, cf
+
+    def _fine_dog(self, strips0, strips1, masks=None):
+        lib, ctx = _lib.load(), _lib.ctx()
+        n, H, W = self.P, self.H, self.W
+        if self.cds == 1:
+            self.d_dogf_view = self.d_dogc
+            return
+        _lib.check(lib.fb_dog_sizes_dev(ctx, strips0, 0, n, H, W, self.d_sizes.ptr, self.sigma, 1, self.d_dogf.ptr))
+        _lib.check(lib.fb_dog_sizes_dev(ctx, strips1, 0, n, H, W, self.d_sizes.ptr, self.sigma, 1, self.d_dogf.offset(n * H * W * 4)))
+        self.d_dogf_view = self.d_dogf
+
+    def _photometric(self, *a, **k):
+        raise NotImplementedError('RaggedStripBatchMatcher: photometric statistics are not taken (use StripBatchMatcher per shape)')
+
+    # ---- one mesh geometry per pair inside the shared system
+    def _relax_system(self):
+        if self._relax_sys is not None:
+            return self._relax_sys
+        lib, ctx = _lib.load(), _lib.ctx()
+        P = self.P
+        meshes = [Mesh.from_bbox((0, 0, int(w), int(h)), cartesian=True, mesh_size=float(np.min(self._sp[p])), min_num_blocks=self.mnb, uid=1)
+                  for p, (h, w) in enumerate(zip(self._Hs, self._Ws))]
+        m = meshes[0]
+        if any(mm.grid_xs.size != m.grid_xs.size or mm.grid_ys.size != m.grid_ys.size for mm in meshes):
+            raise ValueError('RaggedStripBatchMatcher: the pairs of a batch must share the node grid of their meshes (bucket_key)')
+        self._mesh = m                                        # the topology (triangles, node grid sizes)
+        self._meshes = meshes
+        V, T = m.num_vertices, m.num_triangles
+        self._sys_key = (P, m.grid_xs.size, m.grid_ys.size)
+        sysh = self._pool.systems.pop(self._sys_key, None) if self._pool is not None else None
+        if sysh is None:
+            sysh = C.c_void_p()
+            _lib.check(lib.fb_sys_create(ctx, P * V, C.byref(sysh)))
+            tri_u = np.ascontiguousarray((m.triangles[None, :, :] + (np.arange(P) * V)[:, None, None]).reshape(-1, 3), dtype=np.int32)
+            mid = C.c_int()
+            _lib.check(lib.fb_sys_add_mesh(ctx, sysh, 0, _lib.ptr(tri_u), P * V, P * T, C.byref(mid)))
+            _lib.check(lib.fb_sys_set_links(ctx, sysh, 0, None))
+            nnzb = C.c_int64()
+            _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
+        self._mult_u = np.ascontiguousarray(np.tile(m.element_multiplier(), P), dtype=np.float32)
+        self._v_init_u = np.ascontiguousarray(np.concatenate([mm.vertices(const.MESH_GEAR_INITIAL) for mm in meshes], axis=0), dtype=np.float64)
+        self._relax_sys = sysh
+        self._k_state = None
+        self._assemble_union(self._v_init_u, 'initial')
+        v0 = self._v_init_u.reshape(P, V, 2)
+        v0 = np.ascontiguousarray((v0 - v0.mean(axis=1, keepdims=True)).reshape(-1, 2))
+        es0 = np.empty(P)
+        _lib.check(lib.fb_sys_group_energy(ctx, sysh, P, _lib.ptr(v0), _lib.ptr(es0)))
+        self._es0_each = es0
+        self._es0 = float(es0[0])
+        self._gx = np.stack([mm.grid_xs for mm in meshes]); self._gy = np.stack([mm.grid_ys for mm in meshes])
+        area = np.array([abs(float(mm.triangle_areas(const.MESH_GEAR_INITIAL)[0])) for mm in meshes])
+        self._sample_err_each = 0.4387 * area ** 0.5 * DEFAULT_AVG_DEFORM          # optimizer.py:26-30, per pair
+        return sysh
+
+    def _pair_mesh(self, p):
+        src = self._meshes[p]
+        m = src.copy(uid=1)
+        m.grid_xs, m.grid_ys = src.grid_xs, src.grid_ys
+        return m
+
+    def _locate_grid(self, pid, pts):
+        """triangle + barycentric coordinates of points given in the INITIAL gear of their pair's grid mesh (cart2bary on
+        the right triangles of a cell; the statements of pairs_build_links in fb_fem.hip with per-pair node coordinates)"""
+        self._relax_system()
+        pid = np.asarray(pid)
+        gx, gy = self._gx[pid], self._gy[pid]
+        nx, ny = gx.shape[1], gy.shape[1]
+        i = np.clip(np.sum(gx <= pts[:, 0:1], axis=1) - 1, 0, nx - 2)
+        j = np.clip(np.sum(gy <= pts[:, 1:2], axis=1) - 1, 0, ny - 2)
+        k = np.arange(pid.size)
+        u = (pts[:, 0] - gx[k, i]) / (gx[k, i + 1] - gx[k, i]); w = (pts[:, 1] - gy[k, j]) / (gy[k, j + 1] - gy[k, j])
+        up = w > u
+        tid = 2 * (j * (nx - 1) + i) + up
+        B = np.where(up[:, None], np.stack((1.0 - w, u, w - u), axis=-1), np.stack((1.0 - u, u - w, w), axis=-1))
+        return tid, B
+
+    def _rows_bary(self, pid, xy1_init, nodes3, B1):
+        V = self._relax_system() and self._mesh.num_vertices
+        tid, B = self._locate_grid(pid, np.asarray(xy1_init, dtype=np.float64))
+        nodes = self._mesh.triangles[tid] + (np.asarray(pid) * V)[:, None]
+        return nodes.astype(np.int64), B
+
+    def _strain(self, pid, xy0, xy1, wt, txy, reuse_links=False):
+        lib, ctx = _lib.load(), _lib.ctx()
+        sysh = self._relax_system()
+        P = self.P
+        if pid.size == 0:
+            return np.full(P, DEFAULT_AVG_DEFORM)
+        nseg = 1 + int(np.count_nonzero(np.diff(pid) != 0))
+        if nseg != int(np.count_nonzero(np.bincount(pid, minlength=P))):
+            o = np.argsort(pid, kind='stable')
+            pid, xy0, xy1, wt = pid[o], xy0[o], xy1[o], wt[o]
+        p0 = np.ascontiguousarray(xy0 + txy[pid], dtype=np.float64)
+        xy1c = np.ascontiguousarray(xy1, dtype=np.float64)
+        w32 = np.ascontiguousarray(wt, dtype=np.float32)
+        R = np.ascontiguousarray(self._rigid_fits(pid, p0, xy1c, w32))
+        nodes, B = self._rows_bary(pid, xy1c, None, None)
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32); B = np.ascontiguousarray(B)
+        pid32 = np.ascontiguousarray(pid, dtype=np.int32)
+        strain = np.empty(P)
+        iters, relres = C.c_int(), C.c_double()
+        es0 = np.ascontiguousarray(self._es0_each)
+        _lib.check(lib.fb_pairs_strain_bary(ctx, sysh, P, pid.size, _lib.ptr(pid32), _lib.ptr(nodes), _lib.ptr(B), _lib.ptr(p0), _lib.ptr(xy1c),
+                                            _lib.ptr(w32), _lib.ptr(R), self.stiffness_lambda, _lib.ptr(es0), DEFAULT_AVG_DEFORM, _lib.ptr(strain),
+                                            C.byref(iters), C.byref(relres)))
+        self.last_strain_solve = dict(iters=iters.value, relres=relres.value, matches=int(pid.size))
+        return strain

@@ -137,6 +137,12 @@ int fb_dog_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, dou
 /* cv2.resize(fx=fy=0.5, INTER_AREA) of even-sized uint8 images (matcher.py:255-256) */
 int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out);
 int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out);
+/* Images of unequal size in one padded stack (the strips of a real section differ in shape from pair to pair,
+ * stitcher.py:561-571): image n is the sizes[n] = {h, w} corner (device int32 [N][2]) of its H x W slot and is
+ * downsampled / filtered as an h x w image; the downsampled stack has half_size(H) x half_size(W) slots. */
+int fb_area_downsample2_sizes_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, const int* sizes, uint8_t* out);
+int fb_dog_sizes_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, const int* sizes, double sigma, int signed_out,
+                     float* out);
 /* common.remap = cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) (common.py:218-255, called at 329-330) of resident float32
  * images through explicit per-pixel maps: the exact piecewise-linear tier of MeshRenderer.crop_multiple
  * (renderer.py:511-563).  All pointers are device pointers.  imgs [P][IH][IW]; img_id [N]; map_x, map_y float32
@@ -227,8 +233,13 @@ int fb_pairs_relax(fb_ctx* ctx, fb_system* sys, int P, int nx, int ny, const dou
  * with mesh1 at its FIXED gear.  x_out = TOTAL displacement from the FIXED gear (the stress term of
  * optimizer.py:1417-1418 is inside the system). */
 int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* sys, int P, int64_t K, const int32_t* nodes3, const double* B1, const double* dxy0,
-                        const float* conf, double residue_len, double sample_err, double stiffness_lambda, double rtol, float* rw,
-                        double* x_out, int* iters, double* relres);
+                        const float* conf, double residue_len, double sample_err, const double* sample_err_each /* [K] or NULL */,
+                        double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres);
+/* fb_pairs_strain for pairs whose meshes share a topology but not a geometry (strips of unequal size): matches located by
+ * the caller (nodes3, B1 in the INITIAL mesh of their pair), es0 [P] = v0^T K v0 of every pair's centred mesh. */
+int fb_pairs_strain_bary(fb_ctx* ctx, fb_system* sys, int P, int64_t K, const int32_t* pid, const int32_t* nodes3, const double* B1,
+                         const double* xy0_fixed, const double* xy1_initial, const float* weight, const double* R, double stiffness_lambda,
+                         const double* es0, double default_strain, double* strain, int* iters, double* relres);
 /* ---- host geometry of pairs whose mesh1 is deformed (no device work; ctx may be NULL).
  * fb_deformed_block_affines: the tier decision of MeshRenderer.crop_field with the affine approximator of
  *   MeshRenderer.from_mesh (renderer.py:90-109, 397-416, 453-511) for the nblk blocks of Q pairs.  vm [Q][nx ny][2] =

@@ -591,3 +591,35 @@ def test_config0_readme_grid_matching_stage(fb):
     np.testing.assert_allclose(xy1 - (b1[:2] - bboxes[j][:2]), exp['xy1'], atol=2e-4)
     np.testing.assert_allclose(wt, exp['weight'], atol=2e-4)
     fb.matcher.stitching_matcher_batch_release()
+
+
+@pytest.mark.parametrize('shapes', [[(1024, 256), (1020, 250), (1016, 252), (1030, 262), (1024, 256)],
+                                    [(3000, 500), (2990, 496), (3011, 505)]])
+def test_ragged_batch_matches_the_per_pair_surface(fb, shapes):
+    """strips of unequal size in ONE batch (RaggedStripBatchMatcher: padded slots, per-image extents in the downsample / DoG
+    kernels, per-pair block grids, spacings and mesh geometry inside a shared system) against the same pairs through
+    matchers of their own shape"""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import RaggedStripBatchMatcher, StripBatchMatcher
+    keys = {RaggedStripBatchMatcher.bucket_key(h, w) for h, w in shapes}
+    assert len(keys) == 1
+    pairs = [_warped_pair(h, w, 90 + k, shift=(3 - 2 * k, k - 2), warp=0.3) for k, (h, w) in enumerate(shapes)]
+    P = len(shapes)
+    Hm, Wm = max(h for h, _ in shapes), max(w for _, w in shapes)
+    stage = np.zeros((2, P, Hm, Wm), dtype=np.uint8)
+    for k, (a, b) in enumerate(pairs):
+        stage[0, k, :a.shape[0], :a.shape[1]] = a
+        stage[1, k, :b.shape[0], :b.shape[1]] = b
+    dev = _lib.DeviceBuffer.from_array(stage)
+    junk = _lib.DeviceBuffer.from_array(np.full(4 * 2 * P * Hm * Wm, 77, dtype=np.uint8))     # dirty memory for the pool to hand out
+    junk.free()
+    m = RaggedStripBatchMatcher(shapes, residue_len=2.0)
+    got = StripBatchMatcher.per_pair(m.match(dev.ptr, dev.offset(P * Hm * Wm)))
+    cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+    for k, (a, b) in enumerate(pairs):
+        exp = fb.matcher.stitching_matcher(a, b, **cfg)
+        g = got[k]
+        assert not g['deferred'] and g['xy0'] is not None and g['xy0'].shape == exp[0].shape
+        np.testing.assert_allclose(g['xy0'], exp[0], atol=1e-5); np.testing.assert_allclose(g['xy1'], exp[1], atol=1e-5)
+        np.testing.assert_allclose(g['weight'], exp[2], atol=1e-5); np.testing.assert_allclose(g['strain'], exp[3], rtol=1e-4, atol=1e-7)
+    m.free(); dev.free()
