@@ -369,3 +369,43 @@ def test_slm_relax_higly_deformed(fb):
     assert fb.optimizer.relax_mesh_most_deformed(c, gear=gear, deform_cutoff=1 - 1 / 1.35)
     np.testing.assert_allclose(a.vertices(gear[1]), c.vertices(gear[1]), atol=1e-9)
     assert np.abs(a.vertices(gear[1]) - g['vmov']).max() > 1.0
+
+
+def test_section_of_tile_meshes_removes_stage_errors(fb):
+    """stitching optimisation at section level (config 4, FEM side; stitcher.py:1012-1018): a 5 x 5 grid of tile meshes placed
+    at wrong stage coordinates, matches between neighbours in tile pixel frames, one SLM.optimize_linear: the tiles end
+    where the matches put them (size-independent property: relative tile positions = the true grid)"""
+    from feabas_amd import mesh, optimizer, constant as const
+    G, T, ov = 5, 1024, 128
+    rng = np.random.default_rng(3)
+    nom = np.array([[gx * (T - ov), gy * (T - ov)] for gy in range(G) for gx in range(G)], dtype=np.float64)
+    err = rng.normal(0, 5.0, nom.shape); err[0] = 0
+    meshes = []
+    for k in range(G * G):
+        m = mesh.Mesh.from_bbox((0, 0, T, T), cartesian=True, mesh_size=128.0, uid=k)
+        m.apply_translation(nom[k] + err[k], const.MESH_GEAR_FIXED)
+        meshes.append(m)
+    meshes[0].lock()
+    slm = optimizer.SLM(meshes, stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    for gy in range(G):
+        for gx in range(G):
+            k = gy * G + gx
+            for dx_, dy_ in ((1, 0), (0, 1)):
+                if gx + dx_ >= G or gy + dy_ >= G:
+                    continue
+                j = (gy + dy_) * G + gx + dx_
+                n = 120
+                lo = np.maximum(nom[k], nom[j]) + 4; hi = np.minimum(nom[k], nom[j]) + T - 4
+                w = np.stack((rng.uniform(lo[0], hi[0], n), rng.uniform(lo[1], hi[1], n)), -1)
+                assert slm.add_link_from_coordinates(k, j, w - nom[k], w - nom[j], gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL),
+                                                     weight=rng.uniform(0.4, 1.0, n).astype(np.float32))
+    cost = slm.optimize_linear(tol=1e-9)
+    assert cost[1] < 1e-6 * cost[0]
+    c = np.array([m.vertices_w_offset(const.MESH_GEAR_MOVING).mean(axis=0) for m in meshes])
+    c0 = np.array([m.vertices_w_offset(const.MESH_GEAR_INITIAL).mean(axis=0) for m in meshes]) + nom
+    res = (c - c[0]) - (c0 - c0[0])
+    assert np.abs(err).max() > 8 and np.abs(res).max() < 1e-3            # exact matches: the stage errors vanish
+    # no tile is strained: the matches are consistent with rigid placement
+    for m in meshes[1:]:
+        d = m.vertices_w_offset(const.MESH_GEAR_MOVING) - m.vertices_w_offset(const.MESH_GEAR_INITIAL)
+        assert np.ptp(d[:, 0]) < 1e-3 and np.ptp(d[:, 1]) < 1e-3
