@@ -342,6 +342,12 @@ class Mesh:
         a single finder over the whole mesh covers the non-overlapping meshes used here."""
         from matplotlib.tri import Triangulation
         gear = self._current_gear if gear is None else gear
+        if gear == const.MESH_GEAR_INITIAL and getattr(self, 'grid_xs', None) is not None:
+            # the undeformed grid of from_bbox(cartesian=True): the cell follows from the coordinates
+            p = (np.asarray(pts, dtype=np.float64) - self.offset(gear)).reshape(-1, 2)
+            xs, ys = self.grid_xs, self.grid_ys
+            inside = (p[:, 0] >= xs[0]) & (p[:, 0] <= xs[-1]) & (p[:, 1] >= ys[0]) & (p[:, 1] <= ys[-1])
+            return np.where(inside, self.locate_cartesian(p), -1).astype(np.int32)
         if gear not in self._trifinders:
             v = self.vertices(gear)
             self._trifinders[gear] = Triangulation(v[:, 0], v[:, 1], self.triangles).get_trifinder()
