@@ -88,18 +88,23 @@ extern "C" {
 // A6 [Q][nblk][6] = {A00, A10, t0, A01, A11, t1} (image x = X A00 + Y A10 + t0, image y = X A01 + Y A11 + t1);
 // lo [Q][2] = smallest image x / y any affine block of the pair samples (+inf without one): the remap origin of
 // render_by_subregions (common.py:316-321) is floor(lo) - 4 once the exact-field blocks are included.
-int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int nblk,
-                              const int32_t* bboxes, double tol, int32_t* tier, double* A6, double* lo) {
-    FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs && ys && vm && nblk >= 0 && bboxes && tier && A6 && lo);
+int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* xs_all, const double* ys_all, int per_pair_grid,
+                              const double* vm, int nblk, const int32_t* bboxes, double tol_all, const double* tol_each, int32_t* tier,
+                              double* A6, double* lo) {
+    FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs_all && ys_all && vm && nblk >= 0 && bboxes && tier && A6 && lo);
     const int V = nx * ny;
     std::vector<double> vi(2 * (size_t)V);
-    for (int j = 0; j < ny; ++j)
-        for (int i = 0; i < nx; ++i) { vi[2 * (j * nx + i)] = xs[i]; vi[2 * (j * nx + i) + 1] = ys[j]; }
     std::vector<int> all(V), stamp(V), members;
     for (int v = 0; v < V; ++v) all[v] = v;
     members.reserve(64);
     const double inf = std::numeric_limits<double>::infinity();
     for (int q = 0; q < Q; ++q) {
+        // the INITIAL node grid of pair q (pairs of unequal strip size have their own)
+        const double* xs = xs_all + (per_pair_grid ? (size_t)q * nx : 0);
+        const double* ys = ys_all + (per_pair_grid ? (size_t)q * ny : 0);
+        const double tol = tol_each ? tol_each[q] : tol_all;
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) { vi[2 * (j * nx + i)] = xs[i]; vi[2 * (j * nx + i) + 1] = ys[j]; }
         const double* v = vm + 2 * (size_t)q * V;
         int32_t* tq = tier + (size_t)q * nblk;
         double* aq = A6 + 6 * (size_t)q * nblk;
@@ -164,15 +169,18 @@ int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* 
 // mapped to the image by linear interpolation of the INITIAL vertices (matplotlib.tri.LinearTriInterpolator in the
 // reference).  map_x, map_y [NB][h][w] float64, mask [NB][h][w] uint8 (0 = outside every triangle).
 // deformed.exact_field is the numpy statement of the same computation.
-int fb_deformed_exact_field(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int NB,
-                            const int32_t* pair_of, const int32_t* org, int h, int w, double* map_x, double* map_y, uint8_t* mask) {
-    FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs && ys && vm && NB >= 0 && h > 0 && w > 0 && (NB == 0 || (pair_of && org && map_x && map_y && mask)));
+int fb_deformed_exact_field(fb_ctx* ctx, int Q, int nx, int ny, const double* xs_all, const double* ys_all, int per_pair_grid,
+                            const double* vm, int NB, const int32_t* pair_of, const int32_t* org, int h, int w, double* map_x, double* map_y,
+                            uint8_t* mask) {
+    FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs_all && ys_all && vm && NB >= 0 && h > 0 && w > 0 && (NB == 0 || (pair_of && org && map_x && map_y && mask)));
     const int V = nx * ny;
     const double inf = std::numeric_limits<double>::infinity();
     std::vector<int> cand;
     for (int e = 0; e < NB; ++e) {
         const int q = pair_of[e];
         if (q < 0 || q >= Q) return fb_fail(ctx, FB_ERR_ARG, "fb_deformed_exact_field: pair %d outside [0, %d)", q, Q);
+        const double* xs = xs_all + (per_pair_grid ? (size_t)q * nx : 0);
+        const double* ys = ys_all + (per_pair_grid ? (size_t)q * ny : 0);
         const double* v = vm + 2 * (size_t)q * V;
         double uminx = inf, umaxx = -inf, uminy = inf, umaxy = -inf;
         for (int j = 0; j < ny; ++j)
@@ -228,13 +236,15 @@ int fb_deformed_exact_field(fb_ctx* ctx, int Q, int nx, int ny, const double* xs
 // The cell is guessed by pulling the point back with the displacement of its nearest node (two passes), then the
 // triangles of the 3 x 3 cells around it are tested in a fixed order; the first that contains the point wins.
 // tid [K] = triangle (cells (a b / c d) -> 2 cell: (a, b, d), 2 cell + 1: (a, d, c)) or -1 outside; B [K][3] (nan outside).
-int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int64_t K,
-                       const int32_t* pair_of, const double* pts, int32_t* tid, double* B) {
-    FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs && ys && vm && K >= 0 && (K == 0 || (pair_of && pts && tid && B)));
+int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs_all, const double* ys_all, int per_pair_grid, const double* vm,
+                       int64_t K, const int32_t* pair_of, const double* pts, int32_t* tid, double* B) {
+    FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs_all && ys_all && vm && K >= 0 && (K == 0 || (pair_of && pts && tid && B)));
     const int V = nx * ny;
     const double eps = 1e-9, nan = std::numeric_limits<double>::quiet_NaN(), inf = std::numeric_limits<double>::infinity();
     std::vector<double> mean(2 * (size_t)std::max(Q, 1), 0.0);
     for (int q = 0; q < Q; ++q) {
+        const double* xs = xs_all + (per_pair_grid ? (size_t)q * nx : 0);
+        const double* ys = ys_all + (per_pair_grid ? (size_t)q * ny : 0);
         const double* v = vm + 2 * (size_t)q * V;
         double mx = 0, my = 0;
         for (int j = 0; j < ny; ++j)
@@ -245,6 +255,8 @@ int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, con
     for (int64_t k = 0; k < K; ++k) {
         const int q = pair_of[k];
         if (q < 0 || q >= Q) return fb_fail(ctx, FB_ERR_ARG, "fb_deformed_locate: pair %d outside [0, %d)", q, Q);
+        const double* xs = xs_all + (per_pair_grid ? (size_t)q * nx : 0);
+        const double* ys = ys_all + (per_pair_grid ? (size_t)q * ny : 0);
         const double* v = vm + 2 * (size_t)q * V;
         const double px = pts[2 * k], py = pts[2 * k + 1];
         double qx = px - mean[2 * q], qy = py - mean[2 * q + 1];

@@ -375,14 +375,18 @@ class StripBatchMatcher:
         n, H, W = self.P, self.H, self.W
         self._relax_system()
         m = self._mesh
-        v_init = m.vertices(const.MESH_GEAR_INITIAL)
+        V = m.num_vertices
+        v_all = self._v_init_u.reshape(n, V, 2)                              # INITIAL nodes of every pair's mesh1
         tris = m.triangles
-        tol = 0.1 if is_last else max(1.0, 0.02 * float(spacing))
-        vm = v_init[None, :, :] + U[pairs]                                   # [Q, V, 2]
+        spacing = np.broadcast_to(np.asarray(spacing, dtype=np.float64), (n,))[pairs]
+        tol_q = np.full(pairs.size, 0.1) if is_last else np.maximum(1.0, 0.02 * spacing)      # matcher.py:578-603
+        Hs, Ws = self._Hs[pairs], self._Ws[pairs]
+        vm = v_all[pairs] + U[pairs]                                         # [Q, V, 2]
         xmin = np.maximum(-0.5 + tx[pairs], vm[:, :, 0].min(axis=1)); ymin = np.maximum(-0.5 + ty[pairs], vm[:, :, 1].min(axis=1))
-        xmax = np.minimum(W - 0.5 + tx[pairs], vm[:, :, 0].max(axis=1)); ymax = np.minimum(H - 0.5 + ty[pairs], vm[:, :, 1].max(axis=1))
+        xmax = np.minimum(Ws - 0.5 + tx[pairs], vm[:, :, 0].max(axis=1)); ymax = np.minimum(Hs - 0.5 + ty[pairs], vm[:, :, 1].max(axis=1))
         ok = (xmax > xmin) & (ymax > ymin)                                    # common.intersect_bbox validity
         nx, ny, dx, dy = _divide_bbox_batch(xmin, ymin, xmax, ymax, spacing, mnb)
+        dx = np.where(ok, dx, 1); dy = np.where(ok, dy, 1)
         pf = pad_flags[pairs]
         nfl = self._nfl
         fh = np.where(pf, nfl[np.clip(2 * dy - 1, 0, nfl.size - 1)], nfl[np.clip(dy, 0, nfl.size - 1)])
@@ -398,7 +402,7 @@ class StripBatchMatcher:
             gi = np.flatnonzero(key == kv)
             sel = pairs[gi]
             gfh, gfw, gpad = int(fh[gi[0]]), int(fw[gi[0]]), bool(pf[gi[0]])
-            blk, bb = self._blocks(tx, ty, None, sel, spacing, mnb, bounds=(xmin[gi], ymin[gi], xmax[gi], ymax[gi]))
+            blk, bb = self._blocks(tx, ty, None, sel, spacing[gi], mnb, bounds=(xmin[gi], ymin[gi], xmax[gi], ymax[gi]))
             Q, nblk = blk.shape[:2]
             h, w = int(dy[gi[0]]), int(dx[gi[0]])
             aff = np.zeros((Q, nblk, 10))
@@ -408,14 +412,18 @@ class StripBatchMatcher:
             vmg = np.ascontiguousarray(vm[gi])
             bbi = np.ascontiguousarray(bb, dtype=np.int32)
             tiers = np.empty((Q, nblk), dtype=np.int32); A6 = np.empty((Q, nblk, 6)); lo = np.empty((Q, 2))
-            _lib.check(lib.fb_deformed_block_affines(ctx, Q, m.grid_xs.size, m.grid_ys.size, _lib.ptr(m.grid_xs), _lib.ptr(m.grid_ys),
-                                                     _lib.ptr(vmg), nblk, _lib.ptr(bbi), tol, _lib.ptr(tiers), _lib.ptr(A6), _lib.ptr(lo)))
+            gxs = np.ascontiguousarray(self._gx[sel]); gys = np.ascontiguousarray(self._gy[sel])      # every pair's node grid
+            tolg = np.ascontiguousarray(tol_q[gi])
+            _lib.check(lib.fb_deformed_block_affines(ctx, Q, m.grid_xs.size, m.grid_ys.size, _lib.ptr(gxs), _lib.ptr(gys), 1,
+                                                     _lib.ptr(vmg), nblk, _lib.ptr(bbi), 0.0, _lib.ptr(tolg), _lib.ptr(tiers), _lib.ptr(A6),
+                                                     _lib.ptr(lo)))
             aff[:, :, 0] = bb[:, :, 0]; aff[:, :, 1] = bb[:, :, 1]
             aff[:, :, 2:8] = A6
             for q in range(Q):
                 tier = tiers[q]
+                v_init = v_all[sel[q]]
                 if (tier < 0).any():                                          # degenerate / flipped fit: statement-by-statement route
-                    tier, A, _ = dfm.block_affines(vmg[q], v_init, tris, bb[q], tol)
+                    tier, A, _ = dfm.block_affines(vmg[q], v_init, tris, bb[q], float(tolg[q]))
                     tiers[q] = tier
                     aff[q, :, 2] = A[:, 0, 0]; aff[q, :, 3] = A[:, 1, 0]; aff[q, :, 4] = A[:, 2, 0]
                     aff[q, :, 5] = A[:, 0, 1]; aff[q, :, 6] = A[:, 1, 1]; aff[q, :, 7] = A[:, 2, 1]
@@ -438,7 +446,8 @@ class StripBatchMatcher:
                     org = np.ascontiguousarray(bb[q, ex, :2], dtype=np.int32)
                     emx = np.empty((ex.size, h, w)); emy = np.empty((ex.size, h, w)); emk8 = np.empty((ex.size, h, w), dtype=np.uint8)
                     vq = np.ascontiguousarray(vmg[q][None])
-                    _lib.check(lib.fb_deformed_exact_field(ctx, 1, m.grid_xs.size, m.grid_ys.size, _lib.ptr(m.grid_xs), _lib.ptr(m.grid_ys),
+                    gx1 = np.ascontiguousarray(gxs[q]); gy1 = np.ascontiguousarray(gys[q])
+                    _lib.check(lib.fb_deformed_exact_field(ctx, 1, m.grid_xs.size, m.grid_ys.size, _lib.ptr(gx1), _lib.ptr(gy1), 0,
                                                            _lib.ptr(vq), ex.size, _lib.ptr(po), _lib.ptr(org), h, w, _lib.ptr(emx), _lib.ptr(emy),
                                                            _lib.ptr(emk8)))
                     emk = emk8.astype(bool)
@@ -828,9 +837,10 @@ class StripBatchMatcher:
             groups = [(g, False) for g in self._match_round(tx, ty, t1, live & ~is_deformed, self._sp[:, rnd], mnb, pad, subpixel=is_last)]
             dp = np.flatnonzero(live & is_deformed)
             if dp.size:
-                groups += [(g, True) for g in self._match_round_deformed(tx, ty, U, dp, sp, mnb, pad, is_last, is_last)]
+                groups += [(g, True) for g in self._match_round_deformed(tx, ty, U, dp, self._sp[:, rnd], mnb, pad, is_last, is_last)]
                 m = self._mesh
-                v_init = m.vertices(const.MESH_GEAR_INITIAL); V = m.num_vertices
+                V = m.num_vertices
+                v_all = self._v_init_u.reshape(n, V, 2)
             for (sel, bb, ddx, ddy, dcf), is_def in groups:
                 keep = dcf > self.conf_thresh                # matcher.py:671-683
                 anyk = keep.any(axis=1)
@@ -848,18 +858,19 @@ class StripBatchMatcher:
                     xy1_init = np.zeros_like(xy1)
                     qq, kk = np.nonzero(keep)
                     if qq.size:
-                        vmg = np.ascontiguousarray(v_init[None, :, :] + U[sel])
+                        vmg = np.ascontiguousarray(v_all[sel] + U[sel])
                         pts = np.ascontiguousarray(xy1[qq, kk]); q32 = np.ascontiguousarray(qq, dtype=np.int32)
                         tid = np.empty(qq.size, dtype=np.int32); Bq = np.empty((qq.size, 3))
-                        _lib.check(_lib.load().fb_deformed_locate(_lib.ctx(), sel.size, m.grid_xs.size, m.grid_ys.size, _lib.ptr(m.grid_xs),
-                                                                  _lib.ptr(m.grid_ys), _lib.ptr(vmg), qq.size, _lib.ptr(q32), _lib.ptr(pts),
+                        gxs = np.ascontiguousarray(self._gx[sel]); gys = np.ascontiguousarray(self._gy[sel])
+                        _lib.check(_lib.load().fb_deformed_locate(_lib.ctx(), sel.size, m.grid_xs.size, m.grid_ys.size, _lib.ptr(gxs),
+                                                                  _lib.ptr(gys), 1, _lib.ptr(vmg), qq.size, _lib.ptr(q32), _lib.ptr(pts),
                                                                   _lib.ptr(tid), _lib.ptr(Bq)))
                         inside = tid >= 0
                         keep[qq[~inside], kk[~inside]] = False
                         qq, kk, tid, Bq = qq[inside], kk[inside], tid[inside], Bq[inside]
                         nodes3[qq, kk] = m.triangles[tid] + (sel[qq] * V)[:, None]
                         B1[qq, kk] = Bq
-                        xy1_init[qq, kk] = np.sum(v_init[m.triangles[tid]] * Bq[:, :, None], axis=1)
+                        xy1_init[qq, kk] = np.sum(v_all[sel[qq][:, None], m.triangles[tid]] * Bq[:, :, None], axis=1)
                     has_link = keep.any(axis=1)
                 else:
                     xy1_init = xy1 - t1[sel][:, None, :]     # INITIAL gear of mesh1 at link creation (matcher.py:748-751)
@@ -895,14 +906,6 @@ class StripBatchMatcher:
                 prev = table
                 table = tuple(np.concatenate([r[k] for r in rows], axis=0) for k in range(8))
                 last_links = None
-                if to_relax.any() and self._ragged:
-                    # pairs of unequal strip size take the deformed-mesh branch one by one (the caller re-runs them through a
-                    # matcher of their own): out of this batch
-                    deferred |= to_relax
-                    live[to_relax] = False
-                    keep_rows = ~to_relax[table[0]]
-                    table = tuple(a[keep_rows] for a in table)
-                    to_relax[:] = False
                 pid_l, xy0_l, xy1i_l, wt_l, xy1_l, rl, nd_l, B1_l = table
                 if to_relax.any():
                     # non-rigid relaxation between spacings (matcher.py:725-741): mesh1 of these pairs keeps the field
@@ -971,13 +974,12 @@ class StripBatchMatcher:
 
 class RaggedStripBatchMatcher(StripBatchMatcher):
     """A batch of tile pairs whose strips differ in SIZE (the usual case in a real section: the overlap follows the stage
-    jitter, stitcher.py:561-571) but share the mesh topology and the number of spacings -- `ragged_bucket_key`.  Strips sit
+    jitter, stitcher.py:561-571) but share the mesh topology and the number of spacings -- `bucket_key`.  Strips sit
     in zero-padded slots of the largest size; every stage works on each pair's own extent: x0.5 downsample and DoG with
     per-image sizes (fb_area_downsample2_sizes_dev, fb_dog_sizes_dev), the whole-strip NCC through block descriptors
     grouped by FFT shape, per-pair block grids and spacing values, one mesh GEOMETRY per pair inside the shared
-    block-diagonal system (per-pair node coordinates, Es0 and sample errors; fb_pairs_relax_bary / fb_pairs_strain_bary).
-    A pair whose relaxation between spacings is not a rigid translation is reported `deferred`: the caller runs it
-    through a matcher of its own (`StripBatchMatcher` handles the deformed-mesh branch for equal shapes).
+    block-diagonal system (per-pair node coordinates, Es0 and sample errors; fb_pairs_relax_bary / fb_pairs_strain_bary),
+    and the deformed-mesh branch with per-pair node grids and tolerances (fb_deformed_*).
     Masks and photometric statistics are not taken here."""
 
     @staticmethod

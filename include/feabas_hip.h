@@ -249,14 +249,16 @@ int fb_pairs_strain_bary(fb_ctx* ctx, fb_system* sys, int P, int64_t K, const in
  *   image x / y an affine block samples (the remap origin of common.py:316-321 is floor(lo) - 4).
  * fb_deformed_locate: Mesh.tri_finder + cart2bary (mesh.py:2080-2217) on those meshes: point k of pair pair_of[k] ->
  *   tid [K] (cell (a b / c d): 2 cell = (a, b, d), 2 cell + 1 = (a, d, c); -1 outside) and B [K][3]. */
-int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int nblk,
-                              const int32_t* bboxes, double tol, int32_t* tier, double* A6, double* lo);
+/* per_pair_grid != 0: xs [Q][nx], ys [Q][ny] -- every pair has its own node grid (strips of unequal size);
+ * tol_each (nullable) [Q]: the tolerance of every pair (it follows the pair's spacing, matcher.py:599) */
+int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, int per_pair_grid, const double* vm,
+                              int nblk, const int32_t* bboxes, double tol, const double* tol_each, int32_t* tier, double* A6, double* lo);
 /* fb_deformed_exact_field: field_w_weight (renderer.py:259-300) for NB blocks of h x w pixels at org [NB][2] of pairs
  *   pair_of [NB]: the exact piecewise-linear inverse map (map_x, map_y float64 [NB][h][w]) and its mask (uint8). */
-int fb_deformed_exact_field(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int NB,
-                            const int32_t* pair_of, const int32_t* org, int h, int w, double* map_x, double* map_y, uint8_t* mask);
-int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, const double* vm, int64_t K,
-                       const int32_t* pair_of, const double* pts, int32_t* tid, double* B);
+int fb_deformed_exact_field(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, int per_pair_grid, const double* vm,
+                            int NB, const int32_t* pair_of, const int32_t* org, int h, int w, double* map_x, double* map_y, uint8_t* mask);
+int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs, const double* ys, int per_pair_grid, const double* vm,
+                       int64_t K, const int32_t* pair_of, const double* pts, int32_t* tid, double* B);
 int fb_pairs_strain(fb_ctx* ctx, fb_system* sys, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
                     const double* xy0_fixed, const double* xy1_initial, const float* weight, const double* R, double stiffness_lambda,
                     double es0, int links_loaded, double default_strain, double* strain, int* iters, double* relres);

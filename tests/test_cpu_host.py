@@ -276,7 +276,7 @@ def test_cxx_deformed_geometry_matches_numpy():
     seen = set()
     for tol in (0.1, 0.3, 1.0, 5.0):
         tier = np.empty((Q, nblk), np.int32); A6 = np.empty((Q, nblk, 6)); lo = np.empty((Q, 2))
-        assert lib.fb_deformed_block_affines(None, Q, xs.size, ys.size, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(vm), nblk, _lib.ptr(bb), tol,
+        assert lib.fb_deformed_block_affines(None, Q, xs.size, ys.size, _lib.ptr(xs), _lib.ptr(ys), 0, _lib.ptr(vm), nblk, _lib.ptr(bb), tol, None,
                                              _lib.ptr(tier), _lib.ptr(A6), _lib.ptr(lo)) == 0
         for q in range(Q):
             t2, A, _ = deformed.block_affines(vm[q], v, tri, bb[q], tol)
@@ -294,7 +294,7 @@ def test_cxx_deformed_geometry_matches_numpy():
     po = rng.integers(0, Q, K).astype(np.int32)
     pts = np.stack((rng.uniform(-5, W + 5, K), rng.uniform(-5, H + 5, K)), -1)
     tid = np.empty(K, np.int32); B = np.empty((K, 3))
-    assert lib.fb_deformed_locate(None, Q, xs.size, ys.size, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(vm), K, _lib.ptr(po), _lib.ptr(pts),
+    assert lib.fb_deformed_locate(None, Q, xs.size, ys.size, _lib.ptr(xs), _lib.ptr(ys), 0, _lib.ptr(vm), K, _lib.ptr(po), _lib.ptr(pts),
                                   _lib.ptr(tid), _lib.ptr(B)) == 0
     for q in range(Q):
         s_ = po == q
@@ -308,7 +308,7 @@ def test_cxx_deformed_geometry_matches_numpy():
     org = np.array([[40, 200], [-6, -5], [90, 1500], [60, 700]], dtype=np.int32)
     po = np.ones(4, np.int32)
     mx = np.empty((4, h, w)); my = np.empty((4, h, w)); mk = np.empty((4, h, w), np.uint8)
-    assert lib.fb_deformed_exact_field(None, Q, xs.size, ys.size, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(vm), 4, _lib.ptr(po), _lib.ptr(org), h, w,
+    assert lib.fb_deformed_exact_field(None, Q, xs.size, ys.size, _lib.ptr(xs), _lib.ptr(ys), 0, _lib.ptr(vm), 4, _lib.ptr(po), _lib.ptr(org), h, w,
                                        _lib.ptr(mx), _lib.ptr(my), _lib.ptr(mk)) == 0
     for e in range(4):
         hit = deformed.tri_box_hits(vm[1][tri], np.array([[org[e, 0], org[e, 1], org[e, 0] + w, org[e, 1] + h]]) - 0.5)[0]

@@ -623,3 +623,33 @@ def test_ragged_batch_matches_the_per_pair_surface(fb, shapes):
         np.testing.assert_allclose(g['xy0'], exp[0], atol=1e-5); np.testing.assert_allclose(g['xy1'], exp[1], atol=1e-5)
         np.testing.assert_allclose(g['weight'], exp[2], atol=1e-5); np.testing.assert_allclose(g['strain'], exp[3], rtol=1e-4, atol=1e-7)
     m.free(); dev.free()
+
+
+def test_ragged_batch_with_deformed_meshes_matches_the_per_pair_surface(fb):
+    """strips of unequal size whose mesh1 is relaxed into a non-rigid field between the spacings, in ONE batch (per-pair node
+    grids and tolerances in fb_deformed_block_affines / fb_deformed_locate), against matchers of their own shape"""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import RaggedStripBatchMatcher, StripBatchMatcher
+    shapes = [(1536, 120), (1526, 122), (1520, 120), (1536, 120)]
+    assert len({RaggedStripBatchMatcher.bucket_key(h, w) for h, w in shapes}) == 1
+    warps = [3.0, 2.0, 0.0, 2.5]
+    pairs = [_warped_pair(h, w, 130 + k, shift=(4 - k, k - 3), warp=warps[k]) for k, (h, w) in enumerate(shapes)]
+    P = len(shapes)
+    Hm, Wm = max(h for h, _ in shapes), max(w for _, w in shapes)
+    stage = np.full((2, P, Hm, Wm), 200, dtype=np.uint8)             # the padding of a slot is never read
+    for k, (a, b) in enumerate(pairs):
+        stage[0, k, :a.shape[0], :a.shape[1]] = a
+        stage[1, k, :b.shape[0], :b.shape[1]] = b
+    dev = _lib.DeviceBuffer.from_array(stage)
+    m = RaggedStripBatchMatcher(shapes, residue_len=2.0)
+    res = m.match(dev.ptr, dev.offset(P * Hm * Wm))
+    got = StripBatchMatcher.per_pair(res)
+    assert res['deformed'].tolist() == [True, True, False, True] and not res['deferred'].any()
+    cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+    for k, (a, b) in enumerate(pairs):
+        exp = fb.matcher.stitching_matcher(a, b, **cfg)
+        g = got[k]
+        assert g['xy0'] is not None and g['xy0'].shape == exp[0].shape and g['xy0'].shape[0] > 60
+        np.testing.assert_allclose(g['xy0'], exp[0], atol=2e-4); np.testing.assert_allclose(g['xy1'], exp[1], atol=2e-4)
+        np.testing.assert_allclose(g['weight'], exp[2], atol=2e-4); np.testing.assert_allclose(g['strain'], exp[3], rtol=2e-3, atol=1e-7)
+    m.free(); dev.free()
