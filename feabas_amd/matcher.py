@@ -308,6 +308,8 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
             if mk is not None and np.asarray(mk).shape != img0.shape:
                 raise ValueError('stitching_matcher_batch: a mask must have the shape of its strip')
         items.append((img0, img1, mk0, mk1))
+    if not items:
+        return []
     # chunks: ('uniform', (H, W), indices) -- pairs of one strip shape, through StripBatchMatcher (masks, photometric
     # statistics and the deformed-mesh branch included); ('ragged', key, indices) -- pairs of unequal shape that share the
     # mesh topology and the number of spacings, through RaggedStripBatchMatcher (strips differ in shape from pair to pair

@@ -527,6 +527,7 @@ def test_stitching_matcher_batch_matches_the_per_pair_surface(fb):
             pairs.append((s0, s1[::-1].copy()))                      # unrelated strips: the no-match tuple
         else:
             pairs.append((s0, s1))
+    assert fb.matcher.stitching_matcher_batch([], **cfg) == []
     got = fb.matcher.stitching_matcher_batch(pairs, batch=2, threads=2, **cfg)
     assert len(got) == len(pairs)
     for k, pr in enumerate(pairs):
