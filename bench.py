@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--host-threads', type=int, default=8, help='host threads driving the device (even; steps are dealt round-robin, LR and UD batches alternate)')
     ap.add_argument('--multi-stream', type=int, default=1, help='1: one context (HIP stream) per host thread; 0: all threads share one stream')
     ap.add_argument('--warp', type=float, default=0.4, help='amplitude (px) of the smooth sub-pixel warp between the strips of a pair (SURVEY config 2)')
+    ap.add_argument('--host-ingest-threads', type=int, default=4)
     ap.add_argument('--host-ingest-pairs', type=int, default=512, help='pairs of the PCIe-inclusive measurement (0: skip)')
     ap.add_argument('--no-fem', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -450,13 +451,13 @@ def main():
         h0 = s0.to_array((nh, H, W), np.uint8); h1 = s1.to_array((nh, H, W), np.uint8)
         host_pairs = [(h0[k], h1[k]) for k in range(nh)]
         cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=RESIDUE_LEN)
-        fmatcher.stitching_matcher_batch(host_pairs[:P * 4], batch=P, threads=4, **cfg)        # set-up pass
+        fmatcher.stitching_matcher_batch(host_pairs[:P * args.host_ingest_threads], batch=P, threads=args.host_ingest_threads, **cfg)        # set-up pass
         t0 = time.time()
-        outp = fmatcher.stitching_matcher_batch(host_pairs, batch=P, threads=4, **cfg)
+        outp = fmatcher.stitching_matcher_batch(host_pairs, batch=P, threads=args.host_ingest_threads, **cfg)
         dth = time.time() - t0
         line['host_ingest'] = dict(value=nh / dth, unit='pairs/s', pairs=nh, matched=int(sum(o[0] is not None for o in outp)),
                                    note='strips handed over in host memory (4.2 MB per pair over PCIe), results returned per pair; '
-                                        '4 host threads, 64-pair chunks')
+                                        f'{args.host_ingest_threads} host threads, {P}-pair chunks')
         fmatcher.stitching_matcher_batch_release()
         del h0, h1, host_pairs, outp
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

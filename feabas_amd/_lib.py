@@ -48,6 +48,7 @@ _PROTOS = {
     'fb_memcpy_h2d': (c_i, [c_p, c_p, c_p, c_sz]),
     'fb_host_alloc': (c_i, [c_p, C.c_size_t, C.POINTER(c_p)]),
     'fb_host_free': (c_i, [c_p, c_p]),
+    'fb_host_pack2d': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i]),
     'fb_memcpy_d2h': (c_i, [c_p, c_p, c_p, c_sz]),
     'fb_memset': (c_i, [c_p, c_p, c_i, c_sz]),
     'fb_timer_start': (c_i, [c_p]),

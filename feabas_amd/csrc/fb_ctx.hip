@@ -1,6 +1,9 @@
 // Context, device memory, stopwatch and per-kernel profile of libfeabas_hip.so.
 #include "fb_common.h"
 
+#include <algorithm>
+#include <thread>
+
 #include <cstdlib>
 
 int fb_fail(fb_ctx* ctx, int code, const char* fmt, ...) {
@@ -159,6 +162,38 @@ int fb_host_free(fb_ctx* ctx, void* hptr) {
     if (!hptr) return FB_OK;
     FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FB_HIP(ctx, hipHostFree(hptr));
+    return FB_OK;
+}
+
+// Gather n row-major uint8 images (strips cropped on the host) into the slots of a staging stack [n][H][W]: image k
+// (hs[k] x ws[k], row pitch pitches[k] bytes) goes to the top-left corner of slot k.  Plain host memcpy on `threads`
+// std::threads (the caller's interpreter lock is released for the whole call): packing 4 MB per pair through the
+// interpreter was the largest host cost of the PCIe-inclusive path.
+int fb_host_pack2d(fb_ctx* ctx, uint8_t* dst, int n, int H, int W, const void* const* srcs, const int* hs, const int* ws,
+                   const int64_t* pitches, int threads) {
+    FB_CHECK_ARG(ctx, dst && n >= 0 && H > 0 && W > 0 && (n == 0 || (srcs && hs && ws && pitches)));
+    for (int k = 0; k < n; ++k) FB_CHECK_ARG(ctx, srcs[k] && hs[k] > 0 && ws[k] > 0 && hs[k] <= H && ws[k] <= W && pitches[k] >= ws[k]);
+    const int T = std::max(1, std::min(threads, 16));
+    auto work = [&](int t) {
+        // rows are dealt in contiguous blocks so that every thread streams its own part of the stack
+        int64_t total = 0;
+        for (int k = 0; k < n; ++k) total += hs[k];
+        const int64_t lo = total * t / T, hi = total * (t + 1) / T;
+        int64_t at = 0;
+        for (int k = 0; k < n && at < hi; ++k) {
+            const int64_t r0 = std::max<int64_t>(lo - at, 0), r1 = std::min<int64_t>(hi - at, hs[k]);
+            const uint8_t* s = (const uint8_t*)srcs[k];
+            uint8_t* d = dst + (size_t)k * H * W;
+            if (pitches[k] == ws[k] && ws[k] == W && r1 > r0) std::memcpy(d + (size_t)r0 * W, s + (size_t)r0 * W, (size_t)(r1 - r0) * W);
+            else
+                for (int64_t r = r0; r < r1; ++r) std::memcpy(d + (size_t)r * W, s + (size_t)r * pitches[k], (size_t)ws[k]);
+            at += hs[k];
+        }
+    };
+    if (T == 1) { work(0); return FB_OK; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
     return FB_OK;
 }
 

@@ -4,6 +4,8 @@
 and the block distributor keep the reference's host-side control flow and call
 the GPU kernels for the arithmetic.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import _lib, common
@@ -233,8 +235,12 @@ def _stitching_options(kwargs):
     return opts, mask0, mask1, compute_photometric
 
 
-def _check_strips(img0, img1, coarse_downsample):
-    img0 = np.ascontiguousarray(img0); img1 = np.ascontiguousarray(img1)
+def _check_strips(img0, img1, coarse_downsample, contiguous=True):
+    img0 = np.asarray(img0); img1 = np.asarray(img1)
+    if contiguous or img0.ndim != 2 or img0.strides[-1] != img0.itemsize:      # rows must be contiguous; a row pitch is fine for the batch packer
+        img0 = np.ascontiguousarray(img0)
+    if contiguous or img1.ndim != 2 or img1.strides[-1] != img1.itemsize:
+        img1 = np.ascontiguousarray(img1)
     if img0.ndim != 2 or img0.shape != img1.shape or img0.dtype != np.uint8 or img1.dtype != np.uint8:
         raise NotImplementedError('stitching_matcher: the device path takes two uint8 strips of equal shape')
     if min(img0.shape) < 4:
@@ -302,7 +308,7 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
     opts, _, _, compute_photometric = _stitching_options(kwargs)
     items = []
     for k, pr in enumerate(pairs):
-        img0, img1 = _check_strips(pr[0], pr[1], opts['coarse_downsample'])
+        img0, img1 = _check_strips(pr[0], pr[1], opts['coarse_downsample'], contiguous=False)
         mk0, mk1 = (pr[2], pr[3]) if len(pr) > 2 else (None, None)
         for mk in (mk0, mk1):
             if mk is not None and np.asarray(mk).shape != img0.shape:
@@ -379,10 +385,12 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
                     m = state['res'][0]
                 else:
                     m = RaggedStripBatchMatcher([items[k][0].shape for k in idx], pool=state['pool'], **opts)
-                stage = pin.array((2, n, Hm, Wm), np.uint8)
-                for j, k in enumerate(idx):
-                    h, w = items[k][0].shape
-                    stage[0, j, :h, :w] = items[k][0]; stage[1, j, :h, :w] = items[k][1]
+                # both strips of every pair into the page-locked stack [2][n][Hm][Wm] (C++ memcpy, no interpreter lock)
+                srcs = (C.c_void_p * (2 * n))(*([items[k][0].ctypes.data for k in idx] + [items[k][1].ctypes.data for k in idx]))
+                hs = np.array([items[k][0].shape[0] for k in idx] * 2, dtype=np.int32)
+                ws = np.array([items[k][0].shape[1] for k in idx] * 2, dtype=np.int32)
+                pitches = np.array([items[k][0].strides[0] for k in idx] + [items[k][1].strides[0] for k in idx], dtype=np.int64)
+                _lib.check(_lib.load().fb_host_pack2d(_lib.ctx(), pin.ptr, 2 * n, Hm, Wm, srcs, _lib.ptr(hs), _lib.ptr(ws), _lib.ptr(pitches), 2))
                 _lib.check(_lib.load().fb_memcpy_h2d(_lib.ctx(), dev.ptr, pin.ptr, 2 * n * Hm * Wm))
                 mk0 = [items[k][2] for k in idx]
                 mk1 = [items[k][3] for k in idx]
@@ -413,6 +421,6 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         th.join()
     if errors:
         raise errors[0]
-    for k in deferred:                                        # pairs of a ragged batch that take the deformed-mesh branch
+    for k in deferred:
         results[k] = stitching_matcher(items[k][0], items[k][1], **kwargs)
     return results

@@ -66,6 +66,10 @@ int fb_free(fb_ctx* ctx, void* dptr);
 /* page-locked host staging memory for fb_memcpy_h2d / fb_memcpy_d2h at the link rate */
 int fb_host_alloc(fb_ctx* ctx, size_t bytes, void** hptr);
 int fb_host_free(fb_ctx* ctx, void* hptr);
+/* gather n row-major uint8 images (hs[k] x ws[k], row pitch pitches[k] bytes) into the slots of a host stack [n][H][W]
+ * (top-left corners) with `threads` host threads: the packing of cropped strips into the staging buffer */
+int fb_host_pack2d(fb_ctx* ctx, uint8_t* dst, int n, int H, int W, const void* const* srcs, const int* hs, const int* ws,
+                   const int64_t* pitches, int threads);
 int fb_memcpy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
 int fb_memcpy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
 int fb_memset(fb_ctx* ctx, void* dst, int value, size_t bytes);
