@@ -594,9 +594,10 @@ def test_config0_readme_grid_matching_stage(fb):
     fb.matcher.stitching_matcher_batch_release()
 
 
-@pytest.mark.parametrize('shapes', [[(1024, 256), (1020, 250), (1016, 252), (1030, 262), (1024, 256)],
-                                    [(3000, 500), (2990, 496), (3011, 505)]])
-def test_ragged_batch_matches_the_per_pair_surface(fb, shapes):
+@pytest.mark.parametrize('shapes,cds', [([(1024, 256), (1020, 250), (1016, 252), (1030, 262), (1024, 256)], 0.5),
+                                        ([(1024, 256), (1021, 251), (1016, 252)], 1),
+                                        ([(3000, 500), (2990, 496), (3011, 505)], 0.5)])
+def test_ragged_batch_matches_the_per_pair_surface(fb, shapes, cds):
     """strips of unequal size in ONE batch (RaggedStripBatchMatcher: padded slots, per-image extents in the downsample / DoG
     kernels, per-pair block grids, spacings and mesh geometry inside a shared system) against the same pairs through
     matchers of their own shape"""
@@ -614,9 +615,9 @@ def test_ragged_batch_matches_the_per_pair_surface(fb, shapes):
     dev = _lib.DeviceBuffer.from_array(stage)
     junk = _lib.DeviceBuffer.from_array(np.full(4 * 2 * P * Hm * Wm, 77, dtype=np.uint8))     # dirty memory for the pool to hand out
     junk.free()
-    m = RaggedStripBatchMatcher(shapes, residue_len=2.0)
+    m = RaggedStripBatchMatcher(shapes, residue_len=2.0, coarse_downsample=cds)
     got = StripBatchMatcher.per_pair(m.match(dev.ptr, dev.offset(P * Hm * Wm)))
-    cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+    cfg = dict(sigma=2.5, coarse_downsample=cds, conf_thresh=0.33, residue_len=2)
     for k, (a, b) in enumerate(pairs):
         exp = fb.matcher.stitching_matcher(a, b, **cfg)
         g = got[k]
