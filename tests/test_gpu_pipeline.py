@@ -592,6 +592,24 @@ def test_config0_readme_grid_matching_stage(fb):
     np.testing.assert_allclose(xy1 - (b1[:2] - bboxes[j][:2]), exp['xy1'], atol=2e-4)
     np.testing.assert_allclose(wt, exp['weight'], atol=2e-4)
     fb.matcher.stitching_matcher_batch_release()
+    # ... and the optimisation stage on top of these matches (stitcher.py:1012-1018): one mesh per tile at its nominal stage
+    # position, links from the matches, SLM.optimize_linear on the device.  The tiles must end at their TRUE positions
+    # (nominal + jitter) relative to tile 0 -- both hot paths, end to end.
+    from feabas_amd import mesh, optimizer, constant as const
+    meshes = []
+    for k in range(len(tiles)):
+        mk = mesh.Mesh.from_bbox((0, 0, TW, TH), cartesian=True, mesh_size=300.0, uid=k)
+        mk.apply_translation(nom[k].astype(np.float64), const.MESH_GEAR_FIXED)
+        meshes.append(mk)
+    meshes[0].lock()
+    slm = optimizer.SLM(meshes, stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    for (i, j), (xy0, xy1, wt) in matches.items():
+        assert slm.add_link_from_coordinates(i, j, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=wt)
+    cost = slm.optimize_linear(tol=1e-8)
+    assert cost[1] < 1e-5 * cost[0]
+    ctr = np.array([mk.vertices_w_offset(const.MESH_GEAR_MOVING).mean(axis=0) for mk in meshes])
+    rel = (ctr - ctr[0]) - (nom - nom[0])                    # what the optimisation moved every tile by, relative to tile 0
+    np.testing.assert_allclose(rel, jit - jit[0], atol=0.3)   # = the injected stage jitter
 
 
 @pytest.mark.parametrize('shapes,cds', [([(1024, 256), (1020, 250), (1016, 252), (1030, 262), (1024, 256)], 0.5),
