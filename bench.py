@@ -458,8 +458,22 @@ def main():
         line['host_ingest'] = dict(value=nh / dth, unit='pairs/s', pairs=nh, matched=int(sum(o[0] is not None for o in outp)),
                                    note='strips handed over in host memory (4.2 MB per pair over PCIe), results returned per pair; '
                                         f'{args.host_ingest_threads} host threads, {P}-pair chunks')
+        # the same pairs cropped to strip shapes that all differ (what stage jitter does to the overlaps of a real section):
+        # batches of unequal strips (RaggedStripBatchMatcher)
+        rng_r = np.random.default_rng(5)
+        ragged = []
+        for k in range(min(nh, 256)):
+            dh, dw = int(rng_r.integers(0, 30)), int(rng_r.integers(0, 12))
+            ragged.append((h0[k, :H - dh, :W - dw], h1[k, :H - dh, :W - dw]))
+        fmatcher.stitching_matcher_batch(ragged, batch=32, threads=args.host_ingest_threads, **cfg)
+        t0 = time.time()
+        outr = fmatcher.stitching_matcher_batch(ragged, batch=32, threads=args.host_ingest_threads, **cfg)
+        dtr = time.time() - t0
+        line['host_ingest']['ragged'] = dict(value=len(ragged) / dtr, unit='pairs/s', pairs=len(ragged), distinct_shapes=len({a.shape for a, _ in ragged}),
+                                             matched=int(sum(o[0] is not None for o in outr)),
+                                             note='every pair cropped to its own strip size (up to 29 x 11 px smaller); 32-pair chunks of unequal strips; second pass over the list (buffer pools warm)')
         fmatcher.stitching_matcher_batch_release()
-        del h0, h1, host_pairs, outp
+        del h0, h1, host_pairs, outp, ragged, outr
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         H, W = shapes['LR']
         s0, s1, _ = strips['LR']
