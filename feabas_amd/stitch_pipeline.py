@@ -76,6 +76,19 @@ def _nfl_table(n):
     return _NFL
 
 
+def grid_counts(H, W, mesh_size, min_num_blocks=2, max_aspect_ratio=2):
+    """node counts (nx, ny) of Mesh.from_bbox((0, 0, W, H), cartesian=True) (mesh.py:403-435) without building the mesh"""
+    wd, ht = float(W), float(H)
+    nx = max(np.round(wd / mesh_size), min_num_blocks)
+    ny = max(np.round(ht / mesh_size), min_num_blocks)
+    dx, dy = wd / nx, ht / ny
+    if dx > max_aspect_ratio * dy:
+        dx = max_aspect_ratio * dy
+    elif dy > max_aspect_ratio * dx:
+        dy = max_aspect_ratio * dx
+    return int(np.ceil(wd / dx)) + 1, int(np.ceil(ht / dy)) + 1
+
+
 class MatcherPool:
     """Device buffers and relaxation systems that outlive a StripBatchMatcher.  Strip shapes vary from pair to pair in a
     real section (stitcher.py:561-571), so matchers come and go; their buffers are handed back here instead of to
@@ -986,8 +999,7 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
     def bucket_key(H, W, min_num_blocks=2, spacings=None):
         """pairs with equal keys can share a batch: number of spacings, node grid of Mesh.from_bbox (mesh.py:403-435)"""
         sp = np.sort(auto_spacings((H, W), (H, W)))[::-1] if spacings is None else np.sort(np.asarray(spacings, dtype=np.float64))[::-1]
-        m = Mesh.from_bbox((0, 0, W, H), cartesian=True, mesh_size=float(np.min(sp)), min_num_blocks=min_num_blocks, uid=1)
-        return (sp.size, m.grid_xs.size, m.grid_ys.size)
+        return (sp.size,) + grid_counts(H, W, float(np.min(sp)), min_num_blocks)
 
     def __init__(self, shapes, **opts):
         shapes = np.asarray(shapes, dtype=np.int64).reshape(-1, 2)
@@ -1083,13 +1095,16 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
             return self._relax_sys
         lib, ctx = _lib.load(), _lib.ctx()
         P = self.P
-        meshes = [Mesh.from_bbox((0, 0, int(w), int(h)), cartesian=True, mesh_size=float(np.min(self._sp[p])), min_num_blocks=self.mnb, uid=1)
-                  for p, (h, w) in enumerate(zip(self._Hs, self._Ws))]
-        m = meshes[0]
-        if any(mm.grid_xs.size != m.grid_xs.size or mm.grid_ys.size != m.grid_ys.size for mm in meshes):
-            raise ValueError('RaggedStripBatchMatcher: the pairs of a batch must share the node grid of their meshes (bucket_key)')
+        # one template mesh for the topology; the node coordinates of every pair follow from its strip size
+        m = Mesh.from_bbox((0, 0, int(self._Ws[0]), int(self._Hs[0])), cartesian=True, mesh_size=float(np.min(self._sp[0])),
+                           min_num_blocks=self.mnb, uid=1)
+        nx, ny = m.grid_xs.size, m.grid_ys.size
+        for p in range(P):
+            if grid_counts(int(self._Hs[p]), int(self._Ws[p]), float(np.min(self._sp[p])), self.mnb) != (nx, ny):
+                raise ValueError('RaggedStripBatchMatcher: the pairs of a batch must share the node grid of their meshes (bucket_key)')
         self._mesh = m                                        # the topology (triangles, node grid sizes)
-        self._meshes = meshes
+        self._gx = np.linspace(0.0, self._Ws.astype(np.float64), num=nx, endpoint=True, axis=-1) - 0.5      # mesh.py:430-431 per pair
+        self._gy = np.linspace(0.0, self._Hs.astype(np.float64), num=ny, endpoint=True, axis=-1) - 0.5
         V, T = m.num_vertices, m.num_triangles
         self._sys_key = (P, m.grid_xs.size, m.grid_ys.size)
         sysh = self._pool.systems.pop(self._sys_key, None) if self._pool is not None else None
@@ -1103,7 +1118,8 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
             nnzb = C.c_int64()
             _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
         self._mult_u = np.ascontiguousarray(np.tile(m.element_multiplier(), P), dtype=np.float32)
-        self._v_init_u = np.ascontiguousarray(np.concatenate([mm.vertices(const.MESH_GEAR_INITIAL) for mm in meshes], axis=0), dtype=np.float64)
+        vx = np.broadcast_to(self._gx[:, None, :], (P, ny, nx)); vy = np.broadcast_to(self._gy[:, :, None], (P, ny, nx))
+        self._v_init_u = np.ascontiguousarray(np.stack((vx, vy), axis=-1).reshape(-1, 2), dtype=np.float64)
         self._relax_sys = sysh
         self._k_state = None
         self._assemble_union(self._v_init_u, 'initial')
@@ -1113,28 +1129,25 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
         _lib.check(lib.fb_sys_group_energy(ctx, sysh, P, _lib.ptr(v0), _lib.ptr(es0)))
         self._es0_each = es0
         self._es0 = float(es0[0])
-        self._gx = np.stack([mm.grid_xs for mm in meshes]); self._gy = np.stack([mm.grid_ys for mm in meshes])
-        area = np.array([abs(float(mm.triangle_areas(const.MESH_GEAR_INITIAL)[0])) for mm in meshes])
+        area = 0.5 * (self._gx[:, 1] - self._gx[:, 0]) * (self._gy[:, 1] - self._gy[:, 0])      # the right triangles of a cell
         self._sample_err_each = 0.4387 * area ** 0.5 * DEFAULT_AVG_DEFORM          # optimizer.py:26-30, per pair
         return sysh
 
     def _pair_mesh(self, p):
-        src = self._meshes[p]
-        m = src.copy(uid=1)
-        m.grid_xs, m.grid_ys = src.grid_xs, src.grid_ys
-        return m
+        return Mesh.from_bbox((0, 0, int(self._Ws[p]), int(self._Hs[p])), cartesian=True, mesh_size=float(np.min(self._sp[p])),
+                              min_num_blocks=self.mnb, uid=1)
 
     def _locate_grid(self, pid, pts):
         """triangle + barycentric coordinates of points given in the INITIAL gear of their pair's grid mesh (cart2bary on
         the right triangles of a cell; the statements of pairs_build_links in fb_fem.hip with per-pair node coordinates)"""
         self._relax_system()
         pid = np.asarray(pid)
-        gx, gy = self._gx[pid], self._gy[pid]
-        nx, ny = gx.shape[1], gy.shape[1]
-        i = np.clip(np.sum(gx <= pts[:, 0:1], axis=1) - 1, 0, nx - 2)
-        j = np.clip(np.sum(gy <= pts[:, 1:2], axis=1) - 1, 0, ny - 2)
-        k = np.arange(pid.size)
-        u = (pts[:, 0] - gx[k, i]) / (gx[k, i + 1] - gx[k, i]); w = (pts[:, 1] - gy[k, j]) / (gy[k, j + 1] - gy[k, j])
+        nx, ny = self._gx.shape[1], self._gy.shape[1]
+        # the grids are uniform (Mesh.from_bbox: linspace(0, W, nx) - 0.5): the cell follows from one division per axis
+        cw = ((self._gx[:, -1] - self._gx[:, 0]) / (nx - 1))[pid]; ch = ((self._gy[:, -1] - self._gy[:, 0]) / (ny - 1))[pid]
+        fx = (pts[:, 0] - self._gx[pid, 0]) / cw; fy = (pts[:, 1] - self._gy[pid, 0]) / ch
+        i = np.clip(np.floor(fx), 0, nx - 2).astype(np.int64); j = np.clip(np.floor(fy), 0, ny - 2).astype(np.int64)
+        u = fx - i; w = fy - j
         up = w > u
         tid = 2 * (j * (nx - 1) + i) + up
         B = np.where(up[:, None], np.stack((1.0 - w, u, w - u), axis=-1), np.stack((1.0 - u, u - w, w), axis=-1))
