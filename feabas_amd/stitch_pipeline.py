@@ -52,6 +52,9 @@ def _z_order_batch(ix, iy):
     """feabas/common.py:196-215 along the last axis (base 2, two dimensions)."""
     ix = ix - ix.min(axis=-1, keepdims=True)
     iy = iy - iy.min(axis=-1, keepdims=True)
+    if ix.ndim == 2 and ix.shape[0] > 1 and np.array_equal(ix, np.broadcast_to(ix[:1], ix.shape)) and np.array_equal(iy, np.broadcast_to(iy[:1], iy.shape)):
+        # the usual case: every pair of the group has the same block index grid
+        return np.broadcast_to(_z_order_batch(ix[:1], iy[:1]), ix.shape)
     sx = np.zeros_like(ix)
     sy = np.zeros_like(iy)
     level = 0
