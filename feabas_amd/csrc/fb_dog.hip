@@ -25,6 +25,8 @@ template <>
 __device__ __forceinline__ float load_px<uint8_t>(const uint8_t* p, size_t i) { return (float)p[i]; }
 template <>
 __device__ __forceinline__ float load_px<float>(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float load_px(const uint8_t* p, uint32_t i) { return (float)p[i]; }
+__device__ __forceinline__ float load_px(const float* p, uint32_t i) { return p[i]; }
 
 // 1-D correlation at LDS position `base` with element stride `st` (symmetric taps)
 __device__ __forceinline__ float fir_sym(const float* s, int base, int st, int r, const Taps& t) {
@@ -320,8 +322,9 @@ __global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, floa
             float val[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
+                // 32-bit offsets from the (uniform) image base: one image is far below 4 G pixels (checked by the launcher)
                 const int ty = min(tb + u * nrg, G::AH - 1);
-                val[u] = load_px<T>(src, (size_t)clampi(y0 - G::HAL + ty, 0, H - 1) * SW + gx);
+                val[u] = load_px(src, (uint32_t)(clampi(y0 - G::HAL + ty, 0, H - 1) * SW + gx));
             }
             if (tx < G::AW) {
 #pragma unroll
@@ -379,13 +382,16 @@ __global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, floa
             fir_run<R>(in, taps, o);
             const int gx = x0 + c;
             if (gx >= SW) continue;
+            float* __restrict__ oimg = out + (size_t)n * SH * SW;                 // uniform base, 32-bit offsets below
+            const uint32_t off0 = (uint32_t)((y0 + run * RUN) * SW + gx);
+            const int jmax = min(RUN, SH - (y0 + run * RUN)), jin = gx < W ? H - (y0 + run * RUN) : 0;
 #pragma unroll
             for (int j = 0; j < RUN; ++j) {
-                const int ty = run * RUN + j, gy = y0 + ty;
-                if (gy >= SH) break;
+                if (j >= jmax) break;
+                const int ty = run * RUN + j;
                 float v = bufA[(ty + R) * G::PB + (c + R)] - o[j];
                 if (!signed_out) v = fabsf(v);
-                out[((size_t)n * SH + gy) * SW + gx] = (gx < W && gy < H) ? v : 0.f;      // slot pixels outside the image: 0
+                oimg[off0 + (uint32_t)(j * SW)] = j < jin ? v : 0.f;                  // slot pixels outside the image: 0
             }
         }
     }
@@ -397,6 +403,7 @@ int launch_fast(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int 
     TapsF tf;
     for (int k = 0; k <= kMaxRadius; ++k) tf.w[k] = (float)taps.w[k];
     const size_t lds = (size_t)(G::SZ_A + G::SZ_B) * sizeof(float);
+    if ((size_t)H * W >= ((size_t)1 << 31)) return fb_fail(ctx, FB_ERR_ARG, "fb_dog: image of %d x %d pixels exceeds the 32-bit offsets of the fast kernel", H, W);
     auto kern = dog_fast<T, R>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(fb_cdiv(W, FT), fb_cdiv(H, FT), N);
