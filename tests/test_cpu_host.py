@@ -332,3 +332,24 @@ def test_find_overlaps_readme_grid():
     assert stitcher.find_overlaps(bboxes[:1]).shape == (0, 2)
     m, s, p, err = stitcher.match_list_of_overlaps(np.empty((0, 2), int), [], bboxes)
     assert (m, s, p, err) == ({}, {}, {}, False)
+
+
+def test_host_pack2d():
+    """fb_host_pack2d: row-pitched views gathered into the corners of a staging stack"""
+    from feabas_amd import _lib
+    import ctypes as C
+    rng = np.random.default_rng(2)
+    big = rng.integers(0, 256, (5, 90, 120), dtype=np.uint8)
+    views = [big[0, :80, :100], big[1, 3:90, 7:64], big[2], big[3, ::1, :1], big[4, :1, :]]
+    H, W = 90, 120
+    dst = np.full((len(views), H, W), 255, dtype=np.uint8)
+    srcs = (C.c_void_p * len(views))(*[v.ctypes.data for v in views])
+    hs = np.array([v.shape[0] for v in views], dtype=np.int32); ws = np.array([v.shape[1] for v in views], dtype=np.int32)
+    pitches = np.array([v.strides[0] for v in views], dtype=np.int64)
+    for threads in (1, 3):
+        dst[...] = 255
+        assert _lib.load().fb_host_pack2d(None, _lib.ptr(dst), len(views), H, W, srcs, _lib.ptr(hs), _lib.ptr(ws), _lib.ptr(pitches), threads) == 0
+        for k, v in enumerate(views):
+            np.testing.assert_array_equal(dst[k, :v.shape[0], :v.shape[1]], v)
+            assert (dst[k, v.shape[0]:] == 255).all() and (dst[k, :, v.shape[1]:] == 255).all()
+    assert _lib.load().fb_host_pack2d(None, _lib.ptr(dst), 1, 10, 10, srcs, _lib.ptr(hs), _lib.ptr(ws), _lib.ptr(pitches), 1) != 0     # does not fit

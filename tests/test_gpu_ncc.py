@@ -230,3 +230,33 @@ def test_blocks_affine_gather_vs_oracle(fb, bh, bw, pad):
     assert np.median(exp[2]) > 0.5                       # the blocks do match
     for b in (d0, d1, dblk, daff, out):
         b.free()
+
+
+def test_dog_and_downsample_of_unequal_images_in_one_stack(fb):
+    """fb_area_downsample2_sizes_dev / fb_dog_sizes_dev: images of unequal size in padded slots are processed as images of
+    their own size ('nearest' extension at their own border) -- bit-identical to the equal-size kernels image by image --
+    and the rest of every slot is zero"""
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(12)
+    sizes = np.array([[300, 200], [257, 131], [299, 199], [64, 70]], dtype=np.int32)
+    N, H, W = sizes.shape[0], 300, 200
+    stack = rng.integers(0, 256, (N, H, W), dtype=np.uint8)          # the padding holds junk on purpose
+    d_in = _lib.DeviceBuffer.from_array(stack); d_sz = _lib.DeviceBuffer.from_array(sizes)
+    hc, wc = fb.common.half_size(H), fb.common.half_size(W)
+    d_small = _lib.DeviceBuffer.from_array(np.full((N, hc, wc), 99, dtype=np.uint8)); d_dog = _lib.DeviceBuffer.from_array(np.full((N, H, W), 7.0, dtype=np.float32))
+    _lib.check(lib.fb_area_downsample2_sizes_dev(ctx, d_in.ptr, N, H, W, d_sz.ptr, d_small.ptr))
+    _lib.check(lib.fb_dog_sizes_dev(ctx, d_in.ptr, 0, N, H, W, d_sz.ptr, 2.5, 1, d_dog.ptr))
+    small = d_small.to_array((N, hc, wc), np.uint8); dog = d_dog.to_array((N, H, W), np.float32)
+    for n, (h, w) in enumerate(sizes):
+        img = np.ascontiguousarray(stack[n, :h, :w])
+        exp_s = fb.common.area_downsample2(img)
+        np.testing.assert_array_equal(small[n, :exp_s.shape[0], :exp_s.shape[1]], exp_s)
+        assert not small[n, exp_s.shape[0]:].any() and not small[n, :, exp_s.shape[1]:].any()
+        exp_d = fb.common.masked_dog_filter(img, 2.5)
+        np.testing.assert_array_equal(dog[n, :h, :w], exp_d)
+        assert not dog[n, h:].any() and not dog[n, :, w:].any()
+        np.testing.assert_allclose(exp_d, ncc_ref.masked_dog_filter(img, 2.5), atol=1e-5 * np.abs(exp_d).max() + 1e-4)
+    for b in (d_in, d_sz, d_small, d_dog):
+        b.free()
+
