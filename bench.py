@@ -449,13 +449,13 @@ def main():
         s0, s1, _ = strips['LR']
         nh = min(args.host_ingest_pairs, n_res)
         h0 = s0.to_array((nh, H, W), np.uint8); h1 = s1.to_array((nh, H, W), np.uint8)
-        host_pairs = [(h0[k], h1[k]) for k in range(nh)]
+        host_pairs = [(h0[k % nh], h1[k % nh]) for k in range(args.host_ingest_pairs)]     # the list may wrap around the resident strips
         cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=RESIDUE_LEN)
         fmatcher.stitching_matcher_batch(host_pairs[:P * args.host_ingest_threads], batch=P, threads=args.host_ingest_threads, **cfg)        # set-up pass
         t0 = time.time()
         outp = fmatcher.stitching_matcher_batch(host_pairs, batch=P, threads=args.host_ingest_threads, **cfg)
         dth = time.time() - t0
-        line['host_ingest'] = dict(value=nh / dth, unit='pairs/s', pairs=nh, matched=int(sum(o[0] is not None for o in outp)),
+        line['host_ingest'] = dict(value=len(host_pairs) / dth, unit='pairs/s', pairs=len(host_pairs), matched=int(sum(o[0] is not None for o in outp)),
                                    note='strips handed over in host memory (4.2 MB per pair over PCIe), results returned per pair; '
                                         f'{args.host_ingest_threads} host threads, {P}-pair chunks')
         # the same pairs cropped to strip shapes that all differ (what stage jitter does to the overlaps of a real section):
