@@ -104,6 +104,7 @@ _PROTOS = {
     'fb_csr_destroy': (None, [c_p, c_p]),
     'fb_csr_info': (c_i, [c_p, c_p] + [C.POINTER(c_i64)] * 4),
     'fb_spmv': (c_i, [c_p, c_p, c_p, c_p]),
+    'fb_spmv_dev': (c_i, [c_p, c_p, c_p, c_p]),
     'fb_pcg_csr': (c_i, [c_p, c_p, c_p, c_p, c_i, c_d, c_d, c_i, c_i, C.POINTER(c_i), C.POINTER(c_d)]),
     'fb_pcg_fixed_iters': (c_i, [c_p, c_p, c_p, c_i, C.POINTER(c_d)]),
 }

@@ -722,6 +722,14 @@ int fb_spmv(fb_ctx* ctx, fb_csr* A, const double* x_host, double* y_host) {
     return FB_OK;
 }
 
+// y = A x on device-resident vectors (e.g. torch tensors of a distributed solver): no copies, no synchronisation
+int fb_spmv_dev(fb_ctx* ctx, fb_csr* A, const double* x_dev, double* y_dev) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, A && x_dev && y_dev);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    return fb_bsr_spmv_dev(ctx, A->M, reinterpret_cast<const double2*>(x_dev), reinterpret_cast<double2*>(y_dev));
+}
+
 int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, double rtol, double atol, int maxiter, int precond,
                int* iters, double* relres) {
     FB_LOCK(ctx);

@@ -59,3 +59,172 @@ def gather_match_table(pair_ids, xy0, xy1, weight, pair_offset=0, group=None):
                           np.asarray(weight, dtype=np.float64).reshape(-1, 1)), axis=1)
     parts = allgather_ragged(tab, group=group)
     return np.concatenate(parts, axis=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Coupled-window solve (SURVEY.md sec.8e mode 2 / sec.8f row 4): the sections of an alignment window form ONE system
+# (aligner.py:510-535, 696-727) whose rows are partitioned by section over the ranks.  Links only join neighbouring
+# sections, so a rank needs the entries of a few other ranks' vectors: a point-to-point halo exchange per iteration and
+# ONE fused all-reduce of three scalars (Chronopoulos-Gear form of the preconditioned conjugate gradients: the two inner
+# products and the residual norm of an iteration are taken on the same vectors).
+class RowPartition:
+    """Who owns which rows, which foreign columns the local rows touch (the halo), and the send / receive lists.
+
+    indptr / indices: CSR pattern of the LOCAL rows with GLOBAL column ids; row_start: global id of the first local row.
+    After construction: ``halo`` (sorted global ids of foreign columns), ``local_cols`` (indices with every column mapped
+    to [0, n_loc) for own columns and n_loc + position in halo for foreign ones), ``recv`` {rank: slice of halo},
+    ``send`` {rank: local row ids that rank needs}."""
+
+    def __init__(self, indptr, indices, row_start, group=None):
+        torch, dist = _dist()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        indptr = np.asarray(indptr, dtype=np.int64); indices = np.asarray(indices, dtype=np.int64)
+        self.n_loc = indptr.size - 1
+        self.row_start = int(row_start)
+        spans = [None] * self.world
+        dist.all_gather_object(spans, (self.row_start, self.n_loc), group=group)
+        self.starts = np.array([s for s, _ in spans], dtype=np.int64)
+        self.counts = np.array([c for _, c in spans], dtype=np.int64)
+        if np.any(self.starts[1:] != self.starts[:-1] + self.counts[:-1]):
+            raise ValueError('RowPartition: the row blocks of the ranks must be contiguous and in rank order')
+        own = (indices >= self.row_start) & (indices < self.row_start + self.n_loc)
+        self.halo = np.unique(indices[~own])
+        owner = np.searchsorted(self.starts, self.halo, side='right') - 1
+        self.local_cols = np.where(own, indices - self.row_start, self.n_loc + np.searchsorted(self.halo, indices)).astype(np.int64)
+        self.recv = {}
+        need = {}
+        for r in np.unique(owner):
+            sel = np.flatnonzero(owner == r)
+            self.recv[int(r)] = slice(int(sel[0]), int(sel[-1]) + 1)         # halo is sorted, owners are contiguous runs
+            need[int(r)] = self.halo[sel] - self.starts[r]
+        wants = [None] * self.world
+        dist.all_gather_object(wants, need, group=group)
+        self.send = {src: np.asarray(w[self.rank], dtype=np.int64) for src, w in enumerate(wants) if self.rank in w and src != self.rank}
+        self.n_halo = int(self.halo.size)
+
+    def exchange(self, v_loc, out_halo):
+        """fill out_halo (torch tensor [n_halo]) with the foreign entries of the distributed vector whose local part is v_loc"""
+        torch, dist = _dist()
+        if self.world == 1 or (not self.send and not self.recv):
+            return
+        dev = _device(dist)
+        ops, bufs = [], []
+        for dst, rows in sorted(self.send.items()):
+            t = v_loc[torch.as_tensor(rows, device=v_loc.device)].to(dev).contiguous()
+            ops.append(dist.P2POp(dist.isend, t, dst, group=self.group))
+        for src, sl in sorted(self.recv.items()):
+            t = torch.empty(sl.stop - sl.start, dtype=v_loc.dtype, device=dev)
+            bufs.append((sl, t))
+            ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for sl, t in bufs:
+            out_halo[sl] = t.to(out_halo.device)
+
+
+def pcg_row_partitioned(part, spmv, b_loc, minv_loc, rtol=1e-7, maxiter=10000, check_every=8):
+    """Jacobi-preconditioned conjugate gradients on a row-partitioned system.
+
+    part: RowPartition; spmv(u_ext) -> (A u)_loc for u_ext = [u_loc | u_halo] (torch tensor, n_loc + n_halo);
+    b_loc, minv_loc: torch tensors [n_loc] on the compute device (right-hand side, inverse diagonal).
+    One halo exchange + one SpMV + ONE all-reduce (3 scalars) per iteration; the scalars stay on the device, the host
+    looks at the residual every `check_every` iterations only (with RCCL nothing else synchronises the host).
+    Stops at ||r|| <= rtol ||b||.  Returns (x_loc, iterations, relative residual)."""
+    torch, dist = _dist()
+    cdev = _device(dist)
+    n = part.n_loc
+
+    def reduce3(a, b_, c):
+        t = torch.stack((a, b_, c))
+        if part.world > 1:
+            if t.device != cdev:
+                tc = t.to(cdev)
+                dist.all_reduce(tc, group=part.group)
+                t = tc.to(t.device)
+            else:
+                dist.all_reduce(t, group=part.group)
+        return t
+
+    ext = torch.zeros(n + part.n_halo, dtype=b_loc.dtype, device=b_loc.device)
+    x = torch.zeros_like(b_loc)
+    r = b_loc.clone()
+    u = minv_loc * r
+    ext[:n] = u; part.exchange(u, ext[n:])
+    w = spmv(ext).clone()
+    t = reduce3(torch.dot(r, u), torch.dot(w, u), torch.dot(r, r))
+    gamma, delta, rr = t[0], t[1], t[2]
+    bnorm2 = float(rr)
+    if bnorm2 == 0.0 or maxiter == 0:
+        return x, 0, 0.0
+    p = torch.zeros_like(b_loc); s = torch.zeros_like(b_loc)
+    alpha = gamma / delta
+    beta = torch.zeros((), dtype=b_loc.dtype, device=b_loc.device)
+    it = 0
+    rel = 1.0
+    while it < maxiter:
+        p = u + beta * p
+        s = w + beta * s
+        x += alpha * p
+        r -= alpha * s
+        u = minv_loc * r
+        ext[:n] = u; part.exchange(u, ext[n:])
+        w = spmv(ext).clone()
+        t = reduce3(torch.dot(r, u), torch.dot(w, u), torch.dot(r, r))
+        it += 1
+        if it % check_every == 0 or it == maxiter:
+            rel = (float(t[2]) / bnorm2) ** 0.5                      # the only host synchronisation of the loop
+            if rel <= rtol:
+                break
+        beta = t[0] / gamma
+        alpha = t[0] / (t[1] - beta * t[0] / alpha)
+        gamma = t[0]
+    return x, it, rel
+
+
+class DeviceRows:
+    """the local rows of a partitioned system on the GPU: [A_own | A_halo] stored as one square block-CSR of size
+    n_loc + n_halo (the halo rows are empty), applied to torch tensors through fb_spmv_dev"""
+
+    def __init__(self, part, indptr, data):
+        import ctypes as C
+        from . import _lib
+        n, m = part.n_loc, part.n_loc + part.n_halo
+        if n % 2 or m % 2:
+            raise ValueError('DeviceRows: DoF come in (x, y) pairs')
+        ip = np.concatenate((np.asarray(indptr, dtype=np.int64), np.full(m - n, int(indptr[-1]), dtype=np.int64)))
+        idx = np.ascontiguousarray(part.local_cols, dtype=np.int32)
+        val = np.ascontiguousarray(data, dtype=np.float64)
+        self._lib, self._ctx = _lib, _lib.ctx()
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().fb_csr_upload(self._ctx, m, _lib.ptr(ip), _lib.ptr(idx), _lib.ptr(val), 0, C.byref(self.h)))
+        self.m, self.n = m, n
+        self._y = None
+
+    def stream(self):
+        """the context's HIP stream as a torch stream: run the solver under ``with torch.cuda.stream(rows.stream())`` and the
+        vector updates, the collectives and the SpMV are ordered on ONE stream without host synchronisation"""
+        import torch
+        return torch.cuda.ExternalStream(self._lib.load().fb_stream(self._ctx))
+
+    def __call__(self, ext):
+        import torch
+        if self._y is None:
+            self._y = torch.empty(self.m, dtype=torch.float64, device=ext.device)
+        shared = torch.cuda.current_stream().cuda_stream == self._lib.load().fb_stream(self._ctx)
+        if not shared:
+            torch.cuda.current_stream().synchronize()             # torch's stream -> the context's stream
+        self._lib.check(self._lib.load().fb_spmv_dev(self._ctx, self.h, C_ptr(ext), C_ptr(self._y)))
+        if not shared:
+            self._lib.check(self._lib.load().fb_sync(self._ctx))
+        return self._y[:self.n]
+
+    def free(self):
+        if self.h is not None:
+            self._lib.load().fb_csr_destroy(self._ctx, self.h)
+            self.h = None
+
+
+def C_ptr(t):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr())

@@ -291,6 +291,8 @@ int fb_csr_upload(fb_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* 
 void fb_csr_destroy(fb_ctx* ctx, fb_csr* A);
 int fb_csr_info(fb_ctx* ctx, fb_csr* A, int64_t* n, int64_t* nnz, int64_t* nb, int64_t* nnzb);
 int fb_spmv(fb_ctx* ctx, fb_csr* A, const double* x_host, double* y_host);
+/* y = A x on device-resident vectors of length n (16-byte aligned), on the context's stream; no copies, no sync */
+int fb_spmv_dev(fb_ctx* ctx, fb_csr* A, const double* x_dev, double* y_dev);
 int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, double rtol, double atol,
                int maxiter, int precond, int* iters, double* relres);
 /* exactly `iters` PCG iterations with no convergence exit (throughput bench) */

@@ -53,3 +53,91 @@ def test_gather_match_table_world2(tmp_path):
     assert np.all(np.diff(r0['table'][:, 0]) >= 0)                            # ordered by global pair id
     assert sorted(set(r0['table'][:, 0].astype(int))) == list(range(11))
     np.testing.assert_array_equal(r0['p0'].ravel(), [0, 1, 2]); np.testing.assert_array_equal(r0['p1'].ravel(), [10, 11, 12, 13])
+
+
+def _coupled_system(n_sections=4, nv=150, seed=0):
+    """a chain of `n_sections` sections (2-D elastic-like SPD blocks of nv vertices = 2 nv DoF each) coupled to their
+    neighbours by a few links, like an alignment window (aligner.py:510-535): returns scipy CSR A (SPD) and b"""
+    from scipy import sparse
+    rng = np.random.default_rng(seed)
+    n = 2 * nv
+    blocks = []
+    for s in range(n_sections):
+        L = sparse.diags([-1.0, 2.2, -1.0], [-2, 0, 2], shape=(n, n)) + sparse.diags([-0.3, -0.3], [-1, 1], shape=(n, n))
+        blocks.append(L * rng.uniform(0.8, 1.2))
+    A = sparse.block_diag(blocks, format='lil')
+    N = n * n_sections
+    for s in range(n_sections - 1):                                  # links: w (u_a - u_b)^2 on both coordinates of a vertex pair
+        for _ in range(25):
+            va, vb = rng.integers(0, nv, 2)
+            w = rng.uniform(0.3, 1.0)
+            for c in range(2):
+                i, j = s * n + 2 * va + c, (s + 1) * n + 2 * vb + c
+                A[i, i] += w; A[j, j] += w; A[i, j] -= w; A[j, i] -= w
+    A = A.tocsr()
+    b = rng.standard_normal(N)
+    return A, b
+
+
+def _pcg_worker(rank, world, port, outdir, use_gpu):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    A, b = _coupled_system()
+    n_sec = 4
+    sec0, sec1 = fdist.shard_range(n_sec, rank, world)               # whole sections per rank
+    per = A.shape[0] // n_sec
+    r0, r1 = sec0 * per, sec1 * per
+    rows = A[r0:r1].tocsr()
+    part = fdist.RowPartition(rows.indptr, rows.indices, r0)
+    dev = torch.device('cuda', 0) if use_gpu else torch.device('cpu')
+    b_loc = torch.from_numpy(b[r0:r1].copy()).to(dev)
+    minv = torch.from_numpy(1.0 / A.diagonal()[r0:r1]).to(dev)
+    if use_gpu:
+        spmv = fdist.DeviceRows(part, rows.indptr, rows.data)
+    else:
+        from scipy import sparse
+        loc = sparse.csr_matrix((rows.data, part.local_cols, rows.indptr), shape=(r1 - r0, part.n_loc + part.n_halo))
+        spmv = lambda ext: torch.from_numpy(loc @ ext.numpy())
+    if use_gpu and rank == 0:                                        # one rank on the context's stream, one on torch's default stream
+        with torch.cuda.stream(spmv.stream()):
+            x, it, rel = fdist.pcg_row_partitioned(part, spmv, b_loc, minv, rtol=1e-10, maxiter=5000)
+            torch.cuda.current_stream().synchronize()
+    else:
+        x, it, rel = fdist.pcg_row_partitioned(part, spmv, b_loc, minv, rtol=1e-10, maxiter=5000)
+    np.savez(os.path.join(outdir, f'x{rank}.npz'), x=x.cpu().numpy(), it=it, rel=rel, r0=r0, halo=part.n_halo)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_pcg(tmp_path, world):
+    from scipy.sparse.linalg import spsolve
+    A, b = _coupled_system()
+    exact = spsolve(A.tocsc(), b)
+    parts = [np.load(tmp_path / f'x{r}.npz') for r in range(world)]
+    x = np.concatenate([p['x'] for p in parts])
+    assert all(int(p['it']) == int(parts[0]['it']) for p in parts) and float(parts[0]['rel']) <= 1e-10
+    if world > 1:
+        assert all(int(p['halo']) > 0 for p in parts)
+    np.testing.assert_allclose(x, exact, atol=1e-7 * np.abs(exact).max())
+
+
+@pytest.mark.parametrize('world', [1, 2, 3])
+def test_coupled_window_pcg_gloo(tmp_path, world):
+    """the row-partitioned PCG of the coupled alignment window (halo exchange + one fused all-reduce per iteration) on
+    CPU tensors over gloo, local products by scipy (injected: the product path applies the device SpMV): the assembled
+    solution equals the direct solve of the global system"""
+    import torch.multiprocessing as mp
+    mp.spawn(_pcg_worker, args=(world, _free_port(), str(tmp_path), False), nprocs=world, join=True)
+    _check_pcg(tmp_path, world)
+
+
+@pytest.mark.gpu
+def test_coupled_window_pcg_device_rows_world2(tmp_path):
+    """the same with the local rows on the GPU (DeviceRows: fb_csr_upload + fb_spmv_dev on torch tensors), two processes
+    sharing the one GPU of the box, scalars and halos over gloo"""
+    import torch.multiprocessing as mp
+    mp.spawn(_pcg_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    _check_pcg(tmp_path, 2)
