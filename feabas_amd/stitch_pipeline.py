@@ -976,15 +976,20 @@ class StripBatchMatcher:
     def per_pair(res):
         """split the flat match table into the per-pair tuples stitching_matcher returns"""
         out = []
-        for p in range(res['tx'].size):
-            m = res['pair'] == p
+        n = res['tx'].size
+        pid = np.asarray(res['pair'])
+        order = np.argsort(pid, kind='stable')                # one sort instead of a mask per pair
+        bounds = np.searchsorted(pid[order], np.arange(n + 1))
+        xy0, xy1, wt = res['xy0'][order], res['xy1'][order], res['weight'][order]
+        deferred = res.get('deferred', np.zeros(n, dtype=bool))
+        for p in range(n):
             if res['valid'][p]:
+                a, b = bounds[p], bounds[p + 1]
                 out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=False, deformed=bool(res['deformed'][p]),
-                                deferred=False, xy0=res['xy0'][m], xy1=res['xy1'][m], weight=res['weight'][m], strain=float(res['strain'][p])))
+                                deferred=False, xy0=xy0[a:b], xy1=xy1[a:b], weight=wt[a:b], strain=float(res['strain'][p])))
             else:
                 out.append(dict(tx=res['tx'][p], ty=res['ty'][p], conf0=float(res['conf0'][p]), needs_host=False, deformed=False,
-                                deferred=bool(res['deferred'][p]) if 'deferred' in res else False,
-                                xy0=None, xy1=None, weight=None, strain=DEFAULT_AVG_DEFORM))
+                                deferred=bool(deferred[p]), xy0=None, xy1=None, weight=None, strain=DEFAULT_AVG_DEFORM))
         return out
 
 
