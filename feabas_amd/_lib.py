@@ -87,8 +87,8 @@ _PROTOS = {
     'fb_sys_form_groups': (c_i, [c_p, c_p, c_i, c_d, c_d, c_p]),
     'fb_sys_solve_groups': (c_i, [c_p, c_p, c_i, c_p, c_d, c_d, c_i, c_i, c_p, c_p]),
     'fb_sys_group_energy': (c_i, [c_p, c_p, c_i, c_p, c_p]),
-    'fb_pairs_relax': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_d, c_d, c_d, c_p, c_p, c_p, c_p]),
-    'fb_pairs_relax_bary': (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_d, c_d, c_p, c_d, c_d, c_p, c_p, c_p, c_p]),
+    'fb_pairs_relax': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_i, c_d, c_d, c_d, c_p, c_p, c_p, c_p]),
+    'fb_pairs_relax_bary': (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_d, c_i, c_d, c_p, c_d, c_d, c_p, c_p, c_p, c_p]),
     'fb_pairs_strain_bary': (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_d, c_p, c_p, c_p]),
     'fb_deformed_block_affines': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_d, c_p, c_p, c_p, c_p]),
     'fb_deformed_exact_field': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),

@@ -923,7 +923,7 @@ namespace {
 // residual of every match before the solve.  Solve every pair, then the huber residue weights.
 int pairs_relax_core(fb_ctx* ctx, fb_system* s, int P, int64_t K, const float* conf, double residue_len, double sample_err,
                      double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres,
-                     const double* sample_err_each = nullptr) {
+                     const double* sample_err_each = nullptr, int residue_mode = 0) {
     int rc;
     if ((rc = fb_sys_assemble_links(ctx, s, s->h_bary6.data(), conf, s->h_dxy.data()))) return rc;
     if ((rc = fb_sys_form_groups(ctx, s, P, stiffness_lambda, -1.0, nullptr))) return rc;
@@ -940,7 +940,8 @@ int pairs_relax_core(fb_ctx* ctx, fb_system* s, int P, int64_t K, const float* c
         const double se = sample_err_each ? sample_err_each[k] : sample_err;
         const double d2 = rx * rx + ry * ry - se * se;
         const double dis = std::sqrt(d2 > 0.0 ? d2 : 0.0);
-        rw[k] = (float)(residue_len / std::max(dis, residue_len));
+        // huber: L / max(dis, L) (optimizer.py:203-205); threshold: dis <= L (optimizer.py:198-200)
+        rw[k] = residue_mode == 1 ? (dis <= residue_len ? 1.0f : 0.0f) : (float)(residue_len / std::max(dis, residue_len));
     }
     if (x_out) std::copy(s->h_x.begin(), s->h_x.end(), x_out);
     return FB_OK;
@@ -951,8 +952,8 @@ int pairs_relax_core(fb_ctx* ctx, fb_system* s, int P, int64_t K, const float* c
 // huber residue weight L / max(sqrt(max(|r|^2 - sample_err^2, 0)), L) of every match (optimizer.py:174-205).
 // xy0_mov: mesh0 points in the MOVING gear, xy1_init: mesh1 points in its INITIAL gear, t1 [P][2]: mesh1 offsets.
 int fb_pairs_relax(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
-                   const double* xy0_mov, const double* xy1_init, const double* t1, const float* conf, double residue_len, double sample_err,
-                   double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres) {
+                   const double* xy0_mov, const double* xy1_init, const double* t1, const float* conf, double residue_len, int residue_mode,
+                   double sample_err, double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && P > 0 && s->nv % P == 0 && K > 0 && pid && xy0_mov && xy1_init && t1 && conf && rw);
     int rc = pairs_build_links(ctx, s, P, nx, ny, xs, ys, K, pid, xy1_init);
@@ -963,7 +964,7 @@ int fb_pairs_relax(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const doubl
         s->h_dxy[2 * k] = (xy1_init[2 * k] + t1[2 * p]) - xy0_mov[2 * k];
         s->h_dxy[2 * k + 1] = (xy1_init[2 * k + 1] + t1[2 * p + 1]) - xy0_mov[2 * k + 1];
     }
-    return pairs_relax_core(ctx, s, P, K, conf, residue_len, sample_err, stiffness_lambda, rtol, rw, x_out, iters, relres);
+    return pairs_relax_core(ctx, s, P, K, conf, residue_len, sample_err, stiffness_lambda, rtol, rw, x_out, iters, relres, nullptr, residue_mode);
 }
 
 // The same relaxation for matches that were located in a DEFORMED mesh1 (Link.from_coordinates on the MOVING gear of a
@@ -973,8 +974,8 @@ int fb_pairs_relax(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const doubl
 // energy of the earlier deformation (the `stress` term of optimizer.py:1417-1418) is inside the system: the minimiser
 // is the reference's MOVING gear after optimize_linear, whatever the starting field.
 int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int32_t* nodes3, const double* B1, const double* dxy0,
-                        const float* conf, double residue_len, double sample_err, const double* sample_err_each, double stiffness_lambda,
-                        double rtol, float* rw, double* x_out, int* iters, double* relres) {
+                        const float* conf, double residue_len, int residue_mode, double sample_err, const double* sample_err_each,
+                        double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && P > 0 && s->nv % P == 0 && K > 0 && nodes3 && B1 && dxy0 && conf && rw);
     s->h_nodes6.resize(6 * (size_t)K);
@@ -995,7 +996,7 @@ int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int32
     }
     int rc = fb_sys_update_links(ctx, s, K, s->h_nodes6.data());
     if (rc) return rc;
-    return pairs_relax_core(ctx, s, P, K, conf, residue_len, sample_err, stiffness_lambda, rtol, rw, x_out, iters, relres, sample_err_each);
+    return pairs_relax_core(ctx, s, P, K, conf, residue_len, sample_err, stiffness_lambda, rtol, rw, x_out, iters, relres, sample_err_each, residue_mode);
 }
 
 // matcher.py:752-777 for a batch, after the rigid initialisation R [P][3][3] (row vectors: v_fixed = v_initial R[:2,:2],

@@ -214,7 +214,7 @@ def _stitching_options(kwargs):
     opts = dict(sigma=sigma, coarse_downsample=coarse_downsample, conf_thresh=kw.pop('conf_thresh', 0.3),
                 min_num_blocks=kw.pop('min_num_blocks', 2), conf_mode=kw.pop('conf_mode', const.FFT_CONF_MIRROR),
                 residue_len=kw.pop('residue_len', 5), stiffness_lambda=kw.pop('stiffness_lambda', 1),
-                compute_strain=kw.pop('compute_strain', True))
+                compute_strain=kw.pop('compute_strain', True), residue_mode=residue_mode)
     mask0 = kw.pop('mask0', None)
     mask1 = kw.pop('mask1', None)
     spacings = kw.pop('spacings', None)
@@ -229,9 +229,10 @@ def _stitching_options(kwargs):
     kw.pop('opt_tol', None); kw.pop('pad', None)
     if kw:
         raise NotImplementedError(f'stitching_matcher: unsupported options {sorted(kw)}')
-    if fine_downsample != 1 or coarse_downsample not in (1, 0.5) or residue_mode != 'huber':
-        raise NotImplementedError('stitching_matcher: fine_downsample != 1, coarse_downsample outside (1, 0.5) or a non-huber '
-                                  'residue mode is not on the device path')
+    if residue_mode not in ('huber', 'threshold'):
+        raise ValueError("stitching_matcher: residue_mode must be 'huber' or 'threshold' (matcher.py:730-735)")
+    if fine_downsample != 1 or coarse_downsample not in (1, 0.5):
+        raise NotImplementedError('stitching_matcher: fine_downsample != 1 or coarse_downsample outside (1, 0.5) is not on the device path')
     return opts, mask0, mask1, compute_photometric
 
 
@@ -257,8 +258,8 @@ def stitching_matcher(img0, img1, **kwargs):
     of one; callers with many pairs use ``stitching_matcher_batch``).  Supported: equal-shape 2-D uint8 strips,
     ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, optional masks (mask0 / mask1, True =
     valid pixel) and photometric statistics; mesh relaxations between spacings of any shape (rigid or deformed mesh1).
-    Explicit ``spacings`` are taken in pixels.  Anything the device path does not cover (spacings < 1, fine_downsample != 1,
-    a threshold residue mode) raises NotImplementedError instead of silently taking another route."""
+    Explicit ``spacings`` are taken in pixels, ``residue_mode`` is 'huber' or 'threshold'.  Anything the device path does not
+    cover (spacings < 1, fine_downsample != 1) raises NotImplementedError instead of silently taking another route."""
     from .stitch_pipeline import StripBatchMatcher
     opts, mask0, mask1, compute_photometric = _stitching_options(kwargs)
     img0, img1 = _check_strips(img0, img1, opts['coarse_downsample'])

@@ -131,7 +131,7 @@ class MatcherPool:
 class StripBatchMatcher:
     def __init__(self, P, H, W, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
                  conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9, compute_strain=True, spacings=None,
-                 pool=None):
+                 pool=None, residue_mode='huber'):
         assert coarse_downsample in (0.5, 1)
         self._pool = pool
         alloc = pool.take if pool is not None else _lib.DeviceBuffer
@@ -163,6 +163,9 @@ class StripBatchMatcher:
         self.d_blk = alloc(self.max_blocks * 9 * 4)
         self.d_out = alloc(self.max_blocks * 20)       # per launch: [dx f64 N][dy f64 N][conf f32 N], one D2H copy
         self.residue_len = float(residue_len)                 # matcher.py:236 (fine_downsample = 1)
+        if residue_mode not in ('huber', 'threshold'):
+            raise ValueError("residue_mode must be 'huber' or 'threshold' (matcher.py:730-735)")
+        self.residue_mode = 1 if residue_mode == 'threshold' else 0
         self.stiffness_lambda = float(stiffness_lambda)       # matcher.py:507
         self.relax_tol = float(relax_tol)
         self.compute_strain = bool(compute_strain)          # matcher.py:497
@@ -550,7 +553,7 @@ class StripBatchMatcher:
             x = np.empty(2 * self.P * V, dtype=np.float64)
             iters, relres = C.c_int(), C.c_double()
             _lib.check(lib.fb_pairs_relax_bary(ctx, sysh, self.P, K, _lib.ptr(nodes3), _lib.ptr(B1), _lib.ptr(dxy0), _lib.ptr(w32),
-                                               self.residue_len if self.residue_len > 0 else 1.0, sample_err, _lib.ptr(se_each), self.stiffness_lambda,
+                                               self.residue_len if self.residue_len > 0 else 1.0, self.residue_mode, sample_err, _lib.ptr(se_each), self.stiffness_lambda,
                                                self.relax_tol, _lib.ptr(rw), _lib.ptr(x), C.byref(iters), C.byref(relres)))
             self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K), relaxed_first=0)
             return rw, x.reshape(self.P, V, 2)
@@ -648,7 +651,7 @@ class StripBatchMatcher:
         area = float(np.abs(m.triangle_areas(const.MESH_GEAR_INITIAL)[0]))
         sample_err = 0.4387 * area ** 0.5 * DEFAULT_AVG_DEFORM          # optimizer.py:26-30, equal triangles on both sides
         _lib.check(lib.fb_pairs_relax(ctx, sysh, self.P, m.grid_xs.size, m.grid_ys.size, _lib.ptr(m.grid_xs), _lib.ptr(m.grid_ys), K,
-                                      _lib.ptr(pid32), _lib.ptr(xy0c), _lib.ptr(xy1i), _lib.ptr(t1c), _lib.ptr(w32), self.residue_len,
+                                      _lib.ptr(pid32), _lib.ptr(xy0c), _lib.ptr(xy1i), _lib.ptr(t1c), _lib.ptr(w32), self.residue_len, self.residue_mode,
                                       sample_err, self.stiffness_lambda, self.relax_tol, _lib.ptr(rw), _lib.ptr(x),
                                       C.byref(iters), C.byref(relres)))
         self.last_relax = dict(iters=iters.value, relres=relres.value, matches=int(K), relaxed_first=0)
@@ -697,7 +700,7 @@ class StripBatchMatcher:
             dxy = m1.bary2cart(tid, B, const.MESH_GEAR_MOVING, offsetting=True) - xy0[rows]
             dis = np.sum(dxy ** 2, axis=-1) ** 0.5
             dis = ((dis ** 2 - se_each[rows] ** 2).clip(0, None)) ** 0.5              # optimizer.py:183-185
-            rw[rows] = (self.residue_len / np.maximum(dis, self.residue_len)).astype(np.float32)
+            rw[rows] = ((dis <= self.residue_len) if self.residue_mode == 1 else (self.residue_len / np.maximum(dis, self.residue_len))).astype(np.float32)
             x[p] = m1.vertices_w_offset(const.MESH_GEAR_MOVING) - (v_init + t1[p])
 
     def _rigid_fits(self, pid, p0, p1, wt):
@@ -962,6 +965,10 @@ class StripBatchMatcher:
             table = (np.zeros(0, np.int64), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0, np.float32))
         pid, xy0, xy1, wt = table
         ok = valid[pid]
+        if self.residue_mode == 1:
+            # threshold mode: matches cut by the residue filter are masked out of the link (Link.mask, optimizer.py:399-402)
+            ok = ok & (wt > 0)
+            valid = valid & (np.bincount(pid[ok], minlength=n) > 0)
         if not ok.all():
             pid, xy0, xy1, wt = pid[ok], xy0[ok], xy1[ok], wt[ok]
             last_links = None

@@ -230,15 +230,17 @@ int fb_sys_group_energy(fb_ctx* ctx, fb_system* sys, int ngroups, const double* 
  * fb_pairs_strain : matcher.py:752-777 after the rigid fit R [P][3][3] of every pair (spatial.fit_affine, host). */
 int fb_pairs_relax(fb_ctx* ctx, fb_system* sys, int P, int nx, int ny, const double* xs, const double* ys, int64_t K, const int32_t* pid,
                    const double* xy0_moving, const double* xy1_initial, const double* t1, const float* conf, double residue_len,
-                   double sample_err, double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres);
+                   int residue_mode /* 0 huber, 1 threshold (optimizer.py:198-205) */, double sample_err, double stiffness_lambda,
+                   double rtol, float* rw, double* x_out, int* iters, double* relres);
 /* fb_pairs_relax for matches located in a DEFORMED mesh1 (a pair whose earlier relaxation was not a rigid translation;
  * Link.from_coordinates on the MOVING gear, optimizer.py:51-82 -> mesh.py:2191-2217): nodes3 [K][3] = the mesh1 vertices
  * of every match (ids inside the union mesh), B1 [K][3] its barycentric coordinates, dxy0 [K][2] = the link residual
  * with mesh1 at its FIXED gear.  x_out = TOTAL displacement from the FIXED gear (the stress term of
  * optimizer.py:1417-1418 is inside the system). */
 int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* sys, int P, int64_t K, const int32_t* nodes3, const double* B1, const double* dxy0,
-                        const float* conf, double residue_len, double sample_err, const double* sample_err_each /* [K] or NULL */,
-                        double stiffness_lambda, double rtol, float* rw, double* x_out, int* iters, double* relres);
+                        const float* conf, double residue_len, int residue_mode, double sample_err,
+                        const double* sample_err_each /* [K] or NULL */, double stiffness_lambda, double rtol, float* rw, double* x_out,
+                        int* iters, double* relres);
 /* fb_pairs_strain for pairs whose meshes share a topology but not a geometry (strips of unequal size): matches located by
  * the caller (nodes3, B1 in the INITIAL mesh of their pair), es0 [P] = v0^T K v0 of every pair's centred mesh. */
 int fb_pairs_strain_bary(fb_ctx* ctx, fb_system* sys, int P, int64_t K, const int32_t* pid, const int32_t* nodes3, const double* B1,

@@ -51,7 +51,7 @@ def locate_cartesian(xs, ys, pts):
     return 2 * (j * (nx - 1) + i) + (w > u)
 
 
-def relax_mesh1(W, H, mesh_size, t0, t1, xy0, xy1, weight, residue_len=0.0, min_num_blocks=2, return_mesh=False):
+def relax_mesh1(W, H, mesh_size, t0, t1, xy0, xy1, weight, residue_len=0.0, min_num_blocks=2, return_mesh=False, residue_mode='huber'):
     """matcher.py:717-737 with an exact solve: mesh0 (locked, translated by t0), mesh1 (free, translated by t1),
     one link from the matched points (MOVING gear).  Returns the displacement of every mesh1 vertex and, with
     residue_len > 0, the huber residue weight of every match after the relaxation (optimizer.py:174-191)."""
@@ -77,7 +77,7 @@ def relax_mesh1(W, H, mesh_size, t0, t1, xy0, xy1, weight, residue_len=0.0, min_
     if return_mesh:
         return u, m0, m1, link
     if residue_len > 0:
-        return u, link.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), 'huber', residue_len)
+        return u, link.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), residue_mode, residue_len)
     return u
 
 
@@ -241,7 +241,7 @@ def remap_origin(img, map_x, map_y, origin):
     return ((tap(iy, ix) * w00 + tap(iy, ix + 1) * w01) + tap(iy + 1, ix) * w10) + tap(iy + 1, ix + 1) * w11
 
 
-def relax_deformed(m0, m1, xs, ys, xy0, xy1, weight, residue_len, resolve):
+def relax_deformed(m0, m1, xs, ys, xy0, xy1, weight, residue_len, resolve, residue_mode='huber'):
     """matcher.py:717-742 on a mesh pair that keeps its state: link from the matched points in the MOVING gears (mesh0 is
     the translated grid, mesh1 is located through its deformed triangles; points outside are dropped, optimizer.py:
     51-82), optimize_linear (exact), then -- residue_len > 0 -- relax_higly_deformed + huber residue weights
@@ -260,7 +260,7 @@ def relax_deformed(m0, m1, xs, ys, xy0, xy1, weight, residue_len, resolve):
     if residue_len > 0:
         cutoff = 1 - 1 / (MAXIMUM_DEFORM_ALLOWED + 1)
         fem_ref.relax_mesh_most_deformed(m1, gear=(fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING), deform_cutoff=cutoff)
-        rw = link.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), 'huber', residue_len)
+        rw = link.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), residue_mode, residue_len)
         if np.any(rw != link.residue_weight):
             link.residue_weight = rw
             if resolve:
@@ -287,7 +287,7 @@ def photometric(raw0, raw1, g0, g1, tx0, ty0, mask0_g=None, mask1_g=None):
 
 
 def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
-               conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0, mask0=None, mask1=None, compute_photometric=False, spacings=None):
+               conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0, mask0=None, mask1=None, compute_photometric=False, spacings=None, residue_mode='huber'):
     """strip0/strip1: uint8 H x W overlap strips (mask0/mask1: bool, True = valid pixel).
     Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host, strain, phtm, ...)."""
     H, W = strip0.shape
@@ -361,7 +361,7 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
         if deformed is not None:
             m0, m1, xs, ys = deformed
             if max_dis > 0.1:
-                link, ok = relax_deformed(m0, m1, xs, ys, xy0, xy1, wt, residue_len, resolve=not is_last)
+                link, ok = relax_deformed(m0, m1, xs, ys, xy0, xy1, wt, residue_len, resolve=not is_last, residue_mode=residue_mode)
             else:                                            # link only (matcher.py:717), no relaxation
                 tid1 = locate_deformed(m1, xy1)
                 ok = tid1 >= 0
@@ -383,7 +383,7 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
         if is_last and max_dis > 0.1 and residue_len > 0:
             # matcher.py:725-737: relax, then Link.weight = conf * huber residue weight (no second solve: sp_indx ran out)
             _, rw = relax_mesh1(W, H, mesh_size, (tx, ty), t1, xy0, xy1, wt, residue_len=residue_len,
-                                min_num_blocks=min_num_blocks)
+                                min_num_blocks=min_num_blocks, residue_mode=residue_mode)
             last = (xy0, xy1 - t1, wt * rw, max_dis)
         if not is_last and max_dis > 0.1:
             # mesh relaxation (matcher.py:725-729), exact solve on the cartesian mesh pair
@@ -396,7 +396,7 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
                 if residue_len > 0:
                     cutoff = 1 - 1 / (MAXIMUM_DEFORM_ALLOWED + 1)
                     fem_ref.relax_mesh_most_deformed(m1, gear=(fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING), deform_cutoff=cutoff)
-                    rw = link.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), 'huber', residue_len)
+                    rw = link.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), residue_mode, residue_len)
                     if np.any(rw != link.residue_weight):
                         link.residue_weight = rw
                         fem_ref.optimize_linear([m0, m1], [link], exact=True)
@@ -405,6 +405,11 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
                 deformed = (m0, m1, xs, ys)
                 res['deformed'] = True
                 res['mesh1_field'] = m1.vertices_w_offset(fem_ref.GEAR_MOVING) - m1.vertices_w_offset(fem_ref.GEAR_INITIAL)
+    if last is not None and residue_mode == 'threshold':
+        keep_rows = np.asarray(last[2]) > 0                  # Link.mask (optimizer.py:399-402): use_mask=True at matcher.py:749-751
+        last = (last[0][keep_rows], last[1][keep_rows], last[2][keep_rows], last[3])
+        if not keep_rows.any():
+            last = None
     if last is not None:
         res['xy0'] = last[0] - np.array([tx, ty])
         res['xy1'] = last[1]

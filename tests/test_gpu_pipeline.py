@@ -673,3 +673,28 @@ def test_ragged_batch_with_deformed_meshes_matches_the_per_pair_surface(fb):
         np.testing.assert_allclose(g['xy0'], exp[0], atol=2e-4); np.testing.assert_allclose(g['xy1'], exp[1], atol=2e-4)
         np.testing.assert_allclose(g['weight'], exp[2], atol=2e-4); np.testing.assert_allclose(g['strain'], exp[3], rtol=2e-3, atol=1e-7)
     m.free(); dev.free()
+
+
+def test_stitching_matcher_threshold_residue_mode(fb):
+    """residue_mode='threshold' (matcher.py:732-733, optimizer.py:198-200): matches whose residue after the relaxation
+    exceeds residue_len are cut -- weight 0, masked out of the returned table (Link.mask) -- instead of damped.  A band of
+    strip 1 is displaced by 14 px: its blocks match confidently but inconsistently with the mesh."""
+    H, W = 1024, 256
+    s0, s1 = _warped_pair(H, W, 210, shift=(3, -2), warp=0.2)
+    s1 = s1.copy()
+    s1[470:545] = np.roll(s1[470:545], 14, axis=1)
+    for mode in ('threshold', 'huber'):
+        xy0, xy1, wt, strain, _ = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2,
+                                                               residue_mode=mode)
+        exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0, residue_mode=mode)
+        assert xy0.shape == exp['xy0'].shape
+        np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
+        np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
+        if mode == 'threshold':
+            n_thr = xy0.shape[0]
+            assert (wt > 0).all()
+            assert np.abs(xy1 - xy0 + np.array([3, -2])).max() < 6            # the displaced band is gone
+        else:
+            assert xy0.shape[0] > n_thr and wt.min() < 0.6                    # ... where huber only damps it
+    with pytest.raises(ValueError):
+        fb.matcher.stitching_matcher(s0, s1, residue_mode='none')
