@@ -140,8 +140,8 @@ def bench_fem(args, lib, ctx, _lib):
                assemble_numeric_s=t_asm, assemble_first_s=t_asm_first,
                spmv_kernel_us=1e3 * k1[1] / max(k1[0], 1), update_kernel_us=1e3 * k2[1] / max(k2[0], 1),
                spmv_kernel_gbs=spmv_bytes / max(1e-9, (k1[1] / max(k1[0], 1)) * 1e-3) / 1e9, x=x)
-    if not args.no_cpu_baseline:
-        # reported baseline: the same A, b through the oracle's Jacobi-PCG on scipy CSR, one host thread
+    if not args.no_cpu_baseline and getattr(args, '_solo', True):
+        # reported baseline (rank 0 at N = 1 only): the same A, b through the oracle's Jacobi-PCG on scipy CSR, one host thread
         # (scipy's SpMV is single threaded), a bounded number of iterations
         from feabas_amd.mesh import bsr_download
         from oracle import fem_ref
@@ -426,6 +426,7 @@ def main():
         # (SURVEY.md sec.8e), no collective on the data path; the node displacements are all-gathered afterwards
         for m in matchers.values():
             m.free()
+        args._solo = (world == 1)
         fem = bench_fem(args, lib, ctx, _lib)
         if dist is not None:
             from feabas_amd import dist as fdist
