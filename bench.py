@@ -253,11 +253,14 @@ def main():
         res = matchers[(k, (i // 2) % mper)].match(s0.offset(b * P * H * W), s1.offset(b * P * H * W))
         return k, b, res
 
-    def exchange(i, res):
-        # the one exchange of the sharded run: every rank's match table, gathered over RCCL (feabas_amd/dist.py)
-        if dist is not None:
+    def exchange(batch):
+        # the one exchange of the sharded run: every rank's match table, gathered over RCCL (feabas_amd/dist.py) -- one
+        # gather per STEP (S matcher calls), so that the ranks meet once per 512 pairs and not once per 64
+        if dist is not None and batch:
             from feabas_amd import dist as fdist
-            fdist.gather_match_table(res['pair'], res['xy0'], res['xy1'], res['weight'], pair_offset=(rank * 1000000 + i * P))
+            pid = np.concatenate([res['pair'] + (rank * 1000000 + i * P) for i, res in batch])
+            fdist.gather_match_table(pid, np.concatenate([r['xy0'] for _, r in batch]), np.concatenate([r['xy1'] for _, r in batch]),
+                                     np.concatenate([r['weight'] for _, r in batch]))
 
     # every host thread drives the device through its own context (stream): a thread's synchronisation then waits for
     # its own kernels only, and kernels of different batches may overlap on the device
@@ -282,9 +285,13 @@ def main():
             return None
         if args.host_threads <= 1:
             out = None
+            pending = []
             for i in idx:
                 out = step(i)
-                exchange(i, out[2])
+                pending.append((i, out[2]))
+                if len(pending) == S:
+                    exchange(pending); pending = []
+            exchange(pending)
             return out
         import threading
         results = {}
@@ -299,11 +306,15 @@ def main():
                     cv.notify_all()
 
         def comm():
+            pending = []
             for i in idx:
                 with cv:
                     cv.wait_for(lambda: i in results)
                     r = results[i]
-                exchange(i, r[2])
+                pending.append((i, r[2]))
+                if len(pending) == S:
+                    exchange(pending); pending = []
+            exchange(pending)
         T = nthr
         ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k], ctxs[k % len(ctxs)])) for k in range(T)]
         ths.append(threading.Thread(target=comm))
