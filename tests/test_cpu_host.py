@@ -353,3 +353,62 @@ def test_host_pack2d():
             np.testing.assert_array_equal(dst[k, :v.shape[0], :v.shape[1]], v)
             assert (dst[k, v.shape[0]:] == 255).all() and (dst[k, :, v.shape[1]:] == 255).all()
     assert _lib.load().fb_host_pack2d(None, _lib.ptr(dst), 1, 10, 10, srcs, _lib.ptr(hs), _lib.ptr(ws), _lib.ptr(pitches), 1) != 0     # does not fit
+
+
+def test_match_list_of_overlaps_bookkeeping(monkeypatch):
+    """stitcher.match_list_of_overlaps (stitcher.py:552-603) without a GPU: the strips handed to the matcher are the
+    overlap enlarged by the margin and clipped to each tile, matches come back shifted into tile coordinates, thin
+    overlaps are skipped, maskout_val becomes a dilated mask, index_mapper renames the keys"""
+    from feabas_amd import stitcher
+    TH, TW = 300, 400
+    nom = np.array([[0, 0], [360, 4], [0, 270], [372, 268]])
+    bboxes = np.concatenate((nom, nom + np.array([TW, TH])), axis=1)
+    rng = np.random.default_rng(0)
+    tiles = [rng.integers(1, 255, (TH, TW), dtype=np.uint8) for _ in range(4)]
+    tiles[1][20:30, 5:15] = 255                                   # maskout_val pixels inside an overlap
+    seen = []
+
+    def fake_batch(pairs, batch=32, threads=2, **cfg):
+        seen.append((pairs, cfg))
+        out = []
+        for img0, img1, mk0, mk1 in pairs:
+            assert img0.shape == img1.shape
+            xy = np.array([[1.0, 2.0], [3.0, 4.0]])
+            out.append((xy, xy + 0.5, np.ones(2, np.float32), 0.01, None) if img0.shape[0] > 60 or img0.shape[1] > 60 else (None, None, 0.3, None, None))
+        return out
+    monkeypatch.setattr(stitcher, 'stitching_matcher_batch', fake_batch)
+    overlaps = stitcher.find_overlaps(bboxes, tile_size=(TH, TW))
+    matches, strains, phtm, err = stitcher.match_list_of_overlaps(overlaps, tiles, bboxes, min_overlap_width=25, margin=20, maskout_val=255,
+                                                                  index_mapper={0: 'a', 1: 'b', 2: 'c', 3: 'd'}, matcher_config=dict(sigma=2.5))
+    assert not err and not phtm and seen[0][1] == dict(sigma=2.5)
+    pairs = seen[0][0]
+    # the diagonal overlap of tiles 0 and 3 is 28 x 32 px: wider than min_overlap_width, so it is matched too
+    assert len(pairs) == len(overlaps) == 6 or len(pairs) == len([1 for _ in overlaps])
+    for (i, j), bbox_pair in zip(overlaps, pairs):
+        ov, wd = stitcher.bbox_intersections(bboxes[i], bboxes[j])
+        big = ov + np.array([-20, -20, 20, 20])
+        b0 = stitcher.bbox_intersections(big, bboxes[i])[0]
+        exp0 = tiles[i][b0[1] - bboxes[i][1]:b0[3] - bboxes[i][1], b0[0] - bboxes[i][0]:b0[2] - bboxes[i][0]]
+        np.testing.assert_array_equal(bbox_pair[0], exp0)
+        if i == 1 or j == 1:
+            mk = bbox_pair[2] if i == 1 else bbox_pair[3]
+            src = bbox_pair[0] if i == 1 else bbox_pair[1]
+            if (src == 255).any():
+                assert mk is not None and not mk[src == 255].any() and mk.mean() < 1 and (~mk).sum() > (src == 255).sum()    # dilated
+    for (ki, kj), (xy0, xy1, wt) in matches.items():
+        assert ki in 'abcd' and kj in 'abcd'
+        i, j = 'abcd'.index(ki), 'abcd'.index(kj)
+        ov, _ = stitcher.bbox_intersections(bboxes[i], bboxes[j])
+        big = ov + np.array([-20, -20, 20, 20])
+        off0 = stitcher.bbox_intersections(big, bboxes[i])[0][:2] - bboxes[i][:2]
+        off1 = stitcher.bbox_intersections(big, bboxes[j])[0][:2] - bboxes[j][:2]
+        np.testing.assert_allclose(xy0, np.array([[1.0, 2.0], [3.0, 4.0]]) + off0)
+        np.testing.assert_allclose(xy1, np.array([[1.5, 2.5], [3.5, 4.5]]) + off1)
+        assert strains[(ki, kj)] == 0.01
+    assert 1 <= len(matches) <= len(pairs)
+    # a margin <= 2 is a ratio of the overlap width (stitcher.py:556-559)
+    seen.clear()
+    stitcher.match_list_of_overlaps(overlaps[:1], tiles, bboxes, min_overlap_width=25, margin=0.5, matcher_config={})
+    i, j = overlaps[0]
+    ov, wd = stitcher.bbox_intersections(bboxes[i], bboxes[j])
+    assert seen[0][0][0][0].shape[0] <= ov[3] - ov[1] + 2 * int(0.5 * wd) and min(seen[0][0][0][0].shape) >= wd
