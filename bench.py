@@ -32,8 +32,8 @@ RESIDUE_LEN = 2.0              # configs/default_stitching_configs.yaml:15 (matc
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=16)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=48)
+    ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--pairs-per-step', type=int, default=512, help='tile pairs per step = one batch of the hot path; processed as sub-batches of --sub-batch pairs dealt to the host threads')
     ap.add_argument('--sub-batch', type=int, default=64, help='pairs per StripBatchMatcher call')
     ap.add_argument('--resident-pairs', type=int, default=1024)
