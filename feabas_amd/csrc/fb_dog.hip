@@ -214,23 +214,24 @@ constexpr int FT = 64;     // output tile
 
 __host__ __device__ constexpr int pitch_for(int cols) { int p = (cols + 3) / 4 * 4; return (p / 4) % 2 ? p : p + 4; }
 __host__ __device__ constexpr int up8(int v) { return (v + RUN - 1) / RUN * RUN; }
+__host__ __device__ constexpr int upn(int v, int n) { return (v + n - 1) / n * n; }
 
 template <int R>
 struct FastGeom {
     static constexpr int HAL = 2 * R;
     static constexpr int AH = FT + 2 * HAL, AW = FT + 2 * HAL;      // stage-0 tile
     static constexpr int BW = AW - 2 * R, GH = AH - 2 * R;           // after row pass / after column pass
-    static constexpr int PA = pitch_for(up8(BW) + 2 * R);            // row-pass overread stays inside the row
+    static constexpr int PA = pitch_for((upn(BW, 12) > up8(BW) ? upn(BW, 12) : up8(BW)) + 2 * R);      // row-pass overread stays inside the row
     static constexpr int PB = pitch_for(BW);
     static constexpr int PD = pitch_for(FT);
     static constexpr int SZ_A = (AH * PA > GH * PB ? AH * PA : GH * PB);
     static constexpr int SZ_B = (AH * PB > GH * PD ? AH * PB : GH * PD);
 };
 
-template <int R>
-__device__ __forceinline__ void fir_run(const float (&in)[RUN + 2 * R], const TapsF& t, float (&out)[RUN]) {
+template <int R, int RN>
+__device__ __forceinline__ void fir_run(const float (&in)[RN + 2 * R], const TapsF& t, float (&out)[RN]) {
 #pragma unroll
-    for (int j = 0; j < RUN; ++j) {
+    for (int j = 0; j < RN; ++j) {
         float acc = in[j + R] * t.w[0];
 #pragma unroll
         for (int k = R; k >= 1; --k) acc = fmaf(in[j + R - k] + in[j + R + k], t.w[k], acc);
@@ -238,53 +239,62 @@ __device__ __forceinline__ void fir_run(const float (&in)[RUN + 2 * R], const Ta
     }
 }
 
+// Run lengths per pass.  One pass is one or two sweeps of the 1024 threads over its items, and every wave waits at the
+// barrier for the slowest: the items of a pass should fill ONE sweep as evenly as possible.  At the 64 x 64 tile with
+// R = 10: pass 1 (104 rows x 84 cols) 7 runs of 12 = 728 items, pass 2 (84 x 84) 12 runs of 7 = 1008 items, pass 3
+// (84 x 64) 8 runs of 8 = 672 items, pass 4 (64 x 64) 16 runs of 4 = 1024 items -- 12 + 7 + 8 + 4 = 31 outputs on the
+// critical path of a tile instead of 16 + 8 + 8 + 8 = 40 with runs of 8 everywhere (pass 1 needed a second sweep for
+// 120 of its 1144 items).  Row passes keep run lengths that are multiples of 4 (16-byte aligned ds_read_b128).
+constexpr int RUN1 = 12, RUN2 = 7, RUN3 = 8, RUN4 = 4;
+
 // rows x ncols_out outputs; src/dst are LDS arrays with pitches ps/pd; output col c reads src cols [c, c+2R]
-template <int R>
+template <int R, int RN>
 __device__ __forceinline__ void row_pass(const float* __restrict__ src, int ps, float* __restrict__ dst, int pd, int rows,
                                          int ncols_out, const TapsF& t) {
-    const int nruns = (ncols_out + RUN - 1) / RUN;
+    static_assert(RN % 4 == 0, "row runs are read and written as float4");
+    const int nruns = (ncols_out + RN - 1) / RN;
     for (int item = threadIdx.x; item < rows * nruns; item += blockDim.x) {
         const int run = item / rows, row = item - run * rows;       // lanes walk rows
-        float in[RUN + 2 * R], o[RUN];
+        float in[RN + 2 * R], o[RN];
         // 16-byte aligned by construction (pitches and run offsets are multiples of 4 floats): ds_read_b128
-        const float4* p4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(src, 16)) + ((row * ps + run * RUN) >> 2);
-        const float* p = src + row * ps + run * RUN;
+        const float4* p4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(src, 16)) + ((row * ps + run * RN) >> 2);
+        const float* p = src + row * ps + run * RN;
 #pragma unroll
-        for (int q = 0; q < (RUN + 2 * R) / 4; ++q) {
+        for (int q = 0; q < (RN + 2 * R) / 4; ++q) {
             const float4 v = p4[q];
             in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
         }
 #pragma unroll
-        for (int q = (RUN + 2 * R) / 4 * 4; q < RUN + 2 * R; ++q) in[q] = p[q];
-        fir_run<R>(in, t, o);
-        float* d = dst + row * pd + run * RUN;
-        if (run * RUN + RUN <= ncols_out) {
-            *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<float4*>(d + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        for (int q = (RN + 2 * R) / 4 * 4; q < RN + 2 * R; ++q) in[q] = p[q];
+        fir_run<R, RN>(in, t, o);
+        float* d = dst + row * pd + run * RN;
+        if (run * RN + RN <= ncols_out) {
+#pragma unroll
+            for (int q = 0; q < RN / 4; ++q) *reinterpret_cast<float4*>(d + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
         } else {
 #pragma unroll
-            for (int j = 0; j < RUN; ++j)
-                if (run * RUN + j < ncols_out) d[j] = o[j];
+            for (int j = 0; j < RN; ++j)
+                if (run * RN + j < ncols_out) d[j] = o[j];
         }
     }
 }
 
 // nrows_out x cols outputs; output row y reads src rows [y, y+2R]
-template <int R>
+template <int R, int RN>
 __device__ __forceinline__ void col_pass(const float* __restrict__ src, int ps, int src_rows, float* __restrict__ dst, int pd,
                                          int nrows_out, int cols, const TapsF& t) {
-    const int nruns = (nrows_out + RUN - 1) / RUN;
+    const int nruns = (nrows_out + RN - 1) / RN;
     for (int item = threadIdx.x; item < cols * nruns; item += blockDim.x) {
         const int run = item / cols, c = item - run * cols;         // lanes walk columns
-        float in[RUN + 2 * R], o[RUN];
+        float in[RN + 2 * R], o[RN];
         const float* p = src + c;
 #pragma unroll
-        for (int q = 0; q < RUN + 2 * R; ++q) in[q] = p[min(run * RUN + q, src_rows - 1) * ps];
-        fir_run<R>(in, t, o);
-        float* d = dst + (run * RUN) * pd + c;
+        for (int q = 0; q < RN + 2 * R; ++q) in[q] = p[min(run * RN + q, src_rows - 1) * ps];
+        fir_run<R, RN>(in, t, o);
+        float* d = dst + (run * RN) * pd + c;
 #pragma unroll
-        for (int j = 0; j < RUN; ++j)
-            if (run * RUN + j < nrows_out) d[j * pd] = o[j];
+        for (int j = 0; j < RN; ++j)
+            if (run * RN + j < nrows_out) d[j * pd] = o[j];
     }
 }
 
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, floa
     }
     __syncthreads();
     // stage 1: rows A -> B (AH x BW); B col tx <-> global x = x0 - R + tx
-    row_pass<R>(bufA, G::PA, bufB, G::PB, G::AH, G::BW, taps);
+    row_pass<R, RUN1>(bufA, G::PA, bufB, G::PB, G::AH, G::BW, taps);
     __syncthreads();
     {   // replicate the image-border columns
         const int cl = -(x0 - R), cr = (W - 1) - (x0 - R);          // B columns of global x = 0 and x = W-1
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, floa
         }
     }
     // stage 2: columns B -> G0 (GH x BW) in bufA (pitch PB); G0 row ty <-> global y = y0 - R + ty
-    col_pass<R>(bufB, G::PB, G::AH, bufA, G::PB, G::GH, G::BW, taps);
+    col_pass<R, RUN2>(bufB, G::PB, G::AH, bufA, G::PB, G::GH, G::BW, taps);
     __syncthreads();
     {   // replicate the image-border rows
         const int rt = -(y0 - R), rb = (H - 1) - (y0 - R);
@@ -368,27 +378,27 @@ __global__ __launch_bounds__(1024) void dog_fast(const T* __restrict__ img, floa
         }
     }
     // stage 3: rows G0 -> D (GH x FT) in bufB (pitch PD); D col tx <-> global x = x0 + tx
-    row_pass<R>(bufA, G::PB, bufB, G::PD, G::GH, FT, taps);
+    row_pass<R, RUN3>(bufA, G::PB, bufB, G::PD, G::GH, FT, taps);
     __syncthreads();
     // stage 4: columns D -> G1 (FT x FT); out = G0 - G1
     {
-        const int nruns = FT / RUN;
+        const int nruns = FT / RUN4;
         for (int item = tid; item < FT * nruns; item += nt) {
             const int run = item / FT, c = item - run * FT;
-            float in[RUN + 2 * R], o[RUN];
-            const float* p = bufB + (run * RUN) * G::PD + c;
+            float in[RUN4 + 2 * R], o[RUN4];
+            const float* p = bufB + (run * RUN4) * G::PD + c;
 #pragma unroll
-            for (int q = 0; q < RUN + 2 * R; ++q) in[q] = p[q * G::PD];
-            fir_run<R>(in, taps, o);
+            for (int q = 0; q < RUN4 + 2 * R; ++q) in[q] = p[q * G::PD];
+            fir_run<R, RUN4>(in, taps, o);
             const int gx = x0 + c;
             if (gx >= SW) continue;
             float* __restrict__ oimg = out + (size_t)n * SH * SW;                 // uniform base, 32-bit offsets below
-            const uint32_t off0 = (uint32_t)((y0 + run * RUN) * SW + gx);
-            const int jmax = min(RUN, SH - (y0 + run * RUN)), jin = gx < W ? H - (y0 + run * RUN) : 0;
+            const uint32_t off0 = (uint32_t)((y0 + run * RUN4) * SW + gx);
+            const int jmax = min(RUN4, SH - (y0 + run * RUN4)), jin = gx < W ? H - (y0 + run * RUN4) : 0;
 #pragma unroll
-            for (int j = 0; j < RUN; ++j) {
+            for (int j = 0; j < RUN4; ++j) {
                 if (j >= jmax) break;
-                const int ty = run * RUN + j;
+                const int ty = run * RUN4 + j;
                 float v = bufA[(ty + R) * G::PB + (c + R)] - o[j];
                 if (!signed_out) v = fabsf(v);
                 oimg[off0 + (uint32_t)(j * SW)] = j < jin ? v : 0.f;                  // slot pixels outside the image: 0
