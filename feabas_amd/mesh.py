@@ -169,6 +169,16 @@ class Mesh:
         return Mesh(self._vertices[const.MESH_GEAR_INITIAL], self.triangles, **kw)
 
     # ------------------------------------------------------------------ transformations
+    def save_to_h5(self, fname, vertex_flags=None, **kwargs):    # mesh.py:822-857 (layout: feabas_amd/h5wire.py)
+        from . import h5wire
+        h5wire.save_mesh_h5(self, fname, prefix=kwargs.get('prefix', ''), vertex_flags=vertex_flags,
+                            save_material=kwargs.get('save_material', True), compression=kwargs.get('compression', True))
+
+    @classmethod
+    def from_h5(cls, fname, prefix='', **kwargs):                # mesh.py:798-819
+        from . import h5wire
+        return h5wire.load_mesh_h5(fname, prefix=prefix, cls=cls, **kwargs)
+
     def _changed(self, gear):
         self._trifinders.pop(gear, None)
 

@@ -1,0 +1,186 @@
+"""HDF5 wire formats (feabas_amd/h5wire.py): the layouts of stitcher.py:126-222, aligner.py:26-44 / 134-141 and
+mesh.py:543-580 / 798-857 written through libhdf5 and read back -- by the module itself, by the reference's reader
+arithmetic restated here, and by the h5dump tool of the HDF5 distribution as an independent decoder."""
+import json
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from feabas_amd import constant as const
+from feabas_amd import h5wire
+from feabas_amd.mesh import Mesh
+
+
+def _h5dump():
+    lib = h5wire.library()
+    cand = os.path.join(os.path.dirname(os.path.dirname(lib.path)), 'bin', 'h5dump')
+    return cand if os.path.exists(cand) else shutil.which('h5dump')
+
+
+def _dump(args):
+    tool = _h5dump()
+    if tool is None:
+        pytest.skip('no h5dump beside libhdf5')
+    return subprocess.run([tool] + args, capture_output=True, text=True, check=True).stdout
+
+
+def _matches(rng, pairs):
+    m, s = {}, {}
+    for k, uid in enumerate(pairs):
+        n = 3 + 5 * k
+        m[uid] = (rng.random((n, 2)) * 100, rng.random((n, 2)) * 100, rng.random(n))
+        s[uid] = 0.01 * (k + 1)
+    return m, s
+
+
+def test_library_and_types(tmp_path):
+    lib = h5wire.library()
+    assert lib.version >= (1, 10, 0) and lib.has_gzip
+    fn = str(tmp_path / 't.h5')
+    data = {'u8': np.arange(5, dtype=np.uint8), 'i16': np.array([[-3, 4]], dtype=np.int16), 'i32': np.arange(6, dtype=np.int32).reshape(2, 3),
+            'i64': np.array([2 ** 40, -1]), 'f32': np.linspace(0, 1, 7, dtype=np.float32), 'f64': np.pi, 'flag': True,
+            'flags': np.array([True, False, True]), 'count': 7, 'empty': np.empty((0, 2)), 'be': np.arange(4, dtype='>f4')}
+    with h5wire.H5File(fn, 'w') as f:
+        for k, v in data.items():
+            f.create_dataset('grp/sub/' + k, v, compression='gzip' if np.ndim(v) else None)
+        with pytest.raises(h5wire.H5Error):
+            f.create_dataset('grp/sub/u8', data['u8'])                 # exists
+        with pytest.raises(TypeError):
+            f.create_dataset('c', np.zeros(2, dtype=np.complex64))
+    with h5wire.H5File(fn) as f:
+        assert 'grp/sub/u8' in f and 'grp/nope/u8' not in f and 'grp' in f and f.is_group('grp/sub')
+        assert f.keys('grp/sub') == sorted(data)
+        for k, v in data.items():
+            got = f['grp/sub/' + k]
+            want = np.asarray(v)
+            assert np.shape(got) == want.shape, k
+            assert np.asarray(got).dtype == want.dtype.newbyteorder('='), k
+            np.testing.assert_array_equal(got, want)
+        assert f.storage('grp/sub/i32') == (True, 1) and f.storage('grp/sub/f64') == (False, 0)
+        assert f.storage('grp/sub/empty') == (False, 0)
+        with pytest.raises(KeyError):
+            f['grp/sub/none']
+    with pytest.raises(h5wire.H5Error):
+        h5wire.H5File(str(tmp_path / 'missing.h5'))
+    head = _dump(['-H', fn])
+    assert 'H5T_ENUM' in head and '"FALSE"' in head and 'H5T_STD_I16LE' in head and 'H5T_IEEE_F32LE' in head
+
+
+def test_stitcher_file_round_trip_and_independent_decode(tmp_path):
+    rng = np.random.default_rng(3)
+    names = [f'row{k // 4}/tile{k % 4}.png' for k in range(12)]
+    bboxes = rng.integers(0, 5000, (12, 4))
+    m, s = _matches(rng, [(1, 0), (5, 4), (10, 2), (11, 10)])
+    bc = {(1, 0): np.array([1.0, 2.0, 3.0, 4.0]), (5, 4): np.array([0.5, 0.25, 8.0, 9.0])}
+    fn = str(tmp_path / 'sec.h5')
+    h5wire.save_stitcher_h5(fn, '/data/sec001', 4.0, names, bboxes, m, s, bc)
+    m2, s2, bc2 = h5wire.load_stitcher_matches(fn)
+    assert list(m2) == sorted(m, key=lambda u: f'{u[0]}_{u[1]}')             # name order, like iterating the h5py group
+    for uid in m:
+        for a, b in zip(m[uid], m2[uid]):
+            np.testing.assert_array_equal(np.asarray(a, np.float32), b)
+        assert s2[uid] == np.float32(s[uid])
+        if uid in bc:
+            np.testing.assert_array_equal(bc[uid], bc2[uid])
+    with h5wire.H5File(fn) as f:
+        assert h5wire.numpy_to_str_ascii(f['imgrootdir']) == '/data/sec001' and f['resolution'] == 4.0
+        assert h5wire.numpy_to_str_ascii(f['imgrelpaths']).split('\n') == names
+        np.testing.assert_array_equal(f['init_bboxes'], bboxes)
+        assert f.storage('matches/1_0') == (True, 1) and f.storage('imgrootdir') == (False, 0)
+    # independent decoder: the raw record of one pair, split with the reader arithmetic of stitcher.py:200-207
+    txt = _dump(['-d', '/matches/10_2', '-y', '-w', '0', '-m', '%.9g', fn])
+    body = txt[txt.index('DATA {') + 6:txt.rindex('}')]
+    vals = np.array([float(v) for v in re.findall(r'[-+0-9.eE]+', body.split('}')[0])], dtype=np.float32)
+    npt = int((vals.size - 1) / 5)
+    xy0, xy1, w = m[(10, 2)]
+    assert npt == len(w)
+    np.testing.assert_allclose(vals[:2 * npt].reshape(-1, 2), xy0, rtol=2e-6)
+    np.testing.assert_allclose(vals[2 * npt:4 * npt].reshape(-1, 2), xy1, rtol=2e-6)
+    np.testing.assert_allclose(vals[4 * npt:5 * npt], w, rtol=2e-6)
+    assert abs(vals[-1] - s[(10, 2)]) < 1e-7
+    head = _dump(['-H', '-p', fn])
+    assert 'COMPRESSION DEFLATE { LEVEL 4 }' in head and 'GROUP "matches"' in head
+
+
+def test_stitcher_file_check_order(tmp_path):
+    rng = np.random.default_rng(4)
+    names = ['a.png', 'b.png', 'c.png', 'd.png']
+    m, s = _matches(rng, [(1, 0), (2, 1), (3, 2)])
+    fn = str(tmp_path / 'sec.h5')
+    h5wire.save_stitcher_h5(fn, '', 8.0, names, np.zeros((4, 4), dtype=np.int64), m, s, {(2, 1): np.ones(4)}, compression=False)
+    mine = ['d.png', 'c.png', 'b.png']                       # another order, one tile unknown to the caller
+    m2, s2, bc2 = h5wire.load_stitcher_matches(fn, imgrelpaths=mine)
+    assert set(m2) == {(1, 2), (0, 1)} and set(bc2) == {(1, 2)}
+    np.testing.assert_array_equal(m2[(1, 2)][2], np.asarray(m[(2, 1)][2], np.float32))
+    with h5wire.H5File(fn) as f:
+        assert f.storage('matches/1_0') == (False, 0)
+    empty = str(tmp_path / 'none.h5')
+    h5wire.save_stitcher_h5(empty, '', 8.0, names, np.zeros((4, 4), dtype=np.int64))
+    assert h5wire.load_stitcher_matches(empty) == ({}, {}, {})
+
+
+def test_section_match_file(tmp_path):
+    rng = np.random.default_rng(5)
+    xy0, xy1, w = rng.random((40, 2)) * 1000, rng.random((40, 2)) * 1000, rng.random(40)
+    fn = str(tmp_path / 's0_s1.h5')
+    h5wire.save_section_match_h5(fn, xy0, xy1, w, 16.0, 0.03, 'sec0', 'sec1')
+    a, b, c, strain = h5wire.read_matches_from_h5(fn)
+    np.testing.assert_array_equal(a, xy0); np.testing.assert_array_equal(b, xy1); np.testing.assert_array_equal(c, w)
+    assert strain == 0.03
+    a4, b4, _, _ = h5wire.read_matches_from_h5(fn, target_resolution=4.0)                # spatial.py:77-86
+    np.testing.assert_allclose(a4, (xy0 + 0.5) * 4 - 0.5)
+    np.testing.assert_allclose(b4, (xy1 + 0.5) * 4 - 0.5)
+    with h5wire.H5File(fn) as f:
+        assert f.keys() == ['name0', 'name1', 'resolution', 'strain', 'weight', 'xy0', 'xy1']
+        assert h5wire.numpy_to_str_ascii(f['name1']) == 'sec1' and np.ndim(f['strain']) == 0
+
+
+def test_mesh_file_round_trip(tmp_path):
+    rng = np.random.default_rng(6)
+    M = Mesh.from_bbox((0, 0, 200, 120), cartesian=True, mesh_size=25, resolution=8.0, soft_factor=0.5, uid=17)
+    nt = M.num_triangles
+    M = Mesh(M.vertices(const.MESH_GEAR_INITIAL), M.triangles, resolution=8.0, soft_factor=0.5, uid=17, locked=True,
+             initial_offset=np.array([[10.0, -4.0]]), stiffness_multiplier=rng.random(nt) + 0.5,
+             tri_model=(np.arange(nt) % 3 == 0).astype(np.int32) * 2, tri_nu=np.where(np.arange(nt) % 3 == 0, 0.3, 0.0),
+             tri_matmult=np.where(np.arange(nt) % 3 == 0, 0.1, 1.0))
+    M.locked = False
+    M.set_vertices(M.vertices(const.MESH_GEAR_INITIAL) + rng.normal(0, 1, (M.num_vertices, 2)), const.MESH_GEAR_MOVING)
+    M.set_offset(np.array([[3.0, 5.0]]), const.MESH_GEAR_MOVING)
+    M.locked = True
+    M.name = 'sec0_tile3'
+    fn = str(tmp_path / 'mesh.h5')
+    M.save_to_h5(fn)
+    with h5wire.H5File(fn) as f:
+        keys = f.keys()
+        assert {'vertices', 'triangles', 'initial_offset', 'moving_vertices', 'moving_offset', 'stiffness_multiplier', 'material_ids',
+                'material_table', 'resolution', 'epsilon', 'name', 'locked', 'uid', 'soft_factor'} == set(keys)
+        assert 'fixed_vertices' not in keys                 # the fixed gear aliases the initial one: not saved, mesh.py:553-559
+        table = json.loads(h5wire.numpy_to_str_ascii(f['material_table']))
+        assert table['default']['uid'] == 0 and table['default']['type'] == 'MATERIAL_MODEL_ENG'
+        assert sorted(m['type'] for m in table.values()) == ['MATERIAL_MODEL_ENG', 'MATERIAL_MODEL_NHK']
+        assert f['locked'] is np.True_ or f['locked'] == True           # noqa: E712
+        assert f.storage('vertices') == (True, 1) and f.storage('uid') == (False, 0)
+    N = Mesh.from_h5(fn)
+    for g in (const.MESH_GEAR_INITIAL, const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING):
+        np.testing.assert_array_equal(N.vertices(g), M.vertices(g))
+        np.testing.assert_array_equal(N.offset(g), M.offset(g))
+    np.testing.assert_array_equal(N.triangles, M.triangles)
+    np.testing.assert_array_equal(N.tri_model, M.tri_model)
+    np.testing.assert_array_equal(N.tri_nu, M.tri_nu)
+    np.testing.assert_array_equal(N.tri_matmult, M.tri_matmult)
+    np.testing.assert_array_equal(N._stiffness_multiplier, M._stiffness_multiplier)
+    assert (N.resolution, N.soft_factor, N.uid, N.locked, N.name) == (8.0, 0.5, 17.0, True, 'sec0_tile3')
+    # several meshes under prefixes of one file, as the Stitcher file keeps them (stitcher.py:158-163)
+    fn2 = str(tmp_path / 'many.h5')
+    plain = Mesh.from_bbox((0, 0, 50, 50), cartesian=True, mesh_size=25)
+    with h5wire.H5File(fn2, 'w') as f:
+        plain.save_to_h5(f, vertex_flags=(const.MESH_GEAR_INITIAL,), prefix='master_meshes/0', save_material=False)
+        M.save_to_h5(f, prefix='master_meshes/1')
+    with h5wire.H5File(fn2) as f:
+        assert f.keys('master_meshes') == ['0', '1'] and 'master_meshes/0/material_ids' not in f
+        P = Mesh.from_h5(f, prefix='master_meshes/0')
+    assert P.tri_model is None and P.num_triangles == plain.num_triangles
