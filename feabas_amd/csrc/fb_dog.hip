@@ -41,7 +41,8 @@ __device__ __forceinline__ float fir_sym(const float* s, int base, int st, int r
 // CLAMPED global coordinate, which is exactly scipy's 'nearest' extension of that stage.
 template <typename T, int NPASS>
 __global__ void dog_tile(const T* __restrict__ img, float* __restrict__ out, const float* __restrict__ halo,
-                         int H, int W, int r, int TY, int TX, int signed_out, float in_scale, const uint8_t* __restrict__ mask, const Taps taps) {
+                         int H, int W, int r, int TY, int TX, int signed_out, float in_scale, const uint8_t* __restrict__ mask, const Taps taps,
+                         size_t per_image) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = blockIdx.z;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
@@ -51,6 +52,9 @@ __global__ void dog_tile(const T* __restrict__ img, float* __restrict__ out, con
     float* bufB = smem + AH * AW;                       // AH x (AW-2r), later (TY+2r|TY) x TX
     const T* src = img + (size_t)n * H * W;
     const int tid = threadIdx.x, nt = blockDim.x;
+    // per_image = H W: every image has its own mask / halo plane (the N x H x W masks of MeshRenderer.crop_multiple); 0: one shared plane
+    if (mask) mask += (size_t)n * per_image;
+    if (halo) halo += (size_t)n * per_image;
 
     // stage 0: load (clamped) input tile.  With a mask, the input is ptp*(mask==0) (common.py:369)
     for (int i = tid; i < AH * AW; i += nt) {
@@ -439,7 +443,7 @@ int launch_fast_any(fb_ctx* ctx, int r, const T* img, float* out, int N, int H, 
 
 template <typename T, int NPASS>
 int launch_tile(fb_ctx* ctx, const T* img, float* out, const float* halo, int N, int H, int W, int r, int signed_out,
-                float in_scale, const uint8_t* mask, const Taps& taps) {
+                float in_scale, const uint8_t* mask, const Taps& taps, size_t per_image = 0) {
     // largest square tile whose two LDS buffers fit in 64 KiB (2 workgroups per CU) or, failing that, 150 KiB
     const int hal = (NPASS == 4) ? 2 * r : r;
     int T_ = 64;
@@ -450,13 +454,14 @@ int launch_tile(fb_ctx* ctx, const T* img, float* out, const float* halo, int N,
     auto kern = dog_tile<T, NPASS>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(fb_cdiv(W, T_), fb_cdiv(H, T_), N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img, out, halo, H, W, r, T_, T_, signed_out, in_scale, mask, taps);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img, out, halo, H, W, r, T_, T_, signed_out, in_scale, mask, taps, per_image);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
 
 template <typename T>
-int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, const uint8_t* mask, int signed_out, float* out) {
+int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, const uint8_t* mask, int signed_out, float* out,
+              bool mask_per_image = false) {
     int rc, r = 0;
     Taps taps;
     float* halo = nullptr;
@@ -465,7 +470,8 @@ int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, cons
         int* flag = nullptr;
         FB_HIP(ctx, hipMalloc(&flag, sizeof(int)));
         FB_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(any_zero_kernel, dim3(256), dim3(256), 0, ctx->stream, mask, (size_t)H * W, flag);
+        const size_t nmask = mask_per_image ? (size_t)N : 1, per_image = mask_per_image ? (size_t)H * W : 0;
+        hipLaunchKernelGGL(any_zero_kernel, dim3(256), dim3(256), 0, ctx->stream, mask, nmask * H * W, flag);
         int hflag = 0;
         FB_HIP(ctx, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -486,8 +492,8 @@ int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, cons
             const double sc = std::sqrt(2.0 * sigma * sigma);
             rc = set_taps(ctx, sc, &r, &taps);
             if (rc) return rc;
-            FB_HIP(ctx, hipMalloc(&halo, sizeof(float) * (size_t)H * W));
-            rc = launch_tile<T, 2>(ctx, (const T*)nullptr, halo, nullptr, 1, H, W, r, 1, ptp, mask, taps);
+            FB_HIP(ctx, hipMalloc(&halo, sizeof(float) * nmask * H * W));
+            rc = launch_tile<T, 2>(ctx, (const T*)nullptr, halo, nullptr, (int)nmask, H, W, r, 1, ptp, mask, taps, per_image);
             if (rc) { hipFree(halo); return rc; }
         }
     }
@@ -500,7 +506,7 @@ int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, cons
         }
         if (!rc && !done) {
             FB_PROF_B(ctx, "dog_tile", (double)N * H * W * (sizeof(T) + 4.0));
-            rc = launch_tile<T, 4>(ctx, img, out, halo, N, H, W, r, signed_out, 0.f, nullptr, taps);
+            rc = launch_tile<T, 4>(ctx, img, out, halo, N, H, W, r, signed_out, 0.f, nullptr, taps, (halo && mask_per_image) ? (size_t)H * W : 0);
         }
     }
     if (halo) {
@@ -524,6 +530,21 @@ int fb_dog_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, dou
     FB_HIP(ctx, hipSetDevice(ctx->device));
     if (dtype == FB_U8) return dog_dev_t<uint8_t>(ctx, (const uint8_t*)img, N, H, W, sigma, mask, signed_out, out);
     return dog_dev_t<float>(ctx, (const float*)img, N, H, W, sigma, mask, signed_out, out);
+}
+
+// common.masked_dog_filter(stack, sigma, mask=masks) with one mask per image (masks [N][H][W]): what
+// MeshRenderer.crop_multiple(log_sigma=sigma) applies to its N x h x w stack (renderer.py:632-641); np.ptp runs over the
+// whole stack, as there.
+int fb_dog_masks_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* masks,
+                     int signed_out, float* out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && sigma > 0);
+    FB_CHECK_ARG(ctx, dtype == FB_U8 || dtype == FB_F32);
+    if (N == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, img && out && masks);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    if (dtype == FB_U8) return dog_dev_t<uint8_t>(ctx, (const uint8_t*)img, N, H, W, sigma, masks, signed_out, out, true);
+    return dog_dev_t<float>(ctx, (const float*)img, N, H, W, sigma, masks, signed_out, out, true);
 }
 
 // DoG of N images of unequal size that share a padded stack: image n is the sizes[n] = {h, w} corner of its H x W slot

@@ -1,0 +1,236 @@
+// MeshRenderer for the block matcher of general (triangulated) meshes: the piecewise-linear MOVING -> image field of
+// MeshRenderer.from_mesh (feabas/renderer.py:47-166), crop_field (453-563) and the sampling of crop_multiple (601-631)
+// -> common.render_by_subregions -> cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) (common.py:218-350), for one region
+// without collisions.  The image, the vertices and every intermediate stay in HBM:
+//   mesh_cand_kernel   one workgroup per block: the triangles whose box meets the block's box (bbox - 0.5, the query box
+//                      of renderer.py:405) -> a capped list per block;
+//   mesh_field_kernel  one workgroup per 16 x 16 pixel tile of a block: candidates of the tile staged in LDS with their
+//                      barycentric / image coefficients, every pixel keeps the hit of the smallest triangle index
+//                      (deterministic for pixels on shared edges).  PASS 0 reduces floor(min) / ceil(max) of the field
+//                      (the remap origin of common.py:316-321), PASS 1 samples.
+#include <climits>
+
+#include "fb_common.h"
+
+namespace {
+
+constexpr int TILE = 16;             // 256 threads = one pixel each
+constexpr int CHUNK = 128;           // candidates staged per sweep
+constexpr int REC = 14;              // doubles per staged candidate
+constexpr double BARY_EPS = 1e-9;
+constexpr int MX_DIS = 16300;        // common.py:264: extent one remap call may cover
+
+__global__ void mesh_cand_kernel(int T, const double* __restrict__ vm, const int* __restrict__ tris, const double* __restrict__ org,
+                                 int h, int w, int cap, int* __restrict__ cand, int* __restrict__ count) {
+    const int b = blockIdx.x;
+    __shared__ int n_hit;
+    if (threadIdx.x == 0) n_hit = 0;
+    __syncthreads();
+    const double bx0 = org[2 * b] - 0.5, by0 = org[2 * b + 1] - 0.5, bx1 = bx0 + (double)w, by1 = by0 + (double)h;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
+        const double x0 = vm[2 * i0], y0 = vm[2 * i0 + 1], x1 = vm[2 * i1], y1 = vm[2 * i1 + 1], x2 = vm[2 * i2], y2 = vm[2 * i2 + 1];
+        const double lx = fmin(x0, fmin(x1, x2)), hx = fmax(x0, fmax(x1, x2));
+        const double ly = fmin(y0, fmin(y1, y2)), hy = fmax(y0, fmax(y1, y2));
+        if (hx < bx0 || lx > bx1 || hy < by0 || ly > by1) continue;
+        const int k = atomicAdd(&n_hit, 1);
+        if (k < cap) cand[(size_t)b * cap + k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) count[b] = n_hit;
+}
+
+struct RenderArgs {
+    const void* img; int dtype, IH, IW, img_x0, img_y0;
+    const double* vm; const double* vi; const int* tris;
+    const double* org; int h, w;
+    const int* tier; const double* A6;
+    int cap; const int* cand; const int* count;
+    int* ext;            // [NB][4]: floor(min x), floor(min y), ceil(max x), ceil(max y) of the masked field
+    const int* origin;   // [NB][2]
+    float* out; uint8_t* mask;
+};
+
+// cv2.remap, CV_8U bilinear: fixed-point table of 1/32-px phases scaled by 2^15 (BilinearTab_i), saturate_cast<short>
+// turns the unit weight 32768 into 32767 and the table's sum fix-up adds the missing 1 to the last tap
+__device__ __forceinline__ float sample_u8(const uint8_t* __restrict__ img, int IH, int IW, int ix, int iy, int a, int b) {
+    int w00 = (32 - a) * (32 - b) * 32, w01 = a * (32 - b) * 32, w10 = (32 - a) * b * 32, w11 = a * b * 32;
+    if ((a | b) == 0) { w00 = 32767; w11 = 1; }
+    const bool x0ok = ix >= 0 && ix < IW, x1ok = ix + 1 >= 0 && ix + 1 < IW, y0ok = iy >= 0 && iy < IH, y1ok = iy + 1 >= 0 && iy + 1 < IH;
+    const int cx0 = min(max(ix, 0), IW - 1), cx1 = min(max(ix + 1, 0), IW - 1), cy0 = min(max(iy, 0), IH - 1), cy1 = min(max(iy + 1, 0), IH - 1);
+    const int v00 = (y0ok && x0ok) ? img[(size_t)cy0 * IW + cx0] : 0, v01 = (y0ok && x1ok) ? img[(size_t)cy0 * IW + cx1] : 0;
+    const int v10 = (y1ok && x0ok) ? img[(size_t)cy1 * IW + cx0] : 0, v11 = (y1ok && x1ok) ? img[(size_t)cy1 * IW + cx1] : 0;
+    const int s = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+    return (float)min(max(s, 0), 255);
+}
+
+__device__ __forceinline__ float sample_f32(const float* __restrict__ img, int IH, int IW, int ix, int iy, int a, int b) {
+#pragma clang fp contract(off)
+    const float ax = (float)a * (1.0f / 32.0f), ay = (float)b * (1.0f / 32.0f);
+    const float w00 = (1.0f - ay) * (1.0f - ax), w01 = (1.0f - ay) * ax, w10 = ay * (1.0f - ax), w11 = ay * ax;
+    const bool x0ok = ix >= 0 && ix < IW, x1ok = ix + 1 >= 0 && ix + 1 < IW, y0ok = iy >= 0 && iy < IH, y1ok = iy + 1 >= 0 && iy + 1 < IH;
+    const int cx0 = min(max(ix, 0), IW - 1), cx1 = min(max(ix + 1, 0), IW - 1), cy0 = min(max(iy, 0), IH - 1), cy1 = min(max(iy + 1, 0), IH - 1);
+    const float v00 = img[(size_t)cy0 * IW + cx0], v01 = img[(size_t)cy0 * IW + cx1];
+    const float v10 = img[(size_t)cy1 * IW + cx0], v11 = img[(size_t)cy1 * IW + cx1];
+    return ((((y0ok && x0ok) ? v00 : 0.f) * w00 + ((y0ok && x1ok) ? v01 : 0.f) * w01) + ((y1ok && x0ok) ? v10 : 0.f) * w10) + ((y1ok && x1ok) ? v11 : 0.f) * w11;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(TILE* TILE) void mesh_field_kernel(const RenderArgs g) {
+#pragma clang fp contract(off)
+    __shared__ double rec[CHUNK * REC];
+    __shared__ int rec_tid[CHUNK];
+    __shared__ int n_rec;
+    __shared__ int red[4];
+    const int b = blockIdx.y;
+    const int tiles_x = (g.w + TILE - 1) / TILE;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tid = threadIdx.x;
+    const int px = tx * TILE + (tid & (TILE - 1)), py = ty * TILE + (tid / TILE);
+    const bool live = px < g.w && py < g.h;
+    const double ox = g.org[2 * b], oy = g.org[2 * b + 1];
+    const double xx = ox + (double)px, yy = oy + (double)py;
+    double fx = 0.0, fy = 0.0;
+    bool ok = false;
+    if (g.tier[b] != 3) {
+        const double* A = g.A6 + 6 * (size_t)b;          // {A00, A10, t0, A01, A11, t1}
+        fx = (xx * A[0] + yy * A[1]) + A[2];
+        fy = (xx * A[3] + yy * A[4]) + A[5];
+        ok = live;
+    } else {
+        // tile box in MOVING coordinates (pixel centres), grown by the inside tolerance
+        const double tx0 = ox + (double)(tx * TILE) - 1e-6, ty0 = oy + (double)(ty * TILE) - 1e-6;
+        const double tx1 = ox + (double)min(tx * TILE + TILE - 1, g.w - 1) + 1e-6, ty1 = oy + (double)min(ty * TILE + TILE - 1, g.h - 1) + 1e-6;
+        const int nc = min(g.count[b], g.cap);
+        const int* cl = g.cand + (size_t)b * g.cap;
+        int best = INT_MAX;
+        int base = 0;
+        while (base < nc) {                              // uniform over the workgroup
+            if (tid == 0) n_rec = 0;
+            __syncthreads();
+            // stage the candidates of this sweep that meet the tile: CHUNK looked at => at most CHUNK staged
+            const int look = min(nc - base, CHUNK);
+            if (tid < look) {
+                const int t = cl[base + tid];
+                const int i0 = g.tris[3 * t], i1 = g.tris[3 * t + 1], i2 = g.tris[3 * t + 2];
+                const double x0 = g.vm[2 * i0], y0 = g.vm[2 * i0 + 1], x1 = g.vm[2 * i1], y1 = g.vm[2 * i1 + 1], x2 = g.vm[2 * i2], y2 = g.vm[2 * i2 + 1];
+                const double lx = fmin(x0, fmin(x1, x2)), hx = fmax(x0, fmax(x1, x2));
+                const double ly = fmin(y0, fmin(y1, y2)), hy = fmax(y0, fmax(y1, y2));
+                const double d = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0);
+                if (!(hx < tx0 || lx > tx1 || hy < ty0 || ly > ty1) && d != 0.0) {
+                    const int k = atomicAdd(&n_rec, 1);
+                    double* r = rec + k * REC;
+                    r[0] = x0; r[1] = y0; r[2] = x1 - x0; r[3] = y1 - y0; r[4] = x2 - x0; r[5] = y2 - y0; r[6] = 1.0 / d;
+                    r[7] = g.vi[2 * i0]; r[8] = g.vi[2 * i0 + 1]; r[9] = g.vi[2 * i1]; r[10] = g.vi[2 * i1 + 1];
+                    r[11] = g.vi[2 * i2]; r[12] = g.vi[2 * i2 + 1];
+                    rec_tid[k] = t;
+                }
+            }
+            __syncthreads();
+            base += look;
+            const int ns = n_rec;
+            if (live) {
+                for (int k = 0; k < ns; ++k) {
+                    const double* r = rec + k * REC;
+                    const double dx = xx - r[0], dy = yy - r[1];
+                    const double l1 = (dx * r[5] - dy * r[4]) * r[6];
+                    const double l2 = (r[2] * dy - r[3] * dx) * r[6];
+                    const double l0 = (1.0 - l1) - l2;
+                    if (l0 >= -BARY_EPS && l1 >= -BARY_EPS && l2 >= -BARY_EPS && rec_tid[k] < best) {
+                        best = rec_tid[k];
+                        fx = (l0 * r[7] + l1 * r[9]) + l2 * r[11];
+                        fy = (l0 * r[8] + l1 * r[10]) + l2 * r[12];
+                        ok = true;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (PASS == 0) {
+        if (tid < 4) red[tid] = (tid < 2) ? INT_MAX : INT_MIN;
+        __syncthreads();
+        if (ok) {
+            atomicMin(&red[0], (int)floor(fx)); atomicMin(&red[1], (int)floor(fy));
+            atomicMax(&red[2], (int)ceil(fx)); atomicMax(&red[3], (int)ceil(fy));
+        }
+        __syncthreads();
+        if (tid < 2 && red[tid] != INT_MAX) atomicMin(&g.ext[4 * b + tid], red[tid]);
+        else if (tid >= 2 && tid < 4 && red[tid] != INT_MIN) atomicMax(&g.ext[4 * b + tid], red[tid]);
+        return;
+    }
+    if (!live) return;
+    const size_t o = ((size_t)b * g.h + py) * g.w + px;
+    g.mask[o] = ok ? 1 : 0;
+    if (!ok) { g.out[o] = 0.f; return; }
+    const int orx = g.origin[2 * b], ory = g.origin[2 * b + 1];
+    const float mx = (float)(fx - (double)orx), my = (float)(fy - (double)ory);
+    const int sx = (int)rintf(mx * 32.0f), sy = (int)rintf(my * 32.0f);
+    const int ix = (sx >> 5) + orx - g.img_x0, iy = (sy >> 5) + ory - g.img_y0;
+    g.out[o] = g.dtype == FB_U8 ? sample_u8((const uint8_t*)g.img, g.IH, g.IW, ix, iy, sx & 31, sy & 31)
+                                : sample_f32((const float*)g.img, g.IH, g.IW, ix, iy, sx & 31, sy & 31);
+}
+
+// origin of every block: one for the whole stack while the field spans less than MX_DIS (render_by_subregions then makes
+// ONE remap call, common.py:305-321), else the block's own floor(min) - 4
+__global__ void mesh_origin_kernel(int NB, const int* __restrict__ ext, int* __restrict__ origin) {
+    __shared__ int red[4];
+    if (threadIdx.x < 4) red[threadIdx.x] = (threadIdx.x < 2) ? INT_MAX : INT_MIN;
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += blockDim.x) {
+        if (ext[4 * b] == INT_MAX) continue;
+        atomicMin(&red[0], ext[4 * b]); atomicMin(&red[1], ext[4 * b + 1]);
+        atomicMax(&red[2], ext[4 * b + 2]); atomicMax(&red[3], ext[4 * b + 3]);
+    }
+    __syncthreads();
+    const bool one = red[0] != INT_MAX && (red[2] - red[0]) < MX_DIS && (red[3] - red[1]) < MX_DIS;
+    for (int b = threadIdx.x; b < NB; b += blockDim.x) {
+        const bool any = ext[4 * b] != INT_MAX;
+        origin[2 * b] = any ? (one ? red[0] : ext[4 * b]) - 4 : 0;
+        origin[2 * b + 1] = any ? (one ? red[1] : ext[4 * b + 1]) - 4 : 0;
+    }
+}
+
+__global__ void fill_ext_kernel(int NB, int* ext) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 4 * NB; i += gridDim.x * blockDim.x) ext[i] = ((i & 3) < 2) ? INT_MAX : INT_MIN;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fb_mesh_candidates_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris, int NB, const double* org, int h, int w, int cap,
+                           int* cand, int* count) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, T >= 0 && NB >= 0 && h > 0 && w > 0 && cap > 0);
+    if (NB == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, v_mov && tris && org && cand && count);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    FB_PROF(ctx, "mesh_cand");
+    hipLaunchKernelGGL(mesh_cand_kernel, dim3(NB), dim3(256), 0, ctx->stream, T, v_mov, tris, org, h, w, cap, cand, count);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+int fb_mesh_render_blocks_dev(fb_ctx* ctx, const void* img, int dtype, int IH, int IW, int img_x0, int img_y0, const double* v_mov,
+                              const double* v_img, const int* tris, int NB, const double* org, int h, int w, const int* tier,
+                              const double* A6, int cap, const int* cand, const int* count, int* ext, int* origin, float* out,
+                              uint8_t* mask) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, NB >= 0 && h > 0 && w > 0 && IH > 0 && IW > 0 && cap > 0);
+    FB_CHECK_ARG(ctx, dtype == FB_U8 || dtype == FB_F32);
+    if (NB == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, img && v_mov && v_img && tris && org && tier && A6 && cand && count && ext && origin && out && mask);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    RenderArgs g{img, dtype, IH, IW, img_x0, img_y0, v_mov, v_img, tris, org, h, w, tier, A6, cap, cand, count, ext, origin, out, mask};
+    const dim3 grid(fb_cdiv(w, TILE) * fb_cdiv(h, TILE), NB);
+    FB_PROF_B(ctx, "mesh_render", (double)NB * h * w * 5.0);
+    hipLaunchKernelGGL(fill_ext_kernel, dim3(fb_cdiv(4 * NB, 256)), dim3(256), 0, ctx->stream, NB, ext);
+    hipLaunchKernelGGL(mesh_field_kernel<0>, grid, dim3(TILE * TILE), 0, ctx->stream, g);
+    hipLaunchKernelGGL(mesh_origin_kernel, dim3(1), dim3(256), 0, ctx->stream, NB, ext, origin);
+    hipLaunchKernelGGL(mesh_field_kernel<1>, grid, dim3(TILE * TILE), 0, ctx->stream, g);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+}  // extern "C"

@@ -171,6 +171,88 @@ def block_displacements_to_points(bboxes0, bboxes1, dx, dy):
     return ctr0 - dxy * ratio, ctr1 + dxy * (1 - ratio)
 
 
+def bboxes_mesh_renderer_matcher(mesh0, mesh1, image_loader0, image_loader1, bboxes0, bboxes1, **kwargs):
+    """feabas/matcher.py:781-861 for general triangulated meshes (one region, no collisions): both block stacks are
+    rendered through the meshes from images resident in HBM (``renderer.MeshRenderer``), band-passed with their masks when
+    ``sigma`` > 0 and cross-correlated, all on the device; only (dx, dy, conf) per block come back.
+    image_loader0/1: a ``renderer.ResidentImage``, a 2-D array (pixel (0, 0) at the image-space origin) or a
+    ``renderer.MeshRenderer`` built before (kept by the caller across spacings).  Returns (xy0, xy1, conf)."""
+    from . import renderer as _rd
+    batch_size = kwargs.get('batch_size', None)
+    sigma = kwargs.get('sigma', 0.0)
+    conf_mode = kwargs.get('conf_mode', const.FFT_CONF_MIRROR)
+    pad = kwargs.get('pad', True)
+    subpixel = kwargs.get('subpixel', False)
+    tol = kwargs.get('affine_approx_tol', 0.0)
+    if kwargs.get('geodesic_mask', False) or kwargs.get('mask_range', None) is not None:
+        raise NotImplementedError('geodesic_mask / mask_range are outside the device renderer')
+    bboxes0 = np.asarray(bboxes0).reshape(-1, 4)
+    bboxes1 = np.asarray(bboxes1).reshape(-1, 4)
+    num_blocks = bboxes0.shape[0]
+    empty = (np.empty((0, 2)), np.empty((0, 2)), np.empty(0))
+    if num_blocks == 0:
+        return empty
+    sz0 = np.round(common.bbox_sizes(bboxes0))
+    sz1 = np.round(common.bbox_sizes(bboxes1))
+    chg = np.flatnonzero(np.any(np.diff(sz0, axis=0), axis=-1) | np.any(np.diff(sz1, axis=0), axis=-1))
+    edges = np.concatenate(([0], chg + 1, [num_blocks]))
+    if batch_size is not None and batch_size < num_blocks:                     # matcher.py:811-817
+        parts = []
+        for a, b in zip(edges[:-1], edges[1:]):
+            nbt = max(1, int(np.ceil((b - a) / batch_size)))
+            parts.append(np.linspace(a, b, num=nbt + 1, endpoint=True))
+        edges = np.unique(np.round(np.concatenate(parts)).astype(np.int32))
+    own = []
+    renders = []
+    for mesh, loader in ((mesh0, image_loader0), (mesh1, image_loader1)):
+        if isinstance(loader, _rd.MeshRenderer):
+            renders.append(loader)
+        else:
+            r = _rd.MeshRenderer.from_mesh(mesh, image_loader=loader, affine_approx_tol=tol)
+            if r is None:
+                for o in own:
+                    o.free()
+                return empty
+            renders.append(r); own.append(r)
+    lib, ctx = _lib.load(), _lib.ctx()
+    xy0, xy1, conf = [], [], []
+    try:
+        for a, b in zip(edges[:-1], edges[1:]):
+            bufs = []
+            try:
+                stacks, shapes, covered = [], [], True
+                for r, bb in ((renders[0], bboxes0[a:b]), (renders[1], bboxes1[a:b])):
+                    d_out, d_mask, shape, _ = r.render_stack_dev(bb)
+                    bufs += [d_out, d_mask]
+                    if not d_mask.to_array(shape, np.uint8).any():             # crop_multiple -> None: batch skipped, matcher.py:835-839
+                        covered = False
+                        break
+                    if sigma > 0:
+                        d_out = r.filter_stack_dev(d_out, d_mask, shape, sigma)
+                        bufs.append(d_out)
+                    stacks.append(d_out); shapes.append(shape)
+                if not covered:
+                    continue
+                n = b - a
+                d_res = _lib.DeviceBuffer(20 * n)
+                bufs.append(d_res)
+                _lib.check(lib.fb_ncc_batch_dev(ctx, stacks[0].ptr, stacks[1].ptr, n, 1, shapes[0][1], shapes[0][2], shapes[1][1], shapes[1][2],
+                                                int(bool(pad)), int(bool(subpixel)), int(conf_mode), d_res.ptr, d_res.offset(8 * n), d_res.offset(16 * n)))
+                raw = d_res.to_array((20 * n,), np.uint8)
+                dx = raw[:8 * n].view(np.float64); dy = raw[8 * n:16 * n].view(np.float64); cf = raw[16 * n:].view(np.float32)
+                p0, p1 = block_displacements_to_points(bboxes0[a:b], bboxes1[a:b], dx, dy)
+                xy0.append(p0); xy1.append(p1); conf.append(cf.copy())
+            finally:
+                for d in bufs:
+                    d.free()
+    finally:
+        for o in own:
+            o.free()
+    if not xy0:
+        return empty
+    return np.concatenate(xy0, axis=0), np.concatenate(xy1, axis=0), np.concatenate(conf, axis=0)
+
+
 def auto_spacings(shape0, shape1):
     """feabas/matcher.py:243-251."""
     shp = np.minimum(shape0, shape1)

@@ -147,6 +147,31 @@ int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W
 int fb_area_downsample2_sizes_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, const int* sizes, uint8_t* out);
 int fb_dog_sizes_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, const int* sizes, double sigma, int signed_out,
                      float* out);
+/* common.masked_dog_filter with one mask per image (masks uint8 [N][H][W], device): the DoG MeshRenderer.crop_multiple
+ * applies to its N x h x w stack when log_sigma > 0 (renderer.py:632-641); np.ptp over the whole stack, as there. */
+int fb_dog_masks_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* masks,
+                     int signed_out, float* out);
+
+/* MeshRenderer for general triangulated meshes (one region, no collisions), all pointers device pointers.
+ * fb_mesh_candidates_dev: for NB blocks of h x w pixels whose first pixel sits at org [NB][2] (float64, MOVING coordinates
+ *   with the mesh offset removed, renderer.py:286-289), the triangles (tris int32 [T][3] over v_mov float64 [V][2]) whose
+ *   box meets the closed box bbox - 0.5 (the STRtree query of renderer.py:405): cand [NB][cap], count [NB] (count may
+ *   exceed cap: the caller retries with a larger cap).
+ * fb_mesh_render_blocks_dev: MeshRenderer.crop_multiple(bboxes, mode=RENDER_FULL, log_sigma=0, remap_interp=INTER_LINEAR)
+ *   (renderer.py:601-631): tier [NB] 1 / 2 = affine field A6 [NB][6] = {A00, A10, t0, A01, A11, t1} (crop_field_affine,
+ *   renderer.py:419-451), 3 = exact piecewise-linear field through the candidates (field_w_weight, renderer.py:259-300);
+ *   v_img [V][2] = image-space vertices (INITIAL gear with offset).  The field is sampled from the resident image
+ *   (dtype FB_U8: cv2's fixed-point bilinear, FB_F32: its float path; pixel (0, 0) of the array at (img_x0, img_y0) in
+ *   image space, 0 outside = StreamLoader fillval + BORDER_CONSTANT) through float32 maps relative to origin [NB][2]
+ *   (out; = floor(min field) - 4 of the whole stack while it spans < 16300 px, common.py:264, 305-321, else per block).
+ *   ext int32 [NB][4] = scratch (field extent per block).  out float32 [NB][h][w], mask uint8 [NB][h][w]. */
+int fb_mesh_candidates_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris, int NB, const double* org, int h, int w, int cap,
+                           int* cand, int* count);
+int fb_mesh_render_blocks_dev(fb_ctx* ctx, const void* img, int dtype, int IH, int IW, int img_x0, int img_y0, const double* v_mov,
+                              const double* v_img, const int* tris, int NB, const double* org, int h, int w, const int* tier,
+                              const double* A6, int cap, const int* cand, const int* count, int* ext, int* origin, float* out,
+                              uint8_t* mask);
+
 /* common.remap = cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) (common.py:218-255, called at 329-330) of resident float32
  * images through explicit per-pixel maps: the exact piecewise-linear tier of MeshRenderer.crop_multiple
  * (renderer.py:511-563).  All pointers are device pointers.  imgs [P][IH][IW]; img_id [N]; map_x, map_y float32

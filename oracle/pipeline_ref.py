@@ -166,7 +166,7 @@ def affine_residue(v1, v0, A):
     return np.max(np.sum((v1 - v0 @ A[:2, :2] - A[-1, :2]) ** 2, axis=-1)) ** 0.5
 
 
-def render_blocks_mesh1(m1, img, bboxes, tol, return_tiers=False):
+def render_blocks_mesh1(m1, img, bboxes, tol, return_tiers=False, img_origin=(0, 0), return_mask=False):
     """MeshRenderer.from_mesh(mesh1, affine_approx_tol=tol) (renderer.py:47-166) + crop_multiple(bboxes, mode=RENDER_FULL,
     log_sigma=0, remap_interp=INTER_LINEAR) (renderer.py:601-648) for a mesh of one region without collisions over a
     StreamLoader of `img` (fillval 0).  Per block (crop_field, renderer.py:453-563): the global affine when its residue
@@ -217,28 +217,62 @@ def render_blocks_mesh1(m1, img, bboxes, tol, return_tiers=False):
     out = np.zeros(map_x.shape, dtype=np.float32)
     if mask.any():
         xmin = np.floor(map_x[mask].min()) - 4; ymin = np.floor(map_y[mask].min()) - 4
-        val = remap_origin(img, map_x, map_y, (int(xmin), int(ymin)))
+        val = remap_origin(img, map_x, map_y, (int(xmin), int(ymin)), img_origin)
         out[mask] = val[mask]
     out = out.reshape(len(fx), -1, map_x.shape[1])
+    if return_mask:
+        return out, mask.reshape(out.shape), np.array(tiers)
     return (out, np.array(tiers)) if return_tiers else out
 
 
-def remap_origin(img, map_x, map_y, origin):
-    """common.remap on the sub-image img_loader.crop((xmin, ymin, xmax, ymax)) (zero outside the strip) with maps made
-    relative to its integer origin in float32 (common.py:329-330): ncc_ref.remap_bilinear_cv on the zero-extended image."""
+def remap_origin(img, map_x, map_y, origin, img_origin=(0, 0)):
+    """common.remap on the sub-image img_loader.crop((xmin, ymin, xmax, ymax)) (zero outside the image, whose pixel (0, 0)
+    sits at img_origin) with maps made relative to its integer origin in float32 (common.py:329-330).  float32 images:
+    ncc_ref.remap_bilinear_cv on the zero-extended image.  uint8 images: cv2's fixed-point bilinear path -- weights of
+    the 1/32-px phases scaled by 2^15 as int16 (the unit weight saturates to 32767, the table's sum fix-up puts the missing
+    1 on the last tap), (sum + 2^14) >> 15 (FixedPtCast); restated from the published OpenCV algorithm, cv2 itself is
+    absent from the image (parity unpinned for this function)."""
     mxt = (map_x - origin[0]).astype(np.float32); myt = (map_y - origin[1]).astype(np.float32)
     H, W = img.shape
     sx = np.rint(mxt * np.float32(32)).astype(np.int64); sy = np.rint(myt * np.float32(32)).astype(np.int64)
-    ix = (sx >> 5) + int(origin[0]); iy = (sy >> 5) + int(origin[1])
-    ax = (sx & 31).astype(np.float32) * np.float32(1 / 32); ay = (sy & 31).astype(np.float32) * np.float32(1 / 32)
+    ix = (sx >> 5) + int(origin[0]) - int(img_origin[0]); iy = (sy >> 5) + int(origin[1]) - int(img_origin[1])
+    a = sx & 31; b = sy & 31
+
+    def tap(src, yy_, xx_, zero):
+        inside = (yy_ >= 0) & (yy_ < H) & (xx_ >= 0) & (xx_ < W)
+        return np.where(inside, src[np.clip(yy_, 0, H - 1), np.clip(xx_, 0, W - 1)], zero)
+    if img.dtype == np.uint8:
+        src = img.astype(np.int64)
+        w00 = (32 - a) * (32 - b) * 32; w01 = a * (32 - b) * 32; w10 = (32 - a) * b * 32; w11 = a * b * 32
+        unit = (a == 0) & (b == 0)
+        w00 = np.where(unit, 32767, w00); w11 = np.where(unit, 1, w11)
+        acc = tap(src, iy, ix, 0) * w00 + tap(src, iy, ix + 1, 0) * w01 + tap(src, iy + 1, ix, 0) * w10 + tap(src, iy + 1, ix + 1, 0) * w11
+        return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.float32)
+    ax = a.astype(np.float32) * np.float32(1 / 32); ay = b.astype(np.float32) * np.float32(1 / 32)
     one = np.float32(1)
     w00 = (one - ay) * (one - ax); w01 = (one - ay) * ax; w10 = ay * (one - ax); w11 = ay * ax
     img = np.asarray(img, dtype=np.float32)
+    z = np.float32(0)
+    return ((tap(img, iy, ix, z) * w00 + tap(img, iy, ix + 1, z) * w01) + tap(img, iy + 1, ix, z) * w10) + tap(img, iy + 1, ix + 1, z) * w11
 
-    def tap(yy_, xx_):
-        inside = (yy_ >= 0) & (yy_ < H) & (xx_ >= 0) & (xx_ < W)
-        return np.where(inside, img[np.clip(yy_, 0, H - 1), np.clip(xx_, 0, W - 1)], np.float32(0))
-    return ((tap(iy, ix) * w00 + tap(iy, ix + 1) * w01) + tap(iy + 1, ix) * w10) + tap(iy + 1, ix + 1) * w11
+
+def bboxes_mesh_renderer_matcher(mesh0, mesh1, img0, img1, bboxes0, bboxes1, sigma=0.0, conf_mode=ncc_ref.FFT_CONF_MIRROR,
+                                 pad=True, subpixel=False, affine_approx_tol=0.0, img_origin0=(0, 0), img_origin1=(0, 0),
+                                 return_stacks=False):
+    """matcher.py:781-861 for blocks of one size, batch_size None, meshes of one region without collisions over
+    StreamLoaders of img0 / img1 (fillval 0): both stacks rendered (render_blocks_mesh1 above), DoG with the stack masks
+    when sigma > 0 (renderer.py:632-641), xcorr_fft, block displacement -> point pair (matcher.py:840-849)."""
+    stacks, masks = [], []
+    for m, img, bb, org in ((mesh0, img0, bboxes0, img_origin0), (mesh1, img1, bboxes1, img_origin1)):
+        st, mk, _ = render_blocks_mesh1(m, img, bb, affine_approx_tol, img_origin=org, return_mask=True)
+        if sigma > 0:
+            st = ncc_ref.masked_dog_filter(st, sigma, mask=mk)
+        stacks.append(st); masks.append(mk)
+    dx, dy, conf = ncc_ref.xcorr_fft(stacks[0], stacks[1], conf_mode=conf_mode, pad=pad, subpixel=subpixel)
+    xy0, xy1 = ncc_ref.block_points(np.asarray(bboxes0), np.asarray(bboxes1), dx, dy)
+    if return_stacks:
+        return xy0, xy1, conf, stacks, masks
+    return xy0, xy1, conf
 
 
 def relax_deformed(m0, m1, xs, ys, xy0, xy1, weight, residue_len, resolve, residue_mode='huber'):

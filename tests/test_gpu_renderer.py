@@ -1,0 +1,141 @@
+"""GPU parity of the general-mesh block renderer / matcher (feabas_amd/renderer.py, matcher.bboxes_mesh_renderer_matcher,
+csrc/fb_render.hip) against the oracle restatement of MeshRenderer.crop_multiple + xcorr_fft (oracle/pipeline_ref.py:
+render_blocks_mesh1, bboxes_mesh_renderer_matcher; matplotlib's LinearTriInterpolator as the reference uses it)."""
+import numpy as np
+import pytest
+from scipy.ndimage import gaussian_filter
+from scipy.spatial import Delaunay
+
+from oracle import fem_ref, ncc_ref, pipeline_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _texture(rng, h, w):
+    a = gaussian_filter(rng.standard_normal((h, w)), 1.5)
+    b = gaussian_filter(rng.standard_normal((h, w)), 12)
+    t = a / a.std() + 0.7 * b / b.std()
+    return np.clip(128 + 40 * t / t.std(), 0, 255).astype(np.uint8)
+
+
+def _meshes(rng, extent=(600, 480), spacing=45.0, warp=3.0, offset=(7.25, -3.5)):
+    """an irregular triangulation (jittered grid -> Delaunay), a smooth non-affine MOVING field and a fractional offset;
+    the same state in the oracle's RefMesh and the product's Mesh"""
+    from feabas_amd import constant as const
+    from feabas_amd.mesh import Mesh
+    gx, gy = np.meshgrid(np.arange(0, extent[0] + 1, spacing), np.arange(0, extent[1] + 1, spacing))
+    v = np.stack((gx.ravel(), gy.ravel()), axis=-1) + rng.uniform(-0.3, 0.3, (gx.size, 2)) * spacing
+    tris = Delaunay(v).simplices.astype(np.int32)
+    # orientation as the mesher gives it (positive area), degenerate slivers on the hull dropped
+    p = v[tris]
+    area = (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1]) - (p[:, 1, 1] - p[:, 0, 1]) * (p[:, 2, 0] - p[:, 0, 0])
+    tris[area < 0] = tris[area < 0][:, ::-1]
+    tris = tris[np.abs(area) > 0.05 * spacing * spacing]
+    s = v / np.array(extent)
+    field = warp * np.stack((np.sin(2.1 * s[:, 1] + 0.3) + 0.5 * s[:, 0] ** 2, np.cos(1.7 * s[:, 0]) - 0.4 * s[:, 0] * s[:, 1]), axis=-1)
+    rot = np.array([[np.cos(0.01), np.sin(0.01)], [-np.sin(0.01), np.cos(0.01)]])
+    vm = (v - v.mean(0)) @ rot + v.mean(0) + field
+    ref = fem_ref.RefMesh(v, tris)
+    ref.set_vertices(vm, fem_ref.GEAR_MOVING); ref.set_offset(np.array([offset]), fem_ref.GEAR_MOVING)
+    M = Mesh(v, tris)
+    M.set_vertices(vm, const.MESH_GEAR_MOVING); M.set_offset(np.array([offset]), const.MESH_GEAR_MOVING)
+    return ref, M
+
+
+def _blocks(rng, n, size, extent, margin):
+    x0 = rng.integers(-margin, extent[0] - size[0] + margin, n)
+    y0 = rng.integers(-margin, extent[1] - size[1] + margin, n)
+    return np.stack((x0, y0, x0 + size[0], y0 + size[1]), axis=-1)
+
+
+def _compare_stacks(got, gmask, exp, emask, max_bad=2e-3):
+    # pixels within 1e-9 of the hull may fall on either side; pixels whose float32 map coordinate sits on a rounding
+    # boundary of the 1/32-px quantisation may take the neighbouring phase
+    assert (gmask != emask).mean() < 2e-4
+    both = gmask & emask
+    d = np.abs(got - exp)[both]
+    assert (d > 1e-3 * max(1.0, np.abs(exp).max())).mean() < max_bad
+    return d
+
+
+@pytest.mark.parametrize('dtype', ['u8', 'f32'])
+@pytest.mark.parametrize('tol', [0.0, 0.08])
+def test_render_stack_vs_oracle(fb, dtype, tol):
+    from feabas_amd import renderer
+    rng = np.random.default_rng(11)
+    ref, M = _meshes(rng)
+    img = _texture(rng, 620, 760)
+    if dtype == 'f32':
+        img = ncc_ref.masked_dog_filter(img, 2.0).astype(np.float32)
+    origin = (-60, -50)
+    bboxes = _blocks(rng, 24, (72, 56), (600, 480), margin=30)
+    exp, emask, etier = pipeline_ref.render_blocks_mesh1(ref, img, bboxes, tol, img_origin=origin, return_mask=True)
+    r = renderer.MeshRenderer.from_mesh(M, image_loader=renderer.ResidentImage(img, origin), affine_approx_tol=tol)
+    d_out, d_mask, shape, tier = r.render_stack_dev(bboxes)
+    got = d_out.to_array(shape, np.float32); gmask = d_mask.to_array(shape, np.uint8).astype(bool)
+    d_out.free(); d_mask.free(); r.free()
+    assert shape == (24, 56, 72)
+    np.testing.assert_array_equal(tier, etier)
+    if tol > 0:
+        assert set(np.unique(tier)) >= {2, 3}                        # the tolerance splits the blocks between the tiers
+    assert 0.5 < emask.mean() < 1.0                                  # some blocks stick out of the mesh
+    d = _compare_stacks(got, gmask, exp, emask)
+    if dtype == 'u8':
+        assert d.max() <= 8                                          # a flipped phase moves a sample by a few grey levels at most
+        assert np.all(got == np.rint(got))
+    assert np.all(got[~gmask] == 0)
+
+
+def test_masked_dog_of_a_stack(fb):
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(12)
+    st = rng.integers(0, 255, (9, 80, 96)).astype(np.float32)
+    mk = np.ones(st.shape, dtype=bool)
+    mk[0, :30] = False; mk[3, :, 50:] = False; mk[5, 20:40, 20:70] = False; mk[8] = False
+    st[~mk] = 0
+    exp = ncc_ref.masked_dog_filter(st, 2.5, mask=mk)
+    d_in, d_m, d_o = _lib.DeviceBuffer.from_array(st), _lib.DeviceBuffer.from_array(mk.astype(np.uint8)), _lib.DeviceBuffer(st.nbytes)
+    _lib.check(lib.fb_dog_masks_dev(ctx, d_in.ptr, 1, 9, 80, 96, 2.5, d_m.ptr, 1, d_o.ptr))
+    got = d_o.to_array(st.shape, np.float32)
+    np.testing.assert_allclose(got, exp, atol=2e-3 * np.abs(exp).max())
+    full = np.ones_like(mk)                                          # no zero in any mask: plain DoG (common.py:368)
+    d_m2 = _lib.DeviceBuffer.from_array(full.astype(np.uint8))
+    _lib.check(lib.fb_dog_masks_dev(ctx, d_in.ptr, 1, 9, 80, 96, 2.5, d_m2.ptr, 1, d_o.ptr))
+    np.testing.assert_allclose(d_o.to_array(st.shape, np.float32), ncc_ref.masked_dog_filter(st, 2.5), atol=2e-3 * np.abs(exp).max())
+    for b in (d_in, d_m, d_m2, d_o):
+        b.free()
+
+
+@pytest.mark.parametrize('sigma,tol', [(0.0, 0.0), (2.5, 0.0), (2.5, 0.08)])
+def test_bboxes_mesh_renderer_matcher_vs_oracle(fb, sigma, tol):
+    from feabas_amd import matcher, renderer
+    rng = np.random.default_rng(13)
+    extent = (600, 480)
+    ref0, M0 = _meshes(rng, warp=2.0, offset=(0.0, 0.0))
+    ref1, M1 = _meshes(rng, warp=3.0, offset=(4.5, 2.25))
+    base = _texture(rng, 700, 820)
+    img0 = base[40:660, 30:790]                                       # section 1 is section 0 shifted by (9, -6) + its own noise
+    img1 = np.clip(base[46:666, 21:781].astype(np.int32) + rng.integers(-6, 7, (620, 760)), 0, 255).astype(np.uint8)
+    if sigma == 0:                                                    # images band-passed beforehand, as the stitching side hands them over
+        img0 = ncc_ref.masked_dog_filter(img0, 2.5).astype(np.float32); img1 = ncc_ref.masked_dog_filter(img1, 2.5).astype(np.float32)
+    org = (-60, -50)
+    # blocks of two sizes (two batches), a few sticking out of mesh1
+    b_a = _blocks(rng, 14, (96, 80), extent, margin=10)
+    b_b = _blocks(rng, 10, (64, 64), extent, margin=10)
+    bboxes0 = np.concatenate((b_a, b_b)); bboxes1 = bboxes0 + np.array([3, -2, 3, -2])
+    exp = [pipeline_ref.bboxes_mesh_renderer_matcher(ref0, ref1, img0, img1, b0, b1, sigma=sigma, affine_approx_tol=tol,
+                                                     img_origin0=org, img_origin1=org)
+           for b0, b1 in ((bboxes0[:14], bboxes1[:14]), (bboxes0[14:], bboxes1[14:]))]
+    exy0, exy1, econf = (np.concatenate([e[k] for e in exp]) for k in range(3))
+    r0 = renderer.ResidentImage(img0, org); r1 = renderer.ResidentImage(img1, org)
+    xy0, xy1, conf = matcher.bboxes_mesh_renderer_matcher(M0, M1, r0, r1, bboxes0, bboxes1, sigma=sigma, affine_approx_tol=tol, batch_size=100)
+    r0.free(); r1.free()
+    assert xy0.shape == (24, 2) and conf.shape == (24,)
+    strong = econf > 0.3
+    assert strong.sum() >= 16
+    np.testing.assert_array_equal(xy0[strong], exy0[strong])         # integer peaks bit-exact
+    np.testing.assert_array_equal(xy1[strong], exy1[strong])
+    np.testing.assert_allclose(conf[strong], econf[strong], atol=2e-3)
+    d = (xy1 - xy0)[strong]
+    assert np.abs(np.median(d, axis=0)).max() < 25                   # a real displacement field, not a constant
