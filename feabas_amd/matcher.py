@@ -253,6 +253,220 @@ def bboxes_mesh_renderer_matcher(mesh0, mesh1, image_loader0, image_loader1, bbo
     return np.concatenate(xy0, axis=0), np.concatenate(xy1, axis=0), np.concatenate(conf, axis=0)
 
 
+DEFAULT_AVG_DEFORM = 0.05                # feabas/config.py:32
+
+
+def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, spacings, **kwargs):
+    """feabas/matcher.py:430-778 for two general meshes over images resident in HBM: block NCC through the meshes
+    (``bboxes_mesh_renderer_matcher``) alternating with the relaxation of the pair (``optimizer.SLM``), coarse to fine over
+    ``spacings``; the spacing schedule, the pad / sub-pixel / tolerance rules per round, the residue re-weighting and the
+    strain estimate follow the reference statement by statement.  Every arithmetic step (render, DoG, NCC, assembly, PCG)
+    runs on the device; the loop and the block lists stay on the host.  ``distributor`` other than 'cartesian_bbox' (the
+    shapely region-aware one) and ``num_workers`` > 1 are outside this mirror.  The batched strip form of the same loop is
+    ``stitch_pipeline.StripBatchMatcher`` (one call = many tile pairs)."""
+    from . import optimizer
+    from . import renderer as _rd
+    conf_thresh = kwargs.get('conf_thresh', 0.3)
+    residue_mode = kwargs.get('residue_mode', 'huber')
+    residue_len = kwargs.get('residue_len', 0)
+    opt_tol = kwargs.get('opt_tol', None)
+    if kwargs.get('distributor', 'cartesian_bbox') != 'cartesian_bbox':
+        raise NotImplementedError("distributor: only 'cartesian_bbox' (matcher.py:865-891)")
+    min_num_blocks = kwargs.get('min_num_blocks', 2)
+    shrink_factor = kwargs.get('shrink_factor', 1)
+    allow_dwell = kwargs.get('allow_dwell', 0)
+    allow_enlarge = kwargs.get('allow_enlarge', False)
+    link_weight_decay = kwargs.get('link_weight_decay', 0.0)
+    compute_strain = kwargs.get('compute_strain', True)
+    batch_size = kwargs.get('batch_size', None)
+    initial_matches = kwargs.get('initial_matches', None)
+    to_pad = kwargs.get('pad', None)
+    do_subpixel = kwargs.get('subpixel', None)
+    max_spacing_skip = kwargs.get('max_spacing_skip', 0)
+    stiffness_lambda = kwargs.get('stiffness_lambda', 1)
+    affine_render = kwargs.get('affine_approximated_render', True)
+    sigma = kwargs.get('sigma', 0.0)
+    conf_mode = kwargs.get('conf_mode', const.FFT_CONF_MIRROR)
+    trace = kwargs.get('trace', None)                  # a list: one record per round (debugging / tests)
+    relax_tol = kwargs.get('relax_tol', 1e-9)
+    if residue_len < 0:
+        raise NotImplementedError('residue_len < 0 (section thickness units) needs the reference configuration')
+    spacings = np.array(spacings, dtype=np.float64).ravel()
+    linear_system = mesh0.is_linear and mesh1.is_linear
+    one_locked = mesh0.locked or mesh1.locked
+    strain = DEFAULT_AVG_DEFORM
+    invalid_output = (None, None, 0, strain)
+    if np.any(spacings < 1):                                                  # relative to the longer side, matcher.py:541-551
+        bbox, valid = common.intersect_bbox(mesh0.bbox(gear=const.MESH_GEAR_MOVING), mesh1.bbox(gear=const.MESH_GEAR_MOVING))
+        if not valid:
+            return invalid_output
+        spacings[spacings < 1] *= max(bbox[2] - bbox[0], bbox[3] - bbox[1])
+    if compute_strain:
+        mesh0_ori, mesh1_ori = mesh0.copy(), mesh1.copy()
+    solve = (lambda o, **kw: o.optimize_linear(**kw)) if linear_system else None
+    opt = optimizer.SLM([mesh0, mesh1], stiffness_lambda=stiffness_lambda)
+    if initial_matches is not None:                                           # matcher.py:555-566
+        xy0, xy1, weight = initial_matches[:3] if isinstance(initial_matches, (tuple, list)) else \
+            (initial_matches.xy0, initial_matches.xy1, initial_matches.weight)
+        opt.add_link_from_coordinates(mesh0.uid, mesh1.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight)
+        opt.optimize_affine_cascade(start_gear=const.MESH_GEAR_FIXED, target_gear=const.MESH_GEAR_FIXED, svd_clip=None)
+        opt.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_CONNECTED_RIGID)
+        if linear_system:
+            opt.optimize_linear(tol=1e-6)
+        else:
+            opt.optimize_Newton_Raphson(max_newtonstep=5, tol=1e-4)
+    else:
+        mesh0.anneal(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT)
+        mesh1.anneal(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT)
+    spacings = np.sort(spacings)[::-1]
+    sp = np.max(spacings)
+    sp_indx = 0
+    initialized = False
+    spacing_enlarged = not allow_enlarge
+    dwelled = 0
+    pad = True if to_pad is None else to_pad
+    images, own_images = [], []
+    for ld in (image_loader0, image_loader1):
+        if isinstance(ld, _rd.ResidentImage):
+            images.append(ld)
+        else:
+            images.append(_rd.ResidentImage(ld)); own_images.append(images[-1])
+
+    def relax(tol):
+        if linear_system:
+            opt.optimize_linear(tol=tol)
+        else:
+            opt.optimize_Newton_Raphson(max_newtonstep=3, tol=tol)
+    try:
+        while sp_indx < spacings.size:
+            last = sp == spacings[-1]
+            mnb = min_num_blocks if last else 1
+            subpixel = do_subpixel if do_subpixel is not None else bool(last)
+            tol_r = (0.1 if last else max(1, 0.02 * sp)) if affine_render else 0
+            bboxes0, bboxes1 = distributor_cartesian_bbox(mesh0, mesh1, sp, min_num_blocks=mnb, shrink_factor=shrink_factor, zorder=True)
+            if bboxes0 is None:
+                return invalid_output
+            xy0, xy1, conf = bboxes_mesh_renderer_matcher(mesh0, mesh1, images[0], images[1], bboxes0, bboxes1, batch_size=batch_size,
+                                                          pad=pad, subpixel=subpixel, affine_approx_tol=tol_r, sigma=sigma, conf_mode=conf_mode)
+            if np.all(conf <= conf_thresh):
+                if not initialized:
+                    return invalid_output
+                break
+            if link_weight_decay == 0:
+                opt.clear_links()
+            else:
+                for lnk in opt.links:
+                    lnk._weight = lnk._weight * link_weight_decay
+            keep = conf > conf_thresh
+            xy0, xy1, wt = xy0[keep], xy1[keep], conf[keep]
+            max_dis = np.max(np.sum((xy0 - xy1) ** 2, axis=-1)) ** 0.5
+            if trace is not None:
+                trace.append(dict(sp=float(sp), blocks=int(conf.size), kept=int(keep.sum()), max_dis=float(max_dis), pad=bool(pad), subpixel=bool(subpixel),
+                                  tol=float(tol_r), conf=conf.copy(), bboxes1=bboxes1.copy()))
+            # the reference's 0.01 / max_dis is an iteration budget: at that tolerance the field in weakly constrained corners
+            # depends on the Krylov path taken.  Like the strip pipeline (and the oracle) the solves here are converged.
+            opt_tol_t = min(relax_tol, 0.01 / max(1, max_dis)) if opt_tol is None else opt_tol
+            min_block_size = 4 * max_dis                                      # min_block_size_multiplier, matcher.py:539
+            next_pos = np.searchsorted(-spacings, -min_block_size) - 1
+            if (not spacing_enlarged) and (next_pos < 0):
+                sp_indx = -1
+                spacing_enlarged = True
+                sp = np.ceil(min_block_size)
+                if to_pad is None:
+                    pad = True
+                continue
+            spacing_enlarged = True
+            if next_pos > sp_indx:
+                next_pos = min(next_pos, sp_indx + 1 + max_spacing_skip)
+                if to_pad is None:
+                    pad = bool(next_pos > sp_indx + 1)
+                sp_indx = next_pos
+                dwelled = 0
+            elif dwelled >= allow_dwell:
+                if to_pad is None:
+                    pad = True
+                sp_indx += 1
+                dwelled = 0
+            else:
+                if to_pad is None:
+                    pad = True
+                dwelled += 1
+            opt.add_link_from_coordinates(mesh0.uid, mesh1.uid, xy0, xy1, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), weight=wt)
+            if len(opt.links) == 0:
+                if not initialized:
+                    return invalid_output
+                break
+            if max_dis > 0.1:
+                relax(opt_tol_t)
+                if residue_len > 0:
+                    if residue_mode == 'huber':
+                        opt.set_link_residue_huber(residue_len)
+                    elif residue_mode == 'threshold':
+                        opt.set_link_residue_threshold(residue_len)
+                    else:
+                        raise ValueError(residue_mode)
+                    weight_modified, _ = opt.adjust_link_weight_by_residue(relax_first=True)
+                    if weight_modified and (sp_indx < spacings.size):
+                        relax(opt_tol_t)
+            if trace is not None:
+                trace[-1]['field1'] = mesh1.vertices_w_offset(const.MESH_GEAR_MOVING) - mesh1.vertices_w_offset(const.MESH_GEAR_INITIAL)
+                trace[-1]['solve'] = dict(getattr(opt, 'last_solve', {}))
+            initialized = True
+            if 0 <= sp_indx < spacings.size:
+                sp = spacings[sp_indx]
+    finally:
+        for im in own_images:
+            im.free()
+    if len(opt.links) == 0:
+        return invalid_output
+    link = opt.links[-1]
+    xy0 = link.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=True, combine=True)
+    xy1 = link.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=True, combine=True)
+    weight = link.weight(use_mask=True)
+    if compute_strain:                                                        # matcher.py:752-777
+        opt = optimizer.SLM([mesh0_ori, mesh1_ori], stiffness_lambda=stiffness_lambda)
+        opt.add_link_from_coordinates(mesh0_ori.uid, mesh1_ori.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight)
+        opt.optimize_affine_cascade(start_gear=const.MESH_GEAR_INITIAL, target_gear=const.MESH_GEAR_FIXED, svd_clip=(1, 1))
+        opt.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_COPY_EXACT)
+        if linear_system:
+            opt.optimize_linear(tol=1e-6)
+        else:
+            opt.optimize_Newton_Raphson(max_newtonstep=5, tol=1e-4)
+        Es0 = Es = 0
+        soft_avg = np.mean([m.soft_factor for m in opt.meshes])
+        for m in opt.meshes:
+            if (one_locked and (not m.locked)) or ((not one_locked) and (m.soft_factor <= soft_avg)):
+                v0 = m.vertices(gear=const.MESH_GEAR_FIXED)
+                dv = m.vertices(gear=const.MESH_GEAR_MOVING) - v0
+                v0 = v0 - np.mean(v0, axis=0, keepdims=True)
+                dv = dv - np.mean(dv, axis=0, keepdims=True)
+                St, _ = m.stiffness_matrix()
+                Es += max(0, St.dot(dv.ravel()).dot(dv.ravel()))
+                Es0 += max(0, St.dot(v0.ravel()).dot(v0.ravel()))
+        strain = (Es / Es0) ** 0.5
+    return xy0, xy1, weight, strain
+
+
+def section_matcher(mesh0, mesh1, image_loader0, image_loader1, **kwargs):
+    """feabas/matcher.py:370-427, the branch for two connected meshes (or no initial matches): the alignment-side defaults
+    around ``iterative_xcorr_matcher_w_mesh``.  Splitting disconnected sub-meshes (``divide_disconnected_submeshes``) and the
+    region-aware block distributor are outside this mirror."""
+    kwargs = dict(kwargs)
+    initial_matches = kwargs.pop('initial_matches', None)
+    spacings = kwargs.pop('spacings', [100])
+    kwargs.setdefault('sigma', 2.5)
+    kwargs.setdefault('batch_size', 100)
+    kwargs.setdefault('distributor', 'cartesian_bbox')
+    kwargs.setdefault('link_weight_decay', 0.0)
+    compute_strain = kwargs.pop('compute_strain', False)
+    kwargs.setdefault('stiffness_lambda', 0.5)
+    for m in (mesh0, mesh1):
+        if m.connected_vertices()[0] != 1 and initial_matches is not None:
+            raise NotImplementedError('section_matcher: disconnected meshes with initial matches')
+    return iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, spacings=spacings, initial_matches=initial_matches,
+                                          compute_strain=compute_strain, **kwargs)
+
+
 def auto_spacings(shape0, shape1):
     """feabas/matcher.py:243-251."""
     shp = np.minimum(shape0, shape1)

@@ -139,3 +139,33 @@ def test_bboxes_mesh_renderer_matcher_vs_oracle(fb, sigma, tol):
     np.testing.assert_allclose(conf[strong], econf[strong], atol=2e-3)
     d = (xy1 - xy0)[strong]
     assert np.abs(np.median(d, axis=0)).max() < 25                   # a real displacement field, not a constant
+
+
+@pytest.mark.parametrize('H,W,seed,shift,amp', [(768, 256, 5, (6, -4), 0.0), (1024, 256, 1, (4, -3), 3.0), (3600, 72, 21, (2, -3), 2.5)])
+def test_iterative_matcher_general_path_vs_strip_oracle(fb, H, W, seed, shift, amp):
+    """matcher.iterative_xcorr_matcher_w_mesh (general meshes: device renderer + SLM) fed the way stitching_matcher feeds it
+    (matcher.py:338-363) against the oracle's statement-by-statement pair pipeline (pipeline_ref.match_pair, pinned by the
+    golden vectors): the same matches, weights and strain must come out of the general code path -- rigid pair, a pair whose
+    mesh1 deforms between the spacings, and three spacings (deformed twice)."""
+    from test_gpu_pipeline import _warped_pair
+    from feabas_amd import matcher
+    from feabas_amd import constant as const
+    from feabas_amd.mesh import Mesh
+    img0, img1 = _warped_pair(H, W, seed, shift, amp)
+    exp = pipeline_ref.match_pair(img0, img1, residue_len=2.0)
+    assert exp['xy0'] is not None
+    f0 = ncc_ref.masked_dog_filter(img0, 2.5).astype(np.float32); f1 = ncc_ref.masked_dog_filter(img1, 2.5).astype(np.float32)
+    spacings = ncc_ref.auto_spacings((H, W), (H, W))
+    m0 = Mesh.from_bbox((0, 0, W, H), cartesian=True, mesh_size=float(np.min(spacings)), min_num_blocks=2, uid=0)
+    m1 = Mesh.from_bbox((0, 0, W, H), cartesian=True, mesh_size=float(np.min(spacings)), min_num_blocks=2, uid=1)
+    m0.apply_translation((exp['tx'], exp['ty']), const.MESH_GEAR_FIXED)
+    m0.lock()
+    xy0, xy1, weight, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, f0, f1, spacings=spacings, distributor='cartesian_bbox',
+                                                                      residue_len=2.0, conf_thresh=0.33, min_num_blocks=2)
+    assert xy0 is not None and xy0.shape == exp['xy0'].shape
+    np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-3)
+    np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-3)
+    np.testing.assert_allclose(weight, exp['weight'], atol=2e-3)
+    assert abs(strain - exp['strain']) < 2e-3 * max(1.0, exp['strain'] / 0.01)
+    if H == 3600:
+        assert exp['deformed'] and len(exp['tiers']) == 2            # the deformed-mesh branch of the oracle, twice
