@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--host-ingest-threads', type=int, default=4)
     ap.add_argument('--host-ingest-pairs', type=int, default=512, help='pairs of the PCIe-inclusive measurement (0: skip)')
     ap.add_argument('--no-fem', action='store_true')
+    ap.add_argument('--no-align', action='store_true', help='skip the alignment-side block matcher section')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fem-grid', type=int, default=708)
     ap.add_argument('--fem-iters', type=int, default=200)
@@ -191,6 +192,47 @@ def bench_xcorr_classes(lib, ctx, _lib):
         for b in (d0, d1, o):
             b.free()
     return out
+
+
+def bench_align(lib, ctx, _lib, S=8192, mesh_size=50.0, nblocks=512, B=280):
+    """alignment side: matcher.bboxes_mesh_renderer_matcher through two general triangulated
+    meshes (smooth non-affine fields) over S x S uint8 sections resident in HBM: render both block stacks, masked DoG, NCC"""
+    from feabas_amd import constant as const
+    from feabas_amd import matcher as fmatcher
+    from feabas_amd import renderer
+    from feabas_amd.mesh import Mesh
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 255, (S, S), dtype=np.uint8)
+    images = [renderer.ResidentImage(img), renderer.ResidentImage(np.roll(img, (3, -5), axis=(0, 1)))]
+    n = int((S - 1) / mesh_size) + 1
+    gx, gy = np.meshgrid(np.linspace(0, S - 1, n), np.linspace(0, S - 1, n))
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+    tris = np.concatenate((np.stack((a, b, d), -1), np.stack((a, d, c), -1))).astype(np.int32)
+    rends = []
+    for k in range(2):
+        v = np.stack((gx.ravel(), gy.ravel()), axis=-1)
+        inner = ((gx > 0) & (gx < S - 1) & (gy > 0) & (gy < S - 1)).ravel()
+        v[inner] += rng.uniform(-0.25, 0.25, (int(inner.sum()), 2)) * mesh_size
+        M = Mesh(v, tris)
+        sxy = v / S
+        M.set_vertices(v + 4.0 * np.stack((np.sin(3.1 * sxy[:, 1] + k), np.cos(2.3 * sxy[:, 0] - k)), axis=-1), const.MESH_GEAR_MOVING)
+        rends.append(renderer.MeshRenderer.from_mesh(M, image_loader=images[k]))
+    x0 = rng.integers(0, S - B, nblocks); y0 = rng.integers(0, S - B, nblocks)
+    bboxes = np.stack((x0, y0, x0 + B, y0 + B), axis=-1)
+    best = np.inf
+    for _ in range(3):
+        t0 = time.time()
+        xy0, xy1, conf = fmatcher.bboxes_mesh_renderer_matcher(rends[0].mesh, rends[1].mesh, rends[0], rends[1], bboxes, bboxes, sigma=2.5)
+        best = min(best, time.time() - t0)
+    for r in rends:
+        r.free()
+    for im in images:
+        im.free()
+    return dict(value=nblocks / best, unit='blocks/s', blocks=nblocks, block=[B, B], triangles=int(tris.shape[0]), image=[S, S], sigma=2.5,
+                median_conf=float(np.median(conf)), ms_per_call=1e3 * best,
+                note='best of 3 calls; both stacks rendered through their meshes from resident uint8 sections (exact piecewise-linear tier), '
+                     'masked DoG, padded NCC; results (dx, dy, conf per block) returned to the host')
 
 
 def cpu_baseline_ncc(h0, h1, seconds=20.0):
@@ -486,6 +528,8 @@ def main():
                                              note='every pair cropped to its own strip size (up to 29 x 11 px smaller); 32-pair chunks of unequal strips; second pass over the list (buffer pools warm)')
         fmatcher.stitching_matcher_batch_release()
         del h0, h1, host_pairs, outp, ragged, outr
+    if rank == 0 and world == 1 and not args.no_align:
+        line['align_block_matcher'] = bench_align(lib, ctx, _lib)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         H, W = shapes['LR']
         s0, s1, _ = strips['LR']
