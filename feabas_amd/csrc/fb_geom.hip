@@ -164,6 +164,38 @@ int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* 
     return FB_OK;
 }
 
+// The same tier decision for GENERAL triangulated meshes (renderer.MeshRenderer): block b = h x w pixels whose first pixel
+// sits at org [NB][2] (MOVING frame, offset removed); its candidate triangles cand [NB][cap] / count [NB] come from
+// fb_mesh_candidates_dev (host copies).  v_mov / v_img [V][2]: field domain and image-space vertices.  tier [NB]: 2 = block
+// affine with residue < tol (A6 filled), 3 = exact field, -1 = degenerate / flipped fit (the caller's statement-by-statement
+// route).  The global-affine test (tier 1) is the caller's (one fit per renderer).
+int fb_mesh_block_affines(fb_ctx* ctx, int V, const double* v_mov, const double* v_img, const int32_t* tris, int NB, const double* org,
+                          int h, int w, int cap, const int32_t* cand, const int32_t* count, double tol, int32_t* tier, double* A6) {
+    FB_CHECK_ARG(ctx, V > 0 && v_mov && v_img && tris && NB >= 0 && org && h > 0 && w > 0 && cap > 0 && cand && count && tier && A6);
+    std::vector<int> stamp((size_t)V, -1), members;
+    members.reserve(256);
+    for (int b = 0; b < NB; ++b) {
+        const double bx0 = org[2 * b] - 0.5, by0 = org[2 * b + 1] - 0.5, bx1 = bx0 + (double)w, by1 = by0 + (double)h;   // bbox0 - 0.5, renderer.py:405
+        members.clear();
+        const int nc = std::min(count[b], cap);
+        for (int k = 0; k < nc; ++k) {
+            const int32_t* t3 = tris + 3 * (size_t)cand[(size_t)b * cap + k];
+            if (!tri_hits_box(v_mov + 2 * (size_t)t3[0], v_mov + 2 * (size_t)t3[1], v_mov + 2 * (size_t)t3[2], bx0, by0, bx1, by1)) continue;
+            for (int a = 0; a < 3; ++a)
+                if (stamp[t3[a]] != b) { stamp[t3[a]] = b; members.push_back(t3[a]); }
+        }
+        tier[b] = 3;
+        double* a = A6 + 6 * (size_t)b;
+        a[0] = 1; a[1] = 0; a[2] = 0; a[3] = 0; a[4] = 1; a[5] = 0;
+        if (!(tol > 0) || members.empty()) continue;
+        std::sort(members.begin(), members.end());
+        const Fit f = fit_rows(v_mov, v_img, members.data(), (int)members.size());
+        if (!f.ok) { tier[b] = -1; continue; }
+        if (f.res < tol) { tier[b] = 2; a[0] = f.a00; a[1] = f.a10; a[2] = f.t0; a[3] = f.a01; a[4] = f.a11; a[5] = f.t1; }
+    }
+    return FB_OK;
+}
+
 // field_w_weight (renderer.py:259-300) for NB blocks: block e belongs to pair pair_of[e] (index into vm) and covers the
 // h x w output pixels at (x0, y0) = org[e]; every pixel is located in the MOVING triangles that can reach the block and
 // mapped to the image by linear interpolation of the INITIAL vertices (matplotlib.tri.LinearTriInterpolator in the

@@ -116,47 +116,20 @@ class MeshRenderer:
             A6[:] = pack(A_g)
             return tier, A6
         cand = d_cand.to_array((nb, cap), np.int32)
-        bi = np.repeat(np.arange(nb), cnt)
-        ti = cand[np.arange(cap)[None, :] < cnt[:, None]]
-        boxes = np.concatenate((org, org + np.array([w, h], dtype=np.float64)), axis=1) - 0.5        # bbox0 - 0.5, renderer.py:405
-        hit = _sat_hits(self.v0[self.tris[ti]], boxes[bi])
-        bi, ti = bi[hit], ti[hit]
-        # vertex subsets of all blocks at once: the least squares of spatial.py:44 on centred points is block diagonal (the
-        # 2x2 part solves the 2x2 normal equations, the translation row is mm0 - mm1 @ A; cf. deformed.fit_affine_rows);
-        # rank-deficient or flipped subsets go through the statement-by-statement function
-        nv = self.v0.shape[0]
-        key = np.unique((bi[:, None].astype(np.int64) * nv + self.tris[ti]).ravel())
-        gb, gv = key // nv, key % nv
-        start = np.searchsorted(gb, np.arange(nb + 1))
-        n = np.diff(start).astype(np.float64)
-        has = n > 0
-        nn = np.maximum(n, 1.0)
-        P1, P0 = self.v1[gv], self.v0[gv]
-        mean = lambda X: np.stack((np.bincount(gb, X[:, 0], nb), np.bincount(gb, X[:, 1], nb)), axis=-1) / nn[:, None]
-        m0, m1 = mean(P1), mean(P0)
-        c0, c1 = P1 - m0[gb], P0 - m1[gb]
-        outer = lambda X, Y: np.stack([np.bincount(gb, X[:, i] * Y[:, j], nb) for i in range(2) for j in range(2)], axis=-1).reshape(nb, 2, 2)
-        G, Hm = outer(c1, c1), outer(c1, c0)
-        detG = G[:, 0, 0] * G[:, 1, 1] - G[:, 0, 1] * G[:, 1, 0]
-        scale = np.maximum(G[:, 0, 0], G[:, 1, 1])
-        ok = has & (n >= 3) & (detG > 1e-9 * scale * scale)
-        A2 = np.tile(np.eye(2), (nb, 1, 1))
-        A2[ok] = np.linalg.solve(G[ok], Hm[ok])
-        ok &= np.linalg.det(A2) > 0
-        A = np.tile(np.eye(3), (nb, 1, 1))
-        A[:, :2, :2] = A2
-        A[:, 2, :2] = m0 - np.einsum('bi,bij->bj', m1, A2)
-        for b in np.flatnonzero(has & ~ok):
-            idx = gv[start[b]:start[b + 1]]
-            A[b] = fit_affine(self.v1[idx], self.v0[idx], return_rigid=True, svd_clip=None)[1]
-        d = P1 - (np.einsum('ki,kij->kj', P0, A[gb, :2, :2]) + A[gb, 2, :2])
-        res = np.full(nb, np.inf)
-        if gb.size:
-            first = start[:-1][has]
-            res[has] = np.sqrt(np.maximum.reduceat(np.sum(d * d, axis=-1), first))
-        good = has & (res < self.tol)                             # no triangle: bbox_affine_tform gives up, the exact tier masks it
-        tier[good] = 2
-        A6[good] = np.stack((A[good, 0, 0], A[good, 1, 0], A[good, 2, 0], A[good, 0, 1], A[good, 1, 1], A[good, 2, 1]), axis=-1)
+        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+        _lib.check(_lib.load().fb_mesh_block_affines(_lib.ctx(), self.v0.shape[0], _lib.ptr(self.v0), _lib.ptr(self.v1), _lib.ptr(self.tris), nb,
+                                                     _lib.ptr(np.ascontiguousarray(org)), h, w, cap, _lib.ptr(cand), _lib.ptr(cnt), self.tol,
+                                                     _lib.ptr(tier), _lib.ptr(A6)))
+        for b in np.flatnonzero(tier == -1):                      # rank-deficient or flipped vertex set: spatial.py:45-60
+            ti = cand[b, :cnt[b]]
+            box = np.concatenate((org[b], org[b] + np.array([w, h], dtype=np.float64))) - 0.5
+            ti = ti[_sat_hits(self.v0[self.tris[ti]], np.tile(box, (ti.size, 1)))]
+            idx = np.unique(self.tris[ti])
+            _, A_b = fit_affine(self.v1[idx], self.v0[idx], return_rigid=True, svd_clip=None)
+            tier[b] = 3
+            if affine_residue(self.v1[idx], self.v0[idx], A_b) < self.tol:
+                tier[b] = 2
+                A6[b] = pack(A_b)
         return tier, A6
 
     def render_stack_dev(self, bboxes):

@@ -165,6 +165,11 @@ int fb_dog_masks_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int 
  *   image space, 0 outside = StreamLoader fillval + BORDER_CONSTANT) through float32 maps relative to origin [NB][2]
  *   (out; = floor(min field) - 4 of the whole stack while it spans < 16300 px, common.py:264, 305-321, else per block).
  *   ext int32 [NB][4] = scratch (field extent per block).  out float32 [NB][h][w], mask uint8 [NB][h][w]. */
+/* fb_mesh_block_affines (host arrays, no device work): bbox_affine_tform + the tolerance test of crop_field
+ *   (renderer.py:397-416, 499-511) for every block from its candidate list: tier [NB] 2 = block affine (A6), 3 = exact field,
+ *   -1 = degenerate / flipped fit (caller's statement-by-statement route). */
+int fb_mesh_block_affines(fb_ctx* ctx, int V, const double* v_mov, const double* v_img, const int32_t* tris, int NB, const double* org,
+                          int h, int w, int cap, const int32_t* cand, const int32_t* count, double tol, int32_t* tier, double* A6);
 int fb_mesh_candidates_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris, int NB, const double* org, int h, int w, int cap,
                            int* cand, int* count);
 int fb_mesh_render_blocks_dev(fb_ctx* ctx, const void* img, int dtype, int IH, int IW, int img_x0, int img_y0, const double* v_mov,

@@ -412,3 +412,40 @@ def test_match_list_of_overlaps_bookkeeping(monkeypatch):
     i, j = overlaps[0]
     ov, wd = stitcher.bbox_intersections(bboxes[i], bboxes[j])
     assert seen[0][0][0][0].shape[0] <= ov[3] - ov[1] + 2 * int(0.5 * wd) and min(seen[0][0][0][0].shape) >= wd
+
+
+def test_renderer_pairwise_sat_matches_the_dense_form():
+    """renderer._sat_hits (candidate pairs) = deformed.tri_box_hits (all pairs): the `intersects` query of renderer.py:405"""
+    from feabas_amd import deformed, renderer
+    rng = np.random.default_rng(31)
+    tp = rng.uniform(0, 100, (40, 3, 2))
+    boxes = np.sort(rng.uniform(-10, 110, (25, 2, 2)), axis=1).reshape(25, 4)[:, [0, 1, 2, 3]]
+    boxes = np.stack((boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]), axis=-1)
+    dense = deformed.tri_box_hits(tp, boxes)
+    bi, ti = np.nonzero(np.ones_like(dense))
+    got = renderer._sat_hits(tp[ti], boxes[bi]).reshape(dense.shape)
+    np.testing.assert_array_equal(got, dense)
+    assert 0.05 < dense.mean() < 0.95
+
+
+def test_oracle_u8_remap_rule():
+    """the restated cv2 uint8 bilinear rule (oracle/pipeline_ref.remap_origin): integer maps return the pixels, a half-pixel
+    phase is the rounded mean, every value stays within 1/2 grey level of the float rule; zero outside the image"""
+    from oracle import pipeline_ref
+    rng = np.random.default_rng(32)
+    img = rng.integers(0, 256, (40, 50), dtype=np.uint8)
+    yy, xx = np.meshgrid(np.arange(30.0), np.arange(35.0), indexing='ij')
+    same = pipeline_ref.remap_origin(img, xx + 5, yy + 3, (2, 1))
+    np.testing.assert_array_equal(same, img[3:33, 5:40].astype(np.float32))
+    half = pipeline_ref.remap_origin(img, xx + 5.5, yy + 3, (2, 1))
+    a, b = img[3:33, 5:40].astype(np.int64), img[3:33, 6:41].astype(np.int64)
+    np.testing.assert_array_equal(half, ((a + b + 1) >> 1).astype(np.float32))
+    mx, my = xx + 4.3 + 0.01 * yy, yy + 2.7 - 0.02 * xx
+    u8 = pipeline_ref.remap_origin(img, mx, my, (0, 0))
+    f32 = pipeline_ref.remap_origin(img.astype(np.float32), mx, my, (0, 0))
+    assert np.abs(u8 - f32).max() <= 0.5 + 1e-4
+    out = pipeline_ref.remap_origin(img, xx - 100, yy, (-104, -4))
+    assert not out.any()
+    shifted = pipeline_ref.remap_origin(img, xx + 5, yy + 3, (2, 1), img_origin=(-7, 4))      # image pixel (0, 0) at (-7, 4)
+    np.testing.assert_array_equal(shifted[1:, :], img[0:29, 12:47].astype(np.float32))
+    assert not shifted[0].any()
