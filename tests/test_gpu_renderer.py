@@ -169,3 +169,38 @@ def test_iterative_matcher_general_path_vs_strip_oracle(fb, H, W, seed, shift, a
     assert abs(strain - exp['strain']) < 2e-3 * max(1.0, exp['strain'] / 0.01)
     if H == 3600:
         assert exp['deformed'] and len(exp['tiers']) == 2            # the deformed-mesh branch of the oracle, twice
+
+
+def test_section_matcher_recovers_a_known_field(fb):
+    """alignment-scale property test (no oracle at this size): section 1 is section 0 resampled through a known smooth
+    field of +-6 px; section_matcher over two irregular meshes (spacings 280 / 70 px, sigma 2.5, residue filter) must
+    return matches whose displacement is that field -- through two rounds of render / NCC / relaxation on the device."""
+    from scipy.ndimage import map_coordinates
+    from feabas_amd import matcher
+    rng = np.random.default_rng(41)
+    S = 1800
+    base = _texture(rng, S, S)
+    yy, xx = np.meshgrid(np.arange(S, dtype=np.float64), np.arange(S, dtype=np.float64), indexing='ij')
+
+    def field(x, y):
+        return (6.0 * np.sin(2 * np.pi * y / 1500.0 + 0.4) + 2.5 * (x / S) ** 2,
+                5.0 * np.cos(2 * np.pi * x / 1300.0) - 2.0 * (x / S) * (y / S))
+    ux, uy = field(xx, yy)
+    img1 = np.clip(np.rint(map_coordinates(base.astype(np.float32), [yy + uy, xx + ux], order=1, mode='nearest')), 0, 255).astype(np.uint8)
+    _, M0 = _meshes(rng, extent=(S - 1, S - 1), spacing=75.0, warp=0.0, offset=(0.0, 0.0))
+    _, M1 = _meshes(rng, extent=(S - 1, S - 1), spacing=75.0, warp=0.0, offset=(0.0, 0.0))
+    M0.uid, M1.uid = 0.0, 1.0
+    for M in (M0, M1):                                              # no prior alignment: MOVING = INITIAL
+        M._vertices[1] = None
+    trace = []
+    xy0, xy1, weight, strain = matcher.section_matcher(M0, M1, base, img1, spacings=[280, 70], conf_thresh=0.3, residue_len=3.0,
+                                                       compute_strain=True, trace=trace)
+    assert xy0 is not None and len(trace) == 2
+    assert trace[0]['blocks'] >= 25 and trace[1]['blocks'] >= 500
+    assert xy0.shape[0] > 0.8 * trace[1]['blocks']
+    ex, ey = field(xy1[:, 0], xy1[:, 1])
+    err = np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)      # q + u(q) = p
+    assert np.median(err) < 0.25 and np.quantile(err, 0.95) < 0.8
+    assert trace[1]['max_dis'] < trace[0]['max_dis']               # the first relaxation took most of the field out
+    assert 0.0 < strain < 0.05
+    assert np.all(weight > 0.3 * 0) and weight.shape[0] == xy0.shape[0]
