@@ -8,6 +8,7 @@
 //                      barycentric / image coefficients, every pixel keeps the hit of the smallest triangle index
 //                      (deterministic for pixels on shared edges).  PASS 0 reduces floor(min) / ceil(max) of the field
 //                      (the remap origin of common.py:316-321), PASS 1 samples.
+#include <algorithm>
 #include <climits>
 
 #include "fb_common.h"
@@ -20,19 +21,29 @@ constexpr int REC = 14;              // doubles per staged candidate
 constexpr double BARY_EPS = 1e-9;
 constexpr int MX_DIS = 16300;        // common.py:264: extent one remap call may cover
 
-__global__ void mesh_cand_kernel(int T, const double* __restrict__ vm, const int* __restrict__ tris, const double* __restrict__ org,
+// boxes of all triangles, rounded outwards to float32: one coalesced 16-byte read per triangle in the scan below instead of
+// three vertex gathers
+__global__ void tri_box_kernel(int T, const double* __restrict__ vm, const int* __restrict__ tris, float4* __restrict__ box) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
+        const double x0 = vm[2 * i0], y0 = vm[2 * i0 + 1], x1 = vm[2 * i1], y1 = vm[2 * i1 + 1], x2 = vm[2 * i2], y2 = vm[2 * i2 + 1];
+        box[t] = make_float4(__double2float_rd(fmin(x0, fmin(x1, x2))), __double2float_rd(fmin(y0, fmin(y1, y2))),
+                             __double2float_ru(fmax(x0, fmax(x1, x2))), __double2float_ru(fmax(y0, fmax(y1, y2))));
+    }
+}
+
+// the list is a superset of the triangles that meet the query box (outward rounding): its users test exactly
+__global__ void mesh_cand_kernel(int T, const float4* __restrict__ box, const double* __restrict__ org,
                                  int h, int w, int cap, int* __restrict__ cand, int* __restrict__ count) {
     const int b = blockIdx.x;
     __shared__ int n_hit;
     if (threadIdx.x == 0) n_hit = 0;
     __syncthreads();
-    const double bx0 = org[2 * b] - 0.5, by0 = org[2 * b + 1] - 0.5, bx1 = bx0 + (double)w, by1 = by0 + (double)h;
+    const double qx0 = org[2 * b] - 0.5, qy0 = org[2 * b + 1] - 0.5;
+    const float bx0 = __double2float_rd(qx0), by0 = __double2float_rd(qy0), bx1 = __double2float_ru(qx0 + (double)w), by1 = __double2float_ru(qy0 + (double)h);
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
-        const double x0 = vm[2 * i0], y0 = vm[2 * i0 + 1], x1 = vm[2 * i1], y1 = vm[2 * i1 + 1], x2 = vm[2 * i2], y2 = vm[2 * i2 + 1];
-        const double lx = fmin(x0, fmin(x1, x2)), hx = fmax(x0, fmax(x1, x2));
-        const double ly = fmin(y0, fmin(y1, y2)), hy = fmax(y0, fmax(y1, y2));
-        if (hx < bx0 || lx > bx1 || hy < by0 || ly > by1) continue;
+        const float4 bb = box[t];
+        if (bb.z < bx0 || bb.x > bx1 || bb.w < by0 || bb.y > by1) continue;
         const int k = atomicAdd(&n_hit, 1);
         if (k < cap) cand[(size_t)b * cap + k] = t;
     }
@@ -206,9 +217,18 @@ int fb_mesh_candidates_dev(fb_ctx* ctx, int T, const double* v_mov, const int* t
     if (NB == 0) return FB_OK;
     FB_CHECK_ARG(ctx, v_mov && tris && org && cand && count);
     FB_HIP(ctx, hipSetDevice(ctx->device));
-    FB_PROF(ctx, "mesh_cand");
-    hipLaunchKernelGGL(mesh_cand_kernel, dim3(NB), dim3(256), 0, ctx->stream, T, v_mov, tris, org, h, w, cap, cand, count);
-    FB_HIP(ctx, hipGetLastError());
+    if (T == 0) { FB_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int) * NB, ctx->stream)); return FB_OK; }
+    float4* box = nullptr;
+    FB_HIP(ctx, hipMalloc(&box, sizeof(float4) * (size_t)T));
+    {
+        FB_PROF_B(ctx, "mesh_cand", (double)T * 16.0 * NB);
+        hipLaunchKernelGGL(tri_box_kernel, dim3(std::min(fb_cdiv(T, 256), 4096)), dim3(256), 0, ctx->stream, T, v_mov, tris, box);
+        hipLaunchKernelGGL(mesh_cand_kernel, dim3(NB), dim3(256), 0, ctx->stream, T, box, org, h, w, cap, cand, count);
+    }
+    const hipError_t e = hipGetLastError();
+    hipStreamSynchronize(ctx->stream);
+    hipFree(box);
+    FB_HIP(ctx, e);
     return FB_OK;
 }
 
