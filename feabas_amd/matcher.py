@@ -186,6 +186,14 @@ def bboxes_mesh_renderer_matcher(mesh0, mesh1, image_loader0, image_loader1, bbo
     tol = kwargs.get('affine_approx_tol', 0.0)
     if kwargs.get('geodesic_mask', False) or kwargs.get('mask_range', None) is not None:
         raise NotImplementedError('geodesic_mask / mask_range are outside the device renderer')
+    from .mesh import Mesh
+
+    def as_mesh(m):                                                            # matcher.py:792-799: init dict or Mesh H5 file
+        if isinstance(m, dict):
+            m = dict(m)
+            return Mesh(m.pop('vertices'), m.pop('triangles'), **m)
+        return Mesh.from_h5(m) if isinstance(m, str) else m
+    mesh0, mesh1 = as_mesh(mesh0), as_mesh(mesh1)
     bboxes0 = np.asarray(bboxes0).reshape(-1, 4)
     bboxes1 = np.asarray(bboxes1).reshape(-1, 4)
     num_blocks = bboxes0.shape[0]

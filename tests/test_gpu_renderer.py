@@ -129,7 +129,16 @@ def test_bboxes_mesh_renderer_matcher_vs_oracle(fb, sigma, tol):
            for b0, b1 in ((bboxes0[:14], bboxes1[:14]), (bboxes0[14:], bboxes1[14:]))]
     exy0, exy1, econf = (np.concatenate([e[k] for e in exp]) for k in range(3))
     r0 = renderer.ResidentImage(img0, org); r1 = renderer.ResidentImage(img1, org)
-    xy0, xy1, conf = matcher.bboxes_mesh_renderer_matcher(M0, M1, r0, r1, bboxes0, bboxes1, sigma=sigma, affine_approx_tol=tol, batch_size=100)
+    if tol > 0:                                                       # meshes handed over as a Mesh H5 file / an init dict (matcher.py:792-799)
+        import os, tempfile
+        from feabas_amd import h5wire
+        with tempfile.TemporaryDirectory() as tmp:
+            M0.save_to_h5(os.path.join(tmp, 'm0.h5'))
+            as_dict = {k: v for k, v in h5wire.mesh_init_dict(M1, save_material=False).items() if k not in ('epsilon', 'name')}
+            xy0, xy1, conf = matcher.bboxes_mesh_renderer_matcher(os.path.join(tmp, 'm0.h5'), as_dict, r0, r1, bboxes0, bboxes1, sigma=sigma,
+                                                                  affine_approx_tol=tol, batch_size=100)
+    else:
+        xy0, xy1, conf = matcher.bboxes_mesh_renderer_matcher(M0, M1, r0, r1, bboxes0, bboxes1, sigma=sigma, affine_approx_tol=tol, batch_size=100)
     r0.free(); r1.free()
     assert xy0.shape == (24, 2) and conf.shape == (24,)
     strong = econf > 0.3
