@@ -592,6 +592,19 @@ def test_config0_readme_grid_matching_stage(fb):
     np.testing.assert_allclose(xy1 - (b1[:2] - bboxes[j][:2]), exp['xy1'], atol=2e-4)
     np.testing.assert_allclose(wt, exp['weight'], atol=2e-4)
     fb.matcher.stitching_matcher_batch_release()
+    # the match table crosses to the optimisation stage as the Stitcher HDF5 file (stitcher.py:126-222): written and read back
+    import os, tempfile
+    from feabas_amd import h5wire
+    with tempfile.TemporaryDirectory() as tmp:
+        fn = os.path.join(tmp, 'section.h5')
+        h5wire.save_stitcher_h5(fn, '/data', 4.0, [f'tile_{k}.png' for k in range(len(tiles))], bboxes, matches, strains)
+        m2, s2, _ = h5wire.load_stitcher_matches(fn)
+    assert set(m2) == set(matches)
+    for key in matches:
+        for a_, b_ in zip(matches[key], m2[key]):
+            np.testing.assert_array_equal(np.asarray(a_, dtype=np.float32), b_)
+        assert s2[key] == np.float32(strains[key])
+    matches = {key: tuple(np.asarray(v, dtype=np.float64) for v in val) for key, val in m2.items()}      # what --mode optimization sees
     # ... and the optimisation stage on top of these matches (stitcher.py:1012-1018): one mesh per tile at its nominal stage
     # position, links from the matches, SLM.optimize_linear on the device.  The tiles must end at their TRUE positions
     # (nominal + jitter) relative to tile 0 -- both hot paths, end to end.
