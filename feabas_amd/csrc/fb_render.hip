@@ -51,6 +51,42 @@ __global__ void mesh_cand_kernel(int T, const float4* __restrict__ box, const do
     if (threadIdx.x == 0) count[b] = n_hit;
 }
 
+// Mesh.tri_finder (mesh.py:2080-2188) for K points: every lane owns a point and walks the triangle boxes (a wave reads the
+// same box: broadcast loads), the exact barycentric test runs on box hits only; the smallest containing triangle index wins
+// (deterministic on shared edges).  blockIdx.y splits the triangle range, merged with atomicMin.
+__global__ void mesh_locate_kernel(int K, const double* __restrict__ pts, int T, int chunk, const float4* __restrict__ box,
+                                   const double* __restrict__ vm, const int* __restrict__ tris, int* __restrict__ tid_out) {
+#pragma clang fp contract(off)
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = k < K;
+    const double px = valid ? pts[2 * k] : 0.0, py = valid ? pts[2 * k + 1] : 0.0;
+    const float xd = __double2float_rd(px), xu = __double2float_ru(px), yd = __double2float_rd(py), yu = __double2float_ru(py);
+    const int t0 = blockIdx.y * chunk, t1 = min(T, t0 + chunk);
+    int best = INT_MAX;
+    for (int t = t0; t < t1; ++t) {
+        const float4 bb = box[t];
+        if (!valid || best != INT_MAX || bb.x > xu || bb.z < xd || bb.y > yu || bb.w < yd) continue;
+        const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
+        const double x0 = vm[2 * i0], y0 = vm[2 * i0 + 1];
+        const double e1x = vm[2 * i1] - x0, e1y = vm[2 * i1 + 1] - y0, e2x = vm[2 * i2] - x0, e2y = vm[2 * i2 + 1] - y0;
+        const double d = e1x * e2y - e1y * e2x;
+        if (d == 0.0) continue;
+        const double dx = px - x0, dy = py - y0;
+        const double l1 = (dx * e2y - dy * e2x) / d, l2 = (e1x * dy - e1y * dx) / d, l0 = (1.0 - l1) - l2;
+        if (l0 >= -BARY_EPS && l1 >= -BARY_EPS && l2 >= -BARY_EPS) best = t;
+    }
+    if (best != INT_MAX) atomicMin(&tid_out[k], best);
+}
+
+__global__ void locate_finish_kernel(int K, int* tid) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
+        if (tid[k] == INT_MAX) tid[k] = -1;
+}
+
+__global__ void fill_int_kernel(int n, int* p, int v) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+
 struct RenderArgs {
     const void* img; int dtype, IH, IW, img_x0, img_y0;
     const double* vm; const double* vi; const int* tris;
@@ -224,6 +260,34 @@ int fb_mesh_candidates_dev(fb_ctx* ctx, int T, const double* v_mov, const int* t
         FB_PROF_B(ctx, "mesh_cand", (double)T * 16.0 * NB);
         hipLaunchKernelGGL(tri_box_kernel, dim3(std::min(fb_cdiv(T, 256), 4096)), dim3(256), 0, ctx->stream, T, v_mov, tris, box);
         hipLaunchKernelGGL(mesh_cand_kernel, dim3(NB), dim3(256), 0, ctx->stream, T, box, org, h, w, cap, cand, count);
+    }
+    const hipError_t e = hipGetLastError();
+    hipStreamSynchronize(ctx->stream);
+    hipFree(box);
+    FB_HIP(ctx, e);
+    return FB_OK;
+}
+
+int fb_mesh_locate_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris, int K, const double* pts, int* tid) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, T >= 0 && K >= 0);
+    if (K == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, pts && tid && (T == 0 || (v_mov && tris)));
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(fill_int_kernel, dim3(fb_cdiv(K, 256)), dim3(256), 0, ctx->stream, K, tid, T == 0 ? -1 : INT_MAX);
+    if (T == 0) { FB_HIP(ctx, hipGetLastError()); return FB_OK; }
+    float4* box = nullptr;
+    FB_HIP(ctx, hipMalloc(&box, sizeof(float4) * (size_t)T));
+    {
+        FB_PROF(ctx, "mesh_locate");
+        hipLaunchKernelGGL(tri_box_kernel, dim3(std::min(fb_cdiv(T, 256), 4096)), dim3(256), 0, ctx->stream, T, v_mov, tris, box);
+        // enough workgroups to fill the chip: the triangle range is split when there are few points
+        const int gx = fb_cdiv(K, 256);
+        int gy = std::max(1, std::min(fb_cdiv(T, 2048), fb_cdiv(2048, gx)));
+        const int chunk = fb_cdiv(T, gy);
+        gy = fb_cdiv(T, chunk);
+        hipLaunchKernelGGL(mesh_locate_kernel, dim3(gx, gy), dim3(256), 0, ctx->stream, K, pts, T, chunk, box, v_mov, tris, tid);
+        hipLaunchKernelGGL(locate_finish_kernel, dim3(std::min(fb_cdiv(K, 256), 1024)), dim3(256), 0, ctx->stream, K, tid);
     }
     const hipError_t e = hipGetLastError();
     hipStreamSynchronize(ctx->stream);

@@ -358,6 +358,19 @@ class Mesh:
             xs, ys = self.grid_xs, self.grid_ys
             inside = (p[:, 0] >= xs[0]) & (p[:, 0] <= xs[-1]) & (p[:, 1] >= ys[0]) & (p[:, 1] <= ys[-1])
             return np.where(inside, self.locate_cartesian(p), -1).astype(np.int32)
+        if _lib._ctx is not None and self.num_triangles > 0:
+            # a device context exists: brute-force location on the GPU (fb_mesh_locate_dev) instead of rebuilding matplotlib's
+            # trapezoid map every time the gear moved
+            p = np.ascontiguousarray((np.asarray(pts, dtype=np.float64) - self.offset(gear)).reshape(-1, 2))
+            lib, ctx = _lib.load(), _lib.ctx()
+            bufs = [_lib.DeviceBuffer.from_array(np.ascontiguousarray(self.vertices(gear), dtype=np.float64)),
+                    _lib.DeviceBuffer.from_array(self.triangles), _lib.DeviceBuffer.from_array(p), _lib.DeviceBuffer(4 * max(1, p.shape[0]))]
+            try:
+                _lib.check(lib.fb_mesh_locate_dev(ctx, self.num_triangles, bufs[0].ptr, bufs[1].ptr, p.shape[0], bufs[2].ptr, bufs[3].ptr))
+                return bufs[3].to_array((p.shape[0],), np.int32)
+            finally:
+                for b in bufs:
+                    b.free()
         if gear not in self._trifinders:
             v = self.vertices(gear)
             self._trifinders[gear] = Triangulation(v[:, 0], v[:, 1], self.triangles).get_trifinder()

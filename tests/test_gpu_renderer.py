@@ -213,3 +213,24 @@ def test_section_matcher_recovers_a_known_field(fb):
     assert trace[1]['max_dis'] < trace[0]['max_dis']               # the first relaxation took most of the field out
     assert 0.0 < strain < 0.05
     assert np.all(weight > 0.3 * 0) and weight.shape[0] == xy0.shape[0]
+
+
+def test_device_point_location_vs_matplotlib(fb):
+    """Mesh.tri_finder on the device (fb_mesh_locate_dev) against matplotlib's trapezoid-map finder, which the reference uses
+    (mesh.py:2080-2188): same triangles for random points inside and outside an irregular deformed mesh"""
+    from matplotlib.tri import Triangulation
+    from feabas_amd import constant as const
+    rng = np.random.default_rng(51)
+    _, M = _meshes(rng, extent=(900, 700), spacing=30.0, warp=4.0, offset=(12.5, -7.25))
+    pts = np.stack((rng.uniform(-40, 960, 20000), rng.uniform(-40, 760, 20000)), axis=-1)
+    tid = M.tri_finder(pts, gear=const.MESH_GEAR_MOVING)
+    v = M.vertices(const.MESH_GEAR_MOVING)
+    p = pts - M.offset(const.MESH_GEAR_MOVING)
+    exp = np.asarray(Triangulation(v[:, 0], v[:, 1], M.triangles).get_trifinder()(p[:, 0], p[:, 1]))
+    assert (tid >= 0).mean() > 0.7 and (tid < 0).sum() > 500
+    differ = np.flatnonzero(tid != exp)
+    assert differ.size <= 5                                         # points within 1e-9 of an edge may go to either side
+    t2, B = M.cart2bary(pts[tid >= 0], const.MESH_GEAR_MOVING, tid=tid[tid >= 0])
+    assert B.min() > -1e-8
+    np.testing.assert_allclose(M.bary2cart(t2, B, const.MESH_GEAR_MOVING), pts[tid >= 0], atol=1e-8)
+    assert M.tri_finder(np.empty((0, 2)), gear=const.MESH_GEAR_MOVING).shape == (0,)
