@@ -204,10 +204,18 @@ def bboxes_mesh_renderer_matcher(mesh0, mesh1, image_loader0, image_loader1, bbo
     sz1 = np.round(common.bbox_sizes(bboxes1))
     chg = np.flatnonzero(np.any(np.diff(sz0, axis=0), axis=-1) | np.any(np.diff(sz1, axis=0), axis=-1))
     edges = np.concatenate(([0], chg + 1, [num_blocks]))
-    if batch_size is not None and batch_size < num_blocks:                     # matcher.py:811-817
+    # batch_size is the reference's host-memory knob (matcher.py:811-817).  With merge_batches (default) the device path sizes
+    # its batches for HBM instead -- at least 2^27 pixels per stack -- so that a round of small blocks is a few launches, not
+    # hundreds; the batch only enters the result through the stack-wide np.ptp of the masked DoG (common.py:369), i.e. for
+    # blocks that stick out of the mesh.  merge_batches=False reproduces the reference's batches exactly.
+    merge = kwargs.get('merge_batches', True)
+    if batch_size is not None and batch_size < num_blocks:
         parts = []
         for a, b in zip(edges[:-1], edges[1:]):
-            nbt = max(1, int(np.ceil((b - a) / batch_size)))
+            bs = batch_size
+            if merge:
+                bs = max(bs, (1 << 27) // max(1, int(sz0[a, 0] * sz0[a, 1]), int(sz1[a, 0] * sz1[a, 1])))
+            nbt = max(1, int(np.ceil((b - a) / bs)))
             parts.append(np.linspace(a, b, num=nbt + 1, endpoint=True))
         edges = np.unique(np.round(np.concatenate(parts)).astype(np.int32))
     own = []

@@ -11,5 +11,5 @@ pr.enable()
 runpy.run_path('tools/bench_section_matcher.py', run_name='__main__')
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
+pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(28)
 print(s.getvalue()[:9000])
