@@ -10,7 +10,14 @@ matcher (feabas_amd/stitch_pipeline.py) over one batch of --pairs-per-step pairs
 JSON line carries the FEM half of the metric ("fem": PCG iterations/s on the 1e6-DoF system of
 config[2]), the roofline of the dominant kernel and a CPU baseline timed with the oracle.
 With N > 1 every rank matches its own shard of pairs (no data-path collective) and the match
-tables are gathered with one RCCL all_gather per step; value = all pairs / max-over-ranks time.
+tables of a step meet on rank 0 through ONE gather (counts, then point-to-point transfers over
+RCCL: fb_gatherv_dev); value = all pairs / max-over-ranks time.  `--gpus N` without a launcher
+environment starts the N ranks itself (python -m torch.distributed.run as a child process, before
+anything in this process touches the GPU).  Beside the headline the line carries the two 8-GPU
+workloads of BASELINE.json scaled to the number of ranks (weak scaling): `stitch_sections`
+(config[3]: 8 sections x 400 tiles per rank = 760 edge + 722 corner pairs per section, one gather
+of the match table) and `align_sections` (config[4]: 16 sections x 250 k nodes per rank, every
+section relaxed against its locked neighbours, one all-gather of the node displacements).
 """
 import argparse
 import ctypes as C
@@ -46,10 +53,39 @@ def parse():
     ap.add_argument('--no-fem', action='store_true')
     ap.add_argument('--no-align', action='store_true', help='skip the alignment-side block matcher section')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-deformed', action='store_true', help='skip the 2-px-warp sub-record (deformed-mesh branch)')
     ap.add_argument('--fem-grid', type=int, default=708)
     ap.add_argument('--fem-iters', type=int, default=200)
     ap.add_argument('--fem-cpu-iters', type=int, default=40, help='iterations of the CPU baseline PCG (about 0.1 s each at 1e6 DoF)')
+    ap.add_argument('--stitch-sections', type=int, default=8, help='config[3]: sections of 400 tiles PER RANK (64 sections on 8 GPUs); 0: skip')
+    ap.add_argument('--align-sections', type=int, default=16, help='config[4]: sections of --align-grid^2 nodes PER RANK (128 sections on 8 GPUs); 0: skip')
+    ap.add_argument('--align-grid', type=int, default=500, help='nodes per side of a section mesh of config[4] (500 x 500 = 250 k nodes)')
+    ap.add_argument('--cpu-pool-seconds', type=float, default=20.0, help='wall-clock budget of the all-core CPU baseline (process pool); 0: skip')
+    ap.add_argument('--dry-run', action='store_true', help='no GPU work: the ranks exercise sharding and the exchange steps on synthetic tables over gloo (CPU tests)')
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`--gpus N` (N > 1) outside a launcher: start the N ranks as children of `python -m torch.distributed.run` and pass
+    rank 0's JSON line through.  Nothing here initialises the GPU (torch.cuda.device_count() does not on this image); a
+    child failure is this process's exit code."""
+    import socket
+    import subprocess
+    if not args.dry_run:
+        try:
+            import torch
+            ndev = torch.cuda.device_count()
+        except Exception:                                 # noqa: BLE001
+            ndev = 0
+        if ndev < args.gpus:
+            sys.stderr.write(f'bench.py: --gpus {args.gpus} asks for {args.gpus} ranks (one process per GPU) but {ndev} GPU(s) are visible on this host\n')
+            sys.exit(2)
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def ncc_bytes_model(H, W, spacings_blocks):
@@ -153,9 +189,12 @@ def bench_fem(args, lib, ctx, _lib):
         _, cit, _ = fem_ref.pcg(A, b, rtol=1e-30, maxiter=args.fem_cpu_iters)
         cdt = time.time() - t0
         out['cpu_baseline'] = dict(value=cit / cdt, unit='PCG iterations/s', cores=1, kind='port',
-                                   sample=f'{cit} iterations of oracle/fem_ref.pcg (scipy CSR, {A.nnz} non-zeros) on the same system, {cdt:.1f} s')
+                                   sample=f'{cit} iterations of oracle/fem_ref.pcg (scipy CSR, {A.nnz} non-zeros) on the same system, {cdt:.1f} s; '
+                                          'scipy SpMV is single threaded, so this is also the all-core figure of the reference path')
+        out['cpu_baseline']['scipy'] = fem_cpu_krylov(A, b)
     # hard variant: 5 k links, about one per 100 nodes -- the elastic term carries the solution
-    # across the mesh, >= 1e3 iterations
+    # across the mesh; solved to 1e-4 like the main system and to the reference's default tolerance 1e-7
+    # (default_alignment_configs.yaml: elastic_params.tol), where the smooth modes cost thousands of iterations
     del slm
     hard = build_fem_system(args.fem_grid, 5000, seed=1)
     hard._assemble(0, 1, 1)
@@ -165,6 +204,11 @@ def bench_fem(args, lib, ctx, _lib):
     t0 = time.time()
     rc = lib.fb_sys_solve(ctx, hard._sys, _lib.ptr(xh), 0, 1e-4, 0.0, 20000, 1, C.byref(it), C.byref(rr))
     out['hard_5k_links'] = dict(solve_to_1e4_s=time.time() - t0, solve_iters=it.value, solve_relres=rr.value, converged=bool(rc == 0))
+    xh[:] = 0
+    t0 = time.time()
+    rc = lib.fb_sys_solve(ctx, hard._sys, _lib.ptr(xh), 0, 1e-7, 0.0, 200000, 1, C.byref(it), C.byref(rr))
+    out['hard_5k_links'].update(solve_to_1e7_s=time.time() - t0, solve_to_1e7_iters=it.value, solve_to_1e7_relres=rr.value, solve_to_1e7_converged=bool(rc == 0))
+    del hard
     return out
 
 
@@ -249,24 +293,347 @@ def cpu_baseline_ncc(h0, h1, seconds=20.0):
     return done / dt, done, dt
 
 
+def run_jobs(jobs, ctxs, work, _lib):
+    """deal `jobs` round-robin to one host thread per context (thread t takes jobs t, t + T, ...) and return the results
+    in job order; every thread drives the device through its own context (HIP stream)"""
+    import threading
+    T = max(1, len(ctxs))
+    out = [None] * len(jobs)
+    errs = []
+
+    def worker(t):
+        try:
+            with _lib.using(ctxs[t]):
+                for j in range(t, len(jobs), T):
+                    out[j] = work(t, jobs[j])
+        except Exception as e:                            # noqa: BLE001 -- re-raised in the caller
+            errs.append(e)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    if errs:
+        raise errs[0]
+    return out
+
+
+def bench_stitch_sections(args, lib, _lib, rank, world, ctxs, ex, barrier, reduce_max):
+    """config[3] at weak scaling: every rank owns --stitch-sections whole sections (the contiguous slices of the section
+    list, stitch_main.py:146-159 / stitcher.py:375-392) of 20 x 20 tiles: 380 left-right + 380 up-down edge overlaps
+    (strips 4096 x 510 / 510 x 4096) and 722 diagonal corner overlaps (510 x 510) per section, all resident in HBM.
+    Edge pairs and corner pairs are timed separately; then ONE gather of the whole match table to rank 0."""
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    from feabas_amd import dist as fdist
+    nsec = args.stitch_sections
+    T = args.tile
+    ov = int(round(0.1 * T)) + 100
+    ov += ov % 2
+    P = args.sub_batch
+    kinds = {'LR': (T, ov, 380 * nsec), 'UD': (ov, T, 380 * nsec), 'corner': (ov, ov, 722 * nsec)}
+    strips, jobs = {}, {'edge': [], 'corner': []}
+    sec0 = rank * nsec                                     # first global section of this rank
+    base = 0
+    with _lib.using(ctxs[0]):
+        for ki, (k, (H, W, n)) in enumerate(kinds.items()):
+            s0 = _lib.DeviceBuffer(n * H * W); s1 = _lib.DeviceBuffer(n * H * W); sh = _lib.DeviceBuffer(n * 8)
+            done = 0
+            while done < n:                                # seeds: unique per (kind, global section, pair)
+                m = min(4096, n - done)
+                _lib.check(lib.fb_synth_strips_dev(ctxs[0], m, 10000000 * (ki + 1) + sec0 * 1000 + done, H, W, 2027, 20, 1, args.warp,
+                                                   s0.offset(done * H * W), s1.offset(done * H * W), sh.offset(done * 8)))
+                done += m
+            strips[k] = (s0, s1, sh.to_array((n, 2), np.int32), base)
+            base += n
+        _lib.check(lib.fb_sync(ctxs[0]))
+    for k in ('LR', 'UD'):                                 # interleaved so that both orientations are in flight
+        n = kinds[k][2]
+        jobs['edge'] += [(k, a, min(P, n - a)) for a in range(0, n, P)]
+    jobs['edge'].sort(key=lambda j: (j[1], j[0]))
+    n = kinds['corner'][2]
+    jobs['corner'] = [('corner', a, min(P, n - a)) for a in range(0, n, P)]
+    matchers = {}
+
+    def work(t, job):
+        k, a, cnt = job
+        H, W, _ = kinds[k]
+        key = (t, k, cnt)
+        if key not in matchers:
+            matchers[key] = StripBatchMatcher(cnt, H, W, residue_len=RESIDUE_LEN)
+        s0, s1, sh, gbase = strips[k]
+        res = matchers[key].match(s0.offset(a * H * W), s1.offset(a * H * W))
+        pid = res['pair'] + (gbase + a)
+        tab = np.concatenate((pid[:, None].astype(np.float32), res['xy0'].astype(np.float32), res['xy1'].astype(np.float32),
+                              res['weight'][:, None].astype(np.float32)), axis=1)
+        d = res['xy1'] - res['xy0'] + sh[a:a + cnt][res['pair']]
+        return tab, int(res['valid'].sum()), int(np.sum(np.abs(d).max(axis=1) < 0.5)) if d.size else 0
+
+    # set-up pass (untimed): every (thread, shape, count) matcher builds its buffers and relaxation system once
+    nthr = len(ctxs)
+    for grp in ('edge', 'corner'):
+        seen, warm = set(), []
+        for t in range(nthr):
+            for j in range(t, len(jobs[grp]), nthr):
+                key = (t, jobs[grp][j][0], jobs[grp][j][2])
+                if key not in seen:
+                    seen.add(key); warm.append((t, jobs[grp][j]))
+        import threading
+
+        def warm_thread(t):
+            with _lib.using(ctxs[t]):
+                for tt, jb in warm:
+                    if tt == t:
+                        work(t, jb)
+        ths = [threading.Thread(target=warm_thread, args=(t,)) for t in range(nthr)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+    out = dict(sections_per_rank=nsec, sections=nsec * world, tiles_per_section=400, pairs_per_matcher_call=P)
+    tables = []
+    for grp in ('edge', 'corner'):
+        barrier()
+        t0 = time.time()
+        res = run_jobs(jobs[grp], ctxs, work, _lib)
+        for h in ctxs:
+            _lib.check(lib.fb_sync(h), h=h)
+        dt_rank = time.time() - t0
+        barrier()
+        dt = reduce_max(time.time() - t0)
+        npairs = sum(j[2] for j in jobs[grp])
+        tables += [r[0] for r in res]
+        rows = sum(r[0].shape[0] for r in res)
+        out[grp] = dict(pairs=npairs * world, pairs_per_s=npairs * world / dt, seconds=dt, pairs_per_s_this_rank=npairs / dt_rank,
+                        matched=sum(r[1] for r in res), mean_matches_per_pair=rows / max(npairs, 1),
+                        matches_within_half_px_of_truth=sum(r[2] for r in res) / max(rows, 1),
+                        strip=list(kinds['LR'][:2]) if grp == 'edge' else list(kinds['corner'][:2]))
+    table = np.concatenate(tables, axis=0) if tables else np.zeros((0, 6), np.float32)
+    if ex is not None:
+        barrier()
+        t0 = time.time()
+        parts = ex.gatherv(table, root=0)
+        barrier()
+        dt = reduce_max(time.time() - t0)
+        rows = int(sum(p_.shape[0] for p_ in parts)) if parts is not None else None
+        out['gather'] = dict(seconds=dt, rows_on_root=rows, bytes_on_root=None if rows is None else rows * 24, backend=ex.backend,
+                             note='ONE gather of the float32 match table (pair id, xy0, xy1, weight: 24 B per match, the record of stitcher.py:144-151) '
+                                  'to rank 0: counts, then point-to-point transfers of exactly the bytes each rank holds')
+        out['edge']['pairs_per_s_incl_gather'] = out['edge']['pairs'] / (out['edge']['seconds'] + dt)
+    else:
+        out['gather'] = dict(seconds=0.0, rows_on_root=int(table.shape[0]), bytes_on_root=int(table.nbytes), backend='none (one rank)')
+    for m in matchers.values():
+        m.free()
+    for s0, s1, _, _ in strips.values():
+        s0.free(); s1.free()
+    return out
+
+
+def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_max):
+    """config[4] at weak scaling: every rank owns --align-sections sections (contiguous slice of the section list) of
+    grid x grid nodes; section g is linked to g - 1 and g + 1 by 50 k matches each and relaxed against them as LOCKED
+    neighbours through SLM.optimize_linear (the independent-unit mode of SURVEY.md sec.8e; aligner.py:696-727 with one
+    free section), then the node displacements of all sections are all-gathered once."""
+    from feabas_amd import mesh, optimizer
+    n = args.align_grid
+    nsec = args.align_sections
+    h = 20.0
+    xs = h * np.arange(n)
+    vx, vy = np.meshgrid(xs, xs)
+    v = np.stack((vx.ravel(), vy.ravel()), axis=-1)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+    tri = np.concatenate((np.stack((a, b, d), -1), np.stack((a, d, c), -1))).astype(np.int32)
+    L = h * (n - 1)
+
+    def field(g):                                           # smooth distortion of section g (a function of g alone: no exchange needed)
+        ph = 0.37 * g
+        return np.stack((6 * np.sin(2 * np.pi * v[:, 1] / L + ph) + 2 * np.cos(4 * np.pi * v[:, 0] / L - ph),
+                         5 * np.cos(2 * np.pi * v[:, 0] / L - ph) + 2 * np.sin(4 * np.pi * v[:, 1] / L + ph)), axis=-1)
+    prev = mesh.Mesh(v.copy(), tri, uid=0, locked=True)
+    cur = mesh.Mesh(v.copy(), tri, uid=1)
+    nxt = mesh.Mesh(v.copy(), tri, uid=2, locked=True)
+    slm = optimizer.SLM([prev, cur, nxt], [], stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    nl = 50000
+    g0 = 1 + rank * nsec                                    # section 0 of the stack is the locked anchor
+    disp = np.empty((nsec, n * n, 2))
+    iters = 0; t_solve = 0.0; relres = []
+    from feabas_amd import constant as const
+    barrier()
+    t0 = time.time()
+    for k in range(nsec):
+        g = g0 + k
+        rng = np.random.default_rng(7000 + g)
+        dg = field(g)
+        for m_, gg in ((prev, g - 1), (nxt, g + 1)):
+            m_.unlock(); m_.set_vertices(v + (field(gg) - dg), const.MESH_GEAR_MOVING); m_.lock()
+        cur.set_vertices(v.copy(), const.MESH_GEAR_MOVING)
+        links = []
+        for m0, m1 in ((prev, cur), (cur, nxt)):
+            tid = rng.integers(0, tri.shape[0], nl); B = rng.dirichlet((1, 1, 1), nl)
+            links.append(optimizer.Link(m0, m1, tid, tid, B, B, weight=rng.uniform(0.3, 1.0, nl).astype(np.float32)))
+        slm.links = links
+        t1 = time.time()
+        slm.optimize_linear(tol=1e-4)
+        t_solve += time.time() - t1
+        iters += slm.last_solve['iters']; relres.append(slm.last_solve['relres'])
+        disp[k] = cur.vertices_w_offset(const.MESH_GEAR_MOVING) - v
+    dt_rank = time.time() - t0
+    barrier()
+    dt = reduce_max(time.time() - t0)
+    # the relaxed section sits between its neighbours: displacement ~ mean of the neighbours' relative fields
+    k = nsec - 1
+    expect = 0.5 * ((field(g0 + k - 1) - field(g0 + k)) + (field(g0 + k + 1) - field(g0 + k)))
+    err = float(np.sqrt(np.mean((disp[k] - expect) ** 2)) / np.sqrt(np.mean(expect ** 2)))
+    out = dict(sections_per_rank=nsec, sections=nsec * world, nodes_per_section=n * n, dof_per_section=2 * n * n, links_per_section=2 * nl,
+               sections_per_s=nsec * world / dt, seconds=dt, seconds_this_rank=dt_rank, pcg_iters_this_rank=iters, optimize_linear_seconds_this_rank=t_solve,
+               worst_relres=float(max(relres)), rel_rms_distance_to_neighbour_mean_last_section=err,
+               note='per section: link set-up (host), device assembly, Jacobi-PCG to 1e-4 through SLM.optimize_linear; the symbolic pattern is kept across '
+                    'sections (matches against locked neighbours stay inside the triangles of the free mesh: fb_sys_update_links)')
+    if ex is not None:
+        barrier()
+        t0 = time.time()
+        allx = ex.allgather(disp)
+        barrier()
+        dtg = reduce_max(time.time() - t0)
+        out['allgather'] = dict(seconds=dtg, bytes=int(allx.nbytes), backend=ex.backend, shape=list(allx.shape))
+        out['sections_per_s_incl_allgather'] = nsec * world / (dt + dtg)
+    del slm
+    return out
+
+
+def _cpu_pool_worker(task):
+    import os as _os
+    for var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        _os.environ[var] = '1'
+    from oracle import pipeline_ref
+    a, b = task
+    pipeline_ref.match_pair(a, b, residue_len=RESIDUE_LEN)
+    return 1
+
+
+def cpu_baseline_pool(h0, h1, seconds):
+    """the reference's own scaling model (stitching_configs.yaml:18, config.py:301-310): a pool of worker processes, one
+    pair at a time each, one BLAS thread per worker, workers = the cores this process may run on"""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    per_pair = 0.3                                         # about 0.27 s per pair on one core
+    ntask = int(max(cores, min(h0.shape[0] * 8, cores * seconds / per_pair)))
+    tasks = [(h0[k % h0.shape[0]], h1[k % h0.shape[0]]) for k in range(ntask)]
+    ctx_mp = mp.get_context('spawn')
+    with ctx_mp.Pool(cores) as pool:
+        pool.map(_cpu_pool_worker, tasks[:cores])          # imports + first-call set-up outside the timed part
+        t0 = time.time()
+        pool.map(_cpu_pool_worker, tasks, chunksize=1)
+        dt = time.time() - t0
+    return ntask / dt, ntask, dt, cores
+
+
+def fem_cpu_krylov(A, b, seconds=12.0):
+    """scipy.sparse.linalg cg and minres with the reference's Jacobi preconditioner (optimizer.py:1962-1966)
+    on the identical A, b: iterations/s and time to ||Ax - b|| <= 1e-4 ||b|| (bounded by `seconds` per solver)"""
+    from scipy import sparse
+    from scipy.sparse import linalg as sla
+    dg = A.diagonal()
+    cond = dg.max() / 1000.0
+    M = sparse.diags(1.0 / np.clip(dg, min(1.0, cond), None))           # optimizer.py:1962-1966
+    bn = np.linalg.norm(b)
+    out = {}
+    for name, fn in (('cg', sla.cg), ('minres', sla.minres)):
+        st = dict(it=0, t0=time.time(), hit=None)
+
+        def cb(xk):
+            st['it'] += 1
+            if st['hit'] is None and st['it'] % 10 == 0:
+                if np.linalg.norm(A @ xk - b) <= 1e-4 * bn:
+                    st['hit'] = (st['it'], time.time() - st['t0'])
+            if time.time() - st['t0'] > seconds or st['hit'] is not None:
+                raise StopIteration
+        try:
+            if name == 'cg':
+                fn(A, b, M=M, rtol=1e-12, maxiter=100000, callback=cb)
+            else:
+                fn(A, b, M=M, rtol=1e-12, maxiter=100000, callback=cb)
+        except StopIteration:
+            pass
+        el = time.time() - st['t0']
+        out[name] = dict(iters_per_s=st['it'] / el, iterations=st['it'], seconds=el,
+                         to_1e4=None if st['hit'] is None else dict(iterations=st['hit'][0], seconds=st['hit'][1]),
+                         note='true residual checked every 10 iterations (its SpMV is inside the timing)')
+    return out
+
+
+def dry_run(args, rank, world):
+    """no GPU: the ranks exercise the sharding and the exchange steps of the sharded workloads over gloo on synthetic tables"""
+    import torch.distributed as dist
+    from feabas_amd import dist as fdist
+    ex = fdist.Exchange() if world > 1 else None
+    nsec = max(1, args.stitch_sections)
+    pairs = (760 + 722) * nsec * world
+    a, b = fdist.shard_range(pairs, rank, world)
+    rng = np.random.default_rng(rank)
+    rows = rng.integers(1, 5, b - a)
+    tab = np.concatenate([np.full((r, 6), a + i, dtype=np.float32) for i, r in enumerate(rows)])
+    parts = ex.gatherv(tab, root=0) if ex is not None else [tab]
+    sec = fdist.shard_range(max(1, args.align_sections) * world, rank, world)
+    allx = ex.allgather(np.full((sec[1] - sec[0], 4, 2), float(rank))) if ex is not None else np.zeros((1, sec[1] - sec[0], 4, 2))
+    if rank == 0:
+        ids = np.concatenate([p_[:, 0] for p_ in parts])
+        ok = bool(np.all(np.diff(ids) >= 0) and ids[0] == 0 and ids[-1] == pairs - 1 and np.unique(ids).size == pairs)
+        print(json.dumps(dict(metric='tile_pair_ncc_matches_per_s', value=None, unit='pairs/s', n_gpus=world, dry_run=True, ranks=world,
+                              pair_shards_cover_the_list=ok, gathered_rows=int(ids.size), allgather_shape=list(allx.shape),
+                              exchange_backend=ex.backend if ex is not None else 'none')))
+    if world > 1:
+        dist.barrier()
+        fdist.release_exchanges()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        spawn_ranks(args)                                  # does not return
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist = None
     torch = None
-    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):      # launched by torch.distributed.run
+    launched = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)      # by torch.distributed.run
+    if args.dry_run:
+        if launched:
+            import torch.distributed as dist
+            dist.init_process_group('gloo')
+        dry_run(args, rank, world)
+        return
+    rccl_ranks = 1
+    if launched:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        one = torch.ones(1, device='cuda')
+        dist.all_reduce(one)                               # an RCCL collective: the number of ranks that really take part
+        rccl_ranks = int(one.item())
     os.environ['FEABAS_HIP_DEVICE'] = str(local_rank)
 
     from feabas_amd import _lib
     from feabas_amd.stitch_pipeline import StripBatchMatcher
     lib, ctx = _lib.load(), _lib.ctx(local_rank)
+    ex = None
+    comm_ctx = None
+    if dist is not None and world > 1:
+        # the exchange steps go through the C ABI (fb_comm_* / fb_gatherv_dev / fb_allgather_dev) on a context of their own, so
+        # that a gather never queues behind the kernels of a matcher thread
+        from feabas_amd import dist as fdist
+        comm_ctx = _lib.new_context(local_rank)
+        ex = fdist.Exchange(ctx=comm_ctx)
+
+    def reduce_max(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     T = args.tile
     ov = int(round(0.1 * T)) + 100                        # 10 % overlap + margin 100 (stitching_configs.yaml:21)
@@ -291,18 +658,24 @@ def main():
         k = 'LR' if i % 2 == 0 else 'UD'
         H, W = shapes[k]
         s0, s1, _ = strips[k]
-        b = (i // 2) % (n_res // P)
+        b = (i // 2) % (strips[k][0].nbytes // (P * H * W))
         res = matchers[(k, (i // 2) % mper)].match(s0.offset(b * P * H * W), s1.offset(b * P * H * W))
         return k, b, res
 
+    gather_stats = dict(calls=0, rows_on_root=0)
+
     def exchange(batch):
-        # the one exchange of the sharded run: every rank's match table, gathered over RCCL (feabas_amd/dist.py) -- one
-        # gather per STEP (S matcher calls), so that the ranks meet once per 512 pairs and not once per 64
-        if dist is not None and batch:
-            from feabas_amd import dist as fdist
-            pid = np.concatenate([res['pair'] + (rank * 1000000 + i * P) for i, res in batch])
-            fdist.gather_match_table(pid, np.concatenate([r['xy0'] for _, r in batch]), np.concatenate([r['xy1'] for _, r in batch]),
-                                     np.concatenate([r['weight'] for _, r in batch]))
+        # the one exchange of the sharded run: every rank's match table of a STEP (S matcher calls) -> rank 0, one gather
+        # (counts, then exactly the bytes of every rank over RCCL point-to-point: fb_gatherv_dev)
+        if ex is not None and batch:
+            pid = np.concatenate([res['pair'] + i * P for i, res in batch])
+            tab = np.concatenate((pid[:, None].astype(np.float32), np.concatenate([r['xy0'] for _, r in batch]).astype(np.float32),
+                                  np.concatenate([r['xy1'] for _, r in batch]).astype(np.float32),
+                                  np.concatenate([r['weight'] for _, r in batch])[:, None].astype(np.float32)), axis=1)
+            parts = ex.gatherv(tab, root=0)
+            gather_stats['calls'] += 1
+            if parts is not None:
+                gather_stats['rows_on_root'] += int(sum(p_.shape[0] for p_ in parts))
 
     # every host thread drives the device through its own context (stream): a thread's synchronisation then waits for
     # its own kernels only, and kernels of different batches may overlap on the device
@@ -337,21 +710,29 @@ def main():
             return out
         import threading
         results = {}
+        errs = []
         cv = threading.Condition()
 
         def worker(mine, h):
             _lib.use_context(h)
-            for i in mine:
-                r = step(i)
+            try:
+                for i in mine:
+                    r = step(i)
+                    with cv:
+                        results[i] = r
+                        cv.notify_all()
+            except Exception as e:                        # noqa: BLE001 -- re-raised below; the other threads must not wait for this one
                 with cv:
-                    results[i] = r
+                    errs.append(e)
                     cv.notify_all()
 
         def comm():
             pending = []
             for i in idx:
                 with cv:
-                    cv.wait_for(lambda: i in results)
+                    cv.wait_for(lambda: i in results or errs)
+                    if errs:
+                        return
                     r = results[i]
                 pending.append((i, r[2]))
                 if len(pending) == S:
@@ -364,6 +745,8 @@ def main():
             t.start()
         for t in ths:
             t.join()
+        if errs:
+            raise errs[0]
         return results[idx[-1]]
 
     # one-time set-up outside the step count: every matcher instance builds its resident relaxation system, twiddle
@@ -409,11 +792,14 @@ def main():
             step((args.warmup + args.steps) * S + i)
         _lib.check(lib.fb_sync(ctx)); _lib.check(lib.fb_prof_enable(ctx, 0))
         prof = _lib.prof_snapshot(ctx)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt_rank = dt
+    dt = reduce_max(dt)
     pairs = args.steps * S * P * world
+    per_rank = [args.steps * S * P / dt_rank]
+    if dist is not None:
+        tl = [torch.zeros(1, dtype=torch.float64, device='cuda') for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([per_rank[0]], dtype=torch.float64, device='cuda'))
+        per_rank = [float(t_.item()) for t_ in tl]
 
     # correctness of the timed work: recovered translations = injected shifts, matches found
     k, b, res = last
@@ -472,7 +858,40 @@ def main():
                             pairs_per_step=P * S, pairs_per_matcher_call=P, strip=[Hl, Wl], sigma=2.5, conf_thresh=0.33, residue_mode='huber', residue_len=RESIDUE_LEN),
                 check=dict(global_shift_within_1px=f'{ok_shift}/{P}', mean_matches_per_pair=n_matches, matches_within_half_px_of_truth=ok_match,
                            pairs_with_deformed_mesh=int(res['deformed'].sum())),
-                roofline=roof)
+                roofline=roof, rccl_ranks=rccl_ranks, pairs_per_s_per_rank=per_rank,
+                match_table_gather=dict(per_step=1, calls=gather_stats['calls'], rows_on_root=gather_stats['rows_on_root'],
+                                        seconds_inside_timed_region_and_warmup=(ex.seconds if ex is not None else 0.0),
+                                        backend=(ex.backend if ex is not None else 'none (one rank)')))
+
+    if world == 1 and not args.no_deformed:
+        # the non-rigid branch, driver-visible: the same step on pairs whose strips differ by a smooth 2 px warp, so that the
+        # coarse blocks of a pair disagree and its mesh1 is relaxed to a deformed state between the spacings
+        n_def = 4 * P
+        dstrips = {}
+        for k, (H, W) in shapes.items():
+            s0 = _lib.DeviceBuffer(n_def * H * W); s1 = _lib.DeviceBuffer(n_def * H * W); sh = _lib.DeviceBuffer(n_def * 8)
+            _lib.check(lib.fb_synth_strips_dev(ctx, n_def, 700000 + (0 if k == 'LR' else 50000), H, W, 2026, 20, 1, 2.0, s0.ptr, s1.ptr, sh.ptr))
+            dstrips[k] = (s0, s1, sh.to_array((n_def, 2), np.int32))
+        _lib.check(lib.fb_sync(ctx))
+        keep = dict(strips)
+        strips.update(dstrips)
+        try:
+            run_steps(0, S)                                # one untimed step (the deformed path sizes its scratch on first use)
+            barrier()
+            t0 = time.time()
+            lastd = run_steps(S, 2 * S)
+            barrier()
+            dtd = time.time() - t0
+            kd, bd, resd = lastd
+            shd = strips[kd][2][bd * P:(bd + 1) * P]
+            dd = resd['xy1'] - resd['xy0'] + shd[resd['pair']]
+            line['deformed'] = dict(value=2 * S * P / dtd, unit='pairs/s', steps=2, warp_px=2.0, pairs_with_deformed_mesh_last_call=int(resd['deformed'].sum()),
+                                    pairs_per_call=P, matches_within_2p5_px_of_rigid_truth=float(np.mean(np.abs(dd).max(axis=1) < 2.5)) if dd.size else 0.0,
+                                    mean_matches_per_pair=resd['pair'].size / P)
+        finally:
+            strips.update(keep)
+            for s0, s1, _ in dstrips.values():
+                s0.free(); s1.free()
 
     if not args.no_fem:
         # FEM path (config[2]): every rank relaxes its own ~1e6-DoF section system -- sections are independent SLMs
@@ -482,11 +901,12 @@ def main():
         args._solo = (world == 1)
         fem = bench_fem(args, lib, ctx, _lib)
         if dist is not None:
-            from feabas_amd import dist as fdist
+            barrier()
             t0 = time.time()
-            parts = fdist.allgather_ragged(fem.pop('x').reshape(-1, 2))
-            fem['allgather_displacements_s'] = time.time() - t0
-            fem['allgather_bytes'] = int(sum(p.nbytes for p in parts))
+            allx = ex.allgather(fem.pop('x').reshape(-1, 2))       # one all-gather of the node displacements (fb_allgather_dev)
+            barrier()
+            fem['allgather_displacements_s'] = reduce_max(time.time() - t0)
+            fem['allgather_bytes'] = int(allx.nbytes)
             tt = torch.tensor([fem['iters_per_s']], dtype=torch.float64, device='cuda')
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             fem['iters_per_s_all_ranks'] = float(tt.item())
@@ -530,19 +950,51 @@ def main():
         del h0, h1, host_pairs, outp, ragged, outr
     if rank == 0 and world == 1 and not args.no_align:
         line['align_block_matcher'] = bench_align(lib, ctx, _lib)
+    cpu_strips = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         H, W = shapes['LR']
         s0, s1, _ = strips['LR']
         ns = min(32, n_res)
-        h0 = s0.to_array((ns, H, W), np.uint8); h1 = s1.to_array((ns, H, W), np.uint8)
+        cpu_strips = (s0.to_array((ns, H, W), np.uint8), s1.to_array((ns, H, W), np.uint8))
+    for s0, s1, _ in strips.values():
+        s0.free(); s1.free()
+    for m in matchers.values():
+        m.free()
+    if args.stitch_sections > 0:
+        st = bench_stitch_sections(args, lib, _lib, rank, world, ctxs, ex, barrier, reduce_max)
+        if dist is not None:
+            tl = [torch.zeros(1, dtype=torch.float64, device='cuda') for _ in range(world)]
+            dist.all_gather(tl, torch.tensor([st['edge'].pop('pairs_per_s_this_rank')], dtype=torch.float64, device='cuda'))
+            st['edge']['pairs_per_s_per_rank'] = [float(t_.item()) for t_ in tl]
+            st['corner'].pop('pairs_per_s_this_rank', None)
+        if rank == 0:
+            line['stitch_sections'] = st
+    if args.align_sections > 0:
+        al = bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_max)
+        if dist is not None:
+            tt = torch.tensor([float(al['pcg_iters_this_rank']), al['optimize_linear_seconds_this_rank']], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            al['pcg_iters_all_ranks'] = float(tt[0].item())
+        if rank == 0:
+            line['align_sections'] = al
+    if cpu_strips is not None:
+        h0, h1 = cpu_strips
         rate, done, secs = cpu_baseline_ncc(h0, h1)
         line['cpu_baseline'] = dict(value=rate, unit='pairs/s', cores=1, kind='port',
                                     sample=f'{done} LR pairs of the same synthetic strips through oracle/pipeline_ref.match_pair '
                                            f'(scipy.fft/ndimage, 1 process, {secs:.1f} s)')
+        if args.cpu_pool_seconds > 0:
+            # all host cores, the reference's own scaling model: a pool of single-threaded worker processes
+            prate, pn, psecs, cores = cpu_baseline_pool(h0, h1, args.cpu_pool_seconds)
+            line['cpu_baseline']['all_cores'] = dict(value=prate, unit='pairs/s', cores=cores, kind='port',
+                                                     sample=f'{pn} pairs (the same {h0.shape[0]} LR pairs repeated) over a pool of {cores} worker processes, one BLAS thread each, '
+                                                            f'{psecs:.1f} s; host logical CPUs {os.cpu_count()}')
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
+        if ex is not None:
+            ex.close()
         dist.destroy_process_group()
 
 

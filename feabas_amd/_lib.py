@@ -24,6 +24,7 @@ class FeabasHipError(RuntimeError):
 
 FB_ERR_NOCONV = -5
 FB_ERR_BREAKDOWN = -6
+FB_ERR_COMM = -7
 
 _lib = None
 _ctx = None
@@ -112,6 +113,14 @@ _PROTOS = {
     'fb_spmv_dev': (c_i, [c_p, c_p, c_p, c_p]),
     'fb_pcg_csr': (c_i, [c_p, c_p, c_p, c_p, c_i, c_d, c_d, c_i, c_i, C.POINTER(c_i), C.POINTER(c_d)]),
     'fb_pcg_fixed_iters': (c_i, [c_p, c_p, c_p, c_i, C.POINTER(c_d)]),
+    'fb_comm_unique_id': (c_i, [c_p, c_p]),
+    'fb_comm_create': (c_i, [c_p, c_p, c_i, c_i, C.POINTER(c_p)]),
+    'fb_comm_destroy': (None, [c_p, c_p]),
+    'fb_comm_info': (c_i, [c_p, c_p, C.POINTER(c_i), C.POINTER(c_i)]),
+    'fb_gatherv_dev': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i]),
+    'fb_allgather_dev': (c_i, [c_p, c_p, c_p, c_p, c_sz]),
+    'fb_allreduce_f64_dev': (c_i, [c_p, c_p, c_p, c_p, c_sz, c_i]),
+    'fb_sendrecv_dev': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
 }
 
 
@@ -161,6 +170,22 @@ def use_context(h):
     _tls.ctx = h
 
 
+class using:
+    """``with using(h):`` -- run the body with `h` as the calling thread's current context"""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __enter__(self):
+        self.prev = getattr(_tls, 'ctx', None)
+        _tls.ctx = self.h
+        return self.h
+
+    def __exit__(self, *exc):
+        _tls.ctx = self.prev
+        return False
+
+
 def destroy_context(h):
     """Destroy a context made by ``new_context`` (its stream, arena and every buffer it still owns)."""
     if h is not None and h != _ctx:
@@ -191,9 +216,10 @@ def ctx(device=None):
     return _ctx
 
 
-def check(rc, allow=()):
+def check(rc, allow=(), h=None):
+    """raise on a non-zero status; h = the context the call was made on (default: the calling thread's current one)"""
     if rc != 0 and rc not in allow:
-        msg = load().fb_last_error(ctx())
+        msg = load().fb_last_error(ctx() if h is None else h)
         raise FeabasHipError(rc, msg.decode() if msg else '?')
     return rc
 
@@ -230,6 +256,8 @@ class DeviceBuffer:
     def to_array(self, shape, dtype):
         out = np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes
+        # on the CALLING thread's context (stream): a buffer is read by the thread that queued the kernels filling it --
+        # matchers are built on one thread and driven from another, each with its own context (bench.py, matcher.py)
         check(load().fb_memcpy_d2h(ctx(), ptr(out), self.ptr, out.nbytes))
         return out
 

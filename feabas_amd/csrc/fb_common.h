@@ -57,10 +57,14 @@ struct fb_ctx {
     std::vector<void*> owned;   // fb_malloc'ed pointers
     size_t ncc_arena_limit = (size_t)8 << 30;
     bool use_rocfft = false;     // FEABAS_HIP_ROCFFT=1: streaming-class FFTs through rocFFT instead of the hand-written kernels
+    bool dog_tiles = false;      // FEABAS_HIP_DOG_TILES=1: the 64 x 64 tile kernel (dog_fast) instead of the streaming one (A/B)
     bool dog_exact = false;      // double-precision tap accumulation (scipy's arithmetic) instead of the float fast path
 };
 
 int fb_fail(fb_ctx* ctx, int code, const char* fmt, ...);
+std::string& fb_tls_err();          // last error message of the calling thread
+int fb_rocfft_acquire();            // process-wide reference count around rocfft_setup / rocfft_cleanup
+void fb_rocfft_release();
 
 #define FB_HIP(ctx, call)                                                                          \
     do {                                                                                           \

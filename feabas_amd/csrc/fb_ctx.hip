@@ -2,6 +2,7 @@
 #include "fb_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 
 #include <cstdlib>
@@ -12,8 +13,26 @@ int fb_fail(fb_ctx* ctx, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    // the message belongs to the calling thread: several host threads may share a context (or use one each), and
+    // fb_last_error is called by the thread whose call failed
+    fb_tls_err() = buf;
+    (void)ctx;
     return code;
+}
+
+std::string& fb_tls_err() {
+    static thread_local std::string e;
+    return e;
+}
+
+// rocFFT's setup / cleanup are process-global: counted over the contexts that initialised it, cleaned up by the last
+std::atomic<int> g_rocfft_users{0};
+int fb_rocfft_acquire() {
+    if (g_rocfft_users.fetch_add(1) == 0) return rocfft_setup() == rocfft_status_success ? 0 : -1;
+    return 0;
+}
+void fb_rocfft_release() {
+    if (g_rocfft_users.fetch_sub(1) == 1) rocfft_cleanup();
 }
 
 int fb_arena_reserve(fb_ctx* ctx, size_t bytes) {
@@ -85,6 +104,7 @@ fb_ctx* fb_create(int device_id) {
     ctx->device = device_id;
     if (const char* e = getenv("FEABAS_HIP_ROCFFT")) ctx->use_rocfft = atoi(e) != 0;
     if (const char* e = getenv("FEABAS_HIP_DOG_EXACT")) ctx->dog_exact = atoi(e) != 0;
+    if (const char* e = getenv("FEABAS_HIP_DOG_TILES")) ctx->dog_tiles = atoi(e) != 0;
     if (hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
@@ -107,14 +127,14 @@ void fb_destroy(fb_ctx* ctx) {
     if (ctx->fft_work) hipFree(ctx->fft_work);
     if (ctx->arena) hipFree(ctx->arena);
     for (void* p : ctx->owned) hipFree(p);
-    if (ctx->rocfft_ready) rocfft_cleanup();
+    if (ctx->rocfft_ready) fb_rocfft_release();
     hipEventDestroy(ctx->t0);
     hipEventDestroy(ctx->t1);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
-const char* fb_last_error(fb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* fb_last_error(fb_ctx* ctx) { (void)ctx; return fb_tls_err().c_str(); }
 
 int fb_sync(fb_ctx* ctx) {
     FB_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -426,10 +426,257 @@ int launch_fast(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int 
     return FB_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Streaming form of the fast path.  DoG = G(I) - G(G(I)) = G(I - G(I)) (G is linear, 'nearest' extension included), and
+// the two 1-D passes of a G commute, so the four passes run in the order  x, y, (I - .), y, x:
+//   A = Gx I        horizontal, out of an LDS staging tile of the input rows
+//   B = Gy A        vertical:   one thread per column, the last 2R rows of A live in registers
+//   D = I - B       (I delayed by R rows in registers)
+//   E = Gy D        vertical, second register window of the same thread
+//   out = Gx E      horizontal, out of an LDS staging tile, stored straight to HBM
+// A workgroup owns a band of TX output columns and a segment of SY rows and streams down the rows 8 at a time: nothing
+// is re-read in y except the 4R warm-up rows of a segment, the x halo costs 1 + 1.5 R / TX in arithmetic (a 64 x 64
+// tile with its 2R apron cost 1.55 x), every LDS address is a per-thread base plus an immediate, and the vertical passes
+// -- half of the arithmetic -- read each value once.  The 'nearest' extensions: rows / columns of the input outside the
+// image are clamped loads (A, B of a virtual column are then the replicas the next stage expects, because a vertical
+// pass commutes with column replication); D is replicated explicitly at the top (window initialised with D[0]) and at
+// the bottom (D[y > H-1] = D[H-1]).
+constexpr int SCH = 8;     // rows per chunk
+constexpr int SRN = 8;     // outputs per horizontal run
+
+__host__ __device__ constexpr int spitch(int cols) { int p = (cols + 3) / 4 * 4; return (p / 4) % 2 ? p : p + 4; }     // pitch / 4 odd
+
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int R>
+__device__ __forceinline__ float fir1(const float* w, const TapsF& t) {           // w[0 .. 2R], centre w[R]
+    float acc = w[R] * t.w[0];
+#pragma unroll
+    for (int k = R; k >= 1; --k) acc = fmaf(w[R - k] + w[R + k], t.w[k], acc);
+    return acc;
+}
+
+template <typename T, int R, int NT>
+__global__ __launch_bounds__(NT) void dog_stream(const T* __restrict__ img, float* __restrict__ out, int SH, int SW, int signed_out,
+                                                const int* __restrict__ sizes, const TapsF taps, int TX, int SY) {
+    constexpr int CH = SCH, RN = SRN;
+    constexpr int PI = spitch(NT + 2 * R + 8), PA = spitch(NT + 8), PE = spitch(NT + 8);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* In = smem;                    // [2][CH][PI]  input rows (float), column i <-> global x0 - 2R + i
+    float* A = In + 2 * CH * PI;         // [CH][PA]     A = Gx I,           column i <-> global x0 - R + i
+    float* E = A + CH * PA;              // [CH][PE]     E = Gy (I - Gy A),  column i <-> global x0 - R + i
+    const int n = blockIdx.z, x0 = blockIdx.x * TX, y0 = blockIdx.y * SY;
+    const int H = sizes ? sizes[2 * n] : SH, W = sizes ? sizes[2 * n + 1] : SW;
+    const int tid = threadIdx.x;
+    float* __restrict__ oimg = out + (size_t)n * SH * SW;
+    const int sw = min(TX, SW - x0);                           // band width inside the slot
+    if (x0 >= W || y0 >= H) {
+        // a band / segment of the slot outside the image: zero, so that windows cropped past the image border read the fill value
+        const int rows = min(SY, SH - y0);
+        for (int i = tid; i < rows * sw; i += NT) oimg[(uint32_t)((y0 + i / sw) * SW + x0 + i % sw)] = 0.f;
+        return;
+    }
+    const T* __restrict__ src = img + (size_t)n * SH * SW;
+    const int bw = min(TX, W - x0);                            // image columns of the band
+    const int NV = bw + 2 * R;                                 // columns of the vertical passes (<= NT)
+    const int NA = (NV + RN - 1) / RN * RN;                    // columns of A computed by the first pass (<= NT)
+    const int NIN = NA + 2 * R;                                // input columns staged
+    const int ye = min(y0 + SY, H);
+    const bool top = y0 == 0;
+    const int a0 = top ? 0 : y0 - 2 * R;                       // first input row fed
+    const int nch = (ye + 2 * R - a0 + CH - 1) / CH;
+    // per-thread constants
+    const int gx_a = min(max(x0 - 2 * R + tid, 0), W - 1), gx_b = min(max(x0 - 2 * R + tid + NT, 0), W - 1);
+    const bool ld_b = tid + NT < NIN;
+    const int nr1 = NA / RN, nr2 = (bw + RN - 1) / RN;
+    const bool h1_on = tid < CH * nr1, h2_on = tid < CH * nr2, v_on = tid < NV;
+    const int r1 = tid / nr1, u1 = tid - r1 * nr1, r2 = tid / nr2, u2 = tid - r2 * nr2;
+    const int cxv = min(max(x0 - R + tid, 0), W - 1) - (x0 - R);     // clamped column (index in A / E space) of the vertical thread
+    float wA[2 * R], dI[R], wD[2 * R], dlast = 0.f;
+    float pa[CH], pb[CH];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < CH; ++r) {
+            const int gy = min(max(a0 + c * CH + r, 0), H - 1);
+            pa[r] = load_px(src, (uint32_t)(gy * SW + gx_a));
+            if (ld_b) pb[r] = load_px(src, (uint32_t)(gy * SW + gx_b));
+        }
+    };
+    auto stage = [&](int c) {
+        float* dst = In + (c & 1) * CH * PI;
+#pragma unroll
+        for (int r = 0; r < CH; ++r) {
+            dst[r * PI + tid] = pa[r];
+            if (ld_b) dst[r * PI + tid + NT] = pb[r];
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const float* in = In + (c & 1) * CH * PI;
+        if (c + 1 < nch) fetch(c + 1);
+        // ---- A = Gx I: RN outputs from RN + 2R staged values
+        if (h1_on) {
+            float v[RN + 2 * R];
+            const float4* p4 = reinterpret_cast<const float4*>(in + r1 * PI + u1 * RN);
+#pragma unroll
+            for (int q = 0; q < (RN + 2 * R) / 4; ++q) { const float4 f = p4[q]; v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
+            float o[RN];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) o[j] = fir1<R>(v + j, taps);
+            float4* d4 = reinterpret_cast<float4*>(A + r1 * PA + u1 * RN);
+            d4[0] = make_float4(o[0], o[1], o[2], o[3]);
+            d4[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (c + 1 < nch) stage(c + 1);
+        __syncthreads();
+        // ---- B = Gy A, D = I - B, E = Gy D on the thread's column
+        if (v_on) {
+            float fa[2 * R + CH], fi[R + CH], fd[2 * R + CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { fa[2 * R + j] = A[j * PA + cxv]; fi[R + j] = in[j * PI + cxv + R]; }
+            if (c == 0) {
+#pragma unroll
+                for (int i = 0; i < 2 * R; ++i) wA[i] = fa[2 * R];          // rows above the first fed row: replicas (exact at the image top)
+#pragma unroll
+                for (int i = 0; i < R; ++i) dI[i] = fi[R];
+#pragma unroll
+                for (int i = 0; i < 2 * R; ++i) wD[i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * R; ++i) { fa[i] = wA[i]; fd[i] = wD[i]; }
+#pragma unroll
+            for (int i = 0; i < R; ++i) fi[i] = dI[i];
+            const int rD0 = a0 + c * CH - R;                                 // image row of D[0] of this chunk
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float d = fi[j] - fir1<R>(fa + j, taps);
+                dlast = (rD0 + j <= H - 1) ? d : dlast;                      // D[y > H-1] = D[H-1]
+                fd[2 * R + j] = dlast;
+            }
+            if (top && c == R / CH) {
+                // the image's first row of D has just been computed: every row above it is its replica
+                const float d0 = fd[2 * R + R % CH];
+#pragma unroll
+                for (int i = 0; i < 2 * R + R % CH; ++i) fd[i] = d0;
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) E[j * PE + tid] = fir1<R>(fd + j, taps);
+#pragma unroll
+            for (int i = 0; i < 2 * R; ++i) { wA[i] = fa[CH + i]; wD[i] = fd[CH + i]; }
+#pragma unroll
+            for (int i = 0; i < R; ++i) dI[i] = fi[CH + i];
+        }
+        __syncthreads();
+        // ---- out = Gx E, rows a0 + c CH - 2R + r
+        if (h2_on) {
+            const int gy = a0 + c * CH - 2 * R + r2;
+            if (gy >= y0 && gy < ye) {
+                float v[RN + 2 * R];
+                const float4* p4 = reinterpret_cast<const float4*>(E + r2 * PE + u2 * RN);
+#pragma unroll
+                for (int q = 0; q < (RN + 2 * R) / 4; ++q) { const float4 f = p4[q]; v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
+                float o[RN];
+#pragma unroll
+                for (int j = 0; j < RN; ++j) { const float g = fir1<R>(v + j, taps); o[j] = signed_out ? g : fabsf(g); }
+                const int gx = x0 + u2 * RN;
+                float* d = oimg + (uint32_t)(gy * SW + gx);
+                if (gx + RN <= W) {
+                    *reinterpret_cast<float4u*>(d) = (float4u){o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<float4u*>(d + 4) = (float4u){o[4], o[5], o[6], o[7]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < RN; ++j)
+                        if (gx + j < x0 + sw) d[j] = gx + j < W ? o[j] : 0.f;          // slot pixels right of the image: 0
+                }
+            }
+        }
+    }
+    // slot pixels of the band right of / below the image (per-image sizes): 0
+    if (sizes) {
+        if (x0 + bw < x0 + sw && bw % RN == 0) {               // the partial-run branch above did not reach them
+            const int wz = sw - bw;
+            for (int i = tid; i < (ye - y0) * wz; i += NT) oimg[(uint32_t)((y0 + i / wz) * SW + x0 + bw + i % wz)] = 0.f;
+        }
+        const int yz = min(y0 + SY, SH);
+        if (ye < yz)
+            for (int i = tid; i < (yz - ye) * sw; i += NT) oimg[(uint32_t)((ye + i / sw) * SW + x0 + i % sw)] = 0.f;
+    }
+}
+
+struct StreamPlan { int NT, TX, nb, SY, nseg; };
+
+// band / segment geometry: TX + 2R <= NT, bands of equal width; segments so that the grid fills the chip in whole rounds
+inline StreamPlan plan_stream(int N, int H, int W, int R, int num_cu) {
+    StreamPlan best{0, 0, 0, 0, 0};
+    double best_cost = 1e300;
+    for (int NT : {64, 192}) {
+        const int txmax = NT - 2 * R;
+        if (txmax < 16) continue;
+        const int nb = (W + txmax - 1) / txmax, TX = (W + nb - 1) / nb;
+        // thread slots per chunk of 8 rows: two horizontal sweeps + two vertical passes of NT threads each
+        const double per_px = (double)nb * NT / W;
+        const double cost = per_px * (NT == 64 ? 1.08 : 1.0);            // small workgroups pay a little more per barrier / prologue
+        if (cost < best_cost) { best_cost = cost; best = StreamPlan{NT, TX, nb, 0, 0}; }
+    }
+    // segments: about 4 workgroups per CU resident; whole rounds of the grid, rows per segment >= 64
+    const int lds_wgs = best.NT == 64 ? 8 : 5;
+    const double cap = (double)num_cu * lds_wgs;
+    int best_seg = 1;
+    double best_t = 1e300;
+    for (int nseg = 1; nseg <= std::max(1, H / 64); ++nseg) {
+        const int SY = ((H + nseg - 1) / nseg + SCH - 1) / SCH * SCH;
+        const int ns = (H + SY - 1) / SY;
+        const double wgs = (double)N * best.nb * ns;
+        const double rounds = std::ceil(wgs / cap);
+        const double t = rounds * (SY + 4.0 * R + 16.0);
+        if (t < best_t - 1e-9) { best_t = t; best_seg = ns; best.SY = SY; }
+    }
+    best.nseg = best_seg;
+    return best;
+}
+
+template <typename T, int R, int NT>
+int launch_stream_nt(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const TapsF& tf, const int* sizes, const StreamPlan& pl) {
+    constexpr int PI = spitch(NT + 2 * R + 8), PA = spitch(NT + 8), PE = spitch(NT + 8);
+    const size_t lds = (size_t)(2 * SCH * PI + SCH * PA + SCH * PE) * sizeof(float);
+    auto kern = dog_stream<T, R, NT>;
+    FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(pl.nb, pl.nseg, N);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, H, W, signed_out, sizes, tf, pl.TX, pl.SY);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+template <typename T, int R>
+int launch_stream(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const Taps& taps, const int* sizes) {
+    TapsF tf;
+    for (int k = 0; k <= kMaxRadius; ++k) tf.w[k] = (float)taps.w[k];
+    if ((size_t)H * W >= ((size_t)1 << 30)) return fb_fail(ctx, FB_ERR_ARG, "fb_dog: image of %d x %d pixels exceeds the 32-bit offsets of the fast kernel", H, W);
+    if (N > 65535) return fb_fail(ctx, FB_ERR_ARG, "fb_dog: more than 65535 images in one launch");
+    const StreamPlan pl = plan_stream(N, H, W, R, ctx->prop.multiProcessorCount);
+    if (pl.nseg > 65535) return fb_fail(ctx, FB_ERR_ARG, "fb_dog: image too tall for one launch");
+    if (pl.NT == 64) return launch_stream_nt<T, R, 64>(ctx, img, out, N, H, W, signed_out, tf, sizes, pl);
+    return launch_stream_nt<T, R, 192>(ctx, img, out, N, H, W, signed_out, tf, sizes, pl);
+}
+
 template <typename T>
 int launch_fast_any(fb_ctx* ctx, int r, const T* img, float* out, int N, int H, int W, int signed_out, const Taps& taps, bool* done,
                     const int* sizes = nullptr) {
     *done = true;
+    if (!ctx->dog_tiles) {
+        switch (r) {
+            case 5: return launch_stream<T, 5>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+            case 6: return launch_stream<T, 6>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+            case 8: return launch_stream<T, 8>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+            case 10: return launch_stream<T, 10>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+            case 12: return launch_stream<T, 12>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+            case 14: return launch_stream<T, 14>(ctx, img, out, N, H, W, signed_out, taps, sizes);
+            default: *done = false; return FB_OK;
+        }
+    }
     switch (r) {
         case 5: return launch_fast<T, 5>(ctx, img, out, N, H, W, signed_out, taps, sizes);
         case 6: return launch_fast<T, 6>(ctx, img, out, N, H, W, signed_out, taps, sizes);

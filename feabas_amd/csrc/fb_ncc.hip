@@ -238,7 +238,8 @@ __global__ void ncc_peak_final(const float* __restrict__ Csurf, const PeakPartia
 
 int ensure_rocfft(fb_ctx* ctx) {
     if (ctx->rocfft_ready) return FB_OK;
-    FB_FFT(ctx, rocfft_setup());
+    if (fb_rocfft_acquire() != 0) return fb_fail(ctx, FB_ERR_FFT, "rocfft_setup failed");
+    ctx->rocfft_ready = true;               // from here on fb_destroy releases the reference
     FB_FFT(ctx, rocfft_execution_info_create(&ctx->fft_info));
     FB_FFT(ctx, rocfft_execution_info_set_stream(ctx->fft_info, ctx->stream));
     ctx->rocfft_ready = true;

@@ -28,37 +28,202 @@ def _device(dist):
     return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
 
 
+class Exchange:
+    """The exchange steps of a sharded run: ``gatherv`` (every rank's variable-length table -> the
+    root: counts first, then point-to-point transfers of exactly the bytes each rank holds -- nothing is padded and only
+    the root receives) and ``allgather`` (equal contributions: node displacements).
+
+    On the GPU box the transfers go through the C ABI (``fb_comm_*`` / ``fb_gatherv_dev`` / ``fb_allgather_dev``: one RCCL
+    communicator on the context's stream, device buffers; the 128-byte communicator id travels through the
+    ``torch.distributed`` group that launched the ranks).  With a gloo group (CPU tests, no GPU) the same steps run as
+    ``torch.distributed`` point-to-point operations on host tensors."""
+
+    def __init__(self, group=None, backend=None, ctx=None):
+        """collective over `group`.  ctx: the fb_ctx whose stream carries the transfers (default: the caller's current
+        context); a host thread that only communicates should own one, so that a gather does not queue behind kernels"""
+        torch, dist = _dist()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if backend is None:
+            backend = 'rccl' if dist.get_backend(group) == 'nccl' else 'torch'
+        self.backend = backend
+        self.comm = None
+        self.seconds = 0.0            # wall time spent inside gatherv / allgather (host view, includes the copies)
+        self.bytes = 0
+        if backend == 'rccl':
+            import ctypes as C
+            from . import _lib
+            self._lib, self._C = _lib, C
+            lib, ctx = _lib.load(), (_lib.ctx() if ctx is None else ctx)
+            ident = np.zeros(128, dtype=np.uint8)
+            if self.rank == 0:
+                _lib.check(lib.fb_comm_unique_id(ctx, _lib.ptr(ident)))
+            box = [ident.tobytes()]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = np.frombuffer(box[0], dtype=np.uint8).copy()
+            h = C.c_void_p()
+            _lib.check(lib.fb_comm_create(ctx, _lib.ptr(ident), self.rank, self.world, C.byref(h)))
+            self.comm, self._ctx = h, ctx
+
+    def close(self):
+        if self.comm is not None:
+            self._lib.load().fb_comm_destroy(self._ctx, self.comm)
+            self.comm = None
+
+    # -- counts of every rank (one int64 each)
+    def _counts(self, n):
+        torch, dist = _dist()
+        if self.backend == 'rccl':
+            _lib, lib = self._lib, self._lib.load()
+            mine = _lib.DeviceBuffer.from_array(np.array([n], dtype=np.int64))
+            allc = _lib.DeviceBuffer(8 * self.world)
+            _lib.check(lib.fb_allgather_dev(self._ctx, self.comm, mine.ptr, allc.ptr, 8), h=self._ctx)
+            out = allc.to_array((self.world,), np.int64)
+            mine.free(); allc.free()
+            return out
+        dev = _device(dist)
+        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+        cnts = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(cnts, cnt, group=self.group)
+        return cnts.cpu().numpy()
+
+    def _scope(self):
+        import contextlib
+        return self._lib.using(self._ctx) if self.backend == 'rccl' else contextlib.nullcontext()
+
+    def gatherv(self, arr, root=0):
+        with self._scope():
+            return self._gatherv(arr, root)
+
+    def allgather(self, arr):
+        with self._scope():
+            return self._allgather(arr)
+
+    def _gatherv(self, arr, root=0):
+        """arr [n_r, ...] (first dimension differs between ranks) -> on `root` the list of every rank's array, elsewhere
+        None.  One count exchange + one grouped set of transfers to the root."""
+        import time
+        t0 = time.perf_counter()
+        torch, dist = _dist()
+        arr = np.ascontiguousarray(arr)
+        tail, row = arr.shape[1:], int(np.prod(arr.shape[1:], dtype=np.int64)) * arr.dtype.itemsize
+        cnts = self._counts(arr.shape[0])
+        nbytes = cnts * row
+        total = int(nbytes.sum())
+        out = None
+        if self.backend == 'rccl':
+            _lib, lib = self._lib, self._lib.load()
+            send = _lib.DeviceBuffer.from_array(arr) if arr.nbytes else None
+            recv = _lib.DeviceBuffer(total) if self.rank == root and total else None
+            cb = np.ascontiguousarray(nbytes, dtype=np.int64)
+            _lib.check(lib.fb_gatherv_dev(self._ctx, self.comm, send.ptr if send else None, _lib.ptr(cb), recv.ptr if recv else None, root), h=self._ctx)
+            if self.rank == root:
+                flat = recv.to_array((total,), np.uint8) if recv else np.empty(0, np.uint8)
+                offs = np.concatenate(([0], np.cumsum(nbytes)))
+                out = [flat[offs[r]:offs[r + 1]].view(arr.dtype).reshape((int(cnts[r]),) + tail) for r in range(self.world)]
+            else:
+                _lib.check(lib.fb_sync(self._ctx), h=self._ctx)
+            for b in (send, recv):
+                if b is not None:
+                    b.free()
+        else:
+            dev = _device(dist)
+            ops, bufs = [], []
+            if self.rank == root:
+                for r in range(self.world):
+                    if r == root or cnts[r] == 0:
+                        continue
+                    t = torch.empty(int(nbytes[r]), dtype=torch.uint8, device=dev)
+                    bufs.append((r, t))
+                    ops.append(dist.P2POp(dist.irecv, t, dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group))
+            elif arr.nbytes:
+                t = torch.from_numpy(arr.reshape(-1).view(np.uint8).copy()).to(dev)
+                ops.append(dist.P2POp(dist.isend, t, dist.get_global_rank(self.group, root) if self.group is not None else root, group=self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if self.rank == root:
+                got = {r: t.cpu().numpy() for r, t in bufs}
+                out = []
+                for r in range(self.world):
+                    if r == root:
+                        out.append(arr)
+                    elif cnts[r] == 0:
+                        out.append(np.empty((0,) + tail, dtype=arr.dtype))
+                    else:
+                        out.append(got[r].view(arr.dtype).reshape((int(cnts[r]),) + tail))
+        self.seconds += time.perf_counter() - t0
+        self.bytes += total if self.rank == root else arr.nbytes
+        return out
+
+    def _allgather(self, arr):
+        """equal-shaped arr of every rank -> array [world, ...] on every rank (one collective)"""
+        import time
+        t0 = time.perf_counter()
+        torch, dist = _dist()
+        arr = np.ascontiguousarray(arr)
+        if self.backend == 'rccl':
+            _lib, lib = self._lib, self._lib.load()
+            send = _lib.DeviceBuffer.from_array(arr)
+            recv = _lib.DeviceBuffer(arr.nbytes * self.world)
+            _lib.check(lib.fb_allgather_dev(self._ctx, self.comm, send.ptr, recv.ptr, arr.nbytes), h=self._ctx)
+            out = recv.to_array((self.world,) + arr.shape, arr.dtype)
+            send.free(); recv.free()
+        else:
+            dev = _device(dist)
+            t = torch.from_numpy(arr.reshape(-1).view(np.uint8).copy()).to(dev)
+            o = torch.empty(t.numel() * self.world, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(o, t, group=self.group)
+            out = o.cpu().numpy().view(arr.dtype).reshape((self.world,) + arr.shape)
+        self.seconds += time.perf_counter() - t0
+        self.bytes += arr.nbytes * self.world
+        return out
+
+
+_default_exchange = {}
+
+
+def exchange(group=None):
+    """the process's Exchange for `group` (created on first use: collective -- every rank of the group must call it)"""
+    key = id(group)
+    if key not in _default_exchange:
+        _default_exchange[key] = Exchange(group)
+    return _default_exchange[key]
+
+
+def release_exchanges():
+    for ex in _default_exchange.values():
+        ex.close()
+    _default_exchange.clear()
+
+
 def allgather_ragged(arr, group=None):
-    """all-gather of per-rank arrays whose first dimension differs.  Returns the list of every rank's array.
-    Two collectives: the row counts, then one padded all_gather_into_tensor."""
+    """all-gather of per-rank arrays whose first dimension differs: the list of every rank's array, on every rank.
+    A gatherv to rank 0 would do for the match table (north star: one gather); this form is for callers that need the
+    table everywhere (the coupled-window set-up, tests).  Counts first, then every rank's exact bytes (no padding)."""
     torch, dist = _dist()
+    ex = exchange(group)
     arr = np.ascontiguousarray(arr)
-    world = dist.get_world_size(group)
-    dev = _device(dist)
-    cnt = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
-    cnts = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(cnts, cnt, group=group)
-    cnts = cnts.cpu().numpy()
-    mx = int(cnts.max())
-    tail = arr.shape[1:]
-    pad = np.zeros((mx,) + tail, dtype=arr.dtype)
-    pad[:arr.shape[0]] = arr
-    t = torch.from_numpy(pad).to(dev)
-    out = torch.empty((world * mx,) + tail, dtype=t.dtype, device=dev)
-    dist.all_gather_into_tensor(out, t, group=group)
-    out = out.cpu().numpy().reshape((world, mx) + tail)
-    return [out[r, :cnts[r]] for r in range(world)]
+    parts = None
+    for root in range(ex.world):
+        got = ex.gatherv(arr, root=root)
+        if got is not None:
+            parts = got
+    return parts
 
 
-def gather_match_table(pair_ids, xy0, xy1, weight, pair_offset=0, group=None):
-    """Match tables of all ranks as one table [M, 6] = (global pair id, x0, y0, x1, y1, weight), float64,
-    ordered by rank (= by global pair id for contiguous shards).  The on-disk layout of the reference
-    concatenates xy0, xy1, weight per pair the same way (stitcher.py:144-151)."""
-    tab = np.concatenate((np.asarray(pair_ids, dtype=np.float64).reshape(-1, 1) + pair_offset,
-                          np.asarray(xy0, dtype=np.float64).reshape(-1, 2), np.asarray(xy1, dtype=np.float64).reshape(-1, 2),
-                          np.asarray(weight, dtype=np.float64).reshape(-1, 1)), axis=1)
-    parts = allgather_ragged(tab, group=group)
-    return np.concatenate(parts, axis=0)
+def gather_match_table(pair_ids, xy0, xy1, weight, pair_offset=0, group=None, root=0, dtype=np.float64):
+    """Match tables of all ranks as one table [M, 6] = (pair id, x0, y0, x1, y1, weight) on `root` (None on the other
+    ranks; root=None: on every rank), ordered by rank (= by global pair id for contiguous shards).  dtype float64 keeps
+    the matcher's precision; float32 is the wire format -- the reference stores concat(xy0, xy1, weight) per pair as
+    float32 (stitcher.py:144-151), 24 bytes per row, pair ids exact up to 2^24."""
+    tab = np.concatenate((np.asarray(pair_ids, dtype=dtype).reshape(-1, 1) + dtype(pair_offset),
+                          np.asarray(xy0, dtype=dtype).reshape(-1, 2), np.asarray(xy1, dtype=dtype).reshape(-1, 2),
+                          np.asarray(weight, dtype=dtype).reshape(-1, 1)), axis=1)
+    if root is None:
+        return np.concatenate(allgather_ragged(tab, group=group), axis=0)
+    parts = exchange(group).gatherv(tab, root=root)
+    return None if parts is None else np.concatenate(parts, axis=0)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

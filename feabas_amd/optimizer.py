@@ -517,9 +517,18 @@ class SLM:
                     cols.append((m.triangles[tid] + offs[m.uid] // 2).astype(np.int32))
             node_rows.append(np.concatenate(cols, axis=-1))
         nodes6 = np.ascontiguousarray(np.concatenate(node_rows, axis=0), dtype=np.int32) if node_rows else np.zeros((0, 6), np.int32)
-        key = (tuple((m.uid, offs[m.uid], m.num_vertices, m.triangles.ctypes.data) for m in self.meshes), nodes6.tobytes())
+        mesh_key = tuple((m.uid, offs[m.uid], m.num_vertices, m.triangles.ctypes.data) for m in self.meshes)
+        key = (mesh_key, nodes6.tobytes())
         if self._sys is not None and key == self._sys_key:
             return links
+        if self._sys is not None and self._sys_key[0] == mesh_key and nodes6.shape[0] and np.all(np.any(nodes6 < 0, axis=1)):
+            # same free meshes, and every match has a locked side: its couplings stay inside one triangle of a free mesh,
+            # which the pattern already holds (a section relaxed against locked neighbours, aligner.py:696-727 with one free
+            # section) -- the links are swapped without a new symbolic phase
+            rc = lib.fb_sys_update_links(ctx, self._sys, nodes6.shape[0], _lib.ptr(nodes6))
+            if rc == 0:
+                self._sys_key = key
+                return links
         self._drop_system()
         nv = dof // 2
         sysh = C.c_void_p()

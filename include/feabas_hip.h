@@ -333,6 +333,33 @@ int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, d
 /* exactly `iters` PCG iterations with no convergence exit (throughput bench) */
 int fb_pcg_fixed_iters(fb_ctx* ctx, fb_csr* A, const double* b_host, int iters, double* relres);
 
+/* ------------------------------------------------------------------ exchange steps of a sharded run
+ * (SURVEY.md sec.8b "fb_gatherv / fb_allgather (RCCL wrappers)", sec.8e).  The reference shards its pair / section
+ * lists over worker PROCESSES and collects their results through the process pool (stitcher.py:375-392, 386-392;
+ * aligner.py:588); here one process per GPU owns a contiguous shard and the results meet through RCCL over xGMI.
+ * One communicator per context; every call enqueues on the context's stream and takes device pointers.  The 128-byte
+ * id comes from fb_comm_unique_id on one rank and reaches the others out of band (torch.distributed store, a file, MPI).
+ * librccl is bound at run time, so a single-GPU process never loads it; every failure returns FB_ERR_COMM. */
+#define FB_COMM_ID_BYTES 128
+#define FB_REDUCE_SUM 0
+#define FB_REDUCE_MAX 1
+typedef struct fb_comm fb_comm;
+int fb_comm_unique_id(fb_ctx* ctx, void* id128);
+int fb_comm_create(fb_ctx* ctx, const void* id128, int rank, int world, fb_comm** out);
+void fb_comm_destroy(fb_ctx* ctx, fb_comm* comm);
+int fb_comm_info(fb_ctx* ctx, fb_comm* comm, int* rank, int* world);
+/* match table of every rank -> `root` (what Stitcher.dispatch_matchers merges from its workers, stitcher.py:386-392):
+ * counts [world] = bytes of every rank's contribution (host array, the same on all ranks); recv (root only) gets the
+ * contributions back to back in rank order.  Point-to-point transfers: nothing is padded, only the root receives. */
+int fb_gatherv_dev(fb_ctx* ctx, fb_comm* comm, const void* send, const int64_t* counts, void* recv, int root);
+/* equal contributions of bytes_per_rank (node displacements of a rank's sections; counts for fb_gatherv_dev) */
+int fb_allgather_dev(fb_ctx* ctx, fb_comm* comm, const void* send, void* recv, size_t bytes_per_rank);
+/* the fused scalar reduction of the coupled-window PCG (aligner.py:510-535, 696-727 solve one system over sections) */
+int fb_allreduce_f64_dev(fb_ctx* ctx, fb_comm* comm, const double* send, double* recv, size_t n, int op);
+/* halo exchange of the coupled window: grouped point-to-point transfers with the ranks of the neighbouring sections */
+int fb_sendrecv_dev(fb_ctx* ctx, fb_comm* comm, int nsend, const int* send_peer, const void* const* send_ptr, const int64_t* send_bytes,
+                    int nrecv, const int* recv_peer, void* const* recv_ptr, const int64_t* recv_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -875,3 +875,27 @@ def mesh_stiffness_mixed(v_shape, v_cur, triangles, tri_mult, model, nu, matmult
                 K = K + sparse.csr_matrix(((Ke * mm).ravel(), (i1.ravel(), i2.ravel())), shape=(ndof, ndof))
                 np.add.at(V, Td[sel].ravel(), (Pe * mm).ravel())
     return sparse.csr_matrix(K), stress + V
+
+
+def newton_fixed_point(m_locked, m_free, links, tri_mult, model, nu, matmult, stiffness_lambda=1.0, crosslink_lambda=1.0,
+                       max_steps=30, tol=1e-6):
+    """Fixed point of SLM.optimize_Newton_Raphson (optimizer.py:1440-1544) for one free mesh with non-linear elements
+    linked to a locked one, with fixed (positive) lambdas: every step re-assembles the tangent stiffness and the internal
+    force at the current MOVING gear (mesh.py:2937-3083), solves the tangent system exactly (sparse LU instead of the
+    reference's Krylov legs, whose exits depend on wall-clock settings) and applies the field like optimize_linear
+    (optimizer.py:1433-1434).  The internal force is float32 like the reference's stress (mesh.py:3068-3072), which floors
+    ||b|| at a few 1e-7 of its first value: `tol` sits above that floor.  The fixed point does not depend on the iteration path.  Returns the list of ||b|| per step."""
+    from scipy.sparse.linalg import spsolve
+    t = m_free.triangles
+    costs = []
+    for _ in range(max_steps):
+        K, stress = mesh_stiffness_mixed(m_free.vertices(GEAR_FIXED), m_free.vertices(GEAR_MOVING), t, tri_mult, model, nu, matmult)
+        C, rhs = crosslink_terms([m_locked, m_free], links, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING)
+        A = (stiffness_lambda * m_free.soft_factor) * K + crosslink_lambda * C.astype(np.float64)
+        b = crosslink_lambda * rhs - (stiffness_lambda * m_free.soft_factor) * stress.astype(np.float64)
+        costs.append(float(np.linalg.norm(b)))
+        if costs[-1] <= tol * costs[0]:
+            break
+        d = spsolve(sparse.csc_matrix(0.5 * (A + A.T)), b)
+        m_free.set_field(d.reshape(-1, 2), gear=(GEAR_MOVING, GEAR_MOVING))
+    return costs

@@ -34,8 +34,18 @@ def _worker(rank, world, port, outdir):
     # ragged local tables: pair p has (p % 4) + 1 matches
     pid = np.concatenate([np.full((p % 4) + 1, p - a) for p in range(a, b)])
     xy0 = rng.standard_normal((pid.size, 2)); xy1 = xy0 + 0.25; w = rng.uniform(0.3, 1, pid.size)
-    table = fdist.gather_match_table(pid, xy0, xy1, w, pair_offset=a)
+    table = fdist.gather_match_table(pid, xy0, xy1, w, pair_offset=a, root=None)          # on every rank
+    root_only = fdist.gather_match_table(pid, xy0, xy1, w, pair_offset=a, root=world - 1, dtype=np.float32)    # one gather to one rank, wire precision
+    assert (root_only is not None) == (rank == world - 1)
+    if root_only is not None:
+        assert root_only.dtype == np.float32
+        np.testing.assert_allclose(root_only, table, rtol=1e-6, atol=1e-6)
     parts = fdist.allgather_ragged(np.arange(3 + rank, dtype=np.float64).reshape(-1, 1) + 10 * rank)
+    eq = fdist.exchange().allgather(np.full((2, 3), float(rank)))
+    assert eq.shape == (world, 2, 3) and all(np.all(eq[r] == r) for r in range(world))
+    empty = fdist.exchange().gatherv(np.zeros((0, 6)) if rank == 0 else np.ones((rank, 6)), root=0)      # an empty contribution
+    if rank == 0:
+        assert [p.shape[0] for p in empty] == list(range(world))
     np.savez(os.path.join(outdir, f'r{rank}.npz'), table=table, local=np.concatenate((pid[:, None] + a, xy0, xy1, w[:, None]), axis=1),
              p0=parts[0], p1=parts[1])
     dist.barrier()
