@@ -209,6 +209,18 @@ def bench_fem(args, lib, ctx, _lib):
     rc = lib.fb_sys_solve(ctx, hard._sys, _lib.ptr(xh), 0, 1e-7, 0.0, 200000, 1, C.byref(it), C.byref(rr))
     out['hard_5k_links'].update(solve_to_1e7_s=time.time() - t0, solve_to_1e7_iters=it.value, solve_to_1e7_relres=rr.value, solve_to_1e7_converged=bool(rc == 0))
     del hard
+    # few links: the mesh is pinned at 50 points only and the smooth modes between them are what the Jacobi-PCG has to work for
+    sparse_ = build_fem_system(args.fem_grid, 50, seed=2)
+    sparse_._assemble(0, 1, 1)
+    sl, cl = sparse_.relative_lambda_trace(1.0, -1.0)
+    _lib.check(lib.fb_sys_form(ctx, sparse_._sys, sl, cl))
+    xh[:] = 0
+    t0 = time.time()
+    rc = lib.fb_sys_solve(ctx, sparse_._sys, _lib.ptr(xh), 0, 1e-7, 0.0, 400000, 1, C.byref(it), C.byref(rr))
+    dt_s = time.time() - t0
+    out['hard_50_links'] = dict(solve_to_1e7_s=dt_s, solve_to_1e7_iters=it.value, solve_to_1e7_relres=rr.value, converged=bool(rc == 0),
+                                iters_per_s=it.value / max(dt_s, 1e-9))
+    del sparse_
     return out
 
 
@@ -458,20 +470,24 @@ def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_
     disp = np.empty((nsec, n * n, 2))
     iters = 0; t_solve = 0.0; relres = []
     from feabas_amd import constant as const
-    barrier()
-    t0 = time.time()
+    # the matches of every section pair (what the matching stage delivers) and the neighbours' fields are inputs: made
+    # before the clock starts
+    inputs = []
     for k in range(nsec):
         g = g0 + k
         rng = np.random.default_rng(7000 + g)
         dg = field(g)
-        for m_, gg in ((prev, g - 1), (nxt, g + 1)):
-            m_.unlock(); m_.set_vertices(v + (field(gg) - dg), const.MESH_GEAR_MOVING); m_.lock()
-        cur.set_vertices(v.copy(), const.MESH_GEAR_MOVING)
-        links = []
-        for m0, m1 in ((prev, cur), (cur, nxt)):
-            tid = rng.integers(0, tri.shape[0], nl); B = rng.dirichlet((1, 1, 1), nl)
-            links.append(optimizer.Link(m0, m1, tid, tid, B, B, weight=rng.uniform(0.3, 1.0, nl).astype(np.float32)))
-        slm.links = links
+        lk = [(rng.integers(0, tri.shape[0], nl), rng.dirichlet((1, 1, 1), nl), rng.uniform(0.3, 1.0, nl).astype(np.float32)) for _ in range(2)]
+        inputs.append((v + (field(g - 1) - dg), v + (field(g + 1) - dg), lk))
+    zero = np.zeros((1, 2))
+    barrier()
+    t0 = time.time()
+    for k in range(nsec):
+        vp, vn, lk = inputs[k]
+        for m_, vv in ((prev, vp), (nxt, vn)):
+            m_.unlock(); m_.set_vertices(vv, const.MESH_GEAR_MOVING); m_.lock()
+        cur.set_vertices(v.copy(), const.MESH_GEAR_MOVING); cur.set_offset(zero, const.MESH_GEAR_MOVING)
+        slm.links = [optimizer.Link(m0, m1, tid, tid, B, B, weight=w) for (m0, m1), (tid, B, w) in zip(((prev, cur), (cur, nxt)), lk)]
         t1 = time.time()
         slm.optimize_linear(tol=1e-4)
         t_solve += time.time() - t1

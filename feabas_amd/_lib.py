@@ -73,6 +73,7 @@ _PROTOS = {
     'fb_dog_sizes_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_d, c_i, c_p]),
     'fb_dog_masks_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
     'fb_mesh_block_affines': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_d, c_p, c_p]),
+    'fb_mesh_block_uncovered': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_mesh_locate_dev': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
     'fb_mesh_candidates_dev': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     'fb_mesh_render_blocks_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -458,10 +458,11 @@ __device__ __forceinline__ float fir1(const float* w, const TapsF& t) {         
 }
 
 template <typename T, int R, int NT>
-__global__ __launch_bounds__(NT) void dog_stream(const T* __restrict__ img, float* __restrict__ out, int SH, int SW, int signed_out,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 : (R <= 12 ? 3 : 2)))) void dog_stream(const T* __restrict__ img, float* __restrict__ out, int SH, int SW, int signed_out,
                                                 const int* __restrict__ sizes, const TapsF taps, int TX, int SY) {
     constexpr int CH = SCH, RN = SRN;
-    constexpr int PI = spitch(NT + 2 * R + 8), PA = spitch(NT + 8), PE = spitch(NT + 8);
+    constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
+    constexpr int NQ = (RN + 2 * R + 3) / 4;               // float4 reads per horizontal run (over-reads up to 3 staged values)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* In = smem;                    // [2][CH][PI]  input rows (float), column i <-> global x0 - 2R + i
     float* A = In + 2 * CH * PI;         // [CH][PA]     A = Gx I,           column i <-> global x0 - R + i
@@ -495,20 +496,35 @@ __global__ __launch_bounds__(NT) void dog_stream(const T* __restrict__ img, floa
     const int cxv = min(max(x0 - R + tid, 0), W - 1) - (x0 - R);     // clamped column (index in A / E space) of the vertical thread
     float wA[2 * R], dI[R], wD[2 * R], dlast = 0.f;
     float pa[CH], pb[CH];
+    // LDS offsets of the thread's items (floats): every access below is one of these plus an immediate
+    const int o1r = r1 * PI + u1 * RN, o1w = r1 * PA + u1 * RN, o2r = r2 * PE + u2 * RN;
+    const uint32_t absmask = signed_out ? 0xffffffffu : 0x7fffffffu;
     auto fetch = [&](int c) {
+        const int ya = a0 + c * CH;
+        if (ya >= 0 && ya + CH <= H) {                     // uniform: rows inside the image
+            const uint32_t oa = (uint32_t)(ya * SW + gx_a), ob = (uint32_t)(ya * SW + gx_b);
 #pragma unroll
-        for (int r = 0; r < CH; ++r) {
-            const int gy = min(max(a0 + c * CH + r, 0), H - 1);
-            pa[r] = load_px(src, (uint32_t)(gy * SW + gx_a));
-            if (ld_b) pb[r] = load_px(src, (uint32_t)(gy * SW + gx_b));
+            for (int r = 0; r < CH; ++r) pa[r] = load_px(src, oa + (uint32_t)(r * SW));
+            if (ld_b) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) pb[r] = load_px(src, ob + (uint32_t)(r * SW));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < CH; ++r) pa[r] = load_px(src, (uint32_t)(min(max(ya + r, 0), H - 1) * SW + gx_a));
+            if (ld_b) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) pb[r] = load_px(src, (uint32_t)(min(max(ya + r, 0), H - 1) * SW + gx_b));
+            }
         }
     };
     auto stage = [&](int c) {
-        float* dst = In + (c & 1) * CH * PI;
+        float* dst = In + (c & 1) * CH * PI + tid;
 #pragma unroll
-        for (int r = 0; r < CH; ++r) {
-            dst[r * PI + tid] = pa[r];
-            if (ld_b) dst[r * PI + tid + NT] = pb[r];
+        for (int r = 0; r < CH; ++r) dst[r * PI] = pa[r];
+        if (ld_b) {
+#pragma unroll
+            for (int r = 0; r < CH; ++r) dst[r * PI + NT] = pb[r];
         }
     };
     fetch(0);
@@ -519,14 +535,14 @@ __global__ __launch_bounds__(NT) void dog_stream(const T* __restrict__ img, floa
         if (c + 1 < nch) fetch(c + 1);
         // ---- A = Gx I: RN outputs from RN + 2R staged values
         if (h1_on) {
-            float v[RN + 2 * R];
-            const float4* p4 = reinterpret_cast<const float4*>(in + r1 * PI + u1 * RN);
+            float v[4 * NQ];
+            const float4* p4 = reinterpret_cast<const float4*>(in + o1r);
 #pragma unroll
-            for (int q = 0; q < (RN + 2 * R) / 4; ++q) { const float4 f = p4[q]; v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
+            for (int q = 0; q < NQ; ++q) { const float4 f = p4[q]; v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
             float o[RN];
 #pragma unroll
             for (int j = 0; j < RN; ++j) o[j] = fir1<R>(v + j, taps);
-            float4* d4 = reinterpret_cast<float4*>(A + r1 * PA + u1 * RN);
+            float4* d4 = reinterpret_cast<float4*>(A + o1w);
             d4[0] = make_float4(o[0], o[1], o[2], o[3]);
             d4[1] = make_float4(o[4], o[5], o[6], o[7]);
         }
@@ -574,29 +590,29 @@ __global__ __launch_bounds__(NT) void dog_stream(const T* __restrict__ img, floa
         if (h2_on) {
             const int gy = a0 + c * CH - 2 * R + r2;
             if (gy >= y0 && gy < ye) {
-                float v[RN + 2 * R];
-                const float4* p4 = reinterpret_cast<const float4*>(E + r2 * PE + u2 * RN);
+                float v[4 * NQ];
+                const float4* p4 = reinterpret_cast<const float4*>(E + o2r);
 #pragma unroll
-                for (int q = 0; q < (RN + 2 * R) / 4; ++q) { const float4 f = p4[q]; v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
+                for (int q = 0; q < NQ; ++q) { const float4 f = p4[q]; v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
                 float o[RN];
 #pragma unroll
-                for (int j = 0; j < RN; ++j) { const float g = fir1<R>(v + j, taps); o[j] = signed_out ? g : fabsf(g); }
+                for (int j = 0; j < RN; ++j) o[j] = __uint_as_float(__float_as_uint(fir1<R>(v + j, taps)) & absmask);
                 const int gx = x0 + u2 * RN;
                 float* d = oimg + (uint32_t)(gy * SW + gx);
-                if (gx + RN <= W) {
+                if (gx + RN <= x0 + bw) {                  // a whole run inside the band (the last run of a band may hang over into the next one)
                     *reinterpret_cast<float4u*>(d) = (float4u){o[0], o[1], o[2], o[3]};
                     *reinterpret_cast<float4u*>(d + 4) = (float4u){o[4], o[5], o[6], o[7]};
                 } else {
 #pragma unroll
                     for (int j = 0; j < RN; ++j)
-                        if (gx + j < x0 + sw) d[j] = gx + j < W ? o[j] : 0.f;          // slot pixels right of the image: 0
+                        if (gx + j < x0 + bw) d[j] = o[j];
                 }
             }
         }
     }
     // slot pixels of the band right of / below the image (per-image sizes): 0
     if (sizes) {
-        if (x0 + bw < x0 + sw && bw % RN == 0) {               // the partial-run branch above did not reach them
+        if (bw < sw) {
             const int wz = sw - bw;
             for (int i = tid; i < (ye - y0) * wz; i += NT) oimg[(uint32_t)((y0 + i / wz) * SW + x0 + bw + i % wz)] = 0.f;
         }
@@ -640,7 +656,7 @@ inline StreamPlan plan_stream(int N, int H, int W, int R, int num_cu) {
 
 template <typename T, int R, int NT>
 int launch_stream_nt(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const TapsF& tf, const int* sizes, const StreamPlan& pl) {
-    constexpr int PI = spitch(NT + 2 * R + 8), PA = spitch(NT + 8), PE = spitch(NT + 8);
+    constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
     const size_t lds = (size_t)(2 * SCH * PI + SCH * PA + SCH * PE) * sizeof(float);
     auto kern = dog_stream<T, R, NT>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -700,8 +716,13 @@ int launch_tile(fb_ctx* ctx, const T* img, float* out, const float* halo, int N,
     const size_t lds = lds_bytes(T_);
     auto kern = dog_tile<T, NPASS>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid(fb_cdiv(W, T_), fb_cdiv(H, T_), N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img, out, halo, H, W, r, T_, T_, signed_out, in_scale, mask, taps, per_image);
+    constexpr int kMaxZ = 32768;                          // images per launch: the grid's z extent is limited to 65535
+    for (int n0 = 0; n0 < N; n0 += kMaxZ) {
+        const size_t io = (size_t)n0 * H * W, mo = (size_t)n0 * per_image;
+        dim3 grid(fb_cdiv(W, T_), fb_cdiv(H, T_), std::min(kMaxZ, N - n0));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img ? img + io : img, out + io, halo ? halo + mo : halo, H, W, r, T_, T_, signed_out,
+                           in_scale, mask ? mask + mo : mask, taps, per_image);
+    }
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }

@@ -196,6 +196,46 @@ int fb_mesh_block_affines(fb_ctx* ctx, int V, const double* v_mov, const double*
     return FB_OK;
 }
 
+// Area of every block's box (bbox0 - 0.5, renderer.py:438) that no candidate triangle covers, in MOVING coordinates: what the
+// precise mask of crop_field_affine (renderer.py:437-447) compares with 1 px^2.  The reference takes the area in image
+// space, between the affine image of the box and the mesh region eroded by 0.5 px (shapely); here every candidate
+// triangle is clipped to the box (Sutherland-Hodgman against the four box sides) and the areas are summed -- the
+// triangles of a valid mesh do not overlap.  uncovered [NB] >= 1 selects the per-pixel mask (tier + 10).
+int fb_mesh_block_uncovered(fb_ctx* ctx, int V, const double* v_mov, const int32_t* tris, int NB, const double* org, int h, int w, int cap,
+                            const int32_t* cand, const int32_t* count, double* uncovered) {
+    FB_CHECK_ARG(ctx, V > 0 && v_mov && tris && NB >= 0 && org && h > 0 && w > 0 && cap > 0 && cand && count && uncovered);
+    for (int b = 0; b < NB; ++b) {
+        const double bx0 = org[2 * b] - 0.5, by0 = org[2 * b + 1] - 0.5, bx1 = bx0 + (double)w, by1 = by0 + (double)h;
+        double covered = 0.0;
+        const int nc = std::min(count[b], cap);
+        for (int k = 0; k < nc; ++k) {
+            const int32_t* t3 = tris + 3 * (size_t)cand[(size_t)b * cap + k];
+            double px[16], py[16], qx[16], qy[16];
+            int n = 3;
+            for (int a = 0; a < 3; ++a) { px[a] = v_mov[2 * (size_t)t3[a]]; py[a] = v_mov[2 * (size_t)t3[a] + 1]; }
+            // clip against x >= bx0, x <= bx1, y >= by0, y <= by1
+            for (int side = 0; side < 4 && n > 0; ++side) {
+                int m = 0;
+                for (int i = 0; i < n; ++i) {
+                    const int j = (i + 1) % n;
+                    const double ax = px[i], ay = py[i], cx = px[j], cy = py[j];
+                    const double da = side == 0 ? ax - bx0 : side == 1 ? bx1 - ax : side == 2 ? ay - by0 : by1 - ay;
+                    const double dc = side == 0 ? cx - bx0 : side == 1 ? bx1 - cx : side == 2 ? cy - by0 : by1 - cy;
+                    if (da >= 0) { qx[m] = ax; qy[m] = ay; ++m; }
+                    if ((da >= 0) != (dc >= 0)) { const double s_ = da / (da - dc); qx[m] = ax + s_ * (cx - ax); qy[m] = ay + s_ * (cy - ay); ++m; }
+                }
+                n = m;
+                for (int i = 0; i < n; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+            }
+            double a2 = 0.0;
+            for (int i = 0; i < n; ++i) { const int j = (i + 1) % n; a2 += px[i] * py[j] - px[j] * py[i]; }
+            covered += 0.5 * std::fabs(a2);
+        }
+        uncovered[b] = (double)w * (double)h - covered;
+    }
+    return FB_OK;
+}
+
 // field_w_weight (renderer.py:259-300) for NB blocks: block e belongs to pair pair_of[e] (index into vm) and covers the
 // h x w output pixels at (x0, y0) = org[e]; every pixel is located in the MOVING triangles that can reach the block and
 // mapped to the image by linear interpolation of the INITIAL vertices (matplotlib.tri.LinearTriInterpolator in the

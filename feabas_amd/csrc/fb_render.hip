@@ -96,6 +96,7 @@ struct RenderArgs {
     int* ext;            // [NB][4]: floor(min x), floor(min y), ceil(max x), ceil(max y) of the masked field
     const int* origin;   // [NB][2]
     float* out; uint8_t* mask;
+    int b0;              // first block of this launch (grid y is limited to 65535 blocks)
 };
 
 // cv2.remap, CV_8U bilinear: fixed-point table of 1/32-px phases scaled by 2^15 (BilinearTab_i), saturate_cast<short>
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(TILE* TILE) void mesh_field_kernel(const RenderArgs
     __shared__ int rec_tid[CHUNK];
     __shared__ int n_rec;
     __shared__ int red[4];
-    const int b = blockIdx.y;
+    const int b = g.b0 + blockIdx.y;
     const int tiles_x = (g.w + TILE - 1) / TILE;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int tid = threadIdx.x;
@@ -139,12 +140,17 @@ __global__ __launch_bounds__(TILE* TILE) void mesh_field_kernel(const RenderArgs
     const double xx = ox + (double)px, yy = oy + (double)py;
     double fx = 0.0, fy = 0.0;
     bool ok = false;
-    if (g.tier[b] != 3) {
+    // tier 1 / 2: affine field, every pixel valid; 11 / 12: affine field, valid where the pixel lies inside the mesh (the
+    // precise mask of crop_field_affine, renderer.py:437-447, for a block that sticks out of the mesh); 3: exact field
+    const int tr = g.tier[b];
+    const bool exact = tr == 3;
+    if (!exact) {
         const double* A = g.A6 + 6 * (size_t)b;          // {A00, A10, t0, A01, A11, t1}
         fx = (xx * A[0] + yy * A[1]) + A[2];
         fy = (xx * A[3] + yy * A[4]) + A[5];
-        ok = live;
-    } else {
+        ok = live && tr < 10;
+    }
+    if (exact || tr >= 10) {
         // tile box in MOVING coordinates (pixel centres), grown by the inside tolerance
         const double tx0 = ox + (double)(tx * TILE) - 1e-6, ty0 = oy + (double)(ty * TILE) - 1e-6;
         const double tx1 = ox + (double)min(tx * TILE + TILE - 1, g.w - 1) + 1e-6, ty1 = oy + (double)min(ty * TILE + TILE - 1, g.h - 1) + 1e-6;
@@ -185,8 +191,10 @@ __global__ __launch_bounds__(TILE* TILE) void mesh_field_kernel(const RenderArgs
                     const double l0 = (1.0 - l1) - l2;
                     if (l0 >= -BARY_EPS && l1 >= -BARY_EPS && l2 >= -BARY_EPS && rec_tid[k] < best) {
                         best = rec_tid[k];
-                        fx = (l0 * r[7] + l1 * r[9]) + l2 * r[11];
-                        fy = (l0 * r[8] + l1 * r[10]) + l2 * r[12];
+                        if (exact) {
+                            fx = (l0 * r[7] + l1 * r[9]) + l2 * r[11];
+                            fy = (l0 * r[8] + l1 * r[10]) + l2 * r[12];
+                        }
                         ok = true;
                     }
                 }
@@ -306,13 +314,19 @@ int fb_mesh_render_blocks_dev(fb_ctx* ctx, const void* img, int dtype, int IH, i
     if (NB == 0) return FB_OK;
     FB_CHECK_ARG(ctx, img && v_mov && v_img && tris && org && tier && A6 && cand && count && ext && origin && out && mask);
     FB_HIP(ctx, hipSetDevice(ctx->device));
-    RenderArgs g{img, dtype, IH, IW, img_x0, img_y0, v_mov, v_img, tris, org, h, w, tier, A6, cap, cand, count, ext, origin, out, mask};
-    const dim3 grid(fb_cdiv(w, TILE) * fb_cdiv(h, TILE), NB);
+    RenderArgs g{img, dtype, IH, IW, img_x0, img_y0, v_mov, v_img, tris, org, h, w, tier, A6, cap, cand, count, ext, origin, out, mask, 0};
     FB_PROF_B(ctx, "mesh_render", (double)NB * h * w * 5.0);
     hipLaunchKernelGGL(fill_ext_kernel, dim3(fb_cdiv(4 * NB, 256)), dim3(256), 0, ctx->stream, NB, ext);
-    hipLaunchKernelGGL(mesh_field_kernel<0>, grid, dim3(TILE * TILE), 0, ctx->stream, g);
+    constexpr int kMaxY = 32768;                          // blocks per launch: the grid's y extent is limited to 65535
+    for (int b0 = 0; b0 < NB; b0 += kMaxY) {
+        g.b0 = b0;
+        hipLaunchKernelGGL(mesh_field_kernel<0>, dim3(fb_cdiv(w, TILE) * fb_cdiv(h, TILE), std::min(kMaxY, NB - b0)), dim3(TILE * TILE), 0, ctx->stream, g);
+    }
     hipLaunchKernelGGL(mesh_origin_kernel, dim3(1), dim3(256), 0, ctx->stream, NB, ext, origin);
-    hipLaunchKernelGGL(mesh_field_kernel<1>, grid, dim3(TILE * TILE), 0, ctx->stream, g);
+    for (int b0 = 0; b0 < NB; b0 += kMaxY) {
+        g.b0 = b0;
+        hipLaunchKernelGGL(mesh_field_kernel<1>, dim3(fb_cdiv(w, TILE) * fb_cdiv(h, TILE), std::min(kMaxY, NB - b0)), dim3(TILE * TILE), 0, ctx->stream, g);
+    }
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }

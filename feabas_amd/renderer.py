@@ -102,8 +102,21 @@ class MeshRenderer:
             d_cand.free(); d_cnt.free()
             cap = int(2 ** np.ceil(np.log2(cnt.max())))
 
-    def _tiers(self, org, h, w, d_cand, cnt, cap):
-        """crop_field's choice per block (renderer.py:453-511): 1 global affine, 2 block affine, 3 exact field"""
+    def _precise(self, tier, org, h, w, cand, cnt, cap):
+        """precise_mask of crop_field_affine (renderer.py:437-447): an affine block of which 1 px^2 or more lies outside the
+        mesh is masked pixel by pixel (tier + 10); the area is taken in MOVING coordinates from the candidate triangles"""
+        sel = np.flatnonzero((tier == 1) | (tier == 2))
+        if sel.size:
+            unc = np.empty(org.shape[0])
+            _lib.check(_lib.load().fb_mesh_block_uncovered(_lib.ctx(), self.v0.shape[0], _lib.ptr(self.v0), _lib.ptr(self.tris), org.shape[0],
+                                                           _lib.ptr(np.ascontiguousarray(org)), h, w, cap, _lib.ptr(cand), _lib.ptr(cnt), _lib.ptr(unc)))
+            out = sel[unc[sel] >= 1.0]
+            tier[out] += 10
+        return tier
+
+    def _tiers(self, org, h, w, d_cand, cnt, cap, precise=False):
+        """crop_field's choice per block (renderer.py:453-511): 1 global affine, 2 block affine, 3 exact field; + 10 when the
+        precise mask applies (log_sigma > 0 and the block sticks out of the mesh)"""
         nb = org.shape[0]
         tier = np.full(nb, 3, dtype=np.int32)
         A6 = np.zeros((nb, 6))
@@ -111,12 +124,12 @@ class MeshRenderer:
         if not self.tol > 0:
             return tier, A6
         A_g, res_g = self._global
+        cand = d_cand.to_array((nb, cap), np.int32)
+        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
         if res_g < self.tol:
             tier[:] = 1
             A6[:] = pack(A_g)
-            return tier, A6
-        cand = d_cand.to_array((nb, cap), np.int32)
-        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+            return (self._precise(tier, org, h, w, cand, cnt, cap) if precise else tier), A6
         _lib.check(_lib.load().fb_mesh_block_affines(_lib.ctx(), self.v0.shape[0], _lib.ptr(self.v0), _lib.ptr(self.v1), _lib.ptr(self.tris), nb,
                                                      _lib.ptr(np.ascontiguousarray(org)), h, w, cap, _lib.ptr(cand), _lib.ptr(cnt), self.tol,
                                                      _lib.ptr(tier), _lib.ptr(A6)))
@@ -130,11 +143,12 @@ class MeshRenderer:
             if affine_residue(self.v1[idx], self.v0[idx], A_b) < self.tol:
                 tier[b] = 2
                 A6[b] = pack(A_b)
-        return tier, A6
+        return (self._precise(tier, org, h, w, cand, cnt, cap) if precise else tier), A6
 
-    def render_stack_dev(self, bboxes):
-        """crop_multiple(bboxes, mode=RENDER_FULL, log_sigma=0, remap_interp=INTER_LINEAR) for blocks of ONE size:
-        (stack float32 [N][h][w], mask uint8 [N][h][w]) as device buffers + (N, h, w) + the tiers"""
+    def render_stack_dev(self, bboxes, precise_mask=False):
+        """crop_multiple(bboxes, mode=RENDER_FULL, remap_interp=INTER_LINEAR) before its DoG, for blocks of ONE size:
+        (stack float32 [N][h][w], mask uint8 [N][h][w]) as device buffers + (N, h, w) + the tiers.  precise_mask = log_sigma > 0
+        (crop_field passes it on to crop_field_affine, renderer.py:491-511)"""
         lib, ctx = _lib.load(), _lib.ctx()
         bboxes = np.asarray(bboxes).reshape(-1, 4)
         nb = bboxes.shape[0]
@@ -145,7 +159,7 @@ class MeshRenderer:
         org = np.ascontiguousarray(bbox0[:, :2])
         d_org = _lib.DeviceBuffer.from_array(org)
         d_cand, d_cnt, cnt, cap = self._candidates(d_org, nb, h, w)
-        tier, A6 = self._tiers(org, h, w, d_cand, cnt, cap)
+        tier, A6 = self._tiers(org, h, w, d_cand, cnt, cap, precise=precise_mask)
         d_tier, d_A6 = _lib.DeviceBuffer.from_array(tier), _lib.DeviceBuffer.from_array(A6)
         d_ext, d_origin = _lib.DeviceBuffer(16 * nb), _lib.DeviceBuffer(8 * nb)
         d_out, d_mask = _lib.DeviceBuffer(4 * nb * h * w), _lib.DeviceBuffer(nb * h * w)
@@ -174,7 +188,7 @@ class MeshRenderer:
     def crop_multiple(self, bboxes, **kwargs):
         """renderer.py:601-648 -> float32 [N, h, w] on the host (None when nothing is covered)"""
         log_sigma = kwargs.get('log_sigma', 0)
-        d_out, d_mask, shape, _ = self.render_stack_dev(bboxes)
+        d_out, d_mask, shape, _ = self.render_stack_dev(bboxes, precise_mask=log_sigma > 0)
         try:
             if not d_mask.to_array(shape, np.uint8).any():
                 return None

@@ -170,6 +170,12 @@ int fb_dog_masks_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int 
  *   -1 = degenerate / flipped fit (caller's statement-by-statement route). */
 int fb_mesh_block_affines(fb_ctx* ctx, int V, const double* v_mov, const double* v_img, const int32_t* tris, int NB, const double* org,
                           int h, int w, int cap, const int32_t* cand, const int32_t* count, double tol, int32_t* tier, double* A6);
+/* fb_mesh_block_uncovered (host arrays, no device work): the area of every block's box that no candidate triangle covers (MOVING
+ *   coordinates) -- the quantity the precise mask of crop_field_affine compares with 1 px^2 (renderer.py:437-447).  Blocks of
+ *   tier 1 / 2 with uncovered >= 1 are rendered with tier 11 / 12: the affine field, masked where the pixel lies outside the
+ *   mesh (fb_mesh_render_blocks_dev). */
+int fb_mesh_block_uncovered(fb_ctx* ctx, int V, const double* v_mov, const int32_t* tris, int NB, const double* org, int h, int w, int cap,
+                            const int32_t* cand, const int32_t* count, double* uncovered);
 /* fb_mesh_locate_dev: Mesh.tri_finder (mesh.py:2080-2188) for K points pts [K][2] (device, frame of v_mov): tid [K] = the
  *   containing triangle of smallest index, -1 outside the mesh. */
 int fb_mesh_locate_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris, int K, const double* pts, int* tid);

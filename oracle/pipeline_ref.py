@@ -166,13 +166,47 @@ def affine_residue(v1, v0, A):
     return np.max(np.sum((v1 - v0 @ A[:2, :2] - A[-1, :2]) ** 2, axis=-1)) ** 0.5
 
 
-def render_blocks_mesh1(m1, img, bboxes, tol, return_tiers=False, img_origin=(0, 0), return_mask=False):
+def _clip_convex(poly, clip):
+    """Sutherland-Hodgman: convex polygon `poly` [n, 2] clipped by the convex polygon `clip` [m, 2] (either orientation)"""
+    clip = np.asarray(clip, dtype=np.float64)
+    if np.sum(clip[:, 0] * np.roll(clip[:, 1], -1) - np.roll(clip[:, 0], -1) * clip[:, 1]) < 0:
+        clip = clip[::-1]
+    out = [tuple(p) for p in np.asarray(poly, dtype=np.float64)]
+    for k in range(clip.shape[0]):
+        a, b = clip[k], clip[(k + 1) % clip.shape[0]]
+        side = lambda p: (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])       # >= 0: inside (counter-clockwise clip)
+        inp, out = out, []
+        for i in range(len(inp)):
+            p, q = inp[i], inp[(i + 1) % len(inp)]
+            sp, sq = side(p), side(q)
+            if sp >= 0:
+                out.append(p)
+            if (sp >= 0) != (sq >= 0):
+                t = sp / (sp - sq)
+                out.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+        if not out:
+            return np.zeros((0, 2))
+    return np.array(out)
+
+
+def _poly_area(p):
+    if p.shape[0] < 3:
+        return 0.0
+    return 0.5 * abs(np.sum(p[:, 0] * np.roll(p[:, 1], -1) - np.roll(p[:, 0], -1) * p[:, 1]))
+
+
+def render_blocks_mesh1(m1, img, bboxes, tol, return_tiers=False, img_origin=(0, 0), return_mask=False, precise_mask=False):
     """MeshRenderer.from_mesh(mesh1, affine_approx_tol=tol) (renderer.py:47-166) + crop_multiple(bboxes, mode=RENDER_FULL,
     log_sigma=0, remap_interp=INTER_LINEAR) (renderer.py:601-648) for a mesh of one region without collisions over a
     StreamLoader of `img` (fillval 0).  Per block (crop_field, renderer.py:453-563): the global affine when its residue
     is below tol, else the affine fitted to the vertices of the triangles that touch the block when that is below tol,
     else the exact piecewise-linear field (masked outside the mesh).  All fields are rendered as ONE map
-    (render_by_subregions, common.py:257-350: one remap origin for the whole stack)."""
+    (render_by_subregions, common.py:257-350: one remap origin for the whole stack).
+    precise_mask (= log_sigma > 0, renderer.py:491-511): the mask of an affine block follows crop_field_affine
+    (renderer.py:437-447) -- the affine image of the box (bbox0 - 0.5) is intersected with the mesh region in IMAGE space;
+    when 1 px^2 or more of it lies outside, the mask keeps the pixels whose source point lies in the region.  The region is
+    the union of the image-space triangles; the reference's shapely buffer(-0.5).simplify(0.5) of it is not restated
+    (shapely is absent): tier numbers 11 / 12 mark such blocks."""
     import matplotlib.tri
     off = m1.offset(fem_ref.GEAR_MOVING).ravel()
     v0 = m1.vertices(fem_ref.GEAR_MOVING)
@@ -180,6 +214,7 @@ def render_blocks_mesh1(m1, img, bboxes, tol, return_tiers=False, img_origin=(0,
     A_g = fem_ref.fit_affine(v1, v0)
     res_g = affine_residue(v1, v0, A_g)
     tri = None
+    tri_img = None
     fx, fy, msk, tiers = [], [], [], []
     for bbox in np.asarray(bboxes):
         bbox0 = np.asarray(bbox, dtype=np.float64) - np.tile(off, 2)
@@ -202,6 +237,19 @@ def render_blocks_mesh1(m1, img, bboxes, tol, return_tiers=False, img_origin=(0,
             x_f = xx * A[0, 0] + yy * A[1, 0] + A[2, 0]
             y_f = xx * A[0, 1] + yy * A[1, 1] + A[2, 1]
             mk = np.ones_like(x_f, dtype=bool)
+            if precise_mask:
+                b = bbox0 - 0.5
+                box = np.array([[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]])
+                shpbox = box @ A[:2, :2] + A[2, :2]
+                tp = v1[m1.triangles]
+                near = (tp[:, :, 0].max(1) >= shpbox[:, 0].min()) & (tp[:, :, 0].min(1) <= shpbox[:, 0].max()) & \
+                       (tp[:, :, 1].max(1) >= shpbox[:, 1].min()) & (tp[:, :, 1].min(1) <= shpbox[:, 1].max())
+                inter = sum(_poly_area(_clip_convex(t3, shpbox)) for t3 in tp[near])
+                if _poly_area(shpbox) - inter >= 1:
+                    if tri_img is None:
+                        tri_img = matplotlib.tri.Triangulation(v1[:, 0], v1[:, 1], triangles=m1.triangles).get_trifinder()
+                    mk = np.asarray(tri_img(x_f, y_f)) >= 0
+                    tier += 10
         else:
             tier = 3
             if tri is None:
@@ -264,7 +312,7 @@ def bboxes_mesh_renderer_matcher(mesh0, mesh1, img0, img1, bboxes0, bboxes1, sig
     when sigma > 0 (renderer.py:632-641), xcorr_fft, block displacement -> point pair (matcher.py:840-849)."""
     stacks, masks = [], []
     for m, img, bb, org in ((mesh0, img0, bboxes0, img_origin0), (mesh1, img1, bboxes1, img_origin1)):
-        st, mk, _ = render_blocks_mesh1(m, img, bb, affine_approx_tol, img_origin=org, return_mask=True)
+        st, mk, _ = render_blocks_mesh1(m, img, bb, affine_approx_tol, img_origin=org, return_mask=True, precise_mask=sigma > 0)
         if sigma > 0:
             st = ncc_ref.masked_dog_filter(st, sigma, mask=mk)
         stacks.append(st); masks.append(mk)

@@ -28,7 +28,7 @@ def test_pair_pipeline_at_the_4k_strip_size_vs_oracle(fb, H, W):
     s0 = np.stack([p[0] for p in pairs]); s1 = np.stack([p[1] for p in pairs])
     d0 = _lib.DeviceBuffer.from_array(s0); d1 = _lib.DeviceBuffer.from_array(s1)
     m = StripBatchMatcher(2, H, W, residue_len=2.0)
-    np.testing.assert_array_equal(m.spacings, [1024.0, 75.0])
+    np.testing.assert_allclose(m.spacings, [1024.0, 75.0], rtol=1e-12)
     got = StripBatchMatcher.per_pair(m.match(d0.ptr, d1.ptr))
     ndef = 0
     for p in range(2):

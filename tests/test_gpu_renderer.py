@@ -86,6 +86,41 @@ def test_render_stack_vs_oracle(fb, dtype, tol):
     assert np.all(got[~gmask] == 0)
 
 
+@pytest.mark.parametrize('tol', [0.5, 50.0])
+def test_render_stack_precise_mask_of_affine_blocks(fb, tol):
+    """log_sigma > 0 makes crop_field_affine mask an affine block pixel by pixel when 1 px^2 or more of it lies outside the
+    mesh (renderer.py:437-447): block-affine tier at tol 0.5, the global-affine tier at tol 50.  The oracle
+    takes area and containment in image space like the reference, the device in MOVING coordinates: the decisions agree,
+    the masks agree except for pixels within the affine tolerance of the mesh border."""
+    from feabas_amd import renderer
+    rng = np.random.default_rng(19)
+    ref, M = _meshes(rng, warp=3.0)
+    img = _texture(rng, 620, 760)
+    origin = (-60, -50)
+    bboxes = _blocks(rng, 32, (72, 56), (600, 480), margin=40)
+    exp, emask, etier = pipeline_ref.render_blocks_mesh1(ref, img, bboxes, tol, img_origin=origin, return_mask=True, precise_mask=True)
+    plain, pmask, ptier = pipeline_ref.render_blocks_mesh1(ref, img, bboxes, tol, img_origin=origin, return_mask=True)
+    r = renderer.MeshRenderer.from_mesh(M, image_loader=renderer.ResidentImage(img, origin), affine_approx_tol=tol)
+    d_out, d_mask, shape, tier = r.render_stack_dev(bboxes, precise_mask=True)
+    got = d_out.to_array(shape, np.float32); gmask = d_mask.to_array(shape, np.uint8).astype(bool)
+    d_out.free(); d_mask.free()
+    d_out, d_mask, shape, tier0 = r.render_stack_dev(bboxes)          # log_sigma = 0: every pixel of an affine block is valid
+    gmask0 = d_mask.to_array(shape, np.uint8).astype(bool)
+    d_out.free(); d_mask.free(); r.free()
+    np.testing.assert_array_equal(tier, etier)
+    np.testing.assert_array_equal(tier0, ptier)
+    assert np.sum(tier >= 10) >= 4 and np.sum((tier == 1) | (tier == 2)) >= 4          # blocks that stick out, blocks that do not
+    assert set(np.unique(tier % 10)) <= ({1} if tol > 10 else {2, 3}) and (tol > 10 or np.sum(tier % 10 == 2) >= 8)
+    aff = tier0 != 3
+    assert gmask0[aff].all() and pmask[aff].all()
+    out = tier >= 10
+    assert 0.02 < 1 - gmask[out].mean() < 0.9                        # the precise mask removes the part outside the mesh
+    assert (gmask != emask).mean() < (2e-3 if tol < 10 else 2e-2)    # border pixels within the affine tolerance may differ
+    both = gmask & emask
+    assert np.abs(got - exp)[both].max() <= 8 and (np.abs(got - exp)[both] > 1).mean() < 2e-3
+    assert np.all(got[~gmask] == 0)
+
+
 def test_masked_dog_of_a_stack(fb):
     from feabas_amd import _lib
     lib, ctx = _lib.load(), _lib.ctx()
