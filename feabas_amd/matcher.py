@@ -160,6 +160,179 @@ def distributor_cartesian_bbox(mesh0, mesh1, spacing, **kwargs):
     return bb0, bb1
 
 
+class _RegionPair:
+    """The region both meshes cover (shapely: region0.intersection(region1), matcher.py:944-946) as a point predicate on
+    triangles: a point lies in it when it lies in a triangle of each mesh, and its distance to the region's outline is the
+    smaller of its distances to the outlines (boundary edges) of the two meshes -- so ``buffer(-d)`` (matcher.py:987) is
+    ``inside & (distance >= d)``.  Areas and connected parts are taken on a raster of the predicate (step `res`): shapely is
+    not in the image, and nothing downstream needs the polygons themselves."""
+
+    def __init__(self, mesh0, mesh1, gear):
+        self.meshes = (mesh0, mesh1)
+        self.gear = gear
+        self.segs = []
+        for m in (mesh0, mesh1):
+            v = m.vertices_w_offset(gear)
+            self.segs.append(v[m.boundary_edges()])                          # [E, 2, 2]
+        self.segs = np.concatenate(self.segs, axis=0)
+        bb, self.valid = common.intersect_bbox(mesh0.bbox(gear=gear), mesh1.bbox(gear=gear))
+        self.bbox = np.asarray(bb, dtype=np.float64)
+
+    def inside(self, pts):
+        pts = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+        ok = np.ones(pts.shape[0], dtype=bool)
+        for m in self.meshes:
+            idx = np.flatnonzero(ok)
+            if idx.size:
+                ok[idx] = m.tri_finder(pts[idx], gear=self.gear) >= 0
+        return ok
+
+    def boundary_distance(self, pts, cap=np.inf):
+        """distance of every point to the nearest outline segment (values above `cap` need not be exact)"""
+        pts = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+        out = np.full(pts.shape[0], np.inf)
+        a, b = self.segs[:, 0], self.segs[:, 1]
+        ab = b - a
+        l2 = np.maximum(np.sum(ab * ab, axis=1), 1e-300)
+        lo, hi = np.minimum(a, b) - cap, np.maximum(a, b) + cap
+        step = max(1, int(4e6 // max(1, a.shape[0])))
+        for s0 in range(0, pts.shape[0], step):
+            p = pts[s0:s0 + step]
+            near = np.all((p[:, None, :] >= lo[None]) & (p[:, None, :] <= hi[None]), axis=2) if np.isfinite(cap) else None
+            t = np.clip(np.einsum('pej,ej->pe', p[:, None, :] - a[None], ab) / l2[None], 0.0, 1.0)
+            d2 = np.sum((p[:, None, :] - (a[None] + t[..., None] * ab[None])) ** 2, axis=2)
+            if near is not None:
+                d2 = np.where(near, d2, np.inf)
+            out[s0:s0 + step] = np.sqrt(d2.min(axis=1)) if d2.shape[1] else np.inf
+        return out
+
+    def select(self, pts, erode=0.0):
+        ok = self.inside(pts)
+        if erode > 0 and ok.any():
+            idx = np.flatnonzero(ok)
+            ok[idx] = self.boundary_distance(np.asarray(pts).reshape(-1, 2)[idx], cap=erode) >= erode
+        return ok
+
+    def raster(self, res, erode=0.0):
+        x0, y0, x1, y1 = self.bbox
+        xs = np.arange(x0 + 0.5 * res, x1, res); ys = np.arange(y0 + 0.5 * res, y1, res)
+        xx, yy = np.meshgrid(xs, ys)
+        return xs, ys, self.select(np.stack((xx.ravel(), yy.ravel()), axis=-1), erode).reshape(yy.shape)
+
+
+def _region2grid_cartesian(region, spacing, erode=0.0, res=None, **kwargs):
+    """matcher.py:1019-1043: a lattice of step `spacing` per connected part of the region, anchored at the part's
+    representative point, kept where it falls inside the part.  `region` is a _RegionPair; the parts, their bounds and their
+    representative points (GEOS takes the middle of the widest stretch of the scan line through the middle of the bounds)
+    come from a raster of the region with step `res`; membership of the lattice points is tested exactly."""
+    from scipy import ndimage
+    res = max(spacing / 4.0, 1.0) if res is None else res
+    xs, ys, msk = region.raster(res, erode)
+    if not msk.any():
+        return None
+    lab, nlab = ndimage.label(msk, structure=np.ones((3, 3), dtype=bool))
+    cntrs = []
+    for k in range(1, nlab + 1):
+        rr, cc = np.nonzero(lab == k)
+        rx_mn, rx_mx = xs[cc.min()] - 0.5 * res, xs[cc.max()] + 0.5 * res
+        ry_mn, ry_mx = ys[rr.min()] - 0.5 * res, ys[rr.max()] + 0.5 * res
+        row = min(max(int(round((0.5 * (ry_mn + ry_mx) - ys[0]) / res)), rr.min()), rr.max())
+        run = np.flatnonzero(lab[row] == k)
+        if run.size == 0:                                          # the middle row misses the part (a ring, a C): take its fullest row
+            row = rr[np.argmax(np.bincount(rr)[rr])]
+            run = np.flatnonzero(lab[row] == k)
+        brk = np.flatnonzero(np.diff(run) > 1)
+        starts = np.concatenate(([0], brk + 1)); ends = np.concatenate((brk, [run.size - 1]))
+        w = int(np.argmax(ends - starts))
+        rx = 0.5 * (xs[run[starts[w]]] + xs[run[ends[w]]]); ry = ys[row]
+        gx0 = rx - ((rx - rx_mn) // spacing) * spacing
+        gy0 = ry - ((ry - ry_mn) // spacing) * spacing
+        gxx, gyy = np.meshgrid(np.arange(gx0, rx_mx, spacing), np.arange(gy0, ry_mx, spacing))
+        rv = np.stack((gxx.ravel(), gyy.ravel()), axis=-1)
+        if rv.shape[0] == 0:
+            continue
+        # part of the lattice point: the label of its raster cell or of a neighbouring one (the raster is coarser than the outline)
+        ci = np.clip(np.round((rv[:, 0] - xs[0]) / res).astype(int), 0, xs.size - 1)
+        ri = np.clip(np.round((rv[:, 1] - ys[0]) / res).astype(int), 0, ys.size - 1)
+        mine = np.zeros(rv.shape[0], dtype=bool)
+        for dr in (-1, 0, 1):
+            for dc in (-1, 0, 1):
+                mine |= lab[np.clip(ri + dr, 0, ys.size - 1), np.clip(ci + dc, 0, xs.size - 1)] == k
+        rv = rv[mine]
+        if rv.shape[0]:
+            cntrs.append(rv[region.select(rv, erode)])
+    cntrs = [c for c in cntrs if c.shape[0]]
+    if not cntrs:
+        return None
+    pts = np.unique(np.concatenate(cntrs, axis=0), axis=0)            # unary_union of the MultiPoints: duplicates merged, sorted
+    return pts
+
+
+def distribute_matching_blocks(mesh0, mesh1, spacing, dfunc='cartesian_region', **kwargs):
+    """feabas/matcher.py:894-1016: blocks on a lattice over the region BOTH meshes cover, at least `min_boundary_distance`
+    away from its outline (relaxed until half of the region survives), z-ordered.  The reference builds the region with
+    shapely polygons; here it is a point predicate on the triangles of the two meshes (_RegionPair) -- same lattice rule,
+    same block sizes; the lattice anchor of a connected part is its representative point as GEOS defines it, located on a
+    raster of the region (step spacing / 4), so anchors agree with shapely's up to that step.  Refinement regions need
+    material tables with an ``area_constraint`` (not part of this mirror's Mesh): refine_mode acts as 0."""
+    gear = kwargs.get('gear', const.MESH_GEAR_MOVING)
+    shrink_factor = kwargs.get('shrink_factor', 1)
+    min_box_side = kwargs.get('min_box_side', 5)
+    max_box_side = kwargs.get('max_box_side', np.inf)
+    min_boundary_distance = kwargs.get('min_boundary_distance', 0)
+    zorder = kwargs.get('zorder', True)
+    render_weight_threshold = kwargs.get('render_weight_threshold', 0)
+    if isinstance(dfunc, str):
+        if dfunc.lower() == 'cartesian_region':
+            dfunc = _region2grid_cartesian
+        elif dfunc.lower() == 'intersect_triangulation':
+            raise NotImplementedError("distributor 'intersect_triangulation' meshes the region with `triangle` (matcher.py:1046-1058), which is not in the image")
+        else:
+            raise ValueError(f'unsupported distributor type {dfunc}')
+    empty = (np.empty((0, 4)), np.empty((0, 4)))
+    if render_weight_threshold > 0:
+        mesh0 = mesh0.submesh(mesh0.triangle_mask_for_render(render_weight_threshold=render_weight_threshold))
+        mesh1 = mesh1.submesh(mesh1.triangle_mask_for_render(render_weight_threshold=render_weight_threshold))
+    region = _RegionPair(mesh0, mesh1, gear)
+    if not region.valid:
+        return empty
+    res = max(spacing / 4.0, 1.0)
+    area_r = float(region.raster(res)[2].sum()) * res * res
+    if area_r == 0:
+        return empty
+    if not hasattr(shrink_factor, '__len__'):
+        shrink_factor = (shrink_factor, shrink_factor)
+    else:
+        a0 = np.sum(mesh0.triangle_areas(gear=gear)) / mesh0.num_triangles
+        a1 = np.sum(mesh1.triangle_areas(gear=gear)) / mesh1.num_triangles
+        shrink_factor = (max(shrink_factor), min(shrink_factor)) if a0 > a1 else (min(shrink_factor), max(shrink_factor))
+    erode = 0.0
+    if min_boundary_distance > 0:
+        bound_coeff = 1.0
+        for _ in range(64):
+            erode = min_boundary_distance * bound_coeff
+            area_c = float(region.raster(res, erode)[2].sum()) * res * res
+            if area_c >= 0.5 * area_r:
+                break
+            bound_coeff *= 0.3 / (1 - area_c / area_r)
+            if bound_coeff < 1e-3:
+                erode = 0.0
+                break
+    cntrs = dfunc(region, spacing, erode=erode, res=res)
+    if cntrs is None:
+        return empty
+    sides = (spacing * np.array(shrink_factor, dtype=np.float64)).clip(min_box_side, max_box_side)
+    h0, h1 = np.ceil(sides[0] / 2), np.ceil(sides[1] / 2)
+    bboxes0 = np.concatenate((cntrs - h0, cntrs + h0), axis=-1)
+    bboxes1 = np.concatenate((cntrs - h1, cntrs + h1), axis=-1)
+    if zorder:
+        x_rnd = np.round((cntrs[:, 0] - cntrs[:, 0].min()) / spacing)
+        y_rnd = np.round((cntrs[:, 1] - cntrs[:, 1].min()) / spacing)
+        idx = common.z_order(np.stack((x_rnd, y_rnd), axis=-1))
+        bboxes0, bboxes1 = bboxes0[idx], bboxes1[idx]
+    return bboxes0, bboxes1
+
+
 def block_displacements_to_points(bboxes0, bboxes1, dx, dy):
     """feabas/matcher.py:840-849: block displacement -> a pair of matched points."""
     ctr0 = common.bbox_centers(bboxes0)
@@ -286,8 +459,13 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
     residue_mode = kwargs.get('residue_mode', 'huber')
     residue_len = kwargs.get('residue_len', 0)
     opt_tol = kwargs.get('opt_tol', None)
-    if kwargs.get('distributor', 'cartesian_bbox') != 'cartesian_bbox':
-        raise NotImplementedError("distributor: only 'cartesian_bbox' (matcher.py:865-891)")
+    distributor = kwargs.get('distributor', 'cartesian_bbox')
+    min_boundary_distance = kwargs.get('min_boundary_distance', 0)
+    render_weight_threshold = kwargs.get('render_weight_threshold', 0)
+    if kwargs.get('num_workers', 1) > 1:
+        # the reference cuts a round into sub-mesh jobs for its process pool (matcher.py:619-666); one device renders and
+        # correlates the whole round, so the knob has nothing to distribute
+        pass
     min_num_blocks = kwargs.get('min_num_blocks', 2)
     shrink_factor = kwargs.get('shrink_factor', 1)
     allow_dwell = kwargs.get('allow_dwell', 0)
@@ -305,8 +483,9 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
     conf_mode = kwargs.get('conf_mode', const.FFT_CONF_MIRROR)
     trace = kwargs.get('trace', None)                  # a list: one record per round (debugging / tests)
     relax_tol = kwargs.get('relax_tol', 1e-9)
-    if residue_len < 0:
-        raise NotImplementedError('residue_len < 0 (section thickness units) needs the reference configuration')
+    if residue_len < 0:                                                       # matcher.py:518-520: in units of the section thickness
+        thickness = kwargs.get('section_thickness', const.DEFAULT_THICKNESS)
+        residue_len = max(1, abs(residue_len) * thickness / mesh0.resolution)
     spacings = np.array(spacings, dtype=np.float64).ravel()
     linear_system = mesh0.is_linear and mesh1.is_linear
     one_locked = mesh0.locked or mesh1.locked
@@ -359,9 +538,17 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
             mnb = min_num_blocks if last else 1
             subpixel = do_subpixel if do_subpixel is not None else bool(last)
             tol_r = (0.1 if last else max(1, 0.02 * sp)) if affine_render else 0
-            bboxes0, bboxes1 = distributor_cartesian_bbox(mesh0, mesh1, sp, min_num_blocks=mnb, shrink_factor=shrink_factor, zorder=True)
+            if distributor == 'cartesian_bbox':
+                bboxes0, bboxes1 = distributor_cartesian_bbox(mesh0, mesh1, sp, min_num_blocks=mnb, shrink_factor=shrink_factor, zorder=True)
+            else:
+                bboxes0, bboxes1 = distribute_matching_blocks(mesh0, mesh1, sp, dfunc=distributor, min_boundary_distance=min_boundary_distance,
+                                                              shrink_factor=shrink_factor, zorder=True, render_weight_threshold=render_weight_threshold)
             if bboxes0 is None:
                 return invalid_output
+            if bboxes0.shape[0] == 0:                                         # the meshes do not overlap any more: nothing to correlate
+                if not initialized:
+                    return invalid_output
+                break
             xy0, xy1, conf = bboxes_mesh_renderer_matcher(mesh0, mesh1, images[0], images[1], bboxes0, bboxes1, batch_size=batch_size,
                                                           pad=pad, subpixel=subpixel, affine_approx_tol=tol_r, sigma=sigma, conf_mode=conf_mode)
             if np.all(conf <= conf_thresh):
@@ -463,24 +650,92 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
     return xy0, xy1, weight, strain
 
 
+_SECTION_MATCHER_KW = {
+    # honoured
+    'initial_matches', 'spacings', 'sigma', 'batch_size', 'distributor', 'link_weight_decay', 'compute_strain', 'stiffness_multiplier_threshold',
+    'render_weight_threshold', 'stiffness_lambda', 'conf_thresh', 'residue_mode', 'residue_len', 'opt_tol', 'min_num_blocks', 'shrink_factor',
+    'allow_dwell', 'allow_enlarge', 'pad', 'subpixel', 'max_spacing_skip', 'affine_approximated_render', 'conf_mode', 'min_boundary_distance',
+    'section_thickness', 'trace', 'relax_tol', 'merge_batches',
+    # accepted and without effect on the device path, each for a stated reason
+    'num_workers',          # one device renders and correlates a whole round: nothing to distribute over a process pool
+    'callback_settings',    # the PCG runs to its tolerance: no early-stop / timeout exits
+    'check_duplicates',     # Link.from_coordinates option of the reference; duplicates do not occur in lattice matches
+    'refine_mode',          # refinement regions need material tables with area_constraint (acts as 0)
+    'geodesic_mask',        # False only
+}
+
+
 def section_matcher(mesh0, mesh1, image_loader0, image_loader1, **kwargs):
-    """feabas/matcher.py:370-427, the branch for two connected meshes (or no initial matches): the alignment-side defaults
-    around ``iterative_xcorr_matcher_w_mesh``.  Splitting disconnected sub-meshes (``divide_disconnected_submeshes``) and the
-    region-aware block distributor are outside this mirror."""
+    """feabas/matcher.py:370-427 with the reference's defaults (``distributor='cartesian_region'``, sigma 2.5, batch_size 100,
+    stiffness_lambda 0.5, thresholds 0.1): triangles of soft materials are dropped first (``stiffness_multiplier_threshold``);
+    two connected meshes (or no initial matches) go straight to ``iterative_xcorr_matcher_w_mesh``; otherwise the meshes are
+    cut into their connected parts, the initial matches are dealt to the part pairs (``SLM.divide_disconnected_submeshes``)
+    and every pair is matched on its own.  Image loaders: ``renderer.ResidentImage``, a 2-D array, or any object with the
+    ``crop(bbox, **kw)`` method of the reference's loaders (``ResidentImage.from_loader``).
+    A keyword this mirror does not know raises instead of being swallowed."""
+    from . import optimizer
+    from . import renderer as _rd
     kwargs = dict(kwargs)
+    unknown = set(kwargs) - _SECTION_MATCHER_KW
+    if unknown:
+        raise TypeError(f'section_matcher: keyword(s) not honoured by the device path: {sorted(unknown)}')
+    if kwargs.get('geodesic_mask', False):
+        raise NotImplementedError('geodesic_mask=True is outside the device renderer')
     initial_matches = kwargs.pop('initial_matches', None)
     spacings = kwargs.pop('spacings', [100])
     kwargs.setdefault('sigma', 2.5)
     kwargs.setdefault('batch_size', 100)
-    kwargs.setdefault('distributor', 'cartesian_bbox')
+    kwargs.setdefault('distributor', 'cartesian_region')
     kwargs.setdefault('link_weight_decay', 0.0)
     compute_strain = kwargs.pop('compute_strain', False)
-    kwargs.setdefault('stiffness_lambda', 0.5)
-    for m in (mesh0, mesh1):
-        if m.connected_vertices()[0] != 1 and initial_matches is not None:
-            raise NotImplementedError('section_matcher: disconnected meshes with initial matches')
-    return iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, spacings=spacings, initial_matches=initial_matches,
-                                          compute_strain=compute_strain, **kwargs)
+    stiffness_multiplier_threshold = kwargs.get('stiffness_multiplier_threshold', 0.1)
+    kwargs.setdefault('render_weight_threshold', 0.1)
+    stiffness_lambda = kwargs.setdefault('stiffness_lambda', 0.5)
+    if stiffness_multiplier_threshold > 0:
+        mesh0 = mesh0.submesh(mesh0.triangle_mask_for_stiffness(stiffness_multiplier_threshold=stiffness_multiplier_threshold))
+        mesh1 = mesh1.submesh(mesh1.triangle_mask_for_stiffness(stiffness_multiplier_threshold=stiffness_multiplier_threshold))
+    # loaders of the reference (dal.*Loader: crop(bbox)) become resident images once, over the area the meshes can reach
+    images, own = [], []
+    for m, ld in ((mesh0, image_loader0), (mesh1, image_loader1)):
+        if isinstance(ld, (_rd.ResidentImage, _rd.MeshRenderer, np.ndarray)):
+            images.append(ld)
+        elif hasattr(ld, 'crop'):
+            b = m.bbox(gear=const.MESH_GEAR_INITIAL)
+            pad_px = int(np.ceil(4 * kwargs['sigma'])) + 8
+            images.append(_rd.ResidentImage.from_loader(ld, (int(np.floor(b[0])) - pad_px, int(np.floor(b[1])) - pad_px,
+                                                             int(np.ceil(b[2])) + pad_px, int(np.ceil(b[3])) + pad_px)))
+            own.append(images[-1])
+        else:
+            images.append(ld)
+    try:
+        if (initial_matches is None) or (mesh0.connected_triangles()[0] == 1 and mesh1.connected_triangles()[0] == 1):
+            return iterative_xcorr_matcher_w_mesh(mesh0, mesh1, images[0], images[1], spacings=spacings, initial_matches=initial_matches,
+                                                  compute_strain=compute_strain, **kwargs)
+        opt = optimizer.SLM([mesh0, mesh1], stiffness_lambda=stiffness_lambda)
+        xy0, xy1, weight = initial_matches[:3] if isinstance(initial_matches, (tuple, list)) else \
+            (initial_matches.xy0, initial_matches.xy1, initial_matches.weight)
+        opt.add_link_from_coordinates(mesh0.uid, mesh1.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight)
+        opt.divide_disconnected_submeshes(prune_links=True)
+        xy0, xy1, weight = [], [], []
+        strain = DEFAULT_AVG_DEFORM
+        for lnk in opt.links:
+            m0_t, m1_t = lnk.meshes
+            ini = (lnk.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True),
+                   lnk.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True), lnk.weight(use_mask=False))
+            xy0_t, xy1_t, wt_t, strain = iterative_xcorr_matcher_w_mesh(m0_t.copy(), m1_t.copy(), images[0], images[1], spacings=spacings,
+                                                                        compute_strain=compute_strain, initial_matches=ini, **kwargs)
+            if xy0_t is not None:
+                if (m0_t.uid - m1_t.uid) * (mesh0.uid - mesh1.uid) > 0:
+                    xy0.append(xy0_t); xy1.append(xy1_t)
+                else:
+                    xy0.append(xy1_t); xy1.append(xy0_t)
+                weight.append(wt_t)
+        if len(xy0) == 0:
+            return None, None, 0, DEFAULT_AVG_DEFORM
+        return np.concatenate(xy0, axis=0), np.concatenate(xy1, axis=0), np.concatenate(weight, axis=0), strain
+    finally:
+        for im in own:
+            im.free()
 
 
 def auto_spacings(shape0, shape1):

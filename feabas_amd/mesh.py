@@ -284,6 +284,88 @@ class Mesh:
         adj = sparse.csr_matrix((np.ones(e.shape[0], dtype=bool), (e[:, 0], e[:, 1])), shape=(n, n))
         return csgraph.connected_components(adj, directed=False, return_labels=True)
 
+    def _edge_table(self, tri_mask=None):
+        """undirected edges of the (masked) triangles: (edge vertex pairs [3T, 2] sorted within a pair, owning triangle [3T])"""
+        tid = np.arange(self.num_triangles) if tri_mask is None else np.flatnonzero(np.asarray(tri_mask)) if np.asarray(tri_mask).dtype == bool else np.asarray(tri_mask)
+        t = self.triangles[tid]
+        e = np.sort(np.concatenate((t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]), axis=0), axis=1)
+        return e, np.tile(tid, 3)
+
+    def connected_triangles(self, tri_mask=None):          # mesh.py:1784-1791: triangles that share an EDGE are adjacent
+        """(number of components, component label of every (masked) triangle)"""
+        e, owner = self._edge_table(tri_mask)
+        nt = owner.size // 3
+        local = np.tile(np.arange(nt), 3)
+        key = e[:, 0].astype(np.int64) * self.num_vertices + e[:, 1]
+        order = np.argsort(key, kind='stable')
+        ks, ls = key[order], local[order]
+        same = np.flatnonzero(ks[1:] == ks[:-1])
+        adj = sparse.csr_matrix((np.ones(same.size, dtype=bool), (ls[same], ls[same + 1])), shape=(nt, nt))
+        return csgraph.connected_components(adj, directed=False, return_labels=True)
+
+    def boundary_edges(self, tri_mask=None):
+        """edges that belong to exactly one (masked) triangle: the outline of the region (outer rings and holes), what
+        shapely_regions (mesh.py:1876-1905) chains into polygons.  [E, 2] vertex ids."""
+        e, _ = self._edge_table(tri_mask)
+        key = e[:, 0].astype(np.int64) * self.num_vertices + e[:, 1]
+        u, idx, cnt = np.unique(key, return_index=True, return_counts=True)
+        return e[idx[cnt == 1]]
+
+    def material_stiffness_multiplier(self):
+        """per-triangle stiffness multiplier of the triangle's MATERIAL (material.py: Material.stiffness_multiplier)"""
+        if self.tri_model is not None:
+            return np.asarray(self.tri_matmult, dtype=np.float32)
+        return np.full(self.num_triangles, self.material_multiplier, dtype=np.float32)
+
+    def triangle_mask_for_stiffness(self, **kwargs):       # mesh.py:1863-1873
+        thr = kwargs.get('stiffness_multiplier_threshold', 0)
+        return ~(self.material_stiffness_multiplier() < thr)
+
+    def triangle_mask_for_render(self, **kwargs):          # mesh.py:1847-1859; render weights default to 1 (default material table)
+        thr = kwargs.get('render_weight_threshold', 0)
+        wt = getattr(self, 'tri_render_weight', None)
+        if wt is None:
+            return np.ones(self.num_triangles, dtype=bool)
+        return ~(np.asarray(wt) < thr) & (np.asarray(wt) > 0)
+
+    def submesh(self, tri_mask, **kwargs):                 # mesh.py:598-626
+        """the triangles selected by tri_mask (bool mask or index list) with the vertices they use, every gear kept"""
+        tri_mask = np.asarray(tri_mask)
+        if tri_mask.dtype == bool:
+            if tri_mask.all():
+                return self
+            sel = np.flatnonzero(tri_mask)
+        else:
+            sel = tri_mask
+            if sel.size == self.num_triangles and np.array_equal(np.sort(sel), np.arange(self.num_triangles)):
+                return self
+        t = self.triangles[sel]
+        vidx, inv = np.unique(t, return_inverse=True)
+        pick_v = lambda a: None if a is None else a[vidx]
+        pick_t = lambda a: None if (a is None or np.ndim(a) == 0) else np.asarray(a)[sel]
+        kw = dict(fixed_vertices=pick_v(self._vertices[const.MESH_GEAR_FIXED]), moving_vertices=pick_v(self._vertices[const.MESH_GEAR_MOVING]),
+                  staging_vertices=pick_v(self._vertices[const.MESH_GEAR_STAGING]),
+                  initial_offset=self._offsets[const.MESH_GEAR_INITIAL], fixed_offset=self._offsets[const.MESH_GEAR_FIXED],
+                  moving_offset=self._offsets[const.MESH_GEAR_MOVING], staging_offset=self._offsets[const.MESH_GEAR_STAGING],
+                  stiffness_multiplier=pick_t(self._stiffness_multiplier), poisson_ratio=self.poisson_ratio,
+                  material_multiplier=self.material_multiplier, resolution=self.resolution, locked=self.locked,
+                  soft_factor=self.soft_factor, uid=self.uid)
+        if self.tri_model is not None:
+            kw.update(tri_model=self.tri_model[sel], tri_nu=self.tri_nu[sel], tri_matmult=self.tri_matmult[sel])
+        kw.update(kwargs)
+        m = Mesh(self._vertices[const.MESH_GEAR_INITIAL][vidx], inv.reshape(-1, 3), **kw)
+        if getattr(self, 'tri_render_weight', None) is not None:
+            m.tri_render_weight = np.asarray(self.tri_render_weight)[sel]
+        return m
+
+    def divide_disconnected_mesh(self, **kwargs):          # mesh.py:689-704
+        n, lab = self.connected_triangles()
+        if n == 1:
+            return [self]
+        lbls = np.unique(lab)
+        uids = self.uid + 0.5 * (np.arange(lbls.size) + 1) / (10 ** (np.ceil(np.log10(lbls.size + 1))))
+        return [self.submesh(lab == lb, uid=float(u), **kwargs) for lb, u in zip(lbls, uids)]
+
     def anneal(self, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_CONNECTED_RIGID):
         """feabas/mesh.py:2421-2458: move the resting state gear[1] towards gear[0] -- one rigid / affine fit for the
         whole mesh, one per connected component (after the global rigid one), or an exact copy."""

@@ -215,6 +215,82 @@ class SLM:
         self.links.append(link)
         return True
 
+    # ------------------------------------------------------------------ sub-meshes (optimizer.py:688-754, 1778-1858)
+    def select_mesh_from_uid(self, uid):
+        """meshes that carry `uid`, or -- for the uid of a mesh that has been cut into parts -- its parts (uids within 0.5
+        above the parent's); the flag tells whether the match is exact and unique (optimizer.py:1798-1816)"""
+        exact = [m for m in self.meshes if m.uid == uid]
+        if exact:
+            return exact, len(exact) == 1
+        parts = [m for m in self.meshes if np.floor(m.uid) == np.floor(uid)]
+        return parts, False
+
+    def link_is_relevant(self, link):                      # optimizer.py:1778-1795
+        if link is None or not link.relevant:
+            return 0
+        for lid in link.uids:
+            sel, exact = self.select_mesh_from_uid(lid)
+            if len(sel) == 0:
+                return 0
+            if not exact:
+                return -1
+        return 1
+
+    @staticmethod
+    def distribute_link(mesh0_list, mesh1_list, link, exclusive=True, working_gear=const.MESH_GEAR_INITIAL, **kwargs):
+        """optimizer.py:1818-1858: the matches of one link dealt to the pairs of parts that contain them"""
+        xy0 = link.xy0(gear=working_gear, use_mask=False, combine=True)
+        xy1 = link.xy1(gear=working_gear, use_mask=False, combine=True)
+        weight = link.weight(use_mask=False)
+        out = []
+        for m0 in mesh0_list:
+            for m1 in mesh1_list:
+                if xy0.shape[0] == 0:
+                    break
+                lnk, mask = Link.from_coordinates(m0, m1, xy0, xy1, gear=(working_gear, working_gear), weight=weight, strain=link.strain)
+                if lnk is None:
+                    continue
+                lnk._weight_func = link._weight_func
+                out.append(lnk)
+                if exclusive:
+                    xy0, xy1, weight = xy0[~mask], xy1[~mask], weight[~mask]
+        return out
+
+    def prune_links(self, **kwargs):                       # optimizer.py:688-717
+        if len(self.links) == 0:
+            return False
+        relevance = np.array([self.link_is_relevant(lnk) for lnk in self.links])
+        if np.all(relevance == 1):
+            return False
+        new_links = []
+        for lnk, flag in zip(self.links, relevance):
+            if flag == 1:
+                new_links.append(lnk)
+            elif flag == -1:
+                m0_list, _ = self.select_mesh_from_uid(lnk.uids[0])
+                m1_list, _ = self.select_mesh_from_uid(lnk.uids[1])
+                new_links.extend(SLM.distribute_link(m0_list, m1_list, lnk, working_gear=kwargs.get('working_gear', const.MESH_GEAR_INITIAL),
+                                                     exclusive=kwargs.get('submesh_exclusive', True)))
+        self.links = new_links
+        return True
+
+    def divide_disconnected_submeshes(self, prune_links=True, **kwargs):      # optimizer.py:738-754
+        modified = False
+        new_meshes = []
+        for m in self.meshes:
+            if m.locked:
+                new_meshes.append(m)
+            else:
+                dm = m.divide_disconnected_mesh()
+                new_meshes.extend(dm)
+                modified |= len(dm) > 1
+        if modified:
+            self.meshes = new_meshes
+            self._drop_system()
+            if prune_links:
+                self.prune_links(**kwargs)
+        return modified
+
     def clear_links(self):
         self.links = []
 

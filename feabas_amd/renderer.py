@@ -32,6 +32,18 @@ class ResidentImage:
         self.origin = (int(origin[0]), int(origin[1]))
         self.buf = _lib.DeviceBuffer.from_array(image)
 
+    @classmethod
+    def from_loader(cls, loader, bbox, **kwargs):
+        """the area `bbox` = (xmin, ymin, xmax, ymax) of a reference-style image loader (dal.StreamLoader /
+        MosaicLoader / ...: ``crop(bbox, return_empty=, fillval=)``, dal.py:1045-1050) read ONCE and kept in HBM: what the
+        reference's renderer asks its loader for block by block (renderer.py:601-631) is served from this copy.  Pixels of
+        the area outside the loader's image hold the loader's fill value (its crop fills them); outside `bbox` reads 0."""
+        bbox = [int(v) for v in bbox]
+        img = loader.crop(bbox, return_empty=True, **kwargs)
+        if img is None:
+            img = np.zeros((bbox[3] - bbox[1], bbox[2] - bbox[0]), dtype=np.uint8)
+        return cls(np.ascontiguousarray(img), origin=(bbox[0], bbox[1]))
+
     def free(self):
         self.buf.free()
 

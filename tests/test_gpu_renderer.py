@@ -252,6 +252,79 @@ def test_section_matcher_recovers_a_known_field(fb):
     assert np.all(weight > 0.3 * 0) and weight.shape[0] == xy0.shape[0]
 
 
+def test_section_matcher_defaults_on_islands_with_a_hole(fb):
+    """the reference's alignment defaults end to end (matcher.py:370-427, default_alignment_configs.yaml:13-27): region-aware
+    block lattice (`cartesian_region`, min_boundary_distance), residue_len in units of the section thickness (< 0), soft
+    triangles dropped by `stiffness_multiplier_threshold`, and -- with initial matches -- the meshes cut into their connected
+    parts, each pair of parts matched on its own.  Two islands (one with a hole); section 1 = section 0 through a known field;
+    the images come from a loader with the reference's crop() interface."""
+    from scipy.ndimage import map_coordinates
+    from feabas_amd import matcher, constant as const
+    from feabas_amd.mesh import Mesh
+    rng = np.random.default_rng(43)
+    SH, SW = 1000, 1900
+    base = _texture(rng, SH, SW)
+    yy, xx = np.meshgrid(np.arange(SH, dtype=np.float64), np.arange(SW, dtype=np.float64), indexing='ij')
+
+    def field(x, y):
+        return (4.0 * np.sin(2 * np.pi * y / 900.0 + 0.4) + 1.5 * (x / SW) ** 2, 3.5 * np.cos(2 * np.pi * x / 1100.0) - 1.0 * (x / SW) * (y / SH))
+    ux, uy = field(xx, yy)
+    img1 = np.clip(np.rint(map_coordinates(base.astype(np.float32), [yy + uy, xx + ux], order=1, mode='nearest')), 0, 255).astype(np.uint8)
+
+    class Loader:                                                    # dal.StreamLoader's interface (dal.py:1045-1050)
+        def __init__(self, img):
+            self.img, self.calls = img, 0
+
+        def crop(self, bbox, return_empty=False, **kwargs):
+            self.calls += 1
+            x0, y0, x1, y1 = (int(v) for v in bbox)
+            out = np.zeros((y1 - y0, x1 - x0), dtype=self.img.dtype)
+            ya, yb, xa, xb = max(y0, 0), min(y1, self.img.shape[0]), max(x0, 0), min(x1, self.img.shape[1])
+            if ya < yb and xa < xb:
+                out[ya - y0:yb - y0, xa - x0:xb - x0] = self.img[ya:yb, xa:xb]
+            return out
+
+    def islands(seed, uid):
+        r = np.random.default_rng(seed)
+        vs, ts, soft = [], [], []
+        nv = 0
+        for (x0, y0, w, h, hole) in ((40, 40, 900, 900, (330, 330, 600, 600)), (1060, 120, 780, 760, None)):
+            gx, gy = np.meshgrid(np.arange(x0, x0 + w + 1, 60.0), np.arange(y0, y0 + h + 1, 60.0))
+            v = np.stack((gx.ravel(), gy.ravel()), axis=-1)
+            inner = (gx.ravel() > x0) & (gx.ravel() < x0 + w) & (gy.ravel() > y0) & (gy.ravel() < y0 + h)
+            v[inner] += r.uniform(-0.25, 0.25, (int(inner.sum()), 2)) * 60.0
+            t = Delaunay(v).simplices.astype(np.int32)
+            p = v[t]
+            area = (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1]) - (p[:, 1, 1] - p[:, 0, 1]) * (p[:, 2, 0] - p[:, 0, 0])
+            t[area < 0] = t[area < 0][:, ::-1]
+            c = p.mean(axis=1)
+            in_hole = np.zeros(t.shape[0], dtype=bool) if hole is None else ((c[:, 0] > hole[0]) & (c[:, 0] < hole[2]) & (c[:, 1] > hole[1]) & (c[:, 1] < hole[3]))
+            vs.append(v); ts.append(t + nv); soft.append(in_hole); nv += v.shape[0]
+        t = np.concatenate(ts); soft = np.concatenate(soft)
+        # the hole is a soft material (stiffness multiplier 0.01): section_matcher drops its triangles
+        return Mesh(np.concatenate(vs), t, uid=uid, tri_model=np.zeros(t.shape[0], np.int32), tri_matmult=np.where(soft, 0.01, 1.0).astype(np.float32))
+    M0, M1 = islands(1, 0.0), islands(2, 1.0)
+    assert M0.connected_triangles()[0] == 2
+    # initial matches: a sparse set of true correspondences (what the thumbnail stage delivers)
+    q = np.stack((rng.uniform(80, 1800, 400), rng.uniform(80, 900, 400)), axis=-1)
+    ex, ey = field(q[:, 0], q[:, 1])
+    ini = (q + np.stack((ex, ey), axis=-1) + rng.normal(0, 0.5, q.shape), q, np.ones(400, dtype=np.float32))
+    ld0, ld1 = Loader(base), Loader(img1)
+    xy0, xy1, weight, strain = matcher.section_matcher(M0, M1, ld0, ld1, spacings=[200, 70], conf_thresh=0.3, residue_len=-1, section_thickness=12.0,
+                                                       min_boundary_distance=20, initial_matches=ini, compute_strain=True, num_workers=4)
+    assert ld0.calls == 1 and ld1.calls == 1                          # one read per section, not one per block
+    assert xy0 is not None and xy0.shape[0] > 150
+    ex, ey = field(xy1[:, 0], xy1[:, 1])
+    err = np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)
+    assert np.median(err) < 0.3 and np.quantile(err, 0.9) < 1.0
+    # matches of both islands, none in the hole, none in the gap between the islands, all >= 20 px inside the outline
+    assert np.any(xy1[:, 0] < 950) and np.any(xy1[:, 0] > 1050)
+    assert not np.any((xy1[:, 0] > 345) & (xy1[:, 0] < 585) & (xy1[:, 1] > 345) & (xy1[:, 1] < 585))
+    assert not np.any((xy1[:, 0] > 945) & (xy1[:, 0] < 1055))
+    with pytest.raises(TypeError):
+        matcher.section_matcher(M0, M1, ld0, ld1, spacings=[200], bogus=1)
+
+
 def test_device_point_location_vs_matplotlib(fb):
     """Mesh.tri_finder on the device (fb_mesh_locate_dev) against matplotlib's trapezoid-map finder, which the reference uses
     (mesh.py:2080-2188): same triangles for random points inside and outside an irregular deformed mesh"""
