@@ -114,6 +114,9 @@ _PROTOS = {
     'fb_spmv_dev': (c_i, [c_p, c_p, c_p, c_p]),
     'fb_pcg_csr': (c_i, [c_p, c_p, c_p, c_p, c_i, c_d, c_d, c_i, c_i, C.POINTER(c_i), C.POINTER(c_d)]),
     'fb_pcg_fixed_iters': (c_i, [c_p, c_p, c_p, c_i, C.POINTER(c_d)]),
+    'fb_cgcg_update_dev': (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'fb_cgcg_dots_dev': (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    'fb_cgcg_scalars_dev': (c_i, [c_p, c_p, c_p, c_i]),
     'fb_comm_unique_id': (c_i, [c_p, c_p]),
     'fb_comm_create': (c_i, [c_p, c_p, c_i, c_i, C.POINTER(c_p)]),
     'fb_comm_destroy': (None, [c_p, c_p]),

@@ -730,6 +730,113 @@ int fb_spmv_dev(fb_ctx* ctx, fb_csr* A, const double* x_dev, double* y_dev) {
     return fb_bsr_spmv_dev(ctx, A->M, reinterpret_cast<const double2*>(x_dev), reinterpret_cast<double2*>(y_dev));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Vector side of the row-partitioned (coupled-window) PCG in its Chronopoulos-Gear form (feabas_amd/dist.py): between two
+// halo exchanges a rank runs  update -> [exchange u] -> SpMV -> dots -> [all-reduce 3 scalars] -> scalars,  all on device
+// pointers on the context's stream.  state (device double[8]) = {gamma, alpha, beta, r.r, breakdown flag, iterations, -, -}.
+namespace {
+constexpr int kCgWG = 1024;       // workgroups of the update / dot kernels; partial sums in a fixed order (reproducible)
+
+__global__ __launch_bounds__(256) void cgcg_update_kernel(int64_t n, const double* __restrict__ state, const double* __restrict__ minv,
+                                                          double* __restrict__ x, double* __restrict__ r, double* __restrict__ u,
+                                                          const double* __restrict__ w, double* __restrict__ p, double* __restrict__ s) {
+    const double alpha = state[1], beta = state[2];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double pi = u[i] + beta * p[i];
+        const double si = w[i] + beta * s[i];
+        const double ri = r[i] - alpha * si;
+        p[i] = pi; s[i] = si;
+        x[i] += alpha * pi;
+        r[i] = ri;
+        u[i] = minv[i] * ri;
+    }
+}
+
+__global__ __launch_bounds__(256) void cgcg_dots_kernel(int64_t n, const double* __restrict__ r, const double* __restrict__ u,
+                                                        const double* __restrict__ w, double* __restrict__ part) {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double ri = r[i], ui = u[i];
+        a += ri * ui; b += w[i] * ui; c += ri * ri;
+    }
+    __shared__ double sh[3][4];
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; sh[2][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3) part[(size_t)threadIdx.x * kCgWG + blockIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(256) void cgcg_dots_final_kernel(int nblk, const double* __restrict__ part, double* __restrict__ out3) {
+    __shared__ double sh[256];
+    for (int k = 0; k < 3; ++k) {
+        double a = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += 256) a += part[(size_t)k * kCgWG + i];
+        sh[threadIdx.x] = a;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out3[k] = sh[0];
+        __syncthreads();
+    }
+}
+
+// t3 = (r.u, w.u, r.r) summed over the ranks.  first != 0: the start of the iteration (alpha = gamma / delta, beta = 0)
+__global__ void cgcg_scalars_kernel(const double* __restrict__ t3, double* __restrict__ state, int first) {
+    const double g_new = t3[0], delta = t3[1];
+    double alpha, beta;
+    if (first) {
+        beta = 0.0;
+        alpha = delta > 0.0 ? g_new / delta : 0.0;
+        state[4] = delta > 0.0 || g_new == 0.0 ? 0.0 : 1.0;
+        state[5] = 0.0;
+    } else {
+        const double g_old = state[0], a_old = state[1];
+        beta = g_old != 0.0 ? g_new / g_old : 0.0;
+        const double den = a_old != 0.0 ? delta - beta * g_new / a_old : 0.0;
+        // den <= 0 (loss of positive definiteness in floating point, or an exactly converged residual): the step is dropped
+        // instead of poisoning x with 0 / 0; the flag tells the host
+        alpha = den > 0.0 ? g_new / den : 0.0;
+        if (!(den > 0.0) && g_new != 0.0) state[4] = 1.0;
+        if (!(den > 0.0)) beta = 0.0;
+        state[5] += 1.0;
+    }
+    state[0] = g_new; state[1] = alpha; state[2] = beta; state[3] = t3[2];
+}
+}  // namespace
+
+int fb_cgcg_update_dev(fb_ctx* ctx, int64_t n, const double* state, const double* minv, double* x, double* r, double* u, const double* w,
+                       double* p, double* s) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, n >= 0 && state && (n == 0 || (minv && x && r && u && w && p && s)));
+    if (n == 0) return FB_OK;
+    FB_PROF_B(ctx, "cgcg_update", (double)n * 8.0 * 12.0);
+    hipLaunchKernelGGL(cgcg_update_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kCgWG)), dim3(256), 0, ctx->stream, n, state, minv, x, r, u, w, p, s);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+// out3 = (r.u, w.u, r.r) of the local parts; scratch: device double[3 * 1024]
+int fb_cgcg_dots_dev(fb_ctx* ctx, int64_t n, const double* r, const double* u, const double* w, double* scratch, double* out3) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, n >= 0 && scratch && out3 && (n == 0 || (r && u && w)));
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, kCgWG));
+    FB_PROF_B(ctx, "cgcg_dots", (double)n * 8.0 * 3.0);
+    hipLaunchKernelGGL(cgcg_dots_kernel, dim3(nblk), dim3(256), 0, ctx->stream, n, r, u, w, scratch);
+    hipLaunchKernelGGL(cgcg_dots_final_kernel, dim3(1), dim3(256), 0, ctx->stream, nblk, scratch, out3);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+int fb_cgcg_scalars_dev(fb_ctx* ctx, const double* t3, double* state, int first) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, t3 && state);
+    hipLaunchKernelGGL(cgcg_scalars_kernel, dim3(1), dim3(1), 0, ctx->stream, t3, state, first);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
 int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, double rtol, double atol, int maxiter, int precond,
                int* iters, double* relres) {
     FB_LOCK(ctx);

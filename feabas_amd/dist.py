@@ -288,15 +288,23 @@ class RowPartition:
             out_halo[sl] = t.to(out_halo.device)
 
 
-def pcg_row_partitioned(part, spmv, b_loc, minv_loc, rtol=1e-7, maxiter=10000, check_every=8):
+def pcg_row_partitioned(part, spmv, b_loc, minv_loc, rtol=1e-7, maxiter=10000, check_every=8, fused=None):
     """Jacobi-preconditioned conjugate gradients on a row-partitioned system.
 
     part: RowPartition; spmv(u_ext) -> (A u)_loc for u_ext = [u_loc | u_halo] (torch tensor, n_loc + n_halo);
     b_loc, minv_loc: torch tensors [n_loc] on the compute device (right-hand side, inverse diagonal).
     One halo exchange + one SpMV + ONE all-reduce (3 scalars) per iteration; the scalars stay on the device, the host
     looks at the residual every `check_every` iterations only (with RCCL nothing else synchronises the host).
-    Stops at ||r|| <= rtol ||b||.  Returns (x_loc, iterations, relative residual)."""
+    fused (default: when `spmv` is a DeviceRows and the vectors live on the GPU): the vector updates, the three inner
+    products and the scalar recurrences run as the library's fused kernels (fb_cgcg_*_dev) on the rows' stream.
+    A non-positive denominator of the recurrence (a system that is not positive definite in floating point, or a residual
+    that has reached exactly zero) drops the step instead of dividing by zero; a non-finite residual ends the loop with the
+    last iterate and raises.  Stops at ||r|| <= rtol ||b||.  Returns (x_loc, iterations, relative residual)."""
     torch, dist = _dist()
+    if fused is None:
+        fused = isinstance(spmv, DeviceRows) and b_loc.is_cuda
+    if fused:
+        return _pcg_row_partitioned_fused(part, spmv, b_loc, minv_loc, rtol, maxiter, check_every)
     cdev = _device(dist)
     n = part.n_loc
 
@@ -322,9 +330,10 @@ def pcg_row_partitioned(part, spmv, b_loc, minv_loc, rtol=1e-7, maxiter=10000, c
     bnorm2 = float(rr)
     if bnorm2 == 0.0 or maxiter == 0:
         return x, 0, 0.0
+    zero = torch.zeros((), dtype=b_loc.dtype, device=b_loc.device)
     p = torch.zeros_like(b_loc); s = torch.zeros_like(b_loc)
-    alpha = gamma / delta
-    beta = torch.zeros((), dtype=b_loc.dtype, device=b_loc.device)
+    alpha = torch.where(delta > 0, gamma / delta, zero)
+    beta = zero.clone()
     it = 0
     rel = 1.0
     while it < maxiter:
@@ -339,11 +348,73 @@ def pcg_row_partitioned(part, spmv, b_loc, minv_loc, rtol=1e-7, maxiter=10000, c
         it += 1
         if it % check_every == 0 or it == maxiter:
             rel = (float(t[2]) / bnorm2) ** 0.5                      # the only host synchronisation of the loop
+            if not np.isfinite(rel):
+                raise FloatingPointError('pcg_row_partitioned: the residual is not finite (system not positive definite?)')
             if rel <= rtol:
                 break
-        beta = t[0] / gamma
-        alpha = t[0] / (t[1] - beta * t[0] / alpha)
+        beta = torch.where(gamma != 0, t[0] / gamma, zero)
+        den = t[1] - beta * t[0] / torch.where(alpha != 0, alpha, torch.ones_like(alpha))
+        ok = (den > 0) & (alpha != 0)
+        alpha = torch.where(ok, t[0] / torch.where(ok, den, torch.ones_like(den)), zero)
+        beta = torch.where(ok, beta, zero)
         gamma = t[0]
+    return x, it, rel
+
+
+def _pcg_row_partitioned_fused(part, rows, b_loc, minv_loc, rtol, maxiter, check_every):
+    """the same iteration with the library's fused kernels: per iteration  fb_cgcg_update_dev -> halo exchange ->
+    fb_spmv_dev -> fb_cgcg_dots_dev -> all-reduce (3 doubles) -> fb_cgcg_scalars_dev, on the stream of `rows`"""
+    torch, dist = _dist()
+    from . import _lib
+    lib, ctx = _lib.load(), rows._ctx
+    cdev = _device(dist)
+    n = part.n_loc
+    dev = b_loc.device
+    f64 = torch.float64
+    with torch.cuda.stream(rows.stream()):
+        ext = torch.zeros(n + part.n_halo, dtype=f64, device=dev)
+        x = torch.zeros(n, dtype=f64, device=dev)
+        r = b_loc.to(f64).clone()
+        p = torch.zeros(n, dtype=f64, device=dev); s = torch.zeros(n, dtype=f64, device=dev)
+        w = torch.zeros(n, dtype=f64, device=dev)
+        minv = minv_loc.to(f64).contiguous()
+        state = torch.zeros(8, dtype=f64, device=dev)
+        t3 = torch.zeros(3, dtype=f64, device=dev)
+        scratch = torch.zeros(3 * 1024, dtype=f64, device=dev)
+        u = ext[:n]                                                  # u lives at the head of the extended vector: no copy before the SpMV
+
+        def product_and_dots(first):
+            part.exchange(u, ext[n:])
+            y = rows(ext)                                            # fb_spmv_dev on the same stream
+            w.copy_(y)
+            _lib.check(lib.fb_cgcg_dots_dev(ctx, n, C_ptr(r), C_ptr(u), C_ptr(w), C_ptr(scratch), C_ptr(t3)), h=ctx)
+            if part.world > 1:
+                if cdev != dev:
+                    tc = t3.to(cdev)
+                    dist.all_reduce(tc, group=part.group)
+                    t3.copy_(tc)
+                else:
+                    dist.all_reduce(t3, group=part.group)
+            _lib.check(lib.fb_cgcg_scalars_dev(ctx, C_ptr(t3), C_ptr(state), 1 if first else 0), h=ctx)
+        u.copy_(minv * r)
+        product_and_dots(True)
+        bnorm2 = float(state[3])
+        if bnorm2 == 0.0 or maxiter == 0:
+            return x, 0, 0.0
+        it = 0
+        rel = 1.0
+        while it < maxiter:
+            _lib.check(lib.fb_cgcg_update_dev(ctx, n, C_ptr(state), C_ptr(minv), C_ptr(x), C_ptr(r), C_ptr(u), C_ptr(w), C_ptr(p), C_ptr(s)), h=ctx)
+            product_and_dots(False)
+            it += 1
+            if it % check_every == 0 or it == maxiter:
+                st = state.cpu()                                     # the only host synchronisation of the loop
+                rel = (float(st[3]) / bnorm2) ** 0.5
+                if not np.isfinite(rel):
+                    raise FloatingPointError('pcg_row_partitioned: the residual is not finite (system not positive definite?)')
+                if rel <= rtol:
+                    break
+        torch.cuda.current_stream().synchronize()
     return x, it, rel
 
 

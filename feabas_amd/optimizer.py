@@ -633,7 +633,7 @@ class SLM:
         links = self._ensure_system(groupings)
         offs = self._offs
         for m in self.meshes:
-            if offs[m.uid] < 0:
+            if offs[m.uid] < 0 or m.uid in getattr(self, '_skip_stiffness', ()):
                 continue
             v0 = np.ascontiguousarray(m.vertices(shape_gear), dtype=np.float64)
             v1 = m.vertices(start_gear)
@@ -688,6 +688,15 @@ class SLM:
         crosslink_lambda = kwargs.get('crosslink_lambda', self._crosslink_lambda)
         precondition = kwargs.get('precondition', 'jacobi')
         groupings = kwargs.get('groupings', None)
+        if isinstance(precondition, str) and precondition.lower().startswith(('smooth', 'sa')):
+            # matcher.py:561 asks for pyamg's smoothed aggregation in its in-loop solves; pyamg is not in the image and the
+            # Jacobi-PCG runs to the requested tolerance, so the fixed point is the same
+            precondition = 'jacobi'
+        if kwargs.get('distributed', None) is not None:
+            if groupings is not None:
+                raise NotImplementedError('optimize_linear(distributed=...) with groupings')
+            return self._optimize_linear_distributed(kwargs['distributed'], kwargs.get('owned', None), tol, atol, maxiter, shape_gear,
+                                                     start_gear, target_gear, stiffness_lambda, crosslink_lambda)
         if kwargs.get('remove_material_dof', None) is not None:
             raise NotImplementedError('optimize_linear(remove_material_dof=...) is outside the hot path')
         if kwargs.get('remove_extra_dof', False):
@@ -727,6 +736,123 @@ class SLM:
                 if m.locked or o < 0:
                     continue
                 m.set_field(dd[o:o + 2 * m.num_vertices].reshape(-1, 2), gear=(start_gear, target_gear))
+        return cost
+
+    def _optimize_linear_distributed(self, group, owned, tol, atol, maxiter, shape_gear, start_gear, target_gear, stiffness_lambda, crosslink_lambda):
+        """optimize_linear of a coupled window (aligner.py:510-535, 696-727: all free sections of a window are ONE system)
+        with the rows partitioned by section over the ranks of `group` (torch.distributed; True = the default group).
+        Every rank holds the sections it OWNS (default: a contiguous shard of the free meshes in list order, every rank
+        listing the same meshes; or the uids in `owned`, the rank then only needs its own sections and the ones they are
+        linked to) plus the links that touch them.  Its rows -- stiffness of the own sections, link terms of every match that
+        touches them, including the blocks that couple to a neighbour's section -- are assembled on the device (fb_sys_*),
+        and solved with the row-partitioned Jacobi-PCG of feabas_amd/dist.py (halo exchange with the neighbouring ranks +
+        one fused all-reduce per iteration; fused vector kernels on the GPU).  The trace-relative lambdas come from
+        all-reduced sums.  Returns (||b||, ||A d - b||) of the whole window; every rank moves the sections it owns."""
+        import torch
+        import torch.distributed as dist
+        from . import dist as fdist
+        from .mesh import bsr_download
+        grp = None if group is True else group
+        rank, world = dist.get_rank(grp), dist.get_world_size(grp)
+        free = [m for m in self.meshes if not m.locked]
+        if owned is None:
+            a, b = fdist.shard_range(len(free), rank, world)
+            own = free[a:b]
+        else:
+            owned = {float(u) for u in owned}
+            own = [m for m in free if m.uid in owned]
+        own_ids = {id(m) for m in own}
+        links = [lk for lk in self._active_links() if id(lk.meshes[0]) in own_ids or id(lk.meshes[1]) in own_ids]
+        halo, seen = [], set(own_ids)
+        for lk in links:
+            for m in lk.meshes:
+                if not m.locked and id(m) not in seen:
+                    seen.add(id(m)); halo.append(m)
+        locked = [m for m in self.meshes if m.locked]
+        n_own = int(sum(2 * m.num_vertices for m in own))
+        sizes = [None] * world
+        dist.all_gather_object(sizes, [(m.uid, 2 * m.num_vertices) for m in own], group=grp)
+        gstart, cur, row_start = {}, 0, 0
+        for r_, lst in enumerate(sizes):
+            if r_ == rank:
+                row_start = cur
+            for uid, nd in lst:
+                gstart[uid] = cur
+                cur += nd
+        missing = [m.uid for m in halo if m.uid not in gstart]
+        if missing:
+            raise ValueError(f'optimize_linear(distributed): sections {missing} are linked to this rank but owned by no rank')
+        if n_own > 0:
+            local = SLM(own + halo + locked, links, stiffness_lambda=stiffness_lambda, crosslink_lambda=crosslink_lambda)
+            local._skip_stiffness = {m.uid for m in halo}
+            local._assemble(shape_gear, start_gear, target_gear)
+            nv, nnzb = local._nv, local._nnzb
+            K = bsr_download(local._sys, 0, nv, nnzb)[:n_own]
+            Cm = bsr_download(local._sys, 1, nv, nnzb)[:n_own]
+            rhs = np.empty(2 * nv); stress = np.empty(2 * nv, dtype=np.float32)
+            _lib.check(_lib.load().fb_sys_get(_lib.ctx(), local._sys, 2, _lib.ptr(rhs)))
+            _lib.check(_lib.load().fb_sys_get(_lib.ctx(), local._sys, 3, _lib.ptr(stress)))
+            rhs, stress = rhs[:n_own], stress[:n_own].astype(np.float64)
+            dk = K[:, :n_own].diagonal(); dc = Cm[:, :n_own].diagonal()
+            sums = np.array([dc.sum(), dk[dc != 0].sum()])
+        else:
+            sums = np.zeros(2)
+        on_gpu = dist.get_backend(grp) == 'nccl' or _lib._ctx is not None
+        cdev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(grp) == 'nccl' else torch.device('cpu')
+        ts = torch.from_numpy(sums).to(cdev)
+        dist.all_reduce(ts, group=grp)
+        tr_c, sum_k = (float(v) for v in ts.cpu())
+        sl, cl = float(stiffness_lambda), float(crosslink_lambda)
+        if sl < 0 or cl < 0:                                    # optimizer.py:1573-1590 on the all-reduced sums
+            sl = 0.0 if tr_c == 0 else abs(abs(sl / cl) * tr_c / sum_k)
+            cl = 1.0
+        if n_own > 0:
+            A = (sl * K + cl * Cm).tocsr()
+            A.sort_indices()
+            bvec = cl * rhs - sl * stress
+            # local column -> global DoF: own columns first, then the halo sections at their owner's offsets
+            col_map = np.empty(2 * nv, dtype=np.int64)
+            col_map[:n_own] = row_start + np.arange(n_own)
+            o = n_own
+            for m in halo:
+                nd = 2 * m.num_vertices
+                col_map[o:o + nd] = gstart[m.uid] + np.arange(nd)
+                o += nd
+            indptr, gcols, data = A.indptr.astype(np.int64), col_map[A.indices], A.data
+            diag = A[:, :n_own].diagonal()
+        else:
+            indptr, gcols, data, bvec, diag = np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0), np.zeros(0), np.zeros(0)
+        part = fdist.RowPartition(indptr, gcols, row_start, group=grp)
+        bn2 = torch.tensor([float(bvec @ bvec)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(bn2, group=grp)
+        bnorm = float(bn2.item()) ** 0.5
+        if bnorm == 0 or maxiter == 0:
+            return 0.0, 0.0
+        rtol = max(float(tol), float(atol or 0.0) / bnorm)
+        minv = 1.0 / np.clip(diag, min(1.0, diag.max(initial=0.0) / 1000.0) if diag.size else 1.0, None)       # optimizer.py:1962-1966 on the local rows
+        if on_gpu and n_own > 0:
+            dev = torch.device('cuda', torch.cuda.current_device())
+            rows = fdist.DeviceRows(part, indptr, data)
+            try:
+                x, it, rel = fdist.pcg_row_partitioned(part, rows, torch.from_numpy(bvec).to(dev), torch.from_numpy(minv).to(dev), rtol=rtol,
+                                                       maxiter=10000 if maxiter is None else int(maxiter))
+                x = x.cpu().numpy()
+            finally:
+                rows.free()
+        else:
+            from scipy import sparse as _sp
+            loc = _sp.csr_matrix((data, part.local_cols, indptr), shape=(n_own, part.n_loc + part.n_halo))
+            x, it, rel = fdist.pcg_row_partitioned(part, lambda ext: torch.from_numpy(loc @ ext.numpy()), torch.from_numpy(bvec), torch.from_numpy(minv),
+                                                   rtol=rtol, maxiter=10000 if maxiter is None else int(maxiter))
+            x = x.numpy()
+        self.last_solve = dict(iters=int(it), relres=float(rel), stiffness_lambda=sl, crosslink_lambda=cl, rows=n_own, halo=int(part.n_halo))
+        cost = (bnorm, float(rel) * bnorm)
+        if cost[1] < cost[0]:
+            o = 0
+            for m in own:
+                nd = 2 * m.num_vertices
+                m.set_field(x[o:o + nd].reshape(-1, 2), gear=(start_gear, target_gear))
+                o += nd
         return cost
 
     @property

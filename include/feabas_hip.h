@@ -336,6 +336,18 @@ int fb_spmv(fb_ctx* ctx, fb_csr* A, const double* x_host, double* y_host);
 int fb_spmv_dev(fb_ctx* ctx, fb_csr* A, const double* x_dev, double* y_dev);
 int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, double rtol, double atol,
                int maxiter, int precond, int* iters, double* relres);
+/* vector side of the row-partitioned PCG of a coupled alignment window (aligner.py:510-535, 696-727 solve all free sections
+ * of a window as one system; here its rows are partitioned by section over the ranks): Chronopoulos-Gear form, one fused
+ * all-reduce of three scalars per iteration.  All pointers are device pointers, nothing synchronises the host.
+ *   state double[8] = {gamma, alpha, beta, r.r, breakdown flag, iterations, -, -}
+ *   fb_cgcg_update_dev : p = u + beta p; s = w + beta s; x += alpha p; r -= alpha s; u = minv r   (one pass over 12 vectors)
+ *   fb_cgcg_dots_dev   : out3 = (r.u, w.u, r.r) of the local rows, fixed summation order; scratch double[3 * 1024]
+ *   fb_cgcg_scalars_dev: alpha, beta, gamma from the all-reduced out3 (first != 0: the start of the iteration); a
+ *                        non-positive denominator zeroes the step and raises the flag instead of producing NaN */
+int fb_cgcg_update_dev(fb_ctx* ctx, int64_t n, const double* state, const double* minv, double* x, double* r, double* u, const double* w,
+                       double* p, double* s);
+int fb_cgcg_dots_dev(fb_ctx* ctx, int64_t n, const double* r, const double* u, const double* w, double* scratch, double* out3);
+int fb_cgcg_scalars_dev(fb_ctx* ctx, const double* t3, double* state, int first);
 /* exactly `iters` PCG iterations with no convergence exit (throughput bench) */
 int fb_pcg_fixed_iters(fb_ctx* ctx, fb_csr* A, const double* b_host, int iters, double* relres);
 

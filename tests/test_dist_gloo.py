@@ -73,7 +73,7 @@ def _coupled_system(n_sections=4, nv=150, seed=0):
     n = 2 * nv
     blocks = []
     for s in range(n_sections):
-        L = sparse.diags([-1.0, 2.2, -1.0], [-2, 0, 2], shape=(n, n)) + sparse.diags([-0.3, -0.3], [-1, 1], shape=(n, n))
+        L = sparse.diags([-1.0, 2.8, -1.0], [-2, 0, 2], shape=(n, n)) + sparse.diags([-0.3, -0.3], [-1, 1], shape=(n, n))
         blocks.append(L * rng.uniform(0.8, 1.2))
     A = sparse.block_diag(blocks, format='lil')
     N = n * n_sections
@@ -151,3 +151,69 @@ def test_coupled_window_pcg_device_rows_world2(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_pcg_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
     _check_pcg(tmp_path, 2)
+
+
+def _window(n_sections=5, seed=3):
+    """an alignment window: a locked first section and four free ones (grid meshes of different sizes, smoothly displaced
+    relative to each other), every section linked to the next by 300 matches"""
+    from feabas_amd import mesh, optimizer
+    from oracle import fem_ref
+    rng = np.random.default_rng(seed)
+    meshes = []
+    for s in range(n_sections):
+        nx, ny = 22 + 2 * (s % 3), 18 + (s % 2)
+        v, t = fem_ref.grid_mesh(nx, ny, 10.0)
+        L = 10.0 * nx
+        d = np.stack((1.5 * np.sin(2 * np.pi * v[:, 1] / L + 0.7 * s), 1.2 * np.cos(2 * np.pi * v[:, 0] / L - 0.4 * s)), axis=-1)
+        meshes.append(mesh.Mesh(v + d, t, uid=float(s), locked=(s == 0)))
+    links = []
+    for s in range(n_sections - 1):
+        m0, m1 = meshes[s], meshes[s + 1]
+        n = 300
+        xy = np.stack((rng.uniform(5, 200, n), rng.uniform(5, 160, n)), axis=-1)
+        lk, _ = optimizer.Link.from_coordinates(m0, m1, xy, xy + rng.normal(0, 0.05, xy.shape), weight=rng.uniform(0.3, 1, n).astype(np.float32))
+        links.append(lk)
+    return meshes, links
+
+
+def _window_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from feabas_amd import optimizer
+    meshes, links = _window()
+    slm = optimizer.SLM(meshes, links, stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    cost = slm.optimize_linear(tol=1e-10, distributed=True)
+    a, b = fdist.shard_range(4, rank, world)
+    out = {f'v{m.uid:.0f}': m.vertices_w_offset(1) for m in meshes[1:][a:b]}
+    np.savez(os.path.join(outdir, f'w{rank}.npz'), cost=np.array(cost), iters=slm.last_solve['iters'], halo=slm.last_solve['halo'], **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [1, 2, 3])
+def test_optimize_linear_distributed_equals_single_gpu(tmp_path, world):
+    """SLM.optimize_linear(distributed=group): the coupled window (aligner.py:696-727) with its rows partitioned by section
+    over 1 / 2 / 3 ranks (processes sharing the GPU, gloo between them): device assembly of every rank's rows, halo exchange,
+    fused CG kernels -- the sections end where the single-GPU solve of the whole window puts them"""
+    import torch.multiprocessing as mp
+    from feabas_amd import optimizer
+    meshes, links = _window()
+    v_before = [m.vertices_w_offset(1).copy() for m in meshes]
+    ref_cost = optimizer.SLM(meshes, links, stiffness_lambda=1.0, crosslink_lambda=-1.0).optimize_linear(tol=1e-10)
+    motion = max(np.abs(m.vertices_w_offset(1) - v0).max() for m, v0 in zip(meshes, v_before))
+    assert motion > 0.5
+    mp.spawn(_window_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = {}
+    for r in range(world):
+        d = np.load(tmp_path / f'w{r}.npz')
+        got.update({k: d[k] for k in d.files if k.startswith('v')})
+        assert abs(d['cost'][0] - ref_cost[0]) <= 1e-9 * ref_cost[0]              # the same ||b||: same lambdas, same assembly
+        assert d['cost'][1] <= 1e-10 * d['cost'][0] * 1.01
+        assert (int(d['halo']) > 0) == (world > 1)
+    assert sorted(got) == ['v1', 'v2', 'v3', 'v4']
+    for m in meshes[1:]:
+        np.testing.assert_allclose(got[f'v{m.uid:.0f}'], m.vertices_w_offset(1), atol=1e-6 * motion)
