@@ -171,7 +171,8 @@ def _window(n_sections=5, seed=3):
         m0, m1 = meshes[s], meshes[s + 1]
         n = 300
         xy = np.stack((rng.uniform(5, 200, n), rng.uniform(5, 160, n)), axis=-1)
-        lk, _ = optimizer.Link.from_coordinates(m0, m1, xy, xy + rng.normal(0, 0.05, xy.shape), weight=rng.uniform(0.3, 1, n).astype(np.float32))
+        rel = np.stack((1.5 * np.sin(xy[:, 1] / 40.0 + s), 1.0 * np.cos(xy[:, 0] / 50.0 - s)), axis=-1)       # what the next section must follow
+        lk, _ = optimizer.Link.from_coordinates(m0, m1, xy, xy + rel + rng.normal(0, 0.05, xy.shape), weight=rng.uniform(0.3, 1, n).astype(np.float32))
         links.append(lk)
     return meshes, links
 
