@@ -787,9 +787,10 @@ def _stitching_options(kwargs):
     spacings = kw.pop('spacings', None)
     if spacings is not None:
         spacings = np.asarray(spacings, dtype=np.float64).ravel()
-        if spacings.size == 0 or np.any(spacings < 1):
-            raise NotImplementedError('stitching_matcher: spacings relative to the overlap (< 1) are not on the device path')
+        if spacings.size == 0:
+            raise ValueError('stitching_matcher: empty spacings')
     opts['spacings'] = spacings
+    opts['_relative_spacings'] = spacings is not None and bool(np.any(spacings < 1))
     compute_photometric = bool(kw.pop('compute_photometric', False))
     if compute_photometric and not sigma > 0:
         raise NotImplementedError('stitching_matcher(compute_photometric=True) needs sigma > 0 on the device path')
@@ -809,11 +810,83 @@ def _check_strips(img0, img1, coarse_downsample, contiguous=True):
         img0 = np.ascontiguousarray(img0)
     if contiguous or img1.ndim != 2 or img1.strides[-1] != img1.itemsize:
         img1 = np.ascontiguousarray(img1)
-    if img0.ndim != 2 or img0.shape != img1.shape or img0.dtype != np.uint8 or img1.dtype != np.uint8:
-        raise NotImplementedError('stitching_matcher: the device path takes two uint8 strips of equal shape')
-    if min(img0.shape) < 4:
+    if img0.ndim != 2 or img1.ndim != 2 or img0.dtype != np.uint8 or img1.dtype != np.uint8:
+        raise NotImplementedError('stitching_matcher: the device path takes two 2-D uint8 strips')
+    if min(img0.shape) < 4 or min(img1.shape) < 4:
         raise NotImplementedError('stitching_matcher: strips thinner than 4 pixels are not on the device path')
     return img0, img1
+
+
+def _stitching_matcher_general(img0, img1, opts, mask0, mask1, compute_photometric):
+    """feabas/matcher.py:224-367 statement by statement for the pairs the batched strip pipeline does not take -- strips of
+    UNEQUAL shape (the reference works on whatever the two crops are, matcher.py:244) or spacings relative to the overlap
+    (< 1, matcher.py:343-350): x0.5 area downsample, DoG and the global translation on the device, two cartesian meshes of
+    their own size, and the general-mesh loop ``iterative_xcorr_matcher_w_mesh`` (device renderer + NCC + SLM)."""
+    from . import renderer as _rd
+    from .mesh import Mesh
+    sigma, cds = opts['sigma'], opts['coarse_downsample']
+    conf_thresh, conf_mode, mnb = opts['conf_thresh'], opts['conf_mode'], opts['min_num_blocks']
+    spacings = opts['spacings']
+    spacings = auto_spacings(img0.shape, img1.shape) if spacings is None else np.array(spacings, dtype=np.float64)
+
+    def coarse_mask(mk, shape):
+        if mk is None:
+            return None
+        mk = np.asarray(mk, dtype=bool)
+        return mk[::2, ::2][:shape[0], :shape[1]] if cds == 0.5 else mk       # cv2.resize(INTER_NEAREST, 0.5): every second pixel
+    if cds == 0.5:
+        r0, r1 = common.area_downsample2(img0), common.area_downsample2(img1)
+    else:
+        r0, r1 = img0, img1
+    mg0, mg1 = coarse_mask(mask0, r0.shape), coarse_mask(mask1, r1.shape)
+    if sigma > 0:
+        g0 = common.masked_dog_filter(r0, sigma * cds, mask=mg0); g1 = common.masked_dog_filter(r1, sigma * cds, mask=mg1)
+    else:
+        g0, g1 = r0.astype(np.float32), r1.astype(np.float32)
+    tx0, ty0, conf0 = global_translation_matcher(g0, g1, conf_mode=conf_mode, conf_thresh=conf_thresh)
+    if conf0 < conf_thresh:
+        return None, None, conf_thresh, None, None
+    phtm = None
+    if compute_photometric:                                                   # matcher.py:279-314
+        txx, tyy = int(tx0), int(ty0)
+        bb, _ = common.intersect_bbox((txx, tyy, g0.shape[1] + txx, g0.shape[0] + tyy), (0, 0, g1.shape[1], g1.shape[0]))
+        xa, ya, xb, yb = (int(v) for v in bb)
+        i0 = (slice(ya - tyy, yb - tyy), slice(xa - txx, xb - txx)); i1 = (slice(ya, yb), slice(xa, xb))
+        m0p = np.ones((yb - ya, xb - xa), dtype=bool) if mg0 is None else mg0[i0]
+        m1p = np.ones((yb - ya, xb - xa), dtype=bool) if mg1 is None else mg1[i1]
+        mp = m0p & m1p
+        if np.sum(m0p) > 3:
+            if sigma > 0:
+                phtm = (np.mean(r0[i0][mp]), np.mean(r1[i1][mp]), np.mean(np.abs(g0[i0][mp])), np.mean(np.abs(g1[i1][mp])))
+            else:
+                phtm = (np.mean(g0[i0][mp]), np.mean(g1[i1][mp]), np.std(g0[i0][mp]), np.std(g1[i1][mp]))
+    if cds == 1:
+        f0, f1 = g0, g1
+    elif sigma > 0:
+        f0 = common.masked_dog_filter(img0, sigma, mask=mask0); f1 = common.masked_dog_filter(img1, sigma, mask=mask1)
+    else:
+        f0, f1 = img0.astype(np.float32), img1.astype(np.float32)
+    tx0, ty0 = tx0 / cds, ty0 / cds
+    if np.any(spacings < 1):                                                  # matcher.py:343-350
+        bb, _ = common.intersect_bbox(np.array((0, 0, f0.shape[1], f0.shape[0])) + np.tile((tx0, ty0), 2), (0, 0, f1.shape[1], f1.shape[0]))
+        spacings = spacings.copy()
+        spacings[spacings < 1] *= max(bb[2] - bb[0], bb[3] - bb[1])
+    min_spacing = float(np.min(spacings))
+    mesh0 = Mesh.from_bbox((0, 0, f0.shape[1], f0.shape[0]), cartesian=True, mesh_size=min_spacing, min_num_blocks=mnb, uid=0)
+    mesh1 = Mesh.from_bbox((0, 0, f1.shape[1], f1.shape[0]), cartesian=True, mesh_size=min_spacing, min_num_blocks=mnb, uid=1)
+    mesh0.apply_translation((tx0, ty0), const.MESH_GEAR_FIXED)
+    mesh0.lock()
+    im0, im1 = _rd.ResidentImage(np.ascontiguousarray(f0, dtype=np.float32)), _rd.ResidentImage(np.ascontiguousarray(f1, dtype=np.float32))
+    try:
+        xy0, xy1, weight, strain = iterative_xcorr_matcher_w_mesh(mesh0, mesh1, im0, im1, spacings=spacings, distributor='cartesian_bbox',
+                                                                  residue_len=opts['residue_len'], residue_mode=('threshold' if opts['residue_mode'] == 'threshold' else 'huber'),
+                                                                  conf_thresh=conf_thresh, conf_mode=conf_mode, min_num_blocks=mnb,
+                                                                  stiffness_lambda=opts['stiffness_lambda'], compute_strain=opts['compute_strain'])
+    finally:
+        im0.free(); im1.free()
+    if xy0 is None:
+        return None, None, conf_thresh, None, None
+    return xy0, xy1, weight, strain, phtm
 
 
 def stitching_matcher(img0, img1, **kwargs):
@@ -830,6 +903,9 @@ def stitching_matcher(img0, img1, **kwargs):
     from .stitch_pipeline import StripBatchMatcher
     opts, mask0, mask1, compute_photometric = _stitching_options(kwargs)
     img0, img1 = _check_strips(img0, img1, opts['coarse_downsample'])
+    relative = opts.pop('_relative_spacings')
+    if img0.shape != img1.shape or relative:
+        return _stitching_matcher_general(img0, img1, opts, mask0, mask1, compute_photometric)
     H, W = img0.shape
     spacings = opts['spacings']
     key = (H, W) + tuple(None if v is None else (tuple(v.tolist()) if isinstance(v, np.ndarray) else v) for v in opts.values()) + (id(_lib.ctx()),)
@@ -874,16 +950,32 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         if kwargs.get(name, None) is not None:
             raise ValueError('stitching_matcher_batch: masks are given per pair, as (img0, img1, mask0, mask1)')
     opts, _, _, compute_photometric = _stitching_options(kwargs)
+    relative = opts.pop('_relative_spacings')
     items = []
+    general = {}
     for k, pr in enumerate(pairs):
         img0, img1 = _check_strips(pr[0], pr[1], opts['coarse_downsample'], contiguous=False)
         mk0, mk1 = (pr[2], pr[3]) if len(pr) > 2 else (None, None)
-        for mk in (mk0, mk1):
-            if mk is not None and np.asarray(mk).shape != img0.shape:
+        for mk, im in ((mk0, img0), (mk1, img1)):
+            if mk is not None and np.asarray(mk).shape != im.shape:
                 raise ValueError('stitching_matcher_batch: a mask must have the shape of its strip')
+        if img0.shape != img1.shape or relative:
+            # two crops of different size (an overlap clipped by a tile border on one side only), or spacings relative to the
+            # overlap: the general-mesh route, pair by pair
+            general[k] = _stitching_matcher_general(np.ascontiguousarray(img0), np.ascontiguousarray(img1), opts, mk0, mk1, compute_photometric)
+            img0 = img1 = None
         items.append((img0, img1, mk0, mk1))
     if not items:
         return []
+    if general:
+        keep = [k for k in range(len(items)) if k not in general]
+        rest = stitching_matcher_batch([pairs[k] for k in keep], batch=batch, threads=threads, **kwargs) if keep else []
+        out = [None] * len(items)
+        for k, r in zip(keep, rest):
+            out[k] = r
+        for k, r in general.items():
+            out[k] = r
+        return out
     # chunks: ('uniform', (H, W), indices) -- pairs of one strip shape, through StripBatchMatcher (masks, photometric
     # statistics and the deformed-mesh branch included); ('ragged', key, indices) -- pairs of unequal shape that share the
     # mesh topology and the number of spacings, through RaggedStripBatchMatcher (strips differ in shape from pair to pair

@@ -711,3 +711,28 @@ def test_stitching_matcher_threshold_residue_mode(fb):
             assert xy0.shape[0] > n_thr and wt.min() < 0.6                    # ... where huber only damps it
     with pytest.raises(ValueError):
         fb.matcher.stitching_matcher(s0, s1, residue_mode='none')
+
+
+def test_stitching_matcher_unequal_strip_shapes(fb):
+    """the two crops of an overlap need not have the same size (an overlap clipped by a tile border on one side only;
+    the reference takes np.minimum of the shapes for its spacings and works on both crops as they are, matcher.py:244,
+    354-363): such a pair goes through the general-mesh route.  Strip 1 of an ordinary pair is cropped by 6 rows / 4 columns
+    at its far ends: the matches inside the common area must be those of the uncropped pair (same coordinates: the crop keeps
+    the origin), through the per-pair surface and through the batch surface, which mixes it with equal-shape pairs."""
+    H, W = 1024, 256
+    s0, s1 = _warped_pair(H, W, 77, shift=(5, -4), warp=0.3)
+    full = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+    s1c = np.ascontiguousarray(s1[:H - 6, :W - 4])
+    cut = fb.matcher.stitching_matcher(s0, s1c, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+    assert cut[0] is not None and cut[0].shape[0] >= 0.8 * full[0].shape[0]
+    d_full = np.median(full[1] - full[0], axis=0); d_cut = np.median(cut[1] - cut[0], axis=0)
+    assert np.abs(d_full + np.array([5, -4])).max() < 0.3 and np.abs(d_cut - d_full).max() < 0.15       # the same displacement field
+    assert np.all(cut[1][:, 0] <= W - 4) and np.all(cut[1][:, 1] <= H - 6)                              # matches inside the smaller strip
+    assert cut[2].min() > 0.3 and abs(cut[3] - full[3]) < 0.01
+    t0, t1 = _warped_pair(H, W, 78, shift=(-3, 2), warp=0.3)
+    outs = fb.matcher.stitching_matcher_batch([(s0, s1), (s0, s1c), (t0, t1)], batch=2, threads=1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+    np.testing.assert_allclose(outs[0][0], full[0], atol=1e-5); np.testing.assert_allclose(outs[1][0], cut[0], atol=1e-5)
+    assert outs[2][0] is not None and np.abs(np.median(outs[2][1] - outs[2][0], axis=0) + np.array([-3, 2])).max() < 0.3
+    # spacings relative to the overlap (< 1, matcher.py:343-350) take the same route
+    rel = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2, spacings=[0.25, 75])
+    assert rel[0] is not None and np.abs(np.median(rel[1] - rel[0], axis=0) - d_full).max() < 0.15
