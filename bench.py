@@ -637,12 +637,25 @@ def main():
     lib, ctx = _lib.load(), _lib.ctx(local_rank)
     ex = None
     comm_ctx = None
-    if dist is not None and world > 1:
+    if dist is not None and (world > 1 or os.environ.get('FEABAS_BENCH_EXCHANGE') == '1'):       # the env switch: a 1-rank rehearsal of the N-rank path
         # the exchange steps go through the C ABI (fb_comm_* / fb_gatherv_dev / fb_allgather_dev) on a context of their own, so
         # that a gather never queues behind the kernels of a matcher thread
         from feabas_amd import dist as fdist
         comm_ctx = _lib.new_context(local_rank)
-        ex = fdist.Exchange(ctx=comm_ctx)
+        ex_note = None
+        try:
+            ex = fdist.Exchange(ctx=comm_ctx)
+            ok = torch.ones(1, device='cuda')
+        except Exception as e:                            # noqa: BLE001 -- reported in the line; the run goes on over torch.distributed
+            ex_note = f'C-ABI RCCL communicator unavailable ({e}); exchange through torch.distributed point-to-point transfers'
+            ok = torch.zeros(1, device='cuda')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)         # one rank without it: every rank takes the torch route (collectives must match)
+        if float(ok.item()) < 1:
+            if ex_note is None:
+                ex.close()
+                ex_note = 'another rank has no C-ABI RCCL communicator; exchange through torch.distributed point-to-point transfers'
+            ex = fdist.Exchange(backend='torch')
+        ex.note = ex_note
 
     def reduce_max(x):
         if dist is None:
@@ -877,7 +890,7 @@ def main():
                 roofline=roof, rccl_ranks=rccl_ranks, pairs_per_s_per_rank=per_rank,
                 match_table_gather=dict(per_step=1, calls=gather_stats['calls'], rows_on_root=gather_stats['rows_on_root'],
                                         seconds_inside_timed_region_and_warmup=(ex.seconds if ex is not None else 0.0),
-                                        backend=(ex.backend if ex is not None else 'none (one rank)')))
+                                        backend=(ex.backend if ex is not None else 'none (one rank)'), note=(getattr(ex, 'note', None) if ex is not None else None)))
 
     if world == 1 and not args.no_deformed:
         # the non-rigid branch, driver-visible: the same step on pairs whose strips differ by a smooth 2 px warp, so that the

@@ -11,6 +11,8 @@
 #include <rccl/rccl.h>
 
 #include <cstdlib>
+#include <string>
+#include <vector>
 
 namespace {
 
@@ -41,15 +43,30 @@ bool bind(void* h, const char* name, F& fn) {
 const RcclApi* rccl_api() {
     std::lock_guard<std::mutex> lk(g_api_mtx);
     if (g_api.handle || !g_api.why.empty()) return &g_api;
-    const char* names[] = {getenv("FEABAS_HIP_RCCL"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // The RCCL to bind is the one built against the HIP runtime THIS library runs on: a process may hold a second ROCm stack
+    // (PyTorch wheels bundle their own libamdhip64 / librccl with the same SONAME), and a communicator of that copy cannot
+    // touch this runtime's streams and allocations.  So: the librccl next to our libamdhip64 first, by absolute path, bound
+    // to its own symbols (RTLD_DEEPBIND); a bare SONAME -- which the loader may resolve to the other copy -- only last.
+    std::vector<std::string> names;
+    if (const char* e = getenv("FEABAS_HIP_RCCL")) if (*e) names.push_back(e);
+    Dl_info info;
+    if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t cut = dir.find_last_of('/');
+        if (cut != std::string::npos) names.push_back(dir.substr(0, cut) + "/librccl.so.1");
+    }
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
     void* h = nullptr;
-    for (const char* n : names) {
-        if (!n || !*n) continue;
-        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    std::string tried;
+    for (const std::string& n : names) {
+        h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
         if (h) break;
+        tried += n + " ";
     }
     if (!h) {
-        g_api.why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?");
+        g_api.why = std::string("librccl not loadable (tried ") + tried + "): " + (dlerror() ? dlerror() : "?");
         return &g_api;
     }
     RcclApi a;
