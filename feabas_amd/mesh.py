@@ -181,6 +181,8 @@ class Mesh:
 
     def _changed(self, gear):
         self._trifinders.pop(gear, None)
+        if gear == const.MESH_GEAR_INITIAL:
+            self._area_initial = None
 
     def set_vertices(self, v, gear, vtx_mask=None):        # mesh.py:2232-2243
         if self.locked:
@@ -403,6 +405,12 @@ class Mesh:
 
     # ------------------------------------------------------------------ geometry
     def triangle_areas(self, gear=const.MESH_GEAR_INITIAL):   # mesh.py:1753-1758
+        if gear == const.MESH_GEAR_INITIAL:
+            # the reference caches per gear (config_cache); the INITIAL vertices never change, and every Link of a large
+            # section asks for these areas again (optimizer.py:26-30)
+            if getattr(self, '_area_initial', None) is None:
+                self._area_initial = common.signed_area(self.vertices(gear), self.triangles)
+            return self._area_initial
         return common.signed_area(self.vertices(gear), self.triangles)
 
     def triangle_area_deform(self, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING)):   # mesh.py:1979-1986
