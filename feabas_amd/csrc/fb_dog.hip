@@ -191,6 +191,14 @@ __global__ void area_down2_kernel(const uint8_t* __restrict__ in, uint8_t* __res
     }
 }
 
+// mask &= (lo <= img <= hi): the mask_range of MeshRenderer.crop_multiple (renderer.py:634-637), before the masked DoG
+__global__ void mask_range_kernel(const float* __restrict__ img, size_t total, float lo, float hi, uint8_t* __restrict__ mask) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = img[i];
+        if (!(v >= lo && v <= hi)) mask[i] = 0;
+    }
+}
+
 int set_taps(fb_ctx* ctx, double sigma, int* radius, Taps* out) {
     const int r = (int)(4.0 * sigma + 0.5);
     if (r < 1 || r > kMaxRadius) return fb_fail(ctx, FB_ERR_ARG, "fb_dog: sigma %.3f gives radius %d outside [1,%d]", sigma, r, kMaxRadius);
@@ -836,6 +844,15 @@ int fb_dog_sizes_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int 
     else rc = launch_fast_any<float>(ctx, r, (const float*)img, out, N, H, W, signed_out, taps, &done, sizes);
     if (!rc && !done) return fb_fail(ctx, FB_ERR_ARG, "fb_dog_sizes_dev: sigma %.3f (radius %d) has no fast kernel", sigma, r);
     return rc;
+}
+
+int fb_mask_range_dev(fb_ctx* ctx, const float* img, size_t n, float lo, float hi, uint8_t* mask) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, n == 0 || (img && mask));
+    if (n == 0) return FB_OK;
+    hipLaunchKernelGGL(mask_range_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, img, n, lo, hi, mask);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
 }
 
 int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* mask, int signed_out,

@@ -357,8 +357,9 @@ def bboxes_mesh_renderer_matcher(mesh0, mesh1, image_loader0, image_loader1, bbo
     pad = kwargs.get('pad', True)
     subpixel = kwargs.get('subpixel', False)
     tol = kwargs.get('affine_approx_tol', 0.0)
-    if kwargs.get('geodesic_mask', False) or kwargs.get('mask_range', None) is not None:
-        raise NotImplementedError('geodesic_mask / mask_range are outside the device renderer')
+    mask_range = kwargs.get('mask_range', None)
+    if kwargs.get('geodesic_mask', False):
+        raise NotImplementedError('geodesic_mask=True is outside the device renderer (the default of the alignment configuration is False)')
     from .mesh import Mesh
 
     def as_mesh(m):                                                            # matcher.py:792-799: init dict or Mesh H5 file
@@ -417,7 +418,7 @@ def bboxes_mesh_renderer_matcher(mesh0, mesh1, image_loader0, image_loader1, bbo
                         covered = False
                         break
                     if sigma > 0:
-                        d_out = r.filter_stack_dev(d_out, d_mask, shape, sigma)
+                        d_out = r.filter_stack_dev(d_out, d_mask, shape, sigma, mask_range=mask_range)
                         bufs.append(d_out)
                     stacks.append(d_out); shapes.append(shape)
                 if not covered:
@@ -550,7 +551,8 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
                     return invalid_output
                 break
             xy0, xy1, conf = bboxes_mesh_renderer_matcher(mesh0, mesh1, images[0], images[1], bboxes0, bboxes1, batch_size=batch_size,
-                                                          pad=pad, subpixel=subpixel, affine_approx_tol=tol_r, sigma=sigma, conf_mode=conf_mode)
+                                                          pad=pad, subpixel=subpixel, affine_approx_tol=tol_r, sigma=sigma, conf_mode=conf_mode,
+                                                          mask_range=kwargs.get('mask_range', None))
             if np.all(conf <= conf_thresh):
                 if not initialized:
                     return invalid_output
@@ -655,7 +657,7 @@ _SECTION_MATCHER_KW = {
     'initial_matches', 'spacings', 'sigma', 'batch_size', 'distributor', 'link_weight_decay', 'compute_strain', 'stiffness_multiplier_threshold',
     'render_weight_threshold', 'stiffness_lambda', 'conf_thresh', 'residue_mode', 'residue_len', 'opt_tol', 'min_num_blocks', 'shrink_factor',
     'allow_dwell', 'allow_enlarge', 'pad', 'subpixel', 'max_spacing_skip', 'affine_approximated_render', 'conf_mode', 'min_boundary_distance',
-    'section_thickness', 'trace', 'relax_tol', 'merge_batches',
+    'section_thickness', 'trace', 'relax_tol', 'merge_batches', 'mask_range',
     # accepted and without effect on the device path, each for a stated reason
     'num_workers',          # one device renders and correlates a whole round: nothing to distribute over a process pool
     'callback_settings',    # the PCG runs to its tolerance: no early-stop / timeout exits

@@ -190,8 +190,9 @@ class MeshRenderer:
         """the log_sigma branch of crop_multiple (renderer.py:632-641) in place of the stack"""
         lib, ctx = _lib.load(), _lib.ctx()
         nb, h, w = shape
-        if mask_range is not None:
-            raise NotImplementedError('mask_range')
+        if mask_range is not None:                                      # renderer.py:634-637: grey levels outside the range are masked out
+            mr = np.atleast_1d(mask_range)
+            _lib.check(lib.fb_mask_range_dev(ctx, d_out.ptr, nb * h * w, float(mr[0]), float(mr[-1]), d_mask.ptr))
         d_f = _lib.DeviceBuffer(4 * nb * h * w)
         _lib.check(lib.fb_dog_masks_dev(ctx, d_out.ptr, 1, nb, h, w, float(log_sigma), d_mask.ptr, 1, d_f.ptr))
         _lib.check(lib.fb_sync(ctx))

@@ -152,6 +152,10 @@ int fb_dog_sizes_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int 
 int fb_dog_masks_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* masks,
                      int signed_out, float* out);
 
+/* mask[i] &= (lo <= img[i] <= hi) on device arrays: the `mask_range` of MeshRenderer.crop_multiple (renderer.py:634-637),
+ * applied to the rendered stack before its masked DoG */
+int fb_mask_range_dev(fb_ctx* ctx, const float* img, size_t n, float lo, float hi, uint8_t* mask);
+
 /* MeshRenderer for general triangulated meshes (one region, no collisions), all pointers device pointers.
  * fb_mesh_candidates_dev: for NB blocks of h x w pixels whose first pixel sits at org [NB][2] (float64, MOVING coordinates
  *   with the mesh offset removed, renderer.py:286-289), the triangles (tris int32 [T][3] over v_mov float64 [V][2]) whose

@@ -121,6 +121,28 @@ def test_render_stack_precise_mask_of_affine_blocks(fb, tol):
     assert np.all(got[~gmask] == 0)
 
 
+def test_crop_multiple_mask_range(fb):
+    """crop_multiple(log_sigma, mask_range=(lo, hi)) (renderer.py:632-641): rendered grey levels outside the range leave the
+    mask before the masked DoG -- against the oracle's render + range + masked_dog_filter"""
+    from feabas_amd import renderer
+    rng = np.random.default_rng(21)
+    ref, M = _meshes(rng)
+    img = _texture(rng, 620, 760)
+    origin = (-60, -50)
+    bboxes = _blocks(rng, 12, (72, 56), (600, 480), margin=20)
+    st, mk, _ = pipeline_ref.render_blocks_mesh1(ref, img, bboxes, 0.0, img_origin=origin, return_mask=True)
+    lo, hi = 70.0, 190.0
+    inr = (st >= lo) & (st <= hi)
+    assert 0.02 < 1 - inr[mk].mean() < 0.5                            # the range really cuts pixels
+    exp = ncc_ref.masked_dog_filter(st, 2.5, mask=mk & inr)
+    r = renderer.MeshRenderer.from_mesh(M, image_loader=renderer.ResidentImage(img, origin))
+    got = r.crop_multiple(bboxes, log_sigma=2.5, mask_range=(lo, hi))
+    plain = r.crop_multiple(bboxes, log_sigma=2.5)
+    r.free()
+    assert np.abs(got - exp).max() <= 3e-3 * np.abs(exp).max() or (np.abs(got - exp) > 3e-3 * np.abs(exp).max()).mean() < 2e-3
+    assert np.abs(got - plain).max() > 0.05 * np.abs(plain).max()      # and changes the result
+
+
 def test_masked_dog_of_a_stack(fb):
     from feabas_amd import _lib
     lib, ctx = _lib.load(), _lib.ctx()
