@@ -268,8 +268,9 @@ def test_stitching_matcher_drop_in(fb):
     # unrelated strips: no match is a value, not an exception (matcher.py:278)
     out = fb.matcher.stitching_matcher(h0[0], h1[1][::-1].copy(), sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33)
     assert out[0] is None and out[1] is None and out[2] == 0.33 and out[3] is None and out[4] is None
-    with pytest.raises(NotImplementedError):
-        fb.matcher.stitching_matcher(h0[0], h1[0], spacings=[0.5])
+    # spacings relative to the overlap (< 1, matcher.py:343-350): the general-mesh route, same displacement
+    rel = fb.matcher.stitching_matcher(h0[0], h1[0], sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, spacings=[0.2])
+    assert rel[0] is not None and np.abs(np.median(rel[1] - rel[0], axis=0) - np.median(xy1 - xy0, axis=0)).max() < 0.2
     # explicit spacings in pixels (matcher.py:252-253)
     xy0, xy1, wt, strain, _ = fb.matcher.stitching_matcher(h0[0], h1[0], sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, spacings=[60.0, 200.0])
     exp = pipeline_ref.match_pair(h0[0], h1[0], spacings=[60.0, 200.0])
