@@ -465,9 +465,12 @@ __device__ __forceinline__ float fir1(const float* w, const TapsF& t) {         
     return acc;
 }
 
-template <typename T, int R, int NT>
+// DS2: `img` is the FULL-resolution uint8 stack [N][H2][W2] and the filtered image is its x0.5 area downsample
+// (cv2.resize(fx = fy = 0.5, INTER_AREA), the rule of area_down2_kernel): the 2 x 2 cells are averaged in the loader, so the
+// coarse image of matcher.py:255-256 is never written (SH, SW = half_size(H2), half_size(W2))
+template <typename T, int R, int NT, bool DS2 = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 : (R <= 12 ? 3 : 2)))) void dog_stream(const T* __restrict__ img, float* __restrict__ out, int SH, int SW, int signed_out,
-                                                const int* __restrict__ sizes, const TapsF taps, int TX, int SY) {
+                                                const int* __restrict__ sizes, const TapsF taps, int TX, int SY, int H2 = 0, int W2 = 0) {
     constexpr int CH = SCH, RN = SRN;
     constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
     constexpr int NQ = (RN + 2 * R + 3) / 4;               // float4 reads per horizontal run (over-reads up to 3 staged values)
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 
         for (int i = tid; i < rows * sw; i += NT) oimg[(uint32_t)((y0 + i / sw) * SW + x0 + i % sw)] = 0.f;
         return;
     }
-    const T* __restrict__ src = img + (size_t)n * SH * SW;
+    const T* __restrict__ src = img + (DS2 ? (size_t)n * H2 * W2 : (size_t)n * SH * SW);
     const int bw = min(TX, W - x0);                            // image columns of the band
     const int NV = bw + 2 * R;                                 // columns of the vertical passes (<= NT)
     const int NA = (NV + RN - 1) / RN * RN;                    // columns of A computed by the first pass (<= NT)
@@ -507,8 +510,43 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 
     // LDS offsets of the thread's items (floats): every access below is one of these plus an immediate
     const int o1r = r1 * PI + u1 * RN, o1w = r1 * PA + u1 * RN, o2r = r2 * PE + u2 * RN;
     const uint32_t absmask = signed_out ? 0xffffffffu : 0x7fffffffu;
+    // one coarse pixel from its 2 x 2 cell of the full-resolution image (cells cut by the edge of an odd-sized image average
+    // the pixels that exist, round half to even: resizeAreaFast)
+    auto cell = [&](int gy, int gx) -> float {
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(src) + (uint32_t)(2 * gy * W2 + 2 * gx);
+        const bool x1 = 2 * gx + 1 < W2, y1 = 2 * gy + 1 < H2;
+        const int a = p[0], b = x1 ? p[1] : 0, c2 = y1 ? p[W2] : 0, d = (x1 && y1) ? p[W2 + 1] : 0;
+        if (x1 && y1) return (float)((a + b + c2 + d + 2) >> 2);
+        return rintf((float)(a + b + c2) / (float)(1 + (int)x1 + (int)y1));
+    };
     auto fetch = [&](int c) {
         const int ya = a0 + c * CH;
+        if (DS2) {
+            if ((W2 & 1) == 0 && ya >= 0 && 2 * (ya + CH) <= H2) {
+                // uniform fast path: every cell of the chunk is a whole 2 x 2 cell and both of its rows start on an even
+                // address: two 16-bit loads per cell
+                const uint8_t* base = reinterpret_cast<const uint8_t*>(src);
+                auto cell2 = [&](uint32_t off) -> float {
+                    const uint32_t u = *reinterpret_cast<const uint16_t*>(base + off), v = *reinterpret_cast<const uint16_t*>(base + off + (uint32_t)W2);
+                    return (float)(((u & 0xffu) + (u >> 8) + (v & 0xffu) + (v >> 8) + 2u) >> 2);
+                };
+                const uint32_t oa = (uint32_t)(2 * ya * W2 + 2 * gx_a), ob = (uint32_t)(2 * ya * W2 + 2 * gx_b);
+#pragma unroll
+                for (int r = 0; r < CH; ++r) pa[r] = cell2(oa + (uint32_t)(2 * r * W2));
+                if (ld_b) {
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) pb[r] = cell2(ob + (uint32_t)(2 * r * W2));
+                }
+                return;
+            }
+#pragma unroll
+            for (int r = 0; r < CH; ++r) pa[r] = cell(min(max(ya + r, 0), H - 1), gx_a);
+            if (ld_b) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) pb[r] = cell(min(max(ya + r, 0), H - 1), gx_b);
+            }
+            return;
+        }
         if (ya >= 0 && ya + CH <= H) {                     // uniform: rows inside the image
             const uint32_t oa = (uint32_t)(ya * SW + gx_a), ob = (uint32_t)(ya * SW + gx_b);
 #pragma unroll
@@ -662,6 +700,28 @@ inline StreamPlan plan_stream(int N, int H, int W, int R, int num_cu) {
     return best;
 }
 
+template <int R, int NT>
+int launch_stream_ds2_nt(fb_ctx* ctx, const uint8_t* img, float* out, int N, int H2, int W2, int signed_out, const TapsF& tf, const StreamPlan& pl) {
+    constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
+    const size_t lds = (size_t)(2 * SCH * PI + SCH * PA + SCH * PE) * sizeof(float);
+    auto kern = dog_stream<uint8_t, R, NT, true>;
+    FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(pl.nb, pl.nseg, N);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, half_size(H2), half_size(W2), signed_out, (const int*)nullptr, tf, pl.TX, pl.SY, H2, W2);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+template <int R>
+int launch_stream_ds2(fb_ctx* ctx, const uint8_t* img, float* out, int N, int H2, int W2, int signed_out, const Taps& taps) {
+    TapsF tf;
+    for (int k = 0; k <= kMaxRadius; ++k) tf.w[k] = (float)taps.w[k];
+    if ((size_t)H2 * W2 >= ((size_t)1 << 30) || N > 65535) return fb_fail(ctx, FB_ERR_ARG, "fb_dog_down2_dev: stack too large for one launch");
+    const StreamPlan pl = plan_stream(N, half_size(H2), half_size(W2), R, ctx->prop.multiProcessorCount);
+    if (pl.NT == 64) return launch_stream_ds2_nt<R, 64>(ctx, img, out, N, H2, W2, signed_out, tf, pl);
+    return launch_stream_ds2_nt<R, 192>(ctx, img, out, N, H2, W2, signed_out, tf, pl);
+}
+
 template <typename T, int R, int NT>
 int launch_stream_nt(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const TapsF& tf, const int* sizes, const StreamPlan& pl) {
     constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
@@ -669,7 +729,7 @@ int launch_stream_nt(fb_ctx* ctx, const T* img, float* out, int N, int H, int W,
     auto kern = dog_stream<T, R, NT>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(pl.nb, pl.nseg, N);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, H, W, signed_out, sizes, tf, pl.TX, pl.SY);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, H, W, signed_out, sizes, tf, pl.TX, pl.SY, 0, 0);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
@@ -844,6 +904,28 @@ int fb_dog_sizes_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int 
     else rc = launch_fast_any<float>(ctx, r, (const float*)img, out, N, H, W, signed_out, taps, &done, sizes);
     if (!rc && !done) return fb_fail(ctx, FB_ERR_ARG, "fb_dog_sizes_dev: sigma %.3f (radius %d) has no fast kernel", sigma, r);
     return rc;
+}
+
+// masked_dog_filter(cv2.resize(img, fx = fy = 0.5, INTER_AREA), sigma) without the intermediate image: matcher.py:255-256 +
+// 273-274 for N resident uint8 images [N][H2][W2]; out float32 [N][half_size(H2)][half_size(W2)]
+int fb_dog_down2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H2, int W2, double sigma, int signed_out, float* out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, N >= 0 && H2 > 1 && W2 > 1 && sigma > 0);
+    if (N == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, img && out);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    int r = 0;
+    Taps taps;
+    int rc = set_taps(ctx, sigma, &r, &taps);
+    if (rc) return rc;
+    FB_PROF_B(ctx, "dog_fast", (double)N * ((double)H2 * W2 + 4.0 * half_size(H2) * half_size(W2)));
+    switch (r) {
+        case 5: return launch_stream_ds2<5>(ctx, img, out, N, H2, W2, signed_out, taps);
+        case 6: return launch_stream_ds2<6>(ctx, img, out, N, H2, W2, signed_out, taps);
+        case 8: return launch_stream_ds2<8>(ctx, img, out, N, H2, W2, signed_out, taps);
+        case 10: return launch_stream_ds2<10>(ctx, img, out, N, H2, W2, signed_out, taps);
+        default: return fb_fail(ctx, FB_ERR_ARG, "fb_dog_down2_dev: sigma %.3f (radius %d) has no streaming kernel", sigma, r);
+    }
 }
 
 int fb_mask_range_dev(fb_ctx* ctx, const float* img, size_t n, float lo, float hi, uint8_t* mask) {

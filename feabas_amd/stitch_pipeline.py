@@ -206,10 +206,15 @@ class StripBatchMatcher:
         finally:
             d_m.free()
 
-    def _global(self, strips0, strips1, masks=None):
+    def _global(self, strips0, strips1, masks=None, need_small=False):
         lib, ctx = _lib.load(), _lib.ctx()
         n, H, W, hc, wc = self.P, self.H, self.W, self.hc, self.wc
-        if self.cds == 0.5:
+        if self.cds == 0.5 and masks is None and not need_small and int(4.0 * self.sigma * self.cds + 0.5) in (5, 6, 8, 10):
+            # the x0.5 area downsample inside the loader of the coarse DoG: the coarse uint8 image (only the masked DoG and the
+            # photometric statistics read it again) is never written
+            _lib.check(lib.fb_dog_down2_dev(ctx, strips0, n, H, W, self.sigma * self.cds, 1, self.d_dogc.ptr))
+            _lib.check(lib.fb_dog_down2_dev(ctx, strips1, n, H, W, self.sigma * self.cds, 1, self.d_dogc.offset(n * hc * wc * 4)))
+        elif self.cds == 0.5:
             _lib.check(lib.fb_area_downsample2_dev(ctx, strips0, n, H, W, self.d_small.ptr))
             _lib.check(lib.fb_area_downsample2_dev(ctx, strips1, n, H, W, self.d_small.offset(n * hc * wc)))
             _lib.check(lib.fb_dog_dev(ctx, self.d_small.ptr, 0, 2 * n, hc, wc, self.sigma * self.cds, None, 1, self.d_dogc.ptr))
@@ -829,7 +834,7 @@ class StripBatchMatcher:
             masks = tuple([None if (mk is None or np.all(mk)) else mk for mk in ml] for ml in masks)
             if all(mk is None for ml in masks for mk in ml):
                 masks = None
-        tx, ty, cf0 = self._global(strips0, strips1, masks)
+        tx, ty, cf0 = self._global(strips0, strips1, masks, need_small=compute_photometric)
         phtm = self._photometric(strips0, strips1, tx, ty, masks) if compute_photometric else None
         scale = 1.0 / self.cds
         tx = tx * scale; ty = ty * scale                     # matcher.py:338-339
@@ -1047,7 +1052,7 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
         super().free()
 
     # ---- image stages on per-image extents
-    def _global(self, strips0, strips1, masks=None):
+    def _global(self, strips0, strips1, masks=None, need_small=False):
         if masks is not None:
             raise NotImplementedError('RaggedStripBatchMatcher: masks are not taken (use StripBatchMatcher per shape)')
         lib, ctx = _lib.load(), _lib.ctx()

@@ -152,6 +152,11 @@ int fb_dog_sizes_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int 
 int fb_dog_masks_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double sigma, const uint8_t* masks,
                      int signed_out, float* out);
 
+/* common.masked_dog_filter(cv2.resize(img, fx=fy=0.5, INTER_AREA), sigma) (matcher.py:255-256 + 273-274) of N resident uint8
+ * images [N][H2][W2] in one kernel: the 2 x 2 cells are averaged in the DoG's loader, the coarse image is never written.
+ * out float32 [N][half_size(H2)][half_size(W2)], half_size = cvRound(n / 2). */
+int fb_dog_down2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H2, int W2, double sigma, int signed_out, float* out);
+
 /* mask[i] &= (lo <= img[i] <= hi) on device arrays: the `mask_range` of MeshRenderer.crop_multiple (renderer.py:634-637),
  * applied to the rendered stack before its masked DoG */
 int fb_mask_range_dev(fb_ctx* ctx, const float* img, size_t n, float lo, float hi, uint8_t* mask);

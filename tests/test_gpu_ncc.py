@@ -260,3 +260,22 @@ def test_dog_and_downsample_of_unequal_images_in_one_stack(fb):
     for b in (d_in, d_sz, d_small, d_dog):
         b.free()
 
+
+
+def test_dog_of_the_half_resolution_image_in_one_kernel(fb):
+    """fb_dog_down2_dev = masked_dog_filter(cv2.resize(img, 0.5, INTER_AREA), sigma) with the 2 x 2 average taken in the DoG's
+    loader (matcher.py:255-256 + 273-274): bit-identical to area downsample followed by the DoG, even and odd sizes"""
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(8)
+    for (n, h2, w2, s) in ((3, 4096, 510, 1.25), (2, 510, 4096, 1.25), (2, 511, 1021, 1.25), (2, 257, 130, 2.5)):
+        img = rng.integers(0, 256, size=(n, h2, w2), dtype=np.uint8)
+        small = fb.common.area_downsample2(img)
+        exp = fb.common.masked_dog_filter(small, s)
+        d_in = _lib.DeviceBuffer.from_array(img); d_out = _lib.DeviceBuffer(exp.nbytes)
+        _lib.check(lib.fb_dog_down2_dev(ctx, d_in.ptr, n, h2, w2, s, 1, d_out.ptr))
+        got = d_out.to_array(exp.shape, np.float32)
+        np.testing.assert_array_equal(got, exp)
+        ref = ncc_ref.masked_dog_filter(ncc_ref.area_downsample2(img[0]), s)
+        assert np.abs(got[0] - ref).max() <= 1e-5 * np.abs(ref).max()
+        d_in.free(); d_out.free()
