@@ -782,7 +782,10 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
         FB_PROF_B(ctx, "ncc_stream_cols", (double)nb * g.Sw * (16.0 * g.Hs + 8.0 * nq * Fh));
         if (p2) {
             q.tiles = (g.Kp + p2_np(Fh) - 1) / p2_np(Fh); q.total = q.tiles * nb;       // groups of column pairs
-            FB_P2_SWITCH(Fh, cols(ctx->stream, std::min(q.total, wg_slots), lds_cols2, g, q, T0, T1, V0, V1));
+            // zero-padded columns (every padded correlation) take the direct form: first pass from HBM, last pass to HBM
+            const bool direct = 2 * g.Hs <= Fh && Fh >= 256 && slots_per_cu == 0 && !(getenv("FB_COLS_STAGED") && atoi(getenv("FB_COLS_STAGED")));
+            if (direct) { FB_P2_SWITCH(Fh, cols2(ctx->stream, q.total, lds_cols2, g, q, T0, T1, V0, V1)); }
+            else { FB_P2_SWITCH(Fh, cols(ctx->stream, std::min(q.total, wg_slots), lds_cols2, g, q, T0, T1, V0, V1)); }
         } else hipLaunchKernelGGL(ncc_stream_cols, dim3(g.Kp, nb), dim3(kStreamThreads), lds_cols, ctx->stream, g, T0, T1, V0, V1);
     }
     {
