@@ -55,6 +55,23 @@ def _z_order_batch(ix, iy):
     if ix.ndim == 2 and ix.shape[0] > 1 and np.array_equal(ix, np.broadcast_to(ix[:1], ix.shape)) and np.array_equal(iy, np.broadcast_to(iy[:1], iy.shape)):
         # the usual case: every pair of the group has the same block index grid
         return np.broadcast_to(_z_order_batch(ix[:1], iy[:1]), ix.shape)
+    if ix.ndim == 2 and ix.shape[0] == 1:
+        # one grid: the same few grids come back call after call (one per spacing and strip shape)
+        key = (ix.shape[1], ix.tobytes(), iy.tobytes())
+        hit = _ZORDER_CACHE.get(key)
+        if hit is not None:
+            return hit
+        out = _z_order_rows(ix, iy)
+        if len(_ZORDER_CACHE) < 256:
+            _ZORDER_CACHE[key] = out
+        return out
+    return _z_order_rows(ix, iy)
+
+
+_ZORDER_CACHE = {}
+
+
+def _z_order_rows(ix, iy):
     sx = np.zeros_like(ix)
     sy = np.zeros_like(iy)
     level = 0
