@@ -470,14 +470,14 @@ def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_
     disp = np.empty((nsec, n * n, 2))
     iters = 0; t_solve = 0.0; relres = []
     from feabas_amd import constant as const
-    # the matches of every section pair (what the matching stage delivers) and the neighbours' fields are inputs: made
-    # before the clock starts
+    # the matches of every section pair (what the matching stage delivers, in the raster order of its block grid) and the
+    # neighbours' fields are inputs: made before the clock starts
     inputs = []
     for k in range(nsec):
         g = g0 + k
         rng = np.random.default_rng(7000 + g)
         dg = field(g)
-        lk = [(rng.integers(0, tri.shape[0], nl), rng.dirichlet((1, 1, 1), nl), rng.uniform(0.3, 1.0, nl).astype(np.float32)) for _ in range(2)]
+        lk = [(np.sort(rng.integers(0, tri.shape[0], nl)), rng.dirichlet((1, 1, 1), nl), rng.uniform(0.3, 1.0, nl).astype(np.float32)) for _ in range(2)]
         inputs.append((v + (field(g - 1) - dg), v + (field(g + 1) - dg), lk))
     zero = np.zeros((1, 2))
     barrier()

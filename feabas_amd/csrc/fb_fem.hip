@@ -9,6 +9,9 @@
 // host (C++), the numeric phases run on the device.
 #include "fb_solver.h"
 
+#include <climits>
+#include <thread>
+#include <vector>
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -607,20 +610,38 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
 int fb_sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && K >= 0 && (K == 0 || nodes6) && K < (1LL << 31) / 6);
-    for (int64_t i = 0; i < K; ++i) {
-        for (int a = 0; a < 6; ++a) {
-            const int u = nodes6[6 * i + a];
-            FB_CHECK_ARG(ctx, u >= -1 && u < s->nv);
-            if (u < 0) continue;
-            for (int b = 0; b < 6; ++b) {
-                const int w = nodes6[6 * i + b];
-                if (w < 0) continue;
-                const int* lo = s->bcol.data() + s->browptr[u];
-                const int* hi = s->bcol.data() + s->browptr[u + 1];
-                if (!std::binary_search(lo, hi, w))
-                    return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld couples vertices %d and %d outside the pattern", (long long)i, u, w);
+    // membership of every coupled vertex pair in the pattern, on a few host threads (K x <=36 binary searches; a section of
+    // 1e5 matches took 40 ms on one core, most of the host time of an update)
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, K / 4096));
+    std::vector<int64_t> bad((size_t)T, -1);
+    std::vector<int> badu((size_t)T, 0), badw((size_t)T, 0);
+    auto work = [&](int t) {
+        const int64_t lo = K * t / T, hi = K * (t + 1) / T;
+        for (int64_t i = lo; i < hi; ++i) {
+            for (int a = 0; a < 6; ++a) {
+                const int u = nodes6[6 * i + a];
+                if (u < -1 || u >= s->nv) { bad[t] = i; badu[t] = u; badw[t] = INT_MIN; return; }
+                if (u < 0) continue;
+                const int* lo_ = s->bcol.data() + s->browptr[u];
+                const int* hi_ = s->bcol.data() + s->browptr[u + 1];
+                for (int b = 0; b < 6; ++b) {
+                    const int w = nodes6[6 * i + b];
+                    if (w < 0 || w == u) continue;
+                    if (w >= s->nv || !std::binary_search(lo_, hi_, w)) { bad[t] = i; badu[t] = u; badw[t] = w; return; }
+                }
             }
         }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    for (int t = 0; t < T; ++t) {
+        if (bad[t] < 0) continue;
+        if (badw[t] == INT_MIN) return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld names vertex %d outside [-1, %d)", (long long)bad[t], badu[t], s->nv);
+        return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld couples vertices %d and %d outside the pattern", (long long)bad[t], badu[t], badw[t]);
     }
     s->nlink = K;
     s->nodes.assign(nodes6, nodes6 + 6 * K);

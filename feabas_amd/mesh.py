@@ -488,8 +488,15 @@ class Mesh:
 
     def bary2cart(self, tid, B, gear, offsetting=True):    # mesh.py:2220-2228
         idx = np.atleast_2d(self.triangles[tid, :])
-        v = self.vertices_w_offset(gear) if offsetting else self.vertices(gear)
-        return np.sum(v[idx] * np.asarray(B).reshape(-1, 3, 1), axis=-2)
+        v = self.vertices(gear)
+        B = np.asarray(B, dtype=np.float64).reshape(-1, 3)
+        # sum_k B_k v_k term by term (the offset of the gear is added to the K results, not to all V vertices first)
+        out = v[idx[:, 0]] * B[:, 0:1]
+        out += v[idx[:, 1]] * B[:, 1:2]
+        out += v[idx[:, 2]] * B[:, 2:3]
+        if offsetting:
+            out += self.offset(gear)
+        return out
 
     # ------------------------------------------------------------------ stiffness (GPU)
     def element_multiplier(self):
