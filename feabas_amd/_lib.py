@@ -51,6 +51,7 @@ _PROTOS = {
     'fb_host_free': (c_i, [c_p, c_p]),
     'fb_host_pack2d': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i]),
     'fb_memcpy_d2h': (c_i, [c_p, c_p, c_p, c_sz]),
+    'fb_memcpy_d2d': (c_i, [c_p, c_p, c_p, C.c_size_t]),
     'fb_memset': (c_i, [c_p, c_p, c_i, c_sz]),
     'fb_timer_start': (c_i, [c_p]),
     'fb_timer_stop': (c_i, [c_p, C.POINTER(C.c_float)]),
@@ -102,6 +103,11 @@ _PROTOS = {
     'fb_deformed_block_affines': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_d, c_p, c_p, c_p, c_p]),
     'fb_deformed_exact_field': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     'fb_deformed_locate': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    'fb_strip_matcher_create': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    'fb_strip_matcher_destroy': (None, [c_p, c_p]),
+    'fb_strip_matcher_info': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'fb_match_strips': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'fb_match_strips_table': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p]),
     'fb_pairs_strain': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_d, c_i, c_d, c_p, c_p, c_p]),
     'fb_sys_lambda': (c_i, [c_p, c_p, c_d, c_d, C.POINTER(c_d), C.POINTER(c_d)]),
     'fb_sys_form': (c_i, [c_p, c_p, c_d, c_d]),
@@ -136,6 +142,13 @@ def declared_symbols():
         txt = f.read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     return sorted(set(re.findall(r'\b(fb_[a-z0-9_]+)\s*\(', txt)))
+
+
+class StripOpts(C.Structure):
+    """fb_strip_opts (include/feabas_hip.h)"""
+    _fields_ = [('sigma', C.c_double), ('coarse_downsample2', C.c_int), ('conf_thresh', C.c_double), ('min_num_blocks', C.c_int),
+                ('conf_mode', C.c_int), ('residue_len', C.c_double), ('residue_mode', C.c_int), ('stiffness_lambda', C.c_double),
+                ('relax_tol', C.c_double), ('compute_strain', C.c_int), ('nspacings', C.c_int), ('spacings', C.c_void_p)]
 
 
 def load():

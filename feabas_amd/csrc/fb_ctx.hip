@@ -243,6 +243,11 @@ int fb_memcpy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return FB_OK;
 }
 
+int fb_memcpy_d2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return FB_OK;
+}
+
 int fb_memset(fb_ctx* ctx, void* dst, int value, size_t bytes) {
     FB_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
     return FB_OK;

@@ -1,0 +1,660 @@
+// matcher.stitching_matcher (feabas/matcher.py:224-367) for a BATCH of P equal-shaped overlap-strip pairs resident in
+// HBM, as ONE C entry: x0.5 downsample + DoG + global NCC (255-278), fine DoG (336-337), the coarse-to-fine block rounds
+// of iterative_xcorr_matcher_w_mesh (578-745: block grids of distributor_cartesian_bbox 865-891, pad / subpixel
+// schedule 579-603 and 689-716, block -> point pairs 840-849, rigid relaxations between rounds), the last-round relaxation
+// with its residue weights (725-737) and the strain estimate (752-777).  Only host bookkeeping lives here -- every
+// device stage is one of the library's own entry points -- but it is O(pairs x blocks) work per round that serialised
+// on the interpreter lock of the calling threads when it was written in numpy (feabas_amd/stitch_pipeline.py keeps that
+// statement of it for masked / photometric / ragged batches and as the route of the pairs this entry hands back).
+//
+// Pairs this entry does NOT finish are reported in flags[] and left to the caller's general route:
+//   FB_STRIP_LOWCONF    global confidence <= conf_thresh: the second shot of global_translation_matcher (159-221)
+//   FB_STRIP_NONRIGID   the relaxation between two spacings is not a rigid translation: mesh1 deforms (725-742)
+//   FB_STRIP_RELAXFIRST the last relaxation deformed mesh1 beyond the screen of relax_first (optimizer.py:763-779)
+//   FB_STRIP_RIGIDFIT   the rigid initialisation of the strain stage is rank deficient / reflected / < 3 matches
+#include "fb_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <numeric>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+struct fb_strip_matcher {
+    int P = 0, H = 0, W = 0, hc = 0, wc = 0;
+    double sigma = 2.5;
+    int cds2 = 1;
+    double conf_thresh = 0.33;
+    int mnb = 2, conf_mode = 2;
+    double residue_len = 5.0;
+    int residue_mode = 0;
+    double stiffness_lambda = 1.0, relax_tol = 1e-9;
+    int compute_strain = 1;
+    std::vector<double> sp;            // spacings in pixels, descending (matcher.py:567)
+    float* d_dogc = nullptr;
+    float* d_dogf = nullptr;
+    uint8_t* d_small = nullptr;
+    int* d_blk = nullptr;
+    uint8_t* d_out = nullptr;
+    size_t max_blocks = 0;
+    fb_system* sys = nullptr;
+    int gnx = 0, gny = 0;
+    std::vector<double> gxs, gys;
+    double es0 = 0.0, area = 0.0;
+    std::vector<int32_t> r_pid;
+    std::vector<double> r_xy0, r_xy1;
+    std::vector<float> r_w;
+    int relax_iters = 0, strain_iters = 0;
+    double relax_relres = 0.0, strain_relres = 0.0;
+    int64_t relax_matches = 0, strain_matches = 0;
+    std::vector<uint8_t> raw;          // D2H staging of one launch: [dx f64 N][dy f64 N][conf f32 N]
+};
+
+namespace {
+
+const double kDefaultAvgDeform = 0.05;          // feabas/config.py:32
+
+// numpy.linspace(start, stop, num, endpoint=True)[i]
+inline double linspace_at(double start, double stop, int num, int i) {
+    if (num == 1) return start;
+    if (i == num - 1) return stop;
+    const double delta = stop - start;
+    const double step = delta / (double)(num - 1);
+    if (step == 0.0) return ((double)i / (double)(num - 1)) * delta + start;
+    return (double)i * step + start;
+}
+
+inline int round_i(double v) { return (int)std::nearbyint(v); }      // np.round: half to even
+
+// the matcher's grid: node counts and coordinates of Mesh.from_bbox((0, 0, W, H), cartesian=True) (mesh.py:403-435)
+void grid_nodes(int H, int W, double mesh_size, int mnb, std::vector<double>& xs, std::vector<double>& ys) {
+    const double wd = (double)W, ht = (double)H;
+    const double nx0 = std::max(std::nearbyint(wd / mesh_size), (double)mnb), ny0 = std::max(std::nearbyint(ht / mesh_size), (double)mnb);
+    double dx = wd / nx0, dy = ht / ny0;
+    if (dx > 2.0 * dy) dx = 2.0 * dy;
+    else if (dy > 2.0 * dx) dy = 2.0 * dx;
+    const int nx = (int)std::ceil(wd / dx) + 1, ny = (int)std::ceil(ht / dy) + 1;
+    xs.resize(nx); ys.resize(ny);
+    for (int i = 0; i < nx; ++i) xs[i] = linspace_at(0.0, 0.0 + wd, nx, i) - 0.5;
+    for (int j = 0; j < ny; ++j) ys[j] = linspace_at(0.0, 0.0 + ht, ny, j) - 0.5;
+}
+
+// P copies of the grid mesh as one block-diagonal system (the stiffness never changes: mesh0 is locked, matcher.py:361)
+int ensure_system(fb_ctx* ctx, fb_strip_matcher* m) {
+    if (m->sys) return FB_OK;
+    grid_nodes(m->H, m->W, *std::min_element(m->sp.begin(), m->sp.end()), m->mnb, m->gxs, m->gys);
+    const int nx = (int)m->gxs.size(), ny = (int)m->gys.size(), V = nx * ny, T = 2 * (nx - 1) * (ny - 1), P = m->P;
+    m->gnx = nx; m->gny = ny;
+    std::vector<int32_t> tri((size_t)3 * P * T);
+    for (int p = 0; p < P; ++p) {
+        int32_t* t = &tri[(size_t)3 * p * T];
+        for (int j = 0; j < ny - 1; ++j)
+            for (int i = 0; i < nx - 1; ++i) {
+                const int a = p * V + j * nx + i, b = a + 1, c = a + nx, d = c + 1;
+                t[0] = a; t[1] = b; t[2] = d; t[3] = a; t[4] = d; t[5] = c;
+                t += 6;
+            }
+    }
+    int rc;
+    fb_system* s = nullptr;
+    if ((rc = fb_sys_create(ctx, (int64_t)P * V, &s))) return rc;
+    int mid = 0;
+    int64_t nnzb = 0;
+    std::vector<float> mult((size_t)P * T, 1.0f);
+    std::vector<double> v((size_t)2 * P * V), v0((size_t)2 * P * V);
+    double mx = 0.0, my = 0.0;
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) { mx += m->gxs[i]; my += m->gys[j]; }
+    mx /= V; my /= V;
+    for (int p = 0; p < P; ++p)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const size_t k = 2 * ((size_t)p * V + (size_t)j * nx + i);
+                v[k] = m->gxs[i]; v[k + 1] = m->gys[j];
+                v0[k] = m->gxs[i] - mx; v0[k + 1] = m->gys[j] - my;
+            }
+    std::vector<double> es((size_t)P);
+    if ((rc = fb_sys_add_mesh(ctx, s, 0, tri.data(), P * V, P * T, &mid)) || (rc = fb_sys_set_links(ctx, s, 0, nullptr)) ||
+        (rc = fb_sys_finalize(ctx, s, &nnzb)) || (rc = fb_sys_assemble_mesh(ctx, s, mid, v.data(), nullptr, mult.data(), 0.0, 1.0)) ||
+        (rc = fb_sys_group_energy(ctx, s, P, v0.data(), es.data()))) {
+        fb_sys_destroy(ctx, s);
+        return rc;
+    }
+    m->sys = s;
+    m->es0 = es[0];                                        // the same for every copy (and rotation free)
+    // signed_area of the first triangle (a, b, d): cross((dx, 0), (0, dy))
+    m->area = std::fabs((m->gxs[1] - m->gxs[0]) * (m->gys[1] - m->gys[0]) - 0.0 * 0.0);
+    return FB_OK;
+}
+
+int fetch(fb_ctx* ctx, fb_strip_matcher* m, size_t nb, const double** dx, const double** dy, const float** cf) {
+    m->raw.resize(20 * nb);
+    int rc = fb_memcpy_d2h(ctx, m->raw.data(), m->d_out, 20 * nb);
+    if (rc) return rc;
+    *dx = (const double*)m->raw.data();
+    *dy = (const double*)(m->raw.data() + 8 * nb);
+    *cf = (const float*)(m->raw.data() + 16 * nb);
+    return FB_OK;
+}
+
+struct Rows {                                   // a match table: rows of one pair are contiguous
+    std::vector<int32_t> pid;
+    std::vector<double> xy0, xy1i, xy1;         // mesh0 point (MOVING), mesh1 point (INITIAL), mesh1 point (MOVING)
+    std::vector<float> wt;
+    std::vector<char> rl;                       // the pair's blocks moved by more than 0.1 px (matcher.py:725)
+    size_t size() const { return pid.size(); }
+    void push(int32_t p, double x0, double y0, double xi, double yi, double x1, double y1, float w, char r) {
+        pid.push_back(p); xy0.push_back(x0); xy0.push_back(y0); xy1i.push_back(xi); xy1i.push_back(yi);
+        xy1.push_back(x1); xy1.push_back(y1); wt.push_back(w); rl.push_back(r);
+    }
+    void push_from(const Rows& o, size_t k) {
+        push(o.pid[k], o.xy0[2 * k], o.xy0[2 * k + 1], o.xy1i[2 * k], o.xy1i[2 * k + 1], o.xy1[2 * k], o.xy1[2 * k + 1], o.wt[k], o.rl[k]);
+    }
+};
+
+// eigenvalues of a symmetric 3x3 matrix (cyclic Jacobi), ascending
+void sym3_eig(const double G[3][3], double ev[3]) {
+    double a[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = G[i][j];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0) continue;
+                const double th = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+            }
+    }
+    ev[0] = a[0][0]; ev[1] = a[1][1]; ev[2] = a[2][2];
+    std::sort(ev, ev + 3);
+}
+
+// A = G^-1 Hm by elimination with partial pivoting; false when a pivot vanishes
+bool solve3(const double G[3][3], const double Hm[3][3], double A[3][3]) {
+    double a[3][6];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { a[i][j] = G[i][j]; a[i][3 + j] = Hm[i][j]; }
+    for (int c = 0; c < 3; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 3; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return false;
+        if (piv != c) for (int j = 0; j < 6; ++j) std::swap(a[c][j], a[piv][j]);
+        for (int r = c + 1; r < 3; ++r) {
+            const double f = a[r][c] / a[c][c];
+            for (int j = c; j < 6; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int j = 0; j < 3; ++j)
+        for (int r = 2; r >= 0; --r) {
+            double v = a[r][3 + j];
+            for (int k = r + 1; k < 3; ++k) v -= a[r][k] * A[k][j];
+            A[r][j] = v / a[r][r];
+        }
+    return true;
+}
+
+// spatial.fit_affine(p0, p1, return_rigid=True, weight, svd_clip=(1, 1)) (spatial.py:21-73) of every pair through the
+// moments of its rows (the statement feabas_amd/stitch_pipeline.py::_rigid_fits makes in numpy).  R [P][9] row major;
+// bad[p] = 1 where the fit needs the rank-deficient / reflected branches of the host function.
+void rigid_fits(int P, const std::vector<int32_t>& pid, const std::vector<double>& p0, const std::vector<double>& p1, const std::vector<float>& wt,
+                std::vector<double>& R, std::vector<char>& bad) {
+    R.assign((size_t)9 * P, 0.0);
+    bad.assign((size_t)P, 0);
+    for (int p = 0; p < P; ++p) { R[9 * (size_t)p] = R[9 * (size_t)p + 4] = R[9 * (size_t)p + 8] = 1.0; }
+    const size_t K = pid.size();
+    size_t a = 0;
+    while (a < K) {
+        size_t b = a;
+        const int p = pid[a];
+        double S[21];
+        for (int j = 0; j < 21; ++j) S[j] = 0.0;
+        for (; b < K && pid[b] == p; ++b) {
+            const double x0 = p0[2 * b], y0 = p0[2 * b + 1], x1 = p1[2 * b], y1 = p1[2 * b + 1], w = (double)wt[b];
+            const double wx1 = w * x1, wy1 = w * y1;
+            const double F[21] = {1.0, x0, y0, x1, y1, x0 * x0, y0 * y0, x1 * x1, y1 * y1, w, wx1, wy1, w * x0, w * y0,
+                                  wx1 * x1, wx1 * y1, wy1 * y1, wx1 * x0, wx1 * y0, wy1 * x0, wy1 * y0};
+            for (int j = 0; j < 21; ++j) S[j] += F[j];
+        }
+        a = b;
+        const double cnt = S[0], n = std::max(cnt, 1.0);
+        const double m0x = S[1] / n, m0y = S[2] / n, m1x = S[3] / n, m1y = S[4] / n;
+        const double var0 = (S[5] / n - m0x * m0x) + (S[6] / n - m0y * m0y);
+        const double var1 = (S[7] / n - m1x * m1x) + (S[8] / n - m1y * m1y);
+        double scl = std::sqrt(std::max(std::max(var0, var1), 0.0));
+        if (scl < 1e-6) scl = 1.0;
+        const double sw = S[9], sx1 = S[10], sy1 = S[11], sx0 = S[12], sy0 = S[13];
+        const double cx1 = sx1 - m1x * sw, cy1 = sy1 - m1y * sw, cx0 = sx0 - m0x * sw, cy0 = sy0 - m0y * sw;
+        const double s2 = scl * scl;
+        double G[3][3], Hm[3][3], A[3][3];
+        G[0][0] = (S[14] - 2 * m1x * sx1 + m1x * m1x * sw) / s2;
+        G[0][1] = G[1][0] = (S[15] - m1x * sy1 - m1y * sx1 + m1x * m1y * sw) / s2;
+        G[1][1] = (S[16] - 2 * m1y * sy1 + m1y * m1y * sw) / s2;
+        G[0][2] = G[2][0] = cx1 / scl;
+        G[1][2] = G[2][1] = cy1 / scl;
+        G[2][2] = sw;
+        Hm[0][0] = (S[17] - m1x * sx0 - m0x * sx1 + m1x * m0x * sw) / s2;
+        Hm[0][1] = (S[18] - m1x * sy0 - m0y * sx1 + m1x * m0y * sw) / s2;
+        Hm[1][0] = (S[19] - m1y * sx0 - m0x * sy1 + m1y * m0x * sw) / s2;
+        Hm[1][1] = (S[20] - m1y * sy0 - m0y * sy1 + m1y * m0y * sw) / s2;
+        Hm[0][2] = cx1 / scl; Hm[1][2] = cy1 / scl;
+        Hm[2][0] = cx0 / scl; Hm[2][1] = cy0 / scl; Hm[2][2] = sw;
+        bool ok = cnt >= 3;
+        if (ok) {
+            double ev[3];
+            sym3_eig(G, ev);
+            ok = ev[0] > 1e-9 * ev[2];
+        }
+        if (ok) ok = solve3(G, Hm, A);
+        if (ok) {
+            const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                               A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+            ok = det > 0.0 && (A[0][0] * A[1][1] - A[0][1] * A[1][0]) > 0.0;
+        }
+        double c = 1.0, s = 0.0;
+        if (ok) {
+            // u @ vh of the 2x2 block (singular values clipped to 1): the rotation of its polar decomposition
+            const double pc = A[0][0] + A[1][1], ps = A[1][0] - A[0][1];
+            const double hyp = std::hypot(pc, ps);
+            ok = hyp > 0.0 && std::isfinite(hyp);
+            if (ok) { c = pc / hyp; s = ps / hyp; }
+        }
+        if (!ok) { bad[p] = 1; continue; }
+        double* r = &R[9 * (size_t)p];
+        r[0] = c; r[1] = -s; r[3] = s; r[4] = c;
+        r[6] = A[2][0] + m0x - (m1x * r[0] + m1y * r[3]);
+        r[7] = A[2][1] + m0y - (m1x * r[1] + m1y * r[4]);
+        r[2] = 0.0; r[5] = 0.0; r[8] = 1.0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* o, fb_strip_matcher** out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, P > 0 && H > 1 && W > 1 && o && out && (o->coarse_downsample2 == 0 || o->coarse_downsample2 == 1));
+    FB_CHECK_ARG(ctx, o->sigma > 0.0 && o->min_num_blocks >= 1 && (o->residue_mode == 0 || o->residue_mode == 1) && o->nspacings >= 0 &&
+                          (o->nspacings == 0 || o->spacings) && o->nspacings <= 64);
+    fb_strip_matcher* m = new fb_strip_matcher();
+    m->P = P; m->H = H; m->W = W;
+    m->sigma = o->sigma; m->cds2 = o->coarse_downsample2; m->conf_thresh = o->conf_thresh; m->mnb = o->min_num_blocks;
+    m->conf_mode = o->conf_mode; m->residue_len = o->residue_len; m->residue_mode = o->residue_mode;
+    m->stiffness_lambda = o->stiffness_lambda; m->relax_tol = o->relax_tol; m->compute_strain = o->compute_strain;
+    if (o->nspacings) {
+        m->sp.assign(o->spacings, o->spacings + o->nspacings);
+        for (double v : m->sp)
+            if (!(v >= 1.0)) { delete m; return fb_fail(ctx, FB_ERR_ARG, "fb_strip_matcher_create: spacings are pixels (>= 1); relative ones (matcher.py:343-350) are resolved by the caller"); }
+    } else {
+        // matcher.py:243-251 with both shapes equal
+        const double smax = std::max(H, W) * 0.25, smin = std::max(std::min(75.0, std::min(H, W) / 3.0), 25.0);
+        if (smin > smax) m->sp.assign(1, smin);
+        else {
+            const int count = (int)std::max(1.0, std::nearbyint(std::log(smax / smin) / std::log(4.0)));
+            for (int i = 0; i < count; ++i) m->sp.push_back(std::exp(linspace_at(std::log(smin), std::log(smax), count, i)));
+        }
+    }
+    std::sort(m->sp.begin(), m->sp.end());
+    std::reverse(m->sp.begin(), m->sp.end());
+    // cv2.resize(fx=0.5): cvRound(n / 2), half to even
+    m->hc = m->cds2 ? round_i(H * 0.5) : H;
+    m->wc = m->cds2 ? round_i(W * 0.5) : W;
+    m->max_blocks = (size_t)P * 1024;
+    const size_t n = (size_t)P, cpix = (size_t)m->hc * m->wc, fpix = (size_t)H * W;
+    int rc = 0;
+    void* ptr = nullptr;
+    if (!(rc = fb_malloc(ctx, 2 * n * cpix * 4, &ptr))) m->d_dogc = (float*)ptr;
+    if (!rc && m->cds2 && !(rc = fb_malloc(ctx, 2 * n * fpix * 4, &ptr))) m->d_dogf = (float*)ptr;
+    if (!rc && m->cds2 && !(rc = fb_malloc(ctx, 2 * n * cpix, &ptr))) m->d_small = (uint8_t*)ptr;
+    if (!rc && !(rc = fb_malloc(ctx, m->max_blocks * 9 * 4, &ptr))) m->d_blk = (int*)ptr;
+    if (!rc && !(rc = fb_malloc(ctx, m->max_blocks * 20, &ptr))) m->d_out = (uint8_t*)ptr;
+    if (rc) { fb_strip_matcher_destroy(ctx, m); return rc; }
+    *out = m;
+    return FB_OK;
+}
+
+void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m) {
+    if (!m) return;
+    FB_LOCK(ctx);
+    if (m->sys) fb_sys_destroy(ctx, m->sys);
+    fb_free(ctx, m->d_dogc); fb_free(ctx, m->d_dogf); fb_free(ctx, m->d_small); fb_free(ctx, m->d_blk); fb_free(ctx, m->d_out);
+    delete m;
+}
+
+int fb_strip_matcher_info(fb_ctx* ctx, fb_strip_matcher* m, int* nspacings, double* spacings, int* grid_nx, int* grid_ny,
+                          int* relax_iters, double* relax_relres, int* strain_iters, double* strain_relres) {
+    FB_CHECK_ARG(ctx, m != nullptr);
+    if (spacings) FB_CHECK_ARG(ctx, nspacings && *nspacings >= (int)m->sp.size());
+    if (spacings) std::copy(m->sp.begin(), m->sp.end(), spacings);
+    if (nspacings) *nspacings = (int)m->sp.size();
+    if (grid_nx) *grid_nx = m->gnx;
+    if (grid_ny) *grid_ny = m->gny;
+    if (relax_iters) *relax_iters = m->relax_iters;
+    if (relax_relres) *relax_relres = m->relax_relres;
+    if (strain_iters) *strain_iters = m->strain_iters;
+    if (strain_relres) *strain_relres = m->strain_relres;
+    return FB_OK;
+}
+
+int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, const uint8_t* strips1, double* tx, double* ty, float* conf0,
+                    uint8_t* valid, uint8_t* flags, double* strain, int64_t* nrows) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, m && strips0 && strips1 && tx && ty && conf0 && valid && flags && strain && nrows);
+    const int n = m->P, H = m->H, W = m->W, hc = m->hc, wc = m->wc;
+    const size_t cpix = (size_t)hc * wc, fpix = (size_t)H * W;
+    const float thr = (float)m->conf_thresh;               // numpy compares float32 confidences with the threshold in float32
+    int rc;
+    // ---- global translation on the coarse DoG images (matcher.py:255-278)
+    if (m->cds2) {
+        const int taps = (int)(4.0 * m->sigma * 0.5 + 0.5);
+        if (taps == 5 || taps == 6 || taps == 8 || taps == 10) {
+            if ((rc = fb_dog_down2_dev(ctx, strips0, n, H, W, m->sigma * 0.5, 1, m->d_dogc))) return rc;
+            if ((rc = fb_dog_down2_dev(ctx, strips1, n, H, W, m->sigma * 0.5, 1, m->d_dogc + n * cpix))) return rc;
+        } else {
+            if ((rc = fb_area_downsample2_dev(ctx, strips0, n, H, W, m->d_small))) return rc;
+            if ((rc = fb_area_downsample2_dev(ctx, strips1, n, H, W, m->d_small + n * cpix))) return rc;
+            if ((rc = fb_dog_dev(ctx, m->d_small, 0, 2 * n, hc, wc, m->sigma * 0.5, nullptr, 1, m->d_dogc))) return rc;
+        }
+    } else {
+        if ((rc = fb_dog_dev(ctx, strips0, 0, n, hc, wc, m->sigma, nullptr, 1, m->d_dogc))) return rc;
+        if ((rc = fb_dog_dev(ctx, strips1, 0, n, hc, wc, m->sigma, nullptr, 1, m->d_dogc + n * cpix))) return rc;
+    }
+    if ((rc = fb_ncc_batch_dev(ctx, m->d_dogc, m->d_dogc + n * cpix, n, 1, hc, wc, hc, wc, 1, 0, m->conf_mode, (double*)m->d_out,
+                               (double*)(m->d_out + 8 * (size_t)n), (float*)(m->d_out + 16 * (size_t)n))))
+        return rc;
+    // the fine DoG is independent of the answer: enqueue it before waiting for the global peaks
+    const float* dogf = m->d_dogc;                         // matcher.py:315-317: same image when fine == coarse
+    if (m->cds2) {
+        if ((rc = fb_dog_dev(ctx, strips0, 0, n, H, W, m->sigma, nullptr, 1, m->d_dogf))) return rc;
+        if ((rc = fb_dog_dev(ctx, strips1, 0, n, H, W, m->sigma, nullptr, 1, m->d_dogf + n * fpix))) return rc;
+        dogf = m->d_dogf;
+    }
+    const float* img1 = dogf + n * fpix;
+    {
+        const double *gx, *gy; const float* gc;
+        if ((rc = fetch(ctx, m, (size_t)n, &gx, &gy, &gc))) return rc;
+        const double scale = m->cds2 ? 2.0 : 1.0;          // matcher.py:338-339
+        for (int p = 0; p < n; ++p) { tx[p] = gx[p] * scale; ty[p] = gy[p] * scale; conf0[p] = gc[p]; }
+    }
+    std::vector<char> active((size_t)n), live((size_t)n), pad((size_t)n, 1), has_last((size_t)n, 0);
+    for (int p = 0; p < n; ++p) {
+        flags[p] = (conf0[p] > thr) ? 0 : FB_STRIP_LOWCONF;
+        active[p] = conf0[p] >= thr;                        // matcher.py:277-278
+        live[p] = active[p] && !flags[p];
+    }
+    std::vector<double> t1((size_t)2 * n, 0.0);            // translation of mesh1 acquired by rigid relaxations
+    const int nsp = (int)m->sp.size();
+    Rows table, prev;
+    bool have_table = false, last_links = false;
+    std::vector<int> nxv((size_t)n), nyv((size_t)n), dxv((size_t)n), dyv((size_t)n), fhv((size_t)n), fwv((size_t)n);
+    std::vector<double> xminv((size_t)n), yminv((size_t)n), xmaxv((size_t)n), ymaxv((size_t)n);
+    std::vector<int32_t> blk;
+    std::vector<int> bbx0, bby0, xt, yt, order, ordc;
+    std::vector<long long> zk, zkc;
+    std::vector<char> in_cur((size_t)n);
+    for (int rnd = 0; rnd < nsp; ++rnd) {
+        const double spc = m->sp[rnd];
+        const bool is_last = rnd == nsp - 1;
+        const int mnb = is_last ? m->mnb : 1;
+        // ---- group the live pairs by block grid and FFT shape (matcher.py:59-62 on the block size)
+        std::map<long long, std::vector<int>> groups;
+        for (int p = 0; p < n; ++p) {
+            if (!live[p]) continue;
+            const double xmin = std::max(-0.5 + tx[p], -0.5 + t1[2 * p]), xmax = std::min(W - 0.5 + tx[p], W - 0.5 + t1[2 * p]);
+            const double ymin = std::max(-0.5 + ty[p], -0.5 + t1[2 * p + 1]), ymax = std::min(H - 0.5 + ty[p], H - 0.5 + t1[2 * p + 1]);
+            if (!(xmax > xmin && ymax > ymin)) continue;
+            // common.divide_bbox (common.py:380-409)
+            const double wd = xmax - xmin, ht = ymax - ymin;
+            const double nx = std::max(std::ceil(wd / spc), (double)mnb), ny = std::max(std::ceil(ht / spc), (double)mnb);
+            const long long dx = (long long)std::ceil(wd / nx), dy = (long long)std::ceil(ht / ny);
+            if (dx < 1 || dy < 1 || 2 * dx > 8192 || 2 * dy > 8192 || nx >= 4096 || ny >= 4096)
+                return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: pair %d: block %lld x %lld on a %g x %g grid is outside the block matcher", p, dy, dx, ny, nx);
+            xminv[p] = xmin; xmaxv[p] = xmax; yminv[p] = ymin; ymaxv[p] = ymax;
+            nxv[p] = (int)nx; nyv[p] = (int)ny; dxv[p] = (int)dx; dyv[p] = (int)dy;
+            fhv[p] = fb_next_fast_len(pad[p] ? std::max(2 * (int)dy - 1, 0) : (int)dy);
+            fwv[p] = fb_next_fast_len(pad[p] ? std::max(2 * (int)dx - 1, 0) : (int)dx);
+            const long long key = ((((long long)nx * 4096 + (long long)ny) * 8192 + fhv[p]) * 8192 + fwv[p]);
+            groups[key].push_back(p);
+        }
+        if (groups.empty()) continue;
+        Rows cur;
+        for (auto& kv : groups) {
+            const std::vector<int>& sel = kv.second;
+            const int Q = (int)sel.size(), nxi = nxv[sel[0]], nyi = nyv[sel[0]], nblk = nxi * nyi;
+            const size_t nb = (size_t)Q * nblk;
+            if (nb > m->max_blocks) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: %zu blocks in one launch (limit %zu)", nb, m->max_blocks);
+            blk.resize(nb * 9); bbx0.resize(nb); bby0.resize(nb);
+            int hmax = 0, wmax = 0;
+            bool have_c = false;
+            for (int q = 0; q < Q; ++q) {
+                const int p = sel[q];
+                const int dx = dxv[p], dy = dyv[p];
+                hmax = std::max(hmax, dy); wmax = std::max(wmax, dx);
+                xt.resize(nxi); yt.resize(nyi);
+                for (int i = 0; i < nxi; ++i) xt[i] = round_i(linspace_at(xminv[p], xmaxv[p] - (double)dx, nxi, i));
+                for (int j = 0; j < nyi; ++j) yt[j] = round_i(linspace_at(yminv[p], ymaxv[p] - (double)dy, nyi, j));
+                const int xlo = *std::min_element(xt.begin(), xt.end()), ylo = *std::min_element(yt.begin(), yt.end());
+                // z-order of the block index grid (common.z_order, common.py:196-215), stable
+                zk.resize(nblk);
+                for (int j = 0; j < nyi; ++j)
+                    for (int i = 0; i < nxi; ++i) {
+                        unsigned ix = (unsigned)std::nearbyint((double)(xt[i] - xlo) / spc), iy = (unsigned)std::nearbyint((double)(yt[j] - ylo) / spc);
+                        long long k = 0;
+                        for (int l = 0; ix || iy; ++l, ix >>= 1, iy >>= 1) k += ((long long)(ix & 1) + 2 * (long long)(iy & 1)) << (2 * l);
+                        zk[(size_t)j * nxi + i] = k;
+                    }
+                if (!have_c || zk != zkc) {
+                    order.resize(nblk);
+                    std::iota(order.begin(), order.end(), 0);
+                    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return zk[a] < zk[b]; });
+                    ordc = order; zkc = zk; have_c = true;
+                }
+                const int rtx = round_i(tx[p]), rty = round_i(ty[p]), r1x = round_i(t1[2 * p]), r1y = round_i(t1[2 * p + 1]);
+                for (int b = 0; b < nblk; ++b) {
+                    const int o = ordc[b], x0 = xt[o % nxi], y0 = yt[o / nxi];
+                    const size_t at = (size_t)q * nblk + b;
+                    bbx0[at] = x0; bby0[at] = y0;
+                    int32_t* d = &blk[9 * at];
+                    d[0] = p; d[1] = x0 - rtx; d[2] = y0 - rty; d[3] = dy; d[4] = dx; d[5] = x0 - r1x; d[6] = y0 - r1y; d[7] = dy; d[8] = dx;
+                }
+            }
+            if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), nb * 9 * 4))) return rc;
+            if ((rc = fb_ncc_blocks_dev(ctx, dogf, img1, H, W, H, W, (int)nb, m->d_blk, hmax, wmax, fhv[sel[0]], fwv[sel[0]], is_last ? 1 : 0,
+                                        m->conf_mode, (double*)m->d_out, (double*)(m->d_out + 8 * nb), (float*)(m->d_out + 16 * nb))))
+                return rc;
+            const double *ddx, *ddy; const float* dcf;
+            if ((rc = fetch(ctx, m, nb, &ddx, &ddy, &dcf))) return rc;
+            // ---- blocks -> point pairs (matcher.py:671-683, 840-849), spacing schedule (689-716), rigid relaxation (725-742)
+            for (int q = 0; q < Q; ++q) {
+                const int p = sel[q];
+                const int dx = dxv[p], dy = dyv[p];
+                const size_t base = (size_t)q * nblk;
+                double dis2max = -1.0;
+                int first = -1;
+                for (int b = 0; b < nblk; ++b) {
+                    if (!(dcf[base + b] > thr)) continue;
+                    if (first < 0) first = b;
+                    const double hx = ddx[base + b] * 0.5, hy = ddy[base + b] * 0.5;
+                    const double cx = 0.5 * (double)(bbx0[base + b] + (bbx0[base + b] + dx)) - 0.5, cy = 0.5 * (double)(bby0[base + b] + (bby0[base + b] + dy)) - 0.5;
+                    const double ex = (cx - hx) - (cx + hx), ey = (cy - hy) - (cy + hy);
+                    dis2max = std::max(dis2max, ex * ex + ey * ey);
+                }
+                const bool has_link = first >= 0;
+                const double max_dis = std::sqrt(std::max(dis2max, 0.0));
+                if (!has_link) {
+                    if (rnd == 0) active[p] = 0;            // invalid_output (matcher.py:672-673, 719-721)
+                    live[p] = 0;                            // ... or break with the links so far (674-675, 722-723)
+                }
+                const double t1x = t1[2 * p], t1y = t1[2 * p + 1];        // mesh1 offset at link creation (matcher.py:748-751)
+                bool nonrigid = false;
+                if (!is_last) {
+                    int next_pos = -1;
+                    for (int k = 0; k < nsp; ++k) next_pos += m->sp[k] > 4.0 * max_dis;
+                    pad[p] = !(next_pos > rnd);             // max_spacing_skip = 0
+                    if (has_link && max_dis > 0.1) {
+                        // every kept block reports the same displacement: the relaxation of mesh1 is that translation
+                        const double hx0 = ddx[base + first] * 0.5, hy0 = ddy[base + first] * 0.5;
+                        const double c0x = 0.5 * (double)(bbx0[base + first] + (bbx0[base + first] + dx)) - 0.5, c0y = 0.5 * (double)(bby0[base + first] + (bby0[base + first] + dy)) - 0.5;
+                        const double u0x = (c0x - hx0) - (c0x + hx0), u0y = (c0y - hy0) - (c0y + hy0);
+                        for (int b = 0; b < nblk && !nonrigid; ++b) {
+                            if (!(dcf[base + b] > thr)) continue;
+                            const double hx = ddx[base + b] * 0.5, hy = ddy[base + b] * 0.5;
+                            const double cx = 0.5 * (double)(bbx0[base + b] + (bbx0[base + b] + dx)) - 0.5, cy = 0.5 * (double)(bby0[base + b] + (bby0[base + b] + dy)) - 0.5;
+                            nonrigid = ((cx - hx) - (cx + hx)) != u0x || ((cy - hy) - (cy + hy)) != u0y;
+                        }
+                        if (!nonrigid) { t1[2 * p] += u0x; t1[2 * p + 1] += u0y; }
+                    }
+                }
+                if (nonrigid) { flags[p] |= FB_STRIP_NONRIGID; live[p] = 0; continue; }
+                const char rl = max_dis > 0.1;
+                for (int b = 0; b < nblk; ++b) {
+                    if (!(dcf[base + b] > thr)) continue;
+                    const double hx = ddx[base + b] * 0.5, hy = ddy[base + b] * 0.5;
+                    const double cx = 0.5 * (double)(bbx0[base + b] + (bbx0[base + b] + dx)) - 0.5, cy = 0.5 * (double)(bby0[base + b] + (bby0[base + b] + dy)) - 0.5;
+                    const double x1 = cx + hx, y1 = cy + hy;
+                    cur.push(p, cx - hx, cy - hy, x1 - t1x, y1 - t1y, x1, y1, dcf[base + b], rl);
+                }
+                if (has_link) has_last[p] = 1;
+            }
+        }
+        prev = std::move(table);
+        const bool had_prev = have_table;
+        table = std::move(cur);
+        have_table = true;
+        last_links = false;
+        if (is_last && m->residue_len > 0 && table.size()) {
+            bool any_rl = false;
+            for (char r : table.rl) any_rl |= r != 0;
+            if (any_rl) {
+                // last round (matcher.py:725-737): relaxation + residue weights of every pair at once; all rows enter
+                // the block-diagonal system so that the strain stage can reuse the links
+                if ((rc = ensure_system(ctx, m))) return rc;
+                const int V = m->gnx * m->gny;
+                const int64_t K = (int64_t)table.size();
+                std::vector<float> rw((size_t)K);
+                std::vector<double> x((size_t)2 * n * V);
+                const double sample_err = 0.4387 * std::pow(m->area, 0.5) * kDefaultAvgDeform;       // optimizer.py:26-30
+                rc = fb_pairs_relax(ctx, m->sys, n, m->gnx, m->gny, m->gxs.data(), m->gys.data(), K, table.pid.data(), table.xy0.data(), table.xy1i.data(),
+                                    t1.data(), table.wt.data(), m->residue_len, m->residue_mode, sample_err, m->stiffness_lambda, m->relax_tol,
+                                    rw.data(), x.data(), &m->relax_iters, &m->relax_relres);
+                if (rc) return rc;
+                m->relax_matches = K;
+                last_links = true;
+                // screen of relax_first (optimizer.py:763-779): the largest displacement difference along a grid edge
+                // relative to that edge; beyond 0.1 the pair takes the reference's statements on the general route
+                for (int p = 0; p < n; ++p) {
+                    const double* g = &x[(size_t)2 * p * V];
+                    double d = 0.0;
+                    for (int j = 0; j < m->gny; ++j)
+                        for (int i = 0; i < m->gnx; ++i) {
+                            const double* a = g + 2 * ((size_t)j * m->gnx + i);
+                            if (i + 1 < m->gnx) d = std::max(d, std::sqrt((a[2] - a[0]) * (a[2] - a[0]) + (a[3] - a[1]) * (a[3] - a[1])) / (m->gxs[i + 1] - m->gxs[i]));
+                            if (j + 1 < m->gny) {
+                                const double* b = a + 2 * (size_t)m->gnx;
+                                d = std::max(d, std::sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1])) / (m->gys[j + 1] - m->gys[j]));
+                            }
+                        }
+                    if (d > 0.1 || !(d == d)) flags[p] |= FB_STRIP_RELAXFIRST;
+                }
+                for (int64_t k = 0; k < K; ++k)
+                    if (table.rl[k]) table.wt[k] = table.wt[k] * rw[k];                 // Link.weight (optimizer.py:313-317)
+            }
+        }
+        if (had_prev && prev.size()) {
+            // a pair without a confident block in this round keeps the links of its last good round (the reference
+            // breaks out of the loop before clear_links, matcher.py:671-679)
+            std::fill(in_cur.begin(), in_cur.end(), 0);
+            for (int32_t p : table.pid) in_cur[p] = 1;
+            for (size_t k = 0; k < prev.size(); ++k)
+                if (!in_cur[prev.pid[k]]) { table.push_from(prev, k); last_links = false; }
+        }
+    }
+    // ---- the table in the INITIAL gears (matcher.py:748-751)
+    std::vector<char> ok_pair((size_t)n);
+    for (int p = 0; p < n; ++p) ok_pair[p] = active[p] && has_last[p] && !flags[p];
+    if (m->residue_mode == 1) {
+        // threshold mode: matches cut by the residue filter are masked out of the link (optimizer.py:399-402)
+        std::vector<char> any((size_t)n, 0);
+        for (size_t k = 0; k < table.size(); ++k) if (ok_pair[table.pid[k]] && table.wt[k] > 0) any[table.pid[k]] = 1;
+        for (int p = 0; p < n; ++p) ok_pair[p] = ok_pair[p] && any[p];
+    }
+    m->r_pid.clear(); m->r_xy0.clear(); m->r_xy1.clear(); m->r_w.clear();
+    for (size_t k = 0; k < table.size(); ++k) {
+        const int p = table.pid[k];
+        if (!ok_pair[p] || (m->residue_mode == 1 && !(table.wt[k] > 0))) { last_links = false; continue; }
+        m->r_pid.push_back(p);
+        m->r_xy0.push_back(table.xy0[2 * k] - tx[p]); m->r_xy0.push_back(table.xy0[2 * k + 1] - ty[p]);
+        m->r_xy1.push_back(table.xy1i[2 * k]); m->r_xy1.push_back(table.xy1i[2 * k + 1]);
+        m->r_w.push_back(table.wt[k]);
+    }
+    for (int p = 0; p < n; ++p) { valid[p] = ok_pair[p]; strain[p] = kDefaultAvgDeform; }
+    // ---- strain (matcher.py:752-777)
+    const size_t K = m->r_pid.size();
+    if (m->compute_strain && K) {
+        if ((rc = ensure_system(ctx, m))) return rc;
+        // rows of a pair are contiguous by construction; a caller-visible guarantee, so check it
+        std::vector<char> seen((size_t)n, 0);
+        bool contiguous = true;
+        for (size_t k = 0; k < K; ++k) {
+            if (k && m->r_pid[k] == m->r_pid[k - 1]) continue;
+            if (seen[m->r_pid[k]]) contiguous = false;
+            seen[m->r_pid[k]] = 1;
+        }
+        if (!contiguous) {
+            std::vector<size_t> o(K);
+            std::iota(o.begin(), o.end(), (size_t)0);
+            std::stable_sort(o.begin(), o.end(), [&](size_t a, size_t b) { return m->r_pid[a] < m->r_pid[b]; });
+            std::vector<int32_t> pid2(K); std::vector<double> a0(2 * K), a1(2 * K); std::vector<float> w2(K);
+            for (size_t k = 0; k < K; ++k) {
+                pid2[k] = m->r_pid[o[k]]; w2[k] = m->r_w[o[k]];
+                a0[2 * k] = m->r_xy0[2 * o[k]]; a0[2 * k + 1] = m->r_xy0[2 * o[k] + 1]; a1[2 * k] = m->r_xy1[2 * o[k]]; a1[2 * k + 1] = m->r_xy1[2 * o[k] + 1];
+            }
+            m->r_pid.swap(pid2); m->r_xy0.swap(a0); m->r_xy1.swap(a1); m->r_w.swap(w2);
+            last_links = false;
+        }
+        std::vector<double> p0(2 * K), R;
+        std::vector<char> bad;
+        for (size_t k = 0; k < K; ++k) { p0[2 * k] = m->r_xy0[2 * k] + tx[m->r_pid[k]]; p0[2 * k + 1] = m->r_xy0[2 * k + 1] + ty[m->r_pid[k]]; }   // mesh0 points, FIXED gear
+        rigid_fits(n, m->r_pid, p0, m->r_xy1, m->r_w, R, bad);
+        rc = fb_pairs_strain(ctx, m->sys, n, m->gnx, m->gny, m->gxs.data(), m->gys.data(), (int64_t)K, m->r_pid.data(), p0.data(), m->r_xy1.data(),
+                             m->r_w.data(), R.data(), m->stiffness_lambda, m->es0, last_links ? 1 : 0, kDefaultAvgDeform, strain, &m->strain_iters,
+                             &m->strain_relres);
+        if (rc) return rc;
+        m->strain_matches = (int64_t)K;
+        bool any_bad = false;
+        for (int p = 0; p < n; ++p)
+            if (bad[p]) { flags[p] |= FB_STRIP_RIGIDFIT; valid[p] = 0; strain[p] = kDefaultAvgDeform; any_bad = true; }
+        if (any_bad) {
+            size_t w = 0;
+            for (size_t k = 0; k < K; ++k) {
+                if (bad[m->r_pid[k]]) continue;
+                m->r_pid[w] = m->r_pid[k]; m->r_w[w] = m->r_w[k];
+                m->r_xy0[2 * w] = m->r_xy0[2 * k]; m->r_xy0[2 * w + 1] = m->r_xy0[2 * k + 1];
+                m->r_xy1[2 * w] = m->r_xy1[2 * k]; m->r_xy1[2 * w + 1] = m->r_xy1[2 * k + 1];
+                ++w;
+            }
+            m->r_pid.resize(w); m->r_w.resize(w); m->r_xy0.resize(2 * w); m->r_xy1.resize(2 * w);
+        }
+    }
+    *nrows = (int64_t)m->r_pid.size();
+    return FB_OK;
+}
+
+int fb_match_strips_table(fb_ctx* ctx, fb_strip_matcher* m, int32_t* pair, double* xy0, double* xy1, float* weight) {
+    FB_CHECK_ARG(ctx, m != nullptr);
+    const size_t K = m->r_pid.size();
+    if (K == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, pair && xy0 && xy1 && weight);
+    std::copy(m->r_pid.begin(), m->r_pid.end(), pair);
+    std::copy(m->r_xy0.begin(), m->r_xy0.end(), xy0);
+    std::copy(m->r_xy1.begin(), m->r_xy1.end(), xy1);
+    std::copy(m->r_w.begin(), m->r_w.end(), weight);
+    return FB_OK;
+}
+
+}  // extern "C"

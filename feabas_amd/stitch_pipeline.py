@@ -24,6 +24,7 @@ fb_remap_dev + fb_ncc_batch_dev), matches are located in the deformed triangles 
 INITIAL gear through their barycentric coordinates (matcher.py:748-751).  SURVEY.md sec.8f rows 1-2.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -145,13 +146,54 @@ class MatcherPool:
         self.systems = {}
 
 
+class _LazyBuffer:
+    """device buffer of the host route, taken from the pool the first time that route touches it (a matcher that stays on
+    fb_match_strips, which owns its own buffers, never allocates them)"""
+
+    def __init__(self, name):
+        self.key = '_buf_' + name
+
+    def __get__(self, obj, cls=None):
+        if obj is None:
+            return self
+        b = obj.__dict__.get(self.key)
+        if b is None:
+            nbytes = obj._buf_bytes.get(self.key)
+            if nbytes is None:
+                return None
+            b = obj._pool.take(nbytes) if obj._pool is not None else _lib.DeviceBuffer(int(nbytes))
+            obj.__dict__[self.key] = b
+        return b
+
+    def __set__(self, obj, val):
+        obj.__dict__[self.key] = val
+
+
 class StripBatchMatcher:
+    d_small = _LazyBuffer('small')
+    d_dogc = _LazyBuffer('dogc')
+    d_dogf = _LazyBuffer('dogf')
+    d_blk = _LazyBuffer('blk')
+    d_out = _LazyBuffer('out')
+
     def __init__(self, P, H, W, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
                  conf_mode=const.FFT_CONF_MIRROR, residue_len=5, stiffness_lambda=1.0, relax_tol=1e-9, compute_strain=True, spacings=None,
-                 pool=None, residue_mode='huber'):
+                 pool=None, residue_mode='huber', route=None):
         assert coarse_downsample in (0.5, 1)
         self._pool = pool
-        alloc = pool.take if pool is not None else _lib.DeviceBuffer
+        # 'native': fb_match_strips (the whole sequence behind one C entry; pairs it hands back take the host route);
+        # 'host': the numpy statement below for every pair.  Masks, photometric statistics and ragged batches are host only.
+        self._route = route or os.environ.get('FEABAS_HIP_STRIP_ROUTE', 'native')
+        if self._route not in ('native', 'host'):
+            raise ValueError("route must be 'native' or 'host'")
+        self._opts = dict(sigma=sigma, coarse_downsample=coarse_downsample, conf_thresh=conf_thresh, min_num_blocks=min_num_blocks, conf_mode=conf_mode,
+                          residue_len=residue_len, stiffness_lambda=stiffness_lambda, relax_tol=relax_tol, compute_strain=compute_strain,
+                          spacings=spacings, residue_mode=residue_mode)
+        self._native = None
+        self._general = {}
+        self._gather = None
+        self._prefer_host = False
+        self.last_flags = None
         self.P, self.H, self.W = int(P), int(H), int(W)
         self.sigma = float(sigma)
         self.cds = coarse_downsample
@@ -173,12 +215,10 @@ class StripBatchMatcher:
         hc, wc = (half_size(H), half_size(W)) if coarse_downsample == 0.5 else (H, W)      # cv2.resize(fx=0.5): cvRound(n / 2)
         self.hc, self.wc = hc, wc
         n = self.P
-        self.d_small = alloc(2 * n * hc * wc) if coarse_downsample == 0.5 else None
-        self.d_dogc = alloc(2 * n * hc * wc * 4)
-        self.d_dogf = alloc(2 * n * H * W * 4)
         self.max_blocks = n * 1024
-        self.d_blk = alloc(self.max_blocks * 9 * 4)
-        self.d_out = alloc(self.max_blocks * 20)       # per launch: [dx f64 N][dy f64 N][conf f32 N], one D2H copy
+        self._buf_bytes = {'_buf_small': 2 * n * hc * wc if coarse_downsample == 0.5 else None, '_buf_dogc': 2 * n * hc * wc * 4,
+                           '_buf_dogf': 2 * n * H * W * 4, '_buf_blk': self.max_blocks * 9 * 4,
+                           '_buf_out': self.max_blocks * 20}       # d_out per launch: [dx f64 N][dy f64 N][conf f32 N], one D2H copy
         self.residue_len = float(residue_len)                 # matcher.py:236 (fine_downsample = 1)
         if residue_mode not in ('huber', 'threshold'):
             raise ValueError("residue_mode must be 'huber' or 'threshold' (matcher.py:730-735)")
@@ -200,11 +240,20 @@ class StripBatchMatcher:
             else:
                 _lib.load().fb_sys_destroy(_lib.ctx(), self._relax_sys)
             self._relax_sys = None
-        for name in ('d_small', 'd_dogc', 'd_dogf', 'd_blk', 'd_out'):
-            b = getattr(self, name, None)
+        for key in ('_buf_small', '_buf_dogc', '_buf_dogf', '_buf_blk', '_buf_out'):
+            b = self.__dict__.pop(key, None)
             if b is not None:
                 pool.give(b) if pool is not None else b.free()
-                setattr(self, name, None)
+        if self._native is not None:
+            _lib.load().fb_strip_matcher_destroy(_lib.ctx(), self._native)
+            self._native = None
+        for sub in self._general.values():
+            sub.free()
+        self._general = {}
+        if self._gather is not None:
+            for b in self._gather:
+                pool.give(b) if pool is not None else b.free()
+            self._gather = None
         for name in [k for k in vars(self) if k.startswith('_scr_')]:
             b = getattr(self, name)
             pool.give(b) if pool is not None else b.free()
@@ -834,6 +883,99 @@ class StripBatchMatcher:
         return nodes3, B1
 
     def match(self, strips0, strips1, masks0=None, masks1=None, compute_photometric=False):
+        """stitching_matcher for the P resident pairs; see `_match_host` for the arguments and the result.  Unmasked
+        batches of equal strips go through fb_match_strips (one C entry for the whole sequence); the pairs it hands back
+        (flags != 0: second shot of the global matcher, deformed mesh1, relax_first, degenerate rigid fit) and every
+        other kind of batch take the numpy statement of the same sequence."""
+        if self._route == 'native' and not self._ragged and masks0 is None and masks1 is None and not compute_photometric:
+            if self._prefer_host:
+                res = self._match_host(strips0, strips1)
+                self._prefer_host = int(np.count_nonzero(res['deformed'])) > self.P // 2
+                return res
+            return self._match_native(strips0, strips1)
+        return self._match_host(strips0, strips1, masks0, masks1, compute_photometric)
+
+    def _native_matcher(self):
+        if self._native is None:
+            lib, ctx = _lib.load(), _lib.ctx()
+            sp = np.ascontiguousarray(self.spacings, dtype=np.float64)
+            o = _lib.StripOpts(self.sigma, 1 if self.cds == 0.5 else 0, self.conf_thresh, self.mnb, self.conf_mode, self.residue_len,
+                               self.residue_mode, self.stiffness_lambda, self.relax_tol, int(self.compute_strain), int(sp.size), sp.ctypes.data)
+            h = C.c_void_p()
+            _lib.check(lib.fb_strip_matcher_create(ctx, self.P, self.H, self.W, C.byref(o), C.byref(h)))
+            self._native = h
+        return self._native
+
+    def _match_native(self, strips0, strips1):
+        lib, ctx = _lib.load(), _lib.ctx()
+        n = self.P
+        strips0 = strips0.value if hasattr(strips0, 'value') else strips0
+        strips1 = strips1.value if hasattr(strips1, 'value') else strips1
+        h = self._native_matcher()
+        tx = np.empty(n); ty = np.empty(n); cf0 = np.empty(n, dtype=np.float32); strain = np.empty(n)
+        valid = np.empty(n, dtype=np.uint8); flags = np.empty(n, dtype=np.uint8)
+        nrows = C.c_int64()
+        _lib.check(lib.fb_match_strips(ctx, h, C.c_void_p(strips0), C.c_void_p(strips1), _lib.ptr(tx), _lib.ptr(ty), _lib.ptr(cf0), _lib.ptr(valid),
+                                       _lib.ptr(flags), _lib.ptr(strain), C.byref(nrows)))
+        K = nrows.value
+        pid = np.empty(K, dtype=np.int32); xy0 = np.empty((K, 2)); xy1 = np.empty((K, 2)); wt = np.empty(K, dtype=np.float32)
+        _lib.check(lib.fb_match_strips_table(ctx, h, _lib.ptr(pid), _lib.ptr(xy0), _lib.ptr(xy1), _lib.ptr(wt)))
+        it_r, it_s, rr_r, rr_s = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        _lib.check(lib.fb_strip_matcher_info(ctx, h, None, None, None, None, C.byref(it_r), C.byref(rr_r), C.byref(it_s), C.byref(rr_s)))
+        self.last_relax = dict(iters=it_r.value, relres=rr_r.value, matches=int(K), relaxed_first=0)
+        self.last_strain_solve = dict(iters=it_s.value, relres=rr_s.value, matches=int(K))
+        self.last_flags = flags
+        self.last_field = None
+        self.last_tiers = {}
+        zeros = np.zeros(n, dtype=bool)
+        res = dict(tx=tx, ty=ty, conf0=cf0, valid=valid.astype(bool), needs_host=zeros, deformed=zeros.copy(), deferred=zeros.copy(),
+                   pair=pid.astype(np.int64), xy0=xy0, xy1=xy1, weight=wt, strain=strain, phtm=None)
+        fl = np.flatnonzero(flags)
+        if fl.size:
+            self._general_route(res, fl, strips0, strips1)
+        return res
+
+    def _general_route(self, res, fl, strips0, strips1):
+        """the pairs `fl` of the batch through the host route; their results replace those of fb_match_strips in `res`"""
+        lib, ctx = _lib.load(), _lib.ctx()
+        n, H, W = self.P, self.H, self.W
+        self._prefer_host = fl.size > n // 2
+        if fl.size == n:
+            res.update(self._match_host(strips0, strips1))
+            return
+        sub = self._general.pop(fl.size, None)
+        if sub is None:
+            if len(self._general) >= 4:                          # sub-matchers are kept for the sizes that came last
+                self._general.pop(next(iter(self._general))).free()
+            sub = StripBatchMatcher(fl.size, H, W, pool=self._pool, route='host', **self._opts)
+        self._general[fl.size] = sub
+        need = fl.size * H * W
+        if self._gather is None or self._gather[0].nbytes < need:
+            if self._gather is not None:
+                for b in self._gather:
+                    self._pool.give(b) if self._pool is not None else b.free()
+            take = self._pool.take if self._pool is not None else _lib.DeviceBuffer
+            self._gather = (take(need), take(need))
+        # gather the strips of the flagged pairs, runs of consecutive pairs in one copy
+        runs = np.split(fl, np.flatnonzero(np.diff(fl) != 1) + 1)
+        at = 0
+        for r in runs:
+            for buf, src in zip(self._gather, (strips0, strips1)):
+                _lib.check(lib.fb_memcpy_d2d(ctx, buf.offset(at * H * W), C.c_void_p(src + int(r[0]) * H * W), r.size * H * W))
+            at += r.size
+        g = sub._match_host(self._gather[0].ptr, self._gather[1].ptr)
+        for k in ('tx', 'ty', 'conf0', 'valid', 'deformed', 'deferred', 'strain'):
+            res[k][fl] = g[k]
+        for k, src in (('pair', fl[g['pair']]), ('xy0', g['xy0']), ('xy1', g['xy1']), ('weight', g['weight'])):
+            res[k] = np.concatenate((res[k], src), axis=0)
+        if sub.last_field is not None:
+            self.last_field = np.zeros((n,) + sub.last_field.shape[1:])
+            self.last_field[fl] = sub.last_field
+        self.last_tiers = {int(fl[k]): v for k, v in sub.last_tiers.items()}
+        if sub.last_relax is not None and self.last_relax is not None:
+            self.last_relax['relaxed_first'] += sub.last_relax.get('relaxed_first', 0)
+
+    def _match_host(self, strips0, strips1, masks0=None, masks1=None, compute_photometric=False):
         """strips0/strips1: device pointers to uint8 [P][H][W].  masks0/masks1: optional lists of P host arrays (H x W,
         non-zero = valid pixel) or None entries -- the masked DoG of matcher.py:257-274, 336-337.  compute_photometric:
         result['phtm'] = per pair (av0, av1, std0, std1) of matcher.py:279-314.  Returns a dict of arrays:

@@ -72,6 +72,8 @@ int fb_host_pack2d(fb_ctx* ctx, uint8_t* dst, int n, int H, int W, const void* c
                    const int64_t* pitches, int threads);
 int fb_memcpy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
 int fb_memcpy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* device -> device on the context's stream (asynchronous, ordered with the kernels) */
+int fb_memcpy_d2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
 int fb_memset(fb_ctx* ctx, void* dst, int value, size_t bytes);
 
 /* HIP-event stopwatch on the context stream (bench.py's timed region) and
@@ -294,6 +296,42 @@ int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* sys, int P, int64_t K, const int
 int fb_pairs_strain_bary(fb_ctx* ctx, fb_system* sys, int P, int64_t K, const int32_t* pid, const int32_t* nodes3, const double* B1,
                          const double* xy0_fixed, const double* xy1_initial, const float* weight, const double* R, double stiffness_lambda,
                          const double* es0, double default_strain, double* strain, int* iters, double* relres);
+/* ---- matcher.stitching_matcher (matcher.py:224-367) for a batch of P equal-shaped overlap-strip pairs resident in HBM,
+ * as one entry: what stitcher.py:593 calls once per overlap (downsample, DoG, global NCC, fine DoG, coarse-to-fine block
+ * NCC rounds with the pad / subpixel / spacing schedule, rigid relaxations between rounds, last-round relaxation + residue
+ * weights, strain).  strips0 / strips1: device uint8 [P][H][W].  Per pair: tx, ty (global translation at full resolution),
+ * conf0, valid, flags, strain (DEFAULT_AVG_DEFORM where there is none).  The match table (rows of a pair contiguous;
+ * xy0 / xy1 in the INITIAL gears of mesh0 / mesh1 like stitching_matcher's return value) stays in the matcher until
+ * fb_match_strips_table copies its *nrows rows out.  Pairs with flags != 0 are NOT finished here (valid = 0, no rows):
+ * they need a branch of the reference that works pair by pair (second shot of global_translation_matcher, a deformed
+ * mesh1 between spacings, relax_first, the degenerate branches of fit_affine) -- the caller's general route
+ * (feabas_amd.stitch_pipeline) takes them.  Masks and the photometric statistics are on that route too. */
+typedef struct fb_strip_matcher fb_strip_matcher;
+typedef struct fb_strip_opts {
+    double sigma;              /* DoG sigma at full resolution (matcher.py:233) */
+    int coarse_downsample2;    /* 1: coarse_downsample = 0.5, 0: coarse_downsample = 1 (matcher.py:234) */
+    double conf_thresh;        /* matcher.py:232 */
+    int min_num_blocks;        /* last round (matcher.py:572) */
+    int conf_mode;             /* FB_CONF_* */
+    double residue_len;        /* pixels at full resolution; <= 0: no residue filter (matcher.py:236) */
+    int residue_mode;          /* 0 huber, 1 threshold (matcher.py:730-735) */
+    double stiffness_lambda;   /* matcher.py:507 */
+    double relax_tol;          /* PCG tolerance of the last-round relaxation */
+    int compute_strain;        /* matcher.py:497 */
+    int nspacings;             /* 0: the automatic spacings of matcher.py:243-251 */
+    const double* spacings;    /* pixels (>= 1) */
+} fb_strip_opts;
+#define FB_STRIP_LOWCONF 1
+#define FB_STRIP_NONRIGID 2
+#define FB_STRIP_RELAXFIRST 4
+#define FB_STRIP_RIGIDFIT 8
+int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* opts, fb_strip_matcher** out);
+void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m);
+int fb_strip_matcher_info(fb_ctx* ctx, fb_strip_matcher* m, int* nspacings, double* spacings, int* grid_nx, int* grid_ny,
+                          int* relax_iters, double* relax_relres, int* strain_iters, double* strain_relres);
+int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, const uint8_t* strips1, double* tx, double* ty,
+                    float* conf0, uint8_t* valid, uint8_t* flags, double* strain, int64_t* nrows);
+int fb_match_strips_table(fb_ctx* ctx, fb_strip_matcher* m, int32_t* pair, double* xy0, double* xy1, float* weight);
 /* ---- host geometry of pairs whose mesh1 is deformed (no device work; ctx may be NULL).
  * fb_deformed_block_affines: the tier decision of MeshRenderer.crop_field with the affine approximator of
  *   MeshRenderer.from_mesh (renderer.py:90-109, 397-416, 453-511) for the nblk blocks of Q pairs.  vm [Q][nx ny][2] =

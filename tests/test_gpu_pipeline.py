@@ -737,3 +737,68 @@ def test_stitching_matcher_unequal_strip_shapes(fb):
     # spacings relative to the overlap (< 1, matcher.py:343-350) take the same route
     rel = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2, spacings=[0.25, 75])
     assert rel[0] is not None and np.abs(np.median(rel[1] - rel[0], axis=0) - d_full).max() < 0.15
+
+
+@pytest.mark.parametrize('H,W,P,cds,mode', [(1024, 256, 10, 0.5, 'huber'), (256, 1024, 7, 0.5, 'threshold'), (640, 200, 6, 1, 'huber'),
+                                             (1023, 255, 5, 0.5, 'huber')])
+def test_native_entry_equals_the_host_statement(fb, H, W, P, cds, mode):
+    """fb_match_strips (the whole stitching_matcher sequence behind one C entry) against the numpy statement of the same
+    sequence in stitch_pipeline.py: identical tables for the pairs it finishes; the pairs it hands back -- here one
+    without a match (second shot of global_translation_matcher) and one whose mesh1 deforms between the spacings -- come
+    back through the host route with the results that route gives them inside a full batch."""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    s0, s1, shifts = _synth(fb, P, H, W, seed=23, max_shift=14, warp=0.3)
+    h0 = s0.to_array((P, H, W), np.uint8); h1 = s1.to_array((P, H, W), np.uint8)
+    rng = np.random.default_rng(5)
+    h1[1] = rng.integers(0, 256, (H, W), dtype=np.uint8)                   # nothing to find
+    w0, w1 = _warped_pair(H, W, 3, (3, -2), 3.0)
+    h0[2], h1[2] = w0, w1                                                  # non-rigid between the spacings
+    d0 = _lib.DeviceBuffer.from_array(h0); d1 = _lib.DeviceBuffer.from_array(h1)
+    kw = dict(coarse_downsample=cds, residue_mode=mode, residue_len=3.0)
+    mn = StripBatchMatcher(P, H, W, route='native', **kw)
+    mh = StripBatchMatcher(P, H, W, route='host', **kw)
+    rn = mn.match(d0.ptr, d1.ptr); rh = mh.match(d0.ptr, d1.ptr)
+    assert mn.last_flags[1] & 1 and mn.last_flags.astype(bool).sum() <= 3 and not mn.last_flags[0]
+    if mn.spacings.size > 1:
+        assert mn.last_flags[2] & 2 and rn['deformed'][2]
+    for k in ('tx', 'ty', 'conf0', 'valid', 'deformed'):
+        np.testing.assert_array_equal(rn[k], rh[k], err_msg=k)
+    assert rn['valid'].sum() >= P - 2
+    gn = StripBatchMatcher.per_pair(rn); gh = StripBatchMatcher.per_pair(rh)
+    for p in range(P):
+        if not rh['valid'][p]:
+            assert gn[p]['xy0'] is None
+            continue
+        exact = not mn.last_flags[p]
+        for k in ('xy0', 'xy1', 'weight'):
+            if exact:
+                np.testing.assert_array_equal(gn[p][k], gh[p][k], err_msg=f'{k} of pair {p}')
+            else:
+                np.testing.assert_allclose(gn[p][k], gh[p][k], atol=1e-6, err_msg=f'{k} of pair {p}')
+        np.testing.assert_allclose(gn[p]['strain'], gh[p]['strain'], rtol=1e-6, atol=1e-10)
+    # a second call reuses everything that is resident
+    rn2 = mn.match(d0.ptr, d1.ptr)
+    np.testing.assert_array_equal(rn2['xy0'], rn['xy0']); np.testing.assert_array_equal(rn2['weight'], rn['weight'])
+    mn.free(); mh.free(); d0.free(); d1.free(); s0.free(); s1.free()
+
+
+def test_native_entry_automatic_spacings_and_grid(fb):
+    """fb_strip_matcher_create without spacings restates matcher.py:243-251; its relaxation grid is Mesh.from_bbox's"""
+    from feabas_amd import _lib
+    from feabas_amd.matcher import auto_spacings
+    from feabas_amd.stitch_pipeline import grid_counts
+    lib, ctx = _lib.load(), _lib.ctx()
+    for H, W in [(4096, 510), (510, 4096), (256, 256), (90, 1200), (3000, 500), (1023, 255)]:
+        o = _lib.StripOpts(2.5, 1, 0.33, 2, 2, 5.0, 0, 1.0, 1e-9, 1, 0, None)
+        h = C.c_void_p()
+        _lib.check(lib.fb_strip_matcher_create(ctx, 1, H, W, C.byref(o), C.byref(h)))
+        nsp = C.c_int(64); sp = np.zeros(64)
+        _lib.check(lib.fb_strip_matcher_info(ctx, h, C.byref(nsp), _lib.ptr(sp), None, None, None, None, None, None))
+        exp = np.sort(auto_spacings((H, W), (H, W)))[::-1]
+        np.testing.assert_allclose(sp[:nsp.value], exp, rtol=1e-14)
+        lib.fb_strip_matcher_destroy(ctx, h)
+    with pytest.raises(RuntimeError):
+        bad = np.array([0.5])
+        o = _lib.StripOpts(2.5, 1, 0.33, 2, 2, 5.0, 0, 1.0, 1e-9, 1, 1, bad.ctypes.data)
+        _lib.check(lib.fb_strip_matcher_create(ctx, 1, 256, 256, C.byref(o), C.byref(C.c_void_p())))
