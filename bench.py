@@ -719,6 +719,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    stagger_ms = float(os.environ.get("FEABAS_BENCH_STAGGER_MS", "3"))      # experiment: offset the first call of host thread k by k x this
+
     def run_steps(first, count):
         """`count` steps starting at index `first`, dealt round-robin to the host threads so that one thread's block-list
         bookkeeping overlaps the others' kernels (the library serialises calls per context; every step runs completely
@@ -742,9 +744,11 @@ def main():
         errs = []
         cv = threading.Condition()
 
-        def worker(mine, h):
+        def worker(mine, h, k=0):
             _lib.use_context(h)
             try:
+                if stagger_ms:
+                    time.sleep(1e-3 * stagger_ms * k)
                 for i in mine:
                     r = step(i)
                     with cv:
@@ -768,7 +772,7 @@ def main():
                     exchange(pending); pending = []
             exchange(pending)
         T = nthr
-        ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k], ctxs[k % len(ctxs)])) for k in range(T)]
+        ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k], ctxs[k % len(ctxs)], k)) for k in range(T)]
         ths.append(threading.Thread(target=comm))
         for t in ths:
             t.start()

@@ -607,9 +607,12 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
 // Replace the links of a finalized system by links that add no new vertex coupling (every pair of free
 // vertices of a match is already in the pattern -- e.g. matches against locked meshes, whose three free
 // vertices share a triangle).  Only the vertex -> match index is rebuilt; the symbolic pattern is reused.
-int fb_sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6) {
+// trusted != 0: the caller built the matches from cells of the system's own meshes (fb_pairs_*: a match couples the three
+// vertices of ONE grid triangle), so the membership test of every coupled pair is skipped
+static int sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6, int trusted) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && K >= 0 && (K == 0 || nodes6) && K < (1LL << 31) / 6);
+    if (!trusted) {
     // membership of every coupled vertex pair in the pattern, on a few host threads (K x <=36 binary searches; a section of
     // 1e5 matches took 40 ms on one core, most of the host time of an update)
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, K / 4096));
@@ -643,10 +646,13 @@ int fb_sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nod
         if (badw[t] == INT_MIN) return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld names vertex %d outside [-1, %d)", (long long)bad[t], badu[t], s->nv);
         return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld couples vertices %d and %d outside the pattern", (long long)bad[t], badu[t], badw[t]);
     }
+    }
     s->nlink = K;
     s->nodes.assign(nodes6, nodes6 + 6 * K);
     return build_link_index(ctx, s);
 }
+
+int fb_sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6) { return sys_update_links(ctx, s, K, nodes6, 0); }
 
 int fb_sys_pattern(fb_ctx* ctx, fb_system* s, int64_t* browptr, int32_t* bcol) {
     FB_CHECK_ARG(ctx, s && s->finalized);
@@ -935,7 +941,7 @@ int pairs_build_links(fb_ctx* ctx, fb_system* s, int P, int nx, int ny, const do
         double* b6 = &s->h_bary6[6 * (size_t)k];
         b6[0] = 1.0; b6[1] = 0.0; b6[2] = 0.0; b6[3] = -b1[0]; b6[4] = -b1[1]; b6[5] = -b1[2];
     }
-    return fb_sys_update_links(ctx, s, K, s->h_nodes6.data());
+    return sys_update_links(ctx, s, K, s->h_nodes6.data(), 1);     // the three vertices of one grid triangle: in the pattern by construction
 }
 }  // namespace
 

@@ -15,7 +15,9 @@
 #include "fb_common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <numeric>
 #include <vector>
@@ -50,11 +52,27 @@ struct fb_strip_matcher {
     double relax_relres = 0.0, strain_relres = 0.0;
     int64_t relax_matches = 0, strain_matches = 0;
     std::vector<uint8_t> raw;          // D2H staging of one launch: [dx f64 N][dy f64 N][conf f32 N]
+    // FEABAS_HIP_MATCH_TRACE=1: wall time of the stages of fb_match_strips, printed by fb_strip_matcher_destroy
+    bool trace = false;
+    double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // enqueue global, wait global, blocks host, blocks h2d+launch, blocks wait, relax, table+fits, strain
+    int calls = 0;
 };
 
 namespace {
 
 const double kDefaultAvgDeform = 0.05;          // feabas/config.py:32
+
+struct StageClock {
+    fb_strip_matcher* m;
+    std::chrono::steady_clock::time_point t;
+    explicit StageClock(fb_strip_matcher* mm) : m(mm), t(std::chrono::steady_clock::now()) {}
+    void lap(int stage) {
+        if (!m->trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        m->t_stage[stage] += std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
+    }
+};
 
 // numpy.linspace(start, stop, num, endpoint=True)[i]
 inline double linspace_at(double start, double stop, int num, int i) {
@@ -145,6 +163,7 @@ struct Rows {                                   // a match table: rows of one pa
     std::vector<float> wt;
     std::vector<char> rl;                       // the pair's blocks moved by more than 0.1 px (matcher.py:725)
     size_t size() const { return pid.size(); }
+    void reserve(size_t k) { pid.reserve(k); xy0.reserve(2 * k); xy1i.reserve(2 * k); xy1.reserve(2 * k); wt.reserve(k); rl.reserve(k); }
     void push(int32_t p, double x0, double y0, double xi, double yi, double x1, double y1, float w, char r) {
         pid.push_back(p); xy0.push_back(x0); xy0.push_back(y0); xy1i.push_back(xi); xy1i.push_back(yi);
         xy1.push_back(x1); xy1.push_back(y1); wt.push_back(w); rl.push_back(r);
@@ -283,6 +302,7 @@ int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opt
                           (o->nspacings == 0 || o->spacings) && o->nspacings <= 64);
     fb_strip_matcher* m = new fb_strip_matcher();
     m->P = P; m->H = H; m->W = W;
+    { const char* e = std::getenv("FEABAS_HIP_MATCH_TRACE"); m->trace = e && e[0] == '1'; }
     m->sigma = o->sigma; m->cds2 = o->coarse_downsample2; m->conf_thresh = o->conf_thresh; m->mnb = o->min_num_blocks;
     m->conf_mode = o->conf_mode; m->residue_len = o->residue_len; m->residue_mode = o->residue_mode;
     m->stiffness_lambda = o->stiffness_lambda; m->relax_tol = o->relax_tol; m->compute_strain = o->compute_strain;
@@ -321,6 +341,12 @@ int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opt
 void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m) {
     if (!m) return;
     FB_LOCK(ctx);
+    if (m->trace && m->calls > 3) {
+        const int c = m->calls - 3;
+        std::fprintf(stderr, "fb_match_strips P=%d %dx%d: %d calls, ms per call after the first 3: enqueue %.3f wait-global %.3f blocks-host %.3f blocks-launch %.3f blocks-wait %.3f relax %.3f table %.3f strain %.3f\n",
+                     m->P, m->H, m->W, m->calls, m->t_stage[0] / c, m->t_stage[1] / c, m->t_stage[2] / c, m->t_stage[3] / c, m->t_stage[4] / c, m->t_stage[5] / c,
+                     m->t_stage[6] / c, m->t_stage[7] / c);
+    }
     if (m->sys) fb_sys_destroy(ctx, m->sys);
     fb_free(ctx, m->d_dogc); fb_free(ctx, m->d_dogf); fb_free(ctx, m->d_small); fb_free(ctx, m->d_blk); fb_free(ctx, m->d_out);
     delete m;
@@ -349,6 +375,9 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
     const size_t cpix = (size_t)hc * wc, fpix = (size_t)H * W;
     const float thr = (float)m->conf_thresh;               // numpy compares float32 confidences with the threshold in float32
     int rc;
+    StageClock clk(m);
+    if (m->trace && m->calls == 3) { for (double& t : m->t_stage) t = 0.0; }      // the first calls load code objects and grow arenas
+    m->calls++;
     // ---- global translation on the coarse DoG images (matcher.py:255-278)
     if (m->cds2) {
         const int taps = (int)(4.0 * m->sigma * 0.5 + 0.5);
@@ -375,9 +404,11 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         dogf = m->d_dogf;
     }
     const float* img1 = dogf + n * fpix;
+    clk.lap(0);
     {
         const double *gx, *gy; const float* gc;
         if ((rc = fetch(ctx, m, (size_t)n, &gx, &gy, &gc))) return rc;
+        clk.lap(1);
         const double scale = m->cds2 ? 2.0 : 1.0;          // matcher.py:338-339
         for (int p = 0; p < n; ++p) { tx[p] = gx[p] * scale; ty[p] = gy[p] * scale; conf0[p] = gc[p]; }
     }
@@ -423,6 +454,11 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         }
         if (groups.empty()) continue;
         Rows cur;
+        {
+            size_t cap = 0;
+            for (auto& kv : groups) cap += kv.second.size() * (size_t)nxv[kv.second[0]] * nyv[kv.second[0]];
+            cur.reserve(cap + (have_table ? table.size() : 0));
+        }
         for (auto& kv : groups) {
             const std::vector<int>& sel = kv.second;
             const int Q = (int)sel.size(), nxi = nxv[sel[0]], nyi = nyv[sel[0]], nblk = nxi * nyi;
@@ -463,12 +499,15 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                     d[0] = p; d[1] = x0 - rtx; d[2] = y0 - rty; d[3] = dy; d[4] = dx; d[5] = x0 - r1x; d[6] = y0 - r1y; d[7] = dy; d[8] = dx;
                 }
             }
+            clk.lap(2);
             if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), nb * 9 * 4))) return rc;
             if ((rc = fb_ncc_blocks_dev(ctx, dogf, img1, H, W, H, W, (int)nb, m->d_blk, hmax, wmax, fhv[sel[0]], fwv[sel[0]], is_last ? 1 : 0,
                                         m->conf_mode, (double*)m->d_out, (double*)(m->d_out + 8 * nb), (float*)(m->d_out + 16 * nb))))
                 return rc;
+            clk.lap(3);
             const double *ddx, *ddy; const float* dcf;
             if ((rc = fetch(ctx, m, nb, &ddx, &ddy, &dcf))) return rc;
+            clk.lap(4);
             // ---- blocks -> point pairs (matcher.py:671-683, 840-849), spacing schedule (689-716), rigid relaxation (725-742)
             for (int q = 0; q < Q; ++q) {
                 const int p = sel[q];
@@ -527,6 +566,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         table = std::move(cur);
         have_table = true;
         last_links = false;
+        clk.lap(2);
         if (is_last && m->residue_len > 0 && table.size()) {
             bool any_rl = false;
             for (char r : table.rl) any_rl |= r != 0;
@@ -565,6 +605,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                     if (table.rl[k]) table.wt[k] = table.wt[k] * rw[k];                 // Link.weight (optimizer.py:313-317)
             }
         }
+        clk.lap(5);
         if (had_prev && prev.size()) {
             // a pair without a confident block in this round keeps the links of its last good round (the reference
             // breaks out of the loop before clear_links, matcher.py:671-679)
@@ -621,11 +662,13 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         std::vector<char> bad;
         for (size_t k = 0; k < K; ++k) { p0[2 * k] = m->r_xy0[2 * k] + tx[m->r_pid[k]]; p0[2 * k + 1] = m->r_xy0[2 * k + 1] + ty[m->r_pid[k]]; }   // mesh0 points, FIXED gear
         rigid_fits(n, m->r_pid, p0, m->r_xy1, m->r_w, R, bad);
+        clk.lap(6);
         rc = fb_pairs_strain(ctx, m->sys, n, m->gnx, m->gny, m->gxs.data(), m->gys.data(), (int64_t)K, m->r_pid.data(), p0.data(), m->r_xy1.data(),
                              m->r_w.data(), R.data(), m->stiffness_lambda, m->es0, last_links ? 1 : 0, kDefaultAvgDeform, strain, &m->strain_iters,
                              &m->strain_relres);
         if (rc) return rc;
         m->strain_matches = (int64_t)K;
+        clk.lap(7);
         bool any_bad = false;
         for (int p = 0; p < n; ++p)
             if (bad[p]) { flags[p] |= FB_STRIP_RIGIDFIT; valid[p] = 0; strain[p] = kDefaultAvgDeform; any_bad = true; }
