@@ -874,11 +874,17 @@ def main():
     tfile = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*pmc_traffic.json')))
     if tfile and dom[0] is not None:
         tk = json.load(open(tfile[-1]))['kernels']
-        alias = {'ncc_stream_cols': 'ncc_cols_p2', 'ncc_stream_rows': 'ncc_rows_p2', 'ncc_stream_inv': 'ncc_inv_p2'}     # profile label -> device symbol
-        hit = [v for k_, v in tk.items() if k_.startswith(dom[0]) or k_ == alias.get(dom[0])]
+        # profile label of the library -> device symbols as rocprofv3 names them (the column pass runs in its direct form
+        # ncc_cols2_p2 where the correlation is zero padded, in the staged form ncc_cols_p2 elsewhere)
+        alias = {'ncc_stream_cols': ('ncc_cols2_p2', 'ncc_cols_p2'), 'ncc_stream_rows': ('ncc_rows_p2',), 'ncc_stream_inv': ('ncc_inv_p2',),
+                 'dog_fast': ('dog_stream',)}
+        syms = alias.get(dom[0], (dom[0],))
+        hit = [v for k_, v in tk.items() if k_ in syms]
         if hit:
-            roof['traffic'] = hit[0]['hbm_bytes_per_launch']
+            nl = sum(v['launches'] for v in hit)
+            roof['traffic'] = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit) / max(nl, 1)
             roof['traffic_source'] = 'profiles/' + os.path.basename(tfile[-1])
+            roof['kernel_symbols'] = [k_ for k_ in tk if k_ in syms]
     roof['per_kernel_gbs'] = {k_: round(v[2] / (v[1] * 1e-3) / 1e9, 1) for k_, v in prof.items() if v[1] > 0 and v[2] > 0}
 
     line = dict(metric='tile_pair_ncc_matches_per_s', value=pairs / dt, unit='pairs/s', n_gpus=world, steps=args.steps,
