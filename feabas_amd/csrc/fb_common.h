@@ -59,6 +59,10 @@ struct fb_ctx {
     bool use_rocfft = false;     // FEABAS_HIP_ROCFFT=1: streaming-class FFTs through rocFFT instead of the hand-written kernels
     bool dog_tiles = false;      // FEABAS_HIP_DOG_TILES=1: the 64 x 64 tile kernel (dog_fast) instead of the streaming one (A/B)
     bool dog_exact = false;      // double-precision tap accumulation (scipy's arithmetic) instead of the float fast path
+    // device buffers and relaxation systems that outlive a strip matcher (fb_match.hip): matchers of ragged batches come and
+    // go with every chunk of a section, their buffers and the symbolic phase of their block-diagonal system do not
+    std::vector<std::pair<void*, size_t>> match_pool;
+    std::map<std::tuple<int, int, int>, std::vector<fb_system*>> match_systems;
 };
 
 int fb_fail(fb_ctx* ctx, int code, const char* fmt, ...);

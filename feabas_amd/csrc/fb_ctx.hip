@@ -119,6 +119,9 @@ void fb_destroy(fb_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->match_systems)
+        for (fb_system* sy : kv.second) fb_sys_destroy(ctx, sy);
+    ctx->match_systems.clear();
     prof_drain(ctx);
     for (auto& kv : ctx->plans) {
         if (kv.second.fwd) rocfft_plan_destroy(kv.second.fwd);

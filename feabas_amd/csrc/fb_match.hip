@@ -34,7 +34,13 @@ struct fb_strip_matcher {
     int residue_mode = 0;
     double stiffness_lambda = 1.0, relax_tol = 1e-9;
     int compute_strain = 1;
-    std::vector<double> sp;            // spacings in pixels, descending (matcher.py:567)
+    std::vector<double> sp;            // spacings in pixels, descending (matcher.py:567): [P][nsp], one row per pair
+    int nsp = 0;
+    bool ragged = false;               // strips of unequal size in slots of H x W (stitcher.py:561-571)
+    std::vector<int> Hs, Ws, hcs, wcs; // per-pair strip extents, full resolution and coarse
+    int* d_sizes = nullptr;            // device [2P][2] = {h, w} of every image of the two stacks
+    int* d_sizes_c = nullptr;
+    size_t b_dogc = 0, b_dogf = 0, b_small = 0, b_blk = 0, b_out = 0, b_sizes = 0;      // byte sizes of the pooled buffers
     float* d_dogc = nullptr;
     float* d_dogf = nullptr;
     uint8_t* d_small = nullptr;
@@ -43,8 +49,9 @@ struct fb_strip_matcher {
     size_t max_blocks = 0;
     fb_system* sys = nullptr;
     int gnx = 0, gny = 0;
-    std::vector<double> gxs, gys;
-    double es0 = 0.0, area = 0.0;
+    std::vector<double> gxs, gys;      // node coordinates of every pair's grid: [P][gnx], [P][gny]
+    std::vector<double> es0, se;       // per pair: v0^T K v0 of the centred mesh, sample error of its matches (optimizer.py:26-30)
+    double se0 = 0.0;                  // sample error on the template mesh (pair 0)
     std::vector<int32_t> r_pid;
     std::vector<double> r_xy0, r_xy1;
     std::vector<float> r_w;
@@ -86,64 +93,122 @@ inline double linspace_at(double start, double stop, int num, int i) {
 
 inline int round_i(double v) { return (int)std::nearbyint(v); }      // np.round: half to even
 
-// the matcher's grid: node counts and coordinates of Mesh.from_bbox((0, 0, W, H), cartesian=True) (mesh.py:403-435)
-void grid_nodes(int H, int W, double mesh_size, int mnb, std::vector<double>& xs, std::vector<double>& ys) {
+// the matcher's grid: node counts of Mesh.from_bbox((0, 0, W, H), cartesian=True) (mesh.py:403-435)
+void grid_counts(int H, int W, double mesh_size, int mnb, int* nx_out, int* ny_out) {
     const double wd = (double)W, ht = (double)H;
     const double nx0 = std::max(std::nearbyint(wd / mesh_size), (double)mnb), ny0 = std::max(std::nearbyint(ht / mesh_size), (double)mnb);
     double dx = wd / nx0, dy = ht / ny0;
     if (dx > 2.0 * dy) dx = 2.0 * dy;
     else if (dy > 2.0 * dx) dy = 2.0 * dx;
-    const int nx = (int)std::ceil(wd / dx) + 1, ny = (int)std::ceil(ht / dy) + 1;
-    xs.resize(nx); ys.resize(ny);
-    for (int i = 0; i < nx; ++i) xs[i] = linspace_at(0.0, 0.0 + wd, nx, i) - 0.5;
-    for (int j = 0; j < ny; ++j) ys[j] = linspace_at(0.0, 0.0 + ht, ny, j) - 0.5;
+    *nx_out = (int)std::ceil(wd / dx) + 1;
+    *ny_out = (int)std::ceil(ht / dy) + 1;
 }
 
-// P copies of the grid mesh as one block-diagonal system (the stiffness never changes: mesh0 is locked, matcher.py:361)
+// device buffers handed from matcher to matcher through the context (fb_common.h: match_pool)
+int pool_take(fb_ctx* ctx, size_t bytes, void** out, size_t* got) {
+    int best = -1;
+    for (int k = 0; k < (int)ctx->match_pool.size(); ++k) {
+        const size_t nb = ctx->match_pool[k].second;
+        if (nb >= bytes && nb <= 4 * std::max<size_t>(bytes, 4096) && (best < 0 || nb < ctx->match_pool[best].second)) best = k;
+    }
+    if (best >= 0) {
+        *out = ctx->match_pool[best].first; *got = ctx->match_pool[best].second;
+        ctx->match_pool.erase(ctx->match_pool.begin() + best);
+        return FB_OK;
+    }
+    *got = bytes;
+    return fb_malloc(ctx, bytes, out);
+}
+void pool_give(fb_ctx* ctx, void* ptr, size_t bytes) {
+    if (!ptr) return;
+    ctx->match_pool.emplace_back(ptr, bytes);
+    if (ctx->match_pool.size() > 32) {                       // bound the pool: drop the smallest
+        size_t k = 0;
+        for (size_t i = 1; i < ctx->match_pool.size(); ++i) if (ctx->match_pool[i].second < ctx->match_pool[k].second) k = i;
+        fb_free(ctx, ctx->match_pool[k].first);
+        ctx->match_pool.erase(ctx->match_pool.begin() + k);
+    }
+}
+
+// P copies of the grid topology as one block-diagonal system, every copy with the node coordinates of its pair's strip
+// (mesh0 is locked, matcher.py:361: the stiffness of a matcher never changes).  The symbolic phase is kept per
+// (P, nx, ny) in the context, so a matcher of a new batch of shapes only re-assembles the values.
 int ensure_system(fb_ctx* ctx, fb_strip_matcher* m) {
     if (m->sys) return FB_OK;
-    grid_nodes(m->H, m->W, *std::min_element(m->sp.begin(), m->sp.end()), m->mnb, m->gxs, m->gys);
-    const int nx = (int)m->gxs.size(), ny = (int)m->gys.size(), V = nx * ny, T = 2 * (nx - 1) * (ny - 1), P = m->P;
+    const int P = m->P, nsp = m->nsp;
+    int nx = 0, ny = 0;
+    grid_counts(m->Hs[0], m->Ws[0], *std::min_element(m->sp.begin(), m->sp.begin() + nsp), m->mnb, &nx, &ny);
+    for (int p = 1; p < P; ++p) {
+        int a = 0, b = 0;
+        grid_counts(m->Hs[p], m->Ws[p], *std::min_element(m->sp.begin() + (size_t)p * nsp, m->sp.begin() + (size_t)(p + 1) * nsp), m->mnb, &a, &b);
+        if (a != nx || b != ny)
+            return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: pair %d has a %d x %d node grid, pair 0 %d x %d (the pairs of a batch share the mesh topology)", p, a, b, nx, ny);
+    }
+    const int V = nx * ny, T = 2 * (nx - 1) * (ny - 1);
     m->gnx = nx; m->gny = ny;
-    std::vector<int32_t> tri((size_t)3 * P * T);
-    for (int p = 0; p < P; ++p) {
-        int32_t* t = &tri[(size_t)3 * p * T];
-        for (int j = 0; j < ny - 1; ++j)
-            for (int i = 0; i < nx - 1; ++i) {
-                const int a = p * V + j * nx + i, b = a + 1, c = a + nx, d = c + 1;
-                t[0] = a; t[1] = b; t[2] = d; t[3] = a; t[4] = d; t[5] = c;
-                t += 6;
-            }
+    m->gxs.resize((size_t)P * nx); m->gys.resize((size_t)P * ny);
+    for (int p = 0; p < P; ++p) {                            // mesh.py:430-431 per pair
+        for (int i = 0; i < nx; ++i) m->gxs[(size_t)p * nx + i] = linspace_at(0.0, (double)m->Ws[p], nx, i) - 0.5;
+        for (int j = 0; j < ny; ++j) m->gys[(size_t)p * ny + j] = linspace_at(0.0, (double)m->Hs[p], ny, j) - 0.5;
     }
     int rc;
     fb_system* s = nullptr;
-    if ((rc = fb_sys_create(ctx, (int64_t)P * V, &s))) return rc;
     int mid = 0;
-    int64_t nnzb = 0;
+    auto key = std::make_tuple(P, nx, ny);
+    auto it = ctx->match_systems.find(key);
+    if (it != ctx->match_systems.end() && !it->second.empty()) {
+        s = it->second.back();
+        it->second.pop_back();
+    } else {
+        std::vector<int32_t> tri((size_t)3 * P * T);
+        for (int p = 0; p < P; ++p) {
+            int32_t* t = &tri[(size_t)3 * p * T];
+            for (int j = 0; j < ny - 1; ++j)
+                for (int i = 0; i < nx - 1; ++i) {
+                    const int a = p * V + j * nx + i, b = a + 1, c = a + nx, d = c + 1;
+                    t[0] = a; t[1] = b; t[2] = d; t[3] = a; t[4] = d; t[5] = c;
+                    t += 6;
+                }
+        }
+        int64_t nnzb = 0;
+        if ((rc = fb_sys_create(ctx, (int64_t)P * V, &s))) return rc;
+        if ((rc = fb_sys_add_mesh(ctx, s, 0, tri.data(), P * V, P * T, &mid)) || (rc = fb_sys_set_links(ctx, s, 0, nullptr)) ||
+            (rc = fb_sys_finalize(ctx, s, &nnzb))) {
+            fb_sys_destroy(ctx, s);
+            return rc;
+        }
+    }
     std::vector<float> mult((size_t)P * T, 1.0f);
     std::vector<double> v((size_t)2 * P * V), v0((size_t)2 * P * V);
-    double mx = 0.0, my = 0.0;
-    for (int j = 0; j < ny; ++j)
-        for (int i = 0; i < nx; ++i) { mx += m->gxs[i]; my += m->gys[j]; }
-    mx /= V; my /= V;
-    for (int p = 0; p < P; ++p)
+    for (int p = 0; p < P; ++p) {
+        const double* gx = &m->gxs[(size_t)p * nx];
+        const double* gy = &m->gys[(size_t)p * ny];
+        double mx = 0.0, my = 0.0;
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) { mx += gx[i]; my += gy[j]; }
+        mx /= V; my /= V;
         for (int j = 0; j < ny; ++j)
             for (int i = 0; i < nx; ++i) {
                 const size_t k = 2 * ((size_t)p * V + (size_t)j * nx + i);
-                v[k] = m->gxs[i]; v[k + 1] = m->gys[j];
-                v0[k] = m->gxs[i] - mx; v0[k + 1] = m->gys[j] - my;
+                v[k] = gx[i]; v[k + 1] = gy[j];
+                v0[k] = gx[i] - mx; v0[k + 1] = gy[j] - my;
             }
-    std::vector<double> es((size_t)P);
-    if ((rc = fb_sys_add_mesh(ctx, s, 0, tri.data(), P * V, P * T, &mid)) || (rc = fb_sys_set_links(ctx, s, 0, nullptr)) ||
-        (rc = fb_sys_finalize(ctx, s, &nnzb)) || (rc = fb_sys_assemble_mesh(ctx, s, mid, v.data(), nullptr, mult.data(), 0.0, 1.0)) ||
-        (rc = fb_sys_group_energy(ctx, s, P, v0.data(), es.data()))) {
+    }
+    m->es0.resize((size_t)P);
+    if ((rc = fb_sys_assemble_mesh(ctx, s, 0, v.data(), nullptr, mult.data(), 0.0, 1.0)) ||
+        (rc = fb_sys_group_energy(ctx, s, P, v0.data(), m->es0.data()))) {
         fb_sys_destroy(ctx, s);
         return rc;
     }
     m->sys = s;
-    m->es0 = es[0];                                        // the same for every copy (and rotation free)
-    // signed_area of the first triangle (a, b, d): cross((dx, 0), (0, dy))
-    m->area = std::fabs((m->gxs[1] - m->gxs[0]) * (m->gys[1] - m->gys[0]) - 0.0 * 0.0);
+    // sample error of a match, 0.4387 sqrt(A) strain (optimizer.py:26-30) with A = Mesh.triangle_areas = the cross product
+    // of two edges (common.py:672-676): (dx, 0) x (0, dy) for the triangles of a grid cell
+    m->se.resize((size_t)P);
+    for (int p = 0; p < P; ++p) {
+        const double area = std::fabs((m->gxs[(size_t)p * nx + 1] - m->gxs[(size_t)p * nx]) * (m->gys[(size_t)p * ny + 1] - m->gys[(size_t)p * ny]) - 0.0 * 0.0);
+        m->se[p] = 0.4387 * std::pow(area, 0.5) * kDefaultAvgDeform;
+    }
+    m->se0 = m->se[0];
     return FB_OK;
 }
 
@@ -155,6 +220,27 @@ int fetch(fb_ctx* ctx, fb_strip_matcher* m, size_t nb, const double** dx, const 
     *dy = (const double*)(m->raw.data() + 8 * nb);
     *cf = (const float*)(m->raw.data() + 16 * nb);
     return FB_OK;
+}
+
+// triangle (three vertex ids inside the union mesh, in the order of the triangle list) and barycentric coordinates of
+// points given in the INITIAL gear of their pair's grid mesh: Mesh.cart2bary (mesh.py:2191-2217) on a uniform grid, the
+// cell from one division per axis (the statement feabas_amd/stitch_pipeline.py::_locate_grid makes for ragged batches)
+void locate_grid(const fb_strip_matcher* m, size_t K, const int32_t* pid, const double* pts, std::vector<int32_t>& nodes3, std::vector<double>& B) {
+    const int nx = m->gnx, ny = m->gny, V = nx * ny;
+    nodes3.resize(3 * K); B.resize(3 * K);
+    for (size_t k = 0; k < K; ++k) {
+        const int p = pid[k];
+        const double* gx = &m->gxs[(size_t)p * nx];
+        const double* gy = &m->gys[(size_t)p * ny];
+        const double cw = (gx[nx - 1] - gx[0]) / (double)(nx - 1), ch = (gy[ny - 1] - gy[0]) / (double)(ny - 1);
+        const double fx = (pts[2 * k] - gx[0]) / cw, fy = (pts[2 * k + 1] - gy[0]) / ch;
+        const double i = std::min(std::max(std::floor(fx), 0.0), (double)(nx - 2)), j = std::min(std::max(std::floor(fy), 0.0), (double)(ny - 2));
+        const double u = fx - i, w = fy - j;
+        const bool up = w > u;
+        const int na = (int)j * nx + (int)i + p * V;
+        nodes3[3 * k] = na; nodes3[3 * k + 1] = up ? na + nx + 1 : na + 1; nodes3[3 * k + 2] = up ? na + nx : na + nx + 1;
+        B[3 * k] = up ? 1.0 - w : 1.0 - u; B[3 * k + 1] = up ? u : u - w; B[3 * k + 2] = up ? w - u : w;
+    }
 }
 
 struct Rows {                                   // a match table: rows of one pair are contiguous
@@ -293,49 +379,107 @@ void rigid_fits(int P, const std::vector<int32_t>& pid, const std::vector<double
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* o, fb_strip_matcher** out) {
-    FB_LOCK(ctx);
+// matcher.py:243-251 with both shapes equal, descending
+void auto_spacings(int H, int W, std::vector<double>& out) {
+    out.clear();
+    const double smax = std::max(H, W) * 0.25, smin = std::max(std::min(75.0, std::min(H, W) / 3.0), 25.0);
+    if (smin > smax) out.assign(1, smin);
+    else {
+        const int count = (int)std::max(1.0, std::nearbyint(std::log(smax / smin) / std::log(4.0)));
+        for (int i = 0; i < count; ++i) out.push_back(std::exp(linspace_at(std::log(smin), std::log(smax), count, i)));
+    }
+    std::sort(out.begin(), out.end());
+    std::reverse(out.begin(), out.end());
+}
+
+int matcher_create(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, const fb_strip_opts* o, fb_strip_matcher** out) {
     FB_CHECK_ARG(ctx, P > 0 && H > 1 && W > 1 && o && out && (o->coarse_downsample2 == 0 || o->coarse_downsample2 == 1));
     FB_CHECK_ARG(ctx, o->sigma > 0.0 && o->min_num_blocks >= 1 && (o->residue_mode == 0 || o->residue_mode == 1) && o->nspacings >= 0 &&
                           (o->nspacings == 0 || o->spacings) && o->nspacings <= 64);
     fb_strip_matcher* m = new fb_strip_matcher();
     m->P = P; m->H = H; m->W = W;
+    m->ragged = shapes != nullptr;
     { const char* e = std::getenv("FEABAS_HIP_MATCH_TRACE"); m->trace = e && e[0] == '1'; }
     m->sigma = o->sigma; m->cds2 = o->coarse_downsample2; m->conf_thresh = o->conf_thresh; m->mnb = o->min_num_blocks;
     m->conf_mode = o->conf_mode; m->residue_len = o->residue_len; m->residue_mode = o->residue_mode;
     m->stiffness_lambda = o->stiffness_lambda; m->relax_tol = o->relax_tol; m->compute_strain = o->compute_strain;
+    m->Hs.resize((size_t)P); m->Ws.resize((size_t)P); m->hcs.resize((size_t)P); m->wcs.resize((size_t)P);
+    for (int p = 0; p < P; ++p) {
+        m->Hs[p] = shapes ? shapes[2 * p] : H;
+        m->Ws[p] = shapes ? shapes[2 * p + 1] : W;
+        if (m->Hs[p] < 2 || m->Ws[p] < 2 || m->Hs[p] > H || m->Ws[p] > W) {
+            delete m;
+            return fb_fail(ctx, FB_ERR_ARG, "fb_strip_matcher_create: pair %d: a %d x %d strip does not fit its %d x %d slot", p, shapes[2 * p], shapes[2 * p + 1], H, W);
+        }
+        // cv2.resize(fx=0.5): cvRound(n / 2), half to even
+        m->hcs[p] = m->cds2 ? round_i(m->Hs[p] * 0.5) : m->Hs[p];
+        m->wcs[p] = m->cds2 ? round_i(m->Ws[p] * 0.5) : m->Ws[p];
+    }
+    std::vector<double> one;
     if (o->nspacings) {
-        m->sp.assign(o->spacings, o->spacings + o->nspacings);
-        for (double v : m->sp)
+        one.assign(o->spacings, o->spacings + o->nspacings);
+        for (double v : one)
             if (!(v >= 1.0)) { delete m; return fb_fail(ctx, FB_ERR_ARG, "fb_strip_matcher_create: spacings are pixels (>= 1); relative ones (matcher.py:343-350) are resolved by the caller"); }
+        std::sort(one.begin(), one.end());
+        std::reverse(one.begin(), one.end());
+        m->nsp = (int)one.size();
+        for (int p = 0; p < P; ++p) m->sp.insert(m->sp.end(), one.begin(), one.end());
     } else {
-        // matcher.py:243-251 with both shapes equal
-        const double smax = std::max(H, W) * 0.25, smin = std::max(std::min(75.0, std::min(H, W) / 3.0), 25.0);
-        if (smin > smax) m->sp.assign(1, smin);
-        else {
-            const int count = (int)std::max(1.0, std::nearbyint(std::log(smax / smin) / std::log(4.0)));
-            for (int i = 0; i < count; ++i) m->sp.push_back(std::exp(linspace_at(std::log(smin), std::log(smax), count, i)));
+        for (int p = 0; p < P; ++p) {
+            auto_spacings(m->Hs[p], m->Ws[p], one);
+            if (p == 0) m->nsp = (int)one.size();
+            if ((int)one.size() != m->nsp) {
+                delete m;
+                return fb_fail(ctx, FB_ERR_ARG, "fb_strip_matcher_create: pair %d has %d automatic spacings, pair 0 %d (the pairs of a batch share the number of rounds)", p, (int)one.size(), m->nsp);
+            }
+            m->sp.insert(m->sp.end(), one.begin(), one.end());
         }
     }
-    std::sort(m->sp.begin(), m->sp.end());
-    std::reverse(m->sp.begin(), m->sp.end());
-    // cv2.resize(fx=0.5): cvRound(n / 2), half to even
     m->hc = m->cds2 ? round_i(H * 0.5) : H;
     m->wc = m->cds2 ? round_i(W * 0.5) : W;
     m->max_blocks = (size_t)P * 1024;
     const size_t n = (size_t)P, cpix = (size_t)m->hc * m->wc, fpix = (size_t)H * W;
     int rc = 0;
     void* ptr = nullptr;
-    if (!(rc = fb_malloc(ctx, 2 * n * cpix * 4, &ptr))) m->d_dogc = (float*)ptr;
-    if (!rc && m->cds2 && !(rc = fb_malloc(ctx, 2 * n * fpix * 4, &ptr))) m->d_dogf = (float*)ptr;
-    if (!rc && m->cds2 && !(rc = fb_malloc(ctx, 2 * n * cpix, &ptr))) m->d_small = (uint8_t*)ptr;
-    if (!rc && !(rc = fb_malloc(ctx, m->max_blocks * 9 * 4, &ptr))) m->d_blk = (int*)ptr;
-    if (!rc && !(rc = fb_malloc(ctx, m->max_blocks * 20, &ptr))) m->d_out = (uint8_t*)ptr;
+    if (!(rc = pool_take(ctx, 2 * n * cpix * 4, &ptr, &m->b_dogc))) m->d_dogc = (float*)ptr;
+    if (!rc && m->cds2 && !(rc = pool_take(ctx, 2 * n * fpix * 4, &ptr, &m->b_dogf))) m->d_dogf = (float*)ptr;
+    if (!rc && m->cds2 && !(rc = pool_take(ctx, 2 * n * cpix, &ptr, &m->b_small))) m->d_small = (uint8_t*)ptr;
+    if (!rc && !(rc = pool_take(ctx, m->max_blocks * 9 * 4, &ptr, &m->b_blk))) m->d_blk = (int*)ptr;
+    if (!rc && !(rc = pool_take(ctx, m->max_blocks * 20, &ptr, &m->b_out))) m->d_out = (uint8_t*)ptr;
+    if (!rc && m->ragged) {
+        // per-image extents of the two stacks, full resolution and coarse (fb_dog_sizes_dev, fb_area_downsample2_sizes_dev)
+        std::vector<int32_t> sz((size_t)8 * P);
+        for (int side = 0; side < 2; ++side)
+            for (int p = 0; p < P; ++p) {
+                sz[2 * ((size_t)side * P + p)] = m->Hs[p]; sz[2 * ((size_t)side * P + p) + 1] = m->Ws[p];
+                sz[4 * (size_t)P + 2 * ((size_t)side * P + p)] = m->hcs[p]; sz[4 * (size_t)P + 2 * ((size_t)side * P + p) + 1] = m->wcs[p];
+            }
+        if (!(rc = pool_take(ctx, sz.size() * 4, &ptr, &m->b_sizes))) {
+            m->d_sizes = (int*)ptr;
+            m->d_sizes_c = m->d_sizes + 4 * (size_t)P;
+            rc = fb_memcpy_h2d(ctx, m->d_sizes, sz.data(), sz.size() * 4);
+        }
+    }
     if (rc) { fb_strip_matcher_destroy(ctx, m); return rc; }
     *out = m;
     return FB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* o, fb_strip_matcher** out) {
+    FB_LOCK(ctx);
+    return matcher_create(ctx, P, H, W, nullptr, o, out);
+}
+
+int fb_strip_matcher_create_ragged(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, const fb_strip_opts* o, fb_strip_matcher** out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, shapes != nullptr);
+    return matcher_create(ctx, P, H, W, shapes, o, out);
 }
 
 void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m) {
@@ -347,17 +491,23 @@ void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m) {
                      m->P, m->H, m->W, m->calls, m->t_stage[0] / c, m->t_stage[1] / c, m->t_stage[2] / c, m->t_stage[3] / c, m->t_stage[4] / c, m->t_stage[5] / c,
                      m->t_stage[6] / c, m->t_stage[7] / c);
     }
-    if (m->sys) fb_sys_destroy(ctx, m->sys);
-    fb_free(ctx, m->d_dogc); fb_free(ctx, m->d_dogf); fb_free(ctx, m->d_small); fb_free(ctx, m->d_blk); fb_free(ctx, m->d_out);
+    hipStreamSynchronize(ctx->stream);                      // nothing of this matcher is in flight when its buffers change hands
+    if (m->sys) {
+        auto& keep = ctx->match_systems[std::make_tuple(m->P, m->gnx, m->gny)];
+        if (keep.size() < 2) keep.push_back(m->sys);
+        else fb_sys_destroy(ctx, m->sys);
+    }
+    pool_give(ctx, m->d_dogc, m->b_dogc); pool_give(ctx, m->d_dogf, m->b_dogf); pool_give(ctx, m->d_small, m->b_small);
+    pool_give(ctx, m->d_blk, m->b_blk); pool_give(ctx, m->d_out, m->b_out); pool_give(ctx, m->d_sizes, m->b_sizes);
     delete m;
 }
 
 int fb_strip_matcher_info(fb_ctx* ctx, fb_strip_matcher* m, int* nspacings, double* spacings, int* grid_nx, int* grid_ny,
                           int* relax_iters, double* relax_relres, int* strain_iters, double* strain_relres) {
     FB_CHECK_ARG(ctx, m != nullptr);
-    if (spacings) FB_CHECK_ARG(ctx, nspacings && *nspacings >= (int)m->sp.size());
-    if (spacings) std::copy(m->sp.begin(), m->sp.end(), spacings);
-    if (nspacings) *nspacings = (int)m->sp.size();
+    if (spacings) FB_CHECK_ARG(ctx, nspacings && *nspacings >= m->nsp);
+    if (spacings) std::copy(m->sp.begin(), m->sp.begin() + m->nsp, spacings);      // of pair 0
+    if (nspacings) *nspacings = m->nsp;
     if (grid_nx) *grid_nx = m->gnx;
     if (grid_ny) *grid_ny = m->gny;
     if (relax_iters) *relax_iters = m->relax_iters;
@@ -374,43 +524,86 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
     const int n = m->P, H = m->H, W = m->W, hc = m->hc, wc = m->wc;
     const size_t cpix = (size_t)hc * wc, fpix = (size_t)H * W;
     const float thr = (float)m->conf_thresh;               // numpy compares float32 confidences with the threshold in float32
+    const int nsp = m->nsp;
     int rc;
     StageClock clk(m);
     if (m->trace && m->calls == 3) { for (double& t : m->t_stage) t = 0.0; }      // the first calls load code objects and grow arenas
     m->calls++;
-    // ---- global translation on the coarse DoG images (matcher.py:255-278)
-    if (m->cds2) {
-        const int taps = (int)(4.0 * m->sigma * 0.5 + 0.5);
-        if (taps == 5 || taps == 6 || taps == 8 || taps == 10) {
-            if ((rc = fb_dog_down2_dev(ctx, strips0, n, H, W, m->sigma * 0.5, 1, m->d_dogc))) return rc;
-            if ((rc = fb_dog_down2_dev(ctx, strips1, n, H, W, m->sigma * 0.5, 1, m->d_dogc + n * cpix))) return rc;
-        } else {
-            if ((rc = fb_area_downsample2_dev(ctx, strips0, n, H, W, m->d_small))) return rc;
-            if ((rc = fb_area_downsample2_dev(ctx, strips1, n, H, W, m->d_small + n * cpix))) return rc;
-            if ((rc = fb_dog_dev(ctx, m->d_small, 0, 2 * n, hc, wc, m->sigma * 0.5, nullptr, 1, m->d_dogc))) return rc;
-        }
-    } else {
-        if ((rc = fb_dog_dev(ctx, strips0, 0, n, hc, wc, m->sigma, nullptr, 1, m->d_dogc))) return rc;
-        if ((rc = fb_dog_dev(ctx, strips1, 0, n, hc, wc, m->sigma, nullptr, 1, m->d_dogc + n * cpix))) return rc;
-    }
-    if ((rc = fb_ncc_batch_dev(ctx, m->d_dogc, m->d_dogc + n * cpix, n, 1, hc, wc, hc, wc, 1, 0, m->conf_mode, (double*)m->d_out,
-                               (double*)(m->d_out + 8 * (size_t)n), (float*)(m->d_out + 16 * (size_t)n))))
-        return rc;
-    // the fine DoG is independent of the answer: enqueue it before waiting for the global peaks
     const float* dogf = m->d_dogc;                         // matcher.py:315-317: same image when fine == coarse
-    if (m->cds2) {
-        if ((rc = fb_dog_dev(ctx, strips0, 0, n, H, W, m->sigma, nullptr, 1, m->d_dogf))) return rc;
-        if ((rc = fb_dog_dev(ctx, strips1, 0, n, H, W, m->sigma, nullptr, 1, m->d_dogf + n * fpix))) return rc;
-        dogf = m->d_dogf;
-    }
-    const float* img1 = dogf + n * fpix;
-    clk.lap(0);
-    {
+    std::vector<int32_t> blk;
+    // ---- global translation on the coarse DoG images (matcher.py:255-278); the fine DoG is independent of the answer and
+    //      is enqueued before the host waits for the global peaks
+    if (!m->ragged) {
+        if (m->cds2) {
+            const int taps = (int)(4.0 * m->sigma * 0.5 + 0.5);
+            if (taps == 5 || taps == 6 || taps == 8 || taps == 10) {
+                if ((rc = fb_dog_down2_dev(ctx, strips0, n, H, W, m->sigma * 0.5, 1, m->d_dogc))) return rc;
+                if ((rc = fb_dog_down2_dev(ctx, strips1, n, H, W, m->sigma * 0.5, 1, m->d_dogc + n * cpix))) return rc;
+            } else {
+                if ((rc = fb_area_downsample2_dev(ctx, strips0, n, H, W, m->d_small))) return rc;
+                if ((rc = fb_area_downsample2_dev(ctx, strips1, n, H, W, m->d_small + n * cpix))) return rc;
+                if ((rc = fb_dog_dev(ctx, m->d_small, 0, 2 * n, hc, wc, m->sigma * 0.5, nullptr, 1, m->d_dogc))) return rc;
+            }
+        } else {
+            if ((rc = fb_dog_dev(ctx, strips0, 0, n, hc, wc, m->sigma, nullptr, 1, m->d_dogc))) return rc;
+            if ((rc = fb_dog_dev(ctx, strips1, 0, n, hc, wc, m->sigma, nullptr, 1, m->d_dogc + n * cpix))) return rc;
+        }
+        if ((rc = fb_ncc_batch_dev(ctx, m->d_dogc, m->d_dogc + n * cpix, n, 1, hc, wc, hc, wc, 1, 0, m->conf_mode, (double*)m->d_out,
+                                   (double*)(m->d_out + 8 * (size_t)n), (float*)(m->d_out + 16 * (size_t)n))))
+            return rc;
+        if (m->cds2) {
+            if ((rc = fb_dog_dev(ctx, strips0, 0, n, H, W, m->sigma, nullptr, 1, m->d_dogf))) return rc;
+            if ((rc = fb_dog_dev(ctx, strips1, 0, n, H, W, m->sigma, nullptr, 1, m->d_dogf + n * fpix))) return rc;
+            dogf = m->d_dogf;
+        }
+        clk.lap(0);
         const double *gx, *gy; const float* gc;
         if ((rc = fetch(ctx, m, (size_t)n, &gx, &gy, &gc))) return rc;
+        for (int p = 0; p < n; ++p) { tx[p] = gx[p]; ty[p] = gy[p]; conf0[p] = gc[p]; }
         clk.lap(1);
+    } else {
+        // every stage on each pair's own extent ('nearest' extension at the image's own border, zeros in the rest of its slot)
+        if (m->cds2) {
+            if ((rc = fb_area_downsample2_sizes_dev(ctx, strips0, n, H, W, m->d_sizes, m->d_small))) return rc;
+            if ((rc = fb_area_downsample2_sizes_dev(ctx, strips1, n, H, W, m->d_sizes, m->d_small + n * cpix))) return rc;
+            if ((rc = fb_dog_sizes_dev(ctx, m->d_small, 0, 2 * n, hc, wc, m->d_sizes_c, m->sigma * 0.5, 1, m->d_dogc))) return rc;
+            if ((rc = fb_dog_sizes_dev(ctx, strips0, 0, n, H, W, m->d_sizes, m->sigma, 1, m->d_dogf))) return rc;
+            if ((rc = fb_dog_sizes_dev(ctx, strips1, 0, n, H, W, m->d_sizes, m->sigma, 1, m->d_dogf + n * fpix))) return rc;
+            dogf = m->d_dogf;
+        } else {
+            if ((rc = fb_dog_sizes_dev(ctx, strips0, 0, n, hc, wc, m->d_sizes_c, m->sigma, 1, m->d_dogc))) return rc;
+            if ((rc = fb_dog_sizes_dev(ctx, strips1, 0, n, hc, wc, m->d_sizes_c, m->sigma, 1, m->d_dogc + n * cpix))) return rc;
+        }
+        clk.lap(0);
+        // whole-strip NCC (matcher.py:153) through block descriptors, one launch per padded FFT shape
+        std::map<long long, std::vector<int>> shapes;
+        for (int p = 0; p < n; ++p)
+            shapes[(long long)fb_next_fast_len(2 * m->hcs[p] - 1) * 65536 + fb_next_fast_len(2 * m->wcs[p] - 1)].push_back(p);
+        for (auto& kv : shapes) {
+            const std::vector<int>& sel = kv.second;
+            const size_t nb = sel.size();
+            blk.assign(nb * 9, 0);
+            int hmax = 0, wmax = 0;
+            for (size_t q = 0; q < nb; ++q) {
+                const int p = sel[q];
+                int32_t* d = &blk[9 * q];
+                d[0] = p; d[3] = m->hcs[p]; d[4] = m->wcs[p]; d[7] = m->hcs[p]; d[8] = m->wcs[p];
+                hmax = std::max(hmax, m->hcs[p]); wmax = std::max(wmax, m->wcs[p]);
+            }
+            if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), nb * 9 * 4))) return rc;
+            if ((rc = fb_ncc_blocks_dev(ctx, m->d_dogc, m->d_dogc + n * cpix, hc, wc, hc, wc, (int)nb, m->d_blk, hmax, wmax, (int)(kv.first / 65536), (int)(kv.first % 65536),
+                                        0, m->conf_mode, (double*)m->d_out, (double*)(m->d_out + 8 * nb), (float*)(m->d_out + 16 * nb))))
+                return rc;
+            const double *gx, *gy; const float* gc;
+            if ((rc = fetch(ctx, m, nb, &gx, &gy, &gc))) return rc;
+            for (size_t q = 0; q < nb; ++q) { tx[sel[q]] = gx[q]; ty[sel[q]] = gy[q]; conf0[sel[q]] = gc[q]; }
+        }
+        clk.lap(1);
+    }
+    const float* img1 = dogf + n * fpix;
+    {
         const double scale = m->cds2 ? 2.0 : 1.0;          // matcher.py:338-339
-        for (int p = 0; p < n; ++p) { tx[p] = gx[p] * scale; ty[p] = gy[p] * scale; conf0[p] = gc[p]; }
+        for (int p = 0; p < n; ++p) { tx[p] = tx[p] * scale; ty[p] = ty[p] * scale; }
     }
     std::vector<char> active((size_t)n), live((size_t)n), pad((size_t)n, 1), has_last((size_t)n, 0);
     for (int p = 0; p < n; ++p) {
@@ -419,25 +612,24 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         live[p] = active[p] && !flags[p];
     }
     std::vector<double> t1((size_t)2 * n, 0.0);            // translation of mesh1 acquired by rigid relaxations
-    const int nsp = (int)m->sp.size();
     Rows table, prev;
     bool have_table = false, last_links = false;
     std::vector<int> nxv((size_t)n), nyv((size_t)n), dxv((size_t)n), dyv((size_t)n), fhv((size_t)n), fwv((size_t)n);
     std::vector<double> xminv((size_t)n), yminv((size_t)n), xmaxv((size_t)n), ymaxv((size_t)n);
-    std::vector<int32_t> blk;
     std::vector<int> bbx0, bby0, xt, yt, order, ordc;
     std::vector<long long> zk, zkc;
     std::vector<char> in_cur((size_t)n);
     for (int rnd = 0; rnd < nsp; ++rnd) {
-        const double spc = m->sp[rnd];
         const bool is_last = rnd == nsp - 1;
         const int mnb = is_last ? m->mnb : 1;
         // ---- group the live pairs by block grid and FFT shape (matcher.py:59-62 on the block size)
         std::map<long long, std::vector<int>> groups;
         for (int p = 0; p < n; ++p) {
             if (!live[p]) continue;
-            const double xmin = std::max(-0.5 + tx[p], -0.5 + t1[2 * p]), xmax = std::min(W - 0.5 + tx[p], W - 0.5 + t1[2 * p]);
-            const double ymin = std::max(-0.5 + ty[p], -0.5 + t1[2 * p + 1]), ymax = std::min(H - 0.5 + ty[p], H - 0.5 + t1[2 * p + 1]);
+            const double spc = m->sp[(size_t)p * nsp + rnd];
+            const double Wp = (double)m->Ws[p], Hp = (double)m->Hs[p];
+            const double xmin = std::max(-0.5 + tx[p], -0.5 + t1[2 * p]), xmax = std::min(Wp - 0.5 + tx[p], Wp - 0.5 + t1[2 * p]);
+            const double ymin = std::max(-0.5 + ty[p], -0.5 + t1[2 * p + 1]), ymax = std::min(Hp - 0.5 + ty[p], Hp - 0.5 + t1[2 * p + 1]);
             if (!(xmax > xmin && ymax > ymin)) continue;
             // common.divide_bbox (common.py:380-409)
             const double wd = xmax - xmin, ht = ymax - ymin;
@@ -470,6 +662,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
             for (int q = 0; q < Q; ++q) {
                 const int p = sel[q];
                 const int dx = dxv[p], dy = dyv[p];
+                const double spc = m->sp[(size_t)p * nsp + rnd];
                 hmax = std::max(hmax, dy); wmax = std::max(wmax, dx);
                 xt.resize(nxi); yt.resize(nyi);
                 for (int i = 0; i < nxi; ++i) xt[i] = round_i(linspace_at(xminv[p], xmaxv[p] - (double)dx, nxi, i));
@@ -533,7 +726,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                 bool nonrigid = false;
                 if (!is_last) {
                     int next_pos = -1;
-                    for (int k = 0; k < nsp; ++k) next_pos += m->sp[k] > 4.0 * max_dis;
+                    for (int k = 0; k < nsp; ++k) next_pos += m->sp[(size_t)p * nsp + k] > 4.0 * max_dis;
                     pad[p] = !(next_pos > rnd);             // max_spacing_skip = 0
                     if (has_link && max_dis > 0.1) {
                         // every kept block reports the same displacement: the relaxation of mesh1 is that translation
@@ -574,29 +767,52 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                 // last round (matcher.py:725-737): relaxation + residue weights of every pair at once; all rows enter
                 // the block-diagonal system so that the strain stage can reuse the links
                 if ((rc = ensure_system(ctx, m))) return rc;
-                const int V = m->gnx * m->gny;
+                const int nx = m->gnx, ny = m->gny, V = nx * ny;
                 const int64_t K = (int64_t)table.size();
                 std::vector<float> rw((size_t)K);
                 std::vector<double> x((size_t)2 * n * V);
-                const double sample_err = 0.4387 * std::pow(m->area, 0.5) * kDefaultAvgDeform;       // optimizer.py:26-30
-                rc = fb_pairs_relax(ctx, m->sys, n, m->gnx, m->gny, m->gxs.data(), m->gys.data(), K, table.pid.data(), table.xy0.data(), table.xy1i.data(),
-                                    t1.data(), table.wt.data(), m->residue_len, m->residue_mode, sample_err, m->stiffness_lambda, m->relax_tol,
-                                    rw.data(), x.data(), &m->relax_iters, &m->relax_relres);
+                if (!m->ragged) {
+                    rc = fb_pairs_relax(ctx, m->sys, n, nx, ny, m->gxs.data(), m->gys.data(), K, table.pid.data(), table.xy0.data(), table.xy1i.data(),
+                                        t1.data(), table.wt.data(), m->residue_len, m->residue_mode, m->se0, m->stiffness_lambda, m->relax_tol,
+                                        rw.data(), x.data(), &m->relax_iters, &m->relax_relres);
+                    last_links = true;
+                } else {
+                    // one mesh geometry per pair: the matches by triangle and barycentric coordinates, the unknown the total
+                    // displacement of mesh1 from its FIXED gear (fb_pairs_relax_bary), sample errors per pair
+                    std::vector<int32_t> nodes3;
+                    std::vector<double> B1, dxy0((size_t)2 * K), se_rows((size_t)K);
+                    locate_grid(m, (size_t)K, table.pid.data(), table.xy1i.data(), nodes3, B1);
+                    for (int64_t k = 0; k < K; ++k) {
+                        const int p = table.pid[k];
+                        double fx[3], fy[3];
+                        for (int a = 0; a < 3; ++a) {
+                            const int loc = nodes3[3 * k + a] - p * V;
+                            fx[a] = m->gxs[(size_t)p * nx + loc % nx]; fy[a] = m->gys[(size_t)p * ny + loc / nx];
+                        }
+                        const double* b = &B1[3 * (size_t)k];
+                        dxy0[2 * k] = ((fx[0] * b[0] + fx[1] * b[1]) + fx[2] * b[2]) - table.xy0[2 * k];          // mesh1 at its FIXED gear (= INITIAL, no offset)
+                        dxy0[2 * k + 1] = ((fy[0] * b[0] + fy[1] * b[1]) + fy[2] * b[2]) - table.xy0[2 * k + 1];
+                        se_rows[k] = m->se[p];
+                    }
+                    rc = fb_pairs_relax_bary(ctx, m->sys, n, K, nodes3.data(), B1.data(), dxy0.data(), table.wt.data(), m->residue_len, m->residue_mode, m->se0,
+                                             se_rows.data(), m->stiffness_lambda, m->relax_tol, rw.data(), x.data(), &m->relax_iters, &m->relax_relres);
+                }
                 if (rc) return rc;
                 m->relax_matches = K;
-                last_links = true;
                 // screen of relax_first (optimizer.py:763-779): the largest displacement difference along a grid edge
                 // relative to that edge; beyond 0.1 the pair takes the reference's statements on the general route
                 for (int p = 0; p < n; ++p) {
                     const double* g = &x[(size_t)2 * p * V];
+                    const double* gx = &m->gxs[m->ragged ? (size_t)p * nx : 0];
+                    const double* gy = &m->gys[m->ragged ? (size_t)p * ny : 0];
                     double d = 0.0;
-                    for (int j = 0; j < m->gny; ++j)
-                        for (int i = 0; i < m->gnx; ++i) {
-                            const double* a = g + 2 * ((size_t)j * m->gnx + i);
-                            if (i + 1 < m->gnx) d = std::max(d, std::sqrt((a[2] - a[0]) * (a[2] - a[0]) + (a[3] - a[1]) * (a[3] - a[1])) / (m->gxs[i + 1] - m->gxs[i]));
-                            if (j + 1 < m->gny) {
-                                const double* b = a + 2 * (size_t)m->gnx;
-                                d = std::max(d, std::sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1])) / (m->gys[j + 1] - m->gys[j]));
+                    for (int j = 0; j < ny; ++j)
+                        for (int i = 0; i < nx; ++i) {
+                            const double* a = g + 2 * ((size_t)j * nx + i);
+                            if (i + 1 < nx) d = std::max(d, std::sqrt((a[2] - a[0]) * (a[2] - a[0]) + (a[3] - a[1]) * (a[3] - a[1])) / (gx[i + 1] - gx[i]));
+                            if (j + 1 < ny) {
+                                const double* b = a + 2 * (size_t)nx;
+                                d = std::max(d, std::sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1])) / (gy[j + 1] - gy[j]));
                             }
                         }
                     if (d > 0.1 || !(d == d)) flags[p] |= FB_STRIP_RELAXFIRST;
@@ -663,9 +879,17 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         for (size_t k = 0; k < K; ++k) { p0[2 * k] = m->r_xy0[2 * k] + tx[m->r_pid[k]]; p0[2 * k + 1] = m->r_xy0[2 * k + 1] + ty[m->r_pid[k]]; }   // mesh0 points, FIXED gear
         rigid_fits(n, m->r_pid, p0, m->r_xy1, m->r_w, R, bad);
         clk.lap(6);
-        rc = fb_pairs_strain(ctx, m->sys, n, m->gnx, m->gny, m->gxs.data(), m->gys.data(), (int64_t)K, m->r_pid.data(), p0.data(), m->r_xy1.data(),
-                             m->r_w.data(), R.data(), m->stiffness_lambda, m->es0, last_links ? 1 : 0, kDefaultAvgDeform, strain, &m->strain_iters,
-                             &m->strain_relres);
+        if (!m->ragged) {
+            rc = fb_pairs_strain(ctx, m->sys, n, m->gnx, m->gny, m->gxs.data(), m->gys.data(), (int64_t)K, m->r_pid.data(), p0.data(), m->r_xy1.data(),
+                                 m->r_w.data(), R.data(), m->stiffness_lambda, m->es0[0], last_links ? 1 : 0, kDefaultAvgDeform, strain, &m->strain_iters,
+                                 &m->strain_relres);
+        } else {
+            std::vector<int32_t> nodes3;
+            std::vector<double> B1;
+            locate_grid(m, K, m->r_pid.data(), m->r_xy1.data(), nodes3, B1);
+            rc = fb_pairs_strain_bary(ctx, m->sys, n, (int64_t)K, m->r_pid.data(), nodes3.data(), B1.data(), p0.data(), m->r_xy1.data(), m->r_w.data(), R.data(),
+                                      m->stiffness_lambda, m->es0.data(), kDefaultAvgDeform, strain, &m->strain_iters, &m->strain_relres);
+        }
         if (rc) return rc;
         m->strain_matches = (int64_t)K;
         clk.lap(7);

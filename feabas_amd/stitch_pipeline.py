@@ -887,7 +887,7 @@ class StripBatchMatcher:
         batches of equal strips go through fb_match_strips (one C entry for the whole sequence); the pairs it hands back
         (flags != 0: second shot of the global matcher, deformed mesh1, relax_first, degenerate rigid fit) and every
         other kind of batch take the numpy statement of the same sequence."""
-        if self._route == 'native' and not self._ragged and masks0 is None and masks1 is None and not compute_photometric:
+        if self._route == 'native' and masks0 is None and masks1 is None and not compute_photometric:
             if self._prefer_host:
                 res = self._match_host(strips0, strips1)
                 self._prefer_host = int(np.count_nonzero(res['deformed'])) > self.P // 2
@@ -898,11 +898,17 @@ class StripBatchMatcher:
     def _native_matcher(self):
         if self._native is None:
             lib, ctx = _lib.load(), _lib.ctx()
+            auto = self._ragged and self._opts.get('spacings') is None          # automatic spacings per strip shape
             sp = np.ascontiguousarray(self.spacings, dtype=np.float64)
             o = _lib.StripOpts(self.sigma, 1 if self.cds == 0.5 else 0, self.conf_thresh, self.mnb, self.conf_mode, self.residue_len,
-                               self.residue_mode, self.stiffness_lambda, self.relax_tol, int(self.compute_strain), int(sp.size), sp.ctypes.data)
+                               self.residue_mode, self.stiffness_lambda, self.relax_tol, int(self.compute_strain), 0 if auto else int(sp.size),
+                               None if auto else sp.ctypes.data)
             h = C.c_void_p()
-            _lib.check(lib.fb_strip_matcher_create(ctx, self.P, self.H, self.W, C.byref(o), C.byref(h)))
+            if self._ragged:
+                shapes = np.ascontiguousarray(np.stack((self._Hs, self._Ws), axis=-1), dtype=np.int32)
+                _lib.check(lib.fb_strip_matcher_create_ragged(ctx, self.P, self.H, self.W, _lib.ptr(shapes), C.byref(o), C.byref(h)))
+            else:
+                _lib.check(lib.fb_strip_matcher_create(ctx, self.P, self.H, self.W, C.byref(o), C.byref(h)))
             self._native = h
         return self._native
 
@@ -943,11 +949,11 @@ class StripBatchMatcher:
         if fl.size == n:
             res.update(self._match_host(strips0, strips1))
             return
-        sub = self._general.pop(fl.size, None)
+        sub = self._general.pop(fl.size, None) if not self._ragged else None      # a ragged sub-batch has its own shapes
         if sub is None:
             if len(self._general) >= 4:                          # sub-matchers are kept for the sizes that came last
                 self._general.pop(next(iter(self._general))).free()
-            sub = StripBatchMatcher(fl.size, H, W, pool=self._pool, route='host', **self._opts)
+            sub = self._sub_matcher(fl)
         self._general[fl.size] = sub
         need = fl.size * H * W
         if self._gather is None or self._gather[0].nbytes < need:
@@ -974,6 +980,10 @@ class StripBatchMatcher:
         self.last_tiers = {int(fl[k]): v for k, v in sub.last_tiers.items()}
         if sub.last_relax is not None and self.last_relax is not None:
             self.last_relax['relaxed_first'] += sub.last_relax.get('relaxed_first', 0)
+
+    def _sub_matcher(self, fl):
+        """a host-route matcher for the pairs `fl` of this batch (strips gathered into slots of this matcher's size)"""
+        return StripBatchMatcher(fl.size, self.H, self.W, pool=self._pool, route='host', **self._opts)
 
     def _match_host(self, strips0, strips1, masks0=None, masks1=None, compute_photometric=False):
         """strips0/strips1: device pointers to uint8 [P][H][W].  masks0/masks1: optional lists of P host arrays (H x W,
@@ -1180,9 +1190,12 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
         sp = np.sort(auto_spacings((H, W), (H, W)))[::-1] if spacings is None else np.sort(np.asarray(spacings, dtype=np.float64))[::-1]
         return (sp.size,) + grid_counts(H, W, float(np.min(sp)), min_num_blocks)
 
-    def __init__(self, shapes, **opts):
+    def __init__(self, shapes, slot=None, **opts):
         shapes = np.asarray(shapes, dtype=np.int64).reshape(-1, 2)
         Hmax, Wmax = int(shapes[:, 0].max()), int(shapes[:, 1].max())
+        if slot is not None:                                  # strips sit in slots larger than the largest of them
+            assert slot[0] >= Hmax and slot[1] >= Wmax
+            Hmax, Wmax = int(slot[0]), int(slot[1])
         spacings = opts.get('spacings', None)
         super().__init__(shapes.shape[0], Hmax, Wmax, **opts)
         self._ragged = True
@@ -1199,11 +1212,26 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
         else:
             self._hcs, self._wcs = self._Hs, self._Ws
         n = self.P
-        self.d_sizes = _lib.DeviceBuffer.from_array(np.ascontiguousarray(np.tile(shapes, (2, 1)), dtype=np.int32))
-        self.d_sizes_c = _lib.DeviceBuffer.from_array(np.ascontiguousarray(np.tile(np.stack((self._hcs, self._wcs), -1), (2, 1)), dtype=np.int32))
+        self._d_sizes = self._d_sizes_c = None               # device copies of the extents, made when the host route first needs them
+
+    @property
+    def d_sizes(self):
+        if self._d_sizes is None:
+            self._d_sizes = _lib.DeviceBuffer.from_array(np.ascontiguousarray(np.tile(np.stack((self._Hs, self._Ws), -1), (2, 1)), dtype=np.int32))
+        return self._d_sizes
+
+    @property
+    def d_sizes_c(self):
+        if self._d_sizes_c is None:
+            self._d_sizes_c = _lib.DeviceBuffer.from_array(np.ascontiguousarray(np.tile(np.stack((self._hcs, self._wcs), -1), (2, 1)), dtype=np.int32))
+        return self._d_sizes_c
+
+    def _sub_matcher(self, fl):
+        opts = dict(self._opts)
+        return RaggedStripBatchMatcher(np.stack((self._Hs[fl], self._Ws[fl]), axis=-1), slot=(self.H, self.W), pool=self._pool, route='host', **opts)
 
     def free(self):
-        for name in ('d_sizes', 'd_sizes_c'):
+        for name in ('_d_sizes', '_d_sizes_c'):
             b = getattr(self, name, None)
             if b is not None:
                 b.free()
@@ -1308,7 +1336,8 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
         _lib.check(lib.fb_sys_group_energy(ctx, sysh, P, _lib.ptr(v0), _lib.ptr(es0)))
         self._es0_each = es0
         self._es0 = float(es0[0])
-        area = 0.5 * (self._gx[:, 1] - self._gx[:, 0]) * (self._gy[:, 1] - self._gy[:, 0])      # the right triangles of a cell
+        # Mesh.triangle_areas is the cross product of two edges (common.py:672-676): (dx, 0) x (0, dy) for the triangles of a cell
+        area = (self._gx[:, 1] - self._gx[:, 0]) * (self._gy[:, 1] - self._gy[:, 0])
         self._sample_err_each = 0.4387 * area ** 0.5 * DEFAULT_AVG_DEFORM          # optimizer.py:26-30, per pair
         return sysh
 

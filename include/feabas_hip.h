@@ -326,6 +326,11 @@ typedef struct fb_strip_opts {
 #define FB_STRIP_RELAXFIRST 4
 #define FB_STRIP_RIGIDFIT 8
 int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* opts, fb_strip_matcher** out);
+/* Strips of unequal size (the usual case in a real section: every overlap follows the stage jitter of its two tiles,
+ * stitcher.py:561-571): pair p is the shapes[p] = {h, w} top-left corner of its H x W slot; every stage works on the pair's own
+ * extent, with its own block grids, spacings (automatic ones per shape) and mesh geometry.  The pairs of a batch must share the
+ * number of spacings and the node grid of Mesh.from_bbox (feabas_amd.stitch_pipeline.RaggedStripBatchMatcher.bucket_key). */
+int fb_strip_matcher_create_ragged(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, const fb_strip_opts* opts, fb_strip_matcher** out);
 void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m);
 int fb_strip_matcher_info(fb_ctx* ctx, fb_strip_matcher* m, int* nspacings, double* spacings, int* grid_nx, int* grid_ny,
                           int* relax_iters, double* relax_relres, int* strain_iters, double* strain_relres);

@@ -802,3 +802,39 @@ def test_native_entry_automatic_spacings_and_grid(fb):
         bad = np.array([0.5])
         o = _lib.StripOpts(2.5, 1, 0.33, 2, 2, 5.0, 0, 1.0, 1e-9, 1, 1, bad.ctypes.data)
         _lib.check(lib.fb_strip_matcher_create(ctx, 1, 256, 256, C.byref(o), C.byref(C.c_void_p())))
+
+
+@pytest.mark.parametrize('cds', [0.5, 1])
+def test_native_entry_ragged_equals_the_host_statement(fb, cds):
+    """fb_strip_matcher_create_ragged: strips of unequal size through the C entry against the numpy statement of the ragged
+    batch -- per-pair extents, block grids, spacings and mesh geometry; one pair deforms between the spacings and comes
+    back through the host route on its own extent inside this matcher's slots"""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import RaggedStripBatchMatcher, StripBatchMatcher
+    shapes = [(1536, 120), (1526, 122), (1520, 120), (1530, 121), (1536, 120), (1522, 121)]
+    assert len({RaggedStripBatchMatcher.bucket_key(h, w) for h, w in shapes}) == 1
+    warps = [0.3, 0.0, 2.5, 0.2, 0.4, 0.1]
+    pairs = [_warped_pair(h, w, 210 + k, shift=(4 - k, k - 3), warp=warps[k]) for k, (h, w) in enumerate(shapes)]
+    P = len(shapes)
+    Hm, Wm = max(h for h, _ in shapes), max(w for _, w in shapes)
+    stage = np.full((2, P, Hm, Wm), 200, dtype=np.uint8)
+    for k, (a, b) in enumerate(pairs):
+        stage[0, k, :a.shape[0], :a.shape[1]] = a
+        stage[1, k, :b.shape[0], :b.shape[1]] = b
+    dev = _lib.DeviceBuffer.from_array(stage)
+    mn = RaggedStripBatchMatcher(shapes, residue_len=2.0, coarse_downsample=cds, route='native')
+    mh = RaggedStripBatchMatcher(shapes, residue_len=2.0, coarse_downsample=cds, route='host')
+    rn = mn.match(dev.ptr, dev.offset(P * Hm * Wm)); rh = mh.match(dev.ptr, dev.offset(P * Hm * Wm))
+    assert mn.last_flags is not None and mn.last_flags[2] & 2 and not mn.last_flags[[0, 1, 3, 4, 5]].any()
+    for k in ('tx', 'ty', 'conf0', 'valid', 'deformed'):
+        np.testing.assert_array_equal(rn[k], rh[k], err_msg=k)
+    assert rn['valid'].all() and rn['deformed'].tolist() == [False, False, True, False, False, False]
+    gn = StripBatchMatcher.per_pair(rn); gh = StripBatchMatcher.per_pair(rh)
+    for p in range(P):
+        for k in ('xy0', 'xy1', 'weight'):
+            if mn.last_flags[p]:
+                np.testing.assert_allclose(gn[p][k], gh[p][k], atol=1e-6, err_msg=f'{k} of pair {p}')
+            else:
+                np.testing.assert_array_equal(gn[p][k], gh[p][k], err_msg=f'{k} of pair {p}')
+        np.testing.assert_allclose(gn[p]['strain'], gh[p]['strain'], rtol=1e-6, atol=1e-10)
+    mn.free(); mh.free(); dev.free()
