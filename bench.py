@@ -48,8 +48,9 @@ def parse():
     ap.add_argument('--host-threads', type=int, default=8, help='host threads driving the device (even; steps are dealt round-robin, LR and UD batches alternate)')
     ap.add_argument('--multi-stream', type=int, default=1, help='1: one context (HIP stream) per host thread; 0: all threads share one stream')
     ap.add_argument('--warp', type=float, default=0.4, help='amplitude (px) of the smooth sub-pixel warp between the strips of a pair (SURVEY config 2)')
-    ap.add_argument('--host-ingest-threads', type=int, default=4)
-    ap.add_argument('--host-ingest-pairs', type=int, default=512, help='pairs of the PCIe-inclusive measurement (0: skip)')
+    ap.add_argument('--host-ingest-threads', type=int, default=8)
+    ap.add_argument('--host-ingest-batch', type=int, default=64, help='pairs per chunk of the PCIe-inclusive measurement (a chunk is packed, copied and matched by one host thread)')
+    ap.add_argument('--host-ingest-pairs', type=int, default=1024, help='pairs of the PCIe-inclusive measurement (0: skip)')
     ap.add_argument('--no-fem', action='store_true')
     ap.add_argument('--no-align', action='store_true', help='skip the alignment-side block matcher section')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -915,10 +916,11 @@ def main():
         keep = dict(strips)
         strips.update(dstrips)
         try:
-            run_steps(0, S)                                # one untimed step (the deformed path sizes its scratch on first use)
+            w0 = max(S, 2 * nthr)                          # untimed: every host thread's matcher sizes the scratch of the deformed
+            run_steps(0, w0)                               # path and learns that its pairs take the general route
             barrier()
             t0 = time.time()
-            lastd = run_steps(S, 2 * S)
+            lastd = run_steps(w0, 2 * S)
             barrier()
             dtd = time.time() - t0
             kd, bd, resd = lastd
@@ -961,16 +963,17 @@ def main():
         H, W = shapes['LR']
         s0, s1, _ = strips['LR']
         nh = min(args.host_ingest_pairs, n_res)
+        IB = max(1, args.host_ingest_batch)
         h0 = s0.to_array((nh, H, W), np.uint8); h1 = s1.to_array((nh, H, W), np.uint8)
         host_pairs = [(h0[k % nh], h1[k % nh]) for k in range(args.host_ingest_pairs)]     # the list may wrap around the resident strips
         cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=RESIDUE_LEN)
-        fmatcher.stitching_matcher_batch(host_pairs[:P * args.host_ingest_threads], batch=P, threads=args.host_ingest_threads, **cfg)        # set-up pass
+        fmatcher.stitching_matcher_batch(host_pairs[:IB * args.host_ingest_threads], batch=IB, threads=args.host_ingest_threads, **cfg)        # set-up pass
         t0 = time.time()
-        outp = fmatcher.stitching_matcher_batch(host_pairs, batch=P, threads=args.host_ingest_threads, **cfg)
+        outp = fmatcher.stitching_matcher_batch(host_pairs, batch=IB, threads=args.host_ingest_threads, **cfg)
         dth = time.time() - t0
         line['host_ingest'] = dict(value=len(host_pairs) / dth, unit='pairs/s', pairs=len(host_pairs), matched=int(sum(o[0] is not None for o in outp)),
                                    note='strips handed over in host memory (4.2 MB per pair over PCIe), results returned per pair; '
-                                        f'{args.host_ingest_threads} host threads, {P}-pair chunks')
+                                        f'{args.host_ingest_threads} host threads, {IB}-pair chunks')
         # the same pairs cropped to strip shapes that all differ (what stage jitter does to the overlaps of a real section):
         # batches of unequal strips (RaggedStripBatchMatcher)
         rng_r = np.random.default_rng(5)
