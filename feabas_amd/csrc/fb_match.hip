@@ -122,9 +122,15 @@ int pool_take(fb_ctx* ctx, size_t bytes, void** out, size_t* got) {
 void pool_give(fb_ctx* ctx, void* ptr, size_t bytes) {
     if (!ptr) return;
     ctx->match_pool.emplace_back(ptr, bytes);
-    if (ctx->match_pool.size() > 32) {                       // bound the pool: drop the smallest
+    // bound the pool: at most 32 buffers (the smallest goes first) and 16 GB (the largest goes first)
+    size_t total = 0;
+    for (auto& b : ctx->match_pool) total += b.second;
+    while (ctx->match_pool.size() > 32 || (total > ((size_t)16 << 30) && ctx->match_pool.size() > 1)) {
+        const bool by_count = ctx->match_pool.size() > 32;
         size_t k = 0;
-        for (size_t i = 1; i < ctx->match_pool.size(); ++i) if (ctx->match_pool[i].second < ctx->match_pool[k].second) k = i;
+        for (size_t i = 1; i < ctx->match_pool.size(); ++i)
+            if (by_count ? ctx->match_pool[i].second < ctx->match_pool[k].second : ctx->match_pool[i].second > ctx->match_pool[k].second) k = i;
+        total -= ctx->match_pool[k].second;
         fb_free(ctx, ctx->match_pool[k].first);
         ctx->match_pool.erase(ctx->match_pool.begin() + k);
     }

@@ -25,3 +25,5 @@ ts = [one(k) for k in range(4)]
 pr.disable()
 print('optimize_linear per section', np.round(ts, 3), 'iters', slm.last_solve['iters'])
 pstats.Stats(pr).sort_stats('tottime').print_stats(18)
+pstats.Stats(pr).print_callers('reduce')
+pstats.Stats(pr).print_callers('_collections_abc')
