@@ -654,6 +654,57 @@ static int sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t*
 
 int fb_sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6) { return sys_update_links(ctx, s, K, nodes6, 0); }
 
+// Link.xy0 / xy1 / dxy (optimizer.py:121-135, 248-255) and the rows fb_sys_set_links / fb_sys_assemble_links take, for the
+// K matches of one link: nodes6 = global free-vertex ids of the two triangles (-1 on a locked side), bary6 = [B0 | -B1],
+// rxy = (B1 . v1[tri1[tid1]] - B0 . v0[tri0[tid0]]) + (ox, oy).  Host only, a few threads: a section of 1e5 matches cost
+// 60 ms of numpy gathers per solve.  voff < 0: that mesh is locked.  bary6 / rxy may be NULL (nodes only).
+int fb_link_terms(fb_ctx* ctx, int64_t K, const int32_t* tri0, int64_t T0, const double* v0, const int64_t* tid0, const double* B0, int64_t voff0,
+                  const int32_t* tri1, int64_t T1, const double* v1, const int64_t* tid1, const double* B1, int64_t voff1, double ox, double oy,
+                  int32_t* nodes6, double* bary6, double* rxy) {
+#pragma clang fp contract(off)
+    FB_CHECK_ARG(ctx, K >= 0 && tri0 && tri1 && T0 > 0 && T1 > 0 && (K == 0 || (tid0 && tid1 && nodes6)));
+    FB_CHECK_ARG(ctx, (!bary6 && !rxy) || (B0 && B1));
+    FB_CHECK_ARG(ctx, !rxy || (v0 && v1));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, K / 8192));
+    std::vector<int64_t> bad((size_t)T, -1);
+    auto work = [&](int t) {
+        const int64_t lo = K * t / T, hi = K * (t + 1) / T;
+        for (int64_t k = lo; k < hi; ++k) {
+            int64_t a = tid0[k], b = tid1[k];
+            if (a < 0) a += T0;                            // numpy's wrap-around: a match outside its mesh (tid -1) carries weight 0
+            if (b < 0) b += T1;
+            if (a < 0 || a >= T0 || b < 0 || b >= T1) { bad[t] = k; return; }
+            const int32_t* ta = tri0 + 3 * a;
+            const int32_t* tb = tri1 + 3 * b;
+            int32_t* n6 = nodes6 + 6 * k;
+            for (int c = 0; c < 3; ++c) {
+                n6[c] = voff0 < 0 ? -1 : (int32_t)(ta[c] + voff0);
+                n6[3 + c] = voff1 < 0 ? -1 : (int32_t)(tb[c] + voff1);
+            }
+            if (bary6) {
+                double* b6 = bary6 + 6 * k;
+                for (int c = 0; c < 3; ++c) { b6[c] = B0[3 * k + c]; b6[3 + c] = -B1[3 * k + c]; }
+            }
+            if (rxy) {
+                for (int d = 0; d < 2; ++d) {
+                    const double p0 = (v0[2 * (size_t)ta[0] + d] * B0[3 * k] + v0[2 * (size_t)ta[1] + d] * B0[3 * k + 1]) + v0[2 * (size_t)ta[2] + d] * B0[3 * k + 2];
+                    const double p1 = (v1[2 * (size_t)tb[0] + d] * B1[3 * k] + v1[2 * (size_t)tb[1] + d] * B1[3 * k + 1]) + v1[2 * (size_t)tb[2] + d] * B1[3 * k + 2];
+                    rxy[2 * k + d] = (p1 - p0) + (d ? oy : ox);
+                }
+            }
+        }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    for (int t = 0; t < T; ++t)
+        if (bad[t] >= 0) return fb_fail(ctx, FB_ERR_ARG, "fb_link_terms: match %lld names a triangle outside its mesh", (long long)bad[t]);
+    return FB_OK;
+}
+
 int fb_sys_pattern(fb_ctx* ctx, fb_system* s, int64_t* browptr, int32_t* bcol) {
     FB_CHECK_ARG(ctx, s && s->finalized);
     if (browptr) for (size_t i = 0; i < s->browptr.size(); ++i) browptr[i] = s->browptr[i];

@@ -575,6 +575,24 @@ class SLM:
     def _active_links(self):
         return [lk for lk in self.links if lk.relevant and lk._tid0.size > 0]
 
+    @staticmethod
+    def _link_terms(lk, offs, nodes6, bary6=None, rxy=None, gears=None):
+        """rows of one link for fb_sys_set_links / fb_sys_assemble_links (fb_link_terms: vertex ids of the two triangles of
+        every match, [B0 | -B1], xy1 - xy0 at the given gears), written into slices of the caller's arrays"""
+        m0, m1 = lk.meshes
+        tid0 = np.ascontiguousarray(lk._tid0, dtype=np.int64); tid1 = np.ascontiguousarray(lk._tid1, dtype=np.int64)
+        B0 = np.ascontiguousarray(lk._B0, dtype=np.float64); B1 = np.ascontiguousarray(lk._B1, dtype=np.float64)
+        v0 = v1 = None
+        ox = oy = 0.0
+        if rxy is not None:
+            v0 = np.ascontiguousarray(m0.vertices(gears[0]), dtype=np.float64); v1 = np.ascontiguousarray(m1.vertices(gears[1]), dtype=np.float64)
+            d = np.asarray(m1.offset(gears[1]), dtype=np.float64).reshape(-1) - np.asarray(m0.offset(gears[0]), dtype=np.float64).reshape(-1)
+            ox, oy = float(d[0]), float(d[1])
+        _lib.check(_lib.load().fb_link_terms(_lib.ctx(), tid0.size, _lib.ptr(m0.triangles), m0.num_triangles, _lib.ptr(v0), _lib.ptr(tid0), _lib.ptr(B0),
+                                             offs[m0.uid] // 2 if offs[m0.uid] >= 0 else -1, _lib.ptr(m1.triangles), m1.num_triangles, _lib.ptr(v1),
+                                             _lib.ptr(tid1), _lib.ptr(B1), offs[m1.uid] // 2 if offs[m1.uid] >= 0 else -1, ox, oy,
+                                             _lib.ptr(nodes6), _lib.ptr(bary6), _lib.ptr(rxy)))
+
     def _ensure_system(self, groupings=None):
         """(Re)build the symbolic GPU system when the topology (free meshes, link
         connectivity, groupings) changed; numeric re-assembly reuses it."""
@@ -583,16 +601,11 @@ class SLM:
         offs, dof, adders, gmean = self._layout(groupings)
         self._offs, self._adders, self._gmean = offs, adders, gmean
         links = [lk for lk in self._active_links() if offs[lk.meshes[0].uid] >= 0 or offs[lk.meshes[1].uid] >= 0]
-        node_rows = []
+        nodes6 = np.empty((sum(lk._tid0.size for lk in links), 6), dtype=np.int32)
+        at = 0
         for lk in links:
-            cols = []
-            for side, (m, tid) in enumerate(zip(lk.meshes, (lk._tid0, lk._tid1))):
-                if offs[m.uid] < 0:
-                    cols.append(np.full((tid.size, 3), -1, dtype=np.int32))
-                else:
-                    cols.append((m.triangles[tid] + offs[m.uid] // 2).astype(np.int32))
-            node_rows.append(np.concatenate(cols, axis=-1))
-        nodes6 = np.ascontiguousarray(np.concatenate(node_rows, axis=0), dtype=np.int32) if node_rows else np.zeros((0, 6), np.int32)
+            self._link_terms(lk, offs, nodes6[at:at + lk._tid0.size])
+            at += lk._tid0.size
         mesh_key = tuple((m.uid, offs[m.uid], m.num_vertices, m.triangles.ctypes.data) for m in self.meshes)
         key = (mesh_key, nodes6.tobytes())
         if self._sys is not None and key == self._sys_key:
@@ -639,16 +652,18 @@ class SLM:
             v1 = m.vertices(start_gear)
             v1c = None if v1 is m.vertices(shape_gear) else np.ascontiguousarray(v1, dtype=np.float64)
             m.assemble_into(self._sys, self._mesh_ids[m.uid], v0, v1c, float(m.soft_factor), add=m.uid in self._adders)
-        bary, wts, res = [], [], []
-        for lk in links:
-            gears = [target_gear if offs[m.uid] < 0 else start_gear for m in lk.meshes]
-            bary.append(np.concatenate((lk._B0, -lk._B1), axis=-1))
-            wts.append(lk.weight(use_mask=False))
-            res.append(lk.dxy(gear=gears, use_mask=False))
         if links:
-            bary = np.ascontiguousarray(np.concatenate(bary, axis=0), dtype=np.float64)
-            wts = np.ascontiguousarray(np.concatenate(wts), dtype=np.float32)
-            res = np.ascontiguousarray(np.concatenate(res, axis=0), dtype=np.float64)
+            K = sum(lk._tid0.size for lk in links)
+            bary = np.empty((K, 6)); res = np.empty((K, 2)); wts = np.empty(K, dtype=np.float32)
+            scratch = np.empty((max(lk._tid0.size for lk in links), 6), dtype=np.int32)
+            at = 0
+            for lk in links:
+                n = lk._tid0.size
+                gears = [target_gear if offs[m.uid] < 0 else start_gear for m in lk.meshes]
+                # [B0 | -B1] and Link.dxy (optimizer.py:248-255) of the link's matches straight into the rows of the system
+                self._link_terms(lk, offs, scratch[:n], bary[at:at + n], res[at:at + n], gears)
+                wts[at:at + n] = lk.weight(use_mask=False)
+                at += n
             _lib.check(lib.fb_sys_assemble_links(ctx, self._sys, _lib.ptr(bary), _lib.ptr(wts), _lib.ptr(res)))
         else:
             _lib.check(lib.fb_sys_assemble_links(ctx, self._sys, None, None, None))

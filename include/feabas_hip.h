@@ -260,6 +260,13 @@ int fb_sys_assemble_links(fb_ctx* ctx, fb_system* sys, const double* bary6, cons
 /* Replace the links of a finalized system without touching the symbolic pattern (the new matches must
  * couple only vertices that are already coupled, e.g. matches against locked meshes). */
 int fb_sys_update_links(fb_ctx* ctx, fb_system* sys, int64_t K, const int32_t* nodes6);
+/* Link.xy0 / xy1 / dxy (optimizer.py:121-135, 248-255) for the K matches of one link, laid out as fb_sys_set_links /
+ * fb_sys_assemble_links take them (host only): tri [T][3], v [V][2] of the two meshes at the gears of the solve, tid [K] int64,
+ * B [K][3]; voff = first global free vertex of the mesh, < 0 when it is locked; (ox, oy) = offset(mesh1) - offset(mesh0).
+ * nodes6 [K][6]; bary6 [K][6] = [B0 | -B1] and rxy [K][2] = xy1 - xy0 may be NULL. */
+int fb_link_terms(fb_ctx* ctx, int64_t K, const int32_t* tri0, int64_t T0, const double* v0, const int64_t* tid0, const double* B0, int64_t voff0,
+                  const int32_t* tri1, int64_t T1, const double* v1, const int64_t* tid1, const double* B1, int64_t voff1, double ox, double oy,
+                  int32_t* nodes6, double* bary6, double* rxy);
 /* Block-diagonal batch of `ngroups` independent systems stored as equal consecutive vertex ranges (one
  * tile pair each, matcher.py:551): relative_lambda_trace per range, then A and b as in fb_sys_form. */
 int fb_sys_form_groups(fb_ctx* ctx, fb_system* sys, int ngroups, double stiffness_lambda, double crosslink_lambda,
