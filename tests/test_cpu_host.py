@@ -449,3 +449,37 @@ def test_oracle_u8_remap_rule():
     shifted = pipeline_ref.remap_origin(img, xx + 5, yy + 3, (2, 1), img_origin=(-7, 4))      # image pixel (0, 0) at (-7, 4)
     np.testing.assert_array_equal(shifted[1:, :], img[0:29, 12:47].astype(np.float32))
     assert not shifted[0].any()
+
+
+def test_link_terms_match_the_numpy_statement():
+    """fb_link_terms (host C++): vertex ids, [B0 | -B1] and Link.dxy (optimizer.py:248-255) of the matches of one link,
+    against the numpy statement Mesh.bary2cart makes -- bit for bit, negative triangle ids wrapping like numpy's"""
+    from feabas_amd import _lib
+    from oracle import fem_ref
+    rng = np.random.default_rng(12)
+    v, t = fem_ref.grid_mesh(31, 23, 7.5)
+    t = np.ascontiguousarray(t, dtype=np.int32)
+    K = 30000
+    v0 = v + rng.normal(0, 0.4, v.shape); v1 = v + rng.normal(0, 0.4, v.shape)
+    tid0 = rng.integers(0, t.shape[0], K).astype(np.int64); tid1 = rng.integers(0, t.shape[0], K).astype(np.int64)
+    tid0[5] = -1; tid1[9] = -2
+    B0 = rng.dirichlet((1, 1, 1), K); B1 = rng.dirichlet((1, 1, 1), K)
+    off = np.array([0.37, -1.25])
+    for voff0, voff1 in ((-1, 0), (400, -1), (0, v.shape[0])):
+        nodes6 = np.empty((K, 6), dtype=np.int32); bary6 = np.empty((K, 6)); rxy = np.empty((K, 2))
+        rc = _lib.load().fb_link_terms(None, K, _lib.ptr(t), t.shape[0], _lib.ptr(v0), _lib.ptr(tid0), _lib.ptr(B0), voff0, _lib.ptr(t), t.shape[0], _lib.ptr(v1),
+                                       _lib.ptr(tid1), _lib.ptr(B1), voff1, float(off[0]), float(off[1]), _lib.ptr(nodes6), _lib.ptr(bary6), _lib.ptr(rxy))
+        assert rc == 0
+        e0 = np.full((K, 3), -1) if voff0 < 0 else t[tid0] + voff0
+        e1 = np.full((K, 3), -1) if voff1 < 0 else t[tid1] + voff1
+        np.testing.assert_array_equal(nodes6, np.concatenate((e0, e1), axis=1))
+        np.testing.assert_array_equal(bary6, np.concatenate((B0, -B1), axis=1))
+
+        def b2c(vv, tid, B):
+            idx = t[tid]
+            out = vv[idx[:, 0]] * B[:, 0:1]; out += vv[idx[:, 1]] * B[:, 1:2]; out += vv[idx[:, 2]] * B[:, 2:3]
+            return out
+        np.testing.assert_array_equal(rxy, (b2c(v1, tid1, B1) - b2c(v0, tid0, B0)) + off)
+    bad = tid0.copy(); bad[3] = t.shape[0]
+    assert _lib.load().fb_link_terms(None, K, _lib.ptr(t), t.shape[0], None, _lib.ptr(bad), None, 0, _lib.ptr(t), t.shape[0], None, _lib.ptr(tid1), None, -1,
+                                     0.0, 0.0, _lib.ptr(nodes6), None, None) != 0
