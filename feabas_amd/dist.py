@@ -7,6 +7,8 @@ shard -- the same contiguous-slice partitioning the reference uses for its worke
   * the variable-length match table of every rank   -> ``gather_match_table``
   * per-section node displacement vectors           -> ``allgather_ragged``
 """
+import os
+
 import numpy as np
 
 
@@ -55,14 +57,35 @@ class Exchange:
             from . import _lib
             self._lib, self._C = _lib, C
             lib, ctx = _lib.load(), (_lib.ctx() if ctx is None else ctx)
+            # every rank makes an id (the cheapest call that needs the RCCL library): a rank that cannot load it must not
+            # leave the others waiting in the broadcast below, so the ranks agree on that first
             ident = np.zeros(128, dtype=np.uint8)
-            if self.rank == 0:
-                _lib.check(lib.fb_comm_unique_id(ctx, _lib.ptr(ident)))
+            rc = lib.fb_comm_unique_id(ctx, _lib.ptr(ident))
+            err = None if rc == 0 else (lib.fb_last_error(ctx) or b'?').decode()
+            flags = [None] * self.world
+            dist.all_gather_object(flags, err, group=group)
+            bad = [(r, e) for r, e in enumerate(flags) if e is not None]
+            if bad:
+                raise RuntimeError(f'RCCL is not available on rank {bad[0][0]}: {bad[0][1]}')
             box = [ident.tobytes()]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             ident = np.frombuffer(box[0], dtype=np.uint8).copy()
             h = C.c_void_p()
-            _lib.check(lib.fb_comm_create(ctx, _lib.ptr(ident), self.rank, self.world, C.byref(h)))
+            # ncclCommInitRank blocks until every rank has joined; a rank stuck in it is given up after a while (the thread
+            # is left behind) so that the caller can fall back to another route instead of hanging the job
+            import threading
+            res = {}
+
+            def init():
+                res['rc'] = lib.fb_comm_create(ctx, _lib.ptr(ident), self.rank, self.world, C.byref(h))
+                res['err'] = (lib.fb_last_error(ctx) or b'').decode() if res['rc'] else ''
+            th = threading.Thread(target=init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get('FEABAS_HIP_COMM_TIMEOUT', '120')))
+            if th.is_alive():
+                raise RuntimeError('fb_comm_create did not return (ncclCommInitRank waiting for the other ranks)')
+            if res['rc'] != 0:
+                raise _lib.FeabasHipError(res['rc'], res['err'] or '?')
             self.comm, self._ctx = h, ctx
 
     def close(self):
