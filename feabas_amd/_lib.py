@@ -74,6 +74,8 @@ _PROTOS = {
     'fb_dog_sizes_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_d, c_i, c_p]),
     'fb_dog_masks_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
     'fb_dog_down2_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_d, c_i, c_p]),
+    'fb_dog_pair_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_i, c_p]),
+    'fb_dog_down2_pair_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_d, c_i, c_p]),
     'fb_mask_range_dev': (c_i, [c_p, c_p, c_sz, C.c_float, C.c_float, c_p]),
     'fb_mesh_block_affines': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_d, c_p, c_p]),
     'fb_mesh_block_uncovered': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),

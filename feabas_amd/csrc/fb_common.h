@@ -59,6 +59,8 @@ struct fb_ctx {
     bool use_rocfft = false;     // FEABAS_HIP_ROCFFT=1: streaming-class FFTs through rocFFT instead of the hand-written kernels
     bool dog_tiles = false;      // FEABAS_HIP_DOG_TILES=1: the 64 x 64 tile kernel (dog_fast) instead of the streaming one (A/B)
     bool dog_exact = false;      // double-precision tap accumulation (scipy's arithmetic) instead of the float fast path
+    const void* dog_img1 = nullptr;    // second image stack of the launch being enqueued (fb_dog_pair_dev); set and cleared under the lock
+    int dog_nsplit = 0;
     // device buffers and relaxation systems that outlive a strip matcher (fb_match.hip): matchers of ragged batches come and
     // go with every chunk of a section, their buffers and the symbolic phase of their block-diagonal system do not
     std::vector<std::pair<void*, size_t>> match_pool;

@@ -470,7 +470,8 @@ __device__ __forceinline__ float fir1(const float* w, const TapsF& t) {         
 // coarse image of matcher.py:255-256 is never written (SH, SW = half_size(H2), half_size(W2))
 template <typename T, int R, int NT, bool DS2 = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 : (R <= 12 ? 3 : 2)))) void dog_stream(const T* __restrict__ img, float* __restrict__ out, int SH, int SW, int signed_out,
-                                                const int* __restrict__ sizes, const TapsF taps, int TX, int SY, int H2 = 0, int W2 = 0) {
+                                                const int* __restrict__ sizes, const TapsF taps, int TX, int SY, int H2 = 0, int W2 = 0,
+                                                const T* __restrict__ img1 = nullptr, int nsplit = 0x7fffffff) {
     constexpr int CH = SCH, RN = SRN;
     constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
     constexpr int NQ = (RN + 2 * R + 3) / 4;               // float4 reads per horizontal run (over-reads up to 3 staged values)
@@ -489,7 +490,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 
         for (int i = tid; i < rows * sw; i += NT) oimg[(uint32_t)((y0 + i / sw) * SW + x0 + i % sw)] = 0.f;
         return;
     }
-    const T* __restrict__ src = img + (DS2 ? (size_t)n * H2 * W2 : (size_t)n * SH * SW);
+    // images nsplit .. of the launch come from a second stack (the two strips of a batch of pairs filtered in one launch)
+    const T* __restrict__ src = (n < nsplit ? img : img1) + (size_t)(n < nsplit ? n : n - nsplit) * (DS2 ? (size_t)H2 * W2 : (size_t)SH * SW);
     const int bw = min(TX, W - x0);                            // image columns of the band
     const int NV = bw + 2 * R;                                 // columns of the vertical passes (<= NT)
     const int NA = (NV + RN - 1) / RN * RN;                    // columns of A computed by the first pass (<= NT)
@@ -707,7 +709,8 @@ int launch_stream_ds2_nt(fb_ctx* ctx, const uint8_t* img, float* out, int N, int
     auto kern = dog_stream<uint8_t, R, NT, true>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(pl.nb, pl.nseg, N);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, half_size(H2), half_size(W2), signed_out, (const int*)nullptr, tf, pl.TX, pl.SY, H2, W2);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, half_size(H2), half_size(W2), signed_out, (const int*)nullptr, tf, pl.TX, pl.SY, H2, W2,
+                       (const uint8_t*)ctx->dog_img1, ctx->dog_img1 ? ctx->dog_nsplit : 0x7fffffff);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
@@ -729,7 +732,8 @@ int launch_stream_nt(fb_ctx* ctx, const T* img, float* out, int N, int H, int W,
     auto kern = dog_stream<T, R, NT>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(pl.nb, pl.nseg, N);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, H, W, signed_out, sizes, tf, pl.TX, pl.SY, 0, 0);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, H, W, signed_out, sizes, tf, pl.TX, pl.SY, 0, 0, (const T*)ctx->dog_img1,
+                       ctx->dog_img1 ? ctx->dog_nsplit : 0x7fffffff);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
@@ -926,6 +930,40 @@ int fb_dog_down2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H2, int W2, dou
         case 10: return launch_stream_ds2<10>(ctx, img, out, N, H2, W2, signed_out, taps);
         default: return fb_fail(ctx, FB_ERR_ARG, "fb_dog_down2_dev: sigma %.3f (radius %d) has no streaming kernel", sigma, r);
     }
+}
+
+// The two strip stacks of a batch of pairs in ONE launch: images 0 .. N-1 from img0, N .. 2N-1 from img1, out [2N].  A launch
+// of 2N images is cut into fewer row segments than two of N (the segments of plan_stream fill the chip in whole rounds), so
+// fewer warm-up rows are filtered twice: 6-7 % less work at 128 pairs of 4096 x 510.
+int fb_dog_pair_dev(fb_ctx* ctx, const void* img0, const void* img1, int dtype, int N, int H, int W, double sigma, int signed_out, float* out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && sigma > 0 && (dtype == FB_U8 || dtype == FB_F32));
+    if (N == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, img0 && img1 && out);
+    int r = 0;
+    Taps taps;
+    int rc = set_taps(ctx, sigma, &r, &taps);
+    if (rc) return rc;
+    const bool streamed = !ctx->dog_tiles && !ctx->dog_exact && (r == 5 || r == 6 || r == 8 || r == 10 || r == 12 || r == 14) && 2 * (long long)N <= 65535;
+    if (!streamed) {
+        if ((rc = fb_dog_dev(ctx, img0, dtype, N, H, W, sigma, nullptr, signed_out, out))) return rc;
+        return fb_dog_dev(ctx, img1, dtype, N, H, W, sigma, nullptr, signed_out, out + (size_t)N * H * W);
+    }
+    ctx->dog_img1 = img1; ctx->dog_nsplit = N;
+    rc = fb_dog_dev(ctx, img0, dtype, 2 * N, H, W, sigma, nullptr, signed_out, out);
+    ctx->dog_img1 = nullptr;
+    return rc;
+}
+
+int fb_dog_down2_pair_dev(fb_ctx* ctx, const uint8_t* img0, const uint8_t* img1, int N, int H2, int W2, double sigma, int signed_out, float* out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, N >= 0 && H2 > 1 && W2 > 1 && sigma > 0 && 2 * (long long)N <= 65535);
+    if (N == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, img0 && img1 && out);
+    ctx->dog_img1 = img1; ctx->dog_nsplit = N;
+    const int rc = fb_dog_down2_dev(ctx, img0, 2 * N, H2, W2, sigma, signed_out, out);
+    ctx->dog_img1 = nullptr;
+    return rc;
 }
 
 int fb_mask_range_dev(fb_ctx* ctx, const float* img, size_t n, float lo, float hi, uint8_t* mask) {

@@ -543,23 +543,20 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         if (m->cds2) {
             const int taps = (int)(4.0 * m->sigma * 0.5 + 0.5);
             if (taps == 5 || taps == 6 || taps == 8 || taps == 10) {
-                if ((rc = fb_dog_down2_dev(ctx, strips0, n, H, W, m->sigma * 0.5, 1, m->d_dogc))) return rc;
-                if ((rc = fb_dog_down2_dev(ctx, strips1, n, H, W, m->sigma * 0.5, 1, m->d_dogc + n * cpix))) return rc;
+                if ((rc = fb_dog_down2_pair_dev(ctx, strips0, strips1, n, H, W, m->sigma * 0.5, 1, m->d_dogc))) return rc;
             } else {
                 if ((rc = fb_area_downsample2_dev(ctx, strips0, n, H, W, m->d_small))) return rc;
                 if ((rc = fb_area_downsample2_dev(ctx, strips1, n, H, W, m->d_small + n * cpix))) return rc;
                 if ((rc = fb_dog_dev(ctx, m->d_small, 0, 2 * n, hc, wc, m->sigma * 0.5, nullptr, 1, m->d_dogc))) return rc;
             }
         } else {
-            if ((rc = fb_dog_dev(ctx, strips0, 0, n, hc, wc, m->sigma, nullptr, 1, m->d_dogc))) return rc;
-            if ((rc = fb_dog_dev(ctx, strips1, 0, n, hc, wc, m->sigma, nullptr, 1, m->d_dogc + n * cpix))) return rc;
+            if ((rc = fb_dog_pair_dev(ctx, strips0, strips1, 0, n, hc, wc, m->sigma, 1, m->d_dogc))) return rc;
         }
         if ((rc = fb_ncc_batch_dev(ctx, m->d_dogc, m->d_dogc + n * cpix, n, 1, hc, wc, hc, wc, 1, 0, m->conf_mode, (double*)m->d_out,
                                    (double*)(m->d_out + 8 * (size_t)n), (float*)(m->d_out + 16 * (size_t)n))))
             return rc;
         if (m->cds2) {
-            if ((rc = fb_dog_dev(ctx, strips0, 0, n, H, W, m->sigma, nullptr, 1, m->d_dogf))) return rc;
-            if ((rc = fb_dog_dev(ctx, strips1, 0, n, H, W, m->sigma, nullptr, 1, m->d_dogf + n * fpix))) return rc;
+            if ((rc = fb_dog_pair_dev(ctx, strips0, strips1, 0, n, H, W, m->sigma, 1, m->d_dogf))) return rc;
             dogf = m->d_dogf;
         }
         clk.lap(0);

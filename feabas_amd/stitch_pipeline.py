@@ -278,15 +278,13 @@ class StripBatchMatcher:
         if self.cds == 0.5 and masks is None and not need_small and int(4.0 * self.sigma * self.cds + 0.5) in (5, 6, 8, 10):
             # the x0.5 area downsample inside the loader of the coarse DoG: the coarse uint8 image (only the masked DoG and the
             # photometric statistics read it again) is never written
-            _lib.check(lib.fb_dog_down2_dev(ctx, strips0, n, H, W, self.sigma * self.cds, 1, self.d_dogc.ptr))
-            _lib.check(lib.fb_dog_down2_dev(ctx, strips1, n, H, W, self.sigma * self.cds, 1, self.d_dogc.offset(n * hc * wc * 4)))
+            _lib.check(lib.fb_dog_down2_pair_dev(ctx, strips0, strips1, n, H, W, self.sigma * self.cds, 1, self.d_dogc.ptr))
         elif self.cds == 0.5:
             _lib.check(lib.fb_area_downsample2_dev(ctx, strips0, n, H, W, self.d_small.ptr))
             _lib.check(lib.fb_area_downsample2_dev(ctx, strips1, n, H, W, self.d_small.offset(n * hc * wc)))
             _lib.check(lib.fb_dog_dev(ctx, self.d_small.ptr, 0, 2 * n, hc, wc, self.sigma * self.cds, None, 1, self.d_dogc.ptr))
         else:
-            _lib.check(lib.fb_dog_dev(ctx, strips0, 0, n, hc, wc, self.sigma, None, 1, self.d_dogc.ptr))
-            _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, hc, wc, self.sigma, None, 1, self.d_dogc.offset(n * hc * wc * 4)))
+            _lib.check(lib.fb_dog_pair_dev(ctx, strips0, strips1, 0, n, hc, wc, self.sigma, 1, self.d_dogc.ptr))
         if masks is not None:
             # masked pairs: the coarse DoG of their images again, with the halo suppression of common.py:368-374; the
             # coarse mask is cv2.resize(mask, fx=0.5, INTER_NEAREST) = every second pixel (matcher.py:257-264)
@@ -325,8 +323,7 @@ class StripBatchMatcher:
         if self.cds == 1:
             self.d_dogf_view = self.d_dogc        # matcher.py:315-317: same image when fine == coarse
             return
-        _lib.check(lib.fb_dog_dev(ctx, strips0, 0, n, H, W, self.sigma, None, 1, self.d_dogf.ptr))
-        _lib.check(lib.fb_dog_dev(ctx, strips1, 0, n, H, W, self.sigma, None, 1, self.d_dogf.offset(n * H * W * 4)))
+        _lib.check(lib.fb_dog_pair_dev(ctx, strips0, strips1, 0, n, H, W, self.sigma, 1, self.d_dogf.ptr))
         if masks is not None:
             for side, (strips, mlist) in enumerate(((strips0, masks[0]), (strips1, masks[1]))):
                 for p, mk in enumerate(mlist):

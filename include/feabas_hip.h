@@ -158,6 +158,10 @@ int fb_dog_masks_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int 
  * images [N][H2][W2] in one kernel: the 2 x 2 cells are averaged in the DoG's loader, the coarse image is never written.
  * out float32 [N][half_size(H2)][half_size(W2)], half_size = cvRound(n / 2). */
 int fb_dog_down2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H2, int W2, double sigma, int signed_out, float* out);
+/* the two strip stacks of a batch of pairs (matcher.py:273-274, 336-337: both images of a pair get the same filter) in ONE
+ * launch: images 0 .. N-1 from img0, N .. 2N-1 from img1, out [2N] */
+int fb_dog_pair_dev(fb_ctx* ctx, const void* img0, const void* img1, int dtype, int N, int H, int W, double sigma, int signed_out, float* out);
+int fb_dog_down2_pair_dev(fb_ctx* ctx, const uint8_t* img0, const uint8_t* img1, int N, int H2, int W2, double sigma, int signed_out, float* out);
 
 /* mask[i] &= (lo <= img[i] <= hi) on device arrays: the `mask_range` of MeshRenderer.crop_multiple (renderer.py:634-637),
  * applied to the rendered stack before its masked DoG */

@@ -279,3 +279,32 @@ def test_dog_of_the_half_resolution_image_in_one_kernel(fb):
         ref = ncc_ref.masked_dog_filter(ncc_ref.area_downsample2(img[0]), s)
         assert np.abs(got[0] - ref).max() <= 1e-5 * np.abs(ref).max()
         d_in.free(); d_out.free()
+
+
+def test_dog_of_two_stacks_in_one_launch(fb):
+    """fb_dog_pair_dev / fb_dog_down2_pair_dev: the two strip stacks of a batch of pairs filtered by one launch (images N .. 2N-1
+    come from the second stack) -- bit-identical to a launch per stack, whatever row segments the larger launch is cut into"""
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(18)
+    for (n, h, w, s) in ((5, 4096, 510, 2.5), (3, 510, 4096, 2.5), (2, 511, 1021, 1.25), (40, 300, 120, 2.5)):
+        a = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8); b = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+        da = _lib.DeviceBuffer.from_array(a); db = _lib.DeviceBuffer.from_array(b)
+        d_out = _lib.DeviceBuffer(2 * n * h * w * 4)
+        _lib.check(lib.fb_dog_pair_dev(ctx, da.ptr, db.ptr, 0, n, h, w, s, 1, d_out.ptr))
+        got = d_out.to_array((2, n, h, w), np.float32)
+        np.testing.assert_array_equal(got[0], fb.common.masked_dog_filter(a, s)); np.testing.assert_array_equal(got[1], fb.common.masked_dog_filter(b, s))
+        # float32 input
+        fa = a.astype(np.float32) * 0.5; fb_ = b.astype(np.float32) * 0.25
+        dfa = _lib.DeviceBuffer.from_array(fa); dfb = _lib.DeviceBuffer.from_array(fb_)
+        _lib.check(lib.fb_dog_pair_dev(ctx, dfa.ptr, dfb.ptr, 1, n, h, w, s, 1, d_out.ptr))
+        got = d_out.to_array((2, n, h, w), np.float32)
+        np.testing.assert_array_equal(got[0], fb.common.masked_dog_filter(fa, s)); np.testing.assert_array_equal(got[1], fb.common.masked_dog_filter(fb_, s))
+        # the x0.5 form
+        hs, ws = fb.common.half_size(h), fb.common.half_size(w)
+        _lib.check(lib.fb_dog_down2_pair_dev(ctx, da.ptr, db.ptr, n, h, w, 1.25, 1, d_out.ptr))
+        got = d_out.to_array((2 * n * hs * ws,), np.float32).reshape(2, n, hs, ws)
+        for k, src in enumerate((a, b)):
+            np.testing.assert_array_equal(got[k], fb.common.masked_dog_filter(fb.common.area_downsample2(src), 1.25))
+        for buf in (da, db, dfa, dfb, d_out):
+            buf.free()
