@@ -887,6 +887,23 @@ def main():
             roof['traffic_source'] = 'profiles/' + os.path.basename(tfile[-1])
             roof['kernel_symbols'] = [k_ for k_ in tk if k_ in syms]
     roof['per_kernel_gbs'] = {k_: round(v[2] / (v[1] * 1e-3) / 1e9, 1) for k_, v in prof.items() if v[1] > 0 and v[2] > 0}
+    if rank == 0:
+        # what a plain streaming kernel reaches on THIS device at the read : write mixes of the NCC passes (fb_hbm_probe, 1 GiB per
+        # stream): `peak` above is the data-sheet read figure the contract asks for; the column and row passes write twice what they
+        # read, the inverse pass only reads
+        cal = {}
+        for name, (nr, nw) in (('read', (1, 0)), ('copy_1r_1w', (1, 1)), ('1r_2w', (1, 2)), ('write', (0, 1))):
+            gbs = C.c_double()
+            if lib.fb_hbm_probe(ctx, nr, nw, C.byref(gbs)) == 0:
+                cal[name] = round(gbs.value, 1)
+        if cal:
+            mix = {'ncc_stream_cols': '1r_2w', 'ncc_stream_rows': '1r_2w', 'ncc_stream_inv': 'read', 'dog_fast': 'write', 'ncc_small_fused': 'read'}
+            roof['hbm_calibration_gbs'] = cal
+            roof['hbm_calibration_note'] = ('plain streaming kernels, 1 GiB per stream, measured in this run; frac_of_calibrated = achieved / the rate '
+                                            'of the mix the dominant kernel has (ncc_cols: reads 16 S_h, writes 16 S = 1 : 2)')
+            if dom[0] in mix and mix[dom[0]] in cal and roof.get('achieved'):
+                roof['frac_of_calibrated'] = roof['achieved'] / cal[mix[dom[0]]]
+            roof['per_kernel_frac_of_calibrated'] = {k_: round(v / cal[mix[k_]], 3) for k_, v in roof['per_kernel_gbs'].items() if k_ in mix and mix[k_] in cal}
 
     line = dict(metric='tile_pair_ncc_matches_per_s', value=pairs / dt, unit='pairs/s', n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='weak',

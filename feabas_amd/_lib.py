@@ -105,6 +105,7 @@ _PROTOS = {
     'fb_deformed_block_affines': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_d, c_p, c_p, c_p, c_p]),
     'fb_deformed_exact_field': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     'fb_deformed_locate': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    'fb_hbm_probe': (c_i, [c_p, c_i, c_i, c_p]),
     'fb_strip_matcher_create': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     'fb_strip_matcher_create_ragged': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_strip_matcher_destroy': (None, [c_p, c_p]),

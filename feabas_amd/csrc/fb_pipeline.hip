@@ -67,9 +67,60 @@ __global__ void synth_strips_kernel(int P, int pair0, int H, int W, uint32_t see
     }
 }
 
+// plain streaming kernel: every element is read from NR streams and written to NW streams (unit stride across the grid)
+template <int NR, int NW>
+__global__ __launch_bounds__(256) void hbm_mix_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float4 acc = make_float4(1.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { const float4 v = src[(size_t)r * n + i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dst[(size_t)w * n + i] = make_float4(acc.x + w, acc.y, acc.z, acc.w);
+        if (NW == 0 && acc.x == -12345.f) dst[i] = acc;         // keeps the loads of a read-only run alive
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// Calibration of the HBM roofline: the rate a plain streaming kernel reaches on this device at a given mix of read and
+// write streams (nr : nw in {1:0, 2:1, 1:1, 1:2, 0:1}), 1 GiB per stream.  The data-sheet 8 TB/s is a read figure; the
+// NCC passes write as much as or twice what they read.  Not a reference function (bench.py reports it beside `roofline`).
+int fb_hbm_probe(fb_ctx* ctx, int nr, int nw, double* gbs) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, gbs && nr >= 0 && nr <= 2 && nw >= 0 && nw <= 2 && nr + nw > 0);
+    const size_t n = (size_t)64 << 20;
+    float4 *src = nullptr, *dst = nullptr;
+    FB_HIP(ctx, hipMalloc((void**)&src, n * 16 * 2));
+    if (hipMalloc((void**)&dst, n * 16 * 2) != hipSuccess) { hipFree(src); return fb_fail(ctx, FB_ERR_NOMEM, "fb_hbm_probe: hipMalloc"); }
+    hipMemsetAsync(src, 0, n * 16 * 2, ctx->stream);
+    hipMemsetAsync(dst, 0, n * 16 * 2, ctx->stream);
+    auto launch = [&]() {
+        const dim3 grid(256 * 16), block(256);
+        if (nr == 1 && nw == 0) hipLaunchKernelGGL((hbm_mix_kernel<1, 0>), grid, block, 0, ctx->stream, src, dst, n);
+        else if (nr == 2 && nw == 0) hipLaunchKernelGGL((hbm_mix_kernel<2, 0>), grid, block, 0, ctx->stream, src, dst, n);
+        else if (nr == 2 && nw == 1) hipLaunchKernelGGL((hbm_mix_kernel<2, 1>), grid, block, 0, ctx->stream, src, dst, n);
+        else if (nr == 1 && nw == 1) hipLaunchKernelGGL((hbm_mix_kernel<1, 1>), grid, block, 0, ctx->stream, src, dst, n);
+        else if (nr == 1 && nw == 2) hipLaunchKernelGGL((hbm_mix_kernel<1, 2>), grid, block, 0, ctx->stream, src, dst, n);
+        else if (nr == 2 && nw == 2) hipLaunchKernelGGL((hbm_mix_kernel<2, 2>), grid, block, 0, ctx->stream, src, dst, n);
+        else if (nr == 0 && nw == 1) hipLaunchKernelGGL((hbm_mix_kernel<0, 1>), grid, block, 0, ctx->stream, src, dst, n);
+        else hipLaunchKernelGGL((hbm_mix_kernel<0, 2>), grid, block, 0, ctx->stream, src, dst, n);
+    };
+    launch();
+    hipEventRecord(ctx->t0, ctx->stream);
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) launch();
+    hipEventRecord(ctx->t1, ctx->stream);
+    hipError_t e = hipEventSynchronize(ctx->t1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
+    hipFree(src); hipFree(dst);
+    if (e != hipSuccess) return fb_fail(ctx, FB_ERR_HIP, "fb_hbm_probe: %s", hipGetErrorString(e));
+    *gbs = (double)reps * n * 16.0 * (nr + nw) / (ms * 1e-3) / 1e9;
+    return FB_OK;
+}
+
 
 int fb_synth_strips_dev(fb_ctx* ctx, int P, int pair0, int H, int W, uint32_t seed, int max_shift, int shift_step, float warp,
                         uint8_t* strips0, uint8_t* strips1, int* shifts_dev) {

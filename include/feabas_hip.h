@@ -209,6 +209,10 @@ int fb_mesh_render_blocks_dev(fb_ctx* ctx, const void* img, int dtype, int IH, i
 int fb_remap_dev(fb_ctx* ctx, const float* imgs, int IH, int IW, int N, const int* img_id, int h, int w, const float* map_x,
                  const float* map_y, const uint8_t* mask, const int* origin, float* out);
 
+/* Calibration of the HBM roofline (bench support, not a reference function): GB/s of a plain streaming kernel reading nr
+ * and writing nw unit-stride streams of 1 GiB each (nr, nw in 0..2).  The 8 TB/s of the data sheet is a read figure; the NCC
+ * passes write as much as or twice what they read. */
+int fb_hbm_probe(fb_ctx* ctx, int nr, int nw, double* gbs);
 /* Synthetic overlap strips for benchmarks (not a reference function): pair p gets an integer
  * offset (sx, sy), multiples of shift_step in [-max_shift, max_shift]^2, derived from (seed, pair0 + p); strips0/strips1 are
  * uint8 [P][H][W] with strips1(x, y) = texture(x + sx + wx, y + sy + wy), (wx, wy) a smooth warp of amplitude `warp` px
