@@ -12,7 +12,8 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfeabas_hip.so')
+# FEABAS_HIP_LIB: an A/B build of the library (tools/build_variant.sh); never needed in production
+LIB_PATH = os.path.abspath(os.environ['FEABAS_HIP_LIB']) if os.environ.get('FEABAS_HIP_LIB') else os.path.join(_HERE, 'libfeabas_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'feabas_hip.h')
 
 

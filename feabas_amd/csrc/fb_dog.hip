@@ -452,27 +452,75 @@ int launch_fast(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int 
 // the bottom (D[y > H-1] = D[H-1]).
 constexpr int SCH = 8;     // rows per chunk
 constexpr int SRN = 8;     // outputs per horizontal run
+#ifndef FB_DOG_FIL
+#define FB_DOG_FIL 2
+#endif
+constexpr int FIL = FB_DOG_FIL;   // outputs whose accumulators are interleaved
+#ifndef FB_DOG_R4
+#define FB_DOG_R4 10
+#endif
 
 __host__ __device__ constexpr int spitch(int cols) { int p = (cols + 3) / 4 * 4; return (p / 4) % 2 ? p : p + 4; }     // pitch / 4 odd
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// Packed-FP32 form of the 1-D pass (v_pk_fma_f32: two multiply-adds per lane and instruction; the scalar v_fma_f32 runs at
+// half the FP32 rate of the chip).  Values sit in aligned pairs p[i] = (x[2i], x[2i+1]); an output o[j] = sum_i w[i] x[j+i],
+// i = 0 .. 2R, w[i] = tap |i - R|, is accumulated over TAP PAIRS, so that every operand is an aligned pair whatever the
+// parity of j:
+//   j = 2a      acc  = sum_m (w[2m],   w[2m+1]) * p[a+m],     m < R;   o = acc.x + acc.y + w[2R] x[j+2R]   (= p[a+R].x)
+//   j = 2a + 1  acc  = sum_m (w[2m+1], w[2m+2]) * p[a+1+m],   m < R;   o = acc.x + acc.y + w[0]  x[j]      (= p[a].y)
+// R + 2 instructions per output instead of 2R + 1.  The two pair tables and the edge tap are kernel arguments (SGPR pairs).
+typedef float f2 __attribute__((ext_vector_type(2)));
 template <int R>
-__device__ __forceinline__ float fir1(const float* w, const TapsF& t) {           // w[0 .. 2R], centre w[R]
-    float acc = w[R] * t.w[0];
+struct TapsP { f2 we[R], wo[R]; float w0; };
+
+// NO outputs (NO even) from the R + NO / 2 pairs p[]: o[j] = sum_i w[i] x[j + i].  The tap-pair loop is the OUTER loop, so that
+// consecutive packed multiply-adds are independent (a dependent v_pk_fma_f32 chain costs a wait state per link).
+template <int R, int NO>
+__device__ __forceinline__ void fir_run_pk(const f2* p, const TapsP<R>& t, float* o) {
+    f2 acc[NO];
 #pragma unroll
-    for (int k = R; k >= 1; --k) acc = fmaf(w[R - k] + w[R + k], t.w[k], acc);
-    return acc;
+    for (int a = 0; a < NO / 2; ++a) { acc[2 * a] = p[a] * t.we[0]; acc[2 * a + 1] = p[a + 1] * t.wo[0]; }
+#pragma unroll
+    for (int m = 1; m < R; ++m) {
+#pragma unroll
+        for (int a = 0; a < NO / 2; ++a) {
+            acc[2 * a] = __builtin_elementwise_fma(p[a + m], t.we[m], acc[2 * a]);
+            acc[2 * a + 1] = __builtin_elementwise_fma(p[a + 1 + m], t.wo[m], acc[2 * a + 1]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NO / 2; ++a) {
+        o[2 * a] = fmaf(p[a + R].x, t.w0, acc[2 * a].x) + acc[2 * a].y;
+        o[2 * a + 1] = fmaf(p[a].y, t.w0, acc[2 * a + 1].y) + acc[2 * a + 1].x;
+    }
+}
+// the same in groups of IL outputs (IL / 2 pairs of accumulators live at a time)
+template <int R, int NO, int IL>
+__device__ __forceinline__ void fir_run_pk_il(const f2* p, const TapsP<R>& t, float* o) {
+#pragma unroll
+    for (int g = 0; g < NO / IL; ++g) fir_run_pk<R, IL>(p + g * IL / 2, t, o + g * IL);
+}
+template <int R>
+inline TapsP<R> pack_taps(const Taps& taps) {
+    float w[2 * R + 1];
+    for (int i = 0; i <= 2 * R; ++i) w[i] = (float)taps.w[i < R ? R - i : i - R];
+    TapsP<R> t;
+    for (int m = 0; m < R; ++m) { t.we[m] = (f2){w[2 * m], w[2 * m + 1]}; t.wo[m] = (f2){w[2 * m + 1], w[2 * m + 2]}; }
+    t.w0 = w[0];
+    return t;
 }
 
 // DS2: `img` is the FULL-resolution uint8 stack [N][H2][W2] and the filtered image is its x0.5 area downsample
 // (cv2.resize(fx = fy = 0.5, INTER_AREA), the rule of area_down2_kernel): the 2 x 2 cells are averaged in the loader, so the
 // coarse image of matcher.py:255-256 is never written (SH, SW = half_size(H2), half_size(W2))
 template <typename T, int R, int NT, bool DS2 = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 : (R <= 12 ? 3 : 2)))) void dog_stream(const T* __restrict__ img, float* __restrict__ out, int SH, int SW, int signed_out,
-                                                const int* __restrict__ sizes, const TapsF taps, int TX, int SY, int H2 = 0, int W2 = 0,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= FB_DOG_R4 ? 4 : (R <= 12 ? 3 : 2)))) void dog_stream(const T* __restrict__ img, float* __restrict__ out, int SH, int SW, int signed_out,
+                                                const int* __restrict__ sizes, const TapsP<R> taps, int TX, int SY, int H2 = 0, int W2 = 0,
                                                 const T* __restrict__ img1 = nullptr, int nsplit = 0x7fffffff) {
     constexpr int CH = SCH, RN = SRN;
+    static_assert(CH % 2 == 0 && RN % 2 == 0, "pairs");
     constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
     constexpr int NQ = (RN + 2 * R + 3) / 4;               // float4 reads per horizontal run (over-reads up to 3 staged values)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -504,10 +552,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 
     const int gx_a = min(max(x0 - 2 * R + tid, 0), W - 1), gx_b = min(max(x0 - 2 * R + tid + NT, 0), W - 1);
     const bool ld_b = tid + NT < NIN;
     const int nr1 = NA / RN, nr2 = (bw + RN - 1) / RN;
-    const bool h1_on = tid < CH * nr1, h2_on = tid < CH * nr2, v_on = tid < NV;
-    const int r1 = tid / nr1, u1 = tid - r1 * nr1, r2 = tid / nr2, u2 = tid - r2 * nr2;
+    // horizontal sweeps: 16 consecutive lanes = 8 consecutive runs x 2 consecutive rows.  A run starts every 32 B and the row
+    // pitch is an odd multiple of 16 B, so the sixteen 16-byte reads of every lane group of a ds_read_b128
+    // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) fall on sixteen different bank quads: no conflicts (lanes in run
+    // order on one row conflict two ways)
+    const int r1 = 2 * ((tid >> 4) % (CH / 2)) + ((tid >> 3) & 1), u1 = 8 * ((tid >> 4) / (CH / 2)) + (tid & 7), r2 = r1, u2 = u1;
+    const bool h1_on = u1 < nr1, h2_on = u1 < nr2, v_on = tid < NV;
     const int cxv = min(max(x0 - R + tid, 0), W - 1) - (x0 - R);     // clamped column (index in A / E space) of the vertical thread
-    float wA[2 * R], dI[R], wD[2 * R], dlast = 0.f;
+    f2 wA[R], wD[R];                                            // the last 2R rows of A and D of the thread's column, as row pairs
+    float dI[R], dlast = 0.f;
     float pa[CH], pb[CH];
     // LDS offsets of the thread's items (floats): every access below is one of these plus an immediate
     const int o1r = r1 * PI + u1 * RN, o1w = r1 * PA + u1 * RN, o2r = r2 * PE + u2 * RN;
@@ -575,21 +628,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 
             for (int r = 0; r < CH; ++r) dst[r * PI + NT] = pb[r];
         }
     };
+    // input rows of chunk c + 2 are requested between the vertical phase of chunk c and its output sweep and staged after the
+    // first sweep of chunk c + 1: in flight over two sweeps, and not live in registers during the vertical phase (the register peak)
     fetch(0);
     stage(0);
     __syncthreads();
+    if (nch > 1) fetch(1);
     for (int c = 0; c < nch; ++c) {
         const float* in = In + (c & 1) * CH * PI;
-        if (c + 1 < nch) fetch(c + 1);
         // ---- A = Gx I: RN outputs from RN + 2R staged values
         if (h1_on) {
-            float v[4 * NQ];
+            f2 v[2 * NQ];
             const float4* p4 = reinterpret_cast<const float4*>(in + o1r);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { const float4 f = p4[q]; v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
+            for (int q = 0; q < NQ; ++q) { const float4 f = p4[q]; v[2 * q] = (f2){f.x, f.y}; v[2 * q + 1] = (f2){f.z, f.w}; }
             float o[RN];
-#pragma unroll
-            for (int j = 0; j < RN; ++j) o[j] = fir1<R>(v + j, taps);
+            fir_run_pk_il<R, RN, FIL>(v, taps, o);
             float4* d4 = reinterpret_cast<float4*>(A + o1w);
             d4[0] = make_float4(o[0], o[1], o[2], o[3]);
             d4[1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -598,53 +652,64 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 4 
         __syncthreads();
         // ---- B = Gy A, D = I - B, E = Gy D on the thread's column
         if (v_on) {
-            float fa[2 * R + CH], fi[R + CH], fd[2 * R + CH];
+            f2 fa[R + CH / 2], fd[R + CH / 2];                               // row pairs: fa[i] = rows (2i, 2i + 1) of the window
+            float fi[R + CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) { fa[2 * R + j] = A[j * PA + cxv]; fi[R + j] = in[j * PI + cxv + R]; }
+            for (int j = 0; j < CH; ++j) { fa[R + j / 2][j & 1] = A[j * PA + cxv]; fi[R + j] = in[j * PI + cxv + R]; }
             if (c == 0) {
 #pragma unroll
-                for (int i = 0; i < 2 * R; ++i) wA[i] = fa[2 * R];          // rows above the first fed row: replicas (exact at the image top)
+                for (int i = 0; i < R; ++i) wA[i] = fa[R].xx;               // rows above the first fed row: replicas (exact at the image top)
 #pragma unroll
                 for (int i = 0; i < R; ++i) dI[i] = fi[R];
 #pragma unroll
-                for (int i = 0; i < 2 * R; ++i) wD[i] = 0.f;
+                for (int i = 0; i < R; ++i) wD[i] = (f2){0.f, 0.f};
             }
 #pragma unroll
-            for (int i = 0; i < 2 * R; ++i) { fa[i] = wA[i]; fd[i] = wD[i]; }
+            for (int i = 0; i < R; ++i) { fa[i] = wA[i]; fd[i] = wD[i]; }
 #pragma unroll
             for (int i = 0; i < R; ++i) fi[i] = dI[i];
             const int rD0 = a0 + c * CH - R;                                 // image row of D[0] of this chunk
+            {
+                float bv[CH];
+                fir_run_pk_il<R, CH, FIL>(fa, taps, bv);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const float d = fi[j] - fir1<R>(fa + j, taps);
-                dlast = (rD0 + j <= H - 1) ? d : dlast;                      // D[y > H-1] = D[H-1]
-                fd[2 * R + j] = dlast;
+                for (int j = 0; j < CH; ++j) {
+                    const float d = fi[j] - bv[j];
+                    dlast = (rD0 + j <= H - 1) ? d : dlast;                  // D[y > H-1] = D[H-1]
+                    fd[R + j / 2][j & 1] = dlast;
+                }
             }
             if (top && c == R / CH) {
                 // the image's first row of D has just been computed: every row above it is its replica
-                const float d0 = fd[2 * R + R % CH];
+                const float d0 = fd[R + (R % CH) / 2][(R % CH) & 1];
 #pragma unroll
-                for (int i = 0; i < 2 * R + R % CH; ++i) fd[i] = d0;
+                for (int i = 0; i < 2 * R + R % CH; ++i) fd[i / 2][i & 1] = d0;
+            }
+            {
+                float ev[CH];
+                fir_run_pk_il<R, CH, FIL>(fd, taps, ev);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) E[j * PE + tid] = ev[j];
             }
 #pragma unroll
-            for (int j = 0; j < CH; ++j) E[j * PE + tid] = fir1<R>(fd + j, taps);
-#pragma unroll
-            for (int i = 0; i < 2 * R; ++i) { wA[i] = fa[CH + i]; wD[i] = fd[CH + i]; }
+            for (int i = 0; i < R; ++i) { wA[i] = fa[CH / 2 + i]; wD[i] = fd[CH / 2 + i]; }
 #pragma unroll
             for (int i = 0; i < R; ++i) dI[i] = fi[CH + i];
         }
         __syncthreads();
+        if (c + 2 < nch) fetch(c + 2);
         // ---- out = Gx E, rows a0 + c CH - 2R + r
         if (h2_on) {
             const int gy = a0 + c * CH - 2 * R + r2;
             if (gy >= y0 && gy < ye) {
-                float v[4 * NQ];
+                f2 v[2 * NQ];
                 const float4* p4 = reinterpret_cast<const float4*>(E + o2r);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) { const float4 f = p4[q]; v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
+                for (int q = 0; q < NQ; ++q) { const float4 f = p4[q]; v[2 * q] = (f2){f.x, f.y}; v[2 * q + 1] = (f2){f.z, f.w}; }
                 float o[RN];
+                fir_run_pk_il<R, RN, FIL>(v, taps, o);
 #pragma unroll
-                for (int j = 0; j < RN; ++j) o[j] = __uint_as_float(__float_as_uint(fir1<R>(v + j, taps)) & absmask);
+                for (int j = 0; j < RN; ++j) o[j] = __uint_as_float(__float_as_uint(o[j]) & absmask);
                 const int gx = x0 + u2 * RN;
                 float* d = oimg + (uint32_t)(gy * SW + gx);
                 if (gx + RN <= x0 + bw) {                  // a whole run inside the band (the last run of a band may hang over into the next one)
@@ -679,7 +744,9 @@ inline StreamPlan plan_stream(int N, int H, int W, int R, int num_cu) {
     for (int NT : {64, 192}) {
         const int txmax = NT - 2 * R;
         if (txmax < 16) continue;
-        const int nb = (W + txmax - 1) / txmax, TX = (W + nb - 1) / nb;
+        // TX even: the tap pairing of an output follows the parity of its position in the band (fir_run_pk), and a pixel's
+        // value must not depend on how a launch cuts the image into bands (a slot of another width, a stack of two strips)
+        const int nb = (W + txmax - 1) / txmax, TX = ((W + nb - 1) / nb + 1) & ~1;
         // thread slots per chunk of 8 rows: two horizontal sweeps + two vertical passes of NT threads each
         const double per_px = (double)nb * NT / W;
         const double cost = per_px * (NT == 64 ? 1.08 : 1.0);            // small workgroups pay a little more per barrier / prologue
@@ -703,7 +770,7 @@ inline StreamPlan plan_stream(int N, int H, int W, int R, int num_cu) {
 }
 
 template <int R, int NT>
-int launch_stream_ds2_nt(fb_ctx* ctx, const uint8_t* img, float* out, int N, int H2, int W2, int signed_out, const TapsF& tf, const StreamPlan& pl) {
+int launch_stream_ds2_nt(fb_ctx* ctx, const uint8_t* img, float* out, int N, int H2, int W2, int signed_out, const TapsP<R>& tf, const StreamPlan& pl) {
     constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
     const size_t lds = (size_t)(2 * SCH * PI + SCH * PA + SCH * PE) * sizeof(float);
     auto kern = dog_stream<uint8_t, R, NT, true>;
@@ -717,8 +784,7 @@ int launch_stream_ds2_nt(fb_ctx* ctx, const uint8_t* img, float* out, int N, int
 
 template <int R>
 int launch_stream_ds2(fb_ctx* ctx, const uint8_t* img, float* out, int N, int H2, int W2, int signed_out, const Taps& taps) {
-    TapsF tf;
-    for (int k = 0; k <= kMaxRadius; ++k) tf.w[k] = (float)taps.w[k];
+    const TapsP<R> tf = pack_taps<R>(taps);
     if ((size_t)H2 * W2 >= ((size_t)1 << 30) || N > 65535) return fb_fail(ctx, FB_ERR_ARG, "fb_dog_down2_dev: stack too large for one launch");
     const StreamPlan pl = plan_stream(N, half_size(H2), half_size(W2), R, ctx->prop.multiProcessorCount);
     if (pl.NT == 64) return launch_stream_ds2_nt<R, 64>(ctx, img, out, N, H2, W2, signed_out, tf, pl);
@@ -726,7 +792,7 @@ int launch_stream_ds2(fb_ctx* ctx, const uint8_t* img, float* out, int N, int H2
 }
 
 template <typename T, int R, int NT>
-int launch_stream_nt(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const TapsF& tf, const int* sizes, const StreamPlan& pl) {
+int launch_stream_nt(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const TapsP<R>& tf, const int* sizes, const StreamPlan& pl) {
     constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
     const size_t lds = (size_t)(2 * SCH * PI + SCH * PA + SCH * PE) * sizeof(float);
     auto kern = dog_stream<T, R, NT>;
@@ -740,8 +806,7 @@ int launch_stream_nt(fb_ctx* ctx, const T* img, float* out, int N, int H, int W,
 
 template <typename T, int R>
 int launch_stream(fb_ctx* ctx, const T* img, float* out, int N, int H, int W, int signed_out, const Taps& taps, const int* sizes) {
-    TapsF tf;
-    for (int k = 0; k <= kMaxRadius; ++k) tf.w[k] = (float)taps.w[k];
+    const TapsP<R> tf = pack_taps<R>(taps);
     if ((size_t)H * W >= ((size_t)1 << 30)) return fb_fail(ctx, FB_ERR_ARG, "fb_dog: image of %d x %d pixels exceeds the 32-bit offsets of the fast kernel", H, W);
     if (N > 65535) return fb_fail(ctx, FB_ERR_ARG, "fb_dog: more than 65535 images in one launch");
     const StreamPlan pl = plan_stream(N, H, W, R, ctx->prop.multiProcessorCount);
