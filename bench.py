@@ -232,6 +232,10 @@ def bench_xcorr_classes(lib, ctx, _lib):
     rng = np.random.default_rng(1)
     for name, (N, h, w, pad, sub) in {'fine_75x73_fft75x75': (24640, 75, 73, 0, 1), 'coarse_1024x510_fft2048x1024': (128, 1024, 510, 1, 0),
                                       'global_2048x255_fft4096x512': (32, 2048, 255, 1, 0),
+                                      # alignment block classes (default_alignment_configs.yaml:16-23: spacings [400, 100] x 0.7) and the
+                                      # README stitching grid, all padded: compile-time mixed-radix streaming kernels (fb_ncc_ct.hip)
+                                      'align_280x280_fft576x576': (1024, 280, 280, 1, 1), 'align_70x70_fft144x144': (1024, 70, 70, 1, 1),
+                                      'readme_74x72_fft150x144_run_at_160x144': (1024, 74, 72, 1, 1), 'readme_67x75_fft135x150_run_at_144x160': (1024, 67, 75, 1, 1),
                                       # literal stress variant of SURVEY.md sec.8d: whole 4096 x 4096 tiles
                                       'full_4096x4096_fft4096x4096': (4, 4096, 4096, 0, 1), 'full_4096x4096_fft8192x8192_padded': (4, 4096, 4096, 1, 1)}.items():
         a = rng.standard_normal((min(N, 256), h, w)).astype(np.float32)

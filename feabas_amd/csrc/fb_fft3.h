@@ -77,12 +77,24 @@ __device__ __forceinline__ void pk_dft_any(f2* v) {
 constexpr int p3_pick(int m, int maxr) {
     if (maxr == 9)           // the plans of fft_make_plan(., ., 9): 8, 9, then 4 / 2 / 5 / 3
         return (m % 8 == 0) ? 8 : (m % 9 == 0) ? 9 : (m % 4 == 0) ? 4 : (m % 2 == 0) ? 2 : (m % 5 == 0) ? 5 : 3;
+    if (maxr == 17)          // the plans of fft_make_plan(., ., 17), streaming class: 16, 9, 8, then 4 / 2 / 5 / 3 (576 = 16 x 9 x 4, 144 = 16 x 9)
+        return (m % 16 == 0) ? 16 : (m % 9 == 0) ? 9 : (m % 8 == 0) ? 8 : (m % 4 == 0) ? 4 : (m % 2 == 0) ? 2 : (m % 5 == 0) ? 5 : 3;
     return (maxr >= 16 && m % 16 == 0) ? 16 : (maxr >= 8 && m % 8 == 0) ? 8 : (m % 4 == 0) ? 4 : (m % 2 == 0) ? 2 : (m % 5 == 0) ? 5 : 3;
 }
 constexpr int p3_nf(int N, int maxr) { int m = N, c = 0; while (m > 1) { m /= p3_pick(m, maxr); ++c; } return c; }
 constexpr int p3_len(int N, int maxr, int s) { int m = N; for (int i = 0; i < s; ++i) m /= p3_pick(m, maxr); return m; }   // L of pass s
 constexpr int p3_radix(int N, int maxr, int s) { return p3_pick(p3_len(N, maxr, s), maxr); }
 constexpr bool p3_smooth(int N) { int m = N; while (m % 2 == 0) m /= 2; while (m % 3 == 0) m /= 3; while (m % 5 == 0) m /= 5; return m == 1 && N >= 2; }
+
+// position of frequency k in the digit-reversed output of the forward transform of plan (N, MAXR)
+template <int N, int MAXR, int S = 0>
+__device__ __forceinline__ int p3_pos(int k) {
+    if constexpr (S >= p3_nf(N, MAXR)) return 0;
+    else {
+        constexpr int r = p3_radix(N, MAXR, S), stride = p3_len(N, MAXR, S) / r;
+        return (k % r) * stride + p3_pos<N, MAXR, S + 1>(k / r);
+    }
+}
 
 template <int N, int R, int L, bool INV, bool COLS>
 __device__ __forceinline__ void p3_pass(f2* base, int M, int stride, const f2* tw, float inv_M, int tid, int nt) {

@@ -31,6 +31,11 @@ static inline bool fft_make_plan(int n, FftPlan* p, int max_radix = 16) {
         while (m % 9 == 0) { p->radix[p->nf++] = 9; m /= 9; if (p->nf >= kFftMaxFactors) return false; }
         max_radix = 4;
     }
+    if (max_radix == 17) {          // compile-time streaming class (fb_ncc_ct.hip, p3_pick(., 17)): 16, 9, 8, then 4 / 2 / 5 / 3
+        while (m % 16 == 0) { p->radix[p->nf++] = 16; m /= 16; if (p->nf >= kFftMaxFactors) return false; }
+        while (m % 9 == 0) { p->radix[p->nf++] = 9; m /= 9; if (p->nf >= kFftMaxFactors) return false; }
+        max_radix = 8;
+    }
     while (max_radix >= 16 && m % 16 == 0) { p->radix[p->nf++] = 16; m /= 16; if (p->nf >= kFftMaxFactors) return false; }
     while (max_radix >= 8 && m % 8 == 0) { p->radix[p->nf++] = 8; m /= 8; if (p->nf >= kFftMaxFactors) return false; }
     while (m % 4 == 0) { p->radix[p->nf++] = 4; m /= 4; if (p->nf >= kFftMaxFactors) return false; }

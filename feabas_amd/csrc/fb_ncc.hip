@@ -4,6 +4,7 @@
 #include "fb_common.h"
 #include "fb_ldsfft.h"
 #include "fb_fft2.h"
+#include "fb_ncc_stream.h"
 
 #include <algorithm>
 #include <cmath>
@@ -16,15 +17,6 @@ namespace {
 
 constexpr int kPeakChunks = 64;   // partial reductions per surface
 constexpr int kThreads = 256;
-
-struct PeakPartial {
-    float vmax;      // max of C in the chunk
-    int imax;        // first index achieving it
-    float mmax;      // max |Cm|
-    int pad_;
-    double sum;      // sum C      (STD confidence)
-    double sumsq;    // sum C^2
-};
 
 // img [n][H][W] -> R [n][Fh][Fw], zero padded bottom/right (rfft2(s=...), matcher.py:63-64)
 __global__ void ncc_pad_load(const float* __restrict__ img0, const float* __restrict__ img1,
@@ -44,9 +36,6 @@ __global__ void ncc_pad_load(const float* __restrict__ img0, const float* __rest
         dst[i] = v;
     }
 }
-
-// block descriptor of the crop loader: {image, x0, y0, h0, w0, x1, y1, h1, w1}
-constexpr int kBlkStride = 9;
 
 // crop mode: block n of side `sel` is the h x w window at (x,y) of image blk[n][0] of that side's image stack,
 // zero outside the image (dal.StreamLoader fillval=0, matcher.py:342-343), zero padded to Fh x Fw.
@@ -100,10 +89,6 @@ __global__ void ncc_spectral_mul(const float2* F0, const float2* F1, float2* Pou
         Pout[i] = p;
         if (want_q) Qout[i] = q;
     }
-}
-
-__device__ __forceinline__ void peak_merge(float& v, int& i, float v2, int i2) {
-    if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
 }
 
 // stage 1: per (image, chunk) partial of max/argmax C, max|Cm|, sum, sumsq
@@ -397,20 +382,6 @@ int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
 //          max/arg-max of C, max |Cm| (the correlation surfaces are never written)
 // HBM traffic per block pair = inputs + 16 S_h (T write) + 16 S_h (T read) + 16 S (V write)
 // + 16 S (V read), S = Fh (Fw/2+1), S_h = Hs (Fw/2+1): the algorithmic minimum of SURVEY.md 8(d).
-struct StreamGeom {
-    int N, Fh, Fw, Sw, Kp, Hs, TR, TRI;   // Kp = ceil(Sw / 2): spectra are stored as interleaved column pairs
-    int H0, W0, H1, W1;
-    FftPlan pw, ph;
-    const float2 *twW_hi, *twW_lo, *twH_hi, *twH_lo;
-    const float* img0;
-    const float* img1;
-    const int* blk;
-    int IH0, IW0, IH1, IW1;
-    int want_q, want_std;
-    const double* aff;            // per block affine gather of image 1 (crop mode only) or nullptr
-};
-
-constexpr int kStreamThreads = 512;
 
 __device__ __forceinline__ void load_tw(float2* hi, float2* lo, const float2* ghi, const float2* glo) {
     for (int i = threadIdx.x; i < 64; i += blockDim.x) { hi[i] = ghi[i]; lo[i] = glo[i]; }
@@ -709,7 +680,9 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     const size_t lds_budget = (getenv("FB_TRB") ? (size_t)atoi(getenv("FB_TRB")) : 70) * 1024;
     g.TR = std::min(16, pow2_floor((int)std::max<size_t>(1, lds_budget / ((size_t)(Fw + Fw / 16 + 1) * sizeof(float2)))));
     const bool p2 = p2_shape(Fh) && p2_shape(Fw) && !getenv("FEABAS_HIP_FFT_GENERIC");
+    const bool ct = !p2 && fb_ncc_ct_len(Fh) && fb_ncc_ct_len(Fw) && !getenv("FEABAS_HIP_FFT_GENERIC");     // compile-time mixed-radix plans
     if (p2) g.TR = p2_tr(Fw);
+    if (ct) g.TR = fb_ncc_ct_tr(Fw);
     g.TRI = g.TR;
     // inverse pass on half tiles (workgroups of 256 threads, twice as many per CU: half as many waves meet at each barrier):
     // 11-13 % faster at FW <= 1024; narrower tiles would cut the contiguous runs of V below 64 B (FB_INV_HALF=0/1 overrides)
@@ -751,6 +724,16 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_inv, ((size_t)4 * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) * sizeof(short))));
     const double in_bytes = crop ? 8.0 * hmax * wmax : 4.0 * ((double)H0 * W0 + (double)H1 * W1);
     const double nq = g.want_q ? 2.0 : 1.0;
+    if (ct) {
+        rc = fb_ncc_ct_run(ctx, g, nb, T0, T1, V0, V1, part, ntiles, ct9, subpixel, in_bytes);
+        if (rc) return rc;
+        FB_PROF(ctx, "ncc_peak_final");
+        hipLaunchKernelGGL(ncc_peak_final, dim3(nb), dim3(64), 0, ctx->stream, (const float*)nullptr, part, ntiles, Fh, Fw, H0, W0, H1,
+                           W1, crop ? crop->blk : (const int*)nullptr, subpixel, conf_mode, dx, dy, conf, nb, subpixel ? ct9 : (const float*)nullptr);
+        FB_HIP(ctx, hipGetLastError());
+        ctx->last_C = nullptr; ctx->last_Cm = nullptr;
+        return FB_OK;
+    }
     P2Geom q;
     size_t lds_rows2 = 0, lds_cols2 = 0, lds_inv2 = 0, lds_n2 = 0;
     // grid: one workgroup per item by default (measured fastest: the hardware dispatcher overlaps one workgroup's loads
@@ -825,7 +808,12 @@ void promote_linear_shape(int& Fh, int& Fw, int need_h, int need_w, int conf_mod
         return (P <= 4096 && 5 * P <= 6 * F) ? P : F;
     };
     const int ph = up(Fh, need_h), pw = up(Fw, need_w);
-    if (p2_shape(ph) && p2_shape(pw)) { Fh = ph; Fw = pw; }
+    if (p2_shape(ph) && p2_shape(pw)) { Fh = ph; Fw = pw; return; }
+    // otherwise a length with a compile-time mixed-radix plan (fb_ncc_ct.hip: 2^a, 3 2^a, 5 2^a, 9 2^a) within 1.2 x, axis by
+    // axis; a circular axis must have such a length as it stands
+    auto ct = [](int F, int need) { return F < need ? (fb_ncc_ct_len(F) ? F : 0) : fb_ncc_ct_up(need, F); };
+    const int ch = ct(Fh, need_h), cw = ct(Fw, need_w);
+    if (ch && cw) { Fh = ch; Fw = cw; }
 }
 
 size_t custom_bytes_per_pair(int Fh, int Fw, int hmax) {

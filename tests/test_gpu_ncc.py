@@ -80,6 +80,36 @@ def test_xcorr_vs_oracle(fb, shape, n, pad):
         _check(got, exp)
 
 
+@pytest.mark.parametrize('s0,s1,n,pad', [
+    ((280, 280), (280, 280), 6, True),      # alignment spacing 400 x 0.7, padded: 576 x 576 = (16 x 9 x 4)^2
+    ((70, 70), (70, 70), 40, True),         # alignment spacing 100 x 0.7, padded: 144 x 144 (too large for the on-chip class)
+    ((280, 280), (280, 280), 5, False),     # the same blocks in a round without padding: 288 x 288
+    ((74, 72), (67, 75), 33, True),         # README grid: 150 x 144 runs at 160 x 144
+    ((67, 75), (74, 72), 9, True),          # ... and 144 x 160
+    ((300, 90), (280, 100), 7, True),       # unequal blocks, 579 x 189 -> 600 x 192 runs at 640 x 192
+    ((400, 130), (400, 130), 3, True),      # 799 x 259 -> 800 x 270 runs at 1024 x 288 (a power of two beside a 9 x 2^a)
+])
+def test_xcorr_compile_time_mixed_radix_class(fb, s0, s1, n, pad):
+    """the block classes of the alignment matcher (configs/default_alignment_configs.yaml:16-23, matcher.py:59-62) and of the
+    README grid run on the compile-time mixed-radix streaming kernels (fb_ncc_ct.hip), padded axes at the next length with
+    such a plan: integer peaks bit-exact, sub-pixel offsets and confidences within the bars of _check, and the same
+    answers as the run-time mixed-radix kernels at the reference's own FFT size"""
+    import os
+    rng = np.random.default_rng(s0[0] * 7 + s1[1] + n)
+    i0, i1 = _pairs(rng, n, s0, s1, maxshift=max(1, min(s0 + s1) // 4))
+    for sub in (True, False):
+        exp = ncc_ref.xcorr_fft(i0, i1, pad=pad, subpixel=sub)
+        got = fb.matcher.xcorr_fft(i0, i1, pad=pad, subpixel=sub)
+        _check(got, exp)
+        os.environ['FEABAS_HIP_FFT_GENERIC'] = '1'; os.environ['FEABAS_HIP_FFT_EXACT'] = '1'
+        try:
+            gen = fb.matcher.xcorr_fft(i0, i1, pad=pad, subpixel=sub)
+        finally:
+            del os.environ['FEABAS_HIP_FFT_GENERIC'], os.environ['FEABAS_HIP_FFT_EXACT']
+        np.testing.assert_array_equal(np.round(got[0]), np.round(gen[0])); np.testing.assert_array_equal(np.round(got[1]), np.round(gen[1]))
+        np.testing.assert_allclose(got[2], gen[2], atol=2e-5)
+
+
 def test_xcorr_streaming_class(fb):
     """coarse classes of the 4k tile pair at reduced count: 1024x510 blocks (FFT 2048x1024)
     and the 2048x255 global strip (FFT 4096x512)."""
