@@ -31,6 +31,51 @@ _lib = None
 _ctx = None
 _ctx_device = None
 
+
+def cpu_budget():
+    """CPUs this process may really use: the smaller of its affinity mask and its cgroup quota (a GPU box shows 256 logical
+    CPUs to a container whose quota is 16: pools sized by os.cpu_count() then spin their way through the quota and every
+    host thread -- the ones that feed the device included -- is throttled for tens of milliseconds at a time)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != 'max':
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def limit_host_pools():
+    """Caps the BLAS / OpenMP pools of the process at a quarter of cpu_budget() (at least 1, at most 8): numpy's OpenBLAS
+    starts one spinning thread per logical CPU it sees, and on the host side of the two paths nothing larger than a 3 x 3
+    system goes through BLAS.  Measured on a 16-CPU-quota / 256-CPU box: SLM.optimize_linear of a 500 k-DoF section 50-80 ms
+    with the default pool, 11-12 ms with it capped (tools/prof_align_section.py).  FEABAS_HIP_KEEP_POOLS=1 leaves the pools alone."""
+    if os.environ.get('FEABAS_HIP_KEEP_POOLS'):
+        return None
+    lim = max(1, min(8, cpu_budget() // 4))
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=lim)
+    except Exception:           # threadpoolctl absent: the environment variables still reach pools that start later
+        pass
+    for var in ('OPENBLAS_NUM_THREADS', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ.setdefault(var, str(lim))
+    return lim
+
+
+limit_host_pools()
+
 c_p = C.c_void_p
 c_i = C.c_int
 c_i64 = C.c_int64

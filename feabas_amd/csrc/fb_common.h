@@ -63,6 +63,13 @@ struct fb_ctx {
     int dog_nsplit = 0;
     // device buffers and relaxation systems that outlive a strip matcher (fb_match.hip): matchers of ragged batches come and
     // go with every chunk of a section, their buffers and the symbolic phase of their block-diagonal system do not
+    // pinned staging ring of the host <-> device copies (fb_copy_h2d / fb_copy_d2h): a pageable buffer HIP sees for the first
+    // time costs 8-20 ms per 4 MB to map (measured, tools/prof_h2d.py), whatever its size afterwards -- and every section, every
+    // numpy temporary is such a buffer; through the ring a copy costs one host memcpy + one DMA
+    std::mutex stage_mtx;
+    void* stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int stage_next = 0;
     std::vector<std::pair<void*, size_t>> match_pool;
     std::map<std::tuple<int, int, int>, std::vector<fb_system*>> match_systems;
 };
@@ -96,6 +103,11 @@ void fb_rocfft_release();
 
 // grow-only scratch arena
 int fb_arena_reserve(fb_ctx* ctx, size_t bytes);
+// host -> device on the context's stream through the pinned staging ring: returns when `src` may be reused (the DMA of the
+// last chunk may still be in flight, ordered on the stream like a hipMemcpyAsync from pageable memory)
+int fb_copy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
+// device -> host through the ring: returns when `dst` holds the data (everything enqueued on the stream before it has completed)
+int fb_copy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 // per-kernel profiling scope: records an event pair around a launch when enabled
 struct fb_prof_scope {

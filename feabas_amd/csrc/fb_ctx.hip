@@ -91,6 +91,71 @@ static void prof_drain(fb_ctx* ctx) {
     }
 }
 
+namespace {
+constexpr size_t kStageChunk = (size_t)4 << 20;        // bytes per slot of the staging ring
+constexpr size_t kStageDirect = (size_t)32 << 10;      // smaller copies go straight through hipMemcpyAsync (the runtime stages them itself)
+
+int stage_init(fb_ctx* ctx) {
+    if (ctx->stage[0]) return FB_OK;
+    for (int k = 0; k < 2; ++k) {
+        FB_HIP(ctx, hipHostMalloc(&ctx->stage[k], kStageChunk, hipHostMallocDefault));
+        FB_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+    }
+    return FB_OK;
+}
+}  // namespace
+
+int fb_copy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return FB_OK;
+    if (bytes <= kStageDirect) {
+        FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return FB_OK;
+    }
+    std::lock_guard<std::mutex> lk(ctx->stage_mtx);
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += kStageChunk) {
+        const size_t n = std::min(kStageChunk, bytes - off);
+        const int k = ctx->stage_next;
+        ctx->stage_next ^= 1;
+        FB_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));            // the slot's previous DMA has read it
+        memcpy(ctx->stage[k], (const char*)src + off, n);
+        FB_HIP(ctx, hipMemcpyAsync((char*)dst + off, ctx->stage[k], n, hipMemcpyHostToDevice, ctx->stream));
+        FB_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->stream));
+    }
+    return FB_OK;
+}
+
+int fb_copy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return FB_OK;
+    if (bytes <= kStageDirect) {
+        FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FB_OK;
+    }
+    std::lock_guard<std::mutex> lk(ctx->stage_mtx);
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    // chunk c + 1 is on its way while chunk c is copied out of its slot
+    size_t pend_off = 0, pend_n = 0; int pend_k = -1;
+    for (size_t off = 0; off < bytes; off += kStageChunk) {
+        const size_t n = std::min(kStageChunk, bytes - off);
+        const int k = ctx->stage_next;
+        ctx->stage_next ^= 1;
+        FB_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));
+        FB_HIP(ctx, hipMemcpyAsync(ctx->stage[k], (const char*)src + off, n, hipMemcpyDeviceToHost, ctx->stream));
+        FB_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->stream));
+        if (pend_k >= 0) {
+            FB_HIP(ctx, hipEventSynchronize(ctx->stage_ev[pend_k]));
+            memcpy((char*)dst + pend_off, ctx->stage[pend_k], pend_n);
+        }
+        pend_off = off; pend_n = n; pend_k = k;
+    }
+    FB_HIP(ctx, hipEventSynchronize(ctx->stage_ev[pend_k]));
+    memcpy((char*)dst + pend_off, ctx->stage[pend_k], pend_n);
+    return FB_OK;
+}
+
 extern "C" {
 
 const char* fb_version(void) { return "feabas_hip 0.1 (gfx950)"; }
@@ -134,6 +199,10 @@ void fb_destroy(fb_ctx* ctx) {
     if (ctx->rocfft_ready) fb_rocfft_release();
     hipEventDestroy(ctx->t0);
     hipEventDestroy(ctx->t1);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->stage[k]) hipHostFree(ctx->stage[k]);
+        if (ctx->stage_ev[k]) hipEventDestroy(ctx->stage_ev[k]);
+    }
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -236,15 +305,14 @@ int fb_free(fb_ctx* ctx, void* dptr) {
 }
 
 int fb_memcpy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
-    FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = fb_copy_h2d(ctx, dst, src, bytes);
+    if (rc) return rc;
     FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FB_OK;
 }
 
 int fb_memcpy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
-    FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FB_OK;
+    return fb_copy_d2h(ctx, dst, src, bytes);
 }
 
 int fb_memcpy_d2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {

@@ -1051,17 +1051,13 @@ int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double 
     void* din = nullptr; float* dout = nullptr; uint8_t* dmask = nullptr;
     FB_HIP(ctx, hipMalloc(&din, px * esz));
     FB_HIP(ctx, hipMalloc(&dout, px * sizeof(float)));
-    hipMemcpyAsync(din, img, px * esz, hipMemcpyHostToDevice, ctx->stream);
-    if (mask) {
+    int rc = fb_copy_h2d(ctx, din, img, px * esz);
+    if (!rc && mask) {
         FB_HIP(ctx, hipMalloc(&dmask, (size_t)H * W));
-        hipMemcpyAsync(dmask, mask, (size_t)H * W, hipMemcpyHostToDevice, ctx->stream);
+        rc = fb_copy_h2d(ctx, dmask, mask, (size_t)H * W);
     }
-    int rc = fb_dog_dev(ctx, din, dtype, N, H, W, sigma, dmask, signed_out, dout);
-    if (!rc) {
-        hipMemcpyAsync(out, dout, px * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) rc = fb_fail(ctx, FB_ERR_HIP, "fb_dog: %s", hipGetErrorString(e));
-    }
+    if (!rc) rc = fb_dog_dev(ctx, din, dtype, N, H, W, sigma, dmask, signed_out, dout);
+    if (!rc) rc = fb_copy_d2h(ctx, out, dout, px * sizeof(float));
     hipFree(din); hipFree(dout); if (dmask) hipFree(dmask);
     return rc;
 }
@@ -1106,13 +1102,9 @@ int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, ui
     uint8_t *din = nullptr, *dout = nullptr;
     FB_HIP(ctx, hipMalloc(&din, bi));
     FB_HIP(ctx, hipMalloc(&dout, bo));
-    hipMemcpyAsync(din, img, bi, hipMemcpyHostToDevice, ctx->stream);
-    int rc = fb_area_downsample2_dev(ctx, din, N, H, W, dout);
-    if (!rc) {
-        hipMemcpyAsync(out, dout, bo, hipMemcpyDeviceToHost, ctx->stream);
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) rc = fb_fail(ctx, FB_ERR_HIP, "fb_area_downsample2: %s", hipGetErrorString(e));
-    }
+    int rc = fb_copy_h2d(ctx, din, img, bi);
+    if (!rc) rc = fb_area_downsample2_dev(ctx, din, N, H, W, dout);
+    if (!rc) rc = fb_copy_d2h(ctx, out, dout, bo);
     hipFree(din); hipFree(dout);
     return rc;
 }

@@ -440,7 +440,7 @@ __global__ void form_groups_kernel(int nv, int gs, const int* __restrict__ rowpt
 template <typename T>
 int upload(fb_ctx* ctx, T** dptr, const T* host, size_t count) {
     if (!*dptr) FB_HIP(ctx, hipMalloc((void**)dptr, std::max<size_t>(16, sizeof(T) * count)));
-    if (host && count) FB_HIP(ctx, hipMemcpyAsync(*dptr, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+    if (host && count) { const int rc_ = fb_copy_h2d(ctx, *dptr, host, sizeof(T) * count); if (rc_) return rc_; }
     return FB_OK;
 }
 
@@ -470,9 +470,9 @@ static int build_link_index(fb_ctx* ctx, fb_system* s) {
         s->link_cap = (int64_t)cap;
     }
     if (!s->d_vmptr) FB_HIP(ctx, hipMalloc((void**)&s->d_vmptr, sizeof(int) * ((size_t)nv + 1)));
-    FB_HIP(ctx, hipMemcpyAsync(s->d_vmptr, ptr.data(), sizeof(int) * ptr.size(), hipMemcpyHostToDevice, ctx->stream));
-    if (!idx.empty()) FB_HIP(ctx, hipMemcpyAsync(s->d_vmidx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice, ctx->stream));
-    if (s->nlink) FB_HIP(ctx, hipMemcpyAsync(s->d_nodes, s->nodes.data(), sizeof(int) * s->nodes.size(), hipMemcpyHostToDevice, ctx->stream));
+    { const int rc_ = fb_copy_h2d(ctx, s->d_vmptr, ptr.data(), sizeof(int) * ptr.size()); if (rc_) return rc_; }
+    if (!idx.empty()) { const int rc_ = fb_copy_h2d(ctx, s->d_vmidx, idx.data(), sizeof(int) * idx.size()); if (rc_) return rc_; }
+    if (s->nlink) { const int rc_ = fb_copy_h2d(ctx, s->d_nodes, s->nodes.data(), sizeof(int) * s->nodes.size()); if (rc_) return rc_; }
     FB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // ptr/idx are locals
     return FB_OK;
 }
@@ -568,8 +568,8 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
     // ---- device pattern lives in the solver matrix
     int rc = fb_bsr_alloc(ctx, nv, nnzb, &s->M);
     if (rc) return rc;
-    FB_HIP(ctx, hipMemcpyAsync(s->M->d.rowptr, s->browptr.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice, ctx->stream));
-    FB_HIP(ctx, hipMemcpyAsync(s->M->d.col, s->bcol.data(), sizeof(int) * (size_t)nnzb, hipMemcpyHostToDevice, ctx->stream));
+    { const int rc_ = fb_copy_h2d(ctx, s->M->d.rowptr, s->browptr.data(), sizeof(int) * ((size_t)nv + 1)); if (rc_) return rc_; }
+    { const int rc_ = fb_copy_h2d(ctx, s->M->d.col, s->bcol.data(), sizeof(int) * (size_t)nnzb); if (rc_) return rc_; }
     FB_HIP(ctx, hipMalloc((void**)&s->d_K, sizeof(double) * 4 * (size_t)nnzb));
     FB_HIP(ctx, hipMalloc((void**)&s->d_Cacc, sizeof(double) * (size_t)nnzb));
     FB_HIP(ctx, hipMalloc((void**)&s->d_C, sizeof(float) * (size_t)nnzb));
@@ -718,9 +718,9 @@ static int assemble_mesh_impl(fb_ctx* ctx, fb_system* s, int mesh_id, const doub
     FB_CHECK_ARG(ctx, s && s->finalized && mesh_id >= 0 && mesh_id < (int)s->meshes.size() && v_shape);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     fb_mesh_blk& m = s->meshes[mesh_id];
-    FB_HIP(ctx, hipMemcpyAsync(m.d_vshape, v_shape, sizeof(double2) * (size_t)m.V, hipMemcpyHostToDevice, ctx->stream));
-    if (v_cur) FB_HIP(ctx, hipMemcpyAsync(m.d_vcur, v_cur, sizeof(double2) * (size_t)m.V, hipMemcpyHostToDevice, ctx->stream));
-    if (tri_mult) FB_HIP(ctx, hipMemcpyAsync(m.d_mult, tri_mult, sizeof(float) * (size_t)m.T, hipMemcpyHostToDevice, ctx->stream));
+    { const int rc_ = fb_copy_h2d(ctx, m.d_vshape, v_shape, sizeof(double2) * (size_t)m.V); if (rc_) return rc_; }
+    if (v_cur) { const int rc_ = fb_copy_h2d(ctx, m.d_vcur, v_cur, sizeof(double2) * (size_t)m.V); if (rc_) return rc_; }
+    if (tri_mult) { const int rc_ = fb_copy_h2d(ctx, m.d_mult, tri_mult, sizeof(float) * (size_t)m.T); if (rc_) return rc_; }
     if (tri_model) {
         FB_CHECK_ARG(ctx, tri_nu && tri_matmult);
         for (int t = 0; t < m.T; ++t) FB_CHECK_ARG(ctx, tri_model[t] >= 0 && tri_model[t] <= 2);
@@ -778,9 +778,10 @@ int fb_sys_assemble_links(fb_ctx* ctx, fb_system* s, const double* bary6, const 
     FB_CHECK_ARG(ctx, s && s->finalized && (s->nlink == 0 || (bary6 && w && rxy)));
     FB_HIP(ctx, hipSetDevice(ctx->device));
     if (s->nlink) {
-        FB_HIP(ctx, hipMemcpyAsync(s->d_bary, bary6, sizeof(double) * 6 * (size_t)s->nlink, hipMemcpyHostToDevice, ctx->stream));
-        FB_HIP(ctx, hipMemcpyAsync(s->d_w, w, sizeof(float) * (size_t)s->nlink, hipMemcpyHostToDevice, ctx->stream));
-        FB_HIP(ctx, hipMemcpyAsync(s->d_rxy, rxy, sizeof(double2) * (size_t)s->nlink, hipMemcpyHostToDevice, ctx->stream));
+        int rc_ = fb_copy_h2d(ctx, s->d_bary, bary6, sizeof(double) * 6 * (size_t)s->nlink);
+        if (!rc_) rc_ = fb_copy_h2d(ctx, s->d_w, w, sizeof(float) * (size_t)s->nlink);
+        if (!rc_) rc_ = fb_copy_h2d(ctx, s->d_rxy, rxy, sizeof(double2) * (size_t)s->nlink);
+        if (rc_) return rc_;
     }
     {
         FB_PROF(ctx, "fem_asm_links");
@@ -853,14 +854,13 @@ int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, 
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && x);
     FB_HIP(ctx, hipSetDevice(ctx->device));
-    if (use_x0) FB_HIP(ctx, hipMemcpyAsync(s->M->x, x, sizeof(double2) * (size_t)s->nv, hipMemcpyHostToDevice, ctx->stream));
+    if (use_x0) { const int rc_ = fb_copy_h2d(ctx, s->M->x, x, sizeof(double2) * (size_t)s->nv); if (rc_) return rc_; }
     else FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
     int rc = fb_bsr_setup_jacobi(ctx, s->M, precond);
     if (rc) return rc;
     rc = fb_bsr_pcg_dev(ctx, s->M, rtol, atol, maxiter, 0, iters, relres);
     if (rc && rc != FB_ERR_NOCONV) return rc;
-    FB_HIP(ctx, hipMemcpyAsync(x, s->M->x, sizeof(double2) * (size_t)s->nv, hipMemcpyDeviceToHost, ctx->stream));
-    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { const int rc_ = fb_copy_d2h(ctx, x, s->M->x, sizeof(double2) * (size_t)s->nv); if (rc_) return rc_; }
     return rc;
 }
 
@@ -883,7 +883,7 @@ int fb_sys_solve_groups(fb_ctx* ctx, fb_system* s, int ngroups, double* x, doubl
     int rc = fb_bsr_pcg_groups(ctx, s->M, ngroups, rtol, atol, maxiter, precond, d_it, d_rel, d_fl);
     if (rc) return rc;
     std::vector<char> hs(16 * (size_t)ngroups);
-    FB_HIP(ctx, hipMemcpyAsync(x, s->M->x, sizeof(double2) * (size_t)s->nv, hipMemcpyDeviceToHost, ctx->stream));
+    { const int rc_ = fb_copy_d2h(ctx, x, s->M->x, sizeof(double2) * (size_t)s->nv); if (rc_) return rc_; }
     FB_HIP(ctx, hipMemcpyAsync(hs.data(), s->d_gstat, hs.size(), hipMemcpyDeviceToHost, ctx->stream));
     FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const double* hr = reinterpret_cast<const double*>(hs.data());
@@ -912,7 +912,7 @@ int fb_sys_group_energy(fb_ctx* ctx, fb_system* s, int ngroups, const double* x,
         s->gstat_cap = ngroups;
     }
     // M->z is free outside a solve: staging area for x
-    FB_HIP(ctx, hipMemcpyAsync(s->M->z, x, sizeof(double2) * (size_t)s->nv, hipMemcpyHostToDevice, ctx->stream));
+    { const int rc_ = fb_copy_h2d(ctx, s->M->z, x, sizeof(double2) * (size_t)s->nv); if (rc_) return rc_; }
     hipLaunchKernelGGL(group_energy_kernel, dim3(ngroups), dim3(kT), 0, ctx->stream, s->nv / ngroups, s->M->d.rowptr, s->M->d.col, s->d_K, s->M->z,
                        reinterpret_cast<double*>(s->d_gstat));
     FB_HIP(ctx, hipGetLastError());
@@ -946,9 +946,7 @@ int fb_sys_get(fb_ctx* ctx, fb_system* s, int which, void* out) {
         case 4: src = s->M->d.val; bytes = sizeof(double) * 4 * nnzb; break;
         default: src = s->M->b; bytes = sizeof(double2) * nv; break;
     }
-    FB_HIP(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FB_OK;
+    return fb_copy_d2h(ctx, out, src, bytes);
 }
 
 int fb_sys_info(fb_ctx* ctx, fb_system* s, int64_t* nv, int64_t* nnzb, int64_t* nlink) {

@@ -897,16 +897,14 @@ int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C
         rc = fb_fail(ctx, FB_ERR_NOMEM, "fb_ncc_batch: hipMalloc: %s", hipGetErrorString(e));
     }
     if (!rc) {
-        hipMemcpyAsync(d0, img0, b0, hipMemcpyHostToDevice, ctx->stream);
-        hipMemcpyAsync(d1, img1, b1, hipMemcpyHostToDevice, ctx->stream);
-        rc = fb_ncc_batch_dev(ctx, d0, d1, N, C, H0, W0, H1, W1, pad, subpixel, conf_mode, ddx, ddy, dconf);
+        rc = fb_copy_h2d(ctx, d0, img0, b0);
+        if (!rc) rc = fb_copy_h2d(ctx, d1, img1, b1);
+        if (!rc) rc = fb_ncc_batch_dev(ctx, d0, d1, N, C, H0, W0, H1, W1, pad, subpixel, conf_mode, ddx, ddy, dconf);
     }
     if (!rc) {
-        hipMemcpyAsync(dx, ddx, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        hipMemcpyAsync(dy, ddy, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        hipMemcpyAsync(conf, dconf, N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-        e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) rc = fb_fail(ctx, FB_ERR_HIP, "fb_ncc_batch: %s", hipGetErrorString(e));
+        rc = fb_copy_d2h(ctx, dx, ddx, N * sizeof(double));
+        if (!rc) rc = fb_copy_d2h(ctx, dy, ddy, N * sizeof(double));
+        if (!rc) rc = fb_copy_d2h(ctx, conf, dconf, N * sizeof(float));
     }
     hipFree(d0); hipFree(d1); hipFree(ddx); hipFree(ddy); hipFree(dconf);
     return rc;

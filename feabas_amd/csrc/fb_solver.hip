@@ -478,9 +478,10 @@ int fb_bsr_upload(fb_ctx* ctx, int nb, const std::vector<int>& rowptr, const std
     fb_bsr* M = nullptr;
     int rc = fb_bsr_alloc(ctx, nb, (int64_t)col.size(), &M);
     if (rc) return rc;
-    FB_HIP(ctx, hipMemcpyAsync(M->d.rowptr, rowptr.data(), sizeof(int) * rowptr.size(), hipMemcpyHostToDevice, ctx->stream));
-    FB_HIP(ctx, hipMemcpyAsync(M->d.col, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice, ctx->stream));
-    FB_HIP(ctx, hipMemcpyAsync(M->d.val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice, ctx->stream));
+    rc = fb_copy_h2d(ctx, M->d.rowptr, rowptr.data(), sizeof(int) * rowptr.size());
+    if (!rc) rc = fb_copy_h2d(ctx, M->d.col, col.data(), sizeof(int) * col.size());
+    if (!rc) rc = fb_copy_h2d(ctx, M->d.val, val.data(), sizeof(double) * val.size());
+    if (rc) return rc;
     FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = M;
     return FB_OK;
@@ -706,7 +707,7 @@ int fb_csr_info(fb_ctx* ctx, fb_csr* A, int64_t* n, int64_t* nnz, int64_t* nb, i
 static int upload_vec(fb_ctx* ctx, fb_csr* A, double2* dst, const double* src) {
     const size_t nbytes = sizeof(double) * (size_t)A->n;
     FB_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(double2) * (size_t)A->M->d.nb, ctx->stream));
-    if (src) FB_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (src) return fb_copy_h2d(ctx, dst, src, nbytes);
     return FB_OK;
 }
 
@@ -717,9 +718,7 @@ int fb_spmv(fb_ctx* ctx, fb_csr* A, const double* x_host, double* y_host) {
     if (rc) return rc;
     rc = fb_bsr_spmv_dev(ctx, A->M, A->M->x, A->M->Ap);
     if (rc) return rc;
-    FB_HIP(ctx, hipMemcpyAsync(y_host, A->M->Ap, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToHost, ctx->stream));
-    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FB_OK;
+    return fb_copy_d2h(ctx, y_host, A->M->Ap, sizeof(double) * (size_t)A->n);
 }
 
 // y = A x on device-resident vectors (e.g. torch tensors of a distributed solver): no copies, no synchronisation
@@ -850,8 +849,7 @@ int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, d
     if (rc) return rc;
     rc = fb_bsr_pcg_dev(ctx, A->M, rtol, atol, maxiter, 0, iters, relres);
     if (rc && rc != FB_ERR_NOCONV) return rc;
-    FB_HIP(ctx, hipMemcpyAsync(x, A->M->x, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToHost, ctx->stream));
-    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { const int rc_ = fb_copy_d2h(ctx, x, A->M->x, sizeof(double) * (size_t)A->n); if (rc_) return rc_; }
     return rc;
 }
 

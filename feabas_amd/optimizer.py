@@ -593,19 +593,33 @@ class SLM:
                                              _lib.ptr(tid1), _lib.ptr(B1), offs[m1.uid] // 2 if offs[m1.uid] >= 0 else -1, ox, oy,
                                              _lib.ptr(nodes6), _lib.ptr(bary6), _lib.ptr(rxy)))
 
-    def _ensure_system(self, groupings=None):
+    def _ensure_system(self, groupings=None, terms=None):
         """(Re)build the symbolic GPU system when the topology (free meshes, link
-        connectivity, groupings) changed; numeric re-assembly reuses it."""
+        connectivity, groupings) changed; numeric re-assembly reuses it.  terms = (start_gear, target_gear): the numeric
+        rows of the links ([B0 | -B1], xy1 - xy0, weights) are produced in the same pass over the matches and kept in
+        self._link_rows for _assemble."""
         lib = _lib.load()
         ctx = _lib.ctx()
         offs, dof, adders, gmean = self._layout(groupings)
         self._offs, self._adders, self._gmean = offs, adders, gmean
         links = [lk for lk in self._active_links() if offs[lk.meshes[0].uid] >= 0 or offs[lk.meshes[1].uid] >= 0]
-        nodes6 = np.empty((sum(lk._tid0.size for lk in links), 6), dtype=np.int32)
+        K = sum(lk._tid0.size for lk in links)
+        nodes6 = np.empty((K, 6), dtype=np.int32)
+        self._link_rows = None
+        if terms is not None and K:
+            bary = np.empty((K, 6)); res = np.empty((K, 2)); wts = np.empty(K, dtype=np.float32)
+            self._link_rows = (bary, res, wts)
         at = 0
         for lk in links:
-            self._link_terms(lk, offs, nodes6[at:at + lk._tid0.size])
-            at += lk._tid0.size
+            n = lk._tid0.size
+            if self._link_rows is not None:
+                gears = [terms[1] if offs[m.uid] < 0 else terms[0] for m in lk.meshes]
+                # [B0 | -B1] and Link.dxy (optimizer.py:248-255) of the link's matches straight into the rows of the system
+                self._link_terms(lk, offs, nodes6[at:at + n], bary[at:at + n], res[at:at + n], gears)
+                wts[at:at + n] = lk.weight(use_mask=False)
+            else:
+                self._link_terms(lk, offs, nodes6[at:at + n])
+            at += n
         mesh_key = tuple((m.uid, offs[m.uid], m.num_vertices, m.triangles.ctypes.data) for m in self.meshes)
         key = (mesh_key, nodes6.tobytes())
         if self._sys is not None and key == self._sys_key:
@@ -643,7 +657,7 @@ class SLM:
         """numeric assembly of K, stress, C, rhs on the GPU (optimizer.py:1307-1310)."""
         lib = _lib.load()
         ctx = _lib.ctx()
-        links = self._ensure_system(groupings)
+        links = self._ensure_system(groupings, terms=(start_gear, target_gear))
         offs = self._offs
         for m in self.meshes:
             if offs[m.uid] < 0 or m.uid in getattr(self, '_skip_stiffness', ()):
@@ -653,17 +667,8 @@ class SLM:
             v1c = None if v1 is m.vertices(shape_gear) else np.ascontiguousarray(v1, dtype=np.float64)
             m.assemble_into(self._sys, self._mesh_ids[m.uid], v0, v1c, float(m.soft_factor), add=m.uid in self._adders)
         if links:
-            K = sum(lk._tid0.size for lk in links)
-            bary = np.empty((K, 6)); res = np.empty((K, 2)); wts = np.empty(K, dtype=np.float32)
-            scratch = np.empty((max(lk._tid0.size for lk in links), 6), dtype=np.int32)
-            at = 0
-            for lk in links:
-                n = lk._tid0.size
-                gears = [target_gear if offs[m.uid] < 0 else start_gear for m in lk.meshes]
-                # [B0 | -B1] and Link.dxy (optimizer.py:248-255) of the link's matches straight into the rows of the system
-                self._link_terms(lk, offs, scratch[:n], bary[at:at + n], res[at:at + n], gears)
-                wts[at:at + n] = lk.weight(use_mask=False)
-                at += n
+            bary, res, wts = self._link_rows
+            self._link_rows = None
             _lib.check(lib.fb_sys_assemble_links(ctx, self._sys, _lib.ptr(bary), _lib.ptr(wts), _lib.ptr(res)))
         else:
             _lib.check(lib.fb_sys_assemble_links(ctx, self._sys, None, None, None))
