@@ -123,6 +123,7 @@ _PROTOS = {
     'fb_dog_pair_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_i, c_p]),
     'fb_dog_down2_pair_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_d, c_i, c_p]),
     'fb_mask_range_dev': (c_i, [c_p, c_p, c_sz, C.c_float, C.c_float, c_p]),
+    'fb_count_nonzero_dev': (c_i, [c_p, c_p, c_sz, C.POINTER(c_i64)]),
     'fb_mesh_block_affines': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_d, c_p, c_p]),
     'fb_mesh_block_uncovered': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_mesh_locate_dev': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
@@ -322,6 +323,12 @@ class DeviceBuffer:
         buf = cls(a.nbytes)
         check(load().fb_memcpy_h2d(ctx(), buf.ptr, ptr(a), a.nbytes))
         return buf
+
+    def count_nonzero(self, nbytes=None):
+        """non-zero bytes among the first nbytes of the buffer, counted on the device (fb_count_nonzero_dev)"""
+        n = c_i64()
+        check(load().fb_count_nonzero_dev(ctx(), self.ptr, self.nbytes if nbytes is None else int(nbytes), C.byref(n)))
+        return n.value
 
     def to_array(self, shape, dtype):
         out = np.empty(shape, dtype=dtype)

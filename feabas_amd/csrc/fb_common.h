@@ -54,7 +54,12 @@ struct fb_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof_on = false;
     std::vector<fb_prof_entry> prof;
-    std::vector<void*> owned;   // fb_malloc'ed pointers
+    std::vector<std::pair<void*, size_t>> owned;        // fb_malloc'ed blocks (pointer, capacity)
+    // blocks handed back by fb_free are kept for the next fb_malloc of a similar size (hipMalloc / hipFree cost 0.1-0.3 ms each
+    // and hipFree drains the device; the Python surface allocates its temporaries per call), up to free_limit bytes
+    std::vector<std::pair<void*, size_t>> free_blocks;
+    size_t free_bytes = 0, free_limit = (size_t)4 << 30;
+    void* small = nullptr;      // 64 KiB of device scratch for flags and partial reductions (allocated with the context)
     size_t ncc_arena_limit = (size_t)8 << 30;
     bool use_rocfft = false;     // FEABAS_HIP_ROCFFT=1: streaming-class FFTs through rocFFT instead of the hand-written kernels
     bool dog_tiles = false;      // FEABAS_HIP_DOG_TILES=1: the 64 x 64 tile kernel (dog_fast) instead of the streaming one (A/B)

@@ -170,10 +170,11 @@ fb_ctx* fb_create(int device_id) {
     if (const char* e = getenv("FEABAS_HIP_ROCFFT")) ctx->use_rocfft = atoi(e) != 0;
     if (const char* e = getenv("FEABAS_HIP_DOG_EXACT")) ctx->dog_exact = atoi(e) != 0;
     if (const char* e = getenv("FEABAS_HIP_DOG_TILES")) ctx->dog_tiles = atoi(e) != 0;
+    if (const char* e = getenv("FEABAS_HIP_MALLOC_CACHE_MB")) ctx->free_limit = (size_t)std::max(0L, atol(e)) << 20;
     if (const char* e = getenv("FEABAS_HIP_NCC_ARENA_MB")) { const long mb = atol(e); if (mb >= 16) ctx->ncc_arena_limit = (size_t)mb << 20; }   // sub-batch size of the streaming NCC class (A/B: small chunks keep T and V in the 256 MiB Infinity Cache)
     if (hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
+        hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess || hipMalloc(&ctx->small, 64 << 10) != hipSuccess) {
         delete ctx;
         return nullptr;
     }
@@ -195,7 +196,9 @@ void fb_destroy(fb_ctx* ctx) {
     if (ctx->fft_info) rocfft_execution_info_destroy(ctx->fft_info);
     if (ctx->fft_work) hipFree(ctx->fft_work);
     if (ctx->arena) hipFree(ctx->arena);
-    for (void* p : ctx->owned) hipFree(p);
+    for (auto& p : ctx->owned) hipFree(p.first);
+    for (auto& p : ctx->free_blocks) hipFree(p.first);
+    if (ctx->small) hipFree(ctx->small);
     if (ctx->rocfft_ready) fb_rocfft_release();
     hipEventDestroy(ctx->t0);
     hipEventDestroy(ctx->t1);
@@ -229,10 +232,32 @@ int fb_malloc(fb_ctx* ctx, size_t bytes, void** dptr) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, dptr != nullptr);
     FB_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = bytes ? (bytes + 255) / 256 * 256 : 256;
+    // best fit among the blocks fb_free kept: at least `need`, at most twice that (+ 1 MiB)
+    int best = -1;
+    for (size_t i = 0; i < ctx->free_blocks.size(); ++i) {
+        const size_t cap = ctx->free_blocks[i].second;
+        if (cap >= need && cap <= 2 * need + ((size_t)1 << 20) && (best < 0 || cap < ctx->free_blocks[best].second)) best = (int)i;
+    }
+    if (best >= 0) {
+        const auto blk = ctx->free_blocks[best];
+        ctx->free_blocks.erase(ctx->free_blocks.begin() + best);
+        ctx->free_bytes -= blk.second;
+        ctx->owned.push_back(blk);
+        *dptr = blk.first;
+        return FB_OK;
+    }
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess && !ctx->free_blocks.empty()) {          // out of memory with blocks in the cache: give them back and retry
+        (void)hipGetLastError();
+        hipStreamSynchronize(ctx->stream);
+        for (auto& b : ctx->free_blocks) hipFree(b.first);
+        ctx->free_blocks.clear(); ctx->free_bytes = 0;
+        e = hipMalloc(&p, need);
+    }
     if (e != hipSuccess) return fb_fail(ctx, FB_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-    ctx->owned.push_back(p);
+    ctx->owned.emplace_back(p, need);
     *dptr = p;
     return FB_OK;
 }
@@ -294,10 +319,16 @@ int fb_free(fb_ctx* ctx, void* dptr) {
     FB_LOCK(ctx);
     if (!dptr) return FB_OK;
     for (size_t i = 0; i < ctx->owned.size(); ++i) {
-        if (ctx->owned[i] == dptr) {
+        if (ctx->owned[i].first == dptr) {
+            const auto blk = ctx->owned[i];
             ctx->owned.erase(ctx->owned.begin() + i);
-            FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            FB_HIP(ctx, hipFree(dptr));
+            FB_HIP(ctx, hipStreamSynchronize(ctx->stream));       // nothing enqueued on this context still uses the block
+            if (ctx->free_bytes + blk.second <= ctx->free_limit) {
+                ctx->free_blocks.push_back(blk);
+                ctx->free_bytes += blk.second;
+            } else {
+                FB_HIP(ctx, hipFree(dptr));
+            }
             return FB_OK;
         }
     }

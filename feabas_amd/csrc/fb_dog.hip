@@ -133,6 +133,31 @@ __global__ void minmax_kernel(const T* __restrict__ img, size_t total, float* __
     }
 }
 
+// non-zero bytes of m[0 .. total): 16 bytes per lane and trip where the pointer allows it, one atomic per wave
+__global__ __launch_bounds__(256) void count_nonzero_kernel(const uint8_t* __restrict__ m, size_t total, unsigned long long* __restrict__ count) {
+    unsigned long long c = 0;
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(m) & 15)) & 15;
+    const size_t h = head < total ? head : total, nv = (total - h) / 16;
+    const uint4* v = reinterpret_cast<const uint4*>(m + h);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 q = v[i];
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // one bit per non-zero byte: fold every byte onto its top bit
+            unsigned t = w[k];
+            t |= t >> 4; t |= t >> 2; t |= t >> 1;                     // bit 0 of each byte = OR of the byte's bits (low bits of t)
+            c += __popc(t & 0x01010101u);
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = threadIdx.x; i < h; i += blockDim.x) c += m[i] != 0;
+        for (size_t i = h + 16 * nv + threadIdx.x; i < total; i += blockDim.x) c += m[i] != 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
 __global__ void any_zero_kernel(const uint8_t* __restrict__ m, size_t total, int* flag) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
         if (m[i] == 0) { *flag = 1; return; }
@@ -872,24 +897,20 @@ int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, cons
     float* halo = nullptr;
     if (mask) {
         // common.py:368: only when the mask has a zero somewhere
-        int* flag = nullptr;
-        FB_HIP(ctx, hipMalloc(&flag, sizeof(int)));
+        int* flag = reinterpret_cast<int*>(ctx->small);              // the context's scratch: no hipMalloc / hipFree (a device-wide drain) per call
         FB_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
         const size_t nmask = mask_per_image ? (size_t)N : 1, per_image = mask_per_image ? (size_t)H * W : 0;
         hipLaunchKernelGGL(any_zero_kernel, dim3(256), dim3(256), 0, ctx->stream, mask, nmask * H * W, flag);
         int hflag = 0;
         FB_HIP(ctx, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        FB_HIP(ctx, hipFree(flag));
         if (hflag) {
             const int nblk = 256, nslots = nblk * 4;
-            float* mm = nullptr;
-            FB_HIP(ctx, hipMalloc(&mm, sizeof(float) * 2 * nslots));
+            float* mm = reinterpret_cast<float*>(ctx->small) + 64;       // 8 KiB of the 64 KiB scratch
             hipLaunchKernelGGL(minmax_kernel<T>, dim3(nblk), dim3(256), 0, ctx->stream, img, (size_t)N * H * W, mm);
             std::vector<float> hmm(2 * nslots);
             FB_HIP(ctx, hipMemcpyAsync(hmm.data(), mm, sizeof(float) * 2 * nslots, hipMemcpyDeviceToHost, ctx->stream));
             FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            FB_HIP(ctx, hipFree(mm));
             float lo = INFINITY, hi = -INFINITY;
             for (int i = 0; i < nslots; ++i) { lo = std::min(lo, hmm[2 * i]); hi = std::max(hi, hmm[2 * i + 1]); }
             const float ptp = hi - lo;
@@ -1037,6 +1058,22 @@ int fb_mask_range_dev(fb_ctx* ctx, const float* img, size_t n, float lo, float h
     if (n == 0) return FB_OK;
     hipLaunchKernelGGL(mask_range_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, img, n, lo, hi, mask);
     FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+int fb_count_nonzero_dev(fb_ctx* ctx, const uint8_t* m, size_t n, int64_t* count) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, count && (n == 0 || m));
+    *count = 0;
+    if (n == 0) return FB_OK;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(ctx->small);
+    FB_HIP(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3((unsigned)std::min<size_t>((n / 16 + 255) / 256 + 1, 2048)), dim3(256), 0, ctx->stream, m, n, d);
+    FB_HIP(ctx, hipGetLastError());
+    unsigned long long h = 0;
+    FB_HIP(ctx, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count = (int64_t)h;
     return FB_OK;
 }
 

@@ -414,7 +414,7 @@ def bboxes_mesh_renderer_matcher(mesh0, mesh1, image_loader0, image_loader1, bbo
                 for r, bb in ((renders[0], bboxes0[a:b]), (renders[1], bboxes1[a:b])):
                     d_out, d_mask, shape, _ = r.render_stack_dev(bb, precise_mask=sigma > 0)
                     bufs += [d_out, d_mask]
-                    if not d_mask.to_array(shape, np.uint8).any():             # crop_multiple -> None: batch skipped, matcher.py:835-839
+                    if not d_mask.count_nonzero(int(np.prod(shape))):             # crop_multiple -> None: batch skipped, matcher.py:835-839
                         covered = False
                         break
                     if sigma > 0:

@@ -203,7 +203,7 @@ class MeshRenderer:
         log_sigma = kwargs.get('log_sigma', 0)
         d_out, d_mask, shape, _ = self.render_stack_dev(bboxes, precise_mask=log_sigma > 0)
         try:
-            if not d_mask.to_array(shape, np.uint8).any():
+            if not d_mask.count_nonzero(int(np.prod(shape))):
                 return None
             if log_sigma > 0:
                 d_f = self.filter_stack_dev(d_out, d_mask, shape, log_sigma, kwargs.get('mask_range', None))

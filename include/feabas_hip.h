@@ -166,6 +166,10 @@ int fb_dog_down2_pair_dev(fb_ctx* ctx, const uint8_t* img0, const uint8_t* img1,
 /* mask[i] &= (lo <= img[i] <= hi) on device arrays: the `mask_range` of MeshRenderer.crop_multiple (renderer.py:634-637),
  * applied to the rendered stack before its masked DoG */
 int fb_mask_range_dev(fb_ctx* ctx, const float* img, size_t n, float lo, float hi, uint8_t* mask);
+/* number of non-zero bytes of a device array, returned to the host: the `mask.any()` test of MeshRenderer.crop_multiple
+ * (renderer.py:601-648 returns None for a stack no pixel of which is covered; matcher.py:835-839 then skips the batch)
+ * without bringing the N x h x w mask across the link */
+int fb_count_nonzero_dev(fb_ctx* ctx, const uint8_t* m, size_t n, int64_t* count);
 
 /* MeshRenderer for general triangulated meshes (one region, no collisions), all pointers device pointers.
  * fb_mesh_candidates_dev: for NB blocks of h x w pixels whose first pixel sits at org [NB][2] (float64, MOVING coordinates
