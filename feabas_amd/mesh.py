@@ -141,6 +141,14 @@ class Mesh:
     def vertices_w_offset(self, gear=None):
         return self.vertices(gear) + self.offset(gear)
 
+    def clear_staging(self):
+        """the STAGING gear falls back to MOVING again (what the Newton-Raphson loop does with a mesh after it annealed its
+        resting shape from STAGING, optimizer.py:1511-1515)"""
+        if self.locked:
+            return
+        self._vertices[const.MESH_GEAR_STAGING] = None
+        self._offsets[const.MESH_GEAR_STAGING] = np.zeros((1, 2), dtype=np.float64)
+
     def bbox(self, gear=const.MESH_GEAR_MOVING, offsetting=True):
         v = self.vertices_w_offset(gear) if offsetting else self.vertices(gear)
         lo, hi = v.min(axis=0), v.max(axis=0)

@@ -621,16 +621,14 @@ class SLM:
                 self._link_terms(lk, offs, nodes6[at:at + n])
             at += n
         mesh_key = tuple((m.uid, offs[m.uid], m.num_vertices, m.triangles.ctypes.data) for m in self.meshes)
-        key = (mesh_key, nodes6.tobytes())
-        if self._sys is not None and key == self._sys_key:
-            return links
-        if self._sys is not None and self._sys_key[0] == mesh_key and nodes6.shape[0] and np.all(np.any(nodes6 < 0, axis=1)):
-            # same free meshes, and every match has a locked side: its couplings stay inside one triangle of a free mesh,
-            # which the pattern already holds (a section relaxed against locked neighbours, aligner.py:696-727 with one free
-            # section) -- the links are swapped without a new symbolic phase
-            rc = lib.fb_sys_update_links(ctx, self._sys, nodes6.shape[0], _lib.ptr(nodes6))
+        if self._sys is not None and self._sys_key == mesh_key:
+            # same free meshes: the links are swapped without a new symbolic phase when every coupling they make is in the
+            # pattern already -- fb_sys_update_links checks exactly that (in threaded C++, no copy of the table is kept or
+            # compared on this side).  Always true for matches with a locked side, whose couplings stay inside one triangle
+            # of the free mesh (a section relaxed against locked neighbours, aligner.py:696-727 with one free section), and
+            # for the same matches again (Newton-Raphson steps, residue re-weighting)
+            rc = lib.fb_sys_update_links(ctx, self._sys, nodes6.shape[0], _lib.ptr(nodes6) if nodes6.shape[0] else None)
             if rc == 0:
-                self._sys_key = key
                 return links
         self._drop_system()
         nv = dof // 2
@@ -650,7 +648,7 @@ class SLM:
         _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
         self._nnzb = nnzb.value
         self._nv = nv
-        self._sys_key = key
+        self._sys_key = mesh_key
         return links
 
     def _assemble(self, shape_gear, start_gear, target_gear, groupings=None):
@@ -888,33 +886,88 @@ class SLM:
         _lib.check(lib.fb_sys_get(ctx, self._sys, 3, _lib.ptr(stress)))
         return float(np.linalg.norm(cl * rhs - sl * stress))
 
+    @staticmethod
+    def _ladder(value, steps, toward_first=None):
+        """Per-step schedule of a Newton-Raphson keyword (SLM.expand_to_list, optimizer.py:1862-1873): a scalar is the value
+        of the LAST step, a sequence is right-aligned; the steps before are derived one by one from the step that follows
+        them (`toward_first`), or repeat it."""
+        given = [value] if (not hasattr(value, '__len__') or isinstance(value, str) or len(value) == 0) else list(value)
+        sched = given[-steps:] if len(given) > steps else given
+        while len(sched) < steps:
+            sched.insert(0, toward_first(sched[0]) if toward_first is not None else sched[0])
+        return sched
+
     def optimize_Newton_Raphson(self, **kwargs):
-        """Newton iteration for meshes with non-linear elements (structure of optimizer.py:1440-1544): every step
-        re-assembles the tangent stiffness / internal force at the current MOVING gear on the GPU and solves the
-        tangent problem with optimize_linear.  Annealing and residue re-weighting between steps are not included."""
-        max_newtonstep = kwargs.pop('max_newtonstep', 5)
+        """feabas/optimizer.py:1440-1544.  Every step re-assembles the tangent stiffness and the internal force at the
+        current MOVING gear on the device and solves the tangent problem with optimize_linear; the step tolerances tighten
+        geometrically from max(tol, 1e-5) to tol, every inner solve also stops at the absolute floor tol * cost0, and a step
+        whose out-of-balance force is below that floor is followed by one last step.  Between steps, as asked per step:
+        annealing of the resting shape (anneal_mode, after relaxing the most deformed regions when deform_outlier_constant
+        > 0 -- the `online_anneal` of optimize_elastic) and residue re-weighting of the links (residue_mode 'huber' /
+        'hard' with residue_len, which doubles towards the earlier steps; negative = units of the section thickness over
+        the working resolution, keywords section_thickness / working_resolution).  Returns (cost0, cost): the
+        out-of-balance force ||lc rhs - ls stress|| before the first step and the smallest one met after a step."""
+        n = int(kwargs.pop('max_newtonstep', 5))
+        if n < 1:
+            raise ValueError('max_newtonstep < 1')
         tol = kwargs.pop('tol', 1e-7)
-        step_tol = max(tol, 1e-5) if max_newtonstep > 1 else tol
-        cost0 = None
-        cost = np.inf
-        for ke in range(max_newtonstep):
-            step_cost = self.optimize_linear(tol=step_tol, shape_gear=const.MESH_GEAR_FIXED, start_gear=const.MESH_GEAR_MOVING,
-                                             target_gear=const.MESH_GEAR_MOVING, **kwargs)
-            if cost0 is None:
-                cost0 = step_cost[0]
-            if step_cost[0] < step_cost[1]:
+        atol = kwargs.pop('atol', 0)
+        growth = (max(tol, 1e-5) / tol) ** (1.0 / (n - 1)) if n > 1 else 1.0
+        maxiter = self._ladder(kwargs.pop('maxiter', None), n)
+        step_tol = self._ladder(kwargs.pop('step_tol', tol), n, lambda t: t * growth)
+        step_atol = self._ladder(kwargs.pop('step_atol', atol), n)
+        ls = self._ladder(kwargs.pop('stiffness_lambda', self._stiffness_lambda), n)
+        lc = self._ladder(kwargs.pop('crosslink_lambda', self._crosslink_lambda), n)
+        residue_mode = self._ladder(kwargs.pop('residue_mode', None), n, lambda _: None)
+        residue_len = self._ladder(kwargs.pop('residue_len', 0), n, lambda r: 2 * r)
+        anneal_mode = self._ladder(kwargs.pop('anneal_mode', None), n)
+        outlier = self._ladder(kwargs.pop('deform_outlier_constant', 0), n)
+        kwargs.pop('check_converge', None); kwargs.pop('inner_cache', None)       # the device PCG always runs to its tolerance
+        aspect = kwargs.pop('section_thickness', const.DEFAULT_THICKNESS) / kwargs.pop('working_resolution', self.meshes[0].resolution)
+        residue_len = [abs(r) * aspect if r < 0 else r for r in residue_len]
+        target_gear = kwargs.pop('target_gear', const.MESH_GEAR_MOVING)
+        shape_gear, start_gear = const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING
+        if np.all(self.lock_flags):
+            return None, None
+        self._assemble(shape_gear, start_gear, target_gear)
+        cost0 = self.cost(ls[-1], lc[-1])
+        floor = atol if tol is None else (cost0 * tol if atol is None else max(cost0 * tol, atol))
+        best = np.inf
+        ke = 0
+        while ke < n:
+            bnorm, rnorm = self.optimize_linear(maxiter=maxiter[ke], tol=step_tol[ke], atol=max(step_atol[ke], floor), shape_gear=shape_gear,
+                                                start_gear=start_gear, target_gear=target_gear, stiffness_lambda=ls[ke], crosslink_lambda=lc[ke],
+                                                **kwargs)
+            if bnorm < rnorm:                                # the step made things worse: nothing was applied
                 break
-            cost = min(cost, step_cost[0])
-            if step_cost[0] <= tol * cost0:
-                break
-            step_tol = max(tol, step_tol * 0.1)
-        return cost0, cost
+            annealed = anneal_mode[ke] is not None
+            if annealed:
+                if outlier[ke] > 0:
+                    self.relax_higly_deformed(gear=(shape_gear, const.MESH_GEAR_STAGING), iqr=outlier[ke])
+                self.anneal(gear=(const.MESH_GEAR_STAGING, shape_gear), mode=anneal_mode[ke])
+                for m in self.meshes:
+                    if not m.locked:
+                        m.clear_staging()
+            if residue_mode[ke] is not None:
+                if residue_len[ke] > 0:
+                    (self.set_link_residue_huber if residue_mode[ke] == 'huber' else self.set_link_residue_threshold)(residue_len[ke])
+                self.adjust_link_weight_by_residue(gear=(target_gear, target_gear), relax_first=not annealed)
+            if start_gear != target_gear:
+                self.anneal(gear=(target_gear, start_gear), mode=const.ANNEAL_COPY_EXACT)
+            self._assemble(shape_gear, target_gear, target_gear)
+            best = min(best, self.cost(ls[-1], lc[-1]))
+            ke += 1
+            if floor is not None and best < floor:
+                ke = max(ke, n - 1)                          # converged: one last step at the final tolerance
+        return cost0, best
 
     def optimize_elastic(self, **kwargs):
         """optimizer.py:1547-1555."""
-        if kwargs.get('online_anneal', False):
-            raise NotImplementedError('online annealing is outside the hot path (rigid fits on the host)')
-        if self.is_linear:
+        online = kwargs.pop('online_anneal', False)
+        if online:
+            kwargs.setdefault('anneal_mode', const.ANNEAL_COPY_EXACT)
+            kwargs.setdefault('deform_outlier_constant', 1.5)
+        if self.is_linear and not online:
             return self.optimize_linear(**kwargs)
         return self.optimize_Newton_Raphson(**kwargs)
 

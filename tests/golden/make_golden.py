@@ -610,7 +610,95 @@ def g16_relax():
     np.savez_compressed(os.path.join(OUT, 'g16_relax.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G17
+def g17_newton():
+    """SLM.optimize_Newton_Raphson / optimize_elastic (optimizer.py:1440-1555) on the mixed-material mesh of G12 (engineering +
+    Neo-Hookean + St-Venant-Kirchhoff regions) pulled by links towards a displaced locked twin.  Deterministic settings: no
+    random-perturbation exit, no `chances` exit, so every inner solve runs to its tolerance and the result is the fixed point
+    of the iteration up to that tolerance."""
+    rng = np.random.default_rng(1717)
+    v, t = grid(14, 10, 10.0)
+    mids = np.zeros(t.shape[0], dtype=np.int16)
+    ctr = v[t].mean(axis=1)
+    mids[ctr[:, 0] > 90] = 5
+    mids[(ctr[:, 0] <= 90) & (ctr[:, 1] > 60)] = 6
+    tab = {'default': dict(material.MATERIAL_DEFAULT),
+           'nhk': {'type': const.MATERIAL_MODEL_NHK, 'uid': 5, 'stiffness_multiplier': 0.7},
+           'svk': {'type': const.MATERIAL_MODEL_SVK, 'uid': 6, 'poisson_ratio': 0.25, 'stiffness_multiplier': 1.3}}
+    mult = rng.uniform(0.5, 1.5, t.shape[0]).astype(np.float32)
+    disp = 0.6 * np.stack((2 * np.sin(v[:, 1] / 30), 1.5 * np.cos(v[:, 0] / 40)), -1) + np.array([[0.4, -0.3]])
+    n = 300
+    out = {}
+
+    def build():
+        mt = material.MaterialTable(table=tab)
+        m0 = Mesh(v + disp, t.copy(), uid=0, locked=True)
+        m1 = Mesh(v.copy(), t.copy(), material_table=mt, material_ids=mids.copy(), stiffness_multiplier=mult.copy(), uid=1)
+        return mt, m0, m1
+    mt, m0, m1 = build()
+    # the Mesh sorts its triangles by material: matches are drawn in that order so that tid means the same to everybody
+    tt = m1.triangles
+    tid = rng.integers(0, tt.shape[0], n); B = rng.dirichlet((1, 1, 1), n)
+    w = rng.uniform(0.4, 1.0, n).astype(np.float32)
+    model = np.zeros(tt.shape[0], dtype=np.int32); nu = np.zeros(tt.shape[0]); mm = np.ones(tt.shape[0])
+    for name, uid in (('nhk', 5), ('svk', 6)):
+        sel = m1._material_ids == uid
+        model[sel] = mt[name]._type; nu[sel] = mt[name]._poisson_ratio; mm[sel] = mt[name]._stiffness_multiplier
+    out.update(v=v, disp=disp, t0=m0.triangles, t1=tt, mult=m1._stiffness_multiplier, model=model, nu=nu, matmult=mm,
+               tid=tid, B=B, w=w)
+    # the locked twin keeps the input triangle order; a match (tid, B) on it is expressed through the free mesh's triangle:
+    # same three vertices in the same order, so the locked side uses the triangle LIST of the free mesh
+    det = dict(tolerated_perturbation=None, callback_settings={'chances': None, 'eval_step': 10})
+    for case, call in (('nr', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=8, tol=1e-9, **det)),
+                       ('nr3', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=3, tol=1e-6, **det)),
+                       ('elastic', lambda slm: slm.optimize_elastic(max_newtonstep=6, tol=1e-8, **det)),
+                       ('huber', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=6, tol=1e-8, residue_mode='huber', residue_len=0.2, **det))):
+        mt, m0, m1 = build()
+        m0 = Mesh(v + disp, tt.copy(), uid=0, locked=True)
+        lk = optimizer.Link(m0, m1, tid, tid, B, B, weight=w)
+        slm = optimizer.SLM([m0, m1], links=[lk], stiffness_lambda=1.0, crosslink_lambda=1.0)
+        c0, c1 = call(slm)
+        out[f'{case}_cost'] = np.array([c0, c1], dtype=np.float64)
+        out[f'{case}_v_after'] = m1.vertices(gear=const.MESH_GEAR_MOVING)
+        out[f'{case}_off_after'] = m1.offset(gear=const.MESH_GEAR_MOVING)
+        out[f'{case}_residue_weight'] = np.asarray(lk._residue_weight, dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, 'g17_newton.npz'), **out)
+
+
+# ----------------------------------------------------------------------- G18
+def g18_locked_neighbours():
+    """SLM.optimize_linear of ONE free section between two LOCKED neighbours (the independent-unit mode of the aligner's
+    sliding window, aligner.py:696-727 with one free section): the unit of BASELINE.json config[4]."""
+    rng = np.random.default_rng(1818)
+    v, t = grid(40, 36, 12.0)
+    L = 12.0 * 39
+
+    def field(g):
+        ph = 1.1 * g
+        return np.stack((3 * np.sin(2 * np.pi * v[:, 1] / L + ph) + np.cos(4 * np.pi * v[:, 0] / L - ph),
+                         2.5 * np.cos(2 * np.pi * v[:, 0] / L - ph) + np.sin(4 * np.pi * v[:, 1] / L + ph)), axis=-1)
+    prev = Mesh(v + (field(0) - field(1)), t.copy(), uid=0, locked=True)
+    cur = Mesh(v.copy(), t.copy(), uid=1)
+    nxt = Mesh(v + (field(2) - field(1)), t.copy(), uid=2, locked=True)
+    out = dict(v=v, t=t, v_prev=prev.vertices(gear=const.MESH_GEAR_INITIAL), v_next=nxt.vertices(gear=const.MESH_GEAR_INITIAL))
+    links = []
+    for k, (a, b) in enumerate(((prev, cur), (cur, nxt))):
+        n = 900
+        tid = np.sort(rng.integers(0, t.shape[0], n)); B = rng.dirichlet((1, 1, 1), n)
+        w = rng.uniform(0.3, 1.0, n).astype(np.float32)
+        links.append(optimizer.Link(a, b, tid, tid, B, B, weight=w))
+        out[f'l{k}_tid'] = tid; out[f'l{k}_B'] = B; out[f'l{k}_w'] = w
+    slm = optimizer.SLM([prev, cur, nxt], links=links, stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    cost = slm.optimize_linear(tol=1e-11, tolerated_perturbation=None, callback_settings={'chances': None, 'eval_step': 10}, check_converge=True)
+    out['cost'] = np.array(cost, dtype=np.float64)
+    out['v_after'] = cur.vertices(gear=const.MESH_GEAR_MOVING)
+    out['off_after'] = cur.offset(gear=const.MESH_GEAR_MOVING)
+    np.savez_compressed(os.path.join(OUT, 'g18_locked_neighbours.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours):
+        if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
+            continue
         fn()
         print('wrote', fn.__name__)

@@ -409,3 +409,73 @@ def test_section_of_tile_meshes_removes_stage_errors(fb):
     for m in meshes[1:]:
         d = m.vertices_w_offset(const.MESH_GEAR_MOVING) - m.vertices_w_offset(const.MESH_GEAR_INITIAL)
         assert np.ptp(d[:, 0]) < 1e-3 and np.ptp(d[:, 1]) < 1e-3
+
+
+# ----------------------------------------------------------------------- G17: Newton-Raphson driver (optimizer.py:1440-1555)
+def _g17_system(fb, g):
+    m0 = fb.mesh.Mesh(g['v'] + g['disp'], g['t1'], uid=0, locked=True)
+    m1 = fb.mesh.Mesh(g['v'].copy(), g['t1'], stiffness_multiplier=g['mult'], tri_model=g['model'], tri_nu=g['nu'],
+                      tri_matmult=g['matmult'].astype(np.float32), uid=1)
+    lk = fb.optimizer.Link(m0, m1, g['tid'], g['tid'], g['B'], g['B'], weight=g['w'])
+    return m0, m1, lk, fb.optimizer.SLM([m0, m1], [lk], stiffness_lambda=1.0, crosslink_lambda=1.0)
+
+
+@pytest.mark.parametrize('case,call', [
+    ('nr', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=8, tol=1e-9)),
+    ('nr3', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=3, tol=1e-6)),
+    ('elastic', lambda slm: slm.optimize_elastic(max_newtonstep=6, tol=1e-8)),
+    ('huber', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=6, tol=1e-8, residue_mode='huber', residue_len=0.2)),
+])
+def test_g17_newton_raphson_vs_reference(fb, case, call):
+    """SLM.optimize_Newton_Raphson / optimize_elastic against the REFERENCE's own run on the mixed-material mesh (golden G17,
+    deterministic settings): the out-of-balance force before the first step to 1e-6, the final field to 1e-4 of the motion
+    (the reference stops at its float32 stress floor, 4e-7 of the first force; three steps at 1e-6 end 1e-6 from it), the
+    returned cost at or below the reference's floor, and the huber weights of the last step"""
+    from conftest import load_golden
+    g = load_golden('g17_newton.npz')
+    m0, m1, lk, slm = _g17_system(fb, g)
+    c0, c1 = call(slm)
+    ref0, ref1 = g[f'{case}_cost']
+    assert abs(c0 - ref0) <= 1e-6 * ref0
+    assert c1 <= max(3.0 * ref1, 1e-6 * ref0)
+    exp = g[f'{case}_v_after'] + g[f'{case}_off_after'] - g['v']
+    got = m1.vertices_w_offset(fb.constant.MESH_GEAR_MOVING) - g['v']
+    scale = np.abs(exp).max()
+    assert np.abs(got - exp).max() <= 1e-4 * scale, np.abs(got - exp).max() / scale
+    np.testing.assert_allclose(lk._residue_weight, g[f'{case}_residue_weight'], atol=2e-4)
+
+
+def test_newton_ladder_follows_the_reference_schedule(fb):
+    """the per-step schedules (SLM.expand_to_list, optimizer.py:1862-1873): a scalar is the LAST step's value, lists are
+    right-aligned, earlier steps derive from the following one"""
+    lad = fb.optimizer.SLM._ladder
+    assert lad(1e-9, 4, lambda t: t * 10) == pytest.approx([1e-6, 1e-7, 1e-8, 1e-9])
+    assert lad('huber', 3, lambda _: None) == [None, None, 'huber']
+    assert lad([0.5, 0.25], 4, lambda r: 2 * r) == [2.0, 1.0, 0.5, 0.25]
+    assert lad([5, 6, 7], 2) == [6, 7]
+    assert lad(None, 2) == [None, None]
+
+
+# ----------------------------------------------------------------------- G18: one free section between two locked neighbours
+def test_g18_section_between_locked_neighbours_vs_reference(fb):
+    """the unit of BASELINE.json config[4] (aligner.py:696-727 with one free section): SLM.optimize_linear of a section
+    linked to two LOCKED neighbours, against the reference's own run (golden G18): ||b|| to 1e-6, field to 1e-5 of the motion;
+    a second section through the same SLM (links swapped without a new symbolic phase) gives the same answer"""
+    from conftest import load_golden
+    g = load_golden('g18_locked_neighbours.npz')
+    const = fb.constant
+    prev = fb.mesh.Mesh(g['v_prev'], g['t'], uid=0, locked=True)
+    cur = fb.mesh.Mesh(g['v'].copy(), g['t'], uid=1)
+    nxt = fb.mesh.Mesh(g['v_next'], g['t'], uid=2, locked=True)
+    slm = fb.optimizer.SLM([prev, cur, nxt], [], stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    exp = g['v_after'] + g['off_after'] - g['v']
+    for rep in range(2):
+        cur.set_vertices(g['v'].copy(), const.MESH_GEAR_MOVING); cur.set_offset(np.zeros((1, 2)), const.MESH_GEAR_MOVING)
+        slm.links = [fb.optimizer.Link(a, b, g[f'l{k}_tid'], g[f'l{k}_tid'], g[f'l{k}_B'], g[f'l{k}_B'], weight=g[f'l{k}_w'])
+                     for k, (a, b) in enumerate(((prev, cur), (cur, nxt)))]
+        sys_before = slm._sys
+        cost = slm.optimize_linear(tol=1e-11)
+        assert rep == 0 or slm._sys is sys_before
+        assert abs(cost[0] - g['cost'][0]) <= 1e-6 * g['cost'][0]
+        got = cur.vertices_w_offset(const.MESH_GEAR_MOVING) - g['v']
+        assert np.abs(got - exp).max() <= 1e-5 * np.abs(exp).max(), np.abs(got - exp).max() / np.abs(exp).max()

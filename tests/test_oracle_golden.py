@@ -350,3 +350,59 @@ def test_g16_anneal_modes(name, mode):
     m.anneal(gear=(fem_ref.GEAR_MOVING, fem_ref.GEAR_FIXED), mode=mode)
     np.testing.assert_allclose(m.vertices(fem_ref.GEAR_FIXED), g[f'an_{name}_vfix'], atol=1e-9)
     np.testing.assert_allclose(m.offset(fem_ref.GEAR_FIXED), g[f'an_{name}_foff'], atol=1e-9)
+
+
+# ----------------------------------------------------------------------- G17: Newton-Raphson driver (optimizer.py:1440-1555)
+def g17_oracle_system(g):
+    r0 = fem_ref.RefMesh(g['v'] + g['disp'], g['t1'], uid=0, locked=True)
+    r1 = fem_ref.RefMesh(g['v'].copy(), g['t1'], uid=1)
+    rl = fem_ref.RefLink(r0, r1, g['tid'], g['tid'], g['B'], g['B'], weight=g['w'])
+    return r0, r1, rl
+
+
+@pytest.mark.parametrize('case', ['nr', 'elastic'])
+def test_g17_newton_fixed_point(case):
+    """the oracle's exact Newton iteration ends where the reference's optimize_Newton_Raphson / optimize_elastic ends on
+    the mixed-material mesh (the reference stops at a relative out-of-balance force of 4e-7, its float32 stress floor):
+    same first out-of-balance force, fields equal to 1e-5 of the motion"""
+    g = load_golden('g17_newton.npz')
+    r0, r1, rl = g17_oracle_system(g)
+    costs = fem_ref.newton_fixed_point(r0, r1, [rl], g['mult'], g['model'], g['nu'], g['matmult'].astype(np.float32))
+    assert abs(costs[0] - g[f'{case}_cost'][0]) <= 1e-6 * g[f'{case}_cost'][0]
+    assert g[f'{case}_cost'][1] <= 1e-6 * g[f'{case}_cost'][0]
+    exp = g[f'{case}_v_after'] + g[f'{case}_off_after'] - g['v']
+    got = r1.vertices_w_offset(fem_ref.GEAR_MOVING) - g['v']
+    scale = np.abs(exp).max()
+    assert scale > 1.0
+    assert np.abs(got - exp).max() <= 1e-5 * scale
+
+
+def test_g17_residue_weights_after_the_last_step():
+    """residue_mode on the last step only (the ladder of optimizer.py:1470-1471 gives the earlier steps None): the weights
+    are re-evaluated once, after the last solve -- the oracle's huber rule on the reference's final field reproduces them"""
+    g = load_golden('g17_newton.npz')
+    r0, r1, rl = g17_oracle_system(g)
+    r1.set_field((g['huber_v_after'] + g['huber_off_after'] - g['v']), gear=(fem_ref.GEAR_FIXED, fem_ref.GEAR_MOVING))
+    np.testing.assert_allclose(rl.residue_weights((fem_ref.GEAR_MOVING, fem_ref.GEAR_MOVING), 'huber', 0.2), g['huber_residue_weight'], atol=2e-6)
+    assert int((g['huber_residue_weight'] < 1).sum()) >= 1
+    np.testing.assert_array_equal(g['huber_v_after'], g['elastic_v_after'])
+
+
+# ----------------------------------------------------------------------- G18: one free section between two locked neighbours
+def g18_oracle_system(g):
+    prev = fem_ref.RefMesh(g['v_prev'], g['t'], uid=0, locked=True)
+    cur = fem_ref.RefMesh(g['v'].copy(), g['t'], uid=1)
+    nxt = fem_ref.RefMesh(g['v_next'], g['t'], uid=2, locked=True)
+    links = [fem_ref.RefLink(a, b, g[f'l{k}_tid'], g[f'l{k}_tid'], g[f'l{k}_B'], g[f'l{k}_B'], weight=g[f'l{k}_w'])
+             for k, (a, b) in enumerate(((prev, cur), (cur, nxt)))]
+    return [prev, cur, nxt], links
+
+
+def test_g18_locked_neighbours():
+    g = load_golden('g18_locked_neighbours.npz')
+    ms, links = g18_oracle_system(g)
+    cost = fem_ref.optimize_linear(ms, links, exact=True)
+    assert abs(cost[0] - g['cost'][0]) <= 1e-6 * g['cost'][0]
+    exp = g['v_after'] + g['off_after'] - g['v']
+    got = ms[1].vertices_w_offset(fem_ref.GEAR_MOVING) - g['v']
+    assert np.abs(got - exp).max() <= 1e-6 * np.abs(exp).max()
