@@ -124,6 +124,7 @@ _PROTOS = {
     'fb_dog_down2_pair_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_d, c_i, c_p]),
     'fb_mask_range_dev': (c_i, [c_p, c_p, c_sz, C.c_float, C.c_float, c_p]),
     'fb_count_nonzero_dev': (c_i, [c_p, c_p, c_sz, C.POINTER(c_i64)]),
+    'fb_divide_bbox': (c_i, [c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p, c_p, c_i, c_p, c_i]),
     'fb_mesh_block_affines': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_d, c_p, c_p]),
     'fb_mesh_block_uncovered': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_mesh_locate_dev': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
@@ -290,7 +291,7 @@ def ctx(device=None):
 def check(rc, allow=(), h=None):
     """raise on a non-zero status; h = the context the call was made on (default: the calling thread's current one)"""
     if rc != 0 and rc not in allow:
-        msg = load().fb_last_error(ctx() if h is None else h)
+        msg = load().fb_last_error(h)                      # the message belongs to the calling thread, whatever the context (host-only entries have none)
         raise FeabasHipError(rc, msg.decode() if msg else '?')
     return rc
 

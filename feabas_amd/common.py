@@ -59,35 +59,27 @@ def numpy_array(obj, copy=False):
 
 
 def divide_bbox(bbox, **kwargs):
-    """feabas/common.py:380-409."""
-    xmin, ymin, xmax, ymax = bbox
-    ht = ymax - ymin
-    wd = xmax - xmin
-    block_size = kwargs.get('block_size', max(ht, wd))
-    min_num_blocks = kwargs.get('min_num_blocks', 1)
-    round_output = kwargs.get('round_output', True)
-    shrink_factor = kwargs.get('shrink_factor', 1)
-    if not hasattr(block_size, '__len__'):
-        block_size = (block_size, block_size)
-    if not hasattr(min_num_blocks, '__len__'):
-        min_num_blocks = (min_num_blocks, min_num_blocks)
-    n_x = max(np.ceil(wd / block_size[1]), min_num_blocks[1])
-    n_y = max(np.ceil(ht / block_size[0]), min_num_blocks[0])
-    step_x = int(np.ceil(wd / n_x))
-    step_y = int(np.ceil(ht / n_y))
-    x_start = np.linspace(xmin, xmax - step_x, num=int(n_x), endpoint=True)
-    y_start = np.linspace(ymin, ymax - step_y, num=int(n_y), endpoint=True)
-    if shrink_factor != 1:
-        sx, sy = step_x * shrink_factor, step_y * shrink_factor
-        x_start = x_start + (step_x - sx) / 2
-        y_start = y_start + (step_y - sy) / 2
-        step_x, step_y = int(np.ceil(sx)), int(np.ceil(sy))
-    if round_output:
-        x_start = np.round(x_start).astype(np.int32)
-        y_start = np.round(y_start).astype(np.int32)
-    gx, gy = np.meshgrid(x_start, y_start)
-    gx, gy = gx.ravel(), gy.ravel()
-    return gx, gy, gx + step_x, gy + step_y
+    """feabas/common.py:380-409 -> (x0, y0, x1, y1) of the blocks, row-major over (y, x).  The cut of each axis is made by the
+    C++ that also makes the block grids of fb_match_strips (fb_divide_bbox, csrc/fb_match.hip); needs no GPU."""
+    block = kwargs.get('block_size', max(bbox[3] - bbox[1], bbox[2] - bbox[0]))
+    least = kwargs.get('min_num_blocks', 1)
+    rounded = bool(kwargs.get('round_output', True))
+    block_hw = np.array(block if hasattr(block, '__len__') else (block, block), dtype=np.float64)
+    least_yx = np.array(least if hasattr(least, '__len__') else (least, least), dtype=np.int32)
+    box = np.array(bbox, dtype=np.float64)
+    counts, steps = np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.int32)
+    lib = _lib.load()
+    call = lambda xs, ys: _lib.check(lib.fb_divide_bbox(None, _lib.ptr(box), _lib.ptr(block_hw), _lib.ptr(least_yx), float(kwargs.get('shrink_factor', 1)),
+                                                        int(rounded), _lib.ptr(counts), _lib.ptr(steps), _lib.ptr(xs), 0 if xs is None else xs.size,
+                                                        _lib.ptr(ys), 0 if ys is None else ys.size))
+    call(None, None)                                        # sizing
+    xs, ys = np.empty(counts[0]), np.empty(counts[1])
+    call(xs, ys)
+    if rounded:
+        xs, ys = xs.astype(np.int32), ys.astype(np.int32)
+    x0 = np.tile(xs, ys.size)
+    y0 = np.repeat(ys, xs.size)
+    return x0, y0, x0 + int(steps[0]), y0 + int(steps[1])
 
 
 def intersect_bbox(bbox0, bbox1):

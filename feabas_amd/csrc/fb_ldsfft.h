@@ -207,6 +207,35 @@ __device__ __forceinline__ void twiddle_powers(float2 w1, float2* w) {
     for (int q = 2; q < R; ++q) w[q] = (q & 1) ? cmulf(w[q - 1], w1) : cmulf(w[q / 2], w[q / 2]);
 }
 
+// ---- packing two real images into one complex transform, z = img0 + i img1 (matcher.py:63-64 transforms them apart)
+// The split of the packed spectrum, A = (Z_k + conj Z_-k) / 2, B = -i (Z_k - conj Z_-k) / 2, carries the rounding of the
+// LARGER image into the smaller one's spectrum: with one side of a block (almost) blank -- a masked or saturated region, a
+// window that only grazes the texture -- its spectrum drowned in 6e-8 x the other side's and the confidence of such a block
+// became noise that changed with the FFT length.  So the weaker image of a tile (rows kernels) or block (on-chip kernel) is
+// brought to the magnitude of the stronger one by a power of two (exact) before the transform whenever they differ by 2^6 or
+// more, and the rows kernels divide it out again when they store the split spectra; peak, sub-pixel fit and confidences do
+// not depend on the scale of either image.  Tiles of comparable images (every block of a textured pair) are left as they are.
+__device__ __forceinline__ float2 pack_scales(float m0, float m1) {          // m = max |.| of each image over the tile / block
+    float s0 = 1.f, s1 = 1.f;
+    if (m0 > 0.f && m1 > 0.f && m0 < 3.0e38f && m1 < 3.0e38f) {
+        const int e0 = ilogbf(m0), e1 = ilogbf(m1);
+        if (e0 - e1 >= 6) s1 = ldexpf(1.f, e0 - e1);
+        else if (e1 - e0 >= 6) s0 = ldexpf(1.f, e1 - e0);
+    }
+    return make_float2(s0, s1);
+}
+// workgroup-wide max of two per-thread values; red: 2 * (threads / 64) floats of LDS; contains two barriers
+__device__ __forceinline__ float2 wg_max2(float m0, float m1, float* red) {
+    for (int off = 32; off > 0; off >>= 1) { m0 = fmaxf(m0, __shfl_down(m0, off)); m1 = fmaxf(m1, __shfl_down(m1, off)); }
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { red[2 * wave] = m0; red[2 * wave + 1] = m1; }
+    __syncthreads();
+    float a = red[0], b = red[1];
+    for (int w = 1; w < nw; ++w) { a = fmaxf(a, red[2 * w]); b = fmaxf(b, red[2 * w + 1]); }
+    __syncthreads();
+    return make_float2(a, b);
+}
+
 // LDS skew for unit-stride transforms: one spare slot every 16 elements.  Late passes walk the data with
 // strides of 8..128 elements; without the skew 4 to 8 lanes of a half-wave land on the same banks.
 __device__ __forceinline__ int fft_padx(int e) { return e + (e >> 4); }

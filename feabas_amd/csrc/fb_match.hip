@@ -93,6 +93,26 @@ inline double linspace_at(double start, double stop, int num, int i) {
 
 inline int round_i(double v) { return (int)std::nearbyint(v); }      // np.round: half to even
 
+// one axis of common.divide_bbox (feabas/common.py:380-409): the interval [lo, hi) cut into max(ceil(len / block), min_blocks)
+// blocks of ceil(len / count) pixels whose starts are numpy.linspace(lo, hi - step, count); a shrink factor keeps the centres
+// and scales the blocks
+struct AxisCut { int count; long long step0, step; double shift; };      // step0: before the shrink factor (the linspace ends at hi - step0)
+inline AxisCut cut_axis(double lo, double hi, double block, double min_blocks, double shrink) {
+    const double len = hi - lo;
+    const double cnt = std::max(std::ceil(len / block), min_blocks);
+    AxisCut c;
+    c.count = (int)cnt;
+    c.step0 = c.step = (long long)std::ceil(len / cnt);
+    c.shift = 0.0;
+    if (shrink != 1.0) {
+        const double s = (double)c.step0 * shrink;
+        c.shift = ((double)c.step0 - s) / 2.0;
+        c.step = (long long)std::ceil(s);
+    }
+    return c;
+}
+inline double cut_start(double lo, double hi, const AxisCut& c, int i) { return linspace_at(lo, hi - (double)c.step0, c.count, i) + c.shift; }
+
 // the matcher's grid: node counts of Mesh.from_bbox((0, 0, W, H), cartesian=True) (mesh.py:403-435)
 void grid_counts(int H, int W, double mesh_size, int mnb, int* nx_out, int* ny_out) {
     const double wd = (double)W, ht = (double)H;
@@ -477,6 +497,25 @@ int matcher_create(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, cons
 
 extern "C" {
 
+int fb_divide_bbox(fb_ctx* ctx, const double* bbox, const double* block_hw, const int* min_blocks_yx, double shrink_factor, int round_output,
+                   int* counts_xy, int* steps_xy, double* x_start, int cap_x, double* y_start, int cap_y) {
+    FB_CHECK_ARG(ctx, bbox && block_hw && min_blocks_yx && counts_xy && steps_xy);
+    FB_CHECK_ARG(ctx, bbox[2] > bbox[0] && bbox[3] > bbox[1] && block_hw[0] > 0 && block_hw[1] > 0 && shrink_factor > 0);
+    const AxisCut cx = cut_axis(bbox[0], bbox[2], block_hw[1], (double)min_blocks_yx[1], shrink_factor);
+    const AxisCut cy = cut_axis(bbox[1], bbox[3], block_hw[0], (double)min_blocks_yx[0], shrink_factor);
+    counts_xy[0] = cx.count; counts_xy[1] = cy.count;
+    steps_xy[0] = (int)cx.step; steps_xy[1] = (int)cy.step;
+    if (x_start) {
+        FB_CHECK_ARG(ctx, cap_x >= cx.count);
+        for (int i = 0; i < cx.count; ++i) { const double v = cut_start(bbox[0], bbox[2], cx, i); x_start[i] = round_output ? std::nearbyint(v) : v; }
+    }
+    if (y_start) {
+        FB_CHECK_ARG(ctx, cap_y >= cy.count);
+        for (int j = 0; j < cy.count; ++j) { const double v = cut_start(bbox[1], bbox[3], cy, j); y_start[j] = round_output ? std::nearbyint(v) : v; }
+    }
+    return FB_OK;
+}
+
 int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* o, fb_strip_matcher** out) {
     FB_LOCK(ctx);
     return matcher_create(ctx, P, H, W, nullptr, o, out);
@@ -635,9 +674,9 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
             const double ymin = std::max(-0.5 + ty[p], -0.5 + t1[2 * p + 1]), ymax = std::min(Hp - 0.5 + ty[p], Hp - 0.5 + t1[2 * p + 1]);
             if (!(xmax > xmin && ymax > ymin)) continue;
             // common.divide_bbox (common.py:380-409)
-            const double wd = xmax - xmin, ht = ymax - ymin;
-            const double nx = std::max(std::ceil(wd / spc), (double)mnb), ny = std::max(std::ceil(ht / spc), (double)mnb);
-            const long long dx = (long long)std::ceil(wd / nx), dy = (long long)std::ceil(ht / ny);
+            const AxisCut cx = cut_axis(xmin, xmax, spc, (double)mnb, 1.0), cy = cut_axis(ymin, ymax, spc, (double)mnb, 1.0);
+            const double nx = (double)cx.count, ny = (double)cy.count;
+            const long long dx = cx.step, dy = cy.step;
             if (dx < 1 || dy < 1 || 2 * dx > 8192 || 2 * dy > 8192 || nx >= 4096 || ny >= 4096)
                 return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: pair %d: block %lld x %lld on a %g x %g grid is outside the block matcher", p, dy, dx, ny, nx);
             xminv[p] = xmin; xmaxv[p] = xmax; yminv[p] = ymin; ymaxv[p] = ymax;

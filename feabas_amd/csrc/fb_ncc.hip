@@ -411,33 +411,47 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
     }
     load_tw(thi, tlo, g.twW_hi, g.twW_lo);
     for (int i = tid; i < Fw; i += nt) posW[i] = (short)fft_padx(fft_pos(g.pw, i));
-    // packed load z = img0 + i img1 (zero padded), branch-free; all rows of a column chunk are fetched before
-    // any LDS store so that the loads overlap
-    for (int xb = 0; xb < Fw; xb += nt) {
-        const int x = xb + tid;
-        const int gx0 = ox0 + x, gx1 = ox1 + x;
-        const bool vx0 = x < w0 && gx0 >= 0 && gx0 <= mx0, vx1 = x < w1 && gx1 >= 0 && gx1 <= mx1;
-        const int cx0 = min(max(gx0, 0), mx0), cx1 = min(max(gx1, 0), mx1);
-        float a[16], b[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (r < TR) {
-                const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
-                if (g.aff) b[r] = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
-                else b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
-            }
-        }
-        if (x < Fw) {
+    // packed load z = s0 img0 + i s1 img1 (zero padded), branch-free; all rows of a column chunk are fetched before any LDS
+    // store so that the loads overlap.  Two sweeps over the tile's input (the second one comes from L2): the first takes the
+    // maxima of the two images for pack_scales (fb_ldsfft.h), the second stores
+    __shared__ float s_red[2 * (kStreamThreads / 64)];
+    float2 sc = make_float2(1.f, 1.f);
+    float mmx = 0.f, mmy = 0.f;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        float m0 = 0.f, m1 = 0.f;
+        for (int xb = 0; xb < Fw; xb += nt) {
+            const int x = xb + tid;
+            const int gx0 = ox0 + x, gx1 = ox1 + x;
+            const bool vx0 = x < w0 && gx0 >= 0 && gx0 <= mx0, vx1 = x < w1 && gx1 >= 0 && gx1 <= mx1;
+            const int cx0 = min(max(gx0, 0), mx0), cx1 = min(max(gx1, 0), mx1);
+            float a[16], b[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (r < TR) {
                     const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                    const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
-                    const bool v1 = g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1);
-                    G[r * pitch + fft_padx(x)] = make_float2(v0 ? a[r] : 0.f, v1 ? b[r] : 0.f);
+                    a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
+                    if (g.aff) b[r] = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
+                    else b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
                 }
             }
+            if (x < Fw) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r < TR) {
+                        const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
+                        const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
+                        const bool v1 = g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1);
+                        const float va = v0 ? a[r] : 0.f, vb = v1 ? b[r] : 0.f;
+                        if (sweep == 0) { m0 = fmaxf(m0, fabsf(va)); m1 = fmaxf(m1, fabsf(vb)); }
+                        else G[r * pitch + fft_padx(x)] = make_float2(va * sc.x, vb * sc.y);
+                    }
+                }
+            }
+        }
+        if (sweep == 0) {
+            const float2 mm = wg_max2(m0, m1, s_red);
+            sc = pack_scales(mm.x, mm.y);
+            mmx = mm.x; mmy = mm.y;
         }
     }
     __syncthreads();
@@ -445,6 +459,8 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
     // split the packed spectra and store transposed as interleaved column pairs T[n][kx/2][y][kx&1]:
     // a (pair, tile) is 2*TR consecutive float2 = 128 B at TR = 8, lanes walk it contiguously
     const size_t tbase = (size_t)n * g.Kp * g.Hs * 2;
+    const float ia = mmx > 0.f ? 0.5f / sc.x : 0.f, ib = mmy > 0.f ? 0.5f / sc.y : 0.f;
+              // powers of two: exact; an image that is exactly zero on the tile gets an exactly zero spectrum (the split leaves rounding noise of the other image there)
     for (int t = tid; t < 2 * g.Kp * TR; t += nt) {
         const int c = t & 1, r = (t >> 1) & (TR - 1), kp = t / (2 * TR);
         const int kx = 2 * kp + c;
@@ -452,8 +468,8 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
         if (kx < Sw) {
             const float2 zk = G[r * pitch + posW[kx]];
             const float2 zn = G[r * pitch + posW[kx == 0 ? 0 : Fw - kx]];
-            a = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-            b = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+            a = make_float2(ia * (zk.x + zn.x), ia * (zk.y - zn.y));
+            b = make_float2(ib * (zk.y + zn.y), -ib * (zk.x - zn.x));
         }
         const size_t o = tbase + ((size_t)kp * g.Hs + y0 + r) * 2 + c;
         T0[o] = a;

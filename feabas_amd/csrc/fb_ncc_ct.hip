@@ -24,6 +24,8 @@ constexpr int kCtThreads = 256;
 __host__ __device__ constexpr int ct_pitch(int F) { return F | 1; }
 // column pairs per workgroup of the column pass: about 2 K points per transform set
 __host__ __device__ constexpr int ct_np(int FH) { return FH >= 1024 ? 1 : 1024 / FH; }
+// rows per tile of the row passes: the largest power of two <= 16 with at most 8 K points per tile
+__host__ __device__ constexpr int ct_tr(int FW) { int t = 16; while (t > 1 && t * FW > 8192) t >>= 1; return t; }
 
 template <int F>
 __device__ __forceinline__ void ct_tables(f2* tw, short* pos, const float2* __restrict__ tw_g, int tid, int nt) {
@@ -35,8 +37,7 @@ __device__ __forceinline__ void ct_tables(f2* tw, short* pos, const float2* __re
 template <int FW>
 __global__ __launch_bounds__(kCtThreads) void ncc_rows_ct(const StreamGeom g, const float2* __restrict__ tw_g, float2* __restrict__ T0, float2* __restrict__ T1) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    constexpr int pitch = ct_pitch(FW), Sw = FW / 2 + 1, NX = (FW + kCtThreads - 1) / kCtThreads;
-    const int TR = g.TR;
+    constexpr int pitch = ct_pitch(FW), Sw = FW / 2 + 1, NX = (FW + kCtThreads - 1) / kCtThreads, TR = ct_tr(FW);      // g.TR == TR (fb_ncc_ct_tr)
     f2* G = reinterpret_cast<f2*>(lds);
     f2* tw = G + (size_t)TR * pitch;
     short* posW = reinterpret_cast<short*>(tw + FW);
@@ -56,42 +57,50 @@ __global__ __launch_bounds__(kCtThreads) void ncc_rows_ct(const StreamGeom g, co
         s1 = g.img1 + (size_t)n * h1 * w1;
     }
     ct_tables<FW>(tw, posW, tw_g, tid, kCtThreads);
-    // packed load, zero padded, branch-free; columns beyond both crops are never read
+    // packed load, zero padded, branch-free; columns beyond both crops are never read.  Pass 1 fetches into registers and
+    // takes the maxima of the tile, pass 2 stores z = s0 img0 + i s1 img1 (pack_scales, fb_ldsfft.h)
     const int wmax = max(w0, w1);
+    __shared__ float s_red[2 * (kCtThreads / 64)];
+    float a[NX][TR], b[NX][TR];
+    float m0 = 0.f, m1 = 0.f;
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
         const int x = c * kCtThreads + tid;
         const int gx0 = ox0 + x, gx1 = ox1 + x;
         const bool vx0 = x < w0 && gx0 >= 0 && gx0 <= mx0, vx1 = x < w1 && gx1 >= 0 && gx1 <= mx1;
         const int cx0 = min(max(gx0, 0), mx0), cx1 = min(max(gx1, 0), mx1);
-        float a[16], b[16];
-        if (c * kCtThreads < wmax) {
+        const bool in = c * kCtThreads < wmax;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r < TR) {
-                    const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                    a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
-                    if (g.aff) b[r] = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
-                    else b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
-                }
+        for (int r = 0; r < TR; ++r) {
+            a[c][r] = 0.f; b[c][r] = 0.f;
+            if (in) {
+                const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
+                const float va = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
+                float vb;
+                if (g.aff) vb = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
+                else vb = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
+                const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
+                const bool v1 = g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1);
+                a[c][r] = v0 ? va : 0.f; b[c][r] = v1 ? vb : 0.f;
+                m0 = fmaxf(m0, fabsf(a[c][r])); m1 = fmaxf(m1, fabsf(b[c][r]));
             }
         }
+    }
+    const float2 mm = wg_max2(m0, m1, s_red);
+    const float2 sc = pack_scales(mm.x, mm.y);
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+        const int x = c * kCtThreads + tid;
         if (x < FW) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r < TR) {
-                    const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                    const bool in = c * kCtThreads < wmax;
-                    const bool v0 = in && vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
-                    const bool v1 = in && (g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1));
-                    G[r * pitch + x] = (f2){v0 ? a[r] : 0.f, v1 ? b[r] : 0.f};
-                }
-            }
+            for (int r = 0; r < TR; ++r) G[r * pitch + x] = (f2){a[c][r] * sc.x, b[c][r] * sc.y};
         }
     }
     __syncthreads();
     p3_fft<FW, kCtFam, false, false>(G, TR, pitch, tw);
     const size_t tbase = (size_t)n * g.Kp * g.Hs * 2;
+    const float ia = mm.x > 0.f ? 0.5f / sc.x : 0.f, ib = mm.y > 0.f ? 0.5f / sc.y : 0.f;
+              // powers of two: exact; an image that is exactly zero on the tile gets an exactly zero spectrum (the split leaves rounding noise of the other image there)
     for (int t = tid; t < 2 * g.Kp * TR; t += kCtThreads) {
         const int c = t & 1, r = (t >> 1) & (TR - 1), kp = t / (2 * TR);
         const int kx = 2 * kp + c;
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(kCtThreads) void ncc_rows_ct(const StreamGeom g, co
         if (kx < Sw) {
             const f2 zk = G[r * pitch + posW[kx]];
             const f2 zn = G[r * pitch + posW[kx == 0 ? 0 : FW - kx]];
-            a = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-            b = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+            a = make_float2(ia * (zk.x + zn.x), ia * (zk.y - zn.y));
+            b = make_float2(ib * (zk.y + zn.y), -ib * (zk.x - zn.x));
         }
         const size_t o = tbase + ((size_t)kp * g.Hs + y0 + r) * 2 + c;
         T0[o] = a;
@@ -362,11 +371,7 @@ int fb_ncc_ct_up(int need, int ref) {
     return 0;
 }
 
-int fb_ncc_ct_tr(int Fw) {
-    int t = 16;
-    while (t > 1 && t * Fw > 8192) t >>= 1;
-    return t;
-}
+int fb_ncc_ct_tr(int Fw) { return ct_tr(Fw); }
 
 int fb_ncc_ct_run(fb_ctx* ctx, const StreamGeom& g, int nb, float2* T0, float2* T1, float2* V0, float2* V1, PeakPartial* part,
                   int ntiles, float* ct9, int subpixel, double in_bytes) {

@@ -99,10 +99,12 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
     for (int i = tid; i < Fw; i += nt) { twW[i] = prm.tw_w[i]; posW[i] = (short)fft_pos(prm.pw, i); }
     for (int i = tid; i < Fh; i += nt) twH[i] = prm.tw_h[i];
     // branch-free (clamped address + select) so that the loads of several rows are in flight together
+    float fa = 1.f, fb = 1.f;        // 0 for an image that is exactly zero on the block: its spectrum is then exactly zero
     {
         int pitch0, pitch1, maxy0, maxx0, maxy1, maxx1;
         if (prm.blk) { pitch0 = IW0; pitch1 = IW1; maxy0 = IH0 - 1; maxx0 = IW0 - 1; maxy1 = IH1 - 1; maxx1 = IW1 - 1; }
         else { pitch0 = w0; pitch1 = w1; maxy0 = h0 - 1; maxx0 = w0 - 1; maxy1 = h1 - 1; maxx1 = w1 - 1; }
+        float m0 = 0.f, m1 = 0.f;
         for (int xc = 0; xc < RS; xc += 64) {
             const int x = xc + lane;
             const int gx0 = ox0 + x, gx1 = ox1 + x;
@@ -121,8 +123,18 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
                     v1e = x < w1 && y < h1;
                     b = fb_sample_affine(s1, IH1, IW1, prm.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
                 } else b = s1[(size_t)min(max(gy1, 0), maxy1) * pitch1 + cx1];
-                if (x < RS) G[y * RS + x] = make_float2(v0 ? a : 0.f, v1e ? b : 0.f);
+                const float va = v0 ? a : 0.f, vb = v1e ? b : 0.f;
+                m0 = fmaxf(m0, fabsf(va)); m1 = fmaxf(m1, fabsf(vb));
+                if (x < RS) G[y * RS + x] = make_float2(va, vb);
             }
+        }
+        // a block one side of which is (almost) blank: the weaker image is brought to the magnitude of the stronger one before
+        // the packed transform (pack_scales, fb_ldsfft.h); nothing downstream depends on the scale of either image
+        const float2 mm = wg_max2(m0, m1, red);               // ends with a barrier: G is complete
+        const float2 sc = pack_scales(mm.x, mm.y);
+        fa = mm.x > 0.f ? 1.f : 0.f; fb = mm.y > 0.f ? 1.f : 0.f;
+        if (sc.x != 1.f || sc.y != 1.f) {
+            for (int i = tid; i < Fh * RS; i += nt) { const float2 z = G[i]; G[i] = make_float2(z.x * sc.x, z.y * sc.y); }
         }
     }
     __syncthreads();
@@ -148,8 +160,10 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
         for (int q = 0; q < 3; ++q) {
             const int kx = lane + 64 * q;
             if (kx < Sw) {
-                row[kx] = make_float2(0.5f * (zk[q].x + zn[q].x), 0.5f * (zk[q].y - zn[q].y));            // A = (Zk + conj Zn)/2
-                row[Sw + kx] = make_float2(0.5f * (zk[q].y + zn[q].y), -0.5f * (zk[q].x - zn[q].x));     // B = -i (Zk - conj Zn)/2
+                // the split leaves rounding noise of one image in the other's spectrum: an all-zero image (the reference's rfft2 of
+                // zeros) gets exact zeros, so that its correlation surface is exactly zero and the confidence 0 (matcher.py:124-126)
+                row[kx] = make_float2(0.5f * fa * (zk[q].x + zn[q].x), 0.5f * fa * (zk[q].y - zn[q].y));            // A = (Zk + conj Zn)/2
+                row[Sw + kx] = make_float2(0.5f * fb * (zk[q].y + zn[q].y), -0.5f * fb * (zk[q].x - zn[q].x));     // B = -i (Zk - conj Zn)/2
             }
         }
     }

@@ -256,40 +256,37 @@ class SLM:
                     xy0, xy1, weight = xy0[~mask], xy1[~mask], weight[~mask]
         return out
 
-    def prune_links(self, **kwargs):                       # optimizer.py:688-717
-        if len(self.links) == 0:
-            return False
-        relevance = np.array([self.link_is_relevant(lnk) for lnk in self.links])
-        if np.all(relevance == 1):
-            return False
-        new_links = []
-        for lnk, flag in zip(self.links, relevance):
-            if flag == 1:
-                new_links.append(lnk)
-            elif flag == -1:
-                m0_list, _ = self.select_mesh_from_uid(lnk.uids[0])
-                m1_list, _ = self.select_mesh_from_uid(lnk.uids[1])
-                new_links.extend(SLM.distribute_link(m0_list, m1_list, lnk, working_gear=kwargs.get('working_gear', const.MESH_GEAR_INITIAL),
-                                                     exclusive=kwargs.get('submesh_exclusive', True)))
-        self.links = new_links
-        return True
+    def prune_links(self, **kwargs):
+        """optimizer.py:688-717: links that still name whole meshes stay, links an end of which was cut into parts
+        (uid 3 -> 3.0, 3.01, ...) are dealt to the pairs of parts that hold their matches (distribute_link), links to meshes
+        that are gone are dropped.  Returns whether the list changed."""
+        gear = kwargs.get('working_gear', const.MESH_GEAR_INITIAL)
+        exclusive = kwargs.get('submesh_exclusive', True)
+        kept, changed = [], False
+        for lk in self.links:
+            state = self.link_is_relevant(lk)
+            if state == 1:
+                kept.append(lk)
+                continue
+            changed = True
+            if state == -1:
+                ends = [self.select_mesh_from_uid(u)[0] for u in lk.uids]
+                kept += SLM.distribute_link(ends[0], ends[1], lk, working_gear=gear, exclusive=exclusive)
+        if changed:
+            self.links = kept
+        return changed
 
-    def divide_disconnected_submeshes(self, prune_links=True, **kwargs):      # optimizer.py:738-754
-        modified = False
-        new_meshes = []
-        for m in self.meshes:
-            if m.locked:
-                new_meshes.append(m)
-            else:
-                dm = m.divide_disconnected_mesh()
-                new_meshes.extend(dm)
-                modified |= len(dm) > 1
-        if modified:
-            self.meshes = new_meshes
-            self._drop_system()
-            if prune_links:
-                self.prune_links(**kwargs)
-        return modified
+    def divide_disconnected_submeshes(self, prune_links=True, **kwargs):
+        """optimizer.py:738-754: every free mesh that falls into several connected parts is replaced by its parts (locked
+        meshes stay whole); the links follow unless prune_links is False.  Returns whether a mesh was divided."""
+        pieces = [[m] if m.locked else list(m.divide_disconnected_mesh()) for m in self.meshes]
+        if max((len(p) for p in pieces), default=1) <= 1:
+            return False
+        self.meshes = [part for p in pieces for part in p]
+        self._drop_system()
+        if prune_links:
+            self.prune_links(**kwargs)
+        return True
 
     def clear_links(self):
         self.links = []
@@ -1015,80 +1012,99 @@ def solve(A, b, solver='minres', x0=None, tol=1e-7, atol=None, maxiter=None, M=N
     return x
 
 
+def _free_vertex_mask(M, free_vertices, free_triangles):
+    """vertices a relaxation may move: the listed ones, or every vertex that no HELD triangle uses"""
+    mask = np.zeros(M.num_vertices, dtype=bool)
+    if free_vertices is not None:
+        mask[free_vertices] = True
+    elif free_triangles is not None:
+        held = np.zeros(M.num_vertices, dtype=bool)
+        held[M.triangles[~np.asarray(free_triangles, dtype=bool)].ravel()] = True
+        mask = ~held
+    return mask
+
+
+class _RestingShapeAligned:
+    """For the duration of a local relaxation the resting shape (gear[0]) of the mesh is its INITIAL shape laid rigidly,
+    connected part by connected part, over the current state (gear[1]); afterwards gear[0] is what it was, and so is the
+    lock (optimizer.py:2131-2135, 2149-2153)."""
+
+    def __init__(self, M, gear):
+        self.M, self.gear = M, gear
+
+    def __enter__(self):
+        M, g = self.M, self.gear
+        self.lock, M.locked = M.locked, False
+        self.saved = (M.vertices(gear=g[0]), M.offset(gear=g[0]))
+        M.anneal(gear=(const.MESH_GEAR_INITIAL, g[0]), mode=const.ANNEAL_COPY_EXACT)
+        M.anneal(gear=g[::-1], mode=const.ANNEAL_CONNECTED_RIGID)
+        return self
+
+    def __exit__(self, *exc):
+        M, g = self.M, self.gear
+        if g[0] != g[1]:
+            M.set_vertices(self.saved[0], gear=g[0])
+            M.set_offset(self.saved[1], gear=g[0])
+        M.locked = self.lock
+        return False
+
+
 def relax_mesh(M, free_vertices=None, free_triangles=None, **kwargs):
     """feabas/optimizer.py:2110-2154: relax a region of one mesh with the rest of it held.  The free vertices are the
-    given ones, or those that belong to free triangles only.  The resting shape is the INITIAL one, rigidly aligned to
-    the current state per connected component; the sub-mesh of triangles touching a free vertex is assembled with
-    clipped multipliers (``Mesh.stiffness_matrix_local_normalized``, HIP) and the free block solved by the device PCG.
-    Returns whether the mesh was modified.  ``tolerated_perturbation`` / ``callback_settings`` are accepted and unused:
-    the PCG runs to ``tol``."""
+    given ones, or those no held triangle uses.  The triangles that touch a free vertex are assembled on the device with
+    clipped multipliers against the rigidly aligned INITIAL shape (``Mesh.stiffness_matrix_local_normalized``) and the
+    held degrees of freedom are taken out by the solver itself (``solve(extra_dof_constraint=)``: the device PCG works on
+    the free block); the field is applied when it lowers the residual.  Returns whether the mesh was modified.
+    ``tolerated_perturbation`` / ``callback_settings`` are accepted and unused: the PCG runs to ``tol``."""
     gear = kwargs.get('gear', (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING))
-    maxiter = kwargs.get('maxiter', None)
-    tol = kwargs.get('tol', 1e-7)
-    atol = kwargs.get('atol', 0.0)
-    cond = kwargs.get('precondition', 'jacobi')
-    modified = False
-    locked = M.locked
-    M.locked = False
-    try:
-        if free_vertices is not None:
-            vindx = free_vertices
-        elif free_triangles is not None:
-            T = M.triangles[~np.asarray(free_triangles, dtype=bool)]
-            vindx = ~np.isin(np.arange(M.num_vertices), np.unique(T))
-        else:
-            return modified
-        vmask = np.zeros(M.num_vertices, dtype=bool)
-        vmask[vindx] = True
-        if not np.any(vmask):
-            return modified
-        tmask = np.any(vmask[M.triangles], axis=-1)
-        vmask_pad = np.repeat(vmask, 2)
-        fixed_vertices = M.vertices(gear=gear[0])
-        fixed_offset = M.offset(gear=gear[0])
-        M.anneal(gear=(const.MESH_GEAR_INITIAL, gear[0]), mode=const.ANNEAL_COPY_EXACT)
-        M.anneal(gear=gear[::-1], mode=const.ANNEAL_CONNECTED_RIGID)
-        stiff_M, stress_v = M.stiffness_matrix_local_normalized(gear=gear, tri_mask=tmask)
-        if stiff_M is not None:
-            A = stiff_M[vmask_pad][:, vmask_pad]
-            b = -stress_v[vmask_pad].astype(np.float64)
-            dd = solve(A, b, kwargs.get('solver', 'minres'), tol=tol, maxiter=maxiter, atol=atol, M=cond)
-            cost = (np.linalg.norm(b), np.linalg.norm(A.dot(dd) - b))
-            if (cost[1] < cost[0]) and np.any(dd != 0):
-                modified = True
-                M.apply_field(dd.reshape(-1, 2), gear[-1], vtx_mask=vmask)
-        if gear[0] != gear[1]:
-            M.set_vertices(fixed_vertices, gear=gear[0])
-            M.set_offset(fixed_offset, gear=gear[0])
-    finally:
-        M.locked = locked
-    return modified
+    if free_vertices is None and free_triangles is None:
+        return False
+    free = _free_vertex_mask(M, free_vertices, free_triangles)
+    if not free.any():
+        return False
+    dof = np.repeat(free, 2)
+    with _RestingShapeAligned(M, gear):
+        K, stress = M.stiffness_matrix_local_normalized(gear=gear, tri_mask=free[M.triangles].any(axis=1))
+        if K is None:
+            return False
+        force = -stress.astype(np.float64)
+        move = solve(K, force, kwargs.get('solver', 'minres'), tol=kwargs.get('tol', 1e-7), maxiter=kwargs.get('maxiter', None),
+                     atol=kwargs.get('atol', 0.0), M=kwargs.get('precondition', 'jacobi'), extra_dof_constraint=dof)
+        # the held entries of `move` are zero, so (K move)[free] is the free block applied to the free part
+        before, after = np.linalg.norm(force[dof]), np.linalg.norm((K @ move - force)[dof])
+        if not (after < before and np.any(move[dof] != 0)):
+            return False
+        M.apply_field(move.reshape(-1, 2)[free], gear[-1], vtx_mask=free)
+    return True
+
+
+def _deformation_beyond_usual(M, gear):
+    """per triangle: the larger of its area and edge deformation (0 = none, 1 = flipped), minus the median over the
+    normally stiff triangles (multiplier at least half the median one), and that reference set"""
+    area = Mesh.svds_to_deform(M.triangle_area_deform(gear=gear).reshape(-1, 1))
+    edge = Mesh.svds_to_deform(M.triangle_edge_deform(gear=gear).reshape(-1, 1))
+    mult = M.effective_stiffness_multiplier()
+    usual = mult >= 0.5 * np.median(mult)
+    score = np.maximum(area, edge)
+    return score - np.median(score[usual]), usual
 
 
 def relax_mesh_most_deformed(M, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), deform_cutoff=const.MAXIMUM_DEFORM_ALLOWED, iqr=0):
-    """feabas/optimizer.py:2157-2190: free the flipped triangles' vertices (``deform_cutoff`` < 0) or the triangles
-    around those deformed beyond the cutoff (area or edge stretch, relative to the median of the normally stiff
-    triangles; optionally an inter-quartile outlier rule), and relax them."""
-    modified = False
-    sa = M.triangle_area_deform(gear=gear).reshape(-1, 1)
+    """feabas/optimizer.py:2157-2190.  deform_cutoff < 0: only flipped triangles count and their vertices are freed.
+    Otherwise a triangle counts when its deformation exceeds the usual one by more than 1 - 1 / (cutoff + 1) (with
+    iqr > 0 also capped at the upper quartile + iqr inter-quartile ranges of the normally stiff triangles; never below
+    1e-3), and the triangles that lie wholly on vertices of such triangles are relaxed."""
     if deform_cutoff < 0:
-        tmask = Mesh.svds_to_deform(sa) >= 1
-        if not np.any(tmask):
-            return modified
-        return relax_mesh(M, free_vertices=np.unique(M.triangles[tmask]), gear=gear)
-    deform_thresh = 1 - 1 / (abs(deform_cutoff) + 1)
-    sd = M.triangle_edge_deform(gear=gear).reshape(-1, 1)
-    defm = np.maximum(Mesh.svds_to_deform(sa), Mesh.svds_to_deform(sd))
-    m0 = M.effective_stiffness_multiplier()
-    idx_m = m0 >= 0.5 * np.median(m0)
-    defm = defm - np.median(defm[idx_m])
-    thresh_t = max(deform_thresh, 0)
+        flipped = np.ravel(Mesh.svds_to_deform(M.triangle_area_deform(gear=gear).reshape(-1, 1)) >= 1)
+        return relax_mesh(M, free_vertices=np.unique(M.triangles[flipped]), gear=gear) if flipped.any() else False
+    score, usual = _deformation_beyond_usual(M, gear)
+    limit = max(1 - 1 / (abs(deform_cutoff) + 1), 0)
     if iqr > 0:
-        qq = np.quantile(defm[idx_m], (0.25, 0.75))
-        thresh_t = min(thresh_t, np.max(qq) + iqr * np.ptp(qq))
-    tmask = defm > max(thresh_t, 1.0e-3)
-    if not np.any(tmask):
-        return modified
-    vid = np.unique(M.triangles[tmask])
-    tmask = np.all(np.isin(M.triangles, vid), axis=-1)
-    return relax_mesh(M, free_triangles=tmask, gear=gear)
+        q1, q3 = np.quantile(score[usual], (0.25, 0.75))
+        limit = min(limit, max(q1, q3) + iqr * abs(q3 - q1))
+    hot = np.ravel(score > max(limit, 1.0e-3))
+    if not hot.any():
+        return False
+    touched = np.zeros(M.num_vertices, dtype=bool)
+    touched[M.triangles[hot].ravel()] = True
+    return relax_mesh(M, free_triangles=touched[M.triangles].all(axis=1), gear=gear)

@@ -344,6 +344,13 @@ typedef struct fb_strip_opts {
 #define FB_STRIP_NONRIGID 2
 #define FB_STRIP_RELAXFIRST 4
 #define FB_STRIP_RIGIDFIT 8
+/* common.divide_bbox (feabas/common.py:380-409), host only: the bounding box bbox = {xmin, ymin, xmax, ymax} cut into
+ * max(ceil(extent / block), min_blocks) blocks per axis (block_hw = {h, w}, min_blocks_yx = {ny, nx}) of ceil(extent / count)
+ * pixels, starts = numpy.linspace(lo, hi - step, count), a shrink_factor != 1 scales the blocks about their centres, round_output
+ * rounds the starts half to even (np.round).  counts_xy = {nx, ny}, steps_xy = {step_x, step_y}; x_start / y_start (capacity cap_x /
+ * cap_y doubles, may be NULL for a sizing call).  The block grid fb_match_strips walks is made by the same code. */
+int fb_divide_bbox(fb_ctx* ctx, const double* bbox, const double* block_hw, const int* min_blocks_yx, double shrink_factor, int round_output,
+                   int* counts_xy, int* steps_xy, double* x_start, int cap_x, double* y_start, int cap_y);
 int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* opts, fb_strip_matcher** out);
 /* Strips of unequal size (the usual case in a real section: every overlap follows the stage jitter of its two tiles,
  * stitcher.py:561-571): pair p is the shapes[p] = {h, w} top-left corner of its H x W slot; every stage works on the pair's own

@@ -110,6 +110,36 @@ def test_xcorr_compile_time_mixed_radix_class(fb, s0, s1, n, pad):
         np.testing.assert_allclose(got[2], gen[2], atol=2e-5)
 
 
+@pytest.mark.parametrize('shape,pad', [((75, 73), False), ((75, 73), True), ((70, 70), True), ((256, 120), True), ((150, 150), False), ((280, 280), True)])
+def test_xcorr_one_image_almost_blank(fb, shape, pad):
+    """a block one side of which is almost blank (a masked or saturated region, a window that only grazes the texture): the
+    reference transforms the two images apart (matcher.py:63-64) and its answer does not depend on the magnitude of either;
+    the device packs them into ONE complex transform, where the weak image used to drown in the rounding of the strong one
+    (its confidence became noise that changed with the FFT length).  With pack_scales (fb_ldsfft.h) every class -- on-chip,
+    power-of-two, compile-time mixed radix, run-time mixed radix -- gives the oracle's peak, offset and confidence with one
+    image scaled by 1e-6 or 1e+5, and the same answer as for the unscaled pair"""
+    rng = np.random.default_rng(shape[0] + 7 * int(pad))
+    i0, i1 = _pairs(rng, 6, shape, shape, maxshift=max(1, min(shape) // 5))
+    base = fb.matcher.xcorr_fft(i0, i1, pad=pad, subpixel=True)
+    for s0, s1 in ((1.0, 1e-6), (1e-6, 1.0), (1e5, 1.0), (1.0, 3e-3)):
+        a, b = (i0 * np.float32(s0)).astype(np.float32), (i1 * np.float32(s1)).astype(np.float32)
+        got = fb.matcher.xcorr_fft(a, b, pad=pad, subpixel=True)
+        exp = ncc_ref.xcorr_fft(a, b, pad=pad, subpixel=True)
+        _check(got, exp)
+        np.testing.assert_array_equal(np.round(got[0]), np.round(base[0])); np.testing.assert_array_equal(np.round(got[1]), np.round(base[1]))
+        np.testing.assert_allclose(got[0], base[0], atol=2e-4); np.testing.assert_allclose(got[1], base[1], atol=2e-4)
+        np.testing.assert_allclose(got[2], base[2], atol=1e-4)
+    # one image exactly zero (a window inside a masked region): zero surface, first index, confidence 0 -- not the noise of
+    # the other image's rounding
+    z = np.zeros_like(i1)
+    z[3, :shape[0] // 2] = i1[3, :shape[0] // 2]                       # ... also when only some rows of the stack's blocks are blank
+    for a, b in ((i0, z), (z, i1)):
+        got = fb.matcher.xcorr_fft(a, b, pad=pad, subpixel=True)
+        exp = ncc_ref.xcorr_fft(a, b, pad=pad, subpixel=True)
+        _check(got, exp)
+        assert np.all(got[2][[0, 1, 2, 4, 5]] == 0)
+
+
 def test_xcorr_streaming_class(fb):
     """coarse classes of the 4k tile pair at reduced count: 1024x510 blocks (FFT 2048x1024)
     and the 2048x255 global strip (FFT 4096x512)."""
