@@ -651,13 +651,12 @@ def main():
         return
     rccl_ranks = 1
     if launched:
+        # torch.distributed is the launcher's rendezvous, the barrier and the max-over-ranks of the timings: a gloo group on
+        # host tensors.  Every byte of the data path goes through the C ABI on the library's own RCCL communicator, so ONE
+        # ROCm stack touches the device (torch's wheel bundles a second one; round 2 initialised both).
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        one = torch.ones(1, device='cuda')
-        dist.all_reduce(one)                               # an RCCL collective: the number of ranks that really take part
-        rccl_ranks = int(one.item())
+        dist.init_process_group('gloo')
     os.environ['FEABAS_HIP_DEVICE'] = str(local_rank)
 
     from feabas_amd import _lib
@@ -672,23 +671,23 @@ def main():
         comm_ctx = _lib.new_context(local_rank)
         ex_note = None
         try:
-            ex = fdist.Exchange(ctx=comm_ctx)
-            ok = torch.ones(1, device='cuda')
-        except Exception as e:                            # noqa: BLE001 -- reported in the line; the run goes on over torch.distributed
-            ex_note = f'C-ABI RCCL communicator unavailable ({e}); exchange through torch.distributed point-to-point transfers'
-            ok = torch.zeros(1, device='cuda')
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)         # one rank without it: every rank takes the torch route (collectives must match)
-        if float(ok.item()) < 1:
+            ex = fdist.Exchange(backend='rccl', ctx=comm_ctx)
+            ok = 1.0
+        except Exception as e:                            # noqa: BLE001 -- reported in the line; the run goes on over the host group
+            ex_note = f'C-ABI RCCL communicator unavailable ({e}); exchange through the gloo group on host arrays'
+            ok = 0.0
+        if fdist.host_sum([ok]) [0] < world:              # one rank without it: every rank takes the host route (collectives must match)
             if ex_note is None:
                 ex.close()
-                ex_note = 'another rank has no C-ABI RCCL communicator; exchange through torch.distributed point-to-point transfers'
+                ex_note = 'another rank has no C-ABI RCCL communicator; exchange through the gloo group on host arrays'
             ex = fdist.Exchange(backend='torch')
         ex.note = ex_note
+        rccl_ranks = ex.rccl_ranks()                      # an all-reduce of ones through fb_allreduce_f64_dev: the ranks of the LIBRARY's communicator
 
     def reduce_max(x):
         if dist is None:
             return x
-        tt = torch.tensor([x], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
@@ -743,11 +742,11 @@ def main():
         for h in ctxs:
             _lib.check(lib.fb_sync(h))
         if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            dist.barrier()                                # gloo; the device side of the bracket is the fb_sync of every context above
+            for h in ctxs:
+                _lib.check(lib.fb_sync(h))
 
-    stagger_ms = float(os.environ.get("FEABAS_BENCH_STAGGER_MS", "3"))      # experiment: offset the first call of host thread k by k x this
+    stagger_ms = float(os.environ.get("FEABAS_HIP_STAGGER_MS", os.environ.get("FEABAS_BENCH_STAGGER_MS", "3")))      # first call of host thread k offset by k x this: the stagger matcher.stitching_matcher_batch applies to its worker threads
 
     def run_steps(first, count):
         """`count` steps starting at index `first`, dealt round-robin to the host threads so that one thread's block-list
@@ -778,6 +777,8 @@ def main():
                 if stagger_ms:
                     time.sleep(1e-3 * stagger_ms * k)
                 for i in mine:
+                    if errs:
+                        return
                     r = step(i)
                     with cv:
                         results[i] = r
@@ -788,17 +789,24 @@ def main():
                     cv.notify_all()
 
         def comm():
-            pending = []
-            for i in idx:
+            # a failed gather must not pass for a finished one: the error joins `errs`, the workers stop at their next step and the
+            # exception leaves main() -- a non-zero exit, on which the launcher tears the other ranks (blocked in their transfer) down
+            try:
+                pending = []
+                for i in idx:
+                    with cv:
+                        cv.wait_for(lambda: i in results or errs)
+                        if errs:
+                            return
+                        r = results[i]
+                    pending.append((i, r[2]))
+                    if len(pending) == S:
+                        exchange(pending); pending = []
+                exchange(pending)
+            except BaseException as e:                    # noqa: BLE001
                 with cv:
-                    cv.wait_for(lambda: i in results or errs)
-                    if errs:
-                        return
-                    r = results[i]
-                pending.append((i, r[2]))
-                if len(pending) == S:
-                    exchange(pending); pending = []
-            exchange(pending)
+                    errs.append(e)
+                    cv.notify_all()
         T = nthr
         ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k], ctxs[k % len(ctxs)], k)) for k in range(T)]
         ths.append(threading.Thread(target=comm))
@@ -858,8 +866,8 @@ def main():
     pairs = args.steps * S * P * world
     per_rank = [args.steps * S * P / dt_rank]
     if dist is not None:
-        tl = [torch.zeros(1, dtype=torch.float64, device='cuda') for _ in range(world)]
-        dist.all_gather(tl, torch.tensor([per_rank[0]], dtype=torch.float64, device='cuda'))
+        tl = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([per_rank[0]], dtype=torch.float64))
         per_rank = [float(t_.item()) for t_ in tl]
 
     # correctness of the timed work: recovered translations = injected shifts, matches found
@@ -992,7 +1000,7 @@ def main():
             barrier()
             fem['allgather_displacements_s'] = reduce_max(time.time() - t0)
             fem['allgather_bytes'] = int(allx.nbytes)
-            tt = torch.tensor([fem['iters_per_s']], dtype=torch.float64, device='cuda')
+            tt = torch.tensor([fem['iters_per_s']], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             fem['iters_per_s_all_ranks'] = float(tt.item())
         fem.pop('x', None)
@@ -1049,8 +1057,8 @@ def main():
     if args.stitch_sections > 0:
         st = bench_stitch_sections(args, lib, _lib, rank, world, ctxs, ex, barrier, reduce_max)
         if dist is not None:
-            tl = [torch.zeros(1, dtype=torch.float64, device='cuda') for _ in range(world)]
-            dist.all_gather(tl, torch.tensor([st['edge'].pop('pairs_per_s_this_rank')], dtype=torch.float64, device='cuda'))
+            tl = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(tl, torch.tensor([st['edge'].pop('pairs_per_s_this_rank')], dtype=torch.float64))
             st['edge']['pairs_per_s_per_rank'] = [float(t_.item()) for t_ in tl]
             st['corner'].pop('pairs_per_s_this_rank', None)
         if rank == 0:
@@ -1058,7 +1066,7 @@ def main():
     if args.align_sections > 0:
         al = bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_max)
         if dist is not None:
-            tt = torch.tensor([float(al['pcg_iters_this_rank']), al['optimize_linear_seconds_this_rank']], dtype=torch.float64, device='cuda')
+            tt = torch.tensor([float(al['pcg_iters_this_rank']), al['optimize_linear_seconds_this_rank']], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             al['pcg_iters_all_ranks'] = float(tt[0].item())
         if rank == 0:

@@ -178,6 +178,8 @@ _PROTOS = {
     'fb_cgcg_update_dev': (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'fb_cgcg_dots_dev': (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
     'fb_cgcg_scalars_dev': (c_i, [c_p, c_p, c_p, c_i]),
+    'fb_gather_f64_dev': (c_i, [c_p, c_i64, c_p, c_p, c_p]),
+    'fb_cgcg_solve_dev': (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_d, c_i, c_i, C.POINTER(c_i), C.POINTER(c_d), C.POINTER(c_d)]),
     'fb_comm_unique_id': (c_i, [c_p, c_p]),
     'fb_comm_create': (c_i, [c_p, c_p, c_i, c_i, C.POINTER(c_p)]),
     'fb_comm_destroy': (None, [c_p, c_p]),
@@ -222,6 +224,15 @@ def load():
 
 
 _tls = threading.local()
+
+
+def gpu_available():
+    """whether this process can have a context (a GPU is visible and the library loads)"""
+    try:
+        ctx()
+        return True
+    except Exception:
+        return False
 
 
 def new_context(device=None):

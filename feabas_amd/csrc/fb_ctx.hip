@@ -105,9 +105,18 @@ int stage_init(fb_ctx* ctx) {
 }
 }  // namespace
 
+namespace {
+// page-locked host memory (fb_host_alloc, hipHostMalloc / hipHostRegister of the caller) goes straight to the DMA engine
+bool host_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+}  // namespace
+
 int fb_copy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return FB_OK;
-    if (bytes <= kStageDirect) {
+    if (bytes <= kStageDirect || host_pinned(src)) {
         FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         return FB_OK;
     }
@@ -128,7 +137,7 @@ int fb_copy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 int fb_copy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return FB_OK;
-    if (bytes <= kStageDirect) {
+    if (bytes <= kStageDirect || host_pinned(dst)) {
         FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return FB_OK;

@@ -213,8 +213,10 @@ __device__ __forceinline__ void twiddle_powers(float2 w1, float2* w) {
 // window that only grazes the texture -- its spectrum drowned in 6e-8 x the other side's and the confidence of such a block
 // became noise that changed with the FFT length.  So the weaker image of a tile (rows kernels) or block (on-chip kernel) is
 // brought to the magnitude of the stronger one by a power of two (exact) before the transform whenever they differ by 2^6 or
-// more, and the rows kernels divide it out again when they store the split spectra; peak, sub-pixel fit and confidences do
-// not depend on the scale of either image.  Tiles of comparable images (every block of a textured pair) are left as they are.
+// more -- an extra sweep over the tile in LDS, taken by such tiles only: the maxima ride the barrier that precedes the
+// transform anyway -- and the rows kernels divide it out again when they store the split spectra; peak, sub-pixel fit and
+// confidences do not depend on the scale of either image.  Tiles of comparable images (every block of a textured pair) are
+// left exactly as they were.
 __device__ __forceinline__ float2 pack_scales(float m0, float m1) {          // m = max |.| of each image over the tile / block
     float s0 = 1.f, s1 = 1.f;
     if (m0 > 0.f && m1 > 0.f && m0 < 3.0e38f && m1 < 3.0e38f) {
@@ -224,15 +226,17 @@ __device__ __forceinline__ float2 pack_scales(float m0, float m1) {          // 
     }
     return make_float2(s0, s1);
 }
-// workgroup-wide max of two per-thread values; red: 2 * (threads / 64) floats of LDS; contains two barriers
-__device__ __forceinline__ float2 wg_max2(float m0, float m1, float* red) {
+// workgroup-wide max of two per-thread values in two halves around a barrier the caller has anyway: wg_max2_post (every
+// thread) before it, wg_max2_read after it.  red: 2 * (threads / 64) floats of LDS that nobody writes again before the next
+// barrier.
+__device__ __forceinline__ void wg_max2_post(float m0, float m1, float* red) {
     for (int off = 32; off > 0; off >>= 1) { m0 = fmaxf(m0, __shfl_down(m0, off)); m1 = fmaxf(m1, __shfl_down(m1, off)); }
-    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) { red[2 * wave] = m0; red[2 * wave + 1] = m1; }
-    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = m0; red[2 * (threadIdx.x >> 6) + 1] = m1; }
+}
+__device__ __forceinline__ float2 wg_max2_read(const float* red) {
+    const int nw = (blockDim.x + 63) >> 6;
     float a = red[0], b = red[1];
     for (int w = 1; w < nw; ++w) { a = fmaxf(a, red[2 * w]); b = fmaxf(b, red[2 * w + 1]); }
-    __syncthreads();
     return make_float2(a, b);
 }
 

@@ -25,6 +25,7 @@
 #pragma clang fp contract(off)
 
 struct fb_strip_matcher {
+    fb_ctx* owner = nullptr;           // the context that made the matcher: its buffers and its system go back THERE
     int P = 0, H = 0, W = 0, hc = 0, wc = 0;
     double sigma = 2.5;
     int cds2 = 1;
@@ -151,7 +152,8 @@ void pool_give(fb_ctx* ctx, void* ptr, size_t bytes) {
         for (size_t i = 1; i < ctx->match_pool.size(); ++i)
             if (by_count ? ctx->match_pool[i].second < ctx->match_pool[k].second : ctx->match_pool[i].second > ctx->match_pool[k].second) k = i;
         total -= ctx->match_pool[k].second;
-        fb_free(ctx, ctx->match_pool[k].first);
+        if (fb_free(ctx, ctx->match_pool[k].first) != FB_OK)
+            std::fprintf(stderr, "libfeabas_hip: strip-matcher pool: %s\n", fb_last_error(ctx));     // a pointer of another context: never after the owner rule of fb_strip_matcher_destroy
         ctx->match_pool.erase(ctx->match_pool.begin() + k);
     }
 }
@@ -425,6 +427,7 @@ int matcher_create(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, cons
     FB_CHECK_ARG(ctx, o->sigma > 0.0 && o->min_num_blocks >= 1 && (o->residue_mode == 0 || o->residue_mode == 1) && o->nspacings >= 0 &&
                           (o->nspacings == 0 || o->spacings) && o->nspacings <= 64);
     fb_strip_matcher* m = new fb_strip_matcher();
+    m->owner = ctx;
     m->P = P; m->H = H; m->W = W;
     m->ragged = shapes != nullptr;
     { const char* e = std::getenv("FEABAS_HIP_MATCH_TRACE"); m->trace = e && e[0] == '1'; }
@@ -529,6 +532,14 @@ int fb_strip_matcher_create_ragged(fb_ctx* ctx, int P, int H, int W, const int32
 
 void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m) {
     if (!m) return;
+    // whatever context the caller is on, the matcher's buffers (fb_malloc'ed by its creator) and its relaxation system return
+    // to the context that made it: handed to another one, the pool would hold pointers that context does not own (fb_free
+    // refuses them, so the bound of the pool was not enforced) and would hand them out after their owner is gone
+    if (m->owner && m->owner != ctx) {
+        FB_LOCK(ctx);
+        hipStreamSynchronize(ctx->stream);                  // the caller's stream may have run the matcher's last kernels
+        ctx = m->owner;
+    }
     FB_LOCK(ctx);
     if (m->trace && m->calls > 3) {
         const int c = m->calls - 3;

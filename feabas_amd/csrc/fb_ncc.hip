@@ -411,50 +411,48 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
     }
     load_tw(thi, tlo, g.twW_hi, g.twW_lo);
     for (int i = tid; i < Fw; i += nt) posW[i] = (short)fft_padx(fft_pos(g.pw, i));
-    // packed load z = s0 img0 + i s1 img1 (zero padded), branch-free; all rows of a column chunk are fetched before any LDS
-    // store so that the loads overlap.  Two sweeps over the tile's input (the second one comes from L2): the first takes the
-    // maxima of the two images for pack_scales (fb_ldsfft.h), the second stores
+    // packed load z = img0 + i img1 (zero padded), branch-free; all rows of a column chunk are fetched before
+    // any LDS store so that the loads overlap
     __shared__ float s_red[2 * (kStreamThreads / 64)];
-    float2 sc = make_float2(1.f, 1.f);
-    float mmx = 0.f, mmy = 0.f;
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        float m0 = 0.f, m1 = 0.f;
-        for (int xb = 0; xb < Fw; xb += nt) {
-            const int x = xb + tid;
-            const int gx0 = ox0 + x, gx1 = ox1 + x;
-            const bool vx0 = x < w0 && gx0 >= 0 && gx0 <= mx0, vx1 = x < w1 && gx1 >= 0 && gx1 <= mx1;
-            const int cx0 = min(max(gx0, 0), mx0), cx1 = min(max(gx1, 0), mx1);
-            float a[16], b[16];
+    float m0 = 0.f, m1 = 0.f;
+    for (int xb = 0; xb < Fw; xb += nt) {
+        const int x = xb + tid;
+        const int gx0 = ox0 + x, gx1 = ox1 + x;
+        const bool vx0 = x < w0 && gx0 >= 0 && gx0 <= mx0, vx1 = x < w1 && gx1 >= 0 && gx1 <= mx1;
+        const int cx0 = min(max(gx0, 0), mx0), cx1 = min(max(gx1, 0), mx1);
+        float a[16], b[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r < TR) {
+                const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
+                a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
+                if (g.aff) b[r] = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
+                else b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
+            }
+        }
+        if (x < Fw) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (r < TR) {
                     const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                    a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
-                    if (g.aff) b[r] = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
-                    else b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
+                    const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
+                    const bool v1 = g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1);
+                    const float va = v0 ? a[r] : 0.f, vb = v1 ? b[r] : 0.f;
+                    m0 = fmaxf(m0, fabsf(va)); m1 = fmaxf(m1, fabsf(vb));
+                    G[r * pitch + fft_padx(x)] = make_float2(va, vb);
                 }
             }
-            if (x < Fw) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (r < TR) {
-                        const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                        const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
-                        const bool v1 = g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1);
-                        const float va = v0 ? a[r] : 0.f, vb = v1 ? b[r] : 0.f;
-                        if (sweep == 0) { m0 = fmaxf(m0, fabsf(va)); m1 = fmaxf(m1, fabsf(vb)); }
-                        else G[r * pitch + fft_padx(x)] = make_float2(va * sc.x, vb * sc.y);
-                    }
-                }
-            }
-        }
-        if (sweep == 0) {
-            const float2 mm = wg_max2(m0, m1, s_red);
-            sc = pack_scales(mm.x, mm.y);
-            mmx = mm.x; mmy = mm.y;
         }
     }
+    wg_max2_post(m0, m1, s_red);
     __syncthreads();
+    const float2 mm = wg_max2_read(s_red);
+    const float2 sc = pack_scales(mm.x, mm.y);                // (fb_ldsfft.h) != 1 only for a tile one side of which is almost blank
+    const float mmx = mm.x, mmy = mm.y;
+    if (sc.x != 1.f || sc.y != 1.f) {
+        for (int i = tid; i < TR * Fw; i += nt) { float2* z = G + (i / Fw) * pitch + fft_padx(i % Fw); *z = make_float2(z->x * sc.x, z->y * sc.y); }
+        __syncthreads();
+    }
     fft_batch_tw<false, TwSplit, 16, true>(G, g.pw, TR, 1, pitch, TwSplit{thi, tlo}, false);
     // split the packed spectra and store transposed as interleaved column pairs T[n][kx/2][y][kx&1]:
     // a (pair, tile) is 2*TR consecutive float2 = 128 B at TR = 8, lanes walk it contiguously

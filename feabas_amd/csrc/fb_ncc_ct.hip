@@ -57,11 +57,9 @@ __global__ __launch_bounds__(kCtThreads) void ncc_rows_ct(const StreamGeom g, co
         s1 = g.img1 + (size_t)n * h1 * w1;
     }
     ct_tables<FW>(tw, posW, tw_g, tid, kCtThreads);
-    // packed load, zero padded, branch-free; columns beyond both crops are never read.  Pass 1 fetches into registers and
-    // takes the maxima of the tile, pass 2 stores z = s0 img0 + i s1 img1 (pack_scales, fb_ldsfft.h)
+    // packed load, zero padded, branch-free; columns beyond both crops are never read
     const int wmax = max(w0, w1);
     __shared__ float s_red[2 * (kCtThreads / 64)];
-    float a[NX][TR], b[NX][TR];
     float m0 = 0.f, m1 = 0.f;
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
@@ -69,34 +67,37 @@ __global__ __launch_bounds__(kCtThreads) void ncc_rows_ct(const StreamGeom g, co
         const int gx0 = ox0 + x, gx1 = ox1 + x;
         const bool vx0 = x < w0 && gx0 >= 0 && gx0 <= mx0, vx1 = x < w1 && gx1 >= 0 && gx1 <= mx1;
         const int cx0 = min(max(gx0, 0), mx0), cx1 = min(max(gx1, 0), mx1);
-        const bool in = c * kCtThreads < wmax;
+        float a[TR], b[TR];
+        if (c * kCtThreads < wmax) {
 #pragma unroll
-        for (int r = 0; r < TR; ++r) {
-            a[c][r] = 0.f; b[c][r] = 0.f;
-            if (in) {
+            for (int r = 0; r < TR; ++r) {
                 const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                const float va = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
-                float vb;
-                if (g.aff) vb = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
-                else vb = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
-                const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
-                const bool v1 = g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1);
-                a[c][r] = v0 ? va : 0.f; b[c][r] = v1 ? vb : 0.f;
-                m0 = fmaxf(m0, fabsf(a[c][r])); m1 = fmaxf(m1, fabsf(b[c][r]));
+                a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
+                if (g.aff) b[r] = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
+                else b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
+            }
+        }
+        if (x < FW) {
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
+                const bool in = c * kCtThreads < wmax;
+                const bool v0 = in && vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
+                const bool v1 = in && (g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1));
+                const float va = v0 ? a[r] : 0.f, vb = v1 ? b[r] : 0.f;
+                m0 = fmaxf(m0, fabsf(va)); m1 = fmaxf(m1, fabsf(vb));
+                G[r * pitch + x] = (f2){va, vb};
             }
         }
     }
-    const float2 mm = wg_max2(m0, m1, s_red);
-    const float2 sc = pack_scales(mm.x, mm.y);
-#pragma unroll
-    for (int c = 0; c < NX; ++c) {
-        const int x = c * kCtThreads + tid;
-        if (x < FW) {
-#pragma unroll
-            for (int r = 0; r < TR; ++r) G[r * pitch + x] = (f2){a[c][r] * sc.x, b[c][r] * sc.y};
-        }
-    }
+    wg_max2_post(m0, m1, s_red);
     __syncthreads();
+    const float2 mm = wg_max2_read(s_red);
+    const float2 sc = pack_scales(mm.x, mm.y);                // (fb_ldsfft.h) != 1 only for a tile one side of which is almost blank
+    if (sc.x != 1.f || sc.y != 1.f) {
+        for (int i = tid; i < TR * FW; i += kCtThreads) { f2* z = G + (i / FW) * pitch + (i % FW); *z = (f2){z->x * sc.x, z->y * sc.y}; }
+        __syncthreads();
+    }
     p3_fft<FW, kCtFam, false, false>(G, TR, pitch, tw);
     const size_t tbase = (size_t)n * g.Kp * g.Hs * 2;
     const float ia = mm.x > 0.f ? 0.5f / sc.x : 0.f, ib = mm.y > 0.f ? 0.5f / sc.y : 0.f;

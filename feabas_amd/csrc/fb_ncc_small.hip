@@ -130,14 +130,16 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
         }
         // a block one side of which is (almost) blank: the weaker image is brought to the magnitude of the stronger one before
         // the packed transform (pack_scales, fb_ldsfft.h); nothing downstream depends on the scale of either image
-        const float2 mm = wg_max2(m0, m1, red);               // ends with a barrier: G is complete
+        wg_max2_post(m0, m1, red);
+        __syncthreads();                                      // G and the tables are complete
+        const float2 mm = wg_max2_read(red);
         const float2 sc = pack_scales(mm.x, mm.y);
         fa = mm.x > 0.f ? 1.f : 0.f; fb = mm.y > 0.f ? 1.f : 0.f;
         if (sc.x != 1.f || sc.y != 1.f) {
             for (int i = tid; i < Fh * RS; i += nt) { const float2 z = G[i]; G[i] = make_float2(z.x * sc.x, z.y * sc.y); }
+            __syncthreads();
         }
     }
-    __syncthreads();
     const int rows_nz = max(h0, h1);
     // ---- forward along x on the non-zero rows
     FB_SMALL_FFT(Fw, false, false, rows_nz, reinterpret_cast<const f2*>(twW), fft_batch<false>(G, prm.pw, rows_nz, 1, RS, twW, false));

@@ -781,15 +781,23 @@ __global__ __launch_bounds__(256) void cgcg_dots_final_kernel(int nblk, const do
     }
 }
 
+// dst[i] = src[idx[i]]: the entries of u a neighbouring rank needs, packed for one transfer
+__global__ __launch_bounds__(256) void gather_f64_kernel(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ src, double* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+
 // t3 = (r.u, w.u, r.r) summed over the ranks.  first != 0: the start of the iteration (alpha = gamma / delta, beta = 0)
 __global__ void cgcg_scalars_kernel(const double* __restrict__ t3, double* __restrict__ state, int first) {
     const double g_new = t3[0], delta = t3[1];
     double alpha, beta;
-    if (first) {
+    if (first || state[1] == 0.0) {
+        // the start of the iteration, or the step after a dropped one: p = u, s = w (beta = 0), alpha = gamma / delta -- a
+        // restart of the recurrence from the current iterate.  (A dropped step used to be absorbing: alpha = 0 made the next
+        // denominator 0 and every later step was dropped too, up to maxiter.)  state[4] counts the dropped steps.
         beta = 0.0;
         alpha = delta > 0.0 ? g_new / delta : 0.0;
-        state[4] = delta > 0.0 || g_new == 0.0 ? 0.0 : 1.0;
-        state[5] = 0.0;
+        if (first) { state[4] = 0.0; state[5] = 0.0; } else state[5] += 1.0;
+        if (!(delta > 0.0) && g_new != 0.0) state[4] += 1.0;
     } else {
         const double g_old = state[0], a_old = state[1];
         beta = g_old != 0.0 ? g_new / g_old : 0.0;
@@ -797,7 +805,7 @@ __global__ void cgcg_scalars_kernel(const double* __restrict__ t3, double* __res
         // den <= 0 (loss of positive definiteness in floating point, or an exactly converged residual): the step is dropped
         // instead of poisoning x with 0 / 0; the flag tells the host
         alpha = den > 0.0 ? g_new / den : 0.0;
-        if (!(den > 0.0) && g_new != 0.0) state[4] = 1.0;
+        if (!(den > 0.0) && g_new != 0.0) state[4] += 1.0;
         if (!(den > 0.0)) beta = 0.0;
         state[5] += 1.0;
     }
@@ -834,6 +842,97 @@ int fb_cgcg_scalars_dev(fb_ctx* ctx, const double* t3, double* state, int first)
     hipLaunchKernelGGL(cgcg_scalars_kernel, dim3(1), dim3(1), 0, ctx->stream, t3, state, first);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
+}
+
+int fb_gather_f64_dev(fb_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, n >= 0 && (n == 0 || (idx && src && dst)));
+    if (n == 0) return FB_OK;
+    hipLaunchKernelGGL(gather_f64_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kCgWG)), dim3(256), 0, ctx->stream, n, idx, src, dst);
+    FB_HIP(ctx, hipGetLastError());
+    return FB_OK;
+}
+
+// The whole row-partitioned PCG of a coupled window behind one call (the loop of feabas_amd/dist.py in C++): per iteration
+//   update (one pass over 12 vectors) -> pack + halo exchange (fb_sendrecv_dev) -> SpMV on [own | halo] -> three inner
+//   products -> ONE all-reduce of 3 doubles (fb_allreduce_f64_dev) -> scalar recurrences on the device,
+// everything on the context's stream; the host reads the 64-byte state every `check_every` iterations.
+int fb_cgcg_solve_dev(fb_ctx* ctx, fb_comm* comm, fb_csr* rows, int64_t n_loc, int64_t n_halo, const double* b, const double* minv, double* x,
+                      int nsend, const int* send_peer, const int64_t* send_off, const int32_t* send_idx, int nrecv, const int* recv_peer,
+                      const int64_t* recv_off, double rtol, int maxiter, int check_every, int* iters, double* relres, double* bnorm) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, n_loc >= 0 && n_halo >= 0 && (n_loc + n_halo == 0 || (rows && rows->n == n_loc + n_halo)) && (n_loc == 0 || (b && minv && x)));     // a rank may own nothing: it still takes part in every reduction
+    FB_CHECK_ARG(ctx, nsend >= 0 && nrecv >= 0 && (nsend == 0 || (send_peer && send_off && send_idx)) && (nrecv == 0 || (recv_peer && recv_off)));
+    FB_CHECK_ARG(ctx, (nsend + nrecv == 0) || comm);
+    FB_CHECK_ARG(ctx, nrecv == 0 || recv_off[nrecv] <= n_halo);
+    if (check_every < 1) check_every = 8;
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n = n_loc, m = n_loc + n_halo;
+    const int64_t nsb = nsend ? send_off[nsend] : 0;
+    // work vectors in one block: ext [m] (u at its head), r, p, s, w [n each], y [m], sendbuf, state[8], t3[4], scratch[3 * 1024]
+    const size_t words = (size_t)m + 4 * (size_t)n + (size_t)m + (size_t)nsb + 8 + 4 + 3 * 1024 + 16;
+    double* blk = nullptr;
+    int rc = fb_malloc(ctx, words * sizeof(double), (void**)&blk);
+    if (rc) return rc;
+    struct Guard { fb_ctx* c; void* p; ~Guard() { fb_free(c, p); } } guard{ctx, blk};
+    FB_HIP(ctx, hipMemsetAsync(blk, 0, words * sizeof(double), ctx->stream));
+    double* ext = blk; double* r = ext + m + (m & 1); double* p = r + n; double* s = p + n; double* w = s + n;
+    double* y = w + n + (n & 1); double* sb = y + m + (m & 1); double* state = sb + nsb + (nsb & 1); double* t3 = state + 8; double* scratch = t3 + 4;
+    double* u = ext;
+    if (n) {
+        FB_HIP(ctx, hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, ctx->stream));
+        FB_HIP(ctx, hipMemcpyAsync(r, b, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    std::vector<const void*> sp((size_t)nsend); std::vector<int64_t> sbytes((size_t)nsend);
+    std::vector<void*> rp((size_t)nrecv); std::vector<int64_t> rbytes((size_t)nrecv);
+    for (int k = 0; k < nsend; ++k) { sp[k] = sb + send_off[k]; sbytes[k] = 8 * (send_off[k + 1] - send_off[k]); }
+    for (int k = 0; k < nrecv; ++k) { rp[k] = ext + n + recv_off[k]; rbytes[k] = 8 * (recv_off[k + 1] - recv_off[k]); }
+    auto product_and_dots = [&](int first) -> int {
+        int e;
+        if (nsend + nrecv) {
+            if ((e = fb_gather_f64_dev(ctx, nsb, send_idx, u, sb))) return e;
+            if ((e = fb_sendrecv_dev(ctx, comm, nsend, send_peer, sp.data(), sbytes.data(), nrecv, recv_peer, rp.data(), rbytes.data()))) return e;
+        }
+        if (m && (e = fb_bsr_spmv_dev(ctx, rows->M, reinterpret_cast<const double2*>(ext), reinterpret_cast<double2*>(y)))) return e;
+        if (n) FB_HIP(ctx, hipMemcpyAsync(w, y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        if ((e = fb_cgcg_dots_dev(ctx, n, r, u, w, scratch, t3))) return e;
+        if (comm && (e = fb_allreduce_f64_dev(ctx, comm, t3, t3, 3, FB_REDUCE_SUM))) return e;
+        return fb_cgcg_scalars_dev(ctx, t3, state, first);
+    };
+    // u = minv r through the update kernel with alpha = beta = 0 (state is zero, p = s = 0)
+    if ((rc = fb_cgcg_update_dev(ctx, n, state, minv, x, r, u, w, p, s))) return rc;
+    if ((rc = product_and_dots(1))) return rc;
+    double hs[8];
+    FB_HIP(ctx, hipMemcpyAsync(hs, state, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double bb = hs[3];
+    if (bnorm) *bnorm = std::sqrt(bb);
+    if (iters) *iters = 0;
+    if (relres) *relres = 0.0;
+    if (bb == 0.0 || maxiter == 0) return FB_OK;
+    if (!(bb == bb) || bb < 0) return fb_fail(ctx, FB_ERR_BREAKDOWN, "fb_cgcg_solve_dev: ||b||^2 = %g", bb);
+    const int limit = maxiter > 0 ? maxiter : 100 * 1000;
+    int it = 0;
+    double rel = 1.0, dropped_seen = 0.0;
+    while (it < limit) {
+        const int batch = std::min(check_every, limit - it);
+        for (int k = 0; k < batch; ++k) {
+            if ((rc = fb_cgcg_update_dev(ctx, n, state, minv, x, r, u, w, p, s))) return rc;
+            if ((rc = product_and_dots(0))) return rc;
+        }
+        it += batch;
+        FB_HIP(ctx, hipMemcpyAsync(hs, state, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rel = std::sqrt(hs[3] / bb);
+        if (iters) *iters = it;
+        if (relres) *relres = rel;
+        if (!(rel == rel)) return fb_fail(ctx, FB_ERR_BREAKDOWN, "fb_cgcg_solve_dev: the residual is not finite after %d iterations", it);
+        if (rel <= rtol) return FB_OK;
+        // dropped steps restart the recurrence (cgcg_scalars_kernel); a system that keeps dropping them is not positive definite
+        if (hs[4] - dropped_seen >= (double)batch) return fb_fail(ctx, FB_ERR_BREAKDOWN, "fb_cgcg_solve_dev: every step of the last %d was dropped (p^T A p <= 0): the system is not positive definite", batch);
+        dropped_seen = hs[4];
+    }
+    return FB_ERR_NOCONV;
 }
 
 int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, double rtol, double atol, int maxiter, int precond,

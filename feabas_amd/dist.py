@@ -1,11 +1,16 @@
-"""Sharding and the (only) exchange steps of the multi-GPU runs.
+"""Sharding and the exchange steps of the multi-GPU runs.
 
-One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
-in the CPU tests).  Tile pairs / sections are independent units: every rank works on a contiguous
-shard -- the same contiguous-slice partitioning the reference uses for its worker jobs
-(feabas/stitcher.py:375-392) -- with no collective on the data path.  What is exchanged afterwards:
-  * the variable-length match table of every rank   -> ``gather_match_table``
-  * per-section node displacement vectors           -> ``allgather_ragged``
+One process per GPU.  Tile pairs / sections are independent units: every rank works on a contiguous shard -- the same
+contiguous-slice partitioning the reference uses for its worker jobs (feabas/stitcher.py:375-392) -- with no collective on
+the data path.  What is exchanged afterwards:
+  * the variable-length match table of every rank   -> ``Exchange.gatherv`` / ``gather_match_table``
+  * per-section node displacement vectors           -> ``Exchange.allgather`` / ``allgather_ragged``
+and, for a coupled alignment window, the halo entries and three scalars of every PCG iteration (second half of this file).
+
+``torch.distributed`` is the RENDEZVOUS (a gloo group: who is who, counts, the 128-byte RCCL id) and the transport of the
+CPU tests.  On the GPU every byte of the data path moves through the C ABI of libfeabas_hip.so on the library's own RCCL
+communicator (fb_comm_*, fb_gatherv_dev, fb_allgather_dev, fb_sendrecv_dev, fb_allreduce_f64_dev): torch never touches
+the device here.
 """
 import os
 
@@ -25,9 +30,9 @@ def _dist():
     return torch, dist
 
 
-def _device(dist):
+def _cpu():
     import torch
-    return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    return torch.device('cpu')
 
 
 class Exchange:
@@ -41,38 +46,48 @@ class Exchange:
     ``torch.distributed`` point-to-point operations on host tensors."""
 
     def __init__(self, group=None, backend=None, ctx=None):
-        """collective over `group`.  ctx: the fb_ctx whose stream carries the transfers (default: the caller's current
-        context); a host thread that only communicates should own one, so that a gather does not queue behind kernels"""
+        """collective over `group`.  backend 'rccl': transfers through the C ABI on an RCCL communicator (default when a GPU
+        context exists or the group's backend is nccl); 'torch': host tensors over the gloo group (CPU tests).  ctx: the
+        fb_ctx whose stream carries the transfers -- default: a context of the Exchange's own, so that a gather never queues
+        behind the kernels of a matcher thread and a communicator that could not be made leaves no lock behind on a context
+        somebody else uses.  (The coupled-window solver needs the communicator on the context of its vectors: pass that
+        context.)"""
         torch, dist = _dist()
-        self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if backend is None:
             backend = 'rccl' if dist.get_backend(group) == 'nccl' else 'torch'
+        self.group = host_group(group)                       # rendezvous and host transport: never torch's GPU stack
         self.backend = backend
         self.comm = None
+        self._own_ctx = None
         self.seconds = 0.0            # wall time spent inside gatherv / allgather (host view, includes the copies)
         self.bytes = 0
         if backend == 'rccl':
             import ctypes as C
             from . import _lib
             self._lib, self._C = _lib, C
-            lib, ctx = _lib.load(), (_lib.ctx() if ctx is None else ctx)
+            lib = _lib.load()
+            if ctx is None:
+                ctx = self._own_ctx = _lib.new_context()
             # every rank makes an id (the cheapest call that needs the RCCL library): a rank that cannot load it must not
             # leave the others waiting in the broadcast below, so the ranks agree on that first
             ident = np.zeros(128, dtype=np.uint8)
             rc = lib.fb_comm_unique_id(ctx, _lib.ptr(ident))
             err = None if rc == 0 else (lib.fb_last_error(ctx) or b'?').decode()
             flags = [None] * self.world
-            dist.all_gather_object(flags, err, group=group)
+            dist.all_gather_object(flags, err, group=self.group)
             bad = [(r, e) for r, e in enumerate(flags) if e is not None]
             if bad:
+                self._drop_ctx()
                 raise RuntimeError(f'RCCL is not available on rank {bad[0][0]}: {bad[0][1]}')
             box = [ident.tobytes()]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
             ident = np.frombuffer(box[0], dtype=np.uint8).copy()
             h = C.c_void_p()
-            # ncclCommInitRank blocks until every rank has joined; a rank stuck in it is given up after a while (the thread
-            # is left behind) so that the caller can fall back to another route instead of hanging the job
+            # ncclCommInitRank blocks until every rank has joined; a rank stuck in it is given up after a while so that the
+            # caller can take another route instead of hanging the job.  The abandoned thread keeps the lock of `ctx` for as
+            # long as it blocks: with a context of the Exchange's own nobody else ever waits for that lock; a caller that
+            # passed its context must not use it again after this error.
             import threading
             res = {}
 
@@ -83,15 +98,36 @@ class Exchange:
             th.start()
             th.join(float(os.environ.get('FEABAS_HIP_COMM_TIMEOUT', '120')))
             if th.is_alive():
+                self._own_ctx = None                         # left to the stuck thread: destroying it would block on its lock
                 raise RuntimeError('fb_comm_create did not return (ncclCommInitRank waiting for the other ranks)')
             if res['rc'] != 0:
+                self._drop_ctx()
                 raise _lib.FeabasHipError(res['rc'], res['err'] or '?')
             self.comm, self._ctx = h, ctx
+
+    def _drop_ctx(self):
+        if self._own_ctx is not None:
+            self._lib.load().fb_destroy(self._own_ctx)
+            self._own_ctx = None
 
     def close(self):
         if self.comm is not None:
             self._lib.load().fb_comm_destroy(self._ctx, self.comm)
             self.comm = None
+            self._drop_ctx()
+
+    def rccl_ranks(self):
+        """the number of ranks that really take part in the library's communicator: an all-reduce of ones through
+        fb_allreduce_f64_dev (1 without a communicator)"""
+        if self.comm is None:
+            return 1
+        _lib, lib = self._lib, self._lib.load()
+        with _lib.using(self._ctx):
+            d = _lib.DeviceBuffer.from_array(np.ones(1))
+            _lib.check(lib.fb_allreduce_f64_dev(self._ctx, self.comm, d.ptr, d.ptr, 1, 0), h=self._ctx)
+            out = int(round(float(d.to_array((1,), np.float64)[0])))
+            d.free()
+        return out
 
     # -- counts of every rank (one int64 each)
     def _counts(self, n):
@@ -104,7 +140,7 @@ class Exchange:
             out = allc.to_array((self.world,), np.int64)
             mine.free(); allc.free()
             return out
-        dev = _device(dist)
+        dev = _cpu()
         cnt = torch.tensor([n], dtype=torch.int64, device=dev)
         cnts = torch.zeros(self.world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(cnts, cnt, group=self.group)
@@ -150,7 +186,7 @@ class Exchange:
                 if b is not None:
                     b.free()
         else:
-            dev = _device(dist)
+            dev = _cpu()
             ops, bufs = [], []
             if self.rank == root:
                 for r in range(self.world):
@@ -193,7 +229,7 @@ class Exchange:
             out = recv.to_array((self.world,) + arr.shape, arr.dtype)
             send.free(); recv.free()
         else:
-            dev = _device(dist)
+            dev = _cpu()
             t = torch.from_numpy(arr.reshape(-1).view(np.uint8).copy()).to(dev)
             o = torch.empty(t.numel() * self.world, dtype=torch.uint8, device=dev)
             dist.all_gather_into_tensor(o, t, group=self.group)
@@ -216,23 +252,51 @@ def exchange(group=None):
 
 def release_exchanges():
     for ex in _default_exchange.values():
-        ex.close()
+        if isinstance(ex, Exchange):
+            ex.close()
     _default_exchange.clear()
+
+
+def solver_comm(group=None):
+    """the RCCL communicator of the coupled-window solver over `group`, on the CALLING thread's context (where the solver's
+    vectors live), made on first use and kept; None when the ranks cannot have one -- a single rank, no GPU, or two ranks on
+    one device (RCCL refuses that: the tests of the multi-rank logic on a one-GPU box) -- every rank reaches the same
+    answer.  Collective: every rank of the group must call it."""
+    torch, dist = _dist()
+    from . import _lib
+    hg = host_group(group)
+    world = dist.get_world_size(hg)
+    key = ('solver', id(group), _lib._ctx_device)
+    if key in _default_exchange:
+        return _default_exchange[key].comm
+    force = os.environ.get('FEABAS_HIP_EXCHANGE') == 'rccl'        # a one-rank communicator: the rehearsal of the N-rank code path
+    if world == 1 and not force:
+        return None
+    import socket
+    here = (socket.gethostname(), int(os.environ.get('FEABAS_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0'))), _lib._ctx is not None or _lib.gpu_available())
+    seats = [None] * world
+    dist.all_gather_object(seats, here, group=hg)
+    if not all(s[2] for s in seats) or len({s[:2] for s in seats}) < world or os.environ.get('FEABAS_HIP_EXCHANGE') == 'host':
+        return None                                          # (every rank sees the same list: the same answer everywhere)
+    ex = Exchange(group, backend='rccl', ctx=_lib.ctx())
+    _default_exchange[key] = ex
+    return ex.comm
 
 
 def allgather_ragged(arr, group=None):
     """all-gather of per-rank arrays whose first dimension differs: the list of every rank's array, on every rank.
     A gatherv to rank 0 would do for the match table (north star: one gather); this form is for callers that need the
-    table everywhere (the coupled-window set-up, tests).  Counts first, then every rank's exact bytes (no padding)."""
-    torch, dist = _dist()
+    table everywhere (tests, small set-up tables).  ONE exchange of the counts and ONE all-gather of blocks padded to the
+    largest contribution (2 collectives whatever the number of ranks; a loop of gathervs took 2 per rank)."""
     ex = exchange(group)
     arr = np.ascontiguousarray(arr)
-    parts = None
-    for root in range(ex.world):
-        got = ex.gatherv(arr, root=root)
-        if got is not None:
-            parts = got
-    return parts
+    with ex._scope():
+        cnts = ex._counts(arr.shape[0])
+        cap = int(cnts.max())
+        pad = np.zeros((cap,) + arr.shape[1:], dtype=arr.dtype)
+        pad[:arr.shape[0]] = arr
+        allp = ex._allgather(pad) if cap else np.zeros((ex.world, 0) + arr.shape[1:], dtype=arr.dtype)
+    return [allp[r, :int(cnts[r])] for r in range(ex.world)]
 
 
 def gather_match_table(pair_ids, xy0, xy1, weight, pair_offset=0, group=None, root=0, dtype=np.float64):
@@ -255,6 +319,32 @@ def gather_match_table(pair_ids, xy0, xy1, weight, pair_offset=0, group=None, ro
 # sections, so a rank needs the entries of a few other ranks' vectors: a point-to-point halo exchange per iteration and
 # ONE fused all-reduce of three scalars (Chronopoulos-Gear form of the preconditioned conjugate gradients: the two inner
 # products and the residual norm of an iteration are taken on the same vectors).
+#
+# Who touches what: torch.distributed (a gloo group) is the RENDEZVOUS -- spans, halo lists, the RCCL id, a few host scalars --
+# and the transport of the CPU tests.  On the GPU the vectors live in fb_malloc buffers, the loop is fb_cgcg_solve_dev, the halo
+# travels through fb_sendrecv_dev and the scalars through fb_allreduce_f64_dev on the library's own RCCL communicator: one
+# ROCm stack touches the device.
+def host_group(group=None):
+    """the gloo group over the ranks of `group` (itself when it already is one): object collectives of an nccl group would go
+    through torch's bundled ROCm stack"""
+    torch, dist = _dist()
+    if dist.get_backend(group) == 'gloo':
+        return group
+    key = ('gloo', id(group))
+    if key not in _default_exchange:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        _default_exchange[key] = dist.new_group(ranks=ranks, backend='gloo')
+    return _default_exchange[key]
+
+
+def host_sum(values, group=None):
+    """sum over the ranks of a small host array (rendezvous-sized: lambdas, norms)"""
+    torch, dist = _dist()
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, np.asarray(values, dtype=np.float64), group=group)
+    return np.sum(parts, axis=0)
+
+
 class RowPartition:
     """Who owns which rows, which foreign columns the local rows touch (the halo), and the send / receive lists.
 
@@ -291,192 +381,113 @@ class RowPartition:
         self.send = {src: np.asarray(w[self.rank], dtype=np.int64) for src, w in enumerate(wants) if self.rank in w and src != self.rank}
         self.n_halo = int(self.halo.size)
 
-    def exchange(self, v_loc, out_halo):
-        """fill out_halo (torch tensor [n_halo]) with the foreign entries of the distributed vector whose local part is v_loc"""
+    def lists(self):
+        """the halo lists in the form fb_cgcg_solve_dev takes: (send_peer int32 [ns], send_off int64 [ns + 1], send_idx int32,
+        recv_peer int32 [nr], recv_off int64 [nr + 1])"""
+        sp = np.array(sorted(self.send), dtype=np.int32)
+        so = np.concatenate(([0], np.cumsum([self.send[int(d)].size for d in sp]))).astype(np.int64)
+        si = np.concatenate([self.send[int(d)] for d in sp]).astype(np.int32) if sp.size else np.zeros(0, np.int32)
+        rp = np.array(sorted(self.recv), dtype=np.int32)
+        ro = np.array([self.recv[int(r)].start for r in rp] + ([self.recv[int(rp[-1])].stop] if rp.size else [0]), dtype=np.int64)
+        return sp, so, si, rp, ro
+
+    def exchange(self, v_loc):
+        """host path (CPU tests, processes that share one GPU): the foreign entries [n_halo] of the distributed vector whose
+        local part is the numpy array v_loc, through point-to-point transfers of the torch.distributed group"""
         torch, dist = _dist()
+        out = np.zeros(self.n_halo, dtype=np.float64)
         if self.world == 1 or (not self.send and not self.recv):
-            return
-        dev = _device(dist)
+            return out
+        glob = (lambda r: dist.get_global_rank(self.group, r)) if self.group is not None else (lambda r: r)
         ops, bufs = [], []
         for dst, rows in sorted(self.send.items()):
-            t = v_loc[torch.as_tensor(rows, device=v_loc.device)].to(dev).contiguous()
-            ops.append(dist.P2POp(dist.isend, t, dst, group=self.group))
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(v_loc[rows])), glob(dst), group=self.group))
         for src, sl in sorted(self.recv.items()):
-            t = torch.empty(sl.stop - sl.start, dtype=v_loc.dtype, device=dev)
+            t = torch.empty(sl.stop - sl.start, dtype=torch.float64)
             bufs.append((sl, t))
-            ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, t, glob(src), group=self.group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         for sl, t in bufs:
-            out_halo[sl] = t.to(out_halo.device)
+            out[sl] = t.numpy()
+        return out
 
 
-def pcg_row_partitioned(part, spmv, b_loc, minv_loc, rtol=1e-7, maxiter=10000, check_every=8, fused=None):
-    """Jacobi-preconditioned conjugate gradients on a row-partitioned system.
+def _cg_scalars(t, gamma, alpha, first):
+    """the scalar recurrences of the Chronopoulos-Gear iteration (cgcg_scalars_kernel restated for the host path): a step with
+    a non-positive denominator is dropped and the step after it restarts the recurrence (beta = 0) from the current iterate"""
+    g_new, delta = float(t[0]), float(t[1])
+    if first or alpha == 0.0:
+        return g_new, (g_new / delta if delta > 0 else 0.0), 0.0, (not delta > 0) and g_new != 0.0
+    beta = g_new / gamma if gamma != 0 else 0.0
+    den = delta - beta * g_new / alpha
+    if den > 0:
+        return g_new, g_new / den, beta, False
+    return g_new, 0.0, 0.0, g_new != 0.0
 
-    part: RowPartition; spmv(u_ext) -> (A u)_loc for u_ext = [u_loc | u_halo] (torch tensor, n_loc + n_halo);
-    b_loc, minv_loc: torch tensors [n_loc] on the compute device (right-hand side, inverse diagonal).
-    One halo exchange + one SpMV + ONE all-reduce (3 scalars) per iteration; the scalars stay on the device, the host
-    looks at the residual every `check_every` iterations only (with RCCL nothing else synchronises the host).
-    fused (default: when `spmv` is a DeviceRows and the vectors live on the GPU): the vector updates, the three inner
-    products and the scalar recurrences run as the library's fused kernels (fb_cgcg_*_dev) on the rows' stream.
-    A non-positive denominator of the recurrence (a system that is not positive definite in floating point, or a residual
-    that has reached exactly zero) drops the step instead of dividing by zero; a non-finite residual ends the loop with the
-    last iterate and raises.  Stops at ||r|| <= rtol ||b||.  Returns (x_loc, iterations, relative residual)."""
-    torch, dist = _dist()
-    if fused is None:
-        fused = isinstance(spmv, DeviceRows) and b_loc.is_cuda
-    if fused:
-        return _pcg_row_partitioned_fused(part, spmv, b_loc, minv_loc, rtol, maxiter, check_every)
-    cdev = _device(dist)
+
+def pcg_row_partitioned(part, spmv, b_loc, minv_loc, rtol=1e-7, maxiter=10000, check_every=8):
+    """Jacobi-preconditioned conjugate gradients on a row-partitioned system, HOST path (numpy vectors, the exchange steps
+    over the torch.distributed group of `part`): the CPU statement of fb_cgcg_solve_dev, used by the gloo tests and by ranks
+    that cannot have an RCCL communicator (processes sharing one GPU).
+
+    spmv(u_ext) -> (A u)_loc for u_ext = [u_loc | u_halo] (numpy, n_loc + n_halo).  One halo exchange + one SpMV + ONE
+    reduction of 3 scalars per iteration.  A step with a non-positive denominator (loss of positive definiteness in floating
+    point, an exactly converged residual) is dropped and the recurrence restarts from the current iterate; `check_every`
+    dropped steps in a row raise.  Stops at ||r|| <= rtol ||b||.  Returns (x_loc, iterations, relative residual)."""
+    b = np.asarray(b_loc, dtype=np.float64); minv = np.asarray(minv_loc, dtype=np.float64)
     n = part.n_loc
+    x = np.zeros(n); r = b.copy(); p = np.zeros(n); s = np.zeros(n)
 
-    def reduce3(a, b_, c):
-        t = torch.stack((a, b_, c))
-        if part.world > 1:
-            if t.device != cdev:
-                tc = t.to(cdev)
-                dist.all_reduce(tc, group=part.group)
-                t = tc.to(t.device)
-            else:
-                dist.all_reduce(t, group=part.group)
-        return t
-
-    ext = torch.zeros(n + part.n_halo, dtype=b_loc.dtype, device=b_loc.device)
-    x = torch.zeros_like(b_loc)
-    r = b_loc.clone()
-    u = minv_loc * r
-    ext[:n] = u; part.exchange(u, ext[n:])
-    w = spmv(ext).clone()
-    t = reduce3(torch.dot(r, u), torch.dot(w, u), torch.dot(r, r))
-    gamma, delta, rr = t[0], t[1], t[2]
-    bnorm2 = float(rr)
+    def product(u):
+        w = np.asarray(spmv(np.concatenate((u, part.exchange(u)))), dtype=np.float64)
+        return w, host_sum([r @ u, w @ u, r @ r], group=part.group) if part.world > 1 else np.array([r @ u, w @ u, r @ r])
+    u = minv * r
+    w, t = product(u)
+    bnorm2 = float(t[2])
     if bnorm2 == 0.0 or maxiter == 0:
         return x, 0, 0.0
-    zero = torch.zeros((), dtype=b_loc.dtype, device=b_loc.device)
-    p = torch.zeros_like(b_loc); s = torch.zeros_like(b_loc)
-    alpha = torch.where(delta > 0, gamma / delta, zero)
-    beta = zero.clone()
-    it = 0
-    rel = 1.0
+    gamma, alpha, beta, _ = _cg_scalars(t, 0.0, 0.0, True)
+    it, rel, dropped = 0, 1.0, 0
     while it < maxiter:
         p = u + beta * p
         s = w + beta * s
         x += alpha * p
         r -= alpha * s
-        u = minv_loc * r
-        ext[:n] = u; part.exchange(u, ext[n:])
-        w = spmv(ext).clone()
-        t = reduce3(torch.dot(r, u), torch.dot(w, u), torch.dot(r, r))
+        u = minv * r
+        w, t = product(u)
         it += 1
-        if it % check_every == 0 or it == maxiter:
-            rel = (float(t[2]) / bnorm2) ** 0.5                      # the only host synchronisation of the loop
-            if not np.isfinite(rel):
-                raise FloatingPointError('pcg_row_partitioned: the residual is not finite (system not positive definite?)')
-            if rel <= rtol:
-                break
-        beta = torch.where(gamma != 0, t[0] / gamma, zero)
-        den = t[1] - beta * t[0] / torch.where(alpha != 0, alpha, torch.ones_like(alpha))
-        ok = (den > 0) & (alpha != 0)
-        alpha = torch.where(ok, t[0] / torch.where(ok, den, torch.ones_like(den)), zero)
-        beta = torch.where(ok, beta, zero)
-        gamma = t[0]
-    return x, it, rel
-
-
-def _pcg_row_partitioned_fused(part, rows, b_loc, minv_loc, rtol, maxiter, check_every):
-    """the same iteration with the library's fused kernels: per iteration  fb_cgcg_update_dev -> halo exchange ->
-    fb_spmv_dev -> fb_cgcg_dots_dev -> all-reduce (3 doubles) -> fb_cgcg_scalars_dev, on the stream of `rows`"""
-    torch, dist = _dist()
-    from . import _lib
-    lib, ctx = _lib.load(), rows._ctx
-    cdev = _device(dist)
-    n = part.n_loc
-    dev = b_loc.device
-    f64 = torch.float64
-    with torch.cuda.stream(rows.stream()):
-        ext = torch.zeros(n + part.n_halo, dtype=f64, device=dev)
-        x = torch.zeros(n, dtype=f64, device=dev)
-        r = b_loc.to(f64).clone()
-        p = torch.zeros(n, dtype=f64, device=dev); s = torch.zeros(n, dtype=f64, device=dev)
-        w = torch.zeros(n, dtype=f64, device=dev)
-        minv = minv_loc.to(f64).contiguous()
-        state = torch.zeros(8, dtype=f64, device=dev)
-        t3 = torch.zeros(3, dtype=f64, device=dev)
-        scratch = torch.zeros(3 * 1024, dtype=f64, device=dev)
-        u = ext[:n]                                                  # u lives at the head of the extended vector: no copy before the SpMV
-
-        def product_and_dots(first):
-            part.exchange(u, ext[n:])
-            y = rows(ext)                                            # fb_spmv_dev on the same stream
-            w.copy_(y)
-            _lib.check(lib.fb_cgcg_dots_dev(ctx, n, C_ptr(r), C_ptr(u), C_ptr(w), C_ptr(scratch), C_ptr(t3)), h=ctx)
-            if part.world > 1:
-                if cdev != dev:
-                    tc = t3.to(cdev)
-                    dist.all_reduce(tc, group=part.group)
-                    t3.copy_(tc)
-                else:
-                    dist.all_reduce(t3, group=part.group)
-            _lib.check(lib.fb_cgcg_scalars_dev(ctx, C_ptr(t3), C_ptr(state), 1 if first else 0), h=ctx)
-        u.copy_(minv * r)
-        product_and_dots(True)
-        bnorm2 = float(state[3])
-        if bnorm2 == 0.0 or maxiter == 0:
-            return x, 0, 0.0
-        it = 0
-        rel = 1.0
-        while it < maxiter:
-            _lib.check(lib.fb_cgcg_update_dev(ctx, n, C_ptr(state), C_ptr(minv), C_ptr(x), C_ptr(r), C_ptr(u), C_ptr(w), C_ptr(p), C_ptr(s)), h=ctx)
-            product_and_dots(False)
-            it += 1
-            if it % check_every == 0 or it == maxiter:
-                st = state.cpu()                                     # the only host synchronisation of the loop
-                rel = (float(st[3]) / bnorm2) ** 0.5
-                if not np.isfinite(rel):
-                    raise FloatingPointError('pcg_row_partitioned: the residual is not finite (system not positive definite?)')
-                if rel <= rtol:
-                    break
-        torch.cuda.current_stream().synchronize()
+        rel = (float(t[2]) / bnorm2) ** 0.5
+        if not np.isfinite(rel):
+            raise FloatingPointError('pcg_row_partitioned: the residual is not finite (system not positive definite?)')
+        if rel <= rtol:
+            break
+        gamma, alpha, beta, drop = _cg_scalars(t, gamma, alpha, False)
+        dropped = dropped + 1 if drop else 0
+        if dropped >= check_every:
+            raise FloatingPointError(f'pcg_row_partitioned: {dropped} steps in a row were dropped (p^T A p <= 0): the system is not positive definite')
     return x, it, rel
 
 
 class DeviceRows:
     """the local rows of a partitioned system on the GPU: [A_own | A_halo] stored as one square block-CSR of size
-    n_loc + n_halo (the halo rows are empty), applied to torch tensors through fb_spmv_dev"""
+    n_loc + n_halo (the halo rows are empty), applied to device vectors through fb_spmv_dev / fb_cgcg_solve_dev"""
 
     def __init__(self, part, indptr, data):
         import ctypes as C
         from . import _lib
         n, m = part.n_loc, part.n_loc + part.n_halo
+        self._lib, self._ctx = _lib, _lib.ctx()
+        self.h, self.m, self.n = None, m, n
         if n % 2 or m % 2:
             raise ValueError('DeviceRows: DoF come in (x, y) pairs')
+        if m == 0:
+            return                                          # a rank that owns nothing (more ranks than sections)
         ip = np.concatenate((np.asarray(indptr, dtype=np.int64), np.full(m - n, int(indptr[-1]), dtype=np.int64)))
         idx = np.ascontiguousarray(part.local_cols, dtype=np.int32)
         val = np.ascontiguousarray(data, dtype=np.float64)
-        self._lib, self._ctx = _lib, _lib.ctx()
         self.h = C.c_void_p()
         _lib.check(_lib.load().fb_csr_upload(self._ctx, m, _lib.ptr(ip), _lib.ptr(idx), _lib.ptr(val), 0, C.byref(self.h)))
-        self.m, self.n = m, n
-        self._y = None
-
-    def stream(self):
-        """the context's HIP stream as a torch stream: run the solver under ``with torch.cuda.stream(rows.stream())`` and the
-        vector updates, the collectives and the SpMV are ordered on ONE stream without host synchronisation"""
-        import torch
-        return torch.cuda.ExternalStream(self._lib.load().fb_stream(self._ctx))
-
-    def __call__(self, ext):
-        import torch
-        if self._y is None:
-            self._y = torch.empty(self.m, dtype=torch.float64, device=ext.device)
-        shared = torch.cuda.current_stream().cuda_stream == self._lib.load().fb_stream(self._ctx)
-        if not shared:
-            torch.cuda.current_stream().synchronize()             # torch's stream -> the context's stream
-        self._lib.check(self._lib.load().fb_spmv_dev(self._ctx, self.h, C_ptr(ext), C_ptr(self._y)))
-        if not shared:
-            self._lib.check(self._lib.load().fb_sync(self._ctx))
-        return self._y[:self.n]
 
     def free(self):
         if self.h is not None:
@@ -484,6 +495,86 @@ class DeviceRows:
             self.h = None
 
 
-def C_ptr(t):
+def pcg_row_partitioned_dev(part, rows, b_loc, minv_loc, rtol=1e-7, maxiter=10000, check_every=8, comm=None):
+    """the coupled-window PCG on the GPU.  b_loc / minv_loc: numpy [n_loc]; rows: DeviceRows; comm: the fb_comm of the ranks of
+    `part` (an ``Exchange(...).comm`` made on the CALLING thread's context) or None.
+
+    With a communicator, or on a single rank, the whole loop is ONE C call (fb_cgcg_solve_dev): vectors in fb_malloc buffers,
+    halo through fb_sendrecv_dev, scalars through fb_allreduce_f64_dev, the host reads 64 bytes every `check_every` iterations.
+    Several ranks without a communicator (processes that share one GPU -- RCCL refuses two ranks on a device -- as in the
+    tests of this module) run the same kernels step by step and carry halo and scalars over the host group.
+    Returns (x_loc numpy, iterations, relative residual)."""
     import ctypes as C
-    return C.c_void_p(t.data_ptr())
+    from . import _lib
+    lib, ctx = _lib.load(), rows._ctx
+    n, nh = part.n_loc, part.n_halo
+    b = np.ascontiguousarray(b_loc, dtype=np.float64); minv = np.ascontiguousarray(minv_loc, dtype=np.float64)
+    limit = 100000 if maxiter is None or maxiter < 0 else int(maxiter)
+    d_b = _lib.DeviceBuffer.from_array(b) if n else _lib.DeviceBuffer(16)
+    d_minv = _lib.DeviceBuffer.from_array(minv) if n else _lib.DeviceBuffer(16)
+    d_x = _lib.DeviceBuffer(8 * max(n, 2))
+    bufs = [d_b, d_minv, d_x]
+    try:
+        if comm is not None or part.world == 1:
+            sp, so, si, rp, ro = part.lists()
+            d_si = _lib.DeviceBuffer.from_array(si) if si.size else None
+            if d_si is not None:
+                bufs.append(d_si)
+            it, rel, bn = C.c_int(), C.c_double(), C.c_double()
+            rc = lib.fb_cgcg_solve_dev(ctx, comm, rows.h, n, nh, d_b.ptr, d_minv.ptr, d_x.ptr, sp.size, _lib.ptr(sp), _lib.ptr(so),
+                                       d_si.ptr if d_si is not None else None, rp.size, _lib.ptr(rp), _lib.ptr(ro), float(rtol), limit,
+                                       int(check_every), C.byref(it), C.byref(rel), C.byref(bn))
+            if rc == _lib.FB_ERR_BREAKDOWN:
+                raise FloatingPointError((lib.fb_last_error(ctx) or b'?').decode())
+            _lib.check(rc, allow=(_lib.FB_ERR_NOCONV,), h=ctx)
+            return (d_x.to_array((n,), np.float64) if n else np.zeros(0)), it.value, rel.value
+        # ---- ranks without a communicator: the same kernels, halo and scalars over the host group
+        m = n + nh
+        d_ext, d_y = _lib.DeviceBuffer(8 * max(m, 2)), _lib.DeviceBuffer(8 * max(m, 2))
+        d_vec = [_lib.DeviceBuffer(8 * max(n, 1)) for _ in range(4)]          # r, p, s, w
+        d_state, d_t3, d_scr = _lib.DeviceBuffer(64), _lib.DeviceBuffer(32), _lib.DeviceBuffer(8 * 3 * 1024)
+        bufs += [d_ext, d_y, d_state, d_t3, d_scr] + d_vec
+        d_r, d_p, d_s, d_w = d_vec
+        for d in (d_ext, d_y, d_state, d_x, d_p, d_s, d_w):
+            _lib.check(lib.fb_memset(ctx, d.ptr, 0, d.nbytes), h=ctx)
+        if n:
+            _lib.check(lib.fb_memcpy_d2d(ctx, d_r.ptr, d_b.ptr, 8 * n), h=ctx)
+
+        def product_and_dots(first):
+            u = d_ext.to_array((n,), np.float64) if n else np.zeros(0)
+            halo = part.exchange(u)
+            if nh:
+                _lib.check(lib.fb_memcpy_h2d(ctx, d_ext.offset(8 * n), _lib.ptr(halo), 8 * nh), h=ctx)
+            if m:
+                _lib.check(lib.fb_spmv_dev(ctx, rows.h, d_ext.ptr, d_y.ptr), h=ctx)
+            if n:
+                _lib.check(lib.fb_memcpy_d2d(ctx, d_w.ptr, d_y.ptr, 8 * n), h=ctx)
+            _lib.check(lib.fb_cgcg_dots_dev(ctx, n, d_r.ptr, d_ext.ptr, d_w.ptr, d_scr.ptr, d_t3.ptr), h=ctx)
+            t3 = host_sum(d_t3.to_array((3,), np.float64), group=part.group)
+            _lib.check(lib.fb_memcpy_h2d(ctx, d_t3.ptr, _lib.ptr(np.ascontiguousarray(t3)), 24), h=ctx)
+            _lib.check(lib.fb_cgcg_scalars_dev(ctx, d_t3.ptr, d_state.ptr, 1 if first else 0), h=ctx)
+            return d_state.to_array((8,), np.float64)
+        upd = lambda: _lib.check(lib.fb_cgcg_update_dev(ctx, n, d_state.ptr, d_minv.ptr, d_x.ptr, d_r.ptr, d_ext.ptr, d_w.ptr, d_p.ptr, d_s.ptr), h=ctx)
+        upd()                                                   # alpha = beta = 0, p = s = 0: u = minv r
+        st = product_and_dots(True)
+        bnorm2 = float(st[3])
+        if bnorm2 == 0.0 or limit == 0:
+            return (d_x.to_array((n,), np.float64) if n else np.zeros(0)), 0, 0.0
+        it, rel, seen = 0, 1.0, 0.0
+        while it < limit:
+            upd()
+            st = product_and_dots(False)
+            it += 1
+            rel = (float(st[3]) / bnorm2) ** 0.5
+            if not np.isfinite(rel):
+                raise FloatingPointError('pcg_row_partitioned_dev: the residual is not finite (system not positive definite?)')
+            if rel <= rtol:
+                break
+            if it % check_every == 0:
+                if st[4] - seen >= check_every:
+                    raise FloatingPointError(f'pcg_row_partitioned_dev: every step of the last {check_every} was dropped (p^T A p <= 0)')
+                seen = st[4]
+        return (d_x.to_array((n,), np.float64) if n else np.zeros(0)), it, rel
+    finally:
+        for d in bufs:
+            d.free()

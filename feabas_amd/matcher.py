@@ -6,6 +6,9 @@ the GPU kernels for the arithmetic.
 """
 import ctypes as C
 
+import os
+import time
+
 import numpy as np
 
 from . import _lib, common
@@ -1036,6 +1039,13 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
                 state['io'] = (_lib.PinnedBuffer(need), _lib.DeviceBuffer(need))
                 state['bytes'] = need
             pin, dev = state['io']
+            # threads started together march through the stages of a chunk in lockstep (all in the FFT-heavy global stage, then
+            # all in the latency-bound rounds of small kernels), which leaves the device half idle in the second phase: worker t
+            # starts 3 t ms late, so that the heavy kernels of one stream fill the gaps of the others (bench.py does the same
+            # for its resident-strip harness; FEABAS_HIP_STAGGER_MS=0 turns it off)
+            stagger = float(os.environ.get('FEABAS_HIP_STAGGER_MS', '3'))
+            if stagger > 0 and t > 0 and nthr > 1:
+                time.sleep(1e-3 * stagger * t)
             for kind, what, idx in chunks[t::nthr]:
                 n = len(idx)
                 Hm = max(items[k][0].shape[0] for k in idx); Wm = max(items[k][0].shape[1] for k in idx)

@@ -763,11 +763,10 @@ class SLM:
         and solved with the row-partitioned Jacobi-PCG of feabas_amd/dist.py (halo exchange with the neighbouring ranks +
         one fused all-reduce per iteration; fused vector kernels on the GPU).  The trace-relative lambdas come from
         all-reduced sums.  Returns (||b||, ||A d - b||) of the whole window; every rank moves the sections it owns."""
-        import torch
-        import torch.distributed as dist
+        import torch.distributed as dist                        # the rendezvous (who owns what); no tensor of torch's is involved
         from . import dist as fdist
         from .mesh import bsr_download
-        grp = None if group is True else group
+        grp = fdist.host_group(None if group is True else group)
         rank, world = dist.get_rank(grp), dist.get_world_size(grp)
         free = [m for m in self.meshes if not m.locked]
         if owned is None:
@@ -812,11 +811,7 @@ class SLM:
             sums = np.array([dc.sum(), dk[dc != 0].sum()])
         else:
             sums = np.zeros(2)
-        on_gpu = dist.get_backend(grp) == 'nccl' or _lib._ctx is not None
-        cdev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(grp) == 'nccl' else torch.device('cpu')
-        ts = torch.from_numpy(sums).to(cdev)
-        dist.all_reduce(ts, group=grp)
-        tr_c, sum_k = (float(v) for v in ts.cpu())
+        tr_c, sum_k = (float(v) for v in fdist.host_sum(sums, group=grp))
         sl, cl = float(stiffness_lambda), float(crosslink_lambda)
         if sl < 0 or cl < 0:                                    # optimizer.py:1573-1590 on the all-reduced sums
             sl = 0.0 if tr_c == 0 else abs(abs(sl / cl) * tr_c / sum_k)
@@ -838,29 +833,21 @@ class SLM:
         else:
             indptr, gcols, data, bvec, diag = np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0), np.zeros(0), np.zeros(0)
         part = fdist.RowPartition(indptr, gcols, row_start, group=grp)
-        bn2 = torch.tensor([float(bvec @ bvec)], dtype=torch.float64, device=cdev)
-        dist.all_reduce(bn2, group=grp)
-        bnorm = float(bn2.item()) ** 0.5
+        bnorm = float(fdist.host_sum([float(bvec @ bvec)], group=grp)[0]) ** 0.5
         if bnorm == 0 or maxiter == 0:
             return 0.0, 0.0
         rtol = max(float(tol), float(atol or 0.0) / bnorm)
         minv = 1.0 / np.clip(diag, min(1.0, diag.max(initial=0.0) / 1000.0) if diag.size else 1.0, None)       # optimizer.py:1962-1966 on the local rows
-        if on_gpu and n_own > 0:
-            dev = torch.device('cuda', torch.cuda.current_device())
-            rows = fdist.DeviceRows(part, indptr, data)
-            try:
-                x, it, rel = fdist.pcg_row_partitioned(part, rows, torch.from_numpy(bvec).to(dev), torch.from_numpy(minv).to(dev), rtol=rtol,
-                                                       maxiter=10000 if maxiter is None else int(maxiter))
-                x = x.cpu().numpy()
-            finally:
-                rows.free()
-        else:
-            from scipy import sparse as _sp
-            loc = _sp.csr_matrix((data, part.local_cols, indptr), shape=(n_own, part.n_loc + part.n_halo))
-            x, it, rel = fdist.pcg_row_partitioned(part, lambda ext: torch.from_numpy(loc @ ext.numpy()), torch.from_numpy(bvec), torch.from_numpy(minv),
-                                                   rtol=rtol, maxiter=10000 if maxiter is None else int(maxiter))
-            x = x.numpy()
-        self.last_solve = dict(iters=int(it), relres=float(rel), stiffness_lambda=sl, crosslink_lambda=cl, rows=n_own, halo=int(part.n_halo))
+        # the loop itself: fb_cgcg_solve_dev on the library's RCCL communicator (halo: fb_sendrecv_dev, scalars:
+        # fb_allreduce_f64_dev); ranks that share one device (tests) carry halo and scalars over the host group instead
+        comm = fdist.solver_comm(grp)
+        rows = fdist.DeviceRows(part, indptr, data)
+        try:
+            x, it, rel = fdist.pcg_row_partitioned_dev(part, rows, bvec, minv, rtol=rtol, maxiter=10000 if maxiter is None else int(maxiter), comm=comm)
+        finally:
+            rows.free()
+        self.last_solve = dict(iters=int(it), relres=float(rel), stiffness_lambda=sl, crosslink_lambda=cl, rows=n_own, halo=int(part.n_halo),
+                               exchange='rccl' if comm is not None else ('none' if world == 1 else 'host group'))
         cost = (bnorm, float(rel) * bnorm)
         if cost[1] < cost[0]:
             o = 0

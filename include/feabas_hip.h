@@ -426,6 +426,9 @@ int fb_cgcg_update_dev(fb_ctx* ctx, int64_t n, const double* state, const double
                        double* p, double* s);
 int fb_cgcg_dots_dev(fb_ctx* ctx, int64_t n, const double* r, const double* u, const double* w, double* scratch, double* out3);
 int fb_cgcg_scalars_dev(fb_ctx* ctx, const double* t3, double* state, int first);
+/* dst[i] = src[idx[i]], i < n, device pointers: the entries of u a neighbouring rank needs, packed for one transfer */
+int fb_gather_f64_dev(fb_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst);
+
 /* exactly `iters` PCG iterations with no convergence exit (throughput bench) */
 int fb_pcg_fixed_iters(fb_ctx* ctx, fb_csr* A, const double* b_host, int iters, double* relres);
 
@@ -455,6 +458,19 @@ int fb_allreduce_f64_dev(fb_ctx* ctx, fb_comm* comm, const double* send, double*
 /* halo exchange of the coupled window: grouped point-to-point transfers with the ranks of the neighbouring sections */
 int fb_sendrecv_dev(fb_ctx* ctx, fb_comm* comm, int nsend, const int* send_peer, const void* const* send_ptr, const int64_t* send_bytes,
                     int nrecv, const int* recv_peer, void* const* recv_ptr, const int64_t* recv_bytes);
+/* Coupled-window PCG (the fb_cgcg_* kernels above with these exchange steps between them).
+   The whole loop behind one call: the rows of this rank as one square block-CSR `rows` of size n_loc + n_halo over [own | halo]
+ * columns (halo rows empty), b / minv / x device double[n_loc] (x is overwritten, zero start).  Halo lists (host arrays): this
+ * rank sends u[send_idx[send_off[k] .. send_off[k+1])] (send_idx: device int32, local row ids) to send_peer[k] and receives
+ * halo entries [recv_off[k], recv_off[k+1]) from recv_peer[k]; comm may be NULL when there is nothing to exchange (one rank).
+ * Per iteration: fb_cgcg_update_dev, fb_gather_f64_dev + fb_sendrecv_dev, fb_spmv_dev, fb_cgcg_dots_dev, ONE
+ * fb_allreduce_f64_dev of 3 doubles, fb_cgcg_scalars_dev -- all on the context's stream; the host reads 64 bytes every
+ * check_every iterations.  Stops at ||r|| <= rtol ||b|| (recurrence residual); maxiter < 0: no limit (1e5).  A dropped step
+ * (p^T A p <= 0 in floating point) restarts the recurrence from the current iterate; check_every dropped steps in a row return
+ * FB_ERR_BREAKDOWN, the iteration cap FB_ERR_NOCONV (x holds the last iterate).  bnorm: ||b|| over all ranks. */
+int fb_cgcg_solve_dev(fb_ctx* ctx, fb_comm* comm, fb_csr* rows, int64_t n_loc, int64_t n_halo, const double* b, const double* minv, double* x,
+                      int nsend, const int* send_peer, const int64_t* send_off, const int32_t* send_idx, int nrecv, const int* recv_peer,
+                      const int64_t* recv_off, double rtol, int maxiter, int check_every, int* iters, double* relres, double* bnorm);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,6 @@ def _coupled_system(n_sections=4, nv=150, seed=0):
 
 
 def _pcg_worker(rank, world, port, outdir, use_gpu):
-    import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -102,22 +101,21 @@ def _pcg_worker(rank, world, port, outdir, use_gpu):
     r0, r1 = sec0 * per, sec1 * per
     rows = A[r0:r1].tocsr()
     part = fdist.RowPartition(rows.indptr, rows.indices, r0)
-    dev = torch.device('cuda', 0) if use_gpu else torch.device('cpu')
-    b_loc = torch.from_numpy(b[r0:r1].copy()).to(dev)
-    minv = torch.from_numpy(1.0 / A.diagonal()[r0:r1]).to(dev)
+    b_loc = b[r0:r1].copy()
+    minv = 1.0 / A.diagonal()[r0:r1]
     if use_gpu:
-        spmv = fdist.DeviceRows(part, rows.indptr, rows.data)
+        # the rows on the GPU, the vectors in the library's buffers; the ranks share the one GPU of the box, so there is no RCCL
+        # communicator (solver_comm -> None) and halo + scalars travel over the gloo group: every kernel of the loop runs
+        dr = fdist.DeviceRows(part, rows.indptr, rows.data)
+        comm = fdist.solver_comm()
+        assert comm is None or world == 1
+        x, it, rel = fdist.pcg_row_partitioned_dev(part, dr, b_loc, minv, rtol=1e-10, maxiter=5000, comm=comm)
+        dr.free()
     else:
         from scipy import sparse
         loc = sparse.csr_matrix((rows.data, part.local_cols, rows.indptr), shape=(r1 - r0, part.n_loc + part.n_halo))
-        spmv = lambda ext: torch.from_numpy(loc @ ext.numpy())
-    if use_gpu and rank == 0:                                        # one rank on the context's stream, one on torch's default stream
-        with torch.cuda.stream(spmv.stream()):
-            x, it, rel = fdist.pcg_row_partitioned(part, spmv, b_loc, minv, rtol=1e-10, maxiter=5000)
-            torch.cuda.current_stream().synchronize()
-    else:
-        x, it, rel = fdist.pcg_row_partitioned(part, spmv, b_loc, minv, rtol=1e-10, maxiter=5000)
-    np.savez(os.path.join(outdir, f'x{rank}.npz'), x=x.cpu().numpy(), it=it, rel=rel, r0=r0, halo=part.n_halo)
+        x, it, rel = fdist.pcg_row_partitioned(part, lambda ext: loc @ ext, b_loc, minv, rtol=1e-10, maxiter=5000)
+    np.savez(os.path.join(outdir, f'x{rank}.npz'), x=np.asarray(x), it=it, rel=rel, r0=r0, halo=part.n_halo)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -146,8 +144,8 @@ def test_coupled_window_pcg_gloo(tmp_path, world):
 
 @pytest.mark.gpu
 def test_coupled_window_pcg_device_rows_world2(tmp_path):
-    """the same with the local rows on the GPU (DeviceRows: fb_csr_upload + fb_spmv_dev on torch tensors), two processes
-    sharing the one GPU of the box, scalars and halos over gloo"""
+    """the same with the local rows and every vector on the GPU (DeviceRows + the fb_cgcg_* kernels on fb_malloc buffers), two
+    processes sharing the one GPU of the box, scalars and halos over gloo (RCCL refuses two ranks on one device)"""
     import torch.multiprocessing as mp
     mp.spawn(_pcg_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
     _check_pcg(tmp_path, 2)
@@ -218,3 +216,23 @@ def test_optimize_linear_distributed_equals_single_gpu(tmp_path, world):
     assert sorted(got) == ['v1', 'v2', 'v3', 'v4']
     for m in meshes[1:]:
         np.testing.assert_allclose(got[f'v{m.uid:.0f}'], m.vertices_w_offset(1), atol=1e-6 * motion)
+
+
+def test_pcg_host_path_restarts_after_a_dropped_step():
+    """a dropped step (non-positive denominator) used to make every later step a dropped one.  Now the step
+    after it restarts the recurrence: an indefinite system is reported after `check_every` dropped steps instead of running
+    to maxiter, and the scalar recurrence recovers from a single dropped step"""
+    g, a, b_, drop = fdist._cg_scalars([4.0, -1.0, 9.0], 0.0, 0.0, True)            # delta <= 0 at the start: dropped
+    assert (a, b_, drop) == (0.0, 0.0, True)
+    g, a, b_, drop = fdist._cg_scalars([3.0, 2.0, 5.0], g, a, False)                # next step: restart, alpha = gamma / delta
+    assert (a, b_, drop) == (1.5, 0.0, False)
+
+    class _P:                                                                        # a one-rank partition without a process group
+        n_loc, n_halo, world, group = 4, 0, 1, None
+        def exchange(self, u): return np.zeros(0)
+    A = np.diag([1.0, -2.0, 3.0, -4.0])                                              # indefinite
+    with pytest.raises(FloatingPointError):
+        fdist.pcg_row_partitioned(_P(), lambda e: A @ e, np.array([0.0, 1.0, 0.0, 1.0]), np.ones(4), rtol=1e-12, maxiter=100000, check_every=8)
+    S = np.diag([1.0, 2.0, 3.0, 4.0])
+    x, it, rel = fdist.pcg_row_partitioned(_P(), lambda e: S @ e, np.ones(4), 1.0 / np.diag(S), rtol=1e-12, maxiter=50)
+    np.testing.assert_allclose(x, 1.0 / np.diag(S), rtol=1e-10)
