@@ -9,7 +9,11 @@
 // host (C++), the numeric phases run on the device.
 #include "fb_solver.h"
 
+#include <array>
+#include <chrono>
 #include <climits>
+#include <map>
+#include <tuple>
 #include <thread>
 #include <vector>
 #include <algorithm>
@@ -28,6 +32,7 @@ struct fb_mesh_blk {
     float* d_matmult = nullptr;      // [T]
     double2* d_vshape = nullptr;     // [V]
     double2* d_vcur = nullptr;       // [V]
+    std::vector<double> h_v;         // [V][2] host copy of the shape coordinates of the last assembly (aggregates of the multigrid)
 };
 
 struct fb_system {
@@ -477,6 +482,8 @@ static int build_link_index(fb_ctx* ctx, fb_system* s) {
     return FB_OK;
 }
 
+#include "fb_mg.inc"
+
 extern "C" {
 
 int fb_sys_create(fb_ctx* ctx, int64_t nvert_free, fb_system** out) {
@@ -719,6 +726,7 @@ static int assemble_mesh_impl(fb_ctx* ctx, fb_system* s, int mesh_id, const doub
     FB_HIP(ctx, hipSetDevice(ctx->device));
     fb_mesh_blk& m = s->meshes[mesh_id];
     { const int rc_ = fb_copy_h2d(ctx, m.d_vshape, v_shape, sizeof(double2) * (size_t)m.V); if (rc_) return rc_; }
+    m.h_v.assign(v_shape, v_shape + 2 * (size_t)m.V);
     if (v_cur) { const int rc_ = fb_copy_h2d(ctx, m.d_vcur, v_cur, sizeof(double2) * (size_t)m.V); if (rc_) return rc_; }
     if (tri_mult) { const int rc_ = fb_copy_h2d(ctx, m.d_mult, tri_mult, sizeof(float) * (size_t)m.T); if (rc_) return rc_; }
     if (tri_model) {
@@ -849,6 +857,89 @@ int fb_sys_form(fb_ctx* ctx, fb_system* s, double sl, double cl) {
     return FB_OK;
 }
 
+// Chronopoulos-Gear PCG (the fb_cgcg_* kernels) with one multigrid V-cycle as the preconditioner; x0 in M->x, result in M->x.
+// The stopping rule is optimizer.solve's (optimizer.py:1993-1996) on the TRUE residual, re-evaluated at the end of a leg.
+static int sys_solve_mg(fb_ctx* ctx, fb_system* s, double rtol, double atol, int maxiter, int* iters, double* relres) {
+    fb_bsr* M = s->M;
+    const int64_t n = 2 * (int64_t)s->nv;
+    fb_mg* mg = nullptr;
+    int rc = mg_setup(ctx, s, &mg);
+    if (rc) return rc;
+    struct Guard { fb_ctx* c; fb_mg* m; ~Guard() { mg_destroy(c, m); } } guard{ctx, mg};
+    double* x = reinterpret_cast<double*>(M->x); double* r = reinterpret_cast<double*>(M->r); double* p = reinterpret_cast<double*>(M->p0);
+    double* sv = reinterpret_cast<double*>(M->p1); double* w = reinterpret_cast<double*>(M->Ap); double* b = reinterpret_cast<double*>(M->b);
+    double* state = M->parts; double* t3 = state + 8; double* scratch = t3 + 8;           // parts holds 7 * kNP doubles: plenty
+    MgLevel& L0 = mg->L[0];
+    double* own_r = L0.d_r;
+    L0.d_r = r;                                              // the cycle reads the residual where the iteration keeps it
+    struct Restore { MgLevel& l; double* p; ~Restore() { l.d_r = p; } } restore{L0, own_r};
+    const int g = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (s->nv + 255) / 256));
+    auto residual = [&](double* rr_out) -> int {             // r = b - A x, rr = ||r||^2
+        int e = fb_bsr_spmv_dev(ctx, M, M->x, M->Ap);
+        if (e) return e;
+        hipLaunchKernelGGL((mg_fine_axpy_kernel<1>), dim3(g), dim3(256), 0, ctx->stream, s->nv, (const double*)nullptr, reinterpret_cast<const double2*>(b), M->Ap, nullptr, M->r, 0.0);
+        if ((e = fb_cgcg_dots_dev(ctx, n, r, r, r, scratch, t3))) return e;
+        double h[3];
+        FB_HIP(ctx, hipMemcpyAsync(h, t3, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *rr_out = h[2];
+        return FB_OK;
+    };
+    // ||b||
+    double bb = 0.0;
+    if ((rc = fb_cgcg_dots_dev(ctx, n, b, b, b, scratch, t3))) return rc;
+    { double h[3]; FB_HIP(ctx, hipMemcpyAsync(h, t3, sizeof(h), hipMemcpyDeviceToHost, ctx->stream)); FB_HIP(ctx, hipStreamSynchronize(ctx->stream)); bb = h[2]; }
+    if (iters) *iters = 0;
+    if (relres) *relres = 0.0;
+    if (bb == 0.0 || maxiter == 0) { FB_HIP(ctx, hipMemsetAsync(M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream)); return FB_OK; }
+    const double bnorm = std::sqrt(bb);
+    double tol = rtol;
+    if (atol > 0.0) tol = std::max(tol, atol / bnorm);
+    const int limit = maxiter > 0 ? maxiter : 100 * 1000;
+    int total = 0;
+    double rel = 1.0;
+    for (int leg = 0; leg < 6; ++leg) {
+        double rr = 0.0;
+        if ((rc = residual(&rr))) return rc;
+        rel = std::sqrt(rr) / bnorm;
+        if (relres) *relres = rel;
+        if (rel <= tol || total >= limit) break;
+        FB_HIP(ctx, hipMemsetAsync(p, 0, sizeof(double) * (size_t)n, ctx->stream));
+        FB_HIP(ctx, hipMemsetAsync(sv, 0, sizeof(double) * (size_t)n, ctx->stream));
+        FB_HIP(ctx, hipMemsetAsync(state, 0, sizeof(double) * 8, ctx->stream));
+        auto precondition_and_dots = [&](int first) -> int {
+            int e = mg_vcycle(ctx, s, mg, 0);                // u = V(r) -> L0.d_e
+            if (e) return e;
+            if ((e = fb_bsr_spmv_dev(ctx, M, reinterpret_cast<const double2*>(L0.d_e), M->Ap))) return e;
+            if ((e = fb_cgcg_dots_dev(ctx, n, r, L0.d_e, w, scratch, t3))) return e;
+            return fb_cgcg_scalars_dev(ctx, t3, state, first);
+        };
+        if ((rc = precondition_and_dots(1))) return rc;
+        const double target = 0.81 * tol * tol * bb;          // the recurrence residual a little below the target, like fb_bsr_pcg_dev
+        int it = 0;
+        double dropped_seen = 0.0;
+        while (total + it < limit) {
+            const int batch = std::min(8, limit - total - it);
+            for (int k = 0; k < batch; ++k) {
+                if ((rc = fb_cgcg_update_dev(ctx, n, state, nullptr, x, r, L0.d_e, w, p, sv))) return rc;
+                if ((rc = precondition_and_dots(0))) return rc;
+            }
+            it += batch;
+            double hs[8];
+            FB_HIP(ctx, hipMemcpyAsync(hs, state, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+            FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (!(hs[3] == hs[3])) return fb_fail(ctx, FB_ERR_BREAKDOWN, "multigrid PCG: the residual is not finite after %d iterations", total + it);
+            if (hs[3] <= target) break;
+            if (hs[4] - dropped_seen >= (double)batch) return fb_fail(ctx, FB_ERR_BREAKDOWN, "multigrid PCG: every step of the last %d was dropped (p^T A p <= 0): the system is not positive definite", batch);
+            dropped_seen = hs[4];
+        }
+        total += it;
+        if (iters) *iters = total;
+    }
+    if (iters) *iters = total;
+    return rel <= tol ? FB_OK : FB_ERR_NOCONV;
+}
+
 int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, double atol, int maxiter, int precond, int* iters,
                  double* relres) {
     FB_LOCK(ctx);
@@ -858,7 +949,8 @@ int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, 
     else FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
     int rc = fb_bsr_setup_jacobi(ctx, s->M, precond);
     if (rc) return rc;
-    rc = fb_bsr_pcg_dev(ctx, s->M, rtol, atol, maxiter, 0, iters, relres);
+    if (precond == 2) rc = sys_solve_mg(ctx, s, rtol, atol, maxiter, iters, relres);
+    else rc = fb_bsr_pcg_dev(ctx, s->M, rtol, atol, maxiter, 0, iters, relres);
     if (rc && rc != FB_ERR_NOCONV) return rc;
     { const int rc_ = fb_copy_d2h(ctx, x, s->M->x, sizeof(double2) * (size_t)s->nv); if (rc_) return rc_; }
     return rc;

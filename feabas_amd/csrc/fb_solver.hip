@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void cgcg_update_kernel(int64_t n, const doubl
         p[i] = pi; s[i] = si;
         x[i] += alpha * pi;
         r[i] = ri;
-        u[i] = minv[i] * ri;
+        if (minv) u[i] = minv[i] * ri;                      // minv == NULL: the caller applies its own preconditioner to r
     }
 }
 
@@ -816,7 +816,7 @@ __global__ void cgcg_scalars_kernel(const double* __restrict__ t3, double* __res
 int fb_cgcg_update_dev(fb_ctx* ctx, int64_t n, const double* state, const double* minv, double* x, double* r, double* u, const double* w,
                        double* p, double* s) {
     FB_LOCK(ctx);
-    FB_CHECK_ARG(ctx, n >= 0 && state && (n == 0 || (minv && x && r && u && w && p && s)));
+    FB_CHECK_ARG(ctx, n >= 0 && state && (n == 0 || (x && r && u && w && p && s)));
     if (n == 0) return FB_OK;
     FB_PROF_B(ctx, "cgcg_update", (double)n * 8.0 * 12.0);
     hipLaunchKernelGGL(cgcg_update_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kCgWG)), dim3(256), 0, ctx->stream, n, state, minv, x, r, u, w, p, s);

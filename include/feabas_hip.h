@@ -395,7 +395,12 @@ int fb_sys_solve_fixed(fb_ctx* ctx, fb_system* sys, int iters, double* relres);
  * 3 stress [2nv] f32, 4 A [nnzb][2][2] f64, 5 b [2nv] f64 */
 int fb_sys_get(fb_ctx* ctx, fb_system* sys, int which, void* out);
 
-/* optimizer.solve (optimizer.py:1945-2080) fixed point: Jacobi-preconditioned CG
+/* (fb_sys_solve: precond 2 = aggregation multigrid -- what the reference asks pyamg's smoothed_aggregation for,
+ * optimizer.py:1962-1971, matcher.py:561: aggregates = grid cells of ~64 nodes per mesh, 3 rigid-body modes per aggregate,
+ * Galerkin coarse operators, V(1,1) cycles with damped block Jacobi, coarsest level inverted directly; same fixed point as
+ * precond 1, an order of magnitude fewer iterations on weakly pinned meshes.  Needs the meshes' stiffness assembled
+ * (fb_sys_assemble_mesh*: the vertex coordinates of the aggregates are taken from there).)
+ * optimizer.solve (optimizer.py:1945-2080) fixed point: Jacobi-preconditioned CG
  * on the symmetrised CSR system until ||Ax-b|| <= max(rtol, atol/||b||) ||b||.
  * x holds x0 on entry when use_x0 != 0.  precond: 0 none, 1 reference Jacobi
  * (optimizer.py:1962-1966). */
@@ -418,7 +423,8 @@ int fb_pcg_csr(fb_ctx* ctx, fb_csr* A, const double* b, double* x, int use_x0, d
  * of a window as one system; here its rows are partitioned by section over the ranks): Chronopoulos-Gear form, one fused
  * all-reduce of three scalars per iteration.  All pointers are device pointers, nothing synchronises the host.
  *   state double[8] = {gamma, alpha, beta, r.r, breakdown flag, iterations, -, -}
- *   fb_cgcg_update_dev : p = u + beta p; s = w + beta s; x += alpha p; r -= alpha s; u = minv r   (one pass over 12 vectors)
+ *   fb_cgcg_update_dev : p = u + beta p; s = w + beta s; x += alpha p; r -= alpha s; u = minv r   (one pass over 12 vectors;
+ *                        minv == NULL leaves u alone: the caller applies another preconditioner to r, e.g. the multigrid cycle)
  *   fb_cgcg_dots_dev   : out3 = (r.u, w.u, r.r) of the local rows, fixed summation order; scratch double[3 * 1024]
  *   fb_cgcg_scalars_dev: alpha, beta, gamma from the all-reduced out3 (first != 0: the start of the iteration); a
  *                        non-positive denominator zeroes the step and raises the flag instead of producing NaN */

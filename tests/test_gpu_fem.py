@@ -479,3 +479,34 @@ def test_g18_section_between_locked_neighbours_vs_reference(fb):
         assert abs(cost[0] - g['cost'][0]) <= 1e-6 * g['cost'][0]
         got = cur.vertices_w_offset(const.MESH_GEAR_MOVING) - g['v']
         assert np.abs(got - exp).max() <= 1e-5 * np.abs(exp).max(), np.abs(got - exp).max() / np.abs(exp).max()
+
+
+# ----------------------------------------------------------------------- aggregation multigrid (optimizer.py:1962-1971, matcher.py:561)
+@pytest.mark.parametrize('nlinks', [40, 3000])
+def test_multigrid_preconditioner_same_fixed_point_fewer_iterations(fb, nlinks):
+    """precondition='smoothed_aggregation' (what matcher.py:561 asks pyamg for) runs the device's aggregation multigrid as the
+    preconditioner of the PCG: on a 90 x 70 mesh pinned by a few links it reaches the oracle's exact solution (1e-6 of the
+    motion) like the Jacobi-PCG does, in far fewer iterations; with many links it is no worse"""
+    rng = np.random.default_rng(nlinks)
+    v, t = fem_ref.grid_mesh(90, 70, 10.0)
+    L = 900.0
+    disp = np.stack((5 * np.sin(2 * np.pi * v[:, 1] / L), 4 * np.cos(2 * np.pi * v[:, 0] / L)), axis=-1)
+    tid = rng.integers(0, t.shape[0], nlinks); B = rng.dirichlet((1, 1, 1), nlinks)
+    w = rng.uniform(0.3, 1.0, nlinks).astype(np.float32)
+    out = {}
+    for pre in ('jacobi', 'smoothed_aggregation'):
+        m0 = fb.mesh.Mesh(v + disp, t, uid=0, locked=True); m1 = fb.mesh.Mesh(v.copy(), t, uid=1)
+        slm = fb.optimizer.SLM([m0, m1], [fb.optimizer.Link(m0, m1, tid, tid, B, B, weight=w)], stiffness_lambda=1.0, crosslink_lambda=-1.0)
+        cost = slm.optimize_linear(tol=1e-9, precondition=pre)
+        assert cost[1] <= 1e-9 * cost[0] * 1.01
+        out[pre] = (m1.vertices_w_offset(1) - v, slm.last_solve['iters'])
+    r0 = fem_ref.RefMesh(v + disp, t, uid=0, locked=True); r1 = fem_ref.RefMesh(v.copy(), t, uid=1)
+    fem_ref.optimize_linear([r0, r1], [fem_ref.RefLink(r0, r1, tid, tid, B, B, weight=w)], exact=True)
+    exp = r1.vertices_w_offset(fem_ref.GEAR_MOVING) - v
+    scale = np.abs(exp).max()
+    for pre, (got, it) in out.items():
+        assert np.abs(got - exp).max() <= 1e-6 * scale, (pre, np.abs(got - exp).max() / scale)
+    it_j, it_m = out['jacobi'][1], out['smoothed_aggregation'][1]
+    assert it_m <= it_j
+    if nlinks == 40:
+        assert it_m * 5 <= it_j, (it_j, it_m)
