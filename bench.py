@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--no-fem', action='store_true')
     ap.add_argument('--no-align', action='store_true', help='skip the alignment-side block matcher section')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-xcorr-classes', action='store_true', help='skip the kernel-only xcorr_fft rates (the PMC passes of tools/profile_round.sh: only the shapes of the timed steps are launched)')
     ap.add_argument('--no-deformed', action='store_true', help='skip the 2-px-warp sub-record (deformed-mesh branch)')
     ap.add_argument('--fem-grid', type=int, default=708)
     ap.add_argument('--fem-iters', type=int, default=200)
@@ -926,12 +927,14 @@ def main():
         alias = {'ncc_stream_cols': ('ncc_cols2_p2', 'ncc_cols_p2'), 'ncc_stream_rows': ('ncc_rows_p2',), 'ncc_stream_inv': ('ncc_inv_p2',),
                  'dog_fast': ('dog_stream',)}
         syms = alias.get(dom[0], (dom[0],))
-        hit = [v for k_, v in tk.items() if k_ in syms]
+        # the file is keyed by template instance (ncc_cols2_p2<2048>, ...) and comes from a run of THIS command restricted to the
+        # timed steps (--no-xcorr-classes ...): the instances are those of the timed shapes, in the mix of the timed steps
+        hit = [v for k_, v in tk.items() if k_.split('<')[0] in syms]
         if hit:
             nl = sum(v['launches'] for v in hit)
             roof['traffic'] = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit) / max(nl, 1)
             roof['traffic_source'] = 'profiles/' + os.path.basename(tfile[-1])
-            roof['kernel_symbols'] = [k_ for k_ in tk if k_ in syms]
+            roof['kernel_symbols'] = {k_: dict(launches=v['launches'], hbm_bytes_per_launch=v['hbm_bytes_per_launch']) for k_, v in tk.items() if k_.split('<')[0] in syms}
     roof['per_kernel_gbs'] = {k_: round(v[2] / (v[1] * 1e-3) / 1e9, 1) for k_, v in prof.items() if v[1] > 0 and v[2] > 0}
     if rank == 0:
         # what a plain streaming kernel reaches on THIS device at the read : write mixes of the NCC passes (fb_hbm_probe, 1 GiB per
@@ -1017,7 +1020,7 @@ def main():
         fem.pop('x', None)
         if rank == 0:
             line['fem'] = fem
-    if rank == 0:
+    if rank == 0 and not args.no_xcorr_classes:
         line['xcorr_fft_classes'] = bench_xcorr_classes(lib, ctx, _lib)
     if rank == 0 and world == 1 and args.host_ingest_pairs > 0:
         # the boundary as stitcher.py uses it: strips in host memory.  PCIe-inclusive rate through stitching_matcher_batch

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
     FB_SMALL_FFT(Fh, false, true, 2 * Sw, reinterpret_cast<const f2*>(twH), fft_batch<false>(G, prm.ph, 2 * Sw, RS, 1, twH, true));
     // ---- spectral products (matcher.py:65, 114): P = conj(F0) F1 over A's slots, Q = F0 F1 over B's
     const bool want_q = prm.conf_mode == FB_CONF_MIRROR;
+#ifndef FB_CUT_PRODUCTS
     for (int y = wave; y < Fh; y += nwaves)
     for (int kx = lane; kx < Sw; kx += 64) {
         float2* row = G + y * RS;
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(kSmallThreads) void ncc_small_fused(const SmallPara
         row[Sw + kx] = want_q ? make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x) : make_float2(0.f, 0.f);
     }
     __syncthreads();
+#endif
     // ---- inverse along y
     FB_SMALL_FFT(Fh, true, true, 2 * Sw, reinterpret_cast<const f2*>(twH), fft_batch<true>(G, prm.ph, 2 * Sw, RS, 1, twH, true));
     // ---- Hermitian-extend and pack: W = P + iQ in the digit-reversed order the inverse row pass consumes

@@ -17,7 +17,11 @@ def per_kernel(path, counter):
         name = r['Kernel_Name'].replace('(anonymous namespace)::', '')
         if name.startswith('void '):
             name = name[5:]
-        name = name.split('(')[0].split('<')[0].split('::')[-1].strip()
+        # template instances stay apart (ncc_cols2_p2<2048> is not ncc_cols2_p2<512>): a kernel's traffic is compared with the
+        # algorithmic bytes of the SAME shapes
+        name = name.split('(')[0].strip()
+        base, targs = (name.split('<', 1) + [''])[:2]
+        name = base.split('::')[-1].strip() + ('<' + targs.replace('(anonymous namespace)::', '').replace(' ', '') if targs else '')
         a = acc[name]
         a[0] += 1
         a[1] += float(r['Counter_Value'])
@@ -35,10 +39,10 @@ def main():
         wr = 1024.0 * w / max(nw, 1)
         out[k] = dict(launches=int(max(nf, nw)), read_bytes_per_launch=rd, write_bytes_per_launch=wr,
                       hbm_bytes_per_launch=rd + wr)
-    json.dump(dict(note='FETCH_SIZE x2 (gfx950 correction) and WRITE_SIZE, KiB -> bytes, mean per launch; separate --pmc passes',
+    json.dump(dict(note='FETCH_SIZE x2 (gfx950 correction) and WRITE_SIZE, KiB -> bytes, mean per launch; separate --pmc passes; keyed by template instance',
                    kernels=out), open(sys.argv[3], 'w'), indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:14]:
-        print(f"{k[:36]:36s} n={v['launches']:5d} rd={v['read_bytes_per_launch']/1e6:10.2f} MB wr={v['write_bytes_per_launch']/1e6:10.2f} MB")
+        print(f"{k[:44]:44s} n={v['launches']:5d} rd={v['read_bytes_per_launch']/1e6:10.2f} MB wr={v['write_bytes_per_launch']/1e6:10.2f} MB")
 
 
 if __name__ == '__main__':

@@ -15,8 +15,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ms -o ms -- py
 echo "stats (multi-stream) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_os -o os -- python3 bench.py --no-cpu-baseline --no-fem --host-ingest-pairs 0 --no-align --no-deformed --stitch-sections 0 --align-sections 0 --multi-stream 0 > $OUT/bench_one_stream_under_rocprof.json 2> $OUT/prof_os.err || exit 3
 echo "stats (one stream) done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --no-fem --host-ingest-pairs 0 --no-align --no-deformed --stitch-sections 0 --align-sections 0 --multi-stream 0 --steps 1 --warmup 1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 4
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --no-fem --host-ingest-pairs 0 --no-align --no-deformed --stitch-sections 0 --align-sections 0 --multi-stream 0 --steps 2 --warmup 0 --no-xcorr-classes > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 4
 echo "pmc fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 bench.py --no-cpu-baseline --no-fem --host-ingest-pairs 0 --no-align --no-deformed --stitch-sections 0 --align-sections 0 --multi-stream 0 --steps 1 --warmup 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 5
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 bench.py --no-cpu-baseline --no-fem --host-ingest-pairs 0 --no-align --no-deformed --stitch-sections 0 --align-sections 0 --multi-stream 0 --steps 2 --warmup 0 --no-xcorr-classes > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 5
 echo "pmc write done"
 find $OUT -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
+python3 tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1 || exit 6
+echo "pmc traffic done"
