@@ -218,12 +218,12 @@ __device__ __forceinline__ void twiddle_powers(float2 w1, float2* w) {
 // confidences do not depend on the scale of either image.  Tiles of comparable images (every block of a textured pair) are
 // left exactly as they were.
 __device__ __forceinline__ float2 pack_scales(float m0, float m1) {          // m = max |.| of each image over the tile / block
-    float s0 = 1.f, s1 = 1.f;
-    if (m0 > 0.f && m1 > 0.f && m0 < 3.0e38f && m1 < 3.0e38f) {
-        const int e0 = ilogbf(m0), e1 = ilogbf(m1);
-        if (e0 - e1 >= 6) s1 = ldexpf(1.f, e0 - e1);
-        else if (e1 - e0 >= 6) s0 = ldexpf(1.f, e1 - e0);
-    }
+    // exponent fields (biased); 0 = zero or subnormal, 255 = inf / nan: such tiles are left alone
+    const int e0 = (int)((__float_as_uint(m0) >> 23) & 0xffu), e1 = (int)((__float_as_uint(m1) >> 23) & 0xffu);
+    const bool ok = e0 > 0 && e1 > 0 && e0 < 255 && e1 < 255;
+    const int d = e0 - e1;
+    const float s1 = (ok && d >= 6) ? __uint_as_float((unsigned)(127 + d) << 23) : 1.f;      // 2^d, exact
+    const float s0 = (ok && -d >= 6) ? __uint_as_float((unsigned)(127 - d) << 23) : 1.f;
     return make_float2(s0, s1);
 }
 // workgroup-wide max of two per-thread values in two halves around a barrier the caller has anyway: wg_max2_post (every
@@ -235,9 +235,10 @@ __device__ __forceinline__ void wg_max2_post(float m0, float m1, float* red) {
 }
 __device__ __forceinline__ float2 wg_max2_read(const float* red) {
     const int nw = (blockDim.x + 63) >> 6;
-    float a = red[0], b = red[1];
-    for (int w = 1; w < nw; ++w) { a = fmaxf(a, red[2 * w]); b = fmaxf(b, red[2 * w + 1]); }
-    return make_float2(a, b);
+    const float2* r2 = reinterpret_cast<const float2*>(red);
+    float2 m = r2[0];
+    for (int w = 1; w < nw; ++w) { const float2 v = r2[w]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); }
+    return m;
 }
 
 // LDS skew for unit-stride transforms: one spare slot every 16 elements.  Late passes walk the data with

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kStreamThreads) void ncc_stream_rows(const StreamGe
     for (int i = tid; i < Fw; i += nt) posW[i] = (short)fft_padx(fft_pos(g.pw, i));
     // packed load z = img0 + i img1 (zero padded), branch-free; all rows of a column chunk are fetched before
     // any LDS store so that the loads overlap
-    __shared__ float s_red[2 * (kStreamThreads / 64)];
+    __shared__ __attribute__((aligned(8))) float s_red[2 * (kStreamThreads / 64)];
     float m0 = 0.f, m1 = 0.f;
     for (int xb = 0; xb < Fw; xb += nt) {
         const int x = xb + tid;

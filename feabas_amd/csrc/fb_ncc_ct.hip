@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kCtThreads) void ncc_rows_ct(const StreamGeom g, co
     ct_tables<FW>(tw, posW, tw_g, tid, kCtThreads);
     // packed load, zero padded, branch-free; columns beyond both crops are never read
     const int wmax = max(w0, w1);
-    __shared__ float s_red[2 * (kCtThreads / 64)];
+    __shared__ __attribute__((aligned(8))) float s_red[2 * (kCtThreads / 64)];
     float m0 = 0.f, m1 = 0.f;
 #pragma unroll
     for (int c = 0; c < NX; ++c) {

@@ -9,6 +9,7 @@
 #include "fb_fft3.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -346,7 +347,8 @@ int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, in
     const size_t lds = small_lds_bytes(Fh, Fw);
     FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_small_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     FB_PROF_B(ctx, "ncc_small_fused", (double)N * (4.0 * ((double)H0 * W0 + (double)H1 * W1) + 20.0));
-    hipLaunchKernelGGL(ncc_small_fused, dim3(N), dim3(kSmallThreads), lds, ctx->stream, p);
+    static const int nthreads = [] { const char* e = getenv("FB_SMALL_THREADS"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= kSmallThreads && v % 64 == 0) ? v : kSmallThreads; }();
+    hipLaunchKernelGGL(ncc_small_fused, dim3(N), dim3(nthreads), lds, ctx->stream, p);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
