@@ -160,6 +160,8 @@ _PROTOS = {
     'fb_strip_matcher_info': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'fb_match_strips': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'fb_match_strips_table': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p]),
+    'fb_match_strips_deformed': (c_i, [c_p, c_p, c_p, c_p, c_p]),
+    'fb_match_strips_field': (c_i, [c_p, c_p, c_p, c_p]),
     'fb_link_terms': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_d, c_d, c_p, c_p, c_p]),
     'fb_pairs_strain': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_d, c_i, c_d, c_p, c_p, c_p]),
     'fb_sys_lambda': (c_i, [c_p, c_p, c_d, c_d, C.POINTER(c_d), C.POINTER(c_d)]),

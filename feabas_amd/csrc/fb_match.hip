@@ -5,19 +5,25 @@
 // with its residue weights (725-737) and the strain estimate (752-777).  Only host bookkeeping lives here -- every
 // device stage is one of the library's own entry points -- but it is O(pairs x blocks) work per round that serialised
 // on the interpreter lock of the calling threads when it was written in numpy (feabas_amd/stitch_pipeline.py keeps that
-// statement of it for masked / photometric / ragged batches and as the route of the pairs this entry hands back).
+// statement of it for masked / photometric batches and as the route of the pairs this entry hands back).
+// A pair whose relaxation between two spacings is not a rigid translation keeps the node field of its mesh1 (725-742) and
+// takes the deformed-mesh branch in the rounds that follow: block grid on the deformed bounding box (877), image-1 windows
+// through MeshRenderer.crop_multiple's tiers (affine gather inside the NCC loader, exact piecewise-linear field through
+// fb_remap_dev), matches located in the deformed triangles (Link.from_coordinates, optimizer.py:51-82).
 //
 // Pairs this entry does NOT finish are reported in flags[] and left to the caller's general route:
 //   FB_STRIP_LOWCONF    global confidence <= conf_thresh: the second shot of global_translation_matcher (159-221)
-//   FB_STRIP_NONRIGID   the relaxation between two spacings is not a rigid translation: mesh1 deforms (725-742)
+//   FB_STRIP_FOLDED     a block of a deformed mesh1 has a degenerate / flipped affine fit (renderer.py:397-416)
 //   FB_STRIP_RELAXFIRST the last relaxation deformed mesh1 beyond the screen of relax_first (optimizer.py:763-779)
 //   FB_STRIP_RIGIDFIT   the rigid initialisation of the strain stage is rank deficient / reflected / < 3 matches
 #include "fb_common.h"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <limits>
 #include <map>
 #include <numeric>
 #include <vector>
@@ -60,6 +66,13 @@ struct fb_strip_matcher {
     double relax_relres = 0.0, strain_relres = 0.0;
     int64_t relax_matches = 0, strain_matches = 0;
     std::vector<uint8_t> raw;          // D2H staging of one launch: [dx f64 N][dy f64 N][conf f32 N]
+    // deformed-mesh branch: node field of every pair's mesh1 (MOVING - INITIAL, [P][V][2]; zero for a translated grid), tiers
+    // of the blocks of a pair's last deformed round, grow-only device scratch (affine maps; the exact-field tier's stacks)
+    std::vector<double> U;
+    std::vector<uint8_t> is_def;
+    std::vector<std::vector<int32_t>> tiers;
+    void* scr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t b_scr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // FEABAS_HIP_MATCH_TRACE=1: wall time of the stages of fb_match_strips, printed by fb_strip_matcher_destroy
     bool trace = false;
     double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // enqueue global, wait global, blocks host, blocks h2d+launch, blocks wait, relax, table+fits, strain
@@ -271,19 +284,83 @@ void locate_grid(const fb_strip_matcher* m, size_t K, const int32_t* pid, const 
     }
 }
 
+// Mesh.locate_cartesian + Mesh.cart2bary (feabas_amd/mesh.py; reference mesh.py:2191-2217) of a point given in the INITIAL
+// gear of pair p's grid mesh: the cell by bisection of the node coordinates, the triangle of the cell by its diagonal, the
+// barycentric coordinates as ratios of cross products.  The statement of uniform batches (`locate_grid` is the one of
+// ragged ones: the two agree to rounding, and each is what its host route computes)
+void locate_cart(const fb_strip_matcher* m, int p, double x, double y, int32_t n3[3], double B[3]) {
+    const int nx = m->gnx, ny = m->gny, V = nx * ny;
+    const double* xs = &m->gxs[(size_t)p * nx];
+    const double* ys = &m->gys[(size_t)p * ny];
+    int i = (int)(std::upper_bound(xs, xs + nx, x) - xs) - 1, j = (int)(std::upper_bound(ys, ys + ny, y) - ys) - 1;
+    i = std::min(std::max(i, 0), nx - 2); j = std::min(std::max(j, 0), ny - 2);
+    const double u = (x - xs[i]) / (xs[i + 1] - xs[i]), w = (y - ys[j]) / (ys[j + 1] - ys[j]);
+    const bool up = w > u;
+    const int a = j * nx + i;
+    const int loc[3] = {a, up ? a + nx + 1 : a + 1, up ? a + nx : a + nx + 1};
+    double dx[3], dy[3];
+    for (int k = 0; k < 3; ++k) { dx[k] = x - xs[loc[k] % nx]; dy[k] = y - ys[loc[k] / nx]; n3[k] = loc[k] + p * V; }
+    const double a0 = dx[1] * dy[2] - dy[1] * dx[2], a1 = dx[2] * dy[0] - dy[2] * dx[0], a2 = dx[0] * dy[1] - dy[0] * dx[1];
+    const double tot = (a0 + a1) + a2;
+    B[0] = a0 / tot; B[1] = a1 / tot; B[2] = a2 / tot;
+}
+
+// grow-only device scratch of the deformed-mesh branch (slot k of the matcher)
+int scratch(fb_ctx* ctx, fb_strip_matcher* m, int k, size_t bytes, void** out) {
+    if (m->b_scr[k] < bytes) {
+        if (m->scr[k]) pool_give(ctx, m->scr[k], m->b_scr[k]);
+        m->scr[k] = nullptr; m->b_scr[k] = 0;
+        void* ptr = nullptr;
+        const int rc = pool_take(ctx, bytes + bytes / 4, &ptr, &m->b_scr[k]);
+        if (rc) return rc;
+        m->scr[k] = ptr;
+    }
+    *out = m->scr[k];
+    return FB_OK;
+}
+
+// screen of relax_first (adjust_link_weight_by_residue(relax_first=True), matcher.py:736 -> optimizer.py:763-779) on the node
+// field x [P][V][2]: d = the largest displacement difference along a grid edge relative to that edge.  Every triangle's area
+// and edge deformation is below 2 d and nothing is freed below 1 - 1 / (1 + (1 - 1 / 1.35)) = 0.206: pairs with d <= 0.1 are
+// done, the others take the reference's statements on the caller's general route.
+void screen_relax_first(const fb_strip_matcher* m, const std::vector<double>& x, uint8_t* flags) {
+    const int n = m->P, nx = m->gnx, ny = m->gny, V = nx * ny;
+    for (int p = 0; p < n; ++p) {
+        const double* g = &x[(size_t)2 * p * V];
+        const double* gx = &m->gxs[(size_t)p * nx];
+        const double* gy = &m->gys[(size_t)p * ny];
+        double d = 0.0;
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const double* a = g + 2 * ((size_t)j * nx + i);
+                if (i + 1 < nx) d = std::max(d, std::sqrt((a[2] - a[0]) * (a[2] - a[0]) + (a[3] - a[1]) * (a[3] - a[1])) / (gx[i + 1] - gx[i]));
+                if (j + 1 < ny) {
+                    const double* b = a + 2 * (size_t)nx;
+                    d = std::max(d, std::sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1])) / (gy[j + 1] - gy[j]));
+                }
+            }
+        if (d > 0.1 || !(d == d)) flags[p] |= FB_STRIP_RELAXFIRST;
+    }
+}
+
 struct Rows {                                   // a match table: rows of one pair are contiguous
     std::vector<int32_t> pid;
     std::vector<double> xy0, xy1i, xy1;         // mesh0 point (MOVING), mesh1 point (INITIAL), mesh1 point (MOVING)
     std::vector<float> wt;
     std::vector<char> rl;                       // the pair's blocks moved by more than 0.1 px (matcher.py:725)
+    std::vector<int32_t> n3;                    // mesh1 triangle of a match located in a DEFORMED mesh1 (ids in the union mesh; -1: grid)
+    std::vector<double> B;                      // ... and its barycentric coordinates
     size_t size() const { return pid.size(); }
-    void reserve(size_t k) { pid.reserve(k); xy0.reserve(2 * k); xy1i.reserve(2 * k); xy1.reserve(2 * k); wt.reserve(k); rl.reserve(k); }
-    void push(int32_t p, double x0, double y0, double xi, double yi, double x1, double y1, float w, char r) {
+    void reserve(size_t k) { pid.reserve(k); xy0.reserve(2 * k); xy1i.reserve(2 * k); xy1.reserve(2 * k); wt.reserve(k); rl.reserve(k); n3.reserve(3 * k); B.reserve(3 * k); }
+    void push(int32_t p, double x0, double y0, double xi, double yi, double x1, double y1, float w, char r, const int32_t* nodes = nullptr,
+              const double* bary = nullptr) {
         pid.push_back(p); xy0.push_back(x0); xy0.push_back(y0); xy1i.push_back(xi); xy1i.push_back(yi);
         xy1.push_back(x1); xy1.push_back(y1); wt.push_back(w); rl.push_back(r);
+        for (int a = 0; a < 3; ++a) { n3.push_back(nodes ? nodes[a] : -1); B.push_back(bary ? bary[a] : 0.0); }
     }
     void push_from(const Rows& o, size_t k) {
-        push(o.pid[k], o.xy0[2 * k], o.xy0[2 * k + 1], o.xy1i[2 * k], o.xy1i[2 * k + 1], o.xy1[2 * k], o.xy1[2 * k + 1], o.wt[k], o.rl[k]);
+        push(o.pid[k], o.xy0[2 * k], o.xy0[2 * k + 1], o.xy1i[2 * k], o.xy1i[2 * k + 1], o.xy1[2 * k], o.xy1[2 * k + 1], o.wt[k], o.rl[k], &o.n3[3 * k],
+             &o.B[3 * k]);
     }
 };
 
@@ -403,6 +480,70 @@ void rigid_fits(int P, const std::vector<int32_t>& pid, const std::vector<double
         r[7] = A[2][1] + m0y - (m1x * r[1] + m1y * r[4]);
         r[2] = 0.0; r[5] = 0.0; r[8] = 1.0;
     }
+}
+
+// matcher.py:725-741 for matches given by their mesh1 triangle and barycentric coordinates: optimize_linear as the TOTAL
+// displacement of mesh1 from its FIXED gear (fb_pairs_relax_bary), the screen of relax_first, huber / threshold residue
+// weights and -- `resolve`, the rounds before the last -- a second solve for the pairs whose weights changed (737-741).
+// rows: indices into `t`; rows whose triangle is not known (a mesh1 that is still a translated grid) are located on the grid.
+// rw [rows]; x [P][V][2] (pairs without rows: zero).  Pairs beyond the screen get FB_STRIP_RELAXFIRST.
+int relax_general(fb_ctx* ctx, fb_strip_matcher* m, const Rows& t, const std::vector<size_t>& rows, bool resolve, std::vector<float>& rw,
+                  std::vector<double>& x, uint8_t* flags) {
+    int rc;
+    if ((rc = ensure_system(ctx, m))) return rc;
+    const int n = m->P, nx = m->gnx, ny = m->gny, V = nx * ny;
+    const int64_t K = (int64_t)rows.size();
+    std::vector<int32_t> pid((size_t)K), nodes3((size_t)3 * K);
+    std::vector<double> B1((size_t)3 * K), dxy0((size_t)2 * K), se_rows, pts;
+    std::vector<float> w32((size_t)K);
+    for (int64_t k = 0; k < K; ++k) { pid[k] = t.pid[rows[k]]; w32[k] = t.wt[rows[k]]; }
+    if (m->ragged) {
+        // one mesh geometry per pair: every row is located on its pair's grid from its INITIAL coordinates
+        pts.resize((size_t)2 * K); se_rows.resize((size_t)K);
+        for (int64_t k = 0; k < K; ++k) { pts[2 * k] = t.xy1i[2 * rows[k]]; pts[2 * k + 1] = t.xy1i[2 * rows[k] + 1]; se_rows[k] = m->se[pid[k]]; }
+        locate_grid(m, (size_t)K, pid.data(), pts.data(), nodes3, B1);
+    } else {
+        for (int64_t k = 0; k < K; ++k) {
+            const size_t r = rows[k];
+            if (t.n3[3 * r] < 0) locate_cart(m, pid[k], t.xy1i[2 * r], t.xy1i[2 * r + 1], &nodes3[3 * k], &B1[3 * k]);
+            else for (int a = 0; a < 3; ++a) { nodes3[3 * k + a] = t.n3[3 * r + a]; B1[3 * k + a] = t.B[3 * r + a]; }
+        }
+    }
+    for (int64_t k = 0; k < K; ++k) {
+        const int p = pid[k];
+        double fx[3], fy[3];
+        for (int a = 0; a < 3; ++a) {
+            const int loc = nodes3[3 * k + a] - p * V;
+            fx[a] = m->gxs[(size_t)p * nx + loc % nx]; fy[a] = m->gys[(size_t)p * ny + loc / nx];
+        }
+        const double* b = &B1[3 * (size_t)k];
+        dxy0[2 * k] = ((fx[0] * b[0] + fx[1] * b[1]) + fx[2] * b[2]) - t.xy0[2 * rows[k]];          // mesh1 at its FIXED gear (= INITIAL, no offset)
+        dxy0[2 * k + 1] = ((fy[0] * b[0] + fy[1] * b[1]) + fy[2] * b[2]) - t.xy0[2 * rows[k] + 1];
+    }
+    rw.resize((size_t)K);
+    x.resize((size_t)2 * n * V);
+    const double rlen = m->residue_len > 0 ? m->residue_len : 1.0;
+    if ((rc = fb_pairs_relax_bary(ctx, m->sys, n, K, nodes3.data(), B1.data(), dxy0.data(), w32.data(), rlen, m->residue_mode, m->se0,
+                                  m->ragged ? se_rows.data() : nullptr, m->stiffness_lambda, m->relax_tol, rw.data(), x.data(), &m->relax_iters, &m->relax_relres)))
+        return rc;
+    m->relax_matches = K;
+    if (m->residue_len <= 0) { std::fill(rw.begin(), rw.end(), 1.0f); return FB_OK; }
+    screen_relax_first(m, x, flags);
+    bool changed_any = false;
+    for (int64_t k = 0; k < K; ++k) changed_any |= rw[k] != 1.0f;
+    if (resolve && changed_any) {
+        std::vector<char> changed((size_t)n, 0);
+        std::vector<float> w2((size_t)K), rw2((size_t)K);
+        std::vector<double> x2((size_t)2 * n * V);
+        for (int64_t k = 0; k < K; ++k) { if (rw[k] != 1.0f) changed[pid[k]] = 1; w2[k] = w32[k] * rw[k]; }
+        if ((rc = fb_pairs_relax_bary(ctx, m->sys, n, K, nodes3.data(), B1.data(), dxy0.data(), w2.data(), rlen, m->residue_mode, m->se0,
+                                      m->ragged ? se_rows.data() : nullptr, m->stiffness_lambda, m->relax_tol, rw2.data(), x2.data(), &m->relax_iters,
+                                      &m->relax_relres)))
+            return rc;
+        for (int p = 0; p < n; ++p)
+            if (changed[p]) std::copy(x2.begin() + (size_t)2 * p * V, x2.begin() + (size_t)2 * (p + 1) * V, x.begin() + (size_t)2 * p * V);
+    }
+    return FB_OK;
 }
 
 }  // namespace
@@ -555,6 +696,7 @@ void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m) {
     }
     pool_give(ctx, m->d_dogc, m->b_dogc); pool_give(ctx, m->d_dogf, m->b_dogf); pool_give(ctx, m->d_small, m->b_small);
     pool_give(ctx, m->d_blk, m->b_blk); pool_give(ctx, m->d_out, m->b_out); pool_give(ctx, m->d_sizes, m->b_sizes);
+    for (int k = 0; k < 8; ++k) pool_give(ctx, m->scr[k], m->b_scr[k]);
     delete m;
 }
 
@@ -665,24 +807,48 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         live[p] = active[p] && !flags[p];
     }
     std::vector<double> t1((size_t)2 * n, 0.0);            // translation of mesh1 acquired by rigid relaxations
+    m->is_def.assign((size_t)n, 0);
+    m->tiers.assign((size_t)n, std::vector<int32_t>());
+    bool any_def = false;
     Rows table, prev;
     bool have_table = false, last_links = false;
     std::vector<int> nxv((size_t)n), nyv((size_t)n), dxv((size_t)n), dyv((size_t)n), fhv((size_t)n), fwv((size_t)n);
     std::vector<double> xminv((size_t)n), yminv((size_t)n), xmaxv((size_t)n), ymaxv((size_t)n);
     std::vector<int> bbx0, bby0, xt, yt, order, ordc;
     std::vector<long long> zk, zkc;
-    std::vector<char> in_cur((size_t)n);
+    std::vector<char> in_cur((size_t)n), to_relax((size_t)n);
+    std::vector<double> gdx, gdy;                          // results of a deformed group (the exact tier overwrites some)
+    std::vector<float> gcf;
     for (int rnd = 0; rnd < nsp; ++rnd) {
         const bool is_last = rnd == nsp - 1;
         const int mnb = is_last ? m->mnb : 1;
-        // ---- group the live pairs by block grid and FFT shape (matcher.py:59-62 on the block size)
+        std::fill(to_relax.begin(), to_relax.end(), 0);
+        // ---- group the live pairs by block grid and FFT shape (matcher.py:59-62 on the block size); pairs with a deformed
+        //      mesh1 form their own groups (per pad flag and block size: their windows are rendered, not cropped)
         std::map<long long, std::vector<int>> groups;
+        std::map<std::array<int, 7>, std::vector<int>> dgroups;
+        const int gV = m->gnx * m->gny;
         for (int p = 0; p < n; ++p) {
             if (!live[p]) continue;
             const double spc = m->sp[(size_t)p * nsp + rnd];
             const double Wp = (double)m->Ws[p], Hp = (double)m->Hs[p];
-            const double xmin = std::max(-0.5 + tx[p], -0.5 + t1[2 * p]), xmax = std::min(Wp - 0.5 + tx[p], Wp - 0.5 + t1[2 * p]);
-            const double ymin = std::max(-0.5 + ty[p], -0.5 + t1[2 * p + 1]), ymax = std::min(Hp - 0.5 + ty[p], Hp - 0.5 + t1[2 * p + 1]);
+            double xmin, xmax, ymin, ymax;
+            if (!m->is_def[p]) {
+                xmin = std::max(-0.5 + tx[p], -0.5 + t1[2 * p]); xmax = std::min(Wp - 0.5 + tx[p], Wp - 0.5 + t1[2 * p]);
+                ymin = std::max(-0.5 + ty[p], -0.5 + t1[2 * p + 1]); ymax = std::min(Hp - 0.5 + ty[p], Hp - 0.5 + t1[2 * p + 1]);
+            } else {
+                // intersection with the bounding box of the deformed mesh1 (matcher.py:877)
+                const double inf = std::numeric_limits<double>::infinity();
+                double vx0 = inf, vx1 = -inf, vy0 = inf, vy1 = -inf;
+                const double* u = &m->U[(size_t)2 * p * gV];
+                for (int j = 0; j < m->gny; ++j)
+                    for (int i = 0; i < m->gnx; ++i) {
+                        const double vx = m->gxs[(size_t)p * m->gnx + i] + u[2 * (j * m->gnx + i)], vy = m->gys[(size_t)p * m->gny + j] + u[2 * (j * m->gnx + i) + 1];
+                        vx0 = std::min(vx0, vx); vx1 = std::max(vx1, vx); vy0 = std::min(vy0, vy); vy1 = std::max(vy1, vy);
+                    }
+                xmin = std::max(-0.5 + tx[p], vx0); xmax = std::min(Wp - 0.5 + tx[p], vx1);
+                ymin = std::max(-0.5 + ty[p], vy0); ymax = std::min(Hp - 0.5 + ty[p], vy1);
+            }
             if (!(xmax > xmin && ymax > ymin)) continue;
             // common.divide_bbox (common.py:380-409)
             const AxisCut cx = cut_axis(xmin, xmax, spc, (double)mnb, 1.0), cy = cut_axis(ymin, ymax, spc, (double)mnb, 1.0);
@@ -694,16 +860,62 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
             nxv[p] = (int)nx; nyv[p] = (int)ny; dxv[p] = (int)dx; dyv[p] = (int)dy;
             fhv[p] = fb_next_fast_len(pad[p] ? std::max(2 * (int)dy - 1, 0) : (int)dy);
             fwv[p] = fb_next_fast_len(pad[p] ? std::max(2 * (int)dx - 1, 0) : (int)dx);
-            const long long key = ((((long long)nx * 4096 + (long long)ny) * 8192 + fhv[p]) * 8192 + fwv[p]);
-            groups[key].push_back(p);
+            if (!m->is_def[p]) {
+                const long long key = ((((long long)nx * 4096 + (long long)ny) * 8192 + fhv[p]) * 8192 + fwv[p]);
+                groups[key].push_back(p);
+            } else {
+                dgroups[{(int)nx, (int)ny, fhv[p], fwv[p], (int)pad[p], (int)dx, (int)dy}].push_back(p);
+            }
         }
-        if (groups.empty()) continue;
+        if (groups.empty() && dgroups.empty()) continue;
         Rows cur;
         {
             size_t cap = 0;
             for (auto& kv : groups) cap += kv.second.size() * (size_t)nxv[kv.second[0]] * nyv[kv.second[0]];
+            for (auto& kv : dgroups) cap += kv.second.size() * (size_t)nxv[kv.second[0]] * nyv[kv.second[0]];
             cur.reserve(cap + (have_table ? table.size() : 0));
         }
+        // block descriptors of pair p (slot q of its group): starts = round(linspace(lo, hi - step, count)) per axis, blocks in the
+        // z-order of their index grid (common.z_order, common.py:196-215; stable)
+        bool have_c = false;
+        auto pair_blocks = [&](int q, int p, int nxi, int nyi, bool deformed) {
+            const int nblk = nxi * nyi, dx = dxv[p], dy = dyv[p];
+            const double spc = m->sp[(size_t)p * nsp + rnd];
+            xt.resize(nxi); yt.resize(nyi);
+            for (int i = 0; i < nxi; ++i) xt[i] = round_i(linspace_at(xminv[p], xmaxv[p] - (double)dx, nxi, i));
+            for (int j = 0; j < nyi; ++j) yt[j] = round_i(linspace_at(yminv[p], ymaxv[p] - (double)dy, nyi, j));
+            const int xlo = *std::min_element(xt.begin(), xt.end()), ylo = *std::min_element(yt.begin(), yt.end());
+            zk.resize(nblk);
+            for (int j = 0; j < nyi; ++j)
+                for (int i = 0; i < nxi; ++i) {
+                    unsigned ix = (unsigned)std::nearbyint((double)(xt[i] - xlo) / spc), iy = (unsigned)std::nearbyint((double)(yt[j] - ylo) / spc);
+                    long long k = 0;
+                    for (int l = 0; ix || iy; ++l, ix >>= 1, iy >>= 1) k += ((long long)(ix & 1) + 2 * (long long)(iy & 1)) << (2 * l);
+                    zk[(size_t)j * nxi + i] = k;
+                }
+            if (!have_c || zk != zkc) {
+                order.resize(nblk);
+                std::iota(order.begin(), order.end(), 0);
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return zk[a] < zk[b]; });
+                ordc = order; zkc = zk; have_c = true;
+            }
+            const int rtx = round_i(tx[p]), rty = round_i(ty[p]), r1x = round_i(t1[2 * p]), r1y = round_i(t1[2 * p + 1]);
+            for (int b = 0; b < nblk; ++b) {
+                const int o = ordc[b], x0 = xt[o % nxi], y0 = yt[o / nxi];
+                const size_t at = (size_t)q * nblk + b;
+                bbx0[at] = x0; bby0[at] = y0;
+                int32_t* d = &blk[9 * at];
+                d[0] = p; d[1] = x0 - rtx; d[2] = y0 - rty; d[3] = dy; d[4] = dx; d[7] = dy; d[8] = dx;
+                if (deformed) { d[5] = 0; d[6] = 0; }          // the window of image 1 comes from the affine / exact gather
+                else { d[5] = x0 - r1x; d[6] = y0 - r1y; }
+            }
+        };
+        // spacing schedule of pair p after a round that measured max_dis (matcher.py:689-716), max_spacing_skip = 0
+        auto schedule = [&](int p, double max_dis) {
+            int next_pos = -1;
+            for (int k = 0; k < nsp; ++k) next_pos += m->sp[(size_t)p * nsp + k] > 4.0 * max_dis;
+            pad[p] = !(next_pos > rnd);
+        };
         for (auto& kv : groups) {
             const std::vector<int>& sel = kv.second;
             const int Q = (int)sel.size(), nxi = nxv[sel[0]], nyi = nyv[sel[0]], nblk = nxi * nyi;
@@ -711,39 +923,10 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
             if (nb > m->max_blocks) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: %zu blocks in one launch (limit %zu)", nb, m->max_blocks);
             blk.resize(nb * 9); bbx0.resize(nb); bby0.resize(nb);
             int hmax = 0, wmax = 0;
-            bool have_c = false;
+            have_c = false;
             for (int q = 0; q < Q; ++q) {
-                const int p = sel[q];
-                const int dx = dxv[p], dy = dyv[p];
-                const double spc = m->sp[(size_t)p * nsp + rnd];
-                hmax = std::max(hmax, dy); wmax = std::max(wmax, dx);
-                xt.resize(nxi); yt.resize(nyi);
-                for (int i = 0; i < nxi; ++i) xt[i] = round_i(linspace_at(xminv[p], xmaxv[p] - (double)dx, nxi, i));
-                for (int j = 0; j < nyi; ++j) yt[j] = round_i(linspace_at(yminv[p], ymaxv[p] - (double)dy, nyi, j));
-                const int xlo = *std::min_element(xt.begin(), xt.end()), ylo = *std::min_element(yt.begin(), yt.end());
-                // z-order of the block index grid (common.z_order, common.py:196-215), stable
-                zk.resize(nblk);
-                for (int j = 0; j < nyi; ++j)
-                    for (int i = 0; i < nxi; ++i) {
-                        unsigned ix = (unsigned)std::nearbyint((double)(xt[i] - xlo) / spc), iy = (unsigned)std::nearbyint((double)(yt[j] - ylo) / spc);
-                        long long k = 0;
-                        for (int l = 0; ix || iy; ++l, ix >>= 1, iy >>= 1) k += ((long long)(ix & 1) + 2 * (long long)(iy & 1)) << (2 * l);
-                        zk[(size_t)j * nxi + i] = k;
-                    }
-                if (!have_c || zk != zkc) {
-                    order.resize(nblk);
-                    std::iota(order.begin(), order.end(), 0);
-                    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return zk[a] < zk[b]; });
-                    ordc = order; zkc = zk; have_c = true;
-                }
-                const int rtx = round_i(tx[p]), rty = round_i(ty[p]), r1x = round_i(t1[2 * p]), r1y = round_i(t1[2 * p + 1]);
-                for (int b = 0; b < nblk; ++b) {
-                    const int o = ordc[b], x0 = xt[o % nxi], y0 = yt[o / nxi];
-                    const size_t at = (size_t)q * nblk + b;
-                    bbx0[at] = x0; bby0[at] = y0;
-                    int32_t* d = &blk[9 * at];
-                    d[0] = p; d[1] = x0 - rtx; d[2] = y0 - rty; d[3] = dy; d[4] = dx; d[5] = x0 - r1x; d[6] = y0 - r1y; d[7] = dy; d[8] = dx;
-                }
+                hmax = std::max(hmax, dyv[sel[q]]); wmax = std::max(wmax, dxv[sel[q]]);
+                pair_blocks(q, sel[q], nxi, nyi, false);
             }
             clk.lap(2);
             if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), nb * 9 * 4))) return rc;
@@ -776,13 +959,12 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                     live[p] = 0;                            // ... or break with the links so far (674-675, 722-723)
                 }
                 const double t1x = t1[2 * p], t1y = t1[2 * p + 1];        // mesh1 offset at link creation (matcher.py:748-751)
-                bool nonrigid = false;
                 if (!is_last) {
-                    int next_pos = -1;
-                    for (int k = 0; k < nsp; ++k) next_pos += m->sp[(size_t)p * nsp + k] > 4.0 * max_dis;
-                    pad[p] = !(next_pos > rnd);             // max_spacing_skip = 0
+                    schedule(p, max_dis);
                     if (has_link && max_dis > 0.1) {
-                        // every kept block reports the same displacement: the relaxation of mesh1 is that translation
+                        // every kept block reports the same displacement: the relaxation of mesh1 is that translation (zero
+                        // elastic and zero link energy); any other field is solved below and makes the pair deformed
+                        bool nonrigid = false;
                         const double hx0 = ddx[base + first] * 0.5, hy0 = ddy[base + first] * 0.5;
                         const double c0x = 0.5 * (double)(bbx0[base + first] + (bbx0[base + first] + dx)) - 0.5, c0y = 0.5 * (double)(bby0[base + first] + (bby0[base + first] + dy)) - 0.5;
                         const double u0x = (c0x - hx0) - (c0x + hx0), u0y = (c0y - hy0) - (c0y + hy0);
@@ -793,9 +975,9 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                             nonrigid = ((cx - hx) - (cx + hx)) != u0x || ((cy - hy) - (cy + hy)) != u0y;
                         }
                         if (!nonrigid) { t1[2 * p] += u0x; t1[2 * p + 1] += u0y; }
+                        else to_relax[p] = 1;
                     }
                 }
-                if (nonrigid) { flags[p] |= FB_STRIP_NONRIGID; live[p] = 0; continue; }
                 const char rl = max_dis > 0.1;
                 for (int b = 0; b < nblk; ++b) {
                     if (!(dcf[base + b] > thr)) continue;
@@ -807,12 +989,230 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                 if (has_link) has_last[p] = 1;
             }
         }
+        // ---- groups of pairs whose mesh1 is deformed (matcher.py:833-846 -> MeshRenderer.crop_multiple, renderer.py:397-563)
+        for (auto& kv : dgroups) {
+            const std::vector<int>& sel = kv.second;
+            const int Q = (int)sel.size(), nxi = kv.first[0], nyi = kv.first[1], nblk = nxi * nyi, gfh = kv.first[2], gfw = kv.first[3], gpad = kv.first[4];
+            const int w = kv.first[5], h = kv.first[6];
+            const int gnx = m->gnx, gny = m->gny, V = gnx * gny;
+            const size_t nb = (size_t)Q * nblk, px = (size_t)h * w;
+            if (nb > m->max_blocks) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: %zu blocks in one launch (limit %zu)", nb, m->max_blocks);
+            blk.resize(nb * 9); bbx0.resize(nb); bby0.resize(nb);
+            have_c = false;
+            for (int q = 0; q < Q; ++q) pair_blocks(q, sel[q], nxi, nyi, true);
+            // tiers and affine maps of every block (affine_approx_tol = 0.1 in the last round, max(1, 0.02 spacing) before:
+            // matcher.py:578-603), on the MOVING nodes of each pair's mesh1
+            std::vector<double> vmg((size_t)2 * Q * V), gxs_q((size_t)Q * gnx), gys_q((size_t)Q * gny), tolg((size_t)Q), A6(6 * nb), lo((size_t)2 * Q), aff(10 * nb, 0.0);
+            std::vector<int32_t> bb(4 * nb), tier(nb);
+            for (int q = 0; q < Q; ++q) {
+                const int p = sel[q];
+                std::copy(m->gxs.begin() + (size_t)p * gnx, m->gxs.begin() + (size_t)(p + 1) * gnx, gxs_q.begin() + (size_t)q * gnx);
+                std::copy(m->gys.begin() + (size_t)p * gny, m->gys.begin() + (size_t)(p + 1) * gny, gys_q.begin() + (size_t)q * gny);
+                const double* u = &m->U[(size_t)2 * p * V];
+                for (int j = 0; j < gny; ++j)
+                    for (int i = 0; i < gnx; ++i) {
+                        const size_t k = 2 * ((size_t)q * V + (size_t)j * gnx + i);
+                        vmg[k] = gxs_q[(size_t)q * gnx + i] + u[2 * (j * gnx + i)]; vmg[k + 1] = gys_q[(size_t)q * gny + j] + u[2 * (j * gnx + i) + 1];
+                    }
+                tolg[q] = is_last ? 0.1 : std::max(1.0, 0.02 * m->sp[(size_t)p * nsp + rnd]);
+                for (int b = 0; b < nblk; ++b) {
+                    const size_t at = (size_t)q * nblk + b;
+                    bb[4 * at] = bbx0[at]; bb[4 * at + 1] = bby0[at]; bb[4 * at + 2] = bbx0[at] + w; bb[4 * at + 3] = bby0[at] + h;
+                }
+            }
+            if ((rc = fb_deformed_block_affines(ctx, Q, gnx, gny, gxs_q.data(), gys_q.data(), 1, vmg.data(), nblk, bb.data(), 0.0, tolg.data(), tier.data(),
+                                                A6.data(), lo.data())))
+                return rc;
+            // the exact piecewise-linear field of the blocks no affine map follows (renderer.py:511-563)
+            struct Exact { int q, b; size_t at; };
+            std::vector<Exact> exact;
+            std::vector<double> emx, emy;
+            std::vector<uint8_t> emk;
+            for (int q = 0; q < Q; ++q) {
+                const int p = sel[q];
+                bool folded = false;
+                for (int b = 0; b < nblk; ++b) folded |= tier[(size_t)q * nblk + b] < 0;
+                if (folded) { flags[p] |= FB_STRIP_FOLDED; continue; }      // the statement-by-statement host route renders this pair
+                m->tiers[p].assign(tier.begin() + (size_t)q * nblk, tier.begin() + (size_t)(q + 1) * nblk);
+                // one remap origin for the whole stack of a pair (render_by_subregions, common.py:316-321): floor(min of the rendered
+                // maps) - 4; an affine map takes its extremes at the corner pixels (lo)
+                double lo_x = lo[2 * q], lo_y = lo[2 * q + 1];
+                std::vector<int32_t> po, org;
+                const size_t e0 = exact.size();
+                for (int b = 0; b < nblk; ++b)
+                    if (tier[(size_t)q * nblk + b] == 3) {
+                        exact.push_back({q, b, exact.size() * px});
+                        po.push_back(0); org.push_back(bbx0[(size_t)q * nblk + b]); org.push_back(bby0[(size_t)q * nblk + b]);
+                    }
+                const size_t ne = exact.size() - e0;
+                if (ne) {
+                    emx.resize(exact.size() * px); emy.resize(exact.size() * px); emk.resize(exact.size() * px);
+                    if ((rc = fb_deformed_exact_field(ctx, 1, gnx, gny, &gxs_q[(size_t)q * gnx], &gys_q[(size_t)q * gny], 0, &vmg[(size_t)2 * q * V], (int)ne, po.data(),
+                                                      org.data(), h, w, &emx[e0 * px], &emy[e0 * px], &emk[e0 * px])))
+                        return rc;
+                    for (size_t k = e0 * px; k < exact.size() * px; ++k)
+                        if (emk[k]) { lo_x = std::min(lo_x, emx[k]); lo_y = std::min(lo_y, emy[k]); }
+                }
+                const bool fin = std::isfinite(lo_x);
+                for (int b = 0; b < nblk; ++b) {
+                    const size_t at = (size_t)q * nblk + b;
+                    double* a = &aff[10 * at];
+                    a[0] = (double)bbx0[at]; a[1] = (double)bby0[at];
+                    for (int k = 0; k < 6; ++k) a[2 + k] = A6[6 * at + k];
+                    if (fin) { a[8] = std::floor(lo_x) - 4.0; a[9] = std::floor(lo_y) - 4.0; }
+                }
+            }
+            clk.lap(2);
+            void* d_aff = nullptr;
+            if ((rc = scratch(ctx, m, 0, aff.size() * 8, &d_aff))) return rc;
+            if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), nb * 9 * 4)) || (rc = fb_memcpy_h2d(ctx, d_aff, aff.data(), aff.size() * 8))) return rc;
+            if ((rc = fb_ncc_blocks_affine_dev(ctx, dogf, img1, H, W, H, W, (int)nb, m->d_blk, (const double*)d_aff, h, w, gfh, gfw, is_last ? 1 : 0, m->conf_mode,
+                                               (double*)m->d_out, (double*)(m->d_out + 8 * nb), (float*)(m->d_out + 16 * nb))))
+                return rc;
+            clk.lap(3);
+            {
+                const double *ddx, *ddy; const float* dcf;
+                if ((rc = fetch(ctx, m, nb, &ddx, &ddy, &dcf))) return rc;
+                gdx.assign(ddx, ddx + nb); gdy.assign(ddy, ddy + nb); gcf.assign(dcf, dcf + nb);
+            }
+            if (!exact.empty()) {
+                // both windows of these blocks are materialised (fb_remap_dev; the image-0 window through an integer map) and
+                // correlated as a stack (fb_ncc_batch_dev)
+                const size_t ne = exact.size(), N2 = 2 * ne;
+                std::vector<int32_t> ids(N2), eorg(2 * N2);
+                std::vector<float> mxa(N2 * px), mya(N2 * px);
+                std::vector<uint8_t> mka(N2 * px, 1);
+                for (size_t e = 0; e < ne; ++e) {
+                    const Exact& x = exact[e];
+                    const size_t at = (size_t)x.q * nblk + x.b;
+                    const double ox = aff[10 * at + 8], oy = aff[10 * at + 9];
+                    ids[e] = sel[x.q]; eorg[2 * e] = blk[9 * at + 1]; eorg[2 * e + 1] = blk[9 * at + 2];
+                    ids[ne + e] = n + sel[x.q]; eorg[2 * (ne + e)] = (int32_t)ox; eorg[2 * (ne + e) + 1] = (int32_t)oy;
+                    for (int r = 0; r < h; ++r)
+                        for (int c = 0; c < w; ++c) {
+                            const size_t k = (size_t)r * w + c;
+                            mxa[e * px + k] = (float)c; mya[e * px + k] = (float)r;
+                            mxa[(ne + e) * px + k] = (float)(emx[x.at + k] - ox); mya[(ne + e) * px + k] = (float)(emy[x.at + k] - oy);
+                            mka[(ne + e) * px + k] = emk[x.at + k];
+                        }
+                }
+                void *d_ids, *d_org, *d_mx, *d_my, *d_mk, *d_st, *d_res;
+                if ((rc = scratch(ctx, m, 1, 4 * N2, &d_ids)) || (rc = scratch(ctx, m, 2, 8 * N2, &d_org)) || (rc = scratch(ctx, m, 3, 4 * N2 * px, &d_mx)) ||
+                    (rc = scratch(ctx, m, 4, 4 * N2 * px, &d_my)) || (rc = scratch(ctx, m, 5, N2 * px, &d_mk)) || (rc = scratch(ctx, m, 6, 4 * N2 * px, &d_st)) ||
+                    (rc = scratch(ctx, m, 7, 20 * ne, &d_res)))
+                    return rc;
+                if ((rc = fb_memcpy_h2d(ctx, d_ids, ids.data(), 4 * N2)) || (rc = fb_memcpy_h2d(ctx, d_org, eorg.data(), 8 * N2)) ||
+                    (rc = fb_memcpy_h2d(ctx, d_mx, mxa.data(), 4 * N2 * px)) || (rc = fb_memcpy_h2d(ctx, d_my, mya.data(), 4 * N2 * px)) ||
+                    (rc = fb_memcpy_h2d(ctx, d_mk, mka.data(), N2 * px)))
+                    return rc;
+                if ((rc = fb_remap_dev(ctx, dogf, H, W, (int)N2, (const int*)d_ids, h, w, (const float*)d_mx, (const float*)d_my, (const uint8_t*)d_mk, (const int*)d_org,
+                                       (float*)d_st)))
+                    return rc;
+                uint8_t* r8 = (uint8_t*)d_res;
+                if ((rc = fb_ncc_batch_dev(ctx, (const float*)d_st, (const float*)d_st + ne * px, (int)ne, 1, h, w, h, w, gpad, is_last ? 1 : 0, m->conf_mode, (double*)r8,
+                                           (double*)(r8 + 8 * ne), (float*)(r8 + 16 * ne))))
+                    return rc;
+                m->raw.resize(20 * ne);
+                if ((rc = fb_memcpy_d2h(ctx, m->raw.data(), d_res, 20 * ne))) return rc;
+                const double* ex = (const double*)m->raw.data();
+                const double* ey = (const double*)(m->raw.data() + 8 * ne);
+                const float* ec = (const float*)(m->raw.data() + 16 * ne);
+                for (size_t e = 0; e < ne; ++e) {
+                    const size_t at = (size_t)exact[e].q * nblk + exact[e].b;
+                    gdx[at] = ex[e]; gdy[at] = ey[e]; gcf[at] = ec[e];
+                }
+            }
+            clk.lap(4);
+            // ---- blocks -> point pairs; Link.from_coordinates on the MOVING gear of the deformed mesh1 (matcher.py:717,
+            //      optimizer.py:51-82): points outside the mesh are dropped, the INITIAL coordinates follow from the barycentric ones
+            std::vector<int32_t> pq, ptid;
+            std::vector<double> pts, pB;
+            std::vector<size_t> pat;
+            for (int q = 0; q < Q; ++q) {
+                if (flags[sel[q]] & FB_STRIP_FOLDED) continue;
+                for (int b = 0; b < nblk; ++b) {
+                    const size_t at = (size_t)q * nblk + b;
+                    if (!(gcf[at] > thr)) continue;
+                    const double cx = 0.5 * (double)(bbx0[at] + (bbx0[at] + w)) - 0.5, cy = 0.5 * (double)(bby0[at] + (bby0[at] + h)) - 0.5;
+                    pq.push_back(q); pat.push_back(at);
+                    pts.push_back(cx + gdx[at] * 0.5); pts.push_back(cy + gdy[at] * 0.5);
+                }
+            }
+            ptid.resize(pq.size()); pB.resize(3 * pq.size());
+            if (!pq.empty() && (rc = fb_deformed_locate(ctx, Q, gnx, gny, gxs_q.data(), gys_q.data(), 1, vmg.data(), (int64_t)pq.size(), pq.data(), pts.data(), ptid.data(),
+                                                        pB.data())))
+                return rc;
+            size_t cursor = 0;
+            for (int q = 0; q < Q; ++q) {
+                const int p = sel[q];
+                if (flags[p] & FB_STRIP_FOLDED) { live[p] = 0; continue; }
+                double dis2max = -1.0;
+                bool has_link = false;
+                const size_t c0 = cursor;
+                for (; cursor < pq.size() && pq[cursor] == q; ++cursor) {
+                    const size_t at = pat[cursor];
+                    const double hx = gdx[at] * 0.5, hy = gdy[at] * 0.5;
+                    const double cx = 0.5 * (double)(bbx0[at] + (bbx0[at] + w)) - 0.5, cy = 0.5 * (double)(bby0[at] + (bby0[at] + h)) - 0.5;
+                    const double ex = (cx - hx) - (cx + hx), ey = (cy - hy) - (cy + hy);
+                    dis2max = std::max(dis2max, ex * ex + ey * ey);      // before the inside test, like the reference
+                    has_link |= ptid[cursor] >= 0;
+                }
+                const double max_dis = std::sqrt(std::max(dis2max, 0.0));
+                if (!has_link) {
+                    if (rnd == 0) active[p] = 0;
+                    live[p] = 0;
+                }
+                if (!is_last) {
+                    schedule(p, max_dis);
+                    if (has_link && max_dis > 0.1) to_relax[p] = 1;
+                }
+                const char rl = max_dis > 0.1;
+                for (size_t c = c0; c < cursor; ++c) {
+                    if (ptid[c] < 0) continue;
+                    const size_t at = pat[c];
+                    const double hx = gdx[at] * 0.5, hy = gdy[at] * 0.5;
+                    const double cx = 0.5 * (double)(bbx0[at] + (bbx0[at] + w)) - 0.5, cy = 0.5 * (double)(bby0[at] + (bby0[at] + h)) - 0.5;
+                    // triangle of the grid cell (a b / c d): 2 cell = (a, b, d), 2 cell + 1 = (a, d, c)
+                    const int cell = ptid[c] / 2, cj = cell / (gnx - 1), ci = cell % (gnx - 1), na = cj * gnx + ci;
+                    const int loc[3] = {na, (ptid[c] & 1) ? na + gnx + 1 : na + 1, (ptid[c] & 1) ? na + gnx : na + gnx + 1};
+                    int32_t nodes[3];
+                    double fx[3], fy[3];
+                    for (int a = 0; a < 3; ++a) {
+                        nodes[a] = loc[a] + p * V;
+                        fx[a] = m->gxs[(size_t)p * gnx + loc[a] % gnx]; fy[a] = m->gys[(size_t)p * gny + loc[a] / gnx];
+                    }
+                    const double* bq = &pB[3 * c];
+                    const double xi = (fx[0] * bq[0] + fx[1] * bq[1]) + fx[2] * bq[2], yi = (fy[0] * bq[0] + fy[1] * bq[1]) + fy[2] * bq[2];
+                    cur.push(p, cx - hx, cy - hy, xi, yi, cx + hx, cy + hy, gcf[at], rl, nodes, bq);
+                }
+                if (has_link) has_last[p] = 1;
+            }
+        }
         prev = std::move(table);
         const bool had_prev = have_table;
         table = std::move(cur);
         have_table = true;
         last_links = false;
         clk.lap(2);
+        bool any_relax = false;
+        for (int p = 0; p < n; ++p) any_relax |= to_relax[p] != 0;
+        if (any_relax) {
+            // non-rigid relaxation between spacings (matcher.py:725-741): mesh1 of these pairs keeps the node field
+            std::vector<size_t> rows;
+            for (size_t k = 0; k < table.size(); ++k) if (to_relax[table.pid[k]]) rows.push_back(k);
+            std::vector<float> rw;
+            std::vector<double> x;
+            if ((rc = relax_general(ctx, m, table, rows, true, rw, x, flags))) return rc;
+            const int V = m->gnx * m->gny;
+            if (m->U.size() != (size_t)2 * n * V) m->U.assign((size_t)2 * n * V, 0.0);
+            for (int p = 0; p < n; ++p) {
+                if (!to_relax[p]) continue;
+                std::copy(x.begin() + (size_t)2 * p * V, x.begin() + (size_t)2 * (p + 1) * V, m->U.begin() + (size_t)2 * p * V);
+                m->is_def[p] = 1; any_def = true;
+                if (flags[p]) live[p] = 0;                   // beyond the screen of relax_first: the general route finishes the pair
+            }
+            for (size_t k = 0; k < rows.size(); ++k) table.wt[rows[k]] = table.wt[rows[k]] * rw[k];      // Link.weight (optimizer.py:313-317)
+        }
         if (is_last && m->residue_len > 0 && table.size()) {
             bool any_rl = false;
             for (char r : table.rl) any_rl |= r != 0;
@@ -823,52 +1223,22 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                 const int nx = m->gnx, ny = m->gny, V = nx * ny;
                 const int64_t K = (int64_t)table.size();
                 std::vector<float> rw((size_t)K);
-                std::vector<double> x((size_t)2 * n * V);
-                if (!m->ragged) {
-                    rc = fb_pairs_relax(ctx, m->sys, n, nx, ny, m->gxs.data(), m->gys.data(), K, table.pid.data(), table.xy0.data(), table.xy1i.data(),
-                                        t1.data(), table.wt.data(), m->residue_len, m->residue_mode, m->se0, m->stiffness_lambda, m->relax_tol,
-                                        rw.data(), x.data(), &m->relax_iters, &m->relax_relres);
+                std::vector<double> x;
+                if (!m->ragged && !any_def) {
+                    x.resize((size_t)2 * n * V);
+                    if ((rc = fb_pairs_relax(ctx, m->sys, n, nx, ny, m->gxs.data(), m->gys.data(), K, table.pid.data(), table.xy0.data(), table.xy1i.data(),
+                                             t1.data(), table.wt.data(), m->residue_len, m->residue_mode, m->se0, m->stiffness_lambda, m->relax_tol,
+                                             rw.data(), x.data(), &m->relax_iters, &m->relax_relres)))
+                        return rc;
+                    m->relax_matches = K;
                     last_links = true;
+                    screen_relax_first(m, x, flags);
                 } else {
-                    // one mesh geometry per pair: the matches by triangle and barycentric coordinates, the unknown the total
-                    // displacement of mesh1 from its FIXED gear (fb_pairs_relax_bary), sample errors per pair
-                    std::vector<int32_t> nodes3;
-                    std::vector<double> B1, dxy0((size_t)2 * K), se_rows((size_t)K);
-                    locate_grid(m, (size_t)K, table.pid.data(), table.xy1i.data(), nodes3, B1);
-                    for (int64_t k = 0; k < K; ++k) {
-                        const int p = table.pid[k];
-                        double fx[3], fy[3];
-                        for (int a = 0; a < 3; ++a) {
-                            const int loc = nodes3[3 * k + a] - p * V;
-                            fx[a] = m->gxs[(size_t)p * nx + loc % nx]; fy[a] = m->gys[(size_t)p * ny + loc / nx];
-                        }
-                        const double* b = &B1[3 * (size_t)k];
-                        dxy0[2 * k] = ((fx[0] * b[0] + fx[1] * b[1]) + fx[2] * b[2]) - table.xy0[2 * k];          // mesh1 at its FIXED gear (= INITIAL, no offset)
-                        dxy0[2 * k + 1] = ((fy[0] * b[0] + fy[1] * b[1]) + fy[2] * b[2]) - table.xy0[2 * k + 1];
-                        se_rows[k] = m->se[p];
-                    }
-                    rc = fb_pairs_relax_bary(ctx, m->sys, n, K, nodes3.data(), B1.data(), dxy0.data(), table.wt.data(), m->residue_len, m->residue_mode, m->se0,
-                                             se_rows.data(), m->stiffness_lambda, m->relax_tol, rw.data(), x.data(), &m->relax_iters, &m->relax_relres);
-                }
-                if (rc) return rc;
-                m->relax_matches = K;
-                // screen of relax_first (optimizer.py:763-779): the largest displacement difference along a grid edge
-                // relative to that edge; beyond 0.1 the pair takes the reference's statements on the general route
-                for (int p = 0; p < n; ++p) {
-                    const double* g = &x[(size_t)2 * p * V];
-                    const double* gx = &m->gxs[m->ragged ? (size_t)p * nx : 0];
-                    const double* gy = &m->gys[m->ragged ? (size_t)p * ny : 0];
-                    double d = 0.0;
-                    for (int j = 0; j < ny; ++j)
-                        for (int i = 0; i < nx; ++i) {
-                            const double* a = g + 2 * ((size_t)j * nx + i);
-                            if (i + 1 < nx) d = std::max(d, std::sqrt((a[2] - a[0]) * (a[2] - a[0]) + (a[3] - a[1]) * (a[3] - a[1])) / (gx[i + 1] - gx[i]));
-                            if (j + 1 < ny) {
-                                const double* b = a + 2 * (size_t)nx;
-                                d = std::max(d, std::sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1])) / (gy[j + 1] - gy[j]));
-                            }
-                        }
-                    if (d > 0.1 || !(d == d)) flags[p] |= FB_STRIP_RELAXFIRST;
+                    // one mesh geometry per pair, or matches located in deformed triangles: the matches by triangle and barycentric
+                    // coordinates, the unknown the total displacement of mesh1 from its FIXED gear (fb_pairs_relax_bary)
+                    std::vector<size_t> rows((size_t)K);
+                    std::iota(rows.begin(), rows.end(), (size_t)0);
+                    if ((rc = relax_general(ctx, m, table, rows, false, rw, x, flags))) return rc;
                 }
                 for (int64_t k = 0; k < K; ++k)
                     if (table.rl[k]) table.wt[k] = table.wt[k] * rw[k];                 // Link.weight (optimizer.py:313-317)
@@ -962,6 +1332,31 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         }
     }
     *nrows = (int64_t)m->r_pid.size();
+    return FB_OK;
+}
+
+int fb_match_strips_deformed(fb_ctx* ctx, fb_strip_matcher* m, uint8_t* deformed, int32_t* ntiers, int* nodes) {
+    FB_CHECK_ARG(ctx, m != nullptr);
+    const bool have = m->is_def.size() == (size_t)m->P;
+    for (int p = 0; p < m->P; ++p) {
+        if (deformed) deformed[p] = have ? m->is_def[p] : 0;
+        if (ntiers) ntiers[p] = have ? (int32_t)m->tiers[p].size() : 0;
+    }
+    if (nodes) *nodes = m->gnx * m->gny;
+    return FB_OK;
+}
+
+int fb_match_strips_field(fb_ctx* ctx, fb_strip_matcher* m, double* field, int32_t* tiers) {
+    FB_CHECK_ARG(ctx, m != nullptr);
+    const size_t V = (size_t)m->gnx * m->gny;
+    const bool have = m->is_def.size() == (size_t)m->P;
+    for (int p = 0; p < m->P; ++p) {
+        if (field) {
+            if (have && m->is_def[p] && m->U.size() == 2 * V * m->P) std::copy(m->U.begin() + 2 * V * p, m->U.begin() + 2 * V * (p + 1), field + 2 * V * p);
+            else std::fill(field + 2 * V * p, field + 2 * V * (p + 1), 0.0);
+        }
+        if (tiers && have) tiers = std::copy(m->tiers[p].begin(), m->tiers[p].end(), tiers);
+    }
     return FB_OK;
 }
 

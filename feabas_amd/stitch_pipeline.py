@@ -478,15 +478,16 @@ class StripBatchMatcher:
         nfl = self._nfl
         fh = np.where(pf, nfl[np.clip(2 * dy - 1, 0, nfl.size - 1)], nfl[np.clip(dy, 0, nfl.size - 1)])
         fw = np.where(pf, nfl[np.clip(2 * dx - 1, 0, nfl.size - 1)], nfl[np.clip(dx, 0, nfl.size - 1)])
-        key = (((nx * 4096 + ny) * 8192 + fh) * 8192 + fw) * 2 + pf
-        key = np.where(ok, key, -1)
+        # one group per block grid, FFT shape, pad flag and block size (the windows of a group are rendered to one size)
+        cols = np.stack((nx, ny, fh, fw, pf.astype(np.int64), dx, dy), axis=-1).astype(np.int64)
+        cols[~ok] = -1
         dogf = self.d_dogf_view
         img1 = dogf.offset(n * H * W * 4)
         groups = []
-        for kv in np.unique(key):
-            if kv < 0:
+        for kv in np.unique(cols, axis=0):
+            if kv[0] < 0:
                 continue
-            gi = np.flatnonzero(key == kv)
+            gi = np.flatnonzero(np.all(cols == kv, axis=1))
             sel = pairs[gi]
             gfh, gfw, gpad = int(fh[gi[0]]), int(fw[gi[0]]), bool(pf[gi[0]])
             blk, bb = self._blocks(tx, ty, None, sel, spacing[gi], mnb, bounds=(xmin[gi], ymin[gi], xmax[gi], ymax[gi]))
@@ -881,14 +882,15 @@ class StripBatchMatcher:
 
     def match(self, strips0, strips1, masks0=None, masks1=None, compute_photometric=False):
         """stitching_matcher for the P resident pairs; see `_match_host` for the arguments and the result.  Unmasked
-        batches of equal strips go through fb_match_strips (one C entry for the whole sequence); the pairs it hands back
-        (flags != 0: second shot of the global matcher, deformed mesh1, relax_first, degenerate rigid fit) and every
-        other kind of batch take the numpy statement of the same sequence."""
+        batches go through fb_match_strips (one C entry for the whole sequence, the deformed-mesh branch included); the
+        pairs it hands back (flags != 0: second shot of the global matcher, relax_first, folded block of a deformed mesh,
+        degenerate rigid fit) and every other kind of batch take the numpy statement of the same sequence."""
         if self._route == 'native' and masks0 is None and masks1 is None and not compute_photometric:
             if self._prefer_host:
-                res = self._match_host(strips0, strips1)
-                self._prefer_host = int(np.count_nonzero(res['deformed'])) > self.P // 2
-                return res
+                # the entry handed back most pairs of the last batch (no texture: second shot of the global matcher): this batch
+                # takes the host statement directly, the next one tries the entry again
+                self._prefer_host = False
+                return self._match_host(strips0, strips1)
             return self._match_native(strips0, strips1)
         return self._match_host(strips0, strips1, masks0, masks1, compute_photometric)
 
@@ -931,7 +933,16 @@ class StripBatchMatcher:
         self.last_field = None
         self.last_tiers = {}
         zeros = np.zeros(n, dtype=bool)
-        res = dict(tx=tx, ty=ty, conf0=cf0, valid=valid.astype(bool), needs_host=zeros, deformed=zeros.copy(), deferred=zeros.copy(),
+        # pairs whose mesh1 was relaxed into a non-rigid field between two spacings (matcher.py:725-742): node field and tiers
+        deformed = np.zeros(n, dtype=np.uint8); ntier = np.zeros(n, dtype=np.int32); V = C.c_int()
+        _lib.check(lib.fb_match_strips_deformed(ctx, h, _lib.ptr(deformed), _lib.ptr(ntier), C.byref(V)))
+        if deformed.any():
+            field = np.empty((n, V.value, 2)); tiers = np.empty(int(ntier.sum()), dtype=np.int32)
+            _lib.check(lib.fb_match_strips_field(ctx, h, _lib.ptr(field), _lib.ptr(tiers)))
+            self.last_field = field
+            at = np.concatenate(([0], np.cumsum(ntier)))
+            self.last_tiers = {p: tiers[at[p]:at[p + 1]].copy() for p in range(n) if ntier[p]}
+        res = dict(tx=tx, ty=ty, conf0=cf0, valid=valid.astype(bool), needs_host=zeros, deformed=deformed.astype(bool), deferred=zeros.copy(),
                    pair=pid.astype(np.int64), xy0=xy0, xy1=xy1, weight=wt, strain=strain, phtm=None)
         fl = np.flatnonzero(flags)
         if fl.size:
@@ -972,9 +983,14 @@ class StripBatchMatcher:
         for k, src in (('pair', fl[g['pair']]), ('xy0', g['xy0']), ('xy1', g['xy1']), ('weight', g['weight'])):
             res[k] = np.concatenate((res[k], src), axis=0)
         if sub.last_field is not None:
-            self.last_field = np.zeros((n,) + sub.last_field.shape[1:])
+            if self.last_field is None:
+                self.last_field = np.zeros((n,) + sub.last_field.shape[1:])
             self.last_field[fl] = sub.last_field
-        self.last_tiers = {int(fl[k]): v for k, v in sub.last_tiers.items()}
+        elif self.last_field is not None:
+            self.last_field[fl] = 0.0
+        for p in fl:
+            self.last_tiers.pop(int(p), None)
+        self.last_tiers.update({int(fl[k]): v for k, v in sub.last_tiers.items()})
         if sub.last_relax is not None and self.last_relax is not None:
             self.last_relax['relaxed_first'] += sub.last_relax.get('relaxed_first', 0)
 

@@ -341,9 +341,10 @@ typedef struct fb_strip_opts {
     const double* spacings;    /* pixels (>= 1) */
 } fb_strip_opts;
 #define FB_STRIP_LOWCONF 1
-#define FB_STRIP_NONRIGID 2
+#define FB_STRIP_NONRIGID 2     /* not reported any more: the deformed-mesh branch (matcher.py:725-742, 833-846) runs inside the entry */
 #define FB_STRIP_RELAXFIRST 4
 #define FB_STRIP_RIGIDFIT 8
+#define FB_STRIP_FOLDED 16      /* a block of a deformed mesh1 has a degenerate / flipped affine fit (renderer.py:397-416) */
 /* common.divide_bbox (feabas/common.py:380-409), host only: the bounding box bbox = {xmin, ymin, xmax, ymax} cut into
  * max(ceil(extent / block), min_blocks) blocks per axis (block_hw = {h, w}, min_blocks_yx = {ny, nx}) of ceil(extent / count)
  * pixels, starts = numpy.linspace(lo, hi - step, count), a shrink_factor != 1 scales the blocks about their centres, round_output
@@ -363,6 +364,13 @@ int fb_strip_matcher_info(fb_ctx* ctx, fb_strip_matcher* m, int* nspacings, doub
 int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, const uint8_t* strips1, double* tx, double* ty,
                     float* conf0, uint8_t* valid, uint8_t* flags, double* strain, int64_t* nrows);
 int fb_match_strips_table(fb_ctx* ctx, fb_strip_matcher* m, int32_t* pair, double* xy0, double* xy1, float* weight);
+/* The deformed-mesh branch of the last fb_match_strips call (matcher.py:725-742): deformed [P] = the relaxation of mesh1
+ * between two spacings was not a rigid translation; ntiers [P] = number of blocks of the pair's last deformed round; *nodes =
+ * V, the nodes of one mesh (all nullable).  fb_match_strips_field: field [P][V][2] = MOVING - INITIAL of every mesh1 node
+ * (zero for a translated grid), tiers = the MeshRenderer.crop_multiple tier of those blocks (1 global affine, 2 block affine,
+ * 3 exact field), pairs concatenated in order (both nullable). */
+int fb_match_strips_deformed(fb_ctx* ctx, fb_strip_matcher* m, uint8_t* deformed, int32_t* ntiers, int* nodes);
+int fb_match_strips_field(fb_ctx* ctx, fb_strip_matcher* m, double* field, int32_t* tiers);
 /* ---- host geometry of pairs whose mesh1 is deformed (no device work; ctx may be NULL).
  * fb_deformed_block_affines: the tier decision of MeshRenderer.crop_field with the affine approximator of
  *   MeshRenderer.from_mesh (renderer.py:90-109, 397-416, 453-511) for the nblk blocks of Q pairs.  vm [Q][nx ny][2] =

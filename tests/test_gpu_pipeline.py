@@ -743,9 +743,9 @@ def test_stitching_matcher_unequal_strip_shapes(fb):
                                              (1023, 255, 5, 0.5, 'huber')])
 def test_native_entry_equals_the_host_statement(fb, H, W, P, cds, mode):
     """fb_match_strips (the whole stitching_matcher sequence behind one C entry) against the numpy statement of the same
-    sequence in stitch_pipeline.py: identical tables for the pairs it finishes; the pairs it hands back -- here one
-    without a match (second shot of global_translation_matcher) and one whose mesh1 deforms between the spacings -- come
-    back through the host route with the results that route gives them inside a full batch."""
+    sequence in stitch_pipeline.py: identical tables for the pairs it finishes; the pair it hands back -- one without a
+    match (second shot of global_translation_matcher) -- comes back through the host route with the results that route
+    gives it inside a full batch."""
     from feabas_amd import _lib
     from feabas_amd.stitch_pipeline import StripBatchMatcher
     s0, s1, shifts = _synth(fb, P, H, W, seed=23, max_shift=14, warp=0.3)
@@ -761,7 +761,7 @@ def test_native_entry_equals_the_host_statement(fb, H, W, P, cds, mode):
     rn = mn.match(d0.ptr, d1.ptr); rh = mh.match(d0.ptr, d1.ptr)
     assert mn.last_flags[1] & 1 and mn.last_flags.astype(bool).sum() <= 3 and not mn.last_flags[0]
     if mn.spacings.size > 1:
-        assert mn.last_flags[2] & 2 and rn['deformed'][2]
+        assert not mn.last_flags[2] and rn['deformed'][2]
     for k in ('tx', 'ty', 'conf0', 'valid', 'deformed'):
         np.testing.assert_array_equal(rn[k], rh[k], err_msg=k)
     assert rn['valid'].sum() >= P - 2
@@ -770,7 +770,8 @@ def test_native_entry_equals_the_host_statement(fb, H, W, P, cds, mode):
         if not rh['valid'][p]:
             assert gn[p]['xy0'] is None
             continue
-        exact = not mn.last_flags[p]
+        # (the solve of a deformed pair shares its PCG scalars with the batch: the entry composes it without the pair it hands back)
+        exact = not mn.last_flags[p] and not rn['deformed'][p]
         for k in ('xy0', 'xy1', 'weight'):
             if exact:
                 np.testing.assert_array_equal(gn[p][k], gh[p][k], err_msg=f'{k} of pair {p}')
@@ -807,8 +808,8 @@ def test_native_entry_automatic_spacings_and_grid(fb):
 @pytest.mark.parametrize('cds', [0.5, 1])
 def test_native_entry_ragged_equals_the_host_statement(fb, cds):
     """fb_strip_matcher_create_ragged: strips of unequal size through the C entry against the numpy statement of the ragged
-    batch -- per-pair extents, block grids, spacings and mesh geometry; one pair deforms between the spacings and comes
-    back through the host route on its own extent inside this matcher's slots"""
+    batch -- per-pair extents, block grids, spacings and mesh geometry; one pair deforms between the spacings and takes the
+    deformed-mesh branch inside the entry (node field, tiers and matches bit-identical to the host statement's)"""
     from feabas_amd import _lib
     from feabas_amd.stitch_pipeline import RaggedStripBatchMatcher, StripBatchMatcher
     shapes = [(1536, 120), (1526, 122), (1520, 120), (1530, 121), (1536, 120), (1522, 121)]
@@ -825,7 +826,10 @@ def test_native_entry_ragged_equals_the_host_statement(fb, cds):
     mn = RaggedStripBatchMatcher(shapes, residue_len=2.0, coarse_downsample=cds, route='native')
     mh = RaggedStripBatchMatcher(shapes, residue_len=2.0, coarse_downsample=cds, route='host')
     rn = mn.match(dev.ptr, dev.offset(P * Hm * Wm)); rh = mh.match(dev.ptr, dev.offset(P * Hm * Wm))
-    assert mn.last_flags is not None and mn.last_flags[2] & 2 and not mn.last_flags[[0, 1, 3, 4, 5]].any()
+    assert mn.last_flags is not None and not mn.last_flags.any()          # the deformed-mesh branch runs inside the entry
+    assert np.ptp(mn.last_field[2], axis=0).max() > 0.5 and not mn.last_field[[0, 1, 3, 4, 5]].any() and list(mn.last_tiers) == [2]
+    np.testing.assert_array_equal(mn.last_field, mh.last_field)
+    np.testing.assert_array_equal(mn.last_tiers[2], mh.last_tiers[2])
     for k in ('tx', 'ty', 'conf0', 'valid', 'deformed'):
         np.testing.assert_array_equal(rn[k], rh[k], err_msg=k)
     assert rn['valid'].all() and rn['deformed'].tolist() == [False, False, True, False, False, False]

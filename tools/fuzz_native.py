@@ -11,22 +11,24 @@ from feabas_amd import _lib
 from feabas_amd.stitch_pipeline import StripBatchMatcher, RaggedStripBatchMatcher
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-bad = 0; nflag = 0; npair = 0
+bad = 0; nflag = 0; npair = 0; ndef = 0
 t0 = time.time()
 
 
 def compare(mn, mh, rn, rh, P, tag):
-    global bad, nflag, npair
+    global bad, nflag, npair, ndef
     ok = all(np.array_equal(rn[k], rh[k]) for k in ('tx', 'ty', 'conf0', 'valid', 'deformed'))
     gn = StripBatchMatcher.per_pair(rn); gh = StripBatchMatcher.per_pair(rh)
     for p in range(P):
-        npair += 1; nflag += bool(mn.last_flags is not None and mn.last_flags[p])
+        npair += 1; nflag += bool(mn.last_flags is not None and mn.last_flags[p]); ndef += bool(rn['deformed'][p] and not mn.last_flags[p])
         if not rh['valid'][p]:
             ok &= gn[p]['xy0'] is None
             continue
         if gn[p]['xy0'] is None or gn[p]['xy0'].shape != gh[p]['xy0'].shape:
             ok = False; continue
-        exact = mn.last_flags is not None and not mn.last_flags[p]
+        # a pair the entry finishes is bit-identical unless its mesh1 was deformed in a batch whose solve the two routes composed
+        # differently (the entry hands pairs back to a sub-batch; the PCG scalars of the block-diagonal system are shared)
+        exact = mn.last_flags is not None and not mn.last_flags[p] and not (rh['deformed'][p] and mn.last_flags.any())
         for k in ('xy0', 'xy1', 'weight'):
             ok &= np.array_equal(gn[p][k], gh[p][k]) if exact else bool(np.abs(gn[p][k] - gh[p][k]).max() < 1e-6)
         ok &= abs(gn[p]['strain'] - gh[p]['strain']) <= 1e-6 * max(abs(gh[p]['strain']), 1e-4)
@@ -77,4 +79,4 @@ for c in range(max(2, ncase // 3)):
     rn = mn.match(dev.ptr, dev.offset(P * Hm * Wm)); rh = mh.match(dev.ptr, dev.offset(P * Hm * Wm))
     compare(mn, mh, rn, rh, P, ('ragged', shapes, kw))
     mn.free(); mh.free(); dev.free()
-print(f'{ncase} uniform + {max(2, ncase // 3)} ragged batches, {npair} pairs ({nflag} handed back by the entry), mismatching batches {bad}, {time.time() - t0:.0f} s')
+print(f'{ncase} uniform + {max(2, ncase // 3)} ragged batches, {npair} pairs ({nflag} handed back by the entry, {ndef} finished there with a deformed mesh), mismatching batches {bad}, {time.time() - t0:.0f} s')

@@ -22,3 +22,6 @@ echo "pmc write done"
 find $OUT -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
 python3 tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1 || exit 6
 echo "pmc traffic done"
+# issue-rate probe of the VALU forms the DoG / FFT kernels lean on (tools/valu_rate.hip; DESIGN sec.9 quotes its table)
+mkdir -p $ROOT/ab && hipcc -O3 --offload-arch=gfx950 tools/valu_rate.hip -o $ROOT/ab/valu_rate 2> $OUT/valu_rate.err && timeout -k 10 120 $ROOT/ab/valu_rate > $OUT/valu_rate.txt 2>> $OUT/valu_rate.err || exit 7
+echo "valu probe done"
