@@ -30,6 +30,10 @@ struct fb_fft_plan {
 };
 
 struct fb_ctx {
+    // set by fb_match_strips (under the context lock) around its fb_pairs_*_bary calls: the matches it hands over couple the
+    // three vertices of ONE grid triangle (locate_grid / fb_deformed_locate), so fb_sys_update_links' membership test of every
+    // coupled pair in the pattern -- 36 binary searches per match, 1.5 ms per 12 k matches -- is skipped as in fb_pairs_relax
+    int trusted_links = 0;
     // every compute entry point holds this while it enqueues: calls from several host threads interleave at
     // call granularity only (the scratch arena and the profile are shared)
     std::recursive_mutex mtx;

@@ -1162,7 +1162,7 @@ int fb_pairs_relax_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int32
             b6[3 + a] = -B1[3 * k + a];
         }
     }
-    int rc = fb_sys_update_links(ctx, s, K, s->h_nodes6.data());
+    int rc = sys_update_links(ctx, s, K, s->h_nodes6.data(), ctx->trusted_links);
     if (rc) return rc;
     return pairs_relax_core(ctx, s, P, K, conf, residue_len, sample_err, stiffness_lambda, rtol, rw, x_out, iters, relres, sample_err_each, residue_mode);
 }
@@ -1255,7 +1255,7 @@ int fb_pairs_strain_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int3
         s->h_dxy[2 * k] = fx * r[0] + fy * r[1];
         s->h_dxy[2 * k + 1] = fx * r[3] + fy * r[4];
     }
-    int rc = fb_sys_update_links(ctx, s, K, s->h_nodes6.data());
+    int rc = sys_update_links(ctx, s, K, s->h_nodes6.data(), ctx->trusted_links);
     if (rc) return rc;
     for (int p = 0; p < P; ++p) FB_CHECK_ARG(ctx, !has[p] || es0[p] > 0.0);
     return pairs_strain_core(ctx, s, P, has, weight, stiffness_lambda, es0, 1, default_strain, strain, iters, relres);

@@ -74,8 +74,9 @@ struct fb_strip_matcher {
     void* scr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t b_scr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // FEABAS_HIP_MATCH_TRACE=1: wall time of the stages of fb_match_strips, printed by fb_strip_matcher_destroy
-    bool trace = false;
+    bool trace = false, trace_all = false;             // trace_all (=2): every call counts (matchers that live for one call)
     double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // enqueue global, wait global, blocks host, blocks h2d+launch, blocks wait, relax, table+fits, strain
+    double t_relax[3] = {0, 0, 0};     // inside the relax stage: locating the rows, fb_pairs_relax_bary, the screen
     int calls = 0;
 };
 
@@ -236,8 +237,8 @@ int ensure_system(fb_ctx* ctx, fb_strip_matcher* m) {
             }
     }
     m->es0.resize((size_t)P);
-    if ((rc = fb_sys_assemble_mesh(ctx, s, 0, v.data(), nullptr, mult.data(), 0.0, 1.0)) ||
-        (rc = fb_sys_group_energy(ctx, s, P, v0.data(), m->es0.data()))) {
+    rc = fb_sys_assemble_mesh(ctx, s, 0, v.data(), nullptr, mult.data(), 0.0, 1.0);
+    if (rc || (rc = fb_sys_group_energy(ctx, s, P, v0.data(), m->es0.data()))) {
         fb_sys_destroy(ctx, s);
         return rc;
     }
@@ -493,6 +494,12 @@ int relax_general(fb_ctx* ctx, fb_strip_matcher* m, const Rows& t, const std::ve
     if ((rc = ensure_system(ctx, m))) return rc;
     const int n = m->P, nx = m->gnx, ny = m->gny, V = nx * ny;
     const int64_t K = (int64_t)rows.size();
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](int k) {
+        const auto now = std::chrono::steady_clock::now();
+        if (m->trace && (m->calls > 3 || m->trace_all)) m->t_relax[k] += std::chrono::duration<double, std::milli>(now - tick).count();
+        tick = now;
+    };
     std::vector<int32_t> pid((size_t)K), nodes3((size_t)3 * K);
     std::vector<double> B1((size_t)3 * K), dxy0((size_t)2 * K), se_rows, pts;
     std::vector<float> w32((size_t)K);
@@ -522,13 +529,16 @@ int relax_general(fb_ctx* ctx, fb_strip_matcher* m, const Rows& t, const std::ve
     }
     rw.resize((size_t)K);
     x.resize((size_t)2 * n * V);
+    lap(0);
     const double rlen = m->residue_len > 0 ? m->residue_len : 1.0;
     if ((rc = fb_pairs_relax_bary(ctx, m->sys, n, K, nodes3.data(), B1.data(), dxy0.data(), w32.data(), rlen, m->residue_mode, m->se0,
                                   m->ragged ? se_rows.data() : nullptr, m->stiffness_lambda, m->relax_tol, rw.data(), x.data(), &m->relax_iters, &m->relax_relres)))
         return rc;
     m->relax_matches = K;
+    lap(1);
     if (m->residue_len <= 0) { std::fill(rw.begin(), rw.end(), 1.0f); return FB_OK; }
     screen_relax_first(m, x, flags);
+    lap(2);
     bool changed_any = false;
     for (int64_t k = 0; k < K; ++k) changed_any |= rw[k] != 1.0f;
     if (resolve && changed_any) {
@@ -571,7 +581,7 @@ int matcher_create(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, cons
     m->owner = ctx;
     m->P = P; m->H = H; m->W = W;
     m->ragged = shapes != nullptr;
-    { const char* e = std::getenv("FEABAS_HIP_MATCH_TRACE"); m->trace = e && e[0] == '1'; }
+    { const char* e = std::getenv("FEABAS_HIP_MATCH_TRACE"); m->trace = e && (e[0] == '1' || e[0] == '2'); m->trace_all = e && e[0] == '2'; }
     m->sigma = o->sigma; m->cds2 = o->coarse_downsample2; m->conf_thresh = o->conf_thresh; m->mnb = o->min_num_blocks;
     m->conf_mode = o->conf_mode; m->residue_len = o->residue_len; m->residue_mode = o->residue_mode;
     m->stiffness_lambda = o->stiffness_lambda; m->relax_tol = o->relax_tol; m->compute_strain = o->compute_strain;
@@ -682,11 +692,13 @@ void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m) {
         ctx = m->owner;
     }
     FB_LOCK(ctx);
-    if (m->trace && m->calls > 3) {
-        const int c = m->calls - 3;
-        std::fprintf(stderr, "fb_match_strips P=%d %dx%d: %d calls, ms per call after the first 3: enqueue %.3f wait-global %.3f blocks-host %.3f blocks-launch %.3f blocks-wait %.3f relax %.3f table %.3f strain %.3f\n",
+    if (m->trace && (m->calls > 3 || m->trace_all)) {
+        const int c = m->trace_all ? m->calls : m->calls - 3;
+        std::fprintf(stderr, "fb_match_strips P=%d %dx%d: %d calls, ms per call (FEABAS_HIP_MATCH_TRACE=1: after the first 3): enqueue %.3f wait-global %.3f blocks-host %.3f blocks-launch %.3f blocks-wait %.3f relax %.3f table %.3f strain %.3f\n",
                      m->P, m->H, m->W, m->calls, m->t_stage[0] / c, m->t_stage[1] / c, m->t_stage[2] / c, m->t_stage[3] / c, m->t_stage[4] / c, m->t_stage[5] / c,
                      m->t_stage[6] / c, m->t_stage[7] / c);
+        if (m->t_relax[1] > 0)
+            std::fprintf(stderr, "    relax stage, general route: locate rows %.3f fb_pairs_relax_bary %.3f screen %.3f\n", m->t_relax[0] / c, m->t_relax[1] / c, m->t_relax[2] / c);
     }
     hipStreamSynchronize(ctx->stream);                      // nothing of this matcher is in flight when its buffers change hands
     if (m->sys) {
@@ -719,13 +731,18 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                     uint8_t* valid, uint8_t* flags, double* strain, int64_t* nrows) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, m && strips0 && strips1 && tx && ty && conf0 && valid && flags && strain && nrows);
+    struct Trusted {                                        // fb_common.h: trusted_links
+        fb_ctx* c;
+        explicit Trusted(fb_ctx* cc) : c(cc) { c->trusted_links = 1; }
+        ~Trusted() { c->trusted_links = 0; }
+    } trusted_guard(ctx);
     const int n = m->P, H = m->H, W = m->W, hc = m->hc, wc = m->wc;
     const size_t cpix = (size_t)hc * wc, fpix = (size_t)H * W;
     const float thr = (float)m->conf_thresh;               // numpy compares float32 confidences with the threshold in float32
     const int nsp = m->nsp;
     int rc;
     StageClock clk(m);
-    if (m->trace && m->calls == 3) { for (double& t : m->t_stage) t = 0.0; }      // the first calls load code objects and grow arenas
+    if (m->trace && !m->trace_all && m->calls == 3) { for (double& t : m->t_stage) t = 0.0; }      // the first calls load code objects and grow arenas
     m->calls++;
     const float* dogf = m->d_dogc;                         // matcher.py:315-317: same image when fine == coarse
     std::vector<int32_t> blk;

@@ -27,3 +27,4 @@ for warp in (0.4, 2.0):
             m.match(s0.ptr, s1.ptr)
         pr.disable()
         pstats.Stats(pr).sort_stats('tottime').print_stats(18)
+m.free()                                                   # FEABAS_HIP_MATCH_TRACE=1: the stage clock of fb_match_strips prints here

@@ -25,3 +25,13 @@ mu = StripBatchMatcher(P, H, W, residue_len=2.0, pool=pool); mu.match(s0.ptr, s1
 t = time.time(); mu.match(s0.ptr, s1.ptr); print('uniform chunk', 1e3 * (time.time() - t), 'ms')
 pr = cProfile.Profile(); pr.enable(); run(); run(); pr.disable()
 pstats.Stats(pr).sort_stats('tottime').print_stats(22)
+# one matcher, several calls: the stage clock of fb_match_strips (FEABAS_HIP_MATCH_TRACE=1) and the kernels of one call
+for cls, arg in ((RaggedStripBatchMatcher, (shapes,)), (StripBatchMatcher, (P, H, W))):
+    m = cls(*arg, residue_len=2.0, pool=pool)
+    for _ in range(8):
+        m.match(s0.ptr, s1.ptr)
+    lib.fb_prof_enable(ctx, 1); lib.fb_prof_reset(ctx)
+    m.match(s0.ptr, s1.ptr)
+    snap = _lib.prof_snapshot(); lib.fb_prof_enable(ctx, 0)
+    print(cls.__name__, 'kernels', round(sum(v[1] for v in snap.values()), 2), 'ms', {k: (v[0], round(v[1], 2)) for k, v in sorted(snap.items(), key=lambda kv: -kv[1][1])})
+    m.free()
