@@ -692,7 +692,7 @@ class SLM:
     # ------------------------------------------------------------------ optimize
     def optimize_linear(self, **kwargs):
         """feabas/optimizer.py:1257-1437 including `groupings` (members of a group share their degrees of freedom),
-        without the DoF-elimination options.  Returns (||b||, ||A d - b||) and writes the field into the meshes."""
+        and `remove_extra_dof` (`remove_material_dof` needs material tables).  Returns (||b||, ||A d - b||) and writes the field into the meshes."""
         maxiter = kwargs.get('maxiter', None)
         tol = kwargs.get('tol', 1e-7)
         atol = kwargs.get('atol', 0.0)
@@ -713,11 +713,10 @@ class SLM:
             return self._optimize_linear_distributed(kwargs['distributed'], kwargs.get('owned', None), tol, atol, maxiter, shape_gear,
                                                      start_gear, target_gear, stiffness_lambda, crosslink_lambda)
         if kwargs.get('remove_material_dof', None) is not None:
-            raise NotImplementedError('optimize_linear(remove_material_dof=...) is outside the hot path')
-        if kwargs.get('remove_extra_dof', False):
-            raise NotImplementedError('optimize_linear(remove_extra_dof=True) is outside the round-1 hot path')
+            raise NotImplementedError('optimize_linear(remove_material_dof=...) names material tables (optimizer.py:1320-1359), which this mirror\'s Mesh does not carry')
         if np.all(self.lock_flags):
             return 0, 0
+        held = self._extra_dof_mask(groupings) if kwargs.get('remove_extra_dof', False) else None
         lib = _lib.load()
         ctx = _lib.ctx()
         if groupings is not None and all(o < 0 for o in self._layout(groupings)[0].values()):
@@ -739,11 +738,21 @@ class SLM:
         iters, relres = C.c_int(), C.c_double()
         mi = -1 if maxiter is None else int(maxiter)
         pre = 0 if precondition is None else (2 if multigrid and groupings is None else 1)
-        _lib.check(lib.fb_sys_solve(ctx, self._sys, _lib.ptr(dd), 0, float(tol), float(atol or 0.0), mi, pre,
-                                    C.byref(iters), C.byref(relres)), allow=(_lib.FB_ERR_NOCONV,))
         bn = float(np.linalg.norm(b)) / self._gmean           # grouped terms are divided by mean(count) (optimizer.py:1408-1411)
-        cost = (bn, float(relres.value * bn))
-        self.last_solve = dict(iters=iters.value, relres=relres.value, stiffness_lambda=sl, crosslink_lambda=cl)
+        if held is not None and not held.all():
+            # remove_extra_dof (optimizer.py:1360-1377, 1976-1991): three degrees of freedom of the first mesh of every
+            # connected subsystem without a locked member are taken out of the solve -- the assembled A goes through the
+            # masked device PCG of `solve` (the rarely taken option does not warrant a masked variant of fb_sys_solve)
+            A = bsr_download(self._sys, 4, self._nv, self._nnzb)
+            dd = solve(A, b, tol=tol, atol=atol, maxiter=maxiter, M='jacobi', extra_dof_constraint=held)
+            res = float(np.linalg.norm(A @ dd - b)) / self._gmean
+            cost = (bn, res)
+            self.last_solve = dict(iters=None, relres=res / bn if bn else 0.0, stiffness_lambda=sl, crosslink_lambda=cl, held_dofs=int((~held).sum()))
+        else:
+            _lib.check(lib.fb_sys_solve(ctx, self._sys, _lib.ptr(dd), 0, float(tol), float(atol or 0.0), mi, pre,
+                                        C.byref(iters), C.byref(relres)), allow=(_lib.FB_ERR_NOCONV,))
+            cost = (bn, float(relres.value * bn))
+            self.last_solve = dict(iters=iters.value, relres=relres.value, stiffness_lambda=sl, crosslink_lambda=cl)
         if cost[1] < cost[0]:                               # optimizer.py:1421
             offs = self._offs
             for m in self.meshes:
@@ -752,6 +761,31 @@ class SLM:
                     continue
                 m.set_field(dd[o:o + 2 * m.num_vertices].reshape(-1, 2), gear=(start_gear, target_gear))
         return cost
+
+    def _extra_dof_mask(self, groupings):
+        """optimizer.py:1360-1377: a connected subsystem without a locked mesh floats (rigid motion costs nothing); the first
+        three degrees of freedom -- vertex 0 and the x of vertex 1 -- of its first mesh are held.  Returns the boolean
+        selector over the degrees of freedom of the free meshes (True = solved), or None when nothing floats."""
+        if groupings is not None:
+            raise NotImplementedError('optimize_linear(remove_extra_dof=True) with groupings')
+        labels, _ = self.connected_subsystems
+        locks = np.asarray(self.lock_flags, dtype=bool)
+        first = np.zeros(len(self.meshes), dtype=bool)
+        for lbl in np.unique(labels):
+            idx = np.flatnonzero(labels == lbl)
+            if not locks[idx].any():
+                first[idx[0]] = True
+        if not first.any():
+            return None
+        parts = []
+        for flg, m in zip(first, self.meshes):
+            if m.locked:
+                continue
+            sel = np.ones(2 * m.num_vertices, dtype=bool)
+            if flg:
+                sel[:3] = False
+            parts.append(sel)
+        return np.concatenate(parts)
 
     def _optimize_linear_distributed(self, group, owned, tol, atol, maxiter, shape_gear, start_gear, target_gear, stiffness_lambda, crosslink_lambda):
         """optimize_linear of a coupled window (aligner.py:510-535, 696-727: all free sections of a window are ONE system)

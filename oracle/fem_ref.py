@@ -676,14 +676,52 @@ def optimize_linear_grouped(meshes, links, groupings, stiffness_lambda=1.0, cros
     return cost
 
 
+def extra_dof_selector(meshes, links):
+    """optimizer.py:1360-1377 (remove_extra_dof): in every link-connected subsystem without a locked mesh the first three
+    degrees of freedom of its first mesh are held.  Returns the boolean selector over the degrees of freedom of the free
+    meshes (True = solved) or None."""
+    from scipy.sparse import csgraph
+    idx = {id(m): k for k, m in enumerate(meshes)}
+    n = len(meshes)
+    adj = sparse.lil_matrix((n, n))
+    for lk in links:
+        a, b = idx[id(lk.meshes[0])], idx[id(lk.meshes[1])]
+        adj[a, b] = 1; adj[b, a] = 1
+    _, lbl = csgraph.connected_components(adj.tocsr(), directed=False, return_labels=True)
+    lock = np.array([m.locked for m in meshes])
+    rm = np.zeros(n, dtype=bool)
+    for v in np.unique(lbl):
+        k = np.nonzero(lbl == v)[0]
+        if not np.any(lock[k]):
+            rm[k[0]] = True
+    if not np.any(rm):
+        return None
+    edc = []
+    for flg, m in zip(rm, meshes):
+        if m.locked:
+            continue
+        sel = np.ones(m.num_vertices * 2, dtype=bool)
+        if flg:
+            sel[:3] = False
+        edc.append(sel)
+    return np.concatenate(edc, axis=None)
+
+
 def optimize_linear(meshes, links, tol=1e-7, stiffness_lambda=1.0, crosslink_lambda=-1.0,
-                    shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING, exact=True):
-    """optimizer.py:1257-1437 (no groupings / edc).  exact=True solves the
-    system to its fixed point (the parity anchor); otherwise PCG to tol."""
+                    shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING, exact=True, remove_extra_dof=False):
+    """optimizer.py:1257-1437 (no groupings).  exact=True solves the system to its fixed point (the parity anchor);
+    otherwise PCG to tol.  remove_extra_dof: the held degrees of freedom leave the system (optimizer.py:1976-1991: rows and
+    columns are cut out, the solution is zero there)."""
     A, b, _ = linear_system(meshes, links, stiffness_lambda, crosslink_lambda,
                             shape_gear, start_gear, target_gear)
     A = 0.5 * (A + A.T)
-    if exact:
+    edc = extra_dof_selector(meshes, links) if remove_extra_dof else None
+    if edc is not None and not edc.all():
+        Ar = sparse.csr_matrix(A)[edc][:, edc]
+        dr = solve_direct(Ar, b[edc]) if exact else pcg(Ar, b[edc], rtol=tol)[0]
+        dd = np.zeros_like(b)
+        dd[edc] = dr
+    elif exact:
         dd = solve_direct(A, b)
     else:
         dd, _, _ = pcg(A, b, rtol=tol)

@@ -141,6 +141,31 @@ def test_optimize_linear_two_free_meshes(fb):
     assert np.abs(d_p - d_r).max() <= 1e-4 * np.abs(d_r).max()
 
 
+def test_optimize_linear_remove_extra_dof_vs_oracle(fb):
+    """optimize_linear(remove_extra_dof=True) (optimizer.py:1360-1377, 1976-1991): no mesh locked, so the first three
+    degrees of freedom of the first mesh are held and the rest is a definite system -- the node positions themselves are
+    compared with the oracle's exact solve of the reduced system"""
+    rng = np.random.default_rng(28)
+    prod, lp, ref, lr = _random_system(fb, rng, 20, 15, 300, two_free=True)
+    before = [m.vertices_w_offset(1).copy() for m in prod]
+    slm = fb.optimizer.SLM(prod, lp)
+    cost = slm.optimize_linear(tol=1e-11, remove_extra_dof=True)
+    ref_cost = fem_ref.optimize_linear(ref, lr, exact=True, remove_extra_dof=True)
+    assert slm.last_solve['held_dofs'] == 3 and abs(cost[0] - ref_cost[0]) <= 1e-9 * ref_cost[0]
+    moved = max(np.abs(r.vertices_w_offset(1) - v0).max() for r, v0 in zip(ref, before))
+    assert moved > 1.0
+    for m, r in zip(prod, ref):
+        np.testing.assert_allclose(m.vertices_w_offset(1), r.vertices_w_offset(1), atol=1e-4 * moved)
+    # the held degrees of freedom did not move: vertex 0 and the x of vertex 1 of the first mesh
+    np.testing.assert_array_equal(prod[0].vertices_w_offset(1)[0], before[0][0])
+    assert prod[0].vertices_w_offset(1)[1, 0] == before[0][1, 0]
+    # a system with a locked mesh holds nothing
+    prod2, lp2, _, _ = _random_system(fb, rng, 12, 10, 100)
+    slm2 = fb.optimizer.SLM(prod2, lp2)
+    slm2.optimize_linear(tol=1e-9, remove_extra_dof=True)
+    assert 'held_dofs' not in slm2.last_solve
+
+
 def test_spmv_and_pcg_properties(fb):
     """linearity of the SpMV and residual of the solve on a 250k-DoF system (size-independent checks)"""
     import ctypes as C
