@@ -161,6 +161,8 @@ _PROTOS = {
     'fb_match_strips': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'fb_match_strips_table': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p]),
     'fb_match_strips_deformed': (c_i, [c_p, c_p, c_p, c_p, c_p]),
+    'fb_strip_matcher_set_extras': (c_i, [c_p, c_p, c_p, c_p, c_i]),
+    'fb_match_strips_photometric': (c_i, [c_p, c_p, c_p, c_p]),
     'fb_match_strips_field': (c_i, [c_p, c_p, c_p, c_p]),
     'fb_link_terms': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_d, c_d, c_p, c_p, c_p]),
     'fb_pairs_strain': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_d, c_d, c_i, c_d, c_p, c_p, c_p]),

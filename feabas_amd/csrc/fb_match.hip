@@ -30,6 +30,52 @@
 
 #pragma clang fp contract(off)
 
+// matcher.py:279-314 (sigma > 0): sums over the overlap of the two translated coarse strips -- grey levels of the raw images,
+// |DoG| of the filtered ones -- where both masks are valid, and the number of valid pixels of strip 0 there.  One workgroup
+// per (pair, band of rows); part [n][bands][6] = {sum raw0, sum raw1, sum |dog0|, sum |dog1|, count(m0 & m1), count(m0)}
+__global__ __launch_bounds__(256) void photometric_kernel(int n, int hc, int wc, const uint8_t* __restrict__ raw, const float* __restrict__ dog,
+                                                          const uint8_t* __restrict__ masks, const uint8_t* __restrict__ has_mask,
+                                                          const int* __restrict__ txy, int bands, double* __restrict__ part) {
+    const int p = blockIdx.x, band = blockIdx.y, tid = threadIdx.x;
+    const int tx = txy[2 * p], ty = txy[2 * p + 1];
+    const int xa = max(tx, 0), ya = max(ty, 0), xb = min(wc + tx, wc), yb = min(hc + ty, hc);
+    const size_t pix = (size_t)hc * wc;
+    const uint8_t* r0 = raw + (size_t)p * pix;
+    const uint8_t* r1 = raw + (size_t)(n + p) * pix;
+    const float* g0 = dog + (size_t)p * pix;
+    const float* g1 = dog + (size_t)(n + p) * pix;
+    const uint8_t* m0 = has_mask[p] ? masks + (size_t)p * pix : nullptr;
+    const uint8_t* m1 = has_mask[n + p] ? masks + (size_t)(n + p) * pix : nullptr;
+    const int rows = max(yb - ya, 0), cols = max(xb - xa, 0);
+    const int per = (rows + bands - 1) / bands, ra = band * per, rb = min(rows, ra + per);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int r = ra; r < rb; ++r) {
+        const int y1 = ya + r, y0 = y1 - ty;
+        for (int c = tid; c < cols; c += 256) {
+            const int x1 = xa + c, x0 = x1 - tx;
+            const size_t i0 = (size_t)y0 * wc + x0, i1 = (size_t)y1 * wc + x1;
+            const bool v0 = !m0 || m0[i0], v1 = !m1 || m1[i1];
+            if (v0) acc[5] += 1.0;
+            if (v0 && v1) {
+                acc[0] += (double)r0[i0]; acc[1] += (double)r1[i1];
+                acc[2] += (double)fabsf(g0[i0]); acc[3] += (double)fabsf(g1[i1]);
+                acc[4] += 1.0;
+            }
+        }
+    }
+    __shared__ double red[256];
+    for (int k = 0; k < 6; ++k) {
+        red[tid] = acc[k];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) part[((size_t)p * bands + band) * 6 + k] = red[0];
+        __syncthreads();
+    }
+}
+
 struct fb_strip_matcher {
     fb_ctx* owner = nullptr;           // the context that made the matcher: its buffers and its system go back THERE
     int P = 0, H = 0, W = 0, hc = 0, wc = 0;
@@ -71,8 +117,14 @@ struct fb_strip_matcher {
     std::vector<double> U;
     std::vector<uint8_t> is_def;
     std::vector<std::vector<int32_t>> tiers;
-    void* scr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t b_scr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* scr[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t b_scr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // extras of the NEXT fb_match_strips call (fb_strip_matcher_set_extras): valid-pixel masks of the strips (host pointers,
+    // NULL = none; matcher.py:257-274, 336-337) and the photometric statistics of matcher.py:279-314
+    std::vector<const uint8_t*> mask0, mask1;
+    bool want_phtm = false;
+    std::vector<double> phtm;          // [P][4] of the last call that asked for them
+    std::vector<uint8_t> phtm_has;     // [P]: 0 = fewer than 4 valid pixels of strip 0 in the overlap (None in the reference)
     // FEABAS_HIP_MATCH_TRACE=1: wall time of the stages of fb_match_strips, printed by fb_strip_matcher_destroy
     bool trace = false, trace_all = false;             // trace_all (=2): every call counts (matchers that live for one call)
     double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // enqueue global, wait global, blocks host, blocks h2d+launch, blocks wait, relax, table+fits, strain
@@ -708,7 +760,7 @@ void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m) {
     }
     pool_give(ctx, m->d_dogc, m->b_dogc); pool_give(ctx, m->d_dogf, m->b_dogf); pool_give(ctx, m->d_small, m->b_small);
     pool_give(ctx, m->d_blk, m->b_blk); pool_give(ctx, m->d_out, m->b_out); pool_give(ctx, m->d_sizes, m->b_sizes);
-    for (int k = 0; k < 8; ++k) pool_give(ctx, m->scr[k], m->b_scr[k]);
+    for (int k = 0; k < 12; ++k) pool_give(ctx, m->scr[k], m->b_scr[k]);
     delete m;
 }
 
@@ -748,12 +800,30 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
     std::vector<int32_t> blk;
     // ---- global translation on the coarse DoG images (matcher.py:255-278); the fine DoG is independent of the answer and
     //      is enqueued before the host waits for the global peaks
+    // extras of this call (fb_strip_matcher_set_extras); they do not carry over to the next one
+    std::vector<const uint8_t*> mask0, mask1;
+    mask0.swap(m->mask0); mask1.swap(m->mask1);
+    const bool want_phtm = m->want_phtm;
+    m->want_phtm = false;
+    bool any_mask = false;
+    for (const uint8_t* q : mask0) any_mask |= q != nullptr;
+    for (const uint8_t* q : mask1) any_mask |= q != nullptr;
+    if ((any_mask || want_phtm) && m->ragged) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: masks / photometric statistics are not taken on strips of unequal size");
     if (!m->ragged) {
+        const bool extras = any_mask || want_phtm;
+        uint8_t* d_maskc = nullptr;                          // coarse masks [2n][hc][wc] of the masked images
+        std::vector<uint8_t> has_mask((size_t)2 * n, 0);
+        if (any_mask) {
+            void* ptr = nullptr;
+            if ((rc = scratch(ctx, m, 8, 2 * (size_t)n * cpix, &ptr))) return rc;
+            d_maskc = (uint8_t*)ptr;
+        }
         if (m->cds2) {
             const int taps = (int)(4.0 * m->sigma * 0.5 + 0.5);
-            if (taps == 5 || taps == 6 || taps == 8 || taps == 10) {
+            if (!extras && (taps == 5 || taps == 6 || taps == 8 || taps == 10)) {
                 if ((rc = fb_dog_down2_pair_dev(ctx, strips0, strips1, n, H, W, m->sigma * 0.5, 1, m->d_dogc))) return rc;
             } else {
+                // (the coarse uint8 images are kept: the masked DoG and the photometric statistics read them again)
                 if ((rc = fb_area_downsample2_dev(ctx, strips0, n, H, W, m->d_small))) return rc;
                 if ((rc = fb_area_downsample2_dev(ctx, strips1, n, H, W, m->d_small + n * cpix))) return rc;
                 if ((rc = fb_dog_dev(ctx, m->d_small, 0, 2 * n, hc, wc, m->sigma * 0.5, nullptr, 1, m->d_dogc))) return rc;
@@ -761,17 +831,88 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         } else {
             if ((rc = fb_dog_pair_dev(ctx, strips0, strips1, 0, n, hc, wc, m->sigma, 1, m->d_dogc))) return rc;
         }
+        if (any_mask) {
+            // masked images: their coarse DoG again with the halo suppression of common.py:368-374; the coarse mask is
+            // cv2.resize(mask, fx=0.5, INTER_NEAREST) = every second pixel (matcher.py:257-264)
+            std::vector<uint8_t> mc(cpix);
+            for (int side = 0; side < 2; ++side)
+                for (int p = 0; p < n; ++p) {
+                    const uint8_t* mk = (side ? mask1 : mask0).empty() ? nullptr : (side ? mask1 : mask0)[p];
+                    if (!mk) continue;
+                    const size_t img = (size_t)side * n + p;
+                    const int st = m->cds2 ? 2 : 1;
+                    for (int y = 0; y < hc; ++y)
+                        for (int x = 0; x < wc; ++x) mc[(size_t)y * wc + x] = mk[(size_t)(st * y) * W + st * x] != 0;
+                    has_mask[img] = 1;
+                    if ((rc = fb_memcpy_h2d(ctx, d_maskc + img * cpix, mc.data(), cpix))) return rc;
+                    const void* src = m->cds2 ? (const void*)(m->d_small + img * cpix) : (const void*)((side ? strips1 : strips0) + (size_t)p * fpix);
+                    if ((rc = fb_dog_dev(ctx, src, 0, 1, hc, wc, m->cds2 ? m->sigma * 0.5 : m->sigma, d_maskc + img * cpix, 1, m->d_dogc + img * cpix))) return rc;
+                }
+        }
         if ((rc = fb_ncc_batch_dev(ctx, m->d_dogc, m->d_dogc + n * cpix, n, 1, hc, wc, hc, wc, 1, 0, m->conf_mode, (double*)m->d_out,
                                    (double*)(m->d_out + 8 * (size_t)n), (float*)(m->d_out + 16 * (size_t)n))))
             return rc;
         if (m->cds2) {
             if ((rc = fb_dog_pair_dev(ctx, strips0, strips1, 0, n, H, W, m->sigma, 1, m->d_dogf))) return rc;
             dogf = m->d_dogf;
+            if (any_mask) {
+                // (matcher.py:336-337: the fine DoG of a masked image with its full-resolution mask)
+                void* ptr = nullptr;
+                std::vector<uint8_t> mf(fpix);
+                int slot = 0;
+                for (int side = 0; side < 2; ++side)
+                    for (int p = 0; p < n; ++p) {
+                        const uint8_t* mk = (side ? mask1 : mask0).empty() ? nullptr : (side ? mask1 : mask0)[p];
+                        if (!mk) continue;
+                        for (size_t k = 0; k < fpix; ++k) mf[k] = mk[k] != 0;
+                        // two slots alternate (copies and kernels are ordered on the context's stream)
+                        if ((rc = scratch(ctx, m, 9 + (slot & 1), fpix, &ptr))) return rc;
+                        if ((rc = fb_memcpy_h2d(ctx, ptr, mf.data(), fpix))) return rc;
+                        const size_t img = (size_t)side * n + p;
+                        if ((rc = fb_dog_dev(ctx, (side ? strips1 : strips0) + (size_t)p * fpix, 0, 1, H, W, m->sigma, (const uint8_t*)ptr, 1, m->d_dogf + img * fpix))) return rc;
+                        ++slot;
+                    }
+            }
         }
         clk.lap(0);
         const double *gx, *gy; const float* gc;
         if ((rc = fetch(ctx, m, (size_t)n, &gx, &gy, &gc))) return rc;
         for (int p = 0; p < n; ++p) { tx[p] = gx[p]; ty[p] = gy[p]; conf0[p] = gc[p]; }
+        if (want_phtm) {
+            // matcher.py:279-314 at the coarse scale, with the global translation truncated like int() does
+            const int bands = 16;
+            std::vector<int32_t> txy((size_t)2 * n);
+            for (int p = 0; p < n; ++p) { txy[2 * p] = (int32_t)tx[p]; txy[2 * p + 1] = (int32_t)ty[p]; }
+            void *d_txy, *d_part, *d_has;
+            if ((rc = scratch(ctx, m, 1, txy.size() * 4, &d_txy)) || (rc = scratch(ctx, m, 3, (size_t)n * bands * 6 * 8, &d_part)) || (rc = scratch(ctx, m, 2, 2 * (size_t)n, &d_has)))
+                return rc;
+            if ((rc = fb_memcpy_h2d(ctx, d_txy, txy.data(), txy.size() * 4)) || (rc = fb_memcpy_h2d(ctx, d_has, has_mask.data(), has_mask.size()))) return rc;
+            const uint8_t* raw = m->cds2 ? m->d_small : nullptr;
+            if (!m->cds2) {
+                // coarse == fine: the raw images are the strips themselves, two stacks that need not be adjacent
+                void* ptr = nullptr;
+                if ((rc = scratch(ctx, m, 11, 2 * (size_t)n * cpix, &ptr))) return rc;
+                if ((rc = fb_memcpy_d2d(ctx, ptr, strips0, (size_t)n * cpix)) || (rc = fb_memcpy_d2d(ctx, (uint8_t*)ptr + (size_t)n * cpix, strips1, (size_t)n * cpix))) return rc;
+                raw = (const uint8_t*)ptr;
+            }
+            hipLaunchKernelGGL(photometric_kernel, dim3(n, bands), dim3(256), 0, ctx->stream, n, hc, wc, raw, (const float*)m->d_dogc, (const uint8_t*)d_maskc,
+                               (const uint8_t*)d_has, (const int*)d_txy, bands, (double*)d_part);
+            FB_HIP(ctx, hipGetLastError());
+            std::vector<double> part((size_t)n * bands * 6);
+            if ((rc = fb_memcpy_d2h(ctx, part.data(), d_part, part.size() * 8))) return rc;
+            m->phtm.assign((size_t)4 * n, 0.0);
+            m->phtm_has.assign((size_t)n, 0);
+            for (int p = 0; p < n; ++p) {
+                double t[6] = {0, 0, 0, 0, 0, 0};
+                for (int bnd = 0; bnd < bands; ++bnd)
+                    for (int k = 0; k < 6; ++k) t[k] += part[((size_t)p * bands + bnd) * 6 + k];
+                if (!(t[5] > 3.0)) continue;                 // np.sum(m0) <= 3: None
+                m->phtm_has[p] = 1;
+                for (int k = 0; k < 4; ++k) m->phtm[4 * (size_t)p + k] = t[k] / t[4];       // (an empty joint mask gives nan, like np.mean of nothing)
+            }
+        } else {
+            m->phtm.clear(); m->phtm_has.clear();
+        }
         clk.lap(1);
     } else {
         // every stage on each pair's own extent ('nearest' extension at the image's own border, zeros in the rest of its slot)
@@ -1349,6 +1490,23 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         }
     }
     *nrows = (int64_t)m->r_pid.size();
+    return FB_OK;
+}
+
+int fb_strip_matcher_set_extras(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* const* masks0, const uint8_t* const* masks1, int photometric) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, m != nullptr);
+    if (masks0) m->mask0.assign(masks0, masks0 + m->P); else m->mask0.clear();
+    if (masks1) m->mask1.assign(masks1, masks1 + m->P); else m->mask1.clear();
+    m->want_phtm = photometric != 0;
+    return FB_OK;
+}
+
+int fb_match_strips_photometric(fb_ctx* ctx, fb_strip_matcher* m, double* phtm, uint8_t* has) {
+    FB_CHECK_ARG(ctx, m && phtm && has);
+    if (m->phtm_has.size() != (size_t)m->P) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips_photometric: the last call did not ask for the statistics");
+    std::copy(m->phtm.begin(), m->phtm.end(), phtm);
+    std::copy(m->phtm_has.begin(), m->phtm_has.end(), has);
     return FB_OK;
 }
 

@@ -885,13 +885,13 @@ class StripBatchMatcher:
         batches go through fb_match_strips (one C entry for the whole sequence, the deformed-mesh branch included); the
         pairs it hands back (flags != 0: second shot of the global matcher, relax_first, folded block of a deformed mesh,
         degenerate rigid fit) and every other kind of batch take the numpy statement of the same sequence."""
-        if self._route == 'native' and masks0 is None and masks1 is None and not compute_photometric:
+        if self._route == 'native' and (not self._ragged or (masks0 is None and masks1 is None and not compute_photometric)):
             if self._prefer_host:
                 # the entry handed back most pairs of the last batch (no texture: second shot of the global matcher): this batch
                 # takes the host statement directly, the next one tries the entry again
                 self._prefer_host = False
-                return self._match_host(strips0, strips1)
-            return self._match_native(strips0, strips1)
+                return self._match_host(strips0, strips1, masks0, masks1, compute_photometric)
+            return self._match_native(strips0, strips1, masks0, masks1, compute_photometric)
         return self._match_host(strips0, strips1, masks0, masks1, compute_photometric)
 
     def _native_matcher(self):
@@ -911,12 +911,35 @@ class StripBatchMatcher:
             self._native = h
         return self._native
 
-    def _match_native(self, strips0, strips1):
+    @staticmethod
+    def _effective_masks(masks0, masks1, n):
+        """(masks0, masks1) as lists of uint8 arrays / None, or None when no mask has a zero (common.py:368: such a mask
+        changes nothing)"""
+        if masks0 is None and masks1 is None:
+            return None
+        out = []
+        for ml in (masks0, masks1):
+            ml = [None] * n if ml is None else list(ml)
+            out.append([None if (mk is None or np.all(mk)) else np.ascontiguousarray(np.asarray(mk) != 0, dtype=np.uint8) for mk in ml])
+        if all(mk is None for ml in out for mk in ml):
+            return None
+        return tuple(out)
+
+    def _match_native(self, strips0, strips1, masks0=None, masks1=None, compute_photometric=False):
         lib, ctx = _lib.load(), _lib.ctx()
         n = self.P
         strips0 = strips0.value if hasattr(strips0, 'value') else strips0
         strips1 = strips1.value if hasattr(strips1, 'value') else strips1
         h = self._native_matcher()
+        masks = self._effective_masks(masks0, masks1, n)
+        if masks is not None or compute_photometric:
+            arrs = [None, None]
+            if masks is not None:
+                for side in (0, 1):
+                    if any(mk.shape != (self.H, self.W) for mk in masks[side] if mk is not None):
+                        raise ValueError(f'masks must have the shape of the strips, {self.H} x {self.W}')
+                    arrs[side] = (C.c_void_p * n)(*[None if mk is None else mk.ctypes.data for mk in masks[side]])
+            _lib.check(lib.fb_strip_matcher_set_extras(ctx, h, arrs[0], arrs[1], 1 if compute_photometric else 0))
         tx = np.empty(n); ty = np.empty(n); cf0 = np.empty(n, dtype=np.float32); strain = np.empty(n)
         valid = np.empty(n, dtype=np.uint8); flags = np.empty(n, dtype=np.uint8)
         nrows = C.c_int64()
@@ -942,20 +965,26 @@ class StripBatchMatcher:
             self.last_field = field
             at = np.concatenate(([0], np.cumsum(ntier)))
             self.last_tiers = {p: tiers[at[p]:at[p + 1]].copy() for p in range(n) if ntier[p]}
+        phtm = None
+        if compute_photometric:
+            ph = np.empty((n, 4)); has = np.empty(n, dtype=np.uint8)
+            _lib.check(lib.fb_match_strips_photometric(ctx, h, _lib.ptr(ph), _lib.ptr(has)))
+            phtm = [tuple(ph[p]) if has[p] else None for p in range(n)]
         res = dict(tx=tx, ty=ty, conf0=cf0, valid=valid.astype(bool), needs_host=zeros, deformed=deformed.astype(bool), deferred=zeros.copy(),
-                   pair=pid.astype(np.int64), xy0=xy0, xy1=xy1, weight=wt, strain=strain, phtm=None)
+                   pair=pid.astype(np.int64), xy0=xy0, xy1=xy1, weight=wt, strain=strain, phtm=phtm)
         fl = np.flatnonzero(flags)
         if fl.size:
-            self._general_route(res, fl, strips0, strips1)
+            self._general_route(res, fl, strips0, strips1, masks, compute_photometric)
         return res
 
-    def _general_route(self, res, fl, strips0, strips1):
+    def _general_route(self, res, fl, strips0, strips1, masks=None, compute_photometric=False):
         """the pairs `fl` of the batch through the host route; their results replace those of fb_match_strips in `res`"""
         lib, ctx = _lib.load(), _lib.ctx()
         n, H, W = self.P, self.H, self.W
         self._prefer_host = fl.size > n // 2
+        m0, m1 = (None, None) if masks is None else masks
         if fl.size == n:
-            res.update(self._match_host(strips0, strips1))
+            res.update(self._match_host(strips0, strips1, m0, m1, compute_photometric))
             return
         sub = self._general.pop(fl.size, None) if not self._ragged else None      # a ragged sub-batch has its own shapes
         if sub is None:
@@ -977,7 +1006,11 @@ class StripBatchMatcher:
             for buf, src in zip(self._gather, (strips0, strips1)):
                 _lib.check(lib.fb_memcpy_d2d(ctx, buf.offset(at * H * W), C.c_void_p(src + int(r[0]) * H * W), r.size * H * W))
             at += r.size
-        g = sub._match_host(self._gather[0].ptr, self._gather[1].ptr)
+        g = sub._match_host(self._gather[0].ptr, self._gather[1].ptr, None if m0 is None else [m0[p] for p in fl], None if m1 is None else [m1[p] for p in fl],
+                            compute_photometric)
+        if compute_photometric:
+            for k, p in enumerate(fl):
+                res['phtm'][p] = g['phtm'][k]
         for k in ('tx', 'ty', 'conf0', 'valid', 'deformed', 'deferred', 'strain'):
             res[k][fl] = g[k]
         for k, src in (('pair', fl[g['pair']]), ('xy0', g['xy0']), ('xy1', g['xy1']), ('weight', g['weight'])):

@@ -364,6 +364,13 @@ int fb_strip_matcher_info(fb_ctx* ctx, fb_strip_matcher* m, int* nspacings, doub
 int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, const uint8_t* strips1, double* tx, double* ty,
                     float* conf0, uint8_t* valid, uint8_t* flags, double* strain, int64_t* nrows);
 int fb_match_strips_table(fb_ctx* ctx, fb_strip_matcher* m, int32_t* pair, double* xy0, double* xy1, float* weight);
+/* Extras of the NEXT fb_match_strips call on this matcher (equal strips only): masks0 / masks1 = P host pointers each (the
+ * array or an entry may be NULL) to uint8 [H][W] valid-pixel masks, non-zero = valid -- the masked DoG of both scales
+ * (matcher.py:257-274, 336-337; common.py:353-377); photometric != 0: the statistics of matcher.py:279-314, read afterwards
+ * with fb_match_strips_photometric: phtm [P][4] = mean grey level of the two coarse strips and mean |DoG| of the two filtered
+ * ones over the overlap of the translated strips, has [P] = 0 where strip 0 has fewer than 4 valid pixels there (None). */
+int fb_strip_matcher_set_extras(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* const* masks0, const uint8_t* const* masks1, int photometric);
+int fb_match_strips_photometric(fb_ctx* ctx, fb_strip_matcher* m, double* phtm, uint8_t* has);
 /* The deformed-mesh branch of the last fb_match_strips call (matcher.py:725-742): deformed [P] = the relaxation of mesh1
  * between two spacings was not a rigid translation; ntiers [P] = number of blocks of the pair's last deformed round; *nodes =
  * V, the nodes of one mesh (all nullable).  fb_match_strips_field: field [P][V][2] = MOVING - INITIAL of every mesh1 node

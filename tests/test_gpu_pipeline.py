@@ -784,6 +784,44 @@ def test_native_entry_equals_the_host_statement(fb, H, W, P, cds, mode):
     mn.free(); mh.free(); d0.free(); d1.free(); s0.free(); s1.free()
 
 
+@pytest.mark.parametrize('cds', [0.5, 1])
+def test_native_entry_masks_and_photometric_equal_the_host_statement(fb, cds):
+    """fb_strip_matcher_set_extras: valid-pixel masks (masked DoG of both scales, matcher.py:257-274, 336-337) and the
+    photometric statistics (279-314) inside the C entry against the numpy statement of the same batch: identical match
+    tables, statistics to the rounding of their float32 / float64 means"""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    H, W, P = 1024, 256, 5
+    s0, s1, _ = _synth(fb, P, H, W, seed=41, max_shift=10, warp=0.3)
+    rng = np.random.default_rng(3)
+    masks0 = [None] * P; masks1 = [None] * P
+    mk = np.ones((H, W), dtype=np.uint8); mk[:, :40] = 0; mk[700:, :] = 0; masks0[1] = mk
+    mk = np.ones((H, W), dtype=bool); mk[100:300, 100:] = False; masks1[1] = mk
+    mk = np.ones((H, W), dtype=np.uint8); mk[:90] = 0; masks1[3] = mk * 255
+    masks0[4] = np.ones((H, W), dtype=np.uint8)                            # a mask without a zero changes nothing
+    kw = dict(coarse_downsample=cds, residue_len=3.0)
+    mn = StripBatchMatcher(P, H, W, route='native', **kw); mh = StripBatchMatcher(P, H, W, route='host', **kw)
+    rn = mn.match(s0.ptr, s1.ptr, masks0, masks1, compute_photometric=True)
+    rh = mh.match(s0.ptr, s1.ptr, masks0, masks1, compute_photometric=True)
+    assert not mn.last_flags.any() and rn['valid'].all()
+    for k in ('tx', 'ty', 'conf0', 'valid', 'pair', 'xy0', 'xy1', 'weight'):
+        np.testing.assert_array_equal(rn[k], rh[k], err_msg=k)
+    np.testing.assert_allclose(rn['strain'], rh['strain'], rtol=1e-6, atol=1e-10)
+    for p in range(P):
+        np.testing.assert_allclose(rn['phtm'][p], rh['phtm'][p], rtol=2e-6)
+    # the masked pair really differs from the unmasked run, and the extras do not carry over to the next call
+    r0 = mn.match(s0.ptr, s1.ptr)
+    assert r0['phtm'] is None and not np.array_equal(StripBatchMatcher.per_pair(r0)[1]['xy0'], StripBatchMatcher.per_pair(rn)[1]['xy0'])
+    np.testing.assert_array_equal(StripBatchMatcher.per_pair(r0)[0]['xy0'], StripBatchMatcher.per_pair(rn)[0]['xy0'])
+    # photometric statistics alone; a fully masked strip 0 has no statistics (None, matcher.py:296-298)
+    none0 = [np.zeros((H, W), dtype=np.uint8)] + [None] * (P - 1)
+    rp = mn.match(s0.ptr, s1.ptr, none0, None, compute_photometric=True)
+    rq = mh.match(s0.ptr, s1.ptr, none0, None, compute_photometric=True)
+    assert rp['phtm'][0] is None and rq['phtm'][0] is None
+    np.testing.assert_allclose(rp['phtm'][2], rn['phtm'][2], rtol=1e-12)
+    mn.free(); mh.free(); s0.free(); s1.free()
+
+
 def test_native_entry_automatic_spacings_and_grid(fb):
     """fb_strip_matcher_create without spacings restates matcher.py:243-251; its relaxation grid is Mesh.from_bbox's"""
     from feabas_amd import _lib

@@ -1,6 +1,7 @@
 """randomised A/B of fb_match_strips against the numpy statement of the same sequence (StripBatchMatcher route='native' /
 'host'): uniform batches of random shapes / options on device-synthesised strips with some hand-made hard pairs (no
-texture, 2.5 px warp), and ragged batches of random extents inside one bucket.  Tables of pairs the entry finishes must be
+texture, 2.5 px warp), a third of them with valid-pixel masks / photometric statistics, and ragged batches of random
+extents inside one bucket.  Tables of pairs the entry finishes must be
 bit-identical; flagged pairs and the strain agree to rounding."""
 import sys, time, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -55,8 +56,23 @@ for c in range(ncase):
         k = int(rng.integers(0, P)); h0[k], h1[k] = tp._warped_pair(H, W, int(rng.integers(1, 999)), (3, -2), 2.5)
     d0 = _lib.DeviceBuffer.from_array(h0); d1 = _lib.DeviceBuffer.from_array(h1)
     mn = StripBatchMatcher(P, H, W, route='native', **kw); mh = StripBatchMatcher(P, H, W, route='host', **kw)
-    rn = mn.match(d0.ptr, d1.ptr); rh = mh.match(d0.ptr, d1.ptr)
-    compare(mn, mh, rn, rh, P, ('uniform', H, W, P, kw))
+    extras = {}
+    if rng.random() < 0.35:                                        # valid-pixel masks on some strips, photometric statistics
+        mk0 = [None] * P; mk1 = [None] * P
+        for ml in (mk0, mk1):
+            for p in range(P):
+                if rng.random() < 0.4:
+                    mk = np.ones((H, W), dtype=np.uint8)
+                    if rng.random() < 0.5: mk[:, :int(rng.integers(1, W // 3))] = 0
+                    else: mk[int(rng.integers(H // 2, H - 1)):] = 0
+                    ml[p] = mk
+        extras = dict(masks0=mk0, masks1=mk1, compute_photometric=bool(rng.random() < 0.7))
+    rn = mn.match(d0.ptr, d1.ptr, **extras); rh = mh.match(d0.ptr, d1.ptr, **extras)
+    compare(mn, mh, rn, rh, P, ('uniform', H, W, P, kw, bool(extras)))
+    if extras.get('compute_photometric'):
+        for a, b in zip(rn['phtm'], rh['phtm']):
+            if (a is None) != (b is None) or (a is not None and not np.allclose(a, b, rtol=1e-5, equal_nan=True)):
+                bad += 1; print('PHOTOMETRIC MISMATCH', a, b)
     mn.free(); mh.free(); d0.free(); d1.free(); s0.free(); s1.free()
 
 for c in range(max(2, ncase // 3)):
