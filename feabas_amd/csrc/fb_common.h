@@ -29,6 +29,12 @@ struct fb_fft_plan {
     size_t work_bytes = 0;
 };
 
+// host threads a pure-host helper may use for one call (FEABAS_HIP_HOST_THREADS overrides; 1 = none beside the caller)
+inline int fb_host_threads(int cap) {
+    static const int env = [] { const char* e = std::getenv("FEABAS_HIP_HOST_THREADS"); return e ? std::atoi(e) : 0; }();
+    return env > 0 ? std::min(env, std::max(cap, 1)) : cap;
+}
+
 struct fb_ctx {
     // set by fb_match_strips (under the context lock) around its fb_pairs_*_bary calls: the matches it hands over couple the
     // three vertices of ONE grid triangle (locate_grid / fb_deformed_locate), so fb_sys_update_links' membership test of every

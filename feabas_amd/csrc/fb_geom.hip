@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <thread>
+#include <vector>
 
 namespace {
 
@@ -93,12 +95,15 @@ int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* 
                               double* A6, double* lo) {
     FB_CHECK_ARG(ctx, Q >= 0 && nx >= 2 && ny >= 2 && xs_all && ys_all && vm && nblk >= 0 && bboxes && tier && A6 && lo);
     const int V = nx * ny;
+    const double inf = std::numeric_limits<double>::infinity();
+    // pairs are independent: a batch of deformed pairs (24 k blocks at 64 pairs of the 4k configuration) is dealt to a few host
+    // threads -- the calling thread holds the device idle while this runs
+    auto work = [&](int q_lo, int q_hi) {
     std::vector<double> vi(2 * (size_t)V);
     std::vector<int> all(V), stamp(V), members;
     for (int v = 0; v < V; ++v) all[v] = v;
     members.reserve(64);
-    const double inf = std::numeric_limits<double>::infinity();
-    for (int q = 0; q < Q; ++q) {
+    for (int q = q_lo; q < q_hi; ++q) {
         // the INITIAL node grid of pair q (pairs of unequal strip size have their own)
         const double* xs = xs_all + (per_pair_grid ? (size_t)q * nx : 0);
         const double* ys = ys_all + (per_pair_grid ? (size_t)q * ny : 0);
@@ -160,6 +165,14 @@ int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* 
             }
         }
         lo[2 * q] = lox; lo[2 * q + 1] = loy;
+    }
+    };
+    const int T = std::max(1, std::min(fb_host_threads(4), (int)(((int64_t)Q * nblk) / 2048)));
+    if (T <= 1) work(0, Q);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back(work, (int)((int64_t)Q * t / T), (int)((int64_t)Q * (t + 1) / T));
+        for (auto& th : pool) th.join();
     }
     return FB_OK;
 }
@@ -324,9 +337,11 @@ int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs_all,
         mean[2 * q] = mx / V; mean[2 * q + 1] = my / V;
     }
     static const int order[3] = {0, -1, 1};
-    for (int64_t k = 0; k < K; ++k) {
+    for (int64_t k = 0; k < K; ++k)
+        if (pair_of[k] < 0 || pair_of[k] >= Q) return fb_fail(ctx, FB_ERR_ARG, "fb_deformed_locate: pair %d outside [0, %d)", pair_of[k], Q);
+    auto work = [&](int64_t k_lo, int64_t k_hi) {
+    for (int64_t k = k_lo; k < k_hi; ++k) {
         const int q = pair_of[k];
-        if (q < 0 || q >= Q) return fb_fail(ctx, FB_ERR_ARG, "fb_deformed_locate: pair %d outside [0, %d)", q, Q);
         const double* xs = xs_all + (per_pair_grid ? (size_t)q * nx : 0);
         const double* ys = ys_all + (per_pair_grid ? (size_t)q * ny : 0);
         const double* v = vm + 2 * (size_t)q * V;
@@ -363,6 +378,14 @@ int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs_all,
             }
         if (best < -eps) { bt = -1; bb[0] = bb[1] = bb[2] = nan; }
         tid[k] = bt; B[3 * k] = bb[0]; B[3 * k + 1] = bb[1]; B[3 * k + 2] = bb[2];
+    }
+    };
+    const int T = std::max(1, std::min(fb_host_threads(4), (int)(K / 4096)));
+    if (T <= 1) work(0, K);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back(work, K * t / T, K * (t + 1) / T);
+        for (auto& th : pool) th.join();
     }
     return FB_OK;
 }
