@@ -12,7 +12,6 @@
 // fb_remap_dev), matches located in the deformed triangles (Link.from_coordinates, optimizer.py:51-82).
 //
 // Pairs this entry does NOT finish are reported in flags[] and left to the caller's general route:
-//   FB_STRIP_LOWCONF    global confidence <= conf_thresh: the second shot of global_translation_matcher (159-221)
 //   FB_STRIP_FOLDED     a block of a deformed mesh1 has a degenerate / flipped affine fit (renderer.py:397-416)
 //   FB_STRIP_RELAXFIRST the last relaxation deformed mesh1 beyond the screen of relax_first (optimizer.py:763-779)
 //   FB_STRIP_RIGIDFIT   the rigid initialisation of the strain stage is rank deficient / reflected / < 3 matches
@@ -74,6 +73,29 @@ __global__ __launch_bounds__(256) void photometric_kernel(int n, int hc, int wc,
         if (tid == 0) part[((size_t)p * bands + band) * 6 + k] = red[0];
         __syncthreads();
     }
+}
+
+// value range of a window of a float image: out[2 b] = min, out[2 b + 1] = max of block b = {image, x0, y0, h, w} (the
+// `np.ptp(block) == 0` test of global_translation_matcher's second shot, matcher.py:196-205)
+__global__ __launch_bounds__(256) void block_range_kernel(const float* __restrict__ imgs, int IH, int IW, const int* __restrict__ blk, float* __restrict__ out) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int* d = blk + 5 * b;
+    const float* img = imgs + (size_t)d[0] * IH * IW;
+    const int x0 = d[1], y0 = d[2], h = d[3], w = d[4];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = tid; i < h * w; i += 256) {
+        const int r = i / w, c = i - r * w;
+        const float v = img[(size_t)(y0 + r) * IW + x0 + c];
+        lo = fminf(lo, v); hi = fmaxf(hi, v);
+    }
+    __shared__ float slo[256], shi[256];
+    slo[tid] = lo; shi[tid] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { slo[tid] = fminf(slo[tid], slo[tid + s]); shi[tid] = fmaxf(shi[tid], shi[tid + s]); }
+        __syncthreads();
+    }
+    if (tid == 0) { out[2 * b] = slo[0]; out[2 * b + 1] = shi[0]; }
 }
 
 struct fb_strip_matcher {
@@ -358,7 +380,13 @@ void locate_cart(const fb_strip_matcher* m, int p, double x, double y, int32_t n
     B[0] = a0 / tot; B[1] = a1 / tot; B[2] = a2 / tot;
 }
 
-// grow-only device scratch of the deformed-mesh branch (slot k of the matcher)
+// grow-only device scratch of the matcher, by slot
+enum : int {
+    kScrAff = 0,                                                     // affine maps of a deformed group [nb][10] f64
+    kScrIds = 1, kScrOrg = 2, kScrMapX = 3, kScrMapY = 4, kScrMapMask = 5, kScrStack = 6, kScrExactOut = 7,   // exact-field tier
+    kScrMaskCoarse = 8, kScrMaskFine0 = 9, kScrMaskFine1 = 10, kScrRaw = 11,                                   // masks, statistics
+    kScrTxy = kScrIds, kScrHas = kScrOrg, kScrPart = kScrMapX        // photometric statistics (before any deformed round runs)
+};
 int scratch(fb_ctx* ctx, fb_strip_matcher* m, int k, size_t bytes, void** out) {
     if (m->b_scr[k] < bytes) {
         if (m->scr[k]) pool_give(ctx, m->scr[k], m->b_scr[k]);
@@ -701,6 +729,93 @@ int matcher_create(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, cons
 
 }  // namespace
 
+namespace {
+
+// second shot of global_translation_matcher (matcher.py:159-221) for the pairs without a confident whole-strip peak: ~6
+// sub-blocks on the grid of the most moderate aspect ratio, blocks without contrast dropped, the most confident block wins if
+// it is at least as confident as the whole strip.  The two strips of a pair have one shape, so their block grids coincide and
+// the re-centred padding of 184-210 is the block itself; pairs of unequal extent (ragged batches) have their own grids and
+// are launched per FFT shape.
+int second_shot(fb_ctx* ctx, fb_strip_matcher* m, float thr, double* tx, double* ty, float* conf0) {
+    const int n = m->P, hc = m->hc, wc = m->wc;
+    const size_t cpix = (size_t)hc * wc;
+    struct Grid { int p, nx, ny, bw, bh; AxisCut cx, cy; };
+    std::map<long long, std::vector<Grid>> by_shape;
+    for (int p = 0; p < n; ++p) {
+        if (conf0[p] > thr) continue;
+        const int hp = m->hcs[p], wp = m->wcs[p];
+        int gr = 1, gc = 1;
+        {
+            const int df = 6;
+            const double aspect = (double)hp / (double)wp;
+            double best = std::numeric_limits<double>::infinity();
+            for (int f = 1; f <= (int)std::sqrt((double)df); ++f) {
+                if (df % f) continue;
+                const double qf = (double)(f * f) / df;
+                const double v1 = std::fabs(std::log(aspect * qf)), v2 = std::fabs(std::log(aspect / qf));
+                if (v1 < best) { best = v1; gr = df / f; gc = f; }
+                if (v2 < best) { best = v2; gr = f; gc = df / f; }
+            }
+        }
+        const double big = (double)std::max(hp, wp);       // common.divide_bbox: block_size defaults to the larger extent
+        Grid g;
+        g.p = p;
+        g.cx = cut_axis(0.0, (double)wp, big, (double)gc, 1.0); g.cy = cut_axis(0.0, (double)hp, big, (double)gr, 1.0);
+        g.nx = g.cx.count; g.ny = g.cy.count; g.bw = (int)g.cx.step; g.bh = (int)g.cy.step;
+        if (g.bw < 1 || g.bh < 1) continue;
+        by_shape[(long long)fb_next_fast_len(2 * g.bh - 1) * 65536 + fb_next_fast_len(2 * g.bw - 1)].push_back(g);
+    }
+    int rc;
+    for (auto& kv : by_shape) {
+        const std::vector<Grid>& gs = kv.second;
+        size_t nb2 = 0;
+        int hmax = 0, wmax = 0;
+        for (const Grid& g : gs) { nb2 += (size_t)g.nx * g.ny; hmax = std::max(hmax, g.bh); wmax = std::max(wmax, g.bw); }
+        if (nb2 > m->max_blocks) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: %zu blocks in the second shot of the global matcher (limit %zu)", nb2, m->max_blocks);
+        std::vector<int32_t> b5(10 * nb2), b9(9 * nb2);
+        size_t at = 0;
+        for (const Grid& g : gs)
+            for (int j = 0; j < g.ny; ++j)
+                for (int i = 0; i < g.nx; ++i, ++at) {
+                    const int x0 = round_i(cut_start(0.0, (double)m->wcs[g.p], g.cx, i)), y0 = round_i(cut_start(0.0, (double)m->hcs[g.p], g.cy, j));
+                    for (int side = 0; side < 2; ++side) {
+                        int32_t* d = &b5[5 * (2 * at + side)];
+                        d[0] = side * n + g.p; d[1] = x0; d[2] = y0; d[3] = g.bh; d[4] = g.bw;
+                    }
+                    int32_t* d9 = &b9[9 * at];
+                    d9[0] = g.p; d9[1] = x0; d9[2] = y0; d9[3] = g.bh; d9[4] = g.bw; d9[5] = x0; d9[6] = y0; d9[7] = g.bh; d9[8] = g.bw;
+                }
+        void *d_b5, *d_rng;
+        if ((rc = scratch(ctx, m, kScrIds, b5.size() * 4, &d_b5)) || (rc = scratch(ctx, m, kScrOrg, 16 * nb2, &d_rng))) return rc;
+        if ((rc = fb_memcpy_h2d(ctx, d_b5, b5.data(), b5.size() * 4))) return rc;
+        hipLaunchKernelGGL(block_range_kernel, dim3((unsigned)(2 * nb2)), dim3(256), 0, ctx->stream, (const float*)m->d_dogc, hc, wc, (const int*)d_b5, (float*)d_rng);
+        FB_HIP(ctx, hipGetLastError());
+        std::vector<float> rng(4 * nb2);
+        if ((rc = fb_memcpy_d2h(ctx, rng.data(), d_rng, rng.size() * 4))) return rc;
+        if ((rc = fb_memcpy_h2d(ctx, m->d_blk, b9.data(), b9.size() * 4))) return rc;
+        if ((rc = fb_ncc_blocks_dev(ctx, m->d_dogc, m->d_dogc + n * cpix, hc, wc, hc, wc, (int)nb2, m->d_blk, hmax, wmax, (int)(kv.first / 65536), (int)(kv.first % 65536), 0,
+                                    m->conf_mode, (double*)m->d_out, (double*)(m->d_out + 8 * nb2), (float*)(m->d_out + 16 * nb2))))
+            return rc;
+        const double *bx, *by; const float* bc;
+        if ((rc = fetch(ctx, m, nb2, &bx, &by, &bc))) return rc;
+        at = 0;
+        for (const Grid& g : gs) {
+            const int nbk = g.nx * g.ny;
+            int kbest = -1;
+            for (int k = 0; k < nbk; ++k) {
+                const size_t e = at + k;
+                if (rng[4 * e] == rng[4 * e + 1] || rng[4 * e + 2] == rng[4 * e + 3]) continue;      // np.ptp(block) == 0 on either strip
+                if (kbest < 0 || bc[e] > bc[at + kbest]) kbest = k;                                  // np.argmax: the first maximum
+            }
+            if (kbest >= 0 && bc[at + kbest] >= conf0[g.p]) { tx[g.p] = bx[at + kbest]; ty[g.p] = by[at + kbest]; conf0[g.p] = bc[at + kbest]; }
+            at += nbk;
+        }
+    }
+    return FB_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int fb_divide_bbox(fb_ctx* ctx, const double* bbox, const double* block_hw, const int* min_blocks_yx, double shrink_factor, int round_output,
@@ -815,7 +930,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         std::vector<uint8_t> has_mask((size_t)2 * n, 0);
         if (any_mask) {
             void* ptr = nullptr;
-            if ((rc = scratch(ctx, m, 8, 2 * (size_t)n * cpix, &ptr))) return rc;
+            if ((rc = scratch(ctx, m, kScrMaskCoarse, 2 * (size_t)n * cpix, &ptr))) return rc;
             d_maskc = (uint8_t*)ptr;
         }
         if (m->cds2) {
@@ -866,7 +981,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                         if (!mk) continue;
                         for (size_t k = 0; k < fpix; ++k) mf[k] = mk[k] != 0;
                         // two slots alternate (copies and kernels are ordered on the context's stream)
-                        if ((rc = scratch(ctx, m, 9 + (slot & 1), fpix, &ptr))) return rc;
+                        if ((rc = scratch(ctx, m, (slot & 1) ? kScrMaskFine1 : kScrMaskFine0, fpix, &ptr))) return rc;
                         if ((rc = fb_memcpy_h2d(ctx, ptr, mf.data(), fpix))) return rc;
                         const size_t img = (size_t)side * n + p;
                         if ((rc = fb_dog_dev(ctx, (side ? strips1 : strips0) + (size_t)p * fpix, 0, 1, H, W, m->sigma, (const uint8_t*)ptr, 1, m->d_dogf + img * fpix))) return rc;
@@ -878,20 +993,21 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         const double *gx, *gy; const float* gc;
         if ((rc = fetch(ctx, m, (size_t)n, &gx, &gy, &gc))) return rc;
         for (int p = 0; p < n; ++p) { tx[p] = gx[p]; ty[p] = gy[p]; conf0[p] = gc[p]; }
+        if ((rc = second_shot(ctx, m, thr, tx, ty, conf0))) return rc;
         if (want_phtm) {
             // matcher.py:279-314 at the coarse scale, with the global translation truncated like int() does
             const int bands = 16;
             std::vector<int32_t> txy((size_t)2 * n);
             for (int p = 0; p < n; ++p) { txy[2 * p] = (int32_t)tx[p]; txy[2 * p + 1] = (int32_t)ty[p]; }
             void *d_txy, *d_part, *d_has;
-            if ((rc = scratch(ctx, m, 1, txy.size() * 4, &d_txy)) || (rc = scratch(ctx, m, 3, (size_t)n * bands * 6 * 8, &d_part)) || (rc = scratch(ctx, m, 2, 2 * (size_t)n, &d_has)))
+            if ((rc = scratch(ctx, m, kScrTxy, txy.size() * 4, &d_txy)) || (rc = scratch(ctx, m, kScrPart, (size_t)n * bands * 6 * 8, &d_part)) || (rc = scratch(ctx, m, kScrHas, 2 * (size_t)n, &d_has)))
                 return rc;
             if ((rc = fb_memcpy_h2d(ctx, d_txy, txy.data(), txy.size() * 4)) || (rc = fb_memcpy_h2d(ctx, d_has, has_mask.data(), has_mask.size()))) return rc;
             const uint8_t* raw = m->cds2 ? m->d_small : nullptr;
             if (!m->cds2) {
                 // coarse == fine: the raw images are the strips themselves, two stacks that need not be adjacent
                 void* ptr = nullptr;
-                if ((rc = scratch(ctx, m, 11, 2 * (size_t)n * cpix, &ptr))) return rc;
+                if ((rc = scratch(ctx, m, kScrRaw, 2 * (size_t)n * cpix, &ptr))) return rc;
                 if ((rc = fb_memcpy_d2d(ctx, ptr, strips0, (size_t)n * cpix)) || (rc = fb_memcpy_d2d(ctx, (uint8_t*)ptr + (size_t)n * cpix, strips1, (size_t)n * cpix))) return rc;
                 raw = (const uint8_t*)ptr;
             }
@@ -951,6 +1067,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
             if ((rc = fetch(ctx, m, nb, &gx, &gy, &gc))) return rc;
             for (size_t q = 0; q < nb; ++q) { tx[sel[q]] = gx[q]; ty[sel[q]] = gy[q]; conf0[sel[q]] = gc[q]; }
         }
+        if ((rc = second_shot(ctx, m, thr, tx, ty, conf0))) return rc;
         clk.lap(1);
     }
     const float* img1 = dogf + n * fpix;
@@ -960,7 +1077,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
     }
     std::vector<char> active((size_t)n), live((size_t)n), pad((size_t)n, 1), has_last((size_t)n, 0);
     for (int p = 0; p < n; ++p) {
-        flags[p] = (conf0[p] > thr) ? 0 : FB_STRIP_LOWCONF;
+        flags[p] = 0;
         active[p] = conf0[p] >= thr;                        // matcher.py:277-278
         live[p] = active[p] && !flags[p];
     }
@@ -1222,7 +1339,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
             }
             clk.lap(2);
             void* d_aff = nullptr;
-            if ((rc = scratch(ctx, m, 0, aff.size() * 8, &d_aff))) return rc;
+            if ((rc = scratch(ctx, m, kScrAff, aff.size() * 8, &d_aff))) return rc;
             if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), nb * 9 * 4)) || (rc = fb_memcpy_h2d(ctx, d_aff, aff.data(), aff.size() * 8))) return rc;
             if ((rc = fb_ncc_blocks_affine_dev(ctx, dogf, img1, H, W, H, W, (int)nb, m->d_blk, (const double*)d_aff, h, w, gfh, gfw, is_last ? 1 : 0, m->conf_mode,
                                                (double*)m->d_out, (double*)(m->d_out + 8 * nb), (float*)(m->d_out + 16 * nb))))
@@ -1255,9 +1372,9 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                         }
                 }
                 void *d_ids, *d_org, *d_mx, *d_my, *d_mk, *d_st, *d_res;
-                if ((rc = scratch(ctx, m, 1, 4 * N2, &d_ids)) || (rc = scratch(ctx, m, 2, 8 * N2, &d_org)) || (rc = scratch(ctx, m, 3, 4 * N2 * px, &d_mx)) ||
-                    (rc = scratch(ctx, m, 4, 4 * N2 * px, &d_my)) || (rc = scratch(ctx, m, 5, N2 * px, &d_mk)) || (rc = scratch(ctx, m, 6, 4 * N2 * px, &d_st)) ||
-                    (rc = scratch(ctx, m, 7, 20 * ne, &d_res)))
+                if ((rc = scratch(ctx, m, kScrIds, 4 * N2, &d_ids)) || (rc = scratch(ctx, m, kScrOrg, 8 * N2, &d_org)) || (rc = scratch(ctx, m, kScrMapX, 4 * N2 * px, &d_mx)) ||
+                    (rc = scratch(ctx, m, kScrMapY, 4 * N2 * px, &d_my)) || (rc = scratch(ctx, m, kScrMapMask, N2 * px, &d_mk)) || (rc = scratch(ctx, m, kScrStack, 4 * N2 * px, &d_st)) ||
+                    (rc = scratch(ctx, m, kScrExactOut, 20 * ne, &d_res)))
                     return rc;
                 if ((rc = fb_memcpy_h2d(ctx, d_ids, ids.data(), 4 * N2)) || (rc = fb_memcpy_h2d(ctx, d_org, eorg.data(), 8 * N2)) ||
                     (rc = fb_memcpy_h2d(ctx, d_mx, mxa.data(), 4 * N2 * px)) || (rc = fb_memcpy_h2d(ctx, d_my, mya.data(), 4 * N2 * px)) ||

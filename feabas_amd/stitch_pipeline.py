@@ -883,8 +883,7 @@ class StripBatchMatcher:
     def match(self, strips0, strips1, masks0=None, masks1=None, compute_photometric=False):
         """stitching_matcher for the P resident pairs; see `_match_host` for the arguments and the result.  Unmasked
         batches go through fb_match_strips (one C entry for the whole sequence, the deformed-mesh branch included); the
-        pairs it hands back (flags != 0: second shot of the global matcher, relax_first, folded block of a deformed mesh,
-        degenerate rigid fit) and every other kind of batch take the numpy statement of the same sequence."""
+        pairs it hands back (flags != 0: relax_first, folded block of a deformed mesh, degenerate rigid fit) and every other kind of batch take the numpy statement of the same sequence."""
         if self._route == 'native' and (not self._ragged or (masks0 is None and masks1 is None and not compute_photometric)):
             if self._prefer_host:
                 # the entry handed back most pairs of the last batch (no texture: second shot of the global matcher): this batch
@@ -932,14 +931,15 @@ class StripBatchMatcher:
         strips1 = strips1.value if hasattr(strips1, 'value') else strips1
         h = self._native_matcher()
         masks = self._effective_masks(masks0, masks1, n)
-        if masks is not None or compute_photometric:
-            arrs = [None, None]
-            if masks is not None:
-                for side in (0, 1):
-                    if any(mk.shape != (self.H, self.W) for mk in masks[side] if mk is not None):
-                        raise ValueError(f'masks must have the shape of the strips, {self.H} x {self.W}')
-                    arrs[side] = (C.c_void_p * n)(*[None if mk is None else mk.ctypes.data for mk in masks[side]])
-            _lib.check(lib.fb_strip_matcher_set_extras(ctx, h, arrs[0], arrs[1], 1 if compute_photometric else 0))
+        arrs = [None, None]
+        if masks is not None:
+            for side in (0, 1):
+                if any(mk.shape != (self.H, self.W) for mk in masks[side] if mk is not None):
+                    raise ValueError(f'masks must have the shape of the strips, {self.H} x {self.W}')
+                arrs[side] = (C.c_void_p * n)(*[None if mk is None else mk.ctypes.data for mk in masks[side]])
+        # always stated: the extras belong to the call that follows, and a call that never happened (an exception in between)
+        # must not leave its mask pointers behind
+        _lib.check(lib.fb_strip_matcher_set_extras(ctx, h, arrs[0], arrs[1], 1 if compute_photometric else 0))
         tx = np.empty(n); ty = np.empty(n); cf0 = np.empty(n, dtype=np.float32); strain = np.empty(n)
         valid = np.empty(n, dtype=np.uint8); flags = np.empty(n, dtype=np.uint8)
         nrows = C.c_int64()

@@ -340,7 +340,7 @@ typedef struct fb_strip_opts {
     int nspacings;             /* 0: the automatic spacings of matcher.py:243-251 */
     const double* spacings;    /* pixels (>= 1) */
 } fb_strip_opts;
-#define FB_STRIP_LOWCONF 1
+#define FB_STRIP_LOWCONF 1      /* not reported any more: the second shot of global_translation_matcher (matcher.py:159-221) runs inside the entry */
 #define FB_STRIP_NONRIGID 2     /* not reported any more: the deformed-mesh branch (matcher.py:725-742, 833-846) runs inside the entry */
 #define FB_STRIP_RELAXFIRST 4
 #define FB_STRIP_RIGIDFIT 8

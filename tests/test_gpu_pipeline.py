@@ -213,6 +213,8 @@ def test_pipeline_global_translation_second_shot(fb):
     d0 = _lib.DeviceBuffer.from_array(s0); d1 = _lib.DeviceBuffer.from_array(s1)
     m = StripBatchMatcher(P, H, W)
     got = StripBatchMatcher.per_pair(m.match(d0.ptr, d1.ptr))
+    # the second shot ran inside the C entry (pair 0 may still come back for relax_first: 60 matching rows bend its mesh)
+    assert m.last_flags is not None and not (m.last_flags & ~np.uint8(4)).any()
     exp = [pipeline_ref.match_pair(s0[p], s1[p]) for p in range(P)]
     from oracle import ncc_ref
     c0 = ncc_ref.masked_dog_filter(ncc_ref.area_downsample2(s0[0]), 1.25); c1 = ncc_ref.masked_dog_filter(ncc_ref.area_downsample2(s1[0]), 1.25)
@@ -743,9 +745,8 @@ def test_stitching_matcher_unequal_strip_shapes(fb):
                                              (1023, 255, 5, 0.5, 'huber')])
 def test_native_entry_equals_the_host_statement(fb, H, W, P, cds, mode):
     """fb_match_strips (the whole stitching_matcher sequence behind one C entry) against the numpy statement of the same
-    sequence in stitch_pipeline.py: identical tables for the pairs it finishes; the pair it hands back -- one without a
-    match (second shot of global_translation_matcher) -- comes back through the host route with the results that route
-    gives it inside a full batch."""
+    sequence in stitch_pipeline.py: identical tables, including a pair without a match (second shot of
+    global_translation_matcher, matcher.py:159-221) and one whose mesh1 deforms between the spacings."""
     from feabas_amd import _lib
     from feabas_amd.stitch_pipeline import StripBatchMatcher
     s0, s1, shifts = _synth(fb, P, H, W, seed=23, max_shift=14, warp=0.3)
@@ -759,9 +760,10 @@ def test_native_entry_equals_the_host_statement(fb, H, W, P, cds, mode):
     mn = StripBatchMatcher(P, H, W, route='native', **kw)
     mh = StripBatchMatcher(P, H, W, route='host', **kw)
     rn = mn.match(d0.ptr, d1.ptr); rh = mh.match(d0.ptr, d1.ptr)
-    assert mn.last_flags[1] & 1 and mn.last_flags.astype(bool).sum() <= 3 and not mn.last_flags[0]
+    # nothing is handed back: the pair without a match takes the second shot of global_translation_matcher inside the entry
+    assert not mn.last_flags.any()
     if mn.spacings.size > 1:
-        assert not mn.last_flags[2] and rn['deformed'][2]
+        assert rn['deformed'][2]
     for k in ('tx', 'ty', 'conf0', 'valid', 'deformed'):
         np.testing.assert_array_equal(rn[k], rh[k], err_msg=k)
     assert rn['valid'].sum() >= P - 2
@@ -820,6 +822,36 @@ def test_native_entry_masks_and_photometric_equal_the_host_statement(fb, cds):
     assert rp['phtm'][0] is None and rq['phtm'][0] is None
     np.testing.assert_allclose(rp['phtm'][2], rn['phtm'][2], rtol=1e-12)
     mn.free(); mh.free(); s0.free(); s1.free()
+
+
+def test_native_entry_second_shot_on_unequal_strips(fb):
+    """the second shot of global_translation_matcher (matcher.py:159-221) inside the entry for strips of unequal size: every
+    pair has its own 6 x 1 block grid; one pair agrees only inside a sixth of its area (the shot succeeds), one nowhere (it
+    stays without a match), the others are ordinary.  Against the numpy statement of the ragged batch, bit for bit."""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import RaggedStripBatchMatcher, StripBatchMatcher
+    shapes = [(1536, 120), (1526, 122), (1520, 120), (1530, 121)]
+    pairs = [list(_warped_pair(h, w, 310 + k, shift=(3 - k, k - 2), warp=0.2)) for k, (h, w) in enumerate(shapes)]
+    rng = np.random.default_rng(9)
+    h1, w1 = shapes[1]
+    other = _warped_pair(h1, w1, 999, shift=(0, 0), warp=0.0)[0]
+    keep = pairs[1][1][1300:1380].copy()
+    pairs[1][1] = other.copy(); pairs[1][1][1300:1380] = keep                # pair 1: 80 matching rows, the rest unrelated
+    pairs[2][1] = rng.integers(0, 256, shapes[2], dtype=np.uint8)           # pair 2: nothing to find
+    P = len(shapes)
+    Hm, Wm = max(h for h, _ in shapes), max(w for _, w in shapes)
+    stage = np.full((2, P, Hm, Wm), 200, dtype=np.uint8)
+    for k, (a, b) in enumerate(pairs):
+        stage[0, k, :a.shape[0], :a.shape[1]] = a; stage[1, k, :b.shape[0], :b.shape[1]] = b
+    dev = _lib.DeviceBuffer.from_array(stage)
+    mn = RaggedStripBatchMatcher(shapes, residue_len=2.0, route='native'); mh = RaggedStripBatchMatcher(shapes, residue_len=2.0, route='host')
+    rn = mn.match(dev.ptr, dev.offset(P * Hm * Wm)); rh = mh.match(dev.ptr, dev.offset(P * Hm * Wm))
+    assert not mn.last_flags.any()
+    for k in ('tx', 'ty', 'conf0', 'valid', 'pair', 'xy0', 'xy1', 'weight'):
+        np.testing.assert_array_equal(rn[k], rh[k], err_msg=k)
+    assert rn['valid'].tolist() == [True, True, False, True]
+    assert rn["tx"][1] == -2.0 and abs(rn["ty"][1] - 1.0) <= 1.0 and rn["conf0"][1] > 0.33     # found by a block of the second shot (coarse scale: even offsets)
+    mn.free(); mh.free(); dev.free()
 
 
 def test_native_entry_automatic_spacings_and_grid(fb):
