@@ -13,8 +13,8 @@ Per pair, in the reference's order:
                                                             fb_ncc_blocks_dev
   6. last-round mesh relaxation + huber residue weights (725-737) and the strain estimate (752-777)
      for the whole batch as one block-diagonal system             fb_sys_update_links / _form_groups / _solve_groups
-The low-confidence second shot of global_translation_matcher (159-221) runs per affected pair through the host
-mirror in matcher.py (block NCCs on the device).
+The low-confidence second shot of global_translation_matcher (159-221): inside fb_match_strips; the numpy statement of
+this module runs it per affected pair through the host mirror in matcher.py (block NCCs on the device).
 Mesh relaxation between spacings (725-742): a uniform block displacement is applied as the rigid translation it relaxes
 to (crops stay integer translations); any other field makes the pair DEFORMED: mesh1 keeps the relaxed displacement of
 its nodes (fb_pairs_relax_bary: total displacement from the FIXED gear, huber re-weighting and second solve included),
@@ -883,11 +883,12 @@ class StripBatchMatcher:
     def match(self, strips0, strips1, masks0=None, masks1=None, compute_photometric=False):
         """stitching_matcher for the P resident pairs; see `_match_host` for the arguments and the result.  Unmasked
         batches go through fb_match_strips (one C entry for the whole sequence, the deformed-mesh branch included); the
-        pairs it hands back (flags != 0: relax_first, folded block of a deformed mesh, degenerate rigid fit) and every other kind of batch take the numpy statement of the same sequence."""
+        pairs it hands back (flags != 0: relax_first, folded block of a deformed mesh, degenerate rigid fit) and masked /
+        photometric batches of unequal strips take the numpy statement of the same sequence."""
         if self._route == 'native' and (not self._ragged or (masks0 is None and masks1 is None and not compute_photometric)):
             if self._prefer_host:
-                # the entry handed back most pairs of the last batch (no texture: second shot of the global matcher): this batch
-                # takes the host statement directly, the next one tries the entry again
+                # the entry handed back most pairs of the last batch: this one takes the host statement directly, the next
+                # one tries the entry again
                 self._prefer_host = False
                 return self._match_host(strips0, strips1, masks0, masks1, compute_photometric)
             return self._match_native(strips0, strips1, masks0, masks1, compute_photometric)
