@@ -1047,14 +1047,15 @@ def main():
         for k in range(len(host_pairs)):                   # as many pairs as the uniform list above
             dh, dw = int(rng_r.integers(0, 30)), int(rng_r.integers(0, 12))
             ragged.append((h0[k % nh, :H - dh, :W - dw], h1[k % nh, :H - dh, :W - dw]))
-        RB = 32                                             # chunks of unequal strips: smaller ones balance the host threads better
-        fmatcher.stitching_matcher_batch(ragged, batch=RB, threads=args.host_ingest_threads, **cfg)      # first pass: page-locked staging, systems, code objects (1.6 s once per process)
+        RB = 32                                             # chunks of unequal strips: smaller ones balance the host threads better,
+        RT = max(args.host_ingest_threads, min(16, _lib.cpu_budget()))      # and a chunk costs more host time (a matcher per chunk): more threads
+        fmatcher.stitching_matcher_batch(ragged, batch=RB, threads=RT, **cfg)      # first pass: page-locked staging, systems, code objects (1.6 s once per process)
         t0 = time.time()
-        outr = fmatcher.stitching_matcher_batch(ragged, batch=RB, threads=args.host_ingest_threads, **cfg)
+        outr = fmatcher.stitching_matcher_batch(ragged, batch=RB, threads=RT, **cfg)
         dtr = time.time() - t0
         line['host_ingest']['ragged'] = dict(value=len(ragged) / dtr, unit='pairs/s', pairs=len(ragged), distinct_shapes=len({a.shape for a, _ in ragged}),
                                              matched=int(sum(o[0] is not None for o in outr)),
-                                             note=f'every pair cropped to its own strip size (up to 29 x 11 px smaller); {RB}-pair chunks of unequal strips dealt to {args.host_ingest_threads} host threads; second pass over the list')
+                                             note=f'every pair cropped to its own strip size (up to 29 x 11 px smaller); {RB}-pair chunks of unequal strips dealt to {RT} host threads; second pass over the list')
         fmatcher.stitching_matcher_batch_release()
         del h0, h1, host_pairs, outp, ragged, outr
     if rank == 0 and world == 1 and not args.no_align:

@@ -1,4 +1,5 @@
-"""the ragged host-ingest list of bench.py, several passes: wall per pass (one-time costs show in the first ones)"""
+"""the ragged (UNIFORM=1: equal-shape) host-ingest list of bench.py, several passes: wall per pass (one-time costs show in the
+first ones); NT host threads, IB pairs per chunk"""
 import sys, time, os, numpy as np
 sys.path.insert(0, '.')
 from feabas_amd import _lib, matcher as fmatcher
@@ -12,7 +13,7 @@ h0 = s0.to_array((nh, H, W), np.uint8); h1 = s1.to_array((nh, H, W), np.uint8)
 rng = np.random.default_rng(5)
 ragged = []
 for k in range(N):
-    dh, dw = int(rng.integers(0, 30)), int(rng.integers(0, 12))
+    dh, dw = (0, 0) if os.environ.get('UNIFORM') else (int(rng.integers(0, 30)), int(rng.integers(0, 12)))
     ragged.append((h0[k % nh, :H - dh, :W - dw], h1[k % nh, :H - dh, :W - dw]))
 cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2.0)
 for ps in range(int(os.environ.get('PASSES', 4))):
