@@ -854,6 +854,17 @@ def test_native_entry_second_shot_on_unequal_strips(fb):
     mn.free(); mh.free(); dev.free()
 
 
+def test_native_entry_randomised_sweep(fb):
+    """tools/fuzz_native.py, a short run: random shapes / options / masks / statistics, hard pairs (no texture, 2.5 px warp)
+    and ragged batches through fb_match_strips against the numpy statement -- no mismatching batch"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_native.py'), '17', '8'], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    assert 'mismatching batches 0' in last and 'MISMATCH' not in out.stdout, out.stdout[-2000:]
+
+
 def test_native_entry_automatic_spacings_and_grid(fb):
     """fb_strip_matcher_create without spacings restates matcher.py:243-251; its relaxation grid is Mesh.from_bbox's"""
     from feabas_amd import _lib
