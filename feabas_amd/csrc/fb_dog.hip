@@ -158,9 +158,22 @@ __global__ __launch_bounds__(256) void count_nonzero_kernel(const uint8_t* __res
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
 }
 
+// is any byte of the mask zero?  16 bytes per load on the aligned body ((x - 0x01..01) & ~x & 0x80..80 marks the zero bytes of
+// a word), single bytes on the unaligned head and the tail
 __global__ void any_zero_kernel(const uint8_t* __restrict__ m, size_t total, int* flag) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        if (m[i] == 0) { *flag = 1; return; }
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    const size_t head = min(total, (size_t)((16 - (reinterpret_cast<uintptr_t>(m) & 15)) & 15));
+    const size_t nvec = (total - head) / 16;
+    const uint4* v = reinterpret_cast<const uint4*>(m + head);
+    bool hit = false;
+    for (size_t i = gid; i < nvec && !hit; i += gsz) {
+        const uint4 q = v[i];
+        const uint32_t z = ((q.x - 0x01010101u) & ~q.x) | ((q.y - 0x01010101u) & ~q.y) | ((q.z - 0x01010101u) & ~q.z) | ((q.w - 0x01010101u) & ~q.w);
+        hit = (z & 0x80808080u) != 0;
+    }
+    for (size_t i = gid; i < head && !hit; i += gsz) hit = m[i] == 0;
+    for (size_t i = head + 16 * nvec + gid; i < total && !hit; i += gsz) hit = m[i] == 0;
+    if (hit) *flag = 1;
 }
 
 // one thread = one output pixel; maps are float32 relative to the integer origin of the sub-image the reference
@@ -900,7 +913,7 @@ int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, cons
         int* flag = reinterpret_cast<int*>(ctx->small);              // the context's scratch: no hipMalloc / hipFree (a device-wide drain) per call
         FB_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
         const size_t nmask = mask_per_image ? (size_t)N : 1, per_image = mask_per_image ? (size_t)H * W : 0;
-        hipLaunchKernelGGL(any_zero_kernel, dim3(256), dim3(256), 0, ctx->stream, mask, nmask * H * W, flag);
+        hipLaunchKernelGGL(any_zero_kernel, dim3(1024), dim3(256), 0, ctx->stream, mask, nmask * H * W, flag);
         int hflag = 0;
         FB_HIP(ctx, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         FB_HIP(ctx, hipStreamSynchronize(ctx->stream));

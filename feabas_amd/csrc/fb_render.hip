@@ -97,6 +97,8 @@ struct RenderArgs {
     const int* origin;   // [NB][2]
     float* out; uint8_t* mask;
     int b0;              // first block of this launch (grid y is limited to 65535 blocks)
+    double2* field;      // [NB][h][w] scratch (nullable): pass 0 keeps the field (and the mask) it found, pass 1 reads them back
+                         // instead of searching the triangles of every pixel a second time
 };
 
 // cv2.remap, CV_8U bilinear: fixed-point table of 1/32-px phases scaled by 2^15 (BilinearTab_i), saturate_cast<short>
@@ -150,7 +152,10 @@ __global__ __launch_bounds__(TILE* TILE) void mesh_field_kernel(const RenderArgs
         fy = (xx * A[3] + yy * A[4]) + A[5];
         ok = live && tr < 10;
     }
-    if (exact || tr >= 10) {
+    const size_t o_px = ((size_t)b * g.h + py) * g.w + px;
+    if (PASS == 1 && g.field) {
+        if (live) { const double2 f = g.field[o_px]; fx = f.x; fy = f.y; ok = g.mask[o_px] != 0; }
+    } else if (exact || tr >= 10) {
         // tile box in MOVING coordinates (pixel centres), grown by the inside tolerance
         const double tx0 = ox + (double)(tx * TILE) - 1e-6, ty0 = oy + (double)(ty * TILE) - 1e-6;
         const double tx1 = ox + (double)min(tx * TILE + TILE - 1, g.w - 1) + 1e-6, ty1 = oy + (double)min(ty * TILE + TILE - 1, g.h - 1) + 1e-6;
@@ -203,11 +208,20 @@ __global__ __launch_bounds__(TILE* TILE) void mesh_field_kernel(const RenderArgs
         }
     }
     if (PASS == 0) {
+        if (g.field && live) { g.field[o_px] = make_double2(fx, fy); g.mask[o_px] = ok ? 1 : 0; }
         if (tid < 4) red[tid] = (tid < 2) ? INT_MAX : INT_MIN;
         __syncthreads();
-        if (ok) {
-            atomicMin(&red[0], (int)floor(fx)); atomicMin(&red[1], (int)floor(fy));
-            atomicMax(&red[2], (int)ceil(fx)); atomicMax(&red[3], (int)ceil(fy));
+        // extent of the tile: reduced inside every wave first (256 pixels hitting four LDS words with atomics serialised the
+        // whole pass: 1.65 ms per 40 M pixels against 0.3 ms for the triangle search itself)
+        int lo_x = ok ? (int)floor(fx) : INT_MAX, lo_y = ok ? (int)floor(fy) : INT_MAX;
+        int hi_x = ok ? (int)ceil(fx) : INT_MIN, hi_y = ok ? (int)ceil(fy) : INT_MIN;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, off)); lo_y = min(lo_y, __shfl_xor(lo_y, off));
+            hi_x = max(hi_x, __shfl_xor(hi_x, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+        }
+        if ((tid & 63) == 0 && lo_x != INT_MAX) {
+            atomicMin(&red[0], lo_x); atomicMin(&red[1], lo_y);
+            atomicMax(&red[2], hi_x); atomicMax(&red[3], hi_y);
         }
         __syncthreads();
         if (tid < 2 && red[tid] != INT_MAX) atomicMin(&g.ext[4 * b + tid], red[tid]);
@@ -314,7 +328,12 @@ int fb_mesh_render_blocks_dev(fb_ctx* ctx, const void* img, int dtype, int IH, i
     if (NB == 0) return FB_OK;
     FB_CHECK_ARG(ctx, img && v_mov && v_img && tris && org && tier && A6 && cand && count && ext && origin && out && mask);
     FB_HIP(ctx, hipSetDevice(ctx->device));
-    RenderArgs g{img, dtype, IH, IW, img_x0, img_y0, v_mov, v_img, tris, org, h, w, tier, A6, cap, cand, count, ext, origin, out, mask, 0};
+    RenderArgs g{img, dtype, IH, IW, img_x0, img_y0, v_mov, v_img, tris, org, h, w, tier, A6, cap, cand, count, ext, origin, out, mask, 0, nullptr};
+    // the field of pass 0 kept for pass 1 (16 B per pixel) while the stack is not larger than 4 GiB of scratch; FEABAS_HIP_RENDER_FIELD=0: search twice
+    const size_t fbytes = (size_t)NB * h * w * sizeof(double2);
+    void* fbuf = nullptr;
+    static const bool keep = [] { const char* e = std::getenv("FEABAS_HIP_RENDER_FIELD"); return !(e && e[0] == '0'); }();
+    if (keep && fbytes <= ((size_t)4 << 30) && fb_malloc(ctx, fbytes, &fbuf) == FB_OK) g.field = (double2*)fbuf;
     FB_PROF_B(ctx, "mesh_render", (double)NB * h * w * 5.0);
     hipLaunchKernelGGL(fill_ext_kernel, dim3(fb_cdiv(4 * NB, 256)), dim3(256), 0, ctx->stream, NB, ext);
     constexpr int kMaxY = 32768;                          // blocks per launch: the grid's y extent is limited to 65535
@@ -327,7 +346,12 @@ int fb_mesh_render_blocks_dev(fb_ctx* ctx, const void* img, int dtype, int IH, i
         g.b0 = b0;
         hipLaunchKernelGGL(mesh_field_kernel<1>, dim3(fb_cdiv(w, TILE) * fb_cdiv(h, TILE), std::min(kMaxY, NB - b0)), dim3(TILE * TILE), 0, ctx->stream, g);
     }
-    FB_HIP(ctx, hipGetLastError());
+    const hipError_t e = hipGetLastError();
+    if (fbuf) {
+        hipStreamSynchronize(ctx->stream);                  // the scratch goes back to the allocation cache
+        fb_free(ctx, fbuf);
+    }
+    FB_HIP(ctx, e);
     return FB_OK;
 }
 
