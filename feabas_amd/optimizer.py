@@ -737,7 +737,7 @@ class SLM:
         dd = np.zeros(2 * self._nv, dtype=np.float64)
         iters, relres = C.c_int(), C.c_double()
         mi = -1 if maxiter is None else int(maxiter)
-        pre = 0 if precondition is None else (2 if multigrid and groupings is None else 1)
+        pre = 0 if precondition is None else (2 if multigrid and groupings is None and any(m.locked for m in self.meshes) else 1)
         bn = float(np.linalg.norm(b)) / self._gmean           # grouped terms are divided by mean(count) (optimizer.py:1408-1411)
         if held is not None and not held.all():
             # remove_extra_dof (optimizer.py:1360-1377, 1976-1991): three degrees of freedom of the first mesh of every
@@ -749,10 +749,20 @@ class SLM:
             cost = (bn, res)
             self.last_solve = dict(iters=None, relres=res / bn if bn else 0.0, stiffness_lambda=sl, crosslink_lambda=cl, held_dofs=int((~held).sum()))
         else:
-            _lib.check(lib.fb_sys_solve(ctx, self._sys, _lib.ptr(dd), 0, float(tol), float(atol or 0.0), mi, pre,
-                                        C.byref(iters), C.byref(relres)), allow=(_lib.FB_ERR_NOCONV,))
+            rc = lib.fb_sys_solve(ctx, self._sys, _lib.ptr(dd), 0, float(tol), float(atol or 0.0), mi, pre, C.byref(iters), C.byref(relres))
+            _lib.check(rc, allow=(_lib.FB_ERR_NOCONV,))
+            fell_back = False
+            if pre == 2 and (rc == _lib.FB_ERR_NOCONV or not relres.value <= max(float(tol), float(atol or 0.0) / bn if bn else 0.0) * 1.0001):
+                # the aggregation hierarchy needs a definite system (its coarsest level is inverted): a window without a locked
+                # mesh floats, and the cycle then stalls -- the plain Jacobi-PCG handles the consistent semi-definite case
+                dd[:] = 0.0
+                _lib.check(lib.fb_sys_solve(ctx, self._sys, _lib.ptr(dd), 0, float(tol), float(atol or 0.0), mi, 1, C.byref(iters), C.byref(relres)),
+                           allow=(_lib.FB_ERR_NOCONV,))
+                fell_back = True
             cost = (bn, float(relres.value * bn))
             self.last_solve = dict(iters=iters.value, relres=relres.value, stiffness_lambda=sl, crosslink_lambda=cl)
+            if fell_back:
+                self.last_solve['multigrid_fell_back'] = True
         if cost[1] < cost[0]:                               # optimizer.py:1421
             offs = self._offs
             for m in self.meshes:

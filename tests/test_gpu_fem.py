@@ -535,3 +535,15 @@ def test_multigrid_preconditioner_same_fixed_point_fewer_iterations(fb, nlinks):
     assert it_m <= it_j
     if nlinks == 40:
         assert it_m * 5 <= it_j, (it_j, it_m)
+
+
+def test_multigrid_request_on_a_floating_system_takes_the_jacobi_pcg(fb):
+    """precondition='smoothed_aggregation' on a window without a locked mesh (A only semi-definite: the coarsest level of the
+    hierarchy cannot be inverted): the solve goes through the Jacobi-PCG and reaches the same link residuals"""
+    rng = np.random.default_rng(21)
+    prod, lp, _, _ = _random_system(fb, rng, 20, 15, 300, two_free=True)
+    prod2, lp2, _, _ = _random_system(fb, np.random.default_rng(21), 20, 15, 300, two_free=True)
+    c1 = fb.optimizer.SLM(prod, lp).optimize_linear(tol=1e-9, precondition='smoothed_aggregation')
+    c2 = fb.optimizer.SLM(prod2, lp2).optimize_linear(tol=1e-9)
+    assert c1[1] <= 1e-9 * c1[0] * 1.01 and c2[1] <= 1e-9 * c2[0] * 1.01
+    np.testing.assert_allclose(lp[0].dxy(gear=(1, 1)), lp2[0].dxy(gear=(1, 1)), atol=1e-9)
