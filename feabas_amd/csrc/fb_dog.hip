@@ -42,9 +42,9 @@ __device__ __forceinline__ float fir_sym(const float* s, int base, int st, int r
 template <typename T, int NPASS>
 __global__ void dog_tile(const T* __restrict__ img, float* __restrict__ out, const float* __restrict__ halo,
                          int H, int W, int r, int TY, int TX, int signed_out, float in_scale, const uint8_t* __restrict__ mask, const Taps taps,
-                         size_t per_image) {
+                         size_t per_image, const int* __restrict__ ids = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int n = blockIdx.z;
+    const int n = ids ? ids[blockIdx.z] : blockIdx.z;       // ids: the images of the stack this launch works on
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const int hal = (NPASS == 4) ? 2 * r : r;          // input halo
     const int AW = TX + 2 * hal, AH = TY + 2 * hal;     // stage-0 tile
@@ -174,6 +174,19 @@ __global__ void any_zero_kernel(const uint8_t* __restrict__ m, size_t total, int
     for (size_t i = gid; i < head && !hit; i += gsz) hit = m[i] == 0;
     for (size_t i = head + 16 * nvec + gid; i < total && !hit; i += gsz) hit = m[i] == 0;
     if (hit) *flag = 1;
+}
+
+// per image of a stack of masks: does it hold a zero?  (one workgroup per image)
+__global__ __launch_bounds__(256) void any_zero_each_kernel(const uint8_t* __restrict__ m, size_t per, int* __restrict__ flags) {
+    const uint8_t* p = m + (size_t)blockIdx.x * per;
+    bool hit = false;
+    for (size_t i = threadIdx.x; i < per && !hit; i += 256) hit = p[i] == 0;
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    if (hit) any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) flags[blockIdx.x] = any;
 }
 
 // one thread = one output pixel; maps are float32 relative to the integer origin of the sub-image the reference
@@ -881,7 +894,7 @@ int launch_fast_any(fb_ctx* ctx, int r, const T* img, float* out, int N, int H, 
 
 template <typename T, int NPASS>
 int launch_tile(fb_ctx* ctx, const T* img, float* out, const float* halo, int N, int H, int W, int r, int signed_out,
-                float in_scale, const uint8_t* mask, const Taps& taps, size_t per_image = 0) {
+                float in_scale, const uint8_t* mask, const Taps& taps, size_t per_image = 0, const int* ids = nullptr) {
     // largest square tile whose two LDS buffers fit in 64 KiB (2 workgroups per CU) or, failing that, 150 KiB
     const int hal = (NPASS == 4) ? 2 * r : r;
     int T_ = 64;
@@ -895,8 +908,9 @@ int launch_tile(fb_ctx* ctx, const T* img, float* out, const float* halo, int N,
     for (int n0 = 0; n0 < N; n0 += kMaxZ) {
         const size_t io = (size_t)n0 * H * W, mo = (size_t)n0 * per_image;
         dim3 grid(fb_cdiv(W, T_), fb_cdiv(H, T_), std::min(kMaxZ, N - n0));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img ? img + io : img, out + io, halo ? halo + mo : halo, H, W, r, T_, T_, signed_out,
-                           in_scale, mask ? mask + mo : mask, taps, per_image);
+        if (ids) hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img, out, halo, H, W, r, T_, T_, signed_out, in_scale, mask, taps, per_image, ids + n0);
+        else hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, img ? img + io : img, out + io, halo ? halo + mo : halo, H, W, r, T_, T_, signed_out,
+                                in_scale, mask ? mask + mo : mask, taps, per_image, (const int*)nullptr);
     }
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
@@ -905,9 +919,12 @@ int launch_tile(fb_ctx* ctx, const T* img, float* out, const float* halo, int N,
 template <typename T>
 int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, const uint8_t* mask, int signed_out, float* out,
               bool mask_per_image = false) {
-    int rc, r = 0;
-    Taps taps;
+    int rc = FB_OK, r = 0, r_halo = 0;
+    Taps taps, taps_halo;
     float* halo = nullptr;
+    float ptp_halo = 0.f;
+    std::vector<int> sel;                 // images of a per-image mask stack whose mask has a zero (when not all of them)
+    int* d_sel = nullptr;
     if (mask) {
         // common.py:368: only when the mask has a zero somewhere
         int* flag = reinterpret_cast<int*>(ctx->small);              // the context's scratch: no hipMalloc / hipFree (a device-wide drain) per call
@@ -917,6 +934,26 @@ int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, cons
         int hflag = 0;
         FB_HIP(ctx, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hflag && mask_per_image && N > 1 && !ctx->dog_exact) {
+            // a stack with one mask per image (the rendered blocks of crop_multiple): usually only the blocks at the border of
+            // the mesh have holes.  The halo term of an image whose mask has no zero is exactly zero, so only the images with
+            // holes take the masked tile kernels; the others go through the streaming kernel with the rest of the stack
+            int* d_each = nullptr;
+            if (fb_malloc(ctx, sizeof(int) * (size_t)N, (void**)&d_each) == FB_OK) {
+                hipLaunchKernelGGL(any_zero_each_kernel, dim3(N), dim3(256), 0, ctx->stream, mask, (size_t)H * W, d_each);
+                std::vector<int> each((size_t)N);
+                rc = fb_copy_d2h(ctx, each.data(), d_each, sizeof(int) * (size_t)N);
+                if (!rc) for (int i = 0; i < N; ++i) if (each[i]) sel.push_back(i);
+                if (!rc && (int)sel.size() < N) {
+                    if ((rc = fb_copy_h2d(ctx, d_each, sel.data(), sizeof(int) * sel.size()))) { fb_free(ctx, d_each); return rc; }
+                    d_sel = d_each;
+                } else {
+                    sel.clear();
+                    fb_free(ctx, d_each);
+                    if (rc) return rc;
+                }
+            }
+        }
         if (hflag) {
             const int nblk = 256, nslots = nblk * 4;
             float* mm = reinterpret_cast<float*>(ctx->small) + 64;       // 8 KiB of the 64 KiB scratch
@@ -930,27 +967,37 @@ int dog_dev_t(fb_ctx* ctx, const T* img, int N, int H, int W, double sigma, cons
             // halo = G_{sigma*sqrt2}(ptp*(mask==0)) * 2   (common.py:369-371)
             const double sc = std::sqrt(2.0 * sigma * sigma);
             rc = set_taps(ctx, sc, &r, &taps);
-            if (rc) return rc;
+            if (rc) { if (d_sel) fb_free(ctx, d_sel); return rc; }
+            r_halo = r; taps_halo = taps; ptp_halo = ptp;
             FB_HIP(ctx, hipMalloc(&halo, sizeof(float) * nmask * H * W));
-            rc = launch_tile<T, 2>(ctx, (const T*)nullptr, halo, nullptr, (int)nmask, H, W, r, 1, ptp, mask, taps, per_image);
-            if (rc) { hipFree(halo); return rc; }
+            if (d_sel) rc = launch_tile<T, 2>(ctx, (const T*)nullptr, halo, nullptr, (int)sel.size(), H, W, r, 1, ptp, mask, taps, per_image, d_sel);
+            else rc = launch_tile<T, 2>(ctx, (const T*)nullptr, halo, nullptr, (int)nmask, H, W, r, 1, ptp, mask, taps, per_image);
+            if (rc) { hipFree(halo); if (d_sel) fb_free(ctx, d_sel); return rc; }
         }
     }
     rc = set_taps(ctx, sigma, &r, &taps);
     if (!rc) {
         bool done = false;
-        if (!halo && !ctx->dog_exact) {
+        if ((!halo || d_sel) && !ctx->dog_exact) {
             FB_PROF_B(ctx, "dog_fast", (double)N * H * W * (sizeof(T) + 4.0));
             rc = launch_fast_any<T>(ctx, r, img, out, N, H, W, signed_out, taps, &done);
         }
-        if (!rc && !done) {
+        if (!rc && d_sel && done) {
+            // the images with holes again, through the masked kernels (the streaming kernel's values of those are overwritten)
+            FB_PROF_B(ctx, "dog_tile", (double)sel.size() * H * W * (sizeof(T) + 4.0));
+            rc = launch_tile<T, 4>(ctx, img, out, halo, (int)sel.size(), H, W, r, signed_out, 0.f, nullptr, taps, (size_t)H * W, d_sel);
+        } else if (!rc && !done) {
             FB_PROF_B(ctx, "dog_tile", (double)N * H * W * (sizeof(T) + 4.0));
-            rc = launch_tile<T, 4>(ctx, img, out, halo, N, H, W, r, signed_out, 0.f, nullptr, taps, (halo && mask_per_image) ? (size_t)H * W : 0);
+            // (no streaming kernel for this radius: every image through the tile kernels; the halo planes of images without
+            // holes were not written when only the selected ones were made -- they are made now)
+            if (d_sel) rc = launch_tile<T, 2>(ctx, (const T*)nullptr, halo, nullptr, N, H, W, r_halo, 1, ptp_halo, mask, taps_halo, (size_t)H * W);
+            if (!rc) rc = launch_tile<T, 4>(ctx, img, out, halo, N, H, W, r, signed_out, 0.f, nullptr, taps, (halo && mask_per_image) ? (size_t)H * W : 0);
         }
     }
-    if (halo) {
+    if (halo || d_sel) {
         hipStreamSynchronize(ctx->stream);
-        hipFree(halo);
+        if (halo) hipFree(halo);
+        if (d_sel) fb_free(ctx, d_sel);
     }
     return rc;
 }
