@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--size', type=int, default=8192)
     ap.add_argument('--mesh-size', type=float, default=100.0)
+    ap.add_argument('--profile', action='store_true', help='cProfile of a third repetition')
     args = ap.parse_args()
     S = args.size
     rng = np.random.default_rng(0)
@@ -38,12 +39,20 @@ def main():
         meshes.append(Mesh(v, Delaunay(v).simplices.astype(np.int32), uid=k))
     images = [renderer.ResidentImage(base), renderer.ResidentImage(img1)]
     print(f'sections {S}x{S}, meshes {meshes[0].num_triangles} / {meshes[1].num_triangles} triangles')
-    for rep in range(2):
+    for rep in range(3 if args.profile else 2):
         m0, m1 = meshes[0].copy(), meshes[1].copy()
         trace = []
+        prof = None
+        if args.profile and rep == 2:
+            import cProfile
+            prof = cProfile.Profile(); prof.enable()
         t0 = time.perf_counter()
         xy0, xy1, w, strain = matcher.section_matcher(m0, m1, images[0], images[1], spacings=[280, 70], conf_thresh=0.3, residue_len=3.0, trace=trace)
         dt = time.perf_counter() - t0
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof).sort_stats('tottime').print_stats(22)
         ex, ey = field(xy1[:, 0], xy1[:, 1])
         err = np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)
         print(f'rep {rep}: {dt:.2f} s, rounds {[(r["blocks"], r["kept"], round(r["max_dis"], 2), r["solve"].get("iters")) for r in trace]}, '
