@@ -32,7 +32,13 @@
 
 namespace {
 
-constexpr int kPfaN = 75, kPfaThreads = 320;
+#ifndef FB_PFA_THREADS
+#define FB_PFA_THREADS 256
+#endif
+#ifndef FB_PFA_WPE
+#define FB_PFA_WPE 3
+#endif
+constexpr int kPfaN = 75, kPfaThreads = FB_PFA_THREADS;
 constexpr int kPfaSlots = kPfaN * kPfaN;          // complex slots of the tile
 constexpr int kBlkStrideP = 9;
 
@@ -118,11 +124,10 @@ __device__ __forceinline__ int pfa_digits(int n) {        // slot of sample n al
 
 // AFF: image 1 is gathered through a per-block affine map (prm.aff)
 template <bool AFF>
-__global__ __launch_bounds__(kPfaThreads) void ncc_pfa75(const PfaParams prm) {
+__global__ __launch_bounds__(kPfaThreads) __attribute__((amdgpu_waves_per_eu(FB_PFA_WPE, FB_PFA_WPE))) void ncc_pfa75(const PfaParams prm) {
     __shared__ __attribute__((aligned(16))) f2 tile[kPfaSlots];
     __shared__ float red[16];
     __shared__ int red_idx;
-    __shared__ unsigned short tab[kPfaN + 1];
     const int n = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -144,47 +149,49 @@ __global__ __launch_bounds__(kPfaThreads) void ncc_pfa75(const PfaParams prm) {
         s1 = prm.img1 + (size_t)n * h1 * w1;
         pitch0 = w0; pitch1 = w1; maxy0 = h0 - 1; maxx0 = w0 - 1; maxy1 = h1 - 1; maxx1 = w1 - 1;
     }
-    // ---- packed load z = img0 + i img1, zero padded (matcher.py:63-64): thread = column x, rows yg, yg + 4, ...; branch-free
-    //      (clamped address + select) so that all the rows of a thread are in flight together
-    constexpr int kRowsPer = 19;                   // ceil(75 / 4)
-    const int yg = (tid * 13982) >> 20, x = tid - 75 * yg;          // tid / 75, tid % 75 (tid < 320)
-    const bool act = tid < 300;
+    // ---- packed load z = img0 + i img1, zero padded (matcher.py:63-64): thread = column x, rows yg, yg + 3, ... (25 of them).
+    //      The rows of the block that exist in the image are the records of a buffer descriptor (wave-uniform), so a row
+    //      outside the block or the image is dropped by the range check of the load and reads as zero: one address add per
+    //      element, nothing else; a column outside them gets an offset that is out of range on every row.
+    constexpr int kYG = 3, kRowsPer = kPfaN / kYG;
+    static_assert(kPfaThreads >= kYG * kPfaN, "one thread per (column, row group)");
+    const int yg = (tid >= 75) + (tid >= 150) + (tid >= 225), x = tid - 75 * yg;
+    const bool act = tid < kYG * kPfaN;
     float a[kRowsPer], b[kRowsPer];
     {
-        const int gx0 = ox0 + x, gx1 = ox1 + x;
+        const int ylo0 = max(0, -oy0), nrow0 = max(min(h0, maxy0 + 1 - oy0) - ylo0, 0);
+        const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s0 + (ptrdiff_t)(oy0 + ylo0) * pitch0), 0, nrow0 * pitch0 * 4, 0x00020000);
+        const int gx0 = ox0 + x;
         const bool vx0 = act && x < w0 && gx0 >= 0 && gx0 <= maxx0;
-        const bool vx1 = act && x < w1 && gx1 >= 0 && gx1 <= maxx1;
-        const int cx0 = min(max(gx0, 0), maxx0), cx1 = min(max(gx1, 0), maxx1);
+        const int vo0 = vx0 ? ((yg - ylo0) * pitch0 + gx0) * 4 : (int)0x80000000;
+        const int st0 = kYG * pitch0 * 4;
+#pragma unroll
+        for (int j = 0; j < kRowsPer; ++j) a[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs0, vo0 + j * st0, 0, 0));
         if (AFF) {
             // image 1 through the (deformed, affine-approximated) mesh: bilinear gather, zero outside the image.  One sample
             // at a time (double precision map, four taps each), parked in the thread's own words of the tile
             float* park = reinterpret_cast<float*>(tile) + tid;
             const double* prm_aff = prm.aff + (size_t)n * FB_AFFINE_STRIDE;
+            const bool v1x = act && x < w1;
 #pragma unroll 1
             for (int j = 0; j < kRowsPer; ++j) {
-                const int y = yg + 4 * j;
-                park[j * kPfaThreads] = fb_sample_affine(s1, IH1, IW1, prm_aff, min(x, w1 - 1), min(min(y, kPfaN - 1), h1 - 1));
+                const int y = yg + kYG * j;
+                const float vb = fb_sample_affine(s1, IH1, IW1, prm_aff, min(x, w1 - 1), min(y, h1 - 1));
+                park[j * kPfaThreads] = (v1x && y < h1) ? vb : 0.f;
             }
-        }
 #pragma unroll
-        for (int j = 0; j < kRowsPer; ++j) {
-            const int y = yg + 4 * j;
-            const int gy0 = oy0 + y, gy1 = oy1 + y;
-            const bool v0 = vx0 && y < h0 && gy0 >= 0 && gy0 <= maxy0;
-            const float va = s0[(size_t)min(max(gy0, 0), maxy0) * pitch0 + cx0];
-            float vb;
-            bool v1;
-            if (AFF) {
-                v1 = act && x < w1 && y < h1;
-                vb = reinterpret_cast<const float*>(tile)[j * kPfaThreads + tid];
-            } else {
-                v1 = vx1 && y < h1 && gy1 >= 0 && gy1 <= maxy1;
-                vb = s1[(size_t)min(max(gy1, 0), maxy1) * pitch1 + cx1];
-            }
-            a[j] = v0 ? va : 0.f; b[j] = v1 ? vb : 0.f;
+            for (int j = 0; j < kRowsPer; ++j) b[j] = park[j * kPfaThreads];
+        } else {
+            const int ylo1 = max(0, -oy1), nrow1 = max(min(h1, maxy1 + 1 - oy1) - ylo1, 0);
+            const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 + (ptrdiff_t)(oy1 + ylo1) * pitch1), 0, nrow1 * pitch1 * 4, 0x00020000);
+            const int gx1 = ox1 + x;
+            const bool vx1 = act && x < w1 && gx1 >= 0 && gx1 <= maxx1;
+            const int vo1 = vx1 ? ((yg - ylo1) * pitch1 + gx1) * 4 : (int)0x80000000;
+            const int st1 = kYG * pitch1 * 4;
+#pragma unroll
+            for (int j = 0; j < kRowsPer; ++j) b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, vo1 + j * st1, 0, 0));
         }
     }
-    if (tid < kPfaN) tab[tid] = (unsigned short)pfa_digits(tid);
     if (tid == 0) red_idx = 0x7fffffff;
     float m0 = 0.f, m1 = 0.f;
 #pragma unroll
@@ -208,11 +215,16 @@ __global__ __launch_bounds__(kPfaThreads) void ncc_pfa75(const PfaParams prm) {
     }
     {
         const float2 sc = pack_scales(mm2.x, mm2.y);
-        const int xs = act ? (int)tab[x] : 0;
+        if (sc.x != 1.f || sc.y != 1.f) {
 #pragma unroll
-        for (int j = 0; j < kRowsPer; ++j) {
-            const int y = yg + 4 * j;
-            if (act && y < kPfaN) tile[(int)tab[y] * kPfaN + xs] = (f2){a[j] * sc.x, b[j] * sc.y};
+            for (int j = 0; j < kRowsPer; ++j) { a[j] *= sc.x; b[j] *= sc.y; }
+        }
+        // row yg + 3 j sits in row slot 25 yg + (17 yg + j) mod 25 (51 = 1 mod 25): consecutive slots with one wrap
+        if (act) {
+            const int c = 17 * yg - 25 * (yg == 2);
+            f2* q = tile + (25 * yg + c) * kPfaN + pfa_digits(x);
+#pragma unroll
+            for (int j = 0; j < kRowsPer; ++j) (j >= 25 - c ? q - 25 * kPfaN : q)[j * kPfaN] = (f2){a[j], b[j]};
         }
     }
     __syncthreads();
@@ -241,10 +253,11 @@ __global__ __launch_bounds__(kPfaThreads) void ncc_pfa75(const PfaParams prm) {
     }
     __syncthreads();
     // ---- 3 x 3 forward, pointwise products (matcher.py:65, 114), 3 x 3 inverse: item = the blocks of (y2, x2) and (-y2, -x2)
-    if (tid < 313) {
+#pragma unroll 1
+    for (int it = tid; it < 313; it += kPfaThreads) {
         int y2, x2;
-        if (tid < 300) { const int q = (tid * 1311) >> 15; y2 = 1 + q; x2 = tid - 25 * q; }
-        else { y2 = 0; x2 = tid - 300; }
+        if (it < 300) { const int q = (it * 1311) >> 15; y2 = 1 + q; x2 = it - 25 * q; }
+        else { y2 = 0; x2 = it - 300; }
         const int y2n = y2 ? 25 - y2 : 0, x2n = x2 ? 25 - x2 : 0;
         f2* pa = tile + y2 * kPfaN + x2;
         f2* pb = tile + y2n * kPfaN + x2n;
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(kPfaThreads) void ncc_pfa75(const PfaParams prm) {
             float ct[9];
             for (int j = 0; j < 9; ++j) {
                 const int yy = (py + (j / 3 - 1) + kPfaN) % kPfaN, xx = (px + (j % 3 - 1) + kPfaN) % kPfaN;
-                ct[j] = tf[2 * ((int)tab[yy] * kPfaN + (int)tab[xx])];
+                ct[j] = tf[2 * (pfa_digits(yy) * kPfaN + pfa_digits(xx))];
             }
             const float tx = (ct[5] - ct[3]) / 2.f;
             const float ty = (ct[7] - ct[1]) / 2.f;
