@@ -146,7 +146,7 @@ int fb_ncc_small_launch(fb_ctx* ctx, const float* img0, const float* img1, int N
 // register-resident 75 x 75 form of the on-chip class (fb_ncc_pfa.hip); same arguments as fb_ncc_small_launch_ex
 int fb_ncc_pfa_supported(int Fh, int Fw, int conf_mode);
 int fb_ncc_pfa_launch(fb_ctx* ctx, const float* img0, const float* img1, int N, int H0, int W0, int H1, int W1, const int* blk,
-                      int IH0, int IW0, int IH1, int IW1, int subpixel, int conf_mode, double* dx, double* dy, float* conf,
+                      int IH0, int IW0, int IH1, int IW1, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf,
                       const double* aff1);
 // ---- affine patch gather (the affine-approximated branch of MeshRenderer.crop_field, renderer.py:419-451, 499-511,
 // followed by common.render_by_subregions -> cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0), common.py:218-350).

@@ -330,7 +330,7 @@ int fb_ncc_small_launch_ex(fb_ctx* ctx, const float* img0, const float* img1, in
                            int IH0, int IW0, int IH1, int IW1, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy,
                            float* conf, const double* aff1) {
     if (fb_ncc_pfa_supported(Fh, Fw, conf_mode))
-        return fb_ncc_pfa_launch(ctx, img0, img1, N, H0, W0, H1, W1, blk, IH0, IW0, IH1, IW1, subpixel, conf_mode, dx, dy, conf, aff1);
+        return fb_ncc_pfa_launch(ctx, img0, img1, N, H0, W0, H1, W1, blk, IH0, IW0, IH1, IW1, Fh, Fw, subpixel, conf_mode, dx, dy, conf, aff1);
     SmallParams p;
     p.N = N; p.Fh = Fh; p.Fw = Fw; p.Sw = Fw / 2 + 1; p.RS = small_pitch(Fw);
     p.H0 = H0; p.W0 = W0; p.H1 = H1; p.W1 = W1;

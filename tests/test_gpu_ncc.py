@@ -63,7 +63,11 @@ def _pairs(rng, n, s0, s1, maxshift):
 
 
 @pytest.mark.parametrize('shape,n,pad', [
-    (((75, 73), (75, 73)), 385, False),     # the 4k-pair fine class, unpadded round
+    (((75, 73), (75, 73)), 385, False),     # the 4k-pair fine class, unpadded round: 75 x 75 (register-resident kernel, fb_ncc_pfa.hip)
+    (((75, 71), (75, 71)), 200, False),     # ... after a translation of more than 5 px: 75 x 72
+    (((72, 75), (72, 75)), 200, False),     # ... of an up-down pair: 72 x 75
+    (((71, 70), (71, 70)), 120, False),     # 72 x 72
+    (((75, 70), (73, 72)), 60, False),      # unequal blocks, 75 x 72
     (((75, 73), (75, 73)), 64, True),       # padded 150 x 150
     (((74, 72), (67, 75)), 33, True),       # README config, unequal blocks
     (((280, 280), (280, 280)), 16, True),   # alignment spacing 400
@@ -110,7 +114,7 @@ def test_xcorr_compile_time_mixed_radix_class(fb, s0, s1, n, pad):
         np.testing.assert_allclose(got[2], gen[2], atol=2e-5)
 
 
-@pytest.mark.parametrize('shape,pad', [((75, 73), False), ((75, 73), True), ((70, 70), True), ((256, 120), True), ((150, 150), False), ((280, 280), True)])
+@pytest.mark.parametrize('shape,pad', [((75, 73), False), ((75, 72), False), ((70, 75), False), ((72, 71), False), ((75, 73), True), ((70, 70), True), ((256, 120), True), ((150, 150), False), ((280, 280), True)])
 def test_xcorr_one_image_almost_blank(fb, shape, pad):
     """a block one side of which is almost blank (a masked or saturated region, a window that only grazes the texture): the
     reference transforms the two images apart (matcher.py:63-64) and its answer does not depend on the magnitude of either;
@@ -242,7 +246,7 @@ def test_area_downsample(fb):
         np.testing.assert_array_equal(got, ncc_ref.area_downsample2(img))
 
 
-@pytest.mark.parametrize('bh,bw,pad', [(75, 73, False), (75, 73, True), (250, 247, True)])
+@pytest.mark.parametrize('bh,bw,pad', [(75, 73, False), (75, 71, False), (72, 75, False), (70, 72, False), (75, 73, True), (250, 247, True)])
 def test_blocks_affine_gather_vs_oracle(fb, bh, bw, pad):
     """fb_ncc_blocks_affine_dev: image 1 sampled through a per-block affine map with cv2.remap's bilinear rule (oracle
     restatement, unpinned) -- on-chip kernel, generic streaming kernels (150 x 150) and power-of-two kernels (512 x 512)"""
@@ -289,6 +293,81 @@ def test_blocks_affine_gather_vs_oracle(fb, bh, bw, pad):
     _check(got, exp)
     assert np.median(exp[2]) > 0.5                       # the blocks do match
     for b in (d0, d1, dblk, daff, out):
+        b.free()
+
+
+@pytest.mark.parametrize('bh,bw', [(75, 73), (75, 70), (71, 75), (72, 72), (60, 50)])
+def test_blocks_crop_across_the_image_border_vs_oracle(fb, bh, bw):
+    """fb_ncc_blocks_dev (crop mode, the fine rounds of the strip matcher): windows of both images that stick out of their
+    image on every side are zero there (matcher.py:63-64 pads with zeros; the register-resident kernel gets them from the range
+    check of its buffer loads), unequal window sizes inside one launch"""
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(bh * 100 + bw)
+    n_img, IH, IW = 3, 300, 260
+    from scipy.ndimage import gaussian_filter
+    base = np.stack([gaussian_filter(rng.standard_normal((IH + 40, IW + 40)), 1.2) for _ in range(n_img)]).astype(np.float32)
+    img0 = np.ascontiguousarray(base[:, 20:20 + IH, 20:20 + IW]); img1 = np.ascontiguousarray(base[:, 18:18 + IH, 23:23 + IW])
+    N = 40
+    blk = np.zeros((N, 9), dtype=np.int32)
+    c0 = np.zeros((N, bh, bw), np.float32); c1 = np.zeros((N, bh, bw), np.float32)
+    for k in range(N):
+        im = k % n_img
+        x0 = int(rng.integers(-30, IW - bw + 30)); y0 = int(rng.integers(-30, IH - bh + 30))
+        x1 = x0 + int(rng.integers(-4, 5)); y1 = y0 + int(rng.integers(-4, 5))
+        h0, w0 = (bh, bw) if k % 5 else (bh - 3, bw - 2)
+        h1, w1 = (bh, bw) if (k % 7 != 3 or k % 5 == 0) else (bh - 1, bw - 4)           # never both windows smaller: the FFT size stays that of (bh, bw)
+        blk[k] = (im, x0, y0, h0, w0, x1, y1, h1, w1)
+        for c, img, xx, yy, hh, ww in ((c0, img0, x0, y0, h0, w0), (c1, img1, x1, y1, h1, w1)):
+            ya, yb, xa, xb = max(yy, 0), min(yy + hh, IH), max(xx, 0), min(xx + ww, IW)
+            if yb > ya and xb > xa:
+                c[k, ya - yy:yb - yy, xa - xx:xb - xx] = img[im, ya:yb, xa:xb]
+    nfl = ncc_ref.next_fast_len
+    Fh, Fw = nfl(bh), nfl(bw)
+    # the reference call block by block (windows of unequal size: matcher.py:59-64 pads both to the common FFT size, 107-110 re-centres)
+    exp = [[], [], []]; exp64 = [[], [], []]
+    for k in range(N):
+        _, _, _, h0, w0, _, _, h1, w1 = blk[k]
+        e = ncc_ref.xcorr_fft(c0[k:k + 1, :h0, :w0], c1[k:k + 1, :h1, :w1], pad=False, subpixel=True)
+        e64 = ncc_ref.xcorr_fft(c0[k:k + 1, :h0, :w0].astype(np.float64), c1[k:k + 1, :h1, :w1].astype(np.float64), pad=False, subpixel=True)
+        for i in range(3):
+            exp[i].append(e[i][0]); exp64[i].append(e64[i][0])
+    exp = tuple(np.asarray(v) for v in exp); exp64 = tuple(np.asarray(v) for v in exp64)
+
+    def check(got, ref):
+        """integer peaks bit-exact; sub-pixel offsets and confidences within 1e-4 where the reference's own float32 arithmetic
+        pins them that well -- a window that is mostly outside its image has a flat peak, and there the float32 reference is
+        itself some 1e-3 px from the double precision answer: the device may be as far from it as a few times that"""
+        np.testing.assert_array_equal(np.round(got[0]), np.round(ref[0])); np.testing.assert_array_equal(np.round(got[1]), np.round(ref[1]))
+        for i in range(3):
+            slack = ATOL + 4 * np.abs(np.asarray(exp[i], np.float64) - exp64[i])
+            bad = np.nonzero(np.abs(np.asarray(got[i], np.float64) - exp64[i]) > slack)[0]
+            assert bad.size == 0, (i, bad, blk[bad], np.asarray(got[i])[bad], exp64[i][bad])
+    d0 = _lib.DeviceBuffer.from_array(img0); d1 = _lib.DeviceBuffer.from_array(img1); dblk = _lib.DeviceBuffer.from_array(blk)
+    out = _lib.DeviceBuffer(N * 20)
+    def run():
+        _lib.check(lib.fb_ncc_blocks_dev(ctx, d0.ptr, d1.ptr, IH, IW, IH, IW, N, dblk.ptr, bh, bw, Fh, Fw, 1, 2, out.ptr, out.offset(8 * N), out.offset(16 * N)))
+        raw = out.to_array((20 * N,), np.uint8)
+        return raw[:8 * N].view(np.float64).copy(), raw[8 * N:16 * N].view(np.float64).copy(), raw[16 * N:].view(np.float32).copy()
+    got = run()
+    check(got, exp)
+    # the run-time mixed-radix on-chip kernel (ncc_small_fused) is the second opinion on every block
+    import os, subprocess, sys, json
+    code = ('import numpy as np, json, sys; from feabas_amd import _lib; lib, ctx = _lib.load(), _lib.ctx(); d = np.load(sys.argv[1]);'
+            'N = int(d["blk"].shape[0]); d0 = _lib.DeviceBuffer.from_array(d["img0"]); d1 = _lib.DeviceBuffer.from_array(d["img1"]); db = _lib.DeviceBuffer.from_array(d["blk"]);'
+            'out = _lib.DeviceBuffer(N * 20); IH, IW = d["img0"].shape[1:]; bh, bw, Fh, Fw = [int(v) for v in d["geo"]];'
+            '_lib.check(lib.fb_ncc_blocks_dev(ctx, d0.ptr, d1.ptr, IH, IW, IH, IW, N, db.ptr, bh, bw, Fh, Fw, 1, 2, out.ptr, out.offset(8 * N), out.offset(16 * N)));'
+            'raw = out.to_array((20 * N,), np.uint8); np.save(sys.argv[2], raw)')
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, 'in.npz'), img0=img0, img1=img1, blk=blk, geo=np.asarray([bh, bw, Fh, Fw]))
+        env = dict(os.environ, FEABAS_HIP_NO_PFA='1', PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, '-c', code, os.path.join(td, 'in.npz'), os.path.join(td, 'out.npy')], check=True, env=env)
+        raw = np.load(os.path.join(td, 'out.npy'))
+    ref = (raw[:8 * N].view(np.float64), raw[8 * N:16 * N].view(np.float64), raw[16 * N:].view(np.float32))
+    check(ref, exp)            # (the same bar for the older kernel)
+    np.testing.assert_array_equal(np.round(got[0]), np.round(ref[0])); np.testing.assert_array_equal(np.round(got[1]), np.round(ref[1]))
+    for b in (d0, d1, dblk, out):
         b.free()
 
 
