@@ -7,6 +7,6 @@ run the arithmetic through the C ABI of ``libfeabas_hip.so``
 """
 from . import _lib                                  # noqa: F401
 from . import constant                              # noqa: F401
-from . import common, matcher, mesh, optimizer      # noqa: F401
+from . import common, material, matcher, mesh, optimizer      # noqa: F401
 
-__all__ = ['common', 'matcher', 'mesh', 'optimizer', 'constant']
+__all__ = ['common', 'material', 'matcher', 'mesh', 'optimizer', 'constant']

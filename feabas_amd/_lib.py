@@ -142,6 +142,7 @@ _PROTOS = {
     'fb_sys_assemble_mesh': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_d, c_d]),
     'fb_sys_assemble_mesh_add': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_d, c_d]),
     'fb_sys_assemble_mesh_materials': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_d]),
+    'fb_sys_assemble_mesh_stretch': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_d]),
     'fb_sys_assemble_links': (c_i, [c_p, c_p, c_p, c_p, c_p]),
     'fb_sys_update_links': (c_i, [c_p, c_p, c_i64, c_p]),
     'fb_sys_form_groups': (c_i, [c_p, c_p, c_i, c_d, c_d, c_p]),

@@ -32,6 +32,13 @@ struct fb_mesh_blk {
     int* d_model = nullptr;          // [T] material model per triangle (optional)
     double* d_nu = nullptr;          // [T]
     float* d_matmult = nullptr;      // [T]
+    double2* d_vinit = nullptr;      // [V] INITIAL gear (area stretch of the stiffness functions, optional)
+    int* d_func = nullptr;           // [T] stiffness function per triangle, -1 = none (optional)
+    int* d_fptr = nullptr;           // tables of the stiffness functions: knots [fptr[k], fptr[k+1])
+    double* d_fx = nullptr;
+    double* d_fy = nullptr;
+    double* d_fmm = nullptr;         // material multiplier of function k in double (non-engineering elements)
+    size_t ftab_cap = 0, fcnt_cap = 0;
     double2* d_vshape = nullptr;     // [V]
     double2* d_vcur = nullptr;       // [V]
     std::vector<double> h_v;         // [V][2] host copy of the shape coordinates of the last assembly (aggregates of the multigrid)
@@ -182,6 +189,62 @@ __device__ __forceinline__ void nonlinear_element_rows(const double2* pts, const
     }
 }
 
+// Stiffness that follows the area stretch of the triangle (Material._stiffness_func, material.py:172-173, 307-308; the
+// "wrinkle" material of configs/default_material_table.yaml:46-56): per triangle a piecewise-linear function
+// (material.asymmetrical_elasticity, material.py:546-551 = scipy interp1d, linear, constant beyond the ends) of
+// (area at the current gear / area at the INITIAL gear) / base, base = the same ratio of the summed |areas| of the linear
+// triangles (mesh.py:2952-2963, 3030-3040).
+struct StretchArgs {
+    const double2* vi = nullptr;      // INITIAL vertices
+    const int* func = nullptr;        // per triangle, -1 = none
+    const int* fptr = nullptr;
+    const double* fx = nullptr;
+    const double* fy = nullptr;
+    const double* fmm = nullptr;
+    double base = 1.0;
+};
+__device__ __forceinline__ double tri_signed_area(const double2 p0, const double2 p1, const double2 p2) {       // common.py:672-676
+#pragma clang fp contract(off)
+    return (p1.x - p0.x) * (p2.y - p1.y) - (p1.y - p0.y) * (p2.x - p1.x);
+}
+__device__ __forceinline__ double stretch_factor(const StretchArgs& sa, int k, double x) {
+#pragma clang fp contract(off)
+    const int o = sa.fptr[k], n = sa.fptr[k + 1] - o;
+    const double* xs = sa.fx + o;
+    const double* ys = sa.fy + o;
+    int hi = 0;
+    while (hi < n && xs[hi] < x) ++hi;                   // searchsorted, side = left
+    hi = min(max(hi, 1), n - 1);
+    const int lo = hi - 1;
+    const double slope = (ys[hi] - ys[lo]) / (xs[hi] - xs[lo]);
+    double y = slope * (x - xs[lo]) + ys[lo];
+    if (x < xs[0]) y = ys[0];
+    if (x > xs[n - 1]) y = ys[n - 1];
+    return y;
+}
+// sums of |area| at the INITIAL and at the current gear over the linear triangles (engineering, no function) and over all:
+// parts[4 b .. 4 b + 3] of block b = {lin cur, lin ini, all cur, all ini}
+__global__ void area_sums_kernel(int T, const int* __restrict__ tri, const double2* __restrict__ vi, const double2* __restrict__ vc,
+                                 const int* __restrict__ model, const int* __restrict__ func, double* __restrict__ parts) {
+    __shared__ double sh[4][kT];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        const double a1 = fabs(tri_signed_area(vc[i0], vc[i1], vc[i2])), a0 = fabs(tri_signed_area(vi[i0], vi[i1], vi[i2]));
+        acc[2] += a1; acc[3] += a0;
+        if ((model ? model[t] : 0) == 0 && func[t] < 0) { acc[0] += a1; acc[1] += a0; }
+    }
+    for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int off = kT / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; ++k) parts[4 * blockIdx.x + k] = sh[k][0];
+}
+
 // thread per vertex row of one mesh: element stiffness blocks of the incident triangles.
 // model == nullptr: every triangle is a linear engineering element with Poisson ratio cnu_u / multiplier mult.
 // Otherwise per-triangle model (0 ENG, 1 SVK, 2 NHK), nu and material multiplier (mesh.py:2914-2933, 2992-3054).
@@ -190,7 +253,7 @@ __global__ void asm_stiffness_kernel(int voff, int V, const int* __restrict__ tr
                                      const float* __restrict__ mult, double c2_u, double cnu_u, double soft, float softf,
                                      const int* __restrict__ model, const double* __restrict__ tri_nu, const float* __restrict__ matmult,
                                      const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ Kval,
-                                     float2* __restrict__ stress) {
+                                     float2* __restrict__ stress, const StretchArgs sa) {
 #pragma clang fp contract(off)
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
@@ -206,7 +269,14 @@ __global__ void asm_stiffness_kernel(int voff, int V, const int* __restrict__ tr
         const double2 pts[3] = {vs[idx[0]], vs[idx[1]], vs[idx[2]]};
         const int md = model ? model[t] : 0;
         float m = mult ? mult[t] : 1.0f;
-        if (matmult) m = m * matmult[t];
+        const int fk = sa.func ? sa.func[t] : -1;
+        double fs = 1.0;                                  // f(area stretch) of the triangle's material
+        if (fk >= 0) {
+            const double2* vcur = vc ? vc : vs;
+            const double st = tri_signed_area(vcur[idx[0]], vcur[idx[1]], vcur[idx[2]]) / tri_signed_area(sa.vi[idx[0]], sa.vi[idx[1]], sa.vi[idx[2]]);
+            fs = stretch_factor(sa, fk, st / sa.base);
+        }
+        if (matmult && (fk < 0 || md == 0)) m = m * matmult[t];
         if (md == 0) {
             // e_i = p_{i+1} - p_{i-1}   (material.py:146-148)
             double ex[3], ey[3];
@@ -219,9 +289,11 @@ __global__ void asm_stiffness_kernel(int voff, int V, const int* __restrict__ tr
             const double nu = tri_nu ? tri_nu[t] : cnu_u;
             const double c2 = tri_nu ? (1.0 - nu) / 2.0 : c2_u;
             // D = diag(m, m, m(1-nu)/2) + nu*m coupling, stored float32 (material.py:174-180)
-            const double d0 = (double)m;
-            const double d2 = (double)(float)((double)m * c2);
-            const double dn = (double)(float)((double)m * nu);
+            // (with a stiffness function the float32 product of the multipliers goes through double before D is stored)
+            const double mf = fk >= 0 ? (double)m * fs : (double)m;
+            const double d0 = (double)(float)mf;
+            const double d2 = (double)(float)(mf * c2);
+            const double dn = (double)(float)(mf * nu);
             const double exa = ex[a], eya = ey[a];
             for (int b = 0; b < 3; ++b) {
                 const int j = find_col(col, lo, hi, voff + idx[b]);
@@ -248,15 +320,29 @@ __global__ void asm_stiffness_kernel(int voff, int V, const int* __restrict__ tr
             }
             float Krow[2][6], Prow[2];
             nonlinear_element_rows(pts, uv, md, tri_nu ? (float)tri_nu[t] : (float)cnu_u, a, Krow, Prow);
-            for (int b = 0; b < 3; ++b) {
-                const int j = find_col(col, lo, hi, voff + idx[b]);
-                if (j < 0) continue;
-                double4 k = reinterpret_cast<double4*>(Kval)[j];
-                k.x += (double)(Krow[0][2 * b] * m); k.y += (double)(Krow[0][2 * b + 1] * m);
-                k.z += (double)(Krow[1][2 * b] * m); k.w += (double)(Krow[1][2 * b + 1] * m);
-                reinterpret_cast<double4*>(Kval)[j] = k;
+            if (fk < 0) {
+                for (int b = 0; b < 3; ++b) {
+                    const int j = find_col(col, lo, hi, voff + idx[b]);
+                    if (j < 0) continue;
+                    double4 k = reinterpret_cast<double4*>(Kval)[j];
+                    k.x += (double)(Krow[0][2 * b] * m); k.y += (double)(Krow[0][2 * b + 1] * m);
+                    k.z += (double)(Krow[1][2 * b] * m); k.w += (double)(Krow[1][2 * b + 1] * m);
+                    reinterpret_cast<double4*>(Kval)[j] = k;
+                }
+                px += (double)(Prow[0] * m); py += (double)(Prow[1] * m);
+            } else {
+                // modifier = material multiplier x f(J) in double, times the mesh multiplier (material.py:307-308, mesh.py:3041)
+                const double mm = (double)m * (sa.fmm[fk] * fs);
+                for (int b = 0; b < 3; ++b) {
+                    const int j = find_col(col, lo, hi, voff + idx[b]);
+                    if (j < 0) continue;
+                    double4 k = reinterpret_cast<double4*>(Kval)[j];
+                    k.x += (double)Krow[0][2 * b] * mm; k.y += (double)Krow[0][2 * b + 1] * mm;
+                    k.z += (double)Krow[1][2 * b] * mm; k.w += (double)Krow[1][2 * b + 1] * mm;
+                    reinterpret_cast<double4*>(Kval)[j] = k;
+                }
+                px += (double)(float)((double)Prow[0] * mm); py += (double)(float)((double)Prow[1] * mm);
             }
-            px += (double)(Prow[0] * m); py += (double)(Prow[1] * m);
         }
     }
     // stress = K_lin (v_cur - v_shape) -> float32, + internal force, * soft   (mesh.py:3068-3082, optimizer.py:822)
@@ -588,6 +674,7 @@ void fb_sys_destroy(fb_ctx* ctx, fb_system* s) {
     for (auto& m : s->meshes) {
         hipFree(m.d_tri); hipFree(m.d_vtptr); hipFree(m.d_vtidx); hipFree(m.d_mult); hipFree(m.d_vshape); hipFree(m.d_vcur);
         hipFree(m.d_model); hipFree(m.d_nu); hipFree(m.d_matmult);
+        hipFree(m.d_vinit); hipFree(m.d_func); hipFree(m.d_fptr); hipFree(m.d_fx); hipFree(m.d_fy); hipFree(m.d_fmm);
     }
     hipFree(s->d_nodes); hipFree(s->d_vmptr); hipFree(s->d_vmidx); hipFree(s->d_bary); hipFree(s->d_w); hipFree(s->d_rxy);
     hipFree(s->d_glambda); hipFree(s->d_gstat); hipFree(s->d_Kscr); hipFree(s->d_sscr); hipFree(s->d_K); hipFree(s->d_Cacc); hipFree(s->d_C); hipFree(s->d_rhs); hipFree(s->d_stress); hipFree(s->d_parts);
@@ -794,9 +881,19 @@ int fb_sys_pattern(fb_ctx* ctx, fb_system* s, int64_t* browptr, int32_t* bcol) {
     return FB_OK;
 }
 
+struct StretchHost {             // host view of the stiffness functions of one assembly (fb_sys_assemble_mesh_stretch)
+    const double* v_init = nullptr;
+    const int32_t* tri_func = nullptr;
+    int nfunc = 0;
+    const int32_t* func_ptr = nullptr;
+    const double* func_x = nullptr;
+    const double* func_y = nullptr;
+    const double* func_matmult = nullptr;
+};
+
 static int assemble_mesh_impl(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur, const float* tri_mult,
                               double nu, double soft, const int32_t* tri_model, const double* tri_nu, const float* tri_matmult,
-                              bool accumulate = false) {
+                              bool accumulate = false, const StretchHost* sh = nullptr) {
     FB_CHECK_ARG(ctx, s && s->finalized && mesh_id >= 0 && mesh_id < (int)s->meshes.size() && v_shape);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     fb_mesh_blk& m = s->meshes[mesh_id];
@@ -812,13 +909,38 @@ static int assemble_mesh_impl(fb_ctx* ctx, fb_system* s, int mesh_id, const doub
         if ((rc = upload(ctx, &m.d_nu, tri_nu, (size_t)m.T))) return rc;
         if ((rc = upload(ctx, &m.d_matmult, tri_matmult, (size_t)m.T))) return rc;
     }
+    StretchArgs sa;
+    if (sh) {
+        int rc;
+        const size_t nk = (size_t)sh->func_ptr[sh->nfunc];
+        if (m.ftab_cap < nk) { hipFree(m.d_fx); hipFree(m.d_fy); m.d_fx = m.d_fy = nullptr; m.ftab_cap = nk; }
+        if (m.fcnt_cap < (size_t)sh->nfunc) { hipFree(m.d_fptr); hipFree(m.d_fmm); m.d_fptr = nullptr; m.d_fmm = nullptr; m.fcnt_cap = (size_t)sh->nfunc; }
+        if ((rc = upload(ctx, &m.d_vinit, reinterpret_cast<const double2*>(sh->v_init), (size_t)m.V))) return rc;
+        if ((rc = upload(ctx, &m.d_func, sh->tri_func, (size_t)m.T))) return rc;
+        if ((rc = upload(ctx, &m.d_fptr, sh->func_ptr, (size_t)sh->nfunc + 1))) return rc;
+        if ((rc = upload(ctx, &m.d_fx, sh->func_x, nk))) return rc;
+        if ((rc = upload(ctx, &m.d_fy, sh->func_y, nk))) return rc;
+        if ((rc = upload(ctx, &m.d_fmm, sh->func_matmult, (size_t)sh->nfunc))) return rc;
+        // base ratio of the area stretch: summed |areas| of the linear triangles (all triangles if there is none), mesh.py:2952-2958
+        const int g = std::min(256, std::max(1, fb_cdiv(m.T, kT)));
+        if (!s->d_parts) FB_HIP(ctx, hipMalloc((void**)&s->d_parts, sizeof(double) * 2 * 1024));
+        hipLaunchKernelGGL(area_sums_kernel, dim3(g), dim3(kT), 0, ctx->stream, m.T, m.d_tri, m.d_vinit, v_cur ? m.d_vcur : m.d_vshape,
+                           tri_model ? m.d_model : (const int*)nullptr, m.d_func, s->d_parts);
+        std::vector<double> hp(4 * (size_t)g);
+        FB_HIP(ctx, hipMemcpyAsync(hp.data(), s->d_parts, sizeof(double) * 4 * g, hipMemcpyDeviceToHost, ctx->stream));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double acc[4] = {0, 0, 0, 0};
+        for (int i = 0; i < g; ++i) for (int k = 0; k < 4; ++k) acc[k] += hp[4 * i + k];
+        sa.base = acc[1] > 0.0 ? acc[0] / acc[1] : acc[2] / acc[3];
+        sa.vi = m.d_vinit; sa.func = m.d_func; sa.fptr = m.d_fptr; sa.fx = m.d_fx; sa.fy = m.d_fy; sa.fmm = m.d_fmm;
+    }
     {
         FB_PROF(ctx, "fem_asm_stiffness");
         hipLaunchKernelGGL(asm_stiffness_kernel, dim3(fb_cdiv(m.V, kT)), dim3(kT), 0, ctx->stream, m.voff, m.V, m.d_tri, m.d_vtptr,
                            m.d_vtidx, m.d_vshape, v_cur ? m.d_vcur : (const double2*)nullptr, tri_mult ? m.d_mult : (const float*)nullptr,
                            (1.0 - nu) / 2.0, nu, soft, (float)soft, tri_model ? m.d_model : (const int*)nullptr,
                            tri_model ? m.d_nu : (const double*)nullptr, tri_model ? m.d_matmult : (const float*)nullptr,
-                           s->M->d.rowptr, s->M->d.col, accumulate ? s->d_Kscr : s->d_K, accumulate ? s->d_sscr : s->d_stress);
+                           s->M->d.rowptr, s->M->d.col, accumulate ? s->d_Kscr : s->d_K, accumulate ? s->d_sscr : s->d_stress, sa);
         if (accumulate)
             hipLaunchKernelGGL(add_rows_kernel, dim3(fb_cdiv(m.V, kT)), dim3(kT), 0, ctx->stream, m.voff, m.V, s->M->d.rowptr, s->d_Kscr, s->d_sscr,
                                s->d_K, s->d_stress);
@@ -854,6 +976,26 @@ int fb_sys_assemble_mesh_materials(fb_ctx* ctx, fb_system* s, int mesh_id, const
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, tri_model && tri_nu && tri_matmult);
     return assemble_mesh_impl(ctx, s, mesh_id, v_shape, v_cur, tri_mult, 0.0, soft, tri_model, tri_nu, tri_matmult);
+}
+
+int fb_sys_assemble_mesh_stretch(fb_ctx* ctx, fb_system* s, int mesh_id, const double* v_shape, const double* v_cur, const double* v_init,
+                                 const float* tri_mult, const int32_t* tri_model, const double* tri_nu, const float* tri_matmult,
+                                 const int32_t* tri_func, int nfunc, const int32_t* func_ptr, const double* func_x, const double* func_y,
+                                 const double* func_matmult, double soft) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, s && s->finalized && mesh_id >= 0 && mesh_id < (int)s->meshes.size());
+    FB_CHECK_ARG(ctx, tri_model && tri_nu && tri_matmult && v_init && tri_func && nfunc > 0 && func_ptr && func_x && func_y && func_matmult);
+    FB_CHECK_ARG(ctx, func_ptr[0] == 0);
+    for (int k = 0; k < nfunc; ++k) {
+        FB_CHECK_ARG(ctx, func_ptr[k + 1] - func_ptr[k] >= 2);                   // interp1d needs two knots
+        for (int i = func_ptr[k] + 1; i < func_ptr[k + 1]; ++i) FB_CHECK_ARG(ctx, func_x[i] > func_x[i - 1]);
+    }
+    const int T = s->meshes[mesh_id].T;
+    for (int t = 0; t < T; ++t) FB_CHECK_ARG(ctx, tri_func[t] >= -1 && tri_func[t] < nfunc);
+    StretchHost sh;
+    sh.v_init = v_init; sh.tri_func = tri_func; sh.nfunc = nfunc; sh.func_ptr = func_ptr; sh.func_x = func_x; sh.func_y = func_y;
+    sh.func_matmult = func_matmult;
+    return assemble_mesh_impl(ctx, s, mesh_id, v_shape, v_cur, tri_mult, 0.0, soft, tri_model, tri_nu, tri_matmult, false, &sh);
 }
 
 int fb_sys_assemble_links(fb_ctx* ctx, fb_system* s, const double* bary6, const float* w, const double* rxy) {

@@ -443,16 +443,19 @@ _MODEL_NAMES = ('MATERIAL_MODEL_ENG', 'MATERIAL_MODEL_SVK', 'MATERIAL_MODEL_NHK'
 
 
 def _material_entries(mesh):
-    """(material_ids [T] int8, table dict) of a mesh: one entry per distinct (model, Poisson ratio, multiplier); the
-    mesh-wide material is 'default' (uid 0, material.py:333-342)."""
+    """(material_ids [T] int8, table dict) of a mesh: one entry per distinct (model, Poisson ratio, multiplier, stiffness
+    function); the mesh-wide material is 'default' (uid 0, material.py:333-342).  A stiffness function is written the way the
+    reference's Material.to_dict does (material.py:106-113): factory name + the knots of the table."""
     nt = mesh.num_triangles
-    base = (0, float(mesh.poisson_ratio), float(mesh.material_multiplier))
+    base = (0, float(mesh.poisson_ratio), float(mesh.material_multiplier), -1)
+    tri_func = getattr(mesh, 'tri_func', None)
     if mesh.tri_model is None:
         combos, inv = [base], np.zeros(nt, dtype=np.int64)
     else:
-        rows = np.stack((mesh.tri_model.astype(np.float64), mesh.tri_nu, mesh.tri_matmult.astype(np.float64)), axis=1)
+        fk = np.full(nt, -1.0) if tri_func is None else tri_func.astype(np.float64)
+        rows = np.stack((mesh.tri_model.astype(np.float64), mesh.tri_nu, mesh.tri_matmult.astype(np.float64), fk), axis=1)
         uniq, inv = np.unique(rows, axis=0, return_inverse=True)
-        combos = [(int(r[0]), float(r[1]), float(r[2])) for r in uniq]
+        combos = [(int(r[0]), float(r[1]), float(r[2]), int(r[3])) for r in uniq]
         inv = np.asarray(inv).reshape(-1)
     order = sorted(range(len(combos)), key=lambda k: (combos[k] != base, k))         # the mesh-wide material first
     if combos[order[0]] != base:
@@ -461,10 +464,15 @@ def _material_entries(mesh):
     table = {}
     for uid, k in enumerate(order):
         uid_of[k] = uid
-        model, nu, mult = combos[k]
-        table['default' if uid == 0 else f'material_{uid}'] = {
-            'enable_mesh': True, 'area_constraint': 1.0, 'render': True, 'render_weight': 1.0, 'type': _MODEL_NAMES[model],
-            'stiffness_multiplier': mult, 'poisson_ratio': nu, 'uid': uid}
+        model, nu, mult, fk = combos[k]
+        entry = {'enable_mesh': True, 'area_constraint': 1.0, 'render': True, 'render_weight': 1.0, 'type': _MODEL_NAMES[model],
+                 'stiffness_multiplier': mult, 'poisson_ratio': nu, 'uid': uid}
+        if fk >= 0:
+            f = mesh.stiffness_funcs[fk]
+            entry['stiffness_multiplier'] = float(mesh.func_matmult[fk])
+            entry['stiffness_func_factory'] = 'feabas.material.asymmetrical_elasticity'
+            entry['stiffness_func_params'] = {'strain': f.strain.tolist(), 'stiffness': f.stiffness.tolist()}
+        table['default' if uid == 0 else f'material_{uid}'] = entry
     return uid_of[inv].astype(np.int8 if len(combos) < 128 else np.int16), table
 
 
@@ -548,13 +556,24 @@ def load_mesh_h5(f, prefix='', cls=None, **kwargs):
         init['poisson_ratio'] = d.get('poisson_ratio', 0.0)
         init['material_multiplier'] = d.get('stiffness_multiplier', 1.0)
         uids = np.unique(ids)
-        if uids.size > 1 or model_of(by_uid[int(uids[0])]) != 0 or int(uids[0]) != int(d.get('uid', 0)):
+        has_func = any(by_uid[int(u)].get('stiffness_func_factory') is not None for u in uids)
+        if uids.size > 1 or model_of(by_uid[int(uids[0])]) != 0 or int(uids[0]) != int(d.get('uid', 0)) or has_func:
             mats = [by_uid[int(u)] for u in ids.ravel()] if uids.size > 8 else None
             pick = (lambda fn, dt: np.array([fn(m) for m in mats], dtype=dt)) if mats is not None else \
                 (lambda fn, dt: np.select([ids.ravel() == u for u in uids], [fn(by_uid[int(u)]) for u in uids]).astype(dt))
             init['tri_model'] = pick(model_of, np.int32)
             init['tri_nu'] = pick(lambda m: m.get('poisson_ratio', 0.0), np.float64)
             init['tri_matmult'] = pick(lambda m: m.get('stiffness_multiplier', 1.0), np.float32)
+            if has_func:
+                # materials with a stiffness function (material.py:60-62): one table per such material
+                from .material import stiffness_func_from_spec
+                fuids = [int(u) for u in uids if by_uid[int(u)].get('stiffness_func_factory') is not None]
+                init['stiffness_funcs'] = [stiffness_func_from_spec(by_uid[u]['stiffness_func_factory'], by_uid[u].get('stiffness_func_params', {})) for u in fuids]
+                init['func_matmult'] = [float(by_uid[u].get('stiffness_multiplier', 1.0)) for u in fuids]
+                tf = np.full(ids.size, -1, dtype=np.int32)
+                for k, u in enumerate(fuids):
+                    tf[ids.ravel() == u] = k
+                init['tri_func'] = tf
     init.update(kwargs)
     mesh = cls(vertices, triangles, **{k: v for k, v in init.items() if k not in ('name', 'epsilon', 'token')})
     for k in ('name', 'epsilon'):

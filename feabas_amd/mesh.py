@@ -47,6 +47,26 @@ class Mesh:
             nt = self.triangles.shape[0]
             self.tri_nu = np.ascontiguousarray(np.broadcast_to(kwargs.get('tri_nu', self.poisson_ratio), (nt,)), dtype=np.float64)
             self.tri_matmult = np.ascontiguousarray(np.broadcast_to(kwargs.get('tri_matmult', self.material_multiplier), (nt,)), dtype=np.float32)
+        # optional stiffness functions (Material._stiffness_func, material.py:128-131): tri_func[t] = index into stiffness_funcs of
+        # the function of triangle t's material, -1 = none; func_matmult[k] = that material's multiplier in double precision
+        tf = kwargs.get('tri_func', None)
+        self.tri_func = None
+        if tf is not None and np.any(np.asarray(tf) >= 0):
+            from .material import stiffness_func_from_spec
+            self.tri_func = np.ascontiguousarray(tf, dtype=np.int32)
+            self.stiffness_funcs = [stiffness_func_from_spec(f) for f in kwargs['stiffness_funcs']]
+            if self.tri_func.max() >= len(self.stiffness_funcs) or self.tri_func.min() < -1:
+                raise ValueError('tri_func names a stiffness function that is not in stiffness_funcs')
+            if self.tri_model is None:
+                nt = self.triangles.shape[0]
+                self.tri_model = np.zeros(nt, dtype=np.int32)
+                self.tri_nu = np.full(nt, self.poisson_ratio, dtype=np.float64)
+                self.tri_matmult = np.full(nt, self.material_multiplier, dtype=np.float32)
+            fm = kwargs.get('func_matmult', None)
+            if fm is None:
+                fm = [float(self.tri_matmult[np.flatnonzero(self.tri_func == k)[0]]) if np.any(self.tri_func == k) else 1.0
+                      for k in range(len(self.stiffness_funcs))]
+            self.func_matmult = np.ascontiguousarray(fm, dtype=np.float64)
         self.resolution = kwargs.get('resolution', 4.0)
         self.locked = kwargs.get('locked', False)
         self.soft_factor = kwargs.get('soft_factor', 1.0)
@@ -111,8 +131,17 @@ class Mesh:
         return self.triangles.shape[0]
 
     @property
-    def is_linear(self):
-        return self.tri_model is None or not np.any(self.tri_model != const.MATERIAL_MODEL_ENG)
+    def is_linear(self):                                   # mesh.py:1563-1568: engineering materials without a stiffness function only
+        return (self.tri_model is None or not np.any(self.tri_model != const.MATERIAL_MODEL_ENG)) and self.tri_func is None
+
+    @property
+    def linear_triangle_mask(self):                        # mesh.py:1571-1580
+        m = np.ones(self.num_triangles, dtype=bool)
+        if self.tri_model is not None:
+            m &= self.tri_model == const.MATERIAL_MODEL_ENG
+        if self.tri_func is not None:
+            m &= self.tri_func < 0
+        return m
 
     @property
     def stiffness_multiplier(self):
@@ -442,10 +471,20 @@ class Mesh:
         d = np.where(s < 1, 1 - s, 1 - 1 / np.where(s == 0, 1, s))
         return np.max(d, axis=-1)
 
-    def effective_stiffness_multiplier(self, gear=None):   # mesh.py:1600-1621 (materials without a stiffness_func)
+    def effective_stiffness_multiplier(self, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING)):   # mesh.py:1600-1621
         if self.tri_model is None:
             return self.stiffness_multiplier * np.float32(self.material_multiplier)
-        return self.stiffness_multiplier * self.tri_matmult
+        if self.tri_func is None:
+            return self.stiffness_multiplier * self.tri_matmult
+        # materials with a stiffness function: x f(area stretch / its median over the linear triangles)
+        J = self.triangle_area_deform(gear=gear)
+        lin = self.linear_triangle_mask
+        J = J / (np.median(J[lin]) if np.any(lin) else np.median(J))
+        modifier = self.tri_matmult.astype(np.float64)
+        for k, f in enumerate(self.stiffness_funcs):
+            sel = self.tri_func == k
+            modifier[sel] = self.func_matmult[k] * f(J[sel])
+        return self.stiffness_multiplier * modifier
 
     def tri_finder(self, pts, gear=None):
         """point -> triangle id (-1 outside).  The reference goes through
@@ -527,6 +566,16 @@ class Mesh:
                           _lib.ptr(self.element_multiplier()), self.poisson_ratio, float(soft)))
         elif add:
             raise NotImplementedError('grouped meshes with non-linear materials')
+        elif self.tri_func is not None:
+            # stiffness follows the area stretch INITIAL -> current gear (mesh.py:2937-2971, 3026-3043)
+            ptr = np.concatenate(([0], np.cumsum([f.strain.size for f in self.stiffness_funcs]))).astype(np.int32)
+            fx = np.concatenate([f.strain for f in self.stiffness_funcs]); fy = np.concatenate([f.stiffness for f in self.stiffness_funcs])
+            v_init = np.ascontiguousarray(self.vertices(const.MESH_GEAR_INITIAL), dtype=np.float64)
+            _lib.check(lib.fb_sys_assemble_mesh_stretch(ctx, sysh, mesh_id, _lib.ptr(v_shape), _lib.ptr(v_cur), _lib.ptr(v_init),
+                                                        _lib.ptr(np.ascontiguousarray(self.stiffness_multiplier, dtype=np.float32)),
+                                                        _lib.ptr(self.tri_model), _lib.ptr(self.tri_nu), _lib.ptr(self.tri_matmult),
+                                                        _lib.ptr(self.tri_func), len(self.stiffness_funcs), _lib.ptr(ptr), _lib.ptr(fx), _lib.ptr(fy),
+                                                        _lib.ptr(self.func_matmult), float(soft)))
         else:
             _lib.check(lib.fb_sys_assemble_mesh_materials(ctx, sysh, mesh_id, _lib.ptr(v_shape), _lib.ptr(v_cur),
                                                           _lib.ptr(np.ascontiguousarray(self.stiffness_multiplier, dtype=np.float32)),

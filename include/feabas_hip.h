@@ -266,6 +266,19 @@ int fb_sys_assemble_mesh_add(fb_ctx* ctx, fb_system* sys, int mesh_id, const dou
 int fb_sys_assemble_mesh_materials(fb_ctx* ctx, fb_system* sys, int mesh_id, const double* v_shape, const double* v_cur,
                                    const float* tri_mult, const int32_t* tri_model, const double* tri_nu,
                                    const float* tri_matmult, double soft);
+/* Materials whose stiffness follows the area stretch of the triangle (Material._stiffness_func: Mesh.
+ * nonlinear_engineering_stiffness_matrix, mesh.py:2937-2971, for engineering elements; the f(J) modifier of material.py:307-308 for the
+ * others; material.asymmetrical_elasticity, material.py:546-551 -- the default "wrinkle" material, default_material_table.yaml:46-56).
+ * As fb_sys_assemble_mesh_materials, plus: v_init [V][2] the INITIAL gear; tri_func [T] the stiffness function of the triangle's
+ * material (-1 = none); function k is piecewise linear through the knots (func_x, func_y)[func_ptr[k] .. func_ptr[k+1]) (x ascending,
+ * >= 2 knots), constant beyond its ends, and is evaluated at (area(v_cur) / area(v_init)) / base, base = sum|area(v_cur)| /
+ * sum|area(v_init)| over the linear triangles (engineering, no function; all triangles if there is none), mesh.py:2952-2963.
+ * func_matmult [nfunc]: the material multiplier of function k's material in double precision (the reference multiplies it in
+ * double for the non-engineering elements; engineering elements take the float32 tri_matmult as without a function). */
+int fb_sys_assemble_mesh_stretch(fb_ctx* ctx, fb_system* sys, int mesh_id, const double* v_shape, const double* v_cur, const double* v_init,
+                                 const float* tri_mult, const int32_t* tri_model, const double* tri_nu, const float* tri_matmult,
+                                 const int32_t* tri_func, int nfunc, const int32_t* func_ptr, const double* func_x, const double* func_y,
+                                 const double* func_matmult, double soft);
 /* bary6: [K][6] = [+B0 | -B1] (Link.shape_matrix_contrib, optimizer.py:114-131); w: [K] float32
  * (weight * residue_weight); rxy: [K][2] residual x1 - x0 (Link.dxy, optimizer.py:248-255) */
 int fb_sys_assemble_links(fb_ctx* ctx, fb_system* sys, const double* bary6, const float* w, const double* rxy);

@@ -879,23 +879,68 @@ def grid_mesh(nx, ny, h=10.0, origin=(0.0, 0.0), diag='alt'):
     return v, tri
 
 
-def mesh_stiffness_mixed(v_shape, v_cur, triangles, tri_mult, model, nu, matmult):
+def stiffness_func_table(x, strain, stiffness):
+    """material.asymmetrical_elasticity (material.py:546-551): scipy.interpolate.interp1d(strain, stiffness, kind='linear',
+    bounds_error=False, fill_value=(stiffness[0], stiffness[-1])) restated: the segment is found with searchsorted (left) clipped
+    to [1, n - 1], y = slope (x - x_lo) + y_lo; below / above the table the first / last stiffness."""
+    xs = np.asarray(strain, dtype=np.float64); ys = np.asarray(stiffness, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    hi = np.clip(np.searchsorted(xs, x), 1, xs.size - 1)
+    lo = hi - 1
+    slope = (ys[hi] - ys[lo]) / (xs[hi] - xs[lo])
+    y = slope * (x - xs[lo]) + ys[lo]
+    y = np.where(x < xs[0], ys[0], y)
+    y = np.where(x > xs[-1], ys[-1], y)
+    return y
+
+
+def area_stretch(v_init, v_cur, triangles, linear_mask):
+    """mesh.py:2952-2963 (= 3030-3040): signed area of every triangle at the current gear over its INITIAL one, over the same
+    ratio of the summed absolute areas of the linear triangles (of all triangles when there is none)."""
+    T = np.asarray(triangles)
+    def signed_area(v):                                                     # common.py:672-676
+        p = np.asarray(v, dtype=np.float64)[T]
+        return 0.5 * cross2d(p[:, 1, :] - p[:, 0, :], p[:, 2, :] - p[:, 0, :])
+    a0, a1 = signed_area(v_init), signed_area(v_cur)
+    if np.any(linear_mask):
+        base = np.sum(np.abs(a1[linear_mask])) / np.sum(np.abs(a0[linear_mask]))
+    else:
+        base = np.sum(np.abs(a1)) / np.sum(np.abs(a0))
+    return (a1 / a0) / base
+
+
+def mesh_stiffness_mixed(v_shape, v_cur, triangles, tri_mult, model, nu, matmult, func=None, tabs=None, v_init=None):
     """mesh.py:3058-3083 for a mesh that mixes linear engineering triangles (model 0, N^T D N path,
     mesh.py:2914-2933) with St-Venant-Kirchhoff / Neo-Hookean triangles (models 1 / 2, element loop of
     mesh.py:2992-3054).  Per-triangle arrays: tri_mult (mesh multiplier, float32), model, nu, matmult
-    (material multiplier).  Returns (K float64 CSR, stress float32)."""
+    (material multiplier).  func (per triangle, -1 = none) indexes tabs = [(strain, stiffness), ...]: materials whose
+    stiffness is multiplied by a function of the triangle's area stretch INITIAL -> current (v_init; engineering triangles
+    through nonlinear_engineering_stiffness_matrix, mesh.py:2937-2971, the others through the f(J) modifier of
+    material.py:307-308).  Returns (K float64 CSR, stress float32)."""
     v_shape = np.asarray(v_shape, dtype=np.float64)
     v_cur = np.asarray(v_cur, dtype=np.float64)
     T = np.asarray(triangles)
     ndof = 2 * v_shape.shape[0]
     dxy = v_cur - v_shape
     K = sparse.csr_matrix((ndof, ndof), dtype=np.float64)
+    if func is None:
+        func = np.full(T.shape[0], -1, dtype=np.int32)
+    func = np.asarray(func)
+    fac = np.ones(T.shape[0], dtype=np.float64)
+    if np.any(func >= 0):
+        st = area_stretch(v_shape if v_init is None else v_init, v_cur, T, (model == MODEL_ENG) & (func < 0))
+        for k, (xs, ys) in enumerate(tabs):
+            fac[func == k] = stiffness_func_table(st[func == k], xs, ys)
     lin = model == MODEL_ENG
     for nu_v in np.unique(nu[lin]):
         for mm_v in np.unique(matmult[lin & (nu == nu_v)]):
-            sel = np.flatnonzero(lin & (nu == nu_v) & (matmult == mm_v))
-            N = eng_shape_matrix(v_shape[T[sel]], T[sel], ndof)
-            K = K + eng_stiffness_from_shape(N, multiplier=tri_mult[sel], nu=float(nu_v), mat_multiplier=float(mm_v))
+            for has_f in (False, True):                                    # linear materials first (mesh.py:3060-3067)
+                sel = np.flatnonzero(lin & (nu == nu_v) & (matmult == mm_v) & ((func >= 0) == has_f))
+                if sel.size == 0:
+                    continue
+                N = eng_shape_matrix(v_shape[T[sel]], T[sel], ndof)
+                K = K + eng_stiffness_from_shape(N, multiplier=tri_mult[sel], nu=float(nu_v), mat_multiplier=float(mm_v),
+                                                 stretch_factor=fac[sel] if has_f else None)
     stress = K.dot(dxy.ravel()).astype(np.float32)                        # mesh.py:3068-3072
     Td = np.repeat(T * 2, 2, axis=-1)
     Td[:, 1::2] += 1
@@ -907,7 +952,7 @@ def mesh_stiffness_mixed(v_shape, v_cur, triangles, tri_mult, model, nu, matmult
                 B, areas = element_shape_B(v_shape[T[sel]])
                 uv = dxy[T[sel]].reshape(-1, 6)
                 Ke, Pe = element_stiffness(B, areas, uv, md, nu=float(nu_v))
-                mm = tri_mult[sel].reshape(-1, 1, 1) * float(mm_v)       # mesh.py:3041
+                mm = tri_mult[sel].reshape(-1, 1, 1) * (float(mm_v) * fac[sel].reshape(-1, 1, 1))       # mesh.py:3041, material.py:307-308
                 i1 = np.tile(Td[sel].reshape(-1, 1, 6), (1, 6, 1))
                 i2 = np.swapaxes(i1, 1, 2)
                 K = K + sparse.csr_matrix(((Ke * mm).ravel(), (i1.ravel(), i2.ravel())), shape=(ndof, ndof))
@@ -916,7 +961,7 @@ def mesh_stiffness_mixed(v_shape, v_cur, triangles, tri_mult, model, nu, matmult
 
 
 def newton_fixed_point(m_locked, m_free, links, tri_mult, model, nu, matmult, stiffness_lambda=1.0, crosslink_lambda=1.0,
-                       max_steps=30, tol=1e-6):
+                       max_steps=30, tol=1e-6, func=None, tabs=None):
     """Fixed point of SLM.optimize_Newton_Raphson (optimizer.py:1440-1544) for one free mesh with non-linear elements
     linked to a locked one, with fixed (positive) lambdas: every step re-assembles the tangent stiffness and the internal
     force at the current MOVING gear (mesh.py:2937-3083), solves the tangent system exactly (sparse LU instead of the
@@ -927,7 +972,8 @@ def newton_fixed_point(m_locked, m_free, links, tri_mult, model, nu, matmult, st
     t = m_free.triangles
     costs = []
     for _ in range(max_steps):
-        K, stress = mesh_stiffness_mixed(m_free.vertices(GEAR_FIXED), m_free.vertices(GEAR_MOVING), t, tri_mult, model, nu, matmult)
+        K, stress = mesh_stiffness_mixed(m_free.vertices(GEAR_FIXED), m_free.vertices(GEAR_MOVING), t, tri_mult, model, nu, matmult,
+                                         func=func, tabs=tabs, v_init=m_free.vertices(GEAR_INITIAL))
         C, rhs = crosslink_terms([m_locked, m_free], links, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING)
         A = (stiffness_lambda * m_free.soft_factor) * K + crosslink_lambda * C.astype(np.float64)
         b = crosslink_lambda * rhs - (stiffness_lambda * m_free.soft_factor) * stress.astype(np.float64)

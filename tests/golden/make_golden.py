@@ -696,8 +696,119 @@ def g18_locked_neighbours():
     np.savez_compressed(os.path.join(OUT, 'g18_locked_neighbours.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G19
+def g19_area_stretch():
+    """Materials whose stiffness follows the area stretch of the triangle (stiffness_func): Mesh.stiffness_matrix through
+    nonlinear_engineering_stiffness_matrix (mesh.py:2937-2971; the default "wrinkle" material of
+    configs/default_material_table.yaml:46-56, material.asymmetrical_elasticity, material.py:546-551) and the f(J) factor of
+    St-Venant-Kirchhoff / Neo-Hookean elements (material.py:242, 262, 307-308), on a mesh that is compressed in one half and
+    stretched in the other; plus SLM.optimize_Newton_Raphson on it (a mesh with such a material is non-linear: K is
+    re-assembled every step)."""
+    rng = np.random.default_rng(1919)
+    v, t = grid(14, 10, 10.0)
+    ctr = v[t].mean(axis=1)
+    wr = dict(strain=[0.0, 0.75, 1.0, 1.01], stiffness=[1.5, 1.0, 0.5, 1.0e-7])          # default_material_table.yaml:54-56
+    tab_full = {'default': dict(material.MATERIAL_DEFAULT),
+                'wrinkle': {'type': const.MATERIAL_MODEL_ENG, 'uid': 7, 'stiffness_multiplier': 0.4, 'poisson_ratio': 0.0,
+                            'stiffness_func_factory': 'feabas.material.asymmetrical_elasticity', 'stiffness_func_params': wr},
+                'fold': {'type': const.MATERIAL_MODEL_ENG, 'uid': 8, 'stiffness_multiplier': 0.9, 'poisson_ratio': 0.3,
+                         'stiffness_func_factory': 'feabas.material.asymmetrical_elasticity',
+                         'stiffness_func_params': dict(strain=[0.2, 0.9, 1.0, 1.3], stiffness=[3.0, 1.2, 1.0, 0.25])},
+                'svkf': {'type': const.MATERIAL_MODEL_SVK, 'uid': 9, 'poisson_ratio': 0.25, 'stiffness_multiplier': 1.3,
+                         'stiffness_func_factory': 'feabas.material.asymmetrical_elasticity',
+                         'stiffness_func_params': dict(strain=[0.0, 0.5, 1.0, 1.2], stiffness=[2.0, 1.0, 0.8, 0.1])},
+                'nhkf': {'type': const.MATERIAL_MODEL_NHK, 'uid': 10, 'stiffness_multiplier': 0.7,
+                         'stiffness_func_factory': 'feabas.material.asymmetrical_elasticity', 'stiffness_func_params': wr}}
+    # a smooth map: compressed on the left (area ratio down to ~0.7), stretched on the right (up to ~1.15), sheared a little
+    L = 130.0
+    sx = 1.0 + 0.16 * np.sin(np.pi * (v[:, 0] / L - 0.5)); sy = 1.0 - 0.06 * np.cos(2 * np.pi * v[:, 1] / 90.0)
+    vmov = np.stack((np.cumsum(np.ones(1)) * 0 + (v[:, 0] - 65) * sx + 65 + 0.8 * np.sin(v[:, 1] / 25), (v[:, 1] - 45) * sy + 45 + 0.5 * np.cos(v[:, 0] / 35)), -1)
+    mult = rng.uniform(0.5, 1.5, t.shape[0]).astype(np.float32)
+    out = {'v': v, 'vmov': vmov, 'mult_in': mult}
+
+    def describe(m, mt, names):
+        """per-triangle material description in the (material-sorted) triangle order of the Mesh"""
+        T = m.triangles.shape[0]
+        model = np.zeros(T, dtype=np.int32); nu = np.zeros(T); mm = np.ones(T); func = np.full(T, -1, dtype=np.int32)
+        tabs = []
+        for name in names:
+            mat = mt[name]
+            sel = m._material_ids == mat.uid
+            model[sel] = mat._type; nu[sel] = mat._poisson_ratio; mm[sel] = mat._stiffness_multiplier
+            if mat._stiffness_func is not None:
+                func[sel] = len(tabs)
+                tabs.append((np.asarray(mat._stiffness_func_params['strain'], dtype=np.float64), np.asarray(mat._stiffness_func_params['stiffness'], dtype=np.float64)))
+        return model, nu, mm, func, tabs
+
+    cases = {'wr': ({'default': 0, 'wrinkle': 7}, lambda c: np.where((c[:, 0] > 30) & (c[:, 0] < 100) & (c[:, 1] > 20), 7, 0)),
+             'all': ({'wrinkle': 7, 'fold': 8}, lambda c: np.where(c[:, 1] > 45, 8, 7)),                   # no linear triangle: baseline over all
+             'mix': ({'default': 0, 'wrinkle': 7, 'fold': 8, 'svkf': 9, 'nhkf': 10},
+                     lambda c: np.select([c[:, 0] < 30, c[:, 0] < 60, (c[:, 0] < 95) & (c[:, 1] > 50), c[:, 0] >= 95], [7, 9, 8, 10], 0))}
+    for case, (names, region) in cases.items():
+        tab = {k: dict(tab_full[k]) for k in names} if 'default' in names else {**{k: dict(tab_full[k]) for k in names}, 'default': dict(tab_full['default'])}
+        mt = material.MaterialTable(table=tab)
+        mids = region(ctr).astype(np.int16)
+        m = Mesh(v.copy(), t.copy(), material_table=mt, material_ids=mids.copy(), stiffness_multiplier=mult.copy(), moving_vertices=vmov.copy(), uid=3)
+        assert not m.is_linear
+        K, stress = m.stiffness_matrix(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING))
+        model, nu, mm, func, tabs = describe(m, mt, [k for k in names])
+        out[f'{case}_t'] = m.triangles; out[f'{case}_mult'] = m._stiffness_multiplier; out[f'{case}_model'] = model; out[f'{case}_nu'] = nu
+        out[f'{case}_matmult'] = mm; out[f'{case}_func'] = func
+        out[f'{case}_ntab'] = np.array(len(tabs))
+        for k, (xs, ys) in enumerate(tabs):
+            out[f'{case}_tab{k}_x'] = xs; out[f'{case}_tab{k}_y'] = ys
+        r, c, d = coo(K)
+        out[f'{case}_K_r'] = r; out[f'{case}_K_c'] = c; out[f'{case}_K_d'] = d
+        out[f'{case}_stress'] = stress
+        # the same with the shape matrices taken at the MOVING gear (what a Newton-Raphson step asks for): zero stress of the
+        # engineering part, tangent of the others at zero displacement, area stretch still INITIAL -> MOVING
+        K2, stress2 = m.stiffness_matrix(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING))
+        r, c, d = coo(K2)
+        out[f'{case}_K2_r'] = r; out[f'{case}_K2_c'] = c; out[f'{case}_K2_d'] = d
+        out[f'{case}_stress2'] = stress2
+    # ---- Newton-Raphson: wrinkle / SVK regions on the left are pulled into compression (area stretch 0.8 .. 0.95 of the linear
+    #      triangles': the branch the wrinkle material exists for), fold / NHK regions on the right are stretched a little.  (With
+    #      triangles hopping across the cliff of the wrinkle table between 1.0 and 1.01 the reference's iteration -- K re-assembled
+    #      every step, f(J) not differentiated -- oscillates and its end state is not a property of the system; kept out of the pin.)
+    tab_nr = {k: dict(tab_full[k]) for k in ('default', 'wrinkle', 'fold', 'svkf')}
+    tab_nr['nhkf'] = dict(tab_full['nhkf'], stiffness_func_params=dict(strain=[0.5, 0.9, 1.1, 1.5], stiffness=[1.6, 1.1, 0.9, 0.6]))
+    region_nr = lambda c: np.select([c[:, 0] < 30, c[:, 0] < 55, (c[:, 0] >= 70) & (c[:, 0] < 100) & (c[:, 1] > 50), c[:, 0] >= 100], [7, 9, 8, 10], 0)
+    names_nr = ['default', 'wrinkle', 'fold', 'svkf', 'nhkf']
+    n = 300
+    det = dict(tolerated_perturbation=None, callback_settings={'chances': None, 'eval_step': 10})
+    ramp = np.clip((70.0 - v[:, 0]) / 25.0, 0.0, 1.0)                      # 1 on the left, 0 from x = 70 on
+    ramp = ramp * ramp * (3 - 2 * ramp)
+    pull = v + np.stack((0.11 * (60.0 - v[:, 0]) * ramp + 0.02 * np.maximum(v[:, 0] - 90.0, 0.0), 0.4 * np.sin(v[:, 0] / 40.0)), -1) + np.array([[0.3, -0.2]])
+
+    def build():
+        mt = material.MaterialTable(table={k: dict(tab_nr[k]) for k in names_nr})
+        m1 = Mesh(v.copy(), t.copy(), material_table=mt, material_ids=region_nr(ctr).astype(np.int16), stiffness_multiplier=mult.copy(), uid=1)
+        return mt, m1
+    mt, m1 = build()
+    tt = m1.triangles
+    model, nu, mm, func, tabs = describe(m1, mt, names_nr)
+    out.update(nr_t=tt, nr_pull=pull, nr_mult=m1._stiffness_multiplier, nr_model=model, nr_nu=nu, nr_matmult=mm, nr_func=func, nr_ntab=np.array(len(tabs)))
+    for k, (xs, ys) in enumerate(tabs):
+        out[f'nr_tab{k}_x'] = xs; out[f'nr_tab{k}_y'] = ys
+    tid = rng.integers(0, tt.shape[0], n); B = rng.dirichlet((1, 1, 1), n)
+    w = rng.uniform(0.4, 1.0, n).astype(np.float32)
+    out.update(nr_tid=tid, nr_B=B, nr_w=w)
+    for case, call in (('nr', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=12, tol=1e-9, **det)),
+                       ('nr3', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=3, tol=1e-6, **det)),
+                       ('elastic', lambda slm: slm.optimize_elastic(max_newtonstep=10, tol=1e-8, **det))):
+        mt, m1 = build()
+        m0 = Mesh(pull.copy(), tt.copy(), uid=0, locked=True)
+        lk = optimizer.Link(m0, m1, tid, tid, B, B, weight=w)
+        slm = optimizer.SLM([m0, m1], links=[lk], stiffness_lambda=1.0, crosslink_lambda=1.0)
+        c0, c1 = call(slm)
+        out[f'{case}_cost'] = np.array([c0, c1], dtype=np.float64)
+        out[f'{case}_v_after'] = m1.vertices(gear=const.MESH_GEAR_MOVING)
+        out[f'{case}_off_after'] = m1.offset(gear=const.MESH_GEAR_MOVING)
+    np.savez_compressed(os.path.join(OUT, 'g19_area_stretch.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -184,3 +184,41 @@ def test_mesh_file_round_trip(tmp_path):
         assert f.keys('master_meshes') == ['0', '1'] and 'master_meshes/0/material_ids' not in f
         P = Mesh.from_h5(f, prefix='master_meshes/0')
     assert P.tri_model is None and P.num_triangles == plain.num_triangles
+
+
+def test_mesh_file_keeps_the_stiffness_functions(tmp_path):
+    """a material with a stiffness function (the default "wrinkle" material, default_material_table.yaml:46-56) goes into the
+    mesh file the way Material.to_dict writes it (material.py:106-113: factory name + parameters) and comes back as the same
+    table on the same triangles; a mesh with one is not linear"""
+    from feabas_amd import material
+    M0 = Mesh.from_bbox((0, 0, 200, 120), cartesian=True, mesh_size=25)
+    nt = M0.num_triangles
+    func = np.where(np.arange(nt) % 4 == 0, 0, np.where(np.arange(nt) % 4 == 1, 1, -1)).astype(np.int32)
+    wr = material.asymmetrical_elasticity(strain=[0.0, 0.75, 1.0, 1.01], stiffness=[1.5, 1.0, 0.5, 1.0e-7])
+    fold = material.asymmetrical_elasticity(strain=[0.2, 0.9, 1.3], stiffness=[3.0, 1.2, 0.25])
+    M = Mesh(M0.vertices(const.MESH_GEAR_INITIAL), M0.triangles, uid=5,
+             tri_model=np.where(func == 1, 1, 0).astype(np.int32), tri_nu=np.where(func == 1, 0.25, 0.0),
+             tri_matmult=np.where(func == 0, 0.4, np.where(func == 1, 1.3, 1.0)), tri_func=func, stiffness_funcs=[wr, fold], func_matmult=[0.4, 1.3])
+    assert not M.is_linear and M.linear_triangle_mask.sum() == (func < 0).sum()
+    assert float(wr(0.5)) == pytest.approx(1.5 - 0.5 * 0.5 / 0.75) and float(wr(2.0)) == 1.0e-7 and float(wr(-1.0)) == 1.5
+    fn = str(tmp_path / 'mesh.h5')
+    M.save_to_h5(fn)
+    with h5wire.H5File(fn) as f:
+        table = json.loads(h5wire.numpy_to_str_ascii(f['material_table']))
+    with_f = [m for m in table.values() if m.get('stiffness_func_factory')]
+    assert len(with_f) == 2 and all(m['stiffness_func_factory'] == 'feabas.material.asymmetrical_elasticity' for m in with_f)
+    assert sorted(m['stiffness_multiplier'] for m in with_f) == [0.4, 1.3]
+    N = Mesh.from_h5(fn)
+    assert not N.is_linear
+    for k in (0, 1):
+        sel = func == k
+        assert np.all(N.tri_func[sel] == N.tri_func[sel][0]) and np.all(N.tri_func[~sel] != N.tri_func[sel][0])
+        assert N.stiffness_funcs[N.tri_func[sel][0]] == (wr, fold)[k]
+        assert N.func_matmult[N.tri_func[sel][0]] == (0.4, 1.3)[k]
+    np.testing.assert_array_equal(N.tri_model, M.tri_model)
+    # the effective multiplier of mesh.py:1600-1621 (median area stretch of the linear triangles as the base)
+    N.set_vertices(N.vertices(const.MESH_GEAR_INITIAL) * np.array([[0.9, 1.0]]), const.MESH_GEAR_MOVING)
+    eff = N.effective_stiffness_multiplier()
+    assert np.allclose(eff[func < 0], 1.0) and np.allclose(eff[func == 0], 0.4 * 0.5)        # uniform compression: stretch / median = 1
+    with pytest.raises(NotImplementedError):
+        material.stiffness_func_from_spec('lambda x: x')

@@ -470,6 +470,60 @@ def test_g17_newton_raphson_vs_reference(fb, case, call):
     np.testing.assert_allclose(lk._residue_weight, g[f'{case}_residue_weight'], atol=2e-4)
 
 
+# ----------------------------------------------------------------------- G19: stiffness that follows the area stretch
+def _g19_mesh(fb, g, case, **kw):
+    tabs = [fb.material.StiffnessTable(g[f'{case}_tab{k}_x'], g[f'{case}_tab{k}_y']) for k in range(int(g[f'{case}_ntab']))]
+    func = g[f'{case}_func']
+    fmm = [float(g[f'{case}_matmult'][np.flatnonzero(func == k)[0]]) for k in range(len(tabs))]
+    return fb.mesh.Mesh(g['v'].copy(), g[f'{case}_t'], stiffness_multiplier=g[f'{case}_mult'], tri_model=g[f'{case}_model'], tri_nu=g[f'{case}_nu'],
+                        tri_matmult=g[f'{case}_matmult'].astype(np.float32), tri_func=func, stiffness_funcs=tabs, func_matmult=fmm, **kw)
+
+
+@pytest.mark.parametrize('case,tol', [('wr', 1e-10), ('all', 1e-10), ('mix', 5e-6)])
+def test_g19_area_stretch_stiffness_vs_reference(fb, case, tol):
+    """Mesh.stiffness_matrix with materials that carry a stiffness_func -- the default "wrinkle" material
+    (configs/default_material_table.yaml:46-56) through nonlinear_engineering_stiffness_matrix (mesh.py:2937-2971), the f(J)
+    modifier of SVK / NHK elements (material.py:307-308) -- against the REFERENCE's own matrices (golden G19): a mesh compressed on
+    one side and stretched on the other, every segment of the tables visited; engineering elements to 1e-10, the float32 element
+    pipeline of SVK / NHK to 5e-6; shape matrices at the FIXED and at the MOVING gear"""
+    from conftest import load_golden
+    g = load_golden('g19_area_stretch.npz')
+    m = _g19_mesh(fb, g, case, moving_vertices=g['vmov'], uid=3)
+    assert not m.is_linear
+    nd = 2 * g['v'].shape[0]
+    for tag, gear, st in (('K', (0, 1), 'stress'), ('K2', (1, 1), 'stress2')):
+        K, stress = m.stiffness_matrix(gear=gear)
+        Kg = _sp(g, f'{case}_{tag}', (nd, nd))
+        assert abs(K - Kg).max() <= tol * abs(Kg).max(), abs(K - Kg).max() / abs(Kg).max()
+        np.testing.assert_allclose(stress, g[f'{case}_{st}'], atol=max(5e-6 * np.abs(g[f'{case}_{st}']).max(), 1e-30))
+
+
+@pytest.mark.parametrize('case,call,tol', [
+    ('nr', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=12, tol=1e-9), 1e-4),
+    ('nr3', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=3, tol=1e-6), 1e-4),
+    ('elastic', lambda slm: slm.optimize_elastic(max_newtonstep=10, tol=1e-8), 1e-4),
+])
+def test_g19_newton_raphson_vs_reference(fb, case, call, tol):
+    """a mesh with such materials is non-linear: optimize_elastic takes the Newton-Raphson route and every step re-assembles K
+    with the stiffness factors of the current gear.  Against the REFERENCE's own run (golden G19, deterministic settings): the
+    first out-of-balance force to 1e-6, the final field to 1e-4 of the motion"""
+    from conftest import load_golden
+    g = load_golden('g19_area_stretch.npz')
+    m0 = fb.mesh.Mesh(g['nr_pull'], g['nr_t'], uid=0, locked=True)
+    m1 = _g19_mesh(fb, g, 'nr', uid=1)
+    assert not m1.is_linear
+    lk = fb.optimizer.Link(m0, m1, g['nr_tid'], g['nr_tid'], g['nr_B'], g['nr_B'], weight=g['nr_w'])
+    slm = fb.optimizer.SLM([m0, m1], [lk], stiffness_lambda=1.0, crosslink_lambda=1.0)
+    c0, c1 = call(slm)
+    ref0, ref1 = g[f'{case}_cost']
+    assert abs(c0 - ref0) <= 1e-6 * ref0
+    assert c1 <= max(3.0 * ref1, 1e-6 * ref0)
+    exp = g[f'{case}_v_after'] + g[f'{case}_off_after'] - g['v']
+    got = m1.vertices_w_offset(fb.constant.MESH_GEAR_MOVING) - g['v']
+    scale = np.abs(exp).max()
+    assert np.abs(got - exp).max() <= tol * scale, np.abs(got - exp).max() / scale
+
+
 def test_newton_ladder_follows_the_reference_schedule(fb):
     """the per-step schedules (SLM.expand_to_list, optimizer.py:1862-1873): a scalar is the LAST step's value, lists are
     right-aligned, earlier steps derive from the following one"""

@@ -388,6 +388,51 @@ def test_g17_residue_weights_after_the_last_step():
     np.testing.assert_array_equal(g['huber_v_after'], g['elastic_v_after'])
 
 
+# ----------------------------------------------------------------------- G19: stiffness that follows the area stretch
+def g19_tabs(g, case):
+    return [(g[f'{case}_tab{k}_x'], g[f'{case}_tab{k}_y']) for k in range(int(g[f'{case}_ntab']))]
+
+
+@pytest.mark.parametrize('case', ['wr', 'all', 'mix'])
+def test_g19_area_stretch_stiffness(case):
+    """Mesh.stiffness_matrix with materials that carry a stiffness_func (mesh.py:2937-2971, material.py:172-173, 307-308,
+    546-551): the wrinkle material on a compressed / stretched mesh, a mesh without any linear triangle (base ratio over all
+    triangles), SVK / NHK elements with the f(J) modifier; shape matrices at the FIXED and at the MOVING gear"""
+    g = load_golden('g19_area_stretch.npz')
+    nd = 2 * g['v'].shape[0]
+    for tag, vs, st in (('K', g['v'], 'stress'), ('K2', g['vmov'], 'stress2')):
+        K, stress = fem_ref.mesh_stiffness_mixed(vs, g['vmov'], g[f'{case}_t'], g[f'{case}_mult'], g[f'{case}_model'], g[f'{case}_nu'],
+                                                 g[f'{case}_matmult'], func=g[f'{case}_func'], tabs=g19_tabs(g, case), v_init=g['v'])
+        Kg = sparse.csr_matrix((g[f'{case}_{tag}_d'], (g[f'{case}_{tag}_r'], g[f'{case}_{tag}_c'])), shape=(nd, nd))
+        assert abs(K - Kg).max() <= 1e-12 * abs(Kg).max()
+        np.testing.assert_allclose(stress, g[f'{case}_{st}'], atol=1e-6 * max(np.abs(g[f'{case}_{st}']).max(), 1e-30))
+    # the functions do something on this mesh: every segment of the wrinkle table is visited
+    a = fem_ref.area_stretch(g['v'], g['vmov'], g[f'{case}_t'], (g[f'{case}_model'] == 0) & (g[f'{case}_func'] < 0))
+    assert a.min() < 0.75 and a.max() > 1.01 and np.any((a > 0.75) & (a < 1.0))
+
+
+@pytest.mark.parametrize('case,steps,tol', [('nr', 30, 1e-5), ('elastic', 30, 1e-5), ('nr3', 3, 1e-4)])
+def test_g19_newton_fixed_point(case, steps, tol):
+    """the oracle's exact Newton iteration (tangent AND stiffness factors re-evaluated every step, mesh.py:2937-2971) ends where
+    the reference's optimize_Newton_Raphson / optimize_elastic ends on the mesh whose wrinkle / SVK regions are pulled into
+    compression; three steps of it are where the reference is after three steps"""
+    g = load_golden('g19_area_stretch.npz')
+    r0 = fem_ref.RefMesh(g['nr_pull'], g['nr_t'], uid=0, locked=True)
+    r1 = fem_ref.RefMesh(g['v'].copy(), g['nr_t'], uid=1)
+    rl = fem_ref.RefLink(r0, r1, g['nr_tid'], g['nr_tid'], g['nr_B'], g['nr_B'], weight=g['nr_w'])
+    costs = fem_ref.newton_fixed_point(r0, r1, [rl], g['nr_mult'], g['nr_model'], g['nr_nu'], g['nr_matmult'], func=g['nr_func'],
+                                       tabs=g19_tabs(g, 'nr'), max_steps=steps, tol=1e-9)
+    assert abs(costs[0] - g[f'{case}_cost'][0]) <= 1e-6 * g[f'{case}_cost'][0]
+    exp = g[f'{case}_v_after'] + g[f'{case}_off_after'] - g['v']
+    got = r1.vertices_w_offset(fem_ref.GEAR_MOVING) - g['v']
+    scale = np.abs(exp).max()
+    assert scale > 1.0
+    assert np.abs(got - exp).max() <= tol * scale, np.abs(got - exp).max() / scale
+    # the compressed branch of the wrinkle table is where its triangles end up
+    st = fem_ref.area_stretch(g['v'], g['nr_v_after'], g['nr_t'], (g['nr_model'] == 0) & (g['nr_func'] < 0))
+    assert st[g['nr_func'] == 0].min() < 0.9 and st[g['nr_func'] == 0].max() < 1.0
+
+
 # ----------------------------------------------------------------------- G18: one free section between two locked neighbours
 def g18_oracle_system(g):
     prev = fem_ref.RefMesh(g['v_prev'], g['t'], uid=0, locked=True)
