@@ -752,11 +752,13 @@ class SLM:
             self.last_solve = dict(iters=None, relres=res / bn if bn else 0.0, stiffness_lambda=sl, crosslink_lambda=cl, held_dofs=int((~held).sum()))
         else:
             rc = lib.fb_sys_solve(ctx, self._sys, _lib.ptr(dd), 0, float(tol), float(atol or 0.0), mi, pre, C.byref(iters), C.byref(relres))
-            _lib.check(rc, allow=(_lib.FB_ERR_NOCONV,))
+            if pre != 2:
+                _lib.check(rc, allow=(_lib.FB_ERR_NOCONV,))
             fell_back = False
-            if pre == 2 and (rc == _lib.FB_ERR_NOCONV or not relres.value <= max(float(tol), float(atol or 0.0) / bn if bn else 0.0) * 1.0001):
-                # a cycle that stalls (none known since the coarsest level deflates the rigid motions of a floating system, but the
-                # hierarchy is heuristic): the plain Jacobi-PCG takes over
+            if pre == 2 and (rc != 0 or not relres.value <= max(float(tol), float(atol or 0.0) / bn if bn else 0.0) * 1.0001):
+                # the hierarchy is a heuristic: a set-up that cannot be made (a coarsest level that stays too large -- aggregates never
+                # join two meshes, so a window of very many free meshes ends there --, a level that stops coarsening), a breakdown or
+                # a cycle that stalls all end here, and the plain Jacobi-PCG takes over (any error of ITS run is raised)
                 dd[:] = 0.0
                 _lib.check(lib.fb_sys_solve(ctx, self._sys, _lib.ptr(dd), 0, float(tol), float(atol or 0.0), mi, 1, C.byref(iters), C.byref(relres)),
                            allow=(_lib.FB_ERR_NOCONV,))

@@ -601,3 +601,36 @@ def test_multigrid_request_on_a_floating_system_takes_the_jacobi_pcg(fb):
     c2 = fb.optimizer.SLM(prod2, lp2).optimize_linear(tol=1e-9)
     assert c1[1] <= 1e-9 * c1[0] * 1.01 and c2[1] <= 1e-9 * c2[0] * 1.01
     np.testing.assert_allclose(lp[0].dxy(gear=(1, 1)), lp2[0].dxy(gear=(1, 1)), atol=1e-9)
+
+
+def test_multigrid_request_on_a_window_of_very_many_small_meshes_falls_back(fb):
+    """precondition='smoothed_aggregation' where the hierarchy cannot be built: aggregates never join two meshes, so a window of
+    several hundred tiny free meshes (a stitching section's tiles) ends with a coarsest level larger than the dense solve takes;
+    the set-up's error is not raised -- the Jacobi-PCG takes over and reaches the same solution as a plain request"""
+    rng = np.random.default_rng(77)
+    v = np.array([[0.0, 0.0], [10.0, 0.0], [10.0, 10.0], [0.0, 10.0]]); t = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32)
+    nm = 900
+
+    def build():
+        meshes = [fb.mesh.Mesh(v + np.array([[12.0 * k, 0.0]]), t, uid=k, locked=(k == 0)) for k in range(nm)]
+        links = []
+        r = np.random.default_rng(5)
+        for k in range(nm - 1):
+            n = 4
+            tid = r.integers(0, 2, n); B = r.dirichlet((1, 1, 1), n)
+            # neighbours k, k + 1 are tied at matched points; mesh k + 1 wants to sit a little off its place
+            xy0 = meshes[k].bary2cart(tid, B, 0); xy1 = meshes[k + 1].bary2cart(tid, B, 0)
+            lk = fb.optimizer.Link(meshes[k], meshes[k + 1], tid, tid, B, B, weight=np.ones(n, np.float32))
+            links.append(lk)
+        for k in range(1, nm):
+            meshes[k].set_vertices(meshes[k].vertices(0) + r.normal(0, 0.3, (1, 2)), 1)
+        return meshes, links
+    m1, l1 = build()
+    m2, l2 = build()
+    s1 = fb.optimizer.SLM(m1, l1)
+    c1 = s1.optimize_linear(tol=1e-8, precondition='smoothed_aggregation')
+    c2 = fb.optimizer.SLM(m2, l2).optimize_linear(tol=1e-8)
+    assert s1.last_solve.get('multigrid_fell_back')
+    assert c1[1] <= 1e-8 * c1[0] * 1.01 and c2[1] <= 1e-8 * c2[0] * 1.01
+    for a, b in zip(m1[1::97], m2[1::97]):
+        np.testing.assert_allclose(a.vertices_w_offset(1), b.vertices_w_offset(1), atol=1e-6)
