@@ -315,6 +315,60 @@ def bench_align(lib, ctx, _lib, S=8192, mesh_size=50.0, nblocks=512, B=280):
                      'masked DoG, padded NCC; results (dx, dy, conf per block) returned to the host')
 
 
+def bench_section_matcher(lib, ctx, _lib, S=8192, mesh_size=100.0, reps=3):
+    """alignment side end to end (align_main --mode matching): ONE pair of S x S uint8 sections through
+    matcher.section_matcher -- two irregular meshes (both free: the floating system of matcher.py:551), spacings 280 / 70 px
+    (0.7 x the [400, 100] of alignment_configs.yaml:16-23), render + DoG + NCC + relaxation per round -- against the smooth
+    field the second section was resampled through"""
+    from scipy.ndimage import gaussian_filter, map_coordinates
+    from scipy.spatial import Delaunay
+    from feabas_amd import matcher as fmatcher
+    from feabas_amd import renderer
+    from feabas_amd.mesh import Mesh
+    rng = np.random.default_rng(0)
+    t = gaussian_filter(rng.standard_normal((S, S)).astype(np.float32), 1.5)
+    t += 0.7 * t.std() * gaussian_filter(rng.standard_normal((S, S)).astype(np.float32), 12) / 0.03
+    base = np.clip(128 + 40 * t / t.std(), 0, 255).astype(np.uint8)
+    del t
+    yy, xx = np.meshgrid(np.arange(S, dtype=np.float32), np.arange(S, dtype=np.float32), indexing='ij')
+
+    def field(x, y):
+        return (8.0 * np.sin(2 * np.pi * y / (0.8 * S) + 0.4) + 3.0 * (x / S) ** 2, 6.0 * np.cos(2 * np.pi * x / (0.7 * S)) - 2.0 * (x / S) * (y / S))
+    ux, uy = field(xx, yy)
+    img1 = np.clip(np.rint(map_coordinates(base, [yy + uy, xx + ux], order=1, mode='nearest', output=np.float32)), 0, 255).astype(np.uint8)
+    del yy, xx, ux, uy
+    meshes = []
+    for k in range(2):
+        g = np.arange(0, S, mesh_size)
+        gx, gy = np.meshgrid(np.append(g, S - 1), np.append(g, S - 1))
+        v = np.stack((gx.ravel(), gy.ravel()), axis=-1).astype(np.float64)
+        inner = (v[:, 0] > 0) & (v[:, 0] < S - 1) & (v[:, 1] > 0) & (v[:, 1] < S - 1)
+        v[inner] += rng.uniform(-0.3, 0.3, (int(inner.sum()), 2)) * mesh_size
+        meshes.append(Mesh(v, Delaunay(v).simplices.astype(np.int32), uid=k))
+    images = [renderer.ResidentImage(base), renderer.ResidentImage(img1)]
+    best, out = np.inf, None
+    for _ in range(reps):
+        m0, m1 = meshes[0].copy(), meshes[1].copy()
+        trace = []
+        t0 = time.time()
+        xy0, xy1, w, strain = fmatcher.section_matcher(m0, m1, images[0], images[1], spacings=[280, 70], conf_thresh=0.3, residue_len=3.0, trace=trace)
+        dt = time.time() - t0
+        if dt < best:
+            best, out = dt, (xy0, xy1, trace)
+    for im in images:
+        im.free()
+    xy0, xy1, trace = out
+    ex, ey = field(xy1[:, 0], xy1[:, 1])
+    err = np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)
+    return dict(value=1.0 / best, unit='section pairs/s', ms_per_pair=1e3 * best, image=[S, S], triangles=[int(m.num_triangles) for m in meshes],
+                vertices=[int(m.num_vertices) for m in meshes], matches=int(xy0.shape[0]),
+                median_error_px=float(np.median(err)), p95_error_px=float(np.quantile(err, 0.95)),
+                rounds=[dict(blocks=int(r['blocks']), kept=int(r['kept']), max_dis=float(r['max_dis']), solve_iters=r['solve'].get('iters'),
+                             precond=r['solve'].get('precond')) for r in trace],
+                note=f'best of {reps} calls of matcher.section_matcher on resident uint8 sections; error = distance of the matched displacement '
+                     'from the injected field at the matched points')
+
+
 def cpu_baseline_ncc(h0, h1, seconds=20.0):
     """the oracle pair pipeline on the host, one process / one thread, on a bounded sample"""
     from oracle import pipeline_ref
@@ -1060,6 +1114,7 @@ def main():
         del h0, h1, host_pairs, outp, ragged, outr
     if rank == 0 and world == 1 and not args.no_align:
         line['align_block_matcher'] = bench_align(lib, ctx, _lib)
+        line['section_matcher'] = bench_section_matcher(lib, ctx, _lib)
     cpu_strips = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         H, W = shapes['LR']

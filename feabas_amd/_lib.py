@@ -137,6 +137,10 @@ _PROTOS = {
     'fb_sys_add_mesh': (c_i, [c_p, c_p, c_i64, c_p, c_i, c_i, C.POINTER(c_i)]),
     'fb_sys_set_links': (c_i, [c_p, c_p, c_i64, c_p]),
     'fb_sys_finalize': (c_i, [c_p, c_p, C.POINTER(c_i64)]),
+    'fb_schedule_create': (c_p, [c_p, c_i, c_i, c_i, c_i, c_i]),
+    'fb_schedule_destroy': (None, [c_p]),
+    'fb_schedule_round': (c_i, [c_p, C.POINTER(c_d), C.POINTER(c_i), C.POINTER(c_i)]),
+    'fb_schedule_advance': (c_i, [c_p, c_d, c_d, C.POINTER(c_i)]),
     'fb_sys_pattern': (c_i, [c_p, c_p, c_p, c_p]),
     'fb_sys_info': (c_i, [c_p, c_p, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)]),
     'fb_sys_assemble_mesh': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_d, c_d]),

@@ -390,4 +390,76 @@ int fb_deformed_locate(fb_ctx* ctx, int Q, int nx, int ny, const double* xs_all,
     return FB_OK;
 }
 
+
+// ---- round stepper of the coarse-to-fine block matcher (matcher.py:567-716) ---------------------------------------------------
+// The spacings are walked from the largest to the smallest; after a round that measured a largest displacement d the walk jumps
+// to the smallest spacing that is still larger than `multiplier` x d (at most 1 + max_skip places ahead), dwells, or moves one
+// place on; a first round whose displacement outruns even the largest spacing is repeated once at ceil(multiplier x d).  Blocks
+// are zero padded unless the walk jumped over a spacing (the search range then is the block itself).  One state machine for
+// every caller: the general-mesh loop of feabas_amd/matcher.py steps it through the C ABI.
+struct fb_schedule {
+    std::vector<double> sp;          // descending
+    int idx = 0;                     // place of the round that is due (-1: the enlarged extra round)
+    double cur = 0.0;                // its spacing
+    bool enlarged = false;           // the extra round has been spent (or is not allowed)
+    int dwelled = 0, allow_dwell = 0, max_skip = 0;
+    int pad_fixed = -1;              // -1: by rule
+    bool pad = true;
+};
+
+fb_schedule* fb_schedule_create(const double* spacings, int n, int allow_enlarge, int allow_dwell, int max_spacing_skip, int pad_fixed) {
+    if (!spacings || n <= 0) return nullptr;
+    fb_schedule* s = new fb_schedule();
+    s->sp.assign(spacings, spacings + n);
+    std::sort(s->sp.begin(), s->sp.end(), [](double a, double b) { return a > b; });
+    s->idx = 0; s->cur = s->sp[0];
+    s->enlarged = !allow_enlarge;
+    s->allow_dwell = std::max(0, allow_dwell); s->max_skip = std::max(0, max_spacing_skip);
+    s->pad_fixed = pad_fixed < 0 ? -1 : (pad_fixed ? 1 : 0);
+    s->pad = s->pad_fixed < 0 ? true : s->pad_fixed != 0;
+    return s;
+}
+
+void fb_schedule_destroy(fb_schedule* s) { delete s; }
+
+int fb_schedule_round(const fb_schedule* s, double* spacing, int* last, int* pad) {
+    if (!s || s->idx >= (int)s->sp.size()) return 0;
+    if (spacing) *spacing = s->cur;
+    if (last) *last = s->cur == s->sp.back();
+    if (pad) *pad = s->pad ? 1 : 0;
+    return 1;
+}
+
+int fb_schedule_advance(fb_schedule* s, double max_dis, double multiplier, int* redo) {
+    if (!s || !redo) return FB_ERR_ARG;
+    *redo = 0;
+    const int n = (int)s->sp.size();
+    const double reach = multiplier * max_dis;                 // the smallest block that still holds the displacement
+    int target = -1;                                           // place of the smallest spacing above it
+    for (int k = 0; k < n; ++k) target += s->sp[k] > reach;
+    auto set_pad = [&](bool v) { if (s->pad_fixed < 0) s->pad = v; };
+    if (!s->enlarged && target < 0) {
+        s->enlarged = true;
+        s->idx = -1;
+        s->cur = std::ceil(reach);
+        set_pad(true);
+        *redo = 1;
+        return FB_OK;
+    }
+    s->enlarged = true;
+    if (target > s->idx) {
+        target = std::min(target, s->idx + 1 + s->max_skip);
+        set_pad(target > s->idx + 1);
+        s->idx = target; s->dwelled = 0;
+    } else if (s->dwelled >= s->allow_dwell) {
+        set_pad(true);
+        s->idx += 1; s->dwelled = 0;
+    } else {
+        set_pad(true);
+        s->dwelled += 1;
+    }
+    if (s->idx >= 0 && s->idx < n) s->cur = s->sp[s->idx];
+    return FB_OK;
+}
+
 }  // extern "C"

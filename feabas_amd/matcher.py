@@ -449,209 +449,223 @@ def bboxes_mesh_renderer_matcher(mesh0, mesh1, image_loader0, image_loader1, bbo
 DEFAULT_AVG_DEFORM = 0.05                # feabas/config.py:32
 
 
-def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, spacings, **kwargs):
-    """feabas/matcher.py:430-778 for two general meshes over images resident in HBM: block NCC through the meshes
-    (``bboxes_mesh_renderer_matcher``) alternating with the relaxation of the pair (``optimizer.SLM``), coarse to fine over
-    ``spacings``; the spacing schedule, the pad / sub-pixel / tolerance rules per round, the residue re-weighting and the
-    strain estimate follow the reference statement by statement.  Every arithmetic step (render, DoG, NCC, assembly, PCG)
-    runs on the device; the loop and the block lists stay on the host.  ``distributor`` other than 'cartesian_bbox' (the
-    shapely region-aware one) and ``num_workers`` > 1 are outside this mirror.  The batched strip form of the same loop is
-    ``stitch_pipeline.StripBatchMatcher`` (one call = many tile pairs)."""
-    from . import optimizer
-    from . import renderer as _rd
-    conf_thresh = kwargs.get('conf_thresh', 0.3)
-    residue_mode = kwargs.get('residue_mode', 'huber')
-    residue_len = kwargs.get('residue_len', 0)
-    opt_tol = kwargs.get('opt_tol', None)
-    distributor = kwargs.get('distributor', 'cartesian_bbox')
-    min_boundary_distance = kwargs.get('min_boundary_distance', 0)
-    render_weight_threshold = kwargs.get('render_weight_threshold', 0)
-    if kwargs.get('num_workers', 1) > 1:
-        # the reference cuts a round into sub-mesh jobs for its process pool (matcher.py:619-666); one device renders and
-        # correlates the whole round, so the knob has nothing to distribute
-        pass
-    min_num_blocks = kwargs.get('min_num_blocks', 2)
-    shrink_factor = kwargs.get('shrink_factor', 1)
-    allow_dwell = kwargs.get('allow_dwell', 0)
-    allow_enlarge = kwargs.get('allow_enlarge', False)
-    link_weight_decay = kwargs.get('link_weight_decay', 0.0)
-    compute_strain = kwargs.get('compute_strain', True)
-    batch_size = kwargs.get('batch_size', None)
-    initial_matches = kwargs.get('initial_matches', None)
-    to_pad = kwargs.get('pad', None)
-    do_subpixel = kwargs.get('subpixel', None)
-    max_spacing_skip = kwargs.get('max_spacing_skip', 0)
-    stiffness_lambda = kwargs.get('stiffness_lambda', 1)
-    affine_render = kwargs.get('affine_approximated_render', True)
-    sigma = kwargs.get('sigma', 0.0)
-    conf_mode = kwargs.get('conf_mode', const.FFT_CONF_MIRROR)
-    trace = kwargs.get('trace', None)                  # a list: one record per round (debugging / tests)
-    relax_tol = kwargs.get('relax_tol', 1e-9)
-    if residue_len < 0:                                                       # matcher.py:518-520: in units of the section thickness
-        thickness = kwargs.get('section_thickness', const.DEFAULT_THICKNESS)
-        residue_len = max(1, abs(residue_len) * thickness / mesh0.resolution)
-    spacings = np.array(spacings, dtype=np.float64).ravel()
-    linear_system = mesh0.is_linear and mesh1.is_linear
-    one_locked = mesh0.locked or mesh1.locked
-    strain = DEFAULT_AVG_DEFORM
-    invalid_output = (None, None, 0, strain)
-    if np.any(spacings < 1):                                                  # relative to the longer side, matcher.py:541-551
-        bbox, valid = common.intersect_bbox(mesh0.bbox(gear=const.MESH_GEAR_MOVING), mesh1.bbox(gear=const.MESH_GEAR_MOVING))
-        if not valid:
-            return invalid_output
-        spacings[spacings < 1] *= max(bbox[2] - bbox[0], bbox[3] - bbox[1])
-    if compute_strain:
-        mesh0_ori, mesh1_ori = mesh0.copy(), mesh1.copy()
-    solve = (lambda o, **kw: o.optimize_linear(**kw)) if linear_system else None
-    opt = optimizer.SLM([mesh0, mesh1], stiffness_lambda=stiffness_lambda)
-    if initial_matches is not None:                                           # matcher.py:555-566
+class _RoundPlan:
+    """Which spacing the next round of block matching runs at, and with which padding: the stepper of the C ABI
+    (fb_schedule_*, csrc/fb_geom.hip -- feabas/matcher.py:567-716), shared with every other caller of the library."""
+
+    def __init__(self, spacings, allow_enlarge=False, allow_dwell=0, max_spacing_skip=0, pad=None):
+        sp = np.ascontiguousarray(spacings, dtype=np.float64).ravel()
+        self._lib = _lib.load()
+        self.count = int(sp.size)
+        self._h = self._lib.fb_schedule_create(_lib.ptr(sp), sp.size, int(bool(allow_enlarge)), int(allow_dwell), int(max_spacing_skip),
+                                               -1 if pad is None else int(bool(pad)))
+        if not self._h:
+            raise ValueError('no spacings')
+
+    def due(self):
+        """(spacing, is the smallest one, pad the blocks) of the round that is due; None when the walk is over"""
+        sp, last, pad = C.c_double(), C.c_int(), C.c_int()
+        if not self._lib.fb_schedule_round(self._h, C.byref(sp), C.byref(last), C.byref(pad)):
+            return None
+        return sp.value, bool(last.value), bool(pad.value)
+
+    def advance(self, max_dis, multiplier=4.0):
+        """report the largest displacement of the round; True = repeat it at the enlarged spacing before linking anything"""
+        redo = C.c_int()
+        _lib.check(self._lib.fb_schedule_advance(self._h, float(max_dis), float(multiplier), C.byref(redo)))
+        return bool(redo.value)
+
+    def close(self):
+        if self._h:
+            self._lib.fb_schedule_destroy(self._h)
+            self._h = None
+
+
+class _PairRelaxation:
+    """The spring-linked pair of a block matcher: the two meshes, the matches of the current round as their links, and the
+    relaxation that follows every round (feabas/matcher.py:551-566, 717-742)."""
+
+    def __init__(self, mesh0, mesh1, stiffness_lambda, residue_mode, residue_len, link_weight_decay):
+        from . import optimizer
+        self.meshes = (mesh0, mesh1)
+        self.linear = mesh0.is_linear and mesh1.is_linear
+        self.slm = optimizer.SLM([mesh0, mesh1], stiffness_lambda=stiffness_lambda)
+        self.residue_mode, self.residue_len, self.decay = residue_mode, residue_len, link_weight_decay
+        if residue_len > 0 and residue_mode not in ('huber', 'threshold'):
+            raise ValueError(residue_mode)
+
+    def _solve(self, tol, steps):
+        if self.linear:
+            self.slm.optimize_linear(tol=tol)
+        else:
+            self.slm.optimize_Newton_Raphson(max_newtonstep=steps, tol=tol)
+
+    def seed(self, initial_matches):
+        """matcher.py:555-566: a first alignment from matches the caller brings (affine cascade, rigid anneal, one relaxation);
+        without them the current MOVING gear is the start"""
+        m0, m1 = self.meshes
+        if initial_matches is None:
+            for m in self.meshes:
+                m.anneal(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT)
+            return
         xy0, xy1, weight = initial_matches[:3] if isinstance(initial_matches, (tuple, list)) else \
             (initial_matches.xy0, initial_matches.xy1, initial_matches.weight)
-        opt.add_link_from_coordinates(mesh0.uid, mesh1.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight)
-        opt.optimize_affine_cascade(start_gear=const.MESH_GEAR_FIXED, target_gear=const.MESH_GEAR_FIXED, svd_clip=None)
-        opt.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_CONNECTED_RIGID)
-        if linear_system:
-            opt.optimize_linear(tol=1e-6)
-        else:
-            opt.optimize_Newton_Raphson(max_newtonstep=5, tol=1e-4)
-    else:
-        mesh0.anneal(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT)
-        mesh1.anneal(gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_FIXED), mode=const.ANNEAL_COPY_EXACT)
-    spacings = np.sort(spacings)[::-1]
-    sp = np.max(spacings)
-    sp_indx = 0
-    initialized = False
-    spacing_enlarged = not allow_enlarge
-    dwelled = 0
-    pad = True if to_pad is None else to_pad
-    images, own_images = [], []
-    for ld in (image_loader0, image_loader1):
-        if isinstance(ld, _rd.ResidentImage):
-            images.append(ld)
-        else:
-            images.append(_rd.ResidentImage(ld)); own_images.append(images[-1])
+        self.slm.add_link_from_coordinates(m0.uid, m1.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight)
+        self.slm.optimize_affine_cascade(start_gear=const.MESH_GEAR_FIXED, target_gear=const.MESH_GEAR_FIXED, svd_clip=None)
+        self.slm.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_CONNECTED_RIGID)
+        self._solve(1e-6 if self.linear else 1e-4, 5)
 
-    def relax(tol):
-        if linear_system:
-            opt.optimize_linear(tol=tol)
+    def retire_links(self):
+        """the matches of the previous rounds: dropped, or kept with decayed weights (link_weight_decay)"""
+        if self.decay == 0:
+            self.slm.clear_links()
         else:
-            opt.optimize_Newton_Raphson(max_newtonstep=3, tol=tol)
+            for lnk in self.slm.links:
+                lnk._weight = lnk._weight * self.decay
+
+    def link(self, xy0, xy1, weight):
+        m0, m1 = self.meshes
+        self.slm.add_link_from_coordinates(m0.uid, m1.uid, xy0, xy1, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), weight=weight)
+        return len(self.slm.links)
+
+    def relax(self, tol, more_rounds):
+        """relax; with a residue length the matches are re-weighted by what is left of them (huber / threshold) and, when that
+        changed a weight and another round follows, relaxed again"""
+        self._solve(tol, 3)
+        if self.residue_len > 0:
+            if self.residue_mode == 'huber':
+                self.slm.set_link_residue_huber(self.residue_len)
+            else:
+                self.slm.set_link_residue_threshold(self.residue_len)
+            changed, _ = self.slm.adjust_link_weight_by_residue(relax_first=True)
+            if changed and more_rounds:
+                self._solve(tol, 3)
+
+    @property
+    def links(self):
+        return self.slm.links
+
+
+def _strain_of_matches(mesh0, mesh1, xy0, xy1, weight, stiffness_lambda):
+    """matcher.py:752-777: how much elastic energy the matches ask of the pair, as a fraction of the energy of the shape itself:
+    the untouched meshes, brought together rigidly (affine cascade clipped to rotations) and relaxed once; strain = sqrt of
+    dv^T K dv / v0^T K v0 summed over the free (or softer) mesh(es).  The energies are evaluated on the device."""
+    from . import optimizer
+    slm = optimizer.SLM([mesh0, mesh1], stiffness_lambda=stiffness_lambda)
+    slm.add_link_from_coordinates(mesh0.uid, mesh1.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight)
+    slm.optimize_affine_cascade(start_gear=const.MESH_GEAR_INITIAL, target_gear=const.MESH_GEAR_FIXED, svd_clip=(1, 1))
+    slm.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_COPY_EXACT)
+    if mesh0.is_linear and mesh1.is_linear:
+        slm.optimize_linear(tol=1e-6)
+    else:
+        slm.optimize_Newton_Raphson(max_newtonstep=5, tol=1e-4)
+    one_locked = mesh0.locked or mesh1.locked
+    soft_avg = np.mean([m.soft_factor for m in slm.meshes])
+    counted = [m for m in slm.meshes if ((not m.locked) if one_locked else (m.soft_factor <= soft_avg))]
+    moved = shape = 0.0
+    for m in counted:
+        v0 = m.vertices(gear=const.MESH_GEAR_FIXED)
+        dv = m.vertices(gear=const.MESH_GEAR_MOVING) - v0
+        e_dv, e_v0 = m.stiffness_energy([dv - dv.mean(axis=0, keepdims=True), v0 - v0.mean(axis=0, keepdims=True)])
+        moved += max(0.0, e_dv); shape += max(0.0, e_v0)
+    return (moved / shape) ** 0.5
+
+
+def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, spacings, **kwargs):
+    """feabas/matcher.py:430-778 for two general meshes over images resident in HBM: rounds of block NCC through the meshes
+    (``bboxes_mesh_renderer_matcher``) alternate with the relaxation of the pair, coarse to fine.  Which spacing a round runs
+    at comes from the library's round stepper (``_RoundPlan`` -> fb_schedule_*), the pair and its links live in
+    ``_PairRelaxation``, the strain estimate in ``_strain_of_matches``; every arithmetic step (render, DoG, NCC, assembly,
+    PCG, energies) runs on the device.  ``num_workers`` has nothing to distribute here (one device renders and correlates the
+    whole round).  The batched strip form of the same loop is ``stitch_pipeline.StripBatchMatcher`` (one call = many pairs)."""
+    from . import renderer as _rd
+    get = kwargs.get
+    conf_thresh = get('conf_thresh', 0.3)
+    distributor = get('distributor', 'cartesian_bbox')
+    residue_len = get('residue_len', 0)
+    if residue_len < 0:                                 # in units of the section thickness (matcher.py:518-520)
+        residue_len = max(1, abs(residue_len) * get('section_thickness', const.DEFAULT_THICKNESS) / mesh0.resolution)
+    trace = get('trace', None)                          # a list: one record per round (debugging / tests)
+    # the reference's 0.01 / max_dis is an iteration budget: at that tolerance the field in weakly constrained corners depends
+    # on the Krylov path taken.  Like the strip pipeline (and the oracle) the solves here are converged (relax_tol).
+    relax_tol, opt_tol = get('relax_tol', 1e-9), get('opt_tol', None)
+    affine_render = get('affine_approximated_render', True)
+    failed = (None, None, 0, DEFAULT_AVG_DEFORM)
+    spacings = np.array(spacings, dtype=np.float64).ravel()
+    if np.any(spacings < 1):                            # fractions of the longer side of the overlap (matcher.py:541-551)
+        bbox, valid = common.intersect_bbox(mesh0.bbox(gear=const.MESH_GEAR_MOVING), mesh1.bbox(gear=const.MESH_GEAR_MOVING))
+        if not valid:
+            return failed
+        spacings[spacings < 1] *= max(bbox[2] - bbox[0], bbox[3] - bbox[1])
+    untouched = (mesh0.copy(), mesh1.copy()) if get('compute_strain', True) else None
+    pair = _PairRelaxation(mesh0, mesh1, get('stiffness_lambda', 1), get('residue_mode', 'huber'), residue_len, get('link_weight_decay', 0.0))
+    pair.seed(get('initial_matches', None))
+    plan = _RoundPlan(spacings, get('allow_enlarge', False), get('allow_dwell', 0), get('max_spacing_skip', 0), get('pad', None))
+    images, borrowed = [], []
+    for ld in (image_loader0, image_loader1):
+        images.append(ld if isinstance(ld, _rd.ResidentImage) else _rd.ResidentImage(ld))
+        if images[-1] is not ld:
+            borrowed.append(images[-1])
+    linked_once = False
     try:
-        while sp_indx < spacings.size:
-            last = sp == spacings[-1]
-            mnb = min_num_blocks if last else 1
-            subpixel = do_subpixel if do_subpixel is not None else bool(last)
-            tol_r = (0.1 if last else max(1, 0.02 * sp)) if affine_render else 0
+        while True:
+            rnd = plan.due()
+            if rnd is None:
+                break
+            sp, last, pad = rnd
             if distributor == 'cartesian_bbox':
-                bboxes0, bboxes1 = distributor_cartesian_bbox(mesh0, mesh1, sp, min_num_blocks=mnb, shrink_factor=shrink_factor, zorder=True)
+                boxes0, boxes1 = distributor_cartesian_bbox(mesh0, mesh1, sp, min_num_blocks=get('min_num_blocks', 2) if last else 1,
+                                                            shrink_factor=get('shrink_factor', 1), zorder=True)
             else:
-                bboxes0, bboxes1 = distribute_matching_blocks(mesh0, mesh1, sp, dfunc=distributor, min_boundary_distance=min_boundary_distance,
-                                                              shrink_factor=shrink_factor, zorder=True, render_weight_threshold=render_weight_threshold)
-            if bboxes0 is None:
-                return invalid_output
-            if bboxes0.shape[0] == 0:                                         # the meshes do not overlap any more: nothing to correlate
-                if not initialized:
-                    return invalid_output
+                boxes0, boxes1 = distribute_matching_blocks(mesh0, mesh1, sp, dfunc=distributor, min_boundary_distance=get('min_boundary_distance', 0),
+                                                            shrink_factor=get('shrink_factor', 1), zorder=True,
+                                                            render_weight_threshold=get('render_weight_threshold', 0))
+            if boxes0 is None:
+                return failed
+            if boxes0.shape[0] == 0:                    # the meshes do not overlap any more
+                if not linked_once:
+                    return failed
                 break
-            xy0, xy1, conf = bboxes_mesh_renderer_matcher(mesh0, mesh1, images[0], images[1], bboxes0, bboxes1, batch_size=batch_size,
-                                                          pad=pad, subpixel=subpixel, affine_approx_tol=tol_r, sigma=sigma, conf_mode=conf_mode,
-                                                          mask_range=kwargs.get('mask_range', None))
-            if np.all(conf <= conf_thresh):
-                if not initialized:
-                    return invalid_output
+            subpixel = get('subpixel', None)
+            tol_render = ((0.1 if last else max(1, 0.02 * sp)) if affine_render else 0)
+            xy0, xy1, conf = bboxes_mesh_renderer_matcher(mesh0, mesh1, images[0], images[1], boxes0, boxes1, batch_size=get('batch_size', None),
+                                                          pad=pad, subpixel=bool(last) if subpixel is None else subpixel, affine_approx_tol=tol_render,
+                                                          sigma=get('sigma', 0.0), conf_mode=get('conf_mode', const.FFT_CONF_MIRROR),
+                                                          mask_range=get('mask_range', None))
+            good = conf > conf_thresh
+            if not good.any():
+                if not linked_once:
+                    return failed
                 break
-            if link_weight_decay == 0:
-                opt.clear_links()
-            else:
-                for lnk in opt.links:
-                    lnk._weight = lnk._weight * link_weight_decay
-            keep = conf > conf_thresh
-            xy0, xy1, wt = xy0[keep], xy1[keep], conf[keep]
-            max_dis = np.max(np.sum((xy0 - xy1) ** 2, axis=-1)) ** 0.5
+            pair.retire_links()
+            xy0, xy1, wt = xy0[good], xy1[good], conf[good]
+            max_dis = float(np.sqrt(np.max(np.sum((xy0 - xy1) ** 2, axis=-1))))
             if trace is not None:
-                trace.append(dict(sp=float(sp), blocks=int(conf.size), kept=int(keep.sum()), max_dis=float(max_dis), pad=bool(pad), subpixel=bool(subpixel),
-                                  tol=float(tol_r), conf=conf.copy(), bboxes1=bboxes1.copy()))
-            # the reference's 0.01 / max_dis is an iteration budget: at that tolerance the field in weakly constrained corners
-            # depends on the Krylov path taken.  Like the strip pipeline (and the oracle) the solves here are converged.
-            opt_tol_t = min(relax_tol, 0.01 / max(1, max_dis)) if opt_tol is None else opt_tol
-            min_block_size = 4 * max_dis                                      # min_block_size_multiplier, matcher.py:539
-            next_pos = np.searchsorted(-spacings, -min_block_size) - 1
-            if (not spacing_enlarged) and (next_pos < 0):
-                sp_indx = -1
-                spacing_enlarged = True
-                sp = np.ceil(min_block_size)
-                if to_pad is None:
-                    pad = True
-                continue
-            spacing_enlarged = True
-            if next_pos > sp_indx:
-                next_pos = min(next_pos, sp_indx + 1 + max_spacing_skip)
-                if to_pad is None:
-                    pad = bool(next_pos > sp_indx + 1)
-                sp_indx = next_pos
-                dwelled = 0
-            elif dwelled >= allow_dwell:
-                if to_pad is None:
-                    pad = True
-                sp_indx += 1
-                dwelled = 0
-            else:
-                if to_pad is None:
-                    pad = True
-                dwelled += 1
-            opt.add_link_from_coordinates(mesh0.uid, mesh1.uid, xy0, xy1, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), weight=wt)
-            if len(opt.links) == 0:
-                if not initialized:
-                    return invalid_output
+                trace.append(dict(sp=float(sp), blocks=int(conf.size), kept=int(good.sum()), max_dis=max_dis, pad=bool(pad),
+                                  subpixel=bool(last) if subpixel is None else bool(subpixel), tol=float(tol_render), conf=conf.copy(), bboxes1=boxes1.copy()))
+            if plan.advance(max_dis):
+                continue                                # the displacement outran the largest spacing: once more, with larger blocks
+            if pair.link(xy0, xy1, wt) == 0:
+                if not linked_once:
+                    return failed
                 break
             if max_dis > 0.1:
-                relax(opt_tol_t)
-                if residue_len > 0:
-                    if residue_mode == 'huber':
-                        opt.set_link_residue_huber(residue_len)
-                    elif residue_mode == 'threshold':
-                        opt.set_link_residue_threshold(residue_len)
-                    else:
-                        raise ValueError(residue_mode)
-                    weight_modified, _ = opt.adjust_link_weight_by_residue(relax_first=True)
-                    if weight_modified and (sp_indx < spacings.size):
-                        relax(opt_tol_t)
+                pair.relax(min(relax_tol, 0.01 / max(1, max_dis)) if opt_tol is None else opt_tol, more_rounds=plan.due() is not None)
             if trace is not None:
                 trace[-1]['field1'] = mesh1.vertices_w_offset(const.MESH_GEAR_MOVING) - mesh1.vertices_w_offset(const.MESH_GEAR_INITIAL)
-                trace[-1]['solve'] = dict(getattr(opt, 'last_solve', {}))
-            initialized = True
-            if 0 <= sp_indx < spacings.size:
-                sp = spacings[sp_indx]
+                trace[-1]['solve'] = dict(getattr(pair.slm, 'last_solve', {}))
+            linked_once = True
     finally:
-        for im in own_images:
+        plan.close()
+        for im in borrowed:
             im.free()
-    if len(opt.links) == 0:
-        return invalid_output
-    link = opt.links[-1]
-    xy0 = link.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=True, combine=True)
-    xy1 = link.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=True, combine=True)
-    weight = link.weight(use_mask=True)
-    if compute_strain:                                                        # matcher.py:752-777
-        opt = optimizer.SLM([mesh0_ori, mesh1_ori], stiffness_lambda=stiffness_lambda)
-        opt.add_link_from_coordinates(mesh0_ori.uid, mesh1_ori.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight)
-        opt.optimize_affine_cascade(start_gear=const.MESH_GEAR_INITIAL, target_gear=const.MESH_GEAR_FIXED, svd_clip=(1, 1))
-        opt.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_COPY_EXACT)
-        if linear_system:
-            opt.optimize_linear(tol=1e-6)
-        else:
-            opt.optimize_Newton_Raphson(max_newtonstep=5, tol=1e-4)
-        Es0 = Es = 0
-        soft_avg = np.mean([m.soft_factor for m in opt.meshes])
-        for m in opt.meshes:
-            if (one_locked and (not m.locked)) or ((not one_locked) and (m.soft_factor <= soft_avg)):
-                v0 = m.vertices(gear=const.MESH_GEAR_FIXED)
-                dv = m.vertices(gear=const.MESH_GEAR_MOVING) - v0
-                v0 = v0 - np.mean(v0, axis=0, keepdims=True)
-                dv = dv - np.mean(dv, axis=0, keepdims=True)
-                St, _ = m.stiffness_matrix()
-                Es += max(0, St.dot(dv.ravel()).dot(dv.ravel()))
-                Es0 += max(0, St.dot(v0.ravel()).dot(v0.ravel()))
-        strain = (Es / Es0) ** 0.5
+    if len(pair.links) == 0:
+        return failed
+    newest = pair.links[-1]
+    xy0 = newest.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=True, combine=True)
+    xy1 = newest.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=True, combine=True)
+    weight = newest.weight(use_mask=True)
+    strain = DEFAULT_AVG_DEFORM if untouched is None else _strain_of_matches(untouched[0], untouched[1], xy0, xy1, weight, get('stiffness_lambda', 1))
     return xy0, xy1, weight, strain
 
 

@@ -607,6 +607,33 @@ class Mesh:
             lib.fb_sys_destroy(ctx, sysh)
         return K, stress
 
+    def stiffness_energy(self, fields, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)):
+        """x^T K x for every displacement field x (V x 2) of ``fields``, K = this mesh's stiffness matrix at ``gear``: assembled
+        and contracted on the device (fb_sys_group_energy) -- the two energies of the strain estimate, matcher.py:764-777"""
+        lib, ctx = _lib.load(), _lib.ctx()
+        sysh = C.c_void_p()
+        _lib.check(lib.fb_sys_create(ctx, self.num_vertices, C.byref(sysh)))
+        try:
+            mid = C.c_int()
+            _lib.check(lib.fb_sys_add_mesh(ctx, sysh, 0, _lib.ptr(self.triangles), self.num_vertices, self.num_triangles, C.byref(mid)))
+            _lib.check(lib.fb_sys_set_links(ctx, sysh, 0, None))
+            nnzb = C.c_int64()
+            _lib.check(lib.fb_sys_finalize(ctx, sysh, C.byref(nnzb)))
+            v0 = np.ascontiguousarray(self.vertices(gear[0]), dtype=np.float64)
+            v1 = self.vertices(gear[-1])
+            self.assemble_into(sysh, mid.value, v0, None if v1 is self.vertices(gear[0]) else np.ascontiguousarray(v1, dtype=np.float64), 1.0)
+            out = []
+            e = C.c_double()
+            for x in fields:
+                x = np.ascontiguousarray(x, dtype=np.float64)
+                if x.shape != (self.num_vertices, 2):
+                    raise ValueError('a field is V x 2')
+                _lib.check(lib.fb_sys_group_energy(ctx, sysh, 1, _lib.ptr(x), C.byref(e)))
+                out.append(float(e.value))
+        finally:
+            lib.fb_sys_destroy(ctx, sysh)
+        return out
+
     def stiffness_matrix_local_normalized(self, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), tri_mask=None, **kwargs):
         """feabas/mesh.py:3086-3129 -> (scipy CSR, stress float32) of the sub-mesh ``tri_mask``: every triangle as the
         default linear material (Poisson ratio 0, D = m diag(1, 1, 1/2)) with its effective multiplier clipped at

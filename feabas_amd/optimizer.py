@@ -9,6 +9,7 @@ random-perturbation early exits (optimizer.py:1955-1961, 2056-2063) exist, so
 results are deterministic.
 """
 import ctypes as C
+import os
 
 import numpy as np
 from scipy import sparse
@@ -701,7 +702,7 @@ class SLM:
         start_gear = kwargs.get('start_gear', target_gear)
         stiffness_lambda = kwargs.get('stiffness_lambda', self._stiffness_lambda)
         crosslink_lambda = kwargs.get('crosslink_lambda', self._crosslink_lambda)
-        precondition = kwargs.get('precondition', 'jacobi')
+        precondition = kwargs.get('precondition', os.environ.get('FEABAS_HIP_PRECONDITION', 'jacobi'))
         groupings = kwargs.get('groupings', None)
         multigrid = isinstance(precondition, str) and precondition.lower().startswith(('smooth', 'sa', 'amg', 'multigrid', 'mg'))
         # matcher.py:561 asks for pyamg's smoothed aggregation (optimizer.py:1969-1971); here: the device's aggregation
@@ -739,7 +740,7 @@ class SLM:
         mi = -1 if maxiter is None else int(maxiter)
         # (a window without a locked mesh, held together by its links alone, is what the Jacobi-PCG is good at and the
         # hierarchy is not: 115 against 472 iterations on a floating pair of 6 000-node meshes with 800 matches)
-        pre = 0 if precondition is None else (2 if multigrid and groupings is None and any(m.locked for m in self.meshes) else 1)
+        pre = 0 if precondition is None else (2 if multigrid and groupings is None and (any(m.locked for m in self.meshes) or os.environ.get('FEABAS_HIP_MG_FLOATING') == '1') else 1)
         bn = float(np.linalg.norm(b)) / self._gmean           # grouped terms are divided by mean(count) (optimizer.py:1408-1411)
         if held is not None and not held.all():
             # remove_extra_dof (optimizer.py:1360-1377, 1976-1991): three degrees of freedom of the first mesh of every

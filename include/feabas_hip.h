@@ -365,6 +365,18 @@ typedef struct fb_strip_opts {
  * cap_y doubles, may be NULL for a sizing call).  The block grid fb_match_strips walks is made by the same code. */
 int fb_divide_bbox(fb_ctx* ctx, const double* bbox, const double* block_hw, const int* min_blocks_yx, double shrink_factor, int round_output,
                    int* counts_xy, int* steps_xy, double* x_start, int cap_x, double* y_start, int cap_y);
+/* Round stepper of the coarse-to-fine block matcher (iterative_xcorr_matcher_w_mesh, matcher.py:567-716), host only: which
+ * spacing the next round of block matching runs at and whether its blocks are zero padded, given the largest displacement the
+ * last round measured.  create: the spacings (any order), allow_enlarge / allow_dwell / max_spacing_skip as the reference's
+ * keywords, pad_fixed -1 = by rule (1 / 0: the `pad` keyword).  round: 0 when the walk is over, else 1 and the spacing, whether it
+ * is the last (smallest) one and the padding.  advance: after a round with largest displacement max_dis (multiplier = the
+ * reference's min_block_size_multiplier, 4); *redo = 1 when that round has to be repeated at the enlarged spacing before any link
+ * is made (matcher.py:693-699). */
+typedef struct fb_schedule fb_schedule;
+fb_schedule* fb_schedule_create(const double* spacings, int n, int allow_enlarge, int allow_dwell, int max_spacing_skip, int pad_fixed);
+void fb_schedule_destroy(fb_schedule* s);
+int fb_schedule_round(const fb_schedule* s, double* spacing, int* last, int* pad);
+int fb_schedule_advance(fb_schedule* s, double max_dis, double multiplier, int* redo);
 int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* opts, fb_strip_matcher** out);
 /* Strips of unequal size (the usual case in a real section: every overlap follows the stage jitter of its two tiles,
  * stitcher.py:561-571): pair p is the shapes[p] = {h, w} top-left corner of its H x W slot; every stage works on the pair's own

@@ -483,3 +483,49 @@ def test_link_terms_match_the_numpy_statement():
     bad = tid0.copy(); bad[3] = t.shape[0]
     assert _lib.load().fb_link_terms(None, K, _lib.ptr(t), t.shape[0], None, _lib.ptr(bad), None, 0, _lib.ptr(t), t.shape[0], None, _lib.ptr(tid1), None, -1,
                                      0.0, 0.0, _lib.ptr(nodes6), None, None) != 0
+
+
+def test_round_stepper_of_the_block_matcher():
+    """fb_schedule_* (the C-ABI stepper of the coarse-to-fine walk, matcher.py:567-716) on hand-worked walks: the jump to the
+    smallest spacing that still holds 4 x the displacement (one place at a time with max_spacing_skip = 0, padding off when a
+    place was reached by a jump of exactly one), the one-place step with padding when the displacement does not allow a jump,
+    dwelling, the enlarged extra round, a fixed `pad`; and against the one-line rule of the strip oracle (pipeline_ref.py:441-442)"""
+    from feabas_amd.matcher import _RoundPlan
+
+    def walk(plan, dis):
+        out = []
+        for d in dis:
+            r = plan.due()
+            if r is None:
+                break
+            redo = plan.advance(d)
+            out.append(r + (redo,))
+        out.append(plan.due())
+        plan.close()
+        return out
+    # the 4k strip: spacings [1024, 75]; a displacement of 12 px lets the walk go to 75 by a one-place jump: no padding there
+    assert walk(_RoundPlan([75, 1024]), [12.0, 0.3]) == [(1024.0, False, True, False), (75.0, True, False, False), None]
+    # ... of 30 px (4 x 30 > 75) it may not jump: it still moves on (allow_dwell = 0), but with padded blocks
+    assert walk(_RoundPlan([1024, 75]), [30.0, 0.3]) == [(1024.0, False, True, False), (75.0, True, True, False), None]
+    # three spacings, jump over one: max_spacing_skip = 0 clips it to one place; = 1 takes both and pads (the skipped range was never searched)
+    assert walk(_RoundPlan([1000, 300, 75]), [2.0, 2.0, 2.0]) == [(1000.0, False, True, False), (300.0, False, False, False), (75.0, True, False, False), None]
+    assert walk(_RoundPlan([1000, 300, 75], max_spacing_skip=1), [2.0, 2.0]) == [(1000.0, False, True, False), (75.0, True, True, False), None]
+    # dwelling twice on a spacing whose displacement stays large
+    w = walk(_RoundPlan([400, 100], allow_dwell=2), [200.0] * 6)
+    assert [r[0] for r in w[:-1]] == [400.0, 400.0, 400.0, 100.0, 100.0, 100.0] and w[-1] is None
+    # the displacement outruns the largest spacing: one extra round at ceil(4 d), repeated before anything is linked, then the list
+    w = walk(_RoundPlan([400, 100], allow_enlarge=True), [300.2, 300.2, 1.0, 1.0])
+    assert w == [(400.0, False, True, True), (1201.0, False, True, False), (400.0, False, True, False), (100.0, True, False, False), None]
+    assert walk(_RoundPlan([400, 100], allow_enlarge=False), [300.0, 1.0]) == [(400.0, False, True, False), (100.0, True, True, False), None]
+    # a fixed `pad` is never overruled
+    assert [r[2] for r in walk(_RoundPlan([1024, 75], pad=False), [30.0, 0.3])[:-1]] == [False, False]
+    # the strip oracle's rule for its two-spacing walk
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        spacings = np.sort(rng.uniform(30, 1500, 2))[::-1]
+        d = float(rng.uniform(0.05, 400))
+        plan = _RoundPlan(spacings)
+        plan.due(); plan.advance(d)
+        nxt = plan.due(); plan.close()
+        next_pos = np.searchsorted(-spacings, -4 * d) - 1
+        assert nxt is not None and nxt[2] == ((min(next_pos, 1) > 1) if next_pos > 0 else True)
