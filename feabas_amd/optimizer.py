@@ -1007,15 +1007,18 @@ class SLM:
 
 def solve(A, b, solver='minres', x0=None, tol=1e-7, atol=None, maxiter=None, M=None, **kwargs):
     """feabas/optimizer.py:1945-2080: solve A x = b to ||Ax-b|| <= max(tol, atol/||b||) ||b||
-    on the GPU (Jacobi-PCG on 0.5 (A + A^T)).  ``solver`` is accepted for signature
-    compatibility; ``M`` other than None / 'jacobi' is not available (no pyamg on device)."""
+    on the GPU (Jacobi-PCG on 0.5 (A + A^T)).  ``solver`` and ``M`` are accepted for signature
+    compatibility: both only choose HOW the reference iterates, the solution to the tolerance is the same.  A bare matrix
+    carries no mesh geometry, which the device's aggregation multigrid is built from (csrc/fb_mg.inc), so
+    M='smoothed_aggregation' (optimizer.py:1969-1971) is served by the Jacobi-PCG here; the multigrid is reached through
+    ``SLM.optimize_linear(precondition='smoothed_aggregation')``, which knows the meshes."""
     edc = kwargs.get('extra_dof_constraint', None)
     A = sparse.csr_matrix(A)
     b = np.ascontiguousarray(b, dtype=np.float64)
     if (maxiter == 0) or (np.linalg.norm(b) == 0):
         return np.zeros_like(b)
-    if isinstance(M, str) and M.lower().startswith(('smooth', 'sa')):
-        raise NotImplementedError("smoothed-aggregation preconditioning is not on the GPU path; use M='jacobi'")
+    if not (M is None or isinstance(M, str)):
+        raise NotImplementedError('solve(M=<operator>): a host preconditioner object cannot run inside the device PCG')
     full_n = b.size
     if edc is not None:                                     # optimizer.py:1976-1991
         if (not isinstance(edc, np.ndarray)) or (edc.dtype != bool):

@@ -563,15 +563,16 @@ def g16_relax():
     m = fresh()
     out['fv_modified'] = np.array(optimizer.relax_mesh(m, free_vertices=fv, gear=gear, **tight))
     out['fv_vmov'] = m.vertices(gear=gear[1]); out['fv_moff'] = m.offset(gear=gear[1])
-    # relax_mesh_most_deformed: which region it frees (the arguments it hands to relax_mesh) and its result with the
-    # reference's default solver settings
+    # relax_mesh_most_deformed: which region it frees (the arguments it hands to relax_mesh) and its converged result
     captured = {}
     orig = optimizer.relax_mesh
 
     def spy(M, free_vertices=None, free_triangles=None, **kw):
         captured['fv'] = None if free_vertices is None else np.array(free_vertices)
         captured['ft'] = None if free_triangles is None else np.array(free_triangles)
-        return orig(M, free_vertices=free_vertices, free_triangles=free_triangles, **kw)
+        # relax_mesh_most_deformed has no way to pass solver settings on: with the defaults (tol 1e-7, the random-perturbation
+        # exit of optimizer.solve) the end state is one of many; the capture runs the same call converged and deterministic
+        return orig(M, free_vertices=free_vertices, free_triangles=free_triangles, **{**kw, **tight})
 
     optimizer.relax_mesh = spy
     try:

@@ -279,7 +279,7 @@ def test_g13_strain_chain_through_the_class_api(fb):
 def test_g14_optimize_linear_groupings(fb):
     """SLM.optimize_linear(groupings=...) (optimizer.py:1378-1415): the members of a group are entered at the same vertex
     offset and their stiffness / stress rows add up on the device (fb_sys_assemble_mesh_add).  ||b|| against the reference
-    (G14), the field against the oracle's exact solve of the same grouped system (itself pinned by G14)"""
+    (G14), the field against the REFERENCE's own field (G14, deterministic settings) and the oracle's exact solve, to 1e-5 / 1e-4 of the motion"""
     from conftest import load_golden
     from test_oracle_golden import g14_oracle_system
     from oracle import fem_ref
@@ -300,6 +300,8 @@ def test_g14_optimize_linear_groupings(fb):
     for k in range(1, 4):
         np.testing.assert_allclose(ms[k].vertices(const.MESH_GEAR_MOVING) + ms[k].offset(const.MESH_GEAR_MOVING),
                                    oms[k].vertices_w_offset(fem_ref.GEAR_MOVING), atol=1e-4 * scale)
+        np.testing.assert_allclose(ms[k].vertices(const.MESH_GEAR_MOVING) + ms[k].offset(const.MESH_GEAR_MOVING),
+                                   g[f'm{k}_v_after'] + g[f'm{k}_off_after'], atol=1e-5 * scale)
     # meshes 1 and 2 moved as one
     np.testing.assert_allclose(ms[1].vertices(const.MESH_GEAR_MOVING) - g['m1_v'], ms[2].vertices(const.MESH_GEAR_MOVING) - g['m2_v'], atol=1e-9 * scale)
 
@@ -358,8 +360,8 @@ def test_g16_relax_mesh(fb, which):
 @pytest.mark.parametrize('name,kw', [('md_flip', dict(deform_cutoff=-1)), ('md_cut', dict(deform_cutoff=0.35)),
                                      ('md_iqr', dict(deform_cutoff=0.35, iqr=1.5))])
 def test_g16_relax_most_deformed(fb, name, kw):
-    """relax_mesh_most_deformed: same region as the reference (via the oracle's pinned selection), the field at the
-    reference's own stopping size (its default exits stop within 0.25 px of the fixed point), flips removed"""
+    """relax_mesh_most_deformed: same region as the reference (via the oracle's pinned selection), the field against the
+    REFERENCE's own converged result (golden G16, captured with deterministic solver settings) to 1e-4 of the motion, flips removed"""
     from conftest import load_golden
     from test_oracle_golden import g16_oracle_mesh, GEARS_FM
     from oracle import fem_ref
@@ -368,7 +370,7 @@ def test_g16_relax_most_deformed(fb, name, kw):
     gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
     m = _g16_mesh(fb, g)
     assert fb.optimizer.relax_mesh_most_deformed(m, gear=gear, **kw) == bool(g[f'{name}_modified'])
-    np.testing.assert_allclose(m.vertices(gear[1]), g[f'{name}_vmov'], atol=0.25)
+    np.testing.assert_allclose(m.vertices(gear[1]), g[f'{name}_vmov'], atol=1e-4 * np.abs(g[f'{name}_vmov'] - g['vmov']).max())
     om = g16_oracle_mesh(g)
     fem_ref.relax_mesh_most_deformed(om, GEARS_FM, **kw)
     scale = np.abs(om.vertices(fem_ref.GEAR_MOVING) - g['vmov']).max()

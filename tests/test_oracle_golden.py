@@ -248,9 +248,9 @@ def g14_oracle_system(g):
 
 
 def test_g14_groupings():
-    """the grouped system A, b of the restatement is the reference's: ||b|| equal, and the reference's own (iteratively
-    solved, relres 1e-8) displacement field leaves a residual of that size in it.  (The system is ill conditioned: the
-    reference's iterate is ~1 % away from the fixed point, so the fields themselves are compared loosely.)"""
+    """the grouped system A, b of the restatement is the reference's: ||b|| equal, the reference's own (iteratively solved,
+    relres 1e-8, deterministic settings) displacement field leaves a residual of that size in it, and the exact solve of the
+    restatement lands on that field to 1e-6 of the motion"""
     g = load_golden('g14_groupings.npz')
     ms, links = g14_oracle_system(g)
     cost, A, b, expanded = fem_ref.optimize_linear_grouped(ms, links, g['groupings'], return_system=True)
@@ -262,7 +262,7 @@ def test_g14_groupings():
     assert np.linalg.norm(A.dot(dd_ref) - b) <= 3e-8 * np.linalg.norm(b)
     scale = np.abs(g['m1_v_after'] - g['m1_v']).max()
     for k in range(1, 4):
-        np.testing.assert_allclose(ms[k].vertices_w_offset(fem_ref.GEAR_MOVING), g[f'm{k}_v_after'] + g[f'm{k}_off_after'], atol=0.05 * scale)
+        np.testing.assert_allclose(ms[k].vertices_w_offset(fem_ref.GEAR_MOVING), g[f'm{k}_v_after'] + g[f'm{k}_off_after'], atol=1e-6 * scale)
 
 
 # ----------------------------------------------------------------------- G16: relax_mesh
@@ -330,12 +330,14 @@ def test_g16_most_deformed_region():
 @pytest.mark.parametrize('name,kw', [('md_flip', dict(deform_cutoff=-1)), ('md_cut', dict(deform_cutoff=0.35)),
                                      ('md_iqr', dict(deform_cutoff=0.35, iqr=1.5))])
 def test_g16_relax_most_deformed(name, kw):
-    """the reference ran these with its default solver exits (tol 1e-7 + the tolerated-perturbation stop), so the field
-    is compared at the size of that stop (0.25 px), the flips it removes exactly"""
+    """the reference's converged result (captured with tol 1e-11 and without the random-perturbation exit: relax_mesh_most_deformed
+    cannot pass solver settings on, so make_golden.py hands them to the relax_mesh it calls): the field to 1e-6 px (the motion
+    is 14 px), the flips it removes exactly"""
     g = load_golden('g16_relax.npz')
     m = g16_oracle_mesh(g)
     assert fem_ref.relax_mesh_most_deformed(m, GEARS_FM, **kw) == bool(g[f'{name}_modified'])
-    np.testing.assert_allclose(m.vertices(fem_ref.GEAR_MOVING), g[f'{name}_vmov'], atol=0.25)
+    np.testing.assert_allclose(m.vertices(fem_ref.GEAR_MOVING), g[f'{name}_vmov'], atol=1e-6)
+    assert np.abs(g[f'{name}_vmov'] - g['vmov']).max() > 10
     if name == 'md_flip':
         assert (g['area_deform'] < 0).sum() == 3 and (g['md_flip_area_deform'] > 0).all()
         assert (m.triangle_area_deform(GEARS_FM) > 0).all()
