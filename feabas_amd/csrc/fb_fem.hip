@@ -539,6 +539,34 @@ int upload(fb_ctx* ctx, T** dptr, const T* host, size_t count) {
 
 }  // namespace
 
+// ---- symbolic phase: coupled vertex pairs as sortable keys
+__global__ void pattern_tri_keys_kernel(int T, int voff, const int* __restrict__ tri, uint64_t* __restrict__ keys) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int v[3] = {voff + tri[3 * t], voff + tri[3 * t + 1], voff + tri[3 * t + 2]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) keys[9 * (size_t)t + 3 * a + b] = ((uint64_t)(unsigned)v[a] << 32) | (unsigned)v[b];
+}
+__global__ void pattern_link_keys_kernel(int64_t K, const int* __restrict__ nodes, uint64_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    int v[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a] = nodes[6 * i + a];
+    const uint64_t dead = (uint64_t)0xffffffffu << 32;                       // a slot of a locked mesh: sorts behind every row
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+            keys[36 * (size_t)i + 6 * a + b] = (v[a] >= 0 && v[b] >= 0) ? (((uint64_t)(unsigned)v[a] << 32) | (unsigned)v[b]) : dead;
+}
+__global__ void pattern_diag_keys_kernel(int nv, uint64_t* __restrict__ keys) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nv) keys[v] = ((uint64_t)(unsigned)v << 32) | (unsigned)v;
+}
+
 // ---- links on the device: the table of matches is uploaded once; the membership test of an update and the index vertex ->
 // incident match slots (CSR over free vertices, slots ascending: the assembly sums in a fixed order) are made there.  The host
 // statement of the same two steps (36 binary searches per match on a few threads, a counting sort and three more copies) took
@@ -706,45 +734,62 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
     FB_CHECK_ARG(ctx, s && !s->finalized);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     const int nv = s->nv;
-    // ---- symbolic pattern: bucket the (row, col) pairs by row, then sort + unique each short row
-    std::vector<int64_t> cnt((size_t)nv + 1, 0);
-    for (auto& m : s->meshes)
-        for (int t = 0; t < m.T; ++t)
-            for (int a = 0; a < 3; ++a) cnt[(size_t)m.voff + m.tri[3 * (size_t)t + a] + 1] += 3;
-    for (int64_t i = 0; i < s->nlink; ++i) {
-        int live = 0;
-        for (int b = 0; b < 6; ++b) live += s->nodes[6 * i + b] >= 0;
-        for (int a = 0; a < 6; ++a)
-            if (s->nodes[6 * i + a] >= 0) cnt[(size_t)s->nodes[6 * i + a] + 1] += live;
-    }
-    for (int v = 0; v < nv; ++v) cnt[v + 1] += 1;                       // keep the diagonal in every row
-    for (int v = 0; v < nv; ++v) cnt[v + 1] += cnt[v];
-    std::vector<int> raw((size_t)cnt[nv]);
-    std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
-    for (int v = 0; v < nv; ++v) raw[fill[v]++] = v;
-    for (auto& m : s->meshes)
-        for (int t = 0; t < m.T; ++t)
-            for (int a = 0; a < 3; ++a) {
-                const int r = m.voff + m.tri[3 * (size_t)t + a];
-                for (int b = 0; b < 3; ++b) raw[fill[r]++] = m.voff + m.tri[3 * (size_t)t + b];
-            }
-    for (int64_t i = 0; i < s->nlink; ++i)
-        for (int a = 0; a < 6; ++a) {
-            const int r = s->nodes[6 * i + a];
-            if (r < 0) continue;
-            for (int b = 0; b < 6; ++b)
-                if (s->nodes[6 * i + b] >= 0) raw[fill[r]++] = s->nodes[6 * i + b];
+    // ---- symbolic pattern on the device: every coupled vertex pair as a 64-bit key (row << 32 | col) -- 9 per triangle, live^2
+    //      per match, the diagonal of every row -- radix sorted and made unique; the sorted keys ARE the block CSR (the
+    //      host statement of the same steps, a bucket pass and a sort per row, took 57 of the 64 ms of a first assembly at 1e6 DoF)
+    {
+        int rc;
+        size_t ntri_keys = 0;
+        for (auto& m : s->meshes) ntri_keys += 9 * (size_t)m.T;
+        const size_t nkeys = ntri_keys + 36 * (size_t)s->nlink + (size_t)nv;
+        void *d_keys = nullptr, *d_keys2 = nullptr, *d_tmp = nullptr, *d_nodes_tmp = nullptr, *d_tri_tmp = nullptr;
+        auto release = [&]() { fb_free(ctx, d_keys); fb_free(ctx, d_keys2); fb_free(ctx, d_tmp); fb_free(ctx, d_nodes_tmp); fb_free(ctx, d_tri_tmp); };
+        if ((rc = fb_malloc(ctx, sizeof(uint64_t) * nkeys, &d_keys))) return rc;
+        if ((rc = fb_malloc(ctx, sizeof(uint64_t) * nkeys, &d_keys2))) { release(); return rc; }
+        size_t at = 0;
+        for (auto& m : s->meshes) {
+            if (!m.T) continue;
+            if ((rc = fb_malloc(ctx, sizeof(int) * 3 * (size_t)m.T, &d_tri_tmp))) { release(); return rc; }
+            if ((rc = fb_copy_h2d(ctx, d_tri_tmp, m.tri.data(), sizeof(int) * 3 * (size_t)m.T))) { release(); return rc; }
+            hipLaunchKernelGGL(pattern_tri_keys_kernel, dim3((unsigned)fb_cdiv(m.T, kT)), dim3(kT), 0, ctx->stream, m.T, m.voff, (const int*)d_tri_tmp,
+                               (uint64_t*)d_keys + at);
+            at += 9 * (size_t)m.T;
+            FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            fb_free(ctx, d_tri_tmp); d_tri_tmp = nullptr;
         }
-    s->browptr.assign((size_t)nv + 1, 0);
-    s->bcol.clear();
-    s->bcol.reserve(raw.size() / 2);
-    for (int v = 0; v < nv; ++v) {
-        auto b = raw.begin() + cnt[v], e = raw.begin() + cnt[v + 1];
-        std::sort(b, e);
-        e = std::unique(b, e);
-        s->bcol.insert(s->bcol.end(), b, e);
-        if (s->bcol.size() >= (size_t)(1u << 31)) return fb_fail(ctx, FB_ERR_ARG, "pattern exceeds int32 block indexing");
-        s->browptr[v + 1] = (int)s->bcol.size();
+        if (s->nlink) {
+            if ((rc = fb_malloc(ctx, sizeof(int) * 6 * (size_t)s->nlink, &d_nodes_tmp))) { release(); return rc; }
+            if ((rc = fb_copy_h2d(ctx, d_nodes_tmp, s->nodes.data(), sizeof(int) * 6 * (size_t)s->nlink))) { release(); return rc; }
+            hipLaunchKernelGGL(pattern_link_keys_kernel, dim3((unsigned)fb_cdiv(s->nlink, kT)), dim3(kT), 0, ctx->stream, s->nlink, (const int*)d_nodes_tmp,
+                               (uint64_t*)d_keys + at);
+            at += 36 * (size_t)s->nlink;
+        }
+        hipLaunchKernelGGL(pattern_diag_keys_kernel, dim3((unsigned)fb_cdiv(nv, kT)), dim3(kT), 0, ctx->stream, nv, (uint64_t*)d_keys + at);
+        FB_HIP(ctx, hipGetLastError());
+        int row_bits = 1;
+        while ((1LL << row_bits) < (int64_t)nv + 1) ++row_bits;                        // (the all-ones row of a dead link slot sorts behind every row)
+        size_t tmp_sort = 0, tmp_uniq = 0;
+        int* d_count = reinterpret_cast<int*>(ctx->small);
+        FB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, (uint64_t*)d_keys, (uint64_t*)d_keys2, (int)nkeys, 0, 32 + row_bits, ctx->stream));
+        FB_HIP(ctx, hipcub::DeviceSelect::Unique(nullptr, tmp_uniq, (uint64_t*)d_keys2, (uint64_t*)d_keys, d_count, (int)nkeys, ctx->stream));
+        if (nkeys >= (size_t)INT_MAX) { release(); return fb_fail(ctx, FB_ERR_ARG, "pattern exceeds int32 block indexing"); }
+        if ((rc = fb_malloc(ctx, std::max<size_t>(std::max(tmp_sort, tmp_uniq), 16), &d_tmp))) { release(); return rc; }
+        FB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_sort, (uint64_t*)d_keys, (uint64_t*)d_keys2, (int)nkeys, 0, 32 + row_bits, ctx->stream));
+        FB_HIP(ctx, hipcub::DeviceSelect::Unique(d_tmp, tmp_uniq, (uint64_t*)d_keys2, (uint64_t*)d_keys, d_count, (int)nkeys, ctx->stream));
+        int nuniq = 0;
+        if ((rc = fb_copy_d2h(ctx, &nuniq, d_count, sizeof(int)))) { release(); return rc; }
+        // the key of the dead slots is the tail of the sorted list
+        std::vector<uint64_t> hk((size_t)nuniq);
+        if (nuniq && (rc = fb_copy_d2h(ctx, hk.data(), d_keys, sizeof(uint64_t) * (size_t)nuniq))) { release(); return rc; }
+        while (!hk.empty() && (hk.back() >> 32) >= (uint64_t)nv) hk.pop_back();
+        release();
+        s->browptr.assign((size_t)nv + 1, 0);
+        s->bcol.resize(hk.size());
+        for (size_t j = 0; j < hk.size(); ++j) {
+            s->bcol[j] = (int)(hk[j] & 0xffffffffu);
+            s->browptr[(size_t)(hk[j] >> 32) + 1]++;
+        }
+        for (int v = 0; v < nv; ++v) s->browptr[v + 1] += s->browptr[v];
     }
     const int64_t nnzb = (int64_t)s->bcol.size();
     // ---- device pattern lives in the solver matrix
