@@ -61,6 +61,7 @@ def parse():
     ap.add_argument('--fem-cpu-iters', type=int, default=40, help='iterations of the CPU baseline PCG (about 0.1 s each at 1e6 DoF)')
     ap.add_argument('--stitch-sections', type=int, default=8, help='config[3]: sections of 400 tiles PER RANK (64 sections on 8 GPUs); 0: skip')
     ap.add_argument('--align-sections', type=int, default=16, help='config[4]: sections of --align-grid^2 nodes PER RANK (128 sections on 8 GPUs); 0: skip')
+    ap.add_argument('--align-threads', type=int, default=4, help='host threads (one context and one SLM each) that share the sections of config[4]')
     ap.add_argument('--align-grid', type=int, default=500, help='nodes per side of a section mesh of config[4] (500 x 500 = 250 k nodes)')
     ap.add_argument('--cpu-pool-seconds', type=float, default=20.0, help='wall-clock budget of the all-core CPU baseline (process pool); 0: skip')
     ap.add_argument('--dry-run', action='store_true', help='no GPU work: the ranks exercise sharding and the exchange steps on synthetic tables over gloo (CPU tests)')
@@ -544,14 +545,20 @@ def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_
         ph = 1.1 * g
         return np.stack((6 * np.sin(2 * np.pi * v[:, 1] / L + ph) + 2 * np.cos(4 * np.pi * v[:, 0] / L - ph),
                          5 * np.cos(2 * np.pi * v[:, 0] / L - ph) + 2 * np.sin(4 * np.pi * v[:, 1] / L + ph)), axis=-1)
-    prev = mesh.Mesh(v.copy(), tri, uid=0, locked=True)
-    cur = mesh.Mesh(v.copy(), tri, uid=1)
-    nxt = mesh.Mesh(v.copy(), tri, uid=2, locked=True)
-    slm = optimizer.SLM([prev, cur, nxt], [], stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    # sections are independent units: T host threads, each with its own context (HIP stream), its own three meshes and SLM
+    # (one symbolic pattern per thread, kept across its sections), take the sections round-robin -- the host part of a section
+    # (link terms, set_field, the Python around them) of one thread runs beside the device part of another
+    T = max(1, min(args.align_threads, nsec, _lib.cpu_budget()))
+    actxs = [ctx] + [_lib.new_context() for _ in range(T - 1)]
+    units = []
+    for t_ in range(T):
+        prev = mesh.Mesh(v.copy(), tri, uid=0, locked=True)
+        cur = mesh.Mesh(v.copy(), tri, uid=1)
+        nxt = mesh.Mesh(v.copy(), tri, uid=2, locked=True)
+        units.append((prev, cur, nxt, optimizer.SLM([prev, cur, nxt], [], stiffness_lambda=1.0, crosslink_lambda=-1.0)))
     nl = 50000
     g0 = 1 + rank * nsec                                    # section 0 of the stack is the locked anchor
     disp = np.empty((nsec, n * n, 2))
-    iters = 0; t_solve = 0.0; relres = []
     from feabas_amd import constant as const
     # the matches of every section pair (what the matching stage delivers, in the raster order of its block grid) and the
     # neighbours' fields are inputs: made before the clock starts
@@ -563,9 +570,9 @@ def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_
         lk = [(np.sort(rng.integers(0, tri.shape[0], nl)), rng.dirichlet((1, 1, 1), nl), rng.uniform(0.3, 1.0, nl).astype(np.float32)) for _ in range(2)]
         inputs.append((v + (field(g - 1) - dg), v + (field(g + 1) - dg), lk))
     zero = np.zeros((1, 2))
-    barrier()
-    t0 = time.time()
-    for k in range(nsec):
+
+    def one_section(t_, k):
+        prev, cur, nxt, slm = units[t_]
         vp, vn, lk = inputs[k]
         for m_, vv in ((prev, vp), (nxt, vn)):
             m_.unlock(); m_.set_vertices(vv, const.MESH_GEAR_MOVING); m_.lock()
@@ -573,9 +580,14 @@ def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_
         slm.links = [optimizer.Link(m0, m1, tid, tid, B, B, weight=w) for (m0, m1), (tid, B, w) in zip(((prev, cur), (cur, nxt)), lk)]
         t1 = time.time()
         slm.optimize_linear(tol=1e-4)
-        t_solve += time.time() - t1
-        iters += slm.last_solve['iters']; relres.append(slm.last_solve['relres'])
+        ts = time.time() - t1
         disp[k] = cur.vertices_w_offset(const.MESH_GEAR_MOVING) - v
+        return slm.last_solve['iters'], slm.last_solve['relres'], ts
+    barrier()
+    t0 = time.time()
+    res = run_jobs(list(range(nsec)), actxs, one_section, _lib)
+    iters = int(sum(r[0] for r in res)); relres = [r[1] for r in res]; t_solve = float(sum(r[2] for r in res))
+    slm = units[(nsec - 1) % T][3]                          # the unit that solved the last section (checked below)
     dt_rank = time.time() - t0
     barrier()
     dt = reduce_max(time.time() - t0)
@@ -586,16 +598,18 @@ def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_
     # tests/test_gpu_fem.py::test_g18_section_between_locked_neighbours_vs_reference.)
     from feabas_amd.mesh import bsr_download
     k = nsec - 1
-    A_h = bsr_download(slm._sys, 4, slm._nv, slm._nnzb)
-    b_h = np.empty(2 * slm._nv)
-    _lib.check(lib.fb_sys_get(ctx, slm._sys, 5, _lib.ptr(b_h)))
+    with _lib.using(actxs[(nsec - 1) % T]):
+        A_h = bsr_download(slm._sys, 4, slm._nv, slm._nnzb)
+        b_h = np.empty(2 * slm._nv)
+        _lib.check(lib.fb_sys_get(_lib.ctx(), slm._sys, 5, _lib.ptr(b_h)))
     d_h = disp[k].ravel()                                  # vertices + offset - start = the solved displacement (set_field, mesh.py:2400-2413)
     true_relres = float(np.linalg.norm(A_h @ d_h - b_h) / np.linalg.norm(b_h))
     out = dict(sections_per_rank=nsec, sections=nsec * world, nodes_per_section=n * n, dof_per_section=2 * n * n, links_per_section=2 * nl,
                sections_per_s=nsec * world / dt, seconds=dt, seconds_this_rank=dt_rank, pcg_iters_this_rank=iters, optimize_linear_seconds_this_rank=t_solve,
-               worst_relres=float(max(relres)), true_relres_last_section_recomputed_on_host=true_relres,
+               worst_relres=float(max(relres)), true_relres_last_section_recomputed_on_host=true_relres, host_threads=T,
                note='per section: link set-up (host), device assembly, Jacobi-PCG to 1e-4 through SLM.optimize_linear; the symbolic pattern is kept across '
-                    'sections (matches against locked neighbours stay inside the triangles of the free mesh: fb_sys_update_links)')
+                    'sections (matches against locked neighbours stay inside the triangles of the free mesh: fb_sys_update_links); '
+                    f'{T} host threads with a context each take the sections round-robin; optimize_linear_seconds_this_rank sums the threads')
     if ex is not None:
         barrier()
         t0 = time.time()
@@ -604,7 +618,9 @@ def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_
         dtg = reduce_max(time.time() - t0)
         out['allgather'] = dict(seconds=dtg, bytes=int(allx.nbytes), backend=ex.backend, shape=list(allx.shape))
         out['sections_per_s_incl_allgather'] = nsec * world / (dt + dtg)
-    del slm
+    del slm, units
+    for h_ in actxs[1:]:
+        lib.fb_destroy(h_)
     return out
 
 
