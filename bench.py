@@ -49,7 +49,7 @@ def parse():
     ap.add_argument('--multi-stream', type=int, default=1, help='1: one context (HIP stream) per host thread; 0: all threads share one stream')
     ap.add_argument('--warp', type=float, default=0.4, help='amplitude (px) of the smooth sub-pixel warp between the strips of a pair (SURVEY config 2)')
     ap.add_argument('--host-ingest-threads', type=int, default=8)
-    ap.add_argument('--host-ingest-batch', type=int, default=64, help='pairs per chunk of the PCIe-inclusive measurement (a chunk is packed, copied and matched by one host thread)')
+    ap.add_argument('--host-ingest-batch', type=int, default=32, help='pairs per chunk of the PCIe-inclusive measurement (a chunk is packed, copied and matched by one host thread)')
     ap.add_argument('--host-ingest-pairs', type=int, default=1024, help='pairs of the PCIe-inclusive measurement (0: skip)')
     ap.add_argument('--no-fem', action='store_true')
     ap.add_argument('--no-align', action='store_true', help='skip the alignment-side block matcher section')
@@ -64,6 +64,7 @@ def parse():
     ap.add_argument('--align-threads', type=int, default=4, help='host threads (one context and one SLM each) that share the sections of config[4]')
     ap.add_argument('--align-grid', type=int, default=500, help='nodes per side of a section mesh of config[4] (500 x 500 = 250 k nodes)')
     ap.add_argument('--cpu-pool-seconds', type=float, default=20.0, help='wall-clock budget of the all-core CPU baseline (process pool); 0: skip')
+    ap.add_argument('--allow-host-exchange', action='store_true', help='N > 1: if the RCCL communicator of the C ABI cannot be made, run the exchange steps over the gloo group on host arrays instead of exiting non-zero')
     ap.add_argument('--dry-run', action='store_true', help='no GPU work: the ranks exercise sharding and the exchange steps on synthetic tables over gloo (CPU tests)')
     return ap.parse_args()
 
@@ -759,6 +760,12 @@ def main():
             ex_note = f'C-ABI RCCL communicator unavailable ({e}); exchange through the gloo group on host arrays'
             ok = 0.0
         if fdist.host_sum([ok]) [0] < world:              # one rank without it: every rank takes the host route (collectives must match)
+            if not args.allow_host_exchange:
+                # a run whose exchange steps went over gloo on host arrays must not pass for an RCCL measurement
+                if rank == 0:
+                    print(f'bench.py: the C-ABI RCCL communicator could not be made on every rank ({ex_note or "another rank failed"}); '
+                          'pass --allow-host-exchange to run the exchange steps over the gloo group instead', file=sys.stderr, flush=True)
+                sys.exit(3)
             if ex_note is None:
                 ex.close()
                 ex_note = 'another rank has no C-ABI RCCL communicator; exchange through the gloo group on host arrays'
@@ -1108,8 +1115,10 @@ def main():
         outp = fmatcher.stitching_matcher_batch(host_pairs, batch=IB, threads=args.host_ingest_threads, **cfg)
         dth = time.time() - t0
         line['host_ingest'] = dict(value=len(host_pairs) / dth, unit='pairs/s', pairs=len(host_pairs), matched=int(sum(o[0] is not None for o in outp)),
+                                   h2d_gbs=len(host_pairs) * 2 * H * W / dth / 1e9,
                                    note='strips handed over in host memory (4.2 MB per pair over PCIe), results returned per pair; '
-                                        f'{args.host_ingest_threads} host threads, {IB}-pair chunks')
+                                        f'{args.host_ingest_threads} host threads ({3 * args.host_ingest_threads // 8} loaders that pack and copy, the others match), {IB}-pair chunks; '
+                                        'h2d_gbs = strip bytes over the wall time of the whole run')
         # the same pairs cropped to strip shapes that all differ (what stage jitter does to the overlaps of a real section):
         # batches of unequal strips (RaggedStripBatchMatcher)
         rng_r = np.random.default_rng(5)

@@ -777,6 +777,10 @@ _pools = {}                  # context -> MatcherPool of the per-pair surface
 def stitching_matcher_batch_release():
     """free the contexts, staging buffers and matchers that stitching_matcher_batch keeps between calls"""
     for (_, t), slot in list(_batch_workers.items()):
+        if t == 'slots':                                      # the staging slots shared by loaders and matchers
+            for pin_, dev_ in slot.get('io', ()):
+                pin_.free(); dev_.free()
+            continue
         _lib.use_context(slot.get('ctx'))
         st = slot.get('state', {})
         for r in tuple(st.get('res', ())) + tuple(st.get('io', ())):
@@ -784,7 +788,7 @@ def stitching_matcher_batch_release():
         if 'pool' in st:
             st['pool'].free()
         _lib.use_context(None)
-        if t > 0:
+        if t != 0:
             _lib.destroy_context(slot.get('ctx'))
     _batch_workers.clear()
 
@@ -1035,9 +1039,96 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
     nthr = max(1, min(int(threads), len(chunks)))
     main_ctx = _lib.ctx()
     okey = tuple(None if v is None else (tuple(v.tolist()) if isinstance(v, np.ndarray) else v) for v in opts.values())
+    # Two kinds of host threads share the chunks: LOADERS pack the strips of a chunk into a page-locked stack and copy it to the
+    # device on a stream of their own, MATCHERS run the strip matcher on a stack that has landed.  A chunk waits in one of a few
+    # staging slots in between, so the copies of the next chunks overlap the kernels of the current ones whatever the number of
+    # chunks per thread (with every thread doing both in turn the device idled while all of them were copying: 2 chunks per
+    # thread at 1024 pairs).  Below three threads each thread does both.
+    n_load = 0 if nthr < 3 else max(1, (3 * nthr) // 8)
+    n_match = nthr - n_load
+    import queue
+    shared = _batch_workers.setdefault((id(main_ctx), 'slots'), {})
+    n_slots = (n_match + n_load + 1) if n_load else 0
+    if n_load and (shared.get('bytes', 0) < need or len(shared.get('io', ())) < n_slots):
+        for pin_, dev_ in shared.get('io', ()):
+            pin_.free(); dev_.free()
+        shared['io'] = [(_lib.PinnedBuffer(need), _lib.DeviceBuffer(need)) for _ in range(n_slots)]
+        shared['bytes'] = need
+    free_q, ready_q = queue.Queue(), queue.Queue()
+    for sl in range(n_slots):
+        free_q.put(sl)
+    next_chunk = [0]
+    take = threading.Lock()
+
+    def stage(chunk, pin, dev):
+        """both strips of every pair of the chunk into the page-locked stack [2][n][Hm][Wm] (C++ memcpy, no interpreter lock) and
+        on to the device (returns when the copy has completed)"""
+        _, _, idx = chunk
+        n = len(idx)
+        Hm = max(items[k][0].shape[0] for k in idx); Wm = max(items[k][0].shape[1] for k in idx)
+        srcs = (C.c_void_p * (2 * n))(*([items[k][0].ctypes.data for k in idx] + [items[k][1].ctypes.data for k in idx]))
+        hs = np.array([items[k][0].shape[0] for k in idx] * 2, dtype=np.int32)
+        ws = np.array([items[k][0].shape[1] for k in idx] * 2, dtype=np.int32)
+        pitches = np.array([items[k][0].strides[0] for k in idx] + [items[k][1].strides[0] for k in idx], dtype=np.int64)
+        lib_ = _lib.load()
+        _lib.check(lib_.fb_host_pack2d(_lib.ctx(), pin.ptr, 2 * n, Hm, Wm, srcs, _lib.ptr(hs), _lib.ptr(ws), _lib.ptr(pitches), 2))
+        _lib.check(lib_.fb_memcpy_h2d(_lib.ctx(), dev.ptr, pin.ptr, 2 * n * Hm * Wm))
+        _lib.check(lib_.fb_sync(_lib.ctx()))
+        return n, Hm, Wm
+
+    def loader(j):
+        slot = _batch_workers.setdefault((id(main_ctx), ('L', j)), {})
+        if 'ctx' not in slot:
+            slot['ctx'] = _lib.new_context()
+        _lib.use_context(slot['ctx'])
+        try:
+            while not errors:
+                with take:
+                    c = next_chunk[0]; next_chunk[0] += 1
+                if c >= len(chunks):
+                    break
+                sl = free_q.get()
+                pin, dev = shared['io'][sl]
+                ready_q.put((c, sl) + stage(chunks[c], pin, dev))
+        except Exception as e:                                # noqa: BLE001 -- re-raised in the calling thread
+            errors.append(e)
+        finally:
+            ready_q.put(None)                                 # one end mark per loader
+            _lib.use_context(None)
+
+    def match_chunk(state, chunk, dev, n, Hm, Wm):
+        kind, what, idx = chunk
+        if kind == 'uniform':
+            if state.get('key') != (what, n, okey):
+                if 'res' in state:
+                    state.pop('res')[0].free()
+                state.update(key=(what, n, okey), res=(StripBatchMatcher(n, Hm, Wm, pool=state['pool'], **opts),))
+            m = state['res'][0]
+        else:
+            m = RaggedStripBatchMatcher([items[k][0].shape for k in idx], pool=state['pool'], **opts)
+        mk0 = [items[k][2] for k in idx]
+        mk1 = [items[k][3] for k in idx]
+        has_mask = any(v is not None for v in mk0 + mk1)
+        try:
+            out = m.match(dev.ptr, dev.offset(n * Hm * Wm), masks0=mk0 if has_mask else None, masks1=mk1 if has_mask else None,
+                          compute_photometric=compute_photometric)
+        finally:
+            if kind == 'ragged':
+                m.free()
+        per = StripBatchMatcher.per_pair(out)
+        for j, k in enumerate(idx):
+            r = per[j]
+            if r.get('deferred'):
+                deferred.append(k)
+            elif r['xy0'] is None:
+                results[k] = (None, None, opts['conf_thresh'], None, None)
+            else:
+                results[k] = (r['xy0'], r['xy1'], r['weight'], r['strain'], out['phtm'][j] if compute_photometric else None)
+
+    ended = [0]
 
     def worker(t):
-        # worker t keeps its context, staging buffers, buffer pool and the matcher of the last uniform shape between calls
+        # worker t keeps its context, buffer pool and the matcher of the last uniform shape between calls
         # (stitching_matcher_batch_release frees them)
         slot = _batch_workers.setdefault((id(main_ctx), t), {})
         if 'ctx' not in slot:
@@ -1047,63 +1138,55 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         try:
             if 'pool' not in state:
                 state['pool'] = MatcherPool()
-            if state.get('bytes', 0) < need:                  # staging buffers: one pair of allocations for the largest chunk
-                for r in state.get('io', ()):
-                    r.free()
-                state['io'] = (_lib.PinnedBuffer(need), _lib.DeviceBuffer(need))
-                state['bytes'] = need
-            pin, dev = state['io']
-            # threads started together march through the stages of a chunk in lockstep (all in the FFT-heavy global stage, then
-            # all in the latency-bound rounds of small kernels), which leaves the device half idle in the second phase: worker t
-            # starts 3 t ms late, so that the heavy kernels of one stream fill the gaps of the others (bench.py does the same
-            # for its resident-strip harness; FEABAS_HIP_STAGGER_MS=0 turns it off)
-            stagger = float(os.environ.get('FEABAS_HIP_STAGGER_MS', '3'))
-            if stagger > 0 and t > 0 and nthr > 1:
-                time.sleep(1e-3 * stagger * t)
-            for kind, what, idx in chunks[t::nthr]:
-                n = len(idx)
-                Hm = max(items[k][0].shape[0] for k in idx); Wm = max(items[k][0].shape[1] for k in idx)
-                if kind == 'uniform':
-                    if state.get('key') != (what, n, okey):
-                        if 'res' in state:
-                            state.pop('res')[0].free()
-                        state.update(key=(what, n, okey), res=(StripBatchMatcher(n, Hm, Wm, pool=state['pool'], **opts),))
-                    m = state['res'][0]
-                else:
-                    m = RaggedStripBatchMatcher([items[k][0].shape for k in idx], pool=state['pool'], **opts)
-                # both strips of every pair into the page-locked stack [2][n][Hm][Wm] (C++ memcpy, no interpreter lock)
-                srcs = (C.c_void_p * (2 * n))(*([items[k][0].ctypes.data for k in idx] + [items[k][1].ctypes.data for k in idx]))
-                hs = np.array([items[k][0].shape[0] for k in idx] * 2, dtype=np.int32)
-                ws = np.array([items[k][0].shape[1] for k in idx] * 2, dtype=np.int32)
-                pitches = np.array([items[k][0].strides[0] for k in idx] + [items[k][1].strides[0] for k in idx], dtype=np.int64)
-                _lib.check(_lib.load().fb_host_pack2d(_lib.ctx(), pin.ptr, 2 * n, Hm, Wm, srcs, _lib.ptr(hs), _lib.ptr(ws), _lib.ptr(pitches), 2))
-                _lib.check(_lib.load().fb_memcpy_h2d(_lib.ctx(), dev.ptr, pin.ptr, 2 * n * Hm * Wm))
-                mk0 = [items[k][2] for k in idx]
-                mk1 = [items[k][3] for k in idx]
-                has_mask = any(v is not None for v in mk0 + mk1)
+            if n_load == 0:
+                # one or two threads: each stages its own chunks
+                if state.get('bytes', 0) < need:
+                    for r in state.get('io', ()):
+                        r.free()
+                    state['io'] = (_lib.PinnedBuffer(need), _lib.DeviceBuffer(need))
+                    state['bytes'] = need
+                pin, dev = state['io']
+                for chunk in chunks[t::nthr]:
+                    n, Hm, Wm = stage(chunk, pin, dev)
+                    match_chunk(state, chunk, dev, n, Hm, Wm)
+                return
+            while True:
+                got = ready_q.get()
+                if got is None:
+                    with take:
+                        ended[0] += 1
+                        last = ended[0] >= n_load
+                    if last:                                  # every loader is done: wake the other matchers and leave
+                        for _ in range(n_match):
+                            ready_q.put('stop')
+                    continue
+                if got == 'stop':
+                    break
+                c, sl, n, Hm, Wm = got
                 try:
-                    out = m.match(dev.ptr, dev.offset(n * Hm * Wm), masks0=mk0 if has_mask else None, masks1=mk1 if has_mask else None,
-                                  compute_photometric=compute_photometric)
+                    if not errors:
+                        match_chunk(state, chunks[c], shared['io'][sl][1], n, Hm, Wm)
                 finally:
-                    if kind == 'ragged':
-                        m.free()
-                per = StripBatchMatcher.per_pair(out)
-                for j, k in enumerate(idx):
-                    r = per[j]
-                    if r.get('deferred'):
-                        deferred.append(k)
-                    elif r['xy0'] is None:
-                        results[k] = (None, None, opts['conf_thresh'], None, None)
-                    else:
-                        results[k] = (r['xy0'], r['xy1'], r['weight'], r['strain'], out['phtm'][j] if compute_photometric else None)
+                    free_q.put(sl)
         except Exception as e:                                # noqa: BLE001 -- re-raised in the calling thread
             errors.append(e)
+            if n_load:                                        # let the loaders and the other matchers run out
+                while True:
+                    try:
+                        got = ready_q.get(timeout=0.05)
+                    except queue.Empty:
+                        if all(not th.is_alive() for th in lths):
+                            break
+                        continue
+                    if got is not None and got != 'stop':
+                        free_q.put(got[1])
         finally:
             _lib.use_context(None)
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
-    for th in ths:
+    lths = [threading.Thread(target=loader, args=(j,)) for j in range(n_load)]
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_match)]
+    for th in lths + ths:
         th.start()
-    for th in ths:
+    for th in lths + ths:
         th.join()
     if errors:
         raise errors[0]
