@@ -1045,6 +1045,8 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
     # chunks per thread (with every thread doing both in turn the device idled while all of them were copying: 2 chunks per
     # thread at 1024 pairs).  Below three threads each thread does both.
     n_load = 0 if nthr < 3 else max(1, (3 * nthr) // 8)
+    if nthr >= 3 and os.environ.get('FEABAS_HIP_INGEST_LOADERS'):
+        n_load = max(1, min(nthr - 1, int(os.environ['FEABAS_HIP_INGEST_LOADERS'])))
     n_match = nthr - n_load
     import queue
     shared = _batch_workers.setdefault((id(main_ctx), 'slots'), {})
