@@ -553,6 +553,8 @@ def load_mesh_h5(f, prefix='', cls=None, **kwargs):
         by_uid = {int(m['uid']): m for m in table.values()}
         model_of = lambda m: _MODEL_NAMES.index(m['type'].upper()) if isinstance(m.get('type', 0), str) else int(m.get('type', 0))
         d = table.get('default', {})
+        init['material_ids'] = np.asarray(ids).ravel().astype(np.int32)
+        init['material_names'] = {name: int(m['uid']) for name, m in table.items()}
         init['poisson_ratio'] = d.get('poisson_ratio', 0.0)
         init['material_multiplier'] = d.get('stiffness_multiplier', 1.0)
         uids = np.unique(ids)

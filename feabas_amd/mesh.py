@@ -67,6 +67,11 @@ class Mesh:
                 fm = [float(self.tri_matmult[np.flatnonzero(self.tri_func == k)[0]]) if np.any(self.tri_func == k) else 1.0
                       for k in range(len(self.stiffness_funcs))]
             self.func_matmult = np.ascontiguousarray(fm, dtype=np.float64)
+        # optional names of the materials (mesh.py:257-263, MaterialTable.named_table): material_ids[t] = uid of triangle t's
+        # material, material_names = {name: uid} -- what optimize_linear(remove_material_dof=<name>) selects regions by
+        mids = kwargs.get('material_ids', None)
+        self.material_ids = None if mids is None else np.ascontiguousarray(mids).ravel()
+        self.material_names = dict(kwargs.get('material_names', None) or {})
         self.resolution = kwargs.get('resolution', 4.0)
         self.locked = kwargs.get('locked', False)
         self.soft_factor = kwargs.get('soft_factor', 1.0)
@@ -133,6 +138,12 @@ class Mesh:
     @property
     def is_linear(self):                                   # mesh.py:1563-1568: engineering materials without a stiffness function only
         return (self.tri_model is None or not np.any(self.tri_model != const.MATERIAL_MODEL_ENG)) and self.tri_func is None
+
+    def triangles_of_material(self, name):
+        """boolean [T]: the triangles whose material carries this name (none if the mesh has no named materials)"""
+        if self.material_ids is None or name not in self.material_names:
+            return np.zeros(self.num_triangles, dtype=bool)
+        return self.material_ids == self.material_names[name]
 
     @property
     def linear_triangle_mask(self):                        # mesh.py:1571-1580
@@ -201,7 +212,10 @@ class Mesh:
                   tri_model=self.tri_model, tri_nu=getattr(self, 'tri_nu', None) if self.tri_model is not None else self.poisson_ratio,
                   tri_matmult=getattr(self, 'tri_matmult', None) if self.tri_model is not None else self.material_multiplier,
                   material_multiplier=self.material_multiplier, resolution=self.resolution,
-                  locked=self.locked, soft_factor=self.soft_factor, uid=self.uid)
+                  locked=self.locked, soft_factor=self.soft_factor, uid=self.uid,
+                  material_ids=self.material_ids, material_names=self.material_names)
+        if self.tri_func is not None:
+            kw.update(tri_func=self.tri_func, stiffness_funcs=self.stiffness_funcs, func_matmult=self.func_matmult)
         kw.update(override)
         return Mesh(self._vertices[const.MESH_GEAR_INITIAL], self.triangles, **kw)
 

@@ -693,7 +693,7 @@ class SLM:
     # ------------------------------------------------------------------ optimize
     def optimize_linear(self, **kwargs):
         """feabas/optimizer.py:1257-1437 including `groupings` (members of a group share their degrees of freedom),
-        and `remove_extra_dof` (`remove_material_dof` needs material tables).  Returns (||b||, ||A d - b||) and writes the field into the meshes."""
+        `remove_extra_dof` and `remove_material_dof`.  Returns (||b||, ||A d - b||) and writes the field into the meshes."""
         maxiter = kwargs.get('maxiter', None)
         tol = kwargs.get('tol', 1e-7)
         atol = kwargs.get('atol', 0.0)
@@ -713,11 +713,12 @@ class SLM:
                 raise NotImplementedError('optimize_linear(distributed=...) with groupings')
             return self._optimize_linear_distributed(kwargs['distributed'], kwargs.get('owned', None), tol, atol, maxiter, shape_gear,
                                                      start_gear, target_gear, stiffness_lambda, crosslink_lambda)
-        if kwargs.get('remove_material_dof', None) is not None:
-            raise NotImplementedError('optimize_linear(remove_material_dof=...) names material tables (optimizer.py:1320-1359), which this mirror\'s Mesh does not carry')
         if np.all(self.lock_flags):
             return 0, 0
-        held = self._extra_dof_mask(groupings) if kwargs.get('remove_extra_dof', False) else None
+        if kwargs.get('remove_material_dof', None) is not None:
+            held = self._material_dof_mask(kwargs['remove_material_dof'], groupings)
+        else:
+            held = self._extra_dof_mask(groupings) if kwargs.get('remove_extra_dof', False) else None
         lib = _lib.load()
         ctx = _lib.ctx()
         if groupings is not None and all(o < 0 for o in self._layout(groupings)[0].values()):
@@ -776,6 +777,33 @@ class SLM:
                     continue
                 m.set_field(dd[o:o + 2 * m.num_vertices].reshape(-1, 2), gear=(start_gear, target_gear))
         return cost
+
+    def _material_dof_mask(self, names, groupings):
+        """optimizer.py:1320-1359: the regions of the named materials do not take part in the solve -- every vertex of their
+        triangles is held; a name with the suffix '_freeborder' keeps the vertices such a region shares with other materials free
+        (and is applied first).  The materials are those a Mesh was given as ``material_ids`` + ``material_names`` (the mesh file
+        carries both, h5wire.load_mesh_h5); a mesh without them has no named region.  Returns the selector over the degrees of
+        freedom of the free meshes (True = solved)."""
+        if groupings is not None:
+            raise NotImplementedError('optimize_linear(remove_material_dof=...) with groupings')
+        if isinstance(names, str):
+            names = [names]
+        elif not isinstance(names, (tuple, list)):
+            raise TypeError('remove_material_dof: a material name or a list of names')
+        marker = '_freeborder'
+        passes = [(s_.replace(marker, ''), True) for s_ in names if marker in s_] + [(s_, False) for s_ in names if marker not in s_]
+        parts = []
+        for m in self.meshes:
+            if m.locked:
+                continue
+            solved = np.ones(m.num_vertices, dtype=bool)
+            for name, free_border in passes:
+                region = m.triangles_of_material(name)
+                solved[m.triangles[region].ravel()] = False
+                if free_border:
+                    solved[m.triangles[~region].ravel()] = True
+            parts.append(np.repeat(solved, 2))
+        return np.concatenate(parts)
 
     def _extra_dof_mask(self, groupings):
         """optimizer.py:1360-1377: a connected subsystem without a locked mesh floats (rigid motion costs nothing); the first

@@ -707,15 +707,45 @@ def extra_dof_selector(meshes, links):
     return np.concatenate(edc, axis=None)
 
 
+def material_dof_selector(meshes, names, material_ids, named_uids):
+    """optimizer.py:1320-1359 (remove_material_dof): the vertices of the triangles of the named materials are held; a name that
+    carries '_freeborder' frees again every vertex that a triangle of another material uses (those are treated first).
+    material_ids: per mesh the material id of every triangle (or None), named_uids: per mesh {name: uid}.  Returns the boolean
+    selector over the degrees of freedom of the free meshes (True = solved)."""
+    marker = '_freeborder'
+    names = [names] if isinstance(names, str) else list(names)
+    free_border = [s.replace(marker, '') for s in names if marker in s]
+    fixed_border = [s for s in names if marker not in s]
+    edc = []
+    for m, mids, table in zip(meshes, material_ids, named_uids):
+        if m.locked:
+            continue
+        T = np.asarray(m.triangles)
+        sel = np.ones(m.num_vertices * 2, dtype=bool)
+        for grp, border in ((free_border, True), (fixed_border, False)):
+            for name in grp:
+                tid = np.zeros(T.shape[0], dtype=bool)
+                if mids is not None and name in table:
+                    tid = tid | (np.asarray(mids) == table[name])
+                vn = np.unique(T[tid])
+                sel[2 * vn] = False; sel[2 * vn + 1] = False
+                if border:
+                    vp = np.unique(T[~tid])
+                    sel[2 * vp] = True; sel[2 * vp + 1] = True
+        edc.append(sel)
+    return np.concatenate(edc, axis=None)
+
+
 def optimize_linear(meshes, links, tol=1e-7, stiffness_lambda=1.0, crosslink_lambda=-1.0,
-                    shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING, exact=True, remove_extra_dof=False):
+                    shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING, exact=True, remove_extra_dof=False,
+                    dof_selector=None):
     """optimizer.py:1257-1437 (no groupings).  exact=True solves the system to its fixed point (the parity anchor);
     otherwise PCG to tol.  remove_extra_dof: the held degrees of freedom leave the system (optimizer.py:1976-1991: rows and
     columns are cut out, the solution is zero there)."""
     A, b, _ = linear_system(meshes, links, stiffness_lambda, crosslink_lambda,
                             shape_gear, start_gear, target_gear)
     A = 0.5 * (A + A.T)
-    edc = extra_dof_selector(meshes, links) if remove_extra_dof else None
+    edc = dof_selector if dof_selector is not None else (extra_dof_selector(meshes, links) if remove_extra_dof else None)
     if edc is not None and not edc.all():
         Ar = sparse.csr_matrix(A)[edc][:, edc]
         dr = solve_direct(Ar, b[edc]) if exact else pcg(Ar, b[edc], rtol=tol)[0]

@@ -636,3 +636,51 @@ def test_multigrid_request_on_a_window_of_very_many_small_meshes_falls_back(fb):
     assert c1[1] <= 1e-8 * c1[0] * 1.01 and c2[1] <= 1e-8 * c2[0] * 1.01
     for a, b in zip(m1[1::97], m2[1::97]):
         np.testing.assert_allclose(a.vertices_w_offset(1), b.vertices_w_offset(1), atol=1e-6)
+
+
+def _material_region_system(fb_or_ref, rng, cls_mesh, cls_link):
+    """two free meshes + a locked one; mesh 1 carries materials {default, 'fold' (a band in the middle), 'resin' (a corner)}"""
+    from oracle import fem_ref
+    v, t = fem_ref.grid_mesh(14, 11, 10.0)
+    ctr = v[t].mean(axis=1)
+    mids = np.where(np.abs(ctr[:, 0] - 65) < 18, 3, np.where((ctr[:, 0] > 100) & (ctr[:, 1] > 70), 5, 0)).astype(np.int32)
+    names = {'default': 0, 'fold': 3, 'resin': 5}
+    return v, t, mids, names
+
+
+@pytest.mark.parametrize('request_', ['fold', ['fold_freeborder'], ['resin', 'fold_freeborder'], 'no_such_material'])
+def test_optimize_linear_remove_material_dof_vs_oracle(fb, request_):
+    """SLM.optimize_linear(remove_material_dof=...) (optimizer.py:1320-1359): the vertices of the named material regions are held
+    (a '_freeborder' name keeps the vertices shared with other materials free); the rest is solved.  The selector and the field
+    against the oracle's restatement (exact solve of the reduced system)"""
+    from oracle import fem_ref
+    rng = np.random.default_rng(11)
+    v, t, mids, names = _material_region_system(fb, rng, None, None)
+    disp = np.stack((2.0 * np.sin(v[:, 1] / 30), 1.5 * np.cos(v[:, 0] / 40)), -1)
+    n = 260
+    tid = rng.integers(0, t.shape[0], n); B = rng.dirichlet((1, 1, 1), n); w = rng.uniform(0.4, 1.0, n).astype(np.float32)
+    tid2 = rng.integers(0, t.shape[0], n); B2 = rng.dirichlet((1, 1, 1), n)
+    pm = [fb.mesh.Mesh(v + disp, t, uid=0, locked=True), fb.mesh.Mesh(v.copy(), t, uid=1, material_ids=mids, material_names=names),
+          fb.mesh.Mesh(v + np.array([[3.0, -2.0]]), t, uid=2)]
+    pl = [fb.optimizer.Link(pm[0], pm[1], tid, tid, B, B, weight=w), fb.optimizer.Link(pm[1], pm[2], tid2, tid2, B2, B2, weight=w)]
+    om = [fem_ref.RefMesh(v + disp, t, uid=0, locked=True), fem_ref.RefMesh(v.copy(), t, uid=1), fem_ref.RefMesh(v + np.array([[3.0, -2.0]]), t, uid=2)]
+    ol = [fem_ref.RefLink(om[0], om[1], tid, tid, B, B, weight=w), fem_ref.RefLink(om[1], om[2], tid2, tid2, B2, B2, weight=w)]
+    slm = fb.optimizer.SLM(pm, pl, stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    sel = fem_ref.material_dof_selector(om, request_, [None, mids, None], [{}, names, {}])
+    np.testing.assert_array_equal(slm._material_dof_mask(request_, None), sel)
+    if request_ == 'fold':
+        assert 0 < (~sel).sum() < sel.size // 2 and (~sel[2 * v.shape[0]:]).sum() == 0            # only mesh 1 has the region
+    if request_ == ['fold_freeborder']:
+        assert 0 < (~sel).sum() < (~fem_ref.material_dof_selector(om, 'fold', [None, mids, None], [{}, names, {}])).sum()
+    c = slm.optimize_linear(tol=1e-11, remove_material_dof=request_)
+    fem_ref.optimize_linear(om, ol, exact=True, dof_selector=sel)
+    assert c[1] < c[0]                      # (the reference's cost counts the rows of the held degrees of freedom too, optimizer.py:1420)
+    for a, b in zip(pm[1:], om[1:]):
+        got = a.vertices_w_offset(1) - a.vertices_w_offset(0)
+        exp = b.vertices_w_offset(fem_ref.GEAR_MOVING) - b.vertices_w_offset(fem_ref.GEAR_FIXED)
+        np.testing.assert_allclose(got, exp, atol=1e-6 * max(np.abs(exp).max(), 1.0))
+    held_v = ~sel[:2 * v.shape[0]].reshape(-1, 2)[:, 0]
+    if held_v.any():
+        # a held vertex moves with the mean only (set_field splits the mean into the offset, mesh.py:2409-2413)
+        d1 = pm[1].vertices_w_offset(1) - pm[1].vertices_w_offset(0)
+        np.testing.assert_allclose(d1[held_v], 0.0, atol=1e-9)
