@@ -555,6 +555,7 @@ def load_mesh_h5(f, prefix='', cls=None, **kwargs):
         d = table.get('default', {})
         init['material_ids'] = np.asarray(ids).ravel().astype(np.int32)
         init['material_names'] = {name: int(m['uid']) for name, m in table.items()}
+        init['material_area_constraints'] = {name: float(m.get('area_constraint', 1.0)) for name, m in table.items()}
         init['poisson_ratio'] = d.get('poisson_ratio', 0.0)
         init['material_multiplier'] = d.get('stiffness_multiplier', 1.0)
         uids = np.unique(ids)

@@ -170,9 +170,13 @@ class _RegionPair:
     ``inside & (distance >= d)``.  Areas and connected parts are taken on a raster of the predicate (step `res`): shapely is
     not in the image, and nothing downstream needs the polygons themselves."""
 
-    def __init__(self, mesh0, mesh1, gear):
+    def __init__(self, mesh0, mesh1, gear, only=None, exclude=None):
+        """only / exclude: lists of (mesh index, boolean triangle mask) -- the part of the common region that lies in ANY of the
+        `only` triangle sets and in NONE of the `exclude` ones (the material regions of a refinement level and what the finer
+        levels covered already, matcher.py:963-995); None = no restriction"""
         self.meshes = (mesh0, mesh1)
         self.gear = gear
+        self.only, self.exclude = only, exclude
         self.segs = []
         for m in (mesh0, mesh1):
             v = m.vertices_w_offset(gear)
@@ -184,10 +188,22 @@ class _RegionPair:
     def inside(self, pts):
         pts = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
         ok = np.ones(pts.shape[0], dtype=bool)
+        tids = []
         for m in self.meshes:
             idx = np.flatnonzero(ok)
+            tid = np.full(pts.shape[0], -1, dtype=np.int64)
             if idx.size:
-                ok[idx] = m.tri_finder(pts[idx], gear=self.gear) >= 0
+                tid[idx] = m.tri_finder(pts[idx], gear=self.gear)
+                ok[idx] = tid[idx] >= 0
+            tids.append(tid)
+        for sets, want in ((self.only, True), (self.exclude, False)):
+            if sets is None or not ok.any():
+                continue
+            hit = np.zeros(pts.shape[0], dtype=bool)
+            idx = np.flatnonzero(ok)
+            for k, tri_mask in sets:
+                hit[idx] |= np.asarray(tri_mask, dtype=bool)[tids[k][idx]]
+            ok &= hit if want else ~hit
         return ok
 
     def boundary_distance(self, pts, cap=np.inf):
@@ -276,8 +292,13 @@ def distribute_matching_blocks(mesh0, mesh1, spacing, dfunc='cartesian_region', 
     away from its outline (relaxed until half of the region survives), z-ordered.  The reference builds the region with
     shapely polygons; here it is a point predicate on the triangles of the two meshes (_RegionPair) -- same lattice rule,
     same block sizes; the lattice anchor of a connected part is its representative point as GEOS defines it, located on a
-    raster of the region (step spacing / 4), so anchors agree with shapely's up to that step.  Refinement regions need
-    material tables with an ``area_constraint`` (not part of this mirror's Mesh): refine_mode acts as 0."""
+    raster of the region (step spacing / 4), so anchors agree with shapely's up to that step.
+    ``refine_mode`` (0 ignore, 1 refinement regions only, 2 both -- the default): the triangles of a material whose name holds
+    'refine' or whose ``area_constraint`` lies in (0, 1) (Mesh.material_ids / material_names / material_area_constraints) get
+    a lattice of step spacing x area_constraint and blocks of spacing x area_constraint^refine_box_exp, finest level first; a
+    coarser level leaves out what a finer one covered."""
+    refine_mode = kwargs.get('refine_mode', 2)
+    refine_box_exp = kwargs.get('refine_box_exp', 0.5)
     gear = kwargs.get('gear', const.MESH_GEAR_MOVING)
     shrink_factor = kwargs.get('shrink_factor', 1)
     min_box_side = kwargs.get('min_box_side', 5)
@@ -292,16 +313,17 @@ def distribute_matching_blocks(mesh0, mesh1, spacing, dfunc='cartesian_region', 
             raise NotImplementedError("distributor 'intersect_triangulation' meshes the region with `triangle` (matcher.py:1046-1058), which is not in the image")
         else:
             raise ValueError(f'unsupported distributor type {dfunc}')
+    if isinstance(refine_mode, str):
+        refine_mode = 0 if refine_mode.lower() == 'none' else (1 if 'only' in refine_mode.lower() else 2)
     empty = (np.empty((0, 4)), np.empty((0, 4)))
     if render_weight_threshold > 0:
         mesh0 = mesh0.submesh(mesh0.triangle_mask_for_render(render_weight_threshold=render_weight_threshold))
         mesh1 = mesh1.submesh(mesh1.triangle_mask_for_render(render_weight_threshold=render_weight_threshold))
-    region = _RegionPair(mesh0, mesh1, gear)
-    if not region.valid:
+    whole = _RegionPair(mesh0, mesh1, gear)
+    if not whole.valid:
         return empty
-    res = max(spacing / 4.0, 1.0)
-    area_r = float(region.raster(res)[2].sum()) * res * res
-    if area_r == 0:
+    res0 = max(spacing / 4.0, 1.0)
+    if float(whole.raster(res0)[2].sum()) == 0:
         return empty
     if not hasattr(shrink_factor, '__len__'):
         shrink_factor = (shrink_factor, shrink_factor)
@@ -309,31 +331,66 @@ def distribute_matching_blocks(mesh0, mesh1, spacing, dfunc='cartesian_region', 
         a0 = np.sum(mesh0.triangle_areas(gear=gear)) / mesh0.num_triangles
         a1 = np.sum(mesh1.triangle_areas(gear=gear)) / mesh1.num_triangles
         shrink_factor = (max(shrink_factor), min(shrink_factor)) if a0 > a1 else (min(shrink_factor), max(shrink_factor))
-    erode = 0.0
-    if min_boundary_distance > 0:
-        bound_coeff = 1.0
-        for _ in range(64):
-            erode = min_boundary_distance * bound_coeff
-            area_c = float(region.raster(res, erode)[2].sum()) * res * res
-            if area_c >= 0.5 * area_r:
-                break
-            bound_coeff *= 0.3 / (1 - area_c / area_r)
-            if bound_coeff < 1e-3:
-                erode = 0.0
-                break
-    cntrs = dfunc(region, spacing, erode=erode, res=res)
-    if cntrs is None:
+    # levels: area factor -> triangle sets (None = the whole common region)
+    levels = {}
+    if refine_mode != 1:
+        levels[1.0] = None
+    if refine_mode != 0:
+        for k, m in enumerate((mesh0, mesh1)):
+            for name, uid in getattr(m, 'material_names', {}).items():
+                factor = float(getattr(m, 'material_area_constraints', {}).get(name, 1.0))
+                if ('refine' not in name) and (factor == 0 or factor >= 1):
+                    continue
+                tri_mask = m.material_ids == uid
+                if tri_mask.any() and levels.get(factor, ()) is not None:
+                    levels.setdefault(factor, []).append((k, tri_mask))
+    out0, out1 = [], []
+    covered = []                                   # triangle sets of the finer levels
+    everything = False
+    for factor in sorted(levels):
+        if everything:
+            break
+        spc = spacing * factor
+        box_scale = factor ** (refine_box_exp - 1)
+        res = max(spc / 4.0, 1.0)
+        sets = levels[factor]
+        level = _RegionPair(mesh0, mesh1, gear, only=sets)
+        area_r = float(level.raster(res)[2].sum()) * res * res
+        region = _RegionPair(mesh0, mesh1, gear, only=sets, exclude=covered or None)
+        if sets is None:
+            everything = True
+        else:
+            covered = covered + sets
+        if area_r == 0:
+            continue
+        erode = 0.0
+        if min_boundary_distance > 0:
+            bound_coeff = 1.0
+            for _ in range(64):
+                erode = min_boundary_distance * box_scale * bound_coeff
+                area_c = float(region.raster(res, erode)[2].sum()) * res * res
+                if area_c >= 0.5 * area_r:
+                    break
+                bound_coeff *= 0.3 / (1 - area_c / area_r)
+                if bound_coeff < 1e-3:
+                    erode = 0.0
+                    break
+        cntrs = dfunc(region, spc, erode=erode, res=res)
+        if cntrs is None:
+            continue
+        sides = (spc * box_scale * np.array(shrink_factor, dtype=np.float64)).clip(min_box_side, max_box_side)
+        h0, h1 = np.ceil(sides[0] / 2), np.ceil(sides[1] / 2)
+        b0 = np.concatenate((cntrs - h0, cntrs + h0), axis=-1)
+        b1 = np.concatenate((cntrs - h1, cntrs + h1), axis=-1)
+        if zorder:
+            x_rnd = np.round((cntrs[:, 0] - cntrs[:, 0].min()) / spc)
+            y_rnd = np.round((cntrs[:, 1] - cntrs[:, 1].min()) / spc)
+            idx = common.z_order(np.stack((x_rnd, y_rnd), axis=-1))
+            b0, b1 = b0[idx], b1[idx]
+        out0.append(b0); out1.append(b1)
+    if not out0:
         return empty
-    sides = (spacing * np.array(shrink_factor, dtype=np.float64)).clip(min_box_side, max_box_side)
-    h0, h1 = np.ceil(sides[0] / 2), np.ceil(sides[1] / 2)
-    bboxes0 = np.concatenate((cntrs - h0, cntrs + h0), axis=-1)
-    bboxes1 = np.concatenate((cntrs - h1, cntrs + h1), axis=-1)
-    if zorder:
-        x_rnd = np.round((cntrs[:, 0] - cntrs[:, 0].min()) / spacing)
-        y_rnd = np.round((cntrs[:, 1] - cntrs[:, 1].min()) / spacing)
-        idx = common.z_order(np.stack((x_rnd, y_rnd), axis=-1))
-        bboxes0, bboxes1 = bboxes0[idx], bboxes1[idx]
-    return bboxes0, bboxes1
+    return np.concatenate(out0, axis=0), np.concatenate(out1, axis=0)
 
 
 def block_displacements_to_points(bboxes0, bboxes1, dx, dy):
@@ -617,8 +674,12 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
                 boxes0, boxes1 = distributor_cartesian_bbox(mesh0, mesh1, sp, min_num_blocks=get('min_num_blocks', 2) if last else 1,
                                                             shrink_factor=get('shrink_factor', 1), zorder=True)
             else:
+                # refinement regions: on the last spacing as asked; before it, 'both' (2) means none yet (matcher.py:572-590)
+                rfm = get('refine_mode', 2)
+                if isinstance(rfm, str):
+                    rfm = 0 if rfm.lower() == 'none' else (1 if 'only' in rfm.lower() else 2)
                 boxes0, boxes1 = distribute_matching_blocks(mesh0, mesh1, sp, dfunc=distributor, min_boundary_distance=get('min_boundary_distance', 0),
-                                                            shrink_factor=get('shrink_factor', 1), zorder=True,
+                                                            shrink_factor=get('shrink_factor', 1), zorder=True, refine_mode=rfm if (last or rfm != 2) else 0,
                                                             render_weight_threshold=get('render_weight_threshold', 0))
             if boxes0 is None:
                 return failed
@@ -674,12 +735,11 @@ _SECTION_MATCHER_KW = {
     'initial_matches', 'spacings', 'sigma', 'batch_size', 'distributor', 'link_weight_decay', 'compute_strain', 'stiffness_multiplier_threshold',
     'render_weight_threshold', 'stiffness_lambda', 'conf_thresh', 'residue_mode', 'residue_len', 'opt_tol', 'min_num_blocks', 'shrink_factor',
     'allow_dwell', 'allow_enlarge', 'pad', 'subpixel', 'max_spacing_skip', 'affine_approximated_render', 'conf_mode', 'min_boundary_distance',
-    'section_thickness', 'trace', 'relax_tol', 'merge_batches', 'mask_range',
+    'section_thickness', 'trace', 'relax_tol', 'merge_batches', 'mask_range', 'refine_mode',
     # accepted and without effect on the device path, each for a stated reason
     'num_workers',          # one device renders and correlates a whole round: nothing to distribute over a process pool
     'callback_settings',    # the PCG runs to its tolerance: no early-stop / timeout exits
     'check_duplicates',     # Link.from_coordinates option of the reference; duplicates do not occur in lattice matches
-    'refine_mode',          # refinement regions need material tables with area_constraint (acts as 0)
     'geodesic_mask',        # False only
 }
 

@@ -72,6 +72,8 @@ class Mesh:
         mids = kwargs.get('material_ids', None)
         self.material_ids = None if mids is None else np.ascontiguousarray(mids).ravel()
         self.material_names = dict(kwargs.get('material_names', None) or {})
+        # area_constraint of the named materials (material.py:22-26): < 1 marks a refinement region of the block distributor
+        self.material_area_constraints = dict(kwargs.get('material_area_constraints', None) or {})
         self.resolution = kwargs.get('resolution', 4.0)
         self.locked = kwargs.get('locked', False)
         self.soft_factor = kwargs.get('soft_factor', 1.0)
@@ -213,7 +215,7 @@ class Mesh:
                   tri_matmult=getattr(self, 'tri_matmult', None) if self.tri_model is not None else self.material_multiplier,
                   material_multiplier=self.material_multiplier, resolution=self.resolution,
                   locked=self.locked, soft_factor=self.soft_factor, uid=self.uid,
-                  material_ids=self.material_ids, material_names=self.material_names)
+                  material_ids=self.material_ids, material_names=self.material_names, material_area_constraints=self.material_area_constraints)
         if self.tri_func is not None:
             kw.update(tri_func=self.tri_func, stiffness_funcs=self.stiffness_funcs, func_matmult=self.func_matmult)
         kw.update(override)
@@ -408,6 +410,10 @@ class Mesh:
                   soft_factor=self.soft_factor, uid=self.uid)
         if self.tri_model is not None:
             kw.update(tri_model=self.tri_model[sel], tri_nu=self.tri_nu[sel], tri_matmult=self.tri_matmult[sel])
+        if self.tri_func is not None:
+            kw.update(tri_func=self.tri_func[sel], stiffness_funcs=self.stiffness_funcs, func_matmult=self.func_matmult)
+        if self.material_ids is not None:
+            kw.update(material_ids=self.material_ids[sel], material_names=self.material_names, material_area_constraints=self.material_area_constraints)
         kw.update(kwargs)
         m = Mesh(self._vertices[const.MESH_GEAR_INITIAL][vidx], inv.reshape(-1, 3), **kw)
         if getattr(self, 'tri_render_weight', None) is not None:

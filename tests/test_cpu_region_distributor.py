@@ -117,3 +117,44 @@ def test_section_matcher_rejects_unknown_keywords():
     m0 = _two_islands(0.0); m1 = _two_islands(1.0)
     with pytest.raises(TypeError, match='not honoured'):
         matcher.section_matcher(m0, m1, None, None, no_such_option=1)
+
+
+def _mesh_with_a_refinement_region(uid, shift=(0.0, 0.0), factor=0.25):
+    v, t = _grid_mesh(0, 0, 26, 21, 40.0, uid)                               # 1000 x 800
+    ctr = v[t].mean(axis=1)
+    mids = np.where((ctr[:, 0] > 400) & (ctr[:, 0] < 720) & (ctr[:, 1] > 240) & (ctr[:, 1] < 560), 4, 0).astype(np.int32)
+    return Mesh(v + np.asarray(shift), t, uid=uid, material_ids=mids, material_names={'default': 0, 'fold_refine': 4},
+                material_area_constraints={'default': 1.0, 'fold_refine': factor})
+
+
+def test_refinement_regions_get_their_own_lattice():
+    """refine_mode of the block distributor (feabas/matcher.py:914-1016): the triangles of a material with area_constraint 0.25
+    get a lattice of a quarter of the spacing and blocks of spacing x 0.25^0.5 (refine_box_exp 0.5), the rest of the common
+    region the plain lattice WITHOUT what the finer level covered; mode 1 keeps the refinement blocks only, mode 0 ignores the
+    materials; the finest level comes first in the list"""
+    m0 = _mesh_with_a_refinement_region(0)
+    m1 = _mesh_with_a_refinement_region(1, shift=(12.0, -8.0))
+    m1.material_ids[:] = 0                                                    # only mesh 0 marks a refinement region
+    spacing = 160.0
+    in_ref = lambda c: (c[:, 0] > 400) & (c[:, 0] < 720) & (c[:, 1] > 240) & (c[:, 1] < 560)
+    b0_none, _ = matcher.distribute_matching_blocks(m0, m1, spacing, refine_mode=0, zorder=False)
+    b0_both, b1_both = matcher.distribute_matching_blocks(m0, m1, spacing, refine_mode=2, zorder=False)
+    b0_only, _ = matcher.distribute_matching_blocks(m0, m1, spacing, refine_mode='refine_only', zorder=False)
+    side = lambda b: b[:, 2] - b[:, 0]
+    c_none, c_both, c_only = (0.5 * (b[:, :2] + b[:, 2:]) for b in (b0_none, b0_both, b0_only))
+    # mode 0: one lattice of 160 px, blocks of 160 px, some of them inside the marked region
+    assert np.all(side(b0_none) == 160) and in_ref(c_none).any()
+    # refinement only: a 40-px lattice of 80-px blocks inside the marked region, nothing outside
+    assert c_only.shape[0] >= 40 and in_ref(c_only).all() and np.all(side(b0_only) == 80)
+    d = np.abs(c_only[:, None, :] - c_only[None, :, :]).sum(axis=-1)
+    assert np.isclose(np.min(d[d > 0]), 40.0)
+    # both: the refinement blocks first, then the coarse lattice with the marked region left out
+    nf = c_only.shape[0]
+    np.testing.assert_array_equal(b0_both[:nf], b0_only)
+    assert np.all(side(b0_both[nf:]) == 160) and not in_ref(c_both[nf:]).any() and c_both.shape[0] > nf
+    assert c_both[nf:].shape[0] < c_none.shape[0]
+    assert np.all(side(b1_both[:nf]) == 80)
+    # a mesh without named materials: refine_mode changes nothing
+    p0 = Mesh(m0.vertices(const.MESH_GEAR_INITIAL), m0.triangles, uid=5)
+    a, _ = matcher.distribute_matching_blocks(p0, m1, spacing, refine_mode=2, zorder=False)
+    np.testing.assert_array_equal(a, b0_none)
