@@ -177,6 +177,7 @@ class _RegionPair:
         self.meshes = (mesh0, mesh1)
         self.gear = gear
         self.only, self.exclude = only, exclude
+        self._rasters = {}
         self.segs = []
         for m in (mesh0, mesh1):
             v = m.vertices_w_offset(gear)
@@ -232,11 +233,21 @@ class _RegionPair:
             ok[idx] = self.boundary_distance(np.asarray(pts).reshape(-1, 2)[idx], cap=erode) >= erode
         return ok
 
+    def restricted(self, only=None, exclude=None):
+        """the same pair of meshes (outlines shared) with triangle-set restrictions"""
+        r = object.__new__(_RegionPair)
+        r.meshes, r.gear, r.segs, r.bbox, r.valid = self.meshes, self.gear, self.segs, self.bbox, self.valid
+        r.only, r.exclude, r._rasters = only, exclude, {}
+        return r
+
     def raster(self, res, erode=0.0):
-        x0, y0, x1, y1 = self.bbox
-        xs = np.arange(x0 + 0.5 * res, x1, res); ys = np.arange(y0 + 0.5 * res, y1, res)
-        xx, yy = np.meshgrid(xs, ys)
-        return xs, ys, self.select(np.stack((xx.ravel(), yy.ravel()), axis=-1), erode).reshape(yy.shape)
+        key = (float(res), float(erode))
+        if key not in self._rasters:
+            x0, y0, x1, y1 = self.bbox
+            xs = np.arange(x0 + 0.5 * res, x1, res); ys = np.arange(y0 + 0.5 * res, y1, res)
+            xx, yy = np.meshgrid(xs, ys)
+            self._rasters[key] = (xs, ys, self.select(np.stack((xx.ravel(), yy.ravel()), axis=-1), erode).reshape(yy.shape))
+        return self._rasters[key]
 
 
 def _region2grid_cartesian(region, spacing, erode=0.0, res=None, **kwargs):
@@ -354,9 +365,9 @@ def distribute_matching_blocks(mesh0, mesh1, spacing, dfunc='cartesian_region', 
         box_scale = factor ** (refine_box_exp - 1)
         res = max(spc / 4.0, 1.0)
         sets = levels[factor]
-        level = _RegionPair(mesh0, mesh1, gear, only=sets)
+        level = whole if sets is None else whole.restricted(only=sets)
         area_r = float(level.raster(res)[2].sum()) * res * res
-        region = _RegionPair(mesh0, mesh1, gear, only=sets, exclude=covered or None)
+        region = level if not covered else whole.restricted(only=sets, exclude=covered)
         if sets is None:
             everything = True
         else:
