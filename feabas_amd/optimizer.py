@@ -739,9 +739,9 @@ class SLM:
         dd = np.zeros(2 * self._nv, dtype=np.float64)
         iters, relres = C.c_int(), C.c_double()
         mi = -1 if maxiter is None else int(maxiter)
-        # (a window without a locked mesh, held together by its links alone, is what the Jacobi-PCG is good at and the
-        # hierarchy is not: 115 against 472 iterations on a floating pair of 6 000-node meshes with 800 matches)
-        pre = 0 if precondition is None else (2 if multigrid and groupings is None and (any(m.locked for m in self.meshes) or os.environ.get('FEABAS_HIP_MG_FLOATING') == '1') else 1)
+        # (round 3 kept the hierarchy away from windows without a locked mesh: with its fixed smoother damping the cycle was
+        # indefinite there; the damping now follows lambda_max(Dinv A) of every level, csrc/fb_mg.inc::mg_damping)
+        pre = 0 if precondition is None else (2 if multigrid and groupings is None else 1)
         bn = float(np.linalg.norm(b)) / self._gmean           # grouped terms are divided by mean(count) (optimizer.py:1408-1411)
         if held is not None and not held.all():
             # remove_extra_dof (optimizer.py:1360-1377, 1976-1991): three degrees of freedom of the first mesh of every
