@@ -56,25 +56,39 @@ def cpu_budget():
     return n
 
 
-def limit_host_pools():
+_pool_limiter = None
+
+
+def limit_host_pools(limit=None):
     """Caps the BLAS / OpenMP pools of the process at a quarter of cpu_budget() (at least 1, at most 8): numpy's OpenBLAS
     starts one spinning thread per logical CPU it sees, and on the host side of the two paths nothing larger than a 3 x 3
     system goes through BLAS.  Measured on a 16-CPU-quota / 256-CPU box: SLM.optimize_linear of a 500 k-DoF section 50-80 ms
-    with the default pool, 11-12 ms with it capped (tools/prof_align_section.py).  FEABAS_HIP_KEEP_POOLS=1 leaves the pools alone."""
-    if os.environ.get('FEABAS_HIP_KEEP_POOLS'):
+    with the default pool, 11-12 ms with it capped (tools/prof_align_section.py).
+    Not applied at import (importing the accelerator must not slow the host code of the embedding application): the first
+    device context applies it, ``restore_host_pools()`` undoes it, FEABAS_HIP_KEEP_POOLS=1 leaves the pools alone for good.
+    No environment variable is written: child processes and libraries loaded later keep their own defaults."""
+    global _pool_limiter
+    if os.environ.get('FEABAS_HIP_KEEP_POOLS') or _pool_limiter is not None:
         return None
-    lim = max(1, min(8, cpu_budget() // 4))
+    lim = max(1, min(8, cpu_budget() // 4)) if limit is None else int(limit)
     try:
         from threadpoolctl import threadpool_limits
-        threadpool_limits(limits=lim)
-    except Exception:           # threadpoolctl absent: the environment variables still reach pools that start later
-        pass
-    for var in ('OPENBLAS_NUM_THREADS', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
-        os.environ.setdefault(var, str(lim))
+        _pool_limiter = threadpool_limits(limits=lim)
+    except Exception:           # threadpoolctl absent: nothing to cap
+        return None
     return lim
 
 
-limit_host_pools()
+def restore_host_pools():
+    """give the BLAS / OpenMP pools their sizes of before the first device context back"""
+    global _pool_limiter
+    if _pool_limiter is not None:
+        try:
+            _pool_limiter.restore_original_limits()
+        except Exception:
+            pass
+        _pool_limiter = None
+
 
 c_p = C.c_void_p
 c_i = C.c_int
@@ -303,6 +317,7 @@ def ctx(device=None):
     if not h:
         raise RuntimeError(f'fb_create({device}) failed: no usable MI355X/HIP device '
                            '(feabas_amd has no CPU fallback)')
+    limit_host_pools()
     _ctx = h
     _ctx_device = device
     return _ctx

@@ -116,8 +116,19 @@ bool host_pinned(const void* p) {
 
 int fb_copy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return FB_OK;
-    if (bytes <= kStageDirect || host_pinned(src)) {
+    if (bytes <= kStageDirect) {
+        // (the runtime copies a small pageable source into its own staging area before it returns; a small PAGE-LOCKED source
+        // is read by the DMA engine later: wait for it below)
+        const bool pinned = host_pinned(src);
         FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (pinned) FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FB_OK;
+    }
+    if (host_pinned(src)) {
+        // straight to the DMA engine -- which reads the source asynchronously: the contract of this function (the caller may reuse
+        // `src` on return) needs the copy to have completed
+        FB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return FB_OK;
     }
     std::lock_guard<std::mutex> lk(ctx->stage_mtx);

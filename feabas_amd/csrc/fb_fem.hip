@@ -846,8 +846,12 @@ static int sys_update_links(fb_ctx* ctx, fb_system* s, int64_t K, const int32_t*
     const int rc = build_link_index(ctx, s, trusted ? 0 : 1, &bad);
     if (rc) return rc;
     if (bad >= 0) {
-        // (the system keeps no links it could assemble: the caller rebuilds it, fb_sys_set_links + fb_sys_finalize)
+        // the system keeps no links: the table is emptied AND the vertex -> match index (it still described the previous
+        // link set over buffers that now hold the rejected one) -- a caller that handles the error and assembles again finds a
+        // system without links, not a stale index; to use the new links it rebuilds (fb_sys_set_links + fb_sys_finalize)
         s->nlink = 0; (void)old_K;
+        s->nodes.clear();
+        if (s->d_vmptr) FB_HIP(ctx, hipMemsetAsync(s->d_vmptr, 0, sizeof(int) * ((size_t)s->nv + 1), ctx->stream));
         for (int a = 0; a < 6; ++a) {
             const int u = nodes6[6 * bad + a];
             if (u < -1 || u >= s->nv) return fb_fail(ctx, FB_ERR_ARG, "fb_sys_update_links: match %lld names vertex %d outside [-1, %d)", (long long)bad, u, s->nv);

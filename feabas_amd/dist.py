@@ -333,6 +333,11 @@ def host_group(group=None):
     key = ('gloo', id(group))
     if key not in _default_exchange:
         ranks = dist.get_process_group_ranks(group) if group is not None else None
+        if ranks is not None and len(ranks) < dist.get_world_size():
+            # dist.new_group is a collective of the DEFAULT group: called by the members of a proper sub-group only it would
+            # wait for the others for ever
+            raise RuntimeError('host_group: the gloo mirror of a proper sub-group of an nccl world has to be made by every rank of the '
+                               'world at start-up (torch.distributed.new_group(ranks, backend="gloo")) and passed in as the group')
         _default_exchange[key] = dist.new_group(ranks=ranks, backend='gloo')
     return _default_exchange[key]
 

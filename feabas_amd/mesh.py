@@ -364,6 +364,15 @@ class Mesh:
     def boundary_edges(self, tri_mask=None):
         """edges that belong to exactly one (masked) triangle: the outline of the region (outer rings and holes), what
         shapely_regions (mesh.py:1876-1905) chains into polygons.  [E, 2] vertex ids."""
+        if tri_mask is None:
+            # the outline of the whole mesh depends on its triangles only (they never change): kept, every round of a block
+            # matcher asks for it twice
+            if getattr(self, '_outline', None) is None:
+                self._outline = self._boundary_edges_of(None)
+            return self._outline
+        return self._boundary_edges_of(tri_mask)
+
+    def _boundary_edges_of(self, tri_mask):
         e, _ = self._edge_table(tri_mask)
         key = e[:, 0].astype(np.int64) * self.num_vertices + e[:, 1]
         u, idx, cnt = np.unique(key, return_index=True, return_counts=True)

@@ -951,9 +951,10 @@ class SLM:
     def _ladder(value, steps, toward_first=None):
         """Per-step schedule of a Newton-Raphson keyword (SLM.expand_to_list, optimizer.py:1862-1873): a scalar is the value
         of the LAST step, a sequence is right-aligned; the steps before are derived one by one from the step that follows
-        them (`toward_first`), or repeat it."""
+        them (`toward_first`), or repeat it.  A sequence LONGER than the number of steps is kept whole, as the reference keeps
+        it: step k then takes its k-th element from the front and the cost is evaluated with its last one."""
         given = [value] if (not hasattr(value, '__len__') or isinstance(value, str) or len(value) == 0) else list(value)
-        sched = given[-steps:] if len(given) > steps else given
+        sched = list(given)
         while len(sched) < steps:
             sched.insert(0, toward_first(sched[0]) if toward_first is not None else sched[0])
         return sched
@@ -1020,6 +1021,8 @@ class SLM:
             ke += 1
             if floor is not None and best < floor:
                 ke = max(ke, n - 1)                          # converged: one last step at the final tolerance
+            if ke >= len(ls):                                # optimizer.py:1541-1542
+                break
         return cost0, best
 
     def optimize_elastic(self, **kwargs):

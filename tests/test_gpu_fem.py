@@ -533,7 +533,7 @@ def test_newton_ladder_follows_the_reference_schedule(fb):
     assert lad(1e-9, 4, lambda t: t * 10) == pytest.approx([1e-6, 1e-7, 1e-8, 1e-9])
     assert lad('huber', 3, lambda _: None) == [None, None, 'huber']
     assert lad([0.5, 0.25], 4, lambda r: 2 * r) == [2.0, 1.0, 0.5, 0.25]
-    assert lad([5, 6, 7], 2) == [6, 7]
+    assert lad([5, 6, 7], 2) == [5, 6, 7]            # longer than the steps: kept whole (step k takes element k from the front)
     assert lad(None, 2) == [None, None]
 
 
