@@ -71,6 +71,7 @@ struct fb_ctx {
     size_t free_bytes = 0, free_limit = (size_t)4 << 30;
     void* small = nullptr;      // 64 KiB of device scratch for flags and partial reductions (allocated with the context)
     size_t ncc_arena_limit = (size_t)8 << 30;
+    int pcg_graph_max_nb = 1 << 18;        // Jacobi-PCG batches of systems up to this many vertices replay as a graph (0: never)
     bool use_rocfft = false;     // FEABAS_HIP_ROCFFT=1: streaming-class FFTs through rocFFT instead of the hand-written kernels
     bool dog_tiles = false;      // FEABAS_HIP_DOG_TILES=1: the 64 x 64 tile kernel (dog_fast) instead of the streaming one (A/B)
     bool dog_exact = false;      // double-precision tap accumulation (scipy's arithmetic) instead of the float fast path

@@ -191,6 +191,7 @@ fb_ctx* fb_create(int device_id) {
     if (const char* e = getenv("FEABAS_HIP_DOG_EXACT")) ctx->dog_exact = atoi(e) != 0;
     if (const char* e = getenv("FEABAS_HIP_DOG_TILES")) ctx->dog_tiles = atoi(e) != 0;
     if (const char* e = getenv("FEABAS_HIP_MALLOC_CACHE_MB")) ctx->free_limit = (size_t)std::max(0L, atol(e)) << 20;
+    if (const char* e = getenv("FEABAS_HIP_PCG_GRAPH_NB")) ctx->pcg_graph_max_nb = std::max(0, atoi(e));
     if (const char* e = getenv("FEABAS_HIP_NCC_ARENA_MB")) { const long mb = atol(e); if (mb >= 16) ctx->ncc_arena_limit = (size_t)mb << 20; }   // sub-batch size of the streaming NCC class (A/B: small chunks keep T and V in the 256 MiB Infinity Cache)
     if (hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||

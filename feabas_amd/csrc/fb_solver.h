@@ -14,6 +14,7 @@ struct fb_pcg_state {
     double rr;
     int flag;        // 0 running, 1 converged, 2 breakdown
     int iter;
+    double curv_eps; // 1e-9 * max diagonal: the noise level below which p^T A p <= 0 ends the leg instead of failing
 };
 
 struct fb_bsr {
@@ -24,6 +25,10 @@ struct fb_bsr {
     double* parts = nullptr;
     fb_pcg_state* state = nullptr;
     double diag_max = 0.0;
+    // one batch of Jacobi-PCG iterations (no first-iteration special case) as an executable graph: small
+    // systems are bound by the launch rate of the two kernels per iteration, not by their run time
+    hipGraphExec_t pcg_graph = nullptr;
+    int pcg_graph_iters = 0;
 };
 
 struct fb_csr {

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kT) void bsr_spmv_kernel(
 __global__ __launch_bounds__(kT) void pcg_update_kernel(
     int nb, double2* __restrict__ x, double2* __restrict__ r, double2* __restrict__ z, const double2* __restrict__ p,
     const double2* __restrict__ Ap, const double2* __restrict__ minv, const double* __restrict__ part_pAp,
-    const double* __restrict__ part_pp, double curv_eps, int np_pAp,
+    const double* __restrict__ part_pp, int np_pAp,
     const double* __restrict__ part_rz_cur, int np_rz, double* __restrict__ part_rz_out, double* __restrict__ part_rr_out,
     fb_pcg_state* st, int iter) {
     __shared__ double sh[kT / 64];
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kT) void pcg_update_kernel(
         // system (flag 3: end the leg, the host re-evaluates the true residual) or genuine negative
         // curvature (flag 2: the matrix is not positive semi-definite).
         const double pp = sum_partials(part_pp, np_pAp, sh);
-        if (threadIdx.x == 0 && blockIdx.x == 0) { st->flag = (pAp < -curv_eps * pp) ? 2 : 3; st->iter = iter; }
+        if (threadIdx.x == 0 && blockIdx.x == 0) { st->flag = (pAp < -st->curv_eps * pp) ? 2 : 3; st->iter = iter; }
         return;
     }
     const double alpha = rz / pAp;
@@ -448,6 +448,7 @@ int fb_bsr_free(fb_ctx* ctx, fb_bsr* M) {
     hipFree(M->d.rowptr); hipFree(M->d.col); hipFree(M->d.val);
     for (double2* v : {M->x, M->r, M->z, M->p0, M->p1, M->Ap, M->minv, M->b, M->diag}) hipFree(v);
     hipFree(M->parts); hipFree(M->state);
+    if (M->pcg_graph) hipGraphExecDestroy(M->pcg_graph);
     delete M;
     return FB_OK;
 }
@@ -554,6 +555,9 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
     int total_iters = 0;
     double relres = 0.0;
     const int check_every = 32;
+    // launch-bound sizes replay the batch as a graph (not under the per-kernel profiler, whose event pairs
+    // sit between the launches)
+    const bool use_graph = !ctx->prof_on && ctx->pcg_graph_max_nb > 0 && nb <= ctx->pcg_graph_max_nb;
     for (int leg = 0; leg < 8; ++leg) {
         // r = b - A x, rr
         {
@@ -572,32 +576,55 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
         // inside a leg the recurrence residual is compared against a slightly tighter target so that the
         // true residual re-evaluated at the end of the leg meets `tol`
         hs.tol2bb *= 0.81;
-        hs.flag = 0; hs.iter = 0; hs.rr = rr;
+        hs.flag = 0; hs.iter = 0; hs.rr = rr; hs.curv_eps = curv_eps;
         FB_HIP(ctx, hipMemcpyAsync(M->state, &hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->r, M->z, M->minv, part_rz[1], part_rr[1]);
         int it = 0;
         bool stop = false;
+        auto iterate = [&](int i) {                           // one iteration = two launches; `i` is the index inside the leg
+            const int cur = i & 1, prev = cur ^ 1;            // K2 of iteration `i` writes slot cur; slot prev holds r_i.z_i
+            double2* p_new = cur ? M->p1 : M->p0;
+            double2* p_old = cur ? M->p0 : M->p1;
+            {
+                FB_PROF_B(ctx, "pcg_spmv_fused", 36.0 * (double)M->nnzb + 4.0 * nb + 5.0 * 16.0 * nb);
+                hipLaunchKernelGGL(bsr_spmv_kernel<1>, dim3(g1), dim3(kT), 0, ctx->stream, M->d, M->z, p_old, p_new, M->Ap, nullptr,
+                                   part_pAp, part_pp, part_rz[prev], part_rz[cur], part_rr[prev], g2, M->state, i);
+            }
+            {
+                FB_PROF_B(ctx, "pcg_update_fused", 7.0 * 16.0 * nb);
+                hipLaunchKernelGGL(pcg_update_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->r, M->z, p_new, M->Ap, M->minv,
+                                   part_pAp, part_pp, g1, part_rz[prev], g2, part_rz[cur], part_rr[cur], M->state, i);
+            }
+        };
         while (!stop) {
             const int batch = std::min(check_every, limit - total_iters - it);
             if (batch <= 0) break;
-            for (int k = 0; k < batch; ++k, ++it) {
-                const int cur = it & 1, prev = cur ^ 1;      // K2 of iteration `it` writes slot cur; slot prev holds r_it.z_it
-                double2* p_new = cur ? M->p1 : M->p0;
-                double2* p_old = cur ? M->p0 : M->p1;
-                {
-                    FB_PROF_B(ctx, "pcg_spmv_fused", 36.0 * (double)M->nnzb + 4.0 * nb + 5.0 * 16.0 * nb);
-                    hipLaunchKernelGGL(bsr_spmv_kernel<1>, dim3(g1), dim3(kT), 0, ctx->stream, M->d, M->z, p_old, p_new, M->Ap, nullptr,
-                                       part_pAp, part_pp, part_rz[prev], part_rz[cur], part_rr[prev], g2, M->state, it);
+            int graph_base = -1;                              // >= 0: the batch ran as the graph, whose kernels count from check_every
+            if (use_graph && it > 0 && batch == check_every) {
+                // every batch but the first of a leg is the same 2 x check_every launches (the slot parity
+                // repeats, the scalars live in M->state): replay them as one graph.  The kernels of the graph
+                // carry the iteration numbers check_every .. 2 check_every - 1; a stop reports one of those.
+                if (!M->pcg_graph) {
+                    hipGraph_t g = nullptr;
+                    FB_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                    for (int k = 0; k < check_every; ++k) iterate(check_every + k);
+                    const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
+                    if (ce != hipSuccess || !g) return fb_fail(ctx, FB_ERR_HIP, "PCG graph capture: %s", hipGetErrorString(ce));
+                    const hipError_t ie = hipGraphInstantiate(&M->pcg_graph, g, nullptr, nullptr, 0);
+                    hipGraphDestroy(g);
+                    if (ie != hipSuccess) { M->pcg_graph = nullptr; return fb_fail(ctx, FB_ERR_HIP, "PCG graph instantiate: %s", hipGetErrorString(ie)); }
+                    M->pcg_graph_iters = check_every;
                 }
-                {
-                    FB_PROF_B(ctx, "pcg_update_fused", 7.0 * 16.0 * nb);
-                    hipLaunchKernelGGL(pcg_update_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->r, M->z, p_new, M->Ap, M->minv,
-                                       part_pAp, part_pp, curv_eps, g1, part_rz[prev], g2, part_rz[cur], part_rr[cur], M->state, it);
-                }
+                FB_HIP(ctx, hipGraphLaunch(M->pcg_graph, ctx->stream));
+                graph_base = it;
+                it += batch;
+            } else {
+                for (int k = 0; k < batch; ++k, ++it) iterate(it);
             }
             FB_HIP(ctx, hipGetLastError());
             FB_HIP(ctx, hipMemcpyAsync(&hs, M->state, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
             FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (hs.flag && graph_base >= 0) hs.iter = graph_base + (hs.iter - check_every);
             if (hs.flag == 1 || hs.flag == 3) { it = hs.iter; stop = true; }
             else if (hs.flag == 2) {
                 total_iters += hs.iter;

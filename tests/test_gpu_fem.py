@@ -201,6 +201,45 @@ def test_spmv_and_pcg_properties(fb):
         lib.fb_csr_destroy(ctx, h)
 
 
+def test_pcg_graph_replay_is_the_same_iteration(fb):
+    """the Jacobi-PCG batches of a launch-bound system replay as one graph per 32 iterations (fb_solver.hip): same
+    kernels in the same order, so iterate, iteration count and residual equal those of the launch-by-launch loop (run in
+    a second process with the graph switched off) bit for bit -- also when the cap ends a leg in the middle of a batch"""
+    import ctypes as C, subprocess, sys, tempfile, os
+    from feabas_amd import _lib
+    code = ('import sys, numpy as np, ctypes as C\n'
+            'from feabas_amd import _lib\n'
+            'z = np.load(sys.argv[1]); lib = _lib.load(); ctx = _lib.ctx(); h = C.c_void_p(); n = int(z["b"].size)\n'
+            'ip = z["ip"]; ix = z["ix"]; va = z["va"]; b = z["b"]; out = []\n'
+            '_lib.check(lib.fb_csr_upload(ctx, n, _lib.ptr(ip), _lib.ptr(ix), _lib.ptr(va), 1, C.byref(h)))\n'
+            'for mi in (-1, 77, 200):\n'
+            '    x = np.zeros(n); it = C.c_int(); rr = C.c_double()\n'
+            '    _lib.check(lib.fb_pcg_csr(ctx, h, _lib.ptr(b), _lib.ptr(x), 0, 1e-10, 0.0, mi, 1, C.byref(it), C.byref(rr)))\n'
+            '    out += [x, np.array([it.value, rr.value])]\n'
+            'lib.fb_csr_destroy(ctx, h); np.savez(sys.argv[2], *out)\n')
+    rng = np.random.default_rng(4)
+    v, t = fem_ref.grid_mesh(70, 50, 10.0)
+    K, _ = fem_ref.mesh_stiffness(v, None, t)
+    n = K.shape[0]
+    A = sparse.csr_matrix(K + sparse.diags(rng.uniform(1e-4, 1e-3, n))); A.sort_indices()
+    b = A.dot(rng.standard_normal(n))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, 'in.npz'), ip=A.indptr.astype(np.int64), ix=A.indices.astype(np.int32), va=A.data.astype(np.float64), b=b)
+        for tag, nbmax in (('graph', '262144'), ('loop', '0')):
+            env = dict(os.environ, FEABAS_HIP_PCG_GRAPH_NB=nbmax, PYTHONPATH=root)
+            subprocess.run([sys.executable, '-c', code, os.path.join(td, 'in.npz'), os.path.join(td, tag + '.npz')], check=True, env=env)
+            with np.load(os.path.join(td, tag + '.npz')) as z:
+                res[tag] = [z[k] for k in z.files]
+    assert res['graph'][1][0] > 150                          # several graph replays before the stop
+    assert res['graph'][3][0] == 77 and res['graph'][5][0] == 200
+    for g, l in zip(res['graph'], res['loop']):
+        np.testing.assert_array_equal(g, l)
+    x = res['graph'][0]
+    assert np.linalg.norm(A.dot(x) - b) <= 1.0001e-10 * np.linalg.norm(b)
+
+
 def test_pcg_breakdown_reported(fb):
     A = sparse.csr_matrix(np.array([[1.0, 0, 0, 0], [0, -2.0, 0, 0], [0, 0, 1.0, 0], [0, 0, 0, 1.0]]))
     with pytest.raises(Exception) as e:
