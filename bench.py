@@ -611,6 +611,7 @@ def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_
     out = dict(sections_per_rank=nsec, sections=nsec * world, nodes_per_section=n * n, dof_per_section=2 * n * n, links_per_section=2 * nl,
                sections_per_s=nsec * world / dt, seconds=dt, seconds_this_rank=dt_rank, pcg_iters_this_rank=iters, optimize_linear_seconds_this_rank=t_solve,
                worst_relres=float(max(relres)), true_relres_last_section_recomputed_on_host=true_relres, host_threads=T,
+               optimize_linear_s_first_of_a_thread_and_median=[float(np.max([r[2] for r in res[:T]])), float(np.median([r[2] for r in res]))],
                note='per section: link set-up (host), device assembly, Jacobi-PCG to 1e-4 through SLM.optimize_linear; the symbolic pattern is kept across '
                     'sections (matches against locked neighbours stay inside the triangles of the free mesh: fb_sys_update_links); '
                     f'{T} host threads with a context each take the sections round-robin; optimize_linear_seconds_this_rank sums the threads')

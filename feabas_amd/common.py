@@ -121,7 +121,18 @@ def cross2d(v0, v1):
 
 
 def signed_area(vertices, triangles):
-    """feabas/common.py:672-676."""
+    """feabas/common.py:672-676.  Whole meshes (float64 vertices, int32 triangles) take the host loop of the library
+    (fb_signed_area, the same roundings: no fused multiply-add): the numpy gather costs 16 ms per 500 k triangles, and every
+    Link of a section asks for the areas of both its meshes (optimizer.py:26-30)."""
+    vertices = np.asarray(vertices); triangles = np.asarray(triangles)
+    if (vertices.dtype == np.float64 and triangles.dtype == np.int32 and vertices.ndim == 2 and vertices.shape[1] == 2
+            and triangles.ndim == 2 and triangles.shape[1] == 3 and triangles.shape[0] >= 4096):
+        from . import _lib
+        v = np.ascontiguousarray(vertices); t = np.ascontiguousarray(triangles)
+        out = np.empty(t.shape[0])
+        if _lib.load().fb_signed_area(None, v.shape[0], _lib.ptr(v), t.shape[0], _lib.ptr(t), _lib.ptr(out)) == 0:
+            return out
+        raise IndexError('signed_area: a triangle names a vertex outside the vertex list')
     p = vertices[triangles]
     return cross2d(p[:, 1, :] - p[:, 0, :], p[:, 2, :] - p[:, 1, :])
 

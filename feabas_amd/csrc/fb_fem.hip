@@ -734,6 +734,16 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
     FB_CHECK_ARG(ctx, s && !s->finalized);
     FB_HIP(ctx, hipSetDevice(ctx->device));
     const int nv = s->nv;
+    // FEABAS_HIP_FEM_TRACE=1: wall time of the steps of the symbolic phase on stderr
+    const bool trace = std::getenv("FEABAS_HIP_FEM_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "fb_sys_finalize %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     // ---- symbolic pattern on the device: every coupled vertex pair as a 64-bit key (row << 32 | col) -- 9 per triangle, live^2
     //      per match, the diagonal of every row -- radix sorted and made unique; the sorted keys ARE the block CSR (the
     //      host statement of the same steps, a bucket pass and a sort per row, took 57 of the 64 ms of a first assembly at 1e6 DoF)
@@ -766,6 +776,7 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
         }
         hipLaunchKernelGGL(pattern_diag_keys_kernel, dim3((unsigned)fb_cdiv(nv, kT)), dim3(kT), 0, ctx->stream, nv, (uint64_t*)d_keys + at);
         FB_HIP(ctx, hipGetLastError());
+        lap("keys");
         int row_bits = 1;
         while ((1LL << row_bits) < (int64_t)nv + 1) ++row_bits;                        // (the all-ones row of a dead link slot sorts behind every row)
         size_t tmp_sort = 0, tmp_uniq = 0;
@@ -778,6 +789,7 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
         FB_HIP(ctx, hipcub::DeviceSelect::Unique(d_tmp, tmp_uniq, (uint64_t*)d_keys2, (uint64_t*)d_keys, d_count, (int)nkeys, ctx->stream));
         int nuniq = 0;
         if ((rc = fb_copy_d2h(ctx, &nuniq, d_count, sizeof(int)))) { release(); return rc; }
+        lap("sort + unique");
         // the key of the dead slots is the tail of the sorted list
         std::vector<uint64_t> hk((size_t)nuniq);
         if (nuniq && (rc = fb_copy_d2h(ctx, hk.data(), d_keys, sizeof(uint64_t) * (size_t)nuniq))) { release(); return rc; }
@@ -790,6 +802,7 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
             s->browptr[(size_t)(hk[j] >> 32) + 1]++;
         }
         for (int v = 0; v < nv; ++v) s->browptr[v + 1] += s->browptr[v];
+        lap("keys to host, row pointers");
     }
     const int64_t nnzb = (int64_t)s->bcol.size();
     // ---- device pattern lives in the solver matrix
@@ -807,6 +820,7 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
     FB_HIP(ctx, hipMemsetAsync(s->d_C, 0, sizeof(float) * (size_t)nnzb, ctx->stream));
     FB_HIP(ctx, hipMemsetAsync(s->d_rhs, 0, sizeof(double2) * (size_t)nv, ctx->stream));
     FB_HIP(ctx, hipMemsetAsync(s->d_stress, 0, sizeof(float2) * (size_t)nv, ctx->stream));
+    lap("matrix buffers");
     // ---- vertex -> incident triangle slots, per mesh
     for (auto& m : s->meshes) {
         std::vector<int> ptr((size_t)m.V + 1, 0), idx(3 * (size_t)m.T);
@@ -823,9 +837,11 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
         FB_HIP(ctx, hipMalloc((void**)&m.d_vcur, sizeof(double2) * (size_t)m.V));
         FB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // ptr/idx are locals
     }
+    lap("vertex -> triangle index");
     // ---- vertex -> incident match slots
     s->link_cap = 0;
     if ((rc = build_link_index(ctx, s))) return rc;
+    lap("vertex -> match index");
     s->finalized = true;
     if (nnzb_out) *nnzb_out = nnzb;
     return FB_OK;

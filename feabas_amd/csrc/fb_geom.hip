@@ -217,7 +217,8 @@ int fb_mesh_block_affines(fb_ctx* ctx, int V, const double* v_mov, const double*
 int fb_mesh_block_uncovered(fb_ctx* ctx, int V, const double* v_mov, const int32_t* tris, int NB, const double* org, int h, int w, int cap,
                             const int32_t* cand, const int32_t* count, double* uncovered) {
     FB_CHECK_ARG(ctx, V > 0 && v_mov && tris && NB >= 0 && org && h > 0 && w > 0 && cap > 0 && cand && count && uncovered);
-    for (int b = 0; b < NB; ++b) {
+    auto work = [&](int b_lo, int b_hi) {
+    for (int b = b_lo; b < b_hi; ++b) {
         const double bx0 = org[2 * b] - 0.5, by0 = org[2 * b + 1] - 0.5, bx1 = bx0 + (double)w, by1 = by0 + (double)h;
         double covered = 0.0;
         const int nc = std::min(count[b], cap);
@@ -245,6 +246,42 @@ int fb_mesh_block_uncovered(fb_ctx* ctx, int V, const double* v_mov, const int32
             covered += 0.5 * std::fabs(a2);
         }
         uncovered[b] = (double)w * (double)h - covered;
+    }
+    };
+    // blocks are independent: a few host threads for the block counts of a whole section (13 689 blocks: 5 ms on one)
+    const int T = std::max(1, std::min(fb_host_threads(4), NB / 2048));
+    if (T <= 1) work(0, NB);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back(work, (int)((int64_t)NB * t / T), (int)((int64_t)NB * (t + 1) / T));
+        for (auto& th : pool) th.join();
+    }
+    return FB_OK;
+}
+
+// common.signed_area (common.py:672-676): cross(p1 - p0, p2 - p1) of every triangle, the two products and their difference
+// rounded one by one like the numpy statement (no fused multiply-add), so the result is the same bit for bit.  Host arrays.
+int fb_signed_area(fb_ctx* ctx, int V, const double* v, int T, const int32_t* tris, double* area) {
+    FB_CHECK_ARG(ctx, V >= 0 && T >= 0 && (T == 0 || (v && tris && area)));
+    for (int t = 0; t < T; ++t)
+        for (int a = 0; a < 3; ++a) FB_CHECK_ARG(ctx, tris[3 * (size_t)t + a] >= -V && tris[3 * (size_t)t + a] < V);
+    auto work = [&](int lo, int hi) {
+#pragma clang fp contract(off)
+        for (int t = lo; t < hi; ++t) {
+            const int32_t* t3 = tris + 3 * (size_t)t;
+            const size_t i0 = (size_t)(t3[0] < 0 ? t3[0] + V : t3[0]), i1 = (size_t)(t3[1] < 0 ? t3[1] + V : t3[1]), i2 = (size_t)(t3[2] < 0 ? t3[2] + V : t3[2]);
+            const double ax = v[2 * i1] - v[2 * i0], ay = v[2 * i1 + 1] - v[2 * i0 + 1];
+            const double bx = v[2 * i2] - v[2 * i1], by = v[2 * i2 + 1] - v[2 * i1 + 1];
+            const double p = ax * by, q = ay * bx;
+            area[t] = p - q;
+        }
+    };
+    const int NT = std::max(1, std::min(fb_host_threads(4), T / 65536));
+    if (NT <= 1) work(0, T);
+    else {
+        std::vector<std::thread> pool;
+        for (int k = 0; k < NT; ++k) pool.emplace_back(work, (int)((int64_t)T * k / NT), (int)((int64_t)T * (k + 1) / NT));
+        for (auto& th : pool) th.join();
     }
     return FB_OK;
 }

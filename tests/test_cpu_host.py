@@ -529,3 +529,45 @@ def test_round_stepper_of_the_block_matcher():
         nxt = plan.due(); plan.close()
         next_pos = np.searchsorted(-spacings, -4 * d) - 1
         assert nxt is not None and nxt[2] == ((min(next_pos, 1) > 1) if next_pos > 0 else True)
+
+
+def test_signed_area_host_loop_equals_the_numpy_statement():
+    """fb_signed_area (whole meshes) against cross(p1 - p0, p2 - p1) of common.py:672-676: the same bits, negative indices
+    as numpy takes them, an index outside the vertex list refused"""
+    rng = np.random.default_rng(8)
+    V, T = 30000, 70000
+    v = rng.standard_normal((V, 2)) * 300
+    t = rng.integers(0, V, (T, 3)).astype(np.int32)
+    t[11] = [-1, -V, 5]
+    p = v[t]
+    exp = common.cross2d(p[:, 1, :] - p[:, 0, :], p[:, 2, :] - p[:, 1, :])
+    np.testing.assert_array_equal(common.signed_area(v, t), exp)
+    np.testing.assert_array_equal(common.signed_area(v[:, ::-1][:, ::-1], t[::2]), exp[::2])        # non-contiguous views
+    np.testing.assert_array_equal(common.signed_area(v, t[:100]), exp[:100])                         # small: the numpy statement itself
+    t[20, 2] = V
+    with pytest.raises(IndexError):
+        common.signed_area(v, t)
+
+
+def test_block_uncovered_threads_equal_one_thread():
+    """fb_mesh_block_uncovered deals the blocks to host threads above 4 096 blocks: the same numbers block by block as
+    the calls on the halves"""
+    lib = _lib.load()
+    rng = np.random.default_rng(2)
+    n = 40
+    xs = np.arange(n) * 10.0
+    v = np.stack(np.meshgrid(xs, xs), -1).reshape(-1, 2) + rng.uniform(-2, 2, (n * n, 2))
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+    tri = np.ascontiguousarray(np.concatenate((np.stack((a, b, d), -1), np.stack((a, d, c), -1))), dtype=np.int32)
+    NB, cap, h, w = 9000, 8, 12, 9
+    org = np.ascontiguousarray(rng.uniform(-20, 10.0 * n, (NB, 2)))
+    cand = np.ascontiguousarray(rng.integers(0, tri.shape[0], (NB, cap)), dtype=np.int32)
+    cnt = np.ascontiguousarray(rng.integers(0, cap + 3, NB), dtype=np.int32)
+    unc = np.empty(NB)
+    assert lib.fb_mesh_block_uncovered(None, v.shape[0], _lib.ptr(v), _lib.ptr(tri), NB, _lib.ptr(org), h, w, cap, _lib.ptr(cand), _lib.ptr(cnt), _lib.ptr(unc)) == 0
+    for lo, hi in ((0, 1500), (1500, 3000), (7000, 9000)):
+        part = np.empty(hi - lo)
+        o_, c_, k_ = np.ascontiguousarray(org[lo:hi]), np.ascontiguousarray(cand[lo:hi]), np.ascontiguousarray(cnt[lo:hi])
+        assert lib.fb_mesh_block_uncovered(None, v.shape[0], _lib.ptr(v), _lib.ptr(tri), hi - lo, _lib.ptr(o_), h, w, cap, _lib.ptr(c_), _lib.ptr(k_), _lib.ptr(part)) == 0
+        np.testing.assert_array_equal(part, unc[lo:hi])
