@@ -1130,8 +1130,8 @@ def main():
         for k in range(len(host_pairs)):                   # as many pairs as the uniform list above
             dh, dw = int(rng_r.integers(0, 30)), int(rng_r.integers(0, 12))
             ragged.append((h0[k % nh, :H - dh, :W - dw], h1[k % nh, :H - dh, :W - dw]))
-        RB = 32                                             # chunks of unequal strips: smaller ones balance the host threads better,
-        RT = max(args.host_ingest_threads, min(16, _lib.cpu_budget()))      # and a chunk costs more host time (a matcher per chunk): more threads
+        RB = 32                                             # (48-, 64- and 96-pair chunks are 5-10 % slower; 16 host threads are no faster than 8:
+        RT = args.host_ingest_threads                       # the six mesh-grid buckets of this list end in small chunks, gpurun_out sweep of round 4)
         fmatcher.stitching_matcher_batch(ragged, batch=RB, threads=RT, **cfg)      # first pass: page-locked staging, systems, code objects (1.6 s once per process)
         t0 = time.time()
         outr = fmatcher.stitching_matcher_batch(ragged, batch=RB, threads=RT, **cfg)

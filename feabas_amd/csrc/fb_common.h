@@ -146,6 +146,8 @@ int fb_ncc_small_launch(fb_ctx* ctx, const float* img0, const float* img1, int N
                         double* dy, float* conf);
 // register-resident 75 x 75 form of the on-chip class (fb_ncc_pfa.hip); same arguments as fb_ncc_small_launch_ex
 int fb_ncc_pfa_supported(int Fh, int Fw, int conf_mode);
+// the FFT shape a block list of at most hmax x wmax pixels asked at Fh x Fw is run at (fb_ncc.hip)
+void fb_ncc_launch_shape(fb_ctx* ctx, int Fh, int Fw, int hmax, int wmax, int conf_mode, int* oh, int* ow);
 int fb_ncc_pfa_launch(fb_ctx* ctx, const float* img0, const float* img1, int N, int H0, int W0, int H1, int W1, const int* blk,
                       int IH0, int IW0, int IH1, int IW1, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf,
                       const double* aff1);

@@ -328,6 +328,13 @@ int ensure_system(fb_ctx* ctx, fb_strip_matcher* m) {
     return FB_OK;
 }
 
+// the results of several launches issued one behind the other: launch g wrote (dx [nb_g], dy [nb_g], conf [nb_g]) at byte
+// 24 * (blocks of the launches before it) of d_out; one copy brings all of them
+int fetch_all(fb_ctx* ctx, fb_strip_matcher* m, size_t total_blocks) {
+    m->raw.resize(24 * total_blocks);
+    return total_blocks ? fb_memcpy_d2h(ctx, m->raw.data(), m->d_out, 24 * total_blocks) : FB_OK;
+}
+
 int fetch(fb_ctx* ctx, fb_strip_matcher* m, size_t nb, const double** dx, const double** dy, const float** cf) {
     m->raw.resize(20 * nb);
     int rc = fb_memcpy_d2h(ctx, m->raw.data(), m->d_out, 20 * nb);
@@ -707,7 +714,7 @@ int matcher_create(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, cons
     if (!rc && m->cds2 && !(rc = pool_take(ctx, 2 * n * fpix * 4, &ptr, &m->b_dogf))) m->d_dogf = (float*)ptr;
     if (!rc && m->cds2 && !(rc = pool_take(ctx, 2 * n * cpix, &ptr, &m->b_small))) m->d_small = (uint8_t*)ptr;
     if (!rc && !(rc = pool_take(ctx, m->max_blocks * 9 * 4, &ptr, &m->b_blk))) m->d_blk = (int*)ptr;
-    if (!rc && !(rc = pool_take(ctx, m->max_blocks * 20, &ptr, &m->b_out))) m->d_out = (uint8_t*)ptr;
+    if (!rc && !(rc = pool_take(ctx, m->max_blocks * 24, &ptr, &m->b_out))) m->d_out = (uint8_t*)ptr;
     if (!rc && m->ragged) {
         // per-image extents of the two stacks, full resolution and coarse (fb_dog_sizes_dev, fb_area_downsample2_sizes_dev)
         std::vector<int32_t> sz((size_t)8 * P);
@@ -1046,26 +1053,45 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         clk.lap(0);
         // whole-strip NCC (matcher.py:153) through block descriptors, one launch per padded FFT shape
         std::map<long long, std::vector<int>> shapes;
-        for (int p = 0; p < n; ++p)
-            shapes[(long long)fb_next_fast_len(2 * m->hcs[p] - 1) * 65536 + fb_next_fast_len(2 * m->wcs[p] - 1)].push_back(p);
-        for (auto& kv : shapes) {
-            const std::vector<int>& sel = kv.second;
-            const size_t nb = sel.size();
-            blk.assign(nb * 9, 0);
-            int hmax = 0, wmax = 0;
-            for (size_t q = 0; q < nb; ++q) {
-                const int p = sel[q];
-                int32_t* d = &blk[9 * q];
-                d[0] = p; d[3] = m->hcs[p]; d[4] = m->wcs[p]; d[7] = m->hcs[p]; d[8] = m->wcs[p];
-                hmax = std::max(hmax, m->hcs[p]); wmax = std::max(wmax, m->wcs[p]);
+        for (int p = 0; p < n; ++p) {
+            // (the shape the correlation is RUN at: extents whose 5-smooth lengths differ -- 500 and 512 -- often share it)
+            int fh_, fw_;
+            fb_ncc_launch_shape(ctx, fb_next_fast_len(2 * m->hcs[p] - 1), fb_next_fast_len(2 * m->wcs[p] - 1), m->hcs[p], m->wcs[p], m->conf_mode, &fh_, &fw_);
+            shapes[(long long)fh_ * 65536 + fw_].push_back(p);
+        }
+        // (all the launches are issued before the one copy that brings their results: a batch of 32 strips around 4096 x 510 has
+        // two or three FFT shapes, and a copy between two launches drains the stream every time)
+        blk.assign((size_t)n * 9, 0);
+        {
+            size_t at = 0;
+            for (auto& kv : shapes)
+                for (int p : kv.second) {
+                    int32_t* d = &blk[9 * at++];
+                    d[0] = p; d[3] = m->hcs[p]; d[4] = m->wcs[p]; d[7] = m->hcs[p]; d[8] = m->wcs[p];
+                }
+            if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), (size_t)n * 9 * 4))) return rc;
+            at = 0;
+            for (auto& kv : shapes) {
+                const std::vector<int>& sel = kv.second;
+                const size_t nb = sel.size();
+                int hmax = 0, wmax = 0;
+                for (int p : sel) { hmax = std::max(hmax, m->hcs[p]); wmax = std::max(wmax, m->wcs[p]); }
+                uint8_t* o = m->d_out + 24 * at;
+                if ((rc = fb_ncc_blocks_dev(ctx, m->d_dogc, m->d_dogc + n * cpix, hc, wc, hc, wc, (int)nb, m->d_blk + 9 * at, hmax, wmax, (int)(kv.first / 65536),
+                                            (int)(kv.first % 65536), 0, m->conf_mode, (double*)o, (double*)(o + 8 * nb), (float*)(o + 16 * nb))))
+                    return rc;
+                at += nb;
             }
-            if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), nb * 9 * 4))) return rc;
-            if ((rc = fb_ncc_blocks_dev(ctx, m->d_dogc, m->d_dogc + n * cpix, hc, wc, hc, wc, (int)nb, m->d_blk, hmax, wmax, (int)(kv.first / 65536), (int)(kv.first % 65536),
-                                        0, m->conf_mode, (double*)m->d_out, (double*)(m->d_out + 8 * nb), (float*)(m->d_out + 16 * nb))))
-                return rc;
-            const double *gx, *gy; const float* gc;
-            if ((rc = fetch(ctx, m, nb, &gx, &gy, &gc))) return rc;
-            for (size_t q = 0; q < nb; ++q) { tx[sel[q]] = gx[q]; ty[sel[q]] = gy[q]; conf0[sel[q]] = gc[q]; }
+            if ((rc = fetch_all(ctx, m, (size_t)n))) return rc;
+            at = 0;
+            for (auto& kv : shapes) {
+                const std::vector<int>& sel = kv.second;
+                const size_t nb = sel.size();
+                const uint8_t* o = m->raw.data() + 24 * at;
+                const double *gx = (const double*)o, *gy = (const double*)(o + 8 * nb); const float* gc = (const float*)(o + 16 * nb);
+                for (size_t q = 0; q < nb; ++q) { tx[sel[q]] = gx[q]; ty[sel[q]] = gy[q]; conf0[sel[q]] = gc[q]; }
+                at += nb;
+            }
         }
         if ((rc = second_shot(ctx, m, thr, tx, ty, conf0))) return rc;
         clk.lap(1);
@@ -1136,6 +1162,9 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
             fhv[p] = fb_next_fast_len(pad[p] ? std::max(2 * (int)dy - 1, 0) : (int)dy);
             fwv[p] = fb_next_fast_len(pad[p] ? std::max(2 * (int)dx - 1, 0) : (int)dx);
             if (!m->is_def[p]) {
+                // pairs are grouped by the shape their blocks are RUN at (unequal strips: block sizes a few pixels apart, whose
+                // 5-smooth lengths differ, share the promoted power of two of the streaming class)
+                if (m->ragged) fb_ncc_launch_shape(ctx, fhv[p], fwv[p], (int)dy, (int)dx, m->conf_mode, &fhv[p], &fwv[p]);
                 const long long key = ((((long long)nx * 4096 + (long long)ny) * 8192 + fhv[p]) * 8192 + fwv[p]);
                 groups[key].push_back(p);
             } else {
@@ -1153,6 +1182,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         // block descriptors of pair p (slot q of its group): starts = round(linspace(lo, hi - step, count)) per axis, blocks in the
         // z-order of their index grid (common.z_order, common.py:196-215; stable)
         bool have_c = false;
+        size_t goff = 0;                                    // first block of the group being described inside blk / bbx0 / bby0
         auto pair_blocks = [&](int q, int p, int nxi, int nyi, bool deformed) {
             const int nblk = nxi * nyi, dx = dxv[p], dy = dyv[p];
             const double spc = m->sp[(size_t)p * nsp + rnd];
@@ -1177,7 +1207,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
             const int rtx = round_i(tx[p]), rty = round_i(ty[p]), r1x = round_i(t1[2 * p]), r1y = round_i(t1[2 * p + 1]);
             for (int b = 0; b < nblk; ++b) {
                 const int o = ordc[b], x0 = xt[o % nxi], y0 = yt[o / nxi];
-                const size_t at = (size_t)q * nblk + b;
+                const size_t at = goff + (size_t)q * nblk + b;
                 bbx0[at] = x0; bby0[at] = y0;
                 int32_t* d = &blk[9 * at];
                 d[0] = p; d[1] = x0 - rtx; d[2] = y0 - rty; d[3] = dy; d[4] = dx; d[7] = dy; d[8] = dx;
@@ -1191,27 +1221,51 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
             for (int k = 0; k < nsp; ++k) next_pos += m->sp[(size_t)p * nsp + k] > 4.0 * max_dis;
             pad[p] = !(next_pos > rnd);
         };
+        // the groups of a round are described, launched and fetched together: one copy of the descriptors, the launches one behind
+        // the other, one copy of the results (a chunk of unequal strips has several groups per round; a copy between two
+        // launches drained the stream every time)
+        std::vector<size_t> gbase;
+        size_t gtotal = 0;
+        for (auto& kv : groups) {
+            gbase.push_back(gtotal);
+            gtotal += kv.second.size() * (size_t)nxv[kv.second[0]] * nyv[kv.second[0]];
+        }
+        if (gtotal > m->max_blocks) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: %zu blocks in one round (limit %zu)", gtotal, m->max_blocks);
+        if (gtotal) {
+            blk.resize(gtotal * 9); bbx0.resize(gtotal); bby0.resize(gtotal);
+            size_t gi = 0;
+            for (auto& kv : groups) {
+                const std::vector<int>& sel = kv.second;
+                have_c = false;
+                goff = gbase[gi++];
+                for (int q = 0; q < (int)sel.size(); ++q) pair_blocks(q, sel[q], nxv[sel[0]], nyv[sel[0]], false);
+            }
+            goff = 0;
+            clk.lap(2);
+            if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), gtotal * 9 * 4))) return rc;
+            gi = 0;
+            for (auto& kv : groups) {
+                const std::vector<int>& sel = kv.second;
+                const size_t nb = sel.size() * (size_t)nxv[sel[0]] * nyv[sel[0]], gb = gbase[gi++];
+                int hmax = 0, wmax = 0;
+                for (int p : sel) { hmax = std::max(hmax, dyv[p]); wmax = std::max(wmax, dxv[p]); }
+                uint8_t* o = m->d_out + 24 * gb;
+                if ((rc = fb_ncc_blocks_dev(ctx, dogf, img1, H, W, H, W, (int)nb, m->d_blk + 9 * gb, hmax, wmax, fhv[sel[0]], fwv[sel[0]], is_last ? 1 : 0,
+                                            m->conf_mode, (double*)o, (double*)(o + 8 * nb), (float*)(o + 16 * nb))))
+                    return rc;
+            }
+            clk.lap(3);
+            if ((rc = fetch_all(ctx, m, gtotal))) return rc;
+            clk.lap(4);
+        }
+        size_t gidx = 0;
         for (auto& kv : groups) {
             const std::vector<int>& sel = kv.second;
             const int Q = (int)sel.size(), nxi = nxv[sel[0]], nyi = nyv[sel[0]], nblk = nxi * nyi;
-            const size_t nb = (size_t)Q * nblk;
-            if (nb > m->max_blocks) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: %zu blocks in one launch (limit %zu)", nb, m->max_blocks);
-            blk.resize(nb * 9); bbx0.resize(nb); bby0.resize(nb);
-            int hmax = 0, wmax = 0;
-            have_c = false;
-            for (int q = 0; q < Q; ++q) {
-                hmax = std::max(hmax, dyv[sel[q]]); wmax = std::max(wmax, dxv[sel[q]]);
-                pair_blocks(q, sel[q], nxi, nyi, false);
-            }
-            clk.lap(2);
-            if ((rc = fb_memcpy_h2d(ctx, m->d_blk, blk.data(), nb * 9 * 4))) return rc;
-            if ((rc = fb_ncc_blocks_dev(ctx, dogf, img1, H, W, H, W, (int)nb, m->d_blk, hmax, wmax, fhv[sel[0]], fwv[sel[0]], is_last ? 1 : 0,
-                                        m->conf_mode, (double*)m->d_out, (double*)(m->d_out + 8 * nb), (float*)(m->d_out + 16 * nb))))
-                return rc;
-            clk.lap(3);
-            const double *ddx, *ddy; const float* dcf;
-            if ((rc = fetch(ctx, m, nb, &ddx, &ddy, &dcf))) return rc;
-            clk.lap(4);
+            const size_t nb = (size_t)Q * nblk, gb = gbase[gidx++];
+            const uint8_t* o = m->raw.data() + 24 * gb;
+            const double *ddx = (const double*)o, *ddy = (const double*)(o + 8 * nb); const float* dcf = (const float*)(o + 16 * nb);
+            const int* gx0 = bbx0.data() + gb; const int* gy0 = bby0.data() + gb;       // block origins of this group
             // ---- blocks -> point pairs (matcher.py:671-683, 840-849), spacing schedule (689-716), rigid relaxation (725-742)
             for (int q = 0; q < Q; ++q) {
                 const int p = sel[q];
@@ -1223,7 +1277,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                     if (!(dcf[base + b] > thr)) continue;
                     if (first < 0) first = b;
                     const double hx = ddx[base + b] * 0.5, hy = ddy[base + b] * 0.5;
-                    const double cx = 0.5 * (double)(bbx0[base + b] + (bbx0[base + b] + dx)) - 0.5, cy = 0.5 * (double)(bby0[base + b] + (bby0[base + b] + dy)) - 0.5;
+                    const double cx = 0.5 * (double)(gx0[base + b] + (gx0[base + b] + dx)) - 0.5, cy = 0.5 * (double)(gy0[base + b] + (gy0[base + b] + dy)) - 0.5;
                     const double ex = (cx - hx) - (cx + hx), ey = (cy - hy) - (cy + hy);
                     dis2max = std::max(dis2max, ex * ex + ey * ey);
                 }
@@ -1241,12 +1295,12 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                         // elastic and zero link energy); any other field is solved below and makes the pair deformed
                         bool nonrigid = false;
                         const double hx0 = ddx[base + first] * 0.5, hy0 = ddy[base + first] * 0.5;
-                        const double c0x = 0.5 * (double)(bbx0[base + first] + (bbx0[base + first] + dx)) - 0.5, c0y = 0.5 * (double)(bby0[base + first] + (bby0[base + first] + dy)) - 0.5;
+                        const double c0x = 0.5 * (double)(gx0[base + first] + (gx0[base + first] + dx)) - 0.5, c0y = 0.5 * (double)(gy0[base + first] + (gy0[base + first] + dy)) - 0.5;
                         const double u0x = (c0x - hx0) - (c0x + hx0), u0y = (c0y - hy0) - (c0y + hy0);
                         for (int b = 0; b < nblk && !nonrigid; ++b) {
                             if (!(dcf[base + b] > thr)) continue;
                             const double hx = ddx[base + b] * 0.5, hy = ddy[base + b] * 0.5;
-                            const double cx = 0.5 * (double)(bbx0[base + b] + (bbx0[base + b] + dx)) - 0.5, cy = 0.5 * (double)(bby0[base + b] + (bby0[base + b] + dy)) - 0.5;
+                            const double cx = 0.5 * (double)(gx0[base + b] + (gx0[base + b] + dx)) - 0.5, cy = 0.5 * (double)(gy0[base + b] + (gy0[base + b] + dy)) - 0.5;
                             nonrigid = ((cx - hx) - (cx + hx)) != u0x || ((cy - hy) - (cy + hy)) != u0y;
                         }
                         if (!nonrigid) { t1[2 * p] += u0x; t1[2 * p + 1] += u0y; }
@@ -1257,7 +1311,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
                 for (int b = 0; b < nblk; ++b) {
                     if (!(dcf[base + b] > thr)) continue;
                     const double hx = ddx[base + b] * 0.5, hy = ddy[base + b] * 0.5;
-                    const double cx = 0.5 * (double)(bbx0[base + b] + (bbx0[base + b] + dx)) - 0.5, cy = 0.5 * (double)(bby0[base + b] + (bby0[base + b] + dy)) - 0.5;
+                    const double cx = 0.5 * (double)(gx0[base + b] + (gx0[base + b] + dx)) - 0.5, cy = 0.5 * (double)(gy0[base + b] + (gy0[base + b] + dy)) - 0.5;
                     const double x1 = cx + hx, y1 = cy + hy;
                     cur.push(p, cx - hx, cy - hy, x1 - t1x, y1 - t1y, x1, y1, dcf[base + b], rl);
                 }

@@ -965,6 +965,19 @@ int fb_ncc_blocks_affine_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1
     return FB_OK;
 }
 
+}  // extern "C"
+
+// The FFT shape fb_ncc_blocks_dev runs blocks of at most hmax x wmax pixels at when it is asked for Fh x Fw: the shape itself
+// (on-chip class, circular axes, FFT_CONF_STD, rocFFT shapes) or the promoted one of promote_linear_shape.  Callers that hold
+// several block lists whose shapes promote to the same one may launch them as one list at that shape.
+void fb_ncc_launch_shape(fb_ctx* ctx, int Fh, int Fw, int hmax, int wmax, int conf_mode, int* oh, int* ow) {
+    *oh = Fh; *ow = Fw;
+    if (fb_ncc_small_supported(Fh, Fw, 0, 0, 0, 0, 1)) return;
+    if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, 1)) promote_linear_shape(*oh, *ow, 2 * hmax - 1, 2 * wmax - 1, conf_mode);
+}
+
+extern "C" {
+
 int fb_ncc_blocks_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1, int IH0, int IW0, int IH1, int IW1, int N,
                       const int* blk, int hmax, int wmax, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
     return fb_ncc_blocks_affine_dev(ctx, imgs0, imgs1, IH0, IW0, IH1, IW1, N, blk, nullptr, hmax, wmax, Fh, Fw, subpixel, conf_mode, dx, dy, conf);

@@ -7,6 +7,7 @@ the GPU kernels for the arithmetic.
 import ctypes as C
 
 import os
+import sys
 import time
 
 import numpy as np
@@ -1130,6 +1131,19 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
     free_q, ready_q = queue.Queue(), queue.Queue()
     for sl in range(n_slots):
         free_q.put(sl)
+    # FEABAS_HIP_INGEST_TRACE=1: busy time of every loader and matcher thread (stage / match calls) against the wall, on stderr
+    trace = [] if os.environ.get('FEABAS_HIP_INGEST_TRACE') else None
+    _time = time
+    t_start = _time.perf_counter()
+
+    def timed(kind, who, fn, *a):
+        if trace is None:
+            return fn(*a)
+        t0 = _time.perf_counter()
+        try:
+            return fn(*a)
+        finally:
+            trace.append((kind, who, t0 - t_start, _time.perf_counter() - t_start))
     next_chunk = [0]
     take = threading.Lock()
 
@@ -1162,7 +1176,7 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
                     break
                 sl = free_q.get()
                 pin, dev = shared['io'][sl]
-                ready_q.put((c, sl) + stage(chunks[c], pin, dev))
+                ready_q.put((c, sl) + timed('stage', j, stage, chunks[c], pin, dev))
         except Exception as e:                                # noqa: BLE001 -- re-raised in the calling thread
             errors.append(e)
         finally:
@@ -1238,7 +1252,7 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
                 c, sl, n, Hm, Wm = got
                 try:
                     if not errors:
-                        match_chunk(state, chunks[c], shared['io'][sl][1], n, Hm, Wm)
+                        timed('match', t, match_chunk, state, chunks[c], shared['io'][sl][1], n, Hm, Wm)
                 finally:
                     free_q.put(sl)
         except Exception as e:                                # noqa: BLE001 -- re-raised in the calling thread
@@ -1261,6 +1275,14 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         th.start()
     for th in lths + ths:
         th.join()
+    if trace is not None:
+        wall = _time.perf_counter() - t_start
+        for kind in ('stage', 'match'):
+            who = sorted({w for k_, w, _, _ in trace if k_ == kind})
+            busy = [sum(b - a for k_, w, a, b in trace if k_ == kind and w == x) for x in who]
+            calls = [sum(1 for k_, w, _, _ in trace if k_ == kind and w == x) for x in who]
+            sys.stderr.write(f'stitching_matcher_batch {kind}: wall {1e3 * wall:.1f} ms, threads {len(who)}, calls {calls}, busy ms {[round(1e3 * v, 1) for v in busy]}, '
+                             f'mean call {1e3 * sum(busy) / max(1, sum(calls)):.2f} ms\n')
     if errors:
         raise errors[0]
     for k in deferred:
