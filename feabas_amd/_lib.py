@@ -128,6 +128,9 @@ _PROTOS = {
     'fb_ncc_last_surfaces': (c_i, [c_p, c_p, c_p, C.POINTER(c_i), C.POINTER(c_i)]),
     'fb_dog': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
     'fb_dog_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
+    'fb_area_resize_size': (c_i, [c_i, c_d]),
+    'fb_area_resize_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_d, c_d, c_p]),
+    'fb_area_resize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_d, c_d, c_p]),
     'fb_area_downsample2': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'fb_area_downsample2_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'fb_area_downsample2_sizes_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),

@@ -54,6 +54,48 @@ def area_downsample2(img):
     return out
 
 
+def resize_size(n, f):
+    """output length of cv2.resize(None, fx=f): cvRound(n f), round half to even"""
+    return int(_lib.load().fb_area_resize_size(int(n), float(f)))
+
+
+def area_resize(img, fx, fy=None):
+    """cv2.resize(img, None, fx=fx, fy=fy, interpolation=cv2.INTER_AREA) of uint8 images (last two axes) for shrinking factors
+    (feabas/matcher.py:255-256, 320-321) on the GPU: fb_area_resize (integer 1 / f: cell sums; otherwise fractional-coverage
+    taps).  x0.5 is area_downsample2."""
+    fy = fx if fy is None else fy
+    if not (0 < fx <= 1 and 0 < fy <= 1):
+        raise NotImplementedError('area_resize: INTER_AREA is restated for shrinking factors (0 < f <= 1) only')
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if fx == 1 and fy == 1:
+        return img
+    shp = img.shape
+    h, w = shp[-2:]
+    n = int(np.prod(shp[:-2])) if img.ndim > 2 else 1
+    out = np.empty(shp[:-2] + (resize_size(h, fy), resize_size(w, fx)), dtype=np.uint8)
+    if out.size == 0:
+        raise ValueError(f'area_resize: a {h} x {w} image shrinks to nothing at ({fy}, {fx})')
+    _lib.check(_lib.load().fb_area_resize(_lib.ctx(), _lib.ptr(img), n, h, w, float(fx), float(fy), _lib.ptr(out)))
+    return out
+
+
+def nearest_resize_mask(mask, fx, fy=None):
+    """cv2.resize(mask.astype(np.uint8), None, fx=fx, fy=fy, interpolation=cv2.INTER_NEAREST).astype(bool)
+    (feabas/matcher.py:257-264): source index min(floor(d / f), n - 1)"""
+    mask = np.asarray(mask, dtype=bool)
+    fy = fx if fy is None else fy
+    H, W = mask.shape
+    iy = np.minimum(np.floor(np.arange(resize_size(H, fy)) * (1.0 / fy)).astype(np.int64), H - 1)
+    ix = np.minimum(np.floor(np.arange(resize_size(W, fx)) * (1.0 / fx)).astype(np.int64), W - 1)
+    return mask[np.ix_(iy, ix)]
+
+
+def scale_coordinates(xy, scale):
+    """feabas/spatial.py:77-86: scaling that keeps the centre of the corner pixel at (0, 0)"""
+    xy = np.asarray(xy)
+    return xy if np.all(scale == 1) else (xy + 0.5) * scale - 0.5
+
+
 def numpy_array(obj, copy=False):
     return np.array(obj, copy=True) if copy else np.asarray(obj)
 

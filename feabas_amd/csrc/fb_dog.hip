@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cfloat>
+#include <vector>
 
 namespace {
 
@@ -1203,6 +1205,142 @@ int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, ui
     if (!rc) rc = fb_area_downsample2_dev(ctx, din, N, H, W, dout);
     if (!rc) rc = fb_copy_d2h(ctx, out, dout, bo);
     hipFree(din); hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cv2.resize(img, None, fx, fy, INTER_AREA) of uint8 images for any shrinking factor (matcher.py:255-256, 320-321:
+// coarse_downsample / fine_downsample other than 0.5).  OpenCV's rule as published (imgproc/resize.cpp; cv2 is absent from
+// the build image, so this statement is unpinned like the x0.5 one): output size cvRound(n f) per axis; when 1/f is an
+// integer k on both axes the cell is summed in integers and scaled, saturate_cast<uchar>(sum * (1.f / k^2)) -- round half to
+// even -- with (sum + 2) >> 2 for k = 2 (its vector kernel), and a cell cut by the image edge averages the pixels that exist,
+// (float)sum / count; otherwise every axis gets a table of (source index, weight) taps -- the covered fraction of each source
+// pixel over the cell width -- and the pixel is accumulated in float, taps of a row first, rows after.
+namespace {
+struct AreaAxis { std::vector<int> ptr, si; std::vector<float> alpha; };
+
+// computeResizeAreaTab: taps of every output index along one axis
+AreaAxis area_axis(int ssize, int dsize, double scale) {
+    AreaAxis t;
+    t.ptr.push_back(0);
+    for (int dx = 0; dx < dsize; ++dx) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1); sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) { t.si.push_back(sx1 - 1); t.alpha.push_back((float)((sx1 - fsx1) / cell)); }
+        for (int sx = sx1; sx < sx2; ++sx) { t.si.push_back(sx); t.alpha.push_back((float)(1.0 / cell)); }
+        if (fsx2 - sx2 > 1e-3) { t.si.push_back(sx2); t.alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.0), cell) / cell)); }
+        t.ptr.push_back((int)t.si.size());
+    }
+    return t;
+}
+
+__device__ __forceinline__ uint8_t sat_u8(float v) {
+    const float r = rintf(v);                                // cvRound: to nearest, ties to even (NaN -> 0 after the clamp)
+    return (uint8_t)(r > 255.f ? 255.f : (r > 0.f ? r : 0.f));
+}
+
+__global__ __launch_bounds__(256) void area_fast_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ out, int N, int H, int W, int Ho, int Wo,
+                                                         int kx, int ky) {
+#pragma clang fp contract(off)
+    const size_t total = (size_t)N * Ho * Wo;
+    const float scale = 1.f / (float)(kx * ky);
+    const int wfull = W / kx;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int dx = (int)(i % Wo), dy = (int)((i / Wo) % Ho);
+        const uint8_t* S = img + (i / ((size_t)Wo * Ho)) * (size_t)H * W;
+        const int sy0 = dy * ky, sx0 = dx * kx;
+        if (sy0 >= H || sx0 >= W) { out[i] = 0; continue; }
+        int sum = 0, count = 0;
+        for (int sy = 0; sy < ky && sy0 + sy < H; ++sy)
+            for (int sx = 0; sx < kx && sx0 + sx < W; ++sx) { sum += S[(size_t)(sy0 + sy) * W + sx0 + sx]; ++count; }
+        const bool full = sy0 + ky <= H && dx < wfull;
+        if (full) out[i] = (kx == 2 && ky == 2) ? (uint8_t)((sum + 2) >> 2) : sat_u8((float)sum * scale);
+        else out[i] = sat_u8((float)sum / (float)count);
+    }
+}
+
+__global__ __launch_bounds__(256) void area_taps_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ out, int N, int H, int W, int Ho, int Wo,
+                                                         const int* __restrict__ xptr, const int* __restrict__ xsi, const float* __restrict__ xal,
+                                                         const int* __restrict__ yptr, const int* __restrict__ ysi, const float* __restrict__ yal) {
+#pragma clang fp contract(off)                               // products and sums rounded one by one, like the float loops of ResizeArea
+    const size_t total = (size_t)N * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int dx = (int)(i % Wo), dy = (int)((i / Wo) % Ho);
+        const uint8_t* S = img + (i / ((size_t)Wo * Ho)) * (size_t)H * W;
+        float sum = 0.f;
+        for (int j = yptr[dy]; j < yptr[dy + 1]; ++j) {
+            const uint8_t* row = S + (size_t)ysi[j] * W;
+            float buf = 0.f;
+            for (int k = xptr[dx]; k < xptr[dx + 1]; ++k) { const float t = (float)row[xsi[k]] * xal[k]; buf = buf + t; }
+            const float term = yal[j] * buf;
+            sum = j == yptr[dy] ? term : sum + term;
+        }
+        out[i] = sat_u8(sum);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int fb_area_resize_size(int n, double f) { return (int)std::lrint((double)n * f); }
+
+int fb_area_resize_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, double fx, double fy, uint8_t* out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && fx > 0 && fx <= 1 && fy > 0 && fy <= 1);
+    const int Ho = fb_area_resize_size(H, fy), Wo = fb_area_resize_size(W, fx);
+    FB_CHECK_ARG(ctx, Ho > 0 && Wo > 0);
+    if (N == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, img && out);
+    FB_PROF(ctx, "area_resize");
+    const double sx = 1.0 / fx, sy = 1.0 / fy;
+    const int kx = (int)std::lrint(sx), ky = (int)std::lrint(sy);
+    const size_t total = (size_t)N * Ho * Wo;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    if (std::fabs(sx - kx) < DBL_EPSILON && std::fabs(sy - ky) < DBL_EPSILON) {
+        hipLaunchKernelGGL(area_fast_kernel, dim3(blocks), dim3(256), 0, ctx->stream, img, out, N, H, W, Ho, Wo, kx, ky);
+        FB_HIP(ctx, hipGetLastError());
+        return FB_OK;
+    }
+    const AreaAxis tx = area_axis(W, Wo, sx), ty = area_axis(H, Ho, sy);
+    int *d_i = nullptr; float* d_f = nullptr;
+    const size_t ni = tx.ptr.size() + tx.si.size() + ty.ptr.size() + ty.si.size(), nf = tx.alpha.size() + ty.alpha.size();
+    std::vector<int> hi; hi.reserve(ni);
+    hi.insert(hi.end(), tx.ptr.begin(), tx.ptr.end()); hi.insert(hi.end(), tx.si.begin(), tx.si.end());
+    hi.insert(hi.end(), ty.ptr.begin(), ty.ptr.end()); hi.insert(hi.end(), ty.si.begin(), ty.si.end());
+    std::vector<float> hf(tx.alpha); hf.insert(hf.end(), ty.alpha.begin(), ty.alpha.end());
+    int rc = fb_malloc(ctx, sizeof(int) * ni, (void**)&d_i);
+    if (!rc) rc = fb_malloc(ctx, sizeof(float) * nf, (void**)&d_f);
+    if (!rc) rc = fb_copy_h2d(ctx, d_i, hi.data(), sizeof(int) * ni);
+    if (!rc) rc = fb_copy_h2d(ctx, d_f, hf.data(), sizeof(float) * nf);
+    if (!rc) {
+        const int* xptr = d_i; const int* xsi = xptr + tx.ptr.size(); const int* yptr = xsi + tx.si.size(); const int* ysi = yptr + ty.ptr.size();
+        hipLaunchKernelGGL(area_taps_kernel, dim3(blocks), dim3(256), 0, ctx->stream, img, out, N, H, W, Ho, Wo, xptr, xsi, (const float*)d_f, yptr, ysi,
+                           (const float*)d_f + tx.alpha.size());
+        if (hipGetLastError() != hipSuccess) rc = fb_fail(ctx, FB_ERR_HIP, "area_taps_kernel launch failed");
+    }
+    if (d_i) fb_free(ctx, d_i);                             // (fb_free waits for the stream)
+    if (d_f) fb_free(ctx, d_f);
+    return rc;
+}
+
+int fb_area_resize(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, double fx, double fy, uint8_t* out) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, N >= 0 && H > 0 && W > 0 && fx > 0 && fx <= 1 && fy > 0 && fy <= 1);
+    if (N == 0) return FB_OK;
+    const size_t bi = (size_t)N * H * W, bo = (size_t)N * fb_area_resize_size(H, fy) * fb_area_resize_size(W, fx);
+    FB_CHECK_ARG(ctx, img && out && bo > 0);
+    void *din = nullptr, *dout = nullptr;
+    int rc = fb_malloc(ctx, bi, &din);
+    if (!rc) rc = fb_malloc(ctx, bo, &dout);
+    if (!rc) rc = fb_copy_h2d(ctx, din, img, bi);
+    if (!rc) rc = fb_area_resize_dev(ctx, (const uint8_t*)din, N, H, W, fx, fy, (uint8_t*)dout);
+    if (!rc) rc = fb_copy_d2h(ctx, out, dout, bo);
+    if (din) fb_free(ctx, din);
+    if (dout) fb_free(ctx, dout);
     return rc;
 }
 

@@ -894,8 +894,12 @@ def _stitching_options(kwargs):
         raise NotImplementedError(f'stitching_matcher: unsupported options {sorted(kw)}')
     if residue_mode not in ('huber', 'threshold'):
         raise ValueError("stitching_matcher: residue_mode must be 'huber' or 'threshold' (matcher.py:730-735)")
-    if fine_downsample != 1 or coarse_downsample not in (1, 0.5):
-        raise NotImplementedError('stitching_matcher: fine_downsample != 1 or coarse_downsample outside (1, 0.5) is not on the device path')
+    if not (0 < fine_downsample <= 1 and 0 < coarse_downsample <= 1):
+        raise NotImplementedError('stitching_matcher: coarse_downsample and fine_downsample are shrinking factors in (0, 1]')
+    # fine_downsample != 1 or a coarse_downsample other than 1 / 0.5: the general-mesh route (the batched strip pipeline is
+    # built for full-resolution fine images and the x0.5 coarse level of default_stitching_configs.yaml:18-19)
+    opts['_fine_downsample'] = fine_downsample
+    opts['_general_scales'] = fine_downsample != 1 or coarse_downsample not in (1, 0.5)
     return opts, mask0, mask1, compute_photometric
 
 
@@ -920,24 +924,23 @@ def _stitching_matcher_general(img0, img1, opts, mask0, mask1, compute_photometr
     from . import renderer as _rd
     from .mesh import Mesh
     sigma, cds = opts['sigma'], opts['coarse_downsample']
+    fds = opts.get('_fine_downsample', 1)
     conf_thresh, conf_mode, mnb = opts['conf_thresh'], opts['conf_mode'], opts['min_num_blocks']
     spacings = opts['spacings']
     spacings = auto_spacings(img0.shape, img1.shape) if spacings is None else np.array(spacings, dtype=np.float64)
 
-    def coarse_mask(mk, shape):
-        if mk is None:
-            return None
-        mk = np.asarray(mk, dtype=bool)
-        return mk[::2, ::2][:shape[0], :shape[1]] if cds == 0.5 else mk       # cv2.resize(INTER_NEAREST, 0.5): every second pixel
-    if cds == 0.5:
-        r0, r1 = common.area_downsample2(img0), common.area_downsample2(img1)
-    else:
-        r0, r1 = img0, img1
-    mg0, mg1 = coarse_mask(mask0, r0.shape), coarse_mask(mask1, r1.shape)
-    if sigma > 0:
-        g0 = common.masked_dog_filter(r0, sigma * cds, mask=mg0); g1 = common.masked_dog_filter(r1, sigma * cds, mask=mg1)
-    else:
-        g0, g1 = r0.astype(np.float32), r1.astype(np.float32)
+    def shrink(img, mk, f):
+        """cv2.resize(INTER_AREA) of the image, cv2.resize(INTER_NEAREST) of its mask (matcher.py:254-266, 318-335)"""
+        if f == 1:
+            return img, (None if mk is None else np.asarray(mk, dtype=bool))
+        small = common.area_downsample2(img) if f == 0.5 else common.area_resize(img, f)
+        return small, (None if mk is None else common.nearest_resize_mask(mk, f)[:small.shape[0], :small.shape[1]])
+
+    def dog(img, s_, mk):
+        return common.masked_dog_filter(img, s_, mask=mk) if sigma > 0 else img.astype(np.float32)
+    r0, mg0 = shrink(img0, mask0, cds)
+    r1, mg1 = shrink(img1, mask1, cds)
+    g0, g1 = dog(r0, sigma * cds, mg0), dog(r1, sigma * cds, mg1)
     tx0, ty0, conf0 = global_translation_matcher(g0, g1, conf_mode=conf_mode, conf_thresh=conf_thresh)
     if conf0 < conf_thresh:
         return None, None, conf_thresh, None, None
@@ -955,17 +958,19 @@ def _stitching_matcher_general(img0, img1, opts, mask0, mask1, compute_photometr
                 phtm = (np.mean(r0[i0][mp]), np.mean(r1[i1][mp]), np.mean(np.abs(g0[i0][mp])), np.mean(np.abs(g1[i1][mp])))
             else:
                 phtm = (np.mean(g0[i0][mp]), np.mean(g1[i1][mp]), np.std(g0[i0][mp]), np.std(g1[i1][mp]))
-    if cds == 1:
+    if fds == cds:                                                            # matcher.py:315-317
         f0, f1 = g0, g1
-    elif sigma > 0:
-        f0 = common.masked_dog_filter(img0, sigma, mask=mask0); f1 = common.masked_dog_filter(img1, sigma, mask=mask1)
-    else:
-        f0, f1 = img0.astype(np.float32), img1.astype(np.float32)
-    tx0, ty0 = tx0 / cds, ty0 / cds
+    else:                                                                     # matcher.py:318-337
+        b0, mf0 = shrink(img0, mask0, fds)
+        b1, mf1 = shrink(img1, mask1, fds)
+        f0, f1 = dog(b0, sigma * fds, mf0), dog(b1, sigma * fds, mf1)
+    tx0, ty0 = tx0 * fds / cds, ty0 * fds / cds                               # matcher.py:338-339
+    residue_len = opts['residue_len'] * fds                                   # matcher.py:341
     if np.any(spacings < 1):                                                  # matcher.py:343-350
         bb, _ = common.intersect_bbox(np.array((0, 0, f0.shape[1], f0.shape[0])) + np.tile((tx0, ty0), 2), (0, 0, f1.shape[1], f1.shape[0]))
         spacings = spacings.copy()
         spacings[spacings < 1] *= max(bb[2] - bb[0], bb[3] - bb[1])
+    spacings = spacings * fds                                                 # matcher.py:352
     min_spacing = float(np.min(spacings))
     mesh0 = Mesh.from_bbox((0, 0, f0.shape[1], f0.shape[0]), cartesian=True, mesh_size=min_spacing, min_num_blocks=mnb, uid=0)
     mesh1 = Mesh.from_bbox((0, 0, f1.shape[1], f1.shape[0]), cartesian=True, mesh_size=min_spacing, min_num_blocks=mnb, uid=1)
@@ -974,13 +979,15 @@ def _stitching_matcher_general(img0, img1, opts, mask0, mask1, compute_photometr
     im0, im1 = _rd.ResidentImage(np.ascontiguousarray(f0, dtype=np.float32)), _rd.ResidentImage(np.ascontiguousarray(f1, dtype=np.float32))
     try:
         xy0, xy1, weight, strain = iterative_xcorr_matcher_w_mesh(mesh0, mesh1, im0, im1, spacings=spacings, distributor='cartesian_bbox',
-                                                                  residue_len=opts['residue_len'], residue_mode=('threshold' if opts['residue_mode'] == 'threshold' else 'huber'),
+                                                                  residue_len=residue_len, residue_mode=('threshold' if opts['residue_mode'] == 'threshold' else 'huber'),
                                                                   conf_thresh=conf_thresh, conf_mode=conf_mode, min_num_blocks=mnb,
                                                                   stiffness_lambda=opts['stiffness_lambda'], compute_strain=opts['compute_strain'])
     finally:
         im0.free(); im1.free()
     if xy0 is None:
         return None, None, conf_thresh, None, None
+    if fds != 1:                                                              # matcher.py:365-367
+        xy0, xy1 = common.scale_coordinates(xy0, 1 / fds), common.scale_coordinates(xy1, 1 / fds)
     return xy0, xy1, weight, strain, phtm
 
 
@@ -989,18 +996,22 @@ def stitching_matcher(img0, img1, **kwargs):
     strip-local pixel coordinates, or ``(None, None, conf_thresh, None, None)`` when the strips do not match
     (matcher.py:278) -- no exception for "no match".
 
-    The whole sequence runs on the device through the batch pipeline (``stitch_pipeline.StripBatchMatcher`` with a batch
-    of one; callers with many pairs use ``stitching_matcher_batch``).  Supported: equal-shape 2-D uint8 strips,
-    ``coarse_downsample`` in (1, 0.5), ``fine_downsample = 1``, automatic spacings, optional masks (mask0 / mask1, True =
-    valid pixel) and photometric statistics; mesh relaxations between spacings of any shape (rigid or deformed mesh1).
-    Explicit ``spacings`` are taken in pixels, ``residue_mode`` is 'huber' or 'threshold'.  Anything the device path does not
-    cover (spacings < 1, fine_downsample != 1) raises NotImplementedError instead of silently taking another route."""
+    Equal-shape 2-D uint8 strips with ``coarse_downsample`` in (1, 0.5) and ``fine_downsample = 1`` (the defaults of
+    default_stitching_configs.yaml:18-19) run through the batch pipeline (``stitch_pipeline.StripBatchMatcher`` with a batch
+    of one; callers with many pairs use ``stitching_matcher_batch``): automatic or explicit spacings in pixels, optional masks
+    (mask0 / mask1, True = valid pixel) and photometric statistics, mesh relaxations between spacings of any shape (rigid or
+    deformed mesh1), ``residue_mode`` 'huber' or 'threshold'.  Strips of unequal shape, spacings relative to the overlap
+    (< 1) and any other shrinking factors 0 < ``coarse_downsample``, ``fine_downsample`` <= 1 take the general-mesh route
+    (``_stitching_matcher_general``: area resize, DoG, global translation, renderer + NCC + SLM on the device, pair by pair).
+    Enlarging factors raise NotImplementedError."""
     from .stitch_pipeline import StripBatchMatcher
     opts, mask0, mask1, compute_photometric = _stitching_options(kwargs)
     img0, img1 = _check_strips(img0, img1, opts['coarse_downsample'])
     relative = opts.pop('_relative_spacings')
-    if img0.shape != img1.shape or relative:
+    scales = opts.pop('_general_scales')
+    if img0.shape != img1.shape or relative or scales:
         return _stitching_matcher_general(img0, img1, opts, mask0, mask1, compute_photometric)
+    opts.pop('_fine_downsample')
     H, W = img0.shape
     spacings = opts['spacings']
     key = (H, W) + tuple(None if v is None else (tuple(v.tolist()) if isinstance(v, np.ndarray) else v) for v in opts.values()) + (id(_lib.ctx()),)
@@ -1045,7 +1056,10 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         if kwargs.get(name, None) is not None:
             raise ValueError('stitching_matcher_batch: masks are given per pair, as (img0, img1, mask0, mask1)')
     opts, _, _, compute_photometric = _stitching_options(kwargs)
-    relative = opts.pop('_relative_spacings')
+    relative = opts.pop('_relative_spacings') or opts.pop('_general_scales')
+    opts.pop('_general_scales', None)
+    gen_opts = dict(opts)
+    opts.pop('_fine_downsample')
     items = []
     general = {}
     for k, pr in enumerate(pairs):
@@ -1057,7 +1071,7 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         if img0.shape != img1.shape or relative:
             # two crops of different size (an overlap clipped by a tile border on one side only), or spacings relative to the
             # overlap: the general-mesh route, pair by pair
-            general[k] = _stitching_matcher_general(np.ascontiguousarray(img0), np.ascontiguousarray(img1), opts, mk0, mk1, compute_photometric)
+            general[k] = _stitching_matcher_general(np.ascontiguousarray(img0), np.ascontiguousarray(img1), gen_opts, mk0, mk1, compute_photometric)
             img0 = img1 = None
         items.append((img0, img1, mk0, mk1))
     if not items:

@@ -143,6 +143,13 @@ int fb_dog_dev(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, dou
 /* cv2.resize(fx=fy=0.5, INTER_AREA) of even-sized uint8 images (matcher.py:255-256) */
 int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out);
 int fb_area_downsample2_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, uint8_t* out);
+/* cv2.resize(img, None, fx, fy, INTER_AREA) of uint8 images for any shrinking factor 0 < f <= 1 (the coarse_downsample /
+ * fine_downsample options of stitching_matcher, matcher.py:254-266, 318-335): output fb_area_resize_size(H, fy) x
+ * fb_area_resize_size(W, fx) = cvRound(n f); integer 1 / f: the integer cell sums of resizeAreaFast, otherwise the
+ * fractional-coverage taps of computeResizeAreaTab accumulated in float.  fb_area_resize: host arrays. */
+int fb_area_resize_size(int n, double f);
+int fb_area_resize_dev(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, double fx, double fy, uint8_t* out);
+int fb_area_resize(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, double fx, double fy, uint8_t* out);
 /* Images of unequal size in one padded stack (the strips of a real section differ in shape from pair to pair,
  * stitcher.py:561-571): image n is the sizes[n] = {h, w} corner (device int32 [N][2]) of its H x W slot and is
  * downsampled / filtered as an h x w image; the downsampled stack has half_size(H) x half_size(W) slots. */

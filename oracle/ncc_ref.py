@@ -183,6 +183,95 @@ def area_downsample2(img):
     return np.where(c == 4, full, part).astype(np.uint8)
 
 
+def area_resize(img, fx, fy=None):
+    """cv2.resize(img, None, fx=fx, fy=fy, interpolation=cv2.INTER_AREA) of a uint8 image for shrinking factors
+    (matcher.py:255-256, 320-321), restated from OpenCV's imgproc/resize.cpp; UNPINNED (cv2 is absent here).
+    Output size cvRound(n f) per axis.  Integer 1 / f on both axes (resizeAreaFast): integer cell sums times float32
+    1 / k^2, rounded half to even (k = 2: (sum + 2) >> 2, the vector kernel); a cell cut by the image edge is
+    float32(sum) / count.  Otherwise (computeResizeAreaTab + ResizeArea): per axis every source pixel weighs by the
+    fraction of it inside the cell over the cell width (float32), a row is accumulated tap after tap in float32, then the
+    rows."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 2
+    fy = fx if fy is None else fy
+    H, W = img.shape
+    Ho, Wo = int(np.rint(H * fy)), int(np.rint(W * fx))
+    sx, sy = 1.0 / fx, 1.0 / fy
+    kx, ky = int(np.rint(sx)), int(np.rint(sy))
+    eps = np.finfo(np.float64).eps
+    out = np.zeros((Ho, Wo), dtype=np.uint8)
+    sat = lambda v: np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    if abs(sx - kx) < eps and abs(sy - ky) < eps:
+        scale = np.float32(1.0) / np.float32(kx * ky)
+        wfull = W // kx
+        for dy in range(Ho):
+            y0 = dy * ky
+            if y0 >= H:
+                continue
+            rows = img[y0:min(y0 + ky, H)].astype(np.int64)
+            for dx in range(Wo):
+                x0 = dx * kx
+                if x0 >= W:
+                    continue
+                cell = rows[:, x0:min(x0 + kx, W)]
+                s_ = int(cell.sum())
+                if y0 + ky <= H and dx < wfull:
+                    out[dy, dx] = (s_ + 2) >> 2 if (kx == 2 and ky == 2) else sat(np.float32(s_) * scale)
+                else:
+                    out[dy, dx] = sat(np.float32(s_) / np.float32(cell.size))
+        return out
+
+    def taps(ssize, dsize, scale):
+        tab = []
+        for d in range(dsize):
+            f1 = d * scale; f2 = f1 + scale
+            cell = min(scale, ssize - f1)
+            s1, s2 = int(np.ceil(f1)), int(np.floor(f2))
+            s2 = min(s2, ssize - 1); s1 = min(s1, s2)
+            row = []
+            if s1 - f1 > 1e-3:
+                row.append((s1 - 1, np.float32((s1 - f1) / cell)))
+            for s_ in range(s1, s2):
+                row.append((s_, np.float32(1.0 / cell)))
+            if f2 - s2 > 1e-3:
+                row.append((s2, np.float32(min(min(f2 - s2, 1.0), cell) / cell)))
+            tab.append(row)
+        return tab
+    xt, yt = taps(W, Wo, sx), taps(H, Ho, sy)
+    src = img.astype(np.float32)
+    # rows first: buf[sy, dx] = sum_k S[sy, si_k] * alpha_k accumulated in float32 in tap order
+    buf = np.zeros((H, Wo), dtype=np.float32)
+    for dx, row in enumerate(xt):
+        acc = np.zeros(H, dtype=np.float32)
+        for si, a in row:
+            acc = acc + src[:, si] * a
+        buf[:, dx] = acc
+    for dy, col in enumerate(yt):
+        acc = None
+        for si, b in col:
+            term = b * buf[si]
+            acc = term if acc is None else acc + term
+        out[dy] = sat(acc if acc is not None else np.zeros(Wo, np.float32))
+    return out
+
+
+def nearest_resize_mask(mask, fx, fy=None):
+    """cv2.resize(mask.astype(uint8), None, fx, fy, INTER_NEAREST).astype(bool) (matcher.py:257-264): source index
+    min(floor(d / f), n - 1); UNPINNED."""
+    mask = np.asarray(mask, dtype=bool)
+    fy = fx if fy is None else fy
+    H, W = mask.shape
+    Ho, Wo = int(np.rint(H * fy)), int(np.rint(W * fx))
+    iy = np.minimum(np.floor(np.arange(Ho) * (1.0 / fy)).astype(np.int64), H - 1)
+    ix = np.minimum(np.floor(np.arange(Wo) * (1.0 / fx)).astype(np.int64), W - 1)
+    return mask[np.ix_(iy, ix)]
+
+
+def scale_coordinates(xy, s):
+    """spatial.scale_coordinates (spatial.py): pixel centres keep their meaning, (xy + 0.5) s - 0.5"""
+    return (np.asarray(xy, dtype=np.float64) + 0.5) * s - 0.5
+
+
 # ------------------------------------------------------------------ bbox helpers
 def divide_bbox(bbox, block_size=None, min_num_blocks=1, round_output=True, shrink_factor=1):
     """common.py:380-409."""

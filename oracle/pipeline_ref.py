@@ -369,36 +369,44 @@ def photometric(raw0, raw1, g0, g1, tx0, ty0, mask0_g=None, mask1_g=None):
 
 
 def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
-               conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0, mask0=None, mask1=None, compute_photometric=False, spacings=None, residue_mode='huber'):
+               conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0, mask0=None, mask1=None, compute_photometric=False, spacings=None, residue_mode='huber',
+               fine_downsample=1):
     """strip0/strip1: uint8 H x W overlap strips (mask0/mask1: bool, True = valid pixel).
-    Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host, strain, phtm, ...)."""
-    H, W = strip0.shape
-    if coarse_downsample == 0.5:
-        g0 = ncc_ref.area_downsample2(strip0)
-        g1 = ncc_ref.area_downsample2(strip1)
-        # cv2.resize(mask, fx=0.5, INTER_NEAREST) (matcher.py:257-264): source pixel floor(dst / 0.5) (UNPINNED)
-        mask0_g = None if mask0 is None else np.asarray(mask0, dtype=bool)[::2, ::2][:g0.shape[0], :g0.shape[1]]
-        mask1_g = None if mask1 is None else np.asarray(mask1, dtype=bool)[::2, ::2][:g1.shape[0], :g1.shape[1]]
-    else:
-        g0, g1 = strip0, strip1
-        mask0_g, mask1_g = mask0, mask1
+    Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host, strain, phtm, ...).  tx / ty: the global translation in pixels
+    of the FINE images (the strips themselves unless fine_downsample != 1); xy0 / xy1 in pixels of the strips."""
+    cd, fd = coarse_downsample, fine_downsample
+
+    def shrink(img, mk, f):
+        if f == 1:
+            return img, mk
+        small = ncc_ref.area_downsample2(img) if f == 0.5 else ncc_ref.area_resize(img, f)
+        # cv2.resize(mask, fx=f, INTER_NEAREST) (matcher.py:257-264): source pixel floor(dst / f) (UNPINNED)
+        return small, (None if mk is None else ncc_ref.nearest_resize_mask(mk, f)[:small.shape[0], :small.shape[1]])
+    g0, mask0_g = shrink(strip0, mask0, cd)
+    g1, mask1_g = shrink(strip1, mask1, cd)
     raw0, raw1 = g0, g1
-    g0 = ncc_ref.masked_dog_filter(g0, sigma * coarse_downsample, mask=mask0_g)          # matcher.py:273-274
-    g1 = ncc_ref.masked_dog_filter(g1, sigma * coarse_downsample, mask=mask1_g)
+    g0 = ncc_ref.masked_dog_filter(g0, sigma * cd, mask=mask0_g)          # matcher.py:273-274
+    g1 = ncc_ref.masked_dog_filter(g1, sigma * cd, mask=mask1_g)
     tx, ty, conf0 = ncc_ref.global_translation_matcher(g0, g1, conf_mode=conf_mode, conf_thresh=conf_thresh)
-    res = dict(tx=tx / coarse_downsample, ty=ty / coarse_downsample, conf0=conf0, xy0=None, xy1=None, weight=None,
+    res = dict(tx=tx * fd / cd, ty=ty * fd / cd, conf0=conf0, xy0=None, xy1=None, weight=None,                  # matcher.py:338-339
                needs_host=False, strain=0.05, phtm=None)
     if conf0 < conf_thresh:                                                  # matcher.py:277-278
         return res
     if compute_photometric:
         res['phtm'] = photometric(raw0, raw1, g0, g1, tx, ty, mask0_g, mask1_g)
-    if coarse_downsample == 1:
+    if fd == cd:                                                             # matcher.py:315-317
         f0, f1 = g0, g1
     else:
-        f0 = ncc_ref.masked_dog_filter(strip0, sigma, mask=mask0)            # matcher.py:336-337
-        f1 = ncc_ref.masked_dog_filter(strip1, sigma, mask=mask1)
+        b0, mask0_f = shrink(strip0, mask0, fd)                              # matcher.py:319-335
+        b1, mask1_f = shrink(strip1, mask1, fd)
+        f0 = ncc_ref.masked_dog_filter(b0, sigma * fd, mask=mask0_f)         # matcher.py:336-337
+        f1 = ncc_ref.masked_dog_filter(b1, sigma * fd, mask=mask1_f)
+    # spacings follow the shapes of the strips as given, then scale with the fine images; so does residue_len (matcher.py:243-251, 341, 352)
+    spacings = (ncc_ref.auto_spacings(strip0.shape, strip1.shape) if spacings is None else np.asarray(spacings, dtype=np.float64)) * fd
+    residue_len = residue_len * fd
+    H, W = f0.shape
     tx, ty = res['tx'], res['ty']
-    spacings = np.sort(ncc_ref.auto_spacings((H, W), (H, W)) if spacings is None else np.asarray(spacings, dtype=np.float64))[::-1]
+    spacings = np.sort(spacings)[::-1]
     bbox0 = (-0.5 + tx, -0.5 + ty, W - 0.5 + tx, H - 0.5 + ty)              # Mesh.from_bbox + apply_translation
     pad = True
     itx, ity = int(round(tx)), int(round(ty))
@@ -500,4 +508,7 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
         # matcher.py:752-777 (compute_strain defaults to True)
         res['strain'] = strain_estimate(W, H, float(np.min(spacings)), (tx, ty), res['xy0'], res['xy1'], res['weight'],
                                         min_num_blocks=min_num_blocks)
+        if fd != 1:                                                          # matcher.py:365-367
+            res['xy0'] = ncc_ref.scale_coordinates(res['xy0'], 1 / fd)
+            res['xy1'] = ncc_ref.scale_coordinates(res['xy1'], 1 / fd)
     return res

@@ -239,6 +239,50 @@ def test_iterative_matcher_general_path_vs_strip_oracle(fb, H, W, seed, shift, a
         assert exp['deformed'] and len(exp['tiers']) == 2            # the deformed-mesh branch of the oracle, twice
 
 
+def test_area_resize_vs_oracle(fb):
+    """fb_area_resize (cv2.resize INTER_AREA restated: integer cells and fractional-coverage taps) against the oracle's numpy
+    statement, bit for bit; x0.5 equals the older fb_area_downsample2"""
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (3, 203, 157), dtype=np.uint8)
+    img[1] = np.clip(np.round(128 + 60 * np.sin(np.arange(157)[None, :] / 7.0) * np.cos(np.arange(203)[:, None] / 11.0)), 0, 255).astype(np.uint8)
+    for fx, fy in ((0.5, 0.5), (0.25, 0.25), (1 / 3, 1 / 3), (0.25, 0.5), (0.3, 0.3), (0.7, 0.45), (0.9, 1.0), (0.125, 0.125)):
+        got = fb.common.area_resize(img, fx, fy)
+        for n in range(3):
+            exp = ncc_ref.area_resize(img[n], fx, fy)
+            assert got[n].shape == exp.shape, (fx, fy)
+            np.testing.assert_array_equal(got[n], exp, err_msg=str((fx, fy)))
+    np.testing.assert_array_equal(fb.common.area_resize(img, 0.5), fb.common.area_downsample2(img))
+    mk = rng.random((203, 157)) > 0.3
+    for f in (0.5, 0.25, 0.3):
+        np.testing.assert_array_equal(fb.common.nearest_resize_mask(mk, f), ncc_ref.nearest_resize_mask(mk, f))
+    with pytest.raises(NotImplementedError):
+        fb.common.area_resize(img, 1.5)
+
+
+@pytest.mark.parametrize('cd,fd', [(0.25, 0.5), (0.5, 0.5), (0.25, 1), (0.4, 0.8)])
+def test_stitching_matcher_downsample_factors_vs_oracle(fb, cd, fd):
+    """stitching_matcher(coarse_downsample, fine_downsample) away from the defaults (matcher.py:254-266, 318-341, 352, 365-367):
+    coarse level through the area resize, fine images shrunk, spacings / residue_len / global translation scaled, matches
+    scaled back -- against pipeline_ref.match_pair with the same factors"""
+    from test_gpu_pipeline import _warped_pair
+    from feabas_amd import matcher
+    img0, img1 = _warped_pair(1400, 360, 31, shift=(9, -6), warp=0.6)
+    exp = pipeline_ref.match_pair(img0, img1, residue_len=2.0, coarse_downsample=cd, fine_downsample=fd)
+    assert exp['xy0'] is not None and exp['xy0'].shape[0] > 20
+    xy0, xy1, weight, strain, _ = matcher.stitching_matcher(img0, img1, sigma=2.5, coarse_downsample=cd, fine_downsample=fd, conf_thresh=0.33, residue_len=2.0)
+    assert xy0 is not None and xy0.shape == exp['xy0'].shape
+    np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-3 / fd)
+    np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-3 / fd)
+    np.testing.assert_allclose(weight, exp['weight'], atol=2e-3)
+    assert abs(strain - exp['strain']) < 2e-3 * max(1.0, exp['strain'] / 0.01)
+    # the matches sit where the strips were shifted (strip pixels, not pixels of the shrunk images)
+    d = np.median(xy1 - xy0, axis=0)
+    assert abs(d[0] + 9) < 1.0 and abs(d[1] - 6) < 1.0
+    # the batch entry takes the same route for such options
+    got = matcher.stitching_matcher_batch([(img0, img1)], sigma=2.5, coarse_downsample=cd, fine_downsample=fd, conf_thresh=0.33, residue_len=2.0)
+    np.testing.assert_array_equal(got[0][0], xy0)
+
+
 def test_section_matcher_recovers_a_known_field(fb):
     """alignment-scale property test (no oracle at this size): section 1 is section 0 resampled through a known smooth
     field of +-6 px; section_matcher over two irregular meshes (spacings 280 / 70 px, sigma 2.5, residue filter) must

@@ -453,3 +453,22 @@ def test_g18_locked_neighbours():
     exp = g['v_after'] + g['off_after'] - g['v']
     got = ms[1].vertices_w_offset(fem_ref.GEAR_MOVING) - g['v']
     assert np.abs(got - exp).max() <= 1e-6 * np.abs(exp).max()
+
+
+def test_area_resize_restatement_properties():
+    """ncc_ref.area_resize (cv2.resize INTER_AREA restated; unpinned: cv2 is absent): x0.5 is area_downsample2, a constant
+    image stays constant at any factor, hand-computed cells for k = 3 and a fractional factor"""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 50), dtype=np.uint8)
+    np.testing.assert_array_equal(ncc_ref.area_resize(img, 0.5), ncc_ref.area_downsample2(img))
+    for f in (0.25, 1 / 3, 0.3, 0.77):
+        c = ncc_ref.area_resize(np.full((41, 29), 137, np.uint8), f)
+        assert c.shape == (int(np.rint(41 * f)), int(np.rint(29 * f))) and (c == 137).all()
+    a = np.arange(36, dtype=np.uint8).reshape(6, 6) * 7
+    np.testing.assert_array_equal(ncc_ref.area_resize(a, 1 / 3), np.array([[49, 70], [175, 196]], dtype=np.uint8))      # means of the 3 x 3 cells
+    # 5 -> 2 pixels along a row (scale 2.5): cells [0, 2.5) and [2.5, 5): (p0 + p1 + p2 / 2) / 2.5 and (p2 / 2 + p3 + p4) / 2.5
+    r = np.array([[10, 20, 40, 80, 160]], dtype=np.uint8)
+    np.testing.assert_array_equal(ncc_ref.area_resize(np.repeat(r, 5, 0), 0.4)[0], np.array([20, 104], dtype=np.uint8))
+    mk = np.zeros((5, 7), bool); mk[2, 4] = True
+    assert ncc_ref.nearest_resize_mask(mk, 0.5).shape == (2, 4) and ncc_ref.nearest_resize_mask(mk, 0.5)[1, 2]
+    np.testing.assert_allclose(ncc_ref.scale_coordinates(np.array([[0.0, 3.0]]), 2.0), [[0.5, 6.5]])
