@@ -655,9 +655,12 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
     if residue_len < 0:                                 # in units of the section thickness (matcher.py:518-520)
         residue_len = max(1, abs(residue_len) * get('section_thickness', const.DEFAULT_THICKNESS) / mesh0.resolution)
     trace = get('trace', None)                          # a list: one record per round (debugging / tests)
-    # the reference's 0.01 / max_dis is an iteration budget: at that tolerance the field in weakly constrained corners depends
-    # on the Krylov path taken.  Like the strip pipeline (and the oracle) the solves here are converged (relax_tol).
+    # the reference's 0.01 / max(1, max_dis) (matcher.py:685-688) is an iteration budget: at that tolerance the field in weakly
+    # constrained corners depends on the Krylov path taken.  Like the strip pipeline (and the oracle) the solves here are
+    # converged by default (relax_tol = 1e-9); relax_tol = None takes the reference's tolerance as it stands -- section_matcher's
+    # default, where the two relaxations of a section pair are a third of the time at 1e-9 (2 x ~1 400 PCG iterations)
     relax_tol, opt_tol = get('relax_tol', 1e-9), get('opt_tol', None)
+    relax_tol = np.inf if relax_tol is None else relax_tol
     affine_render = get('affine_approximated_render', True)
     failed = (None, None, 0, DEFAULT_AVG_DEFORM)
     spacings = np.array(spacings, dtype=np.float64).ravel()
@@ -778,6 +781,7 @@ def section_matcher(mesh0, mesh1, image_loader0, image_loader1, **kwargs):
     kwargs.setdefault('batch_size', 100)
     kwargs.setdefault('distributor', 'cartesian_region')
     kwargs.setdefault('link_weight_decay', 0.0)
+    kwargs.setdefault('relax_tol', None)                 # the reference's stopping tolerance of the relaxations (matcher.py:685-688)
     compute_strain = kwargs.pop('compute_strain', False)
     stiffness_multiplier_threshold = kwargs.get('stiffness_multiplier_threshold', 0.1)
     kwargs.setdefault('render_weight_threshold', 0.1)
