@@ -266,6 +266,42 @@ __global__ void fill_ext_kernel(int NB, int* ext) {
 
 }  // namespace
 
+
+// fb_mesh_block_uncovered on the device: one thread per block clips its candidate triangles to the block's box
+// (Sutherland-Hodgman against the four sides) and sums the areas, in the order of the candidate list like the host loop
+__global__ __launch_bounds__(128) void block_uncovered_kernel(const double* __restrict__ v_mov, const int* __restrict__ tris, int NB,
+                                                               const double* __restrict__ org, int h, int w, int cap, const int* __restrict__ cand,
+                                                               const int* __restrict__ count, double* __restrict__ uncovered) {
+    const int b = blockIdx.x * 128 + threadIdx.x;
+    if (b >= NB) return;
+    const double bx0 = org[2 * b] - 0.5, by0 = org[2 * b + 1] - 0.5, bx1 = bx0 + (double)w, by1 = by0 + (double)h;
+    double covered = 0.0;
+    const int nc = min(count[b], cap);
+    for (int k = 0; k < nc; ++k) {
+        const int* t3 = tris + 3 * (size_t)cand[(size_t)b * cap + k];
+        double px[8], py[8], qx[8], qy[8];                    // a triangle cut by four half planes has at most 7 corners
+        int n = 3;
+        for (int a = 0; a < 3; ++a) { px[a] = v_mov[2 * (size_t)t3[a]]; py[a] = v_mov[2 * (size_t)t3[a] + 1]; }
+        for (int side = 0; side < 4 && n > 0; ++side) {
+            int m = 0;
+            for (int i = 0; i < n; ++i) {
+                const int j = (i + 1 == n) ? 0 : i + 1;
+                const double ax = px[i], ay = py[i], cx = px[j], cy = py[j];
+                const double da = side == 0 ? ax - bx0 : side == 1 ? bx1 - ax : side == 2 ? ay - by0 : by1 - ay;
+                const double dc = side == 0 ? cx - bx0 : side == 1 ? bx1 - cx : side == 2 ? cy - by0 : by1 - cy;
+                if (da >= 0 && m < 8) { qx[m] = ax; qy[m] = ay; ++m; }
+                if ((da >= 0) != (dc >= 0) && m < 8) { const double s_ = da / (da - dc); qx[m] = ax + s_ * (cx - ax); qy[m] = ay + s_ * (cy - ay); ++m; }
+            }
+            n = m;
+            for (int i = 0; i < n; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+        }
+        double a2 = 0.0;
+        for (int i = 0; i < n; ++i) { const int j = (i + 1 == n) ? 0 : i + 1; a2 += px[i] * py[j] - px[j] * py[i]; }
+        covered += 0.5 * fabs(a2);
+    }
+    uncovered[b] = (double)w * (double)h - covered;
+}
+
 extern "C" {
 
 int fb_mesh_candidates_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris, int NB, const double* org, int h, int w, int cap,
@@ -287,6 +323,18 @@ int fb_mesh_candidates_dev(fb_ctx* ctx, int T, const double* v_mov, const int* t
     hipStreamSynchronize(ctx->stream);
     hipFree(box);
     FB_HIP(ctx, e);
+    return FB_OK;
+}
+
+int fb_mesh_block_uncovered_dev(fb_ctx* ctx, const double* v_mov, const int* tris, int NB, const double* org, int h, int w, int cap, const int* cand,
+                                const int* count, double* uncovered) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, NB >= 0 && h > 0 && w > 0 && cap > 0);
+    if (NB == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, v_mov && tris && org && cand && count && uncovered);
+    FB_PROF(ctx, "mesh_block_uncovered");
+    hipLaunchKernelGGL(block_uncovered_kernel, dim3(fb_cdiv(NB, 128)), dim3(128), 0, ctx->stream, v_mov, tris, NB, org, h, w, cap, cand, count, uncovered);
+    FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
 

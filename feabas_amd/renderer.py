@@ -114,19 +114,24 @@ class MeshRenderer:
             d_cand.free(); d_cnt.free()
             cap = int(2 ** np.ceil(np.log2(cnt.max())))
 
-    def _precise(self, tier, org, h, w, cand, cnt, cap):
+    def _precise(self, tier, d_org, nb, h, w, d_cand, d_cnt, cap):
         """precise_mask of crop_field_affine (renderer.py:437-447): an affine block of which 1 px^2 or more lies outside the
-        mesh is masked pixel by pixel (tier + 10); the area is taken in MOVING coordinates from the candidate triangles"""
+        mesh is masked pixel by pixel (tier + 10); the area is taken in MOVING coordinates from the candidate triangles
+        (fb_mesh_block_uncovered_dev: the candidate lists never leave the device)"""
         sel = np.flatnonzero((tier == 1) | (tier == 2))
         if sel.size:
-            unc = np.empty(org.shape[0])
-            _lib.check(_lib.load().fb_mesh_block_uncovered(_lib.ctx(), self.v0.shape[0], _lib.ptr(self.v0), _lib.ptr(self.tris), org.shape[0],
-                                                           _lib.ptr(np.ascontiguousarray(org)), h, w, cap, _lib.ptr(cand), _lib.ptr(cnt), _lib.ptr(unc)))
+            d_unc = _lib.DeviceBuffer(8 * nb)
+            try:
+                _lib.check(_lib.load().fb_mesh_block_uncovered_dev(_lib.ctx(), self.d_v0.ptr, self.d_tris.ptr, nb, d_org.ptr, h, w, cap, d_cand.ptr, d_cnt.ptr,
+                                                                   d_unc.ptr))
+                unc = d_unc.to_array((nb,), np.float64)
+            finally:
+                d_unc.free()
             out = sel[unc[sel] >= 1.0]
             tier[out] += 10
         return tier
 
-    def _tiers(self, org, h, w, d_cand, cnt, cap, precise=False):
+    def _tiers(self, org, d_org, h, w, d_cand, d_cnt, cnt, cap, precise=False):
         """crop_field's choice per block (renderer.py:453-511): 1 global affine, 2 block affine, 3 exact field; + 10 when the
         precise mask applies (log_sigma > 0 and the block sticks out of the mesh)"""
         nb = org.shape[0]
@@ -136,12 +141,12 @@ class MeshRenderer:
         if not self.tol > 0:
             return tier, A6
         A_g, res_g = self._global
-        cand = d_cand.to_array((nb, cap), np.int32)
-        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
         if res_g < self.tol:
             tier[:] = 1
             A6[:] = pack(A_g)
-            return (self._precise(tier, org, h, w, cand, cnt, cap) if precise else tier), A6
+            return (self._precise(tier, d_org, nb, h, w, d_cand, d_cnt, cap) if precise else tier), A6
+        cand = d_cand.to_array((nb, cap), np.int32)
+        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
         _lib.check(_lib.load().fb_mesh_block_affines(_lib.ctx(), self.v0.shape[0], _lib.ptr(self.v0), _lib.ptr(self.v1), _lib.ptr(self.tris), nb,
                                                      _lib.ptr(np.ascontiguousarray(org)), h, w, cap, _lib.ptr(cand), _lib.ptr(cnt), self.tol,
                                                      _lib.ptr(tier), _lib.ptr(A6)))
@@ -155,7 +160,7 @@ class MeshRenderer:
             if affine_residue(self.v1[idx], self.v0[idx], A_b) < self.tol:
                 tier[b] = 2
                 A6[b] = pack(A_b)
-        return (self._precise(tier, org, h, w, cand, cnt, cap) if precise else tier), A6
+        return (self._precise(tier, d_org, nb, h, w, d_cand, d_cnt, cap) if precise else tier), A6
 
     def render_stack_dev(self, bboxes, precise_mask=False):
         """crop_multiple(bboxes, mode=RENDER_FULL, remap_interp=INTER_LINEAR) before its DoG, for blocks of ONE size:
@@ -171,7 +176,7 @@ class MeshRenderer:
         org = np.ascontiguousarray(bbox0[:, :2])
         d_org = _lib.DeviceBuffer.from_array(org)
         d_cand, d_cnt, cnt, cap = self._candidates(d_org, nb, h, w)
-        tier, A6 = self._tiers(org, h, w, d_cand, cnt, cap, precise=precise_mask)
+        tier, A6 = self._tiers(org, d_org, h, w, d_cand, d_cnt, cnt, cap, precise=precise_mask)
         d_tier, d_A6 = _lib.DeviceBuffer.from_array(tier), _lib.DeviceBuffer.from_array(A6)
         d_ext, d_origin = _lib.DeviceBuffer(16 * nb), _lib.DeviceBuffer(8 * nb)
         d_out, d_mask = _lib.DeviceBuffer(4 * nb * h * w), _lib.DeviceBuffer(nb * h * w)

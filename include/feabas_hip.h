@@ -202,6 +202,10 @@ int fb_mesh_block_affines(fb_ctx* ctx, int V, const double* v_mov, const double*
  *   mesh (fb_mesh_render_blocks_dev). */
 int fb_mesh_block_uncovered(fb_ctx* ctx, int V, const double* v_mov, const int32_t* tris, int NB, const double* org, int h, int w, int cap,
                             const int32_t* cand, const int32_t* count, double* uncovered);
+/* fb_mesh_block_uncovered_dev: the same quantity from the device-resident vertex / triangle / candidate arrays of
+ *   fb_mesh_candidates_dev (uncovered: device float64 [NB]). */
+int fb_mesh_block_uncovered_dev(fb_ctx* ctx, const double* v_mov, const int* tris, int NB, const double* org, int h, int w, int cap, const int* cand,
+                                const int* count, double* uncovered);
 /* fb_signed_area (host arrays, no device work): common.signed_area (common.py:672-676) -- twice the signed area
  *   cross(p1 - p0, p2 - p1) of the T triangles tris [T][3] over v [V][2] (negative indices count from the end, as numpy
  *   takes them), rounded operation by operation like the numpy statement. */

@@ -239,6 +239,36 @@ def test_iterative_matcher_general_path_vs_strip_oracle(fb, H, W, seed, shift, a
         assert exp['deformed'] and len(exp['tiers']) == 2            # the deformed-mesh branch of the oracle, twice
 
 
+def test_block_uncovered_device_equals_host(fb):
+    """fb_mesh_block_uncovered_dev (one thread per block, candidate lists resident) against the host loop
+    fb_mesh_block_uncovered on the lists fb_mesh_candidates_dev made: the same areas to rounding, the same precise-mask
+    decision (uncovered >= 1 px^2)"""
+    from scipy.spatial import Delaunay
+    from feabas_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx()
+    rng = np.random.default_rng(14)
+    v = np.ascontiguousarray(rng.uniform(0, 900, (700, 2)))
+    tri = np.ascontiguousarray(Delaunay(v).simplices, dtype=np.int32)
+    NB, h, w, cap = 1500, 40, 56, 64
+    org = np.ascontiguousarray(rng.uniform(-60, 900, (NB, 2)))
+    d_v, d_t, d_o = _lib.DeviceBuffer.from_array(v), _lib.DeviceBuffer.from_array(tri), _lib.DeviceBuffer.from_array(org)
+    d_c, d_n, d_u = _lib.DeviceBuffer(4 * NB * cap), _lib.DeviceBuffer(4 * NB), _lib.DeviceBuffer(8 * NB)
+    try:
+        _lib.check(lib.fb_mesh_candidates_dev(ctx, tri.shape[0], d_v.ptr, d_t.ptr, NB, d_o.ptr, h, w, cap, d_c.ptr, d_n.ptr))
+        cnt = d_n.to_array((NB,), np.int32); cand = d_c.to_array((NB, cap), np.int32)
+        assert cnt.max() <= cap and cnt.min() == 0 and cnt.max() > 8
+        _lib.check(lib.fb_mesh_block_uncovered_dev(ctx, d_v.ptr, d_t.ptr, NB, d_o.ptr, h, w, cap, d_c.ptr, d_n.ptr, d_u.ptr))
+        got = d_u.to_array((NB,), np.float64)
+    finally:
+        for b in (d_v, d_t, d_o, d_c, d_n, d_u):
+            b.free()
+    exp = np.empty(NB)
+    _lib.check(lib.fb_mesh_block_uncovered(ctx, v.shape[0], _lib.ptr(v), _lib.ptr(tri), NB, _lib.ptr(org), h, w, cap, _lib.ptr(cand), _lib.ptr(cnt), _lib.ptr(exp)))
+    np.testing.assert_allclose(got, exp, atol=1e-8)
+    assert (exp > 1).any() and (exp < 1e-6).any()               # blocks sticking out of the hull and blocks inside it
+    np.testing.assert_array_equal(got >= 1.0, exp >= 1.0)
+
+
 def test_area_resize_vs_oracle(fb):
     """fb_area_resize (cv2.resize INTER_AREA restated: integer cells and fractional-coverage taps) against the oracle's numpy
     statement, bit for bit; x0.5 equals the older fb_area_downsample2"""

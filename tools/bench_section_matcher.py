@@ -53,9 +53,10 @@ def main():
             import pstats
             prof.disable()
             pstats.Stats(prof).sort_stats('tottime').print_stats(22)
+            pstats.Stats(prof).sort_stats('cumulative').print_stats(45)
         ex, ey = field(xy1[:, 0], xy1[:, 1])
         err = np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)
-        print(f'rep {rep}: {dt:.2f} s, rounds {[(r["blocks"], r["kept"], round(r["max_dis"], 2), r["solve"].get("iters")) for r in trace]}, '
+        print(f'rep {rep}: {dt:.3f} s, rounds {[(r["blocks"], r["kept"], round(r["max_dis"], 2), r["solve"].get("iters")) for r in trace]}, '
               f'{xy0.shape[0]} matches, median error {np.median(err):.3f} px, 95 % {np.quantile(err, 0.95):.3f} px')
 
 
