@@ -15,7 +15,7 @@ namespace {
 constexpr int kT = 256;          // threads per workgroup == block rows per row-chunk
 constexpr int kCap = 3072;       // LDS capacity in blocks (16 B each = 48 KiB)
 constexpr int kMaxWG1 = 1024;    // SpMV workgroups (each loops over row chunks)
-constexpr int kWG2 = 512;        // vector-update workgroups
+constexpr int kWG2 = 256;        // vector-update workgroups (one per CU: 256 / 512 / 1024 give 51.1 / 52.8 / 56.6 us per iteration at 1e6 DoF -- every workgroup of both kernels sums their partials)
 constexpr int kNP = 1024;        // partial-sum slots per array
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -518,7 +518,8 @@ int fb_bsr_setup_jacobi(fb_ctx* ctx, fb_bsr* M, int precond) {
 int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter, int fixed_iters, int* iters_out, double* relres_out) {
     const int nb = M->d.nb;
     const int g1 = grid1(M->d);
-    const int g2 = std::min(kWG2, std::max(1, (nb + kT - 1) / kT));
+    static const int wg2_env = [] { const char* e = getenv("FEABAS_HIP_PCG_WG2"); return e ? std::max(1, std::min(kNP, atoi(e))) : 0; }();
+    const int g2 = std::min(wg2_env ? wg2_env : kWG2, std::max(1, (nb + kT - 1) / kT));
     double* P = M->parts;
     double* part_pAp = P;                 // [kNP]
     double* part_rz[2] = {P + kNP, P + 2 * kNP};
