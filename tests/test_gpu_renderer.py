@@ -311,6 +311,18 @@ def test_stitching_matcher_downsample_factors_vs_oracle(fb, cd, fd):
     # the batch entry takes the same route for such options
     got = matcher.stitching_matcher_batch([(img0, img1)], sigma=2.5, coarse_downsample=cd, fine_downsample=fd, conf_thresh=0.33, residue_len=2.0)
     np.testing.assert_array_equal(got[0][0], xy0)
+    if (cd, fd) == (0.25, 0.5):
+        # masks shrink by the INTER_NEAREST rule with their images (matcher.py:257-264, 322-329); photometric statistics of the coarse level
+        mk0 = np.ones(img0.shape, dtype=bool); mk0[300:420, 40:200] = False
+        mk1 = np.ones(img1.shape, dtype=bool); mk1[900:1000, 150:330] = False
+        exp = pipeline_ref.match_pair(img0, img1, residue_len=2.0, coarse_downsample=cd, fine_downsample=fd, mask0=mk0, mask1=mk1, compute_photometric=True)
+        xy0, xy1, weight, strain, phtm = matcher.stitching_matcher(img0, img1, sigma=2.5, coarse_downsample=cd, fine_downsample=fd, conf_thresh=0.33, residue_len=2.0,
+                                                                    mask0=mk0, mask1=mk1, compute_photometric=True)
+        assert xy0.shape == exp['xy0'].shape
+        np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-3 / fd)
+        np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-3 / fd)
+        np.testing.assert_allclose(weight, exp['weight'], atol=2e-3)
+        np.testing.assert_allclose(phtm, exp['phtm'], rtol=1e-4)
 
 
 def test_section_matcher_recovers_a_known_field(fb):
