@@ -1229,10 +1229,47 @@ int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, 
     FB_HIP(ctx, hipSetDevice(ctx->device));
     if (use_x0) { const int rc_ = fb_copy_h2d(ctx, s->M->x, x, sizeof(double2) * (size_t)s->nv); if (rc_) return rc_; }
     else FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
-    int rc = fb_bsr_setup_jacobi(ctx, s->M, precond);
-    if (rc) return rc;
-    if (precond == 2) rc = sys_solve_mg(ctx, s, rtol, atol, maxiter, iters, relres);
-    else rc = fb_bsr_pcg_dev(ctx, s->M, rtol, atol, maxiter, 0, iters, relres);
+    int rc;
+    if (precond == 3) {
+        // 'auto': the Jacobi-PCG for as many iterations as a multigrid solve of this size is expected to cost in all (set-up +
+        // cycles: ~30 ms; an iteration: 12 us + 0.085 ns per vertex, measured on MI355X), then -- from the iterate reached --
+        // the multigrid-PCG; whatever stops the hierarchy (set-up, breakdown, stall) hands the iterate back to the Jacobi-PCG.
+        // Never more than about twice the cost of the better of the two; a solve that converges inside the budget is the
+        // plain Jacobi-PCG bit for bit.
+        static const double budget_ms = [] { const char* e = getenv("FEABAS_HIP_AUTO_SWITCH_MS"); return e ? std::max(0.0, atof(e)) : 30.0; }();
+        const int budget = (int)std::min(4000.0, std::max(100.0, budget_ms * 1e-3 / (12e-6 + 0.085e-9 * (double)s->nv)));
+        const int cap1 = maxiter > 0 ? std::min(maxiter, budget) : budget;
+        int it1 = 0, it2 = 0, it3 = 0;
+        double rr = 0.0;
+        if ((rc = fb_bsr_setup_jacobi(ctx, s->M, 1))) return rc;
+        rc = fb_bsr_pcg_dev(ctx, s->M, rtol, atol, cap1, 0, &it1, &rr);
+        if (rc) return rc;
+        const double bn = s->M->last_bnorm;
+        const double tol = std::max(rtol, (atol > 0.0 && bn > 0.0) ? atol / bn : 0.0);
+        auto left = [&](int used) { return maxiter > 0 ? maxiter - used : -1; };
+        if (rr > tol && (maxiter <= 0 || it1 < maxiter)) {
+            rc = fb_bsr_setup_jacobi(ctx, s->M, 2);
+            if (!rc) rc = sys_solve_mg(ctx, s, rtol, atol, left(it1), &it2, &rr);
+            if (rc || rr > tol) {
+                // (M->x holds the last iterate the hierarchy reached; a breakdown leaves it finite or the Jacobi leg restarts from zero)
+                if (!(rr == rr)) FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
+                const int rem = left(it1 + it2);
+                if (maxiter <= 0 || rem > 0) {
+                    if ((rc = fb_bsr_setup_jacobi(ctx, s->M, 1))) return rc;
+                    rc = fb_bsr_pcg_dev(ctx, s->M, rtol, atol, rem, 0, &it3, &rr);
+                    if (rc && rc != FB_ERR_NOCONV) return rc;
+                } else rc = FB_OK;
+            }
+        }
+        if (iters) *iters = it1 + it2 + it3;
+        if (relres) *relres = rr;
+        if (!rc && rr > tol && maxiter < 0) rc = fb_fail(ctx, FB_ERR_NOCONV, "PCG stopped at relative residual %.3e > %.3e after %d iterations", rr, tol, it1 + it2 + it3);
+    } else {
+        rc = fb_bsr_setup_jacobi(ctx, s->M, precond);
+        if (rc) return rc;
+        if (precond == 2) rc = sys_solve_mg(ctx, s, rtol, atol, maxiter, iters, relres);
+        else rc = fb_bsr_pcg_dev(ctx, s->M, rtol, atol, maxiter, 0, iters, relres);
+    }
     if (rc && rc != FB_ERR_NOCONV) return rc;
     { const int rc_ = fb_copy_d2h(ctx, x, s->M->x, sizeof(double2) * (size_t)s->nv); if (rc_) return rc_; }
     return rc;

@@ -25,6 +25,7 @@ struct fb_bsr {
     double* parts = nullptr;
     fb_pcg_state* state = nullptr;
     double diag_max = 0.0;
+    double last_bnorm = 0.0;    // ||b|| of the last fb_bsr_pcg_dev
     // one batch of Jacobi-PCG iterations (no first-iteration special case) as an executable graph: small
     // systems are bound by the launch rate of the two kernels per iteration, not by their run time
     hipGraphExec_t pcg_graph = nullptr;

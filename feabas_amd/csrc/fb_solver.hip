@@ -542,6 +542,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
     hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->b, M->z, M->minv, part_tmp, part_rr[0]);
     double bb = 0.0;
     if ((rc = host_sum(part_rr[0], g2, &bb))) return rc;
+    M->last_bnorm = std::sqrt(bb);
     if (iters_out) *iters_out = 0;
     if (relres_out) *relres_out = 0.0;
     if (bb == 0.0 || (maxiter == 0 && fixed_iters <= 0)) {          // maxiter: <0 unlimited, 0 -> zeros, >0 cap          // optimizer.py:1974-1975
@@ -549,6 +550,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
         return FB_OK;
     }
     const double bnorm = std::sqrt(bb);
+    M->last_bnorm = bnorm;
     double tol = rtol;
     if (atol > 0.0) tol = std::max(tol, atol / bnorm);               // optimizer.py:1993-1996
     if (fixed_iters > 0) tol = 0.0;

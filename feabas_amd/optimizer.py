@@ -741,7 +741,10 @@ class SLM:
         mi = -1 if maxiter is None else int(maxiter)
         # (round 3 kept the hierarchy away from windows without a locked mesh: with its fixed smoother damping the cycle was
         # indefinite there; the damping now follows lambda_max(Dinv A) of every level, csrc/fb_mg.inc::mg_damping)
-        pre = 0 if precondition is None else (2 if multigrid and groupings is None else 1)
+        auto = isinstance(precondition, str) and precondition.lower() == 'auto'
+        # 'auto' (not a reference value): Jacobi-PCG for the iterations a multigrid solve would cost, then the multigrid-PCG from
+        # the iterate reached (fb_sys_solve precond 3) -- within about twice the better of the two on any system
+        pre = 0 if precondition is None else (2 if multigrid and groupings is None else (3 if auto and groupings is None else 1))
         bn = float(np.linalg.norm(b)) / self._gmean           # grouped terms are divided by mean(count) (optimizer.py:1408-1411)
         if held is not None and not held.all():
             # remove_extra_dof (optimizer.py:1360-1377, 1976-1991): three degrees of freedom of the first mesh of every

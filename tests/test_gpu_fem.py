@@ -691,6 +691,27 @@ def test_multigrid_on_a_floating_pair_beats_the_jacobi_pcg(fb):
         np.testing.assert_allclose(out[pre][1], exp, atol=1e-5 * np.abs(before).max())
 
 
+def test_precondition_auto_is_the_jacobi_pcg_inside_its_budget_and_multigrid_beyond(fb):
+    """precondition='auto' (fb_sys_solve precond 3): a solve the Jacobi-PCG finishes inside the iteration budget is that solve bit
+    for bit; a weakly pinned 125 k-node mesh (6 matches) exhausts the budget (1 327 iterations at this size), the multigrid-PCG takes the iterate over and the
+    rest takes a fraction of the Jacobi iterations it replaces -- the same displacement field to the tolerance"""
+    import bench
+    out = {}
+    for nlinks in (20000, 6):
+        for pre in ('jacobi', 'auto'):
+            slm = bench.build_fem_system(354, nlinks, seed=3)
+            c = slm.optimize_linear(tol=1e-7, precondition=pre)
+            assert c[1] <= 1.001e-7 * c[0]
+            out[nlinks, pre] = (slm.last_solve['iters'], slm.meshes[1].vertices_w_offset(1).copy())
+    assert out[20000, 'auto'][0] == out[20000, 'jacobi'][0]
+    np.testing.assert_array_equal(out[20000, 'auto'][1], out[20000, 'jacobi'][1])
+    it_j, it_a = out[6, 'jacobi'][0], out[6, 'auto'][0]
+    budget = 1327
+    assert it_j > budget + 500 and budget < it_a < budget + 0.25 * (it_j - budget), (it_j, it_a)
+    move = np.abs(out[6, 'jacobi'][1] - bench.build_fem_system(354, 6, seed=3).meshes[1].vertices_w_offset(1)).max()
+    np.testing.assert_allclose(out[6, 'auto'][1], out[6, 'jacobi'][1], atol=2e-4 * move)
+
+
 def test_multigrid_request_on_a_window_of_very_many_small_meshes_falls_back(fb):
     """precondition='smoothed_aggregation' where the hierarchy cannot be built: aggregates never join two meshes, so a window of
     several hundred tiny free meshes (a stitching section's tiles) ends with a coarsest level larger than the dense solve takes;

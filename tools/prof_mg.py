@@ -12,7 +12,7 @@ for nl in (50, 5000, 200000):
     _lib.check(lib.fb_sys_form(ctx, slm._sys, sl, cl))
     n = 2 * slm._nv
     x = np.zeros(n); it = C.c_int(); rr = C.c_double()
-    for pre in (1, 2, 2):
+    for pre in (1, 2, 3):
         for tol in (1e-4, 1e-7):
             x[:] = 0
             t0 = time.time()
