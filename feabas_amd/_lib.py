@@ -144,6 +144,7 @@ _PROTOS = {
     'fb_divide_bbox': (c_i, [c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p, c_p, c_i, c_p, c_i]),
     'fb_mesh_block_affines': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_d, c_p, c_p]),
     'fb_mesh_block_uncovered_dev': (c_i, [c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'fb_tri_edge_ratio': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
     'fb_signed_area': (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
     'fb_mesh_block_uncovered': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_mesh_locate_dev': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p]),

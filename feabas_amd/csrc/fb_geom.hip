@@ -286,6 +286,27 @@ int fb_signed_area(fb_ctx* ctx, int V, const double* v, int T, const int32_t* tr
     return FB_OK;
 }
 
+// Squared-length ratio of every triangle edge between two vertex sets (the gathers of Mesh.triangle_edge_deform,
+// mesh.py:1966-1976: edge k runs from vertex k - 1 to vertex k of the triangle): ratio [T][3] = |v1[t_k] - v1[t_k-1]|^2 /
+// |v0[t_k] - v0[t_k-1]|^2, every operation rounded on its own like the numpy statement.  Host arrays.
+int fb_tri_edge_ratio(fb_ctx* ctx, int V, const double* v0, const double* v1, int T, const int32_t* tris, double* ratio) {
+    FB_CHECK_ARG(ctx, V >= 0 && T >= 0 && (T == 0 || (v0 && v1 && tris && ratio)));
+    for (int t = 0; t < T; ++t)
+        for (int a = 0; a < 3; ++a) FB_CHECK_ARG(ctx, tris[3 * (size_t)t + a] >= 0 && tris[3 * (size_t)t + a] < V);
+    for (int t = 0; t < T; ++t) {
+#pragma clang fp contract(off)
+        const int32_t* t3 = tris + 3 * (size_t)t;
+        for (int k = 0; k < 3; ++k) {
+            const size_t a = (size_t)t3[k], b = (size_t)t3[(k + 2) % 3];
+            const double x0 = v0[2 * a] - v0[2 * b], y0 = v0[2 * a + 1] - v0[2 * b + 1];
+            const double x1 = v1[2 * a] - v1[2 * b], y1 = v1[2 * a + 1] - v1[2 * b + 1];
+            const double xx0 = x0 * x0, yy0 = y0 * y0, xx1 = x1 * x1, yy1 = y1 * y1;
+            ratio[3 * (size_t)t + k] = (xx1 + yy1) / (xx0 + yy0);
+        }
+    }
+    return FB_OK;
+}
+
 // field_w_weight (renderer.py:259-300) for NB blocks: block e belongs to pair pair_of[e] (index into vm) and covers the
 // h x w output pixels at (x0, y0) = org[e]; every pixel is located in the MOVING triangles that can reach the block and
 // mapped to the image by linear interpolation of the INITIAL vertices (matplotlib.tri.LinearTriInterpolator in the

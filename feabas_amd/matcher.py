@@ -295,7 +295,11 @@ def _region2grid_cartesian(region, spacing, erode=0.0, res=None, **kwargs):
     cntrs = [c for c in cntrs if c.shape[0]]
     if not cntrs:
         return None
-    pts = np.unique(np.concatenate(cntrs, axis=0), axis=0)            # unary_union of the MultiPoints: duplicates merged, sorted
+    # unary_union of the MultiPoints: duplicates merged, rows sorted by (x, y) -- np.unique(axis=0) without its structured-view sort
+    pts = np.concatenate(cntrs, axis=0)
+    pts = pts[np.lexsort((pts[:, 1], pts[:, 0]))]
+    if pts.shape[0] > 1:
+        pts = pts[np.concatenate(([True], np.any(pts[1:] != pts[:-1], axis=1)))]
     return pts
 
 

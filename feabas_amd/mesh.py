@@ -488,6 +488,13 @@ class Mesh:
     def triangle_edge_deform(self, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING)):   # mesh.py:1966-1976
         v0, v1 = self.vertices(gear[0]), self.vertices(gear[-1])
         t = self.triangles
+        if t.shape[0] >= 1024 and t.dtype == np.int32 and v0.dtype == np.float64 and v1.dtype == np.float64:
+            # the six vertex gathers in a host loop of the library (the same roundings); log / exp stay numpy's
+            a0, a1, tt = np.ascontiguousarray(v0), np.ascontiguousarray(v1), np.ascontiguousarray(t)
+            ratio = np.empty((tt.shape[0], 3))
+            if _lib.load().fb_tri_edge_ratio(None, a0.shape[0], _lib.ptr(a0), _lib.ptr(a1), tt.shape[0], _lib.ptr(tt), _lib.ptr(ratio)) != 0:
+                raise IndexError('triangle_edge_deform: a triangle names a vertex outside the vertex list')
+            return np.exp(np.max(np.abs(0.5 * np.log(ratio)), axis=-1))
         tr = np.roll(t, 1, axis=-1)
         d0 = np.sum((v0[t] - v0[tr]) ** 2, axis=-1)
         d1 = np.sum((v1[t] - v1[tr]) ** 2, axis=-1)

@@ -210,6 +210,9 @@ int fb_mesh_block_uncovered_dev(fb_ctx* ctx, const double* v_mov, const int* tri
  *   cross(p1 - p0, p2 - p1) of the T triangles tris [T][3] over v [V][2] (negative indices count from the end, as numpy
  *   takes them), rounded operation by operation like the numpy statement. */
 int fb_signed_area(fb_ctx* ctx, int V, const double* v, int T, const int32_t* tris, double* area);
+/* fb_tri_edge_ratio (host arrays, no device work): the gathers of Mesh.triangle_edge_deform (mesh.py:1966-1976):
+ *   ratio [T][3] = squared length of every triangle edge in v1 over its squared length in v0 (edge k: vertex k - 1 -> vertex k). */
+int fb_tri_edge_ratio(fb_ctx* ctx, int V, const double* v0, const double* v1, int T, const int32_t* tris, double* ratio);
 /* fb_mesh_locate_dev: Mesh.tri_finder (mesh.py:2080-2188) for K points pts [K][2] (device, frame of v_mov): tid [K] = the
  *   containing triangle of smallest index, -1 outside the mesh. */
 int fb_mesh_locate_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris, int K, const double* pts, int* tid);

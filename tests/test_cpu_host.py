@@ -571,3 +571,21 @@ def test_block_uncovered_threads_equal_one_thread():
         o_, c_, k_ = np.ascontiguousarray(org[lo:hi]), np.ascontiguousarray(cand[lo:hi]), np.ascontiguousarray(cnt[lo:hi])
         assert lib.fb_mesh_block_uncovered(None, v.shape[0], _lib.ptr(v), _lib.ptr(tri), hi - lo, _lib.ptr(o_), h, w, cap, _lib.ptr(c_), _lib.ptr(k_), _lib.ptr(part)) == 0
         np.testing.assert_array_equal(part, unc[lo:hi])
+
+
+def test_triangle_edge_deform_host_loop_equals_the_numpy_statement():
+    """Mesh.triangle_edge_deform through fb_tri_edge_ratio (meshes of 1 024 triangles and more) against the numpy statement of
+    mesh.py:1966-1976, bit for bit"""
+    from scipy.spatial import Delaunay
+    from feabas_amd.mesh import Mesh
+    rng = np.random.default_rng(12)
+    v = rng.uniform(0, 500, (1500, 2))
+    t = Delaunay(v).simplices.astype(np.int32)
+    assert t.shape[0] >= 1024
+    m = Mesh(v, t, uid=0)
+    m.set_vertices(v + rng.normal(0, 0.8, v.shape), 1)
+    got = m.triangle_edge_deform(gear=(0, 1))
+    v0, v1 = m.vertices(0), m.vertices(1)
+    tr = np.roll(t, 1, axis=-1)
+    d0 = np.sum((v0[t] - v0[tr]) ** 2, axis=-1); d1 = np.sum((v1[t] - v1[tr]) ** 2, axis=-1)
+    np.testing.assert_array_equal(got, np.exp(np.max(np.abs(0.5 * np.log(d1 / d0)), axis=-1)))
