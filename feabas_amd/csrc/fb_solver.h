@@ -7,6 +7,7 @@ struct fb_bsr_dev {
     int* rowptr = nullptr;
     int* col = nullptr;
     double* val = nullptr;   // [nnzb][4] row-major 2x2
+    int xcd_rows = 1;        // SpMV: the workgroups of one XCD (blockIdx % 8) take one contiguous eighth of the row chunks
 };
 
 struct fb_pcg_state {

@@ -103,7 +103,17 @@ __global__ __launch_bounds__(kT) void bsr_spmv_kernel(
     }
     double acc_dot = 0.0, acc_pp = 0.0;
     const int nchunks = (A.nb + kT - 1) / kT;
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: with chunk = blockIdx the neighbours of a row
+    // chunk (whose vector entries its gathers touch) sit on other XCDs and every L2 ends up holding the whole vector.  The
+    // workgroups of one XCD take a contiguous eighth of the chunks instead, so the gathers of a mesh-ordered matrix stay in
+    // that XCD's L2.
+    int c_first = blockIdx.x, c_stride = gridDim.x, c_limit = nchunks, c_base = 0;
+    if (A.xcd_rows && (gridDim.x & 7) == 0 && nchunks >= 64) {
+        const int per = (nchunks + 7) >> 3;
+        c_base = (blockIdx.x & 7) * per; c_first = blockIdx.x >> 3; c_stride = gridDim.x >> 3; c_limit = min(per, nchunks - c_base);
+    }
+    for (int cc = c_first; cc < c_limit; cc += c_stride) {
+        const int chunk = c_base + cc;
         const int r0 = chunk * kT;
         const int r1 = min(A.nb, r0 + kT);
         const int b0 = A.rowptr[r0], b1 = A.rowptr[r1];
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(kT) void pcg_update_kernel(
     const double2* __restrict__ Ap, const double2* __restrict__ minv, const double* __restrict__ part_pAp,
     const double* __restrict__ part_pp, int np_pAp,
     const double* __restrict__ part_rz_cur, int np_rz, double* __restrict__ part_rz_out, double* __restrict__ part_rr_out,
-    fb_pcg_state* st, int iter) {
+    fb_pcg_state* st, int iter, int xcd_rows) {
     __shared__ double sh[kT / 64];
     __shared__ double sh2[2][kT / 64];
     __shared__ int sflag;
@@ -202,10 +212,18 @@ __global__ __launch_bounds__(kT) void pcg_update_kernel(
     }
     const double alpha = rz / pAp;
     double s_rz = 0.0, s_rr = 0.0;
-    const int stride = gridDim.x * blockDim.x;
-    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nb; i0 += 2 * stride) {
-        const int i1 = i0 + stride;
-        const bool two = i1 < nb;
+    // the rows of one XCD's workgroups are the contiguous eighth that XCD's SpMV workgroups gather from (bsr_spmv_kernel):
+    // what this kernel writes (z, r, x) and the SpMV reads next sits in the same L2
+    int stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x, base = 0, limit = nb;
+    const int nchunks = (nb + kT - 1) / kT;
+    if (xcd_rows && (gridDim.x & 7) == 0 && nchunks >= 64) {
+        const int per = ((nchunks + 7) >> 3) * kT;
+        base = (blockIdx.x & 7) * per; limit = min(per, nb - base);
+        first = (blockIdx.x >> 3) * blockDim.x + threadIdx.x; stride = (gridDim.x >> 3) * blockDim.x;
+    }
+    for (int j0 = first; j0 < limit; j0 += 2 * stride) {
+        const int i0 = base + j0, i1 = i0 + stride;
+        const bool two = j0 + stride < limit;
         const int ib = two ? i1 : i0;
         const double2 pa = p[i0], apa = Ap[i0], ma = minv[i0], pb = p[ib], apb = Ap[ib], mb = minv[ib];
         double2 xa = x[i0], ra = r[i0], xb = x[ib], rb = r[ib];
@@ -457,6 +475,7 @@ int fb_bsr_alloc(fb_ctx* ctx, int nb, int64_t nnzb, fb_bsr** out) {
     if (nnzb >= (1LL << 31)) return fb_fail(ctx, FB_ERR_ARG, "block count %lld exceeds int32 indexing", (long long)nnzb);
     fb_bsr* M = new fb_bsr();
     M->d.nb = nb;
+    { static const int xr = [] { const char* e = getenv("FEABAS_HIP_SPMV_XCD"); return e ? atoi(e) : 1; }(); M->d.xcd_rows = xr; }
     M->nnzb = nnzb;
     hipError_t e = hipSuccess;
     auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
@@ -596,7 +615,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
             {
                 FB_PROF_B(ctx, "pcg_update_fused", 7.0 * 16.0 * nb);
                 hipLaunchKernelGGL(pcg_update_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->r, M->z, p_new, M->Ap, M->minv,
-                                   part_pAp, part_pp, g1, part_rz[prev], g2, part_rz[cur], part_rr[cur], M->state, i);
+                                   part_pAp, part_pp, g1, part_rz[prev], g2, part_rz[cur], part_rr[cur], M->state, i, M->d.xcd_rows);
             }
         };
         while (!stop) {
