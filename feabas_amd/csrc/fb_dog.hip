@@ -1147,17 +1147,19 @@ int fb_dog(fb_ctx* ctx, const void* img, int dtype, int N, int H, int W, double 
     if (N == 0) return FB_OK;
     FB_HIP(ctx, hipSetDevice(ctx->device));
     const size_t px = (size_t)N * H * W, esz = dtype == FB_U8 ? 1 : 4;
-    void* din = nullptr; float* dout = nullptr; uint8_t* dmask = nullptr;
-    FB_HIP(ctx, hipMalloc(&din, px * esz));
-    FB_HIP(ctx, hipMalloc(&dout, px * sizeof(float)));
-    int rc = fb_copy_h2d(ctx, din, img, px * esz);
+    void *din = nullptr, *dout = nullptr, *dmask = nullptr;             // (the context's allocation cache: a hipMalloc / hipFree pair costs ~1 ms)
+    int rc = fb_malloc(ctx, px * esz, &din);
+    if (!rc) rc = fb_malloc(ctx, px * sizeof(float), &dout);
+    if (!rc) rc = fb_copy_h2d(ctx, din, img, px * esz);
     if (!rc && mask) {
-        FB_HIP(ctx, hipMalloc(&dmask, (size_t)H * W));
-        rc = fb_copy_h2d(ctx, dmask, mask, (size_t)H * W);
+        rc = fb_malloc(ctx, (size_t)H * W, &dmask);
+        if (!rc) rc = fb_copy_h2d(ctx, dmask, mask, (size_t)H * W);
     }
-    if (!rc) rc = fb_dog_dev(ctx, din, dtype, N, H, W, sigma, dmask, signed_out, dout);
+    if (!rc) rc = fb_dog_dev(ctx, din, dtype, N, H, W, sigma, (const uint8_t*)dmask, signed_out, (float*)dout);
     if (!rc) rc = fb_copy_d2h(ctx, out, dout, px * sizeof(float));
-    hipFree(din); hipFree(dout); if (dmask) hipFree(dmask);
+    if (din) fb_free(ctx, din);
+    if (dout) fb_free(ctx, dout);
+    if (dmask) fb_free(ctx, dmask);
     return rc;
 }
 
@@ -1198,13 +1200,14 @@ int fb_area_downsample2(fb_ctx* ctx, const uint8_t* img, int N, int H, int W, ui
     FB_CHECK_ARG(ctx, N >= 0 && H > 1 && W > 1);
     if (N == 0) return FB_OK;
     const size_t bi = (size_t)N * H * W, bo = (size_t)N * half_size(H) * half_size(W);
-    uint8_t *din = nullptr, *dout = nullptr;
-    FB_HIP(ctx, hipMalloc(&din, bi));
-    FB_HIP(ctx, hipMalloc(&dout, bo));
-    int rc = fb_copy_h2d(ctx, din, img, bi);
-    if (!rc) rc = fb_area_downsample2_dev(ctx, din, N, H, W, dout);
+    void *din = nullptr, *dout = nullptr;
+    int rc = fb_malloc(ctx, bi, &din);
+    if (!rc) rc = fb_malloc(ctx, bo, &dout);
+    if (!rc) rc = fb_copy_h2d(ctx, din, img, bi);
+    if (!rc) rc = fb_area_downsample2_dev(ctx, (const uint8_t*)din, N, H, W, (uint8_t*)dout);
     if (!rc) rc = fb_copy_d2h(ctx, out, dout, bo);
-    hipFree(din); hipFree(dout);
+    if (din) fb_free(ctx, din);
+    if (dout) fb_free(ctx, dout);
     return rc;
 }
 

@@ -901,26 +901,24 @@ int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C
     if (N == 0) return FB_OK;
     FB_HIP(ctx, hipSetDevice(ctx->device));
     const size_t b0 = (size_t)N * C * H0 * W0 * sizeof(float), b1 = (size_t)N * C * H1 * W1 * sizeof(float);
-    float *d0 = nullptr, *d1 = nullptr, *dconf = nullptr;
-    double *ddx = nullptr, *ddy = nullptr;
-    int rc = FB_OK;
-    hipError_t e;
-    if ((e = hipMalloc(&d0, b0)) != hipSuccess || (e = hipMalloc(&d1, b1)) != hipSuccess ||
-        (e = hipMalloc(&ddx, N * sizeof(double))) != hipSuccess || (e = hipMalloc(&ddy, N * sizeof(double))) != hipSuccess ||
-        (e = hipMalloc(&dconf, N * sizeof(float))) != hipSuccess) {
-        rc = fb_fail(ctx, FB_ERR_NOMEM, "fb_ncc_batch: hipMalloc: %s", hipGetErrorString(e));
-    }
+    void *d0 = nullptr, *d1 = nullptr, *dres = nullptr;        // (the context's allocation cache; results in one block: dx, dy, conf)
+    int rc = fb_malloc(ctx, b0, &d0);
+    if (!rc) rc = fb_malloc(ctx, b1, &d1);
+    if (!rc) rc = fb_malloc(ctx, (size_t)N * 24, &dres);
+    double* ddx = (double*)dres; double* ddy = ddx ? ddx + N : nullptr; float* dconf = ddy ? (float*)(ddy + N) : nullptr;
     if (!rc) {
         rc = fb_copy_h2d(ctx, d0, img0, b0);
         if (!rc) rc = fb_copy_h2d(ctx, d1, img1, b1);
-        if (!rc) rc = fb_ncc_batch_dev(ctx, d0, d1, N, C, H0, W0, H1, W1, pad, subpixel, conf_mode, ddx, ddy, dconf);
+        if (!rc) rc = fb_ncc_batch_dev(ctx, (const float*)d0, (const float*)d1, N, C, H0, W0, H1, W1, pad, subpixel, conf_mode, ddx, ddy, dconf);
     }
     if (!rc) {
         rc = fb_copy_d2h(ctx, dx, ddx, N * sizeof(double));
         if (!rc) rc = fb_copy_d2h(ctx, dy, ddy, N * sizeof(double));
         if (!rc) rc = fb_copy_d2h(ctx, conf, dconf, N * sizeof(float));
     }
-    hipFree(d0); hipFree(d1); hipFree(ddx); hipFree(ddy); hipFree(dconf);
+    if (d0) fb_free(ctx, d0);
+    if (d1) fb_free(ctx, d1);
+    if (dres) fb_free(ctx, dres);
     return rc;
 }
 

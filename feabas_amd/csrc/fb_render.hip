@@ -313,15 +313,14 @@ int fb_mesh_candidates_dev(fb_ctx* ctx, int T, const double* v_mov, const int* t
     FB_HIP(ctx, hipSetDevice(ctx->device));
     if (T == 0) { FB_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int) * NB, ctx->stream)); return FB_OK; }
     float4* box = nullptr;
-    FB_HIP(ctx, hipMalloc(&box, sizeof(float4) * (size_t)T));
+    { const int rc = fb_malloc(ctx, sizeof(float4) * (size_t)T, (void**)&box); if (rc) return rc; }      // (the context's allocation cache)
     {
         FB_PROF_B(ctx, "mesh_cand", (double)T * 16.0 * NB);
         hipLaunchKernelGGL(tri_box_kernel, dim3(std::min(fb_cdiv(T, 256), 4096)), dim3(256), 0, ctx->stream, T, v_mov, tris, box);
         hipLaunchKernelGGL(mesh_cand_kernel, dim3(NB), dim3(256), 0, ctx->stream, T, box, org, h, w, cap, cand, count);
     }
     const hipError_t e = hipGetLastError();
-    hipStreamSynchronize(ctx->stream);
-    hipFree(box);
+    fb_free(ctx, box);                                       // waits for the stream
     FB_HIP(ctx, e);
     return FB_OK;
 }
@@ -347,7 +346,7 @@ int fb_mesh_locate_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris,
     hipLaunchKernelGGL(fill_int_kernel, dim3(fb_cdiv(K, 256)), dim3(256), 0, ctx->stream, K, tid, T == 0 ? -1 : INT_MAX);
     if (T == 0) { FB_HIP(ctx, hipGetLastError()); return FB_OK; }
     float4* box = nullptr;
-    FB_HIP(ctx, hipMalloc(&box, sizeof(float4) * (size_t)T));
+    { const int rc = fb_malloc(ctx, sizeof(float4) * (size_t)T, (void**)&box); if (rc) return rc; }      // (tri_finder is called a dozen times per section pair)
     {
         FB_PROF(ctx, "mesh_locate");
         hipLaunchKernelGGL(tri_box_kernel, dim3(std::min(fb_cdiv(T, 256), 4096)), dim3(256), 0, ctx->stream, T, v_mov, tris, box);
@@ -360,8 +359,7 @@ int fb_mesh_locate_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris,
         hipLaunchKernelGGL(locate_finish_kernel, dim3(std::min(fb_cdiv(K, 256), 1024)), dim3(256), 0, ctx->stream, K, tid);
     }
     const hipError_t e = hipGetLastError();
-    hipStreamSynchronize(ctx->stream);
-    hipFree(box);
+    fb_free(ctx, box);                                       // waits for the stream
     FB_HIP(ctx, e);
     return FB_OK;
 }
