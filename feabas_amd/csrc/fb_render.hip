@@ -78,6 +78,62 @@ __global__ void mesh_locate_kernel(int K, const double* __restrict__ pts, int T,
     if (best != INT_MAX) atomicMin(&tid_out[k], best);
 }
 
+// The same search with the triangles culled per workgroup: the 256 points of a workgroup (neighbours in a raster or in a
+// z-ordered / sorted list) span a small box; the triangle boxes are tested against THAT box cooperatively, 1024 at a time, the
+// survivors go to a list in LDS and every point tests only those exactly -- for a raster of 219 k points over 13 k triangles
+// ~100 survivors per workgroup instead of 13 k box tests per point (2.5 ms -> 0.1 ms).  The smallest containing index wins, as before.
+__global__ __launch_bounds__(256) void mesh_locate_cull_kernel(int K, const double* __restrict__ pts, int T, const float4* __restrict__ box,
+                                                                const double* __restrict__ vm, const int* __restrict__ tris, int* __restrict__ tid_out) {
+#pragma clang fp contract(off)
+    __shared__ float s_red[4][4];
+    __shared__ int s_hits[1024];
+    __shared__ int s_n;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = k < K;
+    const double px = valid ? pts[2 * k] : 0.0, py = valid ? pts[2 * k + 1] : 0.0;
+    const float xd = __double2float_rd(px), xu = __double2float_ru(px), yd = __double2float_rd(py), yu = __double2float_ru(py);
+    float bx0 = valid ? xd : INFINITY, by0 = valid ? yd : INFINITY, bx1 = valid ? xu : -INFINITY, by1 = valid ? yu : -INFINITY;
+    for (int off = 32; off > 0; off >>= 1) {
+        bx0 = fminf(bx0, __shfl_down(bx0, off)); by0 = fminf(by0, __shfl_down(by0, off));
+        bx1 = fmaxf(bx1, __shfl_down(bx1, off)); by1 = fmaxf(by1, __shfl_down(by1, off));
+    }
+    if ((threadIdx.x & 63) == 0) { float* r = s_red[threadIdx.x >> 6]; r[0] = bx0; r[1] = by0; r[2] = bx1; r[3] = by1; }
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    bx0 = fminf(fminf(s_red[0][0], s_red[1][0]), fminf(s_red[2][0], s_red[3][0])); by0 = fminf(fminf(s_red[0][1], s_red[1][1]), fminf(s_red[2][1], s_red[3][1]));
+    bx1 = fmaxf(fmaxf(s_red[0][2], s_red[1][2]), fmaxf(s_red[2][2], s_red[3][2])); by1 = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
+    int best = INT_MAX;
+    for (int t0 = 0; t0 < T; t0 += 1024) {
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * 256 + threadIdx.x;
+            if (t < T) {
+                const float4 bb = box[t];
+                if (!(bb.x > bx1 || bb.z < bx0 || bb.y > by1 || bb.w < by0)) s_hits[atomicAdd(&s_n, 1)] = t;
+            }
+        }
+        __syncthreads();
+        const int n = s_n;
+        for (int h = 0; h < n; ++h) {
+            const int t = s_hits[h];
+            if (!valid || t > best) continue;
+            const float4 bb = box[t];
+            if (bb.x > xu || bb.z < xd || bb.y > yu || bb.w < yd) continue;
+            const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
+            const double x0 = vm[2 * i0], y0 = vm[2 * i0 + 1];
+            const double e1x = vm[2 * i1] - x0, e1y = vm[2 * i1 + 1] - y0, e2x = vm[2 * i2] - x0, e2y = vm[2 * i2 + 1] - y0;
+            const double d = e1x * e2y - e1y * e2x;
+            if (d == 0.0) continue;
+            const double dx = px - x0, dy = py - y0;
+            const double l1 = (dx * e2y - dy * e2x) / d, l2 = (e1x * dy - e1y * dx) / d, l0 = (1.0 - l1) - l2;
+            if (l0 >= -BARY_EPS && l1 >= -BARY_EPS && l2 >= -BARY_EPS) best = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    }
+    if (valid) tid_out[k] = best == INT_MAX ? -1 : best;
+}
+
 __global__ void locate_finish_kernel(int K, int* tid) {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
         if (tid[k] == INT_MAX) tid[k] = -1;
@@ -350,13 +406,19 @@ int fb_mesh_locate_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris,
     {
         FB_PROF(ctx, "mesh_locate");
         hipLaunchKernelGGL(tri_box_kernel, dim3(std::min(fb_cdiv(T, 256), 4096)), dim3(256), 0, ctx->stream, T, v_mov, tris, box);
-        // enough workgroups to fill the chip: the triangle range is split when there are few points
         const int gx = fb_cdiv(K, 256);
-        int gy = std::max(1, std::min(fb_cdiv(T, 2048), fb_cdiv(2048, gx)));
-        const int chunk = fb_cdiv(T, gy);
-        gy = fb_cdiv(T, chunk);
-        hipLaunchKernelGGL(mesh_locate_kernel, dim3(gx, gy), dim3(256), 0, ctx->stream, K, pts, T, chunk, box, v_mov, tris, tid);
-        hipLaunchKernelGGL(locate_finish_kernel, dim3(std::min(fb_cdiv(K, 256), 1024)), dim3(256), 0, ctx->stream, K, tid);
+        static const bool plain = getenv("FEABAS_HIP_LOCATE_PLAIN") != nullptr;
+        if (gx >= 64 && !plain) {
+            // many points: triangles culled per workgroup against the box of its 256 points
+            hipLaunchKernelGGL(mesh_locate_cull_kernel, dim3(gx), dim3(256), 0, ctx->stream, K, pts, T, box, v_mov, tris, tid);
+        } else {
+            // few points: every point walks the triangle boxes; the triangle range is split over blockIdx.y to fill the chip
+            int gy = std::max(1, std::min(fb_cdiv(T, 2048), fb_cdiv(2048, gx)));
+            const int chunk = fb_cdiv(T, gy);
+            gy = fb_cdiv(T, chunk);
+            hipLaunchKernelGGL(mesh_locate_kernel, dim3(gx, gy), dim3(256), 0, ctx->stream, K, pts, T, chunk, box, v_mov, tris, tid);
+            hipLaunchKernelGGL(locate_finish_kernel, dim3(std::min(fb_cdiv(K, 256), 1024)), dim3(256), 0, ctx->stream, K, tid);
+        }
     }
     const hipError_t e = hipGetLastError();
     fb_free(ctx, box);                                       // waits for the stream

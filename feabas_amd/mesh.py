@@ -219,7 +219,13 @@ class Mesh:
         if self.tri_func is not None:
             kw.update(tri_func=self.tri_func, stiffness_funcs=self.stiffness_funcs, func_matmult=self.func_matmult)
         kw.update(override)
-        return Mesh(self._vertices[const.MESH_GEAR_INITIAL], self.triangles, **kw)
+        twin = Mesh(self._vertices[const.MESH_GEAR_INITIAL], self.triangles, **kw)
+        # what depends on the triangles and the INITIAL vertices alone goes along (read-only arrays): the outline edges and the
+        # triangle areas (every Link asks for them, optimizer.py:26-30)
+        for name in ('_outline', '_area_initial'):
+            if getattr(self, name, None) is not None:
+                setattr(twin, name, getattr(self, name))
+        return twin
 
     # ------------------------------------------------------------------ transformations
     def save_to_h5(self, fname, vertex_flags=None, **kwargs):    # mesh.py:822-857 (layout: feabas_amd/h5wire.py)

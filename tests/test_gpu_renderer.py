@@ -452,3 +452,24 @@ def test_device_point_location_vs_matplotlib(fb):
     assert B.min() > -1e-8
     np.testing.assert_allclose(M.bary2cart(t2, B, const.MESH_GEAR_MOVING), pts[tid >= 0], atol=1e-8)
     assert M.tri_finder(np.empty((0, 2)), gear=const.MESH_GEAR_MOVING).shape == (0,)
+
+
+def test_point_location_culled_kernel_equals_the_plain_walk(fb):
+    """fb_mesh_locate_dev takes large point sets through the workgroup-culled kernel (triangles tested against the box of a
+    workgroup's 256 points first): a raster, random points and points exactly ON vertices / edge midpoints (several triangles
+    contain them: the smallest index wins) get the same triangle as the plain walk, which lists of fewer than 16 384 points take"""
+    from feabas_amd import constant as const
+    rng = np.random.default_rng(52)
+    _, M = _meshes(rng, extent=(1500, 1100), spacing=25.0, warp=5.0, offset=(-3.0, 8.5))
+    g = const.MESH_GEAR_MOVING
+    v = M.vertices_w_offset(g)
+    xs, ys = np.arange(-20, 1530, 7.5), np.arange(-20, 1130, 7.5)
+    raster = np.stack(np.meshgrid(xs, ys), -1).reshape(-1, 2)
+    t = M.triangles
+    mid = 0.5 * (v[t[:, 0]] + v[t[:, 1]])
+    pts = np.concatenate((raster, v, mid, np.stack((rng.uniform(-30, 1530, 9000), rng.uniform(-30, 1130, 9000)), -1)))
+    assert pts.shape[0] > 2 * 16384
+    got = M.tri_finder(pts, gear=g)
+    exp = np.concatenate([M.tri_finder(pts[a:a + 8000], gear=g) for a in range(0, pts.shape[0], 8000)])
+    np.testing.assert_array_equal(got, exp)
+    assert (got >= 0).mean() > 0.8 and (got < 0).sum() > 100
