@@ -1,8 +1,8 @@
 """the two linear systems a section pair solves (tools/bench_section_matcher.py workload), saved as scipy CSR + right-hand
 side under gpurun_out/: material for preconditioner experiments on the host"""
 import os, sys, numpy as np
-sys.path.insert(0, '.')
-import tools.bench_section_matcher as bsm                    # noqa: E402
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
+import bench_section_matcher as bsm                          # noqa: E402
 from feabas_amd import optimizer, _lib
 from feabas_amd.mesh import bsr_download
 from scipy import sparse
