@@ -1120,14 +1120,16 @@ def main():
         host_pairs = [(h0[k % nh], h1[k % nh]) for k in range(args.host_ingest_pairs)]     # the list may wrap around the resident strips
         cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=RESIDUE_LEN)
         fmatcher.stitching_matcher_batch(host_pairs[:IB * args.host_ingest_threads], batch=IB, threads=args.host_ingest_threads, **cfg)        # set-up pass
-        t0 = time.time()
-        outp = fmatcher.stitching_matcher_batch(host_pairs, batch=IB, threads=args.host_ingest_threads, **cfg)
-        dth = time.time() - t0
+        dth = np.inf
+        for _ in range(2):                                  # best of two passes: a pass is ~0.12 s and shares the host and the PCIe link with whatever else runs there
+            t0 = time.time()
+            outp = fmatcher.stitching_matcher_batch(host_pairs, batch=IB, threads=args.host_ingest_threads, **cfg)
+            dth = min(dth, time.time() - t0)
         line['host_ingest'] = dict(value=len(host_pairs) / dth, unit='pairs/s', pairs=len(host_pairs), matched=int(sum(o[0] is not None for o in outp)),
                                    h2d_gbs=len(host_pairs) * 2 * H * W / dth / 1e9,
                                    note='strips handed over in host memory (4.2 MB per pair over PCIe), results returned per pair; '
                                         f'{args.host_ingest_threads} host threads ({3 * args.host_ingest_threads // 8} loaders that pack and copy, the others match), {IB}-pair chunks; '
-                                        'h2d_gbs = strip bytes over the wall time of the whole run')
+                                        'h2d_gbs = strip bytes over the wall time of the whole run; best of two passes')
         # the same pairs cropped to strip shapes that all differ (what stage jitter does to the overlaps of a real section):
         # batches of unequal strips (RaggedStripBatchMatcher)
         rng_r = np.random.default_rng(5)
@@ -1138,12 +1140,14 @@ def main():
         RB = 32                                             # (48-, 64- and 96-pair chunks are 5-10 % slower; 16 host threads are no faster than 8:
         RT = args.host_ingest_threads                       # the six mesh-grid buckets of this list end in small chunks, gpurun_out sweep of round 4)
         fmatcher.stitching_matcher_batch(ragged, batch=RB, threads=RT, **cfg)      # first pass: page-locked staging, systems, code objects (1.6 s once per process)
-        t0 = time.time()
-        outr = fmatcher.stitching_matcher_batch(ragged, batch=RB, threads=RT, **cfg)
-        dtr = time.time() - t0
+        dtr = np.inf
+        for _ in range(2):
+            t0 = time.time()
+            outr = fmatcher.stitching_matcher_batch(ragged, batch=RB, threads=RT, **cfg)
+            dtr = min(dtr, time.time() - t0)
         line['host_ingest']['ragged'] = dict(value=len(ragged) / dtr, unit='pairs/s', pairs=len(ragged), distinct_shapes=len({a.shape for a, _ in ragged}),
                                              matched=int(sum(o[0] is not None for o in outr)),
-                                             note=f'every pair cropped to its own strip size (up to 29 x 11 px smaller); {RB}-pair chunks of unequal strips dealt to {RT} host threads; second pass over the list')
+                                             note=f'every pair cropped to its own strip size (up to 29 x 11 px smaller); {RB}-pair chunks of unequal strips dealt to {RT} host threads; best of two passes after a set-up pass')
         fmatcher.stitching_matcher_batch_release()
         del h0, h1, host_pairs, outp, ragged, outr
     if rank == 0 and world == 1 and not args.no_align:

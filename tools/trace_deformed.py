@@ -17,6 +17,9 @@ for warp in (0.4, 2.0):
     for _ in range(8):
         r = m.match(s0.ptr, s1.ptr)
     print(f'warp {warp}: {1e3 * (time.perf_counter() - t) / 8:.2f} ms per call, deformed pairs {int(np.sum(r["deformed"]))}', flush=True)
+    lib.fb_prof_reset(ctx); lib.fb_prof_enable(ctx, 1); m.match(s0.ptr, s1.ptr); lib.fb_prof_enable(ctx, 0)
+    snap = _lib.prof_snapshot()
+    print('   kernels', round(sum(v[1] for v in snap.values()), 2), 'ms:', {k: (v[0], round(v[1], 2)) for k, v in sorted(snap.items(), key=lambda kv: -kv[1][1])[:14]}, flush=True)
     print(f'--- warp {warp}', file=sys.stderr, flush=True)
     m.free()
     for b in (s0, s1, sh):
