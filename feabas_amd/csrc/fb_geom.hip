@@ -185,9 +185,10 @@ int fb_deformed_block_affines(fb_ctx* ctx, int Q, int nx, int ny, const double* 
 int fb_mesh_block_affines(fb_ctx* ctx, int V, const double* v_mov, const double* v_img, const int32_t* tris, int NB, const double* org,
                           int h, int w, int cap, const int32_t* cand, const int32_t* count, double tol, int32_t* tier, double* A6) {
     FB_CHECK_ARG(ctx, V > 0 && v_mov && v_img && tris && NB >= 0 && org && h > 0 && w > 0 && cap > 0 && cand && count && tier && A6);
+    auto work = [&](int b_lo, int b_hi) {
     std::vector<int> stamp((size_t)V, -1), members;
     members.reserve(256);
-    for (int b = 0; b < NB; ++b) {
+    for (int b = b_lo; b < b_hi; ++b) {
         const double bx0 = org[2 * b] - 0.5, by0 = org[2 * b + 1] - 0.5, bx1 = bx0 + (double)w, by1 = by0 + (double)h;   // bbox0 - 0.5, renderer.py:405
         members.clear();
         const int nc = std::min(count[b], cap);
@@ -205,6 +206,15 @@ int fb_mesh_block_affines(fb_ctx* ctx, int V, const double* v_mov, const double*
         const Fit f = fit_rows(v_mov, v_img, members.data(), (int)members.size());
         if (!f.ok) { tier[b] = -1; continue; }
         if (f.res < tol) { tier[b] = 2; a[0] = f.a00; a[1] = f.a10; a[2] = f.t0; a[3] = f.a01; a[4] = f.a11; a[5] = f.t1; }
+    }
+    };
+    // blocks are independent (their own vertex stamps per thread): a few host threads for the block counts of a whole section
+    const int NT = std::max(1, std::min(fb_host_threads(4), NB / 2048));
+    if (NT <= 1) work(0, NB);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < NT; ++t) pool.emplace_back(work, (int)((int64_t)NB * t / NT), (int)((int64_t)NB * (t + 1) / NT));
+        for (auto& th : pool) th.join();
     }
     return FB_OK;
 }

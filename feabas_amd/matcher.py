@@ -192,11 +192,15 @@ class _RegionPair:
         ok = np.ones(pts.shape[0], dtype=bool)
         tids = []
         for m in self.meshes:
-            idx = np.flatnonzero(ok)
-            tid = np.full(pts.shape[0], -1, dtype=np.int64)
-            if idx.size:
-                tid[idx] = m.tri_finder(pts[idx], gear=self.gear)
-                ok[idx] = tid[idx] >= 0
+            if ok.all():                                   # (no gather / scatter of the point list while nothing has dropped out)
+                tid = np.asarray(m.tri_finder(pts, gear=self.gear))
+                ok = tid >= 0
+            else:
+                idx = np.flatnonzero(ok)
+                tid = np.full(pts.shape[0], -1, dtype=np.int32)
+                if idx.size:
+                    tid[idx] = m.tri_finder(pts[idx], gear=self.gear)
+                    ok[idx] = tid[idx] >= 0
             tids.append(tid)
         for sets, want in ((self.only, True), (self.exclude, False)):
             if sets is None or not ok.any():
