@@ -408,8 +408,8 @@ int fb_mesh_locate_dev(fb_ctx* ctx, int T, const double* v_mov, const int* tris,
         hipLaunchKernelGGL(tri_box_kernel, dim3(std::min(fb_cdiv(T, 256), 4096)), dim3(256), 0, ctx->stream, T, v_mov, tris, box);
         const int gx = fb_cdiv(K, 256);
         static const bool plain = getenv("FEABAS_HIP_LOCATE_PLAIN") != nullptr;
-        if (gx >= 64 && !plain) {
-            // many points: triangles culled per workgroup against the box of its 256 points
+        if (gx >= 8 && !plain) {
+            // more than a few workgroups of points: triangles culled per workgroup against the box of its 256 points
             hipLaunchKernelGGL(mesh_locate_cull_kernel, dim3(gx), dim3(256), 0, ctx->stream, K, pts, T, box, v_mov, tris, tid);
         } else {
             // few points: every point walks the triangle boxes; the triangle range is split over blockIdx.y to fill the chip

@@ -457,7 +457,7 @@ def test_device_point_location_vs_matplotlib(fb):
 def test_point_location_culled_kernel_equals_the_plain_walk(fb):
     """fb_mesh_locate_dev takes large point sets through the workgroup-culled kernel (triangles tested against the box of a
     workgroup's 256 points first): a raster, random points and points exactly ON vertices / edge midpoints (several triangles
-    contain them: the smallest index wins) get the same triangle as the plain walk, which lists of fewer than 16 384 points take"""
+    contain them: the smallest index wins) get the same triangle as the plain walk, which lists of fewer than 2 048 points take"""
     from feabas_amd import constant as const
     rng = np.random.default_rng(52)
     _, M = _meshes(rng, extent=(1500, 1100), spacing=25.0, warp=5.0, offset=(-3.0, 8.5))
@@ -470,6 +470,6 @@ def test_point_location_culled_kernel_equals_the_plain_walk(fb):
     pts = np.concatenate((raster, v, mid, np.stack((rng.uniform(-30, 1530, 9000), rng.uniform(-30, 1130, 9000)), -1)))
     assert pts.shape[0] > 2 * 16384
     got = M.tri_finder(pts, gear=g)
-    exp = np.concatenate([M.tri_finder(pts[a:a + 8000], gear=g) for a in range(0, pts.shape[0], 8000)])
+    exp = np.concatenate([M.tri_finder(pts[a:a + 1500], gear=g) for a in range(0, pts.shape[0], 1500)])
     np.testing.assert_array_equal(got, exp)
     assert (got >= 0).mean() > 0.8 and (got < 0).sum() > 100

@@ -17,6 +17,7 @@ def main():
     ap.add_argument('--size', type=int, default=8192)
     ap.add_argument('--mesh-size', type=float, default=100.0)
     ap.add_argument('--profile', action='store_true', help='cProfile of a third repetition')
+    ap.add_argument('--kernels', action='store_true', help='event profile of the kernels of a further repetition')
     args = ap.parse_args()
     S = args.size
     rng = np.random.default_rng(0)
@@ -58,6 +59,20 @@ def main():
         err = np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)
         print(f'rep {rep}: {dt:.3f} s, rounds {[(r["blocks"], r["kept"], round(r["max_dis"], 2), r["solve"].get("iters")) for r in trace]}, '
               f'{xy0.shape[0]} matches, median error {np.median(err):.3f} px, 95 % {np.quantile(err, 0.95):.3f} px')
+
+    if args.kernels:
+        from feabas_amd import _lib
+        lib, ctx = _lib.load(), _lib.ctx()
+        m0, m1 = meshes[0].copy(), meshes[1].copy()
+        lib.fb_prof_reset(ctx); lib.fb_prof_enable(ctx, 1)
+        t0 = time.perf_counter()
+        matcher.section_matcher(m0, m1, images[0], images[1], spacings=[280, 70], conf_thresh=0.3, residue_len=3.0)
+        dt = time.perf_counter() - t0
+        lib.fb_prof_enable(ctx, 0)
+        snap = _lib.prof_snapshot()
+        print(f'with the event profile on: {dt:.3f} s; kernels {sum(v[1] for v in snap.values()):.2f} ms')
+        for k, v in sorted(snap.items(), key=lambda kv: -kv[1][1])[:16]:
+            print(f'   {k:26s} launches {v[0]:4d}  {v[1]:8.3f} ms')
 
 
 if __name__ == '__main__':
