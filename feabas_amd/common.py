@@ -73,8 +73,10 @@ def area_resize(img, fx, fy=None):
     h, w = shp[-2:]
     n = int(np.prod(shp[:-2])) if img.ndim > 2 else 1
     out = np.empty(shp[:-2] + (resize_size(h, fy), resize_size(w, fx)), dtype=np.uint8)
-    if out.size == 0:
+    if out.shape[-1] == 0 or out.shape[-2] == 0:
         raise ValueError(f'area_resize: a {h} x {w} image shrinks to nothing at ({fy}, {fx})')
+    if n == 0:
+        return out
     _lib.check(_lib.load().fb_area_resize(_lib.ctx(), _lib.ptr(img), n, h, w, float(fx), float(fy), _lib.ptr(out)))
     return out
 
