@@ -1242,7 +1242,11 @@ int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, 
         int it1 = 0, it2 = 0, it3 = 0;
         double rr = 0.0;
         if ((rc = fb_bsr_setup_jacobi(ctx, s->M, 1))) return rc;
+        // ... or fewer: from 128 iterations on the Jacobi leg projects what it still needs from the decay of its residual over the
+        // last 64 iterations and ends once the projection passes 1.5 x the budget (CG speeds up as it goes: early projections are high)
+        s->M->probe_limit = budget + budget / 2;
         rc = fb_bsr_pcg_dev(ctx, s->M, rtol, atol, cap1, 0, &it1, &rr);
+        s->M->probe_limit = 0;
         if (rc) return rc;
         const double bn = s->M->last_bnorm;
         const double tol = std::max(rtol, (atol > 0.0 && bn > 0.0) ? atol / bn : 0.0);

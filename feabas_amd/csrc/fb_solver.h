@@ -27,6 +27,10 @@ struct fb_bsr {
     fb_pcg_state* state = nullptr;
     double diag_max = 0.0;
     double last_bnorm = 0.0;    // ||b|| of the last fb_bsr_pcg_dev
+    // fb_bsr_pcg_dev stops early (probe_stopped) once the iterations it projects from the decay of the residual over the last
+    // 64 exceed probe_limit (0: no projection) -- the 'auto' policy of fb_sys_solve hands such a solve to the multigrid
+    int probe_limit = 0;
+    bool probe_stopped = false;
     // one batch of Jacobi-PCG iterations (no first-iteration special case) as an executable graph: small
     // systems are bound by the launch rate of the two kernels per iteration, not by their run time
     hipGraphExec_t pcg_graph = nullptr;

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(kT) void bsr_spmv_kernel(
             if (threadIdx.x == 0 && blockIdx.x == 0) { st->flag = 1; st->iter = iter; st->rr = rr; }
             return;
         }
+        if (threadIdx.x == 0 && blockIdx.x == 0) st->rr = rr;         // (the host reads the decay of the residual between its checks)
         if (iter > 0) beta = rzn / rzo;
     }
     double acc_dot = 0.0, acc_pp = 0.0;
@@ -570,6 +571,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
     }
     const double bnorm = std::sqrt(bb);
     M->last_bnorm = bnorm;
+    M->probe_stopped = false;
     double tol = rtol;
     if (atol > 0.0) tol = std::max(tol, atol / bnorm);               // optimizer.py:1993-1996
     if (fixed_iters > 0) tol = 0.0;
@@ -603,6 +605,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
         hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->r, M->z, M->minv, part_rz[1], part_rr[1]);
         int it = 0;
         bool stop = false;
+        double hist_rr[3] = {rr, rr, rr}; int hist_it[3] = {0, 0, 0};      // residual^2 at the last three checks of this leg
         auto iterate = [&](int i) {                           // one iteration = two launches; `i` is the index inside the leg
             const int cur = i & 1, prev = cur ^ 1;            // K2 of iteration `i` writes slot cur; slot prev holds r_i.z_i
             double2* p_new = cur ? M->p1 : M->p0;
@@ -652,9 +655,27 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
                 total_iters += hs.iter;
                 if (iters_out) *iters_out = total_iters;
                 return fb_fail(ctx, FB_ERR_BREAKDOWN, "PCG breakdown at iteration %d: p^T A p <= 0 (matrix not positive semi-definite)", total_iters);
+            } else if (M->probe_limit > 0 && fixed_iters <= 0 && hs.rr > 0.0) {
+                // iterations still needed at the decay of the last two checks (64 iterations); a stalled residual projects to infinity
+                hist_rr[0] = hist_rr[1]; hist_rr[1] = hist_rr[2]; hist_rr[2] = hs.rr;
+                hist_it[0] = hist_it[1]; hist_it[1] = hist_it[2]; hist_it[2] = it;
+                if (it >= 4 * check_every && hist_it[2] > hist_it[0]) {
+                    const double decay = 0.5 * std::log(hist_rr[2] / hist_rr[0]) / (double)(hist_it[2] - hist_it[0]);     // per iteration, of the norm
+                    const double togo = 0.5 * std::log(hs.tol2bb / hist_rr[2]);                                            // (< 0)
+                    const double need = decay < 0.0 ? togo / decay : INFINITY;
+                    if ((double)(total_iters + it) + need > (double)M->probe_limit) { M->probe_stopped = true; stop = true; }
+                }
             }
         }
         total_iters += it;
+        if (M->probe_stopped) {
+            // the true residual of the iterate reached, then out (like an iteration cap)
+            hipLaunchKernelGGL(bsr_spmv_kernel<2>, dim3(g1), dim3(kT), 0, ctx->stream, M->d, M->x, nullptr, nullptr, M->r, M->b,
+                               part_tmp, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0);
+            if ((rc = host_sum(part_tmp, g1, &rr))) return rc;
+            relres = std::sqrt(rr) / bnorm;
+            break;
+        }
         if (fixed_iters > 0) {
             // report the true residual after the fixed number of iterations
             hipLaunchKernelGGL(bsr_spmv_kernel<2>, dim3(g1), dim3(kT), 0, ctx->stream, M->d, M->x, nullptr, nullptr, M->r, M->b,
@@ -666,7 +687,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
     }
     if (iters_out) *iters_out = total_iters;
     if (relres_out) *relres_out = relres;
-    if (fixed_iters <= 0 && relres > tol && maxiter < 0)
+    if (fixed_iters <= 0 && relres > tol && maxiter < 0 && !M->probe_stopped)
         return fb_fail(ctx, FB_ERR_NOCONV, "PCG stopped at relative residual %.3e > %.3e after %d iterations", relres, tol, total_iters);
     return FB_OK;
 }

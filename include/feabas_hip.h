@@ -458,8 +458,8 @@ int fb_sys_get(fb_ctx* ctx, fb_system* sys, int which, void* out);
  * Galerkin coarse operators, V(1,1) cycles with damped block Jacobi, coarsest level inverted directly; same fixed point as
  * precond 1, an order of magnitude fewer iterations on weakly pinned meshes.  Needs the meshes' stiffness assembled
  * (fb_sys_assemble_mesh*: the vertex coordinates of the aggregates are taken from there).
- * precond 3 = 'auto': precond 1 for the number of iterations a multigrid solve of this size costs in all (~30 ms), then
- * precond 2 from the iterate reached; a hierarchy that cannot be built or stalls hands the iterate back to precond 1.)
+ * precond 3 = 'auto': precond 1 for at most the number of iterations a multigrid solve of this size costs in all (~30 ms; it
+ * gives up earlier once the decay of its residual projects more than 1.5 x that), then precond 2 from the iterate reached; a hierarchy that cannot be built or stalls hands the iterate back to precond 1.)
  * optimizer.solve (optimizer.py:1945-2080) fixed point: Jacobi-preconditioned CG
  * on the symmetrised CSR system until ||Ax-b|| <= max(rtol, atol/||b||) ||b||.
  * x holds x0 on entry when use_x0 != 0.  precond: 0 none, 1 reference Jacobi

@@ -693,8 +693,8 @@ def test_multigrid_on_a_floating_pair_beats_the_jacobi_pcg(fb):
 
 def test_precondition_auto_is_the_jacobi_pcg_inside_its_budget_and_multigrid_beyond(fb):
     """precondition='auto' (fb_sys_solve precond 3): a solve the Jacobi-PCG finishes inside the iteration budget is that solve bit
-    for bit; a weakly pinned 125 k-node mesh (6 matches) exhausts the budget (1 327 iterations at this size), the multigrid-PCG takes the iterate over and the
-    rest takes a fraction of the Jacobi iterations it replaces -- the same displacement field to the tolerance"""
+    for bit; a weakly pinned 125 k-node mesh (6 matches) would exhaust the budget (1 327 iterations at this size): the Jacobi leg projects that from the
+    decay of its residual after 128 iterations, the multigrid-PCG takes the iterate over and the rest takes a fraction of the Jacobi iterations it replaces -- the same displacement field to the tolerance"""
     import bench
     out = {}
     for nlinks in (20000, 6):
@@ -707,7 +707,7 @@ def test_precondition_auto_is_the_jacobi_pcg_inside_its_budget_and_multigrid_bey
     np.testing.assert_array_equal(out[20000, 'auto'][1], out[20000, 'jacobi'][1])
     it_j, it_a = out[6, 'jacobi'][0], out[6, 'auto'][0]
     budget = 1327
-    assert it_j > budget + 500 and budget < it_a < budget + 0.25 * (it_j - budget), (it_j, it_a)
+    assert it_j > budget + 500 and 128 <= it_a < 0.25 * it_j, (it_j, it_a)           # handed over at the first projection past 1.5 x the budget
     move = np.abs(out[6, 'jacobi'][1] - bench.build_fem_system(354, 6, seed=3).meshes[1].vertices_w_offset(1)).max()
     np.testing.assert_allclose(out[6, 'auto'][1], out[6, 'jacobi'][1], atol=2e-4 * move)
 
