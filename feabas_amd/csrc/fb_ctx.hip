@@ -344,12 +344,18 @@ int fb_free(fb_ctx* ctx, void* dptr) {
             const auto blk = ctx->owned[i];
             ctx->owned.erase(ctx->owned.begin() + i);
             FB_HIP(ctx, hipStreamSynchronize(ctx->stream));       // nothing enqueued on this context still uses the block
-            if (ctx->free_bytes + blk.second <= ctx->free_limit) {
-                ctx->free_blocks.push_back(blk);
-                ctx->free_bytes += blk.second;
-            } else {
-                FB_HIP(ctx, hipFree(dptr));
+            if (blk.second > ctx->free_limit) { FB_HIP(ctx, hipFree(dptr)); return FB_OK; }
+            // the block just freed is the one most likely to be asked for again: when the cache is full the OLDEST kept blocks make
+            // room (a phase that worked on a few multi-GB buffers otherwise leaves the cache full of blocks nobody fits into, and
+            // every temporary of the next phase pays hipMalloc / hipFree: +10-20 ms per section pair at the end of bench.py)
+            while (ctx->free_bytes + blk.second > ctx->free_limit && !ctx->free_blocks.empty()) {
+                const auto old = ctx->free_blocks.front();
+                ctx->free_blocks.erase(ctx->free_blocks.begin());
+                ctx->free_bytes -= old.second;
+                FB_HIP(ctx, hipFree(old.first));
             }
+            ctx->free_blocks.push_back(blk);
+            ctx->free_bytes += blk.second;
             return FB_OK;
         }
     }
