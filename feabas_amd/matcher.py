@@ -928,11 +928,32 @@ def _check_strips(img0, img1, coarse_downsample, contiguous=True):
     return img0, img1
 
 
+def _overlap_statistics(raw0, raw1, flt0, flt1, valid0, valid1, tx, ty, band_passed):
+    """photometric record of a pair (matcher.py:279-314): over the window where image 0, shifted by the integer translation
+    (tx, ty), overlaps image 1, and where both masks hold -- (mean grey 0, mean grey 1, mean |DoG| 0, mean |DoG| 1) when the images
+    were band-passed, (mean 0, mean 1, std 0, std 1) of the unfiltered images otherwise; None when image 0's mask leaves three pixels
+    or fewer inside the window"""
+    window, _ = common.intersect_bbox((tx, ty, flt0.shape[1] + tx, flt0.shape[0] + ty), (0, 0, flt1.shape[1], flt1.shape[0]))
+    x_lo, y_lo, x_hi, y_hi = (int(v) for v in window)
+    in0 = (slice(y_lo - ty, y_hi - ty), slice(x_lo - tx, x_hi - tx))
+    in1 = (slice(y_lo, y_hi), slice(x_lo, x_hi))
+    everywhere = np.ones((y_hi - y_lo, x_hi - x_lo), dtype=bool)
+    ok0 = everywhere if valid0 is None else valid0[in0]
+    ok1 = everywhere if valid1 is None else valid1[in1]
+    if np.sum(ok0) <= 3:
+        return None
+    both = ok0 & ok1
+    if band_passed:
+        return (np.mean(raw0[in0][both]), np.mean(raw1[in1][both]), np.mean(np.abs(flt0[in0][both])), np.mean(np.abs(flt1[in1][both])))
+    return (np.mean(flt0[in0][both]), np.mean(flt1[in1][both]), np.std(flt0[in0][both]), np.std(flt1[in1][both]))
+
+
 def _stitching_matcher_general(img0, img1, opts, mask0, mask1, compute_photometric):
-    """feabas/matcher.py:224-367 statement by statement for the pairs the batched strip pipeline does not take -- strips of
-    UNEQUAL shape (the reference works on whatever the two crops are, matcher.py:244) or spacings relative to the overlap
-    (< 1, matcher.py:343-350): x0.5 area downsample, DoG and the global translation on the device, two cartesian meshes of
-    their own size, and the general-mesh loop ``iterative_xcorr_matcher_w_mesh`` (device renderer + NCC + SLM)."""
+    """The pairs the batched strip pipeline does not take -- strips of UNEQUAL shape (the reference works on whatever the two
+    crops are, matcher.py:244), spacings relative to the overlap (< 1, matcher.py:343-350), shrinking factors other than the
+    defaults -- through the same stages as feabas/matcher.py:224-367: area resize, DoG and the global translation on the
+    device, the statistics of the overlap when asked for, two cartesian meshes of the fine images' sizes and the general-mesh
+    loop ``iterative_xcorr_matcher_w_mesh`` (device renderer + NCC + SLM); coordinates come back in pixels of the strips."""
     from . import renderer as _rd
     from .mesh import Mesh
     sigma, cds = opts['sigma'], opts['coarse_downsample']
@@ -956,20 +977,7 @@ def _stitching_matcher_general(img0, img1, opts, mask0, mask1, compute_photometr
     tx0, ty0, conf0 = global_translation_matcher(g0, g1, conf_mode=conf_mode, conf_thresh=conf_thresh)
     if conf0 < conf_thresh:
         return None, None, conf_thresh, None, None
-    phtm = None
-    if compute_photometric:                                                   # matcher.py:279-314
-        txx, tyy = int(tx0), int(ty0)
-        bb, _ = common.intersect_bbox((txx, tyy, g0.shape[1] + txx, g0.shape[0] + tyy), (0, 0, g1.shape[1], g1.shape[0]))
-        xa, ya, xb, yb = (int(v) for v in bb)
-        i0 = (slice(ya - tyy, yb - tyy), slice(xa - txx, xb - txx)); i1 = (slice(ya, yb), slice(xa, xb))
-        m0p = np.ones((yb - ya, xb - xa), dtype=bool) if mg0 is None else mg0[i0]
-        m1p = np.ones((yb - ya, xb - xa), dtype=bool) if mg1 is None else mg1[i1]
-        mp = m0p & m1p
-        if np.sum(m0p) > 3:
-            if sigma > 0:
-                phtm = (np.mean(r0[i0][mp]), np.mean(r1[i1][mp]), np.mean(np.abs(g0[i0][mp])), np.mean(np.abs(g1[i1][mp])))
-            else:
-                phtm = (np.mean(g0[i0][mp]), np.mean(g1[i1][mp]), np.std(g0[i0][mp]), np.std(g1[i1][mp]))
+    phtm = _overlap_statistics(r0, r1, g0, g1, mg0, mg1, int(tx0), int(ty0), sigma > 0) if compute_photometric else None
     if fds == cds:                                                            # matcher.py:315-317
         f0, f1 = g0, g1
     else:                                                                     # matcher.py:318-337
