@@ -7,8 +7,6 @@ affine approximator (global fit, per-block fit over the triangles that touch the
 Outside the scope here (the reference's optional modes): several regions / collision weights (MESH_TRIFINDER_INNERMOST),
 geodesic masks, multichannel images, a renderer resolution different from the loader's.
 """
-import ctypes as C
-
 import numpy as np
 
 from . import _lib
