@@ -798,6 +798,11 @@ def main():
     shapes = {'LR': (T, ov), 'UD': (ov, T)}
     strips = {}
     matchers = {}
+    # host threads of this rank: the flag, capped by the CPUs the rank may use (the ranks of a node share its quota; the threads mostly wait
+    # for their stream, so a floor of 4 stays -- fewer leaves the device idle between sub-batches)
+    budget = _lib.cpu_budget()
+    if args.host_threads > max(4, budget):
+        args.host_threads = max(4, budget)
     mper = max(1, args.host_threads // 2)          # matcher instances per orientation: one per host thread
     for k, (H, W) in shapes.items():
         s0 = _lib.DeviceBuffer(n_res * H * W); s1 = _lib.DeviceBuffer(n_res * H * W); sh = _lib.DeviceBuffer(n_res * 8)

@@ -53,7 +53,12 @@ def cpu_budget():
             n = min(n, max(1, q // per))
     except (OSError, ValueError):
         pass
-    return n
+    # the ranks of one node share the mask and the quota (one process per GPU under torch.distributed.run)
+    try:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', '1'))
+    except ValueError:
+        local_world = 1
+    return max(1, n // max(1, local_world))
 
 
 _pool_limiter = None
