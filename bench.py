@@ -376,7 +376,8 @@ def bench_section_matcher(lib, ctx, _lib, S=8192, mesh_size=100.0, reps=3):
                 rounds=[dict(blocks=int(r['blocks']), kept=int(r['kept']), max_dis=float(r['max_dis']), solve_iters=r['solve'].get('iters'),
                              precond=r['solve'].get('precond')) for r in trace],
                 note=f'best of {reps} calls of matcher.section_matcher on resident uint8 sections; error = distance of the matched displacement '
-                     'from the injected field at the matched points')
+                     'from the injected field at the matched points; the relaxations between the rounds stop at the reference tolerance '
+                     '0.01 / max(1, max_dis) (matcher.py:685-688; relax_tol=1e-9 converges them: 2 x ~1 400 iterations, +40 ms, same error)')
 
 
 def cpu_baseline_ncc(h0, h1, seconds=20.0):
