@@ -80,6 +80,7 @@ struct PfaParams {
     double* dx;
     double* dy;
     float* conf;
+    int per_xcd;                        // > 0: blocks are dealt to the XCDs in contiguous runs of this length (grid = 8 per_xcd)
 };
 
 // a * exp(-+ 2 pi i M / N) with the constant folded into the instruction operands
@@ -190,7 +191,15 @@ __global__ __launch_bounds__(kPfaThreads) __attribute__((amdgpu_waves_per_eu(FB_
     __shared__ float red[16];
     __shared__ int red_idx;
     __shared__ f2 tw72[AY::kTwiddle || AX::kTwiddle ? 48 : 1];       // exp(-2 pi i m / 72), m < 48 (72-long axes only)
-    const int n = blockIdx.x;
+    // Workgroups go to the XCDs round-robin (blockIdx % 8).  The blocks of a pair follow each other in z-order, and a crop row
+    // of ~290 bytes shares its first and last 128-byte line with the crops beside it: with blockIdx as block index the
+    // neighbours sit on eight different L2s and each fetches those lines again (2.0 x the algorithmic bytes on the counters);
+    // with one contiguous run of blocks per XCD they meet in one L2.
+    int n = blockIdx.x;
+    if (prm.per_xcd > 0) {
+        n = (n & 7) * prm.per_xcd + (n >> 3);
+        if (n >= prm.N) return;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
@@ -480,8 +489,9 @@ __global__ __launch_bounds__(kPfaThreads) __attribute__((amdgpu_waves_per_eu(FB_
 
 template <int NY, int NX>
 void pfa_launch(const PfaParams& p, hipStream_t st) {
-    if (p.aff) hipLaunchKernelGGL((ncc_pfa<NY, NX, true>), dim3(p.N), dim3(kPfaThreads), 0, st, p);
-    else hipLaunchKernelGGL((ncc_pfa<NY, NX, false>), dim3(p.N), dim3(kPfaThreads), 0, st, p);
+    const int grid = p.per_xcd > 0 ? 8 * p.per_xcd : p.N;
+    if (p.aff) hipLaunchKernelGGL((ncc_pfa<NY, NX, true>), dim3(grid), dim3(kPfaThreads), 0, st, p);
+    else hipLaunchKernelGGL((ncc_pfa<NY, NX, false>), dim3(grid), dim3(kPfaThreads), 0, st, p);
 }
 
 }  // namespace
@@ -504,6 +514,8 @@ int fb_ncc_pfa_launch(fb_ctx* ctx, const float* img0, const float* img1, int N, 
     p.img0 = img0; p.img1 = img1; p.blk = blk; p.aff = blk ? aff1 : nullptr;
     p.IH0 = IH0; p.IW0 = IW0; p.IH1 = IH1; p.IW1 = IW1;
     p.dx = dx; p.dy = dy; p.conf = conf;
+    static const bool xcd_runs = [] { const char* e = getenv("FEABAS_HIP_PFA_XCD"); return !e || atoi(e) != 0; }();
+    p.per_xcd = (xcd_runs && blk && N >= 64) ? (N + 7) / 8 : 0;
     FB_PROF_B(ctx, "ncc_small_fused", (double)N * (4.0 * ((double)H0 * W0 + (double)H1 * W1) + 20.0));
     if (Fh == 75 && Fw == 75) pfa_launch<75, 75>(p, ctx->stream);
     else if (Fh == 75) pfa_launch<75, 72>(p, ctx->stream);
