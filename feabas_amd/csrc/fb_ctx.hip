@@ -343,7 +343,11 @@ int fb_free(fb_ctx* ctx, void* dptr) {
         if (ctx->owned[i].first == dptr) {
             const auto blk = ctx->owned[i];
             ctx->owned.erase(ctx->owned.begin() + i);
-            FB_HIP(ctx, hipStreamSynchronize(ctx->stream));       // nothing enqueued on this context still uses the block
+            // (from here on the block is in neither list: every error return below first puts it where it can be found again)
+            {
+                const hipError_t se = hipStreamSynchronize(ctx->stream);       // nothing enqueued on this context still uses the block
+                if (se != hipSuccess) { ctx->free_blocks.push_back(blk); ctx->free_bytes += blk.second; return fb_fail(ctx, FB_ERR_HIP, "fb_free: %s", hipGetErrorString(se)); }
+            }
             if (blk.second > ctx->free_limit) { FB_HIP(ctx, hipFree(dptr)); return FB_OK; }
             // the block just freed is the one most likely to be asked for again: when the cache is full the OLDEST kept blocks make
             // room (a phase that worked on a few multi-GB buffers otherwise leaves the cache full of blocks nobody fits into, and
@@ -352,7 +356,13 @@ int fb_free(fb_ctx* ctx, void* dptr) {
                 const auto old = ctx->free_blocks.front();
                 ctx->free_blocks.erase(ctx->free_blocks.begin());
                 ctx->free_bytes -= old.second;
-                FB_HIP(ctx, hipFree(old.first));
+                const hipError_t fe = hipFree(old.first);
+                if (fe != hipSuccess) {
+                    // the evicted block is gone from the books either way; the block being freed still goes into the cache
+                    ctx->free_blocks.push_back(blk);
+                    ctx->free_bytes += blk.second;
+                    return fb_fail(ctx, FB_ERR_HIP, "fb_free: eviction: %s", hipGetErrorString(fe));
+                }
             }
             ctx->free_blocks.push_back(blk);
             ctx->free_bytes += blk.second;

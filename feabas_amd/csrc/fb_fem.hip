@@ -752,15 +752,21 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
         size_t ntri_keys = 0;
         for (auto& m : s->meshes) ntri_keys += 9 * (size_t)m.T;
         const size_t nkeys = ntri_keys + 36 * (size_t)s->nlink + (size_t)nv;
+        // (hipcub takes the number of keys as an int: checked before anything is allocated)
+        if (nkeys >= (size_t)INT_MAX) return fb_fail(ctx, FB_ERR_ARG, "pattern exceeds int32 block indexing");
         void *d_keys = nullptr, *d_keys2 = nullptr, *d_tmp = nullptr, *d_nodes_tmp = nullptr, *d_tri_tmp = nullptr;
-        auto release = [&]() { fb_free(ctx, d_keys); fb_free(ctx, d_keys2); fb_free(ctx, d_tmp); fb_free(ctx, d_nodes_tmp); fb_free(ctx, d_tri_tmp); };
+        // every way out of this block -- the HIP error returns included -- hands the temporaries back to the context's cache
+        struct Release {
+            fb_ctx* c; void **a, **b, **t, **n, **r;
+            ~Release() { fb_free(c, *a); fb_free(c, *b); fb_free(c, *t); fb_free(c, *n); fb_free(c, *r); }
+        } guard{ctx, &d_keys, &d_keys2, &d_tmp, &d_nodes_tmp, &d_tri_tmp};
         if ((rc = fb_malloc(ctx, sizeof(uint64_t) * nkeys, &d_keys))) return rc;
-        if ((rc = fb_malloc(ctx, sizeof(uint64_t) * nkeys, &d_keys2))) { release(); return rc; }
+        if ((rc = fb_malloc(ctx, sizeof(uint64_t) * nkeys, &d_keys2))) return rc;
         size_t at = 0;
         for (auto& m : s->meshes) {
             if (!m.T) continue;
-            if ((rc = fb_malloc(ctx, sizeof(int) * 3 * (size_t)m.T, &d_tri_tmp))) { release(); return rc; }
-            if ((rc = fb_copy_h2d(ctx, d_tri_tmp, m.tri.data(), sizeof(int) * 3 * (size_t)m.T))) { release(); return rc; }
+            if ((rc = fb_malloc(ctx, sizeof(int) * 3 * (size_t)m.T, &d_tri_tmp))) return rc;
+            if ((rc = fb_copy_h2d(ctx, d_tri_tmp, m.tri.data(), sizeof(int) * 3 * (size_t)m.T))) return rc;
             hipLaunchKernelGGL(pattern_tri_keys_kernel, dim3((unsigned)fb_cdiv(m.T, kT)), dim3(kT), 0, ctx->stream, m.T, m.voff, (const int*)d_tri_tmp,
                                (uint64_t*)d_keys + at);
             at += 9 * (size_t)m.T;
@@ -768,8 +774,8 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
             fb_free(ctx, d_tri_tmp); d_tri_tmp = nullptr;
         }
         if (s->nlink) {
-            if ((rc = fb_malloc(ctx, sizeof(int) * 6 * (size_t)s->nlink, &d_nodes_tmp))) { release(); return rc; }
-            if ((rc = fb_copy_h2d(ctx, d_nodes_tmp, s->nodes.data(), sizeof(int) * 6 * (size_t)s->nlink))) { release(); return rc; }
+            if ((rc = fb_malloc(ctx, sizeof(int) * 6 * (size_t)s->nlink, &d_nodes_tmp))) return rc;
+            if ((rc = fb_copy_h2d(ctx, d_nodes_tmp, s->nodes.data(), sizeof(int) * 6 * (size_t)s->nlink))) return rc;
             hipLaunchKernelGGL(pattern_link_keys_kernel, dim3((unsigned)fb_cdiv(s->nlink, kT)), dim3(kT), 0, ctx->stream, s->nlink, (const int*)d_nodes_tmp,
                                (uint64_t*)d_keys + at);
             at += 36 * (size_t)s->nlink;
@@ -783,18 +789,16 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
         int* d_count = reinterpret_cast<int*>(ctx->small);
         FB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, (uint64_t*)d_keys, (uint64_t*)d_keys2, (int)nkeys, 0, 32 + row_bits, ctx->stream));
         FB_HIP(ctx, hipcub::DeviceSelect::Unique(nullptr, tmp_uniq, (uint64_t*)d_keys2, (uint64_t*)d_keys, d_count, (int)nkeys, ctx->stream));
-        if (nkeys >= (size_t)INT_MAX) { release(); return fb_fail(ctx, FB_ERR_ARG, "pattern exceeds int32 block indexing"); }
-        if ((rc = fb_malloc(ctx, std::max<size_t>(std::max(tmp_sort, tmp_uniq), 16), &d_tmp))) { release(); return rc; }
+        if ((rc = fb_malloc(ctx, std::max<size_t>(std::max(tmp_sort, tmp_uniq), 16), &d_tmp))) return rc;
         FB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_sort, (uint64_t*)d_keys, (uint64_t*)d_keys2, (int)nkeys, 0, 32 + row_bits, ctx->stream));
         FB_HIP(ctx, hipcub::DeviceSelect::Unique(d_tmp, tmp_uniq, (uint64_t*)d_keys2, (uint64_t*)d_keys, d_count, (int)nkeys, ctx->stream));
         int nuniq = 0;
-        if ((rc = fb_copy_d2h(ctx, &nuniq, d_count, sizeof(int)))) { release(); return rc; }
+        if ((rc = fb_copy_d2h(ctx, &nuniq, d_count, sizeof(int)))) return rc;
         lap("sort + unique");
         // the key of the dead slots is the tail of the sorted list
         std::vector<uint64_t> hk((size_t)nuniq);
-        if (nuniq && (rc = fb_copy_d2h(ctx, hk.data(), d_keys, sizeof(uint64_t) * (size_t)nuniq))) { release(); return rc; }
+        if (nuniq && (rc = fb_copy_d2h(ctx, hk.data(), d_keys, sizeof(uint64_t) * (size_t)nuniq))) return rc;
         while (!hk.empty() && (hk.back() >> 32) >= (uint64_t)nv) hk.pop_back();
-        release();
         s->browptr.assign((size_t)nv + 1, 0);
         s->bcol.resize(hk.size());
         for (size_t j = 0; j < hk.size(); ++j) {
@@ -1230,6 +1234,7 @@ int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, 
     if (use_x0) { const int rc_ = fb_copy_h2d(ctx, s->M->x, x, sizeof(double2) * (size_t)s->nv); if (rc_) return rc_; }
     else FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
     int rc;
+    if (precond == 3 && maxiter == 0) precond = 1;          // no iterations asked for: the plain path returns the start vector's zeros like every other preconditioner (optimizer.py:1974)
     if (precond == 3) {
         // 'auto': the Jacobi-PCG for as many iterations as a multigrid solve of this size is expected to cost in all (set-up +
         // cycles: ~30 ms; an iteration: 12 us + 0.085 ns per vertex, measured on MI355X), then -- from the iterate reached --
@@ -1252,11 +1257,17 @@ int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, 
         const double tol = std::max(rtol, (atol > 0.0 && bn > 0.0) ? atol / bn : 0.0);
         auto left = [&](int used) { return maxiter > 0 ? maxiter - used : -1; };
         if (rr > tol && (maxiter <= 0 || it1 < maxiter)) {
+            double rr_mg = rr;
             rc = fb_bsr_setup_jacobi(ctx, s->M, 2);
-            if (!rc) rc = sys_solve_mg(ctx, s, rtol, atol, left(it1), &it2, &rr);
+            if (!rc) rc = sys_solve_mg(ctx, s, rtol, atol, left(it1), &it2, &rr_mg);
+            // what the hierarchy may hand back to the Jacobi leg: a stall, a breakdown, a set-up it refuses (FB_ERR_ARG: nothing to
+            // aggregate).  A device or allocation error is an error of the solve.
+            if (rc == FB_ERR_HIP || rc == FB_ERR_NOMEM) return rc;
+            if (!rc || rc == FB_ERR_NOCONV) rr = rr_mg;       // (a failed call may not have written its residual)
             if (rc || rr > tol) {
-                // (M->x holds the last iterate the hierarchy reached; a breakdown leaves it finite or the Jacobi leg restarts from zero)
-                if (!(rr == rr)) FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
+                // M->x holds the last iterate the hierarchy reached; after a breakdown (or a residual that is not a number) the
+                // Jacobi leg restarts from zero
+                if ((rc && rc != FB_ERR_NOCONV) || !(rr == rr)) FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
                 const int rem = left(it1 + it2);
                 if (maxiter <= 0 || rem > 0) {
                     if ((rc = fb_bsr_setup_jacobi(ctx, s->M, 1))) return rc;

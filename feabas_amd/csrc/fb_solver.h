@@ -35,6 +35,7 @@ struct fb_bsr {
     // systems are bound by the launch rate of the two kernels per iteration, not by their run time
     hipGraphExec_t pcg_graph = nullptr;
     int pcg_graph_iters = 0;
+    bool pcg_graph_off = false;      // a capture / instantiation failed once: this matrix stays on plain launches
 };
 
 struct fb_csr {

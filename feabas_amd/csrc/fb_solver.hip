@@ -581,7 +581,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
     const int check_every = 32;
     // launch-bound sizes replay the batch as a graph (not under the per-kernel profiler, whose event pairs
     // sit between the launches)
-    const bool use_graph = !ctx->prof_on && ctx->pcg_graph_max_nb > 0 && nb <= ctx->pcg_graph_max_nb;
+    bool use_graph = !ctx->prof_on && ctx->pcg_graph_max_nb > 0 && nb <= ctx->pcg_graph_max_nb && !M->pcg_graph_off;
     for (int leg = 0; leg < 8; ++leg) {
         // r = b - A x, rr
         {
@@ -630,16 +630,33 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
                 // repeats, the scalars live in M->state): replay them as one graph.  The kernels of the graph
                 // carry the iteration numbers check_every .. 2 check_every - 1; a stop reports one of those.
                 if (!M->pcg_graph) {
+                    // A capture that fails is not a failure of the solve: the plain launches below do the same work.  Whatever
+                    // state the attempt left behind is cleared (the capture is ended, the sticky error read), the graph path is
+                    // switched off for this matrix and the batch runs as launches.
                     hipGraph_t g = nullptr;
-                    FB_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-                    for (int k = 0; k < check_every; ++k) iterate(check_every + k);
-                    const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
-                    if (ce != hipSuccess || !g) return fb_fail(ctx, FB_ERR_HIP, "PCG graph capture: %s", hipGetErrorString(ce));
-                    const hipError_t ie = hipGraphInstantiate(&M->pcg_graph, g, nullptr, nullptr, 0);
-                    hipGraphDestroy(g);
-                    if (ie != hipSuccess) { M->pcg_graph = nullptr; return fb_fail(ctx, FB_ERR_HIP, "PCG graph instantiate: %s", hipGetErrorString(ie)); }
-                    M->pcg_graph_iters = check_every;
+                    hipError_t ge = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+                    if (ge == hipSuccess) {
+                        for (int k = 0; k < check_every; ++k) iterate(check_every + k);
+                        const hipError_t le = hipGetLastError();                   // (a launch refused inside the capture)
+                        ge = hipStreamEndCapture(ctx->stream, &g);                // ends the capture also when it was invalidated
+                        if (ge == hipSuccess && le != hipSuccess) ge = le;
+                        if (ge == hipSuccess && !g) ge = hipErrorUnknown;
+                    }
+                    if (ge == hipSuccess) {
+                        ge = hipGraphInstantiate(&M->pcg_graph, g, nullptr, nullptr, 0);
+                        if (ge != hipSuccess) M->pcg_graph = nullptr;
+                    }
+                    if (g) hipGraphDestroy(g);
+                    if (ge != hipSuccess) {
+                        (void)hipGetLastError();
+                        M->pcg_graph_off = true;
+                        use_graph = false;
+                    } else {
+                        M->pcg_graph_iters = check_every;
+                    }
                 }
+            }
+            if (use_graph && it > 0 && batch == check_every && M->pcg_graph) {
                 FB_HIP(ctx, hipGraphLaunch(M->pcg_graph, ctx->stream));
                 graph_base = it;
                 it += batch;

@@ -442,6 +442,60 @@ _GEAR_NAMES = {const.MESH_GEAR_FIXED: 'fixed', const.MESH_GEAR_MOVING: 'moving',
 _MODEL_NAMES = ('MATERIAL_MODEL_ENG', 'MATERIAL_MODEL_SVK', 'MATERIAL_MODEL_NHK')              # constant.py:37
 
 
+def _material_entry(mesh, uid, model, nu, mult, fk, area_constraint=1.0):
+    entry = {'enable_mesh': True, 'area_constraint': float(area_constraint), 'render': True, 'render_weight': 1.0, 'type': _MODEL_NAMES[model],
+             'stiffness_multiplier': mult, 'poisson_ratio': nu, 'uid': int(uid)}
+    if fk >= 0:
+        f = mesh.stiffness_funcs[fk]
+        entry['stiffness_multiplier'] = float(mesh.func_matmult[fk])
+        entry['stiffness_func_factory'] = 'feabas.material.asymmetrical_elasticity'
+        entry['stiffness_func_params'] = {'strain': f.strain.tolist(), 'stiffness': f.stiffness.tolist()}
+    return entry
+
+
+def _named_material_entries(mesh, base, tri_func):
+    """the table of a mesh that carries NAMED materials (``material_ids`` + ``material_names``, as read from a mesh file or
+    handed over by the mesher; mesh.py:257-263): the names, the uids and the area constraints are written back as they are
+    -- ``optimize_linear(remove_material_dof=name)`` and the refinement regions of ``distribute_matching_blocks`` select by
+    them after the round trip meshing -> matching -> optimisation -- with the constitutive parameters of the triangles of
+    each uid.  None when the mesh has no names or when the triangles of one uid disagree (the caller then writes one
+    synthesized entry per distinct parameter set)."""
+    ids = getattr(mesh, 'material_ids', None)
+    names = getattr(mesh, 'material_names', None)
+    if ids is None or not names:
+        return None
+    ids = np.asarray(ids).ravel()
+    nt = mesh.num_triangles
+    if ids.size != nt:
+        return None
+    if mesh.tri_model is None:
+        rows = np.tile(np.array(base, dtype=np.float64), (nt, 1))
+    else:
+        fk = np.full(nt, -1.0) if tri_func is None else tri_func.astype(np.float64)
+        rows = np.stack((mesh.tri_model.astype(np.float64), mesh.tri_nu, mesh.tri_matmult.astype(np.float64), fk), axis=1)
+    constraints = getattr(mesh, 'material_area_constraints', None) or {}
+    name_of = {}
+    for name, uid in names.items():
+        if int(uid) in name_of:
+            return None                                       # two names for one uid: not a table the reference writes
+        name_of[int(uid)] = name
+    table = {}
+    for uid in sorted(set(name_of) | set(int(u) for u in np.unique(ids))):
+        sel = np.flatnonzero(ids == uid)
+        if sel.size:
+            r = rows[sel[0]]
+            if np.any(rows[sel] != r):
+                return None
+            combo = (int(r[0]), float(r[1]), float(r[2]), int(r[3]))
+        else:
+            combo = base                                      # a named material without triangles in this mesh
+        name = name_of.get(uid, 'default' if uid == 0 and 'default' not in names else f'material_{uid}')
+        table[name] = _material_entry(mesh, uid, *combo, area_constraint=constraints.get(name, 1.0))
+    lo, hi = int(ids.min(initial=0)), int(ids.max(initial=0))
+    dt = np.int8 if -128 <= lo and hi < 128 else (np.int16 if -32768 <= lo and hi < 32768 else np.int32)
+    return ids.astype(dt), table
+
+
 def _material_entries(mesh):
     """(material_ids [T] int8, table dict) of a mesh: one entry per distinct (model, Poisson ratio, multiplier, stiffness
     function); the mesh-wide material is 'default' (uid 0, material.py:333-342).  A stiffness function is written the way the
@@ -449,6 +503,9 @@ def _material_entries(mesh):
     nt = mesh.num_triangles
     base = (0, float(mesh.poisson_ratio), float(mesh.material_multiplier), -1)
     tri_func = getattr(mesh, 'tri_func', None)
+    named = _named_material_entries(mesh, base, tri_func)
+    if named is not None:
+        return named
     if mesh.tri_model is None:
         combos, inv = [base], np.zeros(nt, dtype=np.int64)
     else:
@@ -464,15 +521,7 @@ def _material_entries(mesh):
     table = {}
     for uid, k in enumerate(order):
         uid_of[k] = uid
-        model, nu, mult, fk = combos[k]
-        entry = {'enable_mesh': True, 'area_constraint': 1.0, 'render': True, 'render_weight': 1.0, 'type': _MODEL_NAMES[model],
-                 'stiffness_multiplier': mult, 'poisson_ratio': nu, 'uid': uid}
-        if fk >= 0:
-            f = mesh.stiffness_funcs[fk]
-            entry['stiffness_multiplier'] = float(mesh.func_matmult[fk])
-            entry['stiffness_func_factory'] = 'feabas.material.asymmetrical_elasticity'
-            entry['stiffness_func_params'] = {'strain': f.strain.tolist(), 'stiffness': f.stiffness.tolist()}
-        table['default' if uid == 0 else f'material_{uid}'] = entry
+        table['default' if uid == 0 else f'material_{uid}'] = _material_entry(mesh, uid, *combos[k])
     return uid_of[inv].astype(np.int8 if len(combos) < 128 else np.int16), table
 
 

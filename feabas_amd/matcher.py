@@ -1291,15 +1291,30 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
                     free_q.put(sl)
         except Exception as e:                                # noqa: BLE001 -- re-raised in the calling thread
             errors.append(e)
-            if n_load:                                        # let the loaders and the other matchers run out
+            if n_load:
+                # let the loaders run out: this thread keeps taking what they post -- staged chunks (their slots go back, a
+                # loader may be waiting for one), and END MARKS, which it counts like a healthy matcher does: the 'stop's of
+                # the other matchers are posted by whoever takes the last mark, and a mark swallowed here would leave them
+                # waiting in ready_q.get() for ever.  Its own 'stop' ends the loop.
                 while True:
                     try:
                         got = ready_q.get(timeout=0.05)
                     except queue.Empty:
-                        if all(not th.is_alive() for th in lths):
+                        with take:
+                            done = ended[0] >= n_load
+                        if done and all(not th.is_alive() for th in lths):
                             break
                         continue
-                    if got is not None and got != 'stop':
+                    if got is None:
+                        with take:
+                            ended[0] += 1
+                            last = ended[0] >= n_load
+                        if last:
+                            for _ in range(n_match):
+                                ready_q.put('stop')
+                    elif got == 'stop':
+                        break
+                    else:
                         free_q.put(got[1])
         finally:
             _lib.use_context(None)

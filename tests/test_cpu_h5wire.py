@@ -222,3 +222,51 @@ def test_mesh_file_keeps_the_stiffness_functions(tmp_path):
     assert np.allclose(eff[func < 0], 1.0) and np.allclose(eff[func == 0], 0.4 * 0.5)        # uniform compression: stretch / median = 1
     with pytest.raises(NotImplementedError):
         material.stiffness_func_from_spec('lambda x: x')
+
+
+def test_mesh_file_keeps_the_named_materials(tmp_path):
+    """the names, uids and area constraints of a mesh's material table survive save -> load (the stages meshing ->
+    matching -> optimisation hand meshes over through files): ``triangles_of_material(name)`` selects the same triangles
+    afterwards, two named materials with the SAME constitutive parameters stay two materials, and a second round trip
+    changes nothing"""
+    M0 = Mesh.from_bbox((0, 0, 300, 200), cartesian=True, mesh_size=25)
+    nt = M0.num_triangles
+    c = M0.vertices(const.MESH_GEAR_INITIAL)[M0.triangles].mean(axis=1)
+    ids = np.zeros(nt, dtype=np.int32)
+    ids[c[:, 0] < 80] = 3                                     # 'wrinkle': soft, refined
+    ids[c[:, 0] > 220] = 7                                    # 'refine': same parameters as default, but a refinement region
+    ids[(c[:, 1] > 150) & (ids == 0)] = 50                    # 'hold': stiff
+    names = {'default': 0, 'wrinkle': 3, 'refine': 7, 'hold': 50, 'absent': 9}
+    constraints = {'default': 1.0, 'wrinkle': 0.25, 'refine': 0.5, 'hold': 1.0, 'absent': 0.1}
+    M = Mesh(M0.vertices(const.MESH_GEAR_INITIAL), M0.triangles, uid=2,
+             tri_model=np.zeros(nt, dtype=np.int32), tri_nu=np.where(ids == 50, 0.2, 0.0),
+             tri_matmult=np.where(ids == 3, 0.1, np.where(ids == 50, 8.0, 1.0)),
+             material_ids=ids, material_names=names, material_area_constraints=constraints)
+    fn = str(tmp_path / 'named.h5')
+    M.save_to_h5(fn)
+    with h5wire.H5File(fn) as f:
+        table = json.loads(h5wire.numpy_to_str_ascii(f['material_table']))
+        np.testing.assert_array_equal(np.asarray(f['material_ids']).ravel(), ids)
+    assert {n: m['uid'] for n, m in table.items()} == names
+    assert {n: m['area_constraint'] for n, m in table.items()} == constraints
+    assert table['wrinkle']['stiffness_multiplier'] == pytest.approx(0.1, rel=1e-6) and table['hold']['poisson_ratio'] == 0.2      # (multipliers are float32 in the mesh)
+    assert table['refine']['stiffness_multiplier'] == table['default']['stiffness_multiplier'] == 1.0
+    N = Mesh.from_h5(fn)
+    for name in names:
+        np.testing.assert_array_equal(N.triangles_of_material(name), M.triangles_of_material(name))
+    assert N.triangles_of_material('refine').sum() > 0 and N.triangles_of_material('absent').sum() == 0
+    assert N.material_area_constraints == constraints and N.material_names == names
+    np.testing.assert_array_equal(N.tri_matmult, M.tri_matmult.astype(np.float32))
+    np.testing.assert_array_equal(N.tri_nu, M.tri_nu)
+    fn2 = str(tmp_path / 'named2.h5')
+    N.save_to_h5(fn2)
+    with h5wire.H5File(fn2) as f:
+        assert json.loads(h5wire.numpy_to_str_ascii(f['material_table'])) == table
+    # triangles of one uid that disagree in their parameters cannot be written under one name: synthesized entries instead
+    M.tri_matmult = M.tri_matmult.copy(); M.tri_matmult[np.flatnonzero(ids == 50)[0]] = 2.0
+    fn3 = str(tmp_path / 'named3.h5')
+    M.save_to_h5(fn3)
+    with h5wire.H5File(fn3) as f:
+        t3 = json.loads(h5wire.numpy_to_str_ascii(f['material_table']))
+    assert 'hold' not in t3 and 'default' in t3
+    np.testing.assert_array_equal(Mesh.from_h5(fn3).tri_matmult, M.tri_matmult.astype(np.float32))

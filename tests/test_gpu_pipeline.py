@@ -549,6 +549,37 @@ def test_stitching_matcher_batch_matches_the_per_pair_surface(fb):
     assert not fb.matcher._batch_workers
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('threads', [3, 4, 6])
+def test_stitching_matcher_batch_surfaces_a_matcher_failure(fb, threads, monkeypatch):
+    """a matcher thread that fails (here: the third call of StripBatchMatcher.match raises, like a device OOM in one chunk)
+    must surface its error in the caller -- with loaders and several matchers the failing thread used to swallow the
+    loaders' end marks and the other matchers waited for ever"""
+    import threading
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    cfg = dict(sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
+    pairs = [_warped_pair(512, 256, 90 + k, shift=(k % 3 - 1, 1), warp=0.2) for k in range(12)]
+    calls = [0]
+    lock = threading.Lock()
+    real = StripBatchMatcher.match
+
+    def flaky(self, *a, **kw):
+        with lock:
+            calls[0] += 1
+            n = calls[0]
+        if n == 3:
+            raise RuntimeError('injected failure in one chunk')
+        return real(self, *a, **kw)
+    monkeypatch.setattr(StripBatchMatcher, 'match', flaky)
+    with pytest.raises(RuntimeError, match='injected failure'):
+        fb.matcher.stitching_matcher_batch(pairs, batch=2, threads=threads, **cfg)
+    monkeypatch.setattr(StripBatchMatcher, 'match', real)
+    # the workers are reusable afterwards
+    got = fb.matcher.stitching_matcher_batch(pairs[:4], batch=2, threads=threads, **cfg)
+    assert len(got) == 4 and all(g[0] is not None for g in got)
+    fb.matcher.stitching_matcher_batch_release()
+
+
 def test_config0_readme_grid_matching_stage(fb):
     """BASELINE config[0] (plumbing): the README's 3 x 2 grid of 3000 x 4000 tiles at 10 % overlap, stage jitter of up to
     15 px, through the host mirror of the matching stage (stitcher.find_overlaps -> match_list_of_overlaps): 11 overlaps
