@@ -40,13 +40,13 @@ def test_pair_pipeline_at_the_4k_strip_size_vs_oracle(fb, H, W):
         ndef += int(g['deformed'])
         assert g['xy0'].shape == exp['xy0'].shape and g['xy0'].shape[0] > 300          # 385 fine blocks, most of them confident
         np.testing.assert_array_equal(np.round(g['xy1'] - g['xy0']), np.round(exp['xy1'] - exp['xy0']))
-        # rigid pairs: 1e-4 px; a deformed pair samples image 1 through affine maps that come out of a PCG (1e-9) here and
-        # a sparse LU there: a sample on a 1/32-px rounding boundary may flip and move a sub-pixel peak by ~1e-3
-        tol = 3e-3 if g['deformed'] else 1e-4
+        # rigid and deformed pairs alike: 1e-4 px, 1e-4 on weights and strain (measured, tools/diag_deformed_bars.py: at most 5e-5 px /
+        # 3e-5 / 4e-6 relative on every deformed test pair, whether the device relaxes to 1e-9 or to 1e-13)
+        tol = 1e-4
         np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=tol)
         np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=tol)
-        np.testing.assert_allclose(g['weight'], exp['weight'], atol=2e-3 if g['deformed'] else 1e-4)
-        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=5e-3, atol=1e-6)
+        np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
+        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=1e-4, atol=1e-8)
     assert ndef == 1
     m.free(); d0.free(); d1.free()
 
@@ -158,10 +158,10 @@ def test_corner_pairs_batch_vs_oracle(fb):
         assert (g['tx'], g['ty']) == (exp['tx'], exp['ty'])
         assert g['xy0'].shape == exp['xy0'].shape
         np.testing.assert_array_equal(np.round(g['xy1'] - g['xy0']), np.round(exp['xy1'] - exp['xy0']))
-        tol = 3e-3 if g['deformed'] else 2e-4
+        tol = 1e-4
         np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=tol)
         np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=tol)
-        np.testing.assert_allclose(g['weight'], exp['weight'], atol=2e-3 if g['deformed'] else 1e-4)
+        np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
         dg = g['xy1'] - g['xy0'] + shift[p]; de = exp['xy1'] - exp['xy0'] + shift[p]
         n_got += dg.shape[0]; n_exp += de.shape[0]
         in_got += int(np.sum(np.abs(dg).max(axis=1) < 0.5)); in_exp += int(np.sum(np.abs(de).max(axis=1) < 0.5))

@@ -1,3 +1,4 @@
+        # (the oracle solves exactly, the device by PCG to 1e-9: the matches agree to 5e-5 px, tools/diag_deformed_bars.py)
 """GPU parity of the device-resident tile-pair matcher (feabas_amd/stitch_pipeline.py)
 against the oracle pipeline, on synthetic strips generated on the device."""
 import ctypes as C
@@ -43,7 +44,7 @@ def test_pipeline_vs_oracle(fb, H, W, P):
         np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4)
         np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
         np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
-        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=1e-4, atol=1e-8)
     m.free()
 
 
@@ -250,7 +251,7 @@ def test_pipeline_with_subpixel_warp_vs_oracle(fb):
         np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4)
         np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
         np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
-        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=1e-4, atol=1e-8)
         assert exp['strain'] > 1e-5                      # the warp is seen
         assert np.abs(g['xy1'] - g['xy0'] + shifts[p]).max() < 0.75
     assert nz >= 2
@@ -266,7 +267,7 @@ def test_stitching_matcher_drop_in(fb):
     exp = pipeline_ref.match_pair(h0[0], h1[0])
     assert phtm is None and not exp['needs_host']
     np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4)
-    np.testing.assert_allclose(wt, exp['weight'], atol=1e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(wt, exp['weight'], atol=1e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=1e-4, atol=1e-8)
     # unrelated strips: no match is a value, not an exception (matcher.py:278)
     out = fb.matcher.stitching_matcher(h0[0], h1[1][::-1].copy(), sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33)
     assert out[0] is None and out[1] is None and out[2] == 0.33 and out[3] is None and out[4] is None
@@ -277,8 +278,8 @@ def test_stitching_matcher_drop_in(fb):
     xy0, xy1, wt, strain, _ = fb.matcher.stitching_matcher(h0[0], h1[0], sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, spacings=[60.0, 200.0])
     exp = pipeline_ref.match_pair(h0[0], h1[0], spacings=[60.0, 200.0])
     assert xy0.shape == exp['xy0'].shape
-    np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
-    np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4)
+    np.testing.assert_allclose(wt, exp['weight'], atol=1e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=1e-4, atol=1e-8)
 
 
 @pytest.mark.parametrize('H,W', [(3000, 500), (400, 4000)])
@@ -298,7 +299,7 @@ def test_pipeline_readme_tile_shapes(fb, H, W):
     assert g['xy0'].shape == exp['xy0'].shape and g['xy0'].shape[0] > 100
     np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4); np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
     np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
-    np.testing.assert_allclose(g['strain'], exp['strain'], rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(g['strain'], exp['strain'], rtol=1e-4, atol=1e-8)
     m.free()
 
 
@@ -354,12 +355,52 @@ def test_pipeline_deformed_mesh_between_spacings_vs_oracle(fb, H, W):
             assert np.ptp(field[:, 0]) > 0.5 or np.ptp(field[:, 1]) > 0.5        # really not a translation
         # the exact solve of the oracle and the device PCG (1e-9) give affine maps that differ at the 1e-8 level; a
         # sample position that sits on a 1/32-px rounding boundary may then flip, which moves a sub-pixel peak by ~1e-3
-        np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=3e-3)
-        np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=3e-3)
-        np.testing.assert_allclose(g['weight'], exp['weight'], atol=2e-3)
-        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=5e-3, atol=1e-6)
+        np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4)
+        np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
+        np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
+        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=1e-4, atol=1e-8)
     assert ndef == 2
     m.free(); d0.free(); d1.free()
+
+
+@pytest.mark.parametrize('H,W', [(1536, 120), (120, 1536)])
+def test_relaxation_tolerance_of_the_reference_moves_the_sample_grid_not_the_field(fb, H, W):
+    """the reference stops the relaxation between spacings at a residual of 0.01 / max(1, max_dis) (matcher.py:685-688) with a
+    restarted MINRES; this library converges it (1e-9, so that the result is a property of the system and equals the
+    exact-solve oracle).  What the difference can do to the matches: an unconverged mesh1 puts the fine blocks somewhere
+    else (by a pixel or more), but the DISPLACEMENT FIELD the matches sample is the same -- here: the matches of a run
+    stopped at 1e-2 and at 2e-3 against the field interpolated from the converged run's matches"""
+    from scipy.interpolate import RBFInterpolator
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    pairs = [_warped_pair(H, W, 1, (4, -3), 3.0), _warped_pair(H, W, 3, (1, 5), 2.0)]
+    s0 = np.stack([p[0] for p in pairs]); s1 = np.stack([p[1] for p in pairs])
+    d0 = _lib.DeviceBuffer.from_array(s0); d1 = _lib.DeviceBuffer.from_array(s1)
+    runs = {}
+    for tol in (1e-9, 1e-2, 2e-3):
+        m = StripBatchMatcher(2, H, W, residue_len=2.0, relax_tol=tol)
+        runs[tol] = StripBatchMatcher.per_pair(m.match(d0.ptr, d1.ptr))
+        m.free()
+    for p in range(2):
+        ref = runs[1e-9][p]
+        assert ref['deformed'] and ref['xy0'].shape[0] > 100
+        dref = ref['xy1'] - ref['xy0']
+        f = RBFInterpolator(ref['xy0'], dref, neighbors=12, smoothing=0.0, kernel='thin_plate_spline')
+        # what "the same field" can mean here: the converged run against itself, one half of its matches interpolated at the other
+        half = np.arange(ref['xy0'].shape[0]) % 2 == 0
+        fh = RBFInterpolator(ref['xy0'][half], dref[half], neighbors=12, smoothing=0.0, kernel='thin_plate_spline')
+        own = np.abs(dref[~half] - fh(ref['xy0'][~half])).max(axis=1)
+        inside_lo, inside_hi = ref['xy0'].min(axis=0), ref['xy0'].max(axis=0)
+        for tol in (1e-2, 2e-3):
+            g = runs[tol][p]
+            assert abs(g['xy0'].shape[0] - ref['xy0'].shape[0]) <= 0.05 * ref['xy0'].shape[0]
+            keep = np.all((g['xy0'] >= inside_lo) & (g['xy0'] <= inside_hi), axis=1)
+            err = np.abs(g['xy1'][keep] - g['xy0'][keep] - f(g['xy0'][keep])).max(axis=1)
+            # measured: 0.03-0.07 px median against 0.07-0.10 px of the converged run against itself; strain within 4 %
+            assert np.median(err) <= 1.5 * np.median(own) + 0.02 and np.percentile(err, 90) <= 1.5 * np.percentile(own, 90) + 0.05, \
+                (tol, np.median(err), np.percentile(err, 90), np.median(own), np.percentile(own, 90))
+            assert abs(g['strain'] - ref['strain']) < 0.1 * ref['strain'] + 1e-4
+    d0.free(); d1.free()
 
 
 def test_deformed_round_exact_field_tier_vs_oracle(fb):
@@ -401,8 +442,8 @@ def test_deformed_round_exact_field_tier_vs_oracle(fb):
             good = ec > 0.5
             assert good.sum() > 0.4 * good.size and good[tiers == 3].sum() >= 2
             np.testing.assert_array_equal(np.round(ddx[q][good]), np.round(ex[good]))
-            np.testing.assert_allclose(ddx[q][good], ex[good], atol=1e-3); np.testing.assert_allclose(ddy[q][good], ey[good], atol=1e-3)
-            np.testing.assert_allclose(dcf[q], ec, atol=1e-3)
+            np.testing.assert_allclose(ddx[q][good], ex[good], atol=1e-4); np.testing.assert_allclose(ddy[q][good], ey[good], atol=1e-4)
+            np.testing.assert_allclose(dcf[q], ec, atol=1e-4)
             seen += 1
     assert seen == P
     m.free(); d0.free(); d1.free()
@@ -443,8 +484,8 @@ def test_stitching_matcher_varied_strip_shapes_and_corner_pairs(fb):
         xy0, xy1, wt, strain, _ = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
         exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0)
         assert xy0.shape == exp['xy0'].shape and xy0.shape[0] >= 9
-        np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
-        np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
+        np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4)
+        np.testing.assert_allclose(wt, exp['weight'], atol=1e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=1e-4, atol=1e-8)
         assert np.abs(np.median(xy1 - xy0, axis=0) + np.array([3 - k, 2 * k - 4])).max() < 0.5
     assert len(mt._pair_matchers) <= mt._PAIR_MATCHER_CACHE
 
@@ -458,8 +499,8 @@ def test_stitching_matcher_odd_strip_sizes(fb, H, W):
     xy0, xy1, wt, strain, _ = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
     exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0)
     assert xy0.shape == exp['xy0'].shape and xy0.shape[0] >= 9
-    np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
-    np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4)
+    np.testing.assert_allclose(wt, exp['weight'], atol=1e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=1e-4, atol=1e-8)
     assert np.abs(np.median(xy1 - xy0, axis=0) + np.array([4, -5])).max() < 0.5
 
 
@@ -486,9 +527,9 @@ def test_pipeline_three_spacings_deformed_twice_vs_oracle(fb):
         np.testing.assert_array_equal(m.last_tiers[p], exp['tiers'][-1])
         assert np.abs(m.last_field[p] - exp['mesh1_field']).max() < 1e-5 * max(1.0, np.abs(exp['mesh1_field']).max())
         assert g['xy0'].shape == exp['xy0'].shape and g['xy0'].shape[0] > 200
-        np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=3e-3); np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=3e-3)
-        np.testing.assert_allclose(g['weight'], exp['weight'], atol=2e-3)
-        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=5e-3, atol=1e-6)
+        np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4); np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
+        np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
+        np.testing.assert_allclose(g['strain'], exp['strain'], rtol=1e-4, atol=1e-8)
     m.free(); d0.free(); d1.free()
 
 
@@ -506,8 +547,8 @@ def test_stitching_matcher_masks_and_photometric(fb):
                                                                    mask0=m0, mask1=m1, compute_photometric=True)
         exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0, mask0=m0, mask1=m1, compute_photometric=True)
         assert xy0.shape == exp['xy0'].shape and xy0.shape[0] > 20
-        np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
-        np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
+        np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4)
+        np.testing.assert_allclose(wt, exp['weight'], atol=1e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=1e-4, atol=1e-8)
         np.testing.assert_allclose(phtm, exp['phtm'], rtol=1e-5)
     # the masks matter: without them the blanked regions change the filtered images
     plain = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2)
@@ -622,9 +663,9 @@ def test_config0_readme_grid_matching_stage(fb):
     assert s0.shape == s1.shape == (3000, 500)
     exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0)
     xy0, xy1, wt = matches[(i, j)]
-    np.testing.assert_allclose(xy0 - (b0[:2] - bboxes[i][:2]), exp['xy0'], atol=2e-4)
-    np.testing.assert_allclose(xy1 - (b1[:2] - bboxes[j][:2]), exp['xy1'], atol=2e-4)
-    np.testing.assert_allclose(wt, exp['weight'], atol=2e-4)
+    np.testing.assert_allclose(xy0 - (b0[:2] - bboxes[i][:2]), exp['xy0'], atol=1e-4)
+    np.testing.assert_allclose(xy1 - (b1[:2] - bboxes[j][:2]), exp['xy1'], atol=1e-4)
+    np.testing.assert_allclose(wt, exp['weight'], atol=1e-4)
     fb.matcher.stitching_matcher_batch_release()
     # the match table crosses to the optimisation stage as the Stitcher HDF5 file (stitcher.py:126-222): written and read back
     import os, tempfile
@@ -717,8 +758,8 @@ def test_ragged_batch_with_deformed_meshes_matches_the_per_pair_surface(fb):
         exp = fb.matcher.stitching_matcher(a, b, **cfg)
         g = got[k]
         assert g['xy0'] is not None and g['xy0'].shape == exp[0].shape and g['xy0'].shape[0] > 60
-        np.testing.assert_allclose(g['xy0'], exp[0], atol=2e-4); np.testing.assert_allclose(g['xy1'], exp[1], atol=2e-4)
-        np.testing.assert_allclose(g['weight'], exp[2], atol=2e-4); np.testing.assert_allclose(g['strain'], exp[3], rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(g['xy0'], exp[0], atol=1e-4); np.testing.assert_allclose(g['xy1'], exp[1], atol=1e-4)
+        np.testing.assert_allclose(g['weight'], exp[2], atol=1e-4); np.testing.assert_allclose(g['strain'], exp[3], rtol=1e-4, atol=1e-8)
     m.free(); dev.free()
 
 
@@ -735,8 +776,8 @@ def test_stitching_matcher_threshold_residue_mode(fb):
                                                                residue_mode=mode)
         exp = pipeline_ref.match_pair(s0, s1, residue_len=2.0, residue_mode=mode)
         assert xy0.shape == exp['xy0'].shape
-        np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-4)
-        np.testing.assert_allclose(wt, exp['weight'], atol=2e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=5e-3, atol=1e-6)
+        np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4); np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4)
+        np.testing.assert_allclose(wt, exp['weight'], atol=1e-4); np.testing.assert_allclose(strain, exp['strain'], rtol=1e-4, atol=1e-8)
         if mode == 'threshold':
             n_thr = xy0.shape[0]
             assert (wt > 0).all()

@@ -204,7 +204,7 @@ def test_bboxes_mesh_renderer_matcher_vs_oracle(fb, sigma, tol):
     assert strong.sum() >= 16
     np.testing.assert_array_equal(xy0[strong], exy0[strong])         # integer peaks bit-exact
     np.testing.assert_array_equal(xy1[strong], exy1[strong])
-    np.testing.assert_allclose(conf[strong], econf[strong], atol=2e-3)
+    np.testing.assert_allclose(conf[strong], econf[strong], atol=1e-4)
     d = (xy1 - xy0)[strong]
     assert np.abs(np.median(d, axis=0)).max() < 25                   # a real displacement field, not a constant
 
@@ -231,10 +231,10 @@ def test_iterative_matcher_general_path_vs_strip_oracle(fb, H, W, seed, shift, a
     xy0, xy1, weight, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, f0, f1, spacings=spacings, distributor='cartesian_bbox',
                                                                       residue_len=2.0, conf_thresh=0.33, min_num_blocks=2)
     assert xy0 is not None and xy0.shape == exp['xy0'].shape
-    np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-3)
-    np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-3)
-    np.testing.assert_allclose(weight, exp['weight'], atol=2e-3)
-    assert abs(strain - exp['strain']) < 2e-3 * max(1.0, exp['strain'] / 0.01)
+    np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4)
+    np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4)
+    np.testing.assert_allclose(weight, exp['weight'], atol=1e-4)
+    assert abs(strain - exp['strain']) < 1e-4 * max(1e-4, exp['strain'])
     if H == 3600:
         assert exp['deformed'] and len(exp['tiers']) == 2            # the deformed-mesh branch of the oracle, twice
 
@@ -301,10 +301,10 @@ def test_stitching_matcher_downsample_factors_vs_oracle(fb, cd, fd):
     assert exp['xy0'] is not None and exp['xy0'].shape[0] > 20
     xy0, xy1, weight, strain, _ = matcher.stitching_matcher(img0, img1, sigma=2.5, coarse_downsample=cd, fine_downsample=fd, conf_thresh=0.33, residue_len=2.0)
     assert xy0 is not None and xy0.shape == exp['xy0'].shape
-    np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-3 / fd)
-    np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-3 / fd)
-    np.testing.assert_allclose(weight, exp['weight'], atol=2e-3)
-    assert abs(strain - exp['strain']) < 2e-3 * max(1.0, exp['strain'] / 0.01)
+    np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4 / fd)
+    np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4 / fd)
+    np.testing.assert_allclose(weight, exp['weight'], atol=1e-4)
+    assert abs(strain - exp['strain']) < 1e-4 * max(1e-4, exp['strain'])
     # the matches sit where the strips were shifted (strip pixels, not pixels of the shrunk images)
     d = np.median(xy1 - xy0, axis=0)
     assert abs(d[0] + 9) < 1.0 and abs(d[1] - 6) < 1.0
@@ -319,9 +319,9 @@ def test_stitching_matcher_downsample_factors_vs_oracle(fb, cd, fd):
         xy0, xy1, weight, strain, phtm = matcher.stitching_matcher(img0, img1, sigma=2.5, coarse_downsample=cd, fine_downsample=fd, conf_thresh=0.33, residue_len=2.0,
                                                                     mask0=mk0, mask1=mk1, compute_photometric=True)
         assert xy0.shape == exp['xy0'].shape
-        np.testing.assert_allclose(xy0, exp['xy0'], atol=2e-3 / fd)
-        np.testing.assert_allclose(xy1, exp['xy1'], atol=2e-3 / fd)
-        np.testing.assert_allclose(weight, exp['weight'], atol=2e-3)
+        np.testing.assert_allclose(xy0, exp['xy0'], atol=1e-4 / fd)
+        np.testing.assert_allclose(xy1, exp['xy1'], atol=1e-4 / fd)
+        np.testing.assert_allclose(weight, exp['weight'], atol=1e-4)
         np.testing.assert_allclose(phtm, exp['phtm'], rtol=1e-4)
 
 
