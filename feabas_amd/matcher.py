@@ -249,6 +249,12 @@ class _RegionPair:
         key = (float(res), float(erode))
         if key not in self._rasters:
             x0, y0, x1, y1 = self.bbox
+            # (a pair of meshes whose coordinates ran away -- a relaxation that went wrong upstream -- must fail here with a
+            # message, not take the host down with a raster of 1e10 cells)
+            cells = ((x1 - x0) / res) * ((y1 - y0) / res)
+            if not np.isfinite(cells) or cells > 4e8:
+                raise ValueError(f'distribute_matching_blocks: the common region spans {x1 - x0:.3g} x {y1 - y0:.3g} px at a raster step of {res:.3g}: '
+                                 'the meshes are not where images could be (diverged relaxation?)')
             xs = np.arange(x0 + 0.5 * res, x1, res); ys = np.arange(y0 + 0.5 * res, y1, res)
             xx, yy = np.meshgrid(xs, ys)
             self._rasters[key] = (xs, ys, self.select(np.stack((xx.ravel(), yy.ravel()), axis=-1), erode).reshape(yy.shape))
@@ -266,12 +272,18 @@ def _region2grid_cartesian(region, spacing, erode=0.0, res=None, **kwargs):
     if not msk.any():
         return None
     lab, nlab = ndimage.label(msk, structure=np.ones((3, 3), dtype=bool))
+    # every raster cell -> the label of the nearest cell inside the region: a lattice point in a spur of the region that is
+    # thinner than the raster (no cell centre falls into it) belongs to the part the spur hangs on
+    near = lab if msk.all() else lab[tuple(ndimage.distance_transform_edt(lab == 0, return_distances=False, return_indices=True))]
     cntrs = []
     for k in range(1, nlab + 1):
         rr, cc = np.nonzero(lab == k)
-        rx_mn, rx_mx = xs[cc.min()] - 0.5 * res, xs[cc.max()] + 0.5 * res
-        ry_mn, ry_mx = ys[rr.min()] - 0.5 * res, ys[rr.max()] + 0.5 * res
-        row = min(max(int(round((0.5 * (ry_mn + ry_mx) - ys[0]) / res)), rr.min()), rr.max())
+        # The lattice PHASE comes from the representative point alone; the bounds of the part (matcher.py:1027) only say how
+        # far the lattice reaches.  A spur of the part that the raster does not see can reach far beyond the cells it does
+        # see, so the lattice is laid over the bounds of the whole common region and every point is kept by the two exact
+        # tests: it lies in the region, and the part nearest to it is this one.
+        rx_mn, ry_mn, rx_mx, ry_mx = (float(b) for b in region.bbox)
+        row = min(max(int(round((0.5 * (ys[rr.min()] + ys[rr.max()]) - ys[0]) / res)), rr.min()), rr.max())
         run = np.flatnonzero(lab[row] == k)
         if run.size == 0:                                          # the middle row misses the part (a ring, a C): take its fullest row
             row = rr[np.argmax(np.bincount(rr)[rr])]
@@ -286,14 +298,9 @@ def _region2grid_cartesian(region, spacing, erode=0.0, res=None, **kwargs):
         rv = np.stack((gxx.ravel(), gyy.ravel()), axis=-1)
         if rv.shape[0] == 0:
             continue
-        # part of the lattice point: the label of its raster cell or of a neighbouring one (the raster is coarser than the outline)
         ci = np.clip(np.round((rv[:, 0] - xs[0]) / res).astype(int), 0, xs.size - 1)
         ri = np.clip(np.round((rv[:, 1] - ys[0]) / res).astype(int), 0, ys.size - 1)
-        mine = np.zeros(rv.shape[0], dtype=bool)
-        for dr in (-1, 0, 1):
-            for dc in (-1, 0, 1):
-                mine |= lab[np.clip(ri + dr, 0, ys.size - 1), np.clip(ci + dc, 0, xs.size - 1)] == k
-        rv = rv[mine]
+        rv = rv[near[ri, ci] == k]
         if rv.shape[0]:
             cntrs.append(rv[region.select(rv, erode)])
     cntrs = [c for c in cntrs if c.shape[0]]
@@ -726,7 +733,7 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
             max_dis = float(np.sqrt(np.max(np.sum((xy0 - xy1) ** 2, axis=-1))))
             if trace is not None:
                 trace.append(dict(sp=float(sp), blocks=int(conf.size), kept=int(good.sum()), max_dis=max_dis, pad=bool(pad),
-                                  subpixel=bool(last) if subpixel is None else bool(subpixel), tol=float(tol_render), conf=conf.copy(), bboxes1=boxes1.copy()))
+                                  subpixel=bool(last) if subpixel is None else bool(subpixel), tol=float(tol_render), conf=conf.copy(), bboxes0=boxes0.copy(), bboxes1=boxes1.copy()))
             if plan.advance(max_dis):
                 continue                                # the displacement outran the largest spacing: once more, with larger blocks
             if pair.link(xy0, xy1, wt) == 0:

@@ -6,7 +6,7 @@ import pytest
 from scipy.ndimage import gaussian_filter
 from scipy.spatial import Delaunay
 
-from oracle import fem_ref, ncc_ref, pipeline_ref
+from oracle import fem_ref, ncc_ref, pipeline_ref, region_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -473,3 +473,127 @@ def test_point_location_culled_kernel_equals_the_plain_walk(fb):
     exp = np.concatenate([M.tri_finder(pts[a:a + 1500], gear=g) for a in range(0, pts.shape[0], 1500)])
     np.testing.assert_array_equal(got, exp)
     assert (got >= 0).mean() > 0.8 and (got < 0).sum() > 100
+
+
+# ------------------------------------------------------------------ a8: the region-aware distributor and section_matcher against their oracle
+def _island_pair(rng):
+    """two sections of two islands each (one with a hole), jittered Delaunay meshes, different in the two sections; materials:
+    a 'wrinkle' band (area_constraint 0.25) in section 0, a zone named 'refine_a' (area_constraint 0.5) in section 1"""
+    from feabas_amd.mesh import Mesh
+
+    def islands(r, uid, shift):
+        vs, ts, nv = [], [], 0
+        for (x0, y0, w, h, hole) in ((30, 30, 520, 520, (200, 210, 330, 340)), (640, 90, 380, 420, None)):
+            gx, gy = np.meshgrid(np.arange(x0, x0 + w + 1, 40.0), np.arange(y0, y0 + h + 1, 40.0))
+            v = np.stack((gx.ravel(), gy.ravel()), axis=-1) + shift
+            inner = (gx.ravel() > x0) & (gx.ravel() < x0 + w) & (gy.ravel() > y0) & (gy.ravel() < y0 + h)
+            v[inner] += r.uniform(-0.25, 0.25, (int(inner.sum()), 2)) * 40.0
+            t = Delaunay(v).simplices.astype(np.int32)
+            p = v[t]
+            area = (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1]) - (p[:, 1, 1] - p[:, 0, 1]) * (p[:, 2, 0] - p[:, 0, 0])
+            t[area < 0] = t[area < 0][:, ::-1]
+            c = p.mean(axis=1)
+            if hole is not None:
+                t = t[~((c[:, 0] > hole[0]) & (c[:, 0] < hole[2]) & (c[:, 1] > hole[1]) & (c[:, 1] < hole[3]))]
+            vs.append(v); ts.append(t + nv); nv += v.shape[0]
+        v, t = np.concatenate(vs), np.concatenate(ts)
+        used = np.unique(t)
+        remap = np.full(v.shape[0], -1); remap[used] = np.arange(used.size)
+        return v[used], remap[t].astype(np.int32)
+    v0, t0 = islands(np.random.default_rng(rng.integers(1 << 30)), 0, np.array([0.0, 0.0]))
+    v1, t1 = islands(np.random.default_rng(rng.integers(1 << 30)), 1, np.array([6.0, -4.0]))
+    c0, c1 = v0[t0].mean(axis=1), v1[t1].mean(axis=1)
+    ids0 = np.where((c0[:, 1] > 380) & (c0[:, 0] < 560), 4, 0).astype(np.int32)
+    ids1 = np.where(c1[:, 0] > 860, 7, 0).astype(np.int32)
+    names0, cons0 = {'default': 0, 'wrinkle': 4}, {'default': 1.0, 'wrinkle': 0.25}
+    names1, cons1 = {'default': 0, 'refine_a': 7}, {'default': 1.0, 'refine_a': 0.5}
+    M0 = Mesh(v0, t0, uid=0.0, material_ids=ids0, material_names=names0, material_area_constraints=cons0)
+    M1 = Mesh(v1, t1, uid=1.0, material_ids=ids1, material_names=names1, material_area_constraints=cons1)
+    mats = ((ids0, {n: (u, cons0[n]) for n, u in names0.items()}), (ids1, {n: (u, cons1[n]) for n, u in names1.items()}))
+    return (v0, t0, v1, t1), (M0, M1), mats
+
+
+@pytest.mark.parametrize('case', ['plain', 'boundary', 'refine_both', 'refine_only', 'shrink_pair'])
+def test_distribute_matching_blocks_vs_oracle(fb, case):
+    """SURVEY row a8, distributor: matcher.distribute_matching_blocks ('cartesian_region') against oracle/region_ref.py on two
+    sections of two islands (one with a hole): the blocks of the two agree EXACTLY -- set, sizes and z-order -- once the oracle
+    takes the product's lattice phase part by part (the anchor is GEOS's representative point, which neither side can compute
+    without GEOS: INTEGRATION.md), and the product's own anchors sit within its raster step of the oracle's"""
+    from feabas_amd import matcher, constant as const
+    (v0, t0, v1, t1), (M0, M1), mats = _island_pair(np.random.default_rng(11))
+    kw = dict(plain=dict(refine_mode=0), boundary=dict(refine_mode=0, min_boundary_distance=25),
+              refine_both=dict(refine_mode=2, min_boundary_distance=15), refine_only=dict(refine_mode=1),
+              shrink_pair=dict(refine_mode=0, shrink_factor=(1, 0.6), min_boundary_distance=10))[case]
+    sp = 110.0
+    g0, g1 = matcher.distribute_matching_blocks(M0, M1, sp, gear=const.MESH_GEAR_INITIAL, **kw)
+    assert g0.shape[0] > 20
+    # (1) on the raster the product documents for itself (a quarter of a level's lattice step: connected parts and areas), with
+    #     the product's lattice phase: identical
+    e0, e1 = region_ref.distribute_matching_blocks(v0, t0, v1, t1, sp, materials=mats, anchor_blocks=g0, res=None, **kw)
+    np.testing.assert_array_equal(g0, e0)
+    np.testing.assert_array_equal(g1, e1)
+    if 'refine' in case:
+        sides = np.unique(g0[:, 2] - g0[:, 0])
+        assert sides.size >= 2 + (case == 'refine_both')                      # levels 0.25, 0.5 (and 1.0): different block sizes
+    # (2) on a raster of 1 px (parts as shapely's polygons have them, but for spurs thinner than a pixel): the same blocks except
+    #     where a spur of the region is thinner than the product's raster and hangs on another part than the nearest one
+    #     (one block of 135 in the 'refine_only' case)
+    h0, _ = region_ref.distribute_matching_blocks(v0, t0, v1, t1, sp, materials=mats, anchor_blocks=g0, res=1.0, **kw)
+    gs, hs = set(map(tuple, g0)), set(map(tuple, h0))
+    assert len(gs ^ hs) <= 0.01 * len(gs) + (1 if case == 'refine_only' else 0), (len(gs), len(gs ^ hs))
+    # (3) the product's own lattice phase against the oracle's (no anchors handed over): the same number of blocks up to the
+    #     lattice phase (anchors agree to the product's raster step: the documented difference to shapely)
+    f0, _ = region_ref.distribute_matching_blocks(v0, t0, v1, t1, sp, materials=mats, res=1.0, **kw)
+    assert abs(f0.shape[0] - g0.shape[0]) <= 0.25 * g0.shape[0]
+    for side in np.unique(g0[:, 2] - g0[:, 0]):
+        a = g0[g0[:, 2] - g0[:, 0] == side]; b = f0[f0[:, 2] - f0[:, 0] == side]
+        assert a.shape[0] and b.shape[0]
+
+
+@pytest.mark.skipif(not __import__('os').environ.get('FEABAS_TEST_PENDING'), reason='written after the GPU pool closed for round 5: never run on hardware yet (FEABAS_TEST_PENDING=1 runs it)')
+def test_section_matcher_vs_oracle(fb):
+    """SURVEY row a8 end to end: matcher.section_matcher (cartesian_region lattice with a boundary distance, two spacings, DoG,
+    block NCC through both meshes, relaxation with huber residues, strain) against oracle/region_ref.section_match -- the
+    reference's loop (matcher.py:370-427, 430-778) with every relaxation solved exactly.  Section 0 is LOCKED: the pair then has
+    no soft modes and a PCG at 1e-9 sits on the fixed point (a floating pair has a soft common rotation: at 1e-9 its field is
+    2.7e-3 off the fixed point -- measured, round 5 -- which moves the sample grid of the next round by hundredths of a pixel).
+    Round by round: the same blocks (the oracle takes the lattice phase from the product's blocks, see the distributor test),
+    confidences to 1e-4, mesh field after the relaxation, then matches, weights and strain to 1e-4."""
+    from scipy.ndimage import map_coordinates
+    from feabas_amd import matcher
+    rng = np.random.default_rng(17)
+    (v0, t0, v1, t1), (M0, M1), _ = _island_pair(rng)
+    SH, SW = 600, 1080
+    base = _texture(rng, SH, SW)
+    yy, xx = np.meshgrid(np.arange(SH, dtype=np.float64), np.arange(SW, dtype=np.float64), indexing='ij')
+    ux = 3.0 * np.sin(2 * np.pi * yy / 700.0 + 0.4) + 1.0 * (xx / SW) ** 2
+    uy = 2.5 * np.cos(2 * np.pi * xx / 900.0) - 1.0 * (xx / SW) * (yy / SH)
+    img1 = np.clip(np.rint(map_coordinates(base.astype(np.float32), [yy + uy, xx + ux], order=1, mode='nearest')), 0, 255).astype(np.uint8)
+    for M in (M0, M1):
+        M.material_ids = None; M.material_names = {}; M.material_area_constraints = {}
+    M0.locked = True
+    kw = dict(spacings=[150, 60], sigma=2.5, conf_thresh=0.3, residue_len=3.0, min_boundary_distance=12, stiffness_lambda=0.5)
+    trace = []
+    xy0, xy1, wt, strain = matcher.section_matcher(M0, M1, base, img1, compute_strain=True, relax_tol=1e-9, merge_batches=False, batch_size=100,
+                                                   stiffness_multiplier_threshold=0, trace=trace, **kw)
+    assert xy0 is not None and len(trace) == 2 and trace[1]['blocks'] > 80
+    r0 = fem_ref.RefMesh(v0, t0, uid=0, locked=True); r1 = fem_ref.RefMesh(v1, t1, uid=1)
+    otrace = []
+    ex0, ex1, ewt, estrain = region_ref.section_match(r0, r1, base, img1, compute_strain=True, batch_size=100, anchor_rounds=[t['bboxes0'] for t in trace],
+                                                      trace=otrace, **kw)
+    assert len(otrace) == 2
+    for g, e in zip(trace, otrace):
+        np.testing.assert_allclose(g['bboxes0'], e['bboxes0'], atol=1e-6)
+        np.testing.assert_allclose(g['bboxes1'], e['bboxes1'], atol=1e-6)
+        assert g['pad'] == e['pad']
+        np.testing.assert_allclose(g['conf'], e['conf'], atol=1e-4)
+        if 'field1' in e:
+            assert np.abs(g['field1'] - e['field1']).max() < 1e-4 * max(1.0, np.abs(e['field1']).max())
+    assert xy0.shape == ex0.shape and xy0.shape[0] > 60
+    np.testing.assert_allclose(xy0, ex0, atol=1e-4); np.testing.assert_allclose(xy1, ex1, atol=1e-4)
+    np.testing.assert_allclose(wt, ewt, atol=1e-4)
+    assert abs(strain - estrain) < 1e-4 * max(1e-4, estrain) + 1e-7
+    # and the matches carry the imposed field (q + u(q) = p)
+    ex = 3.0 * np.sin(2 * np.pi * xy1[:, 1] / 700.0 + 0.4) + (xy1[:, 0] / SW) ** 2
+    ey = 2.5 * np.cos(2 * np.pi * xy1[:, 0] / 900.0) - (xy1[:, 0] / SW) * (xy1[:, 1] / SH)
+    assert np.median(np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)) < 0.3
