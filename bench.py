@@ -515,12 +515,7 @@ def bench_stitch_sections(args, lib, _lib, rank, world, ctxs, ex, barrier, reduc
                         strip=list(kinds['LR'][:2]) if grp == 'edge' else list(kinds['corner'][:2]))
     table = np.concatenate(tables, axis=0) if tables else np.zeros((0, 6), np.float32)
     if ex is not None:
-        barrier()
-        t0 = time.time()
-        parts = ex.gatherv(table, root=0)
-        barrier()
-        dt = reduce_max(time.time() - t0)
-        rows = int(sum(p_.shape[0] for p_ in parts)) if parts is not None else None
+        dt, rows = gather_table_timed(ex, table, barrier, reduce_max)
         out['gather'] = dict(seconds=dt, rows_on_root=rows, bytes_on_root=None if rows is None else rows * 24, backend=ex.backend,
                              note='ONE gather of the float32 match table (pair id, xy0, xy1, weight: 24 B per match, the record of stitcher.py:144-151) '
                                   'to rank 0: counts, then point-to-point transfers of exactly the bytes each rank holds')
@@ -622,11 +617,7 @@ def bench_align_sections(args, lib, ctx, _lib, rank, world, ex, barrier, reduce_
                     'sections (matches against locked neighbours stay inside the triangles of the free mesh: fb_sys_update_links); '
                     f'{T} host threads with a context each take the sections round-robin; optimize_linear_seconds_this_rank sums the threads')
     if ex is not None:
-        barrier()
-        t0 = time.time()
-        allx = ex.allgather(disp)
-        barrier()
-        dtg = reduce_max(time.time() - t0)
+        dtg, allx = allgather_timed(ex, disp, barrier, reduce_max)
         out['allgather'] = dict(seconds=dtg, bytes=int(allx.nbytes), backend=ex.backend, shape=list(allx.shape))
         out['sections_per_s_incl_allgather'] = nsec * world / (dt + dtg)
     del slm, units
@@ -699,26 +690,209 @@ def fem_cpu_krylov(A, b, seconds=12.0):
     return out
 
 
+def gather_table_timed(ex, table, barrier, reduce_max):
+    """ONE gather of a rank's float32 match table to rank 0 (Exchange.gatherv: counts, then exactly the bytes every rank
+    holds), bracketed like every timed region.  Returns (seconds, rows on the root or None off the root)."""
+    barrier()
+    t0 = time.time()
+    parts = ex.gatherv(table, root=0)
+    barrier()
+    dt = reduce_max(time.time() - t0)
+    return dt, (int(sum(p_.shape[0] for p_ in parts)) if parts is not None else None)
+
+
+def allgather_timed(ex, arr, barrier, reduce_max):
+    """ONE all-gather of equal blocks (node displacements), bracketed like every timed region.  Returns (seconds, [world, ...])"""
+    barrier()
+    t0 = time.time()
+    allx = ex.allgather(arr)
+    barrier()
+    return reduce_max(time.time() - t0), allx
+
+
+def match_table(batch, P):
+    """the float32 match table of a step: (pair id, xy0, xy1, weight) = 24 B per match, the record the reference stores
+    (stitcher.py:144-151); batch: [(index of the matcher call inside the run, result dict)]"""
+    pid = np.concatenate([res['pair'] + i * P for i, res in batch])
+    return np.concatenate((pid[:, None].astype(np.float32), np.concatenate([r['xy0'] for _, r in batch]).astype(np.float32),
+                           np.concatenate([r['xy1'] for _, r in batch]).astype(np.float32),
+                           np.concatenate([r['weight'] for _, r in batch])[:, None].astype(np.float32)), axis=1)
+
+
+def run_steps_threaded(idx, step, exchange, S, nthr, ctxs, use_context, stagger_ms):
+    """the matcher calls `idx` dealt round-robin to `nthr` host threads (thread k works on context ctxs[k % len(ctxs)]), so that
+    one thread's block-list bookkeeping overlaps the others' kernels (the library serialises calls per context; every call runs
+    completely inside the timed region).  `step(i)` returns a tuple whose third entry is the result of call i; every S results
+    -- in call order, the same order on every rank -- go to `exchange` from ONE extra thread while the workers go on with later
+    calls.  Returns the last call's tuple.  (Module level so that `--dry-run` drives the same code over gloo without a GPU.)"""
+    idx = list(idx)
+    if not idx:
+        return None
+    if nthr <= 1:
+        out = None
+        pending = []
+        for i in idx:
+            out = step(i)
+            pending.append((i, out[2]))
+            if len(pending) == S:
+                exchange(pending); pending = []
+        exchange(pending)
+        return out
+    import threading
+    results = {}
+    errs = []
+    cv = threading.Condition()
+
+    def worker(mine, h, k=0):
+        use_context(h)
+        try:
+            if stagger_ms:
+                time.sleep(1e-3 * stagger_ms * k)
+            for i in mine:
+                if errs:
+                    return
+                r = step(i)
+                with cv:
+                    results[i] = r
+                    cv.notify_all()
+        except Exception as e:                        # noqa: BLE001 -- re-raised below; the other threads must not wait for this one
+            with cv:
+                errs.append(e)
+                cv.notify_all()
+
+    def comm():
+        # a failed gather must not pass for a finished one: the error joins `errs`, the workers stop at their next step and the
+        # exception leaves main() -- a non-zero exit, on which the launcher tears the other ranks (blocked in their transfer) down
+        try:
+            pending = []
+            for i in idx:
+                with cv:
+                    cv.wait_for(lambda: i in results or errs)
+                    if errs:
+                        return
+                    r = results[i]
+                pending.append((i, r[2]))
+                if len(pending) == S:
+                    exchange(pending); pending = []
+            exchange(pending)
+        except BaseException as e:                    # noqa: BLE001
+            with cv:
+                errs.append(e)
+                cv.notify_all()
+    T = nthr
+    ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k], ctxs[k % len(ctxs)], k)) for k in range(T)]
+    ths.append(threading.Thread(target=comm))
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    return results[idx[-1]]
+
+
 def dry_run(args, rank, world):
-    """no GPU: the ranks exercise the sharding and the exchange steps of the sharded workloads over gloo on synthetic tables"""
+    """no GPU: the ranks run the HOST side of every sharded leg of this file over gloo on synthetic results -- the same
+    scheduler (run_steps_threaded), table builder and timed exchange helpers the real run calls, with the shapes and dtypes the
+    legs hand them -- so that the first run on N GPUs cannot fail on host logic (tests/test_cpu_bench_spawn.py)"""
+    import torch
     import torch.distributed as dist
     from feabas_amd import dist as fdist
     ex = fdist.Exchange() if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def reduce_max(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def total(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        return float(tt.item())
+    rng = np.random.default_rng(100 + rank)
+    out = dict(metric='tile_pair_ncc_matches_per_s', value=None, unit='pairs/s', n_gpus=world, dry_run=True, ranks=world,
+               exchange_backend=ex.backend if ex is not None else 'none')
+    # ---- sharding of a global pair list + one gather of a ragged table (the pre-round-5 check, kept)
     nsec = max(1, args.stitch_sections)
     pairs = (760 + 722) * nsec * world
     a, b = fdist.shard_range(pairs, rank, world)
-    rng = np.random.default_rng(rank)
     rows = rng.integers(1, 5, b - a)
     tab = np.concatenate([np.full((r, 6), a + i, dtype=np.float32) for i, r in enumerate(rows)])
     parts = ex.gatherv(tab, root=0) if ex is not None else [tab]
-    sec = fdist.shard_range(max(1, args.align_sections) * world, rank, world)
-    allx = ex.allgather(np.full((sec[1] - sec[0], 4, 2), float(rank))) if ex is not None else np.zeros((1, sec[1] - sec[0], 4, 2))
     if rank == 0:
         ids = np.concatenate([p_[:, 0] for p_ in parts])
-        ok = bool(np.all(np.diff(ids) >= 0) and ids[0] == 0 and ids[-1] == pairs - 1 and np.unique(ids).size == pairs)
-        print(json.dumps(dict(metric='tile_pair_ncc_matches_per_s', value=None, unit='pairs/s', n_gpus=world, dry_run=True, ranks=world,
-                              pair_shards_cover_the_list=ok, gathered_rows=int(ids.size), allgather_shape=list(allx.shape),
-                              exchange_backend=ex.backend if ex is not None else 'none')))
+        out.update(pair_shards_cover_the_list=bool(np.all(np.diff(ids) >= 0) and ids[0] == 0 and ids[-1] == pairs - 1 and np.unique(ids).size == pairs),
+                   gathered_rows=int(ids.size))
+    # ---- headline leg: S matcher calls per step on several host threads, ONE gather per step issued in call order
+    P, S, nthr, W, K = 8, 4, 4, 1, 3
+    sent = dict(calls=0, rows=0, rows_on_root=0)
+
+    def step(i):                                           # a matcher call: (kind, block, result) with a ragged number of matches
+        r_ = np.random.default_rng(1000 * rank + i)
+        n = int(r_.integers(P, 6 * P))
+        res = dict(pair=np.sort(r_.integers(0, P, n)), xy0=r_.random((n, 2)), xy1=r_.random((n, 2)), weight=r_.random(n))
+        time.sleep(0.002 * float(r_.random()))             # calls finish out of order; the gathers must not
+        return 'LR', i % 3, res
+
+    def exchange(batch):
+        if ex is not None and batch:
+            tab_ = match_table(batch, P)
+            assert tab_.dtype == np.float32 and tab_.shape[1] == 6
+            got = ex.gatherv(tab_, root=0)
+            sent['calls'] += 1; sent['rows'] += tab_.shape[0]
+            if got is not None:
+                sent['rows_on_root'] += int(sum(p_.shape[0] for p_ in got))
+    barrier()
+    run_steps_threaded(range(0, W * S), step, exchange, S, nthr, [None], lambda h: None, 1.0)
+    barrier()
+    t0 = time.time()
+    last = run_steps_threaded(range(W * S, (W + K) * S), step, exchange, S, nthr, [None], lambda h: None, 1.0)
+    barrier()
+    dt = reduce_max(time.time() - t0)
+    rows_all = total(sent['rows'])
+    if rank == 0:
+        out['headline'] = dict(gather_calls=sent['calls'], rows_on_root=sent['rows_on_root'], rows_sent_by_all_ranks=int(rows_all), seconds=dt,
+                               last_call=int(last[1]), ok=bool(world == 1 or (sent['calls'] == W + K and sent['rows_on_root'] == int(rows_all))))
+    # ---- stitch_sections leg: the table of a rank's sections (edge + corner pairs), ONE gather
+    tables = [np.asarray(rng.random((int(rng.integers(50, 90)), 6)), dtype=np.float32) for _ in range(2)]
+    table = np.concatenate(tables, axis=0)
+    if ex is not None:
+        dtg, rows_root = gather_table_timed(ex, table, barrier, reduce_max)
+    else:
+        dtg, rows_root = 0.0, int(table.shape[0])
+    rows_all = total(table.shape[0])
+    if rank == 0:
+        out['stitch_sections'] = dict(rows_on_root=rows_root, seconds=dtg, ok=bool(rows_root == int(rows_all)))
+    # ---- align_sections leg: node displacements [sections of the rank][nodes][2], ONE all-gather
+    nalign, nn = max(1, args.align_sections), 4
+    sec = fdist.shard_range(nalign * world, rank, world)
+    disp = np.full((sec[1] - sec[0], nn, 2), float(rank))
+    if ex is not None:
+        dta, allx = allgather_timed(ex, disp, barrier, reduce_max)
+    else:
+        dta, allx = 0.0, disp[None]
+    out_shape = list(allx.shape)
+    ok_align = bool(allx.shape == (world, nalign, nn, 2) and all(np.all(allx[r] == float(r)) for r in range(world)))
+    # ---- fem leg: the displacement vector of a rank's system, ONE all-gather, and the sum of the rates
+    x = np.full((37, 2), 10.0 + rank)
+    if ex is not None:
+        dtf, allf = allgather_timed(ex, x.reshape(-1, 2), barrier, reduce_max)
+    else:
+        dtf, allf = 0.0, x[None]
+    rate = total(1000.0 + rank)
+    if rank == 0:
+        out.update(allgather_shape=out_shape, align_sections=dict(ok=ok_align, seconds=dta),
+                   fem=dict(ok=bool(allf.shape == (world, 37, 2) and np.all(allf[:, 0, 0] == 10.0 + np.arange(world))
+                                    and rate == sum(1000.0 + r for r in range(world))), seconds=dtf, allgather_bytes=int(allf.nbytes)))
+        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         fdist.release_exchanges()
@@ -828,11 +1002,7 @@ def main():
         # the one exchange of the sharded run: every rank's match table of a STEP (S matcher calls) -> rank 0, one gather
         # (counts, then exactly the bytes of every rank over RCCL point-to-point: fb_gatherv_dev)
         if ex is not None and batch:
-            pid = np.concatenate([res['pair'] + i * P for i, res in batch])
-            tab = np.concatenate((pid[:, None].astype(np.float32), np.concatenate([r['xy0'] for _, r in batch]).astype(np.float32),
-                                  np.concatenate([r['xy1'] for _, r in batch]).astype(np.float32),
-                                  np.concatenate([r['weight'] for _, r in batch])[:, None].astype(np.float32)), axis=1)
-            parts = ex.gatherv(tab, root=0)
+            parts = ex.gatherv(match_table(batch, P), root=0)
             gather_stats['calls'] += 1
             if parts is not None:
                 gather_stats['rows_on_root'] += int(sum(p_.shape[0] for p_ in parts))
@@ -853,74 +1023,8 @@ def main():
     stagger_ms = float(os.environ.get("FEABAS_HIP_STAGGER_MS", os.environ.get("FEABAS_BENCH_STAGGER_MS", "3")))      # first call of host thread k offset by k x this: the stagger matcher.stitching_matcher_batch applies to its worker threads
 
     def run_steps(first, count):
-        """`count` steps starting at index `first`, dealt round-robin to the host threads so that one thread's block-list
-        bookkeeping overlaps the others' kernels (the library serialises calls per context; every step runs completely
-        inside the timed region).  Collectives are issued by ONE thread in step order -- the same order on every rank --
-        while the workers go on with later steps."""
-        idx = list(range(first, first + count))
-        if not idx:
-            return None
-        if args.host_threads <= 1:
-            out = None
-            pending = []
-            for i in idx:
-                out = step(i)
-                pending.append((i, out[2]))
-                if len(pending) == S:
-                    exchange(pending); pending = []
-            exchange(pending)
-            return out
-        import threading
-        results = {}
-        errs = []
-        cv = threading.Condition()
-
-        def worker(mine, h, k=0):
-            _lib.use_context(h)
-            try:
-                if stagger_ms:
-                    time.sleep(1e-3 * stagger_ms * k)
-                for i in mine:
-                    if errs:
-                        return
-                    r = step(i)
-                    with cv:
-                        results[i] = r
-                        cv.notify_all()
-            except Exception as e:                        # noqa: BLE001 -- re-raised below; the other threads must not wait for this one
-                with cv:
-                    errs.append(e)
-                    cv.notify_all()
-
-        def comm():
-            # a failed gather must not pass for a finished one: the error joins `errs`, the workers stop at their next step and the
-            # exception leaves main() -- a non-zero exit, on which the launcher tears the other ranks (blocked in their transfer) down
-            try:
-                pending = []
-                for i in idx:
-                    with cv:
-                        cv.wait_for(lambda: i in results or errs)
-                        if errs:
-                            return
-                        r = results[i]
-                    pending.append((i, r[2]))
-                    if len(pending) == S:
-                        exchange(pending); pending = []
-                exchange(pending)
-            except BaseException as e:                    # noqa: BLE001
-                with cv:
-                    errs.append(e)
-                    cv.notify_all()
-        T = nthr
-        ths = [threading.Thread(target=worker, args=([i for i in idx if i % T == k], ctxs[k % len(ctxs)], k)) for k in range(T)]
-        ths.append(threading.Thread(target=comm))
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        if errs:
-            raise errs[0]
-        return results[idx[-1]]
+        return run_steps_threaded(list(range(first, first + count)), step, exchange, S, nthr if args.host_threads > 1 else 1, ctxs,
+                                  _lib.use_context, stagger_ms)
 
     # one-time set-up outside the step count: every matcher instance builds its resident relaxation system, twiddle
     # tables and scratch arena on its first batch (lazy), and every context allocates its arena on first use -- so each
@@ -1099,12 +1203,9 @@ def main():
             m.free()
         args._solo = (world == 1)
         fem = bench_fem(args, lib, ctx, _lib)
-        if dist is not None:
-            barrier()
-            t0 = time.time()
-            allx = ex.allgather(fem.pop('x').reshape(-1, 2))       # one all-gather of the node displacements (fb_allgather_dev)
-            barrier()
-            fem['allgather_displacements_s'] = reduce_max(time.time() - t0)
+        if dist is not None and ex is not None:           # (a one-rank launch under torchrun has a group but nothing to exchange)
+            # one all-gather of the node displacements (fb_allgather_dev)
+            fem['allgather_displacements_s'], allx = allgather_timed(ex, fem.pop('x').reshape(-1, 2), barrier, reduce_max)
             fem['allgather_bytes'] = int(allx.nbytes)
             tt = torch.tensor([fem['iters_per_s']], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)

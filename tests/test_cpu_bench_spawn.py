@@ -23,6 +23,50 @@ def test_gpus2_spawns_two_ranks_and_rank0_prints_one_line():
     assert d['pair_shards_cover_the_list'] is True
     assert d['allgather_shape'] == [2, 3, 4, 2]
     assert d['exchange_backend'] == 'torch'
+    # every sharded leg of the bench through the helpers the real run calls (run_steps_threaded, match_table,
+    # gather_table_timed, allgather_timed): one gather per step in call order although the calls finish out of order on four
+    # host threads, every row of every rank on the root, equal blocks all-gathered rank by rank, rates summed
+    assert d['headline']['ok'] and d['headline']['gather_calls'] == 4 and d['headline']['rows_on_root'] == d['headline']['rows_sent_by_all_ranks'] > 0
+    assert d['stitch_sections']['ok'] and d['align_sections']['ok'] and d['fem']['ok']
+
+
+def test_three_ranks_and_one_rank_take_the_same_code():
+    r = _run('--gpus', '3', '--dry-run', '--stitch-sections', '2', '--align-sections', '2')
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['ranks'] == 3 and d['pair_shards_cover_the_list'] and d['allgather_shape'] == [3, 2, 4, 2]
+    assert d['headline']['ok'] and d['stitch_sections']['ok'] and d['align_sections']['ok'] and d['fem']['ok']
+    r = _run('--dry-run')
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['ranks'] == 1 and d['exchange_backend'] == 'none' and d['headline']['ok'] and d['fem']['ok']
+
+
+def test_a_failing_matcher_call_stops_the_scheduler_instead_of_hanging():
+    """run_steps_threaded: an exception in one worker thread ends the run (the exchange thread must not wait for the result
+    that never comes) and is re-raised"""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module('bench')
+    import pytest
+    seen = []
+
+    def step(i):
+        if i == 5:
+            raise RuntimeError('call 5 failed')
+        return 'LR', i, {'n': i}
+
+    def exchange(batch):
+        seen.append([i for i, _ in batch])
+    with pytest.raises(RuntimeError, match='call 5 failed'):
+        bench.run_steps_threaded(range(12), step, exchange, 4, 3, [None], lambda h: None, 0.0)
+    assert all(b == sorted(b) for b in seen) and (not seen or seen[0] == [0, 1, 2, 3])
+    # the sequential form and the threaded form hand the same batches over, in the same order
+    a, b = [], []
+    ok = lambda i: ('LR', i, {'n': i})
+    bench.run_steps_threaded(range(3, 13), ok, lambda batch: a.append([i for i, _ in batch]), 4, 1, [None], lambda h: None, 0.0)
+    bench.run_steps_threaded(range(3, 13), ok, lambda batch: b.append([i for i, _ in batch]), 4, 4, [None], lambda h: None, 0.0)
+    assert a == b == [[3, 4, 5, 6], [7, 8, 9, 10], [11, 12]]
 
 
 def test_more_ranks_than_gpus_is_an_error_not_a_silent_single_rank():
