@@ -772,7 +772,7 @@ class SLM:
             self.last_solve = dict(iters=iters.value, relres=relres.value, stiffness_lambda=sl, crosslink_lambda=cl)
             if fell_back:
                 self.last_solve['multigrid_fell_back'] = True
-        if cost[1] < cost[0]:                               # optimizer.py:1421
+        if cost[1] < cost[0] and self._solution_is_sane(dd):    # optimizer.py:1421
             offs = self._offs
             for m in self.meshes:
                 o = offs[m.uid]
@@ -780,6 +780,24 @@ class SLM:
                     continue
                 m.set_field(dd[o:o + 2 * m.num_vertices].reshape(-1, 2), gear=(start_gear, target_gear))
         return cost
+
+    def _solution_is_sane(self, dd):
+        """a displacement field that is not finite, or that moves a node by more than a thousand times the extent of all the
+        meshes together, is the null-space drift of a solve that went wrong (a floating system pushed past what doubles can give),
+        never an alignment: it is not applied (the meshes keep their state, like a solve whose residual did not drop), and
+        `last_solve` says so.  Downstream steps size host and device buffers by where the meshes are."""
+        if any(m.locked for m in self.meshes):
+            return True                                       # a locked mesh pins the system: no null space to drift along (and no extra pass over 1e6 unknowns)
+        if not np.all(np.isfinite(dd)):
+            self.last_solve['rejected'] = 'not finite'
+            return False
+        lo = np.min([m.bbox(gear=const.MESH_GEAR_MOVING)[:2] for m in self.meshes], axis=0)
+        hi = np.max([m.bbox(gear=const.MESH_GEAR_MOVING)[2:] for m in self.meshes], axis=0)
+        extent = float(max(np.max(hi - lo), 1.0))
+        if float(np.max(np.abs(dd), initial=0.0)) > 1e3 * extent:
+            self.last_solve['rejected'] = f'displacements up to {float(np.max(np.abs(dd))):.3g} on meshes of extent {extent:.3g}'
+            return False
+        return True
 
     def _material_dof_mask(self, names, groupings):
         """optimizer.py:1320-1359: the regions of the named materials do not take part in the solve -- every vertex of their

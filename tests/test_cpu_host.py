@@ -589,3 +589,22 @@ def test_triangle_edge_deform_host_loop_equals_the_numpy_statement():
     tr = np.roll(t, 1, axis=-1)
     d0 = np.sum((v0[t] - v0[tr]) ** 2, axis=-1); d1 = np.sum((v1[t] - v1[tr]) ** 2, axis=-1)
     np.testing.assert_array_equal(got, np.exp(np.max(np.abs(0.5 * np.log(d1 / d0)), axis=-1)))
+
+
+def test_optimize_linear_does_not_apply_a_runaway_field():
+    """SLM._solution_is_sane: a solved field that is not finite, or that moves nodes by more than a thousand mesh extents (the
+    null-space drift of a floating system pushed past what doubles can give), is not applied -- downstream steps size their
+    buffers by where the meshes are; a system with a locked mesh has no null space and is not screened"""
+    from feabas_amd import mesh, optimizer
+    from oracle import fem_ref
+    v, t = fem_ref.grid_mesh(5, 4, 10.0)
+    m0 = mesh.Mesh(v, t, uid=0); m1 = mesh.Mesh(v + 1.0, t, uid=1)
+    slm = optimizer.SLM([m0, m1], [])
+    n = 2 * (m0.num_vertices + m1.num_vertices)
+    slm.last_solve = {}
+    assert slm._solution_is_sane(np.zeros(n)) and slm._solution_is_sane(np.full(n, 500.0)) and 'rejected' not in slm.last_solve
+    assert not slm._solution_is_sane(np.full(n, 1e9)) and 'extent' in slm.last_solve['rejected']
+    bad = np.zeros(n); bad[3] = np.nan
+    assert not slm._solution_is_sane(bad) and slm.last_solve['rejected'] == 'not finite'
+    m0.locked = True
+    assert slm._solution_is_sane(np.full(n, 1e9))
