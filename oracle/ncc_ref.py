@@ -46,9 +46,13 @@ def fft_shape(shp0, shp1, pad):
 
 
 def xcorr_fft(img0, img1, conf_mode=FFT_CONF_MIRROR, subpixel=False, pad=True,
-              return_surfaces=False):
-    """matcher.py:22-135 with sigma=0, normalize=False, no masks (the only way
-    any call site uses it: matcher.py:153, 213, 846).
+              return_surfaces=False, normalize=False, mask0=None, mask1=None):
+    """matcher.py:22-135 with sigma=0 (the only way any call site uses it:
+    matcher.py:153, 213, 846).  normalize (matcher.py:71-81, 119-122; no call
+    site enables it, pinned by golden G20): the correlation surface is divided by
+    NC = irfft2(conj(M0) M1) of the masks (all ones by default), scaled by its
+    maximum (at least 1) and clipped at 0.1; the mirror surface by the same of
+    irfft2(M0 M1).
 
     img0: (N,H0,W0[,C]) float32, img1: (N,H1,W1[,C]).  Returns dx, dy
     (float64, N), conf (float32, N; float64-derived for STD).
@@ -70,6 +74,14 @@ def xcorr_fft(img0, img1, conf_mode=FFT_CONF_MIRROR, subpixel=False, pad=True,
     C = _fft.irfft2(P, s=(fh, fw), axes=(-2, -1))         # :68
     n = C.shape[0]
     Cf = C.reshape(n, -1)
+    if normalize:                                          # :70-81
+        m0 = np.ones((h0, w0), dtype=img0.dtype) if mask0 is None else np.asarray(mask0)
+        m1 = np.ones((h1, w1), dtype=img1.dtype) if mask1 is None else np.asarray(mask1)
+        M0 = _fft.rfft2(m0, s=(fh, fw))
+        M1 = _fft.rfft2(m1, s=(fh, fw))
+        NC = _fft.irfft2(np.conj(M0) * M1, s=(fh, fw)).reshape(-1, fh * fw)
+        NC = (NC / (NC.max(axis=-1, keepdims=True).clip(1, None))).clip(0.1, None)
+        Cf = Cf / NC
     k = np.argmax(Cf, axis=-1)                             # :82 first max, row-major
     py = k // fw
     px = k % fw
@@ -109,6 +121,10 @@ def xcorr_fft(img0, img1, conf_mode=FFT_CONF_MIRROR, subpixel=False, pad=True,
         if Q.ndim > 3:
             Q = Q.mean(axis=1)
         Cm = np.abs(_fft.irfft2(Q, s=(fh, fw), axes=(-2, -1))).reshape(n, -1)
+        if normalize:                                      # :119-122
+            NCm = _fft.irfft2(M0 * M1, s=(fh, fw)).reshape(-1, fh * fw)
+            NCm = (NCm / (NCm.max(axis=-1, keepdims=True).clip(1, None))).clip(0.1, None)
+            Cm = Cm / NCm
         mx = Cf.max(axis=-1)
         mm = Cm.max(axis=-1)
         conf = np.zeros(n, dtype=np.float32)

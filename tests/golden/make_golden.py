@@ -808,8 +808,38 @@ def g19_area_stretch():
     np.savez_compressed(os.path.join(OUT, 'g19_area_stretch.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G20
+def g20_xcorr_normalized():
+    """xcorr_fft(normalize=True) (matcher.py:71-81, 119-122): the correlation surfaces divided by the clipped, max-normalised
+    correlation of the masks -- with explicit masks (holes), with the default all-ones masks, padded and not, all three confidence
+    modes.  No call site of the reference enables it; pinned for the completeness of row a1."""
+    rng = np.random.default_rng(2020)
+    out = {}
+    H, W, n = 64, 60, 4
+    big = common.masked_dog_filter(to_u8(texture(rng, 4 * H, 4 * W)), 2.0).astype(np.float32)
+    shifts = [(0, 0), (4, -3), (-9, 6), (13, 11)]
+    i0 = np.zeros((n, H, W), np.float32); i1 = np.zeros((n, H, W), np.float32)
+    for k, (sy, sx) in enumerate(shifts):
+        y0 = H + 7 * k; x0 = W + 5 * k
+        i0[k] = big[y0:y0 + H, x0:x0 + W]
+        i1[k] = big[y0 + sy:y0 + sy + H, x0 + sx:x0 + sx + W]
+    i1 += 0.05 * i1.std() * rng.standard_normal(i1.shape).astype(np.float32)
+    m0 = np.ones((H, W), np.float32); m0[:18, :25] = 0; m0[50:, 40:] = 0
+    m1 = np.ones((H, W), np.float32); m1[20:44, 30:] = 0
+    i0m = i0 * m0; i1m = i1 * m1
+    out.update(img0=i0, img1=i1, mask0=m0, mask1=m1)
+    for tag, (a, b, kw) in {'masks': (i0m, i1m, dict(mask0=m0, mask1=m1)), 'ones': (i0, i1, {})}.items():
+        for pad in (True, False):
+            for cm in (0, 1, 2):
+                dx, dy, cf = matcher.xcorr_fft(a, b, conf_mode=cm, pad=pad, subpixel=True, normalize=True, **kw)
+                key = f'{tag}_p{int(pad)}_c{cm}'
+                out[key + '_dx'] = np.asarray(dx, dtype=np.float64); out[key + '_dy'] = np.asarray(dy, dtype=np.float64)
+                out[key + '_conf'] = np.asarray(cf)
+    np.savez_compressed(os.path.join(OUT, 'g20_xcorr_normalized.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -33,6 +33,29 @@ def test_g1_xcorr(case, pad, sub, cm):
     np.testing.assert_allclose(cf, g[key + '_conf'], atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize('tag', ['masks', 'ones'])
+@pytest.mark.parametrize('pad', [1, 0])
+@pytest.mark.parametrize('cm', [0, 1, 2])
+def test_g20_xcorr_normalized(tag, pad, cm):
+    """xcorr_fft(normalize=True) (matcher.py:71-81, 119-122) against the reference: mask-overlap normalisation of both surfaces"""
+    g = load_golden('g20_xcorr_normalized.npz')
+    if tag == 'masks':
+        a, b, kw = g['img0'] * g['mask0'], g['img1'] * g['mask1'], dict(mask0=g['mask0'], mask1=g['mask1'])
+    else:
+        a, b, kw = g['img0'], g['img1'], {}
+    dx, dy, cf = ncc_ref.xcorr_fft(a, b, conf_mode=cm, pad=bool(pad), subpixel=True, normalize=True, **kw)
+    key = f'{tag}_p{pad}_c{cm}'
+    np.testing.assert_array_equal(np.round(dx), np.round(g[key + '_dx']))
+    np.testing.assert_array_equal(np.round(dy), np.round(g[key + '_dy']))
+    np.testing.assert_allclose(dx, g[key + '_dx'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(dy, g[key + '_dy'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(cf, g[key + '_conf'], atol=1e-4, rtol=0)
+    # the normalisation matters on these inputs: without it at least the confidences differ
+    if cm == 2 and tag == 'masks':
+        _, _, cf0 = ncc_ref.xcorr_fft(a, b, conf_mode=cm, pad=bool(pad), subpixel=True)
+        assert np.abs(cf0 - cf).max() > 1e-3
+
+
 @pytest.mark.parametrize('pad', [1, 0])
 def test_g1_xcorr_channels(pad):
     g = load_golden('g1_xcorr.npz')
