@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """every GPU test runs under a timeout of its own (pytest-timeout, 300 s unless the test sets one): a test that hangs
+    -- a kernel that never finishes, a host loop fed by a runaway mesh -- fails there, with a stack dump, instead of holding the
+    box until the caller's limit (a box held to that limit counts against the pool)"""
+    if not config.pluginmanager.hasplugin('timeout'):
+        return
+    for it in items:
+        if it.get_closest_marker('gpu') is not None and it.get_closest_marker('timeout') is None:
+            it.add_marker(pytest.mark.timeout(300, method='thread'))      # 'thread': ends the process even when the main thread sits in a HIP call
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
