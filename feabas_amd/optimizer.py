@@ -805,8 +805,6 @@ class SLM:
         (and is applied first).  The materials are those a Mesh was given as ``material_ids`` + ``material_names`` (the mesh file
         carries both, h5wire.load_mesh_h5); a mesh without them has no named region.  Returns the selector over the degrees of
         freedom of the free meshes (True = solved)."""
-        if groupings is not None:
-            raise NotImplementedError('optimize_linear(remove_material_dof=...) with groupings')
         if isinstance(names, str):
             names = [names]
         elif not isinstance(names, (tuple, list)):
@@ -824,14 +822,30 @@ class SLM:
                 if free_border:
                     solved[m.triangles[~region].ravel()] = True
             parts.append(np.repeat(solved, 2))
-        return np.concatenate(parts)
+        return self._fold_dof_selector(parts, groupings)
+
+    def _fold_dof_selector(self, parts, groupings):
+        """the selector over the degrees of freedom of the free meshes (one boolean array per free mesh, in mesh order; True =
+        solved) in the layout of the system that is solved: concatenated as it is without groupings; with them
+        ``edc = (T_m @ edc) > 0`` (optimizer.py:1412-1413) -- the members of a group share their degrees of freedom, and one
+        is solved when ANY member has it solved (a hold on one member is undone by a member that does not hold it: the
+        reference's rule, golden G21)."""
+        if groupings is None or np.unique(np.asarray(groupings)).size == len(self.meshes):
+            return np.concatenate(parts)
+        offs, ndof, _, _ = self._layout(groupings)
+        out = np.zeros(ndof, dtype=bool)
+        free = [m for m in self.meshes if not m.locked]
+        assert len(free) == len(parts)
+        for m, sel in zip(free, parts):
+            o = offs[m.uid]
+            if o >= 0:                                         # (a free mesh in a group with a locked member is locked with it)
+                out[o:o + sel.size] |= sel
+        return out
 
     def _extra_dof_mask(self, groupings):
         """optimizer.py:1360-1377: a connected subsystem without a locked mesh floats (rigid motion costs nothing); the first
         three degrees of freedom -- vertex 0 and the x of vertex 1 -- of its first mesh are held.  Returns the boolean
         selector over the degrees of freedom of the free meshes (True = solved), or None when nothing floats."""
-        if groupings is not None:
-            raise NotImplementedError('optimize_linear(remove_extra_dof=True) with groupings')
         labels, _ = self.connected_subsystems
         locks = np.asarray(self.lock_flags, dtype=bool)
         first = np.zeros(len(self.meshes), dtype=bool)
@@ -849,7 +863,7 @@ class SLM:
             if flg:
                 sel[:3] = False
             parts.append(sel)
-        return np.concatenate(parts)
+        return self._fold_dof_selector(parts, groupings)
 
     def _optimize_linear_distributed(self, group, owned, tol, atol, maxiter, shape_gear, start_gear, target_gear, stiffness_lambda, crosslink_lambda):
         """optimize_linear of a coupled window (aligner.py:510-535, 696-727: all free sections of a window are ONE system)

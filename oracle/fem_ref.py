@@ -626,9 +626,13 @@ def apply_solution(meshes, dd, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING):
 
 
 def optimize_linear_grouped(meshes, links, groupings, stiffness_lambda=1.0, crosslink_lambda=-1.0,
-                            shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING, return_system=False):
+                            shape_gear=GEAR_FIXED, start_gear=GEAR_MOVING, target_gear=GEAR_MOVING, return_system=False,
+                            remove_extra_dof=False, dof_selector=None):
     """optimizer.py:1378-1437 with `groupings`: the members of a group share their degrees of freedom
-    (T K T^T / mean(count) ...), a group with a locked member is locked; exact solve.  Returns (||b||, ||A d - b||)."""
+    (T K T^T / mean(count) ...), a group with a locked member is locked; exact solve.  Returns (||b||, ||A d - b||).
+    remove_extra_dof / dof_selector: the selector over the degrees of freedom of the free MESHES (optimizer.py:1320-1377) is
+    folded into the groups, `edc = (T_m @ edc) > 0` (optimizer.py:1412-1413): a group's degree of freedom is solved when any
+    member has it solved; held ones leave the system (optimizer.py:1976-1991) and stay zero -- the cost is that of the FULL system."""
     K, stress = system_stiffness(meshes, gear=(shape_gear, start_gear))
     C, rhs = crosslink_terms(meshes, links, start_gear=start_gear, target_gear=target_gear)
     # the lambdas come from the cached MESH-level terms (relative_lambda_trace reads self.stiffness_matrix() /
@@ -664,7 +668,14 @@ def optimize_linear_grouped(meshes, links, groupings, stiffness_lambda=1.0, cros
     A = ls * K + lc * C
     b = lc * rhs - ls * stress
     A = 0.5 * (A + A.T)
-    dd = solve_direct(A, b)
+    edc = dof_selector if dof_selector is not None else (extra_dof_selector(meshes, links) if remove_extra_dof else None)
+    if edc is not None:
+        edc = np.asarray(T @ np.asarray(edc, dtype=np.float32)).ravel() > 0
+    if edc is not None and not edc.all():
+        dd = np.zeros_like(b)
+        dd[edc] = solve_direct(sparse.csr_matrix(A)[edc][:, edc], b[edc])
+    else:
+        dd = solve_direct(A, b)
     cost = (float(np.linalg.norm(b)), float(np.linalg.norm(A.dot(dd) - b)))
     if cost[1] < cost[0]:
         for m, gio in zip(meshes, expanded):

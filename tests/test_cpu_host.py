@@ -608,3 +608,54 @@ def test_optimize_linear_does_not_apply_a_runaway_field():
     assert not slm._solution_is_sane(bad) and slm.last_solve['rejected'] == 'not finite'
     m0.locked = True
     assert slm._solution_is_sane(np.full(n, 1e9))
+
+
+def test_held_dof_selectors_fold_into_groups_like_the_reference():
+    """optimize_linear(groupings=, remove_extra_dof= / remove_material_dof=): the selector over the free meshes' degrees of freedom
+    in the layout of the grouped system, `edc = (T_m @ edc) > 0` (optimizer.py:1412-1413), against the oracle's T_m (pinned by
+    golden G21 from the reference)"""
+    from scipy import sparse
+    from feabas_amd import mesh, optimizer
+    from oracle import fem_ref
+    g = load_golden('g21_grouped_dof.npz')
+    ms = [mesh.Mesh(g[f'm{k}_v'], g[f'm{k}_t'], uid=k, soft_factor=float(g[f'm{k}_soft'])) for k in range(3)]
+    rs = [fem_ref.RefMesh(g[f'm{k}_v'], g[f'm{k}_t'], uid=k) for k in range(3)]
+    links, rlinks = [], []
+    for k in range(2):
+        a, b = g[f'l{k}_ab']
+        args = (g[f'l{k}_tid0'], g[f'l{k}_tid1'], g[f'l{k}_B0'], g[f'l{k}_B1'])
+        links.append(optimizer.Link(ms[a], ms[b], *args, weight=g[f'l{k}_w']))
+        rlinks.append(fem_ref.RefLink(rs[a], rs[b], *args, weight=g[f'l{k}_w']))
+    slm = optimizer.SLM(ms, links)
+
+    def oracle_fold(edc, groupings, meshes):
+        group_u, indx, group_nm, _ = np.unique(groupings, return_index=True, return_inverse=True, return_counts=True)
+        vnum = np.array([meshes[k].num_vertices * 2 for k in indx])
+        goff = np.concatenate(([0], np.cumsum(vnum)[:-1]))
+        i0, i1, cur = [], [], 0
+        for m, gio in zip(meshes, goff[group_nm]):
+            sz = 2 * m.num_vertices
+            i0.append(np.arange(cur, cur + sz)); i1.append(np.arange(gio, gio + sz)); cur += sz
+        T = sparse.csr_matrix((np.ones(cur, dtype=np.float32), (np.concatenate(i1), np.concatenate(i0))), shape=(int(vnum.sum()), cur))
+        return np.asarray(T @ edc.astype(np.float32)).ravel() > 0
+    edc = fem_ref.extra_dof_selector(rs, rlinks)
+    held = slm._extra_dof_mask(g['groupings'])
+    np.testing.assert_array_equal(held, oracle_fold(edc, g['groupings'], rs))
+    assert held.size == 2 * (ms[0].num_vertices + ms[1].num_vertices) and list(np.flatnonzero(~held)) == [0, 1, 2]
+    np.testing.assert_array_equal(slm._extra_dof_mask(None), edc)
+    # a hold on one member of a group is undone by a member that does not hold it: three equal meshes, 0 and 1 grouped
+    eq = [mesh.Mesh(g['m1_v'] + k, g['m1_t'], uid=k) for k in range(3)]
+    tid = np.arange(10); B = np.full((10, 3), 1 / 3)
+    slm2 = optimizer.SLM(eq, [optimizer.Link(eq[0], eq[2], tid, tid, B, B), optimizer.Link(eq[1], eq[2], tid, tid, B, B)])
+    assert slm2._extra_dof_mask(np.array([0, 0, 1])).all() and (~slm2._extra_dof_mask(np.array([0, 1, 1]))).sum() == 3
+    # named materials: held vertices of a region, folded the same way
+    ids = np.zeros(eq[0].num_triangles, dtype=np.int32); ids[:6] = 5
+    eq[1].material_ids = ids; eq[1].material_names = {'default': 0, 'hold': 5}
+    sel = slm2._material_dof_mask('hold', None)
+    vheld = np.unique(eq[1].triangles[:6])
+    assert (~sel).sum() == 2 * vheld.size
+    grouped = slm2._material_dof_mask('hold', np.array([0, 1, 1]))          # mesh 2 (same group) does not hold them: free again
+    assert grouped.all() and grouped.size == 2 * 2 * eq[0].num_vertices
+    eq[2].material_ids = ids; eq[2].material_names = {'default': 0, 'hold': 5}
+    grouped = slm2._material_dof_mask('hold', np.array([0, 1, 1]))
+    assert (~grouped).sum() == 2 * vheld.size and not grouped[2 * eq[0].num_vertices + 2 * vheld[0]]

@@ -288,6 +288,36 @@ def test_g14_groupings():
         np.testing.assert_allclose(ms[k].vertices_w_offset(fem_ref.GEAR_MOVING), g[f'm{k}_v_after'] + g[f'm{k}_off_after'], atol=1e-6 * scale)
 
 
+def g21_oracle_system(g):
+    ms = [fem_ref.RefMesh(g[f'm{k}_v'], g[f'm{k}_t'], uid=k, soft_factor=float(g[f'm{k}_soft'])) for k in range(3)]
+    for k in range(3):
+        ms[k]._off[fem_ref.GEAR_FIXED] = g[f'm{k}_off']
+    links = []
+    for k in range(2):
+        a, b = g[f'l{k}_ab']
+        links.append(fem_ref.RefLink(ms[a], ms[b], g[f'l{k}_tid0'], g[f'l{k}_tid1'], g[f'l{k}_B0'], g[f'l{k}_B1'], weight=g[f'l{k}_w']))
+    return ms, links
+
+
+def test_g21_grouped_system_with_held_dofs():
+    """optimize_linear(groupings=, remove_extra_dof=True) (optimizer.py:1360-1415) against the reference: nothing is locked, the
+    first three degrees of freedom of mesh 0 -- alone in its group -- are held, meshes 1 and 2 share theirs; both costs (the
+    residual of the FULL system: the held rows keep their reaction) and the fields"""
+    g = load_golden('g21_grouped_dof.npz')
+    ms, links = g21_oracle_system(g)
+    cost = fem_ref.optimize_linear_grouped(ms, links, g['groupings'], remove_extra_dof=True)
+    np.testing.assert_allclose(cost[0], g['cost'][0], rtol=1e-9); np.testing.assert_allclose(cost[1], g['cost'][1], rtol=1e-5)      # (the reference keeps the link matrix in float32)
+    scale = np.abs((g['m0_v_after'] + g['m0_off_after']) - (g['m0_v'] + g['m0_off'])).max()
+    assert scale > 10
+    for k in range(3):
+        np.testing.assert_allclose(ms[k].vertices_w_offset(fem_ref.GEAR_MOVING), g[f'm{k}_v_after'] + g[f'm{k}_off_after'], atol=1e-6 * scale)
+    d0 = ms[0].vertices_w_offset(fem_ref.GEAR_MOVING) - (g['m0_v'] + g['m0_off'])
+    assert np.all(d0[0] == 0) and d0[1, 0] == 0 and d0[1, 1] != 0           # the three held degrees of freedom
+    # the fold is an OR over the members: with meshes 0 and 1 grouped instead, mesh 1 frees what mesh 0 holds and nothing is held
+    sel = fem_ref.extra_dof_selector(ms, links)
+    assert sel is not None and (~sel).sum() == 3
+
+
 # ----------------------------------------------------------------------- G16: relax_mesh
 def g16_oracle_mesh(g, cls=None):
     cls = fem_ref.RefMesh if cls is None else cls
