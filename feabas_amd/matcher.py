@@ -275,14 +275,21 @@ def _region2grid_cartesian(region, spacing, erode=0.0, res=None, **kwargs):
     # every raster cell -> the label of the nearest cell inside the region: a lattice point in a spur of the region that is
     # thinner than the raster (no cell centre falls into it) belongs to the part the spur hangs on
     near = lab if msk.all() else lab[tuple(ndimage.distance_transform_edt(lab == 0, return_distances=False, return_indices=True))]
+    territory = ndimage.find_objects(near)
     cntrs = []
     for k in range(1, nlab + 1):
         rr, cc = np.nonzero(lab == k)
         # The lattice PHASE comes from the representative point alone; the bounds of the part (matcher.py:1027) only say how
         # far the lattice reaches.  A spur of the part that the raster does not see can reach far beyond the cells it does
-        # see, so the lattice is laid over the bounds of the whole common region and every point is kept by the two exact
-        # tests: it lies in the region, and the part nearest to it is this one.
-        rx_mn, ry_mn, rx_mx, ry_mx = (float(b) for b in region.bbox)
+        # see, so the lattice is laid over the part's TERRITORY -- the bounds of all raster cells that are nearer to this part
+        # than to any other -- and every point is kept by the two exact tests: it lies in the region, and the part nearest to
+        # it is this one.
+        ty, tx = territory[k - 1]
+        bx0, by0, bx1, by1 = (float(b) for b in region.bbox)               # (the last raster cell may end short of the bounds)
+        rx_mn = bx0 if tx.start == 0 else xs[tx.start] - 0.5 * res
+        rx_mx = bx1 if tx.stop == xs.size else xs[tx.stop - 1] + 0.5 * res
+        ry_mn = by0 if ty.start == 0 else ys[ty.start] - 0.5 * res
+        ry_mx = by1 if ty.stop == ys.size else ys[ty.stop - 1] + 0.5 * res
         row = min(max(int(round((0.5 * (ys[rr.min()] + ys[rr.max()]) - ys[0]) / res)), rr.min()), rr.max())
         run = np.flatnonzero(lab[row] == k)
         if run.size == 0:                                          # the middle row misses the part (a ring, a C): take its fullest row

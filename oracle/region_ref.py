@@ -138,13 +138,19 @@ def region2grid_cartesian(region, spacing, res, anchor_points=None, **pred):
         anchor_points = np.asarray(anchor_points, dtype=np.float64).reshape(-1, 2)
         anchor_points = anchor_points[region.contains(anchor_points, **pred)]          # only points of THIS region can carry its phase
     a_lab = label_of(anchor_points) if anchor_points is not None and len(anchor_points) else None
+    territory = ndimage.find_objects(near)
     cntrs = []
     for k in range(1, nlab + 1):
         part = lab == k
         rr, cc = np.nonzero(part)
         # reg.bounds (matcher.py:1027) only say how far the lattice reaches (its phase is the representative point's): the bounds
-        # of the whole common region are a superset of every part's, spurs thinner than the raster included
-        rx_mn, ry_mn, rx_mx, ry_mx = (float(b) for b in region.bbox)
+        # of the part's territory (all raster cells nearer to it than to another part) hold the part with every spur of it
+        ty, tx = territory[k - 1]
+        bx0, by0, bx1, by1 = (float(b) for b in region.bbox)               # (the last raster cell may end short of the bounds)
+        rx_mn = bx0 if tx.start == 0 else xs[tx.start] - 0.5 * res
+        rx_mx = bx1 if tx.stop == xs.size else xs[tx.stop - 1] + 0.5 * res
+        ry_mn = by0 if ty.start == 0 else ys[ty.start] - 0.5 * res
+        ry_mx = by1 if ty.stop == ys.size else ys[ty.stop - 1] + 0.5 * res
         if a_lab is not None and np.any(a_lab == k):
             rx, ry = anchor_points[np.flatnonzero(a_lab == k)[0]]
         else:

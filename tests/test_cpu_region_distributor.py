@@ -158,3 +158,24 @@ def test_refinement_regions_get_their_own_lattice():
     p0 = Mesh(m0.vertices(const.MESH_GEAR_INITIAL), m0.triangles, uid=5)
     a, _ = matcher.distribute_matching_blocks(p0, m1, spacing, refine_mode=2, zorder=False)
     np.testing.assert_array_equal(a, b0_none)
+
+
+@pytest.mark.parametrize('case', ['boundary', 'refine_both', 'refine_only'])
+def test_distribute_matching_blocks_vs_oracle_on_the_host(case):
+    """the comparison of tests/test_gpu_renderer.py::test_distribute_matching_blocks_vs_oracle without a device (points are then
+    located by matplotlib's trifinder on both sides): the product's blocks equal oracle/region_ref.py's exactly once the oracle
+    takes the product's lattice phase part by part"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_renderer import _island_pair
+    from oracle import region_ref
+    (v0, t0, v1, t1), (M0, M1), mats = _island_pair(np.random.default_rng(11))
+    kw = dict(boundary=dict(refine_mode=0, min_boundary_distance=25), refine_both=dict(refine_mode=2, min_boundary_distance=15),
+              refine_only=dict(refine_mode=1))[case]
+    sp = 110.0
+    g0, g1 = matcher.distribute_matching_blocks(M0, M1, sp, gear=const.MESH_GEAR_INITIAL, **kw)
+    assert g0.shape[0] > 20
+    e0, e1 = region_ref.distribute_matching_blocks(v0, t0, v1, t1, sp, materials=mats, anchor_blocks=g0, res=None, **kw)
+    np.testing.assert_array_equal(g0, e0)
+    np.testing.assert_array_equal(g1, e1)
