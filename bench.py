@@ -325,7 +325,7 @@ def bench_align(lib, ctx, _lib, S=8192, mesh_size=50.0, nblocks=512, B=280):
                      'masked DoG, padded NCC; results (dx, dy, conf per block) returned to the host')
 
 
-def bench_section_matcher(lib, ctx, _lib, S=8192, mesh_size=100.0, reps=3):
+def bench_section_matcher(lib, ctx, _lib, S=8192, mesh_size=100.0, reps=3, config=None):
     """alignment side end to end (align_main --mode matching): ONE pair of S x S uint8 sections through
     matcher.section_matcher -- two irregular meshes (both free: the floating system of matcher.py:551), spacings 280 / 70 px
     (0.7 x the [400, 100] of alignment_configs.yaml:16-23), render + DoG + NCC + relaxation per round -- against the smooth
@@ -361,7 +361,8 @@ def bench_section_matcher(lib, ctx, _lib, S=8192, mesh_size=100.0, reps=3):
         m0, m1 = meshes[0].copy(), meshes[1].copy()
         trace = []
         t0 = time.time()
-        xy0, xy1, w, strain = fmatcher.section_matcher(m0, m1, images[0], images[1], spacings=[280, 70], conf_thresh=0.3, residue_len=3.0, trace=trace)
+        kw = dict(spacings=[280, 70], conf_thresh=0.3, residue_len=3.0) if config is None else dict(config)
+        xy0, xy1, w, strain = fmatcher.section_matcher(m0, m1, images[0], images[1], trace=trace, **kw)
         dt = time.time() - t0
         if dt < best:
             best, out = dt, (xy0, xy1, trace)
@@ -373,8 +374,9 @@ def bench_section_matcher(lib, ctx, _lib, S=8192, mesh_size=100.0, reps=3):
     return dict(value=1.0 / best, unit='section pairs/s', ms_per_pair=1e3 * best, image=[S, S], triangles=[int(m.num_triangles) for m in meshes],
                 vertices=[int(m.num_vertices) for m in meshes], matches=int(xy0.shape[0]),
                 median_error_px=float(np.median(err)), p95_error_px=float(np.quantile(err, 0.95)),
-                rounds=[dict(blocks=int(r['blocks']), kept=int(r['kept']), max_dis=float(r['max_dis']), solve_iters=r['solve'].get('iters'),
-                             precond=r['solve'].get('precond')) for r in trace],
+                rounds=[dict(blocks=int(r['blocks']), kept=int(r['kept']), max_dis=float(r['max_dis']), solve_iters=r.get('solve', {}).get('iters'),
+                             precond=r.get('solve', {}).get('precond')) for r in trace],
+                config='spacings [280, 70], conf_thresh 0.3, residue_len 3, the other keywords at section_matcher\'s defaults' if config is None else config,
                 note=f'best of {reps} calls of matcher.section_matcher on resident uint8 sections; error = distance of the matched displacement '
                      'from the injected field at the matched points; the relaxations between the rounds stop at the reference tolerance '
                      '0.01 / max(1, max_dis) (matcher.py:685-688; relax_tol=1e-9 converges them: 2 x ~1 400 iterations, +40 ms, same error)')
@@ -688,6 +690,16 @@ def fem_cpu_krylov(A, b, seconds=12.0):
                          to_1e4=None if st['hit'] is None else dict(iterations=st['hit'][0], seconds=st['hit'][1]),
                          note='true residual checked every 10 iterations (its SpMV is inside the timing)')
     return out
+
+
+def guarded(line, name, fn, *a, **k):
+    """a side record (one rank, no collective inside) must never take the headline down with it: an exception becomes the record"""
+    try:
+        line[name] = fn(*a, **k)
+    except Exception as e:                                # noqa: BLE001 -- reported in the line, traceback on stderr
+        import traceback
+        traceback.print_exc()
+        line[name] = dict(error=f'{type(e).__name__}: {e}')
 
 
 def gather_table_timed(ex, table, barrier, reduce_max):
@@ -1214,7 +1226,7 @@ def main():
         if rank == 0:
             line['fem'] = fem
     if rank == 0 and not args.no_xcorr_classes:
-        line['xcorr_fft_classes'] = bench_xcorr_classes(lib, ctx, _lib)
+        guarded(line, 'xcorr_fft_classes', bench_xcorr_classes, lib, ctx, _lib)
     if rank == 0 and world == 1 and args.host_ingest_pairs > 0:
         # the boundary as stitcher.py uses it: strips in host memory.  PCIe-inclusive rate through stitching_matcher_batch
         # (page-locked staging, copy and kernels of different chunks overlapped); never `value`
@@ -1258,8 +1270,14 @@ def main():
         fmatcher.stitching_matcher_batch_release()
         del h0, h1, host_pairs, outp, ragged, outr
     if rank == 0 and world == 1 and not args.no_align:
-        line['align_block_matcher'] = bench_align(lib, ctx, _lib)
-        line['section_matcher'] = bench_section_matcher(lib, ctx, _lib)
+        guarded(line, 'align_block_matcher', bench_align, lib, ctx, _lib)
+        guarded(line, 'section_matcher', bench_section_matcher, lib, ctx, _lib)
+        # the same pair with the matcher_config of the reference's default alignment configuration as it stands
+        # (configs/default_alignment_configs.yaml:14-28): spacings [400, 100] x shrink_factor 0.7, sigma 3.5, conf_thresh 0.35,
+        # min_boundary_distance 20, residue_len -2 section thicknesses, batch_size 100
+        guarded(line, 'section_matcher_default_config', bench_section_matcher, lib, ctx, _lib, reps=2,
+                config=dict(spacings=[400, 100], shrink_factor=0.7, sigma=3.5, conf_thresh=0.35, min_boundary_distance=20, residue_mode='huber',
+                            residue_len=-2, batch_size=100, pad=True, stiffness_multiplier_threshold=0.1, render_weight_threshold=0.1))
     cpu_strips = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         H, W = shapes['LR']
