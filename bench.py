@@ -206,6 +206,13 @@ def bench_fem(args, lib, ctx, _lib):
                                    sample=f'{cit} iterations of oracle/fem_ref.pcg (scipy CSR, {A.nnz} non-zeros) on the same system, {cdt:.1f} s; '
                                           'scipy SpMV is single threaded, so this is also the all-core figure of the reference path')
         out['cpu_baseline']['scipy'] = fem_cpu_krylov(A, b)
+        # the 2 x 2 blocks store explicit zeros (on the nu = 0 structured grid of this system almost half of the scalars): the same
+        # figures with the bytes of those zeros taken out -- what a scalar-exact storage would have to move per iteration
+        zeros = 4 * nnzb.value - int(A.nnz)
+        out['stored_scalars'] = 4 * nnzb.value
+        out['nonzero_scalars'] = int(A.nnz)
+        out['useful_bytes_per_iter'] = it_bytes - 8 * zeros
+        out['hbm_frac_zeros_excluded'] = (it_bytes - 8 * zeros) * args.fem_iters / dt / 1e9 / HBM_PEAK_GBS
     # hard variant: 5 k links, about one per 100 nodes -- the elastic term carries the solution
     # across the mesh; solved to 1e-4 like the main system and to the reference's default tolerance 1e-7
     # (default_alignment_configs.yaml: elastic_params.tol), where the smooth modes cost thousands of iterations
