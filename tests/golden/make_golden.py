@@ -877,8 +877,61 @@ def g21_grouped_dof():
     np.savez_compressed(os.path.join(OUT, 'g21_grouped_dof.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G22
+def g22_schedule_walks():
+    """the coarse-to-fine walk of iterative_xcorr_matcher_w_mesh (matcher.py:567-716) captured from the REFERENCE's own loop:
+    the block matcher is replaced by a script (every block reports one prescribed displacement, confidence 1), everything else
+    -- distributor, links, relaxations, the spacing / padding decisions -- runs as it stands.  Per call of the block matcher the
+    record is (block side = spacing, pad, subpixel, affine_approx_tol, number of blocks); scenarios vary the spacing list,
+    allow_enlarge, allow_dwell, max_spacing_skip, a fixed pad, and the displacements the rounds report."""
+    import json
+    v0, t0 = grid(41, 41, 50.0)                             # 2000 x 2000 px
+    scenarios = {
+        'two_jump':         dict(spacings=[1024, 75], dis=[12.0, 0.3]),
+        'two_nojump':       dict(spacings=[1024, 75], dis=[30.0, 0.3]),
+        'three_clip':       dict(spacings=[1000, 300, 75], dis=[2.0, 2.0, 2.0]),
+        'three_skip1':      dict(spacings=[1000, 300, 75], dis=[2.0, 2.0, 2.0], max_spacing_skip=1),
+        'three_skip2_mid':  dict(spacings=[1000, 300, 75], dis=[30.0, 10.0, 2.0], max_spacing_skip=2),
+        'dwell2':           dict(spacings=[400, 100], dis=[200.0] * 8, allow_dwell=2),
+        'dwell1_then_jump': dict(spacings=[400, 100, 30], dis=[150.0, 20.0, 20.0, 1.0, 1.0], allow_dwell=1),
+        'enlarge':          dict(spacings=[400, 100], dis=[300.2, 300.2, 1.0, 1.0], allow_enlarge=True),
+        'enlarge_off':      dict(spacings=[400, 100], dis=[300.0, 1.0], allow_enlarge=False),
+        'pad_false':        dict(spacings=[1024, 75], dis=[30.0, 0.3], pad=False),
+        'pad_true':         dict(spacings=[1000, 300, 75], dis=[2.0, 2.0, 2.0], pad=True),
+        'tiny_dis':         dict(spacings=[600, 150], dis=[0.05, 0.05]),
+        'four':             dict(spacings=[1600, 400, 100, 25], dis=[90.0, 20.0, 5.0, 1.0, 1.0]),
+        'unsorted':         dict(spacings=[75, 1024, 300], dis=[60.0, 15.0, 1.0]),
+    }
+    out = {}
+    real = matcher.bboxes_mesh_renderer_matcher
+    try:
+        for name, sc in scenarios.items():
+            m0 = Mesh(v0, t0, uid=0); m0.lock()
+            m1 = Mesh(v0 + 0.0, t0, uid=1)
+            dis = list(sc['dis'])
+            calls = []
+
+            def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+                k = min(len(calls), len(dis) - 1)
+                c0 = common.bbox_centers(bboxes0)
+                side = float(np.round(bboxes0[0, 2] - bboxes0[0, 0]))
+                calls.append([side, bool(kw.get('pad')), bool(kw.get('subpixel')), float(kw.get('affine_approx_tol')), int(bboxes0.shape[0])])
+                d = np.array([dis[k], 0.0])
+                return c0 - 0.5 * d, c0 + 0.5 * d, np.ones(c0.shape[0], dtype=np.float32)
+            matcher.bboxes_mesh_renderer_matcher = scripted
+            kw = {k: v for k, v in sc.items() if k not in ('spacings', 'dis')}
+            res = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, None, None, spacings=np.array(sc['spacings'], dtype=np.float64), compute_strain=False,
+                                                         conf_thresh=0.3, residue_len=0, opt_tol=1e-10, **kw)
+            out[name + '_calls'] = np.array(calls, dtype=np.float64)
+            out[name + '_nmatch'] = np.int64(0 if res[0] is None else res[0].shape[0])
+    finally:
+        matcher.bboxes_mesh_renderer_matcher = real
+    out['scenarios'] = np.frombuffer(json.dumps(scenarios).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'g22_schedule_walks.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -659,3 +659,33 @@ def test_held_dof_selectors_fold_into_groups_like_the_reference():
     eq[2].material_ids = ids; eq[2].material_names = {'default': 0, 'hold': 5}
     grouped = slm2._material_dof_mask('hold', np.array([0, 1, 1]))
     assert (~grouped).sum() == 2 * vheld.size and not grouped[2 * eq[0].num_vertices + 2 * vheld[0]]
+
+
+def test_round_stepper_against_the_walks_of_the_reference():
+    """golden G22: the coarse-to-fine walk captured from the REFERENCE's own iterative_xcorr_matcher_w_mesh (matcher.py:567-716;
+    its block matcher replaced by a script of displacements, everything else as it stands) against the library's stepper
+    (fb_schedule_*, what every block matcher of this package walks with): the same rounds -- spacing, padding, the sub-pixel
+    round -- for jumps, clipped and allowed skips, dwelling, the enlarged extra round, a fixed pad, unsorted spacing lists"""
+    import json
+    from feabas_amd.matcher import _RoundPlan
+    g = load_golden('g22_schedule_walks.npz')
+    scenarios = json.loads(bytes(g['scenarios']).decode())
+    assert len(scenarios) >= 14
+    for name, sc in scenarios.items():
+        calls = g[name + '_calls']
+        sp_list = np.sort(np.asarray(sc['spacings'], dtype=np.float64))[::-1]
+        plan = _RoundPlan(sp_list, sc.get('allow_enlarge', False), sc.get('allow_dwell', 0), sc.get('max_spacing_skip', 0), sc.get('pad', None))
+        got = []
+        while True:
+            r = plan.due()
+            if r is None or len(got) > 4 * len(calls):
+                break
+            got.append(r)
+            plan.advance(sc['dis'][min(len(got) - 1, len(sc['dis']) - 1)])
+        plan.close()
+        assert len(got) == calls.shape[0], (name, got, calls.tolist())
+        for (sp, last, pad), (side, gpad, gsub, gtol, _) in zip(got, calls):
+            assert bool(pad) == bool(gpad) and bool(last) == bool(gsub), (name, got, calls.tolist())
+            # the reference's record carries the spacing through affine_approx_tol = 0.1 on the last spacing, max(1, 0.02 sp) before
+            assert (gtol == 0.1 and sp == sp_list[-1]) if last else abs(max(1.0, 0.02 * sp) - gtol) < 1e-9, (name, sp, gtol)
+            assert side <= np.ceil(sp) + 1e-9                       # (divide_bbox fits the blocks into the overlap: never larger than the spacing)
