@@ -313,11 +313,16 @@ def _batches(bboxes0, bboxes1, batch_size):
 
 def section_match(m0, m1, img0, img1, spacings=(100,), sigma=2.5, batch_size=100, conf_thresh=0.3, residue_mode='huber', residue_len=0,
                   conf_mode=ncc_ref.FFT_CONF_MIRROR, min_boundary_distance=0, shrink_factor=1, refine_mode=2, stiffness_lambda=0.5,
-                  compute_strain=False, materials=None, res=1.0, anchor_rounds=None, trace=None):
+                  compute_strain=False, materials=None, res=1.0, anchor_rounds=None, trace=None, distributor='cartesian_region',
+                  min_num_blocks=2, block_matcher=None):
     """matcher.py:370-427 (no initial matches: straight into the loop) + 430-778 for a pair of fem_ref.RefMesh with linear
     materials (soft / unrendered triangles already removed by the caller) over two images whose pixel (0, 0) sits at the
     origin.  Every relaxation is solved to its fixed point.  anchor_rounds: per round the mesh-0 blocks of another
-    implementation (lattice phase only, module docstring).  Returns (xy0, xy1, weight, strain)."""
+    implementation (lattice phase only, module docstring).  Returns (xy0, xy1, weight, strain).
+    distributor 'cartesian_bbox': the blocks of matcher.py:865-891 instead (the loop of stitching_matcher).  block_matcher: a
+    callable (round, m0, m1, bboxes0, bboxes1, pad, subpixel, tol) -> (xy0, xy1, conf) in place of render + DoG + NCC -- golden
+    G23 drives the reference's own loop and this one with the same script, which pins everything BETWEEN the block matches
+    (blocks on the moving bounds, links, relaxation, residue weights, the walk, final matches, strain) to the reference."""
     invalid = (None, None, 0, DEFAULT_AVG_DEFORM)
     spacings = np.sort(np.asarray(spacings, dtype=np.float64))[::-1]
     if compute_strain:
@@ -331,17 +336,27 @@ def section_match(m0, m1, img0, img1, spacings=(100,), sigma=2.5, batch_size=100
         rfm = refine_mode if (last or refine_mode != 2) else 0             # matcher.py:572-590
         tol = 0.1 if last else max(1, 0.02 * sp)
         vm = [m.vertices_w_offset(GEAR_MOVING) for m in (m0, m1)]
-        bb0, bb1 = distribute_matching_blocks(vm[0], m0.triangles, vm[1], m1.triangles, sp, refine_mode=rfm, shrink_factor=shrink_factor,
-                                              min_boundary_distance=min_boundary_distance, zorder=True, materials=materials, res=res,
-                                              anchor_blocks=None if anchor_rounds is None or rnd >= len(anchor_rounds) else anchor_rounds[rnd])
+        if distributor == 'cartesian_bbox':                                # matcher.py:865-891 on the bounds of the MOVING gears
+            bounds = [np.concatenate((v.min(axis=0), v.max(axis=0))) for v in vm]
+            bb0, bb1 = ncc_ref.distributor_cartesian_bbox(bounds[0], bounds[1], sp, min_num_blocks=min_num_blocks if last else 1,
+                                                          shrink_factor=shrink_factor, zorder=True)
+            if bb0 is None:
+                return invalid
+        else:
+            bb0, bb1 = distribute_matching_blocks(vm[0], m0.triangles, vm[1], m1.triangles, sp, refine_mode=rfm, shrink_factor=shrink_factor,
+                                                  min_boundary_distance=min_boundary_distance, zorder=True, materials=materials, res=res,
+                                                  anchor_blocks=None if anchor_rounds is None or rnd >= len(anchor_rounds) else anchor_rounds[rnd])
         if bb0.shape[0] == 0:
             if not initialized:
                 return invalid
             break
-        edges = _batches(bb0, bb1, batch_size)
-        parts = [pipeline_ref.bboxes_mesh_renderer_matcher(m0, m1, img0, img1, bb0[a:b], bb1[a:b], sigma=sigma, conf_mode=conf_mode, pad=pad,
-                                                            subpixel=bool(last), affine_approx_tol=tol) for a, b in zip(edges[:-1], edges[1:])]
-        xy0 = np.concatenate([p[0] for p in parts]); xy1 = np.concatenate([p[1] for p in parts]); conf = np.concatenate([p[2] for p in parts])
+        if block_matcher is not None:
+            xy0, xy1, conf = block_matcher(rnd, m0, m1, bb0, bb1, pad, bool(last), tol)
+        else:
+            edges = _batches(bb0, bb1, batch_size)
+            parts = [pipeline_ref.bboxes_mesh_renderer_matcher(m0, m1, img0, img1, bb0[a:b], bb1[a:b], sigma=sigma, conf_mode=conf_mode, pad=pad,
+                                                                subpixel=bool(last), affine_approx_tol=tol) for a, b in zip(edges[:-1], edges[1:])]
+            xy0 = np.concatenate([p[0] for p in parts]); xy1 = np.concatenate([p[1] for p in parts]); conf = np.concatenate([p[2] for p in parts])
         if trace is not None:
             trace.append(dict(sp=sp, bboxes0=bb0, bboxes1=bb1, conf=conf, pad=pad))
         rnd += 1

@@ -930,8 +930,89 @@ def g22_schedule_walks():
     np.savez_compressed(os.path.join(OUT, 'g22_schedule_walks.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G23
+def scripted_block_matches(rnd, bboxes0, bboxes1, seed):
+    """the script both G23 and its test hand to the loop in place of render + DoG + NCC: every block reports a smooth
+    displacement that shrinks from round to round, a deterministic pseudo-random confidence in [0.15, 1) and, for a few blocks,
+    an outlier (what the huber / threshold residue weights are there for); the block -> point rule is matcher.py:840-849"""
+    b0 = np.asarray(bboxes0, dtype=np.float64); b1 = np.asarray(bboxes1, dtype=np.float64)
+    c0 = 0.5 * (b0[:, :2] + b0[:, 2:]); c1 = 0.5 * (b1[:, :2] + b1[:, 2:])
+    s0 = np.stack((b0[:, 3] - b0[:, 1], b0[:, 2] - b0[:, 0]), axis=-1); s1 = np.stack((b1[:, 3] - b1[:, 1], b1[:, 2] - b1[:, 0]), axis=-1)
+    ratio = (s0 / (s0 + s1))[:, ::-1]
+    amp = (6.0, 2.0, 0.6, 0.2)[min(rnd, 3)]
+    dx = amp * np.sin(c0[:, 1] / 310.0 + 0.4 + rnd) + 0.3 * amp * (c0[:, 0] / 2000.0)
+    dy = amp * np.cos(c0[:, 0] / 270.0 - rnd) - 0.2 * amp * (c0[:, 1] / 2000.0)
+    h = np.abs(np.modf(np.sin(np.round(c0[:, 0]) * 12.9898 + np.round(c0[:, 1]) * 78.233 + 37.0 * rnd + seed) * 43758.5453)[0])
+    conf = (0.15 + 0.85 * h).astype(np.float32)
+    dxy = np.stack((dx, dy), axis=-1)
+    dxy[h > 0.93] += np.array([8.0, -5.0])
+    return c0 - dxy * ratio, c1 + dxy * (1 - ratio), conf
+
+
+def g23_matcher_loop():
+    """iterative_xcorr_matcher_w_mesh (matcher.py:430-778) END TO END with its block matcher scripted (scripted_block_matches):
+    blocks on the bounds of the moving gears, confidence filter, links through the moving gears, relaxation, relax_first + huber
+    / threshold residue weights and the second solve, the walk over the spacings, the final matches in the initial gear and the
+    strain chain -- the composite the oracle restates in region_ref.section_match / pipeline_ref.match_pair.  The reference's
+    solves are made deterministic and converged (tol 1e-11, no random-perturbation exit), as for G14 / G16."""
+    real_match = matcher.bboxes_mesh_renderer_matcher
+    real_ol = optimizer.SLM.optimize_linear
+
+    def converged(self, **kw):
+        kw['tol'] = 1e-11; kw['tolerated_perturbation'] = None; kw['callback_settings'] = {'chances': None, 'eval_step': 10}
+        kw['check_converge'] = True
+        return real_ol(self, **kw)
+    rng = np.random.default_rng(2323)
+    out = {}
+    va, ta = grid(27, 20, 60.0)                             # 1560 x 1140 px, locked
+    gx, gy = np.meshgrid(np.arange(0, 1561, 65.0), np.arange(0, 1141, 57.0))
+    vb = np.stack((gx.ravel(), gy.ravel()), axis=-1)
+    inner = (vb[:, 0] > 0) & (vb[:, 0] < gx.max()) & (vb[:, 1] > 0) & (vb[:, 1] < gy.max())
+    vb[inner] += rng.uniform(-0.25, 0.25, (int(inner.sum()), 2)) * 57.0
+    tb = Delaunay(vb).simplices.astype(np.int32)
+    pb = vb[tb]
+    area = (pb[:, 1, 0] - pb[:, 0, 0]) * (pb[:, 2, 1] - pb[:, 0, 1]) - (pb[:, 1, 1] - pb[:, 0, 1]) * (pb[:, 2, 0] - pb[:, 0, 0])
+    tb[area < 0] = tb[area < 0][:, ::-1]
+    out.update(v0=va, t0=ta, v1=vb, t1=tb)
+    cases = {'huber': dict(spacings=[400.0, 100.0], residue_mode='huber', residue_len=3.0, seed=1.0, off0=(3.0, -2.0)),
+             'threshold3': dict(spacings=[600.0, 150.0, 40.0], residue_mode='threshold', residue_len=4.0, seed=2.0, off0=(-1.5, 2.5)),
+             'no_residue': dict(spacings=[300.0, 80.0], residue_mode='huber', residue_len=0.0, seed=3.0, off0=(0.0, 0.0))}
+    try:
+        matcher.bboxes_mesh_renderer_matcher = None        # (set per case below)
+        optimizer.SLM.optimize_linear = converged
+        for name, cs in cases.items():
+            m0 = Mesh(va, ta, uid=0)
+            m0.apply_translation(cs['off0'], const.MESH_GEAR_FIXED)
+            m0.lock()
+            m1 = Mesh(vb.copy(), tb, uid=1)
+            rounds = []
+
+            def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+                k = len(rounds)
+                rounds.append(dict(bboxes0=np.array(bboxes0), bboxes1=np.array(bboxes1), pad=bool(kw.get('pad')), subpixel=bool(kw.get('subpixel')),
+                                   field1=mesh1.vertices_w_offset(gear=const.MESH_GEAR_MOVING) - mesh1.vertices_w_offset(gear=const.MESH_GEAR_INITIAL)))
+                return scripted_block_matches(k, bboxes0, bboxes1, cs['seed'])
+            matcher.bboxes_mesh_renderer_matcher = scripted
+            xy0, xy1, wt, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, None, None, spacings=np.array(cs['spacings']), distributor='cartesian_bbox',
+                                                                          conf_thresh=0.3, residue_len=cs['residue_len'], residue_mode=cs['residue_mode'],
+                                                                          compute_strain=True, stiffness_lambda=0.5, min_num_blocks=2)
+            out[f'{name}_nrounds'] = np.int64(len(rounds))
+            for k, r in enumerate(rounds):
+                for key in ('bboxes0', 'bboxes1', 'field1'):
+                    out[f'{name}_r{k}_{key}'] = r[key]
+                out[f'{name}_r{k}_flags'] = np.array([r['pad'], r['subpixel']])
+            out[f'{name}_xy0'] = xy0; out[f'{name}_xy1'] = xy1; out[f'{name}_weight'] = np.asarray(wt); out[f'{name}_strain'] = np.float64(strain)
+            out[f'{name}_field1_final'] = m1.vertices_w_offset(gear=const.MESH_GEAR_MOVING) - m1.vertices_w_offset(gear=const.MESH_GEAR_INITIAL)
+            out[f'{name}_params'] = np.array([cs['residue_len'], cs['seed'], cs['off0'][0], cs['off0'][1], 1.0 if cs['residue_mode'] == 'threshold' else 0.0])
+            out[f'{name}_spacings'] = np.array(cs['spacings'])
+    finally:
+        matcher.bboxes_mesh_renderer_matcher = real_match
+        optimizer.SLM.optimize_linear = real_ol
+    np.savez_compressed(os.path.join(OUT, 'g23_matcher_loop.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

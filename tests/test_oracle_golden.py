@@ -525,3 +525,59 @@ def test_area_resize_restatement_properties():
     mk = np.zeros((5, 7), bool); mk[2, 4] = True
     assert ncc_ref.nearest_resize_mask(mk, 0.5).shape == (2, 4) and ncc_ref.nearest_resize_mask(mk, 0.5)[1, 2]
     np.testing.assert_allclose(ncc_ref.scale_coordinates(np.array([[0.0, 3.0]]), 2.0), [[0.5, 6.5]])
+
+
+# ----------------------------------------------------------------------- G23: the matcher loop, block matches scripted
+def _g23_scripted_block_matches(rnd, bboxes0, bboxes1, seed):
+    """(the script of tests/golden/make_golden.py::scripted_block_matches, word for word)"""
+    b0 = np.asarray(bboxes0, dtype=np.float64); b1 = np.asarray(bboxes1, dtype=np.float64)
+    c0 = 0.5 * (b0[:, :2] + b0[:, 2:]); c1 = 0.5 * (b1[:, :2] + b1[:, 2:])
+    s0 = np.stack((b0[:, 3] - b0[:, 1], b0[:, 2] - b0[:, 0]), axis=-1); s1 = np.stack((b1[:, 3] - b1[:, 1], b1[:, 2] - b1[:, 0]), axis=-1)
+    ratio = (s0 / (s0 + s1))[:, ::-1]
+    amp = (6.0, 2.0, 0.6, 0.2)[min(rnd, 3)]
+    dx = amp * np.sin(c0[:, 1] / 310.0 + 0.4 + rnd) + 0.3 * amp * (c0[:, 0] / 2000.0)
+    dy = amp * np.cos(c0[:, 0] / 270.0 - rnd) - 0.2 * amp * (c0[:, 1] / 2000.0)
+    h = np.abs(np.modf(np.sin(np.round(c0[:, 0]) * 12.9898 + np.round(c0[:, 1]) * 78.233 + 37.0 * rnd + seed) * 43758.5453)[0])
+    conf = (0.15 + 0.85 * h).astype(np.float32)
+    dxy = np.stack((dx, dy), axis=-1)
+    dxy[h > 0.93] += np.array([8.0, -5.0])
+    return c0 - dxy * ratio, c1 + dxy * (1 - ratio), conf
+
+
+@pytest.mark.parametrize('case', ['huber', 'threshold3', 'no_residue'])
+def test_g23_matcher_loop_between_the_block_matches(case):
+    """iterative_xcorr_matcher_w_mesh END TO END (matcher.py:430-778) against the reference with the block matches scripted on
+    both sides: the oracle's loop (region_ref.section_match, distributor 'cartesian_bbox') lays the same blocks on the moving
+    bounds round after round, relaxes mesh 1 into the same field, walks the spacings the same way and ends on the same matches,
+    weights (confidence x huber / threshold residue weight) and strain -- the composite that rounds 1-4 could only call
+    'pieces pinned, composite unpinned'"""
+    from oracle import region_ref
+    g = load_golden('g23_matcher_loop.npz')
+    res_len, seed, ox, oy, thr = g[f'{case}_params']
+    m0 = fem_ref.RefMesh(g['v0'], g['t0'], uid=0)
+    m0.apply_translation((ox, oy), fem_ref.GEAR_FIXED)
+    m0.locked = True
+    m1 = fem_ref.RefMesh(g['v1'].copy(), g['t1'], uid=1)
+    seen = []
+
+    def scripted(rnd, a, b, bb0, bb1, pad, subpixel, tol):
+        seen.append(dict(bboxes0=bb0, bboxes1=bb1, pad=pad, subpixel=subpixel,
+                         field1=b.vertices_w_offset(fem_ref.GEAR_MOVING) - b.vertices_w_offset(fem_ref.GEAR_INITIAL)))
+        return _g23_scripted_block_matches(rnd, bb0, bb1, seed)
+    xy0, xy1, wt, strain = region_ref.section_match(m0, m1, None, None, spacings=g[f'{case}_spacings'], conf_thresh=0.3, residue_len=float(res_len),
+                                                    residue_mode='threshold' if thr else 'huber', compute_strain=True, stiffness_lambda=0.5,
+                                                    distributor='cartesian_bbox', min_num_blocks=2, block_matcher=scripted)
+    n = int(g[f'{case}_nrounds'])
+    assert len(seen) == n
+    for k, r in enumerate(seen):
+        np.testing.assert_allclose(r['bboxes0'], g[f'{case}_r{k}_bboxes0'], atol=1e-6)
+        np.testing.assert_allclose(r['bboxes1'], g[f'{case}_r{k}_bboxes1'], atol=1e-6)
+        assert [r['pad'], r['subpixel']] == g[f'{case}_r{k}_flags'].tolist()
+        scale = max(1.0, np.abs(g[f'{case}_r{k}_field1']).max())
+        np.testing.assert_allclose(r['field1'], g[f'{case}_r{k}_field1'], atol=1e-6 * scale)
+    scale = np.abs(g[f'{case}_field1_final']).max()
+    np.testing.assert_allclose(m1.vertices_w_offset(fem_ref.GEAR_MOVING) - m1.vertices_w_offset(fem_ref.GEAR_INITIAL), g[f'{case}_field1_final'], atol=1e-6 * scale)
+    assert xy0.shape == g[f'{case}_xy0'].shape
+    np.testing.assert_allclose(xy0, g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g[f'{case}_xy1'], atol=1e-5)
+    np.testing.assert_allclose(wt, g[f'{case}_weight'], atol=1e-5)
+    np.testing.assert_allclose(strain, g[f'{case}_strain'], rtol=1e-5)
