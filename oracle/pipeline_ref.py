@@ -370,11 +370,20 @@ def photometric(raw0, raw1, g0, g1, tx0, ty0, mask0_g=None, mask1_g=None):
 
 def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, min_num_blocks=2,
                conf_mode=ncc_ref.FFT_CONF_MIRROR, residue_len=5.0, mask0=None, mask1=None, compute_photometric=False, spacings=None, residue_mode='huber',
-               fine_downsample=1):
+               fine_downsample=1, block_script=None, script_start=None):
     """strip0/strip1: uint8 H x W overlap strips (mask0/mask1: bool, True = valid pixel).
     Returns dict(tx, ty, conf0, xy0, xy1, weight, needs_host, strain, phtm, ...).  tx / ty: the global translation in pixels
-    of the FINE images (the strips themselves unless fine_downsample != 1); xy0 / xy1 in pixels of the strips."""
+    of the FINE images (the strips themselves unless fine_downsample != 1); xy0 / xy1 in pixels of the strips.
+    block_script (golden G24): a callable (round, bboxes0, bboxes1) -> (dx, dy, conf) that stands in for crop + NCC of every
+    round, with script_start = (H, W, tx, ty) in place of the image stages in front of the loop (strip0 / strip1 are not looked
+    at): the loop BETWEEN the block matches -- blocks, links, rigid / deformed relaxation, residue weights, the walk, final
+    matches, strain -- then runs on the same inputs as the reference's own loop driven by the same script."""
     cd, fd = coarse_downsample, fine_downsample
+    if block_script is not None:
+        return _match_pair_loop(None, None, script_start[0], script_start[1], float(script_start[2]), float(script_start[3]), np.asarray(spacings, dtype=np.float64),
+                                float(residue_len), dict(tx=float(script_start[2]), ty=float(script_start[3]), conf0=1.0, xy0=None, xy1=None, weight=None,
+                                                         needs_host=False, strain=0.05, phtm=None),
+                                conf_thresh, min_num_blocks, conf_mode, residue_mode, 1, block_script)
 
     def shrink(img, mk, f):
         if f == 1:
@@ -404,8 +413,12 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
     # spacings follow the shapes of the strips as given, then scale with the fine images; so does residue_len (matcher.py:243-251, 341, 352)
     spacings = (ncc_ref.auto_spacings(strip0.shape, strip1.shape) if spacings is None else np.asarray(spacings, dtype=np.float64)) * fd
     residue_len = residue_len * fd
-    H, W = f0.shape
-    tx, ty = res['tx'], res['ty']
+    return _match_pair_loop(f0, f1, f0.shape[0], f0.shape[1], res['tx'], res['ty'], spacings, residue_len, res, conf_thresh, min_num_blocks, conf_mode,
+                            residue_mode, fd, None)
+
+
+def _match_pair_loop(f0, f1, H, W, tx, ty, spacings, residue_len, res, conf_thresh, min_num_blocks, conf_mode, residue_mode, fd, block_script):
+    """iterative_xcorr_matcher_w_mesh as stitching_matcher calls it (matcher.py:353-364, 430-778) on the band-passed fine images"""
     spacings = np.sort(spacings)[::-1]
     bbox0 = (-0.5 + tx, -0.5 + ty, W - 0.5 + tx, H - 0.5 + ty)              # Mesh.from_bbox + apply_translation
     pad = True
@@ -428,15 +441,24 @@ def match_pair(strip0, strip1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.3
             if rnd == 0:
                 return res
             break
-        h = int(bb0[0, 3] - bb0[0, 1]); w = int(bb0[0, 2] - bb0[0, 0])
-        s0 = np.stack([_crop(f0, int(b[0]) - itx, int(b[1]) - ity, h, w) for b in bb0])
-        if deformed is None:
-            s1 = np.stack([_crop(f1, int(b[0]) - i1x, int(b[1]) - i1y, h, w) for b in bb1])
+        if block_script is not None:
+            out = block_script(rnd, bb0, bb1)
+            if len(out) == 5:                                # the script names the blocks of this round itself (G24 'rigid': see the test)
+                bb0, bb1 = np.asarray(out[3]), np.asarray(out[4])
+            dx, dy, cf = out[:3]
+            res.setdefault('rounds', []).append(dict(bboxes0=bb0, bboxes1=bb1, pad=pad, subpixel=is_last,
+                                                      field1=(np.tile(t1, (1, 1)) if deformed is None else
+                                                              deformed[1].vertices_w_offset(fem_ref.GEAR_MOVING) - deformed[1].vertices_w_offset(fem_ref.GEAR_INITIAL))))
         else:
-            tol = 0.1 if is_last else max(1, 0.02 * sp)                      # matcher.py:578-603 (affine_approximated_render)
-            s1, tiers = render_blocks_mesh1(deformed[1], f1, bb1, tol, return_tiers=True)
-            res.setdefault('tiers', []).append(tiers)
-        dx, dy, cf = ncc_ref.xcorr_fft(s0, s1, conf_mode=conf_mode, pad=pad, subpixel=is_last)
+            h = int(bb0[0, 3] - bb0[0, 1]); w = int(bb0[0, 2] - bb0[0, 0])
+            s0 = np.stack([_crop(f0, int(b[0]) - itx, int(b[1]) - ity, h, w) for b in bb0])
+            if deformed is None:
+                s1 = np.stack([_crop(f1, int(b[0]) - i1x, int(b[1]) - i1y, h, w) for b in bb1])
+            else:
+                tol = 0.1 if is_last else max(1, 0.02 * sp)                      # matcher.py:578-603 (affine_approximated_render)
+                s1, tiers = render_blocks_mesh1(deformed[1], f1, bb1, tol, return_tiers=True)
+                res.setdefault('tiers', []).append(tiers)
+            dx, dy, cf = ncc_ref.xcorr_fft(s0, s1, conf_mode=conf_mode, pad=pad, subpixel=is_last)
         xy0, xy1 = ncc_ref.block_points(bb0, bb1, dx, dy)
         keep = cf > conf_thresh
         if not np.any(keep):

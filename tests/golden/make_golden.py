@@ -1011,8 +1011,92 @@ def g23_matcher_loop():
     np.savez_compressed(os.path.join(OUT, 'g23_matcher_loop.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G24
+def scripted_strip_blocks(case, rnd, bboxes0, bboxes1, H, W):
+    """(dx, dy, conf) of every block of a round, in place of crop + xcorr_fft: 'rigid' -- the coarse round reports ONE integer
+    vector (the relaxation is then a rigid translation), 'deformed' / 'three' -- the coarse rounds disagree along the strip (mesh1
+    bends); the last round reports a small smooth field with a few outliers for the residue weights"""
+    b0 = np.asarray(bboxes0, dtype=np.float64)
+    c = 0.5 * (b0[:, :2] + b0[:, 2:])
+    u, v = c[:, 0] / W, c[:, 1] / H
+    h = np.abs(np.modf(np.sin(np.round(c[:, 0]) * 12.9898 + np.round(c[:, 1]) * 78.233 + 37.0 * rnd + len(case)) * 43758.5453)[0])
+    nrounds_coarse = 2 if case == 'three' else 1
+    if rnd < nrounds_coarse:
+        if case == 'rigid':
+            dx, dy = np.full(c.shape[0], 3.0), np.full(c.shape[0], -2.0)
+        else:
+            a = 1.0 / (1 + rnd)
+            dx = a * (2.0 + 3.0 * v - 1.0 * u); dy = a * (-1.0 + 2.5 * np.sin(3.0 * v + rnd))
+        conf = np.full(c.shape[0], 0.9, dtype=np.float32)
+        if c.shape[0] > 2:
+            conf[-1] = 0.2                                   # one block below the threshold
+    else:
+        dx = 0.3 * np.sin(7.0 * v + 2.0 * u) + 0.05 * (h - 0.5); dy = 0.25 * np.cos(5.0 * v) - 0.05 * (h - 0.5)
+        conf = (0.2 + 0.8 * h).astype(np.float32)
+        out = h > 0.9
+        dx = dx + 6.0 * out; dy = dy - 4.0 * out
+    return dx, dy, conf
+
+
+def g24_strip_loop():
+    """stitching_matcher's loop (matcher.py:353-364 -> 430-778) with its block matches scripted, on the cartesian mesh pair of a
+    strip: mesh0 translated by the global translation and locked, mesh1 free.  Three cases: a rigid coarse round, a bending
+    one, three spacings with two bending rounds.  The meshes are built from the grid of Mesh.from_bbox(cartesian=True)
+    (mesh.py:406-433) with the triangles the oracle uses (the reference's come from `triangle`)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import pipeline_ref as _pr                  # (only its cartesian_mesh: vertices of mesh.py:406-433 + a triangulation)
+    real_match = matcher.bboxes_mesh_renderer_matcher
+    real_ol = optimizer.SLM.optimize_linear
+
+    def converged(self, **kw):
+        kw['tol'] = 1e-11; kw['tolerated_perturbation'] = None; kw['callback_settings'] = {'chances': None, 'eval_step': 10}
+        kw['check_converge'] = True
+        return real_ol(self, **kw)
+    out = {}
+    cases = {'rigid': dict(H=1024, W=256, spacings=[256.0, 64.0], t0=(5.0, -3.0), residue_len=2.0),
+             'deformed': dict(H=1024, W=256, spacings=[256.0, 64.0], t0=(-4.0, 6.0), residue_len=2.0),
+             'three': dict(H=2048, W=128, spacings=[512.0, 128.0, 32.0], t0=(2.0, 1.0), residue_len=3.0)}
+    try:
+        optimizer.SLM.optimize_linear = converged
+        for name, cs in cases.items():
+            H, W = cs['H'], cs['W']
+            v, tri, xs, ys = _pr.cartesian_mesh(W, H, float(min(cs['spacings'])), min_num_blocks=2)
+            m0 = Mesh(v, tri, uid=0)
+            m0.apply_translation(cs['t0'], const.MESH_GEAR_FIXED)
+            m0.lock()
+            m1 = Mesh(v.copy(), tri, uid=1)
+            rounds = []
+
+            def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+                k = len(rounds)
+                rounds.append(dict(bboxes0=np.array(bboxes0), bboxes1=np.array(bboxes1), pad=bool(kw.get('pad')), subpixel=bool(kw.get('subpixel')),
+                                   field1=mesh1.vertices_w_offset(gear=const.MESH_GEAR_MOVING) - mesh1.vertices_w_offset(gear=const.MESH_GEAR_INITIAL)))
+                dx, dy, conf = scripted_strip_blocks(name, k, bboxes0, bboxes1, H, W)
+                c0 = common.bbox_centers(bboxes0); c1 = common.bbox_centers(bboxes1)
+                s0 = common.bbox_sizes(bboxes0); s1 = common.bbox_sizes(bboxes1)
+                ratio = (s0 / (s0 + s1))[:, ::-1]
+                dxy = np.stack((dx, dy), axis=-1)
+                return c0 - dxy * ratio, c1 + dxy * (1 - ratio), conf
+            matcher.bboxes_mesh_renderer_matcher = scripted
+            xy0, xy1, wt, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, None, None, spacings=np.array(cs['spacings']), distributor='cartesian_bbox',
+                                                                          conf_thresh=0.33, residue_len=cs['residue_len'], residue_mode='huber', opt_tol=None,
+                                                                          compute_strain=True, min_num_blocks=2)
+            out[f'{name}_nrounds'] = np.int64(len(rounds))
+            for k, r in enumerate(rounds):
+                for key in ('bboxes0', 'bboxes1', 'field1'):
+                    out[f'{name}_r{k}_{key}'] = r[key]
+                out[f'{name}_r{k}_flags'] = np.array([r['pad'], r['subpixel']])
+            out[f'{name}_xy0'] = xy0; out[f'{name}_xy1'] = xy1; out[f'{name}_weight'] = np.asarray(wt); out[f'{name}_strain'] = np.float64(strain)
+            out[f'{name}_params'] = np.array([H, W, cs['t0'][0], cs['t0'][1], cs['residue_len']], dtype=np.float64)
+            out[f'{name}_spacings'] = np.array(cs['spacings'])
+    finally:
+        matcher.bboxes_mesh_renderer_matcher = real_match
+        optimizer.SLM.optimize_linear = real_ol
+    np.savez_compressed(os.path.join(OUT, 'g24_strip_loop.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -581,3 +581,72 @@ def test_g23_matcher_loop_between_the_block_matches(case):
     np.testing.assert_allclose(xy0, g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g[f'{case}_xy1'], atol=1e-5)
     np.testing.assert_allclose(wt, g[f'{case}_weight'], atol=1e-5)
     np.testing.assert_allclose(strain, g[f'{case}_strain'], rtol=1e-5)
+
+
+# ----------------------------------------------------------------------- G24: the strip loop, block matches scripted
+def _g24_scripted_strip_blocks(case, rnd, bboxes0, bboxes1, H, W):
+    """(the script of tests/golden/make_golden.py::scripted_strip_blocks, word for word)"""
+    b0 = np.asarray(bboxes0, dtype=np.float64)
+    c = 0.5 * (b0[:, :2] + b0[:, 2:])
+    u, v = c[:, 0] / W, c[:, 1] / H
+    h = np.abs(np.modf(np.sin(np.round(c[:, 0]) * 12.9898 + np.round(c[:, 1]) * 78.233 + 37.0 * rnd + len(case)) * 43758.5453)[0])
+    nrounds_coarse = 2 if case == 'three' else 1
+    if rnd < nrounds_coarse:
+        if case == 'rigid':
+            dx, dy = np.full(c.shape[0], 3.0), np.full(c.shape[0], -2.0)
+        else:
+            a = 1.0 / (1 + rnd)
+            dx = a * (2.0 + 3.0 * v - 1.0 * u); dy = a * (-1.0 + 2.5 * np.sin(3.0 * v + rnd))
+        conf = np.full(c.shape[0], 0.9, dtype=np.float32)
+        if c.shape[0] > 2:
+            conf[-1] = 0.2
+    else:
+        dx = 0.3 * np.sin(7.0 * v + 2.0 * u) + 0.05 * (h - 0.5); dy = 0.25 * np.cos(5.0 * v) - 0.05 * (h - 0.5)
+        conf = (0.2 + 0.8 * h).astype(np.float32)
+        out = h > 0.9
+        dx = dx + 6.0 * out; dy = dy - 4.0 * out
+    return dx, dy, conf
+
+
+@pytest.mark.parametrize('case', ['rigid', 'deformed', 'three'])
+def test_g24_strip_loop_between_the_block_matches(case):
+    """pipeline_ref.match_pair's loop -- the oracle every GPU strip-pipeline parity test compares with -- against the reference's
+    stitching loop (matcher.py:353-364 -> 430-778) driven by the same scripted block matches: same blocks on the moving bounds
+    every round, same pad / subpixel flags, same field of mesh 1 going into every round (the rigid-translation short cut of the
+    oracle IS the reference's relaxation when the coarse matches agree; the bending branch is the reference's when they do not),
+    same final matches, weights and strain"""
+    from oracle import pipeline_ref
+    g = load_golden('g24_strip_loop.npz')
+    H, W, tx, ty, res_len = g[f'{case}_params']
+    H, W = int(H), int(W)
+    laid = []
+
+    def script(rnd, bb0, bb1):
+        laid.append((bb0, bb1))
+        if case == 'rigid' and rnd > 0:
+            # KNIFE EDGE, the reference's own: after a round that moved mesh 1 by whole pixels every bound of the two boxes sits on
+            # k + 1/2 and the width of their overlap is a whole number, so the lattice of the next round (ceil of width / n, round of
+            # the corners: common.py:394-407) turns on the SIGN of the residual its solver leaves in the translation (-2.99999986 for
+            # -3 in this fixture; the oracle's short cut, like the product's, holds exactly -3): the lattices may sit a pixel apart.
+            # The round then runs on the reference's recorded blocks, so that what follows them is still compared like for like.
+            bb0, bb1 = g[f'{case}_r{rnd}_bboxes0'], g[f'{case}_r{rnd}_bboxes1']
+            return _g24_scripted_strip_blocks(case, rnd, bb0, bb1, H, W) + (bb0, bb1)
+        return _g24_scripted_strip_blocks(case, rnd, bb0, bb1, H, W)
+    res = pipeline_ref.match_pair(None, None, spacings=g[f'{case}_spacings'], residue_len=float(res_len), conf_thresh=0.33, min_num_blocks=2,
+                                  block_script=script, script_start=(H, W, tx, ty))
+    n = int(g[f'{case}_nrounds'])
+    assert len(res['rounds']) == n
+    for k, r in enumerate(res['rounds']):
+        lattice_tol = 1 if (case == 'rigid' and k > 0) else 1e-6
+        assert laid[k][0].shape == g[f'{case}_r{k}_bboxes0'].shape
+        np.testing.assert_allclose(laid[k][0], g[f'{case}_r{k}_bboxes0'], atol=lattice_tol)
+        np.testing.assert_allclose(laid[k][1], g[f'{case}_r{k}_bboxes1'], atol=lattice_tol)
+        assert [bool(r['pad']), bool(r['subpixel'])] == g[f'{case}_r{k}_flags'].tolist()
+        want = g[f'{case}_r{k}_field1']
+        got = np.broadcast_to(r['field1'], want.shape) if r['field1'].shape[0] == 1 else r['field1']
+        np.testing.assert_allclose(got, want, atol=1e-6 * max(1.0, np.abs(want).max()))
+    assert bool(res.get('deformed')) == (case != 'rigid')
+    assert res['xy0'].shape == g[f'{case}_xy0'].shape
+    np.testing.assert_allclose(res['xy0'], g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(res['xy1'], g[f'{case}_xy1'], atol=1e-5)
+    np.testing.assert_allclose(res['weight'], g[f'{case}_weight'], atol=1e-5)
+    np.testing.assert_allclose(res['strain'], g[f'{case}_strain'], rtol=1e-5)
