@@ -263,6 +263,38 @@ class _RegionPair:
         out[ip[d2 < d * d]] = True
         return out
 
+    def near_boundary_raster(self, xs, ys, d):
+        """``near_boundary`` for the points of a raster (xs x ys, evenly spaced) as a [len(ys), len(xs)] mask: every outline segment
+        is measured against the raster cells of its own bounding box grown by d and against nothing else -- no tree, no point list
+        (the raster of an 8192^2 section pair at step 17.5 has 219 k points, 330 outline segments and 17 k such cells)"""
+        out = np.zeros((ys.size, xs.size), dtype=bool)
+        if out.size == 0 or self.segs.shape[0] == 0:
+            return out
+        a, b = self.segs[:, 0], self.segs[:, 1]
+        ab = b - a
+        l2 = np.maximum(np.sum(ab * ab, axis=1), 1e-300)
+        lo, hi = np.minimum(a, b) - d, np.maximum(a, b) + d
+        rx = (xs[-1] - xs[0]) / (xs.size - 1) if xs.size > 1 else 1.0
+        ry = (ys[-1] - ys[0]) / (ys.size - 1) if ys.size > 1 else 1.0
+        # one cell of slack on both sides: the candidate box only has to CONTAIN the d-neighbourhood, the distance test is exact
+        ix0 = np.clip(np.floor((lo[:, 0] - xs[0]) / rx).astype(np.int64) - 1, 0, xs.size); ix1 = np.clip(np.ceil((hi[:, 0] - xs[0]) / rx).astype(np.int64) + 2, 0, xs.size)
+        iy0 = np.clip(np.floor((lo[:, 1] - ys[0]) / ry).astype(np.int64) - 1, 0, ys.size); iy1 = np.clip(np.ceil((hi[:, 1] - ys[0]) / ry).astype(np.int64) + 2, 0, ys.size)
+        wx, wy = np.maximum(ix1 - ix0, 0), np.maximum(iy1 - iy0, 0)
+        cnt = wx * wy
+        total = int(cnt.sum())
+        if total == 0:
+            return out
+        iseg = np.repeat(np.arange(a.shape[0]), cnt)
+        local = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        ix = ix0[iseg] + local % wx[iseg]
+        iy = iy0[iseg] + local // wx[iseg]
+        p = np.stack((xs[ix], ys[iy]), axis=-1)
+        t = np.clip(np.einsum('ij,ij->i', p - a[iseg], ab[iseg]) / l2[iseg], 0.0, 1.0)
+        d2 = np.sum((p - (a[iseg] + t[:, None] * ab[iseg])) ** 2, axis=1)
+        hit = d2 < d * d
+        out[iy[hit], ix[hit]] = True
+        return out
+
     def select(self, pts, erode=0.0, tids=None):
         ok = self.inside(pts, tids)
         if erode > 0 and ok.any():
@@ -293,7 +325,10 @@ class _RegionPair:
             pts = np.stack((xx.ravel(), yy.ravel()), axis=-1)
             if float(res) not in self._located:               # located once per raster step, whatever is cut out of the region afterwards
                 self._located[float(res)] = self._locate(pts)
-            self._rasters[key] = (xs, ys, self.select(pts, erode, tids=self._located[float(res)]).reshape(yy.shape))
+            ok = self.inside(pts, self._located[float(res)]).reshape(yy.shape)
+            if erode > 0 and ok.any():
+                ok &= ~self.near_boundary_raster(xs, ys, erode)
+            self._rasters[key] = (xs, ys, ok)
         return self._rasters[key]
 
 
