@@ -127,6 +127,7 @@ _PROTOS = {
     'fb_next_fast_len': (c_i, [c_i]),
     'fb_ncc_batch': (c_i, [c_p, c_p, c_p] + [c_i] * 9 + [c_p, c_p, c_p]),
     'fb_ncc_batch_dev': (c_i, [c_p, c_p, c_p] + [c_i] * 9 + [c_p, c_p, c_p]),
+    'fb_ncc_batch_normalized': (c_i, [c_p, c_p, c_p] + [c_i] * 6 + [c_p, c_p] + [c_i] * 3 + [c_p, c_p, c_p]),
     'fb_ncc_blocks_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_ncc_blocks_affine_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_debug_fft1d': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i]),

@@ -221,6 +221,47 @@ __global__ void ncc_peak_final(const float* __restrict__ Csurf, const PeakPartia
     conf[n] = cf;
 }
 
+// ---- xcorr_fft(normalize=True), matcher.py:70-81, 119-122: the surfaces are divided by the overlap of the two masks at every lag
+// before the peak is looked for.  part[c] = (largest value of chunk c of NC, of NCm); the surfaces are rocFFT's un-normalised ones
+// (F = Fh Fw times the reference's).
+__global__ void ncc_norm_partial_max(const float* __restrict__ NC, const float* __restrict__ NCm, float2* __restrict__ part, int F) {
+    const int per = (F + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(F, lo + per);
+    float a = -INFINITY, b = -INFINITY;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) { a = fmaxf(a, NC[i]); b = fmaxf(b, NCm[i]); }
+    for (int off = 32; off > 0; off >>= 1) { a = fmaxf(a, __shfl_down(a, off)); b = fmaxf(b, __shfl_down(b, off)); }
+    __shared__ float sa[kThreads / 64], sb[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { a = fmaxf(a, sa[w]); b = fmaxf(b, sb[w]); }
+        part[blockIdx.x] = make_float2(a, b);
+    }
+}
+
+// D[0][i] = clip(NC[i] / max(max NC, 1), 0.1), D[1][i] likewise of NCm (both on the reference's scale: raw / F)
+__global__ void ncc_norm_divisors(const float* __restrict__ NC, const float* __restrict__ NCm, const float2* __restrict__ part, int nchunks,
+                                  int F, float* __restrict__ D) {
+    float a = -INFINITY, b = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) { a = fmaxf(a, part[c].x); b = fmaxf(b, part[c].y); }
+    const float inv = 1.0f / (float)F;
+    const float sa = fmaxf(a * inv, 1.0f), sb = fmaxf(b * inv, 1.0f);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F; i += gridDim.x * blockDim.x) {
+        D[i] = fmaxf(NC[i] * inv / sa, 0.1f);
+        D[(size_t)F + i] = fmaxf(NCm[i] * inv / sb, 0.1f);
+    }
+}
+
+__global__ void ncc_norm_apply(float* __restrict__ Csurf, float* __restrict__ Msurf, const float* __restrict__ D, int F, int want_m) {
+    const int n = blockIdx.y;
+    float* c = Csurf + (size_t)n * F;
+    float* m = want_m ? Msurf + (size_t)n * F : nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F; i += gridDim.x * blockDim.x) {
+        c[i] = c[i] / D[i];
+        if (want_m) m[i] = m[i] / D[(size_t)F + i];
+    }
+}
+
 int ensure_rocfft(fb_ctx* ctx) {
     if (ctx->rocfft_ready) return FB_OK;
     if (fb_rocfft_acquire() != 0) return fb_fail(ctx, FB_ERR_FFT, "rocfft_setup failed");
@@ -281,7 +322,7 @@ struct CropSrc { const int* blk; int IH0, IW0, IH1, IW1; const double* aff = nul
 
 int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int nb, int C, int H0, int W0, int H1,
                         int W1, int Fh, int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf,
-                        const CropSrc* crop = nullptr, int nbq = 0) {
+                        const CropSrc* crop = nullptr, int nbq = 0, const float* divisors = nullptr) {
     // nbq >= nb: number of slots the buffers and the rocFFT plans are built for (quantised so that
     // plans are reused across calls); slots [nb, nbq) hold stale data whose transforms are ignored.
     if (nbq < nb) nbq = nb;
@@ -354,6 +395,11 @@ int ncc_stream_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
             void* out[1] = {Csurf};
             FB_FFT(ctx, rocfft_execute(pl1->inv, in, out, ctx->fft_info));
         }
+    }
+    if (divisors) {                          // normalize=True: C / NC and C_mirror / NC_mirror ahead of everything that looks at them
+        FB_PROF(ctx, "ncc_norm_apply");
+        hipLaunchKernelGGL(ncc_norm_apply, dim3((unsigned)std::min<size_t>((F + kThreads - 1) / kThreads, 2048), nreal), dim3(kThreads), 0, ctx->stream,
+                           Csurf, Msurf, divisors, (int)F, want_q);
     }
     {
         FB_PROF(ctx, "ncc_peak_partial");
@@ -919,6 +965,67 @@ int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C
     if (d0) fb_free(ctx, d0);
     if (d1) fb_free(ctx, d1);
     if (dres) fb_free(ctx, dres);
+    return rc;
+}
+
+int fb_ncc_batch_normalized(fb_ctx* ctx, const float* img0, const float* img1, int N, int C, int H0, int W0, int H1, int W1,
+                            const float* mask0, const float* mask1, int pad, int subpixel, int conf_mode, double* dx, double* dy, float* conf) {
+    FB_LOCK(ctx);
+    FB_CHECK_ARG(ctx, N >= 0 && C >= 1 && H0 > 0 && W0 > 0 && H1 > 0 && W1 > 0);
+    FB_CHECK_ARG(ctx, conf_mode >= 0 && conf_mode <= 2);
+    if (N == 0) return FB_OK;
+    FB_CHECK_ARG(ctx, img0 && img1 && dx && dy && conf);
+    FB_HIP(ctx, hipSetDevice(ctx->device));
+    const int Fh = pad ? fb_next_fast_len(H0 + H1 - 1) : fb_next_fast_len(std::max(H0, H1));
+    const int Fw = pad ? fb_next_fast_len(W0 + W1 - 1) : fb_next_fast_len(std::max(W0, W1));
+    const size_t F = (size_t)Fh * Fw;
+    FB_CHECK_ARG(ctx, F < ((size_t)1 << 31));
+    int rc = ensure_rocfft(ctx);
+    if (rc) return rc;
+    const size_t b0 = (size_t)N * C * H0 * W0 * sizeof(float), b1 = (size_t)N * C * H1 * W1 * sizeof(float);
+    const size_t m0b = (size_t)H0 * W0 * sizeof(float), m1b = (size_t)H1 * W1 * sizeof(float);
+    void *d0 = nullptr, *d1 = nullptr, *dm0 = nullptr, *dm1 = nullptr, *dD = nullptr, *dres = nullptr, *dpart = nullptr;
+    rc = fb_malloc(ctx, b0, &d0);
+    if (!rc) rc = fb_malloc(ctx, b1, &d1);
+    if (!rc) rc = fb_malloc(ctx, m0b, &dm0);
+    if (!rc) rc = fb_malloc(ctx, m1b, &dm1);
+    if (!rc) rc = fb_malloc(ctx, 2 * F * sizeof(float), &dD);
+    if (!rc) rc = fb_malloc(ctx, (size_t)(N + 1) * 24, &dres);
+    if (!rc) rc = fb_malloc(ctx, kPeakChunks * sizeof(float2), &dpart);
+    double* ddx = (double*)dres; double* ddy = ddx ? ddx + (N + 1) : nullptr; float* dconf = ddy ? (float*)(ddy + (N + 1)) : nullptr;
+    if (!rc) {
+        // the masks (all ones when absent: matcher.py:71-74)
+        std::vector<float> ones;
+        if (!mask0 || !mask1) ones.assign(std::max((size_t)H0 * W0, (size_t)H1 * W1), 1.0f);
+        rc = fb_copy_h2d(ctx, dm0, mask0 ? mask0 : ones.data(), m0b);
+        if (!rc) rc = fb_copy_h2d(ctx, dm1, mask1 ? mask1 : ones.data(), m1b);
+        if (!rc) rc = fb_copy_h2d(ctx, d0, img0, b0);
+        if (!rc) rc = fb_copy_h2d(ctx, d1, img1, b1);
+    }
+    if (!rc) {
+        // NC = irfft2(conj(M0) M1), NC_mirror = irfft2(M0 M1): the correlation pipeline itself on the pair of masks
+        rc = ncc_stream_subbatch(ctx, (const float*)dm0, (const float*)dm1, 1, 1, H0, W0, H1, W1, Fh, Fw, 0, FB_CONF_MIRROR, ddx + N, ddy + N, dconf + N, nullptr, 1);
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(ncc_norm_partial_max, dim3(kPeakChunks), dim3(kThreads), 0, ctx->stream, ctx->last_C, ctx->last_Cm, (float2*)dpart, (int)F);
+        hipLaunchKernelGGL(ncc_norm_divisors, dim3((unsigned)std::min<size_t>((F + kThreads - 1) / kThreads, 2048)), dim3(kThreads), 0, ctx->stream,
+                           ctx->last_C, ctx->last_Cm, (const float2*)dpart, kPeakChunks, (int)F, (float*)dD);
+        FB_HIP(ctx, hipGetLastError());
+        const size_t per_pair = (size_t)C * (F * 4 + (size_t)Fh * (Fw / 2 + 1) * 8) * 2 + (C > 1 ? (size_t)Fh * (Fw / 2 + 1) * 16 : 0);
+        const int nb_max = quantised_chunk(ctx, N, per_pair);
+        for (int n0 = 0; n0 < N && !rc; n0 += nb_max) {
+            const int nb = std::min(nb_max, N - n0);
+            rc = ncc_stream_subbatch(ctx, (const float*)d0 + (size_t)n0 * C * H0 * W0, (const float*)d1 + (size_t)n0 * C * H1 * W1, nb, C, H0, W0, H1, W1,
+                                     Fh, Fw, subpixel, conf_mode, ddx + n0, ddy + n0, dconf + n0, nullptr, nb_max, (const float*)dD);
+        }
+    }
+    if (!rc) {
+        rc = fb_copy_d2h(ctx, dx, ddx, N * sizeof(double));
+        if (!rc) rc = fb_copy_d2h(ctx, dy, ddy, N * sizeof(double));
+        if (!rc) rc = fb_copy_d2h(ctx, conf, dconf, N * sizeof(float));
+    }
+    for (void* q : {d0, d1, dm0, dm1, dD, dres, dpart})
+        if (q) fb_free(ctx, q);
     return rc;
 }
 

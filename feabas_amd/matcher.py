@@ -27,14 +27,14 @@ def xcorr_fft(img0, img1, conf_mode=const.FFT_CONF_MIRROR, **kwargs):
     img0: N x H0 x W0 (x C), img1: N x H1 x W1 (x C).  Returns dx, dy (float64)
     and conf so that centre(img1) + (dx, dy) corresponds to centre(img0).
     kwargs: sigma, mask0, mask1 (DoG pre-filter, matcher.py:54-56), subpixel,
-    pad.  ``normalize=True`` is not used by any reference call site and is
-    rejected.
+    pad, normalize (matcher.py:70-81, 119-122: the surfaces divided by the overlap
+    of the masks at every lag -- no reference call site enables it; the rocFFT
+    class of the library, ``fb_ncc_batch_normalized``).
     """
     sigma = kwargs.get('sigma', 0)
     mask0 = kwargs.get('mask0', None)
     mask1 = kwargs.get('mask1', None)
-    if kwargs.get('normalize', False):
-        raise NotImplementedError('xcorr_fft(normalize=True) is outside the hot path (no reference call site uses it)')
+    normalize = bool(kwargs.get('normalize', False))
     subpixel = kwargs.get('subpixel', False)
     pad = kwargs.get('pad', True)
     img0 = np.asarray(img0)
@@ -57,7 +57,19 @@ def xcorr_fft(img0, img1, conf_mode=const.FFT_CONF_MIRROR, **kwargs):
     dx = np.empty(n, dtype=np.float64)
     dy = np.empty(n, dtype=np.float64)
     conf = np.empty(n, dtype=np.float32)
-    if n > 0:
+    if n > 0 and normalize:
+        mks = []
+        for mk, shp, name in ((mask0, (h0, w0), 'mask0'), (mask1, (h1, w1), 'mask1')):
+            if mk is not None:
+                mk = np.ascontiguousarray(mk, dtype=np.float32)
+                if mk.shape != shp:
+                    raise ValueError(f'xcorr_fft(normalize=True): {name} must have the shape of one image, {shp}')
+            mks.append(mk)
+        _lib.check(_lib.load().fb_ncc_batch_normalized(_lib.ctx(), _lib.ptr(a), _lib.ptr(b), n, ch, h0, w0, h1, w1,
+                                                       None if mks[0] is None else _lib.ptr(mks[0]), None if mks[1] is None else _lib.ptr(mks[1]),
+                                                       1 if pad else 0, 1 if subpixel else 0, int(conf_mode),
+                                                       _lib.ptr(dx), _lib.ptr(dy), _lib.ptr(conf)))
+    elif n > 0:
         _lib.check(_lib.load().fb_ncc_batch(_lib.ctx(), _lib.ptr(a), _lib.ptr(b), n, ch, h0, w0, h1, w1,
                                             1 if pad else 0, 1 if subpixel else 0, int(conf_mode),
                                             _lib.ptr(dx), _lib.ptr(dy), _lib.ptr(conf)))

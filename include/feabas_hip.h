@@ -104,6 +104,14 @@ int fb_ncc_batch(fb_ctx* ctx, const float* img0, const float* img1, int N, int C
 int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, int C,
                      int H0, int W0, int H1, int W1, int pad, int subpixel, int conf_mode,
                      double* dx, double* dy, float* conf);
+/* matcher.xcorr_fft(normalize=True) (matcher.py:70-81, 119-122; no reference call site enables it): as fb_ncc_batch, with the
+ * correlation surface divided by NC = irfft2(conj(M0) M1) of the two masks -- scaled by its maximum (at least 1) and clipped at
+ * 0.1 -- before the peak, the sub-pixel fit and the confidence look at it, and the mirror surface by the same of irfft2(M0 M1).
+ * mask0 [H0][W0], mask1 [H1][W1]: host float32, one pair for the whole batch; NULL = all ones.  Runs on the rocFFT class (the
+ * surfaces exist in memory there) whatever the shape. */
+int fb_ncc_batch_normalized(fb_ctx* ctx, const float* img0, const float* img1, int N, int C,
+                            int H0, int W0, int H1, int W1, const float* mask0, const float* mask1,
+                            int pad, int subpixel, int conf_mode, double* dx, double* dy, float* conf);
 /* Block matching straight from resident image stacks: the translation-only form of
  * MeshRenderer.crop_multiple + xcorr_fft (matcher.py:834-846).  imgs0 [P][IH0][IW0], imgs1
  * [P][IH1][IW1] float32 (DoG output); blk [N][9] int32 = {image, x0, y0, h0, w0, x1, y1, h1, w1}:

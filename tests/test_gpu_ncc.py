@@ -447,3 +447,25 @@ def test_dog_of_two_stacks_in_one_launch(fb):
             np.testing.assert_array_equal(got[k], fb.common.masked_dog_filter(fb.common.area_downsample2(src), 1.25))
         for buf in (da, db, dfa, dfb, d_out):
             buf.free()
+
+
+@pytest.mark.skipif(not __import__('os').environ.get('FEABAS_TEST_PENDING'), reason='written after the GPU pool closed for round 5: never run on hardware yet (FEABAS_TEST_PENDING=1 runs it)')
+@pytest.mark.parametrize('tag', ['masks', 'ones'])
+@pytest.mark.parametrize('pad', [1, 0])
+@pytest.mark.parametrize('cm', [0, 1, 2])
+def test_g20_xcorr_normalized_vs_reference(fb, tag, pad, cm):
+    """xcorr_fft(normalize=True) (matcher.py:70-81, 119-122; fb_ncc_batch_normalized) against the reference's own outputs: golden
+    G20, the cases the oracle is pinned by (tests/test_oracle_golden.py::test_g20_xcorr_normalized)"""
+    g = load_golden('g20_xcorr_normalized.npz')
+    if tag == 'masks':
+        a, b, kw = g['img0'] * g['mask0'], g['img1'] * g['mask1'], dict(mask0=g['mask0'], mask1=g['mask1'])
+    else:
+        a, b, kw = g['img0'], g['img1'], {}
+    got = fb.matcher.xcorr_fft(a, b, conf_mode=cm, pad=bool(pad), subpixel=True, normalize=True, **kw)
+    key = f'{tag}_p{pad}_c{cm}'
+    fh, fw = ncc_ref.fft_shape(a.shape[-2:], b.shape[-2:], bool(pad))
+    _check(got, (g[key + '_dx'], g[key + '_dy'], g[key + '_conf']), conf_atol=(2.5 * fh * fw * 6e-8 if cm == 1 else None))
+    # and against the plain call: the normalisation must have been applied
+    if cm == 2 and tag == 'masks':
+        plain = fb.matcher.xcorr_fft(a, b, conf_mode=cm, pad=bool(pad), subpixel=True)
+        assert np.abs(plain[2] - got[2]).max() > 1e-3
