@@ -689,3 +689,14 @@ def test_round_stepper_against_the_walks_of_the_reference():
             # the reference's record carries the spacing through affine_approx_tol = 0.1 on the last spacing, max(1, 0.02 sp) before
             assert (gtol == 0.1 and sp == sp_list[-1]) if last else abs(max(1.0, 0.02 * sp) - gtol) < 1e-9, (name, sp, gtol)
             assert side <= np.ceil(sp) + 1e-9                       # (divide_bbox fits the blocks into the overlap: never larger than the spacing)
+
+
+def test_python_sources_have_no_unbound_globals():
+    """tools/check_names.py over the package, bench.py, the entry module, the oracle and the tests: a name that only a GPU run would
+    reach (a side record of bench.py, an error path of the matcher) must not wait for the GPU box to turn out misspelt"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_names.py')], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:]
