@@ -21,6 +21,28 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib._PROTOS) <= set(names)
 
 
+def test_bindings_agree_with_the_header():
+    """every fb_* entry the python side calls has a ctypes prototype (an unprototyped call would pass pointers as C ints), and every
+    prototype has as many arguments as the declaration in include/feabas_hip.h"""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    used = set()
+    for f in glob.glob(os.path.join(root, 'feabas_amd', '*.py')) + [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')] \
+            + glob.glob(os.path.join(root, 'tests', '*.py')) + glob.glob(os.path.join(root, 'tools', '*.py')):
+        used.update(re.findall(r'\.(fb_[a-z0-9_]+)\b', open(f).read()))
+    assert len(used) > 80 and used <= set(_lib._PROTOS), sorted(used - set(_lib._PROTOS))
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(root, 'include', 'feabas_hip.h')).read(), flags=re.S)
+    seen = 0
+    for m in re.finditer(r'\b[A-Za-z_][A-Za-z0-9_]*\s*\*?\s+\*?(fb_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', hdr, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        if name in _lib._PROTOS:
+            seen += 1
+            assert len(_lib._PROTOS[name][1]) == (0 if args in ('', 'void') else len(args.split(','))), name
+    assert seen == len(_lib._PROTOS)
+
+
 def test_no_cpu_fallback_without_gpu():
     lib = _lib.load()
     if lib.fb_create(0):
