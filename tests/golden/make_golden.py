@@ -1095,8 +1095,93 @@ def g24_strip_loop():
     np.savez_compressed(os.path.join(OUT, 'g24_strip_loop.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G25
+def scripted_strip_result(k, img0, img1, mask0, mask1, cfg):
+    """what the scripted stitching_matcher hands back for its k-th call, and what it notes about the call"""
+    note = np.array([img0.shape[0], img0.shape[1], img1.shape[0], img1.shape[1], int(img0.astype(np.int64).sum()), int(img1.astype(np.int64).sum()),
+                     -1 if mask0 is None else int(np.count_nonzero(mask0)), -1 if mask1 is None else int(np.count_nonzero(mask1))], dtype=np.int64)
+    if k % 4 == 3:
+        return note, (None, None, cfg.get('conf_thresh', 0.3), None, None)
+    h0, w0 = img0.shape[:2]; h1, w1 = img1.shape[:2]
+    xy0 = np.array([[1.0, 2.0], [0.5 * w0, 0.5 * h0], [w0 - 3.0 + 0.25 * k, h0 - 2.0]])
+    xy1 = np.array([[2.0, 1.0], [0.5 * w1 - 0.5, 0.5 * h1 + 0.125 * k], [w1 - 4.0, h1 - 1.0]])
+    weight = np.array([0.5, 0.75, 0.25 + 0.01 * k])
+    phtm = (10.0 + k, 20.0 + k, 3.0, 4.0) if cfg.get('compute_photometric', False) else None
+    return note, (xy0, xy1, weight, 0.01 * (k + 1), phtm)
+
+
+def g25_overlap_bookkeeping():
+    """Stitcher.subprocess_match_list_of_overlaps (stitcher.py:474-621) around a scripted stitching_matcher: which strips it
+    crops for every overlap (margins as a ratio and in pixels, the minimum width, boxes clipped to their tiles), the masks it
+    derives from `maskout_val`, the offsets it adds to the matches and the keys it files them under (`index_mapper`).  The image
+    loader is a stand-in that cuts the asked box out of arrays held in memory (dal.StaticImageLoader reads files through cv2)."""
+    from feabas import stitcher as rstitcher
+    rng = np.random.default_rng(25)
+    th, tw = 300, 400
+    bboxes = []
+    for r in range(2):
+        for c in range(3):
+            x0 = c * (tw - 44) + int(rng.integers(-6, 7)); y0 = r * (th - 38) + int(rng.integers(-6, 7))
+            bboxes.append((x0, y0, x0 + tw, y0 + th))
+    bboxes = np.array(bboxes, dtype=np.int64)
+    yy, xx = np.meshgrid(np.arange(-20, 2 * th + 20), np.arange(-20, 3 * tw + 20), indexing='ij')
+    world = ((xx * 7 + yy * 13 + (xx * yy) // 31) % 251 + 1).astype(np.uint8)             # 1..251: no pixel is 0 by itself
+    tiles = []
+    for k, (x0, y0, x1, y1) in enumerate(bboxes):
+        t = world[y0 + 20:y1 + 20, x0 + 20:x1 + 20].copy()
+        if k in (1, 4):                                         # a blanked corner patch and a blanked band (the scanner's fill value)
+            t[:40, -60:] = 0
+            t[-25:, 100:180] = 0
+        tiles.append(t)
+    overlaps = np.array([(1, 0), (2, 1), (3, 0), (4, 1), (4, 3), (5, 2), (5, 4), (4, 0), (3, 1), (5, 1), (4, 2)], dtype=np.int64)
+
+    class ArrayLoader:
+        def __init__(self, imgpaths, bxs, root_dir=None, **cfg):
+            self.imgrootdir = root_dir; self.imgrelpaths = list(imgpaths); self.cfg = cfg; self.bxs = np.asarray(bxs)
+            self.filepaths_generator = list(imgpaths)
+
+        def crop(self, bbox, idx, return_index=False, **kw):
+            x0, y0, x1, y1 = (int(v) for v in bbox)
+            bx0, by0 = self.bxs[idx][:2]
+            assert x0 >= bx0 and y0 >= by0 and x1 <= self.bxs[idx][2] and y1 <= self.bxs[idx][3]
+            return tiles[idx][y0 - by0:y1 - by0, x0 - bx0:x1 - bx0]
+
+        def clear_cache(self):
+            pass
+    cases = {'ratio_margin': dict(margin=1.0, min_overlap_width=0),
+             'masked_mapped': dict(margin=0.5, min_overlap_width=35, maskout_val=0, index_mapper=np.arange(6) + 100,
+                                   matcher_config=dict(compute_photometric=True, conf_thresh=0.4)),
+             'pixel_margin': dict(margin=30, min_overlap_width=10, maskout_val=0)}
+    out = dict(bboxes=bboxes, overlaps=overlaps)
+    for k, t in enumerate(tiles):
+        out[f'tile{k}'] = t
+    real_loader, real_matcher = rstitcher.StaticImageLoader, rstitcher.stitching_matcher
+    try:
+        rstitcher.StaticImageLoader = ArrayLoader
+        for name, kw in cases.items():
+            notes = []
+
+            def scripted(img0, img1, mask0=None, mask1=None, **cfg):
+                note, res = scripted_strip_result(len(notes), img0, img1, mask0, mask1, cfg)
+                notes.append(note)
+                return res
+            rstitcher.stitching_matcher = scripted
+            matches, strains, phtm, err = rstitcher.Stitcher.subprocess_match_list_of_overlaps(overlaps, [f't{k}.png' for k in range(6)], bboxes, **kw)
+            assert not err
+            keys = sorted(matches)
+            out[f'{name}_calls'] = np.stack(notes)
+            out[f'{name}_keys'] = np.array(keys, dtype=np.int64).reshape(-1, 2)
+            for j, key in enumerate(keys):
+                out[f'{name}_m{j}_xy0'], out[f'{name}_m{j}_xy1'], out[f'{name}_m{j}_w'] = matches[key]
+                out[f'{name}_m{j}_strain'] = np.float64(strains[key])
+                out[f'{name}_m{j}_phtm'] = np.array(phtm[key], dtype=np.float64) if key in phtm else np.empty(0)
+    finally:
+        rstitcher.StaticImageLoader, rstitcher.stitching_matcher = real_loader, real_matcher
+    np.savez_compressed(os.path.join(OUT, 'g25_overlap_bookkeeping.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -722,3 +722,44 @@ def test_python_sources_have_no_unbound_globals():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_names.py')], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize('case', ['ratio_margin', 'masked_mapped', 'pixel_margin'])
+def test_g25_overlap_bookkeeping_vs_reference(monkeypatch, case):
+    """stitcher.match_list_of_overlaps against the reference's Stitcher.subprocess_match_list_of_overlaps (stitcher.py:474-621,
+    golden G25): around the same scripted matcher both sides crop the same strips for the same overlaps (margin as a ratio / in
+    pixels, minimum width, boxes clipped to their tiles), derive the same masks from `maskout_val`, add the same offsets to
+    the matches and file them under the same keys"""
+    from feabas_amd import stitcher
+    g = load_golden('g25_overlap_bookkeeping.npz')
+    kw = {'ratio_margin': dict(margin=1.0, min_overlap_width=0),
+          'masked_mapped': dict(margin=0.5, min_overlap_width=35, maskout_val=0, index_mapper=np.arange(6) + 100,
+                                matcher_config=dict(compute_photometric=True, conf_thresh=0.4)),
+          'pixel_margin': dict(margin=30, min_overlap_width=10, maskout_val=0)}[case]
+    notes = []
+
+    def scripted(img0, img1, mask0, mask1, cfg):
+        """(tests/golden/make_golden.py::scripted_strip_result)"""
+        k = len(notes)
+        notes.append(np.array([img0.shape[0], img0.shape[1], img1.shape[0], img1.shape[1], int(img0.astype(np.int64).sum()), int(img1.astype(np.int64).sum()),
+                               -1 if mask0 is None else int(np.count_nonzero(mask0)), -1 if mask1 is None else int(np.count_nonzero(mask1))], dtype=np.int64))
+        if k % 4 == 3:
+            return (None, None, cfg.get('conf_thresh', 0.3), None, None)
+        h0, w0 = img0.shape[:2]; h1, w1 = img1.shape[:2]
+        xy0 = np.array([[1.0, 2.0], [0.5 * w0, 0.5 * h0], [w0 - 3.0 + 0.25 * k, h0 - 2.0]])
+        xy1 = np.array([[2.0, 1.0], [0.5 * w1 - 0.5, 0.5 * h1 + 0.125 * k], [w1 - 4.0, h1 - 1.0]])
+        phtm = (10.0 + k, 20.0 + k, 3.0, 4.0) if cfg.get('compute_photometric', False) else None
+        return (xy0, xy1, np.array([0.5, 0.75, 0.25 + 0.01 * k]), 0.01 * (k + 1), phtm)
+    monkeypatch.setattr(stitcher, 'stitching_matcher_batch', lambda pairs, batch=32, threads=2, **cfg: [scripted(*pr, cfg) for pr in pairs])
+    tiles = [g[f'tile{k}'] for k in range(6)]
+    matches, strains, phtm, err = stitcher.match_list_of_overlaps(g['overlaps'], tiles, g['bboxes'], **kw)
+    assert not err
+    np.testing.assert_array_equal(np.stack(notes), g[f'{case}_calls'])
+    keys = sorted(matches)
+    np.testing.assert_array_equal(np.array(keys, dtype=np.int64).reshape(-1, 2), g[f'{case}_keys'])
+    for j, key in enumerate(keys):
+        np.testing.assert_array_equal(matches[key][0], g[f'{case}_m{j}_xy0'])
+        np.testing.assert_array_equal(matches[key][1], g[f'{case}_m{j}_xy1'])
+        np.testing.assert_array_equal(matches[key][2], g[f'{case}_m{j}_w'])
+        assert strains[key] == float(g[f'{case}_m{j}_strain'])
+        np.testing.assert_array_equal(np.array(phtm[key], dtype=np.float64) if key in phtm else np.empty(0), g[f'{case}_m{j}_phtm'])
