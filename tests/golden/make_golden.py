@@ -1180,8 +1180,96 @@ def g25_overlap_bookkeeping():
     np.savez_compressed(os.path.join(OUT, 'g25_overlap_bookkeeping.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G26
+def g26_inputs():
+    """three meshes: a square (locked), an L-shaped one, and one that falls into two islands; links 0-1, 1-2, 0-2 with a few matches
+    that miss (outside a mesh) and weights; everything at the INITIAL gear, mesh 2 displaced at MOVING"""
+    rng = np.random.default_rng(26)
+
+    def grid(x0, y0, nx, ny, step, drop=None):
+        gx, gy = np.meshgrid(x0 + step * np.arange(nx + 1), y0 + step * np.arange(ny + 1))
+        v = np.stack((gx.ravel(), gy.ravel()), axis=-1).astype(np.float64)
+        tri = []
+        for j in range(ny):
+            for i in range(nx):
+                if drop is not None and drop(i, j):
+                    continue
+                a = j * (nx + 1) + i; b = a + 1; c = a + nx + 1; d = c + 1
+                tri += [(a, b, d), (a, d, c)]
+        tri = np.array(tri, dtype=np.int32)
+        used = np.unique(tri)
+        remap = -np.ones(v.shape[0], dtype=np.int64); remap[used] = np.arange(used.size)
+        return v[used], remap[tri].astype(np.int32)
+    v0, t0 = grid(0, 0, 6, 6, 50.0)
+    v1, t1 = grid(180, 20, 6, 6, 50.0, drop=lambda i, j: i >= 3 and j >= 3)
+    v2, t2 = grid(40, 220, 8, 4, 50.0, drop=lambda i, j: i in (3, 4))            # two islands: columns 0-2 and 5-7
+    pts = {}
+    for name, (lo, hi) in {'01': ((190, 30), (295, 295)), '12': ((185, 225), (440, 330)), '02': ((45, 225), (295, 295))}.items():
+        n = 40
+        p = rng.uniform(lo, hi, (n, 2))
+        pts[name] = (p, p + rng.normal(0, 1.5, (n, 2)), rng.uniform(0.2, 1.0, n))
+    d2 = 3.0 * np.stack((np.sin(v2[:, 1] / 70.0), np.cos(v2[:, 0] / 90.0)), axis=-1)
+    return (v0, t0), (v1, t1), (v2, t2), pts, d2
+
+
+def g26_slm_bookkeeping():
+    """the host-side bookkeeping of SLM around the solves (optimizer.py:637-754, 1678-1703, 1758-1858): links from coordinates
+    (which matches survive the point location), linkage_adjacency, connected_subsystems, match_residues,
+    divide_disconnected_submeshes with prune_links / distribute_link (the sub-mesh uids, which part gets which matches)"""
+    (v0, t0), (v1, t1), (v2, t2), pts, d2 = g26_inputs()
+    out = dict(v0=v0, t0=t0, v1=v1, t1=t1, v2=v2, t2=t2, d2=d2)
+    m0 = Mesh(v0, t0, uid=0); m0.lock()
+    m1 = Mesh(v1, t1, uid=1)
+    m2 = Mesh(v2, t2, uid=2)
+    m2.set_vertices(v2 + d2, const.MESH_GEAR_MOVING)
+    opt = optimizer.SLM([m0, m1, m2])
+    from matplotlib.tri import Triangulation
+    meshes = {0: (m0, v0, t0), 1: (m1, v1, t1), 2: (m2, v2, t2)}
+
+    def locate(k, p):
+        # (the reference's own tri_finder needs shapely as soon as a mesh has two regions, like mesh 2: the links of the whole
+        # meshes are made from triangle ids and barycentric coordinates located here and stored in the fixture)
+        _, v, t = meshes[k]
+        tid = np.asarray(Triangulation(v[:, 0], v[:, 1], t).get_trifinder()(p[:, 0], p[:, 1]))
+        ok = tid >= 0
+        tri = v[t[np.where(ok, tid, 0)]]
+        T = np.stack((tri[:, 0] - tri[:, 2], tri[:, 1] - tri[:, 2]), axis=-1)
+        l12 = np.linalg.solve(T, (p - tri[:, 2])[..., None])[..., 0]
+        return tid, ok, np.concatenate((l12, 1 - l12.sum(axis=1, keepdims=True)), axis=1)
+    for name, (a, b) in {'01': (0, 1), '12': (1, 2), '02': (0, 2)}.items():
+        p0, p1, w = pts[name]
+        tid0, ok0, B0 = locate(a, p0); tid1, ok1, B1 = locate(b, p1)
+        ok = ok0 & ok1
+        out[f'lk{name}_tid0'], out[f'lk{name}_tid1'], out[f'lk{name}_B0'], out[f'lk{name}_B1'], out[f'lk{name}_w'] = tid0[ok], tid1[ok], B0[ok], B1[ok], w[ok]
+        opt.add_link(optimizer.Link(meshes[a][0], meshes[b][0], tid0[ok], tid1[ok], B0[ok], B1[ok], weight=w[ok]))
+
+    def describe(tag):
+        out[f'{tag}_nlinks'] = np.int64(len(opt.links))
+        out[f'{tag}_mesh_uids'] = np.array([m.uid for m in opt.meshes], dtype=np.float64)
+        out[f'{tag}_mesh_ntri'] = np.array([m.num_triangles for m in opt.meshes], dtype=np.int64)
+        for k, lk in enumerate(opt.links):
+            out[f'{tag}_l{k}_uids'] = np.array(lk.uids, dtype=np.float64)
+            out[f'{tag}_l{k}_xy0'] = lk.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True)
+            out[f'{tag}_l{k}_xy1'] = lk.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True)
+            out[f'{tag}_l{k}_w'] = np.asarray(lk.weight(use_mask=False), dtype=np.float64)
+        # (the reference caches the first matrix it makes, whatever `directional` was: the cache is emptied between the two calls)
+        opt._linkage_adjacency = None; opt._connected_subsystems = None
+        out[f'{tag}_adj_dir'] = opt.linkage_adjacency(directional=True).toarray()
+        opt._linkage_adjacency = None
+        out[f'{tag}_adj'] = opt.linkage_adjacency().toarray()
+        lab, ncomp = opt.connected_subsystems
+        out[f'{tag}_ncomp'] = np.int64(ncomp); out[f'{tag}_labels'] = np.asarray(lab, dtype=np.int64)
+        for q in (0, 0.75, 1):
+            out[f'{tag}_res_q{q}'] = opt.match_residues(gear=const.MESH_GEAR_MOVING, quantile=q)
+        out[f'{tag}_res_init'] = opt.match_residues(gear=const.MESH_GEAR_INITIAL, quantile=0.5)
+    describe('whole')
+    out['divided'] = np.bool_(opt.divide_disconnected_submeshes())
+    describe('parts')
+    np.savez_compressed(os.path.join(OUT, 'g26_slm_bookkeeping.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -763,3 +763,42 @@ def test_g25_overlap_bookkeeping_vs_reference(monkeypatch, case):
         np.testing.assert_array_equal(matches[key][2], g[f'{case}_m{j}_w'])
         assert strains[key] == float(g[f'{case}_m{j}_strain'])
         np.testing.assert_array_equal(np.array(phtm[key], dtype=np.float64) if key in phtm else np.empty(0), g[f'{case}_m{j}_phtm'])
+
+
+def test_g26_slm_bookkeeping_vs_reference():
+    """the host-side bookkeeping of SLM around the solves against the reference (golden G26, optimizer.py:688-754, 1678-1703,
+    1758-1858): adjacency of the link graph (directional or not), connected subsystems, match residues, and a mesh that falls
+    into two islands being replaced by its parts with the links dealt to the parts that hold their matches"""
+    from feabas_amd import optimizer
+    from feabas_amd.mesh import Mesh
+    import feabas_amd.constant as const
+    g = load_golden('g26_slm_bookkeeping.npz')
+    m0 = Mesh(g['v0'], g['t0'], uid=0); m0.lock()
+    m1 = Mesh(g['v1'], g['t1'], uid=1)
+    m2 = Mesh(g['v2'], g['t2'], uid=2)
+    m2.set_vertices(g['v2'] + g['d2'], const.MESH_GEAR_MOVING)
+    opt = optimizer.SLM([m0, m1, m2])
+    meshes = {0: m0, 1: m1, 2: m2}
+    for name, (a, b) in {'01': (0, 1), '12': (1, 2), '02': (0, 2)}.items():
+        opt.add_link(optimizer.Link(meshes[a], meshes[b], g[f'lk{name}_tid0'], g[f'lk{name}_tid1'], g[f'lk{name}_B0'], g[f'lk{name}_B1'], weight=g[f'lk{name}_w']))
+
+    def check(tag):
+        assert len(opt.links) == int(g[f'{tag}_nlinks'])
+        np.testing.assert_allclose([m.uid for m in opt.meshes], g[f'{tag}_mesh_uids'], atol=1e-12)
+        np.testing.assert_array_equal([m.num_triangles for m in opt.meshes], g[f'{tag}_mesh_ntri'])
+        for k, lk in enumerate(opt.links):
+            np.testing.assert_allclose(lk.uids, g[f'{tag}_l{k}_uids'], atol=1e-12)
+            np.testing.assert_allclose(lk.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True), g[f'{tag}_l{k}_xy0'], atol=1e-9)
+            np.testing.assert_allclose(lk.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True), g[f'{tag}_l{k}_xy1'], atol=1e-9)
+            np.testing.assert_allclose(lk.weight(use_mask=False), g[f'{tag}_l{k}_w'], atol=1e-12)
+        np.testing.assert_allclose(opt.linkage_adjacency().toarray(), g[f'{tag}_adj'], atol=1e-9)
+        np.testing.assert_allclose(opt.linkage_adjacency(directional=True).toarray(), g[f'{tag}_adj_dir'], atol=1e-9)
+        lab, ncomp = opt.connected_subsystems
+        assert ncomp == int(g[f'{tag}_ncomp'])
+        np.testing.assert_array_equal(lab, g[f'{tag}_labels'])
+        for q in (0, 0.75, 1):
+            np.testing.assert_allclose(opt.match_residues(gear=const.MESH_GEAR_MOVING, quantile=q), g[f'{tag}_res_q{q}'], atol=1e-9)
+        np.testing.assert_allclose(opt.match_residues(gear=const.MESH_GEAR_INITIAL, quantile=0.5), g[f'{tag}_res_init'], atol=1e-9)
+    check('whole')
+    assert opt.divide_disconnected_submeshes() == bool(g['divided'])
+    check('parts')
