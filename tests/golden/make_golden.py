@@ -1268,8 +1268,54 @@ def g26_slm_bookkeeping():
     np.savez_compressed(os.path.join(OUT, 'g26_slm_bookkeeping.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G27
+sys.path.insert(0, OUT)
+from walks import g27_mesh_walk                       # noqa: E402  (the statements that drive the reference here and the product in its test)
+
+
+def g27_mesh_gears():
+    """Mesh's gears (mesh.py:1189-1330, 2232-2413): lazily shared vertex arrays, offsets that fall back from gear to gear, masked and
+    unmasked translations / fields / affine maps, the locked mesh that ignores them; plus areas, deformation measures, bounds,
+    connectivity (vertex- and edge-wise, on a mesh with a bow tie) and a sub-mesh"""
+    out = {}
+    gears = dict(i=const.MESH_GEAR_INITIAL, f=const.MESH_GEAR_FIXED, m=const.MESH_GEAR_MOVING, s=const.MESH_GEAR_STAGING)
+
+    def record(tag, m):
+        for g, gear in gears.items():
+            out[f'{tag}_{g}_vo'] = np.array(m.vertices_w_offset(gear=gear))
+            out[f'{tag}_{g}_off'] = np.array(m.offset(gear=gear), dtype=np.float64).reshape(1, 2)
+        out[f'{tag}_est'] = np.asarray(m.estimate_translation(), dtype=np.float64)
+        out[f'{tag}_est_fs'] = np.asarray(m.estimate_translation(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_STAGING)), dtype=np.float64)
+    m, v, tri, mask = g27_mesh_walk(Mesh, const, record)
+    out['v'], out['tri'], out['mask'] = v, tri, mask
+    for g, gear in gears.items():
+        out[f'areas_{g}'] = m.triangle_areas(gear=gear)
+        out[f'bbox_{g}'] = np.asarray(m.bbox(gear=gear)); out[f'bbox_{g}_raw'] = np.asarray(m.bbox(gear=gear, offsetting=False))
+    out['area_deform'] = m.triangle_area_deform(gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING))
+    out['edge_deform'] = m.triangle_edge_deform(gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING))
+    # connectivity: two grids joined by ONE shared vertex (a bow tie), and a third apart
+    vb = np.array([[0, 0], [10, 0], [0, 10], [10, 10], [20, 10], [10, 20], [20, 20], [40, 0], [50, 0], [40, 10]], dtype=np.float64)
+    tb = np.array([[0, 1, 2], [1, 3, 2], [3, 4, 5], [4, 6, 5], [7, 8, 9]], dtype=np.int32)
+    mb = Mesh(vb, tb, uid=7)
+    nv, lv = mb.connected_vertices()
+    nt, lt = mb.connected_triangles()
+    out['bow_v'], out['bow_t'] = vb, tb
+    out['bow_nv'], out['bow_lv'], out['bow_nt'], out['bow_lt'] = np.int64(nv), np.asarray(lv, dtype=np.int64), np.int64(nt), np.asarray(lt, dtype=np.int64)
+    parts = mb.divide_disconnected_mesh()
+    out['bow_part_uids'] = np.array([p.uid for p in parts], dtype=np.float64)
+    for k, p in enumerate(parts):
+        out[f'bow_part{k}_v'] = p.vertices_w_offset(gear=const.MESH_GEAR_INITIAL); out[f'bow_part{k}_t'] = np.asarray(p.triangles, dtype=np.int64)
+    tmask = np.zeros(m.num_triangles, dtype=bool); tmask[::3] = True
+    sub = m.submesh(tmask, uid=3.5)
+    out['sub_tmask'] = tmask
+    out['sub_t'] = np.asarray(sub.triangles, dtype=np.int64)
+    for g, gear in gears.items():
+        out[f'sub_{g}_vo'] = np.array(sub.vertices_w_offset(gear=gear))
+    np.savez_compressed(os.path.join(OUT, 'g27_mesh_gears.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -802,3 +802,52 @@ def test_g26_slm_bookkeeping_vs_reference():
     check('whole')
     assert opt.divide_disconnected_submeshes() == bool(g['divided'])
     check('parts')
+
+
+def test_g27_mesh_gears_vs_reference():
+    """Mesh's gears against the reference (golden G27, mesh.py:1189-1330, 2232-2413): the walk of tests/golden/walks.py -- masked and
+    unmasked translations, fields and affine maps between and inside gears, a gear that is not set falling back to the one below,
+    a locked mesh ignoring everything -- leaves the same coordinates and offsets at every gear after every step; areas,
+    deformation measures, bounds, connectivity by vertex and by edge, division into parts, sub-mesh"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from walks import g27_mesh_walk
+    from feabas_amd.mesh import Mesh
+    import feabas_amd.constant as const
+    g = load_golden('g27_mesh_gears.npz')
+    gears = dict(i=const.MESH_GEAR_INITIAL, f=const.MESH_GEAR_FIXED, m=const.MESH_GEAR_MOVING, s=const.MESH_GEAR_STAGING)
+    steps = []
+
+    def record(tag, m):
+        steps.append(tag)
+        for k, gear in gears.items():
+            np.testing.assert_allclose(m.vertices_w_offset(gear), g[f'{tag}_{k}_vo'], atol=1e-10, err_msg=f'{tag} {k}')
+            np.testing.assert_allclose(np.asarray(m.offset(gear), dtype=np.float64).reshape(1, 2), g[f'{tag}_{k}_off'], atol=1e-10, err_msg=f'{tag} {k} offset')
+        np.testing.assert_allclose(m.estimate_translation(), g[f'{tag}_est'], atol=1e-10)
+        np.testing.assert_allclose(m.estimate_translation(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_STAGING)), g[f'{tag}_est_fs'], atol=1e-10)
+    m, v, tri, mask = g27_mesh_walk(Mesh, const, record)
+    assert len(steps) == 18
+    np.testing.assert_array_equal(v, g['v']); np.testing.assert_array_equal(tri, g['tri'])
+    for k, gear in gears.items():
+        np.testing.assert_allclose(m.triangle_areas(gear=gear), g[f'areas_{k}'], rtol=1e-12)
+        np.testing.assert_allclose(m.bbox(gear=gear), g[f'bbox_{k}'], atol=1e-10)
+        np.testing.assert_allclose(m.bbox(gear=gear, offsetting=False), g[f'bbox_{k}_raw'], atol=1e-10)
+    np.testing.assert_allclose(m.triangle_area_deform(gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING)), g['area_deform'], rtol=1e-12)
+    np.testing.assert_allclose(m.triangle_edge_deform(gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_MOVING)), g['edge_deform'], rtol=1e-12)
+    mb = Mesh(g['bow_v'], g['bow_t'], uid=7)
+
+    def same_partition(a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        return np.array_equal(a[:, None] == a[None, :], b[:, None] == b[None, :])
+    nv, lv = mb.connected_vertices()
+    nt, lt = mb.connected_triangles()
+    assert nv == int(g['bow_nv']) and nt == int(g['bow_nt']) and same_partition(lv, g['bow_lv']) and same_partition(lt, g['bow_lt'])
+    assert nv == 2 and nt == 3                               # the bow tie: one component by vertex, two by edge
+    parts = mb.divide_disconnected_mesh()
+    np.testing.assert_allclose([p.uid for p in parts], g['bow_part_uids'], atol=1e-12)
+    for k, p in enumerate(parts):
+        np.testing.assert_array_equal(p.vertices_w_offset(const.MESH_GEAR_INITIAL)[p.triangles], g[f'bow_part{k}_v'][g[f'bow_part{k}_t']])
+    sub = m.submesh(g['sub_tmask'], uid=3.5)
+    for k, gear in gears.items():
+        np.testing.assert_allclose(sub.vertices_w_offset(gear)[sub.triangles], g[f'sub_{k}_vo'][g['sub_t']], atol=1e-10)
