@@ -1256,6 +1256,20 @@ def main():
                                    note='strips handed over in host memory (4.2 MB per pair over PCIe), results returned per pair; '
                                         f'{args.host_ingest_threads} host threads ({3 * args.host_ingest_threads // 8} loaders that pack and copy, the others match), {IB}-pair chunks; '
                                         'h2d_gbs = strip bytes over the wall time of the whole run; best of two passes')
+        # the same measurement over a list three times as long (two sections' worth of pairs): what the fixed part of a call -- worker
+        # start-up, the first chunk's pack + copy before any kernel runs, the last chunk's results -- costs the 0.12 s pass above
+        try:
+            long_list = host_pairs * 3
+            t0 = time.time()
+            outl = fmatcher.stitching_matcher_batch(long_list, batch=IB, threads=args.host_ingest_threads, **cfg)
+            dtl = time.time() - t0
+            line['host_ingest']['three_times_the_list'] = dict(value=len(long_list) / dtl, unit='pairs/s', pairs=len(long_list), seconds=dtl,
+                                                               h2d_gbs=len(long_list) * 2 * H * W / dtl / 1e9, matched=int(sum(o[0] is not None for o in outl)),
+                                                               fixed_seconds_per_call=max(0.0, (3 * dth - dtl) / 2),
+                                                               note='one pass; fixed_seconds_per_call = (3 t(list) - t(3 x list)) / 2')
+            del long_list, outl
+        except Exception as e:                              # noqa: BLE001 -- a side record
+            line['host_ingest']['three_times_the_list'] = dict(error=f'{type(e).__name__}: {e}')
         # the same pairs cropped to strip shapes that all differ (what stage jitter does to the overlaps of a real section):
         # batches of unequal strips (RaggedStripBatchMatcher)
         rng_r = np.random.default_rng(5)
