@@ -1228,8 +1228,8 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
     per-image sizes (fb_area_downsample2_sizes_dev, fb_dog_sizes_dev), the whole-strip NCC through block descriptors
     grouped by FFT shape, per-pair block grids and spacing values, one mesh GEOMETRY per pair inside the shared
     block-diagonal system (per-pair node coordinates, Es0 and sample errors; fb_pairs_relax_bary / fb_pairs_strain_bary),
-    and the deformed-mesh branch with per-pair node grids and tolerances (fb_deformed_*).
-    Masks and photometric statistics are not taken here."""
+    and the deformed-mesh branch with per-pair node grids and tolerances (fb_deformed_*); photometric statistics on every
+    pair's own extent (host numpy, like the reference's).  Masks are not taken here."""
 
     @staticmethod
     def bucket_key(H, W, min_num_blocks=2, spacings=None):
@@ -1340,8 +1340,29 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
         _lib.check(lib.fb_dog_sizes_dev(ctx, strips1, 0, n, H, W, self.d_sizes.ptr, self.sigma, 1, self.d_dogf.offset(n * H * W * 4)))
         self.d_dogf_view = self.d_dogf
 
-    def _photometric(self, *a, **k):
-        raise NotImplementedError('RaggedStripBatchMatcher: photometric statistics are not taken (use StripBatchMatcher per shape)')
+    def _photometric(self, strips0, strips1, tx_c, ty_c, masks):
+        """matcher.py:279-314 on every pair's own extent of its slot (the statistics of StripBatchMatcher._photometric with
+        per-pair image sizes; masks are not taken by this class)"""
+        n, hc, wc = self.P, self.hc, self.wc
+        if self.cds == 0.5:
+            raw = self.d_small.to_array((2 * n, hc, wc), np.uint8)
+        else:
+            raw = np.empty((2 * n, hc, wc), dtype=np.uint8)
+            for side, strips in enumerate((strips0, strips1)):
+                _lib.check(_lib.load().fb_memcpy_d2h(_lib.ctx(), _lib.ptr(raw[side * n:(side + 1) * n]), C.c_void_p(strips), n * hc * wc))
+        dog = self.d_dogc.to_array((2 * n, hc, wc), np.float32)
+        out = []
+        for p in range(n):
+            h_, w_ = int(self._hcs[p]), int(self._wcs[p])
+            txx, tyy = int(tx_c[p]), int(ty_c[p])
+            xa, ya = max(txx, 0), max(tyy, 0)
+            xb, yb = min(w_ + txx, w_), min(h_ + tyy, h_)
+            if (yb - ya) * (xb - xa) <= 3 or yb <= ya or xb <= xa:
+                out.append(None)
+                continue
+            i0 = (slice(ya - tyy, yb - tyy), slice(xa - txx, xb - txx)); i1 = (slice(ya, yb), slice(xa, xb))
+            out.append((np.mean(raw[p][i0]), np.mean(raw[n + p][i1]), np.mean(np.abs(dog[p][i0])), np.mean(np.abs(dog[n + p][i1]))))
+        return out
 
     # ---- one mesh geometry per pair inside the shared system
     def _relax_system(self):
