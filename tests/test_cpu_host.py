@@ -851,3 +851,52 @@ def test_g27_mesh_gears_vs_reference():
     sub = m.submesh(g['sub_tmask'], uid=3.5)
     for k, gear in gears.items():
         np.testing.assert_allclose(sub.vertices_w_offset(gear)[sub.triangles], g[f'sub_{k}_vo'][g['sub_t']], atol=1e-10)
+
+
+def test_cxx_general_mesh_block_affines_match_numpy():
+    """fb_mesh_block_affines (host C++, no device work, ctx = NULL) -- the per-block affine fits and the tolerance test of
+    MeshRenderer.crop_field for a GENERAL triangulation (renderer.py:397-416, 499-511) -- against the numpy statement
+    deformed.block_affines (pinned to the renderer restatement by the tests above) on an irregular Delaunay mesh with a
+    smooth + a few rough node displacements: tiers 2 / 3 and the affine maps of the tier-2 blocks"""
+    from scipy.spatial import Delaunay
+    from feabas_amd import _lib, deformed
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    gx, gy = np.meshgrid(np.arange(0, 900, 60.0), np.arange(0, 700, 60.0))
+    v_img = np.stack((gx.ravel(), gy.ravel()), axis=-1) + rng.uniform(-18, 18, (gx.size, 2))
+    tris = np.ascontiguousarray(Delaunay(v_img).simplices, dtype=np.int32)
+    U = np.stack((4.0 * np.sin(v_img[:, 1] / 180.0) + 1.5 * np.cos(v_img[:, 0] / 75.0), 3.0 * np.cos(v_img[:, 1] / 140.0)), axis=-1)
+    rough = rng.integers(0, v_img.shape[0], 12)
+    U[rough] += rng.normal(0, 1.2, (12, 2))
+    v_mov = np.ascontiguousarray(v_img + U + np.array([7.0, -4.0]))
+    h, w = 70, 90
+    org = np.ascontiguousarray(np.stack(np.meshgrid(np.arange(20, 760, 95.0), np.arange(15, 600, 80.0)), axis=-1).reshape(-1, 2))
+    nb = org.shape[0]
+    bboxes = np.concatenate((org, org + np.array([w, h])), axis=1)
+    # candidates: every triangle whose bounding box touches the block's (a superset of the triangles that intersect it, like
+    # the lists of fb_mesh_candidates_dev)
+    p = v_mov[tris]
+    tlo, thi = p.min(axis=1), p.max(axis=1)
+    box = bboxes - 0.5
+    touch = (tlo[None, :, 0] <= box[:, None, 2]) & (thi[None, :, 0] >= box[:, None, 0]) & (tlo[None, :, 1] <= box[:, None, 3]) & (thi[None, :, 1] >= box[:, None, 1])
+    count = np.ascontiguousarray(touch.sum(axis=1), dtype=np.int32)
+    cap = int(count.max())
+    cand = np.full((nb, cap), -1, dtype=np.int32)
+    for b in range(nb):
+        cand[b, :count[b]] = np.flatnonzero(touch[b])
+    seen = set()
+    for tol in (0.05, 0.3, 1.0, 3.0):
+        tier = np.full(nb, 3, dtype=np.int32); A6 = np.zeros((nb, 6))
+        assert lib.fb_mesh_block_affines(None, v_mov.shape[0], _lib.ptr(v_mov), _lib.ptr(np.ascontiguousarray(v_img)), _lib.ptr(tris), nb, _lib.ptr(org), h, w, cap,
+                                         _lib.ptr(cand), _lib.ptr(count), tol, _lib.ptr(tier), _lib.ptr(A6)) == 0
+        # (a tolerance so loose that the ONE global fit passes is decided before the blocks are looked at: MeshRenderer._tiers)
+        t2, A, _ = deformed.block_affines(v_mov, v_img, tris, bboxes, tol)
+        if (t2 == 1).all():
+            continue
+        assert not (tier == -1).any()
+        np.testing.assert_array_equal(tier, t2)
+        seen |= set(tier.tolist())
+        a = tier == 2
+        ref = np.stack((A[:, 0, 0], A[:, 1, 0], A[:, 2, 0], A[:, 0, 1], A[:, 1, 1], A[:, 2, 1]), -1)
+        np.testing.assert_allclose(A6[a], ref[a], atol=1e-9)
+    assert seen == {2, 3}
