@@ -304,9 +304,29 @@ class using:
         return False
 
 
+_destroy_hooks = []
+
+
+def on_context_destroy(fn):
+    """`fn(h)` is called just before a context goes away (``destroy_context``, or the process context being replaced by one on
+    another device), with `h` still alive: modules that keep per-context objects (matchers, pools) let go of them there."""
+    if fn not in _destroy_hooks:
+        _destroy_hooks.append(fn)
+
+
+def _run_destroy_hooks(h):
+    for fn in list(_destroy_hooks):
+        try:
+            fn(h)
+        except Exception:                                  # noqa: BLE001 -- a cache that cannot be emptied must not keep the context alive
+            import traceback
+            traceback.print_exc()
+
+
 def destroy_context(h):
     """Destroy a context made by ``new_context`` (its stream, arena and every buffer it still owns)."""
     if h is not None and h != _ctx:
+        _run_destroy_hooks(h)
         load().fb_destroy(h)
 
 
@@ -323,6 +343,7 @@ def ctx(device=None):
     if _ctx is not None and _ctx_device == device:
         return _ctx
     if _ctx is not None:
+        _run_destroy_hooks(_ctx)
         lib.fb_destroy(_ctx)
         _ctx = None
     h = lib.fb_create(device)

@@ -955,23 +955,41 @@ _batch_workers = {}          # (process context, worker index) -> {ctx, state}: 
 _pools = {}                  # context -> MatcherPool of the per-pair surface
 
 
-def stitching_matcher_batch_release():
-    """free the contexts, staging buffers and matchers that stitching_matcher_batch keeps between calls"""
-    for (_, t), slot in list(_batch_workers.items()):
+def _forget_context(h):
+    """a context is about to be destroyed: the per-pair matchers and the pool made under it are freed while it is still alive,
+    so that nothing in these caches points at a dead stream (a later context may get the same address)"""
+    key = id(h)
+    with _lib.using(h):
+        for k in [k for k in _pair_matchers if k[-1] == key]:
+            _pair_matchers.pop(k).free()
+        pool = _pools.pop(key, None)
+        if pool is not None:
+            pool.free()
+        stitching_matcher_batch_release(h)
+
+
+_lib.on_context_destroy(_forget_context)
+
+
+def stitching_matcher_batch_release(main=None):
+    """free the contexts, staging buffers and matchers that stitching_matcher_batch keeps between calls (main: only those of the
+    calls made under that context)"""
+    for (owner, t), slot in list(_batch_workers.items()):
+        if main is not None and owner != id(main):
+            continue
+        _batch_workers.pop((owner, t))
         if t == 'slots':                                      # the staging slots shared by loaders and matchers
             for pin_, dev_ in slot.get('io', ()):
                 pin_.free(); dev_.free()
             continue
-        _lib.use_context(slot.get('ctx'))
-        st = slot.get('state', {})
-        for r in tuple(st.get('res', ())) + tuple(st.get('io', ())):
-            r.free()
-        if 'pool' in st:
-            st['pool'].free()
-        _lib.use_context(None)
+        with _lib.using(slot.get('ctx')):                     # (the caller's own context is current again afterwards)
+            st = slot.get('state', {})
+            for r in tuple(st.get('res', ())) + tuple(st.get('io', ())):
+                r.free()
+            if 'pool' in st:
+                st['pool'].free()
         if t != 0:
             _lib.destroy_context(slot.get('ctx'))
-    _batch_workers.clear()
 
 
 def _stitching_options(kwargs):

@@ -900,3 +900,39 @@ def test_cxx_general_mesh_block_affines_match_numpy():
         ref = np.stack((A[:, 0, 0], A[:, 1, 0], A[:, 2, 0], A[:, 0, 1], A[:, 1, 1], A[:, 2, 1]), -1)
         np.testing.assert_allclose(A6[a], ref[a], atol=1e-9)
     assert seen == {2, 3}
+
+
+def test_context_destroy_hooks_empty_the_matcher_caches(monkeypatch):
+    """a context that goes away takes the per-pair matchers, the pool and the batch workers made under it along, freed while it is
+    still current -- and only those (no GPU: stand-ins for the handles and the library)"""
+    from feabas_amd import matcher as fm
+    log = []
+
+    class Thing:
+        def __init__(self, name):
+            self.name = name
+
+        def free(self):
+            log.append((self.name, _lib.ctx()))
+
+    class FakeLib:
+        def fb_destroy(self, h):
+            log.append(('destroy', h))
+    ha, hb, hw = object(), object(), object()
+    monkeypatch.setattr(_lib, 'load', lambda: FakeLib())
+    monkeypatch.setattr(_lib, '_ctx', hb)
+    monkeypatch.setattr(fm, '_pair_matchers', {('k1', id(ha)): Thing('pair_a'), ('k2', id(hb)): Thing('pair_b')})
+    monkeypatch.setattr(fm, '_pools', {id(ha): Thing('pool_a'), id(hb): Thing('pool_b')})
+    monkeypatch.setattr(fm, '_batch_workers', {(id(ha), 'slots'): dict(io=[(Thing('pin_a'), Thing('dev_a'))]),
+                                               (id(ha), 0): dict(ctx=ha, state=dict(res=(Thing('matcher_a0'),), pool=Thing('wpool_a0'))),
+                                               (id(ha), 1): dict(ctx=hw, state=dict(res=(Thing('matcher_a1'),))),
+                                               (id(hb), 0): dict(ctx=hb, state=dict(res=(Thing('matcher_b0'),)))})
+    _lib.use_context(None)
+    _lib.destroy_context(ha)
+    names = [n for n, _ in log]
+    assert set(names) == {'pair_a', 'pool_a', 'pin_a', 'dev_a', 'matcher_a0', 'wpool_a0', 'matcher_a1', 'destroy'}
+    assert [c for n, c in log if n in ('pair_a', 'pool_a', 'matcher_a0', 'wpool_a0')] == [ha] * 4       # freed with the dying context current
+    assert [c for n, c in log if n == 'matcher_a1'] == [hw]                                               # a worker's matcher under the worker's context
+    assert [h for n, h in log if n == 'destroy'] == [hw, ha]                                              # the worker's context first, then the owner's
+    assert list(fm._pair_matchers) == [('k2', id(hb))] and list(fm._pools) == [id(hb)] and list(fm._batch_workers) == [(id(hb), 0)]
+    assert getattr(_lib._tls, 'ctx', None) is None                                                        # the caller's context is current again
