@@ -18,6 +18,8 @@ def main():
     ap.add_argument('--mesh-size', type=float, default=100.0)
     ap.add_argument('--profile', action='store_true', help='cProfile of a third repetition')
     ap.add_argument('--kernels', action='store_true', help='event profile of the kernels of a further repetition')
+    ap.add_argument('--entries', action='store_true', help='wall time spent INSIDE every fb_* entry of the library during a further repetition '
+                                                           '(what is left of the wall time is python / numpy between the calls)')
     args = ap.parse_args()
     S = args.size
     rng = np.random.default_rng(0)
@@ -73,6 +75,41 @@ def main():
         print(f'with the event profile on: {dt:.3f} s; kernels {sum(v[1] for v in snap.values()):.2f} ms')
         for k, v in sorted(snap.items(), key=lambda kv: -kv[1][1])[:16]:
             print(f'   {k:26s} launches {v[0]:4d}  {v[1]:8.3f} ms')
+
+    if args.entries:
+        from feabas_amd import _lib
+        real = _lib.load()
+        spent = {}
+
+        class Timed:
+            def __getattr__(self, name):
+                f = getattr(real, name)
+                if not name.startswith('fb_'):
+                    return f
+
+                def call(*a):
+                    t0 = time.perf_counter()
+                    try:
+                        return f(*a)
+                    finally:
+                        e = spent.setdefault(name, [0, 0.0])
+                        e[0] += 1; e[1] += time.perf_counter() - t0
+                return call
+        timed = Timed()
+        real_load = _lib.load
+        _lib.load = lambda: timed
+        try:
+            m0, m1 = meshes[0].copy(), meshes[1].copy()
+            t0 = time.perf_counter()
+            matcher.section_matcher(m0, m1, images[0], images[1], spacings=[280, 70], conf_thresh=0.3, residue_len=3.0)
+            dt = time.perf_counter() - t0
+        finally:
+            _lib.load = real_load
+        inside = sum(v[1] for v in spent.values())
+        print(f'entries: wall {1e3 * dt:.1f} ms, inside the library {1e3 * inside:.1f} ms in {sum(v[0] for v in spent.values())} calls, '
+              f'python between the calls {1e3 * (dt - inside):.1f} ms')
+        for k, v in sorted(spent.items(), key=lambda kv: -kv[1][1])[:24]:
+            print(f'   {k:34s} calls {v[0]:5d}  {1e3 * v[1]:8.2f} ms')
 
 
 if __name__ == '__main__':
