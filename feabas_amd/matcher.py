@@ -329,7 +329,7 @@ class _RegionPair:
             # (a pair of meshes whose coordinates ran away -- a relaxation that went wrong upstream -- must fail here with a
             # message, not take the host down with a raster of 1e10 cells)
             cells = ((x1 - x0) / res) * ((y1 - y0) / res)
-            if not np.isfinite(cells) or cells > 4e8:
+            if not np.isfinite(cells) or cells > 1e8:
                 raise ValueError(f'distribute_matching_blocks: the common region spans {x1 - x0:.3g} x {y1 - y0:.3g} px at a raster step of {res:.3g}: '
                                  'the meshes are not where images could be (diverged relaxation?)')
             xs = np.arange(x0 + 0.5 * res, x1, res); ys = np.arange(y0 + 0.5 * res, y1, res)

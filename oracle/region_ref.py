@@ -90,7 +90,7 @@ class CommonRegion:
     def raster(self, res, **kw):
         x0, y0, x1, y1 = self.bbox
         cells = ((x1 - x0) / res) * ((y1 - y0) / res)
-        if not np.isfinite(cells) or cells > 4e8:                              # (a runaway mesh must not take the host down)
+        if not np.isfinite(cells) or cells > 1e8:                              # (a runaway mesh must not take the host down)
             raise ValueError(f'common region of {x1 - x0:.3g} x {y1 - y0:.3g} px at raster step {res:.3g}')
         xs = np.arange(x0 + 0.5 * res, x1, res); ys = np.arange(y0 + 0.5 * res, y1, res)
         xx, yy = np.meshgrid(xs, ys)
