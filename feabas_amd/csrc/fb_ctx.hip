@@ -388,6 +388,13 @@ int fb_memcpy_d2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return FB_OK;
 }
 
+int fb_memcpy2d_d2d(fb_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows) {
+    FB_CHECK_ARG(ctx, dst && src && dpitch >= width_bytes && spitch >= width_bytes);
+    if (width_bytes == 0 || rows == 0) return FB_OK;
+    FB_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return FB_OK;
+}
+
 int fb_memset(fb_ctx* ctx, void* dst, int value, size_t bytes) {
     FB_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
     return FB_OK;

@@ -1229,7 +1229,7 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
     grouped by FFT shape, per-pair block grids and spacing values, one mesh GEOMETRY per pair inside the shared
     block-diagonal system (per-pair node coordinates, Es0 and sample errors; fb_pairs_relax_bary / fb_pairs_strain_bary),
     and the deformed-mesh branch with per-pair node grids and tolerances (fb_deformed_*); photometric statistics on every
-    pair's own extent (host numpy, like the reference's).  Masks are not taken here."""
+    pair's own extent (host numpy, like the reference's); masked pairs get their masked DoG image by image inside their slots."""
 
     @staticmethod
     def bucket_key(H, W, min_num_blocks=2, spacings=None):
@@ -1286,9 +1286,29 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
         super().free()
 
     # ---- image stages on per-image extents
+    def _masked_dog_in_slot(self, src_ptr, src_pitch, h, w, sigma, mask, dst_ptr, dst_pitch):
+        """common.masked_dog_filter(img, sigma, mask=mask) of ONE uint8 image that occupies the top-left h x w pixels of a slot
+        (row pitch src_pitch bytes) into the same corner of its float32 slot (row pitch dst_pitch bytes): the image is copied
+        out dense, filtered like StripBatchMatcher._masked_dog does, and copied back"""
+        lib, ctx = _lib.load(), _lib.ctx()
+        mk = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        assert mk.shape == (h, w)
+        d_m = _lib.DeviceBuffer.from_array(mk)
+        d_in, d_out = _lib.DeviceBuffer(h * w), _lib.DeviceBuffer(4 * h * w)
+        try:
+            _lib.check(lib.fb_memcpy2d_d2d(ctx, d_in.ptr, w, src_ptr, int(src_pitch), w, h))
+            _lib.check(lib.fb_dog_dev(ctx, d_in.ptr, 0, 1, h, w, sigma, d_m.ptr, 1, d_out.ptr))
+            _lib.check(lib.fb_memcpy2d_d2d(ctx, dst_ptr, int(dst_pitch), d_out.ptr, 4 * w, 4 * w, h))
+            _lib.check(lib.fb_sync(ctx))
+        finally:
+            d_m.free(); d_in.free(); d_out.free()
+
+    def _coarse_mask(self, mk, p):
+        """cv2.resize(mask, fx=0.5, INTER_NEAREST) of pair p's mask = every second pixel (matcher.py:257-264), on the pair's extent"""
+        h_, w_ = int(self._hcs[p]), int(self._wcs[p])
+        return np.asarray(mk)[::2, ::2][:h_, :w_] if self.cds == 0.5 else np.asarray(mk)[:h_, :w_]
+
     def _global(self, strips0, strips1, masks=None, need_small=False):
-        if masks is not None:
-            raise NotImplementedError('RaggedStripBatchMatcher: masks are not taken (use StripBatchMatcher per shape)')
         lib, ctx = _lib.load(), _lib.ctx()
         n, H, W, hc, wc = self.P, self.H, self.W, self.hc, self.wc
         if self.cds == 0.5:
@@ -1298,6 +1318,16 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
         else:
             _lib.check(lib.fb_dog_sizes_dev(ctx, strips0, 0, n, hc, wc, self.d_sizes_c.ptr, self.sigma, 1, self.d_dogc.ptr))
             _lib.check(lib.fb_dog_sizes_dev(ctx, strips1, 0, n, hc, wc, self.d_sizes_c.ptr, self.sigma, 1, self.d_dogc.offset(n * hc * wc * 4)))
+        if masks is not None:
+            # masked pairs: the coarse DoG of their images again with the halo suppression of common.py:368-374, each on its own
+            # extent of its slot (StripBatchMatcher._global does the same on whole slots)
+            for side, (strips, mlist) in enumerate(((strips0, masks[0]), (strips1, masks[1]))):
+                for p, mk in enumerate(mlist):
+                    if mk is None:
+                        continue
+                    src = self.d_small.offset((side * n + p) * hc * wc) if self.cds == 0.5 else C.c_void_p(strips + p * H * W)
+                    self._masked_dog_in_slot(src, wc, int(self._hcs[p]), int(self._wcs[p]), self.sigma * self.cds, self._coarse_mask(mk, p),
+                                             self.d_dogc.offset((side * n + p) * hc * wc * 4), 4 * wc)
         # whole-strip NCC (matcher.py:153) of every pair's own extent: block descriptors, one launch per FFT shape
         fh = self._nfl[2 * self._hcs - 1]; fw = self._nfl[2 * self._wcs - 1]
         tx = np.zeros(n); ty = np.zeros(n); cf = np.zeros(n, dtype=np.float32)
@@ -1338,11 +1368,18 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
             return
         _lib.check(lib.fb_dog_sizes_dev(ctx, strips0, 0, n, H, W, self.d_sizes.ptr, self.sigma, 1, self.d_dogf.ptr))
         _lib.check(lib.fb_dog_sizes_dev(ctx, strips1, 0, n, H, W, self.d_sizes.ptr, self.sigma, 1, self.d_dogf.offset(n * H * W * 4)))
+        if masks is not None:
+            for side, (strips, mlist) in enumerate(((strips0, masks[0]), (strips1, masks[1]))):
+                for p, mk in enumerate(mlist):
+                    if mk is not None:
+                        h_, w_ = int(self._Hs[p]), int(self._Ws[p])
+                        self._masked_dog_in_slot(C.c_void_p(strips + p * H * W), W, h_, w_, self.sigma, np.asarray(mk)[:h_, :w_],
+                                                 self.d_dogf.offset((side * n + p) * H * W * 4), 4 * W)
         self.d_dogf_view = self.d_dogf
 
     def _photometric(self, strips0, strips1, tx_c, ty_c, masks):
         """matcher.py:279-314 on every pair's own extent of its slot (the statistics of StripBatchMatcher._photometric with
-        per-pair image sizes; masks are not taken by this class)"""
+        per-pair image sizes and per-pair coarse masks)"""
         n, hc, wc = self.P, self.hc, self.wc
         if self.cds == 0.5:
             raw = self.d_small.to_array((2 * n, hc, wc), np.uint8)
@@ -1357,11 +1394,19 @@ class RaggedStripBatchMatcher(StripBatchMatcher):
             txx, tyy = int(tx_c[p]), int(ty_c[p])
             xa, ya = max(txx, 0), max(tyy, 0)
             xb, yb = min(w_ + txx, w_), min(h_ + tyy, h_)
-            if (yb - ya) * (xb - xa) <= 3 or yb <= ya or xb <= xa:
+            if yb <= ya or xb <= xa:
                 out.append(None)
                 continue
             i0 = (slice(ya - tyy, yb - tyy), slice(xa - txx, xb - txx)); i1 = (slice(ya, yb), slice(xa, xb))
-            out.append((np.mean(raw[p][i0]), np.mean(raw[n + p][i1]), np.mean(np.abs(dog[p][i0])), np.mean(np.abs(dog[n + p][i1]))))
+            mk0 = None if masks is None or masks[0][p] is None else np.asarray(self._coarse_mask(masks[0][p], p), dtype=bool)
+            mk1 = None if masks is None or masks[1][p] is None else np.asarray(self._coarse_mask(masks[1][p], p), dtype=bool)
+            m0 = np.ones((yb - ya, xb - xa), dtype=bool) if mk0 is None else mk0[i0]
+            m1 = np.ones((yb - ya, xb - xa), dtype=bool) if mk1 is None else mk1[i1]
+            if np.sum(m0) <= 3:                               # matcher.py:297
+                out.append(None)
+                continue
+            mp = m0 & m1
+            out.append((np.mean(raw[p][i0][mp]), np.mean(raw[n + p][i1][mp]), np.mean(np.abs(dog[p][i0][mp])), np.mean(np.abs(dog[n + p][i1][mp]))))
         return out
 
     # ---- one mesh geometry per pair inside the shared system

@@ -74,6 +74,9 @@ int fb_memcpy_h2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
 int fb_memcpy_d2h(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* device -> device on the context's stream (asynchronous, ordered with the kernels) */
 int fb_memcpy_d2d(fb_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* `rows` rows of `width_bytes` bytes between two pitched device arrays (an image inside its slot <-> a dense copy of it), on the
+ * context's stream */
+int fb_memcpy2d_d2d(fb_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);
 int fb_memset(fb_ctx* ctx, void* dst, int value, size_t bytes);
 
 /* HIP-event stopwatch on the context stream (bench.py's timed region) and

@@ -763,6 +763,46 @@ def test_ragged_batch_photometric_statistics_match_the_per_pair_surface(fb, cds)
     m.free(); dev.free()
 
 
+@pytest.mark.skipif(not __import__('os').environ.get('FEABAS_TEST_PENDING'), reason='written after the GPU pool closed for round 5: never run on hardware yet (FEABAS_TEST_PENDING=1 runs it)')
+@pytest.mark.parametrize('cds', [0.5, 1])
+def test_ragged_batch_with_masks_matches_the_per_pair_surface(fb, cds):
+    """masked pairs (matcher.py:257-274, 336-337: the masked DoG of the coarse and of the fine images) inside a batch of strips of
+    unequal size -- every masked image filtered on its own extent of its slot -- with the photometric statistics over the masked
+    overlap, against the same pairs through stitching_matcher one by one"""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import RaggedStripBatchMatcher, StripBatchMatcher
+    shapes = [(1536, 120), (1526, 122), (1520, 120), (1530, 122)]
+    assert len({RaggedStripBatchMatcher.bucket_key(h, w) for h, w in shapes}) == 1
+    pairs = [_warped_pair(h, w, 410 + k, shift=(4 - 2 * k, 2 * k - 3), warp=0.3) for k, (h, w) in enumerate(shapes)]
+    P = len(shapes)
+    masks0, masks1 = [None] * P, [None] * P
+    m = np.ones(shapes[0], dtype=bool); m[300:420, 30:90] = False; m[:40, :] = False
+    masks0[0] = m
+    m = np.ones(shapes[2], dtype=bool); m[900:1100, :50] = False
+    masks1[2] = m
+    m = np.ones(shapes[3], dtype=bool); m[1400:, 60:] = False
+    masks0[3] = m; masks1[3] = ~np.zeros(shapes[3], dtype=bool)                 # (a mask without a zero changes nothing)
+    pairs = [(np.where(masks0[k], a, 0).astype(np.uint8) if masks0[k] is not None else a,
+              np.where(masks1[k], b, 0).astype(np.uint8) if masks1[k] is not None else b) for k, (a, b) in enumerate(pairs)]
+    Hm, Wm = max(h for h, _ in shapes), max(w for _, w in shapes)
+    stage = np.full((2, P, Hm, Wm), 200, dtype=np.uint8)
+    for k, (a, b) in enumerate(pairs):
+        stage[0, k, :a.shape[0], :a.shape[1]] = a
+        stage[1, k, :b.shape[0], :b.shape[1]] = b
+    dev = _lib.DeviceBuffer.from_array(stage)
+    mt = RaggedStripBatchMatcher(shapes, residue_len=2.0, coarse_downsample=cds)
+    res = mt.match(dev.ptr, dev.offset(P * Hm * Wm), masks0=masks0, masks1=masks1, compute_photometric=True)
+    got = StripBatchMatcher.per_pair(res)
+    cfg = dict(sigma=2.5, coarse_downsample=cds, conf_thresh=0.33, residue_len=2, compute_photometric=True)
+    for k, (a, b) in enumerate(pairs):
+        exp = fb.matcher.stitching_matcher(a, b, mask0=masks0[k], mask1=masks1[k], **cfg)
+        assert exp[0] is not None and got[k]['xy0'] is not None and got[k]['xy0'].shape == exp[0].shape
+        np.testing.assert_allclose(got[k]['xy0'], exp[0], atol=1e-4); np.testing.assert_allclose(got[k]['xy1'], exp[1], atol=1e-4)
+        np.testing.assert_allclose(got[k]['weight'], exp[2], atol=1e-4)
+        np.testing.assert_allclose(res['phtm'][k], exp[4], rtol=1e-6)
+    mt.free(); dev.free()
+
+
 def test_ragged_batch_with_deformed_meshes_matches_the_per_pair_surface(fb):
     """strips of unequal size whose mesh1 is relaxed into a non-rigid field between the spacings, in ONE batch (per-pair node
     grids and tolerances in fb_deformed_block_affines / fb_deformed_locate), against matchers of their own shape"""

@@ -28,6 +28,6 @@ echo "ALL GREEN" | tee -a $O/steps.txt
 # NOT part of this call (each ALONE in a call of its own, under a short timeout, after reading tools/pending/README):
 #   FEABAS_TEST_PENDING=1 python -m pytest tests/test_gpu_ncc.py -q -k g20_xcorr_normalized        (new kernels of fb_ncc_batch_normalized)
 #   FEABAS_TEST_PENDING=1 python -m pytest tests/test_gpu_fem.py -q -k g21_grouped
-#   FEABAS_TEST_PENDING=1 python -m pytest tests/test_gpu_pipeline.py -q -k ragged_batch_photometric   (then: stitching_matcher_batch may stop routing photometric lists per shape)
+#   FEABAS_TEST_PENDING=1 python -m pytest tests/test_gpu_pipeline.py -q -k "ragged_batch_photometric or ragged_batch_with_masks"   (then: stitching_matcher_batch may stop routing masked / photometric pairs per shape)
 #   FEABAS_TEST_PENDING=1 python -m pytest tests/test_gpu_renderer.py -q -k section_matcher_vs_oracle
 #   the PCG best-iterate patch (tools/pending/pcg_best_iterate.patch)
