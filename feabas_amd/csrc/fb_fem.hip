@@ -1595,4 +1595,37 @@ int fb_pairs_strain_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int3
     return pairs_strain_core(ctx, s, P, has, weight, stiffness_lambda, es0, 1, default_strain, strain, iters, relres);
 }
 
+// test hook (host only, no context): one coarsening step of the multigrid set-up on a level given as host arrays -- the
+// aggregates, the relative node positions and the coarse pattern mg_build_next uploads (mg_host_coarsen, the threaded host half).
+// A first call with ccol == NULL sizes the coarse pattern (*cnnz).
+int fb_debug_mg_coarsen(int n, int bs, const double* xy, const int32_t* comp, const int32_t* rowptr, const int32_t* col, double fine_scale,
+                        int32_t* nc, double* cell, int32_t* agg, double* rel, double* cxy, int32_t* ccomp, int32_t* crowptr, int64_t* cnnz,
+                        int32_t* ccol, int64_t ccol_cap, int32_t* maxc) {
+    if (n <= 0 || (bs != 2 && bs != 3) || !xy || !comp || !rowptr || !col || !nc || !cnnz) return FB_ERR_ARG;
+    MgLevel f, c;
+    f.n = n; f.bs = bs;
+    f.xy.assign(xy, xy + 2 * (size_t)n);
+    f.comp.assign(comp, comp + n);
+    f.rowptr.assign(rowptr, rowptr + n + 1);
+    f.col.assign(col, col + rowptr[n]);
+    f.nnzb = rowptr[n];
+    std::vector<int> agg_v, aptr, aidx;
+    std::vector<double2> rel_v;
+    int mc = 0;
+    mg_host_coarsen(f, c, bs, fine_scale, agg_v, aptr, aidx, rel_v, mc, [](const char*) {});
+    *nc = f.nc; *cnnz = c.nnzb;
+    if (cell) *cell = f.scale;
+    if (maxc) *maxc = mc;
+    if (agg) std::copy(agg_v.begin(), agg_v.end(), agg);
+    if (rel) for (int i = 0; i < n; ++i) { rel[2 * (size_t)i] = rel_v[i].x; rel[2 * (size_t)i + 1] = rel_v[i].y; }
+    if (ccol) {
+        if (ccol_cap < c.nnzb || !crowptr || !cxy || !ccomp) return FB_ERR_ARG;
+        std::copy(c.rowptr.begin(), c.rowptr.end(), crowptr);
+        std::copy(c.col.begin(), c.col.end(), ccol);
+        std::copy(c.xy.begin(), c.xy.end(), cxy);
+        std::copy(c.comp.begin(), c.comp.end(), ccomp);
+    }
+    return FB_OK;
+}
+
 }  // extern "C"

@@ -140,6 +140,13 @@ int fb_ncc_blocks_affine_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1
  * last fb_ncc_batch* call that went through the streaming (rocFFT) class. */
 int fb_ncc_last_surfaces(fb_ctx* ctx, float* C_out, float* Cm_out, int* Fh, int* Fw);
 
+/* test hook (host only, no context): one coarsening step of the multigrid set-up (csrc/fb_mg.inc: aggregates = grid cells per mesh,
+ * relative node positions, coarse pattern -- the threaded host half of the set-up) on a level given as host arrays: xy [n][2], comp [n]
+ * (mesh of every node), the block pattern rowptr [n + 1] / col.  Outputs: *nc aggregates, *cell, agg [n], rel [n][2], and -- when
+ * ccol is given with capacity ccol_cap >= *cnnz -- cxy [nc][2], ccomp [nc], crowptr [nc + 1], ccol [*cnnz]; *maxc = longest coarse row. */
+int fb_debug_mg_coarsen(int n, int bs, const double* xy, const int32_t* comp, const int32_t* rowptr, const int32_t* col, double fine_scale,
+                        int32_t* nc, double* cell, int32_t* agg, double* rel, double* cxy, int32_t* ccomp, int32_t* crowptr, int64_t* cnnz,
+                        int32_t* ccol, int64_t ccol_cap, int32_t* maxc);
 /* test hook: M complex transforms of length N (5-smooth, <= 4096) through the LDS FFT core the NCC
  * kernels are built on; in/out are host arrays [M][N][2] float32; inverse is un-normalised. */
 int fb_debug_fft1d(fb_ctx* ctx, const float* in_host, float* out_host, int M, int N, int inverse, int pad);

@@ -936,3 +936,79 @@ def test_context_destroy_hooks_empty_the_matcher_caches(monkeypatch):
     assert [h for n, h in log if n == 'destroy'] == [hw, ha]                                              # the worker's context first, then the owner's
     assert list(fm._pair_matchers) == [('k2', id(hb))] and list(fm._pools) == [id(hb)] and list(fm._batch_workers) == [(id(hb), 0)]
     assert getattr(_lib._tls, 'ctx', None) is None                                                        # the caller's context is current again
+
+
+def _mg_level(rng, grids, jitter=0.2):
+    """a level of the multigrid set-up as host arrays: several structured triangulated grids (one mesh each), block pattern =
+    vertex adjacency through the triangles + the diagonal"""
+    from scipy import sparse
+    xy, comp, rows, cols = [], [], [], []
+    off = 0
+    for k, (nx, ny, step, ox, oy) in enumerate(grids):
+        gx, gy = np.meshgrid(ox + step * np.arange(nx), oy + step * np.arange(ny))
+        v = np.stack((gx.ravel(), gy.ravel()), axis=-1) + rng.uniform(-jitter, jitter, (nx * ny, 2)) * step
+        idx = np.arange(nx * ny).reshape(ny, nx)
+        a, b, c_, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+        tri = np.concatenate((np.stack((a, b, d), -1), np.stack((a, d, c_), -1)))
+        for i in range(3):
+            for j in range(3):
+                rows.append(tri[:, i] + off); cols.append(tri[:, j] + off)
+        xy.append(v); comp.append(np.full(nx * ny, k, dtype=np.int32)); off += nx * ny
+    n = off
+    A = sparse.csr_matrix((np.ones(sum(r.size for r in rows)), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    A.sum_duplicates(); A.sort_indices()
+    return np.ascontiguousarray(np.concatenate(xy)), np.ascontiguousarray(np.concatenate(comp)), A
+
+
+def _mg_coarsen(lib, xy, comp, A, bs=2, fine_scale=1.0):
+    n = xy.shape[0]
+    rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32); col = np.ascontiguousarray(A.indices, dtype=np.int32)
+    nc, maxc, cell, cnnz = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double(), ctypes.c_int64()
+    agg = np.empty(n, np.int32); rel = np.empty((n, 2))
+    args = (n, bs, _lib.ptr(xy), _lib.ptr(comp), _lib.ptr(rowptr), _lib.ptr(col), fine_scale, ctypes.byref(nc), ctypes.byref(cell), _lib.ptr(agg), _lib.ptr(rel))
+    assert lib.fb_debug_mg_coarsen(*args, None, None, None, ctypes.byref(cnnz), None, 0, ctypes.byref(maxc)) == 0
+    cxy = np.empty((nc.value, 2)); ccomp = np.empty(nc.value, np.int32); crow = np.empty(nc.value + 1, np.int32); ccol = np.empty(cnnz.value, np.int32)
+    assert lib.fb_debug_mg_coarsen(*args, _lib.ptr(cxy), _lib.ptr(ccomp), _lib.ptr(crow), ctypes.byref(cnnz), _lib.ptr(ccol), ccol.size, ctypes.byref(maxc)) == 0
+    return dict(nc=nc.value, cell=cell.value, agg=agg, rel=rel, cxy=cxy, ccomp=ccomp, crow=crow, ccol=ccol, maxc=maxc.value)
+
+
+def check_mg_coarsening(xy, comp, A, r):
+    """what a coarsening step of csrc/fb_mg.inc promises, whatever the number of host threads that produced it"""
+    from scipy import sparse
+    n, nc, agg = xy.shape[0], r['nc'], r['agg']
+    assert 0 < nc <= n and agg.min() == 0 and agg.max() == nc - 1
+    first = np.full(nc, n, dtype=np.int64)
+    np.minimum.at(first, agg, np.arange(n))
+    assert np.all(np.diff(first) > 0)                                   # aggregates are numbered in the order of their first node
+    assert np.array_equal(r['ccomp'], comp[first])
+    assert np.array_equal(comp, r['ccomp'][agg])                        # an aggregate never joins two meshes
+    cnt = np.bincount(agg, minlength=nc)
+    cen = np.stack((np.bincount(agg, xy[:, 0], nc), np.bincount(agg, xy[:, 1], nc)), -1) / cnt[:, None]
+    np.testing.assert_allclose(r['cxy'], cen, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(r['rel'], (xy - cen[agg]) / r['cell'], rtol=1e-10, atol=1e-10)
+    assert np.abs(r['rel']).max() <= 1.0 + 1e-9                         # the nodes of an aggregate lie in one cell
+    P = sparse.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, nc))
+    Cp = (P.T @ A @ P).tocsr(); Cp.sort_indices()
+    np.testing.assert_array_equal(r['crow'], Cp.indptr)
+    np.testing.assert_array_equal(r['ccol'], Cp.indices)                # the Galerkin pattern, rows sorted
+    assert r['maxc'] == int(np.diff(Cp.indptr).max())
+
+
+def test_cxx_multigrid_coarsening_host_half():
+    """fb_debug_mg_coarsen (host only): one coarsening step of the multigrid set-up -- grid-cell aggregates per mesh, relative node
+    positions, the Galerkin pattern -- on a small two-mesh level and on one large enough for its host loops to run on several
+    threads (>= 131072 nodes / >= 2048 aggregates): invariants against numpy / scipy"""
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    xy, comp, A = _mg_level(rng, [(23, 17, 10.0, 0.0, 0.0), (12, 31, 7.0, 400.0, -50.0)])
+    r = _mg_coarsen(lib, xy, comp, A)
+    check_mg_coarsening(xy, comp, A, r)
+    assert 4 <= r['nc'] < xy.shape[0] // 8
+    xy, comp, A = _mg_level(rng, [(640, 500, 5.0, 0.0, 0.0), (150, 160, 5.0, 5000.0, 100.0)])
+    r = _mg_coarsen(lib, xy, comp, A)
+    check_mg_coarsening(xy, comp, A, r)
+    assert r['nc'] >= 2048
+    # a coarse level (3 degrees of freedom per node) coarsens like a fine one
+    r3 = _mg_coarsen(lib, np.ascontiguousarray(r['cxy']), np.ascontiguousarray(r['ccomp']),
+                     __import__('scipy.sparse', fromlist=['csr_matrix']).csr_matrix((np.ones(r['ccol'].size), r['ccol'], r['crow']), shape=(r['nc'], r['nc'])), bs=3, fine_scale=r['cell'])
+    assert r3['nc'] < r['nc']

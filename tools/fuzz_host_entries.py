@@ -130,9 +130,26 @@ def fuzz_pack(lib, rng, n):
             np.testing.assert_array_equal(dst[j, :s.shape[0], :s.shape[1]], s)
 
 
+def fuzz_multigrid(lib, rng, n):
+    """random levels through fb_debug_mg_coarsen (the host half of the multigrid set-up): the invariants of
+    tests/test_cpu_host.py::check_mg_coarsening"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    import test_cpu_host as T
+    for _ in range(n):
+        grids = [(int(rng.integers(2, 60)), int(rng.integers(2, 60)), float(rng.uniform(2, 30)), float(rng.uniform(-500, 500)) + 3000.0 * k, float(rng.uniform(-500, 500)))
+                 for k in range(int(rng.integers(1, 4)))]
+        xy, comp, A = T._mg_level(rng, grids, jitter=float(rng.choice([0.0, 0.2, 0.45])))
+        r = T._mg_coarsen(lib, xy, comp, A, bs=int(rng.choice([2, 3])), fine_scale=float(rng.uniform(0.5, 20)))
+        T.check_mg_coarsening(xy, comp, A, r)
+
+
 def fuzz_large(lib, rng):
     """sizes at which the host loops go to several threads (>= 4096 blocks, >= 8192 points, >= 131072 triangles): the same checks"""
     from oracle import pipeline_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    import test_cpu_host as T
+    xy, comp, A = T._mg_level(rng, [(640, 500, 5.0, 0.0, 0.0), (150, 160, 5.0, 5000.0, 100.0)])
+    T.check_mg_coarsening(xy, comp, A, T._mg_coarsen(lib, xy, comp, A))
     nv = 70000
     v = np.ascontiguousarray(rng.uniform(0, 9000, (nv, 2)))
     tris = np.ascontiguousarray(Delaunay(v).simplices, dtype=np.int32)
@@ -195,7 +212,7 @@ def main():
     print('library', _lib.LIB_PATH)
     rng = np.random.default_rng(seed)
     for name, fn in (('schedule', fuzz_schedule), ('divide_bbox', fuzz_divide_bbox), ('general_mesh', fuzz_general_mesh), ('deformed', fuzz_deformed),
-                     ('pack', fuzz_pack)):
+                     ('pack', fuzz_pack), ('multigrid', fuzz_multigrid)):
         fn(lib, rng, rounds)
         print(f'{name}: {rounds} rounds ok')
     fuzz_large(lib, rng)
