@@ -677,8 +677,9 @@ int matcher_create(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, cons
         m->Hs[p] = shapes ? shapes[2 * p] : H;
         m->Ws[p] = shapes ? shapes[2 * p + 1] : W;
         if (m->Hs[p] < 2 || m->Ws[p] < 2 || m->Hs[p] > H || m->Ws[p] > W) {
+            const int hp = m->Hs[p], wp = m->Ws[p];
             delete m;
-            return fb_fail(ctx, FB_ERR_ARG, "fb_strip_matcher_create: pair %d: a %d x %d strip does not fit its %d x %d slot", p, shapes[2 * p], shapes[2 * p + 1], H, W);
+            return fb_fail(ctx, FB_ERR_ARG, "fb_strip_matcher_create: pair %d: a %d x %d strip does not fit its %d x %d slot", p, hp, wp, H, W);
         }
         // cv2.resize(fx=0.5): cvRound(n / 2), half to even
         m->hcs[p] = m->cds2 ? round_i(m->Hs[p] * 0.5) : m->Hs[p];
@@ -698,8 +699,9 @@ int matcher_create(fb_ctx* ctx, int P, int H, int W, const int32_t* shapes, cons
             auto_spacings(m->Hs[p], m->Ws[p], one);
             if (p == 0) m->nsp = (int)one.size();
             if ((int)one.size() != m->nsp) {
+                const int nsp0 = m->nsp;                       // (read before the matcher goes: the message used to read it afterwards)
                 delete m;
-                return fb_fail(ctx, FB_ERR_ARG, "fb_strip_matcher_create: pair %d has %d automatic spacings, pair 0 %d (the pairs of a batch share the number of rounds)", p, (int)one.size(), m->nsp);
+                return fb_fail(ctx, FB_ERR_ARG, "fb_strip_matcher_create: pair %d has %d automatic spacings, pair 0 %d (the pairs of a batch share the number of rounds)", p, (int)one.size(), nsp0);
             }
             m->sp.insert(m->sp.end(), one.begin(), one.end());
         }

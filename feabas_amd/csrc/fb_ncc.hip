@@ -737,7 +737,8 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
                         int Fw, int subpixel, int conf_mode, double* dx, double* dy, float* conf, const CropSrc* crop) {
     StreamGeom g;
     g.N = nb; g.Fh = Fh; g.Fw = Fw; g.Sw = Fw / 2 + 1; g.Kp = (g.Sw + 1) / 2;
-    const size_t lds_budget = (getenv("FB_TRB") ? (size_t)atoi(getenv("FB_TRB")) : 70) * 1024;
+    const char* trb = getenv("FB_TRB");
+    const size_t lds_budget = (trb ? (size_t)atoi(trb) : 70) * 1024;
     g.TR = std::min(16, pow2_floor((int)std::max<size_t>(1, lds_budget / ((size_t)(Fw + Fw / 16 + 1) * sizeof(float2)))));
     const bool p2 = p2_shape(Fh) && p2_shape(Fw) && !getenv("FEABAS_HIP_FFT_GENERIC");
     const bool ct = !p2 && fb_ncc_ct_len(Fh) && fb_ncc_ct_len(Fw) && !getenv("FEABAS_HIP_FFT_GENERIC");     // compile-time mixed-radix plans
@@ -746,7 +747,8 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     g.TRI = g.TR;
     // inverse pass on half tiles (workgroups of 256 threads, twice as many per CU: half as many waves meet at each barrier):
     // 11-13 % faster at FW <= 1024; narrower tiles would cut the contiguous runs of V below 64 B (FB_INV_HALF=0/1 overrides)
-    if (p2 && (getenv("FB_INV_HALF") ? atoi(getenv("FB_INV_HALF")) != 0 : g.TR >= 8)) g.TRI = std::max(1, g.TR / 2);
+    const char* inv_half = getenv("FB_INV_HALF");
+    if (p2 && (inv_half ? atoi(inv_half) != 0 : g.TR >= 8)) g.TRI = std::max(1, g.TR / 2);
     const int rows = std::min(Fh, std::max(1, hmax));
     g.Hs = (rows + g.TR - 1) / g.TR * g.TR;
     g.H0 = H0; g.W0 = W0; g.H1 = H1; g.W1 = W1;
