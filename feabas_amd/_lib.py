@@ -118,6 +118,9 @@ _PROTOS = {
     'fb_memcpy_d2h': (c_i, [c_p, c_p, c_p, c_sz]),
     'fb_memcpy_d2d': (c_i, [c_p, c_p, c_p, C.c_size_t]),
     'fb_memcpy2d_d2d': (c_i, [c_p, c_p, c_sz, c_p, c_sz, c_sz, c_sz]),
+    'fb_debug_rigid_fits': (c_i, [c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'fb_debug_auto_spacings': (c_i, [c_i, c_i, c_p, c_i, c_p]),
+    'fb_debug_grid_counts': (c_i, [c_i, c_i, c_d, c_i, c_p, c_p]),
     'fb_debug_mg_coarsen': (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     'fb_memset': (c_i, [c_p, c_p, c_i, c_sz]),
     'fb_timer_start': (c_i, [c_p]),

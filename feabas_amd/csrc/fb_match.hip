@@ -846,6 +846,42 @@ int fb_divide_bbox(fb_ctx* ctx, const double* bbox, const double* block_hw, cons
     return FB_OK;
 }
 
+// test hooks (host only, no context): the host arithmetic fb_match_strips runs between its kernels -- the rigid fits of
+// matcher.py:752-763 (spatial.fit_affine(return_rigid=True, svd_clip=(1, 1)) of every pair's matches; rows of a pair contiguous;
+// R [P][3][3], bad [P] = 1 where the pair needs the statement-by-statement route), the automatic spacings of matcher.py:243-251
+// (descending) and the node grid of Mesh.from_bbox(cartesian=True) (mesh.py:403-435).
+int fb_debug_rigid_fits(int P, int64_t K, const int32_t* pid, const double* p0, const double* p1, const float* wt, double* R, uint8_t* bad) {
+    if (P <= 0 || K < 0 || (K && (!pid || !p0 || !p1 || !wt)) || !R || !bad) return FB_ERR_ARG;
+    for (int64_t k = 0; k < K; ++k)
+        if (pid[k] < 0 || pid[k] >= P) return FB_ERR_ARG;
+    std::vector<int32_t> vp(pid, pid + K);
+    std::vector<double> v0(p0, p0 + 2 * K), v1(p1, p1 + 2 * K), Rv;
+    std::vector<float> vw(wt, wt + K);
+    std::vector<char> bv;
+    rigid_fits(P, vp, v0, v1, vw, Rv, bv);
+    std::copy(Rv.begin(), Rv.end(), R);
+    for (int p = 0; p < P; ++p) bad[p] = (uint8_t)bv[p];
+    return FB_OK;
+}
+
+int fb_debug_auto_spacings(int H, int W, double* out, int cap, int* count) {
+    if (H < 1 || W < 1 || !count) return FB_ERR_ARG;
+    std::vector<double> sp;
+    auto_spacings(H, W, sp);
+    *count = (int)sp.size();
+    if (out) {
+        if (cap < (int)sp.size()) return FB_ERR_ARG;
+        std::copy(sp.begin(), sp.end(), out);
+    }
+    return FB_OK;
+}
+
+int fb_debug_grid_counts(int H, int W, double mesh_size, int min_num_blocks, int* nx, int* ny) {
+    if (H < 1 || W < 1 || !(mesh_size > 0) || min_num_blocks < 1 || !nx || !ny) return FB_ERR_ARG;
+    grid_counts(H, W, mesh_size, min_num_blocks, nx, ny);
+    return FB_OK;
+}
+
 int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* o, fb_strip_matcher** out) {
     FB_LOCK(ctx);
     return matcher_create(ctx, P, H, W, nullptr, o, out);

@@ -1012,3 +1012,47 @@ def test_cxx_multigrid_coarsening_host_half():
     r3 = _mg_coarsen(lib, np.ascontiguousarray(r['cxy']), np.ascontiguousarray(r['ccomp']),
                      __import__('scipy.sparse', fromlist=['csr_matrix']).csr_matrix((np.ones(r['ccol'].size), r['ccol'], r['crow']), shape=(r['nc'], r['nc'])), bs=3, fine_scale=r['cell'])
     assert r3['nc'] < r['nc']
+
+
+def test_cxx_strip_matcher_host_arithmetic_matches_python():
+    """the host arithmetic of fb_match_strips (host-only hooks, no device): the rigid fits of every pair's matches against
+    common.fit_affine (pinned to the reference's spatial.fit_affine by golden G13), the automatic spacings against
+    matcher.auto_spacings (matcher.py:243-251) and the node grid against Mesh.from_bbox(cartesian=True)"""
+    from feabas_amd.mesh import Mesh
+    from feabas_amd.stitch_pipeline import grid_counts
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    P = 9
+    pid, p0, p1, wt = [], [], [], []
+    for p in range(P):
+        n = [40, 3, 2, 0, 25, 60, 5, 12, 30][p]
+        q = rng.uniform(0, 500, (n, 2)) * ([1, 1] if p != 6 else [1, 0])           # pair 6: collinear matches (rank deficient)
+        th = rng.uniform(-0.05, 0.05)
+        Rm = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+        t = q @ Rm * (1.0 + rng.uniform(-0.01, 0.01)) + rng.uniform(-20, 20, 2) + rng.normal(0, 0.3, (n, 2))
+        if p == 7:
+            t = t * np.array([-1.0, 1.0])                                            # a reflection: not a rigid motion
+        pid.append(np.full(n, p, np.int32)); p1.append(q); p0.append(t); wt.append(rng.uniform(0.1, 1.0, n).astype(np.float32))
+    pid, p0, p1, wt = np.concatenate(pid), np.ascontiguousarray(np.concatenate(p0)), np.ascontiguousarray(np.concatenate(p1)), np.concatenate(wt)
+    R = np.empty((P, 3, 3)); bad = np.empty(P, np.uint8)
+    assert lib.fb_debug_rigid_fits(P, pid.size, _lib.ptr(pid), _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(wt), _lib.ptr(R), _lib.ptr(bad)) == 0
+    assert bad.tolist() == [0, 0, 1, 0, 0, 0, 1, 1, 0]          # two matches, collinear matches, a reflection: the statement-by-statement route
+    np.testing.assert_array_equal(R[3], np.eye(3))                 # a pair without matches is not visited
+    for p in range(P):
+        if bad[p] or p == 3:
+            continue
+        s_ = pid == p
+        _, Rr = common.fit_affine(p0[s_], p1[s_], return_rigid=True, weight=wt[s_].astype(np.float64), svd_clip=(1, 1))
+        np.testing.assert_allclose(R[p], Rr, atol=1e-9, rtol=1e-9)
+    for H, W in [(4096, 510), (510, 4096), (1536, 120), (60, 60), (90, 700), (2048, 255), (75, 76), (301, 299)]:
+        cnt = ctypes.c_int()
+        out = np.empty(8)
+        assert lib.fb_debug_auto_spacings(H, W, _lib.ptr(out), 8, ctypes.byref(cnt)) == 0
+        np.testing.assert_allclose(out[:cnt.value], np.sort(matcher.auto_spacings((H, W), (H, W)))[::-1], rtol=1e-14)
+        for ms in (25.0, 40.0, 75.0, float(out[cnt.value - 1])):
+            for mnb in (1, 2, 3):
+                nx, ny = ctypes.c_int(), ctypes.c_int()
+                assert lib.fb_debug_grid_counts(H, W, ms, mnb, ctypes.byref(nx), ctypes.byref(ny)) == 0
+                assert (nx.value, ny.value) == grid_counts(H, W, ms, mnb)
+                m = Mesh.from_bbox((0, 0, W, H), cartesian=True, mesh_size=ms, min_num_blocks=mnb)
+                assert (nx.value, ny.value) == (m.grid_xs.size, m.grid_ys.size)

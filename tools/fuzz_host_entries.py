@@ -143,6 +143,41 @@ def fuzz_multigrid(lib, rng, n):
         T.check_mg_coarsening(xy, comp, A, r)
 
 
+def fuzz_strip_host(lib, rng, n):
+    """the host arithmetic of fb_match_strips: rigid fits of random match tables against common.fit_affine, spacings, node grids"""
+    from feabas_amd import matcher
+    from feabas_amd.stitch_pipeline import grid_counts
+    for _ in range(n):
+        P = int(rng.integers(1, 12))
+        pid, p0, p1, wt = [], [], [], []
+        for p in range(P):
+            k = int(rng.choice([0, 1, 2, 3, 4, 17, 80]))
+            q = rng.uniform(-300, 900, (k, 2))
+            th = rng.uniform(-0.3, 0.3)
+            Rm = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+            t = q @ Rm + rng.uniform(-50, 50, 2) + rng.normal(0, float(rng.choice([0.0, 0.5, 5.0])), (k, 2))
+            pid.append(np.full(k, p, np.int32)); p1.append(q); p0.append(t); wt.append(rng.uniform(0.05, 1.0, k).astype(np.float32))
+        pid = np.ascontiguousarray(np.concatenate(pid)); p0 = np.ascontiguousarray(np.concatenate(p0).reshape(-1, 2)); p1 = np.ascontiguousarray(np.concatenate(p1).reshape(-1, 2))
+        wt = np.ascontiguousarray(np.concatenate(wt))
+        R = np.empty((P, 3, 3)); bad = np.empty(P, np.uint8)
+        assert lib.fb_debug_rigid_fits(P, pid.size, _lib.ptr(pid), _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(wt), _lib.ptr(R), _lib.ptr(bad)) == 0
+        for p in range(P):
+            s_ = pid == p
+            if bad[p] or s_.sum() < 3:
+                continue
+            _, Rr = common.fit_affine(p0[s_], p1[s_], return_rigid=True, weight=wt[s_].astype(np.float64), svd_clip=(1, 1))
+            np.testing.assert_allclose(R[p], Rr, atol=1e-7, rtol=1e-7)
+        H, W = int(rng.integers(30, 5000)), int(rng.integers(30, 5000))
+        cnt = C.c_int(); out = np.empty(16)
+        assert lib.fb_debug_auto_spacings(H, W, _lib.ptr(out), 16, C.byref(cnt)) == 0
+        np.testing.assert_allclose(out[:cnt.value], np.sort(matcher.auto_spacings((H, W), (H, W)))[::-1], rtol=1e-14)
+        assert lib.fb_debug_auto_spacings(H, W, _lib.ptr(out), cnt.value - 1, C.byref(cnt)) != 0          # a capacity that is too small is refused
+        ms = float(rng.uniform(20, 400)); mnb = int(rng.integers(1, 4))
+        nx, ny = C.c_int(), C.c_int()
+        assert lib.fb_debug_grid_counts(H, W, ms, mnb, C.byref(nx), C.byref(ny)) == 0
+        assert (nx.value, ny.value) == grid_counts(H, W, ms, mnb)
+
+
 def fuzz_large(lib, rng):
     """sizes at which the host loops go to several threads (>= 4096 blocks, >= 8192 points, >= 131072 triangles): the same checks"""
     from oracle import pipeline_ref
@@ -153,8 +188,13 @@ def fuzz_large(lib, rng):
     nv = 70000
     v = np.ascontiguousarray(rng.uniform(0, 9000, (nv, 2)))
     tris = np.ascontiguousarray(Delaunay(v).simplices, dtype=np.int32)
-    assert tris.shape[0] > 131072
     vm = np.ascontiguousarray(v + 3.0 * np.stack((np.sin(v[:, 1] / 300.0), np.cos(v[:, 0] / 260.0)), axis=-1))
+    # (the slivers Delaunay leaves on the hull of random points fold under any displacement: a valid mesh has none)
+    pm = vm[tris]; e1, e2 = pm[:, 1] - pm[:, 0], pm[:, 2] - pm[:, 1]
+    pi = v[tris]; f1, f2 = pi[:, 1] - pi[:, 0], pi[:, 2] - pi[:, 1]
+    keep = ((e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]) * np.sign(f1[:, 0] * f2[:, 1] - f1[:, 1] * f2[:, 0]) > 1.0) & (np.abs(f1[:, 0] * f2[:, 1] - f1[:, 1] * f2[:, 0]) > 1.0)
+    tris = np.ascontiguousarray(tris[keep])
+    assert tris.shape[0] > 131072
     area = np.zeros(tris.shape[0]); ratio = np.zeros((tris.shape[0], 3))
     assert lib.fb_signed_area(None, nv, _lib.ptr(v), tris.shape[0], _lib.ptr(tris), _lib.ptr(area)) == 0
     p = v[tris]
@@ -212,7 +252,7 @@ def main():
     print('library', _lib.LIB_PATH)
     rng = np.random.default_rng(seed)
     for name, fn in (('schedule', fuzz_schedule), ('divide_bbox', fuzz_divide_bbox), ('general_mesh', fuzz_general_mesh), ('deformed', fuzz_deformed),
-                     ('pack', fuzz_pack), ('multigrid', fuzz_multigrid)):
+                     ('pack', fuzz_pack), ('multigrid', fuzz_multigrid), ('strip_host', fuzz_strip_host)):
         fn(lib, rng, rounds)
         print(f'{name}: {rounds} rounds ok')
     fuzz_large(lib, rng)
