@@ -1056,3 +1056,102 @@ def test_cxx_strip_matcher_host_arithmetic_matches_python():
                 assert (nx.value, ny.value) == grid_counts(H, W, ms, mnb)
                 m = Mesh.from_bbox((0, 0, W, H), cartesian=True, mesh_size=ms, min_num_blocks=mnb)
                 assert (nx.value, ny.value) == (m.grid_xs.size, m.grid_ys.size)
+
+
+class _FakeBuf:
+    def __init__(self, nbytes=0):
+        self.nbytes = int(nbytes); self.ptr = ctypes.c_void_p(1)
+
+    def offset(self, n):
+        return ctypes.c_void_p(1)
+
+    def free(self):
+        self.ptr = None
+
+
+def _install_fake_device(monkeypatch, match_fn):
+    """stand-ins for everything stitching_matcher_batch touches on the device: contexts, staging buffers, the packing / copy entries
+    and the strip matcher (match_fn(call number, number of pairs) -> per-pair results or an exception)"""
+    import threading
+    from feabas_amd import matcher as fm, stitch_pipeline as sp
+    calls = [0]
+    lock = threading.Lock()
+
+    class FakeLib:
+        def __getattr__(self, name):
+            if name.startswith('fb_'):
+                return lambda *a: 0
+            raise AttributeError(name)
+
+    class FakeMatcher:
+        def __init__(self, n, H, W, pool=None, **opts):
+            self.n = n
+
+        def match(self, d0, d1, masks0=None, masks1=None, compute_photometric=False):
+            with lock:
+                calls[0] += 1
+                k = calls[0]
+            return match_fn(k, self.n)
+
+        def free(self):
+            pass
+
+        @staticmethod
+        def per_pair(out):
+            return out['per']
+
+    class FakePool:
+        def free(self):
+            pass
+    main = object()
+    monkeypatch.setattr(_lib, 'load', lambda: FakeLib())
+    monkeypatch.setattr(_lib, '_ctx', main)
+    monkeypatch.setattr(_lib, 'ctx', lambda device=None: getattr(_lib._tls, 'ctx', None) or main)
+    monkeypatch.setattr(_lib, 'new_context', lambda device=None: object())
+    monkeypatch.setattr(_lib, 'destroy_context', lambda h: None)
+    monkeypatch.setattr(_lib, 'PinnedBuffer', _FakeBuf)
+    monkeypatch.setattr(_lib, 'DeviceBuffer', _FakeBuf)
+    monkeypatch.setattr(sp, 'StripBatchMatcher', FakeMatcher)
+    monkeypatch.setattr(sp, 'MatcherPool', FakePool)
+    monkeypatch.setattr(fm, '_batch_workers', {})
+    return calls
+
+
+@pytest.mark.parametrize('threads', [1, 2, 3, 4, 6])
+def test_stitching_matcher_batch_queues_without_a_gpu(monkeypatch, threads):
+    """the host side of stitching_matcher_batch -- chunks, loader and matcher threads, staging slots, end marks -- on stand-ins for the
+    device objects: every pair comes back in input order whatever the number of threads; a matcher call that raises (like a device
+    out-of-memory in one chunk) surfaces in the caller instead of leaving the other threads waiting, and the next call
+    works again.  (tests/test_gpu_pipeline.py holds the same scenario on the device.)"""
+    from feabas_amd import matcher as fm
+
+    def ok(k, n):
+        return dict(per=[dict(xy0=np.full((2, 2), float(k)), xy1=np.zeros((2, 2)), weight=np.ones(2), strain=0.01, deferred=False) for _ in range(n)], phtm=None)
+    calls = _install_fake_device(monkeypatch, ok)
+    pairs = [(np.full((64, 32), k, np.uint8), np.full((64, 32), k + 1, np.uint8)) for k in range(23)]
+    out = fm.stitching_matcher_batch(pairs, batch=4, threads=threads, sigma=2.5, coarse_downsample=0.5)
+    assert len(out) == 23 and all(o[0] is not None and o[0].shape == (2, 2) for o in out) and calls[0] == 6
+
+    def third_fails(k, n):
+        if k == calls_before[0] + 3:
+            raise RuntimeError('injected failure in one chunk')
+        return ok(k, n)
+    calls_before = [calls[0]]
+    calls2 = _install_fake_device(monkeypatch, third_fails)
+    calls_before[0] = calls2[0]
+    import threading
+    done = []
+
+    def run():
+        try:
+            fm.stitching_matcher_batch(pairs, batch=2, threads=threads, sigma=2.5, coarse_downsample=0.5)
+            done.append('returned')
+        except RuntimeError as e:
+            done.append(str(e))
+    th = threading.Thread(target=run, daemon=True)
+    th.start(); th.join(timeout=60)
+    assert not th.is_alive(), 'stitching_matcher_batch hangs after a matcher failure'
+    assert done == ['injected failure in one chunk']
+    calls3 = _install_fake_device(monkeypatch, ok)
+    out = fm.stitching_matcher_batch(pairs[:5], batch=2, threads=threads, sigma=2.5, coarse_downsample=0.5)
+    assert len(out) == 5 and all(o[0] is not None for o in out) and calls3[0] == 3
