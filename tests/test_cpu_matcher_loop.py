@@ -1,0 +1,170 @@
+"""The PRODUCT's block-matcher loop on the CPU against the reference's (golden G23): feabas_amd.matcher.iterative_xcorr_matcher_w_mesh
+with everything of its own that runs on the host -- the block distributor, the round stepper of the library, _PairRelaxation, Link
+(point location, barycentric coordinates, residue weights, masks), Mesh's gears, the final extraction of the matches -- and two
+stand-ins: the block matcher is the script of the fixture (the reference's was scripted the same way), and SLM.optimize_linear, the
+one step that needs the device, is solved exactly through the oracle's assembly of the SAME meshes and links (the device solve has
+its own parity tests against that oracle, tests/test_gpu_fem.py).  What the reference's loop did around its block matches --
+blocks, flags, the field of mesh 1 going into every round, final matches and weights -- must come out of the product's loop."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+import feabas_amd.constant as const
+from feabas_amd import matcher, optimizer, renderer
+from feabas_amd.mesh import Mesh
+from oracle import fem_ref
+from test_oracle_golden import _g23_scripted_block_matches
+
+GEARS = (const.MESH_GEAR_INITIAL, const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING, const.MESH_GEAR_STAGING)
+
+
+def _mirror(m):
+    r = fem_ref.RefMesh(m._vertices[const.MESH_GEAR_INITIAL], m.triangles, uid=m.uid, locked=m.locked, soft_factor=m.soft_factor,
+                        stiffness_multiplier=m.stiffness_multiplier, nu=m.poisson_ratio)
+    for g in GEARS:
+        r._v[g] = m._vertices[g]
+        r._off[g] = np.asarray(m._offsets[g], dtype=np.float64).reshape(1, 2)
+    return r
+
+
+def _exact_optimize_linear(self, **kwargs):
+    """SLM.optimize_linear (optimizer.py:1257-1437) with the linear system of the oracle, solved directly"""
+    shape_gear = kwargs.get('shape_gear', const.MESH_GEAR_FIXED)
+    target_gear = kwargs.get('target_gear', const.MESH_GEAR_MOVING)
+    start_gear = kwargs.get('start_gear', target_gear)
+    refs = [_mirror(m) for m in self.meshes]
+    at = {m.uid: k for k, m in enumerate(self.meshes)}
+    links = []
+    for lk in self.links:
+        if getattr(lk, '_disabled', False):
+            continue
+        rl = fem_ref.RefLink(refs[at[lk.uids[0]]], refs[at[lk.uids[1]]], lk._tid0, lk._tid1, lk._B0, lk._B1, weight=lk._weight, strain=lk.strain)
+        rl.residue_weight = lk._residue_weight
+        links.append(rl)
+    A, b, _ = fem_ref.linear_system(refs, links, kwargs.get('stiffness_lambda', self._stiffness_lambda), kwargs.get('crosslink_lambda', self._crosslink_lambda),
+                                    shape_gear, start_gear, target_gear)
+    dd = fem_ref.solve_direct(A, np.asarray(b, dtype=np.float64))
+    cost = (float(np.linalg.norm(b)), float(np.linalg.norm(A @ dd - b)))
+    self.last_solve = dict(iters=None, relres=cost[1] / cost[0] if cost[0] else 0.0)
+    if cost[1] < cost[0]:
+        offs, _ = fem_ref.index_offsets(refs)
+        for m, o in zip(self.meshes, offs):
+            if o >= 0:
+                m.set_field(dd[o:o + 2 * m.num_vertices].reshape(-1, 2), gear=(start_gear, target_gear))
+    return cost
+
+
+def _exact_local_stiffness(self, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), tri_mask=None, **kwargs):
+    """Mesh.stiffness_matrix_local_normalized (the masked assembly of relax_mesh, mesh.py / optimizer.py:2110-2154) through the oracle"""
+    return _mirror(self).stiffness_matrix_local_normalized(gear=gear, tri_mask=tri_mask)
+
+
+def _exact_solve(A, b, solver='minres', x0=None, tol=1e-7, atol=None, maxiter=None, M=None, **kwargs):
+    """optimizer.solve with the free block solved directly (the held degrees of freedom stay zero)"""
+    from scipy import sparse
+    A = sparse.csr_matrix(A)
+    b = np.asarray(b, dtype=np.float64)
+    dof = kwargs.get('extra_dof_constraint', None)
+    x = np.zeros_like(b)
+    if dof is None:
+        return fem_ref.solve_direct(A, b)
+    if np.any(b[dof]):
+        x[dof] = fem_ref.solve_direct(A[dof][:, dof], b[dof])
+    return x
+
+
+class _NoImage(renderer.ResidentImage):
+    def __init__(self):
+        pass
+
+    def free(self):
+        pass
+
+
+@pytest.mark.parametrize('case', ['huber', 'threshold3', 'no_residue'])
+def test_product_matcher_loop_between_the_block_matches_vs_reference(monkeypatch, case):
+    g = load_golden('g23_matcher_loop.npz')
+    res_len, seed, ox, oy, thr = g[f'{case}_params']
+    m0 = Mesh(g['v0'], g['t0'], uid=0)
+    m0.apply_translation((ox, oy), const.MESH_GEAR_FIXED)
+    m0.lock()
+    m1 = Mesh(g['v1'].copy(), g['t1'], uid=1)
+    seen = []
+
+    def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+        k = len(seen)
+        seen.append(dict(bboxes0=np.array(bboxes0), bboxes1=np.array(bboxes1), pad=bool(kw.get('pad')), subpixel=bool(kw.get('subpixel')),
+                         field1=mesh1.vertices_w_offset(const.MESH_GEAR_MOVING) - mesh1.vertices_w_offset(const.MESH_GEAR_INITIAL)))
+        return _g23_scripted_block_matches(k, bboxes0, bboxes1, seed)
+    monkeypatch.setattr(matcher, 'bboxes_mesh_renderer_matcher', scripted)
+    monkeypatch.setattr(optimizer.SLM, 'optimize_linear', _exact_optimize_linear)
+
+    def no_device_relaxation(*a, **k):
+        raise AssertionError('relax_mesh needs the device: the fixture does not deform a triangle that far')
+    monkeypatch.setattr(optimizer, 'relax_mesh', no_device_relaxation)
+    xy0, xy1, wt, _ = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, _NoImage(), _NoImage(), spacings=g[f'{case}_spacings'], distributor='cartesian_bbox',
+                                                             conf_thresh=0.3, residue_len=float(res_len), residue_mode='threshold' if thr else 'huber',
+                                                             stiffness_lambda=0.5, min_num_blocks=2, compute_strain=False)
+    n = int(g[f'{case}_nrounds'])
+    assert len(seen) == n
+    for k, r in enumerate(seen):
+        np.testing.assert_allclose(r['bboxes0'], g[f'{case}_r{k}_bboxes0'], atol=1e-6)
+        np.testing.assert_allclose(r['bboxes1'], g[f'{case}_r{k}_bboxes1'], atol=1e-6)
+        assert [r['pad'], r['subpixel']] == g[f'{case}_r{k}_flags'].tolist()
+        scale = max(1.0, np.abs(g[f'{case}_r{k}_field1']).max())
+        np.testing.assert_allclose(r['field1'], g[f'{case}_r{k}_field1'], atol=1e-6 * scale)
+    scale = np.abs(g[f'{case}_field1_final']).max()
+    np.testing.assert_allclose(m1.vertices_w_offset(const.MESH_GEAR_MOVING) - m1.vertices_w_offset(const.MESH_GEAR_INITIAL), g[f'{case}_field1_final'], atol=1e-6 * scale)
+    assert xy0.shape == g[f'{case}_xy0'].shape
+    np.testing.assert_allclose(xy0, g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g[f'{case}_xy1'], atol=1e-5)
+    np.testing.assert_allclose(wt, g[f'{case}_weight'], atol=1e-5)
+
+
+@pytest.mark.parametrize('case', ['rigid', 'deformed', 'three'])
+def test_product_strip_loop_between_the_block_matches_vs_reference(monkeypatch, case):
+    """the same through stitching_matcher's set-up (golden G24, matcher.py:353-364): two cartesian meshes of Mesh.from_bbox, mesh 0
+    translated by the global translation and locked, the general-mesh loop on them -- what feabas_amd.matcher._stitching_matcher_general
+    runs for strips of unequal shape, and the statement the batched strip pipeline is tested against on the device"""
+    from test_oracle_golden import _g24_scripted_strip_blocks
+    g = load_golden('g24_strip_loop.npz')
+    H, W, tx, ty, res_len = g[f'{case}_params']
+    H, W = int(H), int(W)
+    spacings = g[f'{case}_spacings']
+    m0 = Mesh.from_bbox((0, 0, W, H), cartesian=True, mesh_size=float(np.min(spacings)), min_num_blocks=2, uid=0)
+    m1 = Mesh.from_bbox((0, 0, W, H), cartesian=True, mesh_size=float(np.min(spacings)), min_num_blocks=2, uid=1)
+    m0.apply_translation((tx, ty), const.MESH_GEAR_FIXED)
+    m0.lock()
+    seen = []
+
+    def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+        k = len(seen)
+        seen.append(dict(bboxes0=np.array(bboxes0), bboxes1=np.array(bboxes1), pad=bool(kw.get('pad')), subpixel=bool(kw.get('subpixel')),
+                         field1=mesh1.vertices_w_offset(const.MESH_GEAR_MOVING) - mesh1.vertices_w_offset(const.MESH_GEAR_INITIAL)))
+        if case == 'rigid' and k > 0:
+            # the knife edge of tests/test_oracle_golden.py::test_g24_...: after a whole-pixel round the lattice turns on the sign of the
+            # solver's residual (here: of a direct solve); the round goes on with the reference's recorded blocks
+            bboxes0, bboxes1 = g[f'{case}_r{k}_bboxes0'], g[f'{case}_r{k}_bboxes1']
+        dx, dy, cf = _g24_scripted_strip_blocks(case, k, bboxes0, bboxes1, H, W)
+        p0, p1 = matcher.block_displacements_to_points(bboxes0, bboxes1, dx, dy)
+        return p0, p1, cf
+    monkeypatch.setattr(matcher, 'bboxes_mesh_renderer_matcher', scripted)
+    monkeypatch.setattr(optimizer.SLM, 'optimize_linear', _exact_optimize_linear)
+    # relax_first (matcher.py:730, optimizer.py:763-772): the product's own relax_mesh_most_deformed / relax_mesh around the two steps that
+    # need the device -- the masked assembly and the solve of the free block -- which go through the oracle
+    monkeypatch.setattr(Mesh, 'stiffness_matrix_local_normalized', _exact_local_stiffness)
+    monkeypatch.setattr(optimizer, 'solve', _exact_solve)
+    xy0, xy1, wt, _ = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, _NoImage(), _NoImage(), spacings=spacings, distributor='cartesian_bbox', conf_thresh=0.33,
+                                                             residue_len=float(res_len), residue_mode='huber', min_num_blocks=2, compute_strain=False)
+    n = int(g[f'{case}_nrounds'])
+    assert len(seen) == n
+    for k, r in enumerate(seen):
+        lattice_tol = 1 if (case == 'rigid' and k > 0) else 1e-6
+        assert r['bboxes0'].shape == g[f'{case}_r{k}_bboxes0'].shape
+        np.testing.assert_allclose(r['bboxes0'], g[f'{case}_r{k}_bboxes0'], atol=lattice_tol)
+        np.testing.assert_allclose(r['bboxes1'], g[f'{case}_r{k}_bboxes1'], atol=lattice_tol)
+        assert [r['pad'], r['subpixel']] == g[f'{case}_r{k}_flags'].tolist()
+        want = g[f'{case}_r{k}_field1']
+        np.testing.assert_allclose(r['field1'], want, atol=1e-6 * max(1.0, np.abs(want).max()))
+    assert xy0.shape == g[f'{case}_xy0'].shape
+    np.testing.assert_allclose(xy0, g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g[f'{case}_xy1'], atol=1e-5)
+    np.testing.assert_allclose(wt, g[f'{case}_weight'], atol=1e-5)
