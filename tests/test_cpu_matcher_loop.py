@@ -168,3 +168,91 @@ def test_product_strip_loop_between_the_block_matches_vs_reference(monkeypatch, 
     assert xy0.shape == g[f'{case}_xy0'].shape
     np.testing.assert_allclose(xy0, g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g[f'{case}_xy1'], atol=1e-5)
     np.testing.assert_allclose(wt, g[f'{case}_weight'], atol=1e-5)
+
+
+def _section_script(rnd, bboxes0, bboxes1):
+    """block matches of a section pair as a closed form of the block centres and the round: a smooth field that shrinks from round to
+    round, hash-like confidences (some below the threshold) and a few outliers for the residue weights"""
+    b0 = np.asarray(bboxes0, dtype=np.float64); b1 = np.asarray(bboxes1, dtype=np.float64)
+    c0 = 0.5 * (b0[:, :2] + b0[:, 2:])
+    amp = (3.0, 0.8, 0.2)[min(rnd, 2)]
+    dx = amp * np.sin(c0[:, 1] / 260.0 + 0.3 + rnd) + 0.4 * amp * (c0[:, 0] / 1000.0)
+    dy = amp * np.cos(c0[:, 0] / 300.0 - rnd) - 0.3 * amp * (c0[:, 1] / 600.0)
+    h = np.abs(np.modf(np.sin(np.round(c0[:, 0]) * 12.9898 + np.round(c0[:, 1]) * 78.233 + 17.0 * rnd) * 43758.5453)[0])
+    conf = (0.2 + 0.8 * h).astype(np.float32)
+    dxy = np.stack((dx, dy), axis=-1)
+    dxy[h > 0.94] += np.array([7.0, -5.0])
+    p0, p1 = matcher.block_displacements_to_points(b0, b1, dxy[:, 0], dxy[:, 1])
+    return p0, p1, conf
+
+
+@pytest.mark.parametrize('locked', [True, False])
+def test_product_section_matcher_vs_oracle_with_scripted_blocks(monkeypatch, locked):
+    """SURVEY row a8 end to end on the CPU: matcher.section_matcher -- the region-aware distributor ('cartesian_region' with a boundary
+    distance) inside the loop, on meshes that move from round to round -- against oracle/region_ref.section_match, the restatement of the
+    reference's loop, with the same scripted block matches on both sides and the product's device steps solved through the oracle's
+    assembly: the same blocks every round (the oracle takes the lattice phase from the product's blocks, like the distributor test),
+    the same field of section 1 after every relaxation, the same final matches and weights.  With section 0 locked and with both
+    sections free (the floating system of matcher.py:551: the oracle takes the Jacobi-Krylov limit, the stand-in here the
+    minimum-norm-in-diag(A) solution of the same singular system)."""
+    from scipy.spatial import Delaunay                                       # noqa: F401  (used by the helper module)
+    import test_gpu_renderer as tgr
+    from oracle import region_ref
+    rng = np.random.default_rng(17)
+    (v0, t0, v1, t1), (M0, M1), _ = tgr._island_pair(rng)
+    for M in (M0, M1):
+        M.material_ids = None; M.material_names = {}; M.material_area_constraints = {}
+    M0.locked = locked
+
+    def solve_like_the_oracle(self, **kwargs):
+        if any(m.locked for m in self.meshes):
+            return _exact_optimize_linear(self, **kwargs)
+        # a floating pair: the fixed point a Jacobi-preconditioned Krylov method reaches on the singular system
+        refs = [_mirror(m) for m in self.meshes]
+        at = {m.uid: k for k, m in enumerate(self.meshes)}
+        links = []
+        for lk in self.links:
+            rl = fem_ref.RefLink(refs[at[lk.uids[0]]], refs[at[lk.uids[1]]], lk._tid0, lk._tid1, lk._B0, lk._B1, weight=lk._weight, strain=lk.strain)
+            rl.residue_weight = lk._residue_weight
+            links.append(rl)
+        A, b, _ = fem_ref.linear_system(refs, links, kwargs.get('stiffness_lambda', self._stiffness_lambda), -1.0, const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING,
+                                        const.MESH_GEAR_MOVING)
+        dd = region_ref._solve_jacobi_krylov_limit(A, np.asarray(b, dtype=np.float64))
+        self.last_solve = dict(iters=None, relres=0.0)
+        offs, _ = fem_ref.index_offsets(refs)
+        for m, o in zip(self.meshes, offs):
+            if o >= 0:
+                m.set_field(dd[o:o + 2 * m.num_vertices].reshape(-1, 2), gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING))
+        return (float(np.linalg.norm(b)), float(np.linalg.norm(A @ dd - b)))
+    rounds = []
+
+    def scripted_product(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+        rounds.append(dict(bboxes0=np.array(bboxes0), bboxes1=np.array(bboxes1), pad=bool(kw.get('pad')), subpixel=bool(kw.get('subpixel'))))
+        return _section_script(len(rounds) - 1, bboxes0, bboxes1)
+    monkeypatch.setattr(matcher, 'bboxes_mesh_renderer_matcher', scripted_product)
+    monkeypatch.setattr(optimizer.SLM, 'optimize_linear', solve_like_the_oracle)
+    monkeypatch.setattr(Mesh, 'stiffness_matrix_local_normalized', _exact_local_stiffness)
+    monkeypatch.setattr(optimizer, 'solve', _exact_solve)
+    kw = dict(spacings=[150, 60], conf_thresh=0.3, residue_len=3.0, min_boundary_distance=12, stiffness_lambda=0.5)
+    trace = []
+    xy0, xy1, wt, _ = matcher.section_matcher(M0, M1, _NoImage(), _NoImage(), compute_strain=False, stiffness_multiplier_threshold=0, trace=trace, **kw)
+    assert xy0 is not None and len(trace) == 2 and trace[1]['blocks'] > 80
+    r0 = fem_ref.RefMesh(v0, t0, uid=0, locked=locked); r1 = fem_ref.RefMesh(v1, t1, uid=1)
+    orounds = []
+
+    def scripted_oracle(rnd, a, b, bb0, bb1, pad, subpixel, tol):
+        orounds.append(dict(bboxes0=np.array(bb0), bboxes1=np.array(bb1), pad=bool(pad), subpixel=bool(subpixel)))
+        return _section_script(rnd, bb0, bb1)
+    otrace = []
+    ex0, ex1, ewt, _ = region_ref.section_match(r0, r1, None, None, compute_strain=False, anchor_rounds=[t['bboxes0'] for t in trace], trace=otrace, res=None,
+                                                block_matcher=scripted_oracle, **kw)
+    assert len(orounds) == len(rounds) == 2
+    for g, e, tg, te in zip(rounds, orounds, trace, otrace):
+        np.testing.assert_allclose(g['bboxes0'], e['bboxes0'], atol=1e-6)
+        np.testing.assert_allclose(g['bboxes1'], e['bboxes1'], atol=1e-6)
+        assert (g['pad'], g['subpixel']) == (e['pad'], e['subpixel'])
+        if 'field1' in te:
+            np.testing.assert_allclose(tg['field1'], te['field1'], atol=1e-6 * max(1.0, np.abs(te['field1']).max()))
+    assert xy0.shape == ex0.shape and xy0.shape[0] > 60
+    np.testing.assert_allclose(xy0, ex0, atol=1e-5); np.testing.assert_allclose(xy1, ex1, atol=1e-5)
+    np.testing.assert_allclose(wt, ewt, atol=1e-5)
