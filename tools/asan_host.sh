@@ -23,5 +23,5 @@ hipcc --offload-arch=gfx950 $OUT/*.o -shared -L/opt/rocm/lib -lrocfft -ldl -Wl,-
 cd $ROOT
 export FEABAS_HIP_LIB=$OUT/libfeabas_hip.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
        TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0
-python -m pytest tests/test_cpu_host.py tests/test_cpu_region_distributor.py -q -p no:cacheprovider 2>&1 | tail -3 &&
+python -m pytest tests/test_cpu_host.py tests/test_cpu_region_distributor.py tests/test_cpu_matcher_loop.py -q -p no:cacheprovider 2>&1 | tail -3 &&
 python tools/fuzz_host_entries.py 1 ${1:-60} 2>&1 | grep -v "^$" | tail -40
