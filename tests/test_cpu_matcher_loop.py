@@ -256,3 +256,16 @@ def test_product_section_matcher_vs_oracle_with_scripted_blocks(monkeypatch, loc
     assert xy0.shape == ex0.shape and xy0.shape[0] > 60
     np.testing.assert_allclose(xy0, ex0, atol=1e-5); np.testing.assert_allclose(xy1, ex1, atol=1e-5)
     np.testing.assert_allclose(wt, ewt, atol=1e-5)
+
+
+def test_product_global_translation_matcher_vs_reference(monkeypatch):
+    """matcher.global_translation_matcher's host logic (matcher.py:138-221: the second shot on ~6 sub-blocks when the whole-image
+    confidence is low, block extents grown to a common size and slid inside the image, offsets, the best block taking over) against the
+    reference's outputs (golden G3) with the correlation itself -- the device step -- served by the oracle's xcorr_fft (pinned by G1)"""
+    from oracle import ncc_ref
+    monkeypatch.setattr(matcher, 'xcorr_fft', lambda a, b, **kw: ncc_ref.xcorr_fft(a, b, conf_mode=kw.get('conf_mode', const.FFT_CONF_MIRROR),
+                                                                                    pad=kw.get('pad', True), subpixel=kw.get('subpixel', False)))
+    g = load_golden('g3_global.npz')
+    np.testing.assert_allclose(matcher.global_translation_matcher(g['d0'], g['d1'], conf_thresh=0.3), g['plain'], atol=1e-4)
+    np.testing.assert_allclose(matcher.global_translation_matcher(g['d0'], g['e1'], conf_thresh=2.0), g['fallback'], atol=1e-4)
+    np.testing.assert_allclose(matcher.global_translation_matcher(g['d0'], g['f1'], conf_thresh=2.0), g['unequal'], atol=1e-4)
