@@ -1314,8 +1314,25 @@ def g27_mesh_gears():
     np.savez_compressed(os.path.join(OUT, 'g27_mesh_gears.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G28
+def g28_affine_cascade():
+    """SLM.optimize_affine_cascade (optimizer.py:1128-1189) on a multi-tile system: the order in which the free tiles are placed (most
+    link weight to placed tiles first), the fit of each onto its placed neighbours through the links (rigid / clipped / affine), the
+    gears it reads and writes, a tile no link reaches (tests/golden/walks.py::g28_cascade_walk drives reference and product alike)"""
+    from walks import g28_cascade_walk
+    g15 = dict(np.load(os.path.join(OUT, 'g15_translation.npz')))
+    out = {}
+
+    def record(tag, ms, modified):
+        out[f'{tag}_modified'] = np.bool_(modified)
+        for g_, gear in (('f', const.MESH_GEAR_FIXED), ('m', const.MESH_GEAR_MOVING)):
+            out[f'{tag}_{g_}'] = np.stack([m.vertices_w_offset(gear=gear) for m in ms])
+    g28_cascade_walk(Mesh, optimizer.Link, optimizer.SLM, const, g15, record)
+    np.savez_compressed(os.path.join(OUT, 'g28_affine_cascade.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -38,3 +38,36 @@ def g27_mesh_walk(mesh_cls, consts, record):
     m.set_translation((2.0, 2.0), gear=(M, M)); record('s16_translation_in_place', m)
     m.set_affine(A2, gear=(F, F)); record('s17_affine_in_place', m)
     return m, v, tri, mask
+
+
+def g28_cascade_walk(mesh_cls, link_cls, slm_cls, consts, g15, record):
+    """SLM.optimize_affine_cascade on the six-tile system of fixture G15, every tile given a rotation + scale + offset of its own at the
+    start gear so that the per-mesh fits are not translations: rigid (svd_clip (1, 1)), clipped (0.9, 1.1), free affine (None), from the
+    INITIAL and from the FIXED gear, with one and with two locked tiles, and a tile no link reaches"""
+    F, M, I = consts.MESH_GEAR_FIXED, consts.MESH_GEAR_MOVING, consts.MESH_GEAR_INITIAL
+
+    def system(locked=(0,), drop_links=()):
+        ms = [mesh_cls(g15['v'], g15['t'], uid=k) for k in range(6)]
+        for k, m in enumerate(ms):
+            th = 0.02 * (k - 2.5); sc = 1.0 + 0.01 * (k - 3)
+            A = np.array([[sc * np.cos(th), sc * np.sin(th), 0.0], [-sc * np.sin(th), sc * np.cos(th) * (1.0 + 0.005 * k), 0.0], [3.0 * k - 7.0, 2.0 - 1.5 * k, 1.0]])
+            m.apply_affine(A, F)
+        for k in locked:
+            ms[k].lock()
+        links = []
+        for k in range(7):
+            if k in drop_links:
+                continue
+            a, b = (int(x) for x in g15[f'l{k}_ab'])
+            links.append(link_cls(ms[a], ms[b], g15[f'l{k}_tid0'], g15[f'l{k}_tid1'], g15[f'l{k}_B0'], g15[f'l{k}_B1'], weight=g15[f'l{k}_w']))
+        return ms, slm_cls(ms, links=links)
+    for tag, kw, sysargs in (('rigid_f2m', dict(start_gear=F, target_gear=M, svd_clip=(1, 1)), {}),
+                             ('clip_f2m', dict(start_gear=F, target_gear=M, svd_clip=(0.9, 1.1)), {}),
+                             ('affine_f2m', dict(start_gear=F, target_gear=M, svd_clip=None), {}),
+                             ('rigid_i2f', dict(start_gear=I, target_gear=F, svd_clip=(1, 1)), {}),
+                             ('affine_two_locked', dict(start_gear=F, target_gear=M, svd_clip=None), dict(locked=(0, 5))),
+                             ('unreached', dict(start_gear=F, target_gear=M, svd_clip=(1, 1)), dict(drop_links=(1, 6))),
+                             ('in_place', dict(target_gear=M, svd_clip=(1, 1)), {})):
+        ms, slm = system(**sysargs)
+        modified = slm.optimize_affine_cascade(**kw)
+        record(tag, ms, modified)

@@ -1155,3 +1155,26 @@ def test_stitching_matcher_batch_queues_without_a_gpu(monkeypatch, threads):
     calls3 = _install_fake_device(monkeypatch, ok)
     out = fm.stitching_matcher_batch(pairs[:5], batch=2, threads=threads, sigma=2.5, coarse_downsample=0.5)
     assert len(out) == 5 and all(o[0] is not None for o in out) and calls3[0] == 3
+
+
+def test_g28_affine_cascade_vs_reference():
+    """SLM.optimize_affine_cascade (optimizer.py:1128-1189, host code in the reference and here) on the six-tile system of G15, every tile
+    rotated / scaled / offset at the start gear: the order in which tiles are placed, each tile's rigid / clipped / affine fit onto its placed
+    neighbours, the gears read and written, two locked tiles, a tile no link reaches -- golden G28, the walk of tests/golden/walks.py"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from walks import g28_cascade_walk
+    from feabas_amd.mesh import Mesh
+    from feabas_amd.optimizer import Link, SLM
+    import feabas_amd.constant as const
+    g = load_golden('g28_affine_cascade.npz')
+    seen = []
+
+    def record(tag, ms, modified):
+        seen.append(tag)
+        assert bool(modified) == bool(g[f'{tag}_modified'])
+        for k, gear in (('f', const.MESH_GEAR_FIXED), ('m', const.MESH_GEAR_MOVING)):
+            np.testing.assert_allclose(np.stack([m.vertices_w_offset(gear) for m in ms]), g[f'{tag}_{k}'], atol=1e-8, err_msg=f'{tag} {k}')
+    g28_cascade_walk(Mesh, Link, SLM, const, dict(load_golden('g15_translation.npz')), record)
+    assert len(seen) == 7
