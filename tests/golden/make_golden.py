@@ -1331,8 +1331,36 @@ def g28_affine_cascade():
     np.savez_compressed(os.path.join(OUT, 'g28_affine_cascade.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G29
+def g29_cartesian_grid():
+    """Mesh.from_bbox(cartesian=True) (mesh.py:403-435): the node grid it hands to the mesher (vertices and the grid segments; the
+    triangles come from `triangle`, which is absent) for a sweep of boxes, mesh sizes and minimum block counts -- Mesh.from_PSLG is
+    replaced by a recorder"""
+    cases = []
+    for (W, H) in ((510, 4096), (4096, 510), (120, 1536), (122, 1526), (255, 2048), (60, 60), (700, 90), (301, 299), (64, 1000)):
+        for ms in (25.0, 40.0, 75.0, 200.0):
+            for mnb in (1, 2, 3):
+                cases.append((0, 0, W, H, ms, mnb))
+    cases += [(-7.5, 3.25, 500.25, 911.0, 60.0, 2), (10, 20, 30, 40, 100.0, 1)]
+    real = Mesh.from_PSLG
+    got = {}
+
+    def recorder(cls, vertices, segments, **kwargs):
+        got['v'] = np.array(vertices); got['seg'] = np.array(segments); got['mesh_size'] = float(kwargs['mesh_size'])
+        return None
+    out = dict(cases=np.array(cases, dtype=np.float64))
+    try:
+        Mesh.from_PSLG = classmethod(recorder)
+        for k, (x0, y0, x1, y1, ms, mnb) in enumerate(cases):
+            Mesh.from_bbox((x0, y0, x1, y1), cartesian=True, mesh_size=ms, min_num_blocks=int(mnb))
+            out[f'c{k}_v'] = got['v']; out[f'c{k}_nseg'] = np.int64(got['seg'].shape[0]); out[f'c{k}_ms'] = np.float64(got['mesh_size'])
+    finally:
+        Mesh.from_PSLG = real
+    np.savez_compressed(os.path.join(OUT, 'g29_cartesian_grid.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

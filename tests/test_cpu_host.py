@@ -1178,3 +1178,24 @@ def test_g28_affine_cascade_vs_reference():
             np.testing.assert_allclose(np.stack([m.vertices_w_offset(gear) for m in ms]), g[f'{tag}_{k}'], atol=1e-8, err_msg=f'{tag} {k}')
     g28_cascade_walk(Mesh, Link, SLM, const, dict(load_golden('g15_translation.npz')), record)
     assert len(seen) == 7
+
+
+def test_g29_cartesian_node_grid_vs_reference():
+    """Mesh.from_bbox(cartesian=True): the node grid (mesh.py:403-435: block counts with the aspect-ratio rule, linspace - 0.5) the
+    reference hands to its mesher, for 110 boxes / mesh sizes / minimum block counts (golden G29); the library's grid_counts agrees.
+    (The triangles are the mesher's -- `triangle`, absent -- so only the product's two-triangles-per-cell topology is checked.)"""
+    from feabas_amd.mesh import Mesh
+    import feabas_amd.constant as const
+    g = load_golden('g29_cartesian_grid.npz')
+    lib = _lib.load()
+    for k, (x0, y0, x1, y1, ms, mnb) in enumerate(g['cases']):
+        m = Mesh.from_bbox((x0, y0, x1, y1), cartesian=True, mesh_size=float(ms), min_num_blocks=int(mnb))
+        want = g[f'c{k}_v']
+        np.testing.assert_allclose(m.vertices_w_offset(const.MESH_GEAR_INITIAL), want, atol=1e-10, err_msg=str(k))
+        nx, ny = m.grid_xs.size, m.grid_ys.size
+        assert nx * ny == want.shape[0] and int(g[f'c{k}_nseg']) == (nx - 1) * ny + nx * (ny - 1)
+        assert m.num_triangles == 2 * (nx - 1) * (ny - 1)
+        if x0 == 0 and y0 == 0:
+            cx, cy = ctypes.c_int(), ctypes.c_int()
+            assert lib.fb_debug_grid_counts(int(y1), int(x1), float(ms), int(mnb), ctypes.byref(cx), ctypes.byref(cy)) == 0
+            assert (cx.value, cy.value) == (nx, ny)
