@@ -1359,8 +1359,64 @@ def g29_cartesian_grid():
     np.savez_compressed(os.path.join(OUT, 'g29_cartesian_grid.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G30
+def g30_seeded_loop():
+    """iterative_xcorr_matcher_w_mesh WITH initial matches (matcher.py:552-563: a link from the matches, optimize_affine_cascade at the
+    FIXED gear, rigid anneal of the MOVING gear, one relaxation) and then the loop of G23: section 1 comes in its own frame (rotated by
+    0.02 rad and shifted by (40, -25) px), the initial matches say so, the scripted block matches refine.  Meshes of G23.  Solves made
+    converged and deterministic like there (the seed's `precondition='smoothed_aggregation'` asks for pyamg, absent: dropped -- the fixed
+    point does not depend on the preconditioner)."""
+    g23 = np.load(os.path.join(OUT, 'g23_matcher_loop.npz'))
+    va, ta, vb, tb = g23['v0'], g23['t0'], g23['v1'], g23['t1']
+    real_match = matcher.bboxes_mesh_renderer_matcher
+    real_ol = optimizer.SLM.optimize_linear
+
+    def converged(self, **kw):
+        kw['tol'] = 1e-11; kw['tolerated_perturbation'] = None; kw['callback_settings'] = {'chances': None, 'eval_step': 10}
+        kw['check_converge'] = True
+        kw.pop('precondition', None)
+        return real_ol(self, **kw)
+    rng = np.random.default_rng(3030)
+    th = 0.02
+    Rm = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+    shift = np.array([40.0, -25.0])
+    vb1 = vb @ Rm + shift                                  # section 1 in its own frame
+    p = np.stack((rng.uniform(100, 1400, 60), rng.uniform(100, 1000, 60)), axis=-1)
+    ixy0 = p + rng.normal(0, 0.8, p.shape)
+    ixy1 = p @ Rm + shift
+    iw = rng.uniform(0.3, 1.0, 60)
+    out = dict(v1=vb1, ixy0=ixy0, ixy1=ixy1, iw=iw, spacings=np.array([400.0, 100.0]))
+    try:
+        optimizer.SLM.optimize_linear = converged
+        m0 = Mesh(va, ta, uid=0)
+        m0.lock()
+        m1 = Mesh(vb1.copy(), tb, uid=1)
+        rounds = []
+
+        def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+            k = len(rounds)
+            rounds.append(dict(bboxes0=np.array(bboxes0), bboxes1=np.array(bboxes1), pad=bool(kw.get('pad')), subpixel=bool(kw.get('subpixel')),
+                               moving1=mesh1.vertices_w_offset(gear=const.MESH_GEAR_MOVING), fixed1=mesh1.vertices_w_offset(gear=const.MESH_GEAR_FIXED)))
+            return scripted_block_matches(k, bboxes0, bboxes1, 5.0)
+        matcher.bboxes_mesh_renderer_matcher = scripted
+        xy0, xy1, wt, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, None, None, spacings=np.array([400.0, 100.0]), distributor='cartesian_bbox',
+                                                                      conf_thresh=0.3, residue_len=3.0, residue_mode='huber', compute_strain=False,
+                                                                      stiffness_lambda=0.5, min_num_blocks=2, initial_matches=common.Match(ixy0, ixy1, iw))
+        out['nrounds'] = np.int64(len(rounds))
+        for k, r in enumerate(rounds):
+            for key in ('bboxes0', 'bboxes1', 'moving1', 'fixed1'):
+                out[f'r{k}_{key}'] = r[key]
+            out[f'r{k}_flags'] = np.array([r['pad'], r['subpixel']])
+        out['xy0'] = xy0; out['xy1'] = xy1; out['weight'] = np.asarray(wt)
+        out['moving1_final'] = m1.vertices_w_offset(gear=const.MESH_GEAR_MOVING)
+    finally:
+        matcher.bboxes_mesh_renderer_matcher = real_match
+        optimizer.SLM.optimize_linear = real_ol
+    np.savez_compressed(os.path.join(OUT, 'g30_seeded_loop.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -269,3 +269,42 @@ def test_product_global_translation_matcher_vs_reference(monkeypatch):
     np.testing.assert_allclose(matcher.global_translation_matcher(g['d0'], g['d1'], conf_thresh=0.3), g['plain'], atol=1e-4)
     np.testing.assert_allclose(matcher.global_translation_matcher(g['d0'], g['e1'], conf_thresh=2.0), g['fallback'], atol=1e-4)
     np.testing.assert_allclose(matcher.global_translation_matcher(g['d0'], g['f1'], conf_thresh=2.0), g['unequal'], atol=1e-4)
+
+
+def test_product_matcher_loop_with_initial_matches_vs_reference(monkeypatch):
+    """the seeded start of the loop (matcher.py:552-563: a link from the initial matches, optimize_affine_cascade at the FIXED gear, rigid
+    anneal of the MOVING gear, one relaxation) and the rounds after it against the reference (golden G30): section 1 arrives rotated and
+    shifted in its own frame; both gears of mesh 1 going into every round, blocks, flags, final matches and weights"""
+    from collections import namedtuple
+    from test_oracle_golden import _g23_scripted_block_matches as script
+    g = load_golden('g30_seeded_loop.npz')
+    g23 = load_golden('g23_matcher_loop.npz')
+    m0 = Mesh(g23['v0'], g23['t0'], uid=0)
+    m0.lock()
+    m1 = Mesh(g['v1'].copy(), g23['t1'], uid=1)
+    seen = []
+
+    def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+        k = len(seen)
+        seen.append(dict(bboxes0=np.array(bboxes0), bboxes1=np.array(bboxes1), pad=bool(kw.get('pad')), subpixel=bool(kw.get('subpixel')),
+                         moving1=mesh1.vertices_w_offset(const.MESH_GEAR_MOVING), fixed1=mesh1.vertices_w_offset(const.MESH_GEAR_FIXED)))
+        return script(k, bboxes0, bboxes1, 5.0)
+    monkeypatch.setattr(matcher, 'bboxes_mesh_renderer_matcher', scripted)
+    monkeypatch.setattr(optimizer.SLM, 'optimize_linear', _exact_optimize_linear)
+    monkeypatch.setattr(Mesh, 'stiffness_matrix_local_normalized', _exact_local_stiffness)
+    monkeypatch.setattr(optimizer, 'solve', _exact_solve)
+    Match = namedtuple('Match', ('xy0', 'xy1', 'weight'))
+    xy0, xy1, wt, _ = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, _NoImage(), _NoImage(), spacings=g['spacings'], distributor='cartesian_bbox', conf_thresh=0.3,
+                                                             residue_len=3.0, residue_mode='huber', compute_strain=False, stiffness_lambda=0.5, min_num_blocks=2,
+                                                             initial_matches=Match(g['ixy0'], g['ixy1'], g['iw']))
+    assert len(seen) == int(g['nrounds'])
+    for k, r in enumerate(seen):
+        np.testing.assert_allclose(r['fixed1'], g[f'r{k}_fixed1'], atol=1e-6)
+        np.testing.assert_allclose(r['moving1'], g[f'r{k}_moving1'], atol=1e-6)
+        np.testing.assert_allclose(r['bboxes0'], g[f'r{k}_bboxes0'], atol=1e-6)
+        np.testing.assert_allclose(r['bboxes1'], g[f'r{k}_bboxes1'], atol=1e-6)
+        assert [r['pad'], r['subpixel']] == g[f'r{k}_flags'].tolist()
+    np.testing.assert_allclose(m1.vertices_w_offset(const.MESH_GEAR_MOVING), g['moving1_final'], atol=1e-6)
+    assert xy0.shape == g['xy0'].shape
+    np.testing.assert_allclose(xy0, g['xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g['xy1'], atol=1e-5)
+    np.testing.assert_allclose(wt, g['weight'], atol=1e-5)
