@@ -1415,8 +1415,63 @@ def g30_seeded_loop():
     np.savez_compressed(os.path.join(OUT, 'g30_seeded_loop.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G31
+G31_CASES = {
+    'decay': dict(spacings=[600.0, 150.0, 40.0], residue_mode='huber', residue_len=3.0, link_weight_decay=0.5),
+    'enlarge': dict(spacings=[30.0, 12.0], residue_mode='huber', residue_len=3.0, allow_enlarge=True),
+    'skip_shrink': dict(spacings=[600.0, 300.0, 150.0, 75.0], residue_mode='threshold', residue_len=4.0, max_spacing_skip=1, shrink_factor=0.7, pad=False),
+    'dwell': dict(spacings=[200.0, 60.0], residue_mode='huber', residue_len=2.0, allow_dwell=1, subpixel=True, min_num_blocks=3),
+}
+
+
+def g31_loop_options():
+    """the loop of G23 under the keywords that change its course: link_weight_decay (the links of earlier rounds stay, decayed),
+    allow_enlarge (a first round whose displacement outruns the largest spacing is repeated with larger blocks), max_spacing_skip with a
+    shrink factor and fixed padding, allow_dwell with a fixed sub-pixel flag and three blocks minimum"""
+    import json
+    g23 = np.load(os.path.join(OUT, 'g23_matcher_loop.npz'))
+    va, ta, vb, tb = g23['v0'], g23['t0'], g23['v1'], g23['t1']
+    real_match = matcher.bboxes_mesh_renderer_matcher
+    real_ol = optimizer.SLM.optimize_linear
+
+    def converged(self, **kw):
+        kw['tol'] = 1e-11; kw['tolerated_perturbation'] = None; kw['callback_settings'] = {'chances': None, 'eval_step': 10}
+        kw['check_converge'] = True
+        return real_ol(self, **kw)
+    out = dict(cases=np.array(json.dumps(G31_CASES)))
+    try:
+        optimizer.SLM.optimize_linear = converged
+        for name, cs in G31_CASES.items():
+            m0 = Mesh(va, ta, uid=0)
+            m0.apply_translation((2.0, -1.0), const.MESH_GEAR_FIXED)
+            m0.lock()
+            m1 = Mesh(vb.copy(), tb, uid=1)
+            rounds = []
+
+            def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+                k = len(rounds)
+                rounds.append(dict(bboxes0=np.array(bboxes0), bboxes1=np.array(bboxes1), pad=bool(kw.get('pad')), subpixel=bool(kw.get('subpixel')),
+                                   field1=mesh1.vertices_w_offset(gear=const.MESH_GEAR_MOVING) - mesh1.vertices_w_offset(gear=const.MESH_GEAR_INITIAL)))
+                return scripted_block_matches(k, bboxes0, bboxes1, 7.0)
+            matcher.bboxes_mesh_renderer_matcher = scripted
+            kw = dict(cs); kw['spacings'] = np.array(cs['spacings'])
+            xy0, xy1, wt, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, None, None, distributor='cartesian_bbox', conf_thresh=0.3, compute_strain=False,
+                                                                          stiffness_lambda=0.5, **kw)
+            out[f'{name}_nrounds'] = np.int64(len(rounds))
+            for k, r in enumerate(rounds):
+                for key in ('bboxes0', 'bboxes1', 'field1'):
+                    out[f'{name}_r{k}_{key}'] = r[key]
+                out[f'{name}_r{k}_flags'] = np.array([r['pad'], r['subpixel']])
+            out[f'{name}_xy0'] = xy0; out[f'{name}_xy1'] = xy1; out[f'{name}_weight'] = np.asarray(wt)
+            out[f'{name}_field1_final'] = m1.vertices_w_offset(gear=const.MESH_GEAR_MOVING) - m1.vertices_w_offset(gear=const.MESH_GEAR_INITIAL)
+    finally:
+        matcher.bboxes_mesh_renderer_matcher = real_match
+        optimizer.SLM.optimize_linear = real_ol
+    np.savez_compressed(os.path.join(OUT, 'g31_loop_options.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

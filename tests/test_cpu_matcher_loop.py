@@ -308,3 +308,46 @@ def test_product_matcher_loop_with_initial_matches_vs_reference(monkeypatch):
     assert xy0.shape == g['xy0'].shape
     np.testing.assert_allclose(xy0, g['xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g['xy1'], atol=1e-5)
     np.testing.assert_allclose(wt, g['weight'], atol=1e-5)
+
+
+@pytest.mark.parametrize('case', ['decay', 'enlarge', 'skip_shrink', 'dwell'])
+def test_product_matcher_loop_options_vs_reference(monkeypatch, case):
+    """the keywords that change the course of the loop, against the reference (golden G31): link_weight_decay (earlier rounds' links stay,
+    decayed), allow_enlarge (a first round whose displacement outruns the largest spacing is repeated with larger blocks before anything
+    is linked), max_spacing_skip with a shrink factor and fixed padding, allow_dwell with a fixed sub-pixel flag and three blocks minimum"""
+    import json
+    from test_oracle_golden import _g23_scripted_block_matches as script
+    g = load_golden('g31_loop_options.npz')
+    g23 = load_golden('g23_matcher_loop.npz')
+    kw = json.loads(str(g['cases']))[case]
+    m0 = Mesh(g23['v0'], g23['t0'], uid=0)
+    m0.apply_translation((2.0, -1.0), const.MESH_GEAR_FIXED)
+    m0.lock()
+    m1 = Mesh(g23['v1'].copy(), g23['t1'], uid=1)
+    seen = []
+
+    def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **k_):
+        k = len(seen)
+        seen.append(dict(bboxes0=np.array(bboxes0), bboxes1=np.array(bboxes1), pad=bool(k_.get('pad')), subpixel=bool(k_.get('subpixel')),
+                         field1=mesh1.vertices_w_offset(const.MESH_GEAR_MOVING) - mesh1.vertices_w_offset(const.MESH_GEAR_INITIAL)))
+        return script(k, bboxes0, bboxes1, 7.0)
+    monkeypatch.setattr(matcher, 'bboxes_mesh_renderer_matcher', scripted)
+    monkeypatch.setattr(optimizer.SLM, 'optimize_linear', _exact_optimize_linear)
+    monkeypatch.setattr(Mesh, 'stiffness_matrix_local_normalized', _exact_local_stiffness)
+    monkeypatch.setattr(optimizer, 'solve', _exact_solve)
+    xy0, xy1, wt, _ = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, _NoImage(), _NoImage(), distributor='cartesian_bbox', conf_thresh=0.3, compute_strain=False,
+                                                             stiffness_lambda=0.5, **kw)
+    n = int(g[f'{case}_nrounds'])
+    assert len(seen) == n
+    for k, r in enumerate(seen):
+        assert r['bboxes0'].shape == g[f'{case}_r{k}_bboxes0'].shape, k
+        np.testing.assert_allclose(r['bboxes0'], g[f'{case}_r{k}_bboxes0'], atol=1e-6)
+        np.testing.assert_allclose(r['bboxes1'], g[f'{case}_r{k}_bboxes1'], atol=1e-6)
+        assert [r['pad'], r['subpixel']] == g[f'{case}_r{k}_flags'].tolist(), k
+        want = g[f'{case}_r{k}_field1']
+        np.testing.assert_allclose(r['field1'], want, atol=1e-6 * max(1.0, np.abs(want).max()))
+    want = g[f'{case}_field1_final']
+    np.testing.assert_allclose(m1.vertices_w_offset(const.MESH_GEAR_MOVING) - m1.vertices_w_offset(const.MESH_GEAR_INITIAL), want, atol=1e-6 * max(1.0, np.abs(want).max()))
+    assert xy0.shape == g[f'{case}_xy0'].shape
+    np.testing.assert_allclose(xy0, g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g[f'{case}_xy1'], atol=1e-5)
+    np.testing.assert_allclose(wt, g[f'{case}_weight'], atol=1e-5)
