@@ -1470,8 +1470,64 @@ def g31_loop_options():
     np.savez_compressed(os.path.join(OUT, 'g31_loop_options.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G32
+G32_CASES = {
+    'online_huber': dict(online_anneal=True, max_newtonstep=4, tol=1e-8, residue_mode='huber', residue_len=2.0, stiffness_lambda=0.5),
+    'online_threshold': dict(online_anneal=True, max_newtonstep=3, tol=1e-6, residue_mode='threshold', residue_len=3.0, stiffness_lambda=1.0, crosslink_lambda=2.0),
+    'plain_steps': dict(_newton=True, max_newtonstep=3, tol=1e-7, stiffness_lambda=[2.0, 1.0, 0.5], crosslink_lambda=-1.0),
+    'rigid_anneal': dict(_newton=True, max_newtonstep=3, tol=1e-7, anneal_mode=2, residue_mode='huber', residue_len=[4.0, 1.5], stiffness_lambda=0.5),
+}
+
+
+def g32_inputs():
+    g23 = np.load(os.path.join(OUT, 'g23_matcher_loop.npz'))
+    rng = np.random.default_rng(3232)
+    p = np.stack((rng.uniform(60, 1500, 220), rng.uniform(60, 1080, 220)), axis=-1)
+    u = np.stack((5.0 * np.sin(p[:, 1] / 300.0) + 2.0 * (p[:, 0] / 1500.0), 4.0 * np.cos(p[:, 0] / 260.0)), axis=-1)
+    q = p + u + rng.normal(0, 0.2, p.shape)
+    out_ = rng.random(220) > 0.93
+    q[out_] += np.array([9.0, -6.0])
+    return g23['v0'], g23['t0'], g23['v1'], g23['t1'], p, q, rng.uniform(0.3, 1.0, 220)
+
+
+def g32_newton_driver():
+    """SLM.optimize_Newton_Raphson / optimize_elastic(online_anneal=True) (optimizer.py:1440-1555) as a DRIVER, on linear meshes: the
+    per-step ladders (tolerances, lambdas, residue lengths), the annealing of the resting shape from the STAGING gear with its
+    relax_higly_deformed, the residue re-weighting between steps, the cost floor and the early last step -- inner solves converged"""
+    import json
+    va, ta, vb, tb, p, q, w = g32_inputs()
+    real_ol = optimizer.SLM.optimize_linear
+
+    def converged(self, **kw):
+        kw['tol'] = 1e-12; kw['atol'] = 0.0; kw['maxiter'] = None
+        kw['tolerated_perturbation'] = None; kw['callback_settings'] = {'chances': None, 'eval_step': 10}
+        kw['check_converge'] = True
+        return real_ol(self, **kw)
+    out = dict(cases=np.array(json.dumps(G32_CASES)), xy0=p, xy1=q, w=w)
+    gears = dict(i=const.MESH_GEAR_INITIAL, f=const.MESH_GEAR_FIXED, m=const.MESH_GEAR_MOVING, s=const.MESH_GEAR_STAGING)
+    try:
+        optimizer.SLM.optimize_linear = converged
+        for name, kw in G32_CASES.items():
+            m0 = Mesh(va, ta, uid=0)
+            m0.apply_translation((2.0, -1.0), const.MESH_GEAR_FIXED)
+            m0.lock()
+            m1 = Mesh(vb.copy(), tb, uid=1)
+            opt = optimizer.SLM([m0, m1], stiffness_lambda=0.7)
+            opt.add_link_from_coordinates(0, 1, p, q, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=w, check_duplicates=False)
+            kw_ = dict(kw)
+            cost = opt.optimize_Newton_Raphson(**kw_) if kw_.pop('_newton', False) else opt.optimize_elastic(**kw_)
+            out[f'{name}_cost'] = np.array([np.nan if c is None else c for c in cost], dtype=np.float64)
+            for g_, gear in gears.items():
+                out[f'{name}_{g_}'] = m1.vertices_w_offset(gear=gear)
+            lk = opt.links[0]
+            out[f'{name}_lw'] = np.asarray(lk.weight(use_mask=False), dtype=np.float64)
+    finally:
+        optimizer.SLM.optimize_linear = real_ol
+    np.savez_compressed(os.path.join(OUT, 'g32_newton_driver.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -351,3 +351,47 @@ def test_product_matcher_loop_options_vs_reference(monkeypatch, case):
     assert xy0.shape == g[f'{case}_xy0'].shape
     np.testing.assert_allclose(xy0, g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g[f'{case}_xy1'], atol=1e-5)
     np.testing.assert_allclose(wt, g[f'{case}_weight'], atol=1e-5)
+
+
+def _oracle_cost(self, stiffness_lambda, crosslink_lambda):
+    """SLM.cost (optimizer.py:1593-1601): ||lc rhs - ls stress|| of the system at the current gears, through the oracle's assembly"""
+    refs = [_mirror(m) for m in self.meshes]
+    at = {m.uid: k for k, m in enumerate(self.meshes)}
+    links = []
+    for lk in self.links:
+        rl = fem_ref.RefLink(refs[at[lk.uids[0]]], refs[at[lk.uids[1]]], lk._tid0, lk._tid1, lk._B0, lk._B1, weight=lk._weight, strain=lk.strain)
+        rl.residue_weight = lk._residue_weight
+        links.append(rl)
+    _, _, (K, stress, C, rhs, ls, lc) = fem_ref.linear_system(refs, links, stiffness_lambda, crosslink_lambda, const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING,
+                                                              const.MESH_GEAR_MOVING)
+    return float(np.linalg.norm(lc * rhs - ls * stress))
+
+
+@pytest.mark.parametrize('case', ['online_huber', 'online_threshold', 'plain_steps', 'rigid_anneal'])
+def test_product_newton_driver_vs_reference(monkeypatch, case):
+    """SLM.optimize_Newton_Raphson / optimize_elastic(online_anneal=True) as a DRIVER (optimizer.py:1440-1555) against the reference
+    (golden G32) on linear meshes: the per-step ladders of tolerances, lambdas and residue lengths, the resting shape annealed from the
+    STAGING gear (with relax_higly_deformed before it), the links re-weighted by their residues between the steps, the cost floor and the
+    early last step.  Host control flow of the product; the assembly, the cost and the inner solves -- the device steps -- through the
+    oracle (inner solves exact on both sides)."""
+    import json
+    g = load_golden('g32_newton_driver.npz')
+    g23 = load_golden('g23_matcher_loop.npz')
+    kw = dict(json.loads(str(g['cases']))[case])
+    m0 = Mesh(g23['v0'], g23['t0'], uid=0)
+    m0.apply_translation((2.0, -1.0), const.MESH_GEAR_FIXED)
+    m0.lock()
+    m1 = Mesh(g23['v1'].copy(), g23['t1'], uid=1)
+    monkeypatch.setattr(optimizer.SLM, 'optimize_linear', _exact_optimize_linear)
+    monkeypatch.setattr(optimizer.SLM, '_assemble', lambda self, *a, **k: None)
+    monkeypatch.setattr(optimizer.SLM, 'cost', _oracle_cost)
+    monkeypatch.setattr(Mesh, 'stiffness_matrix_local_normalized', _exact_local_stiffness)
+    monkeypatch.setattr(optimizer, 'solve', _exact_solve)
+    opt = optimizer.SLM([m0, m1], stiffness_lambda=0.7)
+    opt.add_link_from_coordinates(0, 1, g['xy0'], g['xy1'], gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=g['w'])
+    cost = opt.optimize_Newton_Raphson(**kw) if kw.pop('_newton', False) else opt.optimize_elastic(**kw)
+    np.testing.assert_allclose(cost[0], g[f'{case}_cost'][0], rtol=1e-7)
+    np.testing.assert_allclose(cost[1], g[f'{case}_cost'][1], rtol=1e-4, atol=1e-6 * g[f'{case}_cost'][0])
+    for k, gear in dict(i=const.MESH_GEAR_INITIAL, f=const.MESH_GEAR_FIXED, m=const.MESH_GEAR_MOVING, s=const.MESH_GEAR_STAGING).items():
+        np.testing.assert_allclose(m1.vertices_w_offset(gear), g[f'{case}_{k}'], atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(opt.links[0].weight(use_mask=False), g[f'{case}_lw'], atol=1e-6)
