@@ -395,3 +395,47 @@ def test_product_newton_driver_vs_reference(monkeypatch, case):
     for k, gear in dict(i=const.MESH_GEAR_INITIAL, f=const.MESH_GEAR_FIXED, m=const.MESH_GEAR_MOVING, s=const.MESH_GEAR_STAGING).items():
         np.testing.assert_allclose(m1.vertices_w_offset(gear), g[f'{case}_{k}'], atol=1e-6, err_msg=k)
     np.testing.assert_allclose(opt.links[0].weight(use_mask=False), g[f'{case}_lw'], atol=1e-6)
+
+
+def _g16_mesh(g):
+    return Mesh(g['v'], g['t'], stiffness_multiplier=g['mult'], moving_vertices=g['vmov'].copy(), moving_offset=g['moff'].copy(), uid=3)
+
+
+@pytest.mark.parametrize('which', ['ft', 'fv'])
+def test_product_relax_mesh_vs_reference(monkeypatch, which):
+    """optimizer.relax_mesh (optimizer.py:2110-2154) on the CPU against the reference's converged result (golden G16): the product's free-
+    vertex selection, the rigid re-alignment of the resting shape around the solve, the field applied to the free vertices only, the locked
+    mesh that is relaxed all the same -- with the masked assembly and the free-block solve through the oracle"""
+    g = load_golden('g16_relax.npz')
+    gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
+    monkeypatch.setattr(Mesh, 'stiffness_matrix_local_normalized', _exact_local_stiffness)
+    monkeypatch.setattr(optimizer, 'solve', _exact_solve)
+    m = _g16_mesh(g)
+    mod = optimizer.relax_mesh(m, free_triangles=g['free_tri'], gear=gear) if which == 'ft' else optimizer.relax_mesh(m, free_vertices=g['free_vtx'], gear=gear)
+    assert mod == bool(g[f'{which}_modified'])
+    moved = np.abs(g[f'{which}_vmov'] - g['vmov']).max()
+    np.testing.assert_allclose(m.vertices(gear[1]), g[f'{which}_vmov'], atol=1e-6 * moved)
+    np.testing.assert_array_equal(m.offset(gear[1]), g[f'{which}_moff'])
+    np.testing.assert_array_equal(m.vertices(gear[0]), g['v'])
+    m2 = _g16_mesh(g)
+    m2.lock()
+    assert optimizer.relax_mesh(m2, free_vertices=g['free_vtx'], gear=gear) and m2.locked
+    np.testing.assert_allclose(m2.vertices(gear[1]), g['fv_vmov'], atol=1e-6 * moved)
+    assert not optimizer.relax_mesh(m, gear=gear)
+    assert not optimizer.relax_mesh(m, free_triangles=np.zeros(g['t'].shape[0], dtype=bool), gear=gear)
+
+
+@pytest.mark.parametrize('name,kw', [('md_flip', dict(deform_cutoff=-1)), ('md_cut', dict(deform_cutoff=0.35)), ('md_iqr', dict(deform_cutoff=0.35, iqr=1.5))])
+def test_product_relax_most_deformed_vs_reference(monkeypatch, name, kw):
+    """relax_mesh_most_deformed (optimizer.py:2157-2190): the region the product frees (flipped triangles only / beyond the cutoff / capped by
+    the inter-quartile rule) and the relaxed field against the reference's converged result (golden G16) on the CPU"""
+    g = load_golden('g16_relax.npz')
+    gear = (const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)
+    monkeypatch.setattr(Mesh, 'stiffness_matrix_local_normalized', _exact_local_stiffness)
+    monkeypatch.setattr(optimizer, 'solve', _exact_solve)
+    m = _g16_mesh(g)
+    assert optimizer.relax_mesh_most_deformed(m, gear=gear, **kw) == bool(g[f'{name}_modified'])
+    np.testing.assert_allclose(m.vertices(gear[1]), g[f'{name}_vmov'], atol=1e-6 * np.abs(g[f'{name}_vmov'] - g['vmov']).max())
+    if name == 'md_flip':
+        assert (m.triangle_area_deform(gear) > 0).all()
+        assert not optimizer.relax_mesh_most_deformed(m, gear=gear, deform_cutoff=-1)
