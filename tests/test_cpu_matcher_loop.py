@@ -102,9 +102,11 @@ def test_product_matcher_loop_between_the_block_matches_vs_reference(monkeypatch
     def no_device_relaxation(*a, **k):
         raise AssertionError('relax_mesh needs the device: the fixture does not deform a triangle that far')
     monkeypatch.setattr(optimizer, 'relax_mesh', no_device_relaxation)
-    xy0, xy1, wt, _ = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, _NoImage(), _NoImage(), spacings=g[f'{case}_spacings'], distributor='cartesian_bbox',
-                                                             conf_thresh=0.3, residue_len=float(res_len), residue_mode='threshold' if thr else 'huber',
-                                                             stiffness_lambda=0.5, min_num_blocks=2, compute_strain=False)
+    monkeypatch.setattr(Mesh, 'stiffness_energy', lambda self, fields, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING): _oracle_energy(self, fields, gear))
+    xy0, xy1, wt, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, _NoImage(), _NoImage(), spacings=g[f'{case}_spacings'], distributor='cartesian_bbox',
+                                                                  conf_thresh=0.3, residue_len=float(res_len), residue_mode='threshold' if thr else 'huber',
+                                                                  stiffness_lambda=0.5, min_num_blocks=2, compute_strain=True)
+    np.testing.assert_allclose(strain, float(g[f'{case}_strain']), rtol=1e-5)
     n = int(g[f'{case}_nrounds'])
     assert len(seen) == n
     for k, r in enumerate(seen):
@@ -439,3 +441,30 @@ def test_product_relax_most_deformed_vs_reference(monkeypatch, name, kw):
     if name == 'md_flip':
         assert (m.triangle_area_deform(gear) > 0).all()
         assert not optimizer.relax_mesh_most_deformed(m, gear=gear, deform_cutoff=-1)
+
+
+def _oracle_energy(self, fields, gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING)):
+    """Mesh.stiffness_energy: x^T K x with the oracle's stiffness matrix of this mesh at `gear`"""
+    K, _ = _mirror(self).stiffness_matrix(gear=gear)
+    return [float(np.ravel(x) @ (K @ np.ravel(x))) for x in fields]
+
+
+def test_product_strain_of_matches_vs_reference(monkeypatch):
+    """matcher._strain_of_matches (matcher.py:752-777: the untouched pair brought together by a rigid affine cascade, relaxed once, strain =
+    sqrt(dv^T K dv / v0^T K v0) over the free mesh) on the CPU against the reference's chain (golden G13): the product's cascade, anneal,
+    gear handling and energy bookkeeping; the relaxation and the two energies through the oracle"""
+    g = load_golden('g13_strain.npz')
+    m0 = Mesh(g['st_v'], g['st_tri'], uid=0)
+    m0.apply_translation(g['st_t0'], const.MESH_GEAR_FIXED)
+    m0.lock()
+    m1 = Mesh(g['st_v'], g['st_tri'], uid=1)
+    lk = optimizer.Link(m0, m1, g['st_tid0'], g['st_tid1'], g['st_B0'], g['st_B1'], weight=g['st_w'])
+    xy0 = lk.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True)
+    xy1 = lk.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True)
+    monkeypatch.setattr(optimizer.SLM, 'optimize_linear', _exact_optimize_linear)
+    monkeypatch.setattr(Mesh, 'stiffness_energy', _oracle_energy)
+    strain = matcher._strain_of_matches(m0, m1, xy0, xy1, lk.weight(use_mask=False), 1.0)
+    np.testing.assert_allclose(m1.vertices(const.MESH_GEAR_FIXED), g['st_v_fixed'], atol=1e-8)
+    np.testing.assert_allclose(m1.offset(const.MESH_GEAR_FIXED), g['st_off_fixed'], atol=1e-8)
+    np.testing.assert_allclose(m1.vertices(const.MESH_GEAR_MOVING), g['st_v_moving'], atol=1e-6)
+    np.testing.assert_allclose(strain, float(g['st_strain']), rtol=1e-6)
