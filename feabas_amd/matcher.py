@@ -571,11 +571,14 @@ def bboxes_mesh_renderer_matcher(mesh0, mesh1, image_loader0, image_loader1, bbo
         edges = np.unique(np.round(np.concatenate(parts)).astype(np.int32))
     own = []
     renders = []
+    rwt = kwargs.get('render_weight_threshold', 0)
     for mesh, loader in ((mesh0, image_loader0), (mesh1, image_loader1)):
         if isinstance(loader, _rd.MeshRenderer):
             renders.append(loader)
         else:
-            r = _rd.MeshRenderer.from_mesh(mesh, image_loader=loader, affine_approx_tol=tol)
+            # renderer.py:59-61: only the triangles of materials that are rendered and weigh at least the threshold carry image
+            shown = mesh.triangle_mask_for_render(render_weight_threshold=rwt)
+            r = None if not shown.any() else _rd.MeshRenderer.from_mesh(mesh if shown.all() else mesh.submesh(shown), image_loader=loader, affine_approx_tol=tol)
             if r is None:
                 for o in own:
                     o.free()
@@ -659,9 +662,10 @@ class _PairRelaxation:
     """The spring-linked pair of a block matcher: the two meshes, the matches of the current round as their links, and the
     relaxation that follows every round (feabas/matcher.py:551-566, 717-742)."""
 
-    def __init__(self, mesh0, mesh1, stiffness_lambda, residue_mode, residue_len, link_weight_decay):
+    def __init__(self, mesh0, mesh1, stiffness_lambda, residue_mode, residue_len, link_weight_decay, render_weight_threshold=0):
         from . import optimizer
         self.meshes = (mesh0, mesh1)
+        self.render_weight_threshold = render_weight_threshold     # matches in triangles of materials that weigh no more are dropped (matcher.py:557, 719)
         self.linear = mesh0.is_linear and mesh1.is_linear
         self.slm = optimizer.SLM([mesh0, mesh1], stiffness_lambda=stiffness_lambda)
         self.residue_mode, self.residue_len, self.decay = residue_mode, residue_len, link_weight_decay
@@ -684,7 +688,8 @@ class _PairRelaxation:
             return
         xy0, xy1, weight = initial_matches[:3] if isinstance(initial_matches, (tuple, list)) else \
             (initial_matches.xy0, initial_matches.xy1, initial_matches.weight)
-        self.slm.add_link_from_coordinates(m0.uid, m1.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight)
+        self.slm.add_link_from_coordinates(m0.uid, m1.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight,
+                                           render_weight_threshold=self.render_weight_threshold)
         self.slm.optimize_affine_cascade(start_gear=const.MESH_GEAR_FIXED, target_gear=const.MESH_GEAR_FIXED, svd_clip=None)
         self.slm.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_CONNECTED_RIGID)
         self._solve(1e-6 if self.linear else 1e-4, 5)
@@ -699,7 +704,8 @@ class _PairRelaxation:
 
     def link(self, xy0, xy1, weight):
         m0, m1 = self.meshes
-        self.slm.add_link_from_coordinates(m0.uid, m1.uid, xy0, xy1, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), weight=weight)
+        self.slm.add_link_from_coordinates(m0.uid, m1.uid, xy0, xy1, gear=(const.MESH_GEAR_MOVING, const.MESH_GEAR_MOVING), weight=weight,
+                                           render_weight_threshold=self.render_weight_threshold)
         return len(self.slm.links)
 
     def relax(self, tol, more_rounds):
@@ -720,13 +726,14 @@ class _PairRelaxation:
         return self.slm.links
 
 
-def _strain_of_matches(mesh0, mesh1, xy0, xy1, weight, stiffness_lambda):
+def _strain_of_matches(mesh0, mesh1, xy0, xy1, weight, stiffness_lambda, render_weight_threshold=0):
     """matcher.py:752-777: how much elastic energy the matches ask of the pair, as a fraction of the energy of the shape itself:
     the untouched meshes, brought together rigidly (affine cascade clipped to rotations) and relaxed once; strain = sqrt of
     dv^T K dv / v0^T K v0 summed over the free (or softer) mesh(es).  The energies are evaluated on the device."""
     from . import optimizer
     slm = optimizer.SLM([mesh0, mesh1], stiffness_lambda=stiffness_lambda)
-    slm.add_link_from_coordinates(mesh0.uid, mesh1.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight)
+    slm.add_link_from_coordinates(mesh0.uid, mesh1.uid, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL), weight=weight,
+                                  render_weight_threshold=render_weight_threshold)
     slm.optimize_affine_cascade(start_gear=const.MESH_GEAR_INITIAL, target_gear=const.MESH_GEAR_FIXED, svd_clip=(1, 1))
     slm.anneal(gear=(const.MESH_GEAR_FIXED, const.MESH_GEAR_MOVING), mode=const.ANNEAL_COPY_EXACT)
     if mesh0.is_linear and mesh1.is_linear:
@@ -775,7 +782,8 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
             return failed
         spacings[spacings < 1] *= max(bbox[2] - bbox[0], bbox[3] - bbox[1])
     untouched = (mesh0.copy(), mesh1.copy()) if get('compute_strain', True) else None
-    pair = _PairRelaxation(mesh0, mesh1, get('stiffness_lambda', 1), get('residue_mode', 'huber'), residue_len, get('link_weight_decay', 0.0))
+    rwt = get('render_weight_threshold', 0)
+    pair = _PairRelaxation(mesh0, mesh1, get('stiffness_lambda', 1), get('residue_mode', 'huber'), residue_len, get('link_weight_decay', 0.0), rwt)
     pair.seed(get('initial_matches', None))
     plan = _RoundPlan(spacings, get('allow_enlarge', False), get('allow_dwell', 0), get('max_spacing_skip', 0), get('pad', None))
     images, borrowed = [], []
@@ -812,7 +820,7 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
             xy0, xy1, conf = bboxes_mesh_renderer_matcher(mesh0, mesh1, images[0], images[1], boxes0, boxes1, batch_size=get('batch_size', None),
                                                           pad=pad, subpixel=bool(last) if subpixel is None else subpixel, affine_approx_tol=tol_render,
                                                           sigma=get('sigma', 0.0), conf_mode=get('conf_mode', const.FFT_CONF_MIRROR),
-                                                          mask_range=get('mask_range', None))
+                                                          mask_range=get('mask_range', None), render_weight_threshold=rwt)
             good = conf > conf_thresh
             if not good.any():
                 if not linked_once:
@@ -846,7 +854,7 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
     xy0 = newest.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=True, combine=True)
     xy1 = newest.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=True, combine=True)
     weight = newest.weight(use_mask=True)
-    strain = DEFAULT_AVG_DEFORM if untouched is None else _strain_of_matches(untouched[0], untouched[1], xy0, xy1, weight, get('stiffness_lambda', 1))
+    strain = DEFAULT_AVG_DEFORM if untouched is None else _strain_of_matches(untouched[0], untouched[1], xy0, xy1, weight, get('stiffness_lambda', 1), rwt)
     return xy0, xy1, weight, strain
 
 

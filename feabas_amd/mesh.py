@@ -74,6 +74,18 @@ class Mesh:
         self.material_names = dict(kwargs.get('material_names', None) or {})
         # area_constraint of the named materials (material.py:22-26): < 1 marks a refinement region of the block distributor
         self.material_area_constraints = dict(kwargs.get('material_area_constraints', None) or {})
+        # render weight of every triangle's material (material.py:27-30, 50-54: 0 for a material that is not rendered): which triangles
+        # take part in block placement and rendering (triangle_mask_for_render) and where matches may land (tri_finder,
+        # mesh.py:2168-2170).  Given per triangle, or per named material (material_render_weights = {name: weight}); absent = all 1
+        rw = kwargs.get('tri_render_weight', None)
+        mrw = kwargs.get('material_render_weights', None)
+        if rw is None and mrw and self.material_ids is not None:
+            rw = np.ones(self.triangles.shape[0], dtype=np.float32)
+            for name, wgt in mrw.items():
+                if name in self.material_names:
+                    rw[self.material_ids == self.material_names[name]] = wgt
+        self.tri_render_weight = None if rw is None else np.ascontiguousarray(rw, dtype=np.float32)
+        self.material_render_weights = dict(mrw or {})
         self.resolution = kwargs.get('resolution', 4.0)
         self.locked = kwargs.get('locked', False)
         self.soft_factor = kwargs.get('soft_factor', 1.0)
@@ -215,7 +227,8 @@ class Mesh:
                   tri_matmult=getattr(self, 'tri_matmult', None) if self.tri_model is not None else self.material_multiplier,
                   material_multiplier=self.material_multiplier, resolution=self.resolution,
                   locked=self.locked, soft_factor=self.soft_factor, uid=self.uid,
-                  material_ids=self.material_ids, material_names=self.material_names, material_area_constraints=self.material_area_constraints)
+                  material_ids=self.material_ids, material_names=self.material_names, material_area_constraints=self.material_area_constraints,
+                  tri_render_weight=getattr(self, 'tri_render_weight', None), material_render_weights=getattr(self, 'material_render_weights', None))
         if self.tri_func is not None:
             kw.update(tri_func=self.tri_func, stiffness_funcs=self.stiffness_funcs, func_matmult=self.func_matmult)
         kw.update(override)
@@ -405,7 +418,11 @@ class Mesh:
         thr = kwargs.get('stiffness_multiplier_threshold', 0)
         return ~(self.material_stiffness_multiplier() < thr)
 
-    def triangle_mask_for_render(self, **kwargs):          # mesh.py:1847-1859; render weights default to 1 (default material table)
+    def weight_multiplier_for_render(self):                # mesh.py:1836-1843
+        wt = getattr(self, 'tri_render_weight', None)
+        return np.ones(self.num_triangles, dtype=np.float32) if wt is None else np.asarray(wt, dtype=np.float32)
+
+    def triangle_mask_for_render(self, **kwargs):          # mesh.py:1847-1859: materials that are not rendered (weight 0) or weigh less than the threshold
         thr = kwargs.get('render_weight_threshold', 0)
         wt = getattr(self, 'tri_render_weight', None)
         if wt is None:
@@ -440,11 +457,10 @@ class Mesh:
             kw.update(tri_func=self.tri_func[sel], stiffness_funcs=self.stiffness_funcs, func_matmult=self.func_matmult)
         if self.material_ids is not None:
             kw.update(material_ids=self.material_ids[sel], material_names=self.material_names, material_area_constraints=self.material_area_constraints)
-        kw.update(kwargs)
-        m = Mesh(self._vertices[const.MESH_GEAR_INITIAL][vidx], inv.reshape(-1, 3), **kw)
         if getattr(self, 'tri_render_weight', None) is not None:
-            m.tri_render_weight = np.asarray(self.tri_render_weight)[sel]
-        return m
+            kw.update(tri_render_weight=np.asarray(self.tri_render_weight)[sel], material_render_weights=self.material_render_weights)
+        kw.update(kwargs)
+        return Mesh(self._vertices[const.MESH_GEAR_INITIAL][vidx], inv.reshape(-1, 3), **kw)
 
     def divide_disconnected_mesh(self, **kwargs):          # mesh.py:689-704
         n, lab = self.connected_triangles()
@@ -539,10 +555,20 @@ class Mesh:
             modifier[sel] = self.func_matmult[k] * f(J[sel])
         return self.stiffness_multiplier * modifier
 
-    def tri_finder(self, pts, gear=None):
+    def tri_finder(self, pts, gear=None, render_weight_threshold=0, **kwargs):
         """point -> triangle id (-1 outside).  The reference goes through
         matplotlib's trapezoid-map finder per connected region (mesh.py:2080-2188);
-        a single finder over the whole mesh covers the non-overlapping meshes used here."""
+        a single finder over the whole mesh covers the non-overlapping meshes used here.
+        render_weight_threshold > 0: a point in a triangle whose material weighs no more than that counts as outside
+        (mesh.py:2168-2170 -- what keeps matches out of soft / wrinkled regions, optimizer.py:59)."""
+        tid = self._tri_finder(pts, gear)
+        if render_weight_threshold > 0 and getattr(self, 'tri_render_weight', None) is not None:
+            tid = np.array(tid, dtype=np.int32)
+            hit = tid >= 0
+            tid[hit] = np.where(self.tri_render_weight[tid[hit]] <= render_weight_threshold, -1, tid[hit])
+        return tid
+
+    def _tri_finder(self, pts, gear=None):
         from matplotlib.tri import Triangulation
         gear = self._current_gear if gear is None else gear
         if gear == const.MESH_GEAR_INITIAL and getattr(self, 'grid_xs', None) is not None:
@@ -573,7 +599,7 @@ class Mesh:
     def cart2bary(self, xy, gear, tid=None, **kwargs):     # mesh.py:2191-2217
         xy = np.atleast_2d(xy)
         if tid is None:
-            tid = self.tri_finder(xy, gear=gear)
+            tid = self.tri_finder(xy, gear=gear, render_weight_threshold=kwargs.get('render_weight_threshold', 0))
         inside = tid >= 0
         if not np.any(inside):
             return tid, np.full((tid.size, 3), np.nan, dtype=np.float32)

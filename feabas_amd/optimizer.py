@@ -54,7 +54,10 @@ class Link:
         xy1 = np.asarray(xy1)
         if xy0.size == 0:
             return None, None
-        tid0, B0 = mesh0.cart2bary(xy0, gear[0], tid=None)
+        # (optimizer.py:59: matches in triangles of a material that weighs no more than 0.1 in rendering -- soft, split, wrinkled
+        # regions of the default material table -- are dropped unless the caller asks otherwise)
+        rwt = kwargs.pop('render_weight_threshold', 0.1)
+        tid0, B0 = mesh0.cart2bary(xy0, gear[0], tid=None, render_weight_threshold=rwt)
         in0 = tid0 >= 0
         if not np.any(in0):
             return None, None
@@ -62,7 +65,7 @@ class Link:
             tid0, B0, xy1 = tid0[in0], B0[in0], xy1[in0]
             if isinstance(weight, np.ndarray):
                 weight = weight[in0]
-        tid1, B1 = mesh1.cart2bary(xy1, gear[1], tid=None)
+        tid1, B1 = mesh1.cart2bary(xy1, gear[1], tid=None, render_weight_threshold=rwt)
         in1 = tid1 >= 0
         if not np.any(in1):
             return None, None
@@ -71,7 +74,6 @@ class Link:
             if isinstance(weight, np.ndarray):
                 weight = weight[in1]
             in0[in0] = in1
-        kwargs.pop('render_weight_threshold', None)
         kwargs.pop('check_duplicates', None)
         return cls(mesh0, mesh1, tid0, tid1, B0, B1, weight=weight, **kwargs), in0
 

@@ -1526,8 +1526,74 @@ def g32_newton_driver():
     np.savez_compressed(os.path.join(OUT, 'g32_newton_driver.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G33
+def g33_render_weights():
+    """render weights of materials in the matcher (material.py:27-30, mesh.py:1836-1859, 2168-2170, optimizer.py:59): mesh 1 of G23 with a
+    band of a material that weighs 1e-3 in rendering (like the soft / wrinkle entries of the default material table).  (a) the masks and
+    per-triangle weights; (b) Link.from_coordinates with its default threshold 0.1, with 0 and with 0.5e-3: which matches survive; (c) the
+    loop of G23 with render_weight_threshold = 0.1: matches that land in the band are dropped round after round."""
+    g23 = np.load(os.path.join(OUT, 'g23_matcher_loop.npz'))
+    va, ta, vb, tb = g23['v0'], g23['t0'], g23['v1'], g23['t1']
+    ctr = vb[tb].mean(axis=1)
+    mids = np.where((ctr[:, 0] > 600) & (ctr[:, 0] < 900), 5, 0).astype(np.int16)
+    tab = {'default': dict(material.MATERIAL_DEFAULT), 'soft_look': {'uid': 5, 'render_weight': 1.0e-3},
+           'hidden': {'uid': 6, 'render': False}}
+    mids[(ctr[:, 1] > 1000) & (ctr[:, 0] < 300)] = 6
+
+    def mesh1():
+        return Mesh(vb.copy(), tb.copy(), material_table=material.MaterialTable(table=tab), material_ids=mids.copy(), uid=1)
+    m1 = mesh1()
+    out = dict(t1=np.asarray(m1.triangles), mids=np.asarray(m1._material_ids, dtype=np.int32))
+    out['weights'] = m1.weight_multiplier_for_render()
+    for thr in (0.0, 0.1, 1.0e-3, 0.5e-3):
+        # (a fresh mesh per threshold: the reference caches the first mask a mesh computes, whatever threshold later calls name)
+        out[f'mask_{thr}'] = mesh1().triangle_mask_for_render(render_weight_threshold=thr)
+    rng = np.random.default_rng(3333)
+    p = np.stack((rng.uniform(30, 1500, 300), rng.uniform(30, 1100, 300)), axis=-1)
+    q = p + rng.normal(0, 1.0, p.shape)
+    w = rng.uniform(0.2, 1.0, 300)
+    out.update(lp=p, lq=q, lw=w)
+    m0 = Mesh(va, ta, uid=0)
+    for tag, kw in (('default', {}), ('zero', dict(render_weight_threshold=0)), ('low', dict(render_weight_threshold=0.5e-3))):
+        lk, mask = optimizer.Link.from_coordinates(m0, m1, p, q, weight=w, **kw)
+        out[f'link_{tag}_mask'] = mask
+        out[f'link_{tag}_xy1'] = lk.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True)
+    real_match = matcher.bboxes_mesh_renderer_matcher
+    real_ol = optimizer.SLM.optimize_linear
+
+    def converged(self, **kw):
+        kw['tol'] = 1e-11; kw['tolerated_perturbation'] = None; kw['callback_settings'] = {'chances': None, 'eval_step': 10}
+        kw['check_converge'] = True
+        return real_ol(self, **kw)
+    try:
+        optimizer.SLM.optimize_linear = converged
+        m0 = Mesh(va, ta, uid=0)
+        m0.apply_translation((2.0, -1.0), const.MESH_GEAR_FIXED)
+        m0.lock()
+        m1 = mesh1()
+        rounds = []
+
+        def scripted(mesh0, mesh1_, ld0, ld1, bboxes0, bboxes1, **kw):
+            k = len(rounds)
+            rounds.append(dict(bboxes0=np.array(bboxes0), rwt=float(kw.get('render_weight_threshold', -1)),
+                               field1=mesh1_.vertices_w_offset(gear=const.MESH_GEAR_MOVING) - mesh1_.vertices_w_offset(gear=const.MESH_GEAR_INITIAL)))
+            return scripted_block_matches(k, bboxes0, bboxes1, 9.0)
+        matcher.bboxes_mesh_renderer_matcher = scripted
+        xy0, xy1, wt, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, None, None, spacings=np.array([400.0, 100.0]), distributor='cartesian_bbox',
+                                                                      conf_thresh=0.3, residue_len=3.0, residue_mode='huber', compute_strain=False,
+                                                                      stiffness_lambda=0.5, min_num_blocks=2, render_weight_threshold=0.1)
+        out['nrounds'] = np.int64(len(rounds))
+        for k, r in enumerate(rounds):
+            out[f'r{k}_bboxes0'] = r['bboxes0']; out[f'r{k}_field1'] = r['field1']; out[f'r{k}_rwt'] = np.float64(r['rwt'])
+        out['xy0'] = xy0; out['xy1'] = xy1; out['weight'] = np.asarray(wt)
+    finally:
+        matcher.bboxes_mesh_renderer_matcher = real_match
+        optimizer.SLM.optimize_linear = real_ol
+    np.savez_compressed(os.path.join(OUT, 'g33_render_weights.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver, g33_render_weights):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

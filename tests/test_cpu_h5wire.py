@@ -270,3 +270,32 @@ def test_mesh_file_keeps_the_named_materials(tmp_path):
         t3 = json.loads(h5wire.numpy_to_str_ascii(f['material_table']))
     assert 'hold' not in t3 and 'default' in t3
     np.testing.assert_array_equal(Mesh.from_h5(fn3).tri_matmult, M.tri_matmult.astype(np.float32))
+
+
+def test_mesh_file_keeps_the_render_weights(tmp_path):
+    """the render weight of every named material (material.py:27-30, 50-54: `render: false` = weight 0) survives save -> load: the render
+    masks by threshold and the per-triangle weights -- what decides where blocks are placed, what is rendered and where matches may land
+    (mesh.py:1836-1859, 2168-2170) -- are the same afterwards"""
+    M0 = Mesh.from_bbox((0, 0, 300, 200), cartesian=True, mesh_size=25)
+    c = M0.vertices(const.MESH_GEAR_INITIAL)[M0.triangles].mean(axis=1)
+    ids = np.zeros(M0.num_triangles, dtype=np.int32)
+    ids[c[:, 0] < 80] = 3
+    ids[c[:, 0] > 220] = 7
+    names = {'default': 0, 'soft': 3, 'hidden': 7}
+    M = Mesh(M0.vertices(const.MESH_GEAR_INITIAL), M0.triangles, uid=2, material_ids=ids, material_names=names,
+             material_render_weights={'soft': 1.0e-6, 'hidden': 0.0})
+    fn = str(tmp_path / 'weights.h5')
+    M.save_to_h5(fn)
+    with h5wire.H5File(fn) as f:
+        table = json.loads(h5wire.numpy_to_str_ascii(f['material_table']))
+    assert table['soft']['render'] is True and table['soft']['render_weight'] == pytest.approx(1.0e-6) and table['hidden']['render'] is False
+    assert table['default']['render_weight'] == 1.0
+    N = Mesh.from_h5(fn)
+    np.testing.assert_array_equal(N.weight_multiplier_for_render(), M.weight_multiplier_for_render())
+    for thr in (0.0, 0.1, 1.0e-6):
+        np.testing.assert_array_equal(N.triangle_mask_for_render(render_weight_threshold=thr), M.triangle_mask_for_render(render_weight_threshold=thr))
+    assert N.triangle_mask_for_render(render_weight_threshold=0.1).sum() == (ids == 0).sum()
+    assert N.triangle_mask_for_render().sum() == (ids != 7).sum()
+    # a mesh without weighted materials writes and reads plain weights
+    M0.save_to_h5(str(tmp_path / 'plain.h5'))
+    assert Mesh.from_h5(str(tmp_path / 'plain.h5')).tri_render_weight is None

@@ -468,3 +468,58 @@ def test_product_strain_of_matches_vs_reference(monkeypatch):
     np.testing.assert_allclose(m1.offset(const.MESH_GEAR_FIXED), g['st_off_fixed'], atol=1e-8)
     np.testing.assert_allclose(m1.vertices(const.MESH_GEAR_MOVING), g['st_v_moving'], atol=1e-6)
     np.testing.assert_allclose(strain, float(g['st_strain']), rtol=1e-6)
+
+
+def test_product_render_weights_vs_reference(monkeypatch):
+    """render weights of materials (material.py:27-30; mesh.py:1836-1859, 2168-2170; optimizer.py:59) against the reference (golden G33):
+    mesh 1 carries a band of a material that weighs 1e-3 in rendering (like soft / wrinkled tissue in the default material table) and a
+    corner that is not rendered at all.  The per-triangle weights and the render masks by threshold; which matches Link.from_coordinates
+    keeps with its default threshold 0.1, with 0 and with 5e-4; and the matcher loop with render_weight_threshold = 0.1, where the
+    matches that land in the band are dropped round after round (no final match in it)."""
+    from test_oracle_golden import _g23_scripted_block_matches as script
+    g = load_golden('g33_render_weights.npz')
+    g23 = load_golden('g23_matcher_loop.npz')
+
+    def mesh1():
+        return Mesh(g23['v1'].copy(), g['t1'], uid=1, material_ids=g['mids'], material_names={'default': 0, 'soft_look': 5, 'hidden': 6},
+                    material_render_weights={'soft_look': 1.0e-3, 'hidden': 0.0})
+    m1 = mesh1()
+    np.testing.assert_array_equal(m1.weight_multiplier_for_render(), g['weights'])
+    for thr in (0.0, 0.1, 1.0e-3, 0.5e-3):
+        np.testing.assert_array_equal(m1.triangle_mask_for_render(render_weight_threshold=thr), g[f'mask_{thr}'])
+    sub = m1.submesh(m1.triangle_mask_for_render(render_weight_threshold=0.1))
+    assert sub.num_triangles == int(g['mask_0.1'].sum()) and np.all(sub.weight_multiplier_for_render() == 1.0)
+    assert np.array_equal(m1.copy().weight_multiplier_for_render(), g['weights'])
+    m0 = Mesh(g23['v0'], g23['t0'], uid=0)
+    for tag, kw in (('default', {}), ('zero', dict(render_weight_threshold=0)), ('low', dict(render_weight_threshold=0.5e-3))):
+        lk, mask = optimizer.Link.from_coordinates(m0, m1, g['lp'], g['lq'], weight=g['lw'], **kw)
+        np.testing.assert_array_equal(mask, g[f'link_{tag}_mask'])
+        np.testing.assert_allclose(lk.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True), g[f'link_{tag}_xy1'], atol=1e-9)
+    m0 = Mesh(g23['v0'], g23['t0'], uid=0)
+    m0.apply_translation((2.0, -1.0), const.MESH_GEAR_FIXED)
+    m0.lock()
+    m1 = mesh1()
+    seen = []
+
+    def scripted(mesh0, mesh1_, ld0, ld1, bboxes0, bboxes1, **kw):
+        k = len(seen)
+        seen.append(dict(bboxes0=np.array(bboxes0), rwt=float(kw.get('render_weight_threshold', -1)),
+                         field1=mesh1_.vertices_w_offset(const.MESH_GEAR_MOVING) - mesh1_.vertices_w_offset(const.MESH_GEAR_INITIAL)))
+        return script(k, bboxes0, bboxes1, 9.0)
+    monkeypatch.setattr(matcher, 'bboxes_mesh_renderer_matcher', scripted)
+    monkeypatch.setattr(optimizer.SLM, 'optimize_linear', _exact_optimize_linear)
+    monkeypatch.setattr(Mesh, 'stiffness_matrix_local_normalized', _exact_local_stiffness)
+    monkeypatch.setattr(optimizer, 'solve', _exact_solve)
+    xy0, xy1, wt, _ = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, _NoImage(), _NoImage(), spacings=np.array([400.0, 100.0]), distributor='cartesian_bbox',
+                                                             conf_thresh=0.3, residue_len=3.0, residue_mode='huber', compute_strain=False, stiffness_lambda=0.5,
+                                                             min_num_blocks=2, render_weight_threshold=0.1)
+    assert len(seen) == int(g['nrounds'])
+    for k, r in enumerate(seen):
+        assert r['rwt'] == float(g[f'r{k}_rwt']) == 0.1                      # the block matcher is told the threshold too (renderer.py:59)
+        np.testing.assert_allclose(r['bboxes0'], g[f'r{k}_bboxes0'], atol=1e-6)
+        want = g[f'r{k}_field1']
+        np.testing.assert_allclose(r['field1'], want, atol=1e-6 * max(1.0, np.abs(want).max()))
+    assert xy0.shape == g['xy0'].shape
+    np.testing.assert_allclose(xy0, g['xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g['xy1'], atol=1e-5)
+    np.testing.assert_allclose(wt, g['weight'], atol=1e-5)
+    assert not np.any((xy1[:, 0] > 620) & (xy1[:, 0] < 880))
