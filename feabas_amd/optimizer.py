@@ -209,14 +209,31 @@ class SLM:
         return True
 
     def add_link_from_coordinates(self, uid0, uid1, xy0, xy1, gear=(const.MESH_GEAR_INITIAL, const.MESH_GEAR_INITIAL),
-                                  weight=None, **kwargs):
-        """optimizer.py:637-701 for two whole meshes addressed by uid."""
-        lut = {m.uid: m for m in self.meshes}
-        link, mask = Link.from_coordinates(lut[float(uid0)], lut[float(uid1)], xy0, xy1, gear=gear, weight=weight, **kwargs)
-        if link is None:
+                                  weight=None, submesh_exclusive=True, check_duplicates=True, **kwargs):
+        """optimizer.py:637-684: matches given by coordinates, between the meshes that carry the two uids -- or, for the uid of a mesh
+        that has been cut into its connected parts, its parts: the matches are dealt to the part pairs that hold them (every match
+        once with submesh_exclusive).  A link whose ``name`` is loaded already is skipped (check_duplicates); a uid the system does not
+        know adds nothing.  Other keywords go to Link.from_coordinates (render_weight_threshold, strain, name)."""
+        if check_duplicates and ('name' in kwargs) and any(lk.name == kwargs['name'] for lk in self.links):
             return False
-        self.links.append(link)
-        return True
+        side0, _ = self.select_mesh_from_uid(uid0)
+        side1, _ = self.select_mesh_from_uid(uid1)
+        if len(side0) == 0 or len(side1) == 0:
+            return False
+        xy0, xy1 = np.asarray(xy0), np.asarray(xy1)
+        added = False
+        for m0 in side0:
+            for m1 in side1:
+                link, took = Link.from_coordinates(m0, m1, xy0, xy1, gear=gear, weight=weight, **dict(kwargs))
+                if link is None:
+                    continue
+                self.links.append(link)
+                added = True
+                if submesh_exclusive:
+                    xy0, xy1 = xy0[~took], xy1[~took]
+                    if isinstance(weight, np.ndarray):
+                        weight = weight[~took]
+        return added
 
     # ------------------------------------------------------------------ sub-meshes (optimizer.py:688-754, 1778-1858)
     def select_mesh_from_uid(self, uid):

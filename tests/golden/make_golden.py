@@ -1592,8 +1592,40 @@ def g33_render_weights():
     np.savez_compressed(os.path.join(OUT, 'g33_render_weights.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G34
+def g34_links_to_divided_meshes():
+    """SLM.add_link_from_coordinates (optimizer.py:637-684) AFTER a mesh has been divided into its connected parts: a link addressed to the
+    parent uid is dealt to the parts that hold its matches (every match once with submesh_exclusive, else wherever it lands), a link whose
+    name is already loaded is skipped (check_duplicates), a uid the system does not know adds nothing.  Meshes and matches of G26."""
+    (v0, t0), (v1, t1), (v2, t2), pts, d2 = g26_inputs()
+    out = {}
+    m0 = Mesh(v0, t0, uid=0); m0.lock()
+    m1 = Mesh(v1, t1, uid=1)
+    m2 = Mesh(v2, t2, uid=2)
+    opt = optimizer.SLM([m0, m1, m2])
+    out['divided'] = np.bool_(opt.divide_disconnected_submeshes())
+    out['mesh_uids'] = np.array([m.uid for m in opt.meshes], dtype=np.float64)
+    res = []
+    res.append(opt.add_link_from_coordinates(0, 2, pts['02'][0], pts['02'][1], weight=pts['02'][2], name='a'))
+    res.append(opt.add_link_from_coordinates(1, 2, pts['12'][0], pts['12'][1], weight=pts['12'][2], name='b', submesh_exclusive=False))
+    res.append(opt.add_link_from_coordinates(0, 2, pts['02'][0], pts['02'][1], weight=pts['02'][2], name='a'))                    # loaded already
+    res.append(opt.add_link_from_coordinates(0, 2, pts['02'][0], pts['02'][1], weight=pts['02'][2], name='a', check_duplicates=False))
+    res.append(opt.add_link_from_coordinates(0, 7, pts['02'][0], pts['02'][1], weight=pts['02'][2]))                              # no such mesh
+    res.append(opt.add_link_from_coordinates(2.1, 1, pts['12'][1], pts['12'][0], weight=pts['12'][2]))                            # a part addressed itself
+    out['added'] = np.array(res)
+    out['nlinks'] = np.int64(len(opt.links))
+    for name in ('02', '12'):
+        out[f'p{name}_xy0'], out[f'p{name}_xy1'], out[f'p{name}_w'] = pts[name]
+    for k, lk in enumerate(opt.links):
+        out[f'l{k}_uids'] = np.array(lk.uids, dtype=np.float64)
+        out[f'l{k}_xy0'] = lk.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True)
+        out[f'l{k}_xy1'] = lk.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True)
+        out[f'l{k}_w'] = np.asarray(lk.weight(use_mask=False), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'g34_links_to_divided_meshes.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver, g33_render_weights):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver, g33_render_weights, g34_links_to_divided_meshes):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

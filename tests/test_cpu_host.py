@@ -1199,3 +1199,31 @@ def test_g29_cartesian_node_grid_vs_reference():
             cx, cy = ctypes.c_int(), ctypes.c_int()
             assert lib.fb_debug_grid_counts(int(y1), int(x1), float(ms), int(mnb), ctypes.byref(cx), ctypes.byref(cy)) == 0
             assert (cx.value, cy.value) == (nx, ny)
+
+
+def test_g34_links_to_divided_meshes_vs_reference():
+    """SLM.add_link_from_coordinates (optimizer.py:637-684) after a mesh fell into its connected parts: a link addressed to the parent uid
+    is dealt to the parts that hold its matches (each match once with submesh_exclusive, else wherever it lands), a name that is loaded
+    already is skipped unless check_duplicates is off, an unknown uid adds nothing, a part can be addressed itself -- golden G34"""
+    from feabas_amd import optimizer
+    from feabas_amd.mesh import Mesh
+    import feabas_amd.constant as const
+    g = load_golden('g34_links_to_divided_meshes.npz')
+    g26 = load_golden('g26_slm_bookkeeping.npz')
+    m0 = Mesh(g26['v0'], g26['t0'], uid=0); m0.lock()
+    opt = optimizer.SLM([m0, Mesh(g26['v1'], g26['t1'], uid=1), Mesh(g26['v2'], g26['t2'], uid=2)])
+    assert opt.divide_disconnected_submeshes() == bool(g['divided'])
+    np.testing.assert_allclose([m.uid for m in opt.meshes], g['mesh_uids'], atol=1e-12)
+    p = {k: (g[f'p{k}_xy0'], g[f'p{k}_xy1'], g[f'p{k}_w']) for k in ('02', '12')}
+    res = [opt.add_link_from_coordinates(0, 2, *p['02'][:2], weight=p['02'][2], name='a'),
+           opt.add_link_from_coordinates(1, 2, *p['12'][:2], weight=p['12'][2], name='b', submesh_exclusive=False),
+           opt.add_link_from_coordinates(0, 2, *p['02'][:2], weight=p['02'][2], name='a'),
+           opt.add_link_from_coordinates(0, 2, *p['02'][:2], weight=p['02'][2], name='a', check_duplicates=False),
+           opt.add_link_from_coordinates(0, 7, *p['02'][:2], weight=p['02'][2]),
+           opt.add_link_from_coordinates(2.1, 1, p['12'][1], p['12'][0], weight=p['12'][2])]
+    assert res == g['added'].tolist() and len(opt.links) == int(g['nlinks'])
+    for k, lk in enumerate(opt.links):
+        np.testing.assert_allclose(lk.uids, g[f'l{k}_uids'], atol=1e-12)
+        np.testing.assert_allclose(lk.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True), g[f'l{k}_xy0'], atol=1e-9)
+        np.testing.assert_allclose(lk.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True), g[f'l{k}_xy1'], atol=1e-9)
+        np.testing.assert_allclose(lk.weight(use_mask=False), g[f'l{k}_w'], atol=1e-7)
