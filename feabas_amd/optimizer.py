@@ -369,6 +369,25 @@ class SLM:
         n, labels = csgraph.connected_components(self.linkage_adjacency(), directed=False, return_labels=True)
         return labels, n
 
+    def flag_outcasts(self):
+        """optimizer.py:1604-1625 (what the aligner asks before it optimises a window, aligner.py:700): with several link-connected
+        subsystems, the meshes that are not connected to a locked mesh -- or, when nothing is locked and nothing was flagged before,
+        those outside the largest subsystem -- are outcasts; the flag is kept on the mesh (``Mesh.is_outcast``).  One subsystem: the
+        flags as they stand."""
+        before = [bool(getattr(m, 'is_outcast', False)) for m in self.meshes]
+        labels, n = self.connected_subsystems
+        if n == 1:
+            return before
+        locks = np.asarray(self.lock_flags, dtype=bool)
+        if np.any(before) or np.any(locks):
+            outcasts = ~np.isin(labels, labels[locks])
+        else:
+            u, cnt = np.unique(labels, return_counts=True)
+            outcasts = labels != u[np.argmax(cnt)]
+        for m, flag in zip(self.meshes, outcasts):
+            m.is_outcast = bool(flag)
+        return outcasts
+
     def match_residues(self, gear=const.MESH_GEAR_MOVING, use_mask=False, quantile=0.75):
         """optimizer.py:1758-1774."""
         dis = []

@@ -1624,8 +1624,22 @@ def g34_links_to_divided_meshes():
     np.savez_compressed(os.path.join(OUT, 'g34_links_to_divided_meshes.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G35
+def g35_outcasts():
+    """SLM.flag_outcasts (optimizer.py:1604-1625): the meshes the aligner leaves out of a window (aligner.py:700)"""
+    from walks import g35_outcast_walk
+    g15 = dict(np.load(os.path.join(OUT, 'g15_translation.npz')))
+    out = {}
+
+    def record(tag, flags, ms):
+        out[tag] = np.asarray(flags, dtype=bool)
+        out[tag + '_kept'] = np.array([bool(m.is_outcast) for m in ms])
+    g35_outcast_walk(Mesh, optimizer.Link, optimizer.SLM, g15, record)
+    np.savez_compressed(os.path.join(OUT, 'g35_outcasts.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver, g33_render_weights, g34_links_to_divided_meshes):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver, g33_render_weights, g34_links_to_divided_meshes, g35_outcasts):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

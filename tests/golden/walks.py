@@ -71,3 +71,25 @@ def g28_cascade_walk(mesh_cls, link_cls, slm_cls, consts, g15, record):
         ms, slm = system(**sysargs)
         modified = slm.optimize_affine_cascade(**kw)
         record(tag, ms, modified)
+
+
+def g35_outcast_walk(mesh_cls, link_cls, slm_cls, g15, record):
+    """SLM.flag_outcasts on the six tiles of G15 with different link sets and locks: one subsystem; two with a locked tile; two without any
+    lock (the minority is cast out); a second call after a tile was flagged; flags kept on the meshes"""
+    def system(keep, locked=()):
+        ms = [mesh_cls(g15['v'], g15['t'], uid=k) for k in range(6)]
+        for k in locked:
+            ms[k].lock()
+        links = []
+        for k in keep:
+            a, b = (int(x) for x in g15[f'l{k}_ab'])
+            links.append(link_cls(ms[a], ms[b], g15[f'l{k}_tid0'], g15[f'l{k}_tid1'], g15[f'l{k}_B0'], g15[f'l{k}_B1'], weight=g15[f'l{k}_w']))
+        return ms, slm_cls(ms, links=links)
+    # links of G15: 0:(0,1) 1:(1,2) 2:(0,3) 3:(3,4) 4:(4,5) 5:(1,4) 6:(2,5)
+    for tag, keep, locked in (('one', range(7), (0,)), ('two_locked', (0, 1, 4), (0,)), ('two_free', (0, 1, 4), ()), ('three_free', (0, 3), ()),
+                              ('two_locks', (0, 4), (0, 5))):
+        ms, slm = system(keep, locked)
+        first = slm.flag_outcasts()
+        record(tag, first, ms)
+        second = slm.flag_outcasts()
+        record(tag + '_again', second, ms)

@@ -1227,3 +1227,24 @@ def test_g34_links_to_divided_meshes_vs_reference():
         np.testing.assert_allclose(lk.xy0(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True), g[f'l{k}_xy0'], atol=1e-9)
         np.testing.assert_allclose(lk.xy1(gear=const.MESH_GEAR_INITIAL, use_mask=False, combine=True), g[f'l{k}_xy1'], atol=1e-9)
         np.testing.assert_allclose(lk.weight(use_mask=False), g[f'l{k}_w'], atol=1e-7)
+
+
+def test_g35_flag_outcasts_vs_reference():
+    """SLM.flag_outcasts (optimizer.py:1604-1625: the meshes the aligner leaves out of a window, aligner.py:700) against golden G35: one
+    subsystem, two subsystems with a locked tile, without any lock (the minority is cast out), with locks in two subsystems, and a second
+    call on the flagged meshes (the reference then casts out everything that is not tied to a lock -- reproduced as it is)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from walks import g35_outcast_walk
+    from feabas_amd.mesh import Mesh
+    from feabas_amd.optimizer import Link, SLM
+    g = load_golden('g35_outcasts.npz')
+    seen = []
+
+    def record(tag, flags, ms):
+        seen.append(tag)
+        np.testing.assert_array_equal(np.asarray(flags, dtype=bool), g[tag], err_msg=tag)
+        np.testing.assert_array_equal([bool(getattr(m, 'is_outcast', False)) for m in ms], g[tag + '_kept'], err_msg=tag)
+    g35_outcast_walk(Mesh, Link, SLM, dict(load_golden('g15_translation.npz')), record)
+    assert len(seen) == 10
