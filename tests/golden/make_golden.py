@@ -1638,8 +1638,71 @@ def g35_outcasts():
     np.savez_compressed(os.path.join(OUT, 'g35_outcasts.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G36
+G36_CASES = {
+    'late_silence': dict(spacings=[400.0, 100.0, 40.0], silent_from=2),       # the last round finds nothing confident: the links of round 1 stand
+    'early_silence': dict(spacings=[400.0, 100.0], silent_from=0),            # the first round finds nothing: no result
+    'apart': dict(spacings=[400.0, 100.0], silent_from=99, shift1=(5000.0, 0.0)),   # the meshes do not overlap
+    'tiny_motion': dict(spacings=[400.0, 100.0], silent_from=99, amp=0.004),  # displacements below 0.1 px: linked, never relaxed
+}
+
+
+def g36_loop_exits():
+    """the ways out of the loop (matcher.py:592-598, 671-679, 719-724, 744-751): a round without a confident block after earlier rounds
+    linked (break: the earlier links are the result) or before anything was linked (no result), meshes that do not overlap, and matches
+    so small that no relaxation is run (max_dis <= 0.1)"""
+    import json
+    g23 = np.load(os.path.join(OUT, 'g23_matcher_loop.npz'))
+    va, ta, vb, tb = g23['v0'], g23['t0'], g23['v1'], g23['t1']
+    real_match = matcher.bboxes_mesh_renderer_matcher
+    real_ol = optimizer.SLM.optimize_linear
+    solves = []
+
+    def converged(self, **kw):
+        solves.append(1)
+        kw['tol'] = 1e-11; kw['tolerated_perturbation'] = None; kw['callback_settings'] = {'chances': None, 'eval_step': 10}
+        kw['check_converge'] = True
+        return real_ol(self, **kw)
+    out = dict(cases=np.array(json.dumps(G36_CASES)))
+    try:
+        optimizer.SLM.optimize_linear = converged
+        for name, cs in G36_CASES.items():
+            m0 = Mesh(va, ta, uid=0)
+            m0.lock()
+            m1 = Mesh(vb.copy() + np.array(cs.get('shift1', (0.0, 0.0))), tb, uid=1)
+            rounds = []
+            del solves[:]
+
+            def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+                k = len(rounds)
+                rounds.append(np.array(bboxes0))
+                xy0, xy1, conf = scripted_block_matches(k, bboxes0, bboxes1, 11.0)
+                if 'amp' in cs:
+                    xy1 = xy0 + (xy1 - xy0) * (cs['amp'] / 6.0)
+                if k >= cs['silent_from']:
+                    conf = conf * 0.1
+                return xy0, xy1, conf
+            matcher.bboxes_mesh_renderer_matcher = scripted
+            xy0, xy1, wt, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, None, None, spacings=np.array(cs['spacings']), distributor='cartesian_bbox',
+                                                                          conf_thresh=0.3, residue_len=3.0, residue_mode='huber', compute_strain=False,
+                                                                          stiffness_lambda=0.5, min_num_blocks=2)
+            out[f'{name}_nrounds'] = np.int64(len(rounds))
+            out[f'{name}_nsolves'] = np.int64(len(solves))
+            out[f'{name}_none'] = np.bool_(xy0 is None)
+            if xy0 is not None:
+                out[f'{name}_xy0'] = xy0; out[f'{name}_xy1'] = xy1; out[f'{name}_weight'] = np.asarray(wt)
+            else:
+                out[f'{name}_wt'] = np.float64(wt)
+            out[f'{name}_strain'] = np.float64(strain)
+            out[f'{name}_field1_final'] = m1.vertices_w_offset(gear=const.MESH_GEAR_MOVING) - m1.vertices_w_offset(gear=const.MESH_GEAR_INITIAL)
+    finally:
+        matcher.bboxes_mesh_renderer_matcher = real_match
+        optimizer.SLM.optimize_linear = real_ol
+    np.savez_compressed(os.path.join(OUT, 'g36_loop_exits.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver, g33_render_weights, g34_links_to_divided_meshes, g35_outcasts):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver, g33_render_weights, g34_links_to_divided_meshes, g35_outcasts, g36_loop_exits):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

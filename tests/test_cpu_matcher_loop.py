@@ -523,3 +523,50 @@ def test_product_render_weights_vs_reference(monkeypatch):
     np.testing.assert_allclose(xy0, g['xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g['xy1'], atol=1e-5)
     np.testing.assert_allclose(wt, g['weight'], atol=1e-5)
     assert not np.any((xy1[:, 0] > 620) & (xy1[:, 0] < 880))
+
+
+@pytest.mark.parametrize('case', ['late_silence', 'early_silence', 'apart', 'tiny_motion'])
+def test_product_matcher_loop_exits_vs_reference(monkeypatch, case):
+    """the ways out of the loop (matcher.py:592-598, 671-679, 719-724, 744-751) against the reference (golden G36): a round without a
+    confident block after earlier rounds linked (their links are the result) or before anything was linked (no result, weight 0, default
+    strain), meshes that do not overlap (no round at all), and matches below 0.1 px (linked, never relaxed: no solve)"""
+    import json
+    from test_oracle_golden import _g23_scripted_block_matches as script
+    g = load_golden('g36_loop_exits.npz')
+    g23 = load_golden('g23_matcher_loop.npz')
+    cs = json.loads(str(g['cases']))[case]
+    m0 = Mesh(g23['v0'], g23['t0'], uid=0)
+    m0.lock()
+    m1 = Mesh(g23['v1'].copy() + np.array(cs.get('shift1', (0.0, 0.0))), g23['t1'], uid=1)
+    rounds, solves = [], []
+
+    def scripted(mesh0, mesh1, ld0, ld1, bboxes0, bboxes1, **kw):
+        k = len(rounds)
+        rounds.append(np.array(bboxes0))
+        xy0, xy1, conf = script(k, bboxes0, bboxes1, 11.0)
+        if 'amp' in cs:
+            xy1 = xy0 + (xy1 - xy0) * (cs['amp'] / 6.0)
+        if k >= cs['silent_from']:
+            conf = conf * 0.1
+        return xy0, xy1, conf
+
+    def counted(self, **kw):
+        solves.append(1)
+        return _exact_optimize_linear(self, **kw)
+    monkeypatch.setattr(matcher, 'bboxes_mesh_renderer_matcher', scripted)
+    monkeypatch.setattr(optimizer.SLM, 'optimize_linear', counted)
+    monkeypatch.setattr(Mesh, 'stiffness_matrix_local_normalized', _exact_local_stiffness)
+    monkeypatch.setattr(optimizer, 'solve', _exact_solve)
+    xy0, xy1, wt, strain = matcher.iterative_xcorr_matcher_w_mesh(m0, m1, _NoImage(), _NoImage(), spacings=np.array(cs['spacings']), distributor='cartesian_bbox',
+                                                                  conf_thresh=0.3, residue_len=3.0, residue_mode='huber', compute_strain=False,
+                                                                  stiffness_lambda=0.5, min_num_blocks=2)
+    assert len(rounds) == int(g[f'{case}_nrounds']) and len(solves) == int(g[f'{case}_nsolves'])
+    assert (xy0 is None) == bool(g[f'{case}_none']) and strain == float(g[f'{case}_strain'])
+    want = g[f'{case}_field1_final']
+    np.testing.assert_allclose(m1.vertices_w_offset(const.MESH_GEAR_MOVING) - m1.vertices_w_offset(const.MESH_GEAR_INITIAL), want, atol=1e-6 * max(1.0, np.abs(want).max()))
+    if xy0 is None:
+        assert xy1 is None and wt == float(g[f'{case}_wt'])
+    else:
+        assert xy0.shape == g[f'{case}_xy0'].shape
+        np.testing.assert_allclose(xy0, g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g[f'{case}_xy1'], atol=1e-5)
+        np.testing.assert_allclose(wt, g[f'{case}_weight'], atol=1e-5)
