@@ -1701,8 +1701,45 @@ def g36_loop_exits():
     np.savez_compressed(os.path.join(OUT, 'g36_loop_exits.npz'), **out)
 
 
+# ----------------------------------------------------------------------- G37
+def g37_section_matcher_call():
+    """section_matcher (matcher.py:370-396) down to its call of the loop: the defaults it fills in (sigma 2.5, batch_size 100, distributor
+    'cartesian_region', link_weight_decay 0, render_weight_threshold 0.1, stiffness_lambda 0.5), what it passes through, and the sub-meshes
+    it hands over after dropping the triangles of materials softer than stiffness_multiplier_threshold -- the loop replaced by a recorder"""
+    import json
+    g23 = np.load(os.path.join(OUT, 'g23_matcher_loop.npz'))
+    vb, tb = g23['v1'], g23['t1']
+    ctr = vb[tb].mean(axis=1)
+    mids = np.where(ctr[:, 0] > 1200, 5, 0).astype(np.int16)
+    tab = {'default': dict(material.MATERIAL_DEFAULT), 'jelly': {'uid': 5, 'stiffness_multiplier': 0.05}}
+    real = matcher.iterative_xcorr_matcher_w_mesh
+    seen = {}
+
+    def recorder(mesh0, mesh1, ld0, ld1, **kw):
+        seen['kw'] = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        seen['ntri'] = [int(mesh0.num_triangles), int(mesh1.num_triangles)]
+        seen['loaders'] = [ld0, ld1]
+        return np.zeros((1, 2)), np.ones((1, 2)), np.ones(1), 0.07
+    out = {}
+    try:
+        matcher.iterative_xcorr_matcher_w_mesh = recorder
+        for tag, kw in (('defaults', {}), ('given', dict(spacings=[200, 50], conf_thresh=0.4, sigma=3.5, stiffness_multiplier_threshold=0.0, compute_strain=True,
+                                                          residue_len=-2, shrink_factor=0.7, distributor='cartesian_bbox', stiffness_lambda=0.25))):
+            m0 = Mesh(g23['v0'], g23['t0'], uid=0)
+            m1 = Mesh(vb.copy(), tb.copy(), material_table=material.MaterialTable(table=tab), material_ids=mids.copy(), uid=1)
+            res = matcher.section_matcher(m0, m1, 'loader0', 'loader1', **kw)
+            out[f'{tag}_kw'] = np.array(json.dumps(seen['kw'], sort_keys=True))
+            out[f'{tag}_ntri'] = np.array(seen['ntri'])
+            out[f'{tag}_strain'] = np.float64(res[3])
+    finally:
+        matcher.iterative_xcorr_matcher_w_mesh = real
+    out['mids'] = np.asarray(Mesh(vb.copy(), tb.copy(), material_table=material.MaterialTable(table=tab), material_ids=mids.copy(), uid=1)._material_ids, dtype=np.int32)
+    out['t1'] = np.asarray(Mesh(vb.copy(), tb.copy(), material_table=material.MaterialTable(table=tab), material_ids=mids.copy(), uid=1).triangles)
+    np.savez_compressed(os.path.join(OUT, 'g37_section_matcher_call.npz'), **out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver, g33_render_weights, g34_links_to_divided_meshes, g35_outcasts, g36_loop_exits):
+    for fn in (g1_xcorr, g2_dog, g3_global, g45_stiffness, g6789_system, g10_elements, g11_bbox, g12_mixed_materials, g13_strain, g14_groupings, g15_translation, g16_relax, g17_newton, g18_locked_neighbours, g19_area_stretch, g20_xcorr_normalized, g21_grouped_dof, g22_schedule_walks, g23_matcher_loop, g24_strip_loop, g25_overlap_bookkeeping, g26_slm_bookkeeping, g27_mesh_gears, g28_affine_cascade, g29_cartesian_grid, g30_seeded_loop, g31_loop_options, g32_newton_driver, g33_render_weights, g34_links_to_divided_meshes, g35_outcasts, g36_loop_exits, g37_section_matcher_call):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

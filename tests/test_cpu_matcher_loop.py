@@ -570,3 +570,33 @@ def test_product_matcher_loop_exits_vs_reference(monkeypatch, case):
         assert xy0.shape == g[f'{case}_xy0'].shape
         np.testing.assert_allclose(xy0, g[f'{case}_xy0'], atol=1e-5); np.testing.assert_allclose(xy1, g[f'{case}_xy1'], atol=1e-5)
         np.testing.assert_allclose(wt, g[f'{case}_weight'], atol=1e-5)
+
+
+@pytest.mark.parametrize('tag,kw', [('defaults', {}), ('given', dict(spacings=[200, 50], conf_thresh=0.4, sigma=3.5, stiffness_multiplier_threshold=0.0, compute_strain=True,
+                                                                      residue_len=-2, shrink_factor=0.7, distributor='cartesian_bbox', stiffness_lambda=0.25))])
+def test_product_section_matcher_call_vs_reference(monkeypatch, tag, kw):
+    """section_matcher down to its call of the loop (matcher.py:370-396) against the reference (golden G37): the defaults it fills in, what
+    it passes through, and the sub-meshes it hands over after dropping the triangles of materials softer than
+    stiffness_multiplier_threshold (a 'jelly' region of multiplier 0.05 against the default threshold 0.1) -- the loop replaced by a recorder
+    on both sides.  The product's one addition is `relax_tol: None` (its loop's default would converge the relaxations)."""
+    import json
+    g = load_golden('g37_section_matcher_call.npz')
+    g23 = load_golden('g23_matcher_loop.npz')
+    seen = {}
+
+    def recorder(mesh0, mesh1, ld0, ld1, **k_):
+        seen['kw'] = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in k_.items()}
+        seen['ntri'] = [int(mesh0.num_triangles), int(mesh1.num_triangles)]
+        return np.zeros((1, 2)), np.ones((1, 2)), np.ones(1), 0.07
+    monkeypatch.setattr(matcher, 'iterative_xcorr_matcher_w_mesh', recorder)
+    m0 = Mesh(g23['v0'], g23['t0'], uid=0)
+    nt = g['t1'].shape[0]
+    m1 = Mesh(g23['v1'].copy(), g['t1'], uid=1, material_ids=g['mids'], material_names={'default': 0, 'jelly': 5},
+              tri_model=np.zeros(nt, dtype=np.int32), tri_matmult=np.where(g['mids'] == 5, 0.05, 1.0))
+    res = matcher.section_matcher(m0, m1, _NoImage(), _NoImage(), **kw)
+    want = json.loads(str(g[f'{tag}_kw']))
+    got = dict(seen['kw'])
+    assert got.pop('relax_tol', None) is None
+    assert json.loads(json.dumps(got, sort_keys=True)) == want
+    assert seen['ntri'] == g[f'{tag}_ntri'].tolist()
+    assert res[3] == float(g[f'{tag}_strain'])
