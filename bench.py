@@ -926,6 +926,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # resident-set watchdog (feabas_amd/_watchdog.py): the bench holds ~10 GB of host tiles for its PCIe-inclusive leg; anything
+    # far above that is a runaway host loop and must end this process, not the box.  FEABAS_RSS_LIMIT_GB (0 = off).
+    from feabas_amd import _watchdog
+    os.environ.setdefault('FEABAS_RSS_LIMIT_GB', '40')
+    if _watchdog.start() > 0:
+        _watchdog.start_backstop()
     dist = None
     torch = None
     launched = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)      # by torch.distributed.run

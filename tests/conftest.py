@@ -15,6 +15,23 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_sessionstart(session):
+    """every test run is under the resident-set watchdog (feabas_amd/_watchdog.py): a runaway host allocation -- round 5's
+    suspected region raster of a mesh thrown far away by a diverged solve -- ends THIS process with exit code 3 and a stack
+    dump instead of taking the box down.  A thread (stack dump) at the limit, a child process (SIGKILL; works while a C call
+    holds the GIL) at 1.15 x the limit.  FEABAS_RSS_LIMIT_GB (default 24; 0 = off)."""
+    from feabas_amd import _watchdog
+    if _watchdog.start() > 0:
+        session.config._fb_backstop = _watchdog.start_backstop()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    p = getattr(session.config, '_fb_backstop', None)
+    if p is not None:
+        p.kill()
+        p.wait()
+
+
 def pytest_collection_modifyitems(config, items):
     """every GPU test runs under a timeout of its own (pytest-timeout, 300 s unless the test sets one): a test that hangs
     -- a kernel that never finishes, a host loop fed by a runaway mesh -- fails there, with a stack dump, instead of holding the

@@ -2,6 +2,7 @@
 every symbol include/feabas_hip.h declares (no compute calls), and the host
 logic (bbox helpers, next_fast_len) matches the golden vectors."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -1248,3 +1249,53 @@ def test_g35_flag_outcasts_vs_reference():
         np.testing.assert_array_equal([bool(getattr(m, 'is_outcast', False)) for m in ms], g[tag + '_kept'], err_msg=tag)
     g35_outcast_walk(Mesh, Link, SLM, dict(load_golden('g15_translation.npz')), record)
     assert len(seen) == 10
+
+
+def test_region_raster_refuses_a_runaway_pair():
+    """round 5's incident, host end (tools/repro_r05_incident.py shows the chain: a floating pair scaled x60 by a diverged
+    relaxation -> 3.9e8 raster cells -> > 6 GB within seconds): _RegionPair.raster and the oracle's raster refuse more than 1e8
+    cells with a message, before anything of that size is allocated"""
+    import tracemalloc
+    from feabas_amd import mesh
+    from oracle import fem_ref, region_ref
+    v, t = fem_ref.grid_mesh(21, 21, 100.0)
+    c = v.mean(axis=0)
+    big = (v - c) * 600.0 + c                                   # 1.2e6 px wide: 2.3e9 cells at the step of spacing / 4
+    m0 = mesh.Mesh(big, t, uid=0); m1 = mesh.Mesh(big + 3.0, t, uid=1)
+    tracemalloc.start()
+    with pytest.raises(ValueError, match='not where images could be'):
+        matcher.distribute_matching_blocks(m0, m1, 100.0, min_boundary_distance=20, shrink_factor=0.7)
+    with pytest.raises(ValueError, match='common region of'):
+        region_ref.distribute_matching_blocks(big, t, big + 3.0, t, 100.0)
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert peak < 64e6, peak
+    nan = v.copy(); nan[5] = np.nan                               # a non-finite mesh has no common region with anything, or is refused
+    try:
+        e0, e1 = matcher.distribute_matching_blocks(mesh.Mesh(nan, t, uid=0), mesh.Mesh(v, t, uid=1), 100.0)
+        assert e0.shape[0] == 0 and e1.shape[0] == 0
+    except ValueError:
+        pass
+    # the same pair where images can be: served
+    b0, b1 = matcher.distribute_matching_blocks(mesh.Mesh(v, t, uid=0), mesh.Mesh(v + 3.0, t, uid=1), 100.0)
+    assert b0.shape[0] > 100 and b0.shape == b1.shape
+
+
+@pytest.mark.parametrize('mode', ['thread', 'backstop'])
+def test_rss_watchdog_ends_a_runaway_process(mode):
+    """feabas_amd/_watchdog.py (every pytest run and bench.py start it): a process whose resident set passes the limit ends with
+    exit code 3 (thread: with a stack dump) or is killed by the backstop child (works while a C call holds the GIL); a process
+    under the limit is left alone and the backstop ends with it"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys, time, os\nsys.path.insert(0, %r)\nos.environ["FEABAS_RSS_LIMIT_GB"] = "0.5"\n'
+            'from feabas_amd import _watchdog\n'
+            '%s\nimport numpy as np\nkeep = []\n'
+            'for i in range(int(sys.argv[1])):\n    keep.append(np.ones(1 << 24)); time.sleep(0.05)\n'
+            'print("alive", flush=True)\n') % (root, '_watchdog.start()' if mode == 'thread' else 'p = _watchdog.start_backstop()')
+    r = subprocess.run([sys.executable, '-c', code, '16'], capture_output=True, text=True, timeout=120)      # 2 GB in 128 MB pieces
+    assert 'alive' not in r.stdout
+    assert 'watchdog' in r.stderr and (r.returncode == 3 if mode == 'thread' else r.returncode == -9), (r.returncode, r.stderr[-300:])
+    r = subprocess.run([sys.executable, '-c', code, '2'], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and 'alive' in r.stdout and 'watchdog' not in r.stderr

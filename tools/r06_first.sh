@@ -5,6 +5,7 @@
 set -o pipefail
 O=gpurun_out/r06
 mkdir -p $O
+(nproc; free -g; ulimit -a) > $O/box.txt 2>&1
 step() {          # step <name> <seconds> <command...>
   local name=$1 secs=$2; shift 2
   echo "== $name" | tee -a $O/steps.txt
