@@ -1012,7 +1012,10 @@ int fb_ncc_batch_normalized(fb_ctx* ctx, const float* img0, const float* img1, i
         hipLaunchKernelGGL(ncc_norm_partial_max, dim3(kPeakChunks), dim3(kThreads), 0, ctx->stream, ctx->last_C, ctx->last_Cm, (float2*)dpart, (int)F);
         hipLaunchKernelGGL(ncc_norm_divisors, dim3((unsigned)std::min<size_t>((F + kThreads - 1) / kThreads, 2048)), dim3(kThreads), 0, ctx->stream,
                            ctx->last_C, ctx->last_Cm, (const float2*)dpart, kPeakChunks, (int)F, (float*)dD);
-        FB_HIP(ctx, hipGetLastError());
+        const hipError_t le = hipGetLastError();               // (no early return: the blocks above are freed below)
+        if (le != hipSuccess) rc = fb_fail(ctx, FB_ERR_HIP, "fb_ncc_batch_normalized: %s", hipGetErrorString(le));
+    }
+    if (!rc) {
         const size_t per_pair = (size_t)C * (F * 4 + (size_t)Fh * (Fw / 2 + 1) * 8) * 2 + (C > 1 ? (size_t)Fh * (Fw / 2 + 1) * 16 : 0);
         const int nb_max = quantised_chunk(ctx, N, per_pair);
         for (int n0 = 0; n0 < N && !rc; n0 += nb_max) {

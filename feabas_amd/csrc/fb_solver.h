@@ -23,6 +23,7 @@ struct fb_bsr {
     int64_t nnzb = 0;
     double2 *x = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *Ap = nullptr, *minv = nullptr, *b = nullptr,
             *diag = nullptr;
+    double2* xbest = nullptr;   // the iterate with the best TRUE residual of a solve that needs more than one leg (allocated then)
     double* parts = nullptr;
     fb_pcg_state* state = nullptr;
     double diag_max = 0.0;
