@@ -1265,9 +1265,11 @@ int fb_sys_solve(fb_ctx* ctx, fb_system* s, double* x, int use_x0, double rtol, 
             if (rc == FB_ERR_HIP || rc == FB_ERR_NOMEM) return rc;
             if (!rc || rc == FB_ERR_NOCONV) rr = rr_mg;       // (a failed call may not have written its residual)
             if (rc || rr > tol) {
-                // M->x holds the last iterate the hierarchy reached; after a breakdown (or a residual that is not a number) the
-                // Jacobi leg restarts from zero
-                if ((rc && rc != FB_ERR_NOCONV) || !(rr == rr)) FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
+                // M->x holds the last iterate the hierarchy reached -- or, when only its SET-UP refused (FB_ERR_ARG: the solve never
+                // touched x), the iterate of the first Jacobi leg, which is kept; after a breakdown (or a residual that is not a
+                // number) the Jacobi leg restarts from zero
+                if (rc == FB_ERR_BREAKDOWN || !(rr == rr)) FB_HIP(ctx, hipMemsetAsync(s->M->x, 0, sizeof(double2) * (size_t)s->nv, ctx->stream));
+                else if (rc && rc != FB_ERR_NOCONV && rc != FB_ERR_ARG) return rc;
                 const int rem = left(it1 + it2);
                 if (maxiter <= 0 || rem > 0) {
                     if ((rc = fb_bsr_setup_jacobi(ctx, s->M, 1))) return rc;

@@ -810,7 +810,11 @@ class SLM:
             self.last_solve = dict(iters=iters.value, relres=relres.value, stiffness_lambda=sl, crosslink_lambda=cl)
             if fell_back:
                 self.last_solve['multigrid_fell_back'] = True
-        if cost[1] < cost[0] and self._solution_is_sane(dd):    # optimizer.py:1421
+        if cost[1] < cost[0] and not self._solution_is_sane(dd):
+            # not applied: the cost must read as 'no step taken' to the callers that look at it (the Newton driver, the matcher's
+            # relaxations; optimizer.py:1421 applies a field exactly when cost[1] < cost[0])
+            cost = (cost[0], cost[0])
+        if cost[1] < cost[0]:                                   # optimizer.py:1421
             offs = self._offs
             for m in self.meshes:
                 o = offs[m.uid]
@@ -820,20 +824,30 @@ class SLM:
         return cost
 
     def _solution_is_sane(self, dd):
-        """a displacement field that is not finite, or that moves a node by more than a thousand times the extent of all the
-        meshes together, is the null-space drift of a solve that went wrong (a floating system pushed past what doubles can give),
-        never an alignment: it is not applied (the meshes keep their state, like a solve whose residual did not drop), and
-        `last_solve` says so.  Downstream steps size host and device buffers by where the meshes are."""
-        if any(m.locked for m in self.meshes):
-            return True                                       # a locked mesh pins the system: no null space to drift along (and no extra pass over 1e6 unknowns)
+        """a displacement field that is not finite, or that moves a node of a FLOATING sub-system -- link-connected meshes none of
+        which is locked: the ones with a null space to drift along -- by more than a thousand times the extent of all the meshes
+        together, is the drift of a solve that went wrong (a floating system pushed past what doubles can give), never an
+        alignment: it is not applied (the meshes keep their state, `optimize_linear` returns a cost that reads 'not improved'), and
+        `last_solve['rejected']` says why.  Downstream steps size host and device buffers by where the meshes are."""
         if not np.all(np.isfinite(dd)):
             self.last_solve['rejected'] = 'not finite'
             return False
+        locks = np.asarray(self.lock_flags, dtype=bool)
+        labels, _ = self.connected_subsystems
+        floating = ~np.isin(labels, labels[locks]) & ~locks
+        if not floating.any():
+            return True
+        offs = getattr(self, '_offs', None) or self.index_offsets
+        worst = 0.0
+        for m, fl in zip(self.meshes, floating):
+            o = offs.get(m.uid, -1)
+            if fl and o >= 0:
+                worst = max(worst, float(np.max(np.abs(dd[o:o + 2 * m.num_vertices]), initial=0.0)))
         lo = np.min([m.bbox(gear=const.MESH_GEAR_MOVING)[:2] for m in self.meshes], axis=0)
         hi = np.max([m.bbox(gear=const.MESH_GEAR_MOVING)[2:] for m in self.meshes], axis=0)
         extent = float(max(np.max(hi - lo), 1.0))
-        if float(np.max(np.abs(dd), initial=0.0)) > 1e3 * extent:
-            self.last_solve['rejected'] = f'displacements up to {float(np.max(np.abs(dd))):.3g} on meshes of extent {extent:.3g}'
+        if worst > 1e3 * extent:
+            self.last_solve['rejected'] = f'displacements up to {worst:.3g} on floating meshes of extent {extent:.3g}'
             return False
         return True
 

@@ -615,22 +615,33 @@ def test_triangle_edge_deform_host_loop_equals_the_numpy_statement():
 
 
 def test_optimize_linear_does_not_apply_a_runaway_field():
-    """SLM._solution_is_sane: a solved field that is not finite, or that moves nodes by more than a thousand mesh extents (the
-    null-space drift of a floating system pushed past what doubles can give), is not applied -- downstream steps size their
-    buffers by where the meshes are; a system with a locked mesh has no null space and is not screened"""
+    """SLM._solution_is_sane: a solved field that is not finite, or that moves nodes of a FLOATING sub-system (link-connected
+    meshes without a locked member) by more than a thousand mesh extents (the null-space drift of a floating system pushed past
+    what doubles can give), is not applied -- downstream steps size their buffers by where the meshes are; meshes linked to a
+    locked one are pinned and not screened for size; a free mesh that is NOT linked to the locked one still floats"""
     from feabas_amd import mesh, optimizer
     from oracle import fem_ref
+    rng = np.random.default_rng(0)
     v, t = fem_ref.grid_mesh(5, 4, 10.0)
-    m0 = mesh.Mesh(v, t, uid=0); m1 = mesh.Mesh(v + 1.0, t, uid=1)
-    slm = optimizer.SLM([m0, m1], [])
-    n = 2 * (m0.num_vertices + m1.num_vertices)
+    m0 = mesh.Mesh(v, t, uid=0); m1 = mesh.Mesh(v + 1.0, t, uid=1); m2 = mesh.Mesh(v + 2.0, t, uid=2)
+    tid = rng.integers(0, t.shape[0], 6); B = rng.dirichlet((1, 1, 1), 6)
+    slm = optimizer.SLM([m0, m1, m2], [optimizer.Link(m0, m1, tid, tid, B, B)])
+    nv = m0.num_vertices
+    n = 2 * 3 * nv
     slm.last_solve = {}
     assert slm._solution_is_sane(np.zeros(n)) and slm._solution_is_sane(np.full(n, 500.0)) and 'rejected' not in slm.last_solve
     assert not slm._solution_is_sane(np.full(n, 1e9)) and 'extent' in slm.last_solve['rejected']
     bad = np.zeros(n); bad[3] = np.nan
     assert not slm._solution_is_sane(bad) and slm.last_solve['rejected'] == 'not finite'
-    m0.locked = True
-    assert slm._solution_is_sane(np.full(n, 1e9))
+    m0.locked = True                                          # m1 is pinned through its link to m0; m2 floats on its own
+    n = 2 * 2 * nv
+    big1 = np.zeros(n); big1[:2 * nv] = 1e9
+    big2 = np.zeros(n); big2[2 * nv:] = 1e9
+    slm.last_solve = {}
+    assert slm._solution_is_sane(big1) and 'rejected' not in slm.last_solve
+    assert not slm._solution_is_sane(big2) and 'floating' in slm.last_solve['rejected']
+    bad = np.zeros(n); bad[1] = np.inf
+    assert not slm._solution_is_sane(bad)
 
 
 def test_held_dof_selectors_fold_into_groups_like_the_reference():

@@ -166,7 +166,6 @@ def test_optimize_linear_remove_extra_dof_vs_oracle(fb):
     assert 'held_dofs' not in slm2.last_solve
 
 
-@pytest.mark.skipif(not __import__('os').environ.get('FEABAS_TEST_PENDING'), reason='written after the GPU pool closed for round 5: never run on hardware yet (FEABAS_TEST_PENDING=1 runs it)')
 def test_g21_grouped_optimize_linear_with_held_dofs_vs_reference(fb):
     """optimize_linear(groupings=, remove_extra_dof=True) (optimizer.py:1360-1415) against the reference's golden G21: nothing is
     locked, mesh 0 (alone in its group) holds its first three degrees of freedom, meshes 1 and 2 share theirs.  The host fold of
