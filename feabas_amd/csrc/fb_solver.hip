@@ -266,6 +266,88 @@ __global__ __launch_bounds__(kT) void pcg_init_kernel(int nb, const double2* __r
     if (threadIdx.x == 0) { part_rz[blockIdx.x] = t1; part_rr[blockIdx.x] = t2; }
 }
 
+
+// ---- deflation of floating translations (the rescue path of fb_bsr_pcg_dev) ------------------------------------------------------
+// comp[i]: the deflated component vertex i belongs to, or -1.  S[c] = {sum v.x, sum v.y, sum (w v).x, sum (w v).y} over the
+// vertices of component c (WEIGHTS false: w = minv; true: v -> v / minv, w -> 1 / minv: the sums of the final M-orthogonalisation).
+// A thread keeps a running sum while the component does not change and the waves of one component combine before they touch
+// memory: a mesh-ordered matrix costs a few thousand atomic adds per pass.
+template <bool WEIGHTS>
+__global__ __launch_bounds__(kT) void defl_accum_kernel(int nb, const double2* __restrict__ v, const double2* __restrict__ minv,
+                                                         const int* __restrict__ comp, double* __restrict__ S) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int cur = -1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const int c = comp[i];
+        if (c < 0) continue;
+        if (c != cur) {
+            if (cur >= 0) { atomicAdd(S + 4 * cur, a0); atomicAdd(S + 4 * cur + 1, a1); atomicAdd(S + 4 * cur + 2, a2); atomicAdd(S + 4 * cur + 3, a3); }
+            cur = c; a0 = a1 = a2 = a3 = 0.0;
+        }
+        const double2 vi = v[i], mi = minv[i];
+        if (WEIGHTS) { a0 += vi.x / mi.x; a1 += vi.y / mi.y; a2 += 1.0 / mi.x; a3 += 1.0 / mi.y; }
+        else { a0 += vi.x; a1 += vi.y; a2 += mi.x * vi.x; a3 += mi.y * vi.y; }
+    }
+    const int first = __shfl(cur, 0);
+    if (__all(cur == first)) {
+        for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); a2 += __shfl_down(a2, off); a3 += __shfl_down(a3, off); }
+        if ((threadIdx.x & 63) != 0) cur = -1;
+    }
+    if (cur >= 0) { atomicAdd(S + 4 * cur, a0); atomicAdd(S + 4 * cur + 1, a1); atomicAdd(S + 4 * cur + 2, a2); atomicAdd(S + 4 * cur + 3, a3); }
+}
+
+// r <- P r, z <- P (minv r) with P = 'subtract the mean over every deflated (component, axis)', partial r.z and r.r in the slots
+// the next SpMV kernel reads; G[c] = {1 / n or 0 for x, for y, sum minv.x, sum minv.y}.  Zeroes the sums of the other parity.
+__global__ __launch_bounds__(kT) void defl_apply_kernel(int nb, double2* __restrict__ r, double2* __restrict__ z, const double2* __restrict__ minv,
+                                                        const int* __restrict__ comp, const double* __restrict__ S, const double* __restrict__ G,
+                                                        double* __restrict__ part_rz, double* __restrict__ part_rr, double* __restrict__ S_next, int ncomp) {
+    __shared__ double sh[kT / 64];
+    if (blockIdx.x == 0) for (int k = threadIdx.x; k < 4 * ncomp; k += blockDim.x) S_next[k] = 0.0;
+    double s_rz = 0.0, s_rr = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const int c = comp[i];
+        double2 ri = r[i];
+        const double2 mi = minv[i];
+        double2 zi;
+        if (c >= 0) {
+            const double* s = S + 4 * c;
+            const double* g = G + 4 * c;
+            const double mrx = s[0] * g[0], mry = s[1] * g[1];
+            ri.x -= mrx; ri.y -= mry;
+            zi.x = mi.x * ri.x - (s[2] - mrx * g[2]) * g[0];
+            zi.y = mi.y * ri.y - (s[3] - mry * g[3]) * g[1];
+            r[i] = ri;
+        } else {
+            zi = make_double2(mi.x * ri.x, mi.y * ri.y);
+        }
+        z[i] = zi;
+        s_rz += ri.x * zi.x + ri.y * zi.y;
+        s_rr += ri.x * ri.x + ri.y * ri.y;
+    }
+    const double t1 = block_sum(s_rz, sh);
+    const double t2 = block_sum(s_rr, sh);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = t1; part_rr[blockIdx.x] = t2; }
+}
+
+// x <- x - sum_g t_g (t_g^T M x) / (t_g^T M t_g), M = 1 / minv: the solution a Jacobi-preconditioned Krylov method started from
+// zero converges to (its iterates never leave minv range(A)); S from defl_accum_kernel<true>
+__global__ void defl_morth_kernel(int nb, double2* __restrict__ x, const int* __restrict__ comp, const double* __restrict__ S, const double* __restrict__ G) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const int c = comp[i];
+        if (c < 0) continue;
+        const double* s = S + 4 * c;
+        const double* g = G + 4 * c;
+        double2 xi = x[i];
+        if (g[0] > 0.0) xi.x -= s[0] / s[2];
+        if (g[1] > 0.0) xi.y -= s[1] / s[3];
+        x[i] = xi;
+    }
+}
+
+__global__ void fill2_kernel(int nb, double2* __restrict__ v, double2 c) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) v[i] = c;
+}
+
 // diagonal of the block matrix (for Jacobi) + partial max
 __global__ void bsr_diag_kernel(fb_bsr_dev A, double2* __restrict__ diag, double* __restrict__ part_max) {
     __shared__ double sh[kT / 64];

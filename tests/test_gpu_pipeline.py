@@ -733,7 +733,6 @@ def test_ragged_batch_matches_the_per_pair_surface(fb, shapes, cds):
     m.free(); dev.free()
 
 
-@pytest.mark.skipif(not __import__('os').environ.get('FEABAS_TEST_PENDING'), reason='written after the GPU pool closed for round 5: never run on hardware yet (FEABAS_TEST_PENDING=1 runs it)')
 @pytest.mark.parametrize('cds', [0.5, 1])
 def test_ragged_batch_photometric_statistics_match_the_per_pair_surface(fb, cds):
     """compute_photometric (matcher.py:279-314) in a batch of strips of unequal size: the statistics of every pair over the overlap of
@@ -763,7 +762,6 @@ def test_ragged_batch_photometric_statistics_match_the_per_pair_surface(fb, cds)
     m.free(); dev.free()
 
 
-@pytest.mark.skipif(not __import__('os').environ.get('FEABAS_TEST_PENDING'), reason='written after the GPU pool closed for round 5: never run on hardware yet (FEABAS_TEST_PENDING=1 runs it)')
 @pytest.mark.parametrize('cds', [0.5, 1])
 def test_ragged_batch_with_masks_matches_the_per_pair_surface(fb, cds):
     """masked pairs (matcher.py:257-274, 336-337: the masked DoG of the coarse and of the fine images) inside a batch of strips of

@@ -550,7 +550,6 @@ def test_distribute_matching_blocks_vs_oracle(fb, case):
         assert a.shape[0] and b.shape[0]
 
 
-@pytest.mark.skipif(not __import__('os').environ.get('FEABAS_TEST_PENDING'), reason='written after the GPU pool closed for round 5: never run on hardware yet (FEABAS_TEST_PENDING=1 runs it)')
 def test_section_matcher_vs_oracle(fb):
     """SURVEY row a8 end to end: matcher.section_matcher (cartesian_region lattice with a boundary distance, two spacings, DoG,
     block NCC through both meshes, relaxation with huber residues, strain) against oracle/region_ref.section_match -- the
