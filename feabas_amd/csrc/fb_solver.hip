@@ -615,6 +615,93 @@ int fb_bsr_setup_jacobi(fb_ctx* ctx, fb_bsr* M, int precond) {
     return FB_OK;
 }
 
+
+// ---- floating sub-systems: which translations lie in the null space ---------------------------------------------------------------
+// A system without a locked mesh is singular: every link-connected set of free meshes (and every island of a mesh) can translate
+// as a whole, A t = 0.  The reference's matrices are float32 in places (cross-link matrix, stress: SURVEY app. B) and so are ours
+// to match them: t^T A t is +-1e-10 of the largest eigenvalue instead of zero, b has a component of ~1e-8 ||b|| along t, and the
+// soft rotation of a floating pair sits only a factor ~50 above that noise.  Plain CG then meets p^T A p <= 0 long before it has
+// converged (measured: true residual 1e-3 at the end of the first leg, profiles/r06b_pcg_floating_probe_*).  The rescue: find the
+// connected components of the matrix graph (host, union-find over the block pattern), test the two translations of each
+// (max |A t| <= 1e-5 of the component's largest diagonal entry), and run the PCG on the system deflated by them: r and
+// z = minv r are kept orthogonal to every such t (defl_accum_kernel / defl_apply_kernel behind every update), so p has no
+// component along t and the noise curvature cannot enter p^T A p.  At the end x is made (1 / minv)-orthogonal to the t's: the
+// limit of a Jacobi-preconditioned Krylov method started from zero, which is what the oracle's exact solve defines.
+struct fb_deflation {
+    int ncomp = 0;
+    int* comp = nullptr;       // [nb] deflated component of a vertex or -1
+    double* G = nullptr;       // [ncomp][4]: 1/n (or 0) for x, for y, sum minv.x, sum minv.y
+    double* S = nullptr;       // [2][ncomp][4] running sums, two parities
+    int parity = 0;
+    ~fb_deflation() { hipFree(comp); hipFree(G); hipFree(S); }
+};
+
+static int defl_setup(fb_ctx* ctx, fb_bsr* M, fb_deflation* D, int g2) {
+    const int nb = M->d.nb;
+    std::vector<int> rowptr(nb + 1), col((size_t)M->nnzb);
+    FB_HIP(ctx, hipMemcpyAsync(rowptr.data(), M->d.rowptr, sizeof(int) * (nb + 1), hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipMemcpyAsync(col.data(), M->d.col, sizeof(int) * col.size(), hipMemcpyDeviceToHost, ctx->stream));
+    // A t_x and A t_y for t = 'every vertex' (components do not couple: the rows of a component see its own t only)
+    std::vector<double2> y[2], diag(nb), minv(nb);
+    for (int a = 0; a < 2; ++a) {
+        y[a].resize(nb);
+        hipLaunchKernelGGL(fill2_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->p0, a == 0 ? make_double2(1.0, 0.0) : make_double2(0.0, 1.0));
+        int rc = fb_bsr_spmv_dev(ctx, M, M->p0, M->Ap);
+        if (rc) return rc;
+        FB_HIP(ctx, hipMemcpyAsync(y[a].data(), M->Ap, sizeof(double2) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FB_HIP(ctx, hipMemcpyAsync(diag.data(), M->diag, sizeof(double2) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipMemcpyAsync(minv.data(), M->minv, sizeof(double2) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> parent(nb);
+    for (int i = 0; i < nb; ++i) parent[i] = i;
+    auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
+    for (int i = 0; i < nb; ++i)
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+            const int a = find(i), b = find(col[j]);
+            if (a != b) parent[std::max(a, b)] = std::min(a, b);
+        }
+    std::vector<int> label(nb, -1), root_of;
+    std::vector<double> dmax, ymax[2];
+    for (int i = 0; i < nb; ++i) {
+        const int r = find(i);
+        if (label[r] < 0) { label[r] = (int)root_of.size(); root_of.push_back(r); dmax.push_back(0.0); ymax[0].push_back(0.0); ymax[1].push_back(0.0); }
+        const int c = label[r];
+        label[i] = c;
+        dmax[c] = std::max(dmax[c], std::max(std::fabs(diag[i].x), std::fabs(diag[i].y)));
+        for (int a = 0; a < 2; ++a) ymax[a][c] = std::max(ymax[a][c], std::max(std::fabs(y[a][i].x), std::fabs(y[a][i].y)));
+    }
+    const int nc_all = (int)root_of.size();
+    std::vector<int> newid(nc_all, -1);
+    std::vector<double> G;
+    int nc = 0;
+    for (int c = 0; c < nc_all; ++c) {
+        const bool nx = dmax[c] > 0.0 && ymax[0][c] <= 1e-5 * dmax[c], ny = dmax[c] > 0.0 && ymax[1][c] <= 1e-5 * dmax[c];
+        if (!nx && !ny) continue;
+        newid[c] = nc++;
+        G.insert(G.end(), {nx ? 1.0 : 0.0, ny ? 1.0 : 0.0, 0.0, 0.0});          // (counts first, inverted below)
+    }
+    D->ncomp = nc;
+    if (nc == 0) return FB_OK;
+    std::vector<double> cnt(nc, 0.0);
+    for (int i = 0; i < nb; ++i) {
+        const int c = newid[label[i]];
+        label[i] = c;
+        if (c < 0) continue;
+        cnt[c] += 1.0;
+        G[4 * c + 2] += minv[i].x; G[4 * c + 3] += minv[i].y;
+    }
+    for (int c = 0; c < nc; ++c) { G[4 * c] = G[4 * c] > 0.0 ? 1.0 / cnt[c] : 0.0; G[4 * c + 1] = G[4 * c + 1] > 0.0 ? 1.0 / cnt[c] : 0.0; }
+    FB_HIP(ctx, hipMalloc((void**)&D->comp, sizeof(int) * nb));
+    FB_HIP(ctx, hipMalloc((void**)&D->G, sizeof(double) * 4 * nc));
+    FB_HIP(ctx, hipMalloc((void**)&D->S, sizeof(double) * 8 * nc));
+    FB_HIP(ctx, hipMemcpyAsync(D->comp, label.data(), sizeof(int) * nb, hipMemcpyHostToDevice, ctx->stream));
+    FB_HIP(ctx, hipMemcpyAsync(D->G, G.data(), sizeof(double) * 4 * nc, hipMemcpyHostToDevice, ctx->stream));
+    FB_HIP(ctx, hipMemsetAsync(D->S, 0, sizeof(double) * 8 * nc, ctx->stream));
+    FB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (the host vectors go out of scope)
+    return FB_OK;
+}
+
 // Solve A x = b for the vectors resident in M (M->b set, M->x = x0).  fixed_iters > 0: run exactly
 // that many iterations with no convergence exit.
 int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter, int fixed_iters, int* iters_out, double* relres_out) {
@@ -671,9 +758,23 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
     // true residual stops improving and then GROWS as round-off feeds the null space, 348 x ||b|| after eight legs, round 5)
     // ends at the best iterate: a leg that does not improve the true residual is undone, one that does not halve it is the
     // last, and so is one that doubles ||x|| (a correction leg refines x; one that doubles it ran away along a null vector).
-    static const int trace = [] { const char* e = getenv("FEABAS_HIP_PCG_TRACE"); return e ? atoi(e) : 0; }();
+    const int trace = [] { const char* e = getenv("FEABAS_HIP_PCG_TRACE"); return e ? atoi(e) : 0; }();      // (read per call: a test switches it on)
     static const int keep_best = [] { const char* e = getenv("FEABAS_HIP_PCG_BEST"); return e ? atoi(e) : 1; }();
+    static const int deflate = [] { const char* e = getenv("FEABAS_HIP_PCG_DEFLATE"); return e ? atoi(e) : 1; }();
+    fb_deflation D;                                  // (frees its device blocks when the solve returns)
+    bool deflated = false, breakdown = false;
+    // r <- P r, z <- P minv r, partials into the slots of parity `slot` (deflated passes only)
+    auto deflate_rz = [&](int slot) {
+        double* S_cur = D.S + (size_t)D.parity * 4 * D.ncomp;
+        double* S_nxt = D.S + (size_t)(D.parity ^ 1) * 4 * D.ncomp;
+        hipLaunchKernelGGL(defl_accum_kernel<false>, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->r, M->minv, D.comp, S_cur);
+        hipLaunchKernelGGL(defl_apply_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->r, M->z, M->minv, D.comp, S_cur, D.G, part_rz[slot],
+                           part_rr[slot], S_nxt, D.ncomp);
+        D.parity ^= 1;
+    };
+    for (int pass = 0; pass < 2; ++pass) {
     double best_rel = INFINITY, xx_ref = 0.0;        // best true residual at the start of a leg >= 1 (its iterate is in M->xbest)
+    bool troubled = false;                           // a leg ended on noise-level curvature, or the legs stopped helping
     for (int leg = 0; leg < 8; ++leg) {
         // r = b - A x, rr
         {
@@ -682,18 +783,23 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
                                part_tmp, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0);
         }
         double rr = 0.0;
-        if ((rc = host_sum(part_tmp, g1, &rr))) return rc;
+        if (deflated) {
+            // the residual that counts is the deflated one: what b holds along the null vectors (float32 noise of the
+            // reference's arithmetic, ~1e-8 ||b||) no x can remove
+            deflate_rz(1);
+            if ((rc = host_sum(part_rr[1], g2, &rr))) return rc;
+        } else if ((rc = host_sum(part_tmp, g1, &rr))) return rc;
         relres = std::sqrt(rr) / bnorm;
         if (trace) {
             double xx = 0.0;
-            hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->z, M->minv, part_tmp, part_rr[0]);
+            hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->p0, M->minv, part_tmp, part_rr[0]);
             if ((rc = host_sum(part_rr[0], g2, &xx))) return rc;
-            fprintf(stderr, "[pcg] nb %d leg %d iters %d true relres %.3e ||x|| %.6e tol %.1e\n", nb, leg, total_iters, relres, std::sqrt(xx), tol);
+            fprintf(stderr, "[pcg] nb %d%s leg %d iters %d true relres %.3e ||x|| %.6e tol %.1e\n", nb, deflated ? " deflated" : "", leg, total_iters, relres, std::sqrt(xx), tol);
         }
         if (fixed_iters <= 0 && relres <= tol) break;
         if (fixed_iters <= 0 && keep_best && leg >= 1) {
-            double xx = 0.0;                             // ||x||^2 (z is scratch here: the leg start below rewrites it)
-            hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->z, M->minv, part_tmp, part_rr[0]);
+            double xx = 0.0;                             // ||x||^2 (p0 is scratch here: iteration 0 of a leg rewrites it)
+            hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->p0, M->minv, part_tmp, part_rr[0]);
             if ((rc = host_sum(part_rr[0], g2, &xx))) return rc;
             const bool ran_away = leg >= 2 && !(xx <= 4.0 * xx_ref);
             if (!(relres < best_rel) || ran_away) {          // (a residual that is not a number ends the solve as well)
@@ -701,11 +807,13 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
                     FB_HIP(ctx, hipMemcpyAsync(M->x, M->xbest, sizeof(double2) * (size_t)nb, hipMemcpyDeviceToDevice, ctx->stream));
                     relres = best_rel;
                 }
+                troubled = true;
                 break;
             }
             const bool stalled = relres > 0.5 * best_rel;
             best_rel = relres;
             if (leg == 1) xx_ref = xx;
+            if (stalled) troubled = true;
             if (stalled || total_iters >= limit) break;
             if (!M->xbest) FB_HIP(ctx, hipMalloc((void**)&M->xbest, sizeof(double2) * (size_t)nb));
             FB_HIP(ctx, hipMemcpyAsync(M->xbest, M->x, sizeof(double2) * (size_t)nb, hipMemcpyDeviceToDevice, ctx->stream));
@@ -719,7 +827,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
         hs.tol2bb *= 0.81;
         hs.flag = 0; hs.iter = 0; hs.rr = rr; hs.curv_eps = curv_eps;
         FB_HIP(ctx, hipMemcpyAsync(M->state, &hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->r, M->z, M->minv, part_rz[1], part_rr[1]);
+        if (!deflated) hipLaunchKernelGGL(pcg_init_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->r, M->z, M->minv, part_rz[1], part_rr[1]);
         int it = 0;
         bool stop = false;
         double hist_rr[3] = {rr, rr, rr}; int hist_it[3] = {0, 0, 0};      // residual^2 at the last three checks of this leg
@@ -737,6 +845,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
                 hipLaunchKernelGGL(pcg_update_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->r, M->z, p_new, M->Ap, M->minv,
                                    part_pAp, part_pp, g1, part_rz[prev], g2, part_rz[cur], part_rr[cur], M->state, i, M->d.xcd_rows);
             }
+            if (deflated) deflate_rz(cur);                   // r - alpha P(A p) = P(r - alpha A p): the update kernel's r, z and dots redone on the deflated vectors
         };
         while (!stop) {
             const int batch = std::min(check_every, limit - total_iters - it);
@@ -784,10 +893,11 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
             FB_HIP(ctx, hipMemcpyAsync(&hs, M->state, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
             FB_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (hs.flag && graph_base >= 0) hs.iter = graph_base + (hs.iter - check_every);
-            if (hs.flag == 1 || hs.flag == 3) { it = hs.iter; stop = true; }
+            if (hs.flag == 1 || hs.flag == 3) { it = hs.iter; stop = true; if (hs.flag == 3) troubled = true; }
             else if (hs.flag == 2) {
                 total_iters += hs.iter;
                 if (iters_out) *iters_out = total_iters;
+                if (pass == 0 && deflate && fixed_iters <= 0) { it = 0; stop = true; troubled = true; breakdown = true; continue; }   // (the float32 noise of a floating system's null vectors can read as negative curvature: the deflated pass decides)
                 return fb_fail(ctx, FB_ERR_BREAKDOWN, "PCG breakdown at iteration %d: p^T A p <= 0 (matrix not positive semi-definite)", total_iters);
             } else if (M->probe_limit > 0 && fixed_iters <= 0 && hs.rr > 0.0) {
                 // iterations still needed at the decay of the last two checks (64 iterations); a stalled residual projects to infinity
@@ -802,6 +912,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
             }
         }
         total_iters += it;
+        if (breakdown) break;
         if (M->probe_stopped) {
             // the true residual of the iterate reached, then out (like an iteration cap)
             hipLaunchKernelGGL(bsr_spmv_kernel<2>, dim3(g1), dim3(kT), 0, ctx->stream, M->d, M->x, nullptr, nullptr, M->r, M->b,
@@ -818,6 +929,23 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
             relres = std::sqrt(rr) / bnorm;
             break;
         }
+    }
+    if (pass == 0 && deflate && fixed_iters <= 0 && troubled && (breakdown || relres > tol) && total_iters < limit && !M->probe_stopped) {
+        if ((rc = defl_setup(ctx, M, &D, g2))) return rc;
+        if (trace) fprintf(stderr, "[pcg] nb %d: legs in trouble at true relres %.3e%s; %d floating component(s) found\n", nb, relres, breakdown ? " (negative curvature)" : "", D.ncomp);
+        if (D.ncomp > 0) { deflated = true; use_graph = false; breakdown = false; continue; }
+    }
+    if (breakdown)
+        return fb_fail(ctx, FB_ERR_BREAKDOWN, "PCG breakdown at iteration %d: p^T A p <= 0 (matrix not positive semi-definite)", total_iters);
+    break;
+    }
+    if (deflated) {
+        // the null-space part of x: the one a Jacobi-preconditioned Krylov method started from zero converges to
+        double* S_cur = D.S + (size_t)D.parity * 4 * D.ncomp;
+        hipLaunchKernelGGL(defl_accum_kernel<true>, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->minv, D.comp, S_cur);
+        hipLaunchKernelGGL(defl_morth_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, D.comp, S_cur, D.G);
+        FB_HIP(ctx, hipGetLastError());
+        FB_HIP(ctx, hipStreamSynchronize(ctx->stream));      // (D's blocks are freed when this function returns)
     }
     if (iters_out) *iters_out = total_iters;
     if (relres_out) *relres_out = relres;

@@ -257,21 +257,62 @@ def distribute_matching_blocks(v0, t0, v1, t1, spacing, refine_mode=2, shrink_fa
 
 
 # ------------------------------------------------------------------ the pair of a section matcher
+def _floating_translations(Ad, tol=1e-5):
+    """the translations that lie in the null space of a 2-DoF-per-vertex system: for every connected component of the vertex
+    graph of A and each axis, the indicator t with max |A t| <= tol x the component's largest diagonal entry (a component that a
+    link ties to a locked mesh has row sums of the order of the link weights).  Returns a list of DoF index arrays.  The
+    reference's matrices carry float32 noise: t^T A t is +-1e-10 of the largest eigenvalue, not zero, and the
+    soft rotation of a floating pair sits only ~50 x above that -- an eigenvalue threshold cannot tell them apart, the
+    structure can."""
+    from scipy import sparse
+    from scipy.sparse import csgraph
+    n = Ad.shape[0]
+    S = sparse.coo_matrix(Ad)
+    keep = S.data != 0
+    G = sparse.csr_matrix((np.ones(int(keep.sum())), (S.row[keep] // 2, S.col[keep] // 2)), shape=((n + 1) // 2, (n + 1) // 2))
+    nc, lab = csgraph.connected_components(G, directed=False)
+    d = np.abs(np.asarray(Ad.diagonal() if hasattr(Ad, 'diagonal') else np.diag(Ad)))
+    groups = []
+    for axis in (0, 1):
+        t = np.zeros(n); t[axis::2] = 1.0
+        y = np.abs(np.asarray(Ad @ t).ravel())
+        for c in range(nc):
+            v = np.flatnonzero(lab == c)
+            dofs = np.concatenate((2 * v, 2 * v + 1)); dofs = dofs[dofs < n]
+            if d[dofs].max() > 0 and y[dofs].max() <= tol * d[dofs].max():
+                g = 2 * v + axis
+                groups.append(g[g < n])
+    return groups
+
+
 def _solve_jacobi_krylov_limit(A, b):
     """what a Jacobi-preconditioned Krylov method started from zero converges to (the reference's restarted MINRES with
-    M = diag(A)^-1, optimizer.py:1962-1971, and a Jacobi-PCG alike): the solution of A x = b that is diag(A)-orthogonal to the
-    null space of A.  Two free meshes linked to each other have one (common rigid translations): the solution is unique only
-    up to it, and the Krylov iterates never leave diag(A)^-1 range(A).  Dense: the pairs of the tests have ~2 k unknowns."""
+    M = diag(A)^-1, optimizer.py:1962-1971, and a Jacobi-PCG alike): the solution of A x = b that is M-orthogonal to the
+    null space of A (M = the clipped diagonal of optimizer.py:1962-1966).  Two free meshes linked to each other have one
+    (common rigid translations, one pair per link-connected set of mesh components): the solution is unique only up to it, and
+    the Krylov iterates never leave M^-1 range(A).  The null vectors are taken from the structure (_floating_translations), the
+    system is deflated by them exactly -- P A P x = P b with P the orthogonal projector off the translations --, solved densely
+    (the pairs of the tests have ~2 k unknowns) and made M-orthogonal to them."""
     Ad = 0.5 * (A + A.T)
+    groups = _floating_translations(Ad)
     Ad = Ad.toarray() if hasattr(Ad, 'toarray') else np.asarray(Ad)
-    w, V = np.linalg.eigh(Ad)
-    null = w < 1e-11 * w.max()
-    Vr = V[:, ~null]
-    x = Vr @ ((Vr.T @ b) / w[~null])
-    if null.any():
-        N = V[:, null]
-        Md = np.diag(Ad)
-        x = x - N @ np.linalg.solve(N.T @ (Md[:, None] * N), N.T @ (Md * x))
+    b = np.asarray(b, dtype=np.float64)
+    if not groups:
+        w, V = np.linalg.eigh(Ad)
+        ok = w > 1e-11 * w.max()
+        return V[:, ok] @ ((V[:, ok].T @ b) / w[ok])
+    n = b.size
+    Q = np.zeros((n, len(groups)))
+    for k, g in enumerate(groups):
+        Q[g, k] = 1.0 / np.sqrt(g.size)
+    P = np.eye(n) - Q @ Q.T
+    w, V = np.linalg.eigh(P @ Ad @ P)
+    ok = w > 1e-11 * w.max()
+    x = V[:, ok] @ ((V[:, ok].T @ (P @ b)) / w[ok])
+    d = np.diag(Ad)
+    Md = d.clip(min(1.0, d.max() / 1000), None) if d.max() > 0 else np.ones(n)
+    for g in groups:
+        x[g] -= np.sum(Md[g] * x[g]) / np.sum(Md[g])
     return x
 
 

@@ -1,5 +1,5 @@
 """The device PCG on FLOATING systems, solver only (nothing is applied to a mesh): the three relaxations of the island pair of
-tests/test_gpu_renderer.py::test_section_matcher_vs_oracle with both sections free (tools/data/floating_island_pair_systems.npz,
+tests/test_gpu_renderer.py::test_section_matcher_vs_oracle with both sections free (tests/golden/floating_island_pair_systems.npz,
 dumped from the oracle's loop on the CPU: 4 null vectors -- two floating sub-systems --, soft rotations at 4e-9 of the
 largest eigenvalue) and a floating 8192^2 section pair built here, at tolerances down to what doubles cannot give.
 FEABAS_HIP_PCG_TRACE=1 prints the legs.  usage: python tools/probe_pcg_floating.py [best=1]"""
@@ -17,7 +17,7 @@ _watchdog.start(8.0)
 
 
 def cases():
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'floating_island_pair_systems.npz'))
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'floating_island_pair_systems.npz'))
     for k in range(3):
         n = z['b%d' % k].size
         yield 'island pair, relaxation %d' % k, sparse.csr_matrix((z['data%d' % k], z['indices%d' % k], z['indptr%d' % k]), shape=(n, n)), z['b%d' % k]
