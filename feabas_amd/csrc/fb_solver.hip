@@ -344,6 +344,18 @@ __global__ void defl_morth_kernel(int nb, double2* __restrict__ x, const int* __
     }
 }
 
+// x <- P x (the mean over every deflated (component, axis) taken out); S from defl_accum_kernel<false>
+__global__ void defl_center_kernel(int nb, double2* __restrict__ x, const int* __restrict__ comp, const double* __restrict__ S, const double* __restrict__ G) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const int c = comp[i];
+        if (c < 0) continue;
+        double2 xi = x[i];
+        xi.x -= S[4 * c] * G[4 * c];
+        xi.y -= S[4 * c + 1] * G[4 * c + 1];
+        x[i] = xi;
+    }
+}
+
 __global__ void fill2_kernel(int nb, double2* __restrict__ v, double2 c) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) v[i] = c;
 }
@@ -933,7 +945,16 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
     if (pass == 0 && deflate && fixed_iters <= 0 && troubled && (breakdown || relres > tol) && total_iters < limit && !M->probe_stopped) {
         if ((rc = defl_setup(ctx, M, &D, g2))) return rc;
         if (trace) fprintf(stderr, "[pcg] nb %d: legs in trouble at true relres %.3e%s; %d floating component(s) found\n", nb, relres, breakdown ? " (negative curvature)" : "", D.ncomp);
-        if (D.ncomp > 0) { deflated = true; use_graph = false; breakdown = false; continue; }
+        if (D.ncomp > 0) {
+            // the deflated operator is P A P: the iterate starts in the range of P (what pass 0 left along the null vectors --
+            // it can be large -- would meet the float32 noise of A t in every residual) and stays there (p = P p throughout)
+            hipLaunchKernelGGL(defl_accum_kernel<false>, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->minv, D.comp, D.S);
+            hipLaunchKernelGGL(defl_center_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, D.comp, D.S, D.G);
+            FB_HIP(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * 8 * D.ncomp, ctx->stream));
+            D.parity = 0;
+            deflated = true; use_graph = false; breakdown = false;
+            continue;
+        }
     }
     if (breakdown)
         return fb_fail(ctx, FB_ERR_BREAKDOWN, "PCG breakdown at iteration %d: p^T A p <= 0 (matrix not positive semi-definite)", total_iters);

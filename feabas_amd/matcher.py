@@ -1228,8 +1228,7 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         for k, r in general.items():
             out[k] = r
         return out
-    # chunks: ('uniform', (H, W), indices) -- pairs of one strip shape, through StripBatchMatcher (masks, photometric
-    # statistics and the deformed-mesh branch included); ('ragged', key, indices) -- pairs of unequal shape that share the
+    # chunks: ('uniform', (H, W), indices) -- pairs of one strip shape, through StripBatchMatcher; ('ragged', key, indices) -- pairs of unequal shape that share the
     # mesh topology and the number of spacings, through RaggedStripBatchMatcher (strips differ in shape from pair to pair
     # in a real section, stitcher.py:561-571; a batch per shape would be a batch of one)
     from .stitch_pipeline import RaggedStripBatchMatcher, MatcherPool
@@ -1238,14 +1237,12 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
         by_shape.setdefault(it[0].shape, []).append(k)
     chunks, loose = [], []
     for shape, idx in by_shape.items():
-        special = [k for k in idx if items[k][2] is not None or items[k][3] is not None or compute_photometric]
-        plain = [k for k in idx if k not in set(special)]
-        for c in range(0, len(special), batch):
-            chunks.append(('uniform', shape, special[c:c + batch]))
-        full = len(plain) // batch * batch if len(plain) >= batch else 0
+        # (masked pairs and photometric statistics go through ragged chunks like any other pair since round 6: the ragged
+        # matcher filters a masked strip inside its slot and takes the statistics over every pair's own overlap)
+        full = len(idx) // batch * batch if len(idx) >= batch else 0
         for c in range(0, full, batch):
-            chunks.append(('uniform', shape, plain[c:c + batch]))
-        loose.extend(plain[full:])
+            chunks.append(('uniform', shape, idx[c:c + batch]))
+        loose.extend(idx[full:])
     by_key = {}
     for k in loose:
         H, W = items[k][0].shape
