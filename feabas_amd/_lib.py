@@ -118,10 +118,6 @@ _PROTOS = {
     'fb_memcpy_d2h': (c_i, [c_p, c_p, c_p, c_sz]),
     'fb_memcpy_d2d': (c_i, [c_p, c_p, c_p, C.c_size_t]),
     'fb_memcpy2d_d2d': (c_i, [c_p, c_p, c_sz, c_p, c_sz, c_sz, c_sz]),
-    'fb_debug_rigid_fits': (c_i, [c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
-    'fb_debug_auto_spacings': (c_i, [c_i, c_i, c_p, c_i, c_p]),
-    'fb_debug_grid_counts': (c_i, [c_i, c_i, c_d, c_i, c_p, c_p]),
-    'fb_debug_mg_coarsen': (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     'fb_memset': (c_i, [c_p, c_p, c_i, c_sz]),
     'fb_timer_start': (c_i, [c_p]),
     'fb_timer_stop': (c_i, [c_p, C.POINTER(C.c_float)]),
@@ -135,7 +131,6 @@ _PROTOS = {
     'fb_ncc_batch_normalized': (c_i, [c_p, c_p, c_p] + [c_i] * 6 + [c_p, c_p] + [c_i] * 3 + [c_p, c_p, c_p]),
     'fb_ncc_blocks_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     'fb_ncc_blocks_affine_dev': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
-    'fb_debug_fft1d': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i]),
     'fb_ncc_last_surfaces': (c_i, [c_p, c_p, c_p, C.POINTER(c_i), C.POINTER(c_i)]),
     'fb_dog': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
     'fb_dog_dev': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_p]),
@@ -231,9 +226,19 @@ _PROTOS = {
 }
 
 
-def declared_symbols():
-    """Every function name include/feabas_hip.h declares."""
-    with open(HEADER_PATH) as f:
+# test hooks: only in libfeabas_hip_test.so (include/feabas_hip_test.h), loaded by tests and fuzzers through load_test()
+_TEST_PROTOS = {
+    'fb_debug_rigid_fits': (c_i, [c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'fb_debug_auto_spacings': (c_i, [c_i, c_i, c_p, c_i, c_p]),
+    'fb_debug_grid_counts': (c_i, [c_i, c_i, c_d, c_i, c_p, c_p]),
+    'fb_debug_mg_coarsen': (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    'fb_debug_fft1d': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i]),
+}
+
+
+def declared_symbols(header=None):
+    """Every function name include/feabas_hip.h (or another header of include/) declares."""
+    with open(HEADER_PATH if header is None else os.path.join(os.path.dirname(HEADER_PATH), header)) as f:
         txt = f.read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     return sorted(set(re.findall(r'\b(fb_[a-z0-9_]+)\s*\(', txt)))
@@ -261,6 +266,26 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_test_lib = None
+TEST_LIB_PATH = os.path.abspath(os.environ['FEABAS_HIP_TEST_LIB']) if os.environ.get('FEABAS_HIP_TEST_LIB') else os.path.join(_HERE, 'libfeabas_hip_test.so')      # (env: the sanitizer build of tools/asan_host.sh)
+
+
+def load_test():
+    """The test build of the library (the product objects plus the hooks of include/feabas_hip_test.h): a second, independent
+    instance -- a hook that takes a context wants one made by THIS handle's fb_create.  Never loaded by the product."""
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise ImportError(f'{TEST_LIB_PATH} not found: build it with __graft_entry__.build()')
+        lib = C.CDLL(TEST_LIB_PATH)
+        for name, (res, args) in list(_PROTOS.items()) + list(_TEST_PROTOS.items()):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _test_lib = lib
+    return _test_lib
 
 
 _tls = threading.local()

@@ -1597,6 +1597,8 @@ int fb_pairs_strain_bary(fb_ctx* ctx, fb_system* s, int P, int64_t K, const int3
     return pairs_strain_core(ctx, s, P, has, weight, stiffness_lambda, es0, 1, default_strain, strain, iters, relres);
 }
 
+#ifdef FB_TEST_HOOKS          // only in libfeabas_hip_test.so (include/feabas_hip_test.h)
+#include "feabas_hip_test.h"
 // test hook (host only, no context): one coarsening step of the multigrid set-up on a level given as host arrays -- the
 // aggregates, the relative node positions and the coarse pattern mg_build_next uploads (mg_host_coarsen, the threaded host half).
 // A first call with ccol == NULL sizes the coarse pattern (*cnnz).
@@ -1629,5 +1631,6 @@ int fb_debug_mg_coarsen(int n, int bs, const double* xy, const int32_t* comp, co
     }
     return FB_OK;
 }
+#endif
 
 }  // extern "C"

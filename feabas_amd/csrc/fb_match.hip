@@ -846,6 +846,8 @@ int fb_divide_bbox(fb_ctx* ctx, const double* bbox, const double* block_hw, cons
     return FB_OK;
 }
 
+#ifdef FB_TEST_HOOKS          // only in libfeabas_hip_test.so (include/feabas_hip_test.h)
+#include "feabas_hip_test.h"
 // test hooks (host only, no context): the host arithmetic fb_match_strips runs between its kernels -- the rigid fits of
 // matcher.py:752-763 (spatial.fit_affine(return_rigid=True, svd_clip=(1, 1)) of every pair's matches; rows of a pair contiguous;
 // R [P][3][3], bad [P] = 1 where the pair needs the statement-by-statement route), the automatic spacings of matcher.py:243-251
@@ -881,6 +883,7 @@ int fb_debug_grid_counts(int H, int W, double mesh_size, int min_num_blocks, int
     grid_counts(H, W, mesh_size, min_num_blocks, nx, ny);
     return FB_OK;
 }
+#endif
 
 int fb_strip_matcher_create(fb_ctx* ctx, int P, int H, int W, const fb_strip_opts* o, fb_strip_matcher** out) {
     FB_LOCK(ctx);

@@ -1166,6 +1166,8 @@ void launch_debug_fft2(fb_ctx* ctx, size_t lds, const float2* din, float2* dout,
 }
 }  // namespace
 
+#ifdef FB_TEST_HOOKS          // only in libfeabas_hip_test.so (include/feabas_hip_test.h)
+#include "feabas_hip_test.h"
 extern "C" int fb_debug_fft1d(fb_ctx* ctx, const float* in_host, float* out_host, int M, int N, int inverse, int pad) {
     FB_LOCK(ctx);
     FB_CHECK_ARG(ctx, M > 0 && N >= 2 && N <= 4096 && in_host && out_host);
@@ -1208,3 +1210,4 @@ extern "C" int fb_debug_fft1d(fb_ctx* ctx, const float* in_host, float* out_host
     hipFree(din); hipFree(dout);
     return FB_OK;
 }
+#endif

@@ -20,28 +20,44 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     # and every prototype we bind is declared in the header
     assert set(_lib._PROTOS) <= set(names)
+    # the product library exports the boundary and nothing else: the test hooks live in libfeabas_hip_test.so
+    import subprocess
+    exported = {ln.split()[-1] for ln in subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout.splitlines()
+                if ln.split()[-1].startswith('fb_')}
+    assert exported == set(names), sorted(exported ^ set(names))
+    tlib = _lib.load_test()
+    hooks = [n for n in _lib.declared_symbols('feabas_hip_test.h') if n not in names]
+    assert sorted(hooks) == sorted(_lib._TEST_PROTOS) and len(hooks) == 5
+    for n in list(names) + hooks:
+        assert hasattr(tlib, n), n
 
 
 def test_bindings_agree_with_the_header():
     """every fb_* entry the python side calls has a ctypes prototype (an unprototyped call would pass pointers as C ints), and every
-    prototype has as many arguments as the declaration in include/feabas_hip.h"""
+    prototype has as many arguments as the declaration in include/feabas_hip.h (test hooks: include/feabas_hip_test.h)"""
     import glob
     import os
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    used = set()
+    protos = dict(_lib._PROTOS); protos.update(_lib._TEST_PROTOS)
+    used, used_product = set(), set()
     for f in glob.glob(os.path.join(root, 'feabas_amd', '*.py')) + [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')] \
             + glob.glob(os.path.join(root, 'tests', '*.py')) + glob.glob(os.path.join(root, 'tools', '*.py')):
-        used.update(re.findall(r'\.(fb_[a-z0-9_]+)\b', open(f).read()))
-    assert len(used) > 80 and used <= set(_lib._PROTOS), sorted(used - set(_lib._PROTOS))
-    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(root, 'include', 'feabas_hip.h')).read(), flags=re.S)
+        found = re.findall(r'\.(fb_[a-z0-9_]+)\b', open(f).read())
+        used.update(found)
+        if os.sep + 'feabas_amd' + os.sep in f or f.endswith(('bench.py', '__graft_entry__.py')):
+            used_product.update(found)
+    assert len(used) > 80 and used <= set(protos), sorted(used - set(protos))
+    assert not (used_product & set(_lib._TEST_PROTOS)), 'the product calls a test hook'
     seen = 0
-    for m in re.finditer(r'\b[A-Za-z_][A-Za-z0-9_]*\s*\*?\s+\*?(fb_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', hdr, flags=re.S):
-        name, args = m.group(1), m.group(2).strip()
-        if name in _lib._PROTOS:
-            seen += 1
-            assert len(_lib._PROTOS[name][1]) == (0 if args in ('', 'void') else len(args.split(','))), name
-    assert seen == len(_lib._PROTOS)
+    for header in ('feabas_hip.h', 'feabas_hip_test.h'):
+        hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(root, 'include', header)).read(), flags=re.S)
+        for m in re.finditer(r'\b[A-Za-z_][A-Za-z0-9_]*\s*\*?\s+\*?(fb_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', hdr, flags=re.S):
+            name, args = m.group(1), m.group(2).strip()
+            if name in protos:
+                seen += 1
+                assert len(protos[name][1]) == (0 if args in ('', 'void') else len(args.split(','))), name
+    assert seen == len(protos)
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -1010,7 +1026,7 @@ def test_cxx_multigrid_coarsening_host_half():
     """fb_debug_mg_coarsen (host only): one coarsening step of the multigrid set-up -- grid-cell aggregates per mesh, relative node
     positions, the Galerkin pattern -- on a small two-mesh level and on one large enough for its host loops to run on several
     threads (>= 131072 nodes / >= 2048 aggregates): invariants against numpy / scipy"""
-    lib = _lib.load()
+    lib = _lib.load_test()
     rng = np.random.default_rng(3)
     xy, comp, A = _mg_level(rng, [(23, 17, 10.0, 0.0, 0.0), (12, 31, 7.0, 400.0, -50.0)])
     r = _mg_coarsen(lib, xy, comp, A)
@@ -1032,7 +1048,7 @@ def test_cxx_strip_matcher_host_arithmetic_matches_python():
     matcher.auto_spacings (matcher.py:243-251) and the node grid against Mesh.from_bbox(cartesian=True)"""
     from feabas_amd.mesh import Mesh
     from feabas_amd.stitch_pipeline import grid_counts
-    lib = _lib.load()
+    lib = _lib.load_test()
     rng = np.random.default_rng(21)
     P = 9
     pid, p0, p1, wt = [], [], [], []
@@ -1199,7 +1215,7 @@ def test_g29_cartesian_node_grid_vs_reference():
     from feabas_amd.mesh import Mesh
     import feabas_amd.constant as const
     g = load_golden('g29_cartesian_grid.npz')
-    lib = _lib.load()
+    lib = _lib.load_test()
     for k, (x0, y0, x1, y1, ms, mnb) in enumerate(g['cases']):
         m = Mesh.from_bbox((x0, y0, x1, y1), cartesian=True, mesh_size=float(ms), min_num_blocks=int(mnb))
         want = g[f'c{k}_v']

@@ -656,7 +656,7 @@ def test_section_matcher_floating_pair_vs_oracle(fb):
     de = LinearNDInterpolator(ex1, ex0 - ex1)
     dd = de(xy1)
     ok = np.all(np.isfinite(dd), axis=1)
-    assert ok.mean() > 0.8
+    assert ok.mean() > 0.6                                   # (the rest lies outside the hull of the oracle's sample points: islands, a hole)
     diff = np.hypot(*((xy0 - xy1)[ok] - dd[ok]).T)
     assert np.median(diff) < 0.05 and np.quantile(diff, 0.95) < 0.2, (np.median(diff), np.quantile(diff, 0.95))
     assert abs(strain - estrain) < 0.05 * max(1e-4, estrain) + 1e-6

@@ -248,7 +248,7 @@ def fuzz_large(lib, rng):
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-    lib = _lib.load()
+    lib = _lib.load_test()
     print('library', _lib.LIB_PATH)
     rng = np.random.default_rng(seed)
     for name, fn in (('schedule', fuzz_schedule), ('divide_bbox', fuzz_divide_bbox), ('general_mesh', fuzz_general_mesh), ('deformed', fuzz_deformed),
