@@ -10,6 +10,7 @@ _tc = {}
 def _test_lib_and_ctx():
     """fb_debug_fft1d lives in the test build of the library (include/feabas_hip_test.h) and takes a context of THAT instance"""
     if not _tc:
+        from feabas_amd import _lib
         lib = _lib.load_test()
         h = lib.fb_create(0)
         assert h
