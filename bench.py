@@ -1294,6 +1294,29 @@ def main():
         line['host_ingest']['ragged'] = dict(value=len(ragged) / dtr, unit='pairs/s', pairs=len(ragged), distinct_shapes=len({a.shape for a, _ in ragged}),
                                              matched=int(sum(o[0] is not None for o in outr)),
                                              note=f'every pair cropped to its own strip size (up to 29 x 11 px smaller); {RB}-pair chunks of unequal strips dealt to {RT} host threads; best of two passes after a set-up pass')
+        # the ragged list again with masks on every 8th pair (tiles with an artefact: stitcher.py:561-571 hands their masks over): since
+        # round 6 masked pairs ride in the ragged chunks of their neighbours instead of in per-shape chunks of their own
+        try:
+            masked = []
+            for k, (a, b) in enumerate(ragged):
+                if k % 8 == 0:
+                    mk = np.ones(a.shape, dtype=bool)
+                    mk[: a.shape[0] // 16, : a.shape[1] // 3] = False
+                    masked.append((a, b, mk, mk.copy()))
+                else:
+                    masked.append((a, b))
+            fmatcher.stitching_matcher_batch(masked, batch=RB, threads=RT, **cfg)
+            dtm = np.inf
+            for _ in range(2):
+                t0 = time.time()
+                outm = fmatcher.stitching_matcher_batch(masked, batch=RB, threads=RT, **cfg)
+                dtm = min(dtm, time.time() - t0)
+            line['host_ingest']['ragged']['with_masks'] = dict(value=len(masked) / dtm, unit='pairs/s', pairs=len(masked), masked_pairs=len(masked[::8]),
+                                                               matched=int(sum(o[0] is not None for o in outm)),
+                                                               note='the ragged list with masks on every 8th pair (both strips): masked pairs go through the ragged chunks of their neighbours')
+            del masked, outm
+        except Exception as e:                              # noqa: BLE001 -- a side record
+            line['host_ingest']['ragged']['with_masks'] = dict(error=f'{type(e).__name__}: {e}')
         fmatcher.stitching_matcher_batch_release()
         del h0, h1, host_pairs, outp, ragged, outr
     if rank == 0 and world == 1 and not args.no_align:

@@ -802,6 +802,16 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     // with its CU neighbour's FFT); FB_P2_SLOTS=k runs k persistent workgroups per CU with register prefetch instead
     const int slots_per_cu = getenv("FB_P2_SLOTS") ? atoi(getenv("FB_P2_SLOTS")) : 0;
     const int wg_slots = slots_per_cu > 0 ? slots_per_cu * ctx->prop.multiProcessorCount : (1 << 30);
+    // FEABAS_HIP_P2_XCD: bit 0 rows, bit 1 columns, bit 2 inverse rows -- the items of the pass in one contiguous eighth per XCD
+    // (fb_ncc_p2.inc: p2_item); default 7.  Only for the one-workgroup-per-item launches.
+    static const int xcd_mask = [] { const char* e = getenv("FEABAS_HIP_P2_XCD"); return e ? atoi(e) : 7; }();
+    q.per8 = 0;
+    auto xcd_grid = [&](int bit, int total, int grid) {       // grid of the launch; sets q.per8
+        q.per8 = 0;
+        if (!(xcd_mask & bit) || grid != total || total < 64) return grid;
+        q.per8 = (total + 7) / 8;
+        return 8 * q.per8;
+    };
     if (p2) {
         rc = get_tw16_table(ctx, Fw, &q.twW);
         if (rc) return rc;
@@ -820,7 +830,7 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
         FB_PROF_B(ctx, "ncc_stream_rows", nb * (in_bytes + 16.0 * g.Sw * g.Hs));
         if (p2) {
             q.tiles = g.Hs / g.TR; q.total = q.tiles * nb;
-            FB_P2_SWITCH(Fw, rows(ctx->stream, std::min(q.total, wg_slots), lds_rows2, g, q, T0, T1));
+            { const int grid = xcd_grid(1, q.total, std::min(q.total, wg_slots)); FB_P2_SWITCH(Fw, rows(ctx->stream, grid, lds_rows2, g, q, T0, T1)); }
         } else hipLaunchKernelGGL(ncc_stream_rows, dim3(g.Hs / g.TR, nb), dim3(kStreamThreads), lds_rows, ctx->stream, g, T0, T1);
     }
     {
@@ -829,21 +839,21 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
             q.tiles = (g.Kp + p2_np(Fh) - 1) / p2_np(Fh); q.total = q.tiles * nb;       // groups of column pairs
             // zero-padded columns (every padded correlation) take the direct form: first pass from HBM, last pass to HBM
             const bool direct = 2 * g.Hs <= Fh && Fh >= 256 && slots_per_cu == 0 && !(getenv("FB_COLS_STAGED") && atoi(getenv("FB_COLS_STAGED")));
-            if (direct) { FB_P2_SWITCH(Fh, cols2(ctx->stream, q.total, lds_cols2, g, q, T0, T1, V0, V1)); }
-            else { FB_P2_SWITCH(Fh, cols(ctx->stream, std::min(q.total, wg_slots), lds_cols2, g, q, T0, T1, V0, V1)); }
+            if (direct) { const int grid = xcd_grid(2, q.total, q.total); FB_P2_SWITCH(Fh, cols2(ctx->stream, grid, lds_cols2, g, q, T0, T1, V0, V1)); }
+            else { const int grid = xcd_grid(2, q.total, std::min(q.total, wg_slots)); FB_P2_SWITCH(Fh, cols(ctx->stream, grid, lds_cols2, g, q, T0, T1, V0, V1)); }
         } else hipLaunchKernelGGL(ncc_stream_cols, dim3(g.Kp, nb), dim3(kStreamThreads), lds_cols, ctx->stream, g, T0, T1, V0, V1);
     }
     {
         FB_PROF_B(ctx, "ncc_stream_inv", (double)nb * g.Sw * 8.0 * nq * Fh);
         if (p2) {
             q.tiles = ntiles; q.total = ntiles * nb;
-            FB_P2_SWITCH(Fw, inv(ctx->stream, std::min(q.total, wg_slots), lds_inv2, g, q, V0, V1, part));
+            { const int grid = xcd_grid(4, q.total, std::min(q.total, wg_slots)); FB_P2_SWITCH(Fw, inv(ctx->stream, grid, lds_inv2, g, q, V0, V1, part)); }
         } else hipLaunchKernelGGL(ncc_stream_inv, dim3(ntiles, nb), dim3(kStreamThreads), lds_inv, ctx->stream, g, V0, V1, part, nullptr, 0, nullptr);
     }
     if (subpixel) {
         FB_PROF(ctx, "ncc_stream_neighbors");
         const size_t lds_n = ((size_t)4 * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
-        if (p2) { FB_P2_SWITCH(Fw, neigh(ctx->stream, nb, lds_n2, g, q, V0, V1, part, ntiles, ct9)); }
+        if (p2) { q.per8 = 0; FB_P2_SWITCH(Fw, neigh(ctx->stream, nb, lds_n2, g, q, V0, V1, part, ntiles, ct9)); }
         else hipLaunchKernelGGL(ncc_stream_inv, dim3(1, nb), dim3(kStreamThreads), lds_n, ctx->stream, g, V0, V1, nullptr, part, ntiles, ct9);
     }
     {

@@ -832,6 +832,8 @@ class SLM:
         if not np.all(np.isfinite(dd)):
             self.last_solve['rejected'] = 'not finite'
             return False
+        if float(np.max(np.abs(dd), initial=0.0)) <= 1e3:
+            return True                                       # (extent >= 1: nothing this small is screened -- the common case, no further pass)
         locks = np.asarray(self.lock_flags, dtype=bool)
         labels, _ = self.connected_subsystems
         floating = ~np.isin(labels, labels[locks]) & ~locks
