@@ -1169,7 +1169,7 @@ def main():
         if cal:
             mix = {'ncc_stream_cols': '1r_2w', 'ncc_stream_rows': '1r_2w', 'ncc_stream_inv': 'read', 'dog_fast': 'write', 'ncc_small_fused': 'read'}
             roof['hbm_calibration_gbs'] = cal
-            roof['hbm_calibration_note'] = ('plain streaming kernels, 1 GiB per stream, measured in this run; frac_of_calibrated = achieved / the rate '
+            roof['hbm_calibration_note'] = ('plain streaming kernels (one contiguous run per workgroup: the form with the best store rate, tools/hbm_store_probe.hip), 1 GiB per stream, measured in this run; frac_of_calibrated = achieved / the rate '
                                             'of the mix the dominant kernel has (ncc_cols: reads 16 S_h, writes 16 S = 1 : 2)')
             if dom[0] in mix and mix[dom[0]] in cal and roof.get('achieved'):
                 roof['frac_of_calibrated'] = roof['achieved'] / cal[mix[dom[0]]]

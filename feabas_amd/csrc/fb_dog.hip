@@ -571,7 +571,7 @@ inline TapsP<R> pack_taps(const Taps& taps) {
 template <typename T, int R, int NT, bool DS2 = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= FB_DOG_R4 ? 4 : (R <= 12 ? 3 : 2)))) void dog_stream(const T* __restrict__ img, float* __restrict__ out, int SH, int SW, int signed_out,
                                                 const int* __restrict__ sizes, const TapsP<R> taps, int TX, int SY, int H2 = 0, int W2 = 0,
-                                                const T* __restrict__ img1 = nullptr, int nsplit = 0x7fffffff) {
+                                                const T* __restrict__ img1 = nullptr, int nsplit = 0x7fffffff, int per8 = 0, int gx = 1, int gy = 1, int gz = 1) {
     constexpr int CH = SCH, RN = SRN;
     static_assert(CH % 2 == 0 && RN % 2 == 0, "pairs");
     constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
@@ -580,7 +580,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(R <= FB_DOG_
     float* In = smem;                    // [2][CH][PI]  input rows (float), column i <-> global x0 - 2R + i
     float* A = In + 2 * CH * PI;         // [CH][PA]     A = Gx I,           column i <-> global x0 - R + i
     float* E = A + CH * PA;              // [CH][PE]     E = Gy (I - Gy A),  column i <-> global x0 - R + i
-    const int n = blockIdx.z, x0 = blockIdx.x * TX, y0 = blockIdx.y * SY;
+    // per8 > 0: a launch of 8 * per8 workgroups in one dimension; workgroup b takes item (b % 8) * per8 + b / 8 of the
+    // (band, segment, image) list -- every XCD (workgroups are dealt to them round-robin) filters a contiguous run of whole
+    // images, so the bands of a row meet in ONE L2 before they go to memory (fb_ncc_p2.inc: p2_item has the measurement)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (per8 > 0) {
+        const int w = (int)(blockIdx.x & 7) * per8 + (int)(blockIdx.x >> 3);
+        if (w >= gx * gy * gz) return;
+        bx = w % gx; by = (w / gx) % gy; bz = w / (gx * gy);
+    }
+    const int n = bz, x0 = bx * TX, y0 = by * SY;
     const int H = sizes ? sizes[2 * n] : SH, W = sizes ? sizes[2 * n + 1] : SW;
     const int tid = threadIdx.x;
     float* __restrict__ oimg = out + (size_t)n * SH * SW;
@@ -822,6 +831,16 @@ inline StreamPlan plan_stream(int N, int H, int W, int R, int num_cu) {
     return best;
 }
 
+// FEABAS_HIP_DOG_XCD=1: one contiguous eighth of the (band, segment, image) grid per XCD instead of launch order.  Off by default:
+// measured 8.99 -> 8.86 ms of DoG per 512 pairs and no change of the headline (profiles/r06j_dog_xcd_ab.txt) -- the kernel is
+// bound by its taps, not by its stores.
+inline int dog_xcd_per8(int gx, int gy, int gz) {
+    static const int on = [] { const char* e = getenv("FEABAS_HIP_DOG_XCD"); return e ? atoi(e) : 0; }();
+    const long long total = (long long)gx * gy * gz;
+    if (!on || total < 64 || total > (1LL << 30)) return 0;
+    return (int)((total + 7) / 8);
+}
+
 template <int R, int NT>
 int launch_stream_ds2_nt(fb_ctx* ctx, const uint8_t* img, float* out, int N, int H2, int W2, int signed_out, const TapsP<R>& tf, const StreamPlan& pl) {
     constexpr int PI = spitch(NT + 2 * R + 4), PA = spitch(NT), PE = spitch(NT + 4);
@@ -829,8 +848,10 @@ int launch_stream_ds2_nt(fb_ctx* ctx, const uint8_t* img, float* out, int N, int
     auto kern = dog_stream<uint8_t, R, NT, true>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(pl.nb, pl.nseg, N);
+    const int per8 = dog_xcd_per8(pl.nb, pl.nseg, N);
+    if (per8 > 0) grid = dim3(8 * per8, 1, 1);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, half_size(H2), half_size(W2), signed_out, (const int*)nullptr, tf, pl.TX, pl.SY, H2, W2,
-                       (const uint8_t*)ctx->dog_img1, ctx->dog_img1 ? ctx->dog_nsplit : 0x7fffffff);
+                       (const uint8_t*)ctx->dog_img1, ctx->dog_img1 ? ctx->dog_nsplit : 0x7fffffff, per8, pl.nb, pl.nseg, N);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
@@ -851,8 +872,10 @@ int launch_stream_nt(fb_ctx* ctx, const T* img, float* out, int N, int H, int W,
     auto kern = dog_stream<T, R, NT>;
     FB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(pl.nb, pl.nseg, N);
+    const int per8 = dog_xcd_per8(pl.nb, pl.nseg, N);
+    if (per8 > 0) grid = dim3(8 * per8, 1, 1);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, img, out, H, W, signed_out, sizes, tf, pl.TX, pl.SY, 0, 0, (const T*)ctx->dog_img1,
-                       ctx->dog_img1 ? ctx->dog_nsplit : 0x7fffffff);
+                       ctx->dog_img1 ? ctx->dog_nsplit : 0x7fffffff, per8, pl.nb, pl.nseg, N);
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }

@@ -139,8 +139,8 @@ struct fb_strip_matcher {
     std::vector<double> U;
     std::vector<uint8_t> is_def;
     std::vector<std::vector<int32_t>> tiers;
-    void* scr[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t b_scr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void* scr[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t b_scr[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // extras of the NEXT fb_match_strips call (fb_strip_matcher_set_extras): valid-pixel masks of the strips (host pointers,
     // NULL = none; matcher.py:257-274, 336-337) and the photometric statistics of matcher.py:279-314
     std::vector<const uint8_t*> mask0, mask1;
@@ -392,6 +392,7 @@ enum : int {
     kScrAff = 0,                                                     // affine maps of a deformed group [nb][10] f64
     kScrIds = 1, kScrOrg = 2, kScrMapX = 3, kScrMapY = 4, kScrMapMask = 5, kScrStack = 6, kScrExactOut = 7,   // exact-field tier
     kScrMaskCoarse = 8, kScrMaskFine0 = 9, kScrMaskFine1 = 10, kScrRaw = 11,                                   // masks, statistics
+    kScrDenseIn = 12, kScrDenseOut = 13,                             // a masked image of a ragged batch, copied out of its slot
     kScrTxy = kScrIds, kScrHas = kScrOrg, kScrPart = kScrMapX        // photometric statistics (before any deformed round runs)
 };
 int scratch(fb_ctx* ctx, fb_strip_matcher* m, int k, size_t bytes, void** out) {
@@ -971,7 +972,7 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
     bool any_mask = false;
     for (const uint8_t* q : mask0) any_mask |= q != nullptr;
     for (const uint8_t* q : mask1) any_mask |= q != nullptr;
-    if ((any_mask || want_phtm) && m->ragged) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: masks / photometric statistics are not taken on strips of unequal size");
+    if (want_phtm && m->ragged) return fb_fail(ctx, FB_ERR_ARG, "fb_match_strips: photometric statistics are not taken on strips of unequal size");
     if (!m->ragged) {
         const bool extras = any_mask || want_phtm;
         uint8_t* d_maskc = nullptr;                          // coarse masks [2n][hc][wc] of the masked images
@@ -1090,6 +1091,38 @@ int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, co
         } else {
             if ((rc = fb_dog_sizes_dev(ctx, strips0, 0, n, hc, wc, m->d_sizes_c, m->sigma, 1, m->d_dogc))) return rc;
             if ((rc = fb_dog_sizes_dev(ctx, strips1, 0, n, hc, wc, m->d_sizes_c, m->sigma, 1, m->d_dogc + n * cpix))) return rc;
+        }
+        if (any_mask) {
+            // masked images of a ragged batch (mask p: a contiguous uint8 array of the pair's OWN shape [Hs[p]][Ws[p]]): their DoG again
+            // with the halo suppression of common.py:368-374 -- the image is copied out of its slot dense, filtered like the uniform
+            // branch filters a whole slot, and copied back into the same corner of its float slot.  Coarse mask = every second pixel
+            // (cv2.resize(mask, fx=0.5, INTER_NEAREST), matcher.py:257-264), fine DoG with the full-resolution mask (336-337).
+            void *d_in = nullptr, *d_o = nullptr, *d_mk = nullptr;
+            if ((rc = scratch(ctx, m, kScrDenseIn, fpix, &d_in)) || (rc = scratch(ctx, m, kScrDenseOut, 4 * fpix, &d_o)) || (rc = scratch(ctx, m, kScrMaskFine0, fpix, &d_mk))) return rc;
+            std::vector<uint8_t> mb(fpix);
+            for (int side = 0; side < 2; ++side)
+                for (int p = 0; p < n; ++p) {
+                    const uint8_t* mk = (side ? mask1 : mask0).empty() ? nullptr : (side ? mask1 : mask0)[p];
+                    if (!mk) continue;
+                    const size_t img = (size_t)side * n + p;
+                    const int Hp = m->Hs[p], Wp = m->Ws[p], hp = m->hcs[p], wp = m->wcs[p];
+                    const int st = m->cds2 ? 2 : 1;
+                    // coarse
+                    for (int y = 0; y < hp; ++y)
+                        for (int x = 0; x < wp; ++x) mb[(size_t)y * wp + x] = mk[(size_t)(st * y) * Wp + st * x] != 0;
+                    if ((rc = fb_memcpy_h2d(ctx, d_mk, mb.data(), (size_t)hp * wp))) return rc;
+                    const uint8_t* src = m->cds2 ? m->d_small + img * cpix : (side ? strips1 : strips0) + (size_t)p * fpix;
+                    if ((rc = fb_memcpy2d_d2d(ctx, d_in, (size_t)wp, src, (size_t)wc, (size_t)wp, (size_t)hp))) return rc;
+                    if ((rc = fb_dog_dev(ctx, d_in, 0, 1, hp, wp, m->cds2 ? m->sigma * 0.5 : m->sigma, (const uint8_t*)d_mk, 1, (float*)d_o))) return rc;
+                    if ((rc = fb_memcpy2d_d2d(ctx, m->d_dogc + img * cpix, 4 * (size_t)wc, d_o, 4 * (size_t)wp, 4 * (size_t)wp, (size_t)hp))) return rc;
+                    if (!m->cds2) continue;
+                    // fine
+                    for (size_t k = 0; k < (size_t)Hp * Wp; ++k) mb[k] = mk[k] != 0;
+                    if ((rc = fb_memcpy_h2d(ctx, d_mk, mb.data(), (size_t)Hp * Wp))) return rc;
+                    if ((rc = fb_memcpy2d_d2d(ctx, d_in, (size_t)Wp, (side ? strips1 : strips0) + (size_t)p * fpix, (size_t)W, (size_t)Wp, (size_t)Hp))) return rc;
+                    if ((rc = fb_dog_dev(ctx, d_in, 0, 1, Hp, Wp, m->sigma, (const uint8_t*)d_mk, 1, (float*)d_o))) return rc;
+                    if ((rc = fb_memcpy2d_d2d(ctx, m->d_dogf + img * fpix, 4 * (size_t)W, d_o, 4 * (size_t)Wp, 4 * (size_t)Wp, (size_t)Hp))) return rc;
+                }
         }
         clk.lap(0);
         // whole-strip NCC (matcher.py:153) through block descriptors, one launch per padded FFT shape

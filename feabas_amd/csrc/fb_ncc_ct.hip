@@ -127,7 +127,13 @@ __global__ __launch_bounds__(kCtThreads) void ncc_cols_ct(const StreamGeom g, co
     constexpr int pitch = ct_pitch(FH), NP = ct_np(FH), NE = NP * 2 * FH, NU = (NE + kCtThreads - 1) / kCtThreads;
     f2* U = reinterpret_cast<f2*>(lds);         // [NP][4][pitch]: (img0,c0) (img0,c1) (img1,c0) (img1,c1) per column pair
     f2* tw = U + (size_t)4 * NP * pitch;
-    const int kp0 = blockIdx.x * NP, n = blockIdx.y;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (g.xg_per8 > 0) {                       // adjacent column groups write adjacent runs of V: one contiguous eighth of the items per XCD
+        const int w = (int)(blockIdx.x & 7) * g.xg_per8 + (int)(blockIdx.x >> 3);
+        if (w >= g.xg_gx * g.xg_gy) return;
+        bx = w % g.xg_gx; by = w / g.xg_gx;
+    }
+    const int kp0 = bx * NP, n = by;
     const int tid = threadIdx.x;
     const int Hs = g.Hs, Kp = g.Kp;
     ct_tables<FH>(tw, nullptr, tw_g, tid, kCtThreads);
@@ -391,7 +397,14 @@ int fb_ncc_ct_run(fb_ctx* ctx, const StreamGeom& g, int nb, float2* T0, float2* 
     {
         FB_PROF_B(ctx, "ncc_stream_cols", (double)nb * g.Sw * (16.0 * g.Hs + 8.0 * nq * Fh));
         const int np = Fh >= 1024 ? 1 : 1024 / Fh;
-        FB_CT_SWITCH(Fh, cols(ctx, dim3((g.Kp + np - 1) / np, nb), g, twH, T0, T1, V0, V1));
+        static const int xcd_mask = [] { const char* e = getenv("FEABAS_HIP_P2_XCD"); return e ? atoi(e) : 7; }();
+        StreamGeom gc = g;
+        dim3 grid((g.Kp + np - 1) / np, nb);
+        if ((xcd_mask & 2) && (long long)grid.x * grid.y >= 64) {
+            gc.xg_gx = (int)grid.x; gc.xg_gy = (int)grid.y; gc.xg_per8 = (int)(((long long)grid.x * grid.y + 7) / 8);
+            grid = dim3(8 * gc.xg_per8, 1);
+        }
+        FB_CT_SWITCH(Fh, cols(ctx, grid, gc, twH, T0, T1, V0, V1));
         if (rc) return rc;
     }
     {

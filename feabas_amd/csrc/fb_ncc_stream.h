@@ -27,6 +27,7 @@ struct StreamGeom {
     int IH0, IW0, IH1, IW1;
     int want_q, want_std;
     const double* aff;            // per block affine gather of image 1 (crop mode only) or nullptr
+    int xg_per8 = 0, xg_gx = 1, xg_gy = 1;   // > 0: a 1-D launch of 8 * xg_per8 workgroups over the (xg_gx, xg_gy) items, one contiguous eighth per XCD (fb_ncc_p2.inc: p2_item)
 };
 
 constexpr int kStreamThreads = 512;

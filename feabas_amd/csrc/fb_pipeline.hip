@@ -67,10 +67,15 @@ __global__ void synth_strips_kernel(int P, int pair0, int H, int W, uint32_t see
     }
 }
 
-// plain streaming kernel: every element is read from NR streams and written to NW streams (unit stride across the grid)
+// plain streaming kernel: every element is read from NR streams and written to NW streams.  Every workgroup owns ONE contiguous
+// run of every stream: that is the form that reaches the best store rate on this device (5.6-6.0 TB/s against 4.2-4.8 with
+// the runs of a grid-strided loop interleaved over the XCDs: tools/hbm_store_probe.hip, profiles/r06g_hbm_store_probe.txt) --
+// the calibration is the rate to beat, so it uses the better form (until round 6 it used the grid-strided one).
 template <int NR, int NW>
 __global__ __launch_bounds__(256) void hbm_mix_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t end = min(n, (size_t)(blockIdx.x + 1) * per);
+    for (size_t i = (size_t)blockIdx.x * per + threadIdx.x; i < end; i += 256) {
         float4 acc = make_float4(1.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < NR; ++r) { const float4 v = src[(size_t)r * n + i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }

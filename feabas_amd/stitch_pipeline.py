@@ -881,11 +881,11 @@ class StripBatchMatcher:
         return nodes3, B1
 
     def match(self, strips0, strips1, masks0=None, masks1=None, compute_photometric=False):
-        """stitching_matcher for the P resident pairs; see `_match_host` for the arguments and the result.  Unmasked
-        batches go through fb_match_strips (one C entry for the whole sequence, the deformed-mesh branch included); the
-        pairs it hands back (flags != 0: relax_first, folded block of a deformed mesh, degenerate rigid fit) and masked /
-        photometric batches of unequal strips take the numpy statement of the same sequence."""
-        if self._route == 'native' and (not self._ragged or (masks0 is None and masks1 is None and not compute_photometric)):
+        """stitching_matcher for the P resident pairs; see `_match_host` for the arguments and the result.  Batches go through
+        fb_match_strips (one C entry for the whole sequence, masks and the deformed-mesh branch included); the pairs it hands back
+        (flags != 0: relax_first, folded block of a deformed mesh, degenerate rigid fit) and photometric batches of unequal strips
+        take the numpy statement of the same sequence."""
+        if self._route == 'native' and (not self._ragged or not compute_photometric):
             if self._prefer_host:
                 # the entry handed back most pairs of the last batch: this one takes the host statement directly, the next
                 # one tries the entry again
@@ -935,8 +935,11 @@ class StripBatchMatcher:
         arrs = [None, None]
         if masks is not None:
             for side in (0, 1):
-                if any(mk.shape != (self.H, self.W) for mk in masks[side] if mk is not None):
-                    raise ValueError(f'masks must have the shape of the strips, {self.H} x {self.W}')
+                for p, mk in enumerate(masks[side]):
+                    # (a ragged batch: the mask of pair p has the pair's own shape, one contiguous array)
+                    want = (int(self._Hs[p]), int(self._Ws[p])) if self._ragged else (self.H, self.W)
+                    if mk is not None and mk.shape != want:
+                        raise ValueError(f'the mask of pair {p} must have the shape of its strip, {want[0]} x {want[1]}')
                 arrs[side] = (C.c_void_p * n)(*[None if mk is None else mk.ctypes.data for mk in masks[side]])
         # always stated: the extras belong to the call that follows, and a call that never happened (an exception in between)
         # must not leave its mask pointers behind
