@@ -373,6 +373,42 @@ def bench_section_matcher(lib, ctx, _lib, S=8192, mesh_size=100.0, reps=3, confi
         dt = time.time() - t0
         if dt < best:
             best, out = dt, (xy0, xy1, trace)
+    # throughput: the aligner matches many section pairs (align_main --mode matching deals them to workers): T host threads with a
+    # context (stream) each run the same pair concurrently -- the kernels and copies of one thread's call run while another
+    # thread is in python between two entries (27 of the 56-62 ms of a call are, tools/bench_section_matcher.py --entries)
+    conc = None
+    if config is None:
+        try:
+            import threading
+            T, R = 4, 3
+            ctxs = [_lib.ctx()] + [_lib.new_context() for _ in range(T - 1)]
+            errs, counts = [], [0] * T
+
+            def worker(t_):
+                try:
+                    with _lib.using(ctxs[t_]):
+                        for _ in range(R):
+                            a, b = meshes[0].copy(), meshes[1].copy()
+                            r_ = fmatcher.section_matcher(a, b, images[0], images[1], spacings=[280, 70], conf_thresh=0.3, residue_len=3.0)
+                            counts[t_] += int(r_[0] is not None)
+                except Exception as e:                      # noqa: BLE001 -- a side record
+                    errs.append(e)
+            for rep in range(2):                            # first pass: per-context code objects and arenas
+                counts = [0] * T
+                ths = [threading.Thread(target=worker, args=(t_,)) for t_ in range(T)]
+                t0 = time.time()
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                dtc = time.time() - t0
+            for h_ in ctxs[1:]:
+                _lib.destroy_context(h_)
+            conc = dict(error=f'{type(errs[0]).__name__}: {errs[0]}') if errs else dict(
+                value=sum(counts) / dtc, unit='section pairs/s', host_threads=T, pairs=sum(counts), seconds=dtc,
+                note='the same pair matched by T host threads at once, one context (stream) each: throughput of the matching stage of a stack, not the latency of a pair')
+        except Exception as e:                              # noqa: BLE001 -- a side record
+            conc = dict(error=f'{type(e).__name__}: {e}')
     for im in images:
         im.free()
     xy0, xy1, trace = out
@@ -380,7 +416,7 @@ def bench_section_matcher(lib, ctx, _lib, S=8192, mesh_size=100.0, reps=3, confi
     err = np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)
     return dict(value=1.0 / best, unit='section pairs/s', ms_per_pair=1e3 * best, image=[S, S], triangles=[int(m.num_triangles) for m in meshes],
                 vertices=[int(m.num_vertices) for m in meshes], matches=int(xy0.shape[0]),
-                median_error_px=float(np.median(err)), p95_error_px=float(np.quantile(err, 0.95)),
+                median_error_px=float(np.median(err)), p95_error_px=float(np.quantile(err, 0.95)), concurrent=conc,
                 rounds=[dict(blocks=int(r['blocks']), kept=int(r['kept']), max_dis=float(r['max_dis']), solve_iters=r.get('solve', {}).get('iters'),
                              precond=r.get('solve', {}).get('precond')) for r in trace],
                 config='spacings [280, 70], conf_thresh 0.3, residue_len 3, the other keywords at section_matcher\'s defaults' if config is None else config,

@@ -992,7 +992,7 @@ def stitching_matcher_batch_release(main=None):
             continue
         with _lib.using(slot.get('ctx')):                     # (the caller's own context is current again afterwards)
             st = slot.get('state', {})
-            for r in tuple(st.get('res', ())) + tuple(st.get('io', ())):
+            for r in tuple(st.get('matchers', {}).values()) + tuple(st.get('io', ())):
                 r.free()
             if 'pool' in st:
                 st['pool'].free()
@@ -1254,6 +1254,21 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
                 chunks.append(('uniform', items[part[0]][0].shape, part))
             else:
                 chunks.append(('ragged', key, part))
+    # fill and drain of the loader -> matcher pipeline: the first kernels wait for the first chunk's pack + copy (8 ms at 32 pairs of
+    # 4096 x 510) and the last chunk is matched (15 ms) while every other thread idles.  The first and the last few uniform chunks are
+    # therefore cut into quarters (a matcher keeps one StripBatchMatcher per chunk size): round 6, profiles/r06e_ingest_trace.txt.
+    nthr0 = max(1, min(int(threads), len(chunks)))
+    if nthr0 >= 3 and len(chunks) >= 4 * nthr0 and batch >= 16 and not os.environ.get('FEABAS_HIP_INGEST_NO_SPLIT'):
+        q = max(4, batch // 4)
+
+        def quarters(ch):
+            kind, what, idx = ch
+            if kind != 'uniform' or len(idx) <= q:
+                return [ch]
+            return [(kind, what, idx[c:c + q]) for c in range(0, len(idx), q)]
+        head = [piece for ch in chunks[:nthr0] for piece in quarters(ch)]
+        tail = [piece for ch in chunks[-nthr0:] for piece in quarters(ch)]
+        chunks = head + chunks[nthr0:-nthr0] + tail
     results = [None] * len(items)
     errors = []
     deferred = []
@@ -1340,11 +1355,14 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
     def match_chunk(state, chunk, dev, n, Hm, Wm):
         kind, what, idx = chunk
         if kind == 'uniform':
-            if state.get('key') != (what, n, okey):
-                if 'res' in state:
-                    state.pop('res')[0].free()
-                state.update(key=(what, n, okey), res=(StripBatchMatcher(n, Hm, Wm, pool=state['pool'], **opts),))
-            m = state['res'][0]
+            cache = state.setdefault('matchers', {})           # (shape, pairs, options) -> StripBatchMatcher, the two used last
+            key = (what, n, okey)
+            m = cache.pop(key, None)
+            if m is None:
+                while len(cache) >= 2:
+                    cache.pop(next(iter(cache))).free()
+                m = StripBatchMatcher(n, Hm, Wm, pool=state['pool'], **opts)
+            cache[key] = m
         else:
             m = RaggedStripBatchMatcher([items[k][0].shape for k in idx], pool=state['pool'], **opts)
         mk0 = [items[k][2] for k in idx]
