@@ -953,9 +953,9 @@ def test_context_destroy_hooks_empty_the_matcher_caches(monkeypatch):
     monkeypatch.setattr(fm, '_pair_matchers', {('k1', id(ha)): Thing('pair_a'), ('k2', id(hb)): Thing('pair_b')})
     monkeypatch.setattr(fm, '_pools', {id(ha): Thing('pool_a'), id(hb): Thing('pool_b')})
     monkeypatch.setattr(fm, '_batch_workers', {(id(ha), 'slots'): dict(io=[(Thing('pin_a'), Thing('dev_a'))]),
-                                               (id(ha), 0): dict(ctx=ha, state=dict(res=(Thing('matcher_a0'),), pool=Thing('wpool_a0'))),
-                                               (id(ha), 1): dict(ctx=hw, state=dict(res=(Thing('matcher_a1'),))),
-                                               (id(hb), 0): dict(ctx=hb, state=dict(res=(Thing('matcher_b0'),)))})
+                                               (id(ha), 0): dict(ctx=ha, state=dict(matchers={('k', 32): Thing('matcher_a0')}, pool=Thing('wpool_a0'))),
+                                               (id(ha), 1): dict(ctx=hw, state=dict(matchers={('k', 8): Thing('matcher_a1')})),
+                                               (id(hb), 0): dict(ctx=hb, state=dict(matchers={('k', 32): Thing('matcher_b0')}))})
     _lib.use_context(None)
     _lib.destroy_context(ha)
     names = [n for n, _ in log]
