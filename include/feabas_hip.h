@@ -414,9 +414,10 @@ int fb_strip_matcher_info(fb_ctx* ctx, fb_strip_matcher* m, int* nspacings, doub
 int fb_match_strips(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* strips0, const uint8_t* strips1, double* tx, double* ty,
                     float* conf0, uint8_t* valid, uint8_t* flags, double* strain, int64_t* nrows);
 int fb_match_strips_table(fb_ctx* ctx, fb_strip_matcher* m, int32_t* pair, double* xy0, double* xy1, float* weight);
-/* Extras of the NEXT fb_match_strips call on this matcher (equal strips only): masks0 / masks1 = P host pointers each (the
- * array or an entry may be NULL) to uint8 [H][W] valid-pixel masks, non-zero = valid -- the masked DoG of both scales
- * (matcher.py:257-274, 336-337; common.py:353-377); photometric != 0: the statistics of matcher.py:279-314, read afterwards
+/* Extras of the NEXT fb_match_strips call on this matcher: masks0 / masks1 = P host pointers each (the
+ * array or an entry may be NULL) to uint8 valid-pixel masks, non-zero = valid -- [H][W] on a matcher of equal strips, one
+ * contiguous array of the pair's own shape [Hs[p]][Ws[p]] on a ragged one (round 6) -- the masked DoG of both scales
+ * (matcher.py:257-274, 336-337; common.py:353-377); photometric != 0 (equal strips only): the statistics of matcher.py:279-314, read afterwards
  * with fb_match_strips_photometric: phtm [P][4] = mean grey level of the two coarse strips and mean |DoG| of the two filtered
  * ones over the overlap of the translated strips, has [P] = 0 where strip 0 has fewer than 4 valid pixels there (None). */
 int fb_strip_matcher_set_extras(fb_ctx* ctx, fb_strip_matcher* m, const uint8_t* const* masks0, const uint8_t* const* masks1, int photometric);
