@@ -924,7 +924,7 @@ void fb_strip_matcher_destroy(fb_ctx* ctx, fb_strip_matcher* m) {
     }
     pool_give(ctx, m->d_dogc, m->b_dogc); pool_give(ctx, m->d_dogf, m->b_dogf); pool_give(ctx, m->d_small, m->b_small);
     pool_give(ctx, m->d_blk, m->b_blk); pool_give(ctx, m->d_out, m->b_out); pool_give(ctx, m->d_sizes, m->b_sizes);
-    for (int k = 0; k < 12; ++k) pool_give(ctx, m->scr[k], m->b_scr[k]);
+    for (int k = 0; k < 14; ++k) pool_give(ctx, m->scr[k], m->b_scr[k]);
     delete m;
 }
 
