@@ -447,6 +447,9 @@ def _material_entry(mesh, uid, model, nu, mult, fk, area_constraint=1.0):
              'stiffness_multiplier': mult, 'poisson_ratio': nu, 'uid': int(uid)}
     if fk >= 0:
         f = mesh.stiffness_funcs[fk]
+        if not hasattr(f, 'strain'):
+            # (the reference serialises arbitrary callables with dill, common.func_to_str: not in the image)
+            raise NotImplementedError('a mesh file can carry piecewise-linear stiffness tables only; this mesh has a Python callable as stiffness function')
         entry['stiffness_multiplier'] = float(mesh.func_matmult[fk])
         entry['stiffness_func_factory'] = 'feabas.material.asymmetrical_elasticity'
         entry['stiffness_func_params'] = {'strain': f.strain.tolist(), 'stiffness': f.stiffness.tolist()}

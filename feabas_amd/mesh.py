@@ -13,6 +13,7 @@ from scipy import sparse
 from scipy.sparse import csgraph
 
 from . import _lib, common
+from .material import StiffnessTable
 from . import constant as const
 
 
@@ -645,6 +646,23 @@ class Mesh:
                           _lib.ptr(self.element_multiplier()), self.poisson_ratio, float(soft)))
         elif add:
             raise NotImplementedError('grouped meshes with non-linear materials')
+        elif self.tri_func is not None and not all(isinstance(f, StiffnessTable) for f in self.stiffness_funcs):
+            # a stiffness function that is not a table (any Python callable, material.py:128-131): evaluated on the host on the
+            # area stretch INITIAL -> current of its triangles (mesh.py:2937-2971) and handed over as the per-triangle material multiplier
+            v_init = np.ascontiguousarray(self.vertices(const.MESH_GEAR_INITIAL), dtype=np.float64)
+            a1 = common.signed_area(v_shape if v_cur is None else v_cur, self.triangles); a0 = common.signed_area(v_init, self.triangles)
+            lin = self.linear_triangle_mask
+            # mesh.py:2952-2963, 3030-3040: the stretch of a triangle relative to the ratio of the summed |areas| of the linear triangles
+            base = (np.sum(np.abs(a1[lin])) / np.sum(np.abs(a0[lin]))) if np.any(lin) else (np.sum(np.abs(a1)) / np.sum(np.abs(a0)))
+            J = (a1 / a0) / base
+            matmult = self.tri_matmult.astype(np.float64)
+            for k, f in enumerate(self.stiffness_funcs):
+                sel = self.tri_func == k
+                matmult[sel] = self.func_matmult[k] * np.asarray(f(J[sel]), dtype=np.float64).ravel()
+            _lib.check(lib.fb_sys_assemble_mesh_materials(ctx, sysh, mesh_id, _lib.ptr(v_shape), _lib.ptr(v_cur),
+                                                          _lib.ptr(np.ascontiguousarray(self.stiffness_multiplier, dtype=np.float32)),
+                                                          _lib.ptr(self.tri_model), _lib.ptr(self.tri_nu),
+                                                          _lib.ptr(np.ascontiguousarray(matmult, dtype=np.float32)), float(soft)))
         elif self.tri_func is not None:
             # stiffness follows the area stretch INITIAL -> current gear (mesh.py:2937-2971, 3026-3043)
             ptr = np.concatenate(([0], np.cumsum([f.strain.size for f in self.stiffness_funcs]))).astype(np.int32)

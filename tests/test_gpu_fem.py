@@ -561,6 +561,30 @@ def test_g19_area_stretch_stiffness_vs_reference(fb, case, tol):
         np.testing.assert_allclose(stress, g[f'{case}_{st}'], atol=max(5e-6 * np.abs(g[f'{case}_{st}']).max(), 1e-30))
 
 
+@pytest.mark.parametrize('case', ['wr', 'mix'])
+def test_g19_callable_stiffness_functions_vs_reference(fb, case):
+    """a stiffness function that is NOT a table (the reference takes any Python callable or 'lambda ...' string, material.py:128-131,
+    common.py:467-491): evaluated on the host on the area stretches and handed to the device as per-triangle multipliers.  The
+    tables of golden G19 wrapped into plain callables must give the REFERENCE's matrices again (to the float32 of the multiplier)"""
+    from conftest import load_golden
+    g = load_golden('g19_area_stretch.npz')
+    tabs = [fb.material.StiffnessTable(g[f'{case}_tab{k}_x'], g[f'{case}_tab{k}_y']) for k in range(int(g[f'{case}_ntab']))]
+    funcs = [(lambda x, t=t: t(x)) for t in tabs]
+    funcs[0] = 'lambda **kw: (lambda x: __import__("numpy").interp(x, %r, %r))' % (tabs[0].strain.tolist(), tabs[0].stiffness.tolist())    # a factory, as a string
+    func = g[f'{case}_func']
+    fmm = [float(g[f'{case}_matmult'][np.flatnonzero(func == k)[0]]) for k in range(len(tabs))]
+    m = fb.mesh.Mesh(g['v'].copy(), g[f'{case}_t'], stiffness_multiplier=g[f'{case}_mult'], tri_model=g[f'{case}_model'], tri_nu=g[f'{case}_nu'],
+                     tri_matmult=g[f'{case}_matmult'].astype(np.float32), tri_func=func, stiffness_funcs=funcs, func_matmult=fmm,
+                     moving_vertices=g['vmov'], uid=3)
+    assert not m.is_linear and not isinstance(m.stiffness_funcs[0], fb.material.StiffnessTable)
+    nd = 2 * g['v'].shape[0]
+    for tag, gear, st in (('K', (0, 1), 'stress'), ('K2', (1, 1), 'stress2')):
+        K, stress = m.stiffness_matrix(gear=gear)
+        Kg = _sp(g, f'{case}_{tag}', (nd, nd))
+        assert abs(K - Kg).max() <= 5e-6 * abs(Kg).max(), abs(K - Kg).max() / abs(Kg).max()
+        np.testing.assert_allclose(stress, g[f'{case}_{st}'], atol=max(5e-6 * np.abs(g[f'{case}_{st}']).max(), 1e-30))
+
+
 @pytest.mark.parametrize('case,call,tol', [
     ('nr', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=12, tol=1e-9), 1e-4),
     ('nr3', lambda slm: slm.optimize_Newton_Raphson(max_newtonstep=3, tol=1e-6), 1e-4),
