@@ -57,6 +57,9 @@ def main():
             prof.disable()
             pstats.Stats(prof).sort_stats('tottime').print_stats(22)
             pstats.Stats(prof).sort_stats('cumulative').print_stats(45)
+            pstats.Stats(prof).print_callers('reduce')
+            pstats.Stats(prof).print_callers('to_array')
+            pstats.Stats(prof).print_callers('from_array')
         ex, ey = field(xy1[:, 0], xy1[:, 1])
         err = np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)
         print(f'rep {rep}: {dt:.3f} s, rounds {[(r["blocks"], r["kept"], round(r["max_dis"], 2), r["solve"].get("iters")) for r in trace]}, '
