@@ -918,3 +918,34 @@ def test_pcg_asked_for_more_than_doubles_can_give_returns_its_best_iterate(fb, m
     assert not any(p == 1 for p, *_ in legs)                      # nothing floats: no deflated pass
     As = 0.5 * (Ad + Ad.T)                                       # (what the solver works on, optimizer.py:1955)
     assert np.linalg.norm(As @ x - bd) <= 1e-12 * np.linalg.norm(bd)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_pcg_floating_random_systems_vs_the_oracle_limit(fb, seed):
+    """random windows of three or four meshes of different sizes, linked in a chain or in two separate parts, WITHOUT a locked
+    mesh or with one that pins only one of the parts (the other floats: partial deflation -- the pinned part keeps comp = -1):
+    device PCG at 1e-12 against the oracle's limit (deflated dense solve, M-orthogonal to the floating translations)"""
+    from oracle import region_ref
+    rng = np.random.default_rng(100 + seed)
+    nmesh = 3 + seed % 2
+    meshes = []
+    for k in range(nmesh):
+        nx, ny = int(rng.integers(6, 14)), int(rng.integers(6, 14))
+        v, t = fem_ref.grid_mesh(nx, ny, 10.0)
+        v = v + rng.normal(0, 0.3, v.shape) + np.array([3.0 * k, -2.0 * k])
+        meshes.append(fem_ref.RefMesh(v, t, uid=k, locked=(seed >= 2 and k == 0)))
+    pairs = [(0, 1), (2, 3)] if (nmesh == 4 and seed % 2 == 1) else [(k, k + 1) for k in range(nmesh - 1)]       # two separate parts / one chain
+    links = []
+    for a, b in pairs:
+        n = 40
+        ta = rng.integers(0, meshes[a].triangles.shape[0], n); tb = rng.integers(0, meshes[b].triangles.shape[0], n)
+        Ba = rng.dirichlet((1, 1, 1), n); Bb = rng.dirichlet((1, 1, 1), n)
+        links.append(fem_ref.RefLink(meshes[a], meshes[b], ta, tb, Ba, Bb, weight=rng.uniform(0.3, 1, n).astype(np.float32)))
+    A, b, _ = fem_ref.linear_system(meshes, links, 0.5, -1.0, 0, 1, 1)
+    A = sparse.csr_matrix(A); b = np.asarray(b, dtype=np.float64)
+    groups = region_ref._floating_translations(0.5 * (A + A.T))
+    assert len(groups) == (0 if seed == 2 else (4 if seed == 1 else 2))   # seed 2: a chain hanging on a locked mesh, nothing floats
+    xl = region_ref._solve_jacobi_krylov_limit(A, b)
+    x = fb.optimizer.solve(A, b, tol=1e-12, M='jacobi')
+    assert np.all(np.isfinite(x))
+    assert np.abs(x - xl).max() <= 1e-5 * np.abs(xl).max(), (np.abs(x - xl).max() / np.abs(xl).max(), len(groups))
