@@ -11,6 +11,7 @@ mkdir -p $ROOT/ab/obj_$NAME
 OBJS=""
 for f in $CS/build/*.o; do
   b=$(basename $f .o)
+  case $b in test_*) continue;; esac          # (the objects of libfeabas_hip_test.so)
   use=$f
   for s in "$@"; do
     if [ "$b" == "$(basename $s .hip)" ]; then
