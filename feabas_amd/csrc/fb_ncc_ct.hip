@@ -34,7 +34,9 @@ __device__ __forceinline__ void ct_tables(f2* tw, short* pos, const float2* __re
 
 // ---- rows: packed R2C (z = img0 + i img1) of one tile of TR non-zero rows, spectra split and stored transposed as
 // interleaved column pairs T[n][kx / 2][y][kx & 1]
-template <int FW>
+// AFF (image 1 gathered through a per-block affine map) is a template parameter and the per-row clamps / validity are taken once
+// per row, like in ncc_rows_p2 (fb_ncc_p2.inc): scalar instructions per item 1 900 -> see profiles/README_r06.md
+template <int FW, bool AFF = false>
 __global__ __launch_bounds__(kCtThreads) void ncc_rows_ct(const StreamGeom g, const float2* __restrict__ tw_g, float2* __restrict__ T0, float2* __restrict__ T1) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     constexpr int pitch = ct_pitch(FW), Sw = FW / 2 + 1, NX = (FW + kCtThreads - 1) / kCtThreads, TR = ct_tr(FW);      // g.TR == TR (fb_ncc_ct_tr)
@@ -61,29 +63,39 @@ __global__ __launch_bounds__(kCtThreads) void ncc_rows_ct(const StreamGeom g, co
     const int wmax = max(w0, w1);
     __shared__ __attribute__((aligned(8))) float s_red[2 * (kCtThreads / 64)];
     float m0 = 0.f, m1 = 0.f;
+    uint32_t ro0[TR], ro1[TR];                                 // clamped source rows as byte offsets from the image base (uniform)
+    bool ry0[TR], ry1[TR];                                     // the row exists in the crop and in the image (uniform)
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
+        ro0[r] = (uint32_t)(min(max(gy0, 0), my0) * p0) * 4u;
+        ro1[r] = (uint32_t)(min(max(gy1, 0), my1) * p1) * 4u;
+        ry0[r] = y < h0 && gy0 >= 0 && gy0 <= my0;
+        ry1[r] = AFF ? (y < h1) : (y < h1 && gy1 >= 0 && gy1 <= my1);
+    }
+    const char* b0 = reinterpret_cast<const char*>(s0);
+    const char* b1 = reinterpret_cast<const char*>(s1);
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
         const int x = c * kCtThreads + tid;
         const int gx0 = ox0 + x, gx1 = ox1 + x;
         const bool vx0 = x < w0 && gx0 >= 0 && gx0 <= mx0, vx1 = x < w1 && gx1 >= 0 && gx1 <= mx1;
-        const int cx0 = min(max(gx0, 0), mx0), cx1 = min(max(gx1, 0), mx1);
+        const uint32_t cx0 = (uint32_t)min(max(gx0, 0), mx0) * 4u, cx1 = (uint32_t)min(max(gx1, 0), mx1) * 4u;
         float a[TR], b[TR];
         if (c * kCtThreads < wmax) {
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
-                a[r] = s0[(size_t)min(max(gy0, 0), my0) * p0 + cx0];
-                if (g.aff) b[r] = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y, h1 - 1));
-                else b[r] = s1[(size_t)min(max(gy1, 0), my1) * p1 + cx1];
+                a[r] = *reinterpret_cast<const float*>(b0 + (ro0[r] + cx0));
+                if (AFF) b[r] = fb_sample_affine(s1, g.IH1, g.IW1, g.aff + (size_t)n * FB_AFFINE_STRIDE, min(x, w1 - 1), min(y0 + r, h1 - 1));
+                else b[r] = *reinterpret_cast<const float*>(b1 + (ro1[r] + cx1));
             }
         }
         if (x < FW) {
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const int y = y0 + r, gy0 = oy0 + y, gy1 = oy1 + y;
                 const bool in = c * kCtThreads < wmax;
-                const bool v0 = in && vx0 && y < h0 && gy0 >= 0 && gy0 <= my0;
-                const bool v1 = in && (g.aff ? (x < w1 && y < h1) : (vx1 && y < h1 && gy1 >= 0 && gy1 <= my1));
+                const bool v0 = in && vx0 && ry0[r];
+                const bool v1 = in && (AFF ? (x < w1 && ry1[r]) : (vx1 && ry1[r]));
                 const float va = v0 ? a[r] : 0.f, vb = v1 ? b[r] : 0.f;
                 m0 = fmaxf(m0, fabsf(va)); m1 = fmaxf(m1, fabsf(vb));
                 G[r * pitch + x] = (f2){va, vb};
@@ -307,8 +319,10 @@ template <int F>
 struct CtLaunch {
     static int rows(fb_ctx* ctx, dim3 grid, const StreamGeom& g, const float2* tw, float2* T0, float2* T1) {
         const size_t lds = lds_rows(F, g.TR);
-        FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_rows_ct<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ncc_rows_ct<F>, grid, dim3(kCtThreads), lds, ctx->stream, g, tw, T0, T1);
+        FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_rows_ct<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_rows_ct<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (g.aff) hipLaunchKernelGGL((ncc_rows_ct<F, true>), grid, dim3(kCtThreads), lds, ctx->stream, g, tw, T0, T1);
+        else hipLaunchKernelGGL((ncc_rows_ct<F, false>), grid, dim3(kCtThreads), lds, ctx->stream, g, tw, T0, T1);
         return FB_OK;
     }
     static int cols(fb_ctx* ctx, dim3 grid, const StreamGeom& g, const float2* tw, const float2* T0, const float2* T1, float2* V0, float2* V1) {
