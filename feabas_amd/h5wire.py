@@ -497,9 +497,9 @@ def _named_material_entries(mesh, base, tri_func):
         rw = (getattr(mesh, 'material_render_weights', None) or {}).get(name, None)
         if rw is None and sel.size and getattr(mesh, 'tri_render_weight', None) is not None:
             rw = float(mesh.tri_render_weight[sel[0]])
-        if rw is not None:                                    # material.py:50-54: a material that is not rendered weighs 0
-            table[name]['render'] = bool(rw > 0)
-            table[name]['render_weight'] = float(rw)
+        if rw is not None:                                    # material.py:50-54; render = False is carried as -(render_weight + 1) (Mesh.triangle_mask_for_render)
+            table[name]['render'] = bool(rw >= 0)
+            table[name]['render_weight'] = float(rw) if rw >= 0 else float(-rw - 1.0)
     lo, hi = int(ids.min(initial=0)), int(ids.max(initial=0))
     dt = np.int8 if -128 <= lo and hi < 128 else (np.int16 if -32768 <= lo and hi < 32768 else np.int32)
     return ids.astype(dt), table
@@ -615,7 +615,7 @@ def load_mesh_h5(f, prefix='', cls=None, **kwargs):
         init['material_names'] = {name: int(m['uid']) for name, m in table.items()}
         init['material_area_constraints'] = {name: float(m.get('area_constraint', 1.0)) for name, m in table.items()}
         # render weights (material.py:50-54): which triangles take part in block placement / rendering and where matches may land
-        rws = {name: (float(m.get('render_weight', 1.0)) if m.get('render', True) else 0.0) for name, m in table.items()}
+        rws = {name: (float(m.get('render_weight', 1.0)) if m.get('render', True) else -(float(m.get('render_weight', 1.0)) + 1.0)) for name, m in table.items()}
         if any(w != 1.0 for w in rws.values()):
             init['material_render_weights'] = rws
         init['poisson_ratio'] = d.get('poisson_ratio', 0.0)

@@ -421,14 +421,16 @@ class Mesh:
 
     def weight_multiplier_for_render(self):                # mesh.py:1836-1843
         wt = getattr(self, 'tri_render_weight', None)
-        return np.ones(self.num_triangles, dtype=np.float32) if wt is None else np.asarray(wt, dtype=np.float32)
+        return np.ones(self.num_triangles, dtype=np.float32) if wt is None else np.maximum(np.asarray(wt, dtype=np.float32), 0)
 
-    def triangle_mask_for_render(self, **kwargs):          # mesh.py:1847-1859: materials that are not rendered (weight 0) or weigh less than the threshold
+    def triangle_mask_for_render(self, **kwargs):          # mesh.py:1847-1859: materials that are not rendered or weigh less than the threshold
         thr = kwargs.get('render_weight_threshold', 0)
         wt = getattr(self, 'tri_render_weight', None)
         if wt is None:
             return np.ones(self.num_triangles, dtype=bool)
-        return ~(np.asarray(wt) < thr) & (np.asarray(wt) > 0)
+        # (a material with render = False is carried as a NEGATIVE weight, -(render_weight + 1): a rendered material of weight 0 stays
+        # rendered at threshold 0, like mesh.py:1850-1854)
+        return ~(np.asarray(wt) < thr) & (np.asarray(wt) >= 0)
 
     def submesh(self, tri_mask, **kwargs):                 # mesh.py:598-626
         """the triangles selected by tri_mask (bool mask or index list) with the vertices they use, every gear kept"""

@@ -220,8 +220,17 @@ def test_mesh_file_keeps_the_stiffness_functions(tmp_path):
     N.set_vertices(N.vertices(const.MESH_GEAR_INITIAL) * np.array([[0.9, 1.0]]), const.MESH_GEAR_MOVING)
     eff = N.effective_stiffness_multiplier()
     assert np.allclose(eff[func < 0], 1.0) and np.allclose(eff[func == 0], 0.4 * 0.5)        # uniform compression: stretch / median = 1
+    # any other callable is taken as it is (evaluated on the host, Mesh.assemble_into) -- a lambda string, a factory with parameters --
+    # but a mesh file can only carry tables, and dill-serialised lambdas need dill
+    f = material.stiffness_func_from_spec('lambda x: 2.0 * x')
+    assert not isinstance(f, material.StiffnessTable) and f(np.array([0.5]))[0] == 1.0
+    g = material.stiffness_func_from_spec(lambda **kw: (lambda x: kw['a'] * x), dict(a=3.0))
+    assert g(2.0) == 6.0
     with pytest.raises(NotImplementedError):
-        material.stiffness_func_from_spec('lambda x: x')
+        material.stiffness_func_from_spec('<lambda_bytes>00')
+    P = Mesh(M.vertices(const.MESH_GEAR_INITIAL), M.triangles, uid=4, tri_func=func, stiffness_funcs=[f, g], func_matmult=[0.4, 1.3])
+    with pytest.raises(NotImplementedError):
+        P.save_to_h5(str(tmp_path / 'callable.h5'))
 
 
 def test_mesh_file_keeps_the_named_materials(tmp_path):
@@ -273,7 +282,8 @@ def test_mesh_file_keeps_the_named_materials(tmp_path):
 
 
 def test_mesh_file_keeps_the_render_weights(tmp_path):
-    """the render weight of every named material (material.py:27-30, 50-54: `render: false` = weight 0) survives save -> load: the render
+    """the render weight and the render flag of every named material (material.py:27-30, 50-54; `render: false` is carried as the
+    negative weight -(render_weight + 1), so that a RENDERED material of weight 0 stays rendered at threshold 0, mesh.py:1850-1854) survive save -> load: the render
     masks by threshold and the per-triangle weights -- what decides where blocks are placed, what is rendered and where matches may land
     (mesh.py:1836-1859, 2168-2170) -- are the same afterwards"""
     M0 = Mesh.from_bbox((0, 0, 300, 200), cartesian=True, mesh_size=25)
@@ -281,21 +291,25 @@ def test_mesh_file_keeps_the_render_weights(tmp_path):
     ids = np.zeros(M0.num_triangles, dtype=np.int32)
     ids[c[:, 0] < 80] = 3
     ids[c[:, 0] > 220] = 7
-    names = {'default': 0, 'soft': 3, 'hidden': 7}
+    ids[(c[:, 0] > 120) & (c[:, 0] < 160)] = 9
+    names = {'default': 0, 'soft': 3, 'hidden': 7, 'weightless': 9}
     M = Mesh(M0.vertices(const.MESH_GEAR_INITIAL), M0.triangles, uid=2, material_ids=ids, material_names=names,
-             material_render_weights={'soft': 1.0e-6, 'hidden': 0.0})
+             material_render_weights={'soft': 1.0e-6, 'hidden': -(0.25 + 1.0), 'weightless': 0.0})
     fn = str(tmp_path / 'weights.h5')
     M.save_to_h5(fn)
     with h5wire.H5File(fn) as f:
         table = json.loads(h5wire.numpy_to_str_ascii(f['material_table']))
-    assert table['soft']['render'] is True and table['soft']['render_weight'] == pytest.approx(1.0e-6) and table['hidden']['render'] is False
+    assert table['soft']['render'] is True and table['soft']['render_weight'] == pytest.approx(1.0e-6)
+    assert table['hidden']['render'] is False and table['hidden']['render_weight'] == pytest.approx(0.25)
+    assert table['weightless']['render'] is True and table['weightless']['render_weight'] == 0.0
     assert table['default']['render_weight'] == 1.0
     N = Mesh.from_h5(fn)
     np.testing.assert_array_equal(N.weight_multiplier_for_render(), M.weight_multiplier_for_render())
     for thr in (0.0, 0.1, 1.0e-6):
         np.testing.assert_array_equal(N.triangle_mask_for_render(render_weight_threshold=thr), M.triangle_mask_for_render(render_weight_threshold=thr))
     assert N.triangle_mask_for_render(render_weight_threshold=0.1).sum() == (ids == 0).sum()
-    assert N.triangle_mask_for_render().sum() == (ids != 7).sum()
+    assert N.triangle_mask_for_render().sum() == (ids != 7).sum()             # weight 0 but render = True: rendered at threshold 0
+    assert N.weight_multiplier_for_render().min() == 0.0
     # a mesh without weighted materials writes and reads plain weights
     M0.save_to_h5(str(tmp_path / 'plain.h5'))
     assert Mesh.from_h5(str(tmp_path / 'plain.h5')).tri_render_weight is None

@@ -482,7 +482,7 @@ def test_product_render_weights_vs_reference(monkeypatch):
 
     def mesh1():
         return Mesh(g23['v1'].copy(), g['t1'], uid=1, material_ids=g['mids'], material_names={'default': 0, 'soft_look': 5, 'hidden': 6},
-                    material_render_weights={'soft_look': 1.0e-3, 'hidden': 0.0})
+                    material_render_weights={'soft_look': 1.0e-3, 'hidden': -1.0})           # (render = False: -(render_weight + 1))
     m1 = mesh1()
     np.testing.assert_array_equal(m1.weight_multiplier_for_render(), g['weights'])
     for thr in (0.0, 0.1, 1.0e-3, 0.5e-3):
