@@ -75,7 +75,7 @@ class Mesh:
         self.material_names = dict(kwargs.get('material_names', None) or {})
         # area_constraint of the named materials (material.py:22-26): < 1 marks a refinement region of the block distributor
         self.material_area_constraints = dict(kwargs.get('material_area_constraints', None) or {})
-        # render weight of every triangle's material (material.py:27-30, 50-54: 0 for a material that is not rendered): which triangles
+        # render weight of every triangle's material (material.py:27-30, 50-54; a material that is NOT rendered carries -(weight + 1)): which triangles
         # take part in block placement and rendering (triangle_mask_for_render) and where matches may land (tri_finder,
         # mesh.py:2168-2170).  Given per triangle, or per named material (material_render_weights = {name: weight}); absent = all 1
         rw = kwargs.get('tri_render_weight', None)
