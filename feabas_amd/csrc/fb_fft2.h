@@ -256,9 +256,11 @@ __device__ __forceinline__ void p2_fft_inv_tail(f2* base, int M, int pitch, cons
 // full transform of M rows; every pass ends with a workgroup barrier
 // inverse transform whose last pass (radix 16, L = N: outputs in natural order) hands its results to `sink`
 // instead of writing them back (N >= 256 so that the last pass is not also the first)
-template <int N, typename SINK>
+// NT > 0: the workgroup size as a compile-time constant (the trip counts of the passes are then known: a thread's butterflies of
+// one pass are unrolled and interleaved instead of running one after the other)
+template <int N, typename SINK, int NT = 0>
 __device__ __forceinline__ void p2_fft_inv_sink(f2* base, int M, int pitch, const f2* tw, const SINK& sink) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = NT > 0 ? NT : (int)blockDim.x;
     constexpr int n16 = p2_n16(N), rem = p2_rem(N);
     if (rem > 1) { p2_pass<N, (rem > 1 ? rem : 2), (rem > 1 ? rem : 2), true>(base, M, pitch, tw, tid, nt); __syncthreads(); }
     if (n16 >= 3) { P2Stage<N, (n16 >= 3 ? 2 : 0), true>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
@@ -266,9 +268,9 @@ __device__ __forceinline__ void p2_fft_inv_sink(f2* base, int M, int pitch, cons
     p2_pass<N, 16, N, true, SINK>(base, M, pitch, tw, tid, nt, sink);
 }
 
-template <int N, bool INV>
+template <int N, bool INV, int NT = 0>
 __device__ __forceinline__ void p2_fft(f2* base, int M, int pitch, const f2* tw) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = NT > 0 ? NT : (int)blockDim.x;
     constexpr int n16 = p2_n16(N), rem = p2_rem(N);
     if (!INV) {
         if (n16 >= 1) { P2Stage<N, 0, false>::run(base, M, pitch, tw, tid, nt); __syncthreads(); }
