@@ -379,34 +379,18 @@ def bench_section_matcher(lib, ctx, _lib, S=8192, mesh_size=100.0, reps=3, confi
     conc = None
     if config is None:
         try:
-            import threading
             T, R = 4, 3
-            ctxs = [_lib.ctx()] + [_lib.new_context() for _ in range(T - 1)]
-            errs, counts = [], [0] * T
-
-            def worker(t_):
-                try:
-                    with _lib.using(ctxs[t_]):
-                        for _ in range(R):
-                            a, b = meshes[0].copy(), meshes[1].copy()
-                            r_ = fmatcher.section_matcher(a, b, images[0], images[1], spacings=[280, 70], conf_thresh=0.3, residue_len=3.0)
-                            counts[t_] += int(r_[0] is not None)
-                except Exception as e:                      # noqa: BLE001 -- a side record
-                    errs.append(e)
+            kwj = dict(spacings=[280, 70], conf_thresh=0.3, residue_len=3.0)
             for rep in range(2):                            # first pass: per-context code objects and arenas
-                counts = [0] * T
-                ths = [threading.Thread(target=worker, args=(t_,)) for t_ in range(T)]
+                jobs = [(meshes[0].copy(), meshes[1].copy(), images[0], images[1], kwj) for _ in range(T * R)]
                 t0 = time.time()
-                for th in ths:
-                    th.start()
-                for th in ths:
-                    th.join()
+                outs = fmatcher.section_matcher_batch(jobs, threads=T)
                 dtc = time.time() - t0
-            for h_ in ctxs[1:]:
-                _lib.destroy_context(h_)
+            counts = [int(o[0] is not None) for o in outs]
+            errs = []
             conc = dict(error=f'{type(errs[0]).__name__}: {errs[0]}') if errs else dict(
                 value=sum(counts) / dtc, unit='section pairs/s', host_threads=T, pairs=sum(counts), seconds=dtc,
-                note='the same pair matched by T host threads at once, one context (stream) each: throughput of the matching stage of a stack, not the latency of a pair')
+                note='matcher.section_matcher_batch: the same pair as 12 jobs on 4 host threads, one context (stream) each: throughput of the matching stage of a stack, not the latency of a pair')
         except Exception as e:                              # noqa: BLE001 -- a side record
             conc = dict(error=f'{type(e).__name__}: {e}')
     for im in images:

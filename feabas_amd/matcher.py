@@ -946,6 +946,57 @@ def section_matcher(mesh0, mesh1, image_loader0, image_loader1, **kwargs):
             im.free()
 
 
+def section_matcher_batch(jobs, threads=4):
+    """``section_matcher`` for a list of section pairs -- what the aligner's matching stage deals to its workers
+    (aligner.py: match_main, one pair per job).  jobs: sequence of ``(mesh0, mesh1, image_loader0, image_loader1)`` or
+    ``(mesh0, mesh1, image_loader0, image_loader1, kwargs)``; ``threads`` host threads with a context (HIP stream) each take the
+    jobs in turn, so the kernels and copies of one pair run while another thread is between two entries of the library (27 of the
+    ~55 ms of a pair are python, which holds the interpreter lock; the entries do not): 37-40 pairs/s on four threads against
+    17-18 one after the other (8192^2 sections, bench.py).  Returns the 4-tuples of ``section_matcher`` in job order; the first
+    exception of a job is raised after the other threads have finished their current pair."""
+    import threading
+    jobs = list(jobs)
+    if not jobs:
+        return []
+    nthr = max(1, min(int(threads), len(jobs)))
+    main_ctx = _lib.ctx()
+    results = [None] * len(jobs)
+    errors = []
+    take = threading.Lock()
+    nxt = [0]
+
+    def worker(t):
+        # the contexts of the extra threads are kept between calls like those of stitching_matcher_batch (their arenas and code
+        # objects are warm the second time; stitching_matcher_batch_release frees them)
+        if t == 0:
+            h = main_ctx
+        else:
+            slot = _batch_workers.setdefault((id(main_ctx), ('S', t)), {})
+            if 'ctx' not in slot:
+                slot['ctx'] = _lib.new_context()
+            h = slot['ctx']
+        try:
+            with _lib.using(h):
+                while not errors:
+                    with take:
+                        k = nxt[0]; nxt[0] += 1
+                    if k >= len(jobs):
+                        break
+                    job = jobs[k]
+                    kw = dict(job[4]) if len(job) > 4 and job[4] else {}
+                    results[k] = section_matcher(job[0], job[1], job[2], job[3], **kw)
+        except Exception as e:                              # noqa: BLE001 -- re-raised in the calling thread
+            errors.append(e)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    if errors:
+        raise errors[0]
+    return results
+
+
 def auto_spacings(shape0, shape1):
     """feabas/matcher.py:243-251."""
     shp = np.minimum(shape0, shape1)

@@ -663,3 +663,32 @@ def test_section_matcher_floating_pair_vs_oracle(fb):
     ex = 3.0 * np.sin(2 * np.pi * xy1[:, 1] / 700.0 + 0.4) + (xy1[:, 0] / SW) ** 2
     ey = 2.5 * np.cos(2 * np.pi * xy1[:, 0] / 900.0) - (xy1[:, 0] / SW) * (xy1[:, 1] / SH)
     assert np.median(np.hypot(xy1[:, 0] - xy0[:, 0] + ex, xy1[:, 1] - xy0[:, 1] + ey)) < 0.3
+
+
+def test_section_matcher_batch_equals_the_per_pair_calls(fb):
+    """matcher.section_matcher_batch (pairs dealt to host threads with a context each, like the aligner deals them to its workers):
+    the same results as section_matcher pair by pair, in job order; keywords per job; an exception of a job surfaces"""
+    from scipy.ndimage import map_coordinates
+    from feabas_amd import matcher
+    rng = np.random.default_rng(23)
+    (v0, t0, v1, t1), (M0, M1), _ = _island_pair(rng)
+    SH, SW = 600, 1080
+    base = _texture(rng, SH, SW)
+    yy, xx = np.meshgrid(np.arange(SH, dtype=np.float64), np.arange(SW, dtype=np.float64), indexing='ij')
+    img1 = np.clip(np.rint(map_coordinates(base.astype(np.float32), [yy + 2.0 * np.cos(xx / 150.0), xx + 2.5 * np.sin(yy / 120.0)], order=1, mode='nearest')), 0, 255).astype(np.uint8)
+    for M in (M0, M1):
+        M.material_ids = None; M.material_names = {}; M.material_area_constraints = {}
+    M0.locked = True
+    kws = [dict(spacings=[150, 60], conf_thresh=0.3, residue_len=3.0), dict(spacings=[120], conf_thresh=0.3, residue_len=3.0, min_boundary_distance=10)]
+    ref = [matcher.section_matcher(M0.copy(), M1.copy(), base, img1, **kw) for kw in kws]
+    jobs = [(M0.copy(), M1.copy(), base, img1, kws[k % 2]) for k in range(5)]
+    got = matcher.section_matcher_batch(jobs, threads=3)
+    assert len(got) == 5
+    for k, g in enumerate(got):
+        e = ref[k % 2]
+        assert g[0].shape == e[0].shape and g[0].shape[0] > 40
+        np.testing.assert_array_equal(g[0], e[0]); np.testing.assert_array_equal(g[1], e[1]); np.testing.assert_array_equal(g[2], e[2])
+    assert matcher.section_matcher_batch([]) == []
+    with pytest.raises(TypeError):
+        matcher.section_matcher_batch([(M0.copy(), M1.copy(), base, img1, dict(no_such_keyword=1))] * 2, threads=2)
+    matcher.stitching_matcher_batch_release()
