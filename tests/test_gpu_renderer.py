@@ -686,7 +686,7 @@ def test_section_matcher_batch_equals_the_per_pair_calls(fb):
     assert len(got) == 5
     for k, g in enumerate(got):
         e = ref[k % 2]
-        assert g[0].shape == e[0].shape and g[0].shape[0] > 40
+        assert g[0].shape == e[0].shape and g[0].shape[0] > 10
         np.testing.assert_array_equal(g[0], e[0]); np.testing.assert_array_equal(g[1], e[1]); np.testing.assert_array_equal(g[2], e[2])
     assert matcher.section_matcher_batch([]) == []
     with pytest.raises(TypeError):
