@@ -2,7 +2,7 @@
 # SQ counters (two passes of 8 slots) of every kernel of the headline pipeline, one stream, one step; summaries per kernel
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r04sq
+OUT=$ROOT/gpurun_out/${1:-r04sq}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
