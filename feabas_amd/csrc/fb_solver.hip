@@ -175,11 +175,11 @@ __global__ __launch_bounds__(kT) void bsr_spmv_kernel(
     }
     if (MODE != 0) {
         const double t = block_sum(acc_dot, sh);
-        if (threadIdx.x == 0) part_out[blockIdx.x] = t;
         if (MODE == 1) {
+            // (p.Ap, p.p) of the workgroup side by side: the update kernel sums both with one 16-byte load per entry
             const double t2 = block_sum(acc_pp, sh);
-            if (threadIdx.x == 0) part_pp[blockIdx.x] = t2;
-        }
+            if (threadIdx.x == 0) reinterpret_cast<double2*>(part_pp)[blockIdx.x] = make_double2(t, t2);
+        } else if (threadIdx.x == 0) part_out[blockIdx.x] = t;
     }
 }
 
@@ -196,11 +196,20 @@ __global__ __launch_bounds__(kT) void pcg_update_kernel(
     if (threadIdx.x == 0) sflag = st->flag;
     double pAp, rz, pp;
     {
-        const double* ptrs[3] = {part_pAp, part_rz_cur, part_pp};
-        const int ns[3] = {np_pAp, np_rz, np_pAp};
-        double o[3];
-        sum_partials_k<3>(ptrs, ns, o, sh2);                 // (its barriers also publish sflag)
-        pAp = o[0]; rz = o[1]; pp = o[2];
+        // p.Ap and p.p: [np_pAp] double2 at part_pp (written by the SpMV kernel), r.z: [np_rz] doubles; every workgroup sums them
+        // in the same order (bitwise the same scalars everywhere).  (part_pAp is not read any more.)
+        const double2* pq = reinterpret_cast<const double2*>(part_pp);
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+        for (int i = threadIdx.x; i < np_pAp; i += blockDim.x) { const double2 a = pq[i]; v0 += a.x; v1 += a.y; }
+        for (int i = threadIdx.x; i < np_rz; i += blockDim.x) v2 += part_rz_cur[i];
+        for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        __syncthreads();                                     // (also publishes sflag)
+        if (lane == 0) { sh2[0][wave] = v0; sh2[1][wave] = v1; sh2[2][wave] = v2; }
+        __syncthreads();
+        pAp = 0.0; pp = 0.0; rz = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { pAp += sh2[0][w]; pp += sh2[1][w]; rz += sh2[2][w]; }
+        (void)part_pAp;
     }
     if (sflag) return;
     if (!(pAp > 1e-5 * st->curv_eps * pp)) {
