@@ -230,6 +230,14 @@ __global__ __launch_bounds__(kT) void pcg_update_kernel(
         const int per = ((nchunks + 7) >> 3) * kT;
         base = (blockIdx.x & 7) * per; limit = min(per, nb - base);
         first = (blockIdx.x >> 3) * blockDim.x + threadIdx.x; stride = (gridDim.x >> 3) * blockDim.x;
+        if (xcd_rows == 2) {
+            // every workgroup owns ONE contiguous run of its XCD's eighth (FEABAS_HIP_PCG_CHUNKED=1): the store form that reaches
+            // the best write rate in isolation (tools/hbm_store_probe.hip)
+            const int nwg = gridDim.x >> 3, wg = blockIdx.x >> 3;
+            const int run = ((limit + nwg - 1) / nwg + 2 * (int)blockDim.x - 1) / (2 * (int)blockDim.x) * (2 * (int)blockDim.x);
+            base += wg * run; limit = max(0, min(run, limit - wg * run));
+            first = threadIdx.x; stride = blockDim.x;
+        }
     }
     for (int j0 = first; j0 < limit; j0 += 2 * stride) {
         const int i0 = base + j0, i1 = i0 + stride;
@@ -781,6 +789,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
     // last, and so is one that doubles ||x|| (a correction leg refines x; one that doubles it ran away along a null vector).
     const int trace = [] { const char* e = getenv("FEABAS_HIP_PCG_TRACE"); return e ? atoi(e) : 0; }();      // (read per call: a test switches it on)
     static const int keep_best = [] { const char* e = getenv("FEABAS_HIP_PCG_BEST"); return e ? atoi(e) : 1; }();
+    static const int upd_chunked = [] { const char* e = getenv("FEABAS_HIP_PCG_CHUNKED"); return e ? atoi(e) : 0; }();
     static const int deflate = [] { const char* e = getenv("FEABAS_HIP_PCG_DEFLATE"); return e ? atoi(e) : 1; }();
     fb_deflation D;                                  // (frees its device blocks when the solve returns)
     bool deflated = false, breakdown = false;
@@ -864,7 +873,7 @@ int fb_bsr_pcg_dev(fb_ctx* ctx, fb_bsr* M, double rtol, double atol, int maxiter
             {
                 FB_PROF_B(ctx, "pcg_update_fused", 7.0 * 16.0 * nb);
                 hipLaunchKernelGGL(pcg_update_kernel, dim3(g2), dim3(kT), 0, ctx->stream, nb, M->x, M->r, M->z, p_new, M->Ap, M->minv,
-                                   part_pAp, part_pp, g1, part_rz[prev], g2, part_rz[cur], part_rr[cur], M->state, i, M->d.xcd_rows);
+                                   part_pAp, part_pp, g1, part_rz[prev], g2, part_rz[cur], part_rr[cur], M->state, i, (M->d.xcd_rows && upd_chunked) ? 2 : M->d.xcd_rows);
             }
             if (deflated) deflate_rz(cur);                   // r - alpha P(A p) = P(r - alpha A p): the update kernel's r, z and dots redone on the deflated vectors
         };
