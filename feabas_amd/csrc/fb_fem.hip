@@ -813,6 +813,7 @@ int fb_sys_finalize(fb_ctx* ctx, fb_system* s, int64_t* nnzb_out) {
     int rc = fb_bsr_alloc(ctx, nv, nnzb, &s->M);
     if (rc) return rc;
     { const int rc_ = fb_copy_h2d(ctx, s->M->d.rowptr, s->browptr.data(), sizeof(int) * ((size_t)nv + 1)); if (rc_) return rc_; }
+    { int mr = 0; for (int v = 0; v < nv; ++v) mr = std::max(mr, s->browptr[v + 1] - s->browptr[v]); s->M->max_row_blocks = mr; }
     { const int rc_ = fb_copy_h2d(ctx, s->M->d.col, s->bcol.data(), sizeof(int) * (size_t)nnzb); if (rc_) return rc_; }
     FB_HIP(ctx, hipMalloc((void**)&s->d_K, sizeof(double) * 4 * (size_t)nnzb));
     FB_HIP(ctx, hipMalloc((void**)&s->d_Cacc, sizeof(double) * (size_t)nnzb));

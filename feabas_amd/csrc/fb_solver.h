@@ -27,6 +27,7 @@ struct fb_bsr {
     double* parts = nullptr;
     fb_pcg_state* state = nullptr;
     double diag_max = 0.0;
+    int max_row_blocks = 0;     // longest block row of the pattern (0 = not known): fb_bsr_pcg_groups keeps the matrix of a group in LDS when it fits
     double last_bnorm = 0.0;    // ||b|| of the last fb_bsr_pcg_dev
     // fb_bsr_pcg_dev stops early (probe_stopped) once the iterations it projects from the decay of the residual over the last
     // 64 exceed probe_limit (0: no projection) -- the 'auto' policy of fb_sys_solve hands such a solve to the multigrid

@@ -423,6 +423,19 @@ __device__ __forceinline__ double group_sum(double v, double* sh) {
     for (int w = 1; w < kGT / 64; ++w) s += sh[w];
     return s;
 }
+// two sums behind ONE barrier (the iteration of pcg_groups_kernel is bound by its barriers: 9 -> 3 per iteration); per value
+// the summation tree is that of group_sum, so the results are bitwise the same
+// (no barrier in front: the two reductions of an iteration use buffers of their own, and between two uses of one buffer lie the
+// barriers of the other reduction and of the direction update -- 3 barriers per iteration)
+__device__ __forceinline__ void group_sum2(double& a, double& b, double (*sh2)[kGT / 64]) {
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh2[0][wave] = a; sh2[1][wave] = b; }
+    __syncthreads();
+    double s = sh2[0][0], t = sh2[1][0];
+    for (int w = 1; w < kGT / 64; ++w) { s += sh2[0][w]; t += sh2[1][w]; }
+    a = s; b = t;
+}
 __device__ __forceinline__ double group_max(double v, double* sh) {
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -432,6 +445,20 @@ __device__ __forceinline__ double group_max(double v, double* sh) {
     double s = sh[0];
     for (int w = 1; w < kGT / 64; ++w) s = fmax(s, sh[w]);
     return s;
+}
+
+// the same row product with the matrix of the group in LDS, slot-major (ELL): slot k of local row i at [k * gs + i] -- consecutive
+// threads read consecutive addresses; rows shorter than K are padded with zero blocks on the diagonal (adding +0.0 at the end of
+// the row's sum: the result is bitwise that of the CSR loop)
+__device__ __forceinline__ double2 group_row_spmv_lds(const double4* vals, const unsigned short* cols, int K, int gs, int i, const double2* v) {
+    double2 acc = make_double2(0.0, 0.0);
+    for (int k = 0; k < K; ++k) {
+        const double4 a = vals[k * gs + i];
+        const double2 u = v[cols[k * gs + i]];
+        acc.x += a.x * u.x + a.y * u.y;
+        acc.y += a.z * u.x + a.w * u.y;
+    }
+    return acc;
 }
 
 // y_i = sum_j A_ij v_j for the rows of this group; columns are group-local (block-diagonal system)
@@ -446,12 +473,32 @@ __device__ __forceinline__ double2 group_row_spmv(const fb_bsr_dev& A, int row, 
     return acc;
 }
 
+// LDSMAT: the K block slots of every row of the group are copied into LDS once (K = longest row of the pattern): the hundreds of
+// iterations of a deformed-mesh relaxation then gather nothing from L2 (7 slots x 448 rows x 34 B = 107 KB beside the 36 KB of
+// vectors at the strip meshes of the 4k configuration)
+template <bool LDSMAT>
 __global__ __launch_bounds__(kGT) void pcg_groups_kernel(fb_bsr_dev A, const double2* __restrict__ b, double2* __restrict__ x, int gs, double rtol,
                                                          double atol, int maxiter, int precond, int* __restrict__ iters,
-                                                         double* __restrict__ relres, int* __restrict__ flags) {
+                                                         double* __restrict__ relres, int* __restrict__ flags, int K) {
     extern __shared__ __attribute__((aligned(16))) double2 gl[];
     double2* xs = gl; double2* r = gl + gs; double2* z = gl + 2 * gs; double2* pv = gl + 3 * gs; double2* mi = gl + 4 * gs;
+    double4* mvals = reinterpret_cast<double4*>(gl + 5 * gs);                       // [K][gs]
+    unsigned short* mcols = reinterpret_cast<unsigned short*>(mvals + (size_t)K * gs);   // [K][gs]
+    if (LDSMAT) {
+        const int gbase = blockIdx.x * gs;
+        for (int i = threadIdx.x; i < gs; i += kGT) {
+            const int row = gbase + i, j0 = A.rowptr[row], n = A.rowptr[row + 1] - j0;
+            for (int k = 0; k < K; ++k) {
+                const bool in = k < n;
+                mvals[k * gs + i] = in ? reinterpret_cast<const double4*>(A.val)[j0 + k] : make_double4(0.0, 0.0, 0.0, 0.0);
+                mcols[k * gs + i] = (unsigned short)(in ? A.col[j0 + k] - gbase : i);
+            }
+        }
+        __syncthreads();
+    }
     __shared__ double sh[kGT / 64];
+    __shared__ double sh2[2][kGT / 64];
+    __shared__ double sh3[2][kGT / 64];
     const int g = blockIdx.x, base = g * gs, tid = threadIdx.x;
     // Jacobi preconditioner of this range (optimizer.py:1958-1966): 1 / clip(diag, min(1, max / 1000))
     double dmax = -INFINITY;
@@ -497,14 +544,13 @@ __global__ __launch_bounds__(kGT) void pcg_groups_kernel(fb_bsr_dev A, const dou
             double pAp = 0.0, pp = 0.0;
             // rows of a thread stay with it through the iteration: Ap is kept in z (z is dead until it is recomputed)
             for (int i = tid; i < gs; i += kGT) {
-                const double2 ap = group_row_spmv(A, base + i, base, pv);
+                const double2 ap = LDSMAT ? group_row_spmv_lds(mvals, mcols, K, gs, i, pv) : group_row_spmv(A, base + i, base, pv);
                 const double2 pi = pv[i];
                 z[i] = ap;
                 pAp += pi.x * ap.x + pi.y * ap.y;
                 pp += pi.x * pi.x + pi.y * pi.y;
             }
-            pAp = group_sum(pAp, sh);
-            pp = group_sum(pp, sh);
+            group_sum2(pAp, pp, sh2);
             if (!(pAp > curv_eps * pp)) { flag = (pAp < -curv_eps * pp) ? 2 : 3; break; }     // breakdown / semi-definite stagnation
             const double alpha = rz / pAp;
             double rr_new = 0.0, rz_new = 0.0;
@@ -519,8 +565,8 @@ __global__ __launch_bounds__(kGT) void pcg_groups_kernel(fb_bsr_dev A, const dou
                 rr_new += ri.x * ri.x + ri.y * ri.y;
                 rz_new += ri.x * zi.x + ri.y * zi.y;
             }
-            rr = group_sum(rr_new, sh);
-            rz_new = group_sum(rz_new, sh);
+            group_sum2(rr_new, rz_new, sh3);
+            rr = rr_new;
             ++it;
             if (rr <= tol2) { flag = 1; break; }
             const double beta = rz_new / rz;
@@ -535,7 +581,7 @@ __global__ __launch_bounds__(kGT) void pcg_groups_kernel(fb_bsr_dev A, const dou
         __syncthreads();
         double rt = 0.0;
         for (int i = tid; i < gs; i += kGT) {
-            const double2 ax = group_row_spmv(A, base + i, base, xs);
+            const double2 ax = LDSMAT ? group_row_spmv_lds(mvals, mcols, K, gs, i, xs) : group_row_spmv(A, base + i, base, xs);
             const double2 bi = b[base + i];
             const double dx = bi.x - ax.x, dy = bi.y - ax.y;
             rt += dx * dx + dy * dy;
@@ -557,10 +603,20 @@ int fb_bsr_pcg_groups(fb_ctx* ctx, fb_bsr* M, int ngroups, double rtol, double a
     const int gs = M->d.nb / ngroups;
     const size_t lds = sizeof(double2) * 5 * (size_t)gs;
     if (M->d.nb % ngroups != 0 || lds > 150 * 1024) return fb_fail(ctx, FB_ERR_ARG, "fb_bsr_pcg_groups: %d vertices per group do not fit the LDS", gs);
-    FB_HIP(ctx, hipFuncSetAttribute((const void*)pcg_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the matrix of a group beside its vectors when both fit (160 KB per CU; the kernel has ~0.3 KB of static LDS); FEABAS_HIP_GROUPS_LDSMAT=0: never
+    static const int ldsmat = [] { const char* e = getenv("FEABAS_HIP_GROUPS_LDSMAT"); return e ? atoi(e) : 1; }();
+    const int K = M->max_row_blocks;
+    const size_t lds_mat = lds + (size_t)K * gs * (sizeof(double4) + sizeof(unsigned short)) + 16;
     FB_PROF(ctx, "pcg_groups");
-    hipLaunchKernelGGL(pcg_groups_kernel, dim3(ngroups), dim3(kGT), lds, ctx->stream, M->d, M->b, M->x, gs, rtol, atol, maxiter, precond, iters_dev,
-                       relres_dev, flags_dev);
+    if (ldsmat && K > 0 && gs <= 65535 && lds_mat <= 158 * 1024) {
+        FB_HIP(ctx, hipFuncSetAttribute((const void*)pcg_groups_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mat));
+        hipLaunchKernelGGL(pcg_groups_kernel<true>, dim3(ngroups), dim3(kGT), lds_mat, ctx->stream, M->d, M->b, M->x, gs, rtol, atol, maxiter, precond, iters_dev,
+                           relres_dev, flags_dev, K);
+    } else {
+        FB_HIP(ctx, hipFuncSetAttribute((const void*)pcg_groups_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pcg_groups_kernel<false>, dim3(ngroups), dim3(kGT), lds, ctx->stream, M->d, M->b, M->x, gs, rtol, atol, maxiter, precond, iters_dev,
+                           relres_dev, flags_dev, 0);
+    }
     FB_HIP(ctx, hipGetLastError());
     return FB_OK;
 }
@@ -610,6 +666,7 @@ int fb_bsr_upload(fb_ctx* ctx, int nb, const std::vector<int>& rowptr, const std
     fb_bsr* M = nullptr;
     int rc = fb_bsr_alloc(ctx, nb, (int64_t)col.size(), &M);
     if (rc) return rc;
+    { int mr = 0; for (int v = 0; v < nb; ++v) mr = std::max(mr, rowptr[v + 1] - rowptr[v]); M->max_row_blocks = mr; }
     rc = fb_copy_h2d(ctx, M->d.rowptr, rowptr.data(), sizeof(int) * rowptr.size());
     if (!rc) rc = fb_copy_h2d(ctx, M->d.col, col.data(), sizeof(int) * col.size());
     if (!rc) rc = fb_copy_h2d(ctx, M->d.val, val.data(), sizeof(double) * val.size());
