@@ -76,8 +76,29 @@ def start(limit_gb=None, period=0.25, exit_code=3):
 
 _BACKSTOP = r'''
 import os, signal, sys, time
-sys.path.insert(0, %(root)r)
-from feabas_amd._watchdog import tree_rss_gb, _children
+def _rss_kb(pid):
+    try:
+        with open('/proc/%%s/statm' %% pid) as f:
+            return int(f.read().split()[1]) * (os.sysconf('SC_PAGE_SIZE') // 1024)
+    except (OSError, ValueError, IndexError):
+        return 0
+def _children(pid):
+    out = []
+    try:
+        for t in os.listdir('/proc/%%s/task' %% pid):
+            with open('/proc/%%s/task/%%s/children' %% (pid, t)) as f:
+                out += [int(c) for c in f.read().split()]
+    except (OSError, ValueError):
+        pass
+    return out
+def tree_rss_gb(pid):
+    todo, kb, seen = [pid], 0, set()
+    while todo:
+        p = todo.pop()
+        if p in seen:
+            continue
+        seen.add(p); kb += _rss_kb(p); todo += _children(p)
+    return kb / 1048576.0
 ppid, limit = %(pid)d, %(limit)r
 while True:
     if os.getppid() != ppid:
@@ -106,6 +127,5 @@ def start_backstop(limit_gb=None):
         limit_gb = float(os.environ.get('FEABAS_RSS_LIMIT_GB', '24'))
     if limit_gb <= 0:
         return None
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = _BACKSTOP % dict(root=root, pid=os.getpid(), limit=1.15 * limit_gb)
-    return subprocess.Popen([sys.executable, '-c', code], stdin=subprocess.DEVNULL, close_fds=True)
+    code = _BACKSTOP % dict(pid=os.getpid(), limit=1.15 * limit_gb)       # (self-contained: the child imports nothing of the package)
+    return subprocess.Popen([sys.executable, '-S', '-c', code], stdin=subprocess.DEVNULL, close_fds=True)
