@@ -708,9 +708,27 @@ class _PairRelaxation:
                                            render_weight_threshold=self.render_weight_threshold)
         return len(self.slm.links)
 
-    def relax(self, tol, more_rounds):
+    def relax(self, tol, more_rounds, snap_rigid=False):
         """relax; with a residue length the matches are re-weighted by what is left of them (huber / threshold) and, when that
-        changed a weight and another round follows, relaxed again"""
+        changed a weight and another round follows, relaxed again.  snap_rigid (the strip routes): a relaxation that moved a mesh by a
+        whole-pixel translation to within 1e-6 -- every block of a round without sub-pixel peaks measured the same -- is taken as
+        exactly that translation, like stitch_pipeline does: the next round's block grid rounds the bounding box of the moved mesh, and
+        a translated image edge sits exactly on a rounding tie, which the noise of the solve would otherwise decide (it does in
+        the reference; the two strip routes of this package then put the last row of blocks a pixel apart)"""
+        before = [None if m.locked else (m.vertices(const.MESH_GEAR_MOVING).copy(), np.array(m.offset(const.MESH_GEAR_MOVING), dtype=np.float64))
+                  for m in self.meshes] if snap_rigid else None
+        self._relax(tol, more_rounds)
+        if before is not None:
+            for m, was in zip(self.meshes, before):
+                if was is None:
+                    continue
+                d = m.vertices_w_offset(const.MESH_GEAR_MOVING) - (was[0] + was[1])
+                whole = np.round(d.mean(axis=0))
+                if np.abs(d - whole).max() < 1e-6:
+                    m.set_vertices(was[0], const.MESH_GEAR_MOVING)          # the vertices as they were, the whole pixels in the offset
+                    m.set_offset(was[1] + whole.reshape(np.shape(was[1])), const.MESH_GEAR_MOVING)
+
+    def _relax(self, tol, more_rounds):
         self._solve(tol, 3)
         if self.residue_len > 0:
             if self.residue_mode == 'huber':
@@ -774,6 +792,7 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
     relax_tol, opt_tol = get('relax_tol', 1e-9), get('opt_tol', None)
     relax_tol = np.inf if relax_tol is None else relax_tol
     affine_render = get('affine_approximated_render', True)
+    snap_rigid = bool(get('snap_rigid', False))        # _PairRelaxation.relax; set by the strip routes of stitching_matcher
     failed = (None, None, 0, DEFAULT_AVG_DEFORM)
     spacings = np.array(spacings, dtype=np.float64).ravel()
     if np.any(spacings < 1):                            # fractions of the longer side of the overlap (matcher.py:541-551)
@@ -839,7 +858,7 @@ def iterative_xcorr_matcher_w_mesh(mesh0, mesh1, image_loader0, image_loader1, s
                     return failed
                 break
             if max_dis > 0.1:
-                pair.relax(min(relax_tol, 0.01 / max(1, max_dis)) if opt_tol is None else opt_tol, more_rounds=plan.due() is not None)
+                pair.relax(min(relax_tol, 0.01 / max(1, max_dis)) if opt_tol is None else opt_tol, more_rounds=plan.due() is not None, snap_rigid=snap_rigid)
             if trace is not None:
                 trace[-1]['field1'] = mesh1.vertices_w_offset(const.MESH_GEAR_MOVING) - mesh1.vertices_w_offset(const.MESH_GEAR_INITIAL)
                 trace[-1]['solve'] = dict(getattr(pair.slm, 'last_solve', {}))
@@ -1175,7 +1194,7 @@ def _stitching_matcher_general(img0, img1, opts, mask0, mask1, compute_photometr
         xy0, xy1, weight, strain = iterative_xcorr_matcher_w_mesh(mesh0, mesh1, im0, im1, spacings=spacings, distributor='cartesian_bbox',
                                                                   residue_len=residue_len, residue_mode=('threshold' if opts['residue_mode'] == 'threshold' else 'huber'),
                                                                   conf_thresh=conf_thresh, conf_mode=conf_mode, min_num_blocks=mnb,
-                                                                  stiffness_lambda=opts['stiffness_lambda'], compute_strain=opts['compute_strain'])
+                                                                  stiffness_lambda=opts['stiffness_lambda'], compute_strain=opts['compute_strain'], snap_rigid=True)
     finally:
         im0.free(); im1.free()
     if xy0 is None:

@@ -747,10 +747,8 @@ class SLM:
         # multigrid (csrc/fb_mg.inc: rigid-body modes per aggregate, V(1,1) cycles) as the preconditioner of the same PCG --
         # the same fixed point, an order of magnitude fewer iterations on weakly pinned meshes
         if kwargs.get('distributed', None) is not None:
-            if groupings is not None:
-                raise NotImplementedError('optimize_linear(distributed=...) with groupings')
             return self._optimize_linear_distributed(kwargs['distributed'], kwargs.get('owned', None), tol, atol, maxiter, shape_gear,
-                                                     start_gear, target_gear, stiffness_lambda, crosslink_lambda)
+                                                     start_gear, target_gear, stiffness_lambda, crosslink_lambda, groupings)
         if np.all(self.lock_flags):
             return 0, 0
         if kwargs.get('remove_material_dof', None) is not None:
@@ -919,7 +917,8 @@ class SLM:
             parts.append(sel)
         return self._fold_dof_selector(parts, groupings)
 
-    def _optimize_linear_distributed(self, group, owned, tol, atol, maxiter, shape_gear, start_gear, target_gear, stiffness_lambda, crosslink_lambda):
+    def _optimize_linear_distributed(self, group, owned, tol, atol, maxiter, shape_gear, start_gear, target_gear, stiffness_lambda, crosslink_lambda,
+                                     groupings=None):
         """optimize_linear of a coupled window (aligner.py:510-535, 696-727: all free sections of a window are ONE system)
         with the rows partitioned by section over the ranks of `group` (torch.distributed; True = the default group).
         Every rank holds the sections it OWNS (default: a contiguous shard of the free meshes in list order, every rank
@@ -928,44 +927,118 @@ class SLM:
         touches them, including the blocks that couple to a neighbour's section -- are assembled on the device (fb_sys_*),
         and solved with the row-partitioned Jacobi-PCG of feabas_amd/dist.py (halo exchange with the neighbouring ranks +
         one fused all-reduce per iteration; fused vector kernels on the GPU).  The trace-relative lambdas come from
-        all-reduced sums.  Returns (||b||, ||A d - b||) of the whole window; every rank moves the sections it owns."""
+        all-reduced sums.  Returns (||b||, ||A d - b||) of the whole window; every rank moves the sections it owns.
+
+        `groupings` (optimizer.py:1378-1415; one label per mesh of self.meshes, the same labels on every rank): the members of
+        a group share their degrees of freedom, so the unit of ownership is the GROUP -- the shard is one of free groups in order of
+        first appearance, `owned` must name every free member of a group it names, and a rank lists every member of the
+        groups it touches (a group with a locked member is locked as a whole, as in the reference).  The lambdas come from the
+        mesh-level (ungrouped) terms like the reference's (optimizer.py:1573-1590), the costs are divided by the mean group size."""
         import torch.distributed as dist                        # the rendezvous (who owns what); no tensor of torch's is involved
         from . import dist as fdist
         from .mesh import bsr_download
         grp = fdist.host_group(None if group is True else group)
         rank, world = dist.get_rank(grp), dist.get_world_size(grp)
-        free = [m for m in self.meshes if not m.locked]
+        if groupings is not None:
+            labels = np.asarray(groupings).ravel().tolist()
+            if len(labels) != len(self.meshes):
+                raise ValueError('optimize_linear(distributed, groupings): one label per mesh')
+            if len(set(labels)) == len(labels):
+                groupings = None                                # every mesh alone in its group
+        if groupings is None:
+            unit_of = {id(m): m.uid for m in self.meshes}      # the unit of ownership: the mesh
+        else:
+            unit_of = {id(m): ('g', lb) for m, lb in zip(self.meshes, labels)}
+        held_units = {unit_of[id(m)] for m in self.meshes if m.locked}
+        units = {}                                              # free units in order of first appearance -> their meshes
+        for m in self.meshes:
+            if unit_of[id(m)] not in held_units:
+                units.setdefault(unit_of[id(m)], []).append(m)
+        wards = [m for m in self.meshes if not m.locked and unit_of[id(m)] in held_units]   # free meshes of a locked group: held, but counted by the lambdas
+        order = list(units)
         if owned is None:
-            a, b = fdist.shard_range(len(free), rank, world)
-            own = free[a:b]
+            a, b = fdist.shard_range(len(order), rank, world)
+            own_units = order[a:b]
+            my_wards = wards[rank::world]
         else:
             owned = {float(u) for u in owned}
-            own = [m for m in free if m.uid in owned]
+            own_units = [u for u in order if any(m.uid in owned for m in units[u])]
+            for u in own_units:
+                if not all(m.uid in owned for m in units[u]):
+                    raise ValueError(f'optimize_linear(distributed, groupings): group {u[1]} is only partly in `owned`')
+            my_wards = [m for m in wards if m.uid in owned]
+        own = [m for u in own_units for m in units[u]]
         own_ids = {id(m) for m in own}
         links = [lk for lk in self._active_links() if id(lk.meshes[0]) in own_ids or id(lk.meshes[1]) in own_ids]
-        halo, seen = [], set(own_ids)
+        halo, halo_units, seen = [], [], set(own_ids)
         for lk in links:
             for m in lk.meshes:
-                if not m.locked and id(m) not in seen:
+                u = unit_of[id(m)]
+                if u not in held_units and id(m) not in seen:
                     seen.add(id(m)); halo.append(m)
-        locked = [m for m in self.meshes if m.locked]
-        n_own = int(sum(2 * m.num_vertices for m in own))
+                    if u not in halo_units:
+                        halo_units.append(u)
+        locked = [m for m in self.meshes if unit_of[id(m)] in held_units]
+        unit_dof = {u: 2 * units[u][0].num_vertices for u in order}
+        n_own = int(sum(unit_dof[u] for u in own_units))
         sizes = [None] * world
-        dist.all_gather_object(sizes, [(m.uid, 2 * m.num_vertices) for m in own], group=grp)
+        dist.all_gather_object(sizes, [(u, unit_dof[u]) for u in own_units], group=grp)
         gstart, cur, row_start = {}, 0, 0
         for r_, lst in enumerate(sizes):
             if r_ == rank:
                 row_start = cur
-            for uid, nd in lst:
-                gstart[uid] = cur
+            for u, nd in lst:
+                gstart[u] = cur
                 cur += nd
-        missing = [m.uid for m in halo if m.uid not in gstart]
+        missing = [m.uid for m in halo if unit_of[id(m)] not in gstart]
         if missing:
             raise ValueError(f'optimize_linear(distributed): sections {missing} are linked to this rank but owned by no rank')
+        gmean = 1.0
+        if groupings is not None:
+            # mean group size over the whole window (optimizer.py:1408-1411 divides the grouped terms by it): free groups from their
+            # owners, held groups from whoever lists them
+            seen_held = [None] * world
+            dist.all_gather_object(seen_held, {u: sum(1 for m in self.meshes if unit_of[id(m)] == u) for u in held_units}, group=grp)
+            held_cnt = {}
+            for d_ in seen_held:
+                for u, c in d_.items():
+                    held_cnt[u] = max(held_cnt.get(u, 0), c)
+            nm, ng = fdist.host_sum([len(own), len(own_units)], group=grp)
+            gmean = float((nm + sum(held_cnt.values())) / max(1.0, ng + len(held_cnt)))
+
+        def mesh_level_sums(first, others, lks):
+            """(sum diag C, sum of diag K where diag C != 0) over the rows of the meshes `first`, from an ungrouped assembly"""
+            if not first:
+                return np.zeros(2)
+            mine = {id(m) for m in first}
+            near, got = [], set(mine)
+            for lk in lks:
+                for m in lk.meshes:
+                    if id(m) not in got and not m.locked:
+                        got.add(id(m)); near.append(m)
+            tmp = SLM(first + near + [m for m in others if m.locked], lks, stiffness_lambda=stiffness_lambda, crosslink_lambda=crosslink_lambda)
+            tmp._skip_stiffness = {m.uid for m in near}
+            try:
+                tmp._assemble(shape_gear, start_gear, target_gear)
+                n1 = int(sum(2 * m.num_vertices for m in first))
+                dk = bsr_download(tmp._sys, 0, tmp._nv, tmp._nnzb)[:n1, :n1].diagonal()
+                dc = bsr_download(tmp._sys, 1, tmp._nv, tmp._nnzb)[:n1, :n1].diagonal()
+            finally:
+                tmp._drop_system()
+            return np.array([dc.sum(), dk[dc != 0].sum()])
         if n_own > 0:
-            local = SLM(own + halo + locked, links, stiffness_lambda=stiffness_lambda, crosslink_lambda=crosslink_lambda)
+            if groupings is None:
+                local = SLM(own + halo + locked, links, stiffness_lambda=stiffness_lambda, crosslink_lambda=crosslink_lambda)
+                local_groups = None
+            else:
+                # local labels in row order: own groups, then the groups of the halo, then the held ones (_layout numbers the
+                # groups in sorted label order)
+                members = own + halo + locked
+                code = {u: k for k, u in enumerate(own_units + halo_units + sorted(held_units, key=repr))}
+                local = SLM(members, links, stiffness_lambda=stiffness_lambda, crosslink_lambda=crosslink_lambda)
+                local_groups = np.array([code[unit_of[id(m)]] for m in members], dtype=np.int64)
             local._skip_stiffness = {m.uid for m in halo}
-            local._assemble(shape_gear, start_gear, target_gear)
+            local._assemble(shape_gear, start_gear, target_gear, local_groups)
             nv, nnzb = local._nv, local._nnzb
             K = bsr_download(local._sys, 0, nv, nnzb)[:n_own]
             Cm = bsr_download(local._sys, 1, nv, nnzb)[:n_own]
@@ -973,10 +1046,15 @@ class SLM:
             _lib.check(_lib.load().fb_sys_get(_lib.ctx(), local._sys, 2, _lib.ptr(rhs)))
             _lib.check(_lib.load().fb_sys_get(_lib.ctx(), local._sys, 3, _lib.ptr(stress)))
             rhs, stress = rhs[:n_own], stress[:n_own].astype(np.float64)
-            dk = K[:, :n_own].diagonal(); dc = Cm[:, :n_own].diagonal()
-            sums = np.array([dc.sum(), dk[dc != 0].sum()])
+            if groupings is None:
+                dk = K[:, :n_own].diagonal(); dc = Cm[:, :n_own].diagonal()
+                sums = np.array([dc.sum(), dk[dc != 0].sum()])
         else:
             sums = np.zeros(2)
+        if groupings is not None:
+            first = own + my_wards
+            ids1 = {id(m) for m in first}
+            sums = mesh_level_sums(first, self.meshes, [lk for lk in self._active_links() if id(lk.meshes[0]) in ids1 or id(lk.meshes[1]) in ids1])
         tr_c, sum_k = (float(v) for v in fdist.host_sum(sums, group=grp))
         sl, cl = float(stiffness_lambda), float(crosslink_lambda)
         if sl < 0 or cl < 0:                                    # optimizer.py:1573-1590 on the all-reduced sums
@@ -986,13 +1064,13 @@ class SLM:
             A = (sl * K + cl * Cm).tocsr()
             A.sort_indices()
             bvec = cl * rhs - sl * stress
-            # local column -> global DoF: own columns first, then the halo sections at their owner's offsets
+            # local column -> global DoF: own columns first, then the halo sections (groups) at their owner's offsets
             col_map = np.empty(2 * nv, dtype=np.int64)
             col_map[:n_own] = row_start + np.arange(n_own)
             o = n_own
-            for m in halo:
-                nd = 2 * m.num_vertices
-                col_map[o:o + nd] = gstart[m.uid] + np.arange(nd)
+            for u in ([unit_of[id(m)] for m in halo] if groupings is None else halo_units):
+                nd = unit_dof[u]
+                col_map[o:o + nd] = gstart[u] + np.arange(nd)
                 o += nd
             indptr, gcols, data = A.indptr.astype(np.int64), col_map[A.indices], A.data
             diag = A[:, :n_own].diagonal()
@@ -1014,12 +1092,13 @@ class SLM:
             rows.free()
         self.last_solve = dict(iters=int(it), relres=float(rel), stiffness_lambda=sl, crosslink_lambda=cl, rows=n_own, halo=int(part.n_halo),
                                exchange='rccl' if comm is not None else ('none' if world == 1 else 'host group'))
-        cost = (bnorm, float(rel) * bnorm)
+        cost = (bnorm / gmean, float(rel) * bnorm / gmean)
         if cost[1] < cost[0]:
             o = 0
-            for m in own:
-                nd = 2 * m.num_vertices
-                m.set_field(x[o:o + nd].reshape(-1, 2), gear=(start_gear, target_gear))
+            for u in own_units:
+                nd = unit_dof[u]
+                for m in units[u]:                              # the members of a group move together (optimizer.py:1425-1432)
+                    m.set_field(x[o:o + nd].reshape(-1, 2), gear=(start_gear, target_gear))
                 o += nd
         return cost
 

@@ -218,6 +218,86 @@ def test_optimize_linear_distributed_equals_single_gpu(tmp_path, world):
         np.testing.assert_allclose(got[f'v{m.uid:.0f}'], m.vertices_w_offset(1), atol=1e-6 * motion)
 
 
+_GROUPS = [0, 0, 1, 1, 2, 3, 3, 4]
+
+
+def _grouped_window(seed=5):
+    """eight sections in five groups whose members share their degrees of freedom (optimizer.py:1378-1415): {0 locked, 1} -- held as
+    a whole, section 1 is free but does not move --, {2, 3}, {4}, {5, 6}, {7}; a chain of links, plus one from section 2 to section 6"""
+    from feabas_amd import mesh, optimizer
+    from oracle import fem_ref
+    rng = np.random.default_rng(seed)
+    meshes = []
+    for s, g in enumerate(_GROUPS):
+        nx, ny = 20 + 2 * (g % 3), 17 + (g % 2)
+        v, t = fem_ref.grid_mesh(nx, ny, 10.0)
+        L = 10.0 * nx
+        d = np.stack((1.5 * np.sin(2 * np.pi * v[:, 1] / L + 0.7 * g), 1.2 * np.cos(2 * np.pi * v[:, 0] / L - 0.4 * g)), axis=-1)
+        meshes.append(mesh.Mesh(v + d, t, uid=float(s), locked=(s == 0)))
+    links = []
+    for a, b in [(s, s + 1) for s in range(len(_GROUPS) - 1)] + [(2, 6)]:
+        n = 250
+        xy = np.stack((rng.uniform(5, 180, n), rng.uniform(5, 150, n)), axis=-1)
+        rel = np.stack((1.5 * np.sin(xy[:, 1] / 40.0 + a), 1.0 * np.cos(xy[:, 0] / 50.0 - b)), axis=-1)
+        lk, _ = optimizer.Link.from_coordinates(meshes[a], meshes[b], xy, xy + rel + rng.normal(0, 0.05, xy.shape), weight=rng.uniform(0.3, 1, n).astype(np.float32))
+        links.append(lk)
+    return meshes, links
+
+
+def _grouped_worker(rank, world, port, outdir, by_uid):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from feabas_amd import optimizer
+    meshes, links = _grouped_window()
+    slm = optimizer.SLM(meshes, links, stiffness_lambda=1.0, crosslink_lambda=-1.0)
+    kw = {}
+    if by_uid:                                      # ownership by uid: whole groups per rank, in an order that is not the list's
+        split = {1: [[1, 2, 3, 4, 5, 6, 7]], 2: [[5, 6, 7, 1], [4, 2, 3]]}[world]      # (1: the free member of the held group, for the lambdas)
+        kw['owned'] = [float(u) for u in split[rank]]
+    cost = slm.optimize_linear(tol=1e-10, distributed=True, groupings=_GROUPS, **kw)
+    np.savez(os.path.join(outdir, f'g{rank}.npz'), cost=np.array(cost), rows=slm.last_solve['rows'], **{f'v{m.uid:.0f}': m.vertices_w_offset(1) for m in meshes})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,by_uid', [(1, False), (2, False), (3, False), (2, True)])
+def test_optimize_linear_distributed_with_groupings_equals_single_gpu(tmp_path, world, by_uid):
+    """optimize_linear(distributed=..., groupings=...): the unit of ownership is the group (its members share the rows); a group with
+    a locked member stays where it is, its free member still counts in the trace-relative lambdas (mesh-level sums, optimizer.py:1573-1590).
+    Same lambdas, costs and node positions as the single-GPU grouped solve, which goldens G19 / G21 pin to the reference"""
+    import torch.multiprocessing as mp
+    from feabas_amd import optimizer
+    meshes, links = _grouped_window()
+    v_before = [m.vertices_w_offset(1).copy() for m in meshes]
+    ref_cost = optimizer.SLM(meshes, links, stiffness_lambda=1.0, crosslink_lambda=-1.0).optimize_linear(tol=1e-10, groupings=_GROUPS)
+    moved = [np.abs(m.vertices_w_offset(1) - v0).max() for m, v0 in zip(meshes, v_before)]
+    motion = max(moved)
+    assert motion > 0.5 and moved[0] == 0 and moved[1] == 0
+    np.testing.assert_allclose(meshes[2].vertices_w_offset(1) - v_before[2], meshes[3].vertices_w_offset(1) - v_before[3], atol=1e-12)
+    mp.spawn(_grouped_worker, args=(world, _free_port(), str(tmp_path), by_uid), nprocs=world, join=True)
+    rows = 0
+    for r in range(world):
+        d = np.load(tmp_path / f'g{r}.npz')
+        rows += int(d['rows'])
+        assert abs(d['cost'][0] - ref_cost[0]) <= 1e-9 * ref_cost[0]
+        assert d['cost'][1] <= 1e-10 * d['cost'][0] * 1.01
+        for k, (m, v0) in enumerate(zip(meshes, v_before)):
+            got = d[f'v{m.uid:.0f}']
+            if np.abs(got - v0).max() == 0 and moved[k] > 0:
+                continue                              # a section of another rank: not moved here
+            np.testing.assert_allclose(got, m.vertices_w_offset(1), atol=1e-6 * motion)
+    free_dofs = sum(2 * meshes[k].num_vertices for k in (2, 4, 5, 7))      # one set of rows per free group
+    assert rows == free_dofs
+    seen = set()
+    for r in range(world):
+        d = np.load(tmp_path / f'g{r}.npz')
+        seen |= {k for k, v0 in enumerate(v_before) if np.abs(d[f'v{k}'] - v0).max() > 0}
+    assert seen == {2, 3, 4, 5, 6, 7}
+
+
 def test_pcg_host_path_restarts_after_a_dropped_step():
     """a dropped step (non-positive denominator) used to make every later step a dropped one.  Now the step
     after it restarts the recurrence: an indefinite system is reported after `check_every` dropped steps instead of running

@@ -879,6 +879,17 @@ def test_stitching_matcher_unequal_strip_shapes(fb):
     # spacings relative to the overlap (< 1, matcher.py:343-350) take the same route
     rel = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2, spacings=[0.25, 75])
     assert rel[0] is not None and np.abs(np.median(rel[1] - rel[0], axis=0) - d_full).max() < 0.15
+    # ... from the batch entry too (pair by pair: the spacings follow every pair's own overlap), and they are the pixel spacings
+    # they resolve to: 0.25 x the longer side of the overlap of the translated strips
+    outs = fb.matcher.stitching_matcher_batch([(s0, s1), (t0, t1)], batch=2, threads=1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2,
+                                              spacings=[0.25, 75])
+    np.testing.assert_allclose(outs[0][0], rel[0], atol=1e-9); np.testing.assert_allclose(outs[0][1], rel[1], atol=1e-9)
+    assert outs[1][0] is not None and np.abs(np.median(outs[1][1] - outs[1][0], axis=0) + np.array([-3, 2])).max() < 0.3
+    g_tx, g_ty = np.round(-d_full)
+    side = max(W - abs(g_tx), H - abs(g_ty))
+    pix = fb.matcher.stitching_matcher(s0, s1, sigma=2.5, coarse_downsample=0.5, conf_thresh=0.33, residue_len=2, spacings=[0.25 * side, 75])
+    assert pix[0].shape == rel[0].shape
+    np.testing.assert_allclose(pix[0], rel[0], atol=2e-3); np.testing.assert_allclose(pix[1], rel[1], atol=2e-3)
 
 
 @pytest.mark.parametrize('H,W,P,cds,mode', [(1024, 256, 10, 0.5, 'huber'), (256, 1024, 7, 0.5, 'threshold'), (640, 200, 6, 1, 'huber'),
