@@ -261,7 +261,7 @@ def bench_fem(args, lib, ctx, _lib):
     return out
 
 
-def bench_xcorr_classes(lib, ctx, _lib):
+def bench_xcorr_classes(lib, ctx, _lib, only=None):
     """kernel-only rate of matcher.xcorr_fft at the three shape classes of the 4k configuration:
     block pairs per second with the stacks resident in HBM"""
     out = {}
@@ -274,6 +274,8 @@ def bench_xcorr_classes(lib, ctx, _lib):
                                       'readme_74x72_fft150x144_run_at_160x144': (1024, 74, 72, 1, 1), 'readme_67x75_fft135x150_run_at_144x160': (1024, 67, 75, 1, 1),
                                       # literal stress variant of SURVEY.md sec.8d: whole 4096 x 4096 tiles
                                       'full_4096x4096_fft4096x4096': (4, 4096, 4096, 0, 1), 'full_4096x4096_fft8192x8192_padded': (4, 4096, 4096, 1, 1)}.items():
+        if only and not any(o_ in name for o_ in only):
+            continue
         a = rng.standard_normal((min(N, 256), h, w)).astype(np.float32)
         a = np.tile(a, (-(-N // a.shape[0]), 1, 1))[:N]
         d0 = _lib.DeviceBuffer.from_array(a); d1 = _lib.DeviceBuffer.from_array(np.roll(a, (2, -3), (1, 2)))
@@ -286,6 +288,14 @@ def bench_xcorr_classes(lib, ctx, _lib):
             if r:
                 best = min(best, ms.value)
         out[name] = dict(block_pairs_per_s=N / (best * 1e-3), us_per_block_pair=1e3 * best / N)
+        if name.startswith('full_'):
+            # whole tiles: the streaming passes at their algorithmic bytes (rows read both images and write T, the
+            # column pass reads T and writes V, the inverse-row pass reads V; MIRROR confidence: V has two planes), against 8 TB/s
+            F = 8192 if pad else 4096
+            sw = F // 2 + 1
+            nbytes = 8.0 * h * w + sw * (2 * 16.0 * h + 2 * 8.0 * 2 * F)
+            out[name].update(fft_shape=[F, F], algorithmic_bytes_per_pair=nbytes, algorithmic_gbs=nbytes * N / (best * 1e-3) / 1e9,
+                             frac_of_8tbs=nbytes * N / (best * 1e-3) / 8e12)
         for b in (d0, d1, o):
             b.free()
     return out

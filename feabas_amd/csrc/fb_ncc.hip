@@ -723,7 +723,59 @@ int get_tw16_table(fb_ctx* ctx, int n, const float2** tw) {
     return FB_OK;
 }
 
+// twS[y] = exp(-2 pi i y / n), y < n / 2 (split columns of length n: the input twiddle of the odd branch, the butterfly of the inverse)
+std::map<std::pair<int, int>, float2*> g_tw_split_tables;
+int get_tw_split_table(fb_ctx* ctx, int n, const float2** tw) {
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lk(mtx);
+    auto key = std::make_pair(ctx->device, n);
+    auto it = g_tw_split_tables.find(key);
+    if (it == g_tw_split_tables.end()) {
+        const int cnt = n / 2;
+        std::vector<float2> h((size_t)cnt);
+        for (int k = 0; k < cnt; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)n;
+            h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        float2* d = nullptr;
+        FB_HIP(ctx, hipMalloc((void**)&d, sizeof(float2) * cnt));
+        FB_HIP(ctx, hipMemcpy(d, h.data(), sizeof(float2) * cnt, hipMemcpyHostToDevice));
+        it = g_tw_split_tables.emplace(key, d).first;
+    }
+    *tw = it->second;
+    return FB_OK;
+}
+
 int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+
+// the 8192-point shapes of the power-of-two core: rows of 8192 points (one per tile), columns of 8192 points whose upper half is
+// zero padding as two half-length items (fb_ncc_p2.inc: split columns); the other axis a power of two of the core
+bool p2_long_shape(int Fh, int Fw, int hmax) {
+    if (getenv("FEABAS_HIP_FFT_GENERIC") || getenv("FEABAS_HIP_NO_LONG")) return false;
+    if (!(Fh == kSplitLen || Fw == kSplitLen) || Fw < 256) return false;
+    if (!(p2_shape(Fw) || Fw == kSplitLen)) return false;
+    if (p2_shape(Fh)) return true;
+    const int tr = p2_tr(Fw);                                  // the row pass stores whole tiles of rows
+    return Fh == kSplitLen && 2 * ((std::max(1, hmax) + tr - 1) / tr * tr) <= Fh;
+}
+
+// A shape with an axis of 4097 .. 8192 points (the reference's next_fast_len of two whole 4096-pixel tiles padded is 8192 itself; of
+// 4000-pixel tiles, 8000) at the 8192-point forms: linear (zero-padded) axes go up to the next power of two, like
+// promote_linear_shape below and for the same reason; a circular axis, and every axis under FFT_CONF_STD, must be one as it stands.
+bool promote_long_shape(int& Fh, int& Fw, int need_h, int need_w, int hmax, int conf_mode) {
+    if ((Fh <= 4096 && Fw <= 4096) || Fh > kSplitLen || Fw > kSplitLen) return false;
+    const bool exact = conf_mode == FB_CONF_STD || getenv("FEABAS_HIP_FFT_EXACT");
+    auto up = [&](int F, int need) {
+        if (F < need || exact) return F;
+        int P = 64;
+        while (P < F) P <<= 1;
+        return P;
+    };
+    const int ph = up(Fh, need_h), pw = up(Fw, need_w);
+    if (!p2_long_shape(ph, pw, hmax)) return false;
+    Fh = ph; Fw = pw;
+    return true;
+}
 
 bool stream_custom_supported(int Fh, int Fw, int C) {
     if (C != 1 || Fw > 4096 || Fh > 4096 || Fw < 4 || Fh < 2) return false;
@@ -740,23 +792,31 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     const char* trb = getenv("FB_TRB");
     const size_t lds_budget = (trb ? (size_t)atoi(trb) : 70) * 1024;
     g.TR = std::min(16, pow2_floor((int)std::max<size_t>(1, lds_budget / ((size_t)(Fw + Fw / 16 + 1) * sizeof(float2)))));
-    const bool p2 = p2_shape(Fh) && p2_shape(Fw) && !getenv("FEABAS_HIP_FFT_GENERIC");
+    const bool p2_long = p2_long_shape(Fh, Fw, hmax);                       // an axis of 8192 points
+    const bool split = p2_long && Fh == kSplitLen;                          // ... the columns: two half-length items per column pair
+    const bool p2 = p2_long || (p2_shape(Fh) && p2_shape(Fw) && !getenv("FEABAS_HIP_FFT_GENERIC"));
     const bool ct = !p2 && fb_ncc_ct_len(Fh) && fb_ncc_ct_len(Fw) && !getenv("FEABAS_HIP_FFT_GENERIC");     // compile-time mixed-radix plans
     if (p2) g.TR = p2_tr(Fw);
     if (ct) g.TR = fb_ncc_ct_tr(Fw);
-    g.TRI = g.TR;
+    g.TRI = split ? p2_trs(Fw) : g.TR;
     // inverse pass on half tiles (workgroups of 256 threads, twice as many per CU: half as many waves meet at each barrier):
     // 11-13 % faster at FW <= 1024; narrower tiles would cut the contiguous runs of V below 64 B (FB_INV_HALF=0/1 overrides)
     const char* inv_half = getenv("FB_INV_HALF");
-    if (p2 && (inv_half ? atoi(inv_half) != 0 : g.TR >= 8)) g.TRI = std::max(1, g.TR / 2);
+    if (p2 && !split && (inv_half ? atoi(inv_half) != 0 : g.TR >= 8)) g.TRI = std::max(1, g.TR / 2);
     const int rows = std::min(Fh, std::max(1, hmax));
     g.Hs = (rows + g.TR - 1) / g.TR * g.TR;
     g.H0 = H0; g.W0 = W0; g.H1 = H1; g.W1 = W1;
-    if (!fft_make_plan(Fw, &g.pw) || !fft_make_plan(Fh, &g.ph)) return fb_fail(ctx, FB_ERR_ARG, "ncc: FFT shape %dx%d is not 5-smooth", Fh, Fw);
-    int rc = get_split_table(ctx, Fw, &g.twW_hi, &g.twW_lo);
-    if (rc) return rc;
-    rc = get_split_table(ctx, Fh, &g.twH_hi, &g.twH_lo);
-    if (rc) return rc;
+    int rc = FB_OK;
+    if (!p2_long) {                         // (plans and two-level twiddles of the generic kernels: lengths up to 4096)
+        if (!fft_make_plan(Fw, &g.pw) || !fft_make_plan(Fh, &g.ph)) return fb_fail(ctx, FB_ERR_ARG, "ncc: FFT shape %dx%d is not 5-smooth", Fh, Fw);
+        rc = get_split_table(ctx, Fw, &g.twW_hi, &g.twW_lo);
+        if (rc) return rc;
+        rc = get_split_table(ctx, Fh, &g.twH_hi, &g.twH_lo);
+        if (rc) return rc;
+    } else {
+        g.twW_hi = g.twW_lo = g.twH_hi = g.twH_lo = nullptr;
+        if (split && 2 * g.Hs > Fh) return fb_fail(ctx, FB_ERR_ARG, "ncc: %d rows in columns of %d points", g.Hs, Fh);
+    }
     g.img0 = img0; g.img1 = img1;
     g.blk = crop ? crop->blk : nullptr;
     g.aff = crop ? crop->aff : nullptr;
@@ -781,9 +841,11 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     const size_t lds_rows = ((size_t)g.TR * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
     const size_t lds_cols = (4 * (size_t)(Fh + Fh / 16 + 1) + 128) * sizeof(float2);
     const size_t lds_inv = ((size_t)g.TRI * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
-    FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
-    FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
-    FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_inv, ((size_t)4 * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) * sizeof(short))));
+    if (!p2 && !ct) {
+        FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+        FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
+        FB_HIP(ctx, hipFuncSetAttribute((const void*)ncc_stream_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_inv, ((size_t)4 * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) * sizeof(short))));
+    }
     const double in_bytes = crop ? 8.0 * hmax * wmax : 4.0 * ((double)H0 * W0 + (double)H1 * W1);
     const double nq = g.want_q ? 2.0 : 1.0;
     if (ct) {
@@ -806,6 +868,13 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     // (fb_ncc_p2.inc: p2_item); default 7.  Only for the one-workgroup-per-item launches.
     static const int xcd_mask = [] { const char* e = getenv("FEABAS_HIP_P2_XCD"); return e ? atoi(e) : 7; }();
     q.per8 = 0;
+    // one persistent workgroup per CU that walks its XCD's eighth of the items (fb_ncc_p2.inc: p2_step / p2_valid)
+    auto xcd_persist = [&](int total) {
+        const int k = std::max(1, ctx->prop.multiProcessorCount / 8);
+        q.per8 = (total + 7) / 8;
+        return 8 * std::min(q.per8, k);
+    };
+    const int persist = !p2_long ? 0 : (getenv("FB_P2_LONG_PERSIST") ? atoi(getenv("FB_P2_LONG_PERSIST")) : 1);    // bit 0: inverse rows, bit 1: rows and columns
     auto xcd_grid = [&](int bit, int total, int grid) {       // grid of the launch; sets q.per8
         q.per8 = 0;
         if (!(xcd_mask & bit) || grid != total || total < 64) return grid;
@@ -815,11 +884,17 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     if (p2) {
         rc = get_tw16_table(ctx, Fw, &q.twW);
         if (rc) return rc;
-        rc = get_tw16_table(ctx, Fh, &q.twH);
+        const int Fc = split ? Fh / 2 : Fh;                 // length of the column transforms
+        rc = get_tw16_table(ctx, Fc, &q.twH);
         if (rc) return rc;
-        const size_t pw = (size_t)(Fw + Fw / 16 + 1), ph = (size_t)(Fh + Fh / 16 + 1);
+        q.twS = nullptr;
+        if (split) {
+            rc = get_tw_split_table(ctx, Fh, &q.twS);
+            if (rc) return rc;
+        }
+        const size_t pw = (size_t)(Fw + Fw / 16 + 1), ph = (size_t)(Fc + Fc / 16 + 1);
         lds_rows2 = ((size_t)g.TR * pw + Fw / 16) * sizeof(float2);
-        lds_cols2 = (4 * (size_t)p2_np(Fh) * ph + Fh / 16) * sizeof(float2);
+        lds_cols2 = (4 * (size_t)p2_np(Fc) * ph + Fc / 16) * sizeof(float2);
         lds_inv2 = ((size_t)g.TRI * pw + Fw / 16) * sizeof(float2);
         lds_n2 = ((size_t)4 * pw + Fw / 16) * sizeof(float2);
         q.lTRI = 0;
@@ -830,12 +905,20 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
         FB_PROF_B(ctx, "ncc_stream_rows", nb * (in_bytes + 16.0 * g.Sw * g.Hs));
         if (p2) {
             q.tiles = g.Hs / g.TR; q.total = q.tiles * nb;
-            { const int grid = xcd_grid(1, q.total, std::min(q.total, wg_slots)); FB_P2_SWITCH(Fw, rows(ctx->stream, grid, lds_rows2, g, q, T0, T1)); }
+            // (rows and columns of the 8192-point shapes as one persistent workgroup per CU with register prefetch -- their tiles fill
+            // the LDS, no neighbour shares the CU -- were measured at HALF the rate of one workgroup per item: the persistent walk
+            // gives up the XCD-contiguous order of the stores.  FB_P2_LONG_PERSIST=3 to repeat; the inverse pass, which only reads, gains 15 %)
+            { const int grid = ((persist & 2) && lds_rows2 > 80 * 1024) ? xcd_persist(q.total) : xcd_grid(1, q.total, std::min(q.total, wg_slots));
+              FB_P2_SWITCH_W(Fw, rows(ctx->stream, grid, lds_rows2, g, q, T0, T1)); }
         } else hipLaunchKernelGGL(ncc_stream_rows, dim3(g.Hs / g.TR, nb), dim3(kStreamThreads), lds_rows, ctx->stream, g, T0, T1);
     }
     {
         FB_PROF_B(ctx, "ncc_stream_cols", (double)nb * g.Sw * (16.0 * g.Hs + 8.0 * nq * Fh));
-        if (p2) {
+        if (split) {
+            q.tiles = 2 * g.Kp; q.total = q.tiles * nb;                                  // (column pair, even / odd frequencies)
+            const int grid = (persist & 2) ? xcd_persist(q.total) : xcd_grid(2, q.total, q.total);
+            p2_cols_split(ctx->stream, grid, lds_cols2, g, q, T0, T1, V0, V1);
+        } else if (p2) {
             q.tiles = (g.Kp + p2_np(Fh) - 1) / p2_np(Fh); q.total = q.tiles * nb;       // groups of column pairs
             // zero-padded columns (every padded correlation) take the direct form: first pass from HBM, last pass to HBM
             const bool direct = 2 * g.Hs <= Fh && Fh >= 256 && slots_per_cu == 0 && !(getenv("FB_COLS_STAGED") && atoi(getenv("FB_COLS_STAGED")));
@@ -847,13 +930,20 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
         FB_PROF_B(ctx, "ncc_stream_inv", (double)nb * g.Sw * 8.0 * nq * Fh);
         if (p2) {
             q.tiles = ntiles; q.total = ntiles * nb;
-            { const int grid = xcd_grid(4, q.total, std::min(q.total, wg_slots)); FB_P2_SWITCH(Fw, inv(ctx->stream, grid, lds_inv2, g, q, V0, V1, part)); }
+            if (split) {
+                // (a tile of rows of 8192 points fills the LDS: one persistent workgroup per CU with register prefetch)
+                const bool fills = (size_t)p2_trs(Fw) * (Fw + Fw / 16 + 1) * sizeof(float2) > 80 * 1024;
+                const int grid = (fills && (persist & 1)) ? xcd_persist(q.total) : xcd_grid(4, q.total, q.total);
+                FB_P2_SWITCH_W(Fw, inv_split(ctx->stream, grid, g, q, V0, V1, part));
+            }
+            else { const int grid = xcd_grid(4, q.total, std::min(q.total, wg_slots)); FB_P2_SWITCH_W(Fw, inv(ctx->stream, grid, lds_inv2, g, q, V0, V1, part)); }
         } else hipLaunchKernelGGL(ncc_stream_inv, dim3(ntiles, nb), dim3(kStreamThreads), lds_inv, ctx->stream, g, V0, V1, part, nullptr, 0, nullptr);
     }
     if (subpixel) {
         FB_PROF(ctx, "ncc_stream_neighbors");
         const size_t lds_n = ((size_t)4 * (Fw + Fw / 16 + 1) + 128) * sizeof(float2) + (size_t)(Fw + 2) / 2 * 2 * sizeof(short);
-        if (p2) { q.per8 = 0; FB_P2_SWITCH(Fw, neigh(ctx->stream, nb, lds_n2, g, q, V0, V1, part, ntiles, ct9)); }
+        if (split) { q.per8 = 0; FB_P2_SWITCH_W(Fw, neigh1(ctx->stream, nb, g, q, V0, V1, part, ntiles, ct9, true)); }
+        else if (p2) { q.per8 = 0; FB_P2_SWITCH_W(Fw, neigh(ctx->stream, nb, lds_n2, g, q, V0, V1, part, ntiles, ct9)); }
         else hipLaunchKernelGGL(ncc_stream_inv, dim3(1, nb), dim3(kStreamThreads), lds_n, ctx->stream, g, V0, V1, nullptr, part, ntiles, ct9);
     }
     {
@@ -925,10 +1015,13 @@ int fb_ncc_batch_dev(fb_ctx* ctx, const float* img0, const float* img1, int N, i
     FB_CHECK_ARG(ctx, (long long)Fh * Fw < (1LL << 31));
     if (C == 1 && fb_ncc_small_supported(Fh, Fw, H0, W0, H1, W1, C))
         return fb_ncc_small_launch(ctx, img0, img1, N, H0, W0, H1, W1, Fh, Fw, subpixel, conf_mode, dx, dy, conf);
-    if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, C)) {
+    int Lh = Fh_ref, Lw = Fw_ref;
+    const bool is_long = C == 1 && !ctx->use_rocfft && promote_long_shape(Lh, Lw, H0 + H1 - 1, W0 + W1 - 1, std::max(H0, H1), conf_mode);
+    if (is_long || (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, C))) {
         const int hmax = std::max(H0, H1);
         int Fh = Fh_ref, Fw = Fw_ref;
-        promote_linear_shape(Fh, Fw, H0 + H1 - 1, W0 + W1 - 1, conf_mode);
+        if (is_long) { Fh = Lh; Fw = Lw; }
+        else promote_linear_shape(Fh, Fw, H0 + H1 - 1, W0 + W1 - 1, conf_mode);
         const int nb_max = (int)std::max<size_t>(1, ctx->ncc_arena_limit / custom_bytes_per_pair(Fh, Fw, hmax));
         for (int n0 = 0; n0 < N; n0 += nb_max) {
             const int nb = std::min(nb_max, N - n0);
@@ -1057,8 +1150,9 @@ int fb_ncc_blocks_affine_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1
     if (wmax <= 0 || wmax > Fw) wmax = Fw;
     if (fb_ncc_small_supported(Fh, Fw, 0, 0, 0, 0, 1))
         return fb_ncc_small_launch_ex(ctx, imgs0, imgs1, N, hmax, wmax, hmax, wmax, blk, IH0, IW0, IH1, IW1, Fh, Fw, subpixel, conf_mode, dx, dy, conf, aff1);
-    if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, 1)) {
-        promote_linear_shape(Fh, Fw, 2 * hmax - 1, 2 * wmax - 1, conf_mode);
+    const bool is_long = !ctx->use_rocfft && promote_long_shape(Fh, Fw, 2 * hmax - 1, 2 * wmax - 1, hmax, conf_mode);
+    if (is_long || (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, 1))) {
+        if (!is_long) promote_linear_shape(Fh, Fw, 2 * hmax - 1, 2 * wmax - 1, conf_mode);
         const int nbm = (int)std::max<size_t>(1, ctx->ncc_arena_limit / custom_bytes_per_pair(Fh, Fw, hmax));
         CropSrc cs{blk, IH0, IW0, IH1, IW1};
         for (int n0 = 0; n0 < N; n0 += nbm) {
@@ -1093,6 +1187,7 @@ int fb_ncc_blocks_affine_dev(fb_ctx* ctx, const float* imgs0, const float* imgs1
 void fb_ncc_launch_shape(fb_ctx* ctx, int Fh, int Fw, int hmax, int wmax, int conf_mode, int* oh, int* ow) {
     *oh = Fh; *ow = Fw;
     if (fb_ncc_small_supported(Fh, Fw, 0, 0, 0, 0, 1)) return;
+    if (!ctx->use_rocfft && promote_long_shape(*oh, *ow, 2 * hmax - 1, 2 * wmax - 1, hmax, conf_mode)) return;
     if (!ctx->use_rocfft && stream_custom_supported(Fh, Fw, 1)) promote_linear_shape(*oh, *ow, 2 * hmax - 1, 2 * wmax - 1, conf_mode);
 }
 
@@ -1156,7 +1251,7 @@ __global__ __launch_bounds__(256) void debug_fft2_kernel(const float2* __restric
     for (int i = threadIdx.x; i < p2_tw_entries(N); i += blockDim.x) tw[i] = (f2){gtw[i].x, gtw[i].y};
     for (int i = threadIdx.x; i < M * N; i += blockDim.x) {
         const int m = i / N, e = i - m * N;
-        const int src = inverse ? fft_pos(plan, e) : e;
+        const int src = inverse ? p2_pos<N>(e) : e;
         G[m * pitch + fft_padx(src)] = (f2){in[i].x, in[i].y};
     }
     __syncthreads();
@@ -1164,7 +1259,7 @@ __global__ __launch_bounds__(256) void debug_fft2_kernel(const float2* __restric
     else p2_fft<N, false>(G, M, pitch, tw);
     for (int i = threadIdx.x; i < M * N; i += blockDim.x) {
         const int m = i / N, k = i - m * N;
-        const int pos = inverse ? k : fft_pos(plan, k);
+        const int pos = inverse ? k : p2_pos<N>(k);
         const f2 v = G[m * pitch + fft_padx(pos)];
         out[i] = make_float2(v.x, v.y);
     }
@@ -1180,12 +1275,15 @@ void launch_debug_fft2(fb_ctx* ctx, size_t lds, const float2* din, float2* dout,
 #include "feabas_hip_test.h"
 extern "C" int fb_debug_fft1d(fb_ctx* ctx, const float* in_host, float* out_host, int M, int N, int inverse, int pad) {
     FB_LOCK(ctx);
-    FB_CHECK_ARG(ctx, M > 0 && N >= 2 && N <= 4096 && in_host && out_host);
+    FB_CHECK_ARG(ctx, M > 0 && N >= 2 && (N <= 4096 || (pad == 2 && N == 8192)) && in_host && out_host);
     FftPlan plan;
-    if (!fft_make_plan(N, &plan)) return fb_fail(ctx, FB_ERR_ARG, "fb_debug_fft1d: %d is not 5-smooth", N);
-    const float2 *hi, *lo;
-    int rc = get_split_table(ctx, N, &hi, &lo);
-    if (rc) return rc;
+    const float2 *hi = nullptr, *lo = nullptr;
+    int rc = FB_OK;
+    if (N <= 4096) {                        // (the generic plans and two-level twiddles stop there; the packed core has its own)
+        if (!fft_make_plan(N, &plan)) return fb_fail(ctx, FB_ERR_ARG, "fb_debug_fft1d: %d is not 5-smooth", N);
+        rc = get_split_table(ctx, N, &hi, &lo);
+        if (rc) return rc;
+    }
     const size_t bytes = sizeof(float2) * (size_t)M * N;
     const size_t lds = ((size_t)M * (N + N / 16 + 2) + 128) * sizeof(float2);
     if (lds > 150 * 1024) return fb_fail(ctx, FB_ERR_ARG, "fb_debug_fft1d: M*N too large for LDS");
@@ -1206,6 +1304,7 @@ extern "C" int fb_debug_fft1d(fb_ctx* ctx, const float* in_host, float* out_host
             case 1024: launch_debug_fft2<1024>(ctx, lds2, din, dout, M, plan, tw, inverse); break;
             case 2048: launch_debug_fft2<2048>(ctx, lds2, din, dout, M, plan, tw, inverse); break;
             case 4096: launch_debug_fft2<4096>(ctx, lds2, din, dout, M, plan, tw, inverse); break;
+            case 8192: launch_debug_fft2<8192>(ctx, lds2 + sizeof(float2) * 256, din, dout, M, plan, tw, inverse); break;
             default: hipFree(din); hipFree(dout); return fb_fail(ctx, FB_ERR_ARG, "fb_debug_fft1d: pad=2 needs a power of two in [64, 4096]");
         }
     } else if (pad) {

@@ -36,7 +36,7 @@ def test_fft1d_vs_numpy(fb, n, pad):
     assert np.abs(out - ref).max() <= 3e-6 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize('n', [64, 128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize('n', [64, 128, 256, 512, 1024, 2048, 4096, 8192])
 def test_fft1d_pow2_packed_core_vs_numpy(fb, n):
     """fb_fft2.h: compile-time plans + packed-FP32 butterflies (the streaming-class kernels at power-of-two shapes)"""
     from feabas_amd import _lib
