@@ -9,4 +9,4 @@ lib, ctx = _lib.load(), _lib.ctx()
 out = bench.bench_xcorr_classes(lib, ctx, _lib, only=sys.argv[1:] or None)
 for k, v in out.items():
     if True:
-        print(k, json.dumps({a: round(b, 3) for a, b in v.items()}))
+        print(k, json.dumps({a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()}))
