@@ -803,6 +803,14 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
     // 11-13 % faster at FW <= 1024; narrower tiles would cut the contiguous runs of V below 64 B (FB_INV_HALF=0/1 overrides)
     const char* inv_half = getenv("FB_INV_HALF");
     if (p2 && !split && (inv_half ? atoi(inv_half) != 0 : g.TR >= 8)) g.TRI = std::max(1, g.TR / 2);
+    if (ct) {
+        // inverse pass of the mixed-radix class: tiles of 4 rows where the row pass has 8 (rows of 513 .. 1024 points: 21 KB of LDS
+        // instead of 43, six workgroups per CU instead of three): 3.63 -> 3.37 us per 280 x 280 block pair at FFT 576 x 576; tiles of 2
+        // rows (32-byte runs of V) and halving the 16-row tiles of shorter rows are slower (FB_CT_TRI = 2 / 4 / 8 / 16 overrides)
+        static const int ct_tri = [] { const char* e = getenv("FB_CT_TRI"); return e ? atoi(e) : 0; }();
+        if (ct_tri == 2 || ct_tri == 4 || ct_tri == 8 || ct_tri == 16) g.TRI = ct_tri;
+        else if (g.TR == 8) g.TRI = 4;
+    }
     const int rows = std::min(Fh, std::max(1, hmax));
     g.Hs = (rows + g.TR - 1) / g.TR * g.TR;
     g.H0 = H0; g.W0 = W0; g.H1 = H1; g.W1 = W1;
