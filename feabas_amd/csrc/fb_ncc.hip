@@ -944,7 +944,12 @@ int ncc_custom_subbatch(fb_ctx* ctx, const float* img0, const float* img1, int n
                 const int grid = (fills && (persist & 1)) ? xcd_persist(q.total) : xcd_grid(4, q.total, q.total);
                 FB_P2_SWITCH_W(Fw, inv_split(ctx->stream, grid, g, q, V0, V1, part));
             }
-            else { const int grid = xcd_grid(4, q.total, std::min(q.total, wg_slots)); FB_P2_SWITCH_W(Fw, inv(ctx->stream, grid, lds_inv2, g, q, V0, V1, part)); }
+            else {
+                // (FB_P2_INV_PERSIST=1: a tile that fills the LDS -- rows of 2048 and 4096 points -- on one persistent workgroup per CU)
+                static const int inv_persist = [] { const char* e = getenv("FB_P2_INV_PERSIST"); return e ? atoi(e) : 0; }();
+                const int grid = (inv_persist && lds_inv2 > 80 * 1024 && slots_per_cu == 0) ? xcd_persist(q.total) : xcd_grid(4, q.total, std::min(q.total, wg_slots));
+                FB_P2_SWITCH_W(Fw, inv(ctx->stream, grid, lds_inv2, g, q, V0, V1, part));
+            }
         } else hipLaunchKernelGGL(ncc_stream_inv, dim3(ntiles, nb), dim3(kStreamThreads), lds_inv, ctx->stream, g, V0, V1, part, nullptr, 0, nullptr);
     }
     if (subpixel) {
