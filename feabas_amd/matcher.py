@@ -1327,7 +1327,9 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
     # largest chunks first (the remainders of the shape / mesh-grid buckets end the list: a short drain, and no thread starts a
     # 32-pair chunk while the others are done); the order of the results does not depend on it.  (Round 6 also tried cutting the
     # first and last chunks into quarters against the fill and drain of the loader -> matcher pipeline: 0.82 instead of 0.86 of
-    # the resident rate -- a small chunk costs more per pair than it saves in waiting.)
+    # the resident rate -- a small chunk costs more per pair than it saves in waiting.  And letting every matcher thread stage its own
+    # first chunk beside the loaders, so that all matchers start after one staging time: eight threads packing at once take 12-18 ms
+    # per chunk instead of 8, the matchers start at 15-25 ms instead of 7-17: 9.0 k against 9.3 k pairs/s.)
     chunks.sort(key=lambda ch: -len(ch[2]))
     results = [None] * len(items)
     errors = []
@@ -1375,7 +1377,6 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
             trace.append((kind, who, t0 - t_start, _time.perf_counter() - t_start))
     next_chunk = [0]
     take = threading.Lock()
-    own_first = bool(n_load) and os.environ.get('FEABAS_HIP_INGEST_OWN_FIRST', '1') != '0' and len(chunks) >= 2 * (n_match + n_load)
 
     def stage(chunk, pin, dev):
         """both strips of every pair of the chunk into the page-locked stack [2][n][Hm][Wm] (C++ memcpy, no interpreter lock) and
@@ -1470,21 +1471,6 @@ def stitching_matcher_batch(pairs, batch=32, threads=2, **kwargs):
                     n, Hm, Wm = stage(chunk, pin, dev)
                     match_chunk(state, chunk, dev, n, Hm, Wm)
                 return
-            # the fill of the pipeline: no staged chunk exists yet, so every matcher stages ONE chunk itself (on its own stream, beside
-            # the loaders) and matches it -- all matchers start matching after one staging time instead of one after the other as
-            # the loaders deliver (first starts at 7 .. 17 ms before, round 6 trace)
-            if own_first:
-                with take:
-                    c = next_chunk[0]; next_chunk[0] += 1
-                if c < len(chunks):
-                    sl = free_q.get()
-                    try:
-                        pin, dev = shared['io'][sl]
-                        n, Hm, Wm = timed('stage', 100 + t, stage, chunks[c], pin, dev)
-                        if not errors:
-                            timed('match', t, match_chunk, state, chunks[c], dev, n, Hm, Wm)
-                    finally:
-                        free_q.put(sl)
             while True:
                 got = ready_q.get()
                 if got is None:
