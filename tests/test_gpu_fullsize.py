@@ -51,6 +51,28 @@ def test_pair_pipeline_at_the_4k_strip_size_vs_oracle(fb, H, W):
     m.free(); d0.free(); d1.free()
 
 
+@pytest.mark.parametrize('H,W', [(4096, 510), (510, 4096)])
+def test_pair_pipeline_with_the_coarse_level_at_full_resolution_vs_oracle(fb, H, W):
+    """coarse_downsample = 1 on a 4k strip: the global translation is ONE correlation at FFT 8192 x 1024 (1024 x 8192) -- the
+    8192-point forms of the power-of-two core (split columns / rows of 8192 points, fb_ncc_p2.inc), reached through the
+    pipeline's own entry; everything after it as in the test above"""
+    from feabas_amd import _lib
+    from feabas_amd.stitch_pipeline import StripBatchMatcher
+    pairs = [_warped_pair(H, W, 31, (9, -6), 0.0)]
+    s0 = np.stack([p[0] for p in pairs]); s1 = np.stack([p[1] for p in pairs])
+    d0 = _lib.DeviceBuffer.from_array(s0); d1 = _lib.DeviceBuffer.from_array(s1)
+    m = StripBatchMatcher(1, H, W, residue_len=2.0, coarse_downsample=1)
+    g = StripBatchMatcher.per_pair(m.match(d0.ptr, d1.ptr))[0]
+    exp = pipeline_ref.match_pair(pairs[0][0], pairs[0][1], residue_len=2.0, coarse_downsample=1)
+    assert (g['tx'], g['ty']) == (exp['tx'], exp['ty']) and abs(exp['tx']) + abs(exp['ty']) > 10
+    assert abs(g['conf0'] - exp['conf0']) < 1e-4
+    assert g['xy0'].shape == exp['xy0'].shape and g['xy0'].shape[0] > 300
+    np.testing.assert_allclose(g['xy0'], exp['xy0'], atol=1e-4)
+    np.testing.assert_allclose(g['xy1'], exp['xy1'], atol=1e-4)
+    np.testing.assert_allclose(g['weight'], exp['weight'], atol=1e-4)
+    m.free(); d0.free(); d1.free()
+
+
 def _grid_system(fb, grid, nlinks, seed=0):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
