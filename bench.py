@@ -268,6 +268,8 @@ def bench_xcorr_classes(lib, ctx, _lib, only=None):
     rng = np.random.default_rng(1)
     for name, (N, h, w, pad, sub) in {'fine_75x73_fft75x75': (24640, 75, 73, 0, 1), 'coarse_1024x510_fft2048x1024': (128, 1024, 510, 1, 0),
                                       'global_2048x255_fft4096x512': (32, 2048, 255, 1, 0),
+                                      # the global strip when the coarse level runs at full resolution (coarse_downsample 1): columns of 8192 points
+                                      'global_fullres_4096x510_fft8192x1024': (32, 4096, 510, 1, 0),
                                       # alignment block classes (default_alignment_configs.yaml:16-23: spacings [400, 100] x 0.7) and the
                                       # README stitching grid, all padded: compile-time mixed-radix streaming kernels (fb_ncc_ct.hip)
                                       'align_280x280_fft576x576': (1024, 280, 280, 1, 1), 'align_70x70_fft144x144': (1024, 70, 70, 1, 1),
